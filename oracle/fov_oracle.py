@@ -1,0 +1,258 @@
+"""CPU oracle for the seq2seq-LSTM hot path of ChengeLi/LongTerm360FoV.
+
+TEST INFRASTRUCTURE ONLY.  Nothing under ``longterm360fov_amd/`` may import this module; only
+``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of ``bench.py`` do, and
+only as the checker.  The product path is the HIP library behind ``include/fov360.h``.
+
+PARITY STATUS
+  * Data side (windowing, mu/sigma^2 features, clip): PINNED against the reference's own NumPy
+    code, executed in the authoring container on seeded inputs
+    (``tests/golden/make_data_fixtures.py`` -> ``tests/golden/data_helpers.npz``).
+  * LSTM / Dense arithmetic: **parity unpinned**.  The reference delegates it to Keras 2.1-2.2
+    on TensorFlow 1.x (``from keras.layers import LSTM, Dense`` - mycode/FoV_seq2seq.py:2-4),
+    neither of which is present in /root/reference or installable here, and the reference holds
+    no tests, golden vectors or trained weights for it.  This file
+    restates the published Keras-2.2 ``LSTMCell`` / ``Dense`` definitions; the restatement is
+    cross-checked against an independent implementation with the same gate order
+    (``torch.nn.LSTM`` on CPU, sigmoid mode) and against hand-computed known-answer cases for
+    ``hard_sigmoid`` in ``tests/test_oracle.py``.
+
+Equations (Keras 2.2 ``LSTMCell.call``; kernel K:(F,4H), recurrent kernel R:(H,4H), bias b:(4H,),
+gate column blocks in the order i, f, c, o):
+    z   = x_t @ K + b + h_{t-1} @ R
+    i   = s(z_i); f = s(z_f); o = s(z_o); g = tanh(z_c)
+    c_t = f * c_{t-1} + i * g
+    h_t = o * tanh(c_t)
+with s = ``hard_sigmoid`` = clip(0.2 x + 0.5, 0, 1) (Keras < 2.3 default for
+``recurrent_activation``; the reference never overrides it) or ``sigmoid`` (what
+BASELINE.json's north_star names).  Both are implemented; callers choose with ``act``.
+"""
+import numpy as np
+
+ACT_SIGMOID = 0
+ACT_HARD_SIGMOID = 1
+_ACT_NAMES = {"sigmoid": ACT_SIGMOID, "hard_sigmoid": ACT_HARD_SIGMOID,
+              ACT_SIGMOID: ACT_SIGMOID, ACT_HARD_SIGMOID: ACT_HARD_SIGMOID}
+
+
+def act_code(act):
+    return _ACT_NAMES[act]
+
+
+def sigmoid(x):
+    # numerically stable logistic in the array's own dtype
+    x = np.asarray(x)
+    out = np.empty_like(x)
+    pos = x >= 0
+    out[pos] = 1 / (1 + np.exp(-x[pos]))
+    e = np.exp(x[~pos])
+    out[~pos] = e / (1 + e)
+    return out
+
+
+def hard_sigmoid(x):
+    """Keras backend hard_sigmoid: clip(0.2*x + 0.5, 0, 1)."""
+    x = np.asarray(x)
+    return np.clip(x.dtype.type(0.2) * x + x.dtype.type(0.5), 0, 1).astype(x.dtype)
+
+
+def _rec_act(act):
+    return hard_sigmoid if act_code(act) == ACT_HARD_SIGMOID else sigmoid
+
+
+# --------------------------------------------------------------------------------------
+# a1/a2: Keras LSTM layer  (mycode/FoV_seq2seq.py:83-86, 93-95)
+# --------------------------------------------------------------------------------------
+def lstm_step(x, h, c, K, R, b, act="sigmoid"):
+    """One LSTMCell step.  x:(B,F) h,c:(B,H) -> (h', c')."""
+    H = h.shape[1]
+    z = x @ K + b + h @ R
+    s = _rec_act(act)
+    i = s(z[:, 0 * H:1 * H])
+    f = s(z[:, 1 * H:2 * H])
+    g = np.tanh(z[:, 2 * H:3 * H])
+    o = s(z[:, 3 * H:4 * H])
+    c_new = f * c + i * g
+    h_new = o * np.tanh(c_new)
+    return h_new.astype(x.dtype), c_new.astype(x.dtype)
+
+
+def lstm_layer(x, K, R, b, h0=None, c0=None, act="sigmoid"):
+    """LSTM over x:(B,T,F).  Returns (hs:(B,T,H), h_T, c_T).  Zero initial state by default
+    (Keras ``get_initial_state``); ``initial_state=[h, c]`` as in FoV_seq2seq.py:94-95."""
+    B, T, _ = x.shape
+    H = R.shape[0]
+    h = np.zeros((B, H), x.dtype) if h0 is None else h0.astype(x.dtype)
+    c = np.zeros((B, H), x.dtype) if c0 is None else c0.astype(x.dtype)
+    hs = np.empty((B, T, H), x.dtype)
+    for t in range(T):
+        h, c = lstm_step(x[:, t], h, c, K, R, b, act)
+        hs[:, t] = h
+    return hs, h, c
+
+
+# a3: Dense(num_decoder_tokens, activation='tanh')  (mycode/FoV_seq2seq.py:96-97)
+def dense(x, W, b, activation="tanh"):
+    y = x @ W + b
+    if activation == "tanh":
+        y = np.tanh(y)
+    return y.astype(x.dtype)
+
+
+# --------------------------------------------------------------------------------------
+# Target-only seq2seq  (mycode/FoV_seq2seq.py)
+# weights: dict(enc_K, enc_R, enc_b, dec_K, dec_R, dec_b, dense_W, dense_b)
+# --------------------------------------------------------------------------------------
+def seq2seq_teacher_forced(enc_in, dec_in, w, act="sigmoid"):
+    """Training-graph forward, FoV_seq2seq.py:82-101: decoder consumes GT inputs (B,T_out,6)."""
+    _, h, c = lstm_layer(enc_in, w["enc_K"], w["enc_R"], w["enc_b"], act=act)
+    hs, _, _ = lstm_layer(dec_in, w["dec_K"], w["dec_R"], w["dec_b"], h, c, act=act)
+    B, T, H = hs.shape
+    return dense(hs.reshape(B * T, H), w["dense_W"], w["dense_b"]).reshape(B, T, -1)
+
+
+def seq2seq_decode(enc_in, dec_in0, w, T_out, act="sigmoid"):
+    """Autoregressive inference, FoV_seq2seq.py:137-178 (batched; the reference runs batch 1):
+    states = encoder(enc_in); target = dec_in0 (B,1,6);
+    repeat T_out: y,h,c = decoder(target,h,c); y = dense(y); target = y."""
+    _, h, c = lstm_layer(enc_in, w["enc_K"], w["enc_R"], w["enc_b"], act=act)
+    y = dec_in0[:, 0].astype(enc_in.dtype)
+    out = []
+    for _ in range(T_out):
+        h, c = lstm_step(y, h, c, w["dec_K"], w["dec_R"], w["dec_b"], act)
+        y = dense(h, w["dense_W"], w["dense_b"])
+        out.append(y)
+    return np.stack(out, axis=1)
+
+
+# --------------------------------------------------------------------------------------
+# a4: target + others mixing, 2-layer, no teacher forcing
+# (mycode/given_others_gt_mean_var_seq2seq.py:98-130, 203-299)
+# weights: enc1_*, enc2_*, dec1_*, dec2_*, dense_W/b (H,6), mix_W (6*U,6), mix_b
+# --------------------------------------------------------------------------------------
+def others_mixing_forward(enc_in, others, dec_in0, w, act="sigmoid"):
+    """enc_in:(B,T_in,F) others:(B,T_out,U-1,6) dec_in0:(B,1,6) -> (B,T_out,6).
+    Per step: d1=LSTM1(x); d2=LSTM2(d1); p=tanh(d2 Wd+bd);
+    m=tanh(flatten(concat_axis1[others[:,t], p]) Wm + bm)  (user-major flatten, pred last); x=m."""
+    hs1, h1, c1 = lstm_layer(enc_in, w["enc1_K"], w["enc1_R"], w["enc1_b"], act=act)
+    _, h2, c2 = lstm_layer(hs1, w["enc2_K"], w["enc2_R"], w["enc2_b"], act=act)
+    x = dec_in0[:, 0].astype(enc_in.dtype)
+    B, T_out = others.shape[0], others.shape[1]
+    out = []
+    for t in range(T_out):
+        h1, c1 = lstm_step(x, h1, c1, w["dec1_K"], w["dec1_R"], w["dec1_b"], act)
+        h2, c2 = lstm_step(h1, h2, c2, w["dec2_K"], w["dec2_R"], w["dec2_b"], act)
+        p = dense(h2, w["dense_W"], w["dense_b"])                      # (B,6)
+        cat = np.concatenate([others[:, t].astype(x.dtype), p[:, None, :]], axis=1)  # (B,U,6)
+        x = dense(cat.reshape(B, -1), w["mix_W"], w["mix_b"])           # (B,6)
+        out.append(x)
+    return np.stack(out, axis=1)
+
+
+# --------------------------------------------------------------------------------------
+# a5: mu / sigma^2 features  (mycode/utility.py:483-517)
+# --------------------------------------------------------------------------------------
+def meanvar_xyz(y):
+    """(N,T,90) interleaved xyzxyz.. or (N,T,30,3) -> (N,T,6) = [mx,my,mz,vx,vy,vz]; ddof=0.
+    Slices per axis exactly as utility.py:484-499 does, so float64 results are bit-identical."""
+    if y.shape[-1] == 3:
+        assert y.ndim == 4
+        comps = [y[:, :, :, a] for a in range(3)]
+    else:
+        assert y.ndim == 3 and y.shape[-1] % 3 == 0
+        comps = [y[:, :, a::3] for a in range(3)]
+    means = [np.mean(c, axis=-1)[:, :, np.newaxis] for c in comps]
+    variances = [np.var(c, axis=-1)[:, :, np.newaxis] for c in comps]
+    return np.concatenate(means + variances, axis=-1)
+
+
+def meanvar_xyz_oth(y):
+    """(N,T,U,30,3) -> (N,T,U,6)   (utility.py:505-517)."""
+    assert y.ndim == 5 and y.shape[-1] == 3
+    comps = [y[:, :, :, :, a] for a in range(3)]
+    means = [np.mean(c, axis=-1)[:, :, :, np.newaxis] for c in comps]
+    variances = [np.var(c, axis=-1)[:, :, :, np.newaxis] for c in comps]
+    return np.concatenate(means + variances, axis=-1)
+
+
+# a6: Keras mean_squared_error + sample mean  (mycode/cost.py:20-22)
+def mse(y_true, y_pred):
+    return float(np.mean(np.mean((y_pred.astype(np.float64) - y_true.astype(np.float64)) ** 2, axis=-1)))
+
+
+# --------------------------------------------------------------------------------------
+# Keras default initialisers (glorot_uniform kernel, orthogonal recurrent, unit_forget_bias)
+# --------------------------------------------------------------------------------------
+def _glorot_uniform(rng, fan_in, fan_out, dtype):
+    lim = np.sqrt(6.0 / (fan_in + fan_out))
+    return rng.uniform(-lim, lim, (fan_in, fan_out)).astype(dtype)
+
+
+def _orthogonal(rng, rows, cols, dtype):
+    a = rng.standard_normal((rows, cols))
+    u, _, vt = np.linalg.svd(a, full_matrices=False)
+    q = u if u.shape == (rows, cols) else vt
+    return q.astype(dtype)
+
+
+def init_lstm(rng, F, H, dtype=np.float32):
+    K = _glorot_uniform(rng, F, 4 * H, dtype)
+    R = _orthogonal(rng, H, 4 * H, dtype)
+    b = np.zeros(4 * H, dtype)
+    b[H:2 * H] = 1  # unit_forget_bias
+    return K, R, b
+
+
+def init_seq2seq(seed, F_enc=90, F_dec=6, H=256, dtype=np.float32, bias_noise=0.0):
+    rng = np.random.default_rng(seed)
+    w = {}
+    w["enc_K"], w["enc_R"], w["enc_b"] = init_lstm(rng, F_enc, H, dtype)
+    w["dec_K"], w["dec_R"], w["dec_b"] = init_lstm(rng, F_dec, H, dtype)
+    w["dense_W"] = _glorot_uniform(rng, H, F_dec, dtype)
+    w["dense_b"] = np.zeros(F_dec, dtype)
+    if bias_noise:
+        for k in ("enc_b", "dec_b", "dense_b"):
+            w[k] = (w[k] + bias_noise * rng.standard_normal(w[k].shape)).astype(dtype)
+    return w
+
+
+def init_others_mixing(seed, F_enc=90, F_dec=6, H=256, num_user=34, dtype=np.float32, bias_noise=0.0):
+    rng = np.random.default_rng(seed)
+    w = {}
+    for name, F in (("enc1", F_enc), ("enc2", H), ("dec1", F_dec), ("dec2", H)):
+        w[name + "_K"], w[name + "_R"], w[name + "_b"] = init_lstm(rng, F, H, dtype)
+    w["dense_W"] = _glorot_uniform(rng, H, F_dec, dtype)
+    w["dense_b"] = np.zeros(F_dec, dtype)
+    w["mix_W"] = _glorot_uniform(rng, num_user * F_dec, F_dec, dtype)
+    w["mix_b"] = np.zeros(F_dec, dtype)
+    if bias_noise:
+        for k in list(w):
+            if k.endswith("_b"):
+                w[k] = (w[k] + bias_noise * rng.standard_normal(w[k].shape)).astype(dtype)
+    return w
+
+
+# --------------------------------------------------------------------------------------
+# Synthetic trajectories of SURVEY.md section 8(d)
+# --------------------------------------------------------------------------------------
+def synthetic_xyz(rng, B, T, fps=30, dtype=np.float32):
+    """(B, T, 3*fps) interleaved xyz per frame, smooth unit-sphere trajectories."""
+    n = T * fps
+    yaw = rng.uniform(-np.pi, np.pi, (B, 1)) + np.cumsum(rng.normal(0, 0.02, (B, n)), axis=1)
+    pitch = np.clip(rng.normal(0, 0.3, (B, 1)) + np.cumsum(rng.normal(0, 0.01, (B, n)), axis=1), -np.pi / 2, np.pi / 2)
+    xyz = np.stack([np.cos(pitch) * np.cos(yaw), np.cos(pitch) * np.sin(yaw), np.sin(pitch)], axis=-1)
+    return xyz.reshape(B, T, fps * 3).astype(dtype)
+
+
+def synthetic_batch(seed, B, T_in, T_out, num_others=0, fps=30, dtype=np.float32):
+    """enc_in (B,T_in,90), dec_in0 (B,1,6), target (B,T_out,6) [, others (B,T_out,U-1,6)]."""
+    rng = np.random.default_rng(seed)
+    traj = synthetic_xyz(rng, B, T_in + T_out, fps, np.float64)
+    enc_in = traj[:, :T_in]
+    target = meanvar_xyz(traj[:, T_in:])
+    dec_in0 = meanvar_xyz(enc_in[:, -1:])
+    out = [enc_in.astype(dtype), dec_in0.astype(dtype), target.astype(dtype)]
+    if num_others:
+        oth = synthetic_xyz(rng, B * num_others, T_out, fps, np.float64).reshape(B, num_others, T_out, fps, 3)
+        out.append(meanvar_xyz_oth(oth.transpose(0, 2, 1, 3, 4)).astype(dtype))
+    return tuple(out)

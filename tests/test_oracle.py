@@ -1,0 +1,117 @@
+"""Pins the CPU oracle: known-answer cases, torch.nn.LSTM cross-check, numpy<->C agreement,
+and the committed LSTM golden vectors (tests/golden/lstm_small.npz, made by make_lstm_fixtures.py)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import c_oracle as C
+from oracle import fov_oracle as O
+
+
+def test_hard_sigmoid_known_answers():
+    x = np.array([-3.0, -2.5, -1.0, 0.0, 1.0, 2.5, 3.0], np.float32)
+    np.testing.assert_allclose(O.hard_sigmoid(x), [0, 0, 0.3, 0.5, 0.7, 1, 1], atol=1e-7)
+
+
+def test_lstm_step_hand_computed():
+    # H=1, F=1: z = x*K + h*R + b with all gates driven by the same scalar pre-activation
+    K = np.array([[1.0, 2.0, 3.0, 4.0]], np.float64)
+    R = np.array([[0.5, -0.5, 0.25, -0.25]], np.float64)
+    b = np.array([0.1, 1.0, -0.1, 0.0], np.float64)
+    x = np.array([[0.2]]); h = np.array([[0.4]]); c = np.array([[-0.3]])
+    z = 0.2 * K[0] + 0.4 * R[0] + b                     # [0.5, 1.2, 0.6, 0.7]
+    np.testing.assert_allclose(z, [0.5, 1.2, 0.6, 0.7], atol=1e-12)
+    sig = lambda v: 1 / (1 + np.exp(-v))
+    c1 = sig(1.2) * -0.3 + sig(0.5) * np.tanh(0.6)
+    h1 = sig(0.7) * np.tanh(c1)
+    hn, cn = O.lstm_step(x, h, c, K, R, b, "sigmoid")
+    np.testing.assert_allclose([hn[0, 0], cn[0, 0]], [h1, c1], atol=1e-12)
+    hs = lambda v: min(max(0.2 * v + 0.5, 0), 1)         # hard_sigmoid: 0.6, 0.74, 0.64
+    c1 = hs(1.2) * -0.3 + hs(0.5) * np.tanh(0.6)
+    h1 = hs(0.7) * np.tanh(c1)
+    hn, cn = O.lstm_step(x, h, c, K, R, b, "hard_sigmoid")
+    np.testing.assert_allclose([hn[0, 0], cn[0, 0]], [h1, c1], atol=1e-12)
+
+
+@pytest.mark.parametrize("H,F", [(16, 6), (64, 90)])
+def test_lstm_layer_matches_torch(H, F):
+    """Independent implementation with the same gate order (i,f,g,o): W_ih = K^T, W_hh = R^T."""
+    rng = np.random.default_rng(5)
+    K, R, b = O.init_lstm(rng, F, H, np.float64)
+    b = b + 0.1 * rng.standard_normal(b.shape)
+    x = rng.standard_normal((7, 9, F))
+    h0 = 0.3 * rng.standard_normal((7, H)); c0 = 0.3 * rng.standard_normal((7, H))
+    hs, hT, cT = O.lstm_layer(x, K, R, b, h0, c0, "sigmoid")
+    m = torch.nn.LSTM(F, H, batch_first=True).double()
+    with torch.no_grad():
+        m.weight_ih_l0.copy_(torch.from_numpy(K.T)); m.weight_hh_l0.copy_(torch.from_numpy(R.T))
+        m.bias_ih_l0.copy_(torch.from_numpy(b)); m.bias_hh_l0.zero_()
+        ths, (thT, tcT) = m(torch.from_numpy(x), (torch.from_numpy(h0)[None], torch.from_numpy(c0)[None]))
+    np.testing.assert_allclose(hs, ths.numpy(), atol=1e-12)
+    np.testing.assert_allclose(hT, thT[0].numpy(), atol=1e-12)
+    np.testing.assert_allclose(cT, tcT[0].numpy(), atol=1e-12)
+
+
+@pytest.mark.parametrize("act", [0, 1])
+def test_c_oracle_matches_numpy(act):
+    w = O.init_seq2seq(11, H=64, bias_noise=0.1)
+    enc, dec0, tgt = O.synthetic_batch(12, 21, 6, 5)       # ragged vs the C tile of 8
+    a = O.seq2seq_decode(enc, dec0, w, 5, act)
+    b = C.seq2seq_decode(enc, dec0, w, 5, act)
+    np.testing.assert_allclose(a, b, atol=2e-6)
+    dec_in = np.concatenate([dec0, tgt[:, :-1]], axis=1)
+    a = O.seq2seq_teacher_forced(enc, dec_in, w, act)
+    b = C.seq2seq_teacher_forced(enc, dec_in, w, act)
+    np.testing.assert_allclose(a, b, atol=2e-6)
+    hs, hT, cT = O.lstm_layer(enc, w["enc_K"], w["enc_R"], w["enc_b"], act=act)
+    chs, chT, ccT = C.lstm_layer(enc, w["enc_K"], w["enc_R"], w["enc_b"], act=act)
+    np.testing.assert_allclose(hs, chs, atol=2e-6)
+    np.testing.assert_allclose(cT, ccT, atol=2e-6)
+
+
+def test_empty_batch():
+    w = O.init_seq2seq(1, H=16)
+    enc = np.zeros((0, 4, 90), np.float32); dec0 = np.zeros((0, 1, 6), np.float32)
+    assert C.seq2seq_decode(enc, dec0, w, 3).shape == (0, 3, 6)
+
+
+def test_meanvar_matches_reference_fixture(golden_dir):
+    g = np.load(os.path.join(golden_dir, "data_helpers.npz"))
+    np.testing.assert_array_equal(O.meanvar_xyz(g["fut"]), g["gt_fut"])
+    np.testing.assert_array_equal(O.meanvar_xyz(g["fut"].reshape(12, 10, 30, 3)), g["gt_fut_4d"])
+    oth = g["pu_oth_fut"].transpose(1, 2, 0, 3).reshape(12, 10, 2, 30, 3)
+    np.testing.assert_array_equal(O.meanvar_xyz_oth(oth), g["gt_oth_fut"])
+
+
+def test_others_mixing_flatten_order():
+    """Mixing input is user-major with the prediction LAST (given_others...py:261-264): a mixing
+    matrix that only reads the last 6 inputs must reproduce tanh(pred)."""
+    w = O.init_others_mixing(3, H=8, num_user=4, dtype=np.float64)
+    w["mix_W"][:] = 0
+    w["mix_W"][-6:] = np.eye(6)
+    enc, dec0, tgt, oth = O.synthetic_batch(4, 3, 4, 3, num_others=3, dtype=np.float64)
+    out = O.others_mixing_forward(enc, oth, dec0, w)
+    # recompute step 0 by hand
+    hs1, h1, c1 = O.lstm_layer(enc, w["enc1_K"], w["enc1_R"], w["enc1_b"])
+    _, h2, c2 = O.lstm_layer(hs1, w["enc2_K"], w["enc2_R"], w["enc2_b"])
+    h1, c1 = O.lstm_step(dec0[:, 0], h1, c1, w["dec1_K"], w["dec1_R"], w["dec1_b"])
+    h2, c2 = O.lstm_step(h1, h2, c2, w["dec2_K"], w["dec2_R"], w["dec2_b"])
+    p = O.dense(h2, w["dense_W"], w["dense_b"])
+    np.testing.assert_allclose(out[:, 0], np.tanh(p), atol=1e-14)
+
+
+def test_lstm_golden_vectors(golden_dir):
+    """Committed input/output vectors (fp64 oracle run, stored fp32) guard against silent edits."""
+    g = np.load(os.path.join(golden_dir, "lstm_small.npz"))
+    for act in (0, 1):
+        w = {k[2:]: g[k] for k in g.files if k.startswith("w_")}
+        out = O.seq2seq_decode(g["enc"], g["dec0"], w, int(g["T_out"]), act)
+        np.testing.assert_allclose(out, g["decode_act%d" % act], atol=5e-6)
+        dec_in = np.concatenate([g["dec0"], g["tgt"][:, :-1]], axis=1)
+        out = O.seq2seq_teacher_forced(g["enc"], dec_in, w, act)
+        np.testing.assert_allclose(out, g["tf_act%d" % act], atol=5e-6)
+    wm = {k[3:]: g[k] for k in g.files if k.startswith("wm_")}
+    out = O.others_mixing_forward(g["enc"], g["oth"], g["dec0"], wm, 0)
+    np.testing.assert_allclose(out, g["mix_act0"], atol=5e-6)
