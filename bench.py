@@ -1,0 +1,182 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: BASELINE.json metric "sequences/sec (batch=1024, T_in=30 ->
+T_out=30, h=256)", configs[1]: target-only seq2seq (mycode/FoV_seq2seq.py), fp32, inference =
+encoder + autoregressive decoder, on synthetic trajectories.
+
+A "step" is one pass of the fused path (fov_seq2seq_decode_fwd: encoder launch + decoder launch)
+over one resident batch of 1024 sequences per GPU.  N > 1 ranks (torchrun) are independent
+replicas on their own batch - the path shards by sequence with no data-path collective
+("scaling": "weak"); torch.distributed (RCCL) is only used for the barrier and the max-over-ranks
+of the timed region.
+
+Prints ONE JSON line (rank 0).  `roofline` prices the step's two persistent-kernel launches
+together against the fp32 MFMA peak, with the duration taken from HIP events on the launch
+stream over the timed region; `kernels` breaks it down per launch (event-timed separately).
+`cpu_baseline` times the C oracle (oracle/lstm_ref.c, "port") on the host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense fp32 matrix peak (spec)
+
+
+def flops_per_seq(T_in, T_out, F_enc, F_dec, H):
+    """Algorithmic forward FLOPs: LSTM step 2(F+H)4H, Dense 2*H*F_dec."""
+    enc = T_in * 2 * (F_enc + H) * 4 * H
+    dec = T_out * (2 * (F_dec + H) * 4 * H + 2 * H * F_dec)
+    return enc, dec
+
+
+def event_time_ms(fn, iters):
+    start = torch.cuda.Event(enable_timing=True)
+    stop = torch.cuda.Event(enable_timing=True)
+    start.record()
+    for _ in range(iters):
+        fn()
+    stop.record()
+    stop.synchronize()
+    return start.elapsed_time(stop) / iters
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=1024)
+    ap.add_argument("--t-in", type=int, default=30)
+    ap.add_argument("--t-out", type=int, default=30)
+    ap.add_argument("--hidden", type=int, default=256)
+    ap.add_argument("--impl", default="auto", choices=["auto", "cluster", "generic"])
+    ap.add_argument("--act", default="sigmoid", choices=["sigmoid", "hard_sigmoid"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    use_dist = world > 1
+    torch.cuda.set_device(local_rank)
+    if use_dist:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from longterm360fov_amd import ops
+    from oracle import fov_oracle as O   # synthetic data + Keras initialisers (test infrastructure)
+
+    B, T_in, T_out, H = args.batch, args.t_in, args.t_out, args.hidden
+    F_enc, F_dec = 90, 6
+    w = O.init_seq2seq(1234, F_enc, F_dec, H, bias_noise=0.05)
+    enc, dec0, _ = O.synthetic_batch(1234 + rank, B, T_in, T_out)
+    dw = {k: torch.from_numpy(v).cuda() for k, v in w.items()}
+    d_enc, d_dec0 = torch.from_numpy(enc).cuda(), torch.from_numpy(dec0).cuda()
+    out = torch.empty((B, T_out, F_dec), dtype=torch.float32, device="cuda")
+    ws = ops.Workspace()
+
+    def step():
+        ops.seq2seq_decode(d_enc, d_dec0, dw, T_out, act=args.act, impl=args.impl, workspace=ws, out=out)
+
+    for _ in range(args.warmup):
+        step()
+    ws.check()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    ev0 = torch.cuda.Event(enable_timing=True)
+    ev1 = torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(args.steps):
+        step()
+    ev1.record()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    ws.check()
+    step_ms_events = ev0.elapsed_time(ev1) / args.steps
+    if use_dist:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    result = None
+    if rank == 0:
+        f_enc, f_dec = flops_per_seq(T_in, T_out, F_enc, F_dec, H)
+        flop_step = (f_enc + f_dec) * B
+        achieved = flop_step / (step_ms_events * 1e-3) / 1e12
+        # per-launch breakdown: the same two kernels, event-timed on their own
+        hT = torch.empty((B, H), dtype=torch.float32, device="cuda")
+
+        def enc_only():
+            ops.lstm_seq(d_enc, dw["enc_K"], dw["enc_R"], dw["enc_b"], act=args.act, impl=args.impl,
+                         return_sequences=False, workspace=ws)
+
+        enc_only()
+        enc_ms = event_time_ms(enc_only, max(5, args.steps // 2))
+        dec_ms = max(step_ms_events - enc_ms, 0.0)
+
+        # parity spot check on the measured configuration (first 64 sequences vs the C oracle)
+        from oracle import c_oracle as C
+        nchk = min(64, B)
+        ref = C.seq2seq_decode(enc[:nchk], dec0[:nchk], w, T_out, ops.act_code(args.act))
+        got = out[:nchk].cpu().numpy()
+        max_abs = float(np.abs(got - ref).max()) if nchk else 0.0
+        mse = float(np.mean((got.astype(np.float64) - ref) ** 2)) if nchk else 0.0
+
+        cpu = None
+        if not args.no_cpu_baseline:
+            reps = 3
+            C.seq2seq_decode(enc[:64], dec0[:64], w, T_out)            # warm
+            tc = time.perf_counter()
+            for _ in range(reps):
+                C.seq2seq_decode(enc, dec0, w, T_out, ops.act_code(args.act))
+            dt = time.perf_counter() - tc
+            cpu = {"value": B * reps / dt, "unit": "sequences/s", "cores": C.num_threads(), "kind": "port",
+                   "sample": "%d passes of the C oracle (oracle/lstm_ref.c, OpenMP) over the same %d-sequence "
+                             "batch, T %d->%d, H=%d" % (reps, B, T_in, T_out, H)}
+
+        value = world * B * args.steps / elapsed
+        result = {
+            "metric": "sequences/sec (batch=1024, T_in=30->T_out=30, h=256)",
+            "value": value, "unit": "sequences/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[1]: target-only seq2seq inference (encoder + autoregressive decoder), "
+                                   "H=%d, batch=%d per GPU, T_in=%d->T_out=%d, F_enc=90, F_dec=6, fp32, act=%s, impl=%s"
+                                   % (H, B, T_in, T_out, args.act, args.impl),
+                       "global_batch": B * world, "parallelism": "replicas x%d (no collective)" % world},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                         "flop_per_launch": flop_step, "launch_ms": step_ms_events,
+                         "note": "launch = one step = encoder kernel + decoder kernel of lstm_cluster_kernel"},
+            "kernels": {"encoder_ms": enc_ms, "decoder_ms": dec_ms,
+                        "encoder_tflops": f_enc * B / (enc_ms * 1e-3) / 1e12,
+                        "decoder_tflops": (f_dec * B / (dec_ms * 1e-3) / 1e12) if dec_ms > 0 else None},
+            "parity": {"max_abs_err_vs_oracle": max_abs, "mse_vs_oracle": mse, "sequences_checked": nchk},
+            "cpu_baseline": cpu,
+        }
+        if cpu:
+            result["speedup_vs_cpu_baseline"] = value / cpu["value"]
+        print(json.dumps(result), flush=True)
+    if use_dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

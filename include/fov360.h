@@ -1,0 +1,136 @@
+/*
+ * fov360.h - C ABI of the MI355X-native seq2seq-LSTM hot path (libfov360_hip.so).
+ *
+ * Drop-in boundary for the path BASELINE.json:north_star names in ChengeLi/LongTerm360FoV:
+ * the reference has no native code; every entry point below replaces a Keras/TensorFlow
+ * layer call made by the reference's model scripts (file:line cited per function, relative to
+ * /root/reference/).  A maintainer of the reference binds these with ctypes.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes; no torch / HIP types in the signatures
+ *     (fov_stream_t is an opaque hipStream_t; NULL = the default stream).
+ *   - All tensors are DEVICE pointers, row-major contiguous fp32.  The caller owns every
+ *     buffer; the library allocates nothing persistent.  Scratch comes from a caller-provided
+ *     workspace whose size is queried first (fov_*_workspace_bytes).
+ *   - Weights use the Keras layout so weight files round-trip:
+ *       kernel K:(F,4H), recurrent_kernel R:(H,4H), bias b:(4H); gate column blocks i,f,c,o.
+ *   - Every function returns FOV_OK (0) or a negative FOV_ERR_*; fov_last_error() gives the
+ *     message of the calling thread's last failure.  No host synchronisation inside a call
+ *     (except fov_check_status, which is the explicit "did the persistent kernel finish
+ *     cleanly" query).
+ *   - Re-entrant and thread-compatible: no mutable globals besides a thread-local error string
+ *     and a read-only device-property cache.  One stream per call.
+ */
+#ifndef FOV360_H
+#define FOV360_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* fov_stream_t; /* hipStream_t */
+
+/* recurrent_activation of keras.layers.LSTM.  Keras < 2.3 (the reference's era) defaults to
+ * hard_sigmoid = clip(0.2x+0.5,0,1); BASELINE.json:north_star names sigmoid. */
+enum { FOV_ACT_SIGMOID = 0, FOV_ACT_HARD_SIGMOID = 1 };
+
+/* kernel family selection */
+enum {
+    FOV_IMPL_AUTO = 0,    /* cluster kernel when the shape is supported, else generic        */
+    FOV_IMPL_GENERIC = 1, /* one workgroup per 4 sequences, weights streamed from L2; any H,F */
+    FOV_IMPL_CLUSTER = 2  /* persistent MFMA kernel: H/64 workgroups per 16-sequence tile,
+                             recurrent weights resident in registers, h exchanged per step   */
+};
+
+enum {
+    FOV_OK = 0,
+    FOV_ERR_INVALID = -1,     /* bad argument (null pointer, negative size, ...)              */
+    FOV_ERR_UNSUPPORTED = -2, /* shape not supported by the requested implementation          */
+    FOV_ERR_WORKSPACE = -3,   /* workspace missing or too small                               */
+    FOV_ERR_LAUNCH = -4,      /* HIP runtime error (message in fov_last_error)                */
+    FOV_ERR_TIMEOUT = -5      /* a bounded in-kernel wait gave up (fov_check_status)          */
+};
+
+const char* fov_last_error(void);
+int fov_version(void);
+
+/* 1 if FOV_IMPL_CLUSTER supports (F,H) for a layer / (F_enc,F_dec,H) for the fused decode. */
+int fov_cluster_supported(int F, int H);
+
+/* ---------------------------------------------------------------------------------------
+ * keras.layers.LSTM(H, return_sequences=True, return_state=True)(x, initial_state=[h0,c0])
+ *   replaces: mycode/FoV_seq2seq.py:83-86 (encoder), :93-95 (teacher-forced decoder),
+ *             mycode/given_others_gt_mean_var_seq2seq.py:108-112.
+ *   x:(B,T,F)  h0,c0:(B,H) or NULL (= zeros)  hs:(B,T,H) or NULL  hT,cT:(B,H) or NULL
+ * ------------------------------------------------------------------------------------- */
+size_t fov_lstm_seq_workspace_bytes(int B, int T, int F, int H, int impl);
+int fov_lstm_seq_fwd(const float* x, const float* K, const float* R, const float* b,
+                     const float* h0, const float* c0, float* hs, float* hT, float* cT,
+                     int B, int T, int F, int H, int act, int impl,
+                     void* workspace, size_t workspace_bytes, fov_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * keras.layers.Dense(Out, activation)(x)   y = act(x W + b), W:(In,Out)
+ *   replaces: mycode/FoV_seq2seq.py:96-97; given_others...py:127-130,168.
+ *   activation: 0 = linear, 1 = tanh.   x:(N,In)  y:(N,Out)
+ * ------------------------------------------------------------------------------------- */
+int fov_dense_fwd(const float* x, const float* W, const float* b, float* y,
+                  int N, int In, int Out, int activation, fov_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Fused inference path: encoder LSTM over T_in steps from zero state, then T_out
+ * autoregressive decoder steps, each = LSTM step + Dense(F_dec,'tanh') + feedback, all on
+ * device in ONE launch.
+ *   replaces: the host loop mycode/FoV_seq2seq.py:154-178 over encoder_model / decoder_model
+ *             (:137-148), batched.
+ *   enc_in:(B,T_in,F_enc)  dec_in0:(B,1,F_dec)  out:(B,T_out,F_dec)
+ *   hT,cT: final decoder state (B,H) or NULL.
+ * ------------------------------------------------------------------------------------- */
+size_t fov_seq2seq_decode_workspace_bytes(int B, int T_in, int T_out, int F_enc, int F_dec, int H, int impl);
+int fov_seq2seq_decode_fwd(const float* enc_in, const float* dec_in0,
+                           const float* enc_K, const float* enc_R, const float* enc_b,
+                           const float* dec_K, const float* dec_R, const float* dec_b,
+                           const float* dense_W, const float* dense_b,
+                           float* out, float* hT, float* cT,
+                           int B, int T_in, int T_out, int F_enc, int F_dec, int H,
+                           int act, int impl,
+                           void* workspace, size_t workspace_bytes, fov_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Teacher-forced training-graph forward: encoder, decoder seeded with the encoder state over
+ * GT decoder inputs, Dense(tanh) on every decoder output.
+ *   replaces: model.predict / the forward half of model.fit on the graph built at
+ *             mycode/FoV_seq2seq.py:82-101.
+ *   dec_in:(B,T_out,F_dec)  out:(B,T_out,F_dec)
+ *   workspace additionally holds the decoder hidden sequence (B,T_out,H).
+ * ------------------------------------------------------------------------------------- */
+size_t fov_seq2seq_tf_workspace_bytes(int B, int T_in, int T_out, int F_enc, int F_dec, int H, int impl);
+int fov_seq2seq_tf_fwd(const float* enc_in, const float* dec_in,
+                       const float* enc_K, const float* enc_R, const float* enc_b,
+                       const float* dec_K, const float* dec_R, const float* dec_b,
+                       const float* dense_W, const float* dense_b,
+                       float* out,
+                       int B, int T_in, int T_out, int F_enc, int F_dec, int H,
+                       int act, int impl,
+                       void* workspace, size_t workspace_bytes, fov_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * mu / sigma^2 feature op: per row of `fps` interleaved xyz frames -> [mx,my,mz,vx,vy,vz]
+ * (population variance, ddof = 0).
+ *   replaces: mycode/utility.py:483-500 (get_gt_target_xyz) and :505-517 (_oth); the (N,T,90)
+ *   and (N,T,30,3) layouts are the same bytes, so `rows` = N*T (or N*T*U for others).
+ *   y:(rows, 3*fps)  out:(rows, 6)
+ * ------------------------------------------------------------------------------------- */
+int fov_meanvar_xyz(const float* y, float* out, int64_t rows, int fps, fov_stream_t stream);
+
+/* Synchronises `stream`, reads the status word a persistent-kernel call left in `workspace`
+ * and returns FOV_OK or FOV_ERR_TIMEOUT.  Workspaces of non-persistent calls report FOV_OK. */
+int fov_check_status(const void* workspace, size_t workspace_bytes, fov_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FOV360_H */

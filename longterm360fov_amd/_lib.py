@@ -1,0 +1,73 @@
+"""ctypes binding of libfov360_hip.so (the C ABI declared in include/fov360.h).
+
+There is NO CPU fallback: if the HIP library is missing the import of any compute entry point
+fails loudly.  Loading the library and querying its symbols does not need a GPU.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libfov360_hip.so")
+
+ACT_SIGMOID = 0
+ACT_HARD_SIGMOID = 1
+IMPL_AUTO = 0
+IMPL_GENERIC = 1
+IMPL_CLUSTER = 2
+
+OK = 0
+ERR_INVALID = -1
+ERR_UNSUPPORTED = -2
+ERR_WORKSPACE = -3
+ERR_LAUNCH = -4
+ERR_TIMEOUT = -5
+
+_P = ctypes.c_void_p
+_I = ctypes.c_int
+_SZ = ctypes.c_size_t
+
+# name -> (restype, argtypes); mirrors include/fov360.h one to one
+SIGNATURES = {
+    "fov_last_error": (ctypes.c_char_p, []),
+    "fov_version": (_I, []),
+    "fov_cluster_supported": (_I, [_I, _I]),
+    "fov_lstm_seq_workspace_bytes": (_SZ, [_I, _I, _I, _I, _I]),
+    "fov_lstm_seq_fwd": (_I, [_P] * 9 + [_I] * 6 + [_P, _SZ, _P]),
+    "fov_dense_fwd": (_I, [_P] * 4 + [_I] * 4 + [_P]),
+    "fov_seq2seq_decode_workspace_bytes": (_SZ, [_I] * 7),
+    "fov_seq2seq_decode_fwd": (_I, [_P] * 13 + [_I] * 8 + [_P, _SZ, _P]),
+    "fov_seq2seq_tf_workspace_bytes": (_SZ, [_I] * 7),
+    "fov_seq2seq_tf_fwd": (_I, [_P] * 11 + [_I] * 8 + [_P, _SZ, _P]),
+    "fov_meanvar_xyz": (_I, [_P, _P, ctypes.c_int64, _I, _P]),
+    "fov_check_status": (_I, [_P, _SZ, _P]),
+}
+
+_lib = None
+
+
+class FovError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("libfov360_hip: error %d: %s" % (code, msg))
+        self.code = code
+
+
+def lib():
+    """The loaded library (raises if the HIP extension has not been built)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "HIP extension missing: %s (build it with `python __graft_entry__.py` or "
+                "`make -C longterm360fov_amd/csrc`); there is no CPU fallback" % LIB_PATH)
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(code):
+    if code != OK:
+        raise FovError(code, lib().fov_last_error().decode("utf-8", "replace"))

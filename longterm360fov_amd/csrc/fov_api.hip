@@ -1,0 +1,259 @@
+// extern "C" entry points of libfov360_hip.so (declared in include/fov360.h) plus the small
+// non-recurrent kernels of the path: Dense(+tanh) and the mu/sigma^2 feature op.
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "fov_common.h"
+
+namespace fov {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+// ---------------------------------------------------------------------------------------
+// Dense: y = act(x W + b).  One wave per output row; lanes stride over In, shuffle-reduce.
+// Memory-bound streaming op (x is read once; W stays in L2): used for the teacher-forced
+// graph's Dense over (B*T_out, H) -> F_dec and for tests.
+// ---------------------------------------------------------------------------------------
+constexpr int DENSE_MAX_OUT = 16;
+
+__global__ __launch_bounds__(256) void dense_kernel(const float* __restrict__ x, const float* __restrict__ W,
+                                                    const float* __restrict__ b, float* __restrict__ y,
+                                                    int N, int In, int Out, int activation) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= N) return;
+    const float* xr = x + (size_t)row * In;
+    for (int o0 = 0; o0 < Out; o0 += DENSE_MAX_OUT) {
+        const int no = (Out - o0 < DENSE_MAX_OUT) ? Out - o0 : DENSE_MAX_OUT;
+        float acc[DENSE_MAX_OUT];
+#pragma unroll
+        for (int o = 0; o < DENSE_MAX_OUT; ++o) acc[o] = 0.f;
+        for (int k = lane; k < In; k += 64) {
+            const float xv = xr[k];
+            const float* wr = W + (size_t)k * Out + o0;
+#pragma unroll
+            for (int o = 0; o < DENSE_MAX_OUT; ++o)
+                if (o < no) acc[o] = fmaf(xv, wr[o], acc[o]);
+        }
+#pragma unroll
+        for (int o = 0; o < DENSE_MAX_OUT; ++o)
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) acc[o] += __shfl_xor(acc[o], m);
+        float mine = 0.f;
+#pragma unroll
+        for (int o = 0; o < DENSE_MAX_OUT; ++o) mine = (lane == o) ? acc[o] : mine;
+        if (lane < no) {
+            float v = mine + (b ? b[o0 + lane] : 0.f);
+            if (activation == 1) v = tanh_f(v);
+            y[(size_t)row * Out + o0 + lane] = v;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// mu / sigma^2 feature op (utility.py:483-517): one thread per (row, axis); two-pass
+// population variance like numpy.var (mean first, then mean of squared deviations).
+// HBM-bound: 12*fps bytes in, 24 bytes out per row.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void meanvar_kernel(const float* __restrict__ y, float* __restrict__ out,
+                                                      long rows, int fps) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * 3) return;
+    const long row = i / 3;
+    const int ax = (int)(i - row * 3);
+    const float* p = y + (size_t)row * 3 * fps + ax;
+    float s = 0.f;
+    for (int f = 0; f < fps; ++f) s += p[3 * f];
+    const float mean = s / (float)fps;
+    float v = 0.f;
+    for (int f = 0; f < fps; ++f) {
+        const float d = p[3 * f] - mean;
+        v = fmaf(d, d, v);
+    }
+    out[row * 6 + ax] = mean;
+    out[row * 6 + 3 + ax] = v / (float)fps;
+}
+
+static bool want_cluster(int impl, int F, int H, int F_dec, bool decode) {
+    if (impl == FOV_IMPL_GENERIC) return false;
+    const bool ok = cluster_shape_ok(F, H) && (!decode || (F_dec >= 1 && F_dec <= 8));
+    return impl == FOV_IMPL_CLUSTER ? true : ok;
+}
+
+static int check_ws(void* ws, size_t have, size_t need) {
+    if (need == 0) return FOV_OK;
+    if (!ws || have < need) {
+        set_error("workspace too small: need %zu bytes, have %zu", need, ws ? have : (size_t)0);
+        return FOV_ERR_WORKSPACE;
+    }
+    if (((uintptr_t)ws & 15) != 0) {
+        set_error("workspace must be 16-byte aligned");
+        return FOV_ERR_WORKSPACE;
+    }
+    return FOV_OK;
+}
+
+}  // namespace fov
+
+using namespace fov;
+
+extern "C" {
+
+const char* fov_last_error(void) { return g_err; }
+int fov_version(void) { return 100; }
+
+int fov_cluster_supported(int F, int H) { return cluster_shape_ok(F, H) ? 1 : 0; }
+
+size_t fov_lstm_seq_workspace_bytes(int B, int T, int F, int H, int impl) {
+    (void)T;
+    if (B <= 0) return kStatusBytes;
+    return want_cluster(impl, F, H, 0, false) && cluster_shape_ok(F, H) ? cluster_workspace_bytes(B, H) : kStatusBytes;
+}
+
+int fov_lstm_seq_fwd(const float* x, const float* K, const float* R, const float* b, const float* h0,
+                     const float* c0, float* hs, float* hT, float* cT, int B, int T, int F, int H, int act,
+                     int impl, void* workspace, size_t workspace_bytes, fov_stream_t stream) {
+    if (B < 0 || T < 0 || F <= 0 || H <= 0 || !K || !R || !b || (B > 0 && T > 0 && !x) ||
+        (act != FOV_ACT_SIGMOID && act != FOV_ACT_HARD_SIGMOID)) {
+        set_error("fov_lstm_seq_fwd: invalid argument");
+        return FOV_ERR_INVALID;
+    }
+    int rc = check_ws(workspace, workspace_bytes, fov_lstm_seq_workspace_bytes(B, T, F, H, impl));
+    if (rc) return rc;
+    LstmParams p = {};
+    p.x = x; p.K = K; p.R = R; p.b = b; p.h0 = h0; p.c0 = c0; p.hs = hs; p.hT = hT; p.cT = cT;
+    p.B = B; p.T = T; p.F = F; p.H = H; p.act = act;
+    p.status = (unsigned*)workspace;
+    p.xch = (unsigned long long*)((char*)workspace + kStatusBytes);
+    hipStream_t s = (hipStream_t)stream;
+    if (want_cluster(impl, F, H, 0, false)) return launch_cluster(p, false, s);
+    if (B > 0) {
+        hipError_t e = hipMemsetAsync(workspace, 0, kStatusBytes, s);
+        if (e != hipSuccess) { set_error("hipMemsetAsync: %s", hipGetErrorString(e)); return FOV_ERR_LAUNCH; }
+    }
+    return launch_generic(p, false, s);
+}
+
+int fov_dense_fwd(const float* x, const float* W, const float* b, float* y, int N, int In, int Out,
+                  int activation, fov_stream_t stream) {
+    if (N < 0 || In <= 0 || Out <= 0 || !W || (N > 0 && (!x || !y)) || (activation != 0 && activation != 1)) {
+        set_error("fov_dense_fwd: invalid argument");
+        return FOV_ERR_INVALID;
+    }
+    if (N == 0) return FOV_OK;
+    hipLaunchKernelGGL(dense_kernel, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, W, b, y, N, In, Out, activation);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_error("dense launch: %s", hipGetErrorString(e)); return FOV_ERR_LAUNCH; }
+    return FOV_OK;
+}
+
+size_t fov_seq2seq_decode_workspace_bytes(int B, int T_in, int T_out, int F_enc, int F_dec, int H, int impl) {
+    (void)T_in; (void)T_out;
+    if (B <= 0) return kStatusBytes;
+    return want_cluster(impl, F_enc, H, F_dec, true) && cluster_shape_ok(F_enc, H) ? cluster_workspace_bytes(B, H) : kStatusBytes;
+}
+
+int fov_seq2seq_decode_fwd(const float* enc_in, const float* dec_in0, const float* enc_K, const float* enc_R,
+                           const float* enc_b, const float* dec_K, const float* dec_R, const float* dec_b,
+                           const float* dense_W, const float* dense_b, float* out, float* hT, float* cT, int B,
+                           int T_in, int T_out, int F_enc, int F_dec, int H, int act, int impl, void* workspace,
+                           size_t workspace_bytes, fov_stream_t stream) {
+    if (B < 0 || T_in < 0 || T_out < 0 || F_enc <= 0 || F_dec <= 0 || H <= 0 || !enc_K || !enc_R || !enc_b ||
+        !dec_K || !dec_R || !dec_b || !dense_W || !dense_b ||
+        (B > 0 && ((T_in > 0 && !enc_in) || !dec_in0 || (T_out > 0 && !out))) ||
+        (act != FOV_ACT_SIGMOID && act != FOV_ACT_HARD_SIGMOID)) {
+        set_error("fov_seq2seq_decode_fwd: invalid argument");
+        return FOV_ERR_INVALID;
+    }
+    if (F_dec > 64) { set_error("fov_seq2seq_decode_fwd: F_dec > 64 unsupported"); return FOV_ERR_UNSUPPORTED; }
+    int rc = check_ws(workspace, workspace_bytes, fov_seq2seq_decode_workspace_bytes(B, T_in, T_out, F_enc, F_dec, H, impl));
+    if (rc) return rc;
+    LstmParams p = {};
+    p.x = enc_in; p.K = enc_K; p.R = enc_R; p.b = enc_b; p.hT = hT; p.cT = cT;
+    p.dec_in0 = dec_in0; p.dK = dec_K; p.dR = dec_R; p.db = dec_b; p.dW = dense_W; p.dbias = dense_b; p.out = out;
+    p.B = B; p.T = T_in; p.F = F_enc; p.H = H; p.T_out = T_out; p.F_dec = F_dec; p.act = act;
+    p.status = (unsigned*)workspace;
+    p.xch = (unsigned long long*)((char*)workspace + kStatusBytes);
+    hipStream_t s = (hipStream_t)stream;
+    if (want_cluster(impl, F_enc, H, F_dec, true)) return launch_cluster(p, true, s);
+    if (B > 0) {
+        hipError_t e = hipMemsetAsync(workspace, 0, kStatusBytes, s);
+        if (e != hipSuccess) { set_error("hipMemsetAsync: %s", hipGetErrorString(e)); return FOV_ERR_LAUNCH; }
+    }
+    return launch_generic(p, true, s);
+}
+
+static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+size_t fov_seq2seq_tf_workspace_bytes(int B, int T_in, int T_out, int F_enc, int F_dec, int H, int impl) {
+    if (B <= 0) return kStatusBytes;
+    size_t a = fov_lstm_seq_workspace_bytes(B, T_in, F_enc, H, impl);
+    size_t c = fov_lstm_seq_workspace_bytes(B, T_out, F_dec, H, impl);
+    size_t lstm = align256(a > c ? a : c);
+    // + encoder final state (h,c) + decoder hidden sequence
+    return lstm + align256((size_t)2 * B * H * sizeof(float)) + align256((size_t)B * T_out * H * sizeof(float));
+}
+
+int fov_seq2seq_tf_fwd(const float* enc_in, const float* dec_in, const float* enc_K, const float* enc_R,
+                       const float* enc_b, const float* dec_K, const float* dec_R, const float* dec_b,
+                       const float* dense_W, const float* dense_b, float* out, int B, int T_in, int T_out,
+                       int F_enc, int F_dec, int H, int act, int impl, void* workspace, size_t workspace_bytes,
+                       fov_stream_t stream) {
+    if (B < 0 || T_in < 0 || T_out < 0 || F_enc <= 0 || F_dec <= 0 || H <= 0) {
+        set_error("fov_seq2seq_tf_fwd: invalid argument");
+        return FOV_ERR_INVALID;
+    }
+    int rc = check_ws(workspace, workspace_bytes, fov_seq2seq_tf_workspace_bytes(B, T_in, T_out, F_enc, F_dec, H, impl));
+    if (rc) return rc;
+    if (B == 0) return FOV_OK;
+    size_t a = fov_lstm_seq_workspace_bytes(B, T_in, F_enc, H, impl);
+    size_t c = fov_lstm_seq_workspace_bytes(B, T_out, F_dec, H, impl);
+    const size_t lstm = align256(a > c ? a : c);
+    char* base = (char*)workspace;
+    float* hT = (float*)(base + lstm);
+    float* cT = hT + (size_t)B * H;
+    float* hs = (float*)(base + lstm + align256((size_t)2 * B * H * sizeof(float)));
+    rc = fov_lstm_seq_fwd(enc_in, enc_K, enc_R, enc_b, nullptr, nullptr, nullptr, hT, cT, B, T_in, F_enc, H, act,
+                          impl, workspace, lstm, stream);
+    if (rc) return rc;
+    rc = fov_lstm_seq_fwd(dec_in, dec_K, dec_R, dec_b, hT, cT, hs, nullptr, nullptr, B, T_out, F_dec, H, act, impl,
+                          workspace, lstm, stream);
+    if (rc) return rc;
+    return fov_dense_fwd(hs, dense_W, dense_b, out, B * T_out, H, F_dec, 1, stream);
+}
+
+int fov_meanvar_xyz(const float* y, float* out, int64_t rows, int fps, fov_stream_t stream) {
+    if (rows < 0 || fps <= 0 || (rows > 0 && (!y || !out))) {
+        set_error("fov_meanvar_xyz: invalid argument");
+        return FOV_ERR_INVALID;
+    }
+    if (rows == 0) return FOV_OK;
+    const long n = rows * 3;
+    hipLaunchKernelGGL(meanvar_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, y, out,
+                       (long)rows, fps);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_error("meanvar launch: %s", hipGetErrorString(e)); return FOV_ERR_LAUNCH; }
+    return FOV_OK;
+}
+
+int fov_check_status(const void* workspace, size_t workspace_bytes, fov_stream_t stream) {
+    if (!workspace || workspace_bytes < kStatusBytes) {
+        set_error("fov_check_status: invalid workspace");
+        return FOV_ERR_INVALID;
+    }
+    unsigned st = 0;
+    hipError_t e = hipMemcpyAsync(&st, workspace, sizeof(st), hipMemcpyDeviceToHost, (hipStream_t)stream);
+    if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+    if (e != hipSuccess) { set_error("fov_check_status: %s", hipGetErrorString(e)); return FOV_ERR_LAUNCH; }
+    if (st != 0) { set_error("a bounded in-kernel wait gave up (status=%u)", st); return FOV_ERR_TIMEOUT; }
+    return FOV_OK;
+}
+
+}  // extern "C"

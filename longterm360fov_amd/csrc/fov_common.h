@@ -1,0 +1,68 @@
+// Shared device/host helpers for libfov360_hip.so (gfx950 only; wave = 64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/fov360.h"
+
+namespace fov {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// Gate activations.  v_exp_f32 / v_rcp_f32 based (about 1 ulp each); absolute error of the
+// logistic and of tanh is below 3e-7, far inside the 1e-3 relative parity bound on outputs.
+__device__ __forceinline__ float sigmoid_f(float x) {
+    return __frcp_rn(1.0f + __expf(-x));
+}
+__device__ __forceinline__ float hard_sigmoid_f(float x) {
+    return fminf(fmaxf(fmaf(0.2f, x, 0.5f), 0.0f), 1.0f);
+}
+__device__ __forceinline__ float tanh_f(float x) {
+    // 1 - 2/(1+e^{2x}); saturates cleanly to +-1, no NaN for any finite x
+    return 1.0f - 2.0f * __frcp_rn(1.0f + __expf(2.0f * x));
+}
+template <int ACT>
+__device__ __forceinline__ float rec_act(float x) {
+    return ACT == FOV_ACT_HARD_SIGMOID ? hard_sigmoid_f(x) : sigmoid_f(x);
+}
+
+// Everything one launch of the LSTM kernels needs.  Phase 1 ("layer"/encoder): T steps over
+// x:(B,T,F) with weights K,R,b from (h0,c0).  Phase 2 (decode only): T_out autoregressive
+// steps with weights dK,dR,db fed by y_{t-1} = tanh(h W + bias), y_{-1} = dec_in0.
+struct LstmParams {
+    const float* x;
+    const float* K;
+    const float* R;
+    const float* b;
+    const float* h0;
+    const float* c0;
+    float* hs;
+    float* hT;
+    float* cT;
+    const float* dec_in0;
+    const float* dK;
+    const float* dR;
+    const float* db;
+    const float* dW;
+    const float* dbias;
+    float* out;
+    int B, T, F, H;
+    int T_out, F_dec;
+    int act;
+    // cluster kernel only
+    unsigned long long* xch;   // granule exchange buffers
+    unsigned* status;          // status[0] = timeout flag
+    int num_groups;            // resident groups (persistent loop over 16-sequence tiles)
+    int num_tiles;
+};
+
+int launch_generic(const LstmParams& p, bool decode, hipStream_t stream);
+int launch_cluster(const LstmParams& p, bool decode, hipStream_t stream);
+bool cluster_shape_ok(int F, int H);
+size_t cluster_workspace_bytes(int B, int H);
+int cluster_num_groups(int B, int H);
+void set_error(const char* fmt, ...);
+
+constexpr size_t kStatusBytes = 256;  // head of every workspace: status words
+
+}  // namespace fov

@@ -1,0 +1,451 @@
+// Persistent cluster LSTM kernel for gfx950 (MI355X) - the fast path.
+//
+// Replaces the keras LSTM / Dense calls of mycode/FoV_seq2seq.py:83-97 and the host-driven
+// decode loop :154-178 (see include/fov360.h).  Gate order i,f,c,o; weights in Keras layout.
+//
+// Decomposition (H = 64*G, G in {1,2,4}):
+//   * a TILE is 16 sequences (the M of v_mfma_f32_16x16x4_f32);
+//   * a GROUP of G workgroups owns one tile at a time; workgroup `slice` owns hidden units
+//     [64*slice, 64*slice+64) for ALL FOUR gates, so the cell update is lane-local and c never
+//     leaves registers;
+//   * wave w of a workgroup owns 16 of those units; lane l = (g4 = l>>4, n = l&15) holds, in the
+//     MFMA D layout, gate pre-activations of unit n for sequences 4*g4 .. 4*g4+3;
+//   * the recurrent weight slice R[:, 4 gates x 16 units] of a wave lives in H VGPRs/AGPRs per
+//     lane for the whole sequence (H=256: 256 registers), used directly as MFMA B operands;
+//   * the input-kernel slice K[:, ...] sits in LDS in B-operand order (lane-linear b128 reads);
+//   * the running h tile (16 x H) sits in LDS and is the MFMA A operand; x_{t+1} is prefetched
+//     global -> registers -> LDS behind the MFMAs of step t;
+//   * per step each workgroup publishes its 16x64 slice of h_t as 8-byte {epoch,value}
+//     granules (one sc1 store each; the data is the flag) and sweeps the other G-1 slices with
+//     sc1 loads until every tag equals the epoch (cdna_hip_programming.md Guideline 16, R2).
+//     Two parity buffers per group make the reuse race-free (a workgroup can only publish
+//     epoch e+2 after every partner has consumed epoch e).
+//   * every spin is bounded; a give-up sets status[0] and all workgroups drain.
+//
+// Two launch modes share one step body: MODE_LAYER (an LSTM layer over x) and MODE_DECODE (the
+// autoregressive decoder with the Dense+tanh feedback inside the loop).  The fused inference
+// path is an encoder launch followed by a decoder launch seeded from the encoder's final
+// (h, c): one kernel holding both weight sets made hipcc spill.
+//
+// k order inside a 16-wide block is permuted so that one ds_read_b128 feeds four MFMAs:
+// MFMA s of block q uses k = 16q + 4*g4 + s on lanes with (l>>4) == g4, for A and B alike.
+#include "fov_common.h"
+
+namespace fov {
+
+constexpr int BT = 16;          // sequences per tile
+constexpr int XR = 6;           // x prefetch registers per thread: 16 rows * F <= 256 * XR
+constexpr int CL_MAX_F = 96;
+constexpr int CL_MAX_O = 8;
+constexpr unsigned SPIN_LIMIT = 1u << 20;
+
+constexpr int MODE_LAYER = 0;   // T steps over x:(B,T,F) from (h0,c0); optional hs / hT / cT
+constexpr int MODE_DECODE = 1;  // T_out autoregressive steps from (h0,c0): y_t = tanh(h_t W + bias) fed back
+
+__device__ __forceinline__ unsigned long long ld_granule(const unsigned long long* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_granule(unsigned long long* p, unsigned long long v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__host__ __device__ constexpr int round16(int v) { return (v + 15) & ~15; }
+
+struct ClusterLds {
+    int ldx, ldh;
+    int off_k, off_h, off_x, off_w, off_bd, off_flag, total_floats;
+};
+__host__ __device__ inline ClusterLds cluster_lds(int H, int F, bool decode) {
+    ClusterLds L;
+    const int fp = round16(F);
+    L.ldx = fp + 4;
+    L.ldh = H + 4;
+    L.off_k = 0;
+    L.off_h = L.off_k + fp * 256;
+    L.off_x = L.off_h + BT * L.ldh;
+    L.off_w = L.off_x + 2 * BT * L.ldx;
+    L.off_bd = L.off_w + (decode ? H * CL_MAX_O : 0);
+    L.off_flag = L.off_bd + 8;
+    L.total_floats = L.off_flag + 8;
+    return L;
+}
+
+// Load one LSTM's weights for this wave: R slice -> registers, K slice -> LDS, bias -> registers.
+template <int H>
+__device__ __forceinline__ void load_weights(f32x4 (&wR)[H / 16][4], float (&bias)[4], float* sKw,
+                                             const float* K, const float* R, const float* b, int F, int Fp,
+                                             int col0, int lane) {
+    const int n = lane & 15, g4 = lane >> 4;
+    const int H4 = 4 * H;
+#pragma unroll
+    for (int q = 0; q < H / 16; ++q)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+                wR[q][g][s] = R[(size_t)(16 * q + 4 * g4 + s) * H4 + g * H + col0 + n];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bias[g] = b[g * H + col0 + n];
+    const int nq = Fp >> 4;
+    for (int q = 0; q < nq; ++q)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4 v;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int k = 16 * q + 4 * g4 + s;
+                v[s] = (k < F) ? K[(size_t)k * H4 + g * H + col0 + n] : 0.f;
+            }
+            *(f32x4*)(sKw + ((q * 4 + g) * 64 + lane) * 4) = v;
+        }
+}
+
+template <int H, int ACT, int MODE>
+__global__ __launch_bounds__(256, 1) void lstm_cluster_kernel(LstmParams p) {
+    constexpr int G = H / 64;
+    constexpr int NQ = H / 16;
+    constexpr int NG = (G - 1) * 4;  // granules gathered per thread per step
+    constexpr bool LAYER = (MODE == MODE_LAYER);
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 15, g4 = lane >> 4;
+    const int group = blockIdx.x / G, slice = blockIdx.x - group * G;
+    const int col0 = slice * 64 + wave * 16;  // first hidden unit of this wave
+
+    // weights / input of the phase this launch runs
+    const float* Kp = LAYER ? p.K : p.dK;
+    const float* Rp = LAYER ? p.R : p.dR;
+    const float* bp = LAYER ? p.b : p.db;
+    const int F = LAYER ? p.F : p.F_dec;
+    const int steps = LAYER ? p.T : p.T_out;
+    const int Fp = round16(F);
+
+    const ClusterLds L = cluster_lds(H, F, !LAYER);
+    const int LDX = L.ldx, LDH = L.ldh;
+    float* sK = smem + L.off_k;
+    float* sH = smem + L.off_h;
+    float* sX = smem + L.off_x;
+    float* sW = smem + L.off_w;
+    float* sBd = smem + L.off_bd;
+    int* sFlag = (int*)(smem + L.off_flag);
+    float* sKw = sK + wave * (Fp >> 4) * 1024;  // this wave's K slice in B-operand order
+
+    if (tid == 0) sFlag[0] = 0;
+    // zero both x buffers once: pad columns [F, Fp) are never written afterwards
+    for (int i = tid; i < 2 * BT * LDX; i += 256) sX[i] = 0.f;
+
+    f32x4 wR[NQ][4];
+    float bias[4];
+    load_weights<H>(wR, bias, sKw, Kp, Rp, bp, F, Fp, col0, lane);
+    if (!LAYER) {
+        const int O = p.F_dec;
+        for (int i = tid; i < H * CL_MAX_O; i += 256) {
+            const int k = i >> 3, o = i & 7;
+            sW[i] = (o < O) ? p.dW[(size_t)k * O + o] : 0.f;
+        }
+        if (tid < CL_MAX_O) sBd[tid] = (tid < O) ? p.dbias[tid] : 0.f;
+    }
+
+    unsigned epoch = 0;
+    bool aborted = false;
+
+    for (int tile = group; tile < p.num_tiles && !aborted; tile += p.num_groups) {
+        const int b0 = tile * BT;
+        // ---- initial state (the previous tile ended on a barrier) ----
+        float c[4], hcur[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = b0 + 4 * g4 + r;
+            const bool live = row < p.B;
+            c[r] = (live && p.c0) ? p.c0[(size_t)row * H + col0 + n] : 0.f;
+            hcur[r] = (live && p.h0) ? p.h0[(size_t)row * H + col0 + n] : 0.f;
+        }
+        for (int i = tid; i < BT * H; i += 256) {
+            const int row = i / H, col = i - row * H;
+            sH[row * LDH + col] = (b0 + row < p.B && p.h0) ? p.h0[(size_t)(b0 + row) * H + col] : 0.f;
+        }
+        const float* xt = LAYER ? p.x + (size_t)b0 * p.T * F : nullptr;
+        if (LAYER) {
+            if (steps > 0) {
+#pragma unroll
+                for (int i = 0; i < XR; ++i) {
+                    const int e = tid + 256 * i;
+                    const int row = e / F, col = e - row * F;
+                    if (e < BT * F) sX[row * LDX + col] = (b0 + row < p.B) ? xt[(size_t)row * p.T * F + col] : 0.f;
+                }
+            }
+        } else {
+            // y_{-1} = dec_in0 (columns >= F stay zero)
+            for (int i = tid; i < BT * F; i += 256) {
+                const int row = i / F, col = i - row * F;
+                sX[row * LDX + col] = (b0 + row < p.B) ? p.dec_in0[(size_t)(b0 + row) * F + col] : 0.f;
+            }
+        }
+        __syncthreads();
+
+        for (int t = 0; t < steps; ++t) {
+            // ---- prefetch x_{t+1}: global -> registers now, registers -> LDS behind the MFMAs ----
+            float xr[XR];
+            const bool pre = LAYER && (t + 1 < steps);
+            if (pre) {
+                const float* xn = xt + (size_t)(t + 1) * F;
+#pragma unroll
+                for (int i = 0; i < XR; ++i) {
+                    const int e = tid + 256 * i;
+                    const int row = e / F, col = e - row * F;
+                    xr[i] = (e < BT * F && b0 + row < p.B) ? xn[(size_t)row * p.T * F + col] : 0.f;
+                }
+            }
+            f32x4 acc[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) acc[g] = (f32x4){bias[g], bias[g], bias[g], bias[g]};
+            {   // input projection x_t . K  (A from the LDS x tile, B from the LDS K slice)
+                const float* arow = sX + (LAYER ? (t & 1) * BT * LDX : 0) + n * LDX + 4 * g4;
+                const int nq = Fp >> 4;
+                for (int q = 0; q < nq; ++q) {
+                    const f32x4 a = *(const f32x4*)(arow + 16 * q);
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const f32x4 bw = *(const f32x4*)(sKw + ((q * 4 + g) * 64 + lane) * 4);
+#pragma unroll
+                        for (int s = 0; s < 4; ++s)
+                            acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], bw[s], acc[g], 0, 0, 0);
+                    }
+                }
+            }
+            {   // recurrent product h_{t-1} . R  (A from the LDS h tile, B from registers)
+                const float* hrow = sH + n * LDH + 4 * g4;
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    const f32x4 a = *(const f32x4*)(hrow + 16 * q);
+#pragma unroll
+                    for (int s = 0; s < 4; ++s)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g)
+                            acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], wR[q][g][s], acc[g], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float ig = rec_act<ACT>(acc[0][r]);
+                const float fg = rec_act<ACT>(acc[1][r]);
+                const float gg = tanh_f(acc[2][r]);
+                const float og = rec_act<ACT>(acc[3][r]);
+                c[r] = fmaf(fg, c[r], ig * gg);
+                hcur[r] = og * tanh_f(c[r]);
+            }
+            if (LAYER && p.hs) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = b0 + 4 * g4 + r;
+                    if (row < p.B) p.hs[((size_t)row * p.T + t) * H + col0 + n] = hcur[r];
+                }
+            }
+            __syncthreads();  // every wave is done reading sH and the current x tile
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sH[(4 * g4 + r) * LDH + col0 + n] = hcur[r];
+            if (pre) {
+                float* xb = sX + ((t + 1) & 1) * BT * LDX;
+#pragma unroll
+                for (int i = 0; i < XR; ++i) {
+                    const int e = tid + 256 * i;
+                    const int row = e / F, col = e - row * F;
+                    if (e < BT * F) xb[row * LDX + col] = xr[i];
+                }
+            }
+            if (G > 1) {
+                // ---- publish this workgroup's slice of h_t, gather the other G-1 slices ----
+                ++epoch;
+                unsigned long long* base = p.xch + ((size_t)(group * 2 + (epoch & 1)) * BT) * H;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    st_granule(base + (size_t)(4 * g4 + r) * H + col0 + n,
+                               ((unsigned long long)epoch << 32) | __float_as_uint(hcur[r]));
+                unsigned long long v[NG > 0 ? NG : 1];
+                unsigned spins = 0;
+                while (true) {
+                    bool ok = true;
+#pragma unroll
+                    for (int j = 0; j < NG; ++j) {
+                        const int idx = j * 256 + tid;
+                        const int si = idx >> 10, within = idx & 1023;
+                        const int osl = si + (si >= slice ? 1 : 0);
+                        v[j] = ld_granule(base + (within >> 6) * H + osl * 64 + (within & 63));
+                        ok = ok && ((unsigned)(v[j] >> 32) == epoch);
+                    }
+                    if (__all(ok)) break;
+                    ++spins;
+                    if (spins > SPIN_LIMIT ||
+                        ((spins & 63u) == 0 &&
+                         __hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                        if (lane == 0) {
+                            __hip_atomic_store(p.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            sFlag[0] = 1;
+                        }
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+#pragma unroll
+                for (int j = 0; j < NG; ++j) {
+                    const int idx = j * 256 + tid;
+                    const int si = idx >> 10, within = idx & 1023;
+                    const int osl = si + (si >= slice ? 1 : 0);
+                    sH[(within >> 6) * LDH + osl * 64 + (within & 63)] = __uint_as_float((unsigned)v[j]);
+                }
+            }
+            __syncthreads();
+            if (G > 1 && sFlag[0]) { aborted = true; break; }
+            if (!LAYER) {
+                // y_t = tanh(h_t . W + bias): 16 lanes per sequence, 16-lane shuffle reduce
+                const int O = p.F_dec;
+                const int drow = tid >> 4, dpart = tid & 15;
+                float ya[CL_MAX_O];
+#pragma unroll
+                for (int o = 0; o < CL_MAX_O; ++o) ya[o] = 0.f;
+                for (int kk = 0; kk < H / 16; ++kk) {
+                    const int k = kk * 16 + dpart;
+                    const float hv = sH[drow * LDH + k];
+                    const f32x4 w0 = *(const f32x4*)(sW + k * 8);
+                    const f32x4 w1 = *(const f32x4*)(sW + k * 8 + 4);
+#pragma unroll
+                    for (int o = 0; o < 4; ++o) {
+                        ya[o] = fmaf(hv, w0[o], ya[o]);
+                        ya[4 + o] = fmaf(hv, w1[o], ya[4 + o]);
+                    }
+                }
+#pragma unroll
+                for (int o = 0; o < CL_MAX_O; ++o)
+#pragma unroll
+                    for (int m = 8; m >= 1; m >>= 1) ya[o] += __shfl_xor(ya[o], m);
+                float mine = 0.f;
+#pragma unroll
+                for (int o = 0; o < CL_MAX_O; ++o) mine = (dpart == o) ? ya[o] : mine;
+                if (dpart < O) {
+                    const float y = tanh_f(mine + sBd[dpart]);
+                    sX[drow * LDX + dpart] = y;
+                    if (slice == 0 && b0 + drow < p.B)
+                        p.out[((size_t)(b0 + drow) * p.T_out + t) * O + dpart] = y;
+                }
+                __syncthreads();
+            }
+        }
+        if (!aborted) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = b0 + 4 * g4 + r;
+                if (row < p.B) {
+                    if (p.hT) p.hT[(size_t)row * H + col0 + n] = hcur[r];
+                    if (p.cT) p.cT[(size_t)row * H + col0 + n] = c[r];
+                }
+            }
+        }
+    }
+}
+
+// --------------------------------------------------------------------------------------
+// host side
+// --------------------------------------------------------------------------------------
+static int device_cu_count() {
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+            cus = prop.multiProcessorCount;
+        if (cus <= 0) cus = 256;
+    }
+    return cus;
+}
+
+bool cluster_shape_ok(int F, int H) {
+    return (H == 64 || H == 128 || H == 256) && F >= 1 && F <= CL_MAX_F;
+}
+
+int cluster_num_groups(int B, int H) {
+    const int G = H / 64;
+    const int tiles = (B + BT - 1) / BT;
+    int groups = device_cu_count() / G;
+    if (groups < 1) groups = 1;
+    return tiles < groups ? (tiles > 0 ? tiles : 1) : groups;
+}
+
+static size_t cluster_xch_bytes(int B, int H) {
+    const size_t b = (size_t)cluster_num_groups(B, H) * 2 * BT * H * sizeof(unsigned long long);
+    return (b + 255) & ~(size_t)255;
+}
+
+// status words + granule exchange buffers + (fused decode) the encoder's final (h, c)
+size_t cluster_workspace_bytes(int B, int H) {
+    return kStatusBytes + cluster_xch_bytes(B, H) + (size_t)2 * B * H * sizeof(float);
+}
+
+template <int H>
+static int launch_cluster_h(const LstmParams& p, int mode, hipStream_t stream) {
+    void (*kern)(LstmParams) = nullptr;
+    if (p.act == FOV_ACT_HARD_SIGMOID)
+        kern = mode == MODE_DECODE ? lstm_cluster_kernel<H, FOV_ACT_HARD_SIGMOID, MODE_DECODE>
+                                   : lstm_cluster_kernel<H, FOV_ACT_HARD_SIGMOID, MODE_LAYER>;
+    else
+        kern = mode == MODE_DECODE ? lstm_cluster_kernel<H, FOV_ACT_SIGMOID, MODE_DECODE>
+                                   : lstm_cluster_kernel<H, FOV_ACT_SIGMOID, MODE_LAYER>;
+    const int F = mode == MODE_DECODE ? p.F_dec : p.F;
+    const ClusterLds L = cluster_lds(H, F, mode == MODE_DECODE);
+    const size_t lds = (size_t)L.total_floats * sizeof(float);
+    if (lds > 160 * 1024) {
+        set_error("cluster kernel: H=%d F=%d needs %zu B of LDS (> 160 KiB)", H, F, lds);
+        return FOV_ERR_UNSUPPORTED;
+    }
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return FOV_ERR_LAUNCH; }
+    const dim3 grid(p.num_groups * (H / 64)), block(256);
+    hipLaunchKernelGGL(kern, grid, block, lds, stream, p);
+    e = hipGetLastError();
+    if (e != hipSuccess) { set_error("cluster launch: %s", hipGetErrorString(e)); return FOV_ERR_LAUNCH; }
+    return FOV_OK;
+}
+
+static int launch_cluster_mode(const LstmParams& p, int mode, hipStream_t stream) {
+    switch (p.H) {
+        case 64: return launch_cluster_h<64>(p, mode, stream);
+        case 128: return launch_cluster_h<128>(p, mode, stream);
+        default: return launch_cluster_h<256>(p, mode, stream);
+    }
+}
+
+// decode == false: one LSTM layer over x.  decode == true: encoder launch (final state into the
+// workspace) followed by the autoregressive decoder launch seeded from it.
+int launch_cluster(const LstmParams& p_in, bool decode, hipStream_t stream) {
+    LstmParams p = p_in;
+    if (p.B == 0) return FOV_OK;
+    if (!cluster_shape_ok(p.F, p.H) || (decode && (p.F_dec < 1 || p.F_dec > CL_MAX_O))) {
+        set_error("cluster kernel supports H in {64,128,256}, 1<=F<=%d, F_dec<=%d (got H=%d F=%d F_dec=%d)",
+                  CL_MAX_F, CL_MAX_O, p.H, p.F, p.F_dec);
+        return FOV_ERR_UNSUPPORTED;
+    }
+    p.num_tiles = (p.B + BT - 1) / BT;
+    p.num_groups = cluster_num_groups(p.B, p.H);
+    // zero the status words and every granule tag (epochs restart at 1 in each launch)
+    const size_t xch_bytes = kStatusBytes + cluster_xch_bytes(p.B, p.H);
+    hipError_t e = hipMemsetAsync((void*)p.status, 0, xch_bytes, stream);
+    if (e != hipSuccess) { set_error("hipMemsetAsync: %s", hipGetErrorString(e)); return FOV_ERR_LAUNCH; }
+    if (!decode) return launch_cluster_mode(p, MODE_LAYER, stream);
+
+    LstmParams enc = p;
+    float* state = (float*)((char*)p.status + xch_bytes);
+    enc.hT = state;
+    enc.cT = state + (size_t)p.B * p.H;
+    enc.hs = nullptr;
+    int rc = launch_cluster_mode(enc, MODE_LAYER, stream);
+    if (rc) return rc;
+    // granule tags only (the status word must survive so an encoder give-up stays visible)
+    e = hipMemsetAsync((char*)p.status + kStatusBytes, 0, xch_bytes - kStatusBytes, stream);
+    if (e != hipSuccess) { set_error("hipMemsetAsync: %s", hipGetErrorString(e)); return FOV_ERR_LAUNCH; }
+    LstmParams dec = p;
+    dec.h0 = enc.hT;
+    dec.c0 = enc.cT;
+    return launch_cluster_mode(dec, MODE_DECODE, stream);
+}
+
+}  // namespace fov

@@ -1,0 +1,156 @@
+"""Torch-tensor wrappers over the C ABI (include/fov360.h).
+
+PyTorch is plumbing only: device memory, streams and (elsewhere) torch.distributed.  Every
+function here hands raw device pointers and sizes to libfov360_hip.so; nothing is computed by
+torch and there is no fallback path.
+"""
+import torch
+
+from . import _lib
+from ._lib import (ACT_HARD_SIGMOID, ACT_SIGMOID, IMPL_AUTO, IMPL_CLUSTER, IMPL_GENERIC,  # noqa: F401
+                   FovError, check)
+
+_ACT = {"sigmoid": ACT_SIGMOID, "hard_sigmoid": ACT_HARD_SIGMOID, ACT_SIGMOID: ACT_SIGMOID,
+        ACT_HARD_SIGMOID: ACT_HARD_SIGMOID}
+_IMPL = {"auto": IMPL_AUTO, "generic": IMPL_GENERIC, "cluster": IMPL_CLUSTER, IMPL_AUTO: IMPL_AUTO,
+         IMPL_GENERIC: IMPL_GENERIC, IMPL_CLUSTER: IMPL_CLUSTER}
+
+
+def act_code(act):
+    return _ACT[act]
+
+
+def impl_code(impl):
+    return _IMPL[impl]
+
+
+def _dev(t, name):
+    if t is None:
+        return None
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+        raise TypeError("%s must be a contiguous float32 tensor on the GPU" % name)
+    return t
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+class Workspace:
+    """Caller-owned scratch for the persistent kernels (grown on demand, reused across calls)."""
+
+    def __init__(self, device=None):
+        self.device = device
+        self.buf = None
+
+    def get(self, nbytes, device):
+        nbytes = max(int(nbytes), 256)
+        if self.buf is None or self.buf.numel() < nbytes or self.buf.device != device:
+            self.buf = torch.empty(nbytes + 256, dtype=torch.uint8, device=device)
+        return self.buf
+
+    def check(self):
+        """Synchronise and raise FovError(ERR_TIMEOUT) if a bounded in-kernel wait gave up."""
+        if self.buf is not None:
+            check(_lib.lib().fov_check_status(self.buf.data_ptr(), self.buf.numel(), _stream()))
+
+
+_default_ws = {}
+
+
+def default_workspace(device):
+    key = (device.type, device.index)
+    if key not in _default_ws:
+        _default_ws[key] = Workspace(device)
+    return _default_ws[key]
+
+
+def lstm_seq(x, K, R, b, h0=None, c0=None, act="sigmoid", impl="auto", return_sequences=True, workspace=None):
+    """keras LSTM(return_sequences, return_state)(x, initial_state=[h0, c0]) -> (hs|None, hT, cT)."""
+    x, K, R, b = _dev(x, "x"), _dev(K, "K"), _dev(R, "R"), _dev(b, "b")
+    h0, c0 = _dev(h0, "h0"), _dev(c0, "c0")
+    B, T, F = x.shape
+    H = R.shape[0]
+    assert K.shape == (F, 4 * H) and R.shape == (H, 4 * H) and b.shape == (4 * H,)
+    hs = torch.empty((B, T, H), dtype=torch.float32, device=x.device) if return_sequences else None
+    hT = torch.empty((B, H), dtype=torch.float32, device=x.device)
+    cT = torch.empty((B, H), dtype=torch.float32, device=x.device)
+    L = _lib.lib()
+    impl = impl_code(impl)
+    ws = (workspace or default_workspace(x.device))
+    buf = ws.get(L.fov_lstm_seq_workspace_bytes(B, T, F, H, impl), x.device)
+    check(L.fov_lstm_seq_fwd(_ptr(x), _ptr(K), _ptr(R), _ptr(b), _ptr(h0), _ptr(c0), _ptr(hs), _ptr(hT), _ptr(cT),
+                             B, T, F, H, act_code(act), impl, buf.data_ptr(), buf.numel(), _stream()))
+    return hs, hT, cT
+
+
+def dense(x, W, b, activation="tanh"):
+    x, W, b = _dev(x, "x"), _dev(W, "W"), _dev(b, "b")
+    lead = x.shape[:-1]
+    In, Out = W.shape
+    x2 = x.reshape(-1, In)
+    y = torch.empty((x2.shape[0], Out), dtype=torch.float32, device=x.device)
+    check(_lib.lib().fov_dense_fwd(_ptr(x2), _ptr(W), _ptr(b), _ptr(y), x2.shape[0], In, Out,
+                                   1 if activation == "tanh" else 0, _stream()))
+    return y.reshape(*lead, Out)
+
+
+_W_ORDER = ("enc_K", "enc_R", "enc_b", "dec_K", "dec_R", "dec_b", "dense_W", "dense_b")
+
+
+def seq2seq_decode(enc_in, dec_in0, w, T_out, act="sigmoid", impl="auto", workspace=None, out=None):
+    """Fused encoder + autoregressive decoder (FoV_seq2seq.py:154-178, batched) -> (B,T_out,F_dec)."""
+    enc_in, dec_in0 = _dev(enc_in, "enc_in"), _dev(dec_in0, "dec_in0")
+    ws_t = [_dev(w[k], k) for k in _W_ORDER]
+    B, T_in, F_enc = enc_in.shape
+    H = ws_t[1].shape[0]
+    F_dec = ws_t[6].shape[1]
+    assert dec_in0.shape == (B, 1, F_dec)
+    if out is None:
+        out = torch.empty((B, T_out, F_dec), dtype=torch.float32, device=enc_in.device)
+    L = _lib.lib()
+    impl = impl_code(impl)
+    ws = (workspace or default_workspace(enc_in.device))
+    buf = ws.get(L.fov_seq2seq_decode_workspace_bytes(B, T_in, T_out, F_enc, F_dec, H, impl), enc_in.device)
+    check(L.fov_seq2seq_decode_fwd(_ptr(enc_in), _ptr(dec_in0), *[_ptr(t) for t in ws_t], _ptr(out), None, None,
+                                   B, T_in, T_out, F_enc, F_dec, H, act_code(act), impl,
+                                   buf.data_ptr(), buf.numel(), _stream()))
+    return out
+
+
+def seq2seq_teacher_forced(enc_in, dec_in, w, act="sigmoid", impl="auto", workspace=None):
+    """Training-graph forward (FoV_seq2seq.py:82-101) -> (B,T_out,F_dec)."""
+    enc_in, dec_in = _dev(enc_in, "enc_in"), _dev(dec_in, "dec_in")
+    ws_t = [_dev(w[k], k) for k in _W_ORDER]
+    B, T_in, F_enc = enc_in.shape
+    T_out, F_dec = dec_in.shape[1], dec_in.shape[2]
+    H = ws_t[1].shape[0]
+    out = torch.empty((B, T_out, F_dec), dtype=torch.float32, device=enc_in.device)
+    L = _lib.lib()
+    impl = impl_code(impl)
+    ws = (workspace or default_workspace(enc_in.device))
+    buf = ws.get(L.fov_seq2seq_tf_workspace_bytes(B, T_in, T_out, F_enc, F_dec, H, impl), enc_in.device)
+    check(L.fov_seq2seq_tf_fwd(_ptr(enc_in), _ptr(dec_in), *[_ptr(t) for t in ws_t], _ptr(out),
+                               B, T_in, T_out, F_enc, F_dec, H, act_code(act), impl,
+                               buf.data_ptr(), buf.numel(), _stream()))
+    return out
+
+
+def meanvar_xyz(y, fps=30):
+    """(..., 3*fps) or (..., fps, 3) device tensor -> (..., 6) = [mean xyz, population var xyz]."""
+    y = _dev(y, "y")
+    if y.shape[-1] == 3 and y.shape[-2] == fps:
+        lead = y.shape[:-2]
+    else:
+        assert y.shape[-1] == 3 * fps
+        lead = y.shape[:-1]
+    rows = 1
+    for d in lead:
+        rows *= d
+    out = torch.empty((*lead, 6), dtype=torch.float32, device=y.device)
+    check(_lib.lib().fov_meanvar_xyz(_ptr(y), _ptr(out), rows, fps, _stream()))
+    return out

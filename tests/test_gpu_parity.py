@@ -1,0 +1,255 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on identical seeded
+inputs.  Tolerance (BASELINE.json north_star): outputs within 1e-3 relative of the reference CPU
+path on fp32 trajectory coordinates; asserted here as |gpu - ref| <= 1e-3 * |ref| + 1e-5, and
+additionally a much tighter absolute bound (2e-5 vs the fp64 oracle) that a correct fp32 kernel
+meets with margin, so an indexing bug cannot hide inside the loose bound.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import c_oracle as C
+from oracle import fov_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+RTOL, ATOL_FLOOR = 1e-3, 1e-5
+TIGHT = 2e-5
+
+
+def _ops():
+    from longterm360fov_amd import ops
+    return ops
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+
+
+def devw(w):
+    return {k: dev(v) for k, v in w.items()}
+
+
+def f64(w):
+    return {k: v.astype(np.float64) for k, v in w.items()}
+
+
+def assert_parity(gpu, ref, what, tight=TIGHT):
+    gpu = gpu.detach().cpu().numpy().astype(np.float64) if isinstance(gpu, torch.Tensor) else np.asarray(gpu, np.float64)
+    ref = np.asarray(ref, np.float64)
+    assert gpu.shape == ref.shape, (what, gpu.shape, ref.shape)
+    assert np.isfinite(gpu).all(), what + ": non-finite values"
+    err = np.abs(gpu - ref)
+    bound = RTOL * np.abs(ref) + ATOL_FLOOR
+    worst = float(err.max()) if err.size else 0.0
+    print("%s: max abs err %.3e (max |ref| %.3f)" % (what, worst, float(np.abs(ref).max()) if ref.size else 0))
+    assert (err <= bound).all(), "%s: max err %.3e exceeds 1e-3 relative" % (what, worst)
+    assert worst <= tight, "%s: max err %.3e exceeds tight bound %.1e" % (what, worst, tight)
+
+
+# ---------------------------------------------------------------------------------------
+# LSTM layer (a1/a2)
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("impl,H,F,B,T", [
+    ("generic", 32, 6, 5, 6), ("generic", 32, 90, 9, 4), ("generic", 256, 90, 7, 3), ("generic", 40, 11, 3, 5),
+    ("cluster", 64, 90, 37, 5), ("cluster", 128, 90, 37, 5), ("cluster", 256, 90, 37, 5),
+    ("cluster", 256, 6, 16, 4), ("cluster", 128, 13, 1, 3), ("cluster", 256, 96, 33, 2),
+])
+@pytest.mark.parametrize("act", ["sigmoid", "hard_sigmoid"])
+def test_lstm_layer(impl, H, F, B, T, act):
+    ops = _ops()
+    rng = np.random.default_rng(100 + H + F + B)
+    K, R, b = O.init_lstm(rng, F, H, np.float32)
+    b = (b + 0.1 * rng.standard_normal(b.shape)).astype(np.float32)
+    x = rng.uniform(-1, 1, (B, T, F)).astype(np.float32)
+    h0 = (0.3 * rng.standard_normal((B, H))).astype(np.float32)
+    c0 = (0.3 * rng.standard_normal((B, H))).astype(np.float32)
+    ws = ops.Workspace()
+    for init in (False, True):
+        a0, a1 = (h0, c0) if init else (None, None)
+        ref = O.lstm_layer(x.astype(np.float64), K.astype(np.float64), R.astype(np.float64), b.astype(np.float64),
+                           None if a0 is None else a0.astype(np.float64), None if a1 is None else a1.astype(np.float64), act)
+        hs, hT, cT = ops.lstm_seq(dev(x), dev(K), dev(R), dev(b), None if a0 is None else dev(a0),
+                                  None if a1 is None else dev(a1), act=act, impl=impl, workspace=ws)
+        ws.check()
+        tag = "%s H%d F%d B%d T%d %s init=%s" % (impl, H, F, B, T, act, init)
+        assert_parity(hs, ref[0], "hs " + tag)
+        assert_parity(hT, ref[1], "hT " + tag)
+        assert_parity(cT, ref[2], "cT " + tag)
+        # return_sequences=False path (hs pointer NULL)
+        _, hT2, cT2 = ops.lstm_seq(dev(x), dev(K), dev(R), dev(b), None if a0 is None else dev(a0),
+                                   None if a1 is None else dev(a1), act=act, impl=impl, return_sequences=False, workspace=ws)
+        assert torch.equal(hT2, hT) and torch.equal(cT2, cT)
+
+
+# ---------------------------------------------------------------------------------------
+# Fused encoder + autoregressive decoder (a2+a3), teacher-forced graph, Dense
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("impl,H,B,T_in,T_out", [
+    ("generic", 32, 5, 6, 4), ("generic", 128, 32, 10, 10),
+    ("cluster", 64, 20, 4, 3), ("cluster", 128, 32, 10, 10), ("cluster", 256, 48, 6, 5), ("cluster", 256, 17, 3, 7),
+])
+@pytest.mark.parametrize("act", ["sigmoid", "hard_sigmoid"])
+def test_seq2seq_decode(impl, H, B, T_in, T_out, act):
+    ops = _ops()
+    w = O.init_seq2seq(7 + H, H=H, bias_noise=0.1)
+    enc, dec0, _ = O.synthetic_batch(8 + B, B, T_in, T_out)
+    ref = O.seq2seq_decode(enc.astype(np.float64), dec0.astype(np.float64), f64(w), T_out, act)
+    ws = ops.Workspace()
+    out = ops.seq2seq_decode(dev(enc), dev(dec0), devw(w), T_out, act=act, impl=impl, workspace=ws)
+    ws.check()
+    assert_parity(out, ref, "decode %s H%d B%d %d->%d %s" % (impl, H, B, T_in, T_out, act))
+
+
+@pytest.mark.parametrize("impl,H,B", [("generic", 32, 5), ("cluster", 128, 32), ("cluster", 256, 40)])
+def test_seq2seq_teacher_forced(impl, H, B):
+    ops = _ops()
+    T_in, T_out = 6, 5
+    w = O.init_seq2seq(17 + H, H=H, bias_noise=0.1)
+    enc, dec0, tgt = O.synthetic_batch(18, B, T_in, T_out)
+    dec_in = np.concatenate([dec0, tgt[:, :-1]], axis=1)
+    ref = O.seq2seq_teacher_forced(enc.astype(np.float64), dec_in.astype(np.float64), f64(w))
+    ws = ops.Workspace()
+    out = ops.seq2seq_teacher_forced(dev(enc), dev(dec_in), devw(w), impl=impl, workspace=ws)
+    ws.check()
+    assert_parity(out, ref, "teacher-forced %s H%d" % (impl, H))
+
+
+def test_dense():
+    ops = _ops()
+    rng = np.random.default_rng(3)
+    for N, In, Out in ((7, 256, 6), (130, 204, 6), (5, 33, 20)):
+        x = rng.standard_normal((N, In)).astype(np.float32)
+        W = (rng.standard_normal((In, Out)) / np.sqrt(In)).astype(np.float32)
+        b = rng.standard_normal(Out).astype(np.float32)
+        ref = O.dense(x.astype(np.float64), W.astype(np.float64), b.astype(np.float64))
+        assert_parity(ops.dense(dev(x), dev(W), dev(b)), ref, "dense %dx%dx%d" % (N, In, Out))
+        ref = x.astype(np.float64) @ W.astype(np.float64) + b
+        assert_parity(ops.dense(dev(x), dev(W), dev(b), activation=None), ref, "dense linear")
+
+
+# ---------------------------------------------------------------------------------------
+# committed golden vectors
+# ---------------------------------------------------------------------------------------
+def test_golden_lstm_vectors(golden_dir):
+    ops = _ops()
+    g = np.load(os.path.join(golden_dir, "lstm_small.npz"))
+    w = {k[2:]: g[k] for k in g.files if k.startswith("w_")}
+    T_out = int(g["T_out"])
+    for act in (0, 1):
+        out = ops.seq2seq_decode(dev(g["enc"]), dev(g["dec0"]), devw(w), T_out, act=act)
+        assert_parity(out, g["decode_act%d" % act], "golden decode act%d" % act)
+        dec_in = np.concatenate([g["dec0"], g["tgt"][:, :-1]], axis=1)
+        out = ops.seq2seq_teacher_forced(dev(g["enc"]), dev(dec_in), devw(w), act=act)
+        assert_parity(out, g["tf_act%d" % act], "golden teacher-forced act%d" % act)
+
+
+def test_meanvar_against_reference_fixture(golden_dir):
+    """mu/sigma^2 op against values produced by the reference's own get_gt_target_xyz[_oth]."""
+    ops = _ops()
+    g = np.load(os.path.join(golden_dir, "data_helpers.npz"))
+    out = ops.meanvar_xyz(dev(g["fut"]))
+    assert_parity(out, g["gt_fut"], "meanvar (N,T,90)", tight=2e-6)
+    out = ops.meanvar_xyz(dev(g["fut"].reshape(12, 10, 30, 3)))
+    assert_parity(out, g["gt_fut_4d"], "meanvar (N,T,30,3)", tight=2e-6)
+    oth = g["pu_oth_fut"].transpose(1, 2, 0, 3).reshape(12, 10, 2, 30, 3)
+    out = ops.meanvar_xyz(dev(oth))
+    assert_parity(out, g["gt_oth_fut"], "meanvar others", tight=2e-6)
+    assert ops.meanvar_xyz(dev(np.zeros((0, 10, 90)))).shape == (0, 10, 6)
+
+
+# ---------------------------------------------------------------------------------------
+# edge cases
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("impl,H", [("generic", 32), ("cluster", 256)])
+def test_empty_and_degenerate(impl, H):
+    ops = _ops()
+    w = O.init_seq2seq(5, H=H)
+    dw = devw(w)
+    out = ops.seq2seq_decode(dev(np.zeros((0, 4, 90))), dev(np.zeros((0, 1, 6))), dw, 3, impl=impl)
+    assert out.shape == (0, 3, 6)
+    # single sequence, single step in and out
+    enc, dec0, _ = O.synthetic_batch(2, 1, 1, 1)
+    ref = O.seq2seq_decode(enc.astype(np.float64), dec0.astype(np.float64), f64(w), 1)
+    assert_parity(ops.seq2seq_decode(dev(enc), dev(dec0), dw, 1, impl=impl), ref, "B=1 T=1 " + impl)
+    # T_in = 0: decoder starts from the zero state
+    enc0 = np.zeros((3, 0, 90), np.float32)
+    dec0 = np.random.default_rng(1).uniform(-1, 1, (3, 1, 6)).astype(np.float32)
+    ref = O.seq2seq_decode(enc0.astype(np.float64), dec0.astype(np.float64), f64(w), 2)
+    assert_parity(ops.seq2seq_decode(dev(enc0), dev(dec0), dw, 2, impl=impl), ref, "T_in=0 " + impl)
+
+
+def test_error_reporting():
+    ops = _ops()
+    from longterm360fov_amd import _lib
+    w = O.init_seq2seq(5, H=48)
+    enc, dec0, _ = O.synthetic_batch(2, 4, 2, 2)
+    with pytest.raises(_lib.FovError) as e:
+        ops.seq2seq_decode(dev(enc), dev(dec0), devw(w), 2, impl="cluster")   # H=48 unsupported
+    assert e.value.code == _lib.ERR_UNSUPPORTED
+    # AUTO falls back to the generic kernel for the same shape
+    ref = O.seq2seq_decode(enc.astype(np.float64), dec0.astype(np.float64), f64(w), 2)
+    assert_parity(ops.seq2seq_decode(dev(enc), dev(dec0), devw(w), 2, impl="auto"), ref, "auto H48")
+    with pytest.raises(TypeError):
+        ops.dense(torch.zeros(2, 3), dev(np.zeros((3, 2))), dev(np.zeros(2)))   # CPU tensor refused
+
+
+# ---------------------------------------------------------------------------------------
+# BASELINE.json full sizes: config 1 and config 2, plus size-independent properties
+# ---------------------------------------------------------------------------------------
+def test_config1_reference_native_shape():
+    """configs[0]: H=128, B=32, T 10->10 (the reference's own operating point)."""
+    ops = _ops()
+    w = O.init_seq2seq(1234, H=128, bias_noise=0.05)
+    enc, dec0, _ = O.synthetic_batch(1234, 32, 10, 10)
+    ref = O.seq2seq_decode(enc.astype(np.float64), dec0.astype(np.float64), f64(w), 10)
+    for impl in ("generic", "cluster"):
+        assert_parity(ops.seq2seq_decode(dev(enc), dev(dec0), devw(w), 10, impl=impl), ref, "config1 " + impl)
+
+
+def test_config2_full_size_and_properties():
+    """configs[1]: H=256, B=1024, T 30->30 on one GPU (the bench workload).  All 1024 sequences
+    against the C oracle, plus determinism, batch-permutation equivariance, independence from
+    tile-mates (a sequence's result must not depend on which other sequences share its tile)."""
+    ops = _ops()
+    B, T_in, T_out, H = 1024, 30, 30, 256
+    w = O.init_seq2seq(1234, H=H, bias_noise=0.05)
+    enc, dec0, _ = O.synthetic_batch(1234, B, T_in, T_out)
+    ref = C.seq2seq_decode(enc, dec0, w, T_out)                      # fp32 C oracle, all sequences
+    ref64 = O.seq2seq_decode(enc[:64].astype(np.float64), dec0[:64].astype(np.float64), f64(w), T_out)
+    dw = devw(w)
+    ws = ops.Workspace()
+    out = ops.seq2seq_decode(dev(enc), dev(dec0), dw, T_out, impl="cluster", workspace=ws)
+    ws.check()
+    assert_parity(out, ref, "config2 cluster vs C oracle (1024 seq)", tight=5e-5)
+    assert_parity(out[:64], ref64, "config2 cluster vs fp64 oracle (64 seq)", tight=5e-5)
+    out2 = ops.seq2seq_decode(dev(enc), dev(dec0), dw, T_out, impl="cluster", workspace=ws)
+    assert torch.equal(out, out2), "not deterministic"
+    perm = np.random.default_rng(0).permutation(B)
+    outp = ops.seq2seq_decode(dev(enc[perm]), dev(dec0[perm]), dw, T_out, impl="cluster", workspace=ws)
+    assert torch.equal(outp, out[torch.from_numpy(perm).cuda()]), "not batch-permutation equivariant"
+    outr = ops.seq2seq_decode(dev(enc[:1000]), dev(dec0[:1000]), dw, T_out, impl="cluster", workspace=ws)
+    assert torch.equal(outr, out[:1000]), "result depends on batch padding"
+    gen = ops.seq2seq_decode(dev(enc[:128]), dev(dec0[:128]), dw, T_out, impl="generic")
+    assert_parity(gen, ref[:128], "config2 generic vs C oracle (128 seq)", tight=5e-5)
+    assert float(out.abs().max()) <= 1.0   # tanh head
+
+
+def test_persistent_tile_loop_more_tiles_than_groups():
+    """B > 16 * (CUs / G): every group walks several tiles; epochs keep counting across tiles."""
+    ops = _ops()
+    B, T_in, T_out, H = 16 * 64 * 2 + 16 * 7 + 5, 3, 3, 256
+    w = O.init_seq2seq(99, H=H, bias_noise=0.05)
+    enc, dec0, _ = O.synthetic_batch(98, B, T_in, T_out)
+    ref = C.seq2seq_decode(enc, dec0, w, T_out)
+    ws = ops.Workspace()
+    out = ops.seq2seq_decode(dev(enc), dev(dec0), devw(w), T_out, impl="cluster", workspace=ws)
+    ws.check()
+    assert_parity(out, ref, "multi-tile cluster B=%d" % B, tight=5e-5)
+    w1 = O.init_seq2seq(97, H=128, bias_noise=0.05)
+    ref = C.seq2seq_decode(enc, dec0, w1, T_out)
+    out = ops.seq2seq_decode(dev(enc), dev(dec0), devw(w1), T_out, impl="cluster", workspace=ws)
+    ws.check()
+    assert_parity(out, ref, "multi-tile cluster H128 B=%d" % B, tight=5e-5)
