@@ -51,6 +51,26 @@ __device__ __forceinline__ void st_granule(unsigned long long* p, unsigned long 
 
 __host__ __device__ constexpr int round16(int v) { return (v + 15) & ~15; }
 
+// Diagnostic build only (-DFOV_STAMPS, tools/stamp_profile.py): per-step s_memtime stamps of one
+// wave.  The shipped library compiles none of this (cdna_hip_programming.md section 7, In-kernel stamps).
+#ifdef FOV_STAMPS
+constexpr int STAMP_SLOTS = 10;
+constexpr int STAMP_STEPS = 64;
+__device__ unsigned long long g_stamps[2][STAMP_STEPS][STAMP_SLOTS];
+#define FOV_STAMP(slot)                                                                         \
+    do {                                                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                      \
+        if (stamp_on && t < STAMP_STEPS) {                                                      \
+            unsigned long long t_;                                                              \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");          \
+            g_stamps[MODE][t][slot] = t_;                                                       \
+        }                                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                      \
+    } while (0)
+#else
+#define FOV_STAMP(slot) do { } while (0)
+#endif
+
 struct ClusterLds {
     int ldx, ldh;
     int off_k, off_h, off_x, off_w, off_bd, off_flag, total_floats;
@@ -149,6 +169,9 @@ __global__ __launch_bounds__(256, 1) void lstm_cluster_kernel(LstmParams p) {
 
     unsigned epoch = 0;
     bool aborted = false;
+#ifdef FOV_STAMPS
+    const bool stamp_on = (blockIdx.x == 5 && tid == 0);
+#endif
 
     for (int tile = group; tile < p.num_tiles && !aborted; tile += p.num_groups) {
         const int b0 = tile * BT;
@@ -186,6 +209,10 @@ __global__ __launch_bounds__(256, 1) void lstm_cluster_kernel(LstmParams p) {
 
         for (int t = 0; t < steps; ++t) {
             // ---- prefetch x_{t+1}: global -> registers now, registers -> LDS behind the MFMAs ----
+            FOV_STAMP(0);
+#ifdef FOV_STAMPS
+            if (stamp_on && t < STAMP_STEPS) g_stamps[MODE][t][9] = __builtin_amdgcn_s_memrealtime();
+#endif
             float xr[XR];
             const bool pre = LAYER && (t + 1 < steps);
             if (pre) {
@@ -214,6 +241,7 @@ __global__ __launch_bounds__(256, 1) void lstm_cluster_kernel(LstmParams p) {
                     }
                 }
             }
+            FOV_STAMP(1);
             {   // recurrent product h_{t-1} . R  (A from the LDS h tile, B from registers)
                 const float* hrow = sH + n * LDH + 4 * g4;
 #pragma unroll
@@ -226,6 +254,7 @@ __global__ __launch_bounds__(256, 1) void lstm_cluster_kernel(LstmParams p) {
                             acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], wR[q][g][s], acc[g], 0, 0, 0);
                 }
             }
+            FOV_STAMP(2);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float ig = rec_act<ACT>(acc[0][r]);
@@ -242,7 +271,9 @@ __global__ __launch_bounds__(256, 1) void lstm_cluster_kernel(LstmParams p) {
                     if (row < p.B) p.hs[((size_t)row * p.T + t) * H + col0 + n] = hcur[r];
                 }
             }
+            FOV_STAMP(3);
             __syncthreads();  // every wave is done reading sH and the current x tile
+            FOV_STAMP(4);
 #pragma unroll
             for (int r = 0; r < 4; ++r) sH[(4 * g4 + r) * LDH + col0 + n] = hcur[r];
             if (pre) {
@@ -262,6 +293,7 @@ __global__ __launch_bounds__(256, 1) void lstm_cluster_kernel(LstmParams p) {
                 for (int r = 0; r < 4; ++r)
                     st_granule(base + (size_t)(4 * g4 + r) * H + col0 + n,
                                ((unsigned long long)epoch << 32) | __float_as_uint(hcur[r]));
+                FOV_STAMP(5);
                 unsigned long long v[NG > 0 ? NG : 1];
                 unsigned spins = 0;
                 while (true) {
@@ -295,7 +327,9 @@ __global__ __launch_bounds__(256, 1) void lstm_cluster_kernel(LstmParams p) {
                     sH[(within >> 6) * LDH + osl * 64 + (within & 63)] = __uint_as_float((unsigned)v[j]);
                 }
             }
+            FOV_STAMP(6);
             __syncthreads();
+            FOV_STAMP(7);
             if (G > 1 && sFlag[0]) { aborted = true; break; }
             if (!LAYER) {
                 // y_t = tanh(h_t . W + bias): 16 lanes per sequence, 16-lane shuffle reduce
@@ -329,6 +363,7 @@ __global__ __launch_bounds__(256, 1) void lstm_cluster_kernel(LstmParams p) {
                         p.out[((size_t)(b0 + drow) * p.T_out + t) * O + dpart] = y;
                 }
                 __syncthreads();
+                FOV_STAMP(8);
             }
         }
         if (!aborted) {
@@ -447,5 +482,11 @@ int launch_cluster(const LstmParams& p_in, bool decode, hipStream_t stream) {
     dec.c0 = enc.cT;
     return launch_cluster_mode(dec, MODE_DECODE, stream);
 }
+
+#ifdef FOV_STAMPS
+extern "C" int fov_debug_read_stamps(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 2 * STAMP_STEPS * STAMP_SLOTS);
+}
+#endif
 
 }  // namespace fov

@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""Where does a step of the cluster kernel spend its cycles?  Loads the DIAGNOSTIC build
+(make -C longterm360fov_amd/csrc stamps -> libfov360_hip_stamps.so), runs the bench workload
+once and prints per-segment s_memtime deltas (shader cycles; clock from s_memrealtime) over the steps of
+one wave (block 5, wave 0).  Shares, not absolute run time, are what to read (the stamps add
+fences the shipped kernel does not have)."""
+import ctypes
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from longterm360fov_amd import _lib  # noqa: E402
+
+_lib.LIB_PATH = os.path.join(ROOT, "longterm360fov_amd", "lib", "libfov360_hip_stamps.so")
+from longterm360fov_amd import ops  # noqa: E402
+from oracle import fov_oracle as O  # noqa: E402
+
+SEG = ["x-prefetch issue + x.K MFMAs", "h.R MFMAs (issue)", "cell update (waits MFMA)", "barrier 1",
+       "LDS writes + publish", "gather spin", "barrier 2", "dense + barrier 3"]
+
+
+def main():
+    B, T_in, T_out, H = 1024, 30, 30, 256
+    w = O.init_seq2seq(1234, H=H, bias_noise=0.05)
+    enc, dec0, _ = O.synthetic_batch(1234, B, T_in, T_out)
+    dw = {k: torch.from_numpy(v).cuda() for k, v in w.items()}
+    d_enc, d_dec0 = torch.from_numpy(enc).cuda(), torch.from_numpy(dec0).cuda()
+    ws = ops.Workspace()
+    for _ in range(3):
+        ops.seq2seq_decode(d_enc, d_dec0, dw, T_out, impl="cluster", workspace=ws)
+    ws.check()
+    L = _lib.lib()
+    buf = np.zeros((2, 64, 10), dtype=np.uint64)
+    L.fov_debug_read_stamps.argtypes = [ctypes.c_void_p]
+    assert L.fov_debug_read_stamps(buf.ctypes.data_as(ctypes.c_void_p)) == 0
+    for mode, name, steps, nslot in ((0, "encoder (MODE_LAYER)", T_in, 8), (1, "decoder (MODE_DECODE)", T_out, 9)):
+        st = buf[mode, :steps, :nslot].astype(np.int64)
+        seg = np.diff(st, axis=1)                      # per step, per segment (shader cycles)
+        step_total = np.diff(st[:, 0])                 # step start to next step start
+        real = buf[mode, :steps, 9].astype(np.int64)   # s_memrealtime, 100 MHz
+        ghz = (st[-1, 0] - st[0, 0]) / ((real[-1] - real[0]) * 10.0)
+        print("== %s: %.0f cycles = %.2f us per step (median over %d steps), in-kernel clock %.2f GHz"
+              % (name, np.median(step_total), np.median(step_total) / ghz * 1e-3, steps - 1, ghz))
+        med = np.median(seg[1:], axis=0)
+        for i, v in enumerate(med):
+            print("   %-34s %8.0f cyc %7.0f ns  %5.1f%%" % (SEG[i], v, v / ghz, 100.0 * v / med.sum()))
+
+
+if __name__ == "__main__":
+    main()
