@@ -35,6 +35,7 @@ namespace fov {
 
 constexpr int BT = 16;          // sequences per tile
 constexpr int XR = 6;           // x prefetch registers per thread: 16 rows * F <= 256 * XR
+constexpr int NXBUF = 3;        // x tiles in LDS: x_{t+2} is written while x_{t+1} and x_t may be read
 constexpr int CL_MAX_F = 96;
 constexpr int CL_MAX_O = 8;
 constexpr unsigned SPIN_LIMIT = 1u << 20;
@@ -83,41 +84,118 @@ __host__ __device__ inline ClusterLds cluster_lds(int H, int F, bool decode) {
     L.off_k = 0;
     L.off_h = L.off_k + fp * 256;
     L.off_x = L.off_h + BT * L.ldh;
-    L.off_w = L.off_x + 2 * BT * L.ldx;
+    L.off_w = L.off_x + NXBUF * BT * L.ldx;
     L.off_bd = L.off_w + (decode ? H * CL_MAX_O : 0);
     L.off_flag = L.off_bd + 8;
     L.total_floats = L.off_flag + 8;
     return L;
 }
 
+// v_mfma_f32_16x16x4_f32 through inline asm.  hipcc's allocator keeps at most 256 values in
+// arch VGPRs and "spills" the rest of the weight set to AGPRs, re-reading each through
+// v_accvgpr_read + s_nop before its MFMA; fp32 MFMA shares the VALU datapath, so those two
+// extra issues per MFMA cost about 10 of 42 cycles (measured, profiles/r01_stamps_v2.txt).  With
+// the "a" constraint the weights live in AGPRs and are MFMA B operands directly; accumulators
+// and A operands stay in VGPRs.  hipcc pads no hazards around asm: mfma_begin / mfma_end carry
+// the VALU-write -> MFMA-read and MFMA-write -> VALU-read wait states (cdna_hip_programming.md 5.7).
+__device__ __forceinline__ void mfma_va(f32x4& acc, float a, float w_agpr) {
+    asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "a"(w_agpr));
+}
+__device__ __forceinline__ void mfma_vv(f32x4& acc, float a, float w_vgpr) {
+    asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(w_vgpr));
+}
+__device__ __forceinline__ void mfma_begin(f32x4 (&acc)[4]) {
+    asm volatile("s_nop 3" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
+}
+__device__ __forceinline__ void mfma_end(f32x4 (&acc)[4]) {
+    asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
+}
+
 // Load one LSTM's weights for this wave: R slice -> registers, K slice -> LDS, bias -> registers.
+// Register block j holds the k-block of hidden units ((slice + j/4) mod G)*64 + (j%4)*16 .. +16:
+// the workgroup's OWN 64 units come first (j < 4), so the part of h_t . R that needs no remote
+// data can start before the gather of the partner slices has landed.
 template <int H>
-__device__ __forceinline__ void load_weights(f32x4 (&wR)[H / 16][4], float (&bias)[4], float* sKw,
+__device__ __forceinline__ void load_weights(float (&wR)[H / 16][4][4], float (&bias)[4], float* sKw,
                                              const float* K, const float* R, const float* b, int F, int Fp,
-                                             int col0, int lane) {
+                                             int col0, int slice, int lane) {
+    constexpr int G = H / 64;
     const int n = lane & 15, g4 = lane >> 4;
     const int H4 = 4 * H;
 #pragma unroll
-    for (int q = 0; q < H / 16; ++q)
+    for (int j = 0; j < H / 16; ++j) {
+        const int kbase = ((slice + (j >> 2)) & (G - 1)) * 64 + (j & 3) * 16 + 4 * g4;
 #pragma unroll
         for (int g = 0; g < 4; ++g)
 #pragma unroll
             for (int s = 0; s < 4; ++s)
-                wR[q][g][s] = R[(size_t)(16 * q + 4 * g4 + s) * H4 + g * H + col0 + n];
+                wR[j][s][g] = R[(size_t)(kbase + s) * H4 + g * H + col0 + n];
+    }
 #pragma unroll
     for (int g = 0; g < 4; ++g) bias[g] = b[g * H + col0 + n];
+    // K slice in B-operand order: block (q,s) = 64 lanes x {i,f,c,o} of input row k = 16q+4*g4+s
     const int nq = Fp >> 4;
     for (int q = 0; q < nq; ++q)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
+        for (int s = 0; s < 4; ++s) {
+            const int k = 16 * q + 4 * g4 + s;
             f32x4 v;
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const int k = 16 * q + 4 * g4 + s;
-                v[s] = (k < F) ? K[(size_t)k * H4 + g * H + col0 + n] : 0.f;
-            }
-            *(f32x4*)(sKw + ((q * 4 + g) * 64 + lane) * 4) = v;
+            for (int g = 0; g < 4; ++g) v[g] = (k < F) ? K[(size_t)k * H4 + g * H + col0 + n] : 0.f;
+            *(f32x4*)(sKw + ((q * 4 + s) * 64 + lane) * 4) = v;
         }
+}
+
+// acc += A(16 x Fp, LDS rows of stride ldx) . Kslice(LDS); B reads run two (q,s) blocks ahead.
+__device__ __forceinline__ void input_proj(f32x4 (&acc)[4], const float* arow, const float* sKw, int nq, int lane) {
+    if (nq <= 0) return;
+    const float* bl = sKw + lane * 4;
+    const int last = nq * 4 - 1;
+    f32x4 a = *(const f32x4*)arow;
+    f32x4 b0 = *(const f32x4*)bl;
+    f32x4 b1 = *(const f32x4*)(bl + 256);
+    for (int q = 0; q < nq; ++q) {
+        const int qn = (q + 1 < nq) ? q + 1 : q;
+        const f32x4 an = *(const f32x4*)(arow + 16 * qn);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            int nxt = q * 4 + s + 2;
+            nxt = nxt > last ? last : nxt;
+            const f32x4 bn = *(const f32x4*)(bl + nxt * 256);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) mfma_vv(acc[g], a[s], b0[g]);
+            b0 = b1;
+            b1 = bn;
+        }
+        a = an;
+    }
+}
+
+// acc += h tile (LDS, columns in rotated slice order) . register-resident R blocks [J0, J1)
+template <int H, int J0, int J1>
+__device__ __forceinline__ void recurrent(f32x4 (&acc)[4], const float* hrow, const float (&wR)[H / 16][4][4]) {
+    if (J0 >= J1) return;
+    f32x4 a = *(const f32x4*)(hrow + 16 * J0);
+#pragma unroll
+    for (int j = J0; j < J1; ++j) {
+        f32x4 an = a;
+        if (j + 1 < J1) an = *(const f32x4*)(hrow + 16 * (j + 1));
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) mfma_va(acc[g], a[s], wR[j][s][g]);
+        a = an;
+    }
+}
+
+// sum over the 16 lanes of a DPP row (all lanes end with the total): xor-1, xor-2 inside quads,
+// then half-row mirror and row mirror.  Four v_add_f32_dpp instead of four ds_bpermute round trips.
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, true));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, true));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xf, 0xf, true));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xf, 0xf, true));
+    return v;
 }
 
 template <int H, int ACT, int MODE>
@@ -140,29 +218,31 @@ __global__ __launch_bounds__(256, 1) void lstm_cluster_kernel(LstmParams p) {
     const int F = LAYER ? p.F : p.F_dec;
     const int steps = LAYER ? p.T : p.T_out;
     const int Fp = round16(F);
+    const int nq = Fp >> 4;
 
     const ClusterLds L = cluster_lds(H, F, !LAYER);
     const int LDX = L.ldx, LDH = L.ldh;
     float* sK = smem + L.off_k;
-    float* sH = smem + L.off_h;
-    float* sX = smem + L.off_x;
+    float* sH = smem + L.off_h;   // h tile, column = ((unit/64 - slice) mod G)*64 + unit%64 (own slice first)
+    float* sX = smem + L.off_x;   // LAYER: three x tiles (t mod 3); DECODE: the y tile
     float* sW = smem + L.off_w;
     float* sBd = smem + L.off_bd;
     int* sFlag = (int*)(smem + L.off_flag);
-    float* sKw = sK + wave * (Fp >> 4) * 1024;  // this wave's K slice in B-operand order
+    float* sKw = sK + wave * nq * 1024;  // this wave's K slice in B-operand order
 
     if (tid == 0) sFlag[0] = 0;
-    // zero both x buffers once: pad columns [F, Fp) are never written afterwards
-    for (int i = tid; i < 2 * BT * LDX; i += 256) sX[i] = 0.f;
+    // zero the x tiles once: pad columns [F, Fp) are never written afterwards
+    for (int i = tid; i < NXBUF * BT * LDX; i += 256) sX[i] = 0.f;
 
-    f32x4 wR[NQ][4];
+    float wR[NQ][4][4];   // [k-block j][k-sub s][gate g], AGPR-resident
     float bias[4];
-    load_weights<H>(wR, bias, sKw, Kp, Rp, bp, F, Fp, col0, lane);
+    load_weights<H>(wR, bias, sKw, Kp, Rp, bp, F, Fp, col0, slice, lane);
     if (!LAYER) {
         const int O = p.F_dec;
         for (int i = tid; i < H * CL_MAX_O; i += 256) {
-            const int k = i >> 3, o = i & 7;
-            sW[i] = (o < O) ? p.dW[(size_t)k * O + o] : 0.f;
+            const int pos = i >> 3, o = i & 7;   // row `pos` of sW pairs with column `pos` of sH
+            const int unit = ((slice + (pos >> 6)) & (G - 1)) * 64 + (pos & 63);
+            sW[i] = (o < O) ? p.dW[(size_t)unit * O + o] : 0.f;
         }
         if (tid < CL_MAX_O) sBd[tid] = (tid < O) ? p.dbias[tid] : 0.f;
     }
@@ -172,6 +252,7 @@ __global__ __launch_bounds__(256, 1) void lstm_cluster_kernel(LstmParams p) {
 #ifdef FOV_STAMPS
     const bool stamp_on = (blockIdx.x == 5 && tid == 0);
 #endif
+    const float* hrow = sH + n * LDH + 4 * g4;   // this lane's A-operand row of the h tile
 
     for (int tile = group; tile < p.num_tiles && !aborted; tile += p.num_groups) {
         const int b0 = tile * BT;
@@ -185,19 +266,23 @@ __global__ __launch_bounds__(256, 1) void lstm_cluster_kernel(LstmParams p) {
             hcur[r] = (live && p.h0) ? p.h0[(size_t)row * H + col0 + n] : 0.f;
         }
         for (int i = tid; i < BT * H; i += 256) {
-            const int row = i / H, col = i - row * H;
-            sH[row * LDH + col] = (b0 + row < p.B && p.h0) ? p.h0[(size_t)(b0 + row) * H + col] : 0.f;
+            const int row = i / H, pos = i - row * H;
+            const int unit = ((slice + (pos >> 6)) & (G - 1)) * 64 + (pos & 63);
+            sH[row * LDH + pos] = (b0 + row < p.B && p.h0) ? p.h0[(size_t)(b0 + row) * H + unit] : 0.f;
         }
-        const float* xt = LAYER ? p.x + (size_t)b0 * p.T * F : nullptr;
+        // x staging: thread (xrw = tid/16, xcl = tid%16) moves columns xcl + 16*i of row xrw
+        const int xrw = tid >> 4, xcl = tid & 15;
+        const bool xlive = LAYER && (b0 + xrw < p.B);
+        const float* xt = LAYER ? p.x + ((size_t)(b0 + xrw) * p.T) * F + xcl : nullptr;
+        float* xl = sX + xrw * LDX + xcl;
         if (LAYER) {
-            if (steps > 0) {
 #pragma unroll
-                for (int i = 0; i < XR; ++i) {
-                    const int e = tid + 256 * i;
-                    const int row = e / F, col = e - row * F;
-                    if (e < BT * F) sX[row * LDX + col] = (b0 + row < p.B) ? xt[(size_t)row * p.T * F + col] : 0.f;
+            for (int tt = 0; tt < 2; ++tt)
+                if (tt < steps) {
+#pragma unroll
+                    for (int i = 0; i < XR; ++i)
+                        if (xcl + 16 * i < F) xl[tt * BT * LDX + 16 * i] = xlive ? xt[(size_t)tt * F + 16 * i] : 0.f;
                 }
-            }
         } else {
             // y_{-1} = dec_in0 (columns >= F stay zero)
             for (int i = tid; i < BT * F; i += 256) {
@@ -207,54 +292,34 @@ __global__ __launch_bounds__(256, 1) void lstm_cluster_kernel(LstmParams p) {
         }
         __syncthreads();
 
+        // ---- pre-activations of step 0 that need no remote data ----
+        f32x4 acc[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc[g] = (f32x4){bias[g], bias[g], bias[g], bias[g]};
+        if (steps > 0) {
+            mfma_begin(acc);
+            input_proj(acc, sX + n * LDX + 4 * g4, sKw, nq, lane);
+            recurrent<H, 0, 4>(acc, hrow, wR);
+            mfma_end(acc);
+        }
+
         for (int t = 0; t < steps; ++t) {
-            // ---- prefetch x_{t+1}: global -> registers now, registers -> LDS behind the MFMAs ----
             FOV_STAMP(0);
 #ifdef FOV_STAMPS
             if (stamp_on && t < STAMP_STEPS) g_stamps[MODE][t][9] = __builtin_amdgcn_s_memrealtime();
 #endif
+            // ---- prefetch x_{t+2}: global -> registers now, registers -> LDS after barrier 1 ----
             float xr[XR];
-            const bool pre = LAYER && (t + 1 < steps);
+            const bool pre = LAYER && (t + 2 < steps);
             if (pre) {
-                const float* xn = xt + (size_t)(t + 1) * F;
+                const float* xn = xt + (size_t)(t + 2) * F;
 #pragma unroll
-                for (int i = 0; i < XR; ++i) {
-                    const int e = tid + 256 * i;
-                    const int row = e / F, col = e - row * F;
-                    xr[i] = (e < BT * F && b0 + row < p.B) ? xn[(size_t)row * p.T * F + col] : 0.f;
-                }
+                for (int i = 0; i < XR; ++i) xr[i] = (xlive && xcl + 16 * i < F) ? xn[16 * i] : 0.f;
             }
-            f32x4 acc[4];
-#pragma unroll
-            for (int g = 0; g < 4; ++g) acc[g] = (f32x4){bias[g], bias[g], bias[g], bias[g]};
-            {   // input projection x_t . K  (A from the LDS x tile, B from the LDS K slice)
-                const float* arow = sX + (LAYER ? (t & 1) * BT * LDX : 0) + n * LDX + 4 * g4;
-                const int nq = Fp >> 4;
-                for (int q = 0; q < nq; ++q) {
-                    const f32x4 a = *(const f32x4*)(arow + 16 * q);
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const f32x4 bw = *(const f32x4*)(sKw + ((q * 4 + g) * 64 + lane) * 4);
-#pragma unroll
-                        for (int s = 0; s < 4; ++s)
-                            acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], bw[s], acc[g], 0, 0, 0);
-                    }
-                }
-            }
+            // ---- the part of h_{t-1} . R that needed the partner slices ----
+            recurrent<H, 4, NQ>(acc, hrow, wR);
+            mfma_end(acc);
             FOV_STAMP(1);
-            {   // recurrent product h_{t-1} . R  (A from the LDS h tile, B from registers)
-                const float* hrow = sH + n * LDH + 4 * g4;
-#pragma unroll
-                for (int q = 0; q < NQ; ++q) {
-                    const f32x4 a = *(const f32x4*)(hrow + 16 * q);
-#pragma unroll
-                    for (int s = 0; s < 4; ++s)
-#pragma unroll
-                        for (int g = 0; g < 4; ++g)
-                            acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], wR[q][g][s], acc[g], 0, 0, 0);
-                }
-            }
-            FOV_STAMP(2);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float ig = rec_act<ACT>(acc[0][r]);
@@ -264,6 +329,16 @@ __global__ __launch_bounds__(256, 1) void lstm_cluster_kernel(LstmParams p) {
                 c[r] = fmaf(fg, c[r], ig * gg);
                 hcur[r] = og * tanh_f(c[r]);
             }
+            unsigned long long* xbase = nullptr;
+            if (G > 1) {
+                // publish this workgroup's slice of h_t: one 8-byte {epoch, value} granule each
+                ++epoch;
+                xbase = p.xch + ((size_t)(group * 2 + (epoch & 1)) * BT) * H;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    st_granule(xbase + (size_t)(4 * g4 + r) * H + col0 + n,
+                               ((unsigned long long)epoch << 32) | __float_as_uint(hcur[r]));
+            }
             if (LAYER && p.hs) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -271,41 +346,52 @@ __global__ __launch_bounds__(256, 1) void lstm_cluster_kernel(LstmParams p) {
                     if (row < p.B) p.hs[((size_t)row * p.T + t) * H + col0 + n] = hcur[r];
                 }
             }
+            FOV_STAMP(2);
+            __syncthreads();  // barrier 1: every wave is done reading sH and the current x tile
             FOV_STAMP(3);
-            __syncthreads();  // every wave is done reading sH and the current x tile
-            FOV_STAMP(4);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) sH[(4 * g4 + r) * LDH + col0 + n] = hcur[r];
+            for (int r = 0; r < 4; ++r) sH[(4 * g4 + r) * LDH + wave * 16 + n] = hcur[r];
             if (pre) {
-                float* xb = sX + ((t + 1) & 1) * BT * LDX;
+                float* xb = xl + ((t + 2) % 3) * BT * LDX;
 #pragma unroll
-                for (int i = 0; i < XR; ++i) {
-                    const int e = tid + 256 * i;
-                    const int row = e / F, col = e - row * F;
-                    if (e < BT * F) xb[row * LDX + col] = xr[i];
+                for (int i = 0; i < XR; ++i)
+                    if (xcl + 16 * i < F) xb[16 * i] = xr[i];
+            }
+            __syncthreads();  // barrier 1b: the own slice of h_t is visible to all four waves
+            FOV_STAMP(4);
+            const bool more = (t + 1 < steps);
+            // Pre-activations of step t+1 that need no remote data are computed while the partner
+            // slices are in flight: x_{t+1} . K first, then the first sweep of the gather is
+            // ISSUED (its ~0.9 us round trip runs under the MFMAs that follow), then the own-slice
+            // k-blocks of h_t . R, and only then are the granule tags checked.
+            if (more) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) acc[g] = (f32x4){bias[g], bias[g], bias[g], bias[g]};
+                mfma_begin(acc);
+                if (LAYER) input_proj(acc, sX + ((t + 1) % 3) * BT * LDX + n * LDX + 4 * g4, sKw, nq, lane);
+            }
+            FOV_STAMP(5);
+            unsigned long long v[NG > 0 ? NG : 1];
+            if (G > 1) {
+#pragma unroll
+                for (int j = 0; j < NG; ++j) {
+                    const int idx = j * 256 + tid;
+                    const int rot = (idx >> 10) + 1, within = idx & 1023;
+                    const int osl = (slice + rot) & (G - 1);
+                    v[j] = ld_granule(xbase + (within >> 6) * H + osl * 64 + (within & 63));
                 }
             }
+            if (more) {
+                recurrent<H, 0, 4>(acc, hrow, wR);
+                mfma_end(acc);
+            }
             if (G > 1) {
-                // ---- publish this workgroup's slice of h_t, gather the other G-1 slices ----
-                ++epoch;
-                unsigned long long* base = p.xch + ((size_t)(group * 2 + (epoch & 1)) * BT) * H;
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    st_granule(base + (size_t)(4 * g4 + r) * H + col0 + n,
-                               ((unsigned long long)epoch << 32) | __float_as_uint(hcur[r]));
-                FOV_STAMP(5);
-                unsigned long long v[NG > 0 ? NG : 1];
+                // complete the gather: sweep again until every tag equals the epoch
                 unsigned spins = 0;
                 while (true) {
                     bool ok = true;
 #pragma unroll
-                    for (int j = 0; j < NG; ++j) {
-                        const int idx = j * 256 + tid;
-                        const int si = idx >> 10, within = idx & 1023;
-                        const int osl = si + (si >= slice ? 1 : 0);
-                        v[j] = ld_granule(base + (within >> 6) * H + osl * 64 + (within & 63));
-                        ok = ok && ((unsigned)(v[j] >> 32) == epoch);
-                    }
+                    for (int j = 0; j < NG; ++j) ok = ok && ((unsigned)(v[j] >> 32) == epoch);
                     if (__all(ok)) break;
                     ++spins;
                     if (spins > SPIN_LIMIT ||
@@ -317,27 +403,34 @@ __global__ __launch_bounds__(256, 1) void lstm_cluster_kernel(LstmParams p) {
                         }
                         break;
                     }
-                    __builtin_amdgcn_s_sleep(2);
+                    __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+                    for (int j = 0; j < NG; ++j) {
+                        const int idx = j * 256 + tid;
+                        const int rot = (idx >> 10) + 1, within = idx & 1023;
+                        const int osl = (slice + rot) & (G - 1);
+                        v[j] = ld_granule(xbase + (within >> 6) * H + osl * 64 + (within & 63));
+                    }
                 }
 #pragma unroll
                 for (int j = 0; j < NG; ++j) {
                     const int idx = j * 256 + tid;
-                    const int si = idx >> 10, within = idx & 1023;
-                    const int osl = si + (si >= slice ? 1 : 0);
-                    sH[(within >> 6) * LDH + osl * 64 + (within & 63)] = __uint_as_float((unsigned)v[j]);
+                    const int rot = (idx >> 10) + 1, within = idx & 1023;
+                    sH[(within >> 6) * LDH + rot * 64 + (within & 63)] = __uint_as_float((unsigned)v[j]);
                 }
             }
             FOV_STAMP(6);
-            __syncthreads();
+            __syncthreads();  // barrier 2: the whole h_t tile is in LDS
             FOV_STAMP(7);
             if (G > 1 && sFlag[0]) { aborted = true; break; }
             if (!LAYER) {
-                // y_t = tanh(h_t . W + bias): 16 lanes per sequence, 16-lane shuffle reduce
+                // y_t = tanh(h_t . W + bias): 16 lanes per sequence, DPP row reduction
                 const int O = p.F_dec;
                 const int drow = tid >> 4, dpart = tid & 15;
                 float ya[CL_MAX_O];
 #pragma unroll
                 for (int o = 0; o < CL_MAX_O; ++o) ya[o] = 0.f;
+#pragma unroll
                 for (int kk = 0; kk < H / 16; ++kk) {
                     const int k = kk * 16 + dpart;
                     const float hv = sH[drow * LDH + k];
@@ -349,20 +442,23 @@ __global__ __launch_bounds__(256, 1) void lstm_cluster_kernel(LstmParams p) {
                         ya[4 + o] = fmaf(hv, w1[o], ya[4 + o]);
                     }
                 }
-#pragma unroll
-                for (int o = 0; o < CL_MAX_O; ++o)
-#pragma unroll
-                    for (int m = 8; m >= 1; m >>= 1) ya[o] += __shfl_xor(ya[o], m);
                 float mine = 0.f;
 #pragma unroll
-                for (int o = 0; o < CL_MAX_O; ++o) mine = (dpart == o) ? ya[o] : mine;
+                for (int o = 0; o < CL_MAX_O; ++o) {
+                    const float tot = row16_sum(ya[o]);
+                    mine = (dpart == o) ? tot : mine;
+                }
                 if (dpart < O) {
                     const float y = tanh_f(mine + sBd[dpart]);
                     sX[drow * LDX + dpart] = y;
                     if (slice == 0 && b0 + drow < p.B)
                         p.out[((size_t)(b0 + drow) * p.T_out + t) * O + dpart] = y;
                 }
-                __syncthreads();
+                __syncthreads();  // barrier 3: y_t is in LDS
+                if (more) {
+                    input_proj(acc, sX + n * LDX + 4 * g4, sKw, nq, lane);
+                    mfma_end(acc);
+                }
                 FOV_STAMP(8);
             }
         }
