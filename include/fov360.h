@@ -130,6 +130,13 @@ int fov_meanvar_xyz(const float* y, float* out, int64_t rows, int fps, fov_strea
  * and returns FOV_OK or FOV_ERR_TIMEOUT.  Workspaces of non-persistent calls report FOV_OK. */
 int fov_check_status(const void* workspace, size_t workspace_bytes, fov_stream_t stream);
 
+/* Diagnostic: which h-exchange protocol the last persistent-kernel call on `workspace` used.
+ * 1 = every group verified (HW_REG_XCC_ID handshake) that its workgroups share an XCD and took the
+ *     L2-resident fast path; 2 = at least one workgroup used the placement-independent
+ *     write-through path (also forced by the environment variable FOV_FORCE_SAFE_EXCHANGE=1).
+ * Results are identical either way.  Synchronises `stream`. */
+int fov_exchange_mode(const void* workspace, size_t workspace_bytes, fov_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -40,6 +40,7 @@ SIGNATURES = {
     "fov_seq2seq_tf_fwd": (_I, [_P] * 11 + [_I] * 8 + [_P, _SZ, _P]),
     "fov_meanvar_xyz": (_I, [_P, _P, ctypes.c_int64, _I, _P]),
     "fov_check_status": (_I, [_P, _SZ, _P]),
+    "fov_exchange_mode": (_I, [_P, _SZ, _P]),
 }
 
 _lib = None

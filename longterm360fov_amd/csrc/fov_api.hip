@@ -256,4 +256,16 @@ int fov_check_status(const void* workspace, size_t workspace_bytes, fov_stream_t
     return FOV_OK;
 }
 
+int fov_exchange_mode(const void* workspace, size_t workspace_bytes, fov_stream_t stream) {
+    if (!workspace || workspace_bytes < kStatusBytes) {
+        set_error("fov_exchange_mode: invalid workspace");
+        return FOV_ERR_INVALID;
+    }
+    unsigned st[2] = {0, 0};
+    hipError_t e = hipMemcpyAsync(st, workspace, sizeof(st), hipMemcpyDeviceToHost, (hipStream_t)stream);
+    if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+    if (e != hipSuccess) { set_error("fov_exchange_mode: %s", hipGetErrorString(e)); return FOV_ERR_LAUNCH; }
+    return st[1] == 0 ? 1 : 2;
+}
+
 }  // extern "C"

@@ -11,15 +11,17 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // Gate activations.  v_exp_f32 / v_rcp_f32 based (about 1 ulp each); absolute error of the
 // logistic and of tanh is below 3e-7, far inside the 1e-3 relative parity bound on outputs.
+// __builtin_amdgcn_rcpf is the bare v_rcp_f32: __frcp_rn expands to the 10-instruction
+// correctly-rounded division sequence, which tripled the cell-update time.
 __device__ __forceinline__ float sigmoid_f(float x) {
-    return __frcp_rn(1.0f + __expf(-x));
+    return __builtin_amdgcn_rcpf(1.0f + __expf(-x));
 }
 __device__ __forceinline__ float hard_sigmoid_f(float x) {
     return fminf(fmaxf(fmaf(0.2f, x, 0.5f), 0.0f), 1.0f);
 }
 __device__ __forceinline__ float tanh_f(float x) {
     // 1 - 2/(1+e^{2x}); saturates cleanly to +-1, no NaN for any finite x
-    return 1.0f - 2.0f * __frcp_rn(1.0f + __expf(2.0f * x));
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x));
 }
 template <int ACT>
 __device__ __forceinline__ float rec_act(float x) {
@@ -54,6 +56,7 @@ struct LstmParams {
     unsigned* status;          // status[0] = timeout flag
     int num_groups;            // resident groups (persistent loop over 16-sequence tiles)
     int num_tiles;
+    int force_safe_exchange;   // 1: never take the same-XCD fast path (tests)
 };
 
 int launch_generic(const LstmParams& p, bool decode, hipStream_t stream);

@@ -29,12 +29,15 @@
 //
 // k order inside a 16-wide block is permuted so that one ds_read_b128 feeds four MFMAs:
 // MFMA s of block q uses k = 16q + 4*g4 + s on lanes with (l>>4) == g4, for A and B alike.
+#include <stdlib.h>
+
 #include "fov_common.h"
 
 namespace fov {
 
 constexpr int BT = 16;          // sequences per tile
 constexpr int XR = 6;           // x prefetch registers per thread: 16 rows * F <= 256 * XR
+constexpr int KPAD = 2;         // spare K-slice blocks per wave for the run-ahead LDS reads
 constexpr int NXBUF = 3;        // x tiles in LDS: x_{t+2} is written while x_{t+1} and x_t may be read
 constexpr int CL_MAX_F = 96;
 constexpr int CL_MAX_O = 8;
@@ -43,11 +46,23 @@ constexpr unsigned SPIN_LIMIT = 1u << 20;
 constexpr int MODE_LAYER = 0;   // T steps over x:(B,T,F) from (h0,c0); optional hs / hT / cT
 constexpr int MODE_DECODE = 1;  // T_out autoregressive steps from (h0,c0): y_t = tanh(h_t W + bias) fed back
 
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
 __device__ __forceinline__ unsigned long long ld_granule(const unsigned long long* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ void st_granule(unsigned long long* p, unsigned long long v) {
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // sc1: write-through
+}
+// Same-XCD fast path only: an sc0 store leaves the line in the XCD's L2, where the partners'
+// sc1 (L1-bypassing, L2-served) loads find it at L2-hit latency instead of a fabric round trip.
+__device__ __forceinline__ void st_granule_l2(unsigned long long* p, unsigned long long v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ unsigned xcc_id() {
+    unsigned x;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(x));
+    return x;
 }
 
 __host__ __device__ constexpr int round16(int v) { return (v + 15) & ~15; }
@@ -55,7 +70,7 @@ __host__ __device__ constexpr int round16(int v) { return (v + 15) & ~15; }
 // Diagnostic build only (-DFOV_STAMPS, tools/stamp_profile.py): per-step s_memtime stamps of one
 // wave.  The shipped library compiles none of this (cdna_hip_programming.md section 7, In-kernel stamps).
 #ifdef FOV_STAMPS
-constexpr int STAMP_SLOTS = 10;
+constexpr int STAMP_SLOTS = 12;
 constexpr int STAMP_STEPS = 64;
 __device__ unsigned long long g_stamps[2][STAMP_STEPS][STAMP_SLOTS];
 #define FOV_STAMP(slot)                                                                         \
@@ -82,12 +97,12 @@ __host__ __device__ inline ClusterLds cluster_lds(int H, int F, bool decode) {
     L.ldx = fp + 4;
     L.ldh = H + 4;
     L.off_k = 0;
-    L.off_h = L.off_k + fp * 256;
+    L.off_h = L.off_k + fp * 256 + 4 * KPAD * 256;
     L.off_x = L.off_h + BT * L.ldh;
     L.off_w = L.off_x + NXBUF * BT * L.ldx;
-    L.off_bd = L.off_w + (decode ? H * CL_MAX_O : 0);
+    L.off_bd = L.off_w + (decode ? 4 * BT * 16 : 0);   // DECODE: four per-wave 16x16 Dense partials
     L.off_flag = L.off_bd + 8;
-    L.total_floats = L.off_flag + 8;
+    L.total_floats = L.off_flag + 8 + 64;   // + tail pad for run-ahead reads of the x tile
     return L;
 }
 
@@ -115,7 +130,7 @@ __device__ __forceinline__ void mfma_end(f32x4 (&acc)[4]) {
 // Register block j holds the k-block of hidden units ((slice + j/4) mod G)*64 + (j%4)*16 .. +16:
 // the workgroup's OWN 64 units come first (j < 4), so the part of h_t . R that needs no remote
 // data can start before the gather of the partner slices has landed.
-template <int H>
+template <int H, bool DEC_KMAP>
 __device__ __forceinline__ void load_weights(float (&wR)[H / 16][4][4], float (&bias)[4], float* sKw,
                                              const float* K, const float* R, const float* b, int F, int Fp,
                                              int col0, int slice, int lane) {
@@ -133,12 +148,14 @@ __device__ __forceinline__ void load_weights(float (&wR)[H / 16][4][4], float (&
     }
 #pragma unroll
     for (int g = 0; g < 4; ++g) bias[g] = b[g * H + col0 + n];
-    // K slice in B-operand order: block (q,s) = 64 lanes x {i,f,c,o} of input row k = 16q+4*g4+s
+    // K slice in B-operand order: block (q,s) = 64 lanes x {i,f,c,o} of input row k = 16q+4*g4+s.
+    // DECODE (F <= 8, one q block): k = 4*s + g4 instead, so that the two MFMA steps s = 0,1 cover
+    // k = 0..7 and the Dense output fragment (y[n][4r + g4] in register r) is their A operand.
     const int nq = Fp >> 4;
     for (int q = 0; q < nq; ++q)
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            const int k = 16 * q + 4 * g4 + s;
+            const int k = DEC_KMAP ? (s < 2 ? 4 * s + g4 : F) : 16 * q + 4 * g4 + s;
             f32x4 v;
 #pragma unroll
             for (int g = 0; g < 4; ++g) v[g] = (k < F) ? K[(size_t)k * H4 + g * H + col0 + n] : 0.f;
@@ -147,21 +164,21 @@ __device__ __forceinline__ void load_weights(float (&wR)[H / 16][4][4], float (&
 }
 
 // acc += A(16 x Fp, LDS rows of stride ldx) . Kslice(LDS); B reads run two (q,s) blocks ahead.
+// No clamping: the K slice carries KPAD spare blocks per wave and the x tiles a spare tail, so
+// the run-ahead reads of the last iterations stay inside LDS (their values are never used) and
+// every block offset is an instruction immediate instead of VALU work.
 __device__ __forceinline__ void input_proj(f32x4 (&acc)[4], const float* arow, const float* sKw, int nq, int lane) {
     if (nq <= 0) return;
     const float* bl = sKw + lane * 4;
-    const int last = nq * 4 - 1;
     f32x4 a = *(const f32x4*)arow;
     f32x4 b0 = *(const f32x4*)bl;
     f32x4 b1 = *(const f32x4*)(bl + 256);
     for (int q = 0; q < nq; ++q) {
-        const int qn = (q + 1 < nq) ? q + 1 : q;
-        const f32x4 an = *(const f32x4*)(arow + 16 * qn);
+        const f32x4 an = *(const f32x4*)(arow + 16 * (q + 1));
+        const float* bq = bl + q * 1024;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            int nxt = q * 4 + s + 2;
-            nxt = nxt > last ? last : nxt;
-            const f32x4 bn = *(const f32x4*)(bl + nxt * 256);
+            const f32x4 bn = *(const f32x4*)(bq + (s + 2) * 256);
 #pragma unroll
             for (int g = 0; g < 4; ++g) mfma_vv(acc[g], a[s], b0[g]);
             b0 = b1;
@@ -169,6 +186,15 @@ __device__ __forceinline__ void input_proj(f32x4 (&acc)[4], const float* arow, c
         }
         a = an;
     }
+}
+
+// DECODE: acc += y(16 x 8) . Kslice, y fragment and the two K blocks already in registers
+__device__ __forceinline__ void input_proj_reg(f32x4 (&acc)[4], f32x4 y4, const f32x4 (&kb)[2]) {
+    asm volatile("s_nop 1" : "+v"(y4));   // VALU-written A operand -> MFMA read
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) mfma_vv(acc[g], y4[s], kb[s][g]);
 }
 
 // acc += h tile (LDS, columns in rotated slice order) . register-resident R blocks [J0, J1)
@@ -188,16 +214,6 @@ __device__ __forceinline__ void recurrent(f32x4 (&acc)[4], const float* hrow, co
     }
 }
 
-// sum over the 16 lanes of a DPP row (all lanes end with the total): xor-1, xor-2 inside quads,
-// then half-row mirror and row mirror.  Four v_add_f32_dpp instead of four ds_bpermute round trips.
-__device__ __forceinline__ float row16_sum(float v) {
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, true));
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, true));
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xf, 0xf, true));
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xf, 0xf, true));
-    return v;
-}
-
 template <int H, int ACT, int MODE>
 __global__ __launch_bounds__(256, 1) void lstm_cluster_kernel(LstmParams p) {
     constexpr int G = H / 64;
@@ -208,7 +224,17 @@ __global__ __launch_bounds__(256, 1) void lstm_cluster_kernel(LstmParams p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 15, g4 = lane >> 4;
-    const int group = blockIdx.x / G, slice = blockIdx.x - group * G;
+    // Blocks b and b+8 are observed to share an XCD (round-robin dispatch), so when the group
+    // count allows it the G members of a group are 8 blocks apart.  This is a SPEED choice only:
+    // whether the members really share an XCD is verified at run time below.
+    int group, slice;
+    if (G > 1 && (p.num_groups & 7) == 0) {
+        group = (blockIdx.x / (8 * G)) * 8 + (blockIdx.x & 7);
+        slice = (blockIdx.x >> 3) & (G - 1);
+    } else {
+        group = blockIdx.x / G;
+        slice = blockIdx.x - group * G;
+    }
     const int col0 = slice * 64 + wave * 16;  // first hidden unit of this wave
 
     // weights / input of the phase this launch runs
@@ -225,34 +251,98 @@ __global__ __launch_bounds__(256, 1) void lstm_cluster_kernel(LstmParams p) {
     float* sK = smem + L.off_k;
     float* sH = smem + L.off_h;   // h tile, column = ((unit/64 - slice) mod G)*64 + unit%64 (own slice first)
     float* sX = smem + L.off_x;   // LAYER: three x tiles (t mod 3); DECODE: the y tile
-    float* sW = smem + L.off_w;
-    float* sBd = smem + L.off_bd;
+    float* sW = smem + L.off_w;   // DECODE: the four per-wave partial products of the Dense
     int* sFlag = (int*)(smem + L.off_flag);
-    float* sKw = sK + wave * nq * 1024;  // this wave's K slice in B-operand order
+    float* sKw = sK + wave * (nq * 4 + KPAD) * 256;  // this wave's K slice in B-operand order
 
-    if (tid == 0) sFlag[0] = 0;
+    if (tid == 0) { sFlag[0] = 0; sFlag[1] = 0; }
+    if (G > 1) {
+        // hello handshake (safe sc1 protocol): do all members of this group sit on one XCD?
+        unsigned long long* hello = p.xch + (size_t)p.num_groups * 2 * BT * H + (size_t)group * G;
+        const unsigned mine = xcc_id();
+        if (tid == 0) st_granule(hello + slice, (1ull << 32) | mine);
+        if (tid < G) {
+            unsigned long long hv = 0;
+            unsigned spins = 0;
+            while (true) {
+                hv = ld_granule(hello + tid);
+                if ((hv >> 32) != 0) break;
+                if (++spins > SPIN_LIMIT) {
+                    __hip_atomic_store(p.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    sFlag[0] = 1;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(4);
+            }
+            if ((unsigned)hv != mine) sFlag[1] = 1;   // a partner lives on another XCD
+        }
+    }
     // zero the x tiles once: pad columns [F, Fp) are never written afterwards
     for (int i = tid; i < NXBUF * BT * LDX; i += 256) sX[i] = 0.f;
 
     float wR[NQ][4][4];   // [k-block j][k-sub s][gate g], AGPR-resident
     float bias[4];
-    load_weights<H>(wR, bias, sKw, Kp, Rp, bp, F, Fp, col0, slice, lane);
+    load_weights<H, !LAYER>(wR, bias, sKw, Kp, Rp, bp, F, Fp, col0, slice, lane);
+    // DECODE: Dense(F_dec, tanh) runs on the matrix pipe, transposed: y^T = Wd^T . h^T.  Wave w
+    // reduces over positions [16*NB*w, 16*NB*(w+1)) of the (rotated) h tile, NB = H/64; lane
+    // (i = l&15, g4) keeps Wd[pos = 16*(NB*w + b) + 4*g4 + s][o(i)], o(i) = 4*(i&3) + (i>>2), as MFMA
+    // A operands (zero where o(i) >= F_dec).  With that row order register r of the D fragment on
+    // lane (n, g4) is y[n][4r + g4]: registers 0,1 are the A operands of the two y . K MFMA steps.
+    // The D fragment of that product has batch on the lane and o = 4*g4 + r in the registers,
+    // which is exactly the A-operand layout of the y . K product that follows: after the 4-way
+    // sum over waves (through LDS) y never leaves registers.
+    constexpr int NB = H / 64;
+    float wd[NB][4];
+    float bd4[4];
     if (!LAYER) {
         const int O = p.F_dec;
-        for (int i = tid; i < H * CL_MAX_O; i += 256) {
-            const int pos = i >> 3, o = i & 7;   // row `pos` of sW pairs with column `pos` of sH
-            const int unit = ((slice + (pos >> 6)) & (G - 1)) * 64 + (pos & 63);
-            sW[i] = (o < O) ? p.dW[(size_t)unit * O + o] : 0.f;
-        }
-        if (tid < CL_MAX_O) sBd[tid] = (tid < O) ? p.dbias[tid] : 0.f;
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int ss = 0; ss < 4; ++ss) {
+                const int pos = 16 * (NB * wave + b) + 4 * g4 + ss;
+                const int unit = ((slice + (pos >> 6)) & (G - 1)) * 64 + (pos & 63);
+                const int o = 4 * (n & 3) + (n >> 2);
+                wd[b][ss] = (o < O) ? p.dW[(size_t)unit * O + o] : 0.f;
+            }
+#pragma unroll
+        for (int ss = 0; ss < 4; ++ss) bd4[ss] = (4 * ss + g4 < O) ? p.dbias[4 * ss + g4] : 0.f;
+    }
+    f32x4 kb[2];   // DECODE: the two K-slice blocks of this lane (loop invariant)
+    if (!LAYER) {
+        __syncthreads();   // K slice written by load_weights above
+        kb[0] = *(const f32x4*)(sKw + lane * 4);
+        kb[1] = *(const f32x4*)(sKw + 256 + lane * 4);
     }
 
     unsigned epoch = 0;
     bool aborted = false;
+    __syncthreads();
+    const bool same_xcd = (G > 1) && (sFlag[1] == 0) && (p.force_safe_exchange == 0);
+    if (G > 1 && sFlag[0]) return;   // a partner never showed up: status word is set, drain
+    if (G > 1 && tid == 0 && !same_xcd)   // status[1]: number of workgroups on the safe (cross-XCD) exchange
+        __hip_atomic_fetch_add(p.status + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #ifdef FOV_STAMPS
     const bool stamp_on = (blockIdx.x == 5 && tid == 0);
 #endif
     const float* hrow = sH + n * LDH + 4 * g4;   // this lane's A-operand row of the h tile
+
+    // Granule I/O goes through one buffer descriptor per group (both parity buffers) with 32-bit
+    // per-lane offsets computed once: fp32 MFMA shares the VALU, so 64-bit address arithmetic
+    // inside the step would come straight out of the MFMA rate.
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+        p.xch + (size_t)group * 2 * BT * H, 0, 2 * BT * H * (int)sizeof(unsigned long long), 0x00020000);
+    const unsigned pub_off = (unsigned)((4 * g4) * H + col0 + n) * 8u;
+    unsigned goff[NG > 0 ? NG : 1];
+    int loff[NG > 0 ? NG : 1];
+#pragma unroll
+    for (int j = 0; j < NG; ++j) {
+        const int idx = j * 256 + tid;
+        const int rot = (idx >> 10) + 1, within = idx & 1023;
+        const int osl = (slice + rot) & (G - 1);
+        goff[j] = (unsigned)((within >> 6) * H + osl * 64 + (within & 63)) * 8u;
+        loff[j] = (within >> 6) * LDH + rot * 64 + (within & 63);
+    }
 
     for (int tile = group; tile < p.num_tiles && !aborted; tile += p.num_groups) {
         const int b0 = tile * BT;
@@ -283,12 +373,12 @@ __global__ __launch_bounds__(256, 1) void lstm_cluster_kernel(LstmParams p) {
                     for (int i = 0; i < XR; ++i)
                         if (xcl + 16 * i < F) xl[tt * BT * LDX + 16 * i] = xlive ? xt[(size_t)tt * F + 16 * i] : 0.f;
                 }
-        } else {
-            // y_{-1} = dec_in0 (columns >= F stay zero)
-            for (int i = tid; i < BT * F; i += 256) {
-                const int row = i / F, col = i - row * F;
-                sX[row * LDX + col] = (b0 + row < p.B) ? p.dec_in0[(size_t)(b0 + row) * F + col] : 0.f;
-            }
+        }
+        f32x4 y4 = (f32x4){0.f, 0.f, 0.f, 0.f};   // DECODE: y_{t-1}[n][4*s + g4], the A fragment of y . K
+        if (!LAYER) {
+#pragma unroll
+            for (int ss = 0; ss < 4; ++ss)
+                y4[ss] = (4 * ss + g4 < F && b0 + n < p.B) ? p.dec_in0[(size_t)(b0 + n) * F + 4 * ss + g4] : 0.f;
         }
         __syncthreads();
 
@@ -298,20 +388,30 @@ __global__ __launch_bounds__(256, 1) void lstm_cluster_kernel(LstmParams p) {
         for (int g = 0; g < 4; ++g) acc[g] = (f32x4){bias[g], bias[g], bias[g], bias[g]};
         if (steps > 0) {
             mfma_begin(acc);
-            input_proj(acc, sX + n * LDX + 4 * g4, sKw, nq, lane);
+            if (LAYER) input_proj(acc, sX + n * LDX + 4 * g4, sKw, nq, lane);
+            else input_proj_reg(acc, y4, kb);
             recurrent<H, 0, 4>(acc, hrow, wR);
             mfma_end(acc);
         }
 
+        float xr[XR];
+#pragma unroll
+        for (int i = 0; i < XR; ++i) xr[i] = 0.f;
         for (int t = 0; t < steps; ++t) {
             FOV_STAMP(0);
 #ifdef FOV_STAMPS
             if (stamp_on && t < STAMP_STEPS) g_stamps[MODE][t][9] = __builtin_amdgcn_s_memrealtime();
 #endif
-            // ---- prefetch x_{t+2}: global -> registers now, registers -> LDS after barrier 1 ----
-            float xr[XR];
-            const bool pre = LAYER && (t + 2 < steps);
-            if (pre) {
+            // ---- x pipeline: x_{t+1} (loaded during step t-1) goes registers -> LDS now; its tile
+            // was last read two steps ago and is next read after barrier 1b of this step.  Then
+            // x_{t+2} is requested, so every load has a full step to land. ----
+            if (LAYER && t > 0 && t + 1 < steps) {
+                float* xb = xl + ((t + 1) % 3) * BT * LDX;
+#pragma unroll
+                for (int i = 0; i < XR; ++i)
+                    if (xcl + 16 * i < F) xb[16 * i] = xr[i];
+            }
+            if (LAYER && t + 2 < steps) {
                 const float* xn = xt + (size_t)(t + 2) * F;
 #pragma unroll
                 for (int i = 0; i < XR; ++i) xr[i] = (xlive && xcl + 16 * i < F) ? xn[16 * i] : 0.f;
@@ -329,15 +429,22 @@ __global__ __launch_bounds__(256, 1) void lstm_cluster_kernel(LstmParams p) {
                 c[r] = fmaf(fg, c[r], ig * gg);
                 hcur[r] = og * tanh_f(c[r]);
             }
-            unsigned long long* xbase = nullptr;
+            unsigned xsoff = 0;
             if (G > 1) {
-                // publish this workgroup's slice of h_t: one 8-byte {epoch, value} granule each
+                // publish this workgroup's slice of h_t: one 8-byte {value, epoch} granule each
                 ++epoch;
-                xbase = p.xch + ((size_t)(group * 2 + (epoch & 1)) * BT) * H;
+                xsoff = (epoch & 1u) * (unsigned)(BT * H * sizeof(unsigned long long));
+                if (same_xcd) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    st_granule(xbase + (size_t)(4 * g4 + r) * H + col0 + n,
-                               ((unsigned long long)epoch << 32) | __float_as_uint(hcur[r]));
+                    for (int r = 0; r < 4; ++r)
+                        __builtin_amdgcn_raw_buffer_store_b64((u32x2){__float_as_uint(hcur[r]), epoch}, xrs,
+                                                              pub_off + r * H * 8, xsoff, 1 /* sc0: stays in L2 */);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        __builtin_amdgcn_raw_buffer_store_b64((u32x2){__float_as_uint(hcur[r]), epoch}, xrs,
+                                                              pub_off + r * H * 8, xsoff, 16 /* sc1: write-through */);
+                }
             }
             if (LAYER && p.hs) {
 #pragma unroll
@@ -351,12 +458,6 @@ __global__ __launch_bounds__(256, 1) void lstm_cluster_kernel(LstmParams p) {
             FOV_STAMP(3);
 #pragma unroll
             for (int r = 0; r < 4; ++r) sH[(4 * g4 + r) * LDH + wave * 16 + n] = hcur[r];
-            if (pre) {
-                float* xb = xl + ((t + 2) % 3) * BT * LDX;
-#pragma unroll
-                for (int i = 0; i < XR; ++i)
-                    if (xcl + 16 * i < F) xb[16 * i] = xr[i];
-            }
             __syncthreads();  // barrier 1b: the own slice of h_t is visible to all four waves
             FOV_STAMP(4);
             const bool more = (t + 1 < steps);
@@ -371,27 +472,23 @@ __global__ __launch_bounds__(256, 1) void lstm_cluster_kernel(LstmParams p) {
                 if (LAYER) input_proj(acc, sX + ((t + 1) % 3) * BT * LDX + n * LDX + 4 * g4, sKw, nq, lane);
             }
             FOV_STAMP(5);
-            unsigned long long v[NG > 0 ? NG : 1];
+            u32x2 v[NG > 0 ? NG : 1];
             if (G > 1) {
 #pragma unroll
-                for (int j = 0; j < NG; ++j) {
-                    const int idx = j * 256 + tid;
-                    const int rot = (idx >> 10) + 1, within = idx & 1023;
-                    const int osl = (slice + rot) & (G - 1);
-                    v[j] = ld_granule(xbase + (within >> 6) * H + osl * 64 + (within & 63));
-                }
+                for (int j = 0; j < NG; ++j) v[j] = __builtin_amdgcn_raw_buffer_load_b64(xrs, goff[j], xsoff, 16);
             }
             if (more) {
                 recurrent<H, 0, 4>(acc, hrow, wR);
                 mfma_end(acc);
             }
+            FOV_STAMP(11);
             if (G > 1) {
                 // complete the gather: sweep again until every tag equals the epoch
                 unsigned spins = 0;
                 while (true) {
                     bool ok = true;
 #pragma unroll
-                    for (int j = 0; j < NG; ++j) ok = ok && ((unsigned)(v[j] >> 32) == epoch);
+                    for (int j = 0; j < NG; ++j) ok = ok && (v[j].y == epoch);
                     if (__all(ok)) break;
                     ++spins;
                     if (spins > SPIN_LIMIT ||
@@ -404,59 +501,57 @@ __global__ __launch_bounds__(256, 1) void lstm_cluster_kernel(LstmParams p) {
                         break;
                     }
                     __builtin_amdgcn_s_sleep(1);
+                    asm volatile("" ::: "memory");   // the sweep below must really re-read memory
 #pragma unroll
-                    for (int j = 0; j < NG; ++j) {
-                        const int idx = j * 256 + tid;
-                        const int rot = (idx >> 10) + 1, within = idx & 1023;
-                        const int osl = (slice + rot) & (G - 1);
-                        v[j] = ld_granule(xbase + (within >> 6) * H + osl * 64 + (within & 63));
-                    }
+                    for (int j = 0; j < NG; ++j) v[j] = __builtin_amdgcn_raw_buffer_load_b64(xrs, goff[j], xsoff, 16);
                 }
+#ifdef FOV_STAMPS
+                if (stamp_on && t < STAMP_STEPS) g_stamps[MODE][t][10] = spins;
+#endif
 #pragma unroll
-                for (int j = 0; j < NG; ++j) {
-                    const int idx = j * 256 + tid;
-                    const int rot = (idx >> 10) + 1, within = idx & 1023;
-                    sH[(within >> 6) * LDH + rot * 64 + (within & 63)] = __uint_as_float((unsigned)v[j]);
-                }
+                for (int j = 0; j < NG; ++j) sH[loff[j]] = __uint_as_float(v[j].x);
             }
             FOV_STAMP(6);
             __syncthreads();  // barrier 2: the whole h_t tile is in LDS
             FOV_STAMP(7);
             if (G > 1 && sFlag[0]) { aborted = true; break; }
             if (!LAYER) {
-                // y_t = tanh(h_t . W + bias): 16 lanes per sequence, DPP row reduction
+                // y_t = tanh(h_t . Wd + bias) on the matrix pipe (see the wd[] comment above)
                 const int O = p.F_dec;
-                const int drow = tid >> 4, dpart = tid & 15;
-                float ya[CL_MAX_O];
+                f32x4 hb[NB];
+                const float* hq = hrow + 16 * NB * wave;
 #pragma unroll
-                for (int o = 0; o < CL_MAX_O; ++o) ya[o] = 0.f;
+                for (int b = 0; b < NB; ++b) hb[b] = *(const f32x4*)(hq + 16 * b);
+                f32x4 dacc[2];
+                dacc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                dacc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                asm volatile("s_nop 1" : "+v"(dacc[0]), "+v"(dacc[1]));
 #pragma unroll
-                for (int kk = 0; kk < H / 16; ++kk) {
-                    const int k = kk * 16 + dpart;
-                    const float hv = sH[drow * LDH + k];
-                    const f32x4 w0 = *(const f32x4*)(sW + k * 8);
-                    const f32x4 w1 = *(const f32x4*)(sW + k * 8 + 4);
+                for (int b = 0; b < NB; ++b)
 #pragma unroll
-                    for (int o = 0; o < 4; ++o) {
-                        ya[o] = fmaf(hv, w0[o], ya[o]);
-                        ya[4 + o] = fmaf(hv, w1[o], ya[4 + o]);
-                    }
+                    for (int ss = 0; ss < 4; ++ss) mfma_vv(dacc[ss & 1], wd[b][ss], hb[b][ss]);
+                asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" : "+v"(dacc[0]), "+v"(dacc[1]));
+#pragma unroll
+                for (int ss = 0; ss < 4; ++ss) dacc[0][ss] += dacc[1][ss];
+                *(f32x4*)(sW + (wave * 16 + n) * 16 + 4 * g4) = dacc[0];   // partial over this wave's positions
+                __syncthreads();  // barrier 3: the four partial products are in LDS
+                f32x4 ysum = *(const f32x4*)(sW + n * 16 + 4 * g4);
+#pragma unroll
+                for (int w2 = 1; w2 < 4; ++w2) {
+                    const f32x4 part = *(const f32x4*)(sW + (w2 * 16 + n) * 16 + 4 * g4);
+#pragma unroll
+                    for (int ss = 0; ss < 4; ++ss) ysum[ss] += part[ss];
                 }
-                float mine = 0.f;
 #pragma unroll
-                for (int o = 0; o < CL_MAX_O; ++o) {
-                    const float tot = row16_sum(ya[o]);
-                    mine = (dpart == o) ? tot : mine;
+                for (int ss = 0; ss < 4; ++ss) y4[ss] = tanh_f(ysum[ss] + bd4[ss]);
+                if (slice == 0 && wave == 0 && b0 + n < p.B) {
+                    float* yo = p.out + ((size_t)(b0 + n) * p.T_out + t) * O + g4;
+#pragma unroll
+                    for (int ss = 0; ss < 2; ++ss)
+                        if (4 * ss + g4 < O) yo[4 * ss] = y4[ss];
                 }
-                if (dpart < O) {
-                    const float y = tanh_f(mine + sBd[dpart]);
-                    sX[drow * LDX + dpart] = y;
-                    if (slice == 0 && b0 + drow < p.B)
-                        p.out[((size_t)(b0 + drow) * p.T_out + t) * O + dpart] = y;
-                }
-                __syncthreads();  // barrier 3: y_t is in LDS
                 if (more) {
-                    input_proj(acc, sX + n * LDX + 4 * g4, sKw, nq, lane);
+                    input_proj_reg(acc, y4, kb);
                     mfma_end(acc);
                 }
                 FOV_STAMP(8);
@@ -503,7 +598,8 @@ int cluster_num_groups(int B, int H) {
 }
 
 static size_t cluster_xch_bytes(int B, int H) {
-    const size_t b = (size_t)cluster_num_groups(B, H) * 2 * BT * H * sizeof(unsigned long long);
+    const size_t groups = (size_t)cluster_num_groups(B, H);
+    const size_t b = (groups * 2 * BT * H + groups * (H / 64)) * sizeof(unsigned long long);   // granules + hello
     return (b + 255) & ~(size_t)255;
 }
 
@@ -557,6 +653,8 @@ int launch_cluster(const LstmParams& p_in, bool decode, hipStream_t stream) {
     }
     p.num_tiles = (p.B + BT - 1) / BT;
     p.num_groups = cluster_num_groups(p.B, p.H);
+    const char* safe = getenv("FOV_FORCE_SAFE_EXCHANGE");
+    p.force_safe_exchange = (safe && safe[0] == '1') ? 1 : 0;
     // zero the status words and every granule tag (epochs restart at 1 in each launch)
     const size_t xch_bytes = kStatusBytes + cluster_xch_bytes(p.B, p.H);
     hipError_t e = hipMemsetAsync((void*)p.status, 0, xch_bytes, stream);

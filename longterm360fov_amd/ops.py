@@ -59,6 +59,11 @@ class Workspace:
             check(_lib.lib().fov_check_status(self.buf.data_ptr(), self.buf.numel(), _stream()))
 
 
+    def exchange_mode(self):
+        """1 = same-XCD fast exchange, 2 = placement-independent exchange (diagnostic)."""
+        return _lib.lib().fov_exchange_mode(self.buf.data_ptr(), self.buf.numel(), _stream())
+
+
 _default_ws = {}
 
 

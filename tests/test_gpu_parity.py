@@ -253,3 +253,30 @@ def test_persistent_tile_loop_more_tiles_than_groups():
     out = ops.seq2seq_decode(dev(enc), dev(dec0), devw(w1), T_out, impl="cluster", workspace=ws)
     ws.check()
     assert_parity(out, ref, "multi-tile cluster H128 B=%d" % B, tight=5e-5)
+
+
+def test_exchange_paths_agree_bitwise():
+    """The same-XCD fast exchange (sc0 stores kept in the XCD's L2, taken only after the
+    HW_REG_XCC_ID handshake proves co-location) and the placement-independent write-through
+    exchange must give bit-identical results; FOV_FORCE_SAFE_EXCHANGE=1 selects the latter."""
+    ops = _ops()
+    B, T_in, T_out, H = 1024, 8, 8, 256
+    w = O.init_seq2seq(4321, H=H, bias_noise=0.05)
+    enc, dec0, _ = O.synthetic_batch(4321, B, T_in, T_out)
+    dw = devw(w)
+    ws = ops.Workspace()
+    outs = {}
+    try:
+        for mode in ("0", "1"):
+            os.environ["FOV_FORCE_SAFE_EXCHANGE"] = mode
+            outs[mode] = ops.seq2seq_decode(dev(enc), dev(dec0), dw, T_out, impl="cluster", workspace=ws).clone()
+            ws.check()
+            got = ws.exchange_mode()
+            print("FOV_FORCE_SAFE_EXCHANGE=%s -> exchange mode %d (1 = same-XCD fast, 2 = write-through)" % (mode, got))
+            if mode == "1":
+                assert got == 2
+    finally:
+        os.environ.pop("FOV_FORCE_SAFE_EXCHANGE", None)
+    assert torch.equal(outs["0"], outs["1"])
+    ref = C.seq2seq_decode(enc, dec0, w, T_out)
+    assert_parity(outs["0"], ref, "exchange paths vs C oracle", tight=5e-5)

@@ -19,8 +19,9 @@ _lib.LIB_PATH = os.path.join(ROOT, "longterm360fov_amd", "lib", "libfov360_hip_s
 from longterm360fov_amd import ops  # noqa: E402
 from oracle import fov_oracle as O  # noqa: E402
 
-SEG = ["x-prefetch issue + x.K MFMAs", "h.R MFMAs (issue)", "cell update (waits MFMA)", "barrier 1",
-       "LDS writes + publish", "gather spin", "barrier 2", "dense + barrier 3"]
+SEG = ["remote-slice h.R MFMAs (192)", "cell update + publish", "barrier 1", "own h -> LDS + barrier 1b",
+       "x(t+1).K MFMAs (96, encoder)", "gather issue + own-slice MFMAs (64) + wait", "barrier 2",
+       "dense + barrier 3 + y.K MFMAs"]
 
 
 def main():
@@ -34,7 +35,7 @@ def main():
         ops.seq2seq_decode(d_enc, d_dec0, dw, T_out, impl="cluster", workspace=ws)
     ws.check()
     L = _lib.lib()
-    buf = np.zeros((2, 64, 10), dtype=np.uint64)
+    buf = np.zeros((2, 64, 12), dtype=np.uint64)
     L.fov_debug_read_stamps.argtypes = [ctypes.c_void_p]
     assert L.fov_debug_read_stamps(buf.ctypes.data_as(ctypes.c_void_p)) == 0
     for mode, name, steps, nslot in ((0, "encoder (MODE_LAYER)", T_in, 8), (1, "decoder (MODE_DECODE)", T_out, 9)):
@@ -45,6 +46,10 @@ def main():
         ghz = (st[-1, 0] - st[0, 0]) / ((real[-1] - real[0]) * 10.0)
         print("== %s: %.0f cycles = %.2f us per step (median over %d steps), in-kernel clock %.2f GHz"
               % (name, np.median(step_total), np.median(step_total) / ghz * 1e-3, steps - 1, ghz))
+        spins = buf[mode, :steps, 10].astype(np.int64)
+        own = (buf[mode, 1:steps, 11].astype(np.int64) - st[1:, 5])
+        print("   gather: extra sweeps per step: mean %.2f max %d; issue->own-MFMAs-done %.0f cyc, then wait+LDS %.0f cyc"
+              % (spins.mean(), spins.max(), np.median(own), np.median(st[1:, 6] - buf[mode, 1:steps, 11].astype(np.int64))))
         med = np.median(seg[1:], axis=0)
         for i, v in enumerate(med):
             print("   %-34s %8.0f cyc %7.0f ns  %5.1f%%" % (SEG[i], v, v / ghz, 100.0 * v / med.sum()))
