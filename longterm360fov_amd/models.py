@@ -1,0 +1,200 @@
+"""Keras-shaped model objects for the hot path, backed by libfov360_hip.so.
+
+Mirrors what the reference's model scripts do with ``keras.models.Model``:
+    mycode/FoV_seq2seq.py:82-101     training graph        -> Seq2SeqLSTM.predict / fit
+    mycode/FoV_seq2seq.py:137-148    sampling models       -> .encoder_model / .decoder_model
+    mycode/FoV_seq2seq.py:154-178    decode_sequence_fov   -> .decode_sequence (one fused device call)
+Inputs and outputs are NumPy arrays in the reference's positional order and shapes; tensors are
+staged through torch (device memory and streams only).  Weights keep the Keras layout and order
+(``[kernel, recurrent_kernel, bias]`` per LSTM, ``[kernel, bias]`` for Dense) so files round-trip.
+"""
+import numpy as np
+
+from .config import cfg
+
+_W_ORDER = ("enc_K", "enc_R", "enc_b", "dec_K", "dec_R", "dec_b", "dense_W", "dense_b")
+
+
+def glorot_uniform(rng, fan_in, fan_out):
+    lim = np.sqrt(6.0 / (fan_in + fan_out))
+    return rng.uniform(-lim, lim, (fan_in, fan_out)).astype(np.float32)
+
+
+def orthogonal(rng, rows, cols):
+    a = rng.standard_normal((rows, cols))
+    u, _, vt = np.linalg.svd(a, full_matrices=False)
+    return (u if u.shape == (rows, cols) else vt).astype(np.float32)
+
+
+def init_lstm_weights(rng, F, H):
+    """Keras LSTM defaults: glorot_uniform kernel, orthogonal recurrent kernel, zero bias with the
+    forget block at one (unit_forget_bias)."""
+    b = np.zeros(4 * H, np.float32)
+    b[H:2 * H] = 1.0
+    return glorot_uniform(rng, F, 4 * H), orthogonal(rng, H, 4 * H), b
+
+
+def _as_f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+class _SubModel:
+    def __init__(self, fn):
+        self._fn = fn
+
+    def predict(self, x, batch_size=None, verbose=0):
+        return self._fn(x)
+
+    predict_on_batch = predict
+
+
+class Seq2SeqLSTM:
+    """Target-only seq2seq LSTM (1-layer encoder, 1-layer decoder, Dense(tanh) head)."""
+
+    def __init__(self, num_encoder_tokens=None, num_decoder_tokens=6, latent_dim=64, recurrent_activation=None,
+                 seed=None, impl="auto", device="cuda"):
+        self.num_encoder_tokens = 3 * cfg.fps if num_encoder_tokens is None else int(num_encoder_tokens)
+        self.num_decoder_tokens = int(num_decoder_tokens)
+        self.latent_dim = int(latent_dim)
+        self.recurrent_activation = recurrent_activation or cfg.recurrent_activation
+        if self.recurrent_activation not in ("sigmoid", "hard_sigmoid"):
+            raise ValueError("recurrent_activation must be 'sigmoid' or 'hard_sigmoid'")
+        self.impl = impl
+        self.device = device
+        rng = np.random.default_rng(seed)
+        w = {}
+        w["enc_K"], w["enc_R"], w["enc_b"] = init_lstm_weights(rng, self.num_encoder_tokens, self.latent_dim)
+        w["dec_K"], w["dec_R"], w["dec_b"] = init_lstm_weights(rng, self.num_decoder_tokens, self.latent_dim)
+        w["dense_W"] = glorot_uniform(rng, self.latent_dim, self.num_decoder_tokens)
+        w["dense_b"] = np.zeros(self.num_decoder_tokens, np.float32)
+        self._w = w
+        self._dw = None          # device copies, created lazily
+        self._ws = None
+        self.optimizer = None
+        self.loss = None
+        self.stop_training = False
+        self.encoder_model = _SubModel(self._encoder_predict)
+        self.decoder_model = _SubModel(self._decoder_predict)
+
+    # ---- weights (Keras order) -------------------------------------------------------------
+    def get_weights(self):
+        return [self._w[k].copy() for k in _W_ORDER]
+
+    def set_weights(self, weights):
+        weights = list(weights)
+        if len(weights) != len(_W_ORDER):
+            raise ValueError("expected %d arrays, got %d" % (len(_W_ORDER), len(weights)))
+        for k, a in zip(_W_ORDER, weights):
+            a = _as_f32(a)
+            if a.shape != self._w[k].shape:
+                raise ValueError("%s: expected shape %s, got %s" % (k, self._w[k].shape, a.shape))
+            self._w[k] = a
+        self._dw = None
+
+    def save_weights(self, path):
+        np.savez(path, **self._w)
+
+    save = save_weights
+
+    def load_weights(self, path):
+        with np.load(path) as z:
+            self.set_weights([z[k] for k in _W_ORDER])
+
+    def count_params(self):
+        return int(sum(v.size for v in self._w.values()))
+
+    # ---- device plumbing -------------------------------------------------------------------
+    def _ops(self):
+        from . import ops   # imported lazily so that host-only use does not need the .so
+        return ops
+
+    def _device_weights(self):
+        import torch
+        if self._dw is None:
+            self._dw = {k: torch.from_numpy(v).to(self.device) for k, v in self._w.items()}
+            self._ws = self._ops().Workspace()
+        return self._dw
+
+    def _dev(self, a):
+        import torch
+        return torch.from_numpy(_as_f32(a)).to(self.device)
+
+    # ---- inference -------------------------------------------------------------------------
+    def predict(self, x, batch_size=None, verbose=0):
+        """Training-graph forward: x = [encoder_input (N,T_in,F_enc), decoder_input (N,T_out,F_dec)]
+        -> (N,T_out,F_dec).  `batch_size` chunks the device calls (None = all at once)."""
+        enc, dec_in = x
+        enc, dec_in = _as_f32(enc), _as_f32(dec_in)
+        ops, dw = self._ops(), self._device_weights()
+        n = enc.shape[0]
+        bs = n if not batch_size else int(batch_size)
+        outs = []
+        for lo in range(0, n, max(bs, 1)):
+            o = ops.seq2seq_teacher_forced(self._dev(enc[lo:lo + bs]), self._dev(dec_in[lo:lo + bs]), dw,
+                                           act=self.recurrent_activation, impl=self.impl, workspace=self._ws)
+            outs.append(o.cpu().numpy())
+        self._ws.check()
+        return np.concatenate(outs, axis=0) if outs else np.zeros((0, dec_in.shape[1], self.num_decoder_tokens), np.float32)
+
+    predict_on_batch = predict
+
+    def decode_sequence(self, input_seq, first_decoder_input=None, predict_step=None, batch_size=None):
+        """Autoregressive inference (FoV_seq2seq.py:154-178, any batch): encoder, then `predict_step`
+        decoder steps feeding each Dense output back.  `first_decoder_input` (N,1,F_dec) defaults to
+        the mu/sigma^2 of the last encoder second when the encoder input is raw (N,T,90) xyz."""
+        from .utility import get_gt_target_xyz
+        input_seq = _as_f32(input_seq)
+        T_out = cfg.predict_step if predict_step is None else int(predict_step)
+        if first_decoder_input is None:
+            if input_seq.shape[-1] == self.num_decoder_tokens:
+                first_decoder_input = input_seq[:, -1:, :]
+            else:
+                first_decoder_input = get_gt_target_xyz(input_seq[:, -1:, :].astype(np.float64))
+        first_decoder_input = _as_f32(first_decoder_input)
+        ops, dw = self._ops(), self._device_weights()
+        n = input_seq.shape[0]
+        bs = n if not batch_size else int(batch_size)
+        outs = []
+        for lo in range(0, n, max(bs, 1)):
+            o = ops.seq2seq_decode(self._dev(input_seq[lo:lo + bs]), self._dev(first_decoder_input[lo:lo + bs]), dw,
+                                   T_out, act=self.recurrent_activation, impl=self.impl, workspace=self._ws)
+            outs.append(o.cpu().numpy())
+        self._ws.check()
+        return np.concatenate(outs, axis=0) if outs else np.zeros((0, T_out, self.num_decoder_tokens), np.float32)
+
+    def _encoder_predict(self, input_seq):
+        """encoder_model.predict(input_seq) -> [state_h, state_c]   (FoV_seq2seq.py:137,156)."""
+        ops, dw = self._ops(), self._device_weights()
+        _, hT, cT = ops.lstm_seq(self._dev(input_seq), dw["enc_K"], dw["enc_R"], dw["enc_b"],
+                                 act=self.recurrent_activation, impl=self.impl, return_sequences=False,
+                                 workspace=self._ws)
+        return [hT.cpu().numpy(), cT.cpu().numpy()]
+
+    def _decoder_predict(self, x):
+        """decoder_model.predict([target_seq (N,T,F_dec), h, c]) -> [outputs (N,T,F_dec), h, c]
+        (FoV_seq2seq.py:139-148,167-168)."""
+        target_seq, h, c = x
+        ops, dw = self._ops(), self._device_weights()
+        hs, hT, cT = ops.lstm_seq(self._dev(target_seq), dw["dec_K"], dw["dec_R"], dw["dec_b"], self._dev(h),
+                                  self._dev(c), act=self.recurrent_activation, impl=self.impl, workspace=self._ws)
+        y = ops.dense(hs, dw["dense_W"], dw["dense_b"], activation="tanh")
+        return [y.cpu().numpy(), hT.cpu().numpy(), cT.cpu().numpy()]
+
+    # ---- training surface ------------------------------------------------------------------
+    def compile(self, optimizer="Adam", loss="mean_squared_error", metrics=None):
+        """Keras `compile`.  Accepted: optimizer 'Adam' | 'RMSprop' (Keras defaults), loss
+        'mean_squared_error' | 'mse' (FoV_seq2seq.py:103)."""
+        opt = optimizer if isinstance(optimizer, str) else getattr(optimizer, "name", str(optimizer))
+        if opt.lower() not in ("adam", "rmsprop"):
+            raise ValueError("unsupported optimizer %r" % (optimizer,))
+        if str(loss).lower() not in ("mean_squared_error", "mse"):
+            raise ValueError("unsupported loss %r" % (loss,))
+        self.optimizer = opt.lower()
+        self.loss = "mse"
+        self.metrics = list(metrics or [])
+
+    def fit(self, x, y, batch_size=32, epochs=1, validation_split=0.0, shuffle=True, callbacks=None,
+            initial_epoch=0, verbose=0):
+        raise NotImplementedError(
+            "training (BPTT + Adam on the GPU) is the next row of DESIGN.md section 7; round 1 ships the "
+            "inference path only and there is deliberately no CPU fallback")

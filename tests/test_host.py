@@ -1,0 +1,124 @@
+"""Host-side mirror of the reference interface (no GPU): cfg knobs, data helpers against fixtures
+produced by the reference's own code, the generator, and the model object's weight handling."""
+import os
+
+import numpy as np
+import pytest
+
+from longterm360fov_amd import utility as U
+from longterm360fov_amd.config import cfg, default_config
+from longterm360fov_amd.models import Seq2SeqLSTM
+
+
+@pytest.fixture(scope="module")
+def g(golden_dir):
+    return np.load(os.path.join(golden_dir, "data_helpers.npz"))
+
+
+def _datadb(g, prefix):
+    return {v: {a: g["%s_%s_%s" % (prefix, v, a)].copy() for a in "xyz"} for v in ("v00", "v01")}
+
+
+def test_cfg_matches_reference_values(g):
+    c = default_config()
+    for name, val in zip(g["cfg_names"], g["cfg_values"]):
+        assert float(c[str(name)]) == float(val), name
+
+
+def test_clip_and_get_data_bit_exact(g):
+    db = U.clip_xyz(_datadb(g, "raw"))
+    for v in db:
+        for a in "xyz":
+            np.testing.assert_array_equal(db[v][a], g["clip_%s_%s" % (v, a)])
+    enc, fut, fut_in = U.get_data(db, pick_user=False)
+    np.testing.assert_array_equal(enc, g["enc"])
+    np.testing.assert_array_equal(fut, g["fut"])
+    np.testing.assert_array_equal(fut_in, g["fut_in"])
+    assert (enc[:, -1] == fut_in[:, 0]).all()       # the reference's own sanity check (given_others...py:315)
+    np.testing.assert_array_equal(U.get_gt_target_xyz(fut), g["gt_fut"])
+    np.testing.assert_array_equal(U.get_gt_target_xyz(fut_in), g["gt_fut_in"])
+    np.testing.assert_array_equal(U.get_gt_target_xyz(fut.reshape(12, 10, 30, 3)), g["gt_fut_4d"])
+
+
+def test_pick_user_and_others(g):
+    db = _datadb(g, "clip")
+    tar, tar_fut, tar_fut_in, oth, oth_fut, oth_fut_in = U.get_data(db, pick_user=True, num_user=3)
+    np.testing.assert_array_equal(tar, g["pu_tar"])
+    np.testing.assert_array_equal(tar_fut, g["pu_tar_fut"])
+    np.testing.assert_array_equal(oth_fut, g["pu_oth_fut"])
+    assert oth.shape == (2, 12, 10, 90) and oth_fut_in.shape == oth.shape
+    o5 = U.reshape_others_data(oth_fut)
+    assert o5.shape == (12, 10, 2, 30, 3)
+    np.testing.assert_array_equal(U.get_gt_target_xyz_oth(o5), g["gt_oth_fut"])
+    np.testing.assert_array_equal(U.slice_layer(1, 2, 3)(g["gt_oth_fut"]), g["slice_1_2_3"])
+
+
+def test_windowing_strides(g):
+    a, b, c = U.reshape2second_stacks(g["s1_in"], collapse_user=True, stride=1, purelly_testing=False)
+    np.testing.assert_array_equal(a, g["s1_enc"]); np.testing.assert_array_equal(b, g["s1_fut"])
+    np.testing.assert_array_equal(c, g["s1_fut_in"])
+    a, b, c = U.reshape2second_stacks(g["s1_in"], collapse_user=False, stride=5, purelly_testing=False)
+    np.testing.assert_array_equal(a, g["s5_enc"]); np.testing.assert_array_equal(b, g["s5_fut"])
+    np.testing.assert_array_equal(c, g["s5_fut_in"])
+    with pytest.raises(AssertionError):
+        U.reshape2second_stacks(g["s1_in"][:, :15], collapse_user=True)    # needs >= 2 x running_length seconds
+
+
+def test_others_padding_uses_np_random(g):
+    db = _datadb(g, "clip")
+    np.random.seed(3)
+    out = U.get_data(db, pick_user=True, num_user=6)     # 2 real others padded to 5 by duplication
+    assert out[3].shape == (5, 12, 10, 90)
+    for u in range(2, 5):                                 # every padded user duplicates a real one
+        for i in range(out[4].shape[1]):                  # (the duplicate is drawn per video/target)
+            assert any((out[4][u, i] == out[4][r, i]).all() for r in range(2))
+
+
+def test_generator_train2_shapes(g):
+    db = _datadb(g, "clip")
+    old = (cfg.batch_size, cfg.predict_mean_var, cfg.input_mean_var)
+    try:
+        cfg.batch_size, cfg.predict_mean_var, cfg.input_mean_var = 3, True, False
+        gen = U.generator_train2(db, phase="train", num_user=4)
+        (enc, oth, dec_in), tgt = next(gen)
+        assert enc.shape == (2, 10, 90) and oth.shape == (2, 10, 3, 90) and dec_in.shape == (2, 1, 90)
+        assert tgt.shape == (2, 10, 6)
+        cfg.input_mean_var = True
+        (enc, oth, dec_in), tgt = next(U.generator_train2(db, phase="train", num_user=4))
+        assert enc.shape == (2, 10, 6) and oth.shape == (2, 10, 3, 6) and dec_in.shape == (2, 1, 6)
+        np.testing.assert_array_equal(dec_in[:, 0], enc[:, -1])
+        (_, _, _), tgt = next(U.generator_train2(db, phase="test", num_user=4))
+        assert tgt.shape == (2, 10, 1, 30, 3)
+    finally:
+        cfg.batch_size, cfg.predict_mean_var, cfg.input_mean_var = old
+
+
+def test_model_weight_handling(tmp_path):
+    m = Seq2SeqLSTM(latent_dim=16, seed=1)
+    w = m.get_weights()
+    assert [a.shape for a in w] == [(90, 64), (16, 64), (64,), (6, 64), (16, 64), (64,), (16, 6), (6,)]
+    assert m.count_params() == 90 * 64 + 16 * 64 + 64 + 6 * 64 + 16 * 64 + 64 + 16 * 6 + 6
+    np.testing.assert_array_equal(w[2][16:32], 1.0)           # unit_forget_bias
+    np.testing.assert_allclose(w[1] @ w[1].T, np.eye(16), atol=1e-5)   # orthogonal recurrent kernel rows
+    p = str(tmp_path / "w.npz")
+    m.save_weights(p)
+    m2 = Seq2SeqLSTM(latent_dim=16, seed=2)
+    assert not np.array_equal(m2.get_weights()[0], w[0])
+    m2.load_weights(p)
+    for a, b in zip(m2.get_weights(), w):
+        np.testing.assert_array_equal(a, b)
+    with pytest.raises(ValueError):
+        m2.set_weights(w[:-1])
+    with pytest.raises(ValueError):
+        Seq2SeqLSTM(recurrent_activation="relu")
+    m.compile(optimizer="Adam", loss="mean_squared_error")
+    with pytest.raises(ValueError):
+        m.compile(optimizer="sgd")
+
+
+def test_missing_extension_fails_loudly(monkeypatch):
+    from longterm360fov_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libfov360_hip.so")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        _lib.lib()
