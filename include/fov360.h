@@ -126,6 +126,53 @@ int fov_seq2seq_tf_fwd(const float* enc_in, const float* dec_in,
  * ------------------------------------------------------------------------------------- */
 int fov_meanvar_xyz(const float* y, float* out, int64_t rows, int fps, fov_stream_t stream);
 
+/* =======================================================================================
+ * Training side (a6/a7): what `model.fit` runs under Keras - mycode/FoV_seq2seq.py:103,112-117
+ * (model.compile(optimizer='Adam', loss='mean_squared_error'); TensorFlow autodiff = BPTT).
+ * ===================================================================================== */
+
+/* fov_lstm_seq_fwd that also writes the reserve (B,T,5,H) = gates i,f,g,o and cell state c of
+ * every step, which the backward consumes. */
+int fov_lstm_seq_fwd_train(const float* x, const float* K, const float* R, const float* b,
+                           const float* h0, const float* c0, float* hs, float* hT, float* cT,
+                           float* reserve, int B, int T, int F, int H, int act, int impl,
+                           void* workspace, size_t workspace_bytes, fov_stream_t stream);
+
+/* BPTT of one LSTM layer.
+ *   in : x (B,T,F), K, R, h0/c0 (B,H) or NULL, hs (B,T,H) and reserve from the forward,
+ *        dhs (B,T,H) or NULL (gradient w.r.t. every h_t), dhT/dcT (B,H) or NULL (w.r.t. final state)
+ *   out: dz (B,T,4H) pre-activation gradients (always), dx (B,T,F) or NULL,
+ *        dK (F,4H), dR (H,4H), db (4H) (each may be NULL), dh0/dc0 (B,H) or NULL
+ *   accumulate != 0 adds into dK/dR/db instead of overwriting. */
+size_t fov_lstm_seq_bwd_workspace_bytes(int B, int T, int F, int H);
+int fov_lstm_seq_bwd(const float* x, const float* K, const float* R, const float* h0, const float* c0,
+                     const float* hs, const float* reserve,
+                     const float* dhs, const float* dhT, const float* dcT,
+                     float* dz, float* dx, float* dK, float* dR, float* db, float* dh0, float* dc0,
+                     int B, int T, int F, int H, int act, int accumulate,
+                     void* workspace, size_t workspace_bytes, fov_stream_t stream);
+
+/* Dense backward from dpre = dL/d(pre-activation) (N,Out): dW (In,Out) = x^T dpre, db = column sums,
+ * dx (N,In) = dpre W^T; each output may be NULL. */
+size_t fov_dense_bwd_workspace_bytes(int N, int In, int Out);
+int fov_dense_bwd(const float* x, const float* W, const float* dpre, float* dx, float* dW, float* db,
+                  int N, int In, int Out, int accumulate,
+                  void* workspace, size_t workspace_bytes, fov_stream_t stream);
+
+/* Keras mean_squared_error averaged over all n elements, fused with the Dense activation
+ * derivative: dpre = 2 (y - target)/n * (activation == 1 ? 1 - y^2 : 1); *loss = mean((y-target)^2)
+ * (loss may be NULL).  workspace >= 4*((n+255)/256 + 64) bytes. */
+int fov_mse_dense_grad(const float* y, const float* target, float* dpre, float* loss, int64_t n,
+                       int activation, void* workspace, size_t workspace_bytes, fov_stream_t stream);
+
+/* Keras-2.2 optimizers on one flat parameter buffer.
+ *   Adam   : lr_t = lr*sqrt(1-beta2^step)/(1-beta1^step); p -= lr_t*m/(sqrt(v)+eps)   (step >= 1)
+ *   RMSprop: a = rho*a + (1-rho) g^2; p -= lr*g/(sqrt(a)+eps) */
+int fov_adam_step(float* params, const float* grads, float* m, float* v, int64_t n,
+                  float lr, float beta1, float beta2, float eps, int64_t step, fov_stream_t stream);
+int fov_rmsprop_step(float* params, const float* grads, float* accum, int64_t n,
+                     float lr, float rho, float eps, fov_stream_t stream);
+
 /* Synchronises `stream`, reads the status word a persistent-kernel call left in `workspace`
  * and returns FOV_OK or FOV_ERR_TIMEOUT.  Workspaces of non-persistent calls report FOV_OK. */
 int fov_check_status(const void* workspace, size_t workspace_bytes, fov_stream_t stream);

@@ -39,6 +39,14 @@ SIGNATURES = {
     "fov_seq2seq_tf_workspace_bytes": (_SZ, [_I] * 7),
     "fov_seq2seq_tf_fwd": (_I, [_P] * 11 + [_I] * 8 + [_P, _SZ, _P]),
     "fov_meanvar_xyz": (_I, [_P, _P, ctypes.c_int64, _I, _P]),
+    "fov_lstm_seq_fwd_train": (_I, [_P] * 10 + [_I] * 6 + [_P, _SZ, _P]),
+    "fov_lstm_seq_bwd_workspace_bytes": (_SZ, [_I] * 4),
+    "fov_lstm_seq_bwd": (_I, [_P] * 17 + [_I] * 6 + [_P, _SZ, _P]),
+    "fov_dense_bwd_workspace_bytes": (_SZ, [_I] * 3),
+    "fov_dense_bwd": (_I, [_P] * 6 + [_I] * 4 + [_P, _SZ, _P]),
+    "fov_mse_dense_grad": (_I, [_P] * 4 + [ctypes.c_int64, _I, _P, _SZ, _P]),
+    "fov_adam_step": (_I, [_P] * 4 + [ctypes.c_int64] + [ctypes.c_float] * 4 + [ctypes.c_int64, _P]),
+    "fov_rmsprop_step": (_I, [_P] * 3 + [ctypes.c_int64] + [ctypes.c_float] * 3 + [_P]),
     "fov_check_status": (_I, [_P, _SZ, _P]),
     "fov_exchange_mode": (_I, [_P, _SZ, _P]),
 }

@@ -1,5 +1,6 @@
 // extern "C" entry points of libfov360_hip.so (declared in include/fov360.h) plus the small
 // non-recurrent kernels of the path: Dense(+tanh) and the mu/sigma^2 feature op.
+#include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
 
@@ -117,9 +118,9 @@ size_t fov_lstm_seq_workspace_bytes(int B, int T, int F, int H, int impl) {
     return want_cluster(impl, F, H, 0, false) && cluster_shape_ok(F, H) ? cluster_workspace_bytes(B, H) : kStatusBytes;
 }
 
-int fov_lstm_seq_fwd(const float* x, const float* K, const float* R, const float* b, const float* h0,
-                     const float* c0, float* hs, float* hT, float* cT, int B, int T, int F, int H, int act,
-                     int impl, void* workspace, size_t workspace_bytes, fov_stream_t stream) {
+static int lstm_seq_fwd_impl(const float* x, const float* K, const float* R, const float* b, const float* h0,
+                             const float* c0, float* hs, float* hT, float* cT, float* reserve, int B, int T, int F,
+                             int H, int act, int impl, void* workspace, size_t workspace_bytes, fov_stream_t stream) {
     if (B < 0 || T < 0 || F <= 0 || H <= 0 || !K || !R || !b || (B > 0 && T > 0 && !x) ||
         (act != FOV_ACT_SIGMOID && act != FOV_ACT_HARD_SIGMOID)) {
         set_error("fov_lstm_seq_fwd: invalid argument");
@@ -129,6 +130,7 @@ int fov_lstm_seq_fwd(const float* x, const float* K, const float* R, const float
     if (rc) return rc;
     LstmParams p = {};
     p.x = x; p.K = K; p.R = R; p.b = b; p.h0 = h0; p.c0 = c0; p.hs = hs; p.hT = hT; p.cT = cT;
+    p.reserve = reserve;
     p.B = B; p.T = T; p.F = F; p.H = H; p.act = act;
     p.status = (unsigned*)workspace;
     p.xch = (unsigned long long*)((char*)workspace + kStatusBytes);
@@ -139,6 +141,97 @@ int fov_lstm_seq_fwd(const float* x, const float* K, const float* R, const float
         if (e != hipSuccess) { set_error("hipMemsetAsync: %s", hipGetErrorString(e)); return FOV_ERR_LAUNCH; }
     }
     return launch_generic(p, false, s);
+}
+
+int fov_lstm_seq_fwd(const float* x, const float* K, const float* R, const float* b, const float* h0,
+                     const float* c0, float* hs, float* hT, float* cT, int B, int T, int F, int H, int act,
+                     int impl, void* workspace, size_t workspace_bytes, fov_stream_t stream) {
+    return lstm_seq_fwd_impl(x, K, R, b, h0, c0, hs, hT, cT, nullptr, B, T, F, H, act, impl, workspace, workspace_bytes,
+                             stream);
+}
+
+int fov_lstm_seq_fwd_train(const float* x, const float* K, const float* R, const float* b, const float* h0,
+                           const float* c0, float* hs, float* hT, float* cT, float* reserve, int B, int T, int F,
+                           int H, int act, int impl, void* workspace, size_t workspace_bytes, fov_stream_t stream) {
+    if (!reserve && B > 0 && T > 0) {
+        set_error("fov_lstm_seq_fwd_train: reserve is NULL");
+        return FOV_ERR_INVALID;
+    }
+    return lstm_seq_fwd_impl(x, K, R, b, h0, c0, hs, hT, cT, reserve, B, T, F, H, act, impl, workspace, workspace_bytes,
+                             stream);
+}
+
+size_t fov_lstm_seq_bwd_workspace_bytes(int B, int T, int F, int H) {
+    if (B <= 0 || T < 0 || F <= 0 || H <= 0) return 256;
+    return sizeof(float) * lstm_bwd_workspace_floats(B, T, F, H);
+}
+
+int fov_lstm_seq_bwd(const float* x, const float* K, const float* R, const float* h0, const float* c0,
+                     const float* hs, const float* reserve, const float* dhs, const float* dhT, const float* dcT,
+                     float* dz, float* dx, float* dK, float* dR, float* db, float* dh0, float* dc0, int B, int T,
+                     int F, int H, int act, int accumulate, void* workspace, size_t workspace_bytes,
+                     fov_stream_t stream) {
+    if (B < 0 || T < 0 || F <= 0 || H <= 0 || !K || !R ||
+        (B > 0 && T > 0 && (!x || !hs || !reserve || !dz)) ||
+        (act != FOV_ACT_SIGMOID && act != FOV_ACT_HARD_SIGMOID)) {
+        set_error("fov_lstm_seq_bwd: invalid argument");
+        return FOV_ERR_INVALID;
+    }
+    if (B == 0) return FOV_OK;
+    int rc = check_ws(workspace, workspace_bytes, fov_lstm_seq_bwd_workspace_bytes(B, T, F, H));
+    if (rc) return rc;
+    return lstm_seq_bwd(x, K, R, h0, c0, hs, reserve, dhs, dhT, dcT, dz, dx, dK, dR, db, dh0, dc0, B, T, F, H, act,
+                        accumulate, (float*)workspace, workspace_bytes / sizeof(float), (hipStream_t)stream);
+}
+
+size_t fov_dense_bwd_workspace_bytes(int N, int In, int Out) {
+    if (N <= 0 || In <= 0 || Out <= 0) return 256;
+    size_t a = (size_t)64 * In * Out, b = (size_t)256 * Out, c = (size_t)(N + 255) / 256 + 64;
+    size_t m = a > b ? a : b;
+    return sizeof(float) * ((m > c ? m : c) + 64);
+}
+
+int fov_dense_bwd(const float* x, const float* W, const float* dpre, float* dx, float* dW, float* db, int N, int In,
+                  int Out, int accumulate, void* workspace, size_t workspace_bytes, fov_stream_t stream) {
+    if (N < 0 || In <= 0 || Out <= 0 || (N > 0 && (!x || !W || !dpre))) {
+        set_error("fov_dense_bwd: invalid argument");
+        return FOV_ERR_INVALID;
+    }
+    int rc = check_ws(workspace, workspace_bytes, fov_dense_bwd_workspace_bytes(N, In, Out));
+    if (rc) return rc;
+    return dense_bwd(x, W, dpre, dx, dW, db, N, In, Out, accumulate, (float*)workspace, workspace_bytes / sizeof(float),
+                     (hipStream_t)stream);
+}
+
+int fov_mse_dense_grad(const float* y, const float* target, float* dpre, float* loss, int64_t n, int activation,
+                       void* workspace, size_t workspace_bytes, fov_stream_t stream) {
+    if (n < 0 || (n > 0 && (!y || !target || !dpre)) || (activation != 0 && activation != 1)) {
+        set_error("fov_mse_dense_grad: invalid argument");
+        return FOV_ERR_INVALID;
+    }
+    int rc = check_ws(workspace, workspace_bytes, sizeof(float) * ((size_t)(n + 255) / 256 + 64));
+    if (rc) return rc;
+    return mse_dense_grad(y, target, dpre, loss, (long)n, activation, (float*)workspace, workspace_bytes / sizeof(float),
+                          (hipStream_t)stream);
+}
+
+int fov_adam_step(float* params, const float* grads, float* m, float* v, int64_t n, float lr, float beta1,
+                  float beta2, float eps, int64_t step, fov_stream_t stream) {
+    if (n < 0 || step < 1 || (n > 0 && (!params || !grads || !m || !v))) {
+        set_error("fov_adam_step: invalid argument");
+        return FOV_ERR_INVALID;
+    }
+    const double lr_t = (double)lr * sqrt(1.0 - pow((double)beta2, (double)step)) / (1.0 - pow((double)beta1, (double)step));
+    return adam_step(params, grads, m, v, (long)n, (float)lr_t, beta1, beta2, eps, (hipStream_t)stream);
+}
+
+int fov_rmsprop_step(float* params, const float* grads, float* accum, int64_t n, float lr, float rho, float eps,
+                     fov_stream_t stream) {
+    if (n < 0 || (n > 0 && (!params || !grads || !accum))) {
+        set_error("fov_rmsprop_step: invalid argument");
+        return FOV_ERR_INVALID;
+    }
+    return rmsprop_step(params, grads, accum, (long)n, lr, rho, eps, (hipStream_t)stream);
 }
 
 int fov_dense_fwd(const float* x, const float* W, const float* b, float* y, int N, int In, int Out,

@@ -41,6 +41,7 @@ struct LstmParams {
     float* hs;
     float* hT;
     float* cT;
+    float* reserve;            // training only: (B,T,5,H) = i,f,g,o,c of every step (phase 1), or NULL
     const float* dec_in0;
     const float* dK;
     const float* dR;
@@ -67,5 +68,19 @@ int cluster_num_groups(int B, int H);
 void set_error(const char* fmt, ...);
 
 constexpr size_t kStatusBytes = 256;  // head of every workspace: status words
+
+// training side (train_kernels.hip)
+size_t lstm_bwd_workspace_floats(int B, int T, int F, int H);
+int lstm_seq_bwd(const float* x, const float* K, const float* R, const float* h0, const float* c0, const float* hs,
+                 const float* reserve, const float* dhs, const float* dhT, const float* dcT, float* dz, float* dx,
+                 float* dK, float* dR, float* db, float* dh0, float* dc0, int B, int T, int F, int H, int act,
+                 int accumulate, float* ws, size_t ws_floats, hipStream_t stream);
+int dense_bwd(const float* x, const float* W, const float* dpre, float* dx, float* dW, float* db, int N, int In, int Out,
+              int accumulate, float* scratch, size_t scratch_floats, hipStream_t stream);
+int mse_dense_grad(const float* y, const float* target, float* dpre, float* loss, long n, int activation, float* scratch,
+                   size_t scratch_floats, hipStream_t stream);
+int adam_step(float* p, const float* g, float* m, float* v, long n, float lr_t, float b1, float b2, float eps,
+              hipStream_t stream);
+int rmsprop_step(float* p, const float* g, float* a, long n, float lr, float rho, float eps, hipStream_t stream);
 
 }  // namespace fov

@@ -428,6 +428,13 @@ __global__ __launch_bounds__(256, 1) void lstm_cluster_kernel(LstmParams p) {
                 const float og = rec_act<ACT>(acc[3][r]);
                 c[r] = fmaf(fg, c[r], ig * gg);
                 hcur[r] = og * tanh_f(c[r]);
+                if (LAYER && p.reserve) {   // training forward: gates and cell state for BPTT
+                    const int row = b0 + 4 * g4 + r;
+                    if (row < p.B) {
+                        float* rp = p.reserve + (((size_t)row * p.T + t) * 5) * H + col0 + n;
+                        rp[0] = ig; rp[H] = fg; rp[2 * H] = gg; rp[3 * H] = og; rp[4 * H] = c[r];
+                    }
+                }
             }
             unsigned xsoff = 0;
             if (G > 1) {

@@ -15,7 +15,8 @@ __device__ __forceinline__ void generic_step(const float* __restrict__ sx, int l
                                              const float* __restrict__ K, const float* __restrict__ R,
                                              const float* __restrict__ b, int H,
                                              const float* __restrict__ sh_prev, float* __restrict__ sh_next,
-                                             float* __restrict__ sc) {
+                                             float* __restrict__ sc, float* __restrict__ reserve = nullptr,
+                                             size_t res_stride = 0, int rows = 0) {
     const int H4 = 4 * H;
     for (int j = threadIdx.x; j < H; j += blockDim.x) {
         float acc[GB][4];
@@ -56,6 +57,10 @@ __device__ __forceinline__ void generic_step(const float* __restrict__ sx, int l
             const float c = fmaf(f, sc[s * H + j], i * g);
             sc[s * H + j] = c;
             sh_next[s * H + j] = o * tanh_f(c);
+            if (reserve && s < rows) {
+                float* rp = reserve + (size_t)s * res_stride + j;
+                rp[0] = i; rp[H] = f; rp[2 * H] = g; rp[3 * H] = o; rp[4 * H] = c;
+            }
         }
     }
 }
@@ -85,7 +90,8 @@ __global__ __launch_bounds__(256) void lstm_generic_kernel(LstmParams p) {
             sh_x[s * ldx + k] = (s < rows) ? p.x[((size_t)(b0 + s) * p.T + t) * p.F + k] : 0.f;
         }
         __syncthreads();
-        generic_step<ACT>(sh_x, ldx, p.F, p.K, p.R, p.b, H, sh_h + cur * GB * H, sh_h + (cur ^ 1) * GB * H, sh_c);
+        generic_step<ACT>(sh_x, ldx, p.F, p.K, p.R, p.b, H, sh_h + cur * GB * H, sh_h + (cur ^ 1) * GB * H, sh_c,
+                          p.reserve ? p.reserve + (((size_t)b0 * p.T + t) * 5) * H : nullptr, (size_t)p.T * 5 * H, rows);
         __syncthreads();
         cur ^= 1;
         if (p.hs) {

@@ -1,0 +1,440 @@
+// Training-side kernels of the hot path (a6: BPTT + Keras optimizers; mycode/FoV_seq2seq.py:103,
+// 112-117 delegate all of it to Keras/TensorFlow autodiff).  Round-1 structure: the backward
+// recurrence is stepped from the host (one pointwise launch + one MFMA GEMM launch per time
+// step); the weight gradients are large split-K MFMA GEMMs over B*T.  Everything is
+// deterministic (no float atomics): split-K partials are summed in a fixed order.
+//
+// Kernels and the roofline that bounds each:
+//   gemm_f32_kernel       fp32 MFMA (v_mfma_f32_16x16x4_f32), LDS-tiled 64x64x16     - MFMA
+//   splitk_reduce_kernel  sums S partial C tiles                                     - HBM
+//   lstm_bwd_pointwise    dz_t, dc from the reserve (24 B read + 16 B written/elem)   - HBM
+//   colsum_*              bias gradients                                             - HBM
+//   mse_dense_grad_kernel dL/d(pre-tanh) of the Dense head + loss partials           - HBM
+//   adam_kernel / rmsprop_kernel  flat-buffer optimizer step (16-28 B per parameter) - HBM
+#include "fov_common.h"
+
+namespace fov {
+
+// ---------------------------------------------------------------------------------------
+// C[m][n] = sum_k A(m,k) * B(k,n);  k = ko*KI + ki.
+//   A(m,k) = a[m*a_sm + ko*a_sko + ki*a_ski],  B(k,n) = b[n*b_sn + ko*b_sko + ki*b_ski]
+// The two-level k lets (batch, time) row pairs with a time shift be contracted without copies
+// (dR = sum_{b,t} h_{t-1}^T dz_t).  blockIdx.z = split-K slice; slice s writes C + s*M*N when
+// `split` > 1 (partials), else C directly.
+// ---------------------------------------------------------------------------------------
+struct GemmArgs {
+    const float* a;
+    const float* b;
+    float* c;
+    int M, N, KO, KI;
+    long a_sm, a_sko, a_ski;
+    long b_sn, b_sko, b_ski;
+    int ldc;
+    int split;       // number of K slices (grid.z)
+    int k_per_split; // multiple of 16
+};
+
+constexpr int GBM = 64, GBN = 64, GBK = 16, GLD = GBM + 4;
+
+__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) float As[GBK][GLD];
+    __shared__ __attribute__((aligned(16))) float Bs[GBK][GLD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.y * GBM, n0 = blockIdx.x * GBN;
+    const int K = g.KO * g.KI;
+    const int kbeg = blockIdx.z * g.k_per_split;
+    int kend = kbeg + g.k_per_split;
+    if (kend > K) kend = K;
+    const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+    const int li = lane & 15, lq = lane >> 4;
+
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // staging: element e = tid + 256*r of the 64x16 tile.  If k is the contiguous index in memory,
+    // consecutive threads walk k (16-wide rows), else they walk m / n.
+    const bool a_kfast = (g.a_ski == 1), b_kfast = (g.b_ski == 1);
+    for (int k0 = kbeg; k0 < kend; k0 += GBK) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int e = tid + 256 * r;
+            int mm, kk;
+            if (a_kfast) { mm = e >> 4; kk = e & 15; } else { kk = e >> 6; mm = e & 63; }
+            const int k = k0 + kk, m = m0 + mm;
+            float v = 0.f;
+            if (m < g.M && k < kend) {
+                const int ko = k / g.KI, ki = k - ko * g.KI;
+                v = g.a[(long)m * g.a_sm + (long)ko * g.a_sko + (long)ki * g.a_ski];
+            }
+            As[kk][mm] = v;
+            int nn, kb;
+            if (b_kfast) { nn = e >> 4; kb = e & 15; } else { kb = e >> 6; nn = e & 63; }
+            const int k2 = k0 + kb, n = n0 + nn;
+            float u = 0.f;
+            if (n < g.N && k2 < kend) {
+                const int ko = k2 / g.KI, ki = k2 - ko * g.KI;
+                u = g.b[(long)n * g.b_sn + (long)ko * g.b_sko + (long)ki * g.b_ski];
+            }
+            Bs[kb][nn] = u;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            float av[2], bv[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) av[i] = As[ks * 4 + lq][wm + i * 16 + li];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bv[j] = Bs[ks * 4 + lq][wn + j * 16 + li];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    float* c = g.c + (g.split > 1 ? (size_t)blockIdx.z * g.M * g.ldc : 0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + wm + i * 16 + lq * 4 + r, n = n0 + wn + j * 16 + li;
+                if (m < g.M && n < g.N) c[(size_t)m * g.ldc + n] = acc[i][j][r];
+            }
+}
+
+// out[i] = (accumulate ? out[i] : 0) + sum_s part[s][i]
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, float* __restrict__ out,
+                                                            long n, int S, int accumulate) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float s = accumulate ? out[i] : 0.f;
+    for (int k = 0; k < S; ++k) s += part[(size_t)k * n + i];
+    out[i] = s;
+}
+
+// ---------------------------------------------------------------------------------------
+// BPTT pointwise step t (Keras LSTMCell backward):
+//   dh = dhs[:,t] + dh_rec;  tc = tanh(c_t);  do = dh*tc;  dc += dh*o*(1-tc^2)
+//   dz = [dc*g*s'(i), dc*c_{t-1}*s'(f), dc*i*(1-g^2), do*s'(o)];  dc *= f
+// s'(a) = a(1-a) (sigmoid) or 0.2*[0<a<1] (hard_sigmoid).  dh_rec / dc live in (B,H) buffers.
+// ---------------------------------------------------------------------------------------
+template <int ACT>
+__device__ __forceinline__ float rec_act_grad(float a) {
+    return ACT == FOV_ACT_HARD_SIGMOID ? ((a > 0.f && a < 1.f) ? 0.2f : 0.f) : a * (1.f - a);
+}
+
+template <int ACT>
+__global__ __launch_bounds__(256) void lstm_bwd_pointwise(const float* __restrict__ reserve, const float* __restrict__ c0,
+                                                          const float* __restrict__ dhs, const float* __restrict__ dh_rec,
+                                                          float* __restrict__ dc, float* __restrict__ dz, int B, int T,
+                                                          int H, int t) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)B * H) return;
+    const int b = (int)(idx / H), j = (int)(idx - (long)b * H);
+    const float* rp = reserve + (((size_t)b * T + t) * 5) * H + j;
+    const float i = rp[0], f = rp[H], g = rp[2 * H], o = rp[3 * H], c = rp[4 * H];
+    const float cprev = (t > 0) ? rp[4 * H - 5 * (long)H] : (c0 ? c0[idx] : 0.f);
+    float dh = dh_rec[idx];
+    if (dhs) dh += dhs[((size_t)b * T + t) * H + j];
+    const float tc = tanh_f(c);
+    const float dov = dh * tc;
+    const float dcv = dc[idx] + dh * o * (1.f - tc * tc);
+    float* zp = dz + ((size_t)b * T + t) * 4 * H + j;
+    zp[0] = dcv * g * rec_act_grad<ACT>(i);
+    zp[H] = dcv * cprev * rec_act_grad<ACT>(f);
+    zp[2 * H] = dcv * i * (1.f - g * g);
+    zp[3 * H] = dov * rec_act_grad<ACT>(o);
+    dc[idx] = dcv * f;
+}
+
+// partial column sums: block (x = column block of 256, y = row chunk) -> part[y][col]
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ x, float* __restrict__ part,
+                                                             long rows, int cols, long rows_per_chunk) {
+    const int col = blockIdx.x * 256 + threadIdx.x;
+    if (col >= cols) return;
+    const long r0 = (long)blockIdx.y * rows_per_chunk;
+    long r1 = r0 + rows_per_chunk;
+    if (r1 > rows) r1 = rows;
+    float s = 0.f;
+    for (long r = r0; r < r1; ++r) s += x[(size_t)r * cols + col];
+    part[(size_t)blockIdx.y * cols + col] = s;
+}
+
+// Dense(tanh|linear) + Keras mean_squared_error: dpre = 2 (y - target) / n * act'(y); per-block
+// partial sums of (y - target)^2 into loss_part[blockIdx.x].
+__global__ __launch_bounds__(256) void mse_dense_grad_kernel(const float* __restrict__ y, const float* __restrict__ target,
+                                                             float* __restrict__ dpre, float* __restrict__ loss_part,
+                                                             long n, float scale, int activation) {
+    __shared__ float red[4];
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    float sq = 0.f;
+    if (i < n) {
+        const float yv = y[i], d = yv - target[i];
+        sq = d * d;
+        float gsc = 2.f * d * scale;
+        if (activation == 1) gsc *= (1.f - yv * yv);
+        dpre[i] = gsc;
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) sq += __shfl_xor(sq, m);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sq;
+    __syncthreads();
+    if (threadIdx.x == 0) loss_part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(256) void sum_scale_kernel(const float* __restrict__ part, float* __restrict__ out, int n,
+                                                        float scale) {
+    __shared__ float red[256];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) s += part[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int m = 128; m >= 1; m >>= 1) {
+        if (threadIdx.x < m) red[threadIdx.x] += red[threadIdx.x + m];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = red[0] * scale;
+}
+
+// Keras-2.2 optimizers on one flat buffer (oracle/fov_oracle.py::adam_step / rmsprop_step)
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, long n, float lr_t, float b1, float b2, float eps) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float gi = g[i];
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    p[i] = p[i] - lr_t * mi / (sqrtf(vi) + eps);
+}
+
+__global__ __launch_bounds__(256) void rmsprop_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ a,
+                                                      long n, float lr, float rho, float eps) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float gi = g[i];
+    const float ai = rho * a[i] + (1.f - rho) * gi * gi;
+    a[i] = ai;
+    p[i] = p[i] - lr * gi / (sqrtf(ai) + eps);
+}
+
+// ---------------------------------------------------------------------------------------
+// host helpers
+// ---------------------------------------------------------------------------------------
+static int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_error("%s launch: %s", what, hipGetErrorString(e)); return FOV_ERR_LAUNCH; }
+    return FOV_OK;
+}
+
+// C (+)= A.B.  Few output tiles and a long K -> split-K: slices write partial tiles into
+// `scratch` ([split][M][N]) and a fixed-order reduce adds them (deterministic, no atomics).
+int gemm_f32(GemmArgs g, int accumulate, float* scratch, size_t scratch_floats, hipStream_t stream) {
+    if (g.M <= 0 || g.N <= 0) return FOV_OK;
+    const long K = (long)g.KO * g.KI;
+    if (K <= 0) {
+        if (!accumulate) (void)hipMemsetAsync(g.c, 0, sizeof(float) * (size_t)g.M * g.ldc, stream);
+        return FOV_OK;
+    }
+    const size_t mn = (size_t)g.M * g.N;
+    const int tiles = ((g.M + GBM - 1) / GBM) * ((g.N + GBN - 1) / GBN);
+    int split = 1;
+    if (tiles < 256 && K >= 512) {
+        split = (512 + tiles - 1) / tiles;
+        const long maxs = K / 256;
+        if (split > maxs) split = (int)maxs;
+        if (split > 64) split = 64;
+        if (split < 1) split = 1;
+    }
+    while (split > 1 && (size_t)split * mn > scratch_floats) --split;
+    long kps = (K + split - 1) / split;
+    kps = (kps + GBK - 1) / GBK * GBK;
+    split = (int)((K + kps - 1) / kps);
+    const bool via_scratch = (split > 1) || accumulate;
+    float* c_final = g.c;
+    if (via_scratch) {
+        if (mn * split > scratch_floats) { set_error("gemm_f32: scratch too small (%zu floats needed)", mn * split); return FOV_ERR_WORKSPACE; }
+        if (g.ldc != g.N) { set_error("gemm_f32: accumulate/split-K needs a dense C (ldc == N)"); return FOV_ERR_INVALID; }
+        g.c = scratch;
+    }
+    g.split = split;
+    g.k_per_split = (int)kps;
+    const dim3 grid((g.N + GBN - 1) / GBN, (g.M + GBM - 1) / GBM, split);
+    hipLaunchKernelGGL(gemm_f32_kernel, grid, dim3(256), 0, stream, g);
+    int rc = check_launch("gemm_f32");
+    if (rc || !via_scratch) return rc;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((mn + 255) / 256)), dim3(256), 0, stream, scratch, c_final, (long)mn,
+                       split, accumulate);
+    return check_launch("splitk_reduce");
+}
+
+int colsum(const float* x, float* out, long rows, int cols, int accumulate, float* scratch, size_t scratch_floats,
+           hipStream_t stream) {
+    if (cols <= 0) return FOV_OK;
+    int chunks = (int)((rows + 511) / 512);
+    if (chunks < 1) chunks = 1;
+    if (chunks > 256) chunks = 256;
+    if ((size_t)chunks * cols > scratch_floats) { set_error("colsum: scratch too small"); return FOV_ERR_WORKSPACE; }
+    const long rpc = (rows + chunks - 1) / chunks;
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3((cols + 255) / 256, chunks), dim3(256), 0, stream, x, scratch, rows, cols,
+                       rpc > 0 ? rpc : 1);
+    int rc = check_launch("colsum_partial");
+    if (rc) return rc;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((cols + 255) / 256), dim3(256), 0, stream, scratch, out, (long)cols, chunks,
+                       accumulate);
+    return check_launch("colsum_reduce");
+}
+
+size_t lstm_bwd_workspace_floats(int B, int T, int F, int H) {
+    // dh_rec (B,H) + dc (B,H) + split-K scratch for the largest weight-gradient GEMM / colsum
+    size_t wg = (size_t)64 * (size_t)(F > H ? F : H) * 4 * H;   // split-K partials of dK / dR
+    size_t cs = (size_t)256 * 4 * H;                             // colsum partials
+    size_t st = (size_t)8 * B * H;                               // split-K partials of the per-step dh GEMM
+    size_t m = wg > cs ? wg : cs;
+    (void)T;
+    return (size_t)2 * B * H + (m > st ? m : st) + 64;
+}
+
+// BPTT of one layer.  dz:(B,T,4H) is an output (kept: the caller may need it for dx of the layer
+// below).  dK,dR,db are overwritten (accumulate = 0) or added to (accumulate = 1).
+int lstm_seq_bwd(const float* x, const float* K, const float* R, const float* h0, const float* c0, const float* hs,
+                 const float* reserve, const float* dhs, const float* dhT, const float* dcT, float* dz, float* dx,
+                 float* dK, float* dR, float* db, float* dh0, float* dc0, int B, int T, int F, int H, int act,
+                 int accumulate, float* ws, size_t ws_floats, hipStream_t stream) {
+    if (ws_floats < lstm_bwd_workspace_floats(B, T, F, H)) { set_error("lstm_seq_bwd: workspace too small"); return FOV_ERR_WORKSPACE; }
+    float* dh_rec = ws;
+    float* dc = ws + (size_t)B * H;
+    float* scratch = ws + (size_t)2 * B * H;
+    const size_t scratch_floats = ws_floats - (size_t)2 * B * H;
+    const size_t bh = sizeof(float) * (size_t)B * H;
+    hipError_t e;
+    e = dhT ? hipMemcpyAsync(dh_rec, dhT, bh, hipMemcpyDeviceToDevice, stream) : hipMemsetAsync(dh_rec, 0, bh, stream);
+    if (e == hipSuccess) e = dcT ? hipMemcpyAsync(dc, dcT, bh, hipMemcpyDeviceToDevice, stream) : hipMemsetAsync(dc, 0, bh, stream);
+    if (e != hipSuccess) { set_error("lstm_seq_bwd init: %s", hipGetErrorString(e)); return FOV_ERR_LAUNCH; }
+    const long nelem = (long)B * H;
+    const dim3 pgrid((unsigned)((nelem + 255) / 256));
+    for (int t = T - 1; t >= 0; --t) {
+        if (act == FOV_ACT_HARD_SIGMOID)
+            hipLaunchKernelGGL(lstm_bwd_pointwise<FOV_ACT_HARD_SIGMOID>, pgrid, dim3(256), 0, stream, reserve, c0, dhs, dh_rec,
+                               dc, dz, B, T, H, t);
+        else
+            hipLaunchKernelGGL(lstm_bwd_pointwise<FOV_ACT_SIGMOID>, pgrid, dim3(256), 0, stream, reserve, c0, dhs, dh_rec, dc,
+                               dz, B, T, H, t);
+        int rc = check_launch("lstm_bwd_pointwise");
+        if (rc) return rc;
+        // dh_rec (B,H) = dz_t (B,4H) . R^T :  A(m,k) = dz[m][t][k], B(k,n) = R[n][k]
+        GemmArgs g = {};
+        g.a = dz + (size_t)t * 4 * H; g.b = R; g.c = dh_rec;
+        g.M = B; g.N = H; g.KO = 1; g.KI = 4 * H;
+        g.a_sm = (long)T * 4 * H; g.a_sko = 0; g.a_ski = 1;
+        g.b_sn = 4 * H; g.b_sko = 0; g.b_ski = 1;
+        g.ldc = H;
+        rc = gemm_f32(g, 0, scratch, scratch_floats, stream);
+        if (rc) return rc;
+    }
+    if (dh0) { e = hipMemcpyAsync(dh0, dh_rec, bh, hipMemcpyDeviceToDevice, stream); if (e != hipSuccess) { set_error("dh0 copy"); return FOV_ERR_LAUNCH; } }
+    if (dc0) { e = hipMemcpyAsync(dc0, dc, bh, hipMemcpyDeviceToDevice, stream); if (e != hipSuccess) { set_error("dc0 copy"); return FOV_ERR_LAUNCH; } }
+    int rc;
+    const long BT = (long)B * T;
+    if (dK) {   // dK (F,4H) = x^T dz : A(m=f,k=(b,t)) = x[k][f], B(k,n) = dz[k][n]
+        GemmArgs g = {};
+        g.a = x; g.b = dz; g.c = dK; g.M = F; g.N = 4 * H; g.KO = 1; g.KI = (int)BT;
+        g.a_sm = 1; g.a_ski = F; g.b_sn = 1; g.b_ski = 4 * H; g.ldc = 4 * H;
+        rc = gemm_f32(g, accumulate, scratch, scratch_floats, stream);
+        if (rc) return rc;
+    }
+    if (dR) {   // dR (H,4H) = sum_b sum_{t>=1} hs[b][t-1]^T dz[b][t]  +  h0^T dz[:,0]
+        GemmArgs g = {};
+        g.a = hs; g.b = dz + (size_t)4 * H; g.c = dR; g.M = H; g.N = 4 * H; g.KO = B; g.KI = T - 1;
+        g.a_sm = 1; g.a_sko = (long)T * H; g.a_ski = H;
+        g.b_sn = 1; g.b_sko = (long)T * 4 * H; g.b_ski = 4 * H; g.ldc = 4 * H;
+        if (T > 1) {
+            rc = gemm_f32(g, accumulate, scratch, scratch_floats, stream);
+            if (rc) return rc;
+        } else if (!accumulate) {
+            (void)hipMemsetAsync(dR, 0, sizeof(float) * (size_t)H * 4 * H, stream);
+        }
+        if (h0 && T > 0) {
+            GemmArgs g0 = {};
+            g0.a = h0; g0.b = dz; g0.c = dR; g0.M = H; g0.N = 4 * H; g0.KO = 1; g0.KI = B;
+            g0.a_sm = 1; g0.a_ski = H; g0.b_sn = 1; g0.b_ski = (long)T * 4 * H; g0.ldc = 4 * H;
+            rc = gemm_f32(g0, 1, scratch, scratch_floats, stream);
+            if (rc) return rc;
+        }
+    }
+    if (db) {
+        rc = colsum(dz, db, BT, 4 * H, accumulate, scratch, scratch_floats, stream);
+        if (rc) return rc;
+    }
+    if (dx) {   // dx (B*T,F) = dz . K^T : A(m,k) = dz[m][k], B(k,n) = K[n][k]
+        GemmArgs g = {};
+        g.a = dz; g.b = K; g.c = dx; g.M = (int)BT; g.N = F; g.KO = 1; g.KI = 4 * H;
+        g.a_sm = 4 * H; g.a_ski = 1; g.b_sn = 4 * H; g.b_ski = 1; g.ldc = F;
+        rc = gemm_f32(g, 0, scratch, scratch_floats, stream);
+        if (rc) return rc;
+    }
+    return FOV_OK;
+}
+
+// Dense backward given dpre (N,Out): dW (In,Out) = x^T dpre, db = colsum(dpre), dx (N,In) = dpre W^T
+int dense_bwd(const float* x, const float* W, const float* dpre, float* dx, float* dW, float* db, int N, int In, int Out,
+              int accumulate, float* scratch, size_t scratch_floats, hipStream_t stream) {
+    int rc;
+    if (dW) {
+        GemmArgs g = {};
+        g.a = x; g.b = dpre; g.c = dW; g.M = In; g.N = Out; g.KO = 1; g.KI = N;
+        g.a_sm = 1; g.a_ski = In; g.b_sn = 1; g.b_ski = Out; g.ldc = Out;
+        rc = gemm_f32(g, accumulate, scratch, scratch_floats, stream);
+        if (rc) return rc;
+    }
+    if (db) {
+        rc = colsum(dpre, db, N, Out, accumulate, scratch, scratch_floats, stream);
+        if (rc) return rc;
+    }
+    if (dx) {
+        GemmArgs g = {};
+        g.a = dpre; g.b = W; g.c = dx; g.M = N; g.N = In; g.KO = 1; g.KI = Out;
+        g.a_sm = Out; g.a_ski = 1; g.b_sn = Out; g.b_ski = 1; g.ldc = In;
+        rc = gemm_f32(g, 0, scratch, scratch_floats, stream);
+        if (rc) return rc;
+    }
+    return FOV_OK;
+}
+
+int mse_dense_grad(const float* y, const float* target, float* dpre, float* loss, long n, int activation, float* scratch,
+                   size_t scratch_floats, hipStream_t stream) {
+    if (n <= 0) return FOV_OK;
+    const long blocks = (n + 255) / 256;
+    if ((size_t)blocks > scratch_floats) { set_error("mse_dense_grad: scratch too small"); return FOV_ERR_WORKSPACE; }
+    hipLaunchKernelGGL(mse_dense_grad_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, y, target, dpre, scratch, n,
+                       1.0f / (float)n, activation);
+    int rc = check_launch("mse_dense_grad");
+    if (rc) return rc;
+    if (loss) {
+        hipLaunchKernelGGL(sum_scale_kernel, dim3(1), dim3(256), 0, stream, scratch, loss, (int)blocks, 1.0f / (float)n);
+        rc = check_launch("sum_scale");
+    }
+    return rc;
+}
+
+int adam_step(float* p, const float* g, float* m, float* v, long n, float lr_t, float b1, float b2, float eps,
+              hipStream_t stream) {
+    if (n <= 0) return FOV_OK;
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, p, g, m, v, n, lr_t, b1, b2, eps);
+    return check_launch("adam");
+}
+
+int rmsprop_step(float* p, const float* g, float* a, long n, float lr, float rho, float eps, hipStream_t stream) {
+    if (n <= 0) return FOV_OK;
+    hipLaunchKernelGGL(rmsprop_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, p, g, a, n, lr, rho, eps);
+    return check_launch("rmsprop");
+}
+
+}  // namespace fov

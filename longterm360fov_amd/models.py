@@ -72,6 +72,8 @@ class Seq2SeqLSTM:
         self._ws = None
         self.optimizer = None
         self.loss = None
+        self._trainer = None
+        self._lr = 1e-3
         self.stop_training = False
         self.encoder_model = _SubModel(self._encoder_predict)
         self.decoder_model = _SubModel(self._decoder_predict)
@@ -90,6 +92,7 @@ class Seq2SeqLSTM:
                 raise ValueError("%s: expected shape %s, got %s" % (k, self._w[k].shape, a.shape))
             self._w[k] = a
         self._dw = None
+        self._trainer = None     # optimizer state belongs to the previous weights
 
     def save_weights(self, path):
         np.savez(path, **self._w)
@@ -193,8 +196,95 @@ class Seq2SeqLSTM:
         self.loss = "mse"
         self.metrics = list(metrics or [])
 
+    @property
+    def lr(self):
+        return self._lr
+
+    @lr.setter
+    def lr(self, value):
+        self._lr = float(value)
+        if getattr(self, "_trainer", None) is not None:
+            self._trainer.lr = self._lr
+
     def fit(self, x, y, batch_size=32, epochs=1, validation_split=0.0, shuffle=True, callbacks=None,
-            initial_epoch=0, verbose=0):
-        raise NotImplementedError(
-            "training (BPTT + Adam on the GPU) is the next row of DESIGN.md section 7; round 1 ships the "
-            "inference path only and there is deliberately no CPU fallback")
+            initial_epoch=0, verbose=0, validation_data=None):
+        """Keras `Model.fit` semantics (FoV_seq2seq.py:112-117): the LAST `validation_split` fraction is
+        held out BEFORE shuffling; train indices are permuted every epoch (np.random); the last
+        partial batch is used; callbacks see {'loss','val_loss','lr'} per epoch.  Under
+        torch.distributed every rank takes its contiguous shard of each global batch and gradients
+        are combined with one all-reduce per step.  Returns a History."""
+        import torch
+        from . import parallel
+        from .callbacks import History
+        from .training import Seq2SeqTrainer
+        if self.optimizer is None:
+            raise RuntimeError("call compile() before fit()")
+        enc, dec_in = _as_f32(x[0]), _as_f32(x[1])
+        tgt = _as_f32(y)
+        n = enc.shape[0]
+        if validation_data is not None:
+            (venc, vdec), vtgt = validation_data
+            venc, vdec, vtgt = _as_f32(venc), _as_f32(vdec), _as_f32(vtgt)
+            n_train = n
+        elif validation_split and 0.0 < validation_split < 1.0:
+            n_train = int(n * (1.0 - validation_split))
+            venc, vdec, vtgt = enc[n_train:], dec_in[n_train:], tgt[n_train:]
+        else:
+            n_train, venc = n, None
+        if getattr(self, "_trainer", None) is None:
+            self._trainer = Seq2SeqTrainer(self._w, act=self.recurrent_activation, impl=self.impl,
+                                           optimizer=self.optimizer, lr=getattr(self, "_lr", 1e-3), device=self.device)
+            self._lr = self._trainer.lr
+        tr = self._trainer
+        hist = History()
+        cbs = [hist] + list(callbacks or [])
+        for cb in cbs:
+            cb.set_model(self)
+            cb.on_train_begin()
+        self.stop_training = False
+        rank, world = parallel.world()
+        d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
+        for epoch in range(initial_epoch, epochs):
+            idx = np.arange(n_train)
+            if shuffle:
+                np.random.shuffle(idx)
+            tot, cnt = 0.0, 0
+            for lo in range(0, n_train, batch_size):
+                gidx = idx[lo:lo + batch_size]
+                a, b = parallel.shard_range(len(gidx), rank, world)
+                lidx = gidx[a:b]
+                loss = tr.train_step(d(enc[lidx]), d(dec_in[lidx]), d(tgt[lidx]), n_global=len(gidx))
+                tot += float(loss.item()) * len(gidx)
+                cnt += len(gidx)
+            logs = {"loss": tot / max(cnt, 1), "lr": tr.lr}
+            if venc is not None and len(venc):
+                vt, vc = 0.0, 0
+                for lo in range(0, len(venc), max(batch_size, 1)):
+                    sl = slice(lo, lo + batch_size)
+                    vt += float(tr.eval_loss(d(venc[sl]), d(vdec[sl]), d(vtgt[sl])).item()) * len(venc[sl])
+                    vc += len(venc[sl])
+                logs["val_loss"] = vt / vc
+            self._w = tr.weights_numpy()
+            self._dw = None
+            for cb in cbs:
+                cb.on_epoch_end(epoch, logs)
+            if self.stop_training:
+                break
+        for cb in cbs:
+            cb.on_train_end()
+        tr.ws.check()
+        return hist
+
+    def train_on_batch(self, x, y):
+        import torch
+        from .training import Seq2SeqTrainer
+        if getattr(self, "_trainer", None) is None:
+            self._trainer = Seq2SeqTrainer(self._w, act=self.recurrent_activation, impl=self.impl,
+                                           optimizer=self.optimizer or "adam", lr=getattr(self, "_lr", 1e-3),
+                                           device=self.device)
+            self._lr = self._trainer.lr
+        d = lambda a: torch.from_numpy(_as_f32(a)).to(self.device)
+        loss = self._trainer.train_step(d(x[0]), d(x[1]), d(y))
+        self._w = self._trainer.weights_numpy()
+        self._dw = None
+        return float(loss.item())

@@ -159,3 +159,108 @@ def meanvar_xyz(y, fps=30):
     out = torch.empty((*lead, 6), dtype=torch.float32, device=y.device)
     check(_lib.lib().fov_meanvar_xyz(_ptr(y), _ptr(out), rows, fps, _stream()))
     return out
+
+
+# ---------------------------------------------------------------------------------------------
+# training side (a6): forward with reserve, BPTT, Dense backward, MSE gradient, optimizers
+# ---------------------------------------------------------------------------------------------
+def lstm_seq_train(x, K, R, b, h0=None, c0=None, act="sigmoid", impl="auto", workspace=None, out=None):
+    """Forward that also returns the reserve (B,T,5,H).  `out` may carry preallocated
+    (hs, hT, cT, reserve) tensors.  -> (hs, hT, cT, reserve)."""
+    x, K, R, b = _dev(x, "x"), _dev(K, "K"), _dev(R, "R"), _dev(b, "b")
+    h0, c0 = _dev(h0, "h0"), _dev(c0, "c0")
+    B, T, F = x.shape
+    H = R.shape[0]
+    if out is None:
+        e = lambda *s: torch.empty(s, dtype=torch.float32, device=x.device)
+        out = (e(B, T, H), e(B, H), e(B, H), e(B, T, 5, H))
+    hs, hT, cT, res = out
+    L = _lib.lib()
+    impl = impl_code(impl)
+    ws = (workspace or default_workspace(x.device))
+    buf = ws.get(L.fov_lstm_seq_workspace_bytes(B, T, F, H, impl), x.device)
+    check(L.fov_lstm_seq_fwd_train(_ptr(x), _ptr(K), _ptr(R), _ptr(b), _ptr(h0), _ptr(c0), _ptr(hs), _ptr(hT),
+                                   _ptr(cT), _ptr(res), B, T, F, H, act_code(act), impl, buf.data_ptr(),
+                                   buf.numel(), _stream()))
+    return hs, hT, cT, res
+
+
+class Scratch:
+    """Second caller-owned buffer for the training kernels (split-K partials, dh/dc carries)."""
+
+    def __init__(self):
+        self.buf = None
+
+    def get(self, nbytes, device):
+        nbytes = max(int(nbytes), 256)
+        if self.buf is None or self.buf.numel() < nbytes or self.buf.device != device:
+            self.buf = torch.empty(nbytes + 256, dtype=torch.uint8, device=device)
+        return self.buf
+
+
+_default_scratch = Scratch()
+
+
+def lstm_seq_bwd(x, K, R, hs, reserve, h0=None, c0=None, dhs=None, dhT=None, dcT=None, dK=None, dR=None, db=None,
+                 need_dx=False, need_state_grads=False, act="sigmoid", accumulate=False, dz=None, scratch=None):
+    """BPTT of one layer -> dict(dz, dx, dK, dR, db, dh0, dc0)."""
+    x, K, R, hs, reserve = _dev(x, "x"), _dev(K, "K"), _dev(R, "R"), _dev(hs, "hs"), _dev(reserve, "reserve")
+    B, T, F = x.shape
+    H = R.shape[0]
+    e = lambda *s: torch.empty(s, dtype=torch.float32, device=x.device)
+    dz = e(B, T, 4 * H) if dz is None else dz
+    dK = e(F, 4 * H) if dK is None else dK
+    dR = e(H, 4 * H) if dR is None else dR
+    db = e(4 * H) if db is None else db
+    dx = e(B, T, F) if need_dx else None
+    dh0 = e(B, H) if need_state_grads else None
+    dc0 = e(B, H) if need_state_grads else None
+    L = _lib.lib()
+    buf = (scratch or _default_scratch).get(L.fov_lstm_seq_bwd_workspace_bytes(B, T, F, H), x.device)
+    check(L.fov_lstm_seq_bwd(_ptr(x), _ptr(K), _ptr(R), _ptr(_dev(h0, "h0")), _ptr(_dev(c0, "c0")), _ptr(hs),
+                             _ptr(reserve), _ptr(_dev(dhs, "dhs")), _ptr(_dev(dhT, "dhT")), _ptr(_dev(dcT, "dcT")),
+                             _ptr(dz), _ptr(dx), _ptr(dK), _ptr(dR), _ptr(db), _ptr(dh0), _ptr(dc0),
+                             B, T, F, H, act_code(act), 1 if accumulate else 0, buf.data_ptr(), buf.numel(), _stream()))
+    return {"dz": dz, "dx": dx, "dK": dK, "dR": dR, "db": db, "dh0": dh0, "dc0": dc0}
+
+
+def dense_bwd(x, W, dpre, dW=None, db=None, need_dx=True, accumulate=False, scratch=None):
+    x, W, dpre = _dev(x, "x"), _dev(W, "W"), _dev(dpre, "dpre")
+    In, Out = W.shape
+    x2, d2 = x.reshape(-1, In), dpre.reshape(-1, Out)
+    N = x2.shape[0]
+    e = lambda *s: torch.empty(s, dtype=torch.float32, device=x.device)
+    dW = e(In, Out) if dW is None else dW
+    db = e(Out) if db is None else db
+    dx = e(N, In) if need_dx else None
+    L = _lib.lib()
+    buf = (scratch or _default_scratch).get(L.fov_dense_bwd_workspace_bytes(N, In, Out), x.device)
+    check(L.fov_dense_bwd(_ptr(x2), _ptr(W), _ptr(d2), _ptr(dx), _ptr(dW), _ptr(db), N, In, Out,
+                          1 if accumulate else 0, buf.data_ptr(), buf.numel(), _stream()))
+    return (dx.reshape(*x.shape[:-1], In) if need_dx else None), dW, db
+
+
+def mse_dense_grad(y, target, activation="tanh", scratch=None, dpre=None, loss=None):
+    """Keras mean_squared_error + Dense activation derivative -> (dpre like y, loss scalar tensor)."""
+    y, target = _dev(y, "y"), _dev(target, "target")
+    assert y.shape == target.shape
+    n = y.numel()
+    dpre = torch.empty_like(y) if dpre is None else dpre
+    loss = torch.zeros(1, dtype=torch.float32, device=y.device) if loss is None else loss
+    buf = (scratch or _default_scratch).get(4 * ((n + 255) // 256 + 64), y.device)
+    check(_lib.lib().fov_mse_dense_grad(_ptr(y), _ptr(target), _ptr(dpre), _ptr(loss), n,
+                                        1 if activation == "tanh" else 0, buf.data_ptr(), buf.numel(), _stream()))
+    return dpre, loss
+
+
+def adam_step(params, grads, m, v, step, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-7):
+    for t in (params, grads, m, v):
+        _dev(t, "flat buffer")
+    check(_lib.lib().fov_adam_step(_ptr(params), _ptr(grads), _ptr(m), _ptr(v), params.numel(), lr, beta1, beta2,
+                                   eps, int(step), _stream()))
+
+
+def rmsprop_step(params, grads, accum, lr=1e-3, rho=0.9, eps=1e-7):
+    for t in (params, grads, accum):
+        _dev(t, "flat buffer")
+    check(_lib.lib().fov_rmsprop_step(_ptr(params), _ptr(grads), _ptr(accum), params.numel(), lr, rho, eps, _stream()))

@@ -256,3 +256,99 @@ def synthetic_batch(seed, B, T_in, T_out, num_others=0, fps=30, dtype=np.float32
         oth = synthetic_xyz(rng, B * num_others, T_out, fps, np.float64).reshape(B, num_others, T_out, fps, 3)
         out.append(meanvar_xyz_oth(oth.transpose(0, 2, 1, 3, 4)).astype(dtype))
     return tuple(out)
+
+
+# --------------------------------------------------------------------------------------
+# a6: training-graph backward (BPTT) and the Keras optimizers
+# model.compile(optimizer='Adam', loss='mean_squared_error') - mycode/FoV_seq2seq.py:103
+# The arithmetic is Keras/TensorFlow autodiff in the reference; this is the closed-form
+# restatement, checked against torch.autograd and finite differences in tests/test_oracle.py.
+# --------------------------------------------------------------------------------------
+def _rec_act_grad(a, act):
+    """d s(z)/dz expressed through the activation value a = s(z)."""
+    if act_code(act) == ACT_HARD_SIGMOID:
+        return np.where((a > 0) & (a < 1), a.dtype.type(0.2), a.dtype.type(0))
+    return a * (1 - a)
+
+
+def lstm_layer_train(x, K, R, b, h0=None, c0=None, act="sigmoid"):
+    """Forward that also returns the reserve (i,f,g,o,c per step) the backward needs."""
+    B, T, _ = x.shape
+    H = R.shape[0]
+    h = np.zeros((B, H), x.dtype) if h0 is None else h0.astype(x.dtype)
+    c = np.zeros((B, H), x.dtype) if c0 is None else c0.astype(x.dtype)
+    s = _rec_act(act)
+    hs = np.empty((B, T, H), x.dtype)
+    res = np.empty((B, T, 5, H), x.dtype)
+    for t in range(T):
+        z = x[:, t] @ K + b + h @ R
+        i, f, g, o = s(z[:, :H]), s(z[:, H:2 * H]), np.tanh(z[:, 2 * H:3 * H]), s(z[:, 3 * H:])
+        c = f * c + i * g
+        h = o * np.tanh(c)
+        hs[:, t] = h
+        res[:, t, 0], res[:, t, 1], res[:, t, 2], res[:, t, 3], res[:, t, 4] = i, f, g, o, c
+    return hs, h, c, res
+
+
+def lstm_layer_backward(x, K, R, h0, c0, hs, res, dhs=None, dhT=None, dcT=None, act="sigmoid"):
+    """BPTT of one LSTM layer.  Returns dict(dx, dK, dR, db, dh0, dc0, dz)."""
+    B, T, F = x.shape
+    H = R.shape[0]
+    dt = x.dtype
+    h0 = np.zeros((B, H), dt) if h0 is None else h0
+    c0 = np.zeros((B, H), dt) if c0 is None else c0
+    dh = np.zeros((B, H), dt) if dhT is None else dhT.astype(dt).copy()
+    dc = np.zeros((B, H), dt) if dcT is None else dcT.astype(dt).copy()
+    dz_all = np.empty((B, T, 4 * H), dt)
+    for t in range(T - 1, -1, -1):
+        i, f, g, o, c = (res[:, t, q] for q in range(5))
+        c_prev = res[:, t - 1, 4] if t > 0 else c0
+        if dhs is not None:
+            dh = dh + dhs[:, t]
+        tc = np.tanh(c)
+        do = dh * tc
+        dc = dc + dh * o * (1 - tc * tc)
+        dz = np.concatenate([dc * g * _rec_act_grad(i, act), dc * c_prev * _rec_act_grad(f, act),
+                             dc * i * (1 - g * g), do * _rec_act_grad(o, act)], axis=1)
+        dz_all[:, t] = dz
+        dc = dc * f
+        dh = dz @ R.T
+    hprev = np.concatenate([h0[:, None], hs[:, :-1]], axis=1)
+    dz2 = dz_all.reshape(B * T, 4 * H)
+    return {"dx": (dz2 @ K.T).reshape(B, T, F), "dK": x.reshape(B * T, F).T @ dz2,
+            "dR": hprev.reshape(B * T, H).T @ dz2, "db": dz2.sum(axis=0), "dh0": dh, "dc0": dc, "dz": dz_all}
+
+
+def seq2seq_loss_and_grads(enc_in, dec_in, target, w, act="sigmoid"):
+    """Teacher-forced graph (FoV_seq2seq.py:82-103): loss = Keras mean_squared_error averaged over
+    every sample and step; returns (loss, grads dict keyed like the weights, prediction)."""
+    ehs, eh, ec, eres = lstm_layer_train(enc_in, w["enc_K"], w["enc_R"], w["enc_b"], act=act)
+    dhs_, _, _, dres = lstm_layer_train(dec_in, w["dec_K"], w["dec_R"], w["dec_b"], eh, ec, act=act)
+    B, T, H = dhs_.shape
+    y = np.tanh(dhs_.reshape(B * T, H) @ w["dense_W"] + w["dense_b"])
+    t2 = target.reshape(B * T, -1)
+    loss = float(np.mean((y - t2) ** 2))
+    dy = 2 * (y - t2) / y.size
+    dpre = dy * (1 - y * y)
+    g = {"dense_W": dhs_.reshape(B * T, H).T @ dpre, "dense_b": dpre.sum(axis=0)}
+    d_dec_hs = (dpre @ w["dense_W"].T).reshape(B, T, H)
+    bd = lstm_layer_backward(dec_in, w["dec_K"], w["dec_R"], eh, ec, dhs_, dres, dhs=d_dec_hs, act=act)
+    g["dec_K"], g["dec_R"], g["dec_b"] = bd["dK"], bd["dR"], bd["db"]
+    be = lstm_layer_backward(enc_in, w["enc_K"], w["enc_R"], None, None, ehs, eres, dhT=bd["dh0"], dcT=bd["dc0"], act=act)
+    g["enc_K"], g["enc_R"], g["enc_b"] = be["dK"], be["dR"], be["db"]
+    return loss, g, y.reshape(B, T, -1)
+
+
+def adam_step(p, g, m, v, t, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-7):
+    """Keras-2.2 Adam.get_updates: lr_t = lr*sqrt(1-b2^t)/(1-b1^t); p -= lr_t * m / (sqrt(v) + eps).
+    `t` is the 1-based step count.  In place on (p, m, v)."""
+    lr_t = lr * np.sqrt(1 - beta2 ** t) / (1 - beta1 ** t)
+    m[...] = beta1 * m + (1 - beta1) * g
+    v[...] = beta2 * v + (1 - beta2) * g * g
+    p[...] = p - lr_t * m / (np.sqrt(v) + eps)
+
+
+def rmsprop_step(p, g, a, lr=1e-3, rho=0.9, eps=1e-7):
+    """Keras-2.2 RMSprop: a = rho*a + (1-rho)*g^2; p -= lr * g / (sqrt(a) + eps).  In place."""
+    a[...] = rho * a + (1 - rho) * g * g
+    p[...] = p - lr * g / (np.sqrt(a) + eps)

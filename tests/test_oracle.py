@@ -115,3 +115,69 @@ def test_lstm_golden_vectors(golden_dir):
     wm = {k[3:]: g[k] for k in g.files if k.startswith("wm_")}
     out = O.others_mixing_forward(g["enc"], g["oth"], g["dec0"], wm, 0)
     np.testing.assert_allclose(out, g["mix_act0"], atol=5e-6)
+
+
+def test_bptt_matches_torch_autograd():
+    """Closed-form BPTT of the oracle vs torch.autograd on the same teacher-forced graph (fp64)."""
+    H, B, T_in, T_out = 12, 4, 5, 3
+    w = {k: v.astype(np.float64) for k, v in O.init_seq2seq(31, H=H, bias_noise=0.2).items()}
+    enc, dec0, tgt = O.synthetic_batch(32, B, T_in, T_out, dtype=np.float64)
+    dec_in = np.concatenate([dec0, tgt[:, :-1]], axis=1)
+    loss, g, y = O.seq2seq_loss_and_grads(enc, dec_in, tgt, w)
+    tw = {k: torch.tensor(v, requires_grad=True) for k, v in w.items()}
+
+    def layer(x, K, R, b, h, c):
+        hs = []
+        for t in range(x.shape[1]):
+            z = x[:, t] @ K + b + h @ R
+            i, f, gg, o = torch.sigmoid(z[:, :H]), torch.sigmoid(z[:, H:2 * H]), torch.tanh(z[:, 2 * H:3 * H]), torch.sigmoid(z[:, 3 * H:])
+            c = f * c + i * gg
+            h = o * torch.tanh(c)
+            hs.append(h)
+        return torch.stack(hs, 1), h, c
+
+    z0 = torch.zeros(B, H, dtype=torch.float64)
+    _, h, c = layer(torch.tensor(enc), tw["enc_K"], tw["enc_R"], tw["enc_b"], z0, z0)
+    hs, _, _ = layer(torch.tensor(dec_in), tw["dec_K"], tw["dec_R"], tw["dec_b"], h, c)
+    ty = torch.tanh(hs @ tw["dense_W"] + tw["dense_b"])
+    tl = torch.mean((ty - torch.tensor(tgt)) ** 2)
+    tl.backward()
+    assert abs(float(tl) - loss) < 1e-14
+    np.testing.assert_allclose(y, ty.detach().numpy(), atol=1e-13)
+    for k in w:
+        np.testing.assert_allclose(g[k], tw[k].grad.numpy(), atol=1e-13, err_msg=k)
+
+
+def test_bptt_hard_sigmoid_finite_differences():
+    H, B = 6, 3
+    w = {k: v.astype(np.float64) for k, v in O.init_seq2seq(41, H=H, bias_noise=0.3).items()}
+    enc, dec0, tgt = O.synthetic_batch(42, B, 4, 3, dtype=np.float64)
+    dec_in = np.concatenate([dec0, tgt[:, :-1]], axis=1)
+    loss, g, _ = O.seq2seq_loss_and_grads(enc, dec_in, tgt, w, "hard_sigmoid")
+    rng = np.random.default_rng(0)
+    for k in w:
+        for _ in range(4):
+            idx = tuple(rng.integers(0, s) for s in w[k].shape)
+            wp = {a: b.copy() for a, b in w.items()}; wp[k][idx] += 1e-6
+            wm = {a: b.copy() for a, b in w.items()}; wm[k][idx] -= 1e-6
+            fd = (O.seq2seq_loss_and_grads(enc, dec_in, tgt, wp, "hard_sigmoid")[0] -
+                  O.seq2seq_loss_and_grads(enc, dec_in, tgt, wm, "hard_sigmoid")[0]) / 2e-6
+            assert abs(fd - g[k][idx]) < 1e-7 + 1e-5 * abs(fd), (k, idx, fd, g[k][idx])
+
+
+def test_adam_matches_torch_with_keras_epsilon_placement():
+    """Keras applies eps OUTSIDE the bias-corrected sqrt: p -= lr_t*m/(sqrt(v)+eps).  torch.optim.Adam
+    uses eps/sqrt(1-b2^t) scaling differently, so compare against the formula, and against torch for a
+    case where eps is negligible."""
+    rng = np.random.default_rng(1)
+    p = rng.standard_normal(50); g = rng.standard_normal(50)
+    m = np.zeros(50); v = np.zeros(50)
+    tp = torch.tensor(p.copy(), requires_grad=True)
+    opt = torch.optim.Adam([tp], lr=1e-3, betas=(0.9, 0.999), eps=1e-30)
+    for t in range(1, 4):
+        O.adam_step(p, g, m, v, t, eps=1e-30)
+        tp.grad = torch.tensor(g.copy()); opt.step()
+    np.testing.assert_allclose(p, tp.detach().numpy(), atol=1e-12)
+    a = np.zeros(50); q = rng.standard_normal(50); q0 = q.copy()
+    O.rmsprop_step(q, g, a)
+    np.testing.assert_allclose(q, q0 - 1e-3 * g / (np.sqrt(0.1 * g * g) + 1e-7), atol=1e-15)
