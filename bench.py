@@ -48,6 +48,55 @@ def event_time_ms(fn, iters):
     return start.elapsed_time(stop) / iters
 
 
+def bench_train(args, rank, world, use_dist):
+    """Secondary measurement: training throughput of the same model/shape (not the BASELINE metric)."""
+    import torch.distributed as dist
+    from longterm360fov_amd.training import Seq2SeqTrainer
+    from oracle import fov_oracle as O
+    B, T_in, T_out, H = args.batch, args.t_in, args.t_out, args.hidden
+    w = O.init_seq2seq(1234, 90, 6, H, bias_noise=0.05)
+    enc, dec0, tgt = O.synthetic_batch(1234 + rank, B, T_in, T_out)
+    dec_in = np.concatenate([dec0, tgt[:, :-1]], axis=1)
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    d_enc, d_dec, d_tgt = d(enc), d(dec_in), d(tgt)
+    tr = Seq2SeqTrainer(w, act=args.act, impl=args.impl)
+    for _ in range(args.warmup):
+        tr.train_step(d_enc, d_dec, d_tgt, n_global=B * world)
+    torch.cuda.synchronize()
+    if use_dist:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = tr.train_step(d_enc, d_dec, d_tgt, n_global=B * world)
+    torch.cuda.synchronize()
+    if use_dist:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if use_dist:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    tr.ws.check()
+    if rank == 0:
+        f_enc, f_dec = flops_per_seq(T_in, T_out, 90, 6, H)
+        flop_step = 3 * (f_enc + f_dec) * B      # training step counted as 3x forward (SURVEY 8(d))
+        ms = elapsed / args.steps * 1e3
+        print(json.dumps({
+            "metric": "training sequences/sec (batch=%d per GPU, T_in=%d->T_out=%d, h=%d)" % (B, T_in, T_out, H),
+            "value": world * B * args.steps / elapsed, "unit": "sequences/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic", "final_loss": float(loss.item()),
+            "config": {"workload": "teacher-forced training step of configs[1] shape (fwd + BPTT + Keras Adam), fp32",
+                       "global_batch": B * world, "parallelism": "dp%d, one flat-buffer all-reduce per step" % world},
+            "roofline": {"bound": "mfma", "achieved": flop_step / (ms * 1e-3) / 1e12, "peak": PEAK_FP32_MFMA_TFLOPS,
+                         "unit": "TFLOP/s", "frac": flop_step / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                         "note": "whole step, 3x forward FLOPs"},
+            "cpu_baseline": None}), flush=True)
+    if use_dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -60,6 +109,9 @@ def main():
     ap.add_argument("--impl", default="auto", choices=["auto", "cluster", "generic"])
     ap.add_argument("--act", default="sigmoid", choices=["sigmoid", "hard_sigmoid"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", default="infer", choices=["infer", "train"],
+                    help="infer (default, the BASELINE metric): encoder + autoregressive decoder; train: one "
+                         "teacher-forced training step (fwd + BPTT + Adam, data-parallel all-reduce when N > 1)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -74,6 +126,8 @@ def main():
 
     from longterm360fov_amd import ops
     from oracle import fov_oracle as O   # synthetic data + Keras initialisers (test infrastructure)
+    if args.mode == "train":
+        return bench_train(args, rank, world, use_dist)
 
     B, T_in, T_out, H = args.batch, args.t_in, args.t_out, args.hidden
     F_enc, F_dec = 90, 6

@@ -5,7 +5,7 @@
 // deterministic (no float atomics): split-K partials are summed in a fixed order.
 //
 // Kernels and the roofline that bounds each:
-//   gemm_f32_kernel       fp32 MFMA (v_mfma_f32_16x16x4_f32), LDS-tiled 64x64x16     - MFMA
+//   gemm_f32_kernel       fp32 MFMA (v_mfma_f32_16x16x4_f32), LDS-tiled 128x128x16   - MFMA
 //   splitk_reduce_kernel  sums S partial C tiles                                     - HBM
 //   lstm_bwd_pointwise    dz_t, dc from the reserve (24 B read + 16 B written/elem)   - HBM
 //   colsum_*              bias gradients                                             - HBM
@@ -34,73 +34,100 @@ struct GemmArgs {
     int k_per_split; // multiple of 16
 };
 
-constexpr int GBM = 64, GBN = 64, GBK = 16, GLD = GBM + 4;
+constexpr int GBM = 128, GBN = 128, GBK = 16, GLD = GBM + 4;
 
+// 128x128x16 block tile, 4 waves as 2x2, each wave 64x64 = 4x4 MFMA tiles (64 accumulator
+// registers); LDS tiles are k-major ([k][m], [k][n]) so a fragment read is 16 consecutive floats
+// per k and every k-step costs 8 LDS reads for 16 MFMAs.  Global->LDS staging goes through
+// registers one k-tile ahead (loads of tile k+1 are issued before the MFMAs of tile k).
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
-    __shared__ __attribute__((aligned(16))) float As[GBK][GLD];
-    __shared__ __attribute__((aligned(16))) float Bs[GBK][GLD];
+    __shared__ __attribute__((aligned(16))) float As[2][GBK][GLD];
+    __shared__ __attribute__((aligned(16))) float Bs[2][GBK][GLD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m0 = blockIdx.y * GBM, n0 = blockIdx.x * GBN;
     const int K = g.KO * g.KI;
     const int kbeg = blockIdx.z * g.k_per_split;
     int kend = kbeg + g.k_per_split;
     if (kend > K) kend = K;
-    const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
     const int li = lane & 15, lq = lane >> 4;
 
-    f32x4 acc[2][2];
+    f32x4 acc[4][4];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // staging: element e = tid + 256*r of the 64x16 tile.  If k is the contiguous index in memory,
-    // consecutive threads walk k (16-wide rows), else they walk m / n.
+    // staging: element e = tid + 256*r (r < 8) of a 128x16 tile.  If k is the contiguous index in
+    // memory consecutive threads walk k (16-wide rows), else they walk m / n.
     const bool a_kfast = (g.a_ski == 1), b_kfast = (g.b_ski == 1);
-    for (int k0 = kbeg; k0 < kend; k0 += GBK) {
+    float ra[8], rb[8];
+    auto fetch = [&](int k0) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
+        for (int r = 0; r < 8; ++r) {
             const int e = tid + 256 * r;
             int mm, kk;
-            if (a_kfast) { mm = e >> 4; kk = e & 15; } else { kk = e >> 6; mm = e & 63; }
+            if (a_kfast) { mm = e >> 4; kk = e & 15; } else { kk = e >> 7; mm = e & 127; }
             const int k = k0 + kk, m = m0 + mm;
             float v = 0.f;
             if (m < g.M && k < kend) {
                 const int ko = k / g.KI, ki = k - ko * g.KI;
                 v = g.a[(long)m * g.a_sm + (long)ko * g.a_sko + (long)ki * g.a_ski];
             }
-            As[kk][mm] = v;
+            ra[r] = v;
             int nn, kb;
-            if (b_kfast) { nn = e >> 4; kb = e & 15; } else { kb = e >> 6; nn = e & 63; }
+            if (b_kfast) { nn = e >> 4; kb = e & 15; } else { kb = e >> 7; nn = e & 127; }
             const int k2 = k0 + kb, n = n0 + nn;
             float u = 0.f;
             if (n < g.N && k2 < kend) {
                 const int ko = k2 / g.KI, ki = k2 - ko * g.KI;
                 u = g.b[(long)n * g.b_sn + (long)ko * g.b_sko + (long)ki * g.b_ski];
             }
-            Bs[kb][nn] = u;
+            rb[r] = u;
         }
-        __syncthreads();
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int e = tid + 256 * r;
+            int mm, kk, nn, kb;
+            if (a_kfast) { mm = e >> 4; kk = e & 15; } else { kk = e >> 7; mm = e & 127; }
+            if (b_kfast) { nn = e >> 4; kb = e & 15; } else { kb = e >> 7; nn = e & 127; }
+            As[buf][kk][mm] = ra[r];
+            Bs[buf][kb][nn] = rb[r];
+        }
+    };
+    int buf = 0;
+    if (kbeg < kend) {
+        fetch(kbeg);
+        stash(0);
+    }
+    __syncthreads();
+    for (int k0 = kbeg; k0 < kend; k0 += GBK) {
+        const bool more = (k0 + GBK < kend);
+        if (more) fetch(k0 + GBK);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            float av[2], bv[2];
+            float av[4], bv[4];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) av[i] = As[ks * 4 + lq][wm + i * 16 + li];
+            for (int i = 0; i < 4; ++i) av[i] = As[buf][ks * 4 + lq][wm + i * 16 + li];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) bv[j] = Bs[ks * 4 + lq][wn + j * 16 + li];
+            for (int j = 0; j < 4; ++j) bv[j] = Bs[buf][ks * 4 + lq][wn + j * 16 + li];
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < 4; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[j], acc[i][j], 0, 0, 0);
         }
+        if (more) stash(buf ^ 1);
         __syncthreads();
+        buf ^= 1;
     }
     float* c = g.c + (g.split > 1 ? (size_t)blockIdx.z * g.M * g.ldc : 0);
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int m = m0 + wm + i * 16 + lq * 4 + r, n = n0 + wn + j * 16 + li;
@@ -294,7 +321,7 @@ int colsum(const float* x, float* out, long rows, int cols, int accumulate, floa
 
 size_t lstm_bwd_workspace_floats(int B, int T, int F, int H) {
     // dh_rec (B,H) + dc (B,H) + split-K scratch for the largest weight-gradient GEMM / colsum
-    size_t wg = (size_t)64 * (size_t)(F > H ? F : H) * 4 * H;   // split-K partials of dK / dR
+    size_t wg = (size_t)64 * (size_t)(F > H ? F : H) * 4 * H;   // split-K partials of dK / dR (<= 64 slices)
     size_t cs = (size_t)256 * 4 * H;                             // colsum partials
     size_t st = (size_t)8 * B * H;                               // split-K partials of the per-step dh GEMM
     size_t m = wg > cs ? wg : cs;

@@ -159,3 +159,51 @@ def test_model_object_sampling_models_match_fused_decode():
     ref = O.seq2seq_decode(enc.astype(np.float64), target_seq * 0 + get_gt_target_xyz(enc[:, -1:, :].astype(np.float64)),
                            f64(w), cfg.predict_step)
     np.testing.assert_allclose(fused, ref, atol=2e-5)
+
+
+def _dp_worker(rank, world_size, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world_size)   # one GPU on the box: gloo carries the CUDA buffers
+    try:
+        from longterm360fov_amd import parallel
+        from longterm360fov_amd.training import Seq2SeqTrainer
+        w = O.init_seq2seq(123, H=64, bias_noise=0.05)
+        enc, dec_in, tgt = batch(124, 37, 6, 5)
+        lo, hi = parallel.shard_range(37)
+        tr = Seq2SeqTrainer(w)
+        losses = [float(tr.train_step(dev(enc[lo:hi]), dev(dec_in[lo:hi]), dev(tgt[lo:hi]), n_global=37).item())
+                  for _ in range(3)]
+        q.put((rank, losses, tr.flat.detach().cpu().numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_data_parallel_two_ranks_equal_single_process():
+    """2 ranks (gloo, both on the one GPU of the box), unequal shards 19/18, three Adam steps:
+    losses and parameters equal the single-process run on the whole batch."""
+    import socket
+    import torch.multiprocessing as mp
+    from longterm360fov_amd.training import Seq2SeqTrainer
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    w = O.init_seq2seq(123, H=64, bias_noise=0.05)
+    enc, dec_in, tgt = batch(124, 37, 6, 5)
+    tr = Seq2SeqTrainer(w)
+    ref_losses = [float(tr.train_step(dev(enc), dev(dec_in), dev(tgt)).item()) for _ in range(3)]
+    ref_flat = tr.flat.detach().cpu().numpy()
+    for rank, losses, flat in res:
+        np.testing.assert_allclose(losses, ref_losses, rtol=1e-5)
+        d = np.abs(flat - ref_flat)
+        assert d.max() <= 3e-3 and np.mean(d <= 2e-5) >= 0.995, (rank, d.max(), np.mean(d <= 2e-5))
+    np.testing.assert_array_equal(res[0][2], res[1][2])     # replicas stay bit-identical
