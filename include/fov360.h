@@ -80,6 +80,28 @@ int fov_lstm_seq_fwd(const float* x, const float* K, const float* R, const float
 int fov_dense_fwd(const float* x, const float* W, const float* b, float* y,
                   int N, int In, int Out, int activation, fov_stream_t stream);
 
+/* y = act(x W + b + add[row*add_row_stride + :]) - Dense with an additive per-row term, used to fold the
+ * precomputed "others" part of the mixing layer into the decoder step:
+ *   replaces: Concatenate(axis=1)([others_t, pred]) -> Flatten -> Dense(6,'tanh')
+ *             (mycode/given_others_gt_mean_var_seq2seq.py:257-265), with W = mix_W[-6:], add = others_t . mix_W[:-6]. */
+int fov_dense_add_fwd(const float* x, const float* W, const float* b, const float* add, int64_t add_row_stride,
+                      float* y, int N, int In, int Out, int activation, fov_stream_t stream);
+
+/* C (M,N) = A (M,K) . B (K,N), row-major dense fp32 (keras.backend.dot on 2-D operands).  The
+ * workspace is optional (NULL allowed): with it, short-and-wide products use split-K. */
+size_t fov_matmul_workspace_bytes(int M, int K, int N);
+int fov_matmul(const float* a, const float* b, float* c, int M, int K, int N,
+               void* workspace, size_t workspace_bytes, fov_stream_t stream);
+
+/* LSTM layer whose input projection zx = x.K (B,T,4H) was computed by the caller (fov_matmul): the
+ * form stacked layers use - given_others...py:111-112 (encoder2 over encoder1's sequence) and
+ * :217 (decoder_lstm2) - because an (H,4H) input kernel does not fit beside the recurrent one.
+ * Bias b is added inside.  Other arguments as fov_lstm_seq_fwd_train (reserve may be NULL). */
+int fov_lstm_seq_fwd_zx(const float* zx, const float* R, const float* b, const float* h0, const float* c0,
+                        float* hs, float* hT, float* cT, float* reserve,
+                        int B, int T, int H, int act, int impl,
+                        void* workspace, size_t workspace_bytes, fov_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------
  * Fused inference path: encoder LSTM over T_in steps from zero state, then T_out
  * autoregressive decoder steps, each = LSTM step + Dense(F_dec,'tanh') + feedback, all on

@@ -34,6 +34,10 @@ SIGNATURES = {
     "fov_lstm_seq_workspace_bytes": (_SZ, [_I, _I, _I, _I, _I]),
     "fov_lstm_seq_fwd": (_I, [_P] * 9 + [_I] * 6 + [_P, _SZ, _P]),
     "fov_dense_fwd": (_I, [_P] * 4 + [_I] * 4 + [_P]),
+    "fov_dense_add_fwd": (_I, [_P] * 4 + [ctypes.c_int64, _P] + [_I] * 4 + [_P]),
+    "fov_matmul_workspace_bytes": (_SZ, [_I] * 3),
+    "fov_matmul": (_I, [_P] * 3 + [_I] * 3 + [_P, _SZ, _P]),
+    "fov_lstm_seq_fwd_zx": (_I, [_P] * 9 + [_I] * 5 + [_P, _SZ, _P]),
     "fov_seq2seq_decode_workspace_bytes": (_SZ, [_I] * 7),
     "fov_seq2seq_decode_fwd": (_I, [_P] * 13 + [_I] * 8 + [_P, _SZ, _P]),
     "fov_seq2seq_tf_workspace_bytes": (_SZ, [_I] * 7),

@@ -25,7 +25,8 @@ void set_error(const char* fmt, ...) {
 constexpr int DENSE_MAX_OUT = 16;
 
 __global__ __launch_bounds__(256) void dense_kernel(const float* __restrict__ x, const float* __restrict__ W,
-                                                    const float* __restrict__ b, float* __restrict__ y,
+                                                    const float* __restrict__ b, const float* __restrict__ add,
+                                                    long add_stride, float* __restrict__ y,
                                                     int N, int In, int Out, int activation) {
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -52,6 +53,7 @@ __global__ __launch_bounds__(256) void dense_kernel(const float* __restrict__ x,
         for (int o = 0; o < DENSE_MAX_OUT; ++o) mine = (lane == o) ? acc[o] : mine;
         if (lane < no) {
             float v = mine + (b ? b[o0 + lane] : 0.f);
+            if (add) v += add[(size_t)row * add_stride + o0 + lane];
             if (activation == 1) v = tanh_f(v);
             y[(size_t)row * Out + o0 + lane] = v;
         }
@@ -161,6 +163,30 @@ int fov_lstm_seq_fwd_train(const float* x, const float* K, const float* R, const
                              stream);
 }
 
+int fov_lstm_seq_fwd_zx(const float* zx, const float* R, const float* b, const float* h0, const float* c0, float* hs,
+                        float* hT, float* cT, float* reserve, int B, int T, int H, int act, int impl, void* workspace,
+                        size_t workspace_bytes, fov_stream_t stream) {
+    if (B < 0 || T < 0 || H <= 0 || !R || !b || (B > 0 && T > 0 && !zx) ||
+        (act != FOV_ACT_SIGMOID && act != FOV_ACT_HARD_SIGMOID)) {
+        set_error("fov_lstm_seq_fwd_zx: invalid argument");
+        return FOV_ERR_INVALID;
+    }
+    int rc = check_ws(workspace, workspace_bytes, fov_lstm_seq_workspace_bytes(B, T, 1, H, impl));
+    if (rc) return rc;
+    LstmParams p = {};
+    p.zx = zx; p.R = R; p.b = b; p.h0 = h0; p.c0 = c0; p.hs = hs; p.hT = hT; p.cT = cT; p.reserve = reserve;
+    p.B = B; p.T = T; p.F = 1; p.H = H; p.act = act;
+    p.status = (unsigned*)workspace;
+    p.xch = (unsigned long long*)((char*)workspace + kStatusBytes);
+    hipStream_t s = (hipStream_t)stream;
+    if (want_cluster(impl, 1, H, 0, false)) return launch_cluster(p, false, s);
+    if (B > 0) {
+        hipError_t e = hipMemsetAsync(workspace, 0, kStatusBytes, s);
+        if (e != hipSuccess) { set_error("hipMemsetAsync: %s", hipGetErrorString(e)); return FOV_ERR_LAUNCH; }
+    }
+    return launch_generic(p, false, s);
+}
+
 size_t fov_lstm_seq_bwd_workspace_bytes(int B, int T, int F, int H) {
     if (B <= 0 || T < 0 || F <= 0 || H <= 0) return 256;
     return sizeof(float) * lstm_bwd_workspace_floats(B, T, F, H);
@@ -241,10 +267,43 @@ int fov_dense_fwd(const float* x, const float* W, const float* b, float* y, int 
         return FOV_ERR_INVALID;
     }
     if (N == 0) return FOV_OK;
-    hipLaunchKernelGGL(dense_kernel, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, W, b, y, N, In, Out, activation);
+    hipLaunchKernelGGL(dense_kernel, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, W, b, (const float*)nullptr,
+                       0L, y, N, In, Out, activation);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("dense launch: %s", hipGetErrorString(e)); return FOV_ERR_LAUNCH; }
     return FOV_OK;
+}
+
+int fov_dense_add_fwd(const float* x, const float* W, const float* b, const float* add, int64_t add_row_stride,
+                      float* y, int N, int In, int Out, int activation, fov_stream_t stream) {
+    if (N < 0 || In <= 0 || Out <= 0 || !W || (N > 0 && (!x || !y || !add)) || (activation != 0 && activation != 1)) {
+        set_error("fov_dense_add_fwd: invalid argument");
+        return FOV_ERR_INVALID;
+    }
+    if (N == 0) return FOV_OK;
+    hipLaunchKernelGGL(dense_kernel, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, W, b, add, (long)add_row_stride,
+                       y, N, In, Out, activation);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_error("dense launch: %s", hipGetErrorString(e)); return FOV_ERR_LAUNCH; }
+    return FOV_OK;
+}
+
+size_t fov_matmul_workspace_bytes(int M, int K, int N) {
+    (void)K;
+    if (M <= 0 || N <= 0) return 256;
+    size_t part = (size_t)64 * M * N;
+    if (part > ((size_t)64 << 20)) part = (size_t)64 << 20;   // split-K partials are optional: cap at 256 MB
+    return sizeof(float) * (part + 64);
+}
+
+int fov_matmul(const float* a, const float* b, float* c, int M, int K, int N, void* workspace, size_t workspace_bytes,
+               fov_stream_t stream) {
+    if (M < 0 || K < 0 || N < 0 || (M > 0 && N > 0 && (!c || (K > 0 && (!a || !b))))) {
+        set_error("fov_matmul: invalid argument");
+        return FOV_ERR_INVALID;
+    }
+    if (workspace && (((uintptr_t)workspace) & 15)) { set_error("workspace must be 16-byte aligned"); return FOV_ERR_WORKSPACE; }
+    return matmul_f32(a, b, c, M, K, N, (float*)workspace, workspace ? workspace_bytes / sizeof(float) : 0, (hipStream_t)stream);
 }
 
 size_t fov_seq2seq_decode_workspace_bytes(int B, int T_in, int T_out, int F_enc, int F_dec, int H, int impl) {

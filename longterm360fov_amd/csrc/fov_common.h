@@ -33,6 +33,7 @@ __device__ __forceinline__ float rec_act(float x) {
 // steps with weights dK,dR,db fed by y_{t-1} = tanh(h W + bias), y_{-1} = dec_in0.
 struct LstmParams {
     const float* x;
+    const float* zx;           // optional (B,T,4H): precomputed x.K (stacked layers); then x/K are unused, b is still added
     const float* K;
     const float* R;
     const float* b;
@@ -79,6 +80,8 @@ int dense_bwd(const float* x, const float* W, const float* dpre, float* dx, floa
               int accumulate, float* scratch, size_t scratch_floats, hipStream_t stream);
 int mse_dense_grad(const float* y, const float* target, float* dpre, float* loss, long n, int activation, float* scratch,
                    size_t scratch_floats, hipStream_t stream);
+int matmul_f32(const float* a, const float* b, float* c, int M, int K, int N, float* scratch, size_t scratch_floats,
+               hipStream_t stream);
 int adam_step(float* p, const float* g, float* m, float* v, long n, float lr_t, float b1, float b2, float eps,
               hipStream_t stream);
 int rmsprop_step(float* p, const float* g, float* a, long n, float lr, float rho, float eps, hipStream_t stream);

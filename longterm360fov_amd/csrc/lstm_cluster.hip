@@ -147,7 +147,7 @@ __device__ __forceinline__ void load_weights(float (&wR)[H / 16][4][4], float (&
                 wR[j][s][g] = R[(size_t)(kbase + s) * H4 + g * H + col0 + n];
     }
 #pragma unroll
-    for (int g = 0; g < 4; ++g) bias[g] = b[g * H + col0 + n];
+    for (int g = 0; g < 4; ++g) bias[g] = b ? b[g * H + col0 + n] : 0.f;
     // K slice in B-operand order: block (q,s) = 64 lanes x {i,f,c,o} of input row k = 16q+4*g4+s.
     // DECODE (F <= 8, one q block): k = 4*s + g4 instead, so that the two MFMA steps s = 0,1 cover
     // k = 0..7 and the Dense output fragment (y[n][4r + g4] in register r) is their A operand.
@@ -241,7 +241,8 @@ __global__ __launch_bounds__(256, 1) void lstm_cluster_kernel(LstmParams p) {
     const float* Kp = LAYER ? p.K : p.dK;
     const float* Rp = LAYER ? p.R : p.dR;
     const float* bp = LAYER ? p.b : p.db;
-    const int F = LAYER ? p.F : p.F_dec;
+    const bool ZX = LAYER && (p.zx != nullptr);     // input projection precomputed by the caller
+    const int F = LAYER ? (ZX ? 0 : p.F) : p.F_dec;
     const int steps = LAYER ? p.T : p.T_out;
     const int Fp = round16(F);
     const int nq = Fp >> 4;
@@ -362,10 +363,13 @@ __global__ __launch_bounds__(256, 1) void lstm_cluster_kernel(LstmParams p) {
         }
         // x staging: thread (xrw = tid/16, xcl = tid%16) moves columns xcl + 16*i of row xrw
         const int xrw = tid >> 4, xcl = tid & 15;
-        const bool xlive = LAYER && (b0 + xrw < p.B);
-        const float* xt = LAYER ? p.x + ((size_t)(b0 + xrw) * p.T) * F + xcl : nullptr;
+        const bool xlive = LAYER && !ZX && (b0 + xrw < p.B);
+        const float* xt = (LAYER && !ZX) ? p.x + ((size_t)(b0 + xrw) * p.T) * F + xcl : nullptr;
+        // ZX mode: this lane's 16 pre-activations of step t live at zxp[(r*T + t)*4H + g*H]
+        const float* zxp = ZX ? p.zx + ((size_t)(b0 + 4 * g4) * p.T) * 4 * H + col0 + n : nullptr;
+        f32x4 zr[4];   // prefetched pre-activations of the NEXT step (ZX mode)
         float* xl = sX + xrw * LDX + xcl;
-        if (LAYER) {
+        if (LAYER && !ZX) {
 #pragma unroll
             for (int tt = 0; tt < 2; ++tt)
                 if (tt < steps) {
@@ -386,6 +390,13 @@ __global__ __launch_bounds__(256, 1) void lstm_cluster_kernel(LstmParams p) {
         f32x4 acc[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) acc[g] = (f32x4){bias[g], bias[g], bias[g], bias[g]};
+        if (ZX && steps > 0) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    acc[g][r] = bias[g] + ((b0 + 4 * g4 + r < p.B) ? zxp[((size_t)r * p.T) * 4 * H + g * H] : 0.f);
+        }
         if (steps > 0) {
             mfma_begin(acc);
             if (LAYER) input_proj(acc, sX + n * LDX + 4 * g4, sKw, nq, lane);
@@ -405,13 +416,20 @@ __global__ __launch_bounds__(256, 1) void lstm_cluster_kernel(LstmParams p) {
             // ---- x pipeline: x_{t+1} (loaded during step t-1) goes registers -> LDS now; its tile
             // was last read two steps ago and is next read after barrier 1b of this step.  Then
             // x_{t+2} is requested, so every load has a full step to land. ----
-            if (LAYER && t > 0 && t + 1 < steps) {
+            if (LAYER && !ZX && t > 0 && t + 1 < steps) {
                 float* xb = xl + ((t + 1) % 3) * BT * LDX;
 #pragma unroll
                 for (int i = 0; i < XR; ++i)
                     if (xcl + 16 * i < F) xb[16 * i] = xr[i];
             }
-            if (LAYER && t + 2 < steps) {
+            if (ZX && t + 1 < steps) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        zr[g][r] = bias[g] + ((b0 + 4 * g4 + r < p.B) ? zxp[((size_t)r * p.T + (t + 1)) * 4 * H + g * H] : 0.f);
+            }
+            if (LAYER && !ZX && t + 2 < steps) {
                 const float* xn = xt + (size_t)(t + 2) * F;
 #pragma unroll
                 for (int i = 0; i < XR; ++i) xr[i] = (xlive && xcl + 16 * i < F) ? xn[16 * i] : 0.f;
@@ -474,7 +492,7 @@ __global__ __launch_bounds__(256, 1) void lstm_cluster_kernel(LstmParams p) {
             // k-blocks of h_t . R, and only then are the granule tags checked.
             if (more) {
 #pragma unroll
-                for (int g = 0; g < 4; ++g) acc[g] = (f32x4){bias[g], bias[g], bias[g], bias[g]};
+                for (int g = 0; g < 4; ++g) acc[g] = ZX ? zr[g] : (f32x4){bias[g], bias[g], bias[g], bias[g]};
                 mfma_begin(acc);
                 if (LAYER) input_proj(acc, sX + ((t + 1) % 3) * BT * LDX + n * LDX + 4 * g4, sKw, nq, lane);
             }
@@ -624,7 +642,7 @@ static int launch_cluster_h(const LstmParams& p, int mode, hipStream_t stream) {
     else
         kern = mode == MODE_DECODE ? lstm_cluster_kernel<H, FOV_ACT_SIGMOID, MODE_DECODE>
                                    : lstm_cluster_kernel<H, FOV_ACT_SIGMOID, MODE_LAYER>;
-    const int F = mode == MODE_DECODE ? p.F_dec : p.F;
+    const int F = mode == MODE_DECODE ? p.F_dec : (p.zx ? 0 : p.F);
     const ClusterLds L = cluster_lds(H, F, mode == MODE_DECODE);
     const size_t lds = (size_t)L.total_floats * sizeof(float);
     if (lds > 160 * 1024) {
@@ -653,6 +671,7 @@ static int launch_cluster_mode(const LstmParams& p, int mode, hipStream_t stream
 int launch_cluster(const LstmParams& p_in, bool decode, hipStream_t stream) {
     LstmParams p = p_in;
     if (p.B == 0) return FOV_OK;
+    if (p.zx) p.F = 1;   // input projection supplied by the caller: F only sizes (empty) LDS regions
     if (!cluster_shape_ok(p.F, p.H) || (decode && (p.F_dec < 1 || p.F_dec > CL_MAX_O))) {
         set_error("cluster kernel supports H in {64,128,256}, 1<=F<=%d, F_dec<=%d (got H=%d F=%d F_dec=%d)",
                   CL_MAX_F, CL_MAX_O, p.H, p.F, p.F_dec);

@@ -16,7 +16,8 @@ __device__ __forceinline__ void generic_step(const float* __restrict__ sx, int l
                                              const float* __restrict__ b, int H,
                                              const float* __restrict__ sh_prev, float* __restrict__ sh_next,
                                              float* __restrict__ sc, float* __restrict__ reserve = nullptr,
-                                             size_t res_stride = 0, int rows = 0) {
+                                             size_t res_stride = 0, int rows = 0,
+                                             const float* __restrict__ zx = nullptr, size_t zx_stride = 0) {
     const int H4 = 4 * H;
     for (int j = threadIdx.x; j < H; j += blockDim.x) {
         float acc[GB][4];
@@ -24,9 +25,10 @@ __device__ __forceinline__ void generic_step(const float* __restrict__ sx, int l
         for (int g = 0; g < 4; ++g) {
             const float bv = b[g * H + j];
 #pragma unroll
-            for (int s = 0; s < GB; ++s) acc[s][g] = bv;
+            for (int s = 0; s < GB; ++s)
+                acc[s][g] = bv + ((zx && s < rows) ? zx[(size_t)s * zx_stride + g * H + j] : 0.f);
         }
-        for (int k = 0; k < F; ++k) {
+        for (int k = 0; k < (zx ? 0 : F); ++k) {
             float w[4];
 #pragma unroll
             for (int g = 0; g < 4; ++g) w[g] = K[(size_t)k * H4 + g * H + j];
@@ -85,13 +87,16 @@ __global__ __launch_bounds__(256) void lstm_generic_kernel(LstmParams p) {
     }
     int cur = 0;
     for (int t = 0; t < p.T; ++t) {
-        for (int i = tid; i < GB * p.F; i += blockDim.x) {
-            const int s = i / p.F, k = i - s * p.F;
-            sh_x[s * ldx + k] = (s < rows) ? p.x[((size_t)(b0 + s) * p.T + t) * p.F + k] : 0.f;
+        if (!p.zx) {
+            for (int i = tid; i < GB * p.F; i += blockDim.x) {
+                const int s = i / p.F, k = i - s * p.F;
+                sh_x[s * ldx + k] = (s < rows) ? p.x[((size_t)(b0 + s) * p.T + t) * p.F + k] : 0.f;
+            }
         }
         __syncthreads();
         generic_step<ACT>(sh_x, ldx, p.F, p.K, p.R, p.b, H, sh_h + cur * GB * H, sh_h + (cur ^ 1) * GB * H, sh_c,
-                          p.reserve ? p.reserve + (((size_t)b0 * p.T + t) * 5) * H : nullptr, (size_t)p.T * 5 * H, rows);
+                          p.reserve ? p.reserve + (((size_t)b0 * p.T + t) * 5) * H : nullptr, (size_t)p.T * 5 * H, rows,
+                          p.zx ? p.zx + ((size_t)b0 * p.T + t) * 4 * H : nullptr, (size_t)p.T * 4 * H);
         __syncthreads();
         cur ^= 1;
         if (p.hs) {

@@ -451,6 +451,15 @@ int mse_dense_grad(const float* y, const float* target, float* dpre, float* loss
     return rc;
 }
 
+// C (M,N) = A (M,K) . B (K,N), all row-major dense
+int matmul_f32(const float* a, const float* b, float* c, int M, int K, int N, float* scratch, size_t scratch_floats,
+               hipStream_t stream) {
+    GemmArgs g = {};
+    g.a = a; g.b = b; g.c = c; g.M = M; g.N = N; g.KO = 1; g.KI = K;
+    g.a_sm = K; g.a_ski = 1; g.b_sn = 1; g.b_ski = N; g.ldc = N;
+    return gemm_f32(g, 0, scratch, scratch_floats, stream);
+}
+
 int adam_step(float* p, const float* g, float* m, float* v, long n, float lr_t, float b1, float b2, float eps,
               hipStream_t stream) {
     if (n <= 0) return FOV_OK;

@@ -288,3 +288,107 @@ class Seq2SeqLSTM:
         self._w = self._trainer.weights_numpy()
         self._dw = None
         return float(loss.item())
+
+
+_MIX_ORDER = ("enc1_K", "enc1_R", "enc1_b", "enc2_K", "enc2_R", "enc2_b", "dec1_K", "dec1_R", "dec1_b",
+              "dec2_K", "dec2_R", "dec2_b", "dense_W", "dense_b", "mix_W", "mix_b")
+
+
+class OthersMixingSeq2Seq:
+    """Target + others mu/sigma^2 mixing seq2seq (mycode/given_others_gt_mean_var_seq2seq.py:98-308 with
+    mlp_mixing, cfg.predict_mean_var=True, no teacher forcing): 2-layer LSTM encoder, 2-layer decoder
+    unrolled `predict_step` times feeding its own output back, per-step Dense(6,tanh) and a mixing
+    Dense(6,tanh) over [others_t (U-1,6) ; prediction (1,6)] flattened user-major.
+
+    predict([encoder_input (N,T_in,F_enc), others_fut_input (N,T_out,U-1,6), decoder_input (N,1,6)])
+    -> (N,T_out,6).  Round 1 runs the decoder as per-step library calls (layer-1 step, the layer-2 input
+    projection as an MFMA GEMM, layer-2 step, Dense, mixing Dense); the "others" half of the mixing
+    product is hoisted out of the loop as one GEMV batch."""
+
+    def __init__(self, num_encoder_tokens=None, num_decoder_tokens=6, latent_dim=32, num_user=34,
+                 recurrent_activation=None, seed=None, impl="auto", device="cuda"):
+        self.num_encoder_tokens = 3 * cfg.fps if num_encoder_tokens is None else int(num_encoder_tokens)
+        self.num_decoder_tokens = int(num_decoder_tokens)
+        self.latent_dim, self.num_user = int(latent_dim), int(num_user)
+        self.recurrent_activation = recurrent_activation or cfg.recurrent_activation
+        self.impl, self.device = impl, device
+        rng = np.random.default_rng(seed)
+        H, O = self.latent_dim, self.num_decoder_tokens
+        w = {}
+        for name, F in (("enc1", self.num_encoder_tokens), ("enc2", H), ("dec1", O), ("dec2", H)):
+            w[name + "_K"], w[name + "_R"], w[name + "_b"] = init_lstm_weights(rng, F, H)
+        w["dense_W"], w["dense_b"] = glorot_uniform(rng, H, O), np.zeros(O, np.float32)
+        w["mix_W"], w["mix_b"] = glorot_uniform(rng, self.num_user * O, O), np.zeros(O, np.float32)
+        self._w, self._dw, self._ws = w, None, None
+
+    def get_weights(self):
+        return [self._w[k].copy() for k in _MIX_ORDER]
+
+    def set_weights(self, weights):
+        weights = list(weights)
+        if len(weights) != len(_MIX_ORDER):
+            raise ValueError("expected %d arrays, got %d" % (len(_MIX_ORDER), len(weights)))
+        for k, a in zip(_MIX_ORDER, weights):
+            a = _as_f32(a)
+            if a.shape != self._w[k].shape:
+                raise ValueError("%s: expected shape %s, got %s" % (k, self._w[k].shape, a.shape))
+            self._w[k] = a
+        self._dw = None
+
+    def save_weights(self, path):
+        np.savez(path, **self._w)
+
+    def load_weights(self, path):
+        with np.load(path) as z:
+            self.set_weights([z[k] for k in _MIX_ORDER])
+
+    def count_params(self):
+        return int(sum(v.size for v in self._w.values()))
+
+    def _device_weights(self):
+        import torch
+        from . import ops
+        if self._dw is None:
+            self._dw = {k: torch.from_numpy(v).to(self.device) for k, v in self._w.items()}
+            n_oth = (self.num_user - 1) * self.num_decoder_tokens
+            self._dw["mix_W_oth"] = self._dw["mix_W"][:n_oth].contiguous()
+            self._dw["mix_W_pred"] = self._dw["mix_W"][n_oth:].contiguous()
+            self._ws = ops.Workspace()
+        return self._dw
+
+    def predict(self, x, batch_size=None, verbose=0):
+        import torch
+        from . import ops
+        enc, others, dec0 = (_as_f32(a) for a in x)
+        dw = self._device_weights()
+        act, impl, ws = self.recurrent_activation, self.impl, self._ws
+        H, O = self.latent_dim, self.num_decoder_tokens
+        n = enc.shape[0]
+        T_out = others.shape[1]
+        bs = n if not batch_size else int(batch_size)
+        outs = []
+        for lo in range(0, n, max(bs, 1)):
+            e = torch.from_numpy(enc[lo:lo + bs]).to(self.device)
+            oth = torch.from_numpy(others[lo:lo + bs]).to(self.device)
+            xin = torch.from_numpy(dec0[lo:lo + bs]).to(self.device)
+            B, T_in = e.shape[0], e.shape[1]
+            hs1, h1, c1 = ops.lstm_seq(e, dw["enc1_K"], dw["enc1_R"], dw["enc1_b"], act=act, impl=impl, workspace=ws)
+            zx = ops.matmul(hs1.reshape(B * T_in, H), dw["enc2_K"]).reshape(B, T_in, 4 * H)
+            _, h2, c2 = ops.lstm_seq_zx(zx, dw["enc2_R"], dw["enc2_b"], act=act, impl=impl, return_sequences=False, workspace=ws)
+            # others half of the mixing layer for every step at once (bias folded in)
+            oth_proj = ops.dense(oth.reshape(B * T_out, -1), dw["mix_W_oth"], dw["mix_b"], activation=None).reshape(B, T_out, O)
+            out = torch.empty((B, T_out, O), dtype=torch.float32, device=self.device)
+            for t in range(T_out):
+                _, h1, c1 = ops.lstm_seq(xin.reshape(B, 1, O), dw["dec1_K"], dw["dec1_R"], dw["dec1_b"], h1, c1, act=act,
+                                         impl=impl, return_sequences=False, workspace=ws)
+                zx = ops.matmul(h1, dw["dec2_K"]).reshape(B, 1, 4 * H)
+                _, h2, c2 = ops.lstm_seq_zx(zx, dw["dec2_R"], dw["dec2_b"], h2, c2, act=act, impl=impl,
+                                            return_sequences=False, workspace=ws)
+                p = ops.dense(h2, dw["dense_W"], dw["dense_b"], activation="tanh")
+                xin = ops.dense_add(p, dw["mix_W_pred"], None, oth_proj[:, t], activation="tanh")
+                out[:, t] = xin
+            outs.append(out.cpu().numpy())
+        self._ws.check()
+        return np.concatenate(outs, axis=0) if outs else np.zeros((0, T_out, O), np.float32)
+
+    predict_on_batch = predict

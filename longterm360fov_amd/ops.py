@@ -264,3 +264,51 @@ def rmsprop_step(params, grads, accum, lr=1e-3, rho=0.9, eps=1e-7):
     for t in (params, grads, accum):
         _dev(t, "flat buffer")
     check(_lib.lib().fov_rmsprop_step(_ptr(params), _ptr(grads), _ptr(accum), params.numel(), lr, rho, eps, _stream()))
+
+
+# ---------------------------------------------------------------------------------------------
+# stacked layers / others mixing (a4): building blocks
+# ---------------------------------------------------------------------------------------------
+def matmul(a, b, scratch=None):
+    """(M,K) @ (K,N) on the fp32 MFMA GEMM of the library."""
+    a, b = _dev(a, "a"), _dev(b, "b")
+    M, K = a.shape
+    N = b.shape[1]
+    c = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    L = _lib.lib()
+    buf = (scratch or _default_scratch).get(min(L.fov_matmul_workspace_bytes(M, K, N), 64 << 20), a.device)
+    check(L.fov_matmul(_ptr(a), _ptr(b), _ptr(c), M, K, N, buf.data_ptr(), buf.numel(), _stream()))
+    return c
+
+
+def dense_add(x, W, b, add, activation="tanh"):
+    """act(x W + b + add) with add (N,Out) possibly a strided row view (last dim contiguous)."""
+    x, W = _dev(x, "x"), _dev(W, "W")
+    In, Out = W.shape
+    x2 = x.reshape(-1, In)
+    N = x2.shape[0]
+    assert add.is_cuda and add.dtype == torch.float32 and add.shape == (N, Out) and add.stride(1) == 1
+    y = torch.empty((N, Out), dtype=torch.float32, device=x.device)
+    check(_lib.lib().fov_dense_add_fwd(_ptr(x2), _ptr(W), _ptr(_dev(b, "b")), add.data_ptr(), add.stride(0), _ptr(y),
+                                       N, In, Out, 1 if activation == "tanh" else 0, _stream()))
+    return y
+
+
+def lstm_seq_zx(zx, R, b, h0=None, c0=None, act="sigmoid", impl="auto", return_sequences=True, workspace=None,
+                reserve=None):
+    """LSTM layer from a precomputed input projection zx = x.K (B,T,4H) -> (hs|None, hT, cT)."""
+    zx, R, b = _dev(zx, "zx"), _dev(R, "R"), _dev(b, "b")
+    B, T, H4 = zx.shape
+    H = R.shape[0]
+    assert H4 == 4 * H
+    e = lambda *s: torch.empty(s, dtype=torch.float32, device=zx.device)
+    hs = e(B, T, H) if return_sequences else None
+    hT, cT = e(B, H), e(B, H)
+    L = _lib.lib()
+    impl = impl_code(impl)
+    ws = (workspace or default_workspace(zx.device))
+    buf = ws.get(L.fov_lstm_seq_workspace_bytes(B, T, 1, H, impl), zx.device)
+    check(L.fov_lstm_seq_fwd_zx(_ptr(zx), _ptr(R), _ptr(b), _ptr(_dev(h0, "h0")), _ptr(_dev(c0, "c0")), _ptr(hs),
+                                _ptr(hT), _ptr(cT), _ptr(reserve), B, T, H, act_code(act), impl, buf.data_ptr(),
+                                buf.numel(), _stream()))
+    return hs, hT, cT

@@ -280,3 +280,50 @@ def test_exchange_paths_agree_bitwise():
     assert torch.equal(outs["0"], outs["1"])
     ref = C.seq2seq_decode(enc, dec0, w, T_out)
     assert_parity(outs["0"], ref, "exchange paths vs C oracle", tight=5e-5)
+
+
+# ---------------------------------------------------------------------------------------
+# a4: target + others mixing, 2+2 layers, no teacher forcing (given_others_gt_mean_var_seq2seq.py)
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("H,B,U,T_in,T_out,act", [(32, 5, 4, 6, 4, "sigmoid"), (64, 20, 34, 5, 4, "hard_sigmoid"),
+                                                  (256, 48, 34, 10, 10, "sigmoid")])
+def test_others_mixing_forward(H, B, U, T_in, T_out, act):
+    from longterm360fov_amd.models import OthersMixingSeq2Seq, _MIX_ORDER
+    w = O.init_others_mixing(60 + H, H=H, num_user=U, bias_noise=0.1)
+    enc, dec0, _, oth = O.synthetic_batch(61 + B, B, T_in, T_out, num_others=U - 1)
+    ref = O.others_mixing_forward(enc.astype(np.float64), oth.astype(np.float64), dec0.astype(np.float64), f64(w), act)
+    m = OthersMixingSeq2Seq(latent_dim=H, num_user=U, recurrent_activation=act)
+    m.set_weights([w[k] for k in _MIX_ORDER])
+    out = m.predict([enc, oth, dec0])
+    assert_parity(out, ref, "others-mixing H%d B%d U%d %s" % (H, B, U, act))
+    assert m.count_params() == sum(v.size for v in w.values())
+
+
+def test_golden_others_mixing_vector(golden_dir):
+    from longterm360fov_amd.models import OthersMixingSeq2Seq, _MIX_ORDER
+    g = np.load(os.path.join(golden_dir, "lstm_small.npz"))
+    wm = {k[3:]: g[k] for k in g.files if k.startswith("wm_")}
+    m = OthersMixingSeq2Seq(latent_dim=wm["enc1_R"].shape[0], num_user=g["oth"].shape[2] + 1)
+    m.set_weights([wm[k] for k in _MIX_ORDER])
+    assert_parity(m.predict([g["enc"], g["oth"], g["dec0"]]), g["mix_act0"], "golden others-mixing")
+
+
+def test_matmul_and_zx_layer():
+    ops = _ops()
+    rng = np.random.default_rng(9)
+    for M, K, N in ((7, 33, 5), (300, 256, 1024), (1, 256, 1024), (130, 6, 70)):
+        a = rng.standard_normal((M, K)).astype(np.float32); b = rng.standard_normal((K, N)).astype(np.float32)
+        ref = a.astype(np.float64) @ b.astype(np.float64)
+        got = ops.matmul(dev(a), dev(b)).cpu().numpy()
+        assert np.abs(got - ref).max() <= 1e-5 * np.abs(ref).max() + 1e-6, (M, K, N)
+    # a stacked layer through zx equals the same layer given x directly
+    H, F, B, T = 128, 40, 21, 5
+    Kk, R, b = O.init_lstm(rng, F, H, np.float32)
+    b = (b + 0.1 * rng.standard_normal(b.shape)).astype(np.float32)
+    x = rng.uniform(-1, 1, (B, T, F)).astype(np.float32)
+    ref = O.lstm_layer(x.astype(np.float64), Kk.astype(np.float64), R.astype(np.float64), b.astype(np.float64))
+    for impl in ("cluster", "generic"):
+        zx = ops.matmul(dev(x.reshape(B * T, F)), dev(Kk)).reshape(B, T, 4 * H)
+        hs, hT, cT = ops.lstm_seq_zx(zx, dev(R), dev(b), impl=impl)
+        assert_parity(hs, ref[0], "zx layer hs " + impl)
+        assert_parity(cT, ref[2], "zx layer cT " + impl)
