@@ -1,0 +1,323 @@
+// Persistent cluster BPTT kernel for gfx950 (MI355X): the backward recurrence of one LSTM layer in
+// ONE launch, the sibling of lstm_cluster.hip.  (The reference delegates this to TensorFlow
+// autodiff under model.fit - mycode/FoV_seq2seq.py:103,112-117.)
+//
+// Same decomposition as the forward: a group of G = H/64 workgroups owns a 16-sequence tile,
+// workgroup `slice` owns hidden units [64*slice, 64*slice+64) for all four gates; wave w / lane
+// (n, g4) owns unit 16w+n of that slice for sequences 4*g4 .. 4*g4+3 and keeps their running dc
+// and dh in registers.
+//
+// Per step t (descending): the lane turns dh_t, dc into the four pre-activation gradients dz of its
+// elements (reserve = i,f,g,o,c from the training forward), stores them to dZ (B,T,4H) for the
+// weight-gradient GEMMs, and writes them into an LDS tile (16 x 256 own gate columns, MFMA A
+// layout).  dh_{t-1} = dz_t . R^T is then split by OUTPUT unit: wave w computes, for every
+// destination slice d, the 16 units [64d+16w, 64d+16w+16) from the workgroup's own 256 gate columns
+// (64 MFMAs per destination; R^T fragment = H AGPRs per lane for the whole sequence).  That
+// (16 x 16) partial belongs to wave w of workgroup d, SAME lane: remote partials travel as 8-byte
+// {value, epoch} granules (4 per lane per destination), the local one never leaves its registers.
+// Destinations are visited remote-first and the gather sweep is issued before the local
+// destination's MFMAs, so most of the exchange latency hides under them.  The G partials of an
+// element are summed in slice order 0..G-1 (deterministic).
+#include <stdlib.h>
+
+#include "fov_common.h"
+
+namespace fov {
+
+constexpr int BBT = 16;
+constexpr unsigned BSPIN_LIMIT = 1u << 20;
+typedef unsigned bu32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void bmfma_va(f32x4& acc, float a, float w_agpr) {
+    asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "a"(w_agpr));
+}
+
+struct BwdParams {
+    const float* R;
+    const float* reserve;   // (B,T,5,H)
+    const float* c0;        // (B,H) or NULL
+    const float* dhs;       // (B,T,H) or NULL
+    const float* dhT;       // (B,H) or NULL
+    const float* dcT;       // (B,H) or NULL
+    float* dz;              // (B,T,4H) out
+    float* dh0;             // (B,H) or NULL
+    float* dc0;             // (B,H) or NULL
+    unsigned long long* xch;
+    unsigned* status;
+    int B, T, H, num_groups, num_tiles;
+};
+
+template <int ACT>
+__device__ __forceinline__ float bwd_act_grad(float a) {
+    return ACT == FOV_ACT_HARD_SIGMOID ? ((a > 0.f && a < 1.f) ? 0.2f : 0.f) : a * (1.f - a);
+}
+
+template <int H, int ACT>
+__global__ __launch_bounds__(256, 1) void lstm_bwd_cluster_kernel(BwdParams p) {
+    constexpr int G = H / 64;
+    constexpr int LDZ = 256 + 4;
+    __shared__ __attribute__((aligned(16))) float sZ[BBT * LDZ];   // dz tile, columns kc = gate*64 + unit_in_slice
+    __shared__ int sFlag[4];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 15, g4 = lane >> 4;
+    int group, slice;
+    if (G > 1 && (p.num_groups & 7) == 0) {
+        group = (blockIdx.x / (8 * G)) * 8 + (blockIdx.x & 7);
+        slice = (blockIdx.x >> 3) & (G - 1);
+    } else {
+        group = blockIdx.x / G;
+        slice = blockIdx.x - group * G;
+    }
+    const int unit = slice * 64 + wave * 16 + n;   // the hidden unit this lane owns
+    if (tid == 0) sFlag[0] = 0;
+
+    // R^T fragments: destination dd visits slice d(dd) = (slice + 1 + dd) mod G, so the local one is last.
+    // wB[dd][q][s] = R[j = 64 d + 16 wave + n][col(kc = 16q + 4 g4 + s)], col = gate*H + 64 slice + unit_in_slice
+    float wB[G][16][4];
+    {
+        const int H4 = 4 * H;
+#pragma unroll
+        for (int dd = 0; dd < G; ++dd) {
+            const int d = (slice + 1 + dd) & (G - 1);
+            const float* rrow = p.R + (size_t)(64 * d + 16 * wave + n) * H4 + 64 * slice;
+#pragma unroll
+            for (int q = 0; q < 16; ++q)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const int kc = 16 * q + 4 * g4 + s;
+                    wB[dd][q][s] = rrow[(kc >> 6) * H + (kc & 63)];
+                }
+        }
+    }
+
+    // granule buffers of this group: [parity][dst slice][src slice][wave][r][lane]
+    constexpr int CHUNK = 4 * 4 * 64;   // granules one workgroup sends to one destination per step
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+        p.xch + (size_t)group * 2 * G * G * CHUNK, 0, 2 * G * G * CHUNK * (int)sizeof(unsigned long long), 0x00020000);
+    const unsigned lane_off = (unsigned)((wave * 4) * 64 + lane) * 8u;   // + r*64*8 per register
+
+    unsigned epoch = 0;
+    bool aborted = false;
+    __syncthreads();
+
+    for (int tile = group; tile < p.num_tiles && !aborted; tile += p.num_groups) {
+        const int b0 = tile * BBT;
+        float dc[4], dh[4];
+        bool live[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = b0 + 4 * g4 + r;
+            live[r] = row < p.B;
+            dc[r] = (live[r] && p.dcT) ? p.dcT[(size_t)row * H + unit] : 0.f;
+            dh[r] = (live[r] && p.dhT) ? p.dhT[(size_t)row * H + unit] : 0.f;
+        }
+        // reserve pipeline: cur = step t, nxt = step t-1 (its c is c_{t-1} of step t)
+        float cur[5][4], nxt[5][4], dhs_cur[4], dhs_nxt[4];
+        auto load_step = [&](int t, float (&dst)[5][4], float (&dd_)[4]) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = b0 + 4 * g4 + r;
+                if (t >= 0 && live[r]) {
+                    const float* rp = p.reserve + (((size_t)row * p.T + t) * 5) * H + unit;
+#pragma unroll
+                    for (int q = 0; q < 5; ++q) dst[q][r] = rp[q * H];
+                    dd_[r] = p.dhs ? p.dhs[((size_t)row * p.T + t) * H + unit] : 0.f;
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 5; ++q) dst[q][r] = 0.f;
+                    dst[4][r] = (t < 0 && live[r] && p.c0) ? p.c0[(size_t)row * H + unit] : 0.f;   // c_{-1} = c0
+                    dd_[r] = 0.f;
+                }
+            }
+        };
+        load_step(p.T - 1, cur, dhs_cur);
+        load_step(p.T - 2, nxt, dhs_nxt);
+
+        for (int t = p.T - 1; t >= 0; --t) {
+            // ---- pointwise: dz of this lane's four elements ----
+            float dzv[4][4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float ig = cur[0][r], fg = cur[1][r], gg = cur[2][r], og = cur[3][r], cc = cur[4][r];
+                const float cprev = nxt[4][r];
+                const float dht = dh[r] + dhs_cur[r];
+                const float tc = tanh_f(cc);
+                const float dcv = dc[r] + dht * og * (1.f - tc * tc);
+                dzv[0][r] = dcv * gg * bwd_act_grad<ACT>(ig);
+                dzv[1][r] = dcv * cprev * bwd_act_grad<ACT>(fg);
+                dzv[2][r] = dcv * ig * (1.f - gg * gg);
+                dzv[3][r] = dht * tc * bwd_act_grad<ACT>(og);
+                dc[r] = dcv * fg;
+                if (live[r]) {
+                    float* zp = p.dz + ((size_t)(b0 + 4 * g4 + r) * p.T + t) * 4 * H + unit;
+                    zp[0] = dzv[0][r]; zp[H] = dzv[1][r]; zp[2 * H] = dzv[2][r]; zp[3 * H] = dzv[3][r];
+                }
+#pragma unroll
+                for (int g = 0; g < 4; ++g) sZ[(4 * g4 + r) * LDZ + g * 64 + wave * 16 + n] = dzv[g][r];
+            }
+            // rotate the reserve pipeline and request step t-2
+#pragma unroll
+            for (int q = 0; q < 5; ++q)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) cur[q][r] = nxt[q][r];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dhs_cur[r] = dhs_nxt[r];
+            load_step(t - 2, nxt, dhs_nxt);
+            __syncthreads();   // barrier A: the dz tile is complete
+            // a give-up of the PREVIOUS step's gather is acted on here, where every wave sees the same flag
+            if (G > 1 && sFlag[0]) { aborted = true; break; }
+
+            // ---- A fragments of the whole tile row (16 x b128), reused for every destination ----
+            f32x4 afr[16];
+            const float* arow = sZ + n * LDZ + 4 * g4;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) afr[q] = *(const f32x4*)(arow + 16 * q);
+
+            ++epoch;
+            const unsigned xsoff = (epoch & 1u) * (unsigned)(G * G * CHUNK * sizeof(unsigned long long));
+            f32x4 part = (f32x4){0.f, 0.f, 0.f, 0.f};   // the local destination's partial
+            bu32x2 v[G > 1 ? (G - 1) * 4 : 1];
+#pragma unroll
+            for (int dd = 0; dd < G; ++dd) {
+                if (dd == G - 1 && G > 1) {
+                    // all remote partials are on their way: issue the gather sweep, then do the local MFMAs
+#pragma unroll
+                    for (int k = 0; k < G - 1; ++k) {
+                        const int s_src = (slice + 1 + k) & (G - 1);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            v[k * 4 + r] = __builtin_amdgcn_raw_buffer_load_b64(
+                                xrs, (unsigned)((slice * G + s_src) * CHUNK) * 8u + lane_off + r * 512u, xsoff, 16);
+                    }
+                }
+                f32x4 a4[4];
+#pragma unroll
+                for (int s = 0; s < 4; ++s) a4[s] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                asm volatile("s_nop 1" : "+v"(a4[0]), "+v"(a4[1]), "+v"(a4[2]), "+v"(a4[3]));
+#pragma unroll
+                for (int q = 0; q < 16; ++q)
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) bmfma_va(a4[s], afr[q][s], wB[dd][q][s]);
+                asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" : "+v"(a4[0]), "+v"(a4[1]), "+v"(a4[2]), "+v"(a4[3]));
+                f32x4 sum;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sum[r] = (a4[0][r] + a4[1][r]) + (a4[2][r] + a4[3][r]);
+                if (dd == G - 1) {
+                    part = sum;
+                } else {
+                    const int d = (slice + 1 + dd) & (G - 1);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        __builtin_amdgcn_raw_buffer_store_b64((bu32x2){__float_as_uint(sum[r]), epoch}, xrs,
+                                                              (unsigned)((d * G + slice) * CHUNK) * 8u + lane_off + r * 512u,
+                                                              xsoff, 16);
+                }
+            }
+            __syncthreads();   // barrier B: every wave is done with the dz tile
+            if (G > 1) {
+                unsigned spins = 0;
+                while (true) {
+                    bool ok = true;
+#pragma unroll
+                    for (int j = 0; j < (G - 1) * 4; ++j) ok = ok && (v[j].y == epoch);
+                    if (__all(ok)) break;
+                    ++spins;
+                    if (spins > BSPIN_LIMIT ||
+                        ((spins & 63u) == 0 &&
+                         __hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                        if (lane == 0) {
+                            __hip_atomic_store(p.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            sFlag[0] = 1;
+                        }
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                    asm volatile("" ::: "memory");
+#pragma unroll
+                    for (int k = 0; k < G - 1; ++k) {
+                        const int s_src = (slice + 1 + k) & (G - 1);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            v[k * 4 + r] = __builtin_amdgcn_raw_buffer_load_b64(
+                                xrs, (unsigned)((slice * G + s_src) * CHUNK) * 8u + lane_off + r * 512u, xsoff, 16);
+                    }
+                }
+            }
+            // dh_{t-1}: partials summed in slice order 0..G-1 (own slice in its place)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float acc = 0.f;
+#pragma unroll
+                for (int s_abs = 0; s_abs < G; ++s_abs) {
+                    // k such that (slice + 1 + k) mod G == s_abs, or the local partial when s_abs == slice
+                    float term = part[r];
+                    if (G > 1) {
+#pragma unroll
+                        for (int k = 0; k < G - 1; ++k)
+                            if (((slice + 1 + k) & (G - 1)) == s_abs) term = __uint_as_float(v[k * 4 + r].x);
+                    }
+                    acc += term;
+                }
+                dh[r] = acc;
+            }
+        }
+        if (!aborted) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = b0 + 4 * g4 + r;
+                if (row < p.B) {
+                    if (p.dh0) p.dh0[(size_t)row * H + unit] = dh[r];
+                    if (p.dc0) p.dc0[(size_t)row * H + unit] = dc[r];
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// --------------------------------------------------------------------------------------
+// host side
+// --------------------------------------------------------------------------------------
+bool bwd_cluster_shape_ok(int H) { return H == 64 || H == 128 || H == 256; }
+
+size_t bwd_cluster_xch_bytes(int B, int H) {
+    const size_t G = H / 64;
+    const size_t groups = (size_t)cluster_num_groups(B, H);
+    const size_t b = groups * 2 * G * G * (4 * 4 * 64) * sizeof(unsigned long long);
+    return (b + 255) & ~(size_t)255;
+}
+
+template <int H>
+static int launch_bwd_h(const BwdParams& p, int act, hipStream_t stream) {
+    void (*kern)(BwdParams) = act == FOV_ACT_HARD_SIGMOID ? lstm_bwd_cluster_kernel<H, FOV_ACT_HARD_SIGMOID>
+                                                          : lstm_bwd_cluster_kernel<H, FOV_ACT_SIGMOID>;
+    const dim3 grid(p.num_groups * (H / 64)), block(256);
+    hipLaunchKernelGGL(kern, grid, block, 0, stream, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_error("bwd cluster launch: %s", hipGetErrorString(e)); return FOV_ERR_LAUNCH; }
+    return FOV_OK;
+}
+
+// status word + granule buffers live at `xch_ws` (kStatusBytes + bwd_cluster_xch_bytes)
+int launch_bwd_cluster(const float* R, const float* reserve, const float* c0, const float* dhs, const float* dhT,
+                       const float* dcT, float* dz, float* dh0, float* dc0, int B, int T, int H, int act, void* xch_ws,
+                       hipStream_t stream) {
+    if (B == 0 || T == 0) return FOV_OK;
+    BwdParams p = {};
+    p.R = R; p.reserve = reserve; p.c0 = c0; p.dhs = dhs; p.dhT = dhT; p.dcT = dcT; p.dz = dz; p.dh0 = dh0; p.dc0 = dc0;
+    p.B = B; p.T = T; p.H = H;
+    p.num_tiles = (B + BBT - 1) / BBT;
+    p.num_groups = cluster_num_groups(B, H);
+    p.status = (unsigned*)xch_ws;
+    p.xch = (unsigned long long*)((char*)xch_ws + kStatusBytes);
+    hipError_t e = hipMemsetAsync(xch_ws, 0, kStatusBytes + bwd_cluster_xch_bytes(B, H), stream);
+    if (e != hipSuccess) { set_error("hipMemsetAsync: %s", hipGetErrorString(e)); return FOV_ERR_LAUNCH; }
+    switch (H) {
+        case 64: return launch_bwd_h<64>(p, act, stream);
+        case 128: return launch_bwd_h<128>(p, act, stream);
+        default: return launch_bwd_h<256>(p, act, stream);
+    }
+}
+
+}  // namespace fov

@@ -11,6 +11,8 @@
 //   colsum_*              bias gradients                                             - HBM
 //   mse_dense_grad_kernel dL/d(pre-tanh) of the Dense head + loss partials           - HBM
 //   adam_kernel / rmsprop_kernel  flat-buffer optimizer step (16-28 B per parameter) - HBM
+#include <stdlib.h>
+
 #include "fov_common.h"
 
 namespace fov {
@@ -326,7 +328,9 @@ size_t lstm_bwd_workspace_floats(int B, int T, int F, int H) {
     size_t st = (size_t)8 * B * H;                               // split-K partials of the per-step dh GEMM
     size_t m = wg > cs ? wg : cs;
     (void)T;
-    return (size_t)2 * B * H + (m > st ? m : st) + 64;
+    // head: status word + granule buffers of the persistent BPTT kernel (when the shape allows it)
+    size_t head = bwd_cluster_shape_ok(H) ? (kStatusBytes + bwd_cluster_xch_bytes(B, H)) / sizeof(float) : 64;
+    return head + (size_t)2 * B * H + (m > st ? m : st) + 64;
 }
 
 // BPTT of one layer.  dz:(B,T,4H) is an output (kept: the caller may need it for dx of the layer
@@ -336,38 +340,60 @@ int lstm_seq_bwd(const float* x, const float* K, const float* R, const float* h0
                  float* dK, float* dR, float* db, float* dh0, float* dc0, int B, int T, int F, int H, int act,
                  int accumulate, float* ws, size_t ws_floats, hipStream_t stream) {
     if (ws_floats < lstm_bwd_workspace_floats(B, T, F, H)) { set_error("lstm_seq_bwd: workspace too small"); return FOV_ERR_WORKSPACE; }
-    float* dh_rec = ws;
-    float* dc = ws + (size_t)B * H;
-    float* scratch = ws + (size_t)2 * B * H;
-    const size_t scratch_floats = ws_floats - (size_t)2 * B * H;
-    const size_t bh = sizeof(float) * (size_t)B * H;
-    hipError_t e;
-    e = dhT ? hipMemcpyAsync(dh_rec, dhT, bh, hipMemcpyDeviceToDevice, stream) : hipMemsetAsync(dh_rec, 0, bh, stream);
-    if (e == hipSuccess) e = dcT ? hipMemcpyAsync(dc, dcT, bh, hipMemcpyDeviceToDevice, stream) : hipMemsetAsync(dc, 0, bh, stream);
-    if (e != hipSuccess) { set_error("lstm_seq_bwd init: %s", hipGetErrorString(e)); return FOV_ERR_LAUNCH; }
-    const long nelem = (long)B * H;
-    const dim3 pgrid((unsigned)((nelem + 255) / 256));
-    for (int t = T - 1; t >= 0; --t) {
-        if (act == FOV_ACT_HARD_SIGMOID)
-            hipLaunchKernelGGL(lstm_bwd_pointwise<FOV_ACT_HARD_SIGMOID>, pgrid, dim3(256), 0, stream, reserve, c0, dhs, dh_rec,
-                               dc, dz, B, T, H, t);
-        else
-            hipLaunchKernelGGL(lstm_bwd_pointwise<FOV_ACT_SIGMOID>, pgrid, dim3(256), 0, stream, reserve, c0, dhs, dh_rec, dc,
-                               dz, B, T, H, t);
-        int rc = check_launch("lstm_bwd_pointwise");
-        if (rc) return rc;
-        // dh_rec (B,H) = dz_t (B,4H) . R^T :  A(m,k) = dz[m][t][k], B(k,n) = R[n][k]
-        GemmArgs g = {};
-        g.a = dz + (size_t)t * 4 * H; g.b = R; g.c = dh_rec;
-        g.M = B; g.N = H; g.KO = 1; g.KI = 4 * H;
-        g.a_sm = (long)T * 4 * H; g.a_sko = 0; g.a_ski = 1;
-        g.b_sn = 4 * H; g.b_sko = 0; g.b_ski = 1;
-        g.ldc = H;
-        rc = gemm_f32(g, 0, scratch, scratch_floats, stream);
-        if (rc) return rc;
+    if (T == 0) {
+        if (!accumulate) {
+            if (dK) (void)hipMemsetAsync(dK, 0, sizeof(float) * (size_t)F * 4 * H, stream);
+            if (dR) (void)hipMemsetAsync(dR, 0, sizeof(float) * (size_t)H * 4 * H, stream);
+            if (db) (void)hipMemsetAsync(db, 0, sizeof(float) * (size_t)4 * H, stream);
+        }
+        const size_t bh0 = sizeof(float) * (size_t)B * H;
+        if (dh0) (void)(dhT ? hipMemcpyAsync(dh0, dhT, bh0, hipMemcpyDeviceToDevice, stream) : hipMemsetAsync(dh0, 0, bh0, stream));
+        if (dc0) (void)(dcT ? hipMemcpyAsync(dc0, dcT, bh0, hipMemcpyDeviceToDevice, stream) : hipMemsetAsync(dc0, 0, bh0, stream));
+        return FOV_OK;
     }
-    if (dh0) { e = hipMemcpyAsync(dh0, dh_rec, bh, hipMemcpyDeviceToDevice, stream); if (e != hipSuccess) { set_error("dh0 copy"); return FOV_ERR_LAUNCH; } }
-    if (dc0) { e = hipMemcpyAsync(dc0, dc, bh, hipMemcpyDeviceToDevice, stream); if (e != hipSuccess) { set_error("dc0 copy"); return FOV_ERR_LAUNCH; } }
+    const bool persistent = bwd_cluster_shape_ok(H) && !getenv("FOV_BWD_STEPPED");
+    const size_t head = bwd_cluster_shape_ok(H) ? (kStatusBytes + bwd_cluster_xch_bytes(B, H)) / sizeof(float) : 64;
+    float* dh_rec = ws + head;
+    float* dc = dh_rec + (size_t)B * H;
+    float* scratch = dc + (size_t)B * H;
+    const size_t scratch_floats = ws_floats - head - (size_t)2 * B * H;
+    const size_t bh = sizeof(float) * (size_t)B * H;
+    hipError_t e = hipSuccess;
+    if (persistent) {
+        // one launch for the whole recurrence: dz (B,T,4H), dh0, dc0
+        int rc = launch_bwd_cluster(R, reserve, c0, dhs, dhT, dcT, dz, dh0 ? dh0 : dh_rec, dc0 ? dc0 : dc, B, T, H, act, ws,
+                                    stream);
+        if (rc) return rc;
+    } else {
+        e = hipMemsetAsync(ws, 0, 256, stream);   // status word of this workspace
+        if (e == hipSuccess)
+            e = dhT ? hipMemcpyAsync(dh_rec, dhT, bh, hipMemcpyDeviceToDevice, stream) : hipMemsetAsync(dh_rec, 0, bh, stream);
+        if (e == hipSuccess) e = dcT ? hipMemcpyAsync(dc, dcT, bh, hipMemcpyDeviceToDevice, stream) : hipMemsetAsync(dc, 0, bh, stream);
+        if (e != hipSuccess) { set_error("lstm_seq_bwd init: %s", hipGetErrorString(e)); return FOV_ERR_LAUNCH; }
+        const long nelem = (long)B * H;
+        const dim3 pgrid((unsigned)((nelem + 255) / 256));
+        for (int t = T - 1; t >= 0; --t) {
+            if (act == FOV_ACT_HARD_SIGMOID)
+                hipLaunchKernelGGL(lstm_bwd_pointwise<FOV_ACT_HARD_SIGMOID>, pgrid, dim3(256), 0, stream, reserve, c0, dhs,
+                                   dh_rec, dc, dz, B, T, H, t);
+            else
+                hipLaunchKernelGGL(lstm_bwd_pointwise<FOV_ACT_SIGMOID>, pgrid, dim3(256), 0, stream, reserve, c0, dhs, dh_rec,
+                                   dc, dz, B, T, H, t);
+            int rc = check_launch("lstm_bwd_pointwise");
+            if (rc) return rc;
+            // dh_rec (B,H) = dz_t (B,4H) . R^T :  A(m,k) = dz[m][t][k], B(k,n) = R[n][k]
+            GemmArgs g = {};
+            g.a = dz + (size_t)t * 4 * H; g.b = R; g.c = dh_rec;
+            g.M = B; g.N = H; g.KO = 1; g.KI = 4 * H;
+            g.a_sm = (long)T * 4 * H; g.a_sko = 0; g.a_ski = 1;
+            g.b_sn = 4 * H; g.b_sko = 0; g.b_ski = 1;
+            g.ldc = H;
+            rc = gemm_f32(g, 0, scratch, scratch_floats, stream);
+            if (rc) return rc;
+        }
+        if (dh0) { e = hipMemcpyAsync(dh0, dh_rec, bh, hipMemcpyDeviceToDevice, stream); if (e != hipSuccess) { set_error("dh0 copy"); return FOV_ERR_LAUNCH; } }
+        if (dc0) { e = hipMemcpyAsync(dc0, dc, bh, hipMemcpyDeviceToDevice, stream); if (e != hipSuccess) { set_error("dc0 copy"); return FOV_ERR_LAUNCH; } }
+    }
     int rc;
     const long BT = (long)B * T;
     if (dK) {   // dK (F,4H) = x^T dz : A(m=f,k=(b,t)) = x[k][f], B(k,n) = dz[k][n]

@@ -392,3 +392,49 @@ class OthersMixingSeq2Seq:
         return np.concatenate(outs, axis=0) if outs else np.zeros((0, T_out, O), np.float32)
 
     predict_on_batch = predict
+
+
+def convert_tf_lstmcell(W, b, forget_bias=1.0):
+    """tf.contrib.rnn.LSTMCell variables -> Keras layout used by the kernels.
+    W:(F+H,4H) fused kernel over [x, h] with gate columns i, j, f, o;  b:(4H).
+    Returns (K:(F,4H), R:(H,4H), b:(4H)) with gate columns i, f, c, o and the cell's forget_bias
+    folded into the f block (the kernels apply plain sigmoid, as LSTMCell does)."""
+    W, b = _as_f32(W), _as_f32(b)
+    H = b.shape[0] // 4
+    F = W.shape[0] - H
+    perm = np.concatenate([np.arange(0, H), np.arange(2 * H, 3 * H), np.arange(H, 2 * H), np.arange(3 * H, 4 * H)])
+    Wk = W[:, perm]
+    bk = b[perm].copy()
+    bk[H:2 * H] += np.float32(forget_bias)
+    return np.ascontiguousarray(Wk[:F]), np.ascontiguousarray(Wk[F:]), bk
+
+
+class StackedTFLSTM:
+    """MultiRNNCell([LSTMCell(n_hidden)] * num_layers) under tf.nn.dynamic_rnn with a fed initial state
+    (mycode/lstm.py:128-132,218-240), inference form (the DropoutWrapper is the identity at keep_prob 1).
+    predict(x (B,T,F), init_state (L,2,B,H) or None) -> (states_series (B,T,H), current_state (L,2,B,H));
+    state tuples are (c, h) as in LSTMStateTuple."""
+
+    def __init__(self, cells, forget_bias=1.0, impl="auto", device="cuda"):
+        self.layers = [convert_tf_lstmcell(W, b, forget_bias) for W, b in cells]
+        self.impl, self.device = impl, device
+        self._dw = None
+
+    def predict(self, x, init_state=None):
+        import torch
+        from . import ops
+        if self._dw is None:
+            self._dw = [tuple(torch.from_numpy(a).to(self.device) for a in layer) for layer in self.layers]
+            self._ws = ops.Workspace()
+        inp = torch.from_numpy(_as_f32(x)).to(self.device)
+        B = inp.shape[0]
+        st = None if init_state is None else torch.from_numpy(_as_f32(init_state)).to(self.device)
+        states = []
+        for l, (K, R, b) in enumerate(self._dw):
+            c0 = None if st is None else st[l, 0].contiguous()
+            h0 = None if st is None else st[l, 1].contiguous()
+            hs, hT, cT = ops.lstm_seq(inp, K, R, b, h0, c0, act="sigmoid", impl=self.impl, workspace=self._ws)
+            states.append(torch.stack([cT, hT], dim=0))
+            inp = hs
+        self._ws.check()
+        return inp.cpu().numpy(), torch.stack(states, dim=0).cpu().numpy()

@@ -194,8 +194,13 @@ class Scratch:
     def get(self, nbytes, device):
         nbytes = max(int(nbytes), 256)
         if self.buf is None or self.buf.numel() < nbytes or self.buf.device != device:
-            self.buf = torch.empty(nbytes + 256, dtype=torch.uint8, device=device)
+            self.buf = torch.zeros(nbytes + 256, dtype=torch.uint8, device=device)
         return self.buf
+
+    def check(self):
+        """Raise FovError(ERR_TIMEOUT) if the persistent BPTT kernel gave up a bounded wait."""
+        if self.buf is not None:
+            check(_lib.lib().fov_check_status(self.buf.data_ptr(), self.buf.numel(), _stream()))
 
 
 _default_scratch = Scratch()

@@ -352,3 +352,35 @@ def rmsprop_step(p, g, a, lr=1e-3, rho=0.9, eps=1e-7):
     """Keras-2.2 RMSprop: a = rho*a + (1-rho)*g^2; p -= lr * g / (sqrt(a) + eps).  In place."""
     a[...] = rho * a + (1 - rho) * g * g
     p[...] = p - lr * g / (np.sqrt(a) + eps)
+
+
+# --------------------------------------------------------------------------------------
+# a10: tf.contrib.rnn.LSTMCell / MultiRNNCell / tf.nn.dynamic_rnn as used by mycode/lstm.py:218-240
+# (TensorFlow 1.x contrib, not in the repo; restated from its published definition: one fused
+# kernel W:(F+H,4H) applied to [x, h], gate column order i, j(=g), f, o, plain sigmoid,
+# forget_bias added inside the cell, state tuple (c, h)).
+# --------------------------------------------------------------------------------------
+def tf_lstm_cell_step(x, c, h, W, b, forget_bias=1.0):
+    H = h.shape[1]
+    z = np.concatenate([x, h], axis=1) @ W + b
+    i, j, f, o = z[:, :H], z[:, H:2 * H], z[:, 2 * H:3 * H], z[:, 3 * H:]
+    c_new = sigmoid(f + forget_bias) * c + sigmoid(i) * np.tanh(j)
+    h_new = sigmoid(o) * np.tanh(c_new)
+    return c_new.astype(x.dtype), h_new.astype(x.dtype)
+
+
+def tf_dynamic_rnn(x, cells, init_state=None, forget_bias=1.0):
+    """cells: list of (W, b) per layer; init_state: (L,2,B,H) with [l,0]=c, [l,1]=h (lstm.py:128-132).
+    Returns (states_series (B,T,H) of the top layer, current_state (L,2,B,H))."""
+    B, T, _ = x.shape
+    L = len(cells)
+    H = cells[0][1].shape[0] // 4
+    st = np.zeros((L, 2, B, H), x.dtype) if init_state is None else init_state.astype(x.dtype).copy()
+    out = np.empty((B, T, H), x.dtype)
+    for t in range(T):
+        inp = x[:, t]
+        for l, (W, b) in enumerate(cells):
+            st[l, 0], st[l, 1] = tf_lstm_cell_step(inp, st[l, 0], st[l, 1], W, b, forget_bias)
+            inp = st[l, 1]
+        out[:, t] = inp
+    return out, st

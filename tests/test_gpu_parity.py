@@ -327,3 +327,29 @@ def test_matmul_and_zx_layer():
         hs, hT, cT = ops.lstm_seq_zx(zx, dev(R), dev(b), impl=impl)
         assert_parity(hs, ref[0], "zx layer hs " + impl)
         assert_parity(cT, ref[2], "zx layer cT " + impl)
+
+
+def test_tf_contrib_stacked_lstm_mapping():
+    """a10: MultiRNNCell[2 x LSTMCell(400)] + dynamic_rnn with a fed state (mycode/lstm.py:218-240)
+    through the Keras-layout kernels via convert_tf_lstmcell (gate order i,j,f,o -> i,f,c,o,
+    forget_bias folded into the bias).  Oracle = restated tf.contrib LSTMCell."""
+    from longterm360fov_amd.models import StackedTFLSTM
+    rng = np.random.default_rng(17)
+    for H, F, B, T in ((400, 90, 32, 10), (64, 90, 7, 3)):
+        cells = []
+        for l in range(2):
+            Fin = F if l == 0 else H
+            W = (rng.standard_normal((Fin + H, 4 * H)) / np.sqrt(Fin + H)).astype(np.float32)
+            b = (0.1 * rng.standard_normal(4 * H)).astype(np.float32)
+            cells.append((W, b))
+        x = rng.uniform(-1, 1, (B, T, F)).astype(np.float32)
+        st0 = (0.3 * rng.standard_normal((2, 2, B, H))).astype(np.float32)
+        ref_out, ref_st = O.tf_dynamic_rnn(x.astype(np.float64), [(W.astype(np.float64), b.astype(np.float64)) for W, b in cells],
+                                           st0.astype(np.float64))
+        m = StackedTFLSTM(cells)
+        out, st = m.predict(x, st0)
+        assert_parity(out, ref_out, "tf stacked LSTM H%d states_series" % H)
+        assert_parity(st, ref_st, "tf stacked LSTM H%d current_state" % H)
+        out0, _ = m.predict(x)                       # zero initial state
+        ref0, _ = O.tf_dynamic_rnn(x.astype(np.float64), [(W.astype(np.float64), b.astype(np.float64)) for W, b in cells])
+        assert_parity(out0, ref0, "tf stacked LSTM H%d zero state" % H)

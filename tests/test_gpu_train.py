@@ -207,3 +207,43 @@ def test_data_parallel_two_ranks_equal_single_process():
         d = np.abs(flat - ref_flat)
         assert d.max() <= 3e-3 and np.mean(d <= 2e-5) >= 0.995, (rank, d.max(), np.mean(d <= 2e-5))
     np.testing.assert_array_equal(res[0][2], res[1][2])     # replicas stay bit-identical
+
+
+def test_persistent_bptt_matches_stepped_and_oracle():
+    """The one-launch cluster BPTT kernel vs the host-stepped recurrence (FOV_BWD_STEPPED=1) and the
+    fp64 oracle: ragged multi-tile batch (more tiles than groups), given initial state, dhs + dhT/dcT."""
+    from longterm360fov_amd import ops
+    rng = np.random.default_rng(7)
+    for H, B, T in ((256, 16 * 64 + 16 * 3 + 5, 3), (128, 37, 6), (64, 21, 4)):
+        F = 11
+        K, R, b = O.init_lstm(rng, F, H, np.float32)
+        b = (b + 0.1 * rng.standard_normal(b.shape)).astype(np.float32)
+        x = rng.uniform(-1, 1, (B, T, F)).astype(np.float32)
+        h0 = (0.3 * rng.standard_normal((B, H))).astype(np.float32)
+        c0 = (0.3 * rng.standard_normal((B, H))).astype(np.float32)
+        dhs = (0.1 * rng.standard_normal((B, T, H))).astype(np.float32)
+        dhT = (0.1 * rng.standard_normal((B, H))).astype(np.float32)
+        dcT = (0.1 * rng.standard_normal((B, H))).astype(np.float32)
+        d64 = lambda a: a.astype(np.float64)
+        hs64, _, _, res64 = O.lstm_layer_train(d64(x), d64(K), d64(R), d64(b), d64(h0), d64(c0))
+        ref = O.lstm_layer_backward(d64(x), d64(K), d64(R), d64(h0), d64(c0), hs64, res64, d64(dhs), d64(dhT), d64(dcT))
+        hs, hT, cT, res = ops.lstm_seq_train(dev(x), dev(K), dev(R), dev(b), dev(h0), dev(c0))
+        outs = {}
+        try:
+            for mode in ("persistent", "stepped"):
+                if mode == "stepped":
+                    os.environ["FOV_BWD_STEPPED"] = "1"
+                sc = ops.Scratch()
+                outs[mode] = ops.lstm_seq_bwd(dev(x), dev(K), dev(R), hs, res, h0=dev(h0), c0=dev(c0), dhs=dev(dhs),
+                                              dhT=dev(dhT), dcT=dev(dcT), need_dx=True, need_state_grads=True, scratch=sc)
+                sc.check()
+        finally:
+            os.environ.pop("FOV_BWD_STEPPED", None)
+        for k in ("dz", "dx", "dK", "dR", "db", "dh0", "dc0"):
+            a = outs["persistent"][k].cpu().numpy().astype(np.float64)
+            s_ = outs["stepped"][k].cpu().numpy().astype(np.float64)
+            r = ref[k]
+            scale = np.abs(r).max()
+            print("H%d %-4s max|ref| %.3e  persistent err %.3e  stepped err %.3e" % (H, k, scale, np.abs(a - r).max(), np.abs(s_ - r).max()))
+            assert np.abs(a - r).max() <= 1e-4 * scale + 1e-9, (H, k)
+            assert np.abs(s_ - r).max() <= 1e-4 * scale + 1e-9, (H, k)

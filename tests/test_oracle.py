@@ -181,3 +181,18 @@ def test_adam_matches_torch_with_keras_epsilon_placement():
     a = np.zeros(50); q = rng.standard_normal(50); q0 = q.copy()
     O.rmsprop_step(q, g, a)
     np.testing.assert_allclose(q, q0 - 1e-3 * g / (np.sqrt(0.1 * g * g) + 1e-7), atol=1e-15)
+
+
+def test_tf_lstmcell_equals_keras_cell_after_mapping():
+    """The tf.contrib LSTMCell restatement and the Keras cell agree once the kernel is split, the
+    gate columns permuted (i,j,f,o -> i,f,c,o) and forget_bias folded into the bias."""
+    from longterm360fov_amd.models import convert_tf_lstmcell
+    rng = np.random.default_rng(2)
+    H, F, B = 5, 3, 4
+    W = rng.standard_normal((F + H, 4 * H)); b = rng.standard_normal(4 * H)
+    x = rng.standard_normal((B, F)); c = rng.standard_normal((B, H)); h = rng.standard_normal((B, H))
+    c1, h1 = O.tf_lstm_cell_step(x, c, h, W, b, forget_bias=1.0)
+    K, R, bk = convert_tf_lstmcell(W, b, 1.0)
+    h2, c2 = O.lstm_step(x, h, c, K.astype(np.float64), R.astype(np.float64), bk.astype(np.float64), "sigmoid")
+    np.testing.assert_allclose(h1, h2, atol=1e-6)
+    np.testing.assert_allclose(c1, c2, atol=1e-6)
