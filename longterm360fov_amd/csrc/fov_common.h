@@ -74,8 +74,8 @@ constexpr size_t kStatusBytes = 256;  // head of every workspace: status words
 bool bwd_cluster_shape_ok(int H);
 size_t bwd_cluster_xch_bytes(int B, int H);
 int launch_bwd_cluster(const float* R, const float* reserve, const float* c0, const float* dhs, const float* dhT,
-                       const float* dcT, float* dz, float* dh0, float* dc0, int B, int T, int H, int act, void* xch_ws,
-                       hipStream_t stream);
+                       const float* dcT, float* dz, float* dh0, float* dc0, float* db_part, int B, int T, int H, int act,
+                       void* xch_ws, hipStream_t stream);
 
 // training side (train_kernels.hip)
 size_t lstm_bwd_workspace_floats(int B, int T, int F, int H);

@@ -42,6 +42,7 @@ struct BwdParams {
     float* dz;              // (B,T,4H) out
     float* dh0;             // (B,H) or NULL
     float* dc0;             // (B,H) or NULL
+    float* db_part;         // (num_tiles, 4H) per-tile bias-gradient partials (sum over the tile's rows and t), or NULL
     unsigned long long* xch;
     unsigned* status;
     int B, T, H, num_groups, num_tiles;
@@ -133,6 +134,7 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_cluster_kernel(BwdParams p) {
         };
         load_step(p.T - 1, cur, dhs_cur);
         load_step(p.T - 2, nxt, dhs_nxt);
+        float dbacc[4] = {0.f, 0.f, 0.f, 0.f};   // sum over t and this lane's 4 sequences of dz, per gate
 
         for (int t = p.T - 1; t >= 0; --t) {
             // ---- pointwise: dz of this lane's four elements ----
@@ -149,6 +151,8 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_cluster_kernel(BwdParams p) {
                 dzv[2][r] = dcv * ig * (1.f - gg * gg);
                 dzv[3][r] = dht * tc * bwd_act_grad<ACT>(og);
                 dc[r] = dcv * fg;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) dbacc[g] += dzv[g][r];
                 if (live[r]) {
                     float* zp = p.dz + ((size_t)(b0 + 4 * g4 + r) * p.T + t) * 4 * H + unit;
                     zp[0] = dzv[0][r]; zp[H] = dzv[1][r]; zp[2 * H] = dzv[2][r]; zp[3 * H] = dzv[3][r];
@@ -262,6 +266,15 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_cluster_kernel(BwdParams p) {
                 dh[r] = acc;
             }
         }
+        if (!aborted && p.db_part) {
+            // the four g4 lane groups hold the same unit: fold them (fixed order), lanes with g4 == 0 store
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float v0 = dbacc[g];
+                const float v1 = __shfl(v0, n + 16), v2 = __shfl(v0, n + 32), v3 = __shfl(v0, n + 48);
+                if (g4 == 0) p.db_part[(size_t)tile * 4 * H + g * H + unit] = (v0 + v1) + (v2 + v3);
+            }
+        }
         if (!aborted) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -301,11 +314,11 @@ static int launch_bwd_h(const BwdParams& p, int act, hipStream_t stream) {
 
 // status word + granule buffers live at `xch_ws` (kStatusBytes + bwd_cluster_xch_bytes)
 int launch_bwd_cluster(const float* R, const float* reserve, const float* c0, const float* dhs, const float* dhT,
-                       const float* dcT, float* dz, float* dh0, float* dc0, int B, int T, int H, int act, void* xch_ws,
-                       hipStream_t stream) {
+                       const float* dcT, float* dz, float* dh0, float* dc0, float* db_part, int B, int T, int H, int act,
+                       void* xch_ws, hipStream_t stream) {
     if (B == 0 || T == 0) return FOV_OK;
     BwdParams p = {};
-    p.R = R; p.reserve = reserve; p.c0 = c0; p.dhs = dhs; p.dhT = dhT; p.dcT = dcT; p.dz = dz; p.dh0 = dh0; p.dc0 = dc0;
+    p.R = R; p.reserve = reserve; p.c0 = c0; p.dhs = dhs; p.dhT = dhT; p.dcT = dcT; p.dz = dz; p.dh0 = dh0; p.dc0 = dc0; p.db_part = db_part;
     p.B = B; p.T = T; p.H = H;
     p.num_tiles = (B + BBT - 1) / BBT;
     p.num_groups = cluster_num_groups(B, H);

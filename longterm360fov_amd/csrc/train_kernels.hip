@@ -190,9 +190,16 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
     const long r0 = (long)blockIdx.y * rows_per_chunk;
     long r1 = r0 + rows_per_chunk;
     if (r1 > rows) r1 = rows;
-    float s = 0.f;
-    for (long r = r0; r < r1; ++r) s += x[(size_t)r * cols + col];
-    part[(size_t)blockIdx.y * cols + col] = s;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    long r = r0;
+    for (; r + 4 <= r1; r += 4) {
+        s0 += x[(size_t)r * cols + col];
+        s1 += x[(size_t)(r + 1) * cols + col];
+        s2 += x[(size_t)(r + 2) * cols + col];
+        s3 += x[(size_t)(r + 3) * cols + col];
+    }
+    for (; r < r1; ++r) s0 += x[(size_t)r * cols + col];
+    part[(size_t)blockIdx.y * cols + col] = (s0 + s1) + (s2 + s3);
 }
 
 // Dense(tanh|linear) + Keras mean_squared_error: dpre = 2 (y - target) / n * act'(y); per-block
@@ -307,7 +314,7 @@ int gemm_f32(GemmArgs g, int accumulate, float* scratch, size_t scratch_floats, 
 int colsum(const float* x, float* out, long rows, int cols, int accumulate, float* scratch, size_t scratch_floats,
            hipStream_t stream) {
     if (cols <= 0) return FOV_OK;
-    int chunks = (int)((rows + 511) / 512);
+    int chunks = (int)((rows + 127) / 128);
     if (chunks < 1) chunks = 1;
     if (chunks > 256) chunks = 256;
     if ((size_t)chunks * cols > scratch_floats) { set_error("colsum: scratch too small"); return FOV_ERR_WORKSPACE; }
@@ -324,7 +331,7 @@ int colsum(const float* x, float* out, long rows, int cols, int accumulate, floa
 size_t lstm_bwd_workspace_floats(int B, int T, int F, int H) {
     // dh_rec (B,H) + dc (B,H) + split-K scratch for the largest weight-gradient GEMM / colsum
     size_t wg = (size_t)64 * (size_t)(F > H ? F : H) * 4 * H;   // split-K partials of dK / dR (<= 64 slices)
-    size_t cs = (size_t)256 * 4 * H;                             // colsum partials
+    size_t cs = (size_t)256 * 4 * H + (size_t)((B + 15) / 16) * 4 * H;   // colsum partials + per-tile db partials
     size_t st = (size_t)8 * B * H;                               // split-K partials of the per-step dh GEMM
     size_t m = wg > cs ? wg : cs;
     (void)T;
@@ -361,9 +368,18 @@ int lstm_seq_bwd(const float* x, const float* K, const float* R, const float* h0
     hipError_t e = hipSuccess;
     if (persistent) {
         // one launch for the whole recurrence: dz (B,T,4H), dh0, dc0
-        int rc = launch_bwd_cluster(R, reserve, c0, dhs, dhT, dcT, dz, dh0 ? dh0 : dh_rec, dc0 ? dc0 : dc, B, T, H, act, ws,
-                                    stream);
+        // bias gradient: per-tile partials from the kernel (db_part lives in the split-K scratch), summed below
+        float* db_part = db ? scratch : nullptr;
+        int rc = launch_bwd_cluster(R, reserve, c0, dhs, dhT, dcT, dz, dh0 ? dh0 : dh_rec, dc0 ? dc0 : dc, db_part, B, T, H,
+                                    act, ws, stream);
         if (rc) return rc;
+        if (db) {
+            const int tiles = (B + 15) / 16;
+            if ((size_t)tiles * 4 * H + (size_t)256 * 4 * H > scratch_floats) { set_error("lstm_seq_bwd: scratch too small for db"); return FOV_ERR_WORKSPACE; }
+            rc = colsum(db_part, db, tiles, 4 * H, accumulate, scratch + (size_t)tiles * 4 * H,
+                        scratch_floats - (size_t)tiles * 4 * H, stream);
+            if (rc) return rc;
+        }
     } else {
         e = hipMemsetAsync(ws, 0, 256, stream);   // status word of this workspace
         if (e == hipSuccess)
@@ -422,7 +438,7 @@ int lstm_seq_bwd(const float* x, const float* K, const float* R, const float* h0
             if (rc) return rc;
         }
     }
-    if (db) {
+    if (db && !persistent) {
         rc = colsum(dz, db, BT, 4 * H, accumulate, scratch, scratch_floats, stream);
         if (rc) return rc;
     }
