@@ -5,7 +5,7 @@
 // deterministic (no float atomics): split-K partials are summed in a fixed order.
 //
 // Kernels and the roofline that bounds each:
-//   gemm_f32_kernel       fp32 MFMA (v_mfma_f32_16x16x4_f32), LDS-tiled 128x128x16   - MFMA
+//   gemm_f32_kernel       fp32 MFMA (v_mfma_f32_16x16x4_f32), LDS-tiled (32|96|128) x (256|128) x 16 - MFMA
 //   splitk_reduce_kernel  sums S partial C tiles                                     - HBM
 //   lstm_bwd_pointwise    dz_t, dc from the reserve (24 B read + 16 B written/elem)   - HBM
 //   colsum_*              bias gradients                                             - HBM
@@ -36,68 +36,78 @@ struct GemmArgs {
     int k_per_split; // multiple of 16
 };
 
-constexpr int GBM = 128, GBN = 128, GBK = 16, GLD = GBM + 4;
+constexpr int GBK = 16;
 
-// 128x128x16 block tile, 4 waves as 2x2, each wave 64x64 = 4x4 MFMA tiles (64 accumulator
-// registers); LDS tiles are k-major ([k][m], [k][n]) so a fragment read is 16 consecutive floats
-// per k and every k-step costs 8 LDS reads for 16 MFMAs.  Global->LDS staging goes through
-// registers one k-tile ahead (loads of tile k+1 are issued before the MFMAs of tile k).
+// Block tile BM x BN x 16 with BM = 16*MI*WAVES_M, BN = 16*NI*(4/WAVES_M); each of the 4 waves owns
+// MI x NI MFMA tiles.  LDS tiles are k-major ([k][m], [k][n]) so a fragment read is 16 consecutive
+// floats per k.  Global->LDS staging goes through registers one k-tile ahead, with the (ko, ki)
+// split of every staged element advanced incrementally (no integer division in the loop: fp32 MFMA
+// shares the VALU, so staging arithmetic is paid for in MFMA slots).
+template <int MI, int NI, int WAVES_M>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
-    __shared__ __attribute__((aligned(16))) float As[2][GBK][GLD];
-    __shared__ __attribute__((aligned(16))) float Bs[2][GBK][GLD];
+    constexpr int WAVES_N = 4 / WAVES_M;
+    constexpr int BM = 16 * MI * WAVES_M, BN = 16 * NI * WAVES_N;
+    constexpr int RA = BM / 16, RB = BN / 16;   // staged elements per thread per k-tile
+    __shared__ __attribute__((aligned(16))) float As[2][GBK][BM + 4];
+    __shared__ __attribute__((aligned(16))) float Bs[2][GBK][BN + 4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int m0 = blockIdx.y * GBM, n0 = blockIdx.x * GBN;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
     const int K = g.KO * g.KI;
     const int kbeg = blockIdx.z * g.k_per_split;
     int kend = kbeg + g.k_per_split;
     if (kend > K) kend = K;
-    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    const int wm = (wave / WAVES_N) * 16 * MI, wn = (wave % WAVES_N) * 16 * NI;
     const int li = lane & 15, lq = lane >> 4;
 
-    f32x4 acc[4][4];
+    f32x4 acc[MI][NI];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // staging: element e = tid + 256*r (r < 8) of a 128x16 tile.  If k is the contiguous index in
-    // memory consecutive threads walk k (16-wide rows), else they walk m / n.
+    // element e = tid + 256*r of a (rows x 16) tile.  k-fast operands: consecutive threads walk k;
+    // otherwise they walk the row index.
     const bool a_kfast = (g.a_ski == 1), b_kfast = (g.b_ski == 1);
-    float ra[8], rb[8];
-    auto fetch = [&](int k0) {
+    int a_mm[RA], a_kk[RA], a_ko[RA], a_ki[RA];
+    int b_nn[RB], b_kk[RB], b_ko[RB], b_ki[RB];
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            const int e = tid + 256 * r;
-            int mm, kk;
-            if (a_kfast) { mm = e >> 4; kk = e & 15; } else { kk = e >> 7; mm = e & 127; }
-            const int k = k0 + kk, m = m0 + mm;
-            float v = 0.f;
-            if (m < g.M && k < kend) {
-                const int ko = k / g.KI, ki = k - ko * g.KI;
-                v = g.a[(long)m * g.a_sm + (long)ko * g.a_sko + (long)ki * g.a_ski];
-            }
-            ra[r] = v;
-            int nn, kb;
-            if (b_kfast) { nn = e >> 4; kb = e & 15; } else { kb = e >> 7; nn = e & 127; }
-            const int k2 = k0 + kb, n = n0 + nn;
-            float u = 0.f;
-            if (n < g.N && k2 < kend) {
-                const int ko = k2 / g.KI, ki = k2 - ko * g.KI;
-                u = g.b[(long)n * g.b_sn + (long)ko * g.b_sko + (long)ki * g.b_ski];
-            }
-            rb[r] = u;
+    for (int r = 0; r < RA; ++r) {
+        const int e = tid + 256 * r;
+        if (a_kfast) { a_mm[r] = e >> 4; a_kk[r] = e & 15; } else { a_kk[r] = e / BM; a_mm[r] = e - a_kk[r] * BM; }
+        const int k = kbeg + a_kk[r];
+        a_ko[r] = k / g.KI; a_ki[r] = k - a_ko[r] * g.KI;
+    }
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+        const int e = tid + 256 * r;
+        if (b_kfast) { b_nn[r] = e >> 4; b_kk[r] = e & 15; } else { b_kk[r] = e / BN; b_nn[r] = e - b_kk[r] * BN; }
+        const int k = kbeg + b_kk[r];
+        b_ko[r] = k / g.KI; b_ki[r] = k - b_ko[r] * g.KI;
+    }
+    float ra[RA], rb[RB];
+    auto fetch = [&](int k0) {   // loads the tile starting at k0, then advances the (ko, ki) state by 16
+#pragma unroll
+        for (int r = 0; r < RA; ++r) {
+            const int m = m0 + a_mm[r];
+            ra[r] = (m < g.M && k0 + a_kk[r] < kend)
+                        ? g.a[(long)m * g.a_sm + (long)a_ko[r] * g.a_sko + (long)a_ki[r] * g.a_ski] : 0.f;
+            a_ki[r] += GBK;
+            while (a_ki[r] >= g.KI) { a_ki[r] -= g.KI; ++a_ko[r]; }
+        }
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+            const int n = n0 + b_nn[r];
+            rb[r] = (n < g.N && k0 + b_kk[r] < kend)
+                        ? g.b[(long)n * g.b_sn + (long)b_ko[r] * g.b_sko + (long)b_ki[r] * g.b_ski] : 0.f;
+            b_ki[r] += GBK;
+            while (b_ki[r] >= g.KI) { b_ki[r] -= g.KI; ++b_ko[r]; }
         }
     };
     auto stash = [&](int buf) {
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            const int e = tid + 256 * r;
-            int mm, kk, nn, kb;
-            if (a_kfast) { mm = e >> 4; kk = e & 15; } else { kk = e >> 7; mm = e & 127; }
-            if (b_kfast) { nn = e >> 4; kb = e & 15; } else { kb = e >> 7; nn = e & 127; }
-            As[buf][kk][mm] = ra[r];
-            Bs[buf][kb][nn] = rb[r];
-        }
+        for (int r = 0; r < RA; ++r) As[buf][a_kk[r]][a_mm[r]] = ra[r];
+#pragma unroll
+        for (int r = 0; r < RB; ++r) Bs[buf][b_kk[r]][b_nn[r]] = rb[r];
     };
     int buf = 0;
     if (kbeg < kend) {
@@ -110,15 +120,15 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
         if (more) fetch(k0 + GBK);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            float av[4], bv[4];
+            float av[MI], bv[NI];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) av[i] = As[buf][ks * 4 + lq][wm + i * 16 + li];
+            for (int i = 0; i < MI; ++i) av[i] = As[buf][ks * 4 + lq][wm + i * 16 + li];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) bv[j] = Bs[buf][ks * 4 + lq][wn + j * 16 + li];
+            for (int j = 0; j < NI; ++j) bv[j] = Bs[buf][ks * 4 + lq][wn + j * 16 + li];
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < MI; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < NI; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[j], acc[i][j], 0, 0, 0);
         }
         if (more) stash(buf ^ 1);
@@ -127,9 +137,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
     }
     float* c = g.c + (g.split > 1 ? (size_t)blockIdx.z * g.M * g.ldc : 0);
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < NI; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int m = m0 + wm + i * 16 + lq * 4 + r, n = n0 + wn + j * 16 + li;
@@ -280,7 +290,12 @@ int gemm_f32(GemmArgs g, int accumulate, float* scratch, size_t scratch_floats, 
         return FOV_OK;
     }
     const size_t mn = (size_t)g.M * g.N;
-    const int tiles = ((g.M + GBM - 1) / GBM) * ((g.N + GBN - 1) / GBN);
+    // tile shape by M: short-and-wide weight-gradient products (M = F or Out) would waste a 128-row tile
+    int BM, BN, variant;
+    if (g.M <= 32) { BM = 32; BN = 256; variant = 0; }
+    else if (g.M <= 96) { BM = 96; BN = 256; variant = 1; }
+    else { BM = 128; BN = 128; variant = 2; }
+    const int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
     int split = 1;
     if (tiles < 256 && K >= 512) {
         split = (512 + tiles - 1) / tiles;
@@ -302,8 +317,10 @@ int gemm_f32(GemmArgs g, int accumulate, float* scratch, size_t scratch_floats, 
     }
     g.split = split;
     g.k_per_split = (int)kps;
-    const dim3 grid((g.N + GBN - 1) / GBN, (g.M + GBM - 1) / GBM, split);
-    hipLaunchKernelGGL(gemm_f32_kernel, grid, dim3(256), 0, stream, g);
+    const dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, split);
+    if (variant == 0) hipLaunchKernelGGL((gemm_f32_kernel<2, 4, 1>), grid, dim3(256), 0, stream, g);
+    else if (variant == 1) hipLaunchKernelGGL((gemm_f32_kernel<6, 4, 1>), grid, dim3(256), 0, stream, g);
+    else hipLaunchKernelGGL((gemm_f32_kernel<4, 4, 2>), grid, dim3(256), 0, stream, g);
     int rc = check_launch("gemm_f32");
     if (rc || !via_scratch) return rc;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((mn + 255) / 256)), dim3(256), 0, stream, scratch, c_final, (long)mn,
