@@ -109,6 +109,9 @@ def main():
     ap.add_argument("--impl", default="auto", choices=["auto", "cluster", "generic"])
     ap.add_argument("--act", default="sigmoid", choices=["sigmoid", "hard_sigmoid"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the N > 1 path "
+                         "with several ranks on ONE GPU)")
     ap.add_argument("--mode", default="infer", choices=["infer", "train"],
                     help="infer (default, the BASELINE metric): encoder + autoregressive decoder; train: one "
                          "teacher-forced training step (fwd + BPTT + Adam, data-parallel all-reduce when N > 1)")
@@ -118,11 +121,15 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     use_dist = world > 1
-    torch.cuda.set_device(local_rank)
+    device_index = local_rank % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(device_index)
     if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group("gloo")
 
     from longterm360fov_amd import ops
     from oracle import fov_oracle as O   # synthetic data + Keras initialisers (test infrastructure)
