@@ -195,6 +195,27 @@ int fov_adam_step(float* params, const float* grads, float* m, float* v, int64_t
 int fov_rmsprop_step(float* params, const float* grads, float* accum, int64_t n,
                      float lr, float rho, float eps, fov_stream_t stream);
 
+/* =======================================================================================
+ * ConvLSTM2D seq2seq building blocks (a8/a9) - mycode/convlstm_seq2seq.py:100-126,146-165 (ConvLSTM2D),
+ * :170-189,224-258 (Conv2D / Conv1D heads, channel Softmax).  NHWC activations, Keras kernel layout
+ * (kh,kw,C,N), zero 'same' padding, stride 1, dilation 1, odd kernel sizes.
+ * ===================================================================================== */
+
+/* y (B,H,W,N) = act(conv2d_same(x, w) + b + add);  x pixels may be strided (x_pixel_stride >= C floats) so a
+ * layer can read its input from a slot of a channel-concatenated map; b, add (B,H,W,N) may be NULL; add may
+ * alias y.  activation: 0 none, 2 relu.  A Conv1D(k) over (B,W,C) is kh = 1, kw = k, H = 1. */
+int fov_conv2d_fwd(const float* x, int64_t x_pixel_stride, const float* w, const float* b, const float* add,
+                   float* y, int B, int H, int W, int C, int N, int kh, int kw, int activation,
+                   fov_stream_t stream);
+
+/* ConvLSTM2DCell gates on z (rows, 4F) = conv(x,K)+b+conv(h,R), channel blocks i,f,c,o; c (rows,F) is
+ * updated in place; h is written with pixel stride h_pixel_stride >= F. */
+int fov_convlstm_gates(const float* z, float* c, float* h, int64_t h_pixel_stride, int64_t rows, int F,
+                       int act, fov_stream_t stream);
+
+/* Softmax over the last dimension of (rows, n) - keras.layers.Softmax(axis=-1), convlstm_seq2seq.py:236. */
+int fov_softmax_lastdim(const float* x, float* y, int64_t rows, int n, fov_stream_t stream);
+
 /* Synchronises `stream`, reads the status word a persistent-kernel call left in `workspace`
  * and returns FOV_OK or FOV_ERR_TIMEOUT.  Workspaces of non-persistent calls report FOV_OK. */
 int fov_check_status(const void* workspace, size_t workspace_bytes, fov_stream_t stream);

@@ -438,3 +438,79 @@ class StackedTFLSTM:
             inp = hs
         self._ws.check()
         return inp.cpu().numpy(), torch.stack(states, dim=0).cpu().numpy()
+
+
+class ConvLSTMSeq2Seq:
+    """ConvLSTM2D seq2seq (mycode/convlstm_seq2seq.py:100-282): 3-layer ConvLSTM2D encoder (filters
+    2L, L, L/2, k x k, padding 'same'), mirrored decoder unrolled `predict_step` times with state hand-off,
+    channel concat of the three layer outputs, head, output fed back as the next input.
+      head 'conv2d' (cfg.use_one_hot, 36x18x30 maps): Conv2D 512 -> 1024 -> 30 (relu) + channel Softmax
+      head 'conv1d' (xyz mode, (1,30,3) "images"): Conv1D k=7 512 -> 1024 -> 3, relu, relu, softmax
+    predict([encoder_input (N,T_in,H,W,C), decoder_input (N,1,H,W,C)]) -> (N,T_out,H,W,C_out).
+    Inference only in round 1 (input dropout acts in training only).  Weights: dict with
+    enc{l}_K/R/b, dec{l}_K/R/b (Keras ConvLSTM2D layout (kh,kw,C,4F)) and head{i}_W/b."""
+
+    def __init__(self, weights, head="conv2d", recurrent_activation="hard_sigmoid", device="cuda"):
+        self.head, self.act, self.device = head, recurrent_activation, device
+        self._w = {k: _as_f32(v) for k, v in weights.items()}
+        self._dw = None
+
+    def predict(self, x, batch_size=None, predict_step=None, verbose=0):
+        import torch
+        from . import ops
+        enc, dec0 = _as_f32(x[0]), _as_f32(x[1])
+        T_out = cfg.predict_step if predict_step is None else int(predict_step)
+        if self._dw is None:
+            self._dw = {k: torch.from_numpy(v).to(self.device) for k, v in self._w.items()}
+        dw, act = self._dw, self.act
+        filters = [dw["enc%d_R" % l].shape[2] for l in range(3)]
+        cat = sum(filters)
+        offs = [0, filters[0], filters[0] + filters[1]]
+        n = enc.shape[0]
+        bs = n if not batch_size else int(batch_size)
+        outs = []
+        e4 = lambda *s: torch.empty(s, dtype=torch.float32, device=self.device)
+        for lo in range(0, n, max(bs, 1)):
+            xe = torch.from_numpy(enc[lo:lo + bs]).to(self.device)
+            inp = torch.from_numpy(dec0[lo:lo + bs, 0]).to(self.device)
+            B, T_in, H, W, _ = xe.shape
+            # encoder: layer l runs over the whole sequence of layer l-1 (return_sequences=True)
+            seq = [xe[:, t] for t in range(T_in)]
+            states = []
+            for l, F in enumerate(filters):
+                h = torch.zeros((B, H, W, F), dtype=torch.float32, device=self.device)
+                c = torch.zeros((B, H, W, F), dtype=torch.float32, device=self.device)
+                K, R, b = dw["enc%d_K" % l], dw["enc%d_R" % l], dw["enc%d_b" % l]
+                nxt = []
+                for t in range(T_in):
+                    z = ops.conv2d(seq[t].contiguous() if not seq[t].is_contiguous() else seq[t], K, b)
+                    z = ops.conv2d(h, R, None, add=z, out=z)
+                    hn = e4(B, H, W, F)
+                    ops.convlstm_gates(z, c, hn, act)
+                    h = hn
+                    nxt.append(h)
+                seq = nxt
+                states.append([h, c])
+            # decoder: three cells per step, each h written straight into its slot of the concat map
+            out = e4(B, T_out, H, W, dw["head2_W"].shape[3])
+            for t in range(T_out):
+                feat = e4(B, H, W, cat)
+                cur = inp
+                for l, F in enumerate(filters):
+                    K, R, b = dw["dec%d_K" % l], dw["dec%d_R" % l], dw["dec%d_b" % l]
+                    z = ops.conv2d(cur, K, b)
+                    z = ops.conv2d(states[l][0], R, None, add=z, out=z)
+                    hslot = feat[..., offs[l]:offs[l] + F]
+                    ops.convlstm_gates(z, states[l][1], hslot, act)
+                    states[l][0] = hslot
+                    cur = hslot
+                y = ops.conv2d(feat, dw["head0_W"], dw["head0_b"], activation="relu")
+                y = ops.conv2d(y, dw["head1_W"], dw["head1_b"], activation="relu")
+                y = ops.conv2d(y, dw["head2_W"], dw["head2_b"], activation="relu" if self.head == "conv2d" else None)
+                y = ops.softmax_lastdim(y)
+                out[:, t] = y
+                inp = y
+            outs.append(out.cpu().numpy())
+        return np.concatenate(outs, axis=0)
+
+    predict_on_batch = predict

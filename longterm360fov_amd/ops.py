@@ -317,3 +317,43 @@ def lstm_seq_zx(zx, R, b, h0=None, c0=None, act="sigmoid", impl="auto", return_s
                                 _ptr(hT), _ptr(cT), _ptr(reserve), B, T, H, act_code(act), impl, buf.data_ptr(),
                                 buf.numel(), _stream()))
     return hs, hT, cT
+
+
+# ---------------------------------------------------------------------------------------------
+# ConvLSTM2D seq2seq (a8/a9): building blocks
+# ---------------------------------------------------------------------------------------------
+def conv2d(x, w, b=None, add=None, activation=None, out=None, in_channels=None):
+    """y (B,H,W,N) = act(conv2d_same(x, w) + b + add).  x may be a channel slice view of a wider NHWC map
+    (only the last-dim stride may differ from dense: pass the view, pixel stride is taken from it)."""
+    assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.stride(3) == 1
+    B, H, W, C = x.shape
+    ldx = x.stride(2)
+    assert x.stride(1) == W * ldx and (B <= 1 or x.stride(0) == H * W * ldx), "x must be NHWC with a uniform pixel stride"
+    w = _dev(w, "w")
+    kh, kw, Cw, N = w.shape
+    assert Cw == C
+    y = torch.empty((B, H, W, N), dtype=torch.float32, device=x.device) if out is None else out
+    act = {None: 0, "linear": 0, "relu": 2}[activation]
+    check(_lib.lib().fov_conv2d_fwd(x.data_ptr(), ldx, _ptr(w), _ptr(_dev(b, "b")), _ptr(add), _ptr(y), B, H, W, C, N,
+                                    kh, kw, act, _stream()))
+    return y
+
+
+def convlstm_gates(z, c, h_out, act="hard_sigmoid"):
+    """Gates + cell update: z (B,H,W,4F), c (B,H,W,F) updated in place, h written into h_out, which may be
+    a channel-slice view of a concatenated feature map."""
+    z, c = _dev(z, "z"), _dev(c, "c")
+    F = c.shape[-1]
+    rows = c.numel() // F
+    assert h_out.is_cuda and h_out.stride(-1) == 1 and h_out.shape == c.shape
+    check(_lib.lib().fov_convlstm_gates(_ptr(z), _ptr(c), h_out.data_ptr(), h_out.stride(-2), rows, F, act_code(act),
+                                        _stream()))
+    return h_out, c
+
+
+def softmax_lastdim(x):
+    x = _dev(x, "x")
+    y = torch.empty_like(x)
+    n = x.shape[-1]
+    check(_lib.lib().fov_softmax_lastdim(_ptr(x), _ptr(y), x.numel() // n, n, _stream()))
+    return y

@@ -384,3 +384,118 @@ def tf_dynamic_rnn(x, cells, init_state=None, forget_bias=1.0):
             inp = st[l, 1]
         out[:, t] = inp
     return out, st
+
+
+# --------------------------------------------------------------------------------------
+# a8/a9: ConvLSTM2D seq2seq (mycode/convlstm_seq2seq.py:100-282).  Keras-2.2 ConvLSTM2DCell restated:
+#   x_g = conv2d(x, K_g, 'same') + b_g ;  h_g = conv2d(h, R_g, 'same')        (cross-correlation, NHWC)
+#   i = s(x_i+h_i); f = s(x_f+h_f); c' = f*c + i*tanh(x_c+h_c); o = s(x_o+h_o); h' = o*tanh(c')
+# kernel K:(kh,kw,C,4F), recurrent R:(kh,kw,F,4F), bias (4F), channel blocks i,f,c,o; s = hard_sigmoid
+# by default (the reference never overrides it).  Dropout 0.3 on the inputs acts in training only.
+# --------------------------------------------------------------------------------------
+def conv2d_same(x, w, b=None):
+    """x:(B,H,W,C), w:(kh,kw,C,N) -> (B,H,W,N); zero 'same' padding, stride 1, no kernel flip."""
+    B, H, W, C = x.shape
+    kh, kw, _, N = w.shape
+    ph, pw = (kh - 1) // 2, (kw - 1) // 2
+    xp = np.zeros((B, H + kh - 1, W + kw - 1, C), x.dtype)
+    xp[:, ph:ph + H, pw:pw + W] = x
+    out = np.zeros((B, H, W, N), x.dtype)
+    for dy in range(kh):
+        for dx in range(kw):
+            out += xp[:, dy:dy + H, dx:dx + W] @ w[dy, dx]
+    if b is not None:
+        out = out + b
+    return out.astype(x.dtype)
+
+
+def convlstm2d_step(x, h, c, K, R, b, act="hard_sigmoid"):
+    F = R.shape[2]
+    z = conv2d_same(x, K, b) + conv2d_same(h, R)
+    s = _rec_act(act)
+    i, f, g, o = s(z[..., :F]), s(z[..., F:2 * F]), np.tanh(z[..., 2 * F:3 * F]), s(z[..., 3 * F:])
+    c_new = f * c + i * g
+    return (o * np.tanh(c_new)).astype(x.dtype), c_new.astype(x.dtype)
+
+
+def convlstm2d_layer(x, K, R, b, h0=None, c0=None, act="hard_sigmoid"):
+    """x:(B,T,H,W,C) -> (hs:(B,T,H,W,F), h_T, c_T)."""
+    B, T, H, W, _ = x.shape
+    F = R.shape[2]
+    h = np.zeros((B, H, W, F), x.dtype) if h0 is None else h0
+    c = np.zeros((B, H, W, F), x.dtype) if c0 is None else c0
+    hs = np.empty((B, T, H, W, F), x.dtype)
+    for t in range(T):
+        h, c = convlstm2d_step(x[:, t], h, c, K, R, b, act)
+        hs[:, t] = h
+    return hs, h, c
+
+
+def softmax_last(x):
+    e = np.exp(x - x.max(axis=-1, keepdims=True))
+    return (e / e.sum(axis=-1, keepdims=True)).astype(x.dtype)
+
+
+def convlstm_seq2seq_forward(enc_in, dec_in0, w, T_out, head="conv2d", act="hard_sigmoid"):
+    """3-layer ConvLSTM2D encoder, mirrored decoder unrolled T_out times with state hand-off, channel
+    concat of the three layer outputs, head, output fed back (convlstm_seq2seq.py:100-126,146-165,209-282).
+      head 'conv2d' (cfg.use_one_hot): Conv2D -> Conv2D -> Conv2D (relu each) + channel softmax
+      head 'conv1d' (xyz mode, H == 1): Conv1D k=7 relu, relu, softmax over the 3 output channels
+    enc_in:(B,T_in,H,W,C)  dec_in0:(B,1,H,W,C)  ->  (B,T_out,H,W,Cout)."""
+    x = enc_in
+    states = []
+    for l in range(3):
+        x, h, c = convlstm2d_layer(x, w["enc%d_K" % l], w["enc%d_R" % l], w["enc%d_b" % l], act=act)
+        states.append((h, c))
+    inp = dec_in0[:, 0]
+    outs = []
+    for _ in range(T_out):
+        feats = []
+        cur = inp
+        for l in range(3):
+            h, c = convlstm2d_step(cur, states[l][0], states[l][1], w["dec%d_K" % l], w["dec%d_R" % l], w["dec%d_b" % l], act)
+            states[l] = (h, c)
+            feats.append(h)
+            cur = h
+        y = np.concatenate(feats, axis=-1)
+        y = np.maximum(conv2d_same(y, w["head0_W"], w["head0_b"]), 0)
+        y = np.maximum(conv2d_same(y, w["head1_W"], w["head1_b"]), 0)
+        y = conv2d_same(y, w["head2_W"], w["head2_b"])
+        if head == "conv2d":
+            y = softmax_last(np.maximum(y, 0))        # relu in the layer, then Softmax(axis=-1)
+        else:
+            y = softmax_last(y)                       # Conv1D(..., activation='softmax')
+        outs.append(y)
+        inp = y
+    return np.stack(outs, axis=1)
+
+
+def init_convlstm_seq2seq(seed, C=30, latent_dim=16, k=5, head="conv2d", head_filters=(512, 1024), dtype=np.float32):
+    """Keras initialisers: glorot_uniform kernels (fan = receptive field x channels), orthogonal recurrent
+    kernels (flattened), unit forget bias."""
+    rng = np.random.default_rng(seed)
+    filters = (latent_dim * 2, latent_dim, latent_dim // 2)
+    kh, kw = (k, k) if head == "conv2d" else (k, k)
+    w = {}
+
+    def glorot(shape):
+        rf = int(np.prod(shape[:-2]))
+        lim = np.sqrt(6.0 / (rf * shape[-2] + rf * shape[-1]))
+        return rng.uniform(-lim, lim, shape).astype(dtype)
+
+    for part in ("enc", "dec"):
+        cin = C
+        for l, F in enumerate(filters):
+            w["%s%d_K" % (part, l)] = glorot((kh, kw, cin, 4 * F))
+            w["%s%d_R" % (part, l)] = _orthogonal(rng, kh * kw * F, 4 * F, dtype).reshape(kh, kw, F, 4 * F)
+            b = (0.05 * rng.standard_normal(4 * F)).astype(dtype)
+            b[F:2 * F] += 1
+            w["%s%d_b" % (part, l)] = b
+            cin = F
+    cat = sum(filters)
+    hk = (k, k) if head == "conv2d" else (1, 7)
+    chans = (cat,) + tuple(head_filters) + ((C,) if head == "conv2d" else (3,))
+    for i in range(3):
+        w["head%d_W" % i] = glorot(hk + (chans[i], chans[i + 1]))
+        w["head%d_b" % i] = (0.05 * rng.standard_normal(chans[i + 1])).astype(dtype)
+    return w

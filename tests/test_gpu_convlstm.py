@@ -1,0 +1,91 @@
+"""GPU parity of the ConvLSTM2D path (a8/a9, mycode/convlstm_seq2seq.py) against the NumPy oracle:
+implicit-GEMM conv2d, ConvLSTM2D cell, channel softmax and the 3+3-layer seq2seq with both heads."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import fov_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+
+
+def close(got, ref, tag, tol=2e-5):
+    got = got.detach().cpu().numpy().astype(np.float64) if isinstance(got, torch.Tensor) else np.asarray(got, np.float64)
+    err = np.abs(got - ref)
+    scale = max(np.abs(ref).max(), 1e-6)
+    print("%s: max err %.3e (max |ref| %.3f)" % (tag, err.max(), scale))
+    assert got.shape == ref.shape and np.isfinite(got).all()
+    assert (err <= 1e-3 * np.abs(ref) + 1e-5 * scale).all(), tag
+    assert err.max() <= tol * scale, tag
+
+
+@pytest.mark.parametrize("B,H,W,C,N,kh,kw", [(2, 4, 5, 3, 7, 5, 5), (3, 36, 18, 30, 128, 5, 5), (2, 1, 30, 3, 128, 5, 5),
+                                             (2, 1, 30, 56, 40, 1, 7), (1, 6, 7, 17, 33, 3, 3), (2, 9, 4, 8, 64, 5, 5)])
+def test_conv2d_same(B, H, W, C, N, kh, kw):
+    from longterm360fov_amd import ops
+    rng = np.random.default_rng(B * 100 + N)
+    x = rng.standard_normal((B, H, W, C)).astype(np.float32)
+    w = (rng.standard_normal((kh, kw, C, N)) / np.sqrt(kh * kw * C)).astype(np.float32)
+    b = rng.standard_normal(N).astype(np.float32)
+    add = rng.standard_normal((B, H, W, N)).astype(np.float32)
+    ref = O.conv2d_same(x.astype(np.float64), w.astype(np.float64), b.astype(np.float64))
+    close(ops.conv2d(dev(x), dev(w), dev(b)), ref, "conv2d")
+    close(ops.conv2d(dev(x), dev(w), dev(b), add=dev(add), activation="relu"), np.maximum(ref + add, 0), "conv2d+add+relu")
+    # strided input: a channel slice of a wider map
+    wide = rng.standard_normal((B, H, W, C + 9)).astype(np.float32)
+    ref2 = O.conv2d_same(wide[..., 4:4 + C].astype(np.float64), w.astype(np.float64))
+    close(ops.conv2d(dev(wide)[..., 4:4 + C], dev(w)), ref2, "conv2d strided input")
+
+
+@pytest.mark.parametrize("act", ["hard_sigmoid", "sigmoid"])
+def test_convlstm_cell_and_softmax(act):
+    from longterm360fov_amd import ops
+    rng = np.random.default_rng(5)
+    B, H, W, C, F = 3, 6, 5, 4, 8
+    K = (rng.standard_normal((5, 5, C, 4 * F)) * 0.2).astype(np.float32)
+    R = (rng.standard_normal((5, 5, F, 4 * F)) * 0.2).astype(np.float32)
+    b = rng.standard_normal(4 * F).astype(np.float32)
+    x = rng.standard_normal((B, H, W, C)).astype(np.float32)
+    h = (0.5 * rng.standard_normal((B, H, W, F))).astype(np.float32)
+    c = (0.5 * rng.standard_normal((B, H, W, F))).astype(np.float32)
+    d = lambda a: a.astype(np.float64)
+    h_ref, c_ref = O.convlstm2d_step(d(x), d(h), d(c), d(K), d(R), d(b), act)
+    z = ops.conv2d(dev(x), dev(K), dev(b))
+    z = ops.conv2d(dev(h), dev(R), None, add=z, out=z)
+    cc = dev(c)
+    wide = torch.zeros((B, H, W, F + 5), dtype=torch.float32, device="cuda")
+    ops.convlstm_gates(z, cc, wide[..., 3:3 + F], act)
+    close(wide[..., 3:3 + F], h_ref, "convlstm h " + act)
+    close(cc, c_ref, "convlstm c " + act)
+    assert float(wide[..., :3].abs().max()) == 0 and float(wide[..., 3 + F:].abs().max()) == 0
+    y = rng.standard_normal((7, 3, 30)).astype(np.float32) * 3
+    close(ops.softmax_lastdim(dev(y)), O.softmax_last(d(y)), "softmax", tol=1e-6)
+
+
+@pytest.mark.parametrize("head,B,T_in,T_out,H,W,C,L,hf", [("conv2d", 2, 3, 2, 9, 6, 10, 8, (24, 40)),
+                                                           ("conv1d", 3, 4, 3, 1, 30, 3, 16, (32, 48)),
+                                                           ("conv2d", 1, 2, 2, 36, 18, 30, 16, (64, 96))])
+def test_convlstm_seq2seq(head, B, T_in, T_out, H, W, C, L, hf):
+    from longterm360fov_amd.models import ConvLSTMSeq2Seq
+    w = O.init_convlstm_seq2seq(3, C=C, latent_dim=L, head=head, head_filters=hf)
+    rng = np.random.default_rng(4)
+    if head == "conv2d":     # one-hot maps: one active cell per frame channel
+        enc = np.zeros((B, T_in, H, W, C), np.float32)
+        idx = rng.integers(0, H * W, (B, T_in, C))
+        for bb in range(B):
+            for t in range(T_in):
+                for ch in range(C):
+                    enc[bb, t].reshape(H * W, C)[idx[bb, t, ch], ch] = 1
+    else:
+        enc = O.synthetic_xyz(rng, B, T_in, 30).reshape(B, T_in, 1, 30, 3)
+    dec0 = enc[:, -1:]
+    d = lambda a: a.astype(np.float64)
+    ref = O.convlstm_seq2seq_forward(d(enc), d(dec0), {k: d(v) for k, v in w.items()}, T_out, head)
+    m = ConvLSTMSeq2Seq(w, head=head)
+    out = m.predict([enc, dec0], predict_step=T_out)
+    close(out, ref, "convlstm seq2seq " + head, tol=5e-5)
+    np.testing.assert_allclose(out.sum(-1), 1.0, atol=1e-5)
