@@ -201,11 +201,12 @@ int fov_rmsprop_step(float* params, const float* grads, float* accum, int64_t n,
  * (kh,kw,C,N), zero 'same' padding, stride 1, dilation 1, odd kernel sizes.
  * ===================================================================================== */
 
-/* y (B,H,W,N) = act(conv2d_same(x, w) + b + add);  x pixels may be strided (x_pixel_stride >= C floats) so a
- * layer can read its input from a slot of a channel-concatenated map; b, add (B,H,W,N) may be NULL; add may
- * alias y.  activation: 0 none, 2 relu.  A Conv1D(k) over (B,W,C) is kh = 1, kw = k, H = 1. */
-int fov_conv2d_fwd(const float* x, int64_t x_pixel_stride, const float* w, const float* b, const float* add,
-                   float* y, int B, int H, int W, int C, int N, int kh, int kw, int activation,
+/* y (B,H,W,N) = act(conv2d_same(x, w) + b + add);  x may be strided: x_pixel_stride >= C floats (a layer can
+ * read its input from a slot of a channel-concatenated map) and x_batch_stride >= H*W*x_pixel_stride (one time
+ * step of a (B,T,H,W,C) sequence); b, add (B,H,W,N) may be NULL; add may alias y.  activation: 0 none, 2 relu.
+ * A Conv1D(k) over (B,W,C) is kh = 1, kw = k, H = 1. */
+int fov_conv2d_fwd(const float* x, int64_t x_pixel_stride, int64_t x_batch_stride, const float* w, const float* b,
+                   const float* add, float* y, int B, int H, int W, int C, int N, int kh, int kw, int activation,
                    fov_stream_t stream);
 
 /* ConvLSTM2DCell gates on z (rows, 4F) = conv(x,K)+b+conv(h,R), channel blocks i,f,c,o; c (rows,F) is

@@ -13,13 +13,14 @@
 namespace fov {
 
 struct ConvArgs {
-    const float* x;     // (B,H,W,*) with pixel stride ldx >= C
+    const float* x;     // (B,H,W,*) with pixel stride ldx >= C and batch stride ldb >= H*W*ldx
     const float* w;     // (kh*kw*C, N)
     const float* bias;  // (N) or NULL
     const float* add;   // (B*H*W, N) or NULL (may alias y)
     float* y;           // (B*H*W, N)
     int B, H, W, C, N, kh, kw, act;   // act: 0 none, 2 relu
-    long ldx;
+    long ldx;   // pixel stride
+    long ldb;   // batch stride
 };
 
 template <int MI, int NI, int WAVES_M>
@@ -59,7 +60,7 @@ __global__ __launch_bounds__(256) void conv2d_igemm_kernel(ConvArgs g) {
         const int rem = (int)(mm - (long)b * g.H * g.W);
         a_y[r] = rem / g.W;
         a_x[r] = rem - a_y[r] * g.W;
-        a_base[r] = g.x + (long)b * g.H * g.W * g.ldx;
+        a_base[r] = g.x + (long)b * g.ldb;
         const int tap = a_kk / g.C;
         a_c[r] = a_kk - tap * g.C;
         a_dy[r] = tap / g.kw;
@@ -176,11 +177,11 @@ static int conv_check_launch(const char* what) {
     return FOV_OK;
 }
 
-int conv2d_fwd(const float* x, long ldx, const float* w, const float* bias, const float* add, float* y, int B, int H, int W,
-               int C, int N, int kh, int kw, int act, hipStream_t stream) {
+int conv2d_fwd(const float* x, long ldx, long ldb, const float* w, const float* bias, const float* add, float* y, int B, int H,
+               int W, int C, int N, int kh, int kw, int act, hipStream_t stream) {
     ConvArgs g = {};
     g.x = x; g.w = w; g.bias = bias; g.add = add; g.y = y;
-    g.B = B; g.H = H; g.W = W; g.C = C; g.N = N; g.kh = kh; g.kw = kw; g.act = act; g.ldx = ldx;
+    g.B = B; g.H = H; g.W = W; g.C = C; g.N = N; g.kh = kh; g.kw = kw; g.act = act; g.ldx = ldx; g.ldb = ldb;
     const long M = (long)B * H * W;
     if (M == 0 || N == 0) return FOV_OK;
     if (N <= 32) {

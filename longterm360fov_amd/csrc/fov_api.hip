@@ -408,14 +408,15 @@ int fov_check_status(const void* workspace, size_t workspace_bytes, fov_stream_t
     return FOV_OK;
 }
 
-int fov_conv2d_fwd(const float* x, int64_t x_pixel_stride, const float* w, const float* b, const float* add, float* y, int B,
-                   int H, int W, int C, int N, int kh, int kw, int activation, fov_stream_t stream) {
+int fov_conv2d_fwd(const float* x, int64_t x_pixel_stride, int64_t x_batch_stride, const float* w, const float* b,
+                   const float* add, float* y, int B, int H, int W, int C, int N, int kh, int kw, int activation,
+                   fov_stream_t stream) {
     if (B < 0 || H <= 0 || W <= 0 || C <= 0 || N <= 0 || kh <= 0 || kw <= 0 || (kh & 1) == 0 || (kw & 1) == 0 ||
-        x_pixel_stride < C || !w || (B > 0 && (!x || !y)) || (activation != 0 && activation != 2)) {
+        x_pixel_stride < C || x_batch_stride < (int64_t)H * W * x_pixel_stride || !w || (B > 0 && (!x || !y)) || (activation != 0 && activation != 2)) {
         set_error("fov_conv2d_fwd: invalid argument (odd kernel sizes only, activation 0 or 2)");
         return FOV_ERR_INVALID;
     }
-    return conv2d_fwd(x, (long)x_pixel_stride, w, b, add, y, B, H, W, C, N, kh, kw, activation, (hipStream_t)stream);
+    return conv2d_fwd(x, (long)x_pixel_stride, (long)x_batch_stride, w, b, add, y, B, H, W, C, N, kh, kw, activation, (hipStream_t)stream);
 }
 
 int fov_convlstm_gates(const float* z, float* c, float* h, int64_t h_pixel_stride, int64_t rows, int F, int act,

@@ -483,7 +483,7 @@ class ConvLSTMSeq2Seq:
                 K, R, b = dw["enc%d_K" % l], dw["enc%d_R" % l], dw["enc%d_b" % l]
                 nxt = []
                 for t in range(T_in):
-                    z = ops.conv2d(seq[t].contiguous() if not seq[t].is_contiguous() else seq[t], K, b)
+                    z = ops.conv2d(seq[t], K, b)
                     z = ops.conv2d(h, R, None, add=z, out=z)
                     hn = e4(B, H, W, F)
                     ops.convlstm_gates(z, c, hn, act)

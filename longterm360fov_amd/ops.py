@@ -328,13 +328,14 @@ def conv2d(x, w, b=None, add=None, activation=None, out=None, in_channels=None):
     assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.stride(3) == 1
     B, H, W, C = x.shape
     ldx = x.stride(2)
-    assert x.stride(1) == W * ldx and (B <= 1 or x.stride(0) == H * W * ldx), "x must be NHWC with a uniform pixel stride"
+    ldb = x.stride(0) if B > 1 else H * W * ldx
+    assert x.stride(1) == W * ldx and ldb >= H * W * ldx, "x must be NHWC with a uniform pixel stride"
     w = _dev(w, "w")
     kh, kw, Cw, N = w.shape
     assert Cw == C
     y = torch.empty((B, H, W, N), dtype=torch.float32, device=x.device) if out is None else out
     act = {None: 0, "linear": 0, "relu": 2}[activation]
-    check(_lib.lib().fov_conv2d_fwd(x.data_ptr(), ldx, _ptr(w), _ptr(_dev(b, "b")), _ptr(add), _ptr(y), B, H, W, C, N,
+    check(_lib.lib().fov_conv2d_fwd(x.data_ptr(), ldx, ldb, _ptr(w), _ptr(_dev(b, "b")), _ptr(add), _ptr(y), B, H, W, C, N,
                                     kh, kw, act, _stream()))
     return y
 

@@ -39,6 +39,10 @@ def test_conv2d_same(B, H, W, C, N, kh, kw):
     wide = rng.standard_normal((B, H, W, C + 9)).astype(np.float32)
     ref2 = O.conv2d_same(wide[..., 4:4 + C].astype(np.float64), w.astype(np.float64))
     close(ops.conv2d(dev(wide)[..., 4:4 + C], dev(w)), ref2, "conv2d strided input")
+    # one time step of a (B,T,H,W,C) sequence: batch stride != H*W*C
+    seq = rng.standard_normal((B, 3, H, W, C)).astype(np.float32)
+    ref3 = O.conv2d_same(seq[:, 1].astype(np.float64), w.astype(np.float64))
+    close(ops.conv2d(dev(seq)[:, 1], dev(w)), ref3, "conv2d batch-strided input")
 
 
 @pytest.mark.parametrize("act", ["hard_sigmoid", "sigmoid"])
