@@ -187,6 +187,12 @@ int fov_dense_bwd(const float* x, const float* W, const float* dpre, float* dx, 
 int fov_mse_dense_grad(const float* y, const float* target, float* dpre, float* loss, int64_t n,
                        int activation, void* workspace, size_t workspace_bytes, fov_stream_t stream);
 
+/* Backward of an elementwise activation given its OUTPUT y: out = base + dy * act'(y), act' = 1 - y^2 for tanh
+ * (activation 1) or 1 (activation 0); base may be NULL; out may alias base or dy.  Used where a Dense output is
+ * fed back as the next decoder input (given_others...py:292-293): the feedback gradient joins the loss gradient. */
+int fov_act_bwd(const float* dy, const float* y, const float* base, float* out, int64_t n, int activation,
+                fov_stream_t stream);
+
 /* Keras-2.2 optimizers on one flat parameter buffer.
  *   Adam   : lr_t = lr*sqrt(1-beta2^step)/(1-beta1^step); p -= lr_t*m/(sqrt(v)+eps)   (step >= 1)
  *   RMSprop: a = rho*a + (1-rho) g^2; p -= lr*g/(sqrt(a)+eps) */

@@ -241,6 +241,15 @@ int fov_mse_dense_grad(const float* y, const float* target, float* dpre, float* 
                           (hipStream_t)stream);
 }
 
+int fov_act_bwd(const float* dy, const float* y, const float* base, float* out, int64_t n, int activation,
+                fov_stream_t stream) {
+    if (n < 0 || (n > 0 && (!dy || !y || !out)) || (activation != 0 && activation != 1)) {
+        set_error("fov_act_bwd: invalid argument");
+        return FOV_ERR_INVALID;
+    }
+    return act_bwd(dy, y, base, out, (long)n, activation, (hipStream_t)stream);
+}
+
 int fov_adam_step(float* params, const float* grads, float* m, float* v, int64_t n, float lr, float beta1,
                   float beta2, float eps, int64_t step, fov_stream_t stream) {
     if (n < 0 || step < 1 || (n > 0 && (!params || !grads || !m || !v))) {

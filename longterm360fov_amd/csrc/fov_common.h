@@ -93,6 +93,7 @@ int dense_bwd(const float* x, const float* W, const float* dpre, float* dx, floa
               int accumulate, float* scratch, size_t scratch_floats, hipStream_t stream);
 int mse_dense_grad(const float* y, const float* target, float* dpre, float* loss, long n, int activation, float* scratch,
                    size_t scratch_floats, hipStream_t stream);
+int act_bwd(const float* dy, const float* y, const float* base, float* out, long n, int activation, hipStream_t stream);
 int matmul_f32(const float* a, const float* b, float* c, int M, int K, int N, float* scratch, size_t scratch_floats,
                hipStream_t stream);
 int adam_step(float* p, const float* g, float* m, float* v, long n, float lr_t, float b1, float b2, float eps,

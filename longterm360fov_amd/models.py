@@ -38,6 +38,67 @@ def _as_f32(a):
     return np.ascontiguousarray(a, dtype=np.float32)
 
 
+def _keras_fit(model, trainer, inputs, y, batch_size, epochs, validation_split, shuffle, callbacks, initial_epoch,
+               validation_data):
+    """Keras `Model.fit` loop shared by the model objects: the LAST `validation_split` fraction is held out
+    BEFORE shuffling, train indices are permuted every epoch (np.random), the last partial batch is used,
+    callbacks see {'loss','val_loss','lr'}.  Under torch.distributed every rank takes its contiguous shard
+    of each global batch (one gradient all-reduce per step inside trainer.train_step)."""
+    import torch
+    from . import parallel
+    from .callbacks import History
+    inputs = [_as_f32(a) for a in inputs]
+    tgt = _as_f32(y)
+    n = inputs[0].shape[0]
+    val = None
+    n_train = n
+    if validation_data is not None:
+        val = ([_as_f32(a) for a in validation_data[0]], _as_f32(validation_data[1]))
+    elif validation_split and 0.0 < validation_split < 1.0:
+        n_train = int(n * (1.0 - validation_split))
+        val = ([a[n_train:] for a in inputs], tgt[n_train:])
+    hist = History()
+    cbs = [hist] + list(callbacks or [])
+    for cb in cbs:
+        cb.set_model(model)
+        cb.on_train_begin()
+    model.stop_training = False
+    rank, world = parallel.world()
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(model.device)
+    for epoch in range(initial_epoch, epochs):
+        idx = np.arange(n_train)
+        if shuffle:
+            np.random.shuffle(idx)
+        tot, cnt = 0.0, 0
+        for lo in range(0, n_train, batch_size):
+            gidx = idx[lo:lo + batch_size]
+            a, b = parallel.shard_range(len(gidx), rank, world)
+            lidx = gidx[a:b]
+            loss = trainer.train_step(*[d(arr[lidx]) for arr in inputs], d(tgt[lidx]), n_global=len(gidx))
+            tot += float(loss.item()) * len(gidx)
+            cnt += len(gidx)
+        logs = {"loss": tot / max(cnt, 1), "lr": trainer.lr}
+        if val is not None and len(val[1]):
+            vt, vc = 0.0, 0
+            for lo in range(0, len(val[1]), max(batch_size, 1)):
+                sl = slice(lo, lo + batch_size)
+                k = len(val[1][sl])
+                vt += float(trainer.eval_loss(*[d(arr[sl]) for arr in val[0]], d(val[1][sl])).item()) * k
+                vc += k
+            logs["val_loss"] = vt / vc
+        model._w = trainer.weights_numpy()
+        model._dw = None
+        for cb in cbs:
+            cb.on_epoch_end(epoch, logs)
+        if model.stop_training:
+            break
+    for cb in cbs:
+        cb.on_train_end()
+    trainer.ws.check()
+    trainer.bwd_scratch.check()
+    return hist
+
+
 class _SubModel:
     def __init__(self, fn):
         self._fn = fn
@@ -208,72 +269,15 @@ class Seq2SeqLSTM:
 
     def fit(self, x, y, batch_size=32, epochs=1, validation_split=0.0, shuffle=True, callbacks=None,
             initial_epoch=0, verbose=0, validation_data=None):
-        """Keras `Model.fit` semantics (FoV_seq2seq.py:112-117): the LAST `validation_split` fraction is
-        held out BEFORE shuffling; train indices are permuted every epoch (np.random); the last
-        partial batch is used; callbacks see {'loss','val_loss','lr'} per epoch.  Under
-        torch.distributed every rank takes its contiguous shard of each global batch and gradients
-        are combined with one all-reduce per step.  Returns a History."""
-        import torch
-        from . import parallel
-        from .callbacks import History
+        """Keras `Model.fit` (FoV_seq2seq.py:112-117); see _keras_fit for the semantics.  Returns a History."""
         from .training import Seq2SeqTrainer
         if self.optimizer is None:
             raise RuntimeError("call compile() before fit()")
-        enc, dec_in = _as_f32(x[0]), _as_f32(x[1])
-        tgt = _as_f32(y)
-        n = enc.shape[0]
-        if validation_data is not None:
-            (venc, vdec), vtgt = validation_data
-            venc, vdec, vtgt = _as_f32(venc), _as_f32(vdec), _as_f32(vtgt)
-            n_train = n
-        elif validation_split and 0.0 < validation_split < 1.0:
-            n_train = int(n * (1.0 - validation_split))
-            venc, vdec, vtgt = enc[n_train:], dec_in[n_train:], tgt[n_train:]
-        else:
-            n_train, venc = n, None
-        if getattr(self, "_trainer", None) is None:
+        if self._trainer is None:
             self._trainer = Seq2SeqTrainer(self._w, act=self.recurrent_activation, impl=self.impl,
-                                           optimizer=self.optimizer, lr=getattr(self, "_lr", 1e-3), device=self.device)
-            self._lr = self._trainer.lr
-        tr = self._trainer
-        hist = History()
-        cbs = [hist] + list(callbacks or [])
-        for cb in cbs:
-            cb.set_model(self)
-            cb.on_train_begin()
-        self.stop_training = False
-        rank, world = parallel.world()
-        d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
-        for epoch in range(initial_epoch, epochs):
-            idx = np.arange(n_train)
-            if shuffle:
-                np.random.shuffle(idx)
-            tot, cnt = 0.0, 0
-            for lo in range(0, n_train, batch_size):
-                gidx = idx[lo:lo + batch_size]
-                a, b = parallel.shard_range(len(gidx), rank, world)
-                lidx = gidx[a:b]
-                loss = tr.train_step(d(enc[lidx]), d(dec_in[lidx]), d(tgt[lidx]), n_global=len(gidx))
-                tot += float(loss.item()) * len(gidx)
-                cnt += len(gidx)
-            logs = {"loss": tot / max(cnt, 1), "lr": tr.lr}
-            if venc is not None and len(venc):
-                vt, vc = 0.0, 0
-                for lo in range(0, len(venc), max(batch_size, 1)):
-                    sl = slice(lo, lo + batch_size)
-                    vt += float(tr.eval_loss(d(venc[sl]), d(vdec[sl]), d(vtgt[sl])).item()) * len(venc[sl])
-                    vc += len(venc[sl])
-                logs["val_loss"] = vt / vc
-            self._w = tr.weights_numpy()
-            self._dw = None
-            for cb in cbs:
-                cb.on_epoch_end(epoch, logs)
-            if self.stop_training:
-                break
-        for cb in cbs:
-            cb.on_train_end()
-        tr.ws.check()
-        return hist
+                                           optimizer=self.optimizer, lr=self._lr, device=self.device)
+        return _keras_fit(self, self._trainer, [x[0], x[1]], y, batch_size, epochs, validation_split, shuffle, callbacks,
+                          initial_epoch, validation_data)
 
     def train_on_batch(self, x, y):
         import torch
@@ -320,6 +324,7 @@ class OthersMixingSeq2Seq:
         w["dense_W"], w["dense_b"] = glorot_uniform(rng, H, O), np.zeros(O, np.float32)
         w["mix_W"], w["mix_b"] = glorot_uniform(rng, self.num_user * O, O), np.zeros(O, np.float32)
         self._w, self._dw, self._ws = w, None, None
+        self._trainer, self._lr, self.optimizer, self.loss, self.stop_training = None, 1e-3, None, None, False
 
     def get_weights(self):
         return [self._w[k].copy() for k in _MIX_ORDER]
@@ -344,6 +349,87 @@ class OthersMixingSeq2Seq:
 
     def count_params(self):
         return int(sum(v.size for v in self._w.values()))
+
+    # ---- training surface (given_others...py:308 compile, :494-506 fit / fit_generator) ----
+    @property
+    def lr(self):
+        return self._lr
+
+    @lr.setter
+    def lr(self, value):
+        self._lr = float(value)
+        if self._trainer is not None:
+            self._trainer.lr = self._lr
+
+    def compile(self, optimizer="Adam", loss="mean_squared_error", metrics=None):
+        opt = optimizer if isinstance(optimizer, str) else getattr(optimizer, "name", str(optimizer))
+        if opt.lower() not in ("adam", "rmsprop") or str(loss).lower() not in ("mean_squared_error", "mse"):
+            raise ValueError("unsupported optimizer/loss %r / %r" % (optimizer, loss))
+        self.optimizer, self.loss, self.metrics = opt.lower(), "mse", list(metrics or [])
+
+    def _get_trainer(self):
+        from .training import OthersMixingTrainer
+        if self._trainer is None:
+            self._trainer = OthersMixingTrainer(self._w, act=self.recurrent_activation, impl=self.impl,
+                                                optimizer=self.optimizer or "adam", lr=self._lr, device=self.device)
+        return self._trainer
+
+    def fit(self, x, y, batch_size=32, epochs=1, validation_split=0.0, shuffle=True, callbacks=None,
+            initial_epoch=0, verbose=0, validation_data=None):
+        if self.optimizer is None:
+            raise RuntimeError("call compile() before fit()")
+        return _keras_fit(self, self._get_trainer(), list(x), y, batch_size, epochs, validation_split, shuffle, callbacks,
+                          initial_epoch, validation_data)
+
+    def fit_generator(self, generator, steps_per_epoch, epochs=1, validation_data=None, validation_steps=None,
+                      callbacks=None, use_multiprocessing=False, shuffle=True, initial_epoch=0, verbose=0):
+        """Keras `fit_generator` (given_others...py:494-498): `steps_per_epoch` batches per epoch from a generator
+        yielding ([enc, others, dec_in], target); validation_data may be a generator (validation_steps batches)."""
+        import torch
+        from .callbacks import History
+        if self.optimizer is None:
+            raise RuntimeError("call compile() before fit_generator()")
+        tr = self._get_trainer()
+        d = lambda a: torch.from_numpy(_as_f32(a)).to(self.device)
+        hist = History()
+        cbs = [hist] + list(callbacks or [])
+        for cb in cbs:
+            cb.set_model(self)
+            cb.on_train_begin()
+        self.stop_training = False
+        for epoch in range(initial_epoch, epochs):
+            tot, cnt = 0.0, 0
+            for _ in range(steps_per_epoch):
+                xb, yb = next(generator)
+                loss = tr.train_step(*[d(a) for a in xb], d(yb))
+                tot += float(loss.item()) * len(yb)
+                cnt += len(yb)
+            logs = {"loss": tot / max(cnt, 1), "lr": tr.lr}
+            if validation_data is not None and validation_steps:
+                vt, vc = 0.0, 0
+                for _ in range(validation_steps):
+                    xb, yb = next(validation_data)
+                    vt += float(tr.eval_loss(*[d(a) for a in xb], d(yb)).item()) * len(yb)
+                    vc += len(yb)
+                logs["val_loss"] = vt / max(vc, 1)
+            self._w = tr.weights_numpy()
+            self._dw = None
+            for cb in cbs:
+                cb.on_epoch_end(epoch, logs)
+            if self.stop_training:
+                break
+        for cb in cbs:
+            cb.on_train_end()
+        return hist
+
+    def train_on_batch(self, x, y):
+        import torch
+        d = lambda a: torch.from_numpy(_as_f32(a)).to(self.device)
+        tr = self._get_trainer()
+        loss = tr.train_step(*[d(a) for a in x], d(y))
+        self._w = tr.weights_numpy()
+        self._dw = None
+        return float(loss.item())
 
     def _device_weights(self):
         import torch

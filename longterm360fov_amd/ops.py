@@ -229,14 +229,24 @@ def lstm_seq_bwd(x, K, R, hs, reserve, h0=None, c0=None, dhs=None, dhT=None, dcT
     return {"dz": dz, "dx": dx, "dK": dK, "dR": dR, "db": db, "dh0": dh0, "dc0": dc0}
 
 
-def dense_bwd(x, W, dpre, dW=None, db=None, need_dx=True, accumulate=False, scratch=None):
+def act_bwd(dy, y, base=None, activation="tanh", out=None):
+    """out = base + dy * act'(y)  (tanh: 1 - y^2)."""
+    dy, y = _dev(dy, "dy"), _dev(y, "y")
+    assert dy.shape == y.shape
+    out = torch.empty_like(y) if out is None else out
+    check(_lib.lib().fov_act_bwd(_ptr(dy), _ptr(y), _ptr(_dev(base, "base")), _ptr(out), y.numel(),
+                                 1 if activation == "tanh" else 0, _stream()))
+    return out
+
+
+def dense_bwd(x, W, dpre, dW=None, db=None, need_dx=True, accumulate=False, scratch=None, need_dW=True, need_db=True):
     x, W, dpre = _dev(x, "x"), _dev(W, "W"), _dev(dpre, "dpre")
     In, Out = W.shape
     x2, d2 = x.reshape(-1, In), dpre.reshape(-1, Out)
     N = x2.shape[0]
     e = lambda *s: torch.empty(s, dtype=torch.float32, device=x.device)
-    dW = e(In, Out) if dW is None else dW
-    db = e(Out) if db is None else db
+    dW = (e(In, Out) if dW is None else dW) if need_dW else None
+    db = (e(Out) if db is None else db) if need_db else None
     dx = e(N, In) if need_dx else None
     L = _lib.lib()
     buf = (scratch or _default_scratch).get(L.fov_dense_bwd_workspace_bytes(N, In, Out), x.device)

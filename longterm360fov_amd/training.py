@@ -30,7 +30,8 @@ class Seq2SeqTrainer:
             off += cnt
         self.step_count = 0
         self.ws = ops.Workspace()
-        self.scratch = ops.Scratch()
+        self.scratch = ops.Scratch()        # split-K partials of the Dense / MSE / matmul calls
+        self.bwd_scratch = ops.Scratch()    # BPTT calls only: its first word is the persistent kernel's status
         self._bufs = {}
 
     def weights_numpy(self):
@@ -66,9 +67,9 @@ class Seq2SeqTrainer:
         d_hs, _, _ = ops.dense_bwd(dhs_, w["dense_W"], dpre, dW=g["dense_W"], db=g["dense_b"], scratch=self.scratch)
         bd = ops.lstm_seq_bwd(dec_in, w["dec_K"], w["dec_R"], dhs_, dres, h0=ehT, c0=ecT, dhs=d_hs, dK=g["dec_K"],
                               dR=g["dec_R"], db=g["dec_b"], need_state_grads=True, act=self.act, dz=bufs["dz_dec"],
-                              scratch=self.scratch)
+                              scratch=self.bwd_scratch)
         ops.lstm_seq_bwd(enc, w["enc_K"], w["enc_R"], ehs, eres, dhT=bd["dh0"], dcT=bd["dc0"], dK=g["enc_K"],
-                         dR=g["enc_R"], db=g["enc_b"], act=self.act, dz=bufs["dz_enc"], scratch=self.scratch)
+                         dR=g["enc_R"], db=g["enc_b"], act=self.act, dz=bufs["dz_enc"], scratch=self.bwd_scratch)
         if grad_weight != 1.0:
             self.grad.mul_(grad_weight)
         return loss, y
@@ -100,3 +101,137 @@ class Seq2SeqTrainer:
         y = ops.seq2seq_teacher_forced(enc, dec_in, self.w, act=self.act, impl=self.impl, workspace=self.ws)
         _, loss = ops.mse_dense_grad(y, target, None, scratch=self.scratch)
         return loss
+
+
+_MIX_ORDER = ("enc1_K", "enc1_R", "enc1_b", "enc2_K", "enc2_R", "enc2_b", "dec1_K", "dec1_R", "dec1_b",
+              "dec2_K", "dec2_R", "dec2_b", "dense_W", "dense_b", "mix_W", "mix_b")
+
+
+class OthersMixingTrainer:
+    """Training step of the 2+2-layer others-mixing model WITHOUT teacher forcing
+    (mycode/given_others_gt_mean_var_seq2seq.py:203-308: Adam + MSE on the unrolled decoder whose output
+    is fed back).  Round-1 structure: the unrolled decoder is walked step by step with the library's
+    layer kernels (T = 1 calls), forward and backward; the feedback path's gradient is the dx of the
+    first decoder layer.  Gradients accumulate into ONE flat buffer (one all-reduce under DP)."""
+
+    def __init__(self, weights, act="sigmoid", impl="auto", optimizer="adam", lr=1e-3, device="cuda"):
+        self.act, self.impl, self.optimizer, self.lr, self.device = act, impl, optimizer, float(lr), device
+        self.shapes = [(k, tuple(weights[k].shape)) for k in _MIX_ORDER]
+        n = int(sum(np.prod(s) for _, s in self.shapes))
+        self.flat = torch.empty(n, dtype=torch.float32, device=device)
+        self.grad = torch.zeros(n, dtype=torch.float32, device=device)
+        self.m = torch.zeros(n, dtype=torch.float32, device=device)
+        self.v = torch.zeros(n, dtype=torch.float32, device=device) if optimizer == "adam" else None
+        self.w, self.g = {}, {}
+        off = 0
+        for k, s in self.shapes:
+            cnt = int(np.prod(s))
+            self.w[k] = self.flat[off:off + cnt].view(*s)
+            self.g[k] = self.grad[off:off + cnt].view(*s)
+            self.w[k].copy_(torch.from_numpy(np.ascontiguousarray(weights[k], dtype=np.float32)))
+            off += cnt
+        self.step_count = 0
+        self.ws, self.scratch, self.bwd_scratch = ops.Workspace(), ops.Scratch(), ops.Scratch()
+
+    def weights_numpy(self):
+        return {k: v.detach().cpu().numpy().copy() for k, v in self.w.items()}
+
+    def forward_backward(self, enc, others, dec0, target, grad_weight=1.0):
+        w, g, act, impl, ws, sc, bsc = self.w, self.g, self.act, self.impl, self.ws, self.scratch, self.bwd_scratch
+        B, T_in, _ = enc.shape
+        T_out = others.shape[1]
+        H = w["enc1_R"].shape[0]
+        O = w["dense_W"].shape[1]
+        n_oth = w["mix_W"].shape[0] - O
+        Wm_o, Wm_p = w["mix_W"][:n_oth], w["mix_W"][n_oth:]
+        gWm_o, gWm_p = g["mix_W"][:n_oth], g["mix_W"][n_oth:]
+        self.grad.zero_()
+        # ---------------- forward (keeping what the backward needs) ----------------
+        hs1, h1, c1, res1 = ops.lstm_seq_train(enc, w["enc1_K"], w["enc1_R"], w["enc1_b"], act=act, impl=impl, workspace=ws)
+        zx2 = ops.matmul(hs1.reshape(B * T_in, H), w["enc2_K"], scratch=sc).reshape(B, T_in, 4 * H)
+        res2 = torch.empty((B, T_in, 5, H), dtype=torch.float32, device=self.device)
+        hs2, h2, c2 = ops.lstm_seq_zx(zx2, w["enc2_R"], w["enc2_b"], act=act, impl=impl, workspace=ws, reserve=res2)
+        oth_flat = others.reshape(B * T_out, n_oth)
+        Wm_o_c, Wm_p_c = Wm_o.contiguous(), Wm_p.contiguous()
+        oth_proj = ops.dense(oth_flat, Wm_o_c, w["mix_b"], activation=None).reshape(B, T_out, O)
+        steps = []
+        x = dec0.reshape(B, 1, O)
+        for t in range(T_out):
+            st = {"x": x, "h1_prev": h1, "c1_prev": c1, "h2_prev": h2, "c2_prev": c2}
+            hs_a, h1, c1, r1 = ops.lstm_seq_train(x, w["dec1_K"], w["dec1_R"], w["dec1_b"], h1, c1, act=act, impl=impl, workspace=ws)
+            zx = ops.matmul(h1, w["dec2_K"], scratch=sc).reshape(B, 1, 4 * H)
+            r2 = torch.empty((B, 1, 5, H), dtype=torch.float32, device=self.device)
+            hs_b, h2, c2 = ops.lstm_seq_zx(zx, w["dec2_R"], w["dec2_b"], h2, c2, act=act, impl=impl, workspace=ws, reserve=r2)
+            p = ops.dense(h2, w["dense_W"], w["dense_b"], activation="tanh")
+            m = ops.dense_add(p, Wm_p_c, None, oth_proj[:, t], activation="tanh")
+            st.update({"hs1": hs_a, "r1": r1, "hs2": hs_b, "r2": r2, "h1": h1, "h2": h2, "p": p, "m": m})
+            steps.append(st)
+            x = m.reshape(B, 1, O)
+        out = torch.empty((B, T_out, O), dtype=torch.float32, device=self.device)
+        for t, st in enumerate(steps):
+            out[:, t].copy_(st["m"])                                            # gather of the step outputs (copy only)
+        # ---------------- backward ----------------
+        # dL/d(pre-tanh of the mixing layer) from the loss, for every step at once
+        dloss, loss = ops.mse_dense_grad(out, target, "tanh", scratch=sc)
+        dpre_all = torch.empty((T_out, B, O), dtype=torch.float32, device=self.device)   # per-step, contiguous
+        dh1_rec = dc1 = dh2_rec = dc2 = None
+        dx_next = None
+        for t in range(T_out - 1, -1, -1):
+            st = steps[t]
+            dpre_m = dpre_all[t]
+            dpre_m.copy_(dloss[:, t])
+            if dx_next is not None:            # x_{t+1} = m_t: the feedback gradient joins through tanh'
+                ops.act_bwd(dx_next.reshape(B, O), st["m"], base=dpre_m, activation="tanh", out=dpre_m)
+            dp, _, _ = ops.dense_bwd(st["p"], Wm_p_c, dpre_m, dW=gWm_p, db=g["mix_b"], accumulate=True, scratch=sc)
+            dpre_p = ops.act_bwd(dp, st["p"], activation="tanh")
+            dh2_dense, _, _ = ops.dense_bwd(st["h2"], w["dense_W"], dpre_p, dW=g["dense_W"], db=g["dense_b"],
+                                            accumulate=True, scratch=sc)
+            # layer 2 step: its input is h1_t, so its dx (= dz2 . K2^T) is the gradient w.r.t. h1_t
+            b2 = ops.lstm_seq_bwd(st["h1"].reshape(B, 1, H), w["dec2_K"], w["dec2_R"], st["hs2"], st["r2"],
+                                  h0=st["h2_prev"], c0=st["c2_prev"], dhs=dh2_dense.reshape(B, 1, H), dhT=dh2_rec, dcT=dc2,
+                                  dK=g["dec2_K"], dR=g["dec2_R"], db=g["dec2_b"], need_dx=True, need_state_grads=True,
+                                  act=act, accumulate=True, scratch=bsc)
+            dh2_rec, dc2 = b2["dh0"], b2["dc0"]
+            b1 = ops.lstm_seq_bwd(st["x"], w["dec1_K"], w["dec1_R"], st["hs1"], st["r1"], h0=st["h1_prev"],
+                                  c0=st["c1_prev"], dhs=b2["dx"], dhT=dh1_rec, dcT=dc1, dK=g["dec1_K"], dR=g["dec1_R"],
+                                  db=g["dec1_b"], need_dx=(t > 0), need_state_grads=True, act=act, accumulate=True, scratch=bsc)
+            dh1_rec, dc1 = b1["dh0"], b1["dc0"]
+            dx_next = b1["dx"]
+        # "others" half of the mixing kernel: one product over all steps, rows ordered (t, b) like dpre_all
+        oth_tb = others.transpose(0, 1).contiguous().reshape(T_out * B, n_oth)
+        ops.dense_bwd(oth_tb, Wm_o_c, dpre_all.reshape(T_out * B, O), dW=gWm_o, need_db=False, need_dx=False,
+                      accumulate=True, scratch=sc)
+        # encoder: layer 2 over hs1 (its dx is the dhs of layer 1), then layer 1
+        e2 = ops.lstm_seq_bwd(hs1, w["enc2_K"], w["enc2_R"], hs2, res2, dhT=dh2_rec, dcT=dc2, dK=g["enc2_K"], dR=g["enc2_R"],
+                              db=g["enc2_b"], need_dx=True, act=act, accumulate=True, scratch=bsc)
+        ops.lstm_seq_bwd(enc, w["enc1_K"], w["enc1_R"], hs1, res1, dhs=e2["dx"], dhT=dh1_rec, dcT=dc1, dK=g["enc1_K"],
+                         dR=g["enc1_R"], db=g["enc1_b"], act=act, accumulate=True, scratch=bsc)
+        if grad_weight != 1.0:
+            self.grad.mul_(grad_weight)
+        return loss, out
+
+    def apply_gradients(self):
+        self.step_count += 1
+        if self.optimizer == "adam":
+            ops.adam_step(self.flat, self.grad, self.m, self.v, self.step_count, lr=self.lr)
+        else:
+            ops.rmsprop_step(self.flat, self.grad, self.m, lr=self.lr)
+
+    def eval_loss(self, enc, others, dec0, target):
+        """Validation loss (forward only, through the same step-wise path)."""
+        loss, _ = self.forward_backward(enc, others, dec0, target)   # gradients are overwritten by the next step
+        return loss
+
+    def train_step(self, enc, others, dec0, target, n_global=None):
+        _, world = parallel.world()
+        n_local = enc.shape[0]
+        weight = 1.0 if world == 1 else n_local / float(n_global if n_global else n_local * world)
+        loss, _ = self.forward_backward(enc, others, dec0, target, grad_weight=weight)
+        if world > 1:
+            torch.distributed.all_reduce(self.grad, op=torch.distributed.ReduceOp.SUM)
+            lw = loss * weight
+            torch.distributed.all_reduce(lw, op=torch.distributed.ReduceOp.SUM)
+            loss = lw
+        self.apply_gradients()
+        return loss
+

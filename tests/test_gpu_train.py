@@ -247,3 +247,79 @@ def test_persistent_bptt_matches_stepped_and_oracle():
             print("H%d %-4s max|ref| %.3e  persistent err %.3e  stepped err %.3e" % (H, k, scale, np.abs(a - r).max(), np.abs(s_ - r).max()))
             assert np.abs(a - r).max() <= 1e-4 * scale + 1e-9, (H, k)
             assert np.abs(s_ - r).max() <= 1e-4 * scale + 1e-9, (H, k)
+
+
+def _torch_mixing_graph(enc, oth, dec0, tgt, w, act):
+    """Independent fp64 reference of the a4 training graph (given_others...py:203-308) on torch.autograd."""
+    t = {k: torch.tensor(v.astype(np.float64), requires_grad=True) for k, v in w.items()}
+    H = w["enc1_R"].shape[0]
+    s = torch.sigmoid if act == "sigmoid" else (lambda z: torch.clamp(0.2 * z + 0.5, 0, 1))
+
+    def step(x, h, c, K, R, b):
+        z = x @ K + b + h @ R
+        i, f, g, o = s(z[:, :H]), s(z[:, H:2 * H]), torch.tanh(z[:, 2 * H:3 * H]), s(z[:, 3 * H:])
+        c = f * c + i * g
+        return o * torch.tanh(c), c
+
+    e, o_, d0, tg = (torch.tensor(a.astype(np.float64)) for a in (enc, oth, dec0, tgt))
+    B = e.shape[0]
+    z0 = torch.zeros(B, H, dtype=torch.float64)
+    h1, c1, h2, c2 = z0, z0, z0, z0
+    for tt in range(e.shape[1]):
+        h1, c1 = step(e[:, tt], h1, c1, t["enc1_K"], t["enc1_R"], t["enc1_b"])
+        h2, c2 = step(h1, h2, c2, t["enc2_K"], t["enc2_R"], t["enc2_b"])
+    x = d0[:, 0]
+    outs = []
+    for tt in range(o_.shape[1]):
+        h1, c1 = step(x, h1, c1, t["dec1_K"], t["dec1_R"], t["dec1_b"])
+        h2, c2 = step(h1, h2, c2, t["dec2_K"], t["dec2_R"], t["dec2_b"])
+        p = torch.tanh(h2 @ t["dense_W"] + t["dense_b"])
+        cat = torch.cat([o_[:, tt], p[:, None, :]], dim=1).reshape(B, -1)
+        x = torch.tanh(cat @ t["mix_W"] + t["mix_b"])
+        outs.append(x)
+    y = torch.stack(outs, 1)
+    loss = torch.mean((y - tg) ** 2)
+    loss.backward()
+    return float(loss), {k: v.grad.numpy() for k, v in t.items()}, y.detach().numpy()
+
+
+@pytest.mark.parametrize("H,B,U,T_in,T_out,act", [(64, 20, 5, 4, 3, "sigmoid"), (128, 33, 34, 5, 4, "hard_sigmoid"),
+                                                  (256, 16, 34, 3, 3, "sigmoid")])
+def test_others_mixing_gradients_and_training(H, B, U, T_in, T_out, act):
+    """a4 training: gradients of the unrolled no-teacher-forcing graph (feedback path included) against
+    torch.autograd in fp64, then three Adam steps reduce the loss."""
+    from longterm360fov_amd.training import OthersMixingTrainer, _MIX_ORDER
+    w = O.init_others_mixing(70 + H, H=H, num_user=U, bias_noise=0.1)
+    enc, dec0, tgt, oth = O.synthetic_batch(71 + B, B, T_in, T_out, num_others=U - 1)
+    loss_ref, g_ref, y_ref = _torch_mixing_graph(enc, oth, dec0, tgt, w, act)
+    tr = OthersMixingTrainer(w, act=act)
+    loss, y = tr.forward_backward(dev(enc), dev(oth), dev(dec0), dev(tgt))
+    tr.ws.check(); tr.bwd_scratch.check()
+    assert abs(float(loss.item()) - loss_ref) <= 1e-5 * loss_ref + 1e-9
+    np.testing.assert_allclose(y.cpu().numpy(), y_ref, atol=2e-5)
+    for k in _MIX_ORDER:
+        a = tr.g[k].detach().cpu().numpy().astype(np.float64)
+        scale = np.abs(g_ref[k]).max()
+        err = np.abs(a - g_ref[k]).max()
+        print("mixing H%d grad %-8s max|ref| %.3e  max err %.3e" % (H, k, scale, err))
+        assert err <= 1e-4 * scale + 1e-9, (k, err, scale)
+    losses = [float(tr.train_step(dev(enc), dev(oth), dev(dec0), dev(tgt)).item()) for _ in range(4)]
+    assert losses[-1] < losses[0]
+
+
+def test_others_mixing_fit_surface():
+    from longterm360fov_amd.models import OthersMixingSeq2Seq
+    np.random.seed(1)
+    enc, dec0, tgt, oth = O.synthetic_batch(3, 96, 6, 5, num_others=33)
+    m = OthersMixingSeq2Seq(latent_dim=64, num_user=34, seed=2)
+    m.compile(optimizer="Adam", loss="mean_squared_error", metrics=["accuracy"])
+    h = m.fit([enc, oth, dec0], tgt, batch_size=32, epochs=3, validation_split=0.1, shuffle=True, initial_epoch=0)
+    assert len(h.history["loss"]) == 3 and h.history["loss"][-1] < h.history["loss"][0] and "val_loss" in h.history
+    assert m.predict([enc[:4], oth[:4], dec0[:4]]).shape == (4, 5, 6)
+
+    def gen():
+        while True:
+            for lo in range(0, 96, 32):
+                yield [enc[lo:lo + 32], oth[lo:lo + 32], dec0[lo:lo + 32]], tgt[lo:lo + 32]
+    h2 = m.fit_generator(gen(), steps_per_epoch=3, epochs=2, validation_data=gen(), validation_steps=1)
+    assert len(h2.history["loss"]) == 2 and "val_loss" in h2.history
