@@ -97,6 +97,58 @@ def bench_train(args, rank, world, use_dist):
         dist.destroy_process_group()
 
 
+def bench_train_mixing(args, rank, world, use_dist):
+    """Secondary measurement, BASELINE.json configs[2]: target+others mixing, 2+2 layers, H=256, T 10->10,
+    global batch 4096 sharded over the ranks (512 per GPU at 8 GPUs), one gradient all-reduce per step."""
+    import torch.distributed as dist
+    from longterm360fov_amd.training import OthersMixingTrainer
+    from oracle import fov_oracle as O
+    H, T_in, T_out, U = args.hidden, 10, 10, 34
+    B = args.batch if args.batch != 1024 else 512
+    w = O.init_others_mixing(1234, H=H, num_user=U, bias_noise=0.05)
+    enc, dec0, tgt, oth = O.synthetic_batch(1234 + rank, B, T_in, T_out, num_others=U - 1)
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    a_enc, a_oth, a_dec, a_tgt = d(enc), d(oth), d(dec0), d(tgt)
+    tr = OthersMixingTrainer(w, act=args.act, impl=args.impl)
+    for _ in range(args.warmup):
+        tr.train_step(a_enc, a_oth, a_dec, a_tgt, n_global=B * world)
+    torch.cuda.synchronize()
+    if use_dist:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = tr.train_step(a_enc, a_oth, a_dec, a_tgt, n_global=B * world)
+    torch.cuda.synchronize()
+    if use_dist:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if use_dist:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    tr.ws.check()
+    tr.bwd_scratch.check()
+    if rank == 0:
+        fwd = (T_in * (2 * (90 + H) * 4 * H + 2 * (H + H) * 4 * H) +
+               T_out * (2 * (6 + H) * 4 * H + 2 * (H + H) * 4 * H + 2 * H * 6 + 2 * U * 6 * 6))
+        ms = elapsed / args.steps * 1e3
+        print(json.dumps({
+            "metric": "training sequences/sec, others-mixing 2+2 layers (batch=%d per GPU, T 10->10, h=%d, U=%d)" % (B, H, U),
+            "value": world * B * args.steps / elapsed, "unit": "sequences/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic", "final_loss": float(loss.item()),
+            "config": {"workload": "configs[2] shape: given_others_gt_mean_var_seq2seq training step, step-wise decoder "
+                                   "(round-1 structure)", "global_batch": B * world,
+                       "parallelism": "dp%d, one flat-buffer all-reduce per step" % world},
+            "roofline": {"bound": "mfma", "achieved": 3 * fwd * B / (ms * 1e-3) / 1e12, "peak": PEAK_FP32_MFMA_TFLOPS,
+                         "unit": "TFLOP/s", "frac": 3 * fwd * B / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                         "note": "whole step, 3x forward FLOPs; launch-bound in round 1"},
+            "cpu_baseline": None}), flush=True)
+    if use_dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -112,7 +164,7 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the N > 1 path "
                          "with several ranks on ONE GPU)")
-    ap.add_argument("--mode", default="infer", choices=["infer", "train"],
+    ap.add_argument("--mode", default="infer", choices=["infer", "train", "train_mixing"],
                     help="infer (default, the BASELINE metric): encoder + autoregressive decoder; train: one "
                          "teacher-forced training step (fwd + BPTT + Adam, data-parallel all-reduce when N > 1)")
     args = ap.parse_args()
@@ -135,6 +187,8 @@ def main():
     from oracle import fov_oracle as O   # synthetic data + Keras initialisers (test infrastructure)
     if args.mode == "train":
         return bench_train(args, rank, world, use_dist)
+    if args.mode == "train_mixing":
+        return bench_train_mixing(args, rank, world, use_dist)
 
     B, T_in, T_out, H = args.batch, args.t_in, args.t_out, args.hidden
     F_enc, F_dec = 90, 6
