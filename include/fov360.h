@@ -223,6 +223,21 @@ int fov_convlstm_gates(const float* z, float* c, float* h, int64_t h_pixel_strid
 /* Softmax over the last dimension of (rows, n) - keras.layers.Softmax(axis=-1), convlstm_seq2seq.py:236. */
 int fov_softmax_lastdim(const float* x, float* y, int64_t rows, int n, fov_stream_t stream);
 
+/* Device-side windowing, the step in front of the path: reshape2second_stacks
+ * (mycode/utility.py:264-305).  x:(U,S,feat) whole seconds of one video -> W = fov_window_count(S,T,stride)
+ * windows; enc / fut / fut_in are (W*U, T, feat) window-major when collapse_user != 0, else (U, W, T, feat).
+ * fut is `T/stride` windows ahead of enc; fut_in is fut shifted right one second, seeded with enc's last second. */
+int64_t fov_window_count(int S, int T, int stride);
+int fov_window_stacks(const float* x, float* enc, float* fut, float* fut_in, int U, int S, int feat, int T,
+                      int stride, int collapse_user, fov_stream_t stream);
+
+/* FoV hit rate per predicted second, the evaluation step that consumes the path's output:
+ * centres as unit xyz vectors -> (theta, phi) (mycode/dataIO.py:77-82), +-2pi seam fix
+ * (baseline_knn_mean.py:78-85), area(pred box ^ gt box) / area(gt box) (:62-82).  Row strides in floats
+ * (>= 3) let `pred_xyz` be the first three columns of the model's (N*T, 6) mean/variance output. */
+int fov_fov_hit_rate(const float* pred_xyz, int64_t pred_row_stride, const float* gt_xyz, int64_t gt_row_stride,
+                     float* out, int64_t rows, float span_deg, float gt_span_deg, fov_stream_t stream);
+
 /* Synchronises `stream`, reads the status word a persistent-kernel call left in `workspace`
  * and returns FOV_OK or FOV_ERR_TIMEOUT.  Workspaces of non-persistent calls report FOV_OK. */
 int fov_check_status(const void* workspace, size_t workspace_bytes, fov_stream_t stream);

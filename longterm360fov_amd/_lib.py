@@ -55,6 +55,9 @@ SIGNATURES = {
     "fov_conv2d_fwd": (_I, [_P, ctypes.c_int64, ctypes.c_int64, _P, _P, _P, _P] + [_I] * 8 + [_P]),
     "fov_convlstm_gates": (_I, [_P, _P, _P, ctypes.c_int64, ctypes.c_int64, _I, _I, _P]),
     "fov_softmax_lastdim": (_I, [_P, _P, ctypes.c_int64, _I, _P]),
+    "fov_window_count": (ctypes.c_int64, [_I, _I, _I]),
+    "fov_window_stacks": (_I, [_P] * 4 + [_I] * 6 + [_P]),
+    "fov_fov_hit_rate": (_I, [_P, ctypes.c_int64, _P, ctypes.c_int64, _P, ctypes.c_int64, ctypes.c_float, ctypes.c_float, _P]),
     "fov_check_status": (_I, [_P, _SZ, _P]),
     "fov_exchange_mode": (_I, [_P, _SZ, _P]),
 }

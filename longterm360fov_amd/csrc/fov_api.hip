@@ -84,6 +84,61 @@ __global__ __launch_bounds__(256) void meanvar_kernel(const float* __restrict__ 
     out[row * 6 + 3 + ax] = v / (float)fps;
 }
 
+// ---------------------------------------------------------------------------------------
+// FoV hit rate per predicted second (the consumer of the path's output):
+// xyz -> (theta, phi) as dataIO.py:77-82, +-2pi seam fix as baseline_knn_mean.py:78-85, overlap of the two
+// span x span boxes over the ground-truth box area as :62-82.  One thread per (sequence, second); HBM-bound.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ float fmod_pos(float a, float m) {
+    float r = fmodf(a, m);
+    return r < 0.f ? r + m : r;
+}
+
+__global__ __launch_bounds__(256) void hit_rate_kernel(const float* __restrict__ pred, long pred_stride,
+                                                       const float* __restrict__ gt, long gt_stride,
+                                                       float* __restrict__ out, long rows, float span, float gt_span) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows) return;
+    const float kPi = 3.14159265358979323846f;
+    const float* p = pred + i * pred_stride;
+    const float* g = gt + i * gt_stride;
+    float pt = fmod_pos(atan2f(p[1], p[0]), 2.f * kPi) - kPi;
+    const float pp = fmod_pos(atan2f(p[2], sqrtf(p[0] * p[0] + p[1] * p[1])) + 0.5f * kPi, kPi);
+    float gth = fmod_pos(atan2f(g[1], g[0]), 2.f * kPi) - kPi;
+    const float gp = fmod_pos(atan2f(g[2], sqrtf(g[0] * g[0] + g[1] * g[1])) + 0.5f * kPi, kPi);
+    if (gth > 2.f / 3.f * kPi && pt < -2.f / 3.f * kPi) pt += 2.f * kPi;
+    else if (gth < -2.f / 3.f * kPi && pt > 2.f / 3.f * kPi) gth += 2.f * kPi;
+    const float iw = fminf(pt + 0.5f * span, gth + 0.5f * gt_span) - fmaxf(pt - 0.5f * span, gth - 0.5f * gt_span);
+    const float ih = fminf(pp + 0.5f * span, gp + 0.5f * gt_span) - fmaxf(pp - 0.5f * span, gp - 0.5f * gt_span);
+    out[i] = (iw > 0.f && ih > 0.f) ? iw * ih / (gt_span * gt_span) : 0.f;
+}
+
+// ---------------------------------------------------------------------------------------
+// Device-side windowing: reshape2second_stacks (mycode/utility.py:264-305) as one gather.
+// x:(U,S,feat) seconds of one video -> enc / future / future_input windows of T seconds every `stride`
+// seconds; collapse_user: window-major (W*U, T, feat), else user-major (U, W, T, feat).  HBM-bound copy.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void window_stacks_kernel(const float* __restrict__ x, float* __restrict__ enc,
+                                                            float* __restrict__ fut, float* __restrict__ fut_in, int U,
+                                                            int S, int feat, int T, int stride, int shift, int W,
+                                                            int collapse) {
+    const long total = (long)W * U * T * feat;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int f = (int)(i % feat);
+    long r = i / feat;
+    const int t = (int)(r % T);
+    r /= T;
+    int w, u;
+    if (collapse) { u = (int)(r % U); w = (int)(r / U); } else { w = (int)(r % W); u = (int)(r / W); }
+    const float* xu = x + (size_t)u * S * feat;
+    const int s_enc = stride * w + t, s_fut = stride * (w + shift) + t;
+    enc[i] = xu[(size_t)s_enc * feat + f];
+    fut[i] = xu[(size_t)s_fut * feat + f];
+    // decoder input = future shifted right by one second, seeded with the encoder's last second
+    fut_in[i] = (t == 0) ? xu[(size_t)(stride * w + T - 1) * feat + f] : xu[(size_t)(s_fut - 1) * feat + f];
+}
+
 static bool want_cluster(int impl, int F, int H, int F_dec, bool decode) {
     if (impl == FOV_IMPL_GENERIC) return false;
     const bool ok = cluster_shape_ok(F, H) && (!decode || (F_dec >= 1 && F_dec <= 8));
@@ -444,6 +499,45 @@ int fov_softmax_lastdim(const float* x, float* y, int64_t rows, int n, fov_strea
         return FOV_ERR_INVALID;
     }
     return softmax_lastdim(x, y, (long)rows, n, (hipStream_t)stream);
+}
+
+int fov_fov_hit_rate(const float* pred_xyz, int64_t pred_row_stride, const float* gt_xyz, int64_t gt_row_stride,
+                     float* out, int64_t rows, float span_deg, float gt_span_deg, fov_stream_t stream) {
+    if (rows < 0 || pred_row_stride < 3 || gt_row_stride < 3 || span_deg <= 0.f || gt_span_deg <= 0.f ||
+        (rows > 0 && (!pred_xyz || !gt_xyz || !out))) {
+        set_error("fov_fov_hit_rate: invalid argument");
+        return FOV_ERR_INVALID;
+    }
+    if (rows == 0) return FOV_OK;
+    const float d2r = 3.14159265358979323846f / 180.f;
+    hipLaunchKernelGGL(hit_rate_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream, pred_xyz,
+                       (long)pred_row_stride, gt_xyz, (long)gt_row_stride, out, (long)rows, span_deg * d2r, gt_span_deg * d2r);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_error("hit_rate launch: %s", hipGetErrorString(e)); return FOV_ERR_LAUNCH; }
+    return FOV_OK;
+}
+
+int64_t fov_window_count(int S, int T, int stride) {
+    if (S < 2 * T || T <= 0 || stride <= 0 || stride > T) return 0;
+    const int shift = T / stride;
+    const int nrows = (S - T) / stride + 1;
+    return nrows - shift > 0 ? nrows - shift : 0;
+}
+
+int fov_window_stacks(const float* x, float* enc, float* fut, float* fut_in, int U, int S, int feat, int T, int stride,
+                      int collapse_user, fov_stream_t stream) {
+    if (U < 0 || S < 0 || feat <= 0 || T <= 0 || stride <= 0 || stride > T || (U > 0 && S >= 2 * T && (!x || !enc || !fut || !fut_in))) {
+        set_error("fov_window_stacks: invalid argument");
+        return FOV_ERR_INVALID;
+    }
+    const int W = (int)fov_window_count(S, T, stride);
+    if (U == 0 || W == 0) return FOV_OK;
+    const long total = (long)W * U * T * feat;
+    hipLaunchKernelGGL(window_stacks_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, enc,
+                       fut, fut_in, U, S, feat, T, stride, T / stride, W, collapse_user ? 1 : 0);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_error("window_stacks launch: %s", hipGetErrorString(e)); return FOV_ERR_LAUNCH; }
+    return FOV_OK;
 }
 
 int fov_exchange_mode(const void* workspace, size_t workspace_bytes, fov_stream_t stream) {

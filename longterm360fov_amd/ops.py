@@ -368,3 +368,31 @@ def softmax_lastdim(x):
     n = x.shape[-1]
     check(_lib.lib().fov_softmax_lastdim(_ptr(x), _ptr(y), x.numel() // n, n, _stream()))
     return y
+
+
+def fov_hit_rate(pred, gt_xyz, span_deg=120.0, gt_span_deg=120.0):
+    """Hit rate per (sequence, second).  pred: (..., >=3) device tensor whose first three columns are the
+    predicted mean x,y,z (e.g. the model's (N,T,6) output); gt_xyz: (..., >=3) likewise (e.g. meanvar_xyz of the
+    ground-truth second).  -> (...,) float32."""
+    assert pred.is_cuda and gt_xyz.is_cuda and pred.dtype == torch.float32 and gt_xyz.dtype == torch.float32
+    assert pred.shape[:-1] == gt_xyz.shape[:-1] and pred.is_contiguous() and gt_xyz.is_contiguous()
+    lead = pred.shape[:-1]
+    rows = 1
+    for d in lead:
+        rows *= d
+    out = torch.empty(lead, dtype=torch.float32, device=pred.device)
+    check(_lib.lib().fov_fov_hit_rate(pred.data_ptr(), pred.shape[-1], gt_xyz.data_ptr(), gt_xyz.shape[-1], _ptr(out), rows,
+                                      float(span_deg), float(gt_span_deg), _stream()))
+    return out
+
+
+def window_stacks(x, T, stride, collapse_user=True):
+    """reshape2second_stacks on the device: x (U,S,feat) -> (enc, future, future_input)."""
+    x = _dev(x, "x")
+    U, S, feat = x.shape
+    L = _lib.lib()
+    W = int(L.fov_window_count(S, T, stride))
+    shape = (W * U, T, feat) if collapse_user else (U, W, T, feat)
+    outs = [torch.empty(shape, dtype=torch.float32, device=x.device) for _ in range(3)]
+    check(L.fov_window_stacks(_ptr(x), *[_ptr(o) for o in outs], U, S, feat, T, stride, 1 if collapse_user else 0, _stream()))
+    return tuple(outs)

@@ -499,3 +499,32 @@ def init_convlstm_seq2seq(seed, C=30, latent_dim=16, k=5, head="conv2d", head_fi
         w["head%d_W" % i] = glorot(hk + (chans[i], chans[i + 1]))
         w["head%d_b" % i] = (0.05 * rng.standard_normal(chans[i + 1])).astype(dtype)
     return w
+
+
+# --------------------------------------------------------------------------------------
+# the consumer of the path's output - FoV hit rate per predicted second
+#   xyz2thetaphi           mycode/dataIO.py:77-82
+#   boundary_cases         mycode/baseline_knn_mean.py:78-85
+#   bbox_overlaps_hit_rate mycode/baseline_knn_mean.py:62-82 via get_iou_or_hitrate :48-60
+# --------------------------------------------------------------------------------------
+def xyz2thetaphi(x, y, z):
+    theta = np.mod(np.arctan2(y, x), 2 * np.pi) - np.pi
+    phi = np.mod(np.arctan2(z, np.sqrt(x ** 2 + y ** 2)) + np.pi / 2, np.pi)
+    return theta, phi
+
+
+def fov_hit_rate(pred_xyz, gt_xyz, span_deg=120.0, gt_span_deg=120.0):
+    """pred_xyz, gt_xyz: (..., 3) FoV-centre unit vectors (per-second means).  Returns the hit rate
+    = area(pred box ∩ gt box) / area(gt box) of the two (theta,phi) boxes of the given angular spans,
+    with the reference's +-2pi wrap fix when the two centres straddle the theta seam."""
+    pt, pp = xyz2thetaphi(pred_xyz[..., 0], pred_xyz[..., 1], pred_xyz[..., 2])
+    gt, gp = xyz2thetaphi(gt_xyz[..., 0], gt_xyz[..., 1], gt_xyz[..., 2])
+    pt, gt = pt.copy(), gt.copy()
+    c1 = (gt > 2 / 3.0 * np.pi) & (pt < -2 / 3.0 * np.pi)
+    pt[c1] += 2 * np.pi
+    c2 = (gt < -2 / 3.0 * np.pi) & (pt > 2 / 3.0 * np.pi)
+    gt[c2] += 2 * np.pi
+    s, gs = span_deg / 180.0 * np.pi, gt_span_deg / 180.0 * np.pi
+    iw = np.minimum(pt + s / 2, gt + gs / 2) - np.maximum(pt - s / 2, gt - gs / 2)
+    ih = np.minimum(pp + s / 2, gp + gs / 2) - np.maximum(pp - s / 2, gp - gs / 2)
+    return np.where((iw > 0) & (ih > 0), iw * ih / (gs * gs), 0.0)

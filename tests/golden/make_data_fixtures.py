@@ -13,6 +13,7 @@ What is pinned (reference file:line):
   * mycode/utility.py:505-517  get_gt_target_xyz_oth
   * mycode/dataIO.py:16-26     clip_xyz
   * mycode/config.py:6-135     cfg knob values
+  * mycode/dataIO.py:77-82     xyz2thetaphi (evaluation side)
   * mycode/given_others_gt_mean_var_seq2seq.py:318-323  _reshape_others_data  (restated inline
     below, because that module executes a training script at import time)
 
@@ -149,6 +150,13 @@ def main():
     # slice_layer on an ndarray (Lambda placeholder returns the python closure)
     sl = util.slice_layer(1, 2, 3)(out["gt_oth_fut"])
     out["slice_1_2_3"] = sl
+
+    # evaluation side: dataIO.xyz2thetaphi (dataIO.py:77-82) on seeded unit vectors
+    v = rng.standard_normal((64, 3))
+    v /= np.linalg.norm(v, axis=1, keepdims=True)
+    v[:4] = [[1, 0, 0], [-1, 1e-9, 0], [0, 0, 1], [0, -1, 0]]
+    th, ph = dataIO.xyz2thetaphi(v[:, 0], v[:, 1], v[:, 2])
+    out["eval_xyz"], out["eval_theta"], out["eval_phi"] = v, th, ph
 
     np.savez_compressed(OUT, **out)
     print("wrote", OUT, {k: getattr(v, "shape", None) for k, v in out.items() if not k.startswith(("raw_", "clip_"))})

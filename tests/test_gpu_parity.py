@@ -353,3 +353,40 @@ def test_tf_contrib_stacked_lstm_mapping():
         out0, _ = m.predict(x)                       # zero initial state
         ref0, _ = O.tf_dynamic_rnn(x.astype(np.float64), [(W.astype(np.float64), b.astype(np.float64)) for W, b in cells])
         assert_parity(out0, ref0, "tf stacked LSTM H%d zero state" % H)
+
+
+def test_fov_hit_rate_against_oracle(golden_dir):
+    """the evaluation step fed by the model output, incl. the theta-seam cases."""
+    ops = _ops()
+    rng = np.random.default_rng(12)
+    N, T = 300, 10
+    gt = rng.standard_normal((N, T, 3)); gt /= np.linalg.norm(gt, axis=-1, keepdims=True)
+    pred6 = np.concatenate([gt + 0.4 * rng.standard_normal((N, T, 3)), rng.uniform(0, 0.1, (N, T, 3))], axis=-1)
+    # force seam cases: gt just below +pi in theta, prediction just above -pi (and the reverse)
+    gt[:20, :, 0], gt[:20, :, 1] = 1.0, -0.05
+    pred6[:20, :, 0], pred6[:20, :, 1] = 1.0, 0.05
+    gt[20:40, :, 0], gt[20:40, :, 1] = 1.0, 0.05
+    pred6[20:40, :, 0], pred6[20:40, :, 1] = 1.0, -0.05
+    ref = O.fov_hit_rate(pred6[..., :3].astype(np.float32).astype(np.float64), gt.astype(np.float32).astype(np.float64))
+    got = ops.fov_hit_rate(dev(pred6), dev(gt)).cpu().numpy()
+    assert got.shape == (N, T)
+    assert np.abs(got - ref).max() < 2e-5, np.abs(got - ref).max()
+    assert (ref[:40] > 0.5).all() and (got[:40] > 0.5).all()      # seam cases overlap instead of scoring 0
+    g = np.load(os.path.join(golden_dir, "data_helpers.npz"))    # reference-pinned angles feed the same formula
+    one = ops.fov_hit_rate(dev(g["eval_xyz"]), dev(g["eval_xyz"])).cpu().numpy()
+    np.testing.assert_allclose(one, 1.0, atol=1e-6)
+
+
+def test_device_windowing_matches_reference_fixture(golden_dir):
+    """reshape2second_stacks as a device gather, against windows produced by the
+    reference's own function (strides 1 and 5, both user layouts) - exact, it is a copy."""
+    ops = _ops()
+    g = np.load(os.path.join(golden_dir, "data_helpers.npz"))
+    x = dev(g["s1_in"])                                   # (2, 23, 90) seconds
+    enc, fut, fut_in = ops.window_stacks(x, T=10, stride=1, collapse_user=True)
+    for got, key in ((enc, "s1_enc"), (fut, "s1_fut"), (fut_in, "s1_fut_in")):
+        np.testing.assert_array_equal(got.cpu().numpy(), g[key].astype(np.float32))
+    enc, fut, fut_in = ops.window_stacks(x, T=10, stride=5, collapse_user=False)
+    for got, key in ((enc, "s5_enc"), (fut, "s5_fut"), (fut_in, "s5_fut_in")):
+        np.testing.assert_array_equal(got.cpu().numpy(), g[key].astype(np.float32))
+    assert (enc[:, :, -1] == fut_in[:, :, 0]).all()       # the reference's sanity check

@@ -196,3 +196,23 @@ def test_tf_lstmcell_equals_keras_cell_after_mapping():
     h2, c2 = O.lstm_step(x, h, c, K.astype(np.float64), R.astype(np.float64), bk.astype(np.float64), "sigmoid")
     np.testing.assert_allclose(h1, h2, atol=1e-6)
     np.testing.assert_allclose(c1, c2, atol=1e-6)
+
+
+def test_xyz2thetaphi_matches_reference_fixture(golden_dir):
+    g = np.load(os.path.join(golden_dir, "data_helpers.npz"))
+    th, ph = O.xyz2thetaphi(g["eval_xyz"][:, 0], g["eval_xyz"][:, 1], g["eval_xyz"][:, 2])
+    np.testing.assert_array_equal(th, g["eval_theta"])
+    np.testing.assert_array_equal(ph, g["eval_phi"])
+
+
+def test_hit_rate_known_answers():
+    e = lambda th, ph: np.array([np.cos(th + np.pi) * np.sin(ph), np.sin(th + np.pi) * np.sin(ph), -np.cos(ph)])
+    # identical centres -> full overlap; far apart -> 0; half a span apart in theta -> 1/2
+    a = e(0.3, 1.2)
+    assert abs(O.fov_hit_rate(a[None], a[None])[0] - 1.0) < 1e-12
+    assert O.fov_hit_rate(e(0.3, 1.2)[None], e(-2.5, 1.2)[None])[0] == 0.0
+    half = O.fov_hit_rate(e(0.3 + np.pi / 3, 1.2)[None], e(0.3, 1.2)[None])[0]
+    assert abs(half - 0.5) < 1e-9
+    # straddling the theta seam: centres 20 degrees apart across +-pi must still overlap (5/6 in theta)
+    seam = O.fov_hit_rate(e(np.pi - np.pi / 18, 1.2)[None], e(-np.pi + np.pi / 18, 1.2)[None])[0]
+    assert abs(seam - (1 - (np.pi / 9) / (2 * np.pi / 3))) < 1e-9
