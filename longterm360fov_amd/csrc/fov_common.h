@@ -58,6 +58,7 @@ struct LstmParams {
     unsigned* status;          // status[0] = timeout flag
     int num_groups;            // resident groups (persistent loop over 16-sequence tiles)
     int num_tiles;
+    int epoch_start;           // first epoch - 1 of this launch (0, or T_in for the decoder launch of a fused call)
     int force_safe_exchange;   // 1: never take the same-XCD fast path (tests)
 };
 

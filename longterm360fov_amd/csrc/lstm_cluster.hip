@@ -261,13 +261,14 @@ __global__ __launch_bounds__(256, 1) void lstm_cluster_kernel(LstmParams p) {
         // hello handshake (safe sc1 protocol): do all members of this group sit on one XCD?
         unsigned long long* hello = p.xch + (size_t)p.num_groups * 2 * BT * H + (size_t)group * G;
         const unsigned mine = xcc_id();
-        if (tid == 0) st_granule(hello + slice, (1ull << 32) | mine);
+        const unsigned long long hello_tag = 2ull * (unsigned)p.epoch_start + (LAYER ? 1 : 2);   // distinct per launch of one call
+        if (tid == 0) st_granule(hello + slice, (hello_tag << 32) | mine);
         if (tid < G) {
             unsigned long long hv = 0;
             unsigned spins = 0;
             while (true) {
                 hv = ld_granule(hello + tid);
-                if ((hv >> 32) != 0) break;
+                if ((hv >> 32) == hello_tag) break;
                 if (++spins > SPIN_LIMIT) {
                     __hip_atomic_store(p.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     sFlag[0] = 1;
@@ -316,7 +317,7 @@ __global__ __launch_bounds__(256, 1) void lstm_cluster_kernel(LstmParams p) {
         kb[1] = *(const f32x4*)(sKw + 256 + lane * 4);
     }
 
-    unsigned epoch = 0;
+    unsigned epoch = (unsigned)p.epoch_start;   // a second launch on the same buffers continues the count
     bool aborted = false;
     __syncthreads();
     const bool same_xcd = (G > 1) && (sFlag[1] == 0) && (p.force_safe_exchange == 0);
@@ -694,12 +695,13 @@ int launch_cluster(const LstmParams& p_in, bool decode, hipStream_t stream) {
     enc.hs = nullptr;
     int rc = launch_cluster_mode(enc, MODE_LAYER, stream);
     if (rc) return rc;
-    // granule tags only (the status word must survive so an encoder give-up stays visible)
-    e = hipMemsetAsync((char*)p.status + kStatusBytes, 0, xch_bytes - kStatusBytes, stream);
-    if (e != hipSuccess) { set_error("hipMemsetAsync: %s", hipGetErrorString(e)); return FOV_ERR_LAUNCH; }
+    // The decoder launch reuses the granule buffers WITHOUT zeroing them: its epochs (and its hello tag)
+    // continue after the encoder's last one (T_in per tile a group visits), so every stale tag is smaller
+    // than any tag it waits for.
     LstmParams dec = p;
     dec.h0 = enc.hT;
     dec.c0 = enc.cT;
+    dec.epoch_start = p.T * ((p.num_tiles + p.num_groups - 1) / p.num_groups);   // encoder epochs: T per tile visit
     return launch_cluster_mode(dec, MODE_DECODE, stream);
 }
 
