@@ -34,6 +34,7 @@ struct GemmArgs {
     int ldc;
     int split;       // number of K slices (grid.z)
     int k_per_split; // multiple of 16
+    int a_vec, b_vec; // operand is row-contiguous (stride 1 along m / n) and 16-byte aligned: stage with float4 loads
 };
 
 constexpr int GBK = 16;
@@ -65,49 +66,95 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
 #pragma unroll
         for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // element e = tid + 256*r of a (rows x 16) tile.  k-fast operands: consecutive threads walk k;
-    // otherwise they walk the row index.
+    // Staging.  Scalar path: element e = tid + 256*r of a (rows x 16) tile (k-fast operands: consecutive
+    // threads walk k, else the row index).  Vector path (row-contiguous, aligned operand): group e4 = tid +
+    // 256*r of (rows/4 x 16) float4 groups, consecutive threads walk the row index, one 16-byte load and one
+    // ds_write_b128 per group - 4x fewer staging instructions, which matters because fp32 MFMA and the
+    // staging VALU share the issue slots.
     const bool a_kfast = (g.a_ski == 1), b_kfast = (g.b_ski == 1);
+    const bool a_vec = g.a_vec != 0, b_vec = g.b_vec != 0;
+    constexpr int RA4 = (RA + 3) / 4, RB4 = (RB + 3) / 4;   // float4 groups per thread (last round may be partial)
     int a_mm[RA], a_kk[RA], a_ko[RA], a_ki[RA];
     int b_nn[RB], b_kk[RB], b_ko[RB], b_ki[RB];
 #pragma unroll
     for (int r = 0; r < RA; ++r) {
         const int e = tid + 256 * r;
-        if (a_kfast) { a_mm[r] = e >> 4; a_kk[r] = e & 15; } else { a_kk[r] = e / BM; a_mm[r] = e - a_kk[r] * BM; }
+        if (a_vec) { a_kk[r] = e / (BM / 4); a_mm[r] = 4 * (e - a_kk[r] * (BM / 4)); }
+        else if (a_kfast) { a_mm[r] = e >> 4; a_kk[r] = e & 15; }
+        else { a_kk[r] = e / BM; a_mm[r] = e - a_kk[r] * BM; }
         const int k = kbeg + a_kk[r];
         a_ko[r] = k / g.KI; a_ki[r] = k - a_ko[r] * g.KI;
     }
 #pragma unroll
     for (int r = 0; r < RB; ++r) {
         const int e = tid + 256 * r;
-        if (b_kfast) { b_nn[r] = e >> 4; b_kk[r] = e & 15; } else { b_kk[r] = e / BN; b_nn[r] = e - b_kk[r] * BN; }
+        if (b_vec) { b_kk[r] = e / (BN / 4); b_nn[r] = 4 * (e - b_kk[r] * (BN / 4)); }
+        else if (b_kfast) { b_nn[r] = e >> 4; b_kk[r] = e & 15; }
+        else { b_kk[r] = e / BN; b_nn[r] = e - b_kk[r] * BN; }
         const int k = kbeg + b_kk[r];
         b_ko[r] = k / g.KI; b_ki[r] = k - b_ko[r] * g.KI;
     }
     float ra[RA], rb[RB];
+    f32x4 va[RA4], vb[RB4];
     auto fetch = [&](int k0) {   // loads the tile starting at k0, then advances the (ko, ki) state by 16
+        if (a_vec) {
 #pragma unroll
-        for (int r = 0; r < RA; ++r) {
-            const int m = m0 + a_mm[r];
-            ra[r] = (m < g.M && k0 + a_kk[r] < kend)
-                        ? g.a[(long)m * g.a_sm + (long)a_ko[r] * g.a_sko + (long)a_ki[r] * g.a_ski] : 0.f;
-            a_ki[r] += GBK;
-            while (a_ki[r] >= g.KI) { a_ki[r] -= g.KI; ++a_ko[r]; }
+            for (int r = 0; r < RA4; ++r) {
+                const int m = m0 + a_mm[r];
+                va[r] = (m < g.M && a_kk[r] < GBK && k0 + a_kk[r] < kend)
+                            ? *(const f32x4*)(g.a + (long)m + (long)a_ko[r] * g.a_sko + (long)a_ki[r] * g.a_ski)
+                            : (f32x4){0.f, 0.f, 0.f, 0.f};
+                a_ki[r] += GBK;
+                while (a_ki[r] >= g.KI) { a_ki[r] -= g.KI; ++a_ko[r]; }
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < RA; ++r) {
+                const int m = m0 + a_mm[r];
+                ra[r] = (m < g.M && k0 + a_kk[r] < kend)
+                            ? g.a[(long)m * g.a_sm + (long)a_ko[r] * g.a_sko + (long)a_ki[r] * g.a_ski] : 0.f;
+                a_ki[r] += GBK;
+                while (a_ki[r] >= g.KI) { a_ki[r] -= g.KI; ++a_ko[r]; }
+            }
         }
+        if (b_vec) {
 #pragma unroll
-        for (int r = 0; r < RB; ++r) {
-            const int n = n0 + b_nn[r];
-            rb[r] = (n < g.N && k0 + b_kk[r] < kend)
-                        ? g.b[(long)n * g.b_sn + (long)b_ko[r] * g.b_sko + (long)b_ki[r] * g.b_ski] : 0.f;
-            b_ki[r] += GBK;
-            while (b_ki[r] >= g.KI) { b_ki[r] -= g.KI; ++b_ko[r]; }
+            for (int r = 0; r < RB4; ++r) {
+                const int n = n0 + b_nn[r];
+                vb[r] = (n < g.N && b_kk[r] < GBK && k0 + b_kk[r] < kend)
+                            ? *(const f32x4*)(g.b + (long)n + (long)b_ko[r] * g.b_sko + (long)b_ki[r] * g.b_ski)
+                            : (f32x4){0.f, 0.f, 0.f, 0.f};
+                b_ki[r] += GBK;
+                while (b_ki[r] >= g.KI) { b_ki[r] -= g.KI; ++b_ko[r]; }
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < RB; ++r) {
+                const int n = n0 + b_nn[r];
+                rb[r] = (n < g.N && k0 + b_kk[r] < kend)
+                            ? g.b[(long)n * g.b_sn + (long)b_ko[r] * g.b_sko + (long)b_ki[r] * g.b_ski] : 0.f;
+                b_ki[r] += GBK;
+                while (b_ki[r] >= g.KI) { b_ki[r] -= g.KI; ++b_ko[r]; }
+            }
         }
     };
     auto stash = [&](int buf) {
+        if (a_vec) {
 #pragma unroll
-        for (int r = 0; r < RA; ++r) As[buf][a_kk[r]][a_mm[r]] = ra[r];
+            for (int r = 0; r < RA4; ++r)
+                if (a_kk[r] < GBK) *(f32x4*)&As[buf][a_kk[r]][a_mm[r]] = va[r];
+        } else {
 #pragma unroll
-        for (int r = 0; r < RB; ++r) Bs[buf][b_kk[r]][b_nn[r]] = rb[r];
+            for (int r = 0; r < RA; ++r) As[buf][a_kk[r]][a_mm[r]] = ra[r];
+        }
+        if (b_vec) {
+#pragma unroll
+            for (int r = 0; r < RB4; ++r)
+                if (b_kk[r] < GBK) *(f32x4*)&Bs[buf][b_kk[r]][b_nn[r]] = vb[r];
+        } else {
+#pragma unroll
+            for (int r = 0; r < RB; ++r) Bs[buf][b_kk[r]][b_nn[r]] = rb[r];
+        }
     };
     int buf = 0;
     if (kbeg < kend) {
@@ -147,15 +194,36 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
             }
 }
 
-// out[i] = (accumulate ? out[i] : 0) + sum_s part[s][i]
+// out[i] = (accumulate ? out[i] : 0) + sum_s part[s][i].  Block = 64 outputs x 4 slice groups: group q adds
+// slices q, q+4, q+8, ... (eight loads in flight per thread), then the four group sums are folded in a fixed
+// order through LDS - deterministic for a given (n, S), and short products with many slices are not
+// serialised on one thread per output.
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, float* __restrict__ out,
                                                             long n, int S, int accumulate) {
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    float s = accumulate ? out[i] : 0.f;
-    for (int k = 0; k < S; ++k) s += part[(size_t)k * n + i];
-    out[i] = s;
+    __shared__ float red[4][64];
+    const int li = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const long i = (long)blockIdx.x * 64 + li;
+    float s = 0.f;
+    if (i < n) {
+        int k = q;
+        for (; k + 28 < S; k += 32) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = part[(size_t)(k + 4 * u) * n + i];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; k < S; k += 4) s += part[(size_t)k * n + i];
+    }
+    red[q][li] = s;
+    __syncthreads();
+    if (q == 0 && i < n) {
+        const float t = ((red[0][li] + red[1][li]) + (red[2][li] + red[3][li]));
+        out[i] = accumulate ? out[i] + t : t;
+    }
 }
+
+static inline dim3 splitk_reduce_grid(size_t n) { return dim3((unsigned)((n + 63) / 64)); }
 
 // ---------------------------------------------------------------------------------------
 // BPTT pointwise step t (Keras LSTMCell backward):
@@ -309,7 +377,7 @@ int gemm_f32(GemmArgs g, int accumulate, float* scratch, size_t scratch_floats, 
     int split = 1;
     if (tiles < 256 && K >= 512) {
         split = (512 + tiles - 1) / tiles;
-        const long maxs = K / 256;
+        const long maxs = K / 64;
         if (split > maxs) split = (int)maxs;
         if (split > 64) split = 64;
         if (split < 1) split = 1;
@@ -327,15 +395,150 @@ int gemm_f32(GemmArgs g, int accumulate, float* scratch, size_t scratch_floats, 
     }
     g.split = split;
     g.k_per_split = (int)kps;
+    // vector staging: the operand's row index is the contiguous one, every row start is 16-byte aligned and a
+    // group of four never straddles the matrix edge
+    g.a_vec = (g.a_sm == 1 && g.a_ski != 1 && (g.M & 3) == 0 && (g.a_sko & 3) == 0 && (g.a_ski & 3) == 0 &&
+               (((uintptr_t)g.a) & 15) == 0) ? 1 : 0;
+    g.b_vec = (g.b_sn == 1 && g.b_ski != 1 && (g.N & 3) == 0 && (g.b_sko & 3) == 0 && (g.b_ski & 3) == 0 &&
+               (((uintptr_t)g.b) & 15) == 0) ? 1 : 0;
     const dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, split);
     if (variant == 0) hipLaunchKernelGGL((gemm_f32_kernel<2, 4, 1>), grid, dim3(256), 0, stream, g);
     else if (variant == 1) hipLaunchKernelGGL((gemm_f32_kernel<6, 4, 1>), grid, dim3(256), 0, stream, g);
     else hipLaunchKernelGGL((gemm_f32_kernel<4, 4, 2>), grid, dim3(256), 0, stream, g);
     int rc = check_launch("gemm_f32");
     if (rc || !via_scratch) return rc;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((mn + 255) / 256)), dim3(256), 0, stream, scratch, c_final, (long)mn,
+    hipLaunchKernelGGL(splitk_reduce_kernel, splitk_reduce_grid(mn), dim3(256), 0, stream, scratch, c_final, (long)mn,
                        split, accumulate);
     return check_launch("splitk_reduce");
+}
+
+// Skinny weight gradients: out[s][w] = sum_r S[r][s] * Wd[r][w] with ns <= 8 (dK of the decoder LSTM, F_dec = 6;
+// dW of Dense(6)).  An MFMA tile would be >= 80 % padding and the product is HBM-bound anyway (Wd is read
+// once): thread = column w, block = (256 columns, chunk of rows), the ns values of a row are wave-uniform
+// scalar loads.  Partials land in scratch already in the output layout (element s*os + w*ow of slice
+// `chunk`), and splitk_reduce adds the slices in a fixed order.
+template <int NS, int VEC>
+__global__ __launch_bounds__(256) void skinny_tn_kernel(const float* __restrict__ S, long ss, const float* __restrict__ Wd,
+                                                        long ldw, float* __restrict__ part, long rows, int nw,
+                                                        long rows_per_chunk, long os, long ow) {
+    // block = 64*VEC columns x 4 row groups (wave q takes rows r0+q, r0+q+4, ...); eight rows in flight per
+    // thread, VEC = 4 reads 16 bytes per lane and row
+    __shared__ float red[4][NS][64 * VEC];
+    const int li = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int w = (blockIdx.x * 64 + li) * VEC;
+    const long r0 = (long)blockIdx.y * rows_per_chunk;
+    long r1 = r0 + rows_per_chunk;
+    if (r1 > rows) r1 = rows;
+    float acc[NS][VEC];
+#pragma unroll
+    for (int i = 0; i < NS; ++i)
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[i][v] = 0.f;
+    if (w < nw) {
+        for (long r = r0 + q; r < r1; r += 32) {
+            float wv[8][VEC];
+            long rr[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const bool ok = r + 4 * u < r1;
+                rr[u] = ok ? r + 4 * u : r;   // rows past the chunk re-read row r and contribute zero
+                if (VEC == 4) {
+                    const f32x4 t = *(const f32x4*)(Wd + rr[u] * ldw + w);
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) wv[u][v] = ok ? t[v] : 0.f;
+                } else {
+                    wv[u][0] = ok ? Wd[rr[u] * ldw + w] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int i = 0; i < NS; ++i) {
+                    const float sv = S[rr[u] * ss + i];
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) acc[i][v] = fmaf(sv, wv[u][v], acc[i][v]);
+                }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NS; ++i)
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) red[q][i][li * VEC + v] = acc[i][v];
+    __syncthreads();
+    if (q == 0 && w < nw) {
+        float* pp = part + (long)blockIdx.y * NS * nw;
+#pragma unroll
+        for (int i = 0; i < NS; ++i)
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) {
+                const int c = li * VEC + v;
+                pp[i * os + (w + v) * ow] = (red[0][i][c] + red[1][i][c]) + (red[2][i][c] + red[3][i][c]);
+            }
+    }
+}
+
+// returns 1 when the product was done here, 0 when the caller should use the MFMA GEMM, < 0 on error
+static int skinny_tn(const float* S, long ss, int ns, const float* Wd, long ldw, int nw, long rows, float* out, long os,
+                     long ow, int accumulate, float* scratch, size_t scratch_floats, hipStream_t stream) {
+    if (ns < 1 || ns > 8 || rows < 1024) return 0;
+    const bool vec = nw >= 512 && (nw & 3) == 0 && (ldw & 3) == 0 && (((uintptr_t)Wd) & 15) == 0;
+    const int colblocks = (nw + (vec ? 255 : 63)) / (vec ? 256 : 64);
+    long chunks = (2048 + colblocks - 1) / colblocks;   // ~2048 blocks when the rows allow it
+    if (chunks > rows / 32) chunks = rows / 32;         // >= 32 rows per chunk
+    if (chunks > 1024) chunks = 1024;
+    const size_t n = (size_t)ns * nw;
+    while (chunks > 1 && (size_t)chunks * n > scratch_floats) chunks >>= 1;
+    if (chunks < 1 || (size_t)chunks * n > scratch_floats) return 0;
+    const long rpc = (rows + chunks - 1) / chunks;
+    const dim3 grid(colblocks, (unsigned)chunks);
+#define FOV_SKINNY(NSV)                                                                                                       \
+    case NSV:                                                                                                                 \
+        if (vec) hipLaunchKernelGGL((skinny_tn_kernel<NSV, 4>), grid, dim3(256), 0, stream, S, ss, Wd, ldw, scratch, rows, nw, \
+                                    rpc, os, ow);                                                                             \
+        else hipLaunchKernelGGL((skinny_tn_kernel<NSV, 1>), grid, dim3(256), 0, stream, S, ss, Wd, ldw, scratch, rows, nw,    \
+                                rpc, os, ow);                                                                                 \
+        break
+    switch (ns) {
+        FOV_SKINNY(1); FOV_SKINNY(2); FOV_SKINNY(3); FOV_SKINNY(4); FOV_SKINNY(5); FOV_SKINNY(6); FOV_SKINNY(7); FOV_SKINNY(8);
+    }
+#undef FOV_SKINNY
+    int rc = check_launch("skinny_tn");
+    if (rc) return rc;
+    hipLaunchKernelGGL(splitk_reduce_kernel, splitk_reduce_grid(n), dim3(256), 0, stream, scratch, out, (long)n, (int)chunks,
+                       accumulate);
+    rc = check_launch("skinny_reduce");
+    return rc ? rc : 1;
+}
+
+// Narrow matrices (cols <= 16, e.g. the Dense(6) bias gradient over B*T rows): the column-per-thread kernel
+// above would keep 6 lanes busy.  Here a block owns a chunk of rows, threads stride over the rows with all
+// columns in registers, and a fixed-order LDS tree folds the 256 per-thread sums - deterministic.
+template <int COLS>
+__global__ __launch_bounds__(256) void colsum_narrow_kernel(const float* __restrict__ x, float* __restrict__ partial,
+                                                            long rows, int cols, long rows_per_chunk) {
+    __shared__ float red[256][COLS + 1];
+    const long r0 = (long)blockIdx.x * rows_per_chunk;
+    long r1 = r0 + rows_per_chunk;
+    if (r1 > rows) r1 = rows;
+    float acc[COLS];
+#pragma unroll
+    for (int c = 0; c < COLS; ++c) acc[c] = 0.f;
+    for (long r = r0 + threadIdx.x; r < r1; r += 256) {
+        const float* xp = x + r * cols;
+#pragma unroll
+        for (int c = 0; c < COLS; ++c)
+            if (c < cols) acc[c] += xp[c];
+    }
+#pragma unroll
+    for (int c = 0; c < COLS; ++c) red[threadIdx.x][c] = acc[c];
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s)
+#pragma unroll
+            for (int c = 0; c < COLS; ++c) red[threadIdx.x][c] += red[threadIdx.x + s][c];
+        __syncthreads();
+    }
+    if ((int)threadIdx.x < cols) partial[(long)blockIdx.x * cols + threadIdx.x] = red[0][threadIdx.x];
 }
 
 int colsum(const float* x, float* out, long rows, int cols, int accumulate, float* scratch, size_t scratch_floats,
@@ -345,12 +548,22 @@ int colsum(const float* x, float* out, long rows, int cols, int accumulate, floa
     if (chunks < 1) chunks = 1;
     if (chunks > 256) chunks = 256;
     if ((size_t)chunks * cols > scratch_floats) { set_error("colsum: scratch too small"); return FOV_ERR_WORKSPACE; }
-    const long rpc = (rows + chunks - 1) / chunks;
-    hipLaunchKernelGGL(colsum_partial_kernel, dim3((cols + 255) / 256, chunks), dim3(256), 0, stream, x, scratch, rows, cols,
-                       rpc > 0 ? rpc : 1);
+    long rpc = (rows + chunks - 1) / chunks;
+    if (cols <= 16 && rows >= 4096) {
+        chunks = (int)((rows + 2047) / 2048);
+        if (chunks > 256) chunks = 256;
+        rpc = (rows + chunks - 1) / chunks;
+        if (cols <= 8)
+            hipLaunchKernelGGL(colsum_narrow_kernel<8>, dim3(chunks), dim3(256), 0, stream, x, scratch, rows, cols, rpc);
+        else
+            hipLaunchKernelGGL(colsum_narrow_kernel<16>, dim3(chunks), dim3(256), 0, stream, x, scratch, rows, cols, rpc);
+    } else {
+        hipLaunchKernelGGL(colsum_partial_kernel, dim3((cols + 255) / 256, chunks), dim3(256), 0, stream, x, scratch, rows,
+                           cols, rpc > 0 ? rpc : 1);
+    }
     int rc = check_launch("colsum_partial");
     if (rc) return rc;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((cols + 255) / 256), dim3(256), 0, stream, scratch, out, (long)cols, chunks,
+    hipLaunchKernelGGL(splitk_reduce_kernel, splitk_reduce_grid((size_t)cols), dim3(256), 0, stream, scratch, out, (long)cols, chunks,
                        accumulate);
     return check_launch("colsum_reduce");
 }
@@ -443,8 +656,9 @@ int lstm_seq_bwd(const float* x, const float* K, const float* R, const float* h0
         GemmArgs g = {};
         g.a = x; g.b = dz; g.c = dK; g.M = F; g.N = 4 * H; g.KO = 1; g.KI = (int)BT;
         g.a_sm = 1; g.a_ski = F; g.b_sn = 1; g.b_ski = 4 * H; g.ldc = 4 * H;
-        rc = gemm_f32(g, accumulate, scratch, scratch_floats, stream);
-        if (rc) return rc;
+        rc = skinny_tn(x, F, F, dz, 4 * H, 4 * H, BT, dK, 4 * H, 1, accumulate, scratch, scratch_floats, stream);
+        if (rc == 0) rc = gemm_f32(g, accumulate, scratch, scratch_floats, stream);
+        if (rc < 0) return rc;
     }
     if (dR) {   // dR (H,4H) = sum_b sum_{t>=1} hs[b][t-1]^T dz[b][t]  +  h0^T dz[:,0]
         GemmArgs g = {};
@@ -487,8 +701,10 @@ int dense_bwd(const float* x, const float* W, const float* dpre, float* dx, floa
         GemmArgs g = {};
         g.a = x; g.b = dpre; g.c = dW; g.M = In; g.N = Out; g.KO = 1; g.KI = N;
         g.a_sm = 1; g.a_ski = In; g.b_sn = 1; g.b_ski = Out; g.ldc = Out;
-        rc = gemm_f32(g, accumulate, scratch, scratch_floats, stream);
-        if (rc) return rc;
+        // skinny form: out[s = output unit][w = input unit] stored transposed into dW (In,Out)
+        rc = skinny_tn(dpre, Out, Out, x, In, In, N, dW, 1, Out, accumulate, scratch, scratch_floats, stream);
+        if (rc == 0) rc = gemm_f32(g, accumulate, scratch, scratch_floats, stream);
+        if (rc < 0) return rc;
     }
     if (db) {
         rc = colsum(dpre, db, N, Out, accumulate, scratch, scratch_floats, stream);

@@ -120,7 +120,9 @@ def test_seq2seq_teacher_forced(impl, H, B):
 def test_dense():
     ops = _ops()
     rng = np.random.default_rng(3)
-    for N, In, Out in ((7, 256, 6), (130, 204, 6), (5, 33, 20)):
+    # (N >= 64, Out <= 8, In % 4 == 0) runs the narrow-head kernel, the rest the generic one
+    for N, In, Out in ((7, 256, 6), (130, 204, 6), (5, 33, 20), (1000, 256, 6), (4099, 40, 3), (65, 2048, 8), (333, 30, 6),
+                       (70, 512, 1)):
         x = rng.standard_normal((N, In)).astype(np.float32)
         W = (rng.standard_normal((In, Out)) / np.sqrt(In)).astype(np.float32)
         b = rng.standard_normal(Out).astype(np.float32)
@@ -128,6 +130,10 @@ def test_dense():
         assert_parity(ops.dense(dev(x), dev(W), dev(b)), ref, "dense %dx%dx%d" % (N, In, Out))
         ref = x.astype(np.float64) @ W.astype(np.float64) + b
         assert_parity(ops.dense(dev(x), dev(W), dev(b), activation=None), ref, "dense linear")
+        # the others-mixing form: + a strided row view (given_others...py:257-265)
+        addbuf = rng.standard_normal((N, Out + 5)).astype(np.float32)
+        ref = np.tanh(x.astype(np.float64) @ W.astype(np.float64) + b + addbuf[:, 2:2 + Out])
+        assert_parity(ops.dense_add(dev(x), dev(W), dev(b), dev(addbuf)[:, 2:2 + Out]), ref, "dense_add")
 
 
 # ---------------------------------------------------------------------------------------
@@ -311,7 +317,8 @@ def test_golden_others_mixing_vector(golden_dir):
 def test_matmul_and_zx_layer():
     ops = _ops()
     rng = np.random.default_rng(9)
-    for M, K, N in ((7, 33, 5), (300, 256, 1024), (1, 256, 1024), (130, 6, 70)):
+    for M, K, N in ((7, 33, 5), (300, 256, 1024), (1, 256, 1024), (130, 6, 70), (20, 64, 1024), (90, 100, 256),
+                    (96, 257, 260), (513, 40, 132)):   # every tile variant, vector and scalar staging, ragged edges
         a = rng.standard_normal((M, K)).astype(np.float32); b = rng.standard_normal((K, N)).astype(np.float32)
         ref = a.astype(np.float64) @ b.astype(np.float64)
         got = ops.matmul(dev(a), dev(b)).cpu().numpy()

@@ -323,3 +323,23 @@ def test_others_mixing_fit_surface():
                 yield [enc[lo:lo + 32], oth[lo:lo + 32], dec0[lo:lo + 32]], tgt[lo:lo + 32]
     h2 = m.fit_generator(gen(), steps_per_epoch=3, epochs=2, validation_data=gen(), validation_steps=1)
     assert len(h2.history["loss"]) == 2 and "val_loss" in h2.history
+
+
+@pytest.mark.parametrize("N,In,Out", [(5000, 64, 6), (9001, 40, 12), (300, 256, 6), (4096, 16, 1)])
+def test_dense_bwd_tall_narrow(N, In, Out):
+    """Dense backward on the (B*T, 6)-shaped operands of the training graph (FoV_seq2seq.py:96-97 under
+    model.fit): every colsum variant (narrow rows-per-thread, column-per-thread) and GEMM staging path."""
+    from longterm360fov_amd import ops
+    rng = np.random.default_rng(N + Out)
+    x = rng.standard_normal((N, In)).astype(np.float32)
+    W = rng.standard_normal((In, Out)).astype(np.float32)
+    d = rng.standard_normal((N, Out)).astype(np.float32)
+    dx, dW, db = ops.dense_bwd(dev(x), dev(W), dev(d))
+    x64, W64, d64 = x.astype(np.float64), W.astype(np.float64), d.astype(np.float64)
+    for got, ref, name in ((dx, d64 @ W64.T, "dx"), (dW, x64.T @ d64, "dW"), (db, d64.sum(0), "db")):
+        err = np.abs(got.cpu().numpy() - ref).max()
+        assert err <= 2e-5 * np.abs(ref).max() + 1e-6, (name, err)
+    # accumulate adds to what is there
+    dW0, db0 = dW.clone(), db.clone()
+    ops.dense_bwd(dev(x), dev(W), dev(d), dW=dW, db=db, need_dx=False, accumulate=True)
+    assert torch.allclose(dW, 2 * dW0, rtol=1e-5, atol=1e-5) and torch.allclose(db, 2 * db0, rtol=1e-5, atol=1e-5)
