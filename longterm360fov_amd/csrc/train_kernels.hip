@@ -33,30 +33,55 @@ struct GemmArgs {
     long b_sn, b_sko, b_ski;
     int ldc;
     int split;       // number of K slices (grid.z)
-    int k_per_split; // multiple of 16
-    int a_vec, b_vec; // operand is row-contiguous (stride 1 along m / n) and 16-byte aligned: stage with float4 loads
+    int tiles_per_split; // k-tiles (of 16, never straddling a ko row) per slice
+    int xcd_remap, grid_n, grid_m;   // 1-D grid with slices pinned to XCDs (split >= 8)
 };
 
 constexpr int GBK = 16;
+typedef unsigned gu32x4 __attribute__((ext_vector_type(4)));
 
 // Block tile BM x BN x 16 with BM = 16*MI*WAVES_M, BN = 16*NI*(4/WAVES_M); each of the 4 waves owns
 // MI x NI MFMA tiles.  LDS tiles are k-major ([k][m], [k][n]) so a fragment read is 16 consecutive
-// floats per k.  Global->LDS staging goes through registers one k-tile ahead, with the (ko, ki)
-// split of every staged element advanced incrementally (no integer division in the loop: fp32 MFMA
-// shares the VALU, so staging arithmetic is paid for in MFMA slots).
-template <int MI, int NI, int WAVES_M>
+// floats per k.  Global->LDS staging goes through registers one k-tile ahead.
+//
+// fp32 MFMA shares the VALU issue slots, so staging arithmetic is paid for in MFMA time.  The k-tiles
+// therefore never straddle a ko row: tile t <-> (ko = t / ntpr, kt = t % ntpr) with ntpr = ceil(KI/16),
+// its k = ko*KI + kt*16 + kk.  The tile's base address is wave-uniform (SALU), each thread adds a 32-bit
+// offset fixed for the whole kernel, and the only per-load VALU work is the mask of the last, partial
+// tile of a row (<= 15 zero columns per ko row; KI = 29 wastes 9 % of the MFMAs and saves far more).
+// AMODE / BMODE (compile-time, so the staged registers never meet at a control-flow merge - a merge makes the
+// compiler wait for the loads before the MFMAs): 0 = k-slow operand, 16-byte buffer loads; 1 = k-slow, 4-byte
+// buffer loads; 2 = any layout, global loads + select at stash time.
+template <int MI, int NI, int WAVES_M, int AMODE, int BMODE>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
     constexpr int WAVES_N = 4 / WAVES_M;
     constexpr int BM = 16 * MI * WAVES_M, BN = 16 * NI * WAVES_N;
     constexpr int RA = BM / 16, RB = BN / 16;   // staged elements per thread per k-tile
-    __shared__ __attribute__((aligned(16))) float As[2][GBK][BM + 4];
-    __shared__ __attribute__((aligned(16))) float Bs[2][GBK][BN + 4];
+    constexpr int RA4 = (RA + 3) / 4, RB4 = (RB + 3) / 4;   // float4 groups per thread (last round may be partial)
+    // row stride = 16 mod 32 floats: the four k rows (lq) of a ds_read_b32 fragment land on disjoint banks
+    __shared__ __attribute__((aligned(16))) float As[2][GBK][BM + 16];
+    __shared__ __attribute__((aligned(16))) float Bs[2][GBK][BN + 16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-    const int K = g.KO * g.KI;
-    const int kbeg = blockIdx.z * g.k_per_split;
-    int kend = kbeg + g.k_per_split;
-    if (kend > K) kend = K;
+    // Block -> (n tile, m tile, K slice).  Workgroups are dealt round-robin to the 8 XCDs, each with its own
+    // L2.  With split-K the blocks of one slice read the same K range of A and B, so a slice is kept on one
+    // XCD (1-D grid, xcd = id % 8): its operands cross the fabric once instead of once per XCD.  Measured on
+    // dR (256 x 1024 x 30720, 32 slices): L2-miss traffic was the bound, not the MFMA pipe.
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (g.xcd_remap) {
+        const int nb = g.grid_n * g.grid_m;
+        const int xcd = blockIdx.x & 7, w = blockIdx.x >> 3;
+        bz = xcd + 8 * (w / nb);
+        if (bz >= g.split) return;   // whole block, before any barrier
+        const int tile = w - (w / nb) * nb;
+        by = tile / g.grid_n;
+        bx = tile - by * g.grid_n;
+    }
+    const int m0 = by * BM, n0 = bx * BN;
+    const int ntpr = (g.KI + GBK - 1) / GBK;
+    const int tiles_total = g.KO * ntpr;
+    const int tbeg = bz * g.tiles_per_split;
+    int tend = tbeg + g.tiles_per_split;
+    if (tend > tiles_total) tend = tiles_total;
     const int wm = (wave / WAVES_N) * 16 * MI, wn = (wave % WAVES_N) * 16 * NI;
     const int li = lane & 15, lq = lane >> 4;
 
@@ -66,24 +91,23 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
 #pragma unroll
         for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // Staging.  Scalar path: element e = tid + 256*r of a (rows x 16) tile (k-fast operands: consecutive
+    // Staging maps.  Scalar path: element e = tid + 256*r of a (rows x 16) tile (k-fast operands: consecutive
     // threads walk k, else the row index).  Vector path (row-contiguous, aligned operand): group e4 = tid +
     // 256*r of (rows/4 x 16) float4 groups, consecutive threads walk the row index, one 16-byte load and one
-    // ds_write_b128 per group - 4x fewer staging instructions, which matters because fp32 MFMA and the
-    // staging VALU share the issue slots.
+    // ds_write_b128 per group.
     const bool a_kfast = (g.a_ski == 1), b_kfast = (g.b_ski == 1);
-    const bool a_vec = g.a_vec != 0, b_vec = g.b_vec != 0;
-    constexpr int RA4 = (RA + 3) / 4, RB4 = (RB + 3) / 4;   // float4 groups per thread (last round may be partial)
-    int a_mm[RA], a_kk[RA], a_ko[RA], a_ki[RA];
-    int b_nn[RB], b_kk[RB], b_ko[RB], b_ki[RB];
+    constexpr bool a_vec = (AMODE == 0), b_vec = (BMODE == 0);
+    int a_mm[RA], a_kk[RA], b_nn[RB], b_kk[RB];
+    unsigned a_off[RA], b_off[RB];   // element offset from the tile base (block rows x 16 k: fits 32 bits, host-checked)
+    bool a_ok[RA], b_ok[RB];
 #pragma unroll
     for (int r = 0; r < RA; ++r) {
         const int e = tid + 256 * r;
         if (a_vec) { a_kk[r] = e / (BM / 4); a_mm[r] = 4 * (e - a_kk[r] * (BM / 4)); }
         else if (a_kfast) { a_mm[r] = e >> 4; a_kk[r] = e & 15; }
         else { a_kk[r] = e / BM; a_mm[r] = e - a_kk[r] * BM; }
-        const int k = kbeg + a_kk[r];
-        a_ko[r] = k / g.KI; a_ki[r] = k - a_ko[r] * g.KI;
+        a_ok[r] = (m0 + a_mm[r] < g.M) && a_kk[r] < GBK;
+        a_off[r] = a_ok[r] ? (unsigned)((long)a_mm[r] * g.a_sm + (long)a_kk[r] * g.a_ski) : 0u;
     }
 #pragma unroll
     for (int r = 0; r < RB; ++r) {
@@ -91,98 +115,132 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
         if (b_vec) { b_kk[r] = e / (BN / 4); b_nn[r] = 4 * (e - b_kk[r] * (BN / 4)); }
         else if (b_kfast) { b_nn[r] = e >> 4; b_kk[r] = e & 15; }
         else { b_kk[r] = e / BN; b_nn[r] = e - b_kk[r] * BN; }
-        const int k = kbeg + b_kk[r];
-        b_ko[r] = k / g.KI; b_ki[r] = k - b_ko[r] * g.KI;
+        b_ok[r] = (n0 + b_nn[r] < g.N) && b_kk[r] < GBK;
+        b_off[r] = b_ok[r] ? (unsigned)((long)b_nn[r] * g.b_sn + (long)b_kk[r] * g.b_ski) : 0u;
     }
+    const float* a_blk = g.a + (long)m0 * g.a_sm;
+    const float* b_blk = g.b + (long)n0 * g.b_sn;
+    int f_ko = tbeg / ntpr, f_kt = tbeg - f_ko * ntpr;   // the tile the next fetch() loads (wave-uniform)
     float ra[RA], rb[RB];
     f32x4 va[RA4], vb[RB4];
-    auto fetch = [&](int k0) {   // loads the tile starting at k0, then advances the (ko, ki) state by 16
-        if (a_vec) {
+    int s_kmax = 0;   // valid k columns of the tile sitting in ra/rb/va/vb
+    // k-slow operands ([k][row] storage, every training GEMM here) go through a per-tile buffer descriptor:
+    // base = the tile (wave-uniform, SALU), num_records = the valid k rows, so k >= kmax is out of range and
+    // the hardware returns 0; rows >= M carry an out-of-range sentinel offset.  No VALU per load at all.
+    // Other operands (k-fast A of NN / NT products) use global loads; invalid elements read offset 0 of the
+    // tile (always in bounds) and are zeroed in stash(), after the MFMAs of the current tile - a select next
+    // to the load would make the wave wait for the memory latency before it starts its MFMAs.
+    constexpr bool a_buf = (AMODE != 2), b_buf = (BMODE != 2);
+    unsigned a_boff[RA], b_boff[RB];
 #pragma unroll
-            for (int r = 0; r < RA4; ++r) {
-                const int m = m0 + a_mm[r];
-                va[r] = (m < g.M && a_kk[r] < GBK && k0 + a_kk[r] < kend)
-                            ? *(const f32x4*)(g.a + (long)m + (long)a_ko[r] * g.a_sko + (long)a_ki[r] * g.a_ski)
-                            : (f32x4){0.f, 0.f, 0.f, 0.f};
-                a_ki[r] += GBK;
-                while (a_ki[r] >= g.KI) { a_ki[r] -= g.KI; ++a_ko[r]; }
+    for (int r = 0; r < RA; ++r) a_boff[r] = a_ok[r] ? a_off[r] * 4u : 0x80000000u;
+#pragma unroll
+    for (int r = 0; r < RB; ++r) b_boff[r] = b_ok[r] ? b_off[r] * 4u : 0x80000000u;
+    auto fetch = [&]() {
+        const float* ta = a_blk + (long)f_ko * g.a_sko + (long)(f_kt * GBK) * g.a_ski;
+        const float* tb = b_blk + (long)f_ko * g.b_sko + (long)(f_kt * GBK) * g.b_ski;
+        const int kmax = g.KI - f_kt * GBK;   // >= 16 except for the row's last tile
+        const int krows = kmax < GBK ? kmax : GBK;
+        s_kmax = kmax;
+        if constexpr (a_buf) {
+            const __amdgpu_buffer_rsrc_t rs =
+                __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ta), 0, krows * (int)g.a_ski * 4, 0x00020000);
+            if constexpr (a_vec) {
+#pragma unroll
+                for (int r = 0; r < RA4; ++r) {
+                    const gu32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs, a_boff[r], 0, 0);
+                    va[r] = (f32x4){__uint_as_float(t[0]), __uint_as_float(t[1]), __uint_as_float(t[2]), __uint_as_float(t[3])};
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < RA; ++r) ra[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, a_boff[r], 0, 0));
             }
         } else {
 #pragma unroll
-            for (int r = 0; r < RA; ++r) {
-                const int m = m0 + a_mm[r];
-                ra[r] = (m < g.M && k0 + a_kk[r] < kend)
-                            ? g.a[(long)m * g.a_sm + (long)a_ko[r] * g.a_sko + (long)a_ki[r] * g.a_ski] : 0.f;
-                a_ki[r] += GBK;
-                while (a_ki[r] >= g.KI) { a_ki[r] -= g.KI; ++a_ko[r]; }
-            }
+            for (int r = 0; r < RA; ++r) ra[r] = ta[(a_ok[r] && a_kk[r] < kmax) ? a_off[r] : 0u];
         }
-        if (b_vec) {
+        if constexpr (b_buf) {
+            const __amdgpu_buffer_rsrc_t rs =
+                __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(tb), 0, krows * (int)g.b_ski * 4, 0x00020000);
+            if constexpr (b_vec) {
 #pragma unroll
-            for (int r = 0; r < RB4; ++r) {
-                const int n = n0 + b_nn[r];
-                vb[r] = (n < g.N && b_kk[r] < GBK && k0 + b_kk[r] < kend)
-                            ? *(const f32x4*)(g.b + (long)n + (long)b_ko[r] * g.b_sko + (long)b_ki[r] * g.b_ski)
-                            : (f32x4){0.f, 0.f, 0.f, 0.f};
-                b_ki[r] += GBK;
-                while (b_ki[r] >= g.KI) { b_ki[r] -= g.KI; ++b_ko[r]; }
+                for (int r = 0; r < RB4; ++r) {
+                    const gu32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs, b_boff[r], 0, 0);
+                    vb[r] = (f32x4){__uint_as_float(t[0]), __uint_as_float(t[1]), __uint_as_float(t[2]), __uint_as_float(t[3])};
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < RB; ++r) rb[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, b_boff[r], 0, 0));
             }
         } else {
 #pragma unroll
-            for (int r = 0; r < RB; ++r) {
-                const int n = n0 + b_nn[r];
-                rb[r] = (n < g.N && k0 + b_kk[r] < kend)
-                            ? g.b[(long)n * g.b_sn + (long)b_ko[r] * g.b_sko + (long)b_ki[r] * g.b_ski] : 0.f;
-                b_ki[r] += GBK;
-                while (b_ki[r] >= g.KI) { b_ki[r] -= g.KI; ++b_ko[r]; }
-            }
+            for (int r = 0; r < RB; ++r) rb[r] = tb[(b_ok[r] && b_kk[r] < kmax) ? b_off[r] : 0u];
         }
+        if (++f_kt == ntpr) { f_kt = 0; ++f_ko; }
     };
     auto stash = [&](int buf) {
-        if (a_vec) {
+        const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (a_vec) {
 #pragma unroll
             for (int r = 0; r < RA4; ++r)
-                if (a_kk[r] < GBK) *(f32x4*)&As[buf][a_kk[r]][a_mm[r]] = va[r];
+                if (a_kk[r] < GBK) *(f32x4*)&As[buf][a_kk[r]][a_mm[r]] = (a_buf || (a_ok[r] && a_kk[r] < s_kmax)) ? va[r] : z4;
         } else {
 #pragma unroll
-            for (int r = 0; r < RA; ++r) As[buf][a_kk[r]][a_mm[r]] = ra[r];
+            for (int r = 0; r < RA; ++r) As[buf][a_kk[r]][a_mm[r]] = (a_buf || (a_ok[r] && a_kk[r] < s_kmax)) ? ra[r] : 0.f;
         }
-        if (b_vec) {
+        if constexpr (b_vec) {
 #pragma unroll
             for (int r = 0; r < RB4; ++r)
-                if (b_kk[r] < GBK) *(f32x4*)&Bs[buf][b_kk[r]][b_nn[r]] = vb[r];
+                if (b_kk[r] < GBK) *(f32x4*)&Bs[buf][b_kk[r]][b_nn[r]] = (b_buf || (b_ok[r] && b_kk[r] < s_kmax)) ? vb[r] : z4;
         } else {
 #pragma unroll
-            for (int r = 0; r < RB; ++r) Bs[buf][b_kk[r]][b_nn[r]] = rb[r];
+            for (int r = 0; r < RB; ++r) Bs[buf][b_kk[r]][b_nn[r]] = (b_buf || (b_ok[r] && b_kk[r] < s_kmax)) ? rb[r] : 0.f;
         }
     };
     int buf = 0;
-    if (kbeg < kend) {
-        fetch(kbeg);
+    if (tbeg < tend) {
+        fetch();
         stash(0);
     }
     __syncthreads();
-    for (int k0 = kbeg; k0 < kend; k0 += GBK) {
-        const bool more = (k0 + GBK < kend);
-        if (more) fetch(k0 + GBK);
+    // Per tile: all fragment reads first (one exposed LDS latency per tile instead of one per k-step), then the
+    // global loads of the next tile, then 16*MI*NI/4 back-to-back MFMAs, then the staged tile goes to the other
+    // LDS buffer.  The last tile is peeled so the staged registers are never live across a branch.
+    float av[4][MI], bv[4][NI];
+    auto read_frags = [&](int buf) {
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            float av[MI], bv[NI];
 #pragma unroll
-            for (int i = 0; i < MI; ++i) av[i] = As[buf][ks * 4 + lq][wm + i * 16 + li];
+            for (int i = 0; i < MI; ++i) av[ks][i] = As[buf][ks * 4 + lq][wm + i * 16 + li];
 #pragma unroll
-            for (int j = 0; j < NI; ++j) bv[j] = Bs[buf][ks * 4 + lq][wn + j * 16 + li];
+            for (int j = 0; j < NI; ++j) bv[ks][j] = Bs[buf][ks * 4 + lq][wn + j * 16 + li];
+        }
+    };
+    auto mfmas = [&]() {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < NI; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[j], acc[i][j], 0, 0, 0);
-        }
-        if (more) stash(buf ^ 1);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks][i], bv[ks][j], acc[i][j], 0, 0, 0);
+    };
+    for (int t = tbeg; t + 1 < tend; ++t) {
+        read_frags(buf);
+        __builtin_amdgcn_sched_barrier(0);
+        fetch();
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas();
+        __builtin_amdgcn_sched_barrier(0);
+        stash(buf ^ 1);
         __syncthreads();
         buf ^= 1;
     }
-    float* c = g.c + (g.split > 1 ? (size_t)blockIdx.z * g.M * g.ldc : 0);
+    if (tbeg < tend) {
+        read_frags(buf);
+        mfmas();
+    }
+    float* c = g.c + (g.split > 1 ? (size_t)bz * g.M * g.ldc : 0);
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -373,19 +431,31 @@ int gemm_f32(GemmArgs g, int accumulate, float* scratch, size_t scratch_floats, 
     if (g.M <= 32) { BM = 32; BN = 256; variant = 0; }
     else if (g.M <= 96) { BM = 96; BN = 256; variant = 1; }
     else { BM = 128; BN = 128; variant = 2; }
+    // per-thread staging offsets span one block tile: they must fit 32 bits
+    {
+        const long amax = (long)BM * (g.a_sm < 0 ? -g.a_sm : g.a_sm) + 16 * (g.a_ski < 0 ? -g.a_ski : g.a_ski);
+        const long bmax = (long)BN * (g.b_sn < 0 ? -g.b_sn : g.b_sn) + 16 * (g.b_ski < 0 ? -g.b_ski : g.b_ski);
+        if (amax >= (1L << 30) || bmax >= (1L << 30) || g.a_sm < 0 || g.a_ski < 0 || g.b_sn < 0 || g.b_ski < 0) {
+            set_error("gemm_f32: operand strides out of range");
+            return FOV_ERR_UNSUPPORTED;
+        }
+    }
+    const int ntpr = (g.KI + GBK - 1) / GBK;
+    const long ktiles = (long)g.KO * ntpr;
+    if (ktiles > 0x7fffffffL) { set_error("gemm_f32: K too large"); return FOV_ERR_UNSUPPORTED; }
     const int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
     int split = 1;
-    if (tiles < 256 && K >= 512) {
+    if (tiles < 256 && ktiles >= 32) {
         split = (512 + tiles - 1) / tiles;
-        const long maxs = K / 64;
+        const long maxs = ktiles / 4;   // >= 4 k-tiles (64 k) per slice
         if (split > maxs) split = (int)maxs;
         if (split > 64) split = 64;
         if (split < 1) split = 1;
     }
+    if (const char* e = getenv("FOV_GEMM_SPLIT")) { const int v = atoi(e); if (v >= 1 && v <= ktiles) split = v; }   // tuning knob
     while (split > 1 && (size_t)split * mn > scratch_floats) --split;
-    long kps = (K + split - 1) / split;
-    kps = (kps + GBK - 1) / GBK * GBK;
-    split = (int)((K + kps - 1) / kps);
+    const long tps = (ktiles + split - 1) / split;
+    split = (int)((ktiles + tps - 1) / tps);
     const bool via_scratch = (split > 1) || accumulate;
     float* c_final = g.c;
     if (via_scratch) {
@@ -394,17 +464,38 @@ int gemm_f32(GemmArgs g, int accumulate, float* scratch, size_t scratch_floats, 
         g.c = scratch;
     }
     g.split = split;
-    g.k_per_split = (int)kps;
-    // vector staging: the operand's row index is the contiguous one, every row start is 16-byte aligned and a
-    // group of four never straddles the matrix edge
-    g.a_vec = (g.a_sm == 1 && g.a_ski != 1 && (g.M & 3) == 0 && (g.a_sko & 3) == 0 && (g.a_ski & 3) == 0 &&
-               (((uintptr_t)g.a) & 15) == 0) ? 1 : 0;
-    g.b_vec = (g.b_sn == 1 && g.b_ski != 1 && (g.N & 3) == 0 && (g.b_sko & 3) == 0 && (g.b_ski & 3) == 0 &&
-               (((uintptr_t)g.b) & 15) == 0) ? 1 : 0;
-    const dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, split);
-    if (variant == 0) hipLaunchKernelGGL((gemm_f32_kernel<2, 4, 1>), grid, dim3(256), 0, stream, g);
-    else if (variant == 1) hipLaunchKernelGGL((gemm_f32_kernel<6, 4, 1>), grid, dim3(256), 0, stream, g);
-    else hipLaunchKernelGGL((gemm_f32_kernel<4, 4, 2>), grid, dim3(256), 0, stream, g);
+    g.tiles_per_split = (int)tps;
+    // staging modes.  k-slow: all row offsets of one k row stay below the k stride and 16 k rows fit a 31-bit
+    // byte range -> buffer loads; 16-byte form when the row index is contiguous, every row start is 16-byte
+    // aligned and a group of four never straddles the matrix edge.
+    const bool a_ks = g.a_ski >= (long)(g.M - 1) * g.a_sm + 1 && g.a_ski < (1L << 24) && (((uintptr_t)g.a) & 3) == 0;
+    const bool b_ks = g.b_ski >= (long)(g.N - 1) * g.b_sn + 1 && g.b_ski < (1L << 24) && (((uintptr_t)g.b) & 3) == 0;
+    const bool a_v4 = a_ks && g.a_sm == 1 && (g.M & 3) == 0 && (g.a_sko & 3) == 0 && (g.a_ski & 3) == 0 && (((uintptr_t)g.a) & 15) == 0;
+    const bool b_v4 = b_ks && g.b_sn == 1 && (g.N & 3) == 0 && (g.b_sko & 3) == 0 && (g.b_ski & 3) == 0 && (((uintptr_t)g.b) & 15) == 0;
+    const int amode = a_v4 ? 0 : (a_ks ? 1 : 2), bmode = b_v4 ? 0 : (b_ks ? 1 : 2);
+    g.grid_n = (g.N + BN - 1) / BN;
+    g.grid_m = (g.M + BM - 1) / BM;
+    g.xcd_remap = split >= 8 ? 1 : 0;
+    const dim3 grid = g.xcd_remap ? dim3((unsigned)(8 * ((split + 7) / 8) * g.grid_n * g.grid_m)) : dim3(g.grid_n, g.grid_m, split);
+#define FOV_GEMM_LAUNCH(MI_, NI_, WM_, A_, B_) \
+    hipLaunchKernelGGL((gemm_f32_kernel<MI_, NI_, WM_, A_, B_>), grid, dim3(256), 0, stream, g)
+#define FOV_GEMM_MODES(MI_, NI_, WM_)                                                            \
+    switch (amode * 3 + bmode) {                                                                 \
+        case 0: FOV_GEMM_LAUNCH(MI_, NI_, WM_, 0, 0); break;                                     \
+        case 1: FOV_GEMM_LAUNCH(MI_, NI_, WM_, 0, 1); break;                                     \
+        case 2: FOV_GEMM_LAUNCH(MI_, NI_, WM_, 0, 2); break;                                     \
+        case 3: FOV_GEMM_LAUNCH(MI_, NI_, WM_, 1, 0); break;                                     \
+        case 4: FOV_GEMM_LAUNCH(MI_, NI_, WM_, 1, 1); break;                                     \
+        case 5: FOV_GEMM_LAUNCH(MI_, NI_, WM_, 1, 2); break;                                     \
+        case 6: FOV_GEMM_LAUNCH(MI_, NI_, WM_, 2, 0); break;                                     \
+        case 7: FOV_GEMM_LAUNCH(MI_, NI_, WM_, 2, 1); break;                                     \
+        default: FOV_GEMM_LAUNCH(MI_, NI_, WM_, 2, 2); break;                                    \
+    }
+    if (variant == 0) { FOV_GEMM_MODES(2, 4, 1) }
+    else if (variant == 1) { FOV_GEMM_MODES(6, 4, 1) }
+    else { FOV_GEMM_MODES(4, 4, 2) }
+#undef FOV_GEMM_MODES
+#undef FOV_GEMM_LAUNCH
     int rc = check_launch("gemm_f32");
     if (rc || !via_scratch) return rc;
     hipLaunchKernelGGL(splitk_reduce_kernel, splitk_reduce_grid(mn), dim3(256), 0, stream, scratch, c_final, (long)mn,
