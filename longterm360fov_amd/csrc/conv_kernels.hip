@@ -23,21 +23,41 @@ struct ConvArgs {
     long ldb;   // batch stride
 };
 
-template <int MI, int NI, int WAVES_M>
+typedef unsigned cu32x4 __attribute__((ext_vector_type(4)));
+
+// Implicit GEMM, M = B*H*W pixels, N = output channels, K = (tap, channel).  The k-tiles (16 wide) never
+// straddle a filter tap: tile <-> (tap, c0), so the tap's spatial shift is wave-uniform and goes into the
+// base address of a per-tile buffer descriptor (SALU); each thread keeps the byte offset of its pixels,
+// fixed for the whole kernel, and only decides per tile whether the shifted pixel is inside the image -
+// outside ('same' zero padding), past the last channel, or past the last pixel it presents an out-of-range
+// offset and the hardware returns 0.  fp32 MFMA shares the VALU issue slots, so this matters: no select on
+// loaded data, no 64-bit address arithmetic per element.
+//   AVEC: C % 4 == 0 and 16-byte aligned pixels -> one 16-byte load per (pixel, 4 channels)
+//   BVEC: N % 4 == 0 -> 16-byte loads of the (K,N) weight rows
+// LDS: As[m][k] (k contiguous, stride 24 floats: conflict-free ds_read_b128), Bs[k][n].  With the MFMA k-slot
+// of lane group lq in step s mapped to k = 4*lq + s (for A and B alike) one ds_read_b128 gives a lane its A
+// operands of all four steps.
+// Staging modes are template parameters and the last tile is peeled: staged registers never cross a branch,
+// so the compiler waits for the loads where they are written to LDS, after the MFMAs.
+template <int MI, int NI, int WAVES_M, int AVEC, int BVEC>
 __global__ __launch_bounds__(256) void conv2d_igemm_kernel(ConvArgs g) {
     constexpr int WAVES_N = 4 / WAVES_M;
     constexpr int BM = 16 * MI * WAVES_M, BN = 16 * NI * WAVES_N, BK = 16;
-    constexpr int RA = BM / 16, RB = BN / 16;
-    __shared__ __attribute__((aligned(16))) float As[2][BK][BM + 4];
-    __shared__ __attribute__((aligned(16))) float Bs[2][BK][BN + 4];
+    constexpr int LDA = 24, LDB = BN + 4;
+    constexpr int RA = AVEC ? BM / 64 : BM / 16;                 // loads per thread per tile (A)
+    constexpr int RB = BVEC ? (BN * 4 + 255) / 256 : BN / 16;    // loads per thread per tile (B)
+    constexpr unsigned OOR = 0x80000000u;
+    __shared__ __attribute__((aligned(16))) float As[2][BM][LDA];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BK][LDB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long M = (long)g.B * g.H * g.W;
-    const int K = g.kh * g.kw * g.C;
     const long m0 = (long)blockIdx.y * BM;
     const int n0 = blockIdx.x * BN;
     const int wm = (wave / WAVES_N) * 16 * MI, wn = (wave % WAVES_N) * 16 * NI;
     const int li = lane & 15, lq = lane >> 4;
     const int ph = (g.kh - 1) / 2, pw = (g.kw - 1) / 2;
+    const int ctiles = (g.C + BK - 1) / BK;
+    const int ntiles = g.kh * g.kw * ctiles;
 
     f32x4 acc[MI][NI];
 #pragma unroll
@@ -45,84 +65,130 @@ __global__ __launch_bounds__(256) void conv2d_igemm_kernel(ConvArgs g) {
 #pragma unroll
         for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // A staging: element e = tid + 256 r -> (pixel mm = e/16, k offset kk = e%16); per element the pixel's
-    // (y, x, base pointer) is fixed and the filter tap (dy, dx, c) advances by 16 channels per k-tile.
-    const int a_kk = tid & 15;
-    int a_y[RA], a_x[RA], a_c[RA], a_dy[RA], a_dx[RA];
-    const float* a_base[RA];
-    bool a_live[RA];
+    // A staging map: AVEC group e = tid + 256 r -> (pixel e/4, channel quad e%4); scalar element e -> (pixel
+    // e/16, channel e%16).  Consecutive lanes walk the channels of a pixel, then the next pixel.
+    int a_mm[RA], a_kc[RA], a_y[RA], a_x[RA];
+    unsigned a_pix[RA];
 #pragma unroll
     for (int r = 0; r < RA; ++r) {
-        const long m = m0 + ((tid + 256 * r) >> 4);
-        a_live[r] = m < M;
-        const long mm = a_live[r] ? m : 0;
-        const int b = (int)(mm / ((long)g.H * g.W));
-        const int rem = (int)(mm - (long)b * g.H * g.W);
-        a_y[r] = rem / g.W;
-        a_x[r] = rem - a_y[r] * g.W;
-        a_base[r] = g.x + (long)b * g.ldb;
-        const int tap = a_kk / g.C;
-        a_c[r] = a_kk - tap * g.C;
-        a_dy[r] = tap / g.kw;
-        a_dx[r] = tap - a_dy[r] * g.kw;
+        const int e = tid + 256 * r;
+        a_mm[r] = AVEC ? (e >> 2) : (e >> 4);
+        a_kc[r] = AVEC ? 4 * (e & 3) : (e & 15);
+        const long m = m0 + a_mm[r];
+        if (m < M) {
+            const int b = (int)(m / ((long)g.H * g.W));
+            const int rem = (int)(m - (long)b * g.H * g.W);
+            a_y[r] = rem / g.W;
+            a_x[r] = rem - a_y[r] * g.W;
+            a_pix[r] = (unsigned)(((long)b * g.ldb + (long)rem * g.ldx + a_kc[r]) * 4);
+        } else {
+            a_y[r] = -(1 << 20);   // never inside the image
+            a_x[r] = 0;
+            a_pix[r] = OOR;
+        }
     }
-    // B staging: w is (K, N) row-major: consecutive threads walk n
-    int b_nn[RB], b_kk[RB];
+    // B staging map: (k row, n) of the (16 x BN) weight tile; byte offset from the tile's first row
+    int b_kk[RB], b_nn[RB];
+    unsigned b_off[RB];
 #pragma unroll
     for (int r = 0; r < RB; ++r) {
         const int e = tid + 256 * r;
-        b_kk[r] = e / BN;
-        b_nn[r] = e - b_kk[r] * BN;
+        b_kk[r] = BVEC ? e / (BN / 4) : e / BN;
+        b_nn[r] = BVEC ? 4 * (e - b_kk[r] * (BN / 4)) : e - b_kk[r] * BN;
+        const bool ok = b_kk[r] < BK && n0 + b_nn[r] < g.N;
+        b_off[r] = ok ? (unsigned)(((long)b_kk[r] * g.N + n0 + b_nn[r]) * 4) : OOR;
     }
-    float ra[RA], rb[RB];
-    auto fetch = [&](int k0) {
+
+    int f_dy = 0, f_dx = 0, f_ct = 0;   // the tile the next fetch() loads (wave-uniform)
+    float ra[AVEC ? 1 : RA], rb[BVEC ? 1 : RB];
+    f32x4 va[AVEC ? RA : 1], vb[BVEC ? RB : 1];
+    auto fetch = [&]() {
+        const int c0 = f_ct * BK;
+        const int sy = f_dy - ph, sx = f_dx - pw;
+        const float* xt = g.x + ((long)sy * g.W + sx) * g.ldx + c0;
+        const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xt), 0, 0x7fffffff, 0x00020000);
+        const int crem = g.C - c0;   // channels left in this tap
 #pragma unroll
         for (int r = 0; r < RA; ++r) {
-            const int yy = a_y[r] + a_dy[r] - ph, xx = a_x[r] + a_dx[r] - pw;
-            const bool ok = a_live[r] && (k0 + a_kk < K) && yy >= 0 && yy < g.H && xx >= 0 && xx < g.W;
-            ra[r] = ok ? a_base[r][((long)yy * g.W + xx) * g.ldx + a_c[r]] : 0.f;
-            a_c[r] += BK;
-            while (a_c[r] >= g.C) {
-                a_c[r] -= g.C;
-                if (++a_dx[r] == g.kw) { a_dx[r] = 0; ++a_dy[r]; }
+            const int yy = a_y[r] + sy, xx = a_x[r] + sx;
+            const bool ok = yy >= 0 && yy < g.H && xx >= 0 && xx < g.W && a_kc[r] < crem;
+            const unsigned off = ok ? a_pix[r] : OOR;
+            if constexpr (AVEC) {
+                const cu32x4 t = __builtin_amdgcn_raw_buffer_load_b128(xrs, off, 0, 0);
+                va[r] = (f32x4){__uint_as_float(t[0]), __uint_as_float(t[1]), __uint_as_float(t[2]), __uint_as_float(t[3])};
+            } else {
+                ra[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrs, off, 0, 0));
             }
         }
+        const int tap = f_dy * g.kw + f_dx;
+        const float* wt = g.w + ((long)tap * g.C + c0) * g.N;
+        const int krows = crem < BK ? crem : BK;
+        const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wt), 0, krows * g.N * 4, 0x00020000);
 #pragma unroll
         for (int r = 0; r < RB; ++r) {
-            const int k = k0 + b_kk[r], n = n0 + b_nn[r];
-            rb[r] = (k < K && n < g.N) ? g.w[(long)k * g.N + n] : 0.f;
+            if constexpr (BVEC) {
+                const cu32x4 t = __builtin_amdgcn_raw_buffer_load_b128(wrs, b_off[r], 0, 0);
+                vb[r] = (f32x4){__uint_as_float(t[0]), __uint_as_float(t[1]), __uint_as_float(t[2]), __uint_as_float(t[3])};
+            } else {
+                rb[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(wrs, b_off[r], 0, 0));
+            }
+        }
+        if (++f_ct == ctiles) {
+            f_ct = 0;
+            if (++f_dx == g.kw) { f_dx = 0; ++f_dy; }
         }
     };
     auto stash = [&](int buf) {
 #pragma unroll
-        for (int r = 0; r < RA; ++r) As[buf][a_kk][(tid + 256 * r) >> 4] = ra[r];
+        for (int r = 0; r < RA; ++r) {
+            if constexpr (AVEC) *(f32x4*)&As[buf][a_mm[r]][a_kc[r]] = va[r];
+            else As[buf][a_mm[r]][a_kc[r]] = ra[r];
+        }
 #pragma unroll
-        for (int r = 0; r < RB; ++r) Bs[buf][b_kk[r]][b_nn[r]] = rb[r];
+        for (int r = 0; r < RB; ++r) {
+            if constexpr (BVEC) {
+                if (b_kk[r] < BK) *(f32x4*)&Bs[buf][b_kk[r]][b_nn[r]] = vb[r];
+            } else {
+                Bs[buf][b_kk[r]][b_nn[r]] = rb[r];
+            }
+        }
     };
-    int buf = 0;
-    fetch(0);
-    stash(0);
-    __syncthreads();
-    for (int k0 = 0; k0 < K; k0 += BK) {
-        const bool more = (k0 + BK < K);
-        if (more) fetch(k0 + BK);
+    f32x4 af[MI];
+    float bv[4][NI];
+    auto read_frags = [&](int buf) {
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            float av[MI], bv[NI];
+        for (int i = 0; i < MI; ++i) af[i] = *(const f32x4*)&As[buf][wm + i * 16 + li][4 * lq];
 #pragma unroll
-            for (int i = 0; i < MI; ++i) av[i] = As[buf][ks * 4 + lq][wm + i * 16 + li];
+        for (int s = 0; s < 4; ++s)
 #pragma unroll
-            for (int j = 0; j < NI; ++j) bv[j] = Bs[buf][ks * 4 + lq][wn + j * 16 + li];
+            for (int j = 0; j < NI; ++j) bv[s][j] = Bs[buf][4 * lq + s][wn + j * 16 + li];
+    };
+    auto mfmas = [&]() {
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < NI; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[j], acc[i][j], 0, 0, 0);
-        }
-        if (more) stash(buf ^ 1);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][s], bv[s][j], acc[i][j], 0, 0, 0);
+    };
+    int buf = 0;
+    fetch();
+    stash(0);
+    __syncthreads();
+    for (int t = 0; t + 1 < ntiles; ++t) {
+        read_frags(buf);
+        __builtin_amdgcn_sched_barrier(0);
+        fetch();
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas();
+        __builtin_amdgcn_sched_barrier(0);
+        stash(buf ^ 1);
         __syncthreads();
         buf ^= 1;
     }
+    read_frags(buf);
+    mfmas();
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -184,16 +250,31 @@ int conv2d_fwd(const float* x, long ldx, long ldb, const float* w, const float* 
     g.B = B; g.H = H; g.W = W; g.C = C; g.N = N; g.kh = kh; g.kw = kw; g.act = act; g.ldx = ldx; g.ldb = ldb;
     const long M = (long)B * H * W;
     if (M == 0 || N == 0) return FOV_OK;
+    // 31-bit byte offsets inside one buffer descriptor
+    if ((long)B * ldb * 4 >= (1L << 31) || (long)kh * kw * C * N * 4 >= (1L << 31)) {
+        set_error("conv2d: operand larger than 2 GiB");
+        return FOV_ERR_UNSUPPORTED;
+    }
+    const bool avec = (C & 3) == 0 && (ldx & 3) == 0 && (ldb & 3) == 0 && (((uintptr_t)x) & 15) == 0;
+    const bool bvec = (N & 3) == 0 && (((uintptr_t)w) & 15) == 0;
+#define FOV_CONV_LAUNCH(MI_, NI_, WM_, grid_)                                                                          \
+    do {                                                                                                               \
+        if (avec && bvec) hipLaunchKernelGGL((conv2d_igemm_kernel<MI_, NI_, WM_, 1, 1>), grid_, dim3(256), 0, stream, g); \
+        else if (avec) hipLaunchKernelGGL((conv2d_igemm_kernel<MI_, NI_, WM_, 1, 0>), grid_, dim3(256), 0, stream, g);  \
+        else if (bvec) hipLaunchKernelGGL((conv2d_igemm_kernel<MI_, NI_, WM_, 0, 1>), grid_, dim3(256), 0, stream, g);  \
+        else hipLaunchKernelGGL((conv2d_igemm_kernel<MI_, NI_, WM_, 0, 0>), grid_, dim3(256), 0, stream, g);            \
+    } while (0)
     if (N <= 32) {
         const dim3 grid((N + 31) / 32, (unsigned)((M + 255) / 256));
-        hipLaunchKernelGGL((conv2d_igemm_kernel<4, 2, 4>), grid, dim3(256), 0, stream, g);
+        FOV_CONV_LAUNCH(4, 2, 4, grid);
     } else if (N <= 64) {
         const dim3 grid((N + 63) / 64, (unsigned)((M + 255) / 256));
-        hipLaunchKernelGGL((conv2d_igemm_kernel<4, 4, 4>), grid, dim3(256), 0, stream, g);
+        FOV_CONV_LAUNCH(4, 4, 4, grid);
     } else {
         const dim3 grid((N + 127) / 128, (unsigned)((M + 127) / 128));
-        hipLaunchKernelGGL((conv2d_igemm_kernel<4, 4, 2>), grid, dim3(256), 0, stream, g);
+        FOV_CONV_LAUNCH(4, 4, 2, grid);
     }
+#undef FOV_CONV_LAUNCH
     return conv_check_launch("conv2d_igemm");
 }
 
