@@ -188,7 +188,7 @@ int fov_mse_dense_grad(const float* y, const float* target, float* dpre, float* 
                        int activation, void* workspace, size_t workspace_bytes, fov_stream_t stream);
 
 /* Backward of an elementwise activation given its OUTPUT y: out = base + dy * act'(y), act' = 1 - y^2 for tanh
- * (activation 1) or 1 (activation 0); base may be NULL; out may alias base or dy.  Used where a Dense output is
+ * (activation 1), [y > 0] for relu (activation 2) or 1 (activation 0); base may be NULL; out may alias base or dy.  Used where a Dense output is
  * fed back as the next decoder input (given_others...py:292-293): the feedback gradient joins the loss gradient. */
 int fov_act_bwd(const float* dy, const float* y, const float* base, float* out, int64_t n, int activation,
                 fov_stream_t stream);
@@ -222,6 +222,41 @@ int fov_convlstm_gates(const float* z, float* c, float* h, int64_t h_pixel_strid
 
 /* Softmax over the last dimension of (rows, n) - keras.layers.Softmax(axis=-1), convlstm_seq2seq.py:236. */
 int fov_softmax_lastdim(const float* x, float* y, int64_t rows, int n, fov_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * ConvLSTM2D training (a8 backward): what model.fit runs under Keras/TF autodiff for the graph of
+ * mycode/convlstm_seq2seq.py:100-126,146-165,209-282 compiled at :287 (RMSprop + costfunc._mse).
+ * ------------------------------------------------------------------------------------- */
+
+/* Forward gates that keep what the backward pass needs: gates (rows,4F) = activated i,f,g,o (may alias z),
+ * c_new (rows,F) = f*c_prev + i*g (c_prev may be NULL = zero state), h = o*tanh(c_new) with pixel stride. */
+int fov_convlstm_gates_train(const float* z, const float* c_prev, float* c_new, float* h, int64_t h_pixel_stride,
+                             float* gates, int64_t rows, int F, int act, fov_stream_t stream);
+
+/* Backward of the gates: dh (rows,F) with pixel stride; dc (rows,F) holds dL/dc_t on entry and dL/dc_{t-1} on
+ * return; gates, c_prev (NULL = zero), c_new from the forward; dz (rows,4F) out (may alias gates). */
+int fov_convlstm_gates_bwd(const float* dh, int64_t dh_pixel_stride, float* dc, const float* gates,
+                           const float* c_prev, const float* c_new, float* dz, int64_t rows, int F, int act,
+                           fov_stream_t stream);
+
+/* Weight gradient of y = conv2d_same(x, w): dw (kh,kw,C,N) (+)= sum over the B*H*W pixels of
+ * x[pixel + tap][c] * dy[pixel][n].  x: batch-dense NHWC with pixel stride x_pixel_stride >= C; dy (B*H*W, N).
+ * workspace >= fov_conv2d_wgrad_workspace_bytes (split-K partials; deterministic fixed-order reduce). */
+size_t fov_conv2d_wgrad_workspace_bytes(int C, int N, int kh, int kw);
+int fov_conv2d_wgrad(const float* x, int64_t x_pixel_stride, const float* dy, float* dw, int B, int H, int W,
+                     int C, int N, int kh, int kw, int accumulate, void* workspace, size_t workspace_bytes,
+                     fov_stream_t stream);
+
+/* wt (kh,kw,N,C) = w (kh,kw,C,N) flipped in both spatial axes and transposed in the channel axes: the data
+ * gradient of y = conv2d_same(x, w) is dx = conv2d_same(dy, wt) (fov_conv2d_fwd). */
+int fov_conv2d_weight_transpose(const float* w, float* wt, int kh, int kw, int C, int N, fov_stream_t stream);
+
+/* Backward of fov_softmax_lastdim given its output p: dy = p * (dp - sum_c dp*p); dy may alias dp. */
+int fov_softmax_lastdim_bwd(const float* dp, const float* p, float* dy, int64_t rows, int n, fov_stream_t stream);
+
+/* out (cols) (+)= column sums of x (rows, cols): bias gradients.  workspace >= 4*(256*cols + 64) bytes. */
+int fov_colsum(const float* x, float* out, int64_t rows, int cols, int accumulate, void* workspace,
+               size_t workspace_bytes, fov_stream_t stream);
 
 /* Device-side windowing, the step in front of the path: reshape2second_stacks
  * (mycode/utility.py:264-305).  x:(U,S,feat) whole seconds of one video -> W = fov_window_count(S,T,stride)

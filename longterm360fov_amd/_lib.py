@@ -55,6 +55,13 @@ SIGNATURES = {
     "fov_conv2d_fwd": (_I, [_P, ctypes.c_int64, ctypes.c_int64, _P, _P, _P, _P] + [_I] * 8 + [_P]),
     "fov_convlstm_gates": (_I, [_P, _P, _P, ctypes.c_int64, ctypes.c_int64, _I, _I, _P]),
     "fov_softmax_lastdim": (_I, [_P, _P, ctypes.c_int64, _I, _P]),
+    "fov_convlstm_gates_train": (_I, [_P] * 4 + [ctypes.c_int64, _P, ctypes.c_int64, _I, _I, _P]),
+    "fov_convlstm_gates_bwd": (_I, [_P, ctypes.c_int64] + [_P] * 5 + [ctypes.c_int64, _I, _I, _P]),
+    "fov_conv2d_wgrad_workspace_bytes": (_SZ, [_I] * 4),
+    "fov_conv2d_wgrad": (_I, [_P, ctypes.c_int64, _P, _P] + [_I] * 8 + [_P, _SZ, _P]),
+    "fov_conv2d_weight_transpose": (_I, [_P, _P] + [_I] * 4 + [_P]),
+    "fov_softmax_lastdim_bwd": (_I, [_P] * 3 + [ctypes.c_int64, _I, _P]),
+    "fov_colsum": (_I, [_P, _P, ctypes.c_int64, _I, _I, _P, _SZ, _P]),
     "fov_window_count": (ctypes.c_int64, [_I, _I, _I]),
     "fov_window_stacks": (_I, [_P] * 4 + [_I] * 6 + [_P]),
     "fov_fov_hit_rate": (_I, [_P, ctypes.c_int64, _P, ctypes.c_int64, _P, ctypes.c_int64, ctypes.c_float, ctypes.c_float, _P]),

@@ -360,7 +360,7 @@ int fov_mse_dense_grad(const float* y, const float* target, float* dpre, float* 
 
 int fov_act_bwd(const float* dy, const float* y, const float* base, float* out, int64_t n, int activation,
                 fov_stream_t stream) {
-    if (n < 0 || (n > 0 && (!dy || !y || !out)) || (activation != 0 && activation != 1)) {
+    if (n < 0 || (n > 0 && (!dy || !y || !out)) || (activation != 0 && activation != 1 && activation != 2)) {
         set_error("fov_act_bwd: invalid argument");
         return FOV_ERR_INVALID;
     }
@@ -553,6 +553,74 @@ int fov_softmax_lastdim(const float* x, float* y, int64_t rows, int n, fov_strea
         return FOV_ERR_INVALID;
     }
     return softmax_lastdim(x, y, (long)rows, n, (hipStream_t)stream);
+}
+
+int fov_convlstm_gates_train(const float* z, const float* c_prev, float* c_new, float* h, int64_t h_pixel_stride,
+                             float* gates, int64_t rows, int F, int act, fov_stream_t stream) {
+    if (rows < 0 || F <= 0 || h_pixel_stride < F || (rows > 0 && (!z || !c_new || !h || !gates)) ||
+        (act != FOV_ACT_SIGMOID && act != FOV_ACT_HARD_SIGMOID)) {
+        set_error("fov_convlstm_gates_train: invalid argument");
+        return FOV_ERR_INVALID;
+    }
+    return convlstm_gates_train(z, c_prev, c_new, h, (long)h_pixel_stride, gates, (long)rows, F, act, (hipStream_t)stream);
+}
+
+int fov_convlstm_gates_bwd(const float* dh, int64_t dh_pixel_stride, float* dc, const float* gates, const float* c_prev,
+                           const float* c_new, float* dz, int64_t rows, int F, int act, fov_stream_t stream) {
+    if (rows < 0 || F <= 0 || dh_pixel_stride < F || (rows > 0 && (!dh || !dc || !gates || !c_new || !dz)) ||
+        (act != FOV_ACT_SIGMOID && act != FOV_ACT_HARD_SIGMOID)) {
+        set_error("fov_convlstm_gates_bwd: invalid argument");
+        return FOV_ERR_INVALID;
+    }
+    return convlstm_gates_bwd(dh, (long)dh_pixel_stride, dc, gates, c_prev, c_new, dz, (long)rows, F, act, (hipStream_t)stream);
+}
+
+size_t fov_conv2d_wgrad_workspace_bytes(int C, int N, int kh, int kw) {
+    if (C <= 0 || N <= 0 || kh <= 0 || kw <= 0) return 256;
+    return sizeof(float) * conv2d_wgrad_workspace_floats(C, N, kh, kw);
+}
+
+int fov_conv2d_wgrad(const float* x, int64_t x_pixel_stride, const float* dy, float* dw, int B, int H, int W, int C, int N,
+                     int kh, int kw, int accumulate, void* workspace, size_t workspace_bytes, fov_stream_t stream) {
+    if (B < 0 || H <= 0 || W <= 0 || C <= 0 || N <= 0 || kh <= 0 || kw <= 0 || (kh & 1) == 0 || (kw & 1) == 0 ||
+        x_pixel_stride < C || !dw || (B > 0 && (!x || !dy))) {
+        set_error("fov_conv2d_wgrad: invalid argument (odd kernel sizes only)");
+        return FOV_ERR_INVALID;
+    }
+    if (workspace && (((uintptr_t)workspace) & 15)) { set_error("workspace must be 16-byte aligned"); return FOV_ERR_WORKSPACE; }
+    return conv2d_wgrad(x, (long)x_pixel_stride, dy, dw, B, H, W, C, N, kh, kw, accumulate, (float*)workspace,
+                        workspace ? workspace_bytes / sizeof(float) : 0, (hipStream_t)stream);
+}
+
+int fov_conv2d_weight_transpose(const float* w, float* wt, int kh, int kw, int C, int N, fov_stream_t stream) {
+    if (kh <= 0 || kw <= 0 || C <= 0 || N <= 0 || !w || !wt) {
+        set_error("fov_conv2d_weight_transpose: invalid argument");
+        return FOV_ERR_INVALID;
+    }
+    return conv_weight_transpose(w, wt, kh, kw, C, N, (hipStream_t)stream);
+}
+
+int fov_softmax_lastdim_bwd(const float* dp, const float* p, float* dy, int64_t rows, int n, fov_stream_t stream) {
+    if (rows < 0 || n <= 0 || (rows > 0 && (!dp || !p || !dy))) {
+        set_error("fov_softmax_lastdim_bwd: invalid argument");
+        return FOV_ERR_INVALID;
+    }
+    return softmax_lastdim_bwd(dp, p, dy, (long)rows, n, (hipStream_t)stream);
+}
+
+int fov_colsum(const float* x, float* out, int64_t rows, int cols, int accumulate, void* workspace, size_t workspace_bytes,
+               fov_stream_t stream) {
+    if (rows < 0 || cols <= 0 || !out || (rows > 0 && !x)) {
+        set_error("fov_colsum: invalid argument");
+        return FOV_ERR_INVALID;
+    }
+    int rc = check_ws(workspace, workspace_bytes, sizeof(float) * ((size_t)256 * cols + 64));
+    if (rc) return rc;
+    if (rows == 0) {
+        if (!accumulate) (void)hipMemsetAsync(out, 0, sizeof(float) * cols, (hipStream_t)stream);
+        return FOV_OK;
+    }
+    return colsum(x, out, (long)rows, cols, accumulate, (float*)workspace, workspace_bytes / sizeof(float), (hipStream_t)stream);
 }
 
 int fov_fov_hit_rate(const float* pred_xyz, int64_t pred_row_stride, const float* gt_xyz, int64_t gt_row_stride,

@@ -77,6 +77,20 @@ int conv2d_fwd(const float* x, long ldx, long ldb, const float* w, const float* 
 int convlstm_gates(const float* z, float* c, float* h, long ldh, long rows, int F, int act, hipStream_t stream);
 int softmax_lastdim(const float* x, float* y, long rows, int n, hipStream_t stream);
 
+// ConvLSTM training (conv_train_kernels.hip)
+size_t conv2d_wgrad_workspace_floats(int C, int N, int kh, int kw);
+int conv2d_wgrad(const float* x, long ldx, const float* dz, float* dw, int B, int H, int W, int C, int N, int kh, int kw,
+                 int accumulate, float* scratch, size_t scratch_floats, hipStream_t stream);
+int convlstm_gates_train(const float* z, const float* c_prev, float* c_new, float* h, long ldh, float* gates, long rows, int F,
+                         int act, hipStream_t stream);
+int convlstm_gates_bwd(const float* dh, long lddh, float* dc, const float* gates, const float* c_prev, const float* c_new,
+                       float* dz, long rows, int F, int act, hipStream_t stream);
+int conv_weight_transpose(const float* w, float* wt, int kh, int kw, int C, int N, hipStream_t stream);
+int softmax_lastdim_bwd(const float* dp, const float* p, float* dy, long rows, int n, hipStream_t stream);
+int splitk_reduce(const float* part, float* out, long n, int S, int accumulate, hipStream_t stream);
+int colsum(const float* x, float* out, long rows, int cols, int accumulate, float* scratch, size_t scratch_floats,
+           hipStream_t stream);
+
 // persistent BPTT recurrence (lstm_bwd_cluster.hip)
 bool bwd_cluster_shape_ok(int H);
 size_t bwd_cluster_xch_bytes(int B, int H);

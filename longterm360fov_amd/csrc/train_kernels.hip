@@ -374,13 +374,13 @@ __global__ __launch_bounds__(256) void sum_scale_kernel(const float* __restrict_
     if (threadIdx.x == 0) out[0] = red[0] * scale;
 }
 
-// out = base + dy * act'(y)   (act' = 1 - y^2 for tanh, 1 for linear); base may be NULL; out may alias base/dy
+// out = base + dy * act'(y)   (act' = 1 - y^2 for tanh, [y > 0] for relu, 1 for linear); base may be NULL; out may alias base/dy
 __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
                                                       const float* base, float* out, long n, int activation) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const float yv = y[i];
-    const float d = dy[i] * (activation == 1 ? (1.f - yv * yv) : 1.f);
+    const float d = dy[i] * (activation == 1 ? (1.f - yv * yv) : (activation == 2 ? (yv > 0.f ? 1.f : 0.f) : 1.f));
     out[i] = (base ? base[i] : 0.f) + d;
 }
 
@@ -834,6 +834,12 @@ int matmul_f32(const float* a, const float* b, float* c, int M, int K, int N, fl
     g.a = a; g.b = b; g.c = c; g.M = M; g.N = N; g.KO = 1; g.KI = K;
     g.a_sm = K; g.a_ski = 1; g.b_sn = 1; g.b_ski = N; g.ldc = N;
     return gemm_f32(g, 0, scratch, scratch_floats, stream);
+}
+
+int splitk_reduce(const float* part, float* out, long n, int S, int accumulate, hipStream_t stream) {
+    if (n <= 0) return FOV_OK;
+    hipLaunchKernelGGL(splitk_reduce_kernel, splitk_reduce_grid((size_t)n), dim3(256), 0, stream, part, out, n, S, accumulate);
+    return check_launch("splitk_reduce");
 }
 
 int act_bwd(const float* dy, const float* y, const float* base, float* out, long n, int activation, hipStream_t stream) {

@@ -230,12 +230,12 @@ def lstm_seq_bwd(x, K, R, hs, reserve, h0=None, c0=None, dhs=None, dhT=None, dcT
 
 
 def act_bwd(dy, y, base=None, activation="tanh", out=None):
-    """out = base + dy * act'(y)  (tanh: 1 - y^2)."""
+    """out = base + dy * act'(y)  (tanh: 1 - y^2; relu: [y > 0]; linear: 1)."""
     dy, y = _dev(dy, "dy"), _dev(y, "y")
     assert dy.shape == y.shape
     out = torch.empty_like(y) if out is None else out
     check(_lib.lib().fov_act_bwd(_ptr(dy), _ptr(y), _ptr(_dev(base, "base")), _ptr(out), y.numel(),
-                                 1 if activation == "tanh" else 0, _stream()))
+                                 {"tanh": 1, "relu": 2}.get(activation, 0), _stream()))
     return out
 
 
@@ -368,6 +368,80 @@ def softmax_lastdim(x):
     n = x.shape[-1]
     check(_lib.lib().fov_softmax_lastdim(_ptr(x), _ptr(y), x.numel() // n, n, _stream()))
     return y
+
+
+def convlstm_gates_train(z, c_prev, h_out, act="hard_sigmoid", gates=None):
+    """Training forward of the gates: -> (h_out, c_new, gates).  gates (B,H,W,4F) keeps the activated i,f,g,o
+    (defaults to overwriting z); c_prev None = zero state; h_out may be a channel-slice view."""
+    z = _dev(z, "z")
+    F = z.shape[-1] // 4
+    rows = z.numel() // (4 * F)
+    gates = z if gates is None else gates
+    c_new = torch.empty(z.shape[:-1] + (F,), dtype=torch.float32, device=z.device)
+    assert h_out.is_cuda and h_out.stride(-1) == 1 and h_out.shape == c_new.shape
+    check(_lib.lib().fov_convlstm_gates_train(_ptr(z), _ptr(_dev(c_prev, "c_prev")), _ptr(c_new), h_out.data_ptr(),
+                                              h_out.stride(-2), _ptr(gates), rows, F, act_code(act), _stream()))
+    return h_out, c_new, gates
+
+
+def convlstm_gates_bwd(dh, dc, gates, c_prev, c_new, act="hard_sigmoid", dz=None):
+    """dh (B,H,W,F) (may be a channel-slice view), dc updated in place (dL/dc_t -> dL/dc_{t-1}) -> dz (B,H,W,4F)."""
+    gates, c_new, dc = _dev(gates, "gates"), _dev(c_new, "c_new"), _dev(dc, "dc")
+    F = c_new.shape[-1]
+    rows = c_new.numel() // F
+    assert dh.is_cuda and dh.dtype == torch.float32 and dh.stride(-1) == 1 and dh.shape == c_new.shape
+    dz = torch.empty_like(gates) if dz is None else dz
+    check(_lib.lib().fov_convlstm_gates_bwd(dh.data_ptr(), dh.stride(-2), _ptr(dc), _ptr(gates), _ptr(_dev(c_prev, "c_prev")),
+                                            _ptr(c_new), _ptr(dz), rows, F, act_code(act), _stream()))
+    return dz
+
+
+def conv2d_wgrad(x, dy, kh, kw, dw=None, accumulate=False, scratch=None):
+    """dw (kh,kw,C,N) (+)= weight gradient of y = conv2d_same(x, w).  x: batch-dense NHWC (leading dims are
+    flattened into the batch; the last dim may be a channel slice of a wider map); dy (..., N) dense."""
+    assert x.is_cuda and x.dtype == torch.float32 and x.stride(-1) == 1
+    H, W, C = x.shape[-3:]
+    ldx = x.stride(-2)
+    B = x.numel() // (H * W * C)
+    assert x.stride(-3) == W * ldx and all(x.stride(i) == x.stride(i + 1) * x.shape[i + 1] for i in range(x.dim() - 4)) and \
+        (x.dim() == 3 or B == 1 or x.stride(-4) == H * W * ldx), "x must be batch-dense NHWC"
+    dy = _dev(dy, "dy")
+    N = dy.shape[-1]
+    assert dy.numel() == B * H * W * N
+    dw = torch.empty((kh, kw, C, N), dtype=torch.float32, device=x.device) if dw is None else dw
+    L = _lib.lib()
+    buf = (scratch or _default_scratch).get(L.fov_conv2d_wgrad_workspace_bytes(C, N, kh, kw), x.device)
+    check(L.fov_conv2d_wgrad(x.data_ptr(), ldx, _ptr(dy), _ptr(dw), B, H, W, C, N, kh, kw, 1 if accumulate else 0,
+                             buf.data_ptr(), buf.numel(), _stream()))
+    return dw
+
+
+def conv2d_weight_transpose(w, out=None):
+    """(kh,kw,C,N) -> (kh,kw,N,C) flipped spatially: dx = conv2d(dy, conv2d_weight_transpose(w))."""
+    w = _dev(w, "w")
+    kh, kw, C, N = w.shape
+    out = torch.empty((kh, kw, N, C), dtype=torch.float32, device=w.device) if out is None else out
+    check(_lib.lib().fov_conv2d_weight_transpose(_ptr(w), _ptr(out), kh, kw, C, N, _stream()))
+    return out
+
+
+def softmax_lastdim_bwd(dp, p, out=None):
+    dp, p = _dev(dp, "dp"), _dev(p, "p")
+    n = p.shape[-1]
+    out = torch.empty_like(p) if out is None else out
+    check(_lib.lib().fov_softmax_lastdim_bwd(_ptr(dp), _ptr(p), _ptr(out), p.numel() // n, n, _stream()))
+    return out
+
+
+def colsum(x, out=None, accumulate=False, scratch=None):
+    """Column sums of x (..., cols) over all leading dims (bias gradients)."""
+    x = _dev(x, "x")
+    cols = x.shape[-1]
+    out = torch.empty(cols, dtype=torch.float32, device=x.device) if out is None else out
+    buf = (scratch or _default_scratch).get(4 * (256 * cols + 64), x.device)
+    check(_lib.lib().fov_colsum(_ptr(x), _ptr(out), x.numel() // cols, cols, 1 if accumulate else 0, buf.data_ptr(),
+                                buf.numel(), _stream()))
+    return out
 
 
 def fov_hit_rate(pred, gt_xyz, span_deg=120.0, gt_span_deg=120.0):

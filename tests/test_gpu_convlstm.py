@@ -93,3 +93,82 @@ def test_convlstm_seq2seq(head, B, T_in, T_out, H, W, C, L, hf):
     out = m.predict([enc, dec0], predict_step=T_out)
     close(out, ref, "convlstm seq2seq " + head, tol=5e-5)
     np.testing.assert_allclose(out.sum(-1), 1.0, atol=1e-5)
+
+
+# ---------------------------------------------------------------------------------------
+# training kernels (a8 backward): checked against torch.autograd in fp64 on the CPU
+# ---------------------------------------------------------------------------------------
+def _tconv(x, w):
+    """conv2d_same on NHWC / (kh,kw,C,N) operands with torch (independent reference)."""
+    import torch.nn.functional as TF
+    kh, kw = w.shape[:2]
+    return TF.conv2d(x.permute(0, 3, 1, 2), w.permute(3, 2, 0, 1), padding=(kh // 2, kw // 2)).permute(0, 2, 3, 1)
+
+
+@pytest.mark.parametrize("B,H,W,C,N,kh,kw", [(2, 4, 5, 3, 7, 5, 5), (3, 36, 18, 30, 128, 5, 5), (2, 1, 30, 3, 128, 5, 5),
+                                             (2, 1, 30, 56, 40, 1, 7), (1, 6, 7, 17, 33, 3, 3), (2, 9, 4, 8, 64, 5, 5),
+                                             (2, 6, 6, 128, 12, 3, 3), (1, 6, 6, 40, 260, 3, 3), (5, 3, 3, 4, 4, 5, 5)])
+def test_conv2d_backward_kernels(B, H, W, C, N, kh, kw):
+    from longterm360fov_amd import ops
+    rng = np.random.default_rng(B * 1000 + C * 10 + N)
+    x = rng.standard_normal((B, H, W, C)).astype(np.float32)
+    w = (rng.standard_normal((kh, kw, C, N)) / np.sqrt(kh * kw * C)).astype(np.float32)
+    dy = rng.standard_normal((B, H, W, N)).astype(np.float32)
+    tx = torch.tensor(x.astype(np.float64), requires_grad=True)
+    tw = torch.tensor(w.astype(np.float64), requires_grad=True)
+    (_tconv(tx, tw) * torch.tensor(dy.astype(np.float64))).sum().backward()
+    dw_ref, dx_ref = tw.grad.numpy(), tx.grad.numpy()
+    dw = ops.conv2d_wgrad(dev(x), dev(dy), kh, kw)
+    close(dw, dw_ref, "wgrad")
+    ops.conv2d_wgrad(dev(x), dev(dy), kh, kw, dw=dw, accumulate=True)
+    close(dw, 2 * dw_ref, "wgrad accumulate")
+    dx = ops.conv2d(dev(dy), ops.conv2d_weight_transpose(dev(w)))
+    close(dx, dx_ref, "dgrad = conv(dy, w')")
+    # x as a channel slice of a wider map, time-major stack of two steps (leading dims flatten into the batch)
+    wide = rng.standard_normal((2, B, H, W, C + 8)).astype(np.float32)
+    dy2 = rng.standard_normal((2, B, H, W, N)).astype(np.float32)
+    tx2 = torch.tensor(wide[..., 4:4 + C].reshape(2 * B, H, W, C).astype(np.float64))
+    tw2 = torch.tensor(w.astype(np.float64), requires_grad=True)
+    (_tconv(tx2, tw2) * torch.tensor(dy2.reshape(2 * B, H, W, N).astype(np.float64))).sum().backward()
+    close(ops.conv2d_wgrad(dev(wide)[..., 4:4 + C], dev(dy2), kh, kw), tw2.grad.numpy(), "wgrad on a channel slice")
+
+
+@pytest.mark.parametrize("act", ["hard_sigmoid", "sigmoid"])
+def test_convlstm_gates_backward_softmax_relu_colsum(act):
+    from longterm360fov_amd import ops
+    rng = np.random.default_rng(11)
+    B, H, W, F = 3, 5, 4, 6
+    z = rng.standard_normal((B, H, W, 4 * F)).astype(np.float32) * 2
+    cp = rng.standard_normal((B, H, W, F)).astype(np.float32)
+    dh = rng.standard_normal((B, H, W, F)).astype(np.float32)
+    dc = rng.standard_normal((B, H, W, F)).astype(np.float32)
+    s = torch.sigmoid if act == "sigmoid" else (lambda v: torch.clamp(0.2 * v + 0.5, 0, 1))
+    tz = torch.tensor(z.astype(np.float64), requires_grad=True)
+    tcp = torch.tensor(cp.astype(np.float64), requires_grad=True)
+    i, f, g, o = s(tz[..., :F]), s(tz[..., F:2 * F]), torch.tanh(tz[..., 2 * F:3 * F]), s(tz[..., 3 * F:])
+    cn = f * tcp + i * g
+    hn = o * torch.tanh(cn)
+    ((hn * torch.tensor(dh.astype(np.float64))).sum() + (cn * torch.tensor(dc.astype(np.float64))).sum()).backward()
+    wide = torch.zeros((B, H, W, F + 3), dtype=torch.float32, device="cuda")
+    h_out, c_new, gates = ops.convlstm_gates_train(dev(z), dev(cp), wide[..., 2:2 + F], act)
+    close(h_out, hn.detach().numpy(), "train gates h")
+    close(c_new, cn.detach().numpy(), "train gates c")
+    dwide = torch.zeros((B, H, W, F + 5), dtype=torch.float32, device="cuda")
+    dwide[..., 1:1 + F] = dev(dh)
+    dcv = dev(dc)
+    dz = ops.convlstm_gates_bwd(dwide[..., 1:1 + F], dcv, gates, dev(cp), c_new, act)
+    close(dz, tz.grad.numpy(), "gates bwd dz " + act, tol=5e-5)
+    close(dcv, tcp.grad.numpy(), "gates bwd dc_prev " + act, tol=5e-5)
+    # zero initial state form
+    h0, c0n, g0 = ops.convlstm_gates_train(dev(z), None, torch.empty((B, H, W, F), device="cuda"), act)
+    close(c0n, (i * g).detach().numpy(), "train gates c from zero state")
+    # softmax / relu backward, column sums
+    y = rng.standard_normal((7, 3, 30)).astype(np.float32) * 2
+    dp = rng.standard_normal((7, 3, 30)).astype(np.float32)
+    ty = torch.tensor(y.astype(np.float64), requires_grad=True)
+    (torch.softmax(ty, -1) * torch.tensor(dp.astype(np.float64))).sum().backward()
+    close(ops.softmax_lastdim_bwd(dev(dp), ops.softmax_lastdim(dev(y))), ty.grad.numpy(), "softmax bwd", tol=1e-5)
+    r = np.maximum(y, 0)
+    close(ops.act_bwd(dev(dp), dev(r), activation="relu"), dp * (r > 0), "relu bwd", tol=1e-6)
+    big = rng.standard_normal((5000, 40)).astype(np.float32)
+    close(ops.colsum(dev(big)), big.astype(np.float64).sum(0), "colsum")
