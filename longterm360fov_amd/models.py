@@ -533,13 +533,55 @@ class ConvLSTMSeq2Seq:
       head 'conv2d' (cfg.use_one_hot, 36x18x30 maps): Conv2D 512 -> 1024 -> 30 (relu) + channel Softmax
       head 'conv1d' (xyz mode, (1,30,3) "images"): Conv1D k=7 512 -> 1024 -> 3, relu, relu, softmax
     predict([encoder_input (N,T_in,H,W,C), decoder_input (N,1,H,W,C)]) -> (N,T_out,H,W,C_out).
-    Inference only in round 1 (input dropout acts in training only).  Weights: dict with
+    compile('RMSprop', loss=costfunc._mse | 'mean_squared_error') / fit / train_on_batch train the same unrolled
+    graph (convlstm_seq2seq.py:287,396-420) through training.ConvLSTMTrainer; input dropout
+    (cfg.dropout_rate) is not implemented in the training path and must be 0.  Weights: dict with
     enc{l}_K/R/b, dec{l}_K/R/b (Keras ConvLSTM2D layout (kh,kw,C,4F)) and head{i}_W/b."""
 
-    def __init__(self, weights, head="conv2d", recurrent_activation="hard_sigmoid", device="cuda"):
+    def __init__(self, weights, head="conv2d", recurrent_activation="hard_sigmoid", device="cuda", dropout_rate=0.0):
         self.head, self.act, self.device = head, recurrent_activation, device
         self._w = {k: _as_f32(v) for k, v in weights.items()}
         self._dw = None
+        self._trainer, self.optimizer, self.loss, self._lr = None, None, None, 1e-3
+        self.dropout_rate = float(dropout_rate)
+        self.stop_training = False
+
+    def get_weights(self):
+        from .training import convlstm_weight_order
+        return [self._w[k].copy() for k in convlstm_weight_order(self._w)]
+
+    def compile(self, optimizer="RMSprop", loss="mean_squared_error", metrics=None):
+        """Keras `compile` (convlstm_seq2seq.py:287).  optimizer 'RMSprop' | 'Adam' (Keras defaults); loss
+        'mean_squared_error' | 'mse' | a callable named `_mse` (cost.py:20-22 without cfg.add_xyz_sum1)."""
+        opt = optimizer if isinstance(optimizer, str) else getattr(optimizer, "name", str(optimizer))
+        lname = loss if isinstance(loss, str) else getattr(loss, "__name__", str(loss))
+        if opt.lower() not in ("adam", "rmsprop") or lname.lower() not in ("mean_squared_error", "mse", "_mse"):
+            raise ValueError("unsupported optimizer/loss %r / %r" % (optimizer, loss))
+        self.optimizer, self.loss, self.metrics = opt.lower(), "mse", list(metrics or [])
+
+    def _get_trainer(self):
+        from .training import ConvLSTMTrainer
+        if self._trainer is None:
+            self._trainer = ConvLSTMTrainer(self._w, head=self.head, act=self.act, optimizer=self.optimizer or "rmsprop",
+                                            lr=self._lr, device=self.device, dropout_rate=self.dropout_rate)
+        return self._trainer
+
+    def fit(self, x, y, batch_size=32, epochs=1, validation_split=0.0, shuffle=True, callbacks=None,
+            initial_epoch=0, verbose=0, validation_data=None):
+        """Keras `Model.fit` (convlstm_seq2seq.py:407-412); y (N,T_out,H,W,C_out).  See _keras_fit."""
+        if self.optimizer is None:
+            raise RuntimeError("call compile() before fit()")
+        return _keras_fit(self, self._get_trainer(), list(x), y, batch_size, epochs, validation_split, shuffle, callbacks,
+                          initial_epoch, validation_data)
+
+    def train_on_batch(self, x, y):
+        import torch
+        d = lambda a: torch.from_numpy(_as_f32(a)).to(self.device)
+        tr = self._get_trainer()
+        loss = tr.train_step(d(x[0]), d(x[1]), d(y))
+        self._w = tr.weights_numpy()
+        self._dw = None
+        return float(loss.item())
 
     def predict(self, x, batch_size=None, predict_step=None, verbose=0):
         import torch

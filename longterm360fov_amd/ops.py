@@ -362,22 +362,22 @@ def convlstm_gates(z, c, h_out, act="hard_sigmoid"):
     return h_out, c
 
 
-def softmax_lastdim(x):
+def softmax_lastdim(x, out=None):
     x = _dev(x, "x")
-    y = torch.empty_like(x)
+    y = torch.empty_like(x) if out is None else _dev(out, "out")
     n = x.shape[-1]
     check(_lib.lib().fov_softmax_lastdim(_ptr(x), _ptr(y), x.numel() // n, n, _stream()))
     return y
 
 
-def convlstm_gates_train(z, c_prev, h_out, act="hard_sigmoid", gates=None):
+def convlstm_gates_train(z, c_prev, h_out, act="hard_sigmoid", gates=None, c_new=None):
     """Training forward of the gates: -> (h_out, c_new, gates).  gates (B,H,W,4F) keeps the activated i,f,g,o
     (defaults to overwriting z); c_prev None = zero state; h_out may be a channel-slice view."""
     z = _dev(z, "z")
     F = z.shape[-1] // 4
     rows = z.numel() // (4 * F)
     gates = z if gates is None else gates
-    c_new = torch.empty(z.shape[:-1] + (F,), dtype=torch.float32, device=z.device)
+    c_new = torch.empty(z.shape[:-1] + (F,), dtype=torch.float32, device=z.device) if c_new is None else _dev(c_new, "c_new")
     assert h_out.is_cuda and h_out.stride(-1) == 1 and h_out.shape == c_new.shape
     check(_lib.lib().fov_convlstm_gates_train(_ptr(z), _ptr(_dev(c_prev, "c_prev")), _ptr(c_new), h_out.data_ptr(),
                                               h_out.stride(-2), _ptr(gates), rows, F, act_code(act), _stream()))
@@ -403,8 +403,10 @@ def conv2d_wgrad(x, dy, kh, kw, dw=None, accumulate=False, scratch=None):
     H, W, C = x.shape[-3:]
     ldx = x.stride(-2)
     B = x.numel() // (H * W * C)
-    assert x.stride(-3) == W * ldx and all(x.stride(i) == x.stride(i + 1) * x.shape[i + 1] for i in range(x.dim() - 4)) and \
-        (x.dim() == 3 or B == 1 or x.stride(-4) == H * W * ldx), "x must be batch-dense NHWC"
+    expect = W * ldx     # stride of the H axis, then of every leading (batch / time) axis; size-1 axes are free
+    for i in range(x.dim() - 3, -1, -1):
+        assert x.shape[i] == 1 or x.stride(i) == expect, "x must be batch-dense NHWC"
+        expect *= x.shape[i]
     dy = _dev(dy, "dy")
     N = dy.shape[-1]
     assert dy.numel() == B * H * W * N

@@ -235,3 +235,219 @@ class OthersMixingTrainer:
         self.apply_gradients()
         return loss
 
+
+
+def convlstm_weight_order(weights):
+    """Parameter order of the ConvLSTM seq2seq: enc0..2, dec0..2 (K, R, b each), then the head layers."""
+    order = []
+    for side in ("enc", "dec"):
+        for l in range(3):
+            order += ["%s%d_K" % (side, l), "%s%d_R" % (side, l), "%s%d_b" % (side, l)]
+    i = 0
+    while "head%d_W" % i in weights:
+        order += ["head%d_W" % i, "head%d_b" % i]
+        i += 1
+    return order
+
+
+class ConvLSTMTrainer:
+    """Training step of the ConvLSTM2D seq2seq (mycode/convlstm_seq2seq.py:100-287: 3-layer encoder, 3-layer
+    decoder unrolled `predict_step` times with its own prediction fed back, conv head + channel softmax,
+    `model.compile(optimizer='RMSprop', loss=costfunc._mse)`).
+
+    Forward keeps a time-major tape (every map of a step is batch-dense, steps stack into one pixel axis):
+    layer outputs, activated gates, cell states, head activations.  Backward walks the unrolled decoder in
+    reverse (softmax -> head -> three cells; the feedback path's gradient is the dx of decoder layer 0), then
+    the encoder layer by layer; the recurrent data gradients are forward convolutions with transposed
+    weights, and every weight / bias gradient is ONE product over all steps of a layer (conv2d_wgrad over the
+    stacked steps).  All arithmetic is in libfov360_hip.so; torch holds the buffers (and adds maps).
+    Input dropout (cfg.dropout_rate, Keras ConvLSTM2D `dropout=`) is not implemented: dropout_rate must be 0."""
+
+    def __init__(self, weights, head="conv2d", act="hard_sigmoid", optimizer="rmsprop", lr=1e-3, device="cuda",
+                 dropout_rate=0.0):
+        if dropout_rate:
+            raise NotImplementedError("ConvLSTM2D input dropout is not implemented in the HIP training path; "
+                                      "set cfg.dropout_rate = 0")
+        self.head, self.act, self.optimizer, self.lr, self.device = head, act, optimizer.lower(), float(lr), device
+        self.order = convlstm_weight_order(weights)
+        self.shapes = [(k, tuple(weights[k].shape)) for k in self.order]
+        n = int(sum(np.prod(s) for _, s in self.shapes))
+        self.flat = torch.empty(n, dtype=torch.float32, device=device)
+        self.grad = torch.zeros(n, dtype=torch.float32, device=device)
+        self.m = torch.zeros(n, dtype=torch.float32, device=device)
+        self.v = torch.zeros(n, dtype=torch.float32, device=device) if self.optimizer == "adam" else None
+        self.w, self.g = {}, {}
+        off = 0
+        for k, s in self.shapes:
+            cnt = int(np.prod(s))
+            self.w[k] = self.flat[off:off + cnt].view(*s)
+            self.g[k] = self.grad[off:off + cnt].view(*s)
+            self.w[k].copy_(torch.from_numpy(np.ascontiguousarray(weights[k], dtype=np.float32)))
+            off += cnt
+        self.n_head = sum(1 for k in self.order if k.startswith("head") and k.endswith("_W"))
+        self.step_count = 0
+        self.scratch = ops.Scratch()
+        self.ws, self.bwd_scratch = ops.Workspace(), ops.Scratch()   # unused here; the shared fit loop checks them
+        self.filters = [self.w["enc%d_R" % l].shape[2] for l in range(3)]
+
+    def weights_numpy(self):
+        return {k: v.detach().cpu().numpy().copy() for k, v in self.w.items()}
+
+    # -- forward with tape ---------------------------------------------------------------------------
+    def _forward(self, enc, dec0, T_out):
+        w, act, F = self.w, self.act, self.filters
+        B, T_in, H, W, C = enc.shape
+        dev = enc.device
+        e = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
+        tape = {"x": enc.permute(1, 0, 2, 3, 4).contiguous()}           # (T_in,B,H,W,C) time-major
+        seq = tape["x"]
+        for l in range(3):
+            K, R, b = w["enc%d_K" % l], w["enc%d_R" % l], w["enc%d_b" % l]
+            hs, cs, gs = e(T_in, B, H, W, F[l]), e(T_in, B, H, W, F[l]), e(T_in, B, H, W, 4 * F[l])
+            for t in range(T_in):
+                z = ops.conv2d(seq[t], K, b, out=gs[t])
+                if t > 0:
+                    ops.conv2d(hs[t - 1], R, None, add=z, out=z)
+                ops.convlstm_gates_train(z, cs[t - 1] if t > 0 else None, hs[t], act, gates=z, c_new=cs[t])
+            tape["eh%d" % l], tape["ec%d" % l], tape["eg%d" % l] = hs, cs, gs
+            seq = hs
+        cat = sum(F)
+        offs = [0, F[0], F[0] + F[1]]
+        Co = w["head%d_W" % (self.n_head - 1)].shape[3]
+        feat = e(T_out, B, H, W, cat)
+        inp = e(T_out, B, H, W, C)                                      # decoder inputs, step by step
+        inp[0].copy_(dec0[:, 0])
+        P = e(T_out, B, H, W, Co)
+        dcs = [e(T_out, B, H, W, F[l]) for l in range(3)]
+        dgs = [e(T_out, B, H, W, 4 * F[l]) for l in range(3)]
+        ys = [e(T_out, B, H, W, w["head%d_W" % i].shape[3]) for i in range(self.n_head)]
+        last_act = "relu" if self.head == "conv2d" else None
+        for t in range(T_out):
+            cur = inp[t]
+            for l in range(3):
+                K, R, b = w["dec%d_K" % l], w["dec%d_R" % l], w["dec%d_b" % l]
+                h_prev = tape["eh%d" % l][T_in - 1] if t == 0 else feat[t - 1][..., offs[l]:offs[l] + F[l]]
+                c_prev = tape["ec%d" % l][T_in - 1] if t == 0 else dcs[l][t - 1]
+                z = ops.conv2d(cur, K, b, out=dgs[l][t])
+                ops.conv2d(h_prev, R, None, add=z, out=z)
+                hslot = feat[t][..., offs[l]:offs[l] + F[l]]
+                ops.convlstm_gates_train(z, c_prev, hslot, act, gates=z, c_new=dcs[l][t])
+                cur = hslot
+            y = feat[t]
+            for i in range(self.n_head):
+                a = "relu" if i < self.n_head - 1 else last_act
+                y = ops.conv2d(y, w["head%d_W" % i], w["head%d_b" % i], activation=a, out=ys[i][t])
+            ops.softmax_lastdim(y, out=P[t])
+            if t + 1 < T_out:
+                assert Co == C, "the head's output is fed back as the next decoder input"
+                inp[t + 1].copy_(P[t])
+        tape.update(feat=feat, inp=inp, P=P, dc=dcs, dg=dgs, ys=ys, offs=offs, last_act=last_act)
+        return P, tape
+
+    def forward_backward(self, enc, dec0, target, grad_weight=1.0):
+        """enc (B,T_in,H,W,C), dec0 (B,1,H,W,C), target (B,T_out,H,W,Co) device tensors.  Fills self.grad with
+        d(mean squared error)/d(parameters); returns (loss (1,), prediction (B,T_out,H,W,Co))."""
+        w, g, act, F, sc = self.w, self.g, self.act, self.filters, self.scratch
+        B, T_in, H, W, C = enc.shape
+        T_out = target.shape[1]
+        P, tp = self._forward(enc, dec0, T_out)
+        offs, feat = tp["offs"], tp["feat"]
+        tgt = target.permute(1, 0, 2, 3, 4).contiguous()
+        dP, loss = ops.mse_dense_grad(P, tgt, None, scratch=sc)
+        wt = {k: ops.conv2d_weight_transpose(w[k]) for k in self.order if not k.endswith("_b")}
+        nh = self.n_head
+        dys = [torch.empty_like(y) for y in tp["ys"]]                    # d(pre-activation) of every head layer
+        dzs = [torch.empty_like(x) for x in tp["dg"]]                    # decoder dz, all steps
+        zeros = lambda l: torch.zeros((B, H, W, F[l]), dtype=torch.float32, device=enc.device)
+        dh_rec, dc = [zeros(l) for l in range(3)], [zeros(l) for l in range(3)]
+        dfeed = None
+        for t in range(T_out - 1, -1, -1):
+            dp = dP[t] if dfeed is None else dP[t] + dfeed
+            d = ops.softmax_lastdim_bwd(dp, P[t], out=dys[nh - 1][t])
+            if tp["last_act"] == "relu":
+                ops.act_bwd(d, tp["ys"][nh - 1][t], activation="relu", out=d)
+            for i in range(nh - 1, 0, -1):                               # head layers, data gradient only
+                d = ops.conv2d(d, wt["head%d_W" % i], out=dys[i - 1][t])
+                ops.act_bwd(d, tp["ys"][i - 1][t], activation="relu", out=d)
+            dfeat = ops.conv2d(d, wt["head0_W"])
+            dx_up = None
+            for l in range(2, -1, -1):
+                dh = dfeat[..., offs[l]:offs[l] + F[l]] + dh_rec[l]
+                if dx_up is not None:
+                    dh = dh + dx_up
+                c_prev = tp["ec%d" % l][T_in - 1] if t == 0 else tp["dc"][l][t - 1]
+                dz = ops.convlstm_gates_bwd(dh, dc[l], tp["dg"][l][t], c_prev, tp["dc"][l][t], act, dz=dzs[l][t])
+                dh_rec[l] = ops.conv2d(dz, wt["dec%d_R" % l])
+                if l > 0 or t > 0:
+                    dx = ops.conv2d(dz, wt["dec%d_K" % l])
+                    if l > 0:
+                        dx_up = dx
+                    else:
+                        dfeed = dx
+        # head weight gradients: one product over all steps per layer
+        x_in = feat
+        for i in range(nh):
+            ops.conv2d_wgrad(x_in, dys[i], *w["head%d_W" % i].shape[:2], dw=g["head%d_W" % i], scratch=sc)
+            ops.colsum(dys[i], out=g["head%d_b" % i], scratch=sc)
+            x_in = tp["ys"][i]
+        # decoder cells
+        for l in range(3):
+            x_in = tp["inp"] if l == 0 else feat[..., offs[l - 1]:offs[l - 1] + F[l - 1]]
+            kh, kw = w["dec%d_K" % l].shape[:2]
+            ops.conv2d_wgrad(x_in, dzs[l], kh, kw, dw=g["dec%d_K" % l], scratch=sc)
+            ops.conv2d_wgrad(tp["eh%d" % l][T_in - 1], dzs[l][0], kh, kw, dw=g["dec%d_R" % l], scratch=sc)
+            if T_out > 1:
+                ops.conv2d_wgrad(feat[:T_out - 1][..., offs[l]:offs[l] + F[l]], dzs[l][1:], kh, kw, dw=g["dec%d_R" % l],
+                                 accumulate=True, scratch=sc)
+            ops.colsum(dzs[l], out=g["dec%d_b" % l], scratch=sc)
+        # encoder, top layer first; dh_rec / dc arrive from the decoder's first step
+        dx_seq = None
+        for l in range(2, -1, -1):
+            gs, cs, hs = tp["eg%d" % l], tp["ec%d" % l], tp["eh%d" % l]
+            edz = torch.empty_like(gs)
+            dhr, dcl = dh_rec[l], dc[l]
+            for t in range(T_in - 1, -1, -1):
+                dh = dhr if dx_seq is None else dhr + dx_seq[t]
+                dz = ops.convlstm_gates_bwd(dh, dcl, gs[t], cs[t - 1] if t > 0 else None, cs[t], act, dz=edz[t])
+                if t > 0:
+                    dhr = ops.conv2d(dz, wt["enc%d_R" % l])
+            kh, kw = w["enc%d_K" % l].shape[:2]
+            x_in = tp["x"] if l == 0 else tp["eh%d" % (l - 1)]
+            ops.conv2d_wgrad(x_in, edz, kh, kw, dw=g["enc%d_K" % l], scratch=sc)
+            if T_in > 1:
+                ops.conv2d_wgrad(hs[:T_in - 1], edz[1:], kh, kw, dw=g["enc%d_R" % l], scratch=sc)
+            else:
+                g["enc%d_R" % l].zero_()
+            ops.colsum(edz, out=g["enc%d_b" % l], scratch=sc)
+            if l > 0:   # data gradient for the layer below, all steps in one launch
+                dx_seq = ops.conv2d(edz.reshape(T_in * B, H, W, 4 * F[l]), wt["enc%d_K" % l]).reshape(T_in, B, H, W, F[l - 1])
+        if grad_weight != 1.0:
+            self.grad.mul_(grad_weight)
+        return loss, P.permute(1, 0, 2, 3, 4)
+
+    def eval_loss(self, enc, dec0, target):
+        P, _ = self._forward(enc, dec0, target.shape[1])
+        _, loss = ops.mse_dense_grad(P, target.permute(1, 0, 2, 3, 4).contiguous(), None, scratch=self.scratch)
+        return loss
+
+    def apply_gradients(self):
+        self.step_count += 1
+        if self.optimizer == "adam":
+            ops.adam_step(self.flat, self.grad, self.m, self.v, self.step_count, lr=self.lr)
+        else:
+            ops.rmsprop_step(self.flat, self.grad, self.m, lr=self.lr)
+
+    def train_step(self, enc, dec0, target, n_global=None):
+        """One optimizer step; under data parallelism gradients combine as sum_r (n_r/n) g_r with ONE
+        all-reduce of the flat buffer (as Seq2SeqTrainer.train_step)."""
+        _, world = parallel.world()
+        n_local = enc.shape[0]
+        weight = 1.0 if world == 1 else n_local / float(n_global if n_global else n_local * world)
+        loss, _ = self.forward_backward(enc, dec0, target, grad_weight=weight)
+        if world > 1:
+            torch.distributed.all_reduce(self.grad, op=torch.distributed.ReduceOp.SUM)
+            lw = loss * weight
+            torch.distributed.all_reduce(lw, op=torch.distributed.ReduceOp.SUM)
+            loss = lw
+        self.apply_gradients()
+        return loss

@@ -172,3 +172,106 @@ def test_convlstm_gates_backward_softmax_relu_colsum(act):
     close(ops.act_bwd(dev(dp), dev(r), activation="relu"), dp * (r > 0), "relu bwd", tol=1e-6)
     big = rng.standard_normal((5000, 40)).astype(np.float32)
     close(ops.colsum(dev(big)), big.astype(np.float64).sum(0), "colsum")
+
+
+def _torch_convlstm_graph(enc, dec0, tgt, w, head, act):
+    """Independent fp64 restatement of the ConvLSTM seq2seq training graph (convlstm_seq2seq.py:100-287,
+    no dropout) on torch.autograd: loss = mean squared error of the unrolled, self-fed decoder."""
+    t = {k: torch.tensor(v.astype(np.float64), requires_grad=True) for k, v in w.items()}
+    s = torch.sigmoid if act == "sigmoid" else (lambda z: torch.clamp(0.2 * z + 0.5, 0, 1))
+
+    def cell(x, h, c, K, R, b):
+        F = R.shape[2]
+        z = _tconv(x, K) + b + _tconv(h, R)
+        i, f, g, o = s(z[..., :F]), s(z[..., F:2 * F]), torch.tanh(z[..., 2 * F:3 * F]), s(z[..., 3 * F:])
+        c = f * c + i * g
+        return o * torch.tanh(c), c
+
+    e, d0, tg = (torch.tensor(a.astype(np.float64)) for a in (enc, dec0, tgt))
+    B, T_in, H, W, _ = e.shape
+    seq = [e[:, tt] for tt in range(T_in)]
+    states = []
+    for l in range(3):
+        F = w["enc%d_R" % l].shape[2]
+        h = torch.zeros(B, H, W, F, dtype=torch.float64)
+        c = torch.zeros(B, H, W, F, dtype=torch.float64)
+        nxt = []
+        for tt in range(T_in):
+            h, c = cell(seq[tt], h, c, t["enc%d_K" % l], t["enc%d_R" % l], t["enc%d_b" % l])
+            nxt.append(h)
+        seq = nxt
+        states.append([h, c])
+    inp = d0[:, 0]
+    outs = []
+    for tt in range(tg.shape[1]):
+        cur, feats = inp, []
+        for l in range(3):
+            h, c = cell(cur, states[l][0], states[l][1], t["dec%d_K" % l], t["dec%d_R" % l], t["dec%d_b" % l])
+            states[l] = [h, c]
+            feats.append(h)
+            cur = h
+        y = torch.cat(feats, -1)
+        y = torch.relu(_tconv(y, t["head0_W"]) + t["head0_b"])
+        y = torch.relu(_tconv(y, t["head1_W"]) + t["head1_b"])
+        y = _tconv(y, t["head2_W"]) + t["head2_b"]
+        y = torch.softmax(torch.relu(y) if head == "conv2d" else y, -1)
+        outs.append(y)
+        inp = y
+    P = torch.stack(outs, 1)
+    loss = torch.mean((P - tg) ** 2)
+    loss.backward()
+    return float(loss), {k: v.grad.numpy() for k, v in t.items()}, P.detach().numpy()
+
+
+@pytest.mark.parametrize("head,B,T_in,T_out,H,W,C,L,hf,act", [("conv2d", 2, 3, 3, 9, 6, 10, 8, (24, 40), "hard_sigmoid"),
+                                                               ("conv1d", 3, 2, 3, 1, 30, 3, 16, (32, 48), "sigmoid"),
+                                                               ("conv2d", 1, 2, 2, 36, 18, 30, 16, (40, 136), "sigmoid")])
+def test_convlstm_seq2seq_gradients_and_training(head, B, T_in, T_out, H, W, C, L, hf, act):
+    """a8 backward: gradients of the whole unrolled graph (feedback path through the head included) against
+    torch.autograd in fp64; the torch graph itself is pinned to the NumPy oracle's forward; then RMSprop steps
+    reduce the loss."""
+    from longterm360fov_amd.training import ConvLSTMTrainer
+    w = O.init_convlstm_seq2seq(5, C=C, latent_dim=L, head=head, head_filters=hf)
+    rng = np.random.default_rng(8)
+    for k in w:
+        if k.endswith("_b"):
+            w[k] = (w[k] + 0.1 * rng.standard_normal(w[k].shape)).astype(np.float32)
+    enc = rng.random((B, T_in, H, W, C)).astype(np.float32)
+    dec0 = enc[:, -1:].copy()
+    tgt = rng.random((B, T_out, H, W, C)).astype(np.float32)
+    tgt /= tgt.sum(-1, keepdims=True)
+    loss_ref, g_ref, P_ref = _torch_convlstm_graph(enc, dec0, tgt, w, head, act)
+    w64 = {k: v.astype(np.float64) for k, v in w.items()}
+    P_orc = O.convlstm_seq2seq_forward(enc.astype(np.float64), dec0.astype(np.float64), w64, T_out, head=head, act=act)
+    assert np.abs(P_orc - P_ref).max() < 1e-10        # the autograd graph computes the oracle's function
+    tr = ConvLSTMTrainer(w, head=head, act=act)
+    loss, P = tr.forward_backward(dev(enc), dev(dec0), dev(tgt))
+    close(P, P_ref, "train-mode forward")
+    assert abs(float(loss.item()) - loss_ref) <= 1e-5 * loss_ref + 1e-9
+    for k in tr.order:
+        a = tr.g[k].detach().cpu().numpy().astype(np.float64)
+        scale = np.abs(g_ref[k]).max()
+        err = np.abs(a - g_ref[k]).max()
+        print("convlstm %s grad %-8s max|ref| %.3e  max err %.3e" % (head, k, scale, err))
+        assert err <= 2e-4 * scale + 1e-9, (k, err, scale)
+    losses = [float(tr.train_step(dev(enc), dev(dec0), dev(tgt)).item()) for _ in range(4)]
+    assert losses[-1] < losses[0]
+
+
+def test_convlstm_fit_surface():
+    from longterm360fov_amd.models import ConvLSTMSeq2Seq
+    np.random.seed(2)
+    rng = np.random.default_rng(3)
+    w = O.init_convlstm_seq2seq(9, C=3, latent_dim=8, head="conv1d", head_filters=(16, 24))
+    enc = rng.random((24, 3, 1, 30, 3)).astype(np.float32)
+    tgt = rng.random((24, 2, 1, 30, 3)).astype(np.float32)
+    tgt /= tgt.sum(-1, keepdims=True)
+    m = ConvLSTMSeq2Seq(w, head="conv1d")
+    with pytest.raises(RuntimeError):
+        m.fit([enc, enc[:, -1:]], tgt)
+    m.compile(optimizer="RMSprop", loss="mean_squared_error")
+    h = m.fit([enc, enc[:, -1:]], tgt, batch_size=8, epochs=3, validation_split=0.25, shuffle=True)
+    assert len(h.history["loss"]) == 3 and h.history["loss"][-1] < h.history["loss"][0] and "val_loss" in h.history
+    assert m.predict([enc[:4], enc[:4, -1:]], predict_step=2).shape == (4, 2, 1, 30, 3)
+    with pytest.raises(NotImplementedError):
+        ConvLSTMSeq2Seq(w, head="conv1d", dropout_rate=0.3).train_on_batch([enc[:2], enc[:2, -1:]], tgt[:2])
