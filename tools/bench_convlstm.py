@@ -24,6 +24,8 @@ def main():
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--whole", action="store_true")
+    ap.add_argument("--train", action="store_true", help="also time one training step (fwd + backward + RMSprop)")
+    ap.add_argument("--train-batch", type=int, default=64)
     a = ap.parse_args()
     H, W, C, T = 36, 18, 30, 10
     w = O.init_convlstm_seq2seq(1, C=C, latent_dim=16, head="conv2d")
@@ -70,6 +72,23 @@ def main():
         head_flop = 2 * 25 * (56 * 512 + 512 * 1024 + 1024 * 30) * H * W
         tot = (2 * cell_flop_step + head_flop) * T * B
         res.update({"whole_model_ms": dt * 1e3, "whole_model_sequences_per_s": B / dt, "whole_model_tflops": tot / dt / 1e12})
+    if a.train:
+        from longterm360fov_amd.training import ConvLSTMTrainer
+        Bt = a.train_batch
+        tr = ConvLSTMTrainer(w, head="conv2d")
+        xe = x[:Bt].contiguous()
+        tgt = torch.softmax(torch.rand((Bt, T, H, W, C), device="cuda"), -1)
+        tr.train_step(xe, xe[:, -1:], tgt)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            loss = tr.train_step(xe, xe[:, -1:], tgt)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / a.steps
+        head_flop = 2 * 25 * (56 * 512 + 512 * 1024 + 1024 * 30) * H * W
+        tot = 3 * (2 * cell_flop_step + head_flop) * T * Bt
+        res.update({"train_batch": Bt, "train_step_ms": dt * 1e3, "train_sequences_per_s": Bt / dt,
+                    "train_tflops_3x_forward": tot / dt / 1e12, "train_loss": float(loss.item())})
     print(json.dumps(res))
 
 
