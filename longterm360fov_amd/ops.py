@@ -93,12 +93,13 @@ def lstm_seq(x, K, R, b, h0=None, c0=None, act="sigmoid", impl="auto", return_se
     return hs, hT, cT
 
 
-def dense(x, W, b, activation="tanh"):
+def dense(x, W, b, activation="tanh", out=None):
     x, W, b = _dev(x, "x"), _dev(W, "W"), _dev(b, "b")
     lead = x.shape[:-1]
     In, Out = W.shape
     x2 = x.reshape(-1, In)
-    y = torch.empty((x2.shape[0], Out), dtype=torch.float32, device=x.device)
+    y = torch.empty((x2.shape[0], Out), dtype=torch.float32, device=x.device) if out is None else _dev(out, "out")
+    assert y.numel() == x2.shape[0] * Out
     check(_lib.lib().fov_dense_fwd(_ptr(x2), _ptr(W), _ptr(b), _ptr(y), x2.shape[0], In, Out,
                                    1 if activation == "tanh" else 0, _stream()))
     return y.reshape(*lead, Out)
@@ -207,16 +208,22 @@ _default_scratch = Scratch()
 
 
 def lstm_seq_bwd(x, K, R, hs, reserve, h0=None, c0=None, dhs=None, dhT=None, dcT=None, dK=None, dR=None, db=None,
-                 need_dx=False, need_state_grads=False, act="sigmoid", accumulate=False, dz=None, scratch=None):
-    """BPTT of one layer -> dict(dz, dx, dK, dR, db, dh0, dc0)."""
+                 need_dx=False, need_state_grads=False, act="sigmoid", accumulate=False, dz=None, scratch=None,
+                 need_weight_grads=True):
+    """BPTT of one layer -> dict(dz, dx, dK, dR, db, dh0, dc0).  need_weight_grads=False computes the data path
+    only (dz, dx, state gradients): a caller that walks a decoder step by step stacks dz and forms the
+    weight gradients once, over all steps."""
     x, K, R, hs, reserve = _dev(x, "x"), _dev(K, "K"), _dev(R, "R"), _dev(hs, "hs"), _dev(reserve, "reserve")
     B, T, F = x.shape
     H = R.shape[0]
     e = lambda *s: torch.empty(s, dtype=torch.float32, device=x.device)
     dz = e(B, T, 4 * H) if dz is None else dz
-    dK = e(F, 4 * H) if dK is None else dK
-    dR = e(H, 4 * H) if dR is None else dR
-    db = e(4 * H) if db is None else db
+    if need_weight_grads:
+        dK = e(F, 4 * H) if dK is None else dK
+        dR = e(H, 4 * H) if dR is None else dR
+        db = e(4 * H) if db is None else db
+    else:
+        dK = dR = db = None
     dx = e(B, T, F) if need_dx else None
     dh0 = e(B, H) if need_state_grads else None
     dc0 = e(B, H) if need_state_grads else None
@@ -296,14 +303,15 @@ def matmul(a, b, scratch=None):
     return c
 
 
-def dense_add(x, W, b, add, activation="tanh"):
+def dense_add(x, W, b, add, activation="tanh", out=None):
     """act(x W + b + add) with add (N,Out) possibly a strided row view (last dim contiguous)."""
     x, W = _dev(x, "x"), _dev(W, "W")
     In, Out = W.shape
     x2 = x.reshape(-1, In)
     N = x2.shape[0]
     assert add.is_cuda and add.dtype == torch.float32 and add.shape == (N, Out) and add.stride(1) == 1
-    y = torch.empty((N, Out), dtype=torch.float32, device=x.device)
+    y = torch.empty((N, Out), dtype=torch.float32, device=x.device) if out is None else _dev(out, "out")
+    assert y.numel() == N * Out
     check(_lib.lib().fov_dense_add_fwd(_ptr(x2), _ptr(W), _ptr(_dev(b, "b")), add.data_ptr(), add.stride(0), _ptr(y),
                                        N, In, Out, 1 if activation == "tanh" else 0, _stream()))
     return y

@@ -154,49 +154,70 @@ class OthersMixingTrainer:
         oth_flat = others.reshape(B * T_out, n_oth)
         Wm_o_c, Wm_p_c = Wm_o.contiguous(), Wm_p.contiguous()
         oth_proj = ops.dense(oth_flat, Wm_o_c, w["mix_b"], activation=None).reshape(B, T_out, O)
-        steps = []
-        x = dec0.reshape(B, 1, O)
+        # Decoder tape, time-major: step t reads row t of the "previous state" stacks and writes row t+1, so the
+        # stacked rows are exactly the operands of the per-layer weight-gradient products formed after the loop.
+        e = lambda *s_: torch.empty(s_, dtype=torch.float32, device=self.device)
+        X = e(T_out, B, O)                                   # decoder inputs x_t
+        H1, C1 = e(T_out + 1, B, H), e(T_out + 1, B, H)       # row 0 = encoder state, row t+1 = state after step t
+        H2, C2 = e(T_out + 1, B, H), e(T_out + 1, B, H)
+        R1, R2 = e(T_out, B, 1, 5, H), e(T_out, B, 1, 5, H)   # reserves (i,f,g,o,c) of every step
+        P, M = e(T_out, B, O), e(T_out, B, O)
+        H1[0].copy_(h1); C1[0].copy_(c1); H2[0].copy_(h2); C2[0].copy_(c2)
+        X[0].copy_(dec0.reshape(B, O))
         for t in range(T_out):
-            st = {"x": x, "h1_prev": h1, "c1_prev": c1, "h2_prev": h2, "c2_prev": c2}
-            hs_a, h1, c1, r1 = ops.lstm_seq_train(x, w["dec1_K"], w["dec1_R"], w["dec1_b"], h1, c1, act=act, impl=impl, workspace=ws)
-            zx = ops.matmul(h1, w["dec2_K"], scratch=sc).reshape(B, 1, 4 * H)
-            r2 = torch.empty((B, 1, 5, H), dtype=torch.float32, device=self.device)
-            hs_b, h2, c2 = ops.lstm_seq_zx(zx, w["dec2_R"], w["dec2_b"], h2, c2, act=act, impl=impl, workspace=ws, reserve=r2)
-            p = ops.dense(h2, w["dense_W"], w["dense_b"], activation="tanh")
-            m = ops.dense_add(p, Wm_p_c, None, oth_proj[:, t], activation="tanh")
-            st.update({"hs1": hs_a, "r1": r1, "hs2": hs_b, "r2": r2, "h1": h1, "h2": h2, "p": p, "m": m})
-            steps.append(st)
-            x = m.reshape(B, 1, O)
-        out = torch.empty((B, T_out, O), dtype=torch.float32, device=self.device)
-        for t, st in enumerate(steps):
-            out[:, t].copy_(st["m"])                                            # gather of the step outputs (copy only)
+            hs_a = H1[t + 1].view(B, 1, H)
+            ops.lstm_seq_train(X[t].view(B, 1, O), w["dec1_K"], w["dec1_R"], w["dec1_b"], H1[t], C1[t], act=act, impl=impl,
+                               workspace=ws, out=(hs_a, e(B, H), C1[t + 1], R1[t]))
+            zx = ops.matmul(H1[t + 1], w["dec2_K"], scratch=sc).reshape(B, 1, 4 * H)
+            hs_b, _, c2n = ops.lstm_seq_zx(zx, w["dec2_R"], w["dec2_b"], H2[t], C2[t], act=act, impl=impl, workspace=ws,
+                                           reserve=R2[t])
+            H2[t + 1].copy_(hs_b.view(B, H)); C2[t + 1].copy_(c2n)
+            ops.dense(H2[t + 1], w["dense_W"], w["dense_b"], activation="tanh", out=P[t])
+            ops.dense_add(P[t], Wm_p_c, None, oth_proj[:, t], activation="tanh", out=M[t])
+            if t + 1 < T_out:
+                X[t + 1].copy_(M[t])
+        out = M.transpose(0, 1).contiguous()                                      # (B,T_out,O)
         # ---------------- backward ----------------
         # dL/d(pre-tanh of the mixing layer) from the loss, for every step at once
         dloss, loss = ops.mse_dense_grad(out, target, "tanh", scratch=sc)
-        dpre_all = torch.empty((T_out, B, O), dtype=torch.float32, device=self.device)   # per-step, contiguous
+        dpre_all = dloss.transpose(0, 1).contiguous()                              # (T_out,B,O), per-step rows
+        dpre_p_all = e(T_out, B, O)
+        DZ1, DZ2 = e(T_out, B, 4 * H), e(T_out, B, 4 * H)
         dh1_rec = dc1 = dh2_rec = dc2 = None
         dx_next = None
         for t in range(T_out - 1, -1, -1):
-            st = steps[t]
             dpre_m = dpre_all[t]
-            dpre_m.copy_(dloss[:, t])
             if dx_next is not None:            # x_{t+1} = m_t: the feedback gradient joins through tanh'
-                ops.act_bwd(dx_next.reshape(B, O), st["m"], base=dpre_m, activation="tanh", out=dpre_m)
-            dp, _, _ = ops.dense_bwd(st["p"], Wm_p_c, dpre_m, dW=gWm_p, db=g["mix_b"], accumulate=True, scratch=sc)
-            dpre_p = ops.act_bwd(dp, st["p"], activation="tanh")
-            dh2_dense, _, _ = ops.dense_bwd(st["h2"], w["dense_W"], dpre_p, dW=g["dense_W"], db=g["dense_b"],
-                                            accumulate=True, scratch=sc)
+                ops.act_bwd(dx_next.reshape(B, O), M[t], base=dpre_m, activation="tanh", out=dpre_m)
+            # data path only inside the loop; every weight gradient is one product over all steps, below
+            dp, _, _ = ops.dense_bwd(P[t], Wm_p_c, dpre_m, need_dW=False, need_db=False, scratch=sc)
+            dpre_p = ops.act_bwd(dp, P[t], activation="tanh", out=dpre_p_all[t])
+            dh2_dense, _, _ = ops.dense_bwd(H2[t + 1], w["dense_W"], dpre_p, need_dW=False, need_db=False, scratch=sc)
             # layer 2 step: its input is h1_t, so its dx (= dz2 . K2^T) is the gradient w.r.t. h1_t
-            b2 = ops.lstm_seq_bwd(st["h1"].reshape(B, 1, H), w["dec2_K"], w["dec2_R"], st["hs2"], st["r2"],
-                                  h0=st["h2_prev"], c0=st["c2_prev"], dhs=dh2_dense.reshape(B, 1, H), dhT=dh2_rec, dcT=dc2,
-                                  dK=g["dec2_K"], dR=g["dec2_R"], db=g["dec2_b"], need_dx=True, need_state_grads=True,
-                                  act=act, accumulate=True, scratch=bsc)
+            b2 = ops.lstm_seq_bwd(H1[t + 1].view(B, 1, H), w["dec2_K"], w["dec2_R"], H2[t + 1].view(B, 1, H), R2[t],
+                                  h0=H2[t], c0=C2[t], dhs=dh2_dense.reshape(B, 1, H), dhT=dh2_rec, dcT=dc2,
+                                  need_dx=True, need_state_grads=True, act=act, dz=DZ2[t].view(B, 1, 4 * H), scratch=bsc,
+                                  need_weight_grads=False)
             dh2_rec, dc2 = b2["dh0"], b2["dc0"]
-            b1 = ops.lstm_seq_bwd(st["x"], w["dec1_K"], w["dec1_R"], st["hs1"], st["r1"], h0=st["h1_prev"],
-                                  c0=st["c1_prev"], dhs=b2["dx"], dhT=dh1_rec, dcT=dc1, dK=g["dec1_K"], dR=g["dec1_R"],
-                                  db=g["dec1_b"], need_dx=(t > 0), need_state_grads=True, act=act, accumulate=True, scratch=bsc)
+            b1 = ops.lstm_seq_bwd(X[t].view(B, 1, O), w["dec1_K"], w["dec1_R"], H1[t + 1].view(B, 1, H), R1[t], h0=H1[t],
+                                  c0=C1[t], dhs=b2["dx"], dhT=dh1_rec, dcT=dc1, need_dx=(t > 0), need_state_grads=True,
+                                  act=act, dz=DZ1[t].view(B, 1, 4 * H), scratch=bsc, need_weight_grads=False)
             dh1_rec, dc1 = b1["dh0"], b1["dc0"]
             dx_next = b1["dx"]
+        # weight gradients of the unrolled decoder: x^T dz (input kernels, biases) and h_prev^T dz (recurrent)
+        TB = T_out * B
+        fl = lambda a, n: a.reshape(TB, n)
+        ops.dense_bwd(fl(P, O), Wm_p_c, fl(dpre_all, O), dW=gWm_p, db=g["mix_b"], need_dx=False, accumulate=True, scratch=sc)
+        ops.dense_bwd(fl(H2[1:], H), w["dense_W"], fl(dpre_p_all, O), dW=g["dense_W"], db=g["dense_b"], need_dx=False,
+                      accumulate=True, scratch=sc)
+        ops.dense_bwd(fl(H1[1:], H), w["dec2_K"], fl(DZ2, 4 * H), dW=g["dec2_K"], db=g["dec2_b"], need_dx=False,
+                      accumulate=True, scratch=sc)
+        ops.dense_bwd(fl(H2[:T_out], H), w["dec2_R"], fl(DZ2, 4 * H), dW=g["dec2_R"], need_db=False, need_dx=False,
+                      accumulate=True, scratch=sc)
+        ops.dense_bwd(fl(X, O), w["dec1_K"], fl(DZ1, 4 * H), dW=g["dec1_K"], db=g["dec1_b"], need_dx=False,
+                      accumulate=True, scratch=sc)
+        ops.dense_bwd(fl(H1[:T_out], H), w["dec1_R"], fl(DZ1, 4 * H), dW=g["dec1_R"], need_db=False, need_dx=False,
+                      accumulate=True, scratch=sc)
         # "others" half of the mixing kernel: one product over all steps, rows ordered (t, b) like dpre_all
         oth_tb = others.transpose(0, 1).contiguous().reshape(T_out * B, n_oth)
         ops.dense_bwd(oth_tb, Wm_o_c, dpre_all.reshape(T_out * B, O), dW=gWm_o, need_db=False, need_dx=False,
