@@ -257,7 +257,10 @@ __global__ __launch_bounds__(256, 1) void lstm_cluster_kernel(LstmParams p) {
     float* sKw = sK + wave * (nq * 4 + KPAD) * 256;  // this wave's K slice in B-operand order
 
     if (tid == 0) { sFlag[0] = 0; sFlag[1] = 0; }
-    if (G > 1) {
+    // A layer's last step publishes nothing (no later step reads h_T from the partners), so a one-step layer
+    // launch - the unit the step-wise decoders of a4 are built from - needs no exchange and no handshake.
+    const bool xch_used = (G > 1) && (!LAYER || p.T > 1);
+    if (xch_used) {
         // hello handshake (safe sc1 protocol): do all members of this group sit on one XCD?
         unsigned long long* hello = p.xch + (size_t)p.num_groups * 2 * BT * H + (size_t)group * G;
         const unsigned mine = xcc_id();
@@ -320,9 +323,9 @@ __global__ __launch_bounds__(256, 1) void lstm_cluster_kernel(LstmParams p) {
     unsigned epoch = (unsigned)p.epoch_start;   // a second launch on the same buffers continues the count
     bool aborted = false;
     __syncthreads();
-    const bool same_xcd = (G > 1) && (sFlag[1] == 0) && (p.force_safe_exchange == 0);
-    if (G > 1 && sFlag[0]) return;   // a partner never showed up: status word is set, drain
-    if (G > 1 && tid == 0 && !same_xcd)   // status[1]: number of workgroups on the safe (cross-XCD) exchange
+    const bool same_xcd = xch_used && (sFlag[1] == 0) && (p.force_safe_exchange == 0);
+    if (xch_used && sFlag[0]) return;   // a partner never showed up: status word is set, drain
+    if (xch_used && tid == 0 && !same_xcd)   // status[1]: number of workgroups on the safe (cross-XCD) exchange
         __hip_atomic_fetch_add(p.status + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #ifdef FOV_STAMPS
     const bool stamp_on = (blockIdx.x == 5 && tid == 0);
@@ -456,7 +459,9 @@ __global__ __launch_bounds__(256, 1) void lstm_cluster_kernel(LstmParams p) {
                 }
             }
             unsigned xsoff = 0;
-            if (G > 1) {
+            // h_t of a layer's last step is needed by nobody inside the kernel: no publish, no gather
+            const bool do_xch = (G > 1) && (!LAYER || t + 1 < steps);
+            if (do_xch) {
                 // publish this workgroup's slice of h_t: one 8-byte {value, epoch} granule each
                 ++epoch;
                 xsoff = (epoch & 1u) * (unsigned)(BT * H * sizeof(unsigned long long));
@@ -499,7 +504,7 @@ __global__ __launch_bounds__(256, 1) void lstm_cluster_kernel(LstmParams p) {
             }
             FOV_STAMP(5);
             u32x2 v[NG > 0 ? NG : 1];
-            if (G > 1) {
+            if (do_xch) {
 #pragma unroll
                 for (int j = 0; j < NG; ++j) v[j] = __builtin_amdgcn_raw_buffer_load_b64(xrs, goff[j], xsoff, 16);
             }
@@ -508,7 +513,7 @@ __global__ __launch_bounds__(256, 1) void lstm_cluster_kernel(LstmParams p) {
                 mfma_end(acc);
             }
             FOV_STAMP(11);
-            if (G > 1) {
+            if (do_xch) {
                 // complete the gather: sweep again until every tag equals the epoch
                 unsigned spins = 0;
                 while (true) {
