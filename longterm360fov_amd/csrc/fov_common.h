@@ -60,6 +60,7 @@ struct LstmParams {
     int num_tiles;
     int epoch_start;           // first epoch - 1 of this launch (0, or T_in for the decoder launch of a fused call)
     int force_safe_exchange;   // 1: never take the same-XCD fast path (tests)
+    int clear_status;          // 1: this launch exchanges nothing; the kernel zeroes the status words itself
 };
 
 int launch_generic(const LstmParams& p, bool decode, hipStream_t stream);

@@ -175,7 +175,7 @@ def lstm_seq_train(x, K, R, b, h0=None, c0=None, act="sigmoid", impl="auto", wor
     if out is None:
         e = lambda *s: torch.empty(s, dtype=torch.float32, device=x.device)
         out = (e(B, T, H), e(B, H), e(B, H), e(B, T, 5, H))
-    hs, hT, cT, res = out
+    hs, hT, cT, res = out      # hT / cT may be None (not written)
     L = _lib.lib()
     impl = impl_code(impl)
     ws = (workspace or default_workspace(x.device))
@@ -318,15 +318,19 @@ def dense_add(x, W, b, add, activation="tanh", out=None):
 
 
 def lstm_seq_zx(zx, R, b, h0=None, c0=None, act="sigmoid", impl="auto", return_sequences=True, workspace=None,
-                reserve=None):
-    """LSTM layer from a precomputed input projection zx = x.K (B,T,4H) -> (hs|None, hT, cT)."""
+                reserve=None, out=None):
+    """LSTM layer from a precomputed input projection zx = x.K (B,T,4H) -> (hs|None, hT, cT).
+    `out` may carry preallocated (hs|None, hT|None, cT|None) tensors (None entries are not written)."""
     zx, R, b = _dev(zx, "zx"), _dev(R, "R"), _dev(b, "b")
     B, T, H4 = zx.shape
     H = R.shape[0]
     assert H4 == 4 * H
     e = lambda *s: torch.empty(s, dtype=torch.float32, device=zx.device)
-    hs = e(B, T, H) if return_sequences else None
-    hT, cT = e(B, H), e(B, H)
+    if out is None:
+        hs = e(B, T, H) if return_sequences else None
+        hT, cT = e(B, H), e(B, H)
+    else:
+        hs, hT, cT = (_dev(t, "out") for t in out)
     L = _lib.lib()
     impl = impl_code(impl)
     ws = (workspace or default_workspace(zx.device))

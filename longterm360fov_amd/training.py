@@ -157,25 +157,23 @@ class OthersMixingTrainer:
         # Decoder tape, time-major: step t reads row t of the "previous state" stacks and writes row t+1, so the
         # stacked rows are exactly the operands of the per-layer weight-gradient products formed after the loop.
         e = lambda *s_: torch.empty(s_, dtype=torch.float32, device=self.device)
-        X = e(T_out, B, O)                                   # decoder inputs x_t
+        XM = e(T_out + 1, B, O)                               # row t = decoder input x_t, row t+1 = output m_t
+        X, M = XM[:T_out], XM[1:]
         H1, C1 = e(T_out + 1, B, H), e(T_out + 1, B, H)       # row 0 = encoder state, row t+1 = state after step t
         H2, C2 = e(T_out + 1, B, H), e(T_out + 1, B, H)
         R1, R2 = e(T_out, B, 1, 5, H), e(T_out, B, 1, 5, H)   # reserves (i,f,g,o,c) of every step
-        P, M = e(T_out, B, O), e(T_out, B, O)
+        P = e(T_out, B, O)
         H1[0].copy_(h1); C1[0].copy_(c1); H2[0].copy_(h2); C2[0].copy_(c2)
         X[0].copy_(dec0.reshape(B, O))
         for t in range(T_out):
-            hs_a = H1[t + 1].view(B, 1, H)
+            # every kernel writes straight into its row of the tape: no copies inside the loop
             ops.lstm_seq_train(X[t].view(B, 1, O), w["dec1_K"], w["dec1_R"], w["dec1_b"], H1[t], C1[t], act=act, impl=impl,
-                               workspace=ws, out=(hs_a, e(B, H), C1[t + 1], R1[t]))
+                               workspace=ws, out=(H1[t + 1].view(B, 1, H), None, C1[t + 1], R1[t]))
             zx = ops.matmul(H1[t + 1], w["dec2_K"], scratch=sc).reshape(B, 1, 4 * H)
-            hs_b, _, c2n = ops.lstm_seq_zx(zx, w["dec2_R"], w["dec2_b"], H2[t], C2[t], act=act, impl=impl, workspace=ws,
-                                           reserve=R2[t])
-            H2[t + 1].copy_(hs_b.view(B, H)); C2[t + 1].copy_(c2n)
+            ops.lstm_seq_zx(zx, w["dec2_R"], w["dec2_b"], H2[t], C2[t], act=act, impl=impl, workspace=ws, reserve=R2[t],
+                            out=(H2[t + 1].view(B, 1, H), None, C2[t + 1]))
             ops.dense(H2[t + 1], w["dense_W"], w["dense_b"], activation="tanh", out=P[t])
             ops.dense_add(P[t], Wm_p_c, None, oth_proj[:, t], activation="tanh", out=M[t])
-            if t + 1 < T_out:
-                X[t + 1].copy_(M[t])
         out = M.transpose(0, 1).contiguous()                                      # (B,T_out,O)
         # ---------------- backward ----------------
         # dL/d(pre-tanh of the mixing layer) from the loss, for every step at once

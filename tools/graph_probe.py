@@ -31,6 +31,14 @@ def main():
     for _ in range(3):
         tr.train_step(*a)
     print("eager  %.3f ms/step" % timeit(lambda: tr.train_step(*a)), flush=True)
+    # host side alone: enqueue one step on an idle GPU and stop the clock before waiting for it
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    tr.train_step(*a)
+    t1 = time.perf_counter()
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    print("one step: host enqueue %.3f ms, then %.3f ms until the GPU is idle" % ((t1 - t0) * 1e3, (t2 - t1) * 1e3), flush=True)
     s = torch.cuda.Stream()
     s.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(s):
