@@ -532,6 +532,8 @@ class ConvLSTMSeq2Seq:
     channel concat of the three layer outputs, head, output fed back as the next input.
       head 'conv2d' (cfg.use_one_hot, 36x18x30 maps): Conv2D 512 -> 1024 -> 30 (relu) + channel Softmax
       head 'conv1d' (xyz mode, (1,30,3) "images"): Conv1D k=7 512 -> 1024 -> 3, relu, relu, softmax
+      head 'dense'  (cfg.predict_mean_var with cfg.input_mean_var, 1x1 maps of 6 channels, :171,225-227,272-273):
+                    Flatten + Dense(6, linear), output (N,T_out,6) fed back as the next 1x1x6 input map
     predict([encoder_input (N,T_in,H,W,C), decoder_input (N,1,H,W,C)]) -> (N,T_out,H,W,C_out).
     compile('RMSprop', loss=costfunc._mse | 'mean_squared_error') / fit / train_on_batch train the same unrolled
     graph (convlstm_seq2seq.py:287,396-420) through training.ConvLSTMTrainer; input dropout
@@ -620,7 +622,8 @@ class ConvLSTMSeq2Seq:
                 seq = nxt
                 states.append([h, c])
             # decoder: three cells per step, each h written straight into its slot of the concat map
-            out = e4(B, T_out, H, W, dw["head2_W"].shape[3])
+            dense_head = self.head == "dense"
+            out = e4(B, T_out, 6) if dense_head else e4(B, T_out, H, W, dw["head2_W"].shape[3])
             for t in range(T_out):
                 feat = e4(B, H, W, cat)
                 cur = inp
@@ -632,6 +635,11 @@ class ConvLSTMSeq2Seq:
                     ops.convlstm_gates(z, states[l][1], hslot, act)
                     states[l][0] = hslot
                     cur = hslot
+                if dense_head:   # Flatten + Dense(6): cfg.predict_mean_var, output fed back as a 1x1x6 map
+                    y = ops.dense(feat.reshape(B, H * W * cat), dw["head0_W"], dw["head0_b"], activation=None)
+                    out[:, t] = y
+                    inp = y.reshape(B, 1, 1, 6)
+                    continue
                 y = ops.conv2d(feat, dw["head0_W"], dw["head0_b"], activation="relu")
                 y = ops.conv2d(y, dw["head1_W"], dw["head1_b"], activation="relu")
                 y = ops.conv2d(y, dw["head2_W"], dw["head2_b"], activation="relu" if self.head == "conv2d" else None)

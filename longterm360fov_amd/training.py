@@ -332,14 +332,15 @@ class ConvLSTMTrainer:
             seq = hs
         cat = sum(F)
         offs = [0, F[0], F[0] + F[1]]
-        Co = w["head%d_W" % (self.n_head - 1)].shape[3]
+        dense_head = self.head == "dense"
+        Co = 6 if dense_head else w["head%d_W" % (self.n_head - 1)].shape[3]
         feat = e(T_out, B, H, W, cat)
         inp = e(T_out, B, H, W, C)                                      # decoder inputs, step by step
         inp[0].copy_(dec0[:, 0])
-        P = e(T_out, B, H, W, Co)
+        P = e(T_out, B, Co) if dense_head else e(T_out, B, H, W, Co)
         dcs = [e(T_out, B, H, W, F[l]) for l in range(3)]
         dgs = [e(T_out, B, H, W, 4 * F[l]) for l in range(3)]
-        ys = [e(T_out, B, H, W, w["head%d_W" % i].shape[3]) for i in range(self.n_head)]
+        ys = [] if dense_head else [e(T_out, B, H, W, w["head%d_W" % i].shape[3]) for i in range(self.n_head)]
         last_act = "relu" if self.head == "conv2d" else None
         for t in range(T_out):
             cur = inp[t]
@@ -352,14 +353,17 @@ class ConvLSTMTrainer:
                 hslot = feat[t][..., offs[l]:offs[l] + F[l]]
                 ops.convlstm_gates_train(z, c_prev, hslot, act, gates=z, c_new=dcs[l][t])
                 cur = hslot
-            y = feat[t]
-            for i in range(self.n_head):
-                a = "relu" if i < self.n_head - 1 else last_act
-                y = ops.conv2d(y, w["head%d_W" % i], w["head%d_b" % i], activation=a, out=ys[i][t])
-            ops.softmax_lastdim(y, out=P[t])
+            if dense_head:     # Flatten + Dense(6, linear); fed back as a 1x1x6 map
+                ops.dense(feat[t].reshape(B, H * W * cat), w["head0_W"], w["head0_b"], activation=None, out=P[t])
+            else:
+                y = feat[t]
+                for i in range(self.n_head):
+                    a = "relu" if i < self.n_head - 1 else last_act
+                    y = ops.conv2d(y, w["head%d_W" % i], w["head%d_b" % i], activation=a, out=ys[i][t])
+                ops.softmax_lastdim(y, out=P[t])
             if t + 1 < T_out:
-                assert Co == C, "the head's output is fed back as the next decoder input"
-                inp[t + 1].copy_(P[t])
+                assert P[t].numel() == inp[t + 1].numel(), "the head's output is fed back as the next decoder input"
+                inp[t + 1].copy_(P[t].reshape(inp[t + 1].shape))
         tape.update(feat=feat, inp=inp, P=P, dc=dcs, dg=dgs, ys=ys, offs=offs, last_act=last_act)
         return P, tape
 
@@ -371,9 +375,11 @@ class ConvLSTMTrainer:
         T_out = target.shape[1]
         P, tp = self._forward(enc, dec0, T_out)
         offs, feat = tp["offs"], tp["feat"]
-        tgt = target.permute(1, 0, 2, 3, 4).contiguous()
+        dense_head = self.head == "dense"
+        tgt = target.transpose(0, 1).contiguous()
         dP, loss = ops.mse_dense_grad(P, tgt, None, scratch=sc)
-        wt = {k: ops.conv2d_weight_transpose(w[k]) for k in self.order if not k.endswith("_b")}
+        wt = {k: ops.conv2d_weight_transpose(w[k]) for k in self.order if k.endswith(("_K", "_R")) or
+              (k.endswith("_W") and not dense_head)}
         nh = self.n_head
         dys = [torch.empty_like(y) for y in tp["ys"]]                    # d(pre-activation) of every head layer
         dzs = [torch.empty_like(x) for x in tp["dg"]]                    # decoder dz, all steps
@@ -381,14 +387,20 @@ class ConvLSTMTrainer:
         dh_rec, dc = [zeros(l) for l in range(3)], [zeros(l) for l in range(3)]
         dfeed = None
         for t in range(T_out - 1, -1, -1):
-            dp = dP[t] if dfeed is None else dP[t] + dfeed
-            d = ops.softmax_lastdim_bwd(dp, P[t], out=dys[nh - 1][t])
-            if tp["last_act"] == "relu":
-                ops.act_bwd(d, tp["ys"][nh - 1][t], activation="relu", out=d)
-            for i in range(nh - 1, 0, -1):                               # head layers, data gradient only
-                d = ops.conv2d(d, wt["head%d_W" % i], out=dys[i - 1][t])
-                ops.act_bwd(d, tp["ys"][i - 1][t], activation="relu", out=d)
-            dfeat = ops.conv2d(d, wt["head0_W"])
+            dp = dP[t] if dfeed is None else dP[t] + dfeed.reshape(dP[t].shape)
+            if dense_head:
+                if dfeed is not None:
+                    dP[t].copy_(dp)                                      # kept: the Dense weight gradient is formed below
+                dfeat, _, _ = ops.dense_bwd(feat[t].reshape(B, -1), w["head0_W"], dP[t], need_dW=False, need_db=False, scratch=sc)
+                dfeat = dfeat.reshape(B, H, W, -1)
+            else:
+                d = ops.softmax_lastdim_bwd(dp, P[t], out=dys[nh - 1][t])
+                if tp["last_act"] == "relu":
+                    ops.act_bwd(d, tp["ys"][nh - 1][t], activation="relu", out=d)
+                for i in range(nh - 1, 0, -1):                           # head layers, data gradient only
+                    d = ops.conv2d(d, wt["head%d_W" % i], out=dys[i - 1][t])
+                    ops.act_bwd(d, tp["ys"][i - 1][t], activation="relu", out=d)
+                dfeat = ops.conv2d(d, wt["head0_W"])
             dx_up = None
             for l in range(2, -1, -1):
                 dh = dfeat[..., offs[l]:offs[l] + F[l]] + dh_rec[l]
@@ -405,7 +417,10 @@ class ConvLSTMTrainer:
                         dfeed = dx
         # head weight gradients: one product over all steps per layer
         x_in = feat
-        for i in range(nh):
+        if dense_head:
+            ops.dense_bwd(feat.reshape(T_out * B, -1), w["head0_W"], dP.reshape(T_out * B, -1), dW=g["head0_W"], db=g["head0_b"],
+                          need_dx=False, scratch=sc)
+        for i in range(0 if dense_head else nh):
             ops.conv2d_wgrad(x_in, dys[i], *w["head%d_W" % i].shape[:2], dw=g["head%d_W" % i], scratch=sc)
             ops.colsum(dys[i], out=g["head%d_b" % i], scratch=sc)
             x_in = tp["ys"][i]
@@ -442,11 +457,11 @@ class ConvLSTMTrainer:
                 dx_seq = ops.conv2d(edz.reshape(T_in * B, H, W, 4 * F[l]), wt["enc%d_K" % l]).reshape(T_in, B, H, W, F[l - 1])
         if grad_weight != 1.0:
             self.grad.mul_(grad_weight)
-        return loss, P.permute(1, 0, 2, 3, 4)
+        return loss, P.transpose(0, 1)
 
     def eval_loss(self, enc, dec0, target):
         P, _ = self._forward(enc, dec0, target.shape[1])
-        _, loss = ops.mse_dense_grad(P, target.permute(1, 0, 2, 3, 4).contiguous(), None, scratch=self.scratch)
+        _, loss = ops.mse_dense_grad(P, target.transpose(0, 1).contiguous(), None, scratch=self.scratch)
         return loss
 
     def apply_gradients(self):

@@ -441,7 +441,8 @@ def convlstm_seq2seq_forward(enc_in, dec_in0, w, T_out, head="conv2d", act="hard
     concat of the three layer outputs, head, output fed back (convlstm_seq2seq.py:100-126,146-165,209-282).
       head 'conv2d' (cfg.use_one_hot): Conv2D -> Conv2D -> Conv2D (relu each) + channel softmax
       head 'conv1d' (xyz mode, H == 1): Conv1D k=7 relu, relu, softmax over the 3 output channels
-    enc_in:(B,T_in,H,W,C)  dec_in0:(B,1,H,W,C)  ->  (B,T_out,H,W,Cout)."""
+      head 'dense'  (cfg.predict_mean_var + cfg.input_mean_var, 1x1 maps of 6 channels): Flatten + Dense(6)
+    enc_in:(B,T_in,H,W,C)  dec_in0:(B,1,H,W,C)  ->  (B,T_out,H,W,Cout)   ('dense': (B,T_out,6))."""
     x = enc_in
     states = []
     for l in range(3):
@@ -458,6 +459,12 @@ def convlstm_seq2seq_forward(enc_in, dec_in0, w, T_out, head="conv2d", act="hard
             feats.append(h)
             cur = h
         y = np.concatenate(feats, axis=-1)
+        if head == "dense":      # cfg.predict_mean_var: Flatten + Dense(6, linear) (convlstm_seq2seq.py:171,225-227)
+            y = y.reshape(y.shape[0], -1) @ w["head0_W"] + w["head0_b"]
+            outs.append(y)
+            # fed back as a 1x1 map of 6 channels (cfg.input_mean_var, :272-273)
+            inp = y.reshape(y.shape[0], 1, 1, -1)
+            continue
         y = np.maximum(conv2d_same(y, w["head0_W"], w["head0_b"]), 0)
         y = np.maximum(conv2d_same(y, w["head1_W"], w["head1_b"]), 0)
         y = conv2d_same(y, w["head2_W"], w["head2_b"])
@@ -470,7 +477,8 @@ def convlstm_seq2seq_forward(enc_in, dec_in0, w, T_out, head="conv2d", act="hard
     return np.stack(outs, axis=1)
 
 
-def init_convlstm_seq2seq(seed, C=30, latent_dim=16, k=5, head="conv2d", head_filters=(512, 1024), dtype=np.float32):
+def init_convlstm_seq2seq(seed, C=30, latent_dim=16, k=5, head="conv2d", head_filters=(512, 1024), dtype=np.float32,
+                          map_hw=(1, 1)):
     """Keras initialisers: glorot_uniform kernels (fan = receptive field x channels), orthogonal recurrent
     kernels (flattened), unit forget bias."""
     rng = np.random.default_rng(seed)
@@ -493,6 +501,12 @@ def init_convlstm_seq2seq(seed, C=30, latent_dim=16, k=5, head="conv2d", head_fi
             w["%s%d_b" % (part, l)] = b
             cin = F
     cat = sum(filters)
+    if head == "dense":
+        n_in = map_hw[0] * map_hw[1] * cat
+        lim = np.sqrt(6.0 / (n_in + 6))
+        w["head0_W"] = rng.uniform(-lim, lim, (n_in, 6)).astype(dtype)
+        w["head0_b"] = (0.05 * rng.standard_normal(6)).astype(dtype)
+        return w
     hk = (k, k) if head == "conv2d" else (1, 7)
     chans = (cat,) + tuple(head_filters) + ((C,) if head == "conv2d" else (3,))
     for i in range(3):

@@ -211,6 +211,11 @@ def _torch_convlstm_graph(enc, dec0, tgt, w, head, act):
             feats.append(h)
             cur = h
         y = torch.cat(feats, -1)
+        if head == "dense":
+            y = y.reshape(B, -1) @ t["head0_W"] + t["head0_b"]
+            outs.append(y)
+            inp = y.reshape(B, 1, 1, -1)
+            continue
         y = torch.relu(_tconv(y, t["head0_W"]) + t["head0_b"])
         y = torch.relu(_tconv(y, t["head1_W"]) + t["head1_b"])
         y = _tconv(y, t["head2_W"]) + t["head2_b"]
@@ -225,21 +230,27 @@ def _torch_convlstm_graph(enc, dec0, tgt, w, head, act):
 
 @pytest.mark.parametrize("head,B,T_in,T_out,H,W,C,L,hf,act", [("conv2d", 2, 3, 3, 9, 6, 10, 8, (24, 40), "hard_sigmoid"),
                                                                ("conv1d", 3, 2, 3, 1, 30, 3, 16, (32, 48), "sigmoid"),
-                                                               ("conv2d", 1, 2, 2, 36, 18, 30, 16, (40, 136), "sigmoid")])
+                                                               ("conv2d", 1, 2, 2, 36, 18, 30, 16, (40, 136), "sigmoid"),
+                                                               ("dense", 5, 3, 4, 1, 1, 6, 8, (), "hard_sigmoid")])
 def test_convlstm_seq2seq_gradients_and_training(head, B, T_in, T_out, H, W, C, L, hf, act):
     """a8 backward: gradients of the whole unrolled graph (feedback path through the head included) against
     torch.autograd in fp64; the torch graph itself is pinned to the NumPy oracle's forward; then RMSprop steps
     reduce the loss."""
     from longterm360fov_amd.training import ConvLSTMTrainer
-    w = O.init_convlstm_seq2seq(5, C=C, latent_dim=L, head=head, head_filters=hf)
+    w = O.init_convlstm_seq2seq(5, C=C, latent_dim=L, head=head, head_filters=hf, map_hw=(H, W))
     rng = np.random.default_rng(8)
     for k in w:
         if k.endswith("_b"):
             w[k] = (w[k] + 0.1 * rng.standard_normal(w[k].shape)).astype(np.float32)
     enc = rng.random((B, T_in, H, W, C)).astype(np.float32)
     dec0 = enc[:, -1:].copy()
-    tgt = rng.random((B, T_out, H, W, C)).astype(np.float32)
-    tgt /= tgt.sum(-1, keepdims=True)
+    if head == "dense":     # predict_mean_var + input_mean_var: 1x1 maps of (mu, sigma^2), output (B,T_out,6)
+        enc = (2 * enc - 1).astype(np.float32)
+        dec0 = enc[:, -1:].copy()
+        tgt = (2 * rng.random((B, T_out, 6)) - 1).astype(np.float32)
+    else:
+        tgt = rng.random((B, T_out, H, W, C)).astype(np.float32)
+        tgt /= tgt.sum(-1, keepdims=True)
     loss_ref, g_ref, P_ref = _torch_convlstm_graph(enc, dec0, tgt, w, head, act)
     w64 = {k: v.astype(np.float64) for k, v in w.items()}
     P_orc = O.convlstm_seq2seq_forward(enc.astype(np.float64), dec0.astype(np.float64), w64, T_out, head=head, act=act)
@@ -275,3 +286,17 @@ def test_convlstm_fit_surface():
     assert m.predict([enc[:4], enc[:4, -1:]], predict_step=2).shape == (4, 2, 1, 30, 3)
     with pytest.raises(NotImplementedError):
         ConvLSTMSeq2Seq(w, head="conv1d", dropout_rate=0.3).train_on_batch([enc[:2], enc[:2, -1:]], tgt[:2])
+
+
+def test_convlstm_dense_head_predict():
+    """cfg.predict_mean_var + cfg.input_mean_var (convlstm_seq2seq.py:96,171,225-227,272-273): 1x1 maps of the six
+    (mu, sigma^2) values, Flatten + Dense(6) head, output (N,T_out,6) fed back as the next input map."""
+    from longterm360fov_amd.models import ConvLSTMSeq2Seq
+    rng = np.random.default_rng(21)
+    w = O.init_convlstm_seq2seq(4, C=6, latent_dim=16, head="dense", map_hw=(1, 1))
+    enc = (2 * rng.random((7, 5, 1, 1, 6)) - 1).astype(np.float32)
+    d = lambda a: a.astype(np.float64)
+    ref = O.convlstm_seq2seq_forward(d(enc), d(enc[:, -1:]), {k: d(v) for k, v in w.items()}, 4, "dense")
+    out = ConvLSTMSeq2Seq(w, head="dense").predict([enc, enc[:, -1:]], predict_step=4)
+    assert out.shape == (7, 4, 6)
+    close(out, ref, "convlstm seq2seq dense head", tol=5e-5)
