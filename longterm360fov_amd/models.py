@@ -536,8 +536,8 @@ class ConvLSTMSeq2Seq:
                     Flatten + Dense(6, linear), output (N,T_out,6) fed back as the next 1x1x6 input map
     predict([encoder_input (N,T_in,H,W,C), decoder_input (N,1,H,W,C)]) -> (N,T_out,H,W,C_out).
     compile('RMSprop', loss=costfunc._mse | 'mean_squared_error') / fit / train_on_batch train the same unrolled
-    graph (convlstm_seq2seq.py:287,396-420) through training.ConvLSTMTrainer; input dropout
-    (cfg.dropout_rate) is not implemented in the training path and must be 0.  Weights: dict with
+    graph (convlstm_seq2seq.py:287,396-420) through training.ConvLSTMTrainer, with Keras's per-gate input
+    dropout when dropout_rate > 0 (training only).  Weights: dict with
     enc{l}_K/R/b, dec{l}_K/R/b (Keras ConvLSTM2D layout (kh,kw,C,4F)) and head{i}_W/b."""
 
     def __init__(self, weights, head="conv2d", recurrent_activation="hard_sigmoid", device="cuda", dropout_rate=0.0):

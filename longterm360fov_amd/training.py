@@ -280,13 +280,23 @@ class ConvLSTMTrainer:
     the encoder layer by layer; the recurrent data gradients are forward convolutions with transposed
     weights, and every weight / bias gradient is ONE product over all steps of a layer (conv2d_wgrad over the
     stacked steps).  All arithmetic is in libfov360_hip.so; torch holds the buffers (and adds maps).
-    Input dropout (cfg.dropout_rate, Keras ConvLSTM2D `dropout=`) is not implemented: dropout_rate must be 0."""
+
+    Input dropout (cfg.dropout_rate, Keras ConvLSTM2D `dropout=`, convlstm_seq2seq.py:103,111,121,149,156,163):
+    Keras draws FOUR masks per layer call (one per gate i,f,c,o; inverted dropout, 1/(1-rate) on the kept
+    entries), reuses them over the time steps of that call, and convolves each masked copy of the input with
+    its gate's slice of the kernel.  The encoder layers are called once per batch, the decoder layers once
+    per unrolled step.  Here the four masked copies are stacked along the channel axis and convolved with the
+    block-diagonal (kh,kw,4C,4F) arrangement of the kernel - the same arithmetic on the same conv kernels
+    (4x the input-convolution FLOPs, training with dropout only).  Masks come from a torch generator (`seed`);
+    TF's random stream is not reproducible, the distribution is the same."""
 
     def __init__(self, weights, head="conv2d", act="hard_sigmoid", optimizer="rmsprop", lr=1e-3, device="cuda",
-                 dropout_rate=0.0):
-        if dropout_rate:
-            raise NotImplementedError("ConvLSTM2D input dropout is not implemented in the HIP training path; "
-                                      "set cfg.dropout_rate = 0")
+                 dropout_rate=0.0, seed=0):
+        if not 0.0 <= dropout_rate < 1.0:
+            raise ValueError("dropout_rate must be in [0, 1)")
+        self.dropout_rate = float(dropout_rate)
+        self._gen = torch.Generator(device=device)
+        self._gen.manual_seed(int(seed))
         self.head, self.act, self.optimizer, self.lr, self.device = head, act, optimizer.lower(), float(lr), device
         self.order = convlstm_weight_order(weights)
         self.shapes = [(k, tuple(weights[k].shape)) for k in self.order]
@@ -313,16 +323,48 @@ class ConvLSTMTrainer:
         return {k: v.detach().cpu().numpy().copy() for k, v in self.w.items()}
 
     # -- forward with tape ---------------------------------------------------------------------------
-    def _forward(self, enc, dec0, T_out):
+    def sample_masks(self, B, H, W, C, T_out):
+        """Dropout masks of one training step: 'enc{l}' (4,B,H,W,C_l), 'dec{l}' (T_out,4,B,H,W,C_l)."""
+        keep = 1.0 - self.dropout_rate
+        cin = [C] + self.filters[:2]
+        m = {}
+        for l in range(3):
+            for key, lead in (("enc%d" % l, (4,)), ("dec%d" % l, (T_out, 4))):
+                u = torch.rand(lead + (B, H, W, cin[l]), generator=self._gen, device=self.device)
+                m[key] = (u < keep).to(torch.float32) / keep
+        return m
+
+    @staticmethod
+    def _stack_masked(x, mask4):
+        """x (..., C) and mask4 (4, ..., C) -> (..., 4C): the four masked copies side by side, gate-major."""
+        return torch.cat([x * mask4[g] for g in range(4)], dim=-1)
+
+    @staticmethod
+    def _block_diag_kernel(K):
+        """(kh,kw,C,4F) -> (kh,kw,4C,4F): gate g's kernel slice sees only the g-th masked copy of the input."""
+        kh, kw, C, F4 = K.shape
+        F = F4 // 4
+        K4 = torch.zeros((kh, kw, 4 * C, F4), dtype=K.dtype, device=K.device)
+        for g in range(4):
+            K4[:, :, g * C:(g + 1) * C, g * F:(g + 1) * F] = K[..., g * F:(g + 1) * F]
+        return K4
+
+    def _forward(self, enc, dec0, T_out, masks=None):
         w, act, F = self.w, self.act, self.filters
         B, T_in, H, W, C = enc.shape
         dev = enc.device
         e = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
         tape = {"x": enc.permute(1, 0, 2, 3, 4).contiguous()}           # (T_in,B,H,W,C) time-major
+        k4 = {} if masks is None else {k: self._block_diag_kernel(w[k]) for k in self.order if k.endswith("_K")}
+        tape["masks"], tape["k4"] = masks, k4
         seq = tape["x"]
         for l in range(3):
             K, R, b = w["enc%d_K" % l], w["enc%d_R" % l], w["enc%d_b" % l]
             hs, cs, gs = e(T_in, B, H, W, F[l]), e(T_in, B, H, W, F[l]), e(T_in, B, H, W, 4 * F[l])
+            if masks is not None:   # one mask set for the whole sequence of this layer call
+                seq = self._stack_masked(seq, masks["enc%d" % l].unsqueeze(1))
+                K = k4["enc%d_K" % l]
+                tape["ex4_%d" % l] = seq
             for t in range(T_in):
                 z = ops.conv2d(seq[t], K, b, out=gs[t])
                 if t > 0:
@@ -342,12 +384,17 @@ class ConvLSTMTrainer:
         dgs = [e(T_out, B, H, W, 4 * F[l]) for l in range(3)]
         ys = [] if dense_head else [e(T_out, B, H, W, w["head%d_W" % i].shape[3]) for i in range(self.n_head)]
         last_act = "relu" if self.head == "conv2d" else None
+        cin = [C] + F[:2]
+        dx4 = [e(T_out, B, H, W, 4 * cin[l]) for l in range(3)] if masks is not None else None
         for t in range(T_out):
             cur = inp[t]
             for l in range(3):
                 K, R, b = w["dec%d_K" % l], w["dec%d_R" % l], w["dec%d_b" % l]
                 h_prev = tape["eh%d" % l][T_in - 1] if t == 0 else feat[t - 1][..., offs[l]:offs[l] + F[l]]
                 c_prev = tape["ec%d" % l][T_in - 1] if t == 0 else dcs[l][t - 1]
+                if masks is not None:   # a fresh mask set for every unrolled call of the decoder layer
+                    dx4[l][t].copy_(self._stack_masked(cur, masks["dec%d" % l][t]))
+                    cur, K = dx4[l][t], k4["dec%d_K" % l]
                 z = ops.conv2d(cur, K, b, out=dgs[l][t])
                 ops.conv2d(h_prev, R, None, add=z, out=z)
                 hslot = feat[t][..., offs[l]:offs[l] + F[l]]
@@ -364,17 +411,35 @@ class ConvLSTMTrainer:
             if t + 1 < T_out:
                 assert P[t].numel() == inp[t + 1].numel(), "the head's output is fed back as the next decoder input"
                 inp[t + 1].copy_(P[t].reshape(inp[t + 1].shape))
-        tape.update(feat=feat, inp=inp, P=P, dc=dcs, dg=dgs, ys=ys, offs=offs, last_act=last_act)
+        tape.update(feat=feat, inp=inp, P=P, dc=dcs, dg=dgs, ys=ys, offs=offs, last_act=last_act, dx4=dx4)
         return P, tape
 
-    def forward_backward(self, enc, dec0, target, grad_weight=1.0):
+    def forward_backward(self, enc, dec0, target, grad_weight=1.0, masks=None):
         """enc (B,T_in,H,W,C), dec0 (B,1,H,W,C), target (B,T_out,H,W,Co) device tensors.  Fills self.grad with
-        d(mean squared error)/d(parameters); returns (loss (1,), prediction (B,T_out,H,W,Co))."""
+        d(mean squared error)/d(parameters); returns (loss (1,), prediction (B,T_out,H,W,Co)).  `masks`: dropout
+        masks as sample_masks() returns them (drawn here when dropout_rate > 0 and none are given)."""
         w, g, act, F, sc = self.w, self.g, self.act, self.filters, self.scratch
         B, T_in, H, W, C = enc.shape
         T_out = target.shape[1]
-        P, tp = self._forward(enc, dec0, T_out)
+        if masks is None and self.dropout_rate > 0:
+            masks = self.sample_masks(B, H, W, C, T_out)
+        P, tp = self._forward(enc, dec0, T_out, masks)
         offs, feat = tp["offs"], tp["feat"]
+        cin = [C] + F[:2]
+
+        def unmask(d4, mask4, c):      # data gradient of the stacked input -> gradient of the unmasked map
+            out = d4[..., :c] * mask4[0]
+            for gi in range(1, 4):
+                out = out + d4[..., gi * c:(gi + 1) * c] * mask4[gi]
+            return out
+
+        def in_kernel_grad(key, x4, dz, c, f):   # weight gradient of the block-diagonal kernel -> its diagonal blocks
+            kh, kw = w[key].shape[:2]
+            d4 = ops.conv2d_wgrad(x4, dz, kh, kw, scratch=sc)
+            for gi in range(4):
+                g[key][..., gi * f:(gi + 1) * f].copy_(d4[:, :, gi * c:(gi + 1) * c, gi * f:(gi + 1) * f])
+
+        wt4 = {k: ops.conv2d_weight_transpose(v) for k, v in tp["k4"].items()}
         dense_head = self.head == "dense"
         tgt = target.transpose(0, 1).contiguous()
         dP, loss = ops.mse_dense_grad(P, tgt, None, scratch=sc)
@@ -410,7 +475,10 @@ class ConvLSTMTrainer:
                 dz = ops.convlstm_gates_bwd(dh, dc[l], tp["dg"][l][t], c_prev, tp["dc"][l][t], act, dz=dzs[l][t])
                 dh_rec[l] = ops.conv2d(dz, wt["dec%d_R" % l])
                 if l > 0 or t > 0:
-                    dx = ops.conv2d(dz, wt["dec%d_K" % l])
+                    if masks is None:
+                        dx = ops.conv2d(dz, wt["dec%d_K" % l])
+                    else:
+                        dx = unmask(ops.conv2d(dz, wt4["dec%d_K" % l]), masks["dec%d" % l][t], cin[l])
                     if l > 0:
                         dx_up = dx
                     else:
@@ -428,7 +496,10 @@ class ConvLSTMTrainer:
         for l in range(3):
             x_in = tp["inp"] if l == 0 else feat[..., offs[l - 1]:offs[l - 1] + F[l - 1]]
             kh, kw = w["dec%d_K" % l].shape[:2]
-            ops.conv2d_wgrad(x_in, dzs[l], kh, kw, dw=g["dec%d_K" % l], scratch=sc)
+            if masks is None:
+                ops.conv2d_wgrad(x_in, dzs[l], kh, kw, dw=g["dec%d_K" % l], scratch=sc)
+            else:
+                in_kernel_grad("dec%d_K" % l, tp["dx4"][l], dzs[l], cin[l], F[l])
             ops.conv2d_wgrad(tp["eh%d" % l][T_in - 1], dzs[l][0], kh, kw, dw=g["dec%d_R" % l], scratch=sc)
             if T_out > 1:
                 ops.conv2d_wgrad(feat[:T_out - 1][..., offs[l]:offs[l] + F[l]], dzs[l][1:], kh, kw, dw=g["dec%d_R" % l],
@@ -447,14 +518,21 @@ class ConvLSTMTrainer:
                     dhr = ops.conv2d(dz, wt["enc%d_R" % l])
             kh, kw = w["enc%d_K" % l].shape[:2]
             x_in = tp["x"] if l == 0 else tp["eh%d" % (l - 1)]
-            ops.conv2d_wgrad(x_in, edz, kh, kw, dw=g["enc%d_K" % l], scratch=sc)
+            if masks is None:
+                ops.conv2d_wgrad(x_in, edz, kh, kw, dw=g["enc%d_K" % l], scratch=sc)
+            else:
+                in_kernel_grad("enc%d_K" % l, tp["ex4_%d" % l], edz, cin[l], F[l])
             if T_in > 1:
                 ops.conv2d_wgrad(hs[:T_in - 1], edz[1:], kh, kw, dw=g["enc%d_R" % l], scratch=sc)
             else:
                 g["enc%d_R" % l].zero_()
             ops.colsum(edz, out=g["enc%d_b" % l], scratch=sc)
             if l > 0:   # data gradient for the layer below, all steps in one launch
-                dx_seq = ops.conv2d(edz.reshape(T_in * B, H, W, 4 * F[l]), wt["enc%d_K" % l]).reshape(T_in, B, H, W, F[l - 1])
+                if masks is None:
+                    dx_seq = ops.conv2d(edz.reshape(T_in * B, H, W, 4 * F[l]), wt["enc%d_K" % l]).reshape(T_in, B, H, W, F[l - 1])
+                else:
+                    d4 = ops.conv2d(edz.reshape(T_in * B, H, W, 4 * F[l]), wt4["enc%d_K" % l]).reshape(T_in, B, H, W, 4 * F[l - 1])
+                    dx_seq = unmask(d4, masks["enc%d" % l].unsqueeze(1), F[l - 1])
         if grad_weight != 1.0:
             self.grad.mul_(grad_weight)
         return loss, P.transpose(0, 1)

@@ -174,15 +174,20 @@ def test_convlstm_gates_backward_softmax_relu_colsum(act):
     close(ops.colsum(dev(big)), big.astype(np.float64).sum(0), "colsum")
 
 
-def _torch_convlstm_graph(enc, dec0, tgt, w, head, act):
-    """Independent fp64 restatement of the ConvLSTM seq2seq training graph (convlstm_seq2seq.py:100-287,
-    no dropout) on torch.autograd: loss = mean squared error of the unrolled, self-fed decoder."""
+def _torch_convlstm_graph(enc, dec0, tgt, w, head, act, masks=None):
+    """Independent fp64 restatement of the ConvLSTM seq2seq training graph (convlstm_seq2seq.py:100-287) on
+    torch.autograd: loss = mean squared error of the unrolled, self-fed decoder.  `masks` (optional): Keras
+    ConvLSTM2D input dropout - per layer call four masks, gate g's kernel slice convolves x * mask_g."""
     t = {k: torch.tensor(v.astype(np.float64), requires_grad=True) for k, v in w.items()}
     s = torch.sigmoid if act == "sigmoid" else (lambda z: torch.clamp(0.2 * z + 0.5, 0, 1))
 
-    def cell(x, h, c, K, R, b):
+    def cell(x, h, c, K, R, b, m4=None):
         F = R.shape[2]
-        z = _tconv(x, K) + b + _tconv(h, R)
+        if m4 is None:
+            zx = _tconv(x, K)
+        else:
+            zx = torch.cat([_tconv(x * m4[g], K[..., g * F:(g + 1) * F]) for g in range(4)], -1)
+        z = zx + b + _tconv(h, R)
         i, f, g, o = s(z[..., :F]), s(z[..., F:2 * F]), torch.tanh(z[..., 2 * F:3 * F]), s(z[..., 3 * F:])
         c = f * c + i * g
         return o * torch.tanh(c), c
@@ -196,8 +201,9 @@ def _torch_convlstm_graph(enc, dec0, tgt, w, head, act):
         h = torch.zeros(B, H, W, F, dtype=torch.float64)
         c = torch.zeros(B, H, W, F, dtype=torch.float64)
         nxt = []
+        m4 = None if masks is None else torch.tensor(masks["enc%d" % l].astype(np.float64))
         for tt in range(T_in):
-            h, c = cell(seq[tt], h, c, t["enc%d_K" % l], t["enc%d_R" % l], t["enc%d_b" % l])
+            h, c = cell(seq[tt], h, c, t["enc%d_K" % l], t["enc%d_R" % l], t["enc%d_b" % l], m4)
             nxt.append(h)
         seq = nxt
         states.append([h, c])
@@ -206,7 +212,8 @@ def _torch_convlstm_graph(enc, dec0, tgt, w, head, act):
     for tt in range(tg.shape[1]):
         cur, feats = inp, []
         for l in range(3):
-            h, c = cell(cur, states[l][0], states[l][1], t["dec%d_K" % l], t["dec%d_R" % l], t["dec%d_b" % l])
+            m4 = None if masks is None else torch.tensor(masks["dec%d" % l][tt].astype(np.float64))
+            h, c = cell(cur, states[l][0], states[l][1], t["dec%d_K" % l], t["dec%d_R" % l], t["dec%d_b" % l], m4)
             states[l] = [h, c]
             feats.append(h)
             cur = h
@@ -284,8 +291,9 @@ def test_convlstm_fit_surface():
     h = m.fit([enc, enc[:, -1:]], tgt, batch_size=8, epochs=3, validation_split=0.25, shuffle=True)
     assert len(h.history["loss"]) == 3 and h.history["loss"][-1] < h.history["loss"][0] and "val_loss" in h.history
     assert m.predict([enc[:4], enc[:4, -1:]], predict_step=2).shape == (4, 2, 1, 30, 3)
-    with pytest.raises(NotImplementedError):
-        ConvLSTMSeq2Seq(w, head="conv1d", dropout_rate=0.3).train_on_batch([enc[:2], enc[:2, -1:]], tgt[:2])
+    md = ConvLSTMSeq2Seq(w, head="conv1d", dropout_rate=0.3)      # Keras default of the script (cfg.dropout_rate)
+    md.compile(optimizer="RMSprop", loss="mse")
+    assert np.isfinite(md.train_on_batch([enc[:8], enc[:8, -1:]], tgt[:8]))
 
 
 def test_convlstm_dense_head_predict():
@@ -300,3 +308,34 @@ def test_convlstm_dense_head_predict():
     out = ConvLSTMSeq2Seq(w, head="dense").predict([enc, enc[:, -1:]], predict_step=4)
     assert out.shape == (7, 4, 6)
     close(out, ref, "convlstm seq2seq dense head", tol=5e-5)
+
+
+@pytest.mark.parametrize("head,B,T_in,T_out,H,W,C,L,hf", [("conv2d", 2, 3, 2, 7, 5, 6, 8, (12, 20)),
+                                                           ("conv1d", 2, 2, 3, 1, 30, 3, 8, (16, 24))])
+def test_convlstm_input_dropout_gradients(head, B, T_in, T_out, H, W, C, L, hf):
+    """ConvLSTM2D(dropout=cfg.dropout_rate): four per-gate input masks per layer call (encoder: one set per
+    batch; decoder: one per unrolled step).  With the same masks the gradients match torch.autograd in fp64."""
+    from longterm360fov_amd.training import ConvLSTMTrainer
+    w = O.init_convlstm_seq2seq(6, C=C, latent_dim=L, head=head, head_filters=hf)
+    rng = np.random.default_rng(12)
+    enc = rng.random((B, T_in, H, W, C)).astype(np.float32)
+    dec0 = enc[:, -1:].copy()
+    tgt = rng.random((B, T_out, H, W, C)).astype(np.float32)
+    tgt /= tgt.sum(-1, keepdims=True)
+    tr = ConvLSTMTrainer(w, head=head, act="hard_sigmoid", dropout_rate=0.3, seed=5)
+    masks = tr.sample_masks(B, H, W, C, T_out)
+    keep = [float((m > 0).float().mean()) for m in masks.values()]
+    assert all(0.5 < k < 0.9 for k in keep) and abs(float(masks["enc0"].max()) - 1 / 0.7) < 1e-6
+    loss_ref, g_ref, P_ref = _torch_convlstm_graph(enc, dec0, tgt, w, head, "hard_sigmoid",
+                                                   masks={k: v.cpu().numpy() for k, v in masks.items()})
+    loss, P = tr.forward_backward(dev(enc), dev(dec0), dev(tgt), masks=masks)
+    close(P, P_ref, "dropout forward")
+    assert abs(float(loss.item()) - loss_ref) <= 1e-5 * loss_ref + 1e-9
+    for k in tr.order:
+        a = tr.g[k].detach().cpu().numpy().astype(np.float64)
+        scale = np.abs(g_ref[k]).max()
+        assert np.abs(a - g_ref[k]).max() <= 2e-4 * scale + 1e-9, k
+    # evaluation never drops anything
+    P_eval, _ = tr._forward(dev(enc), dev(dec0), T_out)
+    _, _, P_plain = _torch_convlstm_graph(enc, dec0, tgt, w, head, "hard_sigmoid")
+    close(P_eval.transpose(0, 1), P_plain, "eval forward without dropout")
