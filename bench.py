@@ -28,6 +28,12 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense fp32 matrix peak (spec)
+# rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of `bench.py --steps 20 --warmup 3`, mean per dispatch:
+# encoder 13150 + 6152 KiB, decoder 7441 + 4824 KiB (raw counter values; the kernel's global traffic is 4- and
+# 8-byte accesses, for which MI355X_MICROARCH.md gives no correction factor)
+PMC_TRAFFIC_CONFIG = (1024, 30, 30, 256, "sigmoid", "auto")
+PMC_TRAFFIC_BYTES = (13150 + 6152 + 7441 + 4824) * 1024
+PMC_TRAFFIC_SOURCE = "profiles/r01_pmc_v8_summary.csv"
 
 
 def flops_per_seq(T_in, T_out, F_enc, F_dec, H):
@@ -266,6 +272,12 @@ def main():
                              "batch, T %d->%d, H=%d" % (reps, B, T_in, T_out, H)}
 
         value = world * B * args.steps / elapsed
+        # HBM-side bytes per step are not measurable from inside this process: they come from separate rocprofv3
+        # --pmc passes over this same command (FETCH_SIZE and WRITE_SIZE, raw KiB per dispatch, encoder +
+        # decoder), committed under profiles/; quoted only for the configuration that was profiled.
+        traffic, traffic_src = None, None
+        if (B, T_in, T_out, H, args.act, args.impl) == PMC_TRAFFIC_CONFIG:
+            traffic, traffic_src = PMC_TRAFFIC_BYTES, PMC_TRAFFIC_SOURCE
         result = {
             "metric": "sequences/sec (batch=1024, T_in=30->T_out=30, h=256)",
             "value": value, "unit": "sequences/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -276,7 +288,8 @@ def main():
                                    % (H, B, T_in, T_out, args.act, args.impl),
                        "global_batch": B * world, "parallelism": "replicas x%d (no collective)" % world},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
+                         "traffic_source": traffic_src,
                          "flop_per_launch": flop_step, "launch_ms": step_ms_events,
                          "note": "launch = one step = encoder kernel + decoder kernel of lstm_cluster_kernel"},
             "kernels": {"encoder_ms": enc_ms, "decoder_ms": dec_ms,
