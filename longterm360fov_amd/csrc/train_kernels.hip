@@ -35,37 +35,121 @@ struct GemmArgs {
     int split;       // number of K slices (grid.z)
     int tiles_per_split; // k-tiles (of 16, never straddling a ko row) per slice
     int xcd_remap, grid_n, grid_m;   // 1-D grid with slices pinned to XCDs (split >= 8)
+    int add_c;       // single-slice accumulate: C += A.B in the epilogue (one writer per element, deterministic)
 };
 
 constexpr int GBK = 16;
 typedef unsigned gu32x4 __attribute__((ext_vector_type(4)));
 
 // Block tile BM x BN x 16 with BM = 16*MI*WAVES_M, BN = 16*NI*(4/WAVES_M); each of the 4 waves owns
-// MI x NI MFMA tiles.  LDS tiles are k-major ([k][m], [k][n]) so a fragment read is 16 consecutive
-// floats per k.  Global->LDS staging goes through registers one k-tile ahead.
+// MI x NI MFMA tiles.  Global->LDS staging goes through registers one k-tile ahead.
 //
 // fp32 MFMA shares the VALU issue slots, so staging arithmetic is paid for in MFMA time.  The k-tiles
 // therefore never straddle a ko row: tile t <-> (ko = t / ntpr, kt = t % ntpr) with ntpr = ceil(KI/16),
-// its k = ko*KI + kt*16 + kk.  The tile's base address is wave-uniform (SALU), each thread adds a 32-bit
-// offset fixed for the whole kernel, and the only per-load VALU work is the mask of the last, partial
-// tile of a row (<= 15 zero columns per ko row; KI = 29 wastes 9 % of the MFMAs and saves far more).
-// AMODE / BMODE (compile-time, so the staged registers never meet at a control-flow merge - a merge makes the
-// compiler wait for the loads before the MFMAs): 0 = k-slow operand, 16-byte buffer loads; 1 = k-slow, 4-byte
-// buffer loads; 2 = any layout, global loads + select at stash time.
+// its k = ko*KI + kt*16 + kk.  The tile's base address is wave-uniform (SALU) and sits in a per-tile buffer
+// descriptor; each thread adds a 32-bit offset fixed for the whole kernel; invalid elements present an
+// out-of-range offset and the hardware returns 0 (<= 15 zero columns per ko row; KI = 29 wastes 9 % of the
+// MFMAs and saves far more).
+//
+// Staging mode of an operand (template parameter, so the staged registers never meet at a control-flow
+// merge - a merge makes the compiler wait for the loads before the MFMAs of the current tile):
+//   0  k-slow ([k][row] storage, row index contiguous), 16-byte buffer loads, LDS [k][rows]
+//   1  k-slow, 4-byte buffer loads (row stride or width not a multiple of 4), LDS [k][rows]
+//   2  anything else: global loads, select at stash time, LDS [k][rows]
+//   3  k-fast ([row][k] storage, k contiguous, KI % 4 == 0), 16-byte buffer loads along k, LDS [rows][k]
+// The MFMA k-slot of lane group lq in step s is k = 4*lq + s (for A and B alike): an operand stored
+// [rows][k] gives a lane its four steps with ONE ds_read_b128, an operand stored [k][rows] reads rows
+// 4*lq + s (row stride = 4 mod 8 floats: the four lane groups land on disjoint banks).
+template <int ROWS, int MODE>
+struct OperandStage {
+    static constexpr bool VEC = (MODE == 0 || MODE == 3);
+    static constexpr bool TR = (MODE == 3);
+    static constexpr int LD = TR ? 24 : ROWS + 4;
+    static constexpr int LDS_FLOATS = TR ? ROWS * 24 : GBK * (ROWS + 4);   // one buffer
+    static constexpr int R = VEC ? (ROWS * 4 + 255) / 256 : ROWS / 16;     // loads per thread per k-tile
+    static constexpr unsigned OOR = 0x80000000u;
+    int kk[R], rr[R];
+    unsigned off[R];   // byte offset from the tile base (OOR when the row is outside the matrix)
+    bool ok[R];
+    float sc[VEC ? 1 : R];
+    f32x4 vv[VEC ? R : 1];
+    int kmax;          // valid k columns of the staged tile
+
+    __device__ __forceinline__ void init(int tid, int row0, int nrows, long s_row, long s_ki) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int e = tid + 256 * r;
+            if (MODE == 0) { kk[r] = e / (ROWS / 4); rr[r] = 4 * (e - kk[r] * (ROWS / 4)); }
+            else if (MODE == 3) { rr[r] = e >> 2; kk[r] = 4 * (e & 3); }
+            else if (MODE == 2 && s_ki == 1) { rr[r] = e >> 4; kk[r] = e & 15; }   // consecutive threads walk k
+            else { kk[r] = e / ROWS; rr[r] = e - kk[r] * ROWS; }
+            ok[r] = rr[r] < ROWS && kk[r] < GBK && row0 + rr[r] < nrows;
+            off[r] = ok[r] ? (unsigned)(((long)rr[r] * s_row + (long)kk[r] * s_ki) * 4) : OOR;
+        }
+        kmax = 0;
+    }
+    // issue the loads of one tile (base = first element of the tile's first row / k)
+    __device__ __forceinline__ void fetch(const float* base, int tile_kmax, long s_ki) {
+        kmax = tile_kmax;
+        if constexpr (MODE == 2) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) sc[r] = base[(ok[r] && kk[r] < tile_kmax) ? (off[r] >> 2) : 0u];
+        } else {
+            const int krows = tile_kmax < GBK ? tile_kmax : GBK;
+            // k-slow: the descriptor ends after the last valid k row; k-fast: per-lane k test (below)
+            const int nrec = TR ? 0x7fffffff : krows * (int)s_ki * 4;
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, nrec, 0x00020000);
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const unsigned o = (TR && kk[r] >= tile_kmax) ? OOR : off[r];
+                if constexpr (VEC) {
+                    const gu32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs, o, 0, 0);
+                    vv[r] = (f32x4){__uint_as_float(t[0]), __uint_as_float(t[1]), __uint_as_float(t[2]), __uint_as_float(t[3])};
+                } else {
+                    sc[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, o, 0, 0));
+                }
+            }
+        }
+    }
+    __device__ __forceinline__ void stash(float* lds) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            if constexpr (MODE == 3) {
+                if (rr[r] < ROWS) *(f32x4*)(lds + rr[r] * LD + kk[r]) = vv[r];
+            } else if constexpr (MODE == 0) {
+                if (kk[r] < GBK) *(f32x4*)(lds + kk[r] * LD + rr[r]) = vv[r];
+            } else if constexpr (MODE == 1) {
+                lds[kk[r] * LD + rr[r]] = sc[r];
+            } else {
+                lds[kk[r] * LD + rr[r]] = (ok[r] && kk[r] < kmax) ? sc[r] : 0.f;   // select here, after the MFMAs
+            }
+        }
+    }
+    // fragment of the 16 rows starting at `row` for this lane: out[s] = element (row + li, k = 4*lq + s)
+    static __device__ __forceinline__ f32x4 frag(const float* lds, int row, int li, int lq) {
+        if constexpr (TR) {
+            return *(const f32x4*)(lds + (row + li) * LD + 4 * lq);
+        } else {
+            f32x4 v;
+#pragma unroll
+            for (int s_ = 0; s_ < 4; ++s_) v[s_] = lds[(4 * lq + s_) * LD + row + li];
+            return v;
+        }
+    }
+};
+
 template <int MI, int NI, int WAVES_M, int AMODE, int BMODE>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
     constexpr int WAVES_N = 4 / WAVES_M;
     constexpr int BM = 16 * MI * WAVES_M, BN = 16 * NI * WAVES_N;
-    constexpr int RA = BM / 16, RB = BN / 16;   // staged elements per thread per k-tile
-    constexpr int RA4 = (RA + 3) / 4, RB4 = (RB + 3) / 4;   // float4 groups per thread (last round may be partial)
-    // row stride = 16 mod 32 floats: the four k rows (lq) of a ds_read_b32 fragment land on disjoint banks
-    __shared__ __attribute__((aligned(16))) float As[2][GBK][BM + 16];
-    __shared__ __attribute__((aligned(16))) float Bs[2][GBK][BN + 16];
+    using StA = OperandStage<BM, AMODE>;
+    using StB = OperandStage<BN, BMODE>;
+    __shared__ __attribute__((aligned(16))) float As[2][StA::LDS_FLOATS];
+    __shared__ __attribute__((aligned(16))) float Bs[2][StB::LDS_FLOATS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // Block -> (n tile, m tile, K slice).  Workgroups are dealt round-robin to the 8 XCDs, each with its own
     // L2.  With split-K the blocks of one slice read the same K range of A and B, so a slice is kept on one
-    // XCD (1-D grid, xcd = id % 8): its operands cross the fabric once instead of once per XCD.  Measured on
-    // dR (256 x 1024 x 30720, 32 slices): L2-miss traffic was the bound, not the MFMA pipe.
+    // XCD (1-D grid, xcd = id % 8): its operands cross the fabric once instead of once per XCD.
     int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
     if (g.xcd_remap) {
         const int nb = g.grid_n * g.grid_m;
@@ -91,130 +175,28 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
 #pragma unroll
         for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // Staging maps.  Scalar path: element e = tid + 256*r of a (rows x 16) tile (k-fast operands: consecutive
-    // threads walk k, else the row index).  Vector path (row-contiguous, aligned operand): group e4 = tid +
-    // 256*r of (rows/4 x 16) float4 groups, consecutive threads walk the row index, one 16-byte load and one
-    // ds_write_b128 per group.
-    const bool a_kfast = (g.a_ski == 1), b_kfast = (g.b_ski == 1);
-    constexpr bool a_vec = (AMODE == 0), b_vec = (BMODE == 0);
-    int a_mm[RA], a_kk[RA], b_nn[RB], b_kk[RB];
-    unsigned a_off[RA], b_off[RB];   // element offset from the tile base (block rows x 16 k: fits 32 bits, host-checked)
-    bool a_ok[RA], b_ok[RB];
-#pragma unroll
-    for (int r = 0; r < RA; ++r) {
-        const int e = tid + 256 * r;
-        if (a_vec) { a_kk[r] = e / (BM / 4); a_mm[r] = 4 * (e - a_kk[r] * (BM / 4)); }
-        else if (a_kfast) { a_mm[r] = e >> 4; a_kk[r] = e & 15; }
-        else { a_kk[r] = e / BM; a_mm[r] = e - a_kk[r] * BM; }
-        a_ok[r] = (m0 + a_mm[r] < g.M) && a_kk[r] < GBK;
-        a_off[r] = a_ok[r] ? (unsigned)((long)a_mm[r] * g.a_sm + (long)a_kk[r] * g.a_ski) : 0u;
-    }
-#pragma unroll
-    for (int r = 0; r < RB; ++r) {
-        const int e = tid + 256 * r;
-        if (b_vec) { b_kk[r] = e / (BN / 4); b_nn[r] = 4 * (e - b_kk[r] * (BN / 4)); }
-        else if (b_kfast) { b_nn[r] = e >> 4; b_kk[r] = e & 15; }
-        else { b_kk[r] = e / BN; b_nn[r] = e - b_kk[r] * BN; }
-        b_ok[r] = (n0 + b_nn[r] < g.N) && b_kk[r] < GBK;
-        b_off[r] = b_ok[r] ? (unsigned)((long)b_nn[r] * g.b_sn + (long)b_kk[r] * g.b_ski) : 0u;
-    }
+    StA sa;
+    StB sb;
+    sa.init(tid, m0, g.M, g.a_sm, g.a_ski);
+    sb.init(tid, n0, g.N, g.b_sn, g.b_ski);
     const float* a_blk = g.a + (long)m0 * g.a_sm;
     const float* b_blk = g.b + (long)n0 * g.b_sn;
     int f_ko = tbeg / ntpr, f_kt = tbeg - f_ko * ntpr;   // the tile the next fetch() loads (wave-uniform)
-    float ra[RA], rb[RB];
-    f32x4 va[RA4], vb[RB4];
-    int s_kmax = 0;   // valid k columns of the tile sitting in ra/rb/va/vb
-    // k-slow operands ([k][row] storage, every training GEMM here) go through a per-tile buffer descriptor:
-    // base = the tile (wave-uniform, SALU), num_records = the valid k rows, so k >= kmax is out of range and
-    // the hardware returns 0; rows >= M carry an out-of-range sentinel offset.  No VALU per load at all.
-    // Other operands (k-fast A of NN / NT products) use global loads; invalid elements read offset 0 of the
-    // tile (always in bounds) and are zeroed in stash(), after the MFMAs of the current tile - a select next
-    // to the load would make the wave wait for the memory latency before it starts its MFMAs.
-    constexpr bool a_buf = (AMODE != 2), b_buf = (BMODE != 2);
-    unsigned a_boff[RA], b_boff[RB];
-#pragma unroll
-    for (int r = 0; r < RA; ++r) a_boff[r] = a_ok[r] ? a_off[r] * 4u : 0x80000000u;
-#pragma unroll
-    for (int r = 0; r < RB; ++r) b_boff[r] = b_ok[r] ? b_off[r] * 4u : 0x80000000u;
     auto fetch = [&]() {
-        const float* ta = a_blk + (long)f_ko * g.a_sko + (long)(f_kt * GBK) * g.a_ski;
-        const float* tb = b_blk + (long)f_ko * g.b_sko + (long)(f_kt * GBK) * g.b_ski;
         const int kmax = g.KI - f_kt * GBK;   // >= 16 except for the row's last tile
-        const int krows = kmax < GBK ? kmax : GBK;
-        s_kmax = kmax;
-        if constexpr (a_buf) {
-            const __amdgpu_buffer_rsrc_t rs =
-                __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ta), 0, krows * (int)g.a_ski * 4, 0x00020000);
-            if constexpr (a_vec) {
-#pragma unroll
-                for (int r = 0; r < RA4; ++r) {
-                    const gu32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs, a_boff[r], 0, 0);
-                    va[r] = (f32x4){__uint_as_float(t[0]), __uint_as_float(t[1]), __uint_as_float(t[2]), __uint_as_float(t[3])};
-                }
-            } else {
-#pragma unroll
-                for (int r = 0; r < RA; ++r) ra[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, a_boff[r], 0, 0));
-            }
-        } else {
-#pragma unroll
-            for (int r = 0; r < RA; ++r) ra[r] = ta[(a_ok[r] && a_kk[r] < kmax) ? a_off[r] : 0u];
-        }
-        if constexpr (b_buf) {
-            const __amdgpu_buffer_rsrc_t rs =
-                __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(tb), 0, krows * (int)g.b_ski * 4, 0x00020000);
-            if constexpr (b_vec) {
-#pragma unroll
-                for (int r = 0; r < RB4; ++r) {
-                    const gu32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs, b_boff[r], 0, 0);
-                    vb[r] = (f32x4){__uint_as_float(t[0]), __uint_as_float(t[1]), __uint_as_float(t[2]), __uint_as_float(t[3])};
-                }
-            } else {
-#pragma unroll
-                for (int r = 0; r < RB; ++r) rb[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, b_boff[r], 0, 0));
-            }
-        } else {
-#pragma unroll
-            for (int r = 0; r < RB; ++r) rb[r] = tb[(b_ok[r] && b_kk[r] < kmax) ? b_off[r] : 0u];
-        }
+        sa.fetch(a_blk + (long)f_ko * g.a_sko + (long)(f_kt * GBK) * g.a_ski, kmax, g.a_ski);
+        sb.fetch(b_blk + (long)f_ko * g.b_sko + (long)(f_kt * GBK) * g.b_ski, kmax, g.b_ski);
         if (++f_kt == ntpr) { f_kt = 0; ++f_ko; }
     };
-    auto stash = [&](int buf) {
-        const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-        if constexpr (a_vec) {
-#pragma unroll
-            for (int r = 0; r < RA4; ++r)
-                if (a_kk[r] < GBK) *(f32x4*)&As[buf][a_kk[r]][a_mm[r]] = (a_buf || (a_ok[r] && a_kk[r] < s_kmax)) ? va[r] : z4;
-        } else {
-#pragma unroll
-            for (int r = 0; r < RA; ++r) As[buf][a_kk[r]][a_mm[r]] = (a_buf || (a_ok[r] && a_kk[r] < s_kmax)) ? ra[r] : 0.f;
-        }
-        if constexpr (b_vec) {
-#pragma unroll
-            for (int r = 0; r < RB4; ++r)
-                if (b_kk[r] < GBK) *(f32x4*)&Bs[buf][b_kk[r]][b_nn[r]] = (b_buf || (b_ok[r] && b_kk[r] < s_kmax)) ? vb[r] : z4;
-        } else {
-#pragma unroll
-            for (int r = 0; r < RB; ++r) Bs[buf][b_kk[r]][b_nn[r]] = (b_buf || (b_ok[r] && b_kk[r] < s_kmax)) ? rb[r] : 0.f;
-        }
-    };
-    int buf = 0;
-    if (tbeg < tend) {
-        fetch();
-        stash(0);
-    }
-    __syncthreads();
     // Per tile: all fragment reads first (one exposed LDS latency per tile instead of one per k-step), then the
     // global loads of the next tile, then 16*MI*NI/4 back-to-back MFMAs, then the staged tile goes to the other
     // LDS buffer.  The last tile is peeled so the staged registers are never live across a branch.
-    float av[4][MI], bv[4][NI];
+    f32x4 af[MI], bf[NI];
     auto read_frags = [&](int buf) {
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
+        for (int i = 0; i < MI; ++i) af[i] = StA::frag(As[buf], wm + i * 16, li, lq);
 #pragma unroll
-            for (int i = 0; i < MI; ++i) av[ks][i] = As[buf][ks * 4 + lq][wm + i * 16 + li];
-#pragma unroll
-            for (int j = 0; j < NI; ++j) bv[ks][j] = Bs[buf][ks * 4 + lq][wn + j * 16 + li];
-        }
+        for (int j = 0; j < NI; ++j) bf[j] = StB::frag(Bs[buf], wn + j * 16, li, lq);
     };
     auto mfmas = [&]() {
 #pragma unroll
@@ -223,8 +205,15 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
             for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < NI; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks][i], bv[ks][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][ks], bf[j][ks], acc[i][j], 0, 0, 0);
     };
+    int buf = 0;
+    if (tbeg < tend) {
+        fetch();
+        sa.stash(As[0]);
+        sb.stash(Bs[0]);
+    }
+    __syncthreads();
     for (int t = tbeg; t + 1 < tend; ++t) {
         read_frags(buf);
         __builtin_amdgcn_sched_barrier(0);
@@ -232,7 +221,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
         __builtin_amdgcn_sched_barrier(0);
         mfmas();
         __builtin_amdgcn_sched_barrier(0);
-        stash(buf ^ 1);
+        sa.stash(As[buf ^ 1]);
+        sb.stash(Bs[buf ^ 1]);
         __syncthreads();
         buf ^= 1;
     }
@@ -248,7 +238,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int m = m0 + wm + i * 16 + lq * 4 + r, n = n0 + wn + j * 16 + li;
-                if (m < g.M && n < g.N) c[(size_t)m * g.ldc + n] = acc[i][j][r];
+                if (m < g.M && n < g.N) {
+                    float* cp = c + (size_t)m * g.ldc + n;
+                    *cp = g.add_c ? *cp + acc[i][j][r] : acc[i][j][r];
+                }
             }
 }
 
@@ -431,6 +424,9 @@ int gemm_f32(GemmArgs g, int accumulate, float* scratch, size_t scratch_floats, 
     if (g.M <= 32) { BM = 32; BN = 256; variant = 0; }
     else if (g.M <= 96) { BM = 96; BN = 256; variant = 1; }
     else { BM = 128; BN = 128; variant = 2; }
+    // mid-size outputs (e.g. 512 x 1024 of a per-step projection): 128 x 128 tiles would occupy a fraction of
+    // the 256 CUs and K is too short to split -> 64 x 64 tiles
+    if (variant == 2 && ((g.M + 127) / 128) * ((g.N + 127) / 128) < 128 && K <= 2048) { BM = 64; BN = 64; variant = 3; }
     // per-thread staging offsets span one block tile: they must fit 32 bits
     {
         const long amax = (long)BM * (g.a_sm < 0 ? -g.a_sm : g.a_sm) + 16 * (g.a_ski < 0 ? -g.a_ski : g.a_ski);
@@ -456,7 +452,9 @@ int gemm_f32(GemmArgs g, int accumulate, float* scratch, size_t scratch_floats, 
     while (split > 1 && (size_t)split * mn > scratch_floats) --split;
     const long tps = (ktiles + split - 1) / split;
     split = (int)((ktiles + tps - 1) / tps);
-    const bool via_scratch = (split > 1) || accumulate;
+    // accumulate with a single K slice happens in the epilogue (C += A.B, one writer per element)
+    g.add_c = (accumulate && split == 1) ? 1 : 0;
+    const bool via_scratch = (split > 1);
     float* c_final = g.c;
     if (via_scratch) {
         if (mn * split > scratch_floats) { set_error("gemm_f32: scratch too small (%zu floats needed)", mn * split); return FOV_ERR_WORKSPACE; }
@@ -472,7 +470,10 @@ int gemm_f32(GemmArgs g, int accumulate, float* scratch, size_t scratch_floats, 
     const bool b_ks = g.b_ski >= (long)(g.N - 1) * g.b_sn + 1 && g.b_ski < (1L << 24) && (((uintptr_t)g.b) & 3) == 0;
     const bool a_v4 = a_ks && g.a_sm == 1 && (g.M & 3) == 0 && (g.a_sko & 3) == 0 && (g.a_ski & 3) == 0 && (((uintptr_t)g.a) & 15) == 0;
     const bool b_v4 = b_ks && g.b_sn == 1 && (g.N & 3) == 0 && (g.b_sko & 3) == 0 && (g.b_ski & 3) == 0 && (((uintptr_t)g.b) & 15) == 0;
-    const int amode = a_v4 ? 0 : (a_ks ? 1 : 2), bmode = b_v4 ? 0 : (b_ks ? 1 : 2);
+    // k-fast: k is the contiguous index, rows and ko rows start 16-byte aligned, KI a multiple of 4
+    const bool a_kf = g.a_ski == 1 && (g.KI & 3) == 0 && (g.a_sm & 3) == 0 && (g.a_sko & 3) == 0 && (((uintptr_t)g.a) & 15) == 0;
+    const bool b_kf = g.b_ski == 1 && (g.KI & 3) == 0 && (g.b_sn & 3) == 0 && (g.b_sko & 3) == 0 && (((uintptr_t)g.b) & 15) == 0;
+    const int amode = a_v4 ? 0 : (a_ks ? 1 : (a_kf ? 3 : 2)), bmode = b_v4 ? 0 : (b_ks ? 1 : (b_kf ? 3 : 2));
     g.grid_n = (g.N + BN - 1) / BN;
     g.grid_m = (g.M + BM - 1) / BM;
     g.xcd_remap = split >= 8 ? 1 : 0;
@@ -480,19 +481,27 @@ int gemm_f32(GemmArgs g, int accumulate, float* scratch, size_t scratch_floats, 
 #define FOV_GEMM_LAUNCH(MI_, NI_, WM_, A_, B_) \
     hipLaunchKernelGGL((gemm_f32_kernel<MI_, NI_, WM_, A_, B_>), grid, dim3(256), 0, stream, g)
 #define FOV_GEMM_MODES(MI_, NI_, WM_)                                                            \
-    switch (amode * 3 + bmode) {                                                                 \
+    switch (amode * 4 + bmode) {                                                                 \
         case 0: FOV_GEMM_LAUNCH(MI_, NI_, WM_, 0, 0); break;                                     \
         case 1: FOV_GEMM_LAUNCH(MI_, NI_, WM_, 0, 1); break;                                     \
         case 2: FOV_GEMM_LAUNCH(MI_, NI_, WM_, 0, 2); break;                                     \
-        case 3: FOV_GEMM_LAUNCH(MI_, NI_, WM_, 1, 0); break;                                     \
-        case 4: FOV_GEMM_LAUNCH(MI_, NI_, WM_, 1, 1); break;                                     \
-        case 5: FOV_GEMM_LAUNCH(MI_, NI_, WM_, 1, 2); break;                                     \
-        case 6: FOV_GEMM_LAUNCH(MI_, NI_, WM_, 2, 0); break;                                     \
-        case 7: FOV_GEMM_LAUNCH(MI_, NI_, WM_, 2, 1); break;                                     \
-        default: FOV_GEMM_LAUNCH(MI_, NI_, WM_, 2, 2); break;                                    \
+        case 3: FOV_GEMM_LAUNCH(MI_, NI_, WM_, 0, 3); break;                                     \
+        case 4: FOV_GEMM_LAUNCH(MI_, NI_, WM_, 1, 0); break;                                     \
+        case 5: FOV_GEMM_LAUNCH(MI_, NI_, WM_, 1, 1); break;                                     \
+        case 6: FOV_GEMM_LAUNCH(MI_, NI_, WM_, 1, 2); break;                                     \
+        case 7: FOV_GEMM_LAUNCH(MI_, NI_, WM_, 1, 3); break;                                     \
+        case 8: FOV_GEMM_LAUNCH(MI_, NI_, WM_, 2, 0); break;                                     \
+        case 9: FOV_GEMM_LAUNCH(MI_, NI_, WM_, 2, 1); break;                                     \
+        case 10: FOV_GEMM_LAUNCH(MI_, NI_, WM_, 2, 2); break;                                    \
+        case 11: FOV_GEMM_LAUNCH(MI_, NI_, WM_, 2, 3); break;                                    \
+        case 12: FOV_GEMM_LAUNCH(MI_, NI_, WM_, 3, 0); break;                                    \
+        case 13: FOV_GEMM_LAUNCH(MI_, NI_, WM_, 3, 1); break;                                    \
+        case 14: FOV_GEMM_LAUNCH(MI_, NI_, WM_, 3, 2); break;                                    \
+        default: FOV_GEMM_LAUNCH(MI_, NI_, WM_, 3, 3); break;                                    \
     }
     if (variant == 0) { FOV_GEMM_MODES(2, 4, 1) }
     else if (variant == 1) { FOV_GEMM_MODES(6, 4, 1) }
+    else if (variant == 3) { FOV_GEMM_MODES(2, 2, 2) }
     else { FOV_GEMM_MODES(4, 4, 2) }
 #undef FOV_GEMM_MODES
 #undef FOV_GEMM_LAUNCH

@@ -40,6 +40,13 @@ def main():
         us = timeit(lambda: ops.matmul(a, dz.reshape(B * T, 4 * H)))
         fl = 2.0 * H * 4 * H * B * T
         print("split %s  NN 256x30720x1024: %.1f us  %.1f TFLOP/s" % (split, us, fl / us / 1e6), flush=True)
+    os.environ.pop("FOV_GEMM_SPLIT", None)
+    # per-step projections of the step-wise decoders: (B x H) . (H x 4H), and a large NN product
+    for (M, Kd, N) in ((512, 256, 1024), (4096, 256, 1024), (30720, 256, 1024), (8192, 1024, 1024)):
+        a = torch.randn(M, Kd, device=dev)
+        b = torch.randn(Kd, N, device=dev)
+        us = timeit(lambda: ops.matmul(a, b))
+        print("NN %dx%dx%d: %.1f us  %.1f TFLOP/s" % (M, Kd, N, us, 2.0 * M * Kd * N / us / 1e6), flush=True)
 
 
 if __name__ == "__main__":
