@@ -37,8 +37,9 @@ typedef unsigned cu32x4 __attribute__((ext_vector_type(4)));
 // LDS: As[m][k] (k contiguous, stride 24 floats: conflict-free ds_read_b128), Bs[k][n].  With the MFMA k-slot
 // of lane group lq in step s mapped to k = 4*lq + s (for A and B alike) one ds_read_b128 gives a lane its A
 // operands of all four steps.
-// Staging modes are template parameters and the last tile is peeled: staged registers never cross a branch,
-// so the compiler waits for the loads where they are written to LDS, after the MFMAs.
+// Staging modes are template parameters and the tile loop has no branch between loads, MFMAs and LDS writes
+// (the final iteration re-stages its own tile, unused): staged registers never cross a control-flow merge, so
+// the compiler waits for the loads where they are written to LDS, after the MFMAs.
 template <int MI, int NI, int WAVES_M, int AVEC, int BVEC>
 __global__ __launch_bounds__(256) void conv2d_igemm_kernel(ConvArgs g) {
     constexpr int WAVES_N = 4 / WAVES_M;
@@ -100,6 +101,7 @@ __global__ __launch_bounds__(256) void conv2d_igemm_kernel(ConvArgs g) {
     }
 
     int f_dy = 0, f_dx = 0, f_ct = 0;   // the tile the next fetch() loads (wave-uniform)
+    int f_left = ntiles;                // tiles not fetched yet
     float ra[AVEC ? 1 : RA], rb[BVEC ? 1 : RB];
     f32x4 va[AVEC ? RA : 1], vb[BVEC ? RB : 1];
     auto fetch = [&]() {
@@ -133,7 +135,9 @@ __global__ __launch_bounds__(256) void conv2d_igemm_kernel(ConvArgs g) {
                 rb[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(wrs, b_off[r], 0, 0));
             }
         }
-        if (++f_ct == ctiles) {
+        // advance (scalar state only); after the last tile the position stays, so the extra fetch of the final
+        // iteration re-reads that tile instead of branching around the loads
+        if (--f_left > 0 && ++f_ct == ctiles) {
             f_ct = 0;
             if (++f_dx == g.kw) { f_dx = 0; ++f_dy; }
         }
@@ -176,7 +180,8 @@ __global__ __launch_bounds__(256) void conv2d_igemm_kernel(ConvArgs g) {
     fetch();
     stash(0);
     __syncthreads();
-    for (int t = 0; t + 1 < ntiles; ++t) {
+    // no branch separates loads, MFMAs and LDS writes: the final iteration stages its own tile once more, unused
+    for (int t = 0; t < ntiles; ++t) {
         read_frags(buf);
         __builtin_amdgcn_sched_barrier(0);
         fetch();
@@ -187,8 +192,6 @@ __global__ __launch_bounds__(256) void conv2d_igemm_kernel(ConvArgs g) {
         __syncthreads();
         buf ^= 1;
     }
-    read_frags(buf);
-    mfmas();
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll

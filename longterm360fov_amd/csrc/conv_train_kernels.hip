@@ -180,10 +180,6 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs g) {
             } else {
                 ra[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrs, off, 0, 0));
             }
-            // this element's pixel advances by 16 for the next tile
-            a_x[r] += BK;
-            while (a_x[r] >= g.W) { a_x[r] -= g.W; ++a_y[r]; }
-            while (a_y[r] >= g.H) a_y[r] -= g.H;
         }
         const float* zt = g.dz + p0 * g.N;
         const int krows = krem < BK ? (int)krem : BK;
@@ -197,7 +193,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs g) {
                 rb[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(zrs, b_off[r], 0, 0));
             }
         }
-        ++f_t;
+        // the final iteration re-reads the last tile (unused): the position and the pixel trackers stay
+        if (f_t + 1 < tend) {
+            ++f_t;
+#pragma unroll
+            for (int r = 0; r < RA; ++r) {   // every element's pixel advances by 16
+                a_x[r] += BK;
+                while (a_x[r] >= g.W) { a_x[r] -= g.W; ++a_y[r]; }
+                while (a_y[r] >= g.H) a_y[r] -= g.H;
+            }
+        }
     };
     auto stash = [&](int buf) {
 #pragma unroll
@@ -242,7 +247,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs g) {
         stash(0);
     }
     __syncthreads();
-    for (long t = tbeg; t + 1 < tend; ++t) {
+    for (long t = tbeg; t < tend; ++t) {
         read_frags(buf);
         __builtin_amdgcn_sched_barrier(0);
         fetch();
@@ -252,10 +257,6 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs g) {
         stash(buf ^ 1);
         __syncthreads();
         buf ^= 1;
-    }
-    if (tbeg < tend) {
-        read_frags(buf);
-        mfmas();
     }
     float* out = g.out + (size_t)blockIdx.z * g.kh * g.kw * g.C * g.N + (size_t)tap * g.C * g.N;
 #pragma unroll

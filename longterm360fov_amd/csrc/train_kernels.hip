@@ -182,15 +182,19 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
     const float* a_blk = g.a + (long)m0 * g.a_sm;
     const float* b_blk = g.b + (long)n0 * g.b_sn;
     int f_ko = tbeg / ntpr, f_kt = tbeg - f_ko * ntpr;   // the tile the next fetch() loads (wave-uniform)
+    int f_left = tend - tbeg;   // tiles not fetched yet
     auto fetch = [&]() {
         const int kmax = g.KI - f_kt * GBK;   // >= 16 except for the row's last tile
         sa.fetch(a_blk + (long)f_ko * g.a_sko + (long)(f_kt * GBK) * g.a_ski, kmax, g.a_ski);
         sb.fetch(b_blk + (long)f_ko * g.b_sko + (long)(f_kt * GBK) * g.b_ski, kmax, g.b_ski);
-        if (++f_kt == ntpr) { f_kt = 0; ++f_ko; }
+        // advance (scalar state only); after the last tile the position stays, so the extra fetch of the final
+        // iteration re-reads that tile instead of branching around the loads
+        if (--f_left > 0 && ++f_kt == ntpr) { f_kt = 0; ++f_ko; }
     };
     // Per tile: all fragment reads first (one exposed LDS latency per tile instead of one per k-step), then the
     // global loads of the next tile, then 16*MI*NI/4 back-to-back MFMAs, then the staged tile goes to the other
-    // LDS buffer.  The last tile is peeled so the staged registers are never live across a branch.
+    // LDS buffer.  No branch separates loads, MFMAs and LDS writes (a merge would make the compiler wait for the
+    // loads early): the final iteration simply stages its own tile once more, unused.
     f32x4 af[MI], bf[NI];
     auto read_frags = [&](int buf) {
 #pragma unroll
@@ -214,7 +218,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
         sb.stash(Bs[0]);
     }
     __syncthreads();
-    for (int t = tbeg; t + 1 < tend; ++t) {
+    for (int t = tbeg; t < tend; ++t) {
         read_frags(buf);
         __builtin_amdgcn_sched_barrier(0);
         fetch();
@@ -225,10 +229,6 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
         sb.stash(Bs[buf ^ 1]);
         __syncthreads();
         buf ^= 1;
-    }
-    if (tbeg < tend) {
-        read_frags(buf);
-        mfmas();
     }
     float* c = g.c + (g.split > 1 ? (size_t)bz * g.M * g.ldc : 0);
 #pragma unroll
