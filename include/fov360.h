@@ -87,6 +87,18 @@ int fov_dense_fwd(const float* x, const float* W, const float* b, float* y,
 int fov_dense_add_fwd(const float* x, const float* W, const float* b, const float* add, int64_t add_row_stride,
                       float* y, int N, int In, int Out, int activation, fov_stream_t stream);
 
+/* One decoder step of the others-mixing head in ONE launch (given_others...py:127-130,168,257-265):
+ *   p (N,O) = tanh(h dense_W + dense_b);   m (N,O) = tanh(p mix_Wp + add[row*add_row_stride + :])
+ * with mix_Wp = mix_W[-O:] (O x O) and add = others_t . mix_W[:-O] + mix_b (fov_dense_fwd, hoisted out of the loop).
+ * O <= 8, H % 4 == 0.  Backward of the same step: dm_loss = dL/d(pre-tanh of m) from the loss, dm_feedback =
+ * dL/dm arriving through x_{t+1} = m_t (NULL at the last step); writes dpre_m, dpre_p (N,O: the pre-activation
+ * gradients the weight-gradient products need) and dh (N,H) = dL/dh.  Outputs must not alias inputs. */
+int fov_mix_head_fwd(const float* h, const float* dense_W, const float* dense_b, const float* mix_Wp, const float* add,
+                     int64_t add_row_stride, float* p, float* m, int N, int H, int O, fov_stream_t stream);
+int fov_mix_head_bwd(const float* dm_loss, const float* dm_feedback, const float* m, const float* p, const float* mix_Wp,
+                     const float* dense_W, float* dpre_m, float* dpre_p, float* dh, int N, int H, int O,
+                     fov_stream_t stream);
+
 /* C (M,N) = A (M,K) . B (K,N), row-major dense fp32 (keras.backend.dot on 2-D operands).  The
  * workspace is optional (NULL allowed): with it, short-and-wide products use split-K. */
 size_t fov_matmul_workspace_bytes(int M, int K, int N);

@@ -123,6 +123,109 @@ static int launch_dense(const float* x, const float* W, const float* b, const fl
 }
 
 // ---------------------------------------------------------------------------------------
+// Mixing head of the others model, one decoder step (given_others...py:127-130,168,257-265):
+//   p = tanh(h W_d + b_d)                     Dense(O,'tanh') on the layer-2 output
+//   m = tanh(p W_p + add)                     mixing Dense: W_p = mix_W[-O:], add = others_t . mix_W[:-O] + mix_b
+// Forward: 16 lanes per row as dense_small_kernel, then the O values of p are exchanged inside the 16-lane group.
+// Backward (one thread per (row, hidden unit); the O-wide row quantities are recomputed by every thread of the
+// row - 2*O*O FMAs): dpre_m = dm_loss + dm_feedback * (1 - m^2), dpre_p = (dpre_m W_p^T) * (1 - p^2),
+// dh = dpre_p W_d^T.  One launch each instead of two / five: the step-wise decoder is launch-bound.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mix_head_fwd_kernel(const float* __restrict__ h, const float* __restrict__ Wd,
+                                                           const float* __restrict__ bd, const float* __restrict__ Wp,
+                                                           const float* __restrict__ add, long add_stride, float* __restrict__ p_out,
+                                                           float* __restrict__ m_out, int N, int H, int O) {
+    extern __shared__ __attribute__((aligned(16))) float Wt[];   // [8][H] transposed W_d, then W_p (O x O)
+    float* sWp = Wt + 8 * H;
+    for (int e = threadIdx.x; e < 8 * H; e += 256) {
+        const int o = e / H, k = e - o * H;
+        Wt[e] = (o < O) ? Wd[(size_t)k * O + o] : 0.f;
+    }
+    for (int e = threadIdx.x; e < 64; e += 256) sWp[e] = (e < O * O) ? Wp[e] : 0.f;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, l16 = lane & 15, g = lane >> 4, wave = threadIdx.x >> 6;
+    for (long row0 = ((long)blockIdx.x * 4 + wave) * 4; row0 < N; row0 += (long)gridDim.x * 16) {
+        const long row = row0 + g;
+        const bool ok = row < N;
+        const float* xr = h + (size_t)(ok ? row : 0) * H;
+        float acc[8];
+#pragma unroll
+        for (int o = 0; o < 8; ++o) acc[o] = 0.f;
+        for (int k = 4 * l16; k < H; k += 64) {
+            const f32x4 xv = *(const f32x4*)(xr + k);
+#pragma unroll
+            for (int o = 0; o < 8; ++o) {
+                const f32x4 wv = *(const f32x4*)&Wt[o * H + k];
+                acc[o] = fmaf(xv[0], wv[0], fmaf(xv[1], wv[1], fmaf(xv[2], wv[2], fmaf(xv[3], wv[3], acc[o]))));
+            }
+        }
+#pragma unroll
+        for (int o = 0; o < 8; ++o)
+#pragma unroll
+            for (int m = 8; m >= 1; m >>= 1) acc[o] += __shfl_xor(acc[o], m);
+        // every lane of the group now holds all eight sums: p[o] = tanh(acc[o] + bd[o])
+        float pv[8];
+#pragma unroll
+        for (int o = 0; o < 8; ++o) pv[o] = (o < O) ? tanh_f(acc[o] + bd[o]) : 0.f;
+        if (ok && l16 < O) {
+            float pm = 0.f, z = add[(size_t)row * add_stride + l16];
+#pragma unroll
+            for (int o = 0; o < 8; ++o) {
+                pm = (l16 == o) ? pv[o] : pm;
+                z = fmaf(pv[o], sWp[o * O + l16], z);   // rows o >= O of sWp are never read past O*O: pv is 0 there
+            }
+            p_out[(size_t)row * O + l16] = pm;
+            m_out[(size_t)row * O + l16] = tanh_f(z);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void mix_head_bwd_kernel(const float* __restrict__ dm_loss, const float* __restrict__ dm_fb,
+                                                           const float* __restrict__ m, const float* __restrict__ p,
+                                                           const float* __restrict__ Wp, const float* __restrict__ Wd,
+                                                           float* __restrict__ dpre_m, float* __restrict__ dpre_p,
+                                                           float* __restrict__ dh, int N, int H, int O) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)N * H) return;
+    const long row = idx / H;
+    const int j = (int)(idx - row * H);
+    float dm[8], dp[8];
+#pragma unroll
+    for (int o = 0; o < 8; ++o) {
+        dm[o] = 0.f;
+        if (o < O) {
+            const float mv = m[row * O + o];
+            dm[o] = dm_loss[row * O + o] + (dm_fb ? dm_fb[row * O + o] * (1.f - mv * mv) : 0.f);
+        }
+    }
+    float out = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        dp[i] = 0.f;
+        if (i < O) {
+            float s = 0.f;
+#pragma unroll
+            for (int o = 0; o < 8; ++o)
+                if (o < O) s = fmaf(dm[o], Wp[i * O + o], s);
+            const float pv = p[row * O + i];
+            dp[i] = s * (1.f - pv * pv);
+            out = fmaf(dp[i], Wd[(size_t)j * O + i], out);
+        }
+    }
+    dh[idx] = out;
+    if (j < O) {
+        float a = 0.f, b = 0.f;
+#pragma unroll
+        for (int o = 0; o < 8; ++o) {
+            a = (j == o) ? dm[o] : a;
+            b = (j == o) ? dp[o] : b;
+        }
+        dpre_m[row * O + j] = a;
+        dpre_p[row * O + j] = b;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // mu / sigma^2 feature op (utility.py:483-517): one thread per (row, axis); two-pass
 // population variance like numpy.var (mean first, then mean of squared deviations).
 // HBM-bound: 12*fps bytes in, 24 bytes out per row.
@@ -404,6 +507,38 @@ int fov_dense_add_fwd(const float* x, const float* W, const float* b, const floa
     }
     if (N == 0) return FOV_OK;
     return launch_dense(x, W, b, add, (long)add_row_stride, y, N, In, Out, activation, (hipStream_t)stream);
+}
+
+int fov_mix_head_fwd(const float* h, const float* dense_W, const float* dense_b, const float* mix_Wp, const float* add,
+                     int64_t add_row_stride, float* p, float* m, int N, int H, int O, fov_stream_t stream) {
+    if (N < 0 || H <= 0 || O <= 0 || O > 8 || (H & 3) || H > 2048 || !dense_W || !dense_b || !mix_Wp ||
+        (N > 0 && (!h || !add || !p || !m)) || (((uintptr_t)h) & 15)) {
+        set_error("fov_mix_head_fwd: invalid argument (O <= 8, H a multiple of 4 and <= 2048, h 16-byte aligned)");
+        return FOV_ERR_INVALID;
+    }
+    if (N == 0) return FOV_OK;
+    long blocks = ((long)N + 15) / 16;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(mix_head_fwd_kernel, dim3((unsigned)blocks), dim3(256), sizeof(float) * (8 * H + 64), (hipStream_t)stream, h,
+                       dense_W, dense_b, mix_Wp, add, (long)add_row_stride, p, m, N, H, O);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_error("mix_head_fwd launch: %s", hipGetErrorString(e)); return FOV_ERR_LAUNCH; }
+    return FOV_OK;
+}
+
+int fov_mix_head_bwd(const float* dm_loss, const float* dm_feedback, const float* m, const float* p, const float* mix_Wp,
+                     const float* dense_W, float* dpre_m, float* dpre_p, float* dh, int N, int H, int O, fov_stream_t stream) {
+    if (N < 0 || H <= 0 || O <= 0 || O > 8 || !mix_Wp || !dense_W || (N > 0 && (!dm_loss || !m || !p || !dpre_m || !dpre_p || !dh))) {
+        set_error("fov_mix_head_bwd: invalid argument (O <= 8)");
+        return FOV_ERR_INVALID;
+    }
+    if (N == 0) return FOV_OK;
+    const long n = (long)N * H;
+    hipLaunchKernelGGL(mix_head_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dm_loss, dm_feedback,
+                       m, p, mix_Wp, dense_W, dpre_m, dpre_p, dh, N, H, O);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_error("mix_head_bwd launch: %s", hipGetErrorString(e)); return FOV_ERR_LAUNCH; }
+    return FOV_OK;
 }
 
 size_t fov_matmul_workspace_bytes(int M, int K, int N) {

@@ -317,6 +317,29 @@ def dense_add(x, W, b, add, activation="tanh", out=None):
     return y
 
 
+def mix_head_fwd(h, dense_W, dense_b, mix_Wp, add, p_out, m_out):
+    """p = tanh(h dense_W + dense_b), m = tanh(p mix_Wp + add) in one launch; add (N,O) may be a strided row view."""
+    h, dense_W, dense_b, mix_Wp = _dev(h, "h"), _dev(dense_W, "dense_W"), _dev(dense_b, "dense_b"), _dev(mix_Wp, "mix_Wp")
+    N, H = h.shape
+    O = dense_W.shape[1]
+    assert add.is_cuda and add.shape == (N, O) and add.stride(1) == 1 and mix_Wp.shape == (O, O)
+    check(_lib.lib().fov_mix_head_fwd(_ptr(h), _ptr(dense_W), _ptr(dense_b), _ptr(mix_Wp), add.data_ptr(), add.stride(0),
+                                      _ptr(_dev(p_out, "p")), _ptr(_dev(m_out, "m")), N, H, O, _stream()))
+    return p_out, m_out
+
+
+def mix_head_bwd(dm_loss, dm_feedback, m, p, mix_Wp, dense_W, dpre_m, dpre_p, dh=None):
+    """Backward of mix_head_fwd -> dh (N,H); dpre_m / dpre_p (N,O) are written (no aliasing with the inputs)."""
+    dm_loss, m, p = _dev(dm_loss, "dm_loss"), _dev(m, "m"), _dev(p, "p")
+    N, O = m.shape
+    H = dense_W.shape[0]
+    dh = torch.empty((N, H), dtype=torch.float32, device=m.device) if dh is None else dh
+    check(_lib.lib().fov_mix_head_bwd(_ptr(dm_loss), _ptr(_dev(dm_feedback, "dm_feedback")), _ptr(m), _ptr(p),
+                                      _ptr(_dev(mix_Wp, "mix_Wp")), _ptr(_dev(dense_W, "dense_W")), _ptr(_dev(dpre_m, "dpre_m")),
+                                      _ptr(_dev(dpre_p, "dpre_p")), _ptr(dh), N, H, O, _stream()))
+    return dh
+
+
 def lstm_seq_zx(zx, R, b, h0=None, c0=None, act="sigmoid", impl="auto", return_sequences=True, workspace=None,
                 reserve=None, out=None):
     """LSTM layer from a precomputed input projection zx = x.K (B,T,4H) -> (hs|None, hT, cT).

@@ -172,25 +172,21 @@ class OthersMixingTrainer:
             zx = ops.matmul(H1[t + 1], w["dec2_K"], scratch=sc).reshape(B, 1, 4 * H)
             ops.lstm_seq_zx(zx, w["dec2_R"], w["dec2_b"], H2[t], C2[t], act=act, impl=impl, workspace=ws, reserve=R2[t],
                             out=(H2[t + 1].view(B, 1, H), None, C2[t + 1]))
-            ops.dense(H2[t + 1], w["dense_W"], w["dense_b"], activation="tanh", out=P[t])
-            ops.dense_add(P[t], Wm_p_c, None, oth_proj[:, t], activation="tanh", out=M[t])
+            ops.mix_head_fwd(H2[t + 1], w["dense_W"], w["dense_b"], Wm_p_c, oth_proj[:, t], P[t], M[t])
         out = M.transpose(0, 1).contiguous()                                      # (B,T_out,O)
         # ---------------- backward ----------------
         # dL/d(pre-tanh of the mixing layer) from the loss, for every step at once
         dloss, loss = ops.mse_dense_grad(out, target, "tanh", scratch=sc)
-        dpre_all = dloss.transpose(0, 1).contiguous()                              # (T_out,B,O), per-step rows
-        dpre_p_all = e(T_out, B, O)
+        dloss_tm = dloss.transpose(0, 1).contiguous()                              # (T_out,B,O), per-step rows
+        dpre_all, dpre_p_all = e(T_out, B, O), e(T_out, B, O)                      # written by the head backward
         DZ1, DZ2 = e(T_out, B, 4 * H), e(T_out, B, 4 * H)
         dh1_rec = dc1 = dh2_rec = dc2 = None
         dx_next = None
         for t in range(T_out - 1, -1, -1):
-            dpre_m = dpre_all[t]
-            if dx_next is not None:            # x_{t+1} = m_t: the feedback gradient joins through tanh'
-                ops.act_bwd(dx_next.reshape(B, O), M[t], base=dpre_m, activation="tanh", out=dpre_m)
-            # data path only inside the loop; every weight gradient is one product over all steps, below
-            dp, _, _ = ops.dense_bwd(P[t], Wm_p_c, dpre_m, need_dW=False, need_db=False, scratch=sc)
-            dpre_p = ops.act_bwd(dp, P[t], activation="tanh", out=dpre_p_all[t])
-            dh2_dense, _, _ = ops.dense_bwd(H2[t + 1], w["dense_W"], dpre_p, need_dW=False, need_db=False, scratch=sc)
+            # mixing head of step t in one launch: the feedback gradient (x_{t+1} = m_t) joins through tanh',
+            # then the two tiny Dense layers backwards; weight gradients are formed after the loop
+            dh2_dense = ops.mix_head_bwd(dloss_tm[t], None if dx_next is None else dx_next.reshape(B, O), M[t], P[t], Wm_p_c,
+                                         w["dense_W"], dpre_all[t], dpre_p_all[t])
             # layer 2 step: its input is h1_t, so its dx (= dz2 . K2^T) is the gradient w.r.t. h1_t
             b2 = ops.lstm_seq_bwd(H1[t + 1].view(B, 1, H), w["dec2_K"], w["dec2_R"], H2[t + 1].view(B, 1, H), R2[t],
                                   h0=H2[t], c0=C2[t], dhs=dh2_dense.reshape(B, 1, H), dhT=dh2_rec, dcT=dc2,

@@ -343,3 +343,39 @@ def test_dense_bwd_tall_narrow(N, In, Out):
     dW0, db0 = dW.clone(), db.clone()
     ops.dense_bwd(dev(x), dev(W), dev(d), dW=dW, db=db, need_dx=False, accumulate=True)
     assert torch.allclose(dW, 2 * dW0, rtol=1e-5, atol=1e-5) and torch.allclose(db, 2 * db0, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("N,H,O", [(37, 64, 6), (512, 256, 6), (5, 128, 3)])
+def test_mix_head_forward_backward(N, H, O):
+    """One decoder step of the mixing head (given_others...py:127-130,168,257-265) as single launches, against
+    torch.autograd fp64; `add` is a strided row view like others_proj[:, t]."""
+    from longterm360fov_amd import ops
+    rng = np.random.default_rng(N + H)
+    h = rng.standard_normal((N, H)).astype(np.float32)
+    Wd = (rng.standard_normal((H, O)) / np.sqrt(H)).astype(np.float32)
+    bd = rng.standard_normal(O).astype(np.float32) * 0.1
+    Wp = (rng.standard_normal((O, O)) * 0.5).astype(np.float32)
+    add = rng.standard_normal((N, 3, O)).astype(np.float32)
+    dml = rng.standard_normal((N, O)).astype(np.float32)
+    dfb = rng.standard_normal((N, O)).astype(np.float32)
+    t = lambda a: torch.tensor(a.astype(np.float64), requires_grad=True)
+    th, tWd, tbd, tWp = t(h), t(Wd), t(bd), t(Wp)
+    p_ref = torch.tanh(th @ tWd + tbd)
+    zm = p_ref @ tWp + torch.tensor(add[:, 1].astype(np.float64))
+    m_ref = torch.tanh(zm)
+    # loss gradient arrives w.r.t. the pre-tanh of m, the feedback gradient w.r.t. m itself
+    ((zm * torch.tensor(dml.astype(np.float64))).sum() + (m_ref * torch.tensor(dfb.astype(np.float64))).sum()).backward()
+    p_out = torch.empty((N, O), device="cuda"); m_out = torch.empty((N, O), device="cuda")
+    ops.mix_head_fwd(dev(h), dev(Wd), dev(bd), dev(Wp), dev(add)[:, 1], p_out, m_out)
+    assert np.abs(p_out.cpu().numpy() - p_ref.detach().numpy()).max() < 2e-6
+    assert np.abs(m_out.cpu().numpy() - m_ref.detach().numpy()).max() < 2e-6
+    dpm = torch.empty((N, O), device="cuda"); dpp = torch.empty((N, O), device="cuda")
+    dh = ops.mix_head_bwd(dev(dml), dev(dfb), m_out, p_out, dev(Wp), dev(Wd), dpm, dpp)
+    assert np.abs(dh.cpu().numpy() - th.grad.numpy()).max() <= 2e-5 * np.abs(th.grad.numpy()).max() + 1e-7
+    # the pre-activation gradients reproduce the weight gradients: dWp = p^T dpre_m, dWd = h^T dpre_p
+    dWp = p_out.double().T @ dpm.double()
+    dWd = dev(h).double().T @ dpp.double()
+    assert np.abs(dWp.cpu().numpy() - tWp.grad.numpy()).max() <= 2e-5 * np.abs(tWp.grad.numpy()).max() + 1e-7
+    assert np.abs(dWd.cpu().numpy() - tWd.grad.numpy()).max() <= 2e-5 * np.abs(tWd.grad.numpy()).max() + 1e-7
+    dh0 = ops.mix_head_bwd(dev(dml), None, m_out, p_out, dev(Wp), dev(Wd), dpm, dpp)   # last step: no feedback
+    assert np.isfinite(dh0.cpu().numpy()).all()
