@@ -463,17 +463,22 @@ class OthersMixingSeq2Seq:
             _, h2, c2 = ops.lstm_seq_zx(zx, dw["enc2_R"], dw["enc2_b"], act=act, impl=impl, return_sequences=False, workspace=ws)
             # others half of the mixing layer for every step at once (bias folded in)
             oth_proj = ops.dense(oth.reshape(B * T_out, -1), dw["mix_W_oth"], dw["mix_b"], activation=None).reshape(B, T_out, O)
-            out = torch.empty((B, T_out, O), dtype=torch.float32, device=self.device)
+            out = torch.empty((T_out, B, O), dtype=torch.float32, device=self.device)   # step-major: row t = m_t
+            p = torch.empty((B, O), dtype=torch.float32, device=self.device)
+            fused_head = O <= 8 and H % 4 == 0
             for t in range(T_out):
                 _, h1, c1 = ops.lstm_seq(xin.reshape(B, 1, O), dw["dec1_K"], dw["dec1_R"], dw["dec1_b"], h1, c1, act=act,
                                          impl=impl, return_sequences=False, workspace=ws)
                 zx = ops.matmul(h1, dw["dec2_K"]).reshape(B, 1, 4 * H)
                 _, h2, c2 = ops.lstm_seq_zx(zx, dw["dec2_R"], dw["dec2_b"], h2, c2, act=act, impl=impl,
                                             return_sequences=False, workspace=ws)
-                p = ops.dense(h2, dw["dense_W"], dw["dense_b"], activation="tanh")
-                xin = ops.dense_add(p, dw["mix_W_pred"], None, oth_proj[:, t], activation="tanh")
-                out[:, t] = xin
-            outs.append(out.cpu().numpy())
+                if fused_head:   # Dense(tanh) + mixing Dense(tanh) in one launch, written straight into the output row
+                    ops.mix_head_fwd(h2, dw["dense_W"], dw["dense_b"], dw["mix_W_pred"], oth_proj[:, t], p, out[t])
+                else:
+                    pp = ops.dense(h2, dw["dense_W"], dw["dense_b"], activation="tanh")
+                    ops.dense_add(pp, dw["mix_W_pred"], None, oth_proj[:, t], activation="tanh", out=out[t])
+                xin = out[t]
+            outs.append(out.transpose(0, 1).cpu().numpy())
         self._ws.check()
         return np.concatenate(outs, axis=0) if outs else np.zeros((0, T_out, O), np.float32)
 
