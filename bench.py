@@ -155,6 +155,61 @@ def bench_train_mixing(args, rank, world, use_dist):
         dist.destroy_process_group()
 
 
+def bench_infer_mixing(args, rank, world, use_dist):
+    """Secondary measurement, BASELINE.json configs[2] shape, inference: 2+2-layer others-mixing model, encoder
+    over T_in steps + autoregressive decoder with the mixing head, device-resident inputs, replicas only."""
+    import torch.distributed as dist
+    from longterm360fov_amd.models import OthersMixingSeq2Seq
+    from oracle import fov_oracle as O
+    H, T_in, T_out, U = args.hidden, 10, 10, 34
+    B = args.batch if args.batch != 1024 else 512
+    w = O.init_others_mixing(1234, H=H, num_user=U, bias_noise=0.05)
+    enc, dec0, tgt, oth = O.synthetic_batch(1234 + rank, B, T_in, T_out, num_others=U - 1)
+    m = OthersMixingSeq2Seq(latent_dim=H, num_user=U, recurrent_activation=args.act, impl=args.impl)
+    from longterm360fov_amd.models import _MIX_ORDER
+    m.set_weights([w[k] for k in _MIX_ORDER])
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    a_enc, a_oth, a_dec = d(enc), d(oth), d(dec0)
+    for _ in range(args.warmup):
+        out = m.predict_device(a_enc, a_oth, a_dec)
+    torch.cuda.synchronize()
+    if use_dist:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = m.predict_device(a_enc, a_oth, a_dec)
+    torch.cuda.synchronize()
+    if use_dist:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if use_dist:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        ref = O.others_mixing_forward(enc[:32].astype(np.float64), oth[:32].astype(np.float64), dec0[:32].astype(np.float64),
+                                      {k: v.astype(np.float64) for k, v in w.items()}, act=args.act)
+        err = float(np.abs(out[:32].cpu().numpy() - ref).max())
+        fwd = (T_in * (2 * (90 + H) * 4 * H + 2 * (H + H) * 4 * H) +
+               T_out * (2 * (6 + H) * 4 * H + 2 * (H + H) * 4 * H + 2 * H * 6 + 2 * U * 6 * 6))
+        ms = elapsed / args.steps * 1e3
+        print(json.dumps({
+            "metric": "sequences/sec, others-mixing 2+2 layers inference (batch=%d per GPU, T 10->10, h=%d, U=%d)" % (B, H, U),
+            "value": world * B * args.steps / elapsed, "unit": "sequences/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[2] shape: given_others_gt_mean_var_seq2seq inference (encoder + unrolled "
+                                   "no-teacher-forcing decoder with others mixing)", "global_batch": B * world,
+                       "parallelism": "replicas x%d (no collective)" % world},
+            "roofline": {"bound": "mfma", "achieved": fwd * B / (ms * 1e-3) / 1e12, "peak": PEAK_FP32_MFMA_TFLOPS,
+                         "unit": "TFLOP/s", "frac": fwd * B / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, "traffic": None},
+            "parity": {"max_abs_err_vs_oracle": err, "sequences_checked": 32},
+            "cpu_baseline": None}), flush=True)
+    if use_dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -170,7 +225,7 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the N > 1 path "
                          "with several ranks on ONE GPU)")
-    ap.add_argument("--mode", default="infer", choices=["infer", "train", "train_mixing"],
+    ap.add_argument("--mode", default="infer", choices=["infer", "train", "train_mixing", "infer_mixing"],
                     help="infer (default, the BASELINE metric): encoder + autoregressive decoder; train: one "
                          "teacher-forced training step (fwd + BPTT + Adam, data-parallel all-reduce when N > 1)")
     args = ap.parse_args()
@@ -195,6 +250,8 @@ def main():
         return bench_train(args, rank, world, use_dist)
     if args.mode == "train_mixing":
         return bench_train_mixing(args, rank, world, use_dist)
+    if args.mode == "infer_mixing":
+        return bench_infer_mixing(args, rank, world, use_dist)
 
     B, T_in, T_out, H = args.batch, args.t_in, args.t_out, args.hidden
     F_enc, F_dec = 90, 6

@@ -99,6 +99,25 @@ int fov_mix_head_bwd(const float* dm_loss, const float* dm_feedback, const float
                      const float* dense_W, float* dpre_m, float* dpre_p, float* dh, int N, int H, int O,
                      fov_stream_t stream);
 
+/* The whole unrolled no-teacher-forcing decoder of the others-mixing model in ONE persistent launch
+ * (given_others...py:203-299): per step LSTM1(x_t) -> LSTM2 -> Dense(O,'tanh') -> mixing Dense -> x_{t+1}.
+ *   dec0 (B,O); h1,c1,h2,c2 (B,H) = encoder states; oth_proj: others_t . mix_W[:-O] + mix_b, element (b,t,o) at
+ *   b*oth_batch_stride + t*oth_step_stride + o; weights in Keras layout; mix_Wp = mix_W[-O:] (O,O).
+ *   out (T_out,B,O) step-major = m_t.  h1T..c2T (B,H): final states or NULL.
+ *   Training buffers (all or none): P (T_out,B,O) = p_t; H1,C1,H2,C2 (T_out,B,H) = states after step t;
+ *   res1,res2 (T_out,B,5,H) = activated i,f,g,o and c (the reserve layout of fov_lstm_seq_fwd_train with T = 1).
+ * Supported: H = 256, O <= 8 (FOV_ERR_UNSUPPORTED otherwise: use the per-step entry points). */
+size_t fov_mix_decoder_workspace_bytes(int B, int H);
+int fov_mix_decoder_fwd(const float* dec0, const float* h1, const float* c1, const float* h2, const float* c2,
+                        const float* oth_proj, int64_t oth_batch_stride, int64_t oth_step_stride,
+                        const float* dec1_K, const float* dec1_R, const float* dec1_b,
+                        const float* dec2_K, const float* dec2_R, const float* dec2_b,
+                        const float* dense_W, const float* dense_b, const float* mix_Wp,
+                        float* out, float* h1T, float* c1T, float* h2T, float* c2T,
+                        float* P, float* H1, float* C1, float* H2, float* C2, float* res1, float* res2,
+                        int B, int T_out, int H, int O, int act,
+                        void* workspace, size_t workspace_bytes, fov_stream_t stream);
+
 /* C (M,N) = A (M,K) . B (K,N), row-major dense fp32 (keras.backend.dot on 2-D operands).  The
  * workspace is optional (NULL allowed): with it, short-and-wide products use split-K. */
 size_t fov_matmul_workspace_bytes(int M, int K, int N);

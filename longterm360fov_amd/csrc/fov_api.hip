@@ -541,6 +541,41 @@ int fov_mix_head_bwd(const float* dm_loss, const float* dm_feedback, const float
     return FOV_OK;
 }
 
+size_t fov_mix_decoder_workspace_bytes(int B, int H) {
+    if (B <= 0 || H != 256) return kStatusBytes;
+    return mix_decoder_workspace_bytes(B);
+}
+
+int fov_mix_decoder_fwd(const float* dec0, const float* h1, const float* c1, const float* h2, const float* c2,
+                        const float* oth_proj, int64_t oth_batch_stride, int64_t oth_step_stride, const float* dec1_K,
+                        const float* dec1_R, const float* dec1_b, const float* dec2_K, const float* dec2_R,
+                        const float* dec2_b, const float* dense_W, const float* dense_b, const float* mix_Wp, float* out,
+                        float* h1T, float* c1T, float* h2T, float* c2T, float* P, float* H1, float* C1, float* H2, float* C2,
+                        float* res1, float* res2, int B, int T_out, int H, int O, int act, void* workspace,
+                        size_t workspace_bytes, fov_stream_t stream) {
+    if (B < 0 || T_out < 0 || O <= 0 || !dec1_K || !dec1_R || !dec1_b || !dec2_K || !dec2_R || !dec2_b || !dense_W ||
+        !dense_b || !mix_Wp || (B > 0 && T_out > 0 && (!dec0 || !h1 || !c1 || !h2 || !c2 || !oth_proj || !out)) ||
+        (act != FOV_ACT_SIGMOID && act != FOV_ACT_HARD_SIGMOID)) {
+        set_error("fov_mix_decoder_fwd: invalid argument");
+        return FOV_ERR_INVALID;
+    }
+    const int ntrain = (P != nullptr) + (H1 != nullptr) + (C1 != nullptr) + (H2 != nullptr) + (C2 != nullptr) + (res1 != nullptr) +
+                       (res2 != nullptr);
+    if (ntrain != 0 && ntrain != 7) { set_error("fov_mix_decoder_fwd: give all training buffers or none"); return FOV_ERR_INVALID; }
+    if (H != 256 || O > 8) { set_error("fov_mix_decoder_fwd: the fused decoder supports H = 256, O <= 8"); return FOV_ERR_UNSUPPORTED; }
+    if (B == 0 || T_out == 0) return FOV_OK;
+    int rc = check_ws(workspace, workspace_bytes, fov_mix_decoder_workspace_bytes(B, H));
+    if (rc) return rc;
+    MixDecParams p = {};
+    p.K1 = dec1_K; p.R1 = dec1_R; p.b1 = dec1_b; p.R2 = dec2_R; p.b2 = dec2_b; p.Wd = dense_W; p.bd = dense_b; p.Wp = mix_Wp;
+    p.oth_proj = oth_proj; p.oth_sb = (long)oth_batch_stride; p.oth_st = (long)oth_step_stride;
+    p.dec0 = dec0; p.h1_0 = h1; p.c1_0 = c1; p.h2_0 = h2; p.c2_0 = c2;
+    p.out = out; p.P = P; p.H1 = H1; p.C1 = C1; p.H2 = H2; p.C2 = C2; p.res1 = res1; p.res2 = res2;
+    p.h1T = h1T; p.c1T = c1T; p.h2T = h2T; p.c2T = c2T;
+    p.B = B; p.T_out = T_out; p.O = O;
+    return mix_decoder_launch(p, dec2_K, act, ntrain == 7, workspace, (hipStream_t)stream);
+}
+
 size_t fov_matmul_workspace_bytes(int M, int K, int N) {
     (void)K;
     if (M <= 0 || N <= 0) return 256;

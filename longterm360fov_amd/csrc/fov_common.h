@@ -92,6 +92,25 @@ int splitk_reduce(const float* part, float* out, long n, int S, int accumulate, 
 int colsum(const float* x, float* out, long rows, int cols, int accumulate, float* scratch, size_t scratch_floats,
            hipStream_t stream);
 
+// fused decoder of the others-mixing model (mix_decoder.hip)
+struct MixDecParams {
+    const float *K1, *R1, *b1, *K2p, *R2, *b2, *Wd, *bd, *Wp;
+    const float* oth_proj;   // others_t . W_oth + b_mix, element (b, t, o) at b*oth_sb + t*oth_st + o
+    long oth_sb, oth_st;
+    const float* dec0;       // (B,O)
+    const float *h1_0, *c1_0, *h2_0, *c2_0;   // (B,H)
+    float* out;              // (T_out,B,O) step-major: m_t
+    float* P;                // TRAIN: (T_out,B,O)
+    float *H1, *C1, *H2, *C2;   // TRAIN: (T_out,B,H), state after step t
+    float *res1, *res2;      // TRAIN: (T_out,B,5,H) activated i,f,g,o and c of step t
+    float *h1T, *c1T, *h2T, *c2T;   // final state (B,H), optional
+    unsigned long long* xch; // granules: [group][layer 2][parity 2][16][256]
+    unsigned* status;
+    int B, T_out, O, num_groups, num_tiles;
+};
+size_t mix_decoder_workspace_bytes(int B);
+int mix_decoder_launch(MixDecParams p, const float* K2, int act, int train, void* workspace, hipStream_t stream);
+
 // persistent BPTT recurrence (lstm_bwd_cluster.hip)
 bool bwd_cluster_shape_ok(int H);
 size_t bwd_cluster_xch_bytes(int B, int H);

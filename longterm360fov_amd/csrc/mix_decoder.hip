@@ -1,0 +1,475 @@
+// Fused decoder of the others-mixing model (a4): the whole unrolled no-teacher-forcing loop of
+// mycode/given_others_gt_mean_var_seq2seq.py:203-299 in ONE persistent launch.
+//
+//   per step t:  h1,c1 = LSTM1(x_t; h1,c1)          K1:(O,4H)  R1:(H,4H)
+//                h2,c2 = LSTM2(h1;  h2,c2)          K2:(H,4H)  R2:(H,4H)
+//                p = tanh(h2 Wd + bd)               Dense(O,'tanh'), :127-130
+//                m = tanh(p Wp + others_t . W_oth + b_mix)      mixing Dense, :257-265 (others part hoisted)
+//                x_{t+1} = m                        :292-293
+//
+// The step-wise path pays ~45 us per decoder step in launches, handshakes and weight reloads for ~6 us
+// of arithmetic.  Here H = 256 and a tile of 16 sequences is owned by a GROUP of 8 workgroups; workgroup
+// `slice` owns hidden units [32*slice, +32) of BOTH layers, wave w 8 of them.  A wave's gate columns form
+// two MFMA N-tiles, [i | f] and [g | o] (8 units each); after the MFMAs the two halves of a 16-lane row
+// swap what the other needs (DPP row_ror:8), so that every lane ends up with all four gates of one unit for
+// two sequences: the cell update is lane-local and c1, c2 never leave registers.
+//   R1, R2 slices : 128 + 128 AGPRs per lane for the whole launch (MFMA B operands)
+//   K2 slice      : 128 KB per workgroup would need all of the LDS next to the two h tiles, so it is streamed
+//                   from L2 each step as 16-byte B-operand fragments, four loads in flight, from a copy of K2
+//                   pre-packed in exactly that order (mix_decoder_pack_k2)
+//   h1, h2 tiles  : 16 x 256 each in LDS (MFMA A operands), exchanged once per layer and step as 8-byte
+//                   {value, epoch} granules (sc1 stores / sc1 loads, two parity buffers, bounded spins) - the
+//                   protocol of lstm_cluster.hip
+//   overlap       : the gather of h1_t runs under h2_{t-1} . R2, the gather of h2_t under h1_t . R1 of the
+//                   next step
+//   head          : every workgroup computes p and m of its 16 sequences from the gathered h2 tile (O = 6:
+//                   cheaper than a third exchange); slice 0 stores them
+// TRAIN additionally stores what the backward pass reads: reserves (i,f,g,o,c) of both layers, h1/h2/c1/c2
+// of every step, p.
+#include <stdlib.h>
+
+#include "fov_common.h"
+
+namespace fov {
+
+namespace {
+
+constexpr int MH = 256;          // hidden units
+constexpr int MG = 8;            // workgroups per tile
+constexpr int MBT = 16;          // sequences per tile
+constexpr int MLDH = MH + 4;     // LDS row stride of an h tile
+constexpr int MNG = 14;          // granules gathered per thread and exchange: 7 slices * 16 rows * 32 units / 256
+constexpr unsigned M_SPIN_LIMIT = 1u << 20;
+
+typedef unsigned mu32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned mu32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void mfma_a(f32x4& acc, float a, float w_agpr) {
+    asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "a"(w_agpr));
+}
+__device__ __forceinline__ void mfma_v(f32x4& acc, float a, float w_vgpr) {
+    asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(w_vgpr));
+}
+__device__ __forceinline__ void mfma_begin2(f32x4 (&acc)[2]) { asm volatile("s_nop 3" : "+v"(acc[0]), "+v"(acc[1])); }
+__device__ __forceinline__ void mfma_end2(f32x4 (&acc)[2]) {
+    asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" : "+v"(acc[0]), "+v"(acc[1]));
+}
+// value of the lane 8 positions away inside the same 16-lane row (row_ror:8)
+__device__ __forceinline__ float swap_half(float v) {
+    return __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x128, 0xf, 0xf, false));
+}
+
+}  // namespace
+
+// acc[tile] += A(h tile rows, LDS) . W (AGPR resident, [16 k-blocks][4][2 tiles])
+__device__ __forceinline__ void recur_agpr(f32x4 (&acc)[2], const float* hrow, const float (&w)[16][4][2]) {
+    f32x4 a = *(const f32x4*)hrow;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        f32x4 an = a;
+        if (j + 1 < 16) an = *(const f32x4*)(hrow + 16 * (j + 1));
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            mfma_a(acc[0], a[s], w[j][s][0]);
+            mfma_a(acc[1], a[s], w[j][s][1]);
+        }
+        a = an;
+    }
+}
+
+// acc[tile] += A(h tile rows, LDS) . K2 slice streamed from the packed copy: block (j, tile) = 64 lanes x 4 k-subs.
+// Buffer loads with the block offset in the scalar operand: one VGPR of address for all 32 loads (plain global
+// loads would make hipcc keep 32 hoisted 64-bit addresses alive across the whole step loop).
+__device__ __forceinline__ f32x4 k2_frag(const __amdgpu_buffer_rsrc_t rs, unsigned voff, int block) {
+    const mu32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, block * 1024, 0);
+    return (f32x4){__uint_as_float(t[0]), __uint_as_float(t[1]), __uint_as_float(t[2]), __uint_as_float(t[3])};
+}
+__device__ __forceinline__ void recur_stream(f32x4 (&acc)[2], const float* hrow, const __amdgpu_buffer_rsrc_t rs, unsigned voff) {
+    f32x4 b[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) b[i] = k2_frag(rs, voff, i);   // (j,tile) = (0,0) (0,1) (1,0) (1,1)
+    f32x4 a = *(const f32x4*)hrow;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        f32x4 an = a;
+        if (j + 1 < 16) an = *(const f32x4*)(hrow + 16 * (j + 1));
+        const f32x4 b0 = b[(2 * j) & 3], b1 = b[(2 * j + 1) & 3];
+        if (j + 2 < 16) {
+            b[(2 * j) & 3] = k2_frag(rs, voff, 2 * j + 4);
+            b[(2 * j + 1) & 3] = k2_frag(rs, voff, 2 * j + 5);
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            mfma_v(acc[0], a[s], b0[s]);
+            mfma_v(acc[1], a[s], b1[s]);
+        }
+        a = an;
+    }
+}
+
+template <int ACT, bool TRAIN>
+__global__ __launch_bounds__(256, 1) void mix_decoder_kernel(MixDecParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sH1 = smem;                       // [16][MLDH]
+    float* sH2 = sH1 + MBT * MLDH;           // [16][MLDH]
+    float* sX = sH2 + MBT * MLDH;            // [16][8]  decoder input x_t (columns >= O are zero)
+    float* sWd = sX + MBT * 8;               // [256][8] Dense kernel, rows padded to 8
+    float* sWp = sWd + MH * 8;               // [8][8]   mixing kernel (pred part)
+    int* sFlag = (int*)(sWp + 64);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 15, g4 = lane >> 4;
+    const int O = p.O;
+    // members of a group 8 blocks apart (round-robin dispatch puts them on one XCD when num_groups % 8 == 0);
+    // only a placement preference: the exchange below is the placement-independent sc1 protocol
+    int group, slice;
+    if ((p.num_groups & 7) == 0) {
+        group = (blockIdx.x / (8 * MG)) * 8 + (blockIdx.x & 7);
+        slice = (blockIdx.x >> 3) & (MG - 1);
+    } else {
+        group = blockIdx.x / MG;
+        slice = blockIdx.x - group * MG;
+    }
+    const int unit = 32 * slice + 8 * wave + (n & 7);   // hidden unit of this lane's columns
+    const int hi = n >> 3;                               // 0: columns i / g, 1: columns f / o
+    const int col0 = hi * MH + unit, col1 = (2 + hi) * MH + unit;   // gate columns of tile 0 / tile 1
+    const int H4 = 4 * MH;
+
+    if (tid == 0) sFlag[0] = 0;
+    // ---- resident weights ----
+    float w1[16][4][2], w2[16][4][2];
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const size_t k = (size_t)(16 * j + 4 * g4 + s) * H4;
+            w1[j][s][0] = p.R1[k + col0];
+            w1[j][s][1] = p.R1[k + col1];
+            w2[j][s][0] = p.R2[k + col0];
+            w2[j][s][1] = p.R2[k + col1];
+        }
+    // K1 (O <= 8 rows): MFMA step s uses input row k = 4*s + g4
+    float k1[2][2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const int k = 4 * s + g4;
+        k1[s][0] = (k < O) ? p.K1[(size_t)k * H4 + col0] : 0.f;
+        k1[s][1] = (k < O) ? p.K1[(size_t)k * H4 + col1] : 0.f;
+    }
+    const float b1v[2] = {p.b1[col0], p.b1[col1]}, b2v[2] = {p.b2[col0], p.b2[col1]};
+    for (int e = tid; e < MH * 8; e += 256) {
+        const int k = e >> 3, o = e & 7;
+        sWd[e] = (o < O) ? p.Wd[(size_t)k * O + o] : 0.f;
+    }
+    for (int e = tid; e < 64; e += 256) sWp[e] = ((e >> 3) < O && (e & 7) < O) ? p.Wp[(e >> 3) * O + (e & 7)] : 0.f;
+    // this wave's 32 KB of packed K2 fragments: block b at byte b*1024, lane fragment at lane*16
+    const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.K2p) + (size_t)(slice * 4 + wave) * 32 * 64 * 4, 0, 32 * 1024, 0x00020000);
+    const unsigned kvoff = lane * 16u;
+
+    // ---- exchange bookkeeping ----
+    unsigned long long* xg = p.xch + (size_t)group * 4 * MBT * MH;   // [layer][parity][16][256]
+    const __amdgpu_buffer_rsrc_t xrs =
+        __builtin_amdgcn_make_buffer_rsrc(xg, 0, 4 * MBT * MH * (int)sizeof(unsigned long long), 0x00020000);
+    const int my_row0 = 4 * g4 + 2 * hi;   // this lane's two cells: rows my_row0, my_row0 + 1 of unit `unit`
+    const unsigned pub_off = (unsigned)(my_row0 * MH + unit) * 8u;
+    // gather: granule j of this thread is (other slice (slice + 1 + j/2) mod 8, row 8*(j&1) + tid/32, unit tid%32):
+    // one per-thread offset, everything else wave-uniform (scalar operand of the buffer load / LDS immediate)
+    const unsigned gvoff = (unsigned)((tid >> 5) * MH + (tid & 31)) * 8u;
+    const int lbase = (tid >> 5) * MLDH + (tid & 31);
+    constexpr unsigned LAYER_BYTES = 2u * MBT * MH * 8u;    // both parities of one layer
+    constexpr unsigned PARITY_BYTES = MBT * MH * 8u;
+    unsigned epoch = 0;
+    bool aborted = false;
+    __syncthreads();
+
+    // gather: issue / complete.  v[] stays in registers between the two so MFMAs can run in between.
+    mu32x2 v[MNG];
+    auto gather_issue = [&](unsigned base) {
+#pragma unroll
+        for (int j = 0; j < MNG; ++j) {
+            const unsigned uo = (unsigned)((j & 1) * 8 * MH + ((slice + 1 + (j >> 1)) & (MG - 1)) * 32) * 8u;
+            v[j] = __builtin_amdgcn_raw_buffer_load_b64(xrs, gvoff, base + uo, 16);
+        }
+    };
+    auto gather_finish = [&](unsigned base, float* sH) {
+        unsigned spins = 0;
+        while (true) {
+            bool ok = true;
+#pragma unroll
+            for (int j = 0; j < MNG; ++j) ok = ok && (v[j].y == epoch);
+            if (__all(ok)) break;
+            ++spins;
+            if (spins > M_SPIN_LIMIT ||
+                ((spins & 63u) == 0 && __hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                if (lane == 0) {
+                    __hip_atomic_store(p.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    sFlag[0] = 1;
+                }
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int j = 0; j < MNG; ++j) {
+                const unsigned uo = (unsigned)((j & 1) * 8 * MH + ((slice + 1 + (j >> 1)) & (MG - 1)) * 32) * 8u;
+                v[j] = __builtin_amdgcn_raw_buffer_load_b64(xrs, gvoff, base + uo, 16);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < MNG; ++j)
+            sH[lbase + (j & 1) * 8 * MLDH + ((slice + 1 + (j >> 1)) & (MG - 1)) * 32] = __uint_as_float(v[j].x);
+    };
+
+    for (int tile = group; tile < p.num_tiles && !aborted; tile += p.num_groups) {
+        const int b0 = tile * MBT;
+        __syncthreads();   // previous tile fully consumed
+        // ---- initial state: full h tiles to LDS, own c cells to registers, x_0 ----
+        for (int e = tid; e < MBT * MH; e += 256) {
+            const int row = e >> 8, u = e & 255;
+            const bool ok = b0 + row < p.B;
+            sH1[row * MLDH + u] = ok ? p.h1_0[(size_t)(b0 + row) * MH + u] : 0.f;
+            sH2[row * MLDH + u] = ok ? p.h2_0[(size_t)(b0 + row) * MH + u] : 0.f;
+        }
+        if (tid < MBT * 8) {
+            const int row = tid >> 3, o = tid & 7;
+            sX[tid] = (o < O && b0 + row < p.B) ? p.dec0[(size_t)(b0 + row) * O + o] : 0.f;
+        }
+        float c1[2], c2[2], h1c[2] = {0.f, 0.f}, h2c[2] = {0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int row = b0 + my_row0 + r;
+            c1[r] = (row < p.B) ? p.c1_0[(size_t)row * MH + unit] : 0.f;
+            c2[r] = (row < p.B) ? p.c2_0[(size_t)row * MH + unit] : 0.f;
+        }
+        __syncthreads();
+        const float* h1row = sH1 + n * MLDH + 4 * g4;
+        const float* h2row = sH2 + n * MLDH + 4 * g4;
+        f32x4 acc1[2], acc2[2];
+        // recurrent half of layer 1, step 0
+        acc1[0] = (f32x4){b1v[0], b1v[0], b1v[0], b1v[0]};
+        acc1[1] = (f32x4){b1v[1], b1v[1], b1v[1], b1v[1]};
+        mfma_begin2(acc1);
+        recur_agpr(acc1, h1row, w1);
+        mfma_end2(acc1);
+        __syncthreads();   // every wave has read h1_0 before the first own-slice write of h1_t into the tile
+        for (int t = 0; t < p.T_out; ++t) {
+            ++epoch;
+            const unsigned par = (epoch & 1u) * PARITY_BYTES;
+            // ================= layer 1: + x_t . K1, cell update =================
+            {
+                float xa[2];
+                xa[0] = sX[n * 8 + g4];
+                xa[1] = sX[n * 8 + 4 + g4];
+                mfma_begin2(acc1);
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    mfma_v(acc1[0], xa[s], k1[s][0]);
+                    mfma_v(acc1[1], xa[s], k1[s][1]);
+                }
+                mfma_end2(acc1);
+            }
+            {
+                // swap halves: lanes hi=0 keep rows 0,1 (own i,g; f,o from the partner), hi=1 keep rows 2,3
+                float snd[4], rcv[4];
+                snd[0] = hi ? acc1[0][0] : acc1[0][2];
+                snd[1] = hi ? acc1[0][1] : acc1[0][3];
+                snd[2] = hi ? acc1[1][0] : acc1[1][2];
+                snd[3] = hi ? acc1[1][1] : acc1[1][3];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) rcv[k] = swap_half(snd[k]);
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    const float zi = hi ? rcv[r] : acc1[0][r];
+                    const float zf = hi ? acc1[0][2 + r] : rcv[r];
+                    const float zg = hi ? rcv[2 + r] : acc1[1][r];
+                    const float zo = hi ? acc1[1][2 + r] : rcv[2 + r];
+                    const float ig = rec_act<ACT>(zi), fg = rec_act<ACT>(zf), gg = tanh_f(zg), og = rec_act<ACT>(zo);
+                    c1[r] = fmaf(fg, c1[r], ig * gg);
+                    h1c[r] = og * tanh_f(c1[r]);
+                    if (TRAIN) {
+                        const int row = b0 + my_row0 + r;
+                        if (row < p.B) {
+                            float* rp = p.res1 + (((size_t)t * p.B + row) * 5) * MH + unit;
+                            rp[0] = ig; rp[MH] = fg; rp[2 * MH] = gg; rp[3 * MH] = og; rp[4 * MH] = c1[r];
+                            p.H1[((size_t)t * p.B + row) * MH + unit] = h1c[r];
+                            p.C1[((size_t)t * p.B + row) * MH + unit] = c1[r];
+                        }
+                    }
+                }
+            }
+            // publish h1_t, then start the gather and run h2_{t-1} . R2 under it
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+                __builtin_amdgcn_raw_buffer_store_b64((mu32x2){__float_as_uint(h1c[r]), epoch}, xrs, pub_off + r * MH * 8, par, 16);
+#pragma unroll
+            for (int r = 0; r < 2; ++r) sH1[(my_row0 + r) * MLDH + unit] = h1c[r];
+            acc2[0] = (f32x4){b2v[0], b2v[0], b2v[0], b2v[0]};
+            acc2[1] = (f32x4){b2v[1], b2v[1], b2v[1], b2v[1]};
+            gather_issue(par);
+            mfma_begin2(acc2);
+            recur_agpr(acc2, h2row, w2);
+            mfma_end2(acc2);
+            gather_finish(par, sH1);
+            __syncthreads();   // barrier D: the whole h1_t tile is in LDS; every wave is done reading sH2
+            if (sFlag[0]) { aborted = true; break; }
+            // ================= layer 2: + h1_t . K2 (streamed), cell update =================
+            mfma_begin2(acc2);
+            recur_stream(acc2, h1row, krs, kvoff);
+            mfma_end2(acc2);
+            {
+                float snd[4], rcv[4];
+                snd[0] = hi ? acc2[0][0] : acc2[0][2];
+                snd[1] = hi ? acc2[0][1] : acc2[0][3];
+                snd[2] = hi ? acc2[1][0] : acc2[1][2];
+                snd[3] = hi ? acc2[1][1] : acc2[1][3];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) rcv[k] = swap_half(snd[k]);
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    const float zi = hi ? rcv[r] : acc2[0][r];
+                    const float zf = hi ? acc2[0][2 + r] : rcv[r];
+                    const float zg = hi ? rcv[2 + r] : acc2[1][r];
+                    const float zo = hi ? acc2[1][2 + r] : rcv[2 + r];
+                    const float ig = rec_act<ACT>(zi), fg = rec_act<ACT>(zf), gg = tanh_f(zg), og = rec_act<ACT>(zo);
+                    c2[r] = fmaf(fg, c2[r], ig * gg);
+                    h2c[r] = og * tanh_f(c2[r]);
+                    if (TRAIN) {
+                        const int row = b0 + my_row0 + r;
+                        if (row < p.B) {
+                            float* rp = p.res2 + (((size_t)t * p.B + row) * 5) * MH + unit;
+                            rp[0] = ig; rp[MH] = fg; rp[2 * MH] = gg; rp[3 * MH] = og; rp[4 * MH] = c2[r];
+                            p.H2[((size_t)t * p.B + row) * MH + unit] = h2c[r];
+                            p.C2[((size_t)t * p.B + row) * MH + unit] = c2[r];
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+                __builtin_amdgcn_raw_buffer_store_b64((mu32x2){__float_as_uint(h2c[r]), epoch}, xrs, pub_off + r * MH * 8,
+                                                      LAYER_BYTES + par, 16);
+#pragma unroll
+            for (int r = 0; r < 2; ++r) sH2[(my_row0 + r) * MLDH + unit] = h2c[r];
+            const bool more = (t + 1 < p.T_out);
+            gather_issue(LAYER_BYTES + par);
+            // recurrent half of layer 1 for step t+1 under the gather of h2_t
+            acc1[0] = (f32x4){b1v[0], b1v[0], b1v[0], b1v[0]};
+            acc1[1] = (f32x4){b1v[1], b1v[1], b1v[1], b1v[1]};
+            if (more) {
+                mfma_begin2(acc1);
+                recur_agpr(acc1, h1row, w1);
+                mfma_end2(acc1);
+            }
+            gather_finish(LAYER_BYTES + par, sH2);
+            __syncthreads();   // barrier G: the whole h2_t tile is in LDS
+            if (sFlag[0]) { aborted = true; break; }
+            // ================= head: p = tanh(h2 Wd + bd), m = tanh(p Wp + add) =================
+            {
+                // thread (row = tid >> 4, part = tid & 15) sums 16 hidden units; the 16 parts meet by butterfly
+                const int row = tid >> 4, part = tid & 15;
+                float ps[8];
+#pragma unroll
+                for (int o = 0; o < 8; ++o) ps[o] = 0.f;
+                const float* hr = sH2 + row * MLDH + part * 16;
+                const float* wr = sWd + part * 16 * 8;
+#pragma unroll
+                for (int k4 = 0; k4 < 4; ++k4) {
+                    const f32x4 hv = *(const f32x4*)(hr + 4 * k4);
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) {
+                        const f32x4 wa = *(const f32x4*)(wr + (4 * k4 + kk) * 8), wb = *(const f32x4*)(wr + (4 * k4 + kk) * 8 + 4);
+#pragma unroll
+                        for (int o = 0; o < 4; ++o) {
+                            ps[o] = fmaf(hv[kk], wa[o], ps[o]);
+                            ps[4 + o] = fmaf(hv[kk], wb[o], ps[4 + o]);
+                        }
+                    }
+                }
+                // fixed-order butterfly over the 16 parts (lanes of one 16-lane row)
+#pragma unroll
+                for (int o = 0; o < 8; ++o)
+#pragma unroll
+                    for (int msk = 8; msk >= 1; msk >>= 1) ps[o] += __shfl_xor(ps[o], msk);
+                float pv[8];
+#pragma unroll
+                for (int o = 0; o < 8; ++o) pv[o] = (o < O) ? tanh_f(ps[o] + p.bd[o]) : 0.f;
+                const int brow = b0 + row;
+                if (part < 8) {
+                    float z = 0.f, mine = 0.f;
+                    if (part < O && brow < p.B) z = p.oth_proj[(size_t)brow * p.oth_sb + (size_t)t * p.oth_st + part];
+#pragma unroll
+                    for (int o = 0; o < 8; ++o) {
+                        z = fmaf(pv[o], sWp[o * 8 + part], z);
+                        mine = (part == o) ? pv[o] : mine;
+                    }
+                    const float mv = (part < O) ? tanh_f(z) : 0.f;
+                    sX[row * 8 + part] = mv;   // x_{t+1}
+                    if (slice == 0 && part < O && brow < p.B) {
+                        p.out[((size_t)t * p.B + brow) * O + part] = mv;
+                        if (TRAIN) p.P[((size_t)t * p.B + brow) * O + part] = mine;
+                    }
+                }
+            }
+            __syncthreads();   // barrier H: x_{t+1} is in LDS
+        }
+        if (!aborted) {
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int row = b0 + my_row0 + r;
+                if (row < p.B) {
+                    if (p.h1T) p.h1T[(size_t)row * MH + unit] = h1c[r];
+                    if (p.c1T) p.c1T[(size_t)row * MH + unit] = c1[r];
+                    if (p.h2T) p.h2T[(size_t)row * MH + unit] = h2c[r];
+                    if (p.c2T) p.c2T[(size_t)row * MH + unit] = c2[r];
+                }
+            }
+        }
+    }
+}
+
+// K2 (H,4H) -> fragments in the order recur_stream reads them:
+// [slice 8][wave 4][k-block j 16][tile 2][lane 64][k-sub s 4], value = K2[16j + 4*(lane>>4) + s][gate column]
+__global__ __launch_bounds__(256) void mix_decoder_pack_k2_kernel(const float* __restrict__ K2, float* __restrict__ out) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;   // one float each, 256*1024 in total
+    if (idx >= MH * 4 * MH) return;
+    const int s = idx & 3, lane = (idx >> 2) & 63, tile = (idx >> 8) & 1, j = (idx >> 9) & 15, wave = (idx >> 13) & 3,
+              slice = idx >> 15;
+    const int n = lane & 15, g4 = lane >> 4;
+    const int unit = 32 * slice + 8 * wave + (n & 7);
+    const int gate = 2 * tile + (n >> 3);
+    out[idx] = K2[(size_t)(16 * j + 4 * g4 + s) * (4 * MH) + gate * MH + unit];
+}
+
+size_t mix_decoder_workspace_bytes(int B) {
+    const int tiles = (B + MBT - 1) / MBT;
+    int groups = tiles < 32 ? tiles : 32;
+    if (groups < 1) groups = 1;
+    return kStatusBytes + (size_t)groups * 4 * MBT * MH * sizeof(unsigned long long) + sizeof(float) * (size_t)MH * 4 * MH;
+}
+
+int mix_decoder_launch(MixDecParams p, const float* K2, int act, int train, void* workspace, hipStream_t stream) {
+    if (p.B == 0 || p.T_out == 0) return FOV_OK;
+    p.num_tiles = (p.B + MBT - 1) / MBT;
+    p.num_groups = p.num_tiles < 32 ? p.num_tiles : 32;   // 8 workgroups per group, one per CU
+    const size_t xch_bytes = (size_t)p.num_groups * 4 * MBT * MH * sizeof(unsigned long long);
+    p.status = (unsigned*)workspace;
+    p.xch = (unsigned long long*)((char*)workspace + kStatusBytes);
+    float* k2p = (float*)((char*)workspace + kStatusBytes + xch_bytes);
+    p.K2p = k2p;
+    hipError_t e = hipMemsetAsync(workspace, 0, kStatusBytes + xch_bytes, stream);
+    if (e != hipSuccess) { set_error("hipMemsetAsync: %s", hipGetErrorString(e)); return FOV_ERR_LAUNCH; }
+    hipLaunchKernelGGL(mix_decoder_pack_k2_kernel, dim3(MH * 4 * MH / 256), dim3(256), 0, stream, K2, k2p);
+    const size_t lds = sizeof(float) * (2 * MBT * MLDH + MBT * 8 + MH * 8 + 64) + 64;
+    void (*kern)(MixDecParams) = nullptr;
+    if (act == FOV_ACT_HARD_SIGMOID) kern = train ? mix_decoder_kernel<FOV_ACT_HARD_SIGMOID, true> : mix_decoder_kernel<FOV_ACT_HARD_SIGMOID, false>;
+    else kern = train ? mix_decoder_kernel<FOV_ACT_SIGMOID, true> : mix_decoder_kernel<FOV_ACT_SIGMOID, false>;
+    e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return FOV_ERR_LAUNCH; }
+    hipLaunchKernelGGL(kern, dim3(p.num_groups * MG), dim3(256), lds, stream, p);
+    e = hipGetLastError();
+    if (e != hipSuccess) { set_error("mix_decoder launch: %s", hipGetErrorString(e)); return FOV_ERR_LAUNCH; }
+    return FOV_OK;
+}
+
+}  // namespace fov

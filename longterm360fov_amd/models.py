@@ -442,43 +442,49 @@ class OthersMixingSeq2Seq:
             self._ws = ops.Workspace()
         return self._dw
 
-    def predict(self, x, batch_size=None, verbose=0):
+    def predict_device(self, e, oth, xin):
+        """The whole prediction on device tensors: e (B,T_in,F_enc), oth (B,T_out,U-1,6), xin (B,1,6) -> (B,T_out,6)
+        device tensor (a transposed view of the step-major buffer the kernels write)."""
         import torch
         from . import ops
-        enc, others, dec0 = (_as_f32(a) for a in x)
         dw = self._device_weights()
         act, impl, ws = self.recurrent_activation, self.impl, self._ws
         H, O = self.latent_dim, self.num_decoder_tokens
+        B, T_in = e.shape[0], e.shape[1]
+        T_out = oth.shape[1]
+        hs1, h1, c1 = ops.lstm_seq(e, dw["enc1_K"], dw["enc1_R"], dw["enc1_b"], act=act, impl=impl, workspace=ws)
+        zx = ops.matmul(hs1.reshape(B * T_in, H), dw["enc2_K"]).reshape(B, T_in, 4 * H)
+        _, h2, c2 = ops.lstm_seq_zx(zx, dw["enc2_R"], dw["enc2_b"], act=act, impl=impl, return_sequences=False, workspace=ws)
+        # others half of the mixing layer for every step at once (bias folded in)
+        oth_proj = ops.dense(oth.reshape(B * T_out, -1), dw["mix_W_oth"], dw["mix_b"], activation=None).reshape(B, T_out, O)
+        out = torch.empty((T_out, B, O), dtype=torch.float32, device=self.device)   # step-major: row t = m_t
+        p = torch.empty((B, O), dtype=torch.float32, device=self.device)
+        fused_head = O <= 8 and H % 4 == 0
+        for t in range(T_out):
+            _, h1, c1 = ops.lstm_seq(xin.reshape(B, 1, O), dw["dec1_K"], dw["dec1_R"], dw["dec1_b"], h1, c1, act=act,
+                                     impl=impl, return_sequences=False, workspace=ws)
+            zx = ops.matmul(h1, dw["dec2_K"]).reshape(B, 1, 4 * H)
+            _, h2, c2 = ops.lstm_seq_zx(zx, dw["dec2_R"], dw["dec2_b"], h2, c2, act=act, impl=impl,
+                                        return_sequences=False, workspace=ws)
+            if fused_head:   # Dense(tanh) + mixing Dense(tanh) in one launch, written straight into the output row
+                ops.mix_head_fwd(h2, dw["dense_W"], dw["dense_b"], dw["mix_W_pred"], oth_proj[:, t], p, out[t])
+            else:
+                pp = ops.dense(h2, dw["dense_W"], dw["dense_b"], activation="tanh")
+                ops.dense_add(pp, dw["mix_W_pred"], None, oth_proj[:, t], activation="tanh", out=out[t])
+            xin = out[t]
+        return out.transpose(0, 1)
+
+    def predict(self, x, batch_size=None, verbose=0):
+        import torch
+        enc, others, dec0 = (_as_f32(a) for a in x)
+        self._device_weights()
         n = enc.shape[0]
-        T_out = others.shape[1]
+        T_out, O = others.shape[1], self.num_decoder_tokens
         bs = n if not batch_size else int(batch_size)
         outs = []
         for lo in range(0, n, max(bs, 1)):
-            e = torch.from_numpy(enc[lo:lo + bs]).to(self.device)
-            oth = torch.from_numpy(others[lo:lo + bs]).to(self.device)
-            xin = torch.from_numpy(dec0[lo:lo + bs]).to(self.device)
-            B, T_in = e.shape[0], e.shape[1]
-            hs1, h1, c1 = ops.lstm_seq(e, dw["enc1_K"], dw["enc1_R"], dw["enc1_b"], act=act, impl=impl, workspace=ws)
-            zx = ops.matmul(hs1.reshape(B * T_in, H), dw["enc2_K"]).reshape(B, T_in, 4 * H)
-            _, h2, c2 = ops.lstm_seq_zx(zx, dw["enc2_R"], dw["enc2_b"], act=act, impl=impl, return_sequences=False, workspace=ws)
-            # others half of the mixing layer for every step at once (bias folded in)
-            oth_proj = ops.dense(oth.reshape(B * T_out, -1), dw["mix_W_oth"], dw["mix_b"], activation=None).reshape(B, T_out, O)
-            out = torch.empty((T_out, B, O), dtype=torch.float32, device=self.device)   # step-major: row t = m_t
-            p = torch.empty((B, O), dtype=torch.float32, device=self.device)
-            fused_head = O <= 8 and H % 4 == 0
-            for t in range(T_out):
-                _, h1, c1 = ops.lstm_seq(xin.reshape(B, 1, O), dw["dec1_K"], dw["dec1_R"], dw["dec1_b"], h1, c1, act=act,
-                                         impl=impl, return_sequences=False, workspace=ws)
-                zx = ops.matmul(h1, dw["dec2_K"]).reshape(B, 1, 4 * H)
-                _, h2, c2 = ops.lstm_seq_zx(zx, dw["dec2_R"], dw["dec2_b"], h2, c2, act=act, impl=impl,
-                                            return_sequences=False, workspace=ws)
-                if fused_head:   # Dense(tanh) + mixing Dense(tanh) in one launch, written straight into the output row
-                    ops.mix_head_fwd(h2, dw["dense_W"], dw["dense_b"], dw["mix_W_pred"], oth_proj[:, t], p, out[t])
-                else:
-                    pp = ops.dense(h2, dw["dense_W"], dw["dense_b"], activation="tanh")
-                    ops.dense_add(pp, dw["mix_W_pred"], None, oth_proj[:, t], activation="tanh", out=out[t])
-                xin = out[t]
-            outs.append(out.transpose(0, 1).cpu().numpy())
+            d = lambda a: torch.from_numpy(a[lo:lo + bs]).to(self.device)
+            outs.append(self.predict_device(d(enc), d(others), d(dec0)).cpu().numpy())
         self._ws.check()
         return np.concatenate(outs, axis=0) if outs else np.zeros((0, T_out, O), np.float32)
 

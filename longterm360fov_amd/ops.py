@@ -317,6 +317,36 @@ def dense_add(x, W, b, add, activation="tanh", out=None):
     return y
 
 
+def mix_decoder_supported(H, O):
+    return H == 256 and O <= 8
+
+
+def mix_decoder(dec0, h1, c1, h2, c2, oth_proj, w, mix_Wp, T_out, act="sigmoid", workspace=None, out=None, train=None,
+                final_state=None):
+    """The whole unrolled others-mixing decoder in one launch -> out (T_out,B,O) step-major.
+    w: dict with dec1_K/R/b, dec2_K/R/b, dense_W/b; oth_proj (B,T_out,O) view (last dim contiguous);
+    train: optional dict of preallocated P, H1, C1, H2, C2 (T_out,B,.), res1, res2 (T_out,B,5,H);
+    final_state: optional (h1T, c1T, h2T, c2T) tensors."""
+    dec0, h1, c1, h2, c2 = (_dev(t, "state") for t in (dec0, h1, c1, h2, c2))
+    B, H = h1.shape
+    O = w["dense_W"].shape[1]
+    assert oth_proj.is_cuda and oth_proj.dtype == torch.float32 and oth_proj.shape == (B, T_out, O) and oth_proj.stride(2) == 1
+    out = torch.empty((T_out, B, O), dtype=torch.float32, device=h1.device) if out is None else _dev(out, "out")
+    L = _lib.lib()
+    ws = workspace or default_workspace(h1.device)
+    buf = ws.get(L.fov_mix_decoder_workspace_bytes(B, H), h1.device)
+    tr = [None] * 7 if train is None else [_dev(train[k], k) for k in ("P", "H1", "C1", "H2", "C2", "res1", "res2")]
+    fs = [None] * 4 if final_state is None else [_dev(t, "final state") for t in final_state]
+    check(L.fov_mix_decoder_fwd(_ptr(dec0.reshape(B, O)), _ptr(h1), _ptr(c1), _ptr(h2), _ptr(c2), oth_proj.data_ptr(),
+                                oth_proj.stride(0), oth_proj.stride(1),
+                                _ptr(_dev(w["dec1_K"], "K1")), _ptr(_dev(w["dec1_R"], "R1")), _ptr(_dev(w["dec1_b"], "b1")),
+                                _ptr(_dev(w["dec2_K"], "K2")), _ptr(_dev(w["dec2_R"], "R2")), _ptr(_dev(w["dec2_b"], "b2")),
+                                _ptr(_dev(w["dense_W"], "Wd")), _ptr(_dev(w["dense_b"], "bd")), _ptr(_dev(mix_Wp, "Wp")),
+                                _ptr(out), *[_ptr(t) for t in fs], *[_ptr(t) for t in tr],
+                                B, T_out, H, O, act_code(act), buf.data_ptr(), buf.numel(), _stream()))
+    return out
+
+
 def mix_head_fwd(h, dense_W, dense_b, mix_Wp, add, p_out, m_out):
     """p = tanh(h dense_W + dense_b), m = tanh(p mix_Wp + add) in one launch; add (N,O) may be a strided row view."""
     h, dense_W, dense_b, mix_Wp = _dev(h, "h"), _dev(dense_W, "dense_W"), _dev(dense_b, "dense_b"), _dev(mix_Wp, "mix_Wp")

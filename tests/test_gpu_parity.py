@@ -397,3 +397,28 @@ def test_device_windowing_matches_reference_fixture(golden_dir):
     for got, key in ((enc, "s5_enc"), (fut, "s5_fut"), (fut_in, "s5_fut_in")):
         np.testing.assert_array_equal(got.cpu().numpy(), g[key].astype(np.float32))
     assert (enc[:, :, -1] == fut_in[:, :, 0]).all()       # the reference's sanity check
+
+
+@pytest.mark.parametrize("B,T_in,T_out,act", [(16, 3, 4, "sigmoid"), (37, 2, 3, "hard_sigmoid"), (512, 4, 10, "sigmoid"),
+                                              (600, 2, 2, "sigmoid")])
+def test_fused_mixing_decoder_matches_oracle(B, T_in, T_out, act):
+    """a4: the unrolled no-teacher-forcing decoder with others mixing in ONE launch (fov_mix_decoder_fwd) against the
+    oracle's others_mixing_forward; encoder states come from the library's layer kernels.  B = 600 makes a group
+    visit more than one tile; B = 37 leaves a ragged last tile."""
+    ops = _ops()
+    H, U, NO = 256, 34, 6
+    w = O.init_others_mixing(300 + B, H=H, num_user=U, bias_noise=0.1)
+    enc, dec0, tgt, oth = O.synthetic_batch(301 + B, B, T_in, T_out, num_others=U - 1)
+    ref = O.others_mixing_forward(enc.astype(np.float64), oth.astype(np.float64), dec0.astype(np.float64),
+                                  {k: v.astype(np.float64) for k, v in w.items()}, act=act)
+    dw = devw(w)
+    n_oth = (U - 1) * NO
+    Wm_o, Wm_p = dw["mix_W"][:n_oth].contiguous(), dw["mix_W"][n_oth:].contiguous()
+    hs1, h1, c1 = ops.lstm_seq(dev(enc), dw["enc1_K"], dw["enc1_R"], dw["enc1_b"], act=act)
+    zx = ops.matmul(hs1.reshape(B * T_in, H), dw["enc2_K"]).reshape(B, T_in, 4 * H)
+    _, h2, c2 = ops.lstm_seq_zx(zx, dw["enc2_R"], dw["enc2_b"], act=act, return_sequences=False)
+    oth_proj = ops.dense(dev(oth).reshape(B * T_out, n_oth), Wm_o, dw["mix_b"], activation=None).reshape(B, T_out, NO)
+    ws = ops.Workspace()
+    out = ops.mix_decoder(dev(dec0), h1, c1, h2, c2, oth_proj, dw, Wm_p, T_out, act=act, workspace=ws)
+    ws.check()
+    assert_parity(out.transpose(0, 1), ref, "fused mixing decoder B=%d" % B)
