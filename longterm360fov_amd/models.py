@@ -309,6 +309,8 @@ class OthersMixingSeq2Seq:
     projection as an MFMA GEMM, layer-2 step, Dense, mixing Dense); the "others" half of the mixing
     product is hoisted out of the loop as one GEMV batch."""
 
+    fused_decoder = True   # H = 256: run the unrolled decoder as ONE launch (fov_mix_decoder_fwd); False = step-wise calls
+
     def __init__(self, num_encoder_tokens=None, num_decoder_tokens=6, latent_dim=32, num_user=34,
                  recurrent_activation=None, seed=None, impl="auto", device="cuda"):
         self.num_encoder_tokens = 3 * cfg.fps if num_encoder_tokens is None else int(num_encoder_tokens)
@@ -458,6 +460,10 @@ class OthersMixingSeq2Seq:
         # others half of the mixing layer for every step at once (bias folded in)
         oth_proj = ops.dense(oth.reshape(B * T_out, -1), dw["mix_W_oth"], dw["mix_b"], activation=None).reshape(B, T_out, O)
         out = torch.empty((T_out, B, O), dtype=torch.float32, device=self.device)   # step-major: row t = m_t
+        if self.fused_decoder and ops.mix_decoder_supported(H, O):
+            # the whole unrolled decoder + mixing head in one persistent launch
+            ops.mix_decoder(xin, h1, c1, h2, c2, oth_proj, dw, dw["mix_W_pred"], T_out, act=act, workspace=ws, out=out)
+            return out.transpose(0, 1)
         p = torch.empty((B, O), dtype=torch.float32, device=self.device)
         fused_head = O <= 8 and H % 4 == 0
         for t in range(T_out):

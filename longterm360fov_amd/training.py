@@ -110,9 +110,13 @@ _MIX_ORDER = ("enc1_K", "enc1_R", "enc1_b", "enc2_K", "enc2_R", "enc2_b", "dec1_
 class OthersMixingTrainer:
     """Training step of the 2+2-layer others-mixing model WITHOUT teacher forcing
     (mycode/given_others_gt_mean_var_seq2seq.py:203-308: Adam + MSE on the unrolled decoder whose output
-    is fed back).  Round-1 structure: the unrolled decoder is walked step by step with the library's
-    layer kernels (T = 1 calls), forward and backward; the feedback path's gradient is the dx of the
-    first decoder layer.  Gradients accumulate into ONE flat buffer (one all-reduce under DP)."""
+    is fed back).  Forward of the unrolled decoder: ONE persistent launch (fov_mix_decoder_fwd, H = 256) that
+    writes the time-major tape, or step-wise layer calls for other shapes.  Backward: the decoder is walked
+    step by step (data path only: mixing head, layer 2, layer 1; the feedback path's gradient is the dx of the
+    first decoder layer), then every weight gradient is one product over all steps.  Gradients accumulate into
+    ONE flat buffer (one all-reduce under DP)."""
+
+    fused_decoder = True   # H = 256: forward of the unrolled decoder as ONE launch; False = step-wise calls
 
     def __init__(self, weights, act="sigmoid", impl="auto", optimizer="adam", lr=1e-3, device="cuda"):
         self.act, self.impl, self.optimizer, self.lr, self.device = act, impl, optimizer, float(lr), device
@@ -165,7 +169,12 @@ class OthersMixingTrainer:
         P = e(T_out, B, O)
         H1[0].copy_(h1); C1[0].copy_(c1); H2[0].copy_(h2); C2[0].copy_(c2)
         X[0].copy_(dec0.reshape(B, O))
-        for t in range(T_out):
+        fused = self.fused_decoder and ops.mix_decoder_supported(H, O)
+        if fused:   # the whole unrolled forward in one persistent launch, writing the same tape
+            ops.mix_decoder(X[0], H1[0], C1[0], H2[0], C2[0], oth_proj, w, Wm_p_c, T_out, act=act, workspace=ws, out=M,
+                            train={"P": P, "H1": H1[1:], "C1": C1[1:], "H2": H2[1:], "C2": C2[1:],
+                                   "res1": R1.view(T_out, B, 5, H), "res2": R2.view(T_out, B, 5, H)})
+        for t in range(0 if fused else T_out):
             # every kernel writes straight into its row of the tape: no copies inside the loop
             ops.lstm_seq_train(X[t].view(B, 1, O), w["dec1_K"], w["dec1_R"], w["dec1_b"], H1[t], C1[t], act=act, impl=impl,
                                workspace=ws, out=(H1[t + 1].view(B, 1, H), None, C1[t + 1], R1[t]))

@@ -303,6 +303,14 @@ def test_others_mixing_gradients_and_training(H, B, U, T_in, T_out, act):
         err = np.abs(a - g_ref[k]).max()
         print("mixing H%d grad %-8s max|ref| %.3e  max err %.3e" % (H, k, scale, err))
         assert err <= 1e-4 * scale + 1e-9, (k, err, scale)
+    if H == 256:   # the fused forward and the step-wise forward leave the same tape: identical gradients
+        tr2 = OthersMixingTrainer(w, act=act)
+        tr2.fused_decoder = False
+        loss2, y2 = tr2.forward_backward(dev(enc), dev(oth), dev(dec0), dev(tgt))
+        assert abs(float(loss2.item()) - float(loss.item())) <= 1e-6 * abs(float(loss.item())) + 1e-9
+        for k in _MIX_ORDER:
+            d = (tr.g[k] - tr2.g[k]).abs().max().item()
+            assert d <= 2e-5 * tr2.g[k].abs().max().item() + 1e-9, (k, d)
     losses = [float(tr.train_step(dev(enc), dev(oth), dev(dec0), dev(tgt)).item()) for _ in range(4)]
     assert losses[-1] < losses[0]
 
