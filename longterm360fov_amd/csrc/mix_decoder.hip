@@ -14,16 +14,19 @@
 // swap what the other needs (DPP row_ror:8), so that every lane ends up with all four gates of one unit for
 // two sequences: the cell update is lane-local and c1, c2 never leave registers.
 //   R1, R2 slices : 128 + 128 AGPRs per lane for the whole launch (MFMA B operands)
-//   K2 slice      : 128 KB per workgroup would need all of the LDS next to the two h tiles, so it is streamed
-//                   from L2 each step as 16-byte B-operand fragments, four loads in flight, from a copy of K2
-//                   pre-packed in exactly that order (mix_decoder_pack_k2)
+//   K2 slice      : 128 KB per workgroup; 7/8 of it sits in LDS as lane-linear B-operand fragments (one
+//                   ds_read_b128 = four MFMA steps), the last eighth in 16 VGPRs - all of it would need the whole
+//                   LDS next to the two h tiles.  Loaded once from a copy of K2 pre-packed in fragment order
+//                   (mix_decoder_pack_k2).  (Streaming it from L2 every step, four loads in flight, was
+//                   latency-bound: 19 us per step.)
 //   h1, h2 tiles  : 16 x 256 each in LDS (MFMA A operands), exchanged once per layer and step as 8-byte
 //                   {value, epoch} granules (sc1 stores / sc1 loads, two parity buffers, bounded spins) - the
 //                   protocol of lstm_cluster.hip
 //   overlap       : the gather of h1_t runs under h2_{t-1} . R2, the gather of h2_t under h1_t . R1 of the
 //                   next step
 //   head          : every workgroup computes p and m of its 16 sequences from the gathered h2 tile (O = 6:
-//                   cheaper than a third exchange); slice 0 stores them
+//                   cheaper than a third exchange) - Dense on the matrix pipe, K split over the four waves -
+//                   slice 0 stores them
 // TRAIN additionally stores what the backward pass reads: reserves (i,f,g,o,c) of both layers, h1/h2/c1/c2
 // of every step, p.
 #include <stdlib.h>
@@ -61,6 +64,25 @@ __device__ __forceinline__ float swap_half(float v) {
 
 }  // namespace
 
+// Diagnostic build only (-DFOV_STAMPS, tools/stamp_mix_decoder.py): s_memtime stamps of one wave per step.
+#ifdef FOV_STAMPS
+constexpr int MSTAMP_SLOTS = 12;
+constexpr int MSTAMP_STEPS = 32;
+__device__ unsigned long long g_mix_stamps[MSTAMP_STEPS][MSTAMP_SLOTS];
+#define MIX_STAMP(slot)                                                                        \
+    do {                                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                     \
+        if (stamp_on && t < MSTAMP_STEPS) {                                                    \
+            unsigned long long t_;                                                             \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");        \
+            g_mix_stamps[t][slot] = t_;                                                        \
+        }                                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                     \
+    } while (0)
+#else
+#define MIX_STAMP(slot) do { } while (0)
+#endif
+
 // acc[tile] += A(h tile rows, LDS) . W (AGPR resident, [16 k-blocks][4][2 tiles])
 __device__ __forceinline__ void recur_agpr(f32x4 (&acc)[2], const float* hrow, const float (&w)[16][4][2]) {
     f32x4 a = *(const f32x4*)hrow;
@@ -77,33 +99,28 @@ __device__ __forceinline__ void recur_agpr(f32x4 (&acc)[2], const float* hrow, c
     }
 }
 
-// acc[tile] += A(h tile rows, LDS) . K2 slice streamed from the packed copy: block (j, tile) = 64 lanes x 4 k-subs.
-// Buffer loads with the block offset in the scalar operand: one VGPR of address for all 32 loads (plain global
-// loads would make hipcc keep 32 hoisted 64-bit addresses alive across the whole step loop).
-__device__ __forceinline__ f32x4 k2_frag(const __amdgpu_buffer_rsrc_t rs, unsigned voff, int block) {
-    const mu32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, block * 1024, 0);
-    return (f32x4){__uint_as_float(t[0]), __uint_as_float(t[1]), __uint_as_float(t[2]), __uint_as_float(t[3])};
-}
-__device__ __forceinline__ void recur_stream(f32x4 (&acc)[2], const float* hrow, const __amdgpu_buffer_rsrc_t rs, unsigned voff) {
-    f32x4 b[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) b[i] = k2_frag(rs, voff, i);   // (j,tile) = (0,0) (0,1) (1,0) (1,1)
+// acc[tile] += A(h tile rows, LDS) . K2 slice: fragment blocks (j, tile), j < 14, from LDS (this wave's region,
+// lane-linear: one ds_read_b128 = the four k-subs of a block), blocks of j = 14, 15 from registers.
+constexpr int K2_LDS_BLOCKS = 28;
+__device__ __forceinline__ void recur_k2(f32x4 (&acc)[2], const float* hrow, const float* sK2l, const f32x4 (&kr)[4]) {
     f32x4 a = *(const f32x4*)hrow;
+    f32x4 b0 = *(const f32x4*)sK2l, b1 = *(const f32x4*)(sK2l + 256);
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
-        f32x4 an = a;
+        f32x4 an = a, n0 = b0, n1 = b1;
         if (j + 1 < 16) an = *(const f32x4*)(hrow + 16 * (j + 1));
-        const f32x4 b0 = b[(2 * j) & 3], b1 = b[(2 * j + 1) & 3];
-        if (j + 2 < 16) {
-            b[(2 * j) & 3] = k2_frag(rs, voff, 2 * j + 4);
-            b[(2 * j + 1) & 3] = k2_frag(rs, voff, 2 * j + 5);
+        if (2 * (j + 1) < K2_LDS_BLOCKS) {
+            n0 = *(const f32x4*)(sK2l + (2 * j + 2) * 256);
+            n1 = *(const f32x4*)(sK2l + (2 * j + 3) * 256);
         }
+        const f32x4 c0 = (2 * j < K2_LDS_BLOCKS) ? b0 : kr[2 * j - K2_LDS_BLOCKS];
+        const f32x4 c1 = (2 * j < K2_LDS_BLOCKS) ? b1 : kr[2 * j + 1 - K2_LDS_BLOCKS];
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            mfma_v(acc[0], a[s], b0[s]);
-            mfma_v(acc[1], a[s], b1[s]);
+            mfma_v(acc[0], a[s], c0[s]);
+            mfma_v(acc[1], a[s], c1[s]);
         }
-        a = an;
+        a = an; b0 = n0; b1 = n1;
     }
 }
 
@@ -116,6 +133,8 @@ __global__ __launch_bounds__(256, 1) void mix_decoder_kernel(MixDecParams p) {
     float* sWd = sX + MBT * 8;               // [256][8] Dense kernel, rows padded to 8
     float* sWp = sWd + MH * 8;               // [8][8]   mixing kernel (pred part)
     int* sFlag = (int*)(sWp + 64);
+    float* sPart = sWp + 64 + 16;            // [4 waves][16 rows][16 cols] partial Dense products
+    float* sK2 = sPart + 4 * 256;            // [4 waves][28 blocks][64 lanes][4]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 15, g4 = lane >> 4;
@@ -147,6 +166,7 @@ __global__ __launch_bounds__(256, 1) void mix_decoder_kernel(MixDecParams p) {
             w1[j][s][1] = p.R1[k + col1];
             w2[j][s][0] = p.R2[k + col0];
             w2[j][s][1] = p.R2[k + col1];
+            if (s == 3) __builtin_amdgcn_sched_barrier(0);   // 16 loads at a time: the weights go to AGPRs chunk by chunk
         }
     // K1 (O <= 8 rows): MFMA step s uses input row k = 4*s + g4
     float k1[2][2];
@@ -157,16 +177,22 @@ __global__ __launch_bounds__(256, 1) void mix_decoder_kernel(MixDecParams p) {
         k1[s][1] = (k < O) ? p.K1[(size_t)k * H4 + col1] : 0.f;
     }
     const float b1v[2] = {p.b1[col0], p.b1[col1]}, b2v[2] = {p.b2[col0], p.b2[col1]};
+    const float bdv = ((tid & 15) < O) ? p.bd[tid & 15] : 0.f;   // Dense bias of this thread's head output
     for (int e = tid; e < MH * 8; e += 256) {
         const int k = e >> 3, o = e & 7;
         sWd[e] = (o < O) ? p.Wd[(size_t)k * O + o] : 0.f;
     }
     for (int e = tid; e < 64; e += 256) sWp[e] = ((e >> 3) < O && (e & 7) < O) ? p.Wp[(e >> 3) * O + (e & 7)] : 0.f;
-    // this wave's 32 KB of packed K2 fragments: block b at byte b*1024, lane fragment at lane*16
-    const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(p.K2p) + (size_t)(slice * 4 + wave) * 32 * 64 * 4, 0, 32 * 1024, 0x00020000);
-    const unsigned kvoff = lane * 16u;
-
+    // this wave's 32 KB of packed K2 fragments (block b at byte b*1024, lane fragment at lane*16): blocks 0..27
+    // into LDS, 28..31 into registers
+    float* sK2l = sK2 + (size_t)wave * K2_LDS_BLOCKS * 256 + lane * 4;
+    f32x4 k2r[4];
+    {
+        const f32x4* kp = (const f32x4*)p.K2p + (size_t)(slice * 4 + wave) * 32 * 64 + lane;
+        for (int b = 0; b < K2_LDS_BLOCKS; ++b) *(f32x4*)(sK2l + b * 256) = kp[64 * b];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) k2r[b] = kp[64 * (K2_LDS_BLOCKS + b)];
+    }
     // ---- exchange bookkeeping ----
     unsigned long long* xg = p.xch + (size_t)group * 4 * MBT * MH;   // [layer][parity][16][256]
     const __amdgpu_buffer_rsrc_t xrs =
@@ -181,6 +207,9 @@ __global__ __launch_bounds__(256, 1) void mix_decoder_kernel(MixDecParams p) {
     constexpr unsigned PARITY_BYTES = MBT * MH * 8u;
     unsigned epoch = 0;
     bool aborted = false;
+#ifdef FOV_STAMPS
+    const bool stamp_on = (blockIdx.x == 5 && tid == 0);
+#endif
     __syncthreads();
 
     // gather: issue / complete.  v[] stays in registers between the two so MFMAs can run in between.
@@ -243,6 +272,7 @@ __global__ __launch_bounds__(256, 1) void mix_decoder_kernel(MixDecParams p) {
             c2[r] = (row < p.B) ? p.c2_0[(size_t)row * MH + unit] : 0.f;
         }
         __syncthreads();
+        const int hd_o = tid & 15, hd_row = b0 + (tid >> 4);   // head: thread = (sequence, output)
         const float* h1row = sH1 + n * MLDH + 4 * g4;
         const float* h2row = sH2 + n * MLDH + 4 * g4;
         f32x4 acc1[2], acc2[2];
@@ -254,6 +284,9 @@ __global__ __launch_bounds__(256, 1) void mix_decoder_kernel(MixDecParams p) {
         mfma_end2(acc1);
         __syncthreads();   // every wave has read h1_0 before the first own-slice write of h1_t into the tile
         for (int t = 0; t < p.T_out; ++t) {
+            MIX_STAMP(0);
+            // the "others" term of the mixing layer for this step: requested now, consumed in the head
+            const float othv = (hd_o < O && hd_row < p.B) ? p.oth_proj[(size_t)hd_row * p.oth_sb + (size_t)t * p.oth_st + hd_o] : 0.f;
             ++epoch;
             const unsigned par = (epoch & 1u) * PARITY_BYTES;
             // ================= layer 1: + x_t . K1, cell update =================
@@ -298,6 +331,7 @@ __global__ __launch_bounds__(256, 1) void mix_decoder_kernel(MixDecParams p) {
                     }
                 }
             }
+            MIX_STAMP(1);
             // publish h1_t, then start the gather and run h2_{t-1} . R2 under it
 #pragma unroll
             for (int r = 0; r < 2; ++r)
@@ -310,13 +344,17 @@ __global__ __launch_bounds__(256, 1) void mix_decoder_kernel(MixDecParams p) {
             mfma_begin2(acc2);
             recur_agpr(acc2, h2row, w2);
             mfma_end2(acc2);
+            MIX_STAMP(2);
             gather_finish(par, sH1);
+            MIX_STAMP(3);
             __syncthreads();   // barrier D: the whole h1_t tile is in LDS; every wave is done reading sH2
+            MIX_STAMP(4);
             if (sFlag[0]) { aborted = true; break; }
             // ================= layer 2: + h1_t . K2 (streamed), cell update =================
             mfma_begin2(acc2);
-            recur_stream(acc2, h1row, krs, kvoff);
+            recur_k2(acc2, h1row, sK2l, k2r);
             mfma_end2(acc2);
+            MIX_STAMP(5);
             {
                 float snd[4], rcv[4];
                 snd[0] = hi ? acc2[0][0] : acc2[0][2];
@@ -352,6 +390,7 @@ __global__ __launch_bounds__(256, 1) void mix_decoder_kernel(MixDecParams p) {
 #pragma unroll
             for (int r = 0; r < 2; ++r) sH2[(my_row0 + r) * MLDH + unit] = h2c[r];
             const bool more = (t + 1 < p.T_out);
+            MIX_STAMP(6);
             gather_issue(LAYER_BYTES + par);
             // recurrent half of layer 1 for step t+1 under the gather of h2_t
             acc1[0] = (f32x4){b1v[0], b1v[0], b1v[0], b1v[0]};
@@ -361,57 +400,64 @@ __global__ __launch_bounds__(256, 1) void mix_decoder_kernel(MixDecParams p) {
                 recur_agpr(acc1, h1row, w1);
                 mfma_end2(acc1);
             }
+            MIX_STAMP(7);
             gather_finish(LAYER_BYTES + par, sH2);
+            MIX_STAMP(8);
             __syncthreads();   // barrier G: the whole h2_t tile is in LDS
+            MIX_STAMP(9);
             if (sFlag[0]) { aborted = true; break; }
             // ================= head: p = tanh(h2 Wd + bd), m = tanh(p Wp + add) =================
             {
-                // thread (row = tid >> 4, part = tid & 15) sums 16 hidden units; the 16 parts meet by butterfly
-                const int row = tid >> 4, part = tid & 15;
-                float ps[8];
+                // Dense on the matrix pipe: wave w contracts hidden units [64w, 64w+64) of the h2 tile (A operand)
+                // with Wd (B operand: column n = output o, zero for n >= 8); the four partial 16 x 16 products meet
+                // in LDS.  (A VALU version with per-thread slices of Wd in LDS cost 12 k cycles per step in bank
+                // conflicts - 39 % of the step.)
+                f32x4 dacc[2];
+                dacc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                dacc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                const float* hq = h2row + 64 * wave;
+                const float* wq = sWd + (64 * wave + 4 * g4) * 8 + (n & 7);
+                f32x4 hb[4];
+                float wb[4][4];
 #pragma unroll
-                for (int o = 0; o < 8; ++o) ps[o] = 0.f;
-                const float* hr = sH2 + row * MLDH + part * 16;
-                const float* wr = sWd + part * 16 * 8;
+                for (int b = 0; b < 4; ++b) {
+                    hb[b] = *(const f32x4*)(hq + 16 * b);
 #pragma unroll
-                for (int k4 = 0; k4 < 4; ++k4) {
-                    const f32x4 hv = *(const f32x4*)(hr + 4 * k4);
-#pragma unroll
-                    for (int kk = 0; kk < 4; ++kk) {
-                        const f32x4 wa = *(const f32x4*)(wr + (4 * k4 + kk) * 8), wb = *(const f32x4*)(wr + (4 * k4 + kk) * 8 + 4);
-#pragma unroll
-                        for (int o = 0; o < 4; ++o) {
-                            ps[o] = fmaf(hv[kk], wa[o], ps[o]);
-                            ps[4 + o] = fmaf(hv[kk], wb[o], ps[4 + o]);
-                        }
-                    }
+                    for (int ss = 0; ss < 4; ++ss) wb[b][ss] = (n < 8) ? wq[(16 * b + ss) * 8] : 0.f;
                 }
-                // fixed-order butterfly over the 16 parts (lanes of one 16-lane row)
+                mfma_begin2(dacc);
 #pragma unroll
-                for (int o = 0; o < 8; ++o)
+                for (int b = 0; b < 4; ++b)
 #pragma unroll
-                    for (int msk = 8; msk >= 1; msk >>= 1) ps[o] += __shfl_xor(ps[o], msk);
-                float pv[8];
+                    for (int ss = 0; ss < 4; ++ss) mfma_v(dacc[ss & 1], hb[b][ss], wb[b][ss]);
+                mfma_end2(dacc);
+                // partial (rows 4*g4 + r, column n) of this wave -> sPart[wave][row][col]
 #pragma unroll
-                for (int o = 0; o < 8; ++o) pv[o] = (o < O) ? tanh_f(ps[o] + p.bd[o]) : 0.f;
+                for (int r = 0; r < 4; ++r) sPart[(wave * 16 + 4 * g4 + r) * 16 + n] = dacc[0][r] + dacc[1][r];
+                __syncthreads();   // the four partials are in LDS
+                const int row = tid >> 4, o = tid & 15;   // the 16 lanes of a row group share a sequence
+                float pv = 0.f;
+                if (o < O) {
+                    pv = sPart[row * 16 + o] + sPart[(16 + row) * 16 + o] + sPart[(32 + row) * 16 + o] + sPart[(48 + row) * 16 + o];
+                    pv = tanh_f(pv + bdv);
+                }
                 const int brow = b0 + row;
-                if (part < 8) {
-                    float z = 0.f, mine = 0.f;
-                    if (part < O && brow < p.B) z = p.oth_proj[(size_t)brow * p.oth_sb + (size_t)t * p.oth_st + part];
+                float z = othv;
 #pragma unroll
-                    for (int o = 0; o < 8; ++o) {
-                        z = fmaf(pv[o], sWp[o * 8 + part], z);
-                        mine = (part == o) ? pv[o] : mine;
-                    }
-                    const float mv = (part < O) ? tanh_f(z) : 0.f;
-                    sX[row * 8 + part] = mv;   // x_{t+1}
-                    if (slice == 0 && part < O && brow < p.B) {
-                        p.out[((size_t)t * p.B + brow) * O + part] = mv;
-                        if (TRAIN) p.P[((size_t)t * p.B + brow) * O + part] = mine;
-                    }
+                for (int k = 0; k < 8; ++k) {
+                    const float pk = __shfl(pv, (lane & ~15) | k);   // p[row][k] from the lane that owns it
+                    z = fmaf(pk, sWp[k * 8 + (o & 7)], z);
+                }
+                const float mv = (o < O) ? tanh_f(z) : 0.f;
+                if (o < 8) sX[row * 8 + o] = mv;   // x_{t+1}
+                if (slice == 0 && o < O && brow < p.B) {
+                    p.out[((size_t)t * p.B + brow) * O + o] = mv;
+                    if (TRAIN) p.P[((size_t)t * p.B + brow) * O + o] = pv;
                 }
             }
+            MIX_STAMP(10);
             __syncthreads();   // barrier H: x_{t+1} is in LDS
+            MIX_STAMP(11);
         }
         if (!aborted) {
 #pragma unroll
@@ -460,7 +506,7 @@ int mix_decoder_launch(MixDecParams p, const float* K2, int act, int train, void
     hipError_t e = hipMemsetAsync(workspace, 0, kStatusBytes + xch_bytes, stream);
     if (e != hipSuccess) { set_error("hipMemsetAsync: %s", hipGetErrorString(e)); return FOV_ERR_LAUNCH; }
     hipLaunchKernelGGL(mix_decoder_pack_k2_kernel, dim3(MH * 4 * MH / 256), dim3(256), 0, stream, K2, k2p);
-    const size_t lds = sizeof(float) * (2 * MBT * MLDH + MBT * 8 + MH * 8 + 64) + 64;
+    const size_t lds = sizeof(float) * (2 * MBT * MLDH + MBT * 8 + MH * 8 + 64 + 16 + 4 * 256 + 4 * 28 * 256);
     void (*kern)(MixDecParams) = nullptr;
     if (act == FOV_ACT_HARD_SIGMOID) kern = train ? mix_decoder_kernel<FOV_ACT_HARD_SIGMOID, true> : mix_decoder_kernel<FOV_ACT_HARD_SIGMOID, false>;
     else kern = train ? mix_decoder_kernel<FOV_ACT_SIGMOID, true> : mix_decoder_kernel<FOV_ACT_SIGMOID, false>;
@@ -471,5 +517,11 @@ int mix_decoder_launch(MixDecParams p, const float* K2, int act, int train, void
     if (e != hipSuccess) { set_error("mix_decoder launch: %s", hipGetErrorString(e)); return FOV_ERR_LAUNCH; }
     return FOV_OK;
 }
+
+#ifdef FOV_STAMPS
+extern "C" int fov_debug_read_mix_stamps(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mix_stamps), sizeof(unsigned long long) * MSTAMP_STEPS * MSTAMP_SLOTS);
+}
+#endif
 
 }  // namespace fov
