@@ -57,6 +57,12 @@ __device__ __forceinline__ void mfma_begin2(f32x4 (&acc)[2]) { asm volatile("s_n
 __device__ __forceinline__ void mfma_end2(f32x4 (&acc)[2]) {
     asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" : "+v"(acc[0]), "+v"(acc[1]));
 }
+// hipcc pads nothing around inline asm and may place a VALU write of an MFMA operand (a select, a copy made under
+// register pressure) right before the asm MFMA that reads it: pin such operands and spend the two wait states
+__device__ __forceinline__ void mfma_guard2(float& a, float& b) { asm volatile("s_nop 1" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ void mfma_guard4(float& a, float& b, float& c, float& d) {
+    asm volatile("s_nop 1" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+}
 // value of the lane 8 positions away inside the same 16-lane row (row_ror:8)
 __device__ __forceinline__ float swap_half(float v) {
     return __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x128, 0xf, 0xf, false));
@@ -294,6 +300,7 @@ __global__ __launch_bounds__(256, 1) void mix_decoder_kernel(MixDecParams p) {
                 float xa[2];
                 xa[0] = sX[n * 8 + g4];
                 xa[1] = sX[n * 8 + 4 + g4];
+                mfma_guard2(xa[0], xa[1]);
                 mfma_begin2(acc1);
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
@@ -424,6 +431,7 @@ __global__ __launch_bounds__(256, 1) void mix_decoder_kernel(MixDecParams p) {
                     hb[b] = *(const f32x4*)(hq + 16 * b);
 #pragma unroll
                     for (int ss = 0; ss < 4; ++ss) wb[b][ss] = (n < 8) ? wq[(16 * b + ss) * 8] : 0.f;
+                    mfma_guard4(wb[b][0], wb[b][1], wb[b][2], wb[b][3]);   // written by the select above
                 }
                 mfma_begin2(dacc);
 #pragma unroll
