@@ -1,0 +1,313 @@
+// Persistent LSTM layer with a WIDE input (96 < F <= 256), H = 256: the stacked layers of the others-mixing
+// model (mycode/given_others_gt_mean_var_seq2seq.py:111-112: encoder layer 2 runs over the 256-wide sequence of
+// layer 1).  lstm_cluster.hip keeps its input kernel in LDS and stops at F = 96; beyond that the callers had to
+// form zx = x . K with a GEMM first (fov_matmul + fov_lstm_seq_fwd_zx: an extra launch and a (B,T,4H) round
+// trip).  Here both K (F x 4H) and R (H x 4H) stay in registers for the whole sequence:
+//   * a tile of 16 sequences is owned by a group of EIGHT workgroups, workgroup `slice` owns hidden units
+//     [32*slice, +32), wave w 8 of them (two MFMA N-tiles [i | f], [g | o]; DPP half swap before the cell
+//     update - the ownership scheme of mix_decoder.hip);
+//   * K slice 128 AGPRs + R slice 128 AGPRs per lane;
+//   * the input tile x_t (16 x F) is double-buffered in LDS (global -> registers -> LDS one step ahead), the h
+//     tile (16 x 256) sits next to it; x_{t+1} . K (128 MFMAs) runs under the gather of h_t.
+#include <stdlib.h>
+
+#include "fov_common.h"
+
+namespace fov {
+
+namespace {
+
+constexpr int WH = 256;
+constexpr int WG = 8;
+constexpr int WBT = 16;
+constexpr int WLD = WH + 4;      // LDS row stride of the h tile and of the x tiles
+constexpr int WNG = 14;
+constexpr unsigned WSPIN = 1u << 20;
+
+typedef unsigned wu32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void wm_a(f32x4& acc, float a, float w_agpr) {
+    asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "a"(w_agpr));
+}
+__device__ __forceinline__ void wm_begin(f32x4 (&acc)[2]) { asm volatile("s_nop 3" : "+v"(acc[0]), "+v"(acc[1])); }
+__device__ __forceinline__ void wm_end(f32x4 (&acc)[2]) {
+    asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" : "+v"(acc[0]), "+v"(acc[1]));
+}
+__device__ __forceinline__ float wswap(float v) {
+    return __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x128, 0xf, 0xf, false));
+}
+
+// acc[tile] += A(tile rows in LDS, k-blocks [0, NJ)) . W (AGPR resident)
+template <int NJ>
+__device__ __forceinline__ void wide_mm(f32x4 (&acc)[2], const float* arow, const float (&w)[16][4][2]) {
+    f32x4 a = *(const f32x4*)arow;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        f32x4 an = a;
+        if (j + 1 < NJ) an = *(const f32x4*)(arow + 16 * (j + 1));
+        asm volatile("s_nop 1" : "+v"(a));   // the fragment may have been moved by the compiler (VALU copy)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            wm_a(acc[0], a[s], w[j][s][0]);
+            wm_a(acc[1], a[s], w[j][s][1]);
+        }
+        a = an;
+    }
+}
+
+template <int ACT>
+__global__ __launch_bounds__(256, 1) void lstm_wide_kernel(LstmParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sH = smem;                    // [16][WLD]
+    float* sX = sH + WBT * WLD;          // [2][16][WLD]
+    int* sFlag = (int*)(sX + 2 * WBT * WLD);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 15, g4 = lane >> 4;
+    int group, slice;
+    if ((p.num_groups & 7) == 0) {   // members 8 blocks apart: likely one XCD (placement preference only)
+        group = (blockIdx.x / (8 * WG)) * 8 + (blockIdx.x & 7);
+        slice = (blockIdx.x >> 3) & (WG - 1);
+    } else {
+        group = blockIdx.x / WG;
+        slice = blockIdx.x - group * WG;
+    }
+    const int F = p.F, steps = p.T;
+    const int unit = 32 * slice + 8 * wave + (n & 7);
+    const int hi = n >> 3;
+    const int col0 = hi * WH + unit, col1 = (2 + hi) * WH + unit;
+    constexpr int H4 = 4 * WH;
+    if (tid == 0) sFlag[0] = 0;
+    if (p.clear_status && blockIdx.x == 0 && tid == 0) { p.status[0] = 0; p.status[1] = 0; }
+
+    // ---- resident weights: K rows >= F are zero ----
+    float wk[16][4][2], wr[16][4][2];
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int k = 16 * j + 4 * g4 + s;
+            wk[j][s][0] = (k < F) ? p.K[(size_t)k * H4 + col0] : 0.f;
+            wk[j][s][1] = (k < F) ? p.K[(size_t)k * H4 + col1] : 0.f;
+            wr[j][s][0] = p.R[(size_t)k * H4 + col0];
+            wr[j][s][1] = p.R[(size_t)k * H4 + col1];
+        }
+    const float bv[2] = {p.b[col0], p.b[col1]};
+    for (int i = tid; i < 2 * WBT * WLD; i += 256) sX[i] = 0.f;   // columns >= F stay zero
+
+    // ---- exchange bookkeeping (the granule protocol of lstm_cluster.hip, placement-independent form) ----
+    const bool xch_used = steps > 1;
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+        p.xch + (size_t)group * 2 * WBT * WH, 0, 2 * WBT * WH * (int)sizeof(unsigned long long), 0x00020000);
+    const int my_row0 = 4 * g4 + 2 * hi;
+    const unsigned pub_off = (unsigned)(my_row0 * WH + unit) * 8u;
+    const unsigned gvoff = (unsigned)((tid >> 5) * WH + (tid & 31)) * 8u;
+    const int lbase = (tid >> 5) * WLD + (tid & 31);
+    constexpr unsigned PARITY = WBT * WH * 8u;
+    unsigned epoch = 0;
+    bool aborted = false;
+    __syncthreads();
+
+    wu32x2 v[WNG];
+    auto gather_issue = [&](unsigned base) {
+#pragma unroll
+        for (int j = 0; j < WNG; ++j) {
+            const unsigned uo = (unsigned)((j & 1) * 8 * WH + ((slice + 1 + (j >> 1)) & (WG - 1)) * 32) * 8u;
+            v[j] = __builtin_amdgcn_raw_buffer_load_b64(xrs, gvoff, base + uo, 16);
+        }
+    };
+    // first pass: current granules go straight to the h tile, stale ones into a bit mask; retry sweeps (rare)
+    // re-read into loop-local temporaries
+    auto gather_finish = [&](unsigned base) {
+        unsigned bad = 0;
+#pragma unroll
+        for (int j = 0; j < WNG; ++j) {
+            const int lo = lbase + (j & 1) * 8 * WLD + ((slice + 1 + (j >> 1)) & (WG - 1)) * 32;
+            if (v[j].y == epoch) sH[lo] = __uint_as_float(v[j].x);
+            else bad |= (1u << j);
+        }
+        unsigned spins = 0;
+        while (__any(bad != 0)) {
+            ++spins;
+            if (spins > WSPIN ||
+                ((spins & 63u) == 0 && __hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                if (lane == 0) {
+                    __hip_atomic_store(p.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    sFlag[0] = 1;
+                }
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+            asm volatile("" ::: "memory");
+            wu32x2 tv[WNG];
+#pragma unroll
+            for (int j = 0; j < WNG; ++j) {
+                const unsigned uo = (unsigned)((j & 1) * 8 * WH + ((slice + 1 + (j >> 1)) & (WG - 1)) * 32) * 8u;
+                tv[j] = __builtin_amdgcn_raw_buffer_load_b64(xrs, gvoff, base + uo, 16);
+            }
+#pragma unroll
+            for (int j = 0; j < WNG; ++j) {
+                const int lo = lbase + (j & 1) * 8 * WLD + ((slice + 1 + (j >> 1)) & (WG - 1)) * 32;
+                if (((bad >> j) & 1u) && tv[j].y == epoch) {
+                    sH[lo] = __uint_as_float(tv[j].x);
+                    bad &= ~(1u << j);
+                }
+            }
+        }
+    };
+
+    const float* hrow = sH + n * WLD + 4 * g4;
+    // x staging: thread (xrw = tid/16, xc = tid%16) moves the 16-byte pieces xc, xc+16, xc+32, xc+48 of row xrw
+    const int xrw = tid >> 4, xc = tid & 15;
+    const int nx4 = F >> 2;   // 16-byte pieces per row (F % 4 == 0, host-checked)
+    for (int tile = group; tile < p.num_tiles && !aborted; tile += p.num_groups) {
+        const int b0 = tile * WBT;
+        __syncthreads();   // previous tile fully consumed
+        for (int e = tid; e < WBT * WH; e += 256) {
+            const int row = e >> 8, u = e & 255;
+            sH[row * WLD + u] = (b0 + row < p.B && p.h0) ? p.h0[(size_t)(b0 + row) * WH + u] : 0.f;
+        }
+        float c[2], hc[2] = {0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int row = b0 + my_row0 + r;
+            c[r] = (row < p.B && p.c0) ? p.c0[(size_t)row * WH + unit] : 0.f;
+            hc[r] = (row < p.B && p.h0) ? p.h0[(size_t)row * WH + unit] : 0.f;
+        }
+        const bool xlive = b0 + xrw < p.B;
+        const float* xt = p.x + ((size_t)(b0 + xrw) * p.T) * F + 4 * xc;
+        float* xl = sX + xrw * WLD + 4 * xc;
+        const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+            if (tt < steps) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (xc + 16 * i < nx4) *(f32x4*)(xl + tt * WBT * WLD + 64 * i) = xlive ? *(const f32x4*)(xt + (size_t)tt * F + 64 * i) : z4;
+            }
+        __syncthreads();
+        // ---- pre-activations of step 0 ----
+        f32x4 acc[2];
+        acc[0] = (f32x4){bv[0], bv[0], bv[0], bv[0]};
+        acc[1] = (f32x4){bv[1], bv[1], bv[1], bv[1]};
+        if (steps > 0) {
+            wm_begin(acc);
+            wide_mm<16>(acc, sX + n * WLD + 4 * g4, wk);
+            wide_mm<16>(acc, hrow, wr);
+            wm_end(acc);
+        }
+        f32x4 xr[4] = {z4, z4, z4, z4};
+        for (int t = 0; t < steps; ++t) {
+            // x pipeline: x_{t+1} (requested during step t-1) registers -> LDS; then request x_{t+2}
+            if (t > 0 && t + 1 < steps) {
+                float* xb = xl + ((t + 1) & 1) * WBT * WLD;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (xc + 16 * i < nx4) *(f32x4*)(xb + 64 * i) = xr[i];
+            }
+            if (t + 2 < steps) {
+                const float* xn = xt + (size_t)(t + 2) * F;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) xr[i] = (xlive && xc + 16 * i < nx4) ? *(const f32x4*)(xn + 64 * i) : z4;
+            }
+            // ---- cell update ----
+            {
+                float snd[4], rcv[4];
+                snd[0] = hi ? acc[0][0] : acc[0][2];
+                snd[1] = hi ? acc[0][1] : acc[0][3];
+                snd[2] = hi ? acc[1][0] : acc[1][2];
+                snd[3] = hi ? acc[1][1] : acc[1][3];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) rcv[k] = wswap(snd[k]);
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    const float zi = hi ? rcv[r] : acc[0][r];
+                    const float zf = hi ? acc[0][2 + r] : rcv[r];
+                    const float zg = hi ? rcv[2 + r] : acc[1][r];
+                    const float zo = hi ? acc[1][2 + r] : rcv[2 + r];
+                    const float ig = rec_act<ACT>(zi), fg = rec_act<ACT>(zf), gg = tanh_f(zg), og = rec_act<ACT>(zo);
+                    c[r] = fmaf(fg, c[r], ig * gg);
+                    hc[r] = og * tanh_f(c[r]);
+                    const int row = b0 + my_row0 + r;
+                    if (row < p.B) {
+                        if (p.reserve) {
+                            float* rp = p.reserve + (((size_t)row * p.T + t) * 5) * WH + unit;
+                            rp[0] = ig; rp[WH] = fg; rp[2 * WH] = gg; rp[3 * WH] = og; rp[4 * WH] = c[r];
+                        }
+                        if (p.hs) p.hs[((size_t)row * p.T + t) * WH + unit] = hc[r];
+                    }
+                }
+            }
+            const bool more = (t + 1 < steps);
+            const bool do_xch = xch_used && more;   // the last h_t is needed by nobody in here
+            unsigned par = 0;
+            if (do_xch) {
+                ++epoch;
+                par = (epoch & 1u) * PARITY;
+#pragma unroll
+                for (int r = 0; r < 2; ++r)
+                    __builtin_amdgcn_raw_buffer_store_b64((wu32x2){__float_as_uint(hc[r]), epoch}, xrs, pub_off + r * WH * 8, par, 16);
+            }
+            __syncthreads();   // barrier 1: every wave is done reading sH; x_{t+1} is in LDS
+            if (do_xch) {
+#pragma unroll
+                for (int r = 0; r < 2; ++r) sH[(my_row0 + r) * WLD + unit] = hc[r];
+                gather_issue(par);
+            }
+            acc[0] = (f32x4){bv[0], bv[0], bv[0], bv[0]};
+            acc[1] = (f32x4){bv[1], bv[1], bv[1], bv[1]};
+            if (more) {   // x_{t+1} . K needs no remote data: it runs under the gather
+                wm_begin(acc);
+                wide_mm<16>(acc, sX + ((t + 1) & 1) * WBT * WLD + n * WLD + 4 * g4, wk);
+                wm_end(acc);
+            }
+            if (do_xch) gather_finish(par);
+            __syncthreads();   // barrier 2: the whole h_t tile is in LDS
+            if (sFlag[0]) { aborted = true; break; }
+            if (more) {
+                wm_begin(acc);
+                wide_mm<16>(acc, hrow, wr);
+                wm_end(acc);
+            }
+        }
+        if (!aborted) {
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int row = b0 + my_row0 + r;
+                if (row < p.B) {
+                    if (p.hT) p.hT[(size_t)row * WH + unit] = hc[r];
+                    if (p.cT) p.cT[(size_t)row * WH + unit] = c[r];
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+bool wide_shape_ok(int F, int H) { return H == WH && F > 96 && F <= 256 && (F & 3) == 0; }
+
+// p.status / p.xch point into the caller's workspace (cluster_workspace_bytes(B, 256): granule area for up to 64
+// groups, this kernel uses at most 32)
+int launch_wide(const LstmParams& p_in, hipStream_t stream) {
+    LstmParams p = p_in;
+    if (p.B == 0) return FOV_OK;
+    if ((((uintptr_t)p.x) & 15) != 0) { set_error("wide LSTM layer: x must be 16-byte aligned"); return FOV_ERR_INVALID; }
+    p.num_tiles = (p.B + WBT - 1) / WBT;
+    p.num_groups = p.num_tiles < 32 ? p.num_tiles : 32;
+    p.clear_status = p.T <= 1 ? 1 : 0;
+    if (!p.clear_status) {
+        const size_t bytes = kStatusBytes + (size_t)p.num_groups * 2 * WBT * WH * sizeof(unsigned long long);
+        hipError_t e = hipMemsetAsync((void*)p.status, 0, bytes, stream);
+        if (e != hipSuccess) { set_error("hipMemsetAsync: %s", hipGetErrorString(e)); return FOV_ERR_LAUNCH; }
+    }
+    const size_t lds = sizeof(float) * (3 * WBT * WLD) + 64;
+    void (*kern)(LstmParams) = p.act == FOV_ACT_HARD_SIGMOID ? lstm_wide_kernel<FOV_ACT_HARD_SIGMOID> : lstm_wide_kernel<FOV_ACT_SIGMOID>;
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return FOV_ERR_LAUNCH; }
+    hipLaunchKernelGGL(kern, dim3(p.num_groups * WG), dim3(256), lds, stream, p);
+    e = hipGetLastError();
+    if (e != hipSuccess) { set_error("wide LSTM launch: %s", hipGetErrorString(e)); return FOV_ERR_LAUNCH; }
+    return FOV_OK;
+}
+
+}  // namespace fov

@@ -422,3 +422,33 @@ def test_fused_mixing_decoder_matches_oracle(B, T_in, T_out, act):
     out = ops.mix_decoder(dev(dec0), h1, c1, h2, c2, oth_proj, dw, Wm_p, T_out, act=act, workspace=ws)
     ws.check()
     assert_parity(out.transpose(0, 1), ref, "fused mixing decoder B=%d" % B)
+
+
+@pytest.mark.parametrize("B,T,F", [(37, 5, 256), (16, 1, 256), (600, 3, 128), (20, 4, 100)])
+@pytest.mark.parametrize("act", ["sigmoid", "hard_sigmoid"])
+def test_wide_input_layer(B, T, F, act):
+    """A stacked layer over a wide sequence (given_others...py:111-112: encoder layer 2 over the 256-wide output of
+    layer 1): K and R both register-resident (lstm_wide.hip), no precomputed input projection.  Also the
+    training form (reserve) and a given initial state; B = 600 makes a group visit several tiles."""
+    ops = _ops()
+    H = 256
+    rng = np.random.default_rng(B + F)
+    K, R, b = O.init_lstm(rng, F, H, np.float32)
+    b = (b + 0.1 * rng.standard_normal(b.shape)).astype(np.float32)
+    x = rng.uniform(-1, 1, (B, T, F)).astype(np.float32)
+    h0 = (0.3 * rng.standard_normal((B, H))).astype(np.float32)
+    c0 = (0.3 * rng.standard_normal((B, H))).astype(np.float32)
+    d = lambda a: a.astype(np.float64)
+    ref = O.lstm_layer(d(x), d(K), d(R), d(b), d(h0), d(c0), act=act)
+    ws = ops.Workspace()
+    hs, hT, cT = ops.lstm_seq(dev(x), dev(K), dev(R), dev(b), dev(h0), dev(c0), act=act, workspace=ws)
+    ws.check()
+    assert_parity(hs, ref[0], "wide layer hs F=%d" % F)
+    assert_parity(hT, ref[1], "wide layer hT")
+    assert_parity(cT, ref[2], "wide layer cT")
+    hs2, hT2, cT2, res = ops.lstm_seq_train(dev(x), dev(K), dev(R), dev(b), dev(h0), dev(c0), act=act, workspace=ws)
+    ws.check()
+    hs_g, _, _, res_g = ops.lstm_seq_train(dev(x), dev(K), dev(R), dev(b), dev(h0), dev(c0), act=act, impl="generic")
+    assert torch.equal(hs2, hs)                                   # deterministic, same kernel
+    assert (res - res_g).abs().max().item() < 2e-6                 # reserve agrees with the generic kernel's
+    assert (hs2 - hs_g).abs().max().item() < 2e-6
