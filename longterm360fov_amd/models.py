@@ -455,8 +455,12 @@ class OthersMixingSeq2Seq:
         B, T_in = e.shape[0], e.shape[1]
         T_out = oth.shape[1]
         hs1, h1, c1 = ops.lstm_seq(e, dw["enc1_K"], dw["enc1_R"], dw["enc1_b"], act=act, impl=impl, workspace=ws)
-        zx = ops.matmul(hs1.reshape(B * T_in, H), dw["enc2_K"]).reshape(B, T_in, 4 * H)
-        _, h2, c2 = ops.lstm_seq_zx(zx, dw["enc2_R"], dw["enc2_b"], act=act, impl=impl, return_sequences=False, workspace=ws)
+        if H == 256 and impl != "generic":   # layer 2 over the 256-wide sequence: K2 and R2 register-resident
+            _, h2, c2 = ops.lstm_seq(hs1, dw["enc2_K"], dw["enc2_R"], dw["enc2_b"], act=act, impl=impl,
+                                     return_sequences=False, workspace=ws)
+        else:                                # other widths: input projection as a GEMM, then the layer on zx
+            zx = ops.matmul(hs1.reshape(B * T_in, H), dw["enc2_K"]).reshape(B, T_in, 4 * H)
+            _, h2, c2 = ops.lstm_seq_zx(zx, dw["enc2_R"], dw["enc2_b"], act=act, impl=impl, return_sequences=False, workspace=ws)
         # others half of the mixing layer for every step at once (bias folded in)
         oth_proj = ops.dense(oth.reshape(B * T_out, -1), dw["mix_W_oth"], dw["mix_b"], activation=None).reshape(B, T_out, O)
         out = torch.empty((T_out, B, O), dtype=torch.float32, device=self.device)   # step-major: row t = m_t

@@ -152,9 +152,12 @@ class OthersMixingTrainer:
         self.grad.zero_()
         # ---------------- forward (keeping what the backward needs) ----------------
         hs1, h1, c1, res1 = ops.lstm_seq_train(enc, w["enc1_K"], w["enc1_R"], w["enc1_b"], act=act, impl=impl, workspace=ws)
-        zx2 = ops.matmul(hs1.reshape(B * T_in, H), w["enc2_K"], scratch=sc).reshape(B, T_in, 4 * H)
-        res2 = torch.empty((B, T_in, 5, H), dtype=torch.float32, device=self.device)
-        hs2, h2, c2 = ops.lstm_seq_zx(zx2, w["enc2_R"], w["enc2_b"], act=act, impl=impl, workspace=ws, reserve=res2)
+        if H == 256 and impl != "generic":   # layer 2 over the 256-wide sequence: K2 and R2 register-resident
+            hs2, h2, c2, res2 = ops.lstm_seq_train(hs1, w["enc2_K"], w["enc2_R"], w["enc2_b"], act=act, impl=impl, workspace=ws)
+        else:
+            zx2 = ops.matmul(hs1.reshape(B * T_in, H), w["enc2_K"], scratch=sc).reshape(B, T_in, 4 * H)
+            res2 = torch.empty((B, T_in, 5, H), dtype=torch.float32, device=self.device)
+            hs2, h2, c2 = ops.lstm_seq_zx(zx2, w["enc2_R"], w["enc2_b"], act=act, impl=impl, workspace=ws, reserve=res2)
         oth_flat = others.reshape(B * T_out, n_oth)
         Wm_o_c, Wm_p_c = Wm_o.contiguous(), Wm_p.contiguous()
         oth_proj = ops.dense(oth_flat, Wm_o_c, w["mix_b"], activation=None).reshape(B, T_out, O)
