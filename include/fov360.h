@@ -118,6 +118,24 @@ int fov_mix_decoder_fwd(const float* dec0, const float* h1, const float* c1, con
                         int B, int T_out, int H, int O, int act,
                         void* workspace, size_t workspace_bytes, fov_stream_t stream);
 
+/* Backward of fov_mix_decoder_fwd (data path): BPTT through the whole unrolled decoder in ONE persistent launch.
+ *   in : M, P (T_out,B,O) from the forward; dloss (T_out,B,O) = dL/d(pre-tanh of m_t) from the loss;
+ *        res1, res2 (T_out,B,5,H); C1, C2 (T_out,B,H) = cell state BEFORE step t (row 0 = initial state);
+ *        weights as in the forward (mix_Wp = mix_W[-O:]).
+ *   out: DZ1, DZ2 (T_out,B,4H) gate pre-activation gradients of both layers and dpre_m, dpre_p (T_out,B,O)
+ *        pre-activation gradients of the mixing / Dense layers, for every step (each weight gradient is then one
+ *        product over all steps: dK = x^T dz, dR = h_prev^T dz, dW = in^T dpre); dh1_0..dc2_0 (B,H) gradient
+ *        w.r.t. the decoder's initial state (= the encoder's final state).
+ * Supported: H = 256, O <= 8. */
+size_t fov_mix_decoder_bwd_workspace_bytes(int B, int H);
+int fov_mix_decoder_bwd(const float* M, const float* P, const float* dloss, const float* res1, const float* res2,
+                        const float* C1, const float* C2, const float* dec1_K, const float* dec1_R,
+                        const float* dec2_K, const float* dec2_R, const float* dense_W, const float* mix_Wp,
+                        float* DZ1, float* DZ2, float* dpre_m, float* dpre_p,
+                        float* dh1_0, float* dc1_0, float* dh2_0, float* dc2_0,
+                        int B, int T_out, int H, int O, int act,
+                        void* workspace, size_t workspace_bytes, fov_stream_t stream);
+
 /* C (M,N) = A (M,K) . B (K,N), row-major dense fp32 (keras.backend.dot on 2-D operands).  The
  * workspace is optional (NULL allowed): with it, short-and-wide products use split-K. */
 size_t fov_matmul_workspace_bytes(int M, int K, int N);

@@ -579,6 +579,36 @@ int fov_mix_decoder_fwd(const float* dec0, const float* h1, const float* c1, con
     return mix_decoder_launch(p, dec2_K, act, ntrain == 7, workspace, (hipStream_t)stream);
 }
 
+size_t fov_mix_decoder_bwd_workspace_bytes(int B, int H) {
+    if (B <= 0 || H != 256) return kStatusBytes;
+    return mix_decoder_bwd_workspace_bytes(B);
+}
+
+int fov_mix_decoder_bwd(const float* M, const float* P, const float* dloss, const float* res1, const float* res2,
+                        const float* C1, const float* C2, const float* dec1_K, const float* dec1_R, const float* dec2_K,
+                        const float* dec2_R, const float* dense_W, const float* mix_Wp, float* DZ1, float* DZ2,
+                        float* dpre_m, float* dpre_p, float* dh1_0, float* dc1_0, float* dh2_0, float* dc2_0, int B,
+                        int T_out, int H, int O, int act, void* workspace, size_t workspace_bytes, fov_stream_t stream) {
+    if (B < 0 || T_out < 0 || O <= 0 || !dec1_K || !dec1_R || !dec2_K || !dec2_R || !dense_W || !mix_Wp ||
+        (B > 0 && T_out > 0 && (!M || !P || !dloss || !res1 || !res2 || !C1 || !C2 || !DZ1 || !DZ2 || !dpre_m || !dpre_p ||
+                                !dh1_0 || !dc1_0 || !dh2_0 || !dc2_0)) ||
+        (act != FOV_ACT_SIGMOID && act != FOV_ACT_HARD_SIGMOID)) {
+        set_error("fov_mix_decoder_bwd: invalid argument");
+        return FOV_ERR_INVALID;
+    }
+    if (H != 256 || O > 8) { set_error("fov_mix_decoder_bwd: the fused decoder supports H = 256, O <= 8"); return FOV_ERR_UNSUPPORTED; }
+    if (B == 0 || T_out == 0) return FOV_OK;
+    int rc = check_ws(workspace, workspace_bytes, fov_mix_decoder_bwd_workspace_bytes(B, H));
+    if (rc) return rc;
+    MixDecBwdParams p = {};
+    p.R1 = dec1_R; p.K1 = dec1_K; p.R2 = dec2_R; p.Wd = dense_W; p.Wp = mix_Wp;
+    p.M = M; p.P = P; p.dloss = dloss; p.res1 = res1; p.res2 = res2; p.C1 = C1; p.C2 = C2;
+    p.DZ1 = DZ1; p.DZ2 = DZ2; p.dpre_m = dpre_m; p.dpre_p = dpre_p;
+    p.dh1_0 = dh1_0; p.dc1_0 = dc1_0; p.dh2_0 = dh2_0; p.dc2_0 = dc2_0;
+    p.B = B; p.T_out = T_out; p.O = O;
+    return mix_decoder_bwd_launch(p, dec2_K, act, workspace, (hipStream_t)stream);
+}
+
 size_t fov_matmul_workspace_bytes(int M, int K, int N) {
     (void)K;
     if (M <= 0 || N <= 0) return 256;

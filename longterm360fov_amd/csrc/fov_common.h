@@ -114,6 +114,22 @@ struct MixDecParams {
 size_t mix_decoder_workspace_bytes(int B);
 int mix_decoder_launch(MixDecParams p, const float* K2, int act, int train, void* workspace, hipStream_t stream);
 
+// backward of the fused decoder (mix_decoder_bwd.hip)
+struct MixDecBwdParams {
+    const float *R1, *K1, *R2, *K2p, *Wd, *Wp;
+    const float *M, *P, *dloss;      // (T_out,B,O): m_t, p_t, dL/d(pre-tanh of m_t) from the loss
+    const float *res1, *res2;        // (T_out,B,5,H) reserves of the forward
+    const float *C1, *C2;            // (T_out,B,H): cell state BEFORE step t (row 0 = the decoder's initial state)
+    float *DZ1, *DZ2;                // (T_out,B,4H) out
+    float *dpre_m, *dpre_p;          // (T_out,B,O) out
+    float *dh1_0, *dc1_0, *dh2_0, *dc2_0;   // (B,H) out: gradient w.r.t. the decoder's initial state
+    unsigned long long* xch;
+    unsigned* status;
+    int B, T_out, O, num_groups, num_tiles;
+};
+size_t mix_decoder_bwd_workspace_bytes(int B);
+int mix_decoder_bwd_launch(MixDecBwdParams p, const float* K2, int act, void* workspace, hipStream_t stream);
+
 // persistent BPTT recurrence (lstm_bwd_cluster.hip)
 bool bwd_cluster_shape_ok(int H);
 size_t bwd_cluster_xch_bytes(int B, int H);

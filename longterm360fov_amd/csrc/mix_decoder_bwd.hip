@@ -1,0 +1,456 @@
+// Backward counterpart of mix_decoder.hip: BPTT through the whole unrolled others-mixing decoder (mixing head,
+// layer 2, layer 1, feedback path) in ONE persistent launch - what Keras/TF autodiff runs under model.fit for
+// mycode/given_others_gt_mean_var_seq2seq.py:203-308.  It produces the DATA gradients only: dz of both layers and
+// the pre-activation gradients of the two head layers for every step (the weight gradients are then one product
+// per layer over all steps, formed by the caller), and the gradient with respect to the decoder's initial state.
+//
+// Same ownership as the forward kernel: a tile of 16 sequences per group of 8 workgroups, workgroup `slice` owns
+// hidden units [32*slice, +32) of both layers, lane (n, g4) the cells (rows 4*g4 + 2*(n>>3) + {0,1}, unit
+// 32*slice + 8*wave + (n&7)): dc1, dc2 and the recurrent dh never leave registers.
+// Per step t = T-1 .. 0:
+//   head      dpre_m = dL/dz_m + dx_{t+1} (1 - m^2);  dpre_p = (dpre_m Wp^T)(1 - p^2);  dh2 += dpre_p Wd^T   (every
+//             workgroup redundantly: O = 6)
+//   layer 2   gates backward (lane-local, from the reserve) -> dz2 (own 128 gate columns) -> LDS
+//             partial[16 x 512] = dz2_own . [R2^T | K2^T]_own  : the contribution of the own gate columns to dh2_{t-1}
+//             (all 256 units) and to dh1_t (all 256 units); 256 MFMAs per wave.  R2^T slice in 128 AGPRs, K2^T slice
+//             28/32 fragment blocks in LDS + 4 in VGPRs (the forward kernel's arrangement).
+//             The 16 x 32 piece of each destination workgroup travels as {value, epoch} granules; every lane
+//             gathers the 8 pieces of its own cells and adds them in slice order (deterministic).
+//   layer 1   the same with R1^T (128 AGPRs) -> dh1_{t-1}; dx_t = dz1 . K1^T (16 x O) is summed the same way and
+//             feeds the head of step t-1 (x_t = m_{t-1}).
+// MFMA-bound in arithmetic (392 per wave and step, as the forward), in practice bound by its two exposed
+// exchanges per step.
+#include <stdlib.h>
+
+#include "fov_common.h"
+
+namespace fov {
+
+namespace {
+
+constexpr int BH = 256;
+constexpr int BG = 8;
+constexpr int BBT = 16;
+constexpr int BLDZ = 128 + 4;    // LDS row stride of the dz tile (16 x 128 own gate columns)
+constexpr unsigned B_SPIN = 1u << 20;
+constexpr int BK2_LDS_BLOCKS = 28;
+
+typedef unsigned bwu32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void bm_a(f32x4& acc, float a, float w_agpr) {
+    asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "a"(w_agpr));
+}
+__device__ __forceinline__ void bm_v(f32x4& acc, float a, float w_vgpr) {
+    asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(w_vgpr));
+}
+template <int N>
+__device__ __forceinline__ void bm_begin(f32x4 (&acc)[N]) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) asm volatile("" : "+v"(acc[i]));
+    asm volatile("s_nop 3");
+}
+template <int N>
+__device__ __forceinline__ void bm_end(f32x4 (&acc)[N]) {
+    asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7");
+#pragma unroll
+    for (int i = 0; i < N; ++i) asm volatile("" : "+v"(acc[i]));
+}
+template <int ACT>
+__device__ __forceinline__ float bact_grad(float a) {
+    return ACT == FOV_ACT_HARD_SIGMOID ? ((a > 0.f && a < 1.f) ? 0.2f : 0.f) : a * (1.f - a);
+}
+
+}  // namespace
+
+// granule areas of one group, in granules (8 bytes each); two parities of each
+constexpr size_t MB2 = (size_t)BG * BG * 2 * BBT * 32;   // [dest][src][product][row][unit]
+constexpr size_t MB1 = (size_t)BG * BG * BBT * 32;       // [dest][src][row][unit]
+constexpr size_t MBX = (size_t)BG * BBT * 8;             // [src][row][o]
+constexpr size_t MB_GROUP = 2 * (MB2 + MB1 + MBX);
+
+template <int ACT>
+__global__ __launch_bounds__(256, 1) void mix_decoder_bwd_kernel(MixDecBwdParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sDZ = smem;                         // [16][BLDZ]
+    float* sDP = sDZ + BBT * BLDZ;             // [16][8]  dpre_p of the step
+    float* sDX = sDP + BBT * 8;                // [16][8]  dx_{t+1} (sum over the workgroups)
+    float* sK1T = sDX + BBT * 8;               // [128][8] K1^T rows of the own gate columns
+    int* sFlag = (int*)(sK1T + 128 * 8);
+    float* sK2 = sK1T + 128 * 8 + 16;          // [4 waves][28 blocks][64 lanes][4]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 15, g4 = lane >> 4;
+    const int O = p.O, T = p.T_out;
+    int group, slice;
+    if ((p.num_groups & 7) == 0) {
+        group = (blockIdx.x / (8 * BG)) * 8 + (blockIdx.x & 7);
+        slice = (blockIdx.x >> 3) & (BG - 1);
+    } else {
+        group = blockIdx.x / BG;
+        slice = blockIdx.x - group * BG;
+    }
+    constexpr int H4 = 4 * BH;
+    const int hi = n >> 3;
+    const int ul = 8 * wave + (n & 7);          // unit inside the workgroup (0..31)
+    const int unit = 32 * slice + ul;
+    const int my_row0 = 4 * g4 + 2 * hi;
+    if (tid == 0) sFlag[0] = 0;
+
+    // ---- resident transposed weights.  Tile tl of this wave: destination slice 2*wave + (tl>>1), half tl&1;
+    // its output unit on this lane is nout; k index lc = 16*jb + 4*g4 + s is an own gate column:
+    // gate lc>>5, unit 32*slice + (lc & 31). ----
+    float r2t[4][8][4], r1t[4][8][4];
+#pragma unroll
+    for (int tl = 0; tl < 4; ++tl) {
+        const int nout = 32 * (2 * wave + (tl >> 1)) + 16 * (tl & 1) + n;
+#pragma unroll
+        for (int jb = 0; jb < 8; ++jb)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int lc = 16 * jb + 4 * g4 + s;
+                const int gcol = (lc >> 5) * BH + 32 * slice + (lc & 31);
+                r2t[tl][jb][s] = p.R2[(size_t)nout * H4 + gcol];
+                r1t[tl][jb][s] = p.R1[(size_t)nout * H4 + gcol];
+            }
+    }
+    // K2^T fragments of this wave (packed by mix_decoder_bwd_pack_k2: block b = tl*8 + jb): 28 blocks to LDS, 4 to registers
+    float* sK2l = sK2 + (size_t)wave * BK2_LDS_BLOCKS * 256 + lane * 4;
+    f32x4 k2r[4];
+    {
+        const f32x4* kp = (const f32x4*)p.K2p + (size_t)(slice * 4 + wave) * 32 * 64 + lane;
+        for (int b = 0; b < BK2_LDS_BLOCKS; ++b) *(f32x4*)(sK2l + b * 256) = kp[64 * b];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) k2r[b] = kp[64 * (BK2_LDS_BLOCKS + b)];
+    }
+    for (int e = tid; e < 128 * 8; e += 256) {
+        const int lc = e >> 3, o = e & 7;
+        sK1T[e] = (o < O) ? p.K1[(size_t)o * H4 + (lc >> 5) * BH + 32 * slice + (lc & 31)] : 0.f;
+    }
+    float wd[8];   // Dense kernel row of this lane's unit
+#pragma unroll
+    for (int o = 0; o < 8; ++o) wd[o] = (o < O) ? p.Wd[(size_t)unit * O + o] : 0.f;
+    const int hrow = tid >> 4, ho = tid & 15;   // head: thread = (sequence of the tile, output)
+    float wpr[8];   // row `ho` of Wp: dp[ho] = sum_k dm[k] Wp[ho][k]
+#pragma unroll
+    for (int k = 0; k < 8; ++k) wpr[k] = (ho < O && k < O) ? p.Wp[ho * O + k] : 0.f;
+
+    // ---- exchange areas of this group ----
+    unsigned long long* gbase = p.xch + (size_t)group * MB_GROUP;
+    const __amdgpu_buffer_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc(gbase, 0, (int)(2 * MB2 * 8), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(gbase + 2 * MB2, 0, (int)(2 * MB1 * 8), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(gbase + 2 * MB2 + 2 * MB1, 0, (int)(2 * MBX * 8), 0x00020000);
+    unsigned epoch = 0;
+    bool aborted = false;
+    auto give_up = [&]() {
+        if (lane == 0) {
+            __hip_atomic_store(p.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            sFlag[0] = 1;
+        }
+    };
+    // gather NQ x 8 granules {src 0..7} for each of this lane's NQ quantities and add them in slice order.
+    // voff[q]: byte offset of the src-0 granule, src stride sstride bytes.
+    auto gather_sum = [&](const __amdgpu_buffer_rsrc_t rs, const unsigned (&voff)[2], unsigned sstride, unsigned base, float (&out)[2]) {
+        // first sweep: current granules into part[], stale ones into a bit mask (v[] is dead afterwards); retry sweeps
+        // (rare) re-read into loop-local temporaries - a loop-carried v[] costs several VGPRs per granule
+        float part[16];
+        unsigned bad = 0;
+        {
+            bwu32x2 v[16];
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int s = 0; s < 8; ++s) v[q * 8 + s] = __builtin_amdgcn_raw_buffer_load_b64(rs, voff[q] + s * sstride, base, 16);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                part[j] = __uint_as_float(v[j].x);
+                if (v[j].y != epoch) bad |= (1u << j);
+            }
+        }
+        unsigned spins = 0;
+        while (__any(bad != 0)) {
+            ++spins;
+            if (spins > B_SPIN ||
+                ((spins & 63u) == 0 && __hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                give_up();
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+            asm volatile("" ::: "memory");
+            bwu32x2 tv[16];
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int s = 0; s < 8; ++s) tv[q * 8 + s] = __builtin_amdgcn_raw_buffer_load_b64(rs, voff[q] + s * sstride, base, 16);
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                if (((bad >> j) & 1u) && tv[j].y == epoch) {
+                    part[j] = __uint_as_float(tv[j].x);
+                    bad &= ~(1u << j);
+                }
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            float acc = 0.f;
+#pragma unroll
+            for (int s = 0; s < 8; ++s) acc += part[q * 8 + s];
+            out[q] = acc;
+        }
+    };
+    __syncthreads();
+
+    for (int tile = group; tile < p.num_tiles && !aborted; tile += p.num_groups) {
+        const int b0 = tile * BBT;
+        __syncthreads();
+        if (tid < BBT * 8) sDX[tid] = 0.f;       // no feedback gradient into the last step
+        float dc1[2] = {0.f, 0.f}, dc2[2] = {0.f, 0.f}, dh1r[2] = {0.f, 0.f}, dh2r[2] = {0.f, 0.f};
+        __syncthreads();
+        for (int t = T - 1; t >= 0; --t) {
+            ++epoch;
+            const unsigned par2 = (epoch & 1u) * (unsigned)(MB2 * 8), par1 = (epoch & 1u) * (unsigned)(MB1 * 8),
+                           parx = (epoch & 1u) * (unsigned)(MBX * 8);
+            // ================= head backward (every workgroup, its 16 sequences) =================
+            {
+                const int brow = b0 + hrow;
+                const bool live = ho < O && brow < p.B;
+                const size_t hidx = ((size_t)t * p.B + brow) * O + ho;
+                const float mv = live ? p.M[hidx] : 0.f, pv = live ? p.P[hidx] : 0.f;
+                const float dm = live ? p.dloss[hidx] + sDX[hrow * 8 + (ho & 7)] * (1.f - mv * mv) : 0.f;
+                float dp = 0.f;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) dp = fmaf(__shfl(dm, (lane & ~15) | k), wpr[k], dp);
+                const float dpp = dp * (1.f - pv * pv);
+                if (ho < 8) sDP[hrow * 8 + ho] = live ? dpp : 0.f;
+                if (slice == 0 && live) {
+                    p.dpre_m[hidx] = dm;
+                    p.dpre_p[hidx] = dpp;
+                }
+            }
+            __syncthreads();   // dpre_p of the step is in LDS; every wave is past the previous step's MFMAs
+            // ================= layer 2: gates backward for this lane's two cells =================
+            float dz[2][4];
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int row = b0 + my_row0 + r;
+                float dhd = 0.f;
+#pragma unroll
+                for (int o = 0; o < 8; ++o) dhd = fmaf(sDP[(my_row0 + r) * 8 + o], wd[o], dhd);
+                float ig = 0.f, fg = 0.f, gg = 0.f, og = 0.f, ct = 0.f, cp = 0.f;
+                if (row < p.B) {
+                    const float* rp = p.res2 + (((size_t)t * p.B + row) * 5) * BH + unit;
+                    ig = rp[0]; fg = rp[BH]; gg = rp[2 * BH]; og = rp[3 * BH]; ct = rp[4 * BH];
+                    cp = p.C2[((size_t)t * p.B + row) * BH + unit];
+                }
+                const float tc = tanh_f(ct);
+                const float dh = dhd + dh2r[r];
+                const float dct = dc2[r] + dh * og * (1.f - tc * tc);
+                dz[r][0] = dct * gg * bact_grad<ACT>(ig);
+                dz[r][1] = dct * cp * bact_grad<ACT>(fg);
+                dz[r][2] = dct * ig * (1.f - gg * gg);
+                dz[r][3] = dh * tc * bact_grad<ACT>(og);
+                dc2[r] = dct * fg;
+                if (row < p.B) {
+                    float* zp = p.DZ2 + ((size_t)t * p.B + row) * H4 + unit;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) zp[g * BH] = dz[r][g];
+                }
+#pragma unroll
+                for (int g = 0; g < 4; ++g) sDZ[(my_row0 + r) * BLDZ + g * 32 + ul] = (row < p.B) ? dz[r][g] : 0.f;
+            }
+            __syncthreads();   // the dz2 tile is in LDS
+            // ================= partial[16 x 512] = dz2_own . [R2^T | K2^T]_own =================
+            {
+                f32x4 acc[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                bm_begin<8>(acc);
+                const float* arow = sDZ + n * BLDZ + 4 * g4;
+#pragma unroll
+                for (int jb = 0; jb < 8; ++jb) {
+                    f32x4 a = *(const f32x4*)(arow + 16 * jb);
+                    asm volatile("s_nop 1" : "+v"(a));
+#pragma unroll
+                    for (int tl = 0; tl < 4; ++tl) {
+                        const int blk = tl * 8 + jb;
+                        const f32x4 kb = (blk < BK2_LDS_BLOCKS) ? *(const f32x4*)(sK2l + blk * 256) : k2r[blk - BK2_LDS_BLOCKS];
+#pragma unroll
+                        for (int s = 0; s < 4; ++s) {
+                            bm_a(acc[tl], a[s], r2t[tl][jb][s]);
+                            bm_v(acc[4 + tl], a[s], kb[s]);
+                        }
+                    }
+                }
+                bm_end<8>(acc);
+                // publish: tile tl of product q goes to destination d = 2*wave + (tl>>1), rows 4*g4 + r, unit 16*(tl&1) + n
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+#pragma unroll
+                    for (int tl = 0; tl < 4; ++tl) {
+                        const int d = 2 * wave + (tl >> 1);
+                        const unsigned off = (unsigned)(((((d * BG + slice) * 2 + q) * BBT + 4 * g4) * 32) + 16 * (tl & 1) + n) * 8u;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            __builtin_amdgcn_raw_buffer_store_b64((bwu32x2){__float_as_uint(acc[q * 4 + tl][r]), epoch}, rs2, off + r * 32 * 8, par2, 16);
+                    }
+            }
+            __syncthreads();   // every wave is done reading the dz2 tile
+            // ================= gather the 8 pieces of this lane's cells: dh2_{t-1} and dh1_t =================
+            float dh1in[2];
+            {
+                // [dest = slice][src][q][row][unit]: src stride = 2*16*32 granules
+                unsigned voff[2];
+                float sum[2];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    voff[0] = (unsigned)((((slice * BG) * 2 + q) * BBT + my_row0) * 32 + ul) * 8u;
+                    voff[1] = voff[0] + 32 * 8;
+                    gather_sum(rs2, voff, 2 * BBT * 32 * 8, par2, sum);
+                    if (q == 0) { dh2r[0] = sum[0]; dh2r[1] = sum[1]; }
+                    else { dh1in[0] = sum[0]; dh1in[1] = sum[1]; }
+                }
+            }
+            if (sFlag[0]) { aborted = true; }
+            // ================= layer 1: gates backward =================
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int row = b0 + my_row0 + r;
+                float ig = 0.f, fg = 0.f, gg = 0.f, og = 0.f, ct = 0.f, cp = 0.f;
+                if (row < p.B) {
+                    const float* rp = p.res1 + (((size_t)t * p.B + row) * 5) * BH + unit;
+                    ig = rp[0]; fg = rp[BH]; gg = rp[2 * BH]; og = rp[3 * BH]; ct = rp[4 * BH];
+                    cp = p.C1[((size_t)t * p.B + row) * BH + unit];
+                }
+                const float tc = tanh_f(ct);
+                const float dh = dh1in[r] + dh1r[r];
+                const float dct = dc1[r] + dh * og * (1.f - tc * tc);
+                dz[r][0] = dct * gg * bact_grad<ACT>(ig);
+                dz[r][1] = dct * cp * bact_grad<ACT>(fg);
+                dz[r][2] = dct * ig * (1.f - gg * gg);
+                dz[r][3] = dh * tc * bact_grad<ACT>(og);
+                dc1[r] = dct * fg;
+                if (row < p.B) {
+                    float* zp = p.DZ1 + ((size_t)t * p.B + row) * H4 + unit;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) zp[g * BH] = dz[r][g];
+                }
+#pragma unroll
+                for (int g = 0; g < 4; ++g) sDZ[(my_row0 + r) * BLDZ + g * 32 + ul] = (row < p.B) ? dz[r][g] : 0.f;
+            }
+            __syncthreads();   // the dz1 tile is in LDS
+            // ================= partial[16 x 256] = dz1_own . R1^T_own, and dx partial = dz1_own . K1^T_own =================
+            {
+                f32x4 acc[5];
+#pragma unroll
+                for (int i = 0; i < 5; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                bm_begin<5>(acc);
+                const float* arow = sDZ + n * BLDZ + 4 * g4;
+#pragma unroll
+                for (int jb = 0; jb < 8; ++jb) {
+                    f32x4 a = *(const f32x4*)(arow + 16 * jb);
+                    asm volatile("s_nop 1" : "+v"(a));
+#pragma unroll
+                    for (int tl = 0; tl < 4; ++tl)
+#pragma unroll
+                        for (int s = 0; s < 4; ++s) bm_a(acc[tl], a[s], r1t[tl][jb][s]);
+                    if (wave == 0) {   // dx tile: B = K1^T rows of the own gate columns, column n = output o (zero for n >= 8)
+                        float kb[4];
+#pragma unroll
+                        for (int s = 0; s < 4; ++s) kb[s] = (n < 8) ? sK1T[(16 * jb + 4 * g4 + s) * 8 + n] : 0.f;
+                        asm volatile("s_nop 1" : "+v"(kb[0]), "+v"(kb[1]), "+v"(kb[2]), "+v"(kb[3]));
+#pragma unroll
+                        for (int s = 0; s < 4; ++s) bm_v(acc[4], a[s], kb[s]);
+                    }
+                }
+                bm_end<5>(acc);
+#pragma unroll
+                for (int tl = 0; tl < 4; ++tl) {
+                    const int d = 2 * wave + (tl >> 1);
+                    const unsigned off = (unsigned)((((d * BG + slice) * BBT + 4 * g4) * 32) + 16 * (tl & 1) + n) * 8u;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        __builtin_amdgcn_raw_buffer_store_b64((bwu32x2){__float_as_uint(acc[tl][r]), epoch}, rs1, off + r * 32 * 8, par1, 16);
+                }
+                if (wave == 0 && n < 8) {
+                    const unsigned off = (unsigned)((slice * BBT + 4 * g4) * 8 + n) * 8u;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        __builtin_amdgcn_raw_buffer_store_b64((bwu32x2){__float_as_uint(acc[4][r]), epoch}, rsx, off + r * 8 * 8, parx, 16);
+                }
+            }
+            // ================= gather: dh1_{t-1} of this lane's cells, and dx_t (every workgroup needs all of it) =================
+            {
+                unsigned voff[2];
+                float sum[2];
+                voff[0] = (unsigned)(((slice * BG) * BBT + my_row0) * 32 + ul) * 8u;
+                voff[1] = voff[0] + 32 * 8;
+                gather_sum(rs1, voff, BBT * 32 * 8, par1, sum);
+                dh1r[0] = sum[0]; dh1r[1] = sum[1];
+                // dx: thread (hrow, ho < 8) sums the 8 sources; the second quantity of gather_sum re-reads the same
+                voff[0] = (unsigned)(hrow * 8 + (ho & 7)) * 8u;
+                voff[1] = voff[0];
+                gather_sum(rsx, voff, BBT * 8 * 8, parx, sum);
+                __syncthreads();   // every wave is done with the dz1 tile and with sDX of this step
+                if (ho < 8) sDX[hrow * 8 + ho] = sum[0];
+            }
+            if (sFlag[0]) aborted = true;
+            __syncthreads();   // dx_t is in LDS (also makes `aborted` uniform below)
+            if (sFlag[0]) { aborted = true; break; }
+        }
+        if (!aborted) {
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int row = b0 + my_row0 + r;
+                if (row < p.B) {
+                    p.dh1_0[(size_t)row * BH + unit] = dh1r[r];
+                    p.dc1_0[(size_t)row * BH + unit] = dc1[r];
+                    p.dh2_0[(size_t)row * BH + unit] = dh2r[r];
+                    p.dc2_0[(size_t)row * BH + unit] = dc2[r];
+                }
+            }
+        }
+    }
+}
+
+// K2 (H,4H) -> K2^T fragments in the order the kernel reads them:
+// [slice 8][wave 4][block = tl*8 + jb, 32][lane 64][s 4] = K2[nout][gcol], nout = 32*(2*wave + (tl>>1)) + 16*(tl&1) + (lane&15),
+// gcol = (lc>>5)*H + 32*slice + (lc&31), lc = 16*jb + 4*(lane>>4) + s
+__global__ __launch_bounds__(256) void mix_decoder_bwd_pack_k2_kernel(const float* __restrict__ K2, float* __restrict__ out) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= BH * 4 * BH) return;
+    const int s = idx & 3, lane = (idx >> 2) & 63, blk = (idx >> 8) & 31, wave = (idx >> 13) & 3, slice = idx >> 15;
+    const int tl = blk >> 3, jb = blk & 7;
+    const int nout = 32 * (2 * wave + (tl >> 1)) + 16 * (tl & 1) + (lane & 15);
+    const int lc = 16 * jb + 4 * (lane >> 4) + s;
+    const int gcol = (lc >> 5) * BH + 32 * slice + (lc & 31);
+    out[idx] = K2[(size_t)nout * (4 * BH) + gcol];
+}
+
+size_t mix_decoder_bwd_workspace_bytes(int B) {
+    const int tiles = (B + BBT - 1) / BBT;
+    int groups = tiles < 32 ? tiles : 32;
+    if (groups < 1) groups = 1;
+    return kStatusBytes + (size_t)groups * MB_GROUP * sizeof(unsigned long long) + sizeof(float) * (size_t)BH * 4 * BH;
+}
+
+int mix_decoder_bwd_launch(MixDecBwdParams p, const float* K2, int act, void* workspace, hipStream_t stream) {
+    if (p.B == 0 || p.T_out == 0) return FOV_OK;
+    p.num_tiles = (p.B + BBT - 1) / BBT;
+    p.num_groups = p.num_tiles < 32 ? p.num_tiles : 32;
+    const size_t xch_bytes = (size_t)p.num_groups * MB_GROUP * sizeof(unsigned long long);
+    p.status = (unsigned*)workspace;
+    p.xch = (unsigned long long*)((char*)workspace + kStatusBytes);
+    float* k2p = (float*)((char*)workspace + kStatusBytes + xch_bytes);
+    p.K2p = k2p;
+    hipError_t e = hipMemsetAsync(workspace, 0, kStatusBytes + xch_bytes, stream);
+    if (e != hipSuccess) { set_error("hipMemsetAsync: %s", hipGetErrorString(e)); return FOV_ERR_LAUNCH; }
+    hipLaunchKernelGGL(mix_decoder_bwd_pack_k2_kernel, dim3(BH * 4 * BH / 256), dim3(256), 0, stream, K2, k2p);
+    const size_t lds = sizeof(float) * (BBT * BLDZ + BBT * 8 + BBT * 8 + 128 * 8 + 16 + 4 * BK2_LDS_BLOCKS * 256);
+    void (*kern)(MixDecBwdParams) = act == FOV_ACT_HARD_SIGMOID ? mix_decoder_bwd_kernel<FOV_ACT_HARD_SIGMOID> : mix_decoder_bwd_kernel<FOV_ACT_SIGMOID>;
+    e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return FOV_ERR_LAUNCH; }
+    hipLaunchKernelGGL(kern, dim3(p.num_groups * BG), dim3(256), lds, stream, p);
+    e = hipGetLastError();
+    if (e != hipSuccess) { set_error("mix_decoder_bwd launch: %s", hipGetErrorString(e)); return FOV_ERR_LAUNCH; }
+    return FOV_OK;
+}
+
+}  // namespace fov

@@ -347,6 +347,27 @@ def mix_decoder(dec0, h1, c1, h2, c2, oth_proj, w, mix_Wp, T_out, act="sigmoid",
     return out
 
 
+def mix_decoder_bwd(M, P, dloss, res1, res2, C1, C2, w, mix_Wp, out, act="sigmoid", workspace=None):
+    """BPTT through the unrolled decoder in one launch.  M, P, dloss (T_out,B,O); res1, res2 (T_out,B,5,H); C1, C2
+    (>= T_out rows of (B,H), row t = cell state before step t); out: dict with preallocated DZ1, DZ2 (T_out,B,4H),
+    dpre_m, dpre_p (T_out,B,O), dh1_0, dc1_0, dh2_0, dc2_0 (B,H)."""
+    M, P, dloss = _dev(M, "M"), _dev(P, "P"), _dev(dloss, "dloss")
+    T_out, B, O = M.shape
+    H = w["dec1_R"].shape[0]
+    L = _lib.lib()
+    ws = workspace or Workspace()
+    buf = ws.get(L.fov_mix_decoder_bwd_workspace_bytes(B, H), M.device)
+    names = ("DZ1", "DZ2", "dpre_m", "dpre_p", "dh1_0", "dc1_0", "dh2_0", "dc2_0")
+    check(L.fov_mix_decoder_bwd(_ptr(M), _ptr(P), _ptr(dloss), _ptr(_dev(res1, "res1")), _ptr(_dev(res2, "res2")),
+                                _ptr(_dev(C1, "C1")), _ptr(_dev(C2, "C2")),
+                                _ptr(_dev(w["dec1_K"], "K1")), _ptr(_dev(w["dec1_R"], "R1")),
+                                _ptr(_dev(w["dec2_K"], "K2")), _ptr(_dev(w["dec2_R"], "R2")),
+                                _ptr(_dev(w["dense_W"], "Wd")), _ptr(_dev(mix_Wp, "Wp")),
+                                *[_ptr(_dev(out[k], k)) for k in names],
+                                B, T_out, H, O, act_code(act), buf.data_ptr(), buf.numel(), _stream()))
+    return out
+
+
 def mix_head_fwd(h, dense_W, dense_b, mix_Wp, add, p_out, m_out):
     """p = tanh(h dense_W + dense_b), m = tanh(p mix_Wp + add) in one launch; add (N,O) may be a strided row view."""
     h, dense_W, dense_b, mix_Wp = _dev(h, "h"), _dev(dense_W, "dense_W"), _dev(dense_b, "dense_b"), _dev(mix_Wp, "mix_Wp")

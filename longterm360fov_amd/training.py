@@ -116,7 +116,8 @@ class OthersMixingTrainer:
     first decoder layer), then every weight gradient is one product over all steps.  Gradients accumulate into
     ONE flat buffer (one all-reduce under DP)."""
 
-    fused_decoder = True   # H = 256: forward of the unrolled decoder as ONE launch; False = step-wise calls
+    fused_decoder = True       # H = 256: forward of the unrolled decoder as ONE launch; False = step-wise calls
+    fused_decoder_bwd = True   # H = 256: BPTT through the unrolled decoder as ONE launch; False = step-wise calls
 
     def __init__(self, weights, act="sigmoid", impl="auto", optimizer="adam", lr=1e-3, device="cuda"):
         self.act, self.impl, self.optimizer, self.lr, self.device = act, impl, optimizer, float(lr), device
@@ -136,6 +137,7 @@ class OthersMixingTrainer:
             off += cnt
         self.step_count = 0
         self.ws, self.scratch, self.bwd_scratch = ops.Workspace(), ops.Scratch(), ops.Scratch()
+        self.ws_bwd = ops.Workspace()   # granule mailboxes of the fused decoder backward
 
     def weights_numpy(self):
         return {k: v.detach().cpu().numpy().copy() for k, v in self.w.items()}
@@ -194,7 +196,13 @@ class OthersMixingTrainer:
         DZ1, DZ2 = e(T_out, B, 4 * H), e(T_out, B, 4 * H)
         dh1_rec = dc1 = dh2_rec = dc2 = None
         dx_next = None
-        for t in range(T_out - 1, -1, -1):
+        fused_bwd = self.fused_decoder_bwd and ops.mix_decoder_supported(H, O)
+        if fused_bwd:   # BPTT through the whole unrolled decoder (head, layer 2, layer 1, feedback) in one launch
+            dh1_rec, dc1, dh2_rec, dc2 = e(B, H), e(B, H), e(B, H), e(B, H)
+            ops.mix_decoder_bwd(M, P, dloss_tm, R1.view(T_out, B, 5, H), R2.view(T_out, B, 5, H), C1, C2, w, Wm_p_c,
+                                {"DZ1": DZ1, "DZ2": DZ2, "dpre_m": dpre_all, "dpre_p": dpre_p_all, "dh1_0": dh1_rec,
+                                 "dc1_0": dc1, "dh2_0": dh2_rec, "dc2_0": dc2}, act=act, workspace=self.ws_bwd)
+        for t in range(-1 if fused_bwd else T_out - 1, -1, -1):
             # mixing head of step t in one launch: the feedback gradient (x_{t+1} = m_t) joins through tanh',
             # then the two tiny Dense layers backwards; weight gradients are formed after the loop
             dh2_dense = ops.mix_head_bwd(dloss_tm[t], None if dx_next is None else dx_next.reshape(B, O), M[t], P[t], Wm_p_c,

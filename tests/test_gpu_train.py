@@ -284,7 +284,8 @@ def _torch_mixing_graph(enc, oth, dec0, tgt, w, act):
 
 
 @pytest.mark.parametrize("H,B,U,T_in,T_out,act", [(64, 20, 5, 4, 3, "sigmoid"), (128, 33, 34, 5, 4, "hard_sigmoid"),
-                                                  (256, 16, 34, 3, 3, "sigmoid")])
+                                                  (256, 16, 34, 3, 3, "sigmoid"), (256, 37, 5, 2, 4, "hard_sigmoid"),
+                                                  (256, 530, 3, 2, 2, "sigmoid")])
 def test_others_mixing_gradients_and_training(H, B, U, T_in, T_out, act):
     """a4 training: gradients of the unrolled no-teacher-forcing graph (feedback path included) against
     torch.autograd in fp64, then three Adam steps reduce the loss."""
@@ -303,9 +304,11 @@ def test_others_mixing_gradients_and_training(H, B, U, T_in, T_out, act):
         err = np.abs(a - g_ref[k]).max()
         print("mixing H%d grad %-8s max|ref| %.3e  max err %.3e" % (H, k, scale, err))
         assert err <= 1e-4 * scale + 1e-9, (k, err, scale)
-    if H == 256:   # the fused forward and the step-wise forward leave the same tape: identical gradients
+    if H == 256:   # the fused forward / backward launches and the step-wise path give the same gradients
+        tr.ws_bwd.check()
         tr2 = OthersMixingTrainer(w, act=act)
         tr2.fused_decoder = False
+        tr2.fused_decoder_bwd = False
         loss2, y2 = tr2.forward_backward(dev(enc), dev(oth), dev(dec0), dev(tgt))
         assert abs(float(loss2.item()) - float(loss.item())) <= 1e-6 * abs(float(loss.item())) + 1e-9
         for k in _MIX_ORDER:
