@@ -153,26 +153,30 @@ class OthersMixingTrainer:
         gWm_o, gWm_p = g["mix_W"][:n_oth], g["mix_W"][n_oth:]
         self.grad.zero_()
         # ---------------- forward (keeping what the backward needs) ----------------
-        hs1, h1, c1, res1 = ops.lstm_seq_train(enc, w["enc1_K"], w["enc1_R"], w["enc1_b"], act=act, impl=impl, workspace=ws)
+        e = lambda *s_: torch.empty(s_, dtype=torch.float32, device=self.device)
+        # decoder state tapes, time-major: row 0 = the encoder's final state (written there by the encoder kernels),
+        # row t+1 = state after decoder step t
+        H1, C1 = e(T_out + 1, B, H), e(T_out + 1, B, H)
+        H2, C2 = e(T_out + 1, B, H), e(T_out + 1, B, H)
+        hs1, h1, c1, res1 = ops.lstm_seq_train(enc, w["enc1_K"], w["enc1_R"], w["enc1_b"], act=act, impl=impl, workspace=ws,
+                                               out=(e(B, T_in, H), H1[0], C1[0], e(B, T_in, 5, H)))
         if H == 256 and impl != "generic":   # layer 2 over the 256-wide sequence: K2 and R2 register-resident
-            hs2, h2, c2, res2 = ops.lstm_seq_train(hs1, w["enc2_K"], w["enc2_R"], w["enc2_b"], act=act, impl=impl, workspace=ws)
+            hs2, h2, c2, res2 = ops.lstm_seq_train(hs1, w["enc2_K"], w["enc2_R"], w["enc2_b"], act=act, impl=impl, workspace=ws,
+                                                   out=(e(B, T_in, H), H2[0], C2[0], e(B, T_in, 5, H)))
         else:
             zx2 = ops.matmul(hs1.reshape(B * T_in, H), w["enc2_K"], scratch=sc).reshape(B, T_in, 4 * H)
             res2 = torch.empty((B, T_in, 5, H), dtype=torch.float32, device=self.device)
-            hs2, h2, c2 = ops.lstm_seq_zx(zx2, w["enc2_R"], w["enc2_b"], act=act, impl=impl, workspace=ws, reserve=res2)
+            hs2, h2, c2 = ops.lstm_seq_zx(zx2, w["enc2_R"], w["enc2_b"], act=act, impl=impl, workspace=ws, reserve=res2,
+                                          out=(e(B, T_in, H), H2[0], C2[0]))
         oth_flat = others.reshape(B * T_out, n_oth)
         Wm_o_c, Wm_p_c = Wm_o.contiguous(), Wm_p.contiguous()
         oth_proj = ops.dense(oth_flat, Wm_o_c, w["mix_b"], activation=None).reshape(B, T_out, O)
         # Decoder tape, time-major: step t reads row t of the "previous state" stacks and writes row t+1, so the
         # stacked rows are exactly the operands of the per-layer weight-gradient products formed after the loop.
-        e = lambda *s_: torch.empty(s_, dtype=torch.float32, device=self.device)
         XM = e(T_out + 1, B, O)                               # row t = decoder input x_t, row t+1 = output m_t
         X, M = XM[:T_out], XM[1:]
-        H1, C1 = e(T_out + 1, B, H), e(T_out + 1, B, H)       # row 0 = encoder state, row t+1 = state after step t
-        H2, C2 = e(T_out + 1, B, H), e(T_out + 1, B, H)
         R1, R2 = e(T_out, B, 1, 5, H), e(T_out, B, 1, 5, H)   # reserves (i,f,g,o,c) of every step
         P = e(T_out, B, O)
-        H1[0].copy_(h1); C1[0].copy_(c1); H2[0].copy_(h2); C2[0].copy_(c2)
         X[0].copy_(dec0.reshape(B, O))
         fused = self.fused_decoder and ops.mix_decoder_supported(H, O)
         if fused:   # the whole unrolled forward in one persistent launch, writing the same tape
