@@ -16,8 +16,9 @@
 //             28/32 fragment blocks in LDS + 4 in VGPRs (the forward kernel's arrangement).
 //             The 16 x 32 piece of each destination workgroup travels as {value, epoch} granules; every lane
 //             gathers the 8 pieces of its own cells and adds them in slice order (deterministic).
-//   layer 1   the same with R1^T (128 AGPRs) -> dh1_{t-1}; dx_t = dz1 . K1^T (16 x O) is summed the same way and
-//             feeds the head of step t-1 (x_t = m_{t-1}).
+//   layer 1   the same with R1^T (128 AGPRs) -> dh1_{t-1}; dx_t = dz1 . K1^T (16 x O, on the VALU: a 17th MFMA tile on one
+//             wave made that wave the straggler of every barrier) is summed the same way and feeds the head of step
+//             t-1 (x_t = m_{t-1}).
 // MFMA-bound in arithmetic (392 per wave and step, as the forward), in practice bound by its two exposed
 // exchanges per step.
 #include <stdlib.h>
@@ -61,6 +62,25 @@ __device__ __forceinline__ float bact_grad(float a) {
 }
 
 }  // namespace
+
+// Diagnostic build only (-DFOV_STAMPS, tools/stamp_mix_decoder.py --bwd): s_memtime stamps of one wave per step.
+#ifdef FOV_STAMPS
+constexpr int BSTAMP_SLOTS = 12;
+constexpr int BSTAMP_STEPS = 32;
+__device__ unsigned long long g_mixb_stamps[BSTAMP_STEPS][BSTAMP_SLOTS];
+#define MIXB_STAMP(slot)                                                                       \
+    do {                                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                     \
+        if (stamp_on && (T - 1 - t) < BSTAMP_STEPS) {                                          \
+            unsigned long long t_;                                                             \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");        \
+            g_mixb_stamps[T - 1 - t][slot] = t_;                                               \
+        }                                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                     \
+    } while (0)
+#else
+#define MIXB_STAMP(slot) do { } while (0)
+#endif
 
 // granule areas of one group, in granules (8 bytes each); two parities of each
 constexpr size_t MB2 = (size_t)BG * BG * 2 * BBT * 32;   // [dest][src][product][row][unit]
@@ -141,6 +161,9 @@ __global__ __launch_bounds__(256, 1) void mix_decoder_bwd_kernel(MixDecBwdParams
     const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(gbase + 2 * MB2 + 2 * MB1, 0, (int)(2 * MBX * 8), 0x00020000);
     unsigned epoch = 0;
     bool aborted = false;
+#ifdef FOV_STAMPS
+    const bool stamp_on = (blockIdx.x == 5 && tid == 0);
+#endif
     auto give_up = [&]() {
         if (lane == 0) {
             __hip_atomic_store(p.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -205,9 +228,24 @@ __global__ __launch_bounds__(256, 1) void mix_decoder_bwd_kernel(MixDecBwdParams
         float dc1[2] = {0.f, 0.f}, dc2[2] = {0.f, 0.f}, dh1r[2] = {0.f, 0.f}, dh2r[2] = {0.f, 0.f};
         __syncthreads();
         for (int t = T - 1; t >= 0; --t) {
+            MIXB_STAMP(0);
             ++epoch;
             const unsigned par2 = (epoch & 1u) * (unsigned)(MB2 * 8), par1 = (epoch & 1u) * (unsigned)(MB1 * 8),
                            parx = (epoch & 1u) * (unsigned)(MBX * 8);
+            // tape of layer 2 for this lane's two cells: requested now, consumed after the head
+            float tp[2][6];
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int row = b0 + my_row0 + r;
+#pragma unroll
+                for (int k = 0; k < 6; ++k) tp[r][k] = 0.f;
+                if (row < p.B) {
+                    const float* rp = p.res2 + (((size_t)t * p.B + row) * 5) * BH + unit;
+#pragma unroll
+                    for (int k = 0; k < 5; ++k) tp[r][k] = rp[k * BH];
+                    tp[r][5] = p.C2[((size_t)t * p.B + row) * BH + unit];
+                }
+            }
             // ================= head backward (every workgroup, its 16 sequences) =================
             {
                 const int brow = b0 + hrow;
@@ -225,7 +263,9 @@ __global__ __launch_bounds__(256, 1) void mix_decoder_bwd_kernel(MixDecBwdParams
                     p.dpre_p[hidx] = dpp;
                 }
             }
+            MIXB_STAMP(1);
             __syncthreads();   // dpre_p of the step is in LDS; every wave is past the previous step's MFMAs
+            MIXB_STAMP(2);
             // ================= layer 2: gates backward for this lane's two cells =================
             float dz[2][4];
 #pragma unroll
@@ -234,12 +274,7 @@ __global__ __launch_bounds__(256, 1) void mix_decoder_bwd_kernel(MixDecBwdParams
                 float dhd = 0.f;
 #pragma unroll
                 for (int o = 0; o < 8; ++o) dhd = fmaf(sDP[(my_row0 + r) * 8 + o], wd[o], dhd);
-                float ig = 0.f, fg = 0.f, gg = 0.f, og = 0.f, ct = 0.f, cp = 0.f;
-                if (row < p.B) {
-                    const float* rp = p.res2 + (((size_t)t * p.B + row) * 5) * BH + unit;
-                    ig = rp[0]; fg = rp[BH]; gg = rp[2 * BH]; og = rp[3 * BH]; ct = rp[4 * BH];
-                    cp = p.C2[((size_t)t * p.B + row) * BH + unit];
-                }
+                const float ig = tp[r][0], fg = tp[r][1], gg = tp[r][2], og = tp[r][3], ct = tp[r][4], cp = tp[r][5];
                 const float tc = tanh_f(ct);
                 const float dh = dhd + dh2r[r];
                 const float dct = dc2[r] + dh * og * (1.f - tc * tc);
@@ -256,6 +291,7 @@ __global__ __launch_bounds__(256, 1) void mix_decoder_bwd_kernel(MixDecBwdParams
 #pragma unroll
                 for (int g = 0; g < 4; ++g) sDZ[(my_row0 + r) * BLDZ + g * 32 + ul] = (row < p.B) ? dz[r][g] : 0.f;
             }
+            MIXB_STAMP(3);
             __syncthreads();   // the dz2 tile is in LDS
             // ================= partial[16 x 512] = dz2_own . [R2^T | K2^T]_own =================
             {
@@ -264,20 +300,29 @@ __global__ __launch_bounds__(256, 1) void mix_decoder_bwd_kernel(MixDecBwdParams
                 for (int i = 0; i < 8; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 bm_begin<8>(acc);
                 const float* arow = sDZ + n * BLDZ + 4 * g4;
+                // software pipeline over the 32 (jb, tl) blocks: the A fragment of the next jb and the K2^T fragment of
+                // the next block are requested one iteration ahead (an LDS read right before its MFMAs costs ~100
+                // cycles each time)
+                auto k2frag = [&](int it) -> f32x4 {   // it = jb*4 + tl -> packed block tl*8 + jb
+                    const int blk = (it & 3) * 8 + (it >> 2);
+                    return (blk < BK2_LDS_BLOCKS) ? *(const f32x4*)(sK2l + blk * 256) : k2r[blk - BK2_LDS_BLOCKS];
+                };
+                f32x4 a = *(const f32x4*)arow, an = a;
+                f32x4 kb = k2frag(0), kn = kb;
 #pragma unroll
-                for (int jb = 0; jb < 8; ++jb) {
-                    f32x4 a = *(const f32x4*)(arow + 16 * jb);
-                    asm volatile("s_nop 1" : "+v"(a));
+                for (int it = 0; it < 32; ++it) {
+                    const int jb = it >> 2, tl = it & 3;
+                    if (it + 1 < 32) kn = k2frag(it + 1);
+                    if (tl == 0 && jb + 1 < 8) an = *(const f32x4*)(arow + 16 * (jb + 1));
+                    if (tl == 0) asm volatile("s_nop 1" : "+v"(a));
+                    asm volatile("s_nop 1" : "+v"(kb));
 #pragma unroll
-                    for (int tl = 0; tl < 4; ++tl) {
-                        const int blk = tl * 8 + jb;
-                        const f32x4 kb = (blk < BK2_LDS_BLOCKS) ? *(const f32x4*)(sK2l + blk * 256) : k2r[blk - BK2_LDS_BLOCKS];
-#pragma unroll
-                        for (int s = 0; s < 4; ++s) {
-                            bm_a(acc[tl], a[s], r2t[tl][jb][s]);
-                            bm_v(acc[4 + tl], a[s], kb[s]);
-                        }
+                    for (int s = 0; s < 4; ++s) {
+                        bm_a(acc[tl], a[s], r2t[tl][jb][s]);
+                        bm_v(acc[4 + tl], a[s], kb[s]);
                     }
+                    kb = kn;
+                    if (tl == 3) a = an;
                 }
                 bm_end<8>(acc);
                 // publish: tile tl of product q goes to destination d = 2*wave + (tl>>1), rows 4*g4 + r, unit 16*(tl&1) + n
@@ -292,6 +337,20 @@ __global__ __launch_bounds__(256, 1) void mix_decoder_bwd_kernel(MixDecBwdParams
                             __builtin_amdgcn_raw_buffer_store_b64((bwu32x2){__float_as_uint(acc[q * 4 + tl][r]), epoch}, rs2, off + r * 32 * 8, par2, 16);
                     }
             }
+            // tape of layer 1: requested under the exchange wait below
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int row = b0 + my_row0 + r;
+#pragma unroll
+                for (int k = 0; k < 6; ++k) tp[r][k] = 0.f;
+                if (row < p.B) {
+                    const float* rp = p.res1 + (((size_t)t * p.B + row) * 5) * BH + unit;
+#pragma unroll
+                    for (int k = 0; k < 5; ++k) tp[r][k] = rp[k * BH];
+                    tp[r][5] = p.C1[((size_t)t * p.B + row) * BH + unit];
+                }
+            }
+            MIXB_STAMP(4);
             __syncthreads();   // every wave is done reading the dz2 tile
             // ================= gather the 8 pieces of this lane's cells: dh2_{t-1} and dh1_t =================
             float dh1in[2];
@@ -308,17 +367,13 @@ __global__ __launch_bounds__(256, 1) void mix_decoder_bwd_kernel(MixDecBwdParams
                     else { dh1in[0] = sum[0]; dh1in[1] = sum[1]; }
                 }
             }
+            MIXB_STAMP(5);
             if (sFlag[0]) { aborted = true; }
             // ================= layer 1: gates backward =================
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
                 const int row = b0 + my_row0 + r;
-                float ig = 0.f, fg = 0.f, gg = 0.f, og = 0.f, ct = 0.f, cp = 0.f;
-                if (row < p.B) {
-                    const float* rp = p.res1 + (((size_t)t * p.B + row) * 5) * BH + unit;
-                    ig = rp[0]; fg = rp[BH]; gg = rp[2 * BH]; og = rp[3 * BH]; ct = rp[4 * BH];
-                    cp = p.C1[((size_t)t * p.B + row) * BH + unit];
-                }
+                const float ig = tp[r][0], fg = tp[r][1], gg = tp[r][2], og = tp[r][3], ct = tp[r][4], cp = tp[r][5];
                 const float tc = tanh_f(ct);
                 const float dh = dh1in[r] + dh1r[r];
                 const float dct = dc1[r] + dh * og * (1.f - tc * tc);
@@ -335,32 +390,44 @@ __global__ __launch_bounds__(256, 1) void mix_decoder_bwd_kernel(MixDecBwdParams
 #pragma unroll
                 for (int g = 0; g < 4; ++g) sDZ[(my_row0 + r) * BLDZ + g * 32 + ul] = (row < p.B) ? dz[r][g] : 0.f;
             }
+            MIXB_STAMP(6);
             __syncthreads();   // the dz1 tile is in LDS
-            // ================= partial[16 x 256] = dz1_own . R1^T_own, and dx partial = dz1_own . K1^T_own =================
+            // ================= dx partial = dz1_own . K1^T_own (16 x O): thread (sequence, output, half of the columns) ======
             {
-                f32x4 acc[5];
+                const int o = ho & 7, half = ho >> 3;
+                const float* zr = sDZ + hrow * BLDZ + 64 * half;
+                const float* kr = sK1T + (64 * half) * 8 + o;
+                float sx = 0.f;
 #pragma unroll
-                for (int i = 0; i < 5; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                bm_begin<5>(acc);
+                for (int c4 = 0; c4 < 16; ++c4) {
+                    const f32x4 zv = *(const f32x4*)(zr + 4 * c4);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) sx = fmaf(zv[k], kr[(4 * c4 + k) * 8], sx);
+                }
+                sx += __shfl_xor(sx, 8);   // the two column halves of one (sequence, output)
+                if (ho < 8)
+                    __builtin_amdgcn_raw_buffer_store_b64((bwu32x2){__float_as_uint(sx), epoch}, rsx,
+                                                          (unsigned)((slice * BBT + hrow) * 8 + ho) * 8u, parx, 16);
+            }
+            // ================= partial[16 x 256] = dz1_own . R1^T_own =================
+            {
+                f32x4 acc[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                bm_begin<4>(acc);
                 const float* arow = sDZ + n * BLDZ + 4 * g4;
+                f32x4 a = *(const f32x4*)arow, an = a;
 #pragma unroll
                 for (int jb = 0; jb < 8; ++jb) {
-                    f32x4 a = *(const f32x4*)(arow + 16 * jb);
+                    if (jb + 1 < 8) an = *(const f32x4*)(arow + 16 * (jb + 1));
                     asm volatile("s_nop 1" : "+v"(a));
 #pragma unroll
                     for (int tl = 0; tl < 4; ++tl)
 #pragma unroll
                         for (int s = 0; s < 4; ++s) bm_a(acc[tl], a[s], r1t[tl][jb][s]);
-                    if (wave == 0) {   // dx tile: B = K1^T rows of the own gate columns, column n = output o (zero for n >= 8)
-                        float kb[4];
-#pragma unroll
-                        for (int s = 0; s < 4; ++s) kb[s] = (n < 8) ? sK1T[(16 * jb + 4 * g4 + s) * 8 + n] : 0.f;
-                        asm volatile("s_nop 1" : "+v"(kb[0]), "+v"(kb[1]), "+v"(kb[2]), "+v"(kb[3]));
-#pragma unroll
-                        for (int s = 0; s < 4; ++s) bm_v(acc[4], a[s], kb[s]);
-                    }
+                    a = an;
                 }
-                bm_end<5>(acc);
+                bm_end<4>(acc);
 #pragma unroll
                 for (int tl = 0; tl < 4; ++tl) {
                     const int d = 2 * wave + (tl >> 1);
@@ -369,13 +436,8 @@ __global__ __launch_bounds__(256, 1) void mix_decoder_bwd_kernel(MixDecBwdParams
                     for (int r = 0; r < 4; ++r)
                         __builtin_amdgcn_raw_buffer_store_b64((bwu32x2){__float_as_uint(acc[tl][r]), epoch}, rs1, off + r * 32 * 8, par1, 16);
                 }
-                if (wave == 0 && n < 8) {
-                    const unsigned off = (unsigned)((slice * BBT + 4 * g4) * 8 + n) * 8u;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        __builtin_amdgcn_raw_buffer_store_b64((bwu32x2){__float_as_uint(acc[4][r]), epoch}, rsx, off + r * 8 * 8, parx, 16);
-                }
             }
+            MIXB_STAMP(7);
             // ================= gather: dh1_{t-1} of this lane's cells, and dx_t (every workgroup needs all of it) =================
             {
                 unsigned voff[2];
@@ -391,6 +453,7 @@ __global__ __launch_bounds__(256, 1) void mix_decoder_bwd_kernel(MixDecBwdParams
                 __syncthreads();   // every wave is done with the dz1 tile and with sDX of this step
                 if (ho < 8) sDX[hrow * 8 + ho] = sum[0];
             }
+            MIXB_STAMP(8);
             if (sFlag[0]) aborted = true;
             __syncthreads();   // dx_t is in LDS (also makes `aborted` uniform below)
             if (sFlag[0]) { aborted = true; break; }
@@ -452,5 +515,11 @@ int mix_decoder_bwd_launch(MixDecBwdParams p, const float* K2, int act, void* wo
     if (e != hipSuccess) { set_error("mix_decoder_bwd launch: %s", hipGetErrorString(e)); return FOV_ERR_LAUNCH; }
     return FOV_OK;
 }
+
+#ifdef FOV_STAMPS
+extern "C" int fov_debug_read_mixb_stamps(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mixb_stamps), sizeof(unsigned long long) * BSTAMP_STEPS * BSTAMP_SLOTS);
+}
+#endif
 
 }  // namespace fov

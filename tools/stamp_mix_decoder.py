@@ -47,5 +47,36 @@ def main():
         print("   %-48s %8.0f cyc  %5.1f%%" % (SEG[i], v, 100.0 * v / med.sum()))
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and "--bwd" not in sys.argv:
     main()
+
+
+def main_bwd():
+    """Same for the backward kernel (python tools/stamp_mix_decoder.py --bwd)."""
+    SEGB = ["head backward", "barrier", "layer-2 gates backward (reserve loads) + dz2 -> LDS", "barrier + MFMAs (256) + publish",
+            "barrier + gather of dh2 / dh1 pieces", "layer-1 gates backward + dz1 -> LDS", "barrier + MFMAs (128+32) + publish",
+            "gather of dh1 / dx pieces + barrier"]
+    from longterm360fov_amd.training import OthersMixingTrainer
+    B, T_in, T_out, H, U = 512, 10, 10, 256, 34
+    w = O.init_others_mixing(1234, H=H, num_user=U, bias_noise=0.05)
+    enc, dec0, tgt, oth = O.synthetic_batch(1234, B, T_in, T_out, num_others=U - 1)
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    tr = OthersMixingTrainer(w)
+    for _ in range(3):
+        tr.forward_backward(d(enc), d(oth), d(dec0), d(tgt))
+    tr.ws.check(); tr.ws_bwd.check()
+    L = _lib.lib()
+    buf = np.zeros((32, 12), dtype=np.uint64)
+    L.fov_debug_read_mixb_stamps.argtypes = [ctypes.c_void_p]
+    assert L.fov_debug_read_mixb_stamps(buf.ctypes.data_as(ctypes.c_void_p)) == 0
+    s = buf[:T_out, :9].astype(np.int64)
+    seg = np.diff(s, axis=1)
+    step = np.diff(s[:, 0])
+    print("backward step: median %.0f cycles (%.2f us at 2.17 GHz)" % (np.median(step), np.median(step) / 2170.0))
+    med = np.median(seg[1:], axis=0)
+    for i, v in enumerate(med):
+        print("   %-60s %8.0f cyc  %5.1f%%" % (SEGB[i], v, 100.0 * v / med.sum()))
+
+
+if __name__ == "__main__" and "--bwd" in sys.argv:
+    main_bwd()
