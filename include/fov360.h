@@ -237,10 +237,25 @@ int fov_mse_dense_grad(const float* y, const float* target, float* dpre, float* 
                        int activation, void* workspace, size_t workspace_bytes, fov_stream_t stream);
 
 /* Backward of an elementwise activation given its OUTPUT y: out = base + dy * act'(y), act' = 1 - y^2 for tanh
- * (activation 1), [y > 0] for relu (activation 2) or 1 (activation 0); base may be NULL; out may alias base or dy.  Used where a Dense output is
+ * (activation 1), [y > 0] for relu (activation 2), y for exp (activation 3) or 1 (activation 0); base may be NULL; out may alias base or dy.  Used where a Dense output is
  * fed back as the next decoder input (given_others...py:292-293): the feedback gradient joins the loss gradient. */
 int fov_act_bwd(const float* dy, const float* y, const float* base, float* out, int64_t n, int activation,
                 fov_stream_t stream);
+
+/* Pieces of the raw-TensorFlow model's training graph (mycode/lstm.py:218-240,321-337,556-567, cost.py:190-229).
+ *   fov_act_fwd: y = act(x), 0 identity, 1 tanh, 2 relu, 3 exp (the two-layer heads of _pred_mean_var_xyz2_new);
+ *     fov_act_bwd takes the same codes (exp: dy * y).
+ *   fov_gauss_nll_grad: likelihood_loss_tf - mu, var (B,3); y (B,T_y,3*fps) interleaved x,y,z; per element
+ *     l = log(var + 1e-20) + (y - mu)^2 / (var + 1e-20) clipped to [-10,10]; *loss = scale * mean_b sum l (scale =
+ *     1/(running_length*fps) under cfg.process_in_seconds); dmu, dvar (B,3).  workspace >= 4*(B + 64) bytes.
+ *   fov_rmsprop_tf_step: tf.train.RMSPropOptimizer (momentum 0): g' = clip_by_value(g, -clip, clip) if clip > 0;
+ *     ms = decay*ms + (1-decay) g'^2; p -= lr * g' / sqrt(ms + eps)   (TF initialises ms to ONE, eps = 1e-10). */
+int fov_act_fwd(const float* x, float* y, int64_t n, int activation, fov_stream_t stream);
+int fov_gauss_nll_grad(const float* mu, const float* var, const float* y, float* loss, float* dmu, float* dvar,
+                       int B, int T_y, int fps, float scale, void* workspace, size_t workspace_bytes,
+                       fov_stream_t stream);
+int fov_rmsprop_tf_step(float* params, const float* grads, float* ms, int64_t n, float lr, float decay, float eps,
+                        float clip_value, fov_stream_t stream);
 
 /* Keras-2.2 optimizers on one flat parameter buffer.
  *   Adam   : lr_t = lr*sqrt(1-beta2^step)/(1-beta1^step); p -= lr_t*m/(sqrt(v)+eps)   (step >= 1)

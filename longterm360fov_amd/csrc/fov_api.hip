@@ -466,11 +466,41 @@ int fov_mse_dense_grad(const float* y, const float* target, float* dpre, float* 
 
 int fov_act_bwd(const float* dy, const float* y, const float* base, float* out, int64_t n, int activation,
                 fov_stream_t stream) {
-    if (n < 0 || (n > 0 && (!dy || !y || !out)) || (activation != 0 && activation != 1 && activation != 2)) {
+    if (n < 0 || (n > 0 && (!dy || !y || !out)) || (activation < 0 || activation > 3)) {
         set_error("fov_act_bwd: invalid argument");
         return FOV_ERR_INVALID;
     }
     return act_bwd(dy, y, base, out, (long)n, activation, (hipStream_t)stream);
+}
+
+int fov_act_fwd(const float* x, float* y, int64_t n, int activation, fov_stream_t stream) {
+    if (n < 0 || (n > 0 && (!x || !y)) || activation < 0 || activation > 3) {
+        set_error("fov_act_fwd: invalid argument");
+        return FOV_ERR_INVALID;
+    }
+    return act_fwd(x, y, (long)n, activation, (hipStream_t)stream);
+}
+
+int fov_gauss_nll_grad(const float* mu, const float* var, const float* y, float* loss, float* dmu, float* dvar, int B,
+                       int T_y, int fps, float scale, void* workspace, size_t workspace_bytes, fov_stream_t stream) {
+    if (B < 0 || T_y <= 0 || fps <= 0 || (B > 0 && (!mu || !var || !y || !dmu || !dvar))) {
+        set_error("fov_gauss_nll_grad: invalid argument");
+        return FOV_ERR_INVALID;
+    }
+    if (B == 0) return FOV_OK;
+    int rc = check_ws(workspace, workspace_bytes, sizeof(float) * ((size_t)B + 64));
+    if (rc) return rc;
+    return gauss_nll_grad(mu, var, y, loss, dmu, dvar, B, T_y, fps, scale, (float*)workspace, workspace_bytes / sizeof(float),
+                          (hipStream_t)stream);
+}
+
+int fov_rmsprop_tf_step(float* params, const float* grads, float* ms, int64_t n, float lr, float decay, float eps,
+                        float clip_value, fov_stream_t stream) {
+    if (n < 0 || (n > 0 && (!params || !grads || !ms))) {
+        set_error("fov_rmsprop_tf_step: invalid argument");
+        return FOV_ERR_INVALID;
+    }
+    return rmsprop_tf_step(params, grads, ms, (long)n, lr, decay, eps, clip_value, (hipStream_t)stream);
 }
 
 int fov_adam_step(float* params, const float* grads, float* m, float* v, int64_t n, float lr, float beta1,

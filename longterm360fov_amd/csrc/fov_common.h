@@ -153,5 +153,10 @@ int matmul_f32(const float* a, const float* b, float* c, int M, int K, int N, fl
 int adam_step(float* p, const float* g, float* m, float* v, long n, float lr_t, float b1, float b2, float eps,
               hipStream_t stream);
 int rmsprop_step(float* p, const float* g, float* a, long n, float lr, float rho, float eps, hipStream_t stream);
+int act_fwd(const float* x, float* y, long n, int activation, hipStream_t stream);
+int gauss_nll_grad(const float* mu, const float* var, const float* y, float* loss, float* dmu, float* dvar, int B, int Ty,
+                   int fps, float scale, float* scratch, size_t scratch_floats, hipStream_t stream);
+int rmsprop_tf_step(float* p, const float* g, float* ms, long n, float lr, float decay, float eps, float clip,
+                    hipStream_t stream);
 
 }  // namespace fov

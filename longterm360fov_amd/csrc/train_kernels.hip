@@ -367,13 +367,13 @@ __global__ __launch_bounds__(256) void sum_scale_kernel(const float* __restrict_
     if (threadIdx.x == 0) out[0] = red[0] * scale;
 }
 
-// out = base + dy * act'(y)   (act' = 1 - y^2 for tanh, [y > 0] for relu, 1 for linear); base may be NULL; out may alias base/dy
+// out = base + dy * act'(y)   (act' = 1 - y^2 for tanh, [y > 0] for relu, y for exp, 1 for linear); base may be NULL; out may alias base/dy
 __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
                                                       const float* base, float* out, long n, int activation) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const float yv = y[i];
-    const float d = dy[i] * (activation == 1 ? (1.f - yv * yv) : (activation == 2 ? (yv > 0.f ? 1.f : 0.f) : 1.f));
+    const float d = dy[i] * (activation == 1 ? (1.f - yv * yv) : (activation == 2 ? (yv > 0.f ? 1.f : 0.f) : (activation == 3 ? yv : 1.f)));
     out[i] = (base ? base[i] : 0.f) + d;
 }
 
@@ -398,6 +398,68 @@ __global__ __launch_bounds__(256) void rmsprop_kernel(float* __restrict__ p, con
     const float ai = rho * a[i] + (1.f - rho) * gi * gi;
     a[i] = ai;
     p[i] = p[i] - lr * gi / (sqrtf(ai) + eps);
+}
+
+// y = act(x): 1 tanh, 2 relu, 3 exp (heads of mycode/lstm.py:321-337); in place allowed
+__global__ __launch_bounds__(256) void act_fwd_kernel(const float* x, float* y, long n, int activation) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float v = x[i];
+    y[i] = activation == 1 ? tanh_f(v) : (activation == 2 ? fmaxf(v, 0.f) : (activation == 3 ? __expf(v) : v));
+}
+
+// Gaussian negative log-likelihood of mycode/cost.py:190-229 (likelihood_loss_tf): per sequence b, target second t,
+// frame f and axis a:  l = log(var_a + eps) + (y - mu_a)^2 / (var_a + eps), clipped to [-10, 10];
+// loss = scale * mean_b sum_{t,f,a} l.  One block per sequence: partial loss into part[b], dmu / dvar (B,3) with the
+// clip's zero gradient outside [-10, 10].
+__global__ __launch_bounds__(256) void gauss_nll_kernel(const float* __restrict__ mu, const float* __restrict__ var,
+                                                        const float* __restrict__ y, float* __restrict__ part,
+                                                        float* __restrict__ dmu, float* __restrict__ dvar, int B, int Ty,
+                                                        int fps, float scale) {
+    __shared__ float red[256][7];
+    const int b = blockIdx.x;
+    const int per = Ty * fps * 3;
+    float acc[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // loss, dmu[3], dvar[3]
+    const float eps = 1e-20f;
+    for (int e = threadIdx.x; e < per; e += 256) {
+        const int a = e % 3;
+        const float m = mu[b * 3 + a], v = var[b * 3 + a] + eps;
+        const float d = y[(size_t)b * per + e] - m;
+        const float l = __logf(v) + d * d / v;
+        acc[0] += fminf(fmaxf(l, -10.f), 10.f);
+        if (l > -10.f && l < 10.f) {
+            acc[1 + a] += -2.f * d / v;
+            acc[4 + a] += 1.f / v - d * d / (v * v);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 7; ++k) red[threadIdx.x][k] = acc[k];
+    __syncthreads();
+    for (int s_ = 128; s_ > 0; s_ >>= 1) {
+        if ((int)threadIdx.x < s_)
+#pragma unroll
+            for (int k = 0; k < 7; ++k) red[threadIdx.x][k] += red[threadIdx.x + s_][k];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) part[b] = red[0][0];
+    if (threadIdx.x < 3) {
+        dmu[b * 3 + threadIdx.x] = red[0][1 + threadIdx.x] * scale / (float)B;
+        dvar[b * 3 + threadIdx.x] = red[0][4 + threadIdx.x] * scale / (float)B;
+    }
+}
+
+// tf.train.RMSPropOptimizer (TF 1.x, momentum 0, not centered; mycode/lstm.py:556-567) with the script's optional
+// clip_by_value(grad, -clip, clip):  ms = decay*ms + (1-decay) g^2;  p -= lr * g / sqrt(ms + eps).  (eps INSIDE the
+// root, ms initialised to ONE - both unlike Keras RMSprop.)
+__global__ __launch_bounds__(256) void rmsprop_tf_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ ms,
+                                                         long n, float lr, float decay, float eps, float clip) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float gi = g[i];
+    if (clip > 0.f) gi = fminf(fmaxf(gi, -clip), clip);
+    const float m = decay * ms[i] + (1.f - decay) * gi * gi;
+    ms[i] = m;
+    p[i] = p[i] - lr * gi / sqrtf(m + eps);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -868,6 +930,30 @@ int rmsprop_step(float* p, const float* g, float* a, long n, float lr, float rho
     if (n <= 0) return FOV_OK;
     hipLaunchKernelGGL(rmsprop_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, p, g, a, n, lr, rho, eps);
     return check_launch("rmsprop");
+}
+
+int act_fwd(const float* x, float* y, long n, int activation, hipStream_t stream) {
+    if (n <= 0) return FOV_OK;
+    hipLaunchKernelGGL(act_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, x, y, n, activation);
+    return check_launch("act_fwd");
+}
+
+int gauss_nll_grad(const float* mu, const float* var, const float* y, float* loss, float* dmu, float* dvar, int B, int Ty,
+                   int fps, float scale, float* scratch, size_t scratch_floats, hipStream_t stream) {
+    if (B <= 0) return FOV_OK;
+    if ((size_t)B > scratch_floats) { set_error("gauss_nll_grad: scratch too small"); return FOV_ERR_WORKSPACE; }
+    hipLaunchKernelGGL(gauss_nll_kernel, dim3(B), dim3(256), 0, stream, mu, var, y, scratch, dmu, dvar, B, Ty, fps, scale);
+    int rc = check_launch("gauss_nll");
+    if (rc || !loss) return rc;
+    hipLaunchKernelGGL(sum_scale_kernel, dim3(1), dim3(256), 0, stream, scratch, loss, B, scale / (float)B);
+    return check_launch("sum_scale");
+}
+
+int rmsprop_tf_step(float* p, const float* g, float* ms, long n, float lr, float decay, float eps, float clip,
+                    hipStream_t stream) {
+    if (n <= 0) return FOV_OK;
+    hipLaunchKernelGGL(rmsprop_tf_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, p, g, ms, n, lr, decay, eps, clip);
+    return check_launch("rmsprop_tf");
 }
 
 }  // namespace fov

@@ -242,8 +242,39 @@ def act_bwd(dy, y, base=None, activation="tanh", out=None):
     assert dy.shape == y.shape
     out = torch.empty_like(y) if out is None else out
     check(_lib.lib().fov_act_bwd(_ptr(dy), _ptr(y), _ptr(_dev(base, "base")), _ptr(out), y.numel(),
-                                 {"tanh": 1, "relu": 2}.get(activation, 0), _stream()))
+                                 _ACT_CODES.get(activation, 0), _stream()))
     return out
+
+
+_ACT_CODES = {None: 0, "linear": 0, "tanh": 1, "relu": 2, "exp": 3}
+
+
+def act_fwd(x, activation, out=None):
+    """y = act(x) elementwise: 'tanh' | 'relu' | 'exp' | None (in place when out is x)."""
+    x = _dev(x, "x")
+    out = torch.empty_like(x) if out is None else out
+    check(_lib.lib().fov_act_fwd(_ptr(x), _ptr(out), x.numel(), _ACT_CODES[activation], _stream()))
+    return out
+
+
+def gauss_nll_grad(mu, var, y, fps, scale, scratch=None):
+    """Gaussian NLL of cost.py:190-229 -> (loss (1,), dmu (B,3), dvar (B,3)).  y (B,T_y,3*fps)."""
+    mu, var, y = _dev(mu, "mu"), _dev(var, "var"), _dev(y, "y")
+    B, T_y = y.shape[0], y.shape[1]
+    assert mu.shape == (B, 3) and var.shape == (B, 3) and y.shape[2] == 3 * fps
+    loss = torch.zeros(1, dtype=torch.float32, device=y.device)
+    dmu, dvar = torch.empty_like(mu), torch.empty_like(var)
+    buf = (scratch or _default_scratch).get(4 * (B + 64), y.device)
+    check(_lib.lib().fov_gauss_nll_grad(_ptr(mu), _ptr(var), _ptr(y), _ptr(loss), _ptr(dmu), _ptr(dvar), B, T_y, fps,
+                                        float(scale), buf.data_ptr(), buf.numel(), _stream()))
+    return loss, dmu, dvar
+
+
+def rmsprop_tf_step(params, grads, ms, lr, decay=0.9, eps=1e-10, clip_value=0.0):
+    for t in (params, grads, ms):
+        _dev(t, "flat buffer")
+    check(_lib.lib().fov_rmsprop_tf_step(_ptr(params), _ptr(grads), _ptr(ms), params.numel(), lr, decay, eps, clip_value,
+                                         _stream()))
 
 
 def dense_bwd(x, W, dpre, dW=None, db=None, need_dx=True, accumulate=False, scratch=None, need_dW=True, need_db=True):

@@ -583,3 +583,128 @@ class ConvLSTMTrainer:
             loss = lw
         self.apply_gradients()
         return loss
+
+
+class TFLSTMTrainer:
+    """Training step of the raw-TensorFlow model of mycode/lstm.py (cfg.use_xyz, cfg.predict_mean_var,
+    predict_len == 1 form): MultiRNNCell of LSTMCell(n_hidden) under dynamic_rnn with a fed state (:218-240),
+    the two two-layer heads of _pred_mean_var_xyz2_new on the top layer's final h (:321-337: relu -> tanh for the
+    means, relu -> linear -> exp for the variances), costfunc.likelihood_loss_tf (cost.py:190-229) and
+    tf.train.RMSPropOptimizer with the script's clip_by_value(-1, 1) (lstm.py:556-567).
+
+    `cells`: [(W (F+H,4H), b (4H))] in tf.contrib LSTMCell layout; they are trained in the kernels' Keras layout
+    (a column permutation plus the constant forget_bias: an element-wise optimizer does not see the difference) and
+    converted back by `cells_tf()`.  `head`: dict mu_W1 (H,32), mu_b1, mu_W2 (32,3), mu_b2, var_W1, var_b1, var_W2,
+    var_b2.  The DropoutWrapper (output_keep_prob) acts on what a layer hands UP, not on its recurrent state: give
+    `masks` [(B,T,H) per non-top layer, already scaled by 1/keep] to reproduce it; the head reads the top state h,
+    which no mask touches.  The predict_len > 1 form of the script re-feeds sampled frames (tf.random_normal) and is
+    not implemented."""
+
+    HEAD = ("mu_W1", "mu_b1", "mu_W2", "mu_b2", "var_W1", "var_b1", "var_W2", "var_b2")
+
+    def __init__(self, cells, head, forget_bias=1.0, lr=1e-5, clip_value=1.0, decay=0.9, eps=1e-10, fps=30, running_length=10,
+                 impl="auto", device="cuda"):
+        from .models import convert_tf_lstmcell
+        self.forget_bias, self.lr, self.clip, self.decay, self.eps = float(forget_bias), float(lr), float(clip_value), decay, eps
+        self.fps, self.running_length, self.impl, self.device = fps, running_length, impl, device
+        conv = [convert_tf_lstmcell(W, b, forget_bias) for W, b in cells]
+        self.L = len(conv)
+        weights = {}
+        for l, (K, R, b) in enumerate(conv):
+            weights.update({"K%d" % l: K, "R%d" % l: R, "b%d" % l: b})
+        weights.update({k: np.ascontiguousarray(head[k], dtype=np.float32) for k in self.HEAD})
+        self.order = ["%s%d" % (n, l) for l in range(self.L) for n in ("K", "R", "b")] + list(self.HEAD)
+        n = int(sum(weights[k].size for k in self.order))
+        self.flat = torch.empty(n, dtype=torch.float32, device=device)
+        self.grad = torch.zeros(n, dtype=torch.float32, device=device)
+        self.ms = torch.ones(n, dtype=torch.float32, device=device)      # TF initialises the rms slot to one
+        self.w, self.g = {}, {}
+        off = 0
+        for k in self.order:
+            cnt, shp = weights[k].size, weights[k].shape
+            self.w[k] = self.flat[off:off + cnt].view(*shp)
+            self.g[k] = self.grad[off:off + cnt].view(*shp)
+            self.w[k].copy_(torch.from_numpy(weights[k]))
+            off += cnt
+        self.ws, self.scratch, self.bwd_scratch = ops.Workspace(), ops.Scratch(), ops.Scratch()
+
+    def cells_tf(self):
+        """Current LSTM weights back in tf.contrib LSTMCell layout [(W (F+H,4H), b)]."""
+        out = []
+        for l in range(self.L):
+            K, R, b = (self.w["%s%d" % (n, l)].detach().cpu().numpy() for n in ("K", "R", "b"))
+            H = R.shape[0]
+            perm = np.concatenate([np.arange(0, H), np.arange(2 * H, 3 * H), np.arange(H, 2 * H), np.arange(3 * H, 4 * H)])
+            W = np.concatenate([K, R], 0)
+            Wt, bt = np.empty_like(W), np.empty_like(b)
+            Wt[:, perm] = W
+            bk = b.copy()
+            bk[H:2 * H] -= np.float32(self.forget_bias)
+            bt[perm] = bk
+            out.append((Wt, bt))
+        return out
+
+    def _head(self, h):
+        w = self.w
+        a1 = ops.dense(h, w["mu_W1"], w["mu_b1"], activation=None)
+        ops.act_fwd(a1, "relu", out=a1)
+        mu = ops.dense(a1, w["mu_W2"], w["mu_b2"], activation="tanh")
+        a3 = ops.dense(h, w["var_W1"], w["var_b1"], activation=None)
+        ops.act_fwd(a3, "relu", out=a3)
+        var = ops.dense(a3, w["var_W2"], w["var_b2"], activation=None)
+        ops.act_fwd(var, "exp", out=var)
+        return a1, mu, a3, var
+
+    def predict(self, x, init_state=None):
+        """(mu (B,3), var (B,3), state (L,2,B,H) as LSTMStateTuple (c,h) per layer) - inference, no dropout."""
+        inp, states = x, []
+        for l in range(self.L):
+            c0 = None if init_state is None else init_state[l, 0].contiguous()
+            h0 = None if init_state is None else init_state[l, 1].contiguous()
+            hs, hT, cT = ops.lstm_seq(inp, self.w["K%d" % l], self.w["R%d" % l], self.w["b%d" % l], h0, c0, act="sigmoid",
+                                      impl=self.impl, workspace=self.ws)
+            states.append(torch.stack([cT, hT], 0))
+            inp = hs
+        _, mu, _, var = self._head(states[-1][1])
+        return mu, var, torch.stack(states, 0)
+
+    def forward_backward(self, x, y, init_state=None, masks=None):
+        """x (B,T,F), y (B,T_y,3*fps), init_state (L,2,B,H) (c,h) or None.  Fills self.grad; returns
+        (loss (1,), mu (B,3), var (B,3), final state (L,2,B,H))."""
+        w, g, sc = self.w, self.g, self.scratch
+        tape, inp, states = [], x, []
+        for l in range(self.L):
+            c0 = None if init_state is None else init_state[l, 0].contiguous()
+            h0 = None if init_state is None else init_state[l, 1].contiguous()
+            hs, hT, cT, res = ops.lstm_seq_train(inp, w["K%d" % l], w["R%d" % l], w["b%d" % l], h0, c0, act="sigmoid",
+                                                 impl=self.impl, workspace=self.ws)
+            tape.append((inp, hs, res, h0, c0))
+            states.append(torch.stack([cT, hT], 0))
+            inp = hs if (masks is None or l == self.L - 1) else hs * masks[l]
+        hT = states[-1][1].contiguous()
+        a1, mu, a3, var = self._head(hT)
+        scale = 1.0 / (self.running_length * self.fps)
+        loss, dmu, dvar = ops.gauss_nll_grad(mu, var, y, self.fps, scale, scratch=sc)
+        d2 = ops.act_bwd(dmu, mu, activation="tanh")
+        da1, _, _ = ops.dense_bwd(a1, w["mu_W2"], d2, dW=g["mu_W2"], db=g["mu_b2"], scratch=sc)
+        d1 = ops.act_bwd(da1, a1, activation="relu")
+        dh_a, _, _ = ops.dense_bwd(hT, w["mu_W1"], d1, dW=g["mu_W1"], db=g["mu_b1"], scratch=sc)
+        d4 = ops.act_bwd(dvar, var, activation="exp")
+        da3, _, _ = ops.dense_bwd(a3, w["var_W2"], d4, dW=g["var_W2"], db=g["var_b2"], scratch=sc)
+        d3 = ops.act_bwd(da3, a3, activation="relu")
+        dh_b, _, _ = ops.dense_bwd(hT, w["var_W1"], d3, dW=g["var_W1"], db=g["var_b1"], scratch=sc)
+        dhT = ops.act_bwd(dh_b, hT, base=dh_a, activation=None)      # dh_a + dh_b
+        dhs = None
+        for l in range(self.L - 1, -1, -1):
+            inp, hs, res, h0, c0 = tape[l]
+            b = ops.lstm_seq_bwd(inp, w["K%d" % l], w["R%d" % l], hs, res, h0=h0, c0=c0, dhs=dhs,
+                                 dhT=dhT if l == self.L - 1 else None, dK=g["K%d" % l], dR=g["R%d" % l], db=g["b%d" % l],
+                                 need_dx=(l > 0), act="sigmoid", scratch=self.bwd_scratch)
+            if l > 0:
+                dhs = b["dx"] if masks is None else b["dx"] * masks[l - 1]
+        return loss, mu, var, torch.stack(states, 0)
+
+    def train_step(self, x, y, init_state=None, masks=None):
+        loss, _, _, state = self.forward_backward(x, y, init_state, masks)
+        ops.rmsprop_tf_step(self.flat, self.grad, self.ms, self.lr, self.decay, self.eps, self.clip)
+        return loss, state

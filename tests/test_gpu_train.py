@@ -390,3 +390,93 @@ def test_mix_head_forward_backward(N, H, O):
     assert np.abs(dWd.cpu().numpy() - tWd.grad.numpy()).max() <= 2e-5 * np.abs(tWd.grad.numpy()).max() + 1e-7
     dh0 = ops.mix_head_bwd(dev(dml), None, m_out, p_out, dev(Wp), dev(Wd), dpm, dpp)   # last step: no feedback
     assert np.isfinite(dh0.cpu().numpy()).all()
+
+
+def _torch_tf_lstm_graph(x, y, cells, head, init, fps, running_length, forget_bias=1.0, masks=None):
+    """Independent fp64 restatement of the lstm.py training graph (tf.contrib LSTMCell: fused [x,h].W, gates
+    i, j, f, o, forget_bias inside the cell; heads of _pred_mean_var_xyz2_new; likelihood_loss_tf)."""
+    t = lambda a: torch.tensor(np.asarray(a, np.float64), requires_grad=True)
+    cw = [(t(W), t(b)) for W, b in cells]
+    hw = {k: t(v) for k, v in head.items()}
+    inp = torch.tensor(x.astype(np.float64))
+    st = torch.tensor(init.astype(np.float64))
+    finals = []
+    for l, (W, b) in enumerate(cw):
+        c, h = st[l, 0], st[l, 1]
+        H = h.shape[1]
+        outs = []
+        for tt in range(inp.shape[1]):
+            z = torch.cat([inp[:, tt], h], 1) @ W + b
+            i, j, f, o = z[:, :H], z[:, H:2 * H], z[:, 2 * H:3 * H], z[:, 3 * H:]
+            c = torch.sigmoid(f + forget_bias) * c + torch.sigmoid(i) * torch.tanh(j)
+            h = torch.sigmoid(o) * torch.tanh(c)
+            outs.append(h)
+        hs = torch.stack(outs, 1)
+        finals.append((c, h))
+        inp = hs if (masks is None or l == len(cw) - 1) else hs * torch.tensor(masks[l].astype(np.float64))
+    hT = finals[-1][1]
+    mu = torch.tanh(torch.relu(hT @ hw["mu_W1"] + hw["mu_b1"]) @ hw["mu_W2"] + hw["mu_b2"])
+    var = torch.exp(torch.relu(hT @ hw["var_W1"] + hw["var_b1"]) @ hw["var_W2"] + hw["var_b2"])
+    yy = torch.tensor(y.astype(np.float64)).reshape(y.shape[0], y.shape[1], fps, 3)
+    eps = 1e-20
+    l = torch.log(var + eps)[:, None, None, :] + (yy - mu[:, None, None, :]) ** 2 / (var + eps)[:, None, None, :]
+    loss = torch.clamp(l, -10, 10).sum((1, 2, 3)).mean() / running_length / fps
+    loss.backward()
+    return float(loss.detach()), [(W.grad.numpy(), b.grad.numpy()) for W, b in cw], {k: v.grad.numpy() for k, v in hw.items()}, \
+        mu.detach().numpy(), var.detach().numpy()
+
+
+@pytest.mark.parametrize("H,B,T,with_masks", [(40, 9, 4, False), (400, 12, 3, True)])
+def test_tf_stacked_lstm_training_graph(H, B, T, with_masks):
+    """a10 training: mycode/lstm.py (2 x LSTMCell(H) with a fed state, mean / variance heads, Gaussian NLL, TF
+    RMSProp with clipping) against torch.autograd fp64; gradients are compared in tf.contrib layout."""
+    from longterm360fov_amd.training import TFLSTMTrainer
+    from longterm360fov_amd.models import convert_tf_lstmcell
+    rng = np.random.default_rng(H + B)
+    F, fps = 90, 30
+    cells = []
+    for l in range(2):
+        Fin = F if l == 0 else H
+        cells.append(((rng.standard_normal((Fin + H, 4 * H)) / np.sqrt(Fin + H)).astype(np.float32),
+                      (0.1 * rng.standard_normal(4 * H)).astype(np.float32)))
+    head = {}
+    for br in ("mu", "var"):
+        head[br + "_W1"] = (rng.standard_normal((H, 32)) / np.sqrt(H)).astype(np.float32)
+        head[br + "_b1"] = (0.1 * rng.standard_normal(32)).astype(np.float32)
+        head[br + "_W2"] = (rng.standard_normal((32, 3)) / np.sqrt(32)).astype(np.float32)
+        head[br + "_b2"] = (0.1 * rng.standard_normal(3)).astype(np.float32)
+    x = rng.uniform(-1, 1, (B, T, F)).astype(np.float32)
+    y = rng.uniform(-1, 1, (B, 1, 3 * fps)).astype(np.float32)
+    init = (0.2 * rng.standard_normal((2, 2, B, H))).astype(np.float32)
+    masks = None
+    if with_masks:   # DropoutWrapper(output_keep_prob=0.9) on what layer 0 hands up
+        masks = [((rng.random((B, T, H)) < 0.9) / 0.9).astype(np.float32), None]
+    loss_ref, cg, hg, mu_ref, var_ref = _torch_tf_lstm_graph(x, y, cells, head, init, fps, 10, masks=masks)
+    tr = TFLSTMTrainer(cells, head, lr=1e-3, clip_value=1.0, fps=fps, running_length=10)
+    dm = None if masks is None else [dev(masks[0]), None]
+    loss, mu, var, state = tr.forward_backward(dev(x), dev(y), dev(init), masks=dm)
+    assert np.abs(mu.cpu().numpy() - mu_ref).max() < 1e-5 and np.abs(var.cpu().numpy() - var_ref).max() < 1e-4 * np.abs(var_ref).max()
+    assert abs(float(loss.item()) - loss_ref) <= 1e-5 * abs(loss_ref) + 1e-7
+    for k in TFLSTMTrainer.HEAD:
+        a = tr.g[k].cpu().numpy()
+        assert np.abs(a - hg[k]).max() <= 2e-4 * np.abs(hg[k]).max() + 1e-9, k
+    for l in range(2):   # gradients in tf.contrib layout: columns i, j, f, o of the fused kernel
+        K, R, b = (tr.g["%s%d" % (n, l)].cpu().numpy() for n in ("K", "R", "b"))
+        perm = np.concatenate([np.arange(0, H), np.arange(2 * H, 3 * H), np.arange(H, 2 * H), np.arange(3 * H, 4 * H)])
+        Wg = np.empty_like(cg[l][0]); Wg[:, perm] = np.concatenate([K, R], 0)
+        bg = np.empty_like(cg[l][1]); bg[perm] = b
+        assert np.abs(Wg - cg[l][0]).max() <= 2e-4 * np.abs(cg[l][0]).max() + 1e-9, ("W", l)
+        assert np.abs(bg - cg[l][1]).max() <= 2e-4 * np.abs(cg[l][1]).max() + 1e-9, ("b", l)
+    # round trip of the layout conversion, then a few optimizer steps reduce the loss
+    for (W0, b0), (W1, b1) in zip(cells, tr.cells_tf()):
+        assert np.abs(W0 - W1).max() < 1e-7 and np.abs(b0 - b1).max() < 1e-6
+    l0 = float(tr.train_step(dev(x), dev(y), dev(init))[0].item())
+    for _ in range(5):
+        l1 = float(tr.train_step(dev(x), dev(y), dev(init))[0].item())
+    assert l1 < l0
+    # TF RMSProp semantics: ms starts at one, eps inside the root, clipped gradient
+    p = torch.zeros(3, device="cuda"); gg = torch.tensor([0.5, -3.0, 0.0], device="cuda"); ms = torch.ones(3, device="cuda")
+    from longterm360fov_amd import ops
+    ops.rmsprop_tf_step(p, gg, ms, lr=0.1, decay=0.9, eps=1e-10, clip_value=1.0)
+    gc = np.array([0.5, -1.0, 0.0]); ms_ref = 0.9 + 0.1 * gc ** 2
+    assert np.allclose(ms.cpu().numpy(), ms_ref, atol=1e-6) and np.allclose(p.cpu().numpy(), -0.1 * gc / np.sqrt(ms_ref + 1e-10), atol=1e-6)
