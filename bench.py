@@ -143,12 +143,12 @@ def bench_train_mixing(args, rank, world, use_dist):
             "value": world * B * args.steps / elapsed, "unit": "sequences/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic", "final_loss": float(loss.item()),
-            "config": {"workload": "configs[2] shape: given_others_gt_mean_var_seq2seq training step, step-wise decoder "
-                                   "(round-1 structure)", "global_batch": B * world,
+            "config": {"workload": "configs[2] shape: given_others_gt_mean_var_seq2seq training step (fused decoder forward "
+                                   "and backward launches)", "global_batch": B * world,
                        "parallelism": "dp%d, one flat-buffer all-reduce per step" % world},
             "roofline": {"bound": "mfma", "achieved": 3 * fwd * B / (ms * 1e-3) / 1e12, "peak": PEAK_FP32_MFMA_TFLOPS,
                          "unit": "TFLOP/s", "frac": 3 * fwd * B / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
-                         "note": "whole step, 3x forward FLOPs; launch-bound in round 1"},
+                         "note": "whole step, 3x forward FLOPs"},
             "cpu_baseline": None}), flush=True)
     if use_dist:
         dist.barrier()

@@ -305,9 +305,10 @@ class OthersMixingSeq2Seq:
     Dense(6,tanh) over [others_t (U-1,6) ; prediction (1,6)] flattened user-major.
 
     predict([encoder_input (N,T_in,F_enc), others_fut_input (N,T_out,U-1,6), decoder_input (N,1,6)])
-    -> (N,T_out,6).  Round 1 runs the decoder as per-step library calls (layer-1 step, the layer-2 input
-    projection as an MFMA GEMM, layer-2 step, Dense, mixing Dense); the "others" half of the mixing
-    product is hoisted out of the loop as one GEMV batch."""
+    -> (N,T_out,6).  H = 256: encoder layer 2 on the wide-input layer kernel and the whole unrolled decoder in ONE
+    persistent launch (fov_mix_decoder_fwd); other widths run per-step library calls (layer-1 step, the layer-2
+    input projection as an MFMA GEMM, layer-2 step, fused head).  The "others" half of the mixing product is
+    hoisted out of the loop as one GEMV batch."""
 
     fused_decoder = True   # H = 256: run the unrolled decoder as ONE launch (fov_mix_decoder_fwd); False = step-wise calls
 
