@@ -279,6 +279,14 @@ int fov_conv2d_fwd(const float* x, int64_t x_pixel_stride, int64_t x_batch_strid
                    const float* add, float* y, int B, int H, int W, int C, int N, int kh, int kw, int activation,
                    fov_stream_t stream);
 
+/* The same convolution over the channel concatenation [x1 | x2] (w: (kh,kw,C1+C2,N)) without the concatenated
+ * map ever existing: one ConvLSTM2D step is z = conv([x_t | h_{t-1}], [K ; R]) + b in ONE launch
+ * (convlstm_seq2seq.py:100-126: Keras runs input_conv and recurrent_conv separately and adds). */
+int fov_conv2d_fwd2(const float* x1, int64_t x1_pixel_stride, int64_t x1_batch_stride, int C1,
+                    const float* x2, int64_t x2_pixel_stride, int64_t x2_batch_stride, int C2,
+                    const float* w, const float* b, const float* add, float* y,
+                    int B, int H, int W, int N, int kh, int kw, int activation, fov_stream_t stream);
+
 /* ConvLSTM2DCell gates on z (rows, 4F) = conv(x,K)+b+conv(h,R), channel blocks i,f,c,o; c (rows,F) is
  * updated in place; h is written with pixel stride h_pixel_stride >= F. */
 int fov_convlstm_gates(const float* z, float* c, float* h, int64_t h_pixel_stride, int64_t rows, int F,

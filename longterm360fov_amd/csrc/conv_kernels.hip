@@ -13,8 +13,13 @@
 namespace fov {
 
 struct ConvArgs {
+    // second input segment (optional): the convolution runs over the channel concatenation [x | x2] without the
+    // concatenated map ever existing - a ConvLSTM2D step is conv([x_t | h_{t-1}], [K ; R]) in ONE launch
+    const float* x2;    // (B,H,W,*) or NULL
+    int C2;             // channels of x2 (w then has C + C2 input channels per tap)
+    long ldx2, ldb2;
     const float* x;     // (B,H,W,*) with pixel stride ldx >= C and batch stride ldb >= H*W*ldx
-    const float* w;     // (kh*kw*C, N)
+    const float* w;     // (kh*kw*(C + C2), N)
     const float* bias;  // (N) or NULL
     const float* add;   // (B*H*W, N) or NULL (may alias y)
     float* y;           // (B*H*W, N)
@@ -57,7 +62,9 @@ __global__ __launch_bounds__(256) void conv2d_igemm_kernel(ConvArgs g) {
     const int wm = (wave / WAVES_N) * 16 * MI, wn = (wave % WAVES_N) * 16 * NI;
     const int li = lane & 15, lq = lane >> 4;
     const int ph = (g.kh - 1) / 2, pw = (g.kw - 1) / 2;
-    const int ctiles = (g.C + BK - 1) / BK;
+    const int ctiles1 = (g.C + BK - 1) / BK;
+    const int ctiles = ctiles1 + (g.C2 + BK - 1) / BK;   // k-tiles per tap: segment 1, then segment 2
+    const int Ctot = g.C + g.C2;
     const int ntiles = g.kh * g.kw * ctiles;
 
     f32x4 acc[MI][NI];
@@ -69,7 +76,7 @@ __global__ __launch_bounds__(256) void conv2d_igemm_kernel(ConvArgs g) {
     // A staging map: AVEC group e = tid + 256 r -> (pixel e/4, channel quad e%4); scalar element e -> (pixel
     // e/16, channel e%16).  Consecutive lanes walk the channels of a pixel, then the next pixel.
     int a_mm[RA], a_kc[RA], a_y[RA], a_x[RA];
-    unsigned a_pix[RA];
+    unsigned a_pix[RA], a_pix2[RA];
 #pragma unroll
     for (int r = 0; r < RA; ++r) {
         const int e = tid + 256 * r;
@@ -82,10 +89,12 @@ __global__ __launch_bounds__(256) void conv2d_igemm_kernel(ConvArgs g) {
             a_y[r] = rem / g.W;
             a_x[r] = rem - a_y[r] * g.W;
             a_pix[r] = (unsigned)(((long)b * g.ldb + (long)rem * g.ldx + a_kc[r]) * 4);
+            a_pix2[r] = (unsigned)(((long)b * g.ldb2 + (long)rem * g.ldx2 + a_kc[r]) * 4);
         } else {
             a_y[r] = -(1 << 20);   // never inside the image
             a_x[r] = 0;
             a_pix[r] = OOR;
+            a_pix2[r] = OOR;
         }
     }
     // B staging map: (k row, n) of the (16 x BN) weight tile; byte offset from the tile's first row
@@ -105,16 +114,17 @@ __global__ __launch_bounds__(256) void conv2d_igemm_kernel(ConvArgs g) {
     float ra[AVEC ? 1 : RA], rb[BVEC ? 1 : RB];
     f32x4 va[AVEC ? RA : 1], vb[BVEC ? RB : 1];
     auto fetch = [&]() {
-        const int c0 = f_ct * BK;
+        const bool seg2 = f_ct >= ctiles1;   // wave-uniform: which input segment this tile reads
+        const int c0 = (seg2 ? f_ct - ctiles1 : f_ct) * BK;
         const int sy = f_dy - ph, sx = f_dx - pw;
-        const float* xt = g.x + ((long)sy * g.W + sx) * g.ldx + c0;
+        const float* xt = (seg2 ? g.x2 + ((long)sy * g.W + sx) * g.ldx2 : g.x + ((long)sy * g.W + sx) * g.ldx) + c0;
         const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xt), 0, 0x7fffffff, 0x00020000);
-        const int crem = g.C - c0;   // channels left in this tap
+        const int crem = (seg2 ? g.C2 : g.C) - c0;   // channels left in this segment of the tap
 #pragma unroll
         for (int r = 0; r < RA; ++r) {
             const int yy = a_y[r] + sy, xx = a_x[r] + sx;
             const bool ok = yy >= 0 && yy < g.H && xx >= 0 && xx < g.W && a_kc[r] < crem;
-            const unsigned off = ok ? a_pix[r] : OOR;
+            const unsigned off = ok ? (seg2 ? a_pix2[r] : a_pix[r]) : OOR;
             if constexpr (AVEC) {
                 const cu32x4 t = __builtin_amdgcn_raw_buffer_load_b128(xrs, off, 0, 0);
                 va[r] = (f32x4){__uint_as_float(t[0]), __uint_as_float(t[1]), __uint_as_float(t[2]), __uint_as_float(t[3])};
@@ -123,7 +133,7 @@ __global__ __launch_bounds__(256) void conv2d_igemm_kernel(ConvArgs g) {
             }
         }
         const int tap = f_dy * g.kw + f_dx;
-        const float* wt = g.w + ((long)tap * g.C + c0) * g.N;
+        const float* wt = g.w + ((long)tap * Ctot + (seg2 ? g.C : 0) + c0) * g.N;
         const int krows = crem < BK ? crem : BK;
         const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wt), 0, krows * g.N * 4, 0x00020000);
 #pragma unroll
@@ -248,17 +258,26 @@ static int conv_check_launch(const char* what) {
 
 int conv2d_fwd(const float* x, long ldx, long ldb, const float* w, const float* bias, const float* add, float* y, int B, int H,
                int W, int C, int N, int kh, int kw, int act, hipStream_t stream) {
+    return conv2d_fwd2(x, ldx, ldb, C, nullptr, 0, 0, 0, w, bias, add, y, B, H, W, N, kh, kw, act, stream);
+}
+
+int conv2d_fwd2(const float* x, long ldx, long ldb, int C, const float* x2, long ldx2, long ldb2, int C2, const float* w,
+                const float* bias, const float* add, float* y, int B, int H, int W, int N, int kh, int kw, int act,
+                hipStream_t stream) {
     ConvArgs g = {};
     g.x = x; g.w = w; g.bias = bias; g.add = add; g.y = y;
     g.B = B; g.H = H; g.W = W; g.C = C; g.N = N; g.kh = kh; g.kw = kw; g.act = act; g.ldx = ldx; g.ldb = ldb;
+    g.x2 = x2; g.C2 = x2 ? C2 : 0; g.ldx2 = ldx2; g.ldb2 = ldb2;
     const long M = (long)B * H * W;
     if (M == 0 || N == 0) return FOV_OK;
     // 31-bit byte offsets inside one buffer descriptor
-    if ((long)B * ldb * 4 >= (1L << 31) || (long)kh * kw * C * N * 4 >= (1L << 31)) {
+    if ((long)B * ldb * 4 >= (1L << 31) || (x2 && (long)B * ldb2 * 4 >= (1L << 31)) ||
+        (long)kh * kw * (C + g.C2) * N * 4 >= (1L << 31)) {
         set_error("conv2d: operand larger than 2 GiB");
         return FOV_ERR_UNSUPPORTED;
     }
-    const bool avec = (C & 3) == 0 && (ldx & 3) == 0 && (ldb & 3) == 0 && (((uintptr_t)x) & 15) == 0;
+    const bool avec = (C & 3) == 0 && (ldx & 3) == 0 && (ldb & 3) == 0 && (((uintptr_t)x) & 15) == 0 &&
+                      (!x2 || ((C2 & 3) == 0 && (ldx2 & 3) == 0 && (ldb2 & 3) == 0 && (((uintptr_t)x2) & 15) == 0));
     const bool bvec = (N & 3) == 0 && (((uintptr_t)w) & 15) == 0;
 #define FOV_CONV_LAUNCH(MI_, NI_, WM_, grid_)                                                                          \
     do {                                                                                                               \

@@ -770,6 +770,20 @@ int fov_conv2d_fwd(const float* x, int64_t x_pixel_stride, int64_t x_batch_strid
     return conv2d_fwd(x, (long)x_pixel_stride, (long)x_batch_stride, w, b, add, y, B, H, W, C, N, kh, kw, activation, (hipStream_t)stream);
 }
 
+int fov_conv2d_fwd2(const float* x1, int64_t x1_pixel_stride, int64_t x1_batch_stride, int C1, const float* x2,
+                    int64_t x2_pixel_stride, int64_t x2_batch_stride, int C2, const float* w, const float* b, const float* add,
+                    float* y, int B, int H, int W, int N, int kh, int kw, int activation, fov_stream_t stream) {
+    if (B < 0 || H <= 0 || W <= 0 || C1 <= 0 || C2 <= 0 || N <= 0 || kh <= 0 || kw <= 0 || (kh & 1) == 0 || (kw & 1) == 0 ||
+        x1_pixel_stride < C1 || x1_batch_stride < (int64_t)H * W * x1_pixel_stride || x2_pixel_stride < C2 ||
+        x2_batch_stride < (int64_t)H * W * x2_pixel_stride || !w || (B > 0 && (!x1 || !x2 || !y)) ||
+        (activation != 0 && activation != 2)) {
+        set_error("fov_conv2d_fwd2: invalid argument (odd kernel sizes only, activation 0 or 2)");
+        return FOV_ERR_INVALID;
+    }
+    return conv2d_fwd2(x1, (long)x1_pixel_stride, (long)x1_batch_stride, C1, x2, (long)x2_pixel_stride, (long)x2_batch_stride, C2,
+                       w, b, add, y, B, H, W, N, kh, kw, activation, (hipStream_t)stream);
+}
+
 int fov_convlstm_gates(const float* z, float* c, float* h, int64_t h_pixel_stride, int64_t rows, int F, int act,
                        fov_stream_t stream) {
     if (rows < 0 || F <= 0 || h_pixel_stride < F || (rows > 0 && (!z || !c || !h)) ||

@@ -78,6 +78,9 @@ constexpr size_t kStatusBytes = 256;  // head of every workspace: status words
 // ConvLSTM building blocks (conv_kernels.hip)
 int conv2d_fwd(const float* x, long ldx, long ldb, const float* w, const float* bias, const float* add, float* y, int B, int H,
                int W, int C, int N, int kh, int kw, int act, hipStream_t stream);
+int conv2d_fwd2(const float* x, long ldx, long ldb, int C, const float* x2, long ldx2, long ldb2, int C2, const float* w,
+                const float* bias, const float* add, float* y, int B, int H, int W, int N, int kh, int kw, int act,
+                hipStream_t stream);
 int convlstm_gates(const float* z, float* c, float* h, long ldh, long rows, int F, int act, hipStream_t stream);
 int softmax_lastdim(const float* x, float* y, long rows, int n, hipStream_t stream);
 

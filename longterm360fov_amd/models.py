@@ -614,6 +614,13 @@ class ConvLSTMSeq2Seq:
         T_out = cfg.predict_step if predict_step is None else int(predict_step)
         if self._dw is None:
             self._dw = {k: torch.from_numpy(v).to(self.device) for k, v in self._w.items()}
+            for side in ("enc", "dec"):     # [K ; R] stacked along the input-channel axis: one convolution per cell step
+                for l in range(3):
+                    K, R = self._dw["%s%d_K" % (side, l)], self._dw["%s%d_R" % (side, l)]
+                    pad = (-K.shape[2]) % 4 if l == 0 else 0
+                    if pad:   # zero weight rows for the zero channels the input map is padded with (16-byte pixel gather)
+                        K = torch.cat([K, torch.zeros(K.shape[:2] + (pad, K.shape[3]), dtype=K.dtype, device=K.device)], 2)
+                    self._dw["%s%d_KR" % (side, l)] = torch.cat([K, R], 2).contiguous()
         dw, act = self._dw, self.act
         filters = [dw["enc%d_R" % l].shape[2] for l in range(3)]
         cat = sum(filters)
@@ -625,18 +632,21 @@ class ConvLSTMSeq2Seq:
         for lo in range(0, n, max(bs, 1)):
             xe = torch.from_numpy(enc[lo:lo + bs]).to(self.device)
             inp = torch.from_numpy(dec0[lo:lo + bs, 0]).to(self.device)
-            B, T_in, H, W, _ = xe.shape
+            B, T_in, H, W, C_in = xe.shape
+            pad = (-C_in) % 4
+            if pad:       # channel-pad the input maps once: 30 -> 32 keeps every pixel 16-byte aligned
+                xe = torch.cat([xe, torch.zeros((B, T_in, H, W, pad), dtype=torch.float32, device=self.device)], -1)
+                inp = torch.cat([inp, torch.zeros(inp.shape[:-1] + (pad,), dtype=torch.float32, device=self.device)], -1)
             # encoder: layer l runs over the whole sequence of layer l-1 (return_sequences=True)
             seq = [xe[:, t] for t in range(T_in)]
             states = []
             for l, F in enumerate(filters):
                 h = torch.zeros((B, H, W, F), dtype=torch.float32, device=self.device)
                 c = torch.zeros((B, H, W, F), dtype=torch.float32, device=self.device)
-                K, R, b = dw["enc%d_K" % l], dw["enc%d_R" % l], dw["enc%d_b" % l]
+                KR, b = dw["enc%d_KR" % l], dw["enc%d_b" % l]
                 nxt = []
                 for t in range(T_in):
-                    z = ops.conv2d(seq[t], K, b)
-                    z = ops.conv2d(h, R, None, add=z, out=z)
+                    z = ops.conv2d_cat(seq[t], h, KR, b)     # conv(x_t, K) + conv(h, R) + b in one launch
                     hn = e4(B, H, W, F)
                     ops.convlstm_gates(z, c, hn, act)
                     h = hn
@@ -650,9 +660,7 @@ class ConvLSTMSeq2Seq:
                 feat = e4(B, H, W, cat)
                 cur = inp
                 for l, F in enumerate(filters):
-                    K, R, b = dw["dec%d_K" % l], dw["dec%d_R" % l], dw["dec%d_b" % l]
-                    z = ops.conv2d(cur, K, b)
-                    z = ops.conv2d(states[l][0], R, None, add=z, out=z)
+                    z = ops.conv2d_cat(cur, states[l][0], dw["dec%d_KR" % l], dw["dec%d_b" % l])
                     hslot = feat[..., offs[l]:offs[l] + F]
                     ops.convlstm_gates(z, states[l][1], hslot, act)
                     states[l][0] = hslot
@@ -660,14 +668,20 @@ class ConvLSTMSeq2Seq:
                 if dense_head:   # Flatten + Dense(6): cfg.predict_mean_var, output fed back as a 1x1x6 map
                     y = ops.dense(feat.reshape(B, H * W * cat), dw["head0_W"], dw["head0_b"], activation=None)
                     out[:, t] = y
-                    inp = y.reshape(B, 1, 1, 6)
+                    if pad:
+                        inp[..., :C_in] = y.reshape(B, 1, 1, 6)
+                    else:
+                        inp = y.reshape(B, 1, 1, 6)
                     continue
                 y = ops.conv2d(feat, dw["head0_W"], dw["head0_b"], activation="relu")
                 y = ops.conv2d(y, dw["head1_W"], dw["head1_b"], activation="relu")
                 y = ops.conv2d(y, dw["head2_W"], dw["head2_b"], activation="relu" if self.head == "conv2d" else None)
                 y = ops.softmax_lastdim(y)
                 out[:, t] = y
-                inp = y
+                if pad:
+                    inp[..., :C_in] = y
+                else:
+                    inp = y
             outs.append(out.cpu().numpy())
         return np.concatenate(outs, axis=0)
 

@@ -467,6 +467,29 @@ def conv2d(x, w, b=None, add=None, activation=None, out=None, in_channels=None):
     return y
 
 
+def conv2d_cat(x1, x2, w, b=None, activation=None, out=None):
+    """y = act(conv2d_same([x1 | x2], w) + b): convolution over the channel concatenation of two NHWC maps (each may
+    be a channel-slice / batch-strided view) without materialising it; w (kh,kw,C1+C2,N)."""
+    def geom(x):
+        assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.stride(3) == 1
+        B, H, W, C = x.shape
+        ldx = x.stride(2)
+        ldb = x.stride(0) if B > 1 else H * W * ldx
+        assert x.stride(1) == W * ldx and ldb >= H * W * ldx, "NHWC with a uniform pixel stride"
+        return B, H, W, C, ldx, ldb
+    B, H, W, C1, ldx1, ldb1 = geom(x1)
+    B2, H2, W2, C2, ldx2, ldb2 = geom(x2)
+    assert (B, H, W) == (B2, H2, W2)
+    w = _dev(w, "w")
+    kh, kw, Cw, N = w.shape
+    assert Cw == C1 + C2
+    y = torch.empty((B, H, W, N), dtype=torch.float32, device=x1.device) if out is None else out
+    act = {None: 0, "linear": 0, "relu": 2}[activation]
+    check(_lib.lib().fov_conv2d_fwd2(x1.data_ptr(), ldx1, ldb1, C1, x2.data_ptr(), ldx2, ldb2, C2, _ptr(w), _ptr(_dev(b, "b")),
+                                     None, _ptr(y), B, H, W, N, kh, kw, act, _stream()))
+    return y
+
+
 def convlstm_gates(z, c, h_out, act="hard_sigmoid"):
     """Gates + cell update: z (B,H,W,4F), c (B,H,W,F) updated in place, h written into h_out, which may be
     a channel-slice view of a concatenated feature map."""

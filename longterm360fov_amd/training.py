@@ -385,10 +385,12 @@ class ConvLSTMTrainer:
                 seq = self._stack_masked(seq, masks["enc%d" % l].unsqueeze(1))
                 K = k4["enc%d_K" % l]
                 tape["ex4_%d" % l] = seq
+            KR = torch.cat([K, R], 2)     # [K ; R]: input and recurrent convolution of a step in one launch
             for t in range(T_in):
-                z = ops.conv2d(seq[t], K, b, out=gs[t])
                 if t > 0:
-                    ops.conv2d(hs[t - 1], R, None, add=z, out=z)
+                    z = ops.conv2d_cat(seq[t], hs[t - 1], KR, b, out=gs[t])
+                else:
+                    z = ops.conv2d(seq[t], K, b, out=gs[t])          # zero initial state
                 ops.convlstm_gates_train(z, cs[t - 1] if t > 0 else None, hs[t], act, gates=z, c_new=cs[t])
             tape["eh%d" % l], tape["ec%d" % l], tape["eg%d" % l] = hs, cs, gs
             seq = hs
@@ -406,6 +408,7 @@ class ConvLSTMTrainer:
         last_act = "relu" if self.head == "conv2d" else None
         cin = [C] + F[:2]
         dx4 = [e(T_out, B, H, W, 4 * cin[l]) for l in range(3)] if masks is not None else None
+        kr = [torch.cat([k4["dec%d_K" % l] if masks is not None else w["dec%d_K" % l], w["dec%d_R" % l]], 2) for l in range(3)]
         for t in range(T_out):
             cur = inp[t]
             for l in range(3):
@@ -415,8 +418,7 @@ class ConvLSTMTrainer:
                 if masks is not None:   # a fresh mask set for every unrolled call of the decoder layer
                     dx4[l][t].copy_(self._stack_masked(cur, masks["dec%d" % l][t]))
                     cur, K = dx4[l][t], k4["dec%d_K" % l]
-                z = ops.conv2d(cur, K, b, out=dgs[l][t])
-                ops.conv2d(h_prev, R, None, add=z, out=z)
+                z = ops.conv2d_cat(cur, h_prev, kr[l], b, out=dgs[l][t])
                 hslot = feat[t][..., offs[l]:offs[l] + F[l]]
                 ops.convlstm_gates_train(z, c_prev, hslot, act, gates=z, c_new=dcs[l][t])
                 cur = hslot

@@ -339,3 +339,21 @@ def test_convlstm_input_dropout_gradients(head, B, T_in, T_out, H, W, C, L, hf):
     P_eval, _ = tr._forward(dev(enc), dev(dec0), T_out)
     _, _, P_plain = _torch_convlstm_graph(enc, dec0, tgt, w, head, "hard_sigmoid")
     close(P_eval.transpose(0, 1), P_plain, "eval forward without dropout")
+
+
+@pytest.mark.parametrize("B,H,W,C1,C2,N,k", [(2, 6, 5, 30, 32, 128, 5), (3, 36, 18, 32, 16, 64, 5), (2, 1, 30, 3, 8, 32, 5),
+                                             (1, 7, 4, 16, 8, 32, 3), (2, 5, 5, 17, 20, 12, 3)])
+def test_conv2d_over_channel_concatenation(B, H, W, C1, C2, N, k):
+    """One ConvLSTM2D step as ONE convolution: conv([x | h], [K ; R]) over two separate maps (fov_conv2d_fwd2) equals the
+    convolution of the concatenated map, for vector and scalar channel paths, channel-slice and batch-strided views."""
+    from longterm360fov_amd import ops
+    rng = np.random.default_rng(C1 * 10 + C2)
+    x1 = rng.standard_normal((B, 2, H, W, C1)).astype(np.float32)            # a (B,T,...) sequence: batch-strided x_t
+    wide = rng.standard_normal((B, H, W, C2 + 8)).astype(np.float32)         # h as a channel slice of a wider map
+    w = (rng.standard_normal((k, k, C1 + C2, N)) / np.sqrt(k * k * (C1 + C2))).astype(np.float32)
+    b = rng.standard_normal(N).astype(np.float32)
+    cat = np.concatenate([x1[:, 1], wide[..., 4:4 + C2]], -1)
+    ref = O.conv2d_same(cat.astype(np.float64), w.astype(np.float64), b.astype(np.float64))
+    got = ops.conv2d_cat(dev(x1)[:, 1], dev(wide)[..., 4:4 + C2], dev(w), dev(b))
+    close(got, ref, "conv over [x | h]")
+    close(ops.conv2d_cat(dev(x1)[:, 1], dev(wide)[..., 4:4 + C2], dev(w), dev(b), activation="relu"), np.maximum(ref, 0), "relu")

@@ -122,3 +122,37 @@ def test_missing_extension_fails_loudly(monkeypatch):
     monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libfov360_hip.so")
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         _lib.lib()
+
+
+def test_trainer_host_helpers_on_cpu():
+    """Host-side pieces of the trainers that need no GPU: the ConvLSTM parameter order, the block-diagonal kernel and
+    channel stacking behind Keras's per-gate input dropout (the stacked convolution equals four per-gate
+    convolutions of the masked inputs), and the tf.contrib <-> Keras LSTM layout conversion."""
+    import torch
+    import torch.nn.functional as TF
+    from longterm360fov_amd.models import convert_tf_lstmcell
+    from longterm360fov_amd.training import ConvLSTMTrainer, convlstm_weight_order
+    w = {"%s%d_%s" % (s, l, n): 0 for s in ("enc", "dec") for l in range(3) for n in "KRb"}
+    w.update({"head0_W": 0, "head0_b": 0, "head1_W": 0, "head1_b": 0})
+    order = convlstm_weight_order(w)
+    assert order[:3] == ["enc0_K", "enc0_R", "enc0_b"] and order[-4:] == ["head0_W", "head0_b", "head1_W", "head1_b"] and len(order) == 22
+    rng = np.random.default_rng(0)
+    B, H, W, C, F = 2, 5, 4, 3, 2
+    K = torch.tensor(rng.standard_normal((3, 3, C, 4 * F)))
+    x = torch.tensor(rng.standard_normal((B, H, W, C)))
+    m4 = torch.tensor((rng.random((4, B, H, W, C)) < 0.7) / 0.7)
+    conv = lambda a, k: TF.conv2d(a.permute(0, 3, 1, 2), k.permute(3, 2, 0, 1), padding=1).permute(0, 2, 3, 1)
+    stacked = conv(ConvLSTMTrainer._stack_masked(x, m4), ConvLSTMTrainer._block_diag_kernel(K))
+    per_gate = torch.cat([conv(x * m4[g], K[..., g * F:(g + 1) * F]) for g in range(4)], -1)
+    assert torch.allclose(stacked, per_gate, atol=1e-12)
+    # tf.contrib LSTMCell (i, j, f, o; forget_bias inside the cell) -> Keras layout (i, f, c, o; bias carries it)
+    Hh, Fi = 5, 3
+    Wt = rng.standard_normal((Fi + Hh, 4 * Hh)).astype(np.float32)
+    bt = rng.standard_normal(4 * Hh).astype(np.float32)
+    Kk, Rk, bk = convert_tf_lstmcell(Wt, bt, forget_bias=1.0)
+    xx, hh = rng.standard_normal((2, Fi)), rng.standard_normal((2, Hh))
+    z_tf = np.concatenate([xx, hh], 1) @ Wt + bt
+    z_k = xx @ Kk + hh @ Rk + bk
+    i, j, f, o = (z_tf[:, k * Hh:(k + 1) * Hh] for k in range(4))
+    assert np.allclose(z_k[:, :Hh], i, atol=1e-5) and np.allclose(z_k[:, Hh:2 * Hh], f + 1.0, atol=1e-5)
+    assert np.allclose(z_k[:, 2 * Hh:3 * Hh], j, atol=1e-5) and np.allclose(z_k[:, 3 * Hh:], o, atol=1e-5)

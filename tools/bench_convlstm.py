@@ -24,6 +24,8 @@ def main():
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--whole", action="store_true")
+    ap.add_argument("--no-pad-input", action="store_true", help="cell bench: keep 30 input channels (scalar gather) "
+                    "instead of the zero-padded 32 the model object uses")
     ap.add_argument("--train", action="store_true", help="also time one training step (fwd + backward + RMSprop)")
     ap.add_argument("--train-batch", type=int, default=64)
     a = ap.parse_args()
@@ -36,16 +38,22 @@ def main():
     cin = (C,) + filters[:2]
     cell_flop_step = sum(2 * 25 * (ci + f) * 4 * f for ci, f in zip(cin, filters)) * H * W   # per sequence-step
 
+    kr = [torch.cat([dw["enc%d_K" % l], dw["enc%d_R" % l]], 2).contiguous() for l in range(3)]
+    x0 = x
+    if not a.no_pad_input:   # as ConvLSTMSeq2Seq.predict does: zero channels 30, 31 in x and zero rows in K: same result, vector gather path
+        x = torch.cat([x, torch.zeros((B, T, H, W, 2), device="cuda")], -1).contiguous()
+        K0 = torch.cat([dw["enc0_K"], torch.zeros((5, 5, 2, 4 * filters[0]), device="cuda")], 2)
+        kr[0] = torch.cat([K0, dw["enc0_R"]], 2).contiguous()
+
     def encoder():
         seq = [x[:, t] for t in range(T)]
         for l, F in enumerate(filters):
             h = torch.zeros((B, H, W, F), device="cuda")
             c = torch.zeros((B, H, W, F), device="cuda")
-            K, R, b = dw["enc%d_K" % l], dw["enc%d_R" % l], dw["enc%d_b" % l]
+            KR, b = kr[l], dw["enc%d_b" % l]
             nxt = []
             for t in range(T):
-                z = ops.conv2d(seq[t], K, b)
-                z = ops.conv2d(h, R, None, add=z, out=z)
+                z = ops.conv2d_cat(seq[t], h, KR, b)     # conv(x_t, K) + conv(h, R) + b in one launch
                 hn = torch.empty((B, H, W, F), device="cuda")
                 ops.convlstm_gates(z, c, hn, "hard_sigmoid")
                 h = hn
@@ -64,7 +72,7 @@ def main():
            "frac_of_fp32_mfma_peak": cell_flop_step * T * B / dt / 1e12 / 157.3}
     if a.whole:
         m = ConvLSTMSeq2Seq(w, head="conv2d")
-        xe = x.cpu().numpy()
+        xe = x0.cpu().numpy()
         m.predict([xe[:8], xe[:8, -1:]], predict_step=1)
         t0 = time.perf_counter()
         m.predict([xe, xe[:, -1:]], predict_step=T)
@@ -76,7 +84,7 @@ def main():
         from longterm360fov_amd.training import ConvLSTMTrainer
         Bt = a.train_batch
         tr = ConvLSTMTrainer(w, head="conv2d")
-        xe = x[:Bt].contiguous()
+        xe = x0[:Bt].contiguous()
         tgt = torch.softmax(torch.rand((Bt, T, H, W, C), device="cuda"), -1)
         tr.train_step(xe, xe[:, -1:], tgt)
         torch.cuda.synchronize()
