@@ -34,6 +34,8 @@ def default_config():
     c.predict_len = 10                # :21
     c.running_length = 10             # :22  encoder length T_in (seconds)
     c.predict_step = 10               # :23  decoder length T_out (seconds)
+    c.add_residual_link = False       # :38  (FoV_seq2seq_no_teac_forc.py)
+    c.has_reconstruct_loss = False    # :40  (not built)
     c.LEARNING_RATE = 1e-5            # :50  (raw-TF path)
     c.lr_epoch_step = 10              # :51
     c.clip_gradient = True            # :52
@@ -54,6 +56,10 @@ def default_config():
     c.cut_data_head = False           # :112
     c.purelly_testing = False         # :113
     c.time_shift = False              # :120
+    c.enc_last_out_as_dec_in = False  # :121
+    c.embed_frame_state_enc2dec = False   # :127 (not built)
+    c.rescale_input = False           # :130
+    c.include_time_ind = False        # :131
     # not in the reference: gate activation of the LSTM cell.  Keras < 2.3 defaults to
     # 'hard_sigmoid'; BASELINE.json's north_star names 'sigmoid'.
     c.recurrent_activation = "sigmoid"

@@ -294,6 +294,136 @@ class Seq2SeqLSTM:
         return float(loss.item())
 
 
+class NoTeacherForcingSeq2Seq(Seq2SeqLSTM):
+    """One-layer target-only seq2seq trained and run WITHOUT teacher forcing
+    (mycode/FoV_seq2seq_no_teac_forc.py:37-149, `onelayer_tar_seq2seq`): the decoder is unrolled `predict_step`
+    times on its own Dense output.  Inputs as the script's Model: [encoder_input (N,T_in,F), decoder_input (N,1,O)],
+    or encoder_input alone under cfg.enc_last_out_as_dec_in (:128-146); returns (N,T_out,O).
+
+    Flags default to the script's: `decoder_no_init_state=True` (:29 — decoder step 0 starts from zero state),
+    cfg.add_residual_link / cfg.enc_last_out_as_dec_in / cfg.rescale_input False.  Not built: the reconstruction
+    decoder (cfg.has_reconstruct_loss), cfg.embed_frame_state_enc2dec, BatchNorm on the feedback (add_bn)."""
+
+    def __init__(self, num_encoder_tokens=None, num_decoder_tokens=6, latent_dim=64, recurrent_activation=None, seed=None,
+                 impl="auto", device="cuda", predict_step=None, decoder_no_init_state=True, add_residual_link=None,
+                 enc_last_out_as_dec_in=None, rescale_input=None):
+        super().__init__(num_encoder_tokens, num_decoder_tokens, latent_dim, recurrent_activation, seed, impl, device)
+        knob = lambda v, name: bool(getattr(cfg, name, False)) if v is None else bool(v)
+        self.predict_step = cfg.predict_step if predict_step is None else int(predict_step)
+        self.decoder_no_init_state = bool(decoder_no_init_state)
+        self.add_residual_link = knob(add_residual_link, "add_residual_link")
+        self.enc_last_out_as_dec_in = knob(enc_last_out_as_dec_in, "enc_last_out_as_dec_in")
+        self.dense_activation = "relu" if knob(rescale_input, "rescale_input") else "tanh"
+        if self.add_residual_link:
+            rng = np.random.default_rng(None if seed is None else seed + 1)
+            self._w["res_W"] = glorot_uniform(rng, self.num_decoder_tokens, self.num_decoder_tokens)
+            self._w["res_b"] = np.zeros(self.num_decoder_tokens, np.float32)
+
+    def _order(self):
+        return _W_ORDER + (("res_W", "res_b") if self.add_residual_link else ())
+
+    def get_weights(self):
+        return [self._w[k].copy() for k in self._order()]
+
+    def set_weights(self, weights):
+        weights = list(weights)
+        if len(weights) != len(self._order()):
+            raise ValueError("expected %d arrays, got %d" % (len(self._order()), len(weights)))
+        for k, a in zip(self._order(), weights):
+            a = _as_f32(a)
+            if a.shape != self._w[k].shape:
+                raise ValueError("%s: expected shape %s, got %s" % (k, self._w[k].shape, a.shape))
+            self._w[k] = a
+        self._dw = None
+        self._trainer = None
+
+    def load_weights(self, path):
+        with np.load(path) as z:
+            self.set_weights([z[k] for k in self._order()])
+
+    def _split_inputs(self, x):
+        if self.enc_last_out_as_dec_in:
+            enc = x[0] if isinstance(x, (list, tuple)) else x
+            return _as_f32(enc), None
+        return _as_f32(x[0]), _as_f32(x[1])
+
+    def predict(self, x, batch_size=None, verbose=0):
+        import torch
+        enc, dec0 = self._split_inputs(x)
+        ops, dw, act = self._ops(), self._device_weights(), self.recurrent_activation
+        T_out, O, H = self.predict_step, self.num_decoder_tokens, self.latent_dim
+        plain = not (self.add_residual_link or self.enc_last_out_as_dec_in or self.dense_activation != "tanh")
+        n = enc.shape[0]
+        bs = n if not batch_size else int(batch_size)
+        outs = []
+
+        def dense(v, W, b):
+            y = ops.dense(v, W, b, activation="tanh" if self.dense_activation == "tanh" else None)
+            return y if self.dense_activation == "tanh" else ops.act_fwd(y, "relu", out=y)
+        for lo in range(0, n, max(bs, 1)):
+            e = self._dev(enc[lo:lo + bs])
+            if plain:     # ONE fused call; a zero-length encoder input is the zero initial state of :98-99
+                o = ops.seq2seq_decode(e[:, :0] if self.decoder_no_init_state else e, self._dev(dec0[lo:lo + bs]), dw, T_out,
+                                       act=act, impl=self.impl, workspace=self._ws)
+                outs.append(o.cpu().numpy())
+                continue
+            B = e.shape[0]
+            _, h, c = ops.lstm_seq(e, dw["enc_K"], dw["enc_R"], dw["enc_b"], act=act, impl=self.impl, return_sequences=False,
+                                   workspace=self._ws)
+            xin = dense(h, dw["dense_W"], dw["dense_b"]) if self.enc_last_out_as_dec_in else self._dev(dec0[lo:lo + bs]).reshape(B, O)
+            if self.decoder_no_init_state:
+                h, c = torch.zeros_like(h), torch.zeros_like(c)
+            r = dense(xin, dw["res_W"], dw["res_b"]) if self.add_residual_link else None
+            o = torch.empty((B, T_out, O), dtype=torch.float32, device=self.device)
+            for t in range(T_out):
+                _, h, c = ops.lstm_seq(xin.reshape(B, 1, O), dw["dec_K"], dw["dec_R"], dw["dec_b"], h, c, act=act, impl=self.impl,
+                                       return_sequences=False, workspace=self._ws)
+                xin = dense(h, dw["dense_W"], dw["dense_b"])
+                if r is not None:
+                    xin = ops.act_bwd(r, r, base=xin, activation=None)     # y_t = Dense(h_t) + residual
+                o[:, t] = xin
+            outs.append(o.cpu().numpy())
+        self._ws.check()
+        return np.concatenate(outs, axis=0) if outs else np.zeros((0, T_out, O), np.float32)
+
+    predict_on_batch = predict
+
+    def _get_trainer(self):
+        from .training import SelfFedSeq2SeqTrainer
+        if self._trainer is None:
+            self._trainer = SelfFedSeq2SeqTrainer(
+                self._w, act=self.recurrent_activation, impl=self.impl, optimizer=self.optimizer or "adam", lr=self._lr,
+                device=self.device, decoder_no_init_state=self.decoder_no_init_state, add_residual_link=self.add_residual_link,
+                enc_last_out_as_dec_in=self.enc_last_out_as_dec_in, dense_activation=self.dense_activation)
+        return self._trainer
+
+    def _fit_inputs(self, x):
+        enc, dec0 = self._split_inputs(x)
+        if dec0 is None:      # the trainer's positional signature keeps a decoder-input slot; it is not read
+            dec0 = np.zeros((enc.shape[0], 1, self.num_decoder_tokens), np.float32)
+        return [enc, dec0]
+
+    def fit(self, x, y, batch_size=32, epochs=1, validation_split=0.0, shuffle=True, callbacks=None, initial_epoch=0,
+            verbose=0, validation_data=None):
+        """Keras `Model.fit` as the script calls it (:289-300); see _keras_fit for the semantics."""
+        if self.optimizer is None:
+            raise RuntimeError("call compile() before fit()")
+        if validation_data is not None:
+            validation_data = (self._fit_inputs(validation_data[0]), validation_data[1])
+        return _keras_fit(self, self._get_trainer(), self._fit_inputs(x), y, batch_size, epochs, validation_split, shuffle,
+                          callbacks, initial_epoch, validation_data)
+
+    def train_on_batch(self, x, y):
+        import torch
+        tr = self._get_trainer()
+        d = lambda a: torch.from_numpy(_as_f32(a)).to(self.device)
+        enc, dec0 = self._fit_inputs(x)
+        loss = tr.train_step(d(enc), d(dec0), d(y))
+        self._w = tr.weights_numpy()
+        self._dw = None
+        return float(loss.item())
+
+
 _MIX_ORDER = ("enc1_K", "enc1_R", "enc1_b", "enc2_K", "enc2_R", "enc2_b", "dec1_K", "dec1_R", "dec1_b",
               "dec2_K", "dec2_R", "dec2_b", "dense_W", "dense_b", "mix_W", "mix_b")
 

@@ -12,9 +12,9 @@ _W_ORDER = ("enc_K", "enc_R", "enc_b", "dec_K", "dec_R", "dec_b", "dense_W", "de
 
 
 class Seq2SeqTrainer:
-    def __init__(self, weights, act="sigmoid", impl="auto", optimizer="adam", lr=1e-3, device="cuda"):
+    def __init__(self, weights, act="sigmoid", impl="auto", optimizer="adam", lr=1e-3, device="cuda", order=_W_ORDER):
         self.act, self.impl, self.optimizer, self.lr, self.device = act, impl, optimizer, float(lr), device
-        self.shapes = [(k, tuple(weights[k].shape)) for k in _W_ORDER]
+        self.shapes = [(k, tuple(weights[k].shape)) for k in order]
         n = int(sum(np.prod(s) for _, s in self.shapes))
         self.flat = torch.empty(n, dtype=torch.float32, device=device)     # parameters, one buffer
         self.grad = torch.zeros(n, dtype=torch.float32, device=device)     # gradients, same layout
@@ -100,6 +100,113 @@ class Seq2SeqTrainer:
     def eval_loss(self, enc, dec_in, target):
         y = ops.seq2seq_teacher_forced(enc, dec_in, self.w, act=self.act, impl=self.impl, workspace=self.ws)
         _, loss = ops.mse_dense_grad(y, target, None, scratch=self.scratch)
+        return loss
+
+
+class SelfFedSeq2SeqTrainer(Seq2SeqTrainer):
+    """Training step of the one-layer target-only model WITHOUT teacher forcing
+    (mycode/FoV_seq2seq_no_teac_forc.py:37-149, `onelayer_tar_seq2seq`; Adam + MSE, :147): the decoder is unrolled
+    T_out times on its own output.  Same layer kernels as the teacher-forced trainer, walked step by step: forward
+    writes a time-major tape, backward joins the loss gradient of step t with the input gradient of step t+1, and
+    every weight gradient is one product over all steps.
+
+    decoder_no_init_state   the script's module flag (:29,98-99): step 0 starts from zero state (the encoder then
+                            only matters through enc_last_out_as_dec_in)
+    add_residual_link       cfg.add_residual_link (:70-72,103-107): y_t += residual_dense(decoder input)
+    enc_last_out_as_dec_in  cfg.enc_last_out_as_dec_in (:75-78): decoder input = decoder_dense(encoder output)
+    dense_activation        'tanh', or 'relu' under cfg.rescale_input (:60-63)"""
+
+    def __init__(self, weights, act="sigmoid", impl="auto", optimizer="adam", lr=1e-3, device="cuda",
+                 decoder_no_init_state=True, add_residual_link=False, enc_last_out_as_dec_in=False,
+                 dense_activation="tanh"):
+        super().__init__(weights, act=act, impl=impl, optimizer=optimizer, lr=lr, device=device,
+                         order=_W_ORDER + (("res_W", "res_b") if add_residual_link else ()))
+        self.no_init, self.residual, self.enc_as_in = bool(decoder_no_init_state), bool(add_residual_link), bool(enc_last_out_as_dec_in)
+        self.dact = dense_activation
+
+    def _dense(self, x, W, b, out=None):
+        y = ops.dense(x, W, b, activation="tanh" if self.dact == "tanh" else None, out=out)
+        if self.dact == "relu":
+            ops.act_fwd(y, "relu", out=y)
+        return y
+
+    def forward_backward(self, enc, dec_in, target, grad_weight=1.0):
+        """dec_in (B,1,O) is ignored under enc_last_out_as_dec_in.  -> (loss (1,), prediction (B,T_out,O))."""
+        w, g, act, impl, ws, sc, bsc = self.w, self.g, self.act, self.impl, self.ws, self.scratch, self.bwd_scratch
+        B, T_in, _ = enc.shape
+        T_out = target.shape[1]
+        H, O = w["dec_R"].shape[0], w["dense_W"].shape[1]
+        e = lambda *s_: torch.empty(s_, dtype=torch.float32, device=self.device)
+        self.grad.zero_()
+        # ---------------- forward ----------------
+        Hs, Cs = e(T_out + 1, B, H), e(T_out + 1, B, H)   # row t = state before decoder step t
+        XA = e(T_out + 1, B, O)                            # row t = decoder input x_t; row t+1 = y_t
+        A = e(T_out, B, O)                                 # Dense outputs before the residual is added
+        RES = e(T_out, B, 1, 5, H)
+        ehs, ehT, ecT, eres = ops.lstm_seq_train(enc, w["enc_K"], w["enc_R"], w["enc_b"], act=act, impl=impl, workspace=ws)
+        if self.enc_as_in:
+            self._dense(ehT, w["dense_W"], w["dense_b"], out=XA[0])
+        else:
+            XA[0].copy_(dec_in.reshape(B, O))
+        if self.no_init:
+            Hs[0].zero_(); Cs[0].zero_()
+        else:
+            Hs[0].copy_(ehT); Cs[0].copy_(ecT)
+        r = self._dense(XA[0], w["res_W"], w["res_b"]) if self.residual else None
+        for t in range(T_out):
+            ops.lstm_seq_train(XA[t].view(B, 1, O), w["dec_K"], w["dec_R"], w["dec_b"], Hs[t], Cs[t], act=act, impl=impl,
+                               workspace=ws, out=(Hs[t + 1].view(B, 1, H), None, Cs[t + 1], RES[t]))
+            if self.residual:
+                self._dense(Hs[t + 1], w["dense_W"], w["dense_b"], out=A[t])
+                ops.act_bwd(r, r, base=A[t], activation=None, out=XA[t + 1])     # y_t = a_t + r
+            else:
+                self._dense(Hs[t + 1], w["dense_W"], w["dense_b"], out=XA[t + 1])
+        Y = XA[1:]
+        Aout = A if self.residual else Y
+        out = Y.transpose(0, 1).contiguous()
+        # ---------------- backward ----------------
+        dloss, loss = ops.mse_dense_grad(out, target, None, scratch=sc)            # dL/dy, all steps
+        dloss_tm = dloss.transpose(0, 1).contiguous()
+        DY, DPRE, DZ = e(T_out, B, O), e(T_out, B, O), e(T_out, B, 4 * H)
+        dh_rec = dc = dx_next = None
+        for t in range(T_out - 1, -1, -1):
+            if dx_next is None:
+                DY[t].copy_(dloss_tm[t])
+            else:                                                                  # x_{t+1} = y_t: feedback gradient joins
+                ops.act_bwd(dx_next.reshape(B, O), Aout[t], base=dloss_tm[t], activation=None, out=DY[t])
+            ops.act_bwd(DY[t], Aout[t], activation=self.dact, out=DPRE[t])
+            dh_dense, _, _ = ops.dense_bwd(Hs[t + 1], w["dense_W"], DPRE[t], need_dx=True, need_dW=False, need_db=False, scratch=sc)
+            b = ops.lstm_seq_bwd(XA[t].view(B, 1, O), w["dec_K"], w["dec_R"], Hs[t + 1].view(B, 1, H), RES[t], h0=Hs[t], c0=Cs[t],
+                                 dhs=dh_dense.reshape(B, 1, H), dhT=dh_rec, dcT=dc, need_dx=True, need_state_grads=True, act=act,
+                                 dz=DZ[t].view(B, 1, 4 * H), scratch=bsc, need_weight_grads=False)
+            dh_rec, dc, dx_next = b["dh0"], b["dc0"], b["dx"]
+        TB = T_out * B
+        fl = lambda a, n: a.reshape(TB, n)
+        ops.dense_bwd(fl(Hs[1:], H), w["dense_W"], fl(DPRE, O), dW=g["dense_W"], db=g["dense_b"], need_dx=False, accumulate=True, scratch=sc)
+        ops.dense_bwd(fl(XA[:T_out], O), w["dec_K"], fl(DZ, 4 * H), dW=g["dec_K"], db=g["dec_b"], need_dx=False, accumulate=True, scratch=sc)
+        ops.dense_bwd(fl(Hs[:T_out], H), w["dec_R"], fl(DZ, 4 * H), dW=g["dec_R"], need_db=False, need_dx=False, accumulate=True, scratch=sc)
+        dx0 = dx_next.reshape(B, O)                       # gradient w.r.t. the decoder input
+        if self.residual:                                 # r is added to every step's output
+            dr = ops.colsum(DY.reshape(T_out, B * O), scratch=sc).reshape(B, O)
+            dpre_r = ops.act_bwd(dr, r, activation=self.dact)
+            dxr, _, _ = ops.dense_bwd(XA[0], w["res_W"], dpre_r, dW=g["res_W"], db=g["res_b"], need_dx=True, accumulate=True, scratch=sc)
+            dx0 = ops.act_bwd(dxr, dxr, base=dx0, activation=None)
+        d_ehT = d_ecT = None
+        if self.enc_as_in:                                # x_0 = Dense(encoder output)
+            dpre0 = ops.act_bwd(dx0, XA[0], activation=self.dact)
+            d_ehT, _, _ = ops.dense_bwd(ehT, w["dense_W"], dpre0, dW=g["dense_W"], db=g["dense_b"], need_dx=True, accumulate=True, scratch=sc)
+        if not self.no_init:
+            d_ehT = dh_rec if d_ehT is None else ops.act_bwd(dh_rec, dh_rec, base=d_ehT, activation=None)
+            d_ecT = dc
+        if d_ehT is not None:                             # otherwise the encoder does not reach the loss (reference quirk)
+            ops.lstm_seq_bwd(enc, w["enc_K"], w["enc_R"], ehs, eres, dhT=d_ehT, dcT=d_ecT, dK=g["enc_K"], dR=g["enc_R"],
+                             db=g["enc_b"], act=act, accumulate=True, scratch=bsc)
+        if grad_weight != 1.0:
+            self.grad.mul_(grad_weight)
+        return loss, out
+
+    def eval_loss(self, enc, dec_in, target):
+        loss, _ = self.forward_backward(enc, dec_in, target)   # gradients are overwritten by the next step
         return loss
 
 

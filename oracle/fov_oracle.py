@@ -125,6 +125,31 @@ def seq2seq_decode(enc_in, dec_in0, w, T_out, act="sigmoid"):
     return np.stack(out, axis=1)
 
 
+def onelayer_tar_seq2seq_forward(enc_in, dec_in0, w, T_out, act="sigmoid", decoder_no_init_state=True,
+                                 add_residual_link=False, enc_last_out_as_dec_in=False, dense_activation="tanh"):
+    """Unrolled no-teacher-forcing target-only model, FoV_seq2seq_no_teac_forc.py:37-149 (onelayer_tar_seq2seq):
+    encoder LSTM (:42-44); decoder input = dec_in0 (B,1,O), or Dense(encoder output) when
+    cfg.enc_last_out_as_dec_in (:75-78); step 0 of the decoder starts from ZERO state when the script's
+    `decoder_no_init_state` is set (:29,98-99), later steps carry the decoder's own state (:118);
+    y_t = Dense(h_t) [+ residual_dense(decoder input), cfg.add_residual_link, :103-107]; y_t is fed back (:115).
+    weights: enc_*, dec_*, dense_W/b and, with the residual link, res_W (O,O) / res_b."""
+    fa = (lambda v: np.tanh(v)) if dense_activation == "tanh" else (lambda v: np.maximum(v, 0))
+    _, h, c = lstm_layer(enc_in, w["enc_K"], w["enc_R"], w["enc_b"], act=act)
+    if enc_last_out_as_dec_in:
+        x0 = fa(h @ w["dense_W"] + w["dense_b"])
+    else:
+        x0 = dec_in0[:, 0].astype(enc_in.dtype)
+    if decoder_no_init_state:
+        h, c = np.zeros_like(h), np.zeros_like(c)
+    r = fa(x0 @ w["res_W"] + w["res_b"]) if add_residual_link else 0.0
+    x, out = x0, []
+    for _ in range(T_out):
+        h, c = lstm_step(x, h, c, w["dec_K"], w["dec_R"], w["dec_b"], act)
+        x = fa(h @ w["dense_W"] + w["dense_b"]) + r
+        out.append(x)
+    return np.stack(out, axis=1)
+
+
 # --------------------------------------------------------------------------------------
 # a4: target + others mixing, 2-layer, no teacher forcing
 # (mycode/given_others_gt_mean_var_seq2seq.py:98-130, 203-299)

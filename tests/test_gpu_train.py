@@ -480,3 +480,89 @@ def test_tf_stacked_lstm_training_graph(H, B, T, with_masks):
     ops.rmsprop_tf_step(p, gg, ms, lr=0.1, decay=0.9, eps=1e-10, clip_value=1.0)
     gc = np.array([0.5, -1.0, 0.0]); ms_ref = 0.9 + 0.1 * gc ** 2
     assert np.allclose(ms.cpu().numpy(), ms_ref, atol=1e-6) and np.allclose(p.cpu().numpy(), -0.1 * gc / np.sqrt(ms_ref + 1e-10), atol=1e-6)
+
+
+def _torch_self_fed_graph(enc, dec0, tgt, w, act, no_init, residual, enc_as_in, dact):
+    """Independent fp64 reference of FoV_seq2seq_no_teac_forc.py:37-149 (onelayer_tar_seq2seq) on torch.autograd."""
+    t = {k: torch.tensor(v.astype(np.float64), requires_grad=True) for k, v in w.items()}
+    H = w["enc_R"].shape[0]
+    s = torch.sigmoid if act == "sigmoid" else (lambda z: torch.clamp(0.2 * z + 0.5, 0, 1))
+    fa = torch.tanh if dact == "tanh" else torch.relu
+
+    def step(x, h, c, K, R, b):
+        z = x @ K + b + h @ R
+        i, f, g, o = s(z[:, :H]), s(z[:, H:2 * H]), torch.tanh(z[:, 2 * H:3 * H]), s(z[:, 3 * H:])
+        c = f * c + i * g
+        return o * torch.tanh(c), c
+
+    e, d0, tg = (torch.tensor(a.astype(np.float64)) for a in (enc, dec0, tgt))
+    B = e.shape[0]
+    h = c = torch.zeros(B, H, dtype=torch.float64)
+    for tt in range(e.shape[1]):
+        h, c = step(e[:, tt], h, c, t["enc_K"], t["enc_R"], t["enc_b"])
+    x0 = fa(h @ t["dense_W"] + t["dense_b"]) if enc_as_in else d0[:, 0]
+    if no_init:
+        h = c = torch.zeros(B, H, dtype=torch.float64)
+    r = fa(x0 @ t["res_W"] + t["res_b"]) if residual else 0.0
+    x, outs = x0, []
+    for _ in range(tg.shape[1]):
+        h, c = step(x, h, c, t["dec_K"], t["dec_R"], t["dec_b"])
+        x = fa(h @ t["dense_W"] + t["dense_b"]) + r
+        outs.append(x)
+    y = torch.stack(outs, 1)
+    loss = torch.mean((y - tg) ** 2)
+    loss.backward()
+    return float(loss), {k: (np.zeros_like(w[k], dtype=np.float64) if v.grad is None else v.grad.numpy()) for k, v in t.items()}, \
+        y.detach().numpy()
+
+
+@pytest.mark.parametrize("H,B,T_in,T_out,act,no_init,residual,enc_as_in,dact", [
+    (64, 21, 4, 5, "sigmoid", True, False, False, "tanh"),          # the script as committed (:29, cfg defaults)
+    (128, 33, 5, 4, "hard_sigmoid", False, False, False, "tanh"),   # decoder seeded with the encoder state
+    (256, 40, 3, 6, "sigmoid", False, True, False, "tanh"),         # cfg.add_residual_link
+    (64, 17, 4, 3, "hard_sigmoid", True, False, True, "tanh"),      # cfg.enc_last_out_as_dec_in
+    (32, 9, 3, 4, "sigmoid", False, True, True, "relu"),            # all of them + cfg.rescale_input
+])
+def test_no_teacher_forcing_one_layer_gradients_and_training(H, B, T_in, T_out, act, no_init, residual, enc_as_in, dact):
+    """§8(f) rank 3 sibling topology: forward against the NumPy oracle, gradients of the self-fed unrolled graph
+    against torch.autograd fp64, the model object's predict against the oracle, and Adam steps reduce the loss."""
+    from longterm360fov_amd.models import NoTeacherForcingSeq2Seq
+    from longterm360fov_amd.training import SelfFedSeq2SeqTrainer
+    w = O.init_seq2seq(90 + H, H=H, bias_noise=0.1)
+    rng = np.random.default_rng(H + B)
+    if residual:
+        w["res_W"] = rng.uniform(-0.5, 0.5, (6, 6)).astype(np.float32)
+        w["res_b"] = rng.uniform(-0.1, 0.1, 6).astype(np.float32)
+    enc, dec0, tgt = O.synthetic_batch(91 + B, B, T_in, T_out)
+    if dact == "relu":
+        tgt = np.abs(tgt)
+    kw = dict(decoder_no_init_state=no_init, add_residual_link=residual, enc_last_out_as_dec_in=enc_as_in)
+    y_np = O.onelayer_tar_seq2seq_forward(enc.astype(np.float64), dec0.astype(np.float64), f64(w), T_out, act=act,
+                                          dense_activation=dact, **kw)
+    loss_ref, g_ref, y_ref = _torch_self_fed_graph(enc, dec0, tgt, w, act, no_init, residual, enc_as_in, dact)
+    np.testing.assert_allclose(y_np, y_ref, atol=1e-12)
+    tr = SelfFedSeq2SeqTrainer(w, act=act, dense_activation=dact, **kw)
+    loss, y = tr.forward_backward(dev(enc), dev(dec0), dev(tgt))
+    tr.ws.check(); tr.bwd_scratch.check()
+    assert abs(float(loss.item()) - loss_ref) <= 1e-5 * loss_ref + 1e-9
+    np.testing.assert_allclose(y.cpu().numpy(), y_ref, atol=2e-5)
+    for k in tr.g:
+        a = tr.g[k].detach().cpu().numpy().astype(np.float64)
+        scale = max(np.abs(g_ref[k]).max(), 1e-30)
+        err = np.abs(a - g_ref[k]).max()
+        print("self-fed H%d grad %-8s max|ref| %.3e  max err %.3e" % (H, k, scale, err))
+        assert err <= 1e-4 * scale + 1e-9, (k, err, scale)
+    if no_init and not enc_as_in:       # reference quirk: the encoder does not reach the loss
+        assert float(tr.g["enc_K"].abs().max()) == 0.0
+    m = NoTeacherForcingSeq2Seq(latent_dim=H, recurrent_activation=act, predict_step=T_out, rescale_input=(dact == "relu"), **kw)
+    order = list(_W_ORDER) + (["res_W", "res_b"] if residual else [])
+    m.set_weights([w[k] for k in order])
+    got = m.predict(enc if enc_as_in else [enc, dec0])
+    assert got.shape == (B, T_out, 6)
+    np.testing.assert_allclose(got, y_ref, atol=2e-5)
+    assert (np.abs(got - y_ref) <= 1e-3 * np.abs(y_ref) + 1e-5).all()
+    m.compile(optimizer="Adam", loss="mean_squared_error")
+    losses = [m.train_on_batch(enc if enc_as_in else [enc, dec0], tgt) for _ in range(4)]
+    assert losses[-1] < losses[0]
+    h = m.fit(enc if enc_as_in else [enc, dec0], tgt, batch_size=16, epochs=2, validation_split=0.2)
+    assert len(h.history["loss"]) == 2 and "val_loss" in h.history

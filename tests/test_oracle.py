@@ -216,3 +216,22 @@ def test_hit_rate_known_answers():
     # straddling the theta seam: centres 20 degrees apart across +-pi must still overlap (5/6 in theta)
     seam = O.fov_hit_rate(e(np.pi - np.pi / 18, 1.2)[None], e(-np.pi + np.pi / 18, 1.2)[None])[0]
     assert abs(seam - (1 - (np.pi / 9) / (2 * np.pi / 3))) < 1e-9
+
+
+def test_onelayer_no_teacher_forcing_oracle_properties():
+    """FoV_seq2seq_no_teac_forc.py:29,98-99: with `decoder_no_init_state` the decoder starts from zero state, so the
+    prediction cannot depend on the encoder input; seeded with the encoder state and without the optional links
+    the model is exactly the autoregressive decode of FoV_seq2seq.py:154-178."""
+    from oracle import fov_oracle as O
+    w = {k: v.astype(np.float64) for k, v in O.init_seq2seq(5, H=16).items()}
+    enc, dec0, _ = O.synthetic_batch(6, 4, 3, 5)
+    enc, dec0 = enc.astype(np.float64), dec0.astype(np.float64)
+    a = O.onelayer_tar_seq2seq_forward(enc, dec0, w, 5)
+    b = O.onelayer_tar_seq2seq_forward(enc[::-1].copy(), dec0, w, 5)
+    np.testing.assert_array_equal(a, b)
+    c = O.onelayer_tar_seq2seq_forward(enc, dec0, w, 5, decoder_no_init_state=False)
+    np.testing.assert_allclose(c, O.seq2seq_decode(enc, dec0, w, 5), atol=1e-15)
+    assert np.abs(c - a).max() > 1e-4
+    w["res_W"], w["res_b"] = np.eye(6) * 0.3, np.zeros(6)
+    d = O.onelayer_tar_seq2seq_forward(enc, dec0, w, 5, decoder_no_init_state=False, add_residual_link=True)
+    assert np.abs(d).max() <= 2.0 and np.abs(d - c).max() > 1e-4      # tanh + tanh
