@@ -257,6 +257,19 @@ int fov_gauss_nll_grad(const float* mu, const float* var, const float* y, float*
 int fov_rmsprop_tf_step(float* params, const float* grads, float* ms, int64_t n, float lr, float decay, float eps,
                         float clip_value, fov_stream_t stream);
 
+/* Sampled re-feed: the next input second drawn around the predicted mean / variance - what lstm.py:460-468 builds from
+ * utility.generate_fake_batch_tf (utility.py:83-89) in its predict_len > 1 training graph, and lstm_keras.py:39-44,139-149
+ * in its cfg.sample_and_refeed sampling model.  x[b, e] = mu[b, a(e)] + sd(var[b, a(e)]) * noise[b, e] for the 3*fps
+ * elements e of one second; noise ~ N(0,1) (B, 3*fps) comes from the caller (TF's generator is not reproducible anyway)
+ * and has the layout of x.  std_mode 0: sd = sqrt(var) (lstm.py), 1: sd = var (lstm_keras.py hands the variance to
+ * `stddev`).  layout 0: a(e) = e % 3, frames interleaved x,y,z; 1: a(e) = e / fps, planar.  Rows of x / dx are ldx floats
+ * apart, so a slot of the (B,T,3*fps) window is written / read in place.  Backward (reparameterisation, what TF
+ * differentiates): dmu[b,a] = sum_e dx, dvar[b,a] = sum_e dx * noise * sd'(var); accumulate != 0 adds into dmu / dvar. */
+int fov_sample_refeed_fwd(const float* mu, const float* var, const float* noise, float* x, int64_t ldx, int B, int fps,
+                          int std_mode, int layout, fov_stream_t stream);
+int fov_sample_refeed_bwd(const float* dx, int64_t ldx, const float* var, const float* noise, float* dmu, float* dvar,
+                          int B, int fps, int std_mode, int layout, int accumulate, fov_stream_t stream);
+
 /* Keras-2.2 optimizers on one flat parameter buffer.
  *   Adam   : lr_t = lr*sqrt(1-beta2^step)/(1-beta1^step); p -= lr_t*m/(sqrt(v)+eps)   (step >= 1)
  *   RMSprop: a = rho*a + (1-rho) g^2; p -= lr*g/(sqrt(a)+eps) */

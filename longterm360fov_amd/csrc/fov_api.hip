@@ -494,6 +494,25 @@ int fov_gauss_nll_grad(const float* mu, const float* var, const float* y, float*
                           (hipStream_t)stream);
 }
 
+int fov_sample_refeed_fwd(const float* mu, const float* var, const float* noise, float* x, int64_t ldx, int B, int fps,
+                          int std_mode, int layout, fov_stream_t stream) {
+    if (B < 0 || fps <= 0 || ldx < 3 * (int64_t)fps || (std_mode | layout) & ~1 || (B > 0 && (!mu || !var || !noise || !x))) {
+        set_error("fov_sample_refeed_fwd: invalid argument");
+        return FOV_ERR_INVALID;
+    }
+    return sample_refeed_fwd(mu, var, noise, x, (long)ldx, B, fps, std_mode, layout, (hipStream_t)stream);
+}
+
+int fov_sample_refeed_bwd(const float* dx, int64_t ldx, const float* var, const float* noise, float* dmu, float* dvar, int B,
+                          int fps, int std_mode, int layout, int accumulate, fov_stream_t stream) {
+    if (B < 0 || fps <= 0 || ldx < 3 * (int64_t)fps || (std_mode | layout) & ~1 ||
+        (B > 0 && (!dx || !var || !noise || !dmu || !dvar))) {
+        set_error("fov_sample_refeed_bwd: invalid argument");
+        return FOV_ERR_INVALID;
+    }
+    return sample_refeed_bwd(dx, (long)ldx, var, noise, dmu, dvar, B, fps, std_mode, layout, accumulate, (hipStream_t)stream);
+}
+
 int fov_rmsprop_tf_step(float* params, const float* grads, float* ms, int64_t n, float lr, float decay, float eps,
                         float clip_value, fov_stream_t stream) {
     if (n < 0 || (n > 0 && (!params || !grads || !ms))) {

@@ -448,6 +448,52 @@ __global__ __launch_bounds__(256) void gauss_nll_kernel(const float* __restrict_
     }
 }
 
+// Sampled re-feed (mycode/lstm.py:460-468 via utility.py:83-89; lstm_keras.py:39-44,139-149): one second of fps frames
+// drawn around the predicted mean, x = mu_a + sd(var_a) * noise, noise ~ N(0,1) supplied by the caller in the layout of x.
+// std_mode 0: sd = sqrt(var) (lstm.py); 1: sd = var (lstm_keras.py passes the variance as stddev).  layout 0: frames
+// interleaved x,y,z (tf.stack axis=-1 + reshape); 1: planar [x*fps | y*fps | z*fps] (Concatenate axis=-1).
+// One wave per sequence; x / dx rows are ldx floats apart (a slot of the (B,T,3*fps) window).
+__global__ __launch_bounds__(64) void sample_refeed_fwd_kernel(const float* __restrict__ mu, const float* __restrict__ var,
+                                                               const float* __restrict__ noise, float* __restrict__ x, long ldx,
+                                                               int fps, int std_mode, int layout) {
+    const int b = blockIdx.x;
+    for (int e = threadIdx.x; e < 3 * fps; e += 64) {
+        const int a = layout ? e / fps : e % 3;
+        const float v = var[b * 3 + a];
+        x[(size_t)b * ldx + e] = mu[b * 3 + a] + (std_mode ? v : sqrtf(v)) * noise[(size_t)b * 3 * fps + e];
+    }
+}
+
+// dmu_a (+)= sum_frames dx;  dvar_a (+)= sum_frames dx * noise * sd'(var_a)   (sd' = 1/(2 sqrt(var)) or 1, IEEE as in TF)
+__global__ __launch_bounds__(64) void sample_refeed_bwd_kernel(const float* __restrict__ dx, long ldx, const float* __restrict__ var,
+                                                               const float* __restrict__ noise, float* __restrict__ dmu,
+                                                               float* __restrict__ dvar, int fps, int std_mode, int layout,
+                                                               int accumulate) {
+    const int b = blockIdx.x;
+    float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int e = threadIdx.x; e < 3 * fps; e += 64) {
+        const int a = layout ? e / fps : e % 3;
+        const float d = dx[(size_t)b * ldx + e], n = noise[(size_t)b * 3 * fps + e];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            acc[k] += a == k ? d : 0.f;
+            acc[3 + k] += a == k ? d * n : 0.f;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k)
+        for (int off = 32; off > 0; off >>= 1) acc[k] += __shfl_xor(acc[k], off, 64);
+    if (threadIdx.x < 3) {
+        const int a = threadIdx.x;
+        const float v = var[b * 3 + a];
+        const float gm = a == 0 ? acc[0] : (a == 1 ? acc[1] : acc[2]);
+        const float gs = a == 0 ? acc[3] : (a == 1 ? acc[4] : acc[5]);
+        const float gv = std_mode ? gs : gs * 0.5f / sqrtf(v);
+        dmu[b * 3 + a] = (accumulate ? dmu[b * 3 + a] : 0.f) + gm;
+        dvar[b * 3 + a] = (accumulate ? dvar[b * 3 + a] : 0.f) + gv;
+    }
+}
+
 // tf.train.RMSPropOptimizer (TF 1.x, momentum 0, not centered; mycode/lstm.py:556-567) with the script's optional
 // clip_by_value(grad, -clip, clip):  ms = decay*ms + (1-decay) g^2;  p -= lr * g / sqrt(ms + eps).  (eps INSIDE the
 // root, ms initialised to ONE - both unlike Keras RMSprop.)
@@ -947,6 +993,21 @@ int gauss_nll_grad(const float* mu, const float* var, const float* y, float* los
     if (rc || !loss) return rc;
     hipLaunchKernelGGL(sum_scale_kernel, dim3(1), dim3(256), 0, stream, scratch, loss, B, scale / (float)B);
     return check_launch("sum_scale");
+}
+
+int sample_refeed_fwd(const float* mu, const float* var, const float* noise, float* x, long ldx, int B, int fps, int std_mode,
+                      int layout, hipStream_t stream) {
+    if (B <= 0) return FOV_OK;
+    hipLaunchKernelGGL(sample_refeed_fwd_kernel, dim3(B), dim3(64), 0, stream, mu, var, noise, x, ldx, fps, std_mode, layout);
+    return check_launch("sample_refeed_fwd");
+}
+
+int sample_refeed_bwd(const float* dx, long ldx, const float* var, const float* noise, float* dmu, float* dvar, int B, int fps,
+                      int std_mode, int layout, int accumulate, hipStream_t stream) {
+    if (B <= 0) return FOV_OK;
+    hipLaunchKernelGGL(sample_refeed_bwd_kernel, dim3(B), dim3(64), 0, stream, dx, ldx, var, noise, dmu, dvar, fps, std_mode, layout,
+                       accumulate);
+    return check_launch("sample_refeed_bwd");
 }
 
 int rmsprop_tf_step(float* p, const float* g, float* ms, long n, float lr, float decay, float eps, float clip,

@@ -270,6 +270,34 @@ def gauss_nll_grad(mu, var, y, fps, scale, scratch=None):
     return loss, dmu, dvar
 
 
+def _row_view(x, width):
+    """(B, width) view whose rows may be a slot of a wider window: -> (data_ptr, row stride in floats)."""
+    assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.shape[1] == width and x.stride(1) == 1
+    return x.data_ptr(), (x.stride(0) if x.shape[0] > 1 else max(x.stride(0), width))
+
+
+def sample_refeed(mu, var, noise, out=None, std="sqrt", planar=False):
+    """One sampled second x = mu + sd(var) * noise (lstm.py:460-468 / lstm_keras.py:139-149).  mu, var (B,3); noise
+    (B,3*fps) standard normal in the layout of x; `out` (B,3*fps) may be a row-strided slot of the input window."""
+    mu, var, noise = _dev(mu, "mu"), _dev(var, "var"), _dev(noise, "noise")
+    B, n = noise.shape
+    out = torch.empty((B, n), dtype=torch.float32, device=mu.device) if out is None else out
+    ptr, ld = _row_view(out, n)
+    check(_lib.lib().fov_sample_refeed_fwd(_ptr(mu), _ptr(var), _ptr(noise), ptr, ld, B, n // 3, 0 if std == "sqrt" else 1,
+                                           1 if planar else 0, _stream()))
+    return out
+
+
+def sample_refeed_bwd(dx, var, noise, dmu, dvar, std="sqrt", planar=False, accumulate=True):
+    """Reparameterisation gradient of sample_refeed into dmu / dvar (B,3); dx (B,3*fps) may be row-strided."""
+    var, noise = _dev(var, "var"), _dev(noise, "noise")
+    B, n = noise.shape
+    ptr, ld = _row_view(dx, n)
+    check(_lib.lib().fov_sample_refeed_bwd(ptr, ld, _ptr(var), _ptr(noise), _ptr(_dev(dmu, "dmu")), _ptr(_dev(dvar, "dvar")), B,
+                                           n // 3, 0 if std == "sqrt" else 1, 1 if planar else 0, 1 if accumulate else 0, _stream()))
+    return dmu, dvar
+
+
 def rmsprop_tf_step(params, grads, ms, lr, decay=0.9, eps=1e-10, clip_value=0.0):
     for t in (params, grads, ms):
         _dev(t, "flat buffer")

@@ -706,8 +706,8 @@ class TFLSTMTrainer:
     converted back by `cells_tf()`.  `head`: dict mu_W1 (H,32), mu_b1, mu_W2 (32,3), mu_b2, var_W1, var_b1, var_W2,
     var_b2.  The DropoutWrapper (output_keep_prob) acts on what a layer hands UP, not on its recurrent state: give
     `masks` [(B,T,H) per non-top layer, already scaled by 1/keep] to reproduce it; the head reads the top state h,
-    which no mask touches.  The predict_len > 1 form of the script re-feeds sampled frames (tf.random_normal) and is
-    not implemented."""
+    which no mask touches.  The predict_len > 1 form of the script (the value mycode/config.py:21 ships) re-feeds
+    sampled seconds: pass `noise` to forward_backward / train_step (fov_sample_refeed_fwd / _bwd)."""
 
     HEAD = ("mu_W1", "mu_b1", "mu_W2", "mu_b2", "var_W1", "var_b1", "var_W2", "var_b2")
 
@@ -777,10 +777,26 @@ class TFLSTMTrainer:
         _, mu, _, var = self._head(states[-1][1])
         return mu, var, torch.stack(states, 0)
 
-    def forward_backward(self, x, y, init_state=None, masks=None):
-        """x (B,T,F), y (B,T_y,3*fps), init_state (L,2,B,H) (c,h) or None.  Fills self.grad; returns
-        (loss (1,), mu (B,3), var (B,3), final state (L,2,B,H))."""
-        w, g, sc = self.w, self.g, self.scratch
+    def rollout(self, x, init_state, noise):
+        """Test-time loop of lstm.py:714-740: noise (P,B,3*fps) standard normal; each step predicts from the window and
+        the state the previous step returned, then shifts in one second sampled around the prediction.
+        -> (mus (P,B,3), vars (P,B,3), final state (L,2,B,H))."""
+        P, B, F = noise.shape
+        T = x.shape[1]
+        mus = torch.empty((P, B, 3), dtype=torch.float32, device=self.device)
+        vs = torch.empty((P, B, 3), dtype=torch.float32, device=self.device)
+        win, st = x, init_state
+        for k in range(P):
+            mu, var, st = self.predict(win, st)
+            mus[k].copy_(mu); vs[k].copy_(var)
+            nxt = torch.empty_like(win)
+            nxt[:, :T - 1].copy_(win[:, 1:])
+            ops.sample_refeed(mu, var, noise[k], out=nxt[:, T - 1], std="sqrt")
+            win = nxt
+        return mus, vs, st
+
+    def _stack_forward(self, x, init_state, masks):
+        w = self.w
         tape, inp, states = [], x, []
         for l in range(self.L):
             c0 = None if init_state is None else init_state[l, 0].contiguous()
@@ -790,30 +806,84 @@ class TFLSTMTrainer:
             tape.append((inp, hs, res, h0, c0))
             states.append(torch.stack([cT, hT], 0))
             inp = hs if (masks is None or l == self.L - 1) else hs * masks[l]
-        hT = states[-1][1].contiguous()
-        a1, mu, a3, var = self._head(hT)
-        scale = 1.0 / (self.running_length * self.fps)
-        loss, dmu, dvar = ops.gauss_nll_grad(mu, var, y, self.fps, scale, scratch=sc)
+        return tape, states
+
+    def _head_backward(self, hT, head, dmu, dvar, accumulate):
+        w, g, sc = self.w, self.g, self.scratch
+        a1, mu, a3, var = head
         d2 = ops.act_bwd(dmu, mu, activation="tanh")
-        da1, _, _ = ops.dense_bwd(a1, w["mu_W2"], d2, dW=g["mu_W2"], db=g["mu_b2"], scratch=sc)
+        da1, _, _ = ops.dense_bwd(a1, w["mu_W2"], d2, dW=g["mu_W2"], db=g["mu_b2"], scratch=sc, accumulate=accumulate)
         d1 = ops.act_bwd(da1, a1, activation="relu")
-        dh_a, _, _ = ops.dense_bwd(hT, w["mu_W1"], d1, dW=g["mu_W1"], db=g["mu_b1"], scratch=sc)
+        dh_a, _, _ = ops.dense_bwd(hT, w["mu_W1"], d1, dW=g["mu_W1"], db=g["mu_b1"], scratch=sc, accumulate=accumulate)
         d4 = ops.act_bwd(dvar, var, activation="exp")
-        da3, _, _ = ops.dense_bwd(a3, w["var_W2"], d4, dW=g["var_W2"], db=g["var_b2"], scratch=sc)
+        da3, _, _ = ops.dense_bwd(a3, w["var_W2"], d4, dW=g["var_W2"], db=g["var_b2"], scratch=sc, accumulate=accumulate)
         d3 = ops.act_bwd(da3, a3, activation="relu")
-        dh_b, _, _ = ops.dense_bwd(hT, w["var_W1"], d3, dW=g["var_W1"], db=g["var_b1"], scratch=sc)
-        dhT = ops.act_bwd(dh_b, hT, base=dh_a, activation=None)      # dh_a + dh_b
-        dhs = None
+        dh_b, _, _ = ops.dense_bwd(hT, w["var_W1"], d3, dW=g["var_W1"], db=g["var_b1"], scratch=sc, accumulate=accumulate)
+        return ops.act_bwd(dh_b, hT, base=dh_a, activation=None)      # dh_a + dh_b
+
+    def _stack_backward(self, tape, dhT, masks, accumulate, need_dx0=False):
+        w, g = self.w, self.g
+        dhs, dx0 = None, None
         for l in range(self.L - 1, -1, -1):
             inp, hs, res, h0, c0 = tape[l]
             b = ops.lstm_seq_bwd(inp, w["K%d" % l], w["R%d" % l], hs, res, h0=h0, c0=c0, dhs=dhs,
                                  dhT=dhT if l == self.L - 1 else None, dK=g["K%d" % l], dR=g["R%d" % l], db=g["b%d" % l],
-                                 need_dx=(l > 0), act="sigmoid", scratch=self.bwd_scratch)
+                                 need_dx=(l > 0 or need_dx0), act="sigmoid", scratch=self.bwd_scratch, accumulate=accumulate)
             if l > 0:
                 dhs = b["dx"] if masks is None else b["dx"] * masks[l - 1]
-        return loss, mu, var, torch.stack(states, 0)
+            else:
+                dx0 = b["dx"]
+        return dx0
 
-    def train_step(self, x, y, init_state=None, masks=None):
-        loss, _, _, state = self.forward_backward(x, y, init_state, masks)
+    def forward_backward(self, x, y, init_state=None, masks=None, noise=None):
+        """x (B,T,F), y (B,T_y,3*fps), init_state (L,2,B,H) (c,h) or None.  Fills self.grad; returns
+        (loss (1,), mu (B,3), var (B,3), final state (L,2,B,H)).
+
+        noise None: the predict_len == 1 / is_test graph (lstm.py:430-434), one loss over all of y.
+        noise (T_y-1, B, 3*fps) standard normal: the predict_len > 1 training graph (:446-468) - second k+1 is scored
+        after re-running the whole stack, from the same fed state, on the window shifted by one second whose last slot
+        is a second SAMPLED around the previous prediction (mean mu, stddev sqrt(var)); losses add up and the gradient
+        flows back through the samples (reparameterisation, as TF differentiates tf.random_normal(mean, stddev)).
+        `masks` is then a list of T_y per-window mask lists (DropoutWrapper draws a new mask per dynamic_rnn call)."""
+        sc = self.scratch
+        scale = 1.0 / (self.running_length * self.fps)
+        if noise is None:
+            tape, states = self._stack_forward(x, init_state, masks)
+            hT = states[-1][1].contiguous()
+            head = self._head(hT)
+            loss, dmu, dvar = ops.gauss_nll_grad(head[1], head[3], y, self.fps, scale, scratch=sc)
+            dhT = self._head_backward(hT, head, dmu, dvar, accumulate=False)
+            self._stack_backward(tape, dhT, masks, accumulate=False)
+            return loss, head[1], head[3], torch.stack(states, 0)
+        B, T, F = x.shape
+        P = y.shape[1]
+        assert F == 3 * self.fps and tuple(noise.shape) == (P - 1, B, F)
+        self.grad.zero_()
+        win, runs, total = x, [], None
+        for k in range(P):
+            if k > 0:       # shift the window by one second, the new last second is a sample around prediction k-1
+                nxt = torch.empty_like(win)
+                nxt[:, :T - 1].copy_(win[:, 1:])
+                ops.sample_refeed(runs[-1]["head"][1], runs[-1]["head"][3], noise[k - 1], out=nxt[:, T - 1], std="sqrt")
+                win = nxt
+            mk = None if masks is None else masks[k]
+            tape, states = self._stack_forward(win, init_state, mk)
+            hT = states[-1][1].contiguous()
+            head = self._head(hT)
+            loss, dmu, dvar = ops.gauss_nll_grad(head[1], head[3], y[:, k:k + 1].contiguous(), self.fps, scale, scratch=sc)
+            total = loss if total is None else ops.act_bwd(loss, loss, base=total, activation=None)
+            runs.append({"tape": tape, "hT": hT, "head": head, "dmu": dmu, "dvar": dvar, "masks": mk})
+        for k in range(P - 1, -1, -1):
+            r = runs[k]     # dmu / dvar of prediction k are complete: loss k plus every later window holding sample k+1
+            dhT = self._head_backward(r["hT"], r["head"], r["dmu"], r["dvar"], accumulate=True)
+            dX = self._stack_backward(r["tape"], dhT, r["masks"], accumulate=True, need_dx0=(k > 0))
+            for j in range(max(1, k - T + 1), k + 1):      # sample j (drawn from prediction j-1) sits in slot T-1-(k-j)
+                src = runs[j - 1]
+                ops.sample_refeed_bwd(dX[:, T - 1 - (k - j)], src["head"][3], noise[j - 1], src["dmu"], src["dvar"], std="sqrt")
+        last = runs[-1]
+        return total, last["head"][1], last["head"][3], torch.stack(states, 0)
+
+    def train_step(self, x, y, init_state=None, masks=None, noise=None):
+        loss, _, _, state = self.forward_backward(x, y, init_state, masks, noise)
         ops.rmsprop_tf_step(self.flat, self.grad, self.ms, self.lr, self.decay, self.eps, self.clip)
         return loss, state

@@ -411,6 +411,30 @@ def tf_dynamic_rnn(x, cells, init_state=None, forget_bias=1.0):
     return out, st
 
 
+def tf_mean_var_head(h, head):
+    """_pred_mean_var_xyz2_new (lstm.py:321-337): relu -> tanh for the means, relu -> linear -> exp for the variances."""
+    mu = np.tanh(np.maximum(h @ head["mu_W1"] + head["mu_b1"], 0) @ head["mu_W2"] + head["mu_b2"])
+    var = np.exp(np.maximum(h @ head["var_W1"] + head["var_b1"], 0) @ head["var_W2"] + head["var_b2"])
+    return mu, var
+
+
+def tf_lstm_sampled_rollout(x, cells, head, init_state, noise, forget_bias=1.0):
+    """Test-time loop of lstm.py:714-740 (cfg.use_xyz, cfg.predict_mean_var): every step runs the stack over the current
+    window from the state the PREVIOUS run returned, predicts (mu, var), draws one second around it
+    (utility.generate_fake_batch_numpy, utility.py:73-80: normal(mu, sqrt(var)), here mu + sqrt(var) * noise[k], frames
+    interleaved x,y,z by np.stack axis=-1) and shifts it into the window.  -> (mus (P,B,3), vars (P,B,3), state)."""
+    win, st = x.copy(), init_state
+    B, fps = x.shape[0], x.shape[2] // 3
+    mus, vs = [], []
+    for k in range(noise.shape[0]):
+        _, st = tf_dynamic_rnn(win, cells, st, forget_bias)
+        mu, var = tf_mean_var_head(st[-1, 1], head)
+        mus.append(mu); vs.append(var)
+        smp = (mu[:, None, :] + np.sqrt(var)[:, None, :] * noise[k].reshape(B, fps, 3)).reshape(B, 1, 3 * fps)
+        win = np.concatenate([win[:, 1:], smp], axis=1)
+    return np.stack(mus), np.stack(vs), st
+
+
 # --------------------------------------------------------------------------------------
 # a8/a9: ConvLSTM2D seq2seq (mycode/convlstm_seq2seq.py:100-282).  Keras-2.2 ConvLSTM2DCell restated:
 #   x_g = conv2d(x, K_g, 'same') + b_g ;  h_g = conv2d(h, R_g, 'same')        (cross-correlation, NHWC)

@@ -566,3 +566,160 @@ def test_no_teacher_forcing_one_layer_gradients_and_training(H, B, T_in, T_out, 
     assert losses[-1] < losses[0]
     h = m.fit(enc if enc_as_in else [enc, dec0], tgt, batch_size=16, epochs=2, validation_split=0.2)
     assert len(h.history["loss"]) == 2 and "val_loss" in h.history
+
+
+def _torch_tf_lstm_refeed_graph(x, y, cells, head, init, fps, running_length, noise, forget_bias=1.0, masks=None):
+    """fp64 restatement of the predict_len > 1 training graph of lstm.py:446-468: the window is shifted by one second,
+    its last slot is tf.random_normal(mean=mu, stddev=sqrt(var)) = mu + sqrt(var) * noise (utility.py:83-89, frames
+    interleaved x,y,z by tf.stack axis=-1), the whole stack re-runs from the same fed state and the losses add up."""
+    t = lambda a: torch.tensor(np.asarray(a, np.float64), requires_grad=True)
+    cw = [(t(W), t(b)) for W, b in cells]
+    hw = {k: t(v) for k, v in head.items()}
+    st = torch.tensor(init.astype(np.float64))
+
+    def run(inp, mk):
+        for l, (W, b) in enumerate(cw):
+            c, h = st[l, 0], st[l, 1]
+            H = h.shape[1]
+            outs = []
+            for tt in range(inp.shape[1]):
+                z = torch.cat([inp[:, tt], h], 1) @ W + b
+                i, j, f, o = z[:, :H], z[:, H:2 * H], z[:, 2 * H:3 * H], z[:, 3 * H:]
+                c = torch.sigmoid(f + forget_bias) * c + torch.sigmoid(i) * torch.tanh(j)
+                h = torch.sigmoid(o) * torch.tanh(c)
+                outs.append(h)
+            hs = torch.stack(outs, 1)
+            inp = hs if (mk is None or l == len(cw) - 1) else hs * torch.tensor(mk[l].astype(np.float64))
+        mu = torch.tanh(torch.relu(h @ hw["mu_W1"] + hw["mu_b1"]) @ hw["mu_W2"] + hw["mu_b2"])
+        var = torch.exp(torch.relu(h @ hw["var_W1"] + hw["var_b1"]) @ hw["var_W2"] + hw["var_b2"])
+        return mu, var
+
+    def nll(mu, var, yk):
+        yy = yk.reshape(yk.shape[0], 1, fps, 3)
+        l = torch.log(var + 1e-20)[:, None, None, :] + (yy - mu[:, None, None, :]) ** 2 / (var + 1e-20)[:, None, None, :]
+        return torch.clamp(l, -10, 10).sum((1, 2, 3)).mean() / running_length / fps
+
+    win = torch.tensor(x.astype(np.float64))
+    yt = torch.tensor(y.astype(np.float64))
+    nz = torch.tensor(noise.astype(np.float64))
+    B = win.shape[0]
+    loss = 0.0
+    for k in range(y.shape[1]):
+        if k > 0:
+            smp = (mu[:, None, :] + torch.sqrt(var)[:, None, :] * nz[k - 1].reshape(B, fps, 3)).reshape(B, 1, 3 * fps)
+            win = torch.cat([win[:, 1:], smp], 1)
+        mu, var = run(win, None if masks is None else masks[k])
+        loss = loss + nll(mu, var, yt[:, k])
+    loss.backward()
+    return float(loss.detach()), [(W.grad.numpy(), b.grad.numpy()) for W, b in cw], {k: v.grad.numpy() for k, v in hw.items()}, \
+        mu.detach().numpy(), var.detach().numpy()
+
+
+@pytest.mark.parametrize("H,B,T,P,with_masks", [(40, 9, 3, 5, False), (400, 12, 4, 3, True)])
+def test_tf_stacked_lstm_sampled_refeed_training_graph(H, B, T, P, with_masks):
+    """a10, the predict_len > 1 form mycode/config.py:21 ships: sampled re-feed through fov_sample_refeed_fwd / _bwd with the
+    noise given explicitly, P windows (P > T: early samples shift out of the window), against torch.autograd fp64."""
+    from longterm360fov_amd.training import TFLSTMTrainer
+    rng = np.random.default_rng(7 * H + B)
+    F, fps = 90, 30
+    cells = []
+    for l in range(2):
+        Fin = F if l == 0 else H
+        cells.append(((rng.standard_normal((Fin + H, 4 * H)) / np.sqrt(Fin + H)).astype(np.float32),
+                      (0.1 * rng.standard_normal(4 * H)).astype(np.float32)))
+    head = {}
+    for br in ("mu", "var"):
+        head[br + "_W1"] = (rng.standard_normal((H, 32)) / np.sqrt(H)).astype(np.float32)
+        head[br + "_b1"] = (0.1 * rng.standard_normal(32)).astype(np.float32)
+        head[br + "_W2"] = (rng.standard_normal((32, 3)) / np.sqrt(32)).astype(np.float32)
+        head[br + "_b2"] = (0.1 * rng.standard_normal(3)).astype(np.float32)
+    x = rng.uniform(-1, 1, (B, T, F)).astype(np.float32)
+    y = rng.uniform(-1, 1, (B, P, 3 * fps)).astype(np.float32)
+    init = (0.2 * rng.standard_normal((2, 2, B, H))).astype(np.float32)
+    noise = rng.standard_normal((P - 1, B, F)).astype(np.float32)
+    masks = None
+    if with_masks:   # a fresh DropoutWrapper mask per dynamic_rnn call
+        masks = [[((rng.random((B, T, H)) < 0.9) / 0.9).astype(np.float32), None] for _ in range(P)]
+    loss_ref, cg, hg, mu_ref, var_ref = _torch_tf_lstm_refeed_graph(x, y, cells, head, init, fps, 10, noise, masks=masks)
+    tr = TFLSTMTrainer(cells, head, lr=1e-3, clip_value=1.0, fps=fps, running_length=10)
+    dm = None if masks is None else [[dev(m[0]), None] for m in masks]
+    loss, mu, var, state = tr.forward_backward(dev(x), dev(y), dev(init), masks=dm, noise=dev(noise))
+    assert state.shape == (2, 2, B, H)
+    assert np.abs(mu.cpu().numpy() - mu_ref).max() < 2e-5 and np.abs(var.cpu().numpy() - var_ref).max() < 1e-4 * np.abs(var_ref).max()
+    assert abs(float(loss.item()) - loss_ref) <= 1e-5 * abs(loss_ref) + 1e-7
+    for k in TFLSTMTrainer.HEAD:
+        a = tr.g[k].cpu().numpy()
+        print("refeed head grad %-7s max|ref| %.3e err %.3e" % (k, np.abs(hg[k]).max(), np.abs(a - hg[k]).max()))
+        assert np.abs(a - hg[k]).max() <= 2e-4 * np.abs(hg[k]).max() + 1e-9, k
+    for l in range(2):
+        K, R, b = (tr.g["%s%d" % (n, l)].cpu().numpy() for n in ("K", "R", "b"))
+        perm = np.concatenate([np.arange(0, H), np.arange(2 * H, 3 * H), np.arange(H, 2 * H), np.arange(3 * H, 4 * H)])
+        Wg = np.empty_like(cg[l][0]); Wg[:, perm] = np.concatenate([K, R], 0)
+        bg = np.empty_like(cg[l][1]); bg[perm] = b
+        assert np.abs(Wg - cg[l][0]).max() <= 2e-4 * np.abs(cg[l][0]).max() + 1e-9, ("W", l)
+        assert np.abs(bg - cg[l][1]).max() <= 2e-4 * np.abs(cg[l][1]).max() + 1e-9, ("b", l)
+    losses = [float(tr.train_step(dev(x), dev(y), dev(init), masks=dm, noise=dev(noise))[0].item()) for _ in range(6)]
+    assert losses[-1] < losses[0]
+
+
+@pytest.mark.parametrize("std,planar", [("sqrt", False), ("var", True)])
+def test_sample_refeed_kernels(std, planar):
+    """fov_sample_refeed_fwd / _bwd: both stddev conventions (lstm.py sqrt(var); lstm_keras.py:39-44 var) and both layouts,
+    writing into / reading from a slot of a (B,T,90) window; backward against torch.autograd."""
+    from longterm360fov_amd import ops
+    rng = np.random.default_rng(3)
+    B, fps, T = 37, 30, 4
+    mu = torch.tensor(rng.uniform(-1, 1, (B, 3)), requires_grad=True)
+    var = torch.tensor(rng.uniform(0.05, 1.0, (B, 3)), requires_grad=True)
+    nz = torch.tensor(rng.standard_normal((B, 3 * fps)))
+    sd = torch.sqrt(var) if std == "sqrt" else var
+    if planar:
+        xr = (mu[:, :, None] + sd[:, :, None] * nz.reshape(B, 3, fps)).reshape(B, 3 * fps)
+    else:
+        xr = (mu[:, None, :] + sd[:, None, :] * nz.reshape(B, fps, 3)).reshape(B, 3 * fps)
+    dxr = torch.tensor(rng.standard_normal((B, 3 * fps)))
+    (xr * dxr).sum().backward()
+    win = torch.zeros((B, T, 3 * fps), dtype=torch.float32, device="cuda")
+    mu_d, var_d, nz_d = dev(mu.detach().numpy()), dev(var.detach().numpy()), dev(nz.numpy())
+    ops.sample_refeed(mu_d, var_d, nz_d, out=win[:, 2], std=std, planar=planar)
+    np.testing.assert_allclose(win[:, 2].cpu().numpy(), xr.detach().numpy(), atol=1e-6)
+    assert float(win[:, [0, 1, 3]].abs().max()) == 0.0
+    dwin = torch.zeros((B, T, 3 * fps), dtype=torch.float32, device="cuda")
+    dwin[:, 1] = dev(dxr.numpy())
+    dmu = torch.full((B, 3), 0.5, dtype=torch.float32, device="cuda")
+    dvar = torch.full((B, 3), -0.25, dtype=torch.float32, device="cuda")
+    ops.sample_refeed_bwd(dwin[:, 1], var_d, nz_d, dmu, dvar, std=std, planar=planar, accumulate=True)
+    np.testing.assert_allclose(dmu.cpu().numpy() - 0.5, mu.grad.numpy(), atol=2e-5)
+    np.testing.assert_allclose(dvar.cpu().numpy() + 0.25, var.grad.numpy(), rtol=1e-4, atol=5e-5)
+    ops.sample_refeed_bwd(dwin[:, 1], var_d, nz_d, dmu, dvar, std=std, planar=planar, accumulate=False)
+    np.testing.assert_allclose(dmu.cpu().numpy(), mu.grad.numpy(), atol=2e-5)
+
+
+def test_tf_stacked_lstm_sampled_rollout():
+    """lstm.py:714-740 test-time loop (state carried from run to run, one sampled second shifted in per step) against the
+    NumPy oracle with the same noise."""
+    from longterm360fov_amd.training import TFLSTMTrainer
+    rng = np.random.default_rng(11)
+    H, B, T, P, F, fps = 48, 10, 4, 6, 90, 30
+    cells = []
+    for l in range(2):
+        Fin = F if l == 0 else H
+        cells.append(((rng.standard_normal((Fin + H, 4 * H)) / np.sqrt(Fin + H)).astype(np.float32),
+                      (0.1 * rng.standard_normal(4 * H)).astype(np.float32)))
+    head = {}
+    for br in ("mu", "var"):
+        head[br + "_W1"] = (rng.standard_normal((H, 32)) / np.sqrt(H)).astype(np.float32)
+        head[br + "_b1"] = (0.1 * rng.standard_normal(32)).astype(np.float32)
+        head[br + "_W2"] = (rng.standard_normal((32, 3)) / np.sqrt(32)).astype(np.float32)
+        head[br + "_b2"] = (0.1 * rng.standard_normal(3)).astype(np.float32)
+    x = rng.uniform(-1, 1, (B, T, F)).astype(np.float32)
+    init = (0.2 * rng.standard_normal((2, 2, B, H))).astype(np.float32)
+    noise = rng.standard_normal((P, B, F)).astype(np.float32)
+    c64 = [(W.astype(np.float64), b.astype(np.float64)) for W, b in cells]
+    mu_ref, var_ref, st_ref = O.tf_lstm_sampled_rollout(x.astype(np.float64), c64, {k: v.astype(np.float64) for k, v in head.items()},
+                                                         init.astype(np.float64), noise.astype(np.float64))
+    tr = TFLSTMTrainer(cells, head, fps=fps, running_length=10)
+    mus, vs, st = tr.rollout(dev(x), dev(init), dev(noise))
+    np.testing.assert_allclose(mus.cpu().numpy(), mu_ref, atol=2e-5)
+    np.testing.assert_allclose(vs.cpu().numpy(), var_ref, rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(st.cpu().numpy(), st_ref, atol=2e-5)
