@@ -424,6 +424,146 @@ class NoTeacherForcingSeq2Seq(Seq2SeqLSTM):
         return float(loss.item())
 
 
+class KerasSingleLSTM:
+    """Single-layer model of mycode/lstm_keras.py: ONE LSTM from zero state + Dense(6, tanh) per step, Adam + MSE.
+      unrolled=False  1st part (:59-83): x (N,T,F) -> (N,T,6), one input second per step;
+      unrolled=True   sampling model / 2nd part (:120-157,214-241): x (N,1,F) -> (N,predict_step,6); under
+                      cfg.predict_mean_var and cfg.sample_and_refeed (`sample_and_refeed`) the next input is a sampled
+                      second (mean mu, stddev = the predicted variance, planar x|y|z layout, :39-44,139-149), otherwise
+                      the same input second is shown to every step.
+    Weights in Keras order [kernel, recurrent_kernel, bias, dense kernel, dense bias]."""
+
+    _ORDER = ("K", "R", "b", "dense_W", "dense_b")
+
+    def __init__(self, num_encoder_tokens=None, num_decoder_tokens=6, latent_dim=64, recurrent_activation=None, seed=None,
+                 impl="auto", device="cuda", unrolled=False, sample_and_refeed=None, predict_step=None):
+        self.F = 3 * cfg.fps if num_encoder_tokens is None else int(num_encoder_tokens)
+        self.O, self.H = int(num_decoder_tokens), int(latent_dim)
+        self.recurrent_activation = recurrent_activation or cfg.recurrent_activation
+        self.impl, self.device, self.unrolled = impl, device, bool(unrolled)
+        if sample_and_refeed is None:
+            sample_and_refeed = bool(cfg.predict_mean_var and cfg.sample_and_refeed)
+        self.sample_and_refeed = bool(unrolled and sample_and_refeed)
+        if self.sample_and_refeed and (self.O != 6 or self.F % 3):
+            raise ValueError("the sampled re-feed needs num_decoder_tokens == 6 and a 3*fps-wide input")
+        self.predict_step = cfg.predict_step if predict_step is None else int(predict_step)
+        rng = np.random.default_rng(seed)
+        w = {}
+        w["K"], w["R"], w["b"] = init_lstm_weights(rng, self.F, self.H)
+        w["dense_W"] = glorot_uniform(rng, self.H, self.O)
+        w["dense_b"] = np.zeros(self.O, np.float32)
+        self._w, self._dw, self._ws, self._trainer = w, None, None, None
+        self.optimizer, self._lr, self.stop_training = None, 1e-3, False
+
+    def get_weights(self):
+        return [self._w[k].copy() for k in self._ORDER]
+
+    def set_weights(self, weights):
+        weights = list(weights)
+        if len(weights) != len(self._ORDER):
+            raise ValueError("expected %d arrays, got %d" % (len(self._ORDER), len(weights)))
+        for k, a in zip(self._ORDER, weights):
+            a = _as_f32(a)
+            if a.shape != self._w[k].shape:
+                raise ValueError("%s: expected shape %s, got %s" % (k, self._w[k].shape, a.shape))
+            self._w[k] = a
+        self._dw = self._trainer = None
+
+    def save_weights(self, path):
+        np.savez(path, **self._w)
+
+    save = save_weights
+
+    def load_weights(self, path):
+        with np.load(path) as z:
+            self.set_weights([z[k] for k in self._ORDER])
+
+    def count_params(self):
+        return int(sum(v.size for v in self._w.values()))
+
+    def predict(self, x, batch_size=None, verbose=0, noise=None):
+        """`noise` (predict_step-1, N, F) standard normal for the sampled re-feed (drawn with torch.randn if None)."""
+        import torch
+        from . import ops
+        x = _as_f32(x)
+        if self._dw is None:
+            self._dw = {k: torch.from_numpy(v).to(self.device) for k, v in self._w.items()}
+            self._ws = ops.Workspace()
+        dw, act = self._dw, self.recurrent_activation
+        n = x.shape[0]
+        bs = n if not batch_size else int(batch_size)
+        P = self.predict_step
+        outs = []
+        for lo in range(0, n, max(bs, 1)):
+            xd = torch.from_numpy(x[lo:lo + bs]).to(self.device)
+            B = xd.shape[0]
+            if self.unrolled and not self.sample_and_refeed:
+                xd = xd.expand(B, P, self.F).contiguous()          # the same second is shown to every step (:131-153)
+            if not self.sample_and_refeed:
+                hs, _, _ = ops.lstm_seq(xd, dw["K"], dw["R"], dw["b"], act=act, impl=self.impl, workspace=self._ws)
+                outs.append(ops.dense(hs, dw["dense_W"], dw["dense_b"], activation="tanh").cpu().numpy())
+                continue
+            nz = torch.randn((P - 1, B, self.F), dtype=torch.float32, device=self.device) if noise is None \
+                else torch.from_numpy(_as_f32(noise[:, lo:lo + bs])).to(self.device)
+            y = torch.empty((B, P, self.O), dtype=torch.float32, device=self.device)
+            xin, h, c = xd.reshape(B, 1, self.F), None, None
+            for t in range(P):
+                _, h, c = ops.lstm_seq(xin, dw["K"], dw["R"], dw["b"], h, c, act=act, impl=self.impl, return_sequences=False,
+                                       workspace=self._ws)
+                yt = ops.dense(h, dw["dense_W"], dw["dense_b"], activation="tanh")
+                y[:, t] = yt
+                if t < P - 1:
+                    xin = ops.sample_refeed(yt[:, :3].contiguous(), yt[:, 3:].contiguous(), nz[t], std="var", planar=True).view(B, 1, self.F)
+            outs.append(y.cpu().numpy())
+        self._ws.check()
+        T = P if self.unrolled else x.shape[1]
+        return np.concatenate(outs, axis=0) if outs else np.zeros((0, T, self.O), np.float32)
+
+    predict_on_batch = predict
+
+    def compile(self, optimizer="Adam", loss="mean_squared_error", metrics=None):
+        opt = optimizer if isinstance(optimizer, str) else getattr(optimizer, "name", str(optimizer))
+        if opt.lower() not in ("adam", "rmsprop") or str(loss).lower() not in ("mean_squared_error", "mse"):
+            raise ValueError("unsupported optimizer / loss %r / %r" % (optimizer, loss))
+        self.optimizer, self.loss, self.metrics = opt.lower(), "mse", list(metrics or [])
+
+    @property
+    def lr(self):
+        return self._lr
+
+    @lr.setter
+    def lr(self, value):
+        self._lr = float(value)
+        if self._trainer is not None:
+            self._trainer.lr = self._lr
+
+    def _get_trainer(self):
+        from .training import SingleLSTMTrainer
+        if self._trainer is None:
+            self._trainer = SingleLSTMTrainer(self._w, act=self.recurrent_activation, impl=self.impl, optimizer=self.optimizer or "adam",
+                                              lr=self._lr, device=self.device, unrolled=self.unrolled,
+                                              sample_and_refeed=self.sample_and_refeed)
+        return self._trainer
+
+    def fit(self, x, y, batch_size=32, epochs=1, validation_split=0.0, shuffle=True, callbacks=None, initial_epoch=0, verbose=0,
+            validation_data=None):
+        """Keras `Model.fit` as lstm_keras.py:101-107,262-268 calls it (single input array)."""
+        if self.optimizer is None:
+            raise RuntimeError("call compile() before fit()")
+        if validation_data is not None:
+            validation_data = ([validation_data[0]], validation_data[1])
+        return _keras_fit(self, self._get_trainer(), [x], y, batch_size, epochs, validation_split, shuffle, callbacks, initial_epoch,
+                          validation_data)
+
+    def train_on_batch(self, x, y, noise=None):
+        import torch
+        d = lambda a: torch.from_numpy(_as_f32(a)).to(self.device)
+        tr = self._get_trainer()
+        loss = tr.train_step(d(x), d(y), noise=None if noise is None else d(noise))
+        self._w, self._dw = tr.weights_numpy(), None
+        return float(loss.item())
+
+
 _MIX_ORDER = ("enc1_K", "enc1_R", "enc1_b", "enc2_K", "enc2_R", "enc2_b", "dec1_K", "dec1_R", "dec1_b",
               "dec2_K", "dec2_R", "dec2_b", "dense_W", "dense_b", "mix_W", "mix_b")
 

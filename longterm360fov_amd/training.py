@@ -210,6 +210,109 @@ class SelfFedSeq2SeqTrainer(Seq2SeqTrainer):
         return loss
 
 
+_SINGLE_ORDER = ("K", "R", "b", "dense_W", "dense_b")
+
+
+class SingleLSTMTrainer(Seq2SeqTrainer):
+    """Training step of the single-layer Keras model of mycode/lstm_keras.py: ONE LSTM from zero state + Dense(6, tanh)
+    per step, Adam + MSE (:59-83,214-241).  Two unrollings:
+      per-step   (1st part, :70-80): the T input seconds are consumed one per step - LSTM(return_sequences) + Dense;
+      unrolled   (2nd part, :218-240): ONE input second, `predict_step` steps.  Without re-feed the same input is shown
+                 to every step; under cfg.predict_mean_var and cfg.sample_and_refeed the next input is a second SAMPLED
+                 around the prediction: K.random_normal(mean = mu, stddev = var) per axis (the variance is handed to
+                 `stddev`, :39-44), the three axes concatenated planar [x*fps | y*fps | z*fps] (:147-149); the gradient
+                 flows through the sample (reparameterisation).  `noise` (T_out-1, B, 3*fps) is given by the caller."""
+
+    def __init__(self, weights, act="sigmoid", impl="auto", optimizer="adam", lr=1e-3, device="cuda", unrolled=False,
+                 sample_and_refeed=False):
+        super().__init__(weights, act=act, impl=impl, optimizer=optimizer, lr=lr, device=device, order=_SINGLE_ORDER)
+        self.unrolled, self.refeed = bool(unrolled), bool(unrolled and sample_and_refeed)
+
+    def _sequence(self, x_seq, target):
+        w, g = self.w, self.g
+        hs, _, _, res = ops.lstm_seq_train(x_seq, w["K"], w["R"], w["b"], act=self.act, impl=self.impl, workspace=self.ws)
+        y = ops.dense(hs, w["dense_W"], w["dense_b"], activation="tanh")
+        dpre, loss = ops.mse_dense_grad(y, target, "tanh", scratch=self.scratch)
+        d_hs, _, _ = ops.dense_bwd(hs, w["dense_W"], dpre, dW=g["dense_W"], db=g["dense_b"], scratch=self.scratch)
+        ops.lstm_seq_bwd(x_seq, w["K"], w["R"], hs, res, dhs=d_hs, dK=g["K"], dR=g["R"], db=g["b"], act=self.act,
+                         scratch=self.bwd_scratch)
+        return loss, y
+
+    def forward_backward(self, x, target, noise=None, grad_weight=1.0):
+        """per-step: x (B,T,F), target (B,T,O).  unrolled: x (B,1,F), target (B,T_out,O); with the sampled re-feed
+        (F = 3*fps, O = 6) `noise` (T_out-1, B, F) standard normal, drawn here when not given.  -> (loss (1,), prediction)."""
+        w, g, act, impl, ws, sc, bsc = self.w, self.g, self.act, self.impl, self.ws, self.scratch, self.bwd_scratch
+        B, T_out, O = target.shape
+        if not self.unrolled:
+            loss, y = self._sequence(x, target)
+        elif not self.refeed:
+            loss, y = self._sequence(x.expand(B, T_out, x.shape[2]).contiguous(), target)
+        else:
+            if noise is None:
+                noise = torch.randn((T_out - 1, B, x.shape[2]), dtype=torch.float32, device=self.device)
+            F, H = x.shape[2], w["R"].shape[0]
+            assert O == 6 and F % 3 == 0 and tuple(noise.shape) == (T_out - 1, B, F)
+            e = lambda *s_: torch.empty(s_, dtype=torch.float32, device=self.device)
+            self.grad.zero_()
+            XS, Hs, Cs, Y, RES = e(T_out, B, F), e(T_out + 1, B, H), e(T_out + 1, B, H), e(T_out, B, O), e(T_out, B, 1, 5, H)
+            XS[0].copy_(x.reshape(B, F))
+            Hs[0].zero_(); Cs[0].zero_()
+            stats = []
+            for t in range(T_out):
+                ops.lstm_seq_train(XS[t].view(B, 1, F), w["K"], w["R"], w["b"], Hs[t], Cs[t], act=act, impl=impl, workspace=ws,
+                                   out=(Hs[t + 1].view(B, 1, H), None, Cs[t + 1], RES[t]))
+                ops.dense(Hs[t + 1], w["dense_W"], w["dense_b"], activation="tanh", out=Y[t])
+                if t < T_out - 1:
+                    stats.append((Y[t, :, :3].contiguous(), Y[t, :, 3:].contiguous()))
+                    ops.sample_refeed(stats[t][0], stats[t][1], noise[t], out=XS[t + 1], std="var", planar=True)
+            y = Y.transpose(0, 1).contiguous()
+            dloss, loss = ops.mse_dense_grad(y, target, None, scratch=sc)
+            dloss_tm = dloss.transpose(0, 1).contiguous()
+            DY, DPRE, DZ = e(T_out, B, O), e(T_out, B, O), e(T_out, B, 4 * H)
+            dh_rec = dc = dstat = None
+            for t in range(T_out - 1, -1, -1):
+                if dstat is None:
+                    DY[t].copy_(dloss_tm[t])
+                else:
+                    ops.act_bwd(dstat, dstat, base=dloss_tm[t], activation=None, out=DY[t])
+                ops.act_bwd(DY[t], Y[t], activation="tanh", out=DPRE[t])
+                dh_dense, _, _ = ops.dense_bwd(Hs[t + 1], w["dense_W"], DPRE[t], need_dx=True, need_dW=False, need_db=False, scratch=sc)
+                b = ops.lstm_seq_bwd(XS[t].view(B, 1, F), w["K"], w["R"], Hs[t + 1].view(B, 1, H), RES[t], h0=Hs[t], c0=Cs[t],
+                                     dhs=dh_dense.reshape(B, 1, H), dhT=dh_rec, dcT=dc, need_dx=(t > 0), need_state_grads=True,
+                                     act=act, dz=DZ[t].view(B, 1, 4 * H), scratch=bsc, need_weight_grads=False)
+                dh_rec, dc = b["dh0"], b["dc0"]
+                if t > 0:
+                    dmu, dvar = e(B, 3), e(B, 3)
+                    ops.sample_refeed_bwd(b["dx"].view(B, F), stats[t - 1][1], noise[t - 1], dmu, dvar, std="var", planar=True,
+                                          accumulate=False)
+                    dstat = torch.cat([dmu, dvar], 1)
+            TB = T_out * B
+            ops.dense_bwd(Hs[1:].reshape(TB, H), w["dense_W"], DPRE.reshape(TB, O), dW=g["dense_W"], db=g["dense_b"], need_dx=False,
+                          accumulate=True, scratch=sc)
+            ops.dense_bwd(XS.reshape(TB, F), w["K"], DZ.reshape(TB, 4 * H), dW=g["K"], db=g["b"], need_dx=False, accumulate=True, scratch=sc)
+            ops.dense_bwd(Hs[:T_out].reshape(TB, H), w["R"], DZ.reshape(TB, 4 * H), dW=g["R"], need_db=False, need_dx=False,
+                          accumulate=True, scratch=sc)
+        if grad_weight != 1.0:
+            self.grad.mul_(grad_weight)
+        return loss, y
+
+    def eval_loss(self, x, target):
+        loss, _ = self.forward_backward(x, target)      # gradients are overwritten by the next step
+        return loss
+
+    def train_step(self, x, target, noise=None, n_global=None):
+        _, world = parallel.world()
+        n_local = x.shape[0]
+        weight = 1.0 if world == 1 else n_local / float(n_global if n_global else n_local * world)
+        loss, _ = self.forward_backward(x, target, noise=noise, grad_weight=weight)
+        if world > 1:
+            torch.distributed.all_reduce(self.grad, op=torch.distributed.ReduceOp.SUM)
+            loss = loss * weight
+            torch.distributed.all_reduce(loss, op=torch.distributed.ReduceOp.SUM)
+        self.apply_gradients()
+        return loss
+
+
 _MIX_ORDER = ("enc1_K", "enc1_R", "enc1_b", "enc2_K", "enc2_R", "enc2_b", "dec1_K", "dec1_R", "dec1_b",
               "dec2_K", "dec2_R", "dec2_b", "dense_W", "dense_b", "mix_W", "mix_b")
 

@@ -150,6 +150,30 @@ def onelayer_tar_seq2seq_forward(enc_in, dec_in0, w, T_out, act="sigmoid", decod
     return np.stack(out, axis=1)
 
 
+def single_lstm_keras_forward(x, w, T_out=None, unrolled=False, noise=None, act="sigmoid"):
+    """mycode/lstm_keras.py, weights K, R, b, dense_W, dense_b.  unrolled False: 1st part (:70-80), one input second per
+    step from zero state, Dense(6,tanh) on every h.  unrolled True: the sampling model / 2nd part (:131-153,218-240) on
+    ONE input second (B,1,F); noise None: `this_inputs` is never replaced, the same second feeds every step; noise
+    (T_out-1,B,3*fps): cfg.predict_mean_var and cfg.sample_and_refeed - the next input is
+    [N(mu_x, var_x) * fps | N(mu_y, var_y) * fps | N(mu_z, var_z) * fps] with the predicted VARIANCE used as stddev
+    (:39-44) = mu + var * noise in that planar layout (:147-149)."""
+    if not unrolled:
+        hs, _, _ = lstm_layer(x, w["K"], w["R"], w["b"], act=act)
+        return dense(hs, w["dense_W"], w["dense_b"])
+    B, F = x.shape[0], x.shape[2]
+    fps = F // 3
+    H = w["R"].shape[0]
+    h, c = np.zeros((B, H), x.dtype), np.zeros((B, H), x.dtype)
+    xin, out = x[:, 0], []
+    for t in range(T_out):
+        h, c = lstm_step(xin, h, c, w["K"], w["R"], w["b"], act)
+        y = dense(h, w["dense_W"], w["dense_b"])
+        out.append(y)
+        if noise is not None and t < T_out - 1:
+            xin = (y[:, :3, None] + y[:, 3:6, None] * noise[t].reshape(B, 3, fps)).reshape(B, F)
+    return np.stack(out, axis=1)
+
+
 # --------------------------------------------------------------------------------------
 # a4: target + others mixing, 2-layer, no teacher forcing
 # (mycode/given_others_gt_mean_var_seq2seq.py:98-130, 203-299)
