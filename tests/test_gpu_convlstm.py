@@ -357,3 +357,30 @@ def test_conv2d_over_channel_concatenation(B, H, W, C1, C2, N, k):
     got = ops.conv2d_cat(dev(x1)[:, 1], dev(wide)[..., 4:4 + C2], dev(w), dev(b))
     close(got, ref, "conv over [x | h]")
     close(ops.conv2d_cat(dev(x1)[:, 1], dev(wide)[..., 4:4 + C2], dev(w), dev(b), activation="relu"), np.maximum(ref, 0), "relu")
+
+
+def test_config4_full_size_and_properties():
+    """configs[3]: 36x18 equirectangular heat maps, 30 one-hot channels, ConvLSTM 32/16/8 + Conv2D 512 -> 1024 -> 30 head,
+    B = 256, T 10 -> 10 on one GPU.  Three sequences of the full batch against the NumPy oracle, plus size-independent
+    properties: every pixel's channel softmax sums to one, and a sequence's result does not depend on its batch-mates."""
+    from longterm360fov_amd.models import ConvLSTMSeq2Seq
+    B, T, H, W, C = 256, 10, 36, 18, 30
+    w = O.init_convlstm_seq2seq(1234, C=C, latent_dim=16, k=5, head="conv2d")
+    assert w["enc0_R"].shape[2] == 32 and w["enc2_R"].shape[2] == 8 and w["head1_W"].shape[2:] == (512, 1024)
+    rng = np.random.default_rng(1234)
+    x = np.zeros((B, T, H, W, C), np.float32)          # one-hot of a 10-degree bin per frame, as cfg.use_one_hot builds it
+    idx = rng.integers(0, H * W, size=(B, T, C))
+    bi, ti, ci = np.meshgrid(np.arange(B), np.arange(T), np.arange(C), indexing="ij")
+    x[bi, ti, idx // W, idx % W, ci] = 1.0
+    m = ConvLSTMSeq2Seq(w, head="conv2d")
+    out = m.predict([x, x[:, -1:]], predict_step=T)
+    assert out.shape == (B, T, H, W, C) and np.isfinite(out).all()
+    np.testing.assert_allclose(out.sum(-1), 1.0, atol=1e-5)
+    rows = [0, 100, 255]
+    ref = O.convlstm_seq2seq_forward(x[rows].astype(np.float64), x[rows, -1:].astype(np.float64),
+                                     {k: v.astype(np.float64) for k, v in w.items()}, T, head="conv2d")
+    err = np.abs(out[rows] - ref)
+    print("config4 full size: max abs err %.3e (max |ref| %.3e)" % (err.max(), np.abs(ref).max()))
+    assert (err <= 1e-3 * np.abs(ref) + 1e-5).all() and err.max() <= 2e-5
+    small = m.predict([x[rows], x[rows, -1:]], predict_step=T)
+    np.testing.assert_allclose(small, out[rows], atol=1e-6)

@@ -452,3 +452,27 @@ def test_wide_input_layer(B, T, F, act):
     assert torch.equal(hs2, hs)                                   # deterministic, same kernel
     assert (res - res_g).abs().max().item() < 2e-6                 # reserve agrees with the generic kernel's
     assert (hs2 - hs_g).abs().max().item() < 2e-6
+
+
+def test_config3_full_size_and_properties():
+    """configs[2]: the 2+2-layer others-mixing model, H=256, 34 users, T 10->10; global batch 4096 = 8 ranks x 512.  One
+    rank's shard (512) through the model object against the fp64 oracle; the whole global batch in ONE call (groups walk
+    several tiles) must equal the eight shard calls bit for bit - which is what makes inference 'replicas only'."""
+    from longterm360fov_amd.models import OthersMixingSeq2Seq
+    B, T_in, T_out, H, U = 4096, 10, 10, 256, 34
+    w = O.init_others_mixing(1234, H=H, num_user=U, bias_noise=0.05)
+    enc, dec0, tgt, oth = O.synthetic_batch(1234, B, T_in, T_out, num_others=U - 1)
+    m = OthersMixingSeq2Seq(latent_dim=H, num_user=U, recurrent_activation="sigmoid")
+    m.set_weights([w[k] for k in ("enc1_K", "enc1_R", "enc1_b", "enc2_K", "enc2_R", "enc2_b", "dec1_K", "dec1_R", "dec1_b",
+                                  "dec2_K", "dec2_R", "dec2_b", "dense_W", "dense_b", "mix_W", "mix_b")])
+    full = m.predict([enc, oth, dec0])
+    assert full.shape == (B, T_out, 6) and np.isfinite(full).all() and np.abs(full).max() <= 1.0
+    ref = O.others_mixing_forward(enc[:512].astype(np.float64), oth[:512].astype(np.float64), dec0[:512].astype(np.float64), f64(w))
+    assert_parity(torch.from_numpy(full[:512]), ref, "config3 shard 0 (512 seq) vs fp64 oracle", tight=5e-5)
+    for r in range(8):
+        sl = slice(512 * r, 512 * (r + 1))
+        shard = m.predict([enc[sl], oth[sl], dec0[sl]])
+        assert np.array_equal(shard, full[sl]), "rank %d shard differs from the global-batch call" % r
+    perm = np.random.default_rng(0).permutation(512)
+    outp = m.predict([enc[:512][perm], oth[:512][perm], dec0[:512][perm]])
+    assert np.array_equal(outp, full[:512][perm]), "not batch-permutation equivariant"
