@@ -424,6 +424,160 @@ class NoTeacherForcingSeq2Seq(Seq2SeqLSTM):
         return float(loss.item())
 
 
+class StackedSeq2SeqLSTM:
+    """L-layer target-only seq2seq of mycode/Fov_seq2seq_2layers.py (:232-272, sampling models :360-397, host loop :399-430)
+    and 3layers.py: every layer `latent_dim` wide (the scripts pass latent_dim//2), encoder layer l seeds decoder layer l,
+    Dense(6, tanh) on the top layer.  predict = the teacher-forced training graph, decode_sequence = the autoregressive
+    loop (batched).  3layers.py wires its third DECODER layer through `decoder_lstm2` in the training graph (:270) and
+    through the never-trained `decoder_lstm3` at inference (:356); here layer 3 simply has its own weights."""
+
+    def __init__(self, num_encoder_tokens=6, num_decoder_tokens=6, latent_dim=32, num_layers=2, recurrent_activation=None,
+                 seed=None, impl="auto", device="cuda"):
+        from .training import stacked_weight_order
+        self.F, self.O, self.H, self.L = int(num_encoder_tokens), int(num_decoder_tokens), int(latent_dim), int(num_layers)
+        self.recurrent_activation = recurrent_activation or cfg.recurrent_activation
+        self.impl, self.device = impl, device
+        self._order = stacked_weight_order(self.L)
+        rng = np.random.default_rng(seed)
+        w = {}
+        for side, f0 in (("enc", self.F), ("dec", self.O)):
+            for l in range(self.L):
+                w["%s%d_K" % (side, l)], w["%s%d_R" % (side, l)], w["%s%d_b" % (side, l)] = \
+                    init_lstm_weights(rng, f0 if l == 0 else self.H, self.H)
+        w["dense_W"] = glorot_uniform(rng, self.H, self.O)
+        w["dense_b"] = np.zeros(self.O, np.float32)
+        self._w, self._dw, self._ws, self._trainer = w, None, None, None
+        self.optimizer, self._lr, self.stop_training = None, 1e-3, False
+
+    def get_weights(self):
+        return [self._w[k].copy() for k in self._order]
+
+    def set_weights(self, weights):
+        weights = list(weights)
+        if len(weights) != len(self._order):
+            raise ValueError("expected %d arrays, got %d" % (len(self._order), len(weights)))
+        for k, a in zip(self._order, weights):
+            a = _as_f32(a)
+            if a.shape != self._w[k].shape:
+                raise ValueError("%s: expected shape %s, got %s" % (k, self._w[k].shape, a.shape))
+            self._w[k] = a
+        self._dw = self._trainer = None
+
+    def save_weights(self, path):
+        np.savez(path, **self._w)
+
+    save = save_weights
+
+    def load_weights(self, path):
+        with np.load(path) as z:
+            self.set_weights([z[k] for k in self._order])
+
+    def count_params(self):
+        return int(sum(v.size for v in self._w.values()))
+
+    def _device(self):
+        import torch
+        from . import ops
+        if self._dw is None:
+            self._dw = {k: torch.from_numpy(v).to(self.device) for k, v in self._w.items()}
+            self._ws = ops.Workspace()
+        return ops, self._dw
+
+    def _encode(self, ops, dw, e):
+        states, inp = [], e
+        for l in range(self.L):
+            inp, h, c = ops.lstm_seq(inp, dw["enc%d_K" % l], dw["enc%d_R" % l], dw["enc%d_b" % l], act=self.recurrent_activation,
+                                     impl=self.impl, workspace=self._ws)
+            states.append((h, c))
+        return states
+
+    def predict(self, x, batch_size=None, verbose=0):
+        """[encoder_input (N,T_in,F), decoder_input (N,T_out,O)] -> (N,T_out,O), teacher-forced graph (:332)."""
+        import torch
+        enc, dec_in = _as_f32(x[0]), _as_f32(x[1])
+        ops, dw = self._device()
+        n = enc.shape[0]
+        bs = n if not batch_size else int(batch_size)
+        outs = []
+        for lo in range(0, n, max(bs, 1)):
+            states = self._encode(ops, dw, torch.from_numpy(enc[lo:lo + bs]).to(self.device))
+            inp = torch.from_numpy(dec_in[lo:lo + bs]).to(self.device)
+            for l in range(self.L):
+                inp, _, _ = ops.lstm_seq(inp, dw["dec%d_K" % l], dw["dec%d_R" % l], dw["dec%d_b" % l], states[l][0], states[l][1],
+                                         act=self.recurrent_activation, impl=self.impl, workspace=self._ws)
+            outs.append(ops.dense(inp, dw["dense_W"], dw["dense_b"], activation="tanh").cpu().numpy())
+        self._ws.check()
+        return np.concatenate(outs, axis=0) if outs else np.zeros((0, dec_in.shape[1], self.O), np.float32)
+
+    predict_on_batch = predict
+
+    def decode_sequence(self, input_seq, first_decoder_input, predict_step=None, batch_size=None):
+        """Autoregressive loop of :399-430, any batch: encoder states, then `predict_step` steps through all decoder
+        layers, each Dense output fed back as the next input."""
+        import torch
+        enc, d0 = _as_f32(input_seq), _as_f32(first_decoder_input)
+        T_out = cfg.predict_step if predict_step is None else int(predict_step)
+        ops, dw = self._device()
+        n = enc.shape[0]
+        bs = n if not batch_size else int(batch_size)
+        outs = []
+        for lo in range(0, n, max(bs, 1)):
+            states = self._encode(ops, dw, torch.from_numpy(enc[lo:lo + bs]).to(self.device))
+            B = states[0][0].shape[0]
+            xin = torch.from_numpy(d0[lo:lo + bs]).to(self.device).reshape(B, 1, self.O)
+            y = torch.empty((B, T_out, self.O), dtype=torch.float32, device=self.device)
+            for t in range(T_out):
+                inp = xin
+                for l in range(self.L):
+                    inp, h, c = ops.lstm_seq(inp, dw["dec%d_K" % l], dw["dec%d_R" % l], dw["dec%d_b" % l], states[l][0], states[l][1],
+                                             act=self.recurrent_activation, impl=self.impl, workspace=self._ws)
+                    states[l] = (h, c)
+                xin = ops.dense(inp, dw["dense_W"], dw["dense_b"], activation="tanh")
+                y[:, t] = xin[:, 0]
+            outs.append(y.cpu().numpy())
+        self._ws.check()
+        return np.concatenate(outs, axis=0) if outs else np.zeros((0, T_out, self.O), np.float32)
+
+    def compile(self, optimizer="Adam", loss="mean_squared_error", metrics=None):
+        opt = optimizer if isinstance(optimizer, str) else getattr(optimizer, "name", str(optimizer))
+        if opt.lower() not in ("adam", "rmsprop") or str(loss).lower() not in ("mean_squared_error", "mse"):
+            raise ValueError("unsupported optimizer / loss %r / %r" % (optimizer, loss))
+        self.optimizer, self.loss, self.metrics = opt.lower(), "mse", list(metrics or [])
+
+    @property
+    def lr(self):
+        return self._lr
+
+    @lr.setter
+    def lr(self, value):
+        self._lr = float(value)
+        if self._trainer is not None:
+            self._trainer.lr = self._lr
+
+    def _get_trainer(self):
+        from .training import StackedSeq2SeqTrainer
+        if self._trainer is None:
+            self._trainer = StackedSeq2SeqTrainer(self._w, self.L, act=self.recurrent_activation, impl=self.impl,
+                                                  optimizer=self.optimizer or "adam", lr=self._lr, device=self.device)
+        return self._trainer
+
+    def fit(self, x, y, batch_size=32, epochs=1, validation_split=0.0, shuffle=True, callbacks=None, initial_epoch=0, verbose=0,
+            validation_data=None):
+        """Keras `Model.fit` as Fov_seq2seq_2layers.py:336-343 calls it."""
+        if self.optimizer is None:
+            raise RuntimeError("call compile() before fit()")
+        return _keras_fit(self, self._get_trainer(), [x[0], x[1]], y, batch_size, epochs, validation_split, shuffle, callbacks,
+                          initial_epoch, validation_data)
+
+    def train_on_batch(self, x, y):
+        import torch
+        d = lambda a: torch.from_numpy(_as_f32(a)).to(self.device)
+        tr = self._get_trainer()
+        loss = tr.train_step(d(x[0]), d(x[1]), d(y))
+        self._w, self._dw = tr.weights_numpy(), None
+        return float(loss.item())
+
+
 class KerasSingleLSTM:
     """Single-layer model of mycode/lstm_keras.py: ONE LSTM from zero state + Dense(6, tanh) per step, Adam + MSE.
       unrolled=False  1st part (:59-83): x (N,T,F) -> (N,T,6), one input second per step;

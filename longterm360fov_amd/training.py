@@ -210,6 +210,61 @@ class SelfFedSeq2SeqTrainer(Seq2SeqTrainer):
         return loss
 
 
+def stacked_weight_order(num_layers):
+    return tuple("%s%d_%s" % (side, l, n) for side in ("enc", "dec") for l in range(num_layers) for n in ("K", "R", "b")) + \
+        ("dense_W", "dense_b")
+
+
+class StackedSeq2SeqTrainer(Seq2SeqTrainer):
+    """Teacher-forced training step of the L-layer target-only seq2seq (mycode/Fov_seq2seq_2layers.py:232-272,332-343 and
+    3layers.py:222-300): encoder layer l hands its final (h, c) to decoder layer l, every layer returns its sequence to
+    the next, Dense(6, tanh) on the top decoder layer; Adam + MSE.  Same layer kernels as the one-layer trainer, one
+    forward-with-reserve and one BPTT launch per layer."""
+
+    def __init__(self, weights, num_layers, act="sigmoid", impl="auto", optimizer="adam", lr=1e-3, device="cuda"):
+        self.L = int(num_layers)
+        super().__init__(weights, act=act, impl=impl, optimizer=optimizer, lr=lr, device=device, order=stacked_weight_order(self.L))
+
+    def forward_backward(self, enc, dec_in, target, grad_weight=1.0):
+        w, g, act, impl, ws, L = self.w, self.g, self.act, self.impl, self.ws, self.L
+        etape, dtape = [], []
+        inp = enc
+        for l in range(L):
+            hs, hT, cT, res = ops.lstm_seq_train(inp, w["enc%d_K" % l], w["enc%d_R" % l], w["enc%d_b" % l], act=act, impl=impl, workspace=ws)
+            etape.append((inp, hs, res, hT, cT))
+            inp = hs
+        inp = dec_in
+        for l in range(L):
+            hs, _, _, res = ops.lstm_seq_train(inp, w["dec%d_K" % l], w["dec%d_R" % l], w["dec%d_b" % l], etape[l][3], etape[l][4],
+                                               act=act, impl=impl, workspace=ws)
+            dtape.append((inp, hs, res))
+            inp = hs
+        y = ops.dense(inp, w["dense_W"], w["dense_b"], activation="tanh")
+        dpre, loss = ops.mse_dense_grad(y, target, "tanh", scratch=self.scratch)
+        d_cur, _, _ = ops.dense_bwd(inp, w["dense_W"], dpre, dW=g["dense_W"], db=g["dense_b"], scratch=self.scratch)
+        dstate = [None] * L
+        for l in range(L - 1, -1, -1):
+            x_l, hs, res = dtape[l]
+            bd = ops.lstm_seq_bwd(x_l, w["dec%d_K" % l], w["dec%d_R" % l], hs, res, h0=etape[l][3], c0=etape[l][4], dhs=d_cur,
+                                  dK=g["dec%d_K" % l], dR=g["dec%d_R" % l], db=g["dec%d_b" % l], need_dx=(l > 0),
+                                  need_state_grads=True, act=act, scratch=self.bwd_scratch)
+            d_cur, dstate[l] = bd["dx"], (bd["dh0"], bd["dc0"])
+        d_cur = None
+        for l in range(L - 1, -1, -1):
+            x_l, hs, res, _, _ = etape[l]
+            be = ops.lstm_seq_bwd(x_l, w["enc%d_K" % l], w["enc%d_R" % l], hs, res, dhs=d_cur, dhT=dstate[l][0], dcT=dstate[l][1],
+                                  dK=g["enc%d_K" % l], dR=g["enc%d_R" % l], db=g["enc%d_b" % l], need_dx=(l > 0), act=act,
+                                  scratch=self.bwd_scratch)
+            d_cur = be["dx"]
+        if grad_weight != 1.0:
+            self.grad.mul_(grad_weight)
+        return loss, y
+
+    def eval_loss(self, enc, dec_in, target):
+        loss, _ = self.forward_backward(enc, dec_in, target)      # gradients are overwritten by the next step
+        return loss
+
+
 _SINGLE_ORDER = ("K", "R", "b", "dense_W", "dense_b")
 
 

@@ -150,6 +150,29 @@ def onelayer_tar_seq2seq_forward(enc_in, dec_in0, w, T_out, act="sigmoid", decod
     return np.stack(out, axis=1)
 
 
+def stacked_seq2seq_forward(enc_in, dec_in, w, num_layers, act="sigmoid", T_out=None):
+    """L-layer target-only seq2seq, Fov_seq2seq_2layers.py:232-272 / 3layers.py:222-277.  weights enc{l}_K/R/b, dec{l}_K/R/b,
+    dense_W/b.  T_out None: teacher-forced graph on dec_in (B,T_out,O).  T_out given: the autoregressive loop of
+    :399-430 from dec_in (B,1,O), each Dense output fed back."""
+    states, inp = [], enc_in
+    for l in range(num_layers):
+        inp, h, c = lstm_layer(inp, w["enc%d_K" % l], w["enc%d_R" % l], w["enc%d_b" % l], act=act)
+        states.append([h, c])
+    if T_out is None:
+        inp = dec_in
+        for l in range(num_layers):
+            inp, _, _ = lstm_layer(inp, w["dec%d_K" % l], w["dec%d_R" % l], w["dec%d_b" % l], states[l][0], states[l][1], act=act)
+        return dense(inp, w["dense_W"], w["dense_b"])
+    x, out = dec_in[:, 0].astype(enc_in.dtype), []
+    for _ in range(T_out):
+        for l in range(num_layers):
+            states[l] = list(lstm_step(x, states[l][0], states[l][1], w["dec%d_K" % l], w["dec%d_R" % l], w["dec%d_b" % l], act))
+            x = states[l][0]
+        x = dense(x, w["dense_W"], w["dense_b"])
+        out.append(x)
+    return np.stack(out, axis=1)
+
+
 def single_lstm_keras_forward(x, w, T_out=None, unrolled=False, noise=None, act="sigmoid"):
     """mycode/lstm_keras.py, weights K, R, b, dense_W, dense_b.  unrolled False: 1st part (:70-80), one input second per
     step from zero state, Dense(6,tanh) on every h.  unrolled True: the sampling model / 2nd part (:131-153,218-240) on
