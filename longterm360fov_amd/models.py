@@ -578,6 +578,186 @@ class StackedSeq2SeqLSTM:
         return float(loss.item())
 
 
+class OthersContextSeq2Seq:
+    """The other decoder heads of mycode/given_others_gt_mean_var_seq2seq.py (2+2-layer model, no teacher forcing), chosen by
+    the script's module flags (:48-56):
+      mode='target_user_only'  y_t = decoder_dense(h2_t)                                         (:219-220)
+      mode='others_mlp'        others_t -> Dense(256, relu) -> Dense(latent_dim, relu), concatenated with h2_t   (:153-156,223-233)
+      mode='others_lstm'       two Bidirectional LSTMs over the others' future mu/var, concatenated with h2_t    (:157-166,234-240)
+    (`mlp_mixing`, the flag the script ships, is OthersMixingSeq2Seq.)  Inputs as the script's Model (:301-307):
+    [encoder_input (N,T_in,F), others_fut_input (N,T_out,U-1,6), decoder_input (N,1,6)] -> (N,T_out,6);
+    'target_user_only' takes [encoder_input, decoder_input]."""
+
+    def __init__(self, mode, num_encoder_tokens=None, num_decoder_tokens=6, latent_dim=32, num_user=34, recurrent_activation=None,
+                 seed=None, impl="auto", device="cuda", predict_step=None):
+        from .training import others_context_order
+        if mode not in ("target_user_only", "others_mlp", "others_lstm"):
+            raise ValueError("mode must be 'target_user_only', 'others_mlp' or 'others_lstm'")
+        self.mode, self._order = mode, others_context_order(mode)
+        self.F = 3 * cfg.fps if num_encoder_tokens is None else int(num_encoder_tokens)
+        self.O, self.H, self.U = int(num_decoder_tokens), int(latent_dim), int(num_user)
+        self.recurrent_activation = recurrent_activation or cfg.recurrent_activation
+        self.impl, self.device = impl, device
+        self.predict_step = cfg.predict_step if predict_step is None else int(predict_step)
+        rng = np.random.default_rng(seed)
+        w, H, n_oth = {}, self.H, (self.U - 1) * self.O
+        for name, f in (("enc1", self.F), ("enc2", H), ("dec1", self.O), ("dec2", H)):
+            w[name + "_K"], w[name + "_R"], w[name + "_b"] = init_lstm_weights(rng, f, H)
+        Cc = {"target_user_only": 0, "others_mlp": H, "others_lstm": 2 * H}[mode]
+        w["dense_W"] = glorot_uniform(rng, Cc + H, self.O)
+        w["dense_b"] = np.zeros(self.O, np.float32)
+        if mode == "others_mlp":
+            w["oth_W1"], w["oth_b1"] = glorot_uniform(rng, n_oth, 256), np.zeros(256, np.float32)
+            w["oth_W2"], w["oth_b2"] = glorot_uniform(rng, 256, H), np.zeros(H, np.float32)
+        elif mode == "others_lstm":
+            for j, f in ((1, n_oth), (2, 2 * H)):
+                for d in ("f", "b"):
+                    n = "ol%d%s" % (j, d)
+                    w[n + "_K"], w[n + "_R"], w[n + "_b"] = init_lstm_weights(rng, f, H)
+        self._w, self._dw, self._ws, self._trainer = w, None, None, None
+        self.optimizer, self._lr, self.stop_training = None, 1e-3, False
+
+    def get_weights(self):
+        return [self._w[k].copy() for k in self._order]
+
+    def set_weights(self, weights):
+        weights = list(weights)
+        if len(weights) != len(self._order):
+            raise ValueError("expected %d arrays, got %d" % (len(self._order), len(weights)))
+        for k, a in zip(self._order, weights):
+            a = _as_f32(a)
+            if a.shape != self._w[k].shape:
+                raise ValueError("%s: expected shape %s, got %s" % (k, self._w[k].shape, a.shape))
+            self._w[k] = a
+        self._dw = self._trainer = None
+
+    def save_weights(self, path):
+        np.savez(path, **self._w)
+
+    save = save_weights
+
+    def load_weights(self, path):
+        with np.load(path) as z:
+            self.set_weights([z[k] for k in self._order])
+
+    def count_params(self):
+        return int(sum(v.size for v in self._w.values()))
+
+    def _inputs(self, x):
+        if self.mode == "target_user_only":
+            enc, dec0 = _as_f32(x[0]), _as_f32(x[-1])
+            return enc, np.zeros((enc.shape[0], self.predict_step, self.U - 1, self.O), np.float32), dec0
+        return _as_f32(x[0]), _as_f32(x[1]), _as_f32(x[2])
+
+    def _context(self, ops, dw, oth):
+        """(B,T_out,U-1,6) device tensor -> [ctx_t W_c + b] (B,T_out,O), or None."""
+        import torch
+        B, T = oth.shape[0], oth.shape[1]
+        H, act = self.H, self.recurrent_activation
+        if self.mode == "target_user_only":
+            return None
+        if self.mode == "others_mlp":
+            a1 = ops.dense(oth.reshape(B * T, -1), dw["oth_W1"], dw["oth_b1"], activation=None)
+            ops.act_fwd(a1, "relu", out=a1)
+            ctx = ops.dense(a1, dw["oth_W2"], dw["oth_b2"], activation=None)
+            ops.act_fwd(ctx, "relu", out=ctx)
+        else:
+            seq, init = oth.reshape(B, T, -1), {"f": (None, None), "b": (None, None)}
+            for j in (1, 2):
+                outs = {}
+                for d, xin in (("f", seq), ("b", torch.flip(seq, (1,)))):
+                    n = "ol%d%s" % (j, d)
+                    outs[d] = ops.lstm_seq(xin, dw[n + "_K"], dw[n + "_R"], dw[n + "_b"], init[d][0], init[d][1], act=act,
+                                           impl=self.impl, workspace=self._ws)
+                seq = torch.cat([outs["f"][0], torch.flip(outs["b"][0], (1,))], 2)
+                init = {d: (outs[d][1], outs[d][2]) for d in ("f", "b")}     # the list the first Bidirectional returns
+            ctx = seq.reshape(B * T, 2 * H)
+        Cc = dw["dense_W"].shape[0] - H
+        return ops.dense(ctx, dw["dense_W"][:Cc], dw["dense_b"], activation=None).reshape(B, T, self.O)
+
+    def predict(self, x, batch_size=None, verbose=0):
+        import torch
+        from . import ops
+        enc, oth, dec0 = self._inputs(x)
+        if self._dw is None:
+            self._dw = {k: torch.from_numpy(v).to(self.device) for k, v in self._w.items()}
+            self._ws = ops.Workspace()
+        dw, act, H, O = self._dw, self.recurrent_activation, self.H, self.O
+        T_out = oth.shape[1]
+        W_h = dw["dense_W"][dw["dense_W"].shape[0] - H:].contiguous()
+        n = enc.shape[0]
+        bs = n if not batch_size else int(batch_size)
+        outs = []
+        for lo in range(0, n, max(bs, 1)):
+            d = lambda a: torch.from_numpy(a[lo:lo + bs]).to(self.device)
+            e = d(enc)
+            B = e.shape[0]
+            ctx_proj = self._context(ops, dw, d(oth))
+            hs1, h1, c1 = ops.lstm_seq(e, dw["enc1_K"], dw["enc1_R"], dw["enc1_b"], act=act, impl=self.impl, workspace=self._ws)
+            _, h2, c2 = ops.lstm_seq(hs1, dw["enc2_K"], dw["enc2_R"], dw["enc2_b"], act=act, impl=self.impl, return_sequences=False,
+                                     workspace=self._ws)
+            xin = d(dec0).reshape(B, 1, O)
+            y = torch.empty((B, T_out, O), dtype=torch.float32, device=self.device)
+            for t in range(T_out):
+                _, h1, c1 = ops.lstm_seq(xin, dw["dec1_K"], dw["dec1_R"], dw["dec1_b"], h1, c1, act=act, impl=self.impl,
+                                         return_sequences=False, workspace=self._ws)
+                _, h2, c2 = ops.lstm_seq(h1.view(B, 1, H), dw["dec2_K"], dw["dec2_R"], dw["dec2_b"], h2, c2, act=act, impl=self.impl,
+                                         return_sequences=False, workspace=self._ws)
+                yt = ops.dense(h2, W_h, dw["dense_b"], activation="tanh") if ctx_proj is None else \
+                    ops.dense_add(h2, W_h, None, ctx_proj[:, t], activation="tanh")
+                y[:, t] = yt
+                xin = yt.view(B, 1, O)
+            outs.append(y.cpu().numpy())
+        self._ws.check()
+        return np.concatenate(outs, axis=0) if outs else np.zeros((0, T_out, O), np.float32)
+
+    predict_on_batch = predict
+
+    def compile(self, optimizer="Adam", loss="mean_squared_error", metrics=None):
+        opt = optimizer if isinstance(optimizer, str) else getattr(optimizer, "name", str(optimizer))
+        if opt.lower() not in ("adam", "rmsprop") or str(loss).lower() not in ("mean_squared_error", "mse"):
+            raise ValueError("unsupported optimizer / loss %r / %r" % (optimizer, loss))
+        self.optimizer, self.loss, self.metrics = opt.lower(), "mse", list(metrics or [])
+
+    @property
+    def lr(self):
+        return self._lr
+
+    @lr.setter
+    def lr(self, value):
+        self._lr = float(value)
+        if self._trainer is not None:
+            self._trainer.lr = self._lr
+
+    def _get_trainer(self):
+        from .training import OthersContextTrainer
+        if self._trainer is None:
+            self._trainer = OthersContextTrainer(self._w, self.mode, act=self.recurrent_activation, impl=self.impl,
+                                                 optimizer=self.optimizer or "adam", lr=self._lr, device=self.device)
+        return self._trainer
+
+    def fit(self, x, y, batch_size=32, epochs=1, validation_split=0.0, shuffle=True, callbacks=None, initial_epoch=0, verbose=0,
+            validation_data=None):
+        """Keras `Model.fit` as the script calls it (:500-506)."""
+        if self.optimizer is None:
+            raise RuntimeError("call compile() before fit()")
+        if validation_data is not None:
+            validation_data = (list(self._inputs(validation_data[0])), validation_data[1])
+        self.predict_step = _as_f32(y).shape[1]
+        return _keras_fit(self, self._get_trainer(), list(self._inputs(x)), y, batch_size, epochs, validation_split, shuffle,
+                          callbacks, initial_epoch, validation_data)
+
+    def train_on_batch(self, x, y):
+        import torch
+        d = lambda a: torch.from_numpy(_as_f32(a)).to(self.device)
+        self.predict_step = _as_f32(y).shape[1]
+        enc, oth, dec0 = self._inputs(x)
+        tr = self._get_trainer()
+        loss = tr.train_step(d(enc), d(oth), d(dec0), d(y))
+        self._w, self._dw = tr.weights_numpy(), None
+        return float(loss.item())
+
+
 class KerasSingleLSTM:
     """Single-layer model of mycode/lstm_keras.py: ONE LSTM from zero state + Dense(6, tanh) per step, Adam + MSE.
       unrolled=False  1st part (:59-83): x (N,T,F) -> (N,T,6), one input second per step;

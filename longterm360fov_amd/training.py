@@ -265,6 +265,170 @@ class StackedSeq2SeqTrainer(Seq2SeqTrainer):
         return loss
 
 
+def others_context_order(mode):
+    base = tuple("%s_%s" % (n, p) for n in ("enc1", "enc2", "dec1", "dec2") for p in ("K", "R", "b")) + ("dense_W", "dense_b")
+    if mode == "others_mlp":
+        return base + ("oth_W1", "oth_b1", "oth_W2", "oth_b2")
+    if mode == "others_lstm":
+        return base + tuple("ol%d%s_%s" % (j, d, p) for j in (1, 2) for d in ("f", "b") for p in ("K", "R", "b"))
+    return base
+
+
+class OthersContextTrainer(Seq2SeqTrainer):
+    """Training step of the other decoder heads of mycode/given_others_gt_mean_var_seq2seq.py (2+2-layer model, no teacher
+    forcing, Adam + MSE): `target_user_only` (:219-220), `others_mlp` (:153-156,223-233), `others_lstm` (two Bidirectional
+    LSTMs over the others' future mu/var, :157-166,234-240).  The others only enter through a per-step context that
+    does not depend on the decoder, so its projection through decoder_dense is ONE product hoisted out of the unrolled
+    loop (y_t = tanh(h2_t W_h + [ctx_t W_c + b])) and so is its gradient; the decoder is walked step by step on the
+    layer kernels, weight gradients are one product over all steps."""
+
+    def __init__(self, weights, mode, act="sigmoid", impl="auto", optimizer="adam", lr=1e-3, device="cuda"):
+        assert mode in ("target_user_only", "others_mlp", "others_lstm")
+        self.mode = mode
+        super().__init__(weights, act=act, impl=impl, optimizer=optimizer, lr=lr, device=device, order=others_context_order(mode))
+
+    # ---- context: forward keeps what its backward needs ----
+    def _bi_fwd(self, x, j, init):
+        w, out = self.w, {}
+        for d, xin in (("f", x), ("b", torch.flip(x, (1,)))):
+            n = "ol%d%s" % (j, d)
+            h0, c0 = (None, None) if init is None else init[d]
+            hs, hT, cT, res = ops.lstm_seq_train(xin, w[n + "_K"], w[n + "_R"], w[n + "_b"], h0, c0, act=self.act, impl=self.impl,
+                                                 workspace=self.ws)
+            out[d] = (xin, hs, res, hT, cT, h0, c0)
+        seq = torch.cat([out["f"][1], torch.flip(out["b"][1], (1,))], 2)
+        return seq, out
+
+    def _bi_bwd(self, dseq, tape, j, dstate, need_dx):
+        """dseq (B,T,2H) -> gradient w.r.t. the layer input (or None) and w.r.t. its initial states {dir: (dh0, dc0)}."""
+        w, g = self.w, self.g
+        H = dseq.shape[2] // 2
+        dx, dinit = None, {}
+        for d in ("f", "b"):
+            n = "ol%d%s" % (j, d)
+            xin, hs, res, _, _, h0, c0 = tape[d]
+            dhs = dseq[..., :H].contiguous() if d == "f" else torch.flip(dseq[..., H:], (1,)).contiguous()
+            dhT, dcT = (None, None) if dstate is None else dstate[d]
+            b = ops.lstm_seq_bwd(xin, w[n + "_K"], w[n + "_R"], hs, res, h0=h0, c0=c0, dhs=dhs, dhT=dhT, dcT=dcT, dK=g[n + "_K"],
+                                 dR=g[n + "_R"], db=g[n + "_b"], need_dx=need_dx, need_state_grads=(h0 is not None), act=self.act,
+                                 accumulate=True, scratch=self.bwd_scratch)
+            dinit[d] = (b["dh0"], b["dc0"])
+            if need_dx:
+                dxd = b["dx"] if d == "f" else torch.flip(b["dx"], (1,)).contiguous()
+                dx = dxd if dx is None else ops.act_bwd(dxd, dxd, base=dx, activation=None)
+        return dx, dinit
+
+    def forward_backward(self, enc, others, dec0, target, grad_weight=1.0):
+        """others (B,T_out,U-1,6) (ignored by 'target_user_only').  -> (loss (1,), prediction (B,T_out,O))."""
+        w, g, act, impl, ws, sc, bsc = self.w, self.g, self.act, self.impl, self.ws, self.scratch, self.bwd_scratch
+        B, T_in, _ = enc.shape
+        T_out, O = target.shape[1], target.shape[2]
+        H = w["enc1_R"].shape[0]
+        e = lambda *s_: torch.empty(s_, dtype=torch.float32, device=self.device)
+        self.grad.zero_()
+        Cc = w["dense_W"].shape[0] - H
+        W_c, W_h = w["dense_W"][:Cc], w["dense_W"][Cc:].contiguous()
+        gW_c, gW_h = g["dense_W"][:Cc], g["dense_W"][Cc:]
+        # ---------------- context ----------------
+        ctx = ctape = None
+        if self.mode == "others_mlp":
+            o2 = others.reshape(B * T_out, -1)
+            a1 = ops.dense(o2, w["oth_W1"], w["oth_b1"], activation=None)
+            ops.act_fwd(a1, "relu", out=a1)
+            ctx = ops.dense(a1, w["oth_W2"], w["oth_b2"], activation=None)
+            ops.act_fwd(ctx, "relu", out=ctx)
+            ctape = (o2, a1)
+        elif self.mode == "others_lstm":
+            o3 = others.reshape(B, T_out, -1)
+            s1, t1 = self._bi_fwd(o3, 1, None)
+            s2, t2 = self._bi_fwd(s1, 2, {d: (t1[d][3], t1[d][4]) for d in ("f", "b")})
+            ctx, ctape = s2.reshape(B * T_out, 2 * H), (t1, t2)
+        if ctx is not None:      # [ctx_t W_c + b] for every step at once, rows (b, t)
+            ctx_proj = ops.dense(ctx, W_c.contiguous(), w["dense_b"], activation=None).reshape(B, T_out, O)
+        # ---------------- encoder + unrolled decoder ----------------
+        H1, C1, H2, C2 = e(T_out + 1, B, H), e(T_out + 1, B, H), e(T_out + 1, B, H), e(T_out + 1, B, H)
+        hs1, _, _, res1 = ops.lstm_seq_train(enc, w["enc1_K"], w["enc1_R"], w["enc1_b"], act=act, impl=impl, workspace=ws,
+                                             out=(e(B, T_in, H), H1[0], C1[0], e(B, T_in, 5, H)))
+        hs2, _, _, res2 = ops.lstm_seq_train(hs1, w["enc2_K"], w["enc2_R"], w["enc2_b"], act=act, impl=impl, workspace=ws,
+                                             out=(e(B, T_in, H), H2[0], C2[0], e(B, T_in, 5, H)))
+        XY = e(T_out + 1, B, O)
+        R1, R2 = e(T_out, B, 1, 5, H), e(T_out, B, 1, 5, H)
+        XY[0].copy_(dec0.reshape(B, O))
+        for t in range(T_out):
+            ops.lstm_seq_train(XY[t].view(B, 1, O), w["dec1_K"], w["dec1_R"], w["dec1_b"], H1[t], C1[t], act=act, impl=impl,
+                               workspace=ws, out=(H1[t + 1].view(B, 1, H), None, C1[t + 1], R1[t]))
+            ops.lstm_seq_train(H1[t + 1].view(B, 1, H), w["dec2_K"], w["dec2_R"], w["dec2_b"], H2[t], C2[t], act=act, impl=impl,
+                               workspace=ws, out=(H2[t + 1].view(B, 1, H), None, C2[t + 1], R2[t]))
+            if ctx is None:
+                ops.dense(H2[t + 1], W_h, w["dense_b"], activation="tanh", out=XY[t + 1])
+            else:
+                ops.dense_add(H2[t + 1], W_h, None, ctx_proj[:, t], activation="tanh", out=XY[t + 1])
+        out = XY[1:].transpose(0, 1).contiguous()
+        # ---------------- backward ----------------
+        dloss, loss = ops.mse_dense_grad(out, target, None, scratch=sc)
+        dloss_tm = dloss.transpose(0, 1).contiguous()
+        DY, DPRE, DZ1, DZ2 = e(T_out, B, O), e(T_out, B, O), e(T_out, B, 4 * H), e(T_out, B, 4 * H)
+        dh1 = dc1 = dh2 = dc2 = dx_next = None
+        for t in range(T_out - 1, -1, -1):
+            if dx_next is None:
+                DY[t].copy_(dloss_tm[t])
+            else:
+                ops.act_bwd(dx_next.reshape(B, O), XY[t + 1], base=dloss_tm[t], activation=None, out=DY[t])
+            ops.act_bwd(DY[t], XY[t + 1], activation="tanh", out=DPRE[t])
+            dh2_dense, _, _ = ops.dense_bwd(H2[t + 1], W_h, DPRE[t], need_dx=True, need_dW=False, need_db=False, scratch=sc)
+            b2 = ops.lstm_seq_bwd(H1[t + 1].view(B, 1, H), w["dec2_K"], w["dec2_R"], H2[t + 1].view(B, 1, H), R2[t], h0=H2[t],
+                                  c0=C2[t], dhs=dh2_dense.reshape(B, 1, H), dhT=dh2, dcT=dc2, need_dx=True, need_state_grads=True,
+                                  act=act, dz=DZ2[t].view(B, 1, 4 * H), scratch=bsc, need_weight_grads=False)
+            dh2, dc2 = b2["dh0"], b2["dc0"]
+            b1 = ops.lstm_seq_bwd(XY[t].view(B, 1, O), w["dec1_K"], w["dec1_R"], H1[t + 1].view(B, 1, H), R1[t], h0=H1[t],
+                                  c0=C1[t], dhs=b2["dx"], dhT=dh1, dcT=dc1, need_dx=(t > 0), need_state_grads=True, act=act,
+                                  dz=DZ1[t].view(B, 1, 4 * H), scratch=bsc, need_weight_grads=False)
+            dh1, dc1, dx_next = b1["dh0"], b1["dc0"], b1["dx"]
+        TB = T_out * B
+        fl = lambda a, n: a.reshape(TB, n)
+        ops.dense_bwd(fl(H2[1:], H), W_h, fl(DPRE, O), dW=gW_h, db=g["dense_b"], need_dx=False, accumulate=True, scratch=sc)
+        ops.dense_bwd(fl(H1[1:], H), w["dec2_K"], fl(DZ2, 4 * H), dW=g["dec2_K"], db=g["dec2_b"], need_dx=False, accumulate=True, scratch=sc)
+        ops.dense_bwd(fl(H2[:T_out], H), w["dec2_R"], fl(DZ2, 4 * H), dW=g["dec2_R"], need_db=False, need_dx=False, accumulate=True, scratch=sc)
+        ops.dense_bwd(fl(XY[:T_out], O), w["dec1_K"], fl(DZ1, 4 * H), dW=g["dec1_K"], db=g["dec1_b"], need_dx=False, accumulate=True, scratch=sc)
+        ops.dense_bwd(fl(H1[:T_out], H), w["dec1_R"], fl(DZ1, 4 * H), dW=g["dec1_R"], need_db=False, need_dx=False, accumulate=True, scratch=sc)
+        if ctx is not None:      # the context's half of decoder_dense and the context module, rows (b, t)
+            dpre_bt = DPRE.transpose(0, 1).contiguous().reshape(B * T_out, O)
+            dctx, _, _ = ops.dense_bwd(ctx, W_c.contiguous(), dpre_bt, dW=gW_c, need_db=False, need_dx=True, accumulate=True, scratch=sc)
+            if self.mode == "others_mlp":
+                o2, a1 = ctape
+                d2 = ops.act_bwd(dctx, ctx, activation="relu")
+                da1, _, _ = ops.dense_bwd(a1, w["oth_W2"], d2, dW=g["oth_W2"], db=g["oth_b2"], accumulate=True, scratch=sc)
+                d1 = ops.act_bwd(da1, a1, activation="relu")
+                ops.dense_bwd(o2, w["oth_W1"], d1, dW=g["oth_W1"], db=g["oth_b1"], need_dx=False, accumulate=True, scratch=sc)
+            else:
+                t1, t2 = ctape
+                ds1, dinit = self._bi_bwd(dctx.reshape(B, T_out, 2 * H), t2, 2, None, need_dx=True)
+                self._bi_bwd(ds1, t1, 1, dinit, need_dx=False)
+        e2 = ops.lstm_seq_bwd(hs1, w["enc2_K"], w["enc2_R"], hs2, res2, dhT=dh2, dcT=dc2, dK=g["enc2_K"], dR=g["enc2_R"],
+                              db=g["enc2_b"], need_dx=True, act=act, accumulate=True, scratch=bsc)
+        ops.lstm_seq_bwd(enc, w["enc1_K"], w["enc1_R"], hs1, res1, dhs=e2["dx"], dhT=dh1, dcT=dc1, dK=g["enc1_K"], dR=g["enc1_R"],
+                         db=g["enc1_b"], act=act, accumulate=True, scratch=bsc)
+        if grad_weight != 1.0:
+            self.grad.mul_(grad_weight)
+        return loss, out
+
+    def eval_loss(self, enc, others, dec0, target):
+        loss, _ = self.forward_backward(enc, others, dec0, target)      # gradients are overwritten by the next step
+        return loss
+
+    def train_step(self, enc, others, dec0, target, n_global=None):
+        _, world = parallel.world()
+        n_local = enc.shape[0]
+        weight = 1.0 if world == 1 else n_local / float(n_global if n_global else n_local * world)
+        loss, _ = self.forward_backward(enc, others, dec0, target, grad_weight=weight)
+        if world > 1:
+            torch.distributed.all_reduce(self.grad, op=torch.distributed.ReduceOp.SUM)
+            loss = loss * weight
+            torch.distributed.all_reduce(loss, op=torch.distributed.ReduceOp.SUM)
+        self.apply_gradients()
+        return loss
+
+
 _SINGLE_ORDER = ("K", "R", "b", "dense_W", "dense_b")
 
 

@@ -221,6 +221,46 @@ def others_mixing_forward(enc_in, others, dec_in0, w, act="sigmoid"):
     return np.stack(out, axis=1)
 
 
+def bidirectional_lstm(x, wf, wb, init=None, act="sigmoid"):
+    """Keras Bidirectional(LSTM(return_sequences, return_state), merge_mode='concat'): the backward layer reads the
+    sequence reversed and its outputs are reversed back before the concat.  wf / wb = (K, R, b); init = (fh, fc, bh, bc) or
+    None.  -> (seq (B,T,2H), fh, fc, bh, bc)."""
+    i = (None,) * 4 if init is None else init
+    f_seq, fh, fc = lstm_layer(x, wf[0], wf[1], wf[2], i[0], i[1], act=act)
+    b_seq, bh, bc = lstm_layer(x[:, ::-1], wb[0], wb[1], wb[2], i[2], i[3], act=act)
+    return np.concatenate([f_seq, b_seq[:, ::-1]], axis=-1), fh, fc, bh, bc
+
+
+def others_context_forward(enc_in, others, dec_in0, w, T_out, mode, act="sigmoid"):
+    """The other decoder heads of given_others_gt_mean_var_seq2seq.py (2+2-layer model, no teacher forcing, :203-299):
+      'target_user_only' (:219-220)  y_t = decoder_dense(h2_t)
+      'others_mlp'       (:153-156,223-233)  ctx_t = relu(relu(flatten(others_t) W1 + b1) W2 + b2);  y_t = decoder_dense([ctx_t ; h2_t])
+      'others_lstm'      (:157-166,234-240)  ctx = BiLSTM2(BiLSTM1(others reshaped (B,T,(U-1)*6))): calling the second
+                         Bidirectional on the LIST the first returns makes layer 1's final states its initial states;
+                         y_t = decoder_dense([ctx_t (2H) ; h2_t])
+    y_t is fed back as the next decoder input.  weights: enc1/enc2/dec1/dec2 _K/_R/_b, dense_W ((Cc+H),6), dense_b, and
+    oth_W1/b1/W2/b2 or ol{1,2}{f,b}_K/_R/_b."""
+    hs1, h1, c1 = lstm_layer(enc_in, w["enc1_K"], w["enc1_R"], w["enc1_b"], act=act)
+    _, h2, c2 = lstm_layer(hs1, w["enc2_K"], w["enc2_R"], w["enc2_b"], act=act)
+    B = enc_in.shape[0]
+    ctx = None
+    if mode == "others_mlp":
+        o = others.reshape(B, T_out, -1).astype(enc_in.dtype)
+        ctx = np.maximum(np.maximum(o @ w["oth_W1"] + w["oth_b1"], 0) @ w["oth_W2"] + w["oth_b2"], 0)
+    elif mode == "others_lstm":
+        o = others.reshape(B, T_out, -1).astype(enc_in.dtype)
+        g = lambda n: (w[n + "_K"], w[n + "_R"], w[n + "_b"])
+        s1, fh, fc, bh, bc = bidirectional_lstm(o, g("ol1f"), g("ol1b"), act=act)
+        ctx = bidirectional_lstm(s1, g("ol2f"), g("ol2b"), (fh, fc, bh, bc), act=act)[0]
+    x, out = dec_in0[:, 0].astype(enc_in.dtype), []
+    for t in range(T_out):
+        h1, c1 = lstm_step(x, h1, c1, w["dec1_K"], w["dec1_R"], w["dec1_b"], act)
+        h2, c2 = lstm_step(h1, h2, c2, w["dec2_K"], w["dec2_R"], w["dec2_b"], act)
+        x = dense(h2 if ctx is None else np.concatenate([ctx[:, t], h2], axis=1), w["dense_W"], w["dense_b"])
+        out.append(x)
+    return np.stack(out, axis=1)
+
+
 # --------------------------------------------------------------------------------------
 # a5: mu / sigma^2 features  (mycode/utility.py:483-517)
 # --------------------------------------------------------------------------------------

@@ -866,3 +866,90 @@ def test_stacked_seq2seq_layers(L, H, B, T_in, T_out, act):
     assert losses[-1] < losses[0]
     h = m.fit([enc, dec_in], tgt, batch_size=16, epochs=2, validation_split=0.1)
     assert len(h.history["loss"]) == 2 and "val_loss" in h.history
+
+
+def _torch_others_context_graph(enc, oth, dec0, tgt, w, mode, act):
+    """fp64 torch.autograd restatement of given_others...py with target_user_only / others_mlp / others_lstm (see the oracle's
+    others_context_forward for the line references)."""
+    t = {k: torch.tensor(v.astype(np.float64), requires_grad=True) for k, v in w.items()}
+    H = w["enc1_R"].shape[0]
+    s = torch.sigmoid if act == "sigmoid" else (lambda z: torch.clamp(0.2 * z + 0.5, 0, 1))
+
+    def step(x, h, c, n):
+        z = x @ t[n + "_K"] + t[n + "_b"] + h @ t[n + "_R"]
+        i, f, g, o = s(z[:, :H]), s(z[:, H:2 * H]), torch.tanh(z[:, 2 * H:3 * H]), s(z[:, 3 * H:])
+        c = f * c + i * g
+        return o * torch.tanh(c), c
+
+    def layer(x, n, h, c):
+        outs = []
+        for tt in range(x.shape[1]):
+            h, c = step(x[:, tt], h, c, n)
+            outs.append(h)
+        return torch.stack(outs, 1), h, c
+
+    e, o_, d0, tg = (torch.tensor(a.astype(np.float64)) for a in (enc, oth, dec0, tgt))
+    B, T_out = e.shape[0], tg.shape[1]
+    z0 = torch.zeros(B, H, dtype=torch.float64)
+    hs1, h1, c1 = layer(e, "enc1", z0, z0)
+    _, h2, c2 = layer(hs1, "enc2", z0, z0)
+    ctx = None
+    if mode == "others_mlp":
+        ctx = torch.relu(torch.relu(o_.reshape(B, T_out, -1) @ t["oth_W1"] + t["oth_b1"]) @ t["oth_W2"] + t["oth_b2"])
+    elif mode == "others_lstm":
+        seq, init = o_.reshape(B, T_out, -1), {"f": (z0, z0), "b": (z0, z0)}
+        for j in (1, 2):
+            fs, fh, fc = layer(seq, "ol%df" % j, *init["f"])
+            bs, bh, bc = layer(torch.flip(seq, (1,)), "ol%db" % j, *init["b"])
+            seq, init = torch.cat([fs, torch.flip(bs, (1,))], 2), {"f": (fh, fc), "b": (bh, bc)}
+        ctx = seq
+    x, outs = d0[:, 0], []
+    for tt in range(T_out):
+        h1, c1 = step(x, h1, c1, "dec1")
+        h2, c2 = step(h1, h2, c2, "dec2")
+        x = torch.tanh((h2 if ctx is None else torch.cat([ctx[:, tt], h2], 1)) @ t["dense_W"] + t["dense_b"])
+        outs.append(x)
+    y = torch.stack(outs, 1)
+    loss = torch.mean((y - tg) ** 2)
+    loss.backward()
+    return float(loss.detach()), {k: v.grad.numpy() for k, v in t.items()}, y.detach().numpy()
+
+
+@pytest.mark.parametrize("mode,H,B,U,T_in,T_out,act", [("target_user_only", 64, 21, 5, 4, 5, "sigmoid"),
+                                                       ("others_mlp", 32, 33, 34, 3, 4, "hard_sigmoid"),
+                                                       ("others_lstm", 32, 19, 6, 3, 5, "sigmoid"),
+                                                       ("others_lstm", 256, 24, 34, 2, 3, "hard_sigmoid")])
+def test_others_context_heads(mode, H, B, U, T_in, T_out, act):
+    """given_others...py with its other module flags (target_user_only, others_mlp, others_lstm = two Bidirectional LSTMs whose
+    second is seeded with the first's final states): forward vs the NumPy oracle, gradients vs torch.autograd fp64."""
+    from longterm360fov_amd.models import OthersContextSeq2Seq
+    from longterm360fov_amd.training import OthersContextTrainer, others_context_order
+    m = OthersContextSeq2Seq(mode, latent_dim=H, num_user=U, recurrent_activation=act, seed=H + B, predict_step=T_out)
+    rng = np.random.default_rng(B)
+    w = {k: (v + (0.1 * rng.standard_normal(v.shape).astype(np.float32) if k.endswith("_b") or k.endswith("b1") or k.endswith("b2") else 0))
+         for k, v in zip(others_context_order(mode), m.get_weights())}
+    m.set_weights([w[k] for k in others_context_order(mode)])
+    enc, dec0, tgt, oth = O.synthetic_batch(71 + B, B, T_in, T_out, num_others=U - 1)
+    loss_ref, g_ref, y_ref = _torch_others_context_graph(enc, oth, dec0, tgt, w, mode, act)
+    y_np = O.others_context_forward(enc.astype(np.float64), oth.astype(np.float64), dec0.astype(np.float64), f64(w), T_out, mode, act)
+    np.testing.assert_allclose(y_np, y_ref, atol=1e-12)
+    tr = OthersContextTrainer(w, mode, act=act)
+    loss, y = tr.forward_backward(dev(enc), dev(oth), dev(dec0), dev(tgt))
+    tr.ws.check(); tr.bwd_scratch.check()
+    assert abs(float(loss.item()) - loss_ref) <= 1e-5 * loss_ref + 1e-9
+    np.testing.assert_allclose(y.cpu().numpy(), y_ref, atol=2e-5)
+    for k in others_context_order(mode):
+        a = tr.g[k].detach().cpu().numpy().astype(np.float64)
+        scale = np.abs(g_ref[k]).max()
+        err = np.abs(a - g_ref[k]).max()
+        print("%s H%d grad %-8s max|ref| %.3e  max err %.3e" % (mode, H, k, scale, err))
+        assert err <= 1e-4 * scale + 1e-9, (k, err, scale)
+    xin = [enc, dec0] if mode == "target_user_only" else [enc, oth, dec0]
+    got = m.predict(xin)
+    np.testing.assert_allclose(got, y_ref, atol=2e-5)
+    assert (np.abs(got - y_ref) <= 1e-3 * np.abs(y_ref) + 1e-5).all()
+    m.compile(optimizer="Adam", loss="mean_squared_error")
+    losses = [m.train_on_batch(xin, tgt) for _ in range(4)]
+    assert losses[-1] < losses[0]
+    h = m.fit(xin, tgt, batch_size=16, epochs=2, validation_split=0.2)
+    assert len(h.history["loss"]) == 2 and "val_loss" in h.history
