@@ -210,3 +210,29 @@ def generator_train2(datadb, phase="train", num_user=34, video_keys=None):
             for lo in range(0, enc.shape[0], bs):
                 yield [enc[lo:lo + bs], oth_in[lo:lo + bs], dec_in[lo:lo + bs]], target_data[lo:lo + bs]
         ii += 1
+
+
+# ---------------------------------------------------------------------------------------------
+# Pickled interchange with the reference's scripts (§8(f) rank 4): the dataset dictionaries they read
+# and the prediction / ground-truth lists their plotting and evaluation scripts consume.
+# ---------------------------------------------------------------------------------------------
+def load_datadb(path):
+    """`pickle.load(open(path,'rb'), encoding='latin1')` as given_others...py:338-340 / lstm_keras.py:84 do (the
+    Shanghai / Tsinghua files were written by Python 2): dict[video] -> {'x','y','z': (n_user, n_frame)}; then
+    clip_xyz, as every script does right after loading."""
+    import pickle
+    with open(path, "rb") as f:
+        return clip_xyz(pickle.load(f, encoding="latin1"))
+
+
+def save_decoded_sentences(decoded_sentence_list, gt_sentence_list, tag="", directory="."):
+    """The two files every test loop of the reference ends with (FoV_seq2seq.py:193-194, given_others...py:699-700,
+    lstm_keras.py:203-204): 'decoded_sentence<tag>.p' = list (one entry per batch) of predictions, and
+    'gt_sentence_list<tag>.p' = list of the raw ground-truth futures, plain pickles of NumPy arrays."""
+    import os
+    import pickle
+    paths = (os.path.join(directory, "decoded_sentence%s.p" % tag), os.path.join(directory, "gt_sentence_list%s.p" % tag))
+    for p, obj in zip(paths, (decoded_sentence_list, gt_sentence_list)):
+        with open(p, "wb") as f:
+            pickle.dump([np.asarray(a) for a in obj], f)
+    return paths

@@ -156,3 +156,23 @@ def test_trainer_host_helpers_on_cpu():
     i, j, f, o = (z_tf[:, k * Hh:(k + 1) * Hh] for k in range(4))
     assert np.allclose(z_k[:, :Hh], i, atol=1e-5) and np.allclose(z_k[:, Hh:2 * Hh], f + 1.0, atol=1e-5)
     assert np.allclose(z_k[:, 2 * Hh:3 * Hh], j, atol=1e-5) and np.allclose(z_k[:, 3 * Hh:], o, atol=1e-5)
+
+
+def test_pickled_interchange_round_trip(tmp_path):
+    """§8(f) rank 4, the pickled half: a Python-2 style dataset pickle (protocol 2) loads and is clipped; the
+    decoded_sentence / gt_sentence_list files are plain pickles of per-batch arrays as the reference's plotting scripts read."""
+    import pickle
+    from longterm360fov_amd import utility as U
+    rng = np.random.default_rng(0)
+    db = {"v%d" % i: {a: rng.uniform(-1.2, 1.2, (3, 90)) for a in "xyz"} for i in range(2)}
+    p = tmp_path / "db.p"
+    with open(p, "wb") as f:
+        pickle.dump(db, f, protocol=2)
+    got = U.load_datadb(str(p))
+    assert set(got) == set(db) and all(np.abs(got[k][a]).max() <= 1.0 for k in got for a in "xyz")
+    dec = [rng.standard_normal((4, 10, 6)).astype(np.float32) for _ in range(3)]
+    gt = [rng.standard_normal((4, 10, 90)) for _ in range(3)]
+    a, b = U.save_decoded_sentences(dec, gt, tag="_t", directory=str(tmp_path))
+    assert a.endswith("decoded_sentence_t.p") and b.endswith("gt_sentence_list_t.p")
+    back = pickle.load(open(a, "rb"))
+    assert len(back) == 3 and np.array_equal(back[1], dec[1]) and np.array_equal(pickle.load(open(b, "rb"))[2], gt[2])
