@@ -99,55 +99,32 @@ def _keras_fit(model, trainer, inputs, y, batch_size, epochs, validation_split, 
     return hist
 
 
-class _SubModel:
-    def __init__(self, fn):
-        self._fn = fn
+class KerasModelSurface:
+    """The part of the Keras `Model` surface every model object here shares (what the reference's scripts call on their
+    models: get/set_weights, save / load_weights, compile, fit, train_on_batch, the `lr` the callbacks adjust).  A
+    subclass fills self._w (name -> float32 array), calls _init_surface(order, impl, device) and provides
+    _make_trainer() and predict().  Weight files are .npz with the arrays under their names (h5py is not available,
+    DESIGN section 1 row f4); the ORDER of get_weights / set_weights is Keras's: per layer kernel, recurrent_kernel,
+    bias, layers in creation order."""
 
-    def predict(self, x, batch_size=None, verbose=0):
-        return self._fn(x)
-
-    predict_on_batch = predict
-
-
-class Seq2SeqLSTM:
-    """Target-only seq2seq LSTM (1-layer encoder, 1-layer decoder, Dense(tanh) head)."""
-
-    def __init__(self, num_encoder_tokens=None, num_decoder_tokens=6, latent_dim=64, recurrent_activation=None,
-                 seed=None, impl="auto", device="cuda"):
-        self.num_encoder_tokens = 3 * cfg.fps if num_encoder_tokens is None else int(num_encoder_tokens)
-        self.num_decoder_tokens = int(num_decoder_tokens)
-        self.latent_dim = int(latent_dim)
-        self.recurrent_activation = recurrent_activation or cfg.recurrent_activation
-        if self.recurrent_activation not in ("sigmoid", "hard_sigmoid"):
-            raise ValueError("recurrent_activation must be 'sigmoid' or 'hard_sigmoid'")
-        self.impl = impl
-        self.device = device
-        rng = np.random.default_rng(seed)
-        w = {}
-        w["enc_K"], w["enc_R"], w["enc_b"] = init_lstm_weights(rng, self.num_encoder_tokens, self.latent_dim)
-        w["dec_K"], w["dec_R"], w["dec_b"] = init_lstm_weights(rng, self.num_decoder_tokens, self.latent_dim)
-        w["dense_W"] = glorot_uniform(rng, self.latent_dim, self.num_decoder_tokens)
-        w["dense_b"] = np.zeros(self.num_decoder_tokens, np.float32)
-        self._w = w
-        self._dw = None          # device copies, created lazily
-        self._ws = None
-        self.optimizer = None
-        self.loss = None
-        self._trainer = None
+    def _init_surface(self, order, impl, device):
+        self._order = tuple(order)
+        self.impl, self.device = impl, device
+        self._dw = self._ws = self._trainer = None       # device copies / workspace (lazy), trainer (lazy)
+        self.optimizer = self.loss = None
+        self.metrics = []
         self._lr = 1e-3
         self.stop_training = False
-        self.encoder_model = _SubModel(self._encoder_predict)
-        self.decoder_model = _SubModel(self._decoder_predict)
 
-    # ---- weights (Keras order) -------------------------------------------------------------
+    # ---- weights ----
     def get_weights(self):
-        return [self._w[k].copy() for k in _W_ORDER]
+        return [self._w[k].copy() for k in self._order]
 
     def set_weights(self, weights):
         weights = list(weights)
-        if len(weights) != len(_W_ORDER):
-            raise ValueError("expected %d arrays, got %d" % (len(_W_ORDER), len(weights)))
-        for k, a in zip(_W_ORDER, weights):
+        if len(weights) != len(self._order):
+            raise ValueError("expected %d arrays, got %d" % (len(self._order), len(weights)))
+        for k, a in zip(self._order, weights):
             a = _as_f32(a)
             if a.shape != self._w[k].shape:
                 raise ValueError("%s: expected shape %s, got %s" % (k, self._w[k].shape, a.shape))
@@ -162,26 +139,115 @@ class Seq2SeqLSTM:
 
     def load_weights(self, path):
         with np.load(path) as z:
-            self.set_weights([z[k] for k in _W_ORDER])
+            self.set_weights([z[k] for k in self._order])
 
     def count_params(self):
         return int(sum(v.size for v in self._w.values()))
 
-    # ---- device plumbing -------------------------------------------------------------------
+    def _device_weights(self):
+        import torch
+        from . import ops   # imported lazily so that host-only use does not need the .so
+        if self._dw is None:
+            self._dw = {k: torch.from_numpy(v).to(self.device) for k, v in self._w.items()}
+            self._ws = ops.Workspace()
+        return self._dw
+
+    def _to_device(self, a):
+        import torch
+        return torch.from_numpy(_as_f32(a)).to(self.device)
+
+    # ---- training surface ----
+    def compile(self, optimizer="Adam", loss="mean_squared_error", metrics=None):
+        """Keras `compile`.  Accepted: optimizer 'Adam' | 'RMSprop' (Keras defaults), loss 'mean_squared_error' | 'mse'
+        (FoV_seq2seq.py:103, given_others...py:308, convlstm_seq2seq.py:287)."""
+        opt = optimizer if isinstance(optimizer, str) else getattr(optimizer, "name", str(optimizer))
+        if opt.lower() not in ("adam", "rmsprop"):
+            raise ValueError("unsupported optimizer %r" % (optimizer,))
+        if str(getattr(loss, "__name__", loss)).lower().lstrip("_") not in ("mean_squared_error", "mse"):
+            raise ValueError("unsupported loss %r" % (loss,))
+        self.optimizer, self.loss, self.metrics = opt.lower(), "mse", list(metrics or [])
+
+    @property
+    def lr(self):
+        return self._lr
+
+    @lr.setter
+    def lr(self, value):
+        self._lr = float(value)
+        if self._trainer is not None:
+            self._trainer.lr = self._lr
+
+    _default_optimizer = "adam"
+
+    def _make_trainer(self, optimizer):
+        raise NotImplementedError
+
+    def _get_trainer(self):
+        if self._trainer is None:
+            self._trainer = self._make_trainer(self.optimizer or self._default_optimizer)
+            self._trainer.lr = self._lr
+        return self._trainer
+
+    def _fit_inputs(self, x):
+        """Model inputs as the list of arrays the trainer's train_step takes (before the target)."""
+        return [_as_f32(a) for a in x] if isinstance(x, (list, tuple)) else [_as_f32(x)]
+
+    def fit(self, x, y, batch_size=32, epochs=1, validation_split=0.0, shuffle=True, callbacks=None, initial_epoch=0,
+            verbose=0, validation_data=None):
+        """Keras `Model.fit` (FoV_seq2seq.py:112-117); see _keras_fit for the semantics.  Returns a History."""
+        if self.optimizer is None:
+            raise RuntimeError("call compile() before fit()")
+        if validation_data is not None:
+            validation_data = (self._fit_inputs(validation_data[0]), validation_data[1])
+        return _keras_fit(self, self._get_trainer(), self._fit_inputs(x), y, batch_size, epochs, validation_split, shuffle,
+                          callbacks, initial_epoch, validation_data)
+
+    def train_on_batch(self, x, y, **kw):
+        tr = self._get_trainer()
+        loss = tr.train_step(*[self._to_device(a) for a in self._fit_inputs(x)], self._to_device(y),
+                             **{k: (None if v is None else self._to_device(v)) for k, v in kw.items()})
+        self._w = tr.weights_numpy()
+        self._dw = None
+        return float(loss.item())
+
+
+class _SubModel:
+    def __init__(self, fn):
+        self._fn = fn
+
+    def predict(self, x, batch_size=None, verbose=0):
+        return self._fn(x)
+
+    predict_on_batch = predict
+
+
+class Seq2SeqLSTM(KerasModelSurface):
+    """Target-only seq2seq LSTM (1-layer encoder, 1-layer decoder, Dense(tanh) head)."""
+
+    def __init__(self, num_encoder_tokens=None, num_decoder_tokens=6, latent_dim=64, recurrent_activation=None,
+                 seed=None, impl="auto", device="cuda"):
+        self.num_encoder_tokens = 3 * cfg.fps if num_encoder_tokens is None else int(num_encoder_tokens)
+        self.num_decoder_tokens = int(num_decoder_tokens)
+        self.latent_dim = int(latent_dim)
+        self.recurrent_activation = recurrent_activation or cfg.recurrent_activation
+        if self.recurrent_activation not in ("sigmoid", "hard_sigmoid"):
+            raise ValueError("recurrent_activation must be 'sigmoid' or 'hard_sigmoid'")
+        rng = np.random.default_rng(seed)
+        w = {}
+        w["enc_K"], w["enc_R"], w["enc_b"] = init_lstm_weights(rng, self.num_encoder_tokens, self.latent_dim)
+        w["dec_K"], w["dec_R"], w["dec_b"] = init_lstm_weights(rng, self.num_decoder_tokens, self.latent_dim)
+        w["dense_W"] = glorot_uniform(rng, self.latent_dim, self.num_decoder_tokens)
+        w["dense_b"] = np.zeros(self.num_decoder_tokens, np.float32)
+        self._w = w
+        self._init_surface(_W_ORDER, impl, device)
+        self.encoder_model = _SubModel(self._encoder_predict)
+        self.decoder_model = _SubModel(self._decoder_predict)
+
     def _ops(self):
         from . import ops   # imported lazily so that host-only use does not need the .so
         return ops
 
-    def _device_weights(self):
-        import torch
-        if self._dw is None:
-            self._dw = {k: torch.from_numpy(v).to(self.device) for k, v in self._w.items()}
-            self._ws = self._ops().Workspace()
-        return self._dw
-
-    def _dev(self, a):
-        import torch
-        return torch.from_numpy(_as_f32(a)).to(self.device)
+    _dev = KerasModelSurface._to_device
 
     # ---- inference -------------------------------------------------------------------------
     def predict(self, x, batch_size=None, verbose=0):
@@ -244,54 +310,11 @@ class Seq2SeqLSTM:
         y = ops.dense(hs, dw["dense_W"], dw["dense_b"], activation="tanh")
         return [y.cpu().numpy(), hT.cpu().numpy(), cT.cpu().numpy()]
 
-    # ---- training surface ------------------------------------------------------------------
-    def compile(self, optimizer="Adam", loss="mean_squared_error", metrics=None):
-        """Keras `compile`.  Accepted: optimizer 'Adam' | 'RMSprop' (Keras defaults), loss
-        'mean_squared_error' | 'mse' (FoV_seq2seq.py:103)."""
-        opt = optimizer if isinstance(optimizer, str) else getattr(optimizer, "name", str(optimizer))
-        if opt.lower() not in ("adam", "rmsprop"):
-            raise ValueError("unsupported optimizer %r" % (optimizer,))
-        if str(loss).lower() not in ("mean_squared_error", "mse"):
-            raise ValueError("unsupported loss %r" % (loss,))
-        self.optimizer = opt.lower()
-        self.loss = "mse"
-        self.metrics = list(metrics or [])
-
-    @property
-    def lr(self):
-        return self._lr
-
-    @lr.setter
-    def lr(self, value):
-        self._lr = float(value)
-        if getattr(self, "_trainer", None) is not None:
-            self._trainer.lr = self._lr
-
-    def fit(self, x, y, batch_size=32, epochs=1, validation_split=0.0, shuffle=True, callbacks=None,
-            initial_epoch=0, verbose=0, validation_data=None):
-        """Keras `Model.fit` (FoV_seq2seq.py:112-117); see _keras_fit for the semantics.  Returns a History."""
+    # ---- training surface: KerasModelSurface (FoV_seq2seq.py:103 compile, :112-117 fit) ----
+    def _make_trainer(self, optimizer):
         from .training import Seq2SeqTrainer
-        if self.optimizer is None:
-            raise RuntimeError("call compile() before fit()")
-        if self._trainer is None:
-            self._trainer = Seq2SeqTrainer(self._w, act=self.recurrent_activation, impl=self.impl,
-                                           optimizer=self.optimizer, lr=self._lr, device=self.device)
-        return _keras_fit(self, self._trainer, [x[0], x[1]], y, batch_size, epochs, validation_split, shuffle, callbacks,
-                          initial_epoch, validation_data)
-
-    def train_on_batch(self, x, y):
-        import torch
-        from .training import Seq2SeqTrainer
-        if getattr(self, "_trainer", None) is None:
-            self._trainer = Seq2SeqTrainer(self._w, act=self.recurrent_activation, impl=self.impl,
-                                           optimizer=self.optimizer or "adam", lr=getattr(self, "_lr", 1e-3),
-                                           device=self.device)
-            self._lr = self._trainer.lr
-        d = lambda a: torch.from_numpy(_as_f32(a)).to(self.device)
-        loss = self._trainer.train_step(d(x[0]), d(x[1]), d(y))
-        self._w = self._trainer.weights_numpy()
-        self._dw = None
-        return float(loss.item())
+        return Seq2SeqTrainer(self._w, act=self.recurrent_activation, impl=self.impl, optimizer=optimizer, lr=self._lr,
+                              device=self.device)
 
 
 class NoTeacherForcingSeq2Seq(Seq2SeqLSTM):
@@ -318,28 +341,7 @@ class NoTeacherForcingSeq2Seq(Seq2SeqLSTM):
             rng = np.random.default_rng(None if seed is None else seed + 1)
             self._w["res_W"] = glorot_uniform(rng, self.num_decoder_tokens, self.num_decoder_tokens)
             self._w["res_b"] = np.zeros(self.num_decoder_tokens, np.float32)
-
-    def _order(self):
-        return _W_ORDER + (("res_W", "res_b") if self.add_residual_link else ())
-
-    def get_weights(self):
-        return [self._w[k].copy() for k in self._order()]
-
-    def set_weights(self, weights):
-        weights = list(weights)
-        if len(weights) != len(self._order()):
-            raise ValueError("expected %d arrays, got %d" % (len(self._order()), len(weights)))
-        for k, a in zip(self._order(), weights):
-            a = _as_f32(a)
-            if a.shape != self._w[k].shape:
-                raise ValueError("%s: expected shape %s, got %s" % (k, self._w[k].shape, a.shape))
-            self._w[k] = a
-        self._dw = None
-        self._trainer = None
-
-    def load_weights(self, path):
-        with np.load(path) as z:
-            self.set_weights([z[k] for k in self._order()])
+            self._order = _W_ORDER + ("res_W", "res_b")
 
     def _split_inputs(self, x):
         if self.enc_last_out_as_dec_in:
@@ -388,14 +390,12 @@ class NoTeacherForcingSeq2Seq(Seq2SeqLSTM):
 
     predict_on_batch = predict
 
-    def _get_trainer(self):
+    def _make_trainer(self, optimizer):
         from .training import SelfFedSeq2SeqTrainer
-        if self._trainer is None:
-            self._trainer = SelfFedSeq2SeqTrainer(
-                self._w, act=self.recurrent_activation, impl=self.impl, optimizer=self.optimizer or "adam", lr=self._lr,
-                device=self.device, decoder_no_init_state=self.decoder_no_init_state, add_residual_link=self.add_residual_link,
-                enc_last_out_as_dec_in=self.enc_last_out_as_dec_in, dense_activation=self.dense_activation)
-        return self._trainer
+        return SelfFedSeq2SeqTrainer(
+            self._w, act=self.recurrent_activation, impl=self.impl, optimizer=optimizer, lr=self._lr, device=self.device,
+            decoder_no_init_state=self.decoder_no_init_state, add_residual_link=self.add_residual_link,
+            enc_last_out_as_dec_in=self.enc_last_out_as_dec_in, dense_activation=self.dense_activation)
 
     def _fit_inputs(self, x):
         enc, dec0 = self._split_inputs(x)
@@ -403,28 +403,8 @@ class NoTeacherForcingSeq2Seq(Seq2SeqLSTM):
             dec0 = np.zeros((enc.shape[0], 1, self.num_decoder_tokens), np.float32)
         return [enc, dec0]
 
-    def fit(self, x, y, batch_size=32, epochs=1, validation_split=0.0, shuffle=True, callbacks=None, initial_epoch=0,
-            verbose=0, validation_data=None):
-        """Keras `Model.fit` as the script calls it (:289-300); see _keras_fit for the semantics."""
-        if self.optimizer is None:
-            raise RuntimeError("call compile() before fit()")
-        if validation_data is not None:
-            validation_data = (self._fit_inputs(validation_data[0]), validation_data[1])
-        return _keras_fit(self, self._get_trainer(), self._fit_inputs(x), y, batch_size, epochs, validation_split, shuffle,
-                          callbacks, initial_epoch, validation_data)
 
-    def train_on_batch(self, x, y):
-        import torch
-        tr = self._get_trainer()
-        d = lambda a: torch.from_numpy(_as_f32(a)).to(self.device)
-        enc, dec0 = self._fit_inputs(x)
-        loss = tr.train_step(d(enc), d(dec0), d(y))
-        self._w = tr.weights_numpy()
-        self._dw = None
-        return float(loss.item())
-
-
-class StackedSeq2SeqLSTM:
+class StackedSeq2SeqLSTM(KerasModelSurface):
     """L-layer target-only seq2seq of mycode/Fov_seq2seq_2layers.py (:232-272, sampling models :360-397, host loop :399-430)
     and 3layers.py: every layer `latent_dim` wide (the scripts pass latent_dim//2), encoder layer l seeds decoder layer l,
     Dense(6, tanh) on the top layer.  predict = the teacher-forced training graph, decode_sequence = the autoregressive
@@ -436,8 +416,6 @@ class StackedSeq2SeqLSTM:
         from .training import stacked_weight_order
         self.F, self.O, self.H, self.L = int(num_encoder_tokens), int(num_decoder_tokens), int(latent_dim), int(num_layers)
         self.recurrent_activation = recurrent_activation or cfg.recurrent_activation
-        self.impl, self.device = impl, device
-        self._order = stacked_weight_order(self.L)
         rng = np.random.default_rng(seed)
         w = {}
         for side, f0 in (("enc", self.F), ("dec", self.O)):
@@ -446,42 +424,12 @@ class StackedSeq2SeqLSTM:
                     init_lstm_weights(rng, f0 if l == 0 else self.H, self.H)
         w["dense_W"] = glorot_uniform(rng, self.H, self.O)
         w["dense_b"] = np.zeros(self.O, np.float32)
-        self._w, self._dw, self._ws, self._trainer = w, None, None, None
-        self.optimizer, self._lr, self.stop_training = None, 1e-3, False
-
-    def get_weights(self):
-        return [self._w[k].copy() for k in self._order]
-
-    def set_weights(self, weights):
-        weights = list(weights)
-        if len(weights) != len(self._order):
-            raise ValueError("expected %d arrays, got %d" % (len(self._order), len(weights)))
-        for k, a in zip(self._order, weights):
-            a = _as_f32(a)
-            if a.shape != self._w[k].shape:
-                raise ValueError("%s: expected shape %s, got %s" % (k, self._w[k].shape, a.shape))
-            self._w[k] = a
-        self._dw = self._trainer = None
-
-    def save_weights(self, path):
-        np.savez(path, **self._w)
-
-    save = save_weights
-
-    def load_weights(self, path):
-        with np.load(path) as z:
-            self.set_weights([z[k] for k in self._order])
-
-    def count_params(self):
-        return int(sum(v.size for v in self._w.values()))
+        self._w = w
+        self._init_surface(stacked_weight_order(self.L), impl, device)
 
     def _device(self):
-        import torch
         from . import ops
-        if self._dw is None:
-            self._dw = {k: torch.from_numpy(v).to(self.device) for k, v in self._w.items()}
-            self._ws = ops.Workspace()
-        return ops, self._dw
+        return ops, self._device_weights()
 
     def _encode(self, ops, dw, e):
         states, inp = [], e
@@ -538,47 +486,13 @@ class StackedSeq2SeqLSTM:
         self._ws.check()
         return np.concatenate(outs, axis=0) if outs else np.zeros((0, T_out, self.O), np.float32)
 
-    def compile(self, optimizer="Adam", loss="mean_squared_error", metrics=None):
-        opt = optimizer if isinstance(optimizer, str) else getattr(optimizer, "name", str(optimizer))
-        if opt.lower() not in ("adam", "rmsprop") or str(loss).lower() not in ("mean_squared_error", "mse"):
-            raise ValueError("unsupported optimizer / loss %r / %r" % (optimizer, loss))
-        self.optimizer, self.loss, self.metrics = opt.lower(), "mse", list(metrics or [])
-
-    @property
-    def lr(self):
-        return self._lr
-
-    @lr.setter
-    def lr(self, value):
-        self._lr = float(value)
-        if self._trainer is not None:
-            self._trainer.lr = self._lr
-
-    def _get_trainer(self):
+    def _make_trainer(self, optimizer):
         from .training import StackedSeq2SeqTrainer
-        if self._trainer is None:
-            self._trainer = StackedSeq2SeqTrainer(self._w, self.L, act=self.recurrent_activation, impl=self.impl,
-                                                  optimizer=self.optimizer or "adam", lr=self._lr, device=self.device)
-        return self._trainer
-
-    def fit(self, x, y, batch_size=32, epochs=1, validation_split=0.0, shuffle=True, callbacks=None, initial_epoch=0, verbose=0,
-            validation_data=None):
-        """Keras `Model.fit` as Fov_seq2seq_2layers.py:336-343 calls it."""
-        if self.optimizer is None:
-            raise RuntimeError("call compile() before fit()")
-        return _keras_fit(self, self._get_trainer(), [x[0], x[1]], y, batch_size, epochs, validation_split, shuffle, callbacks,
-                          initial_epoch, validation_data)
-
-    def train_on_batch(self, x, y):
-        import torch
-        d = lambda a: torch.from_numpy(_as_f32(a)).to(self.device)
-        tr = self._get_trainer()
-        loss = tr.train_step(d(x[0]), d(x[1]), d(y))
-        self._w, self._dw = tr.weights_numpy(), None
-        return float(loss.item())
+        return StackedSeq2SeqTrainer(self._w, self.L, act=self.recurrent_activation, impl=self.impl, optimizer=optimizer,
+                                     lr=self._lr, device=self.device)
 
 
-class OthersContextSeq2Seq:
+class OthersContextSeq2Seq(KerasModelSurface):
     """The other decoder heads of mycode/given_others_gt_mean_var_seq2seq.py (2+2-layer model, no teacher forcing), chosen by
     the script's module flags (:48-56):
       mode='target_user_only'  y_t = decoder_dense(h2_t)                                         (:219-220)
@@ -593,11 +507,10 @@ class OthersContextSeq2Seq:
         from .training import others_context_order
         if mode not in ("target_user_only", "others_mlp", "others_lstm"):
             raise ValueError("mode must be 'target_user_only', 'others_mlp' or 'others_lstm'")
-        self.mode, self._order = mode, others_context_order(mode)
+        self.mode = mode
         self.F = 3 * cfg.fps if num_encoder_tokens is None else int(num_encoder_tokens)
         self.O, self.H, self.U = int(num_decoder_tokens), int(latent_dim), int(num_user)
         self.recurrent_activation = recurrent_activation or cfg.recurrent_activation
-        self.impl, self.device = impl, device
         self.predict_step = cfg.predict_step if predict_step is None else int(predict_step)
         rng = np.random.default_rng(seed)
         w, H, n_oth = {}, self.H, (self.U - 1) * self.O
@@ -614,34 +527,8 @@ class OthersContextSeq2Seq:
                 for d in ("f", "b"):
                     n = "ol%d%s" % (j, d)
                     w[n + "_K"], w[n + "_R"], w[n + "_b"] = init_lstm_weights(rng, f, H)
-        self._w, self._dw, self._ws, self._trainer = w, None, None, None
-        self.optimizer, self._lr, self.stop_training = None, 1e-3, False
-
-    def get_weights(self):
-        return [self._w[k].copy() for k in self._order]
-
-    def set_weights(self, weights):
-        weights = list(weights)
-        if len(weights) != len(self._order):
-            raise ValueError("expected %d arrays, got %d" % (len(self._order), len(weights)))
-        for k, a in zip(self._order, weights):
-            a = _as_f32(a)
-            if a.shape != self._w[k].shape:
-                raise ValueError("%s: expected shape %s, got %s" % (k, self._w[k].shape, a.shape))
-            self._w[k] = a
-        self._dw = self._trainer = None
-
-    def save_weights(self, path):
-        np.savez(path, **self._w)
-
-    save = save_weights
-
-    def load_weights(self, path):
-        with np.load(path) as z:
-            self.set_weights([z[k] for k in self._order])
-
-    def count_params(self):
-        return int(sum(v.size for v in self._w.values()))
+        self._w = w
+        self._init_surface(others_context_order(mode), impl, device)
 
     def _inputs(self, x):
         if self.mode == "target_user_only":
@@ -679,10 +566,7 @@ class OthersContextSeq2Seq:
         import torch
         from . import ops
         enc, oth, dec0 = self._inputs(x)
-        if self._dw is None:
-            self._dw = {k: torch.from_numpy(v).to(self.device) for k, v in self._w.items()}
-            self._ws = ops.Workspace()
-        dw, act, H, O = self._dw, self.recurrent_activation, self.H, self.O
+        dw, act, H, O = self._device_weights(), self.recurrent_activation, self.H, self.O
         T_out = oth.shape[1]
         W_h = dw["dense_W"][dw["dense_W"].shape[0] - H:].contiguous()
         n = enc.shape[0]
@@ -713,52 +597,25 @@ class OthersContextSeq2Seq:
 
     predict_on_batch = predict
 
-    def compile(self, optimizer="Adam", loss="mean_squared_error", metrics=None):
-        opt = optimizer if isinstance(optimizer, str) else getattr(optimizer, "name", str(optimizer))
-        if opt.lower() not in ("adam", "rmsprop") or str(loss).lower() not in ("mean_squared_error", "mse"):
-            raise ValueError("unsupported optimizer / loss %r / %r" % (optimizer, loss))
-        self.optimizer, self.loss, self.metrics = opt.lower(), "mse", list(metrics or [])
-
-    @property
-    def lr(self):
-        return self._lr
-
-    @lr.setter
-    def lr(self, value):
-        self._lr = float(value)
-        if self._trainer is not None:
-            self._trainer.lr = self._lr
-
-    def _get_trainer(self):
+    def _make_trainer(self, optimizer):
         from .training import OthersContextTrainer
-        if self._trainer is None:
-            self._trainer = OthersContextTrainer(self._w, self.mode, act=self.recurrent_activation, impl=self.impl,
-                                                 optimizer=self.optimizer or "adam", lr=self._lr, device=self.device)
-        return self._trainer
+        return OthersContextTrainer(self._w, self.mode, act=self.recurrent_activation, impl=self.impl, optimizer=optimizer,
+                                    lr=self._lr, device=self.device)
 
-    def fit(self, x, y, batch_size=32, epochs=1, validation_split=0.0, shuffle=True, callbacks=None, initial_epoch=0, verbose=0,
-            validation_data=None):
+    def _fit_inputs(self, x):
+        return list(self._inputs(x))
+
+    def fit(self, x, y, **kw):
         """Keras `Model.fit` as the script calls it (:500-506)."""
-        if self.optimizer is None:
-            raise RuntimeError("call compile() before fit()")
-        if validation_data is not None:
-            validation_data = (list(self._inputs(validation_data[0])), validation_data[1])
         self.predict_step = _as_f32(y).shape[1]
-        return _keras_fit(self, self._get_trainer(), list(self._inputs(x)), y, batch_size, epochs, validation_split, shuffle,
-                          callbacks, initial_epoch, validation_data)
+        return super().fit(x, y, **kw)
 
     def train_on_batch(self, x, y):
-        import torch
-        d = lambda a: torch.from_numpy(_as_f32(a)).to(self.device)
         self.predict_step = _as_f32(y).shape[1]
-        enc, oth, dec0 = self._inputs(x)
-        tr = self._get_trainer()
-        loss = tr.train_step(d(enc), d(oth), d(dec0), d(y))
-        self._w, self._dw = tr.weights_numpy(), None
-        return float(loss.item())
+        return super().train_on_batch(x, y)
 
 
-class KerasSingleLSTM:
+class KerasSingleLSTM(KerasModelSurface):
     """Single-layer model of mycode/lstm_keras.py: ONE LSTM from zero state + Dense(6, tanh) per step, Adam + MSE.
       unrolled=False  1st part (:59-83): x (N,T,F) -> (N,T,6), one input second per step;
       unrolled=True   sampling model / 2nd part (:120-157,214-241): x (N,1,F) -> (N,predict_step,6); under
@@ -767,14 +624,12 @@ class KerasSingleLSTM:
                       the same input second is shown to every step.
     Weights in Keras order [kernel, recurrent_kernel, bias, dense kernel, dense bias]."""
 
-    _ORDER = ("K", "R", "b", "dense_W", "dense_b")
-
     def __init__(self, num_encoder_tokens=None, num_decoder_tokens=6, latent_dim=64, recurrent_activation=None, seed=None,
                  impl="auto", device="cuda", unrolled=False, sample_and_refeed=None, predict_step=None):
         self.F = 3 * cfg.fps if num_encoder_tokens is None else int(num_encoder_tokens)
         self.O, self.H = int(num_decoder_tokens), int(latent_dim)
         self.recurrent_activation = recurrent_activation or cfg.recurrent_activation
-        self.impl, self.device, self.unrolled = impl, device, bool(unrolled)
+        self.unrolled = bool(unrolled)
         if sample_and_refeed is None:
             sample_and_refeed = bool(cfg.predict_mean_var and cfg.sample_and_refeed)
         self.sample_and_refeed = bool(unrolled and sample_and_refeed)
@@ -786,44 +641,15 @@ class KerasSingleLSTM:
         w["K"], w["R"], w["b"] = init_lstm_weights(rng, self.F, self.H)
         w["dense_W"] = glorot_uniform(rng, self.H, self.O)
         w["dense_b"] = np.zeros(self.O, np.float32)
-        self._w, self._dw, self._ws, self._trainer = w, None, None, None
-        self.optimizer, self._lr, self.stop_training = None, 1e-3, False
-
-    def get_weights(self):
-        return [self._w[k].copy() for k in self._ORDER]
-
-    def set_weights(self, weights):
-        weights = list(weights)
-        if len(weights) != len(self._ORDER):
-            raise ValueError("expected %d arrays, got %d" % (len(self._ORDER), len(weights)))
-        for k, a in zip(self._ORDER, weights):
-            a = _as_f32(a)
-            if a.shape != self._w[k].shape:
-                raise ValueError("%s: expected shape %s, got %s" % (k, self._w[k].shape, a.shape))
-            self._w[k] = a
-        self._dw = self._trainer = None
-
-    def save_weights(self, path):
-        np.savez(path, **self._w)
-
-    save = save_weights
-
-    def load_weights(self, path):
-        with np.load(path) as z:
-            self.set_weights([z[k] for k in self._ORDER])
-
-    def count_params(self):
-        return int(sum(v.size for v in self._w.values()))
+        self._w = w
+        self._init_surface(("K", "R", "b", "dense_W", "dense_b"), impl, device)
 
     def predict(self, x, batch_size=None, verbose=0, noise=None):
         """`noise` (predict_step-1, N, F) standard normal for the sampled re-feed (drawn with torch.randn if None)."""
         import torch
         from . import ops
         x = _as_f32(x)
-        if self._dw is None:
-            self._dw = {k: torch.from_numpy(v).to(self.device) for k, v in self._w.items()}
-            self._ws = ops.Workspace()
-        dw, act = self._dw, self.recurrent_activation
+        dw, act = self._device_weights(), self.recurrent_activation
         n = x.shape[0]
         bs = n if not batch_size else int(batch_size)
         P = self.predict_step
@@ -855,54 +681,21 @@ class KerasSingleLSTM:
 
     predict_on_batch = predict
 
-    def compile(self, optimizer="Adam", loss="mean_squared_error", metrics=None):
-        opt = optimizer if isinstance(optimizer, str) else getattr(optimizer, "name", str(optimizer))
-        if opt.lower() not in ("adam", "rmsprop") or str(loss).lower() not in ("mean_squared_error", "mse"):
-            raise ValueError("unsupported optimizer / loss %r / %r" % (optimizer, loss))
-        self.optimizer, self.loss, self.metrics = opt.lower(), "mse", list(metrics or [])
-
-    @property
-    def lr(self):
-        return self._lr
-
-    @lr.setter
-    def lr(self, value):
-        self._lr = float(value)
-        if self._trainer is not None:
-            self._trainer.lr = self._lr
-
-    def _get_trainer(self):
+    def _make_trainer(self, optimizer):
         from .training import SingleLSTMTrainer
-        if self._trainer is None:
-            self._trainer = SingleLSTMTrainer(self._w, act=self.recurrent_activation, impl=self.impl, optimizer=self.optimizer or "adam",
-                                              lr=self._lr, device=self.device, unrolled=self.unrolled,
-                                              sample_and_refeed=self.sample_and_refeed)
-        return self._trainer
-
-    def fit(self, x, y, batch_size=32, epochs=1, validation_split=0.0, shuffle=True, callbacks=None, initial_epoch=0, verbose=0,
-            validation_data=None):
-        """Keras `Model.fit` as lstm_keras.py:101-107,262-268 calls it (single input array)."""
-        if self.optimizer is None:
-            raise RuntimeError("call compile() before fit()")
-        if validation_data is not None:
-            validation_data = ([validation_data[0]], validation_data[1])
-        return _keras_fit(self, self._get_trainer(), [x], y, batch_size, epochs, validation_split, shuffle, callbacks, initial_epoch,
-                          validation_data)
+        return SingleLSTMTrainer(self._w, act=self.recurrent_activation, impl=self.impl, optimizer=optimizer, lr=self._lr,
+                                 device=self.device, unrolled=self.unrolled, sample_and_refeed=self.sample_and_refeed)
 
     def train_on_batch(self, x, y, noise=None):
-        import torch
-        d = lambda a: torch.from_numpy(_as_f32(a)).to(self.device)
-        tr = self._get_trainer()
-        loss = tr.train_step(d(x), d(y), noise=None if noise is None else d(noise))
-        self._w, self._dw = tr.weights_numpy(), None
-        return float(loss.item())
+        """`noise` (predict_step-1, N, F): the normal draws of the sampled re-feed (torch.randn when None)."""
+        return super().train_on_batch(x, y, noise=noise)
 
 
 _MIX_ORDER = ("enc1_K", "enc1_R", "enc1_b", "enc2_K", "enc2_R", "enc2_b", "dec1_K", "dec1_R", "dec1_b",
               "dec2_K", "dec2_R", "dec2_b", "dense_W", "dense_b", "mix_W", "mix_b")
 
 
-class OthersMixingSeq2Seq:
+class OthersMixingSeq2Seq(KerasModelSurface):
     """Target + others mu/sigma^2 mixing seq2seq (mycode/given_others_gt_mean_var_seq2seq.py:98-308 with
     mlp_mixing, cfg.predict_mean_var=True, no teacher forcing): 2-layer LSTM encoder, 2-layer decoder
     unrolled `predict_step` times feeding its own output back, per-step Dense(6,tanh) and a mixing
@@ -922,7 +715,6 @@ class OthersMixingSeq2Seq:
         self.num_decoder_tokens = int(num_decoder_tokens)
         self.latent_dim, self.num_user = int(latent_dim), int(num_user)
         self.recurrent_activation = recurrent_activation or cfg.recurrent_activation
-        self.impl, self.device = impl, device
         rng = np.random.default_rng(seed)
         H, O = self.latent_dim, self.num_decoder_tokens
         w = {}
@@ -930,63 +722,14 @@ class OthersMixingSeq2Seq:
             w[name + "_K"], w[name + "_R"], w[name + "_b"] = init_lstm_weights(rng, F, H)
         w["dense_W"], w["dense_b"] = glorot_uniform(rng, H, O), np.zeros(O, np.float32)
         w["mix_W"], w["mix_b"] = glorot_uniform(rng, self.num_user * O, O), np.zeros(O, np.float32)
-        self._w, self._dw, self._ws = w, None, None
-        self._trainer, self._lr, self.optimizer, self.loss, self.stop_training = None, 1e-3, None, None, False
+        self._w = w
+        self._init_surface(_MIX_ORDER, impl, device)
 
-    def get_weights(self):
-        return [self._w[k].copy() for k in _MIX_ORDER]
-
-    def set_weights(self, weights):
-        weights = list(weights)
-        if len(weights) != len(_MIX_ORDER):
-            raise ValueError("expected %d arrays, got %d" % (len(_MIX_ORDER), len(weights)))
-        for k, a in zip(_MIX_ORDER, weights):
-            a = _as_f32(a)
-            if a.shape != self._w[k].shape:
-                raise ValueError("%s: expected shape %s, got %s" % (k, self._w[k].shape, a.shape))
-            self._w[k] = a
-        self._dw = None
-
-    def save_weights(self, path):
-        np.savez(path, **self._w)
-
-    def load_weights(self, path):
-        with np.load(path) as z:
-            self.set_weights([z[k] for k in _MIX_ORDER])
-
-    def count_params(self):
-        return int(sum(v.size for v in self._w.values()))
-
-    # ---- training surface (given_others...py:308 compile, :494-506 fit / fit_generator) ----
-    @property
-    def lr(self):
-        return self._lr
-
-    @lr.setter
-    def lr(self, value):
-        self._lr = float(value)
-        if self._trainer is not None:
-            self._trainer.lr = self._lr
-
-    def compile(self, optimizer="Adam", loss="mean_squared_error", metrics=None):
-        opt = optimizer if isinstance(optimizer, str) else getattr(optimizer, "name", str(optimizer))
-        if opt.lower() not in ("adam", "rmsprop") or str(loss).lower() not in ("mean_squared_error", "mse"):
-            raise ValueError("unsupported optimizer/loss %r / %r" % (optimizer, loss))
-        self.optimizer, self.loss, self.metrics = opt.lower(), "mse", list(metrics or [])
-
-    def _get_trainer(self):
+    # ---- training surface: KerasModelSurface (given_others...py:308 compile, :500-506 fit) + fit_generator (:494-498) ----
+    def _make_trainer(self, optimizer):
         from .training import OthersMixingTrainer
-        if self._trainer is None:
-            self._trainer = OthersMixingTrainer(self._w, act=self.recurrent_activation, impl=self.impl,
-                                                optimizer=self.optimizer or "adam", lr=self._lr, device=self.device)
-        return self._trainer
-
-    def fit(self, x, y, batch_size=32, epochs=1, validation_split=0.0, shuffle=True, callbacks=None,
-            initial_epoch=0, verbose=0, validation_data=None):
-        if self.optimizer is None:
-            raise RuntimeError("call compile() before fit()")
-        return _keras_fit(self, self._get_trainer(), list(x), y, batch_size, epochs, validation_split, shuffle, callbacks,
-                          initial_epoch, validation_data)
+        return OthersMixingTrainer(self._w, act=self.recurrent_activation, impl=self.impl, optimizer=optimizer, lr=self._lr,
+                                   device=self.device)
 
     def fit_generator(self, generator, steps_per_epoch, epochs=1, validation_data=None, validation_steps=None,
                       callbacks=None, use_multiprocessing=False, shuffle=True, initial_epoch=0, verbose=0):
@@ -1028,15 +771,6 @@ class OthersMixingSeq2Seq:
         for cb in cbs:
             cb.on_train_end()
         return hist
-
-    def train_on_batch(self, x, y):
-        import torch
-        d = lambda a: torch.from_numpy(_as_f32(a)).to(self.device)
-        tr = self._get_trainer()
-        loss = tr.train_step(*[d(a) for a in x], d(y))
-        self._w = tr.weights_numpy()
-        self._dw = None
-        return float(loss.item())
 
     def _device_weights(self):
         import torch
@@ -1152,7 +886,7 @@ class StackedTFLSTM:
         return inp.cpu().numpy(), torch.stack(states, dim=0).cpu().numpy()
 
 
-class ConvLSTMSeq2Seq:
+class ConvLSTMSeq2Seq(KerasModelSurface):
     """ConvLSTM2D seq2seq (mycode/convlstm_seq2seq.py:100-282): 3-layer ConvLSTM2D encoder (filters
     2L, L, L/2, k x k, padding 'same'), mirrored decoder unrolled `predict_step` times with state hand-off,
     channel concat of the three layer outputs, head, output fed back as the next input.
@@ -1166,50 +900,24 @@ class ConvLSTMSeq2Seq:
     dropout when dropout_rate > 0 (training only).  Weights: dict with
     enc{l}_K/R/b, dec{l}_K/R/b (Keras ConvLSTM2D layout (kh,kw,C,4F)) and head{i}_W/b."""
 
-    def __init__(self, weights, head="conv2d", recurrent_activation="hard_sigmoid", device="cuda", dropout_rate=0.0):
-        self.head, self.act, self.device = head, recurrent_activation, device
-        self._w = {k: _as_f32(v) for k, v in weights.items()}
-        self._dw = None
-        self._trainer, self.optimizer, self.loss, self._lr = None, None, None, 1e-3
-        self.dropout_rate = float(dropout_rate)
-        self.stop_training = False
+    _default_optimizer = "rmsprop"      # convlstm_seq2seq.py:287
 
-    def get_weights(self):
+    def __init__(self, weights, head="conv2d", recurrent_activation="hard_sigmoid", device="cuda", dropout_rate=0.0):
         from .training import convlstm_weight_order
-        return [self._w[k].copy() for k in convlstm_weight_order(self._w)]
+        self.head, self.act = head, recurrent_activation
+        self._w = {k: _as_f32(v) for k, v in weights.items()}
+        self._init_surface(convlstm_weight_order(self._w), None, device)
+        self.dropout_rate = float(dropout_rate)
 
     def compile(self, optimizer="RMSprop", loss="mean_squared_error", metrics=None):
         """Keras `compile` (convlstm_seq2seq.py:287).  optimizer 'RMSprop' | 'Adam' (Keras defaults); loss
         'mean_squared_error' | 'mse' | a callable named `_mse` (cost.py:20-22 without cfg.add_xyz_sum1)."""
-        opt = optimizer if isinstance(optimizer, str) else getattr(optimizer, "name", str(optimizer))
-        lname = loss if isinstance(loss, str) else getattr(loss, "__name__", str(loss))
-        if opt.lower() not in ("adam", "rmsprop") or lname.lower() not in ("mean_squared_error", "mse", "_mse"):
-            raise ValueError("unsupported optimizer/loss %r / %r" % (optimizer, loss))
-        self.optimizer, self.loss, self.metrics = opt.lower(), "mse", list(metrics or [])
+        super().compile(optimizer, loss, metrics)
 
-    def _get_trainer(self):
+    def _make_trainer(self, optimizer):
         from .training import ConvLSTMTrainer
-        if self._trainer is None:
-            self._trainer = ConvLSTMTrainer(self._w, head=self.head, act=self.act, optimizer=self.optimizer or "rmsprop",
-                                            lr=self._lr, device=self.device, dropout_rate=self.dropout_rate)
-        return self._trainer
-
-    def fit(self, x, y, batch_size=32, epochs=1, validation_split=0.0, shuffle=True, callbacks=None,
-            initial_epoch=0, verbose=0, validation_data=None):
-        """Keras `Model.fit` (convlstm_seq2seq.py:407-412); y (N,T_out,H,W,C_out).  See _keras_fit."""
-        if self.optimizer is None:
-            raise RuntimeError("call compile() before fit()")
-        return _keras_fit(self, self._get_trainer(), list(x), y, batch_size, epochs, validation_split, shuffle, callbacks,
-                          initial_epoch, validation_data)
-
-    def train_on_batch(self, x, y):
-        import torch
-        d = lambda a: torch.from_numpy(_as_f32(a)).to(self.device)
-        tr = self._get_trainer()
-        loss = tr.train_step(d(x[0]), d(x[1]), d(y))
-        self._w = tr.weights_numpy()
-        self._dw = None
-        return float(loss.item())
+        return ConvLSTMTrainer(self._w, head=self.head, act=self.act, optimizer=optimizer, lr=self._lr, device=self.device,
+                               dropout_rate=self.dropout_rate)
 
     def predict(self, x, batch_size=None, predict_step=None, verbose=0):
         import torch

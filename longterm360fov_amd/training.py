@@ -11,15 +11,19 @@ from . import ops, parallel
 _W_ORDER = ("enc_K", "enc_R", "enc_b", "dec_K", "dec_R", "dec_b", "dense_W", "dense_b")
 
 
-class Seq2SeqTrainer:
-    def __init__(self, weights, act="sigmoid", impl="auto", optimizer="adam", lr=1e-3, device="cuda", order=_W_ORDER):
-        self.act, self.impl, self.optimizer, self.lr, self.device = act, impl, optimizer, float(lr), device
+class FlatParamTrainer:
+    """What every trainer of the Keras-optimizer models shares: parameters and gradients live in ONE flat buffer each
+    (views per tensor in self.w / self.g), so the optimizer is one launch and data parallelism is ONE all-reduce; a
+    subclass provides forward_backward(*inputs, grad_weight=1.0) -> (loss (1,), prediction) filling self.grad."""
+
+    def _alloc(self, weights, order, optimizer, lr, device):
+        self.optimizer, self.lr, self.device = optimizer.lower(), float(lr), device
         self.shapes = [(k, tuple(weights[k].shape)) for k in order]
         n = int(sum(np.prod(s) for _, s in self.shapes))
         self.flat = torch.empty(n, dtype=torch.float32, device=device)     # parameters, one buffer
         self.grad = torch.zeros(n, dtype=torch.float32, device=device)     # gradients, same layout
         self.m = torch.zeros(n, dtype=torch.float32, device=device)
-        self.v = torch.zeros(n, dtype=torch.float32, device=device) if optimizer == "adam" else None
+        self.v = torch.zeros(n, dtype=torch.float32, device=device) if self.optimizer == "adam" else None
         self.w, self.g = {}, {}
         off = 0
         for k, s in self.shapes:
@@ -32,10 +36,44 @@ class Seq2SeqTrainer:
         self.ws = ops.Workspace()
         self.scratch = ops.Scratch()        # split-K partials of the Dense / MSE / matmul calls
         self.bwd_scratch = ops.Scratch()    # BPTT calls only: its first word is the persistent kernel's status
-        self._bufs = {}
 
     def weights_numpy(self):
         return {k: v.detach().cpu().numpy().copy() for k, v in self.w.items()}
+
+    def apply_gradients(self):
+        """Keras Adam / RMSprop on the flat buffer (model.compile(optimizer=...), FoV_seq2seq.py:103, convlstm_seq2seq.py:287)."""
+        self.step_count += 1
+        if self.optimizer == "adam":
+            ops.adam_step(self.flat, self.grad, self.m, self.v, self.step_count, lr=self.lr)
+        else:
+            ops.rmsprop_step(self.flat, self.grad, self.m, lr=self.lr)
+
+    def train_step(self, *inputs, n_global=None, **kw):
+        """One optimizer step on (*model inputs, target).  Under data parallelism every rank passes its shard of the
+        global batch and `n_global` = global batch size: gradients are combined as sum_r (n_r/n) g_r with a single
+        all-reduce of the flat buffer, so the update equals the single-process one."""
+        _, world = parallel.world()
+        n_local = inputs[0].shape[0]
+        weight = 1.0 if world == 1 else n_local / float(n_global if n_global else n_local * world)
+        loss, _ = self.forward_backward(*inputs, grad_weight=weight, **kw)
+        if world > 1:
+            torch.distributed.all_reduce(self.grad, op=torch.distributed.ReduceOp.SUM)
+            loss = loss * weight
+            torch.distributed.all_reduce(loss, op=torch.distributed.ReduceOp.SUM)
+        self.apply_gradients()
+        return loss
+
+    def eval_loss(self, *inputs):
+        """Validation loss through the training forward (gradients are overwritten by the next step)."""
+        loss, _ = self.forward_backward(*inputs)
+        return loss
+
+
+class Seq2SeqTrainer(FlatParamTrainer):
+    def __init__(self, weights, act="sigmoid", impl="auto", optimizer="adam", lr=1e-3, device="cuda"):
+        self.act, self.impl = act, impl
+        self._alloc(weights, _W_ORDER, optimizer, lr, device)
+        self._bufs = {}
 
     def _buffers(self, B, T_in, T_out):
         key = (B, T_in, T_out)
@@ -74,36 +112,13 @@ class Seq2SeqTrainer:
             self.grad.mul_(grad_weight)
         return loss, y
 
-    def apply_gradients(self):
-        self.step_count += 1
-        if self.optimizer == "adam":
-            ops.adam_step(self.flat, self.grad, self.m, self.v, self.step_count, lr=self.lr)
-        else:
-            ops.rmsprop_step(self.flat, self.grad, self.m, lr=self.lr)
-
-    def train_step(self, enc, dec_in, target, n_global=None):
-        """One optimizer step.  Under data parallelism every rank passes its shard of the global
-        batch and `n_global` = global batch size: gradients are combined as sum_r (n_r/n) g_r with a
-        single all-reduce of the flat buffer, so the update equals the single-process one."""
-        _, world = parallel.world()
-        n_local = enc.shape[0]
-        weight = 1.0 if world == 1 else n_local / float(n_global if n_global else n_local * world)
-        loss, _ = self.forward_backward(enc, dec_in, target, grad_weight=weight)
-        if world > 1:
-            torch.distributed.all_reduce(self.grad, op=torch.distributed.ReduceOp.SUM)
-            lw = loss * weight
-            torch.distributed.all_reduce(lw, op=torch.distributed.ReduceOp.SUM)
-            loss = lw
-        self.apply_gradients()
-        return loss
-
     def eval_loss(self, enc, dec_in, target):
         y = ops.seq2seq_teacher_forced(enc, dec_in, self.w, act=self.act, impl=self.impl, workspace=self.ws)
         _, loss = ops.mse_dense_grad(y, target, None, scratch=self.scratch)
         return loss
 
 
-class SelfFedSeq2SeqTrainer(Seq2SeqTrainer):
+class SelfFedSeq2SeqTrainer(FlatParamTrainer):
     """Training step of the one-layer target-only model WITHOUT teacher forcing
     (mycode/FoV_seq2seq_no_teac_forc.py:37-149, `onelayer_tar_seq2seq`; Adam + MSE, :147): the decoder is unrolled
     T_out times on its own output.  Same layer kernels as the teacher-forced trainer, walked step by step: forward
@@ -119,8 +134,8 @@ class SelfFedSeq2SeqTrainer(Seq2SeqTrainer):
     def __init__(self, weights, act="sigmoid", impl="auto", optimizer="adam", lr=1e-3, device="cuda",
                  decoder_no_init_state=True, add_residual_link=False, enc_last_out_as_dec_in=False,
                  dense_activation="tanh"):
-        super().__init__(weights, act=act, impl=impl, optimizer=optimizer, lr=lr, device=device,
-                         order=_W_ORDER + (("res_W", "res_b") if add_residual_link else ()))
+        self.act, self.impl = act, impl
+        self._alloc(weights, _W_ORDER + (("res_W", "res_b") if add_residual_link else ()), optimizer, lr, device)
         self.no_init, self.residual, self.enc_as_in = bool(decoder_no_init_state), bool(add_residual_link), bool(enc_last_out_as_dec_in)
         self.dact = dense_activation
 
@@ -205,9 +220,6 @@ class SelfFedSeq2SeqTrainer(Seq2SeqTrainer):
             self.grad.mul_(grad_weight)
         return loss, out
 
-    def eval_loss(self, enc, dec_in, target):
-        loss, _ = self.forward_backward(enc, dec_in, target)   # gradients are overwritten by the next step
-        return loss
 
 
 def stacked_weight_order(num_layers):
@@ -215,15 +227,15 @@ def stacked_weight_order(num_layers):
         ("dense_W", "dense_b")
 
 
-class StackedSeq2SeqTrainer(Seq2SeqTrainer):
+class StackedSeq2SeqTrainer(FlatParamTrainer):
     """Teacher-forced training step of the L-layer target-only seq2seq (mycode/Fov_seq2seq_2layers.py:232-272,332-343 and
     3layers.py:222-300): encoder layer l hands its final (h, c) to decoder layer l, every layer returns its sequence to
     the next, Dense(6, tanh) on the top decoder layer; Adam + MSE.  Same layer kernels as the one-layer trainer, one
     forward-with-reserve and one BPTT launch per layer."""
 
     def __init__(self, weights, num_layers, act="sigmoid", impl="auto", optimizer="adam", lr=1e-3, device="cuda"):
-        self.L = int(num_layers)
-        super().__init__(weights, act=act, impl=impl, optimizer=optimizer, lr=lr, device=device, order=stacked_weight_order(self.L))
+        self.L, self.act, self.impl = int(num_layers), act, impl
+        self._alloc(weights, stacked_weight_order(self.L), optimizer, lr, device)
 
     def forward_backward(self, enc, dec_in, target, grad_weight=1.0):
         w, g, act, impl, ws, L = self.w, self.g, self.act, self.impl, self.ws, self.L
@@ -260,9 +272,6 @@ class StackedSeq2SeqTrainer(Seq2SeqTrainer):
             self.grad.mul_(grad_weight)
         return loss, y
 
-    def eval_loss(self, enc, dec_in, target):
-        loss, _ = self.forward_backward(enc, dec_in, target)      # gradients are overwritten by the next step
-        return loss
 
 
 def others_context_order(mode):
@@ -274,7 +283,7 @@ def others_context_order(mode):
     return base
 
 
-class OthersContextTrainer(Seq2SeqTrainer):
+class OthersContextTrainer(FlatParamTrainer):
     """Training step of the other decoder heads of mycode/given_others_gt_mean_var_seq2seq.py (2+2-layer model, no teacher
     forcing, Adam + MSE): `target_user_only` (:219-220), `others_mlp` (:153-156,223-233), `others_lstm` (two Bidirectional
     LSTMs over the others' future mu/var, :157-166,234-240).  The others only enter through a per-step context that
@@ -284,8 +293,8 @@ class OthersContextTrainer(Seq2SeqTrainer):
 
     def __init__(self, weights, mode, act="sigmoid", impl="auto", optimizer="adam", lr=1e-3, device="cuda"):
         assert mode in ("target_user_only", "others_mlp", "others_lstm")
-        self.mode = mode
-        super().__init__(weights, act=act, impl=impl, optimizer=optimizer, lr=lr, device=device, order=others_context_order(mode))
+        self.mode, self.act, self.impl = mode, act, impl
+        self._alloc(weights, others_context_order(mode), optimizer, lr, device)
 
     # ---- context: forward keeps what its backward needs ----
     def _bi_fwd(self, x, j, init):
@@ -412,27 +421,12 @@ class OthersContextTrainer(Seq2SeqTrainer):
             self.grad.mul_(grad_weight)
         return loss, out
 
-    def eval_loss(self, enc, others, dec0, target):
-        loss, _ = self.forward_backward(enc, others, dec0, target)      # gradients are overwritten by the next step
-        return loss
-
-    def train_step(self, enc, others, dec0, target, n_global=None):
-        _, world = parallel.world()
-        n_local = enc.shape[0]
-        weight = 1.0 if world == 1 else n_local / float(n_global if n_global else n_local * world)
-        loss, _ = self.forward_backward(enc, others, dec0, target, grad_weight=weight)
-        if world > 1:
-            torch.distributed.all_reduce(self.grad, op=torch.distributed.ReduceOp.SUM)
-            loss = loss * weight
-            torch.distributed.all_reduce(loss, op=torch.distributed.ReduceOp.SUM)
-        self.apply_gradients()
-        return loss
 
 
 _SINGLE_ORDER = ("K", "R", "b", "dense_W", "dense_b")
 
 
-class SingleLSTMTrainer(Seq2SeqTrainer):
+class SingleLSTMTrainer(FlatParamTrainer):
     """Training step of the single-layer Keras model of mycode/lstm_keras.py: ONE LSTM from zero state + Dense(6, tanh)
     per step, Adam + MSE (:59-83,214-241).  Two unrollings:
       per-step   (1st part, :70-80): the T input seconds are consumed one per step - LSTM(return_sequences) + Dense;
@@ -444,7 +438,8 @@ class SingleLSTMTrainer(Seq2SeqTrainer):
 
     def __init__(self, weights, act="sigmoid", impl="auto", optimizer="adam", lr=1e-3, device="cuda", unrolled=False,
                  sample_and_refeed=False):
-        super().__init__(weights, act=act, impl=impl, optimizer=optimizer, lr=lr, device=device, order=_SINGLE_ORDER)
+        self.act, self.impl = act, impl
+        self._alloc(weights, _SINGLE_ORDER, optimizer, lr, device)
         self.unrolled, self.refeed = bool(unrolled), bool(unrolled and sample_and_refeed)
 
     def _sequence(self, x_seq, target):
@@ -515,28 +510,13 @@ class SingleLSTMTrainer(Seq2SeqTrainer):
             self.grad.mul_(grad_weight)
         return loss, y
 
-    def eval_loss(self, x, target):
-        loss, _ = self.forward_backward(x, target)      # gradients are overwritten by the next step
-        return loss
-
-    def train_step(self, x, target, noise=None, n_global=None):
-        _, world = parallel.world()
-        n_local = x.shape[0]
-        weight = 1.0 if world == 1 else n_local / float(n_global if n_global else n_local * world)
-        loss, _ = self.forward_backward(x, target, noise=noise, grad_weight=weight)
-        if world > 1:
-            torch.distributed.all_reduce(self.grad, op=torch.distributed.ReduceOp.SUM)
-            loss = loss * weight
-            torch.distributed.all_reduce(loss, op=torch.distributed.ReduceOp.SUM)
-        self.apply_gradients()
-        return loss
 
 
 _MIX_ORDER = ("enc1_K", "enc1_R", "enc1_b", "enc2_K", "enc2_R", "enc2_b", "dec1_K", "dec1_R", "dec1_b",
               "dec2_K", "dec2_R", "dec2_b", "dense_W", "dense_b", "mix_W", "mix_b")
 
 
-class OthersMixingTrainer:
+class OthersMixingTrainer(FlatParamTrainer):
     """Training step of the 2+2-layer others-mixing model WITHOUT teacher forcing
     (mycode/given_others_gt_mean_var_seq2seq.py:203-308: Adam + MSE on the unrolled decoder whose output
     is fed back).  Forward of the unrolled decoder: ONE persistent launch (fov_mix_decoder_fwd, H = 256) that
@@ -549,27 +529,9 @@ class OthersMixingTrainer:
     fused_decoder_bwd = True   # H = 256: BPTT through the unrolled decoder as ONE launch; False = step-wise calls
 
     def __init__(self, weights, act="sigmoid", impl="auto", optimizer="adam", lr=1e-3, device="cuda"):
-        self.act, self.impl, self.optimizer, self.lr, self.device = act, impl, optimizer, float(lr), device
-        self.shapes = [(k, tuple(weights[k].shape)) for k in _MIX_ORDER]
-        n = int(sum(np.prod(s) for _, s in self.shapes))
-        self.flat = torch.empty(n, dtype=torch.float32, device=device)
-        self.grad = torch.zeros(n, dtype=torch.float32, device=device)
-        self.m = torch.zeros(n, dtype=torch.float32, device=device)
-        self.v = torch.zeros(n, dtype=torch.float32, device=device) if optimizer == "adam" else None
-        self.w, self.g = {}, {}
-        off = 0
-        for k, s in self.shapes:
-            cnt = int(np.prod(s))
-            self.w[k] = self.flat[off:off + cnt].view(*s)
-            self.g[k] = self.grad[off:off + cnt].view(*s)
-            self.w[k].copy_(torch.from_numpy(np.ascontiguousarray(weights[k], dtype=np.float32)))
-            off += cnt
-        self.step_count = 0
-        self.ws, self.scratch, self.bwd_scratch = ops.Workspace(), ops.Scratch(), ops.Scratch()
+        self.act, self.impl = act, impl
+        self._alloc(weights, _MIX_ORDER, optimizer, lr, device)
         self.ws_bwd = ops.Workspace()   # granule mailboxes of the fused decoder backward
-
-    def weights_numpy(self):
-        return {k: v.detach().cpu().numpy().copy() for k, v in self.w.items()}
 
     def forward_backward(self, enc, others, dec0, target, grad_weight=1.0):
         w, g, act, impl, ws, sc, bsc = self.w, self.g, self.act, self.impl, self.ws, self.scratch, self.bwd_scratch
@@ -678,32 +640,6 @@ class OthersMixingTrainer:
             self.grad.mul_(grad_weight)
         return loss, out
 
-    def apply_gradients(self):
-        self.step_count += 1
-        if self.optimizer == "adam":
-            ops.adam_step(self.flat, self.grad, self.m, self.v, self.step_count, lr=self.lr)
-        else:
-            ops.rmsprop_step(self.flat, self.grad, self.m, lr=self.lr)
-
-    def eval_loss(self, enc, others, dec0, target):
-        """Validation loss (forward only, through the same step-wise path)."""
-        loss, _ = self.forward_backward(enc, others, dec0, target)   # gradients are overwritten by the next step
-        return loss
-
-    def train_step(self, enc, others, dec0, target, n_global=None):
-        _, world = parallel.world()
-        n_local = enc.shape[0]
-        weight = 1.0 if world == 1 else n_local / float(n_global if n_global else n_local * world)
-        loss, _ = self.forward_backward(enc, others, dec0, target, grad_weight=weight)
-        if world > 1:
-            torch.distributed.all_reduce(self.grad, op=torch.distributed.ReduceOp.SUM)
-            lw = loss * weight
-            torch.distributed.all_reduce(lw, op=torch.distributed.ReduceOp.SUM)
-            loss = lw
-        self.apply_gradients()
-        return loss
-
-
 
 def convlstm_weight_order(weights):
     """Parameter order of the ConvLSTM seq2seq: enc0..2, dec0..2 (K, R, b each), then the head layers."""
@@ -718,7 +654,7 @@ def convlstm_weight_order(weights):
     return order
 
 
-class ConvLSTMTrainer:
+class ConvLSTMTrainer(FlatParamTrainer):
     """Training step of the ConvLSTM2D seq2seq (mycode/convlstm_seq2seq.py:100-287: 3-layer encoder, 3-layer
     decoder unrolled `predict_step` times with its own prediction fed back, conv head + channel softmax,
     `model.compile(optimizer='RMSprop', loss=costfunc._mse)`).
@@ -746,30 +682,11 @@ class ConvLSTMTrainer:
         self.dropout_rate = float(dropout_rate)
         self._gen = torch.Generator(device=device)
         self._gen.manual_seed(int(seed))
-        self.head, self.act, self.optimizer, self.lr, self.device = head, act, optimizer.lower(), float(lr), device
+        self.head, self.act = head, act
         self.order = convlstm_weight_order(weights)
-        self.shapes = [(k, tuple(weights[k].shape)) for k in self.order]
-        n = int(sum(np.prod(s) for _, s in self.shapes))
-        self.flat = torch.empty(n, dtype=torch.float32, device=device)
-        self.grad = torch.zeros(n, dtype=torch.float32, device=device)
-        self.m = torch.zeros(n, dtype=torch.float32, device=device)
-        self.v = torch.zeros(n, dtype=torch.float32, device=device) if self.optimizer == "adam" else None
-        self.w, self.g = {}, {}
-        off = 0
-        for k, s in self.shapes:
-            cnt = int(np.prod(s))
-            self.w[k] = self.flat[off:off + cnt].view(*s)
-            self.g[k] = self.grad[off:off + cnt].view(*s)
-            self.w[k].copy_(torch.from_numpy(np.ascontiguousarray(weights[k], dtype=np.float32)))
-            off += cnt
+        self._alloc(weights, self.order, optimizer, lr, device)   # ws / bwd_scratch stay unused; the shared fit loop checks them
         self.n_head = sum(1 for k in self.order if k.startswith("head") and k.endswith("_W"))
-        self.step_count = 0
-        self.scratch = ops.Scratch()
-        self.ws, self.bwd_scratch = ops.Workspace(), ops.Scratch()   # unused here; the shared fit loop checks them
         self.filters = [self.w["enc%d_R" % l].shape[2] for l in range(3)]
-
-    def weights_numpy(self):
-        return {k: v.detach().cpu().numpy().copy() for k, v in self.w.items()}
 
     # -- forward with tape ---------------------------------------------------------------------------
     def sample_masks(self, B, H, W, C, T_out):
@@ -991,28 +908,6 @@ class ConvLSTMTrainer:
     def eval_loss(self, enc, dec0, target):
         P, _ = self._forward(enc, dec0, target.shape[1])
         _, loss = ops.mse_dense_grad(P, target.transpose(0, 1).contiguous(), None, scratch=self.scratch)
-        return loss
-
-    def apply_gradients(self):
-        self.step_count += 1
-        if self.optimizer == "adam":
-            ops.adam_step(self.flat, self.grad, self.m, self.v, self.step_count, lr=self.lr)
-        else:
-            ops.rmsprop_step(self.flat, self.grad, self.m, lr=self.lr)
-
-    def train_step(self, enc, dec0, target, n_global=None):
-        """One optimizer step; under data parallelism gradients combine as sum_r (n_r/n) g_r with ONE
-        all-reduce of the flat buffer (as Seq2SeqTrainer.train_step)."""
-        _, world = parallel.world()
-        n_local = enc.shape[0]
-        weight = 1.0 if world == 1 else n_local / float(n_global if n_global else n_local * world)
-        loss, _ = self.forward_backward(enc, dec0, target, grad_weight=weight)
-        if world > 1:
-            torch.distributed.all_reduce(self.grad, op=torch.distributed.ReduceOp.SUM)
-            lw = loss * weight
-            torch.distributed.all_reduce(lw, op=torch.distributed.ReduceOp.SUM)
-            loss = lw
-        self.apply_gradients()
         return loss
 
 
