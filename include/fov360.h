@@ -257,6 +257,12 @@ int fov_gauss_nll_grad(const float* mu, const float* var, const float* y, float*
 int fov_rmsprop_tf_step(float* params, const float* grads, float* ms, int64_t n, float lr, float decay, float eps,
                         float clip_value, fov_stream_t stream);
 
+/* The optional term of costfunc._mse under cfg.add_xyz_sum1 (mycode/cost.py:20-29): reg = 0.5 * mean over pixels of
+ * (ux^2 + uy^2 + uz^2 - 1)^2 on the first three channels of p (n_pix, C), C >= 3.  Its gradient 2 (s - 1) u_k / n_pix is
+ * ADDED into dp (which holds the MSE gradient); *reg (may be NULL) receives the term.  workspace >= 4*(n_pix/256 + 65) bytes. */
+int fov_xyz_sum1_grad(const float* p, float* dp, float* reg, int64_t n_pix, int C, void* workspace, size_t workspace_bytes,
+                      fov_stream_t stream);
+
 /* Sampled re-feed: the next input second drawn around the predicted mean / variance - what lstm.py:460-468 builds from
  * utility.generate_fake_batch_tf (utility.py:83-89) in its predict_len > 1 training graph, and lstm_keras.py:39-44,139-149
  * in its cfg.sample_and_refeed sampling model.  x[b, e] = mu[b, a(e)] + sd(var[b, a(e)]) * noise[b, e] for the 3*fps

@@ -494,6 +494,18 @@ int fov_gauss_nll_grad(const float* mu, const float* var, const float* y, float*
                           (hipStream_t)stream);
 }
 
+int fov_xyz_sum1_grad(const float* p, float* dp, float* reg, int64_t n_pix, int C, void* workspace, size_t workspace_bytes,
+                      fov_stream_t stream) {
+    if (n_pix < 0 || C < 3 || (n_pix > 0 && (!p || !dp))) {
+        set_error("fov_xyz_sum1_grad: invalid argument");
+        return FOV_ERR_INVALID;
+    }
+    if (n_pix == 0) return FOV_OK;
+    int rc = check_ws(workspace, workspace_bytes, sizeof(float) * ((size_t)(n_pix + 255) / 256 + 64));
+    if (rc) return rc;
+    return xyz_sum1_grad(p, dp, reg, (long)n_pix, C, (float*)workspace, workspace_bytes / sizeof(float), (hipStream_t)stream);
+}
+
 int fov_sample_refeed_fwd(const float* mu, const float* var, const float* noise, float* x, int64_t ldx, int B, int fps,
                           int std_mode, int layout, fov_stream_t stream) {
     if (B < 0 || fps <= 0 || ldx < 3 * (int64_t)fps || (std_mode | layout) & ~1 || (B > 0 && (!mu || !var || !noise || !x))) {

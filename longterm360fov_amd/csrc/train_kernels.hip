@@ -494,6 +494,32 @@ __global__ __launch_bounds__(64) void sample_refeed_bwd_kernel(const float* __re
     }
 }
 
+// Unit-norm regulariser of costfunc._mse under cfg.add_xyz_sum1 (mycode/cost.py:20-29): per pixel (row of C >= 3 channels)
+// r = ux^2 + uy^2 + uz^2 - 1;  reg = 0.5 * mean_pixels r^2;  d reg / d u_k = 2 r u_k / n_pix, ADDED to dp.  Block partials of
+// sum r^2 go to part[] (reduced in fixed order by sum_scale_kernel, so the loss is deterministic).
+__global__ __launch_bounds__(256) void xyz_sum1_kernel(const float* __restrict__ p, float* __restrict__ dp, float* __restrict__ part,
+                                                       long n_pix, int C) {
+    __shared__ float red[256];
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    float r2 = 0.f;
+    if (i < n_pix) {
+        const float x = p[i * C], y = p[i * C + 1], z = p[i * C + 2];
+        const float r = x * x + y * y + z * z - 1.f;
+        const float gsc = 2.f * r / (float)n_pix;
+        dp[i * C] += gsc * x;
+        dp[i * C + 1] += gsc * y;
+        dp[i * C + 2] += gsc * z;
+        r2 = r * r;
+    }
+    red[threadIdx.x] = r2;
+    __syncthreads();
+    for (int m = 128; m >= 1; m >>= 1) {
+        if ((int)threadIdx.x < m) red[threadIdx.x] += red[threadIdx.x + m];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) part[blockIdx.x] = red[0];
+}
+
 // tf.train.RMSPropOptimizer (TF 1.x, momentum 0, not centered; mycode/lstm.py:556-567) with the script's optional
 // clip_by_value(grad, -clip, clip):  ms = decay*ms + (1-decay) g^2;  p -= lr * g / sqrt(ms + eps).  (eps INSIDE the
 // root, ms initialised to ONE - both unlike Keras RMSprop.)
@@ -992,6 +1018,17 @@ int gauss_nll_grad(const float* mu, const float* var, const float* y, float* los
     int rc = check_launch("gauss_nll");
     if (rc || !loss) return rc;
     hipLaunchKernelGGL(sum_scale_kernel, dim3(1), dim3(256), 0, stream, scratch, loss, B, scale / (float)B);
+    return check_launch("sum_scale");
+}
+
+int xyz_sum1_grad(const float* p, float* dp, float* reg, long n_pix, int C, float* scratch, size_t scratch_floats, hipStream_t stream) {
+    if (n_pix <= 0) return FOV_OK;
+    const long blocks = (n_pix + 255) / 256;
+    if ((size_t)blocks > scratch_floats) { set_error("xyz_sum1_grad: scratch too small"); return FOV_ERR_WORKSPACE; }
+    hipLaunchKernelGGL(xyz_sum1_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, p, dp, scratch, n_pix, C);
+    int rc = check_launch("xyz_sum1");
+    if (rc || !reg) return rc;
+    hipLaunchKernelGGL(sum_scale_kernel, dim3(1), dim3(256), 0, stream, scratch, reg, (int)blocks, 0.5f / (float)n_pix);
     return check_launch("sum_scale");
 }
 

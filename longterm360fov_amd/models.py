@@ -902,8 +902,10 @@ class ConvLSTMSeq2Seq(KerasModelSurface):
 
     _default_optimizer = "rmsprop"      # convlstm_seq2seq.py:287
 
-    def __init__(self, weights, head="conv2d", recurrent_activation="hard_sigmoid", device="cuda", dropout_rate=0.0):
+    def __init__(self, weights, head="conv2d", recurrent_activation="hard_sigmoid", device="cuda", dropout_rate=0.0,
+                 add_xyz_sum1=None):
         from .training import convlstm_weight_order
+        self.add_xyz_sum1 = bool(cfg.add_xyz_sum1 if add_xyz_sum1 is None else add_xyz_sum1)
         self.head, self.act = head, recurrent_activation
         self._w = {k: _as_f32(v) for k, v in weights.items()}
         self._init_surface(convlstm_weight_order(self._w), None, device)
@@ -917,7 +919,7 @@ class ConvLSTMSeq2Seq(KerasModelSurface):
     def _make_trainer(self, optimizer):
         from .training import ConvLSTMTrainer
         return ConvLSTMTrainer(self._w, head=self.head, act=self.act, optimizer=optimizer, lr=self._lr, device=self.device,
-                               dropout_rate=self.dropout_rate)
+                               dropout_rate=self.dropout_rate, add_xyz_sum1=self.add_xyz_sum1)
 
     def predict(self, x, batch_size=None, predict_step=None, verbose=0):
         import torch

@@ -270,6 +270,19 @@ def gauss_nll_grad(mu, var, y, fps, scale, scratch=None):
     return loss, dmu, dvar
 
 
+def xyz_sum1_grad(p, dp, scratch=None):
+    """cfg.add_xyz_sum1 term of costfunc._mse (cost.py:20-29) on p (..., C >= 3): adds its gradient into dp, returns the
+    term as a (1,) tensor."""
+    p, dp = _dev(p, "p"), _dev(dp, "dp")
+    assert p.shape == dp.shape
+    C = p.shape[-1]
+    n_pix = p.numel() // C
+    reg = torch.zeros(1, dtype=torch.float32, device=p.device)
+    buf = (scratch or _default_scratch).get(4 * ((n_pix + 255) // 256 + 64), p.device)
+    check(_lib.lib().fov_xyz_sum1_grad(_ptr(p), _ptr(dp), _ptr(reg), n_pix, C, buf.data_ptr(), buf.numel(), _stream()))
+    return reg
+
+
 def _row_view(x, width):
     """(B, width) view whose rows may be a slot of a wider window: -> (data_ptr, row stride in floats)."""
     assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.shape[1] == width and x.stride(1) == 1

@@ -174,7 +174,7 @@ def test_convlstm_gates_backward_softmax_relu_colsum(act):
     close(ops.colsum(dev(big)), big.astype(np.float64).sum(0), "colsum")
 
 
-def _torch_convlstm_graph(enc, dec0, tgt, w, head, act, masks=None):
+def _torch_convlstm_graph(enc, dec0, tgt, w, head, act, masks=None, xyz_sum1=False):
     """Independent fp64 restatement of the ConvLSTM seq2seq training graph (convlstm_seq2seq.py:100-287) on
     torch.autograd: loss = mean squared error of the unrolled, self-fed decoder.  `masks` (optional): Keras
     ConvLSTM2D input dropout - per layer call four masks, gate g's kernel slice convolves x * mask_g."""
@@ -231,6 +231,8 @@ def _torch_convlstm_graph(enc, dec0, tgt, w, head, act, masks=None):
         inp = y
     P = torch.stack(outs, 1)
     loss = torch.mean((P - tg) ** 2)
+    if xyz_sum1:      # costfunc._mse under cfg.add_xyz_sum1 (cost.py:23-28)
+        loss = loss + 0.5 * torch.mean((1 - (P[..., 0] ** 2 + P[..., 1] ** 2 + P[..., 2] ** 2)) ** 2)
     loss.backward()
     return float(loss), {k: v.grad.numpy() for k, v in t.items()}, P.detach().numpy()
 
@@ -384,3 +386,36 @@ def test_config4_full_size_and_properties():
     assert (err <= 1e-3 * np.abs(ref) + 1e-5).all() and err.max() <= 2e-5
     small = m.predict([x[rows], x[rows, -1:]], predict_step=T)
     np.testing.assert_allclose(small, out[rows], atol=1e-6)
+
+
+def test_convlstm_mse_with_xyz_sum1_term():
+    """costfunc._mse with cfg.add_xyz_sum1 (cost.py:20-29): MSE + 0.5 * MSE(1, ux^2 + uy^2 + uz^2) on the xyz head; loss and
+    every gradient against torch.autograd fp64, and the stand-alone kernel on a ragged pixel count."""
+    from longterm360fov_amd import ops
+    from longterm360fov_amd.training import ConvLSTMTrainer
+    head, B, T_in, T_out, H, W, C, L, hf, act = "conv1d", 3, 2, 3, 1, 30, 3, 16, (32, 48), "hard_sigmoid"
+    w = O.init_convlstm_seq2seq(6, C=C, latent_dim=L, head=head, head_filters=hf, map_hw=(H, W))
+    rng = np.random.default_rng(9)
+    enc = rng.random((B, T_in, H, W, C)).astype(np.float32)
+    dec0 = enc[:, -1:].copy()
+    tgt = rng.random((B, T_out, H, W, C)).astype(np.float32)
+    tgt /= tgt.sum(-1, keepdims=True)
+    loss_ref, g_ref, _ = _torch_convlstm_graph(enc, dec0, tgt, w, head, act, xyz_sum1=True)
+    loss_plain, _, _ = _torch_convlstm_graph(enc, dec0, tgt, w, head, act)
+    assert loss_ref > loss_plain * 1.05
+    tr = ConvLSTMTrainer(w, head=head, act=act, add_xyz_sum1=True)
+    loss, _ = tr.forward_backward(dev(enc), dev(dec0), dev(tgt))
+    assert abs(float(loss.item()) - loss_ref) <= 1e-5 * loss_ref + 1e-9
+    assert abs(float(tr.eval_loss(dev(enc), dev(dec0), dev(tgt)).item()) - loss_ref) <= 1e-5 * loss_ref + 1e-9
+    for k in tr.order:
+        a = tr.g[k].detach().cpu().numpy().astype(np.float64)
+        scale = np.abs(g_ref[k]).max()
+        assert np.abs(a - g_ref[k]).max() <= 2e-4 * scale + 1e-9, k
+    p = rng.standard_normal((1001, 5)).astype(np.float32)
+    tp = torch.tensor(p.astype(np.float64), requires_grad=True)
+    reg_ref = 0.5 * torch.mean((tp[:, 0] ** 2 + tp[:, 1] ** 2 + tp[:, 2] ** 2 - 1) ** 2)
+    reg_ref.backward()
+    dp = torch.full((1001, 5), 0.25, dtype=torch.float32, device="cuda")
+    reg = ops.xyz_sum1_grad(dev(p), dp)
+    assert abs(float(reg.item()) - float(reg_ref)) <= 1e-5 * float(reg_ref)
+    close(dp - 0.25, tp.grad.numpy(), "xyz_sum1 gradient", tol=1e-5)
