@@ -338,6 +338,7 @@ size_t fov_lstm_seq_workspace_bytes(int B, int T, int F, int H, int impl) {
     (void)T;
     if (B <= 0) return kStatusBytes;
     if (impl != FOV_IMPL_GENERIC && wide_shape_ok(F, H)) return cluster_workspace_bytes(B, H);
+    if (impl == FOV_IMPL_AUTO && wide_narrow_preferred(B, F, H)) return cluster_workspace_bytes(B, H);
     return want_cluster(impl, F, H, 0, false) && cluster_shape_ok(F, H) ? cluster_workspace_bytes(B, H) : kStatusBytes;
 }
 
@@ -360,6 +361,8 @@ static int lstm_seq_fwd_impl(const float* x, const float* K, const float* R, con
     hipStream_t s = (hipStream_t)stream;
     // wide inputs (a stacked layer over a 256-wide sequence): K and R both register-resident (lstm_wide.hip)
     if (impl != FOV_IMPL_GENERIC && wide_shape_ok(F, H) && (((uintptr_t)x) & 15) == 0) return launch_wide(p, s);
+    // narrow inputs, at most 32 tiles: groups of eight workgroups fill the chip where lstm_cluster's groups of four leave half idle
+    if (impl == FOV_IMPL_AUTO && T > 0 && wide_narrow_preferred(B, F, H)) return launch_wide(p, s);
     if (want_cluster(impl, F, H, 0, false)) return launch_cluster(p, false, s);
     if (B > 0) {
         hipError_t e = hipMemsetAsync(workspace, 0, kStatusBytes, s);

@@ -71,6 +71,7 @@ int cluster_num_groups(int B, int H);
 void set_error(const char* fmt, ...);
 // wide-input layer, H = 256, 96 < F <= 256 (lstm_wide.hip)
 bool wide_shape_ok(int F, int H);
+bool wide_narrow_preferred(int B, int F, int H);
 int launch_wide(const LstmParams& p, hipStream_t stream);
 
 constexpr size_t kStatusBytes = 256;  // head of every workspace: status words

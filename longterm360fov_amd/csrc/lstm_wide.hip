@@ -9,6 +9,10 @@
 //   * K slice 128 AGPRs + R slice 128 AGPRs per lane;
 //   * the input tile x_t (16 x F) is double-buffered in LDS (global -> registers -> LDS one step ahead), the h
 //     tile (16 x 256) sits next to it; x_{t+1} . K (128 MFMAs) runs under the gather of h_t.
+// NARROW variant (NJX = 6, F <= 96, any F): the same kernel with only the six k-blocks of K that exist and a scalar x
+// stage.  A batch of <= 512 sequences is <= 32 tiles: lstm_cluster.hip's groups of FOUR workgroups would occupy at
+// most half of the 256 CUs, groups of eight fill them, so fov_lstm_seq_fwd(impl = auto) sends such batches here
+// (encoder layer 1 of configs[2] at 512 sequences per GPU).
 #include <stdlib.h>
 
 #include "fov_common.h"
@@ -39,7 +43,7 @@ __device__ __forceinline__ float wswap(float v) {
 
 // acc[tile] += A(tile rows in LDS, k-blocks [0, NJ)) . W (AGPR resident)
 template <int NJ>
-__device__ __forceinline__ void wide_mm(f32x4 (&acc)[2], const float* arow, const float (&w)[16][4][2]) {
+__device__ __forceinline__ void wide_mm(f32x4 (&acc)[2], const float* arow, const float (&w)[NJ][4][2]) {
     f32x4 a = *(const f32x4*)arow;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
@@ -55,8 +59,9 @@ __device__ __forceinline__ void wide_mm(f32x4 (&acc)[2], const float* arow, cons
     }
 }
 
-template <int ACT>
+template <int ACT, int NJX>
 __global__ __launch_bounds__(256, 1) void lstm_wide_kernel(LstmParams p) {
+    constexpr bool XVEC = NJX == 16;   // wide inputs: 16-byte pieces (F % 4 == 0, x aligned); narrow: scalar elements
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* sH = smem;                    // [16][WLD]
     float* sX = sH + WBT * WLD;          // [2][16][WLD]
@@ -80,14 +85,16 @@ __global__ __launch_bounds__(256, 1) void lstm_wide_kernel(LstmParams p) {
     if (p.clear_status && blockIdx.x == 0 && tid == 0) { p.status[0] = 0; p.status[1] = 0; }
 
     // ---- resident weights: K rows >= F are zero ----
-    float wk[16][4][2], wr[16][4][2];
+    float wk[NJX][4][2], wr[16][4][2];
 #pragma unroll
     for (int j = 0; j < 16; ++j)
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const int k = 16 * j + 4 * g4 + s;
-            wk[j][s][0] = (k < F) ? p.K[(size_t)k * H4 + col0] : 0.f;
-            wk[j][s][1] = (k < F) ? p.K[(size_t)k * H4 + col1] : 0.f;
+            if (j < NJX) {
+                wk[j][s][0] = (k < F) ? p.K[(size_t)k * H4 + col0] : 0.f;
+                wk[j][s][1] = (k < F) ? p.K[(size_t)k * H4 + col1] : 0.f;
+            }
             wr[j][s][0] = p.R[(size_t)k * H4 + col0];
             wr[j][s][1] = p.R[(size_t)k * H4 + col1];
         }
@@ -157,8 +164,10 @@ __global__ __launch_bounds__(256, 1) void lstm_wide_kernel(LstmParams p) {
 
     const float* hrow = sH + n * WLD + 4 * g4;
     // x staging: thread (xrw = tid/16, xc = tid%16) moves the 16-byte pieces xc, xc+16, xc+32, xc+48 of row xrw
+    // (narrow variant: the elements xc, xc+16, ..., xc+80)
     const int xrw = tid >> 4, xc = tid & 15;
     const int nx4 = F >> 2;   // 16-byte pieces per row (F % 4 == 0, host-checked)
+    constexpr int NXR = XVEC ? 4 : NJX;
     for (int tile = group; tile < p.num_tiles && !aborted; tile += p.num_groups) {
         const int b0 = tile * WBT;
         __syncthreads();   // previous tile fully consumed
@@ -174,15 +183,20 @@ __global__ __launch_bounds__(256, 1) void lstm_wide_kernel(LstmParams p) {
             hc[r] = (row < p.B && p.h0) ? p.h0[(size_t)row * WH + unit] : 0.f;
         }
         const bool xlive = b0 + xrw < p.B;
-        const float* xt = p.x + ((size_t)(b0 + xrw) * p.T) * F + 4 * xc;
-        float* xl = sX + xrw * WLD + 4 * xc;
+        const float* xt = p.x + ((size_t)(b0 + xrw) * p.T) * F + (XVEC ? 4 : 1) * xc;
+        float* xl = sX + xrw * WLD + (XVEC ? 4 : 1) * xc;
         const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt)
             if (tt < steps) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    if (xc + 16 * i < nx4) *(f32x4*)(xl + tt * WBT * WLD + 64 * i) = xlive ? *(const f32x4*)(xt + (size_t)tt * F + 64 * i) : z4;
+                for (int i = 0; i < NXR; ++i) {
+                    if constexpr (XVEC) {
+                        if (xc + 16 * i < nx4) *(f32x4*)(xl + tt * WBT * WLD + 64 * i) = xlive ? *(const f32x4*)(xt + (size_t)tt * F + 64 * i) : z4;
+                    } else {
+                        if (xc + 16 * i < F) xl[tt * WBT * WLD + 16 * i] = xlive ? xt[(size_t)tt * F + 16 * i] : 0.f;
+                    }
+                }
             }
         __syncthreads();
         // ---- pre-activations of step 0 ----
@@ -191,23 +205,32 @@ __global__ __launch_bounds__(256, 1) void lstm_wide_kernel(LstmParams p) {
         acc[1] = (f32x4){bv[1], bv[1], bv[1], bv[1]};
         if (steps > 0) {
             wm_begin(acc);
-            wide_mm<16>(acc, sX + n * WLD + 4 * g4, wk);
+            wide_mm<NJX>(acc, sX + n * WLD + 4 * g4, wk);
             wide_mm<16>(acc, hrow, wr);
             wm_end(acc);
         }
-        f32x4 xr[4] = {z4, z4, z4, z4};
+        f32x4 xr[XVEC ? 4 : 1] = {z4};
+        float xs[XVEC ? 1 : NJX] = {0.f};
         for (int t = 0; t < steps; ++t) {
             // x pipeline: x_{t+1} (requested during step t-1) registers -> LDS; then request x_{t+2}
             if (t > 0 && t + 1 < steps) {
                 float* xb = xl + ((t + 1) & 1) * WBT * WLD;
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    if (xc + 16 * i < nx4) *(f32x4*)(xb + 64 * i) = xr[i];
+                for (int i = 0; i < NXR; ++i) {
+                    if constexpr (XVEC) {
+                        if (xc + 16 * i < nx4) *(f32x4*)(xb + 64 * i) = xr[i];
+                    } else {
+                        if (xc + 16 * i < F) xb[16 * i] = xs[i];
+                    }
+                }
             }
             if (t + 2 < steps) {
                 const float* xn = xt + (size_t)(t + 2) * F;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) xr[i] = (xlive && xc + 16 * i < nx4) ? *(const f32x4*)(xn + 64 * i) : z4;
+                for (int i = 0; i < NXR; ++i) {
+                    if constexpr (XVEC) xr[i] = (xlive && xc + 16 * i < nx4) ? *(const f32x4*)(xn + 64 * i) : z4;
+                    else xs[i] = (xlive && xc + 16 * i < F) ? xn[16 * i] : 0.f;
+                }
             }
             // ---- cell update ----
             {
@@ -257,7 +280,7 @@ __global__ __launch_bounds__(256, 1) void lstm_wide_kernel(LstmParams p) {
             acc[1] = (f32x4){bv[1], bv[1], bv[1], bv[1]};
             if (more) {   // x_{t+1} . K needs no remote data: it runs under the gather
                 wm_begin(acc);
-                wide_mm<16>(acc, sX + ((t + 1) & 1) * WBT * WLD + n * WLD + 4 * g4, wk);
+                wide_mm<NJX>(acc, sX + ((t + 1) & 1) * WBT * WLD + n * WLD + 4 * g4, wk);
                 wm_end(acc);
             }
             if (do_xch) gather_finish(par);
@@ -286,12 +309,16 @@ __global__ __launch_bounds__(256, 1) void lstm_wide_kernel(LstmParams p) {
 
 bool wide_shape_ok(int F, int H) { return H == WH && F > 96 && F <= 256 && (F & 3) == 0; }
 
+// F <= 96 at H = 256: the narrow variant, preferred over lstm_cluster.hip while the batch is at most 32 tiles
+bool wide_narrow_preferred(int B, int F, int H) { return H == WH && F >= 1 && F <= 96 && B > 0 && B <= 32 * WBT; }
+
 // p.status / p.xch point into the caller's workspace (cluster_workspace_bytes(B, 256): granule area for up to 64
 // groups, this kernel uses at most 32)
 int launch_wide(const LstmParams& p_in, hipStream_t stream) {
     LstmParams p = p_in;
     if (p.B == 0) return FOV_OK;
-    if ((((uintptr_t)p.x) & 15) != 0) { set_error("wide LSTM layer: x must be 16-byte aligned"); return FOV_ERR_INVALID; }
+    const bool narrow = p.F <= 96;
+    if (!narrow && (((uintptr_t)p.x) & 15) != 0) { set_error("wide LSTM layer: x must be 16-byte aligned"); return FOV_ERR_INVALID; }
     p.num_tiles = (p.B + WBT - 1) / WBT;
     p.num_groups = p.num_tiles < 32 ? p.num_tiles : 32;
     p.clear_status = p.T <= 1 ? 1 : 0;
@@ -301,7 +328,9 @@ int launch_wide(const LstmParams& p_in, hipStream_t stream) {
         if (e != hipSuccess) { set_error("hipMemsetAsync: %s", hipGetErrorString(e)); return FOV_ERR_LAUNCH; }
     }
     const size_t lds = sizeof(float) * (3 * WBT * WLD) + 64;
-    void (*kern)(LstmParams) = p.act == FOV_ACT_HARD_SIGMOID ? lstm_wide_kernel<FOV_ACT_HARD_SIGMOID> : lstm_wide_kernel<FOV_ACT_SIGMOID>;
+    void (*kern)(LstmParams) =
+        narrow ? (p.act == FOV_ACT_HARD_SIGMOID ? lstm_wide_kernel<FOV_ACT_HARD_SIGMOID, 6> : lstm_wide_kernel<FOV_ACT_SIGMOID, 6>)
+               : (p.act == FOV_ACT_HARD_SIGMOID ? lstm_wide_kernel<FOV_ACT_HARD_SIGMOID, 16> : lstm_wide_kernel<FOV_ACT_SIGMOID, 16>);
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return FOV_ERR_LAUNCH; }
     hipLaunchKernelGGL(kern, dim3(p.num_groups * WG), dim3(256), lds, stream, p);

@@ -424,12 +424,15 @@ def test_fused_mixing_decoder_matches_oracle(B, T_in, T_out, act):
     assert_parity(out.transpose(0, 1), ref, "fused mixing decoder B=%d" % B)
 
 
-@pytest.mark.parametrize("B,T,F", [(37, 5, 256), (16, 1, 256), (600, 3, 128), (20, 4, 100)])
+@pytest.mark.parametrize("B,T,F", [(37, 5, 256), (16, 1, 256), (600, 3, 128), (20, 4, 100),
+                                   (512, 10, 90), (37, 3, 6), (100, 4, 96), (17, 5, 33), (5, 1, 90)])
 @pytest.mark.parametrize("act", ["sigmoid", "hard_sigmoid"])
 def test_wide_input_layer(B, T, F, act):
     """A stacked layer over a wide sequence (given_others...py:111-112: encoder layer 2 over the 256-wide output of
     layer 1): K and R both register-resident (lstm_wide.hip), no precomputed input projection.  Also the
-    training form (reserve) and a given initial state; B = 600 makes a group visit several tiles."""
+    training form (reserve) and a given initial state; B = 600 makes a group visit several tiles.  F <= 96 with at
+    most 512 sequences (impl auto) is the narrow variant of the same kernel: groups of eight workgroups fill the chip
+    where the cluster kernel's groups of four would leave half of it idle (encoder layer 1 of configs[2])."""
     ops = _ops()
     H = 256
     rng = np.random.default_rng(B + F)
@@ -457,7 +460,8 @@ def test_wide_input_layer(B, T, F, act):
 def test_config3_full_size_and_properties():
     """configs[2]: the 2+2-layer others-mixing model, H=256, 34 users, T 10->10; global batch 4096 = 8 ranks x 512.  One
     rank's shard (512) through the model object against the fp64 oracle; the whole global batch in ONE call (groups walk
-    several tiles) must equal the eight shard calls bit for bit - which is what makes inference 'replicas only'."""
+    several tiles) must agree with the eight shard calls (replicas only: a rank's result depends on nothing but its own
+    shard), and a shard call is deterministic and batch-permutation equivariant bit for bit."""
     from longterm360fov_amd.models import OthersMixingSeq2Seq
     B, T_in, T_out, H, U = 4096, 10, 10, 256, 34
     w = O.init_others_mixing(1234, H=H, num_user=U, bias_noise=0.05)
@@ -469,10 +473,13 @@ def test_config3_full_size_and_properties():
     assert full.shape == (B, T_out, 6) and np.isfinite(full).all() and np.abs(full).max() <= 1.0
     ref = O.others_mixing_forward(enc[:512].astype(np.float64), oth[:512].astype(np.float64), dec0[:512].astype(np.float64), f64(w))
     assert_parity(torch.from_numpy(full[:512]), ref, "config3 shard 0 (512 seq) vs fp64 oracle", tight=5e-5)
-    for r in range(8):
-        sl = slice(512 * r, 512 * (r + 1))
-        shard = m.predict([enc[sl], oth[sl], dec0[sl]])
-        assert np.array_equal(shard, full[sl]), "rank %d shard differs from the global-batch call" % r
+    shards = []
+    for r in range(8):   # a 512-sequence shard takes the eight-workgroup layer kernel for encoder layer 1, the 4096 call the
+        sl = slice(512 * r, 512 * (r + 1))      # four-workgroup one: same arithmetic, different summation order
+        shards.append(m.predict([enc[sl], oth[sl], dec0[sl]]))
+        assert np.abs(shards[r] - full[sl]).max() <= 2e-6, "rank %d shard differs from the global-batch call" % r
+    twice = m.predict([enc[:512], oth[:512], dec0[:512]])
+    assert np.array_equal(twice, shards[0]), "not deterministic"
     perm = np.random.default_rng(0).permutation(512)
     outp = m.predict([enc[:512][perm], oth[:512][perm], dec0[:512][perm]])
-    assert np.array_equal(outp, full[:512][perm]), "not batch-permutation equivariant"
+    assert np.array_equal(outp, shards[0][perm]), "not batch-permutation equivariant"
