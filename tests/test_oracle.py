@@ -235,3 +235,78 @@ def test_onelayer_no_teacher_forcing_oracle_properties():
     w["res_W"], w["res_b"] = np.eye(6) * 0.3, np.zeros(6)
     d = O.onelayer_tar_seq2seq_forward(enc, dec0, w, 5, decoder_no_init_state=False, add_residual_link=True)
     assert np.abs(d).max() <= 2.0 and np.abs(d - c).max() > 1e-4      # tanh + tanh
+
+
+def _load_torch_lstm(m, layer, suffix, K, R, b):
+    with torch.no_grad():
+        getattr(m, "weight_ih_l%d%s" % (layer, suffix)).copy_(torch.from_numpy(K.T))
+        getattr(m, "weight_hh_l%d%s" % (layer, suffix)).copy_(torch.from_numpy(R.T))
+        getattr(m, "bias_ih_l%d%s" % (layer, suffix)).copy_(torch.from_numpy(b))
+        getattr(m, "bias_hh_l%d%s" % (layer, suffix)).zero_()
+
+
+def test_bidirectional_and_stacked_restatements_match_torch():
+    """Independent implementations of the two sibling structures: torch.nn.LSTM(bidirectional=True) for the oracle's
+    Keras-Bidirectional restatement (backward outputs reversed back, concat [fwd | bwd], per-direction final states) and
+    torch.nn.LSTM(num_layers=2) with the encoder's per-layer final states as the decoder's initial states for the stacked
+    seq2seq of Fov_seq2seq_2layers.py."""
+    from oracle import fov_oracle as O
+    rng = np.random.default_rng(17)
+    B, T, F, H = 5, 6, 12, 8
+    x = rng.standard_normal((B, T, F))
+    wf = [a.astype(np.float64) for a in O.init_lstm(rng, F, H, np.float64)]
+    wb = [a.astype(np.float64) for a in O.init_lstm(rng, F, H, np.float64)]
+    wf[2] = wf[2] + 0.1 * rng.standard_normal(4 * H); wb[2] = wb[2] + 0.1 * rng.standard_normal(4 * H)
+    seq, fh, fc, bh, bc = O.bidirectional_lstm(x, wf, wb)
+    m = torch.nn.LSTM(F, H, batch_first=True, bidirectional=True).double()
+    _load_torch_lstm(m, 0, "", *wf)
+    _load_torch_lstm(m, 0, "_reverse", *wb)
+    with torch.no_grad():
+        ts, (th, tc) = m(torch.from_numpy(x))
+    np.testing.assert_allclose(seq, ts.numpy(), atol=1e-12)
+    np.testing.assert_allclose(np.stack([fh, bh]), th.numpy(), atol=1e-12)
+    np.testing.assert_allclose(np.stack([fc, bc]), tc.numpy(), atol=1e-12)
+    # seeded form (the list the first Bidirectional returns becomes the second one's initial state)
+    init = tuple(0.3 * rng.standard_normal((B, H)) for _ in range(4))
+    seq2 = O.bidirectional_lstm(x, wf, wb, init)[0]
+    with torch.no_grad():
+        ts2, _ = m(torch.from_numpy(x), (torch.from_numpy(np.stack([init[0], init[2]])), torch.from_numpy(np.stack([init[1], init[3]]))))
+    np.testing.assert_allclose(seq2, ts2.numpy(), atol=1e-12)
+    # two-layer teacher-forced seq2seq
+    w = {}
+    for side, f0 in (("enc", 6), ("dec", 6)):
+        for l in range(2):
+            K, R, b = O.init_lstm(rng, 6 if l == 0 else H, H, np.float64)
+            w["%s%d_K" % (side, l)], w["%s%d_R" % (side, l)], w["%s%d_b" % (side, l)] = K, R, b + 0.1 * rng.standard_normal(4 * H)
+    w["dense_W"], w["dense_b"] = rng.uniform(-0.3, 0.3, (H, 6)), rng.uniform(-0.1, 0.1, 6)
+    enc, dec_in = rng.standard_normal((B, 4, 6)), rng.standard_normal((B, 5, 6))
+    y = O.stacked_seq2seq_forward(enc, dec_in, w, 2)
+    e, d = torch.nn.LSTM(6, H, 2, batch_first=True).double(), torch.nn.LSTM(6, H, 2, batch_first=True).double()
+    for l in range(2):
+        _load_torch_lstm(e, l, "", w["enc%d_K" % l], w["enc%d_R" % l], w["enc%d_b" % l])
+        _load_torch_lstm(d, l, "", w["dec%d_K" % l], w["dec%d_R" % l], w["dec%d_b" % l])
+    with torch.no_grad():
+        _, st = e(torch.from_numpy(enc))
+        hs, _ = d(torch.from_numpy(dec_in), st)
+    np.testing.assert_allclose(y, np.tanh(hs.numpy() @ w["dense_W"] + w["dense_b"]), atol=1e-12)
+
+
+def test_sampled_refeed_restatements():
+    """lstm_keras.py's planar layout with the variance as stddev, and lstm.py's interleaved layout with sqrt(var): with zero
+    noise the re-fed second is the predicted mean repeated over the frames in the respective layout."""
+    from oracle import fov_oracle as O
+    rng = np.random.default_rng(3)
+    w0 = O.init_seq2seq(4, H=8)
+    w = {"K": w0["enc_K"].astype(np.float64), "R": w0["enc_R"].astype(np.float64), "b": w0["enc_b"].astype(np.float64),
+         "dense_W": w0["dense_W"].astype(np.float64), "dense_b": w0["dense_b"].astype(np.float64)}
+    x = rng.uniform(-1, 1, (3, 1, 90))
+    y0 = O.single_lstm_keras_forward(x, w, 3, True, np.zeros((2, 3, 90)))
+    # step 1 must equal a plain step on the planar repetition of step 0's means from step 0's state
+    h, c = O.lstm_step(x[:, 0], np.zeros((3, 8)), np.zeros((3, 8)), w["K"], w["R"], w["b"])
+    planar = np.repeat(y0[:, 0, :3], 30, axis=1)
+    h, c = O.lstm_step(planar, h, c, w["K"], w["R"], w["b"])
+    np.testing.assert_allclose(y0[:, 1], np.tanh(h @ w["dense_W"] + w["dense_b"]), atol=1e-14)
+    # the constant-input form differs from it, and the per-step form consumes one input second per step
+    assert np.abs(O.single_lstm_keras_forward(x, w, 3, True, None)[:, 1] - y0[:, 1]).max() > 1e-6
+    xs = rng.uniform(-1, 1, (3, 4, 90))
+    np.testing.assert_allclose(O.single_lstm_keras_forward(xs, w)[:, :2], O.single_lstm_keras_forward(xs[:, :2], w), atol=1e-14)
