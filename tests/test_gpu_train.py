@@ -285,7 +285,7 @@ def _torch_mixing_graph(enc, oth, dec0, tgt, w, act):
 
 @pytest.mark.parametrize("H,B,U,T_in,T_out,act", [(64, 20, 5, 4, 3, "sigmoid"), (128, 33, 34, 5, 4, "hard_sigmoid"),
                                                   (256, 16, 34, 3, 3, "sigmoid"), (256, 37, 5, 2, 4, "hard_sigmoid"),
-                                                  (256, 530, 3, 2, 2, "sigmoid")])
+                                                  (256, 530, 3, 2, 2, "sigmoid"), (256, 512, 34, 10, 10, "sigmoid")])
 def test_others_mixing_gradients_and_training(H, B, U, T_in, T_out, act):
     """a4 training: gradients of the unrolled no-teacher-forcing graph (feedback path included) against
     torch.autograd in fp64, then three Adam steps reduce the loss."""
@@ -953,3 +953,20 @@ def test_others_context_heads(mode, H, B, U, T_in, T_out, act):
     assert losses[-1] < losses[0]
     h = m.fit(xin, tgt, batch_size=16, epochs=2, validation_split=0.2)
     assert len(h.history["loss"]) == 2 and "val_loss" in h.history
+
+
+def test_config2_full_size_training_gradients():
+    """configs[1] shape at full size (B = 1024, T 30 -> 30, H = 256): loss, prediction and every gradient of the teacher-forced
+    training step against the fp64 oracle (BPTT through 30 + 30 steps)."""
+    from longterm360fov_amd.training import Seq2SeqTrainer
+    B, T_in, T_out, H = 1024, 30, 30, 256
+    w = O.init_seq2seq(1234, H=H, bias_noise=0.05)
+    enc, dec_in, tgt = batch(1234, B, T_in, T_out)
+    loss_ref, g_ref, y_ref = O.seq2seq_loss_and_grads(enc.astype(np.float64), dec_in.astype(np.float64), tgt.astype(np.float64),
+                                                     f64(w), "sigmoid")
+    tr = Seq2SeqTrainer(w, act="sigmoid")
+    loss, y = tr.forward_backward(dev(enc), dev(dec_in), dev(tgt))
+    tr.ws.check(); tr.bwd_scratch.check()
+    assert abs(float(loss.item()) - loss_ref) <= 1e-5 * loss_ref + 1e-9
+    np.testing.assert_allclose(y.cpu().numpy(), y_ref, atol=2e-5)
+    check_grads(tr.g, g_ref, "config2 full size")
