@@ -257,6 +257,13 @@ int fov_gauss_nll_grad(const float* mu, const float* var, const float* y, float*
 int fov_rmsprop_tf_step(float* params, const float* grads, float* ms, int64_t n, float lr, float decay, float eps,
                         float clip_value, fov_stream_t stream);
 
+/* Keras-2.2 `categorical_crossentropy` on probabilities, TensorFlow backend form - the loss the heat-map fork compiles
+ * (mycode/convlstm_heatmap.py:192): per pixel (row of C channels) q = p / sum p, q' = clip(q, 1e-7, 1 - 1e-7),
+ * l = - sum_c target_c log q'_c; *loss (may be NULL) = mean over the n_pix rows; dp = d loss / d p, through the clip (zero
+ * outside it) and the renormalisation.  p, target, dp (n_pix, C) dense; workspace >= 4*(n_pix/256 + 65) bytes. */
+int fov_categorical_crossentropy_grad(const float* p, const float* target, float* dp, float* loss, int64_t n_pix, int C,
+                                      void* workspace, size_t workspace_bytes, fov_stream_t stream);
+
 /* The optional term of costfunc._mse under cfg.add_xyz_sum1 (mycode/cost.py:20-29): reg = 0.5 * mean over pixels of
  * (ux^2 + uy^2 + uz^2 - 1)^2 on the first three channels of p (n_pix, C), C >= 3.  Its gradient 2 (s - 1) u_k / n_pix is
  * ADDED into dp (which holds the MSE gradient); *reg (may be NULL) receives the term.  workspace >= 4*(n_pix/256 + 65) bytes. */

@@ -497,6 +497,18 @@ int fov_gauss_nll_grad(const float* mu, const float* var, const float* y, float*
                           (hipStream_t)stream);
 }
 
+int fov_categorical_crossentropy_grad(const float* p, const float* target, float* dp, float* loss, int64_t n_pix, int C,
+                                      void* workspace, size_t workspace_bytes, fov_stream_t stream) {
+    if (n_pix < 0 || C <= 0 || (n_pix > 0 && (!p || !target || !dp))) {
+        set_error("fov_categorical_crossentropy_grad: invalid argument");
+        return FOV_ERR_INVALID;
+    }
+    if (n_pix == 0) return FOV_OK;
+    int rc = check_ws(workspace, workspace_bytes, sizeof(float) * ((size_t)(n_pix + 255) / 256 + 64));
+    if (rc) return rc;
+    return cce_grad(p, target, dp, loss, (long)n_pix, C, (float*)workspace, workspace_bytes / sizeof(float), (hipStream_t)stream);
+}
+
 int fov_xyz_sum1_grad(const float* p, float* dp, float* reg, int64_t n_pix, int C, void* workspace, size_t workspace_bytes,
                       fov_stream_t stream) {
     if (n_pix < 0 || C < 3 || (n_pix > 0 && (!p || !dp))) {

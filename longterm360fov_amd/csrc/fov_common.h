@@ -162,6 +162,8 @@ int gauss_nll_grad(const float* mu, const float* var, const float* y, float* los
                    int fps, float scale, float* scratch, size_t scratch_floats, hipStream_t stream);
 int rmsprop_tf_step(float* p, const float* g, float* ms, long n, float lr, float decay, float eps, float clip,
                     hipStream_t stream);
+int cce_grad(const float* p, const float* t, float* dp, float* loss, long n_pix, int C, float* scratch, size_t scratch_floats,
+             hipStream_t stream);
 int xyz_sum1_grad(const float* p, float* dp, float* reg, long n_pix, int C, float* scratch, size_t scratch_floats, hipStream_t stream);
 int sample_refeed_fwd(const float* mu, const float* var, const float* noise, float* x, long ldx, int B, int fps, int std_mode,
                       int layout, hipStream_t stream);

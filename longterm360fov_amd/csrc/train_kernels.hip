@@ -520,6 +520,48 @@ __global__ __launch_bounds__(256) void xyz_sum1_kernel(const float* __restrict__
     if (threadIdx.x == 0) part[blockIdx.x] = red[0];
 }
 
+// Keras-2.2 categorical_crossentropy on probabilities (convlstm_heatmap.py:192: model.compile(loss='categorical_crossentropy',
+// optimizer='adam')), TensorFlow backend form: q = p / sum_c p;  q' = clip(q, 1e-7, 1 - 1e-7);  l = - sum_c t_c log q'_c per pixel,
+// loss = mean over pixels.  Gradient w.r.t. p through the clip (zero outside) and the renormalisation:
+//   g_c = -t_c / q'_c [eps < q_c < 1 - eps];   dl/dp_k = (g_k - sum_c g_c q_c) / S;   dp = that / n_pix.
+// One thread per pixel (C <= 64 channels re-read from cache for the second pass).
+__global__ __launch_bounds__(256) void cce_grad_kernel(const float* __restrict__ p, const float* __restrict__ t, float* __restrict__ dp,
+                                                       float* __restrict__ part, long n_pix, int C) {
+    __shared__ float red[256];
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    float l = 0.f;
+    if (i < n_pix) {
+        const float* pi = p + i * C;
+        const float* ti = t + i * C;
+        const float eps = 1e-7f;
+        float S = 0.f;
+        for (int c = 0; c < C; ++c) S += pi[c];
+        const float inv = 1.f / S;
+        float dot = 0.f;
+        for (int c = 0; c < C; ++c) {
+            const float q = pi[c] * inv;
+            const float qc = fminf(fmaxf(q, eps), 1.f - eps);
+            l -= ti[c] * __logf(qc);
+            const float g = (q > eps && q < 1.f - eps) ? -ti[c] / qc : 0.f;
+            dot += g * q;
+        }
+        const float sc = inv / (float)n_pix;
+        for (int c = 0; c < C; ++c) {
+            const float q = pi[c] * inv;
+            const float qc = fminf(fmaxf(q, eps), 1.f - eps);
+            const float g = (q > eps && q < 1.f - eps) ? -ti[c] / qc : 0.f;
+            dp[i * C + c] = (g - dot) * sc;
+        }
+    }
+    red[threadIdx.x] = l;
+    __syncthreads();
+    for (int m = 128; m >= 1; m >>= 1) {
+        if ((int)threadIdx.x < m) red[threadIdx.x] += red[threadIdx.x + m];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) part[blockIdx.x] = red[0];
+}
+
 // tf.train.RMSPropOptimizer (TF 1.x, momentum 0, not centered; mycode/lstm.py:556-567) with the script's optional
 // clip_by_value(grad, -clip, clip):  ms = decay*ms + (1-decay) g^2;  p -= lr * g / sqrt(ms + eps).  (eps INSIDE the
 // root, ms initialised to ONE - both unlike Keras RMSprop.)
@@ -1018,6 +1060,18 @@ int gauss_nll_grad(const float* mu, const float* var, const float* y, float* los
     int rc = check_launch("gauss_nll");
     if (rc || !loss) return rc;
     hipLaunchKernelGGL(sum_scale_kernel, dim3(1), dim3(256), 0, stream, scratch, loss, B, scale / (float)B);
+    return check_launch("sum_scale");
+}
+
+int cce_grad(const float* p, const float* t, float* dp, float* loss, long n_pix, int C, float* scratch, size_t scratch_floats,
+             hipStream_t stream) {
+    if (n_pix <= 0) return FOV_OK;
+    const long blocks = (n_pix + 255) / 256;
+    if ((size_t)blocks > scratch_floats) { set_error("categorical_crossentropy_grad: scratch too small"); return FOV_ERR_WORKSPACE; }
+    hipLaunchKernelGGL(cce_grad_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, p, t, dp, scratch, n_pix, C);
+    int rc = check_launch("cce_grad");
+    if (rc || !loss) return rc;
+    hipLaunchKernelGGL(sum_scale_kernel, dim3(1), dim3(256), 0, stream, scratch, loss, (int)blocks, 1.0f / (float)n_pix);
     return check_launch("sum_scale");
 }
 

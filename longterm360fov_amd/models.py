@@ -912,14 +912,20 @@ class ConvLSTMSeq2Seq(KerasModelSurface):
         self.dropout_rate = float(dropout_rate)
 
     def compile(self, optimizer="RMSprop", loss="mean_squared_error", metrics=None):
-        """Keras `compile` (convlstm_seq2seq.py:287).  optimizer 'RMSprop' | 'Adam' (Keras defaults); loss
-        'mean_squared_error' | 'mse' | a callable named `_mse` (cost.py:20-22 without cfg.add_xyz_sum1)."""
-        super().compile(optimizer, loss, metrics)
+        """Keras `compile` (convlstm_seq2seq.py:287; the heat-map fork convlstm_heatmap.py:192 compiles
+        loss='categorical_crossentropy', optimizer='adam').  optimizer 'RMSprop' | 'Adam' (Keras defaults); loss
+        'mean_squared_error' | 'mse' | a callable named `_mse` (cost.py:20-29) | 'categorical_crossentropy'."""
+        if str(loss).lower() == "categorical_crossentropy":
+            super().compile(optimizer, "mse", metrics)
+            self.loss = "categorical_crossentropy"
+        else:
+            super().compile(optimizer, loss, metrics)
+        self._trainer = None
 
     def _make_trainer(self, optimizer):
         from .training import ConvLSTMTrainer
         return ConvLSTMTrainer(self._w, head=self.head, act=self.act, optimizer=optimizer, lr=self._lr, device=self.device,
-                               dropout_rate=self.dropout_rate, add_xyz_sum1=self.add_xyz_sum1)
+                               dropout_rate=self.dropout_rate, add_xyz_sum1=self.add_xyz_sum1, loss=self.loss or "mse")
 
     def predict(self, x, batch_size=None, predict_step=None, verbose=0):
         import torch

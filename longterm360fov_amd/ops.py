@@ -270,6 +270,20 @@ def gauss_nll_grad(mu, var, y, fps, scale, scratch=None):
     return loss, dmu, dvar
 
 
+def categorical_crossentropy_grad(p, target, scratch=None, dp=None):
+    """Keras categorical_crossentropy (TF backend, probabilities) over the last axis -> (dp like p, loss (1,))."""
+    p, target = _dev(p, "p"), _dev(target, "target")
+    assert p.shape == target.shape
+    C = p.shape[-1]
+    n_pix = p.numel() // C
+    dp = torch.empty_like(p) if dp is None else dp
+    loss = torch.zeros(1, dtype=torch.float32, device=p.device)
+    buf = (scratch or _default_scratch).get(4 * ((n_pix + 255) // 256 + 64), p.device)
+    check(_lib.lib().fov_categorical_crossentropy_grad(_ptr(p), _ptr(target), _ptr(dp), _ptr(loss), n_pix, C, buf.data_ptr(),
+                                                       buf.numel(), _stream()))
+    return dp, loss
+
+
 def xyz_sum1_grad(p, dp, scratch=None):
     """cfg.add_xyz_sum1 term of costfunc._mse (cost.py:20-29) on p (..., C >= 3): adds its gradient into dp, returns the
     term as a (1,) tensor."""

@@ -676,11 +676,14 @@ class ConvLSTMTrainer(FlatParamTrainer):
     TF's random stream is not reproducible, the distribution is the same."""
 
     def __init__(self, weights, head="conv2d", act="hard_sigmoid", optimizer="rmsprop", lr=1e-3, device="cuda",
-                 dropout_rate=0.0, seed=0, add_xyz_sum1=False):
+                 dropout_rate=0.0, seed=0, add_xyz_sum1=False, loss="mse"):
         if not 0.0 <= dropout_rate < 1.0:
             raise ValueError("dropout_rate must be in [0, 1)")
         self.dropout_rate = float(dropout_rate)
         self.add_xyz_sum1 = bool(add_xyz_sum1)      # cfg.add_xyz_sum1: the optional unit-norm term of costfunc._mse
+        if loss not in ("mse", "categorical_crossentropy"):
+            raise ValueError("loss must be 'mse' or 'categorical_crossentropy'")
+        self.loss = loss
         self._gen = torch.Generator(device=device)
         self._gen.manual_seed(int(seed))
         self.head, self.act = head, act
@@ -811,7 +814,10 @@ class ConvLSTMTrainer(FlatParamTrainer):
         wt4 = {k: ops.conv2d_weight_transpose(v) for k, v in tp["k4"].items()}
         dense_head = self.head == "dense"
         tgt = target.transpose(0, 1).contiguous()
-        dP, loss = ops.mse_dense_grad(P, tgt, None, scratch=sc)
+        if self.loss == "categorical_crossentropy":      # convlstm_heatmap.py:192
+            dP, loss = ops.categorical_crossentropy_grad(P, tgt, scratch=sc)
+        else:
+            dP, loss = ops.mse_dense_grad(P, tgt, None, scratch=sc)
         if self.add_xyz_sum1:      # costfunc._mse, cost.py:23-28: + 0.5 * MSE(1, ux^2 + uy^2 + uz^2)
             reg = ops.xyz_sum1_grad(P, dP, scratch=sc)
             loss = ops.act_bwd(reg, reg, base=loss, activation=None)
@@ -911,7 +917,11 @@ class ConvLSTMTrainer(FlatParamTrainer):
 
     def eval_loss(self, enc, dec0, target):
         P, _ = self._forward(enc, dec0, target.shape[1])
-        dP, loss = ops.mse_dense_grad(P, target.transpose(0, 1).contiguous(), None, scratch=self.scratch)
+        tgt = target.transpose(0, 1).contiguous()
+        if self.loss == "categorical_crossentropy":
+            dP, loss = ops.categorical_crossentropy_grad(P, tgt, scratch=self.scratch)
+        else:
+            dP, loss = ops.mse_dense_grad(P, tgt, None, scratch=self.scratch)
         if self.add_xyz_sum1:
             reg = ops.xyz_sum1_grad(P, dP, scratch=self.scratch)
             loss = ops.act_bwd(reg, reg, base=loss, activation=None)

@@ -174,7 +174,7 @@ def test_convlstm_gates_backward_softmax_relu_colsum(act):
     close(ops.colsum(dev(big)), big.astype(np.float64).sum(0), "colsum")
 
 
-def _torch_convlstm_graph(enc, dec0, tgt, w, head, act, masks=None, xyz_sum1=False):
+def _torch_convlstm_graph(enc, dec0, tgt, w, head, act, masks=None, xyz_sum1=False, xent=False):
     """Independent fp64 restatement of the ConvLSTM seq2seq training graph (convlstm_seq2seq.py:100-287) on
     torch.autograd: loss = mean squared error of the unrolled, self-fed decoder.  `masks` (optional): Keras
     ConvLSTM2D input dropout - per layer call four masks, gate g's kernel slice convolves x * mask_g."""
@@ -231,6 +231,9 @@ def _torch_convlstm_graph(enc, dec0, tgt, w, head, act, masks=None, xyz_sum1=Fal
         inp = y
     P = torch.stack(outs, 1)
     loss = torch.mean((P - tg) ** 2)
+    if xent:          # Keras-2.2 categorical_crossentropy, TF backend (convlstm_heatmap.py:192)
+        q = torch.clamp(P / P.sum(-1, keepdim=True), 1e-7, 1 - 1e-7)
+        loss = torch.mean(-(tg * torch.log(q)).sum(-1))
     if xyz_sum1:      # costfunc._mse under cfg.add_xyz_sum1 (cost.py:23-28)
         loss = loss + 0.5 * torch.mean((1 - (P[..., 0] ** 2 + P[..., 1] ** 2 + P[..., 2] ** 2)) ** 2)
     loss.backward()
@@ -419,3 +422,43 @@ def test_convlstm_mse_with_xyz_sum1_term():
     reg = ops.xyz_sum1_grad(dev(p), dp)
     assert abs(float(reg.item()) - float(reg_ref)) <= 1e-5 * float(reg_ref)
     close(dp - 0.25, tp.grad.numpy(), "xyz_sum1 gradient", tol=1e-5)
+
+
+def test_convlstm_heatmap_fork_categorical_crossentropy():
+    """mycode/convlstm_heatmap.py:192 compiles the same graph with loss='categorical_crossentropy', optimizer='adam': loss and
+    every gradient against torch.autograd fp64; the stand-alone kernel incl. its clip (a zero probability) and its
+    renormalisation (rows that do not sum to one); model-object surface."""
+    from longterm360fov_amd import ops
+    from longterm360fov_amd.models import ConvLSTMSeq2Seq
+    from longterm360fov_amd.training import ConvLSTMTrainer
+    head, B, T_in, T_out, H, W, C, L, hf, act = "conv2d", 2, 3, 3, 9, 6, 10, 8, (24, 40), "hard_sigmoid"
+    w = O.init_convlstm_seq2seq(5, C=C, latent_dim=L, head=head, head_filters=hf, map_hw=(H, W))
+    rng = np.random.default_rng(12)
+    enc = rng.random((B, T_in, H, W, C)).astype(np.float32)
+    dec0 = enc[:, -1:].copy()
+    tgt = np.zeros((B, T_out, H, W, C), np.float32)      # one-hot targets
+    np.put_along_axis(tgt, rng.integers(0, C, (B, T_out, H, W, 1)), 1.0, -1)
+    loss_ref, g_ref, _ = _torch_convlstm_graph(enc, dec0, tgt, w, head, act, xent=True)
+    tr = ConvLSTMTrainer(w, head=head, act=act, optimizer="adam", loss="categorical_crossentropy")
+    loss, _ = tr.forward_backward(dev(enc), dev(dec0), dev(tgt))
+    assert abs(float(loss.item()) - loss_ref) <= 1e-5 * loss_ref
+    assert abs(float(tr.eval_loss(dev(enc), dev(dec0), dev(tgt)).item()) - loss_ref) <= 1e-5 * loss_ref
+    for k in tr.order:
+        a = tr.g[k].detach().cpu().numpy().astype(np.float64)
+        scale = np.abs(g_ref[k]).max()
+        assert np.abs(a - g_ref[k]).max() <= 2e-4 * scale + 1e-9, k
+    p = rng.random((777, 30)).astype(np.float32) + 0.01
+    p[5, 3] = 0.0                                          # clipped: contributes log(1e-7), no gradient
+    t = np.zeros_like(p)
+    t[np.arange(777), rng.integers(0, 30, 777)] = 1.0
+    t[5] = 0.0; t[5, 3] = 1.0
+    tp = torch.tensor(p.astype(np.float64), requires_grad=True)
+    lr = torch.mean(-(torch.tensor(t.astype(np.float64)) * torch.log(torch.clamp(tp / tp.sum(-1, keepdim=True), 1e-7, 1 - 1e-7))).sum(-1))
+    lr.backward()
+    dp, l = ops.categorical_crossentropy_grad(dev(p), dev(t))
+    assert abs(float(l.item()) - float(lr)) <= 1e-5 * float(lr)
+    close(dp, tp.grad.numpy(), "categorical crossentropy gradient", tol=2e-5)
+    m = ConvLSTMSeq2Seq(w, head=head)
+    m.compile(loss="categorical_crossentropy", optimizer="adam", metrics=["accuracy"])
+    losses = [m.train_on_batch([enc, dec0], tgt) for _ in range(4)]
+    assert losses[-1] < losses[0]
