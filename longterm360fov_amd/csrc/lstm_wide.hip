@@ -274,15 +274,18 @@ __global__ __launch_bounds__(256, 1) void lstm_wide_kernel(LstmParams p) {
             if (do_xch) {
 #pragma unroll
                 for (int r = 0; r < 2; ++r) sH[(my_row0 + r) * WLD + unit] = hc[r];
-                gather_issue(par);
             }
             acc[0] = (f32x4){bv[0], bv[0], bv[0], bv[0]};
             acc[1] = (f32x4){bv[1], bv[1], bv[1], bv[1]};
-            if (more) {   // x_{t+1} . K needs no remote data: it runs under the gather
+            if (more) {   // x_{t+1} . K needs no remote data
                 wm_begin(acc);
                 wide_mm<NJX>(acc, sX + ((t + 1) & 1) * WBT * WLD + n * WLD + 4 * g4, wk);
                 wm_end(acc);
             }
+            // The gather is requested only now: the partners published at about the same moment as this workgroup, and
+            // an sc1 store takes most of a microsecond to become visible - loads issued right behind the own publish
+            // came back stale and cost a second sweep (measured: 72 -> 56 us narrow, 79 -> 68 us wide, B = 512, T = 10).
+            if (do_xch) gather_issue(par);
             if (do_xch) gather_finish(par);
             __syncthreads();   // barrier 2: the whole h_t tile is in LDS
             if (sFlag[0]) { aborted = true; break; }

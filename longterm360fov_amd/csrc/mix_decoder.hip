@@ -90,12 +90,14 @@ __device__ unsigned long long g_mix_stamps[MSTAMP_STEPS][MSTAMP_SLOTS];
 #endif
 
 // acc[tile] += A(h tile rows, LDS) . W (AGPR resident, [16 k-blocks][4][2 tiles])
+template <int J0 = 0, int J1 = 16>
 __device__ __forceinline__ void recur_agpr(f32x4 (&acc)[2], const float* hrow, const float (&w)[16][4][2]) {
-    f32x4 a = *(const f32x4*)hrow;
+    if (J0 >= J1) return;
+    f32x4 a = *(const f32x4*)(hrow + 16 * J0);
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
+    for (int j = J0; j < J1; ++j) {
         f32x4 an = a;
-        if (j + 1 < 16) an = *(const f32x4*)(hrow + 16 * (j + 1));
+        if (j + 1 < J1) an = *(const f32x4*)(hrow + 16 * (j + 1));
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             mfma_a(acc[0], a[s], w[j][s][0]);
@@ -108,6 +110,7 @@ __device__ __forceinline__ void recur_agpr(f32x4 (&acc)[2], const float* hrow, c
 // acc[tile] += A(h tile rows, LDS) . K2 slice: fragment blocks (j, tile), j < 14, from LDS (this wave's region,
 // lane-linear: one ds_read_b128 = the four k-subs of a block), blocks of j = 14, 15 from registers.
 constexpr int K2_LDS_BLOCKS = 28;
+constexpr int GATHER_AFTER_BLOCK = 8;   // k-blocks of the covering MFMA product issued before the gather is requested
 __device__ __forceinline__ void recur_k2(f32x4 (&acc)[2], const float* hrow, const float* sK2l, const f32x4 (&kr)[4]) {
     f32x4 a = *(const f32x4*)hrow;
     f32x4 b0 = *(const f32x4*)sK2l, b1 = *(const f32x4*)(sK2l + 256);
@@ -347,9 +350,13 @@ __global__ __launch_bounds__(256, 1) void mix_decoder_kernel(MixDecParams p) {
             for (int r = 0; r < 2; ++r) sH1[(my_row0 + r) * MLDH + unit] = h1c[r];
             acc2[0] = (f32x4){b2v[0], b2v[0], b2v[0], b2v[0]};
             acc2[1] = (f32x4){b2v[1], b2v[1], b2v[1], b2v[1]};
-            gather_issue(par);
+            // the gather is requested part-way through the MFMAs: the partners publish at about the same moment and an sc1
+            // store needs most of a microsecond to become visible - loads issued right behind the own publish came back stale
+            // and cost a second sweep (137 -> 112 us for 10 steps at B = 512; any split point from 4 to 16 measures the same)
             mfma_begin2(acc2);
-            recur_agpr(acc2, h2row, w2);
+            recur_agpr<0, GATHER_AFTER_BLOCK>(acc2, h2row, w2);
+            gather_issue(par);
+            recur_agpr<GATHER_AFTER_BLOCK, 16>(acc2, h2row, w2);
             mfma_end2(acc2);
             MIX_STAMP(2);
             gather_finish(par, sH1);
@@ -398,14 +405,17 @@ __global__ __launch_bounds__(256, 1) void mix_decoder_kernel(MixDecParams p) {
             for (int r = 0; r < 2; ++r) sH2[(my_row0 + r) * MLDH + unit] = h2c[r];
             const bool more = (t + 1 < p.T_out);
             MIX_STAMP(6);
-            gather_issue(LAYER_BYTES + par);
-            // recurrent half of layer 1 for step t+1 under the gather of h2_t
+            // recurrent half of layer 1 for step t+1 under the gather of h2_t (requested part-way, as above)
             acc1[0] = (f32x4){b1v[0], b1v[0], b1v[0], b1v[0]};
             acc1[1] = (f32x4){b1v[1], b1v[1], b1v[1], b1v[1]};
             if (more) {
                 mfma_begin2(acc1);
-                recur_agpr(acc1, h1row, w1);
+                recur_agpr<0, GATHER_AFTER_BLOCK>(acc1, h1row, w1);
+                gather_issue(LAYER_BYTES + par);
+                recur_agpr<GATHER_AFTER_BLOCK, 16>(acc1, h1row, w1);
                 mfma_end2(acc1);
+            } else {
+                gather_issue(LAYER_BYTES + par);
             }
             MIX_STAMP(7);
             gather_finish(LAYER_BYTES + par, sH2);
