@@ -26,6 +26,8 @@ namespace fov {
 
 constexpr int BBT = 16;
 constexpr unsigned BSPIN_LIMIT = 1u << 20;
+constexpr int GATHER_AFTER_Q = 8;   // k-blocks of the local destination's product issued before the gather is requested
+                                    // (0 = right behind the last publish: 225 us; 8: 206 us; 15: 212 us at B = 1024, T = 30)
 typedef unsigned bu32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ void bmfma_va(f32x4& acc, float a, float w_agpr) {
@@ -184,25 +186,28 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_cluster_kernel(BwdParams p) {
             bu32x2 v[G > 1 ? (G - 1) * 4 : 1];
 #pragma unroll
             for (int dd = 0; dd < G; ++dd) {
-                if (dd == G - 1 && G > 1) {
-                    // all remote partials are on their way: issue the gather sweep, then do the local MFMAs
-#pragma unroll
-                    for (int k = 0; k < G - 1; ++k) {
-                        const int s_src = (slice + 1 + k) & (G - 1);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            v[k * 4 + r] = __builtin_amdgcn_raw_buffer_load_b64(
-                                xrs, (unsigned)((slice * G + s_src) * CHUNK) * 8u + lane_off + r * 512u, xsoff, 16);
-                    }
-                }
                 f32x4 a4[4];
 #pragma unroll
                 for (int s = 0; s < 4; ++s) a4[s] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 asm volatile("s_nop 1" : "+v"(a4[0]), "+v"(a4[1]), "+v"(a4[2]), "+v"(a4[3]));
 #pragma unroll
-                for (int q = 0; q < 16; ++q)
+                for (int q = 0; q < 16; ++q) {
+                    if (dd == G - 1 && G > 1 && q == GATHER_AFTER_Q) {
+                        // all remote partials are on their way, the last of them only just: the gather sweep is requested
+                        // part-way through the local destination's MFMAs (an sc1 store takes most of a microsecond to
+                        // become visible; a sweep issued right behind the partners' last publish came back stale)
+#pragma unroll
+                        for (int k = 0; k < G - 1; ++k) {
+                            const int s_src = (slice + 1 + k) & (G - 1);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+                                v[k * 4 + r] = __builtin_amdgcn_raw_buffer_load_b64(
+                                    xrs, (unsigned)((slice * G + s_src) * CHUNK) * 8u + lane_off + r * 512u, xsoff, 16);
+                        }
+                    }
 #pragma unroll
                     for (int s = 0; s < 4; ++s) bmfma_va(a4[s], afr[q][s], wB[dd][q][s]);
+                }
                 asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" : "+v"(a4[0]), "+v"(a4[1]), "+v"(a4[2]), "+v"(a4[3]));
                 f32x4 sum;
 #pragma unroll

@@ -505,12 +505,17 @@ __global__ __launch_bounds__(256, 1) void lstm_cluster_kernel(LstmParams p) {
             }
             FOV_STAMP(5);
             u32x2 v[NG > 0 ? NG : 1];
+            // DECODE has no x . K block between the publish and the gather: one own-slice k-block goes first, so the sweep is
+            // not requested right behind the partners' publish (decoder 0.191 -> 0.188 ms over three paired runs; the
+            // eight-workgroup kernels, whose stores are sc1, gain far more from the same delay - lstm_wide.hip)
+            constexpr int GJ = LAYER ? 0 : 1;
+            if (more) recurrent<H, 0, GJ>(acc, hrow, wR);
             if (do_xch) {
 #pragma unroll
                 for (int j = 0; j < NG; ++j) v[j] = __builtin_amdgcn_raw_buffer_load_b64(xrs, goff[j], xsoff, 16);
             }
             if (more) {
-                recurrent<H, 0, 4>(acc, hrow, wR);
+                recurrent<H, GJ, 4>(acc, hrow, wR);
                 mfma_end(acc);
             }
             FOV_STAMP(11);
