@@ -210,6 +210,194 @@ def bench_infer_mixing(args, rank, world, use_dist):
         dist.destroy_process_group()
 
 
+def cpu_baseline_seq2seq(enc, dec0, w, T_out, act, budget_s, want_out=False):
+    """The reference's CPU path restated two ways, both timed on the host cores of THIS box on the same
+    batch: the C port (oracle/lstm_ref.c, OpenMP) and torch's CPU kernels (torch.nn.LSTM / LSTMCell / Linear: oneDNN /
+    MKL GEMMs), each with every core this process may use and - when that is more than 16 - with 16 threads (one GPU's
+    share of an 8-GPU host).  >= 10 timed passes per leg (more while the time budget allows), median.  The FASTEST
+    leg is the baseline."""
+    from oracle import c_oracle as C
+    from oracle import torch_cpu as TC
+    from longterm360fov_amd import ops
+    B = enc.shape[0]
+    cores = TC.usable_cores()
+    counts = [cores] if cores <= 16 else [16, cores]
+    per_leg = budget_s / (len(counts) * (2 if act == "sigmoid" else 1))
+    legs = []
+    out_t = None
+    for nthr in counts:
+        C.set_num_threads(nthr)
+        med, n = TC.timed_median(lambda: C.seq2seq_decode(enc, dec0, w, T_out, ops.act_code(act)), budget_s=per_leg)
+        legs.append({"impl": "C port (oracle/lstm_ref.c, OpenMP)", "value": B / med, "ms_per_pass": med * 1e3, "passes": n,
+                     "cores": C.num_threads()})
+        if act == "sigmoid":
+            m = TC.Seq2SeqCPU(w, threads=nthr)
+            med, n = TC.timed_median(lambda: m.decode(enc, dec0, T_out), budget_s=per_leg)
+            legs.append({"impl": "torch %s CPU ops (nn.LSTM + LSTMCell + Linear, oneDNN/MKL)" % torch.__version__,
+                         "value": B / med, "ms_per_pass": med * 1e3, "passes": n, "cores": m.threads})
+            if want_out and out_t is None:
+                out_t = m.decode(enc, dec0, T_out)
+    best = max(legs, key=lambda l: l["value"])
+    cpu = {"value": best["value"], "unit": "sequences/s", "cores": best["cores"], "kind": "port",
+           "sample": "median of %d passes over the same %d-sequence batch (T_in=%d -> T_out=%d); fastest of %d legs: %s, %d threads"
+                     % (best["passes"], B, enc.shape[1], T_out, len(legs), best["impl"], best["cores"]),
+           "cpu_model": TC.cpu_model(), "host_cores_usable": cores, "legs": legs}
+    return cpu, out_t
+
+
+def bench_config1(args, rank, world, use_dist):
+    """BASELINE.json configs[0]: the reference's native operating point (FoV_seq2seq.py:20-28,112-117): 1-layer LSTM
+    H = 128, batch 32, T 10 -> 10 - a latency measurement: one fused call per batch, GPU beside the CPU legs."""
+    from longterm360fov_amd import ops
+    from oracle import fov_oracle as O
+    B, T_in, T_out, H = 32, 10, 10, 128
+    w = O.init_seq2seq(1234, 90, 6, H, bias_noise=0.05)
+    enc, dec0, _ = O.synthetic_batch(1234 + rank, B, T_in, T_out)
+    dw = {k: torch.from_numpy(v).cuda() for k, v in w.items()}
+    d_enc, d_dec0 = torch.from_numpy(enc).cuda(), torch.from_numpy(dec0).cuda()
+    out = torch.empty((B, T_out, 6), dtype=torch.float32, device="cuda")
+    ws = ops.Workspace()
+    step = lambda: ops.seq2seq_decode(d_enc, d_dec0, dw, T_out, act=args.act, impl=args.impl, workspace=ws, out=out)
+    for _ in range(max(args.warmup, 3)):
+        step()
+    torch.cuda.synchronize()
+    steps = max(args.steps, 200)
+    t0 = time.perf_counter()
+    ev_ms = event_time_ms(step, steps)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    ws.check()
+    # latency of ONE call seen from the host (launch + run + synchronise), the way model.predict would pay it
+    lat = []
+    for _ in range(50):
+        t1 = time.perf_counter()
+        step()
+        torch.cuda.synchronize()
+        lat.append(time.perf_counter() - t1)
+    if rank == 0:
+        ref = O.seq2seq_decode(enc.astype(np.float64), dec0.astype(np.float64), {k: v.astype(np.float64) for k, v in w.items()},
+                               T_out, act=args.act)
+        err = float(np.abs(out.cpu().numpy() - ref).max())
+        f_enc, f_dec = flops_per_seq(T_in, T_out, 90, 6, H)
+        cpu = None
+        if not args.no_cpu_baseline and world == 1:
+            cpu, _ = cpu_baseline_seq2seq(enc, dec0, w, T_out, args.act, budget_s=8.0)
+        ach = (f_enc + f_dec) * B / (ev_ms * 1e-3) / 1e12
+        print(json.dumps({
+            "metric": "sequences/sec (batch=%d, T_in=%d->T_out=%d, h=%d)" % (B, T_in, T_out, H),
+            "value": world * B * steps / elapsed, "unit": "sequences/s", "n_gpus": world, "steps": steps, "warmup": max(args.warmup, 3),
+            "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[0]: the reference's native operating point, target-only seq2seq inference, H=128, "
+                                   "batch=32, T 10->10 (latency-bound: 2 of 256 CUs' worth of tiles)", "global_batch": B * world,
+                       "parallelism": "replicas x%d" % world},
+            "latency": {"gpu_ms_per_call_async": ev_ms, "gpu_ms_per_call_host_synchronised_median": float(np.median(lat)) * 1e3,
+                        "cpu_ms_per_call": None if cpu is None else min(l["ms_per_pass"] for l in cpu["legs"])},
+            "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                         "note": "two 16-sequence tiles: 4 workgroups busy, per-step latency bound by construction"},
+            "parity": {"max_abs_err_vs_oracle": err, "sequences_checked": B},
+            "cpu_baseline": cpu, "speedup_vs_cpu_baseline": None if cpu is None else world * B * steps / elapsed / cpu["value"]}), flush=True)
+
+
+def bench_convlstm(args, rank, world, use_dist):
+    """BASELINE.json configs[3]: ConvLSTM seq2seq on 36x18x30 heat maps, filters 32/16/8, k = 5, T 10 -> 10, B = 256:
+    cell-only (3-layer encoder) and the whole model incl. the Conv2D 56->512->1024->30 head; training step at
+    --train-batch (the time-major tape of the 1024-channel head activation is 27 MB per sequence-step)."""
+    from longterm360fov_amd import ops
+    from longterm360fov_amd.models import ConvLSTMSeq2Seq
+    from oracle import fov_oracle as O
+    Hh, Ww, C, T = 36, 18, 30, 10
+    B = args.batch if args.batch != 1024 else 256
+    w = O.init_convlstm_seq2seq(1, C=C, latent_dim=16, head="conv2d")
+    dw = {k: torch.from_numpy(v).cuda() for k, v in w.items()}
+    x0 = torch.rand((B, T, Hh, Ww, C), device="cuda")
+    filters = (32, 16, 8)
+    cin = (C,) + filters[:2]
+    cell_flop_step = sum(2 * 25 * (ci + f) * 4 * f for ci, f in zip(cin, filters)) * Hh * Ww   # per sequence-step
+    head_flop = 2 * 25 * (56 * 512 + 512 * 1024 + 1024 * 30) * Hh * Ww
+    kr = [torch.cat([dw["enc%d_K" % l], dw["enc%d_R" % l]], 2).contiguous() for l in range(3)]
+    x = torch.cat([x0, torch.zeros((B, T, Hh, Ww, 2), device="cuda")], -1).contiguous()   # channels 30 -> 32 (zero rows in K)
+    K0 = torch.cat([dw["enc0_K"], torch.zeros((5, 5, 2, 4 * filters[0]), device="cuda")], 2)
+    kr[0] = torch.cat([K0, dw["enc0_R"]], 2).contiguous()
+
+    def encoder():
+        seq = [x[:, t] for t in range(T)]
+        for l, F in enumerate(filters):
+            h = torch.zeros((B, Hh, Ww, F), device="cuda")
+            c = torch.zeros((B, Hh, Ww, F), device="cuda")
+            nxt = []
+            for t in range(T):
+                z = ops.conv2d_cat(seq[t], h, kr[l], dw["enc%d_b" % l])
+                hn = torch.empty((B, Hh, Ww, F), device="cuda")
+                ops.convlstm_gates(z, c, hn, "hard_sigmoid")
+                h = hn
+                nxt.append(h)
+            seq = nxt
+
+    for _ in range(max(1, args.warmup // 2)):
+        encoder()
+    steps = max(3, min(args.steps, 10))
+    cell_ms = event_time_ms(encoder, steps)
+    m = ConvLSTMSeq2Seq(w, head="conv2d")
+    xe = x0.cpu().numpy()
+    m.predict([xe[:8], xe[:8, -1:]], predict_step=1)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    m.predict([xe, xe[:, -1:]], predict_step=T)
+    whole_s = time.perf_counter() - t0
+    res_train = None
+    if args.train_batch > 0:
+        from longterm360fov_amd.training import ConvLSTMTrainer
+        Bt = args.train_batch
+        tr = ConvLSTMTrainer(w, head="conv2d")
+        xt = x0[:Bt].contiguous()
+        tgt = torch.softmax(torch.rand((Bt, T, Hh, Ww, C), device="cuda"), -1)
+        tr.train_step(xt, xt[:, -1:], tgt)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(2):
+            loss = tr.train_step(xt, xt[:, -1:], tgt)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 2
+        tot = 3 * (2 * cell_flop_step + head_flop) * T * Bt
+        res_train = {"batch": Bt, "ms_per_step": dt * 1e3, "sequences_per_s": Bt / dt, "tflops_3x_forward": tot / dt / 1e12,
+                     "frac_of_fp32_mfma_peak": tot / dt / 1e12 / PEAK_FP32_MFMA_TFLOPS, "loss": float(loss.item())}
+    if rank == 0:
+        cell_tf = cell_flop_step * T * B / (cell_ms * 1e-3) / 1e12
+        whole_tf = (2 * cell_flop_step + head_flop) * T * B / whole_s / 1e12
+        print(json.dumps({
+            "metric": "sequences/sec, ConvLSTM seq2seq whole model (batch=%d, 36x18x30 maps, T 10->10)" % B,
+            "value": world * B / whole_s, "unit": "sequences/s", "n_gpus": world, "steps": 1, "warmup": 1,
+            "ms_per_step": whole_s * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "configs[3]: convlstm_seq2seq.py heat-map path, ConvLSTM 32/16/8 k=5 x3 enc + x3 dec + Conv2D "
+                                   "56->512->1024->30 head, B=%d (host arrays in, host arrays out: the Keras predict surface)" % B,
+                       "global_batch": B * world, "parallelism": "replicas x%d" % world},
+            "roofline": {"bound": "mfma", "achieved": whole_tf, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": whole_tf / PEAK_FP32_MFMA_TFLOPS, "traffic": None, "note": "whole model incl. the head (50x the cell's FLOPs)"},
+            "cell_only": {"ms": cell_ms, "sequences_per_s": B / (cell_ms * 1e-3), "tflops": cell_tf,
+                          "frac_of_fp32_mfma_peak": cell_tf / PEAK_FP32_MFMA_TFLOPS,
+                          "workload": "3-layer ConvLSTM encoder over T=10 steps (half the model's cell FLOPs), device-resident"},
+            "training": res_train, "cpu_baseline": None}), flush=True)
+
+
+def bench_dry_run(args, rank, world, use_dist):
+    """Launch plumbing only (tests, no GPU): rendezvous, barrier, max-over-ranks, one JSON line from rank 0."""
+    import torch.distributed as dist
+    elapsed = 0.001 * (rank + 1)
+    if use_dist:
+        dist.barrier()
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps({"metric": "dry-run", "n_gpus": world, "max_elapsed": elapsed}), flush=True)
+    if use_dist:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -221,19 +409,50 @@ def main():
     ap.add_argument("--hidden", type=int, default=256)
     ap.add_argument("--impl", default="auto", choices=["auto", "cluster", "generic"])
     ap.add_argument("--act", default="sigmoid", choices=["sigmoid", "hard_sigmoid"])
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
+                    help="bf16: configs[4] - bf16 operands into the MFMA, fp32 accumulate / cell state / master weights "
+                         "(modes train_mixing and infer_mixing)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU-baseline timing (both legs together)")
+    ap.add_argument("--train-batch", type=int, default=64, help="convlstm mode: batch of the timed training step (0 = skip)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the N > 1 path "
                          "with several ranks on ONE GPU)")
-    ap.add_argument("--mode", default="infer", choices=["infer", "train", "train_mixing", "infer_mixing"],
+    ap.add_argument("--dry-run", action="store_true", help="launch plumbing only: no GPU work (CPU tests)")
+    ap.add_argument("--mode", default="infer",
+                    choices=["infer", "train", "train_mixing", "infer_mixing", "config1", "convlstm"],
                     help="infer (default, the BASELINE metric): encoder + autoregressive decoder; train: one "
-                         "teacher-forced training step (fwd + BPTT + Adam, data-parallel all-reduce when N > 1)")
+                         "teacher-forced training step (fwd + BPTT + Adam, data-parallel all-reduce when N > 1); "
+                         "train_mixing / infer_mixing: configs[2] (512 sequences per GPU); config1: configs[0] latency; "
+                         "convlstm: configs[3]")
     args = ap.parse_args()
 
+    # `python bench.py --gpus N` on its own starts the N ranks itself: one child launcher (torch.distributed.run, one
+    # process per GPU, RCCL rendezvous on 127.0.0.1) BEFORE anything in this process touches the GPU; rank 0's JSON
+    # line comes through the inherited stdout and the child's exit code is returned.  Under a launcher (WORLD_SIZE
+    # set) --gpus must agree with it.
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        import socket
+        import subprocess
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.run(cmd).returncode)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks\n" % (args.gpus, world))
+        sys.exit(2)
     use_dist = world > 1
+    if args.dry_run:
+        if use_dist:
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("gloo")
+        return bench_dry_run(args, rank, world, use_dist)
     device_index = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(device_index)
     if use_dist:
@@ -252,6 +471,12 @@ def main():
         return bench_train_mixing(args, rank, world, use_dist)
     if args.mode == "infer_mixing":
         return bench_infer_mixing(args, rank, world, use_dist)
+    if args.mode in ("config1", "convlstm"):
+        (bench_config1 if args.mode == "config1" else bench_convlstm)(args, rank, world, use_dist)
+        if use_dist:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     B, T_in, T_out, H = args.batch, args.t_in, args.t_out, args.hidden
     F_enc, F_dec = 90, 6
@@ -286,6 +511,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     ws.check()
+    xmode = ws.exchange_mode()
     step_ms_events = ev0.elapsed_time(ev1) / args.steps
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
@@ -297,36 +523,31 @@ def main():
         f_enc, f_dec = flops_per_seq(T_in, T_out, F_enc, F_dec, H)
         flop_step = (f_enc + f_dec) * B
         achieved = flop_step / (step_ms_events * 1e-3) / 1e12
-        # per-launch breakdown: the same two kernels, event-timed on their own
-        hT = torch.empty((B, H), dtype=torch.float32, device="cuda")
+        # per-launch breakdown: each of the step's two kernels event-timed on its own (encoder layer launch; decoder
+        # launch from the encoder's final state)
+        iters = max(5, args.steps // 2)
+        _, hT, cT = ops.lstm_seq(d_enc, dw["enc_K"], dw["enc_R"], dw["enc_b"], act=args.act, impl=args.impl,
+                                 return_sequences=False, workspace=ws)
+        enc_ms = event_time_ms(lambda: ops.lstm_seq(d_enc, dw["enc_K"], dw["enc_R"], dw["enc_b"], act=args.act, impl=args.impl,
+                                                    return_sequences=False, workspace=ws), iters)
+        out2 = torch.empty_like(out)
+        dec_fn = lambda: ops.seq2seq_decoder(d_dec0, hT, cT, dw, T_out, act=args.act, impl=args.impl, workspace=ws, out=out2)
+        dec_fn()
+        dec_ms = event_time_ms(dec_fn, iters)
+        ws.check()
 
-        def enc_only():
-            ops.lstm_seq(d_enc, dw["enc_K"], dw["enc_R"], dw["enc_b"], act=args.act, impl=args.impl,
-                         return_sequences=False, workspace=ws)
-
-        enc_only()
-        enc_ms = event_time_ms(enc_only, max(5, args.steps // 2))
-        dec_ms = max(step_ms_events - enc_ms, 0.0)
-
-        # parity spot check on the measured configuration (first 64 sequences vs the C oracle)
+        # parity on the measured configuration: first 64 sequences vs the C oracle; decoder-only call vs the fused call
         from oracle import c_oracle as C
         nchk = min(64, B)
         ref = C.seq2seq_decode(enc[:nchk], dec0[:nchk], w, T_out, ops.act_code(args.act))
         got = out[:nchk].cpu().numpy()
         max_abs = float(np.abs(got - ref).max()) if nchk else 0.0
         mse = float(np.mean((got.astype(np.float64) - ref) ** 2)) if nchk else 0.0
+        split_equal = bool(torch.equal(out, out2))
 
-        cpu = None
-        if not args.no_cpu_baseline:
-            reps = 3
-            C.seq2seq_decode(enc[:64], dec0[:64], w, T_out)            # warm
-            tc = time.perf_counter()
-            for _ in range(reps):
-                C.seq2seq_decode(enc, dec0, w, T_out, ops.act_code(args.act))
-            dt = time.perf_counter() - tc
-            cpu = {"value": B * reps / dt, "unit": "sequences/s", "cores": C.num_threads(), "kind": "port",
-                   "sample": "%d passes of the C oracle (oracle/lstm_ref.c, OpenMP) over the same %d-sequence "
-                             "batch, T %d->%d, H=%d" % (reps, B, T_in, T_out, H)}
+        cpu, cpu_out = None, None
+        if not args.no_cpu_baseline and world == 1:   # rank 0 at N = 1 only (launchers also pin OMP_NUM_THREADS = 1)
+            cpu, cpu_out = cpu_baseline_seq2seq(enc, dec0, w, T_out, args.act, budget_s=args.cpu_budget, want_out=True)
 
         value = world * B * args.steps / elapsed
         # HBM-side bytes per step are not measurable from inside this process: they come from separate rocprofv3
@@ -336,7 +557,7 @@ def main():
         if (B, T_in, T_out, H, args.act, args.impl) == PMC_TRAFFIC_CONFIG:
             traffic, traffic_src = PMC_TRAFFIC_BYTES, PMC_TRAFFIC_SOURCE
         result = {
-            "metric": "sequences/sec (batch=1024, T_in=30->T_out=30, h=256)",
+            "metric": "sequences/sec (batch=%d, T_in=%d->T_out=%d, h=%d)" % (B, T_in, T_out, H),
             "value": value, "unit": "sequences/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -351,8 +572,13 @@ def main():
                          "note": "launch = one step = encoder kernel + decoder kernel of lstm_cluster_kernel"},
             "kernels": {"encoder_ms": enc_ms, "decoder_ms": dec_ms,
                         "encoder_tflops": f_enc * B / (enc_ms * 1e-3) / 1e12,
-                        "decoder_tflops": (f_dec * B / (dec_ms * 1e-3) / 1e12) if dec_ms > 0 else None},
-            "parity": {"max_abs_err_vs_oracle": max_abs, "mse_vs_oracle": mse, "sequences_checked": nchk},
+                        "decoder_tflops": f_dec * B / (dec_ms * 1e-3) / 1e12,
+                        "note": "each launch event-timed on its own over %d back-to-back calls" % iters},
+            "exchange": {"mode": xmode, "meaning": "1 = every group of the last launch verified a shared XCD and exchanged h "
+                                                   "through that XCD's L2; 2 = at least one group on the write-through path"},
+            "parity": {"max_abs_err_vs_oracle": max_abs, "mse_vs_oracle": mse, "sequences_checked": nchk,
+                       "decoder_only_call_equals_fused_call": split_equal,
+                       "max_abs_err_vs_torch_cpu": None if cpu_out is None else float(np.abs(out.cpu().numpy() - cpu_out).max())},
             "cpu_baseline": cpu,
         }
         if cpu:

@@ -14,6 +14,14 @@
  *     workspace whose size is queried first (fov_*_workspace_bytes).
  *   - Weights use the Keras layout so weight files round-trip:
  *       kernel K:(F,4H), recurrent_kernel R:(H,4H), bias b:(4H); gate column blocks i,f,c,o.
+ *   - A workspace handed to a persistent-kernel entry point (every call that takes `workspace` and whose
+ *     fov_*_workspace_bytes is larger than a few KB) is STATEFUL: zero-fill it ONCE after allocating it
+ *     (fov_workspace_init, or hipMemset) and then leave its contents alone between calls.  It carries a
+ *     256-byte header and a 64 MB granule area whose {value, epoch} words use epoch tags that increase
+ *     monotonically across calls, so no call has to clear anything (csrc/xch_common.h).  One workspace
+ *     serves one stream at a time; different entry points may share it.  The header's timeout word is
+ *     sticky: once a bounded in-kernel wait has given up, every later call on that workspace returns
+ *     without computing until fov_check_status has reported (and cleared) the failure.
  *   - Every function returns FOV_OK (0) or a negative FOV_ERR_*; fov_last_error() gives the
  *     message of the calling thread's last failure.  No host synchronisation inside a call
  *     (except fov_check_status, which is the explicit "did the persistent kernel finish
@@ -170,6 +178,15 @@ int fov_seq2seq_decode_fwd(const float* enc_in, const float* dec_in0,
                            int act, int impl,
                            void* workspace, size_t workspace_bytes, fov_stream_t stream);
 
+/* The decoder half alone: T_out autoregressive steps from a GIVEN state (h0, c0) (B,H) (NULL = zeros) - what the
+ * reference's sampling loop does after encoder_model.predict (FoV_seq2seq.py:156-178: decoder_model.predict fed its own
+ * output), any batch, one launch.  out (B,T_out,F_dec); hT, cT (B,H) optional final state.  Workspace as for
+ * fov_seq2seq_decode_fwd. */
+int fov_seq2seq_decoder_fwd(const float* dec_in0, const float* h0, const float* c0, const float* dec_K,
+                            const float* dec_R, const float* dec_b, const float* dense_W, const float* dense_b,
+                            float* out, float* hT, float* cT, int B, int T_out, int F_dec, int H, int act, int impl,
+                            void* workspace, size_t workspace_bytes, fov_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------
  * Teacher-forced training-graph forward: encoder, decoder seeded with the encoder state over
  * GT decoder inputs, Dense(tanh) on every decoder output.
@@ -236,6 +253,18 @@ int fov_dense_bwd(const float* x, const float* W, const float* dpre, float* dx, 
 int fov_mse_dense_grad(const float* y, const float* target, float* dpre, float* loss, int64_t n,
                        int activation, void* workspace, size_t workspace_bytes, fov_stream_t stream);
 
+/* The same with (1) `weight` applied to dpre AND to *loss - under data parallelism a rank passes
+ * n_local / n_global, so a plain SUM all-reduce of the flat gradient buffer (which also carries the loss) yields the
+ * global-batch mean without a scaling pass - and (2) optionally a time-major prediction: time_major_T > 0 means y
+ * and dpre are (T,B,O) while target stays (B,T,O) (the unrolled decoders of given_others...py keep their tape
+ * time-major); then n must equal B*T*O.  time_major_T = 0: dense, same order (B, O unused). */
+int fov_mse_dense_grad_w(const float* y, const float* target, float* dpre, float* loss, int64_t n, int activation,
+                         float weight, int time_major_B, int time_major_T, int O, void* workspace, size_t workspace_bytes,
+                         fov_stream_t stream);
+
+/* x[0..n) *= s */
+int fov_scale(float* x, int64_t n, float s, fov_stream_t stream);
+
 /* Backward of an elementwise activation given its OUTPUT y: out = base + dy * act'(y), act' = 1 - y^2 for tanh
  * (activation 1), [y > 0] for relu (activation 2), y for exp (activation 3) or 1 (activation 0); base may be NULL; out may alias base or dy.  Used where a Dense output is
  * fed back as the next decoder input (given_others...py:292-293): the feedback gradient joins the loss gradient. */
@@ -290,6 +319,14 @@ int fov_adam_step(float* params, const float* grads, float* m, float* v, int64_t
                   float lr, float beta1, float beta2, float eps, int64_t step, fov_stream_t stream);
 int fov_rmsprop_step(float* params, const float* grads, float* accum, int64_t n,
                      float lr, float rho, float eps, fov_stream_t stream);
+/* The same, fail-stop: guard0..2 (each may be NULL) are the workspaces the training step's persistent-kernel calls
+ * used.  If the sticky timeout word of one of them is set the gradients are garbage and the update is skipped ON THE
+ * DEVICE (no host synchronisation); the parameters stay as they were until fov_check_status reports the failure. */
+int fov_adam_step_guarded(float* params, const float* grads, float* m, float* v, int64_t n, float lr, float beta1,
+                          float beta2, float eps, int64_t step, const void* guard0, const void* guard1,
+                          const void* guard2, fov_stream_t stream);
+int fov_rmsprop_step_guarded(float* params, const float* grads, float* accum, int64_t n, float lr, float rho, float eps,
+                             const void* guard0, const void* guard1, const void* guard2, fov_stream_t stream);
 
 /* =======================================================================================
  * ConvLSTM2D seq2seq building blocks (a8/a9) - mycode/convlstm_seq2seq.py:100-126,146-165 (ConvLSTM2D),
@@ -371,9 +408,15 @@ int fov_window_stacks(const float* x, float* enc, float* fut, float* fut_in, int
 int fov_fov_hit_rate(const float* pred_xyz, int64_t pred_row_stride, const float* gt_xyz, int64_t gt_row_stride,
                      float* out, int64_t rows, float span_deg, float gt_span_deg, fov_stream_t stream);
 
-/* Synchronises `stream`, reads the status word a persistent-kernel call left in `workspace`
- * and returns FOV_OK or FOV_ERR_TIMEOUT.  Workspaces of non-persistent calls report FOV_OK. */
-int fov_check_status(const void* workspace, size_t workspace_bytes, fov_stream_t stream);
+/* Zero-fills a freshly allocated workspace (asynchronously on `stream`): required once before its first use by
+ * a persistent-kernel entry point, and again whenever the buffer is re-allocated. */
+int fov_workspace_init(void* workspace, size_t workspace_bytes, fov_stream_t stream);
+
+/* Synchronises `stream`, reads the sticky status word the persistent-kernel calls leave in `workspace` and
+ * returns FOV_OK or FOV_ERR_TIMEOUT (= some call since the previous check gave up a bounded wait; its outputs and
+ * those of every later call on this workspace are invalid).  Reporting a failure clears it (the workspace is
+ * re-zeroed and usable again).  Workspaces of non-persistent calls report FOV_OK. */
+int fov_check_status(void* workspace, size_t workspace_bytes, fov_stream_t stream);
 
 /* Diagnostic: which h-exchange protocol the last persistent-kernel call on `workspace` used.
  * 1 = every group verified (HW_REG_XCC_ID handshake) that its workgroups share an XCD and took the

@@ -46,6 +46,7 @@ SIGNATURES = {
     "fov_lstm_seq_fwd_zx": (_I, [_P] * 9 + [_I] * 5 + [_P, _SZ, _P]),
     "fov_seq2seq_decode_workspace_bytes": (_SZ, [_I] * 7),
     "fov_seq2seq_decode_fwd": (_I, [_P] * 13 + [_I] * 8 + [_P, _SZ, _P]),
+    "fov_seq2seq_decoder_fwd": (_I, [_P] * 11 + [_I] * 6 + [_P, _SZ, _P]),
     "fov_seq2seq_tf_workspace_bytes": (_SZ, [_I] * 7),
     "fov_seq2seq_tf_fwd": (_I, [_P] * 11 + [_I] * 8 + [_P, _SZ, _P]),
     "fov_meanvar_xyz": (_I, [_P, _P, ctypes.c_int64, _I, _P]),
@@ -55,6 +56,8 @@ SIGNATURES = {
     "fov_dense_bwd_workspace_bytes": (_SZ, [_I] * 3),
     "fov_dense_bwd": (_I, [_P] * 6 + [_I] * 4 + [_P, _SZ, _P]),
     "fov_mse_dense_grad": (_I, [_P] * 4 + [ctypes.c_int64, _I, _P, _SZ, _P]),
+    "fov_mse_dense_grad_w": (_I, [_P] * 4 + [ctypes.c_int64, _I, ctypes.c_float, _I, _I, _I, _P, _SZ, _P]),
+    "fov_scale": (_I, [_P, ctypes.c_int64, ctypes.c_float, _P]),
     "fov_act_bwd": (_I, [_P] * 4 + [ctypes.c_int64, _I, _P]),
     "fov_act_fwd": (_I, [_P, _P, ctypes.c_int64, _I, _P]),
     "fov_gauss_nll_grad": (_I, [_P] * 6 + [_I] * 3 + [ctypes.c_float, _P, _SZ, _P]),
@@ -65,6 +68,8 @@ SIGNATURES = {
     "fov_sample_refeed_bwd": (_I, [_P, ctypes.c_int64] + [_P] * 4 + [_I] * 5 + [_P]),
     "fov_adam_step": (_I, [_P] * 4 + [ctypes.c_int64] + [ctypes.c_float] * 4 + [ctypes.c_int64, _P]),
     "fov_rmsprop_step": (_I, [_P] * 3 + [ctypes.c_int64] + [ctypes.c_float] * 3 + [_P]),
+    "fov_adam_step_guarded": (_I, [_P] * 4 + [ctypes.c_int64] + [ctypes.c_float] * 4 + [ctypes.c_int64] + [_P] * 4),
+    "fov_rmsprop_step_guarded": (_I, [_P] * 3 + [ctypes.c_int64] + [ctypes.c_float] * 3 + [_P] * 4),
     "fov_conv2d_fwd": (_I, [_P, ctypes.c_int64, ctypes.c_int64, _P, _P, _P, _P] + [_I] * 8 + [_P]),
     "fov_conv2d_fwd2": (_I, [_P, ctypes.c_int64, ctypes.c_int64, _I, _P, ctypes.c_int64, ctypes.c_int64, _I, _P, _P, _P, _P] + [_I] * 7 + [_P]),
     "fov_convlstm_gates": (_I, [_P, _P, _P, ctypes.c_int64, ctypes.c_int64, _I, _I, _P]),
@@ -79,6 +84,7 @@ SIGNATURES = {
     "fov_window_count": (ctypes.c_int64, [_I, _I, _I]),
     "fov_window_stacks": (_I, [_P] * 4 + [_I] * 6 + [_P]),
     "fov_fov_hit_rate": (_I, [_P, ctypes.c_int64, _P, ctypes.c_int64, _P, ctypes.c_int64, ctypes.c_float, ctypes.c_float, _P]),
+    "fov_workspace_init": (_I, [_P, _SZ, _P]),
     "fov_check_status": (_I, [_P, _SZ, _P]),
     "fov_exchange_mode": (_I, [_P, _SZ, _P]),
 }

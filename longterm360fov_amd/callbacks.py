@@ -40,9 +40,7 @@ class ModelCheckpoint(Callback):
         if self._since < self.period:
             return
         self._since = 0
-        path = self.filepath.format(epoch=epoch + 1, **logs)
-        if path.endswith(".h5"):
-            path = path[:-3] + ".npz"
+        path = self.model.weights_path(self.filepath.format(epoch=epoch + 1, **logs))   # '.h5' names map to '.npz'
         if self.save_best_only:
             cur = logs.get(self.monitor)
             if cur is None or not self.op(cur, self.best):

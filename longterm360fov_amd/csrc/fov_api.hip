@@ -5,6 +5,7 @@
 #include <stdio.h>
 
 #include "fov_common.h"
+#include "xch_common.h"
 
 namespace fov {
 
@@ -364,10 +365,6 @@ static int lstm_seq_fwd_impl(const float* x, const float* K, const float* R, con
     // narrow inputs, at most 32 tiles: groups of eight workgroups fill the chip where lstm_cluster's groups of four leave half idle
     if (impl == FOV_IMPL_AUTO && T > 0 && wide_narrow_preferred(B, F, H)) return launch_wide(p, s);
     if (want_cluster(impl, F, H, 0, false)) return launch_cluster(p, false, s);
-    if (B > 0) {
-        hipError_t e = hipMemsetAsync(workspace, 0, kStatusBytes, s);
-        if (e != hipSuccess) { set_error("hipMemsetAsync: %s", hipGetErrorString(e)); return FOV_ERR_LAUNCH; }
-    }
     return launch_generic(p, false, s);
 }
 
@@ -406,10 +403,6 @@ int fov_lstm_seq_fwd_zx(const float* zx, const float* R, const float* b, const f
     p.xch = (unsigned long long*)((char*)workspace + kStatusBytes);
     hipStream_t s = (hipStream_t)stream;
     if (want_cluster(impl, 1, H, 0, false)) return launch_cluster(p, false, s);
-    if (B > 0) {
-        hipError_t e = hipMemsetAsync(workspace, 0, kStatusBytes, s);
-        if (e != hipSuccess) { set_error("hipMemsetAsync: %s", hipGetErrorString(e)); return FOV_ERR_LAUNCH; }
-    }
     return launch_generic(p, false, s);
 }
 
@@ -465,6 +458,26 @@ int fov_mse_dense_grad(const float* y, const float* target, float* dpre, float* 
     if (rc) return rc;
     return mse_dense_grad(y, target, dpre, loss, (long)n, activation, (float*)workspace, workspace_bytes / sizeof(float),
                           (hipStream_t)stream);
+}
+
+int fov_mse_dense_grad_w(const float* y, const float* target, float* dpre, float* loss, int64_t n, int activation,
+                         float weight, int time_major_B, int time_major_T, int O, void* workspace, size_t workspace_bytes,
+                         fov_stream_t stream) {
+    const bool tm = time_major_T > 0;
+    if (n < 0 || (n > 0 && (!y || !target || !dpre)) || (activation != 0 && activation != 1) ||
+        (tm && (time_major_B <= 0 || O <= 0 || (int64_t)time_major_B * time_major_T * O != n))) {
+        set_error("fov_mse_dense_grad_w: invalid argument");
+        return FOV_ERR_INVALID;
+    }
+    int rc = check_ws(workspace, workspace_bytes, sizeof(float) * ((size_t)(n + 255) / 256 + 64));
+    if (rc) return rc;
+    return mse_dense_grad_w(y, target, dpre, loss, (long)n, activation, weight, tm ? time_major_B : 1, tm ? time_major_T : 0,
+                            tm ? O : 1, (float*)workspace, workspace_bytes / sizeof(float), (hipStream_t)stream);
+}
+
+int fov_scale(float* x, int64_t n, float s, fov_stream_t stream) {
+    if (n < 0 || (n > 0 && !x)) { set_error("fov_scale: invalid argument"); return FOV_ERR_INVALID; }
+    return scale_inplace(x, (long)n, s, (hipStream_t)stream);
 }
 
 int fov_act_bwd(const float* dy, const float* y, const float* base, float* out, int64_t n, int activation,
@@ -549,23 +562,36 @@ int fov_rmsprop_tf_step(float* params, const float* grads, float* ms, int64_t n,
     return rmsprop_tf_step(params, grads, ms, (long)n, lr, decay, eps, clip_value, (hipStream_t)stream);
 }
 
-int fov_adam_step(float* params, const float* grads, float* m, float* v, int64_t n, float lr, float beta1,
-                  float beta2, float eps, int64_t step, fov_stream_t stream) {
+int fov_adam_step_guarded(float* params, const float* grads, float* m, float* v, int64_t n, float lr, float beta1,
+                          float beta2, float eps, int64_t step, const void* guard0, const void* guard1, const void* guard2,
+                          fov_stream_t stream) {
     if (n < 0 || step < 1 || (n > 0 && (!params || !grads || !m || !v))) {
         set_error("fov_adam_step: invalid argument");
         return FOV_ERR_INVALID;
     }
     const double lr_t = (double)lr * sqrt(1.0 - pow((double)beta2, (double)step)) / (1.0 - pow((double)beta1, (double)step));
-    return adam_step(params, grads, m, v, (long)n, (float)lr_t, beta1, beta2, eps, (hipStream_t)stream);
+    const unsigned* guards[3] = {(const unsigned*)guard0, (const unsigned*)guard1, (const unsigned*)guard2};
+    return adam_step(params, grads, m, v, (long)n, (float)lr_t, beta1, beta2, eps, guards, (hipStream_t)stream);
 }
 
-int fov_rmsprop_step(float* params, const float* grads, float* accum, int64_t n, float lr, float rho, float eps,
-                     fov_stream_t stream) {
+int fov_adam_step(float* params, const float* grads, float* m, float* v, int64_t n, float lr, float beta1,
+                  float beta2, float eps, int64_t step, fov_stream_t stream) {
+    return fov_adam_step_guarded(params, grads, m, v, n, lr, beta1, beta2, eps, step, nullptr, nullptr, nullptr, stream);
+}
+
+int fov_rmsprop_step_guarded(float* params, const float* grads, float* accum, int64_t n, float lr, float rho, float eps,
+                             const void* guard0, const void* guard1, const void* guard2, fov_stream_t stream) {
     if (n < 0 || (n > 0 && (!params || !grads || !accum))) {
         set_error("fov_rmsprop_step: invalid argument");
         return FOV_ERR_INVALID;
     }
-    return rmsprop_step(params, grads, accum, (long)n, lr, rho, eps, (hipStream_t)stream);
+    const unsigned* guards[3] = {(const unsigned*)guard0, (const unsigned*)guard1, (const unsigned*)guard2};
+    return rmsprop_step(params, grads, accum, (long)n, lr, rho, eps, guards, (hipStream_t)stream);
+}
+
+int fov_rmsprop_step(float* params, const float* grads, float* accum, int64_t n, float lr, float rho, float eps,
+                     fov_stream_t stream) {
+    return fov_rmsprop_step_guarded(params, grads, accum, n, lr, rho, eps, nullptr, nullptr, nullptr, stream);
 }
 
 int fov_dense_fwd(const float* x, const float* W, const float* b, float* y, int N, int In, int Out,
@@ -732,11 +758,30 @@ int fov_seq2seq_decode_fwd(const float* enc_in, const float* dec_in0, const floa
     p.xch = (unsigned long long*)((char*)workspace + kStatusBytes);
     hipStream_t s = (hipStream_t)stream;
     if (want_cluster(impl, F_enc, H, F_dec, true)) return launch_cluster(p, true, s);
-    if (B > 0) {
-        hipError_t e = hipMemsetAsync(workspace, 0, kStatusBytes, s);
-        if (e != hipSuccess) { set_error("hipMemsetAsync: %s", hipGetErrorString(e)); return FOV_ERR_LAUNCH; }
-    }
     return launch_generic(p, true, s);
+}
+
+int fov_seq2seq_decoder_fwd(const float* dec_in0, const float* h0, const float* c0, const float* dec_K,
+                            const float* dec_R, const float* dec_b, const float* dense_W, const float* dense_b, float* out,
+                            float* hT, float* cT, int B, int T_out, int F_dec, int H, int act, int impl, void* workspace,
+                            size_t workspace_bytes, fov_stream_t stream) {
+    if (B < 0 || T_out < 0 || F_dec <= 0 || H <= 0 || !dec_K || !dec_R || !dec_b || !dense_W || !dense_b ||
+        (B > 0 && (!dec_in0 || (T_out > 0 && !out))) || (act != FOV_ACT_SIGMOID && act != FOV_ACT_HARD_SIGMOID)) {
+        set_error("fov_seq2seq_decoder_fwd: invalid argument");
+        return FOV_ERR_INVALID;
+    }
+    if (F_dec > 64) { set_error("fov_seq2seq_decoder_fwd: F_dec > 64 unsupported"); return FOV_ERR_UNSUPPORTED; }
+    int rc = check_ws(workspace, workspace_bytes, fov_seq2seq_decode_workspace_bytes(B, 0, T_out, 1, F_dec, H, impl));
+    if (rc) return rc;
+    LstmParams p = {};
+    p.h0 = h0; p.c0 = c0; p.hT = hT; p.cT = cT;
+    p.dec_in0 = dec_in0; p.dK = dec_K; p.dR = dec_R; p.db = dec_b; p.dW = dense_W; p.dbias = dense_b; p.out = out;
+    p.B = B; p.T = 0; p.F = 1; p.H = H; p.T_out = T_out; p.F_dec = F_dec; p.act = act;
+    p.status = (unsigned*)workspace;
+    p.xch = (unsigned long long*)((char*)workspace + kStatusBytes);
+    if (want_cluster(impl, 1, H, F_dec, true)) return launch_cluster_decoder(p, (hipStream_t)stream);
+    p.K = dec_K; p.R = dec_R; p.b = dec_b;   // unused by the generic kernel's empty encoder phase (T = 0)
+    return launch_generic(p, true, (hipStream_t)stream);
 }
 
 static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -792,16 +837,38 @@ int fov_meanvar_xyz(const float* y, float* out, int64_t rows, int fps, fov_strea
     return FOV_OK;
 }
 
-int fov_check_status(const void* workspace, size_t workspace_bytes, fov_stream_t stream) {
+int fov_workspace_init(void* workspace, size_t workspace_bytes, fov_stream_t stream) {
+    if (!workspace || workspace_bytes < kStatusBytes) {
+        set_error("fov_workspace_init: invalid workspace");
+        return FOV_ERR_INVALID;
+    }
+    hipError_t e = hipMemsetAsync(workspace, 0, workspace_bytes, (hipStream_t)stream);
+    if (e != hipSuccess) { set_error("fov_workspace_init: %s", hipGetErrorString(e)); return FOV_ERR_LAUNCH; }
+    return FOV_OK;
+}
+
+int fov_check_status(void* workspace, size_t workspace_bytes, fov_stream_t stream) {
     if (!workspace || workspace_bytes < kStatusBytes) {
         set_error("fov_check_status: invalid workspace");
         return FOV_ERR_INVALID;
     }
-    unsigned st = 0;
-    hipError_t e = hipMemcpyAsync(&st, workspace, sizeof(st), hipMemcpyDeviceToHost, (hipStream_t)stream);
+    unsigned st[8] = {0};
+    hipError_t e = hipMemcpyAsync(st, workspace, sizeof(st), hipMemcpyDeviceToHost, (hipStream_t)stream);
     if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
     if (e != hipSuccess) { set_error("fov_check_status: %s", hipGetErrorString(e)); return FOV_ERR_LAUNCH; }
-    if (st != 0) { set_error("a bounded in-kernel wait gave up (status=%u)", st); return FOV_ERR_TIMEOUT; }
+    // The timeout word is sticky (no launch clears it, later launches skip their bodies): reading it here is what
+    // clears it.  After a give-up, or long before the 32-bit epoch tags could wrap, the whole workspace is re-zeroed;
+    // the stream is idle at this point.
+    if (st[ST_TIMEOUT] != 0 || st[ST_EPOCH] > 0x7fff0000u) {
+        e = hipMemsetAsync(workspace, 0, workspace_bytes, (hipStream_t)stream);
+        if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+        if (e != hipSuccess) { set_error("fov_check_status: %s", hipGetErrorString(e)); return FOV_ERR_LAUNCH; }
+    }
+    if (st[ST_TIMEOUT] != 0) {
+        set_error("a bounded in-kernel wait gave up (launches completed on this workspace: %u); results since the last check are invalid",
+                  st[ST_LAUNCHES]);
+        return FOV_ERR_TIMEOUT;
+    }
     return FOV_OK;
 }
 
@@ -960,11 +1027,11 @@ int fov_exchange_mode(const void* workspace, size_t workspace_bytes, fov_stream_
         set_error("fov_exchange_mode: invalid workspace");
         return FOV_ERR_INVALID;
     }
-    unsigned st[2] = {0, 0};
+    unsigned st[8] = {0};
     hipError_t e = hipMemcpyAsync(st, workspace, sizeof(st), hipMemcpyDeviceToHost, (hipStream_t)stream);
     if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
     if (e != hipSuccess) { set_error("fov_exchange_mode: %s", hipGetErrorString(e)); return FOV_ERR_LAUNCH; }
-    return st[1] == 0 ? 1 : 2;
+    return st[ST_SAFE_LAST] == 0 ? 1 : 2;   // of the last completed exchange launch
 }
 
 }  // extern "C"

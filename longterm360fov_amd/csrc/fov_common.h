@@ -58,23 +58,25 @@ struct LstmParams {
     unsigned* status;          // status[0] = timeout flag
     int num_groups;            // resident groups (persistent loop over 16-sequence tiles)
     int num_tiles;
-    int epoch_start;           // first epoch - 1 of this launch (0, or T_in for the decoder launch of a fused call)
+    int epoch_span;            // epochs this launch may consume: the last workgroup to leave adds it to the header's base
     int force_safe_exchange;   // 1: never take the same-XCD fast path (tests)
-    int clear_status;          // 1: this launch exchanges nothing; the kernel zeroes the status words itself
 };
 
 int launch_generic(const LstmParams& p, bool decode, hipStream_t stream);
 int launch_cluster(const LstmParams& p, bool decode, hipStream_t stream);
+int launch_cluster_decoder(const LstmParams& p, hipStream_t stream);   // MODE_DECODE alone, from (p.h0, p.c0)
 bool cluster_shape_ok(int F, int H);
 size_t cluster_workspace_bytes(int B, int H);
 int cluster_num_groups(int B, int H);
+int device_cu_count();                               // CUs of the current device
+int ensure_dynamic_lds(const void* kern, size_t lds);  // cached hipFuncSetAttribute(MaxDynamicSharedMemorySize)
 void set_error(const char* fmt, ...);
 // wide-input layer, H = 256, 96 < F <= 256 (lstm_wide.hip)
 bool wide_shape_ok(int F, int H);
 bool wide_narrow_preferred(int B, int F, int H);
 int launch_wide(const LstmParams& p, hipStream_t stream);
 
-constexpr size_t kStatusBytes = 256;  // head of every workspace: status words
+constexpr size_t kStatusBytes = 256;  // head of every workspace: status words (layout: xch_common.h)
 
 // ConvLSTM building blocks (conv_kernels.hip)
 int conv2d_fwd(const float* x, long ldx, long ldb, const float* w, const float* bias, const float* add, float* y, int B, int H,
@@ -114,6 +116,7 @@ struct MixDecParams {
     unsigned long long* xch; // granules: [group][layer 2][parity 2][16][256]
     unsigned* status;
     int B, T_out, O, num_groups, num_tiles;
+    int epoch_span;          // epochs this launch may consume (xch_common.h)
 };
 size_t mix_decoder_workspace_bytes(int B);
 int mix_decoder_launch(MixDecParams p, const float* K2, int act, int train, void* workspace, hipStream_t stream);
@@ -130,6 +133,7 @@ struct MixDecBwdParams {
     unsigned long long* xch;
     unsigned* status;
     int B, T_out, O, num_groups, num_tiles;
+    int epoch_span;          // epochs this launch may consume (xch_common.h)
 };
 size_t mix_decoder_bwd_workspace_bytes(int B);
 int mix_decoder_bwd_launch(MixDecBwdParams p, const float* K2, int act, void* workspace, hipStream_t stream);
@@ -151,12 +155,16 @@ int dense_bwd(const float* x, const float* W, const float* dpre, float* dx, floa
               int accumulate, float* scratch, size_t scratch_floats, hipStream_t stream);
 int mse_dense_grad(const float* y, const float* target, float* dpre, float* loss, long n, int activation, float* scratch,
                    size_t scratch_floats, hipStream_t stream);
+int mse_dense_grad_w(const float* y, const float* target, float* dpre, float* loss, long n, int activation, float weight,
+                     int tmB, int tmT, int O, float* scratch, size_t scratch_floats, hipStream_t stream);
+int scale_inplace(float* x, long n, float s, hipStream_t stream);
 int act_bwd(const float* dy, const float* y, const float* base, float* out, long n, int activation, hipStream_t stream);
 int matmul_f32(const float* a, const float* b, float* c, int M, int K, int N, float* scratch, size_t scratch_floats,
                hipStream_t stream);
 int adam_step(float* p, const float* g, float* m, float* v, long n, float lr_t, float b1, float b2, float eps,
-              hipStream_t stream);
-int rmsprop_step(float* p, const float* g, float* a, long n, float lr, float rho, float eps, hipStream_t stream);
+              const unsigned* const* guards, hipStream_t stream);   // guards: NULL or three (nullable) timeout words
+int rmsprop_step(float* p, const float* g, float* a, long n, float lr, float rho, float eps, const unsigned* const* guards,
+                 hipStream_t stream);
 int act_fwd(const float* x, float* y, long n, int activation, hipStream_t stream);
 int gauss_nll_grad(const float* mu, const float* var, const float* y, float* loss, float* dmu, float* dvar, int B, int Ty,
                    int fps, float scale, float* scratch, size_t scratch_floats, hipStream_t stream);

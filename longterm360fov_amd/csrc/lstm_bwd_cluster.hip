@@ -21,6 +21,7 @@
 #include <stdlib.h>
 
 #include "fov_common.h"
+#include "xch_common.h"
 
 namespace fov {
 
@@ -48,6 +49,7 @@ struct BwdParams {
     unsigned long long* xch;
     unsigned* status;
     int B, T, H, num_groups, num_tiles;
+    int epoch_span;         // epochs this launch may consume (xch_common.h)
 };
 
 template <int ACT>
@@ -73,7 +75,10 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_cluster_kernel(BwdParams p) {
         slice = blockIdx.x - group * G;
     }
     const int unit = slice * 64 + wave * 16 + n;   // the hidden unit this lane owns
-    if (tid == 0) sFlag[0] = 0;
+    // epoch tags continue from the workspace header, a poisoned workspace skips the body (xch_common.h)
+    const unsigned epoch_base = G > 1 ? xch_epoch_base(p.status) : 0u;
+    const bool poisoned = G > 1 && xch_poisoned(p.status);
+    if (tid == 0) sFlag[0] = poisoned ? 1 : 0;
 
     // R^T fragments: destination dd visits slice d(dd) = (slice + 1 + dd) mod G, so the local one is last.
     // wB[dd][q][s] = R[j = 64 d + 16 wave + n][col(kc = 16q + 4 g4 + s)], col = gate*H + 64 slice + unit_in_slice
@@ -100,9 +105,9 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_cluster_kernel(BwdParams p) {
         p.xch + (size_t)group * 2 * G * G * CHUNK, 0, 2 * G * G * CHUNK * (int)sizeof(unsigned long long), 0x00020000);
     const unsigned lane_off = (unsigned)((wave * 4) * 64 + lane) * 8u;   // + r*64*8 per register
 
-    unsigned epoch = 0;
-    bool aborted = false;
+    unsigned epoch = epoch_base;
     __syncthreads();
+    bool aborted = sFlag[0] != 0;
 
     for (int tile = group; tile < p.num_tiles && !aborted; tile += p.num_groups) {
         const int b0 = tile * BBT;
@@ -232,11 +237,9 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_cluster_kernel(BwdParams p) {
                     for (int j = 0; j < (G - 1) * 4; ++j) ok = ok && (v[j].y == epoch);
                     if (__all(ok)) break;
                     ++spins;
-                    if (spins > BSPIN_LIMIT ||
-                        ((spins & 63u) == 0 &&
-                         __hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                    if (spins > BSPIN_LIMIT || ((spins & 63u) == 0 && xch_poisoned(p.status))) {
                         if (lane == 0) {
-                            __hip_atomic_store(p.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            xch_give_up(p.status);
                             sFlag[0] = 1;
                         }
                         break;
@@ -292,6 +295,7 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_cluster_kernel(BwdParams p) {
         }
         __syncthreads();
     }
+    if (G > 1) xch_leave(p.status, (unsigned)p.epoch_span);
 }
 
 // --------------------------------------------------------------------------------------
@@ -329,8 +333,8 @@ int launch_bwd_cluster(const float* R, const float* reserve, const float* c0, co
     p.num_groups = cluster_num_groups(B, H);
     p.status = (unsigned*)xch_ws;
     p.xch = (unsigned long long*)((char*)xch_ws + kStatusBytes);
-    hipError_t e = hipMemsetAsync(xch_ws, 0, kStatusBytes + bwd_cluster_xch_bytes(B, H), stream);
-    if (e != hipSuccess) { set_error("hipMemsetAsync: %s", hipGetErrorString(e)); return FOV_ERR_LAUNCH; }
+    if (bwd_cluster_xch_bytes(B, H) > kXchBytes) { set_error("BPTT kernel: granule area exceeds the workspace's"); return FOV_ERR_WORKSPACE; }
+    p.epoch_span = T * ((p.num_tiles + p.num_groups - 1) / p.num_groups) + 1;   // no memset: tags continue from the header
     switch (H) {
         case 64: return launch_bwd_h<64>(p, act, stream);
         case 128: return launch_bwd_h<128>(p, act, stream);

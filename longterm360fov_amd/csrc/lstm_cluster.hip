@@ -31,7 +31,10 @@
 // MFMA s of block q uses k = 16q + 4*g4 + s on lanes with (l>>4) == g4, for A and B alike.
 #include <stdlib.h>
 
+#include <mutex>
+
 #include "fov_common.h"
+#include "xch_common.h"
 
 namespace fov {
 
@@ -256,16 +259,19 @@ __global__ __launch_bounds__(256, 1) void lstm_cluster_kernel(LstmParams p) {
     int* sFlag = (int*)(smem + L.off_flag);
     float* sKw = sK + wave * (nq * 4 + KPAD) * 256;  // this wave's K slice in B-operand order
 
-    if (tid == 0) { sFlag[0] = 0; sFlag[1] = 0; }
-    if (p.clear_status && blockIdx.x == 0 && tid == 0) { p.status[0] = 0; p.status[1] = 0; }
     // A layer's last step publishes nothing (no later step reads h_T from the partners), so a one-step layer
     // launch - the unit the step-wise decoders of a4 are built from - needs no exchange and no handshake.
     const bool xch_used = (G > 1) && (!LAYER || p.T > 1);
-    if (xch_used) {
+    // Epoch tags continue from the workspace header (xch_common.h): no memset between launches.  A workspace whose
+    // sticky timeout word is set is poisoned: the body is skipped (fail-stop) until fov_check_status clears it.
+    const unsigned epoch_base = xch_used ? xch_epoch_base(p.status) : 0u;
+    const bool poisoned = xch_used && xch_poisoned(p.status);   // one wave-wide load per wave; wave 0's value decides (sFlag[0])
+    if (tid == 0) { sFlag[0] = poisoned ? 1 : 0; sFlag[1] = 0; }
+    if (xch_used && !poisoned) {
         // hello handshake (safe sc1 protocol): do all members of this group sit on one XCD?
         unsigned long long* hello = p.xch + (size_t)p.num_groups * 2 * BT * H + (size_t)group * G;
         const unsigned mine = xcc_id();
-        const unsigned long long hello_tag = 2ull * (unsigned)p.epoch_start + (LAYER ? 1 : 2);   // distinct per launch of one call
+        const unsigned long long hello_tag = (unsigned long long)epoch_base + 1ull;   // larger than any tag of an earlier launch
         if (tid == 0) st_granule(hello + slice, (hello_tag << 32) | mine);
         if (tid < G) {
             unsigned long long hv = 0;
@@ -273,8 +279,8 @@ __global__ __launch_bounds__(256, 1) void lstm_cluster_kernel(LstmParams p) {
             while (true) {
                 hv = ld_granule(hello + tid);
                 if ((hv >> 32) == hello_tag) break;
-                if (++spins > SPIN_LIMIT) {
-                    __hip_atomic_store(p.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (++spins > SPIN_LIMIT || ((spins & 63u) == 0 && xch_poisoned(p.status))) {
+                    xch_give_up(p.status);
                     sFlag[0] = 1;
                     break;
                 }
@@ -321,13 +327,12 @@ __global__ __launch_bounds__(256, 1) void lstm_cluster_kernel(LstmParams p) {
         kb[1] = *(const f32x4*)(sKw + 256 + lane * 4);
     }
 
-    unsigned epoch = (unsigned)p.epoch_start;   // a second launch on the same buffers continues the count
-    bool aborted = false;
+    unsigned epoch = epoch_base;
     __syncthreads();
     const bool same_xcd = xch_used && (sFlag[1] == 0) && (p.force_safe_exchange == 0);
-    if (xch_used && sFlag[0]) return;   // a partner never showed up: status word is set, drain
-    if (xch_used && tid == 0 && !same_xcd)   // status[1]: number of workgroups on the safe (cross-XCD) exchange
-        __hip_atomic_fetch_add(p.status + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    bool aborted = xch_used && sFlag[0] != 0;   // poisoned workspace, or a partner never showed up: drain
+    if (xch_used && tid == 0 && !same_xcd && !aborted)   // number of workgroups on the safe (cross-XCD) exchange
+        __hip_atomic_fetch_add(p.status + ST_SAFE_COUNT, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #ifdef FOV_STAMPS
     const bool stamp_on = (blockIdx.x == 5 && tid == 0);
 #endif
@@ -528,11 +533,9 @@ __global__ __launch_bounds__(256, 1) void lstm_cluster_kernel(LstmParams p) {
                     for (int j = 0; j < NG; ++j) ok = ok && (v[j].y == epoch);
                     if (__all(ok)) break;
                     ++spins;
-                    if (spins > SPIN_LIMIT ||
-                        ((spins & 63u) == 0 &&
-                         __hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                    if (spins > SPIN_LIMIT || ((spins & 63u) == 0 && xch_poisoned(p.status))) {
                         if (lane == 0) {
-                            __hip_atomic_store(p.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            xch_give_up(p.status);
                             sFlag[0] = 1;
                         }
                         break;
@@ -605,21 +608,39 @@ __global__ __launch_bounds__(256, 1) void lstm_cluster_kernel(LstmParams p) {
             }
         }
     }
+    if (xch_used) xch_leave(p.status, (unsigned)p.epoch_span);
 }
 
 // --------------------------------------------------------------------------------------
 // host side
 // --------------------------------------------------------------------------------------
-static int device_cu_count() {
-    static int cus = 0;
-    if (cus == 0) {
-        int dev = 0;
+// CUs of the CURRENT device (cached per device ordinal: a process may drive several GPUs)
+int device_cu_count() {
+    static int cus[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (cus[dev] == 0) {
         hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-            cus = prop.multiProcessorCount;
-        if (cus <= 0) cus = 256;
+        cus[dev] = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
     }
-    return cus;
+    return cus[dev];
+}
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (device, kernel, size) instead of on every launch
+int ensure_dynamic_lds(const void* kern, size_t lds) {
+    struct Seen { const void* k; size_t lds; int dev; };
+    static Seen seen[256];
+    static int n_seen = 0;
+    static std::mutex mu;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lock(mu);
+    for (int i = 0; i < n_seen; ++i)
+        if (seen[i].k == kern && seen[i].dev == dev && seen[i].lds >= lds) return FOV_OK;
+    hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return FOV_ERR_LAUNCH; }
+    if (n_seen < 256) seen[n_seen++] = Seen{kern, lds, dev};
+    return FOV_OK;
 }
 
 bool cluster_shape_ok(int F, int H) {
@@ -640,9 +661,10 @@ static size_t cluster_xch_bytes(int B, int H) {
     return (b + 255) & ~(size_t)255;
 }
 
-// status words + granule exchange buffers + (fused decode) the encoder's final (h, c)
+// header + the fixed granule area + (fused decode) the encoder's final (h, c)
 size_t cluster_workspace_bytes(int B, int H) {
-    return kStatusBytes + cluster_xch_bytes(B, H) + (size_t)2 * B * H * sizeof(float);
+    (void)cluster_xch_bytes;
+    return kStatusBytes + kXchBytes + (size_t)2 * B * H * sizeof(float);
 }
 
 template <int H>
@@ -661,11 +683,11 @@ static int launch_cluster_h(const LstmParams& p, int mode, hipStream_t stream) {
         set_error("cluster kernel: H=%d F=%d needs %zu B of LDS (> 160 KiB)", H, F, lds);
         return FOV_ERR_UNSUPPORTED;
     }
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return FOV_ERR_LAUNCH; }
+    int rc = ensure_dynamic_lds((const void*)kern, lds);
+    if (rc) return rc;
     const dim3 grid(p.num_groups * (H / 64)), block(256);
     hipLaunchKernelGGL(kern, grid, block, lds, stream, p);
-    e = hipGetLastError();
+    hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("cluster launch: %s", hipGetErrorString(e)); return FOV_ERR_LAUNCH; }
     return FOV_OK;
 }
@@ -691,34 +713,49 @@ int launch_cluster(const LstmParams& p_in, bool decode, hipStream_t stream) {
     }
     p.num_tiles = (p.B + BT - 1) / BT;
     p.num_groups = cluster_num_groups(p.B, p.H);
-    const char* safe = getenv("FOV_FORCE_SAFE_EXCHANGE");
+    const char* safe = getenv("FOV_FORCE_SAFE_EXCHANGE");   // read per call: the tests flip it between calls
     p.force_safe_exchange = (safe && safe[0] == '1') ? 1 : 0;
-    // zero the status words and every granule tag (epochs restart at 1 in each launch).  A launch that
-    // exchanges nothing (one workgroup per tile, or a one-step layer) has no tags to clear and cannot time
-    // out: it zeroes the status words itself and the memset - a separate fill kernel - is skipped.
-    const size_t xch_bytes = kStatusBytes + cluster_xch_bytes(p.B, p.H);
-    p.clear_status = (!decode && (p.H == 64 || p.T <= 1)) ? 1 : 0;
-    if (!p.clear_status) {
-        hipError_t e = hipMemsetAsync((void*)p.status, 0, xch_bytes, stream);
-        if (e != hipSuccess) { set_error("hipMemsetAsync: %s", hipGetErrorString(e)); return FOV_ERR_LAUNCH; }
+    if (cluster_xch_bytes(p.B, p.H) > kXchBytes) { set_error("cluster kernel: granule area exceeds the workspace's"); return FOV_ERR_WORKSPACE; }
+    // No memset: epoch tags continue from the workspace header.  A group visits ceil(tiles / groups) tiles and
+    // advances its epoch once per step of each.
+    const int visits = (p.num_tiles + p.num_groups - 1) / p.num_groups;
+    if (!decode) {
+        p.epoch_span = p.T * visits + 1;
+        return launch_cluster_mode(p, MODE_LAYER, stream);
     }
-    if (!decode) return launch_cluster_mode(p, MODE_LAYER, stream);
 
     LstmParams enc = p;
-    float* state = (float*)((char*)p.status + xch_bytes);
+    float* state = (float*)((char*)p.status + kStatusBytes + kXchBytes);
     enc.hT = state;
     enc.cT = state + (size_t)p.B * p.H;
     enc.hs = nullptr;
+    enc.epoch_span = p.T * visits + 1;
     int rc = launch_cluster_mode(enc, MODE_LAYER, stream);
     if (rc) return rc;
-    // The decoder launch reuses the granule buffers WITHOUT zeroing them: its epochs (and its hello tag)
-    // continue after the encoder's last one (T_in per tile a group visits), so every stale tag is smaller
-    // than any tag it waits for.
+    // the decoder launch reads the base the encoder launch left behind: its tags (and its hello tag) are larger
+    // than every stale one
     LstmParams dec = p;
     dec.h0 = enc.hT;
     dec.c0 = enc.cT;
-    dec.epoch_start = p.T * ((p.num_tiles + p.num_groups - 1) / p.num_groups);   // encoder epochs: T per tile visit
+    dec.epoch_span = p.T_out * visits + 1;
     return launch_cluster_mode(dec, MODE_DECODE, stream);
+}
+
+// Decoder alone: T_out autoregressive steps from a given state (p.h0, p.c0) - the sampling loop of
+// FoV_seq2seq.py:154-178 after encoder_model.predict, in one launch.
+int launch_cluster_decoder(const LstmParams& p_in, hipStream_t stream) {
+    LstmParams p = p_in;
+    if (p.B == 0 || p.T_out == 0) return FOV_OK;
+    if (!(p.H == 64 || p.H == 128 || p.H == 256) || p.F_dec < 1 || p.F_dec > CL_MAX_O) {
+        set_error("cluster decoder supports H in {64,128,256}, F_dec<=%d (got H=%d F_dec=%d)", CL_MAX_O, p.H, p.F_dec);
+        return FOV_ERR_UNSUPPORTED;
+    }
+    p.num_tiles = (p.B + BT - 1) / BT;
+    p.num_groups = cluster_num_groups(p.B, p.H);
+    const char* safe = getenv("FOV_FORCE_SAFE_EXCHANGE");
+    p.force_safe_exchange = (safe && safe[0] == '1') ? 1 : 0;
+    p.epoch_span = p.T_out * ((p.num_tiles + p.num_groups - 1) / p.num_groups) + 1;
+    return launch_cluster_mode(p, MODE_DECODE, stream);
 }
 
 #ifdef FOV_STAMPS

@@ -16,6 +16,7 @@
 #include <stdlib.h>
 
 #include "fov_common.h"
+#include "xch_common.h"
 
 namespace fov {
 
@@ -81,8 +82,11 @@ __global__ __launch_bounds__(256, 1) void lstm_wide_kernel(LstmParams p) {
     const int hi = n >> 3;
     const int col0 = hi * WH + unit, col1 = (2 + hi) * WH + unit;
     constexpr int H4 = 4 * WH;
-    if (tid == 0) sFlag[0] = 0;
-    if (p.clear_status && blockIdx.x == 0 && tid == 0) { p.status[0] = 0; p.status[1] = 0; }
+    // epoch tags continue from the workspace header, a poisoned workspace skips the body (xch_common.h)
+    const bool xch_used = steps > 1;
+    const unsigned epoch_base = xch_used ? xch_epoch_base(p.status) : 0u;
+    const bool poisoned = xch_used && xch_poisoned(p.status);
+    if (tid == 0) sFlag[0] = poisoned ? 1 : 0;
 
     // ---- resident weights: K rows >= F are zero ----
     float wk[NJX][4][2], wr[16][4][2];
@@ -102,7 +106,6 @@ __global__ __launch_bounds__(256, 1) void lstm_wide_kernel(LstmParams p) {
     for (int i = tid; i < 2 * WBT * WLD; i += 256) sX[i] = 0.f;   // columns >= F stay zero
 
     // ---- exchange bookkeeping (the granule protocol of lstm_cluster.hip, placement-independent form) ----
-    const bool xch_used = steps > 1;
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
         p.xch + (size_t)group * 2 * WBT * WH, 0, 2 * WBT * WH * (int)sizeof(unsigned long long), 0x00020000);
     const int my_row0 = 4 * g4 + 2 * hi;
@@ -110,9 +113,9 @@ __global__ __launch_bounds__(256, 1) void lstm_wide_kernel(LstmParams p) {
     const unsigned gvoff = (unsigned)((tid >> 5) * WH + (tid & 31)) * 8u;
     const int lbase = (tid >> 5) * WLD + (tid & 31);
     constexpr unsigned PARITY = WBT * WH * 8u;
-    unsigned epoch = 0;
-    bool aborted = false;
+    unsigned epoch = epoch_base;
     __syncthreads();
+    bool aborted = sFlag[0] != 0;
 
     wu32x2 v[WNG];
     auto gather_issue = [&](unsigned base) {
@@ -135,10 +138,9 @@ __global__ __launch_bounds__(256, 1) void lstm_wide_kernel(LstmParams p) {
         unsigned spins = 0;
         while (__any(bad != 0)) {
             ++spins;
-            if (spins > WSPIN ||
-                ((spins & 63u) == 0 && __hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+            if (spins > WSPIN || ((spins & 63u) == 0 && xch_poisoned(p.status))) {
                 if (lane == 0) {
-                    __hip_atomic_store(p.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    xch_give_up(p.status);
                     sFlag[0] = 1;
                 }
                 break;
@@ -306,6 +308,7 @@ __global__ __launch_bounds__(256, 1) void lstm_wide_kernel(LstmParams p) {
             }
         }
     }
+    if (xch_used) xch_leave(p.status, (unsigned)p.epoch_span);
 }
 
 }  // namespace
@@ -323,21 +326,18 @@ int launch_wide(const LstmParams& p_in, hipStream_t stream) {
     const bool narrow = p.F <= 96;
     if (!narrow && (((uintptr_t)p.x) & 15) != 0) { set_error("wide LSTM layer: x must be 16-byte aligned"); return FOV_ERR_INVALID; }
     p.num_tiles = (p.B + WBT - 1) / WBT;
-    p.num_groups = p.num_tiles < 32 ? p.num_tiles : 32;
-    p.clear_status = p.T <= 1 ? 1 : 0;
-    if (!p.clear_status) {
-        const size_t bytes = kStatusBytes + (size_t)p.num_groups * 2 * WBT * WH * sizeof(unsigned long long);
-        hipError_t e = hipMemsetAsync((void*)p.status, 0, bytes, stream);
-        if (e != hipSuccess) { set_error("hipMemsetAsync: %s", hipGetErrorString(e)); return FOV_ERR_LAUNCH; }
-    }
+    const int max_groups = device_cu_count() / WG;   // one workgroup per CU: every group must be co-resident
+    if (max_groups < 1) { set_error("wide LSTM layer needs at least %d CUs", WG); return FOV_ERR_UNSUPPORTED; }
+    p.num_groups = p.num_tiles < max_groups ? p.num_tiles : max_groups;
+    p.epoch_span = p.T * ((p.num_tiles + p.num_groups - 1) / p.num_groups) + 1;   // no memset: tags continue from the header
     const size_t lds = sizeof(float) * (3 * WBT * WLD) + 64;
     void (*kern)(LstmParams) =
         narrow ? (p.act == FOV_ACT_HARD_SIGMOID ? lstm_wide_kernel<FOV_ACT_HARD_SIGMOID, 6> : lstm_wide_kernel<FOV_ACT_SIGMOID, 6>)
                : (p.act == FOV_ACT_HARD_SIGMOID ? lstm_wide_kernel<FOV_ACT_HARD_SIGMOID, 16> : lstm_wide_kernel<FOV_ACT_SIGMOID, 16>);
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return FOV_ERR_LAUNCH; }
+    int rc = ensure_dynamic_lds((const void*)kern, lds);
+    if (rc) return rc;
     hipLaunchKernelGGL(kern, dim3(p.num_groups * WG), dim3(256), lds, stream, p);
-    e = hipGetLastError();
+    hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("wide LSTM launch: %s", hipGetErrorString(e)); return FOV_ERR_LAUNCH; }
     return FOV_OK;
 }

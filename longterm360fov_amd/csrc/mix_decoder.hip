@@ -32,6 +32,7 @@
 #include <stdlib.h>
 
 #include "fov_common.h"
+#include "xch_common.h"
 
 namespace fov {
 
@@ -163,7 +164,10 @@ __global__ __launch_bounds__(256, 1) void mix_decoder_kernel(MixDecParams p) {
     const int col0 = hi * MH + unit, col1 = (2 + hi) * MH + unit;   // gate columns of tile 0 / tile 1
     const int H4 = 4 * MH;
 
-    if (tid == 0) sFlag[0] = 0;
+    // epoch tags continue from the workspace header, a poisoned workspace skips the body (xch_common.h)
+    const unsigned epoch_base = xch_epoch_base(p.status);
+    const bool poisoned = xch_poisoned(p.status);
+    if (tid == 0) sFlag[0] = poisoned ? 1 : 0;
     // ---- resident weights ----
     float w1[16][4][2], w2[16][4][2];
 #pragma unroll
@@ -214,12 +218,12 @@ __global__ __launch_bounds__(256, 1) void mix_decoder_kernel(MixDecParams p) {
     const int lbase = (tid >> 5) * MLDH + (tid & 31);
     constexpr unsigned LAYER_BYTES = 2u * MBT * MH * 8u;    // both parities of one layer
     constexpr unsigned PARITY_BYTES = MBT * MH * 8u;
-    unsigned epoch = 0;
-    bool aborted = false;
+    unsigned epoch = epoch_base;
 #ifdef FOV_STAMPS
     const bool stamp_on = (blockIdx.x == 5 && tid == 0);
 #endif
     __syncthreads();
+    bool aborted = sFlag[0] != 0;
 
     // gather: issue / complete.  v[] stays in registers between the two so MFMAs can run in between.
     mu32x2 v[MNG];
@@ -238,10 +242,9 @@ __global__ __launch_bounds__(256, 1) void mix_decoder_kernel(MixDecParams p) {
             for (int j = 0; j < MNG; ++j) ok = ok && (v[j].y == epoch);
             if (__all(ok)) break;
             ++spins;
-            if (spins > M_SPIN_LIMIT ||
-                ((spins & 63u) == 0 && __hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+            if (spins > M_SPIN_LIMIT || ((spins & 63u) == 0 && xch_poisoned(p.status))) {
                 if (lane == 0) {
-                    __hip_atomic_store(p.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    xch_give_up(p.status);
                     sFlag[0] = 1;
                 }
                 break;
@@ -490,6 +493,7 @@ __global__ __launch_bounds__(256, 1) void mix_decoder_kernel(MixDecParams p) {
             }
         }
     }
+    xch_leave(p.status, (unsigned)p.epoch_span);
 }
 
 // K2 (H,4H) -> fragments in the order recur_stream reads them:
@@ -505,33 +509,33 @@ __global__ __launch_bounds__(256) void mix_decoder_pack_k2_kernel(const float* _
     out[idx] = K2[(size_t)(16 * j + 4 * g4 + s) * (4 * MH) + gate * MH + unit];
 }
 
+// header + fixed granule area + the packed copy of K2
 size_t mix_decoder_workspace_bytes(int B) {
-    const int tiles = (B + MBT - 1) / MBT;
-    int groups = tiles < 32 ? tiles : 32;
-    if (groups < 1) groups = 1;
-    return kStatusBytes + (size_t)groups * 4 * MBT * MH * sizeof(unsigned long long) + sizeof(float) * (size_t)MH * 4 * MH;
+    (void)B;
+    return kStatusBytes + kXchBytes + sizeof(float) * (size_t)MH * 4 * MH;
 }
 
 int mix_decoder_launch(MixDecParams p, const float* K2, int act, int train, void* workspace, hipStream_t stream) {
     if (p.B == 0 || p.T_out == 0) return FOV_OK;
     p.num_tiles = (p.B + MBT - 1) / MBT;
-    p.num_groups = p.num_tiles < 32 ? p.num_tiles : 32;   // 8 workgroups per group, one per CU
-    const size_t xch_bytes = (size_t)p.num_groups * 4 * MBT * MH * sizeof(unsigned long long);
+    const int max_groups = device_cu_count() / MG;   // one workgroup per CU: every group must be co-resident
+    if (max_groups < 1) { set_error("fused mixing decoder needs at least %d CUs", MG); return FOV_ERR_UNSUPPORTED; }
+    p.num_groups = p.num_tiles < max_groups ? p.num_tiles : max_groups;
+    if ((size_t)p.num_groups * 4 * MBT * MH * sizeof(unsigned long long) > kXchBytes) { set_error("mix_decoder: granule area too small"); return FOV_ERR_WORKSPACE; }
     p.status = (unsigned*)workspace;
     p.xch = (unsigned long long*)((char*)workspace + kStatusBytes);
-    float* k2p = (float*)((char*)workspace + kStatusBytes + xch_bytes);
+    float* k2p = (float*)((char*)workspace + kStatusBytes + kXchBytes);
     p.K2p = k2p;
-    hipError_t e = hipMemsetAsync(workspace, 0, kStatusBytes + xch_bytes, stream);
-    if (e != hipSuccess) { set_error("hipMemsetAsync: %s", hipGetErrorString(e)); return FOV_ERR_LAUNCH; }
+    p.epoch_span = p.T_out * ((p.num_tiles + p.num_groups - 1) / p.num_groups) + 1;   // no memset: tags continue from the header
     hipLaunchKernelGGL(mix_decoder_pack_k2_kernel, dim3(MH * 4 * MH / 256), dim3(256), 0, stream, K2, k2p);
     const size_t lds = sizeof(float) * (2 * MBT * MLDH + MBT * 8 + MH * 8 + 64 + 16 + 4 * 256 + 4 * 28 * 256);
     void (*kern)(MixDecParams) = nullptr;
     if (act == FOV_ACT_HARD_SIGMOID) kern = train ? mix_decoder_kernel<FOV_ACT_HARD_SIGMOID, true> : mix_decoder_kernel<FOV_ACT_HARD_SIGMOID, false>;
     else kern = train ? mix_decoder_kernel<FOV_ACT_SIGMOID, true> : mix_decoder_kernel<FOV_ACT_SIGMOID, false>;
-    e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return FOV_ERR_LAUNCH; }
+    int rc = ensure_dynamic_lds((const void*)kern, lds);
+    if (rc) return rc;
     hipLaunchKernelGGL(kern, dim3(p.num_groups * MG), dim3(256), lds, stream, p);
-    e = hipGetLastError();
+    hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("mix_decoder launch: %s", hipGetErrorString(e)); return FOV_ERR_LAUNCH; }
     return FOV_OK;
 }

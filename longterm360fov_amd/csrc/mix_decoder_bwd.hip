@@ -24,6 +24,7 @@
 #include <stdlib.h>
 
 #include "fov_common.h"
+#include "xch_common.h"
 
 namespace fov {
 
@@ -114,7 +115,10 @@ __global__ __launch_bounds__(256, 1) void mix_decoder_bwd_kernel(MixDecBwdParams
     const int ul = 8 * wave + (n & 7);          // unit inside the workgroup (0..31)
     const int unit = 32 * slice + ul;
     const int my_row0 = 4 * g4 + 2 * hi;
-    if (tid == 0) sFlag[0] = 0;
+    // epoch tags continue from the workspace header, a poisoned workspace skips the body (xch_common.h)
+    const unsigned epoch_base = xch_epoch_base(p.status);
+    const bool poisoned = xch_poisoned(p.status);
+    if (tid == 0) sFlag[0] = poisoned ? 1 : 0;
 
     // ---- resident transposed weights.  Tile tl of this wave: destination slice 2*wave + (tl>>1), half tl&1;
     // its output unit on this lane is nout; k index lc = 16*jb + 4*g4 + s is an own gate column:
@@ -159,14 +163,14 @@ __global__ __launch_bounds__(256, 1) void mix_decoder_bwd_kernel(MixDecBwdParams
     const __amdgpu_buffer_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc(gbase, 0, (int)(2 * MB2 * 8), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(gbase + 2 * MB2, 0, (int)(2 * MB1 * 8), 0x00020000);
     const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(gbase + 2 * MB2 + 2 * MB1, 0, (int)(2 * MBX * 8), 0x00020000);
-    unsigned epoch = 0;
+    unsigned epoch = epoch_base;
     bool aborted = false;
 #ifdef FOV_STAMPS
     const bool stamp_on = (blockIdx.x == 5 && tid == 0);
 #endif
     auto give_up = [&]() {
         if (lane == 0) {
-            __hip_atomic_store(p.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            xch_give_up(p.status);
             sFlag[0] = 1;
         }
     };
@@ -192,8 +196,7 @@ __global__ __launch_bounds__(256, 1) void mix_decoder_bwd_kernel(MixDecBwdParams
         unsigned spins = 0;
         while (__any(bad != 0)) {
             ++spins;
-            if (spins > B_SPIN ||
-                ((spins & 63u) == 0 && __hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+            if (spins > B_SPIN || ((spins & 63u) == 0 && xch_poisoned(p.status))) {
                 give_up();
                 break;
             }
@@ -220,6 +223,7 @@ __global__ __launch_bounds__(256, 1) void mix_decoder_bwd_kernel(MixDecBwdParams
         }
     };
     __syncthreads();
+    aborted = sFlag[0] != 0;
 
     for (int tile = group; tile < p.num_tiles && !aborted; tile += p.num_groups) {
         const int b0 = tile * BBT;
@@ -471,6 +475,7 @@ __global__ __launch_bounds__(256, 1) void mix_decoder_bwd_kernel(MixDecBwdParams
             }
         }
     }
+    xch_leave(p.status, (unsigned)p.epoch_span);
 }
 
 // K2 (H,4H) -> K2^T fragments in the order the kernel reads them:
@@ -487,31 +492,31 @@ __global__ __launch_bounds__(256) void mix_decoder_bwd_pack_k2_kernel(const floa
     out[idx] = K2[(size_t)nout * (4 * BH) + gcol];
 }
 
+// header + fixed granule area + the packed copy of K2^T
 size_t mix_decoder_bwd_workspace_bytes(int B) {
-    const int tiles = (B + BBT - 1) / BBT;
-    int groups = tiles < 32 ? tiles : 32;
-    if (groups < 1) groups = 1;
-    return kStatusBytes + (size_t)groups * MB_GROUP * sizeof(unsigned long long) + sizeof(float) * (size_t)BH * 4 * BH;
+    (void)B;
+    return kStatusBytes + kXchBytes + sizeof(float) * (size_t)BH * 4 * BH;
 }
 
 int mix_decoder_bwd_launch(MixDecBwdParams p, const float* K2, int act, void* workspace, hipStream_t stream) {
     if (p.B == 0 || p.T_out == 0) return FOV_OK;
     p.num_tiles = (p.B + BBT - 1) / BBT;
-    p.num_groups = p.num_tiles < 32 ? p.num_tiles : 32;
-    const size_t xch_bytes = (size_t)p.num_groups * MB_GROUP * sizeof(unsigned long long);
+    const int max_groups = device_cu_count() / BG;   // one workgroup per CU: every group must be co-resident
+    if (max_groups < 1) { set_error("fused mixing decoder backward needs at least %d CUs", BG); return FOV_ERR_UNSUPPORTED; }
+    p.num_groups = p.num_tiles < max_groups ? p.num_tiles : max_groups;
+    if ((size_t)p.num_groups * MB_GROUP * sizeof(unsigned long long) > kXchBytes) { set_error("mix_decoder_bwd: granule area too small"); return FOV_ERR_WORKSPACE; }
     p.status = (unsigned*)workspace;
     p.xch = (unsigned long long*)((char*)workspace + kStatusBytes);
-    float* k2p = (float*)((char*)workspace + kStatusBytes + xch_bytes);
+    float* k2p = (float*)((char*)workspace + kStatusBytes + kXchBytes);
     p.K2p = k2p;
-    hipError_t e = hipMemsetAsync(workspace, 0, kStatusBytes + xch_bytes, stream);
-    if (e != hipSuccess) { set_error("hipMemsetAsync: %s", hipGetErrorString(e)); return FOV_ERR_LAUNCH; }
+    p.epoch_span = p.T_out * ((p.num_tiles + p.num_groups - 1) / p.num_groups) + 1;   // no memset: tags continue from the header
     hipLaunchKernelGGL(mix_decoder_bwd_pack_k2_kernel, dim3(BH * 4 * BH / 256), dim3(256), 0, stream, K2, k2p);
     const size_t lds = sizeof(float) * (BBT * BLDZ + BBT * 8 + BBT * 8 + 128 * 8 + 16 + 4 * BK2_LDS_BLOCKS * 256);
     void (*kern)(MixDecBwdParams) = act == FOV_ACT_HARD_SIGMOID ? mix_decoder_bwd_kernel<FOV_ACT_HARD_SIGMOID> : mix_decoder_bwd_kernel<FOV_ACT_SIGMOID>;
-    e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return FOV_ERR_LAUNCH; }
+    int rc = ensure_dynamic_lds((const void*)kern, lds);
+    if (rc) return rc;
     hipLaunchKernelGGL(kern, dim3(p.num_groups * BG), dim3(256), lds, stream, p);
-    e = hipGetLastError();
+    hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("mix_decoder_bwd launch: %s", hipGetErrorString(e)); return FOV_ERR_LAUNCH; }
     return FOV_OK;
 }

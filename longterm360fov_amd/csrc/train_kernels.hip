@@ -14,6 +14,7 @@
 #include <stdlib.h>
 
 #include "fov_common.h"
+#include "xch_common.h"
 
 namespace fov {
 
@@ -335,12 +336,21 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
 // partial sums of (y - target)^2 into loss_part[blockIdx.x].
 __global__ __launch_bounds__(256) void mse_dense_grad_kernel(const float* __restrict__ y, const float* __restrict__ target,
                                                              float* __restrict__ dpre, float* __restrict__ loss_part,
-                                                             long n, float scale, int activation) {
+                                                             long n, float scale, int activation, int tmB, int tmT, int O) {
+    // tmT > 0: y / dpre are time-major (T,B,O) against a batch-major target (B,T,O) - the unrolled decoders keep
+    // their tape time-major, no transposed copies
     __shared__ float red[4];
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     float sq = 0.f;
     if (i < n) {
-        const float yv = y[i], d = yv - target[i];
+        long ti = i;
+        if (tmT > 0) {   // i = (t*B + b)*O + o  ->  (b*T + t)*O + o
+            const long row = i / O;
+            const int o = (int)(i - row * O);
+            const long t = row / tmB, b = row - t * tmB;
+            ti = (b * tmT + t) * O + o;
+        }
+        const float yv = y[i], d = yv - target[ti];
         sq = d * d;
         float gsc = 2.f * d * scale;
         if (activation == 1) gsc *= (1.f - yv * yv);
@@ -351,6 +361,12 @@ __global__ __launch_bounds__(256) void mse_dense_grad_kernel(const float* __rest
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sq;
     __syncthreads();
     if (threadIdx.x == 0) loss_part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+// x *= s (fallback gradient weighting of the trainers that do not fold the weight into their loss kernel)
+__global__ __launch_bounds__(256) void scale_kernel(float* __restrict__ x, long n, float s) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) x[i] *= s;
 }
 
 __global__ __launch_bounds__(256) void sum_scale_kernel(const float* __restrict__ part, float* __restrict__ out, int n,
@@ -378,10 +394,18 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ 
 }
 
 // Keras-2.2 optimizers on one flat buffer (oracle/fov_oracle.py::adam_step / rmsprop_step)
+// guard0..2 (each may be NULL): sticky timeout words of the workspaces the step's persistent kernels used
+// (xch_common.h).  If one is set the gradients are garbage: the update is skipped on the device - no host sync - and
+// the parameters stay as they were until fov_check_status reports the failure.
+__device__ __forceinline__ bool optimizer_poisoned(const unsigned* g0, const unsigned* g1, const unsigned* g2) {
+    return (g0 && *g0 != 0u) || (g1 && *g1 != 0u) || (g2 && *g2 != 0u);
+}
+
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                                                   float* __restrict__ v, long n, float lr_t, float b1, float b2, float eps) {
+                                                   float* __restrict__ v, long n, float lr_t, float b1, float b2, float eps,
+                                                   const unsigned* g0, const unsigned* g1, const unsigned* g2) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
+    if (i >= n || optimizer_poisoned(g0, g1, g2)) return;
     const float gi = g[i];
     const float mi = b1 * m[i] + (1.f - b1) * gi;
     const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
@@ -391,9 +415,10 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 }
 
 __global__ __launch_bounds__(256) void rmsprop_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ a,
-                                                      long n, float lr, float rho, float eps) {
+                                                      long n, float lr, float rho, float eps, const unsigned* g0,
+                                                      const unsigned* g1, const unsigned* g2) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
+    if (i >= n || optimizer_poisoned(g0, g1, g2)) return;
     const float gi = g[i];
     const float ai = rho * a[i] + (1.f - rho) * gi * gi;
     a[i] = ai;
@@ -852,7 +877,7 @@ size_t lstm_bwd_workspace_floats(int B, int T, int F, int H) {
     size_t m = wg > cs ? wg : cs;
     (void)T;
     // head: status word + granule buffers of the persistent BPTT kernel (when the shape allows it)
-    size_t head = bwd_cluster_shape_ok(H) ? (kStatusBytes + bwd_cluster_xch_bytes(B, H)) / sizeof(float) : 64;
+    size_t head = (kStatusBytes + kXchBytes) / sizeof(float);   // header + the fixed granule area (xch_common.h)
     return head + (size_t)2 * B * H + (m > st ? m : st) + 64;
 }
 
@@ -875,7 +900,7 @@ int lstm_seq_bwd(const float* x, const float* K, const float* R, const float* h0
         return FOV_OK;
     }
     const bool persistent = bwd_cluster_shape_ok(H) && !getenv("FOV_BWD_STEPPED");
-    const size_t head = bwd_cluster_shape_ok(H) ? (kStatusBytes + bwd_cluster_xch_bytes(B, H)) / sizeof(float) : 64;
+    const size_t head = (kStatusBytes + kXchBytes) / sizeof(float);
     float* dh_rec = ws + head;
     float* dc = dh_rec + (size_t)B * H;
     float* scratch = dc + (size_t)B * H;
@@ -897,9 +922,7 @@ int lstm_seq_bwd(const float* x, const float* K, const float* R, const float* h0
             if (rc) return rc;
         }
     } else {
-        e = hipMemsetAsync(ws, 0, 256, stream);   // status word of this workspace
-        if (e == hipSuccess)
-            e = dhT ? hipMemcpyAsync(dh_rec, dhT, bh, hipMemcpyDeviceToDevice, stream) : hipMemsetAsync(dh_rec, 0, bh, stream);
+        e = dhT ? hipMemcpyAsync(dh_rec, dhT, bh, hipMemcpyDeviceToDevice, stream) : hipMemsetAsync(dh_rec, 0, bh, stream);
         if (e == hipSuccess) e = dcT ? hipMemcpyAsync(dc, dcT, bh, hipMemcpyDeviceToDevice, stream) : hipMemsetAsync(dc, 0, bh, stream);
         if (e != hipSuccess) { set_error("lstm_seq_bwd init: %s", hipGetErrorString(e)); return FOV_ERR_LAUNCH; }
         const long nelem = (long)B * H;
@@ -1002,7 +1025,7 @@ int mse_dense_grad(const float* y, const float* target, float* dpre, float* loss
     const long blocks = (n + 255) / 256;
     if ((size_t)blocks > scratch_floats) { set_error("mse_dense_grad: scratch too small"); return FOV_ERR_WORKSPACE; }
     hipLaunchKernelGGL(mse_dense_grad_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, y, target, dpre, scratch, n,
-                       1.0f / (float)n, activation);
+                       1.0f / (float)n, activation, 0, 0, 1);
     int rc = check_launch("mse_dense_grad");
     if (rc) return rc;
     if (loss) {
@@ -1010,6 +1033,31 @@ int mse_dense_grad(const float* y, const float* target, float* dpre, float* loss
         rc = check_launch("sum_scale");
     }
     return rc;
+}
+
+// The same with a weight on the gradient AND the loss (data parallelism: this rank's share n_local / n_global of the
+// global mean, so that a SUM all-reduce of gradients and loss gives the global-batch values without a scaling pass)
+// and optionally a time-major prediction.
+int mse_dense_grad_w(const float* y, const float* target, float* dpre, float* loss, long n, int activation, float weight,
+                     int tmB, int tmT, int O, float* scratch, size_t scratch_floats, hipStream_t stream) {
+    if (n <= 0) return FOV_OK;
+    const long blocks = (n + 255) / 256;
+    if ((size_t)blocks > scratch_floats) { set_error("mse_dense_grad_w: scratch too small"); return FOV_ERR_WORKSPACE; }
+    hipLaunchKernelGGL(mse_dense_grad_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, y, target, dpre, scratch, n,
+                       weight / (float)n, activation, tmB, tmT, O);
+    int rc = check_launch("mse_dense_grad_w");
+    if (rc) return rc;
+    if (loss) {
+        hipLaunchKernelGGL(sum_scale_kernel, dim3(1), dim3(256), 0, stream, scratch, loss, (int)blocks, weight / (float)n);
+        rc = check_launch("sum_scale");
+    }
+    return rc;
+}
+
+int scale_inplace(float* x, long n, float s, hipStream_t stream) {
+    if (n <= 0) return FOV_OK;
+    hipLaunchKernelGGL(scale_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, x, n, s);
+    return check_launch("scale");
 }
 
 // C (M,N) = A (M,K) . B (K,N), all row-major dense
@@ -1034,15 +1082,18 @@ int act_bwd(const float* dy, const float* y, const float* base, float* out, long
 }
 
 int adam_step(float* p, const float* g, float* m, float* v, long n, float lr_t, float b1, float b2, float eps,
-              hipStream_t stream) {
+              const unsigned* const* guards, hipStream_t stream) {
     if (n <= 0) return FOV_OK;
-    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, p, g, m, v, n, lr_t, b1, b2, eps);
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, p, g, m, v, n, lr_t, b1, b2, eps,
+                       guards ? guards[0] : nullptr, guards ? guards[1] : nullptr, guards ? guards[2] : nullptr);
     return check_launch("adam");
 }
 
-int rmsprop_step(float* p, const float* g, float* a, long n, float lr, float rho, float eps, hipStream_t stream) {
+int rmsprop_step(float* p, const float* g, float* a, long n, float lr, float rho, float eps, const unsigned* const* guards,
+                 hipStream_t stream) {
     if (n <= 0) return FOV_OK;
-    hipLaunchKernelGGL(rmsprop_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, p, g, a, n, lr, rho, eps);
+    hipLaunchKernelGGL(rmsprop_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, p, g, a, n, lr, rho, eps,
+                       guards ? guards[0] : nullptr, guards ? guards[1] : nullptr, guards ? guards[2] : nullptr);
     return check_launch("rmsprop");
 }
 

@@ -69,6 +69,9 @@ def _keras_fit(model, trainer, inputs, y, batch_size, epochs, validation_split, 
         idx = np.arange(n_train)
         if shuffle:
             np.random.shuffle(idx)
+            # every rank must slice the SAME permutation: rank 0's is broadcast (the ranks' np.random states are
+            # not synchronised), then each takes its contiguous shard of every global batch
+            idx = parallel.broadcast_index(idx)
         tot, cnt = 0.0, 0
         for lo in range(0, n_train, batch_size):
             gidx = idx[lo:lo + batch_size]
@@ -86,6 +89,7 @@ def _keras_fit(model, trainer, inputs, y, batch_size, epochs, validation_split, 
                 vt += float(trainer.eval_loss(*[d(arr[sl]) for arr in val[0]], d(val[1][sl])).item()) * k
                 vc += k
             logs["val_loss"] = vt / vc
+        trainer.check()      # a persistent kernel that gave up poisons its workspace and the optimizer skips the update
         model._w = trainer.weights_numpy()
         model._dw = None
         for cb in cbs:
@@ -94,8 +98,7 @@ def _keras_fit(model, trainer, inputs, y, batch_size, epochs, validation_split, 
             break
     for cb in cbs:
         cb.on_train_end()
-    trainer.ws.check()
-    trainer.bwd_scratch.check()
+    trainer.check()
     return hist
 
 
@@ -130,15 +133,40 @@ class KerasModelSurface:
                 raise ValueError("%s: expected shape %s, got %s" % (k, self._w[k].shape, a.shape))
             self._w[k] = a
         self._dw = None
-        self._trainer = None     # optimizer state belongs to the previous weights
+        if self._trainer is not None:     # Keras keeps the optimizer state across set_weights / load_weights
+            self._trainer.load_weights_(self._w)
+
+    @staticmethod
+    def weights_path(path):
+        """The file a weights path names: '.npz' as given; Keras-style '.h5' / '.hdf5' names map to '<stem>.npz' when
+        WRITING (h5py is absent: the container written here is .npz with the Keras array order); anything else gets
+        '.npz' appended - so save_weights(p) / load_weights(p) / ModelCheckpoint(p) agree for every p."""
+        path = str(path)
+        low = path.lower()
+        if low.endswith(".npz"):
+            return path
+        for ext in (".h5", ".hdf5"):
+            if low.endswith(ext):
+                return path[:-len(ext)] + ".npz"
+        return path + ".npz"
 
     def save_weights(self, path):
-        np.savez(path, **self._w)
+        with open(self.weights_path(path), "wb") as f:
+            np.savez(f, **self._w)
 
     save = save_weights
 
     def load_weights(self, path):
-        with np.load(path) as z:
+        """'.npz' written by save_weights (also addressed by the '.h5' name it was saved under), or a real Keras HDF5
+        weight file (model.save_weights / ModelCheckpoint of the reference, given_others...py:484,570) read by the
+        package's own HDF5 subset reader (keras_h5.py)."""
+        import os
+        p = str(path)
+        if p.lower().endswith((".h5", ".hdf5")) and os.path.exists(p):
+            from .keras_h5 import read_keras_weights
+            self.set_weights(read_keras_weights(p, expected_shapes=[self._w[k].shape for k in self._order]))
+            return
+        with np.load(self.weights_path(p)) as z:
             self.set_weights([z[k] for k in self._order])
 
     def count_params(self):
@@ -206,9 +234,11 @@ class KerasModelSurface:
         tr = self._get_trainer()
         loss = tr.train_step(*[self._to_device(a) for a in self._fit_inputs(x)], self._to_device(y),
                              **{k: (None if v is None else self._to_device(v)) for k, v in kw.items()})
+        value = float(loss.item())
+        tr.check()
         self._w = tr.weights_numpy()
         self._dw = None
-        return float(loss.item())
+        return value
 
 
 class _SubModel:
@@ -298,6 +328,7 @@ class Seq2SeqLSTM(KerasModelSurface):
         _, hT, cT = ops.lstm_seq(self._dev(input_seq), dw["enc_K"], dw["enc_R"], dw["enc_b"],
                                  act=self.recurrent_activation, impl=self.impl, return_sequences=False,
                                  workspace=self._ws)
+        self._ws.check()
         return [hT.cpu().numpy(), cT.cpu().numpy()]
 
     def _decoder_predict(self, x):
@@ -308,6 +339,7 @@ class Seq2SeqLSTM(KerasModelSurface):
         hs, hT, cT = ops.lstm_seq(self._dev(target_seq), dw["dec_K"], dw["dec_R"], dw["dec_b"], self._dev(h),
                                   self._dev(c), act=self.recurrent_activation, impl=self.impl, workspace=self._ws)
         y = ops.dense(hs, dw["dense_W"], dw["dense_b"], activation="tanh")
+        self._ws.check()
         return [y.cpu().numpy(), hT.cpu().numpy(), cT.cpu().numpy()]
 
     # ---- training surface: KerasModelSurface (FoV_seq2seq.py:103 compile, :112-117 fit) ----
@@ -762,6 +794,7 @@ class OthersMixingSeq2Seq(KerasModelSurface):
                     vt += float(tr.eval_loss(*[d(a) for a in xb], d(yb)).item()) * len(yb)
                     vc += len(yb)
                 logs["val_loss"] = vt / max(vc, 1)
+            tr.check()
             self._w = tr.weights_numpy()
             self._dw = None
             for cb in cbs:

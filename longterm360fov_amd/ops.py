@@ -40,8 +40,18 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+def _new_workspace(nbytes, device):
+    """A fresh workspace buffer, zero-filled ONCE through the C ABI (fov_workspace_init): the persistent kernels keep
+    a header and monotone epoch tags in it across calls, no call clears anything (include/fov360.h, Conventions)."""
+    buf = torch.empty(nbytes + 256, dtype=torch.uint8, device=device)
+    with torch.cuda.device(buf.device):
+        check(_lib.lib().fov_workspace_init(buf.data_ptr(), buf.numel(), _stream()))
+    return buf
+
+
 class Workspace:
-    """Caller-owned scratch for the persistent kernels (grown on demand, reused across calls)."""
+    """Caller-owned, stateful scratch of the persistent kernels (grown on demand, reused across calls, one stream at
+    a time).  Its sticky timeout word makes a failed launch poison every later one until check() reports it."""
 
     def __init__(self, device=None):
         self.device = device
@@ -50,11 +60,12 @@ class Workspace:
     def get(self, nbytes, device):
         nbytes = max(int(nbytes), 256)
         if self.buf is None or self.buf.numel() < nbytes or self.buf.device != device:
-            self.buf = torch.empty(nbytes + 256, dtype=torch.uint8, device=device)
+            self.buf = _new_workspace(nbytes, device)
         return self.buf
 
     def check(self):
-        """Synchronise and raise FovError(ERR_TIMEOUT) if a bounded in-kernel wait gave up."""
+        """Synchronise and raise FovError(ERR_TIMEOUT) if a bounded in-kernel wait has given up since the last check
+        (the failure is cleared by reporting it)."""
         if self.buf is not None:
             check(_lib.lib().fov_check_status(self.buf.data_ptr(), self.buf.numel(), _stream()))
 
@@ -128,6 +139,25 @@ def seq2seq_decode(enc_in, dec_in0, w, T_out, act="sigmoid", impl="auto", worksp
     return out
 
 
+def seq2seq_decoder(dec_in0, h0, c0, w, T_out, act="sigmoid", impl="auto", workspace=None, out=None):
+    """The decoder half alone from a given state (decoder_model.predict fed its own output, FoV_seq2seq.py:156-178)
+    -> (B,T_out,F_dec)."""
+    dec_in0, h0, c0 = _dev(dec_in0, "dec_in0"), _dev(h0, "h0"), _dev(c0, "c0")
+    ws_t = [_dev(w[k], k) for k in _W_ORDER[3:]]
+    B, H = h0.shape
+    F_dec = ws_t[3].shape[1]
+    assert dec_in0.shape == (B, 1, F_dec)
+    if out is None:
+        out = torch.empty((B, T_out, F_dec), dtype=torch.float32, device=h0.device)
+    L = _lib.lib()
+    impl = impl_code(impl)
+    ws = (workspace or default_workspace(h0.device))
+    buf = ws.get(L.fov_seq2seq_decode_workspace_bytes(B, 0, T_out, 1, F_dec, H, impl), h0.device)
+    check(L.fov_seq2seq_decoder_fwd(_ptr(dec_in0), _ptr(h0), _ptr(c0), *[_ptr(t) for t in ws_t], _ptr(out), None, None,
+                                    B, T_out, F_dec, H, act_code(act), impl, buf.data_ptr(), buf.numel(), _stream()))
+    return out
+
+
 def seq2seq_teacher_forced(enc_in, dec_in, w, act="sigmoid", impl="auto", workspace=None):
     """Training-graph forward (FoV_seq2seq.py:82-101) -> (B,T_out,F_dec)."""
     enc_in, dec_in = _dev(enc_in, "enc_in"), _dev(dec_in, "dec_in")
@@ -195,7 +225,7 @@ class Scratch:
     def get(self, nbytes, device):
         nbytes = max(int(nbytes), 256)
         if self.buf is None or self.buf.numel() < nbytes or self.buf.device != device:
-            self.buf = torch.zeros(nbytes + 256, dtype=torch.uint8, device=device)
+            self.buf = _new_workspace(nbytes, device)
         return self.buf
 
     def check(self):
@@ -348,30 +378,53 @@ def dense_bwd(x, W, dpre, dW=None, db=None, need_dx=True, accumulate=False, scra
     return (dx.reshape(*x.shape[:-1], In) if need_dx else None), dW, db
 
 
-def mse_dense_grad(y, target, activation="tanh", scratch=None, dpre=None, loss=None):
-    """Keras mean_squared_error + Dense activation derivative -> (dpre like y, loss scalar tensor)."""
+def mse_dense_grad(y, target, activation="tanh", scratch=None, dpre=None, loss=None, weight=1.0, time_major=False):
+    """Keras mean_squared_error + Dense activation derivative -> (dpre like y, loss (1,) tensor), both multiplied by
+    `weight` (a rank's share n_local / n_global under data parallelism).  time_major: y / dpre are (T,B,O) while
+    target is (B,T,O) - the tape layout of the unrolled decoders, no transposed copies."""
     y, target = _dev(y, "y"), _dev(target, "target")
-    assert y.shape == target.shape
     n = y.numel()
+    tmB = tmT = O = 0
+    if time_major:
+        tmT, tmB, O = y.shape
+        assert target.shape == (tmB, tmT, O)
+    else:
+        assert y.shape == target.shape
     dpre = torch.empty_like(y) if dpre is None else dpre
-    loss = torch.zeros(1, dtype=torch.float32, device=y.device) if loss is None else loss
+    loss = torch.empty(1, dtype=torch.float32, device=y.device) if loss is None else loss
     buf = (scratch or _default_scratch).get(4 * ((n + 255) // 256 + 64), y.device)
-    check(_lib.lib().fov_mse_dense_grad(_ptr(y), _ptr(target), _ptr(dpre), _ptr(loss), n,
-                                        1 if activation == "tanh" else 0, buf.data_ptr(), buf.numel(), _stream()))
+    check(_lib.lib().fov_mse_dense_grad_w(_ptr(y), _ptr(target), _ptr(dpre), _ptr(loss), n,
+                                          1 if activation == "tanh" else 0, float(weight), tmB, tmT, O,
+                                          buf.data_ptr(), buf.numel(), _stream()))
     return dpre, loss
 
 
-def adam_step(params, grads, m, v, step, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-7):
+def scale_(x, s):
+    """x *= s in place (HIP kernel; torch computes nothing on the product path)."""
+    x = _dev(x, "x")
+    check(_lib.lib().fov_scale(_ptr(x), x.numel(), float(s), _stream()))
+    return x
+
+
+def _guard_ptrs(guards):
+    g = [t.data_ptr() for t in (guards or [])][:3]
+    return g + [None] * (3 - len(g))
+
+
+def adam_step(params, grads, m, v, step, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-7, guards=None):
+    """Keras Adam on flat buffers.  guards: up to three workspace buffers; the update is skipped on the device when
+    one of their sticky timeout words is set."""
     for t in (params, grads, m, v):
         _dev(t, "flat buffer")
-    check(_lib.lib().fov_adam_step(_ptr(params), _ptr(grads), _ptr(m), _ptr(v), params.numel(), lr, beta1, beta2,
-                                   eps, int(step), _stream()))
+    check(_lib.lib().fov_adam_step_guarded(_ptr(params), _ptr(grads), _ptr(m), _ptr(v), params.numel(), lr, beta1, beta2,
+                                           eps, int(step), *_guard_ptrs(guards), _stream()))
 
 
-def rmsprop_step(params, grads, accum, lr=1e-3, rho=0.9, eps=1e-7):
+def rmsprop_step(params, grads, accum, lr=1e-3, rho=0.9, eps=1e-7, guards=None):
     for t in (params, grads, accum):
         _dev(t, "flat buffer")
-    check(_lib.lib().fov_rmsprop_step(_ptr(params), _ptr(grads), _ptr(accum), params.numel(), lr, rho, eps, _stream()))
+    check(_lib.lib().fov_rmsprop_step_guarded(_ptr(params), _ptr(grads), _ptr(accum), params.numel(), lr, rho, eps,
+                                              *_guard_ptrs(guards), _stream()))
 
 
 # ---------------------------------------------------------------------------------------------

@@ -54,3 +54,16 @@ def gather_rows(local, n_total, device=None):
     parts = [torch.empty_like(pad) for _ in range(w)]
     dist.all_gather(parts, pad)
     return torch.cat([p[:hi - lo] for p, (lo, hi) in zip(parts, sizes)], dim=0)
+
+
+def broadcast_index(idx):
+    """Rank 0's index permutation on every rank (fit(shuffle=True) under data parallelism)."""
+    import numpy as np
+    _, w = world()
+    if w == 1:
+        return idx
+    t = torch.from_numpy(np.ascontiguousarray(idx, dtype=np.int64))
+    if dist.get_backend() == "nccl":
+        t = t.cuda()
+    dist.broadcast(t, src=0)
+    return t.cpu().numpy()

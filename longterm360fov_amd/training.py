@@ -13,53 +13,108 @@ _W_ORDER = ("enc_K", "enc_R", "enc_b", "dec_K", "dec_R", "dec_b", "dense_W", "de
 
 class FlatParamTrainer:
     """What every trainer of the Keras-optimizer models shares: parameters and gradients live in ONE flat buffer each
-    (views per tensor in self.w / self.g), so the optimizer is one launch and data parallelism is ONE all-reduce; a
-    subclass provides forward_backward(*inputs, grad_weight=1.0) -> (loss (1,), prediction) filling self.grad."""
+    (views per tensor in self.w / self.g), so the optimizer is one launch.  The gradient buffer carries one extra
+    slot for the loss, so data parallelism needs no collective of its own for it.  A subclass provides
+    forward_backward(*inputs, grad_weight=1.0) -> (loss (1,), prediction) filling self.grad (already multiplied by
+    grad_weight) and, where it can, calls grads_final(name) as soon as every gradient from parameter `name` to the end
+    of the buffer is final: under DP that tail is all-reduced (async, RCCL's own stream) while the rest of the
+    backward pass is still running, the head of the buffer follows at the end of the step."""
 
     def _alloc(self, weights, order, optimizer, lr, device):
         self.optimizer, self.lr, self.device = optimizer.lower(), float(lr), device
         self.shapes = [(k, tuple(weights[k].shape)) for k in order]
         n = int(sum(np.prod(s) for _, s in self.shapes))
         self.flat = torch.empty(n, dtype=torch.float32, device=device)     # parameters, one buffer
-        self.grad = torch.zeros(n, dtype=torch.float32, device=device)     # gradients, same layout
+        self.gradbuf = torch.zeros(n + 1, dtype=torch.float32, device=device)   # gradients, same layout, + the loss slot
+        self.grad = self.gradbuf[:n]
+        self.loss_slot = self.gradbuf[n:]
         self.m = torch.zeros(n, dtype=torch.float32, device=device)
         self.v = torch.zeros(n, dtype=torch.float32, device=device) if self.optimizer == "adam" else None
-        self.w, self.g = {}, {}
+        self.w, self.g, self.offset = {}, {}, {}
         off = 0
         for k, s in self.shapes:
             cnt = int(np.prod(s))
             self.w[k] = self.flat[off:off + cnt].view(*s)
             self.g[k] = self.grad[off:off + cnt].view(*s)
             self.w[k].copy_(torch.from_numpy(np.ascontiguousarray(weights[k], dtype=np.float32)))
+            self.offset[k] = off
             off += cnt
         self.step_count = 0
         self.ws = ops.Workspace()
         self.scratch = ops.Scratch()        # split-K partials of the Dense / MSE / matmul calls
-        self.bwd_scratch = ops.Scratch()    # BPTT calls only: its first word is the persistent kernel's status
+        self.bwd_scratch = ops.Scratch()    # BPTT calls only: its head is the persistent kernel's header + granule area
+        self._dp = False
+        self._pending, self._reduced_from = [], n + 1
 
     def weights_numpy(self):
         return {k: v.detach().cpu().numpy().copy() for k, v in self.w.items()}
+
+    def load_weights_(self, weights):
+        """Overwrite the parameters in place (Keras set_weights / load_weights keep the optimizer state)."""
+        for k, _ in self.shapes:
+            self.w[k].copy_(torch.from_numpy(np.ascontiguousarray(weights[k], dtype=np.float32)))
+
+    def check(self):
+        """Raise FovError(ERR_TIMEOUT) if a persistent kernel of this trainer gave up a bounded wait (synchronises)."""
+        self.ws.check()
+        self.bwd_scratch.check()
+        ws_bwd = getattr(self, "ws_bwd", None)
+        if ws_bwd is not None:
+            ws_bwd.check()
+
+    def _guards(self):
+        """The workspaces whose sticky timeout word the optimizer launch looks at: if a persistent kernel of this step
+        gave up, the update is skipped ON THE DEVICE (no host synchronisation), the parameters stay as they were and
+        the next check() reports the failure."""
+        return [b.buf for b in (self.ws, self.bwd_scratch, getattr(self, "ws_bwd", None)) if b is not None and b.buf is not None]
 
     def apply_gradients(self):
         """Keras Adam / RMSprop on the flat buffer (model.compile(optimizer=...), FoV_seq2seq.py:103, convlstm_seq2seq.py:287)."""
         self.step_count += 1
         if self.optimizer == "adam":
-            ops.adam_step(self.flat, self.grad, self.m, self.v, self.step_count, lr=self.lr)
+            ops.adam_step(self.flat, self.grad, self.m, self.v, self.step_count, lr=self.lr, guards=self._guards())
         else:
-            ops.rmsprop_step(self.flat, self.grad, self.m, lr=self.lr)
+            ops.rmsprop_step(self.flat, self.grad, self.m, lr=self.lr, guards=self._guards())
+
+    # ---- data parallelism: the flat buffer (gradients + loss slot) is SUM all-reduced, tail first ----
+    def grads_final(self, name):
+        """Called from forward_backward: every gradient from parameter `name` to the end of the buffer (and the loss
+        slot) is final.  Under DP the tail goes out now, overlapping whatever backward work is still to come."""
+        if self._dp and self.offset[name] < self._reduced_from:
+            lo = self.offset[name]
+            self._pending.append(torch.distributed.all_reduce(self.gradbuf[lo:self._reduced_from],
+                                                              op=torch.distributed.ReduceOp.SUM, async_op=True))
+            self._reduced_from = lo
+
+    def _weigh(self, loss, grad_weight):
+        """Fallback for trainers whose loss kernel takes no weight: scale gradients and loss after the fact."""
+        if grad_weight != 1.0:
+            ops.scale_(self.grad, grad_weight)
+            loss = ops.scale_(loss, grad_weight)
+        return loss
 
     def train_step(self, *inputs, n_global=None, **kw):
         """One optimizer step on (*model inputs, target).  Under data parallelism every rank passes its shard of the
-        global batch and `n_global` = global batch size: gradients are combined as sum_r (n_r/n) g_r with a single
-        all-reduce of the flat buffer, so the update equals the single-process one."""
+        global batch and `n_global` = global batch size: gradients and loss are combined as sum_r (n_r/n) x_r by SUM
+        all-reduces of the flat buffer (one for the tail named by grads_final, overlapped with the remaining backward
+        work, one for the head; a trainer that names no tail does a single one), so the update equals the
+        single-process one.  Returns the (global) loss as a (1,) tensor that the NEXT step overwrites."""
         _, world = parallel.world()
         n_local = inputs[0].shape[0]
         weight = 1.0 if world == 1 else n_local / float(n_global if n_global else n_local * world)
+        self._dp = world > 1
+        self._pending, self._reduced_from = [], self.gradbuf.numel()
         loss, _ = self.forward_backward(*inputs, grad_weight=weight, **kw)
-        if world > 1:
-            torch.distributed.all_reduce(self.grad, op=torch.distributed.ReduceOp.SUM)
-            loss = loss * weight
-            torch.distributed.all_reduce(loss, op=torch.distributed.ReduceOp.SUM)
+        if self._dp:
+            if loss.data_ptr() != self.loss_slot.data_ptr():
+                self.loss_slot.copy_(loss.reshape(1))
+            if self._reduced_from > 0:
+                self._pending.append(torch.distributed.all_reduce(self.gradbuf[:self._reduced_from],
+                                                                  op=torch.distributed.ReduceOp.SUM, async_op=True))
+            for work in self._pending:
+                work.wait()      # the launch stream waits for the collective; the host does not block
+            self._pending, self._dp = [], False
+            loss = self.loss_slot
         self.apply_gradients()
         return loss
 
@@ -85,7 +140,7 @@ class Seq2SeqTrainer(FlatParamTrainer):
                 "enc": (e(B, T_in, H), e(B, H), e(B, H), e(B, T_in, 5, H)),
                 "dec": (e(B, T_out, H), e(B, H), e(B, H), e(B, T_out, 5, H)),
                 "dz_enc": e(B, T_in, 4 * H), "dz_dec": e(B, T_out, 4 * H),
-                "dpre": e(B, T_out, O), "loss": torch.zeros(1, dtype=torch.float32, device=self.device),
+                "dpre": e(B, T_out, O),
             }
         return self._bufs[key]
 
@@ -101,15 +156,17 @@ class Seq2SeqTrainer(FlatParamTrainer):
         dhs_, _, _, dres = ops.lstm_seq_train(dec_in, w["dec_K"], w["dec_R"], w["dec_b"], ehT, ecT, act=self.act,
                                               impl=self.impl, workspace=self.ws, out=bufs["dec"])
         y = ops.dense(dhs_, w["dense_W"], w["dense_b"], activation="tanh")
-        dpre, loss = ops.mse_dense_grad(y, target, "tanh", scratch=self.scratch, dpre=bufs["dpre"], loss=bufs["loss"])
+        # the DP weight rides on the loss gradient (everything downstream is linear in it); the loss lands in the
+        # flat buffer's last slot
+        dpre, loss = ops.mse_dense_grad(y, target, "tanh", scratch=self.scratch, dpre=bufs["dpre"], loss=self.loss_slot,
+                                        weight=grad_weight)
         d_hs, _, _ = ops.dense_bwd(dhs_, w["dense_W"], dpre, dW=g["dense_W"], db=g["dense_b"], scratch=self.scratch)
         bd = ops.lstm_seq_bwd(dec_in, w["dec_K"], w["dec_R"], dhs_, dres, h0=ehT, c0=ecT, dhs=d_hs, dK=g["dec_K"],
                               dR=g["dec_R"], db=g["dec_b"], need_state_grads=True, act=self.act, dz=bufs["dz_dec"],
                               scratch=self.bwd_scratch)
+        self.grads_final("dec_K")     # decoder + head + loss: all-reduced under the encoder's BPTT
         ops.lstm_seq_bwd(enc, w["enc_K"], w["enc_R"], ehs, eres, dhT=bd["dh0"], dcT=bd["dc0"], dK=g["enc_K"],
                          dR=g["enc_R"], db=g["enc_b"], act=self.act, dz=bufs["dz_enc"], scratch=self.bwd_scratch)
-        if grad_weight != 1.0:
-            self.grad.mul_(grad_weight)
         return loss, y
 
     def eval_loss(self, enc, dec_in, target):
@@ -216,8 +273,7 @@ class SelfFedSeq2SeqTrainer(FlatParamTrainer):
         if d_ehT is not None:                             # otherwise the encoder does not reach the loss (reference quirk)
             ops.lstm_seq_bwd(enc, w["enc_K"], w["enc_R"], ehs, eres, dhT=d_ehT, dcT=d_ecT, dK=g["enc_K"], dR=g["enc_R"],
                              db=g["enc_b"], act=act, accumulate=True, scratch=bsc)
-        if grad_weight != 1.0:
-            self.grad.mul_(grad_weight)
+        loss = self._weigh(loss, grad_weight)
         return loss, out
 
 
@@ -268,8 +324,7 @@ class StackedSeq2SeqTrainer(FlatParamTrainer):
                                   dK=g["enc%d_K" % l], dR=g["enc%d_R" % l], db=g["enc%d_b" % l], need_dx=(l > 0), act=act,
                                   scratch=self.bwd_scratch)
             d_cur = be["dx"]
-        if grad_weight != 1.0:
-            self.grad.mul_(grad_weight)
+        loss = self._weigh(loss, grad_weight)
         return loss, y
 
 
@@ -417,8 +472,7 @@ class OthersContextTrainer(FlatParamTrainer):
                               db=g["enc2_b"], need_dx=True, act=act, accumulate=True, scratch=bsc)
         ops.lstm_seq_bwd(enc, w["enc1_K"], w["enc1_R"], hs1, res1, dhs=e2["dx"], dhT=dh1, dcT=dc1, dK=g["enc1_K"], dR=g["enc1_R"],
                          db=g["enc1_b"], act=act, accumulate=True, scratch=bsc)
-        if grad_weight != 1.0:
-            self.grad.mul_(grad_weight)
+        loss = self._weigh(loss, grad_weight)
         return loss, out
 
 
@@ -506,8 +560,7 @@ class SingleLSTMTrainer(FlatParamTrainer):
             ops.dense_bwd(XS.reshape(TB, F), w["K"], DZ.reshape(TB, 4 * H), dW=g["K"], db=g["b"], need_dx=False, accumulate=True, scratch=sc)
             ops.dense_bwd(Hs[:T_out].reshape(TB, H), w["R"], DZ.reshape(TB, 4 * H), dW=g["R"], need_db=False, need_dx=False,
                           accumulate=True, scratch=sc)
-        if grad_weight != 1.0:
-            self.grad.mul_(grad_weight)
+        loss = self._weigh(loss, grad_weight)
         return loss, y
 
 
@@ -542,7 +595,7 @@ class OthersMixingTrainer(FlatParamTrainer):
         n_oth = w["mix_W"].shape[0] - O
         Wm_o, Wm_p = w["mix_W"][:n_oth], w["mix_W"][n_oth:]
         gWm_o, gWm_p = g["mix_W"][:n_oth], g["mix_W"][n_oth:]
-        self.grad.zero_()
+        acc = False               # every gradient below is written exactly once: nothing to zero, nothing to accumulate
         # ---------------- forward (keeping what the backward needs) ----------------
         e = lambda *s_: torch.empty(s_, dtype=torch.float32, device=self.device)
         # decoder state tapes, time-major: row 0 = the encoder's final state (written there by the encoder kernels),
@@ -582,11 +635,13 @@ class OthersMixingTrainer(FlatParamTrainer):
             ops.lstm_seq_zx(zx, w["dec2_R"], w["dec2_b"], H2[t], C2[t], act=act, impl=impl, workspace=ws, reserve=R2[t],
                             out=(H2[t + 1].view(B, 1, H), None, C2[t + 1]))
             ops.mix_head_fwd(H2[t + 1], w["dense_W"], w["dense_b"], Wm_p_c, oth_proj[:, t], P[t], M[t])
-        out = M.transpose(0, 1).contiguous()                                      # (B,T_out,O)
+        out = M.transpose(0, 1)                                                   # (B,T_out,O) view of the time-major tape
         # ---------------- backward ----------------
-        # dL/d(pre-tanh of the mixing layer) from the loss, for every step at once
-        dloss, loss = ops.mse_dense_grad(out, target, "tanh", scratch=sc)
-        dloss_tm = dloss.transpose(0, 1).contiguous()                              # (T_out,B,O), per-step rows
+        # dL/d(pre-tanh of the mixing layer) from the loss, for every step at once, straight in the tape's time-major
+        # order; the DP weight rides on it (everything downstream is linear in it), the loss lands in the flat
+        # buffer's last slot
+        dloss_tm, loss = ops.mse_dense_grad(M, target, "tanh", scratch=sc, loss=self.loss_slot, weight=grad_weight,
+                                            time_major=True)                       # (T_out,B,O), per-step rows
         dpre_all, dpre_p_all = e(T_out, B, O), e(T_out, B, O)                      # written by the head backward
         DZ1, DZ2 = e(T_out, B, 4 * H), e(T_out, B, 4 * H)
         dh1_rec = dc1 = dh2_rec = dc2 = None
@@ -616,28 +671,27 @@ class OthersMixingTrainer(FlatParamTrainer):
         # weight gradients of the unrolled decoder: x^T dz (input kernels, biases) and h_prev^T dz (recurrent)
         TB = T_out * B
         fl = lambda a, n: a.reshape(TB, n)
-        ops.dense_bwd(fl(P, O), Wm_p_c, fl(dpre_all, O), dW=gWm_p, db=g["mix_b"], need_dx=False, accumulate=True, scratch=sc)
+        ops.dense_bwd(fl(P, O), Wm_p_c, fl(dpre_all, O), dW=gWm_p, db=g["mix_b"], need_dx=False, accumulate=acc, scratch=sc)
         ops.dense_bwd(fl(H2[1:], H), w["dense_W"], fl(dpre_p_all, O), dW=g["dense_W"], db=g["dense_b"], need_dx=False,
-                      accumulate=True, scratch=sc)
+                      accumulate=acc, scratch=sc)
         ops.dense_bwd(fl(H1[1:], H), w["dec2_K"], fl(DZ2, 4 * H), dW=g["dec2_K"], db=g["dec2_b"], need_dx=False,
-                      accumulate=True, scratch=sc)
+                      accumulate=acc, scratch=sc)
         ops.dense_bwd(fl(H2[:T_out], H), w["dec2_R"], fl(DZ2, 4 * H), dW=g["dec2_R"], need_db=False, need_dx=False,
-                      accumulate=True, scratch=sc)
+                      accumulate=acc, scratch=sc)
         ops.dense_bwd(fl(X, O), w["dec1_K"], fl(DZ1, 4 * H), dW=g["dec1_K"], db=g["dec1_b"], need_dx=False,
-                      accumulate=True, scratch=sc)
+                      accumulate=acc, scratch=sc)
         ops.dense_bwd(fl(H1[:T_out], H), w["dec1_R"], fl(DZ1, 4 * H), dW=g["dec1_R"], need_db=False, need_dx=False,
-                      accumulate=True, scratch=sc)
+                      accumulate=acc, scratch=sc)
         # "others" half of the mixing kernel: one product over all steps, rows ordered (t, b) like dpre_all
         oth_tb = others.transpose(0, 1).contiguous().reshape(T_out * B, n_oth)
         ops.dense_bwd(oth_tb, Wm_o_c, dpre_all.reshape(T_out * B, O), dW=gWm_o, need_db=False, need_dx=False,
-                      accumulate=True, scratch=sc)
+                      accumulate=acc, scratch=sc)
+        self.grads_final("dec1_K")    # decoder, heads and loss: all-reduced under the encoder's BPTT
         # encoder: layer 2 over hs1 (its dx is the dhs of layer 1), then layer 1
         e2 = ops.lstm_seq_bwd(hs1, w["enc2_K"], w["enc2_R"], hs2, res2, dhT=dh2_rec, dcT=dc2, dK=g["enc2_K"], dR=g["enc2_R"],
-                              db=g["enc2_b"], need_dx=True, act=act, accumulate=True, scratch=bsc)
+                              db=g["enc2_b"], need_dx=True, act=act, accumulate=acc, scratch=bsc)
         ops.lstm_seq_bwd(enc, w["enc1_K"], w["enc1_R"], hs1, res1, dhs=e2["dx"], dhT=dh1_rec, dcT=dc1, dK=g["enc1_K"],
-                         dR=g["enc1_R"], db=g["enc1_b"], act=act, accumulate=True, scratch=bsc)
-        if grad_weight != 1.0:
-            self.grad.mul_(grad_weight)
+                         dR=g["enc1_R"], db=g["enc1_b"], act=act, accumulate=acc, scratch=bsc)
         return loss, out
 
 
@@ -911,8 +965,7 @@ class ConvLSTMTrainer(FlatParamTrainer):
                 else:
                     d4 = ops.conv2d(edz.reshape(T_in * B, H, W, 4 * F[l]), wt4["enc%d_K" % l]).reshape(T_in, B, H, W, 4 * F[l - 1])
                     dx_seq = unmask(d4, masks["enc%d" % l].unsqueeze(1), F[l - 1])
-        if grad_weight != 1.0:
-            self.grad.mul_(grad_weight)
+        loss = self._weigh(loss, grad_weight)
         return loss, P.transpose(0, 1)
 
     def eval_loss(self, enc, dec0, target):

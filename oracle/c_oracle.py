@@ -36,6 +36,10 @@ def num_threads():
     return int(lib().oracle_num_threads())
 
 
+def set_num_threads(n):
+    lib().oracle_set_num_threads(int(n))
+
+
 def lstm_layer(x, K, R, b, h0=None, c0=None, act=0):
     x, K, R, b, h0, c0 = map(_f32, (x, K, R, b, h0, c0))
     B, T, F = x.shape

@@ -89,6 +89,10 @@ static void tile_dense_tanh(const float* h, int rows, int H, const float* W, con
     }
 }
 
+void oracle_set_num_threads(int n) {
+    if (n > 0) omp_set_num_threads(n);
+}
+
 int oracle_num_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

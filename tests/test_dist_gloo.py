@@ -30,7 +30,12 @@ def _worker(rank, world_size, port, q):
         mx = parallel.max_over_ranks(0.5 + rank)
         rows = torch.arange(lo, hi, dtype=torch.float32)[:, None].repeat(1, 3)
         full = parallel.gather_rows(rows, n)
-        q.put((rank, lo, hi, float(flat[0]), float(flat.std()), mx, bool((full[:, 0] == torch.arange(n)).all())))
+        import numpy as np
+        np.random.seed(100 + rank)                       # the ranks' own random states differ ...
+        idx = np.arange(57)
+        np.random.shuffle(idx)
+        idx = parallel.broadcast_index(idx)              # ... rank 0's permutation wins (fit(shuffle=True) under DP)
+        q.put((rank, lo, hi, float(flat[0]), float(flat.std()), mx, bool((full[:, 0] == torch.arange(n)).all()), idx.tolist()))
     finally:
         dist.destroy_process_group()
 
@@ -46,7 +51,12 @@ def test_gloo_world2():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    (r0, lo0, hi0, m0, s0, mx0, ok0), (r1, lo1, hi1, m1, s1, mx1, ok1) = res
+    (r0, lo0, hi0, m0, s0, mx0, ok0, idx0), (r1, lo1, hi1, m1, s1, mx1, ok1, idx1) = res
+    import numpy as np
+    np.random.seed(100)
+    want = np.arange(57)
+    np.random.shuffle(want)
+    assert idx0 == idx1 == want.tolist()                        # both ranks slice rank 0's permutation
     assert (lo0, hi0, lo1, hi1) == (0, 513, 513, 1025)          # contiguous cover, sizes differ by <= 1
     assert m0 == m1 == 1.5 and s0 == s1 == 0.0                  # mean of the flat buffer
     assert mx0 == mx1 == 1.5                                    # max over ranks
@@ -61,3 +71,22 @@ def test_single_process_defaults():
     t = torch.ones(4)
     assert parallel.allreduce_mean_(t) is t
     assert parallel.max_over_ranks(2.5) == 2.5
+
+
+def test_bench_gpus_flag_starts_the_ranks():
+    """`python bench.py --gpus 2` on its own launches two ranks (torch.distributed.run, 127.0.0.1) and rank 0 reports
+    n_gpus = 2; under a launcher a mismatching --gpus is refused.  --dry-run: launch plumbing only, no GPU."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    assert json.loads(line)["n_gpus"] == 2
+    env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run"], env=env2,
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 2

@@ -209,6 +209,84 @@ def test_data_parallel_two_ranks_equal_single_process():
     np.testing.assert_array_equal(res[0][2], res[1][2])     # replicas stay bit-identical
 
 
+def _fit_worker(rank, world_size, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world_size)
+    try:
+        q.put((rank, _fit_shuffled(seed=5 if rank == 0 else 991)))   # rank 1's own np.random state must not matter
+    finally:
+        dist.destroy_process_group()
+
+
+def _fit_shuffled(seed):
+    from longterm360fov_amd.models import Seq2SeqLSTM
+    enc, dec_in, tgt = batch(31, 45, 5, 4)
+    m = Seq2SeqLSTM(latent_dim=64, seed=8)
+    m.compile(optimizer="Adam", loss="mean_squared_error")
+    np.random.seed(seed)
+    h = m.fit([enc, dec_in], tgt, batch_size=16, epochs=2, validation_split=0.2, shuffle=True)
+    return h.history["loss"], h.history["val_loss"], np.concatenate([a.ravel() for a in m.get_weights()])
+
+
+def test_fit_shuffle_two_ranks_equal_single_process():
+    """fit(shuffle=True) under data parallelism: rank 0's permutation is broadcast every epoch, each rank takes its
+    contiguous shard of every global batch - losses and weights equal the single-process fit with rank 0's seed
+    (the ranks' own np.random states differ on purpose)."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_fit_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ref_loss, ref_val, ref_w = _fit_shuffled(seed=5)
+    for rank, (loss, val, wts) in res:
+        np.testing.assert_allclose(loss, ref_loss, rtol=2e-5)
+        np.testing.assert_allclose(val, ref_val, rtol=2e-5)
+        d = np.abs(wts - ref_w)
+        assert d.max() <= 3e-3 and np.mean(d <= 2e-5) >= 0.99, (rank, d.max(), np.mean(d <= 2e-5))
+    np.testing.assert_array_equal(res[0][1][2], res[1][1][2])     # replicas stay bit-identical
+
+
+def test_poisoned_workspace_is_fail_stop_and_sticky():
+    """A set timeout word is never cleared by a launch: later persistent-kernel calls on that workspace skip their
+    bodies (outputs untouched), the guarded optimizer leaves the parameters alone, check() reports the failure ONCE
+    and clears it, after which the workspace works again."""
+    from longterm360fov_amd import ops, _lib
+    w = O.init_seq2seq(3, H=256, bias_noise=0.05)
+    enc, dec0, _ = O.synthetic_batch(4, 40, 5, 4)
+    dw = {k: dev(v) for k, v in w.items()}
+    ws = ops.Workspace()
+    good = ops.seq2seq_decode(dev(enc), dev(dec0), dw, 4, workspace=ws).cpu().numpy()
+    ws.check()
+    ws.buf[:4] = torch.tensor([1, 0, 0, 0], dtype=torch.uint8, device="cuda")     # what a give-up leaves behind
+    out = torch.full((40, 4, 6), 7.0, dtype=torch.float32, device="cuda")
+    ops.seq2seq_decode(dev(enc), dev(dec0), dw, 4, workspace=ws, out=out)
+    ops.seq2seq_decode(dev(enc), dev(dec0), dw, 4, workspace=ws, out=out)          # still poisoned: nothing clears it
+    assert float(out.min()) == 7.0 and float(out.max()) == 7.0
+    p = torch.ones(1000, device="cuda"); g = torch.ones(1000, device="cuda")
+    m = torch.zeros(1000, device="cuda"); v = torch.zeros(1000, device="cuda")
+    ops.adam_step(p, g, m, v, 1, guards=[ws.buf])
+    assert float(p.min()) == 1.0 and float(m.abs().max()) == 0.0                   # update skipped on the device
+    with pytest.raises(_lib.FovError) as ei:
+        ws.check()
+    assert ei.value.code == _lib.ERR_TIMEOUT
+    ws.check()                                                                     # reported once, then clean
+    again = ops.seq2seq_decode(dev(enc), dev(dec0), dw, 4, workspace=ws).cpu().numpy()
+    ws.check()
+    np.testing.assert_array_equal(again, good)
+    ops.adam_step(p, g, m, v, 1, guards=[ws.buf])
+    assert float(p.max()) < 1.0
+
+
 def test_persistent_bptt_matches_stepped_and_oracle():
     """The one-launch cluster BPTT kernel vs the host-stepped recurrence (FOV_BWD_STEPPED=1) and the
     fp64 oracle: ragged multi-tile batch (more tiles than groups), given initial state, dhs + dhT/dcT."""
