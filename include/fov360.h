@@ -126,6 +126,51 @@ int fov_mix_decoder_fwd(const float* dec0, const float* h1, const float* c1, con
                         int B, int T_out, int H, int O, int act,
                         void* workspace, size_t workspace_bytes, fov_stream_t stream);
 
+/* =======================================================================================
+ * bf16 forms (BASELINE.json configs[4]): the SAME fp32 tensors in and out, but every product with x or h on its left
+ * (gate GEMMs, the Dense(6) head of the fused decoder) takes bf16 operands - round-to-nearest-even of the fp32 values,
+ * made on the fly - into v_mfma_f32_16x16x32_bf16 with fp32 accumulation; gates, cell state, mixing layer, tapes and
+ * the master weights stay fp32.  H = 256 (F <= 256 for the layer).  Outputs differ from the fp32 entry points by the
+ * operand rounding: ~1e-2 absolute on tanh-range outputs after 20 recurrent steps (bound stated in the tests).
+ * ======================================================================================= */
+int fov_mix_decoder_fwd_bf16(const float* dec0, const float* h1, const float* c1, const float* h2, const float* c2,
+                             const float* oth_proj, int64_t oth_batch_stride, int64_t oth_step_stride,
+                             const float* dec1_K, const float* dec1_R, const float* dec1_b,
+                             const float* dec2_K, const float* dec2_R, const float* dec2_b,
+                             const float* dense_W, const float* dense_b, const float* mix_Wp, float* out,
+                             float* h1T, float* c1T, float* h2T, float* c2T,
+                             float* P, float* H1, float* C1, float* H2, float* C2, float* res1, float* res2,
+                             int B, int T_out, int H, int O, int act,
+                             void* workspace, size_t workspace_bytes, fov_stream_t stream);
+
+/* fov_mix_decoder_bwd with bf16 operands in its three transposed products (dz2 R2^T, dz2 K2^T, dz1 R1^T). */
+int fov_mix_decoder_bwd_bf16(const float* M, const float* P, const float* dloss, const float* res1, const float* res2,
+                             const float* C1, const float* C2,
+                             const float* dec1_K, const float* dec1_R, const float* dec2_K, const float* dec2_R,
+                             const float* dense_W, const float* mix_Wp,
+                             float* DZ1, float* DZ2, float* dpre_m, float* dpre_p,
+                             float* dh1_0, float* dc1_0, float* dh2_0, float* dc2_0,
+                             int B, int T_out, int H, int O, int act,
+                             void* workspace, size_t workspace_bytes, fov_stream_t stream);
+
+/* fov_lstm_seq_bwd / fov_dense_bwd with bf16 operands: the recurrence dh_{t-1} = dz_t R^T (eight-workgroup BPTT
+ * kernel), the weight-gradient products x^T dz, h_prev^T dz and the data gradient dz K^T all round their operands to
+ * bf16 on the fly and accumulate in fp32; gates backward, dz, dc stay fp32.  Same arguments, same workspaces.
+ * fov_dense_bwd_bf16 uses the bf16 product for dW when Out >= 64 (the K / R gradients of an unrolled decoder). */
+int fov_lstm_seq_bwd_bf16(const float* x, const float* K, const float* R, const float* h0, const float* c0,
+                          const float* hs, const float* reserve, const float* dhs, const float* dhT, const float* dcT,
+                          float* dz, float* dx, float* dK, float* dR, float* db, float* dh0, float* dc0,
+                          int B, int T, int F, int H, int act, int accumulate,
+                          void* workspace, size_t workspace_bytes, fov_stream_t stream);
+int fov_dense_bwd_bf16(const float* x, const float* W, const float* dpre, float* dx, float* dW, float* db,
+                       int N, int In, int Out, int accumulate,
+                       void* workspace, size_t workspace_bytes, fov_stream_t stream);
+
+/* fov_lstm_seq_fwd_train with bf16 operands (reserve may be NULL for inference); workspace >= 256 + 64 MB. */
+int fov_lstm_seq_fwd_bf16(const float* x, const float* K, const float* R, const float* b, const float* h0,
+                          const float* c0, float* hs, float* hT, float* cT, float* reserve, int B, int T, int F, int H,
+                          int act, void* workspace, size_t workspace_bytes, fov_stream_t stream);
+
 /* Backward of fov_mix_decoder_fwd (data path): BPTT through the whole unrolled decoder in ONE persistent launch.
  *   in : M, P (T_out,B,O) from the forward; dloss (T_out,B,O) = dL/d(pre-tanh of m_t) from the loss;
  *        res1, res2 (T_out,B,5,H); C1, C2 (T_out,B,H) = cell state BEFORE step t (row 0 = initial state);

@@ -39,8 +39,11 @@ SIGNATURES = {
     "fov_mix_head_bwd": (_I, [_P] * 9 + [_I] * 3 + [_P]),
     "fov_mix_decoder_workspace_bytes": (_SZ, [_I] * 2),
     "fov_mix_decoder_fwd": (_I, [_P] * 6 + [ctypes.c_int64] * 2 + [_P] * 21 + [_I] * 5 + [_P, _SZ, _P]),
+    "fov_mix_decoder_fwd_bf16": (_I, [_P] * 6 + [ctypes.c_int64] * 2 + [_P] * 21 + [_I] * 5 + [_P, _SZ, _P]),
+    "fov_lstm_seq_fwd_bf16": (_I, [_P] * 10 + [_I] * 5 + [_P, _SZ, _P]),
     "fov_mix_decoder_bwd_workspace_bytes": (_SZ, [_I] * 2),
     "fov_mix_decoder_bwd": (_I, [_P] * 21 + [_I] * 5 + [_P, _SZ, _P]),
+    "fov_mix_decoder_bwd_bf16": (_I, [_P] * 21 + [_I] * 5 + [_P, _SZ, _P]),
     "fov_matmul_workspace_bytes": (_SZ, [_I] * 3),
     "fov_matmul": (_I, [_P] * 3 + [_I] * 3 + [_P, _SZ, _P]),
     "fov_lstm_seq_fwd_zx": (_I, [_P] * 9 + [_I] * 5 + [_P, _SZ, _P]),
@@ -53,6 +56,8 @@ SIGNATURES = {
     "fov_lstm_seq_fwd_train": (_I, [_P] * 10 + [_I] * 6 + [_P, _SZ, _P]),
     "fov_lstm_seq_bwd_workspace_bytes": (_SZ, [_I] * 4),
     "fov_lstm_seq_bwd": (_I, [_P] * 17 + [_I] * 6 + [_P, _SZ, _P]),
+    "fov_lstm_seq_bwd_bf16": (_I, [_P] * 17 + [_I] * 6 + [_P, _SZ, _P]),
+    "fov_dense_bwd_bf16": (_I, [_P] * 6 + [_I] * 4 + [_P, _SZ, _P]),
     "fov_dense_bwd_workspace_bytes": (_SZ, [_I] * 3),
     "fov_dense_bwd": (_I, [_P] * 6 + [_I] * 4 + [_P, _SZ, _P]),
     "fov_mse_dense_grad": (_I, [_P] * 4 + [ctypes.c_int64, _I, _P, _SZ, _P]),

@@ -1,0 +1,187 @@
+// Shared pieces of the bf16 kernels (BASELINE.json configs[4]: the config-3 model with bf16 operands into
+// v_mfma_f32_16x16x32_bf16, fp32 accumulation, fp32 gates / cell state / master weights).
+//
+// Fragment conventions (cdna_hip_programming.md section 3), lane l = (n = l & 15, g4 = l >> 4):
+//   A (16 x 32): lane holds A[row n][k = 8*g4 + j], j = 0..7   - 16 bytes of a bf16 row image in LDS
+//   B (32 x 16): lane holds B[k = 8*g4 + j][col n]             - packed once from the fp32 weights, register-resident
+//   D (16 x 16): lane holds D[row 4*g4 + r][col n], r = 0..3   - same as the fp32 MFMA the fp32 kernels use
+// Ownership is the fp32 eight-workgroup kernels' (lstm_wide.hip, mix_decoder.hip): a 16-sequence tile per group of 8
+// workgroups, workgroup `slice` owns hidden units [32*slice, +32), a wave 8 of them as two N-tiles [i | f], [g | o];
+// after a DPP half swap every lane holds all four gates of ONE unit for TWO sequences (rows row0, row0 + 1).
+// Those two h values travel as ONE granule {bf16 pair, epoch}: half the granules of the fp32 exchange.
+#pragma once
+#include "fov_common.h"
+#include "xch_common.h"
+
+namespace fov {
+
+constexpr int QH = 256;     // hidden units
+constexpr int QG = 8;       // workgroups per tile
+constexpr int QBT = 16;     // sequences per tile
+constexpr int QLD = 272;    // bf16 elements per LDS row of an activation tile: 544 B, conflict-free ds_read_b128 of A fragments
+constexpr int QNG = 7;      // granules gathered per thread and exchange: 7 slices * 8 row pairs * 32 units / 256
+constexpr unsigned Q_SPIN = 1u << 20;
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned qu32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned qu32x2 __attribute__((ext_vector_type(2)));
+
+// round-to-nearest-even (v_cvt_pk_bf16_f32); lo in bits 0..15
+__device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
+    bf16x2 v = {(__bf16)lo, (__bf16)hi};
+    return __builtin_bit_cast(unsigned, v);
+}
+__device__ __forceinline__ unsigned short bf16_bits(float v) { return (unsigned short)(pack_bf16(v, 0.f) & 0xffffu); }
+__device__ __forceinline__ float bf16_to_f32(unsigned short b) { return __uint_as_float((unsigned)b << 16); }
+
+__device__ __forceinline__ void qmfma(f32x4& acc, qu32x4 a, qu32x4 b) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+}
+
+// B fragment of k-block kb for gate column `col` from a row-major fp32 matrix W (rows x ld); rows >= nrows are zero
+__device__ __forceinline__ qu32x4 load_bfrag(const float* __restrict__ W, int ld, int nrows, int kb, int g4, int col) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = 32 * kb + 8 * g4 + j;
+        v[j] = (k < nrows) ? W[(size_t)k * ld + col] : 0.f;
+    }
+    return (qu32x4){pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7])};
+}
+// B fragment of a TRANSPOSED product: B[k][col] = W[row = out][k index along a row]; the 8 values are contiguous
+__device__ __forceinline__ qu32x4 load_bfrag_rowmajor(const float* __restrict__ wrow) {
+    const f32x4 a = *(const f32x4*)wrow, b = *(const f32x4*)(wrow + 4);
+    return (qu32x4){pack_bf16(a[0], a[1]), pack_bf16(a[2], a[3]), pack_bf16(b[0], b[1]), pack_bf16(b[2], b[3])};
+}
+
+// A fragment (row n, k-block kb) of a bf16 tile image in LDS with row stride QLD
+__device__ __forceinline__ qu32x4 lds_afrag(const unsigned short* tile, int n, int g4, int kb) {
+    return *(const qu32x4*)(tile + n * QLD + 32 * kb + 8 * g4);
+}
+
+// acc[tile] += A(tile image, k-blocks [KB0, KB1)) . W   (W[kb][nt] register-resident B fragments)
+template <int KB0, int KB1, int NKB>
+__device__ __forceinline__ void qmm(f32x4 (&acc)[2], const unsigned short* tile, int n, int g4, const qu32x4 (&w)[NKB][2]) {
+#pragma unroll
+    for (int kb = KB0; kb < KB1; ++kb) {
+        const qu32x4 a = lds_afrag(tile, n, g4, kb);
+        qmfma(acc[0], a, w[kb][0]);
+        qmfma(acc[1], a, w[kb][1]);
+    }
+}
+
+// value of the lane 8 positions away inside the same 16-lane row (row_ror:8)
+__device__ __forceinline__ float qswap(float v) {
+    return __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x128, 0xf, 0xf, false));
+}
+
+// The four gate pre-activations of this lane's two cells out of the two D tiles ([i | f], [g | o]).
+// hi = (n >> 3): lanes hi = 0 keep rows 0,1 of their 4-row block, lanes hi = 1 rows 2,3.
+__device__ __forceinline__ void gates_of_lane(const f32x4 (&acc)[2], int hi, float (&zi)[2], float (&zf)[2], float (&zg)[2],
+                                              float (&zo)[2]) {
+    float snd[4], rcv[4];
+    snd[0] = hi ? acc[0][0] : acc[0][2];
+    snd[1] = hi ? acc[0][1] : acc[0][3];
+    snd[2] = hi ? acc[1][0] : acc[1][2];
+    snd[3] = hi ? acc[1][1] : acc[1][3];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) rcv[k] = qswap(snd[k]);
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        zi[r] = hi ? rcv[r] : acc[0][r];
+        zf[r] = hi ? acc[0][2 + r] : rcv[r];
+        zg[r] = hi ? rcv[2 + r] : acc[1][r];
+        zo[r] = hi ? acc[1][2 + r] : rcv[2 + r];
+    }
+}
+
+// Exchange of one (16 x 256) bf16 activation tile among the 8 workgroups of a group.
+// Granule buffer of one tile exchange: [row pair 8][unit 256] x 8 bytes = 16 KB (per parity).
+constexpr unsigned Q_TILE_BYTES = 8u * QH * 8u;
+
+struct QGather {
+    qu32x2 v[QNG];
+};
+
+// thread tid gathers granule (row pair tid >> 5, unit tid & 31) of each of the 7 other slices
+__device__ __forceinline__ void q_gather_issue(QGather& g, const __amdgpu_buffer_rsrc_t rs, unsigned base, int slice, int tid) {
+    const unsigned voff = (unsigned)((tid >> 5) * QH + (tid & 31)) * 8u;
+#pragma unroll
+    for (int j = 0; j < QNG; ++j) {
+        const unsigned uo = (unsigned)(((slice + 1 + j) & (QG - 1)) * 32) * 8u;
+        g.v[j] = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, base + uo, 16);
+    }
+}
+// first pass: current granules go straight into the tile image, stale ones into a bit mask; retry sweeps (rare)
+// re-read into loop-local temporaries.  Returns false after a give-up (status word set, caller drains).
+__device__ __forceinline__ bool q_gather_finish(QGather& g, const __amdgpu_buffer_rsrc_t rs, unsigned base, int slice, int tid,
+                                                unsigned epoch, unsigned short* tile, unsigned* status) {
+    const int lbase = (tid >> 5) * 2 * QLD + (tid & 31);
+    unsigned bad = 0;
+#pragma unroll
+    for (int j = 0; j < QNG; ++j) {
+        const int lo = lbase + ((slice + 1 + j) & (QG - 1)) * 32;
+        if (g.v[j].y == epoch) {
+            tile[lo] = (unsigned short)(g.v[j].x & 0xffffu);
+            tile[lo + QLD] = (unsigned short)(g.v[j].x >> 16);
+        } else {
+            bad |= (1u << j);
+        }
+    }
+    unsigned spins = 0;
+    bool ok = true;
+    while (__any(bad != 0)) {
+        ++spins;
+        if (spins > Q_SPIN || ((spins & 63u) == 0 && xch_poisoned(status))) {
+            if ((tid & 63) == 0) xch_give_up(status);
+            ok = false;
+            break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+        asm volatile("" ::: "memory");
+        const unsigned voff = (unsigned)((tid >> 5) * QH + (tid & 31)) * 8u;
+        qu32x2 tv[QNG];
+#pragma unroll
+        for (int j = 0; j < QNG; ++j) {
+            const unsigned uo = (unsigned)(((slice + 1 + j) & (QG - 1)) * 32) * 8u;
+            tv[j] = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, base + uo, 16);
+        }
+#pragma unroll
+        for (int j = 0; j < QNG; ++j) {
+            const int lo = lbase + ((slice + 1 + j) & (QG - 1)) * 32;
+            if (((bad >> j) & 1u) && tv[j].y == epoch) {
+                tile[lo] = (unsigned short)(tv[j].x & 0xffffu);
+                tile[lo + QLD] = (unsigned short)(tv[j].x >> 16);
+                bad &= ~(1u << j);
+            }
+        }
+    }
+    return ok;
+}
+
+// group / slice of a workgroup: members of a group 8 blocks apart (round-robin dispatch puts them on one XCD when
+// num_groups % 8 == 0); a placement preference only - the exchange is the placement-independent sc1 protocol
+__device__ __forceinline__ void q_group_slice(int num_groups, int& group, int& slice) {
+    if ((num_groups & 7) == 0) {
+        group = (blockIdx.x / (8 * QG)) * 8 + (blockIdx.x & 7);
+        slice = (blockIdx.x >> 3) & (QG - 1);
+    } else {
+        group = blockIdx.x / QG;
+        slice = blockIdx.x - group * QG;
+    }
+}
+
+// host side
+int launch_layer_bf16(const LstmParams& p, hipStream_t stream);   // lstm_layer_bf16.hip
+bool layer_bf16_shape_ok(int F, int H);
+// lstm_bwd8.hip: BPTT recurrence in groups of eight workgroups (H = 256), fp32 or bf16 operands
+bool bwd8_preferred(int B, int H);
+int launch_bwd8(const float* R, const float* reserve, const float* c0, const float* dhs, const float* dhT, const float* dcT,
+                float* dz, float* dh0, float* dc0, float* db_part, int B, int T, int act, int bf16, void* xch_ws, hipStream_t stream);
+// gemm_bf16.hip
+int gemm_bf16_tn(const float* a, long lda, long a_so, const float* b, long ldb, long b_so, float* c, int ldc, int M, int N, int RO,
+                 int RI, int accumulate, float* scratch, size_t scratch_floats, hipStream_t stream);
+int gemm_bf16_nt(const float* a, long lda, const float* b, long ldb, float* c, int ldc, int M, int N, int K, hipStream_t stream);
+
+}  // namespace fov

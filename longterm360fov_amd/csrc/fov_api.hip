@@ -6,6 +6,7 @@
 
 #include "fov_common.h"
 #include "xch_common.h"
+#include "bf16_common.h"
 
 namespace fov {
 
@@ -386,6 +387,25 @@ int fov_lstm_seq_fwd_train(const float* x, const float* K, const float* R, const
                              stream);
 }
 
+int fov_lstm_seq_fwd_bf16(const float* x, const float* K, const float* R, const float* b, const float* h0, const float* c0,
+                          float* hs, float* hT, float* cT, float* reserve, int B, int T, int F, int H, int act,
+                          void* workspace, size_t workspace_bytes, fov_stream_t stream) {
+    if (B < 0 || T < 0 || F <= 0 || H <= 0 || !K || !R || !b || (B > 0 && T > 0 && !x) ||
+        (act != FOV_ACT_SIGMOID && act != FOV_ACT_HARD_SIGMOID)) {
+        set_error("fov_lstm_seq_fwd_bf16: invalid argument");
+        return FOV_ERR_INVALID;
+    }
+    if (!layer_bf16_shape_ok(F, H)) { set_error("fov_lstm_seq_fwd_bf16: H = 256 and F <= 256 only"); return FOV_ERR_UNSUPPORTED; }
+    int rc = check_ws(workspace, workspace_bytes, B > 0 ? kStatusBytes + kXchBytes : kStatusBytes);
+    if (rc) return rc;
+    LstmParams p = {};
+    p.x = x; p.K = K; p.R = R; p.b = b; p.h0 = h0; p.c0 = c0; p.hs = hs; p.hT = hT; p.cT = cT; p.reserve = reserve;
+    p.B = B; p.T = T; p.F = F; p.H = H; p.act = act;
+    p.status = (unsigned*)workspace;
+    p.xch = (unsigned long long*)((char*)workspace + kStatusBytes);
+    return launch_layer_bf16(p, (hipStream_t)stream);
+}
+
 int fov_lstm_seq_fwd_zx(const float* zx, const float* R, const float* b, const float* h0, const float* c0, float* hs,
                         float* hT, float* cT, float* reserve, int B, int T, int H, int act, int impl, void* workspace,
                         size_t workspace_bytes, fov_stream_t stream) {
@@ -426,7 +446,25 @@ int fov_lstm_seq_bwd(const float* x, const float* K, const float* R, const float
     int rc = check_ws(workspace, workspace_bytes, fov_lstm_seq_bwd_workspace_bytes(B, T, F, H));
     if (rc) return rc;
     return lstm_seq_bwd(x, K, R, h0, c0, hs, reserve, dhs, dhT, dcT, dz, dx, dK, dR, db, dh0, dc0, B, T, F, H, act,
-                        accumulate, (float*)workspace, workspace_bytes / sizeof(float), (hipStream_t)stream);
+                        accumulate, (float*)workspace, workspace_bytes / sizeof(float), (hipStream_t)stream, 0);
+}
+
+int fov_lstm_seq_bwd_bf16(const float* x, const float* K, const float* R, const float* h0, const float* c0,
+                          const float* hs, const float* reserve, const float* dhs, const float* dhT, const float* dcT,
+                          float* dz, float* dx, float* dK, float* dR, float* db, float* dh0, float* dc0, int B, int T,
+                          int F, int H, int act, int accumulate, void* workspace, size_t workspace_bytes,
+                          fov_stream_t stream) {
+    if (B < 0 || T < 0 || F <= 0 || H != 256 || !K || !R ||
+        (B > 0 && T > 0 && (!x || !hs || !reserve || !dz)) ||
+        (act != FOV_ACT_SIGMOID && act != FOV_ACT_HARD_SIGMOID)) {
+        set_error("fov_lstm_seq_bwd_bf16: invalid argument (H = 256 only)");
+        return FOV_ERR_INVALID;
+    }
+    if (B == 0) return FOV_OK;
+    int rc = check_ws(workspace, workspace_bytes, fov_lstm_seq_bwd_workspace_bytes(B, T, F, H));
+    if (rc) return rc;
+    return lstm_seq_bwd(x, K, R, h0, c0, hs, reserve, dhs, dhT, dcT, dz, dx, dK, dR, db, dh0, dc0, B, T, F, H, act,
+                        accumulate, (float*)workspace, workspace_bytes / sizeof(float), (hipStream_t)stream, 1);
 }
 
 size_t fov_dense_bwd_workspace_bytes(int N, int In, int Out) {
@@ -445,7 +483,19 @@ int fov_dense_bwd(const float* x, const float* W, const float* dpre, float* dx, 
     int rc = check_ws(workspace, workspace_bytes, fov_dense_bwd_workspace_bytes(N, In, Out));
     if (rc) return rc;
     return dense_bwd(x, W, dpre, dx, dW, db, N, In, Out, accumulate, (float*)workspace, workspace_bytes / sizeof(float),
-                     (hipStream_t)stream);
+                     (hipStream_t)stream, 0);
+}
+
+int fov_dense_bwd_bf16(const float* x, const float* W, const float* dpre, float* dx, float* dW, float* db, int N, int In,
+                       int Out, int accumulate, void* workspace, size_t workspace_bytes, fov_stream_t stream) {
+    if (N < 0 || In <= 0 || Out <= 0 || (N > 0 && (!x || !W || !dpre))) {
+        set_error("fov_dense_bwd_bf16: invalid argument");
+        return FOV_ERR_INVALID;
+    }
+    int rc = check_ws(workspace, workspace_bytes, fov_dense_bwd_workspace_bytes(N, In, Out));
+    if (rc) return rc;
+    return dense_bwd(x, W, dpre, dx, dW, db, N, In, Out, accumulate, (float*)workspace, workspace_bytes / sizeof(float),
+                     (hipStream_t)stream, 1);
 }
 
 int fov_mse_dense_grad(const float* y, const float* target, float* dpre, float* loss, int64_t n, int activation,
@@ -651,13 +701,13 @@ size_t fov_mix_decoder_workspace_bytes(int B, int H) {
     return mix_decoder_workspace_bytes(B);
 }
 
-int fov_mix_decoder_fwd(const float* dec0, const float* h1, const float* c1, const float* h2, const float* c2,
+static int mix_decoder_fwd_impl(const float* dec0, const float* h1, const float* c1, const float* h2, const float* c2,
                         const float* oth_proj, int64_t oth_batch_stride, int64_t oth_step_stride, const float* dec1_K,
                         const float* dec1_R, const float* dec1_b, const float* dec2_K, const float* dec2_R,
                         const float* dec2_b, const float* dense_W, const float* dense_b, const float* mix_Wp, float* out,
                         float* h1T, float* c1T, float* h2T, float* c2T, float* P, float* H1, float* C1, float* H2, float* C2,
                         float* res1, float* res2, int B, int T_out, int H, int O, int act, void* workspace,
-                        size_t workspace_bytes, fov_stream_t stream) {
+                        size_t workspace_bytes, fov_stream_t stream, bool bf16) {
     if (B < 0 || T_out < 0 || O <= 0 || !dec1_K || !dec1_R || !dec1_b || !dec2_K || !dec2_R || !dec2_b || !dense_W ||
         !dense_b || !mix_Wp || (B > 0 && T_out > 0 && (!dec0 || !h1 || !c1 || !h2 || !c2 || !oth_proj || !out)) ||
         (act != FOV_ACT_SIGMOID && act != FOV_ACT_HARD_SIGMOID)) {
@@ -678,7 +728,32 @@ int fov_mix_decoder_fwd(const float* dec0, const float* h1, const float* c1, con
     p.out = out; p.P = P; p.H1 = H1; p.C1 = C1; p.H2 = H2; p.C2 = C2; p.res1 = res1; p.res2 = res2;
     p.h1T = h1T; p.c1T = c1T; p.h2T = h2T; p.c2T = c2T;
     p.B = B; p.T_out = T_out; p.O = O;
-    return mix_decoder_launch(p, dec2_K, act, ntrain == 7, workspace, (hipStream_t)stream);
+    return bf16 ? mix_decoder_bf16_launch(p, dec2_K, act, ntrain == 7, workspace, (hipStream_t)stream)
+                : mix_decoder_launch(p, dec2_K, act, ntrain == 7, workspace, (hipStream_t)stream);
+}
+
+int fov_mix_decoder_fwd(const float* dec0, const float* h1, const float* c1, const float* h2, const float* c2,
+                        const float* oth_proj, int64_t oth_batch_stride, int64_t oth_step_stride, const float* dec1_K,
+                        const float* dec1_R, const float* dec1_b, const float* dec2_K, const float* dec2_R,
+                        const float* dec2_b, const float* dense_W, const float* dense_b, const float* mix_Wp, float* out,
+                        float* h1T, float* c1T, float* h2T, float* c2T, float* P, float* H1, float* C1, float* H2, float* C2,
+                        float* res1, float* res2, int B, int T_out, int H, int O, int act, void* workspace,
+                        size_t workspace_bytes, fov_stream_t stream) {
+    return mix_decoder_fwd_impl(dec0, h1, c1, h2, c2, oth_proj, oth_batch_stride, oth_step_stride, dec1_K, dec1_R, dec1_b, dec2_K,
+                                dec2_R, dec2_b, dense_W, dense_b, mix_Wp, out, h1T, c1T, h2T, c2T, P, H1, C1, H2, C2, res1, res2,
+                                B, T_out, H, O, act, workspace, workspace_bytes, stream, false);
+}
+
+int fov_mix_decoder_fwd_bf16(const float* dec0, const float* h1, const float* c1, const float* h2, const float* c2,
+                             const float* oth_proj, int64_t oth_batch_stride, int64_t oth_step_stride, const float* dec1_K,
+                             const float* dec1_R, const float* dec1_b, const float* dec2_K, const float* dec2_R,
+                             const float* dec2_b, const float* dense_W, const float* dense_b, const float* mix_Wp, float* out,
+                             float* h1T, float* c1T, float* h2T, float* c2T, float* P, float* H1, float* C1, float* H2,
+                             float* C2, float* res1, float* res2, int B, int T_out, int H, int O, int act, void* workspace,
+                             size_t workspace_bytes, fov_stream_t stream) {
+    return mix_decoder_fwd_impl(dec0, h1, c1, h2, c2, oth_proj, oth_batch_stride, oth_step_stride, dec1_K, dec1_R, dec1_b, dec2_K,
+                                dec2_R, dec2_b, dense_W, dense_b, mix_Wp, out, h1T, c1T, h2T, c2T, P, H1, C1, H2, C2, res1, res2,
+                                B, T_out, H, O, act, workspace, workspace_bytes, stream, true);
 }
 
 size_t fov_mix_decoder_bwd_workspace_bytes(int B, int H) {
@@ -686,11 +761,11 @@ size_t fov_mix_decoder_bwd_workspace_bytes(int B, int H) {
     return mix_decoder_bwd_workspace_bytes(B);
 }
 
-int fov_mix_decoder_bwd(const float* M, const float* P, const float* dloss, const float* res1, const float* res2,
+static int mix_decoder_bwd_impl(const float* M, const float* P, const float* dloss, const float* res1, const float* res2,
                         const float* C1, const float* C2, const float* dec1_K, const float* dec1_R, const float* dec2_K,
                         const float* dec2_R, const float* dense_W, const float* mix_Wp, float* DZ1, float* DZ2,
                         float* dpre_m, float* dpre_p, float* dh1_0, float* dc1_0, float* dh2_0, float* dc2_0, int B,
-                        int T_out, int H, int O, int act, void* workspace, size_t workspace_bytes, fov_stream_t stream) {
+                        int T_out, int H, int O, int act, void* workspace, size_t workspace_bytes, fov_stream_t stream, bool bf16) {
     if (B < 0 || T_out < 0 || O <= 0 || !dec1_K || !dec1_R || !dec2_K || !dec2_R || !dense_W || !mix_Wp ||
         (B > 0 && T_out > 0 && (!M || !P || !dloss || !res1 || !res2 || !C1 || !C2 || !DZ1 || !DZ2 || !dpre_m || !dpre_p ||
                                 !dh1_0 || !dc1_0 || !dh2_0 || !dc2_0)) ||
@@ -708,7 +783,26 @@ int fov_mix_decoder_bwd(const float* M, const float* P, const float* dloss, cons
     p.DZ1 = DZ1; p.DZ2 = DZ2; p.dpre_m = dpre_m; p.dpre_p = dpre_p;
     p.dh1_0 = dh1_0; p.dc1_0 = dc1_0; p.dh2_0 = dh2_0; p.dc2_0 = dc2_0;
     p.B = B; p.T_out = T_out; p.O = O;
-    return mix_decoder_bwd_launch(p, dec2_K, act, workspace, (hipStream_t)stream);
+    return bf16 ? mix_decoder_bwd_bf16_launch(p, dec2_K, act, workspace, (hipStream_t)stream)
+                : mix_decoder_bwd_launch(p, dec2_K, act, workspace, (hipStream_t)stream);
+}
+
+int fov_mix_decoder_bwd(const float* M, const float* P, const float* dloss, const float* res1, const float* res2,
+                        const float* C1, const float* C2, const float* dec1_K, const float* dec1_R, const float* dec2_K,
+                        const float* dec2_R, const float* dense_W, const float* mix_Wp, float* DZ1, float* DZ2,
+                        float* dpre_m, float* dpre_p, float* dh1_0, float* dc1_0, float* dh2_0, float* dc2_0, int B,
+                        int T_out, int H, int O, int act, void* workspace, size_t workspace_bytes, fov_stream_t stream) {
+    return mix_decoder_bwd_impl(M, P, dloss, res1, res2, C1, C2, dec1_K, dec1_R, dec2_K, dec2_R, dense_W, mix_Wp, DZ1, DZ2, dpre_m,
+                                dpre_p, dh1_0, dc1_0, dh2_0, dc2_0, B, T_out, H, O, act, workspace, workspace_bytes, stream, false);
+}
+
+int fov_mix_decoder_bwd_bf16(const float* M, const float* P, const float* dloss, const float* res1, const float* res2,
+                             const float* C1, const float* C2, const float* dec1_K, const float* dec1_R, const float* dec2_K,
+                             const float* dec2_R, const float* dense_W, const float* mix_Wp, float* DZ1, float* DZ2,
+                             float* dpre_m, float* dpre_p, float* dh1_0, float* dc1_0, float* dh2_0, float* dc2_0, int B,
+                             int T_out, int H, int O, int act, void* workspace, size_t workspace_bytes, fov_stream_t stream) {
+    return mix_decoder_bwd_impl(M, P, dloss, res1, res2, C1, C2, dec1_K, dec1_R, dec2_K, dec2_R, dense_W, mix_Wp, DZ1, DZ2, dpre_m,
+                                dpre_p, dh1_0, dc1_0, dh2_0, dc2_0, B, T_out, H, O, act, workspace, workspace_bytes, stream, true);
 }
 
 size_t fov_matmul_workspace_bytes(int M, int K, int N) {

@@ -120,6 +120,7 @@ struct MixDecParams {
 };
 size_t mix_decoder_workspace_bytes(int B);
 int mix_decoder_launch(MixDecParams p, const float* K2, int act, int train, void* workspace, hipStream_t stream);
+int mix_decoder_bf16_launch(MixDecParams p, const float* K2, int act, int train, void* workspace, hipStream_t stream);   // mix_decoder_bf16.hip
 
 // backward of the fused decoder (mix_decoder_bwd.hip)
 struct MixDecBwdParams {
@@ -137,6 +138,7 @@ struct MixDecBwdParams {
 };
 size_t mix_decoder_bwd_workspace_bytes(int B);
 int mix_decoder_bwd_launch(MixDecBwdParams p, const float* K2, int act, void* workspace, hipStream_t stream);
+int mix_decoder_bwd_bf16_launch(MixDecBwdParams p, const float* K2, int act, void* workspace, hipStream_t stream);   // mix_decoder_bwd_bf16.hip
 
 // persistent BPTT recurrence (lstm_bwd_cluster.hip)
 bool bwd_cluster_shape_ok(int H);
@@ -150,9 +152,9 @@ size_t lstm_bwd_workspace_floats(int B, int T, int F, int H);
 int lstm_seq_bwd(const float* x, const float* K, const float* R, const float* h0, const float* c0, const float* hs,
                  const float* reserve, const float* dhs, const float* dhT, const float* dcT, float* dz, float* dx,
                  float* dK, float* dR, float* db, float* dh0, float* dc0, int B, int T, int F, int H, int act,
-                 int accumulate, float* ws, size_t ws_floats, hipStream_t stream);
+                 int accumulate, float* ws, size_t ws_floats, hipStream_t stream, int bf16 = 0);
 int dense_bwd(const float* x, const float* W, const float* dpre, float* dx, float* dW, float* db, int N, int In, int Out,
-              int accumulate, float* scratch, size_t scratch_floats, hipStream_t stream);
+              int accumulate, float* scratch, size_t scratch_floats, hipStream_t stream, int bf16 = 0);
 int mse_dense_grad(const float* y, const float* target, float* dpre, float* loss, long n, int activation, float* scratch,
                    size_t scratch_floats, hipStream_t stream);
 int mse_dense_grad_w(const float* y, const float* target, float* dpre, float* loss, long n, int activation, float weight,

@@ -1,0 +1,280 @@
+// bf16 matrix-core GEMMs of the bf16 training step (BASELINE.json configs[4]): fp32 tensors in HBM, operands rounded to
+// bf16 (RNE) while they are staged into LDS, v_mfma_f32_16x16x32_bf16, fp32 accumulation, fp32 result.
+//
+//   gemm_bf16_tn : C (M,N) (+)= sum_r A[r][m] * B[r][n]        weight gradients  dK = x^T dz,  dR = h_prev^T dz
+//                  rows r = (ro, ri), ro < RO, ri < RI; A row at a + ro*a_so + ri*lda, B row at b + ro*b_so + ri*ldb:
+//                  the two-level row index contracts (batch, time) pairs with a time shift without copies
+//                  (dR = sum_b sum_{t>=1} hs[b][t-1]^T dz[b][t]).  Split over the rows (deterministic: partials +
+//                  fixed-order reduce, no float atomics).
+//   gemm_bf16_nt : C (M,N) = sum_k A[m][k] * B[n][k]           data gradient  dx = dz . K^T
+//
+// TN: both operands have the contraction index on their slow axis.  They are staged as they lie ([r][m], [r][n] bf16
+// images, 16-byte global loads along the fast axis, ds_write_b64) and the MFMA fragments - 8 consecutive-k values of
+// one column - come out of the image through ds_read_b64_tr_b16, the hardware transpose read (cdna_hip_programming.md
+// T10): no transposed copy, no ds_permute.  The k order inside a 32-block is permuted (element j of lane group g4 is
+// row 16*(j>>2) + 4*g4 + (j&3)) - the same for A and B, so the product is unchanged - which makes the eight rows a
+// 32-lane half touches contiguous: with a row stride of 72 dwords every transposed read is bank-conflict-free.
+// Both kernels are HBM/L2-bound at the sizes of this path (a 5120 x 256 x 1024 product is 2.7 GFLOP = 1 us of bf16
+// matrix time against 26 MB of fp32 operands).
+#include <stdlib.h>
+
+#include "bf16_common.h"
+
+namespace fov {
+
+namespace {
+
+typedef short qs16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int GT = 128;          // output tile (GT x GT), 4 waves as 2 x 2, each 64 x 64 = 4 x 4 MFMA tiles
+constexpr int GKB = 32;          // rows (k) per stage
+constexpr int GLD_TN = 144;      // bf16 per LDS row of a [k][GT] image: 72 dwords = 8 (mod 64)
+constexpr int GLD_NT = 40;       // bf16 per LDS row of a [GT][k] image
+
+struct GemmTN {
+    const float* a;
+    const float* b;
+    float* c;            // split == 1: C (ldc); else partials [slice][M][N]
+    int M, N, RO, RI;
+    long lda, ldb, a_so, b_so;
+    int ldc;
+    int split;           // row slices (grid.z)
+    long rows_per_split; // multiple of GKB
+    int add_c;           // split == 1 only: C += A^T B
+};
+
+// two transposed reads = the 8 k-values of one column for this lane group (k permutation in the file header)
+__device__ __forceinline__ qu32x4 tr_frag(const unsigned short* img, int g4, int n, int col0) {
+    const int q = n >> 2, p = n & 3;
+    const unsigned short* p0 = img + (4 * g4 + q) * GLD_TN + col0 + 4 * p;
+    const qs16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((qs16x4 __attribute__((address_space(3)))*)p0);
+    const qs16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((qs16x4 __attribute__((address_space(3)))*)(p0 + 16 * GLD_TN));
+    const qu32x2 l2 = __builtin_bit_cast(qu32x2, lo), h2 = __builtin_bit_cast(qu32x2, hi);
+    return (qu32x4){l2.x, l2.y, h2.x, h2.y};
+}
+
+template <bool AVEC>   // AVEC: 16-byte loads of A rows (lda % 4 == 0, a 16-byte aligned, M % 4 == 0); B always is
+__global__ __launch_bounds__(256) void gemm_bf16_tn_kernel(GemmTN g) {
+    __shared__ __attribute__((aligned(16))) unsigned short sA[2][GKB * GLD_TN];
+    __shared__ __attribute__((aligned(16))) unsigned short sB[2][GKB * GLD_TN];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 15, g4 = lane >> 4;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * GT, n0 = blockIdx.x * GT;
+    const long rows = (long)g.RO * g.RI;
+    const long r_lo = (long)blockIdx.z * g.rows_per_split;
+    long r_hi = r_lo + g.rows_per_split;
+    if (r_hi > rows) r_hi = rows;
+    // staging: thread = (row tid >> 5 (+ 8 i), 4 columns (tid & 31) * 4)
+    const int srow = tid >> 5, scol = (tid & 31) * 4;
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 ra[4], rb[4];
+    auto load_stage = [&](long r0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const long r = r0 + srow + 8 * i;
+            ra[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            rb[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (r < r_hi) {
+                const long ro = r / g.RI, ri = r - ro * g.RI;
+                const float* ap = g.a + ro * g.a_so + ri * g.lda + m0 + scol;
+                const float* bp = g.b + ro * g.b_so + ri * g.ldb + n0 + scol;
+                if (AVEC) {
+                    if (m0 + scol < g.M) ra[i] = *(const f32x4*)ap;
+                } else {
+#pragma unroll
+                    for (int v = 0; v < 4; ++v)
+                        if (m0 + scol + v < g.M) ra[i][v] = ap[v];
+                }
+                if (n0 + scol + 3 < g.N) {
+                    rb[i] = *(const f32x4*)bp;
+                } else {
+#pragma unroll
+                    for (int v = 0; v < 4; ++v)
+                        if (n0 + scol + v < g.N) rb[i][v] = bp[v];
+                }
+            }
+        }
+    };
+    auto store_stage = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *(qu32x2*)(sA[buf] + (srow + 8 * i) * GLD_TN + scol) = (qu32x2){pack_bf16(ra[i][0], ra[i][1]), pack_bf16(ra[i][2], ra[i][3])};
+            *(qu32x2*)(sB[buf] + (srow + 8 * i) * GLD_TN + scol) = (qu32x2){pack_bf16(rb[i][0], rb[i][1]), pack_bf16(rb[i][2], rb[i][3])};
+        }
+    };
+    const long nstages = (r_hi > r_lo) ? (r_hi - r_lo + GKB - 1) / GKB : 0;
+    if (nstages > 0) {
+        load_stage(r_lo);
+        store_stage(0);
+    }
+    __syncthreads();
+    for (long s = 0; s < nstages; ++s) {
+        const int buf = (int)(s & 1);
+        if (s + 1 < nstages) load_stage(r_lo + (s + 1) * GKB);   // global loads of the next stage fly under the MFMAs
+        qu32x4 af[4], bf[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            af[i] = tr_frag(sA[buf], g4, n, wm * 64 + i * 16);
+            bf[i] = tr_frag(sB[buf], g4, n, wn * 64 + i * 16);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) qmfma(acc[i][j], af[i], bf[j]);
+        if (s + 1 < nstages) store_stage(buf ^ 1);
+        __syncthreads();
+    }
+    float* cbase = g.split > 1 ? g.c + (size_t)blockIdx.z * g.M * g.N : g.c;
+    const int ldc = g.split > 1 ? g.N : g.ldc;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int col = n0 + wn * 64 + j * 16 + n;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m0 + wm * 64 + i * 16 + 4 * g4 + r;
+                if (row < g.M && col < g.N) {
+                    float* cp = cbase + (size_t)row * ldc + col;
+                    *cp = (g.split == 1 && g.add_c) ? *cp + acc[i][j][r] : acc[i][j][r];
+                }
+            }
+        }
+}
+
+struct GemmNT {
+    const float* a;   // (M, K) row-major, lda
+    const float* b;   // (N, K) row-major, ldb
+    float* c;         // (M, N), ldc
+    int M, N, K;
+    long lda, ldb;
+    int ldc;
+};
+
+// K % 4 == 0, lda % 4 == 0, ldb % 4 == 0, 16-byte aligned bases (host-checked)
+__global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(GemmNT g) {
+    __shared__ __attribute__((aligned(16))) unsigned short sA[2][GT * GLD_NT];
+    __shared__ __attribute__((aligned(16))) unsigned short sB[2][GT * GLD_NT];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 15, g4 = lane >> 4;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * GT, n0 = blockIdx.x * GT;
+    // staging: thread = (row tid >> 3 (+ 32 i), 4 k-values (tid & 7) * 4)
+    const int srow = tid >> 3, scol = (tid & 7) * 4;
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 ra[4], rb[4];
+    auto load_stage = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = srow + 32 * i;
+            const bool kin = k0 + scol < g.K;
+            ra[i] = (kin && m0 + row < g.M) ? *(const f32x4*)(g.a + (size_t)(m0 + row) * g.lda + k0 + scol) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            rb[i] = (kin && n0 + row < g.N) ? *(const f32x4*)(g.b + (size_t)(n0 + row) * g.ldb + k0 + scol) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto store_stage = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *(qu32x2*)(sA[buf] + (srow + 32 * i) * GLD_NT + scol) = (qu32x2){pack_bf16(ra[i][0], ra[i][1]), pack_bf16(ra[i][2], ra[i][3])};
+            *(qu32x2*)(sB[buf] + (srow + 32 * i) * GLD_NT + scol) = (qu32x2){pack_bf16(rb[i][0], rb[i][1]), pack_bf16(rb[i][2], rb[i][3])};
+        }
+    };
+    const int nstages = (g.K + GKB - 1) / GKB;
+    load_stage(0);
+    store_stage(0);
+    __syncthreads();
+    for (int s = 0; s < nstages; ++s) {
+        const int buf = s & 1;
+        if (s + 1 < nstages) load_stage((s + 1) * GKB);
+        qu32x4 af[4], bf[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            af[i] = *(const qu32x4*)(sA[buf] + (wm * 64 + i * 16 + n) * GLD_NT + 8 * g4);
+            bf[i] = *(const qu32x4*)(sB[buf] + (wn * 64 + i * 16 + n) * GLD_NT + 8 * g4);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) qmfma(acc[i][j], af[i], bf[j]);
+        if (s + 1 < nstages) store_stage(buf ^ 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int col = n0 + wn * 64 + j * 16 + n;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m0 + wm * 64 + i * 16 + 4 * g4 + r;
+                if (row < g.M && col < g.N) g.c[(size_t)row * g.ldc + col] = acc[i][j][r];
+            }
+        }
+}
+
+}  // namespace
+
+size_t gemm_bf16_tn_scratch_floats(int M, int N) { return (size_t)32 * M * N; }
+
+// C (M,N) (+)= sum over rows (ro, ri) of A[row][m] B[row][n]; scratch holds the split partials
+int gemm_bf16_tn(const float* a, long lda, long a_so, const float* b, long ldb, long b_so, float* c, int ldc, int M, int N, int RO,
+                 int RI, int accumulate, float* scratch, size_t scratch_floats, hipStream_t stream) {
+    if (M <= 0 || N <= 0) return FOV_OK;
+    const long rows = (long)RO * RI;
+    if ((ldb & 3) || (b_so & 3) || (((uintptr_t)b) & 15) || (N & 3)) { set_error("gemm_bf16_tn: B must be 16-byte aligned with N, ldb % 4 == 0"); return FOV_ERR_INVALID; }
+    if (rows <= 0) {
+        if (!accumulate) (void)hipMemsetAsync(c, 0, sizeof(float) * (size_t)M * ldc, stream);
+        return FOV_OK;
+    }
+    GemmTN g = {};
+    g.a = a; g.b = b; g.M = M; g.N = N; g.RO = RO; g.RI = RI; g.lda = lda; g.ldb = ldb; g.a_so = a_so; g.b_so = b_so; g.ldc = ldc;
+    const int tiles = ((M + GT - 1) / GT) * ((N + GT - 1) / GT);
+    // enough row slices to fill the chip, at least 8 stages each, at most 32 slices and what the scratch holds
+    int split = (2 * device_cu_count() + tiles - 1) / tiles;
+    const long max_by_rows = rows / (8 * GKB);
+    if (split > max_by_rows) split = (int)max_by_rows;
+    if (split > 32) split = 32;
+    while (split > 1 && (size_t)split * M * N > scratch_floats) --split;
+    if (split < 1) split = 1;
+    long rps = (rows + split - 1) / split;
+    rps = (rps + GKB - 1) / GKB * GKB;
+    split = (int)((rows + rps - 1) / rps);
+    g.split = split;
+    g.rows_per_split = rps;
+    g.add_c = accumulate;
+    g.c = split > 1 ? scratch : c;
+    if (split > 1 && ldc != N) { set_error("gemm_bf16_tn: split products need a dense C"); return FOV_ERR_INVALID; }
+    const dim3 grid((N + GT - 1) / GT, (M + GT - 1) / GT, split);
+    const bool avec = (lda & 3) == 0 && (a_so & 3) == 0 && (((uintptr_t)a) & 15) == 0 && (M & 3) == 0;
+    if (avec) hipLaunchKernelGGL(gemm_bf16_tn_kernel<true>, grid, dim3(256), 0, stream, g);
+    else hipLaunchKernelGGL(gemm_bf16_tn_kernel<false>, grid, dim3(256), 0, stream, g);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_error("gemm_bf16_tn launch: %s", hipGetErrorString(e)); return FOV_ERR_LAUNCH; }
+    if (split > 1) return splitk_reduce(scratch, c, (long)M * N, split, accumulate, stream);
+    return FOV_OK;
+}
+
+int gemm_bf16_nt(const float* a, long lda, const float* b, long ldb, float* c, int ldc, int M, int N, int K, hipStream_t stream) {
+    if (M <= 0 || N <= 0) return FOV_OK;
+    if ((K & 3) || (lda & 3) || (ldb & 3) || (((uintptr_t)a) & 15) || (((uintptr_t)b) & 15) || K <= 0) {
+        set_error("gemm_bf16_nt: K, lda, ldb must be multiples of 4 and the operands 16-byte aligned");
+        return FOV_ERR_INVALID;
+    }
+    GemmNT g = {};
+    g.a = a; g.b = b; g.c = c; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+    hipLaunchKernelGGL(gemm_bf16_nt_kernel, dim3((N + GT - 1) / GT, (M + GT - 1) / GT), dim3(256), 0, stream, g);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_error("gemm_bf16_nt launch: %s", hipGetErrorString(e)); return FOV_ERR_LAUNCH; }
+    return FOV_OK;
+}
+
+}  // namespace fov

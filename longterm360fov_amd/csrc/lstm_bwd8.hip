@@ -1,0 +1,312 @@
+// Persistent BPTT recurrence of one LSTM layer, H = 256, in groups of EIGHT workgroups per 16-sequence tile - fp32
+// and bf16 operand forms of one kernel.  (What Keras/TF autodiff runs under model.fit for the LSTM layers of
+// mycode/given_others_gt_mean_var_seq2seq.py:108-115.)
+//
+// lstm_bwd_cluster.hip uses groups of H/64 = 4 workgroups: at 512 sequences per GPU (BASELINE configs[2]/[4]: 32 tiles)
+// that occupies 128 of the 256 CUs.  Here workgroup `slice` owns hidden units [32*slice, +32) for all four gates -
+// the ownership of lstm_wide.hip / mix_decoder_bwd.hip - so 32 tiles fill the chip.  Lane (n, g4) owns the cells
+// (rows 4*g4 + 2*(n>>3) + {0,1}, unit 32*slice + 8*wave + (n&7)): dc and the recurrent dh never leave registers.
+// Per step t = T-1 .. 0:
+//   gates backward for the lane's two cells (from the reserve i,f,g,o,c of the training forward) -> dz (4 gates), to
+//   dZ (B,T,4H) for the weight-gradient products and into an LDS tile (16 x 128 own gate columns);
+//   partial[16 x 256] = dz_own . R^T_own : the contribution of the own gate columns to dh_{t-1} of ALL 256 units
+//   (fp32: 128 x v_mfma_f32_16x16x4_f32 per wave, R^T slice in 128 AGPRs; bf16: 16 x v_mfma_f32_16x16x32_bf16, R^T
+//   slice as 64 registers of packed B fragments, dz rounded to bf16 in the LDS image);
+//   the 16 x 32 piece of every destination workgroup travels as fp32 {value, epoch} granules; each lane gathers
+//   the eight pieces of its own cells and adds them in slice order (deterministic).
+// The bias gradient leaves as one (tiles, 4H) partial (sum over the tile's rows and all steps), as in the 4-group kernel.
+#include <stdlib.h>
+
+#include "bf16_common.h"
+
+namespace fov {
+
+namespace {
+
+constexpr int B8LDZ = 128 + 4;     // fp32 LDS row stride of the dz tile
+constexpr int B8LDQ = 128 + 16;    // bf16 LDS row stride: 288 B = 72 dwords = 8 (mod 64): conflict-free ds_read_b128
+constexpr size_t B8_PAR = (size_t)QG * QG * QBT * 32;   // granules per parity: [dest][src][row][unit]
+
+struct Bwd8Params {
+    const float* R;
+    const float* reserve;   // (B,T,5,H)
+    const float* c0;        // (B,H) or NULL
+    const float* dhs;       // (B,T,H) or NULL
+    const float* dhT;       // (B,H) or NULL
+    const float* dcT;       // (B,H) or NULL
+    float* dz;              // (B,T,4H) out
+    float* dh0;             // (B,H) or NULL
+    float* dc0;             // (B,H) or NULL
+    float* db_part;         // (num_tiles, 4H) or NULL
+    unsigned long long* xch;
+    unsigned* status;
+    int B, T, num_groups, num_tiles, epoch_span;
+};
+
+__device__ __forceinline__ void b8_mfma_a(f32x4& acc, float a, float w_agpr) {
+    asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "a"(w_agpr));
+}
+template <int ACT>
+__device__ __forceinline__ float b8_act_grad(float a) {
+    return ACT == FOV_ACT_HARD_SIGMOID ? ((a > 0.f && a < 1.f) ? 0.2f : 0.f) : a * (1.f - a);
+}
+
+template <int ACT, bool BF16>
+__global__ __launch_bounds__(256, 1) void lstm_bwd8_kernel(Bwd8Params p) {
+    __shared__ __attribute__((aligned(16))) float sDZ[BF16 ? 4 : QBT * B8LDZ];
+    __shared__ __attribute__((aligned(16))) unsigned short sDQ[BF16 ? QBT * B8LDQ : 8];
+    __shared__ int sFlag[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 15, g4 = lane >> 4;
+    int group, slice;
+    q_group_slice(p.num_groups, group, slice);
+    constexpr int H4 = 4 * QH;
+    const int hi = n >> 3;
+    const int ul = 8 * wave + (n & 7);          // unit inside the workgroup (0..31)
+    const int unit = 32 * slice + ul;
+    const int my_row0 = 4 * g4 + 2 * hi;
+    const int T = p.T;
+    // epoch tags continue from the workspace header, a poisoned workspace skips the body (xch_common.h)
+    const unsigned epoch_base = xch_epoch_base(p.status);
+    const bool poisoned = xch_poisoned(p.status);
+    if (tid == 0) sFlag[0] = poisoned ? 1 : 0;
+
+    // ---- resident R^T fragments.  Tile tl of this wave: destination slice 2*wave + (tl>>1), half tl&1; its output unit
+    // on this lane is nout; k index lc is an own gate column: gate lc>>5, unit 32*slice + (lc & 31). ----
+    float rt[BF16 ? 1 : 4][BF16 ? 1 : 8][4];   // fp32: [tl][jb][s], lc = 16*jb + 4*g4 + s
+    qu32x4 rq[BF16 ? 4 : 1][BF16 ? 4 : 1];     // bf16: [tl][kb],    lc = 32*kb + 8*g4 + j
+#pragma unroll
+    for (int tl = 0; tl < 4; ++tl) {
+        const int nout = 32 * (2 * wave + (tl >> 1)) + 16 * (tl & 1) + n;
+        if constexpr (BF16) {
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) rq[tl][kb] = load_bfrag_rowmajor(p.R + (size_t)nout * H4 + kb * QH + 32 * slice + 8 * g4);
+        } else {
+#pragma unroll
+            for (int jb = 0; jb < 8; ++jb) {
+                const int lc = 16 * jb + 4 * g4;
+                const f32x4 v = *(const f32x4*)(p.R + (size_t)nout * H4 + (lc >> 5) * QH + 32 * slice + (lc & 31));
+#pragma unroll
+                for (int s = 0; s < 4; ++s) rt[tl][jb][s] = v[s];
+            }
+        }
+    }
+    unsigned long long* gbase = p.xch + (size_t)group * 2 * B8_PAR;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(gbase, 0, (int)(2 * B8_PAR * 8), 0x00020000);
+    unsigned epoch = epoch_base;
+    __syncthreads();
+    bool aborted = sFlag[0] != 0;
+
+    for (int tile = group; tile < p.num_tiles && !aborted; tile += p.num_groups) {
+        const int b0 = tile * QBT;
+        float dc[2], dh[2];
+        bool live[2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int row = b0 + my_row0 + r;
+            live[r] = row < p.B;
+            dc[r] = (live[r] && p.dcT) ? p.dcT[(size_t)row * QH + unit] : 0.f;
+            dh[r] = (live[r] && p.dhT) ? p.dhT[(size_t)row * QH + unit] : 0.f;
+        }
+        // tape pipeline: cur = step t, nxt = step t-1 (its c is c_{t-1} of step t)
+        float cur[5][2], nxt[5][2], dhs_cur[2], dhs_nxt[2];
+        auto load_step = [&](int t, float (&dst)[5][2], float (&dd_)[2]) {
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int row = b0 + my_row0 + r;
+                if (t >= 0 && live[r]) {
+                    const float* rp = p.reserve + (((size_t)row * T + t) * 5) * QH + unit;
+#pragma unroll
+                    for (int q = 0; q < 5; ++q) dst[q][r] = rp[q * QH];
+                    dd_[r] = p.dhs ? p.dhs[((size_t)row * T + t) * QH + unit] : 0.f;
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 5; ++q) dst[q][r] = 0.f;
+                    dst[4][r] = (t < 0 && live[r] && p.c0) ? p.c0[(size_t)row * QH + unit] : 0.f;   // c_{-1} = c0
+                    dd_[r] = 0.f;
+                }
+            }
+        };
+        load_step(T - 1, cur, dhs_cur);
+        load_step(T - 2, nxt, dhs_nxt);
+        float dbacc[4] = {0.f, 0.f, 0.f, 0.f};   // sum over t and this lane's 2 sequences of dz, per gate
+        __syncthreads();   // the previous tile's last step is done with the dz tile
+
+        for (int t = T - 1; t >= 0; --t) {
+            ++epoch;
+            const unsigned par = (epoch & 1u) * (unsigned)(B8_PAR * 8);
+            // ---- pointwise: dz of this lane's two cells ----
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const float ig = cur[0][r], fg = cur[1][r], gg = cur[2][r], og = cur[3][r], cc = cur[4][r];
+                const float cprev = nxt[4][r];
+                const float dht = dh[r] + dhs_cur[r];
+                const float tc = tanh_f(cc);
+                const float dcv = dc[r] + dht * og * (1.f - tc * tc);
+                float dzv[4];
+                dzv[0] = dcv * gg * b8_act_grad<ACT>(ig);
+                dzv[1] = dcv * cprev * b8_act_grad<ACT>(fg);
+                dzv[2] = dcv * ig * (1.f - gg * gg);
+                dzv[3] = dht * tc * b8_act_grad<ACT>(og);
+                dc[r] = dcv * fg;
+                if (live[r]) {
+                    float* zp = p.dz + ((size_t)(b0 + my_row0 + r) * T + t) * H4 + unit;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) zp[g * QH] = dzv[g];
+                }
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float v = live[r] ? dzv[g] : 0.f;
+                    dbacc[g] += v;
+                    if constexpr (BF16) sDQ[(my_row0 + r) * B8LDQ + g * 32 + ul] = bf16_bits(v);
+                    else sDZ[(my_row0 + r) * B8LDZ + g * 32 + ul] = v;
+                }
+            }
+            // rotate the tape pipeline and request step t-2
+#pragma unroll
+            for (int q = 0; q < 5; ++q)
+#pragma unroll
+                for (int r = 0; r < 2; ++r) cur[q][r] = nxt[q][r];
+#pragma unroll
+            for (int r = 0; r < 2; ++r) dhs_cur[r] = dhs_nxt[r];
+            load_step(t - 2, nxt, dhs_nxt);
+            __syncthreads();   // barrier A: the dz tile is complete
+            // ---- partial[16 x 256] = dz_own . R^T_own ; tile tl -> destination 2*wave + (tl>>1) ----
+            f32x4 acc[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if constexpr (BF16) {
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb) {
+                    const qu32x4 a = *(const qu32x4*)(sDQ + n * B8LDQ + 32 * kb + 8 * g4);
+#pragma unroll
+                    for (int tl = 0; tl < 4; ++tl) qmfma(acc[tl], a, rq[tl][kb]);
+                }
+            } else {
+                asm volatile("s_nop 3" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
+                const float* arow = sDZ + n * B8LDZ + 4 * g4;
+                f32x4 a = *(const f32x4*)arow, an = a;
+#pragma unroll
+                for (int jb = 0; jb < 8; ++jb) {
+                    if (jb + 1 < 8) an = *(const f32x4*)(arow + 16 * (jb + 1));
+                    asm volatile("s_nop 1" : "+v"(a));
+#pragma unroll
+                    for (int tl = 0; tl < 4; ++tl)
+#pragma unroll
+                        for (int s = 0; s < 4; ++s) b8_mfma_a(acc[tl], a[s], rt[tl][jb][s]);
+                    a = an;
+                }
+                asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
+            }
+#pragma unroll
+            for (int tl = 0; tl < 4; ++tl) {
+                const int d = 2 * wave + (tl >> 1);
+                const unsigned off = (unsigned)((((d * QG + slice) * QBT + 4 * g4) * 32) + 16 * (tl & 1) + n) * 8u;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    __builtin_amdgcn_raw_buffer_store_b64((qu32x2){__float_as_uint(acc[tl][r]), epoch}, rs, off + r * 32 * 8, par, 16);
+            }
+            // ---- gather the 8 pieces of this lane's two cells, add in slice order ----
+            {
+                const unsigned voff = (unsigned)(((slice * QG) * QBT + my_row0) * 32 + ul) * 8u;
+                constexpr unsigned SSTR = QBT * 32 * 8;   // src stride in bytes
+                float part[16];
+                unsigned bad = 0;
+                {
+                    qu32x2 v[16];
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+#pragma unroll
+                        for (int s = 0; s < 8; ++s) v[q * 8 + s] = __builtin_amdgcn_raw_buffer_load_b64(rs, voff + q * 32 * 8 + s * SSTR, par, 16);
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) {
+                        part[j] = __uint_as_float(v[j].x);
+                        if (v[j].y != epoch) bad |= (1u << j);
+                    }
+                }
+                unsigned spins = 0;
+                while (__any(bad != 0)) {
+                    ++spins;
+                    if (spins > Q_SPIN || ((spins & 63u) == 0 && xch_poisoned(p.status))) {
+                        if (lane == 0) { xch_give_up(p.status); sFlag[0] = 1; }
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                    asm volatile("" ::: "memory");
+                    qu32x2 tv[16];
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+#pragma unroll
+                        for (int s = 0; s < 8; ++s) tv[q * 8 + s] = __builtin_amdgcn_raw_buffer_load_b64(rs, voff + q * 32 * 8 + s * SSTR, par, 16);
+#pragma unroll
+                    for (int j = 0; j < 16; ++j)
+                        if (((bad >> j) & 1u) && tv[j].y == epoch) {
+                            part[j] = __uint_as_float(tv[j].x);
+                            bad &= ~(1u << j);
+                        }
+                }
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    float a = 0.f;
+#pragma unroll
+                    for (int s = 0; s < 8; ++s) a += part[q * 8 + s];
+                    dh[q] = a;
+                }
+            }
+            __syncthreads();   // barrier B: every wave is done reading the dz tile; sFlag is uniform below
+            if (sFlag[0]) { aborted = true; break; }
+        }
+        if (!aborted && p.db_part) {
+            // the 8 lanes (g4 0..3, hi 0..1) that share a unit hold different rows: fold them in a fixed order
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float v = dbacc[g];
+                v += __shfl_xor(v, 8);
+                const float v1 = __shfl(v, (lane + 16) & 63), v2 = __shfl(v, (lane + 32) & 63), v3 = __shfl(v, (lane + 48) & 63);
+                if (g4 == 0 && hi == 0) p.db_part[(size_t)tile * H4 + g * QH + unit] = (v + v1) + (v2 + v3);
+            }
+        }
+        if (!aborted) {
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int row = b0 + my_row0 + r;
+                if (row < p.B) {
+                    if (p.dh0) p.dh0[(size_t)row * QH + unit] = dh[r];
+                    if (p.dc0) p.dc0[(size_t)row * QH + unit] = dc[r];
+                }
+            }
+        }
+    }
+    xch_leave(p.status, (unsigned)p.epoch_span);
+}
+
+}  // namespace
+
+// one workgroup per CU: groups of eight fill the chip up to 32 tiles; beyond that the 4-group kernel is as good
+bool bwd8_preferred(int B, int H) { return H == QH && B > 0 && B <= 32 * QBT; }
+
+// status word + granule buffers live at `xch_ws` (kStatusBytes + kXchBytes)
+int launch_bwd8(const float* R, const float* reserve, const float* c0, const float* dhs, const float* dhT, const float* dcT,
+                float* dz, float* dh0, float* dc0, float* db_part, int B, int T, int act, int bf16, void* xch_ws, hipStream_t stream) {
+    if (B == 0 || T == 0) return FOV_OK;
+    Bwd8Params p = {};
+    p.R = R; p.reserve = reserve; p.c0 = c0; p.dhs = dhs; p.dhT = dhT; p.dcT = dcT; p.dz = dz; p.dh0 = dh0; p.dc0 = dc0; p.db_part = db_part;
+    p.B = B; p.T = T;
+    p.num_tiles = (B + QBT - 1) / QBT;
+    const int max_groups = device_cu_count() / QG;
+    if (max_groups < 1) { set_error("8-group BPTT kernel needs at least %d CUs", QG); return FOV_ERR_UNSUPPORTED; }
+    p.num_groups = p.num_tiles < max_groups ? p.num_tiles : max_groups;
+    if ((size_t)p.num_groups * 2 * B8_PAR * 8 > kXchBytes) { set_error("8-group BPTT kernel: granule area too small"); return FOV_ERR_WORKSPACE; }
+    p.status = (unsigned*)xch_ws;
+    p.xch = (unsigned long long*)((char*)xch_ws + kStatusBytes);
+    p.epoch_span = T * ((p.num_tiles + p.num_groups - 1) / p.num_groups) + 1;
+    void (*kern)(Bwd8Params) = nullptr;
+    if (bf16) kern = act == FOV_ACT_HARD_SIGMOID ? lstm_bwd8_kernel<FOV_ACT_HARD_SIGMOID, true> : lstm_bwd8_kernel<FOV_ACT_SIGMOID, true>;
+    else kern = act == FOV_ACT_HARD_SIGMOID ? lstm_bwd8_kernel<FOV_ACT_HARD_SIGMOID, false> : lstm_bwd8_kernel<FOV_ACT_SIGMOID, false>;
+    hipLaunchKernelGGL(kern, dim3(p.num_groups * QG), dim3(256), 0, stream, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_error("8-group BPTT launch: %s", hipGetErrorString(e)); return FOV_ERR_LAUNCH; }
+    return FOV_OK;
+}
+
+}  // namespace fov

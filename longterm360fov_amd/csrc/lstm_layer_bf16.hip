@@ -1,0 +1,200 @@
+// Persistent LSTM layer with bf16 matrix-core operands (BASELINE.json configs[4]), H = 256, F <= 256: the encoder
+// layers of the others-mixing model (mycode/given_others_gt_mean_var_seq2seq.py:108-115) when the model runs in bf16.
+//
+// The bf16 sibling of lstm_wide.hip.  z_t = bf16(x_t) . bf16(K) + bf16(h_{t-1}) . bf16(R) + b on
+// v_mfma_f32_16x16x32_bf16 with fp32 accumulation; gates, cell state c and every stored tensor (hs, reserve, hT, cT)
+// stay fp32.  K and R slices live in registers for the whole launch as packed B fragments (64 + 64 registers per
+// lane at F = H = 256); x_t and h_t tiles sit in LDS as bf16 row images (one ds_read_b128 = one A fragment).
+// Per step and wave the matrix work is (NKB + 8) x 2 MFMAs of 16 cycles (fp32 path: (NJX + 16) x 8 of 32 cycles): the step is
+// bound by the exchange of h_t, which carries the two bf16 values a lane owns in ONE granule (half the granules of
+// the fp32 kernels).
+#include <stdlib.h>
+
+#include "bf16_common.h"
+
+namespace fov {
+
+namespace {
+
+template <int ACT, int NKB>   // NKB: 32-wide k-blocks of the input kernel (3: F <= 96, 8: F <= 256)
+__global__ __launch_bounds__(256, 1) void lstm_layer_bf16_kernel(LstmParams p) {
+    __shared__ __attribute__((aligned(16))) unsigned short sH[QBT * QLD];
+    __shared__ __attribute__((aligned(16))) unsigned short sX[2 * QBT * QLD];
+    __shared__ int sFlag[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 15, g4 = lane >> 4;
+    int group, slice;
+    q_group_slice(p.num_groups, group, slice);
+    const int F = p.F, steps = p.T;
+    const int unit = 32 * slice + 8 * wave + (n & 7);
+    const int hi = n >> 3;
+    const int col0 = hi * QH + unit, col1 = (2 + hi) * QH + unit;   // gate columns of N-tile 0 ([i | f]) / 1 ([g | o])
+    constexpr int H4 = 4 * QH;
+    // epoch tags continue from the workspace header, a poisoned workspace skips the body (xch_common.h)
+    const bool xch_used = steps > 1;
+    const unsigned epoch_base = xch_used ? xch_epoch_base(p.status) : 0u;
+    const bool poisoned = xch_used && xch_poisoned(p.status);
+    if (tid == 0) sFlag[0] = poisoned ? 1 : 0;
+
+    // ---- resident weights: packed bf16 B fragments (rows of K beyond F are zero) ----
+    qu32x4 wk[NKB][2], wr[8][2];
+#pragma unroll
+    for (int kb = 0; kb < 8; ++kb) {
+        if (kb < NKB) {
+            wk[kb][0] = load_bfrag(p.K, H4, F, kb, g4, col0);
+            wk[kb][1] = load_bfrag(p.K, H4, F, kb, g4, col1);
+        }
+        wr[kb][0] = load_bfrag(p.R, H4, QH, kb, g4, col0);
+        wr[kb][1] = load_bfrag(p.R, H4, QH, kb, g4, col1);
+    }
+    const float bv[2] = {p.b[col0], p.b[col1]};
+    for (int i = tid; i < 2 * QBT * QLD; i += 256) sX[i] = 0;   // columns >= F stay zero
+
+    // ---- exchange bookkeeping ----
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+        p.xch + (size_t)group * 2 * (Q_TILE_BYTES / 8), 0, (int)(2 * Q_TILE_BYTES), 0x00020000);
+    const int my_row0 = 4 * g4 + 2 * hi;                                       // this lane's cells: rows my_row0, +1 of `unit`
+    const unsigned pub_off = (unsigned)((my_row0 >> 1) * QH + unit) * 8u;
+    unsigned epoch = epoch_base;
+    __syncthreads();
+    bool aborted = sFlag[0] != 0;
+
+    // x staging: thread (xrw = tid / 16, xc = tid % 16) moves the elements xc, xc + 16, ... of row xrw
+    const int xrw = tid >> 4, xc = tid & 15;
+    constexpr int NXE = 2 * NKB;   // elements per thread: 32 * NKB columns / 16
+    QGather gq;
+    for (int tile = group; tile < p.num_tiles && !aborted; tile += p.num_groups) {
+        const int b0 = tile * QBT;
+        __syncthreads();   // previous tile fully consumed
+        for (int e = tid; e < QBT * QH; e += 256) {
+            const int row = e >> 8, u = e & 255;
+            sH[row * QLD + u] = bf16_bits((b0 + row < p.B && p.h0) ? p.h0[(size_t)(b0 + row) * QH + u] : 0.f);
+        }
+        float c[2], hc[2] = {0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int row = b0 + my_row0 + r;
+            c[r] = (row < p.B && p.c0) ? p.c0[(size_t)row * QH + unit] : 0.f;
+            hc[r] = (row < p.B && p.h0) ? p.h0[(size_t)row * QH + unit] : 0.f;
+        }
+        const bool xlive = b0 + xrw < p.B;
+        const float* xt = p.x + ((size_t)(b0 + xrw) * p.T) * F + xc;
+        unsigned short* xl = sX + xrw * QLD + xc;
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+            if (tt < steps) {
+#pragma unroll
+                for (int i = 0; i < NXE; ++i)
+                    if (xc + 16 * i < F) xl[tt * QBT * QLD + 16 * i] = bf16_bits(xlive ? xt[(size_t)tt * F + 16 * i] : 0.f);
+            }
+        __syncthreads();
+        // ---- pre-activations of step 0 ----
+        f32x4 acc[2];
+        acc[0] = (f32x4){bv[0], bv[0], bv[0], bv[0]};
+        acc[1] = (f32x4){bv[1], bv[1], bv[1], bv[1]};
+        if (steps > 0) {
+            qmm<0, NKB, NKB>(acc, sX, n, g4, wk);
+            qmm<0, 8, 8>(acc, sH, n, g4, wr);
+        }
+        float xs[NXE];
+#pragma unroll
+        for (int i = 0; i < NXE; ++i) xs[i] = 0.f;
+        for (int t = 0; t < steps; ++t) {
+            // x pipeline: x_{t+1} (requested during step t-1) registers -> LDS; then request x_{t+2}
+            if (t > 0 && t + 1 < steps) {
+                unsigned short* xb = xl + ((t + 1) & 1) * QBT * QLD;
+#pragma unroll
+                for (int i = 0; i < NXE; ++i)
+                    if (xc + 16 * i < F) xb[16 * i] = bf16_bits(xs[i]);
+            }
+            if (t + 2 < steps) {
+                const float* xn = xt + (size_t)(t + 2) * F;
+#pragma unroll
+                for (int i = 0; i < NXE; ++i) xs[i] = (xlive && xc + 16 * i < F) ? xn[16 * i] : 0.f;
+            }
+            // ---- cell update (fp32) ----
+            {
+                float zi[2], zf[2], zg[2], zo[2];
+                gates_of_lane(acc, hi, zi, zf, zg, zo);
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    const float ig = rec_act<ACT>(zi[r]), fg = rec_act<ACT>(zf[r]), gg = tanh_f(zg[r]), og = rec_act<ACT>(zo[r]);
+                    c[r] = fmaf(fg, c[r], ig * gg);
+                    hc[r] = og * tanh_f(c[r]);
+                    const int row = b0 + my_row0 + r;
+                    if (row < p.B) {
+                        if (p.reserve) {
+                            float* rp = p.reserve + (((size_t)row * p.T + t) * 5) * QH + unit;
+                            rp[0] = ig; rp[QH] = fg; rp[2 * QH] = gg; rp[3 * QH] = og; rp[4 * QH] = c[r];
+                        }
+                        if (p.hs) p.hs[((size_t)row * p.T + t) * QH + unit] = hc[r];
+                    }
+                }
+            }
+            const bool more = (t + 1 < steps);
+            const bool do_xch = xch_used && more;   // the last h_t is needed by nobody in here
+            unsigned par = 0;
+            const unsigned hpair = pack_bf16(hc[0], hc[1]);
+            if (do_xch) {
+                ++epoch;
+                par = (epoch & 1u) * Q_TILE_BYTES;
+                __builtin_amdgcn_raw_buffer_store_b64((qu32x2){hpair, epoch}, xrs, pub_off, par, 16);
+            }
+            __syncthreads();   // barrier 1: every wave is done reading sH; x_{t+1} is in LDS
+            if (more) {
+                sH[my_row0 * QLD + unit] = (unsigned short)(hpair & 0xffffu);
+                sH[(my_row0 + 1) * QLD + unit] = (unsigned short)(hpair >> 16);
+            }
+            acc[0] = (f32x4){bv[0], bv[0], bv[0], bv[0]};
+            acc[1] = (f32x4){bv[1], bv[1], bv[1], bv[1]};
+            // x_{t+1} . K needs no remote data; the gather is requested behind it (the partners publish at about the same
+            // moment and an sc1 store takes most of a microsecond to become visible)
+            if (more) qmm<0, NKB, NKB>(acc, sX + ((t + 1) & 1) * QBT * QLD, n, g4, wk);
+            if (do_xch) {
+                q_gather_issue(gq, xrs, par, slice, tid);
+                if (!q_gather_finish(gq, xrs, par, slice, tid, epoch, sH, p.status)) sFlag[0] = 1;
+            }
+            __syncthreads();   // barrier 2: the whole h_t tile is in LDS
+            if (sFlag[0]) { aborted = true; break; }
+            if (more) qmm<0, 8, 8>(acc, sH, n, g4, wr);
+        }
+        if (!aborted) {
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int row = b0 + my_row0 + r;
+                if (row < p.B) {
+                    if (p.hT) p.hT[(size_t)row * QH + unit] = hc[r];
+                    if (p.cT) p.cT[(size_t)row * QH + unit] = c[r];
+                }
+            }
+        }
+    }
+    if (xch_used) xch_leave(p.status, (unsigned)p.epoch_span);
+}
+
+}  // namespace
+
+bool layer_bf16_shape_ok(int F, int H) { return H == QH && F >= 1 && F <= 256; }
+
+// p.status / p.xch point into the caller's workspace (header + the fixed granule area)
+int launch_layer_bf16(const LstmParams& p_in, hipStream_t stream) {
+    LstmParams p = p_in;
+    if (p.B == 0) return FOV_OK;
+    if (!layer_bf16_shape_ok(p.F, p.H)) { set_error("bf16 LSTM layer: H = 256 and F <= 256 only (got H=%d F=%d)", p.H, p.F); return FOV_ERR_UNSUPPORTED; }
+    p.num_tiles = (p.B + QBT - 1) / QBT;
+    const int max_groups = device_cu_count() / QG;   // one workgroup per CU: every group must be co-resident
+    if (max_groups < 1) { set_error("bf16 LSTM layer needs at least %d CUs", QG); return FOV_ERR_UNSUPPORTED; }
+    p.num_groups = p.num_tiles < max_groups ? p.num_tiles : max_groups;
+    if ((size_t)p.num_groups * 2 * Q_TILE_BYTES > kXchBytes) { set_error("bf16 LSTM layer: granule area too small"); return FOV_ERR_WORKSPACE; }
+    p.epoch_span = p.T * ((p.num_tiles + p.num_groups - 1) / p.num_groups) + 1;
+    const bool narrow = p.F <= 96;
+    void (*kern)(LstmParams) =
+        narrow ? (p.act == FOV_ACT_HARD_SIGMOID ? lstm_layer_bf16_kernel<FOV_ACT_HARD_SIGMOID, 3> : lstm_layer_bf16_kernel<FOV_ACT_SIGMOID, 3>)
+               : (p.act == FOV_ACT_HARD_SIGMOID ? lstm_layer_bf16_kernel<FOV_ACT_HARD_SIGMOID, 8> : lstm_layer_bf16_kernel<FOV_ACT_SIGMOID, 8>);
+    hipLaunchKernelGGL(kern, dim3(p.num_groups * QG), dim3(256), 0, stream, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_error("bf16 LSTM layer launch: %s", hipGetErrorString(e)); return FOV_ERR_LAUNCH; }
+    return FOV_OK;
+}
+
+}  // namespace fov

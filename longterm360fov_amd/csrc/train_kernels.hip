@@ -15,6 +15,7 @@
 
 #include "fov_common.h"
 #include "xch_common.h"
+#include "bf16_common.h"
 
 namespace fov {
 
@@ -886,7 +887,8 @@ size_t lstm_bwd_workspace_floats(int B, int T, int F, int H) {
 int lstm_seq_bwd(const float* x, const float* K, const float* R, const float* h0, const float* c0, const float* hs,
                  const float* reserve, const float* dhs, const float* dhT, const float* dcT, float* dz, float* dx,
                  float* dK, float* dR, float* db, float* dh0, float* dc0, int B, int T, int F, int H, int act,
-                 int accumulate, float* ws, size_t ws_floats, hipStream_t stream) {
+                 int accumulate, float* ws, size_t ws_floats, hipStream_t stream, int bf16) {
+    if (bf16 && H != 256) { set_error("lstm_seq_bwd: the bf16 path is built for H = 256"); return FOV_ERR_UNSUPPORTED; }
     if (ws_floats < lstm_bwd_workspace_floats(B, T, F, H)) { set_error("lstm_seq_bwd: workspace too small"); return FOV_ERR_WORKSPACE; }
     if (T == 0) {
         if (!accumulate) {
@@ -911,8 +913,12 @@ int lstm_seq_bwd(const float* x, const float* K, const float* R, const float* h0
         // one launch for the whole recurrence: dz (B,T,4H), dh0, dc0
         // bias gradient: per-tile partials from the kernel (db_part lives in the split-K scratch), summed below
         float* db_part = db ? scratch : nullptr;
-        int rc = launch_bwd_cluster(R, reserve, c0, dhs, dhT, dcT, dz, dh0 ? dh0 : dh_rec, dc0 ? dc0 : dc, db_part, B, T, H,
-                                    act, ws, stream);
+        // H = 256: groups of eight workgroups fill the chip up to 32 tiles (the 4-group kernel leaves half of it idle
+        // at 512 sequences); bf16 operands exist in the 8-group kernel only
+        int rc = (bf16 || (bwd8_preferred(B, H) && !getenv("FOV_BWD_GROUPS4")))
+                     ? launch_bwd8(R, reserve, c0, dhs, dhT, dcT, dz, dh0 ? dh0 : dh_rec, dc0 ? dc0 : dc, db_part, B, T, act, bf16, ws, stream)
+                     : launch_bwd_cluster(R, reserve, c0, dhs, dhT, dcT, dz, dh0 ? dh0 : dh_rec, dc0 ? dc0 : dc, db_part, B, T, H,
+                                          act, ws, stream);
         if (rc) return rc;
         if (db) {
             const int tiles = (B + 15) / 16;
@@ -956,7 +962,8 @@ int lstm_seq_bwd(const float* x, const float* K, const float* R, const float* h0
         g.a = x; g.b = dz; g.c = dK; g.M = F; g.N = 4 * H; g.KO = 1; g.KI = (int)BT;
         g.a_sm = 1; g.a_ski = F; g.b_sn = 1; g.b_ski = 4 * H; g.ldc = 4 * H;
         rc = skinny_tn(x, F, F, dz, 4 * H, 4 * H, BT, dK, 4 * H, 1, accumulate, scratch, scratch_floats, stream);
-        if (rc == 0) rc = gemm_f32(g, accumulate, scratch, scratch_floats, stream);
+        if (rc == 0) rc = bf16 ? gemm_bf16_tn(x, F, 0, dz, 4 * H, 0, dK, 4 * H, F, 4 * H, 1, (int)BT, accumulate, scratch, scratch_floats, stream)
+                               : gemm_f32(g, accumulate, scratch, scratch_floats, stream);
         if (rc < 0) return rc;
     }
     if (dR) {   // dR (H,4H) = sum_b sum_{t>=1} hs[b][t-1]^T dz[b][t]  +  h0^T dz[:,0]
@@ -965,7 +972,9 @@ int lstm_seq_bwd(const float* x, const float* K, const float* R, const float* h0
         g.a_sm = 1; g.a_sko = (long)T * H; g.a_ski = H;
         g.b_sn = 1; g.b_sko = (long)T * 4 * H; g.b_ski = 4 * H; g.ldc = 4 * H;
         if (T > 1) {
-            rc = gemm_f32(g, accumulate, scratch, scratch_floats, stream);
+            rc = bf16 ? gemm_bf16_tn(hs, H, (long)T * H, dz + (size_t)4 * H, 4 * H, (long)T * 4 * H, dR, 4 * H, H, 4 * H, B, T - 1,
+                                     accumulate, scratch, scratch_floats, stream)
+                      : gemm_f32(g, accumulate, scratch, scratch_floats, stream);
             if (rc) return rc;
         } else if (!accumulate) {
             (void)hipMemsetAsync(dR, 0, sizeof(float) * (size_t)H * 4 * H, stream);
@@ -974,7 +983,8 @@ int lstm_seq_bwd(const float* x, const float* K, const float* R, const float* h0
             GemmArgs g0 = {};
             g0.a = h0; g0.b = dz; g0.c = dR; g0.M = H; g0.N = 4 * H; g0.KO = 1; g0.KI = B;
             g0.a_sm = 1; g0.a_ski = H; g0.b_sn = 1; g0.b_ski = (long)T * 4 * H; g0.ldc = 4 * H;
-            rc = gemm_f32(g0, 1, scratch, scratch_floats, stream);
+            rc = bf16 ? gemm_bf16_tn(h0, H, 0, dz, (long)T * 4 * H, 0, dR, 4 * H, H, 4 * H, 1, B, 1, scratch, scratch_floats, stream)
+                      : gemm_f32(g0, 1, scratch, scratch_floats, stream);
             if (rc) return rc;
         }
     }
@@ -986,7 +996,8 @@ int lstm_seq_bwd(const float* x, const float* K, const float* R, const float* h0
         GemmArgs g = {};
         g.a = dz; g.b = K; g.c = dx; g.M = (int)BT; g.N = F; g.KO = 1; g.KI = 4 * H;
         g.a_sm = 4 * H; g.a_ski = 1; g.b_sn = 4 * H; g.b_ski = 1; g.ldc = F;
-        rc = gemm_f32(g, 0, scratch, scratch_floats, stream);
+        rc = (bf16 && (((uintptr_t)K) & 15) == 0) ? gemm_bf16_nt(dz, 4 * H, K, 4 * H, dx, F, (int)BT, F, 4 * H, stream)
+                                                 : gemm_f32(g, 0, scratch, scratch_floats, stream);
         if (rc) return rc;
     }
     return FOV_OK;
@@ -994,8 +1005,14 @@ int lstm_seq_bwd(const float* x, const float* K, const float* R, const float* h0
 
 // Dense backward given dpre (N,Out): dW (In,Out) = x^T dpre, db = colsum(dpre), dx (N,In) = dpre W^T
 int dense_bwd(const float* x, const float* W, const float* dpre, float* dx, float* dW, float* db, int N, int In, int Out,
-              int accumulate, float* scratch, size_t scratch_floats, hipStream_t stream) {
+              int accumulate, float* scratch, size_t scratch_floats, hipStream_t stream, int bf16) {
     int rc;
+    if (dW && bf16 && Out >= 64 && (Out & 3) == 0 && (((uintptr_t)dpre) & 15) == 0) {
+        // dW (In,Out) = x^T dpre with bf16 operands (the unrolled decoder's K / R gradients: one product over all steps)
+        rc = gemm_bf16_tn(x, In, 0, dpre, Out, 0, dW, Out, In, Out, 1, N, accumulate, scratch, scratch_floats, stream);
+        if (rc) return rc;
+        dW = nullptr;
+    }
     if (dW) {
         GemmArgs g = {};
         g.a = x; g.b = dpre; g.c = dW; g.M = In; g.N = Out; g.KO = 1; g.KI = N;

@@ -742,7 +742,14 @@ class OthersMixingSeq2Seq(KerasModelSurface):
     fused_decoder = True   # H = 256: run the unrolled decoder as ONE launch (fov_mix_decoder_fwd); False = step-wise calls
 
     def __init__(self, num_encoder_tokens=None, num_decoder_tokens=6, latent_dim=32, num_user=34,
-                 recurrent_activation=None, seed=None, impl="auto", device="cuda"):
+                 recurrent_activation=None, seed=None, impl="auto", device="cuda", dtype="f32"):
+        """dtype 'bf16' (BASELINE configs[4], latent_dim = 256 only): gate GEMMs and the Dense head take bf16
+        operands on the matrix cores; accumulation, gates, cell state and the weights the optimizer updates stay fp32."""
+        if dtype not in ("f32", "bf16"):
+            raise ValueError("dtype must be 'f32' or 'bf16'")
+        if dtype == "bf16" and int(latent_dim) != 256:
+            raise ValueError("the bf16 path is built for latent_dim = 256")
+        self.dtype = dtype
         self.num_encoder_tokens = 3 * cfg.fps if num_encoder_tokens is None else int(num_encoder_tokens)
         self.num_decoder_tokens = int(num_decoder_tokens)
         self.latent_dim, self.num_user = int(latent_dim), int(num_user)
@@ -761,7 +768,7 @@ class OthersMixingSeq2Seq(KerasModelSurface):
     def _make_trainer(self, optimizer):
         from .training import OthersMixingTrainer
         return OthersMixingTrainer(self._w, act=self.recurrent_activation, impl=self.impl, optimizer=optimizer, lr=self._lr,
-                                   device=self.device)
+                                   device=self.device, dtype=self.dtype)
 
     def fit_generator(self, generator, steps_per_epoch, epochs=1, validation_data=None, validation_steps=None,
                       callbacks=None, use_multiprocessing=False, shuffle=True, initial_epoch=0, verbose=0):
@@ -826,6 +833,15 @@ class OthersMixingSeq2Seq(KerasModelSurface):
         H, O = self.latent_dim, self.num_decoder_tokens
         B, T_in = e.shape[0], e.shape[1]
         T_out = oth.shape[1]
+        if self.dtype == "bf16":   # configs[4]: both encoder layers and the fused decoder with bf16 matrix-core operands
+            hs1, h1, c1, _ = ops.lstm_seq_bf16(e, dw["enc1_K"], dw["enc1_R"], dw["enc1_b"], act=act, workspace=ws, reserve=False)
+            e3 = lambda *s_: torch.empty(s_, dtype=torch.float32, device=self.device)
+            _, h2, c2, _ = ops.lstm_seq_bf16(hs1, dw["enc2_K"], dw["enc2_R"], dw["enc2_b"], act=act, workspace=ws,
+                                             out=(None, e3(B, H), e3(B, H), None))
+            oth_proj = ops.dense(oth.reshape(B * T_out, -1), dw["mix_W_oth"], dw["mix_b"], activation=None).reshape(B, T_out, O)
+            out = torch.empty((T_out, B, O), dtype=torch.float32, device=self.device)
+            ops.mix_decoder(xin, h1, c1, h2, c2, oth_proj, dw, dw["mix_W_pred"], T_out, act=act, workspace=ws, out=out, dtype="bf16")
+            return out.transpose(0, 1)
         hs1, h1, c1 = ops.lstm_seq(e, dw["enc1_K"], dw["enc1_R"], dw["enc1_b"], act=act, impl=impl, workspace=ws)
         if H == 256 and impl != "generic":   # layer 2 over the 256-wide sequence: K2 and R2 register-resident
             _, h2, c2 = ops.lstm_seq(hs1, dw["enc2_K"], dw["enc2_R"], dw["enc2_b"], act=act, impl=impl,

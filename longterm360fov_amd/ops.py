@@ -195,9 +195,35 @@ def meanvar_xyz(y, fps=30):
 # ---------------------------------------------------------------------------------------------
 # training side (a6): forward with reserve, BPTT, Dense backward, MSE gradient, optimizers
 # ---------------------------------------------------------------------------------------------
-def lstm_seq_train(x, K, R, b, h0=None, c0=None, act="sigmoid", impl="auto", workspace=None, out=None):
+def bf16_layer_supported(F, H):
+    return H == 256 and 1 <= F <= 256
+
+
+def lstm_seq_bf16(x, K, R, b, h0=None, c0=None, act="sigmoid", workspace=None, out=None, reserve=True):
+    """LSTM layer with bf16 matrix-core operands (configs[4]; fp32 tensors in and out, H = 256, F <= 256).
+    `out` may carry preallocated (hs, hT, cT, reserve) tensors (None entries are not written).
+    -> (hs, hT, cT, reserve)."""
+    x, K, R, b = _dev(x, "x"), _dev(K, "K"), _dev(R, "R"), _dev(b, "b")
+    h0, c0 = _dev(h0, "h0"), _dev(c0, "c0")
+    B, T, F = x.shape
+    H = R.shape[0]
+    if out is None:
+        e = lambda *s: torch.empty(s, dtype=torch.float32, device=x.device)
+        out = (e(B, T, H), e(B, H), e(B, H), e(B, T, 5, H) if reserve else None)
+    hs, hT, cT, res = out
+    L = _lib.lib()
+    ws = (workspace or default_workspace(x.device))
+    buf = ws.get(L.fov_lstm_seq_workspace_bytes(B, T, 128, 256, IMPL_CLUSTER), x.device)
+    check(L.fov_lstm_seq_fwd_bf16(_ptr(x), _ptr(K), _ptr(R), _ptr(b), _ptr(h0), _ptr(c0), _ptr(hs), _ptr(hT), _ptr(cT),
+                                  _ptr(res), B, T, F, H, act_code(act), buf.data_ptr(), buf.numel(), _stream()))
+    return hs, hT, cT, res
+
+
+def lstm_seq_train(x, K, R, b, h0=None, c0=None, act="sigmoid", impl="auto", workspace=None, out=None, dtype="f32"):
     """Forward that also returns the reserve (B,T,5,H).  `out` may carry preallocated
-    (hs, hT, cT, reserve) tensors.  -> (hs, hT, cT, reserve)."""
+    (hs, hT, cT, reserve) tensors.  -> (hs, hT, cT, reserve).  dtype 'bf16': bf16 matrix-core operands."""
+    if dtype == "bf16":
+        return lstm_seq_bf16(x, K, R, b, h0, c0, act=act, workspace=workspace, out=out)
     x, K, R, b = _dev(x, "x"), _dev(K, "K"), _dev(R, "R"), _dev(b, "b")
     h0, c0 = _dev(h0, "h0"), _dev(c0, "c0")
     B, T, F = x.shape
@@ -239,7 +265,7 @@ _default_scratch = Scratch()
 
 def lstm_seq_bwd(x, K, R, hs, reserve, h0=None, c0=None, dhs=None, dhT=None, dcT=None, dK=None, dR=None, db=None,
                  need_dx=False, need_state_grads=False, act="sigmoid", accumulate=False, dz=None, scratch=None,
-                 need_weight_grads=True):
+                 need_weight_grads=True, dtype="f32"):
     """BPTT of one layer -> dict(dz, dx, dK, dR, db, dh0, dc0).  need_weight_grads=False computes the data path
     only (dz, dx, state gradients): a caller that walks a decoder step by step stacks dz and forms the
     weight gradients once, over all steps."""
@@ -259,10 +285,11 @@ def lstm_seq_bwd(x, K, R, hs, reserve, h0=None, c0=None, dhs=None, dhT=None, dcT
     dc0 = e(B, H) if need_state_grads else None
     L = _lib.lib()
     buf = (scratch or _default_scratch).get(L.fov_lstm_seq_bwd_workspace_bytes(B, T, F, H), x.device)
-    check(L.fov_lstm_seq_bwd(_ptr(x), _ptr(K), _ptr(R), _ptr(_dev(h0, "h0")), _ptr(_dev(c0, "c0")), _ptr(hs),
-                             _ptr(reserve), _ptr(_dev(dhs, "dhs")), _ptr(_dev(dhT, "dhT")), _ptr(_dev(dcT, "dcT")),
-                             _ptr(dz), _ptr(dx), _ptr(dK), _ptr(dR), _ptr(db), _ptr(dh0), _ptr(dc0),
-                             B, T, F, H, act_code(act), 1 if accumulate else 0, buf.data_ptr(), buf.numel(), _stream()))
+    bwd = L.fov_lstm_seq_bwd_bf16 if dtype == "bf16" else L.fov_lstm_seq_bwd
+    check(bwd(_ptr(x), _ptr(K), _ptr(R), _ptr(_dev(h0, "h0")), _ptr(_dev(c0, "c0")), _ptr(hs),
+              _ptr(reserve), _ptr(_dev(dhs, "dhs")), _ptr(_dev(dhT, "dhT")), _ptr(_dev(dcT, "dcT")),
+              _ptr(dz), _ptr(dx), _ptr(dK), _ptr(dR), _ptr(db), _ptr(dh0), _ptr(dc0),
+              B, T, F, H, act_code(act), 1 if accumulate else 0, buf.data_ptr(), buf.numel(), _stream()))
     return {"dz": dz, "dx": dx, "dK": dK, "dR": dR, "db": db, "dh0": dh0, "dc0": dc0}
 
 
@@ -362,7 +389,8 @@ def rmsprop_tf_step(params, grads, ms, lr, decay=0.9, eps=1e-10, clip_value=0.0)
                                          _stream()))
 
 
-def dense_bwd(x, W, dpre, dW=None, db=None, need_dx=True, accumulate=False, scratch=None, need_dW=True, need_db=True):
+def dense_bwd(x, W, dpre, dW=None, db=None, need_dx=True, accumulate=False, scratch=None, need_dW=True, need_db=True,
+              dtype="f32"):
     x, W, dpre = _dev(x, "x"), _dev(W, "W"), _dev(dpre, "dpre")
     In, Out = W.shape
     x2, d2 = x.reshape(-1, In), dpre.reshape(-1, Out)
@@ -373,8 +401,9 @@ def dense_bwd(x, W, dpre, dW=None, db=None, need_dx=True, accumulate=False, scra
     dx = e(N, In) if need_dx else None
     L = _lib.lib()
     buf = (scratch or _default_scratch).get(L.fov_dense_bwd_workspace_bytes(N, In, Out), x.device)
-    check(L.fov_dense_bwd(_ptr(x2), _ptr(W), _ptr(d2), _ptr(dx), _ptr(dW), _ptr(db), N, In, Out,
-                          1 if accumulate else 0, buf.data_ptr(), buf.numel(), _stream()))
+    fn = L.fov_dense_bwd_bf16 if dtype == "bf16" else L.fov_dense_bwd
+    check(fn(_ptr(x2), _ptr(W), _ptr(d2), _ptr(dx), _ptr(dW), _ptr(db), N, In, Out,
+             1 if accumulate else 0, buf.data_ptr(), buf.numel(), _stream()))
     return (dx.reshape(*x.shape[:-1], In) if need_dx else None), dW, db
 
 
@@ -461,7 +490,7 @@ def mix_decoder_supported(H, O):
 
 
 def mix_decoder(dec0, h1, c1, h2, c2, oth_proj, w, mix_Wp, T_out, act="sigmoid", workspace=None, out=None, train=None,
-                final_state=None):
+                final_state=None, dtype="f32"):
     """The whole unrolled others-mixing decoder in one launch -> out (T_out,B,O) step-major.
     w: dict with dec1_K/R/b, dec2_K/R/b, dense_W/b; oth_proj (B,T_out,O) view (last dim contiguous);
     train: optional dict of preallocated P, H1, C1, H2, C2 (T_out,B,.), res1, res2 (T_out,B,5,H);
@@ -476,17 +505,18 @@ def mix_decoder(dec0, h1, c1, h2, c2, oth_proj, w, mix_Wp, T_out, act="sigmoid",
     buf = ws.get(L.fov_mix_decoder_workspace_bytes(B, H), h1.device)
     tr = [None] * 7 if train is None else [_dev(train[k], k) for k in ("P", "H1", "C1", "H2", "C2", "res1", "res2")]
     fs = [None] * 4 if final_state is None else [_dev(t, "final state") for t in final_state]
-    check(L.fov_mix_decoder_fwd(_ptr(dec0.reshape(B, O)), _ptr(h1), _ptr(c1), _ptr(h2), _ptr(c2), oth_proj.data_ptr(),
-                                oth_proj.stride(0), oth_proj.stride(1),
-                                _ptr(_dev(w["dec1_K"], "K1")), _ptr(_dev(w["dec1_R"], "R1")), _ptr(_dev(w["dec1_b"], "b1")),
-                                _ptr(_dev(w["dec2_K"], "K2")), _ptr(_dev(w["dec2_R"], "R2")), _ptr(_dev(w["dec2_b"], "b2")),
-                                _ptr(_dev(w["dense_W"], "Wd")), _ptr(_dev(w["dense_b"], "bd")), _ptr(_dev(mix_Wp, "Wp")),
-                                _ptr(out), *[_ptr(t) for t in fs], *[_ptr(t) for t in tr],
-                                B, T_out, H, O, act_code(act), buf.data_ptr(), buf.numel(), _stream()))
+    fwd = L.fov_mix_decoder_fwd_bf16 if dtype == "bf16" else L.fov_mix_decoder_fwd
+    check(fwd(_ptr(dec0.reshape(B, O)), _ptr(h1), _ptr(c1), _ptr(h2), _ptr(c2), oth_proj.data_ptr(),
+              oth_proj.stride(0), oth_proj.stride(1),
+              _ptr(_dev(w["dec1_K"], "K1")), _ptr(_dev(w["dec1_R"], "R1")), _ptr(_dev(w["dec1_b"], "b1")),
+              _ptr(_dev(w["dec2_K"], "K2")), _ptr(_dev(w["dec2_R"], "R2")), _ptr(_dev(w["dec2_b"], "b2")),
+              _ptr(_dev(w["dense_W"], "Wd")), _ptr(_dev(w["dense_b"], "bd")), _ptr(_dev(mix_Wp, "Wp")),
+              _ptr(out), *[_ptr(t) for t in fs], *[_ptr(t) for t in tr],
+              B, T_out, H, O, act_code(act), buf.data_ptr(), buf.numel(), _stream()))
     return out
 
 
-def mix_decoder_bwd(M, P, dloss, res1, res2, C1, C2, w, mix_Wp, out, act="sigmoid", workspace=None):
+def mix_decoder_bwd(M, P, dloss, res1, res2, C1, C2, w, mix_Wp, out, act="sigmoid", workspace=None, dtype="f32"):
     """BPTT through the unrolled decoder in one launch.  M, P, dloss (T_out,B,O); res1, res2 (T_out,B,5,H); C1, C2
     (>= T_out rows of (B,H), row t = cell state before step t); out: dict with preallocated DZ1, DZ2 (T_out,B,4H),
     dpre_m, dpre_p (T_out,B,O), dh1_0, dc1_0, dh2_0, dc2_0 (B,H)."""
@@ -497,13 +527,14 @@ def mix_decoder_bwd(M, P, dloss, res1, res2, C1, C2, w, mix_Wp, out, act="sigmoi
     ws = workspace or Workspace()
     buf = ws.get(L.fov_mix_decoder_bwd_workspace_bytes(B, H), M.device)
     names = ("DZ1", "DZ2", "dpre_m", "dpre_p", "dh1_0", "dc1_0", "dh2_0", "dc2_0")
-    check(L.fov_mix_decoder_bwd(_ptr(M), _ptr(P), _ptr(dloss), _ptr(_dev(res1, "res1")), _ptr(_dev(res2, "res2")),
-                                _ptr(_dev(C1, "C1")), _ptr(_dev(C2, "C2")),
-                                _ptr(_dev(w["dec1_K"], "K1")), _ptr(_dev(w["dec1_R"], "R1")),
-                                _ptr(_dev(w["dec2_K"], "K2")), _ptr(_dev(w["dec2_R"], "R2")),
-                                _ptr(_dev(w["dense_W"], "Wd")), _ptr(_dev(mix_Wp, "Wp")),
-                                *[_ptr(_dev(out[k], k)) for k in names],
-                                B, T_out, H, O, act_code(act), buf.data_ptr(), buf.numel(), _stream()))
+    bwd = L.fov_mix_decoder_bwd_bf16 if dtype == "bf16" else L.fov_mix_decoder_bwd
+    check(bwd(_ptr(M), _ptr(P), _ptr(dloss), _ptr(_dev(res1, "res1")), _ptr(_dev(res2, "res2")),
+              _ptr(_dev(C1, "C1")), _ptr(_dev(C2, "C2")),
+              _ptr(_dev(w["dec1_K"], "K1")), _ptr(_dev(w["dec1_R"], "R1")),
+              _ptr(_dev(w["dec2_K"], "K2")), _ptr(_dev(w["dec2_R"], "R2")),
+              _ptr(_dev(w["dense_W"], "Wd")), _ptr(_dev(mix_Wp, "Wp")),
+              *[_ptr(_dev(out[k], k)) for k in names],
+              B, T_out, H, O, act_code(act), buf.data_ptr(), buf.numel(), _stream()))
     return out
 
 

@@ -581,9 +581,15 @@ class OthersMixingTrainer(FlatParamTrainer):
     fused_decoder = True       # H = 256: forward of the unrolled decoder as ONE launch; False = step-wise calls
     fused_decoder_bwd = True   # H = 256: BPTT through the unrolled decoder as ONE launch; False = step-wise calls
 
-    def __init__(self, weights, act="sigmoid", impl="auto", optimizer="adam", lr=1e-3, device="cuda"):
-        self.act, self.impl = act, impl
+    def __init__(self, weights, act="sigmoid", impl="auto", optimizer="adam", lr=1e-3, device="cuda", dtype="f32"):
+        """dtype 'bf16' (BASELINE configs[4], H = 256): forward and backward matrix products take bf16 operands on the
+        matrix cores with fp32 accumulation; gates, cell state, tapes, gradients' accumulation, the flat parameter
+        buffer and the optimizer stay fp32 (fp32 master weights)."""
+        assert dtype in ("f32", "bf16")
+        self.act, self.impl, self.dtype = act, impl, dtype
         self._alloc(weights, _MIX_ORDER, optimizer, lr, device)
+        if dtype == "bf16":
+            assert self.w["enc1_R"].shape[0] == 256, "the bf16 path is built for H = 256"
         self.ws_bwd = ops.Workspace()   # granule mailboxes of the fused decoder backward
 
     def forward_backward(self, enc, others, dec0, target, grad_weight=1.0):
@@ -602,11 +608,12 @@ class OthersMixingTrainer(FlatParamTrainer):
         # row t+1 = state after decoder step t
         H1, C1 = e(T_out + 1, B, H), e(T_out + 1, B, H)
         H2, C2 = e(T_out + 1, B, H), e(T_out + 1, B, H)
+        dt = self.dtype
         hs1, h1, c1, res1 = ops.lstm_seq_train(enc, w["enc1_K"], w["enc1_R"], w["enc1_b"], act=act, impl=impl, workspace=ws,
-                                               out=(e(B, T_in, H), H1[0], C1[0], e(B, T_in, 5, H)))
+                                               out=(e(B, T_in, H), H1[0], C1[0], e(B, T_in, 5, H)), dtype=dt)
         if H == 256 and impl != "generic":   # layer 2 over the 256-wide sequence: K2 and R2 register-resident
             hs2, h2, c2, res2 = ops.lstm_seq_train(hs1, w["enc2_K"], w["enc2_R"], w["enc2_b"], act=act, impl=impl, workspace=ws,
-                                                   out=(e(B, T_in, H), H2[0], C2[0], e(B, T_in, 5, H)))
+                                                   out=(e(B, T_in, H), H2[0], C2[0], e(B, T_in, 5, H)), dtype=dt)
         else:
             zx2 = ops.matmul(hs1.reshape(B * T_in, H), w["enc2_K"], scratch=sc).reshape(B, T_in, 4 * H)
             res2 = torch.empty((B, T_in, 5, H), dtype=torch.float32, device=self.device)
@@ -626,7 +633,7 @@ class OthersMixingTrainer(FlatParamTrainer):
         if fused:   # the whole unrolled forward in one persistent launch, writing the same tape
             ops.mix_decoder(X[0], H1[0], C1[0], H2[0], C2[0], oth_proj, w, Wm_p_c, T_out, act=act, workspace=ws, out=M,
                             train={"P": P, "H1": H1[1:], "C1": C1[1:], "H2": H2[1:], "C2": C2[1:],
-                                   "res1": R1.view(T_out, B, 5, H), "res2": R2.view(T_out, B, 5, H)})
+                                   "res1": R1.view(T_out, B, 5, H), "res2": R2.view(T_out, B, 5, H)}, dtype=dt)
         for t in range(0 if fused else T_out):
             # every kernel writes straight into its row of the tape: no copies inside the loop
             ops.lstm_seq_train(X[t].view(B, 1, O), w["dec1_K"], w["dec1_R"], w["dec1_b"], H1[t], C1[t], act=act, impl=impl,
@@ -651,7 +658,7 @@ class OthersMixingTrainer(FlatParamTrainer):
             dh1_rec, dc1, dh2_rec, dc2 = e(B, H), e(B, H), e(B, H), e(B, H)
             ops.mix_decoder_bwd(M, P, dloss_tm, R1.view(T_out, B, 5, H), R2.view(T_out, B, 5, H), C1, C2, w, Wm_p_c,
                                 {"DZ1": DZ1, "DZ2": DZ2, "dpre_m": dpre_all, "dpre_p": dpre_p_all, "dh1_0": dh1_rec,
-                                 "dc1_0": dc1, "dh2_0": dh2_rec, "dc2_0": dc2}, act=act, workspace=self.ws_bwd)
+                                 "dc1_0": dc1, "dh2_0": dh2_rec, "dc2_0": dc2}, act=act, workspace=self.ws_bwd, dtype=dt)
         for t in range(-1 if fused_bwd else T_out - 1, -1, -1):
             # mixing head of step t in one launch: the feedback gradient (x_{t+1} = m_t) joins through tanh',
             # then the two tiny Dense layers backwards; weight gradients are formed after the loop
@@ -675,13 +682,13 @@ class OthersMixingTrainer(FlatParamTrainer):
         ops.dense_bwd(fl(H2[1:], H), w["dense_W"], fl(dpre_p_all, O), dW=g["dense_W"], db=g["dense_b"], need_dx=False,
                       accumulate=acc, scratch=sc)
         ops.dense_bwd(fl(H1[1:], H), w["dec2_K"], fl(DZ2, 4 * H), dW=g["dec2_K"], db=g["dec2_b"], need_dx=False,
-                      accumulate=acc, scratch=sc)
+                      accumulate=acc, scratch=sc, dtype=dt)
         ops.dense_bwd(fl(H2[:T_out], H), w["dec2_R"], fl(DZ2, 4 * H), dW=g["dec2_R"], need_db=False, need_dx=False,
-                      accumulate=acc, scratch=sc)
+                      accumulate=acc, scratch=sc, dtype=dt)
         ops.dense_bwd(fl(X, O), w["dec1_K"], fl(DZ1, 4 * H), dW=g["dec1_K"], db=g["dec1_b"], need_dx=False,
                       accumulate=acc, scratch=sc)
         ops.dense_bwd(fl(H1[:T_out], H), w["dec1_R"], fl(DZ1, 4 * H), dW=g["dec1_R"], need_db=False, need_dx=False,
-                      accumulate=acc, scratch=sc)
+                      accumulate=acc, scratch=sc, dtype=dt)
         # "others" half of the mixing kernel: one product over all steps, rows ordered (t, b) like dpre_all
         oth_tb = others.transpose(0, 1).contiguous().reshape(T_out * B, n_oth)
         ops.dense_bwd(oth_tb, Wm_o_c, dpre_all.reshape(T_out * B, O), dW=gWm_o, need_db=False, need_dx=False,
@@ -689,9 +696,9 @@ class OthersMixingTrainer(FlatParamTrainer):
         self.grads_final("dec1_K")    # decoder, heads and loss: all-reduced under the encoder's BPTT
         # encoder: layer 2 over hs1 (its dx is the dhs of layer 1), then layer 1
         e2 = ops.lstm_seq_bwd(hs1, w["enc2_K"], w["enc2_R"], hs2, res2, dhT=dh2_rec, dcT=dc2, dK=g["enc2_K"], dR=g["enc2_R"],
-                              db=g["enc2_b"], need_dx=True, act=act, accumulate=acc, scratch=bsc)
+                              db=g["enc2_b"], need_dx=True, act=act, accumulate=acc, scratch=bsc, dtype=dt)
         ops.lstm_seq_bwd(enc, w["enc1_K"], w["enc1_R"], hs1, res1, dhs=e2["dx"], dhT=dh1_rec, dcT=dc1, dK=g["enc1_K"],
-                         dR=g["enc1_R"], db=g["enc1_b"], act=act, accumulate=acc, scratch=bsc)
+                         dR=g["enc1_R"], db=g["enc1_b"], act=act, accumulate=acc, scratch=bsc, dtype=dt)
         return loss, out
 
 

@@ -63,10 +63,45 @@ def _rec_act(act):
 # --------------------------------------------------------------------------------------
 # a1/a2: Keras LSTM layer  (mycode/FoV_seq2seq.py:83-86, 93-95)
 # --------------------------------------------------------------------------------------
+# configs[4] (bf16): the HIP path feeds bf16 operands (round-to-nearest-even of the fp32 value) into the matrix cores
+# and accumulates in fp32; cell state, gates and everything elementwise stay fp32.  `bf16_operands()` makes the
+# matrix products of the LSTM steps and of the Dense(6) head below round BOTH operands the same way, so the
+# restatement can be compared with the bf16 kernels far more tightly than the full-precision one.
+OPERAND_ROUND = None
+
+
+def round_bf16(a):
+    """Round-to-nearest-even to bfloat16, returned in the input's dtype (what v_cvt_pk_bf16_f32 does to an fp32)."""
+    a32 = np.ascontiguousarray(a, dtype=np.float32)
+    u = a32.view(np.uint32).astype(np.uint64)
+    r = ((u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000).astype(np.uint32)
+    return r.view(np.float32).reshape(a32.shape).astype(np.asarray(a).dtype)
+
+
+class bf16_operands:
+    """with bf16_operands(): ... -> matrix products of lstm_step / the Dense head see bf16-rounded operands."""
+
+    def __enter__(self):
+        global OPERAND_ROUND
+        self._prev, OPERAND_ROUND = OPERAND_ROUND, round_bf16
+        return self
+
+    def __exit__(self, *exc):
+        global OPERAND_ROUND
+        OPERAND_ROUND = self._prev
+        return False
+
+
+def _mm(a, w):
+    if OPERAND_ROUND is not None:
+        a, w = OPERAND_ROUND(a), OPERAND_ROUND(w)
+    return a @ w
+
+
 def lstm_step(x, h, c, K, R, b, act="sigmoid"):
     """One LSTMCell step.  x:(B,F) h,c:(B,H) -> (h', c')."""
     H = h.shape[1]
-    z = x @ K + b + h @ R
+    z = _mm(x, K) + b + _mm(h, R)
     s = _rec_act(act)
     i = s(z[:, 0 * H:1 * H])
     f = s(z[:, 1 * H:2 * H])
@@ -92,8 +127,9 @@ def lstm_layer(x, K, R, b, h0=None, c0=None, act="sigmoid"):
 
 
 # a3: Dense(num_decoder_tokens, activation='tanh')  (mycode/FoV_seq2seq.py:96-97)
-def dense(x, W, b, activation="tanh"):
-    y = x @ W + b
+def dense(x, W, b, activation="tanh", matrix_core=False):
+    """matrix_core: this product runs on the matrix cores in the bf16 path (operands rounded under bf16_operands())."""
+    y = (_mm(x, W) if matrix_core else x @ W) + b
     if activation == "tanh":
         y = np.tanh(y)
     return y.astype(x.dtype)
@@ -214,7 +250,7 @@ def others_mixing_forward(enc_in, others, dec_in0, w, act="sigmoid"):
     for t in range(T_out):
         h1, c1 = lstm_step(x, h1, c1, w["dec1_K"], w["dec1_R"], w["dec1_b"], act)
         h2, c2 = lstm_step(h1, h2, c2, w["dec2_K"], w["dec2_R"], w["dec2_b"], act)
-        p = dense(h2, w["dense_W"], w["dense_b"])                      # (B,6)
+        p = dense(h2, w["dense_W"], w["dense_b"], matrix_core=True)    # (B,6)
         cat = np.concatenate([others[:, t].astype(x.dtype), p[:, None, :]], axis=1)  # (B,U,6)
         x = dense(cat.reshape(B, -1), w["mix_W"], w["mix_b"])           # (B,6)
         out.append(x)
