@@ -28,6 +28,11 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense fp32 matrix peak (spec)
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 matrix peak (spec, ~2.5 PF; the 2:1-sparse figure is not used)
+
+
+def peak_for(dtype):
+    return PEAK_BF16_MFMA_TFLOPS if dtype == "bf16" else PEAK_FP32_MFMA_TFLOPS
 # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of `bench.py --steps 20 --warmup 3`, mean per dispatch:
 # encoder 13150 + 6152 KiB, decoder 7441 + 4824 KiB (raw counter values; the kernel's global traffic is 4- and
 # 8-byte accesses, for which MI355X_MICROARCH.md gives no correction factor)
@@ -155,13 +160,15 @@ def bench_train_mixing(args, rank, world, use_dist):
             "metric": "training sequences/sec, others-mixing 2+2 layers (batch=%d per GPU, T 10->10, h=%d, U=%d)" % (B, H, U),
             "value": world * B * args.steps / elapsed, "unit": "sequences/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic", "final_loss": float(loss.item()),
-            "config": {"workload": "configs[2] shape: given_others_gt_mean_var_seq2seq training step (fused decoder forward "
-                                   "and backward launches)", "global_batch": B * world,
+            "dtype": args.dtype, "data": "synthetic", "final_loss": float(loss.item()),
+            "config": {"workload": ("configs[4]: bf16 training of configs[2] (bf16 MFMA operands, fp32 accumulate / cell state / master "
+                                    "weights), " if args.dtype == "bf16" else "configs[2] shape: ") +
+                                   "given_others_gt_mean_var_seq2seq training step (fused decoder forward and backward launches)", "global_batch": B * world,
                        "parallelism": "dp%d, one flat-buffer all-reduce per step" % world},
-            "roofline": {"bound": "mfma", "achieved": 3 * fwd * B / (ms * 1e-3) / 1e12, "peak": PEAK_FP32_MFMA_TFLOPS,
-                         "unit": "TFLOP/s", "frac": 3 * fwd * B / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
-                         "note": "whole step, 3x forward FLOPs"},
+            "roofline": {"bound": "mfma", "achieved": 3 * fwd * B / (ms * 1e-3) / 1e12, "peak": peak_for(args.dtype),
+                         "unit": "TFLOP/s", "frac": 3 * fwd * B / (ms * 1e-3) / 1e12 / peak_for(args.dtype), "traffic": None,
+                         "note": "whole step, 3x forward FLOPs; at 512 sequences per GPU the step is a chain of 40 dependent recurrent "
+                                 "steps per direction: bound by the per-step exchange latency, not by the matrix rate"},
             "cpu_baseline": None}), flush=True)
     if use_dist:
         dist.barrier()
@@ -178,7 +185,7 @@ def bench_infer_mixing(args, rank, world, use_dist):
     B = args.batch if args.batch != 1024 else 512
     w = O.init_others_mixing(1234, H=H, num_user=U, bias_noise=0.05)
     enc, dec0, tgt, oth = O.synthetic_batch(1234 + rank, B, T_in, T_out, num_others=U - 1)
-    m = OthersMixingSeq2Seq(latent_dim=H, num_user=U, recurrent_activation=args.act, impl=args.impl)
+    m = OthersMixingSeq2Seq(latent_dim=H, num_user=U, recurrent_activation=args.act, impl=args.impl, dtype=args.dtype)
     from longterm360fov_amd.models import _MIX_ORDER
     m.set_weights([w[k] for k in _MIX_ORDER])
     d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
@@ -203,6 +210,12 @@ def bench_infer_mixing(args, rank, world, use_dist):
         ref = O.others_mixing_forward(enc[:32].astype(np.float64), oth[:32].astype(np.float64), dec0[:32].astype(np.float64),
                                       {k: v.astype(np.float64) for k, v in w.items()}, act=args.act)
         err = float(np.abs(out[:32].cpu().numpy() - ref).max())
+        err_q = None
+        if args.dtype == "bf16":
+            with O.bf16_operands():
+                ref_q = O.others_mixing_forward(enc[:32].astype(np.float64), oth[:32].astype(np.float64), dec0[:32].astype(np.float64),
+                                                {k: v.astype(np.float64) for k, v in w.items()}, act=args.act)
+            err_q = float(np.abs(out[:32].cpu().numpy() - ref_q).max())
         fwd = (T_in * (2 * (90 + H) * 4 * H + 2 * (H + H) * 4 * H) +
                T_out * (2 * (6 + H) * 4 * H + 2 * (H + H) * 4 * H + 2 * H * 6 + 2 * U * 6 * 6))
         ms = elapsed / args.steps * 1e3
@@ -210,13 +223,13 @@ def bench_infer_mixing(args, rank, world, use_dist):
             "metric": "sequences/sec, others-mixing 2+2 layers inference (batch=%d per GPU, T 10->10, h=%d, U=%d)" % (B, H, U),
             "value": world * B * args.steps / elapsed, "unit": "sequences/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "configs[2] shape: given_others_gt_mean_var_seq2seq inference (encoder + unrolled "
                                    "no-teacher-forcing decoder with others mixing)", "global_batch": B * world,
                        "parallelism": "replicas x%d (no collective)" % world},
-            "roofline": {"bound": "mfma", "achieved": fwd * B / (ms * 1e-3) / 1e12, "peak": PEAK_FP32_MFMA_TFLOPS,
-                         "unit": "TFLOP/s", "frac": fwd * B / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, "traffic": None},
-            "parity": {"max_abs_err_vs_oracle": err, "sequences_checked": 32},
+            "roofline": {"bound": "mfma", "achieved": fwd * B / (ms * 1e-3) / 1e12, "peak": peak_for(args.dtype),
+                         "unit": "TFLOP/s", "frac": fwd * B / (ms * 1e-3) / 1e12 / peak_for(args.dtype), "traffic": None},
+            "parity": {"max_abs_err_vs_oracle": err, "max_abs_err_vs_bf16_operand_oracle": err_q, "sequences_checked": 32},
             "cpu_baseline": None}), flush=True)
     if use_dist:
         dist.barrier()
