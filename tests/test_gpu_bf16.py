@@ -7,8 +7,9 @@ Two references, both from oracle/fov_oracle.py in fp64:
     absolute on values in (-1, 1); measured ~1e-4: what is left are accumulation order, the fast exp/rcp and the rare
     flip of an h value that sits on a bf16 rounding boundary);
   * the full-precision restatement: north_star's 1e-3 relative bound cannot hold for bf16 operands (8 mantissa bits,
-    20 recurrent steps).  The bound stated and asserted here is 5e-2 absolute on the tanh-range outputs; the measured
-    maximum is printed (about 1e-2).
+    20 recurrent steps) in general.  The bound stated and asserted here is 5e-3 absolute on the tanh-range outputs (hidden
+    states and model outputs in (-1, 1)); the measured maxima are printed: 1.7e-3 on the hidden states of a single layer,
+    3e-4 on the outputs of the whole configs[4] model at full size.
 """
 import numpy as np
 import pytest
@@ -19,7 +20,7 @@ from oracle import fov_oracle as O
 pytestmark = pytest.mark.gpu
 
 TIGHT = 1e-3     # vs the bf16-operand restatement
-LOOSE = 5e-2     # vs the full-precision restatement
+LOOSE = 5e-3     # vs the full-precision restatement
 
 
 def dev(a):
@@ -122,3 +123,118 @@ def test_bf16_config5_full_size_and_properties():
     np.testing.assert_array_equal(got, m.predict([enc, oth, dec0]))
     perm = np.random.default_rng(3).permutation(B)
     np.testing.assert_array_equal(got[perm], m.predict([enc[perm], oth[perm], dec0[perm]]))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# backward pass / training (configs[4])
+# ---------------------------------------------------------------------------------------------------------------
+def rb(a):
+    return O.round_bf16(np.asarray(a, dtype=np.float64))
+
+
+@pytest.mark.parametrize("N,In,Out", [(5120, 256, 1024), (1000, 90, 1024), (333, 256, 128), (40, 7, 64)])
+def test_bf16_weight_gradient_product(N, In, Out):
+    """dW = x^T dpre on the bf16 TN GEMM (hardware transpose reads, split over the rows): first EXACT on small-integer
+    data (every product and partial sum is representable: any wrong lane / k mapping shows up as an integer error),
+    then against the bf16-operand product in fp64 on real-valued data."""
+    from longterm360fov_amd import ops
+    rng = np.random.default_rng(N + In)
+    xi = rng.integers(-4, 5, (N, In)).astype(np.float32)
+    di = rng.integers(-4, 5, (N, Out)).astype(np.float32)
+    W = np.zeros((In, Out), np.float32)
+    _, dW, _ = ops.dense_bwd(dev(xi), dev(W), dev(di), need_dx=False, need_db=False, dtype="bf16")
+    np.testing.assert_array_equal(dW.cpu().numpy(), xi.astype(np.float64).T @ di.astype(np.float64))
+    x = rng.standard_normal((N, In)).astype(np.float32)
+    d = (0.1 * rng.standard_normal((N, Out))).astype(np.float32)
+    _, dW, db = ops.dense_bwd(dev(x), dev(W), dev(d), need_dx=False, dtype="bf16")
+    ref = rb(x).T @ rb(d)
+    err = np.abs(dW.cpu().numpy() - ref).max()
+    print("bf16 dW N=%d In=%d Out=%d: max err %.2e of max %.2e" % (N, In, Out, err, np.abs(ref).max()))
+    assert err <= 1e-5 * np.abs(ref).max() + 1e-6
+    np.testing.assert_allclose(db.cpu().numpy(), d.astype(np.float64).sum(0), atol=1e-4)
+    # accumulate form
+    base = rng.standard_normal((In, Out)).astype(np.float32)
+    acc = dev(base)
+    ops.dense_bwd(dev(x), dev(W), dev(d), dW=acc, need_dx=False, need_db=False, accumulate=True, dtype="bf16")
+    assert np.abs(acc.cpu().numpy() - (base + ref)).max() <= 1e-5 * np.abs(ref).max() + 1e-5
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("B,T,F,act,state", [(100, 5, 256, "sigmoid", True), (37, 1, 90, "hard_sigmoid", False),
+                                             (16 * 32, 4, 256, "sigmoid", False), (16 * 40 + 3, 2, 128, "sigmoid", True)])
+def test_eight_group_bptt_layer(dtype, B, T, F, act, state):
+    """lstm_seq_bwd at H = 256 on the eight-workgroup BPTT kernel (fp32: chosen for <= 512 sequences; bf16: always)
+    against the fp64 oracle: every output (dz, dx, dK, dR, db, dh0, dc0).  fp32: 1e-4 of the tensor's scale; bf16: the
+    recurrence and the products round their operands to 8 mantissa bits - bound 2e-2 of the tensor's scale (the
+    measured errors are printed)."""
+    from longterm360fov_amd import ops
+    rng = np.random.default_rng(B + T)
+    H = 256
+    K, R, b = O.init_lstm(rng, F, H, np.float32)
+    b = (b + 0.1 * rng.standard_normal(b.shape)).astype(np.float32)
+    x = rng.uniform(-1, 1, (B, T, F)).astype(np.float32)
+    h0 = (0.3 * rng.standard_normal((B, H))).astype(np.float32) if state else None
+    c0 = (0.3 * rng.standard_normal((B, H))).astype(np.float32) if state else None
+    dhs = (0.1 * rng.standard_normal((B, T, H))).astype(np.float32)
+    dhT = (0.1 * rng.standard_normal((B, H))).astype(np.float32)
+    dcT = (0.1 * rng.standard_normal((B, H))).astype(np.float32)
+    d64 = lambda a: None if a is None else a.astype(np.float64)
+    hs64, _, _, res64 = O.lstm_layer_train(d64(x), d64(K), d64(R), d64(b), d64(h0), d64(c0), act=act)
+    ref = O.lstm_layer_backward(d64(x), d64(K), d64(R), d64(h0), d64(c0), hs64, res64, d64(dhs), d64(dhT), d64(dcT), act=act)
+    # the HIP backward consumes an fp32 tape: give both dtypes the SAME (fp32-forward) tape so that only the backward differs
+    hs, hT, cT, res = ops.lstm_seq_train(dev(x), dev(K), dev(R), dev(b), None if h0 is None else dev(h0),
+                                         None if c0 is None else dev(c0), act=act)
+    sc = ops.Scratch()
+    got = ops.lstm_seq_bwd(dev(x), dev(K), dev(R), hs, res, h0=None if h0 is None else dev(h0), c0=None if c0 is None else dev(c0),
+                           dhs=dev(dhs), dhT=dev(dhT), dcT=dev(dcT), need_dx=(F % 4 == 0), need_state_grads=True, act=act,
+                           scratch=sc, dtype=dtype)
+    sc.check()
+    tol = 1e-4 if dtype == "f32" else 2e-2
+    for k in ("dz", "dx", "dK", "dR", "db", "dh0", "dc0"):
+        if got[k] is None:
+            continue
+        a, r = got[k].cpu().numpy().astype(np.float64), ref[k]
+        scale = np.abs(r).max()
+        print("%s 8-group BPTT B=%d T=%d F=%d %-4s max|ref| %.3e err %.3e" % (dtype, B, T, F, k, scale, np.abs(a - r).max()))
+        assert np.abs(a - r).max() <= tol * scale + 1e-9, (dtype, k)
+
+
+@pytest.mark.parametrize("B,U,T_in,T_out,act", [(37, 5, 2, 4, "hard_sigmoid"), (530, 3, 2, 2, "sigmoid"), (512, 34, 10, 10, "sigmoid")])
+def test_bf16_mixing_training_step(B, U, T_in, T_out, act):
+    """configs[4] training: loss and every gradient of the bf16 step against torch.autograd in fp64 on the
+    full-precision graph.  Stated bound: loss within 2e-3 relative; every gradient tensor within 3e-2 of its own scale
+    (max |g|) and cosine similarity >= 0.999 (measured values are printed); then three Adam steps on fp32 master
+    weights reduce the loss, and the fp32 trainer on the same data lands within 2 % of the same loss."""
+    from longterm360fov_amd.training import OthersMixingTrainer, _MIX_ORDER
+    from test_gpu_train import _torch_mixing_graph
+    w = O.init_others_mixing(170, H=256, num_user=U, bias_noise=0.1)
+    enc, dec0, tgt, oth = O.synthetic_batch(171 + B, B, T_in, T_out, num_others=U - 1)
+    loss_ref, g_ref, y_ref = _torch_mixing_graph(enc, oth, dec0, tgt, w, act)
+    tr = OthersMixingTrainer(w, act=act, dtype="bf16")
+    loss, y = tr.forward_backward(dev(enc), dev(oth), dev(dec0), dev(tgt))
+    tr.check()
+    assert abs(float(loss.item()) - loss_ref) <= 2e-3 * loss_ref + 1e-7
+    assert np.abs(y.cpu().numpy() - y_ref).max() <= LOOSE
+    worst = (0.0, None, 1.0, None)
+    for k in _MIX_ORDER:
+        a = tr.g[k].detach().cpu().numpy().astype(np.float64).ravel()
+        r = g_ref[k].ravel()
+        rel = np.abs(a - r).max() / (np.abs(r).max() + 1e-30)
+        cos = float(a @ r / (np.linalg.norm(a) * np.linalg.norm(r) + 1e-30))
+        if rel > worst[0]:
+            worst = (rel, k, worst[2], worst[3])
+        if cos < worst[2]:
+            worst = (worst[0], worst[1], cos, k)
+        assert rel <= 3e-2 and cos >= 0.999, (k, rel, cos)
+    print("bf16 training B=%d %d->%d: worst gradient error %.2e of its scale (%s), worst cosine %.6f (%s)"
+          % (B, T_in, T_out, worst[0], worst[1], worst[2], worst[3]))
+    l0 = float(loss.item())
+    for _ in range(3):
+        l = float(tr.train_step(dev(enc), dev(oth), dev(dec0), dev(tgt)).item())
+    tr.check()
+    assert l < l0
+    t32 = OthersMixingTrainer(w, act=act)
+    t32.forward_backward(dev(enc), dev(oth), dev(dec0), dev(tgt))
+    for _ in range(3):
+        l32 = float(t32.train_step(dev(enc), dev(oth), dev(dec0), dev(tgt)).item())
+    assert abs(l - l32) <= 2e-2 * l32
