@@ -49,6 +49,37 @@ __device__ __forceinline__ qu32x4 load_bfrag(const float* __restrict__ W, int ld
     }
     return (qu32x4){pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7])};
 }
+// The [NKB][2] fragment set of one (nrows x ld) fp32 kernel for this lane's two gate columns.
+// Loads go through a buffer descriptor whose num_records ends at the last real row: rows beyond it read as zero in
+// hardware, so every load is UNCONDITIONAL and hipcc keeps a whole batch in flight.  (Written as `k < nrows ? W[..] :
+// 0` each load sits in its own exec-masked branch with an s_waitcnt vmcnt(0) behind it: 2 500 cycles per fragment,
+// 81 000 cycles = 38 us for the 32 fragments of a layer kernel - tools/stamp_bf16_layer.py.)
+template <int NKB>
+__device__ __forceinline__ void load_weight_set(qu32x4 (&w)[NKB][2], const float* __restrict__ W, int ld, int nrows, int g4, int col0,
+                                                int col1) {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(W), 0, nrows * ld * 4, 0x00020000);
+    constexpr int CH = NKB < 4 ? NKB : 4;   // k-blocks per batch: 16*CH loads in flight
+    static_assert(NKB % CH == 0, "NKB must be a multiple of the batch");
+#pragma unroll
+    for (int c = 0; c < NKB / CH; ++c) {
+        float v[CH][2][8];
+#pragma unroll
+        for (int i = 0; i < CH; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const unsigned row = (unsigned)(32 * (c * CH + i) + 8 * g4 + j) * (unsigned)ld;
+                v[i][0][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (row + (unsigned)col0) * 4u, 0, 0));
+                v[i][1][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (row + (unsigned)col1) * 4u, 0, 0));
+            }
+#pragma unroll
+        for (int i = 0; i < CH; ++i)
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+                w[c * CH + i][t] = (qu32x4){pack_bf16(v[i][t][0], v[i][t][1]), pack_bf16(v[i][t][2], v[i][t][3]),
+                                            pack_bf16(v[i][t][4], v[i][t][5]), pack_bf16(v[i][t][6], v[i][t][7])};
+    }
+}
+
 // B fragment of a TRANSPOSED product: B[k][col] = W[row = out][k index along a row]; the 8 values are contiguous
 __device__ __forceinline__ qu32x4 load_bfrag_rowmajor(const float* __restrict__ wrow) {
     const f32x4 a = *(const f32x4*)wrow, b = *(const f32x4*)(wrow + 4);
@@ -63,11 +94,13 @@ __device__ __forceinline__ qu32x4 lds_afrag(const unsigned short* tile, int n, i
 // acc[tile] += A(tile image, k-blocks [KB0, KB1)) . W   (W[kb][nt] register-resident B fragments)
 template <int KB0, int KB1, int NKB>
 __device__ __forceinline__ void qmm(f32x4 (&acc)[2], const unsigned short* tile, int n, int g4, const qu32x4 (&w)[NKB][2]) {
+    qu32x4 a[KB1 - KB0 > 0 ? KB1 - KB0 : 1];   // all LDS reads in flight before the first MFMA
+#pragma unroll
+    for (int kb = KB0; kb < KB1; ++kb) a[kb - KB0] = lds_afrag(tile, n, g4, kb);
 #pragma unroll
     for (int kb = KB0; kb < KB1; ++kb) {
-        const qu32x4 a = lds_afrag(tile, n, g4, kb);
-        qmfma(acc[0], a, w[kb][0]);
-        qmfma(acc[1], a, w[kb][1]);
+        qmfma(acc[0], a[kb - KB0], w[kb][0]);
+        qmfma(acc[1], a[kb - KB0], w[kb][1]);
     }
 }
 
@@ -156,6 +189,85 @@ __device__ __forceinline__ bool q_gather_finish(QGather& g, const __amdgpu_buffe
                 bad &= ~(1u << j);
             }
         }
+    }
+    return ok;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Backward kernels: all-gather of the (16 x 1024) dz tile.  A bf16 product rounds dz to bf16 anyway, so what travels
+// is the rounded dz itself, two rows per granule, instead of fp32 partial sums of dz . R^T: a lane publishes 4
+// granules per step (K-split with partial sums: 16 to 48) and every workgroup then forms ITS 32 output units of
+// dz . R^T from the whole tile (N-split) - no reduction across workgroups, the 8-byte write-through stores (the
+// expensive side of the exchange) shrink 4 to 12 times.
+// Granules of one tile and parity: [gate 4][row pair 8][unit 256].
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int QLDZ = 1024 + 16;                   // bf16 per LDS row of a dz tile: 520 dwords = 8 (mod 64): conflict-free b128 reads
+constexpr unsigned Q_DZ_BYTES = 4u * 8u * QH * 8u;   // 64 KB
+constexpr int QNDZ = 28;                          // granules gathered per thread: 7 slices * 4 gates
+
+// this lane's cells: rows row0, row0 + 1 of `unit`; dzp[g] = packed bf16 pair of gate g
+__device__ __forceinline__ void q_dz_publish(const __amdgpu_buffer_rsrc_t rs, unsigned base, int row0, int unit, const unsigned (&dzp)[4],
+                                             unsigned epoch, unsigned short* tile) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        __builtin_amdgcn_raw_buffer_store_b64((qu32x2){dzp[g], epoch}, rs, (unsigned)((g * 8 + (row0 >> 1)) * QH + unit) * 8u, base, 16);
+        tile[row0 * QLDZ + g * QH + unit] = (unsigned short)(dzp[g] & 0xffffu);
+        tile[(row0 + 1) * QLDZ + g * QH + unit] = (unsigned short)(dzp[g] >> 16);
+    }
+}
+__device__ __forceinline__ bool q_dz_gather(const __amdgpu_buffer_rsrc_t rs, unsigned base, int slice, int tid, unsigned epoch,
+                                            unsigned short* tile, unsigned* status) {
+    const int p = tid >> 5, u = tid & 31;
+    const unsigned voff = (unsigned)(p * QH + u) * 8u;
+    const int lbase = 2 * p * QLDZ + u;
+    unsigned bad = 0;
+    {
+        qu32x2 v[QNDZ];
+#pragma unroll
+        for (int j = 0; j < 7; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                v[j * 4 + g] = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, base + (unsigned)(g * 8 * QH + ((slice + 1 + j) & (QG - 1)) * 32) * 8u, 16);
+#pragma unroll
+        for (int j = 0; j < 7; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int lo = lbase + g * QH + ((slice + 1 + j) & (QG - 1)) * 32;
+                if (v[j * 4 + g].y == epoch) {
+                    tile[lo] = (unsigned short)(v[j * 4 + g].x & 0xffffu);
+                    tile[lo + QLDZ] = (unsigned short)(v[j * 4 + g].x >> 16);
+                } else {
+                    bad |= (1u << (j * 4 + g));
+                }
+            }
+    }
+    unsigned spins = 0;
+    bool ok = true;
+    while (__any(bad != 0)) {
+        ++spins;
+        if (spins > Q_SPIN || ((spins & 63u) == 0 && xch_poisoned(status))) {
+            if ((tid & 63) == 0) xch_give_up(status);
+            ok = false;
+            break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+        asm volatile("" ::: "memory");
+        // re-read only what is still missing (wave-uniform loop over the 28 slots, lanes with the bit set load)
+#pragma unroll
+        for (int j = 0; j < 7; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const unsigned bit = 1u << (j * 4 + g);
+                if (__any((bad & bit) != 0)) {
+                    const qu32x2 tv = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, base + (unsigned)(g * 8 * QH + ((slice + 1 + j) & (QG - 1)) * 32) * 8u, 16);
+                    if ((bad & bit) && tv.y == epoch) {
+                        const int lo = lbase + g * QH + ((slice + 1 + j) & (QG - 1)) * 32;
+                        tile[lo] = (unsigned short)(tv.x & 0xffffu);
+                        tile[lo + QLDZ] = (unsigned short)(tv.x >> 16);
+                        bad &= ~bit;
+                    }
+                }
+            }
     }
     return ok;
 }

@@ -959,7 +959,7 @@ int fov_check_status(void* workspace, size_t workspace_bytes, fov_stream_t strea
         if (e != hipSuccess) { set_error("fov_check_status: %s", hipGetErrorString(e)); return FOV_ERR_LAUNCH; }
     }
     if (st[ST_TIMEOUT] != 0) {
-        set_error("a bounded in-kernel wait gave up (launches completed on this workspace: %u); results since the last check are invalid",
+        set_error("a bounded in-kernel wait gave up (exchange launches on this workspace so far: %u); results since the last check are invalid",
                   st[ST_LAUNCHES]);
         return FOV_ERR_TIMEOUT;
     }
@@ -1125,7 +1125,8 @@ int fov_exchange_mode(const void* workspace, size_t workspace_bytes, fov_stream_
     hipError_t e = hipMemcpyAsync(st, workspace, sizeof(st), hipMemcpyDeviceToHost, (hipStream_t)stream);
     if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
     if (e != hipSuccess) { set_error("fov_exchange_mode: %s", hipGetErrorString(e)); return FOV_ERR_LAUNCH; }
-    return st[ST_SAFE_LAST] == 0 ? 1 : 2;   // of the last completed exchange launch
+    if (st[ST_LAUNCHES] == 0) return 1;
+    return st[ST_SAFE0 + ((st[ST_LAUNCHES] - 1u) & 1u)] == 0 ? 1 : 2;   // of the last exchange launch
 }
 
 }  // extern "C"

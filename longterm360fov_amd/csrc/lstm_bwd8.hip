@@ -10,8 +10,8 @@
 //   gates backward for the lane's two cells (from the reserve i,f,g,o,c of the training forward) -> dz (4 gates), to
 //   dZ (B,T,4H) for the weight-gradient products and into an LDS tile (16 x 128 own gate columns);
 //   partial[16 x 256] = dz_own . R^T_own : the contribution of the own gate columns to dh_{t-1} of ALL 256 units
-//   (fp32: 128 x v_mfma_f32_16x16x4_f32 per wave, R^T slice in 128 AGPRs; bf16: 16 x v_mfma_f32_16x16x32_bf16, R^T
-//   slice as 64 registers of packed B fragments, dz rounded to bf16 in the LDS image);
+//   (fp32 kernel: 128 x v_mfma_f32_16x16x4_f32 per wave, R^T slice in 128 AGPRs; the bf16 kernel further down splits
+//   the product by OUTPUT unit instead and all-gathers the rounded dz tile);
 //   the 16 x 32 piece of every destination workgroup travels as fp32 {value, epoch} granules; each lane gathers
 //   the eight pieces of its own cells and adds them in slice order (deterministic).
 // The bias gradient leaves as one (tiles, 4H) partial (sum over the tile's rows and all steps), as in the 4-group kernel.
@@ -51,8 +51,9 @@ __device__ __forceinline__ float b8_act_grad(float a) {
     return ACT == FOV_ACT_HARD_SIGMOID ? ((a > 0.f && a < 1.f) ? 0.2f : 0.f) : a * (1.f - a);
 }
 
-template <int ACT, bool BF16>
+template <int ACT>
 __global__ __launch_bounds__(256, 1) void lstm_bwd8_kernel(Bwd8Params p) {
+    constexpr bool BF16 = false;   // the bf16 form is lstm_bwd8n_bf16_kernel below (N-split)
     __shared__ __attribute__((aligned(16))) float sDZ[BF16 ? 4 : QBT * B8LDZ];
     __shared__ __attribute__((aligned(16))) unsigned short sDQ[BF16 ? QBT * B8LDQ : 8];
     __shared__ int sFlag[4];
@@ -67,7 +68,8 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd8_kernel(Bwd8Params p) {
     const int my_row0 = 4 * g4 + 2 * hi;
     const int T = p.T;
     // epoch tags continue from the workspace header, a poisoned workspace skips the body (xch_common.h)
-    const unsigned epoch_base = xch_epoch_base(p.status);
+    __shared__ unsigned sXch[2];
+    const unsigned arrival = xch_arrive(p.status, sXch);
     const bool poisoned = xch_poisoned(p.status);
     if (tid == 0) sFlag[0] = poisoned ? 1 : 0;
 
@@ -93,8 +95,9 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd8_kernel(Bwd8Params p) {
     }
     unsigned long long* gbase = p.xch + (size_t)group * 2 * B8_PAR;
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(gbase, 0, (int)(2 * B8_PAR * 8), 0x00020000);
-    unsigned epoch = epoch_base;
     __syncthreads();
+    const XchTicket ticket = xch_ticket(sXch, arrival);
+    unsigned epoch = ticket.base;
     bool aborted = sFlag[0] != 0;
 
     for (int tile = group; tile < p.num_tiles && !aborted; tile += p.num_groups) {
@@ -277,7 +280,174 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd8_kernel(Bwd8Params p) {
             }
         }
     }
-    xch_leave(p.status, (unsigned)p.epoch_span);
+    xch_settle(p.status, ticket, (unsigned)p.epoch_span);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// bf16 form (BASELINE configs[4]), N-SPLIT: the rounded dz tile is all-gathered (bf16_common.h: 4 granules per lane
+// and step instead of 16 fp32 partial sums) and every workgroup computes dh_{t-1} of ITS 32 units from the whole
+// (16 x 1024) tile: wave w contracts gate w's 256 columns (8 k-blocks x 2 N-tiles = 16 MFMAs, R^T slice = 64
+// registers of packed B fragments: eight contiguous floats of a row of R each), the four partial 16 x 32 tiles meet
+// in LDS and are added in wave order.
+// ---------------------------------------------------------------------------------------------------------------
+template <int ACT>
+__global__ __launch_bounds__(256, 1) void lstm_bwd8n_bf16_kernel(Bwd8Params p) {
+    __shared__ __attribute__((aligned(16))) unsigned short sDZ[QBT * QLDZ];   // the whole dz tile, bf16
+    __shared__ float sRed[4 * QBT * 33];                                      // [wave][row][unit] partial dh
+    __shared__ int sFlag[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 15, g4 = lane >> 4;
+    int group, slice;
+    q_group_slice(p.num_groups, group, slice);
+    constexpr int H4 = 4 * QH;
+    const int hi = n >> 3;
+    const int ul = 8 * wave + (n & 7);          // unit inside the workgroup (0..31)
+    const int unit = 32 * slice + ul;
+    const int my_row0 = 4 * g4 + 2 * hi;
+    const int T = p.T;
+    __shared__ unsigned sXch[2];
+    const unsigned arrival = xch_arrive(p.status, sXch);
+    const bool poisoned = xch_poisoned(p.status);
+    if (tid == 0) sFlag[0] = poisoned ? 1 : 0;
+
+    // R^T fragments of this wave: k-block kb of gate `wave` (columns 256*wave + 32*kb + 8*g4 + j), N-tile nt (own unit 16*nt + n)
+    qu32x4 rq[8][2];
+#pragma unroll
+    for (int kb = 0; kb < 8; ++kb)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+            rq[kb][nt] = load_bfrag_rowmajor(p.R + (size_t)(32 * slice + 16 * nt + n) * H4 + QH * wave + 32 * kb + 8 * g4);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        p.xch + (size_t)group * 2 * (Q_DZ_BYTES / 8), 0, (int)(2 * Q_DZ_BYTES), 0x00020000);
+    __syncthreads();
+    const XchTicket ticket = xch_ticket(sXch, arrival);
+    unsigned epoch = ticket.base;
+    bool aborted = sFlag[0] != 0;
+
+    for (int tile = group; tile < p.num_tiles && !aborted; tile += p.num_groups) {
+        const int b0 = tile * QBT;
+        float dc[2], dh[2];
+        bool live[2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int row = b0 + my_row0 + r;
+            live[r] = row < p.B;
+            dc[r] = (live[r] && p.dcT) ? p.dcT[(size_t)row * QH + unit] : 0.f;
+            dh[r] = (live[r] && p.dhT) ? p.dhT[(size_t)row * QH + unit] : 0.f;
+        }
+        float cur[5][2], nxt[5][2], dhs_cur[2], dhs_nxt[2];
+        auto load_step = [&](int t, float (&dst)[5][2], float (&dd_)[2]) {
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int row = b0 + my_row0 + r;
+                if (t >= 0 && live[r]) {
+                    const float* rp = p.reserve + (((size_t)row * T + t) * 5) * QH + unit;
+#pragma unroll
+                    for (int q = 0; q < 5; ++q) dst[q][r] = rp[q * QH];
+                    dd_[r] = p.dhs ? p.dhs[((size_t)row * T + t) * QH + unit] : 0.f;
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 5; ++q) dst[q][r] = 0.f;
+                    dst[4][r] = (t < 0 && live[r] && p.c0) ? p.c0[(size_t)row * QH + unit] : 0.f;   // c_{-1} = c0
+                    dd_[r] = 0.f;
+                }
+            }
+        };
+        load_step(T - 1, cur, dhs_cur);
+        load_step(T - 2, nxt, dhs_nxt);
+        float dbacc[4] = {0.f, 0.f, 0.f, 0.f};
+        __syncthreads();   // the previous tile's last step is done with the LDS tiles
+
+        for (int t = T - 1; t >= 0; --t) {
+            ++epoch;
+            const unsigned par = (epoch & 1u) * Q_DZ_BYTES;
+            // ---- pointwise: dz of this lane's two cells ----
+            float dzv[2][4];
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const float ig = cur[0][r], fg = cur[1][r], gg = cur[2][r], og = cur[3][r], cc = cur[4][r];
+                const float cprev = nxt[4][r];
+                const float dht = dh[r] + dhs_cur[r];
+                const float tc = tanh_f(cc);
+                const float dcv = dc[r] + dht * og * (1.f - tc * tc);
+                dzv[r][0] = live[r] ? dcv * gg * b8_act_grad<ACT>(ig) : 0.f;
+                dzv[r][1] = live[r] ? dcv * cprev * b8_act_grad<ACT>(fg) : 0.f;
+                dzv[r][2] = live[r] ? dcv * ig * (1.f - gg * gg) : 0.f;
+                dzv[r][3] = live[r] ? dht * tc * b8_act_grad<ACT>(og) : 0.f;
+                dc[r] = dcv * fg;
+            }
+            // publish first (the partners wait for it), then the tape traffic of this step
+            unsigned dzp[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) dzp[g] = pack_bf16(dzv[0][g], dzv[1][g]);
+            q_dz_publish(rs, par, my_row0, unit, dzp, epoch, sDZ);
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) dbacc[g] += dzv[r][g];
+                if (live[r]) {
+                    float* zp = p.dz + ((size_t)(b0 + my_row0 + r) * T + t) * H4 + unit;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) zp[g * QH] = dzv[r][g];
+                }
+            }
+            // rotate the tape pipeline and request step t-2
+#pragma unroll
+            for (int q = 0; q < 5; ++q)
+#pragma unroll
+                for (int r = 0; r < 2; ++r) cur[q][r] = nxt[q][r];
+#pragma unroll
+            for (int r = 0; r < 2; ++r) dhs_cur[r] = dhs_nxt[r];
+            load_step(t - 2, nxt, dhs_nxt);
+            if (!q_dz_gather(rs, par, slice, tid, epoch, sDZ, p.status)) sFlag[0] = 1;
+            __syncthreads();   // barrier A: the whole dz tile is in LDS
+            if (sFlag[0]) { aborted = true; break; }
+            // ---- this wave's share of dh_{t-1}[16 x 32 own units]: gate `wave`'s 256 columns ----
+            f32x4 acc[2];
+            acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            {
+                qu32x4 a[8];
+#pragma unroll
+                for (int kb = 0; kb < 8; ++kb) a[kb] = *(const qu32x4*)(sDZ + n * QLDZ + QH * wave + 32 * kb + 8 * g4);
+#pragma unroll
+                for (int kb = 0; kb < 8; ++kb) {
+                    qmfma(acc[0], a[kb], rq[kb][0]);
+                    qmfma(acc[1], a[kb], rq[kb][1]);
+                }
+            }
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sRed[(wave * QBT + 4 * g4 + r) * 33 + 16 * nt + n] = acc[nt][r];
+            __syncthreads();   // barrier B: the four partial tiles are in LDS; every wave is done reading the dz tile
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const float* q = sRed + (my_row0 + r) * 33 + ul;
+                dh[r] = (q[0] + q[QBT * 33]) + (q[2 * QBT * 33] + q[3 * QBT * 33]);
+            }
+        }
+        if (!aborted && p.db_part) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float v = dbacc[g];
+                v += __shfl_xor(v, 8);
+                const float v1 = __shfl(v, (lane + 16) & 63), v2 = __shfl(v, (lane + 32) & 63), v3 = __shfl(v, (lane + 48) & 63);
+                if (g4 == 0 && hi == 0) p.db_part[(size_t)tile * H4 + g * QH + unit] = (v + v1) + (v2 + v3);
+            }
+        }
+        if (!aborted) {
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int row = b0 + my_row0 + r;
+                if (row < p.B) {
+                    if (p.dh0) p.dh0[(size_t)row * QH + unit] = dh[r];
+                    if (p.dc0) p.dc0[(size_t)row * QH + unit] = dc[r];
+                }
+            }
+        }
+    }
+    xch_settle(p.status, ticket, (unsigned)p.epoch_span);
 }
 
 }  // namespace
@@ -296,13 +466,14 @@ int launch_bwd8(const float* R, const float* reserve, const float* c0, const flo
     const int max_groups = device_cu_count() / QG;
     if (max_groups < 1) { set_error("8-group BPTT kernel needs at least %d CUs", QG); return FOV_ERR_UNSUPPORTED; }
     p.num_groups = p.num_tiles < max_groups ? p.num_tiles : max_groups;
-    if ((size_t)p.num_groups * 2 * B8_PAR * 8 > kXchBytes) { set_error("8-group BPTT kernel: granule area too small"); return FOV_ERR_WORKSPACE; }
+    if ((size_t)p.num_groups * 2 * (bf16 ? (size_t)Q_DZ_BYTES : B8_PAR * 8) > kXchBytes) { set_error("8-group BPTT kernel: granule area too small"); return FOV_ERR_WORKSPACE; }
+    if (bf16 && (((uintptr_t)R) & 15)) { set_error("8-group BPTT kernel: R must be 16-byte aligned"); return FOV_ERR_INVALID; }
     p.status = (unsigned*)xch_ws;
     p.xch = (unsigned long long*)((char*)xch_ws + kStatusBytes);
     p.epoch_span = T * ((p.num_tiles + p.num_groups - 1) / p.num_groups) + 1;
     void (*kern)(Bwd8Params) = nullptr;
-    if (bf16) kern = act == FOV_ACT_HARD_SIGMOID ? lstm_bwd8_kernel<FOV_ACT_HARD_SIGMOID, true> : lstm_bwd8_kernel<FOV_ACT_SIGMOID, true>;
-    else kern = act == FOV_ACT_HARD_SIGMOID ? lstm_bwd8_kernel<FOV_ACT_HARD_SIGMOID, false> : lstm_bwd8_kernel<FOV_ACT_SIGMOID, false>;
+    if (bf16) kern = act == FOV_ACT_HARD_SIGMOID ? lstm_bwd8n_bf16_kernel<FOV_ACT_HARD_SIGMOID> : lstm_bwd8n_bf16_kernel<FOV_ACT_SIGMOID>;
+    else kern = act == FOV_ACT_HARD_SIGMOID ? lstm_bwd8_kernel<FOV_ACT_HARD_SIGMOID> : lstm_bwd8_kernel<FOV_ACT_SIGMOID>;
     hipLaunchKernelGGL(kern, dim3(p.num_groups * QG), dim3(256), 0, stream, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("8-group BPTT launch: %s", hipGetErrorString(e)); return FOV_ERR_LAUNCH; }

@@ -76,7 +76,8 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_cluster_kernel(BwdParams p) {
     }
     const int unit = slice * 64 + wave * 16 + n;   // the hidden unit this lane owns
     // epoch tags continue from the workspace header, a poisoned workspace skips the body (xch_common.h)
-    const unsigned epoch_base = G > 1 ? xch_epoch_base(p.status) : 0u;
+    __shared__ unsigned sXch[2];
+    const unsigned arrival = G > 1 ? xch_arrive(p.status, sXch) : 0u;
     const bool poisoned = G > 1 && xch_poisoned(p.status);
     if (tid == 0) sFlag[0] = poisoned ? 1 : 0;
 
@@ -105,8 +106,10 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_cluster_kernel(BwdParams p) {
         p.xch + (size_t)group * 2 * G * G * CHUNK, 0, 2 * G * G * CHUNK * (int)sizeof(unsigned long long), 0x00020000);
     const unsigned lane_off = (unsigned)((wave * 4) * 64 + lane) * 8u;   // + r*64*8 per register
 
-    unsigned epoch = epoch_base;
     __syncthreads();
+    XchTicket ticket = {0u, 0u, 0u};
+    if (G > 1) ticket = xch_ticket(sXch, arrival);
+    unsigned epoch = ticket.base;
     bool aborted = sFlag[0] != 0;
 
     for (int tile = group; tile < p.num_tiles && !aborted; tile += p.num_groups) {
@@ -295,7 +298,7 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_cluster_kernel(BwdParams p) {
         }
         __syncthreads();
     }
-    if (G > 1) xch_leave(p.status, (unsigned)p.epoch_span);
+    if (G > 1) xch_settle(p.status, ticket, (unsigned)p.epoch_span);
 }
 
 // --------------------------------------------------------------------------------------

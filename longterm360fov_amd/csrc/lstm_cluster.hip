@@ -264,10 +264,12 @@ __global__ __launch_bounds__(256, 1) void lstm_cluster_kernel(LstmParams p) {
     const bool xch_used = (G > 1) && (!LAYER || p.T > 1);
     // Epoch tags continue from the workspace header (xch_common.h): no memset between launches.  A workspace whose
     // sticky timeout word is set is poisoned: the body is skipped (fail-stop) until fov_check_status clears it.
-    const unsigned epoch_base = xch_used ? xch_epoch_base(p.status) : 0u;
+    unsigned* sXch = (unsigned*)(sFlag + 4);     // base / launch index of this launch (thread 0 -> all, xch_common.h)
+    const unsigned arrival = xch_used ? xch_arrive(p.status, sXch) : 0u;
     const bool poisoned = xch_used && xch_poisoned(p.status);   // one wave-wide load per wave; wave 0's value decides (sFlag[0])
     if (tid == 0) { sFlag[0] = poisoned ? 1 : 0; sFlag[1] = 0; }
-    if (xch_used && !poisoned) {
+    if (xch_used && !poisoned && tid < 64) {   // wave 0 only: thread 0 has just written sXch (same wave: program order)
+        const unsigned epoch_base = sXch[0];
         // hello handshake (safe sc1 protocol): do all members of this group sit on one XCD?
         unsigned long long* hello = p.xch + (size_t)p.num_groups * 2 * BT * H + (size_t)group * G;
         const unsigned mine = xcc_id();
@@ -327,12 +329,14 @@ __global__ __launch_bounds__(256, 1) void lstm_cluster_kernel(LstmParams p) {
         kb[1] = *(const f32x4*)(sKw + 256 + lane * 4);
     }
 
-    unsigned epoch = epoch_base;
     __syncthreads();
+    XchTicket ticket = {0u, 0u, 0u};
+    if (xch_used) ticket = xch_ticket(sXch, arrival);
+    unsigned epoch = ticket.base;
     const bool same_xcd = xch_used && (sFlag[1] == 0) && (p.force_safe_exchange == 0);
     bool aborted = xch_used && sFlag[0] != 0;   // poisoned workspace, or a partner never showed up: drain
     if (xch_used && tid == 0 && !same_xcd && !aborted)   // number of workgroups on the safe (cross-XCD) exchange
-        __hip_atomic_fetch_add(p.status + ST_SAFE_COUNT, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        xch_count_safe(p.status, ticket);
 #ifdef FOV_STAMPS
     const bool stamp_on = (blockIdx.x == 5 && tid == 0);
 #endif
@@ -608,7 +612,7 @@ __global__ __launch_bounds__(256, 1) void lstm_cluster_kernel(LstmParams p) {
             }
         }
     }
-    if (xch_used) xch_leave(p.status, (unsigned)p.epoch_span);
+    if (xch_used) xch_settle(p.status, ticket, (unsigned)p.epoch_span);
 }
 
 // --------------------------------------------------------------------------------------

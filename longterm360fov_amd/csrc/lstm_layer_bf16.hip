@@ -14,9 +14,30 @@
 
 namespace fov {
 
+// Diagnostic build only (-DFOV_STAMPS, tools/stamp_bf16_layer.py): s_memtime stamps of one wave per step.
+#ifdef FOV_STAMPS
+constexpr int QSTAMP_SLOTS = 12;
+constexpr int QSTAMP_STEPS = 32;
+__device__ unsigned long long g_q_stamps[QSTAMP_STEPS][QSTAMP_SLOTS];
+#define Q_STAMP(slot)                                                                          \
+    do {                                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                     \
+        if (stamp_on && t < QSTAMP_STEPS) {                                                    \
+            unsigned long long t_;                                                             \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");        \
+            g_q_stamps[t][slot] = t_;                                                          \
+        }                                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                     \
+    } while (0)
+#else
+#define Q_STAMP(slot) do { } while (0)
+#endif
+
 namespace {
 
-template <int ACT, int NKB>   // NKB: 32-wide k-blocks of the input kernel (3: F <= 96, 8: F <= 256)
+// NKB: 32-wide k-blocks of the input kernel (3: F <= 96, 8: F <= 256).  XVEC: x rows are read in 16-byte pieces
+// (F % 4 == 0, x 16-byte aligned: the stacked layer over a 256-wide sequence); otherwise element by element.
+template <int ACT, int NKB, bool XVEC>
 __global__ __launch_bounds__(256, 1) void lstm_layer_bf16_kernel(LstmParams p) {
     __shared__ __attribute__((aligned(16))) unsigned short sH[QBT * QLD];
     __shared__ __attribute__((aligned(16))) unsigned short sX[2 * QBT * QLD];
@@ -32,21 +53,19 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_bf16_kernel(LstmParams p) {
     constexpr int H4 = 4 * QH;
     // epoch tags continue from the workspace header, a poisoned workspace skips the body (xch_common.h)
     const bool xch_used = steps > 1;
-    const unsigned epoch_base = xch_used ? xch_epoch_base(p.status) : 0u;
+    __shared__ unsigned sXch[2];
+    const unsigned arrival = xch_used ? xch_arrive(p.status, sXch) : 0u;
     const bool poisoned = xch_used && xch_poisoned(p.status);
     if (tid == 0) sFlag[0] = poisoned ? 1 : 0;
+#ifdef FOV_STAMPS
+    const bool stamp_on = (blockIdx.x == 5 && tid == 0);
+    if (stamp_on) g_q_stamps[QSTAMP_STEPS - 1][0] = __builtin_amdgcn_s_memtime();   // kernel entry
+#endif
 
     // ---- resident weights: packed bf16 B fragments (rows of K beyond F are zero) ----
     qu32x4 wk[NKB][2], wr[8][2];
-#pragma unroll
-    for (int kb = 0; kb < 8; ++kb) {
-        if (kb < NKB) {
-            wk[kb][0] = load_bfrag(p.K, H4, F, kb, g4, col0);
-            wk[kb][1] = load_bfrag(p.K, H4, F, kb, g4, col1);
-        }
-        wr[kb][0] = load_bfrag(p.R, H4, QH, kb, g4, col0);
-        wr[kb][1] = load_bfrag(p.R, H4, QH, kb, g4, col1);
-    }
+    load_weight_set<NKB>(wk, p.K, H4, F, g4, col0, col1);
+    load_weight_set<8>(wr, p.R, H4, QH, g4, col0, col1);
     const float bv[2] = {p.b[col0], p.b[col1]};
     for (int i = tid; i < 2 * QBT * QLD; i += 256) sX[i] = 0;   // columns >= F stay zero
 
@@ -55,13 +74,21 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_bf16_kernel(LstmParams p) {
         p.xch + (size_t)group * 2 * (Q_TILE_BYTES / 8), 0, (int)(2 * Q_TILE_BYTES), 0x00020000);
     const int my_row0 = 4 * g4 + 2 * hi;                                       // this lane's cells: rows my_row0, +1 of `unit`
     const unsigned pub_off = (unsigned)((my_row0 >> 1) * QH + unit) * 8u;
-    unsigned epoch = epoch_base;
+#ifdef FOV_STAMPS
+    asm volatile("" :: "v"(wr[7][1]), "v"(wr[0][0]), "v"(wk[0][0]), "v"(wk[NKB - 1][1]));   // the fragments exist by now
+    if (stamp_on) g_q_stamps[QSTAMP_STEPS - 1][1] = __builtin_amdgcn_s_memtime();   // weights resident
+#endif
     __syncthreads();
+    XchTicket ticket = {0u, 0u, 0u};
+    if (xch_used) ticket = xch_ticket(sXch, arrival);
+    unsigned epoch = ticket.base;
     bool aborted = sFlag[0] != 0;
 
     // x staging: thread (xrw = tid / 16, xc = tid % 16) moves the elements xc, xc + 16, ... of row xrw
+    // (XVEC: the 16-byte pieces xc, xc + 16, ...: four elements each)
     const int xrw = tid >> 4, xc = tid & 15;
-    constexpr int NXE = 2 * NKB;   // elements per thread: 32 * NKB columns / 16
+    constexpr int NXE = XVEC ? NKB / 2 : 2 * NKB;   // pieces (XVEC) / elements per thread
+    const int nx4 = F >> 2;
     QGather gq;
     for (int tile = group; tile < p.num_tiles && !aborted; tile += p.num_groups) {
         const int b0 = tile * QBT;
@@ -78,15 +105,31 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_bf16_kernel(LstmParams p) {
             hc[r] = (row < p.B && p.h0) ? p.h0[(size_t)row * QH + unit] : 0.f;
         }
         const bool xlive = b0 + xrw < p.B;
-        const float* xt = p.x + ((size_t)(b0 + xrw) * p.T) * F + xc;
-        unsigned short* xl = sX + xrw * QLD + xc;
+        const float* xt = p.x + ((size_t)(b0 + xrw) * p.T) * F + (XVEC ? 4 : 1) * xc;
+        unsigned short* xl = sX + xrw * QLD + (XVEC ? 4 : 1) * xc;
+        const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+        {
+            f32x4 v4[2][XVEC ? NXE : 1];
+            float v1[2][XVEC ? 1 : NXE];
 #pragma unroll
-        for (int tt = 0; tt < 2; ++tt)
-            if (tt < steps) {
+            for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
-                for (int i = 0; i < NXE; ++i)
-                    if (xc + 16 * i < F) xl[tt * QBT * QLD + 16 * i] = bf16_bits(xlive ? xt[(size_t)tt * F + 16 * i] : 0.f);
-            }
+                for (int i = 0; i < NXE; ++i) {
+                    if constexpr (XVEC) v4[tt][i] = (tt < steps && xlive && xc + 16 * i < nx4) ? *(const f32x4*)(xt + (size_t)tt * F + 64 * i) : z4;
+                    else v1[tt][i] = (tt < steps && xlive && xc + 16 * i < F) ? xt[(size_t)tt * F + 16 * i] : 0.f;
+                }
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                for (int i = 0; i < NXE; ++i) {
+                    if constexpr (XVEC) {
+                        if (xc + 16 * i < nx4)
+                            *(qu32x2*)(xl + tt * QBT * QLD + 64 * i) = (qu32x2){pack_bf16(v4[tt][i][0], v4[tt][i][1]), pack_bf16(v4[tt][i][2], v4[tt][i][3])};
+                    } else {
+                        if (xc + 16 * i < F) xl[tt * QBT * QLD + 16 * i] = bf16_bits(v1[tt][i]);
+                    }
+                }
+        }
         __syncthreads();
         // ---- pre-activations of step 0 ----
         f32x4 acc[2];
@@ -96,22 +139,35 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_bf16_kernel(LstmParams p) {
             qmm<0, NKB, NKB>(acc, sX, n, g4, wk);
             qmm<0, 8, 8>(acc, sH, n, g4, wr);
         }
-        float xs[NXE];
+        f32x4 xr[XVEC ? NXE : 1];
+        float xs[XVEC ? 1 : NXE];
 #pragma unroll
-        for (int i = 0; i < NXE; ++i) xs[i] = 0.f;
+        for (int i = 0; i < (XVEC ? NXE : 1); ++i) xr[i] = z4;
+#pragma unroll
+        for (int i = 0; i < (XVEC ? 1 : NXE); ++i) xs[i] = 0.f;
         for (int t = 0; t < steps; ++t) {
+            Q_STAMP(0);
             // x pipeline: x_{t+1} (requested during step t-1) registers -> LDS; then request x_{t+2}
             if (t > 0 && t + 1 < steps) {
                 unsigned short* xb = xl + ((t + 1) & 1) * QBT * QLD;
 #pragma unroll
-                for (int i = 0; i < NXE; ++i)
-                    if (xc + 16 * i < F) xb[16 * i] = bf16_bits(xs[i]);
+                for (int i = 0; i < NXE; ++i) {
+                    if constexpr (XVEC) {
+                        if (xc + 16 * i < nx4) *(qu32x2*)(xb + 64 * i) = (qu32x2){pack_bf16(xr[i][0], xr[i][1]), pack_bf16(xr[i][2], xr[i][3])};
+                    } else {
+                        if (xc + 16 * i < F) xb[16 * i] = bf16_bits(xs[i]);
+                    }
+                }
             }
             if (t + 2 < steps) {
                 const float* xn = xt + (size_t)(t + 2) * F;
 #pragma unroll
-                for (int i = 0; i < NXE; ++i) xs[i] = (xlive && xc + 16 * i < F) ? xn[16 * i] : 0.f;
+                for (int i = 0; i < NXE; ++i) {
+                    if constexpr (XVEC) xr[i] = (xlive && xc + 16 * i < nx4) ? *(const f32x4*)(xn + 64 * i) : z4;
+                    else xs[i] = (xlive && xc + 16 * i < F) ? xn[16 * i] : 0.f;
+                }
             }
+            Q_STAMP(1);
             // ---- cell update (fp32) ----
             {
                 float zi[2], zf[2], zg[2], zo[2];
@@ -131,6 +187,7 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_bf16_kernel(LstmParams p) {
                     }
                 }
             }
+            Q_STAMP(2);
             const bool more = (t + 1 < steps);
             const bool do_xch = xch_used && more;   // the last h_t is needed by nobody in here
             unsigned par = 0;
@@ -140,7 +197,9 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_bf16_kernel(LstmParams p) {
                 par = (epoch & 1u) * Q_TILE_BYTES;
                 __builtin_amdgcn_raw_buffer_store_b64((qu32x2){hpair, epoch}, xrs, pub_off, par, 16);
             }
+            Q_STAMP(3);
             __syncthreads();   // barrier 1: every wave is done reading sH; x_{t+1} is in LDS
+            Q_STAMP(4);
             if (more) {
                 sH[my_row0 * QLD + unit] = (unsigned short)(hpair & 0xffffu);
                 sH[(my_row0 + 1) * QLD + unit] = (unsigned short)(hpair >> 16);
@@ -150,13 +209,18 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_bf16_kernel(LstmParams p) {
             // x_{t+1} . K needs no remote data; the gather is requested behind it (the partners publish at about the same
             // moment and an sc1 store takes most of a microsecond to become visible)
             if (more) qmm<0, NKB, NKB>(acc, sX + ((t + 1) & 1) * QBT * QLD, n, g4, wk);
+            Q_STAMP(5);
             if (do_xch) {
                 q_gather_issue(gq, xrs, par, slice, tid);
+                Q_STAMP(6);
                 if (!q_gather_finish(gq, xrs, par, slice, tid, epoch, sH, p.status)) sFlag[0] = 1;
             }
+            Q_STAMP(7);
             __syncthreads();   // barrier 2: the whole h_t tile is in LDS
+            Q_STAMP(8);
             if (sFlag[0]) { aborted = true; break; }
             if (more) qmm<0, 8, 8>(acc, sH, n, g4, wr);
+            Q_STAMP(9);
         }
         if (!aborted) {
 #pragma unroll
@@ -169,10 +233,22 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_bf16_kernel(LstmParams p) {
             }
         }
     }
-    if (xch_used) xch_leave(p.status, (unsigned)p.epoch_span);
+#ifdef FOV_STAMPS
+    if (stamp_on) g_q_stamps[QSTAMP_STEPS - 1][2] = __builtin_amdgcn_s_memtime();   // all tiles done
+#endif
+    if (xch_used) xch_settle(p.status, ticket, (unsigned)p.epoch_span);
+#ifdef FOV_STAMPS
+    if (stamp_on) g_q_stamps[QSTAMP_STEPS - 1][3] = __builtin_amdgcn_s_memtime();   // left
+#endif
 }
 
 }  // namespace
+
+#ifdef FOV_STAMPS
+extern "C" int fov_debug_read_q_stamps(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_q_stamps), sizeof(unsigned long long) * QSTAMP_STEPS * QSTAMP_SLOTS);
+}
+#endif
 
 bool layer_bf16_shape_ok(int F, int H) { return H == QH && F >= 1 && F <= 256; }
 
@@ -188,9 +264,12 @@ int launch_layer_bf16(const LstmParams& p_in, hipStream_t stream) {
     if ((size_t)p.num_groups * 2 * Q_TILE_BYTES > kXchBytes) { set_error("bf16 LSTM layer: granule area too small"); return FOV_ERR_WORKSPACE; }
     p.epoch_span = p.T * ((p.num_tiles + p.num_groups - 1) / p.num_groups) + 1;
     const bool narrow = p.F <= 96;
+    const bool xvec = !narrow && (p.F & 3) == 0 && (((uintptr_t)p.x) & 15) == 0;
+    const bool hs_ = p.act == FOV_ACT_HARD_SIGMOID;
     void (*kern)(LstmParams) =
-        narrow ? (p.act == FOV_ACT_HARD_SIGMOID ? lstm_layer_bf16_kernel<FOV_ACT_HARD_SIGMOID, 3> : lstm_layer_bf16_kernel<FOV_ACT_SIGMOID, 3>)
-               : (p.act == FOV_ACT_HARD_SIGMOID ? lstm_layer_bf16_kernel<FOV_ACT_HARD_SIGMOID, 8> : lstm_layer_bf16_kernel<FOV_ACT_SIGMOID, 8>);
+        narrow ? (hs_ ? lstm_layer_bf16_kernel<FOV_ACT_HARD_SIGMOID, 3, false> : lstm_layer_bf16_kernel<FOV_ACT_SIGMOID, 3, false>)
+        : xvec ? (hs_ ? lstm_layer_bf16_kernel<FOV_ACT_HARD_SIGMOID, 8, true> : lstm_layer_bf16_kernel<FOV_ACT_SIGMOID, 8, true>)
+               : (hs_ ? lstm_layer_bf16_kernel<FOV_ACT_HARD_SIGMOID, 8, false> : lstm_layer_bf16_kernel<FOV_ACT_SIGMOID, 8, false>);
     hipLaunchKernelGGL(kern, dim3(p.num_groups * QG), dim3(256), 0, stream, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("bf16 LSTM layer launch: %s", hipGetErrorString(e)); return FOV_ERR_LAUNCH; }

@@ -84,7 +84,8 @@ __global__ __launch_bounds__(256, 1) void lstm_wide_kernel(LstmParams p) {
     constexpr int H4 = 4 * WH;
     // epoch tags continue from the workspace header, a poisoned workspace skips the body (xch_common.h)
     const bool xch_used = steps > 1;
-    const unsigned epoch_base = xch_used ? xch_epoch_base(p.status) : 0u;
+    __shared__ unsigned sXch[2];
+    const unsigned arrival = xch_used ? xch_arrive(p.status, sXch) : 0u;
     const bool poisoned = xch_used && xch_poisoned(p.status);
     if (tid == 0) sFlag[0] = poisoned ? 1 : 0;
 
@@ -113,8 +114,10 @@ __global__ __launch_bounds__(256, 1) void lstm_wide_kernel(LstmParams p) {
     const unsigned gvoff = (unsigned)((tid >> 5) * WH + (tid & 31)) * 8u;
     const int lbase = (tid >> 5) * WLD + (tid & 31);
     constexpr unsigned PARITY = WBT * WH * 8u;
-    unsigned epoch = epoch_base;
     __syncthreads();
+    XchTicket ticket = {0u, 0u, 0u};
+    if (xch_used) ticket = xch_ticket(sXch, arrival);
+    unsigned epoch = ticket.base;
     bool aborted = sFlag[0] != 0;
 
     wu32x2 v[WNG];
@@ -308,7 +311,7 @@ __global__ __launch_bounds__(256, 1) void lstm_wide_kernel(LstmParams p) {
             }
         }
     }
-    if (xch_used) xch_leave(p.status, (unsigned)p.epoch_span);
+    if (xch_used) xch_settle(p.status, ticket, (unsigned)p.epoch_span);
 }
 
 }  // namespace

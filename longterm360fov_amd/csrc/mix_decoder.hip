@@ -165,7 +165,8 @@ __global__ __launch_bounds__(256, 1) void mix_decoder_kernel(MixDecParams p) {
     const int H4 = 4 * MH;
 
     // epoch tags continue from the workspace header, a poisoned workspace skips the body (xch_common.h)
-    const unsigned epoch_base = xch_epoch_base(p.status);
+    __shared__ unsigned sXch[2];
+    const unsigned arrival = xch_arrive(p.status, sXch);
     const bool poisoned = xch_poisoned(p.status);
     if (tid == 0) sFlag[0] = poisoned ? 1 : 0;
     // ---- resident weights ----
@@ -218,11 +219,12 @@ __global__ __launch_bounds__(256, 1) void mix_decoder_kernel(MixDecParams p) {
     const int lbase = (tid >> 5) * MLDH + (tid & 31);
     constexpr unsigned LAYER_BYTES = 2u * MBT * MH * 8u;    // both parities of one layer
     constexpr unsigned PARITY_BYTES = MBT * MH * 8u;
-    unsigned epoch = epoch_base;
 #ifdef FOV_STAMPS
     const bool stamp_on = (blockIdx.x == 5 && tid == 0);
 #endif
     __syncthreads();
+    const XchTicket ticket = xch_ticket(sXch, arrival);
+    unsigned epoch = ticket.base;
     bool aborted = sFlag[0] != 0;
 
     // gather: issue / complete.  v[] stays in registers between the two so MFMAs can run in between.
@@ -493,7 +495,7 @@ __global__ __launch_bounds__(256, 1) void mix_decoder_kernel(MixDecParams p) {
             }
         }
     }
-    xch_leave(p.status, (unsigned)p.epoch_span);
+    xch_settle(p.status, ticket, (unsigned)p.epoch_span);
 }
 
 // K2 (H,4H) -> fragments in the order recur_stream reads them:

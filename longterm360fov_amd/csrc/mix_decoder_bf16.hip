@@ -43,22 +43,16 @@ __global__ __launch_bounds__(256, 1) void mix_decoder_bf16_kernel(MixDecParams p
     const int col0 = hi * QH + unit, col1 = (2 + hi) * QH + unit;
     constexpr int H4 = 4 * QH;
 
-    const unsigned epoch_base = xch_epoch_base(p.status);
+    __shared__ unsigned sXch[2];
+    const unsigned arrival = xch_arrive(p.status, sXch);
     const bool poisoned = xch_poisoned(p.status);
     if (tid == 0) sFlag[0] = poisoned ? 1 : 0;
     // ---- resident weights (packed bf16 B fragments) ----
     qu32x4 w1[8][2], wk2[8][2], w2[8][2], wk1[1][2];
-#pragma unroll
-    for (int kb = 0; kb < 8; ++kb) {
-        w1[kb][0] = load_bfrag(p.R1, H4, QH, kb, g4, col0);
-        w1[kb][1] = load_bfrag(p.R1, H4, QH, kb, g4, col1);
-        wk2[kb][0] = load_bfrag(p.K2p, H4, QH, kb, g4, col0);   // K2p: here the plain (H,4H) kernel of layer 2
-        wk2[kb][1] = load_bfrag(p.K2p, H4, QH, kb, g4, col1);
-        w2[kb][0] = load_bfrag(p.R2, H4, QH, kb, g4, col0);
-        w2[kb][1] = load_bfrag(p.R2, H4, QH, kb, g4, col1);
-    }
-    wk1[0][0] = load_bfrag(p.K1, H4, O, 0, g4, col0);           // K1 (O <= 8 rows): one zero-padded k-block
-    wk1[0][1] = load_bfrag(p.K1, H4, O, 0, g4, col1);
+    load_weight_set<8>(w1, p.R1, H4, QH, g4, col0, col1);
+    load_weight_set<8>(wk2, p.K2p, H4, QH, g4, col0, col1);    // K2p: here the plain (H,4H) kernel of layer 2
+    load_weight_set<8>(w2, p.R2, H4, QH, g4, col0, col1);
+    load_weight_set<1>(wk1, p.K1, H4, O, g4, col0, col1);      // K1 (O <= 8 rows): one zero-padded k-block
     const float b1v[2] = {p.b1[col0], p.b1[col1]}, b2v[2] = {p.b2[col0], p.b2[col1]};
     const float bdv = ((tid & 15) < O) ? p.bd[tid & 15] : 0.f;   // Dense bias of this thread's head output
     // Dense kernel as B fragments: wave w contracts hidden units [64w, 64w + 64) = k-blocks 2w, 2w + 1; column n = output
@@ -79,8 +73,9 @@ __global__ __launch_bounds__(256, 1) void mix_decoder_bf16_kernel(MixDecParams p
     const int my_row0 = 4 * g4 + 2 * hi;
     const unsigned pub_off = (unsigned)((my_row0 >> 1) * QH + unit) * 8u;
     constexpr unsigned LAYER_BYTES = 2u * Q_TILE_BYTES;
-    unsigned epoch = epoch_base;
     __syncthreads();
+    const XchTicket ticket = xch_ticket(sXch, arrival);
+    unsigned epoch = ticket.base;
     bool aborted = sFlag[0] != 0;
     QGather gq;
 
@@ -235,7 +230,7 @@ __global__ __launch_bounds__(256, 1) void mix_decoder_bf16_kernel(MixDecParams p
             }
         }
     }
-    xch_leave(p.status, (unsigned)p.epoch_span);
+    xch_settle(p.status, ticket, (unsigned)p.epoch_span);
 }
 
 }  // namespace

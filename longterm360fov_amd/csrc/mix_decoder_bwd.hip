@@ -116,7 +116,8 @@ __global__ __launch_bounds__(256, 1) void mix_decoder_bwd_kernel(MixDecBwdParams
     const int unit = 32 * slice + ul;
     const int my_row0 = 4 * g4 + 2 * hi;
     // epoch tags continue from the workspace header, a poisoned workspace skips the body (xch_common.h)
-    const unsigned epoch_base = xch_epoch_base(p.status);
+    __shared__ unsigned sXch[2];
+    const unsigned arrival = xch_arrive(p.status, sXch);
     const bool poisoned = xch_poisoned(p.status);
     if (tid == 0) sFlag[0] = poisoned ? 1 : 0;
 
@@ -163,7 +164,7 @@ __global__ __launch_bounds__(256, 1) void mix_decoder_bwd_kernel(MixDecBwdParams
     const __amdgpu_buffer_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc(gbase, 0, (int)(2 * MB2 * 8), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(gbase + 2 * MB2, 0, (int)(2 * MB1 * 8), 0x00020000);
     const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(gbase + 2 * MB2 + 2 * MB1, 0, (int)(2 * MBX * 8), 0x00020000);
-    unsigned epoch = epoch_base;
+    unsigned epoch = 0;
     bool aborted = false;
 #ifdef FOV_STAMPS
     const bool stamp_on = (blockIdx.x == 5 && tid == 0);
@@ -223,6 +224,8 @@ __global__ __launch_bounds__(256, 1) void mix_decoder_bwd_kernel(MixDecBwdParams
         }
     };
     __syncthreads();
+    const XchTicket ticket = xch_ticket(sXch, arrival);
+    epoch = ticket.base;
     aborted = sFlag[0] != 0;
 
     for (int tile = group; tile < p.num_tiles && !aborted; tile += p.num_groups) {
@@ -475,7 +478,7 @@ __global__ __launch_bounds__(256, 1) void mix_decoder_bwd_kernel(MixDecBwdParams
             }
         }
     }
-    xch_leave(p.status, (unsigned)p.epoch_span);
+    xch_settle(p.status, ticket, (unsigned)p.epoch_span);
 }
 
 // K2 (H,4H) -> K2^T fragments in the order the kernel reads them:

@@ -8,7 +8,8 @@
 //     [256 + kXchBytes, ...)   whatever else the entry point keeps in its workspace (packed weights, carried state)
 //
 // Epoch tags are MONOTONE ACROSS LAUNCHES: a launch reads the base from the header, every tag it writes lies in
-// (base, base + span], and the last workgroup to leave adds `span` to the base.  Stale granules of any earlier
+// (base, base + span], and the last workgroup to ARRIVE (= the moment every workgroup has read the base) writes
+// base + span for the next launch - no workgroup waits for another at either end of a kernel.  Stale granules of any earlier
 // launch (of any kernel, any shape) therefore carry smaller tags than anything a later launch waits for, and the
 // per-call memset of the granule area - a 5 us fill kernel in front of every launch - is gone.
 //
@@ -21,11 +22,10 @@ namespace fov {
 
 enum : int {
     ST_TIMEOUT = 0,     // != 0: a bounded in-kernel wait gave up; cleared only by fov_check_status
-    ST_SAFE_COUNT = 1,  // workgroups of the running launch that use the placement-independent (sc1) exchange
-    ST_DONE = 2,        // workgroups of the running launch that have left
-    ST_SAFE_LAST = 3,   // ST_SAFE_COUNT of the last completed launch (fov_exchange_mode)
-    ST_EPOCH = 4,       // epoch base: every tag written so far is <= this value
-    ST_LAUNCHES = 5,    // completed exchange launches (diagnostic)
+    ST_ARRIVED = 1,     // workgroups of the running launch that have read the header (self-resetting)
+    ST_LAUNCHES = 2,    // exchange launches whose workgroups have all arrived
+    ST_EPOCH = 3,       // epoch base: every tag written by launches < ST_LAUNCHES is <= this value
+    ST_SAFE0 = 4,       // ST_SAFE0 + (launch & 1): workgroups of that launch on the placement-independent (sc1) exchange
 };
 
 constexpr size_t kXchBytes = (size_t)64 << 20;   // fixed granule area: the largest user (fused decoder backward, 32 groups) needs 50.9 MB
@@ -33,25 +33,55 @@ constexpr size_t kXchBytes = (size_t)64 << 20;   // fixed granule area: the larg
 __device__ __forceinline__ unsigned xch_status_load(const unsigned* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// epoch base of this launch.  Uniform over the grid: the word is only rewritten by the last workgroup to leave.
-__device__ __forceinline__ unsigned xch_epoch_base(const unsigned* status) { return xch_status_load(status + ST_EPOCH); }
 __device__ __forceinline__ bool xch_poisoned(const unsigned* status) { return xch_status_load(status + ST_TIMEOUT) != 0u; }
 __device__ __forceinline__ void xch_give_up(unsigned* status) {
     __hip_atomic_store(status + ST_TIMEOUT, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// Every workgroup of an exchanging launch calls this exactly once, on every path, as its last action.
-__device__ __forceinline__ void xch_leave(unsigned* status, unsigned span) {
-    __syncthreads();
+
+// What a workgroup takes from the header when it starts.  `base` and `launch` are uniform over the grid: the words are
+// only rewritten by the LAST workgroup to arrive, i.e. after every workgroup of the launch has read them.
+struct XchTicket {
+    unsigned base;      // epoch base of this launch: its tags lie in (base, base + span]
+    unsigned launch;    // index of this launch on the workspace
+    unsigned arrival;   // thread 0 only: this workgroup's arrival number
+};
+
+// Kernel entry, in two halves around the prologue's first workgroup barrier: THREAD 0 reads the header, takes the
+// arrival ticket and leaves base / launch in two LDS words (`lds2`); after the barrier every thread picks them up with
+// xch_ticket().  Only one thread reads the header: a wave that starts late must not read it by itself - the last
+// arriver (of another workgroup) may already have rewritten it for the next launch.
+__device__ __forceinline__ unsigned xch_arrive(unsigned* status, unsigned* lds2) {
+    unsigned arrival = 0;
     if (threadIdx.x == 0) {
-        const unsigned done = __hip_atomic_fetch_add(status + ST_DONE, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-        if (done == gridDim.x * gridDim.y * gridDim.z - 1u) {
-            const unsigned safe = __hip_atomic_exchange(status + ST_SAFE_COUNT, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(status + ST_SAFE_LAST, safe, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(status + ST_DONE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_fetch_add(status + ST_LAUNCHES, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_fetch_add(status + ST_EPOCH, span, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        unsigned base = xch_status_load(status + ST_EPOCH);
+        unsigned launch = xch_status_load(status + ST_LAUNCHES);
+        // both words are read before the ticket is taken: the last arriver may rewrite them at once
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(base), "+v"(launch)::"memory");
+        arrival = __hip_atomic_fetch_add(status + ST_ARRIVED, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        lds2[0] = base;
+        lds2[1] = launch;
     }
+    return arrival;
+}
+__device__ __forceinline__ XchTicket xch_ticket(const unsigned* lds2, unsigned arrival) {
+    XchTicket t;
+    t.base = lds2[0];
+    t.launch = lds2[1];
+    t.arrival = arrival;
+    return t;
+}
+// Thread 0 calls it once, any time later (the kernels do at their very end, when the ticket's round trip is long over):
+// the last arriver publishes the header of the NEXT launch.  Nothing here waits for the other workgroups.
+__device__ __forceinline__ void xch_settle(unsigned* status, const XchTicket& t, unsigned span) {
+    if (threadIdx.x == 0 && t.arrival == gridDim.x * gridDim.y * gridDim.z - 1u) {
+        __hip_atomic_store(status + ST_ARRIVED, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(status + ST_SAFE0 + ((t.launch + 1u) & 1u), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // next launch's counter
+        __hip_atomic_store(status + ST_EPOCH, t.base + span, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(status + ST_LAUNCHES, t.launch + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+__device__ __forceinline__ void xch_count_safe(unsigned* status, const XchTicket& t) {
+    __hip_atomic_fetch_add(status + ST_SAFE0 + (t.launch & 1u), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 }  // namespace fov

@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Per-segment cycle shares of one step of the bf16 LSTM layer kernel (diagnostic build: make -C longterm360fov_amd/csrc
+stamps).  One wave (block 5, wave 0) stamps s_memtime at the phase boundaries."""
+import ctypes
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from longterm360fov_amd import _lib  # noqa: E402
+
+_lib.LIB_PATH = os.path.join(ROOT, "longterm360fov_amd", "lib", "libfov360_hip_stamps.so")
+from longterm360fov_amd import ops  # noqa: E402
+from oracle import fov_oracle as O  # noqa: E402
+
+SEG = ["x staging (LDS write of x_{t+1}, loads of x_{t+2})", "cell update + tape stores", "publish", "barrier 1",
+       "own h -> LDS + x.K MFMAs", "gather issue", "gather wait + LDS", "barrier 2", "h.R MFMAs"]
+
+
+def main():
+    F = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+    B, T, H = 512, 10, 256
+    rng = np.random.default_rng(0)
+    K, R, b = O.init_lstm(rng, F, H, np.float32)
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+    x = d(rng.uniform(-1, 1, (B, T, F)))
+    dK, dR, db = d(K), d(R), d(b)
+    ws = ops.Workspace()
+    for _ in range(3):
+        ops.lstm_seq_bf16(x, dK, dR, db, workspace=ws)
+    ws.check()
+    L = _lib.lib()
+    buf = np.zeros((32, 12), dtype=np.uint64)
+    L.fov_debug_read_q_stamps.argtypes = [ctypes.c_void_p]
+    assert L.fov_debug_read_q_stamps(buf.ctypes.data_as(ctypes.c_void_p)) == 0
+    s = buf[:T, :10].astype(np.int64)
+    seg = np.diff(s, axis=1)
+    step = np.diff(s[:, 0])
+    e = buf[31].astype(np.int64)
+    print("F=%d: entry -> weights resident %d cycles; -> first step %d; last step end -> tiles done %d; leave %d; whole %d cycles"
+          % (F, e[1] - e[0], s[0, 0] - e[1], e[2] - s[T - 1, 9], e[3] - e[2], e[3] - e[0]))
+    print("step: median %.0f cycles (%.2f us at 2.1 GHz)" % (np.median(step), np.median(step) / 2100.0))
+    med = np.median(seg[1:T - 1], axis=0)
+    for i, v in enumerate(med):
+        print("   %-52s %8.0f cyc  %5.1f%%" % (SEG[i], v, 100.0 * v / med.sum()))
+    print("per-step segment table (cycles):")
+    for t in range(T):
+        print("   t=%d " % t + " ".join("%6d" % v for v in seg[t]))
+
+
+if __name__ == "__main__":
+    main()
