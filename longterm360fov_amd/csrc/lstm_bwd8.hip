@@ -290,6 +290,23 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd8_kernel(Bwd8Params p) {
 // registers of packed B fragments: eight contiguous floats of a row of R each), the four partial 16 x 32 tiles meet
 // in LDS and are added in wave order.
 // ---------------------------------------------------------------------------------------------------------------
+// Diagnostic build only (-DFOV_STAMPS, tools/stamp_bf16_layer.py --bwd): s_memtime stamps of one wave per step.
+#ifdef FOV_STAMPS
+__device__ unsigned long long g_b8_stamps[32][12];
+#define B8_STAMP(slot)                                                                         \
+    do {                                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                     \
+        if (stamp_on && (T - 1 - t) < 32) {                                                    \
+            unsigned long long t_;                                                             \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");        \
+            g_b8_stamps[T - 1 - t][slot] = t_;                                                 \
+        }                                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                     \
+    } while (0)
+#else
+#define B8_STAMP(slot) do { } while (0)
+#endif
+
 template <int ACT>
 __global__ __launch_bounds__(256, 1) void lstm_bwd8n_bf16_kernel(Bwd8Params p) {
     __shared__ __attribute__((aligned(16))) unsigned short sDZ[QBT * QLDZ];   // the whole dz tile, bf16
@@ -309,6 +326,10 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd8n_bf16_kernel(Bwd8Params p) {
     const unsigned arrival = xch_arrive(p.status, sXch);
     const bool poisoned = xch_poisoned(p.status);
     if (tid == 0) sFlag[0] = poisoned ? 1 : 0;
+#ifdef FOV_STAMPS
+    const bool stamp_on = (blockIdx.x == 5 && tid == 0);
+    if (stamp_on) g_b8_stamps[31][0] = __builtin_amdgcn_s_memtime();
+#endif
 
     // R^T fragments of this wave: k-block kb of gate `wave` (columns 256*wave + 32*kb + 8*g4 + j), N-tile nt (own unit 16*nt + n)
     qu32x4 rq[8][2];
@@ -335,39 +356,42 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd8n_bf16_kernel(Bwd8Params p) {
             dc[r] = (live[r] && p.dcT) ? p.dcT[(size_t)row * QH + unit] : 0.f;
             dh[r] = (live[r] && p.dhT) ? p.dhT[(size_t)row * QH + unit] : 0.f;
         }
-        float cur[5][2], nxt[5][2], dhs_cur[2], dhs_nxt[2];
-        auto load_step = [&](int t, float (&dst)[5][2], float (&dd_)[2]) {
+        // Tape of this lane's two cells, ONE step ahead: tp[0..3] = i,f,g,o and tp[4] = c of the step, tp[5] = c of the
+        // step before it (c0 / zero in front of step 0), tp[6] = dhs of the step.  The loads are UNCONDITIONAL (rows and
+        // steps clamped into the tensor, dead rows masked where dz is formed): a load inside a branch gets an
+        // s_waitcnt vmcnt(0) at the merge and the step would wait for HBM right there (measured: 3 800 cycles).
+        float cur[7][2], pre[7][2];
+        auto load_step = [&](int t, float (&dst)[7][2]) {
+            const int tc = t > 0 ? t : 0;
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
                 const int row = b0 + my_row0 + r;
-                if (t >= 0 && live[r]) {
-                    const float* rp = p.reserve + (((size_t)row * T + t) * 5) * QH + unit;
+                const size_t rowc = (size_t)(row < p.B ? row : p.B - 1);
+                const float* rp = p.reserve + ((rowc * T + tc) * 5) * QH + unit;
 #pragma unroll
-                    for (int q = 0; q < 5; ++q) dst[q][r] = rp[q * QH];
-                    dd_[r] = p.dhs ? p.dhs[((size_t)row * T + t) * QH + unit] : 0.f;
-                } else {
-#pragma unroll
-                    for (int q = 0; q < 5; ++q) dst[q][r] = 0.f;
-                    dst[4][r] = (t < 0 && live[r] && p.c0) ? p.c0[(size_t)row * QH + unit] : 0.f;   // c_{-1} = c0
-                    dd_[r] = 0.f;
-                }
+                for (int q = 0; q < 5; ++q) dst[q][r] = rp[q * QH];
+                const float* cp = tc > 0 ? rp - QH : (p.c0 ? p.c0 + rowc * QH + unit : rp);   // no c0: any valid address, masked at use
+                dst[5][r] = *cp;
+                dst[6][r] = p.dhs ? p.dhs[(rowc * T + tc) * QH + unit] : 0.f;
             }
         };
-        load_step(T - 1, cur, dhs_cur);
-        load_step(T - 2, nxt, dhs_nxt);
+        load_step(T - 1, cur);
         float dbacc[4] = {0.f, 0.f, 0.f, 0.f};
         __syncthreads();   // the previous tile's last step is done with the LDS tiles
 
         for (int t = T - 1; t >= 0; --t) {
+            B8_STAMP(0);
             ++epoch;
             const unsigned par = (epoch & 1u) * Q_DZ_BYTES;
+
+            B8_STAMP(1);
             // ---- pointwise: dz of this lane's two cells ----
             float dzv[2][4];
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
                 const float ig = cur[0][r], fg = cur[1][r], gg = cur[2][r], og = cur[3][r], cc = cur[4][r];
-                const float cprev = nxt[4][r];
-                const float dht = dh[r] + dhs_cur[r];
+                const float cprev = (t > 0 || p.c0) ? cur[5][r] : 0.f;   // step 0 without a given state: c_{-1} = 0
+                const float dht = dh[r] + cur[6][r];
                 const float tc = tanh_f(cc);
                 const float dcv = dc[r] + dht * og * (1.f - tc * tc);
                 dzv[r][0] = live[r] ? dcv * gg * b8_act_grad<ACT>(ig) : 0.f;
@@ -376,11 +400,16 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd8n_bf16_kernel(Bwd8Params p) {
                 dzv[r][3] = live[r] ? dht * tc * b8_act_grad<ACT>(og) : 0.f;
                 dc[r] = dcv * fg;
             }
+            B8_STAMP(2);
             // publish first (the partners wait for it), then the tape traffic of this step
             unsigned dzp[4];
 #pragma unroll
             for (int g = 0; g < 4; ++g) dzp[g] = pack_bf16(dzv[0][g], dzv[1][g]);
             q_dz_publish(rs, par, my_row0, unit, dzp, epoch, sDZ);
+            // Everything that does not depend on the partners goes between the publish and the gather: an sc1 store
+            // takes about a microsecond to become visible, a sweep issued earlier comes back stale and costs a second
+            // round trip.  The tape of step t-1 is requested here, a whole step before its use.
+            load_step(t - 1, pre);
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
 #pragma unroll
@@ -391,16 +420,12 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd8n_bf16_kernel(Bwd8Params p) {
                     for (int g = 0; g < 4; ++g) zp[g * QH] = dzv[r][g];
                 }
             }
-            // rotate the tape pipeline and request step t-2
-#pragma unroll
-            for (int q = 0; q < 5; ++q)
-#pragma unroll
-                for (int r = 0; r < 2; ++r) cur[q][r] = nxt[q][r];
-#pragma unroll
-            for (int r = 0; r < 2; ++r) dhs_cur[r] = dhs_nxt[r];
-            load_step(t - 2, nxt, dhs_nxt);
+            B8_STAMP(3);
+            B8_STAMP(4);
             if (!q_dz_gather(rs, par, slice, tid, epoch, sDZ, p.status)) sFlag[0] = 1;
+            B8_STAMP(5);
             __syncthreads();   // barrier A: the whole dz tile is in LDS
+            B8_STAMP(6);
             if (sFlag[0]) { aborted = true; break; }
             // ---- this wave's share of dh_{t-1}[16 x 32 own units]: gate `wave`'s 256 columns ----
             f32x4 acc[2];
@@ -420,12 +445,19 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd8n_bf16_kernel(Bwd8Params p) {
             for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) sRed[(wave * QBT + 4 * g4 + r) * 33 + 16 * nt + n] = acc[nt][r];
+            B8_STAMP(7);
             __syncthreads();   // barrier B: the four partial tiles are in LDS; every wave is done reading the dz tile
+            B8_STAMP(8);
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
                 const float* q = sRed + (my_row0 + r) * 33 + ul;
                 dh[r] = (q[0] + q[QBT * 33]) + (q[2 * QBT * 33] + q[3 * QBT * 33]);
             }
+#pragma unroll
+            for (int q = 0; q < 7; ++q)
+#pragma unroll
+                for (int r = 0; r < 2; ++r) cur[q][r] = pre[q][r];   // requested most of a step ago: long landed
+            B8_STAMP(9);
         }
         if (!aborted && p.db_part) {
 #pragma unroll
@@ -447,10 +479,19 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd8n_bf16_kernel(Bwd8Params p) {
             }
         }
     }
+#ifdef FOV_STAMPS
+    if (stamp_on) g_b8_stamps[31][1] = __builtin_amdgcn_s_memtime();
+#endif
     xch_settle(p.status, ticket, (unsigned)p.epoch_span);
 }
 
 }  // namespace
+
+#ifdef FOV_STAMPS
+extern "C" int fov_debug_read_b8_stamps(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_b8_stamps), sizeof(unsigned long long) * 32 * 12);
+}
+#endif
 
 // one workgroup per CU: groups of eight fill the chip up to 32 tiles; beyond that the 4-group kernel is as good
 bool bwd8_preferred(int B, int H) { return H == QH && B > 0 && B <= 32 * QBT; }

@@ -169,6 +169,7 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_bf16_kernel(LstmParams p) {
             }
             Q_STAMP(1);
             // ---- cell update (fp32) ----
+            float gt[2][4];   // activated gates: the tape stores wait until the publish and the gather are out
             {
                 float zi[2], zf[2], zg[2], zo[2];
                 gates_of_lane(acc, hi, zi, zf, zg, zo);
@@ -177,14 +178,7 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_bf16_kernel(LstmParams p) {
                     const float ig = rec_act<ACT>(zi[r]), fg = rec_act<ACT>(zf[r]), gg = tanh_f(zg[r]), og = rec_act<ACT>(zo[r]);
                     c[r] = fmaf(fg, c[r], ig * gg);
                     hc[r] = og * tanh_f(c[r]);
-                    const int row = b0 + my_row0 + r;
-                    if (row < p.B) {
-                        if (p.reserve) {
-                            float* rp = p.reserve + (((size_t)row * p.T + t) * 5) * QH + unit;
-                            rp[0] = ig; rp[QH] = fg; rp[2 * QH] = gg; rp[3 * QH] = og; rp[4 * QH] = c[r];
-                        }
-                        if (p.hs) p.hs[((size_t)row * p.T + t) * QH + unit] = hc[r];
-                    }
+                    gt[r][0] = ig; gt[r][1] = fg; gt[r][2] = gg; gt[r][3] = og;
                 }
             }
             Q_STAMP(2);
@@ -210,8 +204,19 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_bf16_kernel(LstmParams p) {
             // moment and an sc1 store takes most of a microsecond to become visible)
             if (more) qmm<0, NKB, NKB>(acc, sX + ((t + 1) & 1) * QBT * QLD, n, g4, wk);
             Q_STAMP(5);
+            if (do_xch) q_gather_issue(gq, xrs, par, slice, tid);
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {   // tape of the step, under the gather's round trip
+                const int row = b0 + my_row0 + r;
+                if (row < p.B) {
+                    if (p.reserve) {
+                        float* rp = p.reserve + (((size_t)row * p.T + t) * 5) * QH + unit;
+                        rp[0] = gt[r][0]; rp[QH] = gt[r][1]; rp[2 * QH] = gt[r][2]; rp[3 * QH] = gt[r][3]; rp[4 * QH] = c[r];
+                    }
+                    if (p.hs) p.hs[((size_t)row * p.T + t) * QH + unit] = hc[r];
+                }
+            }
             if (do_xch) {
-                q_gather_issue(gq, xrs, par, slice, tid);
                 Q_STAMP(6);
                 if (!q_gather_finish(gq, xrs, par, slice, tid, epoch, sH, p.status)) sFlag[0] = 1;
             }

@@ -120,6 +120,7 @@ __global__ __launch_bounds__(256, 1) void mix_decoder_bf16_kernel(MixDecParams p
                 qmfma(acc1[0], xa, wk1[0][0]);
                 qmfma(acc1[1], xa, wk1[0][1]);
             }
+            float gt[2][4];   // activated gates of the step: the tape stores wait until the publish and the gather are out
             {
                 float zi[2], zf[2], zg[2], zo[2];
                 gates_of_lane(acc1, hi, zi, zf, zg, zo);
@@ -128,15 +129,7 @@ __global__ __launch_bounds__(256, 1) void mix_decoder_bf16_kernel(MixDecParams p
                     const float ig = rec_act<ACT>(zi[r]), fg = rec_act<ACT>(zf[r]), gg = tanh_f(zg[r]), og = rec_act<ACT>(zo[r]);
                     c1[r] = fmaf(fg, c1[r], ig * gg);
                     h1c[r] = og * tanh_f(c1[r]);
-                    if (TRAIN) {
-                        const int row = b0 + my_row0 + r;
-                        if (row < p.B) {
-                            float* rp = p.res1 + (((size_t)t * p.B + row) * 5) * QH + unit;
-                            rp[0] = ig; rp[QH] = fg; rp[2 * QH] = gg; rp[3 * QH] = og; rp[4 * QH] = c1[r];
-                            p.H1[((size_t)t * p.B + row) * QH + unit] = h1c[r];
-                            p.C1[((size_t)t * p.B + row) * QH + unit] = c1[r];
-                        }
-                    }
+                    gt[r][0] = ig; gt[r][1] = fg; gt[r][2] = gg; gt[r][3] = og;
                 }
             }
             // publish h1_t, write the own cells into the tile, run h2_{t-1} . R2 under the exchange
@@ -148,6 +141,18 @@ __global__ __launch_bounds__(256, 1) void mix_decoder_bf16_kernel(MixDecParams p
             acc2[1] = (f32x4){b2v[1], b2v[1], b2v[1], b2v[1]};
             qmm<0, 8, 8>(acc2, sH2, n, g4, w2);
             q_gather_issue(gq, xrs, par, slice, tid);
+            if (TRAIN) {   // tape of layer 1, under the gather's round trip
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    const int row = b0 + my_row0 + r;
+                    if (row < p.B) {
+                        float* rp = p.res1 + (((size_t)t * p.B + row) * 5) * QH + unit;
+                        rp[0] = gt[r][0]; rp[QH] = gt[r][1]; rp[2 * QH] = gt[r][2]; rp[3 * QH] = gt[r][3]; rp[4 * QH] = c1[r];
+                        p.H1[((size_t)t * p.B + row) * QH + unit] = h1c[r];
+                        p.C1[((size_t)t * p.B + row) * QH + unit] = c1[r];
+                    }
+                }
+            }
             if (!q_gather_finish(gq, xrs, par, slice, tid, epoch, sH1, p.status)) sFlag[0] = 1;
             __syncthreads();   // barrier D: the whole h1_t tile is in LDS; every wave is done reading sH2
             if (sFlag[0]) { aborted = true; break; }
@@ -161,15 +166,7 @@ __global__ __launch_bounds__(256, 1) void mix_decoder_bf16_kernel(MixDecParams p
                     const float ig = rec_act<ACT>(zi[r]), fg = rec_act<ACT>(zf[r]), gg = tanh_f(zg[r]), og = rec_act<ACT>(zo[r]);
                     c2[r] = fmaf(fg, c2[r], ig * gg);
                     h2c[r] = og * tanh_f(c2[r]);
-                    if (TRAIN) {
-                        const int row = b0 + my_row0 + r;
-                        if (row < p.B) {
-                            float* rp = p.res2 + (((size_t)t * p.B + row) * 5) * QH + unit;
-                            rp[0] = ig; rp[QH] = fg; rp[2 * QH] = gg; rp[3 * QH] = og; rp[4 * QH] = c2[r];
-                            p.H2[((size_t)t * p.B + row) * QH + unit] = h2c[r];
-                            p.C2[((size_t)t * p.B + row) * QH + unit] = c2[r];
-                        }
-                    }
+                    gt[r][0] = ig; gt[r][1] = fg; gt[r][2] = gg; gt[r][3] = og;
                 }
             }
             const unsigned h2pair = pack_bf16(h2c[0], h2c[1]);
@@ -182,6 +179,18 @@ __global__ __launch_bounds__(256, 1) void mix_decoder_bf16_kernel(MixDecParams p
             acc1[1] = (f32x4){b1v[1], b1v[1], b1v[1], b1v[1]};
             if (more) qmm<0, 8, 8>(acc1, sH1, n, g4, w1);
             q_gather_issue(gq, xrs, LAYER_BYTES + par, slice, tid);
+            if (TRAIN) {   // tape of layer 2, under the gather's round trip
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    const int row = b0 + my_row0 + r;
+                    if (row < p.B) {
+                        float* rp = p.res2 + (((size_t)t * p.B + row) * 5) * QH + unit;
+                        rp[0] = gt[r][0]; rp[QH] = gt[r][1]; rp[2 * QH] = gt[r][2]; rp[3 * QH] = gt[r][3]; rp[4 * QH] = c2[r];
+                        p.H2[((size_t)t * p.B + row) * QH + unit] = h2c[r];
+                        p.C2[((size_t)t * p.B + row) * QH + unit] = c2[r];
+                    }
+                }
+            }
             if (!q_gather_finish(gq, xrs, LAYER_BYTES + par, slice, tid, epoch, sH2, p.status)) sFlag[0] = 1;
             __syncthreads();   // barrier G: the whole h2_t tile is in LDS
             if (sFlag[0]) { aborted = true; break; }

@@ -93,23 +93,36 @@ __global__ __launch_bounds__(256, 1) void mix_decoder_bwd_bf16_kernel(MixDecBwdP
         if (tid < QBT * 8) sDX[tid] = 0.f;       // no feedback gradient into the last step
         float dc1[2] = {0.f, 0.f}, dc2[2] = {0.f, 0.f}, dh1r[2] = {0.f, 0.f}, dh2r[2] = {0.f, 0.f};
         __syncthreads();
-        for (int t = T - 1; t >= 0; --t) {
-            ++epoch;
-            const unsigned par = (epoch & 1u) * Q_DZ_BYTES;
-            // tape of layer 2 for this lane's two cells: requested now, consumed after the head
-            float tp[2][6];
+        // Tapes (reserve i,f,g,o,c and the previous cell state) of this lane's two cells, both layers, one step AHEAD: the
+        // loads of step t-1 are issued at the top of step t.  Vector-memory operations retire in order - HBM loads issued
+        // right in front of a gather would put their whole latency into the gather's wait.
+        float tq2[2][6], tq1[2][6];
+        // UNCONDITIONAL loads (step and row clamped into the tape; dead rows are masked where dz is formed): a load inside
+        // a branch gets an s_waitcnt vmcnt(0) at the merge and the step would wait for HBM right there
+        auto load_tape = [&](int t, const float* res, const float* Cst, float (&dst)[2][6]) {
+            const size_t tc = (size_t)(t > 0 ? t : 0);
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
                 const int row = b0 + my_row0 + r;
+                const size_t rowc = (size_t)(row < p.B ? row : p.B - 1);
+                const float* rp = res + ((tc * p.B + rowc) * 5) * QH + unit;
 #pragma unroll
-                for (int k = 0; k < 6; ++k) tp[r][k] = 0.f;
-                if (row < p.B) {
-                    const float* rp = p.res2 + (((size_t)t * p.B + row) * 5) * QH + unit;
-#pragma unroll
-                    for (int k = 0; k < 5; ++k) tp[r][k] = rp[k * QH];
-                    tp[r][5] = p.C2[((size_t)t * p.B + row) * QH + unit];
-                }
+                for (int k = 0; k < 5; ++k) dst[r][k] = rp[k * QH];
+                dst[r][5] = Cst[(tc * p.B + rowc) * QH + unit];
             }
+        };
+        load_tape(T - 1, p.res2, p.C2, tq2);
+        load_tape(T - 1, p.res1, p.C1, tq1);
+        for (int t = T - 1; t >= 0; --t) {
+            ++epoch;
+            const unsigned par = (epoch & 1u) * Q_DZ_BYTES;
+            float tp[2][6], tp1[2][6];
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int k = 0; k < 6; ++k) { tp[r][k] = tq2[r][k]; tp1[r][k] = tq1[r][k]; }
+            load_tape(t - 1, p.res2, p.C2, tq2);
+            load_tape(t - 1, p.res1, p.C1, tq1);
             // ================= head backward (every workgroup, its 16 sequences) =================
             {
                 const int brow = b0 + hrow;
@@ -162,19 +175,6 @@ __global__ __launch_bounds__(256, 1) void mix_decoder_bwd_bf16_kernel(MixDecBwdP
                     }
                 }
             }
-            // tape of layer 1: requested under the exchange wait below
-#pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                const int row = b0 + my_row0 + r;
-#pragma unroll
-                for (int k = 0; k < 6; ++k) tp[r][k] = 0.f;
-                if (row < p.B) {
-                    const float* rp = p.res1 + (((size_t)t * p.B + row) * 5) * QH + unit;
-#pragma unroll
-                    for (int k = 0; k < 5; ++k) tp[r][k] = rp[k * QH];
-                    tp[r][5] = p.C1[((size_t)t * p.B + row) * QH + unit];
-                }
-            }
             if (!q_dz_gather(rs, LAYER_BYTES + par, slice, tid, epoch, sDZ, p.status)) sFlag[1] = 1;
             __syncthreads();   // barrier 2: the whole dz2 tile is in LDS
             if (sFlag[1]) { aborted = true; break; }
@@ -216,7 +216,7 @@ __global__ __launch_bounds__(256, 1) void mix_decoder_bwd_bf16_kernel(MixDecBwdP
 #pragma unroll
                 for (int r = 0; r < 2; ++r) {
                     const int row = b0 + my_row0 + r;
-                    const float ig = tp[r][0], fg = tp[r][1], gg = tp[r][2], og = tp[r][3], ct = tp[r][4], cp = tp[r][5];
+                    const float ig = tp1[r][0], fg = tp1[r][1], gg = tp1[r][2], og = tp1[r][3], ct = tp1[r][4], cp = tp1[r][5];
                     const float tc = tanh_f(ct);
                     const float dh = dh1in[r] + dh1r[r];
                     const float dct = dc1[r] + dh * og * (1.f - tc * tc);

@@ -51,5 +51,38 @@ def main():
         print("   t=%d " % t + " ".join("%6d" % v for v in seg[t]))
 
 
+def main_bwd():
+    """python tools/stamp_bf16_layer.py --bwd : the N-split bf16 BPTT kernel (lstm_bwd8n_bf16_kernel)."""
+    SEGB = ["tape loads of step t-2 (issue)", "gates backward", "publish dz + own LDS + dz stores", "rotate", "gather (issue, wait, LDS)",
+            "barrier A", "MFMAs + partials -> LDS", "barrier B", "sum of the four partials"]
+    B, T, F, H = 512, 10, 256, 256
+    rng = np.random.default_rng(0)
+    K, R, b = O.init_lstm(rng, F, H, np.float32)
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+    x = d(rng.uniform(-1, 1, (B, T, F)))
+    dK, dR, db = d(K), d(R), d(b)
+    hs, hT, cT, res = ops.lstm_seq_bf16(x, dK, dR, db)
+    dhs = d(0.1 * rng.standard_normal((B, T, H)))
+    sc = ops.Scratch()
+    for _ in range(3):
+        ops.lstm_seq_bwd(x, dK, dR, hs, res, dhs=dhs, need_state_grads=True, scratch=sc, dtype="bf16")
+    sc.check()
+    L = _lib.lib()
+    buf = np.zeros((32, 12), dtype=np.uint64)
+    L.fov_debug_read_b8_stamps.argtypes = [ctypes.c_void_p]
+    assert L.fov_debug_read_b8_stamps(buf.ctypes.data_as(ctypes.c_void_p)) == 0
+    s = buf[:T, :10].astype(np.int64)
+    seg = np.diff(s, axis=1)
+    step = np.diff(s[:, 0])
+    e = buf[31].astype(np.int64)
+    print("BPTT bf16: entry -> first step %d cycles; whole %d cycles; step: median %.0f cycles (%.2f us at 2.1 GHz)"
+          % (s[0, 0] - e[0], e[1] - e[0], np.median(step), np.median(step) / 2100.0))
+    med = np.median(seg[1:T - 1], axis=0)
+    for i, v in enumerate(med):
+        print("   %-52s %8.0f cyc  %5.1f%%" % (SEGB[i], v, 100.0 * v / med.sum()))
+    for t in range(T):
+        print("   step %d " % t + " ".join("%6d" % v for v in seg[t]))
+
+
 if __name__ == "__main__":
-    main()
+    main_bwd() if "--bwd" in sys.argv else main()
