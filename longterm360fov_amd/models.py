@@ -38,6 +38,51 @@ def _as_f32(a):
     return np.ascontiguousarray(a, dtype=np.float32)
 
 
+# ---- MFMA coverage for widths the persistent kernels are not built for (the reference ships latent_dim = 32,
+# given_others_gt_mean_var_seq2seq.py:38): the layer is run at the next supported width with zero-padded weights.
+# This is EXACT: a padded unit has zero kernel / recurrent columns and zero bias, so its gates are sigma(0), tanh(0) = 0
+# and, from a zero state, c stays 0 and h = o * tanh(0) = 0 for every step; zero recurrent ROWS keep it from reaching
+# the real units. ----
+MFMA_WIDTHS = (64, 128, 256)
+
+
+def padded_width(H, widths=MFMA_WIDTHS):
+    """The width a layer of H units runs at on the MFMA kernels (H itself when supported), or None (H > 256)."""
+    for w in widths:
+        if H <= w:
+            return w
+    return None
+
+
+def pad_lstm(K, R, b, Hp, pad_input=False):
+    """Keras LSTM weights (F,4H), (H,4H), (4H,) -> (F',4Hp), (Hp,4Hp), (4Hp,): every gate block padded with zero columns,
+    R (and K when the layer's input is itself a padded hidden sequence) with zero rows."""
+    F, H = K.shape[0], R.shape[0]
+    Fp = Hp if pad_input else F
+    Kp = np.zeros((Fp, 4 * Hp), np.float32)
+    Rp = np.zeros((Hp, 4 * Hp), np.float32)
+    bp = np.zeros(4 * Hp, np.float32)
+    for g in range(4):
+        Kp[:F, g * Hp:g * Hp + H] = K[:, g * H:(g + 1) * H]
+        Rp[:H, g * Hp:g * Hp + H] = R[:, g * H:(g + 1) * H]
+        bp[g * Hp:g * Hp + H] = b[g * H:(g + 1) * H]
+    return Kp, Rp, bp
+
+
+def pad_rows(W, Hp):
+    out = np.zeros((Hp,) + W.shape[1:], np.float32)
+    out[:W.shape[0]] = W
+    return out
+
+
+def pad_cols(a, Hp):
+    """(N,H) state -> (N,Hp) with zero columns."""
+    a = _as_f32(a)
+    out = np.zeros((a.shape[0], Hp), np.float32)
+    out[:, :a.shape[1]] = a
+    return out
+
+
 def _keras_fit(model, trainer, inputs, y, batch_size, epochs, validation_split, shuffle, callbacks, initial_epoch,
                validation_data):
     """Keras `Model.fit` loop shared by the model objects: the LAST `validation_split` fraction is held out
@@ -279,6 +324,29 @@ class Seq2SeqLSTM(KerasModelSurface):
 
     _dev = KerasModelSurface._to_device
 
+    def _run_width(self):
+        """Width the inference kernels run at: latent_dim, or the next MFMA width with zero-padded weights (exact)."""
+        H = self.latent_dim
+        if self.impl == "generic" or H in MFMA_WIDTHS:
+            return H
+        return padded_width(H) or H
+
+    def _device_weights(self):
+        import torch
+        if self._dw is None:
+            Hp, w = self._run_width(), self._w
+            if Hp != self.latent_dim:
+                pw = {}
+                pw["enc_K"], pw["enc_R"], pw["enc_b"] = pad_lstm(w["enc_K"], w["enc_R"], w["enc_b"], Hp)
+                pw["dec_K"], pw["dec_R"], pw["dec_b"] = pad_lstm(w["dec_K"], w["dec_R"], w["dec_b"], Hp)
+                pw["dense_W"], pw["dense_b"] = pad_rows(w["dense_W"], Hp), w["dense_b"]
+                for k in w:                    # subclasses' extra tensors (residual Dense, ...) are width-independent
+                    pw.setdefault(k, w[k])
+                w = pw
+            self._dw = {k: torch.from_numpy(np.ascontiguousarray(v)).to(self.device) for k, v in w.items()}
+            self._ws = self._ops().Workspace()
+        return self._dw
+
     # ---- inference -------------------------------------------------------------------------
     def predict(self, x, batch_size=None, verbose=0):
         """Training-graph forward: x = [encoder_input (N,T_in,F_enc), decoder_input (N,T_out,F_dec)]
@@ -329,18 +397,22 @@ class Seq2SeqLSTM(KerasModelSurface):
                                  act=self.recurrent_activation, impl=self.impl, return_sequences=False,
                                  workspace=self._ws)
         self._ws.check()
-        return [hT.cpu().numpy(), cT.cpu().numpy()]
+        H = self.latent_dim
+        return [hT.cpu().numpy()[:, :H], cT.cpu().numpy()[:, :H]]
 
     def _decoder_predict(self, x):
         """decoder_model.predict([target_seq (N,T,F_dec), h, c]) -> [outputs (N,T,F_dec), h, c]
         (FoV_seq2seq.py:139-148,167-168)."""
         target_seq, h, c = x
         ops, dw = self._ops(), self._device_weights()
+        H, Hp = self.latent_dim, self._run_width()
+        if Hp != H:
+            h, c = pad_cols(h, Hp), pad_cols(c, Hp)
         hs, hT, cT = ops.lstm_seq(self._dev(target_seq), dw["dec_K"], dw["dec_R"], dw["dec_b"], self._dev(h),
                                   self._dev(c), act=self.recurrent_activation, impl=self.impl, workspace=self._ws)
         y = ops.dense(hs, dw["dense_W"], dw["dense_b"], activation="tanh")
         self._ws.check()
-        return [y.cpu().numpy(), hT.cpu().numpy(), cT.cpu().numpy()]
+        return [y.cpu().numpy(), hT.cpu().numpy()[:, :H], cT.cpu().numpy()[:, :H]]
 
     # ---- training surface: KerasModelSurface (FoV_seq2seq.py:103 compile, :112-117 fit) ----
     def _make_trainer(self, optimizer):
@@ -812,11 +884,28 @@ class OthersMixingSeq2Seq(KerasModelSurface):
             cb.on_train_end()
         return hist
 
+    def _run_width(self):
+        """Width the inference kernels run at.  H < 256 (the script's latent_dim = 32): 256 with zero-padded weights,
+        so the prediction takes the fused path (wide-input layer kernel + ONE decoder launch) instead of per-step
+        launches on the generic kernels - 8x the arithmetic at H = 32 and still far faster."""
+        H = self.latent_dim
+        if self.impl == "generic" or H >= 256 or not self.fused_decoder:
+            return H
+        return 256
+
     def _device_weights(self):
         import torch
         from . import ops
         if self._dw is None:
-            self._dw = {k: torch.from_numpy(v).to(self.device) for k, v in self._w.items()}
+            Hp, w = self._run_width(), self._w
+            if Hp != self.latent_dim:
+                pw = dict(w)
+                for name, hidden_in in (("enc1", False), ("enc2", True), ("dec1", False), ("dec2", True)):
+                    pw[name + "_K"], pw[name + "_R"], pw[name + "_b"] = pad_lstm(w[name + "_K"], w[name + "_R"], w[name + "_b"], Hp,
+                                                                                 pad_input=hidden_in)
+                pw["dense_W"] = pad_rows(w["dense_W"], Hp)
+                w = pw
+            self._dw = {k: torch.from_numpy(np.ascontiguousarray(v)).to(self.device) for k, v in w.items()}
             n_oth = (self.num_user - 1) * self.num_decoder_tokens
             self._dw["mix_W_oth"] = self._dw["mix_W"][:n_oth].contiguous()
             self._dw["mix_W_pred"] = self._dw["mix_W"][n_oth:].contiguous()
@@ -830,7 +919,7 @@ class OthersMixingSeq2Seq(KerasModelSurface):
         from . import ops
         dw = self._device_weights()
         act, impl, ws = self.recurrent_activation, self.impl, self._ws
-        H, O = self.latent_dim, self.num_decoder_tokens
+        H, O = self._run_width(), self.num_decoder_tokens
         B, T_in = e.shape[0], e.shape[1]
         T_out = oth.shape[1]
         if self.dtype == "bf16":   # configs[4]: both encoder layers and the fused decoder with bf16 matrix-core operands

@@ -483,3 +483,47 @@ def test_config3_full_size_and_properties():
     perm = np.random.default_rng(0).permutation(512)
     outp = m.predict([enc[:512][perm], oth[:512][perm], dec0[:512][perm]])
     assert np.array_equal(outp, shards[0][perm]), "not batch-permutation equivariant"
+
+
+@pytest.mark.parametrize("H", [32, 40, 100, 200])
+def test_unsupported_widths_run_padded_on_the_mfma_kernels(H):
+    """Widths the persistent kernels are not built for run at the next MFMA width with zero-padded weights - exact, not
+    an approximation: the model object's answers (fused decode, encoder / decoder sampling models) match the fp64
+    oracle at the model's own width to the usual bound, and the generic kernel at the true width agrees."""
+    from longterm360fov_amd.models import Seq2SeqLSTM, _W_ORDER
+    m = Seq2SeqLSTM(latent_dim=H, seed=H)
+    assert m._run_width() in (64, 128, 256) and m._run_width() >= H
+    w = dict(zip(_W_ORDER, m.get_weights()))
+    enc, dec0, _ = O.synthetic_batch(H, 37, 6, 5)
+    ref = O.seq2seq_decode(enc.astype(np.float64), dec0.astype(np.float64), {k: v.astype(np.float64) for k, v in w.items()}, 5)
+    got = m.decode_sequence(enc, dec0, predict_step=5)
+    assert np.abs(got - ref).max() <= 2e-5
+    h, c = m.encoder_model.predict(enc)
+    assert h.shape == (37, H) and c.shape == (37, H)
+    _, rh, rc = O.lstm_layer(enc.astype(np.float64), *(w[k].astype(np.float64) for k in ("enc_K", "enc_R", "enc_b")))
+    assert np.abs(h - rh).max() <= 2e-5 and np.abs(c - rc).max() <= 2e-5
+    y, h2, c2 = m.decoder_model.predict([dec0, h, c])
+    assert y.shape == (37, 1, 6) and h2.shape == (37, H)
+    np.testing.assert_allclose(y[:, 0], got[:, 0], atol=2e-6)
+    g = Seq2SeqLSTM(latent_dim=H, seed=H, impl="generic")
+    assert g._run_width() == H
+    np.testing.assert_allclose(g.decode_sequence(enc, dec0, predict_step=5), got, atol=2e-5)
+
+
+def test_others_mixing_reference_width_takes_the_fused_path():
+    """given_others_gt_mean_var_seq2seq.py:38 ships latent_dim = 32: the prediction runs zero-padded at 256 on the
+    wide-input layer kernel + the ONE-launch decoder and matches the oracle at width 32."""
+    from longterm360fov_amd.models import OthersMixingSeq2Seq, _MIX_ORDER
+    U = 34
+    w = O.init_others_mixing(5, H=32, num_user=U, bias_noise=0.05)
+    enc, dec0, _, oth = O.synthetic_batch(6, 45, 4, 5, num_others=U - 1)
+    m = OthersMixingSeq2Seq(latent_dim=32, num_user=U)
+    m.set_weights([w[k] for k in _MIX_ORDER])
+    assert m._run_width() == 256
+    got = m.predict([enc, oth, dec0])
+    ref = O.others_mixing_forward(enc.astype(np.float64), oth.astype(np.float64), dec0.astype(np.float64),
+                                  {k: v.astype(np.float64) for k, v in w.items()})
+    assert np.abs(got - ref).max() <= 2e-5
+    g = OthersMixingSeq2Seq(latent_dim=32, num_user=U, impl="generic")
+    g.set_weights([w[k] for k in _MIX_ORDER])
+    np.testing.assert_allclose(g.predict([enc, oth, dec0]), got, atol=2e-5)
