@@ -25,8 +25,8 @@ def _monitor_op(mode, monitor):
 
 
 class ModelCheckpoint(Callback):
-    """Saves weights to `filepath.format(epoch=epoch+1, **logs)` (.npz instead of Keras' .h5: h5py
-    is not available here; same arrays, same order)."""
+    """Saves weights to `filepath.format(epoch=epoch+1, **logs)`: '.h5' names as Keras-layout HDF5 (keras_h5.py),
+    anything else as '.npz' (same arrays, same order)."""
 
     def __init__(self, filepath, monitor="val_loss", verbose=0, save_best_only=False, mode="auto", period=1):
         self.filepath, self.monitor, self.save_best_only, self.period = filepath, monitor, save_best_only, period
@@ -40,7 +40,7 @@ class ModelCheckpoint(Callback):
         if self._since < self.period:
             return
         self._since = 0
-        path = self.model.weights_path(self.filepath.format(epoch=epoch + 1, **logs))   # '.h5' names map to '.npz'
+        path = self.model.weights_path(self.filepath.format(epoch=epoch + 1, **logs))
         if self.save_best_only:
             cur = logs.get(self.monitor)
             if cur is None or not self.op(cur, self.best):

@@ -183,35 +183,51 @@ class KerasModelSurface:
 
     @staticmethod
     def weights_path(path):
-        """The file a weights path names: '.npz' as given; Keras-style '.h5' / '.hdf5' names map to '<stem>.npz' when
-        WRITING (h5py is absent: the container written here is .npz with the Keras array order); anything else gets
-        '.npz' appended - so save_weights(p) / load_weights(p) / ModelCheckpoint(p) agree for every p."""
+        """The file a weights path names: '.npz', '.h5', '.hdf5' as given, anything else gets '.npz' appended - so
+        save_weights(p) / load_weights(p) / ModelCheckpoint(p) agree for every p."""
         path = str(path)
-        low = path.lower()
-        if low.endswith(".npz"):
-            return path
-        for ext in (".h5", ".hdf5"):
-            if low.endswith(ext):
-                return path[:-len(ext)] + ".npz"
-        return path + ".npz"
+        return path if path.lower().endswith((".npz", ".h5", ".hdf5")) else path + ".npz"
+
+    def _keras_layers(self):
+        """[(layer, [(weight_name, array), ...])] the way Keras groups them: consecutive tensors that share a prefix form
+        one layer - '<p>_K', '<p>_R', '<p>_b' an LSTM / ConvLSTM2D (kernel, recurrent_kernel, bias), '<p>_W', '<p>_b' a
+        Dense / Conv (kernel, bias) - in creation order (= get_weights order)."""
+        kinds = {"K": "kernel:0", "R": "recurrent_kernel:0", "b": "bias:0", "W": "kernel:0"}
+        layers = []
+        for k in self._order:
+            prefix, _, suffix = k.rpartition("_")
+            if suffix not in kinds or not prefix:
+                prefix, suffix = k, "W"
+            if not layers or layers[-1][0] != prefix:
+                layers.append((prefix, []))
+            layers[-1][1].append(("%s/%s" % (prefix, kinds[suffix]), self._w[k]))
+        return layers
 
     def save_weights(self, path):
-        with open(self.weights_path(path), "wb") as f:
+        """'.h5' / '.hdf5' names: a Keras-layout HDF5 weight file (keras_h5.py: superblock 0, one group per layer with
+        `weight_names`, contiguous float32 datasets - what keras.Model.load_weights reads); otherwise '.npz'."""
+        path = self.weights_path(path)
+        if path.lower().endswith((".h5", ".hdf5")):
+            from .keras_h5 import write_keras_layers
+            write_keras_layers(path, self._keras_layers())
+            return
+        with open(path, "wb") as f:
             np.savez(f, **self._w)
 
     save = save_weights
 
     def load_weights(self, path):
-        """'.npz' written by save_weights (also addressed by the '.h5' name it was saved under), or a real Keras HDF5
-        weight file (model.save_weights / ModelCheckpoint of the reference, given_others...py:484,570) read by the
-        package's own HDF5 subset reader (keras_h5.py)."""
-        import os
-        p = str(path)
-        if p.lower().endswith((".h5", ".hdf5")) and os.path.exists(p):
+        """A Keras HDF5 weight file (model.save_weights / ModelCheckpoint / model.save of the reference,
+        given_others...py:484,570; read by the package's own HDF5 subset reader, keras_h5.py) or an '.npz' written by
+        save_weights.  The file's tensors must match the model's shapes one to one, in Keras's order."""
+        path = self.weights_path(path)
+        with open(path, "rb") as f:
+            magic = f.read(8)
+        if magic == b"\x89HDF\r\n\x1a\n":
             from .keras_h5 import read_keras_weights
-            self.set_weights(read_keras_weights(p, expected_shapes=[self._w[k].shape for k in self._order]))
+            self.set_weights(read_keras_weights(path, expected_shapes=[self._w[k].shape for k in self._order]))
             return
-        with np.load(self.weights_path(p)) as z:
+        with np.load(path) as z:
             self.set_weights([z[k] for k in self._order])
 
     def count_params(self):

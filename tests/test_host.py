@@ -176,3 +176,92 @@ def test_pickled_interchange_round_trip(tmp_path):
     assert a.endswith("decoded_sentence_t.p") and b.endswith("gt_sentence_list_t.p")
     back = pickle.load(open(a, "rb"))
     assert len(back) == 3 and np.array_equal(back[1], dec[1]) and np.array_equal(pickle.load(open(b, "rb"))[2], gt[2])
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# f4: Keras HDF5 weight files (longterm360fov_amd/keras_h5.py)
+# ---------------------------------------------------------------------------------------------------------------
+def _real_h5_value(k, shape):
+    """Values tests/golden/make_keras_h5_real.c wrote into the k-th tensor of its files."""
+    i = np.arange(int(np.prod(shape)), dtype=np.int64)
+    return (((37 * i + 11 * k) % 1000 - 500) / 256.0).astype(np.float32).reshape(shape)
+
+
+@pytest.mark.parametrize("name", ["keras_real_weights.h5", "keras_real_model.h5"])
+def test_keras_h5_reader_against_files_written_by_the_hdf5_library(golden_dir, name):
+    """Ground truth: files written by the real HDF5 C library (1.10.6) in the Keras layout - model.save_weights form and
+    model.save form (tree under model_weights/)."""
+    from longterm360fov_amd import keras_h5
+    layers = keras_h5.read_keras_layers(os.path.join(golden_dir, name))
+    assert [n for n, _ in layers] == ["input_1", "input_2", "lstm_1", "lstm_2", "dense_1"]
+    assert [w for w, _ in layers[2][1]] == ["lstm_1/kernel:0", "lstm_1/recurrent_kernel:0", "lstm_1/bias:0"]
+    assert [a.shape for _, a in layers[2][1]] == [(5, 16), (4, 16), (16,)]
+    assert [a.shape for _, a in layers[4][1]] == [(4, 3), (3,)]
+    k = 0
+    for _, ws in layers:
+        for _, a in ws:
+            assert a.dtype == np.float32
+            np.testing.assert_array_equal(a, _real_h5_value(k, a.shape))
+            k += 1
+    assert k == 8
+
+
+def test_keras_h5_loads_into_the_model_object_and_refuses_other_topologies(golden_dir):
+    from longterm360fov_amd.models import Seq2SeqLSTM
+    m = Seq2SeqLSTM(num_encoder_tokens=5, num_decoder_tokens=3, latent_dim=4, seed=0)
+    m.load_weights(os.path.join(golden_dir, "keras_real_weights.h5"))
+    for k, a in enumerate(m.get_weights()):
+        np.testing.assert_array_equal(a, _real_h5_value(k, a.shape))
+    m.load_weights(os.path.join(golden_dir, "keras_real_model.h5"))       # model.save() form
+    wrong = Seq2SeqLSTM(num_encoder_tokens=5, num_decoder_tokens=3, latent_dim=8, seed=0)
+    with pytest.raises(ValueError):
+        wrong.load_weights(os.path.join(golden_dir, "keras_real_weights.h5"))
+
+
+def test_keras_h5_writer_round_trip_and_fixture(golden_dir, tmp_path):
+    """save_weights('x.h5') writes a Keras-layout HDF5 file (checked with the real library's h5ls / h5dump when the
+    fixture was made); load_weights reads it back bit for bit; the committed fixture is what the writer produces."""
+    import importlib.util
+    from longterm360fov_amd import keras_h5
+    from longterm360fov_amd.models import Seq2SeqLSTM
+    m = Seq2SeqLSTM(num_encoder_tokens=7, num_decoder_tokens=6, latent_dim=12, seed=3)
+    for name in ("w.h5", "w.hdf5", "w.npz", "w"):
+        p = str(tmp_path / name)
+        m.save_weights(p)
+        assert os.path.exists(m.weights_path(p))
+        m2 = Seq2SeqLSTM(num_encoder_tokens=7, num_decoder_tokens=6, latent_dim=12, seed=4)
+        m2.load_weights(p)
+        for a, b in zip(m.get_weights(), m2.get_weights()):
+            np.testing.assert_array_equal(a, b)
+    layers = keras_h5.read_keras_layers(str(tmp_path / "w.h5"))
+    assert [n for n, _ in layers] == ["enc", "dec", "dense"]
+    assert [w for w, _ in layers[0][1]] == ["enc/kernel:0", "enc/recurrent_kernel:0", "enc/bias:0"]
+    spec = importlib.util.spec_from_file_location("mk", os.path.join(golden_dir, "make_keras_h5_fixture.py"))
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    keras_h5.write_keras_layers(str(tmp_path / "tiny.h5"), mk.tiny_layers())
+    assert open(str(tmp_path / "tiny.h5"), "rb").read() == open(os.path.join(golden_dir, "keras_seq2seq_tiny.h5"), "rb").read()
+    ref = mk.tiny_layers()
+    for fixture in ("keras_seq2seq_tiny.h5", "keras_seq2seq_tiny_full.h5"):
+        got = keras_h5.read_keras_layers(os.path.join(golden_dir, fixture))
+        assert [n for n, _ in got] == [n for n, _ in ref]
+        for (_, ws), (_, ws2) in zip(got, ref):
+            for (wn, a), (wn2, b) in zip(ws, ws2):
+                assert wn == wn2
+                np.testing.assert_array_equal(a, b)
+
+
+def test_model_checkpoint_h5_name_round_trips(tmp_path):
+    """ModelCheckpoint('...{epoch:02d}-{val_loss:.4f}.h5') (given_others...py:484) and load_weights of the same name."""
+    from longterm360fov_amd.callbacks import ModelCheckpoint
+    from longterm360fov_amd.models import Seq2SeqLSTM
+    m = Seq2SeqLSTM(num_encoder_tokens=7, num_decoder_tokens=6, latent_dim=8, seed=5)
+    cb = ModelCheckpoint(str(tmp_path / "fov{epoch:02d}-{val_loss:.4f}.h5"))
+    cb.set_model(m)
+    cb.on_epoch_end(2, {"val_loss": 0.1234})
+    path = str(tmp_path / "fov03-0.1234.h5")
+    assert cb.saved == [path] and os.path.exists(path)
+    m2 = Seq2SeqLSTM(num_encoder_tokens=7, num_decoder_tokens=6, latent_dim=8, seed=6)
+    m2.load_weights(path)
+    for a, b in zip(m.get_weights(), m2.get_weights()):
+        np.testing.assert_array_equal(a, b)
