@@ -126,7 +126,7 @@ def test_fit_surface_and_callbacks(tmp_path):
     h = m.fit([enc, dec_in], tgt, batch_size=32, epochs=6, validation_split=0.2, shuffle=True, callbacks=[ck, rl, es])
     assert len(h.history["loss"]) == 6 and len(h.history["val_loss"]) == 6
     assert h.history["loss"][-1] < h.history["loss"][0]
-    assert ck.saved and all(os.path.exists(p) and p.endswith(".npz") for p in ck.saved)
+    assert ck.saved and all(os.path.exists(p) and p.endswith(".h5") for p in ck.saved)   # Keras-layout HDF5 (keras_h5.py)
     # the checkpoint round-trips into a fresh model and reproduces predictions
     m2 = Seq2SeqLSTM(latent_dim=64, seed=9, recurrent_activation="hard_sigmoid")
     m2.load_weights(ck.saved[-1])
