@@ -361,9 +361,8 @@ def bench_convlstm(args, rank, world, use_dist):
             c = torch.zeros((B, Hh, Ww, F), device="cuda")
             nxt = []
             for t in range(T):
-                z = ops.conv2d_cat(seq[t], h, kr[l], dw["enc%d_b" % l])
                 hn = torch.empty((B, Hh, Ww, F), device="cuda")
-                ops.convlstm_gates(z, c, hn, "hard_sigmoid")
+                ops.convlstm_cell(seq[t], h, kr[l], dw["enc%d_b" % l], c, hn, "hard_sigmoid")   # one launch per cell step
                 h = hn
                 nxt.append(h)
             seq = nxt

@@ -395,6 +395,22 @@ int fov_conv2d_fwd2(const float* x1, int64_t x1_pixel_stride, int64_t x1_batch_s
                     const float* w, const float* b, const float* add, float* y,
                     int B, int H, int W, int N, int kh, int kw, int activation, fov_stream_t stream);
 
+/* One whole ConvLSTM2D step in ONE launch (convlstm_seq2seq.py:100-126,146-165: Keras' ConvLSTM2DCell.call =
+ * input_conv + recurrent_conv + bias, gate activations, c and h update):
+ *     z = conv_same([x_t | h_prev], [K ; R]) + b;  i,f,o = recurrent_activation(z_i, z_f, z_o);  g = tanh(z_c)
+ *     c_new = f * c_prev + i * g;  h = o * tanh(c_new)
+ * x (B,H,W,C) and h_prev (B,H,W,F) with their pixel / batch strides; w (kh,kw,C+F,4F) with Keras' gate order i,f,c,o
+ * in the last axis (w = K alone, (kh,kw,C,4F), when h_prev is NULL = zero state); b (4F) or NULL; c_prev (B*H*W,F) or
+ * NULL; c_new may alias c_prev; h is written with pixel stride h_pixel_stride >= F and must NOT alias h_prev; gates
+ * (B*H*W,4F) or NULL receives the ACTIVATED i,f,g,o (the tape fov_convlstm_gates_bwd reads).  The gate columns of a
+ * unit are brought into one lane by the weight staging, so z never exists in memory.  Results are bit-identical to
+ * fov_conv2d_fwd2 followed by fov_convlstm_gates[_train]. */
+int fov_convlstm_cell_fwd(const float* x, int64_t x_pixel_stride, int64_t x_batch_stride, int C,
+                          const float* h_prev, int64_t h_prev_pixel_stride, int64_t h_prev_batch_stride,
+                          const float* w, const float* b, const float* c_prev, float* c_new,
+                          float* h, int64_t h_pixel_stride, float* gates,
+                          int B, int H, int W, int F, int kh, int kw, int recurrent_activation, fov_stream_t stream);
+
 /* ConvLSTM2DCell gates on z (rows, 4F) = conv(x,K)+b+conv(h,R), channel blocks i,f,c,o; c (rows,F) is
  * updated in place; h is written with pixel stride h_pixel_stride >= F. */
 int fov_convlstm_gates(const float* z, float* c, float* h, int64_t h_pixel_stride, int64_t rows, int F,

@@ -26,6 +26,12 @@ struct ConvArgs {
     int B, H, W, C, N, kh, kw, act;   // act: 0 none, 2 relu
     long ldx;   // pixel stride
     long ldb;   // batch stride
+    // CELL form (ConvLSTM2D step in one launch): N = 4F gate columns, the epilogue applies the gates and the cell update
+    const float* c_prev;   // (B*H*W, F) or NULL (zero state)
+    float* c_new;          // (B*H*W, F), may alias c_prev
+    float* h;              // (B*H*W, F) with pixel stride ldh
+    long ldh;
+    float* gates;          // (B*H*W, 4F) activated i,f,g,o in Keras column order, or NULL (training tape)
 };
 
 typedef unsigned cu32x4 __attribute__((ext_vector_type(4)));
@@ -45,8 +51,17 @@ typedef unsigned cu32x4 __attribute__((ext_vector_type(4)));
 // Staging modes are template parameters and the tile loop has no branch between loads, MFMAs and LDS writes
 // (the final iteration re-stages its own tile, unused): staged registers never cross a control-flow merge, so
 // the compiler waits for the loads where they are written to LDS, after the MFMAs.
-template <int MI, int NI, int WAVES_M, int AVEC, int BVEC>
+//   CELL (0 none, else 1 + FOV_ACT_* of the recurrent activation): the block's BN GEMM columns are the FOUR gates of
+// BN/4 units, permuted so that the gates of a unit meet in one lane - z never goes to memory and the separate gates
+// launch (a read and a write of the (pixels, 4F) map) is gone.  The permutation costs nothing: it only changes which
+// 16-byte piece of a weight row a staging lane loads.
+//   NI == 4: GEMM column wn + 16 j + li of a wave is Keras column j*F + unit, unit = n0/4 + wn/4 + li: accumulator tiles
+//            j = 0..3 of a lane are i, f, g, o of ONE (pixel, unit).
+//   NI == 2 (F <= 8, one 32-column tile pair): column 16 j + li is gate 2 j + (li >> 3) of unit n0/4 + (li & 7): a lane
+//            holds (i, g) or (f, o) and gets the other pair from the lane 8 places away in its row (DPP row_ror:8).
+template <int MI, int NI, int WAVES_M, int AVEC, int BVEC, int CELL = 0>
 __global__ __launch_bounds__(256) void conv2d_igemm_kernel(ConvArgs g) {
+    static_assert(CELL == 0 || NI == 4 || (NI == 2 && WAVES_M == 4), "cell epilogue: four column tiles per lane, or the 32-column form");
     constexpr int WAVES_N = 4 / WAVES_M;
     constexpr int BM = 16 * MI * WAVES_M, BN = 16 * NI * WAVES_N, BK = 16;
     constexpr int LDA = 24, LDB = BN + 4;
@@ -105,8 +120,16 @@ __global__ __launch_bounds__(256) void conv2d_igemm_kernel(ConvArgs g) {
         const int e = tid + 256 * r;
         b_kk[r] = BVEC ? e / (BN / 4) : e / BN;
         b_nn[r] = BVEC ? 4 * (e - b_kk[r] * (BN / 4)) : e - b_kk[r] * BN;
-        const bool ok = b_kk[r] < BK && n0 + b_nn[r] < g.N;
-        b_off[r] = ok ? (unsigned)(((long)b_kk[r] * g.N + n0 + b_nn[r]) * 4) : OOR;
+        if constexpr (CELL != 0) {
+            const int F = g.N >> 2;
+            const int gate = NI == 4 ? (b_nn[r] & 63) >> 4 : 2 * (b_nn[r] >> 4) + ((b_nn[r] >> 3) & 1);
+            const int unit = (n0 >> 2) + (NI == 4 ? (b_nn[r] >> 6) * 16 + (b_nn[r] & 15) : (b_nn[r] & 7));
+            const bool ok = b_kk[r] < BK && unit < F;
+            b_off[r] = ok ? (unsigned)(((long)b_kk[r] * g.N + gate * F + unit) * 4) : OOR;
+        } else {
+            const bool ok = b_kk[r] < BK && n0 + b_nn[r] < g.N;
+            b_off[r] = ok ? (unsigned)(((long)b_kk[r] * g.N + n0 + b_nn[r]) * 4) : OOR;
+        }
     }
 
     int f_dy = 0, f_dx = 0, f_ct = 0;   // the tile the next fetch() loads (wave-uniform)
@@ -201,6 +224,43 @@ __global__ __launch_bounds__(256) void conv2d_igemm_kernel(ConvArgs g) {
         stash(buf ^ 1);
         __syncthreads();
         buf ^= 1;
+    }
+    if constexpr (CELL != 0) {
+        const int F = g.N >> 2;
+        const int half = NI == 4 ? 0 : li >> 3;       // NI == 2: which gate pair this lane accumulated
+        const int unit = (n0 >> 2) + (NI == 4 ? (wn >> 2) + li : (li & 7));
+        const bool mine = unit < F && half == 0;
+        float bz[4] = {0.f, 0.f, 0.f, 0.f};           // NI == 2: bz[0], bz[1] = bias of the lane's own two gates
+        if (g.bias && unit < F) {
+#pragma unroll
+            for (int j = 0; j < NI; ++j) bz[j] = g.bias[(NI == 4 ? j : 2 * j + half) * F + unit];
+        }
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const long m = m0 + wm + i * 16 + lq * 4 + r;
+                float zi, zf, zg, zo;
+                if constexpr (NI == 4) {
+                    zi = acc[i][0][r] + bz[0]; zf = acc[i][1][r] + bz[1]; zg = acc[i][2][r] + bz[2]; zo = acc[i][3][r] + bz[3];
+                } else {
+                    const float z0 = acc[i][0][r] + bz[0], z1 = acc[i][1][r] + bz[1];   // (i, g) in lanes 0-7, (f, o) in lanes 8-15
+                    const float p0 = __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(z0), 0x128, 0xf, 0xf, false));
+                    const float p1 = __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(z1), 0x128, 0xf, 0xf, false));
+                    zi = z0; zf = p0; zg = z1; zo = p1;    // right for half == 0, the lanes that store
+                }
+                if (mine && m < M) {
+                    const float gi = rec_act<CELL - 1>(zi), gf = rec_act<CELL - 1>(zf), gg = tanh_f(zg), go = rec_act<CELL - 1>(zo);
+                    const float cn = fmaf(gf, g.c_prev ? g.c_prev[m * F + unit] : 0.f, gi * gg);
+                    g.c_new[m * F + unit] = cn;
+                    g.h[m * g.ldh + unit] = go * tanh_f(cn);
+                    if (g.gates) {
+                        float* gp = g.gates + m * g.N + unit;
+                        gp[0] = gi; gp[F] = gf; gp[2 * F] = gg; gp[3 * F] = go;
+                    }
+                }
+            }
+        return;
     }
 #pragma unroll
     for (int i = 0; i < MI; ++i)
@@ -298,6 +358,53 @@ int conv2d_fwd2(const float* x, long ldx, long ldb, int C, const float* x2, long
     }
 #undef FOV_CONV_LAUNCH
     return conv_check_launch("conv2d_igemm");
+}
+
+// One ConvLSTM2D step: h, c <- cell(conv([x | h_prev], [K ; R]) + b, c_prev).  h_prev may be NULL (zero state: w then holds
+// K alone).  h must not alias h_prev (neighbouring pixels read it); c_new may alias c_prev.
+int convlstm_cell_fwd(const float* x, long ldx, long ldb, int C, const float* h_prev, long ldx2, long ldb2, const float* w,
+                      const float* bias, const float* c_prev, float* c_new, float* h, long ldh, float* gates, int B, int H, int W,
+                      int F, int kh, int kw, int act, hipStream_t stream) {
+    ConvArgs g = {};
+    g.x = x; g.w = w; g.bias = bias; g.B = B; g.H = H; g.W = W; g.C = C; g.N = 4 * F; g.kh = kh; g.kw = kw; g.ldx = ldx; g.ldb = ldb;
+    g.x2 = h_prev; g.C2 = h_prev ? F : 0; g.ldx2 = ldx2; g.ldb2 = ldb2;
+    g.c_prev = c_prev; g.c_new = c_new; g.h = h; g.ldh = ldh; g.gates = gates;
+    const long M = (long)B * H * W;
+    if (M == 0 || F == 0) return FOV_OK;
+    if ((long)B * ldb * 4 >= (1L << 31) || (h_prev && (long)B * ldb2 * 4 >= (1L << 31)) ||
+        (long)kh * kw * (C + g.C2) * 4 * F * 4 >= (1L << 31)) {
+        set_error("convlstm_cell: operand larger than 2 GiB");
+        return FOV_ERR_UNSUPPORTED;
+    }
+    const bool avec = (C & 3) == 0 && (ldx & 3) == 0 && (ldb & 3) == 0 && (((uintptr_t)x) & 15) == 0 &&
+                      (!h_prev || ((F & 3) == 0 && (ldx2 & 3) == 0 && (ldb2 & 3) == 0 && (((uintptr_t)h_prev) & 15) == 0));
+    const bool bvec = (F & 3) == 0 && (((uintptr_t)w) & 15) == 0;
+    // tile shapes as conv2d_fwd2 picks them for N = 4F: 8 / 16 / 32 units per block
+#define FOV_CELL_LAUNCH(MI_, NI_, WM_, grid_, ACT_)                                                                              \
+    do {                                                                                                                         \
+        if (avec && bvec) hipLaunchKernelGGL((conv2d_igemm_kernel<MI_, NI_, WM_, 1, 1, ACT_ + 1>), grid_, dim3(256), 0, stream, g); \
+        else if (avec) hipLaunchKernelGGL((conv2d_igemm_kernel<MI_, NI_, WM_, 1, 0, ACT_ + 1>), grid_, dim3(256), 0, stream, g);  \
+        else if (bvec) hipLaunchKernelGGL((conv2d_igemm_kernel<MI_, NI_, WM_, 0, 1, ACT_ + 1>), grid_, dim3(256), 0, stream, g);  \
+        else hipLaunchKernelGGL((conv2d_igemm_kernel<MI_, NI_, WM_, 0, 0, ACT_ + 1>), grid_, dim3(256), 0, stream, g);            \
+    } while (0)
+#define FOV_CELL_SHAPES(ACT_)                                                                  \
+    do {                                                                                       \
+        if (F <= 8) {                                                                          \
+            const dim3 grid(1, (unsigned)((M + 255) / 256));                                   \
+            FOV_CELL_LAUNCH(4, 2, 4, grid, ACT_);                                              \
+        } else if (F <= 16) {                                                                  \
+            const dim3 grid(1, (unsigned)((M + 255) / 256));                                   \
+            FOV_CELL_LAUNCH(4, 4, 4, grid, ACT_);                                              \
+        } else {                                                                               \
+            const dim3 grid((F + 31) / 32, (unsigned)((M + 127) / 128));                       \
+            FOV_CELL_LAUNCH(4, 4, 2, grid, ACT_);                                              \
+        }                                                                                      \
+    } while (0)
+    if (act == FOV_ACT_HARD_SIGMOID) FOV_CELL_SHAPES(FOV_ACT_HARD_SIGMOID);
+    else FOV_CELL_SHAPES(FOV_ACT_SIGMOID);
+#undef FOV_CELL_SHAPES
+#undef FOV_CELL_LAUNCH
+    return conv_check_launch("convlstm_cell");
 }
 
 int convlstm_gates(const float* z, float* c, float* h, long ldh, long rows, int F, int act, hipStream_t stream) {

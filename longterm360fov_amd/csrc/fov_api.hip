@@ -991,6 +991,23 @@ int fov_conv2d_fwd2(const float* x1, int64_t x1_pixel_stride, int64_t x1_batch_s
                        w, b, add, y, B, H, W, N, kh, kw, activation, (hipStream_t)stream);
 }
 
+int fov_convlstm_cell_fwd(const float* x, int64_t x_pixel_stride, int64_t x_batch_stride, int C, const float* h_prev,
+                          int64_t h_prev_pixel_stride, int64_t h_prev_batch_stride, const float* w, const float* b,
+                          const float* c_prev, float* c_new, float* h, int64_t h_pixel_stride, float* gates, int B, int H, int W,
+                          int F, int kh, int kw, int recurrent_activation, fov_stream_t stream) {
+    if (B < 0 || H <= 0 || W <= 0 || C <= 0 || F <= 0 || kh <= 0 || kw <= 0 || !(kh & 1) || !(kw & 1) ||
+        (B > 0 && (!x || !w || !c_new || !h)) || x_pixel_stride < C || x_batch_stride < (int64_t)H * W * x_pixel_stride ||
+        h_pixel_stride < F ||
+        (h_prev && (h_prev_pixel_stride < F || h_prev_batch_stride < (int64_t)H * W * h_prev_pixel_stride || h_prev == h)) ||
+        (recurrent_activation != FOV_ACT_SIGMOID && recurrent_activation != FOV_ACT_HARD_SIGMOID)) {
+        set_error("fov_convlstm_cell_fwd: invalid argument");
+        return FOV_ERR_INVALID;
+    }
+    return convlstm_cell_fwd(x, (long)x_pixel_stride, (long)x_batch_stride, C, h_prev, (long)h_prev_pixel_stride,
+                             (long)h_prev_batch_stride, w, b, c_prev, c_new, h, (long)h_pixel_stride, gates, B, H, W, F, kh, kw,
+                             recurrent_activation, (hipStream_t)stream);
+}
+
 int fov_convlstm_gates(const float* z, float* c, float* h, int64_t h_pixel_stride, int64_t rows, int F, int act,
                        fov_stream_t stream) {
     if (rows < 0 || F <= 0 || h_pixel_stride < F || (rows > 0 && (!z || !c || !h)) ||

@@ -85,6 +85,9 @@ int conv2d_fwd2(const float* x, long ldx, long ldb, int C, const float* x2, long
                 const float* bias, const float* add, float* y, int B, int H, int W, int N, int kh, int kw, int act,
                 hipStream_t stream);
 int convlstm_gates(const float* z, float* c, float* h, long ldh, long rows, int F, int act, hipStream_t stream);
+int convlstm_cell_fwd(const float* x, long ldx, long ldb, int C, const float* h_prev, long ldx2, long ldb2, const float* w,
+                      const float* bias, const float* c_prev, float* c_new, float* h, long ldh, float* gates, int B, int H, int W,
+                      int F, int kh, int kw, int act, hipStream_t stream);
 int softmax_lastdim(const float* x, float* y, long rows, int n, hipStream_t stream);
 
 // ConvLSTM training (conv_train_kernels.hip)

@@ -1120,9 +1120,8 @@ class ConvLSTMSeq2Seq(KerasModelSurface):
                 KR, b = dw["enc%d_KR" % l], dw["enc%d_b" % l]
                 nxt = []
                 for t in range(T_in):
-                    z = ops.conv2d_cat(seq[t], h, KR, b)     # conv(x_t, K) + conv(h, R) + b in one launch
                     hn = e4(B, H, W, F)
-                    ops.convlstm_gates(z, c, hn, act)
+                    ops.convlstm_cell(seq[t], h, KR, b, c, hn, act)   # conv(x_t, K) + conv(h, R) + b, gates, c / h update: one launch
                     h = hn
                     nxt.append(h)
                 seq = nxt
@@ -1134,9 +1133,8 @@ class ConvLSTMSeq2Seq(KerasModelSurface):
                 feat = e4(B, H, W, cat)
                 cur = inp
                 for l, F in enumerate(filters):
-                    z = ops.conv2d_cat(cur, states[l][0], dw["dec%d_KR" % l], dw["dec%d_b" % l])
                     hslot = feat[..., offs[l]:offs[l] + F]
-                    ops.convlstm_gates(z, states[l][1], hslot, act)
+                    ops.convlstm_cell(cur, states[l][0], dw["dec%d_KR" % l], dw["dec%d_b" % l], states[l][1], hslot, act)
                     states[l][0] = hslot
                     cur = hslot
                 if dense_head:   # Flatten + Dense(6): cfg.predict_mean_var, output fed back as a 1x1x6 map

@@ -629,6 +629,45 @@ def conv2d_cat(x1, x2, w, b=None, activation=None, out=None):
     return y
 
 
+def convlstm_cell(x, h_prev, w, b, c_prev, h_out, act="hard_sigmoid", c_new=None, gates=None):
+    """One ConvLSTM2D step in one launch: -> (h_out, c_new).  x (B,H,W,C) and h_prev (B,H,W,F) NHWC maps (channel-slice /
+    batch-strided views allowed; h_prev None = zero state, w is then K alone); w (kh,kw,C+F,4F) = [K ; R]; c_prev None = zero
+    state; c_new defaults to updating c_prev in place; h_out may be a channel-slice view and must not be h_prev; gates
+    (B,H,W,4F) receives the activated i,f,g,o when given (training tape)."""
+    def geom(t):
+        assert t.is_cuda and t.dtype == torch.float32 and t.dim() == 4 and t.stride(3) == 1
+        B, H, W, C = t.shape
+        ldx = t.stride(2)
+        ldb = t.stride(0) if B > 1 else H * W * ldx
+        assert t.stride(1) == W * ldx and ldb >= H * W * ldx, "NHWC with a uniform pixel stride"
+        return B, H, W, C, ldx, ldb
+    B, H, W, C, ldx, ldb = geom(x)
+    w = _dev(w, "w")
+    kh, kw, Cw, N = w.shape
+    F = N // 4
+    assert N == 4 * F
+    ldx2 = ldb2 = 0
+    if h_prev is not None:
+        B2, H2, W2, F2, ldx2, ldb2 = geom(h_prev)
+        assert (B2, H2, W2, F2) == (B, H, W, F) and Cw == C + F
+    else:
+        assert Cw == C
+    c_prev = _dev(c_prev, "c_prev")
+    if c_new is None:
+        c_new = c_prev if c_prev is not None else torch.empty((B, H, W, F), dtype=torch.float32, device=x.device)
+    c_new = _dev(c_new, "c_new")
+    assert c_new.shape == (B, H, W, F) and (c_prev is None or c_prev.shape == c_new.shape)
+    assert h_out.is_cuda and h_out.dtype == torch.float32 and h_out.stride(-1) == 1 and h_out.shape == c_new.shape
+    assert h_out.stride(1) == W * h_out.stride(2) and (B == 1 or h_out.stride(0) == H * W * h_out.stride(2)), "h_out: uniform pixel stride"
+    if gates is not None:
+        gates = _dev(gates, "gates")
+        assert gates.shape == (B, H, W, N)
+    check(_lib.lib().fov_convlstm_cell_fwd(x.data_ptr(), ldx, ldb, C, h_prev.data_ptr() if h_prev is not None else None, ldx2, ldb2,
+                                           _ptr(w), _ptr(_dev(b, "b")), _ptr(c_prev), _ptr(c_new), h_out.data_ptr(),
+                                           h_out.stride(-2), _ptr(gates), B, H, W, F, kh, kw, act_code(act), _stream()))
+    return h_out, c_new
+
+
 def convlstm_gates(z, c, h_out, act="hard_sigmoid"):
     """Gates + cell update: z (B,H,W,4F), c (B,H,W,F) updated in place, h written into h_out, which may be
     a channel-slice view of a concatenated feature map."""

@@ -798,11 +798,10 @@ class ConvLSTMTrainer(FlatParamTrainer):
                 tape["ex4_%d" % l] = seq
             KR = torch.cat([K, R], 2)     # [K ; R]: input and recurrent convolution of a step in one launch
             for t in range(T_in):
-                if t > 0:
-                    z = ops.conv2d_cat(seq[t], hs[t - 1], KR, b, out=gs[t])
-                else:
-                    z = ops.conv2d(seq[t], K, b, out=gs[t])          # zero initial state
-                ops.convlstm_gates_train(z, cs[t - 1] if t > 0 else None, hs[t], act, gates=z, c_new=cs[t])
+                if t > 0:     # the whole step (both convolutions, gates, c / h update, gates tape) is one launch
+                    ops.convlstm_cell(seq[t], hs[t - 1], KR, b, cs[t - 1], hs[t], act, c_new=cs[t], gates=gs[t])
+                else:         # zero initial state
+                    ops.convlstm_cell(seq[t], None, K, b, None, hs[t], act, c_new=cs[t], gates=gs[t])
             tape["eh%d" % l], tape["ec%d" % l], tape["eg%d" % l] = hs, cs, gs
             seq = hs
         cat = sum(F)
@@ -829,9 +828,8 @@ class ConvLSTMTrainer(FlatParamTrainer):
                 if masks is not None:   # a fresh mask set for every unrolled call of the decoder layer
                     dx4[l][t].copy_(self._stack_masked(cur, masks["dec%d" % l][t]))
                     cur, K = dx4[l][t], k4["dec%d_K" % l]
-                z = ops.conv2d_cat(cur, h_prev, kr[l], b, out=dgs[l][t])
                 hslot = feat[t][..., offs[l]:offs[l] + F[l]]
-                ops.convlstm_gates_train(z, c_prev, hslot, act, gates=z, c_new=dcs[l][t])
+                ops.convlstm_cell(cur, h_prev, kr[l], b, c_prev, hslot, act, c_new=dcs[l][t], gates=dgs[l][t])
                 cur = hslot
             if dense_head:     # Flatten + Dense(6, linear); fed back as a 1x1x6 map
                 ops.dense(feat[t].reshape(B, H * W * cat), w["head0_W"], w["head0_b"], activation=None, out=P[t])

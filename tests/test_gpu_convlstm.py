@@ -364,6 +364,53 @@ def test_conv2d_over_channel_concatenation(B, H, W, C1, C2, N, k):
     close(ops.conv2d_cat(dev(x1)[:, 1], dev(wide)[..., 4:4 + C2], dev(w), dev(b), activation="relu"), np.maximum(ref, 0), "relu")
 
 
+@pytest.mark.parametrize("act", ["hard_sigmoid", "sigmoid"])
+@pytest.mark.parametrize("B,H,W,C,F,k", [(3, 36, 18, 32, 128, 5), (2, 6, 5, 30, 32, 5), (2, 1, 30, 3, 8, 5), (1, 7, 4, 17, 20, 3),
+                                         (2, 9, 4, 8, 50, 3), (5, 36, 18, 128, 64, 5), (3, 36, 18, 32, 16, 5), (3, 36, 18, 16, 8, 5),
+                                         (2, 5, 4, 6, 6, 3), (2, 5, 4, 7, 13, 3)])
+def test_convlstm_cell_one_launch(B, H, W, C, F, k, act):
+    """fov_convlstm_cell_fwd (convolution over [x | h], gates, c / h update and the gates tape in ONE launch, the four gate
+    columns of a unit brought into one lane by the weight staging) against the oracle's ConvLSTM2D step, and bit for bit
+    against the two-launch form (fov_conv2d_fwd2 + fov_convlstm_gates_train); ragged F (not a multiple of 32 / of 4), scalar and
+    vector channel paths, channel-slice and batch-strided views, zero initial state, in-place c."""
+    from longterm360fov_amd import ops
+    rng = np.random.default_rng(C * 7 + F)
+    K = (rng.standard_normal((k, k, C, 4 * F)) / np.sqrt(k * k * C)).astype(np.float32)
+    R = (rng.standard_normal((k, k, F, 4 * F)) / np.sqrt(k * k * F)).astype(np.float32)
+    b = rng.standard_normal(4 * F).astype(np.float32)
+    xs = rng.standard_normal((B, 2, H, W, C)).astype(np.float32)                 # x_t of a (B,T,...) sequence
+    hw = (0.5 * rng.standard_normal((B, H, W, F + 8))).astype(np.float32)        # h_prev: channel slice of a wider map
+    c = (0.5 * rng.standard_normal((B, H, W, F))).astype(np.float32)
+    x, h = xs[:, 1], hw[..., 4:4 + F]
+    d = lambda a: a.astype(np.float64)
+    h_ref, c_ref = O.convlstm2d_step(d(x), d(h), d(c), d(K), d(R), d(b), act)
+    KR = torch.cat([dev(K), dev(R)], 2).contiguous()
+    xd, hd = dev(xs)[:, 1], dev(hw)[..., 4:4 + F]
+    wide = torch.zeros((B, H, W, F + 5), dtype=torch.float32, device="cuda")
+    gates = torch.empty((B, H, W, 4 * F), dtype=torch.float32, device="cuda")
+    c_new = torch.empty((B, H, W, F), dtype=torch.float32, device="cuda")
+    ops.convlstm_cell(xd, hd, KR, dev(b), dev(c), wide[..., 3:3 + F], act, c_new=c_new, gates=gates)
+    close(wide[..., 3:3 + F], h_ref, "cell h")
+    close(c_new, c_ref, "cell c")
+    assert float(wide[..., :3].abs().max()) == 0 and float(wide[..., 3 + F:].abs().max()) == 0
+    # the two-launch form computes the same sums in the same order
+    z = ops.conv2d_cat(xd, hd, KR, dev(b))
+    h2 = torch.empty((B, H, W, F), dtype=torch.float32, device="cuda")
+    _, c2, g2 = ops.convlstm_gates_train(z, dev(c), h2, act)
+    assert torch.equal(h2, wide[..., 3:3 + F]) and torch.equal(c2, c_new) and torch.equal(g2, gates)
+    # in-place cell state, no tape
+    cc = dev(c)
+    h3 = torch.empty((B, H, W, F), dtype=torch.float32, device="cuda")
+    ops.convlstm_cell(xd, hd, KR, dev(b), cc, h3, act)
+    assert torch.equal(cc, c_new) and torch.equal(h3, h2)
+    # zero initial state: K alone
+    h0_ref, c0_ref = O.convlstm2d_step(d(x), np.zeros_like(d(h)), np.zeros_like(d(c)), d(K), d(R), d(b), act)
+    h4 = torch.empty((B, H, W, F), dtype=torch.float32, device="cuda")
+    _, c4 = ops.convlstm_cell(xd, None, dev(K), dev(b), None, h4, act)
+    close(h4, h0_ref, "cell h, zero state")
+    close(c4, c0_ref, "cell c, zero state")
+
+
 def test_config4_full_size_and_properties():
     """configs[3]: 36x18 equirectangular heat maps, 30 one-hot channels, ConvLSTM 32/16/8 + Conv2D 512 -> 1024 -> 30 head,
     B = 256, T 10 -> 10 on one GPU.  Three sequences of the full batch against the NumPy oracle, plus size-independent

@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--whole", action="store_true")
     ap.add_argument("--no-pad-input", action="store_true", help="cell bench: keep 30 input channels (scalar gather) "
                     "instead of the zero-padded 32 the model object uses")
+    ap.add_argument("--two-launch", action="store_true", help="cell bench: convolution and gates as two launches (round-1 form)")
     ap.add_argument("--train", action="store_true", help="also time one training step (fwd + backward + RMSprop)")
     ap.add_argument("--train-batch", type=int, default=64)
     a = ap.parse_args()
@@ -53,9 +54,12 @@ def main():
             KR, b = kr[l], dw["enc%d_b" % l]
             nxt = []
             for t in range(T):
-                z = ops.conv2d_cat(seq[t], h, KR, b)     # conv(x_t, K) + conv(h, R) + b in one launch
                 hn = torch.empty((B, H, W, F), device="cuda")
-                ops.convlstm_gates(z, c, hn, "hard_sigmoid")
+                if a.two_launch:
+                    z = ops.conv2d_cat(seq[t], h, KR, b)     # conv(x_t, K) + conv(h, R) + b in one launch, gates in a second
+                    ops.convlstm_gates(z, c, hn, "hard_sigmoid")
+                else:
+                    ops.convlstm_cell(seq[t], h, KR, b, c, hn, "hard_sigmoid")   # the whole step in one launch
                 h = hn
                 nxt.append(h)
             seq = nxt
