@@ -15,9 +15,9 @@ from .config import cfg
 _W_ORDER = ("enc_K", "enc_R", "enc_b", "dec_K", "dec_R", "dec_b", "dense_W", "dense_b")
 
 
-def glorot_uniform(rng, fan_in, fan_out):
+def glorot_uniform(rng, fan_in, fan_out, shape=None):
     lim = np.sqrt(6.0 / (fan_in + fan_out))
-    return rng.uniform(-lim, lim, (fan_in, fan_out)).astype(np.float32)
+    return rng.uniform(-lim, lim, (fan_in, fan_out) if shape is None else shape).astype(np.float32)
 
 
 def orthogonal(rng, rows, cols):
@@ -444,24 +444,41 @@ class NoTeacherForcingSeq2Seq(Seq2SeqLSTM):
     or encoder_input alone under cfg.enc_last_out_as_dec_in (:128-146); returns (N,T_out,O).
 
     Flags default to the script's: `decoder_no_init_state=True` (:29 — decoder step 0 starts from zero state),
-    cfg.add_residual_link / cfg.enc_last_out_as_dec_in / cfg.rescale_input False.  Not built: the reconstruction
-    decoder (cfg.has_reconstruct_loss), cfg.embed_frame_state_enc2dec, BatchNorm on the feedback (add_bn)."""
+    cfg.add_residual_link / cfg.enc_last_out_as_dec_in / cfg.rescale_input / cfg.embed_frame_state_enc2dec /
+    cfg.has_reconstruct_loss False.  With the reconstruction decoder (:56-59,90-95,120-139) the model has two outputs,
+    as the script's `Model(..., [decoder_outputs, recons_decoder_outputs])`: predict returns [prediction (N,T_out,O),
+    reconstruction (N,T_out,F)], fit / train_on_batch take y = [decoder_target, reconstruction_target] (the script passes
+    encoder_input_data[:, ::-1, :], :267) and minimise MSE + MSE; its Model lists [encoder_inputs, time_ind_input] as
+    inputs (:135) - the second one is never read by the graph and is ignored here too.  Not built: BatchNorm on the
+    feedback (add_bn, a module constant that is False)."""
 
     def __init__(self, num_encoder_tokens=None, num_decoder_tokens=6, latent_dim=64, recurrent_activation=None, seed=None,
                  impl="auto", device="cuda", predict_step=None, decoder_no_init_state=True, add_residual_link=None,
-                 enc_last_out_as_dec_in=None, rescale_input=None):
+                 enc_last_out_as_dec_in=None, rescale_input=None, embed_frame_state_enc2dec=None, has_reconstruct_loss=None):
         super().__init__(num_encoder_tokens, num_decoder_tokens, latent_dim, recurrent_activation, seed, impl, device)
+        from .training import self_fed_weight_order
         knob = lambda v, name: bool(getattr(cfg, name, False)) if v is None else bool(v)
         self.predict_step = cfg.predict_step if predict_step is None else int(predict_step)
         self.decoder_no_init_state = bool(decoder_no_init_state)
         self.add_residual_link = knob(add_residual_link, "add_residual_link")
         self.enc_last_out_as_dec_in = knob(enc_last_out_as_dec_in, "enc_last_out_as_dec_in")
         self.dense_activation = "relu" if knob(rescale_input, "rescale_input") else "tanh"
+        self.embed_frame_state_enc2dec = knob(embed_frame_state_enc2dec, "embed_frame_state_enc2dec")
+        self.has_reconstruct_loss = knob(has_reconstruct_loss, "has_reconstruct_loss")
+        H, F, O = self.latent_dim, self.num_encoder_tokens, self.num_decoder_tokens
+        rng = np.random.default_rng(None if seed is None else seed + 1)
         if self.add_residual_link:
-            rng = np.random.default_rng(None if seed is None else seed + 1)
-            self._w["res_W"] = glorot_uniform(rng, self.num_decoder_tokens, self.num_decoder_tokens)
-            self._w["res_b"] = np.zeros(self.num_decoder_tokens, np.float32)
-            self._order = _W_ORDER + ("res_W", "res_b")
+            self._w["res_W"] = glorot_uniform(rng, O, O)
+            self._w["res_b"] = np.zeros(O, np.float32)
+        if self.embed_frame_state_enc2dec:
+            for n in ("emb1", "emb2"):
+                self._w[n + "_W"] = glorot_uniform(rng, H, H)
+                self._w[n + "_b"] = np.zeros(H, np.float32)
+        if self.has_reconstruct_loss:
+            self._w["rec_K"], self._w["rec_R"], self._w["rec_b"] = init_lstm_weights(rng, F, H)
+            self._w["recd_W"] = glorot_uniform(rng, H, F)
+            self._w["recd_b"] = np.zeros(F, np.float32)
+        self._order = self_fed_weight_order(self.add_residual_link, self.embed_frame_state_enc2dec, self.has_reconstruct_loss)
 
     def _split_inputs(self, x):
         if self.enc_last_out_as_dec_in:
@@ -473,15 +490,28 @@ class NoTeacherForcingSeq2Seq(Seq2SeqLSTM):
         import torch
         enc, dec0 = self._split_inputs(x)
         ops, dw, act = self._ops(), self._device_weights(), self.recurrent_activation
-        T_out, O, H = self.predict_step, self.num_decoder_tokens, self.latent_dim
-        plain = not (self.add_residual_link or self.enc_last_out_as_dec_in or self.dense_activation != "tanh")
+        T_out, O, H, F = self.predict_step, self.num_decoder_tokens, self.latent_dim, self.num_encoder_tokens
+        plain = not (self.add_residual_link or self.enc_last_out_as_dec_in or self.dense_activation != "tanh" or
+                     self.has_reconstruct_loss or (self.embed_frame_state_enc2dec and not self.decoder_no_init_state))
         n = enc.shape[0]
         bs = n if not batch_size else int(batch_size)
-        outs = []
+        outs, recs = [], []
 
-        def dense(v, W, b):
-            y = ops.dense(v, W, b, activation="tanh" if self.dense_activation == "tanh" else None)
-            return y if self.dense_activation == "tanh" else ops.act_fwd(y, "relu", out=y)
+        def dense(v, W, b, dact=None):
+            dact = dact or self.dense_activation
+            y = ops.dense(v, W, b, activation="tanh" if dact == "tanh" else None)
+            return y if dact == "tanh" else ops.act_fwd(y, "relu", out=y)
+
+        def unroll(pre, head, xin, h, c, r, dact, width):
+            o = torch.empty((xin.shape[0], T_out, width), dtype=torch.float32, device=self.device)
+            for t in range(T_out):
+                _, h, c = ops.lstm_seq(xin.reshape(-1, 1, width), dw[pre + "_K"], dw[pre + "_R"], dw[pre + "_b"], h, c, act=act,
+                                       impl=self.impl, return_sequences=False, workspace=self._ws)
+                xin = dense(h, dw[head + "_W"], dw[head + "_b"], dact)
+                if r is not None:
+                    xin = ops.act_bwd(r, r, base=xin, activation=None)     # y_t = Dense(h_t) + residual
+                o[:, t] = xin
+            return o
         for lo in range(0, n, max(bs, 1)):
             e = self._dev(enc[lo:lo + bs])
             if plain:     # ONE fused call; a zero-length encoder input is the zero initial state of :98-99
@@ -490,23 +520,23 @@ class NoTeacherForcingSeq2Seq(Seq2SeqLSTM):
                 outs.append(o.cpu().numpy())
                 continue
             B = e.shape[0]
-            _, h, c = ops.lstm_seq(e, dw["enc_K"], dw["enc_R"], dw["enc_b"], act=act, impl=self.impl, return_sequences=False,
-                                   workspace=self._ws)
-            xin = dense(h, dw["dense_W"], dw["dense_b"]) if self.enc_last_out_as_dec_in else self._dev(dec0[lo:lo + bs]).reshape(B, O)
-            if self.decoder_no_init_state:
-                h, c = torch.zeros_like(h), torch.zeros_like(c)
+            _, h_enc, c_enc = ops.lstm_seq(e, dw["enc_K"], dw["enc_R"], dw["enc_b"], act=act, impl=self.impl, return_sequences=False,
+                                           workspace=self._ws)
+            sh, sc = h_enc, c_enc
+            if self.embed_frame_state_enc2dec:
+                sh, sc = dense(h_enc, dw["emb1_W"], dw["emb1_b"], "tanh"), dense(c_enc, dw["emb2_W"], dw["emb2_b"], "tanh")
+            xin = dense(h_enc, dw["dense_W"], dw["dense_b"]) if self.enc_last_out_as_dec_in else self._dev(dec0[lo:lo + bs]).reshape(B, O)
+            h, c = (torch.zeros_like(sh), torch.zeros_like(sc)) if self.decoder_no_init_state else (sh, sc)
             r = dense(xin, dw["res_W"], dw["res_b"]) if self.add_residual_link else None
-            o = torch.empty((B, T_out, O), dtype=torch.float32, device=self.device)
-            for t in range(T_out):
-                _, h, c = ops.lstm_seq(xin.reshape(B, 1, O), dw["dec_K"], dw["dec_R"], dw["dec_b"], h, c, act=act, impl=self.impl,
-                                       return_sequences=False, workspace=self._ws)
-                xin = dense(h, dw["dense_W"], dw["dense_b"])
-                if r is not None:
-                    xin = ops.act_bwd(r, r, base=xin, activation=None)     # y_t = Dense(h_t) + residual
-                o[:, t] = xin
-            outs.append(o.cpu().numpy())
+            outs.append(unroll("dec", "dense", xin, h, c, r, None, O).cpu().numpy())
+            if self.has_reconstruct_loss:
+                xr = dense(h_enc, dw["recd_W"], dw["recd_b"], "tanh")
+                recs.append(unroll("rec", "recd", xr, sh, sc, None, "tanh", F).cpu().numpy())
         self._ws.check()
-        return np.concatenate(outs, axis=0) if outs else np.zeros((0, T_out, O), np.float32)
+        y = np.concatenate(outs, axis=0) if outs else np.zeros((0, T_out, O), np.float32)
+        if self.has_reconstruct_loss:
+            return [y, np.concatenate(recs, axis=0) if recs else np.zeros((0, T_out, F), np.float32)]
+        return y
 
     predict_on_batch = predict
 
@@ -515,13 +545,33 @@ class NoTeacherForcingSeq2Seq(Seq2SeqLSTM):
         return SelfFedSeq2SeqTrainer(
             self._w, act=self.recurrent_activation, impl=self.impl, optimizer=optimizer, lr=self._lr, device=self.device,
             decoder_no_init_state=self.decoder_no_init_state, add_residual_link=self.add_residual_link,
-            enc_last_out_as_dec_in=self.enc_last_out_as_dec_in, dense_activation=self.dense_activation)
+            enc_last_out_as_dec_in=self.enc_last_out_as_dec_in, dense_activation=self.dense_activation,
+            embed_frame_state_enc2dec=self.embed_frame_state_enc2dec, has_reconstruct_loss=self.has_reconstruct_loss)
 
     def _fit_inputs(self, x):
         enc, dec0 = self._split_inputs(x)
         if dec0 is None:      # the trainer's positional signature keeps a decoder-input slot; it is not read
             dec0 = np.zeros((enc.shape[0], 1, self.num_decoder_tokens), np.float32)
         return [enc, dec0]
+
+    def _fit_target(self, y):
+        """[decoder_target (N,T,O), reconstruction_target (N,T,F)] -> one (N,T,O+F) array for the shared fit loop."""
+        if not self.has_reconstruct_loss:
+            return y
+        if not isinstance(y, (list, tuple)) or len(y) != 2:
+            raise ValueError("a model with the reconstruction decoder takes y = [decoder_target, reconstruction_target]")
+        a, b = _as_f32(y[0]), _as_f32(y[1])
+        if a.shape[:2] != b.shape[:2] or b.shape[2] != self.num_encoder_tokens:
+            raise ValueError("reconstruction target %s does not match (N, %d, %d)" % (b.shape, a.shape[1], self.num_encoder_tokens))
+        return np.concatenate([a, b], -1)
+
+    def fit(self, x, y, validation_data=None, **kw):
+        if validation_data is not None:
+            validation_data = (validation_data[0], self._fit_target(validation_data[1]))
+        return super().fit(x, self._fit_target(y), validation_data=validation_data, **kw)
+
+    def train_on_batch(self, x, y, **kw):
+        return super().train_on_batch(x, self._fit_target(y), **kw)
 
 
 class StackedSeq2SeqLSTM(KerasModelSurface):
@@ -992,6 +1042,68 @@ class OthersMixingSeq2Seq(KerasModelSurface):
         return np.concatenate(outs, axis=0) if outs else np.zeros((0, T_out, O), np.float32)
 
     predict_on_batch = predict
+
+
+_CONV_MIX_ORDER = tuple(k for k in _MIX_ORDER if not k.startswith("mix_")) + \
+    ("mixc0_W", "mixc0_b", "mixc1_W", "mixc1_b", "mixc2_W", "mixc2_b")
+
+
+class OthersConvMixingSeq2Seq(OthersMixingSeq2Seq):
+    """The `conv_mixing` form of the same script (given_others_gt_mean_var_seq2seq.py:56,188-197,284-290): instead of the
+    mixing Dense, the per-step stack [others_t (U-1,6) ; prediction (1,6)] is permuted into a 1 x 6 map with the U users
+    as channels and passes Conv2D(8, (1,3)) -> Conv2D(8, (1,3)) -> Conv2D(1, (1,3)), all 'same' + relu; the single output
+    channel is the step's output and the next step's input.  Runs step-wise on the layer kernels and the implicit-GEMM
+    convolution (the convolution reads [others_t | prediction] as two maps: the concatenation never exists); same predict /
+    fit surface and inputs as OthersMixingSeq2Seq."""
+
+    def __init__(self, num_encoder_tokens=None, num_decoder_tokens=6, latent_dim=32, num_user=34, recurrent_activation=None,
+                 seed=None, impl="auto", device="cuda", filters=8):
+        super().__init__(num_encoder_tokens, num_decoder_tokens, latent_dim, num_user, recurrent_activation, seed, impl, device)
+        rng = np.random.default_rng(None if seed is None else seed + 1)
+        w = {k: v for k, v in self._w.items() if not k.startswith("mix_")}
+        for i, (c, n) in enumerate(((self.num_user, filters), (filters, filters), (filters, 1))):
+            w["mixc%d_W" % i] = glorot_uniform(rng, 3 * c, 3 * n, shape=(1, 3, c, n))     # Keras: fan_in = kh*kw*C, fan_out = kh*kw*N
+            w["mixc%d_b" % i] = np.zeros(n, np.float32)
+        self._w = w
+        self._init_surface(_CONV_MIX_ORDER, impl, device)
+
+    def _make_trainer(self, optimizer):
+        from .training import OthersConvMixingTrainer
+        return OthersConvMixingTrainer(self._w, act=self.recurrent_activation, impl=self.impl, optimizer=optimizer, lr=self._lr,
+                                       device=self.device)
+
+    def _device_weights(self):
+        import torch
+        from . import ops
+        if self._dw is None:
+            self._dw = {k: torch.from_numpy(np.ascontiguousarray(v)).to(self.device) for k, v in self._w.items()}
+            self._ws = ops.Workspace()
+        return self._dw
+
+    def predict_device(self, e, oth, xin):
+        import torch
+        from . import ops
+        dw = self._device_weights()
+        act, impl, ws = self.recurrent_activation, self.impl, self._ws
+        H, O = self.latent_dim, self.num_decoder_tokens
+        B, T_in = e.shape[0], e.shape[1]
+        T_out = oth.shape[1]
+        hs1, h1, c1 = ops.lstm_seq(e, dw["enc1_K"], dw["enc1_R"], dw["enc1_b"], act=act, impl=impl, workspace=ws)
+        _, h2, c2 = ops.lstm_seq(hs1, dw["enc2_K"], dw["enc2_R"], dw["enc2_b"], act=act, impl=impl, return_sequences=False, workspace=ws)
+        othT = oth.permute(1, 0, 3, 2).contiguous()          # (T_out,B,6,U-1): Permute((2,1)) of every step, once
+        out = torch.empty((T_out, B, O), dtype=torch.float32, device=self.device)
+        xin = xin.reshape(B, O)
+        for t in range(T_out):
+            _, h1, c1 = ops.lstm_seq(xin.reshape(B, 1, O), dw["dec1_K"], dw["dec1_R"], dw["dec1_b"], h1, c1, act=act, impl=impl,
+                                     return_sequences=False, workspace=ws)
+            _, h2, c2 = ops.lstm_seq(h1.reshape(B, 1, H), dw["dec2_K"], dw["dec2_R"], dw["dec2_b"], h2, c2, act=act, impl=impl,
+                                     return_sequences=False, workspace=ws)
+            p = ops.dense(h2, dw["dense_W"], dw["dense_b"], activation="tanh")
+            a = ops.conv2d_cat(othT[t].view(B, 1, O, -1), p.view(B, 1, O, 1), dw["mixc0_W"], dw["mixc0_b"], activation="relu")
+            a = ops.conv2d(a, dw["mixc1_W"], dw["mixc1_b"], activation="relu")
+            ops.conv2d(a, dw["mixc2_W"], dw["mixc2_b"], activation="relu", out=out[t].view(B, 1, O, 1))
+            xin = out[t]
+        return out.transpose(0, 1)
 
 
 def convert_tf_lstmcell(W, b, forget_bias=1.0):

@@ -175,6 +175,20 @@ class Seq2SeqTrainer(FlatParamTrainer):
         return loss
 
 
+def self_fed_weight_order(add_residual_link=False, embed_frame_state_enc2dec=False, has_reconstruct_loss=False):
+    """Parameter order of onelayer_tar_seq2seq (FoV_seq2seq_no_teac_forc.py:37-149) with its optional layers."""
+    order = ("enc_K", "enc_R", "enc_b")
+    if embed_frame_state_enc2dec:
+        order += ("emb1_W", "emb1_b", "emb2_W", "emb2_b")
+    order += ("dec_K", "dec_R", "dec_b")
+    if has_reconstruct_loss:
+        order += ("rec_K", "rec_R", "rec_b", "recd_W", "recd_b")
+    order += ("dense_W", "dense_b")
+    if add_residual_link:
+        order += ("res_W", "res_b")
+    return order
+
+
 class SelfFedSeq2SeqTrainer(FlatParamTrainer):
     """Training step of the one-layer target-only model WITHOUT teacher forcing
     (mycode/FoV_seq2seq_no_teac_forc.py:37-149, `onelayer_tar_seq2seq`; Adam + MSE, :147): the decoder is unrolled
@@ -182,99 +196,154 @@ class SelfFedSeq2SeqTrainer(FlatParamTrainer):
     writes a time-major tape, backward joins the loss gradient of step t with the input gradient of step t+1, and
     every weight gradient is one product over all steps.
 
-    decoder_no_init_state   the script's module flag (:29,98-99): step 0 starts from zero state (the encoder then
-                            only matters through enc_last_out_as_dec_in)
-    add_residual_link       cfg.add_residual_link (:70-72,103-107): y_t += residual_dense(decoder input)
-    enc_last_out_as_dec_in  cfg.enc_last_out_as_dec_in (:75-78): decoder input = decoder_dense(encoder output)
-    dense_activation        'tanh', or 'relu' under cfg.rescale_input (:60-63)"""
+    decoder_no_init_state       the script's module flag (:29,98-99): step 0 starts from zero state (the encoder then
+                                only matters through enc_last_out_as_dec_in / the reconstruction decoder)
+    add_residual_link           cfg.add_residual_link (:70-72,103-107): y_t += residual_dense(decoder input)
+    enc_last_out_as_dec_in      cfg.enc_last_out_as_dec_in (:75-78): decoder input = decoder_dense(encoder output)
+    dense_activation            'tanh', or 'relu' under cfg.rescale_input (:60-63)
+    embed_frame_state_enc2dec   cfg.embed_frame_state_enc2dec (:47-52): Dense(latent_dim, tanh) on the encoder's h and c
+    has_reconstruct_loss        cfg.has_reconstruct_loss (:56-59,90-95,120-126,134-139): a second self-fed LSTM +
+                                Dense(num_encoder_tokens, tanh) reconstructs input seconds; loss = MSE + MSE (weights 1, 1);
+                                the target is then (B, T_out, O + F): prediction target | reconstruction target"""
 
     def __init__(self, weights, act="sigmoid", impl="auto", optimizer="adam", lr=1e-3, device="cuda",
                  decoder_no_init_state=True, add_residual_link=False, enc_last_out_as_dec_in=False,
-                 dense_activation="tanh"):
+                 dense_activation="tanh", embed_frame_state_enc2dec=False, has_reconstruct_loss=False):
         self.act, self.impl = act, impl
-        self._alloc(weights, _W_ORDER + (("res_W", "res_b") if add_residual_link else ()), optimizer, lr, device)
         self.no_init, self.residual, self.enc_as_in = bool(decoder_no_init_state), bool(add_residual_link), bool(enc_last_out_as_dec_in)
+        self.embed, self.recons = bool(embed_frame_state_enc2dec), bool(has_reconstruct_loss)
+        self._alloc(weights, self_fed_weight_order(self.residual, self.embed, self.recons), optimizer, lr, device)
         self.dact = dense_activation
 
-    def _dense(self, x, W, b, out=None):
-        y = ops.dense(x, W, b, activation="tanh" if self.dact == "tanh" else None, out=out)
-        if self.dact == "relu":
+    def _dense(self, x, W, b, out=None, dact=None):
+        dact = dact or self.dact
+        y = ops.dense(x, W, b, activation="tanh" if dact == "tanh" else None, out=out)
+        if dact == "relu":
             ops.act_fwd(y, "relu", out=y)
         return y
 
-    def forward_backward(self, enc, dec_in, target, grad_weight=1.0):
-        """dec_in (B,1,O) is ignored under enc_last_out_as_dec_in.  -> (loss (1,), prediction (B,T_out,O))."""
-        w, g, act, impl, ws, sc, bsc = self.w, self.g, self.act, self.impl, self.ws, self.scratch, self.bwd_scratch
-        B, T_in, _ = enc.shape
-        T_out = target.shape[1]
-        H, O = w["dec_R"].shape[0], w["dense_W"].shape[1]
+    # ---- one self-fed unrolled decoder: LSTM `lstm`_K/R/b + Dense `head`_W/b, y_t fed back as x_{t+1} ----
+    def _unroll_forward(self, lstm, head, x0, h0, c0, T, dact, r=None):
+        w, act, impl, ws = self.w, self.act, self.impl, self.ws
+        B, O = x0.shape
+        H = w[lstm + "_R"].shape[0]
         e = lambda *s_: torch.empty(s_, dtype=torch.float32, device=self.device)
-        self.grad.zero_()
-        # ---------------- forward ----------------
-        Hs, Cs = e(T_out + 1, B, H), e(T_out + 1, B, H)   # row t = state before decoder step t
-        XA = e(T_out + 1, B, O)                            # row t = decoder input x_t; row t+1 = y_t
-        A = e(T_out, B, O)                                 # Dense outputs before the residual is added
-        RES = e(T_out, B, 1, 5, H)
-        ehs, ehT, ecT, eres = ops.lstm_seq_train(enc, w["enc_K"], w["enc_R"], w["enc_b"], act=act, impl=impl, workspace=ws)
-        if self.enc_as_in:
-            self._dense(ehT, w["dense_W"], w["dense_b"], out=XA[0])
+        tp = {"Hs": e(T + 1, B, H), "Cs": e(T + 1, B, H),    # row t = state before step t
+              "XA": e(T + 1, B, O),                           # row t = input x_t; row t+1 = y_t
+              "A": e(T, B, O) if r is not None else None,     # Dense outputs before the residual is added
+              "RES": e(T, B, 1, 5, H), "lstm": lstm, "head": head, "dact": dact, "r": r, "T": T}
+        tp["XA"][0].copy_(x0)
+        if h0 is None:
+            tp["Hs"][0].zero_(); tp["Cs"][0].zero_()
         else:
-            XA[0].copy_(dec_in.reshape(B, O))
-        if self.no_init:
-            Hs[0].zero_(); Cs[0].zero_()
-        else:
-            Hs[0].copy_(ehT); Cs[0].copy_(ecT)
-        r = self._dense(XA[0], w["res_W"], w["res_b"]) if self.residual else None
-        for t in range(T_out):
-            ops.lstm_seq_train(XA[t].view(B, 1, O), w["dec_K"], w["dec_R"], w["dec_b"], Hs[t], Cs[t], act=act, impl=impl,
-                               workspace=ws, out=(Hs[t + 1].view(B, 1, H), None, Cs[t + 1], RES[t]))
-            if self.residual:
-                self._dense(Hs[t + 1], w["dense_W"], w["dense_b"], out=A[t])
+            tp["Hs"][0].copy_(h0); tp["Cs"][0].copy_(c0)
+        Hs, Cs, XA, A = tp["Hs"], tp["Cs"], tp["XA"], tp["A"]
+        for t in range(T):
+            ops.lstm_seq_train(XA[t].view(B, 1, O), w[lstm + "_K"], w[lstm + "_R"], w[lstm + "_b"], Hs[t], Cs[t], act=act, impl=impl,
+                               workspace=ws, out=(Hs[t + 1].view(B, 1, H), None, Cs[t + 1], tp["RES"][t]))
+            if r is not None:
+                self._dense(Hs[t + 1], w[head + "_W"], w[head + "_b"], out=A[t], dact=dact)
                 ops.act_bwd(r, r, base=A[t], activation=None, out=XA[t + 1])     # y_t = a_t + r
             else:
-                self._dense(Hs[t + 1], w["dense_W"], w["dense_b"], out=XA[t + 1])
-        Y = XA[1:]
-        Aout = A if self.residual else Y
-        out = Y.transpose(0, 1).contiguous()
-        # ---------------- backward ----------------
-        dloss, loss = ops.mse_dense_grad(out, target, None, scratch=sc)            # dL/dy, all steps
-        dloss_tm = dloss.transpose(0, 1).contiguous()
-        DY, DPRE, DZ = e(T_out, B, O), e(T_out, B, O), e(T_out, B, 4 * H)
+                self._dense(Hs[t + 1], w[head + "_W"], w[head + "_b"], out=XA[t + 1], dact=dact)
+        return tp
+
+    def _unroll_backward(self, tp, dloss_tm):
+        """dloss_tm (T,B,O): dL/dy_t.  Accumulates the gradients of the unrolled LSTM and its head; -> (dx0, dh0, dc0, DY)."""
+        w, g, act, sc, bsc = self.w, self.g, self.act, self.scratch, self.bwd_scratch
+        lstm, head, dact, T = tp["lstm"], tp["head"], tp["dact"], tp["T"]
+        Hs, Cs, XA = tp["Hs"], tp["Cs"], tp["XA"]
+        _, B, O = XA.shape
+        H = Hs.shape[2]
+        e = lambda *s_: torch.empty(s_, dtype=torch.float32, device=self.device)
+        Aout = tp["A"] if tp["r"] is not None else XA[1:]
+        DY, DPRE, DZ = e(T, B, O), e(T, B, O), e(T, B, 4 * H)
         dh_rec = dc = dx_next = None
-        for t in range(T_out - 1, -1, -1):
+        for t in range(T - 1, -1, -1):
             if dx_next is None:
                 DY[t].copy_(dloss_tm[t])
             else:                                                                  # x_{t+1} = y_t: feedback gradient joins
                 ops.act_bwd(dx_next.reshape(B, O), Aout[t], base=dloss_tm[t], activation=None, out=DY[t])
-            ops.act_bwd(DY[t], Aout[t], activation=self.dact, out=DPRE[t])
-            dh_dense, _, _ = ops.dense_bwd(Hs[t + 1], w["dense_W"], DPRE[t], need_dx=True, need_dW=False, need_db=False, scratch=sc)
-            b = ops.lstm_seq_bwd(XA[t].view(B, 1, O), w["dec_K"], w["dec_R"], Hs[t + 1].view(B, 1, H), RES[t], h0=Hs[t], c0=Cs[t],
-                                 dhs=dh_dense.reshape(B, 1, H), dhT=dh_rec, dcT=dc, need_dx=True, need_state_grads=True, act=act,
-                                 dz=DZ[t].view(B, 1, 4 * H), scratch=bsc, need_weight_grads=False)
+            ops.act_bwd(DY[t], Aout[t], activation=dact, out=DPRE[t])
+            dh_dense, _, _ = ops.dense_bwd(Hs[t + 1], w[head + "_W"], DPRE[t], need_dx=True, need_dW=False, need_db=False, scratch=sc)
+            b = ops.lstm_seq_bwd(XA[t].view(B, 1, O), w[lstm + "_K"], w[lstm + "_R"], Hs[t + 1].view(B, 1, H), tp["RES"][t], h0=Hs[t],
+                                 c0=Cs[t], dhs=dh_dense.reshape(B, 1, H), dhT=dh_rec, dcT=dc, need_dx=True, need_state_grads=True,
+                                 act=act, dz=DZ[t].view(B, 1, 4 * H), scratch=bsc, need_weight_grads=False)
             dh_rec, dc, dx_next = b["dh0"], b["dc0"], b["dx"]
-        TB = T_out * B
+        TB = T * B
         fl = lambda a, n: a.reshape(TB, n)
-        ops.dense_bwd(fl(Hs[1:], H), w["dense_W"], fl(DPRE, O), dW=g["dense_W"], db=g["dense_b"], need_dx=False, accumulate=True, scratch=sc)
-        ops.dense_bwd(fl(XA[:T_out], O), w["dec_K"], fl(DZ, 4 * H), dW=g["dec_K"], db=g["dec_b"], need_dx=False, accumulate=True, scratch=sc)
-        ops.dense_bwd(fl(Hs[:T_out], H), w["dec_R"], fl(DZ, 4 * H), dW=g["dec_R"], need_db=False, need_dx=False, accumulate=True, scratch=sc)
-        dx0 = dx_next.reshape(B, O)                       # gradient w.r.t. the decoder input
+        ops.dense_bwd(fl(Hs[1:], H), w[head + "_W"], fl(DPRE, O), dW=g[head + "_W"], db=g[head + "_b"], need_dx=False, accumulate=True, scratch=sc)
+        ops.dense_bwd(fl(XA[:T], O), w[lstm + "_K"], fl(DZ, 4 * H), dW=g[lstm + "_K"], db=g[lstm + "_b"], need_dx=False, accumulate=True, scratch=sc)
+        ops.dense_bwd(fl(Hs[:T], H), w[lstm + "_R"], fl(DZ, 4 * H), dW=g[lstm + "_R"], need_db=False, need_dx=False, accumulate=True, scratch=sc)
+        return dx_next.reshape(B, O), dh_rec, dc, DY
+
+    @staticmethod
+    def _sum(a, b):
+        if a is None or b is None:
+            return a if b is None else b
+        return ops.act_bwd(b, b, base=a, activation=None)
+
+    def forward_backward(self, enc, dec_in, target, grad_weight=1.0):
+        """dec_in (B,1,O) is ignored under enc_last_out_as_dec_in.  -> (loss (1,), prediction (B,T_out,O)); with the
+        reconstruction decoder target is (B,T_out,O+F) and the second return value (B,T_out,O+F) likewise."""
+        w, g, act, impl, ws, sc, bsc = self.w, self.g, self.act, self.impl, self.ws, self.scratch, self.bwd_scratch
+        B, T_in, F = enc.shape
+        T_out = target.shape[1]
+        O = w["dense_W"].shape[1]
+        self.grad.zero_()
+        # ---------------- forward ----------------
+        ehs, ehT, ecT, eres = ops.lstm_seq_train(enc, w["enc_K"], w["enc_R"], w["enc_b"], act=act, impl=impl, workspace=ws)
+        sh, sc_ = ehT, ecT
+        if self.embed:
+            sh = self._dense(ehT, w["emb1_W"], w["emb1_b"], dact="tanh")
+            sc_ = self._dense(ecT, w["emb2_W"], w["emb2_b"], dact="tanh")
+        x0 = self._dense(ehT, w["dense_W"], w["dense_b"]) if self.enc_as_in else dec_in.reshape(B, O)
+        r = self._dense(x0, w["res_W"], w["res_b"]) if self.residual else None
+        main = self._unroll_forward("dec", "dense", x0, None if self.no_init else sh, None if self.no_init else sc_, T_out, self.dact, r)
+        out = main["XA"][1:].transpose(0, 1).contiguous()
+        rec = None
+        if self.recons:
+            xr0 = self._dense(ehT, w["recd_W"], w["recd_b"], dact="tanh")
+            rec = self._unroll_forward("rec", "recd", xr0, sh, sc_, T_out, "tanh")
+            rec_out = rec["XA"][1:].transpose(0, 1).contiguous()
+            tgt_main, tgt_rec = target[..., :O].contiguous(), target[..., O:].contiguous()
+        else:
+            tgt_main = target
+        # ---------------- backward ----------------
+        dloss, loss = ops.mse_dense_grad(out, tgt_main, None, scratch=sc)            # dL/dy, all steps
+        dx0, dsh, dsc, DY = self._unroll_backward(main, dloss.transpose(0, 1).contiguous())
+        if self.no_init:
+            dsh = dsc = None
+        d_ehT = None
         if self.residual:                                 # r is added to every step's output
             dr = ops.colsum(DY.reshape(T_out, B * O), scratch=sc).reshape(B, O)
             dpre_r = ops.act_bwd(dr, r, activation=self.dact)
-            dxr, _, _ = ops.dense_bwd(XA[0], w["res_W"], dpre_r, dW=g["res_W"], db=g["res_b"], need_dx=True, accumulate=True, scratch=sc)
+            dxr, _, _ = ops.dense_bwd(x0, w["res_W"], dpre_r, dW=g["res_W"], db=g["res_b"], need_dx=True, accumulate=True, scratch=sc)
             dx0 = ops.act_bwd(dxr, dxr, base=dx0, activation=None)
-        d_ehT = d_ecT = None
         if self.enc_as_in:                                # x_0 = Dense(encoder output)
-            dpre0 = ops.act_bwd(dx0, XA[0], activation=self.dact)
+            dpre0 = ops.act_bwd(dx0, x0, activation=self.dact)
             d_ehT, _, _ = ops.dense_bwd(ehT, w["dense_W"], dpre0, dW=g["dense_W"], db=g["dense_b"], need_dx=True, accumulate=True, scratch=sc)
-        if not self.no_init:
-            d_ehT = dh_rec if d_ehT is None else ops.act_bwd(dh_rec, dh_rec, base=d_ehT, activation=None)
-            d_ecT = dc
+        if self.recons:
+            dloss_r, loss_r = ops.mse_dense_grad(rec_out, tgt_rec, None, scratch=sc)
+            loss = ops.act_bwd(loss_r, loss_r, base=loss, activation=None)          # loss weights [1, 1] (:137)
+            dxr0, dsh_r, dsc_r, _ = self._unroll_backward(rec, dloss_r.transpose(0, 1).contiguous())
+            dpre_x = ops.act_bwd(dxr0, rec["XA"][0], activation="tanh")
+            d_x, _, _ = ops.dense_bwd(ehT, w["recd_W"], dpre_x, dW=g["recd_W"], db=g["recd_b"], need_dx=True, accumulate=True, scratch=sc)
+            d_ehT = self._sum(d_ehT, d_x)
+            dsh, dsc = self._sum(dsh, dsh_r), self._sum(dsc, dsc_r)
+        d_ecT = None
+        if dsh is not None:                               # the (embedded) encoder state reaches a decoder
+            if self.embed:
+                dp_h = ops.act_bwd(dsh, sh, activation="tanh")
+                dp_c = ops.act_bwd(dsc, sc_, activation="tanh")
+                dsh, _, _ = ops.dense_bwd(ehT, w["emb1_W"], dp_h, dW=g["emb1_W"], db=g["emb1_b"], need_dx=True, accumulate=True, scratch=sc)
+                dsc, _, _ = ops.dense_bwd(ecT, w["emb2_W"], dp_c, dW=g["emb2_W"], db=g["emb2_b"], need_dx=True, accumulate=True, scratch=sc)
+            d_ehT, d_ecT = self._sum(d_ehT, dsh), dsc
         if d_ehT is not None:                             # otherwise the encoder does not reach the loss (reference quirk)
             ops.lstm_seq_bwd(enc, w["enc_K"], w["enc_R"], ehs, eres, dhT=d_ehT, dcT=d_ecT, dK=g["enc_K"], dR=g["enc_R"],
                              db=g["enc_b"], act=act, accumulate=True, scratch=bsc)
         loss = self._weigh(loss, grad_weight)
-        return loss, out
+        return loss, (torch.cat([out, rec_out], -1) if self.recons else out)
 
 
 
@@ -699,6 +768,103 @@ class OthersMixingTrainer(FlatParamTrainer):
                               db=g["enc2_b"], need_dx=True, act=act, accumulate=acc, scratch=bsc, dtype=dt)
         ops.lstm_seq_bwd(enc, w["enc1_K"], w["enc1_R"], hs1, res1, dhs=e2["dx"], dhT=dh1_rec, dcT=dc1, dK=g["enc1_K"],
                          dR=g["enc1_R"], db=g["enc1_b"], act=act, accumulate=acc, scratch=bsc, dtype=dt)
+        return loss, out
+
+
+_CONV_MIX_ORDER = tuple(k for k in _MIX_ORDER if not k.startswith("mix_")) + \
+    ("mixc0_W", "mixc0_b", "mixc1_W", "mixc1_b", "mixc2_W", "mixc2_b")
+
+
+class OthersConvMixingTrainer(FlatParamTrainer):
+    """Training step of the `conv_mixing` form of the others-mixing model
+    (mycode/given_others_gt_mean_var_seq2seq.py:56,188-197,284-290,308): the mixing head is three Conv2D(1x3, same, relu)
+    layers over the 1 x 6 map whose channels are the U users (others' mean/variance of the step, then the decoder's own
+    prediction).  Step-wise on the layer kernels and the implicit-GEMM convolution; the data gradient of a convolution is
+    the convolution with the transposed, flipped kernel; every weight gradient is ONE product over all steps."""
+
+    def __init__(self, weights, act="sigmoid", impl="auto", optimizer="adam", lr=1e-3, device="cuda"):
+        self.act, self.impl = act, impl
+        self._alloc(weights, _CONV_MIX_ORDER, optimizer, lr, device)
+
+    def forward_backward(self, enc, others, dec0, target, grad_weight=1.0):
+        w, g, act, impl, ws, sc, bsc = self.w, self.g, self.act, self.impl, self.ws, self.scratch, self.bwd_scratch
+        B, T_in, _ = enc.shape
+        T_out = others.shape[1]
+        H, O = w["enc1_R"].shape[0], w["dense_W"].shape[1]
+        U = w["mixc0_W"].shape[2]
+        N0, N1 = w["mixc0_W"].shape[3], w["mixc1_W"].shape[3]
+        e = lambda *s_: torch.empty(s_, dtype=torch.float32, device=self.device)
+        self.grad.zero_()
+        # ---------------- forward ----------------
+        H1, C1, H2, C2 = e(T_out + 1, B, H), e(T_out + 1, B, H), e(T_out + 1, B, H), e(T_out + 1, B, H)
+        hs1, _, _, res1 = ops.lstm_seq_train(enc, w["enc1_K"], w["enc1_R"], w["enc1_b"], act=act, impl=impl, workspace=ws,
+                                             out=(e(B, T_in, H), H1[0], C1[0], e(B, T_in, 5, H)))
+        hs2, _, _, res2 = ops.lstm_seq_train(hs1, w["enc2_K"], w["enc2_R"], w["enc2_b"], act=act, impl=impl, workspace=ws,
+                                             out=(e(B, T_in, H), H2[0], C2[0], e(B, T_in, 5, H)))
+        othT = others.permute(1, 0, 3, 2).contiguous()       # (T_out,B,6,U-1): the users as channels of a 1 x 6 map
+        XM = e(T_out + 1, B, O)                               # row t = decoder input x_t, row t+1 = output m_t
+        X, M = XM[:T_out], XM[1:]
+        R1, R2 = e(T_out, B, 1, 5, H), e(T_out, B, 1, 5, H)
+        P, A1, A2 = e(T_out, B, O), e(T_out, B, 1, O, N0), e(T_out, B, 1, O, N1)
+        X[0].copy_(dec0.reshape(B, O))
+        for t in range(T_out):
+            ops.lstm_seq_train(X[t].view(B, 1, O), w["dec1_K"], w["dec1_R"], w["dec1_b"], H1[t], C1[t], act=act, impl=impl,
+                               workspace=ws, out=(H1[t + 1].view(B, 1, H), None, C1[t + 1], R1[t]))
+            ops.lstm_seq_train(H1[t + 1].view(B, 1, H), w["dec2_K"], w["dec2_R"], w["dec2_b"], H2[t], C2[t], act=act, impl=impl,
+                               workspace=ws, out=(H2[t + 1].view(B, 1, H), None, C2[t + 1], R2[t]))
+            ops.dense(H2[t + 1], w["dense_W"], w["dense_b"], activation="tanh", out=P[t])
+            ops.conv2d_cat(othT[t].view(B, 1, O, U - 1), P[t].view(B, 1, O, 1), w["mixc0_W"], w["mixc0_b"], activation="relu", out=A1[t])
+            ops.conv2d(A1[t], w["mixc1_W"], w["mixc1_b"], activation="relu", out=A2[t])
+            ops.conv2d(A2[t], w["mixc2_W"], w["mixc2_b"], activation="relu", out=M[t].view(B, 1, O, 1))
+        out = M.transpose(0, 1)
+        # ---------------- backward ----------------
+        dloss_tm, loss = ops.mse_dense_grad(M, target, None, scratch=sc, time_major=True)     # (T_out,B,O): dL/dm_t
+        wt2, wt1 = ops.conv2d_weight_transpose(w["mixc2_W"]), ops.conv2d_weight_transpose(w["mixc1_W"])
+        wt0_p = ops.conv2d_weight_transpose(w["mixc0_W"])[..., U - 1:].contiguous()           # only the prediction's channel
+        D3, D2, D1 = e(T_out, B, 1, O, 1), e(T_out, B, 1, O, N1), e(T_out, B, 1, O, N0)       # pre-activation gradients
+        DPRE, DZ1, DZ2 = e(T_out, B, O), e(T_out, B, 4 * H), e(T_out, B, 4 * H)
+        dh1_rec = dc1 = dh2_rec = dc2 = dx_next = None
+        for t in range(T_out - 1, -1, -1):
+            m4 = M[t].view(B, 1, O, 1)
+            if dx_next is None:
+                ops.act_bwd(dloss_tm[t].view(B, 1, O, 1), m4, activation="relu", out=D3[t])
+            else:        # x_{t+1} = m_t: the feedback gradient joins before the relu
+                dy = ops.act_bwd(dx_next.reshape(B, O), M[t], base=dloss_tm[t], activation=None)
+                ops.act_bwd(dy.view(B, 1, O, 1), m4, activation="relu", out=D3[t])
+            ops.act_bwd(ops.conv2d(D3[t], wt2), A2[t], activation="relu", out=D2[t])
+            ops.act_bwd(ops.conv2d(D2[t], wt1), A1[t], activation="relu", out=D1[t])
+            dp = ops.conv2d(D1[t], wt0_p)                                                      # (B,1,O,1): dL/dp_t
+            ops.act_bwd(dp.view(B, O), P[t], activation="tanh", out=DPRE[t])
+            dh2_dense, _, _ = ops.dense_bwd(H2[t + 1], w["dense_W"], DPRE[t], need_dx=True, need_dW=False, need_db=False, scratch=sc)
+            b2 = ops.lstm_seq_bwd(H1[t + 1].view(B, 1, H), w["dec2_K"], w["dec2_R"], H2[t + 1].view(B, 1, H), R2[t], h0=H2[t],
+                                  c0=C2[t], dhs=dh2_dense.reshape(B, 1, H), dhT=dh2_rec, dcT=dc2, need_dx=True, need_state_grads=True,
+                                  act=act, dz=DZ2[t].view(B, 1, 4 * H), scratch=bsc, need_weight_grads=False)
+            dh2_rec, dc2 = b2["dh0"], b2["dc0"]
+            b1 = ops.lstm_seq_bwd(X[t].view(B, 1, O), w["dec1_K"], w["dec1_R"], H1[t + 1].view(B, 1, H), R1[t], h0=H1[t], c0=C1[t],
+                                  dhs=b2["dx"], dhT=dh1_rec, dcT=dc1, need_dx=(t > 0), need_state_grads=True, act=act,
+                                  dz=DZ1[t].view(B, 1, 4 * H), scratch=bsc, need_weight_grads=False)
+            dh1_rec, dc1, dx_next = b1["dh0"], b1["dc0"], b1["dx"]
+        TB = T_out * B
+        fl = lambda a, n: a.reshape(TB, n)
+        # mixing convolutions: one weight-gradient product per layer over all steps; the first layer's input is two maps
+        ops.conv2d_wgrad(A2.view(TB, 1, O, N1), D3.view(TB, 1, O, 1), 1, 3, dw=g["mixc2_W"], scratch=sc)
+        ops.conv2d_wgrad(A1.view(TB, 1, O, N0), D2.view(TB, 1, O, N1), 1, 3, dw=g["mixc1_W"], scratch=sc)
+        g0_o = ops.conv2d_wgrad(othT.view(TB, 1, O, U - 1), D1.view(TB, 1, O, N0), 1, 3, scratch=sc)
+        g0_p = ops.conv2d_wgrad(P.view(TB, 1, O, 1), D1.view(TB, 1, O, N0), 1, 3, scratch=sc)
+        g["mixc0_W"][:, :, :U - 1].copy_(g0_o)
+        g["mixc0_W"][:, :, U - 1:].copy_(g0_p)
+        for i, D in enumerate((D1, D2, D3)):
+            ops.colsum(D.view(TB * O, -1), out=g["mixc%d_b" % i], scratch=sc)
+        ops.dense_bwd(fl(H2[1:], H), w["dense_W"], fl(DPRE, O), dW=g["dense_W"], db=g["dense_b"], need_dx=False, scratch=sc)
+        ops.dense_bwd(fl(H1[1:], H), w["dec2_K"], fl(DZ2, 4 * H), dW=g["dec2_K"], db=g["dec2_b"], need_dx=False, scratch=sc)
+        ops.dense_bwd(fl(H2[:T_out], H), w["dec2_R"], fl(DZ2, 4 * H), dW=g["dec2_R"], need_db=False, need_dx=False, scratch=sc)
+        ops.dense_bwd(fl(X, O), w["dec1_K"], fl(DZ1, 4 * H), dW=g["dec1_K"], db=g["dec1_b"], need_dx=False, scratch=sc)
+        ops.dense_bwd(fl(H1[:T_out], H), w["dec1_R"], fl(DZ1, 4 * H), dW=g["dec1_R"], need_db=False, need_dx=False, scratch=sc)
+        e2 = ops.lstm_seq_bwd(hs1, w["enc2_K"], w["enc2_R"], hs2, res2, dhT=dh2_rec, dcT=dc2, dK=g["enc2_K"], dR=g["enc2_R"],
+                              db=g["enc2_b"], need_dx=True, act=act, scratch=bsc)
+        ops.lstm_seq_bwd(enc, w["enc1_K"], w["enc1_R"], hs1, res1, dhs=e2["dx"], dhT=dh1_rec, dcT=dc1, dK=g["enc1_K"],
+                         dR=g["enc1_R"], db=g["enc1_b"], act=act, scratch=bsc)
+        loss = self._weigh(loss, grad_weight)
         return loss, out
 
 

@@ -162,28 +162,45 @@ def seq2seq_decode(enc_in, dec_in0, w, T_out, act="sigmoid"):
 
 
 def onelayer_tar_seq2seq_forward(enc_in, dec_in0, w, T_out, act="sigmoid", decoder_no_init_state=True,
-                                 add_residual_link=False, enc_last_out_as_dec_in=False, dense_activation="tanh"):
+                                 add_residual_link=False, enc_last_out_as_dec_in=False, dense_activation="tanh",
+                                 embed_frame_state_enc2dec=False, has_reconstruct_loss=False):
     """Unrolled no-teacher-forcing target-only model, FoV_seq2seq_no_teac_forc.py:37-149 (onelayer_tar_seq2seq):
     encoder LSTM (:42-44); decoder input = dec_in0 (B,1,O), or Dense(encoder output) when
     cfg.enc_last_out_as_dec_in (:75-78); step 0 of the decoder starts from ZERO state when the script's
     `decoder_no_init_state` is set (:29,98-99), later steps carry the decoder's own state (:118);
     y_t = Dense(h_t) [+ residual_dense(decoder input), cfg.add_residual_link, :103-107]; y_t is fed back (:115).
-    weights: enc_*, dec_*, dense_W/b and, with the residual link, res_W (O,O) / res_b."""
+    cfg.embed_frame_state_enc2dec (:47-52): the encoder's final h and c each pass a Dense(latent_dim, tanh) before they
+    seed the decoders (the decoder INPUT under enc_last_out_as_dec_in still comes from the raw encoder output, :78).
+    cfg.has_reconstruct_loss (:56-59,90-95,120-126): a second self-fed LSTM + Dense(num_encoder_tokens, tanh), seeded with
+    the same (embedded) states and fed Dense_recons(encoder output) first, emits T_out reconstructed input seconds;
+    the function then returns (prediction, reconstruction).
+    weights: enc_*, dec_*, dense_W/b; res_W (O,O) / res_b; emb1_W/b, emb2_W/b (H,H); rec_K/R/b, recd_W (H,F) / recd_b."""
     fa = (lambda v: np.tanh(v)) if dense_activation == "tanh" else (lambda v: np.maximum(v, 0))
-    _, h, c = lstm_layer(enc_in, w["enc_K"], w["enc_R"], w["enc_b"], act=act)
+    _, h_enc, c_enc = lstm_layer(enc_in, w["enc_K"], w["enc_R"], w["enc_b"], act=act)
+    sh, sc = h_enc, c_enc
+    if embed_frame_state_enc2dec:
+        sh = np.tanh(h_enc @ w["emb1_W"] + w["emb1_b"])
+        sc = np.tanh(c_enc @ w["emb2_W"] + w["emb2_b"])
     if enc_last_out_as_dec_in:
-        x0 = fa(h @ w["dense_W"] + w["dense_b"])
+        x0 = fa(h_enc @ w["dense_W"] + w["dense_b"])
     else:
         x0 = dec_in0[:, 0].astype(enc_in.dtype)
-    if decoder_no_init_state:
-        h, c = np.zeros_like(h), np.zeros_like(c)
+    h, c = (np.zeros_like(sh), np.zeros_like(sc)) if decoder_no_init_state else (sh, sc)
     r = fa(x0 @ w["res_W"] + w["res_b"]) if add_residual_link else 0.0
     x, out = x0, []
     for _ in range(T_out):
         h, c = lstm_step(x, h, c, w["dec_K"], w["dec_R"], w["dec_b"], act)
         x = fa(h @ w["dense_W"] + w["dense_b"]) + r
         out.append(x)
-    return np.stack(out, axis=1)
+    y = np.stack(out, axis=1)
+    if not has_reconstruct_loss:
+        return y
+    x, h, c, rec = np.tanh(h_enc @ w["recd_W"] + w["recd_b"]), sh, sc, []
+    for _ in range(T_out):
+        h, c = lstm_step(x, h, c, w["rec_K"], w["rec_R"], w["rec_b"], act)
+        x = np.tanh(h @ w["recd_W"] + w["recd_b"])
+        rec.append(x)
+    return y, np.stack(rec, axis=1)
 
 
 def stacked_seq2seq_forward(enc_in, dec_in, w, num_layers, act="sigmoid", T_out=None):
@@ -238,10 +255,13 @@ def single_lstm_keras_forward(x, w, T_out=None, unrolled=False, noise=None, act=
 # (mycode/given_others_gt_mean_var_seq2seq.py:98-130, 203-299)
 # weights: enc1_*, enc2_*, dec1_*, dec2_*, dense_W/b (H,6), mix_W (6*U,6), mix_b
 # --------------------------------------------------------------------------------------
-def others_mixing_forward(enc_in, others, dec_in0, w, act="sigmoid"):
+def others_mixing_forward(enc_in, others, dec_in0, w, act="sigmoid", mixing="mlp"):
     """enc_in:(B,T_in,F) others:(B,T_out,U-1,6) dec_in0:(B,1,6) -> (B,T_out,6).
     Per step: d1=LSTM1(x); d2=LSTM2(d1); p=tanh(d2 Wd+bd);
-    m=tanh(flatten(concat_axis1[others[:,t], p]) Wm + bm)  (user-major flatten, pred last); x=m."""
+    mixing 'mlp' (mlp_mixing, :166-168,262-265): m=tanh(flatten(concat_axis1[others[:,t], p]) Wm + bm) (user-major flatten,
+    pred last); mixing 'conv' (conv_mixing, :188-197,284-290): the (U,6) stack is permuted to a 1x6 map with the U users
+    as channels and passes three Conv2D(1x3, same, relu) layers with 8, 8 and 1 filters (weights mixc{0,1,2}_W (1,3,C,N),
+    mixc{0,1,2}_b); the single output channel is m.  x=m is fed back."""
     hs1, h1, c1 = lstm_layer(enc_in, w["enc1_K"], w["enc1_R"], w["enc1_b"], act=act)
     _, h2, c2 = lstm_layer(hs1, w["enc2_K"], w["enc2_R"], w["enc2_b"], act=act)
     x = dec_in0[:, 0].astype(enc_in.dtype)
@@ -252,7 +272,13 @@ def others_mixing_forward(enc_in, others, dec_in0, w, act="sigmoid"):
         h2, c2 = lstm_step(h1, h2, c2, w["dec2_K"], w["dec2_R"], w["dec2_b"], act)
         p = dense(h2, w["dense_W"], w["dense_b"], matrix_core=True)    # (B,6)
         cat = np.concatenate([others[:, t].astype(x.dtype), p[:, None, :]], axis=1)  # (B,U,6)
-        x = dense(cat.reshape(B, -1), w["mix_W"], w["mix_b"])           # (B,6)
+        if mixing == "conv":
+            a = np.transpose(cat, (0, 2, 1))[:, None]                   # Permute((2,1)) + expand_dims(1): (B,1,6,U)
+            for i in range(3):
+                a = np.maximum(conv2d_same(a, w["mixc%d_W" % i], w["mixc%d_b" % i]), 0)
+            x = a[:, 0, :, 0]                                           # get_dim1 + Permute((2,1)): (B,6)
+        else:
+            x = dense(cat.reshape(B, -1), w["mix_W"], w["mix_b"])       # (B,6)
         out.append(x)
     return np.stack(out, axis=1)
 

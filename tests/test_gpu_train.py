@@ -327,7 +327,7 @@ def test_persistent_bptt_matches_stepped_and_oracle():
             assert np.abs(s_ - r).max() <= 1e-4 * scale + 1e-9, (H, k)
 
 
-def _torch_mixing_graph(enc, oth, dec0, tgt, w, act):
+def _torch_mixing_graph(enc, oth, dec0, tgt, w, act, mixing="mlp"):
     """Independent fp64 reference of the a4 training graph (given_others...py:203-308) on torch.autograd."""
     t = {k: torch.tensor(v.astype(np.float64), requires_grad=True) for k, v in w.items()}
     H = w["enc1_R"].shape[0]
@@ -352,8 +352,14 @@ def _torch_mixing_graph(enc, oth, dec0, tgt, w, act):
         h1, c1 = step(x, h1, c1, t["dec1_K"], t["dec1_R"], t["dec1_b"])
         h2, c2 = step(h1, h2, c2, t["dec2_K"], t["dec2_R"], t["dec2_b"])
         p = torch.tanh(h2 @ t["dense_W"] + t["dense_b"])
-        cat = torch.cat([o_[:, tt], p[:, None, :]], dim=1).reshape(B, -1)
-        x = torch.tanh(cat @ t["mix_W"] + t["mix_b"])
+        cat = torch.cat([o_[:, tt], p[:, None, :]], dim=1)
+        if mixing == "conv":      # conv_mixing (:188-197,284-290): users = channels of a 1 x 6 map, three Conv2D(1x3, same, relu)
+            a = cat[:, :, None, :]                                       # NCHW (B,U,1,6)
+            for i in range(3):
+                a = torch.relu(torch.nn.functional.conv2d(a, t["mixc%d_W" % i].permute(3, 2, 0, 1), t["mixc%d_b" % i], padding=(0, 1)))
+            x = a[:, 0, 0, :]
+        else:
+            x = torch.tanh(cat.reshape(B, -1) @ t["mix_W"] + t["mix_b"])
         outs.append(x)
     y = torch.stack(outs, 1)
     loss = torch.mean((y - tg) ** 2)
@@ -394,6 +400,54 @@ def test_others_mixing_gradients_and_training(H, B, U, T_in, T_out, act):
             assert d <= 2e-5 * tr2.g[k].abs().max().item() + 1e-9, (k, d)
     losses = [float(tr.train_step(dev(enc), dev(oth), dev(dec0), dev(tgt)).item()) for _ in range(4)]
     assert losses[-1] < losses[0]
+
+
+@pytest.mark.parametrize("H,B,U,T_in,T_out,act", [(64, 20, 5, 4, 3, "sigmoid"), (128, 33, 34, 5, 4, "hard_sigmoid"),
+                                                  (256, 48, 34, 3, 5, "sigmoid")])
+def test_others_conv_mixing_gradients_and_training(H, B, U, T_in, T_out, act):
+    """conv_mixing (given_others_gt_mean_var_seq2seq.py:56,188-197,284-290): forward against the NumPy oracle, gradients of the
+    unrolled graph (three 1x3 convolutions over the users-as-channels map, feedback path included) against torch.autograd
+    fp64, the model object's predict / fit surface and an HDF5 round trip."""
+    from longterm360fov_amd.models import OthersConvMixingSeq2Seq
+    from longterm360fov_amd.training import OthersConvMixingTrainer, _CONV_MIX_ORDER
+    w = {k: v for k, v in O.init_others_mixing(170 + H, H=H, num_user=U, bias_noise=0.1).items() if not k.startswith("mix_")}
+    rng = np.random.default_rng(H + U)
+    for i, (c, n) in enumerate(((U, 8), (8, 8), (8, 1))):
+        w["mixc%d_W" % i] = (rng.standard_normal((1, 3, c, n)) / np.sqrt(3 * c)).astype(np.float32)
+        w["mixc%d_b" % i] = rng.uniform(0.05, 0.3, n).astype(np.float32)       # keeps most relu units alive
+    w["mixc2_W"] = np.abs(w["mixc2_W"])     # the single output channel stays positive: the feedback path carries gradient
+    enc, dec0, tgt, oth = O.synthetic_batch(171 + B, B, T_in, T_out, num_others=U - 1)
+    tgt = np.abs(tgt)
+    y_np = O.others_mixing_forward(enc.astype(np.float64), oth.astype(np.float64), dec0.astype(np.float64), f64(w), act=act, mixing="conv")
+    loss_ref, g_ref, y_ref = _torch_mixing_graph(enc, oth, dec0, tgt, w, act, mixing="conv")
+    np.testing.assert_allclose(y_np, y_ref, atol=1e-12)
+    assert (y_ref > 0).mean() > 0.5
+    tr = OthersConvMixingTrainer(w, act=act)
+    loss, y = tr.forward_backward(dev(enc), dev(oth), dev(dec0), dev(tgt))
+    tr.check()
+    assert abs(float(loss.item()) - loss_ref) <= 1e-5 * loss_ref + 1e-9
+    np.testing.assert_allclose(y.cpu().numpy(), y_ref, atol=2e-5)
+    for k in _CONV_MIX_ORDER:
+        a = tr.g[k].detach().cpu().numpy().astype(np.float64)
+        scale = np.abs(g_ref[k]).max()
+        err = np.abs(a - g_ref[k]).max()
+        print("conv mixing H%d grad %-8s max|ref| %.3e  max err %.3e" % (H, k, scale, err))
+        assert scale > 0 and err <= 1e-4 * scale + 1e-9, (k, err, scale)
+    m = OthersConvMixingSeq2Seq(latent_dim=H, num_user=U, recurrent_activation=act, seed=1)
+    m.set_weights([w[k] for k in _CONV_MIX_ORDER])
+    got = m.predict([enc, oth, dec0])
+    np.testing.assert_allclose(got, y_ref, atol=2e-5)
+    m.compile(optimizer="Adam", loss="mean_squared_error")
+    losses = [m.train_on_batch([enc, oth, dec0], tgt) for _ in range(5)]
+    assert abs(losses[0] - loss_ref) <= 1e-5 * loss_ref + 1e-9 and losses[-1] < losses[0]
+    h = m.fit([enc, oth, dec0], tgt, batch_size=16, epochs=2, validation_split=0.2)
+    assert len(h.history["loss"]) == 2 and "val_loss" in h.history
+    import os, tempfile
+    with tempfile.TemporaryDirectory() as d:
+        m.save_weights(os.path.join(d, "conv_mixing.h5"))
+        m2 = OthersConvMixingSeq2Seq(latent_dim=H, num_user=U, recurrent_activation=act, seed=9)
+        m2.load_weights(os.path.join(d, "conv_mixing.h5"))
+        np.testing.assert_array_equal(m2.predict([enc, oth, dec0]), m.predict([enc, oth, dec0]))
 
 
 def test_others_mixing_fit_surface():
@@ -560,7 +614,7 @@ def test_tf_stacked_lstm_training_graph(H, B, T, with_masks):
     assert np.allclose(ms.cpu().numpy(), ms_ref, atol=1e-6) and np.allclose(p.cpu().numpy(), -0.1 * gc / np.sqrt(ms_ref + 1e-10), atol=1e-6)
 
 
-def _torch_self_fed_graph(enc, dec0, tgt, w, act, no_init, residual, enc_as_in, dact):
+def _torch_self_fed_graph(enc, dec0, tgt, w, act, no_init, residual, enc_as_in, dact, embed=False, tgt_rec=None):
     """Independent fp64 reference of FoV_seq2seq_no_teac_forc.py:37-149 (onelayer_tar_seq2seq) on torch.autograd."""
     t = {k: torch.tensor(v.astype(np.float64), requires_grad=True) for k, v in w.items()}
     H = w["enc_R"].shape[0]
@@ -578,9 +632,11 @@ def _torch_self_fed_graph(enc, dec0, tgt, w, act, no_init, residual, enc_as_in, 
     h = c = torch.zeros(B, H, dtype=torch.float64)
     for tt in range(e.shape[1]):
         h, c = step(e[:, tt], h, c, t["enc_K"], t["enc_R"], t["enc_b"])
-    x0 = fa(h @ t["dense_W"] + t["dense_b"]) if enc_as_in else d0[:, 0]
-    if no_init:
-        h = c = torch.zeros(B, H, dtype=torch.float64)
+    h_enc, sh, sc = h, h, c
+    if embed:
+        sh, sc = torch.tanh(h @ t["emb1_W"] + t["emb1_b"]), torch.tanh(c @ t["emb2_W"] + t["emb2_b"])
+    x0 = fa(h_enc @ t["dense_W"] + t["dense_b"]) if enc_as_in else d0[:, 0]
+    h, c = (torch.zeros(B, H, dtype=torch.float64),) * 2 if no_init else (sh, sc)
     r = fa(x0 @ t["res_W"] + t["res_b"]) if residual else 0.0
     x, outs = x0, []
     for _ in range(tg.shape[1]):
@@ -589,9 +645,20 @@ def _torch_self_fed_graph(enc, dec0, tgt, w, act, no_init, residual, enc_as_in, 
         outs.append(x)
     y = torch.stack(outs, 1)
     loss = torch.mean((y - tg) ** 2)
+    rec = None
+    if tgt_rec is not None:     # reconstruction decoder: its own LSTM + Dense(F, tanh), seeded with the same states
+        x, h, c, outs = torch.tanh(h_enc @ t["recd_W"] + t["recd_b"]), sh, sc, []
+        for _ in range(tg.shape[1]):
+            h, c = step(x, h, c, t["rec_K"], t["rec_R"], t["rec_b"])
+            x = torch.tanh(h @ t["recd_W"] + t["recd_b"])
+            outs.append(x)
+        rec = torch.stack(outs, 1)
+        loss = loss + torch.mean((rec - torch.tensor(tgt_rec.astype(np.float64))) ** 2)
     loss.backward()
-    return float(loss), {k: (np.zeros_like(w[k], dtype=np.float64) if v.grad is None else v.grad.numpy()) for k, v in t.items()}, \
-        y.detach().numpy()
+    grads = {k: (np.zeros_like(w[k], dtype=np.float64) if v.grad is None else v.grad.numpy()) for k, v in t.items()}
+    if rec is not None:
+        return float(loss), grads, y.detach().numpy(), rec.detach().numpy()
+    return float(loss), grads, y.detach().numpy()
 
 
 @pytest.mark.parametrize("H,B,T_in,T_out,act,no_init,residual,enc_as_in,dact", [
@@ -644,6 +711,92 @@ def test_no_teacher_forcing_one_layer_gradients_and_training(H, B, T_in, T_out, 
     assert losses[-1] < losses[0]
     h = m.fit(enc if enc_as_in else [enc, dec0], tgt, batch_size=16, epochs=2, validation_split=0.2)
     assert len(h.history["loss"]) == 2 and "val_loss" in h.history
+
+
+@pytest.mark.parametrize("H,B,T,act,no_init,residual,enc_as_in,embed,recons", [
+    (64, 19, 4, "sigmoid", False, False, False, True, False),       # cfg.embed_frame_state_enc2dec alone
+    (64, 21, 5, "sigmoid", True, False, True, False, True),         # cfg.has_reconstruct_loss as the script wires it (:135, :267)
+    (128, 33, 4, "hard_sigmoid", False, True, True, True, True),    # both, + residual link, decoder seeded with the embedded state
+    (256, 24, 3, "sigmoid", True, False, False, True, True),        # zero-state decoder: the encoder is reached only through the reconstruction
+])
+def test_no_teacher_forcing_embedded_state_and_reconstruction_decoder(H, B, T, act, no_init, residual, enc_as_in, embed, recons):
+    """cfg.embed_frame_state_enc2dec (FoV_seq2seq_no_teac_forc.py:47-52: Dense(latent_dim, tanh) on the encoder's h and c) and
+    cfg.has_reconstruct_loss (:56-59,90-95,120-139: second self-fed LSTM + Dense(num_encoder_tokens, tanh), two outputs,
+    MSE + MSE, target encoder_input[:, ::-1] :267): forward against the NumPy oracle, all gradients against torch.autograd
+    fp64, the model object's two-output predict / fit surface."""
+    from longterm360fov_amd.models import NoTeacherForcingSeq2Seq
+    from longterm360fov_amd.training import SelfFedSeq2SeqTrainer, self_fed_weight_order
+    F = 90
+    w = O.init_seq2seq(190 + H, H=H, bias_noise=0.1)
+    rng = np.random.default_rng(H + B)
+    u = lambda *shape: rng.uniform(-0.3, 0.3, shape).astype(np.float32)
+    if residual:
+        w["res_W"], w["res_b"] = u(6, 6), u(6)
+    if embed:
+        w["emb1_W"], w["emb1_b"], w["emb2_W"], w["emb2_b"] = u(H, H) / 4, u(H), u(H, H) / 4, u(H)
+    if recons:
+        w["rec_K"], w["rec_R"], w["rec_b"] = O.init_lstm(rng, F, H)
+        w["recd_W"], w["recd_b"] = u(H, F), u(F)
+    enc, dec0, tgt = O.synthetic_batch(291 + B, B, T, T)
+    tgt_rec = np.ascontiguousarray(enc[:, ::-1, :]) if recons else None
+    kw = dict(decoder_no_init_state=no_init, add_residual_link=residual, enc_last_out_as_dec_in=enc_as_in,
+              embed_frame_state_enc2dec=embed, has_reconstruct_loss=recons)
+    ref = _torch_self_fed_graph(enc, dec0, tgt, w, act, no_init, residual, enc_as_in, "tanh", embed=embed, tgt_rec=tgt_rec)
+    loss_ref, g_ref, y_ref = ref[:3]
+    y_np = O.onelayer_tar_seq2seq_forward(enc.astype(np.float64), dec0.astype(np.float64), f64(w), T, act=act, **kw)
+    if recons:
+        np.testing.assert_allclose(y_np[0], y_ref, atol=1e-12)
+        np.testing.assert_allclose(y_np[1], ref[3], atol=1e-12)
+    else:
+        np.testing.assert_allclose(y_np, y_ref, atol=1e-12)
+    tr = SelfFedSeq2SeqTrainer(w, act=act, **kw)
+    packed = np.concatenate([tgt, tgt_rec], -1) if recons else tgt
+    loss, y = tr.forward_backward(dev(enc), dev(dec0), dev(packed))
+    tr.check()
+    assert abs(float(loss.item()) - loss_ref) <= 1e-5 * loss_ref + 1e-9
+    np.testing.assert_allclose(y.cpu().numpy()[..., :6], y_ref, atol=2e-5)
+    if recons:
+        np.testing.assert_allclose(y.cpu().numpy()[..., 6:], ref[3], atol=2e-5)
+    assert set(tr.g) == set(self_fed_weight_order(residual, embed, recons))
+    for k in tr.g:
+        a = tr.g[k].detach().cpu().numpy().astype(np.float64)
+        scale = max(np.abs(g_ref[k]).max(), 1e-30)
+        err = np.abs(a - g_ref[k]).max()
+        print("self-fed+ H%d grad %-8s max|ref| %.3e  max err %.3e" % (H, k, scale, err))
+        assert err <= 1e-4 * scale + 1e-9, (k, err, scale)
+    if embed and no_init and not recons:
+        assert float(tr.g["emb1_W"].abs().max()) == 0.0       # zero-state decoder: the embedding is not reached
+    assert float(tr.g["enc_K"].abs().max()) > 0.0 or (no_init and not enc_as_in and not recons)
+    m = NoTeacherForcingSeq2Seq(latent_dim=H, recurrent_activation=act, predict_step=T, **kw)
+    m.set_weights([w[k] for k in self_fed_weight_order(residual, embed, recons)])
+    x = [enc, np.zeros((B, T, 6), np.float32)] if enc_as_in else [enc, dec0]     # [encoder_inputs, time_ind_input] (:135) / [enc, dec0]
+    got = m.predict(x)
+    if recons:
+        assert isinstance(got, list) and got[0].shape == (B, T, 6) and got[1].shape == (B, T, F)
+        np.testing.assert_allclose(got[0], y_ref, atol=2e-5)
+        np.testing.assert_allclose(got[1], ref[3], atol=2e-5)
+    else:
+        np.testing.assert_allclose(got, y_ref, atol=2e-5)
+    m.compile(optimizer="Adam", loss="mean_squared_error")
+    yt = [tgt, tgt_rec] if recons else tgt
+    l0 = m.train_on_batch(x, yt)
+    assert abs(l0 - loss_ref) <= 1e-5 * loss_ref + 1e-9
+    losses = [l0] + [m.train_on_batch(x, yt) for _ in range(4)]
+    assert losses[-1] < losses[0]
+    h = m.fit(x, yt, batch_size=8, epochs=2, validation_split=0.25)
+    assert len(h.history["loss"]) == 2 and "val_loss" in h.history
+    if recons:
+        with pytest.raises(ValueError):
+            m.train_on_batch(x, tgt)
+    # Keras HDF5 round trip with the extra layers
+    import os, tempfile
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "self_fed.h5")
+        m.save_weights(path)
+        m2 = NoTeacherForcingSeq2Seq(latent_dim=H, recurrent_activation=act, predict_step=T, seed=3, **kw)
+        m2.load_weights(path)
+        for a, b in zip(m.get_weights(), m2.get_weights()):
+            assert np.array_equal(a, b)
 
 
 def _torch_tf_lstm_refeed_graph(x, y, cells, head, init, fps, running_length, noise, forget_bias=1.0, masks=None):

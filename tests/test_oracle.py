@@ -235,6 +235,20 @@ def test_onelayer_no_teacher_forcing_oracle_properties():
     w["res_W"], w["res_b"] = np.eye(6) * 0.3, np.zeros(6)
     d = O.onelayer_tar_seq2seq_forward(enc, dec0, w, 5, decoder_no_init_state=False, add_residual_link=True)
     assert np.abs(d).max() <= 2.0 and np.abs(d - c).max() > 1e-4      # tanh + tanh
+    # cfg.embed_frame_state_enc2dec (:47-52) only matters when the decoder is seeded; the reconstruction decoder (:56-59,
+    # 120-126) is a second output that leaves the prediction alone and is bounded by its tanh head
+    rng = np.random.default_rng(0)
+    w.update(emb1_W=rng.normal(size=(16, 16)), emb1_b=np.zeros(16), emb2_W=rng.normal(size=(16, 16)), emb2_b=np.zeros(16))
+    w["rec_K"], w["rec_R"], w["rec_b"] = (v.astype(np.float64) for v in O.init_lstm(rng, 90, 16))
+    w["recd_W"], w["recd_b"] = rng.normal(size=(16, 90)) * 0.3, np.zeros(90)
+    np.testing.assert_array_equal(O.onelayer_tar_seq2seq_forward(enc, dec0, w, 5, embed_frame_state_enc2dec=True), a)
+    e = O.onelayer_tar_seq2seq_forward(enc, dec0, w, 5, decoder_no_init_state=False, embed_frame_state_enc2dec=True)
+    assert np.abs(e - c).max() > 1e-4
+    y, rec = O.onelayer_tar_seq2seq_forward(enc, dec0, w, 5, decoder_no_init_state=False, has_reconstruct_loss=True)
+    np.testing.assert_array_equal(y, c)
+    assert rec.shape == (4, 5, 90) and np.abs(rec).max() < 1.0
+    _, rec2 = O.onelayer_tar_seq2seq_forward(enc[::-1].copy(), dec0, w, 5, has_reconstruct_loss=True)
+    assert np.abs(rec2[::-1] - rec).max() < 1e-15       # the reconstruction is seeded by the encoder whatever decoder_no_init_state says
 
 
 def _load_torch_lstm(m, layer, suffix, K, R, b):
