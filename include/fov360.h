@@ -166,6 +166,21 @@ int fov_dense_bwd_bf16(const float* x, const float* W, const float* dpre, float*
                        int N, int In, int Out, int accumulate,
                        void* workspace, size_t workspace_bytes, fov_stream_t stream);
 
+/* The three weight gradients of an (unrolled) LSTM layer as ONE product and one reduce - what Keras/TF autodiff
+ * computes as three (given_others...py:308 under model.fit):
+ *     out (In1 + In2 + bias, Out) (+)= [x1 | x2 | 1]^T dpre        over the N rows (all steps x sequences)
+ * i.e. rows [0, In1) = dK = x^T dz, rows [In1, In1+In2) = dR = h_prev^T dz, last row = db = column sums of dz: the layout
+ * of a layer's kernel, recurrent_kernel and bias when they are adjacent in a flat gradient buffer.  x1 (N,In1), x2
+ * (N,In2) or NULL with In2 = 0, dpre (N,Out), all dense row-major.  dpre is read once instead of three times and the
+ * split partials are reduced by one launch.  bf16 != 0: operands rounded to bf16 (the bias row is summed in fp32 from
+ * the unrounded values).  Shapes the fused kernel does not take (operands not 16-byte aligned, In1 not a multiple of
+ * 128 with x2 given, In1 + In2 <= 96) produce the same result from the separate products.
+ * fov_lstm_seq_bwd[_bf16] does the same internally when it is handed adjacent dK, dR, db and no initial state. */
+size_t fov_wgrad_fused_workspace_bytes(int64_t N, int In1, int In2, int Out);
+int fov_wgrad_fused(const float* x1, int In1, const float* x2, int In2, const float* dpre, float* out,
+                    int64_t N, int Out, int bias, int accumulate, int bf16,
+                    void* workspace, size_t workspace_bytes, fov_stream_t stream);
+
 /* fov_lstm_seq_fwd_train with bf16 operands (reserve may be NULL for inference); workspace >= 256 + 64 MB. */
 int fov_lstm_seq_fwd_bf16(const float* x, const float* K, const float* R, const float* b, const float* h0,
                           const float* c0, float* hs, float* hT, float* cT, float* reserve, int B, int T, int F, int H,

@@ -296,6 +296,10 @@ bool bwd8_preferred(int B, int H);
 int launch_bwd8(const float* R, const float* reserve, const float* c0, const float* dhs, const float* dhT, const float* dcT,
                 float* dz, float* dh0, float* dc0, float* db_part, int B, int T, int act, int bf16, void* xch_ws, hipStream_t stream);
 // gemm_bf16.hip
+size_t gemm_bf16_tn_scratch_floats(int M, int N);
+int gemm_bf16_tn_fused(const float* a1, long lda1, long a1_so, int M1, int shift1, const float* a2, long lda2, long a2_so, int M2,
+                       int shift2, const float* b, long ldb, long b_so, float* c, int ldc, int N, int RO, int RI, int bias_row,
+                       int accumulate, float* scratch, size_t scratch_floats, hipStream_t stream);
 int gemm_bf16_tn(const float* a, long lda, long a_so, const float* b, long ldb, long b_so, float* c, int ldc, int M, int N, int RO,
                  int RI, int accumulate, float* scratch, size_t scratch_floats, hipStream_t stream);
 int gemm_bf16_nt(const float* a, long lda, const float* b, long ldb, float* c, int ldc, int M, int N, int K, hipStream_t stream);

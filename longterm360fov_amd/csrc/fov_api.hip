@@ -486,6 +486,36 @@ int fov_dense_bwd(const float* x, const float* W, const float* dpre, float* dx, 
                      (hipStream_t)stream, 0);
 }
 
+size_t fov_wgrad_fused_workspace_bytes(int64_t N, int In1, int In2, int Out) {
+    if (N <= 0 || In1 <= 0 || In2 < 0 || Out <= 0) return 256;
+    const size_t a = fov_dense_bwd_workspace_bytes((int)N, In1 + In2 + 1, Out);
+    const size_t b = sizeof(float) * gemm_bf16_tn_scratch_floats(In1 + In2 + 1, Out);
+    return a > b ? a : b;
+}
+
+int fov_wgrad_fused(const float* x1, int In1, const float* x2, int In2, const float* dpre, float* out, int64_t N, int Out,
+                    int bias, int accumulate, int bf16, void* workspace, size_t workspace_bytes, fov_stream_t stream) {
+    if (N < 0 || In1 <= 0 || In2 < 0 || Out <= 0 || !out || (N > 0 && (!x1 || !dpre || (In2 > 0 && !x2))) || N > 0x7fffffffL) {
+        set_error("fov_wgrad_fused: invalid argument");
+        return FOV_ERR_INVALID;
+    }
+    int rc = check_ws(workspace, workspace_bytes, fov_wgrad_fused_workspace_bytes(N, In1, In2, Out));
+    if (rc) return rc;
+    float* ws = (float*)workspace;
+    const size_t wsf = workspace_bytes / sizeof(float);
+    const float* a2 = In2 > 0 ? x2 : nullptr;
+    if (N > 0 && wgrad_fusable(x1, In1, 0, In1, a2, In2, 0, In2, dpre, Out, 0, out, Out) && (!bf16 || Out >= 64))
+        return wgrad_fused(x1, In1, 0, In1, 0, a2, In2, 0, In2, 0, dpre, Out, 0, out, Out, 1, (int)N, bias, accumulate, bf16, ws, wsf,
+                           (hipStream_t)stream);
+    // shapes the fused product does not take: the same result from the separate products
+    rc = dense_bwd(x1, nullptr, dpre, nullptr, out, bias ? out + (size_t)(In1 + In2) * Out : nullptr, (int)N, In1, Out, accumulate, ws,
+                   wsf, (hipStream_t)stream, bf16);
+    if (rc == 0 && In2 > 0)
+        rc = dense_bwd(x2, nullptr, dpre, nullptr, out + (size_t)In1 * Out, nullptr, (int)N, In2, Out, accumulate, ws, wsf,
+                       (hipStream_t)stream, bf16);
+    return rc;
+}
+
 int fov_dense_bwd_bf16(const float* x, const float* W, const float* dpre, float* dx, float* dW, float* db, int N, int In,
                        int Out, int accumulate, void* workspace, size_t workspace_bytes, fov_stream_t stream) {
     if (N < 0 || In <= 0 || Out <= 0 || (N > 0 && (!x || !W || !dpre))) {

@@ -156,6 +156,11 @@ int lstm_seq_bwd(const float* x, const float* K, const float* R, const float* h0
                  const float* reserve, const float* dhs, const float* dhT, const float* dcT, float* dz, float* dx,
                  float* dK, float* dR, float* db, float* dh0, float* dc0, int B, int T, int F, int H, int act,
                  int accumulate, float* ws, size_t ws_floats, hipStream_t stream, int bf16 = 0);
+bool wgrad_fusable(const float* a1, long lda1, long a1_so, int M1, const float* a2, long lda2, long a2_so, int M2, const float* b,
+                   long ldb, long b_so, const float* c, int N);
+int wgrad_fused(const float* a1, long lda1, long a1_so, int M1, int shift1, const float* a2, long lda2, long a2_so, int M2, int shift2,
+                const float* b, long ldb, long b_so, float* c, int N, int RO, int RI, int bias_row, int accumulate, int bf16,
+                float* scratch, size_t scratch_floats, hipStream_t stream);
 int dense_bwd(const float* x, const float* W, const float* dpre, float* dx, float* dW, float* db, int N, int In, int Out,
               int accumulate, float* scratch, size_t scratch_floats, hipStream_t stream, int bf16 = 0);
 int mse_dense_grad(const float* y, const float* target, float* dpre, float* loss, long n, int activation, float* scratch,

@@ -34,13 +34,21 @@ constexpr int GLD_NT = 40;       // bf16 per LDS row of a [GT][k] image
 struct GemmTN {
     const float* a;
     const float* b;
-    float* c;            // split == 1: C (ldc); else partials [slice][M][N]
+    float* c;            // split == 1: C (ldc); else partials [slice][M + bias_row][N]
     int M, N, RO, RI;
     long lda, ldb, a_so, b_so;
     int ldc;
     int split;           // row slices (grid.z)
     long rows_per_split; // multiple of GKB
     int add_c;           // split == 1 only: C += A^T B
+    int xcd_remap, grid_n, grid_m;   // 1-D grid, slice s on XCD s % 8 (split >= 8): the blocks of a slice read the same rows of
+                                     // A and B, so each XCD's L2 fetches 1/8 of the operands once instead of all of A
+    // fused weight gradient [dK ; dR ; db] = [x | h_prev | 1]^T dz (one product, one reduce):
+    const float* a2;     // second A operand: rows [M1, M) of C come from it (M1 % GT == 0), or NULL
+    long lda2, a2_so;
+    int M1;
+    int a_shift, a2_shift;   // 1: operand row (ro, ri) is its element (ro, ri - 1), zero at ri == 0 (h_{t-1} of a (B,T,H) tape)
+    int bias_row;        // 1: row M of C = column sums of B (fp32, taken from the staged values before they are rounded)
 };
 
 // two transposed reads = the 8 k-values of one column for this lane group (k permutation in the file header)
@@ -60,9 +68,27 @@ __global__ __launch_bounds__(256) void gemm_bf16_tn_kernel(GemmTN g) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 15, g4 = lane >> 4;
     const int wm = wave >> 1, wn = wave & 1;
-    const int m0 = blockIdx.y * GT, n0 = blockIdx.x * GT;
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (g.xcd_remap) {
+        const int nb = g.grid_n * g.grid_m;
+        const int xcd = blockIdx.x & 7, w = blockIdx.x >> 3;
+        bz = xcd + 8 * (w / nb);
+        if (bz >= g.split) return;   // whole block, before any barrier
+        const int tile = w - (w / nb) * nb;
+        by = tile / g.grid_n;
+        bx = tile - by * g.grid_n;
+    }
+    const int m0 = by * GT, n0 = bx * GT;
+    // which A operand this row tile reads (block-uniform)
+    const bool second = g.a2 != nullptr && m0 >= g.M1;
+    const float* abase = second ? g.a2 : g.a;
+    const long a_ld = second ? g.lda2 : g.lda, a_so = second ? g.a2_so : g.a_so;
+    const int a_shift = second ? g.a2_shift : g.a_shift;
+    const int am0 = second ? m0 - g.M1 : m0;                           // first row of the tile inside its operand
+    const int a_M = second ? g.M - g.M1 : (g.a2 ? g.M1 : g.M);          // width of that operand
+    const bool bias_blk = g.bias_row && by == 0;
     const long rows = (long)g.RO * g.RI;
-    const long r_lo = (long)blockIdx.z * g.rows_per_split;
+    const long r_lo = (long)bz * g.rows_per_split;
     long r_hi = r_lo + g.rows_per_split;
     if (r_hi > rows) r_hi = rows;
     // staging: thread = (row tid >> 5 (+ 8 i), 4 columns (tid & 31) * 4)
@@ -73,6 +99,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_tn_kernel(GemmTN g) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     f32x4 ra[4], rb[4];
+    f32x4 bsum = (f32x4){0.f, 0.f, 0.f, 0.f};   // bias_blk: column sums of this thread's B elements
     auto load_stage = [&](long r0) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -81,14 +108,16 @@ __global__ __launch_bounds__(256) void gemm_bf16_tn_kernel(GemmTN g) {
             rb[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
             if (r < r_hi) {
                 const long ro = r / g.RI, ri = r - ro * g.RI;
-                const float* ap = g.a + ro * g.a_so + ri * g.lda + m0 + scol;
+                const float* ap = abase + ro * a_so + (ri - a_shift) * a_ld + am0 + scol;
                 const float* bp = g.b + ro * g.b_so + ri * g.ldb + n0 + scol;
-                if (AVEC) {
-                    if (m0 + scol < g.M) ra[i] = *(const f32x4*)ap;
+                if (a_shift && ri == 0) {
+                    // h_{-1} = 0
+                } else if (AVEC) {
+                    if (am0 + scol < a_M) ra[i] = *(const f32x4*)ap;
                 } else {
 #pragma unroll
                     for (int v = 0; v < 4; ++v)
-                        if (m0 + scol + v < g.M) ra[i][v] = ap[v];
+                        if (am0 + scol + v < a_M) ra[i][v] = ap[v];
                 }
                 if (n0 + scol + 3 < g.N) {
                     rb[i] = *(const f32x4*)bp;
@@ -105,6 +134,10 @@ __global__ __launch_bounds__(256) void gemm_bf16_tn_kernel(GemmTN g) {
         for (int i = 0; i < 4; ++i) {
             *(qu32x2*)(sA[buf] + (srow + 8 * i) * GLD_TN + scol) = (qu32x2){pack_bf16(ra[i][0], ra[i][1]), pack_bf16(ra[i][2], ra[i][3])};
             *(qu32x2*)(sB[buf] + (srow + 8 * i) * GLD_TN + scol) = (qu32x2){pack_bf16(rb[i][0], rb[i][1]), pack_bf16(rb[i][2], rb[i][3])};
+        }
+        if (bias_blk) {   // every stage is stored exactly once
+#pragma unroll
+            for (int i = 0; i < 4; ++i) bsum += rb[i];
         }
     };
     const long nstages = (r_hi > r_lo) ? (r_hi - r_lo + GKB - 1) / GKB : 0;
@@ -129,8 +162,20 @@ __global__ __launch_bounds__(256) void gemm_bf16_tn_kernel(GemmTN g) {
         if (s + 1 < nstages) store_stage(buf ^ 1);
         __syncthreads();
     }
-    float* cbase = g.split > 1 ? g.c + (size_t)blockIdx.z * g.M * g.N : g.c;
+    float* cbase = g.split > 1 ? g.c + (size_t)bz * (g.M + g.bias_row) * g.N : g.c;
     const int ldc = g.split > 1 ? g.N : g.ldc;
+    if (bias_blk) {   // row M: the eight row groups' column sums, folded in a fixed order (the loop ended on a barrier)
+        float* red = reinterpret_cast<float*>(sA[0]);
+        *(f32x4*)(red + srow * GT + scol) = bsum;
+        __syncthreads();
+        if (tid < GT && n0 + tid < g.N) {
+            float t = 0.f;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) t += red[q * GT + tid];
+            float* cp = cbase + (size_t)g.M * ldc + n0 + tid;
+            *cp = (g.split == 1 && g.add_c) ? *cp + t : t;
+        }
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -223,27 +268,32 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(GemmNT g) {
 
 }  // namespace
 
-size_t gemm_bf16_tn_scratch_floats(int M, int N) { return (size_t)32 * M * N; }
+size_t gemm_bf16_tn_scratch_floats(int M, int N) { return (size_t)32 * (M + 1) * N; }
 
-// C (M,N) (+)= sum over rows (ro, ri) of A[row][m] B[row][n]; scratch holds the split partials
-int gemm_bf16_tn(const float* a, long lda, long a_so, const float* b, long ldb, long b_so, float* c, int ldc, int M, int N, int RO,
-                 int RI, int accumulate, float* scratch, size_t scratch_floats, hipStream_t stream) {
+// C (M + bias_row, N) (+)= [A1 | A2 | 1]^T B over rows (ro, ri); scratch holds the split partials.  A2 may be NULL (M2 = 0).
+int gemm_bf16_tn_fused(const float* a1, long lda1, long a1_so, int M1, int shift1, const float* a2, long lda2, long a2_so, int M2,
+                       int shift2, const float* b, long ldb, long b_so, float* c, int ldc, int N, int RO, int RI, int bias_row,
+                       int accumulate, float* scratch, size_t scratch_floats, hipStream_t stream) {
+    const int M = M1 + (a2 ? M2 : 0);
     if (M <= 0 || N <= 0) return FOV_OK;
     const long rows = (long)RO * RI;
     if ((ldb & 3) || (b_so & 3) || (((uintptr_t)b) & 15) || (N & 3)) { set_error("gemm_bf16_tn: B must be 16-byte aligned with N, ldb % 4 == 0"); return FOV_ERR_INVALID; }
+    if (a2 && (M1 % GT)) { set_error("gemm_bf16_tn: the first operand of a fused product must be a multiple of %d wide", GT); return FOV_ERR_INVALID; }
     if (rows <= 0) {
-        if (!accumulate) (void)hipMemsetAsync(c, 0, sizeof(float) * (size_t)M * ldc, stream);
+        if (!accumulate) (void)hipMemsetAsync(c, 0, sizeof(float) * (size_t)(M + bias_row) * ldc, stream);
         return FOV_OK;
     }
     GemmTN g = {};
-    g.a = a; g.b = b; g.M = M; g.N = N; g.RO = RO; g.RI = RI; g.lda = lda; g.ldb = ldb; g.a_so = a_so; g.b_so = b_so; g.ldc = ldc;
+    g.a = a1; g.b = b; g.M = M; g.N = N; g.RO = RO; g.RI = RI; g.lda = lda1; g.ldb = ldb; g.a_so = a1_so; g.b_so = b_so; g.ldc = ldc;
+    g.a2 = a2; g.lda2 = lda2; g.a2_so = a2_so; g.M1 = M1; g.a_shift = shift1; g.a2_shift = shift2; g.bias_row = bias_row ? 1 : 0;
     const int tiles = ((M + GT - 1) / GT) * ((N + GT - 1) / GT);
     // enough row slices to fill the chip, at least 8 stages each, at most 32 slices and what the scratch holds
     int split = (2 * device_cu_count() + tiles - 1) / tiles;
     const long max_by_rows = rows / (8 * GKB);
     if (split > max_by_rows) split = (int)max_by_rows;
     if (split > 32) split = 32;
-    while (split > 1 && (size_t)split * M * N > scratch_floats) --split;
+    if (const char* e = getenv("FOV_GEMM_BF16_SPLIT")) { const int v = atoi(e); if (v >= 1 && v <= max_by_rows) split = v; }   // tuning knob
+    while (split > 1 && (size_t)split * (M + g.bias_row) * N > scratch_floats) --split;
     if (split < 1) split = 1;
     long rps = (rows + split - 1) / split;
     rps = (rps + GKB - 1) / GKB * GKB;
@@ -253,14 +303,25 @@ int gemm_bf16_tn(const float* a, long lda, long a_so, const float* b, long ldb, 
     g.add_c = accumulate;
     g.c = split > 1 ? scratch : c;
     if (split > 1 && ldc != N) { set_error("gemm_bf16_tn: split products need a dense C"); return FOV_ERR_INVALID; }
-    const dim3 grid((N + GT - 1) / GT, (M + GT - 1) / GT, split);
-    const bool avec = (lda & 3) == 0 && (a_so & 3) == 0 && (((uintptr_t)a) & 15) == 0 && (M & 3) == 0;
+    g.grid_n = (N + GT - 1) / GT;
+    g.grid_m = (M + GT - 1) / GT;
+    g.xcd_remap = (split >= 8 && !getenv("FOV_GEMM_BF16_NOREMAP")) ? 1 : 0;
+    const dim3 grid = g.xcd_remap ? dim3((unsigned)(8 * ((split + 7) / 8) * g.grid_n * g.grid_m)) : dim3(g.grid_n, g.grid_m, split);
+    const bool avec = (lda1 & 3) == 0 && (a1_so & 3) == 0 && (((uintptr_t)a1) & 15) == 0 && (M1 & 3) == 0 &&
+                      (!a2 || ((lda2 & 3) == 0 && (a2_so & 3) == 0 && (((uintptr_t)a2) & 15) == 0 && (M2 & 3) == 0));
     if (avec) hipLaunchKernelGGL(gemm_bf16_tn_kernel<true>, grid, dim3(256), 0, stream, g);
     else hipLaunchKernelGGL(gemm_bf16_tn_kernel<false>, grid, dim3(256), 0, stream, g);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("gemm_bf16_tn launch: %s", hipGetErrorString(e)); return FOV_ERR_LAUNCH; }
-    if (split > 1) return splitk_reduce(scratch, c, (long)M * N, split, accumulate, stream);
+    if (split > 1) return splitk_reduce(scratch, c, (long)(M + g.bias_row) * N, split, accumulate, stream);
     return FOV_OK;
+}
+
+// C (M,N) (+)= sum over rows (ro, ri) of A[row][m] B[row][n]
+int gemm_bf16_tn(const float* a, long lda, long a_so, const float* b, long ldb, long b_so, float* c, int ldc, int M, int N, int RO,
+                 int RI, int accumulate, float* scratch, size_t scratch_floats, hipStream_t stream) {
+    return gemm_bf16_tn_fused(a, lda, a_so, M, 0, nullptr, 0, 0, 0, 0, b, ldb, b_so, c, ldc, N, RO, RI, 0, accumulate, scratch,
+                              scratch_floats, stream);
 }
 
 int gemm_bf16_nt(const float* a, long lda, const float* b, long ldb, float* c, int ldc, int M, int N, int K, hipStream_t stream) {

@@ -38,6 +38,12 @@ struct GemmArgs {
     int tiles_per_split; // k-tiles (of 16, never straddling a ko row) per slice
     int xcd_remap, grid_n, grid_m;   // 1-D grid with slices pinned to XCDs (split >= 8)
     int add_c;       // single-slice accumulate: C += A.B in the epilogue (one writer per element, deterministic)
+    // fused weight gradient [dK ; dR ; db] = [x | h_prev | 1]^T dz (one product, one reduce); k-slow operands only
+    const float* a2;   // second A operand: rows [M1, M) of C come from it (M1 a multiple of the row tile), or NULL
+    long a2_sko, a2_ski;
+    int M1;
+    int a_shift, a2_shift;   // 1: k index (ko, ki) of the operand is its element (ko, ki - 1), zero at ki == 0
+    int bias_row;      // 1: row M of C = column sums of B (B staged with 16-byte loads)
 };
 
 constexpr int GBK = 16;
@@ -91,19 +97,22 @@ struct OperandStage {
         kmax = 0;
     }
     // issue the loads of one tile (base = first element of the tile's first row / k)
-    __device__ __forceinline__ void fetch(const float* base, int tile_kmax, long s_ki) {
+    // skip0 (k-slow modes only, wave-uniform): the tile's k row 0 is a zero row and `base` is the tile's k row 1
+    __device__ __forceinline__ void fetch(const float* base, int tile_kmax, long s_ki, int skip0 = 0) {
         kmax = tile_kmax;
         if constexpr (MODE == 2) {
 #pragma unroll
             for (int r = 0; r < R; ++r) sc[r] = base[(ok[r] && kk[r] < tile_kmax) ? (off[r] >> 2) : 0u];
         } else {
-            const int krows = tile_kmax < GBK ? tile_kmax : GBK;
+            const int krows = (tile_kmax < GBK ? tile_kmax : GBK) - skip0;
             // k-slow: the descriptor ends after the last valid k row; k-fast: per-lane k test (below)
             const int nrec = TR ? 0x7fffffff : krows * (int)s_ki * 4;
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, nrec, 0x00020000);
+            const unsigned back = skip0 ? (unsigned)(s_ki * 4) : 0u;
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                const unsigned o = (TR && kk[r] >= tile_kmax) ? OOR : off[r];
+                unsigned o = (TR && kk[r] >= tile_kmax) ? OOR : off[r];
+                if (!TR) o = (skip0 && kk[r] == 0) ? OOR : o - back;   // OOR - back stays far outside the descriptor
                 if constexpr (VEC) {
                     const gu32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs, o, 0, 0);
                     vv[r] = (f32x4){__uint_as_float(t[0]), __uint_as_float(t[1]), __uint_as_float(t[2]), __uint_as_float(t[3])};
@@ -179,15 +188,21 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
 
     StA sa;
     StB sb;
-    sa.init(tid, m0, g.M, g.a_sm, g.a_ski);
+    // which A operand this row tile reads (block-uniform)
+    const bool second = g.a2 != nullptr && m0 >= g.M1;
+    const int am0 = second ? m0 - g.M1 : m0;
+    const long a_sko = second ? g.a2_sko : g.a_sko, a_ski = second ? g.a2_ski : g.a_ski;
+    const int a_shift = second ? g.a2_shift : g.a_shift;
+    sa.init(tid, am0, second ? g.M - g.M1 : (g.a2 ? g.M1 : g.M), g.a_sm, a_ski);
     sb.init(tid, n0, g.N, g.b_sn, g.b_ski);
-    const float* a_blk = g.a + (long)m0 * g.a_sm;
+    const float* a_blk = (second ? g.a2 : g.a) + (long)am0 * g.a_sm;
     const float* b_blk = g.b + (long)n0 * g.b_sn;
     int f_ko = tbeg / ntpr, f_kt = tbeg - f_ko * ntpr;   // the tile the next fetch() loads (wave-uniform)
     int f_left = tend - tbeg;   // tiles not fetched yet
     auto fetch = [&]() {
         const int kmax = g.KI - f_kt * GBK;   // >= 16 except for the row's last tile
-        sa.fetch(a_blk + (long)f_ko * g.a_sko + (long)(f_kt * GBK) * g.a_ski, kmax, g.a_ski);
+        const int skip0 = (a_shift && f_kt == 0) ? 1 : 0;
+        sa.fetch(a_blk + (long)f_ko * a_sko + (long)(f_kt * GBK - a_shift + skip0) * a_ski, kmax, a_ski, skip0);
         sb.fetch(b_blk + (long)f_ko * g.b_sko + (long)(f_kt * GBK) * g.b_ski, kmax, g.b_ski);
         // advance (scalar state only); after the last tile the position stays, so the extra fetch of the final
         // iteration re-reads that tile instead of branching around the loads
@@ -213,11 +228,23 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
                 for (int j = 0; j < NI; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][ks], bf[j][ks], acc[i][j], 0, 0, 0);
     };
+    // bias row: column sums of B from the staged registers (row tile 0 only; B in 16-byte mode, host-checked)
+    const bool bias_blk = g.bias_row && by == 0;
+    f32x4 bsum[StB::VEC ? StB::R : 1];
+#pragma unroll
+    for (int r = 0; r < (StB::VEC ? StB::R : 1); ++r) bsum[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    auto add_bias = [&]() {
+        if constexpr (BMODE == 0) {
+#pragma unroll
+            for (int r = 0; r < StB::R; ++r) bsum[r] += sb.vv[r];
+        }
+    };
     int buf = 0;
     if (tbeg < tend) {
         fetch();
         sa.stash(As[0]);
         sb.stash(Bs[0]);
+        if (bias_blk) add_bias();
     }
     __syncthreads();
     for (int t = tbeg; t < tend; ++t) {
@@ -229,10 +256,28 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
         __builtin_amdgcn_sched_barrier(0);
         sa.stash(As[buf ^ 1]);
         sb.stash(Bs[buf ^ 1]);
+        if (bias_blk && t + 1 < tend) add_bias();   // the final iteration re-stages its own tile: not summed twice
         __syncthreads();
         buf ^= 1;
     }
-    float* c = g.c + (g.split > 1 ? (size_t)bz * g.M * g.ldc : 0);
+    float* c = g.c + (g.split > 1 ? (size_t)bz * (g.M + g.bias_row) * g.ldc : 0);
+    if constexpr (BMODE == 0) {
+        if (bias_blk) {   // fold the k rows of the staging map (kk = e / (BN/4)) in a fixed order through LDS
+            float* red = Bs[0];
+            constexpr int KR = 256 * StB::R / (BN / 4);   // distinct k rows a column quad is staged by
+            static_assert(KR * BN <= 2 * StB::LDS_FLOATS, "bias reduction scratch");
+#pragma unroll
+            for (int r = 0; r < StB::R; ++r)
+                if (sb.kk[r] < KR && sb.rr[r] < BN) *(f32x4*)(red + sb.kk[r] * BN + sb.rr[r]) = bsum[r];
+            __syncthreads();
+            if (tid < BN && n0 + tid < g.N) {
+                float t = 0.f;
+                for (int q = 0; q < KR; ++q) t += red[q * BN + tid];
+                float* cp = c + (size_t)g.M * g.ldc + n0 + tid;
+                *cp = g.add_c ? *cp + t : t;
+            }
+        }
+    }
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -620,7 +665,7 @@ int gemm_f32(GemmArgs g, int accumulate, float* scratch, size_t scratch_floats, 
         if (!accumulate) (void)hipMemsetAsync(g.c, 0, sizeof(float) * (size_t)g.M * g.ldc, stream);
         return FOV_OK;
     }
-    const size_t mn = (size_t)g.M * g.N;
+    const size_t mn = (size_t)(g.M + g.bias_row) * g.N;
     // tile shape by M: short-and-wide weight-gradient products (M = F or Out) would waste a 128-row tile
     int BM, BN, variant;
     if (g.M <= 32) { BM = 32; BN = 256; variant = 0; }
@@ -668,14 +713,21 @@ int gemm_f32(GemmArgs g, int accumulate, float* scratch, size_t scratch_floats, 
     // staging modes.  k-slow: all row offsets of one k row stay below the k stride and 16 k rows fit a 31-bit
     // byte range -> buffer loads; 16-byte form when the row index is contiguous, every row start is 16-byte
     // aligned and a group of four never straddles the matrix edge.
-    const bool a_ks = g.a_ski >= (long)(g.M - 1) * g.a_sm + 1 && g.a_ski < (1L << 24) && (((uintptr_t)g.a) & 3) == 0;
+    const int Ma = g.a2 ? g.M1 : g.M;   // width of the first A operand
+    const bool a_ks = g.a_ski >= (long)(Ma - 1) * g.a_sm + 1 && g.a_ski < (1L << 24) && (((uintptr_t)g.a) & 3) == 0;
     const bool b_ks = g.b_ski >= (long)(g.N - 1) * g.b_sn + 1 && g.b_ski < (1L << 24) && (((uintptr_t)g.b) & 3) == 0;
-    const bool a_v4 = a_ks && g.a_sm == 1 && (g.M & 3) == 0 && (g.a_sko & 3) == 0 && (g.a_ski & 3) == 0 && (((uintptr_t)g.a) & 15) == 0;
+    const bool a_v4 = a_ks && g.a_sm == 1 && (g.M & 3) == 0 && (g.a_sko & 3) == 0 && (g.a_ski & 3) == 0 && (((uintptr_t)g.a) & 15) == 0 &&
+                      (!g.a2 || ((g.M1 & 3) == 0 && (g.a2_sko & 3) == 0 && (g.a2_ski & 3) == 0 && (((uintptr_t)g.a2) & 15) == 0 &&
+                                 g.a2_ski >= (long)(g.M - g.M1) && g.a2_ski < (1L << 24)));
     const bool b_v4 = b_ks && g.b_sn == 1 && (g.N & 3) == 0 && (g.b_sko & 3) == 0 && (g.b_ski & 3) == 0 && (((uintptr_t)g.b) & 15) == 0;
     // k-fast: k is the contiguous index, rows and ko rows start 16-byte aligned, KI a multiple of 4
     const bool a_kf = g.a_ski == 1 && (g.KI & 3) == 0 && (g.a_sm & 3) == 0 && (g.a_sko & 3) == 0 && (((uintptr_t)g.a) & 15) == 0;
     const bool b_kf = g.b_ski == 1 && (g.KI & 3) == 0 && (g.b_sn & 3) == 0 && (g.b_sko & 3) == 0 && (((uintptr_t)g.b) & 15) == 0;
     const int amode = a_v4 ? 0 : (a_ks ? 1 : (a_kf ? 3 : 2)), bmode = b_v4 ? 0 : (b_ks ? 1 : (b_kf ? 3 : 2));
+    if ((g.bias_row && bmode != 0) || ((g.a_shift || g.a2_shift) && amode > 1) || (g.a2 && (g.M1 % BM || amode != 0))) {
+        set_error("gemm_f32: fused weight gradient needs 16-byte-aligned k-slow operands and M1 a multiple of the row tile");
+        return FOV_ERR_UNSUPPORTED;
+    }
     g.grid_n = (g.N + BN - 1) / BN;
     g.grid_m = (g.M + BM - 1) / BM;
     g.xcd_remap = split >= 8 ? 1 : 0;
@@ -882,6 +934,31 @@ size_t lstm_bwd_workspace_floats(int B, int T, int F, int H) {
     return head + (size_t)2 * B * H + (m > st ? m : st) + 64;
 }
 
+// [dK ; dR ; db] = [A1 | A2 | 1]^T B as ONE product and one reduce: c is a dense (M1 + M2 + bias_row, N) matrix - the
+// layout of a layer's kernel, recurrent kernel and bias in a trainer's flat gradient buffer.  Rows of the product are
+// (ro, ri) pairs; a shifted operand presents its element (ro, ri - 1) at (ro, ri) and zero at ri == 0 (h_{t-1} read
+// from the (B,T,H) tape of h_t).  A2 may be NULL.
+bool wgrad_fusable(const float* a1, long lda1, long a1_so, int M1, const float* a2, long lda2, long a2_so, int M2, const float* b,
+                   long ldb, long b_so, const float* c, int N) {
+    auto al = [](const void* p) { return (((uintptr_t)p) & 15) == 0; };
+    if (!al(a1) || !al(b) || !al(c) || (lda1 & 3) || (a1_so & 3) || (M1 & 3) || (ldb & 3) || (b_so & 3) || (N & 3) || M1 <= 0) return false;
+    if (a2 && (!al(a2) || (lda2 & 3) || (a2_so & 3) || (M2 & 3) || (M1 % 128) || M2 <= 0)) return false;
+    return M1 + (a2 ? M2 : 0) > 96;   // the 128-row tile shape (gemm_f32) / the 128 x 128 bf16 tile
+}
+
+int wgrad_fused(const float* a1, long lda1, long a1_so, int M1, int shift1, const float* a2, long lda2, long a2_so, int M2, int shift2,
+                const float* b, long ldb, long b_so, float* c, int N, int RO, int RI, int bias_row, int accumulate, int bf16,
+                float* scratch, size_t scratch_floats, hipStream_t stream) {
+    if (bf16)
+        return gemm_bf16_tn_fused(a1, lda1, a1_so, M1, shift1, a2, lda2, a2_so, M2, shift2, b, ldb, b_so, c, N, N, RO, RI, bias_row,
+                                  accumulate, scratch, scratch_floats, stream);
+    GemmArgs g = {};
+    g.a = a1; g.b = b; g.c = c; g.M = M1 + (a2 ? M2 : 0); g.N = N; g.KO = RO; g.KI = RI;
+    g.a_sm = 1; g.a_sko = a1_so; g.a_ski = lda1; g.b_sn = 1; g.b_sko = b_so; g.b_ski = ldb; g.ldc = N;
+    g.a2 = a2; g.a2_sko = a2_so; g.a2_ski = lda2; g.M1 = M1; g.a_shift = shift1; g.a2_shift = shift2; g.bias_row = bias_row ? 1 : 0;
+    return gemm_f32(g, accumulate, scratch, scratch_floats, stream);
+}
+
 // BPTT of one layer.  dz:(B,T,4H) is an output (kept: the caller may need it for dx of the layer
 // below).  dK,dR,db are overwritten (accumulate = 0) or added to (accumulate = 1).
 int lstm_seq_bwd(const float* x, const float* K, const float* R, const float* h0, const float* c0, const float* hs,
@@ -902,6 +979,7 @@ int lstm_seq_bwd(const float* x, const float* K, const float* R, const float* h0
         return FOV_OK;
     }
     const bool persistent = bwd_cluster_shape_ok(H) && !getenv("FOV_BWD_STEPPED");
+    bool fuse_kr = false, fuse_r = false;
     const size_t head = (kStatusBytes + kXchBytes) / sizeof(float);
     float* dh_rec = ws + head;
     float* dc = dh_rec + (size_t)B * H;
@@ -912,7 +990,15 @@ int lstm_seq_bwd(const float* x, const float* K, const float* R, const float* h0
     if (persistent) {
         // one launch for the whole recurrence: dz (B,T,4H), dh0, dc0
         // bias gradient: per-tile partials from the kernel (db_part lives in the split-K scratch), summed below
-        float* db_part = db ? scratch : nullptr;
+        // dK, dR, db adjacent (a trainer's flat gradient buffer) and no initial state: ONE product [x | h_{t-1} | 1]^T dz
+        // below gives all three (no bias partials from the kernel, no column-sum launches); F too narrow for a row tile:
+        // [h_{t-1} | 1]^T dz gives dR and db
+        const int N4 = 4 * H;
+        fuse_kr = dK && dR && db && !h0 && T > 1 && dR == dK + (size_t)F * N4 && db == dR + (size_t)H * N4 &&
+                  wgrad_fusable(x, F, (long)T * F, F, hs, H, (long)T * H, H, dz, N4, (long)T * N4, dK, N4) && !getenv("FOV_NO_WGRAD_FUSION");
+        fuse_r = !fuse_kr && dR && db && !h0 && T > 1 && db == dR + (size_t)H * N4 &&
+                 wgrad_fusable(hs, H, (long)T * H, H, nullptr, 0, 0, 0, dz, N4, (long)T * N4, dR, N4) && !getenv("FOV_NO_WGRAD_FUSION");
+        float* db_part = (db && !fuse_kr && !fuse_r) ? scratch : nullptr;
         // H = 256: groups of eight workgroups fill the chip up to 32 tiles (the 4-group kernel leaves half of it idle
         // at 512 sequences); bf16 operands exist in the 8-group kernel only
         int rc = (bf16 || (bwd8_preferred(B, H) && !getenv("FOV_BWD_GROUPS4")))
@@ -920,7 +1006,7 @@ int lstm_seq_bwd(const float* x, const float* K, const float* R, const float* h0
                      : launch_bwd_cluster(R, reserve, c0, dhs, dhT, dcT, dz, dh0 ? dh0 : dh_rec, dc0 ? dc0 : dc, db_part, B, T, H,
                                           act, ws, stream);
         if (rc) return rc;
-        if (db) {
+        if (db_part) {
             const int tiles = (B + 15) / 16;
             if ((size_t)tiles * 4 * H + (size_t)256 * 4 * H > scratch_floats) { set_error("lstm_seq_bwd: scratch too small for db"); return FOV_ERR_WORKSPACE; }
             rc = colsum(db_part, db, tiles, 4 * H, accumulate, scratch + (size_t)tiles * 4 * H,
@@ -957,6 +1043,17 @@ int lstm_seq_bwd(const float* x, const float* K, const float* R, const float* h0
     }
     int rc;
     const long BT = (long)B * T;
+    if (fuse_kr) {
+        rc = wgrad_fused(x, F, (long)T * F, F, 0, hs, H, (long)T * H, H, 1, dz, 4 * H, (long)T * 4 * H, dK, 4 * H, B, T, 1, accumulate,
+                         bf16, scratch, scratch_floats, stream);
+        if (rc) return rc;
+        dK = dR = db = nullptr;
+    } else if (fuse_r) {
+        rc = wgrad_fused(hs, H, (long)T * H, H, 1, nullptr, 0, 0, 0, 0, dz, 4 * H, (long)T * 4 * H, dR, 4 * H, B, T, 1, accumulate, bf16,
+                         scratch, scratch_floats, stream);
+        if (rc) return rc;
+        dR = db = nullptr;
+    }
     if (dK) {   // dK (F,4H) = x^T dz : A(m=f,k=(b,t)) = x[k][f], B(k,n) = dz[k][n]
         GemmArgs g = {};
         g.a = x; g.b = dz; g.c = dK; g.M = F; g.N = 4 * H; g.KO = 1; g.KI = (int)BT;

@@ -261,6 +261,9 @@ class Scratch:
 
 
 _default_scratch = Scratch()
+# fov_lstm_seq_bwd keeps the persistent kernel's header and granule area at the head of its workspace (stateful, zero-filled
+# once): its default buffer is never shared with the calls that use theirs for split partials
+_default_bwd_scratch = Scratch()
 
 
 def lstm_seq_bwd(x, K, R, hs, reserve, h0=None, c0=None, dhs=None, dhT=None, dcT=None, dK=None, dR=None, db=None,
@@ -284,7 +287,7 @@ def lstm_seq_bwd(x, K, R, hs, reserve, h0=None, c0=None, dhs=None, dhT=None, dcT
     dh0 = e(B, H) if need_state_grads else None
     dc0 = e(B, H) if need_state_grads else None
     L = _lib.lib()
-    buf = (scratch or _default_scratch).get(L.fov_lstm_seq_bwd_workspace_bytes(B, T, F, H), x.device)
+    buf = (scratch or _default_bwd_scratch).get(L.fov_lstm_seq_bwd_workspace_bytes(B, T, F, H), x.device)
     bwd = L.fov_lstm_seq_bwd_bf16 if dtype == "bf16" else L.fov_lstm_seq_bwd
     check(bwd(_ptr(x), _ptr(K), _ptr(R), _ptr(_dev(h0, "h0")), _ptr(_dev(c0, "c0")), _ptr(hs),
               _ptr(reserve), _ptr(_dev(dhs, "dhs")), _ptr(_dev(dhT, "dhT")), _ptr(_dev(dcT, "dcT")),
@@ -405,6 +408,26 @@ def dense_bwd(x, W, dpre, dW=None, db=None, need_dx=True, accumulate=False, scra
     check(fn(_ptr(x2), _ptr(W), _ptr(d2), _ptr(dx), _ptr(dW), _ptr(db), N, In, Out,
              1 if accumulate else 0, buf.data_ptr(), buf.numel(), _stream()))
     return (dx.reshape(*x.shape[:-1], In) if need_dx else None), dW, db
+
+
+def wgrad_fused(x1, x2, dpre, out, bias=True, accumulate=False, scratch=None, dtype="f32"):
+    """out (In1 + In2 + bias, Out) (+)= [x1 | x2 | 1]^T dpre over all rows: a layer's dK, dR and db in ONE product and one
+    reduce, written where the three lie adjacent in a flat gradient buffer.  x2 may be None."""
+    x1, dpre, out = _dev(x1, "x1"), _dev(dpre, "dpre"), _dev(out, "out")
+    Out = dpre.shape[-1]
+    In1 = x1.shape[-1]
+    N = dpre.numel() // Out
+    In2 = 0
+    if x2 is not None:
+        x2 = _dev(x2, "x2")
+        In2 = x2.shape[-1]
+        assert x2.numel() == N * In2
+    assert x1.numel() == N * In1 and out.numel() == (In1 + In2 + (1 if bias else 0)) * Out
+    L = _lib.lib()
+    buf = (scratch or _default_scratch).get(L.fov_wgrad_fused_workspace_bytes(N, In1, In2, Out), x1.device)
+    check(L.fov_wgrad_fused(_ptr(x1), In1, _ptr(x2), In2, _ptr(dpre), _ptr(out), N, Out, 1 if bias else 0, 1 if accumulate else 0,
+                            1 if dtype == "bf16" else 0, buf.data_ptr(), buf.numel(), _stream()))
+    return out
 
 
 def mse_dense_grad(y, target, activation="tanh", scratch=None, dpre=None, loss=None, weight=1.0, time_major=False):

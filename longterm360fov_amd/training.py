@@ -46,6 +46,11 @@ class FlatParamTrainer:
         self._dp = False
         self._pending, self._reduced_from = [], n + 1
 
+    def _span(self, first, last):
+        """The slice of the flat gradient buffer from parameter `first` through parameter `last` (adjacent in the order)."""
+        hi = self.offset[last] + self.g[last].numel()
+        return self.grad[self.offset[first]:hi]
+
     def weights_numpy(self):
         return {k: v.detach().cpu().numpy().copy() for k, v in self.w.items()}
 
@@ -750,14 +755,14 @@ class OthersMixingTrainer(FlatParamTrainer):
         ops.dense_bwd(fl(P, O), Wm_p_c, fl(dpre_all, O), dW=gWm_p, db=g["mix_b"], need_dx=False, accumulate=acc, scratch=sc)
         ops.dense_bwd(fl(H2[1:], H), w["dense_W"], fl(dpre_p_all, O), dW=g["dense_W"], db=g["dense_b"], need_dx=False,
                       accumulate=acc, scratch=sc)
-        ops.dense_bwd(fl(H1[1:], H), w["dec2_K"], fl(DZ2, 4 * H), dW=g["dec2_K"], db=g["dec2_b"], need_dx=False,
-                      accumulate=acc, scratch=sc, dtype=dt)
-        ops.dense_bwd(fl(H2[:T_out], H), w["dec2_R"], fl(DZ2, 4 * H), dW=g["dec2_R"], need_db=False, need_dx=False,
-                      accumulate=acc, scratch=sc, dtype=dt)
-        ops.dense_bwd(fl(X, O), w["dec1_K"], fl(DZ1, 4 * H), dW=g["dec1_K"], db=g["dec1_b"], need_dx=False,
+        # a layer's kernel, recurrent kernel and bias are adjacent in the flat buffer: [h1_t | h2_{t-1} | 1]^T dz2 is ONE
+        # product + one reduce (dz2 read once), [h1_{t-1} | 1]^T dz1 likewise; the 6-wide dK1 stays a skinny product
+        ops.wgrad_fused(fl(H1[1:], H), fl(H2[:T_out], H), fl(DZ2, 4 * H), self._span("dec2_K", "dec2_b"), accumulate=acc,
+                        scratch=sc, dtype=dt)
+        ops.dense_bwd(fl(X, O), w["dec1_K"], fl(DZ1, 4 * H), dW=g["dec1_K"], need_db=False, need_dx=False,
                       accumulate=acc, scratch=sc)
-        ops.dense_bwd(fl(H1[:T_out], H), w["dec1_R"], fl(DZ1, 4 * H), dW=g["dec1_R"], need_db=False, need_dx=False,
-                      accumulate=acc, scratch=sc, dtype=dt)
+        ops.wgrad_fused(fl(H1[:T_out], H), None, fl(DZ1, 4 * H), self._span("dec1_R", "dec1_b"), accumulate=acc, scratch=sc,
+                        dtype=dt)
         # "others" half of the mixing kernel: one product over all steps, rows ordered (t, b) like dpre_all
         oth_tb = others.transpose(0, 1).contiguous().reshape(T_out * B, n_oth)
         ops.dense_bwd(oth_tb, Wm_o_c, dpre_all.reshape(T_out * B, O), dW=gWm_o, need_db=False, need_dx=False,

@@ -327,6 +327,76 @@ def test_persistent_bptt_matches_stepped_and_oracle():
             assert np.abs(s_ - r).max() <= 1e-4 * scale + 1e-9, (H, k)
 
 
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("N,In1,In2,Out", [(5120, 256, 256, 1024), (5120, 256, 0, 1024), (40, 128, 64, 256), (1000, 90, 256, 1024),
+                                           (777, 256, 128, 512), (33, 256, 0, 64)])
+def test_fused_weight_gradient_product(N, In1, In2, Out, dtype):
+    """fov_wgrad_fused: [dK ; dR ; db] = [x1 | x2 | 1]^T dz as ONE product + one reduce, written where the three lie adjacent
+    in a flat gradient buffer - against the fp64 products, against the three separate launches (same operand rounding),
+    overwrite and accumulate, split and single-slice shapes, and the shapes that fall back to the separate products."""
+    from longterm360fov_amd import ops
+    rng = np.random.default_rng(N + In1)
+    x1 = rng.standard_normal((N, In1)).astype(np.float32)
+    x2 = rng.standard_normal((N, In2)).astype(np.float32) if In2 else None
+    dz = rng.standard_normal((N, Out)).astype(np.float32)
+    rows = In1 + In2 + 1
+    r = (lambda a: O.round_bf16(a.astype(np.float64))) if dtype == "bf16" else (lambda a: a.astype(np.float64))
+    ref = np.concatenate([r(x1).T @ r(dz)] + ([r(x2).T @ r(dz)] if In2 else []) + [dz.astype(np.float64).sum(0, keepdims=True)], 0)
+    out = torch.full((rows * Out + 7,), 3.0, device="cuda")              # the tail must stay untouched
+    view = out[:rows * Out]
+    ops.wgrad_fused(dev(x1), None if x2 is None else dev(x2), dev(dz), view, dtype=dtype)
+    got = view.view(rows, Out).cpu().numpy().astype(np.float64)
+    scale = np.abs(ref[:-1]).max()
+    assert np.abs(got[:-1] - ref[:-1]).max() <= 2e-5 * scale, np.abs(got[:-1] - ref[:-1]).max() / scale
+    assert np.abs(got[-1] - ref[-1]).max() <= 2e-5 * np.abs(ref[-1]).max() + 1e-4      # the bias row is an fp32 sum in both modes
+    assert float(out[rows * Out:].min()) == 3.0 and float(out[rows * Out:].max()) == 3.0
+    # the separate launches
+    sep = torch.empty(rows, Out, device="cuda")
+    ops.dense_bwd(dev(x1), torch.empty(In1, Out, device="cuda"), dev(dz), dW=sep[:In1], db=sep[rows - 1], need_dx=False, dtype=dtype)
+    if In2:
+        ops.dense_bwd(dev(x2), torch.empty(In2, Out, device="cuda"), dev(dz), dW=sep[In1:In1 + In2], need_db=False, need_dx=False,
+                      dtype=dtype)
+    assert (view.view(rows, Out) - sep).abs().max().item() <= 2e-5 * scale
+    # accumulate: twice the product on top of the first result
+    ops.wgrad_fused(dev(x1), None if x2 is None else dev(x2), dev(dz), view, accumulate=True, dtype=dtype)
+    got2 = view.view(rows, Out).cpu().numpy().astype(np.float64)
+    assert np.abs(got2 - 2 * got).max() <= 4e-5 * scale + 2e-4
+    # no bias row
+    nb = torch.empty((rows - 1) * Out, device="cuda")
+    ops.wgrad_fused(dev(x1), None if x2 is None else dev(x2), dev(dz), nb, bias=False, dtype=dtype)
+    assert (nb.view(rows - 1, Out) - torch.from_numpy(got[:-1].astype(np.float32)).cuda()).abs().max().item() <= 1e-6 * scale + 1e-6
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("B,T,F,H", [(64, 6, 256, 256), (40, 5, 90, 256), (33, 2, 256, 256), (48, 4, 128, 128)])
+def test_layer_backward_adjacent_gradients_take_the_fused_product(B, T, F, H, dtype):
+    """fov_lstm_seq_bwd handed dK, dR, db that lie adjacent (a trainer's flat buffer) forms them as ONE product
+    [x | h_{t-1} | 1]^T dz - h_{t-1} read from the h_t tape shifted by a step, zero at t = 0 - or, when F is no multiple of the
+    row tile, dR and db as [h_{t-1} | 1]^T dz: same gradients as with three separate buffers (three products + column sums)."""
+    from longterm360fov_amd import ops
+    if dtype == "bf16" and H != 256:
+        pytest.skip("the bf16 path is built for H = 256")
+    rng = np.random.default_rng(B + F)
+    K, R, b = O.init_lstm(rng, F, H)
+    x = rng.standard_normal((B, T, F)).astype(np.float32)
+    dhs = rng.standard_normal((B, T, H)).astype(np.float32)
+    hs, hT, cT, res = ops.lstm_seq_train(dev(x), dev(K), dev(R), dev(b), act="sigmoid", dtype=dtype)
+    sep = ops.lstm_seq_bwd(dev(x), dev(K), dev(R), hs, res, dhs=dev(dhs), act="sigmoid", dtype=dtype)
+    flat = torch.zeros((F + H + 1) * 4 * H, device="cuda")
+    dK, dR, db = flat[:F * 4 * H].view(F, 4 * H), flat[F * 4 * H:(F + H) * 4 * H].view(H, 4 * H), flat[(F + H) * 4 * H:]
+    fused = ops.lstm_seq_bwd(dev(x), dev(K), dev(R), hs, res, dhs=dev(dhs), dK=dK, dR=dR, db=db, act="sigmoid", dtype=dtype)
+    assert torch.equal(fused["dz"], sep["dz"])
+    for k in ("dK", "dR", "db"):
+        scale = sep[k].abs().max().item()
+        err = (fused[k] - sep[k]).abs().max().item()
+        print("adjacent-gradient backward %s %s: max|ref| %.3e err %.3e" % (dtype, k, scale, err))
+        assert err <= 2e-5 * scale + 1e-6, (k, err, scale)
+    # accumulate on top
+    ops.lstm_seq_bwd(dev(x), dev(K), dev(R), hs, res, dhs=dev(dhs), dK=dK, dR=dR, db=db, act="sigmoid", accumulate=True, dtype=dtype)
+    for k in ("dK", "dR", "db"):
+        assert (fused[k] - 2 * sep[k]).abs().max().item() <= 4e-5 * sep[k].abs().max().item() + 2e-6, k
+
+
 def _torch_mixing_graph(enc, oth, dec0, tgt, w, act, mixing="mlp"):
     """Independent fp64 reference of the a4 training graph (given_others...py:203-308) on torch.autograd."""
     t = {k: torch.tensor(v.astype(np.float64), requires_grad=True) for k, v in w.items()}
