@@ -107,6 +107,17 @@ int fov_mix_head_bwd(const float* dm_loss, const float* dm_feedback, const float
                      const float* dense_W, float* dpre_m, float* dpre_p, float* dh, int N, int H, int O,
                      fov_stream_t stream);
 
+/* Weight gradients of that head over ALL steps of the unrolled decoder in one launch + one reduce (what Keras/TF
+ * autodiff forms as six separate reductions, given_others...py:308): with rows r = (t, b),
+ *     [dense_W ; dense_b] = [h2_t | 1]^T dpre_p,      [mix_W ; mix_b] = [others_t | p_t | 1]^T dpre_m
+ * written into out as one (H + 1 + n_others + O + 1, O) block - dense_W, dense_b, mix_W (others' rows, then the
+ * prediction's), mix_b as they lie adjacent in a flat gradient buffer.  h2 (T_out*B, H), dpre_p, p, dpre_m (T_out*B, O)
+ * time-major; others (B, T_out, n_others) batch-major as the model receives it (no transposed copy).  O <= 8. */
+size_t fov_mix_head_wgrad_workspace_bytes(int B, int T_out, int H, int O, int n_others);
+int fov_mix_head_wgrad(const float* h2, const float* dpre_p, const float* others, const float* p, const float* dpre_m,
+                       float* out, int B, int T_out, int H, int O, int n_others, int accumulate,
+                       void* workspace, size_t workspace_bytes, fov_stream_t stream);
+
 /* The whole unrolled no-teacher-forcing decoder of the others-mixing model in ONE persistent launch
  * (given_others...py:203-299): per step LSTM1(x_t) -> LSTM2 -> Dense(O,'tanh') -> mixing Dense -> x_{t+1}.
  *   dec0 (B,O); h1,c1,h2,c2 (B,H) = encoder states; oth_proj: others_t . mix_W[:-O] + mix_b, element (b,t,o) at

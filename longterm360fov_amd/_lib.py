@@ -59,6 +59,8 @@ SIGNATURES = {
     "fov_lstm_seq_bwd_bf16": (_I, [_P] * 17 + [_I] * 6 + [_P, _SZ, _P]),
     "fov_dense_bwd_bf16": (_I, [_P] * 6 + [_I] * 4 + [_P, _SZ, _P]),
     "fov_dense_bwd_workspace_bytes": (_SZ, [_I] * 3),
+    "fov_mix_head_wgrad_workspace_bytes": (_SZ, [_I] * 5),
+    "fov_mix_head_wgrad": (_I, [_P] * 6 + [_I] * 6 + [_P, _SZ, _P]),
     "fov_wgrad_fused_workspace_bytes": (_SZ, [ctypes.c_int64, _I, _I, _I]),
     "fov_wgrad_fused": (_I, [_P, _I, _P, _I, _P, _P, ctypes.c_int64, _I, _I, _I, _I, _P, _SZ, _P]),
     "fov_dense_bwd": (_I, [_P] * 6 + [_I] * 4 + [_P, _SZ, _P]),

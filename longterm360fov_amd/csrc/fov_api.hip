@@ -726,6 +726,25 @@ int fov_mix_head_bwd(const float* dm_loss, const float* dm_feedback, const float
     return FOV_OK;
 }
 
+size_t fov_mix_head_wgrad_workspace_bytes(int B, int T_out, int H, int O, int n_others) {
+    if (B <= 0 || T_out <= 0 || H <= 0 || O <= 0 || n_others < 0) return 256;
+    return sizeof(float) * mix_head_wgrad_scratch_floats(B, T_out, H, O, n_others);
+}
+
+int fov_mix_head_wgrad(const float* h2, const float* dpre_p, const float* others, const float* p, const float* dpre_m, float* out,
+                       int B, int T_out, int H, int O, int n_others, int accumulate, void* workspace, size_t workspace_bytes,
+                       fov_stream_t stream) {
+    if (B < 0 || T_out < 0 || H <= 0 || O <= 0 || O > 8 || n_others < 0 || !out ||
+        (B > 0 && T_out > 0 && (!h2 || !dpre_p || !p || !dpre_m || (n_others > 0 && !others)))) {
+        set_error("fov_mix_head_wgrad: invalid argument (O <= 8)");
+        return FOV_ERR_INVALID;
+    }
+    int rc = check_ws(workspace, workspace_bytes, fov_mix_head_wgrad_workspace_bytes(B, T_out, H, O, n_others));
+    if (rc) return rc;
+    return mix_head_wgrad(h2, dpre_p, others, p, dpre_m, out, B, T_out, H, O, n_others, accumulate, (float*)workspace,
+                          workspace_bytes / sizeof(float), (hipStream_t)stream);
+}
+
 size_t fov_mix_decoder_workspace_bytes(int B, int H) {
     if (B <= 0 || H != 256) return kStatusBytes;
     return mix_decoder_workspace_bytes(B);

@@ -156,6 +156,9 @@ int lstm_seq_bwd(const float* x, const float* K, const float* R, const float* h0
                  const float* reserve, const float* dhs, const float* dhT, const float* dcT, float* dz, float* dx,
                  float* dK, float* dR, float* db, float* dh0, float* dc0, int B, int T, int F, int H, int act,
                  int accumulate, float* ws, size_t ws_floats, hipStream_t stream, int bf16 = 0);
+size_t mix_head_wgrad_scratch_floats(int B, int T, int H, int O, int n_oth);
+int mix_head_wgrad(const float* h2, const float* dpre_p, const float* others, const float* p, const float* dpre_m, float* out, int B,
+                   int T, int H, int O, int n_oth, int accumulate, float* scratch, size_t scratch_floats, hipStream_t stream);
 bool wgrad_fusable(const float* a1, long lda1, long a1_so, int M1, const float* a2, long lda2, long a2_so, int M2, const float* b,
                    long ldb, long b_so, const float* c, int N);
 int wgrad_fused(const float* a1, long lda1, long a1_so, int M1, int shift1, const float* a2, long lda2, long a2_so, int M2, int shift2,

@@ -29,7 +29,8 @@ typedef short qs16x4 __attribute__((ext_vector_type(4)));
 constexpr int GT = 128;          // output tile (GT x GT), 4 waves as 2 x 2, each 64 x 64 = 4 x 4 MFMA tiles
 constexpr int GKB = 32;          // rows (k) per stage
 constexpr int GLD_TN = 144;      // bf16 per LDS row of a [k][GT] image: 72 dwords = 8 (mod 64)
-constexpr int GLD_NT = 40;       // bf16 per LDS row of a [GT][k] image
+constexpr int GKN = 64;          // k-values per stage of the NT product
+constexpr int GLD_NT = 72;       // bf16 per LDS row of a [GT][k] image: 36 dwords = 4 (mod 32), conflict-free 16-byte reads
 
 struct GemmTN {
     const float* a;
@@ -201,7 +202,9 @@ struct GemmNT {
     int ldc;
 };
 
-// K % 4 == 0, lda % 4 == 0, ldb % 4 == 0, 16-byte aligned bases (host-checked)
+// K % 4 == 0, lda % 4 == 0, ldb % 4 == 0, 16-byte aligned bases (host-checked).  64 k-values per stage: a block's
+// serial chain of (global load -> convert -> LDS -> MFMA) stages is what bounds this product (80 blocks of a
+// 5120 x 256 x 1024 data gradient, 1.2 us per stage whatever its size), so the stages are made large and few.
 __global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(GemmNT g) {
     __shared__ __attribute__((aligned(16))) unsigned short sA[2][GT * GLD_NT];
     __shared__ __attribute__((aligned(16))) unsigned short sB[2][GT * GLD_NT];
@@ -209,47 +212,50 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(GemmNT g) {
     const int n = lane & 15, g4 = lane >> 4;
     const int wm = wave >> 1, wn = wave & 1;
     const int m0 = blockIdx.y * GT, n0 = blockIdx.x * GT;
-    // staging: thread = (row tid >> 3 (+ 32 i), 4 k-values (tid & 7) * 4)
-    const int srow = tid >> 3, scol = (tid & 7) * 4;
+    // staging: thread = (row tid >> 4 (+ 16 i), 4 k-values (tid & 15) * 4)
+    const int srow = tid >> 4, scol = (tid & 15) * 4;
     f32x4 acc[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    f32x4 ra[4], rb[4];
+    f32x4 ra[8], rb[8];
     auto load_stage = [&](int k0) {
+        const bool kin = k0 + scol < g.K;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = srow + 32 * i;
-            const bool kin = k0 + scol < g.K;
+        for (int i = 0; i < 8; ++i) {
+            const int row = srow + 16 * i;
             ra[i] = (kin && m0 + row < g.M) ? *(const f32x4*)(g.a + (size_t)(m0 + row) * g.lda + k0 + scol) : (f32x4){0.f, 0.f, 0.f, 0.f};
             rb[i] = (kin && n0 + row < g.N) ? *(const f32x4*)(g.b + (size_t)(n0 + row) * g.ldb + k0 + scol) : (f32x4){0.f, 0.f, 0.f, 0.f};
         }
     };
     auto store_stage = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            *(qu32x2*)(sA[buf] + (srow + 32 * i) * GLD_NT + scol) = (qu32x2){pack_bf16(ra[i][0], ra[i][1]), pack_bf16(ra[i][2], ra[i][3])};
-            *(qu32x2*)(sB[buf] + (srow + 32 * i) * GLD_NT + scol) = (qu32x2){pack_bf16(rb[i][0], rb[i][1]), pack_bf16(rb[i][2], rb[i][3])};
+        for (int i = 0; i < 8; ++i) {
+            *(qu32x2*)(sA[buf] + (srow + 16 * i) * GLD_NT + scol) = (qu32x2){pack_bf16(ra[i][0], ra[i][1]), pack_bf16(ra[i][2], ra[i][3])};
+            *(qu32x2*)(sB[buf] + (srow + 16 * i) * GLD_NT + scol) = (qu32x2){pack_bf16(rb[i][0], rb[i][1]), pack_bf16(rb[i][2], rb[i][3])};
         }
     };
-    const int nstages = (g.K + GKB - 1) / GKB;
+    const int nstages = (g.K + GKN - 1) / GKN;
     load_stage(0);
     store_stage(0);
     __syncthreads();
     for (int s = 0; s < nstages; ++s) {
         const int buf = s & 1;
-        if (s + 1 < nstages) load_stage((s + 1) * GKB);
-        qu32x4 af[4], bf[4];
+        if (s + 1 < nstages) load_stage((s + 1) * GKN);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            af[i] = *(const qu32x4*)(sA[buf] + (wm * 64 + i * 16 + n) * GLD_NT + 8 * g4);
-            bf[i] = *(const qu32x4*)(sB[buf] + (wn * 64 + i * 16 + n) * GLD_NT + 8 * g4);
+        for (int kb = 0; kb < GKN / 32; ++kb) {
+            qu32x4 af[4], bf[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                af[i] = *(const qu32x4*)(sA[buf] + (wm * 64 + i * 16 + n) * GLD_NT + 32 * kb + 8 * g4);
+                bf[i] = *(const qu32x4*)(sB[buf] + (wn * 64 + i * 16 + n) * GLD_NT + 32 * kb + 8 * g4);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) qmfma(acc[i][j], af[i], bf[j]);
         }
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) qmfma(acc[i][j], af[i], bf[j]);
         if (s + 1 < nstages) store_stage(buf ^ 1);
         __syncthreads();
     }

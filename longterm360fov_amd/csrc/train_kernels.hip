@@ -42,7 +42,8 @@ struct GemmArgs {
     const float* a2;   // second A operand: rows [M1, M) of C come from it (M1 a multiple of the row tile), or NULL
     long a2_sko, a2_ski;
     int M1;
-    int a_shift, a2_shift;   // 1: k index (ko, ki) of the operand is its element (ko, ki - 1), zero at ki == 0
+    int a_period, a2_period;   // T > 0 (KO == 1): k index r of the operand is its row r - 1, zero where r % T == 0 - h_{t-1}
+                               // read from the (B,T,H) tape of h_t with the rows kept flat (full 16-row k-tiles)
     int bias_row;      // 1: row M of C = column sums of B (B staged with 16-byte loads)
 };
 
@@ -82,6 +83,7 @@ struct OperandStage {
     float sc[VEC ? 1 : R];
     f32x4 vv[VEC ? R : 1];
     int kmax;          // valid k columns of the staged tile
+    int ph[R];         // periodic-shift operands: (k row of this thread's element) % period
 
     __device__ __forceinline__ void init(int tid, int row0, int nrows, long s_row, long s_ki) {
 #pragma unroll
@@ -97,22 +99,30 @@ struct OperandStage {
         kmax = 0;
     }
     // issue the loads of one tile (base = first element of the tile's first row / k)
-    // skip0 (k-slow modes only, wave-uniform): the tile's k row 0 is a zero row and `base` is the tile's k row 1
-    __device__ __forceinline__ void fetch(const float* base, int tile_kmax, long s_ki, int skip0 = 0) {
+    __device__ __forceinline__ void init_phase(long k0, int period) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) ph[r] = period > 0 ? (int)((k0 + kk[r]) % period) : 1;
+    }
+    // period > 0 (k-slow modes only): elements whose k row is a multiple of the period read as zero (`base` already points
+    // one row back); inc = GBK % period advances the phases to the next tile
+    __device__ __forceinline__ void fetch(const float* base, int tile_kmax, long s_ki, int period = 0, int inc = 0) {
         kmax = tile_kmax;
         if constexpr (MODE == 2) {
 #pragma unroll
             for (int r = 0; r < R; ++r) sc[r] = base[(ok[r] && kk[r] < tile_kmax) ? (off[r] >> 2) : 0u];
         } else {
-            const int krows = (tile_kmax < GBK ? tile_kmax : GBK) - skip0;
+            const int krows = tile_kmax < GBK ? tile_kmax : GBK;
             // k-slow: the descriptor ends after the last valid k row; k-fast: per-lane k test (below)
             const int nrec = TR ? 0x7fffffff : krows * (int)s_ki * 4;
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, nrec, 0x00020000);
-            const unsigned back = skip0 ? (unsigned)(s_ki * 4) : 0u;
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 unsigned o = (TR && kk[r] >= tile_kmax) ? OOR : off[r];
-                if (!TR) o = (skip0 && kk[r] == 0) ? OOR : o - back;   // OOR - back stays far outside the descriptor
+                if (!TR && period > 0) {
+                    o = ph[r] == 0 ? OOR : o;
+                    ph[r] += inc;
+                    ph[r] -= ph[r] >= period ? period : 0;
+                }
                 if constexpr (VEC) {
                     const gu32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs, o, 0, 0);
                     vv[r] = (f32x4){__uint_as_float(t[0]), __uint_as_float(t[1]), __uint_as_float(t[2]), __uint_as_float(t[3])};
@@ -192,8 +202,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
     const bool second = g.a2 != nullptr && m0 >= g.M1;
     const int am0 = second ? m0 - g.M1 : m0;
     const long a_sko = second ? g.a2_sko : g.a_sko, a_ski = second ? g.a2_ski : g.a_ski;
-    const int a_shift = second ? g.a2_shift : g.a_shift;
+    const int a_period = second ? g.a2_period : g.a_period;
+    const int a_inc = a_period > 0 ? GBK % a_period : 0;
     sa.init(tid, am0, second ? g.M - g.M1 : (g.a2 ? g.M1 : g.M), g.a_sm, a_ski);
+    sa.init_phase((long)tbeg * GBK, a_period);
     sb.init(tid, n0, g.N, g.b_sn, g.b_ski);
     const float* a_blk = (second ? g.a2 : g.a) + (long)am0 * g.a_sm;
     const float* b_blk = g.b + (long)n0 * g.b_sn;
@@ -201,8 +213,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
     int f_left = tend - tbeg;   // tiles not fetched yet
     auto fetch = [&]() {
         const int kmax = g.KI - f_kt * GBK;   // >= 16 except for the row's last tile
-        const int skip0 = (a_shift && f_kt == 0) ? 1 : 0;
-        sa.fetch(a_blk + (long)f_ko * a_sko + (long)(f_kt * GBK - a_shift + skip0) * a_ski, kmax, a_ski, skip0);
+        sa.fetch(a_blk + (long)f_ko * a_sko + (long)(f_kt * GBK - (a_period > 0 ? 1 : 0)) * a_ski, kmax, a_ski, a_period, a_inc);
         sb.fetch(b_blk + (long)f_ko * g.b_sko + (long)(f_kt * GBK) * g.b_ski, kmax, g.b_ski);
         // advance (scalar state only); after the last tile the position stays, so the extra fetch of the final
         // iteration re-reads that tile instead of branching around the loads
@@ -724,7 +735,7 @@ int gemm_f32(GemmArgs g, int accumulate, float* scratch, size_t scratch_floats, 
     const bool a_kf = g.a_ski == 1 && (g.KI & 3) == 0 && (g.a_sm & 3) == 0 && (g.a_sko & 3) == 0 && (((uintptr_t)g.a) & 15) == 0;
     const bool b_kf = g.b_ski == 1 && (g.KI & 3) == 0 && (g.b_sn & 3) == 0 && (g.b_sko & 3) == 0 && (((uintptr_t)g.b) & 15) == 0;
     const int amode = a_v4 ? 0 : (a_ks ? 1 : (a_kf ? 3 : 2)), bmode = b_v4 ? 0 : (b_ks ? 1 : (b_kf ? 3 : 2));
-    if ((g.bias_row && bmode != 0) || ((g.a_shift || g.a2_shift) && amode > 1) || (g.a2 && (g.M1 % BM || amode != 0))) {
+    if ((g.bias_row && bmode != 0) || ((g.a_period || g.a2_period) && (amode > 1 || g.KO != 1)) || (g.a2 && (g.M1 % BM || amode != 0))) {
         set_error("gemm_f32: fused weight gradient needs 16-byte-aligned k-slow operands and M1 a multiple of the row tile");
         return FOV_ERR_UNSUPPORTED;
     }
@@ -864,6 +875,112 @@ static int skinny_tn(const float* S, long ss, int ns, const float* Wd, long ldw,
     return rc ? rc : 1;
 }
 
+// Weight gradients of the others-mixing head (given_others...py:127-130,166-168,257-265 under model.fit) in ONE launch and
+// one reduce: with rows r = (t, b) of the unrolled decoder's tape,
+//     [dense_W ; dense_b]       = [h2_t | 1]^T dpre_p              (H + 1, O)
+//     [mix_W ; mix_b]           = [others_t | p_t | 1]^T dpre_m    (n_oth + O + 1, O)
+// written as one (H + 1 + n_oth + O + 1, O) block - the layout of dense_W, dense_b, mix_W, mix_b in a trainer's flat
+// gradient buffer.  Same scheme as skinny_tn (thread = one column of the wide operand, block = 64 columns x 4 row
+// groups, eight rows in flight, the O values of a row are broadcast loads), the column decides which array it reads;
+// `others` stays in its (B, T, n_oth) layout (row (t, b) is others[b][t]).
+template <int NS>
+__global__ __launch_bounds__(256) void mix_head_wgrad_kernel(const float* __restrict__ h2, const float* __restrict__ dpre_p,
+                                                             const float* __restrict__ others, const float* __restrict__ p,
+                                                             const float* __restrict__ dpre_m, float* __restrict__ part, int B,
+                                                             int T, int H, int n_oth, long rows_per_chunk) {
+    __shared__ float red[4][NS][64];
+    const int li = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int w = blockIdx.x * 64 + li;
+    const int ncol = H + 1 + n_oth + NS + 1;
+    const long rows = (long)B * T;
+    const long r0 = (long)blockIdx.y * rows_per_chunk;
+    long r1 = r0 + rows_per_chunk;
+    if (r1 > rows) r1 = rows;
+    // what this thread's column reads: kind 0 = array with row stride ld (row r), 1 = ones, 2 = others[b][t][col]
+    int kind = 1, col = 0;
+    long ld = 0;
+    const float* src = dpre_p;
+    const float* S = dpre_p;
+    if (w < H) { kind = 0; src = h2; ld = H; col = w; }
+    else if (w == H) { kind = 1; }
+    else {
+        S = dpre_m;
+        const int j = w - (H + 1);
+        if (j < n_oth) { kind = 2; src = others; col = j; }
+        else if (j < n_oth + NS) { kind = 0; src = p; ld = NS; col = j - n_oth; }
+    }
+    float acc[NS];
+#pragma unroll
+    for (int i = 0; i < NS; ++i) acc[i] = 0.f;
+    if (w < ncol) {
+        for (long r = r0 + q; r < r1; r += 32) {
+            float wv[8];
+            long rr[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const bool ok = r + 4 * u < r1;
+                rr[u] = ok ? r + 4 * u : r;
+                float v = 1.f;
+                if (kind == 0) v = src[rr[u] * ld + col];
+                else if (kind == 2) {
+                    const int t = (int)(rr[u] / B), b = (int)(rr[u] - (long)t * B);
+                    v = src[((long)b * T + t) * n_oth + col];
+                }
+                wv[u] = ok ? v : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int i = 0; i < NS; ++i) acc[i] = fmaf(S[rr[u] * NS + i], wv[u], acc[i]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NS; ++i) red[q][i][li] = acc[i];
+    __syncthreads();
+    if (q == 0 && w < ncol) {
+        float* pp = part + (long)blockIdx.y * NS * ncol + (long)w * NS;
+#pragma unroll
+        for (int i = 0; i < NS; ++i) pp[i] = (red[0][i][li] + red[1][i][li]) + (red[2][i][li] + red[3][i][li]);
+    }
+}
+
+size_t mix_head_wgrad_scratch_floats(int B, int T, int H, int O, int n_oth) {
+    const long rows = (long)B * T;
+    long chunks = rows / 32;
+    if (chunks > 256) chunks = 256;
+    if (chunks < 1) chunks = 1;
+    return (size_t)chunks * (H + 1 + n_oth + O + 1) * O + 64;
+}
+
+int mix_head_wgrad(const float* h2, const float* dpre_p, const float* others, const float* p, const float* dpre_m, float* out, int B,
+                   int T, int H, int O, int n_oth, int accumulate, float* scratch, size_t scratch_floats, hipStream_t stream) {
+    const long rows = (long)B * T;
+    const int ncol = H + 1 + n_oth + O + 1;
+    const size_t n = (size_t)ncol * O;
+    if (rows <= 0) {
+        if (!accumulate) (void)hipMemsetAsync(out, 0, sizeof(float) * n, stream);
+        return FOV_OK;
+    }
+    long chunks = rows / 32;
+    if (chunks > 256) chunks = 256;
+    if (chunks < 1) chunks = 1;
+    if ((size_t)chunks * n > scratch_floats) { set_error("mix_head_wgrad: scratch too small"); return FOV_ERR_WORKSPACE; }
+    const long rpc = (rows + chunks - 1) / chunks;
+    chunks = (rows + rpc - 1) / rpc;
+    const dim3 grid((ncol + 63) / 64, (unsigned)chunks);
+#define FOV_HEADW(NSV) \
+    case NSV: hipLaunchKernelGGL(mix_head_wgrad_kernel<NSV>, grid, dim3(256), 0, stream, h2, dpre_p, others, p, dpre_m, scratch, B, T, H, n_oth, rpc); break
+    switch (O) {
+        FOV_HEADW(1); FOV_HEADW(2); FOV_HEADW(3); FOV_HEADW(4); FOV_HEADW(5); FOV_HEADW(6); FOV_HEADW(7); FOV_HEADW(8);
+        default: set_error("mix_head_wgrad: O <= 8"); return FOV_ERR_UNSUPPORTED;
+    }
+#undef FOV_HEADW
+    int rc = check_launch("mix_head_wgrad");
+    if (rc) return rc;
+    hipLaunchKernelGGL(splitk_reduce_kernel, splitk_reduce_grid(n), dim3(256), 0, stream, scratch, out, (long)n, (int)chunks, accumulate);
+    return check_launch("mix_head_wgrad reduce");
+}
+
 // Narrow matrices (cols <= 16, e.g. the Dense(6) bias gradient over B*T rows): the column-per-thread kernel
 // above would keep 6 lanes busy.  Here a block owns a chunk of rows, threads stride over the rows with all
 // columns in registers, and a fixed-order LDS tree folds the 256 per-thread sums - deterministic.
@@ -955,7 +1072,18 @@ int wgrad_fused(const float* a1, long lda1, long a1_so, int M1, int shift1, cons
     GemmArgs g = {};
     g.a = a1; g.b = b; g.c = c; g.M = M1 + (a2 ? M2 : 0); g.N = N; g.KO = RO; g.KI = RI;
     g.a_sm = 1; g.a_sko = a1_so; g.a_ski = lda1; g.b_sn = 1; g.b_sko = b_so; g.b_ski = ldb; g.ldc = N;
-    g.a2 = a2; g.a2_sko = a2_so; g.a2_ski = lda2; g.M1 = M1; g.a_shift = shift1; g.a2_shift = shift2; g.bias_row = bias_row ? 1 : 0;
+    g.a2 = a2; g.a2_sko = a2_so; g.a2_ski = lda2; g.M1 = M1; g.bias_row = bias_row ? 1 : 0;
+    if (shift1 || shift2) {
+        // the (ro, ri) rows are kept flat - full 16-row k-tiles instead of tiles that end with every ro row - and the
+        // shifted operand is masked where ri == 0; needs rows that are contiguous across ro
+        if (a1_so != (long)RI * lda1 || (a2 && a2_so != (long)RI * lda2) || b_so != (long)RI * ldb) {
+            set_error("wgrad_fused: a shifted operand needs (ro, ri) rows that are contiguous");
+            return FOV_ERR_UNSUPPORTED;
+        }
+        g.KO = 1; g.KI = RO * RI; g.a_sko = g.a2_sko = g.b_sko = 0;
+        g.a_period = shift1 ? RI : 0;
+        g.a2_period = shift2 ? RI : 0;
+    }
     return gemm_f32(g, accumulate, scratch, scratch_floats, stream);
 }
 
@@ -1114,8 +1242,10 @@ int dense_bwd(const float* x, const float* W, const float* dpre, float* dx, floa
         GemmArgs g = {};
         g.a = x; g.b = dpre; g.c = dW; g.M = In; g.N = Out; g.KO = 1; g.KI = N;
         g.a_sm = 1; g.a_ski = In; g.b_sn = 1; g.b_ski = Out; g.ldc = Out;
-        // skinny form: out[s = output unit][w = input unit] stored transposed into dW (In,Out)
+        // skinny forms: out[s = output unit][w = input unit] stored transposed into dW (In,Out) for a narrow output (Dense(6)),
+        // out[s = input unit][w = output unit] for a narrow input (the decoder LSTM's 6-wide kernel over all steps)
         rc = skinny_tn(dpre, Out, Out, x, In, In, N, dW, 1, Out, accumulate, scratch, scratch_floats, stream);
+        if (rc == 0) rc = skinny_tn(x, In, In, dpre, Out, Out, N, dW, Out, 1, accumulate, scratch, scratch_floats, stream);
         if (rc == 0) rc = gemm_f32(g, accumulate, scratch, scratch_floats, stream);
         if (rc < 0) return rc;
     }

@@ -410,6 +410,24 @@ def dense_bwd(x, W, dpre, dW=None, db=None, need_dx=True, accumulate=False, scra
     return (dx.reshape(*x.shape[:-1], In) if need_dx else None), dW, db
 
 
+def mix_head_wgrad(h2, dpre_p, others, p, dpre_m, out, accumulate=False, scratch=None):
+    """[dense_W ; dense_b ; mix_W ; mix_b] gradients of the others-mixing head over all steps in one launch + one reduce.
+    h2 (T,B,H), dpre_p / p / dpre_m (T,B,O) time-major tapes, others (B,T,U-1,6) or (B,T,n_oth) as the model receives it; out = the
+    flat-buffer span of the four tensors ((H + 1 + n_oth + O + 1) * O floats)."""
+    h2, dpre_p, others, p, dpre_m, out = (_dev(a, n) for a, n in ((h2, "h2"), (dpre_p, "dpre_p"), (others, "others"), (p, "p"),
+                                                                      (dpre_m, "dpre_m"), (out, "out")))
+    T, B, H = h2.shape
+    O = p.shape[-1]
+    n_oth = others.numel() // (B * T)
+    assert others.shape[0] == B and others.shape[1] == T and p.shape == (T, B, O) and dpre_p.shape == p.shape and dpre_m.shape == p.shape
+    assert out.numel() == (H + 1 + n_oth + O + 1) * O
+    L = _lib.lib()
+    buf = (scratch or _default_scratch).get(L.fov_mix_head_wgrad_workspace_bytes(B, T, H, O, n_oth), h2.device)
+    check(L.fov_mix_head_wgrad(_ptr(h2), _ptr(dpre_p), _ptr(others), _ptr(p), _ptr(dpre_m), _ptr(out), B, T, H, O, n_oth,
+                               1 if accumulate else 0, buf.data_ptr(), buf.numel(), _stream()))
+    return out
+
+
 def wgrad_fused(x1, x2, dpre, out, bias=True, accumulate=False, scratch=None, dtype="f32"):
     """out (In1 + In2 + bias, Out) (+)= [x1 | x2 | 1]^T dpre over all rows: a layer's dK, dR and db in ONE product and one
     reduce, written where the three lie adjacent in a flat gradient buffer.  x2 may be None."""

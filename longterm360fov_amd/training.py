@@ -674,7 +674,6 @@ class OthersMixingTrainer(FlatParamTrainer):
         O = w["dense_W"].shape[1]
         n_oth = w["mix_W"].shape[0] - O
         Wm_o, Wm_p = w["mix_W"][:n_oth], w["mix_W"][n_oth:]
-        gWm_o, gWm_p = g["mix_W"][:n_oth], g["mix_W"][n_oth:]
         acc = False               # every gradient below is written exactly once: nothing to zero, nothing to accumulate
         # ---------------- forward (keeping what the backward needs) ----------------
         e = lambda *s_: torch.empty(s_, dtype=torch.float32, device=self.device)
@@ -752,9 +751,9 @@ class OthersMixingTrainer(FlatParamTrainer):
         # weight gradients of the unrolled decoder: x^T dz (input kernels, biases) and h_prev^T dz (recurrent)
         TB = T_out * B
         fl = lambda a, n: a.reshape(TB, n)
-        ops.dense_bwd(fl(P, O), Wm_p_c, fl(dpre_all, O), dW=gWm_p, db=g["mix_b"], need_dx=False, accumulate=acc, scratch=sc)
-        ops.dense_bwd(fl(H2[1:], H), w["dense_W"], fl(dpre_p_all, O), dW=g["dense_W"], db=g["dense_b"], need_dx=False,
-                      accumulate=acc, scratch=sc)
+        # head: dense_W, dense_b, mix_W (others' rows and the prediction's), mix_b are adjacent in the flat buffer - one launch
+        # and one reduce form all four, reading `others` in the (B,T,...) layout it arrived in
+        ops.mix_head_wgrad(H2[1:], dpre_p_all, others, P, dpre_all, self._span("dense_W", "mix_b"), accumulate=acc, scratch=sc)
         # a layer's kernel, recurrent kernel and bias are adjacent in the flat buffer: [h1_t | h2_{t-1} | 1]^T dz2 is ONE
         # product + one reduce (dz2 read once), [h1_{t-1} | 1]^T dz1 likewise; the 6-wide dK1 stays a skinny product
         ops.wgrad_fused(fl(H1[1:], H), fl(H2[:T_out], H), fl(DZ2, 4 * H), self._span("dec2_K", "dec2_b"), accumulate=acc,
@@ -763,10 +762,6 @@ class OthersMixingTrainer(FlatParamTrainer):
                       accumulate=acc, scratch=sc)
         ops.wgrad_fused(fl(H1[:T_out], H), None, fl(DZ1, 4 * H), self._span("dec1_R", "dec1_b"), accumulate=acc, scratch=sc,
                         dtype=dt)
-        # "others" half of the mixing kernel: one product over all steps, rows ordered (t, b) like dpre_all
-        oth_tb = others.transpose(0, 1).contiguous().reshape(T_out * B, n_oth)
-        ops.dense_bwd(oth_tb, Wm_o_c, dpre_all.reshape(T_out * B, O), dW=gWm_o, need_db=False, need_dx=False,
-                      accumulate=acc, scratch=sc)
         self.grads_final("dec1_K")    # decoder, heads and loss: all-reduced under the encoder's BPTT
         # encoder: layer 2 over hs1 (its dx is the dhs of layer 1), then layer 1
         e2 = ops.lstm_seq_bwd(hs1, w["enc2_K"], w["enc2_R"], hs2, res2, dhT=dh2_rec, dcT=dc2, dK=g["enc2_K"], dR=g["enc2_R"],

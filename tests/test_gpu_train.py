@@ -367,6 +367,34 @@ def test_fused_weight_gradient_product(N, In1, In2, Out, dtype):
     assert (nb.view(rows - 1, Out) - torch.from_numpy(got[:-1].astype(np.float32)).cuda()).abs().max().item() <= 1e-6 * scale + 1e-6
 
 
+@pytest.mark.parametrize("B,T,H,O,U", [(512, 10, 256, 6, 34), (37, 3, 64, 6, 5), (8, 2, 32, 3, 1), (130, 7, 128, 8, 3)])
+def test_mixing_head_weight_gradients_one_launch(B, T, H, O, U):
+    """fov_mix_head_wgrad: [dense_W ; dense_b] = [h2 | 1]^T dpre_p and [mix_W ; mix_b] = [others | p | 1]^T dpre_m over all
+    steps, one launch + one reduce, `others` read in its (B,T,...) layout - against fp64 products; accumulate; untouched tail."""
+    from longterm360fov_amd import ops
+    rng = np.random.default_rng(B + H)
+    n_oth = (U - 1) * O
+    h2 = rng.standard_normal((T, B, H)).astype(np.float32)
+    dp = rng.standard_normal((T, B, O)).astype(np.float32)
+    dm = rng.standard_normal((T, B, O)).astype(np.float32)
+    p = rng.standard_normal((T, B, O)).astype(np.float32)
+    oth = rng.standard_normal((B, T, max(U - 1, 0), O)).astype(np.float32)
+    d = lambda a: a.astype(np.float64)
+    fl = lambda a: d(a).reshape(T * B, -1)
+    oth_tb = d(oth).transpose(1, 0, 2, 3).reshape(T * B, n_oth)
+    ref = np.concatenate([fl(h2).T @ fl(dp), fl(dp).sum(0, keepdims=True), oth_tb.T @ fl(dm), fl(p).T @ fl(dm),
+                          fl(dm).sum(0, keepdims=True)], 0)
+    n = ref.size
+    out = torch.full((n + 5,), 7.0, device="cuda")
+    ops.mix_head_wgrad(dev(h2), dev(dp), dev(oth), dev(p), dev(dm), out[:n])
+    got = out[:n].view(-1, O).cpu().numpy().astype(np.float64)
+    scale = np.abs(ref).max()
+    assert np.abs(got - ref).max() <= 2e-5 * scale, np.abs(got - ref).max() / scale
+    assert float(out[n:].min()) == 7.0 and float(out[n:].max()) == 7.0
+    ops.mix_head_wgrad(dev(h2), dev(dp), dev(oth), dev(p), dev(dm), out[:n], accumulate=True)
+    assert np.abs(out[:n].view(-1, O).cpu().numpy() - 2 * got).max() <= 4e-5 * scale
+
+
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 @pytest.mark.parametrize("B,T,F,H", [(64, 6, 256, 256), (40, 5, 90, 256), (33, 2, 256, 256), (48, 4, 128, 128)])
 def test_layer_backward_adjacent_gradients_take_the_fused_product(B, T, F, H, dtype):
