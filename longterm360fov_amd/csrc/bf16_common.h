@@ -294,7 +294,8 @@ bool layer_bf16_shape_ok(int F, int H);
 // lstm_bwd8.hip: BPTT recurrence in groups of eight workgroups (H = 256), fp32 or bf16 operands
 bool bwd8_preferred(int B, int H);
 int launch_bwd8(const float* R, const float* reserve, const float* c0, const float* dhs, const float* dhT, const float* dcT,
-                float* dz, float* dh0, float* dc0, float* db_part, int B, int T, int act, int bf16, void* xch_ws, hipStream_t stream);
+                float* dz, float* dh0, float* dc0, float* db_part, int B, int T, int act, int bf16, void* xch_ws, hipStream_t stream,
+                const float* K_dx = nullptr, float* dx = nullptr);
 // gemm_bf16.hip
 size_t gemm_bf16_tn_scratch_floats(int M, int N);
 int gemm_bf16_tn_fused(const float* a1, long lda1, long a1_so, int M1, int shift1, const float* a2, long lda2, long a2_so, int M2,

@@ -38,6 +38,8 @@ struct Bwd8Params {
     float* dh0;             // (B,H) or NULL
     float* dc0;             // (B,H) or NULL
     float* db_part;         // (num_tiles, 4H) or NULL
+    const float* K;         // bf16 DX form: input kernel (256, 4H) of the layer ...
+    float* dx;              // ... and its data gradient dx_t = dz_t K^T (B,T,256), the dhs of the layer below
     unsigned long long* xch;
     unsigned* status;
     int B, T, num_groups, num_tiles, epoch_span;
@@ -307,10 +309,13 @@ __device__ unsigned long long g_b8_stamps[32][12];
 #define B8_STAMP(slot) do { } while (0)
 #endif
 
-template <int ACT>
+// DX: the data gradient dx_t = dz_t K^T of a 256-wide input (the stacked layer: dx is the dhs of the layer below) is formed
+// here as well, from the SAME gathered dz tile and the own 32 rows of K - 16 more MFMAs per wave and step and 64 more
+// registers of fragments instead of a separate (B*T x 1024 x 256) product that re-reads dz from HBM.
+template <int ACT, bool DX>
 __global__ __launch_bounds__(256, 1) void lstm_bwd8n_bf16_kernel(Bwd8Params p) {
     __shared__ __attribute__((aligned(16))) unsigned short sDZ[QBT * QLDZ];   // the whole dz tile, bf16
-    __shared__ float sRed[4 * QBT * 33];                                      // [wave][row][unit] partial dh
+    __shared__ float sRed[(DX ? 8 : 4) * QBT * 33];                           // [wave][row][unit] partial dh (+ partial dx)
     __shared__ int sFlag[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 15, g4 = lane >> 4;
@@ -338,6 +343,14 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd8n_bf16_kernel(Bwd8Params p) {
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
             rq[kb][nt] = load_bfrag_rowmajor(p.R + (size_t)(32 * slice + 16 * nt + n) * H4 + QH * wave + 32 * kb + 8 * g4);
+    qu32x4 kq[DX ? 8 : 1][2];   // K^T fragments, same shape: input unit 32*slice + 16*nt + n
+    if constexpr (DX) {
+#pragma unroll
+        for (int kb = 0; kb < 8; ++kb)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+                kq[kb][nt] = load_bfrag_rowmajor(p.K + (size_t)(32 * slice + 16 * nt + n) * H4 + QH * wave + 32 * kb + 8 * g4);
+    }
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
         p.xch + (size_t)group * 2 * (Q_DZ_BYTES / 8), 0, (int)(2 * Q_DZ_BYTES), 0x00020000);
     __syncthreads();
@@ -428,9 +441,11 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd8n_bf16_kernel(Bwd8Params p) {
             B8_STAMP(6);
             if (sFlag[0]) { aborted = true; break; }
             // ---- this wave's share of dh_{t-1}[16 x 32 own units]: gate `wave`'s 256 columns ----
-            f32x4 acc[2];
+            f32x4 acc[2], accx[2];
             acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
             acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            accx[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            accx[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
             {
                 qu32x4 a[8];
 #pragma unroll
@@ -439,12 +454,19 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd8n_bf16_kernel(Bwd8Params p) {
                 for (int kb = 0; kb < 8; ++kb) {
                     qmfma(acc[0], a[kb], rq[kb][0]);
                     qmfma(acc[1], a[kb], rq[kb][1]);
+                    if constexpr (DX) {
+                        qmfma(accx[0], a[kb], kq[kb][0]);
+                        qmfma(accx[1], a[kb], kq[kb][1]);
+                    }
                 }
             }
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) sRed[(wave * QBT + 4 * g4 + r) * 33 + 16 * nt + n] = acc[nt][r];
+                for (int r = 0; r < 4; ++r) {
+                    sRed[(wave * QBT + 4 * g4 + r) * 33 + 16 * nt + n] = acc[nt][r];
+                    if constexpr (DX) sRed[((4 + wave) * QBT + 4 * g4 + r) * 33 + 16 * nt + n] = accx[nt][r];
+                }
             B8_STAMP(7);
             __syncthreads();   // barrier B: the four partial tiles are in LDS; every wave is done reading the dz tile
             B8_STAMP(8);
@@ -452,6 +474,11 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd8n_bf16_kernel(Bwd8Params p) {
             for (int r = 0; r < 2; ++r) {
                 const float* q = sRed + (my_row0 + r) * 33 + ul;
                 dh[r] = (q[0] + q[QBT * 33]) + (q[2 * QBT * 33] + q[3 * QBT * 33]);
+                if constexpr (DX) {
+                    const float* qx = q + 4 * QBT * 33;
+                    if (live[r])
+                        p.dx[((size_t)(b0 + my_row0 + r) * T + t) * QH + unit] = (qx[0] + qx[QBT * 33]) + (qx[2 * QBT * 33] + qx[3 * QBT * 33]);
+                }
             }
 #pragma unroll
             for (int q = 0; q < 7; ++q)
@@ -498,9 +525,13 @@ bool bwd8_preferred(int B, int H) { return H == QH && B > 0 && B <= 32 * QBT; }
 
 // status word + granule buffers live at `xch_ws` (kStatusBytes + kXchBytes)
 int launch_bwd8(const float* R, const float* reserve, const float* c0, const float* dhs, const float* dhT, const float* dcT,
-                float* dz, float* dh0, float* dc0, float* db_part, int B, int T, int act, int bf16, void* xch_ws, hipStream_t stream) {
+                float* dz, float* dh0, float* dc0, float* db_part, int B, int T, int act, int bf16, void* xch_ws, hipStream_t stream,
+                const float* K_dx, float* dx) {
     if (B == 0 || T == 0) return FOV_OK;
     Bwd8Params p = {};
+    p.K = K_dx; p.dx = dx;
+    const bool with_dx = bf16 && K_dx && dx;
+    if (with_dx && (((uintptr_t)K_dx) & 15)) { set_error("8-group BPTT kernel: K must be 16-byte aligned"); return FOV_ERR_INVALID; }
     p.R = R; p.reserve = reserve; p.c0 = c0; p.dhs = dhs; p.dhT = dhT; p.dcT = dcT; p.dz = dz; p.dh0 = dh0; p.dc0 = dc0; p.db_part = db_part;
     p.B = B; p.T = T;
     p.num_tiles = (B + QBT - 1) / QBT;
@@ -513,7 +544,8 @@ int launch_bwd8(const float* R, const float* reserve, const float* c0, const flo
     p.xch = (unsigned long long*)((char*)xch_ws + kStatusBytes);
     p.epoch_span = T * ((p.num_tiles + p.num_groups - 1) / p.num_groups) + 1;
     void (*kern)(Bwd8Params) = nullptr;
-    if (bf16) kern = act == FOV_ACT_HARD_SIGMOID ? lstm_bwd8n_bf16_kernel<FOV_ACT_HARD_SIGMOID> : lstm_bwd8n_bf16_kernel<FOV_ACT_SIGMOID>;
+    if (bf16 && with_dx) kern = act == FOV_ACT_HARD_SIGMOID ? lstm_bwd8n_bf16_kernel<FOV_ACT_HARD_SIGMOID, true> : lstm_bwd8n_bf16_kernel<FOV_ACT_SIGMOID, true>;
+    else if (bf16) kern = act == FOV_ACT_HARD_SIGMOID ? lstm_bwd8n_bf16_kernel<FOV_ACT_HARD_SIGMOID, false> : lstm_bwd8n_bf16_kernel<FOV_ACT_SIGMOID, false>;
     else kern = act == FOV_ACT_HARD_SIGMOID ? lstm_bwd8_kernel<FOV_ACT_HARD_SIGMOID> : lstm_bwd8_kernel<FOV_ACT_SIGMOID>;
     hipLaunchKernelGGL(kern, dim3(p.num_groups * QG), dim3(256), 0, stream, p);
     hipError_t e = hipGetLastError();

@@ -1107,7 +1107,7 @@ int lstm_seq_bwd(const float* x, const float* K, const float* R, const float* h0
         return FOV_OK;
     }
     const bool persistent = bwd_cluster_shape_ok(H) && !getenv("FOV_BWD_STEPPED");
-    bool fuse_kr = false, fuse_r = false;
+    bool fuse_kr = false, fuse_r = false, dx_in_kernel = false;
     const size_t head = (kStatusBytes + kXchBytes) / sizeof(float);
     float* dh_rec = ws + head;
     float* dc = dh_rec + (size_t)B * H;
@@ -1127,10 +1127,13 @@ int lstm_seq_bwd(const float* x, const float* K, const float* R, const float* h0
         fuse_r = !fuse_kr && dR && db && !h0 && T > 1 && db == dR + (size_t)H * N4 &&
                  wgrad_fusable(hs, H, (long)T * H, H, nullptr, 0, 0, 0, dz, N4, (long)T * N4, dR, N4) && !getenv("FOV_NO_WGRAD_FUSION");
         float* db_part = (db && !fuse_kr && !fuse_r) ? scratch : nullptr;
+        // bf16, 256-wide input (the stacked layer): the BPTT kernel forms dx = dz K^T from the dz tile it has gathered anyway
+        dx_in_kernel = bf16 && dx && F == 256 && (((uintptr_t)K) & 15) == 0 && !getenv("FOV_NO_DX_FUSION");
         // H = 256: groups of eight workgroups fill the chip up to 32 tiles (the 4-group kernel leaves half of it idle
         // at 512 sequences); bf16 operands exist in the 8-group kernel only
         int rc = (bf16 || (bwd8_preferred(B, H) && !getenv("FOV_BWD_GROUPS4")))
-                     ? launch_bwd8(R, reserve, c0, dhs, dhT, dcT, dz, dh0 ? dh0 : dh_rec, dc0 ? dc0 : dc, db_part, B, T, act, bf16, ws, stream)
+                     ? launch_bwd8(R, reserve, c0, dhs, dhT, dcT, dz, dh0 ? dh0 : dh_rec, dc0 ? dc0 : dc, db_part, B, T, act, bf16, ws, stream,
+                                   dx_in_kernel ? K : nullptr, dx_in_kernel ? dx : nullptr)
                      : launch_bwd_cluster(R, reserve, c0, dhs, dhT, dcT, dz, dh0 ? dh0 : dh_rec, dc0 ? dc0 : dc, db_part, B, T, H,
                                           act, ws, stream);
         if (rc) return rc;
@@ -1217,7 +1220,7 @@ int lstm_seq_bwd(const float* x, const float* K, const float* R, const float* h0
         rc = colsum(dz, db, BT, 4 * H, accumulate, scratch, scratch_floats, stream);
         if (rc) return rc;
     }
-    if (dx) {   // dx (B*T,F) = dz . K^T : A(m,k) = dz[m][k], B(k,n) = K[n][k]
+    if (dx && !dx_in_kernel) {   // dx (B*T,F) = dz . K^T : A(m,k) = dz[m][k], B(k,n) = K[n][k]
         GemmArgs g = {};
         g.a = dz; g.b = K; g.c = dx; g.M = (int)BT; g.N = F; g.KO = 1; g.KI = 4 * H;
         g.a_sm = 4 * H; g.a_ski = 1; g.b_sn = 4 * H; g.b_ski = 1; g.ldc = F;

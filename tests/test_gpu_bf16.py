@@ -197,6 +197,22 @@ def test_eight_group_bptt_layer(dtype, B, T, F, act, state):
         scale = np.abs(r).max()
         print("%s 8-group BPTT B=%d T=%d F=%d %-4s max|ref| %.3e err %.3e" % (dtype, B, T, F, k, scale, np.abs(a - r).max()))
         assert np.abs(a - r).max() <= tol * scale + 1e-9, (dtype, k)
+    if dtype == "bf16" and F == 256:
+        # dx = dz K^T was formed inside the BPTT kernel (from the gathered bf16 dz tile and the own rows of K); the separate
+        # product rounds the same operands: equal up to the summation order
+        import os
+        os.environ["FOV_NO_DX_FUSION"] = "1"
+        try:
+            sep = ops.lstm_seq_bwd(dev(x), dev(K), dev(R), hs, res, h0=None if h0 is None else dev(h0), c0=None if c0 is None else dev(c0),
+                                   dhs=dev(dhs), dhT=dev(dhT), dcT=dev(dcT), need_dx=True, need_state_grads=True, act=act, scratch=sc,
+                                   dtype=dtype)
+        finally:
+            del os.environ["FOV_NO_DX_FUSION"]
+        sc.check()
+        assert torch.equal(sep["dz"], got["dz"])
+        err = (sep["dx"] - got["dx"]).abs().max().item()
+        print("dx in the BPTT kernel vs separate product: %.3e of %.3e" % (err, sep["dx"].abs().max().item()))
+        assert err <= 1e-5 * sep["dx"].abs().max().item() + 1e-8
 
 
 @pytest.mark.parametrize("B,U,T_in,T_out,act", [(37, 5, 2, 4, "hard_sigmoid"), (530, 3, 2, 2, "sigmoid"), (512, 34, 10, 10, "sigmoid")])
