@@ -101,33 +101,34 @@ __global__ __launch_bounds__(256) void gemm_bf16_tn_kernel(GemmTN g) {
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     f32x4 ra[4], rb[4];
     f32x4 bsum = (f32x4){0.f, 0.f, 0.f, 0.f};   // bias_blk: column sums of this thread's B elements
+    // Every load is UNCONDITIONAL: buffer loads through descriptors of the whole operands, rows past the slice, the
+    // zero row of a shifted operand and columns past the matrix present an out-of-range offset and read as 0.  (A load
+    // inside a branch gets an s_waitcnt vmcnt(0) at the merge: the eight loads of a stage then complete one after the
+    // other - measured 1.7 us per stage instead of one memory latency.)
+    constexpr unsigned OOR = 0x80000000u;
+    const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(abase), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.b), 0, 0x7fffffff, 0x00020000);
+    const bool a_col_ok = am0 + scol < a_M;             // AVEC: a_M % 4 == 0, the whole quad is in or out
+    const bool b_col_ok = n0 + scol + 3 < g.N;          // N % 4 == 0 (host-checked)
     auto load_stage = [&](long r0) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const long r = r0 + srow + 8 * i;
-            ra[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            rb[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (r < r_hi) {
-                const long ro = r / g.RI, ri = r - ro * g.RI;
-                const float* ap = abase + ro * a_so + (ri - a_shift) * a_ld + am0 + scol;
-                const float* bp = g.b + ro * g.b_so + ri * g.ldb + n0 + scol;
-                if (a_shift && ri == 0) {
-                    // h_{-1} = 0
-                } else if (AVEC) {
-                    if (am0 + scol < a_M) ra[i] = *(const f32x4*)ap;
-                } else {
+            const unsigned ro = (unsigned)r / (unsigned)g.RI, ri = (unsigned)r - ro * (unsigned)g.RI;
+            const bool rok = r < r_hi;
+            const bool a_ok = rok && !(a_shift && ri == 0);
+            const unsigned aoff = (unsigned)(((long)ro * a_so + ((long)ri - a_shift) * a_ld + am0 + scol) * 4);
+            const unsigned boff = (unsigned)(((long)ro * g.b_so + (long)ri * g.ldb + n0 + scol) * 4);
+            if (AVEC) {
+                const qu32x4 t = __builtin_amdgcn_raw_buffer_load_b128(ars, (a_ok && a_col_ok) ? aoff : OOR, 0, 0);
+                ra[i] = (f32x4){__uint_as_float(t[0]), __uint_as_float(t[1]), __uint_as_float(t[2]), __uint_as_float(t[3])};
+            } else {
 #pragma unroll
-                    for (int v = 0; v < 4; ++v)
-                        if (am0 + scol + v < a_M) ra[i][v] = ap[v];
-                }
-                if (n0 + scol + 3 < g.N) {
-                    rb[i] = *(const f32x4*)bp;
-                } else {
-#pragma unroll
-                    for (int v = 0; v < 4; ++v)
-                        if (n0 + scol + v < g.N) rb[i][v] = bp[v];
-                }
+                for (int v = 0; v < 4; ++v)
+                    ra[i][v] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ars, (a_ok && am0 + scol + v < a_M) ? aoff + 4 * v : OOR, 0, 0));
             }
+            const qu32x4 t = __builtin_amdgcn_raw_buffer_load_b128(brs, (rok && b_col_ok) ? boff : OOR, 0, 0);
+            rb[i] = (f32x4){__uint_as_float(t[0]), __uint_as_float(t[1]), __uint_as_float(t[2]), __uint_as_float(t[3])};
         }
     };
     auto store_stage = [&](int buf) {
@@ -142,6 +143,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_tn_kernel(GemmTN g) {
         }
     };
     const long nstages = (r_hi > r_lo) ? (r_hi - r_lo + GKB - 1) / GKB : 0;
+    // (two stages in flight from one block - a second register set - was measured slower: 322 registers, one block per CU
+    // instead of three; the other blocks of the CU are what keeps more loads in flight)
     if (nstages > 0) {
         load_stage(r_lo);
         store_stage(0);
@@ -220,13 +223,21 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(GemmNT g) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     f32x4 ra[8], rb[8];
+    // unconditional buffer loads (see the TN kernel): rows past the matrix and k past K present an out-of-range offset
+    constexpr unsigned OOR = 0x80000000u;
+    const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.a), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.b), 0, 0x7fffffff, 0x00020000);
     auto load_stage = [&](int k0) {
         const bool kin = k0 + scol < g.K;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int row = srow + 16 * i;
-            ra[i] = (kin && m0 + row < g.M) ? *(const f32x4*)(g.a + (size_t)(m0 + row) * g.lda + k0 + scol) : (f32x4){0.f, 0.f, 0.f, 0.f};
-            rb[i] = (kin && n0 + row < g.N) ? *(const f32x4*)(g.b + (size_t)(n0 + row) * g.ldb + k0 + scol) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            const unsigned aoff = (unsigned)(((long)(m0 + row) * g.lda + k0 + scol) * 4);
+            const unsigned boff = (unsigned)(((long)(n0 + row) * g.ldb + k0 + scol) * 4);
+            const qu32x4 ta = __builtin_amdgcn_raw_buffer_load_b128(ars, (kin && m0 + row < g.M) ? aoff : OOR, 0, 0);
+            const qu32x4 tb = __builtin_amdgcn_raw_buffer_load_b128(brs, (kin && n0 + row < g.N) ? boff : OOR, 0, 0);
+            ra[i] = (f32x4){__uint_as_float(ta[0]), __uint_as_float(ta[1]), __uint_as_float(ta[2]), __uint_as_float(ta[3])};
+            rb[i] = (f32x4){__uint_as_float(tb[0]), __uint_as_float(tb[1]), __uint_as_float(tb[2]), __uint_as_float(tb[3])};
         }
     };
     auto store_stage = [&](int buf) {
@@ -285,6 +296,14 @@ int gemm_bf16_tn_fused(const float* a1, long lda1, long a1_so, int M1, int shift
     const long rows = (long)RO * RI;
     if ((ldb & 3) || (b_so & 3) || (((uintptr_t)b) & 15) || (N & 3)) { set_error("gemm_bf16_tn: B must be 16-byte aligned with N, ldb % 4 == 0"); return FOV_ERR_INVALID; }
     if (a2 && (M1 % GT)) { set_error("gemm_bf16_tn: the first operand of a fused product must be a multiple of %d wide", GT); return FOV_ERR_INVALID; }
+    {   // 31-bit byte offsets inside one buffer descriptor per operand
+        auto span = [&](long so, long ld, int width) { return ((long)(RO - 1) * so + (long)RI * ld + width) * 4; };
+        if (span(a1_so, lda1, M1) >= (1L << 31) || (a2 && span(a2_so, lda2, M2) >= (1L << 31)) || span(b_so, ldb, N) >= (1L << 31) ||
+            rows >= (1L << 31)) {
+            set_error("gemm_bf16_tn: operand larger than 2 GiB");
+            return FOV_ERR_UNSUPPORTED;
+        }
+    }
     if (rows <= 0) {
         if (!accumulate) (void)hipMemsetAsync(c, 0, sizeof(float) * (size_t)(M + bias_row) * ldc, stream);
         return FOV_OK;
@@ -336,6 +355,7 @@ int gemm_bf16_nt(const float* a, long lda, const float* b, long ldb, float* c, i
         set_error("gemm_bf16_nt: K, lda, ldb must be multiples of 4 and the operands 16-byte aligned");
         return FOV_ERR_INVALID;
     }
+    if (((long)M * lda + K) * 4 >= (1L << 31) || ((long)N * ldb + K) * 4 >= (1L << 31)) { set_error("gemm_bf16_nt: operand larger than 2 GiB"); return FOV_ERR_UNSUPPORTED; }
     GemmNT g = {};
     g.a = a; g.b = b; g.c = c; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
     hipLaunchKernelGGL(gemm_bf16_nt_kernel, dim3((N + GT - 1) / GT, (M + GT - 1) / GT), dim3(256), 0, stream, g);

@@ -920,13 +920,11 @@ __global__ __launch_bounds__(256) void mix_head_wgrad_kernel(const float* __rest
             for (int u = 0; u < 8; ++u) {
                 const bool ok = r + 4 * u < r1;
                 rr[u] = ok ? r + 4 * u : r;
-                float v = 1.f;
-                if (kind == 0) v = src[rr[u] * ld + col];
-                else if (kind == 2) {
-                    const int t = (int)(rr[u] / B), b = (int)(rr[u] - (long)t * B);
-                    v = src[((long)b * T + t) * n_oth + col];
-                }
-                wv[u] = ok ? v : 0.f;
+                // one unconditional load per row whatever the column reads (a load inside a branch is waited for at the merge)
+                const int t = (int)((unsigned)rr[u] / (unsigned)B), b = (int)rr[u] - t * B;
+                const long off = kind == 2 ? ((long)b * T + t) * n_oth + col : rr[u] * ld + col;   // kind 1: element 0 of dpre_p, unused
+                const float v = src[off];
+                wv[u] = ok ? (kind == 1 ? 1.f : v) : 0.f;
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u)
