@@ -48,6 +48,10 @@ constexpr unsigned SPIN_LIMIT = 1u << 20;
 
 constexpr int MODE_LAYER = 0;   // T steps over x:(B,T,F) from (h0,c0); optional hs / hT / cT
 constexpr int MODE_DECODE = 1;  // T_out autoregressive steps from (h0,c0): y_t = tanh(h_t W + bias) fed back
+constexpr int MODE_LAYER_ZX = 2;   // MODE_LAYER with the input projection precomputed by the caller (p.zx).  A mode of its own:
+                                // as a run-time flag its loads sat in a uniform branch, and the s_waitcnt vmcnt(0) the compiler
+                                // puts at that merge also waited for the x_{t+2} request issued just before it - one exposed
+                                // memory latency in every step of the plain layer
 
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
@@ -82,7 +86,7 @@ __device__ unsigned long long g_stamps[2][STAMP_STEPS][STAMP_SLOTS];
         if (stamp_on && t < STAMP_STEPS) {                                                      \
             unsigned long long t_;                                                              \
             asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");          \
-            g_stamps[MODE][t][slot] = t_;                                                       \
+            g_stamps[MODE & 1][t][slot] = t_;                                                       \
         }                                                                                       \
         __builtin_amdgcn_sched_barrier(0);                                                      \
     } while (0)
@@ -140,29 +144,52 @@ __device__ __forceinline__ void load_weights(float (&wR)[H / 16][4][4], float (&
     constexpr int G = H / 64;
     const int n = lane & 15, g4 = lane >> 4;
     const int H4 = 4 * H;
+    // Buffer loads: one per-lane offset for the whole slice, the (j, s, g) part of the address is wave-uniform and goes
+    // into the instruction's scalar offset - no per-load address arithmetic, and nothing keeps the loads from being
+    // issued back to back (the counter allows 63 in flight).
+    {
+        const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(R), 0, H * H4 * 4, 0x00020000);
+        const unsigned voff = (unsigned)((4 * g4 * H4 + col0 + n) * 4);
 #pragma unroll
-    for (int j = 0; j < H / 16; ++j) {
-        const int kbase = ((slice + (j >> 2)) & (G - 1)) * 64 + (j & 3) * 16 + 4 * g4;
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
+        for (int j = 0; j < H / 16; ++j) {
+            const unsigned kb = (unsigned)((((slice + (j >> 2)) & (G - 1)) * 64 + (j & 3) * 16) * H4 * 4);
 #pragma unroll
             for (int s = 0; s < 4; ++s)
-                wR[j][s][g] = R[(size_t)(kbase + s) * H4 + g * H + col0 + n];
-    }
 #pragma unroll
-    for (int g = 0; g < 4; ++g) bias[g] = b ? b[g * H + col0 + n] : 0.f;
+                for (int g = 0; g < 4; ++g)
+                    wR[j][s][g] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rrs, voff, kb + (unsigned)((s * H4 + g * H) * 4), 0));
+        }
+    }
+    {
+        const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(b), 0, b ? H4 * 4 : 0, 0x00020000);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) bias[g] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(brs, (unsigned)((g * H + col0 + n) * 4), 0, 0));
+    }
     // K slice in B-operand order: block (q,s) = 64 lanes x {i,f,c,o} of input row k = 16q+4*g4+s.
     // DECODE (F <= 8, one q block): k = 4*s + g4 instead, so that the two MFMA steps s = 0,1 cover
     // k = 0..7 and the Dense output fragment (y[n][4r + g4] in register r) is their A operand.
+    // All loads are unconditional (the descriptor ends with row F - 1: rows k >= F read as 0) and issued before the
+    // first LDS store: a load inside a branch is waited for at the merge - with a branch per (q, s) block the prologue
+    // was up to 24 dependent memory round trips long.
     const int nq = Fp >> 4;
-    for (int q = 0; q < nq; ++q)
+    constexpr int QMAX = CL_MAX_F / 16;
+    const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(K), 0, F * H4 * 4, 0x00020000);
+    f32x4 kv[DEC_KMAP ? 1 : QMAX][4];
+#pragma unroll
+    for (int q = 0; q < (DEC_KMAP ? 1 : QMAX); ++q)
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const int k = DEC_KMAP ? (s < 2 ? 4 * s + g4 : F) : 16 * q + 4 * g4 + s;
-            f32x4 v;
+            const unsigned voff = (unsigned)((k * H4 + col0 + n) * 4);   // k >= F: past the descriptor
 #pragma unroll
-            for (int g = 0; g < 4; ++g) v[g] = (k < F) ? K[(size_t)k * H4 + g * H + col0 + n] : 0.f;
-            *(f32x4*)(sKw + ((q * 4 + s) * 64 + lane) * 4) = v;
+            for (int g = 0; g < 4; ++g)
+                kv[q][s][g] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(krs, voff + (unsigned)(g * H * 4), 0, 0));
+        }
+#pragma unroll
+    for (int q = 0; q < (DEC_KMAP ? 1 : QMAX); ++q)
+        if (q < nq) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) *(f32x4*)(sKw + ((q * 4 + s) * 64 + lane) * 4) = kv[q][s];
         }
 }
 
@@ -222,7 +249,8 @@ __global__ __launch_bounds__(256, 1) void lstm_cluster_kernel(LstmParams p) {
     constexpr int G = H / 64;
     constexpr int NQ = H / 16;
     constexpr int NG = (G - 1) * 4;  // granules gathered per thread per step
-    constexpr bool LAYER = (MODE == MODE_LAYER);
+    constexpr bool LAYER = (MODE != MODE_DECODE);
+    constexpr bool ZX = (MODE == MODE_LAYER_ZX);      // input projection precomputed by the caller
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -244,7 +272,6 @@ __global__ __launch_bounds__(256, 1) void lstm_cluster_kernel(LstmParams p) {
     const float* Kp = LAYER ? p.K : p.dK;
     const float* Rp = LAYER ? p.R : p.dR;
     const float* bp = LAYER ? p.b : p.db;
-    const bool ZX = LAYER && (p.zx != nullptr);     // input projection precomputed by the caller
     const int F = LAYER ? (ZX ? 0 : p.F) : p.F_dec;
     const int steps = LAYER ? p.T : p.T_out;
     const int Fp = round16(F);
@@ -308,8 +335,12 @@ __global__ __launch_bounds__(256, 1) void lstm_cluster_kernel(LstmParams p) {
     constexpr int NB = H / 64;
     float wd[NB][4];
     float bd4[4];
+    constexpr unsigned OORB = 0x80000000u;   // buffer-load offset no descriptor covers: reads as 0
     if (!LAYER) {
         const int O = p.F_dec;
+        // unconditional buffer loads (out-of-range offset = 0): a load inside a branch is waited for at the merge
+        const __amdgpu_buffer_rsrc_t wdrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dW), 0, H * O * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t bdrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dbias), 0, O * 4, 0x00020000);
 #pragma unroll
         for (int b = 0; b < NB; ++b)
 #pragma unroll
@@ -317,10 +348,11 @@ __global__ __launch_bounds__(256, 1) void lstm_cluster_kernel(LstmParams p) {
                 const int pos = 16 * (NB * wave + b) + 4 * g4 + ss;
                 const int unit = ((slice + (pos >> 6)) & (G - 1)) * 64 + (pos & 63);
                 const int o = 4 * (n & 3) + (n >> 2);
-                wd[b][ss] = (o < O) ? p.dW[(size_t)unit * O + o] : 0.f;
+                wd[b][ss] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(wdrs, (o < O) ? (unsigned)((unit * O + o) * 4) : OORB, 0, 0));
             }
 #pragma unroll
-        for (int ss = 0; ss < 4; ++ss) bd4[ss] = (4 * ss + g4 < O) ? p.dbias[4 * ss + g4] : 0.f;
+        for (int ss = 0; ss < 4; ++ss)
+            bd4[ss] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(bdrs, (4 * ss + g4 < O) ? (unsigned)((4 * ss + g4) * 4) : OORB, 0, 0));
     }
     f32x4 kb[2];   // DECODE: the two K-slice blocks of this lane (loop invariant)
     if (!LAYER) {
@@ -362,34 +394,64 @@ __global__ __launch_bounds__(256, 1) void lstm_cluster_kernel(LstmParams p) {
     for (int tile = group; tile < p.num_tiles && !aborted; tile += p.num_groups) {
         const int b0 = tile * BT;
         // ---- initial state (the previous tile ended on a barrier) ----
+        // Every global load of the tile goes through a buffer descriptor that covers exactly the tile's live rows (a NULL
+        // tensor: nothing): rows past the batch, absent tensors and masked columns read as 0 WITHOUT a branch, so the
+        // loads are issued back to back and nothing waits for them before their first use.
+        const int live_rows = p.B - b0 < BT ? p.B - b0 : BT;
+        const __amdgpu_buffer_rsrc_t c0rs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(p.c0 ? p.c0 + (size_t)b0 * H : nullptr), 0, p.c0 ? live_rows * H * 4 : 0, 0x00020000);
+        const __amdgpu_buffer_rsrc_t h0rs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(p.h0 ? p.h0 + (size_t)b0 * H : nullptr), 0, p.h0 ? live_rows * H * 4 : 0, 0x00020000);
         float c[4], hcur[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int row = b0 + 4 * g4 + r;
-            const bool live = row < p.B;
-            c[r] = (live && p.c0) ? p.c0[(size_t)row * H + col0 + n] : 0.f;
-            hcur[r] = (live && p.h0) ? p.h0[(size_t)row * H + col0 + n] : 0.f;
+            const unsigned off = (unsigned)(((4 * g4 + r) * H + col0 + n) * 4);
+            c[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(c0rs, off, 0, 0));
+            hcur[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(h0rs, off, 0, 0));
         }
-        for (int i = tid; i < BT * H; i += 256) {
-            const int row = i / H, pos = i - row * H;
-            const int unit = ((slice + (pos >> 6)) & (G - 1)) * 64 + (pos & 63);
-            sH[row * LDH + pos] = (b0 + row < p.B && p.h0) ? p.h0[(size_t)(b0 + row) * H + unit] : 0.f;
+        {
+            float hv[BT * H / 256];
+#pragma unroll
+            for (int q = 0; q < BT * H / 256; ++q) {
+                const int i = tid + 256 * q;
+                const int row = i / H, pos = i - row * H;
+                const int unit = ((slice + (pos >> 6)) & (G - 1)) * 64 + (pos & 63);
+                hv[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(h0rs, (unsigned)((row * H + unit) * 4), 0, 0));
+            }
+#pragma unroll
+            for (int q = 0; q < BT * H / 256; ++q) {
+                const int i = tid + 256 * q;
+                const int row = i / H, pos = i - row * H;
+                sH[row * LDH + pos] = hv[q];
+            }
         }
         // x staging: thread (xrw = tid/16, xcl = tid%16) moves columns xcl + 16*i of row xrw
         const int xrw = tid >> 4, xcl = tid & 15;
-        const bool xlive = LAYER && !ZX && (b0 + xrw < p.B);
-        const float* xt = (LAYER && !ZX) ? p.x + ((size_t)(b0 + xrw) * p.T) * F + xcl : nullptr;
-        // ZX mode: this lane's 16 pre-activations of step t live at zxp[(r*T + t)*4H + g*H]
-        const float* zxp = ZX ? p.zx + ((size_t)(b0 + 4 * g4) * p.T) * 4 * H + col0 + n : nullptr;
+        const bool xuse = LAYER && !ZX;
+        const __amdgpu_buffer_rsrc_t xgrs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(xuse ? p.x + (size_t)b0 * p.T * F : nullptr), 0, xuse ? live_rows * p.T * F * 4 : 0, 0x00020000);
+        unsigned xoff[XR];   // byte offset of this thread's elements of step 0 (masked columns: out of range)
+#pragma unroll
+        for (int i = 0; i < XR; ++i) xoff[i] = (xcl + 16 * i < F) ? (unsigned)((xrw * p.T * F + xcl + 16 * i) * 4) : OORB;
+        // ZX mode: this lane's 16 pre-activations of step t live at (r*T + t)*4H + g*H of the tile's rows
+        const __amdgpu_buffer_rsrc_t zxrs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(ZX ? p.zx + (size_t)b0 * p.T * 4 * H : nullptr), 0, ZX ? live_rows * p.T * 4 * H * 4 : 0, 0x00020000);
+        const unsigned zxoff = (unsigned)((4 * g4 * p.T * 4 * H + col0 + n) * 4);
         f32x4 zr[4];   // prefetched pre-activations of the NEXT step (ZX mode)
         float* xl = sX + xrw * LDX + xcl;
-        if (LAYER && !ZX) {
+        if (xuse) {
+            float x2[2][XR];
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                for (int i = 0; i < XR; ++i)
+                    x2[tt][i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xgrs, tt < steps ? xoff[i] : OORB, (unsigned)(tt * F * 4), 0));
 #pragma unroll
             for (int tt = 0; tt < 2; ++tt)
                 if (tt < steps) {
 #pragma unroll
                     for (int i = 0; i < XR; ++i)
-                        if (xcl + 16 * i < F) xl[tt * BT * LDX + 16 * i] = xlive ? xt[(size_t)tt * F + 16 * i] : 0.f;
+                        if (xcl + 16 * i < F) xl[tt * BT * LDX + 16 * i] = x2[tt][i];
                 }
         }
         f32x4 y4 = (f32x4){0.f, 0.f, 0.f, 0.f};   // DECODE: y_{t-1}[n][4*s + g4], the A fragment of y . K
@@ -409,7 +471,7 @@ __global__ __launch_bounds__(256, 1) void lstm_cluster_kernel(LstmParams p) {
             for (int g = 0; g < 4; ++g)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    acc[g][r] = bias[g] + ((b0 + 4 * g4 + r < p.B) ? zxp[((size_t)r * p.T) * 4 * H + g * H] : 0.f);
+                    acc[g][r] = bias[g] + __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(zxrs, zxoff + (unsigned)((r * p.T * 4 * H + g * H) * 4), 0, 0));
         }
         if (steps > 0) {
             mfma_begin(acc);
@@ -425,7 +487,7 @@ __global__ __launch_bounds__(256, 1) void lstm_cluster_kernel(LstmParams p) {
         for (int t = 0; t < steps; ++t) {
             FOV_STAMP(0);
 #ifdef FOV_STAMPS
-            if (stamp_on && t < STAMP_STEPS) g_stamps[MODE][t][9] = __builtin_amdgcn_s_memrealtime();
+            if (stamp_on && t < STAMP_STEPS) g_stamps[MODE & 1][t][9] = __builtin_amdgcn_s_memrealtime();
 #endif
             // ---- x pipeline: x_{t+1} (loaded during step t-1) goes registers -> LDS now; its tile
             // was last read two steps ago and is next read after barrier 1b of this step.  Then
@@ -441,12 +503,13 @@ __global__ __launch_bounds__(256, 1) void lstm_cluster_kernel(LstmParams p) {
                 for (int g = 0; g < 4; ++g)
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        zr[g][r] = bias[g] + ((b0 + 4 * g4 + r < p.B) ? zxp[((size_t)r * p.T + (t + 1)) * 4 * H + g * H] : 0.f);
+                        zr[g][r] = bias[g] + __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
+                                                 zxrs, zxoff + (unsigned)(((r * p.T + (t + 1)) * 4 * H + g * H) * 4), 0, 0));
             }
             if (LAYER && !ZX && t + 2 < steps) {
-                const float* xn = xt + (size_t)(t + 2) * F;
 #pragma unroll
-                for (int i = 0; i < XR; ++i) xr[i] = (xlive && xcl + 16 * i < F) ? xn[16 * i] : 0.f;
+                for (int i = 0; i < XR; ++i)
+                    xr[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xgrs, xoff[i], (unsigned)((t + 2) * F * 4), 0));
             }
             // ---- the part of h_{t-1} . R that needed the partner slices ----
             recurrent<H, 4, NQ>(acc, hrow, wR);
@@ -550,7 +613,7 @@ __global__ __launch_bounds__(256, 1) void lstm_cluster_kernel(LstmParams p) {
                     for (int j = 0; j < NG; ++j) v[j] = __builtin_amdgcn_raw_buffer_load_b64(xrs, goff[j], xsoff, 16);
                 }
 #ifdef FOV_STAMPS
-                if (stamp_on && t < STAMP_STEPS) g_stamps[MODE][t][10] = spins;
+                if (stamp_on && t < STAMP_STEPS) g_stamps[MODE & 1][t][10] = spins;
 #endif
 #pragma unroll
                 for (int j = 0; j < NG; ++j) sH[loff[j]] = __uint_as_float(v[j].x);
@@ -674,12 +737,15 @@ size_t cluster_workspace_bytes(int B, int H) {
 template <int H>
 static int launch_cluster_h(const LstmParams& p, int mode, hipStream_t stream) {
     void (*kern)(LstmParams) = nullptr;
+    if (mode == MODE_LAYER && p.zx) mode = MODE_LAYER_ZX;
     if (p.act == FOV_ACT_HARD_SIGMOID)
         kern = mode == MODE_DECODE ? lstm_cluster_kernel<H, FOV_ACT_HARD_SIGMOID, MODE_DECODE>
-                                   : lstm_cluster_kernel<H, FOV_ACT_HARD_SIGMOID, MODE_LAYER>;
+               : mode == MODE_LAYER_ZX ? lstm_cluster_kernel<H, FOV_ACT_HARD_SIGMOID, MODE_LAYER_ZX>
+                                       : lstm_cluster_kernel<H, FOV_ACT_HARD_SIGMOID, MODE_LAYER>;
     else
         kern = mode == MODE_DECODE ? lstm_cluster_kernel<H, FOV_ACT_SIGMOID, MODE_DECODE>
-                                   : lstm_cluster_kernel<H, FOV_ACT_SIGMOID, MODE_LAYER>;
+               : mode == MODE_LAYER_ZX ? lstm_cluster_kernel<H, FOV_ACT_SIGMOID, MODE_LAYER_ZX>
+                                       : lstm_cluster_kernel<H, FOV_ACT_SIGMOID, MODE_LAYER>;
     const int F = mode == MODE_DECODE ? p.F_dec : (p.zx ? 0 : p.F);
     const ClusterLds L = cluster_lds(H, F, mode == MODE_DECODE);
     const size_t lds = (size_t)L.total_floats * sizeof(float);
