@@ -113,27 +113,26 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd8_kernel(Bwd8Params p) {
             dc[r] = (live[r] && p.dcT) ? p.dcT[(size_t)row * QH + unit] : 0.f;
             dh[r] = (live[r] && p.dhT) ? p.dhT[(size_t)row * QH + unit] : 0.f;
         }
-        // tape pipeline: cur = step t, nxt = step t-1 (its c is c_{t-1} of step t)
-        float cur[5][2], nxt[5][2], dhs_cur[2], dhs_nxt[2];
-        auto load_step = [&](int t, float (&dst)[5][2], float (&dd_)[2]) {
+        // Tape of this lane's two cells, ONE step ahead: tp[0..3] = i,f,g,o and tp[4] = c of the step, tp[5] = c of the
+        // step before it (c0 / zero in front of step 0), tp[6] = dhs of the step.  The loads are UNCONDITIONAL (rows and
+        // steps clamped into the tensor, dead rows masked where dz is formed): a load inside a branch is waited for at the
+        // merge and the step would wait for HBM right there.
+        float cur[7][2], pre[7][2];
+        auto load_step = [&](int t, float (&dst)[7][2]) {
+            const int tc = t > 0 ? t : 0;
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
                 const int row = b0 + my_row0 + r;
-                if (t >= 0 && live[r]) {
-                    const float* rp = p.reserve + (((size_t)row * T + t) * 5) * QH + unit;
+                const size_t rowc = (size_t)(row < p.B ? row : p.B - 1);
+                const float* rp = p.reserve + ((rowc * T + tc) * 5) * QH + unit;
 #pragma unroll
-                    for (int q = 0; q < 5; ++q) dst[q][r] = rp[q * QH];
-                    dd_[r] = p.dhs ? p.dhs[((size_t)row * T + t) * QH + unit] : 0.f;
-                } else {
-#pragma unroll
-                    for (int q = 0; q < 5; ++q) dst[q][r] = 0.f;
-                    dst[4][r] = (t < 0 && live[r] && p.c0) ? p.c0[(size_t)row * QH + unit] : 0.f;   // c_{-1} = c0
-                    dd_[r] = 0.f;
-                }
+                for (int q = 0; q < 5; ++q) dst[q][r] = rp[q * QH];
+                const float* cp = tc > 0 ? rp - QH : (p.c0 ? p.c0 + rowc * QH + unit : rp);   // no c0: any valid address, masked at use
+                dst[5][r] = *cp;
+                dst[6][r] = p.dhs ? p.dhs[(rowc * T + tc) * QH + unit] : 0.f;
             }
         };
-        load_step(T - 1, cur, dhs_cur);
-        load_step(T - 2, nxt, dhs_nxt);
+        load_step(T - 1, cur);
         float dbacc[4] = {0.f, 0.f, 0.f, 0.f};   // sum over t and this lane's 2 sequences of dz, per gate
         __syncthreads();   // the previous tile's last step is done with the dz tile
 
@@ -144,15 +143,15 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd8_kernel(Bwd8Params p) {
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
                 const float ig = cur[0][r], fg = cur[1][r], gg = cur[2][r], og = cur[3][r], cc = cur[4][r];
-                const float cprev = nxt[4][r];
-                const float dht = dh[r] + dhs_cur[r];
+                const float cprev = (t > 0 || p.c0) ? cur[5][r] : 0.f;   // step 0 without a given state: c_{-1} = 0
+                const float dht = dh[r] + cur[6][r];
                 const float tc = tanh_f(cc);
                 const float dcv = dc[r] + dht * og * (1.f - tc * tc);
                 float dzv[4];
-                dzv[0] = dcv * gg * b8_act_grad<ACT>(ig);
-                dzv[1] = dcv * cprev * b8_act_grad<ACT>(fg);
-                dzv[2] = dcv * ig * (1.f - gg * gg);
-                dzv[3] = dht * tc * b8_act_grad<ACT>(og);
+                dzv[0] = live[r] ? dcv * gg * b8_act_grad<ACT>(ig) : 0.f;
+                dzv[1] = live[r] ? dcv * cprev * b8_act_grad<ACT>(fg) : 0.f;
+                dzv[2] = live[r] ? dcv * ig * (1.f - gg * gg) : 0.f;
+                dzv[3] = live[r] ? dht * tc * b8_act_grad<ACT>(og) : 0.f;
                 dc[r] = dcv * fg;
                 if (live[r]) {
                     float* zp = p.dz + ((size_t)(b0 + my_row0 + r) * T + t) * H4 + unit;
@@ -161,20 +160,13 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd8_kernel(Bwd8Params p) {
                 }
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const float v = live[r] ? dzv[g] : 0.f;
-                    dbacc[g] += v;
-                    if constexpr (BF16) sDQ[(my_row0 + r) * B8LDQ + g * 32 + ul] = bf16_bits(v);
-                    else sDZ[(my_row0 + r) * B8LDZ + g * 32 + ul] = v;
+                    dbacc[g] += dzv[g];
+                    if constexpr (BF16) sDQ[(my_row0 + r) * B8LDQ + g * 32 + ul] = bf16_bits(dzv[g]);
+                    else sDZ[(my_row0 + r) * B8LDZ + g * 32 + ul] = dzv[g];
                 }
             }
-            // rotate the tape pipeline and request step t-2
-#pragma unroll
-            for (int q = 0; q < 5; ++q)
-#pragma unroll
-                for (int r = 0; r < 2; ++r) cur[q][r] = nxt[q][r];
-#pragma unroll
-            for (int r = 0; r < 2; ++r) dhs_cur[r] = dhs_nxt[r];
-            load_step(t - 2, nxt, dhs_nxt);
+            // the tape of step t-1 is requested here, a whole step before its use
+            load_step(t - 1, pre);
             __syncthreads();   // barrier A: the dz tile is complete
             // ---- partial[16 x 256] = dz_own . R^T_own ; tile tl -> destination 2*wave + (tl>>1) ----
             f32x4 acc[4];
@@ -258,6 +250,10 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd8_kernel(Bwd8Params p) {
                     dh[q] = a;
                 }
             }
+#pragma unroll
+            for (int q = 0; q < 7; ++q)
+#pragma unroll
+                for (int r = 0; r < 2; ++r) cur[q][r] = pre[q][r];   // requested most of a step ago: long landed
             __syncthreads();   // barrier B: every wave is done reading the dz tile; sFlag is uniform below
             if (sFlag[0]) { aborted = true; break; }
         }

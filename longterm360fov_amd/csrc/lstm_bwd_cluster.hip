@@ -123,23 +123,23 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_cluster_kernel(BwdParams p) {
             dc[r] = (live[r] && p.dcT) ? p.dcT[(size_t)row * H + unit] : 0.f;
             dh[r] = (live[r] && p.dhT) ? p.dhT[(size_t)row * H + unit] : 0.f;
         }
-        // reserve pipeline: cur = step t, nxt = step t-1 (its c is c_{t-1} of step t)
+        // reserve pipeline: cur = step t, nxt = step t-1 (its c is c_{t-1} of step t).  The loads are UNCONDITIONAL - rows
+        // and steps clamped into the tensors, absent tensors replaced by a valid address, everything masked where it is
+        // used: a load inside a branch is waited for at the merge, and the prefetch of step t-2 then stalls step t.
         float cur[5][4], nxt[5][4], dhs_cur[4], dhs_nxt[4];
         auto load_step = [&](int t, float (&dst)[5][4], float (&dd_)[4]) {
+            const int tc = t > 0 ? t : 0;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = b0 + 4 * g4 + r;
-                if (t >= 0 && live[r]) {
-                    const float* rp = p.reserve + (((size_t)row * p.T + t) * 5) * H + unit;
+                const size_t rowc = (size_t)(row < p.B ? row : p.B - 1);
+                const float* rp = p.reserve + ((rowc * p.T + tc) * 5) * H + unit;
 #pragma unroll
-                    for (int q = 0; q < 5; ++q) dst[q][r] = rp[q * H];
-                    dd_[r] = p.dhs ? p.dhs[((size_t)row * p.T + t) * H + unit] : 0.f;
-                } else {
-#pragma unroll
-                    for (int q = 0; q < 5; ++q) dst[q][r] = 0.f;
-                    dst[4][r] = (t < 0 && live[r] && p.c0) ? p.c0[(size_t)row * H + unit] : 0.f;   // c_{-1} = c0
-                    dd_[r] = 0.f;
-                }
+                for (int q = 0; q < 4; ++q) dst[q][r] = rp[q * H];
+                const float* cp = t >= 0 ? rp + 4 * H : (p.c0 ? p.c0 + rowc * H + unit : rp);   // c_{-1} = c0 (none: masked at use)
+                dst[4][r] = *cp;
+                const float* dp = p.dhs ? p.dhs + (rowc * p.T + tc) * H + unit : rp;
+                dd_[r] = *dp;
             }
         };
         load_step(p.T - 1, cur, dhs_cur);
@@ -152,15 +152,15 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_cluster_kernel(BwdParams p) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float ig = cur[0][r], fg = cur[1][r], gg = cur[2][r], og = cur[3][r], cc = cur[4][r];
-                const float cprev = nxt[4][r];
-                const float dht = dh[r] + dhs_cur[r];
+                const float cprev = (t > 0 || p.c0) ? nxt[4][r] : 0.f;   // step 0 without a given state: c_{-1} = 0
+                const float dht = dh[r] + (p.dhs ? dhs_cur[r] : 0.f);
                 const float tc = tanh_f(cc);
                 const float dcv = dc[r] + dht * og * (1.f - tc * tc);
-                dzv[0][r] = dcv * gg * bwd_act_grad<ACT>(ig);
-                dzv[1][r] = dcv * cprev * bwd_act_grad<ACT>(fg);
-                dzv[2][r] = dcv * ig * (1.f - gg * gg);
-                dzv[3][r] = dht * tc * bwd_act_grad<ACT>(og);
-                dc[r] = dcv * fg;
+                dzv[0][r] = live[r] ? dcv * gg * bwd_act_grad<ACT>(ig) : 0.f;
+                dzv[1][r] = live[r] ? dcv * cprev * bwd_act_grad<ACT>(fg) : 0.f;
+                dzv[2][r] = live[r] ? dcv * ig * (1.f - gg * gg) : 0.f;
+                dzv[3][r] = live[r] ? dht * tc * bwd_act_grad<ACT>(og) : 0.f;
+                dc[r] = live[r] ? dcv * fg : 0.f;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) dbacc[g] += dzv[g][r];
                 if (live[r]) {

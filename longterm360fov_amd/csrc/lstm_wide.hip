@@ -30,6 +30,7 @@ constexpr int WNG = 14;
 constexpr unsigned WSPIN = 1u << 20;
 
 typedef unsigned wu32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned wu32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ void wm_a(f32x4& acc, float a, float w_agpr) {
     asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "a"(w_agpr));
@@ -90,15 +91,17 @@ __global__ __launch_bounds__(256, 1) void lstm_wide_kernel(LstmParams p) {
     if (tid == 0) sFlag[0] = poisoned ? 1 : 0;
 
     // ---- resident weights: K rows >= F are zero ----
+    constexpr unsigned OORB = 0x80000000u;   // buffer-load offset no descriptor covers: reads as 0
+    const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.K), 0, F * H4 * 4, 0x00020000);
     float wk[NJX][4][2], wr[16][4][2];
 #pragma unroll
     for (int j = 0; j < 16; ++j)
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const int k = 16 * j + 4 * g4 + s;
-            if (j < NJX) {
-                wk[j][s][0] = (k < F) ? p.K[(size_t)k * H4 + col0] : 0.f;
-                wk[j][s][1] = (k < F) ? p.K[(size_t)k * H4 + col1] : 0.f;
+            if (j < NJX) {   // the descriptor ends with row F - 1: rows k >= F read as 0, no load sits in a branch
+                wk[j][s][0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(krs, (unsigned)((k * H4 + col0) * 4), 0, 0));
+                wk[j][s][1] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(krs, (unsigned)((k * H4 + col1) * 4), 0, 0));
             }
             wr[j][s][0] = p.R[(size_t)k * H4 + col0];
             wr[j][s][1] = p.R[(size_t)k * H4 + col1];
@@ -176,33 +179,70 @@ __global__ __launch_bounds__(256, 1) void lstm_wide_kernel(LstmParams p) {
     for (int tile = group; tile < p.num_tiles && !aborted; tile += p.num_groups) {
         const int b0 = tile * WBT;
         __syncthreads();   // previous tile fully consumed
-        for (int e = tid; e < WBT * WH; e += 256) {
-            const int row = e >> 8, u = e & 255;
-            sH[row * WLD + u] = (b0 + row < p.B && p.h0) ? p.h0[(size_t)(b0 + row) * WH + u] : 0.f;
+        // Every global load of the tile goes through a buffer descriptor that covers exactly its live rows (a NULL tensor:
+        // nothing): rows past the batch, absent tensors and masked columns read as 0 without a branch - a load inside a
+        // branch is waited for at the merge, and the waits of this kernel are all vmcnt(0).
+        const int live_rows = p.B - b0 < WBT ? p.B - b0 : WBT;
+        const __amdgpu_buffer_rsrc_t h0rs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(p.h0 ? p.h0 + (size_t)b0 * WH : nullptr), 0, p.h0 ? live_rows * WH * 4 : 0, 0x00020000);
+        const __amdgpu_buffer_rsrc_t c0rs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(p.c0 ? p.c0 + (size_t)b0 * WH : nullptr), 0, p.c0 ? live_rows * WH * 4 : 0, 0x00020000);
+        const __amdgpu_buffer_rsrc_t xgrs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(p.x + (size_t)b0 * p.T * F), 0, live_rows * p.T * F * 4, 0x00020000);
+        {
+            float hv[WBT * WH / 256];
+#pragma unroll
+            for (int q = 0; q < WBT * WH / 256; ++q) hv[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(h0rs, (unsigned)((tid + 256 * q) * 4), 0, 0));
+#pragma unroll
+            for (int q = 0; q < WBT * WH / 256; ++q) {
+                const int e = tid + 256 * q;
+                sH[(e >> 8) * WLD + (e & 255)] = hv[q];
+            }
         }
         float c[2], hc[2] = {0.f, 0.f};
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
-            const int row = b0 + my_row0 + r;
-            c[r] = (row < p.B && p.c0) ? p.c0[(size_t)row * WH + unit] : 0.f;
-            hc[r] = (row < p.B && p.h0) ? p.h0[(size_t)row * WH + unit] : 0.f;
+            const unsigned off = (unsigned)(((my_row0 + r) * WH + unit) * 4);
+            c[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(c0rs, off, 0, 0));
+            hc[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(h0rs, off, 0, 0));
         }
-        const bool xlive = b0 + xrw < p.B;
-        const float* xt = p.x + ((size_t)(b0 + xrw) * p.T) * F + (XVEC ? 4 : 1) * xc;
+        unsigned xoff[NXR];   // byte offset of this thread's pieces of step 0 (masked pieces: out of range)
+#pragma unroll
+        for (int i = 0; i < NXR; ++i) {
+            if constexpr (XVEC) xoff[i] = (xc + 16 * i < nx4) ? (unsigned)((xrw * p.T * F + 4 * xc + 64 * i) * 4) : OORB;
+            else xoff[i] = (xc + 16 * i < F) ? (unsigned)((xrw * p.T * F + xc + 16 * i) * 4) : OORB;
+        }
+        auto load_x4 = [&](int i, int t) {
+            const wu32x4 q = __builtin_amdgcn_raw_buffer_load_b128(xgrs, xoff[i], (unsigned)(t * F * 4), 0);
+            return (f32x4){__uint_as_float(q[0]), __uint_as_float(q[1]), __uint_as_float(q[2]), __uint_as_float(q[3])};
+        };
+        auto load_x1 = [&](int i, int t) { return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xgrs, xoff[i], (unsigned)(t * F * 4), 0)); };
         float* xl = sX + xrw * WLD + (XVEC ? 4 : 1) * xc;
         const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+        {
+            f32x4 x4[2][XVEC ? NXR : 1];
+            float x1[2][XVEC ? 1 : NXR];
 #pragma unroll
-        for (int tt = 0; tt < 2; ++tt)
-            if (tt < steps) {
+            for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
                 for (int i = 0; i < NXR; ++i) {
-                    if constexpr (XVEC) {
-                        if (xc + 16 * i < nx4) *(f32x4*)(xl + tt * WBT * WLD + 64 * i) = xlive ? *(const f32x4*)(xt + (size_t)tt * F + 64 * i) : z4;
-                    } else {
-                        if (xc + 16 * i < F) xl[tt * WBT * WLD + 16 * i] = xlive ? xt[(size_t)tt * F + 16 * i] : 0.f;
+                    const int tc = tt < steps ? tt : 0;     // steps == 1: the second tile is loaded and dropped
+                    if constexpr (XVEC) x4[tt][i] = load_x4(i, tc);
+                    else x1[tt][i] = load_x1(i, tc);
+                }
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt)
+                if (tt < steps) {
+#pragma unroll
+                    for (int i = 0; i < NXR; ++i) {
+                        if constexpr (XVEC) {
+                            if (xc + 16 * i < nx4) *(f32x4*)(xl + tt * WBT * WLD + 64 * i) = x4[tt][i];
+                        } else {
+                            if (xc + 16 * i < F) xl[tt * WBT * WLD + 16 * i] = x1[tt][i];
+                        }
                     }
                 }
-            }
+        }
         __syncthreads();
         // ---- pre-activations of step 0 ----
         f32x4 acc[2];
@@ -230,11 +270,10 @@ __global__ __launch_bounds__(256, 1) void lstm_wide_kernel(LstmParams p) {
                 }
             }
             if (t + 2 < steps) {
-                const float* xn = xt + (size_t)(t + 2) * F;
 #pragma unroll
                 for (int i = 0; i < NXR; ++i) {
-                    if constexpr (XVEC) xr[i] = (xlive && xc + 16 * i < nx4) ? *(const f32x4*)(xn + 64 * i) : z4;
-                    else xs[i] = (xlive && xc + 16 * i < F) ? xn[16 * i] : 0.f;
+                    if constexpr (XVEC) xr[i] = load_x4(i, t + 2);
+                    else xs[i] = load_x1(i, t + 2);
                 }
             }
             // ---- cell update ----
