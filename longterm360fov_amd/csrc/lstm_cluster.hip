@@ -286,6 +286,13 @@ __global__ __launch_bounds__(256, 1) void lstm_cluster_kernel(LstmParams p) {
     int* sFlag = (int*)(smem + L.off_flag);
     float* sKw = sK + wave * (nq * 4 + KPAD) * 256;  // this wave's K slice in B-operand order
 
+    // The weight loads go out FIRST: the header reads, the arrival ticket and the hello handshake below are a chain of
+    // dependent memory round trips (wave 0), which now run while the 300-odd weight loads are in flight instead of in
+    // front of them.
+    float wR[NQ][4][4];   // [k-block j][k-sub s][gate g], AGPR-resident
+    float bias[4];
+    load_weights<H, !LAYER>(wR, bias, sKw, Kp, Rp, bp, F, Fp, col0, slice, lane);
+
     // A layer's last step publishes nothing (no later step reads h_T from the partners), so a one-step layer
     // launch - the unit the step-wise decoders of a4 are built from - needs no exchange and no handshake.
     const bool xch_used = (G > 1) && (!LAYER || p.T > 1);
@@ -321,9 +328,6 @@ __global__ __launch_bounds__(256, 1) void lstm_cluster_kernel(LstmParams p) {
     // zero the x tiles once: pad columns [F, Fp) are never written afterwards
     for (int i = tid; i < NXBUF * BT * LDX; i += 256) sX[i] = 0.f;
 
-    float wR[NQ][4][4];   // [k-block j][k-sub s][gate g], AGPR-resident
-    float bias[4];
-    load_weights<H, !LAYER>(wR, bias, sKw, Kp, Rp, bp, F, Fp, col0, slice, lane);
     // DECODE: Dense(F_dec, tanh) runs on the matrix pipe, transposed: y^T = Wd^T . h^T.  Wave w
     // reduces over positions [16*NB*w, 16*NB*(w+1)) of the (rotated) h tile, NB = H/64; lane
     // (i = l&15, g4) keeps Wd[pos = 16*(NB*w + b) + 4*g4 + s][o(i)], o(i) = 4*(i&3) + (i>>2), as MFMA
