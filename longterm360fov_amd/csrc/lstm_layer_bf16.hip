@@ -93,19 +93,45 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_bf16_kernel(LstmParams p) {
     for (int tile = group; tile < p.num_tiles && !aborted; tile += p.num_groups) {
         const int b0 = tile * QBT;
         __syncthreads();   // previous tile fully consumed
-        for (int e = tid; e < QBT * QH; e += 256) {
-            const int row = e >> 8, u = e & 255;
-            sH[row * QLD + u] = bf16_bits((b0 + row < p.B && p.h0) ? p.h0[(size_t)(b0 + row) * QH + u] : 0.f);
+        // Every global load of the tile goes through a buffer descriptor that covers exactly its live rows (a NULL tensor:
+        // nothing): rows past the batch, absent tensors and masked columns read as 0 without a branch (a load inside a
+        // branch is waited for at the merge).
+        constexpr unsigned OORB = 0x80000000u;
+        const int live_rows = p.B - b0 < QBT ? p.B - b0 : QBT;
+        const __amdgpu_buffer_rsrc_t h0rs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(p.h0 ? p.h0 + (size_t)b0 * QH : nullptr), 0, p.h0 ? live_rows * QH * 4 : 0, 0x00020000);
+        const __amdgpu_buffer_rsrc_t c0rs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(p.c0 ? p.c0 + (size_t)b0 * QH : nullptr), 0, p.c0 ? live_rows * QH * 4 : 0, 0x00020000);
+        const __amdgpu_buffer_rsrc_t xgrs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(p.x + (size_t)b0 * p.T * F), 0, live_rows * p.T * F * 4, 0x00020000);
+        {
+            float hv[QBT * QH / 256];
+#pragma unroll
+            for (int q = 0; q < QBT * QH / 256; ++q) hv[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(h0rs, (unsigned)((tid + 256 * q) * 4), 0, 0));
+#pragma unroll
+            for (int q = 0; q < QBT * QH / 256; ++q) {
+                const int e = tid + 256 * q;
+                sH[(e >> 8) * QLD + (e & 255)] = bf16_bits(hv[q]);
+            }
         }
         float c[2], hc[2] = {0.f, 0.f};
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
-            const int row = b0 + my_row0 + r;
-            c[r] = (row < p.B && p.c0) ? p.c0[(size_t)row * QH + unit] : 0.f;
-            hc[r] = (row < p.B && p.h0) ? p.h0[(size_t)row * QH + unit] : 0.f;
+            const unsigned off = (unsigned)(((my_row0 + r) * QH + unit) * 4);
+            c[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(c0rs, off, 0, 0));
+            hc[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(h0rs, off, 0, 0));
         }
-        const bool xlive = b0 + xrw < p.B;
-        const float* xt = p.x + ((size_t)(b0 + xrw) * p.T) * F + (XVEC ? 4 : 1) * xc;
+        unsigned xoff[NXE];   // byte offset of this thread's pieces of step 0 (masked pieces: out of range)
+#pragma unroll
+        for (int i = 0; i < NXE; ++i) {
+            if constexpr (XVEC) xoff[i] = (xc + 16 * i < nx4) ? (unsigned)((xrw * p.T * F + 4 * xc + 64 * i) * 4) : OORB;
+            else xoff[i] = (xc + 16 * i < F) ? (unsigned)((xrw * p.T * F + xc + 16 * i) * 4) : OORB;
+        }
+        auto load_x4 = [&](int i, int t) {
+            const qu32x4 q = __builtin_amdgcn_raw_buffer_load_b128(xgrs, xoff[i], (unsigned)(t * F * 4), 0);
+            return (f32x4){__uint_as_float(q[0]), __uint_as_float(q[1]), __uint_as_float(q[2]), __uint_as_float(q[3])};
+        };
+        auto load_x1 = [&](int i, int t) { return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xgrs, xoff[i], (unsigned)(t * F * 4), 0)); };
         unsigned short* xl = sX + xrw * QLD + (XVEC ? 4 : 1) * xc;
         const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
         {
@@ -115,8 +141,9 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_bf16_kernel(LstmParams p) {
             for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
                 for (int i = 0; i < NXE; ++i) {
-                    if constexpr (XVEC) v4[tt][i] = (tt < steps && xlive && xc + 16 * i < nx4) ? *(const f32x4*)(xt + (size_t)tt * F + 64 * i) : z4;
-                    else v1[tt][i] = (tt < steps && xlive && xc + 16 * i < F) ? xt[(size_t)tt * F + 16 * i] : 0.f;
+                    const int tc = tt < steps ? tt : 0;     // steps == 1: the second tile is loaded and never read
+                    if constexpr (XVEC) v4[tt][i] = load_x4(i, tc);
+                    else v1[tt][i] = load_x1(i, tc);
                 }
 #pragma unroll
             for (int tt = 0; tt < 2; ++tt)
@@ -160,11 +187,10 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_bf16_kernel(LstmParams p) {
                 }
             }
             if (t + 2 < steps) {
-                const float* xn = xt + (size_t)(t + 2) * F;
 #pragma unroll
                 for (int i = 0; i < NXE; ++i) {
-                    if constexpr (XVEC) xr[i] = (xlive && xc + 16 * i < nx4) ? *(const f32x4*)(xn + 64 * i) : z4;
-                    else xs[i] = (xlive && xc + 16 * i < F) ? xn[16 * i] : 0.f;
+                    if constexpr (XVEC) xr[i] = load_x4(i, t + 2);
+                    else xs[i] = load_x1(i, t + 2);
                 }
             }
             Q_STAMP(1);

@@ -111,7 +111,9 @@ __global__ __launch_bounds__(256, 1) void mix_decoder_bf16_kernel(MixDecParams p
         __syncthreads();   // every wave has read h1_0 before the first own-slice write of h1_t into the tile
         for (int t = 0; t < p.T_out; ++t) {
             // the "others" term of the mixing layer for this step: requested now, consumed in the head
-            const float othv = (hd_o < O && hd_row < p.B) ? p.oth_proj[(size_t)hd_row * p.oth_sb + (size_t)t * p.oth_st + hd_o] : 0.f;
+            const bool oth_live = hd_o < O && hd_row < p.B;   // dead lanes read element 0, masked (no load inside a branch)
+            const float oth_ld = p.oth_proj[oth_live ? (size_t)hd_row * p.oth_sb + (size_t)t * p.oth_st + hd_o : 0];
+            const float othv = oth_live ? oth_ld : 0.f;
             ++epoch;
             const unsigned par = (epoch & 1u) * Q_TILE_BYTES;
             // ================= layer 1: + x_t . K1, cell update =================

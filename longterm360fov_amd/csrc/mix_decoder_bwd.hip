@@ -240,26 +240,26 @@ __global__ __launch_bounds__(256, 1) void mix_decoder_bwd_kernel(MixDecBwdParams
             const unsigned par2 = (epoch & 1u) * (unsigned)(MB2 * 8), par1 = (epoch & 1u) * (unsigned)(MB1 * 8),
                            parx = (epoch & 1u) * (unsigned)(MBX * 8);
             // tape of layer 2 for this lane's two cells: requested now, consumed after the head
+            // (unconditional loads, rows clamped into the batch and masked where dz is formed: a load inside a branch is
+            // waited for at the merge, i.e. right here)
             float tp[2][6];
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
                 const int row = b0 + my_row0 + r;
+                const size_t rowc = (size_t)(row < p.B ? row : p.B - 1);
+                const float* rp = p.res2 + (((size_t)t * p.B + rowc) * 5) * BH + unit;
 #pragma unroll
-                for (int k = 0; k < 6; ++k) tp[r][k] = 0.f;
-                if (row < p.B) {
-                    const float* rp = p.res2 + (((size_t)t * p.B + row) * 5) * BH + unit;
-#pragma unroll
-                    for (int k = 0; k < 5; ++k) tp[r][k] = rp[k * BH];
-                    tp[r][5] = p.C2[((size_t)t * p.B + row) * BH + unit];
-                }
+                for (int k = 0; k < 5; ++k) tp[r][k] = rp[k * BH];
+                tp[r][5] = p.C2[((size_t)t * p.B + rowc) * BH + unit];
             }
             // ================= head backward (every workgroup, its 16 sequences) =================
             {
                 const int brow = b0 + hrow;
                 const bool live = ho < O && brow < p.B;
                 const size_t hidx = ((size_t)t * p.B + brow) * O + ho;
-                const float mv = live ? p.M[hidx] : 0.f, pv = live ? p.P[hidx] : 0.f;
-                const float dm = live ? p.dloss[hidx] + sDX[hrow * 8 + (ho & 7)] * (1.f - mv * mv) : 0.f;
+                const size_t hidc = live ? hidx : 0;     // dead lanes read element 0, masked below
+                const float mv = p.M[hidc], pv = p.P[hidc], dl = p.dloss[hidc];
+                const float dm = live ? dl + sDX[hrow * 8 + (ho & 7)] * (1.f - mv * mv) : 0.f;
                 float dp = 0.f;
 #pragma unroll
                 for (int k = 0; k < 8; ++k) dp = fmaf(__shfl(dm, (lane & ~15) | k), wpr[k], dp);
@@ -285,11 +285,12 @@ __global__ __launch_bounds__(256, 1) void mix_decoder_bwd_kernel(MixDecBwdParams
                 const float tc = tanh_f(ct);
                 const float dh = dhd + dh2r[r];
                 const float dct = dc2[r] + dh * og * (1.f - tc * tc);
-                dz[r][0] = dct * gg * bact_grad<ACT>(ig);
-                dz[r][1] = dct * cp * bact_grad<ACT>(fg);
-                dz[r][2] = dct * ig * (1.f - gg * gg);
-                dz[r][3] = dh * tc * bact_grad<ACT>(og);
-                dc2[r] = dct * fg;
+                const bool rl = row < p.B;
+                dz[r][0] = rl ? dct * gg * bact_grad<ACT>(ig) : 0.f;
+                dz[r][1] = rl ? dct * cp * bact_grad<ACT>(fg) : 0.f;
+                dz[r][2] = rl ? dct * ig * (1.f - gg * gg) : 0.f;
+                dz[r][3] = rl ? dh * tc * bact_grad<ACT>(og) : 0.f;
+                dc2[r] = rl ? dct * fg : 0.f;
                 if (row < p.B) {
                     float* zp = p.DZ2 + ((size_t)t * p.B + row) * H4 + unit;
 #pragma unroll
@@ -348,14 +349,11 @@ __global__ __launch_bounds__(256, 1) void mix_decoder_bwd_kernel(MixDecBwdParams
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
                 const int row = b0 + my_row0 + r;
+                const size_t rowc = (size_t)(row < p.B ? row : p.B - 1);
+                const float* rp = p.res1 + (((size_t)t * p.B + rowc) * 5) * BH + unit;
 #pragma unroll
-                for (int k = 0; k < 6; ++k) tp[r][k] = 0.f;
-                if (row < p.B) {
-                    const float* rp = p.res1 + (((size_t)t * p.B + row) * 5) * BH + unit;
-#pragma unroll
-                    for (int k = 0; k < 5; ++k) tp[r][k] = rp[k * BH];
-                    tp[r][5] = p.C1[((size_t)t * p.B + row) * BH + unit];
-                }
+                for (int k = 0; k < 5; ++k) tp[r][k] = rp[k * BH];
+                tp[r][5] = p.C1[((size_t)t * p.B + rowc) * BH + unit];
             }
             MIXB_STAMP(4);
             __syncthreads();   // every wave is done reading the dz2 tile
@@ -384,11 +382,12 @@ __global__ __launch_bounds__(256, 1) void mix_decoder_bwd_kernel(MixDecBwdParams
                 const float tc = tanh_f(ct);
                 const float dh = dh1in[r] + dh1r[r];
                 const float dct = dc1[r] + dh * og * (1.f - tc * tc);
-                dz[r][0] = dct * gg * bact_grad<ACT>(ig);
-                dz[r][1] = dct * cp * bact_grad<ACT>(fg);
-                dz[r][2] = dct * ig * (1.f - gg * gg);
-                dz[r][3] = dh * tc * bact_grad<ACT>(og);
-                dc1[r] = dct * fg;
+                const bool rl = row < p.B;
+                dz[r][0] = rl ? dct * gg * bact_grad<ACT>(ig) : 0.f;
+                dz[r][1] = rl ? dct * cp * bact_grad<ACT>(fg) : 0.f;
+                dz[r][2] = rl ? dct * ig * (1.f - gg * gg) : 0.f;
+                dz[r][3] = rl ? dh * tc * bact_grad<ACT>(og) : 0.f;
+                dc1[r] = rl ? dct * fg : 0.f;
                 if (row < p.B) {
                     float* zp = p.DZ1 + ((size_t)t * p.B + row) * H4 + unit;
 #pragma unroll

@@ -128,8 +128,9 @@ __global__ __launch_bounds__(256, 1) void mix_decoder_bwd_bf16_kernel(MixDecBwdP
                 const int brow = b0 + hrow;
                 const bool live = ho < O && brow < p.B;
                 const size_t hidx = ((size_t)t * p.B + brow) * O + ho;
-                const float mv = live ? p.M[hidx] : 0.f, pv = live ? p.P[hidx] : 0.f;
-                const float dm = live ? p.dloss[hidx] + sDX[hrow * 8 + (ho & 7)] * (1.f - mv * mv) : 0.f;
+                const size_t hidc = live ? hidx : 0;     // dead lanes read element 0, masked below (no load inside a branch)
+                const float mv = p.M[hidc], pv = p.P[hidc], dl = p.dloss[hidc];
+                const float dm = live ? dl + sDX[hrow * 8 + (ho & 7)] * (1.f - mv * mv) : 0.f;
                 float dp = 0.f;
 #pragma unroll
                 for (int k = 0; k < 8; ++k) dp = fmaf(__shfl(dm, (lane & ~15) | k), wpr[k], dp);
