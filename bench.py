@@ -333,6 +333,56 @@ def bench_config1(args, rank, world, use_dist):
             "cpu_baseline": cpu, "speedup_vs_cpu_baseline": None if cpu is None else world * B * steps / elapsed / cpu["value"]}), flush=True)
 
 
+def bench_a10(args, rank, world, use_dist):
+    """The raw-TensorFlow model's native shape (mycode/lstm.py:59,128-132,218-240): MultiRNNCell of two LSTMCell(400) over
+    (batch 32, 10 steps, 90 features).  H = 400 is above the persistent kernels' widths (64 / 128 / 256): impl='auto' runs
+    the layer step-wise on the fp32 MFMA GEMM (x K for all steps as one product, then h R + one pointwise launch per step).
+    Beside it: the generic VALU kernel on the same shape (what round 1 ran) and the same stack at H = 256 on the persistent
+    matrix-core kernels - what a width-512 persistent instantiation would have to approach."""
+    from longterm360fov_amd import ops
+    from oracle import fov_oracle as O
+    B, T, F = 32, 10, 90
+    rng = np.random.default_rng(7)
+    x = rng.uniform(-1, 1, (B, T, F)).astype(np.float32)
+    res = {}
+    for tag, H, impl in (("h400_stepwise_mfma_gemm", 400, "auto"), ("h400_generic_valu", 400, "generic"), ("h256_persistent_mfma", 256, "auto")):
+        lrng = np.random.default_rng(H)
+        layers = [O.init_lstm(lrng, F, H), O.init_lstm(lrng, H, H)]
+        dl = [tuple(torch.from_numpy(a).cuda() for a in l) for l in layers]
+        dx = torch.from_numpy(x).cuda()
+        ws = ops.Workspace()
+
+        def step():
+            inp = dx
+            for K, R, b in dl:
+                inp, hT, cT = ops.lstm_seq(inp, K, R, b, act="sigmoid", impl=impl, workspace=ws)
+            return inp
+        for _ in range(5):
+            step()
+        ms = event_time_ms(step, max(args.steps, 100))
+        ws.check()
+        got = step().cpu().numpy()
+        ref = x.astype(np.float64)
+        for K, R, b in layers:
+            ref, _, _ = O.lstm_layer(ref, K.astype(np.float64), R.astype(np.float64), b.astype(np.float64), act="sigmoid")
+        flop = 2.0 * B * T * ((F + H) * 4 * H + (H + H) * 4 * H)
+        res[tag] = {"ms": ms, "sequences_per_s": B / (ms * 1e-3), "tflops": flop / (ms * 1e-3) / 1e12,
+                    "max_abs_err_vs_oracle": float(np.abs(got - ref).max())}
+    if rank == 0:
+        r = res["h400_stepwise_mfma_gemm"]
+        print(json.dumps({
+            "metric": "sequences/sec, stacked LSTMCell(400) x2 forward (batch=32, T=10, F=90)", "value": world * r["sequences_per_s"],
+            "unit": "sequences/s", "n_gpus": world, "steps": max(args.steps, 100), "warmup": 5, "ms_per_step": r["ms"],
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "lstm.py native shape: 2 x LSTMCell(400), batch 32, 10 steps, 90 features; step-wise on the fp32 MFMA "
+                                   "GEMM (H = 400 is above the persistent kernels' widths)", "global_batch": B * world,
+                       "parallelism": "replicas x%d" % world},
+            "roofline": {"bound": "mfma", "achieved": r["tflops"], "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": r["tflops"] / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                         "note": "32 sequences, ~3 launches per layer-step: launch-latency-bound by construction"},
+            "variants": res, "cpu_baseline": None}), flush=True)
+
+
 def bench_convlstm(args, rank, world, use_dist):
     """BASELINE.json configs[3]: ConvLSTM seq2seq on 36x18x30 heat maps, filters 32/16/8, k = 5, T 10 -> 10, B = 256:
     cell-only (3-layer encoder) and the whole model incl. the Conv2D 56->512->1024->30 head; training step at
@@ -453,7 +503,7 @@ def main():
                          "with several ranks on ONE GPU)")
     ap.add_argument("--dry-run", action="store_true", help="launch plumbing only: no GPU work (CPU tests)")
     ap.add_argument("--mode", default="infer",
-                    choices=["infer", "train", "train_mixing", "infer_mixing", "config1", "convlstm"],
+                    choices=["infer", "train", "train_mixing", "infer_mixing", "config1", "convlstm", "a10"],
                     help="infer (default, the BASELINE metric): encoder + autoregressive decoder; train: one "
                          "teacher-forced training step (fwd + BPTT + Adam, data-parallel all-reduce when N > 1); "
                          "train_mixing / infer_mixing: configs[2] (512 sequences per GPU); config1: configs[0] latency; "
@@ -506,8 +556,8 @@ def main():
         return bench_train_mixing(args, rank, world, use_dist)
     if args.mode == "infer_mixing":
         return bench_infer_mixing(args, rank, world, use_dist)
-    if args.mode in ("config1", "convlstm"):
-        (bench_config1 if args.mode == "config1" else bench_convlstm)(args, rank, world, use_dist)
+    if args.mode in ("config1", "convlstm", "a10"):
+        {"config1": bench_config1, "convlstm": bench_convlstm, "a10": bench_a10}[args.mode](args, rank, world, use_dist)
         if use_dist:
             dist.barrier()
             dist.destroy_process_group()

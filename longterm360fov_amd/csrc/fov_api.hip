@@ -337,8 +337,8 @@ int fov_version(void) { return 100; }
 int fov_cluster_supported(int F, int H) { return cluster_shape_ok(F, H) ? 1 : 0; }
 
 size_t fov_lstm_seq_workspace_bytes(int B, int T, int F, int H, int impl) {
-    (void)T;
     if (B <= 0) return kStatusBytes;
+    if (impl == FOV_IMPL_AUTO && stepwise_preferred(B, F, H)) return kStatusBytes + sizeof(float) * stepwise_workspace_floats(B, T, H);
     if (impl != FOV_IMPL_GENERIC && wide_shape_ok(F, H)) return cluster_workspace_bytes(B, H);
     if (impl == FOV_IMPL_AUTO && wide_narrow_preferred(B, F, H)) return cluster_workspace_bytes(B, H);
     return want_cluster(impl, F, H, 0, false) && cluster_shape_ok(F, H) ? cluster_workspace_bytes(B, H) : kStatusBytes;
@@ -366,6 +366,9 @@ static int lstm_seq_fwd_impl(const float* x, const float* K, const float* R, con
     // narrow inputs, at most 32 tiles: groups of eight workgroups fill the chip where lstm_cluster's groups of four leave half idle
     if (impl == FOV_IMPL_AUTO && T > 0 && wide_narrow_preferred(B, F, H)) return launch_wide(p, s);
     if (want_cluster(impl, F, H, 0, false)) return launch_cluster(p, false, s);
+    // widths above the persistent kernels': step-wise on the matrix-core GEMM instead of the VALU kernel
+    if (impl == FOV_IMPL_AUTO && stepwise_preferred(B, F, H))
+        return launch_stepwise(p, (float*)((char*)workspace + kStatusBytes), (workspace_bytes - kStatusBytes) / sizeof(float), s);
     return launch_generic(p, false, s);
 }
 

@@ -75,6 +75,10 @@ void set_error(const char* fmt, ...);
 bool wide_shape_ok(int F, int H);
 bool wide_narrow_preferred(int B, int F, int H);
 int launch_wide(const LstmParams& p, hipStream_t stream);
+// step-wise layer forward on the matrix-core GEMM (train_kernels.hip): hidden widths above the persistent kernels' 256
+bool stepwise_preferred(int B, int F, int H);
+size_t stepwise_workspace_floats(int B, int T, int H);
+int launch_stepwise(const LstmParams& p, float* ws, size_t ws_floats, hipStream_t stream);
 
 constexpr size_t kStatusBytes = 256;  // head of every workspace: status words (layout: xch_common.h)
 

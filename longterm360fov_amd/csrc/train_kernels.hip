@@ -1049,6 +1049,101 @@ size_t lstm_bwd_workspace_floats(int B, int T, int F, int H) {
     return head + (size_t)2 * B * H + (m > st ? m : st) + 64;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Step-wise layer forward on the matrix-core GEMM, for hidden widths the persistent kernels do not take (H > 256: the
+// raw-TensorFlow model's LSTMCell(400), mycode/lstm.py:59,128-132).  zx = x K for ALL steps is one product; a step is
+// zr = h_{t-1} R (one product over all sequences, every CU takes a tile) + one pointwise launch (gates, c, h, tape).
+// The generic kernel walks the steps inside one launch but streams all of K and R through every workgroup in every
+// step on the VALU: 6.3 ms for two layers at (32, 10, 90, H = 400); this path is launch-bound at ~3 launches a step.
+// ---------------------------------------------------------------------------------------------------------------
+template <int ACT>
+__global__ __launch_bounds__(256) void lstm_pointwise_fwd_kernel(const float* __restrict__ zx, long ldzx, const float* __restrict__ zr,
+                                                                 const float* __restrict__ b, const float* __restrict__ c_in,
+                                                                 float* __restrict__ c_out, float* __restrict__ h_out, long ldh,
+                                                                 float* __restrict__ reserve, long ldres, float* __restrict__ hT,
+                                                                 float* __restrict__ cT, int B, int H) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)B * H) return;
+    const int row = (int)(i / H), u = (int)(i - (long)row * H);
+    const float* zp = zx + (size_t)row * ldzx + u;
+    const float* rp = zr ? zr + (size_t)row * 4 * H + u : nullptr;
+    float z[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) z[g] = zp[g * H] + b[g * H + u] + (rp ? rp[g * H] : 0.f);
+    const float ig = rec_act<ACT>(z[0]), fg = rec_act<ACT>(z[1]), gg = tanh_f(z[2]), og = rec_act<ACT>(z[3]);
+    const float c = fmaf(fg, c_in ? c_in[i] : 0.f, ig * gg);
+    const float h = og * tanh_f(c);
+    c_out[i] = c;
+    h_out[(size_t)row * ldh + u] = h;
+    if (reserve) {
+        float* q = reserve + (size_t)row * ldres + u;
+        q[0] = ig; q[H] = fg; q[2 * H] = gg; q[3 * H] = og; q[4 * H] = c;
+    }
+    if (hT) hT[i] = h;
+    if (cT) cT[i] = c;
+}
+
+bool stepwise_preferred(int B, int F, int H) { return B > 0 && F > 0 && H > 256; }
+
+size_t stepwise_workspace_floats(int B, int T, int H) {
+    return (size_t)B * T * 4 * H + (size_t)B * 4 * H + (size_t)3 * B * H + ((size_t)1 << 20) + 64;
+}
+
+int launch_stepwise(const LstmParams& p, float* ws, size_t ws_floats, hipStream_t stream) {
+    const int B = p.B, T = p.T, F = p.F, H = p.H;
+    if (B == 0) return FOV_OK;
+    if (ws_floats < stepwise_workspace_floats(B, T, H)) { set_error("step-wise layer: workspace too small"); return FOV_ERR_WORKSPACE; }
+    const size_t bh = (size_t)B * H;
+    if (T == 0) {
+        const size_t nb = sizeof(float) * bh;
+        if (p.hT) (void)(p.h0 ? hipMemcpyAsync(p.hT, p.h0, nb, hipMemcpyDeviceToDevice, stream) : hipMemsetAsync(p.hT, 0, nb, stream));
+        if (p.cT) (void)(p.c0 ? hipMemcpyAsync(p.cT, p.c0, nb, hipMemcpyDeviceToDevice, stream) : hipMemsetAsync(p.cT, 0, nb, stream));
+        return FOV_OK;
+    }
+    float* zx = ws;
+    float* zr = zx + (size_t)B * T * 4 * H;
+    float* cbuf = zr + (size_t)B * 4 * H;
+    float* hbuf[2] = {cbuf + bh, cbuf + 2 * bh};
+    float* scratch = cbuf + 3 * bh;
+    const size_t scratch_floats = ws_floats - (size_t)(scratch - ws);
+    // zx (B*T, 4H) = x (B*T, F) . K (F, 4H)
+    int rc = matmul_f32(p.x, p.K, zx, B * T, F, 4 * H, scratch, scratch_floats, stream);
+    if (rc) return rc;
+    const dim3 pgrid((unsigned)((bh + 255) / 256));
+    const float* hprev = p.h0;
+    long ldhp = H;
+    const float* cprev = p.c0;
+    for (int t = 0; t < T; ++t) {
+        const float* zrp = nullptr;
+        if (hprev) {   // zr (B, 4H) = h_{t-1} (B, H) . R (H, 4H)
+            GemmArgs g = {};
+            g.a = hprev; g.b = p.R; g.c = zr; g.M = B; g.N = 4 * H; g.KO = 1; g.KI = H;
+            g.a_sm = ldhp; g.a_ski = 1; g.b_sn = 1; g.b_ski = 4 * H; g.ldc = 4 * H;
+            rc = gemm_f32(g, 0, scratch, scratch_floats, stream);
+            if (rc) return rc;
+            zrp = zr;
+        }
+        float* hout = p.hs ? p.hs + (size_t)t * H : hbuf[t & 1];
+        const long ldh = p.hs ? (long)T * H : H;
+        const bool last = (t == T - 1);
+        float* res = p.reserve ? p.reserve + (size_t)t * 5 * H : nullptr;
+        if (p.act == FOV_ACT_HARD_SIGMOID)
+            hipLaunchKernelGGL(lstm_pointwise_fwd_kernel<FOV_ACT_HARD_SIGMOID>, pgrid, dim3(256), 0, stream, zx + (size_t)t * 4 * H,
+                               (long)T * 4 * H, zrp, p.b, cprev, cbuf, hout, ldh, res, (long)T * 5 * H, last ? p.hT : nullptr,
+                               last ? p.cT : nullptr, B, H);
+        else
+            hipLaunchKernelGGL(lstm_pointwise_fwd_kernel<FOV_ACT_SIGMOID>, pgrid, dim3(256), 0, stream, zx + (size_t)t * 4 * H,
+                               (long)T * 4 * H, zrp, p.b, cprev, cbuf, hout, ldh, res, (long)T * 5 * H, last ? p.hT : nullptr,
+                               last ? p.cT : nullptr, B, H);
+        rc = check_launch("lstm_pointwise_fwd");
+        if (rc) return rc;
+        hprev = hout;
+        ldhp = ldh;
+        cprev = cbuf;      // in place: element i is read and written by the same thread
+    }
+    return FOV_OK;
+}
+
 // [dK ; dR ; db] = [A1 | A2 | 1]^T B as ONE product and one reduce: c is a dense (M1 + M2 + bias_row, N) matrix - the
 // layout of a layer's kernel, recurrent kernel and bias in a trainer's flat gradient buffer.  Rows of the product are
 // (ro, ri) pairs; a shifted operand presents its element (ro, ri - 1) at (ro, ri) and zero at ri == 0 (h_{t-1} read

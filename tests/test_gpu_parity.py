@@ -527,3 +527,36 @@ def test_others_mixing_reference_width_takes_the_fused_path():
     g = OthersMixingSeq2Seq(latent_dim=32, num_user=U, impl="generic")
     g.set_weights([w[k] for k in _MIX_ORDER])
     np.testing.assert_allclose(g.predict([enc, oth, dec0]), got, atol=2e-5)
+
+
+@pytest.mark.parametrize("B,T,F,H,act,state", [(32, 10, 90, 400, "sigmoid", False), (19, 3, 90, 400, "hard_sigmoid", True),
+                                               (40, 4, 33, 300, "sigmoid", True), (5, 1, 7, 257, "sigmoid", False)])
+def test_wide_hidden_layer_runs_step_wise_on_the_matrix_core_gemm(B, T, F, H, act, state):
+    """H > 256 (lstm.py's LSTMCell(400)): impl='auto' runs the layer step-wise on the fp32 MFMA GEMM (x K for all steps as one
+    product, h_{t-1} R + one pointwise launch per step) instead of the VALU kernel - against the fp64 oracle and against
+    impl='generic'; hidden sequence, final states, the training tape, and the states-only form."""
+    from longterm360fov_amd import ops
+    from oracle import fov_oracle as O
+    rng = np.random.default_rng(H + B)
+    K, R, b = O.init_lstm(rng, F, H)
+    b = (b + 0.1 * rng.standard_normal(b.shape)).astype(np.float32)
+    x = rng.uniform(-1, 1, (B, T, F)).astype(np.float32)
+    h0 = (0.3 * rng.standard_normal((B, H))).astype(np.float32) if state else None
+    c0 = (0.3 * rng.standard_normal((B, H))).astype(np.float32) if state else None
+    d64 = lambda a: None if a is None else a.astype(np.float64)
+    hs_ref, hT_ref, cT_ref, res_ref = O.lstm_layer_train(d64(x), d64(K), d64(R), d64(b), d64(h0), d64(c0), act=act)
+    dv = lambda a: None if a is None else torch.from_numpy(a).cuda()
+    ws = ops.Workspace()
+    hs, hT, cT = ops.lstm_seq(dv(x), dv(K), dv(R), dv(b), dv(h0), dv(c0), act=act, impl="auto", workspace=ws)
+    ws.check()
+    for got, ref, tag in ((hs, hs_ref, "hs"), (hT, hT_ref, "hT"), (cT, cT_ref, "cT")):
+        err = np.abs(got.cpu().numpy() - ref).max()
+        print("step-wise H=%d %s err %.3e" % (H, tag, err))
+        assert err <= 2e-5, (tag, err)
+    g_hs, g_hT, g_cT = ops.lstm_seq(dv(x), dv(K), dv(R), dv(b), dv(h0), dv(c0), act=act, impl="generic", workspace=ops.Workspace())
+    assert (g_hs - hs).abs().max().item() <= 2e-5 and (g_cT - cT).abs().max().item() <= 2e-5
+    hs2, hT2, cT2, res = ops.lstm_seq_train(dv(x), dv(K), dv(R), dv(b), dv(h0), dv(c0), act=act, workspace=ws)
+    assert torch.equal(hs2, hs) and torch.equal(cT2, cT)
+    assert np.abs(res.cpu().numpy() - res_ref).max() <= 2e-5
+    _, hT3, cT3 = ops.lstm_seq(dv(x), dv(K), dv(R), dv(b), dv(h0), dv(c0), act=act, impl="auto", return_sequences=False, workspace=ws)
+    assert torch.equal(hT3, hT) and torch.equal(cT3, cT)
