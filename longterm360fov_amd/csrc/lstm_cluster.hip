@@ -521,12 +521,18 @@ __global__ __launch_bounds__(256, 1) void lstm_cluster_kernel(LstmParams p) {
             FOV_STAMP(1);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
+#ifdef FOV_DBG_NOCELL   // timing experiment only (wrong results): no transcendentals in the cell update
+                const float ig = acc[0][r], fg = acc[1][r], gg = acc[2][r], og = acc[3][r];
+                c[r] = fmaf(fg, c[r], ig * gg);
+                hcur[r] = og * c[r];
+#else
                 const float ig = rec_act<ACT>(acc[0][r]);
                 const float fg = rec_act<ACT>(acc[1][r]);
                 const float gg = tanh_f(acc[2][r]);
                 const float og = rec_act<ACT>(acc[3][r]);
                 c[r] = fmaf(fg, c[r], ig * gg);
                 hcur[r] = og * tanh_f(c[r]);
+#endif
                 if (LAYER && p.reserve) {   // training forward: gates and cell state for BPTT
                     const int row = b0 + 4 * g4 + r;
                     if (row < p.B) {
@@ -598,7 +604,11 @@ __global__ __launch_bounds__(256, 1) void lstm_cluster_kernel(LstmParams p) {
             if (do_xch) {
                 // complete the gather: sweep again until every tag equals the epoch
                 unsigned spins = 0;
+#ifdef FOV_DBG_NOGATHER   // timing experiment only (wrong results): take whatever the first sweep returned
+                while (false) {
+#else
                 while (true) {
+#endif
                     bool ok = true;
 #pragma unroll
                     for (int j = 0; j < NG; ++j) ok = ok && (v[j].y == epoch);
@@ -626,7 +636,11 @@ __global__ __launch_bounds__(256, 1) void lstm_cluster_kernel(LstmParams p) {
             __syncthreads();  // barrier 2: the whole h_t tile is in LDS
             FOV_STAMP(7);
             if (G > 1 && sFlag[0]) { aborted = true; break; }
+#ifdef FOV_DBG_NODENSE   // timing experiment only (wrong results): no Dense section, y = 0
+            if (false) {
+#else
             if (!LAYER) {
+#endif
                 // y_t = tanh(h_t . Wd + bias) on the matrix pipe (see the wd[] comment above)
                 const int O = p.F_dec;
                 f32x4 hb[NB];
