@@ -658,11 +658,11 @@ def main():
                          "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
                          "traffic_source": traffic_src,
                          "flop_per_launch": flop_step, "launch_ms": step_ms_events,
-                         "note": "launch = one step = encoder kernel + decoder kernel of lstm_cluster_kernel"},
+                         "note": "launch = one step = ONE lstm_cluster_fused_kernel launch (encoder phase + decoder phase)"},
             "kernels": {"encoder_ms": enc_ms, "decoder_ms": dec_ms,
                         "encoder_tflops": f_enc * B / (enc_ms * 1e-3) / 1e12,
                         "decoder_tflops": f_dec * B / (dec_ms * 1e-3) / 1e12,
-                        "note": "each launch event-timed on its own over %d back-to-back calls" % iters},
+                        "note": "the two phases timed on their own through the layer and decoder-only entry points (two-launch form), %d back-to-back calls each; the fused call is one launch" % iters},
             "exchange": {"mode": xmode, "meaning": "1 = every group of the last launch verified a shared XCD and exchanged h "
                                                    "through that XCD's L2; 2 = at least one group on the write-through path"},
             "parity": {"max_abs_err_vs_oracle": max_abs, "mse_vs_oracle": mse, "sequences_checked": nchk,

@@ -244,17 +244,43 @@ __device__ __forceinline__ void recurrent(f32x4 (&acc)[4], const float* hrow, co
     }
 }
 
-template <int H, int ACT, int MODE>
-__global__ __launch_bounds__(256, 1) void lstm_cluster_kernel(LstmParams p) {
+// What the encoder phase of the fused (one-launch) encode + decode kernel hands to its decoder phase: the epoch / ticket
+// of the launch, the outcome of the hello handshake, and the final (h, c) of this lane's four cells.  The complete h_T
+// tile stays in LDS (the encoder phase exchanges its last h as well).
+struct ClusterCarry {
+    unsigned epoch;
+    XchTicket ticket;
+    bool same_xcd, aborted, xch_used;
+    float c[4], h[4];
+};
+
+// FUSED: 0 = the whole launch is this phase; 1 = encoder phase of the fused kernel (its last step is exchanged too, the
+// state leaves through `cy` instead of memory, nothing is settled); 2 = decoder phase (no header read, no handshake, no
+// state loads: everything comes from `cy` and the h tile the encoder phase left in LDS).  One tile per group only.
+template <int H, int ACT, int MODE, int FUSED>
+__device__ __forceinline__ void cluster_body(const LstmParams& p, ClusterCarry& cy) {
     constexpr int G = H / 64;
     constexpr int NQ = H / 16;
     constexpr int NG = (G - 1) * 4;  // granules gathered per thread per step
     constexpr bool LAYER = (MODE != MODE_DECODE);
     constexpr bool ZX = (MODE == MODE_LAYER_ZX);      // input projection precomputed by the caller
+    constexpr bool F1 = (FUSED == 1), F2 = (FUSED == 2);
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 15, g4 = lane >> 4;
+    // decoder phase of the fused kernel: the h_T tile sits where the ENCODER phase's LDS layout put it; take it into
+    // registers before this phase's layout (its K slice is smaller, everything behind it moves) overwrites anything
+    float hcarry[BT * H / 256];
+    if constexpr (F2) {
+        const ClusterLds L1 = cluster_lds(H, p.F, false);
+#pragma unroll
+        for (int q = 0; q < BT * H / 256; ++q) {
+            const int i = tid + 256 * q;
+            hcarry[q] = smem[L1.off_h + (i / H) * L1.ldh + (i - (i / H) * H)];
+        }
+        __syncthreads();
+    }
     // Blocks b and b+8 are observed to share an XCD (round-robin dispatch), so when the group
     // count allows it the G members of a group are 8 blocks apart.  This is a SPEED choice only:
     // whether the members really share an XCD is verified at run time below.
@@ -295,14 +321,14 @@ __global__ __launch_bounds__(256, 1) void lstm_cluster_kernel(LstmParams p) {
 
     // A layer's last step publishes nothing (no later step reads h_T from the partners), so a one-step layer
     // launch - the unit the step-wise decoders of a4 are built from - needs no exchange and no handshake.
-    const bool xch_used = (G > 1) && (!LAYER || p.T > 1);
+    const bool xch_used = (G > 1) && (!LAYER || p.T > 1 || F1);
     // Epoch tags continue from the workspace header (xch_common.h): no memset between launches.  A workspace whose
     // sticky timeout word is set is poisoned: the body is skipped (fail-stop) until fov_check_status clears it.
     unsigned* sXch = (unsigned*)(sFlag + 4);     // base / launch index of this launch (thread 0 -> all, xch_common.h)
-    const unsigned arrival = xch_used ? xch_arrive(p.status, sXch) : 0u;
-    const bool poisoned = xch_used && xch_poisoned(p.status);   // one wave-wide load per wave; wave 0's value decides (sFlag[0])
-    if (tid == 0) { sFlag[0] = poisoned ? 1 : 0; sFlag[1] = 0; }
-    if (xch_used && !poisoned && tid < 64) {   // wave 0 only: thread 0 has just written sXch (same wave: program order)
+    const unsigned arrival = (xch_used && !F2) ? xch_arrive(p.status, sXch) : 0u;
+    const bool poisoned = xch_used && !F2 && xch_poisoned(p.status);   // one wave-wide load per wave; wave 0's value decides (sFlag[0])
+    if (tid == 0) { sFlag[0] = (poisoned || (F2 && cy.aborted)) ? 1 : 0; sFlag[1] = 0; }
+    if (xch_used && !F2 && !poisoned && tid < 64) {   // wave 0 only: thread 0 has just written sXch (same wave: program order)
         const unsigned epoch_base = sXch[0];
         // hello handshake (safe sc1 protocol): do all members of this group sit on one XCD?
         unsigned long long* hello = p.xch + (size_t)p.num_groups * 2 * BT * H + (size_t)group * G;
@@ -367,11 +393,12 @@ __global__ __launch_bounds__(256, 1) void lstm_cluster_kernel(LstmParams p) {
 
     __syncthreads();
     XchTicket ticket = {0u, 0u, 0u};
-    if (xch_used) ticket = xch_ticket(sXch, arrival);
-    unsigned epoch = ticket.base;
-    const bool same_xcd = xch_used && (sFlag[1] == 0) && (p.force_safe_exchange == 0);
-    bool aborted = xch_used && sFlag[0] != 0;   // poisoned workspace, or a partner never showed up: drain
-    if (xch_used && tid == 0 && !same_xcd && !aborted)   // number of workgroups on the safe (cross-XCD) exchange
+    if (xch_used && !F2) ticket = xch_ticket(sXch, arrival);
+    if constexpr (F2) ticket = cy.ticket;
+    unsigned epoch = F2 ? cy.epoch : ticket.base;
+    const bool same_xcd = F2 ? cy.same_xcd : (xch_used && (sFlag[1] == 0) && (p.force_safe_exchange == 0));
+    bool aborted = F2 ? cy.aborted : (xch_used && sFlag[0] != 0);   // poisoned workspace, or a partner never showed up: drain
+    if (xch_used && !F2 && tid == 0 && !same_xcd && !aborted)   // number of workgroups on the safe (cross-XCD) exchange
         xch_count_safe(p.status, ticket);
 #ifdef FOV_STAMPS
     const bool stamp_on = (blockIdx.x == 5 && tid == 0);
@@ -410,8 +437,13 @@ __global__ __launch_bounds__(256, 1) void lstm_cluster_kernel(LstmParams p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const unsigned off = (unsigned)(((4 * g4 + r) * H + col0 + n) * 4);
-            c[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(c0rs, off, 0, 0));
-            hcur[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(h0rs, off, 0, 0));
+            if constexpr (F2) {   // handed over in registers by the encoder phase
+                c[r] = cy.c[r];
+                hcur[r] = cy.h[r];
+            } else {
+                c[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(c0rs, off, 0, 0));
+                hcur[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(h0rs, off, 0, 0));
+            }
         }
         {
             float hv[BT * H / 256];
@@ -420,7 +452,8 @@ __global__ __launch_bounds__(256, 1) void lstm_cluster_kernel(LstmParams p) {
                 const int i = tid + 256 * q;
                 const int row = i / H, pos = i - row * H;
                 const int unit = ((slice + (pos >> 6)) & (G - 1)) * 64 + (pos & 63);
-                hv[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(h0rs, (unsigned)((row * H + unit) * 4), 0, 0));
+                if constexpr (F2) hv[q] = hcarry[q];   // the tile the encoder phase left in LDS (same rotated column order)
+                else hv[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(h0rs, (unsigned)((row * H + unit) * 4), 0, 0));
             }
 #pragma unroll
             for (int q = 0; q < BT * H / 256; ++q) {
@@ -543,7 +576,7 @@ __global__ __launch_bounds__(256, 1) void lstm_cluster_kernel(LstmParams p) {
             }
             unsigned xsoff = 0;
             // h_t of a layer's last step is needed by nobody inside the kernel: no publish, no gather
-            const bool do_xch = (G > 1) && (!LAYER || t + 1 < steps);
+            const bool do_xch = (G > 1) && (!LAYER || t + 1 < steps || F1);
             if (do_xch) {
                 // publish this workgroup's slice of h_t: one 8-byte {value, epoch} granule each
                 ++epoch;
@@ -682,6 +715,10 @@ __global__ __launch_bounds__(256, 1) void lstm_cluster_kernel(LstmParams p) {
                 FOV_STAMP(8);
             }
         }
+        if constexpr (F1) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { cy.c[r] = c[r]; cy.h[r] = hcur[r]; }
+        }
         if (!aborted) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -692,8 +729,29 @@ __global__ __launch_bounds__(256, 1) void lstm_cluster_kernel(LstmParams p) {
                 }
             }
         }
+        if constexpr (FUSED != 0) break;   // one tile per group (host-checked)
     }
-    if (xch_used) xch_settle(p.status, ticket, (unsigned)p.epoch_span);
+    if constexpr (F1) {
+        cy.epoch = epoch; cy.ticket = ticket; cy.same_xcd = same_xcd; cy.aborted = aborted; cy.xch_used = xch_used;
+        __syncthreads();   // every wave is done with this phase's LDS regions before the decoder phase lays out its own
+    } else {
+        if (xch_used) xch_settle(p.status, ticket, (unsigned)p.epoch_span);
+    }
+}
+
+template <int H, int ACT, int MODE>
+__global__ __launch_bounds__(256, 1) void lstm_cluster_kernel(LstmParams p) {
+    ClusterCarry cy;
+    cluster_body<H, ACT, MODE, 0>(p, cy);
+}
+
+// Encoder + autoregressive decoder of the fused call in ONE launch (one 16-sequence tile per group): no second dispatch,
+// no second header read / handshake, the state stays in registers and the h_T tile in LDS; only the weights are swapped.
+template <int H, int ACT>
+__global__ __launch_bounds__(256, 1) void lstm_cluster_fused_kernel(LstmParams p) {
+    ClusterCarry cy;
+    cluster_body<H, ACT, MODE_LAYER, 1>(p, cy);
+    cluster_body<H, ACT, MODE_DECODE, 2>(p, cy);
 }
 
 // --------------------------------------------------------------------------------------
@@ -780,6 +838,29 @@ static int launch_cluster_h(const LstmParams& p, int mode, hipStream_t stream) {
     return FOV_OK;
 }
 
+template <int H>
+static int launch_cluster_fused_h(const LstmParams& p, hipStream_t stream) {
+    void (*kern)(LstmParams) = p.act == FOV_ACT_HARD_SIGMOID ? lstm_cluster_fused_kernel<H, FOV_ACT_HARD_SIGMOID>
+                                                             : lstm_cluster_fused_kernel<H, FOV_ACT_SIGMOID>;
+    const ClusterLds L1 = cluster_lds(H, p.F, false), L2 = cluster_lds(H, p.F_dec, true);
+    const size_t lds = (size_t)(L1.total_floats > L2.total_floats ? L1.total_floats : L2.total_floats) * sizeof(float);
+    if (lds > 160 * 1024) { set_error("fused cluster kernel: needs %zu B of LDS (> 160 KiB)", lds); return FOV_ERR_UNSUPPORTED; }
+    int rc = ensure_dynamic_lds((const void*)kern, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL(kern, dim3(p.num_groups * (H / 64)), dim3(256), lds, stream, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_error("fused cluster launch: %s", hipGetErrorString(e)); return FOV_ERR_LAUNCH; }
+    return FOV_OK;
+}
+
+static int launch_cluster_fused(const LstmParams& p, hipStream_t stream) {
+    switch (p.H) {
+        case 64: return launch_cluster_fused_h<64>(p, stream);
+        case 128: return launch_cluster_fused_h<128>(p, stream);
+        default: return launch_cluster_fused_h<256>(p, stream);
+    }
+}
+
 static int launch_cluster_mode(const LstmParams& p, int mode, hipStream_t stream) {
     switch (p.H) {
         case 64: return launch_cluster_h<64>(p, mode, stream);
@@ -812,6 +893,13 @@ int launch_cluster(const LstmParams& p_in, bool decode, hipStream_t stream) {
         return launch_cluster_mode(p, MODE_LAYER, stream);
     }
 
+    if (visits == 1 && p.T > 0 && p.T_out > 0 && !p.hs && !p.reserve && !getenv("FOV_TWO_LAUNCHES")) {
+        // one tile per group: encoder and decoder as ONE launch (state in registers, h_T tile in LDS)
+        LstmParams f = p;
+        f.hT = f.cT = nullptr;
+        f.epoch_span = p.T + p.T_out + 2;
+        return launch_cluster_fused(f, stream);
+    }
     LstmParams enc = p;
     float* state = (float*)((char*)p.status + kStatusBytes + kXchBytes);
     enc.hT = state;
