@@ -34,11 +34,12 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 matrix peak (s
 def peak_for(dtype):
     return PEAK_BF16_MFMA_TFLOPS if dtype == "bf16" else PEAK_FP32_MFMA_TFLOPS
 # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/pmc_run.sh) of `bench.py --steps 20 --warmup 3`, mean per
-# dispatch: encoder 13170 + 6160 KiB, decoder 7461 + 4832 KiB (raw counter values; the kernel's global traffic is 4- and
-# 8-byte accesses, for which MI355X_MICROARCH.md gives no correction factor)
+# dispatch of lstm_cluster_fused_kernel (encoder + decoder in one launch): 17540 + 5606 KiB (raw counter values; the
+# kernel's global traffic is 4- and 8-byte accesses, for which MI355X_MICROARCH.md gives no correction factor).  The
+# two-launch form moved 13170 + 6160 and 7458 + 4832 KiB.
 PMC_TRAFFIC_CONFIG = (1024, 30, 30, 256, "sigmoid", "auto")
-PMC_TRAFFIC_BYTES = (13170 + 6160 + 7461 + 4832) * 1024
-PMC_TRAFFIC_SOURCE = "profiles/r02_pmc_bench_v3.txt"
+PMC_TRAFFIC_BYTES = (17540 + 5606) * 1024
+PMC_TRAFFIC_SOURCE = "profiles/r02_pmc_bench_v4.txt"
 
 
 def log(msg):
