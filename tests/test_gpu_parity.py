@@ -560,3 +560,34 @@ def test_wide_hidden_layer_runs_step_wise_on_the_matrix_core_gemm(B, T, F, H, ac
     assert np.abs(res.cpu().numpy() - res_ref).max() <= 2e-5
     _, hT3, cT3 = ops.lstm_seq(dv(x), dv(K), dv(R), dv(b), dv(h0), dv(c0), act=act, impl="auto", return_sequences=False, workspace=ws)
     assert torch.equal(hT3, hT) and torch.equal(cT3, cT)
+
+
+@pytest.mark.parametrize("B,T_in,T_out,H,act", [(1024, 30, 30, 256, "sigmoid"), (37, 3, 5, 256, "hard_sigmoid"), (48, 4, 4, 128, "sigmoid"),
+                                                (20, 2, 3, 64, "sigmoid"), (16 * 70, 3, 2, 256, "sigmoid")])
+def test_one_launch_encode_decode_equals_two_launches(B, T_in, T_out, H, act):
+    """The fused call runs encoder and decoder as ONE launch when every group has one tile (state handed over in registers,
+    the h_T tile in LDS): bit-identical to the two-launch form (FOV_TWO_LAUNCHES=1), which more tiles than groups still take
+    (the last case: 70 tiles on 64 groups), and to the oracle within the usual bound."""
+    from longterm360fov_amd import ops
+    w = O.init_seq2seq(400 + H, H=H, bias_noise=0.05)
+    enc, dec0, _ = O.synthetic_batch(401 + B, B, T_in, T_out)
+    dw = {k: torch.from_numpy(v).cuda() for k, v in w.items()}
+    d_enc, d_dec0 = torch.from_numpy(enc).cuda(), torch.from_numpy(dec0).cuda()
+    ws = ops.Workspace()
+    one = ops.seq2seq_decode(d_enc, d_dec0, dw, T_out, act=act, impl="cluster", workspace=ws).clone()
+    ws.check()
+    os.environ["FOV_TWO_LAUNCHES"] = "1"
+    try:
+        two = ops.seq2seq_decode(d_enc, d_dec0, dw, T_out, act=act, impl="cluster", workspace=ws).clone()
+    finally:
+        del os.environ["FOV_TWO_LAUNCHES"]
+    ws.check()
+    assert torch.equal(one, two)
+    n = min(B, 48)
+    ref = O.seq2seq_decode(enc[:n].astype(np.float64), dec0[:n].astype(np.float64), {k: v.astype(np.float64) for k, v in w.items()},
+                           T_out, act=act)
+    assert np.abs(one[:n].cpu().numpy() - ref).max() <= 2e-5
+    # a launch after the fused one continues from the header it left behind
+    again = ops.seq2seq_decode(d_enc, d_dec0, dw, T_out, act=act, impl="cluster", workspace=ws)
+    ws.check()
+    assert torch.equal(again, one)
