@@ -66,6 +66,7 @@ __global__ __launch_bounds__(256) void dense_kernel(const float* __restrict__ x,
 // as 16-byte pieces, W transposed in LDS (the four row groups of a wave read the same addresses - broadcast),
 // four butterfly steps instead of six and only over Out values.  ~4x fewer instructions per row than the
 // generic kernel above; HBM-bound on x.
+template <int VEC>   // VEC = 4: In % 4 == 0 and x 16-byte aligned; VEC = 1: any In (the others' projection: In = 198)
 __global__ __launch_bounds__(256) void dense_small_kernel(const float* __restrict__ x, const float* __restrict__ W,
                                                           const float* __restrict__ b, const float* __restrict__ add,
                                                           long add_stride, float* __restrict__ y, int N, int In, int Out,
@@ -84,12 +85,31 @@ __global__ __launch_bounds__(256) void dense_small_kernel(const float* __restric
         float acc[8];
 #pragma unroll
         for (int o = 0; o < 8; ++o) acc[o] = 0.f;
-        for (int k = 4 * l16; k < In; k += 64) {
-            const f32x4 xv = *(const f32x4*)(xr + k);
+        if constexpr (VEC == 4) {
+            for (int k = 4 * l16; k < In; k += 64) {
+                const f32x4 xv = *(const f32x4*)(xr + k);
 #pragma unroll
-            for (int o = 0; o < 8; ++o) {
-                const f32x4 wv = *(const f32x4*)&Wt[o * In + k];
-                acc[o] = fmaf(xv[0], wv[0], fmaf(xv[1], wv[1], fmaf(xv[2], wv[2], fmaf(xv[3], wv[3], acc[o]))));
+                for (int o = 0; o < 8; ++o) {
+                    const f32x4 wv = *(const f32x4*)&Wt[o * In + k];
+                    acc[o] = fmaf(xv[0], wv[0], fmaf(xv[1], wv[1], fmaf(xv[2], wv[2], fmaf(xv[3], wv[3], acc[o]))));
+                }
+            }
+        } else {
+            for (int k0 = 0; k0 < In; k0 += 64) {   // four elements per lane in flight
+                float xv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int k = k0 + 16 * u + l16;
+                    xv[u] = xr[k < In ? k : In - 1];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int k = k0 + 16 * u + l16;
+                    const float xm = k < In ? xv[u] : 0.f;
+                    const int kc = k < In ? k : In - 1;
+#pragma unroll
+                    for (int o = 0; o < 8; ++o) acc[o] = fmaf(xm, Wt[o * In + kc], acc[o]);
+                }
             }
         }
 #pragma unroll
@@ -110,11 +130,15 @@ __global__ __launch_bounds__(256) void dense_small_kernel(const float* __restric
 
 static int launch_dense(const float* x, const float* W, const float* b, const float* add, long add_stride, float* y, int N,
                         int In, int Out, int activation, hipStream_t stream) {
-    if (Out <= 8 && (In & 3) == 0 && In <= 2048 && (((uintptr_t)x) & 15) == 0 && N >= 64) {
+    if (Out <= 8 && In <= 2048 && N >= 64) {
         long blocks = ((long)N + 15) / 16;
         if (blocks > 2048) blocks = 2048;
-        hipLaunchKernelGGL(dense_small_kernel, dim3((unsigned)blocks), dim3(256), sizeof(float) * 8 * In, stream, x, W, b, add,
-                           add_stride, y, N, In, Out, activation);
+        if ((In & 3) == 0 && (((uintptr_t)x) & 15) == 0)
+            hipLaunchKernelGGL(dense_small_kernel<4>, dim3((unsigned)blocks), dim3(256), sizeof(float) * 8 * In, stream, x, W, b, add,
+                               add_stride, y, N, In, Out, activation);
+        else
+            hipLaunchKernelGGL(dense_small_kernel<1>, dim3((unsigned)blocks), dim3(256), sizeof(float) * 8 * In, stream, x, W, b, add,
+                               add_stride, y, N, In, Out, activation);
     } else {
         hipLaunchKernelGGL(dense_kernel, dim3((N + 3) / 4), dim3(256), 0, stream, x, W, b, add, add_stride, y, N, In, Out,
                            activation);

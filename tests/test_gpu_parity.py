@@ -120,9 +120,10 @@ def test_seq2seq_teacher_forced(impl, H, B):
 def test_dense():
     ops = _ops()
     rng = np.random.default_rng(3)
-    # (N >= 64, Out <= 8, In % 4 == 0) runs the narrow-head kernel, the rest the generic one
+    # (N >= 64, Out <= 8) runs the narrow-head kernel (16-byte row loads when In % 4 == 0, scalar ones otherwise: the others'
+    # projection has In = 198), the rest the generic one
     for N, In, Out in ((7, 256, 6), (130, 204, 6), (5, 33, 20), (1000, 256, 6), (4099, 40, 3), (65, 2048, 8), (333, 30, 6),
-                       (70, 512, 1)):
+                       (70, 512, 1), (5120, 198, 6), (100, 65, 8), (64, 1, 2)):
         x = rng.standard_normal((N, In)).astype(np.float32)
         W = (rng.standard_normal((In, Out)) / np.sqrt(In)).astype(np.float32)
         b = rng.standard_normal(Out).astype(np.float32)
