@@ -685,6 +685,12 @@ int gemm_f32(GemmArgs g, int accumulate, float* scratch, size_t scratch_floats, 
     // mid-size outputs (e.g. 512 x 1024 of a per-step projection): 128 x 128 tiles would occupy a fraction of
     // the 256 CUs and K is too short to split -> 64 x 64 tiles
     if (variant == 2 && ((g.M + 127) / 128) * ((g.N + 127) / 128) < 128 && K <= 2048) { BM = 64; BN = 64; variant = 3; }
+    if (const char* e = getenv("FOV_GEMM_VARIANT")) {   // tuning knob (experiments)
+        const int v = atoi(e);
+        if (v == 2) { BM = 128; BN = 128; variant = 2; }
+        if (v == 3) { BM = 64; BN = 64; variant = 3; }
+        if (v == 4) { BM = 64; BN = 128; variant = 4; }
+    }
     // per-thread staging offsets span one block tile: they must fit 32 bits
     {
         const long amax = (long)BM * (g.a_sm < 0 ? -g.a_sm : g.a_sm) + 16 * (g.a_ski < 0 ? -g.a_ski : g.a_ski);
@@ -699,8 +705,10 @@ int gemm_f32(GemmArgs g, int accumulate, float* scratch, size_t scratch_floats, 
     if (ktiles > 0x7fffffffL) { set_error("gemm_f32: K too large"); return FOV_ERR_UNSUPPORTED; }
     const int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
     int split = 1;
-    if (tiles < 256 && ktiles >= 32) {
-        split = (512 + tiles - 1) / tiles;
+    if (tiles < 512 && ktiles >= 32) {
+        // fewer tiles than two per CU and a long K: slices.  (256 <= tiles < 512, e.g. the 5120 x 256 x 1024 data gradient of
+        // the stacked layer on 64 x 64 tiles: four slices measured 55 -> 43 us)
+        split = ((tiles < 256 ? 512 : 1024) + tiles - 1) / tiles;
         const long maxs = ktiles / 4;   // >= 4 k-tiles (64 k) per slice
         if (split > maxs) split = (int)maxs;
         if (split > 64) split = 64;
@@ -767,6 +775,7 @@ int gemm_f32(GemmArgs g, int accumulate, float* scratch, size_t scratch_floats, 
     if (variant == 0) { FOV_GEMM_MODES(2, 4, 1) }
     else if (variant == 1) { FOV_GEMM_MODES(6, 4, 1) }
     else if (variant == 3) { FOV_GEMM_MODES(2, 2, 2) }
+    else if (variant == 4) { FOV_GEMM_MODES(2, 4, 2) }
     else { FOV_GEMM_MODES(4, 4, 2) }
 #undef FOV_GEMM_MODES
 #undef FOV_GEMM_LAUNCH
