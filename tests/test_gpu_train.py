@@ -209,6 +209,59 @@ def test_data_parallel_two_ranks_equal_single_process():
     np.testing.assert_array_equal(res[0][2], res[1][2])     # replicas stay bit-identical
 
 
+def _dp_mixing_worker(rank, world_size, port, q, dtype):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world_size)
+    try:
+        from longterm360fov_amd import parallel
+        from longterm360fov_amd.training import OthersMixingTrainer
+        w = O.init_others_mixing(223, H=256, num_user=5, bias_noise=0.05)
+        enc, dec0, tgt, oth = O.synthetic_batch(224, 41, 3, 4, num_others=4)
+        lo, hi = parallel.shard_range(41)
+        tr = OthersMixingTrainer(w, dtype=dtype)
+        losses = [float(tr.train_step(dev(enc[lo:hi]), dev(oth[lo:hi]), dev(dec0[lo:hi]), dev(tgt[lo:hi]), n_global=41).item())
+                  for _ in range(3)]
+        tr.check()
+        q.put((rank, losses, tr.flat.detach().cpu().numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_data_parallel_mixing_trainer_two_ranks(dtype):
+    """The others-mixing trainer under data parallelism (2 ranks over gloo on the box's one GPU, shards 21 / 20): the shard
+    weight rides on the loss gradient, the decoder / head part of the flat buffer - written by the fused weight-gradient
+    products - is all-reduced while the encoder's BPTT runs, the rest at the end of the step; three Adam steps give the losses
+    and parameters of the single-process run on the whole batch, and the replicas stay bit-identical."""
+    import socket
+    import torch.multiprocessing as mp
+    from longterm360fov_amd.training import OthersMixingTrainer
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_dp_mixing_worker, args=(r, 2, port, q, dtype)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    w = O.init_others_mixing(223, H=256, num_user=5, bias_noise=0.05)
+    enc, dec0, tgt, oth = O.synthetic_batch(224, 41, 3, 4, num_others=4)
+    tr = OthersMixingTrainer(w, dtype=dtype)
+    ref_losses = [float(tr.train_step(dev(enc), dev(oth), dev(dec0), dev(tgt)).item()) for _ in range(3)]
+    ref_flat = tr.flat.detach().cpu().numpy()
+    tol = 1e-5 if dtype == "f32" else 2e-3      # bf16: the two shards round different partial sums
+    for rank, losses, flat in res:
+        np.testing.assert_allclose(losses, ref_losses, rtol=tol)
+        d = np.abs(flat - ref_flat)
+        assert d.max() <= 4e-3 and np.mean(d <= (2e-5 if dtype == "f32" else 2e-3)) >= 0.99, (rank, d.max())
+    np.testing.assert_array_equal(res[0][2], res[1][2])     # replicas stay bit-identical
+
+
 def _fit_worker(rank, world_size, port, q):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
