@@ -700,8 +700,9 @@ __device__ __forceinline__ void cluster_body(const LstmParams& p, ClusterCarry& 
 #pragma unroll
                     for (int ss = 0; ss < 4; ++ss) ysum[ss] += part[ss];
                 }
+                // outputs o = 4*ss + g4 < F_dec <= 8 live in ss = 0, 1 only: the other two registers stay zero
 #pragma unroll
-                for (int ss = 0; ss < 4; ++ss) y4[ss] = tanh_f(ysum[ss] + bd4[ss]);
+                for (int ss = 0; ss < 2; ++ss) y4[ss] = tanh_f(ysum[ss] + bd4[ss]);
                 if (slice == 0 && wave == 0 && b0 + n < p.B) {
                     float* yo = p.out + ((size_t)(b0 + n) * p.T_out + t) * O + g4;
 #pragma unroll
