@@ -1220,13 +1220,14 @@ int lstm_seq_bwd(const float* x, const float* K, const float* R, const float* h0
     if (persistent) {
         // one launch for the whole recurrence: dz (B,T,4H), dh0, dc0
         // bias gradient: per-tile partials from the kernel (db_part lives in the split-K scratch), summed below
-        // dK, dR, db adjacent (a trainer's flat gradient buffer) and no initial state: ONE product [x | h_{t-1} | 1]^T dz
+        // dK, dR, db adjacent (a trainer's flat gradient buffer): ONE product [x | h_{t-1} | 1]^T dz (h_{-1} = 0; a given initial
+        // state adds its h0^T dz_0 afterwards)
         // below gives all three (no bias partials from the kernel, no column-sum launches); F too narrow for a row tile:
         // [h_{t-1} | 1]^T dz gives dR and db
         const int N4 = 4 * H;
-        fuse_kr = dK && dR && db && !h0 && T > 1 && dR == dK + (size_t)F * N4 && db == dR + (size_t)H * N4 &&
+        fuse_kr = dK && dR && db && T > 1 && dR == dK + (size_t)F * N4 && db == dR + (size_t)H * N4 &&
                   wgrad_fusable(x, F, (long)T * F, F, hs, H, (long)T * H, H, dz, N4, (long)T * N4, dK, N4) && !getenv("FOV_NO_WGRAD_FUSION");
-        fuse_r = !fuse_kr && dR && db && !h0 && T > 1 && db == dR + (size_t)H * N4 &&
+        fuse_r = !fuse_kr && dR && db && T > 1 && db == dR + (size_t)H * N4 &&
                  wgrad_fusable(hs, H, (long)T * H, H, nullptr, 0, 0, 0, dz, N4, (long)T * N4, dR, N4) && !getenv("FOV_NO_WGRAD_FUSION");
         float* db_part = (db && !fuse_kr && !fuse_r) ? scratch : nullptr;
         // bf16, 256-wide input (the stacked layer): the BPTT kernel forms dx = dz K^T from the dz tile it has gathered anyway
@@ -1276,15 +1277,21 @@ int lstm_seq_bwd(const float* x, const float* K, const float* R, const float* h0
     }
     int rc;
     const long BT = (long)B * T;
-    if (fuse_kr) {
-        rc = wgrad_fused(x, F, (long)T * F, F, 0, hs, H, (long)T * H, H, 1, dz, 4 * H, (long)T * 4 * H, dK, 4 * H, B, T, 1, accumulate,
-                         bf16, scratch, scratch_floats, stream);
+    if (fuse_kr || fuse_r) {
+        rc = fuse_kr ? wgrad_fused(x, F, (long)T * F, F, 0, hs, H, (long)T * H, H, 1, dz, 4 * H, (long)T * 4 * H, dK, 4 * H, B, T, 1,
+                                   accumulate, bf16, scratch, scratch_floats, stream)
+                     : wgrad_fused(hs, H, (long)T * H, H, 1, nullptr, 0, 0, 0, 0, dz, 4 * H, (long)T * 4 * H, dR, 4 * H, B, T, 1,
+                                   accumulate, bf16, scratch, scratch_floats, stream);
         if (rc) return rc;
-        dK = dR = db = nullptr;
-    } else if (fuse_r) {
-        rc = wgrad_fused(hs, H, (long)T * H, H, 1, nullptr, 0, 0, 0, 0, dz, 4 * H, (long)T * 4 * H, dR, 4 * H, B, T, 1, accumulate, bf16,
-                         scratch, scratch_floats, stream);
-        if (rc) return rc;
+        if (h0) {   // dR += h0^T dz[:, 0]
+            GemmArgs g0 = {};
+            g0.a = h0; g0.b = dz; g0.c = dR; g0.M = H; g0.N = 4 * H; g0.KO = 1; g0.KI = B;
+            g0.a_sm = 1; g0.a_ski = H; g0.b_sn = 1; g0.b_ski = (long)T * 4 * H; g0.ldc = 4 * H;
+            rc = bf16 ? gemm_bf16_tn(h0, H, 0, dz, (long)T * 4 * H, 0, dR, 4 * H, H, 4 * H, 1, B, 1, scratch, scratch_floats, stream)
+                      : gemm_f32(g0, 1, scratch, scratch_floats, stream);
+            if (rc) return rc;
+        }
+        if (fuse_kr) dK = nullptr;
         dR = db = nullptr;
     }
     if (dK) {   // dK (F,4H) = x^T dz : A(m=f,k=(b,t)) = x[k][f], B(k,n) = dz[k][n]

@@ -449,8 +449,9 @@ def test_mixing_head_weight_gradients_one_launch(B, T, H, O, U):
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("state", [False, True])
 @pytest.mark.parametrize("B,T,F,H", [(64, 6, 256, 256), (40, 5, 90, 256), (33, 2, 256, 256), (48, 4, 128, 128)])
-def test_layer_backward_adjacent_gradients_take_the_fused_product(B, T, F, H, dtype):
+def test_layer_backward_adjacent_gradients_take_the_fused_product(B, T, F, H, dtype, state):
     """fov_lstm_seq_bwd handed dK, dR, db that lie adjacent (a trainer's flat buffer) forms them as ONE product
     [x | h_{t-1} | 1]^T dz - h_{t-1} read from the h_t tape shifted by a step, zero at t = 0 - or, when F is no multiple of the
     row tile, dR and db as [h_{t-1} | 1]^T dz: same gradients as with three separate buffers (three products + column sums)."""
@@ -461,11 +462,14 @@ def test_layer_backward_adjacent_gradients_take_the_fused_product(B, T, F, H, dt
     K, R, b = O.init_lstm(rng, F, H)
     x = rng.standard_normal((B, T, F)).astype(np.float32)
     dhs = rng.standard_normal((B, T, H)).astype(np.float32)
-    hs, hT, cT, res = ops.lstm_seq_train(dev(x), dev(K), dev(R), dev(b), act="sigmoid", dtype=dtype)
-    sep = ops.lstm_seq_bwd(dev(x), dev(K), dev(R), hs, res, dhs=dev(dhs), act="sigmoid", dtype=dtype)
+    # a given initial state (a decoder layer seeded by the encoder) adds h0^T dz_0 to dR behind the fused product
+    h0 = dev((0.5 * rng.standard_normal((B, H))).astype(np.float32)) if state else None
+    c0 = dev((0.5 * rng.standard_normal((B, H))).astype(np.float32)) if state else None
+    hs, hT, cT, res = ops.lstm_seq_train(dev(x), dev(K), dev(R), dev(b), h0, c0, act="sigmoid", dtype=dtype)
+    sep = ops.lstm_seq_bwd(dev(x), dev(K), dev(R), hs, res, h0=h0, c0=c0, dhs=dev(dhs), act="sigmoid", dtype=dtype)
     flat = torch.zeros((F + H + 1) * 4 * H, device="cuda")
     dK, dR, db = flat[:F * 4 * H].view(F, 4 * H), flat[F * 4 * H:(F + H) * 4 * H].view(H, 4 * H), flat[(F + H) * 4 * H:]
-    fused = ops.lstm_seq_bwd(dev(x), dev(K), dev(R), hs, res, dhs=dev(dhs), dK=dK, dR=dR, db=db, act="sigmoid", dtype=dtype)
+    fused = ops.lstm_seq_bwd(dev(x), dev(K), dev(R), hs, res, h0=h0, c0=c0, dhs=dev(dhs), dK=dK, dR=dR, db=db, act="sigmoid", dtype=dtype)
     assert torch.equal(fused["dz"], sep["dz"])
     for k in ("dK", "dR", "db"):
         scale = sep[k].abs().max().item()
@@ -473,7 +477,8 @@ def test_layer_backward_adjacent_gradients_take_the_fused_product(B, T, F, H, dt
         print("adjacent-gradient backward %s %s: max|ref| %.3e err %.3e" % (dtype, k, scale, err))
         assert err <= 2e-5 * scale + 1e-6, (k, err, scale)
     # accumulate on top
-    ops.lstm_seq_bwd(dev(x), dev(K), dev(R), hs, res, dhs=dev(dhs), dK=dK, dR=dR, db=db, act="sigmoid", accumulate=True, dtype=dtype)
+    ops.lstm_seq_bwd(dev(x), dev(K), dev(R), hs, res, h0=h0, c0=c0, dhs=dev(dhs), dK=dK, dR=dR, db=db, act="sigmoid", accumulate=True,
+                     dtype=dtype)
     for k in ("dK", "dR", "db"):
         assert (fused[k] - 2 * sep[k]).abs().max().item() <= 4e-5 * sep[k].abs().max().item() + 2e-6, k
 
