@@ -71,6 +71,9 @@ int cluster_num_groups(int B, int H);
 int device_cu_count();                               // CUs of the current device
 int ensure_dynamic_lds(const void* kern, size_t lds);  // cached hipFuncSetAttribute(MaxDynamicSharedMemorySize)
 void set_error(const char* fmt, ...);
+// fused encoder + decoder with two tiles per workgroup, H = 256 (lstm_pair.hip)
+bool pair_shape_ok(int B, int T, int T_out, int F, int F_dec, int H);
+int launch_pair_fused(const LstmParams& p, hipStream_t stream);
 // wide-input layer, H = 256, 96 < F <= 256 (lstm_wide.hip)
 bool wide_shape_ok(int F, int H);
 bool wide_narrow_preferred(int B, int F, int H);

@@ -218,6 +218,47 @@ __device__ __forceinline__ void input_proj(f32x4 (&acc)[4], const float* arow, c
     }
 }
 
+// The same with the block count known at compile time: every LDS offset is an instruction immediate and the operand
+// registers are renamed instead of rotated - the run-time loop above carries two v_mov_b64 and two v_add_u32 per 16
+// MFMAs, and on this chip a VALU instruction is never hidden behind an fp32 MFMA (tools/microbench/mfma_f32_overlap.hip:
+// 32 -> 46 cycles for ONE v_fma_f32 in an MFMA gap).
+template <int NQC>
+__device__ __forceinline__ void input_proj_fixed(f32x4 (&acc)[4], const float* arow, const float* sKw, int lane) {
+    const float* bl = sKw + lane * 4;
+    f32x4 a = *(const f32x4*)arow;
+    f32x4 b0 = *(const f32x4*)bl;
+    f32x4 b1 = *(const f32x4*)(bl + 256);
+#pragma unroll
+    for (int q = 0; q < NQC; ++q) {
+        f32x4 an = a;
+        if (q + 1 < NQC) an = *(const f32x4*)(arow + 16 * (q + 1));
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            f32x4 bn = b1;
+            if (4 * q + s + 2 < 4 * NQC) bn = *(const f32x4*)(bl + (4 * q + s + 2) * 256);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) mfma_vv(acc[g], a[s], b0[g]);
+            b0 = b1;
+            b1 = bn;
+        }
+        a = an;
+    }
+}
+// Both forms end on the MFMA -> VALU wait states: where the two branches meet hipcc may copy the accumulators into the
+// registers the other branch left them in - VALU reads of MFMA results it does not know to pad (cdna_hip_programming.md 5.7).
+__device__ __forceinline__ void input_proj_any(f32x4 (&acc)[4], const float* arow, const float* sKw, int nq, int lane) {
+#ifndef FOV_DBG_NO_XK_UNROLL
+    if (nq == 6) {   // F in (80, 96]: the reference's 90-wide input (FoV_seq2seq.py:24-26)
+        input_proj_fixed<6>(acc, arow, sKw, lane);
+        mfma_end(acc);
+    } else
+#endif
+    if (nq > 0) {
+        input_proj(acc, arow, sKw, nq, lane);
+        mfma_end(acc);
+    }
+}
+
 // DECODE: acc += y(16 x 8) . Kslice, y fragment and the two K blocks already in registers
 __device__ __forceinline__ void input_proj_reg(f32x4 (&acc)[4], f32x4 y4, const f32x4 (&kb)[2]) {
     asm volatile("s_nop 1" : "+v"(y4));   // VALU-written A operand -> MFMA read
@@ -512,7 +553,7 @@ __device__ __forceinline__ void cluster_body(const LstmParams& p, ClusterCarry& 
         }
         if (steps > 0) {
             mfma_begin(acc);
-            if (LAYER) input_proj(acc, sX + n * LDX + 4 * g4, sKw, nq, lane);
+            if (LAYER) input_proj_any(acc, sX + n * LDX + 4 * g4, sKw, nq, lane);
             else input_proj_reg(acc, y4, kb);
             recurrent<H, 0, 4>(acc, hrow, wR);
             mfma_end(acc);
@@ -549,8 +590,31 @@ __device__ __forceinline__ void cluster_body(const LstmParams& p, ClusterCarry& 
                     xr[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xgrs, xoff[i], (unsigned)((t + 2) * F * 4), 0));
             }
             // ---- the part of h_{t-1} . R that needed the partner slices ----
-            recurrent<H, 4, NQ>(acc, hrow, wR);
-            mfma_end(acc);
+            if (LAYER || t == 0) {
+                recurrent<H, 4, NQ>(acc, hrow, wR);
+                mfma_end(acc);   // (inside each branch: see input_proj_any)
+            } else {
+                // DECODE: the four partial Dense products of y_{t-1} were written before these MFMAs, which do not need y; they
+                // meet in LDS meanwhile (barrier 3 and the reads sit one k-block before the end), then y_{t-1} . K completes z_t
+                constexpr int JL = NQ - 1 > 4 ? NQ - 1 : 4;   // H = 64 has no partner slices: nothing covers, nothing to split
+                recurrent<H, 4, JL>(acc, hrow, wR);
+                __syncthreads();  // barrier 3: the four partial products are in LDS
+                f32x4 part[4];
+#pragma unroll
+                for (int w2 = 0; w2 < 4; ++w2) part[w2] = *(const f32x4*)(sW + (w2 * 16 + n) * 16 + 4 * g4);
+                recurrent<H, JL, NQ>(acc, hrow, wR);
+                // outputs o = 4*ss + g4 < F_dec <= 8 live in ss = 0, 1 only
+#pragma unroll
+                for (int ss = 0; ss < 2; ++ss) y4[ss] = tanh_f(((part[0][ss] + part[1][ss]) + part[2][ss]) + part[3][ss] + bd4[ss]);
+                if (slice == 0 && wave == 0 && b0 + n < p.B) {
+                    float* yo = p.out + ((size_t)(b0 + n) * p.T_out + (t - 1)) * p.F_dec + g4;
+#pragma unroll
+                    for (int ss = 0; ss < 2; ++ss)
+                        if (4 * ss + g4 < p.F_dec) yo[4 * ss] = y4[ss];
+                }
+                input_proj_reg(acc, y4, kb);
+                mfma_end(acc);
+            }
             FOV_STAMP(1);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -616,7 +680,7 @@ __device__ __forceinline__ void cluster_body(const LstmParams& p, ClusterCarry& 
 #pragma unroll
                 for (int g = 0; g < 4; ++g) acc[g] = ZX ? zr[g] : (f32x4){bias[g], bias[g], bias[g], bias[g]};
                 mfma_begin(acc);
-                if (LAYER) input_proj(acc, sX + ((t + 1) % 3) * BT * LDX + n * LDX + 4 * g4, sKw, nq, lane);
+                if (LAYER) input_proj_any(acc, sX + ((t + 1) % 3) * BT * LDX + n * LDX + 4 * g4, sKw, nq, lane);
             }
             FOV_STAMP(5);
             u32x2 v[NG > 0 ? NG : 1];
@@ -692,35 +756,31 @@ __device__ __forceinline__ void cluster_body(const LstmParams& p, ClusterCarry& 
 #pragma unroll
                 for (int ss = 0; ss < 4; ++ss) dacc[0][ss] += dacc[1][ss];
                 *(f32x4*)(sW + (wave * 16 + n) * 16 + 4 * g4) = dacc[0];   // partial over this wave's positions
-                __syncthreads();  // barrier 3: the four partial products are in LDS
-                f32x4 ysum = *(const f32x4*)(sW + n * 16 + 4 * g4);
-#pragma unroll
-                for (int w2 = 1; w2 < 4; ++w2) {
-                    const f32x4 part = *(const f32x4*)(sW + (w2 * 16 + n) * 16 + 4 * g4);
-#pragma unroll
-                    for (int ss = 0; ss < 4; ++ss) ysum[ss] += part[ss];
-                }
-                // outputs o = 4*ss + g4 < F_dec <= 8 live in ss = 0, 1 only: the other two registers stay zero
-#pragma unroll
-                for (int ss = 0; ss < 2; ++ss) y4[ss] = tanh_f(ysum[ss] + bd4[ss]);
-                if (slice == 0 && wave == 0 && b0 + n < p.B) {
-                    float* yo = p.out + ((size_t)(b0 + n) * p.T_out + t) * O + g4;
-#pragma unroll
-                    for (int ss = 0; ss < 2; ++ss)
-                        if (4 * ss + g4 < O) yo[4 * ss] = y4[ss];
-                }
-                if (more) {
-                    input_proj_reg(acc, y4, kb);
-                    mfma_end(acc);
-                }
                 FOV_STAMP(8);
+            }
+        }
+        if (!LAYER && steps > 0 && !aborted) {
+            // y of the last step: nothing is left to cover the meeting of its partials
+            __syncthreads();
+            f32x4 ysum = *(const f32x4*)(sW + n * 16 + 4 * g4);
+#pragma unroll
+            for (int w2 = 1; w2 < 4; ++w2) {
+                const f32x4 part = *(const f32x4*)(sW + (w2 * 16 + n) * 16 + 4 * g4);
+#pragma unroll
+                for (int ss = 0; ss < 4; ++ss) ysum[ss] += part[ss];
+            }
+            if (slice == 0 && wave == 0 && b0 + n < p.B) {
+                float* yo = p.out + ((size_t)(b0 + n) * p.T_out + (steps - 1)) * p.F_dec + g4;
+#pragma unroll
+                for (int ss = 0; ss < 2; ++ss)
+                    if (4 * ss + g4 < p.F_dec) yo[4 * ss] = tanh_f(ysum[ss] + bd4[ss]);
             }
         }
         if constexpr (F1) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) { cy.c[r] = c[r]; cy.h[r] = hcur[r]; }
         }
-        if (!aborted) {
+        if (!aborted && !F1) {   // (the encoder phase of the fused kernel hands its state over in registers)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = b0 + 4 * g4 + r;
@@ -889,6 +949,10 @@ int launch_cluster(const LstmParams& p_in, bool decode, hipStream_t stream) {
     // No memset: epoch tags continue from the workspace header.  A group visits ceil(tiles / groups) tiles and
     // advances its epoch once per step of each.
     const int visits = (p.num_tiles + p.num_groups - 1) / p.num_groups;
+    // FOV_PAIR=1 (opt-in, measured slower so far: DESIGN.md section 5): H = 256 with two tiles per workgroup and two waves
+    // per SIMD (lstm_pair.hip)
+    if (decode && p.H == 256 && !p.hs && !p.reserve && getenv("FOV_PAIR") && pair_shape_ok(p.B, p.T, p.T_out, p.F, p.F_dec, p.H))
+        return launch_pair_fused(p, stream);
     if (!decode) {
         p.epoch_span = p.T * visits + 1;
         return launch_cluster_mode(p, MODE_LAYER, stream);
@@ -897,7 +961,6 @@ int launch_cluster(const LstmParams& p_in, bool decode, hipStream_t stream) {
     if (visits == 1 && p.T > 0 && p.T_out > 0 && !p.hs && !p.reserve && !getenv("FOV_TWO_LAUNCHES")) {
         // one tile per group: encoder and decoder as ONE launch (state in registers, h_T tile in LDS)
         LstmParams f = p;
-        f.hT = f.cT = nullptr;
         f.epoch_span = p.T + p.T_out + 2;
         return launch_cluster_fused(f, stream);
     }

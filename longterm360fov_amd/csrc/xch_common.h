@@ -64,9 +64,17 @@ __device__ __forceinline__ unsigned xch_arrive(unsigned* status, unsigned* lds2)
     return arrival;
 }
 __device__ __forceinline__ XchTicket xch_ticket(const unsigned* lds2, unsigned arrival) {
+    // readfirstlane: the words are the same for every lane, but a value loaded from LDS is divergent to the compiler, and an
+    // epoch-derived scalar offset of a buffer load / store (the parity buffer) then becomes a waterfall loop around EVERY
+    // granule access (v_readfirstlane + v_cmp + s_and_saveexec + branch, 16 of them per step of lstm_cluster)
     XchTicket t;
+#ifdef FOV_DBG_OLD_TICKET
     t.base = lds2[0];
     t.launch = lds2[1];
+#else
+    t.base = (unsigned)__builtin_amdgcn_readfirstlane((int)lds2[0]);
+    t.launch = (unsigned)__builtin_amdgcn_readfirstlane((int)lds2[1]);
+#endif
     t.arrival = arrival;
     return t;
 }
