@@ -118,19 +118,34 @@ __host__ __device__ inline ClusterLds cluster_lds(int H, int F, bool decode) {
 // v_accvgpr_read + s_nop before its MFMA; fp32 MFMA shares the VALU datapath, so those two
 // extra issues per MFMA cost about 10 of 42 cycles (measured, profiles/r01_stamps_v2.txt).  With
 // the "a" constraint the weights live in AGPRs and are MFMA B operands directly; accumulators
-// and A operands stay in VGPRs.  hipcc pads no hazards around asm: mfma_begin / mfma_end carry
-// the VALU-write -> MFMA-read and MFMA-write -> VALU-read wait states (cdna_hip_programming.md 5.7).
-__device__ __forceinline__ void mfma_va(f32x4& acc, float a, float w_agpr) {
-    asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "a"(w_agpr));
+// and A operands stay in VGPRs.
+// hipcc pads no hazards around asm (cdna_hip_programming.md 5.7), and a separate "nop" statement behind a run of MFMAs is
+// not enough: where control flow merges hipcc copies accumulators between register sets - VALU reads of MFMA results -
+// and puts those copies BETWEEN the last MFMA statement and the nop statement (round 3: wrong x.K terms with the
+// fully unrolled input projection).  So the wait states live INSIDE the strings: the first MFMA of a run opens with
+// two (a VALU-written accumulator / operand -> MFMA read), the last one ends with twelve (8-pass MFMA result -> any
+// reader).  A run that is followed by another MFMA run on the same accumulators needs neither.
+// tools/isa_mfma_hazard.py checks the generated code for both hazards.
+constexpr int MF_MID = 0, MF_FIRST = 1, MF_LAST = 2;
+#define FOV_MFMA_STR(pre, post) pre "v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" post
+// `pos` is a constant after unrolling / inlining: exactly one of the four statements survives
+template <bool W_AGPR>
+__device__ __forceinline__ void mfma_f32(f32x4& acc, float a, float w, int pos) {
+    if constexpr (W_AGPR) {
+        if (pos == MF_MID) asm volatile(FOV_MFMA_STR("", "") : "+v"(acc) : "v"(a), "a"(w));
+        else if (pos == MF_FIRST) asm volatile(FOV_MFMA_STR("s_nop 1\n\t", "") : "+v"(acc) : "v"(a), "a"(w));
+        else if (pos == MF_LAST) asm volatile(FOV_MFMA_STR("", "\n\ts_nop 7\n\ts_nop 3") : "+v"(acc) : "v"(a), "a"(w));
+        else asm volatile(FOV_MFMA_STR("s_nop 1\n\t", "\n\ts_nop 7\n\ts_nop 3") : "+v"(acc) : "v"(a), "a"(w));
+    } else {
+        if (pos == MF_MID) asm volatile(FOV_MFMA_STR("", "") : "+v"(acc) : "v"(a), "v"(w));
+        else if (pos == MF_FIRST) asm volatile(FOV_MFMA_STR("s_nop 1\n\t", "") : "+v"(acc) : "v"(a), "v"(w));
+        else if (pos == MF_LAST) asm volatile(FOV_MFMA_STR("", "\n\ts_nop 7\n\ts_nop 3") : "+v"(acc) : "v"(a), "v"(w));
+        else asm volatile(FOV_MFMA_STR("s_nop 1\n\t", "\n\ts_nop 7\n\ts_nop 3") : "+v"(acc) : "v"(a), "v"(w));
+    }
 }
-__device__ __forceinline__ void mfma_vv(f32x4& acc, float a, float w_vgpr) {
-    asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(w_vgpr));
-}
-__device__ __forceinline__ void mfma_begin(f32x4 (&acc)[4]) {
-    asm volatile("s_nop 3" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
-}
-__device__ __forceinline__ void mfma_end(f32x4 (&acc)[4]) {
-    asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
+// position of MFMA number i of a run of n: the flags say whether the run opens / closes an MFMA sequence
+__host__ __device__ constexpr int mf_pos(bool first_run, bool last_run, bool is_first, bool is_last) {
+    return ((first_run && is_first) ? MF_FIRST : 0) | ((last_run && is_last) ? MF_LAST : 0);
 }
 
 // Load one LSTM's weights for this wave: R slice -> registers, K slice -> LDS, bias -> registers.
@@ -196,25 +211,37 @@ __device__ __forceinline__ void load_weights(float (&wR)[H / 16][4][4], float (&
 // acc += A(16 x Fp, LDS rows of stride ldx) . Kslice(LDS); B reads run two (q,s) blocks ahead.
 // No clamping: the K slice carries KPAD spare blocks per wave and the x tiles a spare tail, so
 // the run-ahead reads of the last iterations stay inside LDS (their values are never used) and
-// every block offset is an instruction immediate instead of VALU work.
+// every block offset is an instruction immediate instead of VALU work.  The last k-block is peeled: its last MFMA
+// carries the closing wait states.
+template <bool FIRST, bool LAST>
 __device__ __forceinline__ void input_proj(f32x4 (&acc)[4], const float* arow, const float* sKw, int nq, int lane) {
     if (nq <= 0) return;
     const float* bl = sKw + lane * 4;
     f32x4 a = *(const f32x4*)arow;
     f32x4 b0 = *(const f32x4*)bl;
     f32x4 b1 = *(const f32x4*)(bl + 256);
-    for (int q = 0; q < nq; ++q) {
+    if (FIRST) asm volatile("s_nop 1" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));   // (rare path; the first MFMA sits in a loop or in the peeled block)
+    for (int q = 0; q < nq - 1; ++q) {
         const f32x4 an = *(const f32x4*)(arow + 16 * (q + 1));
         const float* bq = bl + q * 1024;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const f32x4 bn = *(const f32x4*)(bq + (s + 2) * 256);
 #pragma unroll
-            for (int g = 0; g < 4; ++g) mfma_vv(acc[g], a[s], b0[g]);
+            for (int g = 0; g < 4; ++g) mfma_f32<false>(acc[g], a[s], b0[g], MF_MID);
             b0 = b1;
             b1 = bn;
         }
         a = an;
+    }
+    const float* bq = bl + (nq - 1) * 1024;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const f32x4 bn = *(const f32x4*)(bq + (s + 2) * 256);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) mfma_f32<false>(acc[g], a[s], b0[g], mf_pos(false, LAST, false, s == 3 && g == 3));
+        b0 = b1;
+        b1 = bn;
     }
 }
 
@@ -222,7 +249,7 @@ __device__ __forceinline__ void input_proj(f32x4 (&acc)[4], const float* arow, c
 // registers are renamed instead of rotated - the run-time loop above carries two v_mov_b64 and two v_add_u32 per 16
 // MFMAs, and on this chip a VALU instruction is never hidden behind an fp32 MFMA (tools/microbench/mfma_f32_overlap.hip:
 // 32 -> 46 cycles for ONE v_fma_f32 in an MFMA gap).
-template <int NQC>
+template <int NQC, bool FIRST, bool LAST>
 __device__ __forceinline__ void input_proj_fixed(f32x4 (&acc)[4], const float* arow, const float* sKw, int lane) {
     const float* bl = sKw + lane * 4;
     f32x4 a = *(const f32x4*)arow;
@@ -237,39 +264,35 @@ __device__ __forceinline__ void input_proj_fixed(f32x4 (&acc)[4], const float* a
             f32x4 bn = b1;
             if (4 * q + s + 2 < 4 * NQC) bn = *(const f32x4*)(bl + (4 * q + s + 2) * 256);
 #pragma unroll
-            for (int g = 0; g < 4; ++g) mfma_vv(acc[g], a[s], b0[g]);
+            for (int g = 0; g < 4; ++g)
+                mfma_f32<false>(acc[g], a[s], b0[g], mf_pos(FIRST, LAST, q == 0 && s == 0 && g == 0, q == NQC - 1 && s == 3 && g == 3));
             b0 = b1;
             b1 = bn;
         }
         a = an;
     }
 }
-// Both forms end on the MFMA -> VALU wait states: where the two branches meet hipcc may copy the accumulators into the
-// registers the other branch left them in - VALU reads of MFMA results it does not know to pad (cdna_hip_programming.md 5.7).
+template <bool FIRST, bool LAST>
 __device__ __forceinline__ void input_proj_any(f32x4 (&acc)[4], const float* arow, const float* sKw, int nq, int lane) {
 #ifndef FOV_DBG_NO_XK_UNROLL
-    if (nq == 6) {   // F in (80, 96]: the reference's 90-wide input (FoV_seq2seq.py:24-26)
-        input_proj_fixed<6>(acc, arow, sKw, lane);
-        mfma_end(acc);
-    } else
+    if (nq == 6) input_proj_fixed<6, FIRST, LAST>(acc, arow, sKw, lane);   // F in (80, 96]: the reference's 90-wide input (FoV_seq2seq.py:24-26)
+    else
 #endif
-    if (nq > 0) {
-        input_proj(acc, arow, sKw, nq, lane);
-        mfma_end(acc);
-    }
+        input_proj<FIRST, LAST>(acc, arow, sKw, nq, lane);
 }
 
-// DECODE: acc += y(16 x 8) . Kslice, y fragment and the two K blocks already in registers
+// DECODE: acc += y(16 x 8) . Kslice, y fragment and the two K blocks already in registers (y is VALU-written: the run
+// always opens with the two wait states)
+template <bool LAST>
 __device__ __forceinline__ void input_proj_reg(f32x4 (&acc)[4], f32x4 y4, const f32x4 (&kb)[2]) {
-    asm volatile("s_nop 1" : "+v"(y4));   // VALU-written A operand -> MFMA read
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) mfma_vv(acc[g], y4[s], kb[s][g]);
+        for (int g = 0; g < 4; ++g) mfma_f32<false>(acc[g], y4[s], kb[s][g], mf_pos(true, LAST, s == 0 && g == 0, s == 1 && g == 3));
 }
 
 // acc += h tile (LDS, columns in rotated slice order) . register-resident R blocks [J0, J1)
-template <int H, int J0, int J1>
+template <int H, int J0, int J1, bool FIRST, bool LAST>
 __device__ __forceinline__ void recurrent(f32x4 (&acc)[4], const float* hrow, const float (&wR)[H / 16][4][4]) {
     if (J0 >= J1) return;
     f32x4 a = *(const f32x4*)(hrow + 16 * J0);
@@ -280,7 +303,8 @@ __device__ __forceinline__ void recurrent(f32x4 (&acc)[4], const float* hrow, co
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) mfma_va(acc[g], a[s], wR[j][s][g]);
+            for (int g = 0; g < 4; ++g)
+                mfma_f32<true>(acc[g], a[s], wR[j][s][g], mf_pos(FIRST, LAST, j == J0 && s == 0 && g == 0, j == J1 - 1 && s == 3 && g == 3));
         a = an;
     }
 }
@@ -310,6 +334,9 @@ __device__ __forceinline__ void cluster_body(const LstmParams& p, ClusterCarry& 
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 15, g4 = lane >> 4;
+#ifdef FOV_STAMPS
+    if (blockIdx.x == 5 && tid == 0) g_stamps[MODE & 1][STAMP_STEPS - 1][0] = __builtin_amdgcn_s_memtime();   // phase entry
+#endif
     // decoder phase of the fused kernel: the h_T tile sits where the ENCODER phase's LDS layout put it; take it into
     // registers before this phase's layout (its K slice is smaller, everything behind it moves) overwrites anything
     float hcarry[BT * H / 256];
@@ -463,6 +490,7 @@ __device__ __forceinline__ void cluster_body(const LstmParams& p, ClusterCarry& 
         loff[j] = (within >> 6) * LDH + rot * 64 + (within & 63);
     }
 
+    const bool h_zero = !F2 && p.h0 == nullptr;   // (the decoder phase of the fused kernel starts from the encoder's state)
     for (int tile = group; tile < p.num_tiles && !aborted; tile += p.num_groups) {
         const int b0 = tile * BT;
         // ---- initial state (the previous tile ended on a barrier) ----
@@ -552,11 +580,11 @@ __device__ __forceinline__ void cluster_body(const LstmParams& p, ClusterCarry& 
                     acc[g][r] = bias[g] + __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(zxrs, zxoff + (unsigned)((r * p.T * 4 * H + g * H) * 4), 0, 0));
         }
         if (steps > 0) {
-            mfma_begin(acc);
-            if (LAYER) input_proj_any(acc, sX + n * LDX + 4 * g4, sKw, nq, lane);
-            else input_proj_reg(acc, y4, kb);
-            recurrent<H, 0, 4>(acc, hrow, wR);
-            mfma_end(acc);
+            if (LAYER) input_proj_any<true, true>(acc, sX + n * LDX + 4 * g4, sKw, nq, lane);
+            else input_proj_reg<true>(acc, y4, kb);
+            // a zero initial state (the encoder of every seq2seq call): h_0 . R is exactly 0 - its 4H/16 k-blocks (256 of the
+            // 352 MFMAs of an encoder step at H = 256) are skipped here and at the top of step 0
+            if (!h_zero) recurrent<H, 0, 4, true, true>(acc, hrow, wR);
         }
 
         float xr[XR];
@@ -591,18 +619,17 @@ __device__ __forceinline__ void cluster_body(const LstmParams& p, ClusterCarry& 
             }
             // ---- the part of h_{t-1} . R that needed the partner slices ----
             if (LAYER || t == 0) {
-                recurrent<H, 4, NQ>(acc, hrow, wR);
-                mfma_end(acc);   // (inside each branch: see input_proj_any)
+                if (!(h_zero && t == 0)) recurrent<H, 4, NQ, true, true>(acc, hrow, wR);
             } else {
                 // DECODE: the four partial Dense products of y_{t-1} were written before these MFMAs, which do not need y; they
                 // meet in LDS meanwhile (barrier 3 and the reads sit one k-block before the end), then y_{t-1} . K completes z_t
                 constexpr int JL = NQ - 1 > 4 ? NQ - 1 : 4;   // H = 64 has no partner slices: nothing covers, nothing to split
-                recurrent<H, 4, JL>(acc, hrow, wR);
+                recurrent<H, 4, JL, true, false>(acc, hrow, wR);
                 __syncthreads();  // barrier 3: the four partial products are in LDS
                 f32x4 part[4];
 #pragma unroll
                 for (int w2 = 0; w2 < 4; ++w2) part[w2] = *(const f32x4*)(sW + (w2 * 16 + n) * 16 + 4 * g4);
-                recurrent<H, JL, NQ>(acc, hrow, wR);
+                recurrent<H, JL, NQ, false, false>(acc, hrow, wR);
                 // outputs o = 4*ss + g4 < F_dec <= 8 live in ss = 0, 1 only
 #pragma unroll
                 for (int ss = 0; ss < 2; ++ss) y4[ss] = tanh_f(((part[0][ss] + part[1][ss]) + part[2][ss]) + part[3][ss] + bd4[ss]);
@@ -612,8 +639,7 @@ __device__ __forceinline__ void cluster_body(const LstmParams& p, ClusterCarry& 
                     for (int ss = 0; ss < 2; ++ss)
                         if (4 * ss + g4 < p.F_dec) yo[4 * ss] = y4[ss];
                 }
-                input_proj_reg(acc, y4, kb);
-                mfma_end(acc);
+                input_proj_reg<true>(acc, y4, kb);
             }
             FOV_STAMP(1);
 #pragma unroll
@@ -679,8 +705,7 @@ __device__ __forceinline__ void cluster_body(const LstmParams& p, ClusterCarry& 
             if (more) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) acc[g] = ZX ? zr[g] : (f32x4){bias[g], bias[g], bias[g], bias[g]};
-                mfma_begin(acc);
-                if (LAYER) input_proj_any(acc, sX + ((t + 1) % 3) * BT * LDX + n * LDX + 4 * g4, sKw, nq, lane);
+                if (LAYER) input_proj_any<true, false>(acc, sX + ((t + 1) % 3) * BT * LDX + n * LDX + 4 * g4, sKw, nq, lane);
             }
             FOV_STAMP(5);
             u32x2 v[NG > 0 ? NG : 1];
@@ -688,14 +713,17 @@ __device__ __forceinline__ void cluster_body(const LstmParams& p, ClusterCarry& 
             // not requested right behind the partners' publish (decoder 0.191 -> 0.188 ms over three paired runs; the
             // eight-workgroup kernels, whose stores are sc1, gain far more from the same delay - lstm_wide.hip)
             constexpr int GJ = LAYER ? 0 : 1;
-            if (more) recurrent<H, 0, GJ>(acc, hrow, wR);
-            if (do_xch) {
+            // (one branch around both MFMA runs: where two `if (more)` met, hipcc copied the accumulators between them)
+            if (more) {
+                recurrent<H, 0, GJ, true, false>(acc, hrow, wR);
+                if (do_xch) {
+#pragma unroll
+                    for (int j = 0; j < NG; ++j) v[j] = __builtin_amdgcn_raw_buffer_load_b64(xrs, goff[j], xsoff, 16);
+                }
+                recurrent<H, GJ, 4, LAYER, true>(acc, hrow, wR);   // (a ZX layer has no x . K run in front: this one opens)
+            } else if (do_xch) {
 #pragma unroll
                 for (int j = 0; j < NG; ++j) v[j] = __builtin_amdgcn_raw_buffer_load_b64(xrs, goff[j], xsoff, 16);
-            }
-            if (more) {
-                recurrent<H, GJ, 4>(acc, hrow, wR);
-                mfma_end(acc);
             }
             FOV_STAMP(11);
             if (do_xch) {
@@ -747,12 +775,11 @@ __device__ __forceinline__ void cluster_body(const LstmParams& p, ClusterCarry& 
                 f32x4 dacc[2];
                 dacc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 dacc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                asm volatile("s_nop 1" : "+v"(dacc[0]), "+v"(dacc[1]));
 #pragma unroll
                 for (int b = 0; b < NB; ++b)
 #pragma unroll
-                    for (int ss = 0; ss < 4; ++ss) mfma_vv(dacc[ss & 1], wd[b][ss], hb[b][ss]);
-                asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" : "+v"(dacc[0]), "+v"(dacc[1]));
+                    for (int ss = 0; ss < 4; ++ss)
+                        mfma_f32<false>(dacc[ss & 1], wd[b][ss], hb[b][ss], mf_pos(true, true, b == 0 && ss == 0, b == NB - 1 && ss == 3));
 #pragma unroll
                 for (int ss = 0; ss < 4; ++ss) dacc[0][ss] += dacc[1][ss];
                 *(f32x4*)(sW + (wave * 16 + n) * 16 + 4 * g4) = dacc[0];   // partial over this wave's positions
@@ -790,6 +817,9 @@ __device__ __forceinline__ void cluster_body(const LstmParams& p, ClusterCarry& 
                 }
             }
         }
+#ifdef FOV_STAMPS
+        if (blockIdx.x == 5 && tid == 0) g_stamps[MODE & 1][STAMP_STEPS - 1][1] = __builtin_amdgcn_s_memtime();   // time loop left
+#endif
         if constexpr (FUSED != 0) break;   // one tile per group (host-checked)
     }
     if constexpr (F1) {

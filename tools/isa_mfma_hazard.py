@@ -59,7 +59,7 @@ for ln, l in enumerate(lines):
     if op.startswith("v_mfma"):
         for r in regs(toks[0]):
             last_mfma_write[r] = (slot, t[:70])
-        for src in toks[1:3]:
+        for src in toks[1:4]:   # A, B and the accumulator input
             for r in regs(src):
                 w = last_valu_write.get(r)
                 if w is not None and slot - w[0] <= 2:

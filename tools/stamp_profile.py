@@ -50,6 +50,9 @@ def main():
         own = (buf[mode, 1:steps, 11].astype(np.int64) - st[1:, 5])
         print("   gather: extra sweeps per step: mean %.2f max %d; issue->own-MFMAs-done %.0f cyc, then wait+LDS %.0f cyc"
               % (spins.mean(), spins.max(), np.median(own), np.median(st[1:, 6] - buf[mode, 1:steps, 11].astype(np.int64))))
+        entry, left = int(buf[mode, 63, 0]), int(buf[mode, 63, 1])
+        print("   phase entry -> first step %.2f us, last stamped step top -> loop left %.2f us, whole phase %.1f us"
+              % ((int(st[0, 0]) - entry) / ghz * 1e-3, (left - int(st[-1, 0])) / ghz * 1e-3, (left - entry) / ghz * 1e-3))
         med = np.median(seg[1:], axis=0)
         for i, v in enumerate(med):
             print("   %-34s %8.0f cyc %7.0f ns  %5.1f%%" % (SEG[i], v, v / ghz, 100.0 * v / med.sum()))
