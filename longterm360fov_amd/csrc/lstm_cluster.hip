@@ -90,8 +90,15 @@ __device__ unsigned long long g_stamps[2][STAMP_STEPS][STAMP_SLOTS];
         }                                                                                       \
         __builtin_amdgcn_sched_barrier(0);                                                      \
     } while (0)
+#define FOV_PSTAMP(slot)                                                                        \
+    do {                                                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                      \
+        if (blockIdx.x == 5 && threadIdx.x == 0) g_stamps[MODE & 1][STAMP_STEPS - 1][slot] = __builtin_amdgcn_s_memtime(); \
+        __builtin_amdgcn_sched_barrier(0);                                                      \
+    } while (0)
 #else
 #define FOV_STAMP(slot) do { } while (0)
+#define FOV_PSTAMP(slot) do { } while (0)
 #endif
 
 struct ClusterLds {
@@ -152,7 +159,8 @@ __host__ __device__ constexpr int mf_pos(bool first_run, bool last_run, bool is_
 // Register block j holds the k-block of hidden units ((slice + j/4) mod G)*64 + (j%4)*16 .. +16:
 // the workgroup's OWN 64 units come first (j < 4), so the part of h_t . R that needs no remote
 // data can start before the gather of the partner slices has landed.
-template <int H, bool DEC_KMAP>
+// Two calls: R blocks [J0, J1) only (REST = false), then the remaining blocks, bias and K (REST = true).
+template <int H, bool DEC_KMAP, int J0, int J1, bool REST>
 __device__ __forceinline__ void load_weights(float (&wR)[H / 16][4][4], float (&bias)[4], float* sKw,
                                              const float* K, const float* R, const float* b, int F, int Fp,
                                              int col0, int slice, int lane) {
@@ -166,7 +174,7 @@ __device__ __forceinline__ void load_weights(float (&wR)[H / 16][4][4], float (&
         const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(R), 0, H * H4 * 4, 0x00020000);
         const unsigned voff = (unsigned)((4 * g4 * H4 + col0 + n) * 4);
 #pragma unroll
-        for (int j = 0; j < H / 16; ++j) {
+        for (int j = J0; j < J1; ++j) {
             const unsigned kb = (unsigned)((((slice + (j >> 2)) & (G - 1)) * 64 + (j & 3) * 16) * H4 * 4);
 #pragma unroll
             for (int s = 0; s < 4; ++s)
@@ -175,6 +183,7 @@ __device__ __forceinline__ void load_weights(float (&wR)[H / 16][4][4], float (&
                     wR[j][s][g] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rrs, voff, kb + (unsigned)((s * H4 + g * H) * 4), 0));
         }
     }
+    if constexpr (!REST) return;
     {
         const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(b), 0, b ? H4 * 4 : 0, 0x00020000);
 #pragma unroll
@@ -380,45 +389,62 @@ __device__ __forceinline__ void cluster_body(const LstmParams& p, ClusterCarry& 
     int* sFlag = (int*)(smem + L.off_flag);
     float* sKw = sK + wave * (nq * 4 + KPAD) * 256;  // this wave's K slice in B-operand order
 
-    // The weight loads go out FIRST: the header reads, the arrival ticket and the hello handshake below are a chain of
-    // dependent memory round trips (wave 0), which now run while the 300-odd weight loads are in flight instead of in
-    // front of them.
-    float wR[NQ][4][4];   // [k-block j][k-sub s][gate g], AGPR-resident
-    float bias[4];
-    load_weights<H, !LAYER>(wR, bias, sKw, Kp, Rp, bp, F, Fp, col0, slice, lane);
-
     // A layer's last step publishes nothing (no later step reads h_T from the partners), so a one-step layer
     // launch - the unit the step-wise decoders of a4 are built from - needs no exchange and no handshake.
     const bool xch_used = (G > 1) && (!LAYER || p.T > 1 || F1);
     // Epoch tags continue from the workspace header (xch_common.h): no memset between launches.  A workspace whose
     // sticky timeout word is set is poisoned: the body is skipped (fail-stop) until fov_check_status clears it.
+    //
+    // Order (round 3, prologue stamps of tools/stamp_profile.py): thread 0 requests the header words, the first 48 weight
+    // loads go out, thread 0 PUBLISHES its hello word and counts the workgroup as arrived (xch_common.h), the other
+    // 300-odd weight loads of every wave follow (5-6 us), and only then are the partners' hello words polled.  With the publish behind all weight
+    // loads every group waited for its slowest member's loads PLUS a store-to-visible round trip: 5.6 us between the
+    // ticket and the end of the handshake.
     unsigned* sXch = (unsigned*)(sFlag + 4);     // base / launch index of this launch (thread 0 -> all, xch_common.h)
-    const unsigned arrival = (xch_used && !F2) ? xch_arrive(p.status, sXch) : 0u;
-    const bool poisoned = xch_used && !F2 && xch_poisoned(p.status);   // one wave-wide load per wave; wave 0's value decides (sFlag[0])
-    if (tid == 0) { sFlag[0] = (poisoned || (F2 && cy.aborted)) ? 1 : 0; sFlag[1] = 0; }
-    if (xch_used && !F2 && !poisoned && tid < 64) {   // wave 0 only: thread 0 has just written sXch (same wave: program order)
-        const unsigned epoch_base = sXch[0];
-        // hello handshake (safe sc1 protocol): do all members of this group sit on one XCD?
-        unsigned long long* hello = p.xch + (size_t)p.num_groups * 2 * BT * H + (size_t)group * G;
-        const unsigned mine = xcc_id();
-        const unsigned long long hello_tag = (unsigned long long)epoch_base + 1ull;   // larger than any tag of an earlier launch
-        if (tid == 0) st_granule(hello + slice, (hello_tag << 32) | mine);
-        if (tid < G) {
-            unsigned long long hv = 0;
-            unsigned spins = 0;
-            while (true) {
-                hv = ld_granule(hello + tid);
-                if ((hv >> 32) == hello_tag) break;
-                if (++spins > SPIN_LIMIT || ((spins & 63u) == 0 && xch_poisoned(p.status))) {
-                    xch_give_up(p.status);
-                    sFlag[0] = 1;
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(4);
-            }
-            if ((unsigned)hv != mine) sFlag[1] = 1;   // a partner lives on another XCD
-        }
+    const bool hdr = xch_used && !F2;
+    // thread 0 requests the header words; their round trip runs under the first weight loads
+    unsigned hdr_base = 0, hdr_launch = 0;
+    if (hdr && tid == 0) {
+        hdr_base = xch_status_load(p.status + ST_EPOCH);
+        hdr_launch = xch_status_load(p.status + ST_LAUNCHES);
     }
+    float wR[NQ][4][4];   // [k-block j][k-sub s][gate g], AGPR-resident
+    float bias[4];
+    constexpr int JA = NQ < 3 ? NQ : 3;
+    load_weights<H, !LAYER, 0, JA, false>(wR, bias, sKw, Kp, Rp, bp, F, Fp, col0, slice, lane);
+    unsigned long long* hello = p.xch + (size_t)p.num_groups * 2 * BT * H + (size_t)group * G;
+    const unsigned my_xcc = xcc_id();
+    if (hdr && tid == 0) {
+        sXch[0] = hdr_base;
+        sXch[1] = hdr_launch;
+        // hello handshake (safe sc1 protocol): do all members of this group sit on one XCD?  The tag is larger than any tag
+        // of an earlier launch.
+        st_granule(hello + slice, (((unsigned long long)hdr_base + 1ull) << 32) | my_xcc);
+        xch_count_arrival(p.status);   // both header words have landed (stored above)
+    }
+    FOV_PSTAMP(3);
+    load_weights<H, !LAYER, JA, NQ, true>(wR, bias, sKw, Kp, Rp, bp, F, Fp, col0, slice, lane);
+    FOV_PSTAMP(2);
+    const bool poisoned = hdr && xch_poisoned(p.status);   // one wave-wide load per wave; wave 0's value decides (sFlag[0])
+    const unsigned arrival = 0;
+    if (tid == 0) { sFlag[0] = (poisoned || (F2 && cy.aborted)) ? 1 : 0; sFlag[1] = 0; }
+    if (hdr && !poisoned && tid < G) {   // (lanes of wave 0: thread 0 has just written sFlag, program order)
+        const unsigned long long hello_tag = (unsigned long long)sXch[0] + 1ull;
+        unsigned long long hv = 0;
+        unsigned spins = 0;
+        while (true) {
+            hv = ld_granule(hello + tid);
+            if ((hv >> 32) == hello_tag) break;
+            if (++spins > SPIN_LIMIT || ((spins & 63u) == 0 && xch_poisoned(p.status))) {
+                xch_give_up(p.status);
+                sFlag[0] = 1;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(4);
+        }
+        if ((unsigned)hv != my_xcc) sFlag[1] = 1;   // a partner lives on another XCD
+    }
+    FOV_PSTAMP(4);
     // zero the x tiles once: pad columns [F, Fp) are never written afterwards
     for (int i = tid; i < NXBUF * BT * LDX; i += 256) sX[i] = 0.f;
 
@@ -460,6 +486,7 @@ __device__ __forceinline__ void cluster_body(const LstmParams& p, ClusterCarry& 
     }
 
     __syncthreads();
+    FOV_PSTAMP(5);
     XchTicket ticket = {0u, 0u, 0u};
     if (xch_used && !F2) ticket = xch_ticket(sXch, arrival);
     if constexpr (F2) ticket = cy.ticket;
@@ -567,6 +594,7 @@ __device__ __forceinline__ void cluster_body(const LstmParams& p, ClusterCarry& 
                 y4[ss] = (4 * ss + g4 < F && b0 + n < p.B) ? p.dec_in0[(size_t)(b0 + n) * F + 4 * ss + g4] : 0.f;
         }
         __syncthreads();
+        FOV_PSTAMP(6);
 
         // ---- pre-activations of step 0 that need no remote data ----
         f32x4 acc[4];
@@ -767,7 +795,6 @@ __device__ __forceinline__ void cluster_body(const LstmParams& p, ClusterCarry& 
             if (!LAYER) {
 #endif
                 // y_t = tanh(h_t . Wd + bias) on the matrix pipe (see the wd[] comment above)
-                const int O = p.F_dec;
                 f32x4 hb[NB];
                 const float* hq = hrow + 16 * NB * wave;
 #pragma unroll

@@ -8,8 +8,9 @@
 //     [256 + kXchBytes, ...)   whatever else the entry point keeps in its workspace (packed weights, carried state)
 //
 // Epoch tags are MONOTONE ACROSS LAUNCHES: a launch reads the base from the header, every tag it writes lies in
-// (base, base + span], and the last workgroup to ARRIVE (= the moment every workgroup has read the base) writes
-// base + span for the next launch - no workgroup waits for another at either end of a kernel.  Stale granules of any earlier
+// (base, base + span], and block 0 writes base + span for the next launch at its end, once the arrival count shows that
+// every workgroup has read the base (a fire-and-forget add at entry) - no workgroup waits for another at the start of a
+// kernel.  Stale granules of any earlier
 // launch (of any kernel, any shape) therefore carry smaller tags than anything a later launch waits for, and the
 // per-call memset of the granule area - a 5 us fill kernel in front of every launch - is gone.
 //
@@ -22,7 +23,7 @@ namespace fov {
 
 enum : int {
     ST_TIMEOUT = 0,     // != 0: a bounded in-kernel wait gave up; cleared only by fov_check_status
-    ST_ARRIVED = 1,     // workgroups of the running launch that have read the header (self-resetting)
+    ST_ARRIVED = 1,     // workgroups of the running launch that have read the header (reset by xch_settle)
     ST_LAUNCHES = 2,    // exchange launches whose workgroups have all arrived
     ST_EPOCH = 3,       // epoch base: every tag written by launches < ST_LAUNCHES is <= this value
     ST_SAFE0 = 4,       // ST_SAFE0 + (launch & 1): workgroups of that launch on the placement-independent (sc1) exchange
@@ -39,29 +40,34 @@ __device__ __forceinline__ void xch_give_up(unsigned* status) {
 }
 
 // What a workgroup takes from the header when it starts.  `base` and `launch` are uniform over the grid: the words are
-// only rewritten by the LAST workgroup to arrive, i.e. after every workgroup of the launch has read them.
+// only rewritten after every workgroup of the launch has read them (xch_settle).
 struct XchTicket {
     unsigned base;      // epoch base of this launch: its tags lie in (base, base + span]
     unsigned launch;    // index of this launch on the workspace
-    unsigned arrival;   // thread 0 only: this workgroup's arrival number
+    unsigned arrival;   // unused since round 3 (kept for the call sites' signature)
 };
 
-// Kernel entry, in two halves around the prologue's first workgroup barrier: THREAD 0 reads the header, takes the
-// arrival ticket and leaves base / launch in two LDS words (`lds2`); after the barrier every thread picks them up with
-// xch_ticket().  Only one thread reads the header: a wave that starts late must not read it by itself - the last
-// arriver (of another workgroup) may already have rewritten it for the next launch.
+// Kernel entry, in two halves around the prologue's first workgroup barrier: THREAD 0 reads the header, counts its
+// workgroup as arrived and leaves base / launch in two LDS words (`lds2`); after the barrier every thread picks them up
+// with xch_ticket().  Only one thread reads the header: a wave that starts late must not read it by itself - it may
+// already have been rewritten for the next launch.
+// The arrival is a fire-and-forget add (round 3).  It used to be a RETURNING add - "the last arriver settles" - which every
+// workgroup waited for at its entry: 256 returning adds on one word take 3 us to drain (11-13 ns each,
+// MI355X_MICROARCH.md price list, row fanin), in front of every exchange launch.
+__device__ __forceinline__ void xch_count_arrival(unsigned* status) {
+    __hip_atomic_fetch_add(status + ST_ARRIVED, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // result unused: no return, no wait
+}
 __device__ __forceinline__ unsigned xch_arrive(unsigned* status, unsigned* lds2) {
-    unsigned arrival = 0;
     if (threadIdx.x == 0) {
         unsigned base = xch_status_load(status + ST_EPOCH);
         unsigned launch = xch_status_load(status + ST_LAUNCHES);
-        // both words are read before the ticket is taken: the last arriver may rewrite them at once
+        // both words are read before the workgroup counts as arrived: once all have, the header may be rewritten
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(base), "+v"(launch)::"memory");
-        arrival = __hip_atomic_fetch_add(status + ST_ARRIVED, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        xch_count_arrival(status);
         lds2[0] = base;
         lds2[1] = launch;
     }
-    return arrival;
+    return 0u;
 }
 __device__ __forceinline__ XchTicket xch_ticket(const unsigned* lds2, unsigned arrival) {
     // readfirstlane: the words are the same for every lane, but a value loaded from LDS is divergent to the compiler, and an
@@ -78,10 +84,21 @@ __device__ __forceinline__ XchTicket xch_ticket(const unsigned* lds2, unsigned a
     t.arrival = arrival;
     return t;
 }
-// Thread 0 calls it once, any time later (the kernels do at their very end, when the ticket's round trip is long over):
-// the last arriver publishes the header of the NEXT launch.  Nothing here waits for the other workgroups.
+// Every workgroup calls it at its very end; thread 0 of BLOCK 0 publishes the header of the NEXT launch once the
+// arrival count shows that every workgroup of this launch has read the current one - hundreds of microseconds ago for a
+// persistent kernel, so the one load it takes is the whole cost.  The wait is bounded like every other one: a grid that
+// is not co-resident (block 0 done before the last block could start) poisons the workspace instead of hanging.
 __device__ __forceinline__ void xch_settle(unsigned* status, const XchTicket& t, unsigned span) {
-    if (threadIdx.x == 0 && t.arrival == gridDim.x * gridDim.y * gridDim.z - 1u) {
+    if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) {
+        const unsigned grid = gridDim.x * gridDim.y * gridDim.z;
+        unsigned spins = 0;
+        while (xch_status_load(status + ST_ARRIVED) != grid) {
+            if (++spins > (1u << 20)) {
+                xch_give_up(status);
+                return;
+            }
+            __builtin_amdgcn_s_sleep(8);
+        }
         __hip_atomic_store(status + ST_ARRIVED, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(status + ST_SAFE0 + ((t.launch + 1u) & 1u), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // next launch's counter
         __hip_atomic_store(status + ST_EPOCH, t.base + span, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

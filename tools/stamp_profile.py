@@ -53,6 +53,10 @@ def main():
         entry, left = int(buf[mode, 63, 0]), int(buf[mode, 63, 1])
         print("   phase entry -> first step %.2f us, last stamped step top -> loop left %.2f us, whole phase %.1f us"
               % ((int(st[0, 0]) - entry) / ghz * 1e-3, (left - int(st[-1, 0])) / ghz * 1e-3, (left - entry) / ghz * 1e-3))
+        pro = buf[mode, 63, :7].astype(np.int64)
+        names = ["entry", "loop left", "weights issued (K in LDS)", "arrival ticket taken", "hello handshake done", "first barrier passed", "tile state + x tiles in LDS"]
+        print("   prologue (us after phase entry): " + ", ".join("%s %.2f" % (names[i], (pro[i] - pro[0]) / ghz * 1e-3) for i in (2, 3, 4, 5, 6))
+              + ", first step %.2f" % ((int(st[0, 0]) - pro[0]) / ghz * 1e-3))
         med = np.median(seg[1:], axis=0)
         for i, v in enumerate(med):
             print("   %-34s %8.0f cyc %7.0f ns  %5.1f%%" % (SEG[i], v, v / ghz, 100.0 * v / med.sum()))
