@@ -343,6 +343,7 @@ __device__ __forceinline__ void cluster_body(const LstmParams& p, ClusterCarry& 
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 15, g4 = lane >> 4;
+    constexpr unsigned OORB = 0x80000000u;   // buffer-load offset no descriptor covers: reads as 0
 #ifdef FOV_STAMPS
     if (blockIdx.x == 5 && tid == 0) g_stamps[MODE & 1][STAMP_STEPS - 1][0] = __builtin_amdgcn_s_memtime();   // phase entry
 #endif
@@ -445,6 +446,23 @@ __device__ __forceinline__ void cluster_body(const LstmParams& p, ClusterCarry& 
         if ((unsigned)hv != my_xcc) sFlag[1] = 1;   // a partner lives on another XCD
     }
     FOV_PSTAMP(4);
+    // x_0, x_1 of the FIRST tile are requested here, in front of the prologue's barrier (their round trip used to sit between
+    // that barrier and the tile's: 1.5 us of the launch's fixed part)
+    float xpre[2][XR];
+    {
+        const int xrw0 = tid >> 4, xcl0 = tid & 15;
+        const bool xuse0 = LAYER && !ZX;
+        const int b00 = group * BT;
+        const int live0 = (group < p.num_tiles) ? (p.B - b00 < BT ? p.B - b00 : BT) : 0;
+        const __amdgpu_buffer_rsrc_t xg0 = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(xuse0 && live0 > 0 ? p.x + (size_t)b00 * p.T * F : nullptr), 0, xuse0 ? live0 * p.T * F * 4 : 0, 0x00020000);
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+            for (int i = 0; i < XR; ++i)
+                xpre[tt][i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
+                    xg0, (tt < steps && xcl0 + 16 * i < F) ? (unsigned)((xrw0 * p.T * F + xcl0 + 16 * i) * 4) : OORB, (unsigned)(tt * F * 4), 0));
+    }
     // zero the x tiles once: pad columns [F, Fp) are never written afterwards
     for (int i = tid; i < NXBUF * BT * LDX; i += 256) sX[i] = 0.f;
 
@@ -459,7 +477,6 @@ __device__ __forceinline__ void cluster_body(const LstmParams& p, ClusterCarry& 
     constexpr int NB = H / 64;
     float wd[NB][4];
     float bd4[4];
-    constexpr unsigned OORB = 0x80000000u;   // buffer-load offset no descriptor covers: reads as 0
     if (!LAYER) {
         const int O = p.F_dec;
         // unconditional buffer loads (out-of-range offset = 0): a load inside a branch is waited for at the merge
@@ -549,7 +566,7 @@ __device__ __forceinline__ void cluster_body(const LstmParams& p, ClusterCarry& 
                 const int row = i / H, pos = i - row * H;
                 const int unit = ((slice + (pos >> 6)) & (G - 1)) * 64 + (pos & 63);
                 if constexpr (F2) hv[q] = hcarry[q];   // the tile the encoder phase left in LDS (same rotated column order)
-                else hv[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(h0rs, (unsigned)((row * H + unit) * 4), 0, 0));
+                else hv[q] = h_zero ? 0.f : __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(h0rs, (unsigned)((row * H + unit) * 4), 0, 0));
             }
 #pragma unroll
             for (int q = 0; q < BT * H / 256; ++q) {
@@ -574,11 +591,18 @@ __device__ __forceinline__ void cluster_body(const LstmParams& p, ClusterCarry& 
         float* xl = sX + xrw * LDX + xcl;
         if (xuse) {
             float x2[2][XR];
+            if (tile == group) {
 #pragma unroll
-            for (int tt = 0; tt < 2; ++tt)
+                for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
-                for (int i = 0; i < XR; ++i)
-                    x2[tt][i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xgrs, tt < steps ? xoff[i] : OORB, (unsigned)(tt * F * 4), 0));
+                    for (int i = 0; i < XR; ++i) x2[tt][i] = xpre[tt][i];
+            } else {
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                    for (int i = 0; i < XR; ++i)
+                        x2[tt][i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xgrs, tt < steps ? xoff[i] : OORB, (unsigned)(tt * F * 4), 0));
+            }
 #pragma unroll
             for (int tt = 0; tt < 2; ++tt)
                 if (tt < steps) {
@@ -719,7 +743,10 @@ __device__ __forceinline__ void cluster_body(const LstmParams& p, ClusterCarry& 
                 }
             }
             FOV_STAMP(2);
-            __syncthreads();  // barrier 1: every wave is done reading sH and the current x tile
+            // (No barrier in front of these stores since round 3.  The own-slice columns of the tile were last read by the
+            // own-slice MFMAs of the previous step, which every wave finished before that step's barrier 2; the partner
+            // columns, which other waves may still be reading for z_t, are only written behind barrier 1b; the x tile written
+            // at the top of this step is one of three and was last read three steps ago.)
             FOV_STAMP(3);
 #pragma unroll
             for (int r = 0; r < 4; ++r) sH[(4 * g4 + r) * LDH + wave * 16 + n] = hcur[r];
@@ -748,7 +775,9 @@ __device__ __forceinline__ void cluster_body(const LstmParams& p, ClusterCarry& 
 #pragma unroll
                     for (int j = 0; j < NG; ++j) v[j] = __builtin_amdgcn_raw_buffer_load_b64(xrs, goff[j], xsoff, 16);
                 }
-                recurrent<H, GJ, 4, LAYER, true>(acc, hrow, wR);   // (a ZX layer has no x . K run in front: this one opens)
+                // (a ZX layer has no x . K run in front: this run opens; with partner slices the next reader of the accumulators is
+                // the partner-slice MFMA run: no closing wait states)
+                recurrent<H, GJ, 4, LAYER, (G == 1)>(acc, hrow, wR);
             } else if (do_xch) {
 #pragma unroll
                 for (int j = 0; j < NG; ++j) v[j] = __builtin_amdgcn_raw_buffer_load_b64(xrs, goff[j], xsoff, 16);
