@@ -217,6 +217,38 @@ __device__ __forceinline__ void load_weights(float (&wR)[H / 16][4][4], float (&
         }
 }
 
+// One k-block (16 loads) of the wave's R slice; `j` is a constant after unrolling.
+template <int H>
+__device__ __forceinline__ void load_r_block(float (&wR)[H / 16][4][4], int j, const float* R, int col0, int slice, int lane) {
+    constexpr int G = H / 64;
+    const int n = lane & 15, g4 = lane >> 4;
+    const int H4 = 4 * H;
+    const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(R), 0, H * H4 * 4, 0x00020000);
+    const unsigned voff = (unsigned)((4 * g4 * H4 + col0 + n) * 4);
+    const unsigned kb = (unsigned)((((slice + (j >> 2)) & (G - 1)) * 64 + (j & 3) * 16) * H4 * 4);
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            wR[j][s][g] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rrs, voff, kb + (unsigned)((s * H4 + g * H) * 4), 0));
+}
+// DECODE: bias and the two K blocks of this lane (input row k = 4*s + g4, see load_weights) straight into registers
+template <int H>
+__device__ __forceinline__ void load_dec_small(float (&bias)[4], f32x4 (&kb)[2], const float* K, const float* b, int F, int col0, int lane) {
+    const int n = lane & 15, g4 = lane >> 4;
+    const int H4 = 4 * H;
+    const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(b), 0, b ? H4 * 4 : 0, 0x00020000);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bias[g] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(brs, (unsigned)((g * H + col0 + n) * 4), 0, 0));
+    const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(K), 0, F * H4 * 4, 0x00020000);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const unsigned voff = (unsigned)(((4 * s + g4) * H4 + col0 + n) * 4);   // k >= F: past the descriptor
+#pragma unroll
+        for (int g = 0; g < 4; ++g) kb[s][g] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(krs, voff + (unsigned)(g * H * 4), 0, 0));
+    }
+}
+
 // acc += A(16 x Fp, LDS rows of stride ldx) . Kslice(LDS); B reads run two (q,s) blocks ahead.
 // No clamping: the K slice carries KPAD spare blocks per wave and the x tiles a spare tail, so
 // the run-ahead reads of the last iterations stay inside LDS (their values are never used) and
@@ -412,7 +444,16 @@ __device__ __forceinline__ void cluster_body(const LstmParams& p, ClusterCarry& 
     float wR[NQ][4][4];   // [k-block j][k-sub s][gate g], AGPR-resident
     float bias[4];
     constexpr int JA = NQ < 3 ? NQ : 3;
-    load_weights<H, !LAYER, 0, JA, false>(wR, bias, sKw, Kp, Rp, bp, F, Fp, col0, slice, lane);
+    // Decoder phase of the fused kernel: the R slice is STREAMED - three k-blocks here, the others three blocks ahead of the
+    // MFMAs of z_0 that consume them (256 loads per wave take 4 us, z_0's 264 MFMAs another 4: now side by side); bias, K
+    // and the Dense kernel go out first and stay in registers (no LDS round trip, no barrier).
+    constexpr int STREAM_LA = 3;
+    f32x4 kb[2];   // DECODE: the two K-slice blocks of this lane (loop invariant)
+    if constexpr (F2) {
+        load_dec_small<H>(bias, kb, Kp, bp, F, col0, lane);
+    } else {
+        load_weights<H, !LAYER, 0, JA, false>(wR, bias, sKw, Kp, Rp, bp, F, Fp, col0, slice, lane);
+    }
     unsigned long long* hello = p.xch + (size_t)p.num_groups * 2 * BT * H + (size_t)group * G;
     const unsigned my_xcc = xcc_id();
     if (hdr && tid == 0) {
@@ -424,7 +465,7 @@ __device__ __forceinline__ void cluster_body(const LstmParams& p, ClusterCarry& 
         xch_count_arrival(p.status);   // both header words have landed (stored above)
     }
     FOV_PSTAMP(3);
-    load_weights<H, !LAYER, JA, NQ, true>(wR, bias, sKw, Kp, Rp, bp, F, Fp, col0, slice, lane);
+    if constexpr (!F2) load_weights<H, !LAYER, JA, NQ, true>(wR, bias, sKw, Kp, Rp, bp, F, Fp, col0, slice, lane);
     FOV_PSTAMP(2);
     const bool poisoned = hdr && xch_poisoned(p.status);   // one wave-wide load per wave; wave 0's value decides (sFlag[0])
     const unsigned arrival = 0;
@@ -495,8 +536,10 @@ __device__ __forceinline__ void cluster_body(const LstmParams& p, ClusterCarry& 
         for (int ss = 0; ss < 4; ++ss)
             bd4[ss] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(bdrs, (4 * ss + g4 < O) ? (unsigned)((4 * ss + g4) * 4) : OORB, 0, 0));
     }
-    f32x4 kb[2];   // DECODE: the two K-slice blocks of this lane (loop invariant)
-    if (!LAYER) {
+    if constexpr (F2) {
+#pragma unroll
+        for (int j = 0; j < STREAM_LA; ++j) load_r_block<H>(wR, j, Rp, col0, slice, lane);
+    } else if (!LAYER) {
         __syncthreads();   // K slice written by load_weights above
         kb[0] = *(const f32x4*)(sKw + lane * 4);
         kb[1] = *(const f32x4*)(sKw + 256 + lane * 4);
@@ -613,9 +656,13 @@ __device__ __forceinline__ void cluster_body(const LstmParams& p, ClusterCarry& 
         }
         f32x4 y4 = (f32x4){0.f, 0.f, 0.f, 0.f};   // DECODE: y_{t-1}[n][4*s + g4], the A fragment of y . K
         if (!LAYER) {
+            // (buffer loads with an out-of-range offset for the masked elements: a `cond ? load : 0` sits in a branch whose
+            // merge waits for every older load - here the streamed R slice)
+            const __amdgpu_buffer_rsrc_t y0rs = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<float*>(p.dec_in0 + (size_t)b0 * F), 0, live_rows * F * 4, 0x00020000);
 #pragma unroll
             for (int ss = 0; ss < 4; ++ss)
-                y4[ss] = (4 * ss + g4 < F && b0 + n < p.B) ? p.dec_in0[(size_t)(b0 + n) * F + 4 * ss + g4] : 0.f;
+                y4[ss] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(y0rs, (4 * ss + g4 < F) ? (unsigned)((n * F + 4 * ss + g4) * 4) : OORB, 0, 0));
         }
         __syncthreads();
         FOV_PSTAMP(6);
@@ -636,7 +683,25 @@ __device__ __forceinline__ void cluster_body(const LstmParams& p, ClusterCarry& 
             else input_proj_reg<true>(acc, y4, kb);
             // a zero initial state (the encoder of every seq2seq call): h_0 . R is exactly 0 - its 4H/16 k-blocks (256 of the
             // 352 MFMAs of an encoder step at H = 256) are skipped here and at the top of step 0
-            if (!h_zero) recurrent<H, 0, 4, true, true>(acc, hrow, wR);
+            if constexpr (F2) {
+                // the whole of h_T . R here (the loop's first partner-slice run is skipped), block j + 3 requested before the
+                // MFMAs of block j
+                f32x4 a = *(const f32x4*)hrow;
+#pragma unroll
+                for (int j = 0; j < NQ; ++j) {
+                    if (j + STREAM_LA < NQ) load_r_block<H>(wR, j + STREAM_LA, Rp, col0, slice, lane);
+                    f32x4 an = a;
+                    if (j + 1 < NQ) an = *(const f32x4*)(hrow + 16 * (j + 1));
+#pragma unroll
+                    for (int s2 = 0; s2 < 4; ++s2)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g)
+                            mfma_f32<true>(acc[g], a[s2], wR[j][s2][g], mf_pos(false, true, false, j == NQ - 1 && s2 == 3 && g == 3));
+                    a = an;
+                }
+            } else if (!h_zero) {
+                recurrent<H, 0, 4, true, true>(acc, hrow, wR);
+            }
         }
 
         float xr[XR];
@@ -671,7 +736,7 @@ __device__ __forceinline__ void cluster_body(const LstmParams& p, ClusterCarry& 
             }
             // ---- the part of h_{t-1} . R that needed the partner slices ----
             if (LAYER || t == 0) {
-                if (!(h_zero && t == 0)) recurrent<H, 4, NQ, true, true>(acc, hrow, wR);
+                if (!((h_zero || F2) && t == 0)) recurrent<H, 4, NQ, true, true>(acc, hrow, wR);
             } else {
                 // DECODE: the four partial Dense products of y_{t-1} were written before these MFMAs, which do not need y; they
                 // meet in LDS meanwhile (barrier 3 and the reads sit one k-block before the end), then y_{t-1} . K completes z_t
