@@ -503,6 +503,9 @@ def main():
                     help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the N > 1 path "
                          "with several ranks on ONE GPU)")
     ap.add_argument("--dry-run", action="store_true", help="launch plumbing only: no GPU work (CPU tests)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="N = 1 only: start this rank under torch.distributed.run on the nccl (= RCCL) backend anyway and take the "
+                         "data-parallel branch of the training modes at world size 1 (FOV_FORCE_DIST=1)")
     ap.add_argument("--mode", default="infer",
                     choices=["infer", "train", "train_mixing", "infer_mixing", "config1", "convlstm", "a10"],
                     help="infer (default, the BASELINE metric): encoder + autoregressive decoder; train: one "
@@ -517,7 +520,9 @@ def main():
     # process per GPU, RCCL rendezvous on 127.0.0.1) BEFORE anything in this process touches the GPU; rank 0's JSON
     # line comes through the inherited stdout and the child's exit code is returned.  Under a launcher (WORLD_SIZE
     # set) --gpus must agree with it.
-    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+    if args.force_dist:
+        os.environ["FOV_FORCE_DIST"] = "1"
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.force_dist):
         import socket
         import subprocess
         with socket.socket() as sock:
@@ -532,7 +537,7 @@ def main():
     if world != args.gpus:
         sys.stderr.write("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks\n" % (args.gpus, world))
         sys.exit(2)
-    use_dist = world > 1
+    use_dist = world > 1 or args.force_dist
     if args.dry_run:
         if use_dist:
             import torch.distributed as dist

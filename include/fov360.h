@@ -398,6 +398,11 @@ int fov_adam_step_guarded(float* params, const float* grads, float* m, float* v,
                           const void* guard2, fov_stream_t stream);
 int fov_rmsprop_step_guarded(float* params, const float* grads, float* accum, int64_t n, float lr, float rho, float eps,
                              const void* guard0, const void* guard1, const void* guard2, fov_stream_t stream);
+/* Data-parallel training (the all-reduce of model.fit's gradients, given_others_gt_mean_var_seq2seq.py:494-506):
+ * *out = 1.0f if the timeout word of one of the workspaces is set, else 0.0f.  The trainers keep `out` inside the flat
+ * gradient buffer: after the SUM all-reduce it is nonzero on EVERY rank if any rank's step failed, and handed to the
+ * guarded optimizer as its guard (a nonzero float is a nonzero word) all replicas skip the update together. */
+int fov_guard_flag(const void* guard0, const void* guard1, const void* guard2, float* out, fov_stream_t stream);
 
 /* =======================================================================================
  * ConvLSTM2D seq2seq building blocks (a8/a9) - mycode/convlstm_seq2seq.py:100-126,146-165 (ConvLSTM2D),

@@ -77,6 +77,7 @@ SIGNATURES = {
     "fov_sample_refeed_bwd": (_I, [_P, ctypes.c_int64] + [_P] * 4 + [_I] * 5 + [_P]),
     "fov_adam_step": (_I, [_P] * 4 + [ctypes.c_int64] + [ctypes.c_float] * 4 + [ctypes.c_int64, _P]),
     "fov_rmsprop_step": (_I, [_P] * 3 + [ctypes.c_int64] + [ctypes.c_float] * 3 + [_P]),
+    "fov_guard_flag": (_I, [_P] * 5),
     "fov_adam_step_guarded": (_I, [_P] * 4 + [ctypes.c_int64] + [ctypes.c_float] * 4 + [ctypes.c_int64] + [_P] * 4),
     "fov_rmsprop_step_guarded": (_I, [_P] * 3 + [ctypes.c_int64] + [ctypes.c_float] * 3 + [_P] * 4),
     "fov_conv2d_fwd": (_I, [_P, ctypes.c_int64, ctypes.c_int64, _P, _P, _P, _P] + [_I] * 8 + [_P]),

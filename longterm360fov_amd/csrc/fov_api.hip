@@ -681,6 +681,12 @@ int fov_adam_step_guarded(float* params, const float* grads, float* m, float* v,
     return adam_step(params, grads, m, v, (long)n, (float)lr_t, beta1, beta2, eps, guards, (hipStream_t)stream);
 }
 
+int fov_guard_flag(const void* guard0, const void* guard1, const void* guard2, float* out, fov_stream_t stream) {
+    if (!out) { set_error("fov_guard_flag: invalid argument"); return FOV_ERR_INVALID; }
+    const unsigned* guards[3] = {(const unsigned*)guard0, (const unsigned*)guard1, (const unsigned*)guard2};
+    return guard_flag(guards, out, (hipStream_t)stream);
+}
+
 int fov_adam_step(float* params, const float* grads, float* m, float* v, int64_t n, float lr, float beta1,
                   float beta2, float eps, int64_t step, fov_stream_t stream) {
     return fov_adam_step_guarded(params, grads, m, v, n, lr, beta1, beta2, eps, step, nullptr, nullptr, nullptr, stream);

@@ -185,6 +185,7 @@ int adam_step(float* p, const float* g, float* m, float* v, long n, float lr_t, 
               const unsigned* const* guards, hipStream_t stream);   // guards: NULL or three (nullable) timeout words
 int rmsprop_step(float* p, const float* g, float* a, long n, float lr, float rho, float eps, const unsigned* const* guards,
                  hipStream_t stream);
+int guard_flag(const unsigned* const* guards, float* out, hipStream_t stream);
 int act_fwd(const float* x, float* y, long n, int activation, hipStream_t stream);
 int gauss_nll_grad(const float* mu, const float* var, const float* y, float* loss, float* dmu, float* dvar, int B, int Ty,
                    int fps, float scale, float* scratch, size_t scratch_floats, hipStream_t stream);

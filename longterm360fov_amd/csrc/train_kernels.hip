@@ -458,6 +458,18 @@ __device__ __forceinline__ bool optimizer_poisoned(const unsigned* g0, const uns
     return (g0 && *g0 != 0u) || (g1 && *g1 != 0u) || (g2 && *g2 != 0u);
 }
 
+// data parallelism: this rank's guard words as ONE float slot of the gradient buffer, so that the SUM all-reduce of that
+// buffer tells every rank whether ANY rank's step failed and all of them skip (or apply) the update together
+__global__ void guard_flag_kernel(const unsigned* g0, const unsigned* g1, const unsigned* g2, float* out) {
+    *out = optimizer_poisoned(g0, g1, g2) ? 1.f : 0.f;
+}
+int guard_flag(const unsigned* const* guards, float* out, hipStream_t stream) {
+    hipLaunchKernelGGL(guard_flag_kernel, dim3(1), dim3(1), 0, stream, guards[0], guards[1], guards[2], out);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_error("guard_flag launch: %s", hipGetErrorString(e)); return FOV_ERR_LAUNCH; }
+    return FOV_OK;
+}
+
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, long n, float lr_t, float b1, float b2, float eps,
                                                    const unsigned* g0, const unsigned* g1, const unsigned* g2) {

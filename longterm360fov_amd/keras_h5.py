@@ -34,6 +34,7 @@ class H5Error(ValueError):
 class _File:
     def __init__(self, data):
         self.d = data
+        self.skipped_attributes = []   # (name, reason) of attributes whose datatype is not decoded
         if data[:8] != SIGNATURE:
             raise H5Error("not an HDF5 file (signature)")
         ver = data[8]
@@ -154,7 +155,11 @@ class _File:
         if cls == 3:
             return "S", size
         if cls == 9:
-            raise H5Error("variable-length data (strings) is not supported: Keras writes fixed-length byte strings")
+            # variable-length: h5py stores a Python bytes / str SCALAR this way (Keras: backend, keras_version, model_config,
+            # training_config); each element is a 16-byte global-heap reference {length u32, collection address u64, index u32}
+            if (bits0 & 0x0F) != 1:
+                raise H5Error("variable-length sequences (non-string) are not supported")
+            return "V", 16
         raise H5Error("datatype class %d not supported" % cls)
 
     def dataspace(self, o):
@@ -170,8 +175,30 @@ class _File:
         _ = flags
         return tuple(self.u64(start + 8 * i) for i in range(rank))
 
+    def global_heap_object(self, addr, index):
+        """Bytes of object `index` of the global heap collection at `addr` (HDF5 file format III.E)."""
+        if self.d[addr:addr + 4] != b"GCOL":
+            raise H5Error("bad global heap collection signature")
+        size = self.u64(addr + 8)
+        o, end = addr + 16, addr + size
+        while o + 16 <= end:
+            idx, osz = self.u16(o), self.u64(o + 8)
+            if idx == 0:      # free space: end of the used part
+                break
+            if idx == index:
+                return bytes(self.d[o + 16:o + 16 + osz])
+            o += 16 + ((osz + 7) & ~7)
+        raise H5Error("global heap object %d not found" % index)
+
     def _array(self, kind, size, shape, raw_off):
         n = int(np.prod(shape)) if shape else 1
+        if kind == "V":
+            vals = []
+            for i in range(n):
+                o = raw_off + 16 * i
+                ln, addr, idx = self.u32(o), self.u64(o + 4), self.u32(o + 12)
+                vals.append(b"" if (ln == 0 or addr == 0) else self.global_heap_object(addr, idx)[:ln])
+            return np.array(vals, dtype=object).reshape(shape)
         if kind == "S":
             raw = self.d[raw_off:raw_off + n * size]
             vals = [raw[i * size:(i + 1) * size].split(b"\x00", 1)[0] for i in range(n)]
@@ -181,33 +208,48 @@ class _File:
 
     # ---- attributes and datasets ----
     def attributes(self, entry):
+        """name -> array.  An attribute whose datatype this reader does not decode (compound, non-string variable length,
+        ...) maps to None instead of failing the whole object: Keras files carry attributes the weights do not need."""
         out = {}
         for mtype, _, body, _ in self.messages(entry["header"]):
             if mtype != 0x000C:
                 continue
-            ver = self.u8(body)
-            nsz, tsz, ssz = self.u16(body + 2), self.u16(body + 4), self.u16(body + 6)
-            if ver == 1:
-                pad = lambda v: (v + 7) & ~7
-                o = body + 8
-                name = self.d[o:o + nsz].split(b"\x00", 1)[0].decode("utf-8")
-                o += pad(nsz)
-                kind, size = self.datatype(o)
-                o += pad(tsz)
-                shape = self.dataspace(o)
-                o += pad(ssz)
-            elif ver in (2, 3):
-                o = body + 8 + (1 if ver == 3 else 0)
-                name = self.d[o:o + nsz].split(b"\x00", 1)[0].decode("utf-8")
-                o += nsz
-                kind, size = self.datatype(o)
-                o += tsz
-                shape = self.dataspace(o)
-                o += ssz
-            else:
-                raise H5Error("attribute message version %d" % ver)
-            out[name] = self._array(kind, size, shape, o)
+            try:
+                name, val = self._attribute(body)
+            except H5Error as e:
+                name, val = self._attribute_name(body), None
+                self.skipped_attributes.append((name, str(e)))
+            out[name] = val
         return out
+
+    def _attribute_name(self, body):
+        ver, nsz = self.u8(body), self.u16(body + 2)
+        o = body + 8 + (1 if ver == 3 else 0)
+        return self.d[o:o + nsz].split(b"\x00", 1)[0].decode("utf-8", "replace")
+
+    def _attribute(self, body):
+        ver = self.u8(body)
+        nsz, tsz, ssz = self.u16(body + 2), self.u16(body + 4), self.u16(body + 6)
+        if ver == 1:
+            pad = lambda v: (v + 7) & ~7
+            o = body + 8
+            name = self.d[o:o + nsz].split(b"\x00", 1)[0].decode("utf-8")
+            o += pad(nsz)
+            kind, size = self.datatype(o)
+            o += pad(tsz)
+            shape = self.dataspace(o)
+            o += pad(ssz)
+        elif ver in (2, 3):
+            o = body + 8 + (1 if ver == 3 else 0)
+            name = self.d[o:o + nsz].split(b"\x00", 1)[0].decode("utf-8")
+            o += nsz
+            kind, size = self.datatype(o)
+            o += tsz
+            shape = self.dataspace(o)
+            o += ssz
+        else:
+            raise H5Error("attribute message version %d" % ver)
+        return name, self._array(kind, size, shape, o)
 
     def dataset(self, entry):
         kind = size = shape = addr = None

@@ -8,6 +8,8 @@ Inputs and outputs are NumPy arrays in the reference's positional order and shap
 staged through torch (device memory and streams only).  Weights keep the Keras layout and order
 (``[kernel, recurrent_kernel, bias]`` per LSTM, ``[kernel, bias]`` for Dense) so files round-trip.
 """
+import os
+
 import numpy as np
 
 from .config import cfg
@@ -207,12 +209,19 @@ class KerasModelSurface:
         """'.h5' / '.hdf5' names: a Keras-layout HDF5 weight file (keras_h5.py: superblock 0, one group per layer with
         `weight_names`, contiguous float32 datasets - what keras.Model.load_weights reads); otherwise '.npz'."""
         path = self.weights_path(path)
+        # Data parallelism: the replicas are bit-identical, every rank runs the callbacks (and the scripts' final
+        # model.save_weights) - only rank 0 writes, through a temporary file, so nobody ever reads a half-written one
+        from . import parallel
+        if parallel.world()[0] != 0:
+            return
+        tmp = "%s.tmp%d" % (path, os.getpid())
         if path.lower().endswith((".h5", ".hdf5")):
             from .keras_h5 import write_keras_layers
-            write_keras_layers(path, self._keras_layers())
-            return
-        with open(path, "wb") as f:
-            np.savez(f, **self._w)
+            write_keras_layers(tmp, self._keras_layers())
+        else:
+            with open(tmp, "wb") as f:
+                np.savez(f, **self._w)
+        os.replace(tmp, path)
 
     save = save_weights
 
@@ -356,12 +365,17 @@ class Seq2SeqLSTM(KerasModelSurface):
                 pw["enc_K"], pw["enc_R"], pw["enc_b"] = pad_lstm(w["enc_K"], w["enc_R"], w["enc_b"], Hp)
                 pw["dec_K"], pw["dec_R"], pw["dec_b"] = pad_lstm(w["dec_K"], w["dec_R"], w["dec_b"], Hp)
                 pw["dense_W"], pw["dense_b"] = pad_rows(w["dense_W"], Hp), w["dense_b"]
-                for k in w:                    # subclasses' extra tensors (residual Dense, ...) are width-independent
-                    pw.setdefault(k, w[k])
+                for k in w:                    # subclasses' extra tensors: padded by their own rule (_pad_extra)
+                    if k not in pw:
+                        pw[k] = self._pad_extra(k, w, Hp)
                 w = pw
             self._dw = {k: torch.from_numpy(np.ascontiguousarray(v)).to(self.device) for k, v in w.items()}
             self._ws = self._ops().Workspace()
         return self._dw
+
+    def _pad_extra(self, k, w, Hp):
+        """A subclass tensor at the padded run width Hp (this class has none; width-independent ones pass through)."""
+        return w[k]
 
     # ---- inference -------------------------------------------------------------------------
     def predict(self, x, batch_size=None, verbose=0):
@@ -479,6 +493,24 @@ class NoTeacherForcingSeq2Seq(Seq2SeqLSTM):
             self._w["recd_W"] = glorot_uniform(rng, H, F)
             self._w["recd_b"] = np.zeros(F, np.float32)
         self._order = self_fed_weight_order(self.add_residual_link, self.embed_frame_state_enc2dec, self.has_reconstruct_loss)
+
+    def _pad_extra(self, k, w, Hp):
+        """The optional layers that carry the hidden width (FoV_seq2seq_no_teac_forc.py:47-59): the state embeddings
+        Dense(latent_dim, tanh) get zero rows AND columns (tanh(0) = 0: a padded unit's embedded state stays exactly 0), the
+        reconstruction LSTM is padded like the other two, its Dense gets zero rows.  The residual Dense is O x O."""
+        if k in ("emb1_W", "emb2_W"):
+            out = np.zeros((Hp, Hp), np.float32)
+            out[:w[k].shape[0], :w[k].shape[1]] = w[k]
+            return out
+        if k in ("emb1_b", "emb2_b"):
+            out = np.zeros(Hp, np.float32)
+            out[:w[k].shape[0]] = w[k]
+            return out
+        if k in ("rec_K", "rec_R", "rec_b"):
+            return dict(zip(("rec_K", "rec_R", "rec_b"), pad_lstm(w["rec_K"], w["rec_R"], w["rec_b"], Hp)))[k]
+        if k == "recd_W":
+            return pad_rows(w[k], Hp)
+        return w[k]
 
     def _split_inputs(self, x):
         if self.enc_last_out_as_dec_in:

@@ -481,6 +481,13 @@ def _guard_ptrs(guards):
     return g + [None] * (3 - len(g))
 
 
+def guard_flag(guards, out):
+    """out (one float of the flat gradient buffer) = 1.0 if a guard workspace's timeout word is set, else 0.0 - the slot
+    the data-parallel all-reduce carries so that every rank skips a failed step together."""
+    check(_lib.lib().fov_guard_flag(*_guard_ptrs(guards), _ptr(out), _stream()))
+    return out
+
+
 def adam_step(params, grads, m, v, step, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-7, guards=None):
     """Keras Adam on flat buffers.  guards: up to three workspace buffers; the update is skipped on the device when
     one of their sticky timeout words is set."""

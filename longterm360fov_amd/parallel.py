@@ -6,10 +6,23 @@ import torch
 import torch.distributed as dist
 
 
+import os
+
+
 def world():
     if dist.is_available() and dist.is_initialized():
         return dist.get_rank(), dist.get_world_size()
     return 0, 1
+
+
+def dp_active():
+    """True when the data-parallel branch (all-reduce of the flat gradient buffer, broadcast of the shuffle index) is to
+    run: more than one rank, or FOV_FORCE_DIST=1 with an initialised process group of ANY size.  The second form lets a
+    box with one GPU drive the real RCCL path (communicator, stream ordering, async work handles) at world size 1
+    (tests/test_gpu_dist_nccl.py, bench.py --force-dist)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or os.environ.get("FOV_FORCE_DIST", "") == "1"
 
 
 def shard_range(n, rank=None, world_size=None):
@@ -59,8 +72,7 @@ def gather_rows(local, n_total, device=None):
 def broadcast_index(idx):
     """Rank 0's index permutation on every rank (fit(shuffle=True) under data parallelism)."""
     import numpy as np
-    _, w = world()
-    if w == 1:
+    if not dp_active():
         return idx
     t = torch.from_numpy(np.ascontiguousarray(idx, dtype=np.int64))
     if dist.get_backend() == "nccl":

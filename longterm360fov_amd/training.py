@@ -3,6 +3,8 @@ mycode/FoV_seq2seq.py:103,112-117): forward with reserve -> MSE -> Dense backwar
 -> encoder BPTT -> (data-parallel: ONE all-reduce of the flat gradient buffer) -> Keras Adam /
 RMSprop on the flat parameter buffer.  All arithmetic happens in libfov360_hip.so; torch holds
 the buffers and runs the RCCL collective."""
+import os
+
 import numpy as np
 import torch
 
@@ -25,9 +27,12 @@ class FlatParamTrainer:
         self.shapes = [(k, tuple(weights[k].shape)) for k in order]
         n = int(sum(np.prod(s) for _, s in self.shapes))
         self.flat = torch.empty(n, dtype=torch.float32, device=device)     # parameters, one buffer
-        self.gradbuf = torch.zeros(n + 1, dtype=torch.float32, device=device)   # gradients, same layout, + the loss slot
-        self.grad = self.gradbuf[:n]
-        self.loss_slot = self.gradbuf[n:]
+        # gradients in the same layout, between a 16-byte head whose first float is the POISON slot (data parallelism: 1.0 if
+        # a persistent kernel of this rank's step gave up; the all-reduce makes it every rank's guard) and the loss slot
+        self.gradbuf = torch.zeros(4 + n + 1, dtype=torch.float32, device=device)
+        self.poison_slot = self.gradbuf[:1]
+        self.grad = self.gradbuf[4:4 + n]
+        self.loss_slot = self.gradbuf[4 + n:]
         self.m = torch.zeros(n, dtype=torch.float32, device=device)
         self.v = torch.zeros(n, dtype=torch.float32, device=device) if self.optimizer == "adam" else None
         self.w, self.g, self.offset = {}, {}, {}
@@ -40,11 +45,13 @@ class FlatParamTrainer:
             self.offset[k] = off
             off += cnt
         self.step_count = 0
+        self._steps_since_check = 0
+        self._dp_guard = None
         self.ws = ops.Workspace()
         self.scratch = ops.Scratch()        # split-K partials of the Dense / MSE / matmul calls
         self.bwd_scratch = ops.Scratch()    # BPTT calls only: its head is the persistent kernel's header + granule area
         self._dp = False
-        self._pending, self._reduced_from = [], n + 1
+        self._pending, self._reduced_from = [], self.gradbuf.numel()
 
     def _span(self, first, last):
         """The slice of the flat gradient buffer from parameter `first` through parameter `last` (adjacent in the order)."""
@@ -61,32 +68,51 @@ class FlatParamTrainer:
 
     def check(self):
         """Raise FovError(ERR_TIMEOUT) if a persistent kernel of this trainer gave up a bounded wait (synchronises)."""
-        self.ws.check()
-        self.bwd_scratch.check()
-        ws_bwd = getattr(self, "ws_bwd", None)
-        if ws_bwd is not None:
-            ws_bwd.check()
+        try:
+            self.ws.check()
+            self.bwd_scratch.check()
+            ws_bwd = getattr(self, "ws_bwd", None)
+            if ws_bwd is not None:
+                ws_bwd.check()
+        except Exception:
+            # the guarded optimizer skipped every update from the failing step on: do not count them (Adam's bias correction)
+            self.step_count -= self._steps_since_check
+            self._steps_since_check = 0
+            raise
+        self._steps_since_check = 0
 
     def _guards(self):
         """The workspaces whose sticky timeout word the optimizer launch looks at: if a persistent kernel of this step
         gave up, the update is skipped ON THE DEVICE (no host synchronisation), the parameters stay as they were and
         the next check() reports the failure."""
+        if self._dp_guard is not None:   # data parallelism: the all-reduced poison slot stands for every rank's workspaces
+            return [self._dp_guard]
         return [b.buf for b in (self.ws, self.bwd_scratch, getattr(self, "ws_bwd", None)) if b is not None and b.buf is not None]
 
     def apply_gradients(self):
         """Keras Adam / RMSprop on the flat buffer (model.compile(optimizer=...), FoV_seq2seq.py:103, convlstm_seq2seq.py:287)."""
         self.step_count += 1
+        self._steps_since_check += 1
         if self.optimizer == "adam":
             ops.adam_step(self.flat, self.grad, self.m, self.v, self.step_count, lr=self.lr, guards=self._guards())
         else:
             ops.rmsprop_step(self.flat, self.grad, self.m, lr=self.lr, guards=self._guards())
 
-    # ---- data parallelism: the flat buffer (gradients + loss slot) is SUM all-reduced, tail first ----
+    # ---- data parallelism: the flat buffer (poison slot + gradients + loss slot) is SUM all-reduced ----
+    # One all-reduce when the step's kernels have all been issued, or - opt-in, FOV_DP_OVERLAP=1 / overlap_allreduce - the
+    # tail first, under the encoder's BPTT.  Opt-in because the BPTT kernels are persistent, one workgroup on EVERY CU
+    # with the whole register file: an RCCL kernel that got CUs first and waits there for a lagging peer keeps some of
+    # their workgroups from starting while the others spin for them, and after about a second that is a (collective,
+    # see train_step) skipped step.  On ONE GPU RCCL launches no device code for an all-reduce at all (rocprofv3 trace
+    # of tools/prof_nccl_step.py, profiles/r03_nccl_world1_kernel_stats.txt), so which of the two orders the hardware
+    # picks at 8 GPUs is unmeasured.
+    overlap_allreduce = os.environ.get("FOV_DP_OVERLAP", "") == "1"
+
     def grads_final(self, name):
         """Called from forward_backward: every gradient from parameter `name` to the end of the buffer (and the loss
-        slot) is final.  Under DP the tail goes out now, overlapping whatever backward work is still to come."""
-        if self._dp and self.offset[name] < self._reduced_from:
-            lo = self.offset[name]
+        slot) is final.  Under DP with overlap_allreduce the tail goes out now, overlapping the backward work still to come."""
+        if self._dp and self.overlap_allreduce and 4 + self.offset[name] < self._reduced_from:
+            lo = 4 + self.offset[name]   # (gradbuf index: the gradients sit behind the 16-byte head)
             self._pending.append(torch.distributed.all_reduce(self.gradbuf[lo:self._reduced_from],
                                                               op=torch.distributed.ReduceOp.SUM, async_op=True))
             self._reduced_from = lo
@@ -107,12 +133,17 @@ class FlatParamTrainer:
         _, world = parallel.world()
         n_local = inputs[0].shape[0]
         weight = 1.0 if world == 1 else n_local / float(n_global if n_global else n_local * world)
-        self._dp = world > 1
+        self._dp = parallel.dp_active()   # more than one rank - or FOV_FORCE_DIST=1 on an initialised group of one (RCCL tests)
         self._pending, self._reduced_from = [], self.gradbuf.numel()
         loss, _ = self.forward_backward(*inputs, grad_weight=weight, **kw)
         if self._dp:
             if loss.data_ptr() != self.loss_slot.data_ptr():
                 self.loss_slot.copy_(loss.reshape(1))
+            # the head goes out last, when every kernel of the step has been issued: its first float says whether one of THIS
+            # rank's persistent kernels gave up; summed over ranks it is the guard of every rank's optimizer launch, so the
+            # replicas skip a failed step together instead of diverging (a rank that alone skipped would hang the others in
+            # the next collective once its check() raises)
+            ops.guard_flag(self._guards(), self.poison_slot)
             if self._reduced_from > 0:
                 self._pending.append(torch.distributed.all_reduce(self.gradbuf[:self._reduced_from],
                                                                   op=torch.distributed.ReduceOp.SUM, async_op=True))
@@ -120,7 +151,11 @@ class FlatParamTrainer:
                 work.wait()      # the launch stream waits for the collective; the host does not block
             self._pending, self._dp = [], False
             loss = self.loss_slot
-        self.apply_gradients()
+            self._dp_guard = self.poison_slot
+        try:
+            self.apply_gradients()
+        finally:
+            self._dp_guard = None
         return loss
 
     def eval_loss(self, *inputs):

@@ -7,7 +7,8 @@
  * Build + run (authoring container only; the .h5 files are the committed fixtures):
  *     /opt/conda/bin/h5cc -o /tmp/mk tests/golden/make_keras_h5_real.c && /tmp/mk tests/golden
  * argv[1] = output directory.  Writes keras_real_weights.h5 (model.save_weights) and keras_real_model.h5 (model.save:
- * the same tree under model_weights/). */
+ * the same tree under model_weights/), and both again with the scalar attributes as VARIABLE-LENGTH strings
+ * (keras_real_weights_vlen.h5, keras_real_model_vlen.h5) - the layout h5py really produces for them. */
 #include <hdf5.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -38,6 +39,22 @@ static void str_scalar_attr(hid_t obj, const char* name, const char* val) {
     hid_t a = H5Acreate2(obj, name, t, s, H5P_DEFAULT, H5P_DEFAULT);
     H5Awrite(a, t, val);
     H5Aclose(a); H5Sclose(s); H5Tclose(t);
+}
+
+/* what h5py does for `f.attrs['backend'] = b'tensorflow'` (a Python bytes / str scalar): a VARIABLE-LENGTH string, the
+ * attribute holds a global-heap reference.  keras/engine/saving.py writes backend, keras_version, model_config and
+ * training_config this way. */
+static void vlen_scalar_attr(hid_t obj, const char* name, const char* val) {
+    hid_t t = H5Tcopy(H5T_C_S1);
+    H5Tset_size(t, H5T_VARIABLE);
+    hid_t s = H5Screate(H5S_SCALAR);
+    hid_t a = H5Acreate2(obj, name, t, s, H5P_DEFAULT, H5P_DEFAULT);
+    H5Awrite(a, t, &val);
+    H5Aclose(a); H5Sclose(s); H5Tclose(t);
+}
+static int g_vlen = 0;
+static void scalar_attr(hid_t obj, const char* name, const char* val) {
+    if (g_vlen) vlen_scalar_attr(obj, name, val); else str_scalar_attr(obj, name, val);
 }
 
 static void dataset(hid_t group, const char* name, int rank, const hsize_t* dims) {
@@ -86,8 +103,8 @@ static void input(hid_t root, const char* name) {
 static void weights_tree(hid_t root) {
     const char* layers[5] = {"input_1", "input_2", "lstm_1", "lstm_2", "dense_1"};
     str_array_attr(root, "layer_names", layers, 5);
-    str_scalar_attr(root, "backend", "tensorflow");
-    str_scalar_attr(root, "keras_version", "2.2.4");
+    scalar_attr(root, "backend", "tensorflow");
+    scalar_attr(root, "keras_version", "2.2.4");
     input(root, "input_1"); input(root, "input_2");
     lstm(root, "lstm_1", 5, 4); lstm(root, "lstm_2", 3, 4); dense(root, "dense_1", 4, 3);
 }
@@ -95,20 +112,26 @@ static void weights_tree(hid_t root) {
 int main(int argc, char** argv) {
     const char* dir = argc > 1 ? argv[1] : ".";
     char path[512];
-    snprintf(path, 512, "%s/keras_real_weights.h5", dir);
-    hid_t f = H5Fcreate(path, H5F_ACC_TRUNC, H5P_DEFAULT, H5P_DEFAULT);
-    g_tensor = 0;
-    weights_tree(f);
-    H5Fclose(f);
-    snprintf(path, 512, "%s/keras_real_model.h5", dir);
-    f = H5Fcreate(path, H5F_ACC_TRUNC, H5P_DEFAULT, H5P_DEFAULT);
-    str_scalar_attr(f, "keras_version", "2.2.4");
-    str_scalar_attr(f, "backend", "tensorflow");
-    str_scalar_attr(f, "model_config", "{\"class_name\": \"Model\"}");
-    hid_t mw = H5Gcreate2(f, "model_weights", H5P_DEFAULT, H5P_DEFAULT, H5P_DEFAULT);
-    g_tensor = 0;
-    weights_tree(mw);
-    H5Gclose(mw);
-    H5Fclose(f);
+    /* [0]: scalar attributes as fixed-length strings; [1]: as variable-length strings (the h5py / Keras form) */
+    const char* wname[2] = {"keras_real_weights.h5", "keras_real_weights_vlen.h5"};
+    const char* mname[2] = {"keras_real_model.h5", "keras_real_model_vlen.h5"};
+    for (g_vlen = 0; g_vlen < 2; ++g_vlen) {
+        snprintf(path, 512, "%s/%s", dir, wname[g_vlen]);
+        hid_t f = H5Fcreate(path, H5F_ACC_TRUNC, H5P_DEFAULT, H5P_DEFAULT);
+        g_tensor = 0;
+        weights_tree(f);
+        H5Fclose(f);
+        snprintf(path, 512, "%s/%s", dir, mname[g_vlen]);
+        f = H5Fcreate(path, H5F_ACC_TRUNC, H5P_DEFAULT, H5P_DEFAULT);
+        scalar_attr(f, "keras_version", "2.2.4");
+        scalar_attr(f, "backend", "tensorflow");
+        scalar_attr(f, "model_config", "{\"class_name\": \"Model\", \"config\": {\"name\": \"model_1\"}}");
+        scalar_attr(f, "training_config", "{\"optimizer_config\": {\"class_name\": \"Adam\"}, \"loss\": \"mean_squared_error\"}");
+        hid_t mw = H5Gcreate2(f, "model_weights", H5P_DEFAULT, H5P_DEFAULT, H5P_DEFAULT);
+        g_tensor = 0;
+        weights_tree(mw);
+        H5Gclose(mw);
+        H5Fclose(f);
+    }
     return 0;
 }

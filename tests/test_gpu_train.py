@@ -222,6 +222,7 @@ def _dp_mixing_worker(rank, world_size, port, q, dtype):
         enc, dec0, tgt, oth = O.synthetic_batch(224, 41, 3, 4, num_others=4)
         lo, hi = parallel.shard_range(41)
         tr = OthersMixingTrainer(w, dtype=dtype)
+        tr.overlap_allreduce = True   # the opt-in order: the decoder's gradients go out under the encoder's BPTT (the default - one all-reduce at the end - is what _dp_worker above runs)
         losses = [float(tr.train_step(dev(enc[lo:hi]), dev(oth[lo:hi]), dev(dec0[lo:hi]), dev(tgt[lo:hi]), n_global=41).item())
                   for _ in range(3)]
         tr.check()
@@ -874,6 +875,7 @@ def test_no_teacher_forcing_one_layer_gradients_and_training(H, B, T_in, T_out, 
     (64, 21, 5, "sigmoid", True, False, True, False, True),         # cfg.has_reconstruct_loss as the script wires it (:135, :267)
     (128, 33, 4, "hard_sigmoid", False, True, True, True, True),    # both, + residual link, decoder seeded with the embedded state
     (256, 24, 3, "sigmoid", True, False, False, True, True),        # zero-state decoder: the encoder is reached only through the reconstruction
+    (32, 17, 3, "sigmoid", False, True, True, True, True),          # the scripts' latent_dim: predict runs zero-padded to 64 units, embeddings / reconstruction layers included
 ])
 def test_no_teacher_forcing_embedded_state_and_reconstruction_decoder(H, B, T, act, no_init, residual, enc_as_in, embed, recons):
     """cfg.embed_frame_state_enc2dec (FoV_seq2seq_no_teac_forc.py:47-52: Dense(latent_dim, tanh) on the encoder's h and c) and

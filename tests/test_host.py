@@ -187,10 +187,13 @@ def _real_h5_value(k, shape):
     return (((37 * i + 11 * k) % 1000 - 500) / 256.0).astype(np.float32).reshape(shape)
 
 
-@pytest.mark.parametrize("name", ["keras_real_weights.h5", "keras_real_model.h5"])
+@pytest.mark.parametrize("name", ["keras_real_weights.h5", "keras_real_model.h5", "keras_real_weights_vlen.h5",
+                                  "keras_real_model_vlen.h5"])
 def test_keras_h5_reader_against_files_written_by_the_hdf5_library(golden_dir, name):
     """Ground truth: files written by the real HDF5 C library (1.10.6) in the Keras layout - model.save_weights form and
-    model.save form (tree under model_weights/)."""
+    model.save form (tree under model_weights/).  The *_vlen files carry backend / keras_version / model_config /
+    training_config as VARIABLE-LENGTH strings (global-heap references): what h5py writes for a Python bytes / str scalar,
+    i.e. what a file saved by Keras really looks like."""
     from longterm360fov_amd import keras_h5
     layers = keras_h5.read_keras_layers(os.path.join(golden_dir, name))
     assert [n for n, _ in layers] == ["input_1", "input_2", "lstm_1", "lstm_2", "dense_1"]
@@ -204,6 +207,35 @@ def test_keras_h5_reader_against_files_written_by_the_hdf5_library(golden_dir, n
             np.testing.assert_array_equal(a, _real_h5_value(k, a.shape))
             k += 1
     assert k == 8
+
+
+def test_keras_h5_variable_length_string_attributes(golden_dir):
+    """The scalar attributes Keras adds are decoded through the global heap, not merely skipped; an attribute whose datatype
+    the reader cannot decode is reported as None instead of failing the file."""
+    from longterm360fov_amd import keras_h5
+    with open(os.path.join(golden_dir, "keras_real_model_vlen.h5"), "rb") as fh:
+        f = keras_h5._File(fh.read())
+    attrs = f.attributes(f.root)
+    assert attrs["backend"].item() == b"tensorflow" and attrs["keras_version"].item() == b"2.2.4"
+    assert attrs["model_config"].item().startswith(b'{"class_name": "Model"')
+    assert b"mean_squared_error" in attrs["training_config"].item()
+    assert f.skipped_attributes == []
+    # corrupt the datatype class of one attribute message (class 9 -> 6, compound): skipped, everything else still reads
+    data = bytearray(open(os.path.join(golden_dir, "keras_real_weights_vlen.h5"), "rb").read())
+    f2 = keras_h5._File(data)
+    hit = 0
+    for mtype, _, body, _ in f2.messages(f2.root["header"]):
+        if mtype == 0x000C and f2._attribute_name(body) == "backend":
+            nsz = f2.u16(body + 2)
+            o = body + 8 + ((nsz + 7) & ~7 if f2.u8(body) == 1 else nsz + (1 if f2.u8(body) == 3 else 0))
+            assert data[o] & 0x0F == 9
+            data[o] = (data[o] & 0xF0) | 6
+            hit += 1
+    assert hit == 1
+    f3 = keras_h5._File(bytes(data))
+    a3 = f3.attributes(f3.root)
+    assert a3["backend"] is None and [n for n, _ in f3.skipped_attributes] == ["backend"]
+    assert list(keras_h5._decode(a3["layer_names"])) == ["input_1", "input_2", "lstm_1", "lstm_2", "dense_1"]
 
 
 def test_keras_h5_loads_into_the_model_object_and_refuses_other_topologies(golden_dir):
