@@ -509,6 +509,10 @@ int fov_workspace_init(void* workspace, size_t workspace_bytes, fov_stream_t str
  * those of every later call on this workspace are invalid).  Reporting a failure clears it (the workspace is
  * re-zeroed and usable again).  Workspaces of non-persistent calls report FOV_OK. */
 int fov_check_status(void* workspace, size_t workspace_bytes, fov_stream_t stream);
+/* Test switch: on != 0 makes every exchanging kernel launched on this workspace keep the placement-independent
+ * (write-through) granule exchange even where its run-time handshake finds a whole group on one XCD.  Results are
+ * bit-identical either way (tests/test_gpu_parity.py, tests/test_gpu_train.py); fov_exchange_mode tells which ran. */
+int fov_workspace_force_safe(void* workspace, size_t workspace_bytes, int on, fov_stream_t stream);
 
 /* Diagnostic: which h-exchange protocol the last persistent-kernel call on `workspace` used.
  * 1 = every group verified (HW_REG_XCC_ID handshake) that its workgroups share an XCD and took the

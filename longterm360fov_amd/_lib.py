@@ -7,7 +7,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libfov360_hip.so")
+# FOV_LIB_PATH: another build of the SAME library (A/B timing of kernel variants, diagnostic builds) - never a fallback
+LIB_PATH = os.environ.get("FOV_LIB_PATH") or os.path.join(_HERE, "lib", "libfov360_hip.so")
 
 ACT_SIGMOID = 0
 ACT_HARD_SIGMOID = 1
@@ -97,6 +98,7 @@ SIGNATURES = {
     "fov_fov_hit_rate": (_I, [_P, ctypes.c_int64, _P, ctypes.c_int64, _P, ctypes.c_int64, ctypes.c_float, ctypes.c_float, _P]),
     "fov_workspace_init": (_I, [_P, _SZ, _P]),
     "fov_check_status": (_I, [_P, _SZ, _P]),
+    "fov_workspace_force_safe": (_I, [_P, _SZ, _I, _P]),
     "fov_exchange_mode": (_I, [_P, _SZ, _P]),
 }
 

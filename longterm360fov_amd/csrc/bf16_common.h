@@ -207,10 +207,10 @@ constexpr int QNDZ = 28;                          // granules gathered per threa
 
 // this lane's cells: rows row0, row0 + 1 of `unit`; dzp[g] = packed bf16 pair of gate g
 __device__ __forceinline__ void q_dz_publish(const __amdgpu_buffer_rsrc_t rs, unsigned base, int row0, int unit, const unsigned (&dzp)[4],
-                                             unsigned epoch, unsigned short* tile) {
+                                             unsigned epoch, unsigned short* tile, bool same_xcd) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-        __builtin_amdgcn_raw_buffer_store_b64((qu32x2){dzp[g], epoch}, rs, (unsigned)((g * 8 + (row0 >> 1)) * QH + unit) * 8u, base, 16);
+        XCH_STORE_B64(same_xcd, ((qu32x2){dzp[g], epoch}), rs, (unsigned)((g * 8 + (row0 >> 1)) * QH + unit) * 8u, base);
         tile[row0 * QLDZ + g * QH + unit] = (unsigned short)(dzp[g] & 0xffffu);
         tile[(row0 + 1) * QLDZ + g * QH + unit] = (unsigned short)(dzp[g] >> 16);
     }

@@ -1023,6 +1023,16 @@ int fov_workspace_init(void* workspace, size_t workspace_bytes, fov_stream_t str
     return FOV_OK;
 }
 
+int fov_workspace_force_safe(void* workspace, size_t workspace_bytes, int on, fov_stream_t stream) {
+    if (!workspace || workspace_bytes < kStatusBytes) {
+        set_error("fov_workspace_force_safe: invalid workspace");
+        return FOV_ERR_INVALID;
+    }
+    hipError_t e = hipMemsetD32Async((hipDeviceptr_t)((unsigned*)workspace + ST_FORCE_SAFE), on ? 1 : 0, 1, (hipStream_t)stream);
+    if (e != hipSuccess) { set_error("fov_workspace_force_safe: %s", hipGetErrorString(e)); return FOV_ERR_LAUNCH; }
+    return FOV_OK;
+}
+
 int fov_check_status(void* workspace, size_t workspace_bytes, fov_stream_t stream) {
     if (!workspace || workspace_bytes < kStatusBytes) {
         set_error("fov_check_status: invalid workspace");
@@ -1037,6 +1047,8 @@ int fov_check_status(void* workspace, size_t workspace_bytes, fov_stream_t strea
     // the stream is idle at this point.
     if (st[ST_TIMEOUT] != 0 || st[ST_EPOCH] > 0x7fff0000u) {
         e = hipMemsetAsync(workspace, 0, workspace_bytes, (hipStream_t)stream);
+        if (e == hipSuccess && st[ST_FORCE_SAFE] != 0)   // the A/B switch is the caller's setting, not launch state: it survives
+            e = hipMemsetD32Async((hipDeviceptr_t)((unsigned*)workspace + ST_FORCE_SAFE), 1, 1, (hipStream_t)stream);
         if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
         if (e != hipSuccess) { set_error("fov_check_status: %s", hipGetErrorString(e)); return FOV_ERR_LAUNCH; }
     }

@@ -70,8 +70,8 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd8_kernel(Bwd8Params p) {
     const int my_row0 = 4 * g4 + 2 * hi;
     const int T = p.T;
     // epoch tags continue from the workspace header, a poisoned workspace skips the body (xch_common.h)
-    __shared__ unsigned sXch[2];
-    const unsigned arrival = xch_arrive(p.status, sXch);
+    __shared__ unsigned sXch[4];
+    const unsigned arrival = xch_arrive(p.status, sXch, group, slice);
     const bool poisoned = xch_poisoned(p.status);
     if (tid == 0) sFlag[0] = poisoned ? 1 : 0;
 
@@ -97,10 +97,12 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd8_kernel(Bwd8Params p) {
     }
     unsigned long long* gbase = p.xch + (size_t)group * 2 * B8_PAR;
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(gbase, 0, (int)(2 * B8_PAR * 8), 0x00020000);
+    xch_hello_poll(p.status, sXch, group, QG, &sFlag[0]);   // same-XCD handshake (xch_common.h): partners' words, published at entry
     __syncthreads();
     const XchTicket ticket = xch_ticket(sXch, arrival);
     unsigned epoch = ticket.base;
     bool aborted = sFlag[0] != 0;
+    if (tid == 0 && !ticket.same_xcd && !aborted) xch_count_safe(p.status, ticket);   // (fov_exchange_mode)
 
     for (int tile = group; tile < p.num_tiles && !aborted; tile += p.num_groups) {
         const int b0 = tile * QBT;
@@ -201,7 +203,7 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd8_kernel(Bwd8Params p) {
                 const unsigned off = (unsigned)((((d * QG + slice) * QBT + 4 * g4) * 32) + 16 * (tl & 1) + n) * 8u;
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    __builtin_amdgcn_raw_buffer_store_b64((qu32x2){__float_as_uint(acc[tl][r]), epoch}, rs, off + r * 32 * 8, par, 16);
+                    XCH_STORE_B64(ticket.same_xcd, ((qu32x2){__float_as_uint(acc[tl][r]), epoch}), rs, off + r * 32 * 8, par);
             }
             // ---- gather the 8 pieces of this lane's two cells, add in slice order ----
             {
@@ -323,8 +325,8 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd8n_bf16_kernel(Bwd8Params p) {
     const int unit = 32 * slice + ul;
     const int my_row0 = 4 * g4 + 2 * hi;
     const int T = p.T;
-    __shared__ unsigned sXch[2];
-    const unsigned arrival = xch_arrive(p.status, sXch);
+    __shared__ unsigned sXch[4];
+    const unsigned arrival = xch_arrive(p.status, sXch, group, slice);
     const bool poisoned = xch_poisoned(p.status);
     if (tid == 0) sFlag[0] = poisoned ? 1 : 0;
 #ifdef FOV_STAMPS
@@ -349,10 +351,12 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd8n_bf16_kernel(Bwd8Params p) {
     }
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
         p.xch + (size_t)group * 2 * (Q_DZ_BYTES / 8), 0, (int)(2 * Q_DZ_BYTES), 0x00020000);
+    xch_hello_poll(p.status, sXch, group, QG, &sFlag[0]);   // same-XCD handshake (xch_common.h): partners' words, published at entry
     __syncthreads();
     const XchTicket ticket = xch_ticket(sXch, arrival);
     unsigned epoch = ticket.base;
     bool aborted = sFlag[0] != 0;
+    if (tid == 0 && !ticket.same_xcd && !aborted) xch_count_safe(p.status, ticket);   // (fov_exchange_mode)
 
     for (int tile = group; tile < p.num_tiles && !aborted; tile += p.num_groups) {
         const int b0 = tile * QBT;
@@ -414,7 +418,7 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd8n_bf16_kernel(Bwd8Params p) {
             unsigned dzp[4];
 #pragma unroll
             for (int g = 0; g < 4; ++g) dzp[g] = pack_bf16(dzv[0][g], dzv[1][g]);
-            q_dz_publish(rs, par, my_row0, unit, dzp, epoch, sDZ);
+            q_dz_publish(rs, par, my_row0, unit, dzp, epoch, sDZ, ticket.same_xcd);
             // Everything that does not depend on the partners goes between the publish and the gather: an sc1 store
             // takes about a microsecond to become visible, a sweep issued earlier comes back stale and costs a second
             // round trip.  The tape of step t-1 is requested here, a whole step before its use.
@@ -534,7 +538,7 @@ int launch_bwd8(const float* R, const float* reserve, const float* c0, const flo
     const int max_groups = device_cu_count() / QG;
     if (max_groups < 1) { set_error("8-group BPTT kernel needs at least %d CUs", QG); return FOV_ERR_UNSUPPORTED; }
     p.num_groups = p.num_tiles < max_groups ? p.num_tiles : max_groups;
-    if ((size_t)p.num_groups * 2 * (bf16 ? (size_t)Q_DZ_BYTES : B8_PAR * 8) > kXchBytes) { set_error("8-group BPTT kernel: granule area too small"); return FOV_ERR_WORKSPACE; }
+    if ((size_t)p.num_groups * 2 * (bf16 ? (size_t)Q_DZ_BYTES : B8_PAR * 8) > kXchBytes - kHelloBytes) { set_error("8-group BPTT kernel: granule area too small"); return FOV_ERR_WORKSPACE; }
     if (bf16 && (((uintptr_t)R) & 15)) { set_error("8-group BPTT kernel: R must be 16-byte aligned"); return FOV_ERR_INVALID; }
     p.status = (unsigned*)xch_ws;
     p.xch = (unsigned long long*)((char*)xch_ws + kStatusBytes);

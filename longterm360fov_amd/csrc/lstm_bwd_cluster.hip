@@ -76,8 +76,8 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_cluster_kernel(BwdParams p) {
     }
     const int unit = slice * 64 + wave * 16 + n;   // the hidden unit this lane owns
     // epoch tags continue from the workspace header, a poisoned workspace skips the body (xch_common.h)
-    __shared__ unsigned sXch[2];
-    const unsigned arrival = G > 1 ? xch_arrive(p.status, sXch) : 0u;
+    __shared__ unsigned sXch[4];
+    const unsigned arrival = G > 1 ? xch_arrive(p.status, sXch, group, slice) : 0u;
     const bool poisoned = G > 1 && xch_poisoned(p.status);
     if (tid == 0) sFlag[0] = poisoned ? 1 : 0;
 
@@ -106,11 +106,13 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_cluster_kernel(BwdParams p) {
         p.xch + (size_t)group * 2 * G * G * CHUNK, 0, 2 * G * G * CHUNK * (int)sizeof(unsigned long long), 0x00020000);
     const unsigned lane_off = (unsigned)((wave * 4) * 64 + lane) * 8u;   // + r*64*8 per register
 
+    if (G > 1) xch_hello_poll(p.status, sXch, group, G, &sFlag[0]);   // same-XCD handshake (xch_common.h): partners' words, published at entry
     __syncthreads();
     XchTicket ticket = {0u, 0u, 0u};
     if (G > 1) ticket = xch_ticket(sXch, arrival);
     unsigned epoch = ticket.base;
     bool aborted = sFlag[0] != 0;
+    if (G > 1 && tid == 0 && !ticket.same_xcd && !aborted) xch_count_safe(p.status, ticket);   // (fov_exchange_mode)
 
     for (int tile = group; tile < p.num_tiles && !aborted; tile += p.num_groups) {
         const int b0 = tile * BBT;
@@ -226,9 +228,8 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_cluster_kernel(BwdParams p) {
                     const int d = (slice + 1 + dd) & (G - 1);
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        __builtin_amdgcn_raw_buffer_store_b64((bu32x2){__float_as_uint(sum[r]), epoch}, xrs,
-                                                              (unsigned)((d * G + slice) * CHUNK) * 8u + lane_off + r * 512u,
-                                                              xsoff, 16);
+                        XCH_STORE_B64(ticket.same_xcd, ((bu32x2){__float_as_uint(sum[r]), epoch}), xrs,
+                                      (unsigned)((d * G + slice) * CHUNK) * 8u + lane_off + r * 512u, xsoff);
                 }
             }
             __syncthreads();   // barrier B: every wave is done with the dz tile
@@ -336,7 +337,7 @@ int launch_bwd_cluster(const float* R, const float* reserve, const float* c0, co
     p.num_groups = cluster_num_groups(B, H);
     p.status = (unsigned*)xch_ws;
     p.xch = (unsigned long long*)((char*)xch_ws + kStatusBytes);
-    if (bwd_cluster_xch_bytes(B, H) > kXchBytes) { set_error("BPTT kernel: granule area exceeds the workspace's"); return FOV_ERR_WORKSPACE; }
+    if (bwd_cluster_xch_bytes(B, H) > kXchBytes - kHelloBytes) { set_error("BPTT kernel: granule area exceeds the workspace's"); return FOV_ERR_WORKSPACE; }
     p.epoch_span = T * ((p.num_tiles + p.num_groups - 1) / p.num_groups) + 1;   // no memset: tags continue from the header
     switch (H) {
         case 64: return launch_bwd_h<64>(p, act, stream);

@@ -1096,7 +1096,7 @@ int launch_cluster(const LstmParams& p_in, bool decode, hipStream_t stream) {
     p.num_groups = cluster_num_groups(p.B, p.H);
     const char* safe = getenv("FOV_FORCE_SAFE_EXCHANGE");   // read per call: the tests flip it between calls
     p.force_safe_exchange = (safe && safe[0] == '1') ? 1 : 0;
-    if (cluster_xch_bytes(p.B, p.H) > kXchBytes) { set_error("cluster kernel: granule area exceeds the workspace's"); return FOV_ERR_WORKSPACE; }
+    if (cluster_xch_bytes(p.B, p.H) > kXchBytes - kHelloBytes) { set_error("cluster kernel: granule area exceeds the workspace's"); return FOV_ERR_WORKSPACE; }
     // No memset: epoch tags continue from the workspace header.  A group visits ceil(tiles / groups) tiles and
     // advances its epoch once per step of each.
     const int visits = (p.num_tiles + p.num_groups - 1) / p.num_groups;

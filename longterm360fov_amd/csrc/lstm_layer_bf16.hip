@@ -53,8 +53,8 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_bf16_kernel(LstmParams p) {
     constexpr int H4 = 4 * QH;
     // epoch tags continue from the workspace header, a poisoned workspace skips the body (xch_common.h)
     const bool xch_used = steps > 1;
-    __shared__ unsigned sXch[2];
-    const unsigned arrival = xch_used ? xch_arrive(p.status, sXch) : 0u;
+    __shared__ unsigned sXch[4];
+    const unsigned arrival = xch_used ? xch_arrive(p.status, sXch, group, slice) : 0u;
     const bool poisoned = xch_used && xch_poisoned(p.status);
     if (tid == 0) sFlag[0] = poisoned ? 1 : 0;
 #ifdef FOV_STAMPS
@@ -78,11 +78,13 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_bf16_kernel(LstmParams p) {
     asm volatile("" :: "v"(wr[7][1]), "v"(wr[0][0]), "v"(wk[0][0]), "v"(wk[NKB - 1][1]));   // the fragments exist by now
     if (stamp_on) g_q_stamps[QSTAMP_STEPS - 1][1] = __builtin_amdgcn_s_memtime();   // weights resident
 #endif
+    if (xch_used) xch_hello_poll(p.status, sXch, group, QG, &sFlag[0]);   // same-XCD handshake (xch_common.h): partners' words, published at entry
     __syncthreads();
     XchTicket ticket = {0u, 0u, 0u};
     if (xch_used) ticket = xch_ticket(sXch, arrival);
     unsigned epoch = ticket.base;
     bool aborted = sFlag[0] != 0;
+    if (xch_used && tid == 0 && !ticket.same_xcd && !aborted) xch_count_safe(p.status, ticket);   // (fov_exchange_mode)
 
     // x staging: thread (xrw = tid / 16, xc = tid % 16) moves the elements xc, xc + 16, ... of row xrw
     // (XVEC: the 16-byte pieces xc, xc + 16, ...: four elements each)
@@ -215,7 +217,7 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_bf16_kernel(LstmParams p) {
             if (do_xch) {
                 ++epoch;
                 par = (epoch & 1u) * Q_TILE_BYTES;
-                __builtin_amdgcn_raw_buffer_store_b64((qu32x2){hpair, epoch}, xrs, pub_off, par, 16);
+                XCH_STORE_B64(ticket.same_xcd, ((qu32x2){hpair, epoch}), xrs, pub_off, par);
             }
             Q_STAMP(3);
             __syncthreads();   // barrier 1: every wave is done reading sH; x_{t+1} is in LDS
@@ -292,7 +294,7 @@ int launch_layer_bf16(const LstmParams& p_in, hipStream_t stream) {
     const int max_groups = device_cu_count() / QG;   // one workgroup per CU: every group must be co-resident
     if (max_groups < 1) { set_error("bf16 LSTM layer needs at least %d CUs", QG); return FOV_ERR_UNSUPPORTED; }
     p.num_groups = p.num_tiles < max_groups ? p.num_tiles : max_groups;
-    if ((size_t)p.num_groups * 2 * Q_TILE_BYTES > kXchBytes) { set_error("bf16 LSTM layer: granule area too small"); return FOV_ERR_WORKSPACE; }
+    if ((size_t)p.num_groups * 2 * Q_TILE_BYTES > kXchBytes - kHelloBytes) { set_error("bf16 LSTM layer: granule area too small"); return FOV_ERR_WORKSPACE; }
     p.epoch_span = p.T * ((p.num_tiles + p.num_groups - 1) / p.num_groups) + 1;
     const bool narrow = p.F <= 96;
     const bool xvec = !narrow && (p.F & 3) == 0 && (((uintptr_t)p.x) & 15) == 0;

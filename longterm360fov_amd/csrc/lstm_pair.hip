@@ -714,7 +714,7 @@ int launch_pair_fused(const LstmParams& p_in, hipStream_t stream) {
     LstmParams p = p_in;
     p.num_tiles = (p.B + PBT - 1) / PBT;
     p.num_groups = (p.num_tiles + 1) / 2;
-    if ((size_t)p.num_groups * (2 * 2 * PBT * PH + PG) * sizeof(unsigned long long) > kXchBytes) {
+    if ((size_t)p.num_groups * (2 * 2 * PBT * PH + PG) * sizeof(unsigned long long) > kXchBytes - kHelloBytes) {
         set_error("pair kernel: granule area exceeds the workspace's");
         return FOV_ERR_WORKSPACE;
     }

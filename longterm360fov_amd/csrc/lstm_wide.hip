@@ -85,8 +85,8 @@ __global__ __launch_bounds__(256, 1) void lstm_wide_kernel(LstmParams p) {
     constexpr int H4 = 4 * WH;
     // epoch tags continue from the workspace header, a poisoned workspace skips the body (xch_common.h)
     const bool xch_used = steps > 1;
-    __shared__ unsigned sXch[2];
-    const unsigned arrival = xch_used ? xch_arrive(p.status, sXch) : 0u;
+    __shared__ unsigned sXch[4];
+    const unsigned arrival = xch_used ? xch_arrive(p.status, sXch, group, slice) : 0u;
     const bool poisoned = xch_used && xch_poisoned(p.status);
     if (tid == 0) sFlag[0] = poisoned ? 1 : 0;
 
@@ -117,11 +117,13 @@ __global__ __launch_bounds__(256, 1) void lstm_wide_kernel(LstmParams p) {
     const unsigned gvoff = (unsigned)((tid >> 5) * WH + (tid & 31)) * 8u;
     const int lbase = (tid >> 5) * WLD + (tid & 31);
     constexpr unsigned PARITY = WBT * WH * 8u;
+    if (xch_used) xch_hello_poll(p.status, sXch, group, WG, &sFlag[0]);   // same-XCD handshake (xch_common.h): partners' words, published at entry
     __syncthreads();
     XchTicket ticket = {0u, 0u, 0u};
     if (xch_used) ticket = xch_ticket(sXch, arrival);
     unsigned epoch = ticket.base;
     bool aborted = sFlag[0] != 0;
+    if (xch_used && tid == 0 && !ticket.same_xcd && !aborted) xch_count_safe(p.status, ticket);   // (fov_exchange_mode)
 
     wu32x2 v[WNG];
     auto gather_issue = [&](unsigned base) {
@@ -312,7 +314,7 @@ __global__ __launch_bounds__(256, 1) void lstm_wide_kernel(LstmParams p) {
                 par = (epoch & 1u) * PARITY;
 #pragma unroll
                 for (int r = 0; r < 2; ++r)
-                    __builtin_amdgcn_raw_buffer_store_b64((wu32x2){__float_as_uint(hc[r]), epoch}, xrs, pub_off + r * WH * 8, par, 16);
+                    XCH_STORE_B64(ticket.same_xcd, ((wu32x2){__float_as_uint(hc[r]), epoch}), xrs, pub_off + r * WH * 8, par);
             }
             __syncthreads();   // barrier 1: every wave is done reading sH; x_{t+1} is in LDS
             if (do_xch) {

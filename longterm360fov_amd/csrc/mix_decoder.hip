@@ -165,8 +165,8 @@ __global__ __launch_bounds__(256, 1) void mix_decoder_kernel(MixDecParams p) {
     const int H4 = 4 * MH;
 
     // epoch tags continue from the workspace header, a poisoned workspace skips the body (xch_common.h)
-    __shared__ unsigned sXch[2];
-    const unsigned arrival = xch_arrive(p.status, sXch);
+    __shared__ unsigned sXch[4];
+    const unsigned arrival = xch_arrive(p.status, sXch, group, slice);
     const bool poisoned = xch_poisoned(p.status);
     if (tid == 0) sFlag[0] = poisoned ? 1 : 0;
     // ---- resident weights ----
@@ -222,10 +222,12 @@ __global__ __launch_bounds__(256, 1) void mix_decoder_kernel(MixDecParams p) {
 #ifdef FOV_STAMPS
     const bool stamp_on = (blockIdx.x == 5 && tid == 0);
 #endif
+    xch_hello_poll(p.status, sXch, group, MG, &sFlag[0]);   // same-XCD handshake (xch_common.h): partners' words, published at entry
     __syncthreads();
     const XchTicket ticket = xch_ticket(sXch, arrival);
     unsigned epoch = ticket.base;
     bool aborted = sFlag[0] != 0;
+    if (tid == 0 && !ticket.same_xcd && !aborted) xch_count_safe(p.status, ticket);   // (fov_exchange_mode)
 
     // gather: issue / complete.  v[] stays in registers between the two so MFMAs can run in between.
     mu32x2 v[MNG];
@@ -352,7 +354,7 @@ __global__ __launch_bounds__(256, 1) void mix_decoder_kernel(MixDecParams p) {
             // publish h1_t, then start the gather and run h2_{t-1} . R2 under it
 #pragma unroll
             for (int r = 0; r < 2; ++r)
-                __builtin_amdgcn_raw_buffer_store_b64((mu32x2){__float_as_uint(h1c[r]), epoch}, xrs, pub_off + r * MH * 8, par, 16);
+                XCH_STORE_B64(ticket.same_xcd, ((mu32x2){__float_as_uint(h1c[r]), epoch}), xrs, pub_off + r * MH * 8, par);
 #pragma unroll
             for (int r = 0; r < 2; ++r) sH1[(my_row0 + r) * MLDH + unit] = h1c[r];
             acc2[0] = (f32x4){b2v[0], b2v[0], b2v[0], b2v[0]};
@@ -406,8 +408,8 @@ __global__ __launch_bounds__(256, 1) void mix_decoder_kernel(MixDecParams p) {
             }
 #pragma unroll
             for (int r = 0; r < 2; ++r)
-                __builtin_amdgcn_raw_buffer_store_b64((mu32x2){__float_as_uint(h2c[r]), epoch}, xrs, pub_off + r * MH * 8,
-                                                      LAYER_BYTES + par, 16);
+                XCH_STORE_B64(ticket.same_xcd, ((mu32x2){__float_as_uint(h2c[r]), epoch}), xrs, pub_off + r * MH * 8,
+                                                      LAYER_BYTES + par);
 #pragma unroll
             for (int r = 0; r < 2; ++r) sH2[(my_row0 + r) * MLDH + unit] = h2c[r];
             const bool more = (t + 1 < p.T_out);
@@ -525,7 +527,7 @@ int mix_decoder_launch(MixDecParams p, const float* K2, int act, int train, void
     const int max_groups = device_cu_count() / MG;   // one workgroup per CU: every group must be co-resident
     if (max_groups < 1) { set_error("fused mixing decoder needs at least %d CUs", MG); return FOV_ERR_UNSUPPORTED; }
     p.num_groups = p.num_tiles < max_groups ? p.num_tiles : max_groups;
-    if ((size_t)p.num_groups * 4 * MBT * MH * sizeof(unsigned long long) > kXchBytes) { set_error("mix_decoder: granule area too small"); return FOV_ERR_WORKSPACE; }
+    if ((size_t)p.num_groups * 4 * MBT * MH * sizeof(unsigned long long) > kXchBytes - kHelloBytes) { set_error("mix_decoder: granule area too small"); return FOV_ERR_WORKSPACE; }
     p.status = (unsigned*)workspace;
     p.xch = (unsigned long long*)((char*)workspace + kStatusBytes);
     float* k2p = (float*)((char*)workspace + kStatusBytes + kXchBytes);

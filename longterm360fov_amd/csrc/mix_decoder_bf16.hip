@@ -43,8 +43,8 @@ __global__ __launch_bounds__(256, 1) void mix_decoder_bf16_kernel(MixDecParams p
     const int col0 = hi * QH + unit, col1 = (2 + hi) * QH + unit;
     constexpr int H4 = 4 * QH;
 
-    __shared__ unsigned sXch[2];
-    const unsigned arrival = xch_arrive(p.status, sXch);
+    __shared__ unsigned sXch[4];
+    const unsigned arrival = xch_arrive(p.status, sXch, group, slice);
     const bool poisoned = xch_poisoned(p.status);
     if (tid == 0) sFlag[0] = poisoned ? 1 : 0;
     // ---- resident weights (packed bf16 B fragments) ----
@@ -73,10 +73,12 @@ __global__ __launch_bounds__(256, 1) void mix_decoder_bf16_kernel(MixDecParams p
     const int my_row0 = 4 * g4 + 2 * hi;
     const unsigned pub_off = (unsigned)((my_row0 >> 1) * QH + unit) * 8u;
     constexpr unsigned LAYER_BYTES = 2u * Q_TILE_BYTES;
+    xch_hello_poll(p.status, sXch, group, QG, &sFlag[0]);   // same-XCD handshake (xch_common.h): partners' words, published at entry
     __syncthreads();
     const XchTicket ticket = xch_ticket(sXch, arrival);
     unsigned epoch = ticket.base;
     bool aborted = sFlag[0] != 0;
+    if (tid == 0 && !ticket.same_xcd && !aborted) xch_count_safe(p.status, ticket);   // (fov_exchange_mode)
     QGather gq;
 
     for (int tile = group; tile < p.num_tiles && !aborted; tile += p.num_groups) {
@@ -136,7 +138,7 @@ __global__ __launch_bounds__(256, 1) void mix_decoder_bf16_kernel(MixDecParams p
             }
             // publish h1_t, write the own cells into the tile, run h2_{t-1} . R2 under the exchange
             const unsigned h1pair = pack_bf16(h1c[0], h1c[1]);
-            __builtin_amdgcn_raw_buffer_store_b64((qu32x2){h1pair, epoch}, xrs, pub_off, par, 16);
+            XCH_STORE_B64(ticket.same_xcd, ((qu32x2){h1pair, epoch}), xrs, pub_off, par);
             sH1[my_row0 * QLD + unit] = (unsigned short)(h1pair & 0xffffu);
             sH1[(my_row0 + 1) * QLD + unit] = (unsigned short)(h1pair >> 16);
             acc2[0] = (f32x4){b2v[0], b2v[0], b2v[0], b2v[0]};
@@ -172,7 +174,7 @@ __global__ __launch_bounds__(256, 1) void mix_decoder_bf16_kernel(MixDecParams p
                 }
             }
             const unsigned h2pair = pack_bf16(h2c[0], h2c[1]);
-            __builtin_amdgcn_raw_buffer_store_b64((qu32x2){h2pair, epoch}, xrs, pub_off, LAYER_BYTES + par, 16);
+            XCH_STORE_B64(ticket.same_xcd, ((qu32x2){h2pair, epoch}), xrs, pub_off, LAYER_BYTES + par);
             sH2[my_row0 * QLD + unit] = (unsigned short)(h2pair & 0xffffu);
             sH2[(my_row0 + 1) * QLD + unit] = (unsigned short)(h2pair >> 16);
             const bool more = (t + 1 < p.T_out);
@@ -252,7 +254,7 @@ int mix_decoder_bf16_launch(MixDecParams p, const float* K2, int act, int train,
     const int max_groups = device_cu_count() / QG;   // one workgroup per CU: every group must be co-resident
     if (max_groups < 1) { set_error("fused mixing decoder needs at least %d CUs", QG); return FOV_ERR_UNSUPPORTED; }
     p.num_groups = p.num_tiles < max_groups ? p.num_tiles : max_groups;
-    if ((size_t)p.num_groups * 4 * Q_TILE_BYTES > kXchBytes) { set_error("mix_decoder_bf16: granule area too small"); return FOV_ERR_WORKSPACE; }
+    if ((size_t)p.num_groups * 4 * Q_TILE_BYTES > kXchBytes - kHelloBytes) { set_error("mix_decoder_bf16: granule area too small"); return FOV_ERR_WORKSPACE; }
     p.status = (unsigned*)workspace;
     p.xch = (unsigned long long*)((char*)workspace + kStatusBytes);
     p.K2p = K2;   // no packed copy: the kernel builds its register-resident fragments from the plain (H,4H) kernel

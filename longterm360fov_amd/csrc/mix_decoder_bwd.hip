@@ -116,8 +116,8 @@ __global__ __launch_bounds__(256, 1) void mix_decoder_bwd_kernel(MixDecBwdParams
     const int unit = 32 * slice + ul;
     const int my_row0 = 4 * g4 + 2 * hi;
     // epoch tags continue from the workspace header, a poisoned workspace skips the body (xch_common.h)
-    __shared__ unsigned sXch[2];
-    const unsigned arrival = xch_arrive(p.status, sXch);
+    __shared__ unsigned sXch[4];
+    const unsigned arrival = xch_arrive(p.status, sXch, group, slice);
     const bool poisoned = xch_poisoned(p.status);
     if (tid == 0) sFlag[0] = poisoned ? 1 : 0;
 
@@ -223,10 +223,12 @@ __global__ __launch_bounds__(256, 1) void mix_decoder_bwd_kernel(MixDecBwdParams
             out[q] = acc;
         }
     };
+    xch_hello_poll(p.status, sXch, group, BG, &sFlag[0]);   // same-XCD handshake (xch_common.h): partners' words, published at entry
     __syncthreads();
     const XchTicket ticket = xch_ticket(sXch, arrival);
     epoch = ticket.base;
     aborted = sFlag[0] != 0;
+    if (tid == 0 && !ticket.same_xcd && !aborted) xch_count_safe(p.status, ticket);   // (fov_exchange_mode)
 
     for (int tile = group; tile < p.num_tiles && !aborted; tile += p.num_groups) {
         const int b0 = tile * BBT;
@@ -342,7 +344,7 @@ __global__ __launch_bounds__(256, 1) void mix_decoder_bwd_kernel(MixDecBwdParams
                         const unsigned off = (unsigned)(((((d * BG + slice) * 2 + q) * BBT + 4 * g4) * 32) + 16 * (tl & 1) + n) * 8u;
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
-                            __builtin_amdgcn_raw_buffer_store_b64((bwu32x2){__float_as_uint(acc[q * 4 + tl][r]), epoch}, rs2, off + r * 32 * 8, par2, 16);
+                            XCH_STORE_B64(ticket.same_xcd, ((bwu32x2){__float_as_uint(acc[q * 4 + tl][r]), epoch}), rs2, off + r * 32 * 8, par2);
                     }
             }
             // tape of layer 1: requested under the exchange wait below
@@ -412,8 +414,8 @@ __global__ __launch_bounds__(256, 1) void mix_decoder_bwd_kernel(MixDecBwdParams
                 }
                 sx += __shfl_xor(sx, 8);   // the two column halves of one (sequence, output)
                 if (ho < 8)
-                    __builtin_amdgcn_raw_buffer_store_b64((bwu32x2){__float_as_uint(sx), epoch}, rsx,
-                                                          (unsigned)((slice * BBT + hrow) * 8 + ho) * 8u, parx, 16);
+                    XCH_STORE_B64(ticket.same_xcd, ((bwu32x2){__float_as_uint(sx), epoch}), rsx,
+                                                          (unsigned)((slice * BBT + hrow) * 8 + ho) * 8u, parx);
             }
             // ================= partial[16 x 256] = dz1_own . R1^T_own =================
             {
@@ -440,7 +442,7 @@ __global__ __launch_bounds__(256, 1) void mix_decoder_bwd_kernel(MixDecBwdParams
                     const unsigned off = (unsigned)((((d * BG + slice) * BBT + 4 * g4) * 32) + 16 * (tl & 1) + n) * 8u;
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        __builtin_amdgcn_raw_buffer_store_b64((bwu32x2){__float_as_uint(acc[tl][r]), epoch}, rs1, off + r * 32 * 8, par1, 16);
+                        XCH_STORE_B64(ticket.same_xcd, ((bwu32x2){__float_as_uint(acc[tl][r]), epoch}), rs1, off + r * 32 * 8, par1);
                 }
             }
             MIXB_STAMP(7);
@@ -506,7 +508,7 @@ int mix_decoder_bwd_launch(MixDecBwdParams p, const float* K2, int act, void* wo
     const int max_groups = device_cu_count() / BG;   // one workgroup per CU: every group must be co-resident
     if (max_groups < 1) { set_error("fused mixing decoder backward needs at least %d CUs", BG); return FOV_ERR_UNSUPPORTED; }
     p.num_groups = p.num_tiles < max_groups ? p.num_tiles : max_groups;
-    if ((size_t)p.num_groups * MB_GROUP * sizeof(unsigned long long) > kXchBytes) { set_error("mix_decoder_bwd: granule area too small"); return FOV_ERR_WORKSPACE; }
+    if ((size_t)p.num_groups * MB_GROUP * sizeof(unsigned long long) > kXchBytes - kHelloBytes) { set_error("mix_decoder_bwd: granule area too small"); return FOV_ERR_WORKSPACE; }
     p.status = (unsigned*)workspace;
     p.xch = (unsigned long long*)((char*)workspace + kStatusBytes);
     float* k2p = (float*)((char*)workspace + kStatusBytes + kXchBytes);

@@ -50,8 +50,8 @@ __global__ __launch_bounds__(256, 1) void mix_decoder_bwd_bf16_kernel(MixDecBwdP
     const int ul = 8 * wave + (n & 7);          // unit inside the workgroup (0..31)
     const int unit = 32 * slice + ul;
     const int my_row0 = 4 * g4 + 2 * hi;
-    __shared__ unsigned sXch[2];
-    const unsigned arrival = xch_arrive(p.status, sXch);
+    __shared__ unsigned sXch[4];
+    const unsigned arrival = xch_arrive(p.status, sXch, group, slice);
     const bool poisoned = xch_poisoned(p.status);
     if (tid == 0) { sFlag[0] = poisoned ? 1 : 0; sFlag[1] = 0; sFlag[2] = 0; }
 
@@ -82,10 +82,12 @@ __global__ __launch_bounds__(256, 1) void mix_decoder_bwd_bf16_kernel(MixDecBwdP
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
         p.xch + (size_t)group * 4 * (Q_DZ_BYTES / 8), 0, (int)(4 * Q_DZ_BYTES), 0x00020000);
     constexpr unsigned LAYER_BYTES = 2u * Q_DZ_BYTES;
+    xch_hello_poll(p.status, sXch, group, QG, &sFlag[0]);   // same-XCD handshake (xch_common.h): partners' words, published at entry
     __syncthreads();
     const XchTicket ticket = xch_ticket(sXch, arrival);
     unsigned epoch = ticket.base;
     bool aborted = sFlag[0] != 0;
+    if (tid == 0 && !ticket.same_xcd && !aborted) xch_count_safe(p.status, ticket);   // (fov_exchange_mode)
 
     for (int tile = group; tile < p.num_tiles && !aborted; tile += p.num_groups) {
         const int b0 = tile * QBT;
@@ -165,7 +167,7 @@ __global__ __launch_bounds__(256, 1) void mix_decoder_bwd_bf16_kernel(MixDecBwdP
                 unsigned dzp[4];
 #pragma unroll
                 for (int g = 0; g < 4; ++g) dzp[g] = pack_bf16(dz[0][g], dz[1][g]);
-                q_dz_publish(rs, LAYER_BYTES + par, my_row0, unit, dzp, epoch, sDZ);
+                q_dz_publish(rs, LAYER_BYTES + par, my_row0, unit, dzp, epoch, sDZ, ticket.same_xcd);
 #pragma unroll
                 for (int r = 0; r < 2; ++r) {
                     const int row = b0 + my_row0 + r;
@@ -231,7 +233,7 @@ __global__ __launch_bounds__(256, 1) void mix_decoder_bwd_bf16_kernel(MixDecBwdP
                 unsigned dzp[4];
 #pragma unroll
                 for (int g = 0; g < 4; ++g) dzp[g] = pack_bf16(dz[0][g], dz[1][g]);
-                q_dz_publish(rs, par, my_row0, unit, dzp, epoch, sDZ);
+                q_dz_publish(rs, par, my_row0, unit, dzp, epoch, sDZ, ticket.same_xcd);
 #pragma unroll
                 for (int r = 0; r < 2; ++r) {
                     const int row = b0 + my_row0 + r;
@@ -305,7 +307,7 @@ int mix_decoder_bwd_bf16_launch(MixDecBwdParams p, const float* K2, int act, voi
     const int max_groups = device_cu_count() / QG;   // one workgroup per CU: every group must be co-resident
     if (max_groups < 1) { set_error("fused mixing decoder backward needs at least %d CUs", QG); return FOV_ERR_UNSUPPORTED; }
     p.num_groups = p.num_tiles < max_groups ? p.num_tiles : max_groups;
-    if ((size_t)p.num_groups * 4 * Q_DZ_BYTES > kXchBytes) { set_error("mix_decoder_bwd_bf16: granule area too small"); return FOV_ERR_WORKSPACE; }
+    if ((size_t)p.num_groups * 4 * Q_DZ_BYTES > kXchBytes - kHelloBytes) { set_error("mix_decoder_bwd_bf16: granule area too small"); return FOV_ERR_WORKSPACE; }
     if ((((uintptr_t)K2) | ((uintptr_t)p.R1) | ((uintptr_t)p.R2) | ((uintptr_t)p.K1)) & 15) {
         set_error("mix_decoder_bwd_bf16: kernels must be 16-byte aligned");
         return FOV_ERR_INVALID;

@@ -19,6 +19,16 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+// A granule store of an exchanging kernel: sc0 (the line stays in the XCD's L2, where the partners' L1-bypassing sc1 loads
+// find it at L2-hit latency) when the hello handshake of this launch has shown every member of the group on ONE XCD
+// (XchTicket::same_xcd), sc1 (write-through, placement-independent) otherwise.  Measured with the handshake forced off /
+// on, same box (round 3): configs[2] training step 0.968 -> 0.884 ms fp32, 0.622 -> 0.545 ms bf16 operands.
+#define XCH_STORE_B64(same, data, rsrc, voff, soff)                                                    \
+    do {                                                                                               \
+        if (same) __builtin_amdgcn_raw_buffer_store_b64(data, rsrc, voff, soff, 1 /* sc0 */);          \
+        else __builtin_amdgcn_raw_buffer_store_b64(data, rsrc, voff, soff, 16 /* sc1 */);              \
+    } while (0)
+
 namespace fov {
 
 enum : int {
@@ -27,9 +37,21 @@ enum : int {
     ST_LAUNCHES = 2,    // exchange launches whose workgroups have all arrived
     ST_EPOCH = 3,       // epoch base: every tag written by launches < ST_LAUNCHES is <= this value
     ST_SAFE0 = 4,       // ST_SAFE0 + (launch & 1): workgroups of that launch on the placement-independent (sc1) exchange
+    ST_FORCE_SAFE = 6,  // != 0: never take the same-XCD fast exchange (fov_workspace_force_safe: the tests' A/B switch)
 };
 
 constexpr size_t kXchBytes = (size_t)64 << 20;   // fixed granule area: the largest user (fused decoder backward, 32 groups) needs 50.9 MB
+constexpr size_t kHelloBytes = (size_t)64 << 10; // its last 64 KB: hello words of the same-XCD handshake, [group][8 members]
+
+// where the members of group `group` publish {launch tag, XCC id}: only the status pointer (= workspace start) is needed
+__device__ __forceinline__ unsigned long long* xch_hello_words(unsigned* status, int group) {
+    return (unsigned long long*)((char*)status + 256 + kXchBytes - kHelloBytes) + (size_t)group * 8;
+}
+__device__ __forceinline__ unsigned xch_xcc_id() {
+    unsigned x;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(x));
+    return x;
+}
 
 __device__ __forceinline__ unsigned xch_status_load(const unsigned* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -45,6 +67,7 @@ struct XchTicket {
     unsigned base;      // epoch base of this launch: its tags lie in (base, base + span]
     unsigned launch;    // index of this launch on the workspace
     unsigned arrival;   // unused since round 3 (kept for the call sites' signature)
+    bool same_xcd;      // the hello handshake of this launch found every member of the group on one XCD (XCH_STORE_B64)
 };
 
 // Kernel entry, in two halves around the prologue's first workgroup barrier: THREAD 0 reads the header, counts its
@@ -57,17 +80,49 @@ struct XchTicket {
 __device__ __forceinline__ void xch_count_arrival(unsigned* status) {
     __hip_atomic_fetch_add(status + ST_ARRIVED, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // result unused: no return, no wait
 }
-__device__ __forceinline__ unsigned xch_arrive(unsigned* status, unsigned* lds2) {
+// `lds2`: FOUR words since round 3 - base, launch, "hello handshake in use", "a partner sits on another XCD / fast path
+// forbidden".  group >= 0 starts the same-XCD handshake of the group's members (blocks 8 apart under the kernels' block
+// -> (group, slice) map, which round-robin dispatch puts on one XCD - a placement PREFERENCE that the handshake verifies
+// at run time): thread 0 publishes {launch tag, HW_REG_XCC_ID} at once, xch_hello_poll() collects the partners' words
+// later, behind the weight loads, when they have long become visible.
+__device__ __forceinline__ unsigned xch_arrive(unsigned* status, unsigned* lds2, int group = -1, int slice = 0) {
     if (threadIdx.x == 0) {
         unsigned base = xch_status_load(status + ST_EPOCH);
         unsigned launch = xch_status_load(status + ST_LAUNCHES);
-        // both words are read before the workgroup counts as arrived: once all have, the header may be rewritten
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(base), "+v"(launch)::"memory");
+        unsigned force = xch_status_load(status + ST_FORCE_SAFE);
+        // the words are read before the workgroup counts as arrived: once all have, the header may be rewritten
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(base), "+v"(launch), "+v"(force)::"memory");
         xch_count_arrival(status);
         lds2[0] = base;
         lds2[1] = launch;
+        lds2[2] = group >= 0 ? 1u : 0u;
+        lds2[3] = force;
+        if (group >= 0)   // the tag is larger than any tag of an earlier launch (every launch advances the base by >= 2)
+            __hip_atomic_store(xch_hello_words(status, group) + slice, ((unsigned long long)(base + 1u) << 32) | xch_xcc_id(),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     return 0u;
+}
+// Every thread may call it (in front of the barrier that precedes xch_ticket); lanes 0..G-1 of wave 0 each wait, bounded,
+// for one member's hello word of THIS launch and record a foreign XCC id.  A give-up poisons the workspace and sets *abort.
+__device__ __forceinline__ void xch_hello_poll(unsigned* status, unsigned* lds2, int group, int G, int* abort_flag) {
+    if (threadIdx.x < (unsigned)G && lds2[2] != 0u) {   // (same wave as thread 0, whose LDS stores precede in program order)
+        const unsigned long long* hello = xch_hello_words(status, group) + threadIdx.x;
+        const unsigned tag = lds2[0] + 1u;
+        unsigned long long hv = 0;
+        unsigned spins = 0;
+        while (true) {
+            hv = __hip_atomic_load(hello, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((unsigned)(hv >> 32) == tag) break;
+            if (++spins > (1u << 20) || ((spins & 63u) == 0 && xch_poisoned(status))) {
+                xch_give_up(status);
+                *abort_flag = 1;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(4);
+        }
+        if ((unsigned)hv != xch_xcc_id()) lds2[3] = 1u;
+    }
 }
 __device__ __forceinline__ XchTicket xch_ticket(const unsigned* lds2, unsigned arrival) {
     // readfirstlane: the words are the same for every lane, but a value loaded from LDS is divergent to the compiler, and an
@@ -82,6 +137,7 @@ __device__ __forceinline__ XchTicket xch_ticket(const unsigned* lds2, unsigned a
     t.launch = (unsigned)__builtin_amdgcn_readfirstlane((int)lds2[1]);
 #endif
     t.arrival = arrival;
+    t.same_xcd = __builtin_amdgcn_readfirstlane((int)lds2[2]) != 0 && __builtin_amdgcn_readfirstlane((int)lds2[3]) == 0;
     return t;
 }
 // Every workgroup calls it at its very end; thread 0 of BLOCK 0 publishes the header of the NEXT launch once the

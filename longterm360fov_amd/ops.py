@@ -4,6 +4,8 @@ PyTorch is plumbing only: device memory, streams and (elsewhere) torch.distribut
 function here hands raw device pointers and sizes to libfov360_hip.so; nothing is computed by
 torch and there is no fallback path.
 """
+import os
+
 import torch
 
 from . import _lib
@@ -40,6 +42,17 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+def _apply_force_safe(holder):
+    """FOV_FORCE_SAFE_EXCHANGE=1 (read per call: the tests flip it between calls) -> the workspace's header word that keeps
+    every exchanging kernel on the placement-independent granule exchange (fov_workspace_force_safe)."""
+    want = os.environ.get("FOV_FORCE_SAFE_EXCHANGE", "") == "1"
+    if holder.buf is not None and getattr(holder, "_forced", (None, False)) != (holder.buf.data_ptr(), want):
+        if want or getattr(holder, "_forced", (None, False))[1]:
+            with torch.cuda.device(holder.buf.device):
+                check(_lib.lib().fov_workspace_force_safe(holder.buf.data_ptr(), holder.buf.numel(), 1 if want else 0, _stream()))
+        holder._forced = (holder.buf.data_ptr(), want)
+
+
 def _new_workspace(nbytes, device):
     """A fresh workspace buffer, zero-filled ONCE through the C ABI (fov_workspace_init): the persistent kernels keep
     a header and monotone epoch tags in it across calls, no call clears anything (include/fov360.h, Conventions)."""
@@ -61,6 +74,7 @@ class Workspace:
         nbytes = max(int(nbytes), 256)
         if self.buf is None or self.buf.numel() < nbytes or self.buf.device != device:
             self.buf = _new_workspace(nbytes, device)
+        _apply_force_safe(self)
         return self.buf
 
     def check(self):
@@ -252,6 +266,7 @@ class Scratch:
         nbytes = max(int(nbytes), 256)
         if self.buf is None or self.buf.numel() < nbytes or self.buf.device != device:
             self.buf = _new_workspace(nbytes, device)
+        _apply_force_safe(self)
         return self.buf
 
     def check(self):

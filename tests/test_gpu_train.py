@@ -1359,3 +1359,29 @@ def test_config2_full_size_training_gradients():
     assert abs(float(loss.item()) - loss_ref) <= 1e-5 * loss_ref + 1e-9
     np.testing.assert_allclose(y.cpu().numpy(), y_ref, atol=2e-5)
     check_grads(tr.g, g_ref, "config2 full size")
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_training_step_same_xcd_and_safe_exchange_agree_bitwise(dtype):
+    """The eight-workgroup kernels of the configs[2] step (wide-input layers, fused decoder forward / backward, BPTT) take
+    the same-XCD granule exchange (sc0 stores) only when their run-time handshake shows the whole group on one XCD;
+    FOV_FORCE_SAFE_EXCHANGE=1 (-> fov_workspace_force_safe) keeps them on the placement-independent write-through
+    exchange.  Three optimizer steps must give bit-identical parameters either way."""
+    from longterm360fov_amd.training import OthersMixingTrainer
+    w = O.init_others_mixing(323, H=256, num_user=6, bias_noise=0.05)
+    enc, dec0, tgt, oth = O.synthetic_batch(324, 512, 4, 3, num_others=5)
+    flats, modes = {}, {}
+    try:
+        for forced in ("0", "1"):
+            os.environ["FOV_FORCE_SAFE_EXCHANGE"] = forced
+            tr = OthersMixingTrainer(w, dtype=dtype)
+            for _ in range(3):
+                tr.train_step(dev(enc), dev(oth), dev(dec0), dev(tgt))
+            tr.check()
+            flats[forced] = tr.flat.clone()
+            modes[forced] = tr.ws.exchange_mode()
+            print("FOV_FORCE_SAFE_EXCHANGE=%s: exchange mode of the last launch on the forward workspace: %d" % (forced, modes[forced]))
+    finally:
+        os.environ.pop("FOV_FORCE_SAFE_EXCHANGE", None)
+    assert modes["1"] == 2
+    assert torch.equal(flats["0"], flats["1"])
