@@ -42,6 +42,29 @@ PMC_TRAFFIC_BYTES = (17540 + 5606) * 1024
 PMC_TRAFFIC_SOURCE = "profiles/r02_pmc_bench_v4.txt"
 
 
+# HBM-side bytes per step of the secondary modes, from the same kind of rocprofv3 --pmc passes (tools/pmc_any.sh: FETCH_SIZE and
+# WRITE_SIZE in separate passes, raw KiB summed over the step's dispatches); None until a profile of the current build is
+# committed.  key = (mode, dtype)
+MODE_TRAFFIC = {}
+
+
+def mode_traffic(mode, dtype, ms):
+    t = MODE_TRAFFIC.get((mode, dtype))
+    if not t:
+        return {"traffic": None}
+    return {"traffic": t[0], "traffic_source": t[1], "hbm_gbps": t[0] / (ms * 1e-3) / 1e9, "hbm_peak_gbps": 8000.0,
+            "hbm_frac": t[0] / (ms * 1e-3) / 1e9 / 8000.0}
+
+
+def cpu_leg(fn, n_units, threads, impl, budget_s, unit="sequences/s"):
+    """A CPU-baseline object from one timed callable (oracle/torch_cpu.py legs): median over a bounded sample."""
+    from oracle import torch_cpu as TC
+    med, n = TC.timed_median(fn, budget_s=budget_s, min_iters=3, max_iters=100, warmup=1)
+    return {"value": n_units / med, "unit": unit, "cores": threads, "kind": "port",
+            "sample": "median of %d passes over the same batch of %d sequences; %s, %d threads" % (n, n_units, impl, threads),
+            "cpu_model": TC.cpu_model(), "host_cores_usable": TC.usable_cores(), "ms_per_pass": med * 1e3}
+
+
 def log(msg):
     """Progress on stderr (stdout carries exactly one JSON line)."""
     sys.stderr.write("[bench %6.1fs] %s\n" % (time.perf_counter() - _T0, msg))
@@ -102,6 +125,13 @@ def bench_train(args, rank, world, use_dist):
         f_enc, f_dec = flops_per_seq(T_in, T_out, 90, 6, H)
         flop_step = 3 * (f_enc + f_dec) * B      # training step counted as 3x forward
         ms = elapsed / args.steps * 1e3
+        cpu = None
+        if not args.no_cpu_baseline and world == 1 and args.act == "sigmoid":
+            from oracle import torch_cpu as TC
+            log("cpu baseline: torch CPU autograd training step, %d threads" % CPU_THREADS)
+            mc = TC.Seq2SeqCPU(w, threads=min(TC.usable_cores(), CPU_THREADS))
+            cpu = cpu_leg(lambda: mc.train_step(enc, dec_in, tgt), B, mc.threads,
+                          "torch %s CPU ops (nn.LSTM x2 + Linear, autograd, Adam)" % torch.__version__, args.cpu_budget)
         print(json.dumps({
             "metric": "training sequences/sec (batch=%d per GPU, T_in=%d->T_out=%d, h=%d)" % (B, T_in, T_out, H),
             "value": world * B * args.steps / elapsed, "unit": "sequences/s", "n_gpus": world, "steps": args.steps,
@@ -110,9 +140,9 @@ def bench_train(args, rank, world, use_dist):
             "config": {"workload": "teacher-forced training step of configs[1] shape (fwd + BPTT + Keras Adam), fp32",
                        "global_batch": B * world, "parallelism": "dp%d, one flat-buffer all-reduce per step" % world},
             "roofline": {"bound": "mfma", "achieved": flop_step / (ms * 1e-3) / 1e12, "peak": PEAK_FP32_MFMA_TFLOPS,
-                         "unit": "TFLOP/s", "frac": flop_step / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
-                         "note": "whole step, 3x forward FLOPs"},
-            "cpu_baseline": None}), flush=True)
+                         "unit": "TFLOP/s", "frac": flop_step / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                         "note": "whole step, 3x forward FLOPs", **mode_traffic("train", "f32", ms)},
+            "cpu_baseline": cpu}), flush=True)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
@@ -157,6 +187,14 @@ def bench_train_mixing(args, rank, world, use_dist):
         fwd = (T_in * (2 * (90 + H) * 4 * H + 2 * (H + H) * 4 * H) +
                T_out * (2 * (6 + H) * 4 * H + 2 * (H + H) * 4 * H + 2 * H * 6 + 2 * U * 6 * 6))
         ms = elapsed / args.steps * 1e3
+        cpu = None
+        if not args.no_cpu_baseline and world == 1 and args.act == "sigmoid":
+            from oracle import torch_cpu as TC
+            log("cpu baseline: torch CPU autograd training step of the unrolled graph, %d threads" % CPU_THREADS)
+            mc = TC.OthersMixingCPU(w, threads=min(TC.usable_cores(), CPU_THREADS))
+            cpu = cpu_leg(lambda: mc.train_step(enc, oth, dec0, tgt), B, mc.threads,
+                          "torch %s CPU ops (nn.LSTM 2 layers + 2 LSTMCell + 2 Linear per step, autograd, Adam), fp32" % torch.__version__,
+                          args.cpu_budget)
         print(json.dumps({
             "metric": "training sequences/sec, others-mixing 2+2 layers (batch=%d per GPU, T 10->10, h=%d, U=%d)" % (B, H, U),
             "value": world * B * args.steps / elapsed, "unit": "sequences/s", "n_gpus": world, "steps": args.steps,
@@ -167,10 +205,11 @@ def bench_train_mixing(args, rank, world, use_dist):
                                    "given_others_gt_mean_var_seq2seq training step (fused decoder forward and backward launches)", "global_batch": B * world,
                        "parallelism": "dp%d, one flat-buffer all-reduce per step" % world},
             "roofline": {"bound": "mfma", "achieved": 3 * fwd * B / (ms * 1e-3) / 1e12, "peak": peak_for(args.dtype),
-                         "unit": "TFLOP/s", "frac": 3 * fwd * B / (ms * 1e-3) / 1e12 / peak_for(args.dtype), "traffic": None,
+                         "unit": "TFLOP/s", "frac": 3 * fwd * B / (ms * 1e-3) / 1e12 / peak_for(args.dtype),
                          "note": "whole step, 3x forward FLOPs; at 512 sequences per GPU the step is a chain of 40 dependent recurrent "
-                                 "steps per direction: bound by the per-step exchange latency, not by the matrix rate"},
-            "cpu_baseline": None}), flush=True)
+                                 "steps per direction: bound by the per-step exchange latency, not by the matrix rate",
+                         **mode_traffic("train_mixing", args.dtype, ms)},
+            "cpu_baseline": cpu}), flush=True)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
@@ -220,6 +259,13 @@ def bench_infer_mixing(args, rank, world, use_dist):
         fwd = (T_in * (2 * (90 + H) * 4 * H + 2 * (H + H) * 4 * H) +
                T_out * (2 * (6 + H) * 4 * H + 2 * (H + H) * 4 * H + 2 * H * 6 + 2 * U * 6 * 6))
         ms = elapsed / args.steps * 1e3
+        cpu = None
+        if not args.no_cpu_baseline and world == 1 and args.act == "sigmoid":
+            from oracle import torch_cpu as TC
+            log("cpu baseline: torch CPU ops, %d threads" % CPU_THREADS)
+            mc = TC.OthersMixingCPU(w, threads=min(TC.usable_cores(), CPU_THREADS))
+            cpu = cpu_leg(lambda: mc.predict(enc, oth, dec0), B, mc.threads,
+                          "torch %s CPU ops (nn.LSTM 2 layers + 2 LSTMCell + 2 Linear per step), fp32" % torch.__version__, args.cpu_budget / 2)
         print(json.dumps({
             "metric": "sequences/sec, others-mixing 2+2 layers inference (batch=%d per GPU, T 10->10, h=%d, U=%d)" % (B, H, U),
             "value": world * B * args.steps / elapsed, "unit": "sequences/s", "n_gpus": world, "steps": args.steps,
@@ -229,9 +275,10 @@ def bench_infer_mixing(args, rank, world, use_dist):
                                    "no-teacher-forcing decoder with others mixing)", "global_batch": B * world,
                        "parallelism": "replicas x%d (no collective)" % world},
             "roofline": {"bound": "mfma", "achieved": fwd * B / (ms * 1e-3) / 1e12, "peak": peak_for(args.dtype),
-                         "unit": "TFLOP/s", "frac": fwd * B / (ms * 1e-3) / 1e12 / peak_for(args.dtype), "traffic": None},
+                         "unit": "TFLOP/s", "frac": fwd * B / (ms * 1e-3) / 1e12 / peak_for(args.dtype),
+                         **mode_traffic("infer_mixing", args.dtype, ms)},
             "parity": {"max_abs_err_vs_oracle": err, "max_abs_err_vs_bf16_operand_oracle": err_q, "sequences_checked": 32},
-            "cpu_baseline": None}), flush=True)
+            "cpu_baseline": cpu}), flush=True)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
@@ -271,6 +318,14 @@ def cpu_baseline_seq2seq(enc, dec0, w, T_out, act, budget_s, want_out=False):
                          "value": B / med, "ms_per_pass": med * 1e3, "passes": n, "cores": m.threads})
             if want_out and out_t is None:
                 out_t = m.decode(enc, dec0, T_out)
+            # leg 3: hand-arranged sgemm loop - input projection of all steps as one sgemm, one sgemm per
+            # recurrent step, fused gates - at the GPU's share of the host AND at every usable core
+            for thr in sorted({nthr, cores}):
+                sg = TC.Seq2SeqSgemmCPU(w, threads=thr)
+                med, n = TC.timed_median(lambda: sg.decode(enc, dec0, T_out), budget_s=per_leg / 2, min_iters=3)
+                legs.append({"impl": "sgemm loop (torch.addmm -> MKL/oneDNN sgemm per step, fused gates)", "value": B / med,
+                             "ms_per_pass": med * 1e3, "passes": n, "cores": thr})
+                log("  sgemm loop, %d threads: %.1f ms per pass (%d passes)" % (thr, med * 1e3, n))
     best = max(legs, key=lambda l: l["value"])
     cpu = {"value": best["value"], "unit": "sequences/s", "cores": best["cores"], "kind": "port",
            "sample": "median of %d passes over the same %d-sequence batch (T_in=%d -> T_out=%d); fastest of %d legs: %s, %d threads"
@@ -369,6 +424,26 @@ def bench_a10(args, rank, world, use_dist):
         flop = 2.0 * B * T * ((F + H) * 4 * H + (H + H) * 4 * H)
         res[tag] = {"ms": ms, "sequences_per_s": B / (ms * 1e-3), "tflops": flop / (ms * 1e-3) / 1e12,
                     "max_abs_err_vs_oracle": float(np.abs(got - ref).max())}
+    cpu = None
+    if rank == 0 and not args.no_cpu_baseline and world == 1:
+        from oracle import torch_cpu as TC
+        thr = min(TC.usable_cores(), CPU_THREADS)
+        lrng = np.random.default_rng(400)
+        layers = [O.init_lstm(lrng, F, 400), O.init_lstm(lrng, 400, 400)]
+        net = torch.nn.LSTM(F, 400, num_layers=2, batch_first=True)
+        with torch.no_grad():
+            for l, (K, R, b) in enumerate(layers):
+                getattr(net, "weight_ih_l%d" % l).copy_(torch.from_numpy(K.T.copy()))
+                getattr(net, "weight_hh_l%d" % l).copy_(torch.from_numpy(R.T.copy()))
+                getattr(net, "bias_ih_l%d" % l).copy_(torch.from_numpy(b))
+                getattr(net, "bias_hh_l%d" % l).zero_()
+        xt = torch.from_numpy(x)
+
+        def cpu_step():
+            torch.set_num_threads(thr)
+            with torch.no_grad():
+                return net(xt)[0]
+        cpu = cpu_leg(cpu_step, B, thr, "torch %s CPU nn.LSTM(90, 400, num_layers=2)" % torch.__version__, 5.0)
     if rank == 0:
         r = res["h400_stepwise_mfma_gemm"]
         print(json.dumps({
@@ -381,7 +456,7 @@ def bench_a10(args, rank, world, use_dist):
             "roofline": {"bound": "mfma", "achieved": r["tflops"], "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": r["tflops"] / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
                          "note": "32 sequences, ~3 launches per layer-step: launch-latency-bound by construction"},
-            "variants": res, "cpu_baseline": None}), flush=True)
+            "variants": res, "cpu_baseline": cpu}), flush=True)
 
 
 def bench_convlstm(args, rank, world, use_dist):
@@ -484,8 +559,8 @@ def bench_dry_run(args, rank, world, use_dist):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=300, help="timed steps (default: >= 100 ms of timed region at the headline shape)")
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=1024)
     ap.add_argument("--t-in", type=int, default=30)
     ap.add_argument("--t-out", type=int, default=30)

@@ -36,7 +36,6 @@ class Seq2SeqCPU:
 
     def __init__(self, w, threads=None):
         self.threads = int(threads or usable_cores())
-        torch.set_num_threads(self.threads)
         F_enc, H4 = w["enc_K"].shape
         H = H4 // 4
         F_dec = w["dec_K"].shape[0]
@@ -56,8 +55,29 @@ class Seq2SeqCPU:
             self.lin.weight.copy_(t(w["dense_W"].T))
             self.lin.bias.copy_(t(w["dense_b"]))
 
+    def train_step(self, enc_in, dec_in, target):
+        """One teacher-forced training step (FoV_seq2seq.py:82-103,112-117: MSE, Adam) with torch autograd on the CPU."""
+        torch.set_num_threads(self.threads)
+        if not hasattr(self, "_dec"):
+            H = self.cell.hidden_size
+            self._dec = torch.nn.LSTM(self.cell.input_size, H, batch_first=True)
+            with torch.no_grad():
+                self._dec.weight_ih_l0.copy_(self.cell.weight_ih); self._dec.weight_hh_l0.copy_(self.cell.weight_hh)
+                self._dec.bias_ih_l0.copy_(self.cell.bias_ih); self._dec.bias_hh_l0.zero_()
+            params = list(self.enc.parameters()) + list(self._dec.parameters()) + list(self.lin.parameters())
+            self._opt = torch.optim.Adam(params, lr=1e-3, eps=1e-7)
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
+        self._opt.zero_grad(set_to_none=True)
+        _, st = self.enc(t(enc_in))
+        hs, _ = self._dec(t(dec_in), st)
+        loss = torch.mean((torch.tanh(self.lin(hs)) - t(target)) ** 2)
+        loss.backward()
+        self._opt.step()
+        return float(loss)
+
     @torch.no_grad()
     def decode(self, enc_in, dec_in0, T_out):
+        torch.set_num_threads(self.threads)
         x = torch.from_numpy(np.ascontiguousarray(enc_in, dtype=np.float32))
         y = torch.from_numpy(np.ascontiguousarray(dec_in0[:, 0], dtype=np.float32))
         if x.shape[1] > 0:
@@ -72,6 +92,109 @@ class Seq2SeqCPU:
             y = torch.tanh(self.lin(h))
             outs.append(y)
         return torch.stack(outs, 1).numpy()
+
+
+class Seq2SeqSgemmCPU:
+    """The same graph as a hand-arranged sgemm loop (what BASELINE.md section 4 asks for as leg 1): the encoder's input
+    projection for ALL steps as one (B*T, F) x (F, 4H) sgemm, then per step one (B, H) x (H, 4H) sgemm (torch.addmm ->
+    MKL / oneDNN sgemm) and fused elementwise gates; the decoder per step one (B, F_dec + H) x (F_dec + H, 4H) sgemm on
+    [y | h].  Gate order i, f, c, o as in Keras; sigmoid recurrent activation."""
+
+    def __init__(self, w, threads=None):
+        self.threads = int(threads or usable_cores())
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
+        self.eK, self.eR, self.eb = t(w["enc_K"]), t(w["enc_R"]), t(w["enc_b"])
+        self.dW = torch.cat([t(w["dec_K"]), t(w["dec_R"])], 0)      # [K ; R]: (F_dec + H, 4H)
+        self.db = t(w["dec_b"])
+        self.W, self.b = t(w["dense_W"]), t(w["dense_b"])
+        self.H = self.eR.shape[0]
+
+    @staticmethod
+    def _cell(z, c, H):
+        i, f, g, o = torch.sigmoid(z[:, :H]), torch.sigmoid(z[:, H:2 * H]), torch.tanh(z[:, 2 * H:3 * H]), torch.sigmoid(z[:, 3 * H:])
+        c = f * c + i * g
+        return o * torch.tanh(c), c
+
+    @torch.no_grad()
+    def decode(self, enc_in, dec_in0, T_out):
+        torch.set_num_threads(self.threads)
+        x = torch.from_numpy(np.ascontiguousarray(enc_in, dtype=np.float32))
+        y = torch.from_numpy(np.ascontiguousarray(dec_in0[:, 0], dtype=np.float32))
+        B, T, F = x.shape
+        H = self.H
+        h = torch.zeros((B, H))
+        c = torch.zeros((B, H))
+        if T > 0:
+            zx = torch.addmm(self.eb, x.reshape(B * T, F), self.eK).reshape(B, T, 4 * H)
+            for t in range(T):
+                h, c = self._cell(torch.addmm(zx[:, t], h, self.eR), c, H)
+        outs = []
+        for _ in range(T_out):
+            h, c = self._cell(torch.addmm(self.db, torch.cat([y, h], 1), self.dW), c, H)
+            y = torch.tanh(torch.addmm(self.b, h, self.W))
+            outs.append(y)
+        return torch.stack(outs, 1).numpy()
+
+
+class OthersMixingCPU:
+    """given_others_gt_mean_var_seq2seq.py:98-130,203-299 (2-layer encoder, unrolled 2-layer decoder without teacher forcing,
+    Dense(6, tanh) + others mixing Dense(204 -> 6, tanh), user-major flatten with the prediction last) on torch CPU ops:
+    nn.LSTM for the encoder stack, two LSTMCell + two Linear per decoder step.  Forward only (inference baseline)."""
+
+    def __init__(self, w, threads=None):
+        self.threads = int(threads or usable_cores())
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
+        F, H4 = w["enc1_K"].shape
+        H, O = H4 // 4, w["dense_W"].shape[1]
+        self.enc = torch.nn.LSTM(F, H, num_layers=2, batch_first=True)
+        self.c1, self.c2 = torch.nn.LSTMCell(O, H), torch.nn.LSTMCell(H, H)
+        self.lin, self.mix = torch.nn.Linear(H, O), torch.nn.Linear(w["mix_W"].shape[0], O)
+        with torch.no_grad():
+            for l, name in ((0, "enc1"), (1, "enc2")):
+                getattr(self.enc, "weight_ih_l%d" % l).copy_(t(w[name + "_K"].T))
+                getattr(self.enc, "weight_hh_l%d" % l).copy_(t(w[name + "_R"].T))
+                getattr(self.enc, "bias_ih_l%d" % l).copy_(t(w[name + "_b"]))
+                getattr(self.enc, "bias_hh_l%d" % l).zero_()
+            for cell, name in ((self.c1, "dec1"), (self.c2, "dec2")):
+                cell.weight_ih.copy_(t(w[name + "_K"].T))
+                cell.weight_hh.copy_(t(w[name + "_R"].T))
+                cell.bias_ih.copy_(t(w[name + "_b"]))
+                cell.bias_hh.zero_()
+            self.lin.weight.copy_(t(w["dense_W"].T)); self.lin.bias.copy_(t(w["dense_b"]))
+            self.mix.weight.copy_(t(w["mix_W"].T)); self.mix.bias.copy_(t(w["mix_b"]))
+
+    def _forward(self, enc_in, others, dec_in0):
+        x = torch.from_numpy(np.ascontiguousarray(enc_in, dtype=np.float32))
+        oth = torch.from_numpy(np.ascontiguousarray(others, dtype=np.float32))
+        y = torch.from_numpy(np.ascontiguousarray(dec_in0[:, 0], dtype=np.float32))
+        _, (h, c) = self.enc(x)
+        h1, c1, h2, c2 = h[0], c[0], h[1], c[1]
+        B, T_out = oth.shape[0], oth.shape[1]
+        outs = []
+        for t in range(T_out):
+            h1, c1 = self.c1(y, (h1, c1))
+            h2, c2 = self.c2(h1, (h2, c2))
+            p = torch.tanh(self.lin(h2))
+            y = torch.tanh(self.mix(torch.cat([oth[:, t].reshape(B, -1), p], 1)))
+            outs.append(y)
+        return torch.stack(outs, 1)
+
+    def train_step(self, enc_in, others, dec_in0, target):
+        """One training step of the unrolled graph (given_others_gt_mean_var_seq2seq.py:308,494-506: MSE, Adam), torch autograd."""
+        torch.set_num_threads(self.threads)
+        if not hasattr(self, "_opt"):
+            params = [q for m in (self.enc, self.c1, self.c2, self.lin, self.mix) for q in m.parameters()]
+            self._opt = torch.optim.Adam(params, lr=1e-3, eps=1e-7)
+        self._opt.zero_grad(set_to_none=True)
+        loss = torch.mean((self._forward(enc_in, others, dec_in0) - torch.from_numpy(np.ascontiguousarray(target, dtype=np.float32))) ** 2)
+        loss.backward()
+        self._opt.step()
+        return float(loss)
+
+    @torch.no_grad()
+    def predict(self, enc_in, others, dec_in0):
+        torch.set_num_threads(self.threads)
+        return self._forward(enc_in, others, dec_in0).numpy()
 
 
 def timed_median(fn, budget_s=10.0, min_iters=10, max_iters=200, warmup=3):
