@@ -513,6 +513,12 @@ int fov_check_status(void* workspace, size_t workspace_bytes, fov_stream_t strea
  * (write-through) granule exchange even where its run-time handshake finds a whole group on one XCD.  Results are
  * bit-identical either way (tests/test_gpu_parity.py, tests/test_gpu_train.py); fov_exchange_mode tells which ran. */
 int fov_workspace_force_safe(void* workspace, size_t workspace_bytes, int on, fov_stream_t stream);
+/* The library reads its environment knobs (FOV_FORCE_SAFE_EXCHANGE, FOV_PAIR, FOV_TWO_LAUNCHES, FOV_DBG_RESIDENT_LIMIT)
+ * once, at first use; call this after changing them.  No launch path calls getenv. */
+void fov_reload_env(void);
+/* Test hook: set the workspace's epoch base (device header and the host-side accounting) - lets a test reach the
+ * re-zero threshold of the 32-bit epoch tags without 10^7 launches. */
+int fov_debug_set_epoch(void* workspace, size_t workspace_bytes, unsigned epoch, fov_stream_t stream);
 
 /* Diagnostic: which h-exchange protocol the last persistent-kernel call on `workspace` used.
  * 1 = every group verified (HW_REG_XCC_ID handshake) that its workgroups share an XCD and took the

@@ -99,6 +99,8 @@ SIGNATURES = {
     "fov_workspace_init": (_I, [_P, _SZ, _P]),
     "fov_check_status": (_I, [_P, _SZ, _P]),
     "fov_workspace_force_safe": (_I, [_P, _SZ, _I, _P]),
+    "fov_reload_env": (None, []),
+    "fov_debug_set_epoch": (_I, [_P, _SZ, ctypes.c_uint, _P]),
     "fov_exchange_mode": (_I, [_P, _SZ, _P]),
 }
 

@@ -4,6 +4,9 @@
 #include <stdarg.h>
 #include <stdio.h>
 
+#include <mutex>
+#include <unordered_map>
+
 #include "fov_common.h"
 #include "xch_common.h"
 #include "bf16_common.h"
@@ -332,7 +335,8 @@ __global__ __launch_bounds__(256) void window_stacks_kernel(const float* __restr
 
 static bool want_cluster(int impl, int F, int H, int F_dec, bool decode) {
     if (impl == FOV_IMPL_GENERIC) return false;
-    const bool ok = cluster_shape_ok(F, H) && (!decode || (F_dec >= 1 && F_dec <= 8));
+    // impl = auto also needs one whole group co-resident (device_cu_count honours FOV_DBG_RESIDENT_LIMIT): otherwise generic
+    const bool ok = cluster_shape_ok(F, H) && (!decode || (F_dec >= 1 && F_dec <= 8)) && device_cu_count() >= H / 64;
     return impl == FOV_IMPL_CLUSTER ? true : ok;
 }
 
@@ -349,6 +353,56 @@ static int check_ws(void* ws, size_t have, size_t need) {
     return FOV_OK;
 }
 
+// ---- cached environment knobs ----
+static EnvKnobs g_env;
+static std::once_flag g_env_once;
+static int env_flag(const char* name) { const char* e = getenv(name); return (e && e[0] == '1') ? 1 : 0; }
+void env_reload() {
+    g_env.force_safe_exchange = env_flag("FOV_FORCE_SAFE_EXCHANGE");
+    g_env.pair_kernel = env_flag("FOV_PAIR");
+    g_env.two_launches = getenv("FOV_TWO_LAUNCHES") ? 1 : 0;
+    const char* lim = getenv("FOV_DBG_RESIDENT_LIMIT");
+    g_env.resident_limit = lim ? atoi(lim) : 0;
+}
+const EnvKnobs& env_knobs() {
+    std::call_once(g_env_once, env_reload);
+    return g_env;
+}
+
+// ---- host-side epoch accounting per workspace ----
+struct XchState { unsigned long long epoch; int force_safe; };
+static std::unordered_map<void*, XchState> g_xch;
+static std::mutex g_xch_mu;
+int xch_account(void* workspace, long span, hipStream_t stream) {
+    std::lock_guard<std::mutex> lock(g_xch_mu);
+    XchState& st = g_xch[workspace];
+    st.epoch += (unsigned long long)(span > 0 ? span : 0) + 2ull;
+    if (st.epoch > 0x70000000ull) {
+        // every launch on this workspace passes here, so the device-side base is at most st.epoch: re-zero the header and the
+        // granule area in front of this launch (stream-ordered; launches on one workspace are serialised by contract)
+        hipError_t e = hipMemsetAsync(workspace, 0, kStatusBytes + kXchBytes, stream);
+        if (e == hipSuccess && st.force_safe)
+            e = hipMemsetD32Async((hipDeviceptr_t)((unsigned*)workspace + ST_FORCE_SAFE), 1, 1, stream);
+        if (e != hipSuccess) { set_error("epoch re-zero: %s", hipGetErrorString(e)); return FOV_ERR_LAUNCH; }
+        st.epoch = (unsigned long long)(span > 0 ? span : 0) + 2ull;
+    }
+    return FOV_OK;
+}
+void xch_forget(void* workspace) {
+    std::lock_guard<std::mutex> lock(g_xch_mu);
+    XchState& st = g_xch[workspace];
+    st.epoch = 0;
+}
+void xch_note_force_safe(void* workspace, int on) {
+    std::lock_guard<std::mutex> lock(g_xch_mu);
+    g_xch[workspace].force_safe = on ? 1 : 0;
+}
+// test hook: pretend `epoch` epochs have been consumed on this workspace (the device header is set to match by the caller)
+void xch_set_epoch_for_test(void* workspace, unsigned long long epoch) {
+    std::lock_guard<std::mutex> lock(g_xch_mu);
+    g_xch[workspace].epoch = epoch;
+}
+
 }  // namespace fov
 
 using namespace fov;
@@ -356,6 +410,16 @@ using namespace fov;
 extern "C" {
 
 const char* fov_last_error(void) { return g_err; }
+
+void fov_reload_env(void) { env_reload(); }
+
+int fov_debug_set_epoch(void* workspace, size_t workspace_bytes, unsigned epoch, fov_stream_t stream) {
+    if (!workspace || workspace_bytes < kStatusBytes) { set_error("fov_debug_set_epoch: invalid workspace"); return FOV_ERR_INVALID; }
+    hipError_t e = hipMemsetD32Async((hipDeviceptr_t)((unsigned*)workspace + ST_EPOCH), (int)epoch, 1, (hipStream_t)stream);
+    if (e != hipSuccess) { set_error("fov_debug_set_epoch: %s", hipGetErrorString(e)); return FOV_ERR_LAUNCH; }
+    xch_set_epoch_for_test(workspace, epoch);
+    return FOV_OK;
+}
 int fov_version(void) { return 100; }
 
 int fov_cluster_supported(int F, int H) { return cluster_shape_ok(F, H) ? 1 : 0; }
@@ -1020,6 +1084,8 @@ int fov_workspace_init(void* workspace, size_t workspace_bytes, fov_stream_t str
     }
     hipError_t e = hipMemsetAsync(workspace, 0, workspace_bytes, (hipStream_t)stream);
     if (e != hipSuccess) { set_error("fov_workspace_init: %s", hipGetErrorString(e)); return FOV_ERR_LAUNCH; }
+    xch_forget(workspace);
+    xch_note_force_safe(workspace, 0);
     return FOV_OK;
 }
 
@@ -1030,6 +1096,7 @@ int fov_workspace_force_safe(void* workspace, size_t workspace_bytes, int on, fo
     }
     hipError_t e = hipMemsetD32Async((hipDeviceptr_t)((unsigned*)workspace + ST_FORCE_SAFE), on ? 1 : 0, 1, (hipStream_t)stream);
     if (e != hipSuccess) { set_error("fov_workspace_force_safe: %s", hipGetErrorString(e)); return FOV_ERR_LAUNCH; }
+    xch_note_force_safe(workspace, on);
     return FOV_OK;
 }
 
@@ -1051,6 +1118,7 @@ int fov_check_status(void* workspace, size_t workspace_bytes, fov_stream_t strea
             e = hipMemsetD32Async((hipDeviceptr_t)((unsigned*)workspace + ST_FORCE_SAFE), 1, 1, (hipStream_t)stream);
         if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
         if (e != hipSuccess) { set_error("fov_check_status: %s", hipGetErrorString(e)); return FOV_ERR_LAUNCH; }
+        xch_forget(workspace);
     }
     if (st[ST_TIMEOUT] != 0) {
         set_error("a bounded in-kernel wait gave up (exchange launches on this workspace so far: %u); results since the last check are invalid",

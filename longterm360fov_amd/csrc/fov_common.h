@@ -68,8 +68,21 @@ int launch_cluster_decoder(const LstmParams& p, hipStream_t stream);   // MODE_D
 bool cluster_shape_ok(int F, int H);
 size_t cluster_workspace_bytes(int B, int H);
 int cluster_num_groups(int B, int H);
-int device_cu_count();                               // CUs of the current device
-int ensure_dynamic_lds(const void* kern, size_t lds);  // cached hipFuncSetAttribute(MaxDynamicSharedMemorySize)
+int device_cu_count();                               // CUs of the current device a persistent grid may count on (FOV_DBG_RESIDENT_LIMIT caps it: tests)
+// getenv results cached at first use (fov_reload_env re-reads them): nothing on a launch path calls getenv
+struct EnvKnobs {
+    int force_safe_exchange, pair_kernel, two_launches, resident_limit;
+};
+const EnvKnobs& env_knobs();
+void env_reload();
+// Host-side epoch accounting of a workspace (xch_common.h): every exchange launch adds its span; long before the 32-bit
+// tags could wrap, the header and the granule area are re-zeroed IN STREAM ORDER in front of the launch - whether or not
+// the caller ever calls fov_check_status.
+int xch_account(void* workspace, long span, hipStream_t stream);
+void xch_forget(void* workspace);                        // the workspace was (re)initialised
+void xch_note_force_safe(void* workspace, int on);
+void xch_set_epoch_for_test(void* workspace, unsigned long long epoch);
+int ensure_dynamic_lds(const void* kern, size_t lds, int block = 256);  // cached hipFuncSetAttribute(MaxDynamicSharedMemorySize) + occupancy check (>= 1 workgroup per CU)
 void set_error(const char* fmt, ...);
 // fused encoder + decoder with two tiles per workgroup, H = 256 (lstm_pair.hip)
 bool pair_shape_ok(int B, int T, int T_out, int F, int F_dec, int H);

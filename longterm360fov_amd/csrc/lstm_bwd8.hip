@@ -543,6 +543,7 @@ int launch_bwd8(const float* R, const float* reserve, const float* c0, const flo
     p.status = (unsigned*)xch_ws;
     p.xch = (unsigned long long*)((char*)xch_ws + kStatusBytes);
     p.epoch_span = T * ((p.num_tiles + p.num_groups - 1) / p.num_groups) + 1;
+    if (int rc_ = xch_account(p.status, p.epoch_span, stream)) return rc_;
     void (*kern)(Bwd8Params) = nullptr;
     if (bf16 && with_dx) kern = act == FOV_ACT_HARD_SIGMOID ? lstm_bwd8n_bf16_kernel<FOV_ACT_HARD_SIGMOID, true> : lstm_bwd8n_bf16_kernel<FOV_ACT_SIGMOID, true>;
     else if (bf16) kern = act == FOV_ACT_HARD_SIGMOID ? lstm_bwd8n_bf16_kernel<FOV_ACT_HARD_SIGMOID, false> : lstm_bwd8n_bf16_kernel<FOV_ACT_SIGMOID, false>;

@@ -339,6 +339,7 @@ int launch_bwd_cluster(const float* R, const float* reserve, const float* c0, co
     p.xch = (unsigned long long*)((char*)xch_ws + kStatusBytes);
     if (bwd_cluster_xch_bytes(B, H) > kXchBytes - kHelloBytes) { set_error("BPTT kernel: granule area exceeds the workspace's"); return FOV_ERR_WORKSPACE; }
     p.epoch_span = T * ((p.num_tiles + p.num_groups - 1) / p.num_groups) + 1;   // no memset: tags continue from the header
+    if (int rc_ = xch_account(p.status, p.epoch_span, stream)) return rc_;
     switch (H) {
         case 64: return launch_bwd_h<64>(p, act, stream);
         case 128: return launch_bwd_h<128>(p, act, stream);

@@ -978,11 +978,12 @@ int device_cu_count() {
         hipDeviceProp_t prop;
         cus[dev] = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
     }
-    return cus[dev];
+    const int lim = env_knobs().resident_limit;   // FOV_DBG_RESIDENT_LIMIT: pretend fewer CUs are available (tests of the fallbacks)
+    return (lim > 0 && lim < cus[dev]) ? lim : cus[dev];
 }
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (device, kernel, size) instead of on every launch
-int ensure_dynamic_lds(const void* kern, size_t lds) {
+int ensure_dynamic_lds(const void* kern, size_t lds, int block) {
     struct Seen { const void* k; size_t lds; int dev; };
     static Seen seen[256];
     static int n_seen = 0;
@@ -994,6 +995,15 @@ int ensure_dynamic_lds(const void* kern, size_t lds) {
         if (seen[i].k == kern && seen[i].dev == dev && seen[i].lds >= lds) return FOV_OK;
     hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return FOV_ERR_LAUNCH; }
+    // the persistent grids are sized as ONE workgroup per CU: ask the runtime once per (device, kernel, LDS size) that a
+    // workgroup of this shape is admitted at all (registers, LDS, waves) instead of assuming it from the CU count
+    int per_cu = 0;
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, block, lds);
+    if (e != hipSuccess || per_cu < 1) {
+        (void)hipGetLastError();
+        set_error("persistent kernel: a %d-thread workgroup with %zu B of LDS is not resident on this device (occupancy %d)", block, lds, per_cu);
+        return FOV_ERR_UNSUPPORTED;
+    }
     if (n_seen < 256) seen[n_seen++] = Seen{kern, lds, dev};
     return FOV_OK;
 }
@@ -1005,8 +1015,8 @@ bool cluster_shape_ok(int F, int H) {
 int cluster_num_groups(int B, int H) {
     const int G = H / 64;
     const int tiles = (B + BT - 1) / BT;
-    int groups = device_cu_count() / G;
-    if (groups < 1) groups = 1;
+    const int groups = device_cu_count() / G;
+    if (groups < 1) return 0;   // not even one group is co-resident: the caller reports FOV_ERR_UNSUPPORTED (explicit impl) or falls back (auto)
     return tiles < groups ? (tiles > 0 ? tiles : 1) : groups;
 }
 
@@ -1094,25 +1104,27 @@ int launch_cluster(const LstmParams& p_in, bool decode, hipStream_t stream) {
     }
     p.num_tiles = (p.B + BT - 1) / BT;
     p.num_groups = cluster_num_groups(p.B, p.H);
-    const char* safe = getenv("FOV_FORCE_SAFE_EXCHANGE");   // read per call: the tests flip it between calls
-    p.force_safe_exchange = (safe && safe[0] == '1') ? 1 : 0;
+    if (p.num_groups < 1) { set_error("cluster kernel: fewer than %d CUs available for one group", p.H / 64); return FOV_ERR_UNSUPPORTED; }
+    p.force_safe_exchange = env_knobs().force_safe_exchange;   // cached (fov_reload_env re-reads the environment)
     if (cluster_xch_bytes(p.B, p.H) > kXchBytes - kHelloBytes) { set_error("cluster kernel: granule area exceeds the workspace's"); return FOV_ERR_WORKSPACE; }
     // No memset: epoch tags continue from the workspace header.  A group visits ceil(tiles / groups) tiles and
     // advances its epoch once per step of each.
     const int visits = (p.num_tiles + p.num_groups - 1) / p.num_groups;
     // FOV_PAIR=1 (opt-in, measured slower so far: DESIGN.md section 5): H = 256 with two tiles per workgroup and two waves
     // per SIMD (lstm_pair.hip)
-    if (decode && p.H == 256 && !p.hs && !p.reserve && getenv("FOV_PAIR") && pair_shape_ok(p.B, p.T, p.T_out, p.F, p.F_dec, p.H))
+    if (decode && p.H == 256 && !p.hs && !p.reserve && env_knobs().pair_kernel && pair_shape_ok(p.B, p.T, p.T_out, p.F, p.F_dec, p.H))
         return launch_pair_fused(p, stream);
     if (!decode) {
         p.epoch_span = p.T * visits + 1;
+        if (int rc_ = xch_account(p.status, p.epoch_span, stream)) return rc_;
         return launch_cluster_mode(p, MODE_LAYER, stream);
     }
 
-    if (visits == 1 && p.T > 0 && p.T_out > 0 && !p.hs && !p.reserve && !getenv("FOV_TWO_LAUNCHES")) {
+    if (visits == 1 && p.T > 0 && p.T_out > 0 && !p.hs && !p.reserve && !env_knobs().two_launches) {
         // one tile per group: encoder and decoder as ONE launch (state in registers, h_T tile in LDS)
         LstmParams f = p;
         f.epoch_span = p.T + p.T_out + 2;
+        if (int rc_ = xch_account(p.status, f.epoch_span, stream)) return rc_;
         return launch_cluster_fused(f, stream);
     }
     LstmParams enc = p;
@@ -1121,6 +1133,7 @@ int launch_cluster(const LstmParams& p_in, bool decode, hipStream_t stream) {
     enc.cT = state + (size_t)p.B * p.H;
     enc.hs = nullptr;
     enc.epoch_span = p.T * visits + 1;
+    if (int rc_ = xch_account(p.status, enc.epoch_span + p.T_out * visits + 1, stream)) return rc_;
     int rc = launch_cluster_mode(enc, MODE_LAYER, stream);
     if (rc) return rc;
     // the decoder launch reads the base the encoder launch left behind: its tags (and its hello tag) are larger
@@ -1143,9 +1156,10 @@ int launch_cluster_decoder(const LstmParams& p_in, hipStream_t stream) {
     }
     p.num_tiles = (p.B + BT - 1) / BT;
     p.num_groups = cluster_num_groups(p.B, p.H);
-    const char* safe = getenv("FOV_FORCE_SAFE_EXCHANGE");
-    p.force_safe_exchange = (safe && safe[0] == '1') ? 1 : 0;
+    if (p.num_groups < 1) { set_error("cluster decoder: fewer than %d CUs available for one group", p.H / 64); return FOV_ERR_UNSUPPORTED; }
+    p.force_safe_exchange = env_knobs().force_safe_exchange;
     p.epoch_span = p.T_out * ((p.num_tiles + p.num_groups - 1) / p.num_groups) + 1;
+    if (int rc_ = xch_account(p.status, p.epoch_span, stream)) return rc_;
     return launch_cluster_mode(p, MODE_DECODE, stream);
 }
 

@@ -296,6 +296,7 @@ int launch_layer_bf16(const LstmParams& p_in, hipStream_t stream) {
     p.num_groups = p.num_tiles < max_groups ? p.num_tiles : max_groups;
     if ((size_t)p.num_groups * 2 * Q_TILE_BYTES > kXchBytes - kHelloBytes) { set_error("bf16 LSTM layer: granule area too small"); return FOV_ERR_WORKSPACE; }
     p.epoch_span = p.T * ((p.num_tiles + p.num_groups - 1) / p.num_groups) + 1;
+    if (int rc_ = xch_account(p.status, p.epoch_span, stream)) return rc_;
     const bool narrow = p.F <= 96;
     const bool xvec = !narrow && (p.F & 3) == 0 && (((uintptr_t)p.x) & 15) == 0;
     const bool hs_ = p.act == FOV_ACT_HARD_SIGMOID;

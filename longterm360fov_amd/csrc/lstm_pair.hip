@@ -719,6 +719,7 @@ int launch_pair_fused(const LstmParams& p_in, hipStream_t stream) {
         return FOV_ERR_WORKSPACE;
     }
     p.epoch_span = p.T + p.T_out + 2;
+    if (int rc_ = xch_account(p.status, p.epoch_span, stream)) return rc_;
     void (*kern)(LstmParams) = p.act == FOV_ACT_HARD_SIGMOID ? lstm_pair_fused_kernel<FOV_ACT_HARD_SIGMOID>
                                                              : lstm_pair_fused_kernel<FOV_ACT_SIGMOID>;
     const PairLds L = pair_lds(p.F);

@@ -374,6 +374,7 @@ int launch_wide(const LstmParams& p_in, hipStream_t stream) {
     if (max_groups < 1) { set_error("wide LSTM layer needs at least %d CUs", WG); return FOV_ERR_UNSUPPORTED; }
     p.num_groups = p.num_tiles < max_groups ? p.num_tiles : max_groups;
     p.epoch_span = p.T * ((p.num_tiles + p.num_groups - 1) / p.num_groups) + 1;   // no memset: tags continue from the header
+    if (int rc_ = xch_account(p.status, p.epoch_span, stream)) return rc_;
     const size_t lds = sizeof(float) * (3 * WBT * WLD) + 64;
     void (*kern)(LstmParams) =
         narrow ? (p.act == FOV_ACT_HARD_SIGMOID ? lstm_wide_kernel<FOV_ACT_HARD_SIGMOID, 6> : lstm_wide_kernel<FOV_ACT_SIGMOID, 6>)

@@ -533,6 +533,7 @@ int mix_decoder_launch(MixDecParams p, const float* K2, int act, int train, void
     float* k2p = (float*)((char*)workspace + kStatusBytes + kXchBytes);
     p.K2p = k2p;
     p.epoch_span = p.T_out * ((p.num_tiles + p.num_groups - 1) / p.num_groups) + 1;   // no memset: tags continue from the header
+    if (int rc_ = xch_account(p.status, p.epoch_span, stream)) return rc_;
     hipLaunchKernelGGL(mix_decoder_pack_k2_kernel, dim3(MH * 4 * MH / 256), dim3(256), 0, stream, K2, k2p);
     const size_t lds = sizeof(float) * (2 * MBT * MLDH + MBT * 8 + MH * 8 + 64 + 16 + 4 * 256 + 4 * 28 * 256);
     void (*kern)(MixDecParams) = nullptr;

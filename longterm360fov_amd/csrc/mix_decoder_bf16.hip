@@ -259,6 +259,7 @@ int mix_decoder_bf16_launch(MixDecParams p, const float* K2, int act, int train,
     p.xch = (unsigned long long*)((char*)workspace + kStatusBytes);
     p.K2p = K2;   // no packed copy: the kernel builds its register-resident fragments from the plain (H,4H) kernel
     p.epoch_span = p.T_out * ((p.num_tiles + p.num_groups - 1) / p.num_groups) + 1;
+    if (int rc_ = xch_account(p.status, p.epoch_span, stream)) return rc_;
     void (*kern)(MixDecParams) = nullptr;
     if (act == FOV_ACT_HARD_SIGMOID) kern = train ? mix_decoder_bf16_kernel<FOV_ACT_HARD_SIGMOID, true> : mix_decoder_bf16_kernel<FOV_ACT_HARD_SIGMOID, false>;
     else kern = train ? mix_decoder_bf16_kernel<FOV_ACT_SIGMOID, true> : mix_decoder_bf16_kernel<FOV_ACT_SIGMOID, false>;

@@ -514,6 +514,7 @@ int mix_decoder_bwd_launch(MixDecBwdParams p, const float* K2, int act, void* wo
     float* k2p = (float*)((char*)workspace + kStatusBytes + kXchBytes);
     p.K2p = k2p;
     p.epoch_span = p.T_out * ((p.num_tiles + p.num_groups - 1) / p.num_groups) + 1;   // no memset: tags continue from the header
+    if (int rc_ = xch_account(p.status, p.epoch_span, stream)) return rc_;
     hipLaunchKernelGGL(mix_decoder_bwd_pack_k2_kernel, dim3(BH * 4 * BH / 256), dim3(256), 0, stream, K2, k2p);
     const size_t lds = sizeof(float) * (BBT * BLDZ + BBT * 8 + BBT * 8 + 128 * 8 + 16 + 4 * BK2_LDS_BLOCKS * 256);
     void (*kern)(MixDecBwdParams) = act == FOV_ACT_HARD_SIGMOID ? mix_decoder_bwd_kernel<FOV_ACT_HARD_SIGMOID> : mix_decoder_bwd_kernel<FOV_ACT_SIGMOID>;

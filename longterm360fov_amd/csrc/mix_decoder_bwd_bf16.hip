@@ -316,6 +316,7 @@ int mix_decoder_bwd_bf16_launch(MixDecBwdParams p, const float* K2, int act, voi
     p.xch = (unsigned long long*)((char*)workspace + kStatusBytes);
     p.K2p = K2;   // no packed copy: fragments are eight contiguous floats of a row of the plain (H,4H) kernel
     p.epoch_span = p.T_out * ((p.num_tiles + p.num_groups - 1) / p.num_groups) + 1;
+    if (int rc_ = xch_account(p.status, p.epoch_span, stream)) return rc_;
     void (*kern)(MixDecBwdParams) = act == FOV_ACT_HARD_SIGMOID ? mix_decoder_bwd_bf16_kernel<FOV_ACT_HARD_SIGMOID> : mix_decoder_bwd_bf16_kernel<FOV_ACT_SIGMOID>;
     hipLaunchKernelGGL(kern, dim3(p.num_groups * QG), dim3(256), 0, stream, p);
     hipError_t e = hipGetLastError();

@@ -42,10 +42,25 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+_ENV_KNOBS = ("FOV_FORCE_SAFE_EXCHANGE", "FOV_PAIR", "FOV_TWO_LAUNCHES", "FOV_DBG_RESIDENT_LIMIT")
+_env_seen = None
+
+
+def _sync_env():
+    """The library caches its environment knobs (no getenv on a launch path): tell it when one of them changed."""
+    global _env_seen
+    cur = tuple(os.environ.get(k) for k in _ENV_KNOBS)
+    if cur != _env_seen:
+        if _env_seen is not None or any(v is not None for v in cur):
+            _lib.lib().fov_reload_env()
+        _env_seen = cur
+
+
 def _apply_force_safe(holder):
     """FOV_FORCE_SAFE_EXCHANGE=1 (read per call: the tests flip it between calls) -> the workspace's header word that keeps
     every exchanging kernel on the placement-independent granule exchange (fov_workspace_force_safe)."""
     want = os.environ.get("FOV_FORCE_SAFE_EXCHANGE", "") == "1"
+    _sync_env()
     if holder.buf is not None and getattr(holder, "_forced", (None, False)) != (holder.buf.data_ptr(), want):
         if want or getattr(holder, "_forced", (None, False))[1]:
             with torch.cuda.device(holder.buf.device):

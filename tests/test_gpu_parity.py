@@ -622,3 +622,39 @@ def test_one_launch_encode_decode_equals_two_launches(B, T_in, T_out, H, act):
     again = ops.seq2seq_decode(d_enc, d_dec0, dw, T_out, act=act, impl="cluster", workspace=ws)
     ws.check()
     assert torch.equal(again, one)
+
+
+def test_launch_contract_resident_limit_and_epoch_rezero():
+    """Hardening of the launch contract (include/fov360.h): (1) when fewer CUs are available than one group of workgroups
+    needs (FOV_DBG_RESIDENT_LIMIT pretends so), an explicit impl='cluster' call is refused with FOV_ERR_UNSUPPORTED and
+    impl='auto' falls back to the generic kernel - same result, no second-long spin; (2) the 32-bit epoch tags are re-zeroed
+    by the launch path itself once the host-side account nears the limit, without fov_check_status ever being called."""
+    from longterm360fov_amd import _lib
+    ops = _ops()
+    H, B, T_in, T_out = 256, 40, 4, 3
+    w = O.init_seq2seq(77, H=H, bias_noise=0.1)
+    enc, dec0, _ = O.synthetic_batch(78, B, T_in, T_out)
+    ref = O.seq2seq_decode(enc.astype(np.float64), dec0.astype(np.float64), f64(w), T_out, "sigmoid")
+    try:
+        os.environ["FOV_DBG_RESIDENT_LIMIT"] = "2"       # < 4 workgroups of an H = 256 group
+        ws = ops.Workspace()
+        with pytest.raises(_lib.FovError) as ei:
+            ops.seq2seq_decode(dev(enc), dev(dec0), devw(w), T_out, impl="cluster", workspace=ws)
+        assert ei.value.code == _lib.ERR_UNSUPPORTED
+        out = ops.seq2seq_decode(dev(enc), dev(dec0), devw(w), T_out, impl="auto", workspace=ws)
+        ws.check()
+        assert_parity(out, ref, "auto falls back to the generic kernel under a resident limit")
+    finally:
+        os.environ.pop("FOV_DBG_RESIDENT_LIMIT", None)
+    ws = ops.Workspace()
+    out0 = ops.seq2seq_decode(dev(enc), dev(dec0), devw(w), T_out, impl="cluster", workspace=ws).clone()
+    L = _lib.lib()
+    check = _lib.check
+    check(L.fov_debug_set_epoch(ws.buf.data_ptr(), ws.buf.numel(), 0x70000000 - 5, torch.cuda.current_stream().cuda_stream))
+    for _ in range(4):      # the first of these crosses the threshold: header and granule area are re-zeroed in front of it
+        out1 = ops.seq2seq_decode(dev(enc), dev(dec0), devw(w), T_out, impl="cluster", workspace=ws)
+    torch.cuda.synchronize()
+    hdr = ws.buf[:32].cpu().numpy().view(np.uint32)
+    assert hdr[3] < 1000, "epoch base %d: the launch path did not re-zero the workspace" % hdr[3]
+    ws.check()
+    assert torch.equal(out0, out1)
