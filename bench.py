@@ -372,6 +372,33 @@ def bench_config1(args, rank, world, use_dist):
         if not args.no_cpu_baseline and world == 1:
             cpu, _ = cpu_baseline_seq2seq(enc, dec0, w, T_out, args.act, budget_s=8.0)
         ach = (f_enc + f_dec) * B / (ev_ms * 1e-3) / 1e12
+        training = None
+        if args.train:
+            # model.fit's inner step (FoV_seq2seq.py:103,112-117) at the batch the scripts use, for the widths they ship: 128
+            # (configs[0]), 64 (FoV_seq2seq.py:22) and 32 (given_others...py:38) - the last one zero-padded to 64 by the trainer
+            from longterm360fov_amd.models import Seq2SeqLSTM
+            from oracle import torch_cpu as TC
+            _, _, tgt = O.synthetic_batch(1234 + rank, B, T_in, T_out)
+            dec_in = np.concatenate([dec0, tgt[:, :-1]], axis=1)
+            training = {}
+            for Ht in (128, 64, 32):
+                for impl in ("auto", "generic"):
+                    m = Seq2SeqLSTM(latent_dim=Ht, recurrent_activation=args.act, impl=impl, seed=1)
+                    m.compile(optimizer="Adam", loss="mean_squared_error")
+                    tr = m._get_trainer()
+                    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+                    batch = [d(enc), d(dec_in), d(tgt)]
+                    for _ in range(5):
+                        tr.train_step(*batch)
+                    tms = event_time_ms(lambda: tr.train_step(*batch), 100)
+                    tr.check()
+                    training["h%d_%s" % (Ht, impl)] = {"ms_per_step": tms, "sequences_per_s": B / (tms * 1e-3),
+                                                       "run_width": getattr(tr, "Hp", Ht)}
+                if not args.no_cpu_baseline and world == 1 and args.act == "sigmoid":
+                    wt = O.init_seq2seq(1, 90, 6, Ht)
+                    mc = TC.Seq2SeqCPU(wt, threads=min(TC.usable_cores(), CPU_THREADS))
+                    training["h%d_cpu" % Ht] = cpu_leg(lambda: mc.train_step(enc, dec_in, tgt), B, mc.threads,
+                                                       "torch %s CPU autograd step" % torch.__version__, 3.0)
         print(json.dumps({
             "metric": "sequences/sec (batch=%d, T_in=%d->T_out=%d, h=%d)" % (B, T_in, T_out, H),
             "value": world * B * steps / elapsed, "unit": "sequences/s", "n_gpus": world, "steps": steps, "warmup": max(args.warmup, 3),
@@ -385,7 +412,7 @@ def bench_config1(args, rank, world, use_dist):
             "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
                          "note": "two 16-sequence tiles: 4 workgroups busy, per-step latency bound by construction"},
-            "parity": {"max_abs_err_vs_oracle": err, "sequences_checked": B},
+            "parity": {"max_abs_err_vs_oracle": err, "sequences_checked": B}, "training": training,
             "cpu_baseline": cpu, "speedup_vs_cpu_baseline": None if cpu is None else world * B * steps / elapsed / cpu["value"]}), flush=True)
 
 
@@ -577,6 +604,7 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the N > 1 path "
                          "with several ranks on ONE GPU)")
+    ap.add_argument("--train", action="store_true", help="config1 mode: also time model.fit's step at the widths the scripts ship (128 / 64 / 32)")
     ap.add_argument("--dry-run", action="store_true", help="launch plumbing only: no GPU work (CPU tests)")
     ap.add_argument("--force-dist", action="store_true",
                     help="N = 1 only: start this rank under torch.distributed.run on the nccl (= RCCL) backend anyway and take the "

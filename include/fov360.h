@@ -516,6 +516,9 @@ int fov_workspace_force_safe(void* workspace, size_t workspace_bytes, int on, fo
 /* The library reads its environment knobs (FOV_FORCE_SAFE_EXCHANGE, FOV_PAIR, FOV_TWO_LAUNCHES, FOV_DBG_RESIDENT_LIMIT)
  * once, at first use; call this after changing them.  No launch path calls getenv. */
 void fov_reload_env(void);
+/* Diagnostic: launches of the generic (VALU, any-shape) LSTM kernel so far in this process - lets a test assert that a
+ * call was served by the persistent matrix-core kernels. */
+int64_t fov_debug_generic_launches(void);
 /* Test hook: set the workspace's epoch base (device header and the host-side accounting) - lets a test reach the
  * re-zero threshold of the 32-bit epoch tags without 10^7 launches. */
 int fov_debug_set_epoch(void* workspace, size_t workspace_bytes, unsigned epoch, fov_stream_t stream);

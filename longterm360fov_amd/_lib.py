@@ -100,6 +100,7 @@ SIGNATURES = {
     "fov_check_status": (_I, [_P, _SZ, _P]),
     "fov_workspace_force_safe": (_I, [_P, _SZ, _I, _P]),
     "fov_reload_env": (None, []),
+    "fov_debug_generic_launches": (ctypes.c_int64, []),
     "fov_debug_set_epoch": (_I, [_P, _SZ, ctypes.c_uint, _P]),
     "fov_exchange_mode": (_I, [_P, _SZ, _P]),
 }

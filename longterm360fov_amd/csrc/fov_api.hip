@@ -413,6 +413,8 @@ const char* fov_last_error(void) { return g_err; }
 
 void fov_reload_env(void) { env_reload(); }
 
+int64_t fov_debug_generic_launches(void) { return (int64_t)generic_launch_count(); }
+
 int fov_debug_set_epoch(void* workspace, size_t workspace_bytes, unsigned epoch, fov_stream_t stream) {
     if (!workspace || workspace_bytes < kStatusBytes) { set_error("fov_debug_set_epoch: invalid workspace"); return FOV_ERR_INVALID; }
     hipError_t e = hipMemsetD32Async((hipDeviceptr_t)((unsigned*)workspace + ST_EPOCH), (int)epoch, 1, (hipStream_t)stream);

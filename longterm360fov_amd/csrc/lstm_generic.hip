@@ -4,6 +4,8 @@
 // fallback and the independent cross-check of the cluster kernel - not the fast path.
 //
 // Replaces keras LSTM / Dense calls of mycode/FoV_seq2seq.py:83-97,137-178 (see include/fov360.h).
+#include <atomic>
+
 #include "fov_common.h"
 
 namespace fov {
@@ -139,8 +141,12 @@ __global__ __launch_bounds__(256) void lstm_generic_kernel(LstmParams p) {
         for (int i = tid; i < rows * H; i += blockDim.x) p.cT[(size_t)b0 * H + i] = sh_c[i];
 }
 
+static std::atomic<long> g_generic_launches{0};
+long generic_launch_count() { return g_generic_launches.load(); }
+
 int launch_generic(const LstmParams& p, bool decode, hipStream_t stream) {
     if (p.B == 0) return FOV_OK;
+    ++g_generic_launches;
     const int ldx = (p.F > p.F_dec ? p.F : p.F_dec) + 1;
     const size_t lds = sizeof(float) * ((size_t)3 * GB * p.H + (size_t)GB * ldx);
     if (lds > 160 * 1024) {

@@ -446,9 +446,13 @@ class Seq2SeqLSTM(KerasModelSurface):
 
     # ---- training surface: KerasModelSurface (FoV_seq2seq.py:103 compile, :112-117 fit) ----
     def _make_trainer(self, optimizer):
-        from .training import Seq2SeqTrainer
-        return Seq2SeqTrainer(self._w, act=self.recurrent_activation, impl=self.impl, optimizer=optimizer, lr=self._lr,
-                              device=self.device)
+        from .training import PaddedTrainer, Seq2SeqTrainer
+        make = lambda w: Seq2SeqTrainer(w, act=self.recurrent_activation, impl=self.impl, optimizer=optimizer, lr=self._lr,
+                                        device=self.device)
+        Hp = self._run_width()
+        if Hp != self.latent_dim:      # latent_dim = 32 / 40 / ...: train on the matrix-core kernels at the next supported width (exact)
+            return PaddedTrainer(make, self._w, self.latent_dim, Hp)
+        return make(self._w)
 
 
 class NoTeacherForcingSeq2Seq(Seq2SeqLSTM):
@@ -936,9 +940,13 @@ class OthersMixingSeq2Seq(KerasModelSurface):
 
     # ---- training surface: KerasModelSurface (given_others...py:308 compile, :500-506 fit) + fit_generator (:494-498) ----
     def _make_trainer(self, optimizer):
-        from .training import OthersMixingTrainer
-        return OthersMixingTrainer(self._w, act=self.recurrent_activation, impl=self.impl, optimizer=optimizer, lr=self._lr,
-                                   device=self.device, dtype=self.dtype)
+        from .training import OthersMixingTrainer, PaddedTrainer
+        make = lambda w: OthersMixingTrainer(w, act=self.recurrent_activation, impl=self.impl, optimizer=optimizer, lr=self._lr,
+                                             device=self.device, dtype=self.dtype)
+        Hp = self._run_width()
+        if Hp != self.latent_dim:      # the script's latent_dim = 32: the fused H = 256 kernels on zero-padded weights (exact)
+            return PaddedTrainer(make, self._w, self.latent_dim, Hp, hidden_inputs=("enc2_K", "dec2_K"))
+        return make(self._w)
 
     def fit_generator(self, generator, steps_per_epoch, epochs=1, validation_data=None, validation_steps=None,
                       callbacks=None, use_multiprocessing=False, shuffle=True, initial_epoch=0, verbose=0):

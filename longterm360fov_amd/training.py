@@ -164,6 +164,115 @@ class FlatParamTrainer:
         return loss
 
 
+def _pad_gates(a, H, Hp):
+    """(..., 4H) -> (..., 4Hp): every gate block padded with zero columns."""
+    out = np.zeros(a.shape[:-1] + (4 * Hp,), np.float32)
+    for g in range(4):
+        out[..., g * Hp:g * Hp + H] = a[..., g * H:(g + 1) * H]
+    return out
+
+
+def _unpad_gates(a, H, Hp):
+    return np.concatenate([a[..., g * Hp:g * Hp + H] for g in range(4)], axis=-1)
+
+
+class PaddedTrainer:
+    """A trainer run at the next matrix-core width Hp with zero-padded weights, so that `fit` at the widths the reference
+    ships (latent_dim = 32 in given_others_gt_mean_var_seq2seq.py:38, 64 in FoV_seq2seq.py:22) takes the persistent MFMA
+    kernels instead of the generic VALU one.  Exact, not approximate: a padded unit has z = 0 for all four gates, so
+    i = f = o = s(0), g = tanh(0) = 0, c stays 0 and h = 0; its dz is 0 because nothing downstream reads it (zero R
+    rows, zero Dense rows), hence every gradient in a padded slice is exactly 0, Adam / RMSprop leave the zeros where
+    they are (checked: padded_slices_are_zero), and the real units see exactly the unpadded arithmetic.
+    `hidden_inputs`: names of the K tensors whose INPUT is a hidden sequence (stacked layers): their rows are padded too."""
+
+    def __init__(self, make_inner, weights, H, Hp, hidden_inputs=()):
+        self.H, self.Hp, self.hidden_inputs = int(H), int(Hp), tuple(hidden_inputs)
+        self._names = list(weights)
+        self.inner = make_inner(self.pad(weights))
+
+    def _kind(self, k, v):
+        H = self.H
+        if k.endswith("_R") and v.shape == (H, 4 * H):
+            return "R"
+        if k.endswith("_K") and v.ndim == 2 and v.shape[1] == 4 * H:
+            return "KH" if k in self.hidden_inputs else "K"
+        if k.endswith("_b") and v.shape == (4 * H,) and (k[:-2] + "_R") in self._names:
+            return "b"
+        if k == "dense_W" and v.shape[0] == H:
+            return "rows"
+        return None
+
+    def pad(self, w):
+        H, Hp, out = self.H, self.Hp, {}
+        for k in self._names:
+            v = np.asarray(w[k], np.float32)
+            kind = self._kind(k, v)
+            if kind in ("R", "KH"):
+                t = np.zeros((Hp, 4 * H), np.float32)
+                t[:H] = v
+                out[k] = _pad_gates(t, H, Hp)
+            elif kind in ("K", "b"):
+                out[k] = _pad_gates(v, H, Hp)
+            elif kind == "rows":
+                t = np.zeros((Hp,) + v.shape[1:], np.float32)
+                t[:H] = v
+                out[k] = t
+            else:
+                out[k] = v
+        return out
+
+    def unpad(self, wp):
+        H, Hp, out = self.H, self.Hp, {}
+        for k in self._names:
+            v = wp[k]
+            ref_shape_kind = None
+            if k.endswith("_R") and v.shape == (Hp, 4 * Hp):
+                ref_shape_kind = "R"
+            elif k.endswith("_K") and v.ndim == 2 and v.shape[1] == 4 * Hp:
+                ref_shape_kind = "KH" if k in self.hidden_inputs else "K"
+            elif k.endswith("_b") and v.shape == (4 * Hp,) and (k[:-2] + "_R") in self._names:
+                ref_shape_kind = "b"
+            elif k == "dense_W" and v.shape[0] == Hp:
+                ref_shape_kind = "rows"
+            if ref_shape_kind in ("R", "KH"):
+                out[k] = _unpad_gates(v[:H], H, Hp)
+            elif ref_shape_kind in ("K", "b"):
+                out[k] = _unpad_gates(v, H, Hp)
+            elif ref_shape_kind == "rows":
+                out[k] = v[:H].copy()
+            else:
+                out[k] = v
+        return out
+
+    def padded_slices_are_zero(self):
+        """True if every padded slice of parameters AND of the last gradients is exactly zero (synchronises)."""
+        wp = self.inner.weights_numpy()
+        gp = {k: v.detach().cpu().numpy() for k, v in self.inner.g.items()}
+        for d in (wp, gp):
+            back = self.pad(self.unpad(d))
+            for k in self._names:
+                if not np.array_equal(back[k], d[k]):
+                    return False
+        return True
+
+    def weights_numpy(self):
+        return self.unpad(self.inner.weights_numpy())
+
+    def load_weights_(self, weights):
+        self.inner.load_weights_(self.pad(weights))
+
+    @property
+    def lr(self):
+        return self.inner.lr
+
+    @lr.setter
+    def lr(self, v):
+        self.inner.lr = v
+
+    def __getattr__(self, name):      # train_step, eval_loss, forward_backward, check, step_count, ws, ...
+        return getattr(self.__dict__["inner"], name)
+
+
 class Seq2SeqTrainer(FlatParamTrainer):
     def __init__(self, weights, act="sigmoid", impl="auto", optimizer="adam", lr=1e-3, device="cuda"):
         self.act, self.impl = act, impl

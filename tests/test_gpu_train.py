@@ -1385,3 +1385,48 @@ def test_training_step_same_xcd_and_safe_exchange_agree_bitwise(dtype):
         os.environ.pop("FOV_FORCE_SAFE_EXCHANGE", None)
     assert modes["1"] == 2
     assert torch.equal(flats["0"], flats["1"])
+
+
+@pytest.mark.parametrize("kind", ["seq2seq", "mixing"])
+def test_fit_at_the_reference_widths_runs_padded_on_the_matrix_core_kernels(kind):
+    """latent_dim = 32 (given_others_gt_mean_var_seq2seq.py:38; FoV_seq2seq.py ships 64) is not a width of the persistent
+    kernels: the trainers pad to the next one (training.PaddedTrainer - 64 for the target-only model, 256 for the fused
+    others-mixing path).  Exactness: padded slices of parameters and gradients stay EXACTLY zero, and parameters after
+    four optimizer steps equal the unpadded run on the generic kernels (impl='generic'); the generic kernel is not
+    launched at all by the padded run."""
+    from longterm360fov_amd import _lib
+    from longterm360fov_amd.models import OthersMixingSeq2Seq, Seq2SeqLSTM, _MIX_ORDER
+    from longterm360fov_amd.training import PaddedTrainer
+    H, B, T = 32, 24, 4
+    if kind == "seq2seq":
+        w = O.init_seq2seq(501, H=H, bias_noise=0.1)
+        enc, dec0, tgt = O.synthetic_batch(502, B, T, T)
+        x = [enc, np.concatenate([dec0, tgt[:, :-1]], axis=1)]
+        make = lambda impl: Seq2SeqLSTM(latent_dim=H, impl=impl, seed=0)
+        order = list(w)
+    else:
+        w = O.init_others_mixing(503, H=H, num_user=5, bias_noise=0.1)
+        enc, dec0, tgt, oth = O.synthetic_batch(504, B, T, T, num_others=4)
+        x = [enc, oth, dec0]
+        make = lambda impl: OthersMixingSeq2Seq(latent_dim=H, num_user=5, impl=impl, seed=0)
+        order = list(_MIX_ORDER)
+    res = {}
+    for impl in ("generic", "auto"):
+        m = make(impl)
+        m.set_weights([w[k] for k in order])
+        m.compile(optimizer="Adam", loss="mean_squared_error")
+        n0 = _lib.lib().fov_debug_generic_launches()
+        losses = [m.train_on_batch(x, tgt) for _ in range(4)]
+        n1 = _lib.lib().fov_debug_generic_launches()
+        tr = m._get_trainer()
+        if impl == "auto":
+            assert isinstance(tr, PaddedTrainer) and tr.Hp == (64 if kind == "seq2seq" else 256)
+            assert n1 == n0, "the padded run launched the generic kernel %d times" % (n1 - n0)
+            assert tr.padded_slices_are_zero()
+        else:
+            assert not isinstance(tr, PaddedTrainer) and n1 > n0
+        res[impl] = (losses, m.get_weights())
+    np.testing.assert_allclose(res["auto"][0], res["generic"][0], rtol=2e-5)
+    for a, b in zip(res["auto"][1], res["generic"][1]):
+        assert a.shape == b.shape
+        np.testing.assert_allclose(a, b, atol=2e-6, rtol=1e-5)
