@@ -54,6 +54,7 @@ constexpr int MODE_LAYER_ZX = 2;   // MODE_LAYER with the input projection preco
                                 // memory latency in every step of the plain layer
 
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ unsigned long long ld_granule(const unsigned long long* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -654,6 +655,13 @@ __device__ __forceinline__ void cluster_body(const LstmParams& p, ClusterCarry& 
                         if (xcl + 16 * i < F) xl[tt * BT * LDX + 16 * i] = x2[tt][i];
                 }
         }
+        // DECODE output: out[b0 + n][t][4*ss + g4]; the descriptor ends with the tile's last live row, masked outputs are out of range
+        const __amdgpu_buffer_rsrc_t yors = __builtin_amdgcn_make_buffer_rsrc(
+            (!LAYER && p.out) ? p.out + (size_t)b0 * p.T_out * p.F_dec : nullptr, 0, (!LAYER && p.out) ? live_rows * p.T_out * p.F_dec * 4 : 0, 0x00020000);
+        unsigned yoff[2];
+#pragma unroll
+        for (int ss = 0; ss < 2; ++ss)
+            yoff[ss] = (!LAYER && 4 * ss + g4 < p.F_dec) ? (unsigned)((n * p.T_out * p.F_dec + 4 * ss + g4) * 4) : OORB;
         f32x4 y4 = (f32x4){0.f, 0.f, 0.f, 0.f};   // DECODE: y_{t-1}[n][4*s + g4], the A fragment of y . K
         if (!LAYER) {
             // (buffer loads with an out-of-range offset for the masked elements: a `cond ? load : 0` sits in a branch whose
@@ -743,19 +751,24 @@ __device__ __forceinline__ void cluster_body(const LstmParams& p, ClusterCarry& 
                 constexpr int JL = NQ - 1 > 4 ? NQ - 1 : 4;   // H = 64 has no partner slices: nothing covers, nothing to split
                 recurrent<H, 4, JL, true, false>(acc, hrow, wR);
                 __syncthreads();  // barrier 3: the four partial products are in LDS
-                f32x4 part[4];
+                // outputs o = 4*ss + g4 < F_dec <= 8 live in ss = 0, 1 only: four independent 8-byte reads, ONE wait (as f32x4 the
+                // four destinations overlapped in hipcc's allocation and each read was waited for before the next was issued)
+                f32x2 part[4];
 #pragma unroll
-                for (int w2 = 0; w2 < 4; ++w2) part[w2] = *(const f32x4*)(sW + (w2 * 16 + n) * 16 + 4 * g4);
+                for (int w2 = 0; w2 < 4; ++w2) part[w2] = *(const f32x2*)(sW + (w2 * 16 + n) * 16 + 4 * g4);
                 recurrent<H, JL, NQ, false, false>(acc, hrow, wR);
-                // outputs o = 4*ss + g4 < F_dec <= 8 live in ss = 0, 1 only
+                // the sums / tanh BEHIND the MFMA run, not sprinkled into it: a VALU instruction in an fp32-MFMA gap is never
+                // hidden and costs a pipeline turn-around on top (tools/microbench/mfma_f32_overlap.hip)
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int ss = 0; ss < 2; ++ss) y4[ss] = tanh_f(((part[0][ss] + part[1][ss]) + part[2][ss]) + part[3][ss] + bd4[ss]);
-                if (slice == 0 && wave == 0 && b0 + n < p.B) {
-                    float* yo = p.out + ((size_t)(b0 + n) * p.T_out + (t - 1)) * p.F_dec + g4;
+                // y_{t-1} leaves through a buffer store: lane offset computed once per tile, the step in the scalar offset
+                if (slice == 0 && wave == 0) {
 #pragma unroll
                     for (int ss = 0; ss < 2; ++ss)
-                        if (4 * ss + g4 < p.F_dec) yo[4 * ss] = y4[ss];
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y4[ss]), yors, yoff[ss], (unsigned)((t - 1) * p.F_dec * 4), 0);
                 }
+                __builtin_amdgcn_sched_barrier(0);
                 input_proj_reg<true>(acc, y4, kb);
             }
             FOV_STAMP(1);
@@ -917,11 +930,11 @@ __device__ __forceinline__ void cluster_body(const LstmParams& p, ClusterCarry& 
 #pragma unroll
                 for (int ss = 0; ss < 4; ++ss) ysum[ss] += part[ss];
             }
-            if (slice == 0 && wave == 0 && b0 + n < p.B) {
-                float* yo = p.out + ((size_t)(b0 + n) * p.T_out + (steps - 1)) * p.F_dec + g4;
+            if (slice == 0 && wave == 0) {
 #pragma unroll
                 for (int ss = 0; ss < 2; ++ss)
-                    if (4 * ss + g4 < p.F_dec) yo[4 * ss] = tanh_f(ysum[ss] + bd4[ss]);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(tanh_f(ysum[ss] + bd4[ss])), yors, yoff[ss],
+                                                          (unsigned)((steps - 1) * p.F_dec * 4), 0);
             }
         }
         if constexpr (F1) {
