@@ -1107,7 +1107,7 @@ int fov_check_status(void* workspace, size_t workspace_bytes, fov_stream_t strea
         set_error("fov_check_status: invalid workspace");
         return FOV_ERR_INVALID;
     }
-    unsigned st[8] = {0};
+    unsigned st[64] = {0};
     hipError_t e = hipMemcpyAsync(st, workspace, sizeof(st), hipMemcpyDeviceToHost, (hipStream_t)stream);
     if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
     if (e != hipSuccess) { set_error("fov_check_status: %s", hipGetErrorString(e)); return FOV_ERR_LAUNCH; }
@@ -1302,7 +1302,7 @@ int fov_exchange_mode(const void* workspace, size_t workspace_bytes, fov_stream_
         set_error("fov_exchange_mode: invalid workspace");
         return FOV_ERR_INVALID;
     }
-    unsigned st[8] = {0};
+    unsigned st[64] = {0};
     hipError_t e = hipMemcpyAsync(st, workspace, sizeof(st), hipMemcpyDeviceToHost, (hipStream_t)stream);
     if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
     if (e != hipSuccess) { set_error("fov_exchange_mode: %s", hipGetErrorString(e)); return FOV_ERR_LAUNCH; }

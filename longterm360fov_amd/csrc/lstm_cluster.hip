@@ -130,8 +130,9 @@ __host__ __device__ inline ClusterLds cluster_lds(int H, int F, bool decode) {
 // hipcc pads no hazards around asm (cdna_hip_programming.md 5.7), and a separate "nop" statement behind a run of MFMAs is
 // not enough: where control flow merges hipcc copies accumulators between register sets - VALU reads of MFMA results -
 // and puts those copies BETWEEN the last MFMA statement and the nop statement (round 3: wrong x.K terms with the
-// fully unrolled input projection).  So the wait states live INSIDE the strings: the first MFMA of a run opens with
-// two (a VALU-written accumulator / operand -> MFMA read), the last one ends with twelve (8-pass MFMA result -> any
+// fully unrolled input projection).  So the wait states live INSIDE the strings: the first MFMA ON EACH ACCUMULATOR of a
+// run opens with two (a VALU-written accumulator / operand -> MFMA read; hipcc also moves bias-initialised accumulators
+// into place one by one, right in front of their first MFMA), the last one ends with twelve (8-pass MFMA result -> any
 // reader).  A run that is followed by another MFMA run on the same accumulators needs neither.
 // tools/isa_mfma_hazard.py checks the generated code for both hazards.
 constexpr int MF_MID = 0, MF_FIRST = 1, MF_LAST = 2;
@@ -307,7 +308,7 @@ __device__ __forceinline__ void input_proj_fixed(f32x4 (&acc)[4], const float* a
             if (4 * q + s + 2 < 4 * NQC) bn = *(const f32x4*)(bl + (4 * q + s + 2) * 256);
 #pragma unroll
             for (int g = 0; g < 4; ++g)
-                mfma_f32<false>(acc[g], a[s], b0[g], mf_pos(FIRST, LAST, q == 0 && s == 0 && g == 0, q == NQC - 1 && s == 3 && g == 3));
+                mfma_f32<false>(acc[g], a[s], b0[g], mf_pos(FIRST, LAST, q == 0 && s == 0, q == NQC - 1 && s == 3 && g == 3));
             b0 = b1;
             b1 = bn;
         }
@@ -330,7 +331,7 @@ __device__ __forceinline__ void input_proj_reg(f32x4 (&acc)[4], f32x4 y4, const 
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) mfma_f32<false>(acc[g], y4[s], kb[s][g], mf_pos(true, LAST, s == 0 && g == 0, s == 1 && g == 3));
+        for (int g = 0; g < 4; ++g) mfma_f32<false>(acc[g], y4[s], kb[s][g], mf_pos(true, LAST, s == 0, s == 1 && g == 3));
 }
 
 // acc += h tile (LDS, columns in rotated slice order) . register-resident R blocks [J0, J1)
@@ -346,7 +347,7 @@ __device__ __forceinline__ void recurrent(f32x4 (&acc)[4], const float* hrow, co
         for (int s = 0; s < 4; ++s)
 #pragma unroll
             for (int g = 0; g < 4; ++g)
-                mfma_f32<true>(acc[g], a[s], wR[j][s][g], mf_pos(FIRST, LAST, j == J0 && s == 0 && g == 0, j == J1 - 1 && s == 3 && g == 3));
+                mfma_f32<true>(acc[g], a[s], wR[j][s][g], mf_pos(FIRST, LAST, j == J0 && s == 0, j == J1 - 1 && s == 3 && g == 3));
         a = an;
     }
 }
@@ -913,7 +914,7 @@ __device__ __forceinline__ void cluster_body(const LstmParams& p, ClusterCarry& 
                 for (int b = 0; b < NB; ++b)
 #pragma unroll
                     for (int ss = 0; ss < 4; ++ss)
-                        mfma_f32<false>(dacc[ss & 1], wd[b][ss], hb[b][ss], mf_pos(true, true, b == 0 && ss == 0, b == NB - 1 && ss == 3));
+                        mfma_f32<false>(dacc[ss & 1], wd[b][ss], hb[b][ss], mf_pos(true, true, b == 0 && ss < 2, b == NB - 1 && ss == 3));
 #pragma unroll
                 for (int ss = 0; ss < 4; ++ss) dacc[0][ss] += dacc[1][ss];
                 *(f32x4*)(sW + (wave * 16 + n) * 16 + 4 * g4) = dacc[0];   // partial over this wave's positions

@@ -33,10 +33,12 @@ namespace fov {
 
 enum : int {
     ST_TIMEOUT = 0,     // != 0: a bounded in-kernel wait gave up; cleared only by fov_check_status
-    ST_ARRIVED = 1,     // workgroups of the running launch that have read the header (reset by xch_settle)
+    ST_ARRIVED = 32,    // workgroups of the running launch that have read the header (reset by xch_settle).  On a cache line of
+                        // its own (byte 128): 256 arrival adds on the line that every workgroup also READS (epoch base, launch
+                        // index, timeout word) held those reads up for microseconds at every launch (round 3, prologue stamps)
     ST_LAUNCHES = 2,    // exchange launches whose workgroups have all arrived
     ST_EPOCH = 3,       // epoch base: every tag written by launches < ST_LAUNCHES is <= this value
-    ST_SAFE0 = 4,       // ST_SAFE0 + (launch & 1): workgroups of that launch on the placement-independent (sc1) exchange
+    ST_SAFE0 = 48,      // ST_SAFE0 + (launch & 1): workgroups of that launch on the placement-independent (sc1) exchange (byte 192: third line)
     ST_FORCE_SAFE = 6,  // != 0: never take the same-XCD fast exchange (fov_workspace_force_safe: the tests' A/B switch)
 };
 
