@@ -540,14 +540,27 @@ def bench_convlstm(args, rank, world, use_dist):
         tgt = torch.softmax(torch.rand((Bt, T, Hh, Ww, C), device="cuda"), -1)
         tr.train_step(xt, xt[:, -1:], tgt)
         torch.cuda.synchronize()
+        log("convlstm: training step at batch %d" % Bt)
+        nrep = 2 if Bt <= 64 else 1
         t0 = time.perf_counter()
-        for _ in range(2):
+        for _ in range(nrep):
             loss = tr.train_step(xt, xt[:, -1:], tgt)
         torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / 2
+        dt = (time.perf_counter() - t0) / nrep
         tot = 3 * (2 * cell_flop_step + head_flop) * T * Bt
         res_train = {"batch": Bt, "ms_per_step": dt * 1e3, "sequences_per_s": Bt / dt, "tflops_3x_forward": tot / dt / 1e12,
                      "frac_of_fp32_mfma_peak": tot / dt / 1e12 / PEAK_FP32_MFMA_TFLOPS, "loss": float(loss.item())}
+    cpu = None
+    if rank == 0 and not args.no_cpu_baseline and world == 1:
+        # bounded sample: the 3-layer ConvLSTM encoder (the cell-only workload) over 16 of the sequences, torch CPU conv2d
+        from oracle import torch_cpu as TC
+        thr = min(TC.usable_cores(), CPU_THREADS)
+        xs = x0[:16].cpu().numpy()
+        layers = [(w["enc%d_K" % l], w["enc%d_R" % l], w["enc%d_b" % l]) for l in range(3)]
+        log("cpu baseline: ConvLSTM encoder on 16 sequences, torch CPU conv2d, %d threads" % thr)
+        cpu = cpu_leg(lambda: TC.convlstm_encoder_cpu(xs, layers, thr), 16, thr,
+                      "cell-only workload (3-layer ConvLSTM encoder, T=10): torch %s CPU conv2d per step over [x | h]" % torch.__version__, 10.0)
+        cpu["compare_with"] = "cell_only.sequences_per_s"
     if rank == 0:
         cell_tf = cell_flop_step * T * B / (cell_ms * 1e-3) / 1e12
         whole_tf = (2 * cell_flop_step + head_flop) * T * B / whole_s / 1e12
@@ -564,7 +577,7 @@ def bench_convlstm(args, rank, world, use_dist):
             "cell_only": {"ms": cell_ms, "sequences_per_s": B / (cell_ms * 1e-3), "tflops": cell_tf,
                           "frac_of_fp32_mfma_peak": cell_tf / PEAK_FP32_MFMA_TFLOPS,
                           "workload": "3-layer ConvLSTM encoder over T=10 steps (half the model's cell FLOPs), device-resident"},
-            "training": res_train, "cpu_baseline": None}), flush=True)
+            "training": res_train, "cpu_baseline": cpu}), flush=True)
 
 
 def bench_dry_run(args, rank, world, use_dist):
@@ -600,7 +613,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU-baseline timing (both legs together)")
     ap.add_argument("--cpu-threads", type=int, default=16, help="threads of the CPU-baseline legs (default: one GPU's share of the host)")
-    ap.add_argument("--train-batch", type=int, default=64, help="convlstm mode: batch of the timed training step (0 = skip)")
+    ap.add_argument("--train-batch", type=int, default=256, help="convlstm mode: batch of the timed training step (0 = skip); default = configs[3]'s B = 256 (tapes: about 10 GB)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the N > 1 path "
                          "with several ranks on ONE GPU)")

@@ -197,6 +197,33 @@ class OthersMixingCPU:
         return self._forward(enc_in, others, dec_in0).numpy()
 
 
+def convlstm_encoder_cpu(x, layers, threads, act="hard_sigmoid"):
+    """convlstm_seq2seq.py:100-126 (3 stacked ConvLSTM2D, return_sequences) on torch CPU ops: per layer and step ONE
+    conv2d over [x_t | h_{t-1}] (NCHW, 'same' padding) + the gates.  x (B,T,H,W,C) float32; layers = [(K (kh,kw,C,4F),
+    R (kh,kw,F,4F), b (4F,)), ...] in Keras layout, gate order i,f,c,o.  Returns the last layer's sequence (B,T,H,W,F)."""
+    import torch.nn.functional as Fn
+    torch.set_num_threads(int(threads))
+    rec = (lambda z: torch.clamp(0.2 * z + 0.5, 0.0, 1.0)) if act == "hard_sigmoid" else torch.sigmoid
+    with torch.no_grad():
+        seq = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).permute(1, 0, 4, 2, 3).contiguous()   # (T,B,C,H,W)
+        for K, R, b in layers:
+            W = torch.from_numpy(np.concatenate([K, R], axis=2).astype(np.float32)).permute(3, 2, 0, 1).contiguous()   # (4F, C+F, kh, kw)
+            bt = torch.from_numpy(np.ascontiguousarray(b, dtype=np.float32))
+            Fh = R.shape[2]
+            pad = (K.shape[0] // 2, K.shape[1] // 2)
+            h = torch.zeros((seq.shape[1], Fh) + tuple(seq.shape[3:]))
+            c = torch.zeros_like(h)
+            out = []
+            for t in range(seq.shape[0]):
+                z = Fn.conv2d(torch.cat([seq[t], h], 1), W, bt, padding=pad)
+                i, f, g, o = rec(z[:, :Fh]), rec(z[:, Fh:2 * Fh]), torch.tanh(z[:, 2 * Fh:3 * Fh]), rec(z[:, 3 * Fh:])
+                c = f * c + i * g
+                h = o * torch.tanh(c)
+                out.append(h)
+            seq = torch.stack(out, 0)
+        return seq.permute(1, 0, 3, 4, 2).contiguous().numpy()
+
+
 def timed_median(fn, budget_s=10.0, min_iters=10, max_iters=200, warmup=3):
     """Median seconds per call of fn(): `warmup` untimed calls, then at least `min_iters` timed ones, more while the
     time budget allows."""

@@ -324,3 +324,27 @@ def test_sampled_refeed_restatements():
     assert np.abs(O.single_lstm_keras_forward(x, w, 3, True, None)[:, 1] - y0[:, 1]).max() > 1e-6
     xs = rng.uniform(-1, 1, (3, 4, 90))
     np.testing.assert_allclose(O.single_lstm_keras_forward(xs, w)[:, :2], O.single_lstm_keras_forward(xs[:, :2], w), atol=1e-14)
+
+
+def test_cpu_baseline_legs_compute_the_same_graphs_as_the_oracle():
+    """bench.py's cpu_baseline legs (oracle/torch_cpu.py) are timed as 'the reference's CPU path restated': each must be the
+    SAME arithmetic as the oracle - the sgemm-loop leg and the torch-op legs of the target-only model, the others-mixing
+    model and the ConvLSTM encoder."""
+    from oracle import torch_cpu as TC
+    w = O.init_seq2seq(1, H=64, bias_noise=0.05)
+    enc, dec0, _ = O.synthetic_batch(2, 9, 5, 4)
+    f64 = lambda d: {k: v.astype(np.float64) for k, v in d.items()}
+    ref = O.seq2seq_decode(enc.astype(np.float64), dec0.astype(np.float64), f64(w), 4)
+    assert np.abs(TC.Seq2SeqSgemmCPU(w, threads=2).decode(enc, dec0, 4) - ref).max() < 2e-6
+    assert np.abs(TC.Seq2SeqCPU(w, threads=2).decode(enc, dec0, 4) - ref).max() < 2e-6
+    wm = O.init_others_mixing(3, H=32, num_user=5, bias_noise=0.05)
+    e, d0, t, oth = O.synthetic_batch(4, 7, 3, 4, num_others=4)
+    refm = O.others_mixing_forward(e.astype(np.float64), oth.astype(np.float64), d0.astype(np.float64), f64(wm))
+    assert np.abs(TC.OthersMixingCPU(wm, threads=2).predict(e, oth, d0) - refm).max() < 2e-6
+    wc = O.init_convlstm_seq2seq(1, C=6, latent_dim=4, head="conv2d")
+    x = np.random.default_rng(0).random((2, 3, 6, 5, 6)).astype(np.float32)
+    layers = [(wc["enc%d_K" % l], wc["enc%d_R" % l], wc["enc%d_b" % l]) for l in range(3)]
+    seq = x.astype(np.float64)
+    for K, R, b in layers:
+        seq = O.convlstm2d_layer(seq, K.astype(np.float64), R.astype(np.float64), b.astype(np.float64))[0]
+    assert np.abs(TC.convlstm_encoder_cpu(x, layers, 2) - seq).max() < 2e-6
