@@ -320,13 +320,25 @@ def cpu_baseline_seq2seq(enc, dec0, w, T_out, act, budget_s, want_out=False):
                 out_t = m.decode(enc, dec0, T_out)
             # leg 3: hand-arranged sgemm loop - input projection of all steps as one sgemm, one sgemm per
             # recurrent step, fused gates - at the GPU's share of the host AND at every usable core
-            for thr in sorted({nthr, cores}):
-                sg = TC.Seq2SeqSgemmCPU(w, threads=thr)
-                med, n = TC.timed_median(lambda: sg.decode(enc, dec0, T_out), budget_s=per_leg / 2, min_iters=3)
-                legs.append({"impl": "sgemm loop (torch.addmm -> MKL/oneDNN sgemm per step, fused gates)", "value": B / med,
-                             "ms_per_pass": med * 1e3, "passes": n, "cores": thr})
-                log("  sgemm loop, %d threads: %.1f ms per pass (%d passes)" % (thr, med * 1e3, n))
-    best = max(legs, key=lambda l: l["value"])
+            sg_impl = "sgemm loop (torch.addmm -> MKL/oneDNN sgemm per step, fused gates)"
+            sg = TC.Seq2SeqSgemmCPU(w, threads=nthr)
+            med, n = TC.timed_median(lambda: sg.decode(enc, dec0, T_out), budget_s=per_leg / 2, min_iters=3)
+            legs.append({"impl": sg_impl, "value": B / med, "ms_per_pass": med * 1e3, "passes": n, "cores": nthr})
+            log("  sgemm loop, %d threads: %.1f ms per pass (%d passes)" % (nthr, med * 1e3, n))
+            if cores > nthr:
+                # OMP_NUM_THREADS = nproc in a child with a wall limit: on a shared host a pool over
+                # every visible thread can take minutes per pass, and this line must stay within its time budget
+                limit = max(30.0, 3.0 * per_leg)
+                got = TC.sgemm_leg_in_child(enc, dec0, w, T_out, cores, per_leg / 2, limit)
+                if got is None:
+                    legs.append({"impl": sg_impl, "value": None, "ms_per_pass": None, "passes": 0, "cores": cores,
+                                 "note": "gave up after %.0f s: 1 warm-up + 3 passes did not finish (oversubscribed shared host)" % limit})
+                    log("  sgemm loop, %d threads: not finished within %.0f s, dropped" % (cores, limit))
+                else:
+                    med, n = got
+                    legs.append({"impl": sg_impl, "value": B / med, "ms_per_pass": med * 1e3, "passes": n, "cores": cores})
+                    log("  sgemm loop, %d threads: %.1f ms per pass (%d passes)" % (cores, med * 1e3, n))
+    best = max((l for l in legs if l["value"] is not None), key=lambda l: l["value"])
     cpu = {"value": best["value"], "unit": "sequences/s", "cores": best["cores"], "kind": "port",
            "sample": "median of %d passes over the same %d-sequence batch (T_in=%d -> T_out=%d); fastest of %d legs: %s, %d threads"
                      % (best["passes"], B, enc.shape[1], T_out, len(legs), best["impl"], best["cores"]),
@@ -408,7 +420,7 @@ def bench_config1(args, rank, world, use_dist):
                                    "batch=32, T 10->10 (latency-bound: 2 of 256 CUs' worth of tiles)", "global_batch": B * world,
                        "parallelism": "replicas x%d" % world},
             "latency": {"gpu_ms_per_call_async": ev_ms, "gpu_ms_per_call_host_synchronised_median": float(np.median(lat)) * 1e3,
-                        "cpu_ms_per_call": None if cpu is None else min(l["ms_per_pass"] for l in cpu["legs"])},
+                        "cpu_ms_per_call": None if cpu is None else min(l["ms_per_pass"] for l in cpu["legs"] if l["ms_per_pass"] is not None)},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
                          "note": "two 16-sequence tiles: 4 workgroups busy, per-step latency bound by construction"},
@@ -418,20 +430,24 @@ def bench_config1(args, rank, world, use_dist):
 
 def bench_a10(args, rank, world, use_dist):
     """The raw-TensorFlow model's native shape (mycode/lstm.py:59,128-132,218-240): MultiRNNCell of two LSTMCell(400) over
-    (batch 32, 10 steps, 90 features).  H = 400 is above the persistent kernels' widths (64 / 128 / 256): impl='auto' runs
-    the layer step-wise on the fp32 MFMA GEMM (x K for all steps as one product, then h R + one pointwise launch per step).
-    Beside it: the generic VALU kernel on the same shape (what round 1 ran) and the same stack at H = 256 on the persistent
-    matrix-core kernels - what a width-512 persistent instantiation would have to approach."""
+    (batch 32, 10 steps, 90 features).  The model object (models.StackedTFLSTM) zero-pads 400 -> 512 and runs the persistent
+    width-512 kernel (lstm_wide.hip: R in registers over sixteen workgroups per tile; layer 2's 512-wide input projected by
+    one GEMM inside the call).  Beside it: the unpadded layer step-wise on the fp32 MFMA GEMM (what round 2 ran: x K for all
+    steps as one product, then h R + one pointwise launch per step), the generic VALU kernel (round 1) and the same stack at
+    H = 256 on the persistent kernels."""
     from longterm360fov_amd import ops
     from oracle import fov_oracle as O
     B, T, F = 32, 10, 90
     rng = np.random.default_rng(7)
     x = rng.uniform(-1, 1, (B, T, F)).astype(np.float32)
     res = {}
-    for tag, H, impl in (("h400_stepwise_mfma_gemm", 400, "auto"), ("h400_generic_valu", 400, "generic"), ("h256_persistent_mfma", 256, "auto")):
+    from longterm360fov_amd.models import pad_lstm
+    for tag, H, impl, Hp in (("h400_padded_to_512_persistent_mfma", 400, "auto", 512), ("h400_stepwise_mfma_gemm", 400, "auto", 400),
+                             ("h400_generic_valu", 400, "generic", 400), ("h256_persistent_mfma", 256, "auto", 256)):
         lrng = np.random.default_rng(H)
         layers = [O.init_lstm(lrng, F, H), O.init_lstm(lrng, H, H)]
-        dl = [tuple(torch.from_numpy(a).cuda() for a in l) for l in layers]
+        run_layers = layers if Hp == H else [pad_lstm(K, R, b, Hp, pad_input=(l > 0)) for l, (K, R, b) in enumerate(layers)]
+        dl = [tuple(torch.from_numpy(a).cuda() for a in l) for l in run_layers]
         dx = torch.from_numpy(x).cuda()
         ws = ops.Workspace()
 
@@ -444,7 +460,7 @@ def bench_a10(args, rank, world, use_dist):
             step()
         ms = event_time_ms(step, max(args.steps, 100))
         ws.check()
-        got = step().cpu().numpy()
+        got = step()[..., :H].cpu().numpy()
         ref = x.astype(np.float64)
         for K, R, b in layers:
             ref, _, _ = O.lstm_layer(ref, K.astype(np.float64), R.astype(np.float64), b.astype(np.float64), act="sigmoid")
@@ -472,17 +488,18 @@ def bench_a10(args, rank, world, use_dist):
                 return net(xt)[0]
         cpu = cpu_leg(cpu_step, B, thr, "torch %s CPU nn.LSTM(90, 400, num_layers=2)" % torch.__version__, 5.0)
     if rank == 0:
-        r = res["h400_stepwise_mfma_gemm"]
+        r = res["h400_padded_to_512_persistent_mfma"]
         print(json.dumps({
             "metric": "sequences/sec, stacked LSTMCell(400) x2 forward (batch=32, T=10, F=90)", "value": world * r["sequences_per_s"],
             "unit": "sequences/s", "n_gpus": world, "steps": max(args.steps, 100), "warmup": 5, "ms_per_step": r["ms"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "lstm.py native shape: 2 x LSTMCell(400), batch 32, 10 steps, 90 features; step-wise on the fp32 MFMA "
-                                   "GEMM (H = 400 is above the persistent kernels' widths)", "global_batch": B * world,
+            "config": {"workload": "lstm.py native shape: 2 x LSTMCell(400), batch 32, 10 steps, 90 features; zero-padded to width 512 "
+                                   "on the persistent register-resident kernel (16 workgroups per 16-sequence tile); flops counted "
+                                   "at H = 400", "global_batch": B * world,
                        "parallelism": "replicas x%d" % world},
             "roofline": {"bound": "mfma", "achieved": r["tflops"], "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": r["tflops"] / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
-                         "note": "32 sequences, ~3 launches per layer-step: launch-latency-bound by construction"},
+                         "note": "32 sequences = two tiles = 32 of 256 CUs busy: latency-bound by construction"},
             "variants": res, "cpu_baseline": cpu}), flush=True)
 
 

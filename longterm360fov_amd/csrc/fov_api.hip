@@ -426,8 +426,17 @@ int fov_version(void) { return 100; }
 
 int fov_cluster_supported(int F, int H) { return cluster_shape_ok(F, H) ? 1 : 0; }
 
+// width 512 (lstm_wide.hip): header + granule area, and for F > 96 the input projection (B,T,4H) + GEMM scratch behind them
+static constexpr size_t kWide512ScratchFloats = ((size_t)1 << 20) + 64;
+static size_t wide512_workspace_bytes(int B, int T, int F) {
+    size_t n = cluster_workspace_bytes(B, 512);
+    if (F > 96) n += sizeof(float) * ((size_t)B * T * 2048 + kWide512ScratchFloats);
+    return n;
+}
+
 size_t fov_lstm_seq_workspace_bytes(int B, int T, int F, int H, int impl) {
     if (B <= 0) return kStatusBytes;
+    if (impl != FOV_IMPL_GENERIC && wide512_shape_ok(F, H, F > 96)) return wide512_workspace_bytes(B, T, F);
     if (impl == FOV_IMPL_AUTO && stepwise_preferred(B, F, H)) return kStatusBytes + sizeof(float) * stepwise_workspace_floats(B, T, H);
     if (impl != FOV_IMPL_GENERIC && wide_shape_ok(F, H)) return cluster_workspace_bytes(B, H);
     if (impl == FOV_IMPL_AUTO && wide_narrow_preferred(B, F, H)) return cluster_workspace_bytes(B, H);
@@ -451,6 +460,19 @@ static int lstm_seq_fwd_impl(const float* x, const float* K, const float* R, con
     p.status = (unsigned*)workspace;
     p.xch = (unsigned long long*)((char*)workspace + kStatusBytes);
     hipStream_t s = (hipStream_t)stream;
+    // width 512 (mycode/lstm.py's LSTMCell(400), zero-padded by the caller): R register-resident over 16 workgroups per tile;
+    // an input wider than 96 is projected first (one GEMM over all steps), the kernel adds it per step
+    if (impl != FOV_IMPL_GENERIC && wide512_shape_ok(F, H, F > 96)) {
+        if (F > 96) {
+            float* zx = (float*)((char*)workspace + cluster_workspace_bytes(B, H));
+            if (B > 0 && T > 0) {
+                rc = matmul_f32(x, K, zx, B * T, F, 4 * H, zx + (size_t)B * T * 4 * H, kWide512ScratchFloats, s);
+                if (rc) return rc;
+            }
+            p.zx = zx;
+        }
+        return launch_wide(p, s);
+    }
     // wide inputs (a stacked layer over a 256-wide sequence): K and R both register-resident (lstm_wide.hip)
     if (impl != FOV_IMPL_GENERIC && wide_shape_ok(F, H) && (((uintptr_t)x) & 15) == 0) return launch_wide(p, s);
     // narrow inputs, at most 32 tiles: groups of eight workgroups fill the chip where lstm_cluster's groups of four leave half idle
@@ -515,6 +537,7 @@ int fov_lstm_seq_fwd_zx(const float* zx, const float* R, const float* b, const f
     p.status = (unsigned*)workspace;
     p.xch = (unsigned long long*)((char*)workspace + kStatusBytes);
     hipStream_t s = (hipStream_t)stream;
+    if (impl != FOV_IMPL_GENERIC && wide512_shape_ok(1, H, true)) return launch_wide(p, s);
     if (want_cluster(impl, 1, H, 0, false)) return launch_cluster(p, false, s);
     return launch_generic(p, false, s);
 }

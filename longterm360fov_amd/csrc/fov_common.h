@@ -91,6 +91,7 @@ int launch_pair_fused(const LstmParams& p, hipStream_t stream);
 // wide-input layer, H = 256, 96 < F <= 256 (lstm_wide.hip)
 bool wide_shape_ok(int F, int H);
 bool wide_narrow_preferred(int B, int F, int H);
+bool wide512_shape_ok(int F, int H, bool zx);   // width 512: 16 workgroups per tile; F <= 96 in-kernel, else precomputed x.K
 int launch_wide(const LstmParams& p, hipStream_t stream);
 // step-wise layer forward on the matrix-core GEMM (train_kernels.hip): hidden widths above the persistent kernels' 256
 bool stepwise_preferred(int B, int F, int H);

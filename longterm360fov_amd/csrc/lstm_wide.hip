@@ -13,6 +13,11 @@
 // stage.  A batch of <= 512 sequences is <= 32 tiles: lstm_cluster.hip's groups of FOUR workgroups would occupy at
 // most half of the 256 CUs, groups of eight fill them, so fov_lstm_seq_fwd(impl = auto) sends such batches here
 // (encoder layer 1 of configs[2] at 512 sequences per GPU).
+// WIDTH 512 (round 3, template parameters HW = 512, GW = 16): the same kernel with SIXTEEN workgroups per tile, 32 units
+// each, R slice 512 x 128 = 256 AGPRs per lane - the persistent form for mycode/lstm.py's LSTMCell(400) x 2 (:59,
+// 218-240), whose weights the model object zero-pads 400 -> 512 (exact: models.pad_lstm).  Layer 1 (F = 90) is the
+// narrow variant; layer 2's input is 512 wide, its K would be another 256 registers, so it takes the ZX form: the input
+// projection zx = x . K comes precomputed (fov_matmul) and is added to the bias at the start of every step.
 #include <stdlib.h>
 
 #include "fov_common.h"
@@ -22,18 +27,16 @@ namespace fov {
 
 namespace {
 
-constexpr int WH = 256;
-constexpr int WG = 8;
 constexpr int WBT = 16;
-constexpr int WLD = WH + 4;      // LDS row stride of the h tile and of the x tiles
-constexpr int WNG = 14;
 constexpr unsigned WSPIN = 1u << 20;
 
 typedef unsigned wu32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned wu32x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ void wm_a(f32x4& acc, float a, float w_agpr) {
-    asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "a"(w_agpr));
+template <bool W_AGPR>
+__device__ __forceinline__ void wm_a(f32x4& acc, float a, float w) {
+    if constexpr (W_AGPR) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "a"(w));
+    else asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(w));
 }
 __device__ __forceinline__ void wm_begin(f32x4 (&acc)[2]) { asm volatile("s_nop 3" : "+v"(acc[0]), "+v"(acc[1])); }
 __device__ __forceinline__ void wm_end(f32x4 (&acc)[2]) {
@@ -43,8 +46,9 @@ __device__ __forceinline__ float wswap(float v) {
     return __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x128, 0xf, 0xf, false));
 }
 
-// acc[tile] += A(tile rows in LDS, k-blocks [0, NJ)) . W (AGPR resident)
-template <int NJ>
+// acc[tile] += A(tile rows in LDS, k-blocks [0, NJ)) . W (register resident: accumulation registers, or - width 512, whose
+// R slice alone fills all 256 of them - the K slice in ordinary vector registers)
+template <int NJ, bool W_AGPR = true>
 __device__ __forceinline__ void wide_mm(f32x4 (&acc)[2], const float* arow, const float (&w)[NJ][4][2]) {
     f32x4 a = *(const f32x4*)arow;
 #pragma unroll
@@ -54,16 +58,23 @@ __device__ __forceinline__ void wide_mm(f32x4 (&acc)[2], const float* arow, cons
         asm volatile("s_nop 1" : "+v"(a));   // the fragment may have been moved by the compiler (VALU copy)
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            wm_a(acc[0], a[s], w[j][s][0]);
-            wm_a(acc[1], a[s], w[j][s][1]);
+            wm_a<W_AGPR>(acc[0], a[s], w[j][s][0]);
+            wm_a<W_AGPR>(acc[1], a[s], w[j][s][1]);
         }
         a = an;
     }
 }
 
-template <int ACT, int NJX>
+// NJX: k-blocks of K held in registers (16: wide input, 16-byte x pieces; 6: narrow input, scalar x stage; 0: ZX mode, the
+// input projection comes precomputed in p.zx).  WH / WG: hidden width and workgroups per tile (256 / 8 or 512 / 16).
+template <int ACT, int NJX, int WH, int WG>
 __global__ __launch_bounds__(256, 1) void lstm_wide_kernel(LstmParams p) {
     constexpr bool XVEC = NJX == 16;   // wide inputs: 16-byte pieces (F % 4 == 0, x aligned); narrow: scalar elements
+    constexpr bool ZXM = NJX == 0;
+    constexpr int WLD = WH + 4;        // LDS row stride of the h tile and of the x tiles
+    constexpr int WNG = (WG - 1) * 2;  // granules gathered per thread and step: (WG-1) slices * 16 rows * 32 units / 256
+    constexpr int NJR = WH / 16;       // k-blocks of R
+    constexpr bool K_AGPR = WH == 256; // width 512: R takes every accumulation register, K (narrow: 48 values) stays in VGPRs
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* sH = smem;                    // [16][WLD]
     float* sX = sH + WBT * WLD;          // [2][16][WLD]
@@ -78,7 +89,7 @@ __global__ __launch_bounds__(256, 1) void lstm_wide_kernel(LstmParams p) {
         group = blockIdx.x / WG;
         slice = blockIdx.x - group * WG;
     }
-    const int F = p.F, steps = p.T;
+    const int F = ZXM ? 0 : p.F, steps = p.T;
     const int unit = 32 * slice + 8 * wave + (n & 7);
     const int hi = n >> 3;
     const int col0 = hi * WH + unit, col1 = (2 + hi) * WH + unit;
@@ -92,10 +103,10 @@ __global__ __launch_bounds__(256, 1) void lstm_wide_kernel(LstmParams p) {
 
     // ---- resident weights: K rows >= F are zero ----
     constexpr unsigned OORB = 0x80000000u;   // buffer-load offset no descriptor covers: reads as 0
-    const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.K), 0, F * H4 * 4, 0x00020000);
-    float wk[NJX][4][2], wr[16][4][2];
+    const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ZXM ? nullptr : p.K), 0, F * H4 * 4, 0x00020000);
+    float wk[NJX > 0 ? NJX : 1][4][2], wr[NJR][4][2];
 #pragma unroll
-    for (int j = 0; j < 16; ++j)
+    for (int j = 0; j < NJR; ++j)
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const int k = 16 * j + 4 * g4 + s;
@@ -155,18 +166,22 @@ __global__ __launch_bounds__(256, 1) void lstm_wide_kernel(LstmParams p) {
             }
             __builtin_amdgcn_s_sleep(1);
             asm volatile("" ::: "memory");
-            wu32x2 tv[WNG];
+            constexpr int RCH = WH == 512 ? 6 : WNG;   // width 512: retry in chunks (register budget)
 #pragma unroll
-            for (int j = 0; j < WNG; ++j) {
-                const unsigned uo = (unsigned)((j & 1) * 8 * WH + ((slice + 1 + (j >> 1)) & (WG - 1)) * 32) * 8u;
-                tv[j] = __builtin_amdgcn_raw_buffer_load_b64(xrs, gvoff, base + uo, 16);
-            }
+            for (int j0 = 0; j0 < WNG; j0 += RCH) {
+                wu32x2 tv[RCH];
 #pragma unroll
-            for (int j = 0; j < WNG; ++j) {
-                const int lo = lbase + (j & 1) * 8 * WLD + ((slice + 1 + (j >> 1)) & (WG - 1)) * 32;
-                if (((bad >> j) & 1u) && tv[j].y == epoch) {
-                    sH[lo] = __uint_as_float(tv[j].x);
-                    bad &= ~(1u << j);
+                for (int j = j0; j < j0 + RCH; ++j) {
+                    const unsigned uo = (unsigned)((j & 1) * 8 * WH + ((slice + 1 + (j >> 1)) & (WG - 1)) * 32) * 8u;
+                    tv[j - j0] = __builtin_amdgcn_raw_buffer_load_b64(xrs, gvoff, base + uo, 16);
+                }
+#pragma unroll
+                for (int j = j0; j < j0 + RCH; ++j) {
+                    const int lo = lbase + (j & 1) * 8 * WLD + ((slice + 1 + (j >> 1)) & (WG - 1)) * 32;
+                    if (((bad >> j) & 1u) && tv[j - j0].y == epoch) {
+                        sH[lo] = __uint_as_float(tv[j - j0].x);
+                        bad &= ~(1u << j);
+                    }
                 }
             }
         }
@@ -177,7 +192,7 @@ __global__ __launch_bounds__(256, 1) void lstm_wide_kernel(LstmParams p) {
     // (narrow variant: the elements xc, xc+16, ..., xc+80)
     const int xrw = tid >> 4, xc = tid & 15;
     const int nx4 = F >> 2;   // 16-byte pieces per row (F % 4 == 0, host-checked)
-    constexpr int NXR = XVEC ? 4 : NJX;
+    constexpr int NXR = XVEC ? 4 : (NJX > 0 ? NJX : 1);
     for (int tile = group; tile < p.num_tiles && !aborted; tile += p.num_groups) {
         const int b0 = tile * WBT;
         __syncthreads();   // previous tile fully consumed
@@ -190,7 +205,7 @@ __global__ __launch_bounds__(256, 1) void lstm_wide_kernel(LstmParams p) {
         const __amdgpu_buffer_rsrc_t c0rs = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<float*>(p.c0 ? p.c0 + (size_t)b0 * WH : nullptr), 0, p.c0 ? live_rows * WH * 4 : 0, 0x00020000);
         const __amdgpu_buffer_rsrc_t xgrs = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<float*>(p.x + (size_t)b0 * p.T * F), 0, live_rows * p.T * F * 4, 0x00020000);
+            const_cast<float*>(ZXM ? nullptr : p.x + (size_t)b0 * p.T * F), 0, ZXM ? 0 : live_rows * p.T * F * 4, 0x00020000);
         {
             float hv[WBT * WH / 256];
 #pragma unroll
@@ -198,7 +213,7 @@ __global__ __launch_bounds__(256, 1) void lstm_wide_kernel(LstmParams p) {
 #pragma unroll
             for (int q = 0; q < WBT * WH / 256; ++q) {
                 const int e = tid + 256 * q;
-                sH[(e >> 8) * WLD + (e & 255)] = hv[q];
+                sH[(e / WH) * WLD + (e % WH)] = hv[q];
             }
         }
         float c[2], hc[2] = {0.f, 0.f};
@@ -221,7 +236,7 @@ __global__ __launch_bounds__(256, 1) void lstm_wide_kernel(LstmParams p) {
         auto load_x1 = [&](int i, int t) { return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xgrs, xoff[i], (unsigned)(t * F * 4), 0)); };
         float* xl = sX + xrw * WLD + (XVEC ? 4 : 1) * xc;
         const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-        {
+        if constexpr (!ZXM) {
             f32x4 x4[2][XVEC ? NXR : 1];
             float x1[2][XVEC ? 1 : NXR];
 #pragma unroll
@@ -246,21 +261,42 @@ __global__ __launch_bounds__(256, 1) void lstm_wide_kernel(LstmParams p) {
                 }
         }
         __syncthreads();
+        // ZX mode: this lane's pre-activations of step t sit at zx[row 4*g4 + r][t][col0 | col1] (the MFMA D layout): eight
+        // loads per step, requested one step ahead
+        const __amdgpu_buffer_rsrc_t zxrs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(ZXM ? p.zx + (size_t)b0 * p.T * H4 : nullptr), 0, ZXM ? live_rows * p.T * H4 * 4 : 0, 0x00020000);
+        f32x4 zn[2] = {z4, z4};   // zx of the NEXT step
+        auto load_zx = [&](int t) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const unsigned o = (unsigned)((((4 * g4 + r) * p.T + t) * H4) * 4);
+                zn[0][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(zxrs, o + (unsigned)(col0 * 4), 0, 0));
+                zn[1][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(zxrs, o + (unsigned)(col1 * 4), 0, 0));
+            }
+        };
         // ---- pre-activations of step 0 ----
         f32x4 acc[2];
         acc[0] = (f32x4){bv[0], bv[0], bv[0], bv[0]};
         acc[1] = (f32x4){bv[1], bv[1], bv[1], bv[1]};
+        if constexpr (ZXM) {
+            if (steps > 0) {
+                load_zx(0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { acc[0][r] += zn[0][r]; acc[1][r] += zn[1][r]; }
+                if (steps > 1) load_zx(1);
+            }
+        }
         if (steps > 0) {
             wm_begin(acc);
-            wide_mm<NJX>(acc, sX + n * WLD + 4 * g4, wk);
-            wide_mm<16>(acc, hrow, wr);
+            if constexpr (NJX > 0) wide_mm<NJX, K_AGPR>(acc, sX + n * WLD + 4 * g4, wk);
+            wide_mm<NJR>(acc, hrow, wr);
             wm_end(acc);
         }
         f32x4 xr[XVEC ? 4 : 1] = {z4};
-        float xs[XVEC ? 1 : NJX] = {0.f};
+        float xs[XVEC ? 1 : (NJX > 0 ? NJX : 1)] = {0.f};
         for (int t = 0; t < steps; ++t) {
             // x pipeline: x_{t+1} (requested during step t-1) registers -> LDS; then request x_{t+2}
-            if (t > 0 && t + 1 < steps) {
+            if (!ZXM && t > 0 && t + 1 < steps) {
                 float* xb = xl + ((t + 1) & 1) * WBT * WLD;
 #pragma unroll
                 for (int i = 0; i < NXR; ++i) {
@@ -271,7 +307,7 @@ __global__ __launch_bounds__(256, 1) void lstm_wide_kernel(LstmParams p) {
                     }
                 }
             }
-            if (t + 2 < steps) {
+            if (!ZXM && t + 2 < steps) {
 #pragma unroll
                 for (int i = 0; i < NXR; ++i) {
                     if constexpr (XVEC) xr[i] = load_x4(i, t + 2);
@@ -323,9 +359,15 @@ __global__ __launch_bounds__(256, 1) void lstm_wide_kernel(LstmParams p) {
             }
             acc[0] = (f32x4){bv[0], bv[0], bv[0], bv[0]};
             acc[1] = (f32x4){bv[1], bv[1], bv[1], bv[1]};
-            if (more) {   // x_{t+1} . K needs no remote data
+            if constexpr (ZXM) {
+                if (more) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { acc[0][r] += zn[0][r]; acc[1][r] += zn[1][r]; }
+                    if (t + 2 < steps) load_zx(t + 2);
+                }
+            } else if (more) {   // x_{t+1} . K needs no remote data
                 wm_begin(acc);
-                wide_mm<NJX>(acc, sX + ((t + 1) & 1) * WBT * WLD + n * WLD + 4 * g4, wk);
+                wide_mm<NJX, K_AGPR>(acc, sX + ((t + 1) & 1) * WBT * WLD + n * WLD + 4 * g4, wk);
                 wm_end(acc);
             }
             // The gather is requested only now: the partners published at about the same moment as this workgroup, and
@@ -337,7 +379,7 @@ __global__ __launch_bounds__(256, 1) void lstm_wide_kernel(LstmParams p) {
             if (sFlag[0]) { aborted = true; break; }
             if (more) {
                 wm_begin(acc);
-                wide_mm<16>(acc, hrow, wr);
+                wide_mm<NJR>(acc, hrow, wr);
                 wm_end(acc);
             }
         }
@@ -357,34 +399,46 @@ __global__ __launch_bounds__(256, 1) void lstm_wide_kernel(LstmParams p) {
 
 }  // namespace
 
-bool wide_shape_ok(int F, int H) { return H == WH && F > 96 && F <= 256 && (F & 3) == 0; }
+bool wide_shape_ok(int F, int H) { return H == 256 && F > 96 && F <= 256 && (F & 3) == 0; }
 
 // F <= 96 at H = 256: the narrow variant, preferred over lstm_cluster.hip while the batch is at most 32 tiles
-bool wide_narrow_preferred(int B, int F, int H) { return H == WH && F >= 1 && F <= 96 && B > 0 && B <= 32 * WBT; }
+bool wide_narrow_preferred(int B, int F, int H) { return H == 256 && F >= 1 && F <= 96 && B > 0 && B <= 32 * WBT; }
 
-// p.status / p.xch point into the caller's workspace (cluster_workspace_bytes(B, 256): granule area for up to 64
-// groups, this kernel uses at most 32)
-int launch_wide(const LstmParams& p_in, hipStream_t stream) {
-    LstmParams p = p_in;
-    if (p.B == 0) return FOV_OK;
-    const bool narrow = p.F <= 96;
-    if (!narrow && (((uintptr_t)p.x) & 15) != 0) { set_error("wide LSTM layer: x must be 16-byte aligned"); return FOV_ERR_INVALID; }
+// width 512 (16 workgroups per tile): narrow input (F <= 96) or a precomputed input projection (p.zx)
+bool wide512_shape_ok(int F, int H, bool zx) { return H == 512 && (zx || (F >= 1 && F <= 96)) && device_cu_count() >= 16; }
+
+template <int NJX, int WH, int WG>
+static int launch_wide_t(LstmParams& p, hipStream_t stream) {
     p.num_tiles = (p.B + WBT - 1) / WBT;
     const int max_groups = device_cu_count() / WG;   // one workgroup per CU: every group must be co-resident
     if (max_groups < 1) { set_error("wide LSTM layer needs at least %d CUs", WG); return FOV_ERR_UNSUPPORTED; }
     p.num_groups = p.num_tiles < max_groups ? p.num_tiles : max_groups;
+    if ((size_t)p.num_groups * 2 * WBT * WH * sizeof(unsigned long long) > kXchBytes - kHelloBytes) { set_error("wide LSTM layer: granule area too small"); return FOV_ERR_WORKSPACE; }
     p.epoch_span = p.T * ((p.num_tiles + p.num_groups - 1) / p.num_groups) + 1;   // no memset: tags continue from the header
     if (int rc_ = xch_account(p.status, p.epoch_span, stream)) return rc_;
-    const size_t lds = sizeof(float) * (3 * WBT * WLD) + 64;
-    void (*kern)(LstmParams) =
-        narrow ? (p.act == FOV_ACT_HARD_SIGMOID ? lstm_wide_kernel<FOV_ACT_HARD_SIGMOID, 6> : lstm_wide_kernel<FOV_ACT_SIGMOID, 6>)
-               : (p.act == FOV_ACT_HARD_SIGMOID ? lstm_wide_kernel<FOV_ACT_HARD_SIGMOID, 16> : lstm_wide_kernel<FOV_ACT_SIGMOID, 16>);
+    const size_t lds = sizeof(float) * (3 * WBT * (WH + 4)) + 64;
+    void (*kern)(LstmParams) = p.act == FOV_ACT_HARD_SIGMOID ? lstm_wide_kernel<FOV_ACT_HARD_SIGMOID, NJX, WH, WG>
+                                                             : lstm_wide_kernel<FOV_ACT_SIGMOID, NJX, WH, WG>;
     int rc = ensure_dynamic_lds((const void*)kern, lds);
     if (rc) return rc;
     hipLaunchKernelGGL(kern, dim3(p.num_groups * WG), dim3(256), lds, stream, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("wide LSTM launch: %s", hipGetErrorString(e)); return FOV_ERR_LAUNCH; }
     return FOV_OK;
+}
+
+// p.status / p.xch point into the caller's workspace (cluster_workspace_bytes(B, H): header + the fixed granule area)
+int launch_wide(const LstmParams& p_in, hipStream_t stream) {
+    LstmParams p = p_in;
+    if (p.B == 0) return FOV_OK;
+    if (p.H == 512) {
+        if (p.zx) return launch_wide_t<0, 512, 16>(p, stream);
+        if (p.F > 96) { set_error("wide LSTM layer, width 512: F > 96 needs the precomputed input projection"); return FOV_ERR_INVALID; }
+        return launch_wide_t<6, 512, 16>(p, stream);
+    }
+    const bool narrow = p.F <= 96;
+    if (!narrow && (((uintptr_t)p.x) & 15) != 0) { set_error("wide LSTM layer: x must be 16-byte aligned"); return FOV_ERR_INVALID; }
+    return narrow ? launch_wide_t<6, 256, 8>(p, stream) : launch_wide_t<16, 256, 8>(p, stream);
 }
 
 }  // namespace fov

@@ -1165,31 +1165,45 @@ class StackedTFLSTM:
     """MultiRNNCell([LSTMCell(n_hidden)] * num_layers) under tf.nn.dynamic_rnn with a fed initial state
     (mycode/lstm.py:128-132,218-240), inference form (the DropoutWrapper is the identity at keep_prob 1).
     predict(x (B,T,F), init_state (L,2,B,H) or None) -> (states_series (B,T,H), current_state (L,2,B,H));
-    state tuples are (c, h) as in LSTMStateTuple."""
+    state tuples are (c, h) as in LSTMStateTuple.
+    Widths between 257 and 512 (the script's n_hidden = 400, lstm.py:59) run zero-padded at width 512 on the persistent
+    register-resident kernel (lstm_wide.hip, sixteen workgroups per tile) - exact, see pad_lstm; impl='generic' or
+    pad=False keeps the layer at its own width (step-wise on the GEMM / the VALU kernel)."""
 
-    def __init__(self, cells, forget_bias=1.0, impl="auto", device="cuda"):
+    def __init__(self, cells, forget_bias=1.0, impl="auto", device="cuda", pad=True):
         self.layers = [convert_tf_lstmcell(W, b, forget_bias) for W, b in cells]
         self.impl, self.device = impl, device
+        self.n_hidden = self.layers[0][1].shape[0]
+        self.run_width = padded_width(self.n_hidden, MFMA_WIDTHS + (512,)) if (pad and impl != "generic") else None
+        if self.run_width is None or self.n_hidden <= MFMA_WIDTHS[-1]:
+            self.run_width = self.n_hidden       # the supported widths need no padding; above 512: as is
         self._dw = None
 
     def predict(self, x, init_state=None):
         import torch
         from . import ops
+        H, Hp = self.n_hidden, self.run_width
         if self._dw is None:
-            self._dw = [tuple(torch.from_numpy(a).to(self.device) for a in layer) for layer in self.layers]
+            layers = self.layers
+            if Hp != H:
+                layers = [pad_lstm(K, R, b, Hp, pad_input=(l > 0)) for l, (K, R, b) in enumerate(layers)]
+            self._dw = [tuple(torch.from_numpy(a).to(self.device) for a in layer) for layer in layers]
             self._ws = ops.Workspace()
         inp = torch.from_numpy(_as_f32(x)).to(self.device)
         B = inp.shape[0]
-        st = None if init_state is None else torch.from_numpy(_as_f32(init_state)).to(self.device)
+        st = None
+        if init_state is not None:
+            st = torch.zeros((len(self._dw), 2, B, Hp), dtype=torch.float32, device=self.device)
+            st[..., :H] = torch.from_numpy(_as_f32(init_state)).to(self.device)
         states = []
         for l, (K, R, b) in enumerate(self._dw):
-            c0 = None if st is None else st[l, 0].contiguous()
-            h0 = None if st is None else st[l, 1].contiguous()
+            c0 = None if st is None else st[l, 0]
+            h0 = None if st is None else st[l, 1]
             hs, hT, cT = ops.lstm_seq(inp, K, R, b, h0, c0, act="sigmoid", impl=self.impl, workspace=self._ws)
             states.append(torch.stack([cT, hT], dim=0))
             inp = hs
         self._ws.check()
-        return inp.cpu().numpy(), torch.stack(states, dim=0).cpu().numpy()
+        return inp[..., :H].cpu().numpy(), torch.stack(states, dim=0)[..., :H].cpu().numpy()
 
 
 class ConvLSTMSeq2Seq(KerasModelSurface):

@@ -236,3 +236,39 @@ def timed_median(fn, budget_s=10.0, min_iters=10, max_iters=200, warmup=3):
         fn()
         times.append(time.perf_counter() - t0)
     return float(np.median(times)), len(times)
+
+
+def sgemm_leg_in_child(enc, dec0, w, T_out, threads, budget_s, wall_limit_s):
+    """Time Seq2SeqSgemmCPU.decode with `threads` threads in a CHILD process that the caller can give up on: on a shared
+    8-GPU host a pool over every visible hardware thread (256) can take minutes per pass (oversubscription), and a torch op
+    cannot be interrupted from inside its own process.  Returns (median_s, passes), or None when the child did not finish
+    within `wall_limit_s` (it is killed by its PID)."""
+    import json
+    import subprocess
+    import sys
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "leg.npz")
+        np.savez(path, enc=enc, dec0=dec0, **{"w_" + k: v for k, v in w.items()})
+        env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="", OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads))
+        try:
+            r = subprocess.run([sys.executable, "-m", "oracle.torch_cpu", path, str(int(T_out)), str(int(threads)), str(float(budget_s))],
+                               cwd=root, env=env, capture_output=True, text=True, timeout=wall_limit_s)
+        except subprocess.TimeoutExpired:
+            return None
+    if r.returncode != 0:
+        raise RuntimeError("sgemm leg child failed: " + r.stderr[-400:])
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    return out["median_s"], out["passes"]
+
+
+if __name__ == "__main__":   # the child of sgemm_leg_in_child
+    import json
+    import sys
+    _path, _T_out, _thr, _budget = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), float(sys.argv[4])
+    _z = np.load(_path)
+    _w = {k[2:]: _z[k] for k in _z.files if k.startswith("w_")}
+    _sg = Seq2SeqSgemmCPU(_w, threads=_thr)
+    _med, _n = timed_median(lambda: _sg.decode(_z["enc"], _z["dec0"], _T_out), budget_s=_budget, min_iters=3, warmup=1)
+    print(json.dumps({"median_s": _med, "passes": _n}))

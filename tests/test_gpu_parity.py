@@ -391,6 +391,12 @@ def test_tf_contrib_stacked_lstm_mapping():
         out0, _ = m.predict(x)                       # zero initial state
         ref0, _ = O.tf_dynamic_rnn(x.astype(np.float64), [(W.astype(np.float64), b.astype(np.float64)) for W, b in cells])
         assert_parity(out0, ref0, "tf stacked LSTM H%d zero state" % H)
+        if H == 400:   # 400 units run zero-padded at width 512 on the persistent kernel; the unpadded step-wise form agrees
+            assert m.run_width == 512
+            u = StackedTFLSTM(cells, pad=False)
+            assert u.run_width == 400
+            out_u, st_u = u.predict(x, st0)
+            assert np.abs(out_u - out).max() <= 2e-5 and np.abs(st_u - st).max() <= 2e-5
 
 
 def test_fov_hit_rate_against_oracle(golden_dir):
@@ -486,6 +492,50 @@ def test_wide_input_layer(B, T, F, act):
     assert torch.equal(hs2, hs)                                   # deterministic, same kernel
     assert (res - res_g).abs().max().item() < 2e-6                 # reserve agrees with the generic kernel's
     assert (hs2 - hs_g).abs().max().item() < 2e-6
+
+
+@pytest.mark.parametrize("B,T,F,state", [(32, 10, 90, False), (32, 10, 512, True), (37, 5, 200, True), (5, 1, 7, False),
+                                         (16, 1, 512, True), (600, 3, 90, True), (300, 4, 400, False)])
+@pytest.mark.parametrize("act", ["sigmoid", "hard_sigmoid"])
+def test_width_512_persistent_layer(B, T, F, state, act):
+    """H = 512 (mycode/lstm.py's LSTMCell(400) x 2 zero-padded, :59,218-240): the recurrent kernel stays in registers across
+    SIXTEEN workgroups per 16-sequence tile (lstm_wide.hip).  F <= 96: the input kernel sits in registers too; wider inputs
+    are projected by one GEMM inside the same C-ABI call and added per step.  Against the fp64 oracle and the generic
+    kernel: hidden sequence, final states, the training tape, a fed initial state, ragged batches, more tiles than groups
+    (B = 600: 38 tiles on 16 groups), and the entry point that takes the projection precomputed."""
+    from longterm360fov_amd import _lib
+    ops = _ops()
+    H = 512
+    rng = np.random.default_rng(B + F)
+    K, R, b = O.init_lstm(rng, F, H, np.float32)
+    b = (b + 0.1 * rng.standard_normal(b.shape)).astype(np.float32)
+    x = rng.uniform(-1, 1, (B, T, F)).astype(np.float32)
+    h0 = (0.3 * rng.standard_normal((B, H))).astype(np.float32) if state else None
+    c0 = (0.3 * rng.standard_normal((B, H))).astype(np.float32) if state else None
+    d = lambda a: None if a is None else a.astype(np.float64)
+    dv = lambda a: None if a is None else dev(a)
+    hs_ref, hT_ref, cT_ref, res_ref = O.lstm_layer_train(d(x), d(K), d(R), d(b), d(h0), d(c0), act=act)
+    ws = ops.Workspace()
+    before = _lib.lib().fov_debug_generic_launches()
+    hs, hT, cT = ops.lstm_seq(dev(x), dev(K), dev(R), dev(b), dv(h0), dv(c0), act=act, workspace=ws)
+    ws.check()
+    assert _lib.lib().fov_debug_generic_launches() == before       # not the VALU kernel
+    assert_parity(hs, hs_ref, "width-512 layer hs F=%d" % F)
+    assert_parity(hT, hT_ref, "width-512 layer hT")
+    assert_parity(cT, cT_ref, "width-512 layer cT")
+    hs2, hT2, cT2, res = ops.lstm_seq_train(dev(x), dev(K), dev(R), dev(b), dv(h0), dv(c0), act=act, workspace=ws)
+    ws.check()
+    assert torch.equal(hs2, hs) and torch.equal(cT2, cT)           # deterministic, same kernel
+    assert np.abs(res.cpu().numpy() - res_ref).max() <= 2e-5
+    g_hs, _, g_cT = ops.lstm_seq(dev(x), dev(K), dev(R), dev(b), dv(h0), dv(c0), act=act, impl="generic", workspace=ops.Workspace())
+    assert (g_hs - hs).abs().max().item() <= 2e-5 and (g_cT - cT).abs().max().item() <= 2e-5
+    _, hT3, cT3 = ops.lstm_seq(dev(x), dev(K), dev(R), dev(b), dv(h0), dv(c0), act=act, return_sequences=False, workspace=ws)
+    assert torch.equal(hT3, hT) and torch.equal(cT3, cT)
+    zx = ops.matmul(dev(x).reshape(B * T, F), dev(K)).reshape(B, T, 4 * H)
+    hs4, _, cT4 = ops.lstm_seq_zx(zx, dev(R), dev(b), dv(h0), dv(c0), act=act, workspace=ws)
+    ws.check()
+    assert_parity(hs4, hs_ref, "width-512 layer, projection given")
+    assert (cT4 - cT).abs().max().item() <= 2e-5
 
 
 def test_config3_full_size_and_properties():

@@ -1,13 +1,30 @@
 #!/bin/bash
 # usage (GPU box, repo root): tools/final_round.sh <outdir>   - the measurements a round's profiles/ are refreshed from
 out=$1; mkdir -p $out
-python3 bench.py --steps 50 --warmup 5 > $out/bench.json 2> $out/bench.err
-for m in train infer_mixing train_mixing; do python3 bench.py --mode $m --steps 30 --warmup 5 > $out/$m.json 2> $out/$m.err; done
-for m in infer_mixing train_mixing; do python3 bench.py --mode $m --dtype bf16 --steps 30 --warmup 5 > $out/${m}_bf16.json 2> $out/${m}_bf16.err; done
-python3 bench.py --mode config1 > $out/config1.json 2> $out/config1.err
+python3 bench.py > $out/bench.json 2> $out/bench.err
+echo "[final_round] bench done"
+for m in train infer_mixing train_mixing; do python3 bench.py --mode $m --steps 30 --warmup 5 --cpu-budget 8 > $out/$m.json 2> $out/$m.err; done
+for m in infer_mixing train_mixing; do python3 bench.py --mode $m --dtype bf16 --steps 30 --warmup 5 --cpu-budget 8 > $out/${m}_bf16.json 2> $out/${m}_bf16.err; done
+echo "[final_round] mixing modes done"
+python3 bench.py --mode config1 --train > $out/config1.json 2> $out/config1.err
 python3 bench.py --mode a10 > $out/a10.json 2> $out/a10.err
+echo "[final_round] config1, a10 done"
 python3 bench.py --mode convlstm > $out/convlstm.json 2> $out/convlstm.err
+echo "[final_round] convlstm done"
 bash tools/pmc_run.sh $out bench -- --steps 20 --warmup 3 --no-cpu-baseline
+bash tools/pmc_sq.sh $out bench -- --steps 20 --warmup 3 --no-cpu-baseline
+echo "[final_round] headline PMC done"
 bash tools/prof_train_mixing.sh $out f32
 bash tools/prof_train_mixing.sh $out bf16
+# HBM-side bytes per step of the multi-launch modes (FETCH_SIZE / WRITE_SIZE in separate passes)
+root=$GRAFT_REPO_ROOT
+for spec in "train_mixing f32 adam_kernel" "train_mixing bf16 adam_kernel" "infer_mixing f32 mix_decoder" "infer_mixing bf16 mix_decoder" "train f32 adam_kernel"; do
+  set -- $spec
+  for ctr in FETCH_SIZE WRITE_SIZE SQ_VALU_MFMA_BUSY_CYCLES; do
+    (cd /tmp && export TMPDIR=/tmp && rocprofv3 --pmc $ctr --output-format csv -d $root/$out/pmcstep_$1_$2_$ctr -o p -- python3 $root/bench.py --mode $1 --dtype $2 --steps 12 --warmup 3 --no-cpu-baseline > /dev/null 2>> $root/$out/pmcstep.err)
+    python3 tools/pmc_step_total.py $out/pmcstep_$1_$2_$ctr $3 fov >> $out/pmcstep_$1_$2.txt
+    rm -rf $out/pmcstep_$1_$2_$ctr
+  done
+  echo "[final_round] pmc $1 $2 done"
+done
 ls -la $out
