@@ -1,16 +1,22 @@
 #!/bin/bash
-# usage (GPU box, repo root): tools/final_round.sh <outdir>   - the measurements a round's profiles/ are refreshed from
-out=$1; mkdir -p $out
+# usage (GPU box, repo root): tools/final_round.sh <outdir> [bench|pmc|all]   - the measurements a round's profiles/ are
+# refreshed from; the two halves fit one 20-minute gpurun call each
+out=$1; part=${2:-all}; mkdir -p $out
+# progress goes to $out/progress.log (gpurun takes a command that writes nothing for 7 minutes to be hung)
+exec >> $out/progress.log 2>&1
+if [ $part != pmc ]; then
 python3 bench.py > $out/bench.json 2> $out/bench.err
 echo "[final_round] bench done"
-for m in train infer_mixing train_mixing; do python3 bench.py --mode $m --steps 30 --warmup 5 --cpu-budget 8 > $out/$m.json 2> $out/$m.err; done
-for m in infer_mixing train_mixing; do python3 bench.py --mode $m --dtype bf16 --steps 30 --warmup 5 --cpu-budget 8 > $out/${m}_bf16.json 2> $out/${m}_bf16.err; done
+for m in train infer_mixing train_mixing; do python3 bench.py --mode $m --steps 200 --warmup 10 --cpu-budget 8 > $out/$m.json 2> $out/$m.err; done
+for m in infer_mixing train_mixing; do python3 bench.py --mode $m --dtype bf16 --steps 200 --warmup 10 --cpu-budget 8 > $out/${m}_bf16.json 2> $out/${m}_bf16.err; done
 echo "[final_round] mixing modes done"
 python3 bench.py --mode config1 --train > $out/config1.json 2> $out/config1.err
 python3 bench.py --mode a10 > $out/a10.json 2> $out/a10.err
 echo "[final_round] config1, a10 done"
 python3 bench.py --mode convlstm > $out/convlstm.json 2> $out/convlstm.err
 echo "[final_round] convlstm done"
+fi
+if [ $part != bench ]; then
 bash tools/pmc_run.sh $out bench -- --steps 20 --warmup 3 --no-cpu-baseline
 bash tools/pmc_sq.sh $out bench -- --steps 20 --warmup 3 --no-cpu-baseline
 echo "[final_round] headline PMC done"
@@ -27,4 +33,5 @@ for spec in "train_mixing f32 adam_kernel" "train_mixing bf16 adam_kernel" "infe
   done
   echo "[final_round] pmc $1 $2 done"
 done
+fi
 ls -la $out
