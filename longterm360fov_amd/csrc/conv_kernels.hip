@@ -376,6 +376,9 @@ int convlstm_cell_fwd(const float* x, long ldx, long ldb, int C, const float* h_
         set_error("convlstm_cell: operand larger than 2 GiB");
         return FOV_ERR_UNSUPPORTED;
     }
+    // the LDS-resident-patch form (convlstm_patch.hip): every tap reads the same staged patch, no barrier in the k loop
+    if (cell_patch_shape_ok(x, ldx, ldb, C, h_prev, ldx2, ldb2, F, H, W, kh, kw))
+        return launch_cell_patch(x, ldx, ldb, C, h_prev, ldx2, ldb2, w, bias, c_prev, c_new, h, ldh, gates, B, H, W, F, kh, kw, act, stream);
     const bool avec = (C & 3) == 0 && (ldx & 3) == 0 && (ldb & 3) == 0 && (((uintptr_t)x) & 15) == 0 &&
                       (!h_prev || ((F & 3) == 0 && (ldx2 & 3) == 0 && (ldb2 & 3) == 0 && (((uintptr_t)h_prev) & 15) == 0));
     const bool bvec = (F & 3) == 0 && (((uintptr_t)w) & 15) == 0;

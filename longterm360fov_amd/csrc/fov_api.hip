@@ -363,6 +363,7 @@ void env_reload() {
     g_env.two_launches = getenv("FOV_TWO_LAUNCHES") ? 1 : 0;
     const char* lim = getenv("FOV_DBG_RESIDENT_LIMIT");
     g_env.resident_limit = lim ? atoi(lim) : 0;
+    g_env.no_cell_patch = env_flag("FOV_NO_CELL_PATCH");
 }
 const EnvKnobs& env_knobs() {
     std::call_once(g_env_once, env_reload);

@@ -73,6 +73,7 @@ int device_cu_count();                               // CUs of the current devic
 // getenv results cached at first use (fov_reload_env re-reads them): nothing on a launch path calls getenv
 struct EnvKnobs {
     int force_safe_exchange, pair_kernel, two_launches, resident_limit;
+    int no_cell_patch;   // FOV_NO_CELL_PATCH=1: ConvLSTM2D steps stay on the implicit-GEMM cell (tests compare the two forms)
 };
 const EnvKnobs& env_knobs();
 void env_reload();
@@ -107,6 +108,12 @@ int conv2d_fwd2(const float* x, long ldx, long ldb, int C, const float* x2, long
                 const float* bias, const float* add, float* y, int B, int H, int W, int N, int kh, int kw, int act,
                 hipStream_t stream);
 int convlstm_gates(const float* z, float* c, float* h, long ldh, long rows, int F, int act, hipStream_t stream);
+// LDS-resident-patch form of the ConvLSTM2D step (convlstm_patch.hip); convlstm_cell_fwd takes it when the shape allows
+bool cell_patch_shape_ok(const float* x, long ldx, long ldb, int C, const float* h_prev, long ldx2, long ldb2, int F, int H, int W,
+                         int kh, int kw);
+int launch_cell_patch(const float* x, long ldx, long ldb, int C, const float* h_prev, long ldx2, long ldb2, const float* w,
+                      const float* bias, const float* c_prev, float* c_new, float* h, long ldh, float* gates, int B, int H, int W,
+                      int F, int kh, int kw, int act, hipStream_t stream);
 int convlstm_cell_fwd(const float* x, long ldx, long ldb, int C, const float* h_prev, long ldx2, long ldb2, const float* w,
                       const float* bias, const float* c_prev, float* c_new, float* h, long ldh, float* gates, int B, int H, int W,
                       int F, int kh, int kw, int act, hipStream_t stream);

@@ -42,7 +42,7 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
-_ENV_KNOBS = ("FOV_FORCE_SAFE_EXCHANGE", "FOV_PAIR", "FOV_TWO_LAUNCHES", "FOV_DBG_RESIDENT_LIMIT")
+_ENV_KNOBS = ("FOV_FORCE_SAFE_EXCHANGE", "FOV_PAIR", "FOV_TWO_LAUNCHES", "FOV_DBG_RESIDENT_LIMIT", "FOV_NO_CELL_PATCH")
 _env_seen = None
 
 
@@ -740,6 +740,7 @@ def convlstm_cell(x, h_prev, w, b, c_prev, h_out, act="hard_sigmoid", c_new=None
     if gates is not None:
         gates = _dev(gates, "gates")
         assert gates.shape == (B, H, W, N)
+    _sync_env()
     check(_lib.lib().fov_convlstm_cell_fwd(x.data_ptr(), ldx, ldb, C, h_prev.data_ptr() if h_prev is not None else None, ldx2, ldb2,
                                            _ptr(w), _ptr(_dev(b, "b")), _ptr(c_prev), _ptr(c_new), h_out.data_ptr(),
                                            h_out.stride(-2), _ptr(gates), B, H, W, F, kh, kw, act_code(act), _stream()))

@@ -1,5 +1,7 @@
 """GPU parity of the ConvLSTM2D path (a8/a9, mycode/convlstm_seq2seq.py) against the NumPy oracle:
 implicit-GEMM conv2d, ConvLSTM2D cell, channel softmax and the 3+3-layer seq2seq with both heads."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -409,6 +411,59 @@ def test_convlstm_cell_one_launch(B, H, W, C, F, k, act):
     _, c4 = ops.convlstm_cell(xd, None, dev(K), dev(b), None, h4, act)
     close(h4, h0_ref, "cell h, zero state")
     close(c4, c0_ref, "cell c, zero state")
+
+
+@pytest.mark.parametrize("act", ["hard_sigmoid", "sigmoid"])
+@pytest.mark.parametrize("B,H,W,C,F,k,state", [(3, 36, 18, 32, 32, 5, True), (2, 20, 18, 32, 32, 5, False), (2, 36, 18, 16, 32, 5, True),
+                                               (2, 7, 9, 12, 16, 3, True), (1, 36, 18, 16, 8, 5, True), (2, 5, 112, 8, 8, 3, True),
+                                               (2, 3, 40, 4, 16, 5, False), (1, 36, 18, 32, 16, 5, True)])
+def test_convlstm_cell_patch_form(B, H, W, C, F, k, state, act):
+    """The LDS-resident-patch form of the ConvLSTM2D step (convlstm_patch.hip: the halo patch of [x | h_prev] staged once, every
+    tap the same patch at a shifted address, weights straight from L2, no barrier in the k loop) for the widths the model
+    ships (convlstm_seq2seq.py: filters 32 / 16 / 8): against the fp64 oracle and against the implicit-GEMM cell
+    (FOV_NO_CELL_PATCH=1).  Covers a partial last row group (H = 20: 6 + 6 + 6 + 2 rows), channel counts that are not a
+    multiple of 16 (short last block, zero-padded in LDS), a map as wide as the block allows, the zero initial state, the
+    gates tape and channel-slice views.  With C a multiple of 16 the two forms add in the same order: bit-identical."""
+    from longterm360fov_amd import ops
+    rng = np.random.default_rng(C * 11 + F + H)
+    K = (rng.standard_normal((k, k, C, 4 * F)) / np.sqrt(k * k * C)).astype(np.float32)
+    R = (rng.standard_normal((k, k, F, 4 * F)) / np.sqrt(k * k * F)).astype(np.float32)
+    b = rng.standard_normal(4 * F).astype(np.float32)
+    xs = rng.standard_normal((B, 2, H, W, C)).astype(np.float32)
+    hw = (0.5 * rng.standard_normal((B, H, W, F + 8))).astype(np.float32)
+    c = (0.5 * rng.standard_normal((B, H, W, F))).astype(np.float32)
+    x, h = xs[:, 1], hw[..., 4:4 + F]
+    d = lambda a: a.astype(np.float64)
+    if state:
+        h_ref, c_ref = O.convlstm2d_step(d(x), d(h), d(c), d(K), d(R), d(b), act)
+        w = torch.cat([dev(K), dev(R)], 2).contiguous()
+    else:
+        h_ref, c_ref = O.convlstm2d_step(d(x), np.zeros_like(d(h)), np.zeros_like(d(c)), d(K), d(R), d(b), act)
+        w = dev(K)
+    xd, hd = dev(xs)[:, 1], (dev(hw)[..., 4:4 + F] if state else None)
+
+    def run():
+        wide = torch.zeros((B, H, W, F + 5), dtype=torch.float32, device="cuda")
+        gates = torch.empty((B, H, W, 4 * F), dtype=torch.float32, device="cuda")
+        c_new = torch.empty((B, H, W, F), dtype=torch.float32, device="cuda")
+        ops.convlstm_cell(xd, hd, w, dev(b), dev(c) if state else None, wide[..., 3:3 + F], act, c_new=c_new, gates=gates)
+        return wide, c_new, gates
+    wide, c_new, gates = run()
+    close(wide[..., 3:3 + F], h_ref, "patch cell h")
+    close(c_new, c_ref, "patch cell c")
+    assert float(wide[..., :3].abs().max()) == 0 and float(wide[..., 3 + F:].abs().max()) == 0
+    os.environ["FOV_NO_CELL_PATCH"] = "1"
+    try:
+        wide2, c2, g2 = run()
+    finally:
+        del os.environ["FOV_NO_CELL_PATCH"]
+    if C % 16 == 0:
+        assert torch.equal(wide2, wide) and torch.equal(c2, c_new) and torch.equal(g2, gates)
+    else:
+        assert (wide2 - wide).abs().max().item() <= 2e-6 and (c2 - c_new).abs().max().item() <= 2e-6
+        assert (g2 - gates).abs().max().item() <= 2e-6
+    wide3, c3, g3 = run()                                         # back on the patch form, deterministic
+    assert torch.equal(wide3, wide) and torch.equal(c3, c_new) and torch.equal(g3, gates)
 
 
 def test_config4_full_size_and_properties():
