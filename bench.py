@@ -34,22 +34,29 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 matrix peak (s
 def peak_for(dtype):
     return PEAK_BF16_MFMA_TFLOPS if dtype == "bf16" else PEAK_FP32_MFMA_TFLOPS
 # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/pmc_run.sh) of `bench.py --steps 20 --warmup 3`, mean per
-# dispatch of lstm_cluster_fused_kernel (encoder + decoder in one launch): 17540 + 5606 KiB (raw counter values; the
+# dispatch of lstm_cluster_fused_kernel (encoder + decoder in one launch): 17550 + 5548 KiB (raw counter values; the
 # kernel's global traffic is 4- and 8-byte accesses, for which MI355X_MICROARCH.md gives no correction factor).  The
 # two-launch form moved 13170 + 6160 and 7458 + 4832 KiB.
 PMC_TRAFFIC_CONFIG = (1024, 30, 30, 256, "sigmoid", "auto")
-PMC_TRAFFIC_BYTES = (17540 + 5606) * 1024
-PMC_TRAFFIC_SOURCE = "profiles/r02_pmc_bench_v4.txt"
+PMC_TRAFFIC_BYTES = (17550 + 5548) * 1024
+PMC_TRAFFIC_SOURCE = "profiles/r03_pmc_bench.txt"
 
 
-# HBM-side bytes per step of the secondary modes, from the same kind of rocprofv3 --pmc passes (tools/pmc_any.sh: FETCH_SIZE and
-# WRITE_SIZE in separate passes, raw KiB summed over the step's dispatches); None until a profile of the current build is
-# committed.  key = (mode, dtype)
-MODE_TRAFFIC = {}
+# HBM-side bytes per step of the secondary modes, from the same kind of rocprofv3 --pmc passes (tools/final_round.sh +
+# tools/pmc_step_total.py: FETCH_SIZE and WRITE_SIZE in separate passes, raw KiB summed over the dispatches of one step -
+# the dispatches between two launches of an anchor kernel); quoted only for the default shape of the mode.  key = (mode, dtype)
+MODE_TRAFFIC = {
+    ("train_mixing", "f32"): ((506126 + 877339) * 1024, "profiles/r03_pmcstep_train_mixing_f32.txt"),
+    ("train_mixing", "bf16"): ((295134 + 443558) * 1024, "profiles/r03_pmcstep_train_mixing_bf16.txt"),
+    # the fp32 file's anchor matched two kernels per call (pack + decoder): its per-"step" means are half calls
+    ("infer_mixing", "f32"): (int(2 * (18992.8 + 8848.19) * 1024), "profiles/r03_pmcstep_infer_mixing_f32.txt (x2: the anchor matched twice per call)"),
+    ("infer_mixing", "bf16"): (int((35218.1 + 11552.4) * 1024), "profiles/r03_pmcstep_infer_mixing_bf16.txt"),
+    ("train", "f32"): ((632320 + 1226270) * 1024, "profiles/r03_pmcstep_train_f32.txt"),
+}
 
 
-def mode_traffic(mode, dtype, ms):
-    t = MODE_TRAFFIC.get((mode, dtype))
+def mode_traffic(mode, dtype, ms, profiled_shape=True):
+    t = MODE_TRAFFIC.get((mode, dtype)) if profiled_shape else None
     if not t:
         return {"traffic": None}
     return {"traffic": t[0], "traffic_source": t[1], "hbm_gbps": t[0] / (ms * 1e-3) / 1e9, "hbm_peak_gbps": 8000.0,
@@ -154,7 +161,7 @@ def bench_train(args, rank, world, use_dist):
                        "global_batch": B * world, "parallelism": "dp%d, one flat-buffer all-reduce per step" % world},
             "roofline": {"bound": "mfma", "achieved": flop_step / (ms * 1e-3) / 1e12, "peak": PEAK_FP32_MFMA_TFLOPS,
                          "unit": "TFLOP/s", "frac": flop_step / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
-                         "note": "whole step, 3x forward FLOPs", **mode_traffic("train", "f32", ms)},
+                         "note": "whole step, 3x forward FLOPs", **mode_traffic("train", "f32", ms, (B, T_in, T_out, H) == (1024, 30, 30, 256))},
             "cpu_baseline": cpu}), flush=True)
     if use_dist:
         dist.barrier()
@@ -222,7 +229,7 @@ def bench_train_mixing(args, rank, world, use_dist):
                          "unit": "TFLOP/s", "frac": 3 * fwd * B / (ms * 1e-3) / 1e12 / peak_for(args.dtype),
                          "note": "whole step, 3x forward FLOPs; at 512 sequences per GPU the step is a chain of 40 dependent recurrent "
                                  "steps per direction: bound by the per-step exchange latency, not by the matrix rate",
-                         **mode_traffic("train_mixing", args.dtype, ms)},
+                         **mode_traffic("train_mixing", args.dtype, ms, (B, H) == (512, 256))},
             "cpu_baseline": cpu}), flush=True)
     if use_dist:
         dist.barrier()
@@ -291,7 +298,7 @@ def bench_infer_mixing(args, rank, world, use_dist):
                        "parallelism": "replicas x%d (no collective)" % world},
             "roofline": {"bound": "mfma", "achieved": fwd * B / (ms * 1e-3) / 1e12, "peak": peak_for(args.dtype),
                          "unit": "TFLOP/s", "frac": fwd * B / (ms * 1e-3) / 1e12 / peak_for(args.dtype),
-                         **mode_traffic("infer_mixing", args.dtype, ms)},
+                         **mode_traffic("infer_mixing", args.dtype, ms, (B, H) == (512, 256))},
             "parity": {"max_abs_err_vs_oracle": err, "max_abs_err_vs_bf16_operand_oracle": err_q, "sequences_checked": 32},
             "cpu_baseline": cpu}), flush=True)
     if use_dist:

@@ -24,7 +24,7 @@ bash tools/prof_train_mixing.sh $out f32
 bash tools/prof_train_mixing.sh $out bf16
 # HBM-side bytes per step of the multi-launch modes (FETCH_SIZE / WRITE_SIZE in separate passes)
 root=$GRAFT_REPO_ROOT
-for spec in "train_mixing f32 adam_kernel" "train_mixing bf16 adam_kernel" "infer_mixing f32 mix_decoder" "infer_mixing bf16 mix_decoder" "train f32 adam_kernel"; do
+for spec in "train_mixing f32 adam_kernel" "train_mixing bf16 adam_kernel" "infer_mixing f32 mix_decoder_kernel" "infer_mixing bf16 mix_decoder_bf16_kernel" "train f32 adam_kernel"; do
   set -- $spec
   for ctr in FETCH_SIZE WRITE_SIZE SQ_VALU_MFMA_BUSY_CYCLES; do
     (cd /tmp && export TMPDIR=/tmp && rocprofv3 --pmc $ctr --output-format csv -d $root/$out/pmcstep_$1_$2_$ctr -o p -- python3 $root/bench.py --mode $1 --dtype $2 --steps 12 --warmup 3 --no-cpu-baseline > /dev/null 2>> $root/$out/pmcstep.err)
