@@ -364,6 +364,17 @@ void env_reload() {
     const char* lim = getenv("FOV_DBG_RESIDENT_LIMIT");
     g_env.resident_limit = lim ? atoi(lim) : 0;
     g_env.no_cell_patch = env_flag("FOV_NO_CELL_PATCH");
+    g_env.bwd_stepped = getenv("FOV_BWD_STEPPED") ? 1 : 0;
+    g_env.no_wgrad_fusion = getenv("FOV_NO_WGRAD_FUSION") ? 1 : 0;
+    g_env.no_dx_fusion = getenv("FOV_NO_DX_FUSION") ? 1 : 0;
+    g_env.bwd_groups4 = getenv("FOV_BWD_GROUPS4") ? 1 : 0;
+    g_env.gemm_bf16_noremap = getenv("FOV_GEMM_BF16_NOREMAP") ? 1 : 0;
+    const char* gb = getenv("FOV_GEMM_BF16_SPLIT");
+    g_env.gemm_bf16_split = gb ? atoi(gb) : 0;
+    const char* gv = getenv("FOV_GEMM_VARIANT");
+    g_env.gemm_variant = gv ? atoi(gv) : 0;
+    const char* gs = getenv("FOV_GEMM_SPLIT");
+    g_env.gemm_split = gs ? atoi(gs) : 0;
 }
 const EnvKnobs& env_knobs() {
     std::call_once(g_env_once, env_reload);

@@ -317,7 +317,7 @@ int gemm_bf16_tn_fused(const float* a1, long lda1, long a1_so, int M1, int shift
     const long max_by_rows = rows / (8 * GKB);
     if (split > max_by_rows) split = (int)max_by_rows;
     if (split > 32) split = 32;
-    if (const char* e = getenv("FOV_GEMM_BF16_SPLIT")) { const int v = atoi(e); if (v >= 1 && v <= max_by_rows) split = v; }   // tuning knob
+    if (const int v = env_knobs().gemm_bf16_split) { if (v >= 1 && v <= max_by_rows) split = v; }   // tuning knob, FOV_GEMM_BF16_SPLIT
     while (split > 1 && (size_t)split * (M + g.bias_row) * N > scratch_floats) --split;
     if (split < 1) split = 1;
     long rps = (rows + split - 1) / split;
@@ -330,7 +330,7 @@ int gemm_bf16_tn_fused(const float* a1, long lda1, long a1_so, int M1, int shift
     if (split > 1 && ldc != N) { set_error("gemm_bf16_tn: split products need a dense C"); return FOV_ERR_INVALID; }
     g.grid_n = (N + GT - 1) / GT;
     g.grid_m = (M + GT - 1) / GT;
-    g.xcd_remap = (split >= 8 && !getenv("FOV_GEMM_BF16_NOREMAP")) ? 1 : 0;
+    g.xcd_remap = (split >= 8 && !env_knobs().gemm_bf16_noremap) ? 1 : 0;
     const dim3 grid = g.xcd_remap ? dim3((unsigned)(8 * ((split + 7) / 8) * g.grid_n * g.grid_m)) : dim3(g.grid_n, g.grid_m, split);
     const bool avec = (lda1 & 3) == 0 && (a1_so & 3) == 0 && (((uintptr_t)a1) & 15) == 0 && (M1 & 3) == 0 &&
                       (!a2 || ((lda2 & 3) == 0 && (a2_so & 3) == 0 && (((uintptr_t)a2) & 15) == 0 && (M2 & 3) == 0));

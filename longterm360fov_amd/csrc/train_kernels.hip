@@ -697,8 +697,7 @@ int gemm_f32(GemmArgs g, int accumulate, float* scratch, size_t scratch_floats, 
     // mid-size outputs (e.g. 512 x 1024 of a per-step projection): 128 x 128 tiles would occupy a fraction of
     // the 256 CUs and K is too short to split -> 64 x 64 tiles
     if (variant == 2 && ((g.M + 127) / 128) * ((g.N + 127) / 128) < 128 && K <= 2048) { BM = 64; BN = 64; variant = 3; }
-    if (const char* e = getenv("FOV_GEMM_VARIANT")) {   // tuning knob (experiments)
-        const int v = atoi(e);
+    if (const int v = env_knobs().gemm_variant) {   // tuning knob (experiments), FOV_GEMM_VARIANT
         if (v == 2) { BM = 128; BN = 128; variant = 2; }
         if (v == 3) { BM = 64; BN = 64; variant = 3; }
         if (v == 4) { BM = 64; BN = 128; variant = 4; }
@@ -725,8 +724,18 @@ int gemm_f32(GemmArgs g, int accumulate, float* scratch, size_t scratch_floats, 
         if (split > maxs) split = (int)maxs;
         if (split > 64) split = 64;
         if (split < 1) split = 1;
+    } else if (tiles < 128 && ktiles >= 8) {
+        // SHORT K on a few tiles (model.fit at the reference's batch of 32: B*T = 320 rows -> 20 k-tiles, dK of a layer is
+        // two 96 x 256 tiles): a block's time is its k-tiles x ~2.2 us of unhidden global -> LDS -> barrier latency, so two
+        // blocks took 46 us for 30 MFLOP.  Slices of >= 2 k-tiles up to about one block per CU; the reduce launch (4.5 us)
+        // is paid back from 4 k-tiles per block on.
+        split = (256 + tiles - 1) / tiles;
+        const long maxs = ktiles / 2;
+        if (split > maxs) split = (int)maxs;
+        if (split > 64) split = 64;
+        if (split < 1) split = 1;
     }
-    if (const char* e = getenv("FOV_GEMM_SPLIT")) { const int v = atoi(e); if (v >= 1 && v <= ktiles) split = v; }   // tuning knob
+    if (const int v = env_knobs().gemm_split) { if (v >= 1 && v <= ktiles) split = v; }   // tuning knob, FOV_GEMM_SPLIT
     while (split > 1 && (size_t)split * mn > scratch_floats) --split;
     const long tps = (ktiles + split - 1) / split;
     split = (int)((ktiles + tps - 1) / tps);
@@ -1220,7 +1229,7 @@ int lstm_seq_bwd(const float* x, const float* K, const float* R, const float* h0
         if (dc0) (void)(dcT ? hipMemcpyAsync(dc0, dcT, bh0, hipMemcpyDeviceToDevice, stream) : hipMemsetAsync(dc0, 0, bh0, stream));
         return FOV_OK;
     }
-    const bool persistent = bwd_cluster_shape_ok(H) && !getenv("FOV_BWD_STEPPED");
+    const bool persistent = bwd_cluster_shape_ok(H) && !env_knobs().bwd_stepped;
     bool fuse_kr = false, fuse_r = false, dx_in_kernel = false;
     const size_t head = (kStatusBytes + kXchBytes) / sizeof(float);
     float* dh_rec = ws + head;
@@ -1238,15 +1247,15 @@ int lstm_seq_bwd(const float* x, const float* K, const float* R, const float* h0
         // [h_{t-1} | 1]^T dz gives dR and db
         const int N4 = 4 * H;
         fuse_kr = dK && dR && db && T > 1 && dR == dK + (size_t)F * N4 && db == dR + (size_t)H * N4 &&
-                  wgrad_fusable(x, F, (long)T * F, F, hs, H, (long)T * H, H, dz, N4, (long)T * N4, dK, N4) && !getenv("FOV_NO_WGRAD_FUSION");
+                  wgrad_fusable(x, F, (long)T * F, F, hs, H, (long)T * H, H, dz, N4, (long)T * N4, dK, N4) && !env_knobs().no_wgrad_fusion;
         fuse_r = !fuse_kr && dR && db && T > 1 && db == dR + (size_t)H * N4 &&
-                 wgrad_fusable(hs, H, (long)T * H, H, nullptr, 0, 0, 0, dz, N4, (long)T * N4, dR, N4) && !getenv("FOV_NO_WGRAD_FUSION");
+                 wgrad_fusable(hs, H, (long)T * H, H, nullptr, 0, 0, 0, dz, N4, (long)T * N4, dR, N4) && !env_knobs().no_wgrad_fusion;
         float* db_part = (db && !fuse_kr && !fuse_r) ? scratch : nullptr;
         // bf16, 256-wide input (the stacked layer): the BPTT kernel forms dx = dz K^T from the dz tile it has gathered anyway
-        dx_in_kernel = bf16 && dx && F == 256 && (((uintptr_t)K) & 15) == 0 && !getenv("FOV_NO_DX_FUSION");
+        dx_in_kernel = bf16 && dx && F == 256 && (((uintptr_t)K) & 15) == 0 && !env_knobs().no_dx_fusion;
         // H = 256: groups of eight workgroups fill the chip up to 32 tiles (the 4-group kernel leaves half of it idle
         // at 512 sequences); bf16 operands exist in the 8-group kernel only
-        int rc = (bf16 || (bwd8_preferred(B, H) && !getenv("FOV_BWD_GROUPS4")))
+        int rc = (bf16 || (bwd8_preferred(B, H) && !env_knobs().bwd_groups4))
                      ? launch_bwd8(R, reserve, c0, dhs, dhT, dcT, dz, dh0 ? dh0 : dh_rec, dc0 ? dc0 : dc, db_part, B, T, act, bf16, ws, stream,
                                    dx_in_kernel ? K : nullptr, dx_in_kernel ? dx : nullptr)
                      : launch_bwd_cluster(R, reserve, c0, dhs, dhT, dcT, dz, dh0 ? dh0 : dh_rec, dc0 ? dc0 : dc, db_part, B, T, H,

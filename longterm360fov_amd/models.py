@@ -119,14 +119,18 @@ def _keras_fit(model, trainer, inputs, y, batch_size, epochs, validation_split, 
             # every rank must slice the SAME permutation: rank 0's is broadcast (the ranks' np.random states are
             # not synchronised), then each takes its contiguous shard of every global batch
             idx = parallel.broadcast_index(idx)
-        tot, cnt = 0.0, 0
+        # the epoch's loss sum stays on the device (fp64): no host synchronisation per step, so the launches of step k + 1 are
+        # queued while step k runs (the returned loss tensor is overwritten by the NEXT step: the add is queued before it)
+        tot_t, cnt = torch.zeros(1, dtype=torch.float64, device=model.device), 0
+        step = trainer.train_step
         for lo in range(0, n_train, batch_size):
             gidx = idx[lo:lo + batch_size]
             a, b = parallel.shard_range(len(gidx), rank, world)
             lidx = gidx[a:b]
-            loss = trainer.train_step(*[d(arr[lidx]) for arr in inputs], d(tgt[lidx]), n_global=len(gidx))
-            tot += float(loss.item()) * len(gidx)
+            loss = step(*[d(arr[lidx]) for arr in inputs], d(tgt[lidx]), n_global=len(gidx))
+            tot_t.add_(loss.reshape(1).double(), alpha=float(len(gidx)))
             cnt += len(gidx)
+        tot = float(tot_t.item())
         logs = {"loss": tot / max(cnt, 1), "lr": trainer.lr}
         if val is not None and len(val[1]):
             vt, vc = 0.0, 0
@@ -965,12 +969,13 @@ class OthersMixingSeq2Seq(KerasModelSurface):
             cb.on_train_begin()
         self.stop_training = False
         for epoch in range(initial_epoch, epochs):
-            tot, cnt = 0.0, 0
+            tot_t, cnt = torch.zeros(1, dtype=torch.float64, device=self.device), 0   # no host synchronisation per step (_keras_fit)
             for _ in range(steps_per_epoch):
                 xb, yb = next(generator)
                 loss = tr.train_step(*[d(a) for a in xb], d(yb))
-                tot += float(loss.item()) * len(yb)
+                tot_t.add_(loss.reshape(1).double(), alpha=float(len(yb)))
                 cnt += len(yb)
+            tot = float(tot_t.item())
             logs = {"loss": tot / max(cnt, 1), "lr": tr.lr}
             if validation_data is not None and validation_steps:
                 vt, vc = 0.0, 0
