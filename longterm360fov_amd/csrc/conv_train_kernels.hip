@@ -117,8 +117,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs g) {
     constexpr int RA = AVEC ? (BM * 4 + 255) / 256 : BM / 16;
     constexpr int RB = BVEC ? (BN * 4 + 255) / 256 : BN / 16;
     constexpr unsigned OOR = 0x80000000u;
-    __shared__ __attribute__((aligned(16))) float As[2][BK][BM + 16];
-    __shared__ __attribute__((aligned(16))) float Bs[2][BK][BN + 16];
+    // row strides and fragment reads as in gemm_f32_kernel (train_kernels.hip, OperandStage): MFMA tile i, row q of a wave is
+    // operand row 4*q + (i%4) of its group of four tiles (ds_read_b128 at [k][4*li]) or 2*q + (i%2) of a trailing pair
+    constexpr int LDA = BM + (MI % 4 == 0 ? 0 : 8), LDB = BN + (NI % 4 == 0 ? 0 : 8);
+    static_assert(MI % 2 == 0 && NI % 2 == 0, "tiles per wave: groups of four plus at most one pair");
+    __shared__ __attribute__((aligned(16))) float As[2][BK][LDA];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BK][LDB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ctile = blockIdx.y % g.ctiles, tap = blockIdx.y / g.ctiles;
     const int c0 = ctile * BM, n0 = blockIdx.x * BN;
@@ -223,15 +227,34 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs g) {
         }
     };
     float av[4][MI], bv[4][NI];
+    typedef float wf32x2 __attribute__((ext_vector_type(2)));
     auto read_frags = [&](int buf) {
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
+            const float* pa = &As[buf][ks * 4 + lq][wm];
+            const float* pb = &Bs[buf][ks * 4 + lq][wn];
 #pragma unroll
-            for (int i = 0; i < MI; ++i) av[ks][i] = As[buf][ks * 4 + lq][wm + i * 16 + li];
+            for (int q = 0; q < MI / 4; ++q) {
+                const f32x4 v = *(const f32x4*)(pa + 64 * q + 4 * li);
+                av[ks][4 * q] = v[0]; av[ks][4 * q + 1] = v[1]; av[ks][4 * q + 2] = v[2]; av[ks][4 * q + 3] = v[3];
+            }
+            if constexpr (MI % 4 == 2) {
+                const wf32x2 v = *(const wf32x2*)(pa + 64 * (MI / 4) + 2 * li);
+                av[ks][MI - 2] = v[0]; av[ks][MI - 1] = v[1];
+            }
 #pragma unroll
-            for (int j = 0; j < NI; ++j) bv[ks][j] = Bs[buf][ks * 4 + lq][wn + j * 16 + li];
+            for (int q = 0; q < NI / 4; ++q) {
+                const f32x4 v = *(const f32x4*)(pb + 64 * q + 4 * li);
+                bv[ks][4 * q] = v[0]; bv[ks][4 * q + 1] = v[1]; bv[ks][4 * q + 2] = v[2]; bv[ks][4 * q + 3] = v[3];
+            }
+            if constexpr (NI % 4 == 2) {
+                const wf32x2 v = *(const wf32x2*)(pb + 64 * (NI / 4) + 2 * li);
+                bv[ks][NI - 2] = v[0]; bv[ks][NI - 1] = v[1];
+            }
         }
     };
+    auto row_a = [&](int i, int q) { return i < 4 * (MI / 4) ? 64 * (i / 4) + 4 * q + (i & 3) : 64 * (MI / 4) + 2 * q + (i & 1); };
+    auto row_b = [&](int j, int q) { return j < 4 * (NI / 4) ? 64 * (j / 4) + 4 * q + (j & 3) : 64 * (NI / 4) + 2 * q + (j & 1); };
     auto mfmas = [&]() {
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
@@ -265,7 +288,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs g) {
         for (int j = 0; j < NI; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int c = c0 + wm + i * 16 + lq * 4 + r, n = n0 + wn + j * 16 + li;
+                const int c = c0 + wm + row_a(i, lq * 4 + r), n = n0 + wn + row_b(j, li);
                 if (c < g.C && n < g.N) out[(size_t)c * g.N + n] = acc[i][j][r];
             }
 }
@@ -292,6 +315,7 @@ int conv2d_wgrad(const float* x, long ldx, const float* dz, float* dw, int B, in
     int BM, BN, variant;
     if (C <= 32) { BM = 32; BN = 256; variant = 0; }
     else if (C <= 96) { BM = 96; BN = 256; variant = 1; }
+    else if (N <= 32) { BM = 256; BN = 32; variant = 3; }   // skinny output (head 1024 -> 30): a 128-wide column tile was 77 % padding
     else { BM = 128; BN = 128; variant = 2; }
     WgradArgs g = {};
     g.x = x; g.dz = dz; g.H = H; g.W = W; g.C = C; g.N = N; g.kh = kh; g.kw = kw; g.P = P; g.ldx = ldx;
@@ -306,6 +330,12 @@ int conv2d_wgrad(const float* x, long ldx, const float* dz, float* dw, int B, in
         if (split > maxs) split = (int)maxs;
         if (split > 64) split = 64;
         if (split < 1) split = 1;
+    }
+    else if (tiles < 4096 && ktiles >= 4096) {
+        // a few hundred long blocks (head 512 -> 1024: 800 tiles of 103 680 k-tiles each) leave the chip a quarter empty
+        // in their last round (800 / 256 CUs = 3.1 rounds): slices until the block count is far above the CU count
+        split = (int)((4096 + tiles - 1) / tiles);
+        if (split > 16) split = 16;
     }
     while (split > 1 && (size_t)split * wn > scratch_floats) --split;
     const long tps = (ktiles + split - 1) / split;
@@ -327,6 +357,7 @@ int conv2d_wgrad(const float* x, long ldx, const float* dz, float* dw, int B, in
     } while (0)
     if (variant == 0) FOV_WGRAD_LAUNCH(2, 4, 1);
     else if (variant == 1) FOV_WGRAD_LAUNCH(6, 4, 1);
+    else if (variant == 3) FOV_WGRAD_LAUNCH(4, 2, 4);
     else FOV_WGRAD_LAUNCH(4, 4, 2);
 #undef FOV_WGRAD_LAUNCH
     int rc = ct_check_launch("conv_wgrad");

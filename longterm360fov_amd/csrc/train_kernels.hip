@@ -69,12 +69,21 @@ typedef unsigned gu32x4 __attribute__((ext_vector_type(4)));
 // The MFMA k-slot of lane group lq in step s is k = 4*lq + s (for A and B alike): an operand stored
 // [rows][k] gives a lane its four steps with ONE ds_read_b128, an operand stored [k][rows] reads rows
 // 4*lq + s (row stride = 4 mod 8 floats: the four lane groups land on disjoint banks).
-template <int ROWS, int MODE>
+// Fragments of a [k][rows] tile (round 3): a lane used to read its four k-steps of every 16-row MFMA tile with four
+// ds_read_b32 each - 32 LDS instructions per k-tile at 4 x 4 tiles per wave.  The MFMA row <-> operand row assignment is
+// free as long as the epilogue uses the same one, so: MFMA tile i, row q of a wave's NTW tiles is operand row
+// 64*(i/4) + 4*q + (i%4) for tiles in complete groups of four (one ds_read_b128 at [k][4*li] serves four tiles) and
+// 2*q + (i%2) for a trailing pair (ds_read_b64): 8 LDS instructions per k-tile, and a lane's four column tiles are four
+// CONSECUTIVE output columns (16-byte stores).  Row stride: a multiple of 16 floats keeps the b128 lane groups on distinct
+// 16-byte slots, == 8 (mod 16) the two halves of a b64 read on distinct banks.  Same products in the same order: results
+// are bit-identical to the old mapping.
+template <int ROWS, int MODE, int NTW>
 struct OperandStage {
+    static_assert(NTW % 2 == 0, "tiles per wave: complete groups of four plus at most one pair");
     static constexpr bool VEC = (MODE == 0 || MODE == 3);
     static constexpr bool TR = (MODE == 3);
-    static constexpr int LD = TR ? 24 : ROWS + 4;
-    static constexpr int LDS_FLOATS = TR ? ROWS * 24 : GBK * (ROWS + 4);   // one buffer
+    static constexpr int LD = TR ? 24 : ROWS + (NTW % 4 == 0 ? 0 : 8);
+    static constexpr int LDS_FLOATS = TR ? ROWS * 24 : GBK * LD;   // one buffer
     static constexpr int R = VEC ? (ROWS * 4 + 255) / 256 : ROWS / 16;     // loads per thread per k-tile
     static constexpr unsigned OOR = 0x80000000u;
     int kk[R], rr[R];
@@ -146,15 +155,31 @@ struct OperandStage {
             }
         }
     }
-    // fragment of the 16 rows starting at `row` for this lane: out[s] = element (row + li, k = 4*lq + s)
-    static __device__ __forceinline__ f32x4 frag(const float* lds, int row, int li, int lq) {
+    // operand row (relative to the wave's first row) that MFMA tile i, row q stands for
+    static __device__ __forceinline__ int row_of(int i, int q) {
+        if constexpr (TR) return 16 * i + q;
+        else return i < 4 * (NTW / 4) ? 64 * (i / 4) + 4 * q + (i & 3) : 64 * (NTW / 4) + 2 * q + (i & 1);
+    }
+    // fragments of the wave's NTW tiles (rows from `row0`) for this lane: out[i][s] = element (row_of(i, li), k = 4*lq + s)
+    static __device__ __forceinline__ void frags(const float* lds, int row0, int li, int lq, f32x4 (&out)[NTW]) {
         if constexpr (TR) {
-            return *(const f32x4*)(lds + (row + li) * LD + 4 * lq);
-        } else {
-            f32x4 v;
 #pragma unroll
-            for (int s_ = 0; s_ < 4; ++s_) v[s_] = lds[(4 * lq + s_) * LD + row + li];
-            return v;
+            for (int i = 0; i < NTW; ++i) out[i] = *(const f32x4*)(lds + (row0 + 16 * i + li) * LD + 4 * lq);
+        } else {
+#pragma unroll
+            for (int s_ = 0; s_ < 4; ++s_) {
+                const float* p = lds + (4 * lq + s_) * LD + row0;
+#pragma unroll
+                for (int g_ = 0; g_ < NTW / 4; ++g_) {
+                    const f32x4 v = *(const f32x4*)(p + 64 * g_ + 4 * li);
+                    out[4 * g_][s_] = v[0]; out[4 * g_ + 1][s_] = v[1]; out[4 * g_ + 2][s_] = v[2]; out[4 * g_ + 3][s_] = v[3];
+                }
+                if constexpr (NTW % 4 == 2) {
+                    typedef float f32x2_ __attribute__((ext_vector_type(2)));
+                    const f32x2_ v = *(const f32x2_*)(p + 64 * (NTW / 4) + 2 * li);
+                    out[NTW - 2][s_] = v[0]; out[NTW - 1][s_] = v[1];
+                }
+            }
         }
     }
 };
@@ -163,8 +188,8 @@ template <int MI, int NI, int WAVES_M, int AMODE, int BMODE>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
     constexpr int WAVES_N = 4 / WAVES_M;
     constexpr int BM = 16 * MI * WAVES_M, BN = 16 * NI * WAVES_N;
-    using StA = OperandStage<BM, AMODE>;
-    using StB = OperandStage<BN, BMODE>;
+    using StA = OperandStage<BM, AMODE, MI>;
+    using StB = OperandStage<BN, BMODE, NI>;
     __shared__ __attribute__((aligned(16))) float As[2][StA::LDS_FLOATS];
     __shared__ __attribute__((aligned(16))) float Bs[2][StB::LDS_FLOATS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -225,10 +250,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
     // loads early): the final iteration simply stages its own tile once more, unused.
     f32x4 af[MI], bf[NI];
     auto read_frags = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < MI; ++i) af[i] = StA::frag(As[buf], wm + i * 16, li, lq);
-#pragma unroll
-        for (int j = 0; j < NI; ++j) bf[j] = StB::frag(Bs[buf], wn + j * 16, li, lq);
+        StA::frags(As[buf], wm, li, lq, af);
+        StB::frags(Bs[buf], wn, li, lq, bf);
     };
     auto mfmas = [&]() {
 #pragma unroll
@@ -289,18 +312,33 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
             }
         }
     }
+    // k-slow B with four column tiles per wave: a lane's tiles j = 0..3 are four consecutive columns -> 16-byte stores
+    const bool vec_out = !StB::TR && NI == 4 && (g.ldc & 3) == 0 && (((uintptr_t)c) & 15) == 0;
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < NI; ++j)
+        for (int r = 0; r < 4; ++r) {
+            const int m = m0 + wm + StA::row_of(i, lq * 4 + r);
+            if (m >= g.M) continue;
+            if constexpr (!StB::TR && NI == 4) {
+                const int nb = n0 + wn + 4 * li;
+                if (vec_out && nb + 3 < g.N) {
+                    f32x4* cp = (f32x4*)(c + (size_t)m * g.ldc + nb);
+                    f32x4 v = {acc[i][0][r], acc[i][1][r], acc[i][2][r], acc[i][3][r]};
+                    if (g.add_c) v += *cp;
+                    *cp = v;
+                    continue;
+                }
+            }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int m = m0 + wm + i * 16 + lq * 4 + r, n = n0 + wn + j * 16 + li;
-                if (m < g.M && n < g.N) {
+            for (int j = 0; j < NI; ++j) {
+                const int n = n0 + wn + StB::row_of(j, li);
+                if (n < g.N) {
                     float* cp = c + (size_t)m * g.ldc + n;
                     *cp = g.add_c ? *cp + acc[i][j][r] : acc[i][j][r];
                 }
             }
+        }
 }
 
 // out[i] = (accumulate ? out[i] : 0) + sum_s part[s][i].  Block = 64 outputs x 4 slice groups: group q adds

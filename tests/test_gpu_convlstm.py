@@ -109,7 +109,7 @@ def _tconv(x, w):
 
 @pytest.mark.parametrize("B,H,W,C,N,kh,kw", [(2, 4, 5, 3, 7, 5, 5), (3, 36, 18, 30, 128, 5, 5), (2, 1, 30, 3, 128, 5, 5),
                                              (2, 1, 30, 56, 40, 1, 7), (1, 6, 7, 17, 33, 3, 3), (2, 9, 4, 8, 64, 5, 5),
-                                             (2, 6, 6, 128, 12, 3, 3), (1, 6, 6, 40, 260, 3, 3), (5, 3, 3, 4, 4, 5, 5)])
+                                             (2, 6, 6, 128, 12, 3, 3), (1, 6, 6, 40, 260, 3, 3), (5, 3, 3, 4, 4, 5, 5), (1, 36, 18, 260, 30, 5, 5)])
 def test_conv2d_backward_kernels(B, H, W, C, N, kh, kw):
     from longterm360fov_amd import ops
     rng = np.random.default_rng(B * 1000 + C * 10 + N)

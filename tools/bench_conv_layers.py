@@ -38,6 +38,32 @@ def main():
         ms = e0.elapsed_time(e1) / a.reps
         flop = 2.0 * 25 * (c1 + c2) * n * B * H * W
         out.append({"layer": name, "ms": round(ms, 4), "tflops": round(flop / ms / 1e9, 1)})
+    # the ConvLSTM2D step itself (convolution + gates + state update in one launch): LDS-patch form and implicit-GEMM form
+    for name, c1, F in (("cell0 [32|32] F=32", 32, 32), ("cell1 [32|16] F=16", 32, 16), ("cell2 [16|8] F=8", 16, 8)):
+        x = torch.rand((B, H, W, c1), device="cuda")
+        hp = torch.rand((B, H, W, F), device="cuda")
+        w = torch.rand((5, 5, c1 + F, 4 * F), device="cuda") * 0.01
+        b = torch.zeros(4 * F, device="cuda")
+        c = torch.zeros((B, H, W, F), device="cuda")
+        h = torch.empty((B, H, W, F), device="cuda")
+        for tag, env in (("patch", None), ("igemm", "1")):
+            if env:
+                os.environ["FOV_NO_CELL_PATCH"] = env
+            else:
+                os.environ.pop("FOV_NO_CELL_PATCH", None)
+            f = lambda: ops.convlstm_cell(x, hp, w, b, c, h, "hard_sigmoid")
+            f()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(a.reps):
+                f()
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / a.reps
+            flop = 2.0 * 25 * (c1 + F) * 4 * F * B * H * W
+            out.append({"layer": name + " " + tag, "ms": round(ms, 4), "tflops": round(flop / ms / 1e9, 1)})
+        os.environ.pop("FOV_NO_CELL_PATCH", None)
     print(json.dumps(out))
 
 
