@@ -757,10 +757,24 @@ int gemm_f32(GemmArgs g, int accumulate, float* scratch, size_t scratch_floats, 
     if (tiles < 512 && ktiles >= 32) {
         // fewer tiles than two per CU and a long K: slices.  (256 <= tiles < 512, e.g. the 5120 x 256 x 1024 data gradient of
         // the stacked layer on 64 x 64 tiles: four slices measured 55 -> 43 us)
-        split = ((tiles < 256 ? 512 : 1024) + tiles - 1) / tiles;
-        const long maxs = ktiles / 4;   // >= 4 k-tiles (64 k) per slice
-        if (split > maxs) split = (int)maxs;
-        if (split > 64) split = 64;
+        // The blocks of a launch are co-resident (2-3 per CU) and share the matrix pipe, so the launch takes
+        // ceil(blocks / CUs) block-times: 40 tiles x 13 slices = 520 blocks on 256 CUs cost THREE rounds for 2.03 rounds of
+        // work (the 513 x 1024 weight gradients of configs[2] ran at 58 % of peak).  Among the slice counts up to the
+        // old target (about 512 resp. 1024 blocks) take the one that fills its last round best; ties go to fewer slices.
+        const int cus = device_cu_count() > 0 ? device_cu_count() : 256;
+        const int want = ((tiles < 256 ? 512 : 1024) + tiles - 1) / tiles;
+        long maxs = ktiles / 4;   // >= 4 k-tiles (64 k) per slice
+        if (maxs > 64) maxs = 64;
+        if (maxs > want) maxs = want;
+        double best = -1.0;
+        for (int sct = 1; sct <= (int)maxs; ++sct) {
+            const long blocks = (long)tiles * sct;
+            const long rounds = (blocks + cus - 1) / cus;
+            double fill = (double)blocks / (double)(rounds * cus);
+            if (blocks < cus) fill *= 0.5;                       // less than one block per CU: only if nothing else is possible
+            else if (rounds == 1) fill *= 0.9;                   // one round: a second one overlaps latencies better
+            if (fill > best + 1e-9) { best = fill; split = sct; }
+        }
         if (split < 1) split = 1;
     } else if (tiles < 128 && ktiles >= 8) {
         // SHORT K on a few tiles (model.fit at the reference's batch of 32: B*T = 320 rows -> 20 k-tiles, dK of a layer is
