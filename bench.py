@@ -423,9 +423,11 @@ def bench_config1(args, rank, world, use_dist):
                     tr = m._get_trainer()
                     d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
                     batch = [d(enc), d(dec_in), d(tgt)]
-                    for _ in range(5):
+                    for _ in range(20):
                         tr.train_step(*batch)
-                    tms = event_time_ms(lambda: tr.train_step(*batch), 100)
+                    # best of three 100-step regions: at 0.25 ms per step the host is close behind the GPU, and the CPU legs of
+                    # this mode leave worker threads spinning for a while (single regions read 0.26 ... 1.2 ms on one box)
+                    tms = min(event_time_ms(lambda: tr.train_step(*batch), 100) for _ in range(3))
                     tr.check()
                     training["h%d_%s" % (Ht, impl)] = {"ms_per_step": tms, "sequences_per_s": B / (tms * 1e-3),
                                                        "run_width": getattr(tr, "Hp", Ht)}
