@@ -64,7 +64,12 @@ __global__ __launch_bounds__(256) void conv2d_igemm_kernel(ConvArgs g) {
     static_assert(CELL == 0 || NI == 4 || (NI == 2 && WAVES_M == 4), "cell epilogue: four column tiles per lane, or the 32-column form");
     constexpr int WAVES_N = 4 / WAVES_M;
     constexpr int BM = 16 * MI * WAVES_M, BN = 16 * NI * WAVES_N, BK = 16;
-    constexpr int LDA = 24, LDB = BN + 4;
+    // B fragments (plain convolution with four column tiles per wave): column tile j, lane li stands for GEMM column
+    // wn + 4*li + j, so one ds_read_b128 at [k][wn + 4*li] serves all column tiles of a k-step and a lane's outputs are four
+    // consecutive channels (the row permutation of gemm_f32_kernel, train_kernels.hip).  The CELL forms keep
+    // the 16*j + li map their gate permutation is written for.
+    constexpr bool BPERM = CELL == 0 && NI == 4;   // (NI == 2 measured slower with the pair form: 54 -> 46 TFLOP/s at N = 32)
+    constexpr int LDA = 24, LDB = BPERM ? BN : BN + 4;
     constexpr int RA = AVEC ? BM / 64 : BM / 16;                 // loads per thread per tile (A)
     constexpr int RB = BVEC ? (BN * 4 + 255) / 256 : BN / 16;    // loads per thread per tile (B)
     constexpr unsigned OOR = 0x80000000u;
@@ -136,17 +141,29 @@ __global__ __launch_bounds__(256) void conv2d_igemm_kernel(ConvArgs g) {
     int f_left = ntiles;                // tiles not fetched yet
     float ra[AVEC ? 1 : RA], rb[BVEC ? 1 : RB];
     f32x4 va[AVEC ? RA : 1], vb[BVEC ? RB : 1];
+    // Whether a pixel's shifted source lies inside the image depends on the TAP only: evaluated when the tap changes (a
+    // wave-uniform branch around VALU work, no load inside), not for every 16-channel tile of it - at 512 input channels
+    // that is 1 tile in 32 (fp32 MFMA shares the VALU port: the 16 compares / selects per tile came out of the MFMA rate).
+    bool a_in[RA];
+#pragma unroll
+    for (int r = 0; r < RA; ++r) a_in[r] = false;
     auto fetch = [&]() {
         const bool seg2 = f_ct >= ctiles1;   // wave-uniform: which input segment this tile reads
         const int c0 = (seg2 ? f_ct - ctiles1 : f_ct) * BK;
         const int sy = f_dy - ph, sx = f_dx - pw;
+        if (f_ct == 0) {
+#pragma unroll
+            for (int r = 0; r < RA; ++r) {
+                const int yy = a_y[r] + sy, xx = a_x[r] + sx;
+                a_in[r] = yy >= 0 && yy < g.H && xx >= 0 && xx < g.W;
+            }
+        }
         const float* xt = (seg2 ? g.x2 + ((long)sy * g.W + sx) * g.ldx2 : g.x + ((long)sy * g.W + sx) * g.ldx) + c0;
         const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xt), 0, 0x7fffffff, 0x00020000);
         const int crem = (seg2 ? g.C2 : g.C) - c0;   // channels left in this segment of the tap
 #pragma unroll
         for (int r = 0; r < RA; ++r) {
-            const int yy = a_y[r] + sy, xx = a_x[r] + sx;
-            const bool ok = yy >= 0 && yy < g.H && xx >= 0 && xx < g.W && a_kc[r] < crem;
+            const bool ok = a_in[r] && a_kc[r] < crem;
             const unsigned off = ok ? (seg2 ? a_pix2[r] : a_pix[r]) : OOR;
             if constexpr (AVEC) {
                 const cu32x4 t = __builtin_amdgcn_raw_buffer_load_b128(xrs, off, 0, 0);
@@ -196,9 +213,15 @@ __global__ __launch_bounds__(256) void conv2d_igemm_kernel(ConvArgs g) {
 #pragma unroll
         for (int i = 0; i < MI; ++i) af[i] = *(const f32x4*)&As[buf][wm + i * 16 + li][4 * lq];
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
+        for (int s = 0; s < 4; ++s) {
+            if constexpr (BPERM && NI == 4) {
+                const f32x4 v = *(const f32x4*)&Bs[buf][4 * lq + s][wn + 4 * li];
+                bv[s][0] = v[0]; bv[s][1] = v[1]; bv[s][2] = v[2]; bv[s][3] = v[3];
+            } else {
 #pragma unroll
-            for (int j = 0; j < NI; ++j) bv[s][j] = Bs[buf][4 * lq + s][wn + j * 16 + li];
+                for (int j = 0; j < NI; ++j) bv[s][j] = Bs[buf][4 * lq + s][wn + j * 16 + li];
+            }
+        }
     };
     auto mfmas = [&]() {
 #pragma unroll
@@ -262,15 +285,29 @@ __global__ __launch_bounds__(256) void conv2d_igemm_kernel(ConvArgs g) {
             }
         return;
     }
+    const bool vec_out = NI == 4 && (g.N & 3) == 0 && (((uintptr_t)g.y) & 15) == 0 && (!g.add || (((uintptr_t)g.add) & 15) == 0) &&
+                         (!g.bias || (((uintptr_t)g.bias) & 15) == 0);
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < NI; ++j)
+        for (int r = 0; r < 4; ++r) {
+            const long m = m0 + wm + i * 16 + lq * 4 + r;
+            if (m >= M) continue;
+            if constexpr (NI == 4) {
+                const int nb = n0 + wn + 4 * li;
+                if (vec_out && nb + 3 < g.N) {   // the lane's four column tiles are four consecutive channels: 16-byte traffic
+                    f32x4 v = {acc[i][0][r], acc[i][1][r], acc[i][2][r], acc[i][3][r]};
+                    if (g.bias) v += *(const f32x4*)(g.bias + nb);
+                    if (g.add) v += *(const f32x4*)(g.add + m * g.N + nb);
+                    if (g.act == 2) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+                    *(f32x4*)(g.y + m * g.N + nb) = v;
+                    continue;
+                }
+            }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const long m = m0 + wm + i * 16 + lq * 4 + r;
-                const int n = n0 + wn + j * 16 + li;
-                if (m < M && n < g.N) {
+            for (int j = 0; j < NI; ++j) {
+                const int n = n0 + wn + (BPERM ? 4 * li + j : j * 16 + li);
+                if (n < g.N) {
                     float v = acc[i][j][r];
                     if (g.bias) v += g.bias[n];
                     if (g.add) v += g.add[m * g.N + n];
@@ -278,6 +315,7 @@ __global__ __launch_bounds__(256) void conv2d_igemm_kernel(ConvArgs g) {
                     g.y[m * g.N + n] = v;
                 }
             }
+        }
 }
 
 // ConvLSTM2DCell gates: z (rows, 4F) channel blocks i,f,c,o; c (rows, F) in/out; h written with pixel
