@@ -483,7 +483,9 @@ def bench_a10(args, rank, world, use_dist):
             return inp
         for _ in range(5):
             step()
-        ms = event_time_ms(step, max(args.steps, 100))
+        # best of three regions: a 0.1 ms call is short enough for a single host hiccup (a 30 ms pause was seen once in 800
+        # calls, tools/a10_variance.py) to double a region's mean
+        ms = min(event_time_ms(step, max(args.steps // 3, 100)) for _ in range(3))
         ws.check()
         got = step()[..., :H].cpu().numpy()
         ref = x.astype(np.float64)

@@ -364,6 +364,7 @@ void env_reload() {
     const char* lim = getenv("FOV_DBG_RESIDENT_LIMIT");
     g_env.resident_limit = lim ? atoi(lim) : 0;
     g_env.no_cell_patch = env_flag("FOV_NO_CELL_PATCH");
+    g_env.no_wide16 = env_flag("FOV_NO_WIDE16");
     g_env.bwd_stepped = getenv("FOV_BWD_STEPPED") ? 1 : 0;
     g_env.no_wgrad_fusion = getenv("FOV_NO_WGRAD_FUSION") ? 1 : 0;
     g_env.no_dx_fusion = getenv("FOV_NO_DX_FUSION") ? 1 : 0;
@@ -474,6 +475,8 @@ static int lstm_seq_fwd_impl(const float* x, const float* K, const float* R, con
     hipStream_t s = (hipStream_t)stream;
     // width 512 (mycode/lstm.py's LSTMCell(400), zero-padded by the caller): R register-resident over 16 workgroups per tile;
     // an input wider than 96 is projected first (one GEMM over all steps), the kernel adds it per step
+    if (impl != FOV_IMPL_GENERIC && !env_knobs().no_wide16 && wide16_preferred(x, B, F, H) && wide512_shape_ok(F, H, F > 96))
+        return launch_wide16(p, s);   // few tiles: 32 workgroups per tile, K and R both in registers (lstm_wide16.hip)
     if (impl != FOV_IMPL_GENERIC && wide512_shape_ok(F, H, F > 96)) {
         if (F > 96) {
             float* zx = (float*)((char*)workspace + cluster_workspace_bytes(B, H));

@@ -75,6 +75,7 @@ struct EnvKnobs {
     int force_safe_exchange, pair_kernel, two_launches, resident_limit;
     int bwd_stepped, no_wgrad_fusion, no_dx_fusion, bwd_groups4, gemm_bf16_split, gemm_bf16_noremap;   // experiment switches (tools/)
     int gemm_variant, gemm_split;   // FOV_GEMM_VARIANT / FOV_GEMM_SPLIT: tile shape / K slices of the fp32 GEMM forced (experiments)
+    int no_wide16;       // FOV_NO_WIDE16=1: width-512 layers stay on the 16-workgroup form (tests / A-B timing)
     int no_cell_patch;   // FOV_NO_CELL_PATCH=1: ConvLSTM2D steps stay on the implicit-GEMM cell (tests compare the two forms)
 };
 const EnvKnobs& env_knobs();
@@ -94,6 +95,9 @@ int launch_pair_fused(const LstmParams& p, hipStream_t stream);
 // wide-input layer, H = 256, 96 < F <= 256 (lstm_wide.hip)
 bool wide_shape_ok(int F, int H);
 bool wide_narrow_preferred(int B, int F, int H);
+// width 512 on 32 workgroups per tile (lstm_wide16.hip): small batches (one tile per group), K in registers for F <= 96 or F = 512
+bool wide16_preferred(const float* x, int B, int F, int H);
+int launch_wide16(const LstmParams& p, hipStream_t stream);
 bool wide512_shape_ok(int F, int H, bool zx);   // width 512: 16 workgroups per tile; F <= 96 in-kernel, else precomputed x.K
 int launch_wide(const LstmParams& p, hipStream_t stream);
 // step-wise layer forward on the matrix-core GEMM (train_kernels.hip): hidden widths above the persistent kernels' 256

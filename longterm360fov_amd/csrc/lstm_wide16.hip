@@ -1,0 +1,375 @@
+// Width-512 persistent LSTM layer for SMALL batches: THIRTY-TWO workgroups per 16-sequence tile, 16 hidden units each
+// (round 3; mycode/lstm.py:59,128-132,218-240: two LSTMCell(400) at batch 32 = two tiles, zero-padded to 512 units).
+//
+// lstm_wide.hip's width-512 form (16 workgroups x 32 units) spends 256 MFMAs per wave and step on h.R (3.4 us) behind an
+// exchange that nothing covers, and needs layer 2's input projection from a separate GEMM (its K slice would be another 256
+// registers).  With two tiles there are 224 idle CUs, so here a tile is spread over twice as many:
+//   * a wave owns FOUR units x 4 gates = ONE 16-column MFMA tile [i f g o] x 4 units; R slice 512 x 16 columns = 128 AGPRs,
+//     and the K slice of a 512-wide input (layer 2) fits beside it in the other 128 - no GEMM, no (B,T,4H) round trip;
+//     a narrow input (F <= 96, layer 1) keeps its six k-blocks there;
+//   * per step and wave 128 MFMAs of x_{t+1}.K UNDER the exchange of h_t and 128 MFMAs of h_t.R behind it (1.7 us each);
+//   * the four gates of a (sequence, unit) sit in four lanes of a wave after the MFMAs: a 16 x 16 transpose through a
+//     wave-private LDS scratch (four ds_write_b32, four ds_read_b32, no barrier: one wave's LDS instructions execute in
+//     order) gives every lane ONE (row, unit) cell - 64 lanes = 16 rows x 4 units, nothing redundant;
+//   * exchange as everywhere (xch_common.h): one {h, epoch} granule per lane and step published, 31 gathered.
+// Taken by fov_lstm_seq_fwd[_train] for H = 512 while a launch has at most one tile per group (<= 8 tiles = 128 sequences on
+// 256 CUs); larger batches stay on the 16-workgroup form, whose groups are half as many CUs.
+#include <stdlib.h>
+
+#include "fov_common.h"
+#include "xch_common.h"
+
+namespace fov {
+
+namespace {
+
+constexpr int VBT = 16;
+constexpr unsigned VSPIN = 1u << 20;
+
+typedef unsigned vu32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned vu32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void vm_a(f32x4& acc, float a, float w_agpr) {
+    asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "a"(w_agpr));
+}
+__device__ __forceinline__ void vm_begin(f32x4 (&acc)[2]) { asm volatile("s_nop 3" : "+v"(acc[0]), "+v"(acc[1])); }
+__device__ __forceinline__ void vm_end(f32x4 (&acc)[2]) {
+    asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" : "+v"(acc[0]), "+v"(acc[1]));
+}
+
+// acc[0] + acc[1] += A(tile rows in LDS, k-blocks [0, NJ)) . W (AGPR resident).  TWO accumulators, even / odd k-steps: with a
+// single one hipcc shifted the accumulator tuple between two MFMAs of a run (v_mov_b64 of a result two slots after the MFMA
+// that writes it: tools/isa_mfma_hazard.py), the alternating form of lstm_wide.hip compiles clean.  Fragments run two
+// k-blocks ahead (4 MFMAs = 128 cycles per block do not cover an LDS round trip).
+template <int NJ>
+__device__ __forceinline__ void wide16_mm(f32x4 (&acc)[2], const float* arow, const float (&w)[NJ][4]) {
+    f32x4 a0 = *(const f32x4*)arow;
+    f32x4 a1 = NJ > 1 ? *(const f32x4*)(arow + 16) : a0;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        f32x4 a2 = a1;
+        if (j + 2 < NJ) a2 = *(const f32x4*)(arow + 16 * (j + 2));
+        asm volatile("s_nop 1" : "+v"(a0));   // the fragment may have been moved by the compiler (VALU copy)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) vm_a(acc[s & 1], a0[s], w[j][s]);
+        a0 = a1;
+        a1 = a2;
+    }
+}
+
+// NJX: k-blocks of K in registers - 6 (narrow input, F <= 96, scalar x stage) or WH / 16 (input as wide as the layer, 16-byte
+// x pieces)
+template <int ACT, int NJX, int WH>
+__global__ __launch_bounds__(256, 1) void lstm_wide16_kernel(LstmParams p) {
+    constexpr int WG = WH / 16;          // workgroups per tile
+    constexpr int NJR = WH / 16;         // k-blocks of R
+    constexpr bool XVEC = NJX == WH / 16;
+    constexpr int WLD = WH + 8;          // LDS row stride == 8 (mod 16) floats: conflict-free ds_read_b128 fragments
+    constexpr int WNG = WG - 1;          // granules gathered per thread and step
+    constexpr int H4 = 4 * WH;
+    constexpr unsigned OORB = 0x80000000u;
+    static_assert((WG & (WG - 1)) == 0 && WG <= kHelloStride, "slice arithmetic, hello words");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sH = smem;                     // [16][WLD]
+    float* sX = sH + VBT * WLD;           // [2][16][WLD]
+    float* sT = sX + 2 * VBT * WLD;       // [4 waves][16][17] gate transpose
+    int* sFlag = (int*)(sT + 4 * 16 * 17);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, g4 = lane >> 4;
+    int group, slice;
+    if ((p.num_groups & 7) == 0) {   // members 8 blocks apart: likely one XCD (placement preference only)
+        group = (blockIdx.x / (8 * WG)) * 8 + (blockIdx.x & 7);
+        slice = (blockIdx.x >> 3) & (WG - 1);
+    } else {
+        group = blockIdx.x / WG;
+        slice = blockIdx.x - group * WG;
+    }
+    const int F = p.F, steps = p.T;
+    // MFMA column of this lane: gate n / 4 of unit n % 4 of the wave's four units
+    const int unit = 16 * slice + 4 * wave + (n & 3);
+    const int col = (n >> 2) * WH + unit;
+    // the cell this lane updates after the transpose: row 4 g4 + n / 4 of the tile, the same unit
+    const int row_o = 4 * g4 + (n >> 2);
+    float* tw = sT + wave * (16 * 17);
+    const bool xch_used = steps > 1;
+    __shared__ unsigned sXch[4];
+    const unsigned arrival = xch_used ? xch_arrive(p.status, sXch, group, slice) : 0u;
+    const bool poisoned = xch_used && xch_poisoned(p.status);
+    if (tid == 0) sFlag[0] = poisoned ? 1 : 0;
+
+    // ---- resident weights: K rows >= F read as zero (the descriptor ends with row F - 1) ----
+    const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.K), 0, F * H4 * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.R), 0, WH * H4 * 4, 0x00020000);
+    float wk[NJX][4], wr[NJR][4];
+#pragma unroll
+    for (int j = 0; j < NJR; ++j)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int k = 16 * j + 4 * g4 + s;
+            if (j < NJX) wk[j][s] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(krs, (unsigned)((k * H4 + col) * 4), 0, 0));
+            wr[j][s] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rrs, (unsigned)((k * H4 + col) * 4), 0, 0));
+        }
+    const float bv = p.b[col];
+    for (int i = tid; i < 2 * VBT * WLD; i += 256) sX[i] = 0.f;   // columns >= F stay zero
+
+    // ---- exchange bookkeeping ----
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+        p.xch + (size_t)group * 2 * VBT * WH, 0, 2 * VBT * WH * (int)sizeof(unsigned long long), 0x00020000);
+    const unsigned pub_off = (unsigned)(row_o * WH + unit) * 8u;
+    const int grow = tid >> 4, gu = tid & 15;             // gather: row and unit-in-slice of this thread's granules
+    const unsigned gvoff = (unsigned)(grow * WH + gu) * 8u;
+    const int lbase = grow * WLD + gu;
+    constexpr unsigned PARITY = VBT * WH * 8u;
+    if (xch_used) xch_hello_poll(p.status, sXch, group, WG, &sFlag[0]);
+    __syncthreads();
+    XchTicket ticket = {0u, 0u, 0u};
+    if (xch_used) ticket = xch_ticket(sXch, arrival);
+    unsigned epoch = ticket.base;
+    bool aborted = sFlag[0] != 0;
+    if (xch_used && tid == 0 && !ticket.same_xcd && !aborted) xch_count_safe(p.status, ticket);
+
+    vu32x2 v[WNG];
+    auto gather_issue = [&](unsigned base) {
+#pragma unroll
+        for (int j = 0; j < WNG; ++j) {
+            const unsigned uo = (unsigned)(((slice + 1 + j) & (WG - 1)) * 16) * 8u;
+            v[j] = __builtin_amdgcn_raw_buffer_load_b64(xrs, gvoff, base + uo, 16);
+        }
+    };
+    auto gather_finish = [&](unsigned base) {
+        unsigned bad = 0;
+#pragma unroll
+        for (int j = 0; j < WNG; ++j) {
+            const int lo = lbase + ((slice + 1 + j) & (WG - 1)) * 16;
+            if (v[j].y == epoch) sH[lo] = __uint_as_float(v[j].x);
+            else bad |= (1u << j);
+        }
+        unsigned spins = 0;
+        while (__any(bad != 0)) {
+            ++spins;
+            if (spins > VSPIN || ((spins & 63u) == 0 && xch_poisoned(p.status))) {
+                if (lane == 0) {
+                    xch_give_up(p.status);
+                    sFlag[0] = 1;
+                }
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+            asm volatile("" ::: "memory");
+            constexpr int RCH = 8;   // retry in chunks (register budget)
+#pragma unroll
+            for (int j0 = 0; j0 < WNG; j0 += RCH) {
+                vu32x2 tv[RCH];
+#pragma unroll
+                for (int j = j0; j < j0 + RCH && j < WNG; ++j) {
+                    const unsigned uo = (unsigned)(((slice + 1 + j) & (WG - 1)) * 16) * 8u;
+                    tv[j - j0] = __builtin_amdgcn_raw_buffer_load_b64(xrs, gvoff, base + uo, 16);
+                }
+#pragma unroll
+                for (int j = j0; j < j0 + RCH && j < WNG; ++j) {
+                    const int lo = lbase + ((slice + 1 + j) & (WG - 1)) * 16;
+                    if (((bad >> j) & 1u) && tv[j - j0].y == epoch) {
+                        sH[lo] = __uint_as_float(tv[j - j0].x);
+                        bad &= ~(1u << j);
+                    }
+                }
+            }
+        }
+    };
+
+    const float* hrow = sH + n * WLD + 4 * g4;
+    // x staging: thread (xrw = tid / 16, xc = tid % 16) moves the 16-byte pieces xc, xc + 16, ... of row xrw (narrow: elements)
+    const int xrw = tid >> 4, xc = tid & 15;
+    const int nx4 = F >> 2;
+    constexpr int NXR = XVEC ? WH / 64 : NJX;
+    for (int tile = group; tile < p.num_tiles && !aborted; tile += p.num_groups) {
+        const int b0 = tile * VBT;
+        __syncthreads();   // previous tile fully consumed
+        // every global load of the tile goes through a descriptor that covers exactly its live rows: rows past the batch and
+        // absent tensors read as 0 without a branch
+        const int live_rows = p.B - b0 < VBT ? p.B - b0 : VBT;
+        const __amdgpu_buffer_rsrc_t h0rs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(p.h0 ? p.h0 + (size_t)b0 * WH : nullptr), 0, p.h0 ? live_rows * WH * 4 : 0, 0x00020000);
+        const __amdgpu_buffer_rsrc_t c0rs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(p.c0 ? p.c0 + (size_t)b0 * WH : nullptr), 0, p.c0 ? live_rows * WH * 4 : 0, 0x00020000);
+        const __amdgpu_buffer_rsrc_t xgrs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(p.x + (size_t)b0 * p.T * F), 0, live_rows * p.T * F * 4, 0x00020000);
+        {
+            float hv[VBT * WH / 256];
+#pragma unroll
+            for (int q = 0; q < VBT * WH / 256; ++q) hv[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(h0rs, (unsigned)((tid + 256 * q) * 4), 0, 0));
+#pragma unroll
+            for (int q = 0; q < VBT * WH / 256; ++q) {
+                const int e = tid + 256 * q;
+                sH[(e / WH) * WLD + (e % WH)] = hv[q];
+            }
+        }
+        const unsigned soff = (unsigned)((row_o * WH + unit) * 4);
+        float c = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(c0rs, soff, 0, 0));
+        float hc = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(h0rs, soff, 0, 0));
+        unsigned xoff[NXR];
+#pragma unroll
+        for (int i = 0; i < NXR; ++i) {
+            if constexpr (XVEC) xoff[i] = (xc + 16 * i < nx4) ? (unsigned)((xrw * p.T * F + 4 * xc + 64 * i) * 4) : OORB;
+            else xoff[i] = (xc + 16 * i < F) ? (unsigned)((xrw * p.T * F + xc + 16 * i) * 4) : OORB;
+        }
+        auto load_x4 = [&](int i, int t) {
+            const vu32x4 q = __builtin_amdgcn_raw_buffer_load_b128(xgrs, xoff[i], (unsigned)(t * F * 4), 0);
+            return (f32x4){__uint_as_float(q[0]), __uint_as_float(q[1]), __uint_as_float(q[2]), __uint_as_float(q[3])};
+        };
+        auto load_x1 = [&](int i, int t) { return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xgrs, xoff[i], (unsigned)(t * F * 4), 0)); };
+        float* xl = sX + xrw * WLD + (XVEC ? 4 : 1) * xc;
+        const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+        {
+            f32x4 x4[2][XVEC ? NXR : 1];
+            float x1[2][XVEC ? 1 : NXR];
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                for (int i = 0; i < NXR; ++i) {
+                    const int tc = tt < steps ? tt : 0;
+                    if constexpr (XVEC) x4[tt][i] = load_x4(i, tc);
+                    else x1[tt][i] = load_x1(i, tc);
+                }
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt)
+                if (tt < steps) {
+#pragma unroll
+                    for (int i = 0; i < NXR; ++i) {
+                        if constexpr (XVEC) {
+                            if (xc + 16 * i < nx4) *(f32x4*)(xl + tt * VBT * WLD + 64 * i) = x4[tt][i];
+                        } else {
+                            if (xc + 16 * i < F) xl[tt * VBT * WLD + 16 * i] = x1[tt][i];
+                        }
+                    }
+                }
+        }
+        __syncthreads();
+        // ---- pre-activations of step 0 ----
+        f32x4 acc[2] = {{bv, bv, bv, bv}, {0.f, 0.f, 0.f, 0.f}};
+        if (steps > 0) {
+            vm_begin(acc);
+            wide16_mm<NJX>(acc, sX + n * WLD + 4 * g4, wk);
+            wide16_mm<NJR>(acc, hrow, wr);
+            vm_end(acc);
+        }
+        f32x4 xr[XVEC ? NXR : 1] = {z4};
+        float xs[XVEC ? 1 : NXR] = {0.f};
+        for (int t = 0; t < steps; ++t) {
+            // x pipeline: x_{t+1} (requested during step t-1) registers -> LDS; then request x_{t+2}
+            if (t > 0 && t + 1 < steps) {
+                float* xb = xl + ((t + 1) & 1) * VBT * WLD;
+#pragma unroll
+                for (int i = 0; i < NXR; ++i) {
+                    if constexpr (XVEC) {
+                        if (xc + 16 * i < nx4) *(f32x4*)(xb + 64 * i) = xr[i];
+                    } else {
+                        if (xc + 16 * i < F) xb[16 * i] = xs[i];
+                    }
+                }
+            }
+            if (t + 2 < steps) {
+#pragma unroll
+                for (int i = 0; i < NXR; ++i) {
+                    if constexpr (XVEC) xr[i] = load_x4(i, t + 2);
+                    else xs[i] = load_x1(i, t + 2);
+                }
+            }
+            // ---- the four gates of a cell meet: 16 x 16 transpose through the wave's scratch ----
+#pragma unroll
+            for (int r = 0; r < 4; ++r) tw[(4 * g4 + r) * 17 + n] = acc[0][r] + acc[1][r];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // one wave's LDS instructions execute in order; the compiler must not reorder either
+            const float zi = tw[row_o * 17 + (n & 3)], zf = tw[row_o * 17 + 4 + (n & 3)], zg = tw[row_o * 17 + 8 + (n & 3)],
+                        zo = tw[row_o * 17 + 12 + (n & 3)];
+            {
+                const float ig = rec_act<ACT>(zi), fg = rec_act<ACT>(zf), gg = tanh_f(zg), og = rec_act<ACT>(zo);
+                c = fmaf(fg, c, ig * gg);
+                hc = og * tanh_f(c);
+                const int row = b0 + row_o;
+                if (row < p.B) {
+                    if (p.reserve) {
+                        float* rp = p.reserve + (((size_t)row * p.T + t) * 5) * WH + unit;
+                        rp[0] = ig; rp[WH] = fg; rp[2 * WH] = gg; rp[3 * WH] = og; rp[4 * WH] = c;
+                    }
+                    if (p.hs) p.hs[((size_t)row * p.T + t) * WH + unit] = hc;
+                }
+            }
+            const bool more = (t + 1 < steps);
+            const bool do_xch = xch_used && more;
+            unsigned par = 0;
+            if (do_xch) {
+                ++epoch;
+                par = (epoch & 1u) * PARITY;
+                XCH_STORE_B64(ticket.same_xcd, ((vu32x2){__float_as_uint(hc), epoch}), xrs, pub_off, par);
+            }
+            __syncthreads();   // barrier 1: every wave is done reading sH; x_{t+1} is in LDS
+            if (do_xch) sH[row_o * WLD + unit] = hc;
+            acc[0] = (f32x4){bv, bv, bv, bv};
+            acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (more) {   // x_{t+1} . K needs no remote data: it runs under the exchange
+                vm_begin(acc);
+                wide16_mm<NJX>(acc, sX + ((t + 1) & 1) * VBT * WLD + n * WLD + 4 * g4, wk);
+                vm_end(acc);
+            }
+            if (do_xch) gather_issue(par);
+            if (do_xch) gather_finish(par);
+            __syncthreads();   // barrier 2: the whole h_t tile is in LDS
+            if (sFlag[0]) { aborted = true; break; }
+            if (more) {
+                vm_begin(acc);
+                wide16_mm<NJR>(acc, hrow, wr);
+                vm_end(acc);
+            }
+        }
+        if (!aborted) {
+            const int row = b0 + row_o;
+            if (row < p.B) {
+                if (p.hT) p.hT[(size_t)row * WH + unit] = hc;
+                if (p.cT) p.cT[(size_t)row * WH + unit] = c;
+            }
+        }
+    }
+    if (xch_used) xch_settle(p.status, ticket, (unsigned)p.epoch_span);
+}
+
+template <int NJX, int WH>
+int launch_wide16_t(LstmParams& p, hipStream_t stream) {
+    constexpr int WG = WH / 16;
+    p.num_tiles = (p.B + VBT - 1) / VBT;
+    const int max_groups = device_cu_count() / WG;
+    if (max_groups < 1) { set_error("width-%d LSTM layer (32 workgroups per tile) needs at least %d CUs", WH, WG); return FOV_ERR_UNSUPPORTED; }
+    p.num_groups = p.num_tiles < max_groups ? p.num_tiles : max_groups;
+    if ((size_t)p.num_groups * 2 * VBT * WH * sizeof(unsigned long long) > kXchBytes - kHelloBytes) { set_error("wide LSTM layer: granule area too small"); return FOV_ERR_WORKSPACE; }
+    p.epoch_span = p.T * ((p.num_tiles + p.num_groups - 1) / p.num_groups) + 1;
+    if (int rc_ = xch_account(p.status, p.epoch_span, stream)) return rc_;
+    const size_t lds = sizeof(float) * (3 * VBT * (WH + 8) + 4 * 16 * 17) + 64;
+    void (*kern)(LstmParams) = p.act == FOV_ACT_HARD_SIGMOID ? lstm_wide16_kernel<FOV_ACT_HARD_SIGMOID, NJX, WH>
+                                                             : lstm_wide16_kernel<FOV_ACT_SIGMOID, NJX, WH>;
+    int rc = ensure_dynamic_lds((const void*)kern, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL(kern, dim3(p.num_groups * WG), dim3(256), lds, stream, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_error("wide16 LSTM launch: %s", hipGetErrorString(e)); return FOV_ERR_LAUNCH; }
+    return FOV_OK;
+}
+
+}  // namespace
+
+// H = 512, at most one tile per group of 32 workgroups, and an input the kernel keeps in registers: narrow (F <= 96) or as
+// wide as the layer (F = 512, 16-byte aligned rows)
+bool wide16_preferred(const float* x, int B, int F, int H) {
+    if (H != 512 || B <= 0) return false;
+    const int tiles = (B + VBT - 1) / VBT;
+    if (tiles > device_cu_count() / 32) return false;
+    return (F >= 1 && F <= 96) || (F == 512 && (((uintptr_t)x) & 15) == 0);
+}
+
+int launch_wide16(const LstmParams& p_in, hipStream_t stream) {
+    LstmParams p = p_in;
+    if (p.B == 0) return FOV_OK;
+    if (p.F <= 96) return launch_wide16_t<6, 512>(p, stream);
+    return launch_wide16_t<32, 512>(p, stream);
+}
+
+}  // namespace fov

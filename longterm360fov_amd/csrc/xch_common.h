@@ -43,11 +43,12 @@ enum : int {
 };
 
 constexpr size_t kXchBytes = (size_t)64 << 20;   // fixed granule area: the largest user (fused decoder backward, 32 groups) needs 50.9 MB
-constexpr size_t kHelloBytes = (size_t)64 << 10; // its last 64 KB: hello words of the same-XCD handshake, [group][8 members]
+constexpr size_t kHelloBytes = (size_t)64 << 10; // its last 64 KB: hello words of the same-XCD handshake, [group][32 members]
+constexpr int kHelloStride = 32;                 // members per group at most (width-512 layer: 16 or 32 workgroups per tile); 256 groups fit
 
 // where the members of group `group` publish {launch tag, XCC id}: only the status pointer (= workspace start) is needed
 __device__ __forceinline__ unsigned long long* xch_hello_words(unsigned* status, int group) {
-    return (unsigned long long*)((char*)status + 256 + kXchBytes - kHelloBytes) + (size_t)group * 8;
+    return (unsigned long long*)((char*)status + 256 + kXchBytes - kHelloBytes) + (size_t)group * kHelloStride;
 }
 __device__ __forceinline__ unsigned xch_xcc_id() {
     unsigned x;

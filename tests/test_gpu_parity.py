@@ -495,7 +495,8 @@ def test_wide_input_layer(B, T, F, act):
 
 
 @pytest.mark.parametrize("B,T,F,state", [(32, 10, 90, False), (32, 10, 512, True), (37, 5, 200, True), (5, 1, 7, False),
-                                         (16, 1, 512, True), (600, 3, 90, True), (300, 4, 400, False)])
+                                         (16, 1, 512, True), (600, 3, 90, True), (300, 4, 400, False), (128, 6, 512, False),
+                                         (100, 7, 33, True), (129, 3, 512, True)])
 @pytest.mark.parametrize("act", ["sigmoid", "hard_sigmoid"])
 def test_width_512_persistent_layer(B, T, F, state, act):
     """H = 512 (mycode/lstm.py's LSTMCell(400) x 2 zero-padded, :59,218-240): the recurrent kernel stays in registers across
@@ -531,6 +532,15 @@ def test_width_512_persistent_layer(B, T, F, state, act):
     assert (g_hs - hs).abs().max().item() <= 2e-5 and (g_cT - cT).abs().max().item() <= 2e-5
     _, hT3, cT3 = ops.lstm_seq(dev(x), dev(K), dev(R), dev(b), dv(h0), dv(c0), act=act, return_sequences=False, workspace=ws)
     assert torch.equal(hT3, hT) and torch.equal(cT3, cT)
+    # small batches (one tile per group of THIRTY-TWO workgroups, lstm_wide16.hip: K and R both in registers for F <= 96 and
+    # F = 512) against the sixteen-workgroup form of the same layer
+    os.environ["FOV_NO_WIDE16"] = "1"
+    try:
+        hs16, _, cT16 = ops.lstm_seq(dev(x), dev(K), dev(R), dev(b), dv(h0), dv(c0), act=act, workspace=ws)
+    finally:
+        del os.environ["FOV_NO_WIDE16"]
+    ws.check()
+    assert (hs16 - hs).abs().max().item() <= 2e-6 and (cT16 - cT).abs().max().item() <= 4e-6
     zx = ops.matmul(dev(x).reshape(B * T, F), dev(K)).reshape(B, T, 4 * H)
     hs4, _, cT4 = ops.lstm_seq_zx(zx, dev(R), dev(b), dv(h0), dv(c0), act=act, workspace=ws)
     ws.check()
