@@ -431,6 +431,18 @@ def bench_config1(args, rank, world, use_dist):
                     tr.check()
                     training["h%d_%s" % (Ht, impl)] = {"ms_per_step": tms, "sequences_per_s": B / (tms * 1e-3),
                                                        "run_width": getattr(tr, "Hp", Ht)}
+                    if impl == "auto":
+                        # the same step INSIDE model.fit (host arrays in, per-epoch shuffle, batches gathered on the device):
+                        # wall time per step over two epochs of 100 steps
+                        ne, nd, nt = O.synthetic_batch(99 + rank, 100 * B, T_in, T_out)
+                        ndi = np.concatenate([nd, nt[:, :-1]], axis=1)
+                        m.fit([ne, ndi], nt, batch_size=B, epochs=1, shuffle=True)
+                        torch.cuda.synchronize()
+                        quiesce_gc()
+                        tf0 = time.perf_counter()
+                        m.fit([ne, ndi], nt, batch_size=B, epochs=2, shuffle=True)
+                        torch.cuda.synchronize()
+                        training["h%d_auto" % Ht]["fit_ms_per_step"] = (time.perf_counter() - tf0) / 200 * 1e3
                 if not args.no_cpu_baseline and world == 1 and args.act == "sigmoid":
                     wt = O.init_seq2seq(1, 90, 6, Ht)
                     mc = TC.Seq2SeqCPU(wt, threads=min(TC.usable_cores(), CPU_THREADS))

@@ -27,7 +27,10 @@ namespace fov {
 
 constexpr int BBT = 16;
 constexpr unsigned BSPIN_LIMIT = 1u << 20;
-constexpr int GATHER_AFTER_Q = 8;   // k-blocks of the local destination's product issued before the gather is requested
+#ifndef FOV_GATHER_AFTER_Q
+#define FOV_GATHER_AFTER_Q 8
+#endif
+constexpr int GATHER_AFTER_Q = FOV_GATHER_AFTER_Q;   // k-blocks of the local destination's product issued before the gather is requested
                                     // (0 = right behind the last publish: 225 us; 8: 206 us; 15: 212 us at B = 1024, T = 30)
 typedef unsigned bu32x2 __attribute__((ext_vector_type(2)));
 
