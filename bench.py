@@ -351,7 +351,11 @@ def cpu_baseline_seq2seq(enc, dec0, w, T_out, act, budget_s, want_out=False):
                 # OMP_NUM_THREADS = nproc in a child with a wall limit: on a shared host a pool over
                 # every visible thread can take minutes per pass, and this line must stay within its time budget
                 limit = max(30.0, 3.0 * per_leg)
-                got = TC.sgemm_leg_in_child(enc, dec0, w, T_out, cores, per_leg / 2, limit)
+                try:
+                    got = TC.sgemm_leg_in_child(enc, dec0, w, T_out, cores, per_leg / 2, limit)
+                except Exception as exc:   # the child could not be started or failed: the leg is dropped, the line still prints
+                    log("  sgemm loop, %d threads: child failed (%s)" % (cores, exc))
+                    got = None
                 if got is None:
                     legs.append({"impl": sg_impl, "value": None, "ms_per_pass": None, "passes": 0, "cores": cores,
                                  "note": "gave up after %.0f s: 1 warm-up + 3 passes did not finish (oversubscribed shared host)" % limit})
