@@ -450,6 +450,7 @@ static size_t wide512_workspace_bytes(int B, int T, int F) {
 size_t fov_lstm_seq_workspace_bytes(int B, int T, int F, int H, int impl) {
     if (B <= 0) return kStatusBytes;
     if (impl != FOV_IMPL_GENERIC && wide512_shape_ok(F, H, F > 96)) return wide512_workspace_bytes(B, T, F);
+    if (impl == FOV_IMPL_AUTO && !env_knobs().no_wide16 && wide16_shape(B, F, H)) return cluster_workspace_bytes(B, H);
     if (impl == FOV_IMPL_AUTO && stepwise_preferred(B, F, H)) return kStatusBytes + sizeof(float) * stepwise_workspace_floats(B, T, H);
     if (impl != FOV_IMPL_GENERIC && wide_shape_ok(F, H)) return cluster_workspace_bytes(B, H);
     if (impl == FOV_IMPL_AUTO && wide_narrow_preferred(B, F, H)) return cluster_workspace_bytes(B, H);
@@ -488,6 +489,10 @@ static int lstm_seq_fwd_impl(const float* x, const float* K, const float* R, con
         }
         return launch_wide(p, s);
     }
+    // few tiles at width 128 / 256: H / 16 workgroups per tile (lstm_wide16.hip) - the latency regime of model.fit at batch 32
+    if (impl == FOV_IMPL_AUTO && H != 512 && T > 0 && !env_knobs().no_wide16 && wide16_preferred(x, B, F, H) &&
+        workspace_bytes >= cluster_workspace_bytes(B, H))
+        return launch_wide16(p, s);
     // wide inputs (a stacked layer over a 256-wide sequence): K and R both register-resident (lstm_wide.hip)
     if (impl != FOV_IMPL_GENERIC && wide_shape_ok(F, H) && (((uintptr_t)x) & 15) == 0) return launch_wide(p, s);
     // narrow inputs, at most 32 tiles: groups of eight workgroups fill the chip where lstm_cluster's groups of four leave half idle

@@ -96,6 +96,7 @@ int launch_pair_fused(const LstmParams& p, hipStream_t stream);
 bool wide_shape_ok(int F, int H);
 bool wide_narrow_preferred(int B, int F, int H);
 // width 512 on 32 workgroups per tile (lstm_wide16.hip): small batches (one tile per group), K in registers for F <= 96 or F = 512
+bool wide16_shape(int B, int F, int H);
 bool wide16_preferred(const float* x, int B, int F, int H);
 int launch_wide16(const LstmParams& p, hipStream_t stream);
 bool wide512_shape_ok(int F, int H, bool zx);   // width 512: 16 workgroups per tile; F <= 96 in-kernel, else precomputed x.K

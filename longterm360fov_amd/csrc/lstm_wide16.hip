@@ -338,7 +338,7 @@ int launch_wide16_t(LstmParams& p, hipStream_t stream) {
     constexpr int WG = WH / 16;
     p.num_tiles = (p.B + VBT - 1) / VBT;
     const int max_groups = device_cu_count() / WG;
-    if (max_groups < 1) { set_error("width-%d LSTM layer (32 workgroups per tile) needs at least %d CUs", WH, WG); return FOV_ERR_UNSUPPORTED; }
+    if (max_groups < 1) { set_error("width-%d LSTM layer (%d workgroups per tile) needs at least %d CUs", WH, WG, WG); return FOV_ERR_UNSUPPORTED; }
     p.num_groups = p.num_tiles < max_groups ? p.num_tiles : max_groups;
     if ((size_t)p.num_groups * 2 * VBT * WH * sizeof(unsigned long long) > kXchBytes - kHelloBytes) { set_error("wide LSTM layer: granule area too small"); return FOV_ERR_WORKSPACE; }
     p.epoch_span = p.T * ((p.num_tiles + p.num_groups - 1) / p.num_groups) + 1;
@@ -356,20 +356,31 @@ int launch_wide16_t(LstmParams& p, hipStream_t stream) {
 
 }  // namespace
 
-// H = 512, at most one tile per group of 32 workgroups, and an input the kernel keeps in registers: narrow (F <= 96) or as
-// wide as the layer (F = 512, 16-byte aligned rows)
-bool wide16_preferred(const float* x, int B, int F, int H) {
-    if (H != 512 || B <= 0) return false;
+// Widths 128 / 256 / 512 (H / 16 workgroups per tile), at most eight tiles and one tile per group, and an input the kernel
+// keeps in registers: narrow (F <= 96) or as wide as the layer (F = H, 16-byte aligned rows).  The latency regime: with
+// so few tiles the other kernels leave most CUs idle and a step is the exchange latency plus ALL of a workgroup's MFMAs.
+bool wide16_shape(int B, int F, int H) {
+    if (!(H == 128 || H == 256 || H == 512) || B <= 0) return false;
     const int tiles = (B + VBT - 1) / VBT;
-    if (tiles > device_cu_count() / 32) return false;
-    return (F >= 1 && F <= 96) || (F == 512 && (((uintptr_t)x) & 15) == 0);
+    const int max_groups = device_cu_count() / (H / 16);
+    if (tiles > 8 || tiles > max_groups) return false;
+    return (F >= 1 && F <= 96) || F == H;
+}
+bool wide16_preferred(const float* x, int B, int F, int H) {
+    return wide16_shape(B, F, H) && (F <= 96 || (((uintptr_t)x) & 15) == 0);
 }
 
 int launch_wide16(const LstmParams& p_in, hipStream_t stream) {
     LstmParams p = p_in;
     if (p.B == 0) return FOV_OK;
-    if (p.F <= 96) return launch_wide16_t<6, 512>(p, stream);
-    return launch_wide16_t<32, 512>(p, stream);
+    const bool narrow = p.F <= 96;
+    switch (p.H) {
+        case 128: return narrow ? launch_wide16_t<6, 128>(p, stream) : launch_wide16_t<8, 128>(p, stream);
+        case 256: return narrow ? launch_wide16_t<6, 256>(p, stream) : launch_wide16_t<16, 256>(p, stream);
+        case 512: return narrow ? launch_wide16_t<6, 512>(p, stream) : launch_wide16_t<32, 512>(p, stream);
+    }
+    set_error("wide16 LSTM layer: unsupported width %d", p.H);
+    return FOV_ERR_UNSUPPORTED;
 }
 
 }  // namespace fov
