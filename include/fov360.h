@@ -398,6 +398,16 @@ int fov_adam_step_guarded(float* params, const float* grads, float* m, float* v,
                           const void* guard2, fov_stream_t stream);
 int fov_rmsprop_step_guarded(float* params, const float* grads, float* accum, int64_t n, float lr, float rho, float eps,
                              const void* guard0, const void* guard1, const void* guard2, fov_stream_t stream);
+/* Deferred split reductions of a training step (model.fit's backward, FoV_seq2seq.py:103,112-117): between _begin and
+ * _flush / _end every weight-gradient entry point of this library whose OUTPUT lies inside [grad_base, grad_base +
+ * grad_floats) - the caller's flat gradient buffer - keeps the partial slices of its split product in `arena` (caller-owned
+ * device memory, any size >= 256 bytes: what does not fit is reduced at once) and the flush sums all of them in ONE launch
+ * instead of one per product; results are bit-identical.  In-stream order is kept for writes made through this library (a
+ * later product over a pending range flushes first); a caller that reads or writes the gradient buffer by other means
+ * between _begin and _end calls _flush before.  One deferral at a time per process; grad_base = NULL switches it off. */
+int fov_reduce_defer_begin(float* grad_base, size_t grad_floats, void* arena, size_t arena_bytes, fov_stream_t stream);
+int fov_reduce_defer_flush(fov_stream_t stream);
+int fov_reduce_defer_end(fov_stream_t stream);
 /* Data-parallel training (the all-reduce of model.fit's gradients, given_others_gt_mean_var_seq2seq.py:494-506):
  * *out = 1.0f if the timeout word of one of the workspaces is set, else 0.0f.  The trainers keep `out` inside the flat
  * gradient buffer: after the SUM all-reduce it is nonzero on EVERY rank if any rank's step failed, and handed to the

@@ -790,6 +790,13 @@ int fov_adam_step_guarded(float* params, const float* grads, float* m, float* v,
     return adam_step(params, grads, m, v, (long)n, (float)lr_t, beta1, beta2, eps, guards, (hipStream_t)stream);
 }
 
+int fov_reduce_defer_begin(float* grad_base, size_t grad_floats, void* arena, size_t arena_bytes, fov_stream_t stream) {
+    if (grad_base && (!arena || arena_bytes < 256)) { set_error("fov_reduce_defer_begin: invalid arena"); return FOV_ERR_INVALID; }
+    return defer_begin(grad_base, grad_floats, (float*)arena, arena_bytes / sizeof(float), (hipStream_t)stream);
+}
+int fov_reduce_defer_flush(fov_stream_t stream) { return defer_flush((hipStream_t)stream); }
+int fov_reduce_defer_end(fov_stream_t stream) { return defer_end((hipStream_t)stream); }
+
 int fov_guard_flag(const void* guard0, const void* guard1, const void* guard2, float* out, fov_stream_t stream) {
     if (!out) { set_error("fov_guard_flag: invalid argument"); return FOV_ERR_INVALID; }
     const unsigned* guards[3] = {(const unsigned*)guard0, (const unsigned*)guard1, (const unsigned*)guard2};

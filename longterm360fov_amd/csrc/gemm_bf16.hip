@@ -326,6 +326,12 @@ int gemm_bf16_tn_fused(const float* a1, long lda1, long a1_so, int M1, int shift
     g.split = split;
     g.rows_per_split = rps;
     g.add_c = accumulate;
+    bool deferred = false;
+    if (split > 1) {
+        if (float* arena = defer_alloc(c, (size_t)(M + g.bias_row) * N, (size_t)split * (M + g.bias_row) * N, stream)) { scratch = arena; deferred = true; }
+    } else if (int rc_ = defer_touch(c, (size_t)(M + g.bias_row) * ldc, stream)) {
+        return rc_;
+    }
     g.c = split > 1 ? scratch : c;
     if (split > 1 && ldc != N) { set_error("gemm_bf16_tn: split products need a dense C"); return FOV_ERR_INVALID; }
     g.grid_n = (N + GT - 1) / GT;
@@ -338,7 +344,7 @@ int gemm_bf16_tn_fused(const float* a1, long lda1, long a1_so, int M1, int shift
     else hipLaunchKernelGGL(gemm_bf16_tn_kernel<false>, grid, dim3(256), 0, stream, g);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("gemm_bf16_tn launch: %s", hipGetErrorString(e)); return FOV_ERR_LAUNCH; }
-    if (split > 1) return splitk_reduce(scratch, c, (long)(M + g.bias_row) * N, split, accumulate, stream);
+    if (split > 1) return reduce_or_defer(deferred, scratch, c, (long)(M + g.bias_row) * N, split, accumulate, stream, "splitk_reduce");
     return FOV_OK;
 }
 

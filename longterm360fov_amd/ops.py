@@ -551,6 +551,20 @@ def adam_step(params, grads, m, v, step, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e
                                            eps, int(step), *_guard_ptrs(guards), _stream()))
 
 
+def reduce_defer_begin(grad, arena):
+    """From here to reduce_defer_end the split weight-gradient products that write into `grad` (a contiguous fp32 view of the
+    trainer's flat gradient buffer) leave their partial slices in `arena` and are summed by ONE launch at the flush."""
+    check(_lib.lib().fov_reduce_defer_begin(_ptr(grad), grad.numel(), arena.data_ptr(), arena.numel() * arena.element_size(), _stream()))
+
+
+def reduce_defer_flush():
+    check(_lib.lib().fov_reduce_defer_flush(_stream()))
+
+
+def reduce_defer_end():
+    check(_lib.lib().fov_reduce_defer_end(_stream()))
+
+
 def rmsprop_step(params, grads, accum, lr=1e-3, rho=0.9, eps=1e-7, guards=None):
     for t in (params, grads, accum):
         _dev(t, "flat buffer")

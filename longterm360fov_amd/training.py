@@ -112,14 +112,33 @@ class FlatParamTrainer:
         """Called from forward_backward: every gradient from parameter `name` to the end of the buffer (and the loss
         slot) is final.  Under DP with overlap_allreduce the tail goes out now, overlapping the backward work still to come."""
         if self._dp and self.overlap_allreduce and 4 + self.offset[name] < self._reduced_from:
+            ops.reduce_defer_flush()     # the tail is read now
             lo = 4 + self.offset[name]   # (gradbuf index: the gradients sit behind the 16-byte head)
             self._pending.append(torch.distributed.all_reduce(self.gradbuf[lo:self._reduced_from],
                                                               op=torch.distributed.ReduceOp.SUM, async_op=True))
             self._reduced_from = lo
 
+    # One reduce launch per step instead of one per split product (ops.reduce_defer_begin): only for trainers whose
+    # forward_backward writes gradients through the library's weight-gradient entry points alone (they keep in-stream
+    # order by themselves); the arena holds the partial slices of a step (FOV_DEFER_ARENA_MB, 0 switches the deferral off).
+    defer_reduces = False
+    _defer_arena = None
+
+    def _defer_begin(self):
+        if not self.defer_reduces:
+            return False
+        if self._defer_arena is None:
+            mb = int(os.environ.get("FOV_DEFER_ARENA_MB", "256"))
+            self._defer_arena = torch.empty(max(mb, 0) << 18, dtype=torch.float32, device=self.device) if mb > 0 else False
+        if self._defer_arena is False:
+            return False
+        ops.reduce_defer_begin(self.grad, self._defer_arena)
+        return True
+
     def _weigh(self, loss, grad_weight):
         """Fallback for trainers whose loss kernel takes no weight: scale gradients and loss after the fact."""
         if grad_weight != 1.0:
+            ops.reduce_defer_flush()
             ops.scale_(self.grad, grad_weight)
             loss = ops.scale_(loss, grad_weight)
         return loss
@@ -135,7 +154,12 @@ class FlatParamTrainer:
         weight = 1.0 if world == 1 else n_local / float(n_global if n_global else n_local * world)
         self._dp = parallel.dp_active()   # more than one rank - or FOV_FORCE_DIST=1 on an initialised group of one (RCCL tests)
         self._pending, self._reduced_from = [], self.gradbuf.numel()
-        loss, _ = self.forward_backward(*inputs, grad_weight=weight, **kw)
+        deferring = self._defer_begin()
+        try:
+            loss, _ = self.forward_backward(*inputs, grad_weight=weight, **kw)
+        finally:
+            if deferring:
+                ops.reduce_defer_end()      # flushes: every gradient is final from here on
         if self._dp:
             if loss.data_ptr() != self.loss_slot.data_ptr():
                 self.loss_slot.copy_(loss.reshape(1))
@@ -274,6 +298,8 @@ class PaddedTrainer:
 
 
 class Seq2SeqTrainer(FlatParamTrainer):
+    defer_reduces = True   # gradients are written by the library's weight-gradient entry points only
+
     def __init__(self, weights, act="sigmoid", impl="auto", optimizer="adam", lr=1e-3, device="cuda"):
         self.act, self.impl = act, impl
         self._alloc(weights, _W_ORDER, optimizer, lr, device)
@@ -506,6 +532,9 @@ class StackedSeq2SeqTrainer(FlatParamTrainer):
     3layers.py:222-300): encoder layer l hands its final (h, c) to decoder layer l, every layer returns its sequence to
     the next, Dense(6, tanh) on the top decoder layer; Adam + MSE.  Same layer kernels as the one-layer trainer, one
     forward-with-reserve and one BPTT launch per layer."""
+
+    defer_reduces = True   # gradients are written by the library's weight-gradient entry points only
+
 
     def __init__(self, weights, num_layers, act="sigmoid", impl="auto", optimizer="adam", lr=1e-3, device="cuda"):
         self.L, self.act, self.impl = int(num_layers), act, impl
@@ -795,6 +824,9 @@ class OthersMixingTrainer(FlatParamTrainer):
     step by step (data path only: mixing head, layer 2, layer 1; the feedback path's gradient is the dx of the
     first decoder layer), then every weight gradient is one product over all steps.  Gradients accumulate into
     ONE flat buffer (one all-reduce under DP)."""
+
+    defer_reduces = True   # gradients are written by the library's weight-gradient entry points only
+
 
     fused_decoder = True       # H = 256: forward of the unrolled decoder as ONE launch; False = step-wise calls
     fused_decoder_bwd = True   # H = 256: BPTT through the unrolled decoder as ONE launch; False = step-wise calls
