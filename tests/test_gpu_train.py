@@ -1430,3 +1430,49 @@ def test_fit_at_the_reference_widths_runs_padded_on_the_matrix_core_kernels(kind
     for a, b in zip(res["auto"][1], res["generic"][1]):
         assert a.shape == b.shape
         np.testing.assert_allclose(a, b, atol=2e-6, rtol=1e-5)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_deferred_split_reductions_equal_immediate(dtype):
+    """fov_reduce_defer_begin / _flush / _end (model.fit's backward: the split weight-gradient products of a step summed by ONE
+    launch): same gradients bit for bit as one reduce per product - several products into adjacent ranges of a flat buffer, an
+    ACCUMULATING product over a range a pending record covers (flushes first: in-stream order), a product whose output lies
+    outside the registered buffer (reduced at once), an arena too small for one of the products (reduced at once) and more
+    products than the record table holds."""
+    from longterm360fov_amd import ops
+    rng = np.random.default_rng(3)
+    N, H, O = 5120, 256, 6
+    t = lambda *s: torch.from_numpy(rng.standard_normal(s).astype(np.float32)).cuda()
+    x1, x2, dz, xs, dp = t(N, H), t(N, H), t(N, 4 * H), t(N, O), t(N, O)
+    nfused = (2 * H + 1) * 4 * H
+    nsk = O * 4 * H
+    nhead = (H + 1) * O
+
+    def run(arena_mb):
+        flat = torch.zeros(nfused + nsk + nhead + 64, dtype=torch.float32, device="cuda")
+        outside = torch.zeros((H + 1) * 4 * H, dtype=torch.float32, device="cuda")
+        sc = ops.Scratch()
+        arena = torch.empty(max(arena_mb, 0) << 18, dtype=torch.float32, device="cuda") if arena_mb else None
+        if arena is not None:
+            ops.reduce_defer_begin(flat, arena)
+        a, b, c = flat[:nfused], flat[nfused:nfused + nsk], flat[nfused + nsk:nfused + nsk + nhead]
+        ops.wgrad_fused(x1, x2, dz, a, scratch=sc, dtype=dtype)                                    # [x1 | x2 | 1]^T dz
+        ops.dense_bwd(xs, torch.zeros((O, 4 * H), device="cuda"), dz, dW=b.view(O, 4 * H), need_db=False, need_dx=False, scratch=sc)   # skinny
+        ops.wgrad_fused(x1, None, dp, c, scratch=sc)                                               # [x1 | 1]^T dp
+        ops.wgrad_fused(x2, x1, dz, a, accumulate=True, scratch=sc, dtype=dtype)                   # overlaps the first record
+        ops.wgrad_fused(x1, None, dz, outside, scratch=sc, dtype=dtype)                            # not in the flat buffer
+        for _ in range(20):                                                                        # more records than the table holds
+            ops.wgrad_fused(x1, None, dp, c, accumulate=True, scratch=sc)
+        if arena is not None:
+            ops.reduce_defer_end()
+        torch.cuda.synchronize()
+        return flat.clone(), outside.clone()
+
+    f0, o0 = run(0)
+    for mb in (256, 8):          # 8 MiB: the large products do not fit and are reduced at once, the small ones are deferred
+        f1, o1 = run(mb)
+        assert torch.equal(f0, f1) and torch.equal(o0, o1)
+    ref = torch.cat([x1, x2, torch.ones(N, 1, device="cuda")], 1).double().T @ dz.double() + \
+        torch.cat([x2, x1, torch.ones(N, 1, device="cuda")], 1).double().T @ dz.double()
+    tol = 2e-3 if dtype == "f32" else 0.5
+    assert (f0[:nfused].view(2 * H + 1, 4 * H).double() - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item() / 100)
