@@ -196,6 +196,17 @@ int fov_wgrad_fused(const float* x1, int In1, const float* x2, int In2, const fl
 int fov_lstm_seq_fwd_bf16(const float* x, const float* K, const float* R, const float* b, const float* h0,
                           const float* c0, float* hs, float* hT, float* cT, float* reserve, int B, int T, int F, int H,
                           int act, void* workspace, size_t workspace_bytes, fov_stream_t stream);
+/* BOTH encoder layers of the others-mixing model with bf16 operands in ONE launch, as a wavefront over (layer, step)
+ * (given_others_gt_mean_var_seq2seq.py:108-112: LSTM(F -> 256) then LSTM(256 -> 256), zero initial states): layer 2 runs one
+ * step behind layer 1 on the same CUs and takes its input tile straight from layer 1's exchange granules - T + 1
+ * exchange-bound steps instead of 2 T.  Same results bit for bit as two fov_lstm_seq_fwd_bf16 calls.  H = 256, F <= 96,
+ * T >= 2, at most CUs / 8 tiles of 16 sequences (fov_lstm_stack2_supported_bf16); hs / hT / cT / reserve of either layer may
+ * be NULL; workspace as fov_lstm_seq_fwd_bf16. */
+int fov_lstm_stack2_supported_bf16(int B, int T, int F, int H);
+int fov_lstm_stack2_fwd_bf16(const float* x, const float* K1, const float* R1, const float* b1, const float* K2,
+                             const float* R2, const float* b2, float* hs1, float* hT1, float* cT1, float* reserve1,
+                             float* hs2, float* hT2, float* cT2, float* reserve2, int B, int T, int F, int H, int act,
+                             void* workspace, size_t workspace_bytes, fov_stream_t stream);
 
 /* Backward of fov_mix_decoder_fwd (data path): BPTT through the whole unrolled decoder in ONE persistent launch.
  *   in : M, P (T_out,B,O) from the forward; dloss (T_out,B,O) = dL/d(pre-tanh of m_t) from the loss;

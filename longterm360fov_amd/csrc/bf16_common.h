@@ -54,11 +54,11 @@ __device__ __forceinline__ qu32x4 load_bfrag(const float* __restrict__ W, int ld
 // hardware, so every load is UNCONDITIONAL and hipcc keeps a whole batch in flight.  (Written as `k < nrows ? W[..] :
 // 0` each load sits in its own exec-masked branch with an s_waitcnt vmcnt(0) behind it: 2 500 cycles per fragment,
 // 81 000 cycles = 38 us for the 32 fragments of a layer kernel - tools/stamp_bf16_layer.py.)
-template <int NKB>
+template <int NKB, int CHMAX = 4>
 __device__ __forceinline__ void load_weight_set(qu32x4 (&w)[NKB][2], const float* __restrict__ W, int ld, int nrows, int g4, int col0,
                                                 int col1) {
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(W), 0, nrows * ld * 4, 0x00020000);
-    constexpr int CH = NKB < 4 ? NKB : 4;   // k-blocks per batch: 16*CH loads in flight
+    constexpr int CH = NKB < CHMAX ? NKB : CHMAX;   // k-blocks per batch: 16*CH loads in flight (CHMAX 2: kernels held to 256 registers)
     static_assert(NKB % CH == 0, "NKB must be a multiple of the batch");
 #pragma unroll
     for (int c = 0; c < NKB / CH; ++c) {
@@ -77,6 +77,9 @@ __device__ __forceinline__ void load_weight_set(qu32x4 (&w)[NKB][2], const float
             for (int t = 0; t < 2; ++t)
                 w[c * CH + i][t] = (qu32x4){pack_bf16(v[i][t][0], v[i][t][1]), pack_bf16(v[i][t][2], v[i][t][3]),
                                             pack_bf16(v[i][t][4], v[i][t][5]), pack_bf16(v[i][t][6], v[i][t][7])};
+        // a kernel held to 256 registers: keep the scheduler from hoisting the NEXT batches' loads above this batch's packing
+        // (it clustered all 256 loads of a layer and spilled 34 of them, each behind its own vmcnt(0))
+        if constexpr (CHMAX < 4) __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -291,6 +294,11 @@ __device__ __forceinline__ void q_group_slice(int num_groups, int& group, int& s
 // host side
 int launch_layer_bf16(const LstmParams& p, hipStream_t stream);   // lstm_layer_bf16.hip
 bool layer_bf16_shape_ok(int F, int H);
+// lstm_stack2_bf16.hip: two stacked layers as one wavefront launch (F <= 96 -> 256 -> 256, zero initial state, one tile per group)
+bool stack2_bf16_shape_ok(int B, int T, int F, int H);
+int launch_stack2_bf16(const float* x, const float* K1, const float* R1, const float* b1, const float* K2, const float* R2,
+                       const float* b2, float* hs1, float* hT1, float* cT1, float* res1, float* hs2, float* hT2, float* cT2,
+                       float* res2, int B, int T, int F, int act, void* workspace, hipStream_t stream);
 // lstm_bwd8.hip: BPTT recurrence in groups of eight workgroups (H = 256), fp32 or bf16 operands
 bool bwd8_preferred(int B, int H);
 int launch_bwd8(const float* R, const float* reserve, const float* c0, const float* dhs, const float* dhT, const float* dcT,

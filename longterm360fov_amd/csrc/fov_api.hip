@@ -541,6 +541,28 @@ int fov_lstm_seq_fwd_bf16(const float* x, const float* K, const float* R, const 
     return launch_layer_bf16(p, (hipStream_t)stream);
 }
 
+int fov_lstm_stack2_supported_bf16(int B, int T, int F, int H) { return stack2_bf16_shape_ok(B, T, F, H) ? 1 : 0; }
+
+int fov_lstm_stack2_fwd_bf16(const float* x, const float* K1, const float* R1, const float* b1, const float* K2, const float* R2,
+                             const float* b2, float* hs1, float* hT1, float* cT1, float* reserve1, float* hs2, float* hT2,
+                             float* cT2, float* reserve2, int B, int T, int F, int H, int act, void* workspace,
+                             size_t workspace_bytes, fov_stream_t stream) {
+    if (B < 0 || T < 0 || F <= 0 || !K1 || !R1 || !b1 || !K2 || !R2 || !b2 || (B > 0 && T > 0 && !x) ||
+        (act != FOV_ACT_SIGMOID && act != FOV_ACT_HARD_SIGMOID)) {
+        set_error("fov_lstm_stack2_fwd_bf16: invalid argument");
+        return FOV_ERR_INVALID;
+    }
+    if (B == 0) return FOV_OK;
+    if (!stack2_bf16_shape_ok(B, T, F, H)) {
+        set_error("fov_lstm_stack2_fwd_bf16: H = 256, F <= 96, T >= 2 and one 16-sequence tile per group of eight workgroups only");
+        return FOV_ERR_UNSUPPORTED;
+    }
+    int rc = check_ws(workspace, workspace_bytes, kStatusBytes + kXchBytes);
+    if (rc) return rc;
+    return launch_stack2_bf16(x, K1, R1, b1, K2, R2, b2, hs1, hT1, cT1, reserve1, hs2, hT2, cT2, reserve2, B, T, F, act, workspace,
+                              (hipStream_t)stream);
+}
+
 int fov_lstm_seq_fwd_zx(const float* zx, const float* R, const float* b, const float* h0, const float* c0, float* hs,
                         float* hT, float* cT, float* reserve, int B, int T, int H, int act, int impl, void* workspace,
                         size_t workspace_bytes, fov_stream_t stream) {

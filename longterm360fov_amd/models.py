@@ -1055,10 +1055,15 @@ class OthersMixingSeq2Seq(KerasModelSurface):
         B, T_in = e.shape[0], e.shape[1]
         T_out = oth.shape[1]
         if self.dtype == "bf16":   # configs[4]: both encoder layers and the fused decoder with bf16 matrix-core operands
-            hs1, h1, c1, _ = ops.lstm_seq_bf16(e, dw["enc1_K"], dw["enc1_R"], dw["enc1_b"], act=act, workspace=ws, reserve=False)
             e3 = lambda *s_: torch.empty(s_, dtype=torch.float32, device=self.device)
-            _, h2, c2, _ = ops.lstm_seq_bf16(hs1, dw["enc2_K"], dw["enc2_R"], dw["enc2_b"], act=act, workspace=ws,
-                                             out=(None, e3(B, H), e3(B, H), None))
+            if ops.lstm_stack2_bf16_supported(B, T_in, e.shape[2], H):   # one wavefront launch for the two layers (only the final states leave)
+                (_, h1, c1, _), (_, h2, c2, _) = ops.lstm_stack2_bf16(
+                    e, (dw["enc1_K"], dw["enc1_R"], dw["enc1_b"]), (dw["enc2_K"], dw["enc2_R"], dw["enc2_b"]), act=act, workspace=ws,
+                    out1=(None, e3(B, H), e3(B, H), None), out2=(None, e3(B, H), e3(B, H), None))
+            else:
+                hs1, h1, c1, _ = ops.lstm_seq_bf16(e, dw["enc1_K"], dw["enc1_R"], dw["enc1_b"], act=act, workspace=ws, reserve=False)
+                _, h2, c2, _ = ops.lstm_seq_bf16(hs1, dw["enc2_K"], dw["enc2_R"], dw["enc2_b"], act=act, workspace=ws,
+                                                 out=(None, e3(B, H), e3(B, H), None))
             oth_proj = ops.dense(oth.reshape(B * T_out, -1), dw["mix_W_oth"], dw["mix_b"], activation=None).reshape(B, T_out, O)
             out = torch.empty((T_out, B, O), dtype=torch.float32, device=self.device)
             ops.mix_decoder(xin, h1, c1, h2, c2, oth_proj, dw, dw["mix_W_pred"], T_out, act=act, workspace=ws, out=out, dtype="bf16")

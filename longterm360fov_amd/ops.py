@@ -272,6 +272,32 @@ def lstm_seq_bf16(x, K, R, b, h0=None, c0=None, act="sigmoid", workspace=None, o
     return hs, hT, cT, res
 
 
+def lstm_stack2_bf16_supported(B, T, F, H):
+    return os.environ.get("FOV_NO_STACK2", "") != "1" and bool(_lib.lib().fov_lstm_stack2_supported_bf16(B, T, F, H))
+
+
+def lstm_stack2_bf16(x, layer1, layer2, act="sigmoid", workspace=None, out1=None, out2=None, reserve=True):
+    """Two stacked bf16 LSTM layers (zero initial states) as ONE wavefront launch: layer = (K, R, b); out1 / out2 may carry
+    preallocated (hs, hT, cT, reserve) of the layer (None entries are not written).  -> (out1, out2)."""
+    x = _dev(x, "x")
+    K1, R1, b1 = (_dev(t, "layer1") for t in layer1)
+    K2, R2, b2 = (_dev(t, "layer2") for t in layer2)
+    B, T, F = x.shape
+    H = R1.shape[0]
+    e = lambda *s: torch.empty(s, dtype=torch.float32, device=x.device)
+    if out1 is None:
+        out1 = (e(B, T, H), e(B, H), e(B, H), e(B, T, 5, H) if reserve else None)
+    if out2 is None:
+        out2 = (e(B, T, H), e(B, H), e(B, H), e(B, T, 5, H) if reserve else None)
+    L = _lib.lib()
+    ws = (workspace or default_workspace(x.device))
+    buf = ws.get(L.fov_lstm_seq_workspace_bytes(B, T, 128, 256, IMPL_CLUSTER), x.device)
+    check(L.fov_lstm_stack2_fwd_bf16(_ptr(x), _ptr(K1), _ptr(R1), _ptr(b1), _ptr(K2), _ptr(R2), _ptr(b2),
+                                     *[_ptr(t) for t in out1], *[_ptr(t) for t in out2], B, T, F, H, act_code(act),
+                                     buf.data_ptr(), buf.numel(), _stream()))
+    return out1, out2
+
+
 def lstm_seq_train(x, K, R, b, h0=None, c0=None, act="sigmoid", impl="auto", workspace=None, out=None, dtype="f32"):
     """Forward that also returns the reserve (B,T,5,H).  `out` may carry preallocated
     (hs, hT, cT, reserve) tensors.  -> (hs, hT, cT, reserve).  dtype 'bf16': bf16 matrix-core operands."""

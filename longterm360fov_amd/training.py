@@ -858,9 +858,17 @@ class OthersMixingTrainer(FlatParamTrainer):
         H1, C1 = e(T_out + 1, B, H), e(T_out + 1, B, H)
         H2, C2 = e(T_out + 1, B, H), e(T_out + 1, B, H)
         dt = self.dtype
-        hs1, h1, c1, res1 = ops.lstm_seq_train(enc, w["enc1_K"], w["enc1_R"], w["enc1_b"], act=act, impl=impl, workspace=ws,
-                                               out=(e(B, T_in, H), H1[0], C1[0], e(B, T_in, 5, H)), dtype=dt)
-        if H == 256 and impl != "generic":   # layer 2 over the 256-wide sequence: K2 and R2 register-resident
+        stacked = dt == "bf16" and impl != "generic" and ops.lstm_stack2_bf16_supported(B, T_in, enc.shape[2], H)
+        if stacked:   # both encoder layers as ONE wavefront launch (layer 2 one step behind layer 1 on the same CUs): same tensors
+            (hs1, h1, c1, res1), (hs2, h2, c2, res2) = ops.lstm_stack2_bf16(
+                enc, (w["enc1_K"], w["enc1_R"], w["enc1_b"]), (w["enc2_K"], w["enc2_R"], w["enc2_b"]), act=act, workspace=ws,
+                out1=(e(B, T_in, H), H1[0], C1[0], e(B, T_in, 5, H)), out2=(e(B, T_in, H), H2[0], C2[0], e(B, T_in, 5, H)))
+        else:
+            hs1, h1, c1, res1 = ops.lstm_seq_train(enc, w["enc1_K"], w["enc1_R"], w["enc1_b"], act=act, impl=impl, workspace=ws,
+                                                   out=(e(B, T_in, H), H1[0], C1[0], e(B, T_in, 5, H)), dtype=dt)
+        if stacked:
+            pass
+        elif H == 256 and impl != "generic":   # layer 2 over the 256-wide sequence: K2 and R2 register-resident
             hs2, h2, c2, res2 = ops.lstm_seq_train(hs1, w["enc2_K"], w["enc2_R"], w["enc2_b"], act=act, impl=impl, workspace=ws,
                                                    out=(e(B, T_in, H), H2[0], C2[0], e(B, T_in, 5, H)), dtype=dt)
         else:

@@ -254,3 +254,35 @@ def test_bf16_mixing_training_step(B, U, T_in, T_out, act):
     for _ in range(3):
         l32 = float(t32.train_step(dev(enc), dev(oth), dev(dec0), dev(tgt)).item())
     assert abs(l - l32) <= 2e-2 * l32
+
+
+@pytest.mark.parametrize("B,T,F,act", [(512, 10, 90, "sigmoid"), (37, 5, 33, "hard_sigmoid"), (100, 2, 96, "sigmoid"), (16, 7, 6, "sigmoid")])
+def test_bf16_two_layer_wavefront_equals_two_launches(B, T, F, act):
+    """fov_lstm_stack2_fwd_bf16 (lstm_stack2_bf16.hip): both encoder layers of the others-mixing model in ONE launch, layer 2
+    one step behind layer 1 on the same CUs, its input tile taken from layer 1's exchange granules - against two
+    fov_lstm_seq_fwd_bf16 calls: hidden sequences, final states and the training tapes of BOTH layers bit for bit (the bf16
+    input of layer 2 is the same rounding of the same fp32 values); ragged batches, the shortest sequence (T = 2), calls
+    without tapes, repeated calls on one workspace."""
+    from longterm360fov_amd import ops
+    H = 256
+    rng = np.random.default_rng(B + T)
+    l1 = O.init_lstm(rng, F, H, np.float32)
+    l2 = O.init_lstm(rng, H, H, np.float32)
+    d1 = tuple(dev(a) for a in l1)
+    d2 = tuple(dev(a) for a in l2)
+    x = dev(rng.uniform(-1, 1, (B, T, F)).astype(np.float32))
+    assert ops.lstm_stack2_bf16_supported(B, T, F, H)
+    ws = ops.Workspace()
+    hs1, h1, c1, r1 = ops.lstm_seq_bf16(x, *d1, act=act, workspace=ws)
+    hs2, h2, c2, r2 = ops.lstm_seq_bf16(hs1, *d2, act=act, workspace=ws)
+    ws.check()
+    for rep in range(3):
+        o1, o2 = ops.lstm_stack2_bf16(x, d1, d2, act=act, workspace=ws)
+        ws.check()
+        for got, ref, tag in zip(o1 + o2, (hs1, h1, c1, r1, hs2, h2, c2, r2), ("hs1", "hT1", "cT1", "res1", "hs2", "hT2", "cT2", "res2")):
+            assert torch.equal(got, ref), (tag, rep, (got - ref).abs().max().item())
+    # inference form: only the final states and layer 1's sequence are wanted
+    e = lambda *s: torch.empty(s, dtype=torch.float32, device="cuda")
+    o1, o2 = ops.lstm_stack2_bf16(x, d1, d2, act=act, workspace=ws, out1=(None, e(B, H), e(B, H), None), out2=(None, e(B, H), e(B, H), None))
+    ws.check()
+    assert torch.equal(o1[1], h1) and torch.equal(o1[2], c1) and torch.equal(o2[1], h2) and torch.equal(o2[2], c2)
