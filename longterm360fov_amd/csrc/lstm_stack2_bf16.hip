@@ -144,16 +144,26 @@ __device__ __forceinline__ void stack2_body(const Stack2Params& p, unsigned shor
     unsigned short* xl = sX + xrw * QLD + xc;
     float xs[NXE];
     // all eight slices of the producer's tile `slot` into the x image (consumer); returns false after a give-up
-    auto gather_x = [&](int slot) {
+    // (the first sweep is REQUESTED by gather_x_issue together with the own exchange's gather, so the two round trips overlap)
+    qu32x2 xg[8];
+    auto gather_x_issue = [&](int slot) {
+        const unsigned sbase = (unsigned)slot * Q_TILE_BYTES;
+        const unsigned voff = (unsigned)((tid >> 5) * QH + (tid & 31)) * 8u;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xg[j] = __builtin_amdgcn_raw_buffer_load_b64(ring, voff, sbase + (unsigned)(j * 32) * 8u, 16);
+    };
+    auto gather_x = [&](int slot, bool issued) {
         const unsigned tag = base + 1u + (unsigned)slot;
         const unsigned sbase = (unsigned)slot * Q_TILE_BYTES;
         const unsigned voff = (unsigned)((tid >> 5) * QH + (tid & 31)) * 8u;
         const int lbase = (tid >> 5) * 2 * QLD + (tid & 31);
         unsigned bad = 0xffu, spins = 0;
+        bool first = issued;
         while (true) {
             qu32x2 tv[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) tv[j] = __builtin_amdgcn_raw_buffer_load_b64(ring, voff, sbase + (unsigned)(j * 32) * 8u, 16);
+            for (int j = 0; j < 8; ++j) tv[j] = first ? xg[j] : __builtin_amdgcn_raw_buffer_load_b64(ring, voff, sbase + (unsigned)(j * 32) * 8u, 16);
+            first = false;
 #pragma unroll
             for (int j = 0; j < 8; ++j)
                 if (((bad >> j) & 1u) && tv[j].y == tag) {
@@ -182,7 +192,7 @@ __device__ __forceinline__ void stack2_body(const Stack2Params& p, unsigned shor
         for (int i = 0; i < NXE; ++i)
             if (xc + 16 * i < F) xl[16 * i] = bf16_bits(v1[i]);
     } else {
-        if (!aborted && steps > 0 && !gather_x(0)) sFlag[0] = 1;
+        if (!aborted && steps > 0 && !gather_x(0, false)) sFlag[0] = 1;
     }
     __syncthreads();
     if (sFlag[0]) aborted = true;
@@ -234,6 +244,9 @@ __device__ __forceinline__ void stack2_body(const Stack2Params& p, unsigned shor
             for (int i = 0; i < NXE; ++i) xs[i] = load_x1(i, t + 2 < steps ? t + 2 : t);
         }
         if (more) q_gather_issue(gq, ROLE == 0 ? ring : own, goff, slice, tid);
+        if constexpr (ROLE == 1) {
+            if (more) gather_x_issue(t + 1);
+        }
 #pragma unroll
         for (int r = 0; r < 2; ++r) {   // tape of the step, under the gather's round trip
             const int row = b0 + my_row0 + r;
@@ -248,7 +261,7 @@ __device__ __forceinline__ void stack2_body(const Stack2Params& p, unsigned shor
         if (more) {
             if (!q_gather_finish(gq, ROLE == 0 ? ring : own, goff, slice, tid, epoch, sH, p.status)) sFlag[0] = 1;
             if constexpr (ROLE == 1) {
-                if (!gather_x(t + 1)) sFlag[0] = 1;     // the producer's tile t + 1 (it runs one step ahead)
+                if (!gather_x(t + 1, true)) sFlag[0] = 1;     // the producer's tile t + 1 (it runs one step ahead)
             }
         }
         __syncthreads();   // barrier 2: h_t and x_{t+1} are in LDS
