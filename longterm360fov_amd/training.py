@@ -941,18 +941,20 @@ class OthersMixingTrainer(FlatParamTrainer):
         # latency-bound persistent kernels (one workgroup per CU, ~300 of 512 registers, matrix pipe a quarter busy) that leave
         # room for GEMM workgroups on the same CUs: the products go to a SIDE stream and run under them
         # (FOV_WGRAD_STREAM=0: in line).  The step's deferred reduce and the optimizer wait for the side stream.
-        def decoder_wgrads():
-            # head: dense_W, dense_b, mix_W (others' rows and the prediction's), mix_b are adjacent in the flat buffer - one
-            # launch and one reduce form all four, reading `others` in the (B,T,...) layout it arrived in
-            ops.mix_head_wgrad(H2[1:], dpre_p_all, others, P, dpre_all, self._span("dense_W", "mix_b"), accumulate=acc, scratch=sc)
-            # a layer's kernel, recurrent kernel and bias are adjacent in the flat buffer: [h1_t | h2_{t-1} | 1]^T dz2 is ONE
-            # product + one reduce (dz2 read once), [h1_{t-1} | 1]^T dz1 likewise; the 6-wide dK1 stays a skinny product
-            ops.wgrad_fused(fl(H1[1:], H), fl(H2[:T_out], H), fl(DZ2, 4 * H), self._span("dec2_K", "dec2_b"), accumulate=acc,
-                            scratch=sc, dtype=dt)
-            ops.dense_bwd(fl(X, O), w["dec1_K"], fl(DZ1, 4 * H), dW=g["dec1_K"], need_db=False, need_dx=False,
-                          accumulate=acc, scratch=sc)
-            ops.wgrad_fused(fl(H1[:T_out], H), None, fl(DZ1, 4 * H), self._span("dec1_R", "dec1_b"), accumulate=acc, scratch=sc,
-                            dtype=dt)
+        def decoder_wgrads(part):
+            if part & 1:
+                # head: dense_W, dense_b, mix_W (others' rows and the prediction's), mix_b are adjacent in the flat buffer - one
+                # launch and one reduce form all four, reading `others` in the (B,T,...) layout it arrived in
+                ops.mix_head_wgrad(H2[1:], dpre_p_all, others, P, dpre_all, self._span("dense_W", "mix_b"), accumulate=acc, scratch=sc)
+                # a layer's kernel, recurrent kernel and bias are adjacent in the flat buffer: [h1_t | h2_{t-1} | 1]^T dz2 is ONE
+                # product + one reduce (dz2 read once), [h1_{t-1} | 1]^T dz1 likewise; the 6-wide dK1 stays a skinny product
+                ops.wgrad_fused(fl(H1[1:], H), fl(H2[:T_out], H), fl(DZ2, 4 * H), self._span("dec2_K", "dec2_b"), accumulate=acc,
+                                scratch=sc, dtype=dt)
+            if part & 2:
+                ops.dense_bwd(fl(X, O), w["dec1_K"], fl(DZ1, 4 * H), dW=g["dec1_K"], need_db=False, need_dx=False,
+                              accumulate=acc, scratch=sc)
+                ops.wgrad_fused(fl(H1[:T_out], H), None, fl(DZ1, 4 * H), self._span("dec1_R", "dec1_b"), accumulate=acc, scratch=sc,
+                                dtype=dt)
         side = self._wgrad_side_stream() if not (self._dp and self.overlap_allreduce) else None
         # the first step of a shape runs in line: the products' scratch buffer grows to its final size on THIS stream (a buffer
         # replaced while the side stream still reads the old one could be handed to another tensor)
@@ -961,12 +963,15 @@ class OthersMixingTrainer(FlatParamTrainer):
             self._side_warm.add(shape_key)
             side = None
         main = torch.cuda.current_stream()
+        # bf16: the products are short enough to be dealt under BOTH recurrences (half under layer 2's, half under layer 1's:
+        # 0.506 -> 0.500 ms); fp32: all under layer 2's (dealt: 0.846 -> 0.859 ms).  FOV_WGRAD_SPLIT=0/1 overrides.
+        split_side = side is not None and os.environ.get("FOV_WGRAD_SPLIT", "1" if dt == "bf16" else "0") == "1"
         if side is None:
-            decoder_wgrads()
+            decoder_wgrads(3)
         else:
             side.wait_stream(main)
             with torch.cuda.stream(side):
-                decoder_wgrads()
+                decoder_wgrads(1 if split_side else 3)
         self.grads_final("dec1_K")    # decoder, heads and loss: all-reduced under the encoder's BPTT
         # encoder: layer 2 over hs1 (its dx is the dhs of layer 1), then layer 1
         # (tried: each encoder layer in two parts, its weight-gradient products on the side stream under the NEXT layer's
@@ -974,6 +979,10 @@ class OthersMixingTrainer(FlatParamTrainer):
         # recurrences slow down more than the products gain)
         e2 = ops.lstm_seq_bwd(hs1, w["enc2_K"], w["enc2_R"], hs2, res2, dhT=dh2_rec, dcT=dc2, dK=g["enc2_K"], dR=g["enc2_R"],
                               db=g["enc2_b"], need_dx=True, act=act, accumulate=acc, scratch=bsc, dtype=dt)
+        if split_side:   # the second half of the decoder's products under layer 1's recurrence
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                decoder_wgrads(2)
         ops.lstm_seq_bwd(enc, w["enc1_K"], w["enc1_R"], hs1, res1, dhs=e2["dx"], dhT=dh1_rec, dcT=dc1, dK=g["enc1_K"],
                          dR=g["enc1_R"], db=g["enc1_b"], act=act, accumulate=acc, scratch=bsc, dtype=dt)
         if side is not None:
