@@ -218,6 +218,13 @@ int fov_lstm_stack2_fwd_bf16(const float* x, const float* K1, const float* R1, c
  *        w.r.t. the decoder's initial state (= the encoder's final state).
  * Supported: H = 256, O <= 8. */
 size_t fov_mix_decoder_bwd_workspace_bytes(int B, int H);
+/* The fp32 fused decoder kernels keep a fragment-ordered copy of dec2_K in their workspaces, packed at every launch (the
+ * weights change every optimizer step).  The pack depends on the weights only: this call runs it for the forward and / or
+ * the backward workspace (either may be NULL) on `stream` - a side stream, under the encoder layers - and marks the
+ * workspaces; the NEXT fov_mix_decoder_fwd / _bwd on a marked workspace with the same dec2_K skips its own pack.  The caller
+ * orders the streams (the launch must come behind the pack). */
+int fov_mix_decoder_prepack(const float* dec2_K, void* workspace_fwd, size_t fwd_bytes, void* workspace_bwd, size_t bwd_bytes,
+                            int H, fov_stream_t stream);
 int fov_mix_decoder_bwd(const float* M, const float* P, const float* dloss, const float* res1, const float* res2,
                         const float* C1, const float* C2, const float* dec1_K, const float* dec1_R,
                         const float* dec2_K, const float* dec2_R, const float* dense_W, const float* mix_Wp,

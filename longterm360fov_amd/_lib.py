@@ -80,6 +80,7 @@ SIGNATURES = {
     "fov_rmsprop_step": (_I, [_P] * 3 + [ctypes.c_int64] + [ctypes.c_float] * 3 + [_P]),
     "fov_lstm_stack2_supported_bf16": (_I, [_I] * 4),
     "fov_lstm_stack2_fwd_bf16": (_I, [_P] * 15 + [_I] * 5 + [_P, ctypes.c_size_t, _P]),
+    "fov_mix_decoder_prepack": (_I, [_P, _P, ctypes.c_size_t, _P, ctypes.c_size_t, _I, _P]),
     "fov_guard_flag": (_I, [_P] * 5),
     "fov_reduce_defer_begin": (_I, [_P, ctypes.c_size_t, _P, ctypes.c_size_t, _P]),
     "fov_reduce_defer_flush": (_I, [_P]),

@@ -416,6 +416,21 @@ void xch_set_epoch_for_test(void* workspace, unsigned long long epoch) {
     g_xch[workspace].epoch = epoch;
 }
 
+static std::unordered_map<void*, const float*> g_prepacked;
+static std::mutex g_prepacked_mu;
+void prepack_mark(void* workspace, const float* K2) {
+    std::lock_guard<std::mutex> lock(g_prepacked_mu);
+    g_prepacked[workspace] = K2;
+}
+bool prepack_consume(void* workspace, const float* K2) {
+    std::lock_guard<std::mutex> lock(g_prepacked_mu);
+    auto it = g_prepacked.find(workspace);
+    if (it == g_prepacked.end()) return false;
+    const bool hit = it->second == K2;
+    g_prepacked.erase(it);
+    return hit;
+}
+
 }  // namespace fov
 
 using namespace fov;
@@ -1005,6 +1020,21 @@ static int mix_decoder_bwd_impl(const float* M, const float* P, const float* dlo
     p.B = B; p.T_out = T_out; p.O = O;
     return bf16 ? mix_decoder_bwd_bf16_launch(p, dec2_K, act, workspace, (hipStream_t)stream)
                 : mix_decoder_bwd_launch(p, dec2_K, act, workspace, (hipStream_t)stream);
+}
+
+int fov_mix_decoder_prepack(const float* dec2_K, void* workspace_fwd, size_t fwd_bytes, void* workspace_bwd, size_t bwd_bytes, int H,
+                            fov_stream_t stream) {
+    if (!dec2_K || H != 256) { set_error("fov_mix_decoder_prepack: invalid argument (H = 256)"); return FOV_ERR_INVALID; }
+    int rc = FOV_OK;
+    if (workspace_fwd) {
+        rc = check_ws(workspace_fwd, fwd_bytes, mix_decoder_workspace_bytes(1));
+        if (!rc) rc = mix_decoder_prepack(dec2_K, workspace_fwd, (hipStream_t)stream);
+    }
+    if (!rc && workspace_bwd) {
+        rc = check_ws(workspace_bwd, bwd_bytes, mix_decoder_bwd_workspace_bytes(1));
+        if (!rc) rc = mix_decoder_bwd_prepack(dec2_K, workspace_bwd, (hipStream_t)stream);
+    }
+    return rc;
 }
 
 int fov_mix_decoder_bwd(const float* M, const float* P, const float* dloss, const float* res1, const float* res2,

@@ -165,6 +165,11 @@ struct MixDecParams {
     int B, T_out, O, num_groups, num_tiles;
     int epoch_span;          // epochs this launch may consume (xch_common.h)
 };
+// one-shot marks 'the packed K2 of this workspace is current' (fov_api.hip)
+void prepack_mark(void* workspace, const float* K2);
+bool prepack_consume(void* workspace, const float* K2);
+int mix_decoder_prepack(const float* K2, void* workspace, hipStream_t stream);
+int mix_decoder_bwd_prepack(const float* K2, void* workspace, hipStream_t stream);
 size_t mix_decoder_workspace_bytes(int B);
 int mix_decoder_launch(MixDecParams p, const float* K2, int act, int train, void* workspace, hipStream_t stream);
 int mix_decoder_bf16_launch(MixDecParams p, const float* K2, int act, int train, void* workspace, hipStream_t stream);   // mix_decoder_bf16.hip

@@ -521,6 +521,17 @@ size_t mix_decoder_workspace_bytes(int B) {
     return kStatusBytes + kXchBytes + sizeof(float) * (size_t)MH * 4 * MH;
 }
 
+// The packed copy of K2 depends on the weights only: a caller that runs it ahead of time (on a side stream, while the
+// encoder layers run) calls this, then orders the streams, then launches - the launch finds the mark and skips its own pack.
+int mix_decoder_prepack(const float* K2, void* workspace, hipStream_t stream) {
+    float* k2p = (float*)((char*)workspace + kStatusBytes + kXchBytes);
+    hipLaunchKernelGGL(mix_decoder_pack_k2_kernel, dim3(MH * 4 * MH / 256), dim3(256), 0, stream, K2, k2p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_error("mix_decoder_prepack launch: %s", hipGetErrorString(e)); return FOV_ERR_LAUNCH; }
+    prepack_mark(workspace, K2);
+    return FOV_OK;
+}
+
 int mix_decoder_launch(MixDecParams p, const float* K2, int act, int train, void* workspace, hipStream_t stream) {
     if (p.B == 0 || p.T_out == 0) return FOV_OK;
     p.num_tiles = (p.B + MBT - 1) / MBT;
@@ -534,7 +545,8 @@ int mix_decoder_launch(MixDecParams p, const float* K2, int act, int train, void
     p.K2p = k2p;
     p.epoch_span = p.T_out * ((p.num_tiles + p.num_groups - 1) / p.num_groups) + 1;   // no memset: tags continue from the header
     if (int rc_ = xch_account(p.status, p.epoch_span, stream)) return rc_;
-    hipLaunchKernelGGL(mix_decoder_pack_k2_kernel, dim3(MH * 4 * MH / 256), dim3(256), 0, stream, K2, k2p);
+    // the packed copy may already be there: mix_decoder_prepack (another stream, under the encoder) marks the workspace for ONE launch
+    if (!prepack_consume(workspace, K2)) hipLaunchKernelGGL(mix_decoder_pack_k2_kernel, dim3(MH * 4 * MH / 256), dim3(256), 0, stream, K2, k2p);
     const size_t lds = sizeof(float) * (2 * MBT * MLDH + MBT * 8 + MH * 8 + 64 + 16 + 4 * 256 + 4 * 28 * 256);
     void (*kern)(MixDecParams) = nullptr;
     if (act == FOV_ACT_HARD_SIGMOID) kern = train ? mix_decoder_kernel<FOV_ACT_HARD_SIGMOID, true> : mix_decoder_kernel<FOV_ACT_HARD_SIGMOID, false>;

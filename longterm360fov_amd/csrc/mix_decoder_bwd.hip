@@ -502,6 +502,17 @@ size_t mix_decoder_bwd_workspace_bytes(int B) {
     return kStatusBytes + kXchBytes + sizeof(float) * (size_t)BH * 4 * BH;
 }
 
+// The packed copy of K2 depends on the weights only: a caller that runs it ahead of time (on a side stream, while the
+// encoder layers run) calls this, then orders the streams, then launches - the launch finds the mark and skips its own pack.
+int mix_decoder_bwd_prepack(const float* K2, void* workspace, hipStream_t stream) {
+    float* k2p = (float*)((char*)workspace + kStatusBytes + kXchBytes);
+    hipLaunchKernelGGL(mix_decoder_bwd_pack_k2_kernel, dim3(BH * 4 * BH / 256), dim3(256), 0, stream, K2, k2p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_error("mix_decoder_bwd_prepack launch: %s", hipGetErrorString(e)); return FOV_ERR_LAUNCH; }
+    prepack_mark(workspace, K2);
+    return FOV_OK;
+}
+
 int mix_decoder_bwd_launch(MixDecBwdParams p, const float* K2, int act, void* workspace, hipStream_t stream) {
     if (p.B == 0 || p.T_out == 0) return FOV_OK;
     p.num_tiles = (p.B + BBT - 1) / BBT;
@@ -515,7 +526,8 @@ int mix_decoder_bwd_launch(MixDecBwdParams p, const float* K2, int act, void* wo
     p.K2p = k2p;
     p.epoch_span = p.T_out * ((p.num_tiles + p.num_groups - 1) / p.num_groups) + 1;   // no memset: tags continue from the header
     if (int rc_ = xch_account(p.status, p.epoch_span, stream)) return rc_;
-    hipLaunchKernelGGL(mix_decoder_bwd_pack_k2_kernel, dim3(BH * 4 * BH / 256), dim3(256), 0, stream, K2, k2p);
+    // the packed copy may already be there: mix_decoder_bwd_prepack (another stream, under the encoder) marks the workspace for ONE launch
+    if (!prepack_consume(workspace, K2)) hipLaunchKernelGGL(mix_decoder_bwd_pack_k2_kernel, dim3(BH * 4 * BH / 256), dim3(256), 0, stream, K2, k2p);
     const size_t lds = sizeof(float) * (BBT * BLDZ + BBT * 8 + BBT * 8 + 128 * 8 + 16 + 4 * BK2_LDS_BLOCKS * 256);
     void (*kern)(MixDecBwdParams) = act == FOV_ACT_HARD_SIGMOID ? mix_decoder_bwd_kernel<FOV_ACT_HARD_SIGMOID> : mix_decoder_bwd_kernel<FOV_ACT_SIGMOID>;
     int rc = ensure_dynamic_lds((const void*)kern, lds);

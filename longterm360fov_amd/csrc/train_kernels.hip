@@ -460,10 +460,11 @@ bool defer_overlaps(const float* out, size_t n) {
 }
 int defer_flush_locked(hipStream_t stream) {
     DeferTable& t = g_defer.table;
-    if (t.count == 0) { g_defer.used = 0; return FOV_OK; }
+    if (t.count == 0) return FOV_OK;
     hipLaunchKernelGGL(splitk_reduce_batch_kernel, dim3((unsigned)t.blocks), dim3(256), 0, stream, t);
     t.count = 0; t.blocks = 0;
-    g_defer.used = 0;     // stream order: the next product's slices are written behind this launch
+    // the arena is NOT rewound here: a caller may flush on one stream (its products run on a side stream) and go on recording
+    // on another - slices are written once per begin ... end, what does not fit any more is reduced at once
     return check_launch("splitk_reduce_batch");
 }
 }  // namespace
@@ -485,6 +486,7 @@ int defer_end(hipStream_t stream) {
     std::lock_guard<std::mutex> lock(g_defer_mu);
     int rc = g_defer.active ? defer_flush_locked(stream) : FOV_OK;
     g_defer.active = false;
+    g_defer.used = 0;
     return rc;
 }
 // A producer is about to write [out, out + n) (directly, or through an immediate reduce): pending records over that range
@@ -500,10 +502,8 @@ float* defer_alloc(const float* out, size_t n, size_t floats, hipStream_t stream
     if (!g_defer.active || out < g_defer.gbase || out + n > g_defer.gend) return nullptr;
     if (g_defer.table.count > 0 && defer_overlaps(out, n)) { if (defer_flush_locked(stream)) return nullptr; }
     const size_t need = (floats + 63) & ~(size_t)63;
-    if (g_defer.table.count == kDeferMax || g_defer.used + need > g_defer.arena_floats) {
-        if (defer_flush_locked(stream)) return nullptr;
-        if (need > g_defer.arena_floats) return nullptr;
-    }
+    if (g_defer.table.count == kDeferMax && defer_flush_locked(stream)) return nullptr;
+    if (g_defer.used + need > g_defer.arena_floats) return nullptr;   // arena exhausted for this step: reduce at once
     float* p = g_defer.arena + g_defer.used;
     g_defer.used += need;
     return p;

@@ -658,6 +658,17 @@ def mix_decoder(dec0, h1, c1, h2, c2, oth_proj, w, mix_Wp, T_out, act="sigmoid",
     return out
 
 
+def mix_decoder_prepack(dec2_K, B, H, workspace=None, workspace_bwd=None):
+    """Pack dec2_K for the fused fp32 decoder kernels ahead of their launches (current stream: a side stream under the
+    encoder); the next mix_decoder / mix_decoder_bwd on these workspaces skips its own pack."""
+    L = _lib.lib()
+    dec2_K = _dev(dec2_K, "dec2_K")
+    bf = workspace.get(L.fov_mix_decoder_workspace_bytes(B, H), dec2_K.device) if workspace is not None else None
+    bb = workspace_bwd.get(L.fov_mix_decoder_bwd_workspace_bytes(B, H), dec2_K.device) if workspace_bwd is not None else None
+    check(L.fov_mix_decoder_prepack(_ptr(dec2_K), None if bf is None else bf.data_ptr(), 0 if bf is None else bf.numel(),
+                                    None if bb is None else bb.data_ptr(), 0 if bb is None else bb.numel(), H, _stream()))
+
+
 def mix_decoder_bwd(M, P, dloss, res1, res2, C1, C2, w, mix_Wp, out, act="sigmoid", workspace=None, dtype="f32"):
     """BPTT through the unrolled decoder in one launch.  M, P, dloss (T_out,B,O); res1, res2 (T_out,B,5,H); C1, C2
     (>= T_out rows of (B,H), row t = cell state before step t); out: dict with preallocated DZ1, DZ2 (T_out,B,4H),

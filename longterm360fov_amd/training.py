@@ -858,6 +858,26 @@ class OthersMixingTrainer(FlatParamTrainer):
         H1, C1 = e(T_out + 1, B, H), e(T_out + 1, B, H)
         H2, C2 = e(T_out + 1, B, H), e(T_out + 1, B, H)
         dt = self.dtype
+        # What depends on the inputs and the weights alone - the others' projection, the decoder's first input row, the fp32
+        # fused kernels' packed copy of dec2_K - runs on the SIDE stream while the encoder layers run here (four launches of
+        # 5-7 us each that used to sit between the encoder and the decoder).  Outputs are allocated on this stream.
+        fused = self.fused_decoder and ops.mix_decoder_supported(H, O)
+        fused_bwd = self.fused_decoder_bwd and ops.mix_decoder_supported(H, O)
+        XM = e(T_out + 1, B, O)                               # row t = decoder input x_t, row t+1 = output m_t
+        oth_proj_buf = e(B * T_out, O)
+        oth_flat = others.reshape(B * T_out, n_oth)
+        Wm_o_c, Wm_p_c = Wm_o.contiguous(), Wm_p.contiguous()
+
+        def input_side_work():
+            ops.dense(oth_flat, Wm_o_c, w["mix_b"], activation=None, out=oth_proj_buf)
+            XM[0].copy_(dec0.reshape(B, O))
+            if dt != "bf16" and (fused or fused_bwd):
+                ops.mix_decoder_prepack(w["dec2_K"], B, H, ws if fused else None, self.ws_bwd if fused_bwd else None)
+        side_in = self._wgrad_side_stream() if (B, T_in, T_out, dt) in self._side_warm else None
+        if side_in is not None:
+            side_in.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side_in):
+                input_side_work()
         stacked = dt == "bf16" and impl != "generic" and ops.lstm_stack2_bf16_supported(B, T_in, enc.shape[2], H)
         if stacked:   # both encoder layers as ONE wavefront launch (layer 2 one step behind layer 1 on the same CUs): same tensors
             (hs1, h1, c1, res1), (hs2, h2, c2, res2) = ops.lstm_stack2_bf16(
@@ -876,17 +896,16 @@ class OthersMixingTrainer(FlatParamTrainer):
             res2 = torch.empty((B, T_in, 5, H), dtype=torch.float32, device=self.device)
             hs2, h2, c2 = ops.lstm_seq_zx(zx2, w["enc2_R"], w["enc2_b"], act=act, impl=impl, workspace=ws, reserve=res2,
                                           out=(e(B, T_in, H), H2[0], C2[0]))
-        oth_flat = others.reshape(B * T_out, n_oth)
-        Wm_o_c, Wm_p_c = Wm_o.contiguous(), Wm_p.contiguous()
-        oth_proj = ops.dense(oth_flat, Wm_o_c, w["mix_b"], activation=None).reshape(B, T_out, O)
+        if side_in is None:
+            input_side_work()
+        else:
+            torch.cuda.current_stream().wait_stream(side_in)
+        oth_proj = oth_proj_buf.reshape(B, T_out, O)
         # Decoder tape, time-major: step t reads row t of the "previous state" stacks and writes row t+1, so the
         # stacked rows are exactly the operands of the per-layer weight-gradient products formed after the loop.
-        XM = e(T_out + 1, B, O)                               # row t = decoder input x_t, row t+1 = output m_t
         X, M = XM[:T_out], XM[1:]
         R1, R2 = e(T_out, B, 1, 5, H), e(T_out, B, 1, 5, H)   # reserves (i,f,g,o,c) of every step
         P = e(T_out, B, O)
-        X[0].copy_(dec0.reshape(B, O))
-        fused = self.fused_decoder and ops.mix_decoder_supported(H, O)
         if fused:   # the whole unrolled forward in one persistent launch, writing the same tape
             ops.mix_decoder(X[0], H1[0], C1[0], H2[0], C2[0], oth_proj, w, Wm_p_c, T_out, act=act, workspace=ws, out=M,
                             train={"P": P, "H1": H1[1:], "C1": C1[1:], "H2": H2[1:], "C2": C2[1:],
@@ -910,7 +929,6 @@ class OthersMixingTrainer(FlatParamTrainer):
         DZ1, DZ2 = e(T_out, B, 4 * H), e(T_out, B, 4 * H)
         dh1_rec = dc1 = dh2_rec = dc2 = None
         dx_next = None
-        fused_bwd = self.fused_decoder_bwd and ops.mix_decoder_supported(H, O)
         if fused_bwd:   # BPTT through the whole unrolled decoder (head, layer 2, layer 1, feedback) in one launch
             dh1_rec, dc1, dh2_rec, dc2 = e(B, H), e(B, H), e(B, H), e(B, H)
             ops.mix_decoder_bwd(M, P, dloss_tm, R1.view(T_out, B, 5, H), R2.view(T_out, B, 5, H), C1, C2, w, Wm_p_c,
@@ -972,6 +990,7 @@ class OthersMixingTrainer(FlatParamTrainer):
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 decoder_wgrads(1 if split_side else 3)
+                ops.reduce_defer_flush()   # their slices are summed on the side stream too (under the recurrences), not at the step's end
         self.grads_final("dec1_K")    # decoder, heads and loss: all-reduced under the encoder's BPTT
         # encoder: layer 2 over hs1 (its dx is the dhs of layer 1), then layer 1
         # (tried: each encoder layer in two parts, its weight-gradient products on the side stream under the NEXT layer's
@@ -983,6 +1002,7 @@ class OthersMixingTrainer(FlatParamTrainer):
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 decoder_wgrads(2)
+                ops.reduce_defer_flush()
         ops.lstm_seq_bwd(enc, w["enc1_K"], w["enc1_R"], hs1, res1, dhs=e2["dx"], dhT=dh1_rec, dcT=dc1, dK=g["enc1_K"],
                          dR=g["enc1_R"], db=g["enc1_b"], act=act, accumulate=acc, scratch=bsc, dtype=dt)
         if side is not None:
