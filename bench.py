@@ -511,6 +511,33 @@ def bench_a10(args, rank, world, use_dist):
         flop = 2.0 * B * T * ((F + H) * 4 * H + (H + H) * 4 * H)
         res[tag] = {"ms": ms, "sequences_per_s": B / (ms * 1e-3), "tflops": flop / (ms * 1e-3) / 1e12,
                     "max_abs_err_vs_oracle": float(np.abs(got - ref).max())}
+    # the script's training step (lstm.py:556-567: Gaussian NLL on the two heads, RMSProp with clipping) at the same shape:
+    # padded to 512 on the persistent kernels (lstm_wide16.hip forward with the tape, lstm_bwd16.hip BPTT) vs unpadded
+    # (H = 400: every step of forward and backward its own GEMM + pointwise launches)
+    from longterm360fov_amd.training import TFLSTMTrainer
+    train = {}
+    trng = np.random.default_rng(11)
+    cells = [((trng.standard_normal((Fin + 400, 1600)) / np.sqrt(Fin + 400)).astype(np.float32), np.zeros(1600, np.float32))
+             for Fin in (F, 400)]
+    head = {}
+    for br in ("mu", "var"):
+        head[br + "_W1"] = (trng.standard_normal((400, 32)) / 20).astype(np.float32)
+        head[br + "_b1"] = np.zeros(32, np.float32)
+        head[br + "_W2"] = (trng.standard_normal((32, 3)) / np.sqrt(32)).astype(np.float32)
+        head[br + "_b2"] = np.zeros(3, np.float32)
+    ty = torch.from_numpy(trng.uniform(-1, 1, (B, 1, 90)).astype(np.float32)).cuda()
+    tx = torch.from_numpy(x).cuda()
+    tinit = torch.zeros((2, 2, B, 400), device="cuda")
+    for tag, pad in (("h400_padded_to_512_persistent_mfma", True), ("h400_stepwise_mfma_gemm", False)):
+        tr = TFLSTMTrainer(cells, head, lr=1e-5, fps=30, running_length=10, pad=pad)
+        tstep = lambda: tr.train_step(tx, ty, tinit)
+        for _ in range(5):
+            tstep()
+        tms = min(event_time_ms(tstep, max(args.steps // 6, 50)) for _ in range(3))
+        tr.ws.check()
+        flop3 = 3 * 2.0 * B * T * ((F + 400) * 1600 + (400 + 400) * 1600)
+        train[tag] = {"ms": tms, "sequences_per_s": B / (tms * 1e-3), "tflops": flop3 / (tms * 1e-3) / 1e12,
+                      "loss": float(tstep()[0].item())}
     cpu = None
     if rank == 0 and not args.no_cpu_baseline and world == 1:
         from oracle import torch_cpu as TC
@@ -544,7 +571,7 @@ def bench_a10(args, rank, world, use_dist):
             "roofline": {"bound": "mfma", "achieved": r["tflops"], "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": r["tflops"] / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
                          "note": "32 sequences = two tiles = 32 of 256 CUs busy: latency-bound by construction"},
-            "variants": res, "cpu_baseline": cpu}), flush=True)
+            "variants": res, "training_step": train, "cpu_baseline": cpu}), flush=True)
 
 
 def bench_convlstm(args, rank, world, use_dist):

@@ -131,8 +131,76 @@ __global__ __launch_bounds__(256) void dense_small_kernel(const float* __restric
     }
 }
 
+// Few rows, a wide input and more than eight outputs (the 400 -> 32 heads of lstm.py:321-337 on a batch of 32 final states):
+// the wave-per-row kernel above walks In / 64 dependent rounds of Out strided loads - 34 us for a 32 x 512 x 32 product.
+// Here a workgroup takes four rows; thread (o, kq) contracts an eighth of In for output o of all four rows: its W loads are
+// independent and coalesced over o (issued back to back), x comes from LDS as a broadcast, the eight partial sums meet in LDS.
+constexpr int DW_ROWS = 4, DW_KQ = 8, DW_OT = 32;
+__global__ __launch_bounds__(256) void dense_fewrows_kernel(const float* __restrict__ x, const float* __restrict__ W,
+                                                            const float* __restrict__ b, const float* __restrict__ add,
+                                                            long add_stride, float* __restrict__ y, int N, int In, int Out,
+                                                            int activation) {
+    extern __shared__ __attribute__((aligned(16))) float dw_lds[];   // [DW_ROWS][In] rows of x, then [DW_KQ][DW_ROWS][DW_OT] partials
+    float* xs = dw_lds;
+    float* red = dw_lds + DW_ROWS * In;
+    const int row0 = blockIdx.x * DW_ROWS;
+    for (int e = threadIdx.x; e < DW_ROWS * In; e += 256) {
+        const int r = e / In, k = e - r * In;
+        xs[e] = (row0 + r < N) ? x[(size_t)(row0 + r) * In + k] : 0.f;
+    }
+    __syncthreads();
+    const int ol = threadIdx.x & (DW_OT - 1), kq = threadIdx.x / DW_OT;
+    const int kc = (In + DW_KQ - 1) / DW_KQ;
+    const int k0 = kq * kc, k1 = (k0 + kc < In) ? k0 + kc : In;
+    for (int o0 = 0; o0 < Out; o0 += DW_OT) {
+        const int o = o0 + ol;
+        float acc[DW_ROWS] = {0.f, 0.f, 0.f, 0.f};
+        if (o < Out) {
+            int k = k0;
+            for (; k + 8 <= k1; k += 8) {
+                float w[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) w[u] = W[(size_t)(k + u) * Out + o];
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+#pragma unroll
+                    for (int r = 0; r < DW_ROWS; ++r) acc[r] = fmaf(xs[r * In + k + u], w[u], acc[r]);
+            }
+            for (; k < k1; ++k) {
+                const float w = W[(size_t)k * Out + o];
+#pragma unroll
+                for (int r = 0; r < DW_ROWS; ++r) acc[r] = fmaf(xs[r * In + k], w, acc[r]);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < DW_ROWS; ++r) red[(kq * DW_ROWS + r) * DW_OT + ol] = acc[r];
+        __syncthreads();
+        if (threadIdx.x < DW_ROWS * DW_OT) {
+            const int r = threadIdx.x / DW_OT, row = row0 + r;
+            float v = 0.f;
+#pragma unroll
+            for (int q = 0; q < DW_KQ; ++q) v += red[(q * DW_ROWS + r) * DW_OT + ol];   // fixed order
+            if (row < N && o < Out) {
+                v += b ? b[o] : 0.f;
+                if (add) v += add[(size_t)row * add_stride + o];
+                if (activation == 1) v = tanh_f(v);
+                y[(size_t)row * Out + o] = v;
+            }
+        }
+        __syncthreads();
+    }
+}
+
 static int launch_dense(const float* x, const float* W, const float* b, const float* add, long add_stride, float* y, int N,
                         int In, int Out, int activation, hipStream_t stream) {
+    if (Out > 8 && N <= 256 && In >= 128 && In <= 2048) {
+        const size_t lds = sizeof(float) * ((size_t)DW_ROWS * In + DW_KQ * DW_ROWS * DW_OT);
+        hipLaunchKernelGGL(dense_fewrows_kernel, dim3((unsigned)((N + DW_ROWS - 1) / DW_ROWS)), dim3(256), lds, stream, x, W, b, add,
+                           add_stride, y, N, In, Out, activation);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) { set_error("dense launch: %s", hipGetErrorString(e)); return FOV_ERR_LAUNCH; }
+        return FOV_OK;
+    }
     if (Out <= 8 && In <= 2048 && N >= 64) {
         long blocks = ((long)N + 15) / 16;
         if (blocks > 2048) blocks = 2048;

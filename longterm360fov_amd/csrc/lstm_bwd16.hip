@@ -1,0 +1,309 @@
+// Persistent BPTT recurrence of one LSTM layer at width 512, in groups of SIXTEEN workgroups per 16-sequence tile, fp32.
+// (What TF autodiff runs under the train_op of mycode/lstm.py:556-567 for its MultiRNNCell of LSTMCell(400), :218-240,
+// zero-padded to the matrix-core width 512 by training.TFLSTMTrainer; any Keras LSTM(512) under model.fit as well.)
+//
+// The K-split form of lstm_bwd8.hip one size up.  Workgroup `slice` (0..15) owns hidden units [32*slice, +32) for all four
+// gates; lane (n, g4) of wave w owns the cells (rows 4*g4 + 2*(n>>3) + {0,1}, unit 32*slice + 8*w + (n&7)): dc and the
+// recurrent dh never leave registers.  Per step t = T-1 .. 0:
+//   gates backward for the lane's two cells (tape i,f,g,o,c of the training forward, requested one step ahead) -> dz, to
+//   dZ (B,T,4H) for the weight-gradient products and into an LDS tile (16 x 128 own gate columns);
+//   partial[16 x 512] = dz_own . R^T_own : the own gate columns' contribution to dh_{t-1} of ALL 512 units - 256 x
+//   v_mfma_f32_16x16x4_f32 per wave (eight 16-unit output tiles x 32 k-steps), the 128 x 512 slice of R^T resident in
+//   ALL 256 accumulation registers of the lane for the whole launch (256 KB per workgroup: the reason for sixteen);
+//   the 16 x 32 piece of every destination workgroup travels as fp32 {value, epoch} granules; each lane gathers the
+//   sixteen pieces of its own two cells and adds them in slice order (deterministic).
+// Bias gradient: one (tiles, 4H) partial, summed over the tile's rows and all steps, as in the other BPTT kernels.
+#include <stdlib.h>
+
+#include "bf16_common.h"
+
+namespace fov {
+
+namespace {
+
+constexpr int XH = 512;            // hidden units
+constexpr int XG = 16;             // workgroups per tile
+constexpr int XBT = 16;            // sequences per tile
+constexpr int XLDZ = 128 + 4;      // fp32 LDS row stride of the dz tile
+constexpr size_t X_PAR = (size_t)XG * XG * XBT * 32;   // granules per parity: [dest][src][row][unit]
+
+struct Bwd16Params {
+    const float* R;
+    const float* reserve;   // (B,T,5,H)
+    const float* c0;        // (B,H) or NULL
+    const float* dhs;       // (B,T,H) or NULL
+    const float* dhT;       // (B,H) or NULL
+    const float* dcT;       // (B,H) or NULL
+    float* dz;              // (B,T,4H) out
+    float* dh0;             // (B,H) or NULL
+    float* dc0;             // (B,H) or NULL
+    float* db_part;         // (num_tiles, 4H) or NULL
+    unsigned long long* xch;
+    unsigned* status;
+    int B, T, num_groups, num_tiles, epoch_span;
+};
+
+__device__ __forceinline__ void x_mfma_a(f32x4& acc, float a, float w_agpr) {
+    asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "a"(w_agpr));
+}
+template <int ACT>
+__device__ __forceinline__ float x_act_grad(float a) {
+    return ACT == FOV_ACT_HARD_SIGMOID ? ((a > 0.f && a < 1.f) ? 0.2f : 0.f) : a * (1.f - a);
+}
+
+template <int ACT>
+__global__ __launch_bounds__(256, 1) void lstm_bwd16_kernel(Bwd16Params p) {
+    __shared__ __attribute__((aligned(16))) float sDZ[XBT * XLDZ];
+    __shared__ int sFlag[4];
+    __shared__ unsigned sXch[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 15, g4 = lane >> 4;
+    int group, slice;
+    if ((p.num_groups & 7) == 0) {   // members 8 blocks apart: likely one XCD (placement preference only)
+        group = (blockIdx.x / (8 * XG)) * 8 + (blockIdx.x & 7);
+        slice = (blockIdx.x >> 3) & (XG - 1);
+    } else {
+        group = blockIdx.x / XG;
+        slice = blockIdx.x - group * XG;
+    }
+    constexpr int H4 = 4 * XH;
+    const int hi = n >> 3;
+    const int ul = 8 * wave + (n & 7);          // unit inside the workgroup (0..31)
+    const int unit = 32 * slice + ul;
+    const int my_row0 = 4 * g4 + 2 * hi;
+    const int T = p.T;
+    // epoch tags continue from the workspace header, a poisoned workspace skips the body (xch_common.h)
+    const unsigned arrival = xch_arrive(p.status, sXch, group, slice);
+    const bool poisoned = xch_poisoned(p.status);
+    if (tid == 0) sFlag[0] = poisoned ? 1 : 0;
+
+    // ---- resident R^T fragments.  Tile tl of this wave: destination slice 4*wave + (tl>>1), half tl&1; its output unit
+    // on this lane is nout; k index lc is an own gate column: gate lc>>5, unit 32*slice + (lc & 31). ----
+    float rt[8][8][4];   // [tl][jb][s], lc = 16*jb + 4*g4 + s
+#pragma unroll
+    for (int tl = 0; tl < 8; ++tl) {
+        const int nout = 32 * (4 * wave + (tl >> 1)) + 16 * (tl & 1) + n;
+#pragma unroll
+        for (int jb = 0; jb < 8; ++jb) {
+            const int lc = 16 * jb + 4 * g4;
+            const f32x4 v = *(const f32x4*)(p.R + (size_t)nout * H4 + (lc >> 5) * XH + 32 * slice + (lc & 31));
+#pragma unroll
+            for (int s = 0; s < 4; ++s) rt[tl][jb][s] = v[s];
+        }
+    }
+    unsigned long long* gbase = p.xch + (size_t)group * 2 * X_PAR;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(gbase, 0, (int)(2 * X_PAR * 8), 0x00020000);
+    xch_hello_poll(p.status, sXch, group, XG, &sFlag[0]);   // same-XCD handshake (xch_common.h)
+    __syncthreads();
+    const XchTicket ticket = xch_ticket(sXch, arrival);
+    unsigned epoch = ticket.base;
+    bool aborted = sFlag[0] != 0;
+    if (tid == 0 && !ticket.same_xcd && !aborted) xch_count_safe(p.status, ticket);   // (fov_exchange_mode)
+
+    for (int tile = group; tile < p.num_tiles && !aborted; tile += p.num_groups) {
+        const int b0 = tile * XBT;
+        float dc[2], dh[2];
+        bool live[2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int row = b0 + my_row0 + r;
+            live[r] = row < p.B;
+            dc[r] = (live[r] && p.dcT) ? p.dcT[(size_t)row * XH + unit] : 0.f;
+            dh[r] = (live[r] && p.dhT) ? p.dhT[(size_t)row * XH + unit] : 0.f;
+        }
+        // Tape of this lane's two cells, ONE step ahead (lstm_bwd8.hip): [0..3] = i,f,g,o, [4] = c of the step, [5] = c of
+        // the step before it, [6] = dhs of the step.  Unconditional loads, rows and steps clamped, dead rows masked at use.
+        float cur[7][2], pre[7][2];
+        auto load_step = [&](int t, float (&dst)[7][2]) {
+            const int tc = t > 0 ? t : 0;
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int row = b0 + my_row0 + r;
+                const size_t rowc = (size_t)(row < p.B ? row : p.B - 1);
+                const float* rp = p.reserve + ((rowc * T + tc) * 5) * XH + unit;
+#pragma unroll
+                for (int q = 0; q < 5; ++q) dst[q][r] = rp[q * XH];
+                const float* cp = tc > 0 ? rp - XH : (p.c0 ? p.c0 + rowc * XH + unit : rp);   // no c0: any valid address, masked at use
+                dst[5][r] = *cp;
+                dst[6][r] = p.dhs ? p.dhs[(rowc * T + tc) * XH + unit] : 0.f;
+            }
+        };
+        load_step(T - 1, cur);
+        float dbacc[4] = {0.f, 0.f, 0.f, 0.f};   // sum over t and this lane's 2 sequences of dz, per gate
+        __syncthreads();   // the previous tile's last step is done with the dz tile
+
+        for (int t = T - 1; t >= 0; --t) {
+            ++epoch;
+            const unsigned par = (epoch & 1u) * (unsigned)(X_PAR * 8);
+            // ---- pointwise: dz of this lane's two cells ----
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const float ig = cur[0][r], fg = cur[1][r], gg = cur[2][r], og = cur[3][r], cc = cur[4][r];
+                const float cprev = (t > 0 || p.c0) ? cur[5][r] : 0.f;   // step 0 without a given state: c_{-1} = 0
+                const float dht = dh[r] + cur[6][r];
+                const float tc = tanh_f(cc);
+                const float dcv = dc[r] + dht * og * (1.f - tc * tc);
+                float dzv[4];
+                dzv[0] = live[r] ? dcv * gg * x_act_grad<ACT>(ig) : 0.f;
+                dzv[1] = live[r] ? dcv * cprev * x_act_grad<ACT>(fg) : 0.f;
+                dzv[2] = live[r] ? dcv * ig * (1.f - gg * gg) : 0.f;
+                dzv[3] = live[r] ? dht * tc * x_act_grad<ACT>(og) : 0.f;
+                dc[r] = dcv * fg;
+                if (live[r]) {
+                    float* zp = p.dz + ((size_t)(b0 + my_row0 + r) * T + t) * H4 + unit;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) zp[g * XH] = dzv[g];
+                }
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    dbacc[g] += dzv[g];
+                    sDZ[(my_row0 + r) * XLDZ + g * 32 + ul] = dzv[g];
+                }
+            }
+            // the tape of step t-1 is requested here, a whole step before its use
+            load_step(t - 1, pre);
+            __syncthreads();   // barrier A: the dz tile is complete
+            // ---- partial[16 x 512] = dz_own . R^T_own ; tile tl -> destination 4*wave + (tl>>1).  Two passes of four tiles:
+            // the granules of the first pass are on their way (an sc1 store takes about a microsecond to become visible)
+            // while the matrix pipe works on the second. ----
+            const unsigned off0 = (unsigned)((((4 * wave * XG + slice) * XBT + 4 * g4) * 32) + n) * 8u;
+            const float* arow = sDZ + n * XLDZ + 4 * g4;
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                f32x4 acc[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                asm volatile("s_nop 3" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
+                f32x4 a = *(const f32x4*)arow, an = a;
+#pragma unroll
+                for (int jb = 0; jb < 8; ++jb) {
+                    if (jb + 1 < 8) an = *(const f32x4*)(arow + 16 * (jb + 1));
+                    asm volatile("s_nop 1" : "+v"(a));
+#pragma unroll
+                    for (int tq = 0; tq < 4; ++tq)
+#pragma unroll
+                        for (int s = 0; s < 4; ++s) x_mfma_a(acc[tq], a[s], rt[4 * half + tq][jb][s]);
+                    a = an;
+                }
+                asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
+                // one address register for all stores: the tile's destination goes into the scalar offset
+#pragma unroll
+                for (int tq = 0; tq < 4; ++tq) {
+                    const int tl = 4 * half + tq;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        XCH_STORE_B64(ticket.same_xcd, ((qu32x2){__float_as_uint(acc[tq][r]), epoch}), rs,
+                                      off0 + (tl & 1) * 16 * 8 + r * 32 * 8, par + (unsigned)(tl >> 1) * (XG * XBT * 32 * 8));
+                }
+            }
+            // ---- gather the 16 pieces of this lane's two cells, add in slice order ----
+            {
+                const unsigned voff = (unsigned)(((slice * XG) * XBT + my_row0) * 32 + ul) * 8u;
+                constexpr unsigned SSTR = XBT * 32 * 8;   // src stride in bytes
+                float part[32];
+                unsigned bad = 0;
+                {
+                    qu32x2 v[32];
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+#pragma unroll
+                        for (int s = 0; s < 16; ++s) v[q * 16 + s] = __builtin_amdgcn_raw_buffer_load_b64(rs, voff + q * 32 * 8, par + s * SSTR, 16);
+#pragma unroll
+                    for (int j = 0; j < 32; ++j) {
+                        part[j] = __uint_as_float(v[j].x);
+                        if (v[j].y != epoch) bad |= (1u << j);
+                    }
+                }
+                unsigned spins = 0;
+                while (__any(bad != 0)) {
+                    ++spins;
+                    if (spins > Q_SPIN || ((spins & 63u) == 0 && xch_poisoned(p.status))) {
+                        if (lane == 0) { xch_give_up(p.status); sFlag[0] = 1; }
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                    asm volatile("" ::: "memory");
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {   // one cell's sixteen sources at a time: half the registers of a full sweep
+                        qu32x2 tv[16];
+#pragma unroll
+                        for (int s = 0; s < 16; ++s) tv[s] = __builtin_amdgcn_raw_buffer_load_b64(rs, voff + h * 32 * 8, par + s * SSTR, 16);
+#pragma unroll
+                        for (int s = 0; s < 16; ++s) {
+                            const int j = h * 16 + s;
+                            if (((bad >> j) & 1u) && tv[s].y == epoch) {
+                                part[j] = __uint_as_float(tv[s].x);
+                                bad &= ~(1u << j);
+                            }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    float a = 0.f;
+#pragma unroll
+                    for (int s = 0; s < 16; ++s) a += part[q * 16 + s];
+                    dh[q] = a;
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 7; ++q)
+#pragma unroll
+                for (int r = 0; r < 2; ++r) cur[q][r] = pre[q][r];   // requested most of a step ago: long landed
+            __syncthreads();   // barrier B: every wave is done reading the dz tile; sFlag is uniform below
+            if (sFlag[0]) { aborted = true; break; }
+        }
+        if (!aborted && p.db_part) {
+            // the 8 lanes (g4 0..3, hi 0..1) that share a unit hold different rows: fold them in a fixed order
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float v = dbacc[g];
+                v += __shfl_xor(v, 8);
+                const float v1 = __shfl(v, (lane + 16) & 63), v2 = __shfl(v, (lane + 32) & 63), v3 = __shfl(v, (lane + 48) & 63);
+                if (g4 == 0 && hi == 0) p.db_part[(size_t)tile * H4 + g * XH + unit] = (v + v1) + (v2 + v3);
+            }
+        }
+        if (!aborted) {
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int row = b0 + my_row0 + r;
+                if (row < p.B) {
+                    if (p.dh0) p.dh0[(size_t)row * XH + unit] = dh[r];
+                    if (p.dc0) p.dc0[(size_t)row * XH + unit] = dc[r];
+                }
+            }
+        }
+    }
+    xch_settle(p.status, ticket, (unsigned)p.epoch_span);
+}
+
+}  // namespace
+
+// width 512 and a device with at least sixteen CUs (one workgroup per CU: the R^T slice takes a whole register file)
+bool bwd16_shape_ok(int H) { return H == XH && device_cu_count() >= XG; }
+
+// status word + granule buffers live at `xch_ws` (kStatusBytes + kXchBytes)
+int launch_bwd16(const float* R, const float* reserve, const float* c0, const float* dhs, const float* dhT, const float* dcT,
+                 float* dz, float* dh0, float* dc0, float* db_part, int B, int T, int act, void* xch_ws, hipStream_t stream) {
+    if (B == 0 || T == 0) return FOV_OK;
+    if (((uintptr_t)R) & 15) { set_error("16-group BPTT kernel: R must be 16-byte aligned"); return FOV_ERR_INVALID; }
+    Bwd16Params p = {};
+    p.R = R; p.reserve = reserve; p.c0 = c0; p.dhs = dhs; p.dhT = dhT; p.dcT = dcT; p.dz = dz; p.dh0 = dh0; p.dc0 = dc0; p.db_part = db_part;
+    p.B = B; p.T = T;
+    p.num_tiles = (B + XBT - 1) / XBT;
+    const int max_groups = device_cu_count() / XG;
+    if (max_groups < 1) { set_error("16-group BPTT kernel needs at least %d CUs", XG); return FOV_ERR_UNSUPPORTED; }
+    p.num_groups = p.num_tiles < max_groups ? p.num_tiles : max_groups;
+    if ((size_t)p.num_groups * 2 * X_PAR * 8 > kXchBytes - kHelloBytes) { set_error("16-group BPTT kernel: granule area too small"); return FOV_ERR_WORKSPACE; }
+    p.status = (unsigned*)xch_ws;
+    p.xch = (unsigned long long*)((char*)xch_ws + kStatusBytes);
+    p.epoch_span = T * ((p.num_tiles + p.num_groups - 1) / p.num_groups) + 1;
+    if (int rc_ = xch_account(p.status, p.epoch_span, stream)) return rc_;
+    void (*kern)(Bwd16Params) = act == FOV_ACT_HARD_SIGMOID ? lstm_bwd16_kernel<FOV_ACT_HARD_SIGMOID> : lstm_bwd16_kernel<FOV_ACT_SIGMOID>;
+    hipLaunchKernelGGL(kern, dim3(p.num_groups * XG), dim3(256), 0, stream, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_error("16-group BPTT launch: %s", hipGetErrorString(e)); return FOV_ERR_LAUNCH; }
+    return FOV_OK;
+}
+
+}  // namespace fov

@@ -1424,16 +1424,28 @@ class TFLSTMTrainer:
     HEAD = ("mu_W1", "mu_b1", "mu_W2", "mu_b2", "var_W1", "var_b1", "var_W2", "var_b2")
 
     def __init__(self, cells, head, forget_bias=1.0, lr=1e-5, clip_value=1.0, decay=0.9, eps=1e-10, fps=30, running_length=10,
-                 impl="auto", device="cuda"):
-        from .models import convert_tf_lstmcell
+                 impl="auto", device="cuda", pad=True):
+        from .models import convert_tf_lstmcell, padded_width, pad_lstm, pad_rows, MFMA_WIDTHS
         self.forget_bias, self.lr, self.clip, self.decay, self.eps = float(forget_bias), float(lr), float(clip_value), decay, eps
         self.fps, self.running_length, self.impl, self.device = fps, running_length, impl, device
         conv = [convert_tf_lstmcell(W, b, forget_bias) for W, b in cells]
         self.L = len(conv)
+        # The stack runs at the next matrix-core width Hp (lstm.py's n_hidden = 400 -> 512: lstm_wide16.hip forward, lstm_bwd16.hip
+        # BPTT) with zero-padded weights - exact, as in PaddedTrainer: a padded unit has z = 0, c = h = 0, dz = 0, so every
+        # gradient in a padded slice is exactly 0 and TF's RMSProp leaves the zeros in place.  States, masks, weights and
+        # gradients cross the object's surface at the caller's width H (cells_tf, grads_numpy, predict, train_step).
+        self.H = int(conv[0][1].shape[0])
+        Hp = padded_width(self.H, MFMA_WIDTHS + (512,)) if (pad and impl != "generic") else None
+        self.Hp = int(Hp) if Hp else self.H
+        if self.Hp != self.H:
+            conv = [pad_lstm(K, R, b, self.Hp, pad_input=(l > 0)) for l, (K, R, b) in enumerate(conv)]
         weights = {}
         for l, (K, R, b) in enumerate(conv):
             weights.update({"K%d" % l: K, "R%d" % l: R, "b%d" % l: b})
         weights.update({k: np.ascontiguousarray(head[k], dtype=np.float32) for k in self.HEAD})
+        if self.Hp != self.H:
+            for k in ("mu_W1", "var_W1"):
+                weights[k] = pad_rows(weights[k], self.Hp)
         self.order = ["%s%d" % (n, l) for l in range(self.L) for n in ("K", "R", "b")] + list(self.HEAD)
         n = int(sum(weights[k].size for k in self.order))
         self.flat = torch.empty(n, dtype=torch.float32, device=device)
@@ -1448,12 +1460,73 @@ class TFLSTMTrainer:
             self.w[k].copy_(torch.from_numpy(weights[k]))
             off += cnt
         self.ws, self.scratch, self.bwd_scratch = ops.Workspace(), ops.Scratch(), ops.Scratch()
+        self._state_pads = {}
+
+    def _unpadded(self, table, k):
+        """Tensor `k` of self.w / self.g at the caller's width H (numpy)."""
+        v = table[k].detach().cpu().numpy()
+        H, Hp = self.H, self.Hp
+        if Hp == H:
+            return v
+        if k[0] in "KRb" and k[1:].isdigit():
+            if k[0] == "R" or (k[0] == "K" and int(k[1:]) > 0):
+                v = v[:H]
+            return _unpad_gates(v, H, Hp)
+        return v[:H].copy() if k in ("mu_W1", "var_W1") else v
+
+    def weights_numpy(self):
+        return {k: self._unpadded(self.w, k) for k in self.order}
+
+    def grads_numpy(self):
+        """Gradients of the last forward_backward, Keras layout, at width H."""
+        return {k: self._unpadded(self.g, k) for k in self.order}
+
+    def padded_slices_are_zero(self):
+        """True if every padded slice of the parameters and of the last gradients is exactly zero (synchronises)."""
+        if self.Hp == self.H:
+            return True
+        nz = 0
+        for table in (self.w, self.g):
+            for k in self.order:
+                full = table[k].detach().cpu().numpy()
+                nz += int(np.count_nonzero(full)) - int(np.count_nonzero(self._unpadded(table, k)))
+        return nz == 0
+
+    def _pad_state(self, st):
+        """(L,2,B,H) -> (L,2,B,Hp), zero columns."""
+        if st is None or self.Hp == self.H or st.shape[-1] == self.Hp:
+            return st
+        key = tuple(st.shape)
+        out = self._state_pads.get(key)      # one buffer per shape: its padded columns are written once (zero), one copy per call
+        if out is None:
+            out = self._state_pads[key] = torch.zeros(st.shape[:-1] + (self.Hp,), dtype=torch.float32, device=st.device)
+        out[..., :self.H].copy_(st)
+        return out
+
+    def _state_out(self, states):
+        """[(cT, hT) per layer] at width Hp -> (L,2,B,H) in one copy."""
+        H = self.H
+        flat = [t[:, :H] for pair in states for t in pair]
+        return torch.stack(flat, 0).view(len(states), 2, flat[0].shape[0], H)
+
+    def _pad_masks(self, masks):
+        if masks is None or self.Hp == self.H:
+            return masks
+        out = []
+        for m in masks:
+            if m is None or m.shape[-1] == self.Hp:
+                out.append(m)
+            else:
+                mp = torch.zeros(m.shape[:-1] + (self.Hp,), dtype=torch.float32, device=m.device)
+                mp[..., :self.H].copy_(m)
+                out.append(mp)
+        return out
 
     def cells_tf(self):
         """Current LSTM weights back in tf.contrib LSTMCell layout [(W (F+H,4H), b)]."""
         out = []
         for l in range(self.L):
-            K, R, b = (self.w["%s%d" % (n, l)].detach().cpu().numpy() for n in ("K", "R", "b"))
+            K, R, b = (self._unpadded(self.w, "%s%d" % (n, l)) for n in ("K", "R", "b"))
             H = R.shape[0]
             perm = np.concatenate([np.arange(0, H), np.arange(2 * H, 3 * H), np.arange(H, 2 * H), np.arange(3 * H, 4 * H)])
             W = np.concatenate([K, R], 0)
@@ -1478,16 +1551,21 @@ class TFLSTMTrainer:
 
     def predict(self, x, init_state=None):
         """(mu (B,3), var (B,3), state (L,2,B,H) as LSTMStateTuple (c,h) per layer) - inference, no dropout."""
+        mu, var, states = self._predict_padded(x, self._pad_state(init_state))
+        return mu, var, self._state_out(states)
+
+    def _predict_padded(self, x, init_state=None):
+        """init_state: (L,2,B,Hp) tensor, or a list of (c, h) pairs at width Hp, or None -> (mu, var, [(cT, hT)])."""
         inp, states = x, []
         for l in range(self.L):
-            c0 = None if init_state is None else init_state[l, 0].contiguous()
-            h0 = None if init_state is None else init_state[l, 1].contiguous()
+            c0 = None if init_state is None else init_state[l][0].contiguous()
+            h0 = None if init_state is None else init_state[l][1].contiguous()
             hs, hT, cT = ops.lstm_seq(inp, self.w["K%d" % l], self.w["R%d" % l], self.w["b%d" % l], h0, c0, act="sigmoid",
                                       impl=self.impl, workspace=self.ws)
-            states.append(torch.stack([cT, hT], 0))
+            states.append((cT, hT))
             inp = hs
         _, mu, _, var = self._head(states[-1][1])
-        return mu, var, torch.stack(states, 0)
+        return mu, var, states
 
     def rollout(self, x, init_state, noise):
         """Test-time loop of lstm.py:714-740: noise (P,B,3*fps) standard normal; each step predicts from the window and
@@ -1497,15 +1575,15 @@ class TFLSTMTrainer:
         T = x.shape[1]
         mus = torch.empty((P, B, 3), dtype=torch.float32, device=self.device)
         vs = torch.empty((P, B, 3), dtype=torch.float32, device=self.device)
-        win, st = x, init_state
+        win, st = x, self._pad_state(init_state)
         for k in range(P):
-            mu, var, st = self.predict(win, st)
+            mu, var, st = self._predict_padded(win, st)
             mus[k].copy_(mu); vs[k].copy_(var)
             nxt = torch.empty_like(win)
             nxt[:, :T - 1].copy_(win[:, 1:])
             ops.sample_refeed(mu, var, noise[k], out=nxt[:, T - 1], std="sqrt")
             win = nxt
-        return mus, vs, st
+        return mus, vs, self._state_out(st)
 
     def _stack_forward(self, x, init_state, masks):
         w = self.w
@@ -1516,7 +1594,7 @@ class TFLSTMTrainer:
             hs, hT, cT, res = ops.lstm_seq_train(inp, w["K%d" % l], w["R%d" % l], w["b%d" % l], h0, c0, act="sigmoid",
                                                  impl=self.impl, workspace=self.ws)
             tape.append((inp, hs, res, h0, c0))
-            states.append(torch.stack([cT, hT], 0))
+            states.append((cT, hT))
             inp = hs if (masks is None or l == self.L - 1) else hs * masks[l]
         return tape, states
 
@@ -1536,6 +1614,9 @@ class TFLSTMTrainer:
     def _stack_backward(self, tape, dhT, masks, accumulate, need_dx0=False):
         w, g = self.w, self.g
         dhs, dx0 = None, None
+        # (tried: each layer's weight-gradient products on a side stream under the next layer's recurrence - at lstm.py's batch a
+        # BPTT launch occupies 32 of 256 CUs.  0.596 -> 0.656 ms: the step is bound by the HOST's launch rate at this size, and the
+        # shifted copy of hs plus two stream hand-offs per layer cost more than the 60 us of overlapped products gain.)
         for l in range(self.L - 1, -1, -1):
             inp, hs, res, h0, c0 = tape[l]
             b = ops.lstm_seq_bwd(inp, w["K%d" % l], w["R%d" % l], hs, res, h0=h0, c0=c0, dhs=dhs,
@@ -1559,14 +1640,17 @@ class TFLSTMTrainer:
         `masks` is then a list of T_y per-window mask lists (DropoutWrapper draws a new mask per dynamic_rnn call)."""
         sc = self.scratch
         scale = 1.0 / (self.running_length * self.fps)
+        init_state = self._pad_state(init_state)
+        unpad = self._state_out
         if noise is None:
+            masks = self._pad_masks(masks)
             tape, states = self._stack_forward(x, init_state, masks)
-            hT = states[-1][1].contiguous()
+            hT = states[-1][1]
             head = self._head(hT)
             loss, dmu, dvar = ops.gauss_nll_grad(head[1], head[3], y, self.fps, scale, scratch=sc)
             dhT = self._head_backward(hT, head, dmu, dvar, accumulate=False)
             self._stack_backward(tape, dhT, masks, accumulate=False)
-            return loss, head[1], head[3], torch.stack(states, 0)
+            return loss, head[1], head[3], unpad(states)
         B, T, F = x.shape
         P = y.shape[1]
         assert F == 3 * self.fps and tuple(noise.shape) == (P - 1, B, F)
@@ -1578,9 +1662,9 @@ class TFLSTMTrainer:
                 nxt[:, :T - 1].copy_(win[:, 1:])
                 ops.sample_refeed(runs[-1]["head"][1], runs[-1]["head"][3], noise[k - 1], out=nxt[:, T - 1], std="sqrt")
                 win = nxt
-            mk = None if masks is None else masks[k]
+            mk = None if masks is None else self._pad_masks(masks[k])
             tape, states = self._stack_forward(win, init_state, mk)
-            hT = states[-1][1].contiguous()
+            hT = states[-1][1]
             head = self._head(hT)
             loss, dmu, dvar = ops.gauss_nll_grad(head[1], head[3], y[:, k:k + 1].contiguous(), self.fps, scale, scratch=sc)
             total = loss if total is None else ops.act_bwd(loss, loss, base=total, activation=None)
@@ -1593,7 +1677,7 @@ class TFLSTMTrainer:
                 src = runs[j - 1]
                 ops.sample_refeed_bwd(dX[:, T - 1 - (k - j)], src["head"][3], noise[j - 1], src["dmu"], src["dvar"], std="sqrt")
         last = runs[-1]
-        return total, last["head"][1], last["head"][3], torch.stack(states, 0)
+        return total, last["head"][1], last["head"][3], unpad(states)
 
     def train_step(self, x, y, init_state=None, masks=None, noise=None):
         loss, _, _, state = self.forward_backward(x, y, init_state, masks, noise)

@@ -123,7 +123,9 @@ def test_dense():
     # (N >= 64, Out <= 8) runs the narrow-head kernel (16-byte row loads when In % 4 == 0, scalar ones otherwise: the others'
     # projection has In = 198), the rest the generic one
     for N, In, Out in ((7, 256, 6), (130, 204, 6), (5, 33, 20), (1000, 256, 6), (4099, 40, 3), (65, 2048, 8), (333, 30, 6),
-                       (70, 512, 1), (5120, 198, 6), (100, 65, 8), (64, 1, 2)):
+                       (70, 512, 1), (5120, 198, 6), (100, 65, 8), (64, 1, 2),
+                       # few rows, In >= 128, Out > 8: the four-rows-per-workgroup kernel (lstm.py's 400 -> 32 heads, padded to 512)
+                       (32, 512, 32), (1, 128, 9), (37, 400, 33), (256, 2047, 70), (5, 131, 64)):
         x = rng.standard_normal((N, In)).astype(np.float32)
         W = (rng.standard_normal((In, Out)) / np.sqrt(In)).astype(np.float32)
         b = rng.standard_normal(Out).astype(np.float32)

@@ -346,8 +346,8 @@ def test_persistent_bptt_matches_stepped_and_oracle():
     fp64 oracle: ragged multi-tile batch (more tiles than groups), given initial state, dhs + dhT/dcT."""
     from longterm360fov_amd import ops
     rng = np.random.default_rng(7)
-    for H, B, T in ((256, 16 * 64 + 16 * 3 + 5, 3), (128, 37, 6), (64, 21, 4)):
-        F = 11
+    for H, B, T in ((256, 16 * 64 + 16 * 3 + 5, 3), (128, 37, 6), (64, 21, 4), (512, 16 * 16 + 16 * 2 + 5, 3), (512, 32, 10)):
+        F = 11      # width 512: lstm_bwd16.hip, sixteen workgroups per tile (293 sequences = 19 tiles on 16 groups; 32 = lstm.py's batch)
         K, R, b = O.init_lstm(rng, F, H, np.float32)
         b = (b + 0.1 * rng.standard_normal(b.shape)).astype(np.float32)
         x = rng.uniform(-1, 1, (B, T, F)).astype(np.float32)
@@ -746,11 +746,15 @@ def test_tf_stacked_lstm_training_graph(H, B, T, with_masks):
     loss, mu, var, state = tr.forward_backward(dev(x), dev(y), dev(init), masks=dm)
     assert np.abs(mu.cpu().numpy() - mu_ref).max() < 1e-5 and np.abs(var.cpu().numpy() - var_ref).max() < 1e-4 * np.abs(var_ref).max()
     assert abs(float(loss.item()) - loss_ref) <= 1e-5 * abs(loss_ref) + 1e-7
+    # H = 400 runs zero-padded at width 512 (lstm_wide16.hip forward with the tape, lstm_bwd16.hip BPTT), H = 40 at 64
+    assert tr.Hp == (512 if H == 400 else 64) and tr.w["R0"].shape == (tr.Hp, 4 * tr.Hp) and state.shape == (2, 2, B, H)
+    assert tr.padded_slices_are_zero()
+    tg = tr.grads_numpy()
     for k in TFLSTMTrainer.HEAD:
-        a = tr.g[k].cpu().numpy()
+        a = tg[k]
         assert np.abs(a - hg[k]).max() <= 2e-4 * np.abs(hg[k]).max() + 1e-9, k
     for l in range(2):   # gradients in tf.contrib layout: columns i, j, f, o of the fused kernel
-        K, R, b = (tr.g["%s%d" % (n, l)].cpu().numpy() for n in ("K", "R", "b"))
+        K, R, b = (tg["%s%d" % (n, l)] for n in ("K", "R", "b"))
         perm = np.concatenate([np.arange(0, H), np.arange(2 * H, 3 * H), np.arange(H, 2 * H), np.arange(3 * H, 4 * H)])
         Wg = np.empty_like(cg[l][0]); Wg[:, perm] = np.concatenate([K, R], 0)
         bg = np.empty_like(cg[l][1]); bg[perm] = b
@@ -763,6 +767,14 @@ def test_tf_stacked_lstm_training_graph(H, B, T, with_masks):
     for _ in range(5):
         l1 = float(tr.train_step(dev(x), dev(y), dev(init))[0].item())
     assert l1 < l0
+    assert tr.padded_slices_are_zero()
+    # the unpadded trainer (step-wise / generic kernels) takes the same steps
+    tu = TFLSTMTrainer(cells, head, lr=1e-3, clip_value=1.0, fps=fps, running_length=10, pad=False)
+    assert tu.Hp == H
+    for _ in range(6):
+        tu.train_step(dev(x), dev(y), dev(init))
+    for (W0, b0), (W1, b1) in zip(tu.cells_tf(), tr.cells_tf()):
+        assert np.abs(W0 - W1).max() < 2e-5 and np.abs(b0 - b1).max() < 2e-5
     # TF RMSProp semantics: ms starts at one, eps inside the root, clipped gradient
     p = torch.zeros(3, device="cuda"); gg = torch.tensor([0.5, -3.0, 0.0], device="cuda"); ms = torch.ones(3, device="cuda")
     from longterm360fov_amd import ops
@@ -1036,12 +1048,14 @@ def test_tf_stacked_lstm_sampled_refeed_training_graph(H, B, T, P, with_masks):
     assert state.shape == (2, 2, B, H)
     assert np.abs(mu.cpu().numpy() - mu_ref).max() < 2e-5 and np.abs(var.cpu().numpy() - var_ref).max() < 1e-4 * np.abs(var_ref).max()
     assert abs(float(loss.item()) - loss_ref) <= 1e-5 * abs(loss_ref) + 1e-7
+    tg = tr.grads_numpy()
+    assert tr.padded_slices_are_zero()
     for k in TFLSTMTrainer.HEAD:
-        a = tr.g[k].cpu().numpy()
+        a = tg[k]
         print("refeed head grad %-7s max|ref| %.3e err %.3e" % (k, np.abs(hg[k]).max(), np.abs(a - hg[k]).max()))
         assert np.abs(a - hg[k]).max() <= 2e-4 * np.abs(hg[k]).max() + 1e-9, k
     for l in range(2):
-        K, R, b = (tr.g["%s%d" % (n, l)].cpu().numpy() for n in ("K", "R", "b"))
+        K, R, b = (tg["%s%d" % (n, l)] for n in ("K", "R", "b"))
         perm = np.concatenate([np.arange(0, H), np.arange(2 * H, 3 * H), np.arange(H, 2 * H), np.arange(3 * H, 4 * H)])
         Wg = np.empty_like(cg[l][0]); Wg[:, perm] = np.concatenate([K, R], 0)
         bg = np.empty_like(cg[l][1]); bg[perm] = b
