@@ -375,6 +375,21 @@ int fov_gauss_nll_grad(const float* mu, const float* var, const float* y, float*
 int fov_rmsprop_tf_step(float* params, const float* grads, float* ms, int64_t n, float lr, float decay, float eps,
                         float clip_value, fov_stream_t stream);
 
+/* The two two-layer heads of _pred_mean_var_xyz2_new (mycode/lstm.py:321-337) on the top layer's final state h (B,H), as one
+ * launch each way: a1 = relu(h mu_W1 + mu_b1), mu = tanh(a1 mu_W2 + mu_b2), a3 = relu(h var_W1 + var_b1),
+ * var = exp(a3 var_W2 + var_b2); W1 (H,M), W2 (M,O).  fov_tf_head_bwd takes d loss / d mu and d loss / d var (B,O) and writes
+ * (accumulate != 0: adds) the eight weight gradients and dh (B,H) (always overwritten).  Shapes the fused kernels take:
+ * fov_tf_head_supported (B <= 64, H <= 2048, M <= 32, O <= 8: the script runs B = 32, H = 400, M = 32, O = 3); for others the
+ * same graph is available from fov_dense_fwd / fov_act_fwd / fov_dense_bwd / fov_act_bwd. */
+int fov_tf_head_supported(int B, int H, int M, int O);
+int fov_tf_head_fwd(const float* h, const float* mu_W1, const float* mu_b1, const float* mu_W2, const float* mu_b2,
+                    const float* var_W1, const float* var_b1, const float* var_W2, const float* var_b2, float* a1, float* mu,
+                    float* a3, float* var, int B, int H, int M, int O, fov_stream_t stream);
+int fov_tf_head_bwd(const float* h, const float* mu_W1, const float* mu_W2, const float* var_W1, const float* var_W2,
+                    const float* a1, const float* mu, const float* a3, const float* var, const float* dmu, const float* dvar,
+                    float* g_mu_W1, float* g_mu_b1, float* g_mu_W2, float* g_mu_b2, float* g_var_W1, float* g_var_b1,
+                    float* g_var_W2, float* g_var_b2, float* dh, int B, int H, int M, int O, int accumulate, fov_stream_t stream);
+
 /* Keras-2.2 `categorical_crossentropy` on probabilities, TensorFlow backend form - the loss the heat-map fork compiles
  * (mycode/convlstm_heatmap.py:192): per pixel (row of C channels) q = p / sum p, q' = clip(q, 1e-7, 1 - 1e-7),
  * l = - sum_c target_c log q'_c; *loss (may be NULL) = mean over the n_pix rows; dp = d loss / d p, through the clip (zero

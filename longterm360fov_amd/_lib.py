@@ -70,6 +70,9 @@ SIGNATURES = {
     "fov_scale": (_I, [_P, ctypes.c_int64, ctypes.c_float, _P]),
     "fov_act_bwd": (_I, [_P] * 4 + [ctypes.c_int64, _I, _P]),
     "fov_act_fwd": (_I, [_P, _P, ctypes.c_int64, _I, _P]),
+    "fov_tf_head_supported": (_I, [_I] * 4),
+    "fov_tf_head_fwd": (_I, [_P] * 13 + [_I] * 4 + [_P]),
+    "fov_tf_head_bwd": (_I, [_P] * 20 + [_I] * 5 + [_P]),
     "fov_gauss_nll_grad": (_I, [_P] * 6 + [_I] * 3 + [ctypes.c_float, _P, _SZ, _P]),
     "fov_rmsprop_tf_step": (_I, [_P] * 3 + [ctypes.c_int64] + [ctypes.c_float] * 4 + [_P]),
     "fov_categorical_crossentropy_grad": (_I, [_P] * 4 + [ctypes.c_int64, _I, _P, _SZ, _P]),

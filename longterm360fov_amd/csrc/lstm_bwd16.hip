@@ -13,6 +13,9 @@
 //   the 16 x 32 piece of every destination workgroup travels as fp32 {value, epoch} granules; each lane gathers the
 //   sixteen pieces of its own two cells and adds them in slice order (deterministic).
 // Bias gradient: one (tiles, 4H) partial, summed over the tile's rows and all steps, as in the other BPTT kernels.
+// Two group sizes of one kernel: XG = 16 as described (any batch), and XG = 32 - sixteen units per workgroup, one cell per lane,
+// half the matrix work per step and workgroup (128 MFMAs per wave, 128 accumulation registers of R^T) - while a launch has at
+// most eight tiles (128 sequences: lstm.py trains at 32), the regime where a step's latency is all that matters.
 #include <stdlib.h>
 
 #include "bf16_common.h"
@@ -22,10 +25,8 @@ namespace fov {
 namespace {
 
 constexpr int XH = 512;            // hidden units
-constexpr int XG = 16;             // workgroups per tile
 constexpr int XBT = 16;            // sequences per tile
-constexpr int XLDZ = 128 + 4;      // fp32 LDS row stride of the dz tile
-constexpr size_t X_PAR = (size_t)XG * XG * XBT * 32;   // granules per parity: [dest][src][row][unit]
+constexpr size_t x_par(int XG) { return (size_t)XG * XBT * XH; }   // granules per parity: [dest][src][row][unit of the dest]
 
 struct Bwd16Params {
     const float* R;
@@ -51,8 +52,15 @@ __device__ __forceinline__ float x_act_grad(float a) {
     return ACT == FOV_ACT_HARD_SIGMOID ? ((a > 0.f && a < 1.f) ? 0.2f : 0.f) : a * (1.f - a);
 }
 
-template <int ACT>
+template <int ACT, int XG>
 __global__ __launch_bounds__(256, 1) void lstm_bwd16_kernel(Bwd16Params p) {
+    constexpr int UW = XH / XG;          // units per workgroup: 32 | 16
+    constexpr int CW = 4 * UW;           // own gate columns: 128 | 64
+    constexpr int XLDZ = CW + 4;         // fp32 LDS row stride of the dz tile
+    constexpr int JB = CW / 16;          // 16-column k-blocks: 8 | 4
+    constexpr int CPL = XBT * UW / 256;  // cells per lane: 2 | 1
+    constexpr int UB = UW / 4;           // units per wave: 8 | 4
+    constexpr size_t X_PAR = x_par(XG);
     __shared__ __attribute__((aligned(16))) float sDZ[XBT * XLDZ];
     __shared__ int sFlag[4];
     __shared__ unsigned sXch[4];
@@ -67,26 +75,27 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd16_kernel(Bwd16Params p) {
         slice = blockIdx.x - group * XG;
     }
     constexpr int H4 = 4 * XH;
-    const int hi = n >> 3;
-    const int ul = 8 * wave + (n & 7);          // unit inside the workgroup (0..31)
-    const int unit = 32 * slice + ul;
-    const int my_row0 = 4 * g4 + 2 * hi;
+    const int hi = n / UB;                          // row selector inside the 4-row block of g4
+    const int ul = UB * wave + (n & (UB - 1));      // unit inside the workgroup
+    const int unit = UW * slice + ul;
+    const int my_row0 = 4 * g4 + CPL * hi;
     const int T = p.T;
     // epoch tags continue from the workspace header, a poisoned workspace skips the body (xch_common.h)
     const unsigned arrival = xch_arrive(p.status, sXch, group, slice);
     const bool poisoned = xch_poisoned(p.status);
     if (tid == 0) sFlag[0] = poisoned ? 1 : 0;
 
-    // ---- resident R^T fragments.  Tile tl of this wave: destination slice 4*wave + (tl>>1), half tl&1; its output unit
-    // on this lane is nout; k index lc is an own gate column: gate lc>>5, unit 32*slice + (lc & 31). ----
-    float rt[8][8][4];   // [tl][jb][s], lc = 16*jb + 4*g4 + s
+    // ---- resident R^T fragments.  Tile tl of this wave: output units 16*(8*wave + tl) .. +16 (destination slice
+    // 16*(8*wave + tl) / UW); its output unit on this lane is nout; k index lc is an own gate column: gate lc / UW, unit
+    // UW*slice + lc % UW. ----
+    float rt[8][JB][4];   // [tl][jb][s], lc = 16*jb + 4*g4 + s
 #pragma unroll
     for (int tl = 0; tl < 8; ++tl) {
-        const int nout = 32 * (4 * wave + (tl >> 1)) + 16 * (tl & 1) + n;
+        const int nout = 16 * (8 * wave + tl) + n;
 #pragma unroll
-        for (int jb = 0; jb < 8; ++jb) {
+        for (int jb = 0; jb < JB; ++jb) {
             const int lc = 16 * jb + 4 * g4;
-            const f32x4 v = *(const f32x4*)(p.R + (size_t)nout * H4 + (lc >> 5) * XH + 32 * slice + (lc & 31));
+            const f32x4 v = *(const f32x4*)(p.R + (size_t)nout * H4 + (lc / UW) * XH + UW * slice + (lc % UW));
 #pragma unroll
             for (int s = 0; s < 4; ++s) rt[tl][jb][s] = v[s];
         }
@@ -102,10 +111,10 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd16_kernel(Bwd16Params p) {
 
     for (int tile = group; tile < p.num_tiles && !aborted; tile += p.num_groups) {
         const int b0 = tile * XBT;
-        float dc[2], dh[2];
-        bool live[2];
+        float dc[CPL], dh[CPL];
+        bool live[CPL];
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
+        for (int r = 0; r < CPL; ++r) {
             const int row = b0 + my_row0 + r;
             live[r] = row < p.B;
             dc[r] = (live[r] && p.dcT) ? p.dcT[(size_t)row * XH + unit] : 0.f;
@@ -113,11 +122,11 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd16_kernel(Bwd16Params p) {
         }
         // Tape of this lane's two cells, ONE step ahead (lstm_bwd8.hip): [0..3] = i,f,g,o, [4] = c of the step, [5] = c of
         // the step before it, [6] = dhs of the step.  Unconditional loads, rows and steps clamped, dead rows masked at use.
-        float cur[7][2], pre[7][2];
-        auto load_step = [&](int t, float (&dst)[7][2]) {
+        float cur[7][CPL], pre[7][CPL];
+        auto load_step = [&](int t, float (&dst)[7][CPL]) {
             const int tc = t > 0 ? t : 0;
 #pragma unroll
-            for (int r = 0; r < 2; ++r) {
+            for (int r = 0; r < CPL; ++r) {
                 const int row = b0 + my_row0 + r;
                 const size_t rowc = (size_t)(row < p.B ? row : p.B - 1);
                 const float* rp = p.reserve + ((rowc * T + tc) * 5) * XH + unit;
@@ -135,9 +144,9 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd16_kernel(Bwd16Params p) {
         for (int t = T - 1; t >= 0; --t) {
             ++epoch;
             const unsigned par = (epoch & 1u) * (unsigned)(X_PAR * 8);
-            // ---- pointwise: dz of this lane's two cells ----
+            // ---- pointwise: dz of this lane's cells ----
 #pragma unroll
-            for (int r = 0; r < 2; ++r) {
+            for (int r = 0; r < CPL; ++r) {
                 const float ig = cur[0][r], fg = cur[1][r], gg = cur[2][r], og = cur[3][r], cc = cur[4][r];
                 const float cprev = (t > 0 || p.c0) ? cur[5][r] : 0.f;   // step 0 without a given state: c_{-1} = 0
                 const float dht = dh[r] + cur[6][r];
@@ -157,16 +166,18 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd16_kernel(Bwd16Params p) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     dbacc[g] += dzv[g];
-                    sDZ[(my_row0 + r) * XLDZ + g * 32 + ul] = dzv[g];
+                    sDZ[(my_row0 + r) * XLDZ + g * UW + ul] = dzv[g];
                 }
             }
             // the tape of step t-1 is requested here, a whole step before its use
             load_step(t - 1, pre);
             __syncthreads();   // barrier A: the dz tile is complete
-            // ---- partial[16 x 512] = dz_own . R^T_own ; tile tl -> destination 4*wave + (tl>>1).  Two passes of four tiles:
+            // ---- partial[16 x 512] = dz_own . R^T_own ; tile tl -> output units 16*(8*wave + tl) .. +16.  Two passes of four tiles:
             // the granules of the first pass are on their way (an sc1 store takes about a microsecond to become visible)
             // while the matrix pipe works on the second. ----
-            const unsigned off0 = (unsigned)((((4 * wave * XG + slice) * XBT + 4 * g4) * 32) + n) * 8u;
+            // one address register for all stores: the wave's first destination is part of it, the tile's goes into the scalar offset
+            constexpr unsigned DSTR = XG * XBT * UW * 8;     // bytes per destination slice
+            const unsigned off0 = (unsigned)(((slice * XBT + 4 * g4) * UW) + n) * 8u + (unsigned)wave * (128 / UW) * DSTR;
             const float* arow = sDZ + n * XLDZ + 4 * g4;
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
@@ -176,8 +187,8 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd16_kernel(Bwd16Params p) {
                 asm volatile("s_nop 3" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
                 f32x4 a = *(const f32x4*)arow, an = a;
 #pragma unroll
-                for (int jb = 0; jb < 8; ++jb) {
-                    if (jb + 1 < 8) an = *(const f32x4*)(arow + 16 * (jb + 1));
+                for (int jb = 0; jb < JB; ++jb) {
+                    if (jb + 1 < JB) an = *(const f32x4*)(arow + 16 * (jb + 1));
                     asm volatile("s_nop 1" : "+v"(a));
 #pragma unroll
                     for (int tq = 0; tq < 4; ++tq)
@@ -186,30 +197,30 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd16_kernel(Bwd16Params p) {
                     a = an;
                 }
                 asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
-                // one address register for all stores: the tile's destination goes into the scalar offset
 #pragma unroll
                 for (int tq = 0; tq < 4; ++tq) {
                     const int tl = 4 * half + tq;
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
                         XCH_STORE_B64(ticket.same_xcd, ((qu32x2){__float_as_uint(acc[tq][r]), epoch}), rs,
-                                      off0 + (tl & 1) * 16 * 8 + r * 32 * 8, par + (unsigned)(tl >> 1) * (XG * XBT * 32 * 8));
+                                      off0 + ((16 * tl) % UW) * 8 + r * UW * 8, par + (unsigned)((16 * tl) / UW) * DSTR);
                 }
             }
-            // ---- gather the 16 pieces of this lane's two cells, add in slice order ----
+            // ---- gather the XG pieces of each of this lane's cells, add in slice order ----
             {
-                const unsigned voff = (unsigned)(((slice * XG) * XBT + my_row0) * 32 + ul) * 8u;
-                constexpr unsigned SSTR = XBT * 32 * 8;   // src stride in bytes
-                float part[32];
+                const unsigned voff = (unsigned)(((slice * XG) * XBT + my_row0) * UW + ul) * 8u;
+                constexpr unsigned SSTR = XBT * UW * 8;   // src stride in bytes
+                constexpr int NP = CPL * XG;              // 32 either way
+                float part[NP];
                 unsigned bad = 0;
                 {
-                    qu32x2 v[32];
+                    qu32x2 v[NP];
 #pragma unroll
-                    for (int q = 0; q < 2; ++q)
+                    for (int q = 0; q < CPL; ++q)
 #pragma unroll
-                        for (int s = 0; s < 16; ++s) v[q * 16 + s] = __builtin_amdgcn_raw_buffer_load_b64(rs, voff + q * 32 * 8, par + s * SSTR, 16);
+                        for (int s = 0; s < XG; ++s) v[q * XG + s] = __builtin_amdgcn_raw_buffer_load_b64(rs, voff + q * UW * 8, par + s * SSTR, 16);
 #pragma unroll
-                    for (int j = 0; j < 32; ++j) {
+                    for (int j = 0; j < NP; ++j) {
                         part[j] = __uint_as_float(v[j].x);
                         if (v[j].y != epoch) bad |= (1u << j);
                     }
@@ -224,48 +235,52 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd16_kernel(Bwd16Params p) {
                     __builtin_amdgcn_s_sleep(1);
                     asm volatile("" ::: "memory");
 #pragma unroll
-                    for (int h = 0; h < 2; ++h) {   // one cell's sixteen sources at a time: half the registers of a full sweep
+                    for (int h = 0; h < 2; ++h) {   // sixteen granules at a time: half the registers of a full sweep
                         qu32x2 tv[16];
 #pragma unroll
-                        for (int s = 0; s < 16; ++s) tv[s] = __builtin_amdgcn_raw_buffer_load_b64(rs, voff + h * 32 * 8, par + s * SSTR, 16);
+                        for (int u = 0; u < 16; ++u) {
+                            const int j = h * 16 + u, q = j / XG, s_ = j % XG;
+                            tv[u] = __builtin_amdgcn_raw_buffer_load_b64(rs, voff + q * UW * 8, par + s_ * SSTR, 16);
+                        }
 #pragma unroll
-                        for (int s = 0; s < 16; ++s) {
-                            const int j = h * 16 + s;
-                            if (((bad >> j) & 1u) && tv[s].y == epoch) {
-                                part[j] = __uint_as_float(tv[s].x);
+                        for (int u = 0; u < 16; ++u) {
+                            const int j = h * 16 + u;
+                            if (((bad >> j) & 1u) && tv[u].y == epoch) {
+                                part[j] = __uint_as_float(tv[u].x);
                                 bad &= ~(1u << j);
                             }
                         }
                     }
                 }
 #pragma unroll
-                for (int q = 0; q < 2; ++q) {
+                for (int q = 0; q < CPL; ++q) {
                     float a = 0.f;
 #pragma unroll
-                    for (int s = 0; s < 16; ++s) a += part[q * 16 + s];
+                    for (int s = 0; s < XG; ++s) a += part[q * XG + s];
                     dh[q] = a;
                 }
             }
 #pragma unroll
             for (int q = 0; q < 7; ++q)
 #pragma unroll
-                for (int r = 0; r < 2; ++r) cur[q][r] = pre[q][r];   // requested most of a step ago: long landed
+                for (int r = 0; r < CPL; ++r) cur[q][r] = pre[q][r];   // requested most of a step ago: long landed
             __syncthreads();   // barrier B: every wave is done reading the dz tile; sFlag is uniform below
             if (sFlag[0]) { aborted = true; break; }
         }
         if (!aborted && p.db_part) {
-            // the 8 lanes (g4 0..3, hi 0..1) that share a unit hold different rows: fold them in a fixed order
+            // the lanes that share a unit (all g4, all row selectors) hold different rows: fold them in a fixed order
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 float v = dbacc[g];
-                v += __shfl_xor(v, 8);
+#pragma unroll
+                for (int m = UB; m < 16; m <<= 1) v += __shfl_xor(v, m);
                 const float v1 = __shfl(v, (lane + 16) & 63), v2 = __shfl(v, (lane + 32) & 63), v3 = __shfl(v, (lane + 48) & 63);
                 if (g4 == 0 && hi == 0) p.db_part[(size_t)tile * H4 + g * XH + unit] = (v + v1) + (v2 + v3);
             }
         }
         if (!aborted) {
 #pragma unroll
-            for (int r = 0; r < 2; ++r) {
+            for (int r = 0; r < CPL; ++r) {
                 const int row = b0 + my_row0 + r;
                 if (row < p.B) {
                     if (p.dh0) p.dh0[(size_t)row * XH + unit] = dh[r];
@@ -280,30 +295,38 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd16_kernel(Bwd16Params p) {
 }  // namespace
 
 // width 512 and a device with at least sixteen CUs (one workgroup per CU: the R^T slice takes a whole register file)
-bool bwd16_shape_ok(int H) { return H == XH && device_cu_count() >= XG; }
+bool bwd16_shape_ok(int H) { return H == XH && device_cu_count() >= 16; }
+
+template <int XG>
+static int launch_bwd16_t(Bwd16Params& p, int act, hipStream_t stream) {
+    const int max_groups = device_cu_count() / XG;
+    p.num_groups = p.num_tiles < max_groups ? p.num_tiles : max_groups;
+    if ((size_t)p.num_groups * 2 * x_par(XG) * 8 > kXchBytes - kHelloBytes) { set_error("width-512 BPTT kernel: granule area too small"); return FOV_ERR_WORKSPACE; }
+    p.epoch_span = p.T * ((p.num_tiles + p.num_groups - 1) / p.num_groups) + 1;
+    if (int rc_ = xch_account(p.status, p.epoch_span, stream)) return rc_;
+    void (*kern)(Bwd16Params) = act == FOV_ACT_HARD_SIGMOID ? lstm_bwd16_kernel<FOV_ACT_HARD_SIGMOID, XG> : lstm_bwd16_kernel<FOV_ACT_SIGMOID, XG>;
+    hipLaunchKernelGGL(kern, dim3(p.num_groups * XG), dim3(256), 0, stream, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_error("width-512 BPTT launch: %s", hipGetErrorString(e)); return FOV_ERR_LAUNCH; }
+    return FOV_OK;
+}
 
 // status word + granule buffers live at `xch_ws` (kStatusBytes + kXchBytes)
 int launch_bwd16(const float* R, const float* reserve, const float* c0, const float* dhs, const float* dhT, const float* dcT,
                  float* dz, float* dh0, float* dc0, float* db_part, int B, int T, int act, void* xch_ws, hipStream_t stream) {
     if (B == 0 || T == 0) return FOV_OK;
-    if (((uintptr_t)R) & 15) { set_error("16-group BPTT kernel: R must be 16-byte aligned"); return FOV_ERR_INVALID; }
+    if (((uintptr_t)R) & 15) { set_error("width-512 BPTT kernel: R must be 16-byte aligned"); return FOV_ERR_INVALID; }
     Bwd16Params p = {};
     p.R = R; p.reserve = reserve; p.c0 = c0; p.dhs = dhs; p.dhT = dhT; p.dcT = dcT; p.dz = dz; p.dh0 = dh0; p.dc0 = dc0; p.db_part = db_part;
     p.B = B; p.T = T;
     p.num_tiles = (B + XBT - 1) / XBT;
-    const int max_groups = device_cu_count() / XG;
-    if (max_groups < 1) { set_error("16-group BPTT kernel needs at least %d CUs", XG); return FOV_ERR_UNSUPPORTED; }
-    p.num_groups = p.num_tiles < max_groups ? p.num_tiles : max_groups;
-    if ((size_t)p.num_groups * 2 * X_PAR * 8 > kXchBytes - kHelloBytes) { set_error("16-group BPTT kernel: granule area too small"); return FOV_ERR_WORKSPACE; }
     p.status = (unsigned*)xch_ws;
     p.xch = (unsigned long long*)((char*)xch_ws + kStatusBytes);
-    p.epoch_span = T * ((p.num_tiles + p.num_groups - 1) / p.num_groups) + 1;
-    if (int rc_ = xch_account(p.status, p.epoch_span, stream)) return rc_;
-    void (*kern)(Bwd16Params) = act == FOV_ACT_HARD_SIGMOID ? lstm_bwd16_kernel<FOV_ACT_HARD_SIGMOID> : lstm_bwd16_kernel<FOV_ACT_SIGMOID>;
-    hipLaunchKernelGGL(kern, dim3(p.num_groups * XG), dim3(256), 0, stream, p);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) { set_error("16-group BPTT launch: %s", hipGetErrorString(e)); return FOV_ERR_LAUNCH; }
-    return FOV_OK;
+    if (device_cu_count() < 16) { set_error("width-512 BPTT kernel needs at least 16 CUs"); return FOV_ERR_UNSUPPORTED; }
+    // at most eight tiles and one tile per group: thirty-two workgroups per tile (FOV_BWD16_GROUPS=16 keeps sixteen)
+    static const bool force16 = [] { const char* e = getenv("FOV_BWD16_GROUPS"); return e && atoi(e) == 16; }();
+    if (!force16 && p.num_tiles <= 8 && p.num_tiles <= device_cu_count() / 32) return launch_bwd16_t<32>(p, act, stream);
+    return launch_bwd16_t<16>(p, act, stream);
 }
 
 }  // namespace fov

@@ -397,6 +397,38 @@ def act_fwd(x, activation, out=None):
     return out
 
 
+def tf_head_supported(B, H, M, O):
+    return bool(_lib.lib().fov_tf_head_supported(B, H, M, O))
+
+
+def tf_head_fwd(h, w):
+    """lstm.py:321-337, both heads in one launch: w has mu_W1, mu_b1, mu_W2, mu_b2, var_W1, ... -> (a1, mu, a3, var)."""
+    h = _dev(h, "h")
+    B, H = h.shape
+    M, O = w["mu_W2"].shape
+    e = lambda *s: torch.empty(s, dtype=torch.float32, device=h.device)
+    a1, mu, a3, var = e(B, M), e(B, O), e(B, M), e(B, O)
+    names = ("mu_W1", "mu_b1", "mu_W2", "mu_b2", "var_W1", "var_b1", "var_W2", "var_b2")
+    check(_lib.lib().fov_tf_head_fwd(_ptr(h), *[_ptr(_dev(w[k], k)) for k in names], _ptr(a1), _ptr(mu), _ptr(a3), _ptr(var),
+                                     B, H, M, O, _stream()))
+    return a1, mu, a3, var
+
+
+def tf_head_bwd(h, w, head, dmu, dvar, g, accumulate=False):
+    """Backward of tf_head_fwd in one launch: head = (a1, mu, a3, var); the eight gradients go to g[name] (added when
+    accumulate); returns dh (B,H)."""
+    h = _dev(h, "h")
+    B, H = h.shape
+    M, O = w["mu_W2"].shape
+    a1, mu, a3, var = head
+    dh = torch.empty((B, H), dtype=torch.float32, device=h.device)
+    gn = ("mu_W1", "mu_b1", "mu_W2", "mu_b2", "var_W1", "var_b1", "var_W2", "var_b2")
+    check(_lib.lib().fov_tf_head_bwd(_ptr(h), _ptr(w["mu_W1"]), _ptr(w["mu_W2"]), _ptr(w["var_W1"]), _ptr(w["var_W2"]), _ptr(a1),
+                                     _ptr(mu), _ptr(a3), _ptr(var), _ptr(_dev(dmu, "dmu")), _ptr(_dev(dvar, "dvar")),
+                                     *[_ptr(_dev(g[k], k)) for k in gn], _ptr(dh), B, H, M, O, 1 if accumulate else 0, _stream()))
+    return dh
+
+
 def gauss_nll_grad(mu, var, y, fps, scale, scratch=None):
     """Gaussian NLL of cost.py:190-229 -> (loss (1,), dmu (B,3), dvar (B,3)).  y (B,T_y,3*fps)."""
     mu, var, y = _dev(mu, "mu"), _dev(var, "var"), _dev(y, "y")

@@ -1538,8 +1538,14 @@ class TFLSTMTrainer:
             out.append((Wt, bt))
         return out
 
+    def _head_fused(self, h):
+        M, O = self.w["mu_W2"].shape
+        return os.environ.get("FOV_NO_TF_HEAD") is None and ops.tf_head_supported(h.shape[0], h.shape[1], M, O)
+
     def _head(self, h):
         w = self.w
+        if self._head_fused(h):      # one launch instead of seven (tf_head.hip)
+            return ops.tf_head_fwd(h, w)
         a1 = ops.dense(h, w["mu_W1"], w["mu_b1"], activation=None)
         ops.act_fwd(a1, "relu", out=a1)
         mu = ops.dense(a1, w["mu_W2"], w["mu_b2"], activation="tanh")
@@ -1600,6 +1606,8 @@ class TFLSTMTrainer:
 
     def _head_backward(self, hT, head, dmu, dvar, accumulate):
         w, g, sc = self.w, self.g, self.scratch
+        if self._head_fused(hT):     # one launch instead of thirteen
+            return ops.tf_head_bwd(hT, w, head, dmu, dvar, g, accumulate=accumulate)
         a1, mu, a3, var = head
         d2 = ops.act_bwd(dmu, mu, activation="tanh")
         da1, _, _ = ops.dense_bwd(a1, w["mu_W2"], d2, dW=g["mu_W2"], db=g["mu_b2"], scratch=sc, accumulate=accumulate)
@@ -1614,9 +1622,11 @@ class TFLSTMTrainer:
     def _stack_backward(self, tape, dhT, masks, accumulate, need_dx0=False):
         w, g = self.w, self.g
         dhs, dx0 = None, None
-        # (tried: each layer's weight-gradient products on a side stream under the next layer's recurrence - at lstm.py's batch a
-        # BPTT launch occupies 32 of 256 CUs.  0.596 -> 0.656 ms: the step is bound by the HOST's launch rate at this size, and the
-        # shifted copy of hs plus two stream hand-offs per layer cost more than the 60 us of overlapped products gain.)
+        # (Tried twice: each layer's weight-gradient products on a second stream beside the next layer's recurrence - at lstm.py's
+        # batch a BPTT launch occupies 32 of 256 CUs.  Arranged from Python (shifted copy of hs + fov_wgrad_fused + two stream
+        # hand-offs per layer) 0.596 -> 0.656 ms; arranged inside fov_lstm_seq_bwd (events, products deferred until the next
+        # recurrence is queued) 0.520 -> 0.538 ms: the 45 us of products do overlap in the timeline, but every cross-stream
+        # hand-off leaves a 7-16 us gap in a step that is a chain of short launches.)
         for l in range(self.L - 1, -1, -1):
             inp, hs, res, h0, c0 = tape[l]
             b = ops.lstm_seq_bwd(inp, w["K%d" % l], w["R%d" % l], hs, res, h0=h0, c0=c0, dhs=dhs,

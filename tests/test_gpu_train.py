@@ -346,8 +346,9 @@ def test_persistent_bptt_matches_stepped_and_oracle():
     fp64 oracle: ragged multi-tile batch (more tiles than groups), given initial state, dhs + dhT/dcT."""
     from longterm360fov_amd import ops
     rng = np.random.default_rng(7)
-    for H, B, T in ((256, 16 * 64 + 16 * 3 + 5, 3), (128, 37, 6), (64, 21, 4), (512, 16 * 16 + 16 * 2 + 5, 3), (512, 32, 10)):
-        F = 11      # width 512: lstm_bwd16.hip, sixteen workgroups per tile (293 sequences = 19 tiles on 16 groups; 32 = lstm.py's batch)
+    for H, B, T in ((256, 16 * 64 + 16 * 3 + 5, 3), (128, 37, 6), (64, 21, 4), (512, 16 * 16 + 16 * 2 + 5, 3), (512, 32, 10), (512, 100, 4)):
+        F = 11      # width 512: lstm_bwd16.hip - sixteen workgroups per tile (293 sequences = 19 tiles on 16 groups), thirty-two up to
+        # eight tiles (32 sequences = lstm.py's batch; 100 = seven tiles, the last one ragged)
         K, R, b = O.init_lstm(rng, F, H, np.float32)
         b = (b + 0.1 * rng.standard_normal(b.shape)).astype(np.float32)
         x = rng.uniform(-1, 1, (B, T, F)).astype(np.float32)
@@ -760,6 +761,16 @@ def test_tf_stacked_lstm_training_graph(H, B, T, with_masks):
         bg = np.empty_like(cg[l][1]); bg[perm] = b
         assert np.abs(Wg - cg[l][0]).max() <= 2e-4 * np.abs(cg[l][0]).max() + 1e-9, ("W", l)
         assert np.abs(bg - cg[l][1]).max() <= 2e-4 * np.abs(cg[l][1]).max() + 1e-9, ("b", l)
+    # the fused two-head launches (tf_head.hip) against the generic Dense / activation entry points
+    os.environ["FOV_NO_TF_HEAD"] = "1"
+    try:
+        loss_u, mu_u, var_u, _ = tr.forward_backward(dev(x), dev(y), dev(init), masks=dm)
+        tg_u = tr.grads_numpy()
+    finally:
+        os.environ.pop("FOV_NO_TF_HEAD", None)
+    assert np.abs(mu_u.cpu().numpy() - mu.cpu().numpy()).max() < 2e-6 and abs(float(loss_u.item()) - float(loss.item())) < 1e-6
+    for k in tr.order:
+        assert np.abs(tg_u[k] - tg[k]).max() <= 2e-5 * np.abs(tg[k]).max() + 1e-9, k
     # round trip of the layout conversion, then a few optimizer steps reduce the loss
     for (W0, b0), (W1, b1) in zip(cells, tr.cells_tf()):
         assert np.abs(W0 - W1).max() < 1e-7 and np.abs(b0 - b1).max() < 1e-6
