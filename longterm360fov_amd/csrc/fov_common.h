@@ -194,10 +194,10 @@ int mix_decoder_bwd_bf16_launch(MixDecBwdParams p, const float* K2, int act, voi
 
 // persistent BPTT recurrence (lstm_bwd_cluster.hip)
 bool bwd_cluster_shape_ok(int H);
-// lstm_bwd16.hip: the width-512 BPTT recurrence, sixteen workgroups per 16-sequence tile (fp32)
-bool bwd16_shape_ok(int H);
+// lstm_bwd16.hip: BPTT recurrence with 16 / 32 units per workgroup (fp32): width 512, and 128 / 256 at small batches
+bool bwd16_takes(int B, int H);
 int launch_bwd16(const float* R, const float* reserve, const float* c0, const float* dhs, const float* dhT, const float* dcT,
-                 float* dz, float* dh0, float* dc0, float* db_part, int B, int T, int act, void* xch_ws, hipStream_t stream);
+                 float* dz, float* dh0, float* dc0, float* db_part, int B, int T, int H, int act, void* xch_ws, hipStream_t stream);
 size_t bwd_cluster_xch_bytes(int B, int H);
 int launch_bwd_cluster(const float* R, const float* reserve, const float* c0, const float* dhs, const float* dhT,
                        const float* dcT, float* dz, float* dh0, float* dc0, float* db_part, int B, int T, int H, int act,

@@ -24,9 +24,8 @@ namespace fov {
 
 namespace {
 
-constexpr int XH = 512;            // hidden units
 constexpr int XBT = 16;            // sequences per tile
-constexpr size_t x_par(int XG) { return (size_t)XG * XBT * XH; }   // granules per parity: [dest][src][row][unit of the dest]
+constexpr size_t x_par(int XG, int XH) { return (size_t)XG * XBT * XH; }   // granules per parity: [dest][src][row][unit of the dest]
 
 struct Bwd16Params {
     const float* R;
@@ -52,15 +51,17 @@ __device__ __forceinline__ float x_act_grad(float a) {
     return ACT == FOV_ACT_HARD_SIGMOID ? ((a > 0.f && a < 1.f) ? 0.2f : 0.f) : a * (1.f - a);
 }
 
-template <int ACT, int XG>
+template <int ACT, int XH, int XG>
 __global__ __launch_bounds__(256, 1) void lstm_bwd16_kernel(Bwd16Params p) {
     constexpr int UW = XH / XG;          // units per workgroup: 32 | 16
+    constexpr int NT = XH / 64;          // 16-unit output tiles per wave: 8 (width 512) | 4 | 2
+    constexpr int NPASS = NT >= 8 ? 2 : 1, TQ = NT / NPASS;   // tiles per pass
     constexpr int CW = 4 * UW;           // own gate columns: 128 | 64
     constexpr int XLDZ = CW + 4;         // fp32 LDS row stride of the dz tile
     constexpr int JB = CW / 16;          // 16-column k-blocks: 8 | 4
     constexpr int CPL = XBT * UW / 256;  // cells per lane: 2 | 1
     constexpr int UB = UW / 4;           // units per wave: 8 | 4
-    constexpr size_t X_PAR = x_par(XG);
+    constexpr size_t X_PAR = x_par(XG, XH);
     __shared__ __attribute__((aligned(16))) float sDZ[XBT * XLDZ];
     __shared__ int sFlag[4];
     __shared__ unsigned sXch[4];
@@ -88,10 +89,10 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd16_kernel(Bwd16Params p) {
     // ---- resident R^T fragments.  Tile tl of this wave: output units 16*(8*wave + tl) .. +16 (destination slice
     // 16*(8*wave + tl) / UW); its output unit on this lane is nout; k index lc is an own gate column: gate lc / UW, unit
     // UW*slice + lc % UW. ----
-    float rt[8][JB][4];   // [tl][jb][s], lc = 16*jb + 4*g4 + s
+    float rt[NT][JB][4];   // [tl][jb][s], lc = 16*jb + 4*g4 + s
 #pragma unroll
-    for (int tl = 0; tl < 8; ++tl) {
-        const int nout = 16 * (8 * wave + tl) + n;
+    for (int tl = 0; tl < NT; ++tl) {
+        const int nout = 16 * (NT * wave + tl) + n;
 #pragma unroll
         for (int jb = 0; jb < JB; ++jb) {
             const int lc = 16 * jb + 4 * g4;
@@ -177,29 +178,31 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd16_kernel(Bwd16Params p) {
             // while the matrix pipe works on the second. ----
             // one address register for all stores: the wave's first destination is part of it, the tile's goes into the scalar offset
             constexpr unsigned DSTR = XG * XBT * UW * 8;     // bytes per destination slice
-            const unsigned off0 = (unsigned)(((slice * XBT + 4 * g4) * UW) + n) * 8u + (unsigned)wave * (128 / UW) * DSTR;
+            const unsigned off0 = (unsigned)(((slice * XBT + 4 * g4) * UW) + n) * 8u + (unsigned)wave * (16 * NT / UW) * DSTR;
             const float* arow = sDZ + n * XLDZ + 4 * g4;
 #pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                f32x4 acc[4];
+            for (int pass = 0; pass < NPASS; ++pass) {
+                f32x4 acc[TQ];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                asm volatile("s_nop 3" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
+                for (int i = 0; i < TQ; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if constexpr (TQ == 4) asm volatile("s_nop 3" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
+                else asm volatile("s_nop 3" : "+v"(acc[0]), "+v"(acc[1]));
                 f32x4 a = *(const f32x4*)arow, an = a;
 #pragma unroll
                 for (int jb = 0; jb < JB; ++jb) {
                     if (jb + 1 < JB) an = *(const f32x4*)(arow + 16 * (jb + 1));
                     asm volatile("s_nop 1" : "+v"(a));
 #pragma unroll
-                    for (int tq = 0; tq < 4; ++tq)
+                    for (int tq = 0; tq < TQ; ++tq)
 #pragma unroll
-                        for (int s = 0; s < 4; ++s) x_mfma_a(acc[tq], a[s], rt[4 * half + tq][jb][s]);
+                        for (int s = 0; s < 4; ++s) x_mfma_a(acc[tq], a[s], rt[TQ * pass + tq][jb][s]);
                     a = an;
                 }
-                asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
+                if constexpr (TQ == 4) asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
+                else asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" : "+v"(acc[0]), "+v"(acc[1]));
 #pragma unroll
-                for (int tq = 0; tq < 4; ++tq) {
-                    const int tl = 4 * half + tq;
+                for (int tq = 0; tq < TQ; ++tq) {
+                    const int tl = TQ * pass + tq;
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
                         XCH_STORE_B64(ticket.same_xcd, ((qu32x2){__float_as_uint(acc[tq][r]), epoch}), rs,
@@ -210,7 +213,8 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd16_kernel(Bwd16Params p) {
             {
                 const unsigned voff = (unsigned)(((slice * XG) * XBT + my_row0) * UW + ul) * 8u;
                 constexpr unsigned SSTR = XBT * UW * 8;   // src stride in bytes
-                constexpr int NP = CPL * XG;              // 32 either way
+                constexpr int NP = CPL * XG;              // 32 at width 512; 16 | 8 at the narrower widths
+                constexpr int CH = NP < 16 ? NP : 16;     // granules per retry sweep
                 float part[NP];
                 unsigned bad = 0;
                 {
@@ -235,16 +239,16 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd16_kernel(Bwd16Params p) {
                     __builtin_amdgcn_s_sleep(1);
                     asm volatile("" ::: "memory");
 #pragma unroll
-                    for (int h = 0; h < 2; ++h) {   // sixteen granules at a time: half the registers of a full sweep
-                        qu32x2 tv[16];
+                    for (int h = 0; h < NP / CH; ++h) {   // at most sixteen granules at a time: half the registers of a full sweep
+                        qu32x2 tv[CH];
 #pragma unroll
-                        for (int u = 0; u < 16; ++u) {
-                            const int j = h * 16 + u, q = j / XG, s_ = j % XG;
+                        for (int u = 0; u < CH; ++u) {
+                            const int j = h * CH + u, q = j / XG, s_ = j % XG;
                             tv[u] = __builtin_amdgcn_raw_buffer_load_b64(rs, voff + q * UW * 8, par + s_ * SSTR, 16);
                         }
 #pragma unroll
-                        for (int u = 0; u < 16; ++u) {
-                            const int j = h * 16 + u;
+                        for (int u = 0; u < CH; ++u) {
+                            const int j = h * CH + u;
                             if (((bad >> j) & 1u) && tv[u].y == epoch) {
                                 part[j] = __uint_as_float(tv[u].x);
                                 bad &= ~(1u << j);
@@ -294,39 +298,50 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd16_kernel(Bwd16Params p) {
 
 }  // namespace
 
-// width 512 and a device with at least sixteen CUs (one workgroup per CU: the R^T slice takes a whole register file)
-bool bwd16_shape_ok(int H) { return H == XH && device_cu_count() >= 16; }
+// Width 512 at any batch; widths 128 / 256 (sixteen units per workgroup: 8 / 16 workgroups per tile) while a launch has at most
+// eight tiles and one tile per group - the latency regime of model.fit at the reference's batch of 32, where the 2- and
+// 4-workgroup kernels of lstm_bwd_cluster.hip spend a step's time on ONE workgroup's share of the product.
+bool bwd16_takes(int B, int H) {
+    const int cus = device_cu_count();
+    if (H == 512) return cus >= 16;
+    if (H != 128 && H != 256) return false;
+    static const bool off = getenv("FOV_NO_BWD16_NARROW") != nullptr;
+    const int tiles = (B + XBT - 1) / XBT;
+    return !off && tiles >= 1 && tiles <= 8 && tiles <= cus / (H / 16);
+}
 
-template <int XG>
+template <int XH, int XG>
 static int launch_bwd16_t(Bwd16Params& p, int act, hipStream_t stream) {
     const int max_groups = device_cu_count() / XG;
     p.num_groups = p.num_tiles < max_groups ? p.num_tiles : max_groups;
-    if ((size_t)p.num_groups * 2 * x_par(XG) * 8 > kXchBytes - kHelloBytes) { set_error("width-512 BPTT kernel: granule area too small"); return FOV_ERR_WORKSPACE; }
+    if ((size_t)p.num_groups * 2 * x_par(XG, XH) * 8 > kXchBytes - kHelloBytes) { set_error("16-unit BPTT kernel: granule area too small"); return FOV_ERR_WORKSPACE; }
     p.epoch_span = p.T * ((p.num_tiles + p.num_groups - 1) / p.num_groups) + 1;
     if (int rc_ = xch_account(p.status, p.epoch_span, stream)) return rc_;
-    void (*kern)(Bwd16Params) = act == FOV_ACT_HARD_SIGMOID ? lstm_bwd16_kernel<FOV_ACT_HARD_SIGMOID, XG> : lstm_bwd16_kernel<FOV_ACT_SIGMOID, XG>;
+    void (*kern)(Bwd16Params) = act == FOV_ACT_HARD_SIGMOID ? lstm_bwd16_kernel<FOV_ACT_HARD_SIGMOID, XH, XG> : lstm_bwd16_kernel<FOV_ACT_SIGMOID, XH, XG>;
     hipLaunchKernelGGL(kern, dim3(p.num_groups * XG), dim3(256), 0, stream, p);
     hipError_t e = hipGetLastError();
-    if (e != hipSuccess) { set_error("width-512 BPTT launch: %s", hipGetErrorString(e)); return FOV_ERR_LAUNCH; }
+    if (e != hipSuccess) { set_error("16-unit BPTT launch: %s", hipGetErrorString(e)); return FOV_ERR_LAUNCH; }
     return FOV_OK;
 }
 
 // status word + granule buffers live at `xch_ws` (kStatusBytes + kXchBytes)
 int launch_bwd16(const float* R, const float* reserve, const float* c0, const float* dhs, const float* dhT, const float* dcT,
-                 float* dz, float* dh0, float* dc0, float* db_part, int B, int T, int act, void* xch_ws, hipStream_t stream) {
+                 float* dz, float* dh0, float* dc0, float* db_part, int B, int T, int H, int act, void* xch_ws, hipStream_t stream) {
     if (B == 0 || T == 0) return FOV_OK;
-    if (((uintptr_t)R) & 15) { set_error("width-512 BPTT kernel: R must be 16-byte aligned"); return FOV_ERR_INVALID; }
+    if (((uintptr_t)R) & 15) { set_error("16-unit BPTT kernel: R must be 16-byte aligned"); return FOV_ERR_INVALID; }
+    if (!bwd16_takes(B, H)) { set_error("16-unit BPTT kernel: unsupported shape B = %d, H = %d", B, H); return FOV_ERR_UNSUPPORTED; }
     Bwd16Params p = {};
     p.R = R; p.reserve = reserve; p.c0 = c0; p.dhs = dhs; p.dhT = dhT; p.dcT = dcT; p.dz = dz; p.dh0 = dh0; p.dc0 = dc0; p.db_part = db_part;
     p.B = B; p.T = T;
     p.num_tiles = (B + XBT - 1) / XBT;
     p.status = (unsigned*)xch_ws;
     p.xch = (unsigned long long*)((char*)xch_ws + kStatusBytes);
-    if (device_cu_count() < 16) { set_error("width-512 BPTT kernel needs at least 16 CUs"); return FOV_ERR_UNSUPPORTED; }
-    // at most eight tiles and one tile per group: thirty-two workgroups per tile (FOV_BWD16_GROUPS=16 keeps sixteen)
+    if (H == 128) return launch_bwd16_t<128, 8>(p, act, stream);
+    if (H == 256) return launch_bwd16_t<256, 16>(p, act, stream);
+    // width 512: at most eight tiles and one tile per group -> thirty-two workgroups per tile (FOV_BWD16_GROUPS=16 keeps sixteen)
     static const bool force16 = [] { const char* e = getenv("FOV_BWD16_GROUPS"); return e && atoi(e) == 16; }();
-    if (!force16 && p.num_tiles <= 8 && p.num_tiles <= device_cu_count() / 32) return launch_bwd16_t<32>(p, act, stream);
-    return launch_bwd16_t<16>(p, act, stream);
+    if (!force16 && p.num_tiles <= 8 && p.num_tiles <= device_cu_count() / 32) return launch_bwd16_t<512, 32>(p, act, stream);
+    return launch_bwd16_t<512, 16>(p, act, stream);
 }
 
 }  // namespace fov

@@ -1440,7 +1440,7 @@ int lstm_seq_bwd(const float* x, const float* K, const float* R, const float* h0
         if (dc0) (void)(dcT ? hipMemcpyAsync(dc0, dcT, bh0, hipMemcpyDeviceToDevice, stream) : hipMemsetAsync(dc0, 0, bh0, stream));
         return FOV_OK;
     }
-    const bool wide16 = !bf16 && bwd16_shape_ok(H) && (((uintptr_t)R) & 15) == 0;   // width 512: lstm_bwd16.hip
+    const bool wide16 = !bf16 && bwd16_takes(B, H) && (((uintptr_t)R) & 15) == 0;   // width 512, small batches at 128 / 256: lstm_bwd16.hip
     const bool persistent = (bwd_cluster_shape_ok(H) || wide16) && !env_knobs().bwd_stepped;
     bool fuse_kr = false, fuse_r = false, dx_in_kernel = false;
     const size_t head = (kStatusBytes + kXchBytes) / sizeof(float);
@@ -1467,7 +1467,7 @@ int lstm_seq_bwd(const float* x, const float* K, const float* R, const float* h0
         dx_in_kernel = bf16 && dx && F == 256 && (((uintptr_t)K) & 15) == 0 && !env_knobs().no_dx_fusion;
         // H = 256: groups of eight workgroups fill the chip up to 32 tiles (the 4-group kernel leaves half of it idle
         // at 512 sequences); bf16 operands exist in the 8-group kernel only
-        int rc = wide16 ? launch_bwd16(R, reserve, c0, dhs, dhT, dcT, dz, dh0 ? dh0 : dh_rec, dc0 ? dc0 : dc, db_part, B, T, act, ws, stream)
+        int rc = wide16 ? launch_bwd16(R, reserve, c0, dhs, dhT, dcT, dz, dh0 ? dh0 : dh_rec, dc0 ? dc0 : dc, db_part, B, T, H, act, ws, stream)
                  : (bf16 || (bwd8_preferred(B, H) && !env_knobs().bwd_groups4))
                      ? launch_bwd8(R, reserve, c0, dhs, dhT, dcT, dz, dh0 ? dh0 : dh_rec, dc0 ? dc0 : dc, db_part, B, T, act, bf16, ws, stream,
                                    dx_in_kernel ? K : nullptr, dx_in_kernel ? dx : nullptr)

@@ -346,9 +346,11 @@ def test_persistent_bptt_matches_stepped_and_oracle():
     fp64 oracle: ragged multi-tile batch (more tiles than groups), given initial state, dhs + dhT/dcT."""
     from longterm360fov_amd import ops
     rng = np.random.default_rng(7)
-    for H, B, T in ((256, 16 * 64 + 16 * 3 + 5, 3), (128, 37, 6), (64, 21, 4), (512, 16 * 16 + 16 * 2 + 5, 3), (512, 32, 10), (512, 100, 4)):
+    for H, B, T in ((256, 16 * 64 + 16 * 3 + 5, 3), (128, 37, 6), (64, 21, 4), (512, 16 * 16 + 16 * 2 + 5, 3), (512, 32, 10), (512, 100, 4),
+                    (256, 100, 5), (128, 16 * 9, 3), (128, 32, 10)):
         F = 11      # width 512: lstm_bwd16.hip - sixteen workgroups per tile (293 sequences = 19 tiles on 16 groups), thirty-two up to
-        # eight tiles (32 sequences = lstm.py's batch; 100 = seven tiles, the last one ragged)
+        # eight tiles (32 sequences = lstm.py's batch; 100 = seven tiles, the last one ragged).  Widths 128 / 256 take the same
+        # kernel (sixteen units per workgroup) up to eight tiles: (128, 37), (256, 100), (128, 32); (128, 144) = nine tiles does not
         K, R, b = O.init_lstm(rng, F, H, np.float32)
         b = (b + 0.1 * rng.standard_normal(b.shape)).astype(np.float32)
         x = rng.uniform(-1, 1, (B, T, F)).astype(np.float32)

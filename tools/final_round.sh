@@ -22,6 +22,13 @@ bash tools/pmc_sq.sh $out bench -- --steps 20 --warmup 3 --no-cpu-baseline
 echo "[final_round] headline PMC done"
 bash tools/prof_train_mixing.sh $out f32
 bash tools/prof_train_mixing.sh $out bf16
+# lstm.py's training step at its native shape: per-launch timeline of the last step
+(cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$out/prof_a10 -o tm -- python3 $GRAFT_REPO_ROOT/tools/a10_train_step.py --steps 20 > $GRAFT_REPO_ROOT/$out/a10_train_profiled.txt 2> $GRAFT_REPO_ROOT/$out/a10_train.err)
+t=$(find $out/prof_a10 -name "*kernel_trace.csv" | head -1)
+[ -n "$t" ] && python3 tools/step_timeline.py $t rmsprop > $out/a10_train_step_timeline.txt
+rm -rf $out/prof_a10
+python3 tools/a10_train_step.py --steps 300 > $out/a10_train_step.txt 2>> $out/a10_train.err
+echo "[final_round] a10 training timeline done"
 # HBM-side bytes per step of the multi-launch modes (FETCH_SIZE / WRITE_SIZE in separate passes)
 root=$GRAFT_REPO_ROOT
 for spec in "train_mixing f32 adam_kernel" "train_mixing bf16 adam_kernel" "infer_mixing f32 mix_decoder_kernel" "infer_mixing bf16 mix_decoder_bf16_kernel" "train f32 adam_kernel"; do
