@@ -60,6 +60,7 @@ struct LstmParams {
     int num_tiles;
     int epoch_span;            // epochs this launch may consume: the last workgroup to leave adds it to the header's base
     int force_safe_exchange;   // 1: never take the same-XCD fast path (tests)
+    int xcd_pad;               // lstm_wide16.hip: grid padded to 8 x (workgroups per tile), block b = member b / 8 of group b % 8
 };
 
 int launch_generic(const LstmParams& p, bool decode, hipStream_t stream);

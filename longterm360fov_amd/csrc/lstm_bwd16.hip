@@ -41,6 +41,7 @@ struct Bwd16Params {
     unsigned long long* xch;
     unsigned* status;
     int B, T, num_groups, num_tiles, epoch_span;
+    int xcd_pad;            // grid padded to 8 x XG blocks: block b = member b / 8 of group b % 8 (same-XCD placement, lstm_wide16.hip)
 };
 
 __device__ __forceinline__ void x_mfma_a(f32x4& acc, float a, float w_agpr) {
@@ -68,7 +69,14 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd16_kernel(Bwd16Params p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 15, g4 = lane >> 4;
     int group, slice;
-    if ((p.num_groups & 7) == 0) {   // members 8 blocks apart: likely one XCD (placement preference only)
+    if (p.xcd_pad) {   // fewer than eight groups: padded grid, the blocks of the absent groups count as arrived and leave
+        group = blockIdx.x & 7;
+        slice = blockIdx.x >> 3;
+        if (group >= p.num_groups) {
+            xch_arrive(p.status, sXch, -1, 0);
+            return;
+        }
+    } else if ((p.num_groups & 7) == 0) {   // members 8 blocks apart: likely one XCD (placement preference only)
         group = (blockIdx.x / (8 * XG)) * 8 + (blockIdx.x & 7);
         slice = (blockIdx.x >> 3) & (XG - 1);
     } else {
@@ -318,7 +326,9 @@ static int launch_bwd16_t(Bwd16Params& p, int act, hipStream_t stream) {
     p.epoch_span = p.T * ((p.num_tiles + p.num_groups - 1) / p.num_groups) + 1;
     if (int rc_ = xch_account(p.status, p.epoch_span, stream)) return rc_;
     void (*kern)(Bwd16Params) = act == FOV_ACT_HARD_SIGMOID ? lstm_bwd16_kernel<FOV_ACT_HARD_SIGMOID, XH, XG> : lstm_bwd16_kernel<FOV_ACT_SIGMOID, XH, XG>;
-    hipLaunchKernelGGL(kern, dim3(p.num_groups * XG), dim3(256), 0, stream, p);
+    static const bool no_pad = getenv("FOV_NO_XCD_PAD") != nullptr;
+    p.xcd_pad = (!no_pad && XG <= 16 && p.num_groups < 8 && device_cu_count() >= 8 * XG) ? 1 : 0;
+    hipLaunchKernelGGL(kern, dim3(p.xcd_pad ? 8 * XG : p.num_groups * XG), dim3(256), 0, stream, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("16-unit BPTT launch: %s", hipGetErrorString(e)); return FOV_ERR_LAUNCH; }
     return FOV_OK;

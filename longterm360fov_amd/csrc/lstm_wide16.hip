@@ -78,7 +78,18 @@ __global__ __launch_bounds__(256, 1) void lstm_wide16_kernel(LstmParams p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 15, g4 = lane >> 4;
     int group, slice;
-    if ((p.num_groups & 7) == 0) {   // members 8 blocks apart: likely one XCD (placement preference only)
+    if (p.xcd_pad) {
+        // Fewer than eight groups: the grid is padded to 8 x WG blocks, block b is member b / 8 of group b % 8, so that the
+        // members of a group sit 8 blocks apart - one XCD under round-robin dispatch, verified by the hello handshake - and
+        // exchange through its L2 (sc0).  The blocks of the absent groups count as arrived and leave.
+        group = blockIdx.x & 7;
+        slice = blockIdx.x >> 3;
+        if (group >= p.num_groups) {
+            __shared__ unsigned sSpare[4];
+            if (p.T > 1) xch_arrive(p.status, sSpare, -1, 0);
+            return;
+        }
+    } else if ((p.num_groups & 7) == 0) {   // members 8 blocks apart: likely one XCD (placement preference only)
         group = (blockIdx.x / (8 * WG)) * 8 + (blockIdx.x & 7);
         slice = (blockIdx.x >> 3) & (WG - 1);
     } else {
@@ -348,7 +359,10 @@ int launch_wide16_t(LstmParams& p, hipStream_t stream) {
                                                              : lstm_wide16_kernel<FOV_ACT_SIGMOID, NJX, WH>;
     int rc = ensure_dynamic_lds((const void*)kern, lds);
     if (rc) return rc;
-    hipLaunchKernelGGL(kern, dim3(p.num_groups * WG), dim3(256), lds, stream, p);
+    // fewer than eight groups of at most sixteen workgroups: same-XCD placement through a padded grid (FOV_NO_XCD_PAD=1: off)
+    static const bool no_pad = getenv("FOV_NO_XCD_PAD") != nullptr;
+    p.xcd_pad = (!no_pad && WG <= 16 && p.num_groups < 8 && device_cu_count() >= 8 * WG) ? 1 : 0;
+    hipLaunchKernelGGL(kern, dim3(p.xcd_pad ? 8 * WG : p.num_groups * WG), dim3(256), lds, stream, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("wide16 LSTM launch: %s", hipGetErrorString(e)); return FOV_ERR_LAUNCH; }
     return FOV_OK;
