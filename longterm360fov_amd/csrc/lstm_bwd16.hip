@@ -327,7 +327,8 @@ static int launch_bwd16_t(Bwd16Params& p, int act, hipStream_t stream) {
     if (int rc_ = xch_account(p.status, p.epoch_span, stream)) return rc_;
     void (*kern)(Bwd16Params) = act == FOV_ACT_HARD_SIGMOID ? lstm_bwd16_kernel<FOV_ACT_HARD_SIGMOID, XH, XG> : lstm_bwd16_kernel<FOV_ACT_SIGMOID, XH, XG>;
     static const bool no_pad = getenv("FOV_NO_XCD_PAD") != nullptr;
-    p.xcd_pad = (!no_pad && XG <= 16 && p.num_groups < 8 && device_cu_count() >= 8 * XG) ? 1 : 0;
+    static const int pad_max = getenv("FOV_XCD_PAD_MAX") ? atoi(getenv("FOV_XCD_PAD_MAX")) : 16;   // members per group at most
+    p.xcd_pad = (!no_pad && XG <= pad_max && p.num_groups < 8 && device_cu_count() >= 8 * XG) ? 1 : 0;
     hipLaunchKernelGGL(kern, dim3(p.xcd_pad ? 8 * XG : p.num_groups * XG), dim3(256), 0, stream, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("16-unit BPTT launch: %s", hipGetErrorString(e)); return FOV_ERR_LAUNCH; }

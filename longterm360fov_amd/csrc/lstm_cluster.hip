@@ -397,7 +397,7 @@ __device__ __forceinline__ void cluster_body(const LstmParams& p, ClusterCarry& 
     // count allows it the G members of a group are 8 blocks apart.  This is a SPEED choice only:
     // whether the members really share an XCD is verified at run time below.
     int group, slice;
-    if (G > 1 && (p.num_groups & 7) == 0) {
+    if (G > 1 && ((p.num_groups & 7) == 0 || (H == 128 && p.xcd_pad))) {
         group = (blockIdx.x / (8 * G)) * 8 + (blockIdx.x & 7);
         slice = (blockIdx.x >> 3) & (G - 1);
     } else {
@@ -975,6 +975,15 @@ __global__ __launch_bounds__(256, 1) void lstm_cluster_kernel(LstmParams p) {
 // no second header read / handshake, the state stays in registers and the h_T tile in LDS; only the weights are swapped.
 template <int H, int ACT>
 __global__ __launch_bounds__(256, 1) void lstm_cluster_fused_kernel(LstmParams p) {
+    if constexpr (H == 128) {
+        // a group count that is no multiple of eight (the reference's batch of 32 = two groups): the grid is padded to the next
+        // multiple so that a group's members sit 8 blocks apart = on one XCD (lstm_wide16.hip); the blocks of the absent groups
+        // count as arrived and leave
+        if (p.xcd_pad && (int)((blockIdx.x / (8 * (H / 64))) * 8 + (blockIdx.x & 7)) >= p.num_groups) {
+            if (threadIdx.x == 0) xch_count_arrival(p.status);
+            return;
+        }
+    }
     ClusterCarry cy;
     cluster_body<H, ACT, MODE_LAYER, 1>(p, cy);
     cluster_body<H, ACT, MODE_DECODE, 2>(p, cy);
@@ -1083,7 +1092,11 @@ static int launch_cluster_fused_h(const LstmParams& p, hipStream_t stream) {
     if (lds > 160 * 1024) { set_error("fused cluster kernel: needs %zu B of LDS (> 160 KiB)", lds); return FOV_ERR_UNSUPPORTED; }
     int rc = ensure_dynamic_lds((const void*)kern, lds);
     if (rc) return rc;
-    hipLaunchKernelGGL(kern, dim3(p.num_groups * (H / 64)), dim3(256), lds, stream, p);
+    LstmParams q = p;
+    static const bool no_pad = getenv("FOV_NO_XCD_PAD") != nullptr;
+    const int padded = (q.num_groups + 7) & ~7;
+    q.xcd_pad = (H == 128 && !no_pad && (q.num_groups & 7) != 0 && device_cu_count() >= padded * (H / 64)) ? 1 : 0;
+    hipLaunchKernelGGL(kern, dim3((q.xcd_pad ? padded : q.num_groups) * (H / 64)), dim3(256), lds, stream, q);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("fused cluster launch: %s", hipGetErrorString(e)); return FOV_ERR_LAUNCH; }
     return FOV_OK;

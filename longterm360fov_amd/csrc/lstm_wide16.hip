@@ -361,7 +361,8 @@ int launch_wide16_t(LstmParams& p, hipStream_t stream) {
     if (rc) return rc;
     // fewer than eight groups of at most sixteen workgroups: same-XCD placement through a padded grid (FOV_NO_XCD_PAD=1: off)
     static const bool no_pad = getenv("FOV_NO_XCD_PAD") != nullptr;
-    p.xcd_pad = (!no_pad && WG <= 16 && p.num_groups < 8 && device_cu_count() >= 8 * WG) ? 1 : 0;
+    static const int pad_max = getenv("FOV_XCD_PAD_MAX") ? atoi(getenv("FOV_XCD_PAD_MAX")) : 16;   // members per group at most
+    p.xcd_pad = (!no_pad && WG <= pad_max && p.num_groups < 8 && device_cu_count() >= 8 * WG) ? 1 : 0;
     hipLaunchKernelGGL(kern, dim3(p.xcd_pad ? 8 * WG : p.num_groups * WG), dim3(256), lds, stream, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("wide16 LSTM launch: %s", hipGetErrorString(e)); return FOV_ERR_LAUNCH; }

@@ -218,6 +218,22 @@ def test_config1_reference_native_shape():
         assert_parity(ops.seq2seq_decode(dev(enc), dev(dec0), devw(w), 10, impl=impl), ref, "config1 " + impl)
 
 
+def test_fused_decode_padded_grid_group_counts():
+    """H = 128 fused encoder + decoder with a group count that is no multiple of eight: the grid is padded so that a group's
+    members share an XCD (spare workgroups leave at once); 2, 9 and 13 tiles (the last ragged), repeated launches on one
+    workspace (the spare blocks take part in the arrival count of the launch protocol)."""
+    ops = _ops()
+    w = O.init_seq2seq(77, H=128, bias_noise=0.05)
+    ws = ops.Workspace()
+    for B in (32, 16 * 9, 16 * 12 + 5):
+        enc, dec0, _ = O.synthetic_batch(B, B, 7, 6)
+        ref = C.seq2seq_decode(enc, dec0, w, 6)
+        for _ in range(3):
+            out = ops.seq2seq_decode(dev(enc), dev(dec0), devw(w), 6, impl="cluster", workspace=ws)
+        ws.check()
+        assert_parity(out, ref.astype(np.float64), "padded fused grid B=%d" % B)
+
+
 def test_config2_full_size_and_properties():
     """configs[1]: H=256, B=1024, T 30->30 on one GPU (the bench workload).  All 1024 sequences
     against the C oracle, plus determinism, batch-permutation equivariance, independence from
