@@ -51,6 +51,14 @@ MODE_TRAFFIC = {
     ("infer_mixing", "f32"): (int((37967.8 + 17696.4) * 1024), "profiles/r03_pmcstep_infer_mixing_f32.txt"),
     ("infer_mixing", "bf16"): (int((34669.1 + 10528.3) * 1024), "profiles/r03_pmcstep_infer_mixing_bf16.txt"),
     ("train", "f32"): ((633464 + 1226760) * 1024, "profiles/r03_pmcstep_train_f32.txt"),
+    # tools/pmc_simple.sh (run total / identical steps: tools/pmc_simple_steps.py, tools/pmc_run_total.py)
+    ("config1", "f32"): (int((864.6 + 3351.7) * 1024), "profiles/r03_pmcstep_config1.txt"),
+    ("a10", "f32"): (int((26059 + 10752.3) * 1024), "profiles/r03_pmcstep_a10.txt"),
+    # whole-model predict at B = 256: 396 GB fetched below the L2s per call (not all from HBM: the counter sits in front of the
+    # 256 MB MALL), 97 % of it by the two deep head convolutions re-reading 25 shifted taps of (pixels x 512 / 1024 channels) and
+    # every workgroup its 6.5 MB of weights - 0.8 TB/s, a tenth of the HBM rate; re-ordering k as (channel slab, tap) did
+    # not change the time
+    ("convlstm", "f32"): (int((3.96045e8 + 1.4751e7) * 1024), "profiles/r03_pmcstep_convlstm.txt"),
 }
 
 
@@ -464,7 +472,7 @@ def bench_config1(args, rank, world, use_dist):
             "latency": {"gpu_ms_per_call_async": ev_ms, "gpu_ms_per_call_host_synchronised_median": float(np.median(lat)) * 1e3,
                         "cpu_ms_per_call": None if cpu is None else min(l["ms_per_pass"] for l in cpu["legs"] if l["ms_per_pass"] is not None)},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                         "frac": ach / PEAK_FP32_MFMA_TFLOPS, **mode_traffic("config1", "f32", ev_ms, (B, H) == (32, 128)),
                          "note": "two 16-sequence tiles: 4 workgroups busy, per-step latency bound by construction"},
             "parity": {"max_abs_err_vs_oracle": err, "sequences_checked": B}, "training": training,
             "cpu_baseline": cpu, "speedup_vs_cpu_baseline": None if cpu is None else world * B * steps / elapsed / cpu["value"]}), flush=True)
@@ -569,8 +577,8 @@ def bench_a10(args, rank, world, use_dist):
                                    "at H = 400", "global_batch": B * world,
                        "parallelism": "replicas x%d" % world},
             "roofline": {"bound": "mfma", "achieved": r["tflops"], "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": r["tflops"] / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
-                         "note": "32 sequences = two tiles = 32 of 256 CUs busy: latency-bound by construction"},
+                         "frac": r["tflops"] / PEAK_FP32_MFMA_TFLOPS, **mode_traffic("a10", "f32", r["ms"]),
+                         "note": "32 sequences = two tiles = 64 of 256 CUs busy (32 workgroups per tile): latency-bound by construction"},
             "variants": res, "training_step": train, "cpu_baseline": cpu}), flush=True)
 
 
@@ -663,7 +671,8 @@ def bench_convlstm(args, rank, world, use_dist):
                                    "56->512->1024->30 head, B=%d (host arrays in, host arrays out: the Keras predict surface)" % B,
                        "global_batch": B * world, "parallelism": "replicas x%d" % world},
             "roofline": {"bound": "mfma", "achieved": whole_tf, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": whole_tf / PEAK_FP32_MFMA_TFLOPS, "traffic": None, "note": "whole model incl. the head (50x the cell's FLOPs)"},
+                         "frac": whole_tf / PEAK_FP32_MFMA_TFLOPS, **mode_traffic("convlstm", "f32", whole_s * 1e3, B == 256),
+                         "note": "whole model incl. the head (50x the cell's FLOPs)"},
             "cell_only": {"ms": cell_ms, "sequences_per_s": B / (cell_ms * 1e-3), "tflops": cell_tf,
                           "frac_of_fp32_mfma_peak": cell_tf / PEAK_FP32_MFMA_TFLOPS,
                           "workload": "3-layer ConvLSTM encoder over T=10 steps (half the model's cell FLOPs), device-resident"},
