@@ -492,8 +492,10 @@ def bench_a10(args, rank, world, use_dist):
     x = rng.uniform(-1, 1, (B, T, F)).astype(np.float32)
     res = {}
     from longterm360fov_amd.models import pad_lstm
-    for tag, H, impl, Hp in (("h400_padded_to_512_persistent_mfma", 400, "auto", 512), ("h400_stepwise_mfma_gemm", 400, "auto", 400),
-                             ("h400_generic_valu", 400, "generic", 400), ("h256_persistent_mfma", 256, "auto", 256)):
+    for tag, H, impl, Hp, one in (("h400_padded_to_512_persistent_mfma", 400, "auto", 512, True),
+                                  ("h400_padded_to_512_two_launches", 400, "auto", 512, False),
+                                  ("h400_stepwise_mfma_gemm", 400, "auto", 400, False),
+                                  ("h400_generic_valu", 400, "generic", 400, False), ("h256_persistent_mfma", 256, "auto", 256, False)):
         lrng = np.random.default_rng(H)
         layers = [O.init_lstm(lrng, F, H), O.init_lstm(lrng, H, H)]
         run_layers = layers if Hp == H else [pad_lstm(K, R, b, Hp, pad_input=(l > 0)) for l, (K, R, b) in enumerate(layers)]
@@ -506,6 +508,9 @@ def bench_a10(args, rank, world, use_dist):
             for K, R, b in dl:
                 inp, hT, cT = ops.lstm_seq(inp, K, R, b, act="sigmoid", impl=impl, workspace=ws)
             return inp
+        if one and ops.lstm_stack2_supported(B, T, F, Hp):
+            def step():   # both layers as ONE launch, layer 2 a few steps behind layer 1 on other CUs (fov_lstm_stack2_fwd)
+                return ops.lstm_stack2(dx, dl[0], dl[1], workspace=ws)[1][0]
         for _ in range(5):
             step()
         # best of three regions: a 0.1 ms call is short enough for a single host hiccup (a 30 ms pause was seen once in 800
@@ -573,8 +578,9 @@ def bench_a10(args, rank, world, use_dist):
             "unit": "sequences/s", "n_gpus": world, "steps": max(args.steps, 100), "warmup": 5, "ms_per_step": r["ms"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "lstm.py native shape: 2 x LSTMCell(400), batch 32, 10 steps, 90 features; zero-padded to width 512 "
-                                   "on the persistent register-resident kernel (16 workgroups per 16-sequence tile); flops counted "
-                                   "at H = 400", "global_batch": B * world,
+                                   "on the persistent register-resident kernel (32 workgroups per 16-sequence tile), both layers "
+                                   "in one launch (layer 2 a few steps behind layer 1 on other CUs); flops counted at H = 400",
+                       "global_batch": B * world,
                        "parallelism": "replicas x%d" % world},
             "roofline": {"bound": "mfma", "achieved": r["tflops"], "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": r["tflops"] / PEAK_FP32_MFMA_TFLOPS, **mode_traffic("a10", "f32", r["ms"]),

@@ -196,6 +196,20 @@ int fov_wgrad_fused(const float* x1, int In1, const float* x2, int In2, const fl
 int fov_lstm_seq_fwd_bf16(const float* x, const float* K, const float* R, const float* b, const float* h0,
                           const float* c0, float* hs, float* hT, float* cT, float* reserve, int B, int T, int F, int H,
                           int act, void* workspace, size_t workspace_bytes, fov_stream_t stream);
+/* Two stacked fp32 LSTM layers (F <= 96 -> 512 -> 512) in ONE launch - mycode/lstm.py:128-132,218-240: MultiRNNCell of two
+ * LSTMCell(400) under dynamic_rnn with a fed state, zero-padded to the matrix-core width 512 (models.pad_lstm).  At the
+ * script's batch a layer occupies 64 of 256 CUs, so layer 2 runs beside layer 1, a few steps behind: layer 1 publishes h_t of
+ * every step as {value, epoch} granules into a ring of T slots and layer 2 takes its input from there (its 512-wide input never
+ * comes from HBM).  Same results as two fov_lstm_seq_fwd[_train] calls (same arithmetic per layer).  h0_* / c0_* (B,H) or
+ * NULL; reserve* (B,T,5,H) or NULL (training tape); hs1 may be NULL when only the top layer's sequence is wanted.
+ * Shapes: fov_lstm_stack2_supported (H = 512, F <= 96, T >= 2, both layers' groups resident: <= 64 sequences on 256 CUs);
+ * workspace >= fov_lstm_seq_workspace_bytes of a width-512 layer (header + granule area). */
+int fov_lstm_stack2_supported(int B, int T, int F, int H);
+int fov_lstm_stack2_fwd(const float* x, const float* K1, const float* R1, const float* b1, const float* h0_1, const float* c0_1,
+                        const float* K2, const float* R2, const float* b2, const float* h0_2, const float* c0_2, float* hs1,
+                        float* hT1, float* cT1, float* reserve1, float* hs2, float* hT2, float* cT2, float* reserve2, int B, int T,
+                        int F, int H, int act, void* workspace, size_t workspace_bytes, fov_stream_t stream);
+
 /* BOTH encoder layers of the others-mixing model with bf16 operands in ONE launch, as a wavefront over (layer, step)
  * (given_others_gt_mean_var_seq2seq.py:108-112: LSTM(F -> 256) then LSTM(256 -> 256), zero initial states): layer 2 runs one
  * step behind layer 1 on the same CUs and takes its input tile straight from layer 1's exchange granules - T + 1

@@ -82,6 +82,8 @@ SIGNATURES = {
     "fov_adam_step": (_I, [_P] * 4 + [ctypes.c_int64] + [ctypes.c_float] * 4 + [ctypes.c_int64, _P]),
     "fov_rmsprop_step": (_I, [_P] * 3 + [ctypes.c_int64] + [ctypes.c_float] * 3 + [_P]),
     "fov_lstm_stack2_supported_bf16": (_I, [_I] * 4),
+    "fov_lstm_stack2_supported": (_I, [_I] * 4),
+    "fov_lstm_stack2_fwd": (_I, [_P] * 19 + [_I] * 5 + [_P, _SZ, _P]),
     "fov_lstm_stack2_fwd_bf16": (_I, [_P] * 15 + [_I] * 5 + [_P, ctypes.c_size_t, _P]),
     "fov_mix_decoder_prepack": (_I, [_P, _P, ctypes.c_size_t, _P, ctypes.c_size_t, _I, _P]),
     "fov_guard_flag": (_I, [_P] * 5),

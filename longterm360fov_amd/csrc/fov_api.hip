@@ -646,6 +646,33 @@ int fov_lstm_stack2_fwd_bf16(const float* x, const float* K1, const float* R1, c
                               (hipStream_t)stream);
 }
 
+int fov_lstm_stack2_supported(int B, int T, int F, int H) { return wide16_pair_shape(B, T, F, H) ? 1 : 0; }
+
+int fov_lstm_stack2_fwd(const float* x, const float* K1, const float* R1, const float* b1, const float* h0_1, const float* c0_1,
+                        const float* K2, const float* R2, const float* b2, const float* h0_2, const float* c0_2, float* hs1,
+                        float* hT1, float* cT1, float* reserve1, float* hs2, float* hT2, float* cT2, float* reserve2, int B, int T,
+                        int F, int H, int act, void* workspace, size_t workspace_bytes, fov_stream_t stream) {
+    if (B < 0 || T < 0 || F <= 0 || !K1 || !R1 || !b1 || !K2 || !R2 || !b2 || (B > 0 && T > 0 && !x) ||
+        (act != FOV_ACT_SIGMOID && act != FOV_ACT_HARD_SIGMOID)) {
+        set_error("fov_lstm_stack2_fwd: invalid argument");
+        return FOV_ERR_INVALID;
+    }
+    if (B == 0) return FOV_OK;
+    if (!wide16_pair_shape(B, T, F, H)) {
+        set_error("fov_lstm_stack2_fwd: H = 512, F <= 96, T >= 2 and both layers' groups resident (<= 64 sequences on 256 CUs) only");
+        return FOV_ERR_UNSUPPORTED;
+    }
+    int rc = check_ws(workspace, workspace_bytes, kStatusBytes + kXchBytes);
+    if (rc) return rc;
+    LstmParams a = {}, b = {};
+    a.x = x; a.K = K1; a.R = R1; a.b = b1; a.h0 = h0_1; a.c0 = c0_1; a.hs = hs1; a.hT = hT1; a.cT = cT1; a.reserve = reserve1;
+    b.x = nullptr; b.K = K2; b.R = R2; b.b = b2; b.h0 = h0_2; b.c0 = c0_2; b.hs = hs2; b.hT = hT2; b.cT = cT2; b.reserve = reserve2;
+    a.B = b.B = B; a.T = b.T = T; a.F = F; b.F = H; a.H = b.H = H; a.act = b.act = act;
+    a.status = b.status = (unsigned*)workspace;
+    a.xch = b.xch = (unsigned long long*)((char*)workspace + kStatusBytes);
+    return launch_wide16_pair(a, b, (hipStream_t)stream);
+}
+
 int fov_lstm_seq_fwd_zx(const float* zx, const float* R, const float* b, const float* h0, const float* c0, float* hs,
                         float* hT, float* cT, float* reserve, int B, int T, int H, int act, int impl, void* workspace,
                         size_t workspace_bytes, fov_stream_t stream) {

@@ -195,6 +195,9 @@ int mix_decoder_bwd_bf16_launch(MixDecBwdParams p, const float* K2, int act, voi
 
 // persistent BPTT recurrence (lstm_bwd_cluster.hip)
 bool bwd_cluster_shape_ok(int H);
+// lstm_wide16.hip: two stacked width-512 layers as one launch (layer 2 a few steps behind layer 1 on other CUs)
+bool wide16_pair_shape(int B, int T, int F, int H);
+int launch_wide16_pair(const LstmParams& a, const LstmParams& b, hipStream_t stream);
 // lstm_bwd16.hip: BPTT recurrence with 16 / 32 units per workgroup (fp32): width 512, and 128 / 256 at small batches
 bool bwd16_takes(int B, int H);
 int launch_bwd16(const float* R, const float* reserve, const float* c0, const float* dhs, const float* dhT, const float* dcT,

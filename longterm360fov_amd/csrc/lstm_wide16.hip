@@ -59,17 +59,21 @@ __device__ __forceinline__ void wide16_mm(f32x4 (&acc)[2], const float* arow, co
 
 // NJX: k-blocks of K in registers - 6 (narrow input, F <= 96, scalar x stage) or WH / 16 (input as wide as the layer, 16-byte
 // x pieces)
-template <int ACT, int NJX, int WH>
-__global__ __launch_bounds__(256, 1) void lstm_wide16_kernel(LstmParams p) {
+// ROLE 0: one layer per launch.  ROLE 1 / 2: the two layers of a stack as ONE launch (lstm_wide16_pair_kernel), layer 2 a
+// few steps behind layer 1 on other CUs - with two tiles a layer occupies 64 of 256 CUs.  Layer 1 (ROLE 1) publishes h_t of
+// EVERY step into a ring of T slots (its partners gather from slot t as well); layer 2 (ROLE 2) takes its input from those
+// granules - x_t of layer 2 IS h_t of layer 1, already travelling as {value, epoch} - two steps ahead of its use, and runs its
+// own exchange in a parity area behind the ring with tags base + T + 1 + t.  `bx`: block index inside the role.
+template <int ACT, int NJX, int WH, int ROLE>
+__device__ __forceinline__ void wide16_body(const LstmParams& p, const int bx, float* smem) {
     constexpr int WG = WH / 16;          // workgroups per tile
     constexpr int NJR = WH / 16;         // k-blocks of R
-    constexpr bool XVEC = NJX == WH / 16;
+    constexpr bool XVEC = ROLE != 2 && NJX == WH / 16;
     constexpr int WLD = WH + 8;          // LDS row stride == 8 (mod 16) floats: conflict-free ds_read_b128 fragments
     constexpr int WNG = WG - 1;          // granules gathered per thread and step
     constexpr int H4 = 4 * WH;
     constexpr unsigned OORB = 0x80000000u;
     static_assert((WG & (WG - 1)) == 0 && WG <= kHelloStride, "slice arithmetic, hello words");
-    extern __shared__ __attribute__((aligned(16))) float smem[];
     float* sH = smem;                     // [16][WLD]
     float* sX = sH + VBT * WLD;           // [2][16][WLD]
     float* sT = sX + 2 * VBT * WLD;       // [4 waves][16][17] gate transpose
@@ -78,24 +82,25 @@ __global__ __launch_bounds__(256, 1) void lstm_wide16_kernel(LstmParams p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 15, g4 = lane >> 4;
     int group, slice;
-    if (p.xcd_pad) {
+    if (ROLE == 0 && p.xcd_pad) {
         // Fewer than eight groups: the grid is padded to 8 x WG blocks, block b is member b / 8 of group b % 8, so that the
         // members of a group sit 8 blocks apart - one XCD under round-robin dispatch, verified by the hello handshake - and
         // exchange through its L2 (sc0).  The blocks of the absent groups count as arrived and leave.
-        group = blockIdx.x & 7;
-        slice = blockIdx.x >> 3;
+        group = bx & 7;
+        slice = bx >> 3;
         if (group >= p.num_groups) {
             __shared__ unsigned sSpare[4];
             if (p.T > 1) xch_arrive(p.status, sSpare, -1, 0);
             return;
         }
-    } else if ((p.num_groups & 7) == 0) {   // members 8 blocks apart: likely one XCD (placement preference only)
-        group = (blockIdx.x / (8 * WG)) * 8 + (blockIdx.x & 7);
-        slice = (blockIdx.x >> 3) & (WG - 1);
+    } else if (ROLE == 0 && (p.num_groups & 7) == 0) {   // members 8 blocks apart: likely one XCD (placement preference only)
+        group = (bx / (8 * WG)) * 8 + (bx & 7);
+        slice = (bx >> 3) & (WG - 1);
     } else {
-        group = blockIdx.x / WG;
-        slice = blockIdx.x - group * WG;
+        group = bx / WG;
+        slice = bx - group * WG;
     }
+    const int hgroup = group + (ROLE == 2 ? p.num_groups : 0);   // hello words: layer 2's groups behind layer 1's
     const int F = p.F, steps = p.T;
     // MFMA column of this lane: gate n / 4 of unit n % 4 of the wave's four units
     const int unit = 16 * slice + 4 * wave + (n & 3);
@@ -103,9 +108,9 @@ __global__ __launch_bounds__(256, 1) void lstm_wide16_kernel(LstmParams p) {
     // the cell this lane updates after the transpose: row 4 g4 + n / 4 of the tile, the same unit
     const int row_o = 4 * g4 + (n >> 2);
     float* tw = sT + wave * (16 * 17);
-    const bool xch_used = steps > 1;
+    const bool xch_used = ROLE != 0 || steps > 1;
     __shared__ unsigned sXch[4];
-    const unsigned arrival = xch_used ? xch_arrive(p.status, sXch, group, slice) : 0u;
+    const unsigned arrival = xch_used ? xch_arrive(p.status, sXch, hgroup, slice) : 0u;
     const bool poisoned = xch_used && xch_poisoned(p.status);
     if (tid == 0) sFlag[0] = poisoned ? 1 : 0;
 
@@ -125,18 +130,24 @@ __global__ __launch_bounds__(256, 1) void lstm_wide16_kernel(LstmParams p) {
     for (int i = tid; i < 2 * VBT * WLD; i += 256) sX[i] = 0.f;   // columns >= F stay zero
 
     // ---- exchange bookkeeping ----
+    constexpr size_t SLOT = (size_t)VBT * WH;   // granules of one h tile
+    // ROLE 0: two parity slots per group.  Pair: layer 1's ring of T slots per group, then layer 2's parity slots.
+    const size_t xbase = ROLE == 0 ? (size_t)group * 2 * SLOT
+                         : ROLE == 1 ? (size_t)group * p.T * SLOT : ((size_t)p.num_groups * p.T + (size_t)group * 2) * SLOT;
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
-        p.xch + (size_t)group * 2 * VBT * WH, 0, 2 * VBT * WH * (int)sizeof(unsigned long long), 0x00020000);
+        p.xch + xbase, 0, (ROLE == 1 ? p.T : 2) * (int)(SLOT * sizeof(unsigned long long)), 0x00020000);
+    const __amdgpu_buffer_rsrc_t ringrs = __builtin_amdgcn_make_buffer_rsrc(   // ROLE 2: layer 1's ring of the same group
+        p.xch + (size_t)group * p.T * SLOT, 0, ROLE == 2 ? p.T * (int)(SLOT * sizeof(unsigned long long)) : 0, 0x00020000);
     const unsigned pub_off = (unsigned)(row_o * WH + unit) * 8u;
     const int grow = tid >> 4, gu = tid & 15;             // gather: row and unit-in-slice of this thread's granules
     const unsigned gvoff = (unsigned)(grow * WH + gu) * 8u;
     const int lbase = grow * WLD + gu;
     constexpr unsigned PARITY = VBT * WH * 8u;
-    if (xch_used) xch_hello_poll(p.status, sXch, group, WG, &sFlag[0]);
+    if (xch_used) xch_hello_poll(p.status, sXch, hgroup, WG, &sFlag[0]);
     __syncthreads();
     XchTicket ticket = {0u, 0u, 0u};
     if (xch_used) ticket = xch_ticket(sXch, arrival);
-    unsigned epoch = ticket.base;
+    unsigned epoch = ticket.base + (ROLE == 2 ? (unsigned)p.T : 0u);   // layer 2's own tags follow layer 1's T
     bool aborted = sFlag[0] != 0;
     if (xch_used && tid == 0 && !ticket.same_xcd && !aborted) xch_count_safe(p.status, ticket);
 
@@ -189,6 +200,53 @@ __global__ __launch_bounds__(256, 1) void lstm_wide16_kernel(LstmParams p) {
         }
     };
 
+    // ROLE 2: thread (xrw, xc) gathers row xrw, units xc + 16 i of layer 1's h tile of step s (slot s, tag base + 1 + s)
+    vu32x2 xg[ROLE == 2 ? WH / 16 : 1];
+    auto ring_issue = [&](int s_) {
+        if constexpr (ROLE == 2) {
+            const unsigned vo = (unsigned)(((tid >> 4) * WH + (tid & 15)) * 8);
+#pragma unroll
+            for (int i = 0; i < WH / 16; ++i) xg[i] = __builtin_amdgcn_raw_buffer_load_b64(ringrs, vo + i * 16 * 8, (unsigned)s_ * PARITY, 16);
+        }
+    };
+    auto ring_store = [&](int s_, float* dst) {   // dst: this thread's first element of the LDS tile
+        if constexpr (ROLE == 2) {
+            const unsigned want = ticket.base + 1u + (unsigned)s_;
+            const unsigned vo = (unsigned)(((tid >> 4) * WH + (tid & 15)) * 8);
+            unsigned bad = 0;
+#pragma unroll
+            for (int i = 0; i < WH / 16; ++i) {
+                if (xg[i].y == want) dst[16 * i] = __uint_as_float(xg[i].x);
+                else bad |= (1u << i);
+            }
+            unsigned spins = 0;
+            while (__any(bad != 0)) {
+                ++spins;
+                if (spins > VSPIN || ((spins & 63u) == 0 && xch_poisoned(p.status))) {
+                    if (lane == 0) {
+                        xch_give_up(p.status);
+                        sFlag[0] = 1;
+                    }
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int i0 = 0; i0 < WH / 16; i0 += 8) {
+                    vu32x2 tv[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) tv[i] = __builtin_amdgcn_raw_buffer_load_b64(ringrs, vo + (i0 + i) * 16 * 8, (unsigned)s_ * PARITY, 16);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i)
+                        if (((bad >> (i0 + i)) & 1u) && tv[i].y == want) {
+                            dst[16 * (i0 + i)] = __uint_as_float(tv[i].x);
+                            bad &= ~(1u << (i0 + i));
+                        }
+                }
+            }
+        }
+    };
+
     const float* hrow = sH + n * WLD + 4 * g4;
     // x staging: thread (xrw = tid / 16, xc = tid % 16) moves the 16-byte pieces xc, xc + 16, ... of row xrw (narrow: elements)
     const int xrw = tid >> 4, xc = tid & 15;
@@ -232,7 +290,14 @@ __global__ __launch_bounds__(256, 1) void lstm_wide16_kernel(LstmParams p) {
         auto load_x1 = [&](int i, int t) { return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xgrs, xoff[i], (unsigned)(t * F * 4), 0)); };
         float* xl = sX + xrw * WLD + (XVEC ? 4 : 1) * xc;
         const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-        {
+        if constexpr (ROLE == 2) {   // x_0 and x_1 = layer 1's h_0, h_1: wait for them (layer 2 starts two steps behind)
+            ring_issue(0);
+            ring_store(0, xl);
+            if (steps > 1) {
+                ring_issue(1);
+                ring_store(1, xl + VBT * WLD);
+            }
+        } else {
             f32x4 x4[2][XVEC ? NXR : 1];
             float x1[2][XVEC ? 1 : NXR];
 #pragma unroll
@@ -269,22 +334,28 @@ __global__ __launch_bounds__(256, 1) void lstm_wide16_kernel(LstmParams p) {
         float xs[XVEC ? 1 : NXR] = {0.f};
         for (int t = 0; t < steps; ++t) {
             // x pipeline: x_{t+1} (requested during step t-1) registers -> LDS; then request x_{t+2}
-            if (t > 0 && t + 1 < steps) {
-                float* xb = xl + ((t + 1) & 1) * VBT * WLD;
+            if constexpr (ROLE == 2) {
+                // layer 1's h_{t+1}, requested late in step t-1 (behind the partner gather: the two sets of granule registers
+                // never live together): registers -> LDS, waiting here if layer 1 is not that far yet
+                if (t > 0 && t + 1 < steps) ring_store(t + 1, xl + ((t + 1) & 1) * VBT * WLD);
+            } else {
+                if (t > 0 && t + 1 < steps) {
+                    float* xb = xl + ((t + 1) & 1) * VBT * WLD;
 #pragma unroll
-                for (int i = 0; i < NXR; ++i) {
-                    if constexpr (XVEC) {
-                        if (xc + 16 * i < nx4) *(f32x4*)(xb + 64 * i) = xr[i];
-                    } else {
-                        if (xc + 16 * i < F) xb[16 * i] = xs[i];
+                    for (int i = 0; i < NXR; ++i) {
+                        if constexpr (XVEC) {
+                            if (xc + 16 * i < nx4) *(f32x4*)(xb + 64 * i) = xr[i];
+                        } else {
+                            if (xc + 16 * i < F) xb[16 * i] = xs[i];
+                        }
                     }
                 }
-            }
-            if (t + 2 < steps) {
+                if (t + 2 < steps) {
 #pragma unroll
-                for (int i = 0; i < NXR; ++i) {
-                    if constexpr (XVEC) xr[i] = load_x4(i, t + 2);
-                    else xs[i] = load_x1(i, t + 2);
+                    for (int i = 0; i < NXR; ++i) {
+                        if constexpr (XVEC) xr[i] = load_x4(i, t + 2);
+                        else xs[i] = load_x1(i, t + 2);
+                    }
                 }
             }
             // ---- the four gates of a cell meet: 16 x 16 transpose through the wave's scratch ----
@@ -307,11 +378,12 @@ __global__ __launch_bounds__(256, 1) void lstm_wide16_kernel(LstmParams p) {
                 }
             }
             const bool more = (t + 1 < steps);
-            const bool do_xch = xch_used && more;
+            const bool do_xch = xch_used && more;              // gather the partners' pieces of h_t
+            const bool pub = ROLE == 1 ? true : do_xch;        // layer 1 of a pair publishes its last step too: layer 2 reads it
             unsigned par = 0;
-            if (do_xch) {
+            if (pub) {
                 ++epoch;
-                par = (epoch & 1u) * PARITY;
+                par = ROLE == 1 ? (unsigned)t * PARITY : (epoch & 1u) * PARITY;
                 XCH_STORE_B64(ticket.same_xcd, ((vu32x2){__float_as_uint(hc), epoch}), xrs, pub_off, par);
             }
             __syncthreads();   // barrier 1: every wave is done reading sH; x_{t+1} is in LDS
@@ -327,6 +399,9 @@ __global__ __launch_bounds__(256, 1) void lstm_wide16_kernel(LstmParams p) {
             if (do_xch) gather_finish(par);
             __syncthreads();   // barrier 2: the whole h_t tile is in LDS
             if (sFlag[0]) { aborted = true; break; }
+            if constexpr (ROLE == 2) {
+                if (t + 2 < steps) ring_issue(t + 2);   // layer 1's h_{t+2}: consumed at the start of the next step
+            }
             if (more) {
                 vm_begin(acc);
                 wide16_mm<NJR>(acc, hrow, wr);
@@ -342,6 +417,24 @@ __global__ __launch_bounds__(256, 1) void lstm_wide16_kernel(LstmParams p) {
         }
     }
     if (xch_used) xch_settle(p.status, ticket, (unsigned)p.epoch_span);
+}
+
+template <int ACT, int NJX, int WH>
+__global__ __launch_bounds__(256, 1) void lstm_wide16_kernel(LstmParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    wide16_body<ACT, NJX, WH, 0>(p, (int)blockIdx.x, smem);
+}
+
+// Two stacked layers, one launch: the first num_groups * WG blocks are layer 1 (narrow input, six k-blocks of K), the rest layer 2
+struct Wide16Pair {
+    LstmParams l1, l2;
+};
+template <int ACT, int WH>
+__global__ __launch_bounds__(256, 1) void lstm_wide16_pair_kernel(Wide16Pair pp) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int per_role = pp.l1.num_groups * (WH / 16);
+    if ((int)blockIdx.x < per_role) wide16_body<ACT, 6, WH, 1>(pp.l1, (int)blockIdx.x, smem);
+    else wide16_body<ACT, WH / 16, WH, 2>(pp.l2, (int)blockIdx.x - per_role, smem);
 }
 
 template <int NJX, int WH>
@@ -383,6 +476,39 @@ bool wide16_shape(int B, int F, int H) {
 }
 bool wide16_preferred(const float* x, int B, int F, int H) {
     return wide16_shape(B, F, H) && (F <= 96 || (((uintptr_t)x) & 15) == 0);
+}
+
+// Two stacked layers (F <= 96 -> 512 -> 512) as one launch: both layers' groups must be resident (2 x tiles x 32 workgroups),
+// T >= 2, the ring (tiles x T slots) and layer 2's parity slots must fit the granule area.
+bool wide16_pair_shape(int B, int T, int F, int H) {
+    static const bool off = getenv("FOV_NO_STACK2") != nullptr;
+    if (off || H != 512 || B <= 0 || T < 2 || F < 1 || F > 96) return false;
+    const int tiles = (B + VBT - 1) / VBT;
+    if (2 * tiles * (H / 16) > device_cu_count()) return false;
+    return (size_t)tiles * (T + 2) * VBT * H * sizeof(unsigned long long) <= kXchBytes - kHelloBytes;
+}
+
+int launch_wide16_pair(const LstmParams& a, const LstmParams& b, hipStream_t stream) {
+    constexpr int WH = 512, WG = WH / 16;
+    if (a.B == 0) return FOV_OK;
+    if (!wide16_pair_shape(a.B, a.T, a.F, a.H)) { set_error("two-layer width-512 launch: unsupported shape"); return FOV_ERR_UNSUPPORTED; }
+    Wide16Pair pp = {a, b};
+    for (LstmParams* q : {&pp.l1, &pp.l2}) {
+        q->num_tiles = (a.B + VBT - 1) / VBT;
+        q->num_groups = q->num_tiles;               // one tile per group
+        q->epoch_span = 2 * a.T + 1;                // layer 1's tags base + 1 .. base + T, layer 2's base + T + 1 .. base + 2T
+        q->xcd_pad = 0;
+    }
+    if (int rc_ = xch_account(pp.l1.status, pp.l1.epoch_span, stream)) return rc_;
+    const size_t lds = sizeof(float) * (3 * VBT * (WH + 8) + 4 * 16 * 17) + 64;
+    void (*kern)(Wide16Pair) = a.act == FOV_ACT_HARD_SIGMOID ? lstm_wide16_pair_kernel<FOV_ACT_HARD_SIGMOID, WH>
+                                                             : lstm_wide16_pair_kernel<FOV_ACT_SIGMOID, WH>;
+    int rc = ensure_dynamic_lds((const void*)kern, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL(kern, dim3(2 * pp.l1.num_groups * WG), dim3(256), lds, stream, pp);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_error("two-layer width-512 launch: %s", hipGetErrorString(e)); return FOV_ERR_LAUNCH; }
+    return FOV_OK;
 }
 
 int launch_wide16(const LstmParams& p_in, hipStream_t stream) {

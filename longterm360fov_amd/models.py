@@ -1227,12 +1227,20 @@ class StackedTFLSTM:
             st = torch.zeros((len(self._dw), 2, B, Hp), dtype=torch.float32, device=self.device)
             st[..., :H] = torch.from_numpy(_as_f32(init_state)).to(self.device)
         states = []
-        for l, (K, R, b) in enumerate(self._dw):
-            c0 = None if st is None else st[l, 0]
-            h0 = None if st is None else st[l, 1]
-            hs, hT, cT = ops.lstm_seq(inp, K, R, b, h0, c0, act="sigmoid", impl=self.impl, workspace=self._ws)
-            states.append(torch.stack([cT, hT], dim=0))
-            inp = hs
+        T, F = inp.shape[1], inp.shape[2]
+        if len(self._dw) == 2 and self.impl == "auto" and ops.lstm_stack2_supported(B, T, F, Hp):
+            # both layers as ONE launch, layer 2 a few steps behind layer 1 on other CUs (fov_lstm_stack2_fwd)
+            sts = [None if st is None else (st[l, 1].contiguous(), st[l, 0].contiguous()) for l in range(2)]
+            o1, o2 = ops.lstm_stack2(inp, self._dw[0], self._dw[1], sts[0], sts[1], act="sigmoid", workspace=self._ws)
+            states = [torch.stack([o1[2], o1[1]], dim=0), torch.stack([o2[2], o2[1]], dim=0)]
+            inp = o2[0]
+        else:
+            for l, (K, R, b) in enumerate(self._dw):
+                c0 = None if st is None else st[l, 0]
+                h0 = None if st is None else st[l, 1]
+                hs, hT, cT = ops.lstm_seq(inp, K, R, b, h0, c0, act="sigmoid", impl=self.impl, workspace=self._ws)
+                states.append(torch.stack([cT, hT], dim=0))
+                inp = hs
         self._ws.check()
         return inp[..., :H].cpu().numpy(), torch.stack(states, dim=0)[..., :H].cpu().numpy()
 

@@ -298,6 +298,32 @@ def lstm_stack2_bf16(x, layer1, layer2, act="sigmoid", workspace=None, out1=None
     return out1, out2
 
 
+def lstm_stack2_supported(B, T, F, H):
+    return os.environ.get("FOV_NO_STACK2", "") != "1" and bool(_lib.lib().fov_lstm_stack2_supported(B, T, F, H))
+
+
+def lstm_stack2(x, layer1, layer2, state1=None, state2=None, act="sigmoid", workspace=None, reserve=False):
+    """Two stacked fp32 LSTM layers (F <= 96 -> 512 -> 512) as ONE launch, layer 2 a few steps behind layer 1 on other CUs
+    (fov_lstm_stack2_fwd).  layer = (K, R, b); state = (h0, c0) or None.  -> ((hs, hT, cT, reserve), (hs, hT, cT, reserve))."""
+    x = _dev(x, "x")
+    K1, R1, b1 = (_dev(t, "layer1") for t in layer1)
+    K2, R2, b2 = (_dev(t, "layer2") for t in layer2)
+    h01, c01 = (None, None) if state1 is None else (_dev(state1[0], "h0"), _dev(state1[1], "c0"))
+    h02, c02 = (None, None) if state2 is None else (_dev(state2[0], "h0"), _dev(state2[1], "c0"))
+    B, T, F = x.shape
+    H = R1.shape[0]
+    e = lambda *s: torch.empty(s, dtype=torch.float32, device=x.device)
+    out1 = (e(B, T, H), e(B, H), e(B, H), e(B, T, 5, H) if reserve else None)
+    out2 = (e(B, T, H), e(B, H), e(B, H), e(B, T, 5, H) if reserve else None)
+    L = _lib.lib()
+    ws = (workspace or default_workspace(x.device))
+    buf = ws.get(L.fov_lstm_seq_workspace_bytes(B, T, F, H, IMPL_AUTO), x.device)
+    check(L.fov_lstm_stack2_fwd(_ptr(x), _ptr(K1), _ptr(R1), _ptr(b1), _ptr(h01), _ptr(c01), _ptr(K2), _ptr(R2), _ptr(b2),
+                                _ptr(h02), _ptr(c02), *[_ptr(t) for t in out1], *[_ptr(t) for t in out2], B, T, F, H,
+                                act_code(act), buf.data_ptr(), buf.numel(), _stream()))
+    return out1, out2
+
+
 def lstm_seq_train(x, K, R, b, h0=None, c0=None, act="sigmoid", impl="auto", workspace=None, out=None, dtype="f32"):
     """Forward that also returns the reserve (B,T,5,H).  `out` may carry preallocated
     (hs, hT, cT, reserve) tensors.  -> (hs, hT, cT, reserve).  dtype 'bf16': bf16 matrix-core operands."""

@@ -1563,13 +1563,17 @@ class TFLSTMTrainer:
     def _predict_padded(self, x, init_state=None):
         """init_state: (L,2,B,Hp) tensor, or a list of (c, h) pairs at width Hp, or None -> (mu, var, [(cT, hT)])."""
         inp, states = x, []
-        for l in range(self.L):
-            c0 = None if init_state is None else init_state[l][0].contiguous()
-            h0 = None if init_state is None else init_state[l][1].contiguous()
-            hs, hT, cT = ops.lstm_seq(inp, self.w["K%d" % l], self.w["R%d" % l], self.w["b%d" % l], h0, c0, act="sigmoid",
-                                      impl=self.impl, workspace=self.ws)
-            states.append((cT, hT))
-            inp = hs
+        if self._stack2(x):
+            o = self._stack2_forward(x, init_state, reserve=False)
+            states = [(o[0][2], o[0][1]), (o[1][2], o[1][1])]
+        else:
+            for l in range(self.L):
+                c0 = None if init_state is None else init_state[l][0].contiguous()
+                h0 = None if init_state is None else init_state[l][1].contiguous()
+                hs, hT, cT = ops.lstm_seq(inp, self.w["K%d" % l], self.w["R%d" % l], self.w["b%d" % l], h0, c0, act="sigmoid",
+                                          impl=self.impl, workspace=self.ws)
+                states.append((cT, hT))
+                inp = hs
         _, mu, _, var = self._head(states[-1][1])
         return mu, var, states
 
@@ -1591,8 +1595,25 @@ class TFLSTMTrainer:
             win = nxt
         return mus, vs, self._state_out(st)
 
+    def _stack2(self, x, masks=None):
+        """Both layers as one launch (fov_lstm_stack2_fwd)?  Not with a dropout mask between the layers."""
+        return (self.L == 2 and self.impl == "auto" and (masks is None or masks[0] is None)
+                and ops.lstm_stack2_supported(x.shape[0], x.shape[1], x.shape[2], self.Hp))
+
+    def _stack2_forward(self, x, init_state, reserve):
+        w = self.w
+        sts = [None if init_state is None else (init_state[l][1].contiguous(), init_state[l][0].contiguous()) for l in range(2)]
+        return ops.lstm_stack2(x, (w["K0"], w["R0"], w["b0"]), (w["K1"], w["R1"], w["b1"]), sts[0], sts[1], act="sigmoid",
+                               workspace=self.ws, reserve=reserve)
+
     def _stack_forward(self, x, init_state, masks):
         w = self.w
+        if self._stack2(x, masks):
+            o1, o2 = self._stack2_forward(x, init_state, reserve=True)
+            sts = [None if init_state is None else (init_state[l][1].contiguous(), init_state[l][0].contiguous()) for l in range(2)]
+            tape = [(x, o1[0], o1[3], None if sts[0] is None else sts[0][0], None if sts[0] is None else sts[0][1]),
+                    (o1[0], o2[0], o2[3], None if sts[1] is None else sts[1][0], None if sts[1] is None else sts[1][1])]
+            return tape, [(o1[2], o1[1]), (o2[2], o2[1])]
         tape, inp, states = [], x, []
         for l in range(self.L):
             c0 = None if init_state is None else init_state[l, 0].contiguous()

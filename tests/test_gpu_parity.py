@@ -218,6 +218,44 @@ def test_config1_reference_native_shape():
         assert_parity(ops.seq2seq_decode(dev(enc), dev(dec0), devw(w), 10, impl=impl), ref, "config1 " + impl)
 
 
+def test_two_width_512_layers_one_launch():
+    """fov_lstm_stack2_fwd: two stacked width-512 layers as one launch (layer 2 behind layer 1, input through the granule
+    ring) against two separate layer launches (bit-identical: same arithmetic per layer) and the fp64 oracle; fed states,
+    ragged batches, the training tape, repeated launches on one workspace."""
+    ops = _ops()
+    rng = np.random.default_rng(21)
+    H, F = 512, 90
+    l1 = O.init_lstm(rng, F, H, np.float32)
+    l2 = O.init_lstm(rng, H, H, np.float32)
+    d1, d2 = tuple(dev(a) for a in l1), tuple(dev(a) for a in l2)
+    ws = ops.Workspace()
+    for B, T, with_state, reserve in ((32, 10, True, True), (7, 2, False, False), (64, 5, False, True), (37, 13, True, False)):
+        assert ops.lstm_stack2_supported(B, T, F, H)
+        x = rng.uniform(-1, 1, (B, T, F)).astype(np.float32)
+        st = [None, None]
+        if with_state:
+            st = [(dev((0.3 * rng.standard_normal((B, H))).astype(np.float32)), dev((0.3 * rng.standard_normal((B, H))).astype(np.float32)))
+                  for _ in range(2)]
+        for _ in range(2):
+            o1, o2 = ops.lstm_stack2(dev(x), d1, d2, st[0], st[1], workspace=ws, reserve=reserve)
+        ws.check()
+        h01, c01 = st[0] if st[0] else (None, None)
+        h02, c02 = st[1] if st[1] else (None, None)
+        r1 = ops.lstm_seq_train(dev(x), *d1, h01, c01)
+        r2 = ops.lstm_seq_train(r1[0], *d2, h02, c02)
+        for got, ref in ((o1, r1), (o2, r2)):
+            for k in range(4 if reserve else 3):
+                assert torch.equal(got[k], ref[k]), (B, T, k)
+        ref = x.astype(np.float64)
+        for l, (K, R, b) in enumerate((l1, l2)):
+            s0 = st[l]
+            ref, _, _ = O.lstm_layer(ref, K.astype(np.float64), R.astype(np.float64), b.astype(np.float64),
+                                     None if s0 is None else s0[0].cpu().numpy().astype(np.float64),
+                                     None if s0 is None else s0[1].cpu().numpy().astype(np.float64), act="sigmoid")
+        assert_parity(o2[0], ref, "two width-512 layers, one launch B=%d T=%d" % (B, T))
+    assert not ops.lstm_stack2_supported(80, 10, F, H) and not ops.lstm_stack2_supported(32, 1, F, H) and not ops.lstm_stack2_supported(32, 10, F, 256)
+
+
 def test_fused_decode_padded_grid_group_counts():
     """H = 128 fused encoder + decoder with a group count that is no multiple of eight: the grid is padded so that a group's
     members share an XCD (spare workgroups leave at once); 2, 9 and 13 tiles (the last ragged), repeated launches on one
