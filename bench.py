@@ -53,7 +53,7 @@ MODE_TRAFFIC = {
     ("train", "f32"): ((633464 + 1226760) * 1024, "profiles/r03_pmcstep_train_f32.txt"),
     # tools/pmc_simple.sh (run total / identical steps: tools/pmc_simple_steps.py, tools/pmc_run_total.py)
     ("config1", "f32"): (int((864.6 + 3351.7) * 1024), "profiles/r03_pmcstep_config1.txt"),
-    ("a10", "f32"): (int((26059 + 10752.3) * 1024), "profiles/r03_pmcstep_a10.txt"),
+    ("a10", "f32"): (int((25504.4 + 7520.2) * 1024), "profiles/r03_pmcstep_a10.txt"),
     # whole-model predict at B = 256: 396 GB fetched below the L2s per call (not all from HBM: the counter sits in front of the
     # 256 MB MALL), 97 % of it by the two deep head convolutions re-reading 25 shifted taps of (pixels x 512 / 1024 channels) and
     # every workgroup its 6.5 MB of weights - 0.8 TB/s, a tenth of the HBM rate; re-ordering k as (channel slab, tap) did

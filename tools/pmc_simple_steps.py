@@ -30,6 +30,9 @@ elif what == "a10":
     dl = [tuple(d(a) for a in pad_lstm(K, R, b, 512, pad_input=(l > 0))) for l, (K, R, b) in enumerate(layers)]
     x, ws = d(np.random.default_rng(7).uniform(-1, 1, (32, 10, 90)).astype(np.float32)), ops.Workspace()
     for _ in range(steps):
+        if ops.lstm_stack2_supported(32, 10, 90, 512):      # both layers as one launch (fov_lstm_stack2_fwd)
+            ops.lstm_stack2(x, dl[0], dl[1], workspace=ws)
+            continue
         inp = x
         for K, R, b in dl:
             inp, hT, cT = ops.lstm_seq(inp, K, R, b, act="sigmoid", workspace=ws)
