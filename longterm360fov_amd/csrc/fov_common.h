@@ -78,6 +78,11 @@ struct EnvKnobs {
     int gemm_variant, gemm_split;   // FOV_GEMM_VARIANT / FOV_GEMM_SPLIT: tile shape / K slices of the fp32 GEMM forced (experiments)
     int no_wide16;       // FOV_NO_WIDE16=1: width-512 layers stay on the 16-workgroup form (tests / A-B timing)
     int no_cell_patch;   // FOV_NO_CELL_PATCH=1: ConvLSTM2D steps stay on the implicit-GEMM cell (tests compare the two forms)
+    int no_xcd_pad;      // FOV_NO_XCD_PAD=1: no padded grids for same-XCD placement (lstm_wide16 / lstm_bwd16 / fused H = 128 kernel)
+    int xcd_pad_max;     // FOV_XCD_PAD_MAX: members per group up to which a grid is padded (default 16; 32 measured slower)
+    int no_bwd16_narrow; // FOV_NO_BWD16_NARROW=1: widths 128 / 256 keep the 2- / 4- / 8-workgroup BPTT kernels at small batches
+    int bwd16_groups16;  // FOV_BWD16_GROUPS=16: width-512 BPTT stays on sixteen workgroups per tile
+    int no_stack2;       // FOV_NO_STACK2=1: two stacked width-512 layers as two launches (fov_lstm_stack2_supported -> 0)
 };
 const EnvKnobs& env_knobs();
 void env_reload();

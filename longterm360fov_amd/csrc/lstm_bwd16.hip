@@ -313,7 +313,7 @@ bool bwd16_takes(int B, int H) {
     const int cus = device_cu_count();
     if (H == 512) return cus >= 16;
     if (H != 128 && H != 256) return false;
-    static const bool off = getenv("FOV_NO_BWD16_NARROW") != nullptr;
+    const bool off = env_knobs().no_bwd16_narrow != 0;
     const int tiles = (B + XBT - 1) / XBT;
     return !off && tiles >= 1 && tiles <= 8 && tiles <= cus / (H / 16);
 }
@@ -326,8 +326,8 @@ static int launch_bwd16_t(Bwd16Params& p, int act, hipStream_t stream) {
     p.epoch_span = p.T * ((p.num_tiles + p.num_groups - 1) / p.num_groups) + 1;
     if (int rc_ = xch_account(p.status, p.epoch_span, stream)) return rc_;
     void (*kern)(Bwd16Params) = act == FOV_ACT_HARD_SIGMOID ? lstm_bwd16_kernel<FOV_ACT_HARD_SIGMOID, XH, XG> : lstm_bwd16_kernel<FOV_ACT_SIGMOID, XH, XG>;
-    static const bool no_pad = getenv("FOV_NO_XCD_PAD") != nullptr;
-    static const int pad_max = getenv("FOV_XCD_PAD_MAX") ? atoi(getenv("FOV_XCD_PAD_MAX")) : 16;   // members per group at most
+    const bool no_pad = env_knobs().no_xcd_pad != 0;
+    const int pad_max = env_knobs().xcd_pad_max;   // members per group at most
     p.xcd_pad = (!no_pad && XG <= pad_max && p.num_groups < 8 && device_cu_count() >= 8 * XG) ? 1 : 0;
     hipLaunchKernelGGL(kern, dim3(p.xcd_pad ? 8 * XG : p.num_groups * XG), dim3(256), 0, stream, p);
     hipError_t e = hipGetLastError();
@@ -350,7 +350,7 @@ int launch_bwd16(const float* R, const float* reserve, const float* c0, const fl
     if (H == 128) return launch_bwd16_t<128, 8>(p, act, stream);
     if (H == 256) return launch_bwd16_t<256, 16>(p, act, stream);
     // width 512: at most eight tiles and one tile per group -> thirty-two workgroups per tile (FOV_BWD16_GROUPS=16 keeps sixteen)
-    static const bool force16 = [] { const char* e = getenv("FOV_BWD16_GROUPS"); return e && atoi(e) == 16; }();
+    const bool force16 = env_knobs().bwd16_groups16 != 0;
     if (!force16 && p.num_tiles <= 8 && p.num_tiles <= device_cu_count() / 32) return launch_bwd16_t<512, 32>(p, act, stream);
     return launch_bwd16_t<512, 16>(p, act, stream);
 }

@@ -1093,7 +1093,7 @@ static int launch_cluster_fused_h(const LstmParams& p, hipStream_t stream) {
     int rc = ensure_dynamic_lds((const void*)kern, lds);
     if (rc) return rc;
     LstmParams q = p;
-    static const bool no_pad = getenv("FOV_NO_XCD_PAD") != nullptr;
+    const bool no_pad = env_knobs().no_xcd_pad != 0;
     const int padded = (q.num_groups + 7) & ~7;
     q.xcd_pad = (H == 128 && !no_pad && (q.num_groups & 7) != 0 && device_cu_count() >= padded * (H / 64)) ? 1 : 0;
     hipLaunchKernelGGL(kern, dim3((q.xcd_pad ? padded : q.num_groups) * (H / 64)), dim3(256), lds, stream, q);

@@ -453,8 +453,8 @@ int launch_wide16_t(LstmParams& p, hipStream_t stream) {
     int rc = ensure_dynamic_lds((const void*)kern, lds);
     if (rc) return rc;
     // fewer than eight groups of at most sixteen workgroups: same-XCD placement through a padded grid (FOV_NO_XCD_PAD=1: off)
-    static const bool no_pad = getenv("FOV_NO_XCD_PAD") != nullptr;
-    static const int pad_max = getenv("FOV_XCD_PAD_MAX") ? atoi(getenv("FOV_XCD_PAD_MAX")) : 16;   // members per group at most
+    const bool no_pad = env_knobs().no_xcd_pad != 0;
+    const int pad_max = env_knobs().xcd_pad_max;   // members per group at most
     p.xcd_pad = (!no_pad && WG <= pad_max && p.num_groups < 8 && device_cu_count() >= 8 * WG) ? 1 : 0;
     hipLaunchKernelGGL(kern, dim3(p.xcd_pad ? 8 * WG : p.num_groups * WG), dim3(256), lds, stream, p);
     hipError_t e = hipGetLastError();
@@ -481,7 +481,7 @@ bool wide16_preferred(const float* x, int B, int F, int H) {
 // Two stacked layers (F <= 96 -> 512 -> 512) as one launch: both layers' groups must be resident (2 x tiles x 32 workgroups),
 // T >= 2, the ring (tiles x T slots) and layer 2's parity slots must fit the granule area.
 bool wide16_pair_shape(int B, int T, int F, int H) {
-    static const bool off = getenv("FOV_NO_STACK2") != nullptr;
+    const bool off = env_knobs().no_stack2 != 0;
     if (off || H != 512 || B <= 0 || T < 2 || F < 1 || F > 96) return false;
     const int tiles = (B + VBT - 1) / VBT;
     if (2 * tiles * (H / 16) > device_cu_count()) return false;

@@ -270,6 +270,13 @@ def test_fused_decode_padded_grid_group_counts():
             out = ops.seq2seq_decode(dev(enc), dev(dec0), devw(w), 6, impl="cluster", workspace=ws)
         ws.check()
         assert_parity(out, ref.astype(np.float64), "padded fused grid B=%d" % B)
+        os.environ["FOV_NO_XCD_PAD"] = "1"     # the unpadded grid (placement-independent exchange): bit-identical
+        try:
+            plain = ops.seq2seq_decode(dev(enc), dev(dec0), devw(w), 6, impl="cluster", workspace=ws)
+        finally:
+            os.environ.pop("FOV_NO_XCD_PAD", None)
+        ws.check()
+        assert torch.equal(plain, out), B
 
 
 def test_config2_full_size_and_properties():
