@@ -186,7 +186,12 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd16_kernel(Bwd16Params p) {
             // while the matrix pipe works on the second. ----
             // one address register for all stores: the wave's first destination is part of it, the tile's goes into the scalar offset
             constexpr unsigned DSTR = XG * XBT * UW * 8;     // bytes per destination slice
-            const unsigned off0 = (unsigned)(((slice * XBT + 4 * g4) * UW) + n) * 8u + (unsigned)wave * (16 * NT / UW) * DSTR;
+            // CPL == 2 (PAIRED): granule order [dest][src][row pair][unit][row of the pair] - the two rows of a lane's cells
+            // are adjacent 8-byte granules, each with its own tag (the protocol's unit of atomicity stays 8 bytes), moved by
+            // ONE 16-byte store / load: half the exchange instructions per step on both sides
+            constexpr bool PAIRED = CPL == 2;
+            const unsigned off0 = PAIRED ? (unsigned)(((slice * (XBT / 2) + 2 * g4) * UW) + n) * 16u + (unsigned)wave * (16 * NT / UW) * DSTR
+                                         : (unsigned)(((slice * XBT + 4 * g4) * UW) + n) * 8u + (unsigned)wave * (16 * NT / UW) * DSTR;
             const float* arow = sDZ + n * XLDZ + 4 * g4;
 #pragma unroll
             for (int pass = 0; pass < NPASS; ++pass) {
@@ -211,13 +216,71 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd16_kernel(Bwd16Params p) {
 #pragma unroll
                 for (int tq = 0; tq < TQ; ++tq) {
                     const int tl = TQ * pass + tq;
+                    if constexpr (PAIRED) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        XCH_STORE_B64(ticket.same_xcd, ((qu32x2){__float_as_uint(acc[tq][r]), epoch}), rs,
-                                      off0 + ((16 * tl) % UW) * 8 + r * UW * 8, par + (unsigned)((16 * tl) / UW) * DSTR);
+                        for (int rp = 0; rp < 2; ++rp) {
+                            const qu32x4 gr = {__float_as_uint(acc[tq][2 * rp]), epoch, __float_as_uint(acc[tq][2 * rp + 1]), epoch};
+                            if (ticket.same_xcd) __builtin_amdgcn_raw_buffer_store_b128(gr, rs, off0 + ((16 * tl) % UW) * 16 + rp * UW * 16, par + (unsigned)((16 * tl) / UW) * DSTR, 1);
+                            else __builtin_amdgcn_raw_buffer_store_b128(gr, rs, off0 + ((16 * tl) % UW) * 16 + rp * UW * 16, par + (unsigned)((16 * tl) / UW) * DSTR, 16);
+                        }
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            XCH_STORE_B64(ticket.same_xcd, ((qu32x2){__float_as_uint(acc[tq][r]), epoch}), rs,
+                                          off0 + ((16 * tl) % UW) * 8 + r * UW * 8, par + (unsigned)((16 * tl) / UW) * DSTR);
+                    }
                 }
             }
             // ---- gather the XG pieces of each of this lane's cells, add in slice order ----
+            if constexpr (PAIRED) {
+                const unsigned voff = (unsigned)(((slice * XG) * (XBT / 2) + 2 * g4 + hi) * UW + ul) * 16u;
+                constexpr unsigned SSTR = XBT * UW * 8;   // src stride in bytes
+                float part[2][XG];
+                unsigned bad = 0;
+                {
+                    qu32x4 v[XG];
+#pragma unroll
+                    for (int s = 0; s < XG; ++s) v[s] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, par + s * SSTR, 16);
+#pragma unroll
+                    for (int s = 0; s < XG; ++s) {
+                        part[0][s] = __uint_as_float(v[s].x);
+                        part[1][s] = __uint_as_float(v[s].z);
+                        if (v[s].y != epoch || v[s].w != epoch) bad |= (1u << s);
+                    }
+                }
+                unsigned spins = 0;
+                while (__any(bad != 0)) {
+                    ++spins;
+                    if (spins > Q_SPIN || ((spins & 63u) == 0 && xch_poisoned(p.status))) {
+                        if (lane == 0) { xch_give_up(p.status); sFlag[0] = 1; }
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                    asm volatile("" ::: "memory");
+#pragma unroll
+                    for (int h = 0; h < XG / 8; ++h) {
+                        qu32x4 tv[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) tv[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, par + (h * 8 + u) * SSTR, 16);
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            const int s_ = h * 8 + u;
+                            if (((bad >> s_) & 1u) && tv[u].y == epoch && tv[u].w == epoch) {
+                                part[0][s_] = __uint_as_float(tv[u].x);
+                                part[1][s_] = __uint_as_float(tv[u].z);
+                                bad &= ~(1u << s_);
+                            }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    float a = 0.f;
+#pragma unroll
+                    for (int s = 0; s < XG; ++s) a += part[q][s];
+                    dh[q] = a;
+                }
+            } else
             {
                 const unsigned voff = (unsigned)(((slice * XG) * XBT + my_row0) * UW + ul) * 8u;
                 constexpr unsigned SSTR = XBT * UW * 8;   // src stride in bytes
