@@ -38,6 +38,7 @@ constexpr unsigned B_SPIN = 1u << 20;
 constexpr int BK2_LDS_BLOCKS = 28;
 
 typedef unsigned bwu32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned bwu32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ void bm_a(f32x4& acc, float a, float w_agpr) {
     asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "a"(w_agpr));
@@ -84,8 +85,8 @@ __device__ unsigned long long g_mixb_stamps[BSTAMP_STEPS][BSTAMP_SLOTS];
 #endif
 
 // granule areas of one group, in granules (8 bytes each); two parities of each
-constexpr size_t MB2 = (size_t)BG * BG * 2 * BBT * 32;   // [dest][src][product][row][unit]
-constexpr size_t MB1 = (size_t)BG * BG * BBT * 32;       // [dest][src][row][unit]
+constexpr size_t MB2 = (size_t)BG * BG * 2 * BBT * 32;   // [dest][src][product][row pair][unit][row of the pair]
+constexpr size_t MB1 = (size_t)BG * BG * BBT * 32;       // [dest][src][row pair][unit][row of the pair]
 constexpr size_t MBX = (size_t)BG * BBT * 8;             // [src][row][o]
 constexpr size_t MB_GROUP = 2 * (MB2 + MB1 + MBX);
 
@@ -223,6 +224,51 @@ __global__ __launch_bounds__(256, 1) void mix_decoder_bwd_kernel(MixDecBwdParams
             out[q] = acc;
         }
     };
+    // The partial sums of a lane's TWO cells (rows 2k, 2k + 1 of one unit) are adjacent tagged granules (round 3): one 16-byte
+    // load per source brings both - eight loads instead of sixteen per gather, half the stores on the publishing side; every
+    // 8-byte granule keeps its own epoch tag, the protocol's unit of atomicity is unchanged.
+    auto gather_pair = [&](const __amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned sstride, unsigned base, float (&out)[2]) {
+        float part[2][8];
+        unsigned bad = 0;
+        {
+            bwu32x4 v[8];
+#pragma unroll
+            for (int s = 0; s < 8; ++s) v[s] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + s * sstride, base, 16);
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                part[0][s] = __uint_as_float(v[s].x);
+                part[1][s] = __uint_as_float(v[s].z);
+                if (v[s].y != epoch || v[s].w != epoch) bad |= (1u << s);
+            }
+        }
+        unsigned spins = 0;
+        while (__any(bad != 0)) {
+            ++spins;
+            if (spins > B_SPIN || ((spins & 63u) == 0 && xch_poisoned(p.status))) {
+                give_up();
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+            asm volatile("" ::: "memory");
+            bwu32x4 tv[8];
+#pragma unroll
+            for (int s = 0; s < 8; ++s) tv[s] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + s * sstride, base, 16);
+#pragma unroll
+            for (int s = 0; s < 8; ++s)
+                if (((bad >> s) & 1u) && tv[s].y == epoch && tv[s].w == epoch) {
+                    part[0][s] = __uint_as_float(tv[s].x);
+                    part[1][s] = __uint_as_float(tv[s].z);
+                    bad &= ~(1u << s);
+                }
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            float acc = 0.f;
+#pragma unroll
+            for (int s = 0; s < 8; ++s) acc += part[q][s];
+            out[q] = acc;
+        }
+    };
     xch_hello_poll(p.status, sXch, group, BG, &sFlag[0]);   // same-XCD handshake (xch_common.h): partners' words, published at entry
     __syncthreads();
     const XchTicket ticket = xch_ticket(sXch, arrival);
@@ -341,10 +387,13 @@ __global__ __launch_bounds__(256, 1) void mix_decoder_bwd_kernel(MixDecBwdParams
 #pragma unroll
                     for (int tl = 0; tl < 4; ++tl) {
                         const int d = 2 * wave + (tl >> 1);
-                        const unsigned off = (unsigned)(((((d * BG + slice) * 2 + q) * BBT + 4 * g4) * 32) + 16 * (tl & 1) + n) * 8u;
+                        const unsigned off = (unsigned)(((((d * BG + slice) * 2 + q) * (BBT / 2) + 2 * g4) * 32) + 16 * (tl & 1) + n) * 16u;
 #pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            XCH_STORE_B64(ticket.same_xcd, ((bwu32x2){__float_as_uint(acc[q * 4 + tl][r]), epoch}), rs2, off + r * 32 * 8, par2);
+                        for (int rp = 0; rp < 2; ++rp) {
+                            const bwu32x4 gr = {__float_as_uint(acc[q * 4 + tl][2 * rp]), epoch, __float_as_uint(acc[q * 4 + tl][2 * rp + 1]), epoch};
+                            if (ticket.same_xcd) __builtin_amdgcn_raw_buffer_store_b128(gr, rs2, off + rp * 32 * 16, par2, 1);
+                            else __builtin_amdgcn_raw_buffer_store_b128(gr, rs2, off + rp * 32 * 16, par2, 16);
+                        }
                     }
             }
             // tape of layer 1: requested under the exchange wait below
@@ -363,13 +412,11 @@ __global__ __launch_bounds__(256, 1) void mix_decoder_bwd_kernel(MixDecBwdParams
             float dh1in[2];
             {
                 // [dest = slice][src][q][row][unit]: src stride = 2*16*32 granules
-                unsigned voff[2];
                 float sum[2];
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
-                    voff[0] = (unsigned)((((slice * BG) * 2 + q) * BBT + my_row0) * 32 + ul) * 8u;
-                    voff[1] = voff[0] + 32 * 8;
-                    gather_sum(rs2, voff, 2 * BBT * 32 * 8, par2, sum);
+                    const unsigned vo = (unsigned)((((slice * BG) * 2 + q) * (BBT / 2) + (my_row0 >> 1)) * 32 + ul) * 16u;
+                    gather_pair(rs2, vo, 2 * BBT * 32 * 8, par2, sum);
                     if (q == 0) { dh2r[0] = sum[0]; dh2r[1] = sum[1]; }
                     else { dh1in[0] = sum[0]; dh1in[1] = sum[1]; }
                 }
@@ -439,10 +486,13 @@ __global__ __launch_bounds__(256, 1) void mix_decoder_bwd_kernel(MixDecBwdParams
 #pragma unroll
                 for (int tl = 0; tl < 4; ++tl) {
                     const int d = 2 * wave + (tl >> 1);
-                    const unsigned off = (unsigned)((((d * BG + slice) * BBT + 4 * g4) * 32) + 16 * (tl & 1) + n) * 8u;
+                    const unsigned off = (unsigned)((((d * BG + slice) * (BBT / 2) + 2 * g4) * 32) + 16 * (tl & 1) + n) * 16u;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        XCH_STORE_B64(ticket.same_xcd, ((bwu32x2){__float_as_uint(acc[tl][r]), epoch}), rs1, off + r * 32 * 8, par1);
+                    for (int rp = 0; rp < 2; ++rp) {
+                        const bwu32x4 gr = {__float_as_uint(acc[tl][2 * rp]), epoch, __float_as_uint(acc[tl][2 * rp + 1]), epoch};
+                        if (ticket.same_xcd) __builtin_amdgcn_raw_buffer_store_b128(gr, rs1, off + rp * 32 * 16, par1, 1);
+                        else __builtin_amdgcn_raw_buffer_store_b128(gr, rs1, off + rp * 32 * 16, par1, 16);
+                    }
                 }
             }
             MIXB_STAMP(7);
@@ -450,9 +500,7 @@ __global__ __launch_bounds__(256, 1) void mix_decoder_bwd_kernel(MixDecBwdParams
             {
                 unsigned voff[2];
                 float sum[2];
-                voff[0] = (unsigned)(((slice * BG) * BBT + my_row0) * 32 + ul) * 8u;
-                voff[1] = voff[0] + 32 * 8;
-                gather_sum(rs1, voff, BBT * 32 * 8, par1, sum);
+                gather_pair(rs1, (unsigned)(((slice * BG) * (BBT / 2) + (my_row0 >> 1)) * 32 + ul) * 16u, BBT * 32 * 8, par1, sum);
                 dh1r[0] = sum[0]; dh1r[1] = sum[1];
                 // dx: thread (hrow, ho < 8) sums the 8 sources; the second quantity of gather_sum re-reads the same
                 voff[0] = (unsigned)(hrow * 8 + (ho & 7)) * 8u;
