@@ -199,28 +199,32 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd8_kernel(Bwd8Params p) {
             }
 #pragma unroll
             for (int tl = 0; tl < 4; ++tl) {
+                // granule order [dest][src][row pair][unit][row of the pair]: the two rows of a lane's cells are adjacent tagged
+                // granules, moved by ONE 16-byte store / load (round 3: half the exchange instructions, same 8-byte atomicity)
                 const int d = 2 * wave + (tl >> 1);
-                const unsigned off = (unsigned)((((d * QG + slice) * QBT + 4 * g4) * 32) + 16 * (tl & 1) + n) * 8u;
+                const unsigned off = (unsigned)((((d * QG + slice) * (QBT / 2) + 2 * g4) * 32) + 16 * (tl & 1) + n) * 16u;
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    XCH_STORE_B64(ticket.same_xcd, ((qu32x2){__float_as_uint(acc[tl][r]), epoch}), rs, off + r * 32 * 8, par);
+                for (int rp = 0; rp < 2; ++rp) {
+                    const qu32x4 gr = {__float_as_uint(acc[tl][2 * rp]), epoch, __float_as_uint(acc[tl][2 * rp + 1]), epoch};
+                    if (ticket.same_xcd) __builtin_amdgcn_raw_buffer_store_b128(gr, rs, off + rp * 32 * 16, par, 1);
+                    else __builtin_amdgcn_raw_buffer_store_b128(gr, rs, off + rp * 32 * 16, par, 16);
+                }
             }
-            // ---- gather the 8 pieces of this lane's two cells, add in slice order ----
+            // ---- gather the 8 pieces of this lane's two cells (one 16-byte load per source), add in slice order ----
             {
-                const unsigned voff = (unsigned)(((slice * QG) * QBT + my_row0) * 32 + ul) * 8u;
+                const unsigned voff = (unsigned)(((slice * QG) * (QBT / 2) + (my_row0 >> 1)) * 32 + ul) * 16u;
                 constexpr unsigned SSTR = QBT * 32 * 8;   // src stride in bytes
-                float part[16];
+                float part[2][8];
                 unsigned bad = 0;
                 {
-                    qu32x2 v[16];
+                    qu32x4 v[8];
 #pragma unroll
-                    for (int q = 0; q < 2; ++q)
+                    for (int s = 0; s < 8; ++s) v[s] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + s * SSTR, par, 16);
 #pragma unroll
-                        for (int s = 0; s < 8; ++s) v[q * 8 + s] = __builtin_amdgcn_raw_buffer_load_b64(rs, voff + q * 32 * 8 + s * SSTR, par, 16);
-#pragma unroll
-                    for (int j = 0; j < 16; ++j) {
-                        part[j] = __uint_as_float(v[j].x);
-                        if (v[j].y != epoch) bad |= (1u << j);
+                    for (int s = 0; s < 8; ++s) {
+                        part[0][s] = __uint_as_float(v[s].x);
+                        part[1][s] = __uint_as_float(v[s].z);
+                        if (v[s].y != epoch || v[s].w != epoch) bad |= (1u << s);
                     }
                 }
                 unsigned spins = 0;
@@ -232,23 +236,22 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd8_kernel(Bwd8Params p) {
                     }
                     __builtin_amdgcn_s_sleep(1);
                     asm volatile("" ::: "memory");
-                    qu32x2 tv[16];
+                    qu32x4 tv[8];
 #pragma unroll
-                    for (int q = 0; q < 2; ++q)
+                    for (int s = 0; s < 8; ++s) tv[s] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + s * SSTR, par, 16);
 #pragma unroll
-                        for (int s = 0; s < 8; ++s) tv[q * 8 + s] = __builtin_amdgcn_raw_buffer_load_b64(rs, voff + q * 32 * 8 + s * SSTR, par, 16);
-#pragma unroll
-                    for (int j = 0; j < 16; ++j)
-                        if (((bad >> j) & 1u) && tv[j].y == epoch) {
-                            part[j] = __uint_as_float(tv[j].x);
-                            bad &= ~(1u << j);
+                    for (int s = 0; s < 8; ++s)
+                        if (((bad >> s) & 1u) && tv[s].y == epoch && tv[s].w == epoch) {
+                            part[0][s] = __uint_as_float(tv[s].x);
+                            part[1][s] = __uint_as_float(tv[s].z);
+                            bad &= ~(1u << s);
                         }
                 }
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
                     float a = 0.f;
 #pragma unroll
-                    for (int s = 0; s < 8; ++s) a += part[q * 8 + s];
+                    for (int s = 0; s < 8; ++s) a += part[q][s];
                     dh[q] = a;
                 }
             }
