@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256, 1) void lstm_wide_kernel(LstmParams p) {
     constexpr bool XVEC = NJX == 16;   // wide inputs: 16-byte pieces (F % 4 == 0, x aligned); narrow: scalar elements
     constexpr bool ZXM = NJX == 0;
     constexpr int WLD = WH + 4;        // LDS row stride of the h tile and of the x tiles
-    constexpr int WNG = (WG - 1) * 2;  // granules gathered per thread and step: (WG-1) slices * 16 rows * 32 units / 256
+    constexpr int WNG = WG - 1;        // 16-byte loads (two adjacent units' tagged granules) per thread and step: (WG-1) slices * 16 rows * 16 pairs / 256
     constexpr int NJR = WH / 16;       // k-blocks of R
     constexpr bool K_AGPR = WH == 256; // width 512: R takes every accumulation register, K (narrow: 48 values) stays in VGPRs
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -125,8 +125,10 @@ __global__ __launch_bounds__(256, 1) void lstm_wide_kernel(LstmParams p) {
         p.xch + (size_t)group * 2 * WBT * WH, 0, 2 * WBT * WH * (int)sizeof(unsigned long long), 0x00020000);
     const int my_row0 = 4 * g4 + 2 * hi;
     const unsigned pub_off = (unsigned)(my_row0 * WH + unit) * 8u;
-    const unsigned gvoff = (unsigned)((tid >> 5) * WH + (tid & 31)) * 8u;
-    const int lbase = (tid >> 5) * WLD + (tid & 31);
+    // gather: thread (row tid / 16, unit pair tid % 16) brings units (2p, 2p + 1) of every partner slice with one 16-byte load
+    // (round 3; adjacent in the [row][unit] order, each granule with its own tag)
+    const unsigned gvoff = (unsigned)((tid >> 4) * WH + 2 * (tid & 15)) * 8u;
+    const int lbase = (tid >> 4) * WLD + 2 * (tid & 15);
     constexpr unsigned PARITY = WBT * WH * 8u;
     if (xch_used) xch_hello_poll(p.status, sXch, group, WG, &sFlag[0]);   // same-XCD handshake (xch_common.h): partners' words, published at entry
     __syncthreads();
@@ -136,12 +138,12 @@ __global__ __launch_bounds__(256, 1) void lstm_wide_kernel(LstmParams p) {
     bool aborted = sFlag[0] != 0;
     if (xch_used && tid == 0 && !ticket.same_xcd && !aborted) xch_count_safe(p.status, ticket);   // (fov_exchange_mode)
 
-    wu32x2 v[WNG];
+    wu32x4 v[WNG];
     auto gather_issue = [&](unsigned base) {
 #pragma unroll
         for (int j = 0; j < WNG; ++j) {
-            const unsigned uo = (unsigned)((j & 1) * 8 * WH + ((slice + 1 + (j >> 1)) & (WG - 1)) * 32) * 8u;
-            v[j] = __builtin_amdgcn_raw_buffer_load_b64(xrs, gvoff, base + uo, 16);
+            const unsigned uo = (unsigned)(((slice + 1 + j) & (WG - 1)) * 32) * 8u;
+            v[j] = __builtin_amdgcn_raw_buffer_load_b128(xrs, gvoff, base + uo, 16);
         }
     };
     // first pass: current granules go straight to the h tile, stale ones into a bit mask; retry sweeps (rare)
@@ -150,9 +152,13 @@ __global__ __launch_bounds__(256, 1) void lstm_wide_kernel(LstmParams p) {
         unsigned bad = 0;
 #pragma unroll
         for (int j = 0; j < WNG; ++j) {
-            const int lo = lbase + (j & 1) * 8 * WLD + ((slice + 1 + (j >> 1)) & (WG - 1)) * 32;
-            if (v[j].y == epoch) sH[lo] = __uint_as_float(v[j].x);
-            else bad |= (1u << j);
+            const int lo = lbase + ((slice + 1 + j) & (WG - 1)) * 32;
+            if (v[j].y == epoch && v[j].w == epoch) {
+                sH[lo] = __uint_as_float(v[j].x);
+                sH[lo + 1] = __uint_as_float(v[j].z);
+            } else {
+                bad |= (1u << j);
+            }
         }
         unsigned spins = 0;
         while (__any(bad != 0)) {
@@ -166,20 +172,21 @@ __global__ __launch_bounds__(256, 1) void lstm_wide_kernel(LstmParams p) {
             }
             __builtin_amdgcn_s_sleep(1);
             asm volatile("" ::: "memory");
-            constexpr int RCH = WH == 512 ? 6 : WNG;   // width 512: retry in chunks (register budget)
+            constexpr int RCH = WH == 512 ? 5 : WNG;   // width 512: retry in chunks (register budget)
 #pragma unroll
             for (int j0 = 0; j0 < WNG; j0 += RCH) {
-                wu32x2 tv[RCH];
+                wu32x4 tv[RCH];
 #pragma unroll
-                for (int j = j0; j < j0 + RCH; ++j) {
-                    const unsigned uo = (unsigned)((j & 1) * 8 * WH + ((slice + 1 + (j >> 1)) & (WG - 1)) * 32) * 8u;
-                    tv[j - j0] = __builtin_amdgcn_raw_buffer_load_b64(xrs, gvoff, base + uo, 16);
+                for (int j = j0; j < j0 + RCH && j < WNG; ++j) {
+                    const unsigned uo = (unsigned)(((slice + 1 + j) & (WG - 1)) * 32) * 8u;
+                    tv[j - j0] = __builtin_amdgcn_raw_buffer_load_b128(xrs, gvoff, base + uo, 16);
                 }
 #pragma unroll
-                for (int j = j0; j < j0 + RCH; ++j) {
-                    const int lo = lbase + (j & 1) * 8 * WLD + ((slice + 1 + (j >> 1)) & (WG - 1)) * 32;
-                    if (((bad >> j) & 1u) && tv[j - j0].y == epoch) {
+                for (int j = j0; j < j0 + RCH && j < WNG; ++j) {
+                    const int lo = lbase + ((slice + 1 + j) & (WG - 1)) * 32;
+                    if (((bad >> j) & 1u) && tv[j - j0].y == epoch && tv[j - j0].w == epoch) {
                         sH[lo] = __uint_as_float(tv[j - j0].x);
+                        sH[lo + 1] = __uint_as_float(tv[j - j0].z);
                         bad &= ~(1u << j);
                     }
                 }

@@ -42,10 +42,11 @@ constexpr int MH = 256;          // hidden units
 constexpr int MG = 8;            // workgroups per tile
 constexpr int MBT = 16;          // sequences per tile
 constexpr int MLDH = MH + 4;     // LDS row stride of an h tile
-constexpr int MNG = 14;          // granules gathered per thread and exchange: 7 slices * 16 rows * 32 units / 256
+constexpr int MNG = 7;           // 16-byte loads (TWO adjacent units' tagged granules) per thread and exchange: 7 slices * 16 rows * 16 pairs / 256
 constexpr unsigned M_SPIN_LIMIT = 1u << 20;
 
 typedef unsigned mu32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned mu32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned mu32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ void mfma_a(f32x4& acc, float a, float w_agpr) {
@@ -213,10 +214,11 @@ __global__ __launch_bounds__(256, 1) void mix_decoder_kernel(MixDecParams p) {
         __builtin_amdgcn_make_buffer_rsrc(xg, 0, 4 * MBT * MH * (int)sizeof(unsigned long long), 0x00020000);
     const int my_row0 = 4 * g4 + 2 * hi;   // this lane's two cells: rows my_row0, my_row0 + 1 of unit `unit`
     const unsigned pub_off = (unsigned)(my_row0 * MH + unit) * 8u;
-    // gather: granule j of this thread is (other slice (slice + 1 + j/2) mod 8, row 8*(j&1) + tid/32, unit tid%32):
-    // one per-thread offset, everything else wave-uniform (scalar operand of the buffer load / LDS immediate)
-    const unsigned gvoff = (unsigned)((tid >> 5) * MH + (tid & 31)) * 8u;
-    const int lbase = (tid >> 5) * MLDH + (tid & 31);
+    // gather: load j of this thread brings the granules of units (2p, 2p + 1) of the other slice (slice + 1 + j) mod 8, row
+    // tid / 16, p = tid % 16 - adjacent in the [row][unit] order, each with its own tag (round 3: seven 16-byte loads instead
+    // of fourteen 8-byte ones); one per-thread offset, everything else wave-uniform
+    const unsigned gvoff = (unsigned)((tid >> 4) * MH + 2 * (tid & 15)) * 8u;
+    const int lbase = (tid >> 4) * MLDH + 2 * (tid & 15);
     constexpr unsigned LAYER_BYTES = 2u * MBT * MH * 8u;    // both parities of one layer
     constexpr unsigned PARITY_BYTES = MBT * MH * 8u;
 #ifdef FOV_STAMPS
@@ -230,12 +232,12 @@ __global__ __launch_bounds__(256, 1) void mix_decoder_kernel(MixDecParams p) {
     if (tid == 0 && !ticket.same_xcd && !aborted) xch_count_safe(p.status, ticket);   // (fov_exchange_mode)
 
     // gather: issue / complete.  v[] stays in registers between the two so MFMAs can run in between.
-    mu32x2 v[MNG];
+    mu32x4 v[MNG];
     auto gather_issue = [&](unsigned base) {
 #pragma unroll
         for (int j = 0; j < MNG; ++j) {
-            const unsigned uo = (unsigned)((j & 1) * 8 * MH + ((slice + 1 + (j >> 1)) & (MG - 1)) * 32) * 8u;
-            v[j] = __builtin_amdgcn_raw_buffer_load_b64(xrs, gvoff, base + uo, 16);
+            const unsigned uo = (unsigned)(((slice + 1 + j) & (MG - 1)) * 32) * 8u;
+            v[j] = __builtin_amdgcn_raw_buffer_load_b128(xrs, gvoff, base + uo, 16);
         }
     };
     auto gather_finish = [&](unsigned base, float* sH) {
@@ -243,7 +245,7 @@ __global__ __launch_bounds__(256, 1) void mix_decoder_kernel(MixDecParams p) {
         while (true) {
             bool ok = true;
 #pragma unroll
-            for (int j = 0; j < MNG; ++j) ok = ok && (v[j].y == epoch);
+            for (int j = 0; j < MNG; ++j) ok = ok && (v[j].y == epoch) && (v[j].w == epoch);
             if (__all(ok)) break;
             ++spins;
             if (spins > M_SPIN_LIMIT || ((spins & 63u) == 0 && xch_poisoned(p.status))) {
@@ -257,13 +259,16 @@ __global__ __launch_bounds__(256, 1) void mix_decoder_kernel(MixDecParams p) {
             asm volatile("" ::: "memory");
 #pragma unroll
             for (int j = 0; j < MNG; ++j) {
-                const unsigned uo = (unsigned)((j & 1) * 8 * MH + ((slice + 1 + (j >> 1)) & (MG - 1)) * 32) * 8u;
-                v[j] = __builtin_amdgcn_raw_buffer_load_b64(xrs, gvoff, base + uo, 16);
+                const unsigned uo = (unsigned)(((slice + 1 + j) & (MG - 1)) * 32) * 8u;
+                v[j] = __builtin_amdgcn_raw_buffer_load_b128(xrs, gvoff, base + uo, 16);
             }
         }
 #pragma unroll
-        for (int j = 0; j < MNG; ++j)
-            sH[lbase + (j & 1) * 8 * MLDH + ((slice + 1 + (j >> 1)) & (MG - 1)) * 32] = __uint_as_float(v[j].x);
+        for (int j = 0; j < MNG; ++j) {
+            float* d = sH + lbase + ((slice + 1 + j) & (MG - 1)) * 32;
+            d[0] = __uint_as_float(v[j].x);
+            d[1] = __uint_as_float(v[j].z);
+        }
     };
 
     for (int tile = group; tile < p.num_tiles && !aborted; tile += p.num_groups) {
