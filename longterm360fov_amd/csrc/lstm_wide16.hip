@@ -70,7 +70,7 @@ __device__ __forceinline__ void wide16_body(const LstmParams& p, const int bx, f
     constexpr int NJR = WH / 16;         // k-blocks of R
     constexpr bool XVEC = ROLE != 2 && NJX == WH / 16;
     constexpr int WLD = WH + 8;          // LDS row stride == 8 (mod 16) floats: conflict-free ds_read_b128 fragments
-    constexpr int WNG = WG - 1;          // granules gathered per thread and step
+    constexpr int WNG = WG / 2;          // 16-byte loads (two adjacent units' tagged granules) per thread and step
     constexpr int H4 = 4 * WH;
     constexpr unsigned OORB = 0x80000000u;
     static_assert((WG & (WG - 1)) == 0 && WG <= kHelloStride, "slice arithmetic, hello words");
@@ -139,9 +139,12 @@ __device__ __forceinline__ void wide16_body(const LstmParams& p, const int bx, f
     const __amdgpu_buffer_rsrc_t ringrs = __builtin_amdgcn_make_buffer_rsrc(   // ROLE 2: layer 1's ring of the same group
         p.xch + (size_t)group * p.T * SLOT, 0, ROLE == 2 ? p.T * (int)(SLOT * sizeof(unsigned long long)) : 0, 0x00020000);
     const unsigned pub_off = (unsigned)(row_o * WH + unit) * 8u;
-    const int grow = tid >> 4, gu = tid & 15;             // gather: row and unit-in-slice of this thread's granules
-    const unsigned gvoff = (unsigned)(grow * WH + gu) * 8u;
-    const int lbase = grow * WLD + gu;
+    // gather: thread (row tid / 16, half (tid / 8) % 2, unit pair tid % 8) brings units (2p, 2p + 1) of partner slices
+    // slice + 1 + half * WG/2 + j, j < WG/2, with one 16-byte load each (round 3: half the gather instructions; every 8-byte
+    // granule keeps its own tag).  The last load of half 1 would be the own slice: switched off (offset past the descriptor).
+    const int grow = tid >> 4, ghalf = (tid >> 3) & 1, gp = tid & 7;
+    const unsigned gvoff = (unsigned)(grow * WH + 2 * gp) * 8u;
+    const int lbase = grow * WLD + 2 * gp;
     constexpr unsigned PARITY = VBT * WH * 8u;
     if (xch_used) xch_hello_poll(p.status, sXch, hgroup, WG, &sFlag[0]);
     __syncthreads();
@@ -151,21 +154,28 @@ __device__ __forceinline__ void wide16_body(const LstmParams& p, const int bx, f
     bool aborted = sFlag[0] != 0;
     if (xch_used && tid == 0 && !ticket.same_xcd && !aborted) xch_count_safe(p.status, ticket);
 
-    vu32x2 v[WNG];
+    vu32x4 v[WNG];
+    auto gslice = [&](int j) { return (slice + 1 + ghalf * WNG + j) & (WG - 1); };
     auto gather_issue = [&](unsigned base) {
 #pragma unroll
         for (int j = 0; j < WNG; ++j) {
-            const unsigned uo = (unsigned)(((slice + 1 + j) & (WG - 1)) * 16) * 8u;
-            v[j] = __builtin_amdgcn_raw_buffer_load_b64(xrs, gvoff, base + uo, 16);
+            const bool on = !(ghalf == 1 && j == WNG - 1);
+            v[j] = __builtin_amdgcn_raw_buffer_load_b128(xrs, on ? gvoff + (unsigned)(gslice(j) * 16) * 8u : OORB, base, 16);
         }
     };
     auto gather_finish = [&](unsigned base) {
         unsigned bad = 0;
 #pragma unroll
         for (int j = 0; j < WNG; ++j) {
-            const int lo = lbase + ((slice + 1 + j) & (WG - 1)) * 16;
-            if (v[j].y == epoch) sH[lo] = __uint_as_float(v[j].x);
-            else bad |= (1u << j);
+            const bool on = !(ghalf == 1 && j == WNG - 1);
+            const int lo = lbase + gslice(j) * 16;
+            if (!on) continue;
+            if (v[j].y == epoch && v[j].w == epoch) {
+                sH[lo] = __uint_as_float(v[j].x);
+                sH[lo + 1] = __uint_as_float(v[j].z);
+            } else {
+                bad |= (1u << j);
+            }
         }
         unsigned spins = 0;
         while (__any(bad != 0)) {
@@ -179,20 +189,21 @@ __device__ __forceinline__ void wide16_body(const LstmParams& p, const int bx, f
             }
             __builtin_amdgcn_s_sleep(1);
             asm volatile("" ::: "memory");
-            constexpr int RCH = 8;   // retry in chunks (register budget)
+            constexpr int RCH = WNG < 8 ? WNG : 8;   // retry in chunks (register budget)
 #pragma unroll
             for (int j0 = 0; j0 < WNG; j0 += RCH) {
-                vu32x2 tv[RCH];
+                vu32x4 tv[RCH];
 #pragma unroll
-                for (int j = j0; j < j0 + RCH && j < WNG; ++j) {
-                    const unsigned uo = (unsigned)(((slice + 1 + j) & (WG - 1)) * 16) * 8u;
-                    tv[j - j0] = __builtin_amdgcn_raw_buffer_load_b64(xrs, gvoff, base + uo, 16);
+                for (int j = j0; j < j0 + RCH; ++j) {
+                    const bool on = !(ghalf == 1 && j == WNG - 1);
+                    tv[j - j0] = __builtin_amdgcn_raw_buffer_load_b128(xrs, on ? gvoff + (unsigned)(gslice(j) * 16) * 8u : OORB, base, 16);
                 }
 #pragma unroll
-                for (int j = j0; j < j0 + RCH && j < WNG; ++j) {
-                    const int lo = lbase + ((slice + 1 + j) & (WG - 1)) * 16;
-                    if (((bad >> j) & 1u) && tv[j - j0].y == epoch) {
+                for (int j = j0; j < j0 + RCH; ++j) {
+                    const int lo = lbase + gslice(j) * 16;
+                    if (((bad >> j) & 1u) && tv[j - j0].y == epoch && tv[j - j0].w == epoch) {
                         sH[lo] = __uint_as_float(tv[j - j0].x);
+                        sH[lo + 1] = __uint_as_float(tv[j - j0].z);
                         bad &= ~(1u << j);
                     }
                 }
@@ -200,24 +211,30 @@ __device__ __forceinline__ void wide16_body(const LstmParams& p, const int bx, f
         }
     };
 
-    // ROLE 2: thread (xrw, xc) gathers row xrw, units xc + 16 i of layer 1's h tile of step s (slot s, tag base + 1 + s)
-    vu32x2 xg[ROLE == 2 ? WH / 16 : 1];
+    // ROLE 2: thread (row tid / 16, c = tid % 16) gathers the unit pairs c + 16 i of layer 1's h tile of step s (slot s, tags
+    // base + 1 + s), one 16-byte load per pair
+    constexpr int NRG = WH / 32;
+    vu32x4 xg[ROLE == 2 ? NRG : 1];
     auto ring_issue = [&](int s_) {
         if constexpr (ROLE == 2) {
-            const unsigned vo = (unsigned)(((tid >> 4) * WH + (tid & 15)) * 8);
+            const unsigned vo = (unsigned)(((tid >> 4) * WH + 2 * (tid & 15)) * 8);
 #pragma unroll
-            for (int i = 0; i < WH / 16; ++i) xg[i] = __builtin_amdgcn_raw_buffer_load_b64(ringrs, vo + i * 16 * 8, (unsigned)s_ * PARITY, 16);
+            for (int i = 0; i < NRG; ++i) xg[i] = __builtin_amdgcn_raw_buffer_load_b128(ringrs, vo + i * 32 * 8, (unsigned)s_ * PARITY, 16);
         }
     };
-    auto ring_store = [&](int s_, float* dst) {   // dst: this thread's first element of the LDS tile
+    auto ring_store = [&](int s_, float* dst) {   // dst: the LDS tile's element [row tid / 16][2 (tid % 16)]
         if constexpr (ROLE == 2) {
             const unsigned want = ticket.base + 1u + (unsigned)s_;
-            const unsigned vo = (unsigned)(((tid >> 4) * WH + (tid & 15)) * 8);
+            const unsigned vo = (unsigned)(((tid >> 4) * WH + 2 * (tid & 15)) * 8);
             unsigned bad = 0;
 #pragma unroll
-            for (int i = 0; i < WH / 16; ++i) {
-                if (xg[i].y == want) dst[16 * i] = __uint_as_float(xg[i].x);
-                else bad |= (1u << i);
+            for (int i = 0; i < NRG; ++i) {
+                if (xg[i].y == want && xg[i].w == want) {
+                    dst[32 * i] = __uint_as_float(xg[i].x);
+                    dst[32 * i + 1] = __uint_as_float(xg[i].z);
+                } else {
+                    bad |= (1u << i);
+                }
             }
             unsigned spins = 0;
             while (__any(bad != 0)) {
@@ -232,14 +249,15 @@ __device__ __forceinline__ void wide16_body(const LstmParams& p, const int bx, f
                 __builtin_amdgcn_s_sleep(2);
                 asm volatile("" ::: "memory");
 #pragma unroll
-                for (int i0 = 0; i0 < WH / 16; i0 += 8) {
-                    vu32x2 tv[8];
+                for (int i0 = 0; i0 < NRG; i0 += 8) {
+                    vu32x4 tv[8];
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) tv[i] = __builtin_amdgcn_raw_buffer_load_b64(ringrs, vo + (i0 + i) * 16 * 8, (unsigned)s_ * PARITY, 16);
+                    for (int i = 0; i < 8; ++i) tv[i] = __builtin_amdgcn_raw_buffer_load_b128(ringrs, vo + (i0 + i) * 32 * 8, (unsigned)s_ * PARITY, 16);
 #pragma unroll
                     for (int i = 0; i < 8; ++i)
-                        if (((bad >> (i0 + i)) & 1u) && tv[i].y == want) {
-                            dst[16 * (i0 + i)] = __uint_as_float(tv[i].x);
+                        if (((bad >> (i0 + i)) & 1u) && tv[i].y == want && tv[i].w == want) {
+                            dst[32 * (i0 + i)] = __uint_as_float(tv[i].x);
+                            dst[32 * (i0 + i) + 1] = __uint_as_float(tv[i].z);
                             bad &= ~(1u << (i0 + i));
                         }
                 }
@@ -288,7 +306,7 @@ __device__ __forceinline__ void wide16_body(const LstmParams& p, const int bx, f
             return (f32x4){__uint_as_float(q[0]), __uint_as_float(q[1]), __uint_as_float(q[2]), __uint_as_float(q[3])};
         };
         auto load_x1 = [&](int i, int t) { return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xgrs, xoff[i], (unsigned)(t * F * 4), 0)); };
-        float* xl = sX + xrw * WLD + (XVEC ? 4 : 1) * xc;
+        float* xl = sX + xrw * WLD + (ROLE == 2 ? 2 : XVEC ? 4 : 1) * xc;   // ROLE 2: unit pairs from the ring (ring_store)
         const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
         if constexpr (ROLE == 2) {   // x_0 and x_1 = layer 1's h_0, h_1: wait for them (layer 2 starts two steps behind)
             ring_issue(0);
