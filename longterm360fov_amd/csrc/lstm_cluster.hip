@@ -54,6 +54,7 @@ constexpr int MODE_LAYER_ZX = 2;   // MODE_LAYER with the input projection preco
                                 // memory latency in every step of the plain layer
 
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4g __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ unsigned long long ld_granule(const unsigned long long* p) {
@@ -369,7 +370,7 @@ template <int H, int ACT, int MODE, int FUSED>
 __device__ __forceinline__ void cluster_body(const LstmParams& p, ClusterCarry& cy) {
     constexpr int G = H / 64;
     constexpr int NQ = H / 16;
-    constexpr int NG = (G - 1) * 4;  // granules gathered per thread per step
+    constexpr int NG = (G - 1) * 2;  // 16-byte loads (two adjacent units' tagged granules) per thread per step
     constexpr bool LAYER = (MODE != MODE_DECODE);
     constexpr bool ZX = (MODE == MODE_LAYER_ZX);      // input projection precomputed by the caller
     constexpr bool F1 = (FUSED == 1), F2 = (FUSED == 2);
@@ -572,11 +573,12 @@ __device__ __forceinline__ void cluster_body(const LstmParams& p, ClusterCarry& 
     int loff[NG > 0 ? NG : 1];
 #pragma unroll
     for (int j = 0; j < NG; ++j) {
+        // pair `within` of partner slice `osl`: row within / 32, units 2 (within % 32) and + 1 - adjacent granules, one load
         const int idx = j * 256 + tid;
-        const int rot = (idx >> 10) + 1, within = idx & 1023;
+        const int rot = (idx >> 9) + 1, within = idx & 511;
         const int osl = (slice + rot) & (G - 1);
-        goff[j] = (unsigned)((within >> 6) * H + osl * 64 + (within & 63)) * 8u;
-        loff[j] = (within >> 6) * LDH + rot * 64 + (within & 63);
+        goff[j] = (unsigned)((within >> 5) * H + osl * 64 + 2 * (within & 31)) * 8u;
+        loff[j] = (within >> 5) * LDH + rot * 64 + 2 * (within & 31);
     }
 
     const bool h_zero = !F2 && p.h0 == nullptr;   // (the decoder phase of the fused kernel starts from the encoder's state)
@@ -842,7 +844,7 @@ __device__ __forceinline__ void cluster_body(const LstmParams& p, ClusterCarry& 
                 if (LAYER) input_proj_any<true, false>(acc, sX + ((t + 1) % 3) * BT * LDX + n * LDX + 4 * g4, sKw, nq, lane);
             }
             FOV_STAMP(5);
-            u32x2 v[NG > 0 ? NG : 1];
+            u32x4g v[NG > 0 ? NG : 1];
             // DECODE has no x . K block between the publish and the gather: one own-slice k-block goes first, so the sweep is
             // not requested right behind the partners' publish (decoder 0.191 -> 0.188 ms over three paired runs; the
             // eight-workgroup kernels, whose stores are sc1, gain far more from the same delay - lstm_wide.hip)
@@ -852,14 +854,14 @@ __device__ __forceinline__ void cluster_body(const LstmParams& p, ClusterCarry& 
                 recurrent<H, 0, GJ, true, false>(acc, hrow, wR);
                 if (do_xch) {
 #pragma unroll
-                    for (int j = 0; j < NG; ++j) v[j] = __builtin_amdgcn_raw_buffer_load_b64(xrs, goff[j], xsoff, 16);
+                    for (int j = 0; j < NG; ++j) v[j] = __builtin_amdgcn_raw_buffer_load_b128(xrs, goff[j], xsoff, 16);
                 }
                 // (a ZX layer has no x . K run in front: this run opens; with partner slices the next reader of the accumulators is
                 // the partner-slice MFMA run: no closing wait states)
                 recurrent<H, GJ, 4, LAYER, (G == 1)>(acc, hrow, wR);
             } else if (do_xch) {
 #pragma unroll
-                for (int j = 0; j < NG; ++j) v[j] = __builtin_amdgcn_raw_buffer_load_b64(xrs, goff[j], xsoff, 16);
+                for (int j = 0; j < NG; ++j) v[j] = __builtin_amdgcn_raw_buffer_load_b128(xrs, goff[j], xsoff, 16);
             }
             FOV_STAMP(11);
             if (do_xch) {
@@ -872,7 +874,7 @@ __device__ __forceinline__ void cluster_body(const LstmParams& p, ClusterCarry& 
 #endif
                     bool ok = true;
 #pragma unroll
-                    for (int j = 0; j < NG; ++j) ok = ok && (v[j].y == epoch);
+                    for (int j = 0; j < NG; ++j) ok = ok && (v[j].y == epoch) && (v[j].w == epoch);
                     if (__all(ok)) break;
                     ++spins;
                     if (spins > SPIN_LIMIT || ((spins & 63u) == 0 && xch_poisoned(p.status))) {
@@ -885,13 +887,16 @@ __device__ __forceinline__ void cluster_body(const LstmParams& p, ClusterCarry& 
                     __builtin_amdgcn_s_sleep(1);
                     asm volatile("" ::: "memory");   // the sweep below must really re-read memory
 #pragma unroll
-                    for (int j = 0; j < NG; ++j) v[j] = __builtin_amdgcn_raw_buffer_load_b64(xrs, goff[j], xsoff, 16);
+                    for (int j = 0; j < NG; ++j) v[j] = __builtin_amdgcn_raw_buffer_load_b128(xrs, goff[j], xsoff, 16);
                 }
 #ifdef FOV_STAMPS
                 if (stamp_on && t < STAMP_STEPS) g_stamps[MODE & 1][t][10] = spins;
 #endif
 #pragma unroll
-                for (int j = 0; j < NG; ++j) sH[loff[j]] = __uint_as_float(v[j].x);
+                for (int j = 0; j < NG; ++j) {
+                    sH[loff[j]] = __uint_as_float(v[j].x);
+                    sH[loff[j] + 1] = __uint_as_float(v[j].z);
+                }
             }
             FOV_STAMP(6);
             __syncthreads();  // barrier 2: the whole h_t tile is in LDS
