@@ -19,7 +19,7 @@ constexpr int QH = 256;     // hidden units
 constexpr int QG = 8;       // workgroups per tile
 constexpr int QBT = 16;     // sequences per tile
 constexpr int QLD = 272;    // bf16 elements per LDS row of an activation tile: 544 B, conflict-free ds_read_b128 of A fragments
-constexpr int QNG = 7;      // granules gathered per thread and exchange: 7 slices * 8 row pairs * 32 units / 256
+constexpr int QNG = 4;      // 16-byte loads (two adjacent units' tagged granules) per thread and exchange: 7 slices * 8 row pairs * 16 unit pairs / 256, rounded up
 constexpr unsigned Q_SPIN = 1u << 20;
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -137,33 +137,39 @@ __device__ __forceinline__ void gates_of_lane(const f32x4 (&acc)[2], int hi, flo
 constexpr unsigned Q_TILE_BYTES = 8u * QH * 8u;
 
 struct QGather {
-    qu32x2 v[QNG];
+    qu32x4 v[QNG];
 };
 
-// thread tid gathers granule (row pair tid >> 5, unit tid & 31) of each of the 7 other slices
+// Thread tid = (row pair tid / 32, half (tid / 16) % 2, unit pair tid % 16) gathers units (2p, 2p + 1) of the slices
+// slice + 1 + 4 half + j, j < 4, with one 16-byte load each (round 3: adjacent granules of the [row pair][unit] order, each with
+// its own tag).  The fourth load of half 1 would be the own slice: switched off (offset past the descriptor).
+__device__ __forceinline__ unsigned q_gather_voff(int tid) { return (unsigned)((tid >> 5) * QH + 2 * (tid & 15)) * 8u; }
+__device__ __forceinline__ int q_gather_slice(int slice, int tid, int j) { return (slice + 1 + ((tid >> 4) & 1) * QNG + j) & (QG - 1); }
+__device__ __forceinline__ bool q_gather_on(int tid, int j) { return !(((tid >> 4) & 1) == 1 && j == QNG - 1); }
+
 __device__ __forceinline__ void q_gather_issue(QGather& g, const __amdgpu_buffer_rsrc_t rs, unsigned base, int slice, int tid) {
-    const unsigned voff = (unsigned)((tid >> 5) * QH + (tid & 31)) * 8u;
+    const unsigned voff = q_gather_voff(tid);
 #pragma unroll
-    for (int j = 0; j < QNG; ++j) {
-        const unsigned uo = (unsigned)(((slice + 1 + j) & (QG - 1)) * 32) * 8u;
-        g.v[j] = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, base + uo, 16);
-    }
+    for (int j = 0; j < QNG; ++j)
+        g.v[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, q_gather_on(tid, j) ? voff + (unsigned)(q_gather_slice(slice, tid, j) * 32) * 8u : 0x80000000u, base, 16);
+}
+// two granules {rows 2k, 2k+1 of unit u} and {.. of unit u+1} -> two 32-bit LDS stores (units u, u+1 are adjacent bf16)
+__device__ __forceinline__ void q_tile_put(unsigned short* tile, int lo, int ld, unsigned x0, unsigned x1) {
+    *(unsigned*)(tile + lo) = (x0 & 0xffffu) | (x1 << 16);
+    *(unsigned*)(tile + lo + ld) = (x0 >> 16) | (x1 & 0xffff0000u);
 }
 // first pass: current granules go straight into the tile image, stale ones into a bit mask; retry sweeps (rare)
 // re-read into loop-local temporaries.  Returns false after a give-up (status word set, caller drains).
 __device__ __forceinline__ bool q_gather_finish(QGather& g, const __amdgpu_buffer_rsrc_t rs, unsigned base, int slice, int tid,
                                                 unsigned epoch, unsigned short* tile, unsigned* status) {
-    const int lbase = (tid >> 5) * 2 * QLD + (tid & 31);
+    const int lbase = (tid >> 5) * 2 * QLD + 2 * (tid & 15);
     unsigned bad = 0;
 #pragma unroll
     for (int j = 0; j < QNG; ++j) {
-        const int lo = lbase + ((slice + 1 + j) & (QG - 1)) * 32;
-        if (g.v[j].y == epoch) {
-            tile[lo] = (unsigned short)(g.v[j].x & 0xffffu);
-            tile[lo + QLD] = (unsigned short)(g.v[j].x >> 16);
-        } else {
-            bad |= (1u << j);
-        }
+        if (!q_gather_on(tid, j)) continue;
+        const int lo = lbase + q_gather_slice(slice, tid, j) * 32;
+        if (g.v[j].y == epoch && g.v[j].w == epoch) q_tile_put(tile, lo, QLD, g.v[j].x, g.v[j].z);
+        else bad |= (1u << j);
     }
     unsigned spins = 0;
     bool ok = true;
@@ -176,19 +182,16 @@ __device__ __forceinline__ bool q_gather_finish(QGather& g, const __amdgpu_buffe
         }
         __builtin_amdgcn_s_sleep(1);
         asm volatile("" ::: "memory");
-        const unsigned voff = (unsigned)((tid >> 5) * QH + (tid & 31)) * 8u;
-        qu32x2 tv[QNG];
+        const unsigned voff = q_gather_voff(tid);
+        qu32x4 tv[QNG];
+#pragma unroll
+        for (int j = 0; j < QNG; ++j)
+            tv[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, q_gather_on(tid, j) ? voff + (unsigned)(q_gather_slice(slice, tid, j) * 32) * 8u : 0x80000000u, base, 16);
 #pragma unroll
         for (int j = 0; j < QNG; ++j) {
-            const unsigned uo = (unsigned)(((slice + 1 + j) & (QG - 1)) * 32) * 8u;
-            tv[j] = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, base + uo, 16);
-        }
-#pragma unroll
-        for (int j = 0; j < QNG; ++j) {
-            const int lo = lbase + ((slice + 1 + j) & (QG - 1)) * 32;
-            if (((bad >> j) & 1u) && tv[j].y == epoch) {
-                tile[lo] = (unsigned short)(tv[j].x & 0xffffu);
-                tile[lo + QLD] = (unsigned short)(tv[j].x >> 16);
+            const int lo = lbase + q_gather_slice(slice, tid, j) * 32;
+            if (((bad >> j) & 1u) && tv[j].y == epoch && tv[j].w == epoch) {
+                q_tile_put(tile, lo, QLD, tv[j].x, tv[j].z);
                 bad &= ~(1u << j);
             }
         }
@@ -202,18 +205,26 @@ __device__ __forceinline__ bool q_gather_finish(QGather& g, const __amdgpu_buffe
 // granules per step (K-split with partial sums: 16 to 48) and every workgroup then forms ITS 32 output units of
 // dz . R^T from the whole tile (N-split) - no reduction across workgroups, the 8-byte write-through stores (the
 // expensive side of the exchange) shrink 4 to 12 times.
-// Granules of one tile and parity: [gate 4][row pair 8][unit 256].
+// Granules of one tile and parity: [row pair 8][unit 256][gate 4] (round 3): the four gate granules of a lane's cells are 32
+// adjacent bytes - two 16-byte stores to publish, two 16-byte loads per (row pair, unit, slice) to gather, each 8-byte
+// granule with its own tag.
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int QLDZ = 1024 + 16;                   // bf16 per LDS row of a dz tile: 520 dwords = 8 (mod 64): conflict-free b128 reads
 constexpr unsigned Q_DZ_BYTES = 4u * 8u * QH * 8u;   // 64 KB
-constexpr int QNDZ = 28;                          // granules gathered per thread: 7 slices * 4 gates
+constexpr int QNDZ = 14;                          // 16-byte loads per thread: 7 slices * 2 gate pairs
 
 // this lane's cells: rows row0, row0 + 1 of `unit`; dzp[g] = packed bf16 pair of gate g
 __device__ __forceinline__ void q_dz_publish(const __amdgpu_buffer_rsrc_t rs, unsigned base, int row0, int unit, const unsigned (&dzp)[4],
                                              unsigned epoch, unsigned short* tile, bool same_xcd) {
+    const unsigned off = (unsigned)(((row0 >> 1) * QH + unit) * 4) * 8u;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const qu32x4 gr = {dzp[2 * h], epoch, dzp[2 * h + 1], epoch};
+        if (same_xcd) __builtin_amdgcn_raw_buffer_store_b128(gr, rs, off + h * 16, base, 1);
+        else __builtin_amdgcn_raw_buffer_store_b128(gr, rs, off + h * 16, base, 16);
+    }
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-        XCH_STORE_B64(same_xcd, ((qu32x2){dzp[g], epoch}), rs, (unsigned)((g * 8 + (row0 >> 1)) * QH + unit) * 8u, base);
         tile[row0 * QLDZ + g * QH + unit] = (unsigned short)(dzp[g] & 0xffffu);
         tile[(row0 + 1) * QLDZ + g * QH + unit] = (unsigned short)(dzp[g] >> 16);
     }
@@ -221,27 +232,29 @@ __device__ __forceinline__ void q_dz_publish(const __amdgpu_buffer_rsrc_t rs, un
 __device__ __forceinline__ bool q_dz_gather(const __amdgpu_buffer_rsrc_t rs, unsigned base, int slice, int tid, unsigned epoch,
                                             unsigned short* tile, unsigned* status) {
     const int p = tid >> 5, u = tid & 31;
-    const unsigned voff = (unsigned)(p * QH + u) * 8u;
+    const unsigned voff = (unsigned)((p * QH + u) * 4) * 8u;
     const int lbase = 2 * p * QLDZ + u;
+    auto put = [&](int j, int h, const qu32x4& q) {   // gates 2h, 2h + 1 of (row pair p, unit u of slice slice + 1 + j)
+        const int lo = lbase + ((slice + 1 + j) & (QG - 1)) * 32 + 2 * h * QH;
+        tile[lo] = (unsigned short)(q.x & 0xffffu);
+        tile[lo + QLDZ] = (unsigned short)(q.x >> 16);
+        tile[lo + QH] = (unsigned short)(q.z & 0xffffu);
+        tile[lo + QH + QLDZ] = (unsigned short)(q.z >> 16);
+    };
     unsigned bad = 0;
     {
-        qu32x2 v[QNDZ];
+        qu32x4 v[QNDZ];
 #pragma unroll
         for (int j = 0; j < 7; ++j)
 #pragma unroll
-            for (int g = 0; g < 4; ++g)
-                v[j * 4 + g] = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, base + (unsigned)(g * 8 * QH + ((slice + 1 + j) & (QG - 1)) * 32) * 8u, 16);
+            for (int h = 0; h < 2; ++h)
+                v[j * 2 + h] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + h * 16, base + (unsigned)(((slice + 1 + j) & (QG - 1)) * 32 * 4) * 8u, 16);
 #pragma unroll
         for (int j = 0; j < 7; ++j)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int lo = lbase + g * QH + ((slice + 1 + j) & (QG - 1)) * 32;
-                if (v[j * 4 + g].y == epoch) {
-                    tile[lo] = (unsigned short)(v[j * 4 + g].x & 0xffffu);
-                    tile[lo + QLDZ] = (unsigned short)(v[j * 4 + g].x >> 16);
-                } else {
-                    bad |= (1u << (j * 4 + g));
-                }
+            for (int h = 0; h < 2; ++h) {
+                if (v[j * 2 + h].y == epoch && v[j * 2 + h].w == epoch) put(j, h, v[j * 2 + h]);
+                else bad |= (1u << (j * 2 + h));
             }
     }
     unsigned spins = 0;
@@ -255,23 +268,21 @@ __device__ __forceinline__ bool q_dz_gather(const __amdgpu_buffer_rsrc_t rs, uns
         }
         __builtin_amdgcn_s_sleep(1);
         asm volatile("" ::: "memory");
-        // a whole new sweep, all 28 loads in flight together (re-reading slot by slot serialises 28 round trips: measured
+        // a whole new sweep, all loads in flight together (re-reading slot by slot serialises the round trips: measured
         // 10 000 cycles per stale step against 3 000 for the first sweep, tools/stamp_bf16_layer.py --bwd)
-        qu32x2 tv[QNDZ];
+        qu32x4 tv[QNDZ];
 #pragma unroll
         for (int j = 0; j < 7; ++j)
 #pragma unroll
-            for (int g = 0; g < 4; ++g)
-                tv[j * 4 + g] = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, base + (unsigned)(g * 8 * QH + ((slice + 1 + j) & (QG - 1)) * 32) * 8u, 16);
+            for (int h = 0; h < 2; ++h)
+                tv[j * 2 + h] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + h * 16, base + (unsigned)(((slice + 1 + j) & (QG - 1)) * 32 * 4) * 8u, 16);
 #pragma unroll
         for (int j = 0; j < 7; ++j)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const unsigned bit = 1u << (j * 4 + g);
-                if ((bad & bit) && tv[j * 4 + g].y == epoch) {
-                    const int lo = lbase + g * QH + ((slice + 1 + j) & (QG - 1)) * 32;
-                    tile[lo] = (unsigned short)(tv[j * 4 + g].x & 0xffffu);
-                    tile[lo + QLDZ] = (unsigned short)(tv[j * 4 + g].x >> 16);
+            for (int h = 0; h < 2; ++h) {
+                const unsigned bit = 1u << (j * 2 + h);
+                if ((bad & bit) && tv[j * 2 + h].y == epoch && tv[j * 2 + h].w == epoch) {
+                    put(j, h, tv[j * 2 + h]);
                     bad &= ~bit;
                 }
             }

@@ -145,30 +145,30 @@ __device__ __forceinline__ void stack2_body(const Stack2Params& p, unsigned shor
     float xs[NXE];
     // all eight slices of the producer's tile `slot` into the x image (consumer); returns false after a give-up
     // (the first sweep is REQUESTED by gather_x_issue together with the own exchange's gather, so the two round trips overlap)
-    qu32x2 xg[8];
+    // thread (row pair tid / 32, half (tid / 16) % 2, unit pair tid % 16): units (2p, 2p + 1) of slices 4 half + j, one 16-byte load each
+    qu32x4 xg[4];
+    const unsigned xvoff = (unsigned)((tid >> 5) * QH + 2 * (tid & 15)) * 8u;
+    const int xsl0 = ((tid >> 4) & 1) * 4;
     auto gather_x_issue = [&](int slot) {
         const unsigned sbase = (unsigned)slot * Q_TILE_BYTES;
-        const unsigned voff = (unsigned)((tid >> 5) * QH + (tid & 31)) * 8u;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) xg[j] = __builtin_amdgcn_raw_buffer_load_b64(ring, voff, sbase + (unsigned)(j * 32) * 8u, 16);
+        for (int j = 0; j < 4; ++j) xg[j] = __builtin_amdgcn_raw_buffer_load_b128(ring, xvoff + (unsigned)((xsl0 + j) * 32) * 8u, sbase, 16);
     };
     auto gather_x = [&](int slot, bool issued) {
         const unsigned tag = base + 1u + (unsigned)slot;
         const unsigned sbase = (unsigned)slot * Q_TILE_BYTES;
-        const unsigned voff = (unsigned)((tid >> 5) * QH + (tid & 31)) * 8u;
-        const int lbase = (tid >> 5) * 2 * QLD + (tid & 31);
-        unsigned bad = 0xffu, spins = 0;
+        const int lbase = (tid >> 5) * 2 * QLD + 2 * (tid & 15);
+        unsigned bad = 0xfu, spins = 0;
         bool first = issued;
         while (true) {
-            qu32x2 tv[8];
+            qu32x4 tv[4];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) tv[j] = first ? xg[j] : __builtin_amdgcn_raw_buffer_load_b64(ring, voff, sbase + (unsigned)(j * 32) * 8u, 16);
+            for (int j = 0; j < 4; ++j) tv[j] = first ? xg[j] : __builtin_amdgcn_raw_buffer_load_b128(ring, xvoff + (unsigned)((xsl0 + j) * 32) * 8u, sbase, 16);
             first = false;
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
-                if (((bad >> j) & 1u) && tv[j].y == tag) {
-                    sX[lbase + j * 32] = (unsigned short)(tv[j].x & 0xffffu);
-                    sX[lbase + j * 32 + QLD] = (unsigned short)(tv[j].x >> 16);
+            for (int j = 0; j < 4; ++j)
+                if (((bad >> j) & 1u) && tv[j].y == tag && tv[j].w == tag) {
+                    q_tile_put(sX, lbase + (xsl0 + j) * 32, QLD, tv[j].x, tv[j].z);
                     bad &= ~(1u << j);
                 }
             if (!__any(bad != 0)) return true;
