@@ -33,6 +33,7 @@ constexpr unsigned BSPIN_LIMIT = 1u << 20;
 constexpr int GATHER_AFTER_Q = FOV_GATHER_AFTER_Q;   // k-blocks of the local destination's product issued before the gather is requested
                                     // (0 = right behind the last publish: 225 us; 8: 206 us; 15: 212 us at B = 1024, T = 30)
 typedef unsigned bu32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned bu32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ void bmfma_va(f32x4& acc, float a, float w_agpr) {
     asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "a"(w_agpr));
@@ -107,7 +108,9 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_cluster_kernel(BwdParams p) {
     constexpr int CHUNK = 4 * 4 * 64;   // granules one workgroup sends to one destination per step
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
         p.xch + (size_t)group * 2 * G * G * CHUNK, 0, 2 * G * G * CHUNK * (int)sizeof(unsigned long long), 0x00020000);
-    const unsigned lane_off = (unsigned)((wave * 4) * 64 + lane) * 8u;   // + r*64*8 per register
+    // chunk order [wave][register pair][lane][register of the pair]: a lane's registers 2k, 2k + 1 are adjacent tagged granules,
+    // moved by ONE 16-byte store / load (round 3: half the exchange instructions, the 8-byte unit of atomicity unchanged)
+    const unsigned lane_off = (unsigned)((wave * 2) * 64 + lane) * 16u;   // + k*64*16 per register pair
 
     if (G > 1) xch_hello_poll(p.status, sXch, group, G, &sFlag[0]);   // same-XCD handshake (xch_common.h): partners' words, published at entry
     __syncthreads();
@@ -196,7 +199,7 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_cluster_kernel(BwdParams p) {
             ++epoch;
             const unsigned xsoff = (epoch & 1u) * (unsigned)(G * G * CHUNK * sizeof(unsigned long long));
             f32x4 part = (f32x4){0.f, 0.f, 0.f, 0.f};   // the local destination's partial
-            bu32x2 v[G > 1 ? (G - 1) * 4 : 1];
+            bu32x4 v[G > 1 ? (G - 1) * 2 : 1];
 #pragma unroll
             for (int dd = 0; dd < G; ++dd) {
                 f32x4 a4[4];
@@ -213,9 +216,9 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_cluster_kernel(BwdParams p) {
                         for (int k = 0; k < G - 1; ++k) {
                             const int s_src = (slice + 1 + k) & (G - 1);
 #pragma unroll
-                            for (int r = 0; r < 4; ++r)
-                                v[k * 4 + r] = __builtin_amdgcn_raw_buffer_load_b64(
-                                    xrs, (unsigned)((slice * G + s_src) * CHUNK) * 8u + lane_off + r * 512u, xsoff, 16);
+                            for (int r = 0; r < 2; ++r)
+                                v[k * 2 + r] = __builtin_amdgcn_raw_buffer_load_b128(
+                                    xrs, (unsigned)((slice * G + s_src) * CHUNK) * 8u + lane_off + r * 1024u, xsoff, 16);
                         }
                     }
 #pragma unroll
@@ -230,9 +233,11 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_cluster_kernel(BwdParams p) {
                 } else {
                     const int d = (slice + 1 + dd) & (G - 1);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        XCH_STORE_B64(ticket.same_xcd, ((bu32x2){__float_as_uint(sum[r]), epoch}), xrs,
-                                      (unsigned)((d * G + slice) * CHUNK) * 8u + lane_off + r * 512u, xsoff);
+                    for (int r = 0; r < 2; ++r) {
+                        const bu32x4 gr = {__float_as_uint(sum[2 * r]), epoch, __float_as_uint(sum[2 * r + 1]), epoch};
+                        if (ticket.same_xcd) __builtin_amdgcn_raw_buffer_store_b128(gr, xrs, (unsigned)((d * G + slice) * CHUNK) * 8u + lane_off + r * 1024u, xsoff, 1);
+                        else __builtin_amdgcn_raw_buffer_store_b128(gr, xrs, (unsigned)((d * G + slice) * CHUNK) * 8u + lane_off + r * 1024u, xsoff, 16);
+                    }
                 }
             }
             __syncthreads();   // barrier B: every wave is done with the dz tile
@@ -241,7 +246,7 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_cluster_kernel(BwdParams p) {
                 while (true) {
                     bool ok = true;
 #pragma unroll
-                    for (int j = 0; j < (G - 1) * 4; ++j) ok = ok && (v[j].y == epoch);
+                    for (int j = 0; j < (G - 1) * 2; ++j) ok = ok && (v[j].y == epoch) && (v[j].w == epoch);
                     if (__all(ok)) break;
                     ++spins;
                     if (spins > BSPIN_LIMIT || ((spins & 63u) == 0 && xch_poisoned(p.status))) {
@@ -257,9 +262,9 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_cluster_kernel(BwdParams p) {
                     for (int k = 0; k < G - 1; ++k) {
                         const int s_src = (slice + 1 + k) & (G - 1);
 #pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            v[k * 4 + r] = __builtin_amdgcn_raw_buffer_load_b64(
-                                xrs, (unsigned)((slice * G + s_src) * CHUNK) * 8u + lane_off + r * 512u, xsoff, 16);
+                        for (int r = 0; r < 2; ++r)
+                            v[k * 2 + r] = __builtin_amdgcn_raw_buffer_load_b128(
+                                xrs, (unsigned)((slice * G + s_src) * CHUNK) * 8u + lane_off + r * 1024u, xsoff, 16);
                     }
                 }
             }
@@ -274,7 +279,7 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_cluster_kernel(BwdParams p) {
                     if (G > 1) {
 #pragma unroll
                         for (int k = 0; k < G - 1; ++k)
-                            if (((slice + 1 + k) & (G - 1)) == s_abs) term = __uint_as_float(v[k * 4 + r].x);
+                            if (((slice + 1 + k) & (G - 1)) == s_abs) term = __uint_as_float((r & 1) ? v[k * 2 + (r >> 1)].z : v[k * 2 + (r >> 1)].x);
                     }
                     acc += term;
                 }
