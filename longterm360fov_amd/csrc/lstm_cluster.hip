@@ -568,17 +568,19 @@ __device__ __forceinline__ void cluster_body(const LstmParams& p, ClusterCarry& 
     // inside the step would come straight out of the MFMA rate.
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
         p.xch + (size_t)group * 2 * BT * H, 0, 2 * BT * H * (int)sizeof(unsigned long long), 0x00020000);
-    const unsigned pub_off = (unsigned)((4 * g4) * H + col0 + n) * 8u;
+    // granule order [row pair][unit][row of the pair] (round 3): a lane publishes its four rows as TWO 16-byte stores, a gather
+    // load brings both rows of one unit; every 8-byte granule keeps its own tag
+    const unsigned pub_off = (unsigned)((2 * g4) * H + col0 + n) * 16u;
     unsigned goff[NG > 0 ? NG : 1];
     int loff[NG > 0 ? NG : 1];
 #pragma unroll
     for (int j = 0; j < NG; ++j) {
-        // pair `within` of partner slice `osl`: row within / 32, units 2 (within % 32) and + 1 - adjacent granules, one load
+        // load `within` of partner slice `osl`: row pair within / 64, unit within % 64 - both rows of the unit in one load
         const int idx = j * 256 + tid;
         const int rot = (idx >> 9) + 1, within = idx & 511;
         const int osl = (slice + rot) & (G - 1);
-        goff[j] = (unsigned)((within >> 5) * H + osl * 64 + 2 * (within & 31)) * 8u;
-        loff[j] = (within >> 5) * LDH + rot * 64 + 2 * (within & 31);
+        goff[j] = (unsigned)((within >> 6) * H + osl * 64 + (within & 63)) * 16u;
+        loff[j] = 2 * (within >> 6) * LDH + rot * 64 + (within & 63);
     }
 
     const bool h_zero = !F2 && p.h0 == nullptr;   // (the decoder phase of the fused kernel starts from the encoder's state)
@@ -806,14 +808,14 @@ __device__ __forceinline__ void cluster_body(const LstmParams& p, ClusterCarry& 
                 xsoff = (epoch & 1u) * (unsigned)(BT * H * sizeof(unsigned long long));
                 if (same_xcd) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        __builtin_amdgcn_raw_buffer_store_b64((u32x2){__float_as_uint(hcur[r]), epoch}, xrs,
-                                                              pub_off + r * H * 8, xsoff, 1 /* sc0: stays in L2 */);
+                    for (int r = 0; r < 2; ++r)
+                        __builtin_amdgcn_raw_buffer_store_b128((u32x4g){__float_as_uint(hcur[2 * r]), epoch, __float_as_uint(hcur[2 * r + 1]), epoch},
+                                                               xrs, pub_off + r * H * 16, xsoff, 1 /* sc0: stays in L2 */);
                 } else {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        __builtin_amdgcn_raw_buffer_store_b64((u32x2){__float_as_uint(hcur[r]), epoch}, xrs,
-                                                              pub_off + r * H * 8, xsoff, 16 /* sc1: write-through */);
+                    for (int r = 0; r < 2; ++r)
+                        __builtin_amdgcn_raw_buffer_store_b128((u32x4g){__float_as_uint(hcur[2 * r]), epoch, __float_as_uint(hcur[2 * r + 1]), epoch},
+                                                               xrs, pub_off + r * H * 16, xsoff, 16 /* sc1: write-through */);
                 }
             }
             if (LAYER && p.hs) {
@@ -895,7 +897,7 @@ __device__ __forceinline__ void cluster_body(const LstmParams& p, ClusterCarry& 
 #pragma unroll
                 for (int j = 0; j < NG; ++j) {
                     sH[loff[j]] = __uint_as_float(v[j].x);
-                    sH[loff[j] + 1] = __uint_as_float(v[j].z);
+                    sH[loff[j] + LDH] = __uint_as_float(v[j].z);
                 }
             }
             FOV_STAMP(6);
