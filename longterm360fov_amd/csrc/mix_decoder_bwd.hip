@@ -176,23 +176,18 @@ __global__ __launch_bounds__(256, 1) void mix_decoder_bwd_kernel(MixDecBwdParams
             sFlag[0] = 1;
         }
     };
-    // gather NQ x 8 granules {src 0..7} for each of this lane's NQ quantities and add them in slice order.
-    // voff[q]: byte offset of the src-0 granule, src stride sstride bytes.
-    auto gather_sum = [&](const __amdgpu_buffer_rsrc_t rs, const unsigned (&voff)[2], unsigned sstride, unsigned base, float (&out)[2]) {
-        // first sweep: current granules into part[], stale ones into a bit mask (v[] is dead afterwards); retry sweeps
-        // (rare) re-read into loop-local temporaries - a loop-carried v[] costs several VGPRs per granule
-        float part[16];
+    // one quantity from the 8 sources (the feedback gradient dx), added in slice order
+    auto gather_one = [&](const __amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned sstride, unsigned base) -> float {
+        float part[8];
         unsigned bad = 0;
         {
-            bwu32x2 v[16];
+            bwu32x2 v[8];
 #pragma unroll
-            for (int q = 0; q < 2; ++q)
+            for (int s = 0; s < 8; ++s) v[s] = __builtin_amdgcn_raw_buffer_load_b64(rs, voff + s * sstride, base, 16);
 #pragma unroll
-                for (int s = 0; s < 8; ++s) v[q * 8 + s] = __builtin_amdgcn_raw_buffer_load_b64(rs, voff[q] + s * sstride, base, 16);
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                part[j] = __uint_as_float(v[j].x);
-                if (v[j].y != epoch) bad |= (1u << j);
+            for (int s = 0; s < 8; ++s) {
+                part[s] = __uint_as_float(v[s].x);
+                if (v[s].y != epoch) bad |= (1u << s);
             }
         }
         unsigned spins = 0;
@@ -204,25 +199,20 @@ __global__ __launch_bounds__(256, 1) void mix_decoder_bwd_kernel(MixDecBwdParams
             }
             __builtin_amdgcn_s_sleep(1);
             asm volatile("" ::: "memory");
-            bwu32x2 tv[16];
+            bwu32x2 tv[8];
 #pragma unroll
-            for (int q = 0; q < 2; ++q)
+            for (int s = 0; s < 8; ++s) tv[s] = __builtin_amdgcn_raw_buffer_load_b64(rs, voff + s * sstride, base, 16);
 #pragma unroll
-                for (int s = 0; s < 8; ++s) tv[q * 8 + s] = __builtin_amdgcn_raw_buffer_load_b64(rs, voff[q] + s * sstride, base, 16);
-#pragma unroll
-            for (int j = 0; j < 16; ++j)
-                if (((bad >> j) & 1u) && tv[j].y == epoch) {
-                    part[j] = __uint_as_float(tv[j].x);
-                    bad &= ~(1u << j);
+            for (int s = 0; s < 8; ++s)
+                if (((bad >> s) & 1u) && tv[s].y == epoch) {
+                    part[s] = __uint_as_float(tv[s].x);
+                    bad &= ~(1u << s);
                 }
         }
+        float acc = 0.f;
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            float acc = 0.f;
-#pragma unroll
-            for (int s = 0; s < 8; ++s) acc += part[q * 8 + s];
-            out[q] = acc;
-        }
+        for (int s = 0; s < 8; ++s) acc += part[s];
+        return acc;
     };
     // The partial sums of a lane's TWO cells (rows 2k, 2k + 1 of one unit) are adjacent tagged granules (round 3): one 16-byte
     // load per source brings both - eight loads instead of sixteen per gather, half the stores on the publishing side; every
@@ -498,14 +488,11 @@ __global__ __launch_bounds__(256, 1) void mix_decoder_bwd_kernel(MixDecBwdParams
             MIXB_STAMP(7);
             // ================= gather: dh1_{t-1} of this lane's cells, and dx_t (every workgroup needs all of it) =================
             {
-                unsigned voff[2];
                 float sum[2];
                 gather_pair(rs1, (unsigned)(((slice * BG) * (BBT / 2) + (my_row0 >> 1)) * 32 + ul) * 16u, BBT * 32 * 8, par1, sum);
                 dh1r[0] = sum[0]; dh1r[1] = sum[1];
-                // dx: thread (hrow, ho < 8) sums the 8 sources; the second quantity of gather_sum re-reads the same
-                voff[0] = (unsigned)(hrow * 8 + (ho & 7)) * 8u;
-                voff[1] = voff[0];
-                gather_sum(rsx, voff, BBT * 8 * 8, parx, sum);
+                // dx: thread (hrow, ho < 8) sums the 8 sources
+                sum[0] = gather_one(rsx, (unsigned)(hrow * 8 + (ho & 7)) * 8u, BBT * 8 * 8, parx);
                 __syncthreads();   // every wave is done with the dz1 tile and with sDX of this step
                 if (ho < 8) sDX[hrow * 8 + ho] = sum[0];
             }
