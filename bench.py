@@ -34,11 +34,11 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 matrix peak (s
 def peak_for(dtype):
     return PEAK_BF16_MFMA_TFLOPS if dtype == "bf16" else PEAK_FP32_MFMA_TFLOPS
 # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/pmc_run.sh) of `bench.py --steps 20 --warmup 3`, mean per
-# dispatch of lstm_cluster_fused_kernel (encoder + decoder in one launch): 17550 + 5516 KiB (raw counter values; the
+# dispatch of lstm_cluster_fused_kernel (encoder + decoder in one launch): 17550 + 5564 KiB (raw counter values; the
 # kernel's global traffic is 4- and 8-byte accesses, for which MI355X_MICROARCH.md gives no correction factor).  The
 # two-launch form moved 13170 + 6160 and 7465 + 4832 KiB.
 PMC_TRAFFIC_CONFIG = (1024, 30, 30, 256, "sigmoid", "auto")
-PMC_TRAFFIC_BYTES = (17550 + 5516) * 1024
+PMC_TRAFFIC_BYTES = (17550 + 5564) * 1024
 PMC_TRAFFIC_SOURCE = "profiles/r03_pmc_bench.txt"
 
 
@@ -46,19 +46,19 @@ PMC_TRAFFIC_SOURCE = "profiles/r03_pmc_bench.txt"
 # tools/pmc_step_total.py: FETCH_SIZE and WRITE_SIZE in separate passes, raw KiB summed over the dispatches of one step -
 # the dispatches between two launches of an anchor kernel); quoted only for the default shape of the mode.  key = (mode, dtype)
 MODE_TRAFFIC = {
-    ("train_mixing", "f32"): ((505488 + 875591) * 1024, "profiles/r03_pmcstep_train_mixing_f32.txt"),
-    ("train_mixing", "bf16"): ((291902 + 446858) * 1024, "profiles/r03_pmcstep_train_mixing_bf16.txt"),
-    ("infer_mixing", "f32"): (int((37967.8 + 17696.4) * 1024), "profiles/r03_pmcstep_infer_mixing_f32.txt"),
-    ("infer_mixing", "bf16"): (int((34669.1 + 10528.3) * 1024), "profiles/r03_pmcstep_infer_mixing_bf16.txt"),
-    ("train", "f32"): ((633464 + 1226760) * 1024, "profiles/r03_pmcstep_train_f32.txt"),
+    ("train_mixing", "f32"): ((494350 + 869887) * 1024, "profiles/r03_pmcstep_train_mixing_f32.txt"),
+    ("train_mixing", "bf16"): ((293108 + 451721) * 1024, "profiles/r03_pmcstep_train_mixing_bf16.txt"),
+    ("infer_mixing", "f32"): (int((37962.6 + 17184.4) * 1024), "profiles/r03_pmcstep_infer_mixing_f32.txt"),
+    ("infer_mixing", "bf16"): (int((34659.6 + 10528.2) * 1024), "profiles/r03_pmcstep_infer_mixing_bf16.txt"),
+    ("train", "f32"): ((631999 + 1216710) * 1024, "profiles/r03_pmcstep_train_f32.txt"),
     # tools/pmc_simple.sh (run total / identical steps: tools/pmc_simple_steps.py, tools/pmc_run_total.py)
-    ("config1", "f32"): (int((864.6 + 3351.7) * 1024), "profiles/r03_pmcstep_config1.txt"),
-    ("a10", "f32"): (int((25504.4 + 7520.2) * 1024), "profiles/r03_pmcstep_a10.txt"),
+    ("config1", "f32"): (int((865.4 + 3351.7) * 1024), "profiles/r03_pmcstep_config1.txt"),
+    ("a10", "f32"): (int((24732.5 + 7520.2) * 1024), "profiles/r03_pmcstep_a10.txt"),
     # whole-model predict at B = 256: 396 GB fetched below the L2s per call (not all from HBM: the counter sits in front of the
     # 256 MB MALL), 97 % of it by the two deep head convolutions re-reading 25 shifted taps of (pixels x 512 / 1024 channels) and
     # every workgroup its 6.5 MB of weights - 0.8 TB/s, a tenth of the HBM rate; re-ordering k as (channel slab, tap) did
     # not change the time
-    ("convlstm", "f32"): (int((3.96045e8 + 1.4751e7) * 1024), "profiles/r03_pmcstep_convlstm.txt"),
+    ("convlstm", "f32"): (int((3.96265e8 + 1.4759e7) * 1024), "profiles/r03_pmcstep_convlstm.txt"),
 }
 
 
