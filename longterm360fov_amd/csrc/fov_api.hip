@@ -436,7 +436,7 @@ void env_reload() {
     g_env.no_xcd_pad = getenv("FOV_NO_XCD_PAD") ? 1 : 0;
     { const char* pm = getenv("FOV_XCD_PAD_MAX"); g_env.xcd_pad_max = pm ? atoi(pm) : 16; }
     g_env.no_bwd16_narrow = getenv("FOV_NO_BWD16_NARROW") ? 1 : 0;
-    { const char* bg = getenv("FOV_BWD16_GROUPS"); g_env.bwd16_groups16 = (bg && atoi(bg) == 16) ? 1 : 0; }
+    { const char* bg = getenv("FOV_BWD16_GROUPS"); g_env.bwd16_groups32 = (bg && atoi(bg) == 32) ? 1 : 0; }
     g_env.no_stack2 = env_flag("FOV_NO_STACK2");
     g_env.bwd_stepped = getenv("FOV_BWD_STEPPED") ? 1 : 0;
     g_env.no_wgrad_fusion = getenv("FOV_NO_WGRAD_FUSION") ? 1 : 0;

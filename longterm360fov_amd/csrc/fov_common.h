@@ -81,7 +81,7 @@ struct EnvKnobs {
     int no_xcd_pad;      // FOV_NO_XCD_PAD=1: no padded grids for same-XCD placement (lstm_wide16 / lstm_bwd16 / fused H = 128 kernel)
     int xcd_pad_max;     // FOV_XCD_PAD_MAX: members per group up to which a grid is padded (default 16; 32 measured slower)
     int no_bwd16_narrow; // FOV_NO_BWD16_NARROW=1: widths 128 / 256 keep the 2- / 4- / 8-workgroup BPTT kernels at small batches
-    int bwd16_groups16;  // FOV_BWD16_GROUPS=16: width-512 BPTT stays on sixteen workgroups per tile
+    int bwd16_groups32;  // FOV_BWD16_GROUPS=32: width-512 BPTT on thirty-two workgroups per tile up to eight tiles (default: sixteen)
     int no_stack2;       // FOV_NO_STACK2=1: two stacked width-512 layers as two launches (fov_lstm_stack2_supported -> 0)
 };
 const EnvKnobs& env_knobs();

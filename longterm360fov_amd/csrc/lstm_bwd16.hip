@@ -13,9 +13,9 @@
 //   the 16 x 32 piece of every destination workgroup travels as fp32 {value, epoch} granules; each lane gathers the
 //   sixteen pieces of its own two cells and adds them in slice order (deterministic).
 // Bias gradient: one (tiles, 4H) partial, summed over the tile's rows and all steps, as in the other BPTT kernels.
-// Two group sizes of one kernel: XG = 16 as described (any batch), and XG = 32 - sixteen units per workgroup, one cell per lane,
-// half the matrix work per step and workgroup (128 MFMAs per wave, 128 accumulation registers of R^T) - while a launch has at
-// most eight tiles (128 sequences: lstm.py trains at 32), the regime where a step's latency is all that matters.
+// Two group sizes of one kernel: XG = 16 as described (the default), and XG = 32 - sixteen units per workgroup, one cell per
+// lane, half the matrix work per step and workgroup (128 MFMAs per wave, 128 accumulation registers of R^T) - for launches of
+// at most eight tiles (FOV_BWD16_GROUPS=32; it was the faster form at lstm.py's batch until XG = 16 got paired granules).
 #include <stdlib.h>
 
 #include "bf16_common.h"
@@ -412,9 +412,10 @@ int launch_bwd16(const float* R, const float* reserve, const float* c0, const fl
     p.xch = (unsigned long long*)((char*)xch_ws + kStatusBytes);
     if (H == 128) return launch_bwd16_t<128, 8>(p, act, stream);
     if (H == 256) return launch_bwd16_t<256, 16>(p, act, stream);
-    // width 512: at most eight tiles and one tile per group -> thirty-two workgroups per tile (FOV_BWD16_GROUPS=16 keeps sixteen)
-    const bool force16 = env_knobs().bwd16_groups16 != 0;
-    if (!force16 && p.num_tiles <= 8 && p.num_tiles <= device_cu_count() / 32) return launch_bwd16_t<512, 32>(p, act, stream);
+    // width 512: sixteen workgroups per tile.  The thirty-two-workgroup form (one cell per lane, half the MFMAs per step) was the
+    // faster one at <= 8 tiles until the sixteen-workgroup form got paired granules and the same-XCD grid (lstm.py's training
+    // step 0.4206 ms with 32, 0.414 ms with 16); FOV_BWD16_GROUPS=32 still selects it.
+    if (env_knobs().bwd16_groups32 && p.num_tiles <= 8 && p.num_tiles <= device_cu_count() / 32) return launch_bwd16_t<512, 32>(p, act, stream);
     return launch_bwd16_t<512, 16>(p, act, stream);
 }
 

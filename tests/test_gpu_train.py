@@ -365,15 +365,23 @@ def test_persistent_bptt_matches_stepped_and_oracle():
         hs, hT, cT, res = ops.lstm_seq_train(dev(x), dev(K), dev(R), dev(b), dev(h0), dev(c0))
         outs = {}
         try:
-            for mode in ("persistent", "stepped"):
+            for mode in ("persistent", "stepped") + (("groups32",) if (H == 512 and B <= 128) else ()):
                 if mode == "stepped":
                     os.environ["FOV_BWD_STEPPED"] = "1"
+                if mode == "groups32":      # the thirty-two-workgroup form of the width-512 kernel (one cell per lane)
+                    os.environ.pop("FOV_BWD_STEPPED", None)
+                    os.environ["FOV_BWD16_GROUPS"] = "32"
                 sc = ops.Scratch()
                 outs[mode] = ops.lstm_seq_bwd(dev(x), dev(K), dev(R), hs, res, h0=dev(h0), c0=dev(c0), dhs=dev(dhs),
                                               dhT=dev(dhT), dcT=dev(dcT), need_dx=True, need_state_grads=True, scratch=sc)
                 sc.check()
         finally:
             os.environ.pop("FOV_BWD_STEPPED", None)
+            os.environ.pop("FOV_BWD16_GROUPS", None)
+        if "groups32" in outs:
+            for k in ("dz", "dx", "dK", "dR", "db", "dh0", "dc0"):
+                g32, ref_k = outs["groups32"][k].cpu().numpy().astype(np.float64), ref[k]
+                assert np.abs(g32 - ref_k).max() <= 1e-4 * np.abs(ref_k).max() + 1e-9, (H, k, "groups32")
         for k in ("dz", "dx", "dK", "dR", "db", "dh0", "dc0"):
             a = outs["persistent"][k].cpu().numpy().astype(np.float64)
             s_ = outs["stepped"][k].cpu().numpy().astype(np.float64)
