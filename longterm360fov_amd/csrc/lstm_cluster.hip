@@ -16,8 +16,10 @@
 //   * the running h tile (16 x H) sits in LDS and is the MFMA A operand; x_{t+1} is prefetched
 //     global -> registers -> LDS behind the MFMAs of step t;
 //   * per step each workgroup publishes its 16x64 slice of h_t as 8-byte {epoch,value}
-//     granules (one sc1 store each; the data is the flag) and sweeps the other G-1 slices with
+//     granules (the data is the flag) and sweeps the other G-1 slices with
 //     sc1 loads until every tag equals the epoch (cdna_hip_programming.md Guideline 16, R2).
+//     Since the end of round 3 granules travel in PAIRS: order [row pair][unit][row of the pair], one 16-byte
+//     store / load moves two tagged granules (each half is still checked on its own tag).
 //     Two parity buffers per group make the reuse race-free (a workgroup can only publish
 //     epoch e+2 after every partner has consumed epoch e).
 //   * every spin is bounded; a give-up sets status[0] and all workgroups drain.

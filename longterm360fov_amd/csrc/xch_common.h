@@ -4,7 +4,8 @@
 // Workspace layout (caller-owned, ZERO-FILLED ONCE after allocation - fov_workspace_init - never per call):
 //     [0, 256)                 header words below
 //     [256, 256 + kXchBytes)   granule / hello words; ONLY exchange kernels write here, always 8-byte words whose
-//                              upper half is an epoch tag
+//                              upper half is an epoch tag (since the end of round 3 usually two of them per 16-byte
+//                              store / load: neighbours in the kernel's granule order, each checked on its own tag)
 //     [256 + kXchBytes, ...)   whatever else the entry point keeps in its workspace (packed weights, carried state)
 //
 // Epoch tags are MONOTONE ACROSS LAUNCHES: a launch reads the base from the header, every tag it writes lies in
