@@ -124,11 +124,12 @@ __global__ __launch_bounds__(256, 1) void lstm_wide_kernel(LstmParams p) {
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
         p.xch + (size_t)group * 2 * WBT * WH, 0, 2 * WBT * WH * (int)sizeof(unsigned long long), 0x00020000);
     const int my_row0 = 4 * g4 + 2 * hi;
-    const unsigned pub_off = (unsigned)(my_row0 * WH + unit) * 8u;
-    // gather: thread (row tid / 16, unit pair tid % 16) brings units (2p, 2p + 1) of every partner slice with one 16-byte load
-    // (round 3; adjacent in the [row][unit] order, each granule with its own tag)
-    const unsigned gvoff = (unsigned)((tid >> 4) * WH + 2 * (tid & 15)) * 8u;
-    const int lbase = (tid >> 4) * WLD + 2 * (tid & 15);
+    // granule order [row pair][unit][row of the pair]: the lane's two rows leave as ONE 16-byte store, a gather load brings
+    // both rows of a unit (two tagged granules)
+    const unsigned pub_off = (unsigned)((my_row0 >> 1) * WH + unit) * 16u;
+    // gather: thread (row pair tid / 32, unit tid % 32) brings both rows of its unit of every partner slice with one 16-byte load
+    const unsigned gvoff = (unsigned)((tid >> 5) * WH + (tid & 31)) * 16u;
+    const int lbase = 2 * (tid >> 5) * WLD + (tid & 31);
     constexpr unsigned PARITY = WBT * WH * 8u;
     if (xch_used) xch_hello_poll(p.status, sXch, group, WG, &sFlag[0]);   // same-XCD handshake (xch_common.h): partners' words, published at entry
     __syncthreads();
@@ -142,7 +143,7 @@ __global__ __launch_bounds__(256, 1) void lstm_wide_kernel(LstmParams p) {
     auto gather_issue = [&](unsigned base) {
 #pragma unroll
         for (int j = 0; j < WNG; ++j) {
-            const unsigned uo = (unsigned)(((slice + 1 + j) & (WG - 1)) * 32) * 8u;
+            const unsigned uo = (unsigned)(((slice + 1 + j) & (WG - 1)) * 32) * 16u;
             v[j] = __builtin_amdgcn_raw_buffer_load_b128(xrs, gvoff, base + uo, 16);
         }
     };
@@ -155,7 +156,7 @@ __global__ __launch_bounds__(256, 1) void lstm_wide_kernel(LstmParams p) {
             const int lo = lbase + ((slice + 1 + j) & (WG - 1)) * 32;
             if (v[j].y == epoch && v[j].w == epoch) {
                 sH[lo] = __uint_as_float(v[j].x);
-                sH[lo + 1] = __uint_as_float(v[j].z);
+                sH[lo + WLD] = __uint_as_float(v[j].z);
             } else {
                 bad |= (1u << j);
             }
@@ -178,7 +179,7 @@ __global__ __launch_bounds__(256, 1) void lstm_wide_kernel(LstmParams p) {
                 wu32x4 tv[RCH];
 #pragma unroll
                 for (int j = j0; j < j0 + RCH && j < WNG; ++j) {
-                    const unsigned uo = (unsigned)(((slice + 1 + j) & (WG - 1)) * 32) * 8u;
+                    const unsigned uo = (unsigned)(((slice + 1 + j) & (WG - 1)) * 32) * 16u;
                     tv[j - j0] = __builtin_amdgcn_raw_buffer_load_b128(xrs, gvoff, base + uo, 16);
                 }
 #pragma unroll
@@ -186,7 +187,7 @@ __global__ __launch_bounds__(256, 1) void lstm_wide_kernel(LstmParams p) {
                     const int lo = lbase + ((slice + 1 + j) & (WG - 1)) * 32;
                     if (((bad >> j) & 1u) && tv[j - j0].y == epoch && tv[j - j0].w == epoch) {
                         sH[lo] = __uint_as_float(tv[j - j0].x);
-                        sH[lo + 1] = __uint_as_float(tv[j - j0].z);
+                        sH[lo + WLD] = __uint_as_float(tv[j - j0].z);
                         bad &= ~(1u << j);
                     }
                 }
@@ -356,8 +357,11 @@ __global__ __launch_bounds__(256, 1) void lstm_wide_kernel(LstmParams p) {
                 ++epoch;
                 par = (epoch & 1u) * PARITY;
 #pragma unroll
-                for (int r = 0; r < 2; ++r)
-                    XCH_STORE_B64(ticket.same_xcd, ((wu32x2){__float_as_uint(hc[r]), epoch}), xrs, pub_off + r * WH * 8, par);
+                for (int r = 0; r < 1; ++r) {
+                    const wu32x4 gr = {__float_as_uint(hc[0]), epoch, __float_as_uint(hc[1]), epoch};
+                    if (ticket.same_xcd) __builtin_amdgcn_raw_buffer_store_b128(gr, xrs, pub_off, par, 1);
+                    else __builtin_amdgcn_raw_buffer_store_b128(gr, xrs, pub_off, par, 16);
+                }
             }
             __syncthreads();   // barrier 1: every wave is done reading sH; x_{t+1} is in LDS
             if (do_xch) {

@@ -213,12 +213,13 @@ __global__ __launch_bounds__(256, 1) void mix_decoder_kernel(MixDecParams p) {
     const __amdgpu_buffer_rsrc_t xrs =
         __builtin_amdgcn_make_buffer_rsrc(xg, 0, 4 * MBT * MH * (int)sizeof(unsigned long long), 0x00020000);
     const int my_row0 = 4 * g4 + 2 * hi;   // this lane's two cells: rows my_row0, my_row0 + 1 of unit `unit`
-    const unsigned pub_off = (unsigned)(my_row0 * MH + unit) * 8u;
-    // gather: load j of this thread brings the granules of units (2p, 2p + 1) of the other slice (slice + 1 + j) mod 8, row
-    // tid / 16, p = tid % 16 - adjacent in the [row][unit] order, each with its own tag (round 3: seven 16-byte loads instead
-    // of fourteen 8-byte ones); one per-thread offset, everything else wave-uniform
-    const unsigned gvoff = (unsigned)((tid >> 4) * MH + 2 * (tid & 15)) * 8u;
-    const int lbase = (tid >> 4) * MLDH + 2 * (tid & 15);
+    // granule order [row pair][unit][row of the pair]: the lane's two rows leave as ONE 16-byte store, a gather load brings
+    // both rows of a unit (two tagged granules)
+    const unsigned pub_off = (unsigned)((my_row0 >> 1) * MH + unit) * 16u;
+    // gather: load j of this thread brings rows (2k, 2k + 1), k = tid / 32, of unit tid % 32 of the other slice (slice + 1 + j) mod 8 -
+    // seven 16-byte loads; one per-thread offset, everything else wave-uniform
+    const unsigned gvoff = (unsigned)((tid >> 5) * MH + (tid & 31)) * 16u;
+    const int lbase = 2 * (tid >> 5) * MLDH + (tid & 31);
     constexpr unsigned LAYER_BYTES = 2u * MBT * MH * 8u;    // both parities of one layer
     constexpr unsigned PARITY_BYTES = MBT * MH * 8u;
 #ifdef FOV_STAMPS
@@ -236,7 +237,7 @@ __global__ __launch_bounds__(256, 1) void mix_decoder_kernel(MixDecParams p) {
     auto gather_issue = [&](unsigned base) {
 #pragma unroll
         for (int j = 0; j < MNG; ++j) {
-            const unsigned uo = (unsigned)(((slice + 1 + j) & (MG - 1)) * 32) * 8u;
+            const unsigned uo = (unsigned)(((slice + 1 + j) & (MG - 1)) * 32) * 16u;
             v[j] = __builtin_amdgcn_raw_buffer_load_b128(xrs, gvoff, base + uo, 16);
         }
     };
@@ -259,7 +260,7 @@ __global__ __launch_bounds__(256, 1) void mix_decoder_kernel(MixDecParams p) {
             asm volatile("" ::: "memory");
 #pragma unroll
             for (int j = 0; j < MNG; ++j) {
-                const unsigned uo = (unsigned)(((slice + 1 + j) & (MG - 1)) * 32) * 8u;
+                const unsigned uo = (unsigned)(((slice + 1 + j) & (MG - 1)) * 32) * 16u;
                 v[j] = __builtin_amdgcn_raw_buffer_load_b128(xrs, gvoff, base + uo, 16);
             }
         }
@@ -267,7 +268,7 @@ __global__ __launch_bounds__(256, 1) void mix_decoder_kernel(MixDecParams p) {
         for (int j = 0; j < MNG; ++j) {
             float* d = sH + lbase + ((slice + 1 + j) & (MG - 1)) * 32;
             d[0] = __uint_as_float(v[j].x);
-            d[1] = __uint_as_float(v[j].z);
+            d[MLDH] = __uint_as_float(v[j].z);
         }
     };
 
@@ -358,8 +359,11 @@ __global__ __launch_bounds__(256, 1) void mix_decoder_kernel(MixDecParams p) {
             MIX_STAMP(1);
             // publish h1_t, then start the gather and run h2_{t-1} . R2 under it
 #pragma unroll
-            for (int r = 0; r < 2; ++r)
-                XCH_STORE_B64(ticket.same_xcd, ((mu32x2){__float_as_uint(h1c[r]), epoch}), xrs, pub_off + r * MH * 8, par);
+            for (int r = 0; r < 1; ++r) {
+                const mu32x4 gr = {__float_as_uint(h1c[0]), epoch, __float_as_uint(h1c[1]), epoch};
+                if (ticket.same_xcd) __builtin_amdgcn_raw_buffer_store_b128(gr, xrs, pub_off, par, 1);
+                else __builtin_amdgcn_raw_buffer_store_b128(gr, xrs, pub_off, par, 16);
+            }
 #pragma unroll
             for (int r = 0; r < 2; ++r) sH1[(my_row0 + r) * MLDH + unit] = h1c[r];
             acc2[0] = (f32x4){b2v[0], b2v[0], b2v[0], b2v[0]};
@@ -412,9 +416,11 @@ __global__ __launch_bounds__(256, 1) void mix_decoder_kernel(MixDecParams p) {
                 }
             }
 #pragma unroll
-            for (int r = 0; r < 2; ++r)
-                XCH_STORE_B64(ticket.same_xcd, ((mu32x2){__float_as_uint(h2c[r]), epoch}), xrs, pub_off + r * MH * 8,
-                                                      LAYER_BYTES + par);
+            for (int r = 0; r < 1; ++r) {
+                const mu32x4 gr = {__float_as_uint(h2c[0]), epoch, __float_as_uint(h2c[1]), epoch};
+                if (ticket.same_xcd) __builtin_amdgcn_raw_buffer_store_b128(gr, xrs, pub_off, LAYER_BYTES + par, 1);
+                else __builtin_amdgcn_raw_buffer_store_b128(gr, xrs, pub_off, LAYER_BYTES + par, 16);
+            }
 #pragma unroll
             for (int r = 0; r < 2; ++r) sH2[(my_row0 + r) * MLDH + unit] = h2c[r];
             const bool more = (t + 1 < p.T_out);
