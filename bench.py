@@ -46,9 +46,9 @@ PMC_TRAFFIC_SOURCE = "profiles/r03_pmc_bench.txt"
 # tools/pmc_step_total.py: FETCH_SIZE and WRITE_SIZE in separate passes, raw KiB summed over the dispatches of one step -
 # the dispatches between two launches of an anchor kernel); quoted only for the default shape of the mode.  key = (mode, dtype)
 MODE_TRAFFIC = {
-    ("train_mixing", "f32"): ((494350 + 869887) * 1024, "profiles/r03_pmcstep_train_mixing_f32.txt"),
+    ("train_mixing", "f32"): ((494096 + 871167) * 1024, "profiles/r03_pmcstep_train_mixing_f32.txt"),
     ("train_mixing", "bf16"): ((293108 + 451721) * 1024, "profiles/r03_pmcstep_train_mixing_bf16.txt"),
-    ("infer_mixing", "f32"): (int((37962.6 + 17184.4) * 1024), "profiles/r03_pmcstep_infer_mixing_f32.txt"),
+    ("infer_mixing", "f32"): (int((37854.8 + 16672.4) * 1024), "profiles/r03_pmcstep_infer_mixing_f32.txt"),
     ("infer_mixing", "bf16"): (int((34659.6 + 10528.2) * 1024), "profiles/r03_pmcstep_infer_mixing_bf16.txt"),
     ("train", "f32"): ((631999 + 1216710) * 1024, "profiles/r03_pmcstep_train_f32.txt"),
     # tools/pmc_simple.sh (run total / identical steps: tools/pmc_simple_steps.py, tools/pmc_run_total.py)
