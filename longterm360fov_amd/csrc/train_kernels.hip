@@ -891,6 +891,11 @@ int gemm_f32(GemmArgs g, int accumulate, float* scratch, size_t scratch_floats, 
     // mid-size outputs (e.g. 512 x 1024 of a per-step projection): 128 x 128 tiles would occupy a fraction of
     // the 256 CUs and K is too short to split -> 64 x 64 tiles
     if (variant == 2 && ((g.M + 127) / 128) * ((g.N + 127) / 128) < 128 && K <= 2048) { BM = 64; BN = 64; variant = 3; }
+    // short K (the weight gradients of a wide layer at a small batch: 1025 x 2048 x 320 for lstm.py's LSTMCell(400) at batch 32,
+    // 144 tiles of 128 x 128): nothing to split, 64 x 64 tiles fill the chip twice over (its training step 0.415 -> 0.397 ms)
+    if (variant == 2 && K <= 512 && ((g.M + 127) / 128) * ((g.N + 127) / 128) < 256) { BM = 64; BN = 64; variant = 3; }
+    // the same regime with a 33..96-row output (dK of a 90-wide input: eight 96 x 256 tiles): 64 x 64 tiles as well
+    if (variant == 1 && K <= 512 && g.N >= 1024) { BM = 64; BN = 64; variant = 3; }
     if (const int v = env_knobs().gemm_variant) {   // tuning knob (experiments), FOV_GEMM_VARIANT
         if (v == 2) { BM = 128; BN = 128; variant = 2; }
         if (v == 3) { BM = 64; BN = 64; variant = 3; }
