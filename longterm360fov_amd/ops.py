@@ -460,7 +460,8 @@ def gauss_nll_grad(mu, var, y, fps, scale, scratch=None):
     mu, var, y = _dev(mu, "mu"), _dev(var, "var"), _dev(y, "y")
     B, T_y = y.shape[0], y.shape[1]
     assert mu.shape == (B, 3) and var.shape == (B, 3) and y.shape[2] == 3 * fps
-    loss = torch.zeros(1, dtype=torch.float32, device=y.device)
+    # the entry point overwrites the loss (an empty batch returns before it: zero then)
+    loss = (torch.empty if B > 0 else torch.zeros)(1, dtype=torch.float32, device=y.device)
     dmu, dvar = torch.empty_like(mu), torch.empty_like(var)
     buf = (scratch or _default_scratch).get(4 * (B + 64), y.device)
     check(_lib.lib().fov_gauss_nll_grad(_ptr(mu), _ptr(var), _ptr(y), _ptr(loss), _ptr(dmu), _ptr(dvar), B, T_y, fps,
