@@ -404,6 +404,43 @@ int fov_tf_head_bwd(const float* h, const float* mu_W1, const float* mu_W2, cons
                     float* g_mu_W1, float* g_mu_b1, float* g_mu_W2, float* g_mu_b2, float* g_var_W1, float* g_var_b1,
                     float* g_var_W2, float* g_var_b2, float* dh, int B, int H, int M, int O, int accumulate, fov_stream_t stream);
 
+/* The heads of mycode/lstm.py's other two branches - the ones taken when cfg.predict_mean_var is False, i.e. under the committed
+ * mycode/config.py:69,71 - as a fused chain of up to four small Dense layers on the top layer's final state (B rows, the script runs 32):
+ *   _GMM_3dgassian (lstm.py:377-400): dims {H, 64, 128, 256, 10 n_mix}, activations relu (2) x3, final_mode 1 = the mixture split
+ *     of :386-399 on the last layer: [n softmax weights (exp / sum exp) | 3n means | 3n sigmas = exp | 3n correlations = tanh];
+ *   pred_cnn_model_fn (lstm.py:147-174): dims {H, 128, 256, 3 fps}, activations relu, relu, tanh (1), final_mode 0 - the centre taps
+ *     of the three k = 5 'same' conv1d kernels, all that one time step ever meets.
+ * W[l] (dims[l], dims[l+1]) row-major, b[l] (dims[l+1]); masks (array or NULL) hold optional (B, dims[l+1]) multipliers applied behind
+ * layer l's activation (tf.layers.dropout, already scaled; the script calls it with training=False, so NULL is the reference);
+ * acts[l] (B, dims[l+1]) receives layer l's output (behind activation and mask; the last one behind the split) - the tape of the
+ * backward.  fov_mlp_head_bwd takes dlast = d loss / d PRE-activation of the last layer (what fov_gmm3d_loss_grad and
+ * fov_mse_dense_grad produce) and writes (accumulate != 0: adds) gW[l], gb[l] and, if dx != NULL, dx (B, dims[0]).
+ * Shapes: 1..4 layers, dims[0] <= 2048, the other widths <= 512 (fov_mlp_head_supported); pointer arrays live on the HOST, what they point to on the device. */
+int fov_mlp_head_supported(int B, int L, const int* dims);
+int fov_mlp_head_fwd(const float* x, const float* const* W, const float* const* b, const float* const* masks, float* const* acts,
+                     const int* dims, const int* act_codes, int L, int final_mode, int n_mix, int B, fov_stream_t stream);
+size_t fov_mlp_head_bwd_workspace_bytes(int B, int L, const int* dims);
+int fov_mlp_head_bwd(const float* x, const float* const* W, const float* const* masks, const float* const* acts, const float* dlast,
+                     float* const* gW, float* const* gb, float* dx, const int* dims, const int* act_codes, int L, int B,
+                     int accumulate, void* workspace, size_t workspace_bytes, fov_stream_t stream);
+
+/* costfunc.mixture_3d_gaussian_loss (mycode/cost.py:486-549) with its gradient.  params (B, 10 n_mix) as fov_mlp_head_fwd's mixture
+ * split lays them out (mixture m: means params[n+3m..], sigmas params[4n+3m..], rho12, rho13, rho23 params[7n+3m..]); y: n_pts frames
+ * (x, y, z interleaved) per row, rows ldy floats apart (cfg.process_in_seconds: second 0 of y (B,T_y,3 fps), ldy = T_y * 3 fps, n_pts =
+ * fps; per frame: y (B,T,3), n_pts = T).  Per (row, mixture): covariance [[s1^2, r12 s1 s2, r13 s1 s3], ...], repaired as
+ * cost.py:335-348 (smallest eigenvalue lambda < 0: Sigma - 10 lambda I), density N(y_t; mu_m, Sigma'_m);
+ *   *loss = scale * sum_{b,t} -log(sum_m [pi_m] N_bmt + 1e-20)      (scale = 1 / (batch_size * running_length [* fps]), cost.py:544-549)
+ * weight_by_pi = 0 is the reference: cost.py:532-538 never multiplies by mixture_pi, so the softmax weights get no gradient.
+ * dpre (B, 10 n_mix) = d loss / d the head's PRE-activations (through softmax / exp / tanh and the eigenvalue repair).  The 3x3
+ * work runs in fp64.  n_mix <= 32, n_pts <= 256; workspace >= 4 * B bytes.
+ * fov_gmm3d_sample: one draw per frame - component = first m with cumsum(pi)[m] > u (u (B, n_pts) uniform), value mu_m + chol(Sigma'_m) z
+ * (z (B, n_pts, 3) normal) -> out rows of 3 n_pts floats, ldo apart: what utility.sample_mixture_3D (utility.py:178-208) documents and
+ * the GMM test loop (lstm.py:735-745,820-825) feeds back; the committed function itself stops in pdb and indexes two dimensions. */
+int fov_gmm3d_loss_grad(const float* params, const float* y, int64_t ldy, float* loss, float* dpre, int B, int n_mix, int n_pts,
+                        float scale, int weight_by_pi, void* workspace, size_t workspace_bytes, fov_stream_t stream);
+int fov_gmm3d_sample(const float* params, const float* u, const float* z, float* out, int64_t ldo, int B, int n_mix, int n_pts,
+                     fov_stream_t stream);
+
 /* Keras-2.2 `categorical_crossentropy` on probabilities, TensorFlow backend form - the loss the heat-map fork compiles
  * (mycode/convlstm_heatmap.py:192): per pixel (row of C channels) q = p / sum p, q' = clip(q, 1e-7, 1 - 1e-7),
  * l = - sum_c target_c log q'_c; *loss (may be NULL) = mean over the n_pix rows; dp = d loss / d p, through the clip (zero

@@ -73,6 +73,12 @@ SIGNATURES = {
     "fov_tf_head_supported": (_I, [_I] * 4),
     "fov_tf_head_fwd": (_I, [_P] * 13 + [_I] * 4 + [_P]),
     "fov_tf_head_bwd": (_I, [_P] * 20 + [_I] * 5 + [_P]),
+    "fov_mlp_head_supported": (_I, [_I, _I, _P]),
+    "fov_mlp_head_fwd": (_I, [_P] * 7 + [_I] * 4 + [_P]),
+    "fov_mlp_head_bwd_workspace_bytes": (_SZ, [_I, _I, _P]),
+    "fov_mlp_head_bwd": (_I, [_P] * 10 + [_I] * 3 + [_P, _SZ, _P]),
+    "fov_gmm3d_loss_grad": (_I, [_P, _P, ctypes.c_int64, _P, _P, _I, _I, _I, ctypes.c_float, _I, _P, _SZ, _P]),
+    "fov_gmm3d_sample": (_I, [_P, _P, _P, _P, ctypes.c_int64, _I, _I, _I, _P]),
     "fov_gauss_nll_grad": (_I, [_P] * 6 + [_I] * 3 + [ctypes.c_float, _P, _SZ, _P]),
     "fov_rmsprop_tf_step": (_I, [_P] * 3 + [ctypes.c_int64] + [ctypes.c_float] * 4 + [_P]),
     "fov_categorical_crossentropy_grad": (_I, [_P] * 4 + [ctypes.c_int64, _I, _P, _SZ, _P]),

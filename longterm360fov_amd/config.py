@@ -46,6 +46,7 @@ def default_config():
     c.conv_kernel_size = 5            # :65
     c.predict_mean_var = False        # :69  (the others-mixing model needs True)
     c.sample_and_refeed = True        # :70
+    c.use_GMM = True                  # :71  mixture-density head of lstm.py (training.TFLSTMTrainer.head_kind_of)
     c.input_mean_var = False          # :74
     c.teacher_forcing = False         # :75
     c.use_one_hot = False             # :76

@@ -455,6 +455,105 @@ def tf_head_bwd(h, w, head, dmu, dvar, g, accumulate=False):
     return dh
 
 
+import ctypes as _ct
+
+_PTR4 = _ct.c_void_p * 4
+_INT4 = _ct.c_int * 4
+_INT5 = _ct.c_int * 5
+
+
+def _mlp_tables(layers, x_width):
+    """layers: [(W (Din,Dout), b (Dout), activation)] -> (dims, codes, W pointers, b pointers) as ctypes arrays."""
+    L = len(layers)
+    assert 1 <= L <= 4
+    dims = [int(x_width)] + [int(W.shape[1]) for W, _, _ in layers]
+    for l, (W, b, _) in enumerate(layers):
+        _dev(W, "W%d" % l); _dev(b, "b%d" % l)
+        assert W.shape[0] == dims[l] and b.shape == (dims[l + 1],)
+    pad = [None] * (4 - L)
+    return (_INT5(*(dims + [0] * (4 - L))), _INT4(*([_ACT_CODES[a] for _, _, a in layers] + [0] * (4 - L))),
+            _PTR4(*([W.data_ptr() for W, _, _ in layers] + pad)), _PTR4(*([b.data_ptr() for _, b, _ in layers] + pad)))
+
+
+def mlp_head_supported(B, dims):
+    L = len(dims) - 1
+    return 1 <= L <= 4 and bool(_lib.lib().fov_mlp_head_supported(B, L, _INT5(*(list(dims) + [0] * (4 - L)))))
+
+
+def mlp_head_fwd(x, layers, masks=None, n_mix=0):
+    """Fused chain of up to four Dense layers on a few rows (mlp_head.hip): the heads of mycode/lstm.py:147-174 and
+    :377-400.  layers [(W, b, activation)]; masks [per layer (B,Dout) or None]; n_mix > 0: the last layer gets the
+    mixture split [softmax n | 3n | exp 3n | tanh 3n] instead of its activation.  -> [output of every layer]."""
+    x = _dev(x, "x")
+    B, D0 = x.shape
+    dims, codes, Wp, bp = _mlp_tables(layers, D0)
+    L = len(layers)
+    acts = [torch.empty((B, W.shape[1]), dtype=torch.float32, device=x.device) for W, _, _ in layers]
+    mp = None
+    if masks is not None and any(m is not None for m in masks):
+        for l, m in enumerate(masks):
+            assert m is None or _dev(m, "mask").shape == acts[l].shape
+        mp = _PTR4(*([_ptr(m) for m in masks] + [None] * (4 - len(masks))))
+    check(_lib.lib().fov_mlp_head_fwd(_ptr(x), Wp, bp, mp, _PTR4(*([a.data_ptr() for a in acts] + [None] * (4 - L))), dims, codes, L,
+                                      1 if n_mix else 0, int(n_mix), B, _stream()))
+    return acts
+
+
+def mlp_head_bwd(x, layers, acts, dlast, gW, gb, masks=None, need_dx=True, accumulate=False, scratch=None):
+    """Backward of mlp_head_fwd: dlast = d loss / d pre-activation of the last layer; gW / gb lists receive (accumulate: are
+    added) the gradients; returns dx (B,D0) or None."""
+    x, dlast = _dev(x, "x"), _dev(dlast, "dlast")
+    B, D0 = x.shape
+    dims, codes, Wp, _ = _mlp_tables(layers, D0)
+    L = len(layers)
+    assert dlast.shape == (B, layers[-1][0].shape[1])
+    for l in range(L):
+        assert _dev(gW[l], "gW").shape == layers[l][0].shape and _dev(gb[l], "gb").shape == layers[l][1].shape
+    dx = torch.empty((B, D0), dtype=torch.float32, device=x.device) if need_dx else None
+    mp = None
+    if masks is not None and any(m is not None for m in masks):
+        mp = _PTR4(*([_ptr(m) for m in masks] + [None] * (4 - len(masks))))
+    lib = _lib.lib()
+    buf = (scratch or _default_scratch).get(lib.fov_mlp_head_bwd_workspace_bytes(B, L, dims), x.device)
+    pad = [None] * (4 - L)
+    check(lib.fov_mlp_head_bwd(_ptr(x), Wp, mp, _PTR4(*([_ptr(_dev(a, "act")) for a in acts] + pad)), _ptr(dlast),
+                               _PTR4(*([g.data_ptr() for g in gW] + pad)), _PTR4(*([g.data_ptr() for g in gb] + pad)), _ptr(dx), dims,
+                               codes, L, B, 1 if accumulate else 0, buf.data_ptr(), buf.numel(), _stream()))
+    return dx
+
+
+def gmm3d_loss_grad(params, y, n_pts, scale, weight_by_pi=False, scratch=None):
+    """costfunc.mixture_3d_gaussian_loss (cost.py:486-549) + gradient at the head's pre-activations.  params (B,10n) from
+    mlp_head_fwd(n_mix=n); y (B, ...) whose rows START with the n_pts scored frames (x,y,z interleaved): (B,T_y,3*fps)
+    under cfg.process_in_seconds (second 0), (B,T,3) per frame.  -> (loss (1,), dpre (B,10n))."""
+    params, y = _dev(params, "params"), _dev(y, "y")
+    B = params.shape[0]
+    n = params.shape[1] // 10
+    assert params.shape[1] == 10 * n and y.shape[0] == B
+    ldy = y.numel() // max(B, 1)
+    loss = (torch.empty if B > 0 else torch.zeros)(1, dtype=torch.float32, device=y.device)
+    dpre = torch.empty_like(params)
+    buf = (scratch or _default_scratch).get(4 * (B + 64), y.device)
+    check(_lib.lib().fov_gmm3d_loss_grad(_ptr(params), _ptr(y), ldy, _ptr(loss), _ptr(dpre), B, n, int(n_pts), float(scale),
+                                         1 if weight_by_pi else 0, buf.data_ptr(), buf.numel(), _stream()))
+    return loss, dpre
+
+
+def gmm3d_sample(params, u, z, out=None):
+    """One draw per frame from the 3-D mixture (utility.sample_mixture_3D's documented intent, utility.py:178-208): u (B,P)
+    uniform picks the component by inverse CDF over pi, z (B,P,3) normal -> mu_m + chol(Sigma'_m) z.  out: (B,3P) rows,
+    possibly a strided slot of a window; -> out."""
+    params, u, z = _dev(params, "params"), _dev(u, "u"), _dev(z, "z")
+    B, P = u.shape
+    n = params.shape[1] // 10
+    assert params.shape == (B, 10 * n) and z.shape == (B, P, 3)
+    if out is None:
+        out = torch.empty((B, 3 * P), dtype=torch.float32, device=u.device)
+    ptr, ld = _row_view(out, 3 * P)
+    check(_lib.lib().fov_gmm3d_sample(_ptr(params), _ptr(u), _ptr(z), ptr, ld, B, n, P, _stream()))
+    return out
+
+
 def gauss_nll_grad(mu, var, y, fps, scale, scratch=None):
     """Gaussian NLL of cost.py:190-229 -> (loss (1,), dmu (B,3), dvar (B,3)).  y (B,T_y,3*fps)."""
     mu, var, y = _dev(mu, "mu"), _dev(var, "var"), _dev(y, "y")

@@ -1422,12 +1422,45 @@ class TFLSTMTrainer:
     sampled seconds: pass `noise` to forward_backward / train_step (fov_sample_refeed_fwd / _bwd)."""
 
     HEAD = ("mu_W1", "mu_b1", "mu_W2", "mu_b2", "var_W1", "var_b1", "var_W2", "var_b2")
+    GMM_HEAD = ("fc1_W", "fc1_b", "fc2_W", "fc2_b", "fc3_W", "fc3_b", "fc4_W", "fc4_b")
+    RAW_HEAD = ("conv1_W", "conv1_b", "conv2_W", "conv2_b", "conv3_W", "conv3_b")
+    HEADS = {"meanvar": HEAD, "gmm": GMM_HEAD, "raw": RAW_HEAD}
+    # the one head tensor that reads h (its H rows are zero-padded to Hp): name -> axis of H
+    FIRST = {"meanvar": {"mu_W1": 0, "var_W1": 0}, "gmm": {"fc1_W": 0}, "raw": {"conv1_W": 1}}
+
+    @staticmethod
+    def head_kind_of(cfg):
+        """The branch of mycode/lstm.py:424-509 a configuration selects (cfg.use_xyz): predict_mean_var -> 'meanvar' (:426),
+        elif use_GMM -> 'gmm' (:482 - what the committed config.py:69,71 runs), else 'raw' (:487)."""
+        if not cfg.get("use_xyz", True):
+            raise NotImplementedError("cfg.use_phi_theta branches of lstm.py (:511-527) are not on the hot path")
+        if cfg.get("predict_mean_var", False):
+            return "meanvar"
+        return "gmm" if cfg.get("use_GMM", True) else "raw"
+
+    @classmethod
+    def from_cfg(cls, cfg, cells, head, **kw):
+        """Trainer for the branch `cfg` selects, with the script's own hyper-parameters (lstm.py:59,554-567, config.py)."""
+        kw.setdefault("lr", cfg.get("LEARNING_RATE", 1e-5))
+        kw.setdefault("clip_value", 1.0 if cfg.get("clip_gradient", True) else 0.0)
+        kw.setdefault("fps", cfg.get("fps", 30))
+        kw.setdefault("running_length", cfg.get("running_length", 10))
+        kw.setdefault("process_in_seconds", cfg.get("process_in_seconds", True))
+        kw.setdefault("batch_size", cfg.get("batch_size", None))
+        return cls(cells, head, head_kind=cls.head_kind_of(cfg), **kw)
 
     def __init__(self, cells, head, forget_bias=1.0, lr=1e-5, clip_value=1.0, decay=0.9, eps=1e-10, fps=30, running_length=10,
-                 impl="auto", device="cuda", pad=True):
-        from .models import convert_tf_lstmcell, padded_width, pad_lstm, pad_rows, MFMA_WIDTHS
+                 impl="auto", device="cuda", pad=True, head_kind="meanvar", n_mix=20, weight_by_pi=False, use_reg=False,
+                 process_in_seconds=True, batch_size=None):
+        from .models import convert_tf_lstmcell, padded_width, pad_lstm, MFMA_WIDTHS
         self.forget_bias, self.lr, self.clip, self.decay, self.eps = float(forget_bias), float(lr), float(clip_value), decay, eps
         self.fps, self.running_length, self.impl, self.device = fps, running_length, impl, device
+        # head_kind: 'meanvar' (_pred_mean_var_xyz2_new + likelihood_loss_tf), 'gmm' (_GMM_3dgassian + mixture_3d_gaussian_loss,
+        # lstm.py:377-400,482-485; cost.py:486-549) or 'raw' (pred_cnn_model_fn + MSE / pred_raw_loss_tf, lstm.py:147-174,486-508)
+        self.head_kind, self.n_mix, self.weight_by_pi, self.use_reg = head_kind, int(n_mix), bool(weight_by_pi), bool(use_reg)
+        self.process_in_seconds, self.batch_size = bool(process_in_seconds), batch_size
+        self.HEAD = self.HEADS[head_kind]
+        first = self.FIRST[head_kind]
         conv = [convert_tf_lstmcell(W, b, forget_bias) for W, b in cells]
         self.L = len(conv)
         # The stack runs at the next matrix-core width Hp (lstm.py's n_hidden = 400 -> 512: lstm_wide16.hip forward, lstm_bwd16.hip
@@ -1444,8 +1477,10 @@ class TFLSTMTrainer:
             weights.update({"K%d" % l: K, "R%d" % l: R, "b%d" % l: b})
         weights.update({k: np.ascontiguousarray(head[k], dtype=np.float32) for k in self.HEAD})
         if self.Hp != self.H:
-            for k in ("mu_W1", "var_W1"):
-                weights[k] = pad_rows(weights[k], self.Hp)
+            for k, ax in first.items():
+                widths = [(0, 0)] * weights[k].ndim
+                widths[ax] = (0, self.Hp - self.H)
+                weights[k] = np.ascontiguousarray(np.pad(weights[k], widths))
         self.order = ["%s%d" % (n, l) for l in range(self.L) for n in ("K", "R", "b")] + list(self.HEAD)
         n = int(sum(weights[k].size for k in self.order))
         self.flat = torch.empty(n, dtype=torch.float32, device=device)
@@ -1472,7 +1507,8 @@ class TFLSTMTrainer:
             if k[0] == "R" or (k[0] == "K" and int(k[1:]) > 0):
                 v = v[:H]
             return _unpad_gates(v, H, Hp)
-        return v[:H].copy() if k in ("mu_W1", "var_W1") else v
+        ax = self.FIRST[self.head_kind].get(k)
+        return v if ax is None else np.ascontiguousarray(np.take(v, np.arange(H), axis=ax))
 
     def weights_numpy(self):
         return {k: self._unpadded(self.w, k) for k in self.order}
@@ -1542,8 +1578,18 @@ class TFLSTMTrainer:
         M, O = self.w["mu_W2"].shape
         return os.environ.get("FOV_NO_TF_HEAD") is None and ops.tf_head_supported(h.shape[0], h.shape[1], M, O)
 
-    def _head(self, h):
+    def _mlp_layers(self, table):
+        """[(W, b, activation)] of the fused chain (mlp_head.hip) over `table` = self.w or self.g."""
+        if self.head_kind == "gmm":
+            return [(table["fc%d_W" % l], table["fc%d_b" % l], "relu" if l < 4 else None) for l in (1, 2, 3, 4)]
+        # one time step under 'same' padding meets only the centre tap of each (k, C_in, C_out) kernel (lstm.py:151)
+        c = table["conv1_W"].shape[0] // 2
+        return [(table["conv%d_W" % l][c], table["conv%d_b" % l], "relu" if l < 3 else "tanh") for l in (1, 2, 3)]
+
+    def _head(self, h, head_masks=None):
         w = self.w
+        if self.head_kind != "meanvar":      # -> [output of every layer]; the last one is the mixture (B,10n) / the second (B,3*fps)
+            return ops.mlp_head_fwd(h, self._mlp_layers(w), masks=head_masks, n_mix=self.n_mix if self.head_kind == "gmm" else 0)
         if self._head_fused(h):      # one launch instead of seven (tf_head.hip)
             return ops.tf_head_fwd(h, w)
         a1 = ops.dense(h, w["mu_W1"], w["mu_b1"], activation=None)
@@ -1556,7 +1602,8 @@ class TFLSTMTrainer:
         return a1, mu, a3, var
 
     def predict(self, x, init_state=None):
-        """(mu (B,3), var (B,3), state (L,2,B,H) as LSTMStateTuple (c,h) per layer) - inference, no dropout."""
+        """(mu (B,3), var (B,3), state (L,2,B,H) as LSTMStateTuple (c,h) per layer) - inference, no dropout.
+        head_kind 'gmm': (params (B,10n) = [pi | us | sigmas | rhos], None, state); 'raw': (second (B,3*fps), None, state)."""
         mu, var, states = self._predict_padded(x, self._pad_state(init_state))
         return mu, var, self._state_out(states)
 
@@ -1574,6 +1621,8 @@ class TFLSTMTrainer:
                                           impl=self.impl, workspace=self.ws)
                 states.append((cT, hT))
                 inp = hs
+        if self.head_kind != "meanvar":
+            return self._head(states[-1][1])[-1], None, states
         _, mu, _, var = self._head(states[-1][1])
         return mu, var, states
 
@@ -1594,6 +1643,42 @@ class TFLSTMTrainer:
             ops.sample_refeed(mu, var, noise[k], out=nxt[:, T - 1], std="sqrt")
             win = nxt
         return mus, vs, self._state_out(st)
+
+    def rollout_gmm(self, x, init_state, u, z):
+        """GMM test loop of lstm.py:690-698,735-745,820-825: the window (the script feeds only the last second, T = 1) and
+        the carried state predict a mixture, one second is drawn from it (ops.gmm3d_sample: u (P,B,fps) uniform, z
+        (P,B,fps,3) normal) and shifted in.  -> (samples (P,B,3*fps), final state (L,2,B,H))."""
+        assert self.head_kind == "gmm"
+        P, B, fps = u.shape
+        T = x.shape[1]
+        outs = torch.empty((P, B, 3 * fps), dtype=torch.float32, device=self.device)
+        win, st = x, self._pad_state(init_state)
+        for k in range(P):
+            params, _, st = self._predict_padded(win, st)
+            nxt = torch.empty_like(win)
+            if T > 1:
+                nxt[:, :T - 1].copy_(win[:, 1:])
+            ops.gmm3d_sample(params, u[k], z[k], out=nxt[:, T - 1])
+            outs[k].copy_(nxt[:, T - 1])
+            win = nxt
+        return outs, self._state_out(st)
+
+    def rollout_raw(self, x, init_state, P):
+        """Raw-prediction test loop (lstm.py:747-757,820-825): the predicted second itself is shifted in.
+        -> (predictions (P,B,3*fps), final state)."""
+        assert self.head_kind == "raw"
+        B, T, F = x.shape
+        outs = torch.empty((P, B, F), dtype=torch.float32, device=self.device)
+        win, st = x, self._pad_state(init_state)
+        for k in range(P):
+            pred, _, st = self._predict_padded(win, st)
+            outs[k].copy_(pred)
+            nxt = torch.empty_like(win)
+            if T > 1:
+                nxt[:, :T - 1].copy_(win[:, 1:])
+            nxt[:, T - 1].copy_(pred)
+            win = nxt
+        return outs, self._state_out(st)
 
     def _stack2(self, x, masks=None):
         """Both layers as one launch (fov_lstm_stack2_fwd)?  Not with a dropout mask between the layers."""
@@ -1624,6 +1709,11 @@ class TFLSTMTrainer:
             states.append((cT, hT))
             inp = hs if (masks is None or l == self.L - 1) else hs * masks[l]
         return tape, states
+
+    def _mlp_backward(self, hT, acts, dlast, accumulate, head_masks=None):
+        gl = self._mlp_layers(self.g)
+        return ops.mlp_head_bwd(hT, self._mlp_layers(self.w), acts, dlast, [g[0] for g in gl], [g[1] for g in gl], masks=head_masks,
+                                need_dx=True, accumulate=accumulate, scratch=self.scratch)
 
     def _head_backward(self, hT, head, dmu, dvar, accumulate):
         w, g, sc = self.w, self.g, self.scratch
@@ -1659,9 +1749,72 @@ class TFLSTMTrainer:
                 dx0 = b["dx"]
         return dx0
 
-    def forward_backward(self, x, y, init_state=None, masks=None, noise=None):
+    def _fb_gmm(self, x, y, init_state, masks, head_masks):
+        """lstm.py:482-485: one window, costfunc.mixture_3d_gaussian_loss on y (second 0 under cfg.process_in_seconds,
+        every frame of (B,T,3) otherwise), divided by batch_size * running_length [* fps] (cost.py:544-549)."""
+        B = x.shape[0]
+        pis = self.process_in_seconds
+        n_pts = self.fps if pis else y.shape[1]
+        scale = 1.0 / ((self.batch_size or B) * self.running_length * (self.fps if pis else 1))
+        init_state, masks = self._pad_state(init_state), self._pad_masks(masks)
+        tape, states = self._stack_forward(x, init_state, masks)
+        hT = states[-1][1]
+        acts = self._head(hT, head_masks)
+        loss, dpre = ops.gmm3d_loss_grad(acts[-1], y, n_pts, scale, self.weight_by_pi, scratch=self.scratch)
+        dhT = self._mlp_backward(hT, acts, dpre, accumulate=False, head_masks=head_masks)
+        self._stack_backward(tape, dhT, masks, accumulate=False)
+        return loss, acts[-1], None, self._state_out(states)
+
+    def _fb_raw(self, x, y, init_state, masks):
+        """lstm.py:486-508: prediction k is scored against second k (tf.losses.mean_squared_error over every element;
+        pred_raw_loss_tf's total-variation term differences an axis of length one and is exactly zero, cost.py:608-618),
+        then shifted into the window for prediction k+1 - no sampling, the gradient flows back through the predictions.
+        use_reg adds 0.1 * sum (x^2+y^2+z^2-1)^2 (cost.py:622-641; the script itself leaves `use_reg` undefined)."""
+        B, T, F = x.shape
+        P = y.shape[1]
+        sc = self.scratch
+        init_state = self._pad_state(init_state)
+        many = P > 1
+        if many:
+            self.grad.zero_()
+        win, runs, total = x, [], None
+        for k in range(P):
+            if k > 0:
+                nxt = torch.empty_like(win)
+                if T > 1:
+                    nxt[:, :T - 1].copy_(win[:, 1:])
+                nxt[:, T - 1].copy_(runs[-1]["acts"][-1])
+                win = nxt
+            mk = None if masks is None else self._pad_masks(masks[k] if many else masks)
+            tape, states = self._stack_forward(win, init_state, mk)
+            hT = states[-1][1]
+            acts = self._head(hT)
+            pred = acts[-1]
+            dP, loss = ops.mse_dense_grad(pred, y[:, k].contiguous(), activation=None, scratch=sc)
+            if self.use_reg:
+                dreg = torch.zeros_like(pred)
+                reg = ops.xyz_sum1_grad(pred.view(B, F // 3, 3), dreg.view(B, F // 3, 3), scratch=sc)   # 0.5 * mean over the B*fps frames
+                w = 0.2 * B * (F // 3)
+                dP.add_(dreg, alpha=w)
+                loss = loss + w * reg
+            total = loss if total is None else ops.act_bwd(loss, loss, base=total, activation=None)
+            runs.append({"tape": tape, "hT": hT, "acts": acts, "dP": dP, "masks": mk})
+        for k in range(P - 1, -1, -1):
+            r = runs[k]      # dP of prediction k is complete: its own loss plus every later window that holds it
+            dpre = ops.act_bwd(r["dP"], r["acts"][-1], activation="tanh")
+            dhT = self._mlp_backward(r["hT"], r["acts"], dpre, accumulate=many)
+            dX = self._stack_backward(r["tape"], dhT, r["masks"], accumulate=many, need_dx0=(k > 0))
+            for j in range(max(1, k - T + 1), k + 1):      # prediction j-1 sits in slot T-1-(k-j) of window k
+                src = runs[j - 1]["dP"]
+                slot = dX[:, T - 1 - (k - j)].contiguous()
+                ops.act_bwd(slot, slot, base=src, activation=None, out=src)
+        return total, runs[-1]["acts"][-1], None, self._state_out(states)
+
+    def forward_backward(self, x, y, init_state=None, masks=None, noise=None, head_masks=None):
         """x (B,T,F), y (B,T_y,3*fps), init_state (L,2,B,H) (c,h) or None.  Fills self.grad; returns
-        (loss (1,), mu (B,3), var (B,3), final state (L,2,B,H)).
+        (loss (1,), mu (B,3), var (B,3), final state (L,2,B,H)) - head_kind 'gmm': (loss, params (B,10n), None, state),
+        'raw': (loss, last predicted second (B,3*fps), None, state).  head_masks: the two dropouts of _GMM_3dgassian
+        [(B,64), (B,128)], pre-scaled; None = the script (tf.layers.dropout without training=True is the identity).
 
         noise None: the predict_len == 1 / is_test graph (lstm.py:430-434), one loss over all of y.
         noise (T_y-1, B, 3*fps) standard normal: the predict_len > 1 training graph (:446-468) - second k+1 is scored
@@ -1669,6 +1822,10 @@ class TFLSTMTrainer:
         is a second SAMPLED around the previous prediction (mean mu, stddev sqrt(var)); losses add up and the gradient
         flows back through the samples (reparameterisation, as TF differentiates tf.random_normal(mean, stddev)).
         `masks` is then a list of T_y per-window mask lists (DropoutWrapper draws a new mask per dynamic_rnn call)."""
+        if self.head_kind == "gmm":
+            return self._fb_gmm(x, y, init_state, masks, head_masks)
+        if self.head_kind == "raw":
+            return self._fb_raw(x, y, init_state, masks)
         sc = self.scratch
         scale = 1.0 / (self.running_length * self.fps)
         init_state = self._pad_state(init_state)
@@ -1710,7 +1867,7 @@ class TFLSTMTrainer:
         last = runs[-1]
         return total, last["head"][1], last["head"][3], unpad(states)
 
-    def train_step(self, x, y, init_state=None, masks=None, noise=None):
-        loss, _, _, state = self.forward_backward(x, y, init_state, masks, noise)
+    def train_step(self, x, y, init_state=None, masks=None, noise=None, head_masks=None):
+        loss, _, _, state = self.forward_backward(x, y, init_state, masks, noise, head_masks)
         ops.rmsprop_tf_step(self.flat, self.grad, self.ms, self.lr, self.decay, self.eps, self.clip)
         return loss, state

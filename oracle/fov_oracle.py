@@ -740,3 +740,164 @@ def fov_hit_rate(pred_xyz, gt_xyz, span_deg=120.0, gt_span_deg=120.0):
     iw = np.minimum(pt + s / 2, gt + gs / 2) - np.maximum(pt - s / 2, gt - gs / 2)
     ih = np.minimum(pp + s / 2, gp + gs / 2) - np.maximum(pp - s / 2, gp - gs / 2)
     return np.where((iw > 0) & (ih > 0), iw * ih / (gs * gs), 0.0)
+
+
+# --------------------------------------------------------------------------------------
+# a10, the branch mycode/config.py:8,69,71 actually selects (use_xyz, predict_mean_var = False, use_GMM = True):
+# the mixture-density head _GMM_3dgassian (lstm.py:377-400) with costfunc.mixture_3d_gaussian_loss
+# (cost.py:486-549, density cost.py:352-383, PSD repair cost.py:335-348), and the third branch (predict raw,
+# lstm.py:147-174,486-508) with costfunc.pred_raw_loss_tf (cost.py:634-641).  TensorFlow-1.x pieces restated from
+# their published definitions (tf.contrib.layers.fully_connected = x W + b then the activation;
+# tf.contrib.distributions.MultivariateNormalFullCovariance.prob = the N(mu, Sigma) density; tf.self_adjoint_eig
+# = ascending eigenvalues): parity unpinned like the rest of the arithmetic; the density is cross-checked
+# against scipy.stats.multivariate_normal in tests/test_oracle.py.
+#
+# Reference quirks kept on purpose (each one changes the numbers):
+#   * tf.layers.dropout(internal, rate=0.2) is called WITHOUT training=True (lstm.py:380,382): it is the
+#     identity in every run of the script.  `masks` exists for a caller who wants the two dropouts.
+#   * mixture_3d_gaussian_loss never multiplies by mixture_pi (cost.py:532-538: `gaussian` is the bare
+#     density, the expanded mixture_pi is dropped; the 2-D loss at cost.py:466 does multiply): the 20
+#     softmax weights get no gradient.  weight_by_pi=True is the textbook mixture.
+#   * process_in_seconds scores only second 0 of y (cost.py:502-505) and divides by
+#     batch_size * running_length * fps whatever the number of frames summed.
+# --------------------------------------------------------------------------------------
+GMM_KEYS = ("fc1_W", "fc1_b", "fc2_W", "fc2_b", "fc3_W", "fc3_b", "fc4_W", "fc4_b")
+
+
+def tf_gmm3d_head(h, head, masks=None, n_mix=20):
+    """_GMM_3dgassian: h (B,H) -> 64 relu -> 128 relu -> 256 relu -> 10*n_mix linear, split
+    [n pi-logits | 3n means | 3n log-sigmas | 3n atanh-rhos].  -> (pi, us, sigmas, rhos), activations (a1,a2,a3)."""
+    a1 = np.maximum(h @ head["fc1_W"] + head["fc1_b"], 0)
+    if masks is not None and masks[0] is not None:
+        a1 = a1 * masks[0]
+    a2 = np.maximum(a1 @ head["fc2_W"] + head["fc2_b"], 0)
+    if masks is not None and masks[1] is not None:
+        a2 = a2 * masks[1]
+    a3 = np.maximum(a2 @ head["fc3_W"] + head["fc3_b"], 0)
+    pred = a3 @ head["fc4_W"] + head["fc4_b"]
+    n = n_mix
+    e = np.exp(pred[:, :n])                       # lstm.py:394-396: exp / sum, no max subtraction
+    pi = e / e.sum(1, keepdims=True)
+    return (pi, pred[:, n:4 * n], np.exp(pred[:, 4 * n:7 * n]), np.tanh(pred[:, 7 * n:10 * n])), (a1, a2, a3)
+
+
+def gmm3d_covariance(sig, rho):
+    """(...,3) sigmas and (...,3) rhos (rho12, rho13, rho23) -> covariance (...,3,3) after the reference's repair
+    (cost.py:335-348): if the smallest eigenvalue is negative, subtract 10 * min_eig * I."""
+    s1, s2, s3 = sig[..., 0], sig[..., 1], sig[..., 2]
+    r12, r13, r23 = rho[..., 0], rho[..., 1], rho[..., 2]
+    S = np.stack([np.stack([s1 * s1, r12 * s1 * s2, r13 * s1 * s3], -1),
+                  np.stack([r12 * s1 * s2, s2 * s2, r23 * s2 * s3], -1),
+                  np.stack([r13 * s1 * s3, r23 * s2 * s3, s3 * s3], -1)], -2)
+    lam = np.linalg.eigvalsh(S)[..., 0]
+    shift = np.where(lam < 0, -10.0 * lam, 0.0)
+    return S + shift[..., None, None] * np.eye(3)
+
+
+def mvn3_prob(y, mu, cov):
+    """N(y; mu, cov) for y (...,3), mu (...,3), cov (...,3,3)."""
+    d = y - mu
+    sol = np.linalg.solve(cov, d[..., None])[..., 0]
+    q = (d * sol).sum(-1)
+    return np.exp(-0.5 * q) / np.sqrt((2 * np.pi) ** 3 * np.linalg.det(cov))
+
+
+def mixture_3d_gaussian_loss(y_true, params, batch_size, running_length, fps=30, process_in_seconds=True,
+                             weight_by_pi=False):
+    """cost.py:486-549.  y_true (B,T_y,3*fps) [process_in_seconds: second 0 only] or (B,T,3) [per frame]."""
+    pi, us, sig, rho = params
+    B, n = pi.shape
+    pts = y_true[:, 0].reshape(B, -1, 3) if process_in_seconds else y_true      # (B,P,3)
+    mu = us.reshape(B, n, 3)                     # us[:, 0::3], [1::3], [2::3] = x, y, z of mixture m
+    cov = gmm3d_covariance(sig.reshape(B, n, 3), rho.reshape(B, n, 3))          # (B,n,3,3)
+    p = mvn3_prob(pts[:, None, :, :], mu[:, :, None, :], cov[:, :, None, :, :])  # (B,n,P)
+    if weight_by_pi:
+        p = p * pi[:, :, None]
+    loss = -np.log(p.sum(1) + 1e-20).sum()
+    return loss / batch_size / (running_length * fps if process_in_seconds else running_length)
+
+
+def sample_mixture_3d(params, u, z):
+    """One draw per frame from the 3-D mixture, what utility.sample_mixture_3D's docstring promises ("randomly one sample
+    from 3D GMM", utility.py:178-208).  The committed function cannot run (pdb.set_trace(), a module-level batch_size
+    that does not exist, 2-D indexing of 3-D parameters, a (B,1,2) result fed to a (B,1,90) placeholder), so the
+    intent is restated: frame f of row b picks component m = first index with cumsum(pi)[m] > u[b,f] and draws
+    mu_m + L_m z[b,f], L_m the Cholesky factor of the repaired covariance.  u (B,P) uniform, z (B,P,3) normal
+    -> (B,1,3*P) interleaved x,y,z."""
+    pi, us, sig, rho = params
+    B, n = pi.shape
+    P = u.shape[1]
+    mu = us.reshape(B, n, 3)
+    L = np.linalg.cholesky(gmm3d_covariance(sig.reshape(B, n, 3), rho.reshape(B, n, 3)))
+    cum = np.cumsum(pi, 1)
+    out = np.empty((B, P, 3), pi.dtype)
+    for b in range(B):
+        for f in range(P):
+            m = min(int(np.searchsorted(cum[b], u[b, f], side="right")), n - 1)
+            out[b, f] = mu[b, m] + L[b, m] @ z[b, f]
+    return out.reshape(B, 1, 3 * P)
+
+
+def tf_lstm_gmm_rollout(x, cells, head, init_state, u, z, forget_bias=1.0):
+    """GMM test loop (lstm.py:690-698,735-745,820-825): only the LAST second is fed (x (B,1,90)), the state is carried,
+    every step predicts the mixture and feeds back one sampled second.  u (P,B,fps), z (P,B,fps,3).
+    -> (samples (P,B,1,90), final state)."""
+    win, st = x.copy(), init_state
+    outs = []
+    for k in range(u.shape[0]):
+        _, st = tf_dynamic_rnn(win, cells, st, forget_bias)
+        params, _ = tf_gmm3d_head(st[-1, 1], head)
+        smp = sample_mixture_3d(params, u[k], z[k])
+        outs.append(smp)
+        win = np.concatenate([win[:, 1:], smp], axis=1)
+    return np.stack(outs), st
+
+
+RAW_KEYS = ("conv1_W", "conv1_b", "conv2_W", "conv2_b", "conv3_W", "conv3_b")
+
+
+def tf_raw_head(h, head):
+    """pred_cnn_model_fn (lstm.py:147-174): three tf.layers.conv1d (k = 5, 'same', relu, relu, tanh; 128, 256, 3*fps
+    filters) on h expanded to ONE time step.  With one step and zero padding only the centre tap k//2 of each kernel
+    (k, C_in, C_out) meets data ("equivalent to 3 fc layers", :151).  -> (B,1,3*fps), activations."""
+    c = head["conv1_W"].shape[0] // 2
+    a1 = np.maximum(h @ head["conv1_W"][c] + head["conv1_b"], 0)
+    a2 = np.maximum(a1 @ head["conv2_W"][c] + head["conv2_b"], 0)
+    out = np.tanh(a2 @ head["conv3_W"][c] + head["conv3_b"])
+    return out[:, None, :], (a1, a2)
+
+
+def total_variation_loss_tf(pred):
+    """cost.py:608-618 on (B,T,3*fps): differences along axis ONE (time steps), not along the frames of a second."""
+    x, y, z = pred[:, :, 0::3], pred[:, :, 1::3], pred[:, :, 2::3]
+    d = (x[:, :-1] - x[:, 1:]) ** 2 + (y[:, :-1] - y[:, 1:]) ** 2 + (z[:, :-1] - z[:, 1:]) ** 2
+    return (d ** 1.25).sum()
+
+
+def sum1reg_tf(pred):
+    """cost.py:622-631: sum (x^2 + y^2 + z^2 - 1)^2."""
+    x, y, z = pred[:, :, 0::3], pred[:, :, 1::3], pred[:, :, 2::3]
+    return ((x * x + y * y + z * z - 1) ** 2).sum()
+
+
+def pred_raw_loss_tf(this_y, pred, use_reg=False):
+    """cost.py:634-641: tf.losses.mean_squared_error (mean over every element) + 0.1 * TV (+ 0.1 * sum-to-one).  In
+    lstm.py every call passes ONE time step (:493-508), so the TV term slices an empty range and is exactly 0."""
+    loss = ((this_y - pred) ** 2).mean() + 0.1 * total_variation_loss_tf(pred)
+    if use_reg:
+        loss = loss + 0.1 * sum1reg_tf(pred)
+    return loss
+
+
+def tf_lstm_raw_refeed_loss(x, y, cells, head, init_state, use_reg=False, forget_bias=1.0):
+    """Training graph of the raw branch, predict_len > 1 (lstm.py:486-508): second k+1 is scored after re-running the
+    stack, from the same fed state, on the window shifted by one second whose last slot is prediction k itself.
+    -> (loss, predictions (P,B,1,3*fps))."""
+    win, preds, loss = x, [], 0.0
+    for k in range(y.shape[1]):
+        _, st = tf_dynamic_rnn(win, cells, init_state, forget_bias)
+        p, _ = tf_raw_head(st[-1, 1], head)
+        loss = loss + pred_raw_loss_tf(y[:, k:k + 1], p, use_reg)
+        preds.append(p)
+        win = np.concatenate([win[:, 1:], p], axis=1)
+    return loss, np.stack(preds)

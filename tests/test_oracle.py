@@ -348,3 +348,116 @@ def test_cpu_baseline_legs_compute_the_same_graphs_as_the_oracle():
     for K, R, b in layers:
         seq = O.convlstm2d_layer(seq, K.astype(np.float64), R.astype(np.float64), b.astype(np.float64))[0]
     assert np.abs(TC.convlstm_encoder_cpu(x, layers, 2) - seq).max() < 2e-6
+
+
+# ---- lstm.py's GMM / raw branches (oracle restatements of TF-1.x pieces; parity unpinned, cross-checked here) ----
+def _gmm_params(rng, B, n, rho_scale):
+    pre = 0.6 * rng.standard_normal((B, 10 * n))
+    pre[:, 7 * n:] += rho_scale * rng.choice([-1.0, 1.0], (B, 3 * n))
+    e = np.exp(pre[:, :n])
+    return e / e.sum(1, keepdims=True), pre[:, n:4 * n], np.exp(pre[:, 4 * n:7 * n] - 0.7), np.tanh(pre[:, 7 * n:])
+
+
+def test_gmm3d_density_against_scipy_and_repair_rule():
+    """mvn3_prob = scipy's multivariate normal density; gmm3d_covariance applies cost.py:335-348 exactly: untouched when the
+    smallest eigenvalue is >= 0, shifted by -10 * min_eig otherwise (new smallest eigenvalue = 9 |min_eig| > 0)."""
+    from scipy.stats import multivariate_normal
+    rng = np.random.default_rng(0)
+    B, n = 6, 20
+    pi, us, sig, rho = _gmm_params(rng, B, n, 1.5)
+    s, r = sig.reshape(B, n, 3), rho.reshape(B, n, 3)
+    cov = O.gmm3d_covariance(s, r)
+    raw = O.gmm3d_covariance(s, 0 * r)          # diagonal: never repaired
+    assert np.allclose(raw, np.eye(3) * (s ** 2)[..., None, :])
+    n_rep = 0
+    for b in range(B):
+        for m in range(n):
+            S = np.array([[s[b, m, 0] ** 2, r[b, m, 0] * s[b, m, 0] * s[b, m, 1], r[b, m, 1] * s[b, m, 0] * s[b, m, 2]],
+                          [r[b, m, 0] * s[b, m, 0] * s[b, m, 1], s[b, m, 1] ** 2, r[b, m, 2] * s[b, m, 1] * s[b, m, 2]],
+                          [r[b, m, 1] * s[b, m, 0] * s[b, m, 2], r[b, m, 2] * s[b, m, 1] * s[b, m, 2], s[b, m, 2] ** 2]])
+            lam = np.linalg.eigvalsh(S)[0]
+            if lam < 0:
+                n_rep += 1
+                assert np.allclose(cov[b, m], S - 10 * lam * np.eye(3))
+                assert abs(np.linalg.eigvalsh(cov[b, m])[0] - 9 * abs(lam)) < 1e-9
+            else:
+                assert np.array_equal(cov[b, m], S)
+            y = rng.uniform(-1, 1, 3)
+            want = multivariate_normal(us.reshape(B, n, 3)[b, m], cov[b, m]).pdf(y)
+            assert abs(O.mvn3_prob(y, us.reshape(B, n, 3)[b, m], cov[b, m]) - want) <= 1e-10 * want + 1e-300
+    assert 10 < n_rep < B * n
+
+
+def test_mixture_3d_gaussian_loss_known_answers():
+    """One mixture, unit sigmas, zero rhos, y = mu: density (2 pi)^-1.5 per frame -> loss = fps * 1.5 log(2 pi) / (running_length
+    * fps) for batch 1; mixture_pi does not enter (cost.py:532-538) unless weight_by_pi; only second 0 is scored."""
+    B, n, fps = 1, 2, 30
+    pi = np.array([[0.25, 0.75]])
+    us = np.zeros((B, 3 * n)); sig = np.ones((B, 3 * n)); rho = np.zeros((B, 3 * n))
+    us[:, 3:] = 50.0          # second component far away: contributes nothing
+    y = np.zeros((B, 4, 3 * fps))
+    y[:, 1:] = 7.0            # later seconds must be ignored
+    got = O.mixture_3d_gaussian_loss(y, (pi, us, sig, rho), batch_size=1, running_length=10, fps=fps)
+    assert abs(got - fps * 1.5 * np.log(2 * np.pi) / (10 * fps)) < 1e-12
+    gw = O.mixture_3d_gaussian_loss(y, (pi, us, sig, rho), 1, 10, fps, weight_by_pi=True)
+    assert abs(gw - fps * (1.5 * np.log(2 * np.pi) - np.log(0.25)) / (10 * fps)) < 1e-12
+    # per-frame layout: (B,T,3), divided by batch * running_length only
+    yf = np.zeros((B, 5, 3))
+    gf = O.mixture_3d_gaussian_loss(yf, (pi, us, sig, rho), 1, 10, fps, process_in_seconds=False)
+    assert abs(gf - 5 * 1.5 * np.log(2 * np.pi) / 10) < 1e-12
+
+
+def test_gmm_head_split_and_raw_head_centre_tap():
+    rng = np.random.default_rng(1)
+    B, H, n = 4, 24, 20
+    dims = [H, 64, 128, 256, 10 * n]
+    head = {}
+    for l in range(4):
+        head["fc%d_W" % (l + 1)] = rng.standard_normal((dims[l], dims[l + 1])) / np.sqrt(dims[l])
+        head["fc%d_b" % (l + 1)] = 0.1 * rng.standard_normal(dims[l + 1])
+    h = rng.standard_normal((B, H))
+    (pi, us, sig, rho), (a1, a2, a3) = O.tf_gmm3d_head(h, head)
+    assert pi.shape == (B, 20) and us.shape == (B, 60) and sig.shape == (B, 60) and rho.shape == (B, 60)
+    assert np.allclose(pi.sum(1), 1) and (sig > 0).all() and (np.abs(rho) < 1).all() and (a3 >= 0).all()
+    m = [(rng.random((B, 64)) < 0.8) / 0.8, None]
+    (pi2, _, _, _), (b1, _, _) = O.tf_gmm3d_head(h, head, masks=m)
+    assert np.array_equal(b1, a1 * m[0]) and not np.allclose(pi2, pi)
+    # raw head: an explicit 'same' conv1d over ONE step equals the centre-tap products
+    rh = {}
+    cd = [H, 128, 256, 90]
+    for l in range(3):
+        rh["conv%d_W" % (l + 1)] = rng.standard_normal((5, cd[l], cd[l + 1])) / np.sqrt(cd[l])
+        rh["conv%d_b" % (l + 1)] = 0.1 * rng.standard_normal(cd[l + 1])
+
+    def conv1d_same(x, w, b):       # x (B,T,C), w (k,C,N): zero padding, cross-correlation (tf.layers.conv1d)
+        k = w.shape[0]
+        xp = np.pad(x, ((0, 0), (k // 2, k // 2), (0, 0)))
+        return np.stack([sum(xp[:, t + j] @ w[j] for j in range(k)) for t in range(x.shape[1])], 1) + b
+
+    z = h[:, None, :]
+    z = np.maximum(conv1d_same(z, rh["conv1_W"], rh["conv1_b"]), 0)
+    z = np.maximum(conv1d_same(z, rh["conv2_W"], rh["conv2_b"]), 0)
+    z = np.tanh(conv1d_same(z, rh["conv3_W"], rh["conv3_b"]))
+    out, _ = O.tf_raw_head(h, rh)
+    assert out.shape == (B, 1, 90) and np.allclose(out, z, atol=1e-13)
+    # pred_raw_loss_tf on one time step: the total-variation term is exactly zero (cost.py:608-618 slices axis 1)
+    y = rng.uniform(-1, 1, (B, 1, 90))
+    assert O.total_variation_loss_tf(out) == 0.0
+    assert abs(O.pred_raw_loss_tf(y, out) - ((y - out) ** 2).mean()) < 1e-15
+    assert O.pred_raw_loss_tf(y, out, use_reg=True) > O.pred_raw_loss_tf(y, out)
+    two = np.concatenate([out, out + 0.1], 1)
+    assert O.total_variation_loss_tf(two) > 0
+
+
+def test_sample_mixture_3d_statistics():
+    """Inverse-CDF component choice + Cholesky draw: a single dominant component reproduces its mean and covariance."""
+    rng = np.random.default_rng(2)
+    B, n, P = 1, 3, 20000
+    pi = np.array([[0.0, 1.0, 0.0]])
+    us = np.array([[9, 9, 9, 0.1, -0.2, 0.3, -9, -9, -9.0]])
+    sig = np.array([[1, 1, 1, 0.5, 0.2, 0.3, 1, 1, 1.0]])
+    rho = np.array([[0, 0, 0, 0.3, -0.2, 0.1, 0, 0, 0.0]])
+    out = O.sample_mixture_3d((pi, us, sig, rho), rng.random((B, P)), rng.standard_normal((B, P, 3))).reshape(P, 3)
+    cov = O.gmm3d_covariance(sig.reshape(1, 3, 3), rho.reshape(1, 3, 3))[0, 1]
+    assert np.abs(out.mean(0) - us[0, 3:6]).max() < 0.02
+    assert np.abs(np.cov(out.T) - cov).max() < 0.01
