@@ -551,6 +551,36 @@ def bench_a10(args, rank, world, use_dist):
         flop3 = 3 * 2.0 * B * T * ((F + 400) * 1600 + (400 + 400) * 1600)
         train[tag] = {"ms": tms, "sequences_per_s": B / (tms * 1e-3), "tflops": flop3 / (tms * 1e-3) / 1e12,
                       "loss": float(tstep()[0].item())}
+    # the same step under the two other branches of lstm.py:424-509 - 'gmm' is what the committed config.py:69,71 trains
+    # (_GMM_3dgassian + mixture_3d_gaussian_loss on second 0 of ten), 'raw' is pred_cnn_model_fn + MSE with predict_len = 1;
+    heads = {}
+    for kind in (("gmm", "raw") if args.head == "all" else () if args.head == "meanvar" else (args.head,)):
+        hrng = np.random.default_rng(13)
+        if kind == "gmm":
+            dims = [400, 64, 128, 256, 200]
+            hw = {}
+            for l in range(4):
+                hw["fc%d_W" % (l + 1)] = (hrng.uniform(-1, 1, (dims[l], dims[l + 1])) * np.sqrt(6.0 / (dims[l] + dims[l + 1]))).astype(np.float32)
+                hw["fc%d_b" % (l + 1)] = np.zeros(dims[l + 1], np.float32)      # tf.contrib fully_connected: xavier weights, zero biases
+            yk = torch.from_numpy(trng.uniform(-1, 1, (B, 10, 90)).astype(np.float32)).cuda()
+        else:
+            dims = [400, 128, 256, 90]
+            hw = {}
+            for l in range(3):
+                hw["conv%d_W" % (l + 1)] = (hrng.uniform(-1, 1, (5, dims[l], dims[l + 1])) * np.sqrt(6.0 / (5 * (dims[l] + dims[l + 1])))).astype(np.float32)
+                hw["conv%d_b" % (l + 1)] = np.zeros(dims[l + 1], np.float32)
+            yk = ty
+        tr = TFLSTMTrainer(cells, hw, lr=1e-5, fps=30, running_length=10, head_kind=kind)
+        tstep = lambda: tr.train_step(tx, yk, tinit)
+        for _ in range(5):
+            tstep()
+        tms = min(event_time_ms(tstep, max(args.steps // 6, 50)) for _ in range(3))
+        tr.ws.check()
+        hflop = 2.0 * B * sum(a * b for a, b in zip(dims[:-1], dims[1:]))
+        heads[kind] = {"ms": tms, "sequences_per_s": B / (tms * 1e-3), "tflops": (flop3 + 3 * hflop) / (tms * 1e-3) / 1e12,
+                       "loss": float(tstep()[0].item()), "head_flop_forward": hflop,
+                       "head_kernels": "device durations of the fused head launches: profiles/r04_a10_%s_train_step_timeline.txt "
+                                       "(HIP events around single ~10 us calls measure the Python caller, not the kernels)" % kind}
     cpu = None
     if rank == 0 and not args.no_cpu_baseline and world == 1:
         from oracle import torch_cpu as TC
@@ -585,7 +615,7 @@ def bench_a10(args, rank, world, use_dist):
             "roofline": {"bound": "mfma", "achieved": r["tflops"], "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": r["tflops"] / PEAK_FP32_MFMA_TFLOPS, **mode_traffic("a10", "f32", r["ms"]),
                          "note": "32 sequences = two tiles = 64 of 256 CUs busy (32 workgroups per tile): latency-bound by construction"},
-            "variants": res, "training_step": train, "cpu_baseline": cpu}), flush=True)
+            "variants": res, "training_step": train, "training_step_other_heads": heads, "cpu_baseline": cpu}), flush=True)
 
 
 def bench_convlstm(args, rank, world, use_dist):
@@ -715,6 +745,8 @@ def main():
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
                     help="bf16: configs[4] - bf16 operands into the MFMA, fp32 accumulate / cell state / master weights "
                          "(modes train_mixing and infer_mixing)")
+    ap.add_argument("--head", default="all", choices=["all", "meanvar", "gmm", "raw"],
+                    help="a10 mode: which of lstm.py's heads to time a training step with besides the mean / variance one")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU-baseline timing (both legs together)")
     ap.add_argument("--cpu-threads", type=int, default=16, help="threads of the CPU-baseline legs (default: one GPU's share of the host)")

@@ -432,7 +432,10 @@ int fov_mlp_head_bwd(const float* x, const float* const* W, const float* const* 
  *   *loss = scale * sum_{b,t} -log(sum_m [pi_m] N_bmt + 1e-20)      (scale = 1 / (batch_size * running_length [* fps]), cost.py:544-549)
  * weight_by_pi = 0 is the reference: cost.py:532-538 never multiplies by mixture_pi, so the softmax weights get no gradient.
  * dpre (B, 10 n_mix) = d loss / d the head's PRE-activations (through softmax / exp / tanh and the eigenvalue repair).  The 3x3
- * work runs in fp64.  n_mix <= 32, n_pts <= 256; workspace >= 4 * B bytes.
+ * work runs in fp64.  n_mix <= 32, n_pts <= 256.  workspace >= 256 + 4 * B bytes, STATEFUL like the exchange workspaces: its first
+ * word is the ticket by which the last workgroup to finish adds the B per-row parts in row order (one launch, run-to-run identical
+ * loss); it must be zero on entry (zero-fill the buffer once), every call leaves it zero, and the buffer must not be shared
+ * with calls on other streams.
  * fov_gmm3d_sample: one draw per frame - component = first m with cumsum(pi)[m] > u (u (B, n_pts) uniform), value mu_m + chol(Sigma'_m) z
  * (z (B, n_pts, 3) normal) -> out rows of 3 n_pts floats, ldo apart: what utility.sample_mixture_3D (utility.py:178-208) documents and
  * the GMM test loop (lstm.py:735-745,820-825) feeds back; the committed function itself stops in pdb and indexes two dimensions. */

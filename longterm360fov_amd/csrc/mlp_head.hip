@@ -15,6 +15,23 @@
 
 namespace fov {
 
+// Diagnostic build only (-DFOV_STAMPS, tools/microbench/head_stamps.py): s_memtime stamps of wave 0 of workgroup 0.
+#ifdef FOV_STAMPS
+__device__ unsigned long long g_mh_stamps[3][48];
+#define MH_STAMP(kern, slot)                                                                   \
+    do {                                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                     \
+        if (blockIdx.x == 0 && threadIdx.x == 0) {                                             \
+            unsigned long long t_;                                                             \
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); \
+            g_mh_stamps[kern][slot] = t_;                                                      \
+        }                                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                     \
+    } while (0)
+#else
+#define MH_STAMP(kern, slot) do { } while (0)
+#endif
+
 namespace {
 
 constexpr int MH_NT = 512;        // threads per workgroup (forward and backward chain)
@@ -22,7 +39,6 @@ constexpr int MH_ROWS = 4;        // rows a workgroup carries through the chain
 constexpr int MH_MAXL = 4;        // layers at most
 constexpr int MH_MAXD = 512;      // width of any layer's OUTPUT at most
 constexpr int MH_MAXD0 = 2048;    // width of the input x at most (lstm.py's n_hidden, padded or not)
-constexpr int MH_TILE = 26 * 1024;   // floats of one transposed weight tile in the backward chain (104 KB of LDS)
 constexpr int GM_MAXMIX = 32;     // mixture components at most
 constexpr int GM_MAXPTS = 256;    // scored frames per row at most
 
@@ -49,78 +65,144 @@ __device__ __forceinline__ float mh_dact(float y, int act) {      // derivative 
     return act == 1 ? 1.f - y * y : act == 2 ? (y > 0.f ? 1.f : 0.f) : act == 3 ? y : 1.f;
 }
 
-// Forward.  Layer l: thread (col, ks) = (tid % cp, tid / cp), cp = the layer's width rounded up to 64 (at most the block), so a
-// wave holds one k-slice and 64 neighbouring columns: W reads are coalesced over col, the rows' inputs come from LDS as a
-// broadcast, the k-slices meet in LDS in a fixed order.
-__global__ __launch_bounds__(MH_NT) void mlp_head_fwd_kernel(MlpParams p) {
-    __shared__ __attribute__((aligned(16))) float xin[MH_ROWS * MH_MAXD0];
-    __shared__ __attribute__((aligned(16))) float bufA[MH_ROWS * MH_MAXD];
-    __shared__ __attribute__((aligned(16))) float bufB[MH_ROWS * MH_MAXD];
-    __shared__ float red[MH_ROWS * MH_NT];
-    const int tid = threadIdx.x, row0 = blockIdx.x * MH_ROWS;
-    const float* in = xin;
-    int istr = MH_MAXD0;              // row stride of `in`
-    float* out = bufA;
-    {
-        const int D0 = p.D[0];
-        for (int e = tid; e < MH_ROWS * D0; e += MH_NT) {
-            const int r = e / D0, k = e - r * D0;
-            xin[r * MH_MAXD0 + k] = (row0 + r < p.B) ? p.x[(size_t)(row0 + r) * D0 + k] : 0.f;
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));   // a 16-byte global access that may start on any float
+
+static_assert(MH_NT == MH_MAXD, "the forward stages one bias per thread and layer");
+constexpr int MH_PF = 16;         // forward: weight vectors a thread holds in flight (one batch of loads)
+constexpr int MH_FWD_LDS = MH_ROWS * MH_MAXD0 + 2 * MH_ROWS * MH_MAXD + 4 * MH_ROWS * MH_NT + MH_MAXL * MH_MAXD;   // floats: x | ping | pong | partial sums | biases
+
+// Forward.  Layer l: thread (c4, ks) = (tid % cgp, tid / cgp) owns FOUR neighbouring columns (one 16-byte weight load per k) and the
+// k-slice ks; cgp = the number of column groups rounded up to a power of two, so the block splits into 512 / cgp slices (32 at
+// width 64, 8 at width 200..256): a thread's whole slice is ONE batch of at most sixteen independent loads - the chain is bound by
+// load latency, not bandwidth - and the next layer's batch is issued before this layer's slices are summed, so it flies
+// behind the reduction.  The rows' inputs come from LDS as broadcasts, the k-slices meet in LDS in a fixed order.
+struct FwdMap { int Din, Dout, cgp, KS, c4, ks, k0, k1; };
+
+__device__ __forceinline__ FwdMap fwd_map(const MlpParams& p, int l, int tid) {
+    FwdMap m;
+    m.Din = p.D[l]; m.Dout = p.D[l + 1];
+    const int cg = (m.Dout + 3) >> 2;
+    m.cgp = 16;
+    while (m.cgp < cg) m.cgp <<= 1;
+    m.KS = MH_NT / m.cgp;
+    m.c4 = tid % m.cgp; m.ks = tid / m.cgp;
+    const int kc = (((m.Din + m.KS - 1) / m.KS) + 3) & ~3;
+    m.k0 = m.ks * kc;
+    m.k1 = (m.k0 + kc < m.Din) ? m.k0 + kc : m.Din;
+    return m;
+}
+
+// w[u] = W[kb + u][4 c4 .. 4 c4 + 3]; rows at or beyond k1 and columns beyond the layer give zeros
+__device__ __forceinline__ void fwd_load(const float* __restrict__ W, const FwdMap& m, int kb, f32x4 (&w)[MH_PF]) {
+    const int col = 4 * m.c4;
+#pragma unroll
+    for (int u = 0; u < MH_PF; ++u) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        const int k = kb + u;
+        if (k < m.k1 && col < m.Dout) {
+            const float* src = W + (size_t)k * m.Dout + col;
+            if (col + 3 < m.Dout) v = *reinterpret_cast<const f32x4u*>(src);
+            else {
+                v[0] = src[0];
+                if (col + 1 < m.Dout) v[1] = src[1];
+                if (col + 2 < m.Dout) v[2] = src[2];
+            }
         }
+        w[u] = v;
+    }
+}
+
+__global__ __launch_bounds__(MH_NT) void mlp_head_fwd_kernel(MlpParams p) {
+    extern __shared__ __attribute__((aligned(16))) float mh_lds[];
+    float* xin = mh_lds;                                  // [MH_ROWS][MH_MAXD0]
+    float* bufA = xin + MH_ROWS * MH_MAXD0;               // [MH_ROWS][MH_MAXD]
+    float* bufB = bufA + MH_ROWS * MH_MAXD;
+    float* red = bufB + MH_ROWS * MH_MAXD;                // [KS][MH_ROWS][cgp][4] = 4 * MH_ROWS * MH_NT floats
+    float* bias = red + 4 * MH_ROWS * MH_NT;              // [MH_MAXL][MH_MAXD]
+    const int tid = threadIdx.x, row0 = blockIdx.x * MH_ROWS;
+    MH_STAMP(0, 0);
+    FwdMap m = fwd_map(p, 0, tid);
+    f32x4 w[MH_PF];
+    fwd_load(p.W[0], m, m.k0, w);                         // in flight while x and the biases are staged
+    {
+        // x and every bias, all loads issued before the first is waited for.  (A bias read inside a layer's reduction would queue
+        // BEHIND the next layer's prefetched weights - loads return in order - and put their latency back on the critical path.)
+        const int D0 = p.D[0], D0p = (D0 + 3) & ~3;       // the pad up to a multiple of four is read (times a zero weight): keep it finite
+        float xv[MH_ROWS * MH_MAXD0 / MH_NT], bv[MH_MAXL];
+#pragma unroll
+        for (int u = 0; u < MH_ROWS * MH_MAXD0 / MH_NT; ++u) {
+            const int e = u * MH_NT + tid, r = e / D0p, k = e - r * D0p;
+            xv[u] = (e < MH_ROWS * D0p && row0 + r < p.B && k < D0) ? p.x[(size_t)(row0 + r) * D0 + k] : 0.f;
+        }
+#pragma unroll
+        for (int l = 0; l < MH_MAXL; ++l) bv[l] = (l < p.L && tid < p.D[l + 1]) ? p.b[l][tid] : 0.f;
+#pragma unroll
+        for (int u = 0; u < MH_ROWS * MH_MAXD0 / MH_NT; ++u) {
+            const int e = u * MH_NT + tid, r = e / D0p, k = e - r * D0p;
+            if (e < MH_ROWS * D0p) xin[r * MH_MAXD0 + k] = xv[u];
+        }
+#pragma unroll
+        for (int l = 0; l < MH_MAXL; ++l) bias[l * MH_MAXD + tid] = bv[l];      // MH_NT == MH_MAXD: one bias per thread and layer
     }
     __syncthreads();
+    MH_STAMP(0, 1);
+    const float* in = xin;
+    int istr = MH_MAXD0;
+    float* out = bufA;
     for (int l = 0; l < p.L; ++l) {
-        const int Din = p.D[l], Dout = p.D[l + 1];
         const float* __restrict__ W = p.W[l];
-        int cp = (Dout + 63) & ~63;
-        if (cp > MH_NT) cp = MH_NT;
-        const int KS = MH_NT / cp;                      // k-slices (threads beyond KS * cp idle in this layer)
-        const int c = tid % cp, ks = tid / cp;
-        const int kc = (((Din + KS - 1) / KS) + 3) & ~3;
-        const int k0 = ks * kc, k1 = (k0 + kc < Din) ? k0 + kc : Din;
         const bool last = (l == p.L - 1);
-        for (int col0 = 0; col0 < Dout; col0 += cp) {
-            const int col = col0 + c;
-            float acc[MH_ROWS] = {0.f, 0.f, 0.f, 0.f};
-            if (ks < KS && col < Dout) {
-                int k = k0;
-                for (; k + 8 <= k1; k += 8) {
-                    float w[8];
+        f32x4 acc[MH_ROWS];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) w[u] = W[(size_t)(k + u) * Dout + col];
+        for (int r = 0; r < MH_ROWS; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int kb = m.k0; kb < m.k1; kb += MH_PF) {
+            if (kb != m.k0) fwd_load(W, m, kb, w);
+#pragma unroll
+            for (int u4 = 0; u4 < MH_PF / 4; ++u4) {
+                const int k = kb + 4 * u4;
+                if (k < m.k1) {
 #pragma unroll
                     for (int r = 0; r < MH_ROWS; ++r) {
-                        const f32x4 x0 = *reinterpret_cast<const f32x4*>(in + r * istr + k);
-                        const f32x4 x1 = *reinterpret_cast<const f32x4*>(in + r * istr + k + 4);
-                        acc[r] = fmaf(x0[0], w[0], acc[r]); acc[r] = fmaf(x0[1], w[1], acc[r]);
-                        acc[r] = fmaf(x0[2], w[2], acc[r]); acc[r] = fmaf(x0[3], w[3], acc[r]);
-                        acc[r] = fmaf(x1[0], w[4], acc[r]); acc[r] = fmaf(x1[1], w[5], acc[r]);
-                        acc[r] = fmaf(x1[2], w[6], acc[r]); acc[r] = fmaf(x1[3], w[7], acc[r]);
+                        const f32x4 x4 = *reinterpret_cast<const f32x4*>(in + r * istr + k);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) acc[r] += x4[q] * w[4 * u4 + q];
                     }
                 }
-                for (; k < k1; ++k) {
-                    const float w = W[(size_t)k * Dout + col];
-#pragma unroll
-                    for (int r = 0; r < MH_ROWS; ++r) acc[r] = fmaf(in[r * istr + k], w, acc[r]);
-                }
             }
-            if (ks < KS)
-#pragma unroll
-                for (int r = 0; r < MH_ROWS; ++r) red[(ks * MH_ROWS + r) * cp + c] = acc[r];
-            __syncthreads();
-            for (int e = tid; e < MH_ROWS * cp; e += MH_NT) {
-                const int r = e / cp, cc = e - r * cp, oc = col0 + cc, row = row0 + r;
-                if (oc < Dout) {
-                    float v = p.b[l][oc];
-                    for (int q = 0; q < KS; ++q) v += red[(q * MH_ROWS + r) * cp + cc];      // fixed order
-                    if (!(last && p.final_mode)) v = mh_act(v, p.act[l]);
-                    if (p.mask[l] && row < p.B) v *= p.mask[l][(size_t)row * Dout + oc];
-                    out[r * MH_MAXD + oc] = v;
-                    if (row < p.B && !(last && p.final_mode)) p.a[l][(size_t)row * Dout + oc] = v;
-                }
-            }
-            __syncthreads();
         }
+        MH_STAMP(0, 2 + 4 * l);
+#pragma unroll
+        for (int r = 0; r < MH_ROWS; ++r) *reinterpret_cast<f32x4*>(red + ((m.ks * MH_ROWS + r) * m.cgp + m.c4) * 4) = acc[r];
+        const int Dout = m.Dout, KS = m.KS, cgp = m.cgp;
+        if (!last) {                                      // the next layer's first batch flies behind this layer's barrier and reduction
+            m = fwd_map(p, l + 1, tid);
+            fwd_load(p.W[l + 1], m, m.k0, w);
+        }
+        __syncthreads();
+        MH_STAMP(0, 3 + 4 * l);
+        const int Dp = (Dout + 3) & ~3;
+        for (int e = tid; e < MH_ROWS * Dp; e += MH_NT) {
+            const int r = e / Dp, oc = e - r * Dp, row = row0 + r;
+            float v = 0.f;
+            if (oc < Dout) {
+                v = bias[l * MH_MAXD + oc];
+                const float* rp = red + (r * cgp + (oc >> 2)) * 4 + (oc & 3);
+                const int qs = MH_ROWS * cgp * 4;
+                int q = 0;
+                for (; q + 4 <= KS; q += 4) {             // fixed order; four independent LDS reads in flight (KS is a power of two >= 4)
+                    const float t0 = rp[q * qs], t1 = rp[(q + 1) * qs], t2 = rp[(q + 2) * qs], t3 = rp[(q + 3) * qs];
+                    v += t0; v += t1; v += t2; v += t3;
+                }
+                for (; q < KS; ++q) v += rp[q * qs];
+                if (!(last && p.final_mode)) v = mh_act(v, p.act[l]);
+                if (p.mask[l] && row < p.B) v *= p.mask[l][(size_t)row * Dout + oc];
+                if (row < p.B && !(last && p.final_mode)) p.a[l][(size_t)row * Dout + oc] = v;
+            }
+            out[r * MH_MAXD + oc] = v;
+        }
+        MH_STAMP(0, 4 + 4 * l);
+        __syncthreads();
+        MH_STAMP(0, 5 + 4 * l);
         in = out;
         istr = MH_MAXD;
         out = (out == bufA) ? bufB : bufA;
@@ -142,79 +224,193 @@ __global__ __launch_bounds__(MH_NT) void mlp_head_fwd_kernel(MlpParams p) {
             p.a[p.L - 1][(size_t)row * Dl + j] = y;
         }
     }
+    MH_STAMP(0, 20);
 }
 
-// Backward chain for four rows: d_{l-1}[r][i] = act'(a_{l-1}[r][i]) mask_{l-1}[r][i] sum_j d_l[r][j] W_l[i][j].  W_l is read in
-// tiles of whole rows (a contiguous, coalesced block of global memory) into LDS with an odd row stride; thread (i, js) then
-// walks its j-slice of row i: lanes differ in i, so their LDS addresses differ by an odd stride - no bank conflict.
+// Backward chain for four rows: d_{l-1}[r][i] = act'(a_{l-1}[r][i]) mask_{l-1}[r][i] sum_j d_l[r][j] W_l[i][j] - a product ALONG the
+// rows of W_l with the lanes ACROSS them, i.e. against the grain of memory.  W_l is therefore read in tiles of whole rows (one
+// contiguous block, 16-byte loads, the next tile already in registers while this one is used) and laid into LDS with a row
+// stride S, S / 4 odd: sixteen neighbouring rows then start in sixteen different 16-byte bank slots, so a lane reads four
+// neighbouring j of ITS row as one conflict-free ds_read_b128.  The gradients sit in LDS transposed, dT[j] = the four rows' d at
+// j (one ds_read_b128 for all lanes of a wave).  Thread (il, js) owns a 4 x 4 register block per step: rows il + {0,1,2,3} IC/4
+// of the tile, four j of its slice js, the four batch rows - eight LDS reads feed 64 multiply-adds.  Slices meet in LDS, fixed order.
+constexpr int CH_JQ = 4;          // 4-wide j steps of a slice whose gradients are held in registers (slices are 8 .. 16 wide)
+constexpr int CH_PF = 13;         // 16-byte vectors of a tile per thread: 13 * 4 * 512 = 26624 floats
+constexpr int CH_TILE = 128 * 204;                        // floats of a tile: 128 rows of the 200-wide mixture layer (S = 204)
+constexpr int CH_LDS = CH_TILE + 16 * MH_NT + 2 * MH_ROWS * MH_MAXD;      // tile | slice sums | dT ping | dT pong
+
+struct ChTile { int l, i0, IC, rows, Dout, S, cnt; const float* src; };
+
+__device__ __forceinline__ ChTile ch_tile(const MlpParams& p, int l, int i0) {
+    ChTile t;
+    t.l = l; t.i0 = i0;
+    const int Din = p.D[l];
+    t.Dout = p.D[l + 1];
+    const int D4 = (t.Dout + 3) & ~3;
+    t.S = (D4 & 4) ? D4 : D4 + 4;                         // multiple of four with S / 4 odd
+    t.IC = l > 0 ? 128 : MH_NT;                           // rows of W per tile: the largest of 512 (layer 0) / 128, ..., 32 that fits the
+    while (t.IC > 32 && (t.IC * t.S > CH_TILE || t.IC >= 2 * Din)) t.IC >>= 1;      // tile and is not twice the layer
+    t.rows = (Din - i0 < t.IC) ? Din - i0 : t.IC;
+    t.cnt = t.rows * t.Dout;
+    t.src = p.W[l] + (size_t)i0 * t.Dout;
+    return t;
+}
+
+__device__ __forceinline__ void ch_load(const ChTile& t, int tid, f32x4 (&g)[CH_PF]) {
+#pragma unroll
+    for (int v = 0; v < CH_PF; ++v) {
+        const int e = (v * MH_NT + tid) * 4;
+        f32x4 x = {0.f, 0.f, 0.f, 0.f};
+        if (e + 3 < t.cnt) x = *reinterpret_cast<const f32x4u*>(t.src + e);
+        else if (e < t.cnt) {
+            x[0] = t.src[e];
+            if (e + 1 < t.cnt) x[1] = t.src[e + 1];
+            if (e + 2 < t.cnt) x[2] = t.src[e + 2];
+        }
+        g[v] = x;
+    }
+}
+
+__device__ __forceinline__ void ch_store(const ChTile& t, int tid, const f32x4 (&g)[CH_PF], float* __restrict__ wt) {
+    const bool vec = (t.Dout & 3) == 0;                   // four consecutive elements never straddle a row
+#pragma unroll
+    for (int v = 0; v < CH_PF; ++v) {
+        const int e = (v * MH_NT + tid) * 4;
+        if (e < t.cnt) {
+            int i = e / t.Dout, j = e - i * t.Dout;
+            if (vec) *reinterpret_cast<f32x4*>(wt + i * t.S + j) = g[v];
+            else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (e + q < t.cnt) wt[i * t.S + j] = g[v][q];
+                    if (++j == t.Dout) { j = 0; ++i; }
+                }
+            }
+        }
+    }
+    if (!vec)                                             // columns Dout .. the next multiple of four are read (times a zero gradient)
+        for (int e = tid; e < t.rows * 4; e += MH_NT) {
+            const int i = e >> 2, j = t.Dout + (e & 3);
+            if (j < ((t.Dout + 3) & ~3)) wt[i * t.S + j] = 0.f;
+        }
+}
+
 __global__ __launch_bounds__(MH_NT) void mlp_head_bwd_chain_kernel(MlpParams p) {
     extern __shared__ __attribute__((aligned(16))) float mh_lds[];
-    float* wt = mh_lds;                                   // [MH_TILE]
-    float* bufA = wt + MH_TILE;                           // [MH_ROWS][MH_MAXD]
+    float* wt = mh_lds;                                   // [CH_TILE]
+    float* red = wt + CH_TILE;                            // [JS][IC][4] = 16 * MH_NT floats
+    float* bufA = red + 16 * MH_NT;                       // dT: [MH_MAXD][MH_ROWS]
     float* bufB = bufA + MH_ROWS * MH_MAXD;
-    float* red = bufB + MH_ROWS * MH_MAXD;                // [MH_ROWS][MH_NT]
     const int tid = threadIdx.x, row0 = blockIdx.x * MH_ROWS;
+    const int lmin = p.dx ? 0 : 1;                        // layer 0's product is only needed for dx
+    if (p.L - 1 < lmin) return;
+    MH_STAMP(1, 0);
+    ChTile t = ch_tile(p, p.L - 1, 0);
+    f32x4 g[CH_PF];
+    ch_load(t, tid, g);
     float* dcur = bufA;
     float* dnew = bufB;
     {
-        const int Dl = p.D[p.L];
-        for (int e = tid; e < MH_ROWS * Dl; e += MH_NT) {
-            const int r = e / Dl, j = e - r * Dl;
-            dcur[r * MH_MAXD + j] = (row0 + r < p.B) ? p.dlast[(size_t)(row0 + r) * Dl + j] : 0.f;
+        const int Dl = p.D[p.L], Dlp = (Dl + 3) & ~3;
+        for (int e = tid; e < MH_ROWS * Dlp; e += MH_NT) {
+            const int j = e >> 2, r = e & 3;
+            dcur[e] = (row0 + r < p.B && j < Dl) ? p.dlast[(size_t)(row0 + r) * Dl + j] : 0.f;
         }
     }
-    __syncthreads();
-    for (int l = p.L - 1; l >= 0; --l) {
-        if (l == 0 && !p.dx) break;
-        const int Din = p.D[l], Dout = p.D[l + 1];
-        const float* __restrict__ W = p.W[l];
-        const int stride = Dout | 1;
-        int IC = MH_NT;                                   // rows of W per tile: the largest of 512, 256, ..., 32 that fits the
-        while (IC > 32 && (IC * stride > MH_TILE || IC >= 2 * Din)) IC >>= 1;      // tile and is not twice the layer
-        const int JS = MH_NT / IC;                        // j-slices
-        const int il = tid % IC, js = tid / IC;
-        const int jc = (Dout + JS - 1) / JS;
-        const int j0 = js * jc, j1 = (j0 + jc < Dout) ? j0 + jc : Dout;
-        for (int i0 = 0; i0 < Din; i0 += IC) {
-            const int rows = (Din - i0 < IC) ? Din - i0 : IC;
-            const float* __restrict__ src = W + (size_t)i0 * Dout;
-            for (int e = tid; e < rows * Dout; e += MH_NT) {
-                const int i = e / Dout, j = e - i * Dout;
-                wt[i * stride + j] = src[e];
-            }
-            __syncthreads();
-            float acc[MH_ROWS] = {0.f, 0.f, 0.f, 0.f};
-            if (js < JS && il < rows) {
-                const float* wrow = wt + il * stride;
-                for (int j = j0; j < j1; ++j) {
-                    const float w = wrow[j];
-#pragma unroll
-                    for (int r = 0; r < MH_ROWS; ++r) acc[r] = fmaf(dcur[r * MH_MAXD + j], w, acc[r]);
-                }
-            }
-            if (js < JS)
-#pragma unroll
-                for (int r = 0; r < MH_ROWS; ++r) red[(js * MH_ROWS + r) * IC + il] = acc[r];
-            __syncthreads();
-            for (int e = tid; e < MH_ROWS * rows; e += MH_NT) {
-                const int r = e / rows, ii = e - r * rows, i = i0 + ii, row = row0 + r;
-                float v = 0.f;
-                for (int q = 0; q < JS; ++q) v += red[(q * MH_ROWS + r) * IC + ii];
-                if (l > 0) {
-                    if (row < p.B) {
-                        v *= mh_dact(p.a[l - 1][(size_t)row * Din + i], p.act[l - 1]);
-                        if (p.mask[l - 1]) v *= p.mask[l - 1][(size_t)row * Din + i];
-                        p.d[l - 1][(size_t)row * Din + i] = v;
-                    } else v = 0.f;
-                    dnew[r * MH_MAXD + i] = v;
-                } else if (row < p.B) {
-                    p.dx[(size_t)row * Din + i] = v;
-                }
-            }
-            __syncthreads();
+    int n_tile = 0;
+    for (;;) {
+        MH_STAMP(1, 1 + 5 * n_tile);
+        ch_store(t, tid, g, wt);
+        const int l = t.l, Din = p.D[l], Dout = t.Dout, IC = t.IC, rows = t.rows, i0 = t.i0, S = t.S;
+        // what the tile's outputs are multiplied with: act'(a_{l-1}) mask_{l-1} of output (i, r) = thread - in flight during the tile
+        float fac = 1.f;
+        if (l > 0) {
+            const int i = i0 + (tid >> 2), row = row0 + (tid & 3);
+            if ((tid >> 2) < rows && row < p.B) {
+                fac = mh_dact(p.a[l - 1][(size_t)row * Din + i], p.act[l - 1]);
+                if (p.mask[l - 1]) fac *= p.mask[l - 1][(size_t)row * Din + i];
+            } else fac = 0.f;
         }
-        float* t = dcur; dcur = dnew; dnew = t;
+        MH_STAMP(1, 2 + 5 * n_tile);
+        __syncthreads();
+        MH_STAMP(1, 3 + 5 * n_tile);
+        const bool layer_done = (i0 + IC >= Din);
+        const bool more = !layer_done || l - 1 >= lmin;
+        if (more) {                                       // the next tile: more rows of this layer, else the layer below
+            t = layer_done ? ch_tile(p, l - 1, 0) : ch_tile(p, l, i0 + IC);
+            ch_load(t, tid, g);
+        }
+        const int IC4 = IC >> 2, JS = MH_NT / IC4;
+        const int il = tid % IC4, js = tid / IC4;
+        const int jc = (((Dout + JS - 1) / JS) + 3) & ~3;
+        const int D4 = (Dout + 3) & ~3;
+        const int j0 = js * jc, j1 = (j0 + jc < D4) ? j0 + jc : D4;
+        f32x4 acc[4];
+#pragma unroll
+        for (int ib = 0; ib < 4; ++ib) acc[ib] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const float* wr = wt + il * S;
+        if (jc <= 4 * CH_JQ) {                            // the slice's gradients: 16 j x 4 rows in registers, read once per tile
+            f32x4 dq[4 * CH_JQ];
+#pragma unroll
+            for (int q = 0; q < 4 * CH_JQ; ++q)
+                dq[q] = (j0 + q < j1) ? *reinterpret_cast<const f32x4*>(dcur + (j0 + q) * MH_ROWS) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int jq = 0; jq < CH_JQ; ++jq) {
+                const int j = j0 + 4 * jq;
+                if (j < j1) {
+#pragma unroll
+                    for (int ib = 0; ib < 4; ++ib) {
+                        const f32x4 w = *reinterpret_cast<const f32x4*>(wr + ib * IC4 * S + j);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) acc[ib] += w[q] * dq[4 * jq + q];
+                    }
+                }
+            }
+        } else {
+            for (int j = j0; j < j1; j += 4) {
+                f32x4 dq[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) dq[q] = *reinterpret_cast<const f32x4*>(dcur + (j + q) * MH_ROWS);
+#pragma unroll
+                for (int ib = 0; ib < 4; ++ib) {
+                    const f32x4 w = *reinterpret_cast<const f32x4*>(wr + ib * IC4 * S + j);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc[ib] += w[q] * dq[4 * 0 + q];
+                }
+            }
+        }
+#pragma unroll
+        for (int ib = 0; ib < 4; ++ib) *reinterpret_cast<f32x4*>(red + (js * IC + il + ib * IC4) * 4) = acc[ib];
+        MH_STAMP(1, 4 + 5 * n_tile);
+        __syncthreads();
+        for (int e = tid; e < rows * MH_ROWS; e += MH_NT) {     // output (i, r) = e: one per thread up to 128 rows (every layer but 0)
+            const int ii = e >> 2, r = e & 3, i = i0 + ii, row = row0 + r;
+            float v = 0.f;
+            for (int q = 0; q < JS; q += 4) {             // fixed order; JS is a multiple of four (8 .. 32)
+                const float t0 = red[(q * IC) * 4 + e], t1 = red[((q + 1) * IC) * 4 + e], t2 = red[((q + 2) * IC) * 4 + e],
+                            t3 = red[((q + 3) * IC) * 4 + e];
+                v += t0; v += t1; v += t2; v += t3;
+            }
+            if (l > 0) {
+                v *= fac;                                 // rows <= 128 there: e == tid
+                if (row < p.B) p.d[l - 1][(size_t)row * Din + i] = v;
+                dnew[i * MH_ROWS + r] = v;
+            } else if (row < p.B) {
+                p.dx[(size_t)row * Din + i] = v;
+            }
+        }
+        if (l > 0 && layer_done && (Din & 3) && tid < 16) {     // zero pad of the next layer's 16-byte reads
+            const int j = Din + (tid >> 2);
+            if (j < ((Din + 3) & ~3)) dnew[j * MH_ROWS + (tid & 3)] = 0.f;
+        }
+        MH_STAMP(1, 5 + 5 * n_tile);
+        __syncthreads();
+        ++n_tile;
+        (void)n_tile;
+        if (!more) break;
+        if (layer_done) { float* s_ = dcur; dcur = dnew; dnew = s_; }
     }
+    MH_STAMP(1, 1 + 5 * n_tile);
 }
 
 // Weight and bias gradients of every layer in one launch: workgroup (l, i0) owns eight rows i of gW_l, thread j a column:
@@ -245,12 +441,12 @@ __global__ __launch_bounds__(256) void mlp_head_wgrad_kernel(MlpParams p, int bl
             __syncthreads();
             if (j < Dout) {
                 int n = 0;
-                for (; n + 4 <= nn; n += 4) {
-                    float dv[4];
+                for (; n + 8 <= nn; n += 8) {
+                    float dv[8];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) dv[q] = dl[(size_t)(n0 + n + q) * Dout + j];
+                    for (int q = 0; q < 8; ++q) dv[q] = dl[(size_t)(n0 + n + q) * Dout + j];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
+                    for (int q = 0; q < 8; ++q) {
                         accb += dv[q];
 #pragma unroll
                         for (int u = 0; u < WG_IR; ++u) acc[u] = fmaf(as[n + q][u], dv[q], acc[u]);
@@ -310,6 +506,8 @@ __device__ void sym3_min_eig(const Sym3& S, double& lam, double (&v)[3]) {
     double a[3][3] = {{S.a00, S.a01, S.a02}, {S.a01, S.a11, S.a12}, {S.a02, S.a12, S.a22}};
     double V[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
     for (int sweep = 0; sweep < 6; ++sweep) {
+        const double off = fabs(a[0][1]) + fabs(a[0][2]) + fabs(a[1][2]);
+        if (off <= 1e-18 * (fabs(a[0][0]) + fabs(a[1][1]) + fabs(a[2][2]))) break;      // diagonal to fp64: usually after 3-4 sweeps
         jacobi_rot<0, 1>(a, V);
         jacobi_rot<0, 2>(a, V);
         jacobi_rot<1, 2>(a, V);
@@ -336,12 +534,23 @@ __device__ void mix_setup(const float* __restrict__ prm, int n, int m, MixSetup&
     const double s1 = prm[4 * n + 3 * m], s2 = prm[4 * n + 3 * m + 1], s3 = prm[4 * n + 3 * m + 2];
     const double r12 = prm[7 * n + 3 * m], r13 = prm[7 * n + 3 * m + 1], r23 = prm[7 * n + 3 * m + 2];
     Sym3 S = {s1 * s1, r12 * s1 * s2, r13 * s1 * s3, s2 * s2, r23 * s2 * s3, s3 * s3};
-    double lam;
-    sym3_min_eig(S, lam, o.v);
-    o.repaired = lam < 0.0;
-    if (o.repaired) { const double k = -10.0 * lam; S.a00 += k; S.a11 += k; S.a22 += k; }
-    const double c00 = S.a11 * S.a22 - S.a12 * S.a12, c01 = S.a02 * S.a12 - S.a01 * S.a22, c02 = S.a01 * S.a12 - S.a02 * S.a11;
-    const double det = S.a00 * c00 + S.a01 * c01 + S.a02 * c02;
+    double c00 = S.a11 * S.a22 - S.a12 * S.a12, c01 = S.a02 * S.a12 - S.a01 * S.a22, c02 = S.a01 * S.a12 - S.a02 * S.a11;
+    double det = S.a00 * c00 + S.a01 * c01 + S.a02 * c02;
+    // Sylvester: all leading minors positive <=> positive definite <=> smallest eigenvalue > 0: no repair, and the eigen-decomposition
+    // (dependent fp64 divisions and square roots, most of this kernel's time) is only run for the matrices that need it
+    o.repaired = 0;
+    o.v[0] = o.v[1] = o.v[2] = 0.0;
+    if (!(S.a00 > 0.0 && S.a00 * S.a11 - S.a01 * S.a01 > 0.0 && det > 0.0)) {
+        double lam;
+        sym3_min_eig(S, lam, o.v);
+        o.repaired = lam < 0.0;
+        if (o.repaired) {
+            const double k = -10.0 * lam;
+            S.a00 += k; S.a11 += k; S.a22 += k;
+            c00 = S.a11 * S.a22 - S.a12 * S.a12; c01 = S.a02 * S.a12 - S.a01 * S.a22; c02 = S.a01 * S.a12 - S.a02 * S.a11;
+            det = S.a00 * c00 + S.a01 * c01 + S.a02 * c02;
+        }
+    }
     const double id = 1.0 / det;
     o.P[0] = c00 * id; o.P[1] = c01 * id; o.P[2] = c02 * id;
     o.P[3] = (S.a00 * S.a22 - S.a02 * S.a02) * id;
@@ -358,20 +567,28 @@ __device__ void mix_setup(const float* __restrict__ prm, int n, int m, MixSetup&
 // costfunc.mixture_3d_gaussian_loss and its gradient at the head's PRE-activations, one workgroup per row.
 //   part[b] = sum_t -log(S_t + 1e-20),  S_t = sum_m [pi_m] N(y_t; mu_m, Sigma'_m);   loss = scale * sum_b part[b]
 //   dpre (B, 10 n): zero for the pi logits unless weight_by_pi (the reference never multiplies by pi, cost.py:532-538).
+// The LAST workgroup to finish (a ticket in the workspace, left at zero again) adds the B parts in row order: one launch, and
+// the same loss bits whatever the order the workgroups ran in.
 __global__ __launch_bounds__(256) void gmm3d_loss_grad_kernel(const float* __restrict__ params, const float* __restrict__ y, long ldy,
-                                                              float* __restrict__ part, float* __restrict__ dpre, int n, int npts,
-                                                              float scale, int weight_by_pi) {
+                                                              unsigned* __restrict__ ticket, float* __restrict__ part,
+                                                              float* __restrict__ loss, float* __restrict__ dpre, int n, int npts,
+                                                              int tc, float scale, int weight_by_pi) {
     extern __shared__ __attribute__((aligned(16))) double gm_lds[];
     __shared__ MixSetup ms[GM_MAXMIX];
     __shared__ double wt[GM_MAXPTS];          // w_t = -scale / (S_t + eps)
-    __shared__ double dpi[GM_MAXMIX];
+    __shared__ double acc10[GM_MAXMIX][10];   // per mixture: d/dmu (3), G (6), d/dpi
     __shared__ double lsum[256];
-    double* pm = gm_lds;                      // [n][npts] densities (times pi when weight_by_pi)
-    const int b = blockIdx.x, tid = threadIdx.x;
+    __shared__ int is_last;
+    double* pm = gm_lds;                      // [n][npts] densities
+    double* terms = pm + n * npts;            // [n][tc][10] per-frame terms of the gradient sums, a chunk of tc frames at a time
+    const int b = blockIdx.x, B = gridDim.x, tid = threadIdx.x;
     const float* prm = params + (size_t)b * 10 * n;
     const float* yb = y + (size_t)b * ldy;
+    MH_STAMP(2, 0);
     if (tid < n) mix_setup(prm, n, tid, ms[tid]);
+    for (int e = tid; e < GM_MAXMIX * 10; e += 256) acc10[e / 10][e % 10] = 0.0;
     __syncthreads();
+    MH_STAMP(2, 1);
     for (int e = tid; e < n * npts; e += 256) {
         const int m = e / npts, t = e - m * npts;
         const MixSetup& s = ms[m];
@@ -380,6 +597,7 @@ __global__ __launch_bounds__(256) void gmm3d_loss_grad_kernel(const float* __res
         pm[e] = exp(s.lognorm - 0.5 * q);
     }
     __syncthreads();
+    MH_STAMP(2, 2);
     double lacc = 0.0;
     for (int t = tid; t < npts; t += 256) {
         double S = 0.0;
@@ -393,25 +611,47 @@ __global__ __launch_bounds__(256) void gmm3d_loss_grad_kernel(const float* __res
         if (tid < s_) lsum[tid] += lsum[tid + s_];
         __syncthreads();
     }
-    if (tid == 0) part[b] = (float)lsum[0];
-    float* dp = dpre + (size_t)b * 10 * n;
-    if (tid < n) {
-        const int m = tid;
-        const MixSetup& s = ms[m];
-        const double pim = weight_by_pi ? (double)prm[m] : 1.0;
-        double gmu[3] = {0, 0, 0}, G[6] = {0, 0, 0, 0, 0, 0}, gp = 0.0;
-        for (int t = 0; t < npts; ++t) {
+    MH_STAMP(2, 3);
+    // the ten sums over t of every mixture m - c 0..2: sum w p a_c; 3..8: sum w p (a a^T - P) / 2 (pairs 00 01 02 11 12 22); 9: sum w p / pi.
+    // Thread (m, t) forms the ten terms of its frame, thread (m, c) then adds a chunk's terms in frame order (fixed order).
+    double a10 = 0.0;                          // running sum of thread (m, c) = tid
+    for (int t0 = 0; t0 < npts; t0 += tc) {
+        const int tn = (npts - t0 < tc) ? npts - t0 : tc;
+        for (int e = tid; e < n * tn; e += 256) {
+            const int m = e / tn, tl = e - m * tn, t = t0 + tl;
+            const MixSetup& s = ms[m];
+            const double pim = weight_by_pi ? (double)prm[m] : 1.0;
             const double p = pm[m * npts + t], wp = wt[t] * pim * p;      // dL/dp_mt * p_mt
             const double d0 = (double)yb[3 * t] - s.mu[0], d1 = (double)yb[3 * t + 1] - s.mu[1], d2 = (double)yb[3 * t + 2] - s.mu[2];
             const double a0 = s.P[0] * d0 + s.P[1] * d1 + s.P[2] * d2;
             const double a1 = s.P[1] * d0 + s.P[3] * d1 + s.P[4] * d2;
             const double a2 = s.P[2] * d0 + s.P[4] * d1 + s.P[5] * d2;
-            gmu[0] += wp * a0; gmu[1] += wp * a1; gmu[2] += wp * a2;
+            double* o = terms + (size_t)(m * tc + tl) * 10;
             const double h = 0.5 * wp;
-            G[0] += h * (a0 * a0 - s.P[0]); G[1] += h * (a0 * a1 - s.P[1]); G[2] += h * (a0 * a2 - s.P[2]);
-            G[3] += h * (a1 * a1 - s.P[3]); G[4] += h * (a1 * a2 - s.P[4]); G[5] += h * (a2 * a2 - s.P[5]);
-            gp += wt[t] * p;
+            o[0] = wp * a0; o[1] = wp * a1; o[2] = wp * a2;
+            o[3] = h * (a0 * a0 - s.P[0]); o[4] = h * (a0 * a1 - s.P[1]); o[5] = h * (a0 * a2 - s.P[2]);
+            o[6] = h * (a1 * a1 - s.P[3]); o[7] = h * (a1 * a2 - s.P[4]); o[8] = h * (a2 * a2 - s.P[5]);
+            o[9] = wt[t] * p;
         }
+        __syncthreads();
+        for (int e = tid; e < n * 10; e += 256) {         // n <= 32: at most two per thread, the second kept in LDS
+            const int m = e / 10, c = e - m * 10;
+            double a = (e == tid) ? a10 : acc10[m][c];
+            for (int tl = 0; tl < tn; ++tl) a += terms[(size_t)(m * tc + tl) * 10 + c];
+            if (e == tid) a10 = a; else acc10[m][c] = a;
+        }
+        __syncthreads();
+    }
+    if (tid < n * 10) acc10[tid / 10][tid % 10] = a10;
+    __syncthreads();
+    MH_STAMP(2, 4);
+    float* dp = dpre + (size_t)b * 10 * n;
+    if (tid < n) {
+        const int m = tid;
+        const MixSetup& s = ms[m];
+        double G[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) G[k] = acc10[m][3 + k];         // G00 G01 G02 G11 G12 G22
         if (s.repaired) {     // Sigma' = Sigma - 10 lambda_min I, d lambda_min / d Sigma = v v^T
             const double k = -10.0 * (G[0] + G[3] + G[5]);
             G[0] += k * s.v[0] * s.v[0]; G[1] += k * s.v[0] * s.v[1]; G[2] += k * s.v[0] * s.v[2];
@@ -422,23 +662,44 @@ __global__ __launch_bounds__(256) void gmm3d_loss_grad_kernel(const float* __res
         const double ds1 = 2.0 * (s1 * G[0] + r12 * s2 * G[1] + r13 * s3 * G[2]);
         const double ds2 = 2.0 * (s2 * G[3] + r12 * s1 * G[1] + r23 * s3 * G[4]);
         const double ds3 = 2.0 * (s3 * G[5] + r13 * s1 * G[2] + r23 * s2 * G[4]);
-        dp[n + 3 * m] = (float)gmu[0]; dp[n + 3 * m + 1] = (float)gmu[1]; dp[n + 3 * m + 2] = (float)gmu[2];
+        dp[n + 3 * m] = (float)acc10[m][0]; dp[n + 3 * m + 1] = (float)acc10[m][1]; dp[n + 3 * m + 2] = (float)acc10[m][2];
         dp[4 * n + 3 * m] = (float)(ds1 * s1); dp[4 * n + 3 * m + 1] = (float)(ds2 * s2); dp[4 * n + 3 * m + 2] = (float)(ds3 * s3);
         dp[7 * n + 3 * m] = (float)(2.0 * G[1] * s1 * s2 * (1.0 - r12 * r12));
         dp[7 * n + 3 * m + 1] = (float)(2.0 * G[2] * s1 * s3 * (1.0 - r13 * r13));
         dp[7 * n + 3 * m + 2] = (float)(2.0 * G[4] * s2 * s3 * (1.0 - r23 * r23));
-        dpi[m] = gp;          // d loss / d pi_m (used only when weight_by_pi)
+        float g = 0.f;
+        if (weight_by_pi) {   // softmax backward; acc10[.][9] = d loss / d pi
+            double dot = 0.0;
+            for (int q = 0; q < n; ++q) dot += (double)prm[q] * acc10[q][9];
+            g = (float)((double)prm[m] * (acc10[m][9] - dot));
+        }
+        dp[m] = g;
+    }
+    MH_STAMP(2, 5);
+    if (!loss) return;
+    if (tid == 0) {
+        __hip_atomic_store(part + b, (float)lsum[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence();
+        const unsigned done = atomicAdd(ticket, 1u);
+        is_last = (done == (unsigned)B - 1u);
     }
     __syncthreads();
-    if (tid < n) {
-        float g = 0.f;
-        if (weight_by_pi) {   // softmax backward
-            double dot = 0.0;
-            for (int q = 0; q < n; ++q) dot += (double)prm[q] * dpi[q];
-            g = (float)((double)prm[tid] * (dpi[tid] - dot));
+    if (is_last) {
+        __threadfence();
+        double a = 0.0;
+        for (int i = tid; i < B; i += 256) a += (double)__hip_atomic_load(part + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        lsum[tid] = a;
+        __syncthreads();
+        for (int s_ = 128; s_ > 0; s_ >>= 1) {
+            if (tid < s_) lsum[tid] += lsum[tid + s_];
+            __syncthreads();
         }
-        dp[tid] = g;
+        if (tid == 0) {
+            loss[0] = (float)(lsum[0] * (double)scale);
+            __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // the next call finds it at zero
+        }
     }
+    MH_STAMP(2, 6);
 }
 
 // One draw per frame: component by inverse CDF over pi, then mu + L z (utility.sample_mixture_3D's documented intent).
@@ -467,19 +728,6 @@ __global__ __launch_bounds__(256) void gmm3d_sample_kernel(const float* __restri
     }
 }
 
-__global__ __launch_bounds__(256) void mh_sum_scale_kernel(const float* __restrict__ part, float* __restrict__ out, int n, float scale) {
-    __shared__ double red[256];
-    double a = 0.0;
-    for (int i = threadIdx.x; i < n; i += 256) a += (double)part[i];
-    red[threadIdx.x] = a;
-    __syncthreads();
-    for (int s_ = 128; s_ > 0; s_ >>= 1) {
-        if ((int)threadIdx.x < s_) red[threadIdx.x] += red[threadIdx.x + s_];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) out[0] = (float)(red[0] * (double)scale);
-}
-
 bool mlp_dims_ok(int B, int L, const int* dims) {
     if (B < 1 || L < 1 || L > MH_MAXL || !dims) return false;
     for (int l = 0; l <= L; ++l)
@@ -498,6 +746,12 @@ int mh_check(const char* what) {
 }  // namespace fov
 
 using namespace fov;
+
+#ifdef FOV_STAMPS
+extern "C" int fov_debug_read_mh_stamps(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mh_stamps), sizeof(unsigned long long) * 3 * 48);
+}
+#endif
 
 extern "C" {
 
@@ -518,7 +772,10 @@ int fov_mlp_head_fwd(const float* x, const float* const* W, const float* const* 
         p.W[l] = W[l]; p.b[l] = b[l]; p.a[l] = acts[l]; p.mask[l] = masks ? masks[l] : nullptr; p.act[l] = act_codes[l];
     }
     for (int l = 0; l <= L; ++l) p.D[l] = dims[l];
-    hipLaunchKernelGGL(mlp_head_fwd_kernel, dim3((unsigned)((B + MH_ROWS - 1) / MH_ROWS)), dim3(MH_NT), 0, (hipStream_t)stream, p);
+    const size_t lds = sizeof(float) * (size_t)MH_FWD_LDS;
+    int rc = ensure_dynamic_lds((const void*)mlp_head_fwd_kernel, lds, MH_NT);
+    if (rc) return rc;
+    hipLaunchKernelGGL(mlp_head_fwd_kernel, dim3((unsigned)((B + MH_ROWS - 1) / MH_ROWS)), dim3(MH_NT), lds, (hipStream_t)stream, p);
     return mh_check("mlp head forward");
 }
 
@@ -547,7 +804,7 @@ int fov_mlp_head_bwd(const float* x, const float* const* W, const float* const* 
     }
     for (int l = 0; l <= L; ++l) p.D[l] = dims[l];
     if (L > 1 || dx) {
-        const size_t lds = sizeof(float) * ((size_t)MH_TILE + 2 * MH_ROWS * MH_MAXD + MH_ROWS * MH_NT);
+        const size_t lds = sizeof(float) * (size_t)CH_LDS;
         int rc = ensure_dynamic_lds((const void*)mlp_head_bwd_chain_kernel, lds, MH_NT);
         if (rc) return rc;
         hipLaunchKernelGGL(mlp_head_bwd_chain_kernel, dim3((unsigned)((B + MH_ROWS - 1) / MH_ROWS)), dim3(MH_NT), lds, (hipStream_t)stream, p);
@@ -568,17 +825,17 @@ int fov_gmm3d_loss_grad(const float* params, const float* y, int64_t ldy, float*
     if (n_mix < 1 || n_mix > GM_MAXMIX || n_pts < 1 || n_pts > GM_MAXPTS || ldy < 3 * (int64_t)n_pts) {
         set_error("fov_gmm3d_loss_grad: n_mix <= 32, n_pts <= 256, ldy >= 3 n_pts"); return FOV_ERR_UNSUPPORTED;
     }
-    if (!workspace || workspace_bytes < sizeof(float) * (size_t)B) { set_error("fov_gmm3d_loss_grad: workspace too small"); return FOV_ERR_WORKSPACE; }
-    float* part = static_cast<float*>(workspace);
-    const size_t lds = sizeof(double) * (size_t)n_mix * n_pts;
+    if (!workspace || workspace_bytes < 256 + sizeof(float) * (size_t)B) { set_error("fov_gmm3d_loss_grad: workspace too small"); return FOV_ERR_WORKSPACE; }
+    unsigned* ticket = static_cast<unsigned*>(workspace);
+    float* part = reinterpret_cast<float*>(static_cast<char*>(workspace) + 256);
+    int tc = 6144 / (10 * n_mix);                      // frames per chunk of the gradient sums: at most 48 KB of terms
+    if (tc > n_pts) tc = n_pts;
+    const size_t lds = sizeof(double) * ((size_t)n_mix * n_pts + (size_t)n_mix * tc * 10);
     int rc = ensure_dynamic_lds((const void*)gmm3d_loss_grad_kernel, lds, 256);
     if (rc) return rc;
-    hipLaunchKernelGGL(gmm3d_loss_grad_kernel, dim3((unsigned)B), dim3(256), lds, (hipStream_t)stream, params, y, (long)ldy, part, dpre,
-                       n_mix, n_pts, scale, weight_by_pi ? 1 : 0);
-    rc = mh_check("gmm3d loss");
-    if (rc || !loss) return rc;
-    hipLaunchKernelGGL(mh_sum_scale_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, part, loss, B, scale);
-    return mh_check("gmm3d loss sum");
+    hipLaunchKernelGGL(gmm3d_loss_grad_kernel, dim3((unsigned)B), dim3(256), lds, (hipStream_t)stream, params, y, (long)ldy, ticket, part, loss,
+                       dpre, n_mix, n_pts, tc, scale, weight_by_pi ? 1 : 0);
+    return mh_check("gmm3d loss");
 }
 
 int fov_gmm3d_sample(const float* params, const float* u, const float* z, float* out, int64_t ldo, int B, int n_mix, int n_pts,

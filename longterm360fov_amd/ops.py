@@ -522,6 +522,9 @@ def mlp_head_bwd(x, layers, acts, dlast, gW, gb, masks=None, need_dx=True, accum
     return dx
 
 
+_gmm_loss_ws = {}
+
+
 def gmm3d_loss_grad(params, y, n_pts, scale, weight_by_pi=False, scratch=None):
     """costfunc.mixture_3d_gaussian_loss (cost.py:486-549) + gradient at the head's pre-activations.  params (B,10n) from
     mlp_head_fwd(n_mix=n); y (B, ...) whose rows START with the n_pts scored frames (x,y,z interleaved): (B,T_y,3*fps)
@@ -533,7 +536,11 @@ def gmm3d_loss_grad(params, y, n_pts, scale, weight_by_pi=False, scratch=None):
     ldy = y.numel() // max(B, 1)
     loss = (torch.empty if B > 0 else torch.zeros)(1, dtype=torch.float32, device=y.device)
     dpre = torch.empty_like(params)
-    buf = (scratch or _default_scratch).get(4 * (B + 64), y.device)
+    # stateful workspace (ticket word, zero between calls): its own zero-filled buffer, never the shared scratch other calls scribble on
+    key = (y.device.index, _stream())
+    buf = _gmm_loss_ws.get(key)
+    if buf is None or buf.numel() < 256 + 4 * B:
+        buf = _gmm_loss_ws[key] = torch.zeros(max(4096, 256 + 4 * B), dtype=torch.uint8, device=y.device)
     check(_lib.lib().fov_gmm3d_loss_grad(_ptr(params), _ptr(y), ldy, _ptr(loss), _ptr(dpre), B, n, int(n_pts), float(scale),
                                          1 if weight_by_pi else 0, buf.data_ptr(), buf.numel(), _stream()))
     return loss, dpre

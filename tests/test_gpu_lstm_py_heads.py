@@ -100,7 +100,7 @@ def test_gmm3d_loss_and_gradient(B, n, P, ldpad, weight_by_pi, rho_bias):
                                          B, 10, 30, process_in_seconds=True, weight_by_pi=weight_by_pi)
     loss, dpre = ops.gmm3d_loss_grad(dev(params), dev(y), P, scale, weight_by_pi=weight_by_pi)
     lv = float(loss.item())
-    print("gmm3d loss B%d n%d P%d: gpu %.6f torch %.6f oracle %.6f, %d of %d covariances repaired" % (B, n, P, lv, float(loss_ref), loss_or, n_rep, B * n))
+    print("gmm3d loss B%d n%d P%d: gpu %.6f torch %.6f oracle %.6f, %d of %d covariances repaired" % (B, n, P, lv, float(loss_ref.detach()), loss_or, n_rep, B * n))
     assert abs(lv - loss_or) <= 2e-5 * abs(loss_or) + 1e-7
     assert abs(lv - float(loss_ref)) <= 1e-4 * abs(float(loss_ref)) + 1e-7     # fp32 parameters vs fp64 pre-activations
     g = dpre.cpu().numpy().astype(np.float64)

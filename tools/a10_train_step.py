@@ -1,6 +1,6 @@
 """lstm.py's training step at its native shape (2 x LSTMCell(400), batch 32, 10 steps, 90 features) on TFLSTMTrainer, padded to
 width 512 (default) or unpadded (--nopad): a few steps for a rocprofv3 --kernel-trace timeline (tools/step_timeline.py <csv> rmsprop)
-and the HIP-event time of a step.   usage: python3 tools/a10_train_step.py [--nopad] [--steps N]"""
+and the HIP-event time of a step.   usage: python3 tools/a10_train_step.py [--nopad] [--steps N] [--head meanvar|gmm|raw]"""
 import os
 import sys
 import numpy as np
@@ -22,7 +22,21 @@ for br in ("mu", "var"):
 x = torch.from_numpy(rng.uniform(-1, 1, (B, T, F)).astype(np.float32)).cuda()
 y = torch.from_numpy(rng.uniform(-1, 1, (B, 1, 90)).astype(np.float32)).cuda()
 init = torch.zeros((2, 2, B, H), device="cuda")
-tr = TFLSTMTrainer(cells, head, lr=1e-5, fps=30, running_length=10, pad=pad)
+kind = sys.argv[sys.argv.index("--head") + 1] if "--head" in sys.argv else "meanvar"      # meanvar | gmm | raw (lstm.py:424-509)
+if kind == "gmm":
+    dims = [H, 64, 128, 256, 200]
+    head = {}
+    for l in range(4):
+        head["fc%d_W" % (l + 1)] = (rng.uniform(-1, 1, (dims[l], dims[l + 1])) * np.sqrt(6.0 / (dims[l] + dims[l + 1]))).astype(np.float32)
+        head["fc%d_b" % (l + 1)] = np.zeros(dims[l + 1], np.float32)
+    y = torch.from_numpy(rng.uniform(-1, 1, (B, 10, 90)).astype(np.float32)).cuda()
+elif kind == "raw":
+    dims = [H, 128, 256, 90]
+    head = {}
+    for l in range(3):
+        head["conv%d_W" % (l + 1)] = (rng.uniform(-1, 1, (5, dims[l], dims[l + 1])) * np.sqrt(6.0 / (5 * (dims[l] + dims[l + 1])))).astype(np.float32)
+        head["conv%d_b" % (l + 1)] = np.zeros(dims[l + 1], np.float32)
+tr = TFLSTMTrainer(cells, head, lr=1e-5, fps=30, running_length=10, pad=pad, head_kind=kind)
 for _ in range(5):
     tr.train_step(x, y, init)
 torch.cuda.synchronize()
@@ -33,4 +47,4 @@ for _ in range(steps):
 e1.record()
 torch.cuda.synchronize()
 tr.ws.check()
-print("pad=%s  %.4f ms per training step" % (pad, e0.elapsed_time(e1) / steps))
+print("pad=%s head=%s  %.4f ms per training step" % (pad, kind, e0.elapsed_time(e1) / steps))
