@@ -236,7 +236,9 @@ size_t fov_mix_decoder_bwd_workspace_bytes(int B, int H);
  * weights change every optimizer step).  The pack depends on the weights only: this call runs it for the forward and / or
  * the backward workspace (either may be NULL) on `stream` - a side stream, under the encoder layers - and marks the
  * workspaces; the NEXT fov_mix_decoder_fwd / _bwd on a marked workspace with the same dec2_K skips its own pack.  The caller
- * orders the streams (the launch must come behind the pack). */
+ * orders the streams (the launch must come behind the pack).  The mark is valid for that one launch and only while dec2_K's
+ * CONTENTS are unchanged (it is keyed by pointer: a caller that updates the weights in place packs again); fov_workspace_init and
+ * the reset inside fov_check_status erase it, since they zero the packed copy. */
 int fov_mix_decoder_prepack(const float* dec2_K, void* workspace_fwd, size_t fwd_bytes, void* workspace_bwd, size_t bwd_bytes,
                             int H, fov_stream_t stream);
 int fov_mix_decoder_bwd(const float* M, const float* P, const float* dloss, const float* res1, const float* res2,
@@ -479,12 +481,15 @@ int fov_rmsprop_step(float* params, const float* grads, float* accum, int64_t n,
                      float lr, float rho, float eps, fov_stream_t stream);
 /* The same, fail-stop: guard0..2 (each may be NULL) are the workspaces the training step's persistent-kernel calls
  * used.  If the sticky timeout word of one of them is set the gradients are garbage and the update is skipped ON THE
- * DEVICE (no host synchronisation); the parameters stay as they were until fov_check_status reports the failure. */
+ * DEVICE (no host synchronisation); the parameters stay as they were until fov_check_status reports the failure.
+ * applied (device pointer, may be NULL): *applied += 1 by every update that was NOT skipped - a caller that counts steps on the
+ * host (Adam's bias correction) and only looks at the status now and then reads back how many updates really ran. */
 int fov_adam_step_guarded(float* params, const float* grads, float* m, float* v, int64_t n, float lr, float beta1,
                           float beta2, float eps, int64_t step, const void* guard0, const void* guard1,
-                          const void* guard2, fov_stream_t stream);
+                          const void* guard2, int64_t* applied, fov_stream_t stream);
 int fov_rmsprop_step_guarded(float* params, const float* grads, float* accum, int64_t n, float lr, float rho, float eps,
-                             const void* guard0, const void* guard1, const void* guard2, fov_stream_t stream);
+                             const void* guard0, const void* guard1, const void* guard2, int64_t* applied,
+                             fov_stream_t stream);
 /* Deferred split reductions of a training step (model.fit's backward, FoV_seq2seq.py:103,112-117): between _begin and
  * _flush / _end every weight-gradient entry point of this library whose OUTPUT lies inside [grad_base, grad_base +
  * grad_floats) - the caller's flat gradient buffer - keeps the partial slices of its split product in `arena` (caller-owned

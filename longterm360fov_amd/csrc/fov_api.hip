@@ -466,7 +466,10 @@ int xch_account(void* workspace, long span, hipStream_t stream) {
     if (st.epoch > 0x70000000ull) {
         // every launch on this workspace passes here, so the device-side base is at most st.epoch: re-zero the header and the
         // granule area in front of this launch (stream-ordered; launches on one workspace are serialised by contract)
-        hipError_t e = hipMemsetAsync(workspace, 0, kStatusBytes + kXchBytes, stream);
+        // ... all of it but the sticky timeout word (header word 0): a give-up since the last fov_check_status must stay visible
+        // to the guarded optimizer and to the next check
+        static_assert(ST_TIMEOUT == 0, "the re-zero below skips header word 0");
+        hipError_t e = hipMemsetAsync((char*)workspace + sizeof(unsigned), 0, kStatusBytes + kXchBytes - sizeof(unsigned), stream);
         if (e == hipSuccess && st.force_safe)
             e = hipMemsetD32Async((hipDeviceptr_t)((unsigned*)workspace + ST_FORCE_SAFE), 1, 1, stream);
         if (e != hipSuccess) { set_error("epoch re-zero: %s", hipGetErrorString(e)); return FOV_ERR_LAUNCH; }
@@ -502,6 +505,11 @@ bool prepack_consume(void* workspace, const float* K2) {
     const bool hit = it->second == K2;
     g_prepacked.erase(it);
     return hit;
+}
+// the workspace was zero-filled (fov_workspace_init, the reset of fov_check_status): a packed copy marked earlier is gone
+void prepack_forget(void* workspace) {
+    std::lock_guard<std::mutex> lock(g_prepacked_mu);
+    g_prepacked.erase(workspace);
 }
 
 }  // namespace fov
@@ -917,14 +925,14 @@ int fov_rmsprop_tf_step(float* params, const float* grads, float* ms, int64_t n,
 
 int fov_adam_step_guarded(float* params, const float* grads, float* m, float* v, int64_t n, float lr, float beta1,
                           float beta2, float eps, int64_t step, const void* guard0, const void* guard1, const void* guard2,
-                          fov_stream_t stream) {
+                          int64_t* applied, fov_stream_t stream) {
     if (n < 0 || step < 1 || (n > 0 && (!params || !grads || !m || !v))) {
         set_error("fov_adam_step: invalid argument");
         return FOV_ERR_INVALID;
     }
     const double lr_t = (double)lr * sqrt(1.0 - pow((double)beta2, (double)step)) / (1.0 - pow((double)beta1, (double)step));
     const unsigned* guards[3] = {(const unsigned*)guard0, (const unsigned*)guard1, (const unsigned*)guard2};
-    return adam_step(params, grads, m, v, (long)n, (float)lr_t, beta1, beta2, eps, guards, (hipStream_t)stream);
+    return adam_step(params, grads, m, v, (long)n, (float)lr_t, beta1, beta2, eps, guards, (long long*)applied, (hipStream_t)stream);
 }
 
 int fov_reduce_defer_begin(float* grad_base, size_t grad_floats, void* arena, size_t arena_bytes, fov_stream_t stream) {
@@ -942,22 +950,22 @@ int fov_guard_flag(const void* guard0, const void* guard1, const void* guard2, f
 
 int fov_adam_step(float* params, const float* grads, float* m, float* v, int64_t n, float lr, float beta1,
                   float beta2, float eps, int64_t step, fov_stream_t stream) {
-    return fov_adam_step_guarded(params, grads, m, v, n, lr, beta1, beta2, eps, step, nullptr, nullptr, nullptr, stream);
+    return fov_adam_step_guarded(params, grads, m, v, n, lr, beta1, beta2, eps, step, nullptr, nullptr, nullptr, nullptr, stream);
 }
 
 int fov_rmsprop_step_guarded(float* params, const float* grads, float* accum, int64_t n, float lr, float rho, float eps,
-                             const void* guard0, const void* guard1, const void* guard2, fov_stream_t stream) {
+                             const void* guard0, const void* guard1, const void* guard2, int64_t* applied, fov_stream_t stream) {
     if (n < 0 || (n > 0 && (!params || !grads || !accum))) {
         set_error("fov_rmsprop_step: invalid argument");
         return FOV_ERR_INVALID;
     }
     const unsigned* guards[3] = {(const unsigned*)guard0, (const unsigned*)guard1, (const unsigned*)guard2};
-    return rmsprop_step(params, grads, accum, (long)n, lr, rho, eps, guards, (hipStream_t)stream);
+    return rmsprop_step(params, grads, accum, (long)n, lr, rho, eps, guards, (long long*)applied, (hipStream_t)stream);
 }
 
 int fov_rmsprop_step(float* params, const float* grads, float* accum, int64_t n, float lr, float rho, float eps,
                      fov_stream_t stream) {
-    return fov_rmsprop_step_guarded(params, grads, accum, n, lr, rho, eps, nullptr, nullptr, nullptr, stream);
+    return fov_rmsprop_step_guarded(params, grads, accum, n, lr, rho, eps, nullptr, nullptr, nullptr, nullptr, stream);
 }
 
 int fov_dense_fwd(const float* x, const float* W, const float* b, float* y, int N, int In, int Out,
@@ -1289,6 +1297,7 @@ int fov_workspace_init(void* workspace, size_t workspace_bytes, fov_stream_t str
     hipError_t e = hipMemsetAsync(workspace, 0, workspace_bytes, (hipStream_t)stream);
     if (e != hipSuccess) { set_error("fov_workspace_init: %s", hipGetErrorString(e)); return FOV_ERR_LAUNCH; }
     xch_forget(workspace);
+    prepack_forget(workspace);
     xch_note_force_safe(workspace, 0);
     return FOV_OK;
 }
@@ -1323,6 +1332,7 @@ int fov_check_status(void* workspace, size_t workspace_bytes, fov_stream_t strea
         if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
         if (e != hipSuccess) { set_error("fov_check_status: %s", hipGetErrorString(e)); return FOV_ERR_LAUNCH; }
         xch_forget(workspace);
+        prepack_forget(workspace);
     }
     if (st[ST_TIMEOUT] != 0) {
         set_error("a bounded in-kernel wait gave up (exchange launches on this workspace so far: %u); results since the last check are invalid",

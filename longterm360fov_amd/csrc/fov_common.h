@@ -174,6 +174,7 @@ struct MixDecParams {
 // one-shot marks 'the packed K2 of this workspace is current' (fov_api.hip)
 void prepack_mark(void* workspace, const float* K2);
 bool prepack_consume(void* workspace, const float* K2);
+void prepack_forget(void* workspace);                    // the workspace was zero-filled: no packed copy in it any more
 int mix_decoder_prepack(const float* K2, void* workspace, hipStream_t stream);
 int mix_decoder_bwd_prepack(const float* K2, void* workspace, hipStream_t stream);
 size_t mix_decoder_workspace_bytes(int B);
@@ -237,9 +238,9 @@ int act_bwd(const float* dy, const float* y, const float* base, float* out, long
 int matmul_f32(const float* a, const float* b, float* c, int M, int K, int N, float* scratch, size_t scratch_floats,
                hipStream_t stream);
 int adam_step(float* p, const float* g, float* m, float* v, long n, float lr_t, float b1, float b2, float eps,
-              const unsigned* const* guards, hipStream_t stream);   // guards: NULL or three (nullable) timeout words
+              const unsigned* const* guards, long long* applied, hipStream_t stream);   // guards: NULL or three (nullable) timeout words; applied: nullable counter of updates that ran
 int rmsprop_step(float* p, const float* g, float* a, long n, float lr, float rho, float eps, const unsigned* const* guards,
-                 hipStream_t stream);
+                 long long* applied, hipStream_t stream);
 int guard_flag(const unsigned* const* guards, float* out, hipStream_t stream);
 int act_fwd(const float* x, float* y, long n, int activation, hipStream_t stream);
 int gauss_nll_grad(const float* mu, const float* var, const float* y, float* loss, float* dmu, float* dvar, int B, int Ty,

@@ -666,9 +666,10 @@ int guard_flag(const unsigned* const* guards, float* out, hipStream_t stream) {
 
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, long n, float lr_t, float b1, float b2, float eps,
-                                                   const unsigned* g0, const unsigned* g1, const unsigned* g2) {
+                                                   const unsigned* g0, const unsigned* g1, const unsigned* g2, long long* applied) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n || optimizer_poisoned(g0, g1, g2)) return;
+    if (i == 0 && applied) *applied += 1;      // updates that really ran: what the host's step counter is set back to after a failure
     const float gi = g[i];
     const float mi = b1 * m[i] + (1.f - b1) * gi;
     const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
@@ -679,9 +680,10 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 
 __global__ __launch_bounds__(256) void rmsprop_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ a,
                                                       long n, float lr, float rho, float eps, const unsigned* g0,
-                                                      const unsigned* g1, const unsigned* g2) {
+                                                      const unsigned* g1, const unsigned* g2, long long* applied) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n || optimizer_poisoned(g0, g1, g2)) return;
+    if (i == 0 && applied) *applied += 1;
     const float gi = g[i];
     const float ai = rho * a[i] + (1.f - rho) * gi * gi;
     a[i] = ai;
@@ -1676,18 +1678,18 @@ int act_bwd(const float* dy, const float* y, const float* base, float* out, long
 }
 
 int adam_step(float* p, const float* g, float* m, float* v, long n, float lr_t, float b1, float b2, float eps,
-              const unsigned* const* guards, hipStream_t stream) {
+              const unsigned* const* guards, long long* applied, hipStream_t stream) {
     if (n <= 0) return FOV_OK;
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, p, g, m, v, n, lr_t, b1, b2, eps,
-                       guards ? guards[0] : nullptr, guards ? guards[1] : nullptr, guards ? guards[2] : nullptr);
+                       guards ? guards[0] : nullptr, guards ? guards[1] : nullptr, guards ? guards[2] : nullptr, applied);
     return check_launch("adam");
 }
 
 int rmsprop_step(float* p, const float* g, float* a, long n, float lr, float rho, float eps, const unsigned* const* guards,
-                 hipStream_t stream) {
+                 long long* applied, hipStream_t stream) {
     if (n <= 0) return FOV_OK;
     hipLaunchKernelGGL(rmsprop_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, p, g, a, n, lr, rho, eps,
-                       guards ? guards[0] : nullptr, guards ? guards[1] : nullptr, guards ? guards[2] : nullptr);
+                       guards ? guards[0] : nullptr, guards ? guards[1] : nullptr, guards ? guards[2] : nullptr, applied);
     return check_launch("rmsprop");
 }
 

@@ -733,13 +733,20 @@ def guard_flag(guards, out):
     return out
 
 
-def adam_step(params, grads, m, v, step, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-7, guards=None):
+def _applied_ptr(applied):
+    if applied is None:
+        return None
+    assert applied.is_cuda and applied.dtype == torch.int64 and applied.numel() == 1
+    return applied.data_ptr()
+
+
+def adam_step(params, grads, m, v, step, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-7, guards=None, applied=None):
     """Keras Adam on flat buffers.  guards: up to three workspace buffers; the update is skipped on the device when
-    one of their sticky timeout words is set."""
+    one of their sticky timeout words is set.  applied: (1,) int64 device counter of the updates that were not skipped."""
     for t in (params, grads, m, v):
         _dev(t, "flat buffer")
     check(_lib.lib().fov_adam_step_guarded(_ptr(params), _ptr(grads), _ptr(m), _ptr(v), params.numel(), lr, beta1, beta2,
-                                           eps, int(step), *_guard_ptrs(guards), _stream()))
+                                           eps, int(step), *_guard_ptrs(guards), _applied_ptr(applied), _stream()))
 
 
 def reduce_defer_begin(grad, arena):
@@ -756,11 +763,11 @@ def reduce_defer_end():
     check(_lib.lib().fov_reduce_defer_end(_stream()))
 
 
-def rmsprop_step(params, grads, accum, lr=1e-3, rho=0.9, eps=1e-7, guards=None):
+def rmsprop_step(params, grads, accum, lr=1e-3, rho=0.9, eps=1e-7, guards=None, applied=None):
     for t in (params, grads, accum):
         _dev(t, "flat buffer")
     check(_lib.lib().fov_rmsprop_step_guarded(_ptr(params), _ptr(grads), _ptr(accum), params.numel(), lr, rho, eps,
-                                              *_guard_ptrs(guards), _stream()))
+                                              *_guard_ptrs(guards), _applied_ptr(applied), _stream()))
 
 
 # ---------------------------------------------------------------------------------------------

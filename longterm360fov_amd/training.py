@@ -45,7 +45,8 @@ class FlatParamTrainer:
             self.offset[k] = off
             off += cnt
         self.step_count = 0
-        self._steps_since_check = 0
+        self.applied = torch.zeros(1, dtype=torch.int64, device=device)     # optimizer launches that were not skipped on the device
+        self._dp_steps_since_check = 0
         self._dp_guard = None
         self.ws = ops.Workspace()
         self.scratch = ops.Scratch()        # split-K partials of the Dense / MSE / matmul calls
@@ -67,7 +68,16 @@ class FlatParamTrainer:
             self.w[k].copy_(torch.from_numpy(np.ascontiguousarray(weights[k], dtype=np.float32)))
 
     def check(self):
-        """Raise FovError(ERR_TIMEOUT) if a persistent kernel of this trainer gave up a bounded wait (synchronises)."""
+        """Raise FovError(ERR_TIMEOUT) if a persistent kernel of this trainer gave up a bounded wait (synchronises).
+
+        Under data parallelism this is a collective in the sense that every rank must call it at the same points (fit does,
+        once per epoch): the timeout word is sticky on the rank that failed, so from the failing step on the all-reduced poison
+        slot is nonzero on EVERY rank at every step - all replicas skip those updates together - and the value the last step
+        left in the slot tells every rank here that some rank failed.  All of them raise, and all set their step counter back
+        to the number of updates that really ran (self.applied, counted on the device by the guarded optimizer: the steps
+        before the failing one stay counted, Adam's bias correction continues where the parameters are)."""
+        peer_failed = self._dp_steps_since_check > 0 and float(self.poison_slot.item()) != 0.0
+        self._dp_steps_since_check = 0
         try:
             self.ws.check()
             self.bwd_scratch.check()
@@ -75,11 +85,13 @@ class FlatParamTrainer:
             if ws_bwd is not None:
                 ws_bwd.check()
         except Exception:
-            # the guarded optimizer skipped every update from the failing step on: do not count them (Adam's bias correction)
-            self.step_count -= self._steps_since_check
-            self._steps_since_check = 0
+            self.step_count = int(self.applied.item())
             raise
-        self._steps_since_check = 0
+        if peer_failed:
+            self.step_count = int(self.applied.item())
+            from ._lib import ERR_TIMEOUT, FovError
+            raise FovError(ERR_TIMEOUT, "a persistent kernel of another data-parallel rank gave up a bounded wait: every rank skipped "
+                                        "the optimizer updates from that step on")
 
     def _guards(self):
         """The workspaces whose sticky timeout word the optimizer launch looks at: if a persistent kernel of this step
@@ -92,11 +104,10 @@ class FlatParamTrainer:
     def apply_gradients(self):
         """Keras Adam / RMSprop on the flat buffer (model.compile(optimizer=...), FoV_seq2seq.py:103, convlstm_seq2seq.py:287)."""
         self.step_count += 1
-        self._steps_since_check += 1
         if self.optimizer == "adam":
-            ops.adam_step(self.flat, self.grad, self.m, self.v, self.step_count, lr=self.lr, guards=self._guards())
+            ops.adam_step(self.flat, self.grad, self.m, self.v, self.step_count, lr=self.lr, guards=self._guards(), applied=self.applied)
         else:
-            ops.rmsprop_step(self.flat, self.grad, self.m, lr=self.lr, guards=self._guards())
+            ops.rmsprop_step(self.flat, self.grad, self.m, lr=self.lr, guards=self._guards(), applied=self.applied)
 
     # ---- data parallelism: the flat buffer (poison slot + gradients + loss slot) is SUM all-reduced ----
     # One all-reduce when the step's kernels have all been issued, or - opt-in, FOV_DP_OVERLAP=1 / overlap_allreduce - the
@@ -176,6 +187,7 @@ class FlatParamTrainer:
             self._pending, self._dp = [], False
             loss = self.loss_slot
             self._dp_guard = self.poison_slot
+            self._dp_steps_since_check += 1
         try:
             self.apply_gradients()
         finally:
@@ -293,8 +305,19 @@ class PaddedTrainer:
     def lr(self, v):
         self.inner.lr = v
 
+    _OWN = ("H", "Hp", "hidden_inputs", "_names", "inner")
+
     def __getattr__(self, name):      # train_step, eval_loss, forward_backward, check, step_count, ws, ...
-        return getattr(self.__dict__["inner"], name)
+        inner = self.__dict__.get("inner")
+        if inner is None:             # not constructed yet (copy / pickle probe attributes first)
+            raise AttributeError(name)
+        return getattr(inner, name)
+
+    def __setattr__(self, name, value):      # overlap_allreduce, defer_reduces, fused_decoder, ...: the inner trainer reads them
+        if name in self._OWN or "inner" not in self.__dict__ or name in type(self).__dict__:
+            object.__setattr__(self, name, value)
+        else:
+            setattr(self.__dict__["inner"], name, value)
 
 
 class Seq2SeqTrainer(FlatParamTrainer):

@@ -1511,3 +1511,177 @@ def test_deferred_split_reductions_equal_immediate(dtype):
         torch.cat([x2, x1, torch.ones(N, 1, device="cuda")], 1).double().T @ dz.double()
     tol = 2e-3 if dtype == "f32" else 0.5
     assert (f0[:nfused].view(2 * H + 1, 4 * H).double() - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item() / 100)
+
+
+def _poison(ws):
+    """What a give-up leaves in a workspace: the sticky timeout word (header word 0)."""
+    ws.buf[:4] = torch.tensor([1, 0, 0, 0], dtype=torch.uint8, device="cuda")
+
+
+def test_failed_steps_are_not_counted_and_earlier_ones_are():
+    """Round-3 advisor finding: check() set Adam's step counter back by EVERY step since the last check, including the ones
+    whose updates had been applied.  The guarded optimizer now counts on the device the updates that ran (fov_adam_step_guarded's
+    `applied`): two good steps, a give-up before the third, two skipped steps -> check() raises once and step_count == 2; the
+    next step is Adam's t = 3 on the parameters of step 2, exactly what an undisturbed third step gives."""
+    from longterm360fov_amd import _lib
+    from longterm360fov_amd.training import Seq2SeqTrainer
+    w = O.init_seq2seq(71, H=64, bias_noise=0.05)
+    enc, dec_in, tgt = batch(72, 24, 5, 4)
+    args = (dev(enc), dev(dec_in), dev(tgt))
+    ref = Seq2SeqTrainer(w)
+    for _ in range(3):
+        ref.train_step(*args)
+    ref.check()
+    tr = Seq2SeqTrainer(w)
+    tr.train_step(*args); tr.train_step(*args)
+    after2 = tr.flat.clone()
+    _poison(tr.ws)
+    tr.train_step(*args); tr.train_step(*args)            # skipped on the device, no host synchronisation
+    assert tr.step_count == 4 and torch.equal(tr.flat, after2)
+    with pytest.raises(_lib.FovError) as ei:
+        tr.check()
+    assert ei.value.code == _lib.ERR_TIMEOUT
+    assert tr.step_count == 2 and int(tr.applied.item()) == 2
+    tr.train_step(*args)
+    tr.check()
+    assert tr.step_count == 3 and torch.equal(tr.flat, ref.flat)
+
+
+def _dp_poison_worker(rank, world_size, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world_size)
+    try:
+        from longterm360fov_amd import _lib, parallel
+        from longterm360fov_amd.training import Seq2SeqTrainer
+        w = O.init_seq2seq(123, H=64, bias_noise=0.05)
+        enc, dec_in, tgt = batch(124, 37, 6, 5)
+        lo, hi = parallel.shard_range(37)
+        a = (dev(enc[lo:hi]), dev(dec_in[lo:hi]), dev(tgt[lo:hi]))
+        tr = Seq2SeqTrainer(w)
+        tr.train_step(*a, n_global=37)
+        after1 = tr.flat.detach().cpu().numpy().copy()
+        if rank == 1:
+            _poison(tr.ws)                                # only rank 1's persistent kernels "gave up"
+        tr.train_step(*a, n_global=37)
+        tr.train_step(*a, n_global=37)
+        raised = None
+        try:
+            tr.check()                                    # every rank must leave here the same way
+        except _lib.FovError as e:
+            raised = e.code
+        skipped = bool(np.array_equal(tr.flat.detach().cpu().numpy(), after1))
+        count = tr.step_count
+        # the group is still in step: the next collectives complete (they would hang if one rank had left alone)
+        tr.train_step(*a, n_global=37)
+        tr.check()
+        q.put((rank, raised, skipped, count, tr.step_count, tr.flat.detach().cpu().numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_data_parallel_failed_step_is_skipped_and_reported_on_every_rank():
+    """Round-3 advisor finding (medium): a give-up on ONE rank made every rank skip its updates - but only that rank's check()
+    raised; the others sailed on into the next collective and hung.  Two ranks (gloo, one GPU), rank 1 poisoned after step 1:
+    both skip steps 2 and 3, BOTH raise ERR_TIMEOUT from check(), both set step_count back to 1, and the following step (a
+    collective) completes with bit-identical replicas."""
+    import socket
+    import torch.multiprocessing as mp
+    from longterm360fov_amd import _lib
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_dp_poison_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, raised, skipped, count, count_after, flat in res:
+        assert raised == _lib.ERR_TIMEOUT, (rank, raised)
+        assert skipped, rank
+        assert count == 1 and count_after == 2, (rank, count, count_after)
+    np.testing.assert_array_equal(res[0][5], res[1][5])
+
+
+def test_epoch_rezero_keeps_the_timeout_word():
+    """Round-3 advisor finding: the launch path's re-zero of header and granule area (host epoch past 0x70000000) also cleared a
+    sticky timeout word set since the last fov_check_status.  It now leaves header word 0 alone: the launch that crosses the
+    threshold on a poisoned workspace still skips its body, and the check still reports the give-up."""
+    from longterm360fov_amd import ops, _lib
+    w = O.init_seq2seq(3, H=256, bias_noise=0.05)
+    enc, dec0, _ = O.synthetic_batch(4, 40, 5, 4)
+    dw = {k: dev(v) for k, v in w.items()}
+    ws = ops.Workspace()
+    good = ops.seq2seq_decode(dev(enc), dev(dec0), dw, 4, impl="cluster", workspace=ws).clone()
+    ws.check()
+    L = _lib.lib()
+    _lib.check(L.fov_debug_set_epoch(ws.buf.data_ptr(), ws.buf.numel(), 0x70000000 - 5, torch.cuda.current_stream().cuda_stream))
+    _poison(ws)
+    out = torch.full((40, 4, 6), 7.0, dtype=torch.float32, device="cuda")
+    for _ in range(3):      # the first crosses the threshold
+        ops.seq2seq_decode(dev(enc), dev(dec0), dw, 4, impl="cluster", workspace=ws, out=out)
+    torch.cuda.synchronize()
+    hdr = ws.buf[:32].cpu().numpy().view(np.uint32)
+    assert hdr[0] != 0, "the re-zero erased the timeout word"
+    assert float(out.min()) == 7.0 and float(out.max()) == 7.0
+    with pytest.raises(_lib.FovError):
+        ws.check()
+    again = ops.seq2seq_decode(dev(enc), dev(dec0), dw, 4, impl="cluster", workspace=ws)
+    ws.check()
+    assert torch.equal(again, good)
+
+
+def test_padded_trainer_forwards_attribute_writes():
+    """Round-3 advisor finding: PaddedTrainer forwarded attribute READS to the trainer it wraps but kept WRITES (except lr) to
+    itself, so tr.overlap_allreduce = True on a latent_dim 32 / 64 model silently did nothing."""
+    import copy
+    from longterm360fov_amd.training import PaddedTrainer, Seq2SeqTrainer
+    w = O.init_seq2seq(9, H=32, bias_noise=0.05)
+    tr = PaddedTrainer(lambda wp: Seq2SeqTrainer(wp), w, 32, 64)
+    tr.overlap_allreduce = True
+    tr.defer_reduces = True
+    tr.lr = 5e-4
+    assert tr.inner.overlap_allreduce is True and tr.inner.defer_reduces is True and tr.inner.lr == 5e-4
+    assert "overlap_allreduce" not in tr.__dict__
+    with pytest.raises(AttributeError):
+        PaddedTrainer.__new__(PaddedTrainer).anything      # before `inner` exists: AttributeError, not KeyError (copy / pickle probe this)
+    assert copy.copy(tr).inner is tr.inner
+
+
+def test_workspace_init_forgets_a_prepacked_weight_copy():
+    """Round-3 advisor finding: fov_mix_decoder_prepack's mark survived fov_workspace_init / the reset in fov_check_status, which
+    zero the packed copy: the next fov_mix_decoder_fwd on that workspace skipped its own pack and ran on zeros (a C-ABI caller's
+    problem: the Python trainer packs at every step).  Through the entry points directly: pack, re-initialise, launch."""
+    from longterm360fov_amd import _lib, ops
+    H, U, NO, B, T_in, T_out = 256, 6, 6, 48, 3, 4
+    w = O.init_others_mixing(41, H=H, num_user=U, bias_noise=0.1)
+    enc, dec0, tgt, oth = O.synthetic_batch(42, B, T_in, T_out, num_others=U - 1)
+    dw = {k: dev(v) for k, v in w.items()}
+    n_oth = (U - 1) * NO
+    Wm_o, Wm_p = dw["mix_W"][:n_oth].contiguous(), dw["mix_W"][n_oth:].contiguous()
+    hs1, h1, c1 = ops.lstm_seq(dev(enc), dw["enc1_K"], dw["enc1_R"], dw["enc1_b"])
+    zx = ops.matmul(hs1.reshape(B * T_in, H), dw["enc2_K"]).reshape(B, T_in, 4 * H)
+    _, h2, c2 = ops.lstm_seq_zx(zx, dw["enc2_R"], dw["enc2_b"], return_sequences=False)
+    oth_proj = ops.dense(dev(oth).reshape(B * T_out, n_oth), Wm_o, dw["mix_b"], activation=None).reshape(B, T_out, NO)
+    ws = ops.Workspace()
+    good = ops.mix_decoder(dev(dec0), h1, c1, h2, c2, oth_proj, dw, Wm_p, T_out, workspace=ws).clone()
+    ws.check()
+    L = _lib.lib()
+    stream = torch.cuda.current_stream().cuda_stream
+    ops.mix_decoder_prepack(dw["dec2_K"], B, H, ws)                               # packed copy + mark ...
+    _lib.check(L.fov_workspace_init(ws.buf.data_ptr(), ws.buf.numel(), stream))   # ... zeroed by the caller: the mark must go too
+    again = ops.mix_decoder(dev(dec0), h1, c1, h2, c2, oth_proj, dw, Wm_p, T_out, workspace=ws)
+    ws.check()
+    assert torch.equal(again, good)
+    # the same through the reset inside fov_check_status (a reported give-up zero-fills the workspace)
+    ops.mix_decoder_prepack(dw["dec2_K"], B, H, ws)
+    _poison(ws)
+    with pytest.raises(_lib.FovError):
+        ws.check()
+    third = ops.mix_decoder(dev(dec0), h1, c1, h2, c2, oth_proj, dw, Wm_p, T_out, workspace=ws)
+    ws.check()
+    assert torch.equal(third, good)
