@@ -427,7 +427,6 @@ static std::once_flag g_env_once;
 static int env_flag(const char* name) { const char* e = getenv(name); return (e && e[0] == '1') ? 1 : 0; }
 void env_reload() {
     g_env.force_safe_exchange = env_flag("FOV_FORCE_SAFE_EXCHANGE");
-    g_env.pair_kernel = env_flag("FOV_PAIR");
     g_env.two_launches = getenv("FOV_TWO_LAUNCHES") ? 1 : 0;
     const char* lim = getenv("FOV_DBG_RESIDENT_LIMIT");
     g_env.resident_limit = lim ? atoi(lim) : 0;

@@ -73,7 +73,7 @@ int cluster_num_groups(int B, int H);
 int device_cu_count();                               // CUs of the current device a persistent grid may count on (FOV_DBG_RESIDENT_LIMIT caps it: tests)
 // getenv results cached at first use (fov_reload_env re-reads them): nothing on a launch path calls getenv
 struct EnvKnobs {
-    int force_safe_exchange, pair_kernel, two_launches, resident_limit;
+    int force_safe_exchange, two_launches, resident_limit;
     int bwd_stepped, no_wgrad_fusion, no_dx_fusion, bwd_groups4, gemm_bf16_split, gemm_bf16_noremap;   // experiment switches (tools/)
     int gemm_variant, gemm_split;   // FOV_GEMM_VARIANT / FOV_GEMM_SPLIT: tile shape / K slices of the fp32 GEMM forced (experiments)
     int no_wide16;       // FOV_NO_WIDE16=1: width-512 layers stay on the 16-workgroup form (tests / A-B timing)
@@ -95,9 +95,6 @@ void xch_note_force_safe(void* workspace, int on);
 void xch_set_epoch_for_test(void* workspace, unsigned long long epoch);
 int ensure_dynamic_lds(const void* kern, size_t lds, int block = 256);  // cached hipFuncSetAttribute(MaxDynamicSharedMemorySize) + occupancy check (>= 1 workgroup per CU)
 void set_error(const char* fmt, ...);
-// fused encoder + decoder with two tiles per workgroup, H = 256 (lstm_pair.hip)
-bool pair_shape_ok(int B, int T, int T_out, int F, int F_dec, int H);
-int launch_pair_fused(const LstmParams& p, hipStream_t stream);
 // wide-input layer, H = 256, 96 < F <= 256 (lstm_wide.hip)
 bool wide_shape_ok(int F, int H);
 bool wide_narrow_preferred(int B, int F, int H);

@@ -1146,10 +1146,6 @@ int launch_cluster(const LstmParams& p_in, bool decode, hipStream_t stream) {
     // No memset: epoch tags continue from the workspace header.  A group visits ceil(tiles / groups) tiles and
     // advances its epoch once per step of each.
     const int visits = (p.num_tiles + p.num_groups - 1) / p.num_groups;
-    // FOV_PAIR=1 (opt-in, measured slower so far: DESIGN.md section 5): H = 256 with two tiles per workgroup and two waves
-    // per SIMD (lstm_pair.hip)
-    if (decode && p.H == 256 && !p.hs && !p.reserve && env_knobs().pair_kernel && pair_shape_ok(p.B, p.T, p.T_out, p.F, p.F_dec, p.H))
-        return launch_pair_fused(p, stream);
     if (!decode) {
         p.epoch_span = p.T * visits + 1;
         if (int rc_ = xch_account(p.status, p.epoch_span, stream)) return rc_;

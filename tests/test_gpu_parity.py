@@ -352,36 +352,6 @@ def test_exchange_paths_agree_bitwise():
     assert_parity(outs["0"], ref, "exchange paths vs C oracle", tight=5e-5)
 
 
-@pytest.mark.parametrize("B,T_in,T_out,act", [(16, 3, 2, "sigmoid"), (37, 6, 5, "hard_sigmoid"), (1024, 9, 7, "sigmoid")])
-def test_two_tiles_per_workgroup_kernel(B, T_in, T_out, act):
-    """csrc/lstm_pair.hip (FOV_PAIR=1, opt-in): two 16-sequence tiles per workgroup, two waves per SIMD, the four waves
-    of a set meeting through flag words in LDS.  Same arithmetic as the one-tile kernel, another summation order: checked
-    against the fp64 oracle (odd tile counts leave the second set of the last group idle), both exchange protocols
-    bit-identical, and the final decoder state is written."""
-    ops = _ops()
-    H = 256
-    w = O.init_seq2seq(99 + B, H=H, bias_noise=0.1)
-    enc, dec0, _ = O.synthetic_batch(98 + B, B, T_in, T_out)
-    n = min(B, 64)
-    ref = O.seq2seq_decode(enc[:n].astype(np.float64), dec0[:n].astype(np.float64), f64(w), T_out, act)
-    ws = ops.Workspace()
-    outs = {}
-    try:
-        os.environ["FOV_PAIR"] = "1"
-        for mode in ("0", "1"):
-            os.environ["FOV_FORCE_SAFE_EXCHANGE"] = mode
-            outs[mode] = ops.seq2seq_decode(dev(enc), dev(dec0), devw(w), T_out, act=act, impl="cluster", workspace=ws).clone()
-            ws.check()
-    finally:
-        os.environ.pop("FOV_PAIR", None)
-        os.environ.pop("FOV_FORCE_SAFE_EXCHANGE", None)
-    assert torch.equal(outs["0"], outs["1"])
-    assert_parity(outs["0"][:n], ref, "pair kernel B%d %d->%d %s" % (B, T_in, T_out, act))
-    single = ops.seq2seq_decode(dev(enc), dev(dec0), devw(w), T_out, act=act, impl="cluster", workspace=ws)
-    ws.check()
-    assert float((single - outs["0"]).abs().max()) < 2e-6
-
-
 # ---------------------------------------------------------------------------------------
 # a4: target + others mixing, 2+2 layers, no teacher forcing (given_others_gt_mean_var_seq2seq.py)
 # ---------------------------------------------------------------------------------------
