@@ -240,6 +240,58 @@ def bench_train_mixing(args, rank, world, use_dist):
         dist.destroy_process_group()
 
 
+def dp_probe(args, rank, world, steps=10):
+    """Every rank: `steps` data-parallel training steps of the configs[2] model at 512 sequences per rank (fp32), and the
+    all-reduce of its flat gradient buffer on its own.  -> dict for rank 0's line (times are the MAX over ranks)."""
+    import torch.distributed as dist
+    from longterm360fov_amd.training import OthersMixingTrainer
+    from oracle import fov_oracle as O
+    H, T_in, T_out, U = 256, 10, 10, 34
+    B = int(os.environ.get("FOV_DP_PROBE_BATCH", "512"))     # (rehearsals of two ranks on ONE GPU use a small batch: two full-chip persistent grids cannot be co-resident)
+    out = {"workload": "configs[2] training step, %d sequences per rank x %d ranks, fp32, one flat-buffer SUM all-reduce per step" % (B, world)}
+    try:
+        w = O.init_others_mixing(1234, H=H, num_user=U, bias_noise=0.05)
+        enc, dec0, tgt, oth = O.synthetic_batch(4321 + rank, B, T_in, T_out, num_others=U - 1)
+        d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+        a = (d(enc), d(oth), d(dec0), d(tgt))
+        tr = OthersMixingTrainer(w)
+        for _ in range(3):
+            tr.train_step(*a, n_global=B * world)
+        tr.check()
+        torch.cuda.synchronize()
+        dist.barrier()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(steps):
+            loss = tr.train_step(*a, n_global=B * world)
+        e1.record()
+        torch.cuda.synchronize()
+        tr.check()
+        step_ms = e0.elapsed_time(e1) / steps
+        final_loss = float(loss.item())       # (read now: the loop below sums the buffer, loss slot included, over and over)
+        # the collective alone: the same buffer, the same call, back to back on the launch stream
+        dist.barrier()
+        e0.record()
+        for _ in range(steps):
+            dist.all_reduce(tr.gradbuf, op=dist.ReduceOp.SUM)
+        e1.record()
+        torch.cuda.synchronize()
+        ar_ms = e0.elapsed_time(e1) / steps
+        t = torch.tensor([step_ms, ar_ms], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        step_ms, ar_ms = (float(v) for v in t.tolist())
+        payload = tr.gradbuf.numel() * 4
+        out.update({"dp_step_ms": step_ms, "allreduce_ms": ar_ms, "allreduce_payload_bytes": payload,
+                    "allreduce_algbw_gbps": payload / (ar_ms * 1e-3) / 1e9,
+                    "dp_sequences_per_s": world * B / (step_ms * 1e-3), "final_loss": final_loss,
+                    "allreduce_share_of_step": ar_ms / step_ms,
+                    "note": "step = forward + BPTT + all-reduce (issued at the end of the step, stream-ordered; FOV_DP_OVERLAP stays off: "
+                            "unvalidated against a real RCCL kernel) + Adam; allreduce_ms = the same collective alone, back to back"})
+    except Exception as exc:      # the headline line must still print
+        out["error"] = "%s: %s" % (type(exc).__name__, exc)
+    return out
+
+
 def bench_infer_mixing(args, rank, world, use_dist):
     """Secondary measurement, BASELINE.json configs[2] shape, inference: 2+2-layer others-mixing model, encoder
     over T_in steps + autoregressive decoder with the mixing head, device-resident inputs, replicas only."""
@@ -744,6 +796,8 @@ def main():
                          "(modes train_mixing and infer_mixing)")
     ap.add_argument("--head", default="all", choices=["all", "meanvar", "gmm", "raw"],
                     help="a10 mode: which of lstm.py's heads to time a training step with besides the mean / variance one")
+    ap.add_argument("--no-dp-probe", action="store_true",
+                    help="N > 1, default mode: skip the ten data-parallel configs[2] training steps that follow the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU-baseline timing (both legs together)")
     ap.add_argument("--cpu-threads", type=int, default=16, help="threads of the CPU-baseline legs (default: one GPU's share of the host)")
@@ -799,10 +853,12 @@ def main():
     if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        import datetime
+        # a collective that cannot complete (a rank died) ends the run after three minutes instead of RCCL's default ten
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index), timeout=datetime.timedelta(seconds=180))
         else:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=180))
 
     from longterm360fov_amd import ops
     from oracle import fov_oracle as O   # synthetic data + Keras initialisers (test infrastructure)
@@ -872,6 +928,12 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # N > 1: the headline is replicas only (no data-path collective), so a scaling run of it exercises RCCL's start-up and one
+    # scalar all-reduce, nothing more.  Ten data-parallel training steps of configs[2] (512 sequences per rank, one SUM all-reduce
+    # of the 6.7 MB flat gradient buffer per step - given_others_gt_mean_var_seq2seq.py:494-506 under DP) ride along AFTER the
+    # timed region, so that the same run also says what the gradient all-reduce costs over xGMI.  Reported under `extra`.
+    extra = dp_probe(args, rank, world) if (use_dist and world > 1 and not args.no_dp_probe) else None
+
     result = None
     if rank == 0:
         f_enc, f_dec = flops_per_seq(T_in, T_out, F_enc, F_dec, H)
@@ -938,6 +1000,8 @@ def main():
                        "max_abs_err_vs_torch_cpu": None if cpu_out is None else float(np.abs(out.cpu().numpy() - cpu_out).max())},
             "cpu_baseline": cpu,
         }
+        if extra is not None:
+            result["extra"] = extra
         if cpu:
             result["speedup_vs_cpu_baseline"] = value / cpu["value"]
         print(json.dumps(result), flush=True)
