@@ -846,6 +846,69 @@ class OthersContextSeq2Seq(KerasModelSurface):
         return super().train_on_batch(x, y)
 
 
+class NoTeacherForcingOthersConvLSTM(KerasModelSurface):
+    """The second model of mycode/FoV_seq2seq_no_teac_forc.py (:420-486): no teacher forcing, the decoder's Dense head
+    concatenates the decoder output with Dense(latent_dim)(Flatten(.)) of a ConvLSTM2D(latent_dim, kernel (num_user-1, 3),
+    'same') run over the other users' future.  Inputs as the script's Model (:486): [encoder_input (N,T_in,F),
+    others_fut_input (N,T_out,num_user-1,fps,3), decoder_input (N,1,6)] -> (N,T_out,6); compile('Adam', 'mean_squared_error'),
+    fit / predict as :553-558,565-570 (training.OthersFutureConvLSTMTrainer)."""
+
+    def __init__(self, num_encoder_tokens=None, num_decoder_tokens=6, latent_dim=64, num_user=34, fps=None, recurrent_activation=None,
+                 seed=None, impl="auto", device="cuda"):
+        from .training import OTHERS_FUTURE_ORDER
+        self.F = 3 * cfg.fps if num_encoder_tokens is None else int(num_encoder_tokens)
+        self.O, self.H, self.U = int(num_decoder_tokens), int(latent_dim), int(num_user)
+        self.fps = cfg.fps if fps is None else int(fps)
+        self.recurrent_activation = recurrent_activation or cfg.recurrent_activation
+        rng = np.random.default_rng(seed)
+        w, H = {}, self.H
+        w["enc_K"], w["enc_R"], w["enc_b"] = init_lstm_weights(rng, self.F, H)
+        kh, kw = self.U - 1, 3
+        rf = kh * kw
+        lim = np.sqrt(6.0 / (rf * 3 + rf * 4 * H))               # glorot_uniform over the receptive field
+        w["oth_K"] = rng.uniform(-lim, lim, (kh, kw, 3, 4 * H)).astype(np.float32)
+        w["oth_R"] = orthogonal(rng, kh * kw * H, 4 * H).reshape(kh, kw, H, 4 * H)
+        w["oth_b"] = np.zeros(4 * H, np.float32)
+        w["oth_b"][H:2 * H] = 1.0                                # unit_forget_bias
+        w["flat_W"] = glorot_uniform(rng, kh * self.fps * H, H)
+        w["flat_b"] = np.zeros(H, np.float32)
+        w["dec_K"], w["dec_R"], w["dec_b"] = init_lstm_weights(rng, self.O, H)
+        w["dense_W"] = glorot_uniform(rng, 2 * H, self.O)
+        w["dense_b"] = np.zeros(self.O, np.float32)
+        self._w = w
+        self._init_surface(OTHERS_FUTURE_ORDER, impl, device)
+
+    def _make_trainer(self, optimizer):
+        from .training import OthersFutureConvLSTMTrainer
+        return OthersFutureConvLSTMTrainer(self._w, act=self.recurrent_activation, impl=self.impl, optimizer=optimizer, lr=self._lr,
+                                           device=self.device)
+
+    def predict(self, x, batch_size=None, verbose=0):
+        import torch
+        from . import ops
+        enc, oth, dec0 = (_as_f32(a) for a in x)
+        tr = self._get_trainer()
+        if self._dw is None:          # weights were set from outside since the trainer last saw them
+            tr.load_weights_(self._w)
+            self._dw = tr.w
+        n, T_out = enc.shape[0], oth.shape[1]
+        bs = n if not batch_size else int(batch_size)
+        outs = []
+        for lo in range(0, n, max(bs, 1)):
+            d = lambda a: torch.from_numpy(a[lo:lo + bs]).to(self.device)
+            e = d(enc)
+            B = e.shape[0]
+            _, hT, cT = ops.lstm_seq(e, tr.w["enc_K"], tr.w["enc_R"], tr.w["enc_b"], act=self.recurrent_activation, impl=self.impl,
+                                     return_sequences=False, workspace=tr.ws)
+            S, _ = tr.branch_forward(d(oth), tape=False)
+            tp = tr.decode(d(dec0).reshape(B, self.O), hT, cT, S, T_out, tape=False)
+            outs.append(tp["XA"][1:].transpose(0, 1).cpu().numpy())
+        tr.check()
+        return np.concatenate(outs, axis=0) if outs else np.zeros((0, T_out, self.O), np.float32)
+
+    predict_on_batch = predict
+
+
 class KerasSingleLSTM(KerasModelSurface):
     """Single-layer model of mycode/lstm_keras.py: ONE LSTM from zero state + Dense(6, tanh) per step, Adam + MSE.
       unrolled=False  1st part (:59-83): x (N,T,F) -> (N,T,6), one input second per step;

@@ -545,6 +545,130 @@ class SelfFedSeq2SeqTrainer(FlatParamTrainer):
 
 
 
+OTHERS_FUTURE_ORDER = ("enc_K", "enc_R", "enc_b", "oth_K", "oth_R", "oth_b", "flat_W", "flat_b", "dec_K", "dec_R", "dec_b",
+                       "dense_W", "dense_b")
+
+
+class OthersFutureConvLSTMTrainer(FlatParamTrainer):
+    """Training step of the SECOND model of mycode/FoV_seq2seq_no_teac_forc.py (:420-486, fit at :553-558): the unrolled
+    no-teacher-forcing decoder (seeded by the encoder's state) whose Dense(6, tanh) head sees concat[decoder output,
+    Dense(latent_dim)(Flatten(ConvLSTM2D output t))], the ConvLSTM2D (filters = latent_dim, kernel (num_user-1, 3), 'same')
+    running over the other users' future (B,T_out,num_user-1,fps,3) from zero state.  Adam + MSE.
+
+    The branch does not depend on the decoder: its T_out steps run first (one fused cell launch per step, conv_kernels.hip),
+    Flatten + Dense is ONE product over all steps, and its share of the head, s_t . dense_W[H:], is added per step inside the
+    decoder's Dense launch (fov_dense_add_fwd).  Backward: the self-fed decoder in reverse (as SelfFedSeq2SeqTrainer), every
+    weight gradient one product over all steps, then the branch's BPTT (gate backward + a forward convolution with the transposed
+    recurrent kernel per step, weight gradients by conv2d_wgrad over the stacked steps), then the encoder's BPTT."""
+
+    def __init__(self, weights, act="sigmoid", conv_act="hard_sigmoid", impl="auto", optimizer="adam", lr=1e-3, device="cuda"):
+        self.act, self.conv_act, self.impl = act, conv_act, impl
+        self._alloc(weights, OTHERS_FUTURE_ORDER, optimizer, lr, device)
+
+    def branch_forward(self, others, tape=True):
+        """others (B,T,U-1,fps,3) -> S (T*B, H) = Dense(Flatten(ConvLSTM2D output)) per step, time-major; + the tape."""
+        w = self.w
+        B, T, U1, Wd, C = others.shape
+        H = w["oth_R"].shape[2]
+        e = lambda *s_: torch.empty(s_, dtype=torch.float32, device=self.device)
+        xs = others.permute(1, 0, 2, 3, 4).contiguous()
+        hs, cs = e(T, B, U1, Wd, H), e(T, B, U1, Wd, H)
+        gs = e(T, B, U1, Wd, 4 * H) if tape else None
+        KR = torch.cat([w["oth_K"], w["oth_R"]], 2)            # [K ; R]: both convolutions of a step in one launch
+        for t in range(T):
+            if t > 0:
+                ops.convlstm_cell(xs[t], hs[t - 1], KR, w["oth_b"], cs[t - 1], hs[t], self.conv_act, c_new=cs[t], gates=None if gs is None else gs[t])
+            else:
+                ops.convlstm_cell(xs[0], None, w["oth_K"], w["oth_b"], None, hs[0], self.conv_act, c_new=cs[0], gates=None if gs is None else gs[0])
+        S = ops.dense(hs.reshape(T * B, U1 * Wd * H), w["flat_W"], w["flat_b"], activation=None)
+        return S, {"xs": xs, "hs": hs, "cs": cs, "gs": gs}
+
+    def decode(self, x0, h0, c0, S, T, tape=True):
+        """The unrolled decoder: x0 (B,O), (h0, c0) the encoder's state, S (T*B,H).  -> tape with XA[1:] = y_t (T,B,O)."""
+        w, act, impl, ws = self.w, self.act, self.impl, self.ws
+        B, O = x0.shape
+        H = w["dec_R"].shape[0]
+        e = lambda *s_: torch.empty(s_, dtype=torch.float32, device=self.device)
+        Wh, Wc = w["dense_W"][:H], w["dense_W"][H:]
+        ADD = ops.matmul(S, Wc, scratch=self.scratch).reshape(T, B, O)      # the branch's share of the head's pre-activation
+        tp = {"Hs": e(T + 1, B, H), "Cs": e(T + 1, B, H), "XA": e(T + 1, B, O), "RES": e(T, B, 1, 5, H) if tape else None, "T": T}
+        tp["XA"][0].copy_(x0); tp["Hs"][0].copy_(h0); tp["Cs"][0].copy_(c0)
+        Hs, Cs, XA = tp["Hs"], tp["Cs"], tp["XA"]
+        for t in range(T):
+            if tape:
+                ops.lstm_seq_train(XA[t].view(B, 1, O), w["dec_K"], w["dec_R"], w["dec_b"], Hs[t], Cs[t], act=act, impl=impl, workspace=ws,
+                                   out=(Hs[t + 1].view(B, 1, H), None, Cs[t + 1], tp["RES"][t]))
+            else:
+                _, hT, cT = ops.lstm_seq(XA[t].view(B, 1, O), w["dec_K"], w["dec_R"], w["dec_b"], Hs[t], Cs[t], act=act, impl=impl,
+                                         return_sequences=False, workspace=ws)
+                Hs[t + 1].copy_(hT); Cs[t + 1].copy_(cT)
+            ops.dense_add(Hs[t + 1], Wh, w["dense_b"], ADD[t], activation="tanh", out=XA[t + 1])
+        return tp
+
+    def forward_backward(self, enc, others, dec_in, target, grad_weight=1.0):
+        """enc (B,T_in,F), others (B,T_out,U-1,fps,3), dec_in (B,1,O), target (B,T_out,O) -> (loss (1,), prediction (B,T_out,O))."""
+        w, g, act, impl, ws, sc, bsc = self.w, self.g, self.act, self.impl, self.ws, self.scratch, self.bwd_scratch
+        B, T_in, F = enc.shape
+        T = target.shape[1]
+        O = w["dense_W"].shape[1]
+        H = w["dec_R"].shape[0]
+        e = lambda *s_: torch.empty(s_, dtype=torch.float32, device=self.device)
+        self.grad.zero_()
+        # ---------------- forward ----------------
+        ehs, ehT, ecT, eres = ops.lstm_seq_train(enc, w["enc_K"], w["enc_R"], w["enc_b"], act=act, impl=impl, workspace=ws)
+        S, bt = self.branch_forward(others)
+        tp = self.decode(dec_in.reshape(B, O), ehT, ecT, S, T)
+        Hs, Cs, XA = tp["Hs"], tp["Cs"], tp["XA"]
+        out = XA[1:].transpose(0, 1).contiguous()
+        # ---------------- backward: the self-fed decoder ----------------
+        dloss, loss = ops.mse_dense_grad(out, target, None, scratch=sc)            # dL/dy, all steps
+        dloss_tm = dloss.transpose(0, 1).contiguous()
+        Wh, Wc = w["dense_W"][:H], w["dense_W"][H:]
+        DY, DPRE, DZ = e(T, B, O), e(T, B, O), e(T, B, 4 * H)
+        dh_rec = dc = dx_next = None
+        for t in range(T - 1, -1, -1):
+            if dx_next is None:
+                DY[t].copy_(dloss_tm[t])
+            else:                                                                  # x_{t+1} = y_t: the feedback gradient joins
+                ops.act_bwd(dx_next.reshape(B, O), XA[t + 1], base=dloss_tm[t], activation=None, out=DY[t])
+            ops.act_bwd(DY[t], XA[t + 1], activation="tanh", out=DPRE[t])
+            dh_dense, _, _ = ops.dense_bwd(Hs[t + 1], Wh, DPRE[t], need_dx=True, need_dW=False, need_db=False, scratch=sc)
+            b = ops.lstm_seq_bwd(XA[t].view(B, 1, O), w["dec_K"], w["dec_R"], Hs[t + 1].view(B, 1, H), tp["RES"][t], h0=Hs[t], c0=Cs[t],
+                                 dhs=dh_dense.reshape(B, 1, H), dhT=dh_rec, dcT=dc, need_dx=True, need_state_grads=True, act=act,
+                                 dz=DZ[t].view(B, 1, 4 * H), scratch=bsc, need_weight_grads=False)
+            dh_rec, dc, dx_next = b["dh0"], b["dc0"], b["dx"]
+        TB = T * B
+        fl = lambda a, n: a.reshape(TB, n)
+        ops.dense_bwd(fl(Hs[1:], H), Wh, fl(DPRE, O), dW=g["dense_W"][:H], db=g["dense_b"], need_dx=False, scratch=sc)
+        dS, _, _ = ops.dense_bwd(S, Wc, fl(DPRE, O), dW=g["dense_W"][H:], need_db=False, need_dx=True, scratch=sc)
+        ops.dense_bwd(fl(XA[:T], O), w["dec_K"], fl(DZ, 4 * H), dW=g["dec_K"], db=g["dec_b"], need_dx=False, scratch=sc)
+        ops.dense_bwd(fl(Hs[:T], H), w["dec_R"], fl(DZ, 4 * H), dW=g["dec_R"], need_db=False, need_dx=False, scratch=sc)
+        # ---------------- the others' future branch ----------------
+        xs, hs, cs, gs = bt["xs"], bt["hs"], bt["cs"], bt["gs"]
+        U1, Wd = xs.shape[2], xs.shape[3]
+        dHS, _, _ = ops.dense_bwd(hs.reshape(TB, U1 * Wd * H), w["flat_W"], dS, dW=g["flat_W"], db=g["flat_b"], need_dx=True, scratch=sc)
+        dHS = dHS.reshape(T, B, U1, Wd, H)
+        kh, kw = w["oth_K"].shape[:2]
+        wtR = ops.conv2d_weight_transpose(w["oth_R"])
+        edz = torch.empty_like(gs)
+        dcl = torch.zeros((B, U1, Wd, H), dtype=torch.float32, device=self.device)
+        dhr = None
+        for t in range(T - 1, -1, -1):
+            dh = dHS[t] if dhr is None else ops.act_bwd(dhr, dhr, base=dHS[t], activation=None)
+            dz = ops.convlstm_gates_bwd(dh, dcl, gs[t], cs[t - 1] if t > 0 else None, cs[t], self.conv_act, dz=edz[t])
+            if t > 0:
+                dhr = ops.conv2d(dz, wtR)
+        ops.conv2d_wgrad(xs, edz, kh, kw, dw=g["oth_K"], scratch=sc)
+        if T > 1:
+            ops.conv2d_wgrad(hs[:T - 1], edz[1:], kh, kw, dw=g["oth_R"], scratch=sc)
+        ops.colsum(edz, out=g["oth_b"], scratch=sc)
+        # ---------------- the encoder (its state seeds the decoder) ----------------
+        ops.lstm_seq_bwd(enc, w["enc_K"], w["enc_R"], ehs, eres, dhT=dh_rec, dcT=dc, dK=g["enc_K"], dR=g["enc_R"], db=g["enc_b"], act=act,
+                         scratch=bsc)
+        loss = self._weigh(loss, grad_weight)
+        return loss, out
+
+
 def stacked_weight_order(num_layers):
     return tuple("%s%d_%s" % (side, l, n) for side in ("enc", "dec") for l in range(num_layers) for n in ("K", "R", "b")) + \
         ("dense_W", "dense_b")

@@ -901,3 +901,58 @@ def tf_lstm_raw_refeed_loss(x, y, cells, head, init_state, use_reg=False, forget
         preds.append(p)
         win = np.concatenate([win[:, 1:], p], axis=1)
     return loss, np.stack(preds)
+
+
+# --------------------------------------------------------------------------------------
+# Second half of mycode/FoV_seq2seq_no_teac_forc.py (:420-486): the unrolled no-teacher-forcing decoder whose Dense head
+# also sees the OTHER users' future through a ConvLSTM2D branch.
+#   encoder LSTM(latent_dim) -> (h, c) seed the decoder (:431-434; this half has no decoder_no_init_state switch)
+#   ConvLSTM2D(filters = latent_dim, kernel_size = (num_user-1, 3), 'same', return_sequences) over the others' future
+#       (B, T_out, num_user-1, fps, 3) from zero state (:438-448) - it does not depend on the decoder
+#   step t: d_t = LSTM(x_t; h, c);  s_t = Dense(latent_dim, linear)(Flatten(convlstm output t))  (:468-470)
+#           y_t = Dense(6, tanh)(concat[d_t, s_t]) (:471-472);  x_{t+1} = y_t (:476)
+# --------------------------------------------------------------------------------------
+OTHERS_FUTURE_ORDER = ("enc_K", "enc_R", "enc_b", "oth_K", "oth_R", "oth_b", "flat_W", "flat_b", "dec_K", "dec_R", "dec_b",
+                       "dense_W", "dense_b")
+
+
+def others_future_convlstm_forward(enc_in, others_fut, dec_in0, w, act="sigmoid", conv_act="hard_sigmoid"):
+    """enc_in (B,T_in,F), others_fut (B,T_out,U-1,fps,3), dec_in0 (B,1,O) -> (B,T_out,O)."""
+    _, h, c = lstm_layer(enc_in, w["enc_K"], w["enc_R"], w["enc_b"], act=act)
+    hs, _, _ = convlstm2d_layer(others_fut, w["oth_K"], w["oth_R"], w["oth_b"], act=conv_act)     # (B,T,U-1,fps,H)
+    B, T = hs.shape[:2]
+    s = hs.reshape(B, T, -1) @ w["flat_W"] + w["flat_b"]          # Keras Flatten of a channels-last map: (row, column, filter)
+    x, out = dec_in0[:, 0].astype(enc_in.dtype), []
+    for t in range(T):
+        h, c = lstm_step(x, h, c, w["dec_K"], w["dec_R"], w["dec_b"], act)
+        x = np.tanh(np.concatenate([h, s[:, t]], axis=1) @ w["dense_W"] + w["dense_b"])
+        out.append(x)
+    return np.stack(out, axis=1)
+
+
+def init_others_future_convlstm(seed, F_enc=90, F_dec=6, H=64, num_user=34, fps=30, dtype=np.float32, bias_noise=0.0):
+    rng = np.random.default_rng(seed)
+    w = {}
+    w["enc_K"], w["enc_R"], w["enc_b"] = init_lstm(rng, F_enc, H, dtype)
+    w["dec_K"], w["dec_R"], w["dec_b"] = init_lstm(rng, F_dec, H, dtype)
+    kh, kw = num_user - 1, 3
+
+    def glorot(shape):
+        rf = int(np.prod(shape[:-2]))
+        lim = np.sqrt(6.0 / (rf * shape[-2] + rf * shape[-1]))
+        return rng.uniform(-lim, lim, shape).astype(dtype)
+
+    w["oth_K"] = glorot((kh, kw, 3, 4 * H))
+    w["oth_R"] = _orthogonal(rng, kh * kw * H, 4 * H, dtype).reshape(kh, kw, H, 4 * H)
+    b = np.zeros(4 * H, dtype)
+    b[H:2 * H] = 1
+    w["oth_b"] = b
+    n_flat = (num_user - 1) * fps * H
+    w["flat_W"] = _glorot_uniform(rng, n_flat, H, dtype)
+    w["flat_b"] = np.zeros(H, dtype)
+    w["dense_W"] = _glorot_uniform(rng, 2 * H, F_dec, dtype)
+    w["dense_b"] = np.zeros(F_dec, dtype)
+    if bias_noise:
+        for k in ("enc_b", "dec_b", "oth_b", "flat_b", "dense_b"):
+            w[k] = (w[k] + bias_noise * rng.standard_normal(w[k].shape)).astype(dtype)
+    return w
