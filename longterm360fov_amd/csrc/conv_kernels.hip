@@ -374,6 +374,9 @@ int conv2d_fwd2(const float* x, long ldx, long ldb, int C, const float* x2, long
         set_error("conv2d: operand larger than 2 GiB");
         return FOV_ERR_UNSUPPORTED;
     }
+    // one input segment, a map small enough to sit in LDS, enough channels to be worth it: the map-resident form (conv_patch.hip)
+    if (!x2 && conv_patch_shape_ok(x, ldx, ldb, B, H, W, C, N, kh, kw))
+        return launch_conv_patch(x, ldx, ldb, w, bias, add, y, B, H, W, C, N, kh, kw, act, stream);
     const bool avec = (C & 3) == 0 && (ldx & 3) == 0 && (ldb & 3) == 0 && (((uintptr_t)x) & 15) == 0 &&
                       (!x2 || ((C2 & 3) == 0 && (ldx2 & 3) == 0 && (ldb2 & 3) == 0 && (((uintptr_t)x2) & 15) == 0));
     const bool bvec = (N & 3) == 0 && (((uintptr_t)w) & 15) == 0;

@@ -431,6 +431,7 @@ void env_reload() {
     const char* lim = getenv("FOV_DBG_RESIDENT_LIMIT");
     g_env.resident_limit = lim ? atoi(lim) : 0;
     g_env.no_cell_patch = env_flag("FOV_NO_CELL_PATCH");
+    g_env.no_conv_patch = env_flag("FOV_NO_CONV_PATCH");
     g_env.no_wide16 = env_flag("FOV_NO_WIDE16");
     g_env.no_xcd_pad = getenv("FOV_NO_XCD_PAD") ? 1 : 0;
     { const char* pm = getenv("FOV_XCD_PAD_MAX"); g_env.xcd_pad_max = pm ? atoi(pm) : 16; }

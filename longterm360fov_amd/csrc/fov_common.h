@@ -78,6 +78,7 @@ struct EnvKnobs {
     int gemm_variant, gemm_split;   // FOV_GEMM_VARIANT / FOV_GEMM_SPLIT: tile shape / K slices of the fp32 GEMM forced (experiments)
     int no_wide16;       // FOV_NO_WIDE16=1: width-512 layers stay on the 16-workgroup form (tests / A-B timing)
     int no_cell_patch;   // FOV_NO_CELL_PATCH=1: ConvLSTM2D steps stay on the implicit-GEMM cell (tests compare the two forms)
+    int no_conv_patch;   // FOV_NO_CONV_PATCH=1: Conv2D layers stay on the tap-gathering implicit GEMM (tests / A-B timing; conv_patch.hip)
     int no_xcd_pad;      // FOV_NO_XCD_PAD=1: no padded grids for same-XCD placement (lstm_wide16 / lstm_bwd16 / fused H = 128 kernel)
     int xcd_pad_max;     // FOV_XCD_PAD_MAX: members per group up to which a grid is padded (default 16; 32 measured slower)
     int no_bwd16_narrow; // FOV_NO_BWD16_NARROW=1: widths 128 / 256 keep the 2- / 4- / 8-workgroup BPTT kernels at small batches
@@ -119,6 +120,10 @@ int conv2d_fwd2(const float* x, long ldx, long ldb, int C, const float* x2, long
                 hipStream_t stream);
 int convlstm_gates(const float* z, float* c, float* h, long ldh, long rows, int F, int act, hipStream_t stream);
 // LDS-resident-patch form of the ConvLSTM2D step (convlstm_patch.hip); convlstm_cell_fwd takes it when the shape allows
+// 'same' Conv2D with the input map resident in LDS (conv_patch.hip): the wide layers of the ConvLSTM prediction head
+bool conv_patch_shape_ok(const float* x, long ldx, long ldb, int B, int H, int W, int C, int N, int kh, int kw);
+int launch_conv_patch(const float* x, long ldx, long ldb, const float* w, const float* bias, const float* add, float* y, int B, int H,
+                      int W, int C, int N, int kh, int kw, int act, hipStream_t stream);
 bool cell_patch_shape_ok(const float* x, long ldx, long ldb, int C, const float* h_prev, long ldx2, long ldb2, int F, int H, int W,
                          int kh, int kw);
 int launch_cell_patch(const float* x, long ldx, long ldb, int C, const float* h_prev, long ldx2, long ldb2, const float* w,

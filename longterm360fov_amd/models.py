@@ -1354,6 +1354,20 @@ class ConvLSTMSeq2Seq(KerasModelSurface):
         from . import ops
         enc, dec0 = _as_f32(x[0]), _as_f32(x[1])
         T_out = cfg.predict_step if predict_step is None else int(predict_step)
+        n = enc.shape[0]
+        bs = n if not batch_size else int(batch_size)
+        outs = []
+        for lo in range(0, n, max(bs, 1)):
+            out = self.predict_device(torch.from_numpy(enc[lo:lo + bs]).to(self.device), torch.from_numpy(dec0[lo:lo + bs]).to(self.device), T_out)
+            outs.append(out.cpu().numpy())
+        return np.concatenate(outs, axis=0) if outs else np.zeros((0, T_out), np.float32)
+
+    def predict_device(self, xe, dec0, predict_step=None):
+        """predict on device-resident inputs: xe (B,T_in,H,W,C), dec0 (B,1,H,W,C) float32 tensors on self.device -> the
+        prediction as a device tensor (B,T_out,H,W,C_out) / (B,T_out,6); no host transfer (what bench.py times)."""
+        import torch
+        from . import ops
+        T_out = cfg.predict_step if predict_step is None else int(predict_step)
         if self._dw is None:
             self._dw = {k: torch.from_numpy(v).to(self.device) for k, v in self._w.items()}
             for side in ("enc", "dec"):     # [K ; R] stacked along the input-channel axis: one convolution per cell step
@@ -1367,62 +1381,56 @@ class ConvLSTMSeq2Seq(KerasModelSurface):
         filters = [dw["enc%d_R" % l].shape[2] for l in range(3)]
         cat = sum(filters)
         offs = [0, filters[0], filters[0] + filters[1]]
-        n = enc.shape[0]
-        bs = n if not batch_size else int(batch_size)
-        outs = []
         e4 = lambda *s: torch.empty(s, dtype=torch.float32, device=self.device)
-        for lo in range(0, n, max(bs, 1)):
-            xe = torch.from_numpy(enc[lo:lo + bs]).to(self.device)
-            inp = torch.from_numpy(dec0[lo:lo + bs, 0]).to(self.device)
-            B, T_in, H, W, C_in = xe.shape
-            pad = (-C_in) % 4
-            if pad:       # channel-pad the input maps once: 30 -> 32 keeps every pixel 16-byte aligned
-                xe = torch.cat([xe, torch.zeros((B, T_in, H, W, pad), dtype=torch.float32, device=self.device)], -1)
-                inp = torch.cat([inp, torch.zeros(inp.shape[:-1] + (pad,), dtype=torch.float32, device=self.device)], -1)
-            # encoder: layer l runs over the whole sequence of layer l-1 (return_sequences=True)
-            seq = [xe[:, t] for t in range(T_in)]
-            states = []
+        inp = dec0[:, 0]
+        B, T_in, H, W, C_in = xe.shape
+        pad = (-C_in) % 4
+        if pad:       # channel-pad the input maps once: 30 -> 32 keeps every pixel 16-byte aligned
+            xe = torch.cat([xe, torch.zeros((B, T_in, H, W, pad), dtype=torch.float32, device=self.device)], -1)
+            inp = torch.cat([inp, torch.zeros(inp.shape[:-1] + (pad,), dtype=torch.float32, device=self.device)], -1)
+        # encoder: layer l runs over the whole sequence of layer l-1 (return_sequences=True)
+        seq = [xe[:, t] for t in range(T_in)]
+        states = []
+        for l, F in enumerate(filters):
+            h = torch.zeros((B, H, W, F), dtype=torch.float32, device=self.device)
+            c = torch.zeros((B, H, W, F), dtype=torch.float32, device=self.device)
+            KR, b = dw["enc%d_KR" % l], dw["enc%d_b" % l]
+            nxt = []
+            for t in range(T_in):
+                hn = e4(B, H, W, F)
+                ops.convlstm_cell(seq[t], h, KR, b, c, hn, act)   # conv(x_t, K) + conv(h, R) + b, gates, c / h update: one launch
+                h = hn
+                nxt.append(h)
+            seq = nxt
+            states.append([h, c])
+        # decoder: three cells per step, each h written straight into its slot of the concat map
+        dense_head = self.head == "dense"
+        out = e4(B, T_out, 6) if dense_head else e4(B, T_out, H, W, dw["head2_W"].shape[3])
+        for t in range(T_out):
+            feat = e4(B, H, W, cat)
+            cur = inp
             for l, F in enumerate(filters):
-                h = torch.zeros((B, H, W, F), dtype=torch.float32, device=self.device)
-                c = torch.zeros((B, H, W, F), dtype=torch.float32, device=self.device)
-                KR, b = dw["enc%d_KR" % l], dw["enc%d_b" % l]
-                nxt = []
-                for t in range(T_in):
-                    hn = e4(B, H, W, F)
-                    ops.convlstm_cell(seq[t], h, KR, b, c, hn, act)   # conv(x_t, K) + conv(h, R) + b, gates, c / h update: one launch
-                    h = hn
-                    nxt.append(h)
-                seq = nxt
-                states.append([h, c])
-            # decoder: three cells per step, each h written straight into its slot of the concat map
-            dense_head = self.head == "dense"
-            out = e4(B, T_out, 6) if dense_head else e4(B, T_out, H, W, dw["head2_W"].shape[3])
-            for t in range(T_out):
-                feat = e4(B, H, W, cat)
-                cur = inp
-                for l, F in enumerate(filters):
-                    hslot = feat[..., offs[l]:offs[l] + F]
-                    ops.convlstm_cell(cur, states[l][0], dw["dec%d_KR" % l], dw["dec%d_b" % l], states[l][1], hslot, act)
-                    states[l][0] = hslot
-                    cur = hslot
-                if dense_head:   # Flatten + Dense(6): cfg.predict_mean_var, output fed back as a 1x1x6 map
-                    y = ops.dense(feat.reshape(B, H * W * cat), dw["head0_W"], dw["head0_b"], activation=None)
-                    out[:, t] = y
-                    if pad:
-                        inp[..., :C_in] = y.reshape(B, 1, 1, 6)
-                    else:
-                        inp = y.reshape(B, 1, 1, 6)
-                    continue
-                y = ops.conv2d(feat, dw["head0_W"], dw["head0_b"], activation="relu")
-                y = ops.conv2d(y, dw["head1_W"], dw["head1_b"], activation="relu")
-                y = ops.conv2d(y, dw["head2_W"], dw["head2_b"], activation="relu" if self.head == "conv2d" else None)
-                y = ops.softmax_lastdim(y)
+                hslot = feat[..., offs[l]:offs[l] + F]
+                ops.convlstm_cell(cur, states[l][0], dw["dec%d_KR" % l], dw["dec%d_b" % l], states[l][1], hslot, act)
+                states[l][0] = hslot
+                cur = hslot
+            if dense_head:   # Flatten + Dense(6): cfg.predict_mean_var, output fed back as a 1x1x6 map
+                y = ops.dense(feat.reshape(B, H * W * cat), dw["head0_W"], dw["head0_b"], activation=None)
                 out[:, t] = y
                 if pad:
-                    inp[..., :C_in] = y
+                    inp[..., :C_in] = y.reshape(B, 1, 1, 6)
                 else:
-                    inp = y
-            outs.append(out.cpu().numpy())
-        return np.concatenate(outs, axis=0)
+                    inp = y.reshape(B, 1, 1, 6)
+                continue
+            y = ops.conv2d(feat, dw["head0_W"], dw["head0_b"], activation="relu")
+            y = ops.conv2d(y, dw["head1_W"], dw["head1_b"], activation="relu")
+            y = ops.conv2d(y, dw["head2_W"], dw["head2_b"], activation="relu" if self.head == "conv2d" else None)
+            y = ops.softmax_lastdim(y)
+            out[:, t] = y
+            if pad:
+                inp[..., :C_in] = y
+            else:
+                inp = y
+        return out
 
     predict_on_batch = predict

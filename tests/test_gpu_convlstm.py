@@ -564,3 +564,40 @@ def test_convlstm_heatmap_fork_categorical_crossentropy():
     m.compile(loss="categorical_crossentropy", optimizer="adam", metrics=["accuracy"])
     losses = [m.train_on_batch([enc, dec0], tgt) for _ in range(4)]
     assert losses[-1] < losses[0]
+
+
+@pytest.mark.parametrize("B,H,W,C,N,kh,kw", [(3, 36, 18, 56, 512, 5, 5), (2, 36, 18, 512, 200, 5, 5), (2, 36, 18, 128, 30, 5, 5),
+                                             (2, 18, 36, 64, 56, 3, 3), (5, 36, 18, 33, 130, 5, 3), (1, 27, 9, 48, 64, 5, 5)])
+def test_conv2d_map_resident_form(B, H, W, C, N, kh, kw):
+    """conv_patch.hip (round 4): the prediction head's convolutions with the whole input map resident in LDS - all three wave
+    arrangements (128 / 64 / 32 output channels per workgroup), channel counts that are no multiple of 16 or of 4, output widths that
+    are no multiple of the block, 3 x 3 and 5 x 3 kernels, strided inputs - against the NumPy oracle, and against the tap-gathering
+    implicit GEMM (FOV_NO_CONV_PATCH=1), which sums in another order."""
+    from longterm360fov_amd import ops, _lib
+    rng = np.random.default_rng(B * 1000 + C + N)
+    x = rng.standard_normal((B, H, W, C)).astype(np.float32)
+    w = (rng.standard_normal((kh, kw, C, N)) / np.sqrt(kh * kw * C)).astype(np.float32)
+    b = rng.standard_normal(N).astype(np.float32)
+    add = rng.standard_normal((B, H, W, N)).astype(np.float32)
+    ref = O.conv2d_same(x.astype(np.float64), w.astype(np.float64), b.astype(np.float64))
+    got = ops.conv2d(dev(x), dev(w), dev(b))
+    close(got, ref, "map-resident conv2d")
+    close(ops.conv2d(dev(x), dev(w), dev(b), add=dev(add), activation="relu"), np.maximum(ref + add, 0), "map-resident conv2d+add+relu")
+    close(ops.conv2d(dev(x), dev(w)), ref - b, "map-resident conv2d, no bias")
+    if C % 4 == 0:
+        wide = rng.standard_normal((B, H, W, C + 12)).astype(np.float32)
+        ref2 = O.conv2d_same(wide[..., 8:8 + C].astype(np.float64), w.astype(np.float64))
+        close(ops.conv2d(dev(wide)[..., 8:8 + C], dev(w)), ref2, "map-resident conv2d, channel slice of a wider map")
+    seq = rng.standard_normal((B, 2, H, W, C)).astype(np.float32)
+    ref3 = O.conv2d_same(seq[:, 1].astype(np.float64), w.astype(np.float64))
+    close(ops.conv2d(dev(seq)[:, 1], dev(w)), ref3, "map-resident conv2d, batch-strided input")
+    try:
+        os.environ["FOV_NO_CONV_PATCH"] = "1"
+        _lib.lib().fov_reload_env()
+        old = ops.conv2d(dev(x), dev(w), dev(b))
+    finally:
+        os.environ.pop("FOV_NO_CONV_PATCH", None)
+        _lib.lib().fov_reload_env()
+    d = (got - old).abs().max().item()
+    assert d <= 2e-5 * float(np.abs(ref).max()), d
+    assert d > 0 or C % 4 != 0        # two kernels really ran (an input whose pixels are not 16-byte aligned stays on the old one)
