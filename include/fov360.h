@@ -576,6 +576,24 @@ int fov_conv2d_wgrad(const float* x, int64_t x_pixel_stride, const float* dy, fl
                      int C, int N, int kh, int kw, int accumulate, void* workspace, size_t workspace_bytes,
                      fov_stream_t stream);
 
+/* The same three with a dilation (Keras `dilation_rate`; cfg.dilation_rate of mycode/config.py:105 reaches the six ConvLSTM2D
+ * layers of mycode/convlstm_seq2seq.py:100-126,146-165): tap (i, j) reads the pixel (i - kh/2, j - kw/2) * dilation away, 'same'
+ * zero padding grows with it.  Keras's ConvLSTM2D dilates its INPUT convolution only: fov_convlstm_cell_dilated_fwd applies
+ * `dilation` to the taps over x and leaves those over h_prev at 1.  The data gradient of a dilated convolution is the dilated
+ * convolution with the transposed weights (fov_conv2d_weight_transpose + fov_conv2d_dilated_fwd).  dilation = 1 is exactly the
+ * entry points above; dilation > 1 runs on the tap-gathering implicit GEMM (the LDS-resident forms are built for dilation 1). */
+int fov_conv2d_dilated_fwd(const float* x, int64_t x_pixel_stride, int64_t x_batch_stride, const float* w, const float* b,
+                           const float* add, float* y, int B, int H, int W, int C, int N, int kh, int kw, int dilation,
+                           int activation, fov_stream_t stream);
+int fov_convlstm_cell_dilated_fwd(const float* x, int64_t x_pixel_stride, int64_t x_batch_stride, int C, const float* h_prev,
+                                  int64_t h_prev_pixel_stride, int64_t h_prev_batch_stride, const float* w, const float* b,
+                                  const float* c_prev, float* c_new, float* h, int64_t h_pixel_stride, float* gates, int B,
+                                  int H, int W, int F, int kh, int kw, int dilation, int recurrent_activation,
+                                  fov_stream_t stream);
+int fov_conv2d_dilated_wgrad(const float* x, int64_t x_pixel_stride, const float* dy, float* dw, int B, int H, int W, int C,
+                             int N, int kh, int kw, int dilation, int accumulate, void* workspace, size_t workspace_bytes,
+                             fov_stream_t stream);
+
 /* wt (kh,kw,N,C) = w (kh,kw,C,N) flipped in both spatial axes and transposed in the channel axes: the data
  * gradient of y = conv2d_same(x, w) is dx = conv2d_same(dy, wt) (fov_conv2d_fwd). */
 int fov_conv2d_weight_transpose(const float* w, float* wt, int kh, int kw, int C, int N, fov_stream_t stream);

@@ -24,6 +24,7 @@ struct ConvArgs {
     const float* add;   // (B*H*W, N) or NULL (may alias y)
     float* y;           // (B*H*W, N)
     int B, H, W, C, N, kh, kw, act;   // act: 0 none, 2 relu
+    int dil;            // dilation of the taps over x (segment 1); segment 2 (the recurrent map of a ConvLSTM2D cell) is never dilated
     long ldx;   // pixel stride
     long ldb;   // batch stride
     // CELL form (ConvLSTM2D step in one launch): N = 4F gate columns, the epilogue applies the gates and the cell update
@@ -150,8 +151,9 @@ __global__ __launch_bounds__(256) void conv2d_igemm_kernel(ConvArgs g) {
     auto fetch = [&]() {
         const bool seg2 = f_ct >= ctiles1;   // wave-uniform: which input segment this tile reads
         const int c0 = (seg2 ? f_ct - ctiles1 : f_ct) * BK;
-        const int sy = f_dy - ph, sx = f_dx - pw;
-        if (f_ct == 0) {
+        const int dl = seg2 ? 1 : g.dil;     // Keras dilates the INPUT convolution of ConvLSTM2D only (dilation_rate), not the recurrent one
+        const int sy = (f_dy - ph) * dl, sx = (f_dx - pw) * dl;
+        if (f_ct == 0 || (f_ct == ctiles1 && g.dil != 1)) {
 #pragma unroll
             for (int r = 0; r < RA; ++r) {
                 const int yy = a_y[r] + sy, xx = a_x[r] + sx;
@@ -355,14 +357,15 @@ static int conv_check_launch(const char* what) {
 }
 
 int conv2d_fwd(const float* x, long ldx, long ldb, const float* w, const float* bias, const float* add, float* y, int B, int H,
-               int W, int C, int N, int kh, int kw, int act, hipStream_t stream) {
-    return conv2d_fwd2(x, ldx, ldb, C, nullptr, 0, 0, 0, w, bias, add, y, B, H, W, N, kh, kw, act, stream);
+               int W, int C, int N, int kh, int kw, int act, hipStream_t stream, int dil) {
+    return conv2d_fwd2(x, ldx, ldb, C, nullptr, 0, 0, 0, w, bias, add, y, B, H, W, N, kh, kw, act, stream, dil);
 }
 
 int conv2d_fwd2(const float* x, long ldx, long ldb, int C, const float* x2, long ldx2, long ldb2, int C2, const float* w,
                 const float* bias, const float* add, float* y, int B, int H, int W, int N, int kh, int kw, int act,
-                hipStream_t stream) {
+                hipStream_t stream, int dil) {
     ConvArgs g = {};
+    g.dil = dil < 1 ? 1 : dil;
     g.x = x; g.w = w; g.bias = bias; g.add = add; g.y = y;
     g.B = B; g.H = H; g.W = W; g.C = C; g.N = N; g.kh = kh; g.kw = kw; g.act = act; g.ldx = ldx; g.ldb = ldb;
     g.x2 = x2; g.C2 = x2 ? C2 : 0; g.ldx2 = ldx2; g.ldb2 = ldb2;
@@ -375,7 +378,7 @@ int conv2d_fwd2(const float* x, long ldx, long ldb, int C, const float* x2, long
         return FOV_ERR_UNSUPPORTED;
     }
     // one input segment, a map small enough to sit in LDS, enough channels to be worth it: the map-resident form (conv_patch.hip)
-    if (!x2 && conv_patch_shape_ok(x, ldx, ldb, B, H, W, C, N, kh, kw))
+    if (!x2 && g.dil == 1 && conv_patch_shape_ok(x, ldx, ldb, B, H, W, C, N, kh, kw))
         return launch_conv_patch(x, ldx, ldb, w, bias, add, y, B, H, W, C, N, kh, kw, act, stream);
     const bool avec = (C & 3) == 0 && (ldx & 3) == 0 && (ldb & 3) == 0 && (((uintptr_t)x) & 15) == 0 &&
                       (!x2 || ((C2 & 3) == 0 && (ldx2 & 3) == 0 && (ldb2 & 3) == 0 && (((uintptr_t)x2) & 15) == 0));
@@ -405,8 +408,9 @@ int conv2d_fwd2(const float* x, long ldx, long ldb, int C, const float* x2, long
 // K alone).  h must not alias h_prev (neighbouring pixels read it); c_new may alias c_prev.
 int convlstm_cell_fwd(const float* x, long ldx, long ldb, int C, const float* h_prev, long ldx2, long ldb2, const float* w,
                       const float* bias, const float* c_prev, float* c_new, float* h, long ldh, float* gates, int B, int H, int W,
-                      int F, int kh, int kw, int act, hipStream_t stream) {
+                      int F, int kh, int kw, int act, hipStream_t stream, int dil) {
     ConvArgs g = {};
+    g.dil = dil < 1 ? 1 : dil;
     g.x = x; g.w = w; g.bias = bias; g.B = B; g.H = H; g.W = W; g.C = C; g.N = 4 * F; g.kh = kh; g.kw = kw; g.ldx = ldx; g.ldb = ldb;
     g.x2 = h_prev; g.C2 = h_prev ? F : 0; g.ldx2 = ldx2; g.ldb2 = ldb2;
     g.c_prev = c_prev; g.c_new = c_new; g.h = h; g.ldh = ldh; g.gates = gates;
@@ -418,7 +422,7 @@ int convlstm_cell_fwd(const float* x, long ldx, long ldb, int C, const float* h_
         return FOV_ERR_UNSUPPORTED;
     }
     // the LDS-resident-patch form (convlstm_patch.hip): every tap reads the same staged patch, no barrier in the k loop
-    if (cell_patch_shape_ok(x, ldx, ldb, C, h_prev, ldx2, ldb2, F, H, W, kh, kw))
+    if (g.dil == 1 && cell_patch_shape_ok(x, ldx, ldb, C, h_prev, ldx2, ldb2, F, H, W, kh, kw))
         return launch_cell_patch(x, ldx, ldb, C, h_prev, ldx2, ldb2, w, bias, c_prev, c_new, h, ldh, gates, B, H, W, F, kh, kw, act, stream);
     const bool avec = (C & 3) == 0 && (ldx & 3) == 0 && (ldb & 3) == 0 && (((uintptr_t)x) & 15) == 0 &&
                       (!h_prev || ((F & 3) == 0 && (ldx2 & 3) == 0 && (ldb2 & 3) == 0 && (((uintptr_t)h_prev) & 15) == 0));

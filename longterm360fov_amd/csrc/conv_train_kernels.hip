@@ -101,6 +101,7 @@ struct WgradArgs {
     const float* dz;
     float* out;   // [split][kh*kw*C*N] partial slices, or dW itself when split == 1
     int H, W, C, N, kh, kw;
+    int dil;      // dilation of the taps over x
     long P;       // pixels (B*H*W)
     long ldx;     // pixel stride of x
     int ctiles;
@@ -126,7 +127,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs g) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ctile = blockIdx.y % g.ctiles, tap = blockIdx.y / g.ctiles;
     const int c0 = ctile * BM, n0 = blockIdx.x * BN;
-    const int sy = tap / g.kw - (g.kh - 1) / 2, sx = tap % g.kw - (g.kw - 1) / 2;
+    const int sy = (tap / g.kw - (g.kh - 1) / 2) * g.dil, sx = (tap % g.kw - (g.kw - 1) / 2) * g.dil;
     const int wm = (wave / WAVES_N) * 16 * MI, wn = (wave % WAVES_N) * 16 * NI;
     const int li = lane & 15, lq = lane >> 4;
     const long ktiles = (g.P + BK - 1) / BK;
@@ -304,7 +305,7 @@ size_t conv2d_wgrad_workspace_floats(int C, int N, int kh, int kw) {
 }
 
 int conv2d_wgrad(const float* x, long ldx, const float* dz, float* dw, int B, int H, int W, int C, int N, int kh, int kw,
-                 int accumulate, float* scratch, size_t scratch_floats, hipStream_t stream) {
+                 int accumulate, float* scratch, size_t scratch_floats, hipStream_t stream, int dil) {
     const long P = (long)B * H * W;
     const size_t wn = (size_t)kh * kw * C * N;
     if (P == 0) {
@@ -319,6 +320,7 @@ int conv2d_wgrad(const float* x, long ldx, const float* dz, float* dw, int B, in
     else { BM = 128; BN = 128; variant = 2; }
     WgradArgs g = {};
     g.x = x; g.dz = dz; g.H = H; g.W = W; g.C = C; g.N = N; g.kh = kh; g.kw = kw; g.P = P; g.ldx = ldx;
+    g.dil = dil < 1 ? 1 : dil;
     g.ctiles = (C + BM - 1) / BM;
     const int gn = (N + BN - 1) / BN;
     const long ktiles = (P + 15) / 16;

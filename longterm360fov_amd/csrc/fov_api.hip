@@ -1353,6 +1353,17 @@ int fov_conv2d_fwd(const float* x, int64_t x_pixel_stride, int64_t x_batch_strid
     return conv2d_fwd(x, (long)x_pixel_stride, (long)x_batch_stride, w, b, add, y, B, H, W, C, N, kh, kw, activation, (hipStream_t)stream);
 }
 
+int fov_conv2d_dilated_fwd(const float* x, int64_t x_pixel_stride, int64_t x_batch_stride, const float* w, const float* b,
+                           const float* add, float* y, int B, int H, int W, int C, int N, int kh, int kw, int dilation, int activation,
+                           fov_stream_t stream) {
+    if (B < 0 || H <= 0 || W <= 0 || C <= 0 || N <= 0 || kh <= 0 || kw <= 0 || (kh & 1) == 0 || (kw & 1) == 0 || dilation < 1 ||
+        x_pixel_stride < C || x_batch_stride < (int64_t)H * W * x_pixel_stride || !w || (B > 0 && (!x || !y)) || (activation != 0 && activation != 2)) {
+        set_error("fov_conv2d_dilated_fwd: invalid argument (odd kernel sizes only, dilation >= 1, activation 0 or 2)");
+        return FOV_ERR_INVALID;
+    }
+    return conv2d_fwd(x, (long)x_pixel_stride, (long)x_batch_stride, w, b, add, y, B, H, W, C, N, kh, kw, activation, (hipStream_t)stream, dilation);
+}
+
 int fov_conv2d_fwd2(const float* x1, int64_t x1_pixel_stride, int64_t x1_batch_stride, int C1, const float* x2,
                     int64_t x2_pixel_stride, int64_t x2_batch_stride, int C2, const float* w, const float* b, const float* add,
                     float* y, int B, int H, int W, int N, int kh, int kw, int activation, fov_stream_t stream) {
@@ -1382,6 +1393,23 @@ int fov_convlstm_cell_fwd(const float* x, int64_t x_pixel_stride, int64_t x_batc
     return convlstm_cell_fwd(x, (long)x_pixel_stride, (long)x_batch_stride, C, h_prev, (long)h_prev_pixel_stride,
                              (long)h_prev_batch_stride, w, b, c_prev, c_new, h, (long)h_pixel_stride, gates, B, H, W, F, kh, kw,
                              recurrent_activation, (hipStream_t)stream);
+}
+
+int fov_convlstm_cell_dilated_fwd(const float* x, int64_t x_pixel_stride, int64_t x_batch_stride, int C, const float* h_prev,
+                                  int64_t h_prev_pixel_stride, int64_t h_prev_batch_stride, const float* w, const float* b,
+                                  const float* c_prev, float* c_new, float* h, int64_t h_pixel_stride, float* gates, int B, int H, int W,
+                                  int F, int kh, int kw, int dilation, int recurrent_activation, fov_stream_t stream) {
+    if (B < 0 || H <= 0 || W <= 0 || C <= 0 || F <= 0 || kh <= 0 || kw <= 0 || !(kh & 1) || !(kw & 1) || dilation < 1 ||
+        (B > 0 && (!x || !w || !c_new || !h)) || x_pixel_stride < C || x_batch_stride < (int64_t)H * W * x_pixel_stride ||
+        h_pixel_stride < F ||
+        (h_prev && (h_prev_pixel_stride < F || h_prev_batch_stride < (int64_t)H * W * h_prev_pixel_stride || h_prev == h)) ||
+        (recurrent_activation != FOV_ACT_SIGMOID && recurrent_activation != FOV_ACT_HARD_SIGMOID)) {
+        set_error("fov_convlstm_cell_dilated_fwd: invalid argument");
+        return FOV_ERR_INVALID;
+    }
+    return convlstm_cell_fwd(x, (long)x_pixel_stride, (long)x_batch_stride, C, h_prev, (long)h_prev_pixel_stride,
+                             (long)h_prev_batch_stride, w, b, c_prev, c_new, h, (long)h_pixel_stride, gates, B, H, W, F, kh, kw,
+                             recurrent_activation, (hipStream_t)stream, dilation);
 }
 
 int fov_convlstm_gates(const float* z, float* c, float* h, int64_t h_pixel_stride, int64_t rows, int F, int act,
@@ -1437,6 +1465,18 @@ int fov_conv2d_wgrad(const float* x, int64_t x_pixel_stride, const float* dy, fl
     if (workspace && (((uintptr_t)workspace) & 15)) { set_error("workspace must be 16-byte aligned"); return FOV_ERR_WORKSPACE; }
     return conv2d_wgrad(x, (long)x_pixel_stride, dy, dw, B, H, W, C, N, kh, kw, accumulate, (float*)workspace,
                         workspace ? workspace_bytes / sizeof(float) : 0, (hipStream_t)stream);
+}
+
+int fov_conv2d_dilated_wgrad(const float* x, int64_t x_pixel_stride, const float* dy, float* dw, int B, int H, int W, int C, int N,
+                             int kh, int kw, int dilation, int accumulate, void* workspace, size_t workspace_bytes, fov_stream_t stream) {
+    if (B < 0 || H <= 0 || W <= 0 || C <= 0 || N <= 0 || kh <= 0 || kw <= 0 || (kh & 1) == 0 || (kw & 1) == 0 || dilation < 1 ||
+        x_pixel_stride < C || !dw || (B > 0 && (!x || !dy))) {
+        set_error("fov_conv2d_dilated_wgrad: invalid argument (odd kernel sizes only, dilation >= 1)");
+        return FOV_ERR_INVALID;
+    }
+    if (workspace && (((uintptr_t)workspace) & 15)) { set_error("workspace must be 16-byte aligned"); return FOV_ERR_WORKSPACE; }
+    return conv2d_wgrad(x, (long)x_pixel_stride, dy, dw, B, H, W, C, N, kh, kw, accumulate, (float*)workspace,
+                        workspace ? workspace_bytes / sizeof(float) : 0, (hipStream_t)stream, dilation);
 }
 
 int fov_conv2d_weight_transpose(const float* w, float* wt, int kh, int kw, int C, int N, fov_stream_t stream) {

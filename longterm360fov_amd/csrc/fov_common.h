@@ -113,11 +113,13 @@ int launch_stepwise(const LstmParams& p, float* ws, size_t ws_floats, hipStream_
 constexpr size_t kStatusBytes = 256;  // head of every workspace: status words (layout: xch_common.h)
 
 // ConvLSTM building blocks (conv_kernels.hip)
+// dil: dilation of the taps over x (Keras dilation_rate; 'same' padding grows with it); the second segment of conv2d_fwd2 / the
+// recurrent map of convlstm_cell_fwd is never dilated (Keras ConvLSTM2D dilates its input convolution only)
 int conv2d_fwd(const float* x, long ldx, long ldb, const float* w, const float* bias, const float* add, float* y, int B, int H,
-               int W, int C, int N, int kh, int kw, int act, hipStream_t stream);
+               int W, int C, int N, int kh, int kw, int act, hipStream_t stream, int dil = 1);
 int conv2d_fwd2(const float* x, long ldx, long ldb, int C, const float* x2, long ldx2, long ldb2, int C2, const float* w,
                 const float* bias, const float* add, float* y, int B, int H, int W, int N, int kh, int kw, int act,
-                hipStream_t stream);
+                hipStream_t stream, int dil = 1);
 int convlstm_gates(const float* z, float* c, float* h, long ldh, long rows, int F, int act, hipStream_t stream);
 // LDS-resident-patch form of the ConvLSTM2D step (convlstm_patch.hip); convlstm_cell_fwd takes it when the shape allows
 // 'same' Conv2D with the input map resident in LDS (conv_patch.hip): the wide layers of the ConvLSTM prediction head
@@ -131,13 +133,13 @@ int launch_cell_patch(const float* x, long ldx, long ldb, int C, const float* h_
                       int F, int kh, int kw, int act, hipStream_t stream);
 int convlstm_cell_fwd(const float* x, long ldx, long ldb, int C, const float* h_prev, long ldx2, long ldb2, const float* w,
                       const float* bias, const float* c_prev, float* c_new, float* h, long ldh, float* gates, int B, int H, int W,
-                      int F, int kh, int kw, int act, hipStream_t stream);
+                      int F, int kh, int kw, int act, hipStream_t stream, int dil = 1);
 int softmax_lastdim(const float* x, float* y, long rows, int n, hipStream_t stream);
 
 // ConvLSTM training (conv_train_kernels.hip)
 size_t conv2d_wgrad_workspace_floats(int C, int N, int kh, int kw);
 int conv2d_wgrad(const float* x, long ldx, const float* dz, float* dw, int B, int H, int W, int C, int N, int kh, int kw,
-                 int accumulate, float* scratch, size_t scratch_floats, hipStream_t stream);
+                 int accumulate, float* scratch, size_t scratch_floats, hipStream_t stream, int dil = 1);
 int convlstm_gates_train(const float* z, const float* c_prev, float* c_new, float* h, long ldh, float* gates, long rows, int F,
                          int act, hipStream_t stream);
 int convlstm_gates_bwd(const float* dh, long lddh, float* dc, const float* gates, const float* c_prev, const float* c_new,

@@ -1319,15 +1319,20 @@ class ConvLSTMSeq2Seq(KerasModelSurface):
     predict([encoder_input (N,T_in,H,W,C), decoder_input (N,1,H,W,C)]) -> (N,T_out,H,W,C_out).
     compile('RMSprop', loss=costfunc._mse | 'mean_squared_error') / fit / train_on_batch train the same unrolled
     graph (convlstm_seq2seq.py:287,396-420) through training.ConvLSTMTrainer, with Keras's per-gate input
-    dropout when dropout_rate > 0 (training only).  Weights: dict with
+    dropout when dropout_rate > 0 (training only).  dilation_rate (default cfg.dilation_rate) spreads the taps of the
+    six input convolutions, as Keras's ConvLSTM2D does (its recurrent convolution stays dense).  Weights: dict with
     enc{l}_K/R/b, dec{l}_K/R/b (Keras ConvLSTM2D layout (kh,kw,C,4F)) and head{i}_W/b."""
 
     _default_optimizer = "rmsprop"      # convlstm_seq2seq.py:287
 
     def __init__(self, weights, head="conv2d", recurrent_activation="hard_sigmoid", device="cuda", dropout_rate=0.0,
-                 add_xyz_sum1=None):
+                 add_xyz_sum1=None, dilation_rate=None):
         from .training import convlstm_weight_order
         self.add_xyz_sum1 = bool(cfg.add_xyz_sum1 if add_xyz_sum1 is None else add_xyz_sum1)
+        # cfg.dilation_rate (config.py:105) -> the six ConvLSTM2D layers' input convolutions (:102,110,120,148,155,162)
+        self.dilation_rate = int(cfg.dilation_rate if dilation_rate is None else dilation_rate)
+        if self.dilation_rate < 1:
+            raise ValueError("dilation_rate must be >= 1")
         self.head, self.act = head, recurrent_activation
         self._w = {k: _as_f32(v) for k, v in weights.items()}
         self._init_surface(convlstm_weight_order(self._w), None, device)
@@ -1347,7 +1352,8 @@ class ConvLSTMSeq2Seq(KerasModelSurface):
     def _make_trainer(self, optimizer):
         from .training import ConvLSTMTrainer
         return ConvLSTMTrainer(self._w, head=self.head, act=self.act, optimizer=optimizer, lr=self._lr, device=self.device,
-                               dropout_rate=self.dropout_rate, add_xyz_sum1=self.add_xyz_sum1, loss=self.loss or "mse")
+                               dropout_rate=self.dropout_rate, add_xyz_sum1=self.add_xyz_sum1, loss=self.loss or "mse",
+                               dilation_rate=self.dilation_rate)
 
     def predict(self, x, batch_size=None, predict_step=None, verbose=0):
         import torch
@@ -1398,7 +1404,8 @@ class ConvLSTMSeq2Seq(KerasModelSurface):
             nxt = []
             for t in range(T_in):
                 hn = e4(B, H, W, F)
-                ops.convlstm_cell(seq[t], h, KR, b, c, hn, act)   # conv(x_t, K) + conv(h, R) + b, gates, c / h update: one launch
+                # conv(x_t, K) + conv(h, R) + b, gates, c / h update: one launch
+                ops.convlstm_cell(seq[t], h, KR, b, c, hn, act, dilation=self.dilation_rate)
                 h = hn
                 nxt.append(h)
             seq = nxt
@@ -1411,7 +1418,8 @@ class ConvLSTMSeq2Seq(KerasModelSurface):
             cur = inp
             for l, F in enumerate(filters):
                 hslot = feat[..., offs[l]:offs[l] + F]
-                ops.convlstm_cell(cur, states[l][0], dw["dec%d_KR" % l], dw["dec%d_b" % l], states[l][1], hslot, act)
+                ops.convlstm_cell(cur, states[l][0], dw["dec%d_KR" % l], dw["dec%d_b" % l], states[l][1], hslot, act,
+                                  dilation=self.dilation_rate)
                 states[l][0] = hslot
                 cur = hslot
             if dense_head:   # Flatten + Dense(6): cfg.predict_mean_var, output fed back as a 1x1x6 map

@@ -913,9 +913,10 @@ def lstm_seq_zx(zx, R, b, h0=None, c0=None, act="sigmoid", impl="auto", return_s
 # ---------------------------------------------------------------------------------------------
 # ConvLSTM2D seq2seq (a8/a9): building blocks
 # ---------------------------------------------------------------------------------------------
-def conv2d(x, w, b=None, add=None, activation=None, out=None, in_channels=None):
+def conv2d(x, w, b=None, add=None, activation=None, out=None, in_channels=None, dilation=1):
     """y (B,H,W,N) = act(conv2d_same(x, w) + b + add).  x may be a channel slice view of a wider NHWC map
-    (only the last-dim stride may differ from dense: pass the view, pixel stride is taken from it)."""
+    (only the last-dim stride may differ from dense: pass the view, pixel stride is taken from it).
+    dilation = Keras `dilation_rate` (taps `dilation` pixels apart, 'same' padding grown to match)."""
     assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.stride(3) == 1
     B, H, W, C = x.shape
     ldx = x.stride(2)
@@ -926,6 +927,10 @@ def conv2d(x, w, b=None, add=None, activation=None, out=None, in_channels=None):
     assert Cw == C
     y = torch.empty((B, H, W, N), dtype=torch.float32, device=x.device) if out is None else out
     act = {None: 0, "linear": 0, "relu": 2}[activation]
+    if dilation != 1:
+        check(_lib.lib().fov_conv2d_dilated_fwd(x.data_ptr(), ldx, ldb, _ptr(w), _ptr(_dev(b, "b")), _ptr(add), _ptr(y), B, H, W,
+                                                C, N, kh, kw, int(dilation), act, _stream()))
+        return y
     check(_lib.lib().fov_conv2d_fwd(x.data_ptr(), ldx, ldb, _ptr(w), _ptr(_dev(b, "b")), _ptr(add), _ptr(y), B, H, W, C, N,
                                     kh, kw, act, _stream()))
     return y
@@ -954,11 +959,12 @@ def conv2d_cat(x1, x2, w, b=None, activation=None, out=None):
     return y
 
 
-def convlstm_cell(x, h_prev, w, b, c_prev, h_out, act="hard_sigmoid", c_new=None, gates=None):
+def convlstm_cell(x, h_prev, w, b, c_prev, h_out, act="hard_sigmoid", c_new=None, gates=None, dilation=1):
     """One ConvLSTM2D step in one launch: -> (h_out, c_new).  x (B,H,W,C) and h_prev (B,H,W,F) NHWC maps (channel-slice /
     batch-strided views allowed; h_prev None = zero state, w is then K alone); w (kh,kw,C+F,4F) = [K ; R]; c_prev None = zero
     state; c_new defaults to updating c_prev in place; h_out may be a channel-slice view and must not be h_prev; gates
-    (B,H,W,4F) receives the activated i,f,g,o when given (training tape)."""
+    (B,H,W,4F) receives the activated i,f,g,o when given (training tape).  dilation spreads the taps over x only, as Keras's
+    ConvLSTM2D does (its recurrent convolution is never dilated)."""
     def geom(t):
         assert t.is_cuda and t.dtype == torch.float32 and t.dim() == 4 and t.stride(3) == 1
         B, H, W, C = t.shape
@@ -988,6 +994,12 @@ def convlstm_cell(x, h_prev, w, b, c_prev, h_out, act="hard_sigmoid", c_new=None
         gates = _dev(gates, "gates")
         assert gates.shape == (B, H, W, N)
     _sync_env()
+    if dilation != 1:
+        check(_lib.lib().fov_convlstm_cell_dilated_fwd(x.data_ptr(), ldx, ldb, C, h_prev.data_ptr() if h_prev is not None else None,
+                                                       ldx2, ldb2, _ptr(w), _ptr(_dev(b, "b")), _ptr(c_prev), _ptr(c_new),
+                                                       h_out.data_ptr(), h_out.stride(-2), _ptr(gates), B, H, W, F, kh, kw,
+                                                       int(dilation), act_code(act), _stream()))
+        return h_out, c_new
     check(_lib.lib().fov_convlstm_cell_fwd(x.data_ptr(), ldx, ldb, C, h_prev.data_ptr() if h_prev is not None else None, ldx2, ldb2,
                                            _ptr(w), _ptr(_dev(b, "b")), _ptr(c_prev), _ptr(c_new), h_out.data_ptr(),
                                            h_out.stride(-2), _ptr(gates), B, H, W, F, kh, kw, act_code(act), _stream()))
@@ -1040,7 +1052,7 @@ def convlstm_gates_bwd(dh, dc, gates, c_prev, c_new, act="hard_sigmoid", dz=None
     return dz
 
 
-def conv2d_wgrad(x, dy, kh, kw, dw=None, accumulate=False, scratch=None):
+def conv2d_wgrad(x, dy, kh, kw, dw=None, accumulate=False, scratch=None, dilation=1):
     """dw (kh,kw,C,N) (+)= weight gradient of y = conv2d_same(x, w).  x: batch-dense NHWC (leading dims are
     flattened into the batch; the last dim may be a channel slice of a wider map); dy (..., N) dense."""
     assert x.is_cuda and x.dtype == torch.float32 and x.stride(-1) == 1
@@ -1057,6 +1069,10 @@ def conv2d_wgrad(x, dy, kh, kw, dw=None, accumulate=False, scratch=None):
     dw = torch.empty((kh, kw, C, N), dtype=torch.float32, device=x.device) if dw is None else dw
     L = _lib.lib()
     buf = (scratch or _default_scratch).get(L.fov_conv2d_wgrad_workspace_bytes(C, N, kh, kw), x.device)
+    if dilation != 1:
+        check(L.fov_conv2d_dilated_wgrad(x.data_ptr(), ldx, _ptr(dy), _ptr(dw), B, H, W, C, N, kh, kw, int(dilation),
+                                         1 if accumulate else 0, buf.data_ptr(), buf.numel(), _stream()))
+        return dw
     check(L.fov_conv2d_wgrad(x.data_ptr(), ldx, _ptr(dy), _ptr(dw), B, H, W, C, N, kh, kw, 1 if accumulate else 0,
                              buf.data_ptr(), buf.numel(), _stream()))
     return dw

@@ -1301,12 +1301,20 @@ class ConvLSTMTrainer(FlatParamTrainer):
     per unrolled step.  Here the four masked copies are stacked along the channel axis and convolved with the
     block-diagonal (kh,kw,4C,4F) arrangement of the kernel - the same arithmetic on the same conv kernels
     (4x the input-convolution FLOPs, training with dropout only).  Masks come from a torch generator (`seed`);
-    TF's random stream is not reproducible, the distribution is the same."""
+    TF's random stream is not reproducible, the distribution is the same.
+
+    dilation_rate (cfg.dilation_rate, convlstm_seq2seq.py:102,110,120,148,155,162): Keras's ConvLSTM2DCell passes it to the
+    input convolution only (`input_conv(..., dilation_rate=self.dilation_rate)`; `recurrent_conv` has none), so K's taps are
+    spread, R's are not; the head's Conv2D layers are not dilated.  Backward: dx through the dilated convolution with the
+    transposed K, dK through the dilated weight gradient."""
 
     def __init__(self, weights, head="conv2d", act="hard_sigmoid", optimizer="rmsprop", lr=1e-3, device="cuda",
-                 dropout_rate=0.0, seed=0, add_xyz_sum1=False, loss="mse"):
+                 dropout_rate=0.0, seed=0, add_xyz_sum1=False, loss="mse", dilation_rate=1):
         if not 0.0 <= dropout_rate < 1.0:
             raise ValueError("dropout_rate must be in [0, 1)")
+        if int(dilation_rate) < 1:
+            raise ValueError("dilation_rate must be >= 1")
+        self.dilation = int(dilation_rate)          # cfg.dilation_rate (config.py:105): the six ConvLSTM2D INPUT convolutions
         self.dropout_rate = float(dropout_rate)
         self.add_xyz_sum1 = bool(add_xyz_sum1)      # cfg.add_xyz_sum1: the optional unit-norm term of costfunc._mse
         if loss not in ("mse", "categorical_crossentropy"):
@@ -1348,7 +1356,7 @@ class ConvLSTMTrainer(FlatParamTrainer):
         return K4
 
     def _forward(self, enc, dec0, T_out, masks=None):
-        w, act, F = self.w, self.act, self.filters
+        w, act, F, dil = self.w, self.act, self.filters, self.dilation
         B, T_in, H, W, C = enc.shape
         dev = enc.device
         e = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
@@ -1366,9 +1374,9 @@ class ConvLSTMTrainer(FlatParamTrainer):
             KR = torch.cat([K, R], 2)     # [K ; R]: input and recurrent convolution of a step in one launch
             for t in range(T_in):
                 if t > 0:     # the whole step (both convolutions, gates, c / h update, gates tape) is one launch
-                    ops.convlstm_cell(seq[t], hs[t - 1], KR, b, cs[t - 1], hs[t], act, c_new=cs[t], gates=gs[t])
+                    ops.convlstm_cell(seq[t], hs[t - 1], KR, b, cs[t - 1], hs[t], act, c_new=cs[t], gates=gs[t], dilation=dil)
                 else:         # zero initial state
-                    ops.convlstm_cell(seq[t], None, K, b, None, hs[t], act, c_new=cs[t], gates=gs[t])
+                    ops.convlstm_cell(seq[t], None, K, b, None, hs[t], act, c_new=cs[t], gates=gs[t], dilation=dil)
             tape["eh%d" % l], tape["ec%d" % l], tape["eg%d" % l] = hs, cs, gs
             seq = hs
         cat = sum(F)
@@ -1396,7 +1404,7 @@ class ConvLSTMTrainer(FlatParamTrainer):
                     dx4[l][t].copy_(self._stack_masked(cur, masks["dec%d" % l][t]))
                     cur, K = dx4[l][t], k4["dec%d_K" % l]
                 hslot = feat[t][..., offs[l]:offs[l] + F[l]]
-                ops.convlstm_cell(cur, h_prev, kr[l], b, c_prev, hslot, act, c_new=dcs[l][t], gates=dgs[l][t])
+                ops.convlstm_cell(cur, h_prev, kr[l], b, c_prev, hslot, act, c_new=dcs[l][t], gates=dgs[l][t], dilation=dil)
                 cur = hslot
             if dense_head:     # Flatten + Dense(6, linear); fed back as a 1x1x6 map
                 ops.dense(feat[t].reshape(B, H * W * cat), w["head0_W"], w["head0_b"], activation=None, out=P[t])
@@ -1416,7 +1424,7 @@ class ConvLSTMTrainer(FlatParamTrainer):
         """enc (B,T_in,H,W,C), dec0 (B,1,H,W,C), target (B,T_out,H,W,Co) device tensors.  Fills self.grad with
         d(mean squared error)/d(parameters); returns (loss (1,), prediction (B,T_out,H,W,Co)).  `masks`: dropout
         masks as sample_masks() returns them (drawn here when dropout_rate > 0 and none are given)."""
-        w, g, act, F, sc = self.w, self.g, self.act, self.filters, self.scratch
+        w, g, act, F, sc, dil = self.w, self.g, self.act, self.filters, self.scratch, self.dilation
         B, T_in, H, W, C = enc.shape
         T_out = target.shape[1]
         if masks is None and self.dropout_rate > 0:
@@ -1433,7 +1441,7 @@ class ConvLSTMTrainer(FlatParamTrainer):
 
         def in_kernel_grad(key, x4, dz, c, f):   # weight gradient of the block-diagonal kernel -> its diagonal blocks
             kh, kw = w[key].shape[:2]
-            d4 = ops.conv2d_wgrad(x4, dz, kh, kw, scratch=sc)
+            d4 = ops.conv2d_wgrad(x4, dz, kh, kw, scratch=sc, dilation=dil)
             for gi in range(4):
                 g[key][..., gi * f:(gi + 1) * f].copy_(d4[:, :, gi * c:(gi + 1) * c, gi * f:(gi + 1) * f])
 
@@ -1480,9 +1488,9 @@ class ConvLSTMTrainer(FlatParamTrainer):
                 dh_rec[l] = ops.conv2d(dz, wt["dec%d_R" % l])
                 if l > 0 or t > 0:
                     if masks is None:
-                        dx = ops.conv2d(dz, wt["dec%d_K" % l])
+                        dx = ops.conv2d(dz, wt["dec%d_K" % l], dilation=dil)
                     else:
-                        dx = unmask(ops.conv2d(dz, wt4["dec%d_K" % l]), masks["dec%d" % l][t], cin[l])
+                        dx = unmask(ops.conv2d(dz, wt4["dec%d_K" % l], dilation=dil), masks["dec%d" % l][t], cin[l])
                     if l > 0:
                         dx_up = dx
                     else:
@@ -1501,7 +1509,7 @@ class ConvLSTMTrainer(FlatParamTrainer):
             x_in = tp["inp"] if l == 0 else feat[..., offs[l - 1]:offs[l - 1] + F[l - 1]]
             kh, kw = w["dec%d_K" % l].shape[:2]
             if masks is None:
-                ops.conv2d_wgrad(x_in, dzs[l], kh, kw, dw=g["dec%d_K" % l], scratch=sc)
+                ops.conv2d_wgrad(x_in, dzs[l], kh, kw, dw=g["dec%d_K" % l], scratch=sc, dilation=dil)
             else:
                 in_kernel_grad("dec%d_K" % l, tp["dx4"][l], dzs[l], cin[l], F[l])
             ops.conv2d_wgrad(tp["eh%d" % l][T_in - 1], dzs[l][0], kh, kw, dw=g["dec%d_R" % l], scratch=sc)
@@ -1523,7 +1531,7 @@ class ConvLSTMTrainer(FlatParamTrainer):
             kh, kw = w["enc%d_K" % l].shape[:2]
             x_in = tp["x"] if l == 0 else tp["eh%d" % (l - 1)]
             if masks is None:
-                ops.conv2d_wgrad(x_in, edz, kh, kw, dw=g["enc%d_K" % l], scratch=sc)
+                ops.conv2d_wgrad(x_in, edz, kh, kw, dw=g["enc%d_K" % l], scratch=sc, dilation=dil)
             else:
                 in_kernel_grad("enc%d_K" % l, tp["ex4_%d" % l], edz, cin[l], F[l])
             if T_in > 1:
@@ -1533,9 +1541,9 @@ class ConvLSTMTrainer(FlatParamTrainer):
             ops.colsum(edz, out=g["enc%d_b" % l], scratch=sc)
             if l > 0:   # data gradient for the layer below, all steps in one launch
                 if masks is None:
-                    dx_seq = ops.conv2d(edz.reshape(T_in * B, H, W, 4 * F[l]), wt["enc%d_K" % l]).reshape(T_in, B, H, W, F[l - 1])
+                    dx_seq = ops.conv2d(edz.reshape(T_in * B, H, W, 4 * F[l]), wt["enc%d_K" % l], dilation=dil).reshape(T_in, B, H, W, F[l - 1])
                 else:
-                    d4 = ops.conv2d(edz.reshape(T_in * B, H, W, 4 * F[l]), wt4["enc%d_K" % l]).reshape(T_in, B, H, W, 4 * F[l - 1])
+                    d4 = ops.conv2d(edz.reshape(T_in * B, H, W, 4 * F[l]), wt4["enc%d_K" % l], dilation=dil).reshape(T_in, B, H, W, 4 * F[l - 1])
                     dx_seq = unmask(d4, masks["enc%d" % l].unsqueeze(1), F[l - 1])
         loss = self._weigh(loss, grad_weight)
         return loss, P.transpose(0, 1)

@@ -591,32 +591,35 @@ def tf_lstm_sampled_rollout(x, cells, head, init_state, noise, forget_bias=1.0):
 # kernel K:(kh,kw,C,4F), recurrent R:(kh,kw,F,4F), bias (4F), channel blocks i,f,c,o; s = hard_sigmoid
 # by default (the reference never overrides it).  Dropout 0.3 on the inputs acts in training only.
 # --------------------------------------------------------------------------------------
-def conv2d_same(x, w, b=None):
-    """x:(B,H,W,C), w:(kh,kw,C,N) -> (B,H,W,N); zero 'same' padding, stride 1, no kernel flip."""
+def conv2d_same(x, w, b=None, dilation=1):
+    """x:(B,H,W,C), w:(kh,kw,C,N) -> (B,H,W,N); zero 'same' padding, stride 1, no kernel flip.  dilation = Keras
+    `dilation_rate` (odd kernels: tap (i,j) reads the pixel (i - kh//2, j - kw//2) * dilation away)."""
     B, H, W, C = x.shape
     kh, kw, _, N = w.shape
-    ph, pw = (kh - 1) // 2, (kw - 1) // 2
-    xp = np.zeros((B, H + kh - 1, W + kw - 1, C), x.dtype)
+    d = int(dilation)
+    ph, pw = d * ((kh - 1) // 2), d * ((kw - 1) // 2)
+    xp = np.zeros((B, H + d * (kh - 1), W + d * (kw - 1), C), x.dtype)
     xp[:, ph:ph + H, pw:pw + W] = x
     out = np.zeros((B, H, W, N), x.dtype)
     for dy in range(kh):
         for dx in range(kw):
-            out += xp[:, dy:dy + H, dx:dx + W] @ w[dy, dx]
+            out += xp[:, d * dy:d * dy + H, d * dx:d * dx + W] @ w[dy, dx]
     if b is not None:
         out = out + b
     return out.astype(x.dtype)
 
 
-def convlstm2d_step(x, h, c, K, R, b, act="hard_sigmoid"):
+def convlstm2d_step(x, h, c, K, R, b, act="hard_sigmoid", dilation=1):
+    """Keras 2.2 ConvLSTM2DCell.call: `dilation_rate` reaches input_conv only; recurrent_conv is never dilated."""
     F = R.shape[2]
-    z = conv2d_same(x, K, b) + conv2d_same(h, R)
+    z = conv2d_same(x, K, b, dilation) + conv2d_same(h, R)
     s = _rec_act(act)
     i, f, g, o = s(z[..., :F]), s(z[..., F:2 * F]), np.tanh(z[..., 2 * F:3 * F]), s(z[..., 3 * F:])
     c_new = f * c + i * g
     return (o * np.tanh(c_new)).astype(x.dtype), c_new.astype(x.dtype)
 
 
-def convlstm2d_layer(x, K, R, b, h0=None, c0=None, act="hard_sigmoid"):
+def convlstm2d_layer(x, K, R, b, h0=None, c0=None, act="hard_sigmoid", dilation=1):
     """x:(B,T,H,W,C) -> (hs:(B,T,H,W,F), h_T, c_T)."""
     B, T, H, W, _ = x.shape
     F = R.shape[2]
@@ -624,7 +627,7 @@ def convlstm2d_layer(x, K, R, b, h0=None, c0=None, act="hard_sigmoid"):
     c = np.zeros((B, H, W, F), x.dtype) if c0 is None else c0
     hs = np.empty((B, T, H, W, F), x.dtype)
     for t in range(T):
-        h, c = convlstm2d_step(x[:, t], h, c, K, R, b, act)
+        h, c = convlstm2d_step(x[:, t], h, c, K, R, b, act, dilation)
         hs[:, t] = h
     return hs, h, c
 
@@ -634,17 +637,18 @@ def softmax_last(x):
     return (e / e.sum(axis=-1, keepdims=True)).astype(x.dtype)
 
 
-def convlstm_seq2seq_forward(enc_in, dec_in0, w, T_out, head="conv2d", act="hard_sigmoid"):
+def convlstm_seq2seq_forward(enc_in, dec_in0, w, T_out, head="conv2d", act="hard_sigmoid", dilation=1):
     """3-layer ConvLSTM2D encoder, mirrored decoder unrolled T_out times with state hand-off, channel
     concat of the three layer outputs, head, output fed back (convlstm_seq2seq.py:100-126,146-165,209-282).
       head 'conv2d' (cfg.use_one_hot): Conv2D -> Conv2D -> Conv2D (relu each) + channel softmax
       head 'conv1d' (xyz mode, H == 1): Conv1D k=7 relu, relu, softmax over the 3 output channels
       head 'dense'  (cfg.predict_mean_var + cfg.input_mean_var, 1x1 maps of 6 channels): Flatten + Dense(6)
+    dilation = cfg.dilation_rate (config.py:105), passed to the six ConvLSTM2D layers (:102,110,120,148,155,162), not to the head.
     enc_in:(B,T_in,H,W,C)  dec_in0:(B,1,H,W,C)  ->  (B,T_out,H,W,Cout)   ('dense': (B,T_out,6))."""
     x = enc_in
     states = []
     for l in range(3):
-        x, h, c = convlstm2d_layer(x, w["enc%d_K" % l], w["enc%d_R" % l], w["enc%d_b" % l], act=act)
+        x, h, c = convlstm2d_layer(x, w["enc%d_K" % l], w["enc%d_R" % l], w["enc%d_b" % l], act=act, dilation=dilation)
         states.append((h, c))
     inp = dec_in0[:, 0]
     outs = []
@@ -652,7 +656,8 @@ def convlstm_seq2seq_forward(enc_in, dec_in0, w, T_out, head="conv2d", act="hard
         feats = []
         cur = inp
         for l in range(3):
-            h, c = convlstm2d_step(cur, states[l][0], states[l][1], w["dec%d_K" % l], w["dec%d_R" % l], w["dec%d_b" % l], act)
+            h, c = convlstm2d_step(cur, states[l][0], states[l][1], w["dec%d_K" % l], w["dec%d_R" % l], w["dec%d_b" % l], act,
+                                   dilation)
             states[l] = (h, c)
             feats.append(h)
             cur = h

@@ -100,11 +100,12 @@ def test_convlstm_seq2seq(head, B, T_in, T_out, H, W, C, L, hf):
 # ---------------------------------------------------------------------------------------
 # training kernels (a8 backward): checked against torch.autograd in fp64 on the CPU
 # ---------------------------------------------------------------------------------------
-def _tconv(x, w):
+def _tconv(x, w, dilation=1):
     """conv2d_same on NHWC / (kh,kw,C,N) operands with torch (independent reference)."""
     import torch.nn.functional as TF
     kh, kw = w.shape[:2]
-    return TF.conv2d(x.permute(0, 3, 1, 2), w.permute(3, 2, 0, 1), padding=(kh // 2, kw // 2)).permute(0, 2, 3, 1)
+    return TF.conv2d(x.permute(0, 3, 1, 2), w.permute(3, 2, 0, 1), padding=(dilation * (kh // 2), dilation * (kw // 2)),
+                     dilation=dilation).permute(0, 2, 3, 1)
 
 
 @pytest.mark.parametrize("B,H,W,C,N,kh,kw", [(2, 4, 5, 3, 7, 5, 5), (3, 36, 18, 30, 128, 5, 5), (2, 1, 30, 3, 128, 5, 5),
@@ -176,7 +177,7 @@ def test_convlstm_gates_backward_softmax_relu_colsum(act):
     close(ops.colsum(dev(big)), big.astype(np.float64).sum(0), "colsum")
 
 
-def _torch_convlstm_graph(enc, dec0, tgt, w, head, act, masks=None, xyz_sum1=False, xent=False):
+def _torch_convlstm_graph(enc, dec0, tgt, w, head, act, masks=None, xyz_sum1=False, xent=False, dilation=1):
     """Independent fp64 restatement of the ConvLSTM seq2seq training graph (convlstm_seq2seq.py:100-287) on
     torch.autograd: loss = mean squared error of the unrolled, self-fed decoder.  `masks` (optional): Keras
     ConvLSTM2D input dropout - per layer call four masks, gate g's kernel slice convolves x * mask_g."""
@@ -186,9 +187,9 @@ def _torch_convlstm_graph(enc, dec0, tgt, w, head, act, masks=None, xyz_sum1=Fal
     def cell(x, h, c, K, R, b, m4=None):
         F = R.shape[2]
         if m4 is None:
-            zx = _tconv(x, K)
+            zx = _tconv(x, K, dilation)
         else:
-            zx = torch.cat([_tconv(x * m4[g], K[..., g * F:(g + 1) * F]) for g in range(4)], -1)
+            zx = torch.cat([_tconv(x * m4[g], K[..., g * F:(g + 1) * F], dilation) for g in range(4)], -1)
         z = zx + b + _tconv(h, R)
         i, f, g, o = s(z[..., :F]), s(z[..., F:2 * F]), torch.tanh(z[..., 2 * F:3 * F]), s(z[..., 3 * F:])
         c = f * c + i * g
@@ -239,7 +240,7 @@ def _torch_convlstm_graph(enc, dec0, tgt, w, head, act, masks=None, xyz_sum1=Fal
     if xyz_sum1:      # costfunc._mse under cfg.add_xyz_sum1 (cost.py:23-28)
         loss = loss + 0.5 * torch.mean((1 - (P[..., 0] ** 2 + P[..., 1] ** 2 + P[..., 2] ** 2)) ** 2)
     loss.backward()
-    return float(loss), {k: v.grad.numpy() for k, v in t.items()}, P.detach().numpy()
+    return float(loss.detach()), {k: v.grad.numpy() for k, v in t.items()}, P.detach().numpy()
 
 
 @pytest.mark.parametrize("head,B,T_in,T_out,H,W,C,L,hf,act", [("conv2d", 2, 3, 3, 9, 6, 10, 8, (24, 40), "hard_sigmoid"),
@@ -601,3 +602,130 @@ def test_conv2d_map_resident_form(B, H, W, C, N, kh, kw):
     d = (got - old).abs().max().item()
     assert d <= 2e-5 * float(np.abs(ref).max()), d
     assert d > 0 or C % 4 != 0        # two kernels really ran (an input whose pixels are not 16-byte aligned stays on the old one)
+
+
+# ---------------------------------------------------------------------------------------
+# cfg.dilation_rate (config.py:105 -> the six ConvLSTM2D layers, convlstm_seq2seq.py:102,110,120,148,155,162)
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("B,H,W,C,N,kh,kw,d", [(2, 9, 7, 3, 7, 5, 5, 2), (3, 36, 18, 32, 128, 5, 5, 2), (2, 1, 30, 3, 128, 1, 7, 3),
+                                               (1, 6, 7, 17, 33, 3, 3, 2), (2, 36, 18, 56, 64, 5, 5, 3), (2, 4, 4, 8, 16, 5, 5, 4),
+                                               (1, 36, 18, 30, 30, 5, 5, 9)])
+def test_dilated_conv2d_forward_and_backward_kernels(B, H, W, C, N, kh, kw, d):
+    """Dilated 'same' convolution, its data gradient (the dilated convolution with the transposed weights) and its weight
+    gradient, against the oracle (forward) and torch.autograd in fp64; taps that fall wholly outside the map (d*(k//2) >= H)
+    contribute zero."""
+    from longterm360fov_amd import ops
+    rng = np.random.default_rng(B * 1000 + C * 10 + N + d)
+    x = rng.standard_normal((B, H, W, C)).astype(np.float32)
+    w = (rng.standard_normal((kh, kw, C, N)) / np.sqrt(kh * kw * C)).astype(np.float32)
+    b = rng.standard_normal(N).astype(np.float32)
+    add = rng.standard_normal((B, H, W, N)).astype(np.float32)
+    dy = rng.standard_normal((B, H, W, N)).astype(np.float32)
+    ref = O.conv2d_same(x.astype(np.float64), w.astype(np.float64), b.astype(np.float64), dilation=d)
+    close(ops.conv2d(dev(x), dev(w), dev(b), dilation=d), ref, "dilated conv")
+    close(ops.conv2d(dev(x), dev(w), dev(b), add=dev(add), activation="relu", dilation=d), np.maximum(ref + add, 0), "dilated conv + add, relu")
+    wide = dev(np.concatenate([rng.standard_normal((B, H, W, 4)).astype(np.float32), x, np.zeros((B, H, W, 4), np.float32)], -1))
+    close(ops.conv2d(wide[..., 4:4 + C], dev(w), dev(b), dilation=d), ref, "dilated conv on a channel slice")
+    tx = torch.tensor(x.astype(np.float64), requires_grad=True)
+    tw = torch.tensor(w.astype(np.float64), requires_grad=True)
+    out = _tconv(tx, tw, d)
+    assert np.abs(out.detach().numpy() + b - ref).max() < 1e-10          # the oracle and torch agree on what dilation means
+    (out * torch.tensor(dy.astype(np.float64))).sum().backward()
+    dw = ops.conv2d_wgrad(dev(x), dev(dy), kh, kw, dilation=d)
+    close(dw, tw.grad.numpy(), "dilated wgrad")
+    ops.conv2d_wgrad(wide[..., 4:4 + C], dev(dy), kh, kw, dw=dw, accumulate=True, dilation=d)
+    close(dw, 2 * tw.grad.numpy(), "dilated wgrad accumulate, channel slice")
+    close(ops.conv2d(dev(dy), ops.conv2d_weight_transpose(dev(w)), dilation=d), tx.grad.numpy(), "dilated dgrad")
+
+
+@pytest.mark.parametrize("act", ["hard_sigmoid", "sigmoid"])
+@pytest.mark.parametrize("B,H,W,C,F,k,d", [(3, 36, 18, 32, 32, 5, 2), (2, 6, 5, 30, 32, 5, 2), (2, 1, 30, 3, 8, 5, 3), (1, 7, 4, 17, 20, 3, 2),
+                                           (2, 36, 18, 128, 64, 5, 2)])
+def test_dilated_convlstm_cell_one_launch(B, H, W, C, F, k, d, act):
+    """Keras's ConvLSTM2DCell dilates input_conv only: in the one-launch cell the taps over x are spread, those over h_prev
+    are not; with and without a previous state, gates tape included."""
+    from longterm360fov_amd import ops
+    rng = np.random.default_rng(C + F + d)
+    f64 = lambda a: a.astype(np.float64)
+    x = rng.standard_normal((B, H, W, C)).astype(np.float32)
+    h = rng.standard_normal((B, H, W, F)).astype(np.float32) * 0.5
+    c = rng.standard_normal((B, H, W, F)).astype(np.float32)
+    K = (rng.standard_normal((k, k, C, 4 * F)) / np.sqrt(k * k * C)).astype(np.float32)
+    R = (rng.standard_normal((k, k, F, 4 * F)) / np.sqrt(k * k * F)).astype(np.float32)
+    b = rng.standard_normal(4 * F).astype(np.float32) * 0.1
+    h_ref, c_ref = O.convlstm2d_step(f64(x), f64(h), f64(c), f64(K), f64(R), f64(b), act, dilation=d)
+    h_plain, _ = O.convlstm2d_step(f64(x), f64(h), f64(c), f64(K), f64(R), f64(b), act)
+    assert np.abs(h_ref - h_plain).max() > 1e-3        # the case distinguishes dilation d from 1
+    KR = dev(np.concatenate([K, R], 2))
+    feat = torch.zeros((B, H, W, F + 8), dtype=torch.float32, device="cuda")
+    gates = torch.empty((B, H, W, 4 * F), dtype=torch.float32, device="cuda")
+    c_new = torch.empty((B, H, W, F), dtype=torch.float32, device="cuda")
+    ops.convlstm_cell(dev(x), dev(h), KR, dev(b), dev(c), feat[..., 4:4 + F], act, c_new=c_new, gates=gates, dilation=d)
+    close(feat[..., 4:4 + F], h_ref, "dilated cell h", tol=5e-5)
+    close(c_new, c_ref, "dilated cell c", tol=5e-5)
+    s = (lambda v: 1 / (1 + np.exp(-v))) if act == "sigmoid" else (lambda v: np.clip(0.2 * v + 0.5, 0, 1))
+    z = O.conv2d_same(f64(x), f64(K), f64(b), dilation=d) + O.conv2d_same(f64(h), f64(R))
+    g_ref = np.concatenate([s(z[..., :F]), s(z[..., F:2 * F]), np.tanh(z[..., 2 * F:3 * F]), s(z[..., 3 * F:])], -1)
+    close(gates, g_ref, "dilated cell gates tape", tol=5e-5)
+    # zero initial state: w is K alone
+    h0_ref, c0_ref = O.convlstm2d_step(f64(x), np.zeros_like(f64(h)), np.zeros_like(f64(c)), f64(K), f64(R), f64(b), act, dilation=d)
+    h0 = torch.empty((B, H, W, F), dtype=torch.float32, device="cuda")
+    _, c0 = ops.convlstm_cell(dev(x), None, dev(K), dev(b), None, h0, act, dilation=d)
+    close(h0, h0_ref, "dilated cell h, zero state", tol=5e-5)
+    close(c0, c0_ref, "dilated cell c, zero state", tol=5e-5)
+
+
+@pytest.mark.parametrize("head,B,T_in,T_out,H,W,C,L,hf,act,d,drop", [("conv2d", 2, 3, 3, 9, 6, 10, 8, (24, 40), "hard_sigmoid", 2, False),
+                                                                      ("conv1d", 3, 2, 3, 1, 30, 3, 16, (32, 48), "sigmoid", 3, False),
+                                                                      ("conv2d", 1, 2, 2, 36, 18, 30, 16, (40, 136), "sigmoid", 2, False),
+                                                                      ("conv2d", 2, 3, 2, 7, 5, 6, 8, (12, 20), "hard_sigmoid", 2, True)])
+def test_dilated_convlstm_seq2seq_predict_gradients_and_training(head, B, T_in, T_out, H, W, C, L, hf, act, d, drop):
+    """The whole model at cfg.dilation_rate = d: predict against the oracle, the unrolled training graph's gradients against
+    torch.autograd in fp64 (with Keras's per-gate input dropout in the last case), and RMSprop steps reduce the loss."""
+    from longterm360fov_amd.models import ConvLSTMSeq2Seq
+    from longterm360fov_amd.training import ConvLSTMTrainer
+    w = O.init_convlstm_seq2seq(5, C=C, latent_dim=L, head=head, head_filters=hf, map_hw=(H, W))
+    rng = np.random.default_rng(8 + d)
+    for k in w:
+        if k.endswith("_b"):
+            w[k] = (w[k] + 0.1 * rng.standard_normal(w[k].shape)).astype(np.float32)
+    enc = rng.random((B, T_in, H, W, C)).astype(np.float32)
+    dec0 = enc[:, -1:].copy()
+    tgt = rng.random((B, T_out, H, W, C)).astype(np.float32)
+    tgt /= tgt.sum(-1, keepdims=True)
+    w64 = {k: v.astype(np.float64) for k, v in w.items()}
+    P_orc = O.convlstm_seq2seq_forward(enc.astype(np.float64), dec0.astype(np.float64), w64, T_out, head=head, act=act, dilation=d)
+    P_one = O.convlstm_seq2seq_forward(enc.astype(np.float64), dec0.astype(np.float64), w64, T_out, head=head, act=act)
+    assert np.abs(P_orc - P_one).max() > 1e-5
+    close(ConvLSTMSeq2Seq(w, head=head, recurrent_activation=act, dilation_rate=d).predict([enc, dec0], predict_step=T_out), P_orc,
+          "dilated predict", tol=5e-5)
+    tr = ConvLSTMTrainer(w, head=head, act=act, dilation_rate=d, dropout_rate=0.3 if drop else 0.0, seed=5)
+    masks = tr.sample_masks(B, H, W, C, T_out) if drop else None
+    loss_ref, g_ref, P_ref = _torch_convlstm_graph(enc, dec0, tgt, w, head, act, dilation=d,
+                                                   masks=None if masks is None else {k: v.cpu().numpy() for k, v in masks.items()})
+    if not drop:
+        assert np.abs(P_orc - P_ref).max() < 1e-10
+    loss, P = tr.forward_backward(dev(enc), dev(dec0), dev(tgt), masks=masks)
+    close(P, P_ref, "dilated train-mode forward")
+    assert abs(float(loss.item()) - loss_ref) <= 1e-5 * loss_ref + 1e-9
+    for k in tr.order:
+        a = tr.g[k].detach().cpu().numpy().astype(np.float64)
+        scale = np.abs(g_ref[k]).max()
+        err = np.abs(a - g_ref[k]).max()
+        assert err <= 2e-4 * scale + 1e-9, (k, err, scale)
+    losses = [float(tr.train_step(dev(enc), dev(dec0), dev(tgt)).item()) for _ in range(4)]
+    assert losses[-1] < losses[0]
+
+
+def test_dilation_rate_defaults_to_cfg_and_rejects_zero():
+    from longterm360fov_amd import ops
+    from longterm360fov_amd.config import cfg
+    from longterm360fov_amd.models import ConvLSTMSeq2Seq
+    from longterm360fov_amd._lib import FovError
+    w = O.init_convlstm_seq2seq(9, C=3, latent_dim=8, head="conv1d", head_filters=(16, 24))
+    assert ConvLSTMSeq2Seq(w, head="conv1d").dilation_rate == cfg.dilation_rate == 1
+    with pytest.raises(ValueError):
+        ConvLSTMSeq2Seq(w, head="conv1d", dilation_rate=0)
+    x = torch.zeros((1, 4, 4, 4), device="cuda")
+    with pytest.raises(FovError):
+        ops.conv2d(x, torch.zeros((3, 3, 4, 4), device="cuda"), dilation=0)

@@ -461,3 +461,28 @@ def test_sample_mixture_3d_statistics():
     cov = O.gmm3d_covariance(sig.reshape(1, 3, 3), rho.reshape(1, 3, 3))[0, 1]
     assert np.abs(out.mean(0) - us[0, 3:6]).max() < 0.02
     assert np.abs(np.cov(out.T) - cov).max() < 0.01
+
+
+def test_dilated_conv_and_convlstm_step_against_torch():
+    """cfg.dilation_rate (config.py:105): the oracle's dilated 'same' convolution is torch's conv2d(dilation=d, padding=d*(k//2)),
+    and the ConvLSTM step dilates the input convolution only (Keras 2.2 ConvLSTM2DCell: input_conv gets dilation_rate,
+    recurrent_conv does not)."""
+    import torch
+    import torch.nn.functional as TF
+    rng = np.random.default_rng(4)
+    x = rng.standard_normal((2, 9, 7, 5))
+    K = rng.standard_normal((5, 5, 5, 12)) * 0.1
+    R = rng.standard_normal((5, 5, 3, 12)) * 0.1
+    b = rng.standard_normal(12) * 0.1
+    tc = lambda a, w, d: TF.conv2d(torch.tensor(a).permute(0, 3, 1, 2), torch.tensor(w).permute(3, 2, 0, 1), padding=(2 * d, 2 * d),
+                                   dilation=d).permute(0, 2, 3, 1).numpy()
+    for d in (1, 2, 3):
+        assert np.abs(O.conv2d_same(x, K, b, dilation=d) - (tc(x, K, d) + b)).max() < 1e-12
+    h = rng.standard_normal((2, 9, 7, 3))
+    c = rng.standard_normal((2, 9, 7, 3))
+    z = tc(x, K, 2) + b + tc(h, R, 1)
+    hs = lambda v: np.clip(0.2 * v + 0.5, 0, 1)
+    cn = hs(z[..., 3:6]) * c + hs(z[..., :3]) * np.tanh(z[..., 6:9])
+    hn = hs(z[..., 9:]) * np.tanh(cn)
+    h2, c2 = O.convlstm2d_step(x, h, c, K, R, b, "hard_sigmoid", dilation=2)
+    assert np.abs(h2 - hn).max() < 1e-12 and np.abs(c2 - cn).max() < 1e-12
