@@ -177,6 +177,24 @@ int fov_dense_bwd_bf16(const float* x, const float* W, const float* dpre, float*
                        int N, int In, int Out, int accumulate,
                        void* workspace, size_t workspace_bytes, fov_stream_t stream);
 
+/* The weight-gradient half of fov_lstm_seq_bwd[_bf16] on its own: dK (F,4H) = x^T dz, dR (H,4H) = h_{t-1}^T dz (h_{-1} = h0, or
+ * zero when h0 is NULL), db (4H) = column sums of dz, from the dz tape (B,T,4H) a call with dK = dR = db = NULL left behind.  Same
+ * products in the same order (one fused product when dK, dR, db lie adjacent), so the results equal the single call's bit for bit.
+ * It exists so that a trainer can enqueue a layer's products on ANOTHER stream, under the next layer's latency-bound recurrence
+ * (Keras computes the same gradients inside `model.fit`, given_others_gt_mean_var_seq2seq.py:494-506).  Any of dK / dR / db may be
+ * NULL.  bf16 != 0: operands rounded to bf16 (H = 256).  workspace: fov_lstm_seq_bwd_workspace_bytes(B, T, F, H) bytes of plain
+ * scratch - NOT the workspace a concurrently running fov_lstm_seq_bwd uses. */
+int fov_lstm_seq_wgrad(const float* x, const float* hs, const float* h0, const float* dz, float* dK, float* dR, float* db,
+                       int B, int T, int F, int H, int accumulate, int bf16,
+                       void* workspace, size_t workspace_bytes, fov_stream_t stream);
+
+/* A HIP stream of a given priority for such side work: priority < 0 high, 0 normal, > 0 low (clamped to the device's range).
+ * Work enqueued on a LOW-priority stream yields the compute units to the caller's stream whenever both have workgroups ready:
+ * weight-gradient products put there fill the gaps of the persistent recurrence kernels instead of delaying their launch.
+ * Destroy with fov_stream_destroy after synchronising it. */
+int fov_stream_create(int priority, fov_stream_t* stream);
+int fov_stream_destroy(fov_stream_t stream);
+
 /* The three weight gradients of an (unrolled) LSTM layer as ONE product and one reduce - what Keras/TF autodiff
  * computes as three (given_others...py:308 under model.fit):
  *     out (In1 + In2 + bias, Out) (+)= [x1 | x2 | 1]^T dpre        over the N rows (all steps x sequences)

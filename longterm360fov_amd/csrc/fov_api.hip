@@ -748,6 +748,40 @@ int fov_lstm_seq_bwd_bf16(const float* x, const float* K, const float* R, const 
                         accumulate, (float*)workspace, workspace_bytes / sizeof(float), (hipStream_t)stream, 1);
 }
 
+int fov_stream_create(int priority, fov_stream_t* stream) {
+    if (!stream) { set_error("fov_stream_create: stream is NULL"); return FOV_ERR_INVALID; }
+    int least = 0, greatest = 0;     // numerically: least = lowest priority (largest value), greatest = highest (smallest value)
+    hipError_t e = hipDeviceGetStreamPriorityRange(&least, &greatest);
+    if (e != hipSuccess) { set_error("hipDeviceGetStreamPriorityRange: %s", hipGetErrorString(e)); return FOV_ERR_LAUNCH; }
+    int p = priority > 0 ? least : (priority < 0 ? greatest : 0);
+    if (p > least) p = least;
+    if (p < greatest) p = greatest;
+    hipStream_t s = nullptr;
+    e = hipStreamCreateWithPriority(&s, hipStreamNonBlocking, p);
+    if (e != hipSuccess) { set_error("hipStreamCreateWithPriority(%d): %s", p, hipGetErrorString(e)); return FOV_ERR_LAUNCH; }
+    *stream = (fov_stream_t)s;
+    return FOV_OK;
+}
+
+int fov_stream_destroy(fov_stream_t stream) {
+    if (!stream) return FOV_OK;
+    hipError_t e = hipStreamDestroy((hipStream_t)stream);
+    if (e != hipSuccess) { set_error("hipStreamDestroy: %s", hipGetErrorString(e)); return FOV_ERR_LAUNCH; }
+    return FOV_OK;
+}
+
+int fov_lstm_seq_wgrad(const float* x, const float* hs, const float* h0, const float* dz, float* dK, float* dR, float* db, int B,
+                       int T, int F, int H, int accumulate, int bf16, void* workspace, size_t workspace_bytes, fov_stream_t stream) {
+    if (B < 0 || T < 0 || F <= 0 || H <= 0 || (B > 0 && T > 0 && (!dz || (dK && !x) || (dR && !hs))) || (bf16 && H != 256)) {
+        set_error("fov_lstm_seq_wgrad: invalid argument (bf16 operands: H = 256 only)");
+        return FOV_ERR_INVALID;
+    }
+    int rc = check_ws(workspace, workspace_bytes, fov_lstm_seq_bwd_workspace_bytes(B, T, F, H));
+    if (rc) return rc;
+    return lstm_seq_wgrad(x, hs, h0, dz, dK, dR, db, B, T, F, H, accumulate, bf16 ? 1 : 0, (float*)workspace,
+                          workspace_bytes / sizeof(float), (hipStream_t)stream);
+}
+
 size_t fov_dense_bwd_workspace_bytes(int N, int In, int Out) {
     if (N <= 0 || In <= 0 || Out <= 0) return 256;
     size_t a = (size_t)(Out <= 8 ? 1024 : 64) * In * Out, b = (size_t)256 * Out, c = (size_t)(N + 255) / 256 + 64;

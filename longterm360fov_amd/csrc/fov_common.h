@@ -219,6 +219,8 @@ int launch_bwd_cluster(const float* R, const float* reserve, const float* c0, co
 
 // training side (train_kernels.hip)
 size_t lstm_bwd_workspace_floats(int B, int T, int F, int H);
+int lstm_seq_wgrad(const float* x, const float* hs, const float* h0, const float* dz, float* dK, float* dR, float* db, int B, int T,
+                   int F, int H, int accumulate, int bf16, float* scratch, size_t scratch_floats, hipStream_t stream);
 int lstm_seq_bwd(const float* x, const float* K, const float* R, const float* h0, const float* c0, const float* hs,
                  const float* reserve, const float* dhs, const float* dhT, const float* dcT, float* dz, float* dx,
                  float* dK, float* dR, float* db, float* dh0, float* dc0, int B, int T, int F, int H, int act,

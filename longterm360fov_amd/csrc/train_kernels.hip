@@ -1428,94 +1428,13 @@ int wgrad_fused(const float* a1, long lda1, long a1_so, int M1, int shift1, cons
     return gemm_f32(g, accumulate, scratch, scratch_floats, stream);
 }
 
-// BPTT of one layer.  dz:(B,T,4H) is an output (kept: the caller may need it for dx of the layer
-// below).  dK,dR,db are overwritten (accumulate = 0) or added to (accumulate = 1).
-int lstm_seq_bwd(const float* x, const float* K, const float* R, const float* h0, const float* c0, const float* hs,
-                 const float* reserve, const float* dhs, const float* dhT, const float* dcT, float* dz, float* dx,
-                 float* dK, float* dR, float* db, float* dh0, float* dc0, int B, int T, int F, int H, int act,
-                 int accumulate, float* ws, size_t ws_floats, hipStream_t stream, int bf16) {
-    if (bf16 && H != 256) { set_error("lstm_seq_bwd: the bf16 path is built for H = 256"); return FOV_ERR_UNSUPPORTED; }
-    if (ws_floats < lstm_bwd_workspace_floats(B, T, F, H)) { set_error("lstm_seq_bwd: workspace too small"); return FOV_ERR_WORKSPACE; }
-    if (T == 0) {
-        if (!accumulate) {
-            if (dK) (void)hipMemsetAsync(dK, 0, sizeof(float) * (size_t)F * 4 * H, stream);
-            if (dR) (void)hipMemsetAsync(dR, 0, sizeof(float) * (size_t)H * 4 * H, stream);
-            if (db) (void)hipMemsetAsync(db, 0, sizeof(float) * (size_t)4 * H, stream);
-        }
-        const size_t bh0 = sizeof(float) * (size_t)B * H;
-        if (dh0) (void)(dhT ? hipMemcpyAsync(dh0, dhT, bh0, hipMemcpyDeviceToDevice, stream) : hipMemsetAsync(dh0, 0, bh0, stream));
-        if (dc0) (void)(dcT ? hipMemcpyAsync(dc0, dcT, bh0, hipMemcpyDeviceToDevice, stream) : hipMemsetAsync(dc0, 0, bh0, stream));
-        return FOV_OK;
-    }
-    const bool wide16 = !bf16 && bwd16_takes(B, H) && (((uintptr_t)R) & 15) == 0;   // width 512, small batches at 128 / 256: lstm_bwd16.hip
-    const bool persistent = (bwd_cluster_shape_ok(H) || wide16) && !env_knobs().bwd_stepped;
-    bool fuse_kr = false, fuse_r = false, dx_in_kernel = false;
-    const size_t head = (kStatusBytes + kXchBytes) / sizeof(float);
-    float* dh_rec = ws + head;
-    float* dc = dh_rec + (size_t)B * H;
-    float* scratch = dc + (size_t)B * H;
-    const size_t scratch_floats = ws_floats - head - (size_t)2 * B * H;
-    const size_t bh = sizeof(float) * (size_t)B * H;
-    hipError_t e = hipSuccess;
-    if (persistent) {
-        // one launch for the whole recurrence: dz (B,T,4H), dh0, dc0
-        // bias gradient: per-tile partials from the kernel (db_part lives in the split-K scratch), summed below
-        // dK, dR, db adjacent (a trainer's flat gradient buffer): ONE product [x | h_{t-1} | 1]^T dz (h_{-1} = 0; a given initial
-        // state adds its h0^T dz_0 afterwards)
-        // below gives all three (no bias partials from the kernel, no column-sum launches); F too narrow for a row tile:
-        // [h_{t-1} | 1]^T dz gives dR and db
-        const int N4 = 4 * H;
-        fuse_kr = dK && dR && db && T > 1 && dR == dK + (size_t)F * N4 && db == dR + (size_t)H * N4 &&
-                  wgrad_fusable(x, F, (long)T * F, F, hs, H, (long)T * H, H, dz, N4, (long)T * N4, dK, N4) && !env_knobs().no_wgrad_fusion;
-        fuse_r = !fuse_kr && dR && db && T > 1 && db == dR + (size_t)H * N4 &&
-                 wgrad_fusable(hs, H, (long)T * H, H, nullptr, 0, 0, 0, dz, N4, (long)T * N4, dR, N4) && !env_knobs().no_wgrad_fusion;
-        float* db_part = (db && !fuse_kr && !fuse_r) ? scratch : nullptr;
-        // bf16, 256-wide input (the stacked layer): the BPTT kernel forms dx = dz K^T from the dz tile it has gathered anyway
-        dx_in_kernel = bf16 && dx && F == 256 && (((uintptr_t)K) & 15) == 0 && !env_knobs().no_dx_fusion;
-        // H = 256: groups of eight workgroups fill the chip up to 32 tiles (the 4-group kernel leaves half of it idle
-        // at 512 sequences); bf16 operands exist in the 8-group kernel only
-        int rc = wide16 ? launch_bwd16(R, reserve, c0, dhs, dhT, dcT, dz, dh0 ? dh0 : dh_rec, dc0 ? dc0 : dc, db_part, B, T, H, act, ws, stream)
-                 : (bf16 || (bwd8_preferred(B, H) && !env_knobs().bwd_groups4))
-                     ? launch_bwd8(R, reserve, c0, dhs, dhT, dcT, dz, dh0 ? dh0 : dh_rec, dc0 ? dc0 : dc, db_part, B, T, act, bf16, ws, stream,
-                                   dx_in_kernel ? K : nullptr, dx_in_kernel ? dx : nullptr)
-                     : launch_bwd_cluster(R, reserve, c0, dhs, dhT, dcT, dz, dh0 ? dh0 : dh_rec, dc0 ? dc0 : dc, db_part, B, T, H,
-                                          act, ws, stream);
-        if (rc) return rc;
-        if (db_part) {
-            const int tiles = (B + 15) / 16;
-            if ((size_t)tiles * 4 * H + (size_t)256 * 4 * H > scratch_floats) { set_error("lstm_seq_bwd: scratch too small for db"); return FOV_ERR_WORKSPACE; }
-            rc = colsum(db_part, db, tiles, 4 * H, accumulate, scratch + (size_t)tiles * 4 * H,
-                        scratch_floats - (size_t)tiles * 4 * H, stream);
-            if (rc) return rc;
-        }
-    } else {
-        e = dhT ? hipMemcpyAsync(dh_rec, dhT, bh, hipMemcpyDeviceToDevice, stream) : hipMemsetAsync(dh_rec, 0, bh, stream);
-        if (e == hipSuccess) e = dcT ? hipMemcpyAsync(dc, dcT, bh, hipMemcpyDeviceToDevice, stream) : hipMemsetAsync(dc, 0, bh, stream);
-        if (e != hipSuccess) { set_error("lstm_seq_bwd init: %s", hipGetErrorString(e)); return FOV_ERR_LAUNCH; }
-        const long nelem = (long)B * H;
-        const dim3 pgrid((unsigned)((nelem + 255) / 256));
-        for (int t = T - 1; t >= 0; --t) {
-            if (act == FOV_ACT_HARD_SIGMOID)
-                hipLaunchKernelGGL(lstm_bwd_pointwise<FOV_ACT_HARD_SIGMOID>, pgrid, dim3(256), 0, stream, reserve, c0, dhs,
-                                   dh_rec, dc, dz, B, T, H, t);
-            else
-                hipLaunchKernelGGL(lstm_bwd_pointwise<FOV_ACT_SIGMOID>, pgrid, dim3(256), 0, stream, reserve, c0, dhs, dh_rec,
-                                   dc, dz, B, T, H, t);
-            int rc = check_launch("lstm_bwd_pointwise");
-            if (rc) return rc;
-            // dh_rec (B,H) = dz_t (B,4H) . R^T :  A(m,k) = dz[m][t][k], B(k,n) = R[n][k]
-            GemmArgs g = {};
-            g.a = dz + (size_t)t * 4 * H; g.b = R; g.c = dh_rec;
-            g.M = B; g.N = H; g.KO = 1; g.KI = 4 * H;
-            g.a_sm = (long)T * 4 * H; g.a_sko = 0; g.a_ski = 1;
-            g.b_sn = 4 * H; g.b_sko = 0; g.b_ski = 1;
-            g.ldc = H;
-            rc = gemm_f32(g, 0, scratch, scratch_floats, stream);
-            if (rc) return rc;
-        }
-        if (dh0) { e = hipMemcpyAsync(dh0, dh_rec, bh, hipMemcpyDeviceToDevice, stream); if (e != hipSuccess) { set_error("dh0 copy"); return FOV_ERR_LAUNCH; } }
-        if (dc0) { e = hipMemcpyAsync(dc0, dc, bh, hipMemcpyDeviceToDevice, stream); if (e != hipSuccess) { set_error("dc0 copy"); return FOV_ERR_LAUNCH; } }
-    }
+// The weight-gradient half of a layer's BPTT, from its dz tape: dK = x^T dz, dR = h_{t-1}^T dz (h_{-1} = h0 or 0), db = colsum(dz).
+// fuse_kr / fuse_r: the adjacent-in-memory forms (one product for all three / for dR and db); db_done: the caller's persistent
+// kernel has produced db already (unfused forms only).
+static int lstm_seq_weight_products(const float* x, const float* hs, const float* h0, const float* dz, float* dK, float* dR, float* db,
+                                    int B, int T, int F, int H, int accumulate, int bf16, bool fuse_kr, bool fuse_r, bool db_done,
+                                    float* scratch, size_t scratch_floats, hipStream_t stream) {
+    const bool persistent = db_done;
     int rc;
     const long BT = (long)B * T;
     if (fuse_kr || fuse_r) {
@@ -1570,7 +1489,126 @@ int lstm_seq_bwd(const float* x, const float* K, const float* R, const float* h0
         rc = colsum(dz, db, BT, 4 * H, accumulate, scratch, scratch_floats, stream);
         if (rc) return rc;
     }
+    return FOV_OK;
+}
+
+static void lstm_seq_wgrad_fusion(const float* x, const float* hs, const float* dz, float* dK, float* dR, float* db, int T, int F, int H,
+                                  bool* fuse_kr, bool* fuse_r) {
+    const int N4 = 4 * H;
+    *fuse_kr = dK && dR && db && T > 1 && dR == dK + (size_t)F * N4 && db == dR + (size_t)H * N4 &&
+               wgrad_fusable(x, F, (long)T * F, F, hs, H, (long)T * H, H, dz, N4, (long)T * N4, dK, N4) && !env_knobs().no_wgrad_fusion;
+    *fuse_r = !*fuse_kr && dR && db && T > 1 && db == dR + (size_t)H * N4 &&
+              wgrad_fusable(hs, H, (long)T * H, H, nullptr, 0, 0, 0, dz, N4, (long)T * N4, dR, N4) && !env_knobs().no_wgrad_fusion;
+}
+
+// Weight gradients of one layer from a dz tape its BPTT left behind (fov_lstm_seq_bwd* with dK = dR = db = NULL): lets a trainer
+// put a layer's products on another stream than the next layer's recurrence.  Same arithmetic, same order as inside lstm_seq_bwd.
+int lstm_seq_wgrad(const float* x, const float* hs, const float* h0, const float* dz, float* dK, float* dR, float* db, int B, int T,
+                   int F, int H, int accumulate, int bf16, float* scratch, size_t scratch_floats, hipStream_t stream) {
+    if (bf16 && H != 256) { set_error("lstm_seq_wgrad: the bf16 path is built for H = 256"); return FOV_ERR_UNSUPPORTED; }
+    if (T == 0 || B == 0) {
+        if (!accumulate) {
+            if (dK) (void)hipMemsetAsync(dK, 0, sizeof(float) * (size_t)F * 4 * H, stream);
+            if (dR) (void)hipMemsetAsync(dR, 0, sizeof(float) * (size_t)H * 4 * H, stream);
+            if (db) (void)hipMemsetAsync(db, 0, sizeof(float) * (size_t)4 * H, stream);
+        }
+        return FOV_OK;
+    }
+    bool fuse_kr, fuse_r;
+    lstm_seq_wgrad_fusion(x, hs, dz, dK, dR, db, T, F, H, &fuse_kr, &fuse_r);
+    return lstm_seq_weight_products(x, hs, h0, dz, dK, dR, db, B, T, F, H, accumulate, bf16, fuse_kr, fuse_r, false, scratch,
+                                    scratch_floats, stream);
+}
+
+// BPTT of one layer.  dz:(B,T,4H) is an output (kept: the caller may need it for dx of the layer
+// below).  dK,dR,db are overwritten (accumulate = 0) or added to (accumulate = 1).
+int lstm_seq_bwd(const float* x, const float* K, const float* R, const float* h0, const float* c0, const float* hs,
+                 const float* reserve, const float* dhs, const float* dhT, const float* dcT, float* dz, float* dx,
+                 float* dK, float* dR, float* db, float* dh0, float* dc0, int B, int T, int F, int H, int act,
+                 int accumulate, float* ws, size_t ws_floats, hipStream_t stream, int bf16) {
+    if (bf16 && H != 256) { set_error("lstm_seq_bwd: the bf16 path is built for H = 256"); return FOV_ERR_UNSUPPORTED; }
+    if (ws_floats < lstm_bwd_workspace_floats(B, T, F, H)) { set_error("lstm_seq_bwd: workspace too small"); return FOV_ERR_WORKSPACE; }
+    if (T == 0) {
+        if (!accumulate) {
+            if (dK) (void)hipMemsetAsync(dK, 0, sizeof(float) * (size_t)F * 4 * H, stream);
+            if (dR) (void)hipMemsetAsync(dR, 0, sizeof(float) * (size_t)H * 4 * H, stream);
+            if (db) (void)hipMemsetAsync(db, 0, sizeof(float) * (size_t)4 * H, stream);
+        }
+        const size_t bh0 = sizeof(float) * (size_t)B * H;
+        if (dh0) (void)(dhT ? hipMemcpyAsync(dh0, dhT, bh0, hipMemcpyDeviceToDevice, stream) : hipMemsetAsync(dh0, 0, bh0, stream));
+        if (dc0) (void)(dcT ? hipMemcpyAsync(dc0, dcT, bh0, hipMemcpyDeviceToDevice, stream) : hipMemsetAsync(dc0, 0, bh0, stream));
+        return FOV_OK;
+    }
+    const bool wide16 = !bf16 && bwd16_takes(B, H) && (((uintptr_t)R) & 15) == 0;   // width 512, small batches at 128 / 256: lstm_bwd16.hip
+    const bool persistent = (bwd_cluster_shape_ok(H) || wide16) && !env_knobs().bwd_stepped;
+    bool fuse_kr = false, fuse_r = false, dx_in_kernel = false;
+    const size_t head = (kStatusBytes + kXchBytes) / sizeof(float);
+    float* dh_rec = ws + head;
+    float* dc = dh_rec + (size_t)B * H;
+    float* scratch = dc + (size_t)B * H;
+    const size_t scratch_floats = ws_floats - head - (size_t)2 * B * H;
+    const size_t bh = sizeof(float) * (size_t)B * H;
+    hipError_t e = hipSuccess;
+    if (persistent) {
+        // one launch for the whole recurrence: dz (B,T,4H), dh0, dc0
+        // bias gradient: per-tile partials from the kernel (db_part lives in the split-K scratch), summed below
+        // dK, dR, db adjacent (a trainer's flat gradient buffer): ONE product [x | h_{t-1} | 1]^T dz (h_{-1} = 0; a given initial
+        // state adds its h0^T dz_0 afterwards)
+        // below gives all three (no bias partials from the kernel, no column-sum launches); F too narrow for a row tile:
+        // [h_{t-1} | 1]^T dz gives dR and db
+        lstm_seq_wgrad_fusion(x, hs, dz, dK, dR, db, T, F, H, &fuse_kr, &fuse_r);
+        float* db_part = (db && !fuse_kr && !fuse_r) ? scratch : nullptr;
+        // bf16, 256-wide input (the stacked layer): the BPTT kernel forms dx = dz K^T from the dz tile it has gathered anyway
+        dx_in_kernel = bf16 && dx && F == 256 && (((uintptr_t)K) & 15) == 0 && !env_knobs().no_dx_fusion;
+        // H = 256: groups of eight workgroups fill the chip up to 32 tiles (the 4-group kernel leaves half of it idle
+        // at 512 sequences); bf16 operands exist in the 8-group kernel only
+        int rc = wide16 ? launch_bwd16(R, reserve, c0, dhs, dhT, dcT, dz, dh0 ? dh0 : dh_rec, dc0 ? dc0 : dc, db_part, B, T, H, act, ws, stream)
+                 : (bf16 || (bwd8_preferred(B, H) && !env_knobs().bwd_groups4))
+                     ? launch_bwd8(R, reserve, c0, dhs, dhT, dcT, dz, dh0 ? dh0 : dh_rec, dc0 ? dc0 : dc, db_part, B, T, act, bf16, ws, stream,
+                                   dx_in_kernel ? K : nullptr, dx_in_kernel ? dx : nullptr)
+                     : launch_bwd_cluster(R, reserve, c0, dhs, dhT, dcT, dz, dh0 ? dh0 : dh_rec, dc0 ? dc0 : dc, db_part, B, T, H,
+                                          act, ws, stream);
+        if (rc) return rc;
+        if (db_part) {
+            const int tiles = (B + 15) / 16;
+            if ((size_t)tiles * 4 * H + (size_t)256 * 4 * H > scratch_floats) { set_error("lstm_seq_bwd: scratch too small for db"); return FOV_ERR_WORKSPACE; }
+            rc = colsum(db_part, db, tiles, 4 * H, accumulate, scratch + (size_t)tiles * 4 * H,
+                        scratch_floats - (size_t)tiles * 4 * H, stream);
+            if (rc) return rc;
+        }
+    } else {
+        e = dhT ? hipMemcpyAsync(dh_rec, dhT, bh, hipMemcpyDeviceToDevice, stream) : hipMemsetAsync(dh_rec, 0, bh, stream);
+        if (e == hipSuccess) e = dcT ? hipMemcpyAsync(dc, dcT, bh, hipMemcpyDeviceToDevice, stream) : hipMemsetAsync(dc, 0, bh, stream);
+        if (e != hipSuccess) { set_error("lstm_seq_bwd init: %s", hipGetErrorString(e)); return FOV_ERR_LAUNCH; }
+        const long nelem = (long)B * H;
+        const dim3 pgrid((unsigned)((nelem + 255) / 256));
+        for (int t = T - 1; t >= 0; --t) {
+            if (act == FOV_ACT_HARD_SIGMOID)
+                hipLaunchKernelGGL(lstm_bwd_pointwise<FOV_ACT_HARD_SIGMOID>, pgrid, dim3(256), 0, stream, reserve, c0, dhs,
+                                   dh_rec, dc, dz, B, T, H, t);
+            else
+                hipLaunchKernelGGL(lstm_bwd_pointwise<FOV_ACT_SIGMOID>, pgrid, dim3(256), 0, stream, reserve, c0, dhs, dh_rec,
+                                   dc, dz, B, T, H, t);
+            int rc = check_launch("lstm_bwd_pointwise");
+            if (rc) return rc;
+            // dh_rec (B,H) = dz_t (B,4H) . R^T :  A(m,k) = dz[m][t][k], B(k,n) = R[n][k]
+            GemmArgs g = {};
+            g.a = dz + (size_t)t * 4 * H; g.b = R; g.c = dh_rec;
+            g.M = B; g.N = H; g.KO = 1; g.KI = 4 * H;
+            g.a_sm = (long)T * 4 * H; g.a_sko = 0; g.a_ski = 1;
+            g.b_sn = 4 * H; g.b_sko = 0; g.b_ski = 1;
+            g.ldc = H;
+            rc = gemm_f32(g, 0, scratch, scratch_floats, stream);
+            if (rc) return rc;
+        }
+        if (dh0) { e = hipMemcpyAsync(dh0, dh_rec, bh, hipMemcpyDeviceToDevice, stream); if (e != hipSuccess) { set_error("dh0 copy"); return FOV_ERR_LAUNCH; } }
+        if (dc0) { e = hipMemcpyAsync(dc0, dc, bh, hipMemcpyDeviceToDevice, stream); if (e != hipSuccess) { set_error("dc0 copy"); return FOV_ERR_LAUNCH; } }
+    }
+    int rc = lstm_seq_weight_products(x, hs, h0, dz, dK, dR, db, B, T, F, H, accumulate, bf16, fuse_kr, fuse_r, /*db_done=*/persistent,
+                                      scratch, scratch_floats, stream);
+    if (rc) return rc;
     if (dx && !dx_in_kernel) {   // dx (B*T,F) = dz . K^T : A(m,k) = dz[m][k], B(k,n) = K[n][k]
+        const long BT = (long)B * T;
         GemmArgs g = {};
         g.a = dz; g.b = K; g.c = dx; g.M = (int)BT; g.N = F; g.KO = 1; g.KI = 4 * H;
         g.a_sm = 4 * H; g.a_ski = 1; g.b_sn = 4 * H; g.b_ski = 1; g.ldc = F;

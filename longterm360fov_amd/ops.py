@@ -402,6 +402,28 @@ def lstm_seq_bwd(x, K, R, hs, reserve, h0=None, c0=None, dhs=None, dhT=None, dcT
     return {"dz": dz, "dx": dx, "dK": dK, "dR": dR, "db": db, "dh0": dh0, "dc0": dc0}
 
 
+def lstm_seq_wgrad(x, hs, dz, dK=None, dR=None, db=None, h0=None, accumulate=False, scratch=None, dtype="f32"):
+    """The weight-gradient half of lstm_seq_bwd from the dz tape a `need_weight_grads=False` call left: dK = x^T dz,
+    dR = h_{t-1}^T dz, db = colsum(dz), bit-identical to the single call.  `scratch` must not be the workspace of a BPTT kernel
+    that may run concurrently on another stream."""
+    x, hs, dz = _dev(x, "x"), _dev(hs, "hs"), _dev(dz, "dz")
+    B, T, F = x.shape
+    H = hs.shape[-1]
+    assert hs.shape == (B, T, H) and dz.shape == (B, T, 4 * H)
+    L = _lib.lib()
+    buf = (scratch or _default_scratch).get(L.fov_lstm_seq_bwd_workspace_bytes(B, T, F, H), x.device)
+    check(L.fov_lstm_seq_wgrad(_ptr(x), _ptr(hs), _ptr(_dev(h0, "h0")), _ptr(dz), _ptr(dK), _ptr(dR), _ptr(db), B, T, F, H,
+                               1 if accumulate else 0, 1 if dtype == "bf16" else 0, buf.data_ptr(), buf.numel(), _stream()))
+    return {"dK": dK, "dR": dR, "db": db}
+
+
+def side_stream(device, priority=1):
+    """A HIP stream of the given priority (> 0 low, 0 normal, < 0 high) owned by the library, as a torch stream object."""
+    h = _ct.c_void_p()
+    check(_lib.lib().fov_stream_create(int(priority), _ct.byref(h)))
+    return torch.cuda.ExternalStream(h.value, device=device)
+
+
 def act_bwd(dy, y, base=None, activation="tanh", out=None):
     """out = base + dy * act'(y)  (tanh: 1 - y^2; relu: [y > 0]; linear: 1)."""
     dy, y = _dev(dy, "dy"), _dev(y, "y")

@@ -1143,12 +1143,23 @@ class OthersMixingTrainer(FlatParamTrainer):
         # (tried: each encoder layer in two parts, its weight-gradient products on the side stream under the NEXT layer's
         # recurrence - 0.846 -> 0.881 ms: with the decoder's products already there the CUs' matrix pipes are full and the
         # recurrences slow down more than the products gain)
-        e2 = ops.lstm_seq_bwd(hs1, w["enc2_K"], w["enc2_R"], hs2, res2, dhT=dh2_rec, dcT=dc2, dK=g["enc2_K"], dR=g["enc2_R"],
-                              db=g["enc2_b"], need_dx=True, act=act, accumulate=acc, scratch=bsc, dtype=dt)
-        if split_side:   # the second half of the decoder's products under layer 1's recurrence
+        # bf16: layer 2's own products go under layer 1's recurrence too (they sat between the two BPTT launches, 35 us of the
+        # critical path); fp32: in line (its products are 3x as long, the recurrences slow down more than is gained)
+        enc_side = side is not None and os.environ.get("FOV_WGRAD_ENC_SIDE", "1" if dt == "bf16" else "0") == "1"
+        if enc_side:
+            e2 = ops.lstm_seq_bwd(hs1, w["enc2_K"], w["enc2_R"], hs2, res2, dhT=dh2_rec, dcT=dc2, need_dx=True, act=act,
+                                  scratch=bsc, dtype=dt, need_weight_grads=False)
+        else:
+            e2 = ops.lstm_seq_bwd(hs1, w["enc2_K"], w["enc2_R"], hs2, res2, dhT=dh2_rec, dcT=dc2, dK=g["enc2_K"], dR=g["enc2_R"],
+                                  db=g["enc2_b"], need_dx=True, act=act, accumulate=acc, scratch=bsc, dtype=dt)
+        if split_side or enc_side:   # the second half of the decoder's products under layer 1's recurrence
             side.wait_stream(main)
             with torch.cuda.stream(side):
-                decoder_wgrads(2)
+                if enc_side:
+                    ops.lstm_seq_wgrad(hs1, hs2, e2["dz"], dK=g["enc2_K"], dR=g["enc2_R"], db=g["enc2_b"], accumulate=acc,
+                                       scratch=self._side_scratch(), dtype=dt)
+                if split_side:
+                    decoder_wgrads(2)
                 ops.reduce_defer_flush()
         ops.lstm_seq_bwd(enc, w["enc1_K"], w["enc1_R"], hs1, res1, dhs=e2["dx"], dhT=dh1_rec, dcT=dc1, dK=g["enc1_K"],
                          dR=g["enc1_R"], db=g["enc1_b"], act=act, accumulate=acc, scratch=bsc, dtype=dt)
@@ -1157,6 +1168,13 @@ class OthersMixingTrainer(FlatParamTrainer):
         return loss, out
 
     _side_stream = None
+    _side_scratch_buf = None
+
+    def _side_scratch(self):
+        """Scratch of the encoder products that run on the side stream (the BPTT workspace is busy under them)."""
+        if self._side_scratch_buf is None:
+            self._side_scratch_buf = ops.Scratch()
+        return self._side_scratch_buf
 
     @property
     def _side_warm(self):
@@ -1168,7 +1186,14 @@ class OthersMixingTrainer(FlatParamTrainer):
         if os.environ.get("FOV_WGRAD_STREAM", "1") == "0":
             return None
         if self._side_stream is None:
-            self._side_stream = torch.cuda.Stream(device=self.device)
+            # LOW priority: when a product and a persistent recurrence kernel become ready together (both wait for the same
+            # BPTT launch), the recurrence's workgroups are placed first and the product's fill what is left of every CU; at equal
+            # priority the product's 512 blocks take the registers and the recurrence starts only when they have drained
+            # (r04 timeline: 42 us between the two encoder BPTT launches).  FOV_SIDE_PRIORITY=normal: a plain torch stream.
+            if os.environ.get("FOV_SIDE_PRIORITY", "low") == "low":
+                self._side_stream = ops.side_stream(self.device, 1)
+            else:
+                self._side_stream = torch.cuda.Stream(device=self.device)
         return self._side_stream
 
 

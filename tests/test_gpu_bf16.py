@@ -286,3 +286,49 @@ def test_bf16_two_layer_wavefront_equals_two_launches(B, T, F, act):
     o1, o2 = ops.lstm_stack2_bf16(x, d1, d2, act=act, workspace=ws, out1=(None, e(B, H), e(B, H), None), out2=(None, e(B, H), e(B, H), None))
     ws.check()
     assert torch.equal(o1[1], h1) and torch.equal(o1[2], c1) and torch.equal(o2[1], h2) and torch.equal(o2[2], c2)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("B,T,F,state,adjacent", [(100, 5, 256, True, True), (37, 1, 90, False, False), (512, 10, 256, False, True),
+                                                  (64, 6, 6, True, True)])
+def test_weight_gradient_half_on_its_own_equals_the_single_call(dtype, B, T, F, state, adjacent):
+    """fov_lstm_seq_wgrad from the dz tape of a data-path-only BPTT call = the weight gradients of the single call, bit for bit
+    (adjacent dK | dR | db as in a trainer's flat buffer -> the fused product; separate tensors -> three products), also when the
+    products run on a low-priority side stream created by the library."""
+    from longterm360fov_amd import ops
+    rng = np.random.default_rng(B + T + F)
+    H = 256
+    K, R, b = O.init_lstm(rng, F, H, np.float32)
+    x = rng.uniform(-1, 1, (B, T, F)).astype(np.float32)
+    h0 = dev((0.3 * rng.standard_normal((B, H))).astype(np.float32)) if state else None
+    c0 = dev((0.3 * rng.standard_normal((B, H))).astype(np.float32)) if state else None
+    dhs = dev((0.1 * rng.standard_normal((B, T, H))).astype(np.float32))
+    xd, Kd, Rd = dev(x), dev(K), dev(R)
+    hs, _, _, res = ops.lstm_seq_train(xd, Kd, Rd, dev(b), h0, c0, act="sigmoid")
+
+    def grads():
+        if adjacent:
+            flat = torch.zeros((F + H + 1) * 4 * H, dtype=torch.float32, device="cuda")
+            return flat, (flat[:F * 4 * H].view(F, 4 * H), flat[F * 4 * H:(F + H) * 4 * H].view(H, 4 * H), flat[(F + H) * 4 * H:])
+        t = tuple(torch.zeros(s, dtype=torch.float32, device="cuda") for s in ((F, 4 * H), (H, 4 * H), (4 * H,)))
+        return t, t
+    sc, sc2 = ops.Scratch(), ops.Scratch()
+    _, (dK, dR, db) = grads()
+    one = ops.lstm_seq_bwd(xd, Kd, Rd, hs, res, h0=h0, c0=c0, dhs=dhs, dK=dK, dR=dR, db=db, act="sigmoid", scratch=sc, dtype=dtype)
+    sc.check()
+    _, (dK2, dR2, db2) = grads()
+    two = ops.lstm_seq_bwd(xd, Kd, Rd, hs, res, h0=h0, c0=c0, dhs=dhs, act="sigmoid", scratch=sc, dtype=dtype, need_weight_grads=False)
+    sc.check()
+    assert two["dK"] is None and torch.equal(two["dz"], one["dz"])
+    side = ops.side_stream(torch.device("cuda", 0), priority=1)
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        ops.lstm_seq_wgrad(xd, hs, two["dz"], dK=dK2, dR=dR2, db=db2, h0=h0, scratch=sc2, dtype=dtype)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    for name, a, r in (("dK", dK2, dK), ("dR", dR2, dR), ("db", db2, db)):
+        assert torch.equal(a, r), (name, float((a - r).abs().max()))
+        assert float(r.abs().max()) > 0 or (name == "dR" and T == 1 and not state)     # h_{-1} = 0: no recurrent gradient
+    # accumulate: twice the gradient
+    ops.lstm_seq_wgrad(xd, hs, two["dz"], dK=dK2, dR=dR2, db=db2, h0=h0, accumulate=True, scratch=sc2, dtype=dtype)
+    assert torch.allclose(dR2, 2 * dR, rtol=1e-6, atol=1e-7) and torch.allclose(db2, 2 * db, rtol=1e-6, atol=1e-7)
