@@ -290,6 +290,82 @@ __device__ __forceinline__ bool q_dz_gather(const __amdgpu_buffer_rsrc_t rs, uns
     return ok;
 }
 
+// UNIT-PAIR form of the same exchange (round 4): a lane owns the cells (row, units u0, u0 + 1) - two ADJACENT units of ONE row
+// instead of one unit of two rows - so that every tape access of the pointwise phase is an 8-byte access that a wave
+// coalesces into whole 128-byte lines (the kernels were bound by the number of VMEM instructions the CU's one address unit
+// processes per step, tools/stamp_bf16_layer.py --bwd), and the bf16 pair of a granule is one 32-bit LDS word of the tile.
+// Granule order [row 16][unit pair 128][gate 4] of {bf16 pair, epoch}: 32 bytes per (row, pair) = two 16-byte stores.
+// dzp[g] = packed bf16 (unit u0 low, u0 + 1 high) of gate g; u0 even, global unit index inside the 256.
+__device__ __forceinline__ void q_dz_publish2(const __amdgpu_buffer_rsrc_t rs, unsigned base, int row, int u0, const unsigned (&dzp)[4],
+                                              unsigned epoch, unsigned short* tile, bool same_xcd) {
+    const unsigned off = (unsigned)(row * (QH / 2) + (u0 >> 1)) * 32u;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const qu32x4 gr = {dzp[2 * h], epoch, dzp[2 * h + 1], epoch};
+        if (same_xcd) __builtin_amdgcn_raw_buffer_store_b128(gr, rs, off + h * 16, base, 1);
+        else __builtin_amdgcn_raw_buffer_store_b128(gr, rs, off + h * 16, base, 16);
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) *(unsigned*)(tile + row * QLDZ + g * QH + u0) = dzp[g];
+}
+// thread tid fetches (row tid >> 4, pair tid & 15) of each of the seven other slices
+__device__ __forceinline__ bool q_dz_gather2(const __amdgpu_buffer_rsrc_t rs, unsigned base, int slice, int tid, unsigned epoch,
+                                             unsigned short* tile, unsigned* status) {
+    const int row = tid >> 4, pr = tid & 15;
+    const unsigned voff = (unsigned)(row * (QH / 2) + pr) * 32u;
+    unsigned short* lrow = tile + row * QLDZ + 2 * pr;
+    auto put = [&](int j, int h, const qu32x4& q) {   // gates 2h, 2h + 1 of (row, pair pr of slice slice + 1 + j)
+        unsigned short* lo = lrow + ((slice + 1 + j) & (QG - 1)) * 32 + 2 * h * QH;
+        *(unsigned*)lo = q.x;
+        *(unsigned*)(lo + QH) = q.z;
+    };
+    unsigned bad = 0;
+    {
+        qu32x4 v[QNDZ];
+#pragma unroll
+        for (int j = 0; j < 7; ++j)
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+                v[j * 2 + h] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + h * 16, base + (unsigned)(((slice + 1 + j) & (QG - 1)) * 16) * 32u, 16);
+#pragma unroll
+        for (int j = 0; j < 7; ++j)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                if (v[j * 2 + h].y == epoch && v[j * 2 + h].w == epoch) put(j, h, v[j * 2 + h]);
+                else bad |= (1u << (j * 2 + h));
+            }
+    }
+    unsigned spins = 0;
+    bool ok = true;
+    while (__any(bad != 0)) {
+        ++spins;
+        if (spins > Q_SPIN || ((spins & 63u) == 0 && xch_poisoned(status))) {
+            if ((tid & 63) == 0) xch_give_up(status);
+            ok = false;
+            break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+        asm volatile("" ::: "memory");
+        qu32x4 tv[QNDZ];   // a whole new sweep, all loads in flight together (see q_dz_gather)
+#pragma unroll
+        for (int j = 0; j < 7; ++j)
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+                tv[j * 2 + h] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + h * 16, base + (unsigned)(((slice + 1 + j) & (QG - 1)) * 16) * 32u, 16);
+#pragma unroll
+        for (int j = 0; j < 7; ++j)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const unsigned bit = 1u << (j * 2 + h);
+                if ((bad & bit) && tv[j * 2 + h].y == epoch && tv[j * 2 + h].w == epoch) {
+                    put(j, h, tv[j * 2 + h]);
+                    bad &= ~bit;
+                }
+            }
+    }
+    return ok;
+}
+
 // group / slice of a workgroup: members of a group 8 blocks apart (round-robin dispatch puts them on one XCD when
 // num_groups % 8 == 0); a placement preference only - the exchange is the placement-independent sc1 protocol
 __device__ __forceinline__ void q_group_slice(int num_groups, int& group, int& slice) {

@@ -50,7 +50,18 @@ struct GemmTN {
     int M1;
     int a_shift, a2_shift;   // 1: operand row (ro, ri) is its element (ro, ri - 1), zero at ri == 0 (h_{t-1} of a (B,T,H) tape)
     int bias_row;        // 1: row M of C = column sums of B (fp32, taken from the staged values before they are rounded)
+    unsigned ri_magic;   // floor(2^32 / RI) (0xffffffff for RI = 1): r / RI = umulhi(r, magic) or that + 1 (tn_row_split)
 };
+
+// (ro, ri) = divmod(r, RI) in five instructions.  The loaders form it for every row of every stage: with the 32-bit integer
+// division the compiler emits (~35 instructions) and 64-bit offset arithmetic the products were VALU-bound on ADDRESS arithmetic
+// - 19 us for a product whose loads, LDS traffic and MFMAs need 7 (r04: tools/bench_wgrad_bf16.py under rocprofv3).
+__device__ __forceinline__ void tn_row_split(unsigned r, unsigned RI, unsigned magic, unsigned& ro, unsigned& ri) {
+    unsigned q = __umulhi(r, magic);
+    unsigned rem = r - q * RI;
+    if (rem >= RI) { ++q; rem -= RI; }
+    ro = q; ri = rem;
+}
 
 // two transposed reads = the 8 k-values of one column for this lane group (k permutation in the file header)
 __device__ __forceinline__ qu32x4 tr_frag(const unsigned short* img, int g4, int n, int col0) {
@@ -110,15 +121,18 @@ __global__ __launch_bounds__(256) void gemm_bf16_tn_kernel(GemmTN g) {
     const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.b), 0, 0x7fffffff, 0x00020000);
     const bool a_col_ok = am0 + scol < a_M;             // AVEC: a_M % 4 == 0, the whole quad is in or out
     const bool b_col_ok = n0 + scol + 3 < g.N;          // N % 4 == 0 (host-checked)
+    const unsigned a_so32 = (unsigned)a_so, a_ld32 = (unsigned)a_ld, b_so32 = (unsigned)g.b_so, b_ld32 = (unsigned)g.ldb;
     auto load_stage = [&](long r0) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const long r = r0 + srow + 8 * i;
-            const unsigned ro = (unsigned)r / (unsigned)g.RI, ri = (unsigned)r - ro * (unsigned)g.RI;
+            unsigned ro, ri;
+            tn_row_split((unsigned)r, (unsigned)g.RI, g.ri_magic, ro, ri);
             const bool rok = r < r_hi;
             const bool a_ok = rok && !(a_shift && ri == 0);
-            const unsigned aoff = (unsigned)(((long)ro * a_so + ((long)ri - a_shift) * a_ld + am0 + scol) * 4);
-            const unsigned boff = (unsigned)(((long)ro * g.b_so + (long)ri * g.ldb + n0 + scol) * 4);
+            // byte offsets < 2^31 (host-checked): 32-bit arithmetic is exact (the shifted row of ri == 0 is masked)
+            const unsigned aoff = (ro * a_so32 + (ri - (unsigned)a_shift) * a_ld32 + (unsigned)(am0 + scol)) * 4u;
+            const unsigned boff = (ro * b_so32 + ri * b_ld32 + (unsigned)(n0 + scol)) * 4u;
             if (AVEC) {
                 const qu32x4 t = __builtin_amdgcn_raw_buffer_load_b128(ars, (a_ok && a_col_ok) ? aoff : OOR, 0, 0);
                 ra[i] = (f32x4){__uint_as_float(t[0]), __uint_as_float(t[1]), __uint_as_float(t[2]), __uint_as_float(t[3])};
@@ -194,6 +208,228 @@ __global__ __launch_bounds__(256) void gemm_bf16_tn_kernel(GemmTN g) {
                 }
             }
         }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Round 4: the same TN product with THREE stages of global loads in flight per block.  The kernel above keeps one stage in
+// flight (its 32 staging registers per thread and stage leave room for no more at three blocks per CU): a block's 13 stages
+// each cost one memory latency (~1.3 us), 21 us for a 5120 x 513 x 1024 product that moves 31 MB - a quarter of the HBM rate.
+// Here a block has 512 threads (8 waves as 2 x 4, a wave owns 64 x 32 of the 128 x 128 tile): the staging of a stage is 16
+// registers per thread, three register sets rotate (loads of stages s+2, s+3, s+4 fly while stage s is multiplied and
+// stage s+1 is rounded into LDS), three LDS images rotate with them, one barrier per stage.  One block per CU, so the
+// row slices are cut to give about one block per CU (fewer, longer slices: 12 MB of partials instead of 27).
+// Same arithmetic per output element (k order inside a slice, fixed-order reduce over slices); slices differ from the
+// kernel above, so the two agree to rounding, not bit for bit.  Takes the 16-byte-aligned forms (AVEC); the rest stays above.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int G3T = 512;                 // threads
+#ifdef FOV_STAMPS
+__device__ unsigned long long g_tn3_stamps[4][8];   // [block 0, 100, 200, last][entry, loads issued, first stage in LDS, loop end, bias done, stored]
+#define TN3_STAMP(slot) do { if (stamp_slot >= 0 && tid == 0) g_tn3_stamps[stamp_slot][slot] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define TN3_STAMP(slot) do { } while (0)
+#endif
+
+constexpr int G3KB = 32;                 // rows (k) per stage (64-row stages were measured: 2 050 cycles per stage against 933 for
+                                         // 32 - no gain per row, a longer prologue and more padding of the stage count)
+constexpr int G3NR = G3KB / 16;          // rows per thread and stage
+constexpr int G3_CLD = 36;               // floats per row of a wave's 64 x 32 result tile in LDS (epilogue)
+constexpr size_t G3_IMG = (size_t)2 * 3 * G3KB * GLD_TN * sizeof(unsigned short), G3_TILES = (size_t)8 * 64 * G3_CLD * sizeof(float);
+constexpr size_t G3_LDS = G3_IMG > G3_TILES ? G3_IMG : G3_TILES;
+struct G3Regs { f32x4 a[G3NR], b[G3NR]; };
+
+__global__ __launch_bounds__(G3T, 1) void gemm_bf16_tn3_kernel(GemmTN g) {
+    __shared__ __attribute__((aligned(16))) unsigned char sRaw[G3_LDS];   // [A | B][image 3][row][column] bf16; the epilogue's tiles
+    unsigned short (*sA)[G3KB * GLD_TN] = reinterpret_cast<unsigned short (*)[G3KB * GLD_TN]>(sRaw);
+    unsigned short (*sB)[G3KB * GLD_TN] = sA + 3;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 15, g4 = lane >> 4;
+    const int wm = wave >> 2, wn = wave & 3;          // 2 x 4 waves: rows 64*wm, columns 32*wn
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (g.xcd_remap) {
+        const int nb = g.grid_n * g.grid_m;
+        const int xcd = blockIdx.x & 7, w = blockIdx.x >> 3;
+        bz = xcd + 8 * (w / nb);
+        if (bz >= g.split) return;   // whole block, before any barrier
+        const int tile = w - (w / nb) * nb;
+        by = tile / g.grid_n;
+        bx = tile - by * g.grid_n;
+    }
+    const int m0 = by * GT, n0 = bx * GT;
+#ifdef FOV_STAMPS
+    const int stamp_slot = blockIdx.x == 0 ? 0 : blockIdx.x == 100 ? 1 : blockIdx.x == 200 ? 2 : blockIdx.x == gridDim.x - 1 ? 3 : -1;
+#endif
+    TN3_STAMP(0);
+    const bool second = g.a2 != nullptr && m0 >= g.M1;
+    const float* abase = second ? g.a2 : g.a;
+    const long a_ld = second ? g.lda2 : g.lda, a_so = second ? g.a2_so : g.a_so;
+    const int a_shift = second ? g.a2_shift : g.a_shift;
+    const int am0 = second ? m0 - g.M1 : m0;
+    const int a_M = second ? g.M - g.M1 : (g.a2 ? g.M1 : g.M);
+    const bool bias_blk = g.bias_row && by == 0;
+    const long rows = (long)g.RO * g.RI;
+    const long r_lo = (long)bz * g.rows_per_split;
+    long r_hi = r_lo + g.rows_per_split;
+    if (r_hi > rows) r_hi = rows;
+    // staging: thread = (row tid >> 5 (+ 16 i, i < G3NR), 4 columns (tid & 31) * 4)
+    const int srow = tid >> 5, scol = (tid & 31) * 4;
+    f32x4 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 bsum = (f32x4){0.f, 0.f, 0.f, 0.f};
+    constexpr unsigned OOR = 0x80000000u;   // unconditional buffer loads, out-of-range offsets read as 0 (see the kernel above)
+    const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(abase), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.b), 0, 0x7fffffff, 0x00020000);
+    const bool a_col_ok = am0 + scol < a_M;
+    const bool b_col_ok = n0 + scol + 3 < g.N;
+    // Row cursors of this thread's rows, advanced by one stage per load_stage call - additions and one wrap
+    // test instead of a division and four integer multiplies per row and stage (quarter-rate instructions: the loop was bound
+    // by instruction issue, 1 236 cycles per 32-row stage of which ~300 were address arithmetic; tools/stamp_tn3.py).
+    //   r = (ro, ri);  G3KB = dq * RI + dr:  ri += dr, ro += dq, one carry;  the byte offsets follow with the same carry.
+    const unsigned RI = (unsigned)g.RI;
+    const unsigned dq = (unsigned)G3KB / RI, dr = (unsigned)G3KB - dq * RI;
+    const unsigned a_so4 = (unsigned)a_so * 4u, a_ld4 = (unsigned)a_ld * 4u, b_so4 = (unsigned)g.b_so * 4u, b_ld4 = (unsigned)g.ldb * 4u;
+    const unsigned a_step = dq * a_so4 + dr * a_ld4, b_step = dq * b_so4 + dr * b_ld4;       // per stage, no carry
+    const unsigned a_carry = a_so4 - RI * a_ld4, b_carry = b_so4 - RI * b_ld4;               // added when ri wraps (mod 2^32)
+    unsigned c_ri[G3NR], c_aoff[G3NR], c_boff[G3NR], c_r[G3NR];   // rows < 2^31 (host-checked)
+    const unsigned r_hi32 = (unsigned)r_hi;
+#pragma unroll
+    for (int i = 0; i < G3NR; ++i) {
+        c_r[i] = (unsigned)r_lo + srow + 16 * i;
+        unsigned ro;
+        tn_row_split(c_r[i], RI, g.ri_magic, ro, c_ri[i]);
+        // byte offsets < 2^31 (host-checked): 32-bit arithmetic is exact (the shifted row of ri == 0 is masked)
+        c_aoff[i] = ro * a_so4 + (c_ri[i] - (unsigned)a_shift) * a_ld4 + (unsigned)(am0 + scol) * 4u;
+        c_boff[i] = ro * b_so4 + c_ri[i] * b_ld4 + (unsigned)(n0 + scol) * 4u;
+    }
+    auto load_stage = [&](G3Regs& R) {   // the NEXT stage of the slice (calls are in stage order)
+#pragma unroll
+        for (int i = 0; i < G3NR; ++i) {
+            const bool rok = c_r[i] < r_hi32;
+            const bool a_ok = rok && !(a_shift && c_ri[i] == 0);
+            const qu32x4 ta = __builtin_amdgcn_raw_buffer_load_b128(ars, (a_ok && a_col_ok) ? c_aoff[i] : OOR, 0, 0);
+            const qu32x4 tb = __builtin_amdgcn_raw_buffer_load_b128(brs, (rok && b_col_ok) ? c_boff[i] : OOR, 0, 0);
+            R.a[i] = (f32x4){__uint_as_float(ta[0]), __uint_as_float(ta[1]), __uint_as_float(ta[2]), __uint_as_float(ta[3])};
+            R.b[i] = (f32x4){__uint_as_float(tb[0]), __uint_as_float(tb[1]), __uint_as_float(tb[2]), __uint_as_float(tb[3])};
+            c_r[i] += G3KB;
+            c_ri[i] += dr;
+            c_aoff[i] += a_step;
+            c_boff[i] += b_step;
+            const bool wrap = c_ri[i] >= RI;
+            c_ri[i] -= wrap ? RI : 0u;
+            c_aoff[i] += wrap ? a_carry : 0u;
+            c_boff[i] += wrap ? b_carry : 0u;
+        }
+    };
+    auto store_stage = [&](int buf, const G3Regs& R) {
+#pragma unroll
+        for (int i = 0; i < G3NR; ++i) {
+            *(qu32x2*)(sA[buf] + (srow + 16 * i) * GLD_TN + scol) = (qu32x2){pack_bf16(R.a[i][0], R.a[i][1]), pack_bf16(R.a[i][2], R.a[i][3])};
+            *(qu32x2*)(sB[buf] + (srow + 16 * i) * GLD_TN + scol) = (qu32x2){pack_bf16(R.b[i][0], R.b[i][1]), pack_bf16(R.b[i][2], R.b[i][3])};
+        }
+        if (bias_blk) {   // every stage is stored exactly once
+#pragma unroll
+            for (int i = 0; i < G3NR; ++i) bsum += R.b[i];
+        }
+    };
+    // The loop body is BRANCH-FREE: the stage count is rounded up to a multiple of three and every load / LDS store runs
+    // unconditionally (rows past the slice present an out-of-range offset and read as zeros: a zero stage adds nothing).  A
+    // load inside an `if` makes its registers a phi of old and new values - the compiler then copies them behind an
+    // s_waitcnt vmcnt(0) right after the issue, and the three stages in flight collapse into one (first version: 22 us).
+    const long nst = (r_hi > r_lo) ? (r_hi - r_lo + G3KB - 1) / G3KB : 0;
+    const long nstages = (nst + 2) / 3 * 3;
+    G3Regs R0, R1, R2;
+    // set (s % 3) holds stage s until it is rounded into LDS image (s % 3); it then takes the loads of stage s + 3
+    load_stage(R0);
+    load_stage(R1);
+    load_stage(R2);
+    TN3_STAMP(1);
+    store_stage(0, R0);
+    load_stage(R0);
+    __syncthreads();
+    TN3_STAMP(2);
+    auto iter = [&](int buf, int nbuf, G3Regs& Rn) {   // multiply the stage in image buf; the next stage (set Rn) -> image nbuf
+        qu32x4 af[G3KB / 32][4], bf[G3KB / 32][2];
+#pragma unroll
+        for (int kb = 0; kb < G3KB / 32; ++kb) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[kb][i] = tr_frag(sA[buf] + kb * 32 * GLD_TN, g4, n, wm * 64 + i * 16);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bf[kb][j] = tr_frag(sB[buf] + kb * 32 * GLD_TN, g4, n, wn * 32 + j * 16);
+        }
+#pragma unroll
+        for (int kb = 0; kb < G3KB / 32; ++kb)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) qmfma(acc[i][j], af[kb][i], bf[kb][j]);
+        store_stage(nbuf, Rn);
+        load_stage(Rn);
+        __syncthreads();
+    };
+    for (long s = 0; s < nstages; s += 3) {
+        iter(0, 1, R1);
+        iter(1, 2, R2);
+        iter(2, 0, R0);
+    }
+    TN3_STAMP(3);
+    float* cbase = g.split > 1 ? g.c + (size_t)bz * (g.M + g.bias_row) * g.N : g.c;
+    const int ldc = g.split > 1 ? g.N : g.ldc;
+    float* red = reinterpret_cast<float*>(sRaw);      // the loop ended on a barrier: the images are free
+    if (bias_blk) {   // row M: the sixteen row groups' column sums, folded in a fixed order
+        *(f32x4*)(red + srow * GT + scol) = bsum;
+        __syncthreads();
+        if (tid < GT && n0 + tid < g.N) {
+            float t = 0.f;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) t += red[q * GT + tid];
+            float* cp = cbase + (size_t)g.M * ldc + n0 + tid;
+            *cp = (g.split == 1 && g.add_c) ? *cp + t : t;
+        }
+        __syncthreads();
+    }
+    // Result tile through LDS: a lane holds four ROWS of one column (the MFMA's layout) - 32 four-byte stores per thread, one
+    // 64-byte piece per row and instruction (3 500 cycles of the block's life).  Each wave lays its 64 x 32 tile down in LDS
+    // (row stride 36: the four row groups of a store land 16 banks apart) and reads it back as four consecutive COLUMNS per
+    // lane: eight 16-byte stores of 128 contiguous bytes per row.
+    {
+        float* tile = red + wave * (64 * G3_CLD);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) tile[(i * 16 + 4 * g4 + r) * G3_CLD + j * 16 + n] = acc[i][j][r];
+        // (a wave reads back only what it wrote: no barrier, the LDS operations of a wave complete in order)
+        const int rr = lane >> 3, c4 = (lane & 7) * 4;
+        const bool vec_ok = (ldc & 3) == 0 && (((uintptr_t)cbase) & 15) == 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int rl = rr + 8 * k;
+            const f32x4 v = *(const f32x4*)(tile + rl * G3_CLD + c4);
+            const int row = m0 + wm * 64 + rl, col = n0 + wn * 32 + c4;
+            if (row < g.M) {
+                float* cp = cbase + (size_t)row * ldc + col;
+                if (vec_ok && col + 3 < g.N) {
+                    f32x4 o = v;
+                    if (g.split == 1 && g.add_c) o += *(const f32x4*)cp;
+                    *(f32x4*)cp = o;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (col + e < g.N) cp[e] = (g.split == 1 && g.add_c) ? cp[e] + v[e] : v[e];
+                }
+            }
+        }
+    }
+#ifdef FOV_STAMPS
+    if (stamp_slot >= 0 && tid == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        g_tn3_stamps[stamp_slot][4] = __builtin_amdgcn_s_memtime();
+        g_tn3_stamps[stamp_slot][5] = (unsigned long long)nstages;
+    }
+#endif
 }
 
 struct GemmNT {
@@ -285,6 +521,12 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(GemmNT g) {
 
 }  // namespace
 
+#ifdef FOV_STAMPS
+extern "C" int fov_debug_read_tn3_stamps(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tn3_stamps), sizeof(unsigned long long) * 4 * 8);
+}
+#endif
+
 size_t gemm_bf16_tn_scratch_floats(int M, int N) { return (size_t)32 * (M + 1) * N; }
 
 // C (M + bias_row, N) (+)= [A1 | A2 | 1]^T B over rows (ro, ri); scratch holds the split partials.  A2 may be NULL (M2 = 0).
@@ -311,9 +553,16 @@ int gemm_bf16_tn_fused(const float* a1, long lda1, long a1_so, int M1, int shift
     GemmTN g = {};
     g.a = a1; g.b = b; g.M = M; g.N = N; g.RO = RO; g.RI = RI; g.lda = lda1; g.ldb = ldb; g.a_so = a1_so; g.b_so = b_so; g.ldc = ldc;
     g.a2 = a2; g.lda2 = lda2; g.a2_so = a2_so; g.M1 = M1; g.a_shift = shift1; g.a2_shift = shift2; g.bias_row = bias_row ? 1 : 0;
+    g.ri_magic = RI <= 1 ? 0xffffffffu : (unsigned)((1ull << 32) / (unsigned)RI);
     const int tiles = ((M + GT - 1) / GT) * ((N + GT - 1) / GT);
-    // enough row slices to fill the chip, at least 8 stages each, at most 32 slices and what the scratch holds
-    int split = (2 * device_cu_count() + tiles - 1) / tiles;
+    const bool avec = (lda1 & 3) == 0 && (a1_so & 3) == 0 && (((uintptr_t)a1) & 15) == 0 && (M1 & 3) == 0 &&
+                      (!a2 || ((lda2 & 3) == 0 && (a2_so & 3) == 0 && (((uintptr_t)a2) & 15) == 0 && (M2 & 3) == 0));
+    const bool deep = avec && !env_knobs().gemm_bf16_shallow;   // three stages in flight, one 512-thread block per CU
+    // enough row slices to fill the chip, at least 8 stages each, at most 32 slices and what the scratch holds; the deep
+    // kernel runs one block per CU: as many slices as give at most one block per CU (a second, partial round would double
+    // the product's time)
+    int split = deep ? device_cu_count() / tiles : (2 * device_cu_count() + tiles - 1) / tiles;
+    if (split < 1) split = 1;
     const long max_by_rows = rows / (8 * GKB);
     if (split > max_by_rows) split = (int)max_by_rows;
     if (split > 32) split = 32;
@@ -338,9 +587,8 @@ int gemm_bf16_tn_fused(const float* a1, long lda1, long a1_so, int M1, int shift
     g.grid_m = (M + GT - 1) / GT;
     g.xcd_remap = (split >= 8 && !env_knobs().gemm_bf16_noremap) ? 1 : 0;
     const dim3 grid = g.xcd_remap ? dim3((unsigned)(8 * ((split + 7) / 8) * g.grid_n * g.grid_m)) : dim3(g.grid_n, g.grid_m, split);
-    const bool avec = (lda1 & 3) == 0 && (a1_so & 3) == 0 && (((uintptr_t)a1) & 15) == 0 && (M1 & 3) == 0 &&
-                      (!a2 || ((lda2 & 3) == 0 && (a2_so & 3) == 0 && (((uintptr_t)a2) & 15) == 0 && (M2 & 3) == 0));
-    if (avec) hipLaunchKernelGGL(gemm_bf16_tn_kernel<true>, grid, dim3(256), 0, stream, g);
+    if (deep) hipLaunchKernelGGL(gemm_bf16_tn3_kernel, grid, dim3(G3T), 0, stream, g);
+    else if (avec) hipLaunchKernelGGL(gemm_bf16_tn_kernel<true>, grid, dim3(256), 0, stream, g);
     else hipLaunchKernelGGL(gemm_bf16_tn_kernel<false>, grid, dim3(256), 0, stream, g);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("gemm_bf16_tn launch: %s", hipGetErrorString(e)); return FOV_ERR_LAUNCH; }

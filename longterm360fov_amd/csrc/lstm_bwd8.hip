@@ -295,24 +295,39 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd8_kernel(Bwd8Params p) {
 // ---------------------------------------------------------------------------------------------------------------
 // Diagnostic build only (-DFOV_STAMPS, tools/stamp_bf16_layer.py --bwd): s_memtime stamps of one wave per step.
 #ifdef FOV_STAMPS
+// stamps go to LDS and leave in one piece at the kernel's end: a global store per stamp would sit in the wave's vmcnt queue and
+// every s_waitcnt vmcnt(0) of the step would wait for its acknowledgement (measured: 2 000 cycles per stamp that way)
 __device__ unsigned long long g_b8_stamps[32][12];
+// branch-free (a stamp inside `if (stamp_on)` splits the basic block and the optimiser sinks the arithmetic in front of it to its
+// uses behind it): every thread reads the clock, all but the stamping thread write a junk slot
 #define B8_STAMP(slot)                                                                         \
     do {                                                                                       \
-        __builtin_amdgcn_sched_barrier(0);                                                     \
-        if (stamp_on && (T - 1 - t) < 32) {                                                    \
-            unsigned long long t_;                                                             \
-            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");        \
-            g_b8_stamps[T - 1 - t][slot] = t_;                                                 \
-        }                                                                                      \
-        __builtin_amdgcn_sched_barrier(0);                                                     \
+        unsigned long long t_;                                                                 \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");            \
+        sStamps[(stamp_on && (T - 1 - t) < 31) ? (T - 1 - t) * 12 + slot : 31 * 12 + 11] = t_; \
+    } while (0)
+// the same, and the listed registers are computed BEFORE the clock is read
+#define B8_STAMP_AFTER(slot, ...)                                                              \
+    do {                                                                                       \
+        unsigned long long t_;                                                                 \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_), __VA_ARGS__::"memory"); \
+        sStamps[(stamp_on && (T - 1 - t) < 31) ? (T - 1 - t) * 12 + slot : 31 * 12 + 11] = t_; \
     } while (0)
 #else
 #define B8_STAMP(slot) do { } while (0)
+#define B8_STAMP_AFTER(slot, ...) do { } while (0)
 #endif
 
 // DX: the data gradient dx_t = dz_t K^T of a 256-wide input (the stacked layer: dx is the dhs of the layer below) is formed
 // here as well, from the SAME gathered dz tile and the own 32 rows of K - 16 more MFMAs per wave and step and 64 more
 // registers of fragments instead of a separate (B*T x 1024 x 256) product that re-reads dz from HBM.
+// Lane -> cell mapping of the POINTWISE phase (round 4): thread tid owns row tid >> 4 of the tile and the two adjacent units
+// 2 * (tid & 15), + 1 of the workgroup's 32: every tape access is an 8-byte access, a wave's instruction covers four whole
+// 128-byte lines (it was one unit of two rows: 4-byte accesses, eight 32-byte pieces per instruction, twice the instructions -
+// and the step was bound by the CU's address unit, 2 300 cycles to issue the 24 tape instructions of a step from four waves).
+// The MFMA phase keeps the matrix layout (lane = (n, g4)); the two meet in LDS (dz tile in, partial dh tiles out) as before.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 template <int ACT, bool DX>
 __global__ __launch_bounds__(256, 1) void lstm_bwd8n_bf16_kernel(Bwd8Params p) {
     __shared__ __attribute__((aligned(16))) unsigned short sDZ[QBT * QLDZ];   // the whole dz tile, bf16
@@ -323,18 +338,18 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd8n_bf16_kernel(Bwd8Params p) {
     int group, slice;
     q_group_slice(p.num_groups, group, slice);
     constexpr int H4 = 4 * QH;
-    const int hi = n >> 3;
-    const int ul = 8 * wave + (n & 7);          // unit inside the workgroup (0..31)
-    const int unit = 32 * slice + ul;
-    const int my_row0 = 4 * g4 + 2 * hi;
+    const int prow = tid >> 4;                   // row of the tile (0..15)
+    const int pu = 2 * (tid & 15);               // first unit of the pair inside the workgroup (0..30)
+    const int unit0 = 32 * slice + pu;
     const int T = p.T;
     __shared__ unsigned sXch[4];
     const unsigned arrival = xch_arrive(p.status, sXch, group, slice);
     const bool poisoned = xch_poisoned(p.status);
     if (tid == 0) sFlag[0] = poisoned ? 1 : 0;
 #ifdef FOV_STAMPS
+    __shared__ unsigned long long sStamps[32 * 12];
     const bool stamp_on = (blockIdx.x == 5 && tid == 0);
-    if (stamp_on) g_b8_stamps[31][0] = __builtin_amdgcn_s_memtime();
+    if (stamp_on) sStamps[31 * 12 + 0] = __builtin_amdgcn_s_memtime();
 #endif
 
     // R^T fragments of this wave: k-block kb of gate `wave` (columns 256*wave + 32*kb + 8*g4 + j), N-tile nt (own unit 16*nt + n)
@@ -363,36 +378,29 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd8n_bf16_kernel(Bwd8Params p) {
 
     for (int tile = group; tile < p.num_tiles && !aborted; tile += p.num_groups) {
         const int b0 = tile * QBT;
-        float dc[2], dh[2];
-        bool live[2];
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const int row = b0 + my_row0 + r;
-            live[r] = row < p.B;
-            dc[r] = (live[r] && p.dcT) ? p.dcT[(size_t)row * QH + unit] : 0.f;
-            dh[r] = (live[r] && p.dhT) ? p.dhT[(size_t)row * QH + unit] : 0.f;
-        }
-        // Tape of this lane's two cells, ONE step ahead: tp[0..3] = i,f,g,o and tp[4] = c of the step, tp[5] = c of the
-        // step before it (c0 / zero in front of step 0), tp[6] = dhs of the step.  The loads are UNCONDITIONAL (rows and
-        // steps clamped into the tensor, dead rows masked where dz is formed): a load inside a branch gets an
-        // s_waitcnt vmcnt(0) at the merge and the step would wait for HBM right there (measured: 3 800 cycles).
-        float cur[7][2], pre[7][2];
-        auto load_step = [&](int t, float (&dst)[7][2]) {
+        const int row = b0 + prow;
+        const bool live = row < p.B;
+        const size_t rowc = (size_t)(live ? row : p.B - 1);
+        f32x2 dc = (live && p.dcT) ? *(const f32x2*)(p.dcT + rowc * QH + unit0) : (f32x2){0.f, 0.f};
+        f32x2 dh = (live && p.dhT) ? *(const f32x2*)(p.dhT + rowc * QH + unit0) : (f32x2){0.f, 0.f};
+        // Tape of this lane's two cells, ONE step ahead: [0..3] = i,f,g,o and [4] = c of the step, [5] = c of the step before it
+        // (c0 / zero in front of step 0), [6] = dhs of the step.  The loads are UNCONDITIONAL (rows and steps clamped into the
+        // tensor, dead rows masked where dz is formed): a load inside a branch gets an s_waitcnt vmcnt(0) at the merge and the
+        // step would wait for HBM right there (measured: 3 800 cycles).
+        f32x2 cur[7], pre[7];
+        auto load_step = [&](int t, f32x2 (&dst)[7]) {
             const int tc = t > 0 ? t : 0;
+            const float* rp = p.reserve + ((rowc * T + tc) * 5) * QH + unit0;
 #pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                const int row = b0 + my_row0 + r;
-                const size_t rowc = (size_t)(row < p.B ? row : p.B - 1);
-                const float* rp = p.reserve + ((rowc * T + tc) * 5) * QH + unit;
-#pragma unroll
-                for (int q = 0; q < 5; ++q) dst[q][r] = rp[q * QH];
-                const float* cp = tc > 0 ? rp - QH : (p.c0 ? p.c0 + rowc * QH + unit : rp);   // no c0: any valid address, masked at use
-                dst[5][r] = *cp;
-                dst[6][r] = p.dhs ? p.dhs[(rowc * T + tc) * QH + unit] : 0.f;
-            }
+            for (int q = 0; q < 5; ++q) dst[q] = *(const f32x2*)(rp + q * QH);
+            const float* cp = tc > 0 ? rp - QH : (p.c0 ? p.c0 + rowc * QH + unit0 : rp);   // no c0: any valid address, masked at use
+            dst[5] = *(const f32x2*)cp;
+            dst[6] = p.dhs ? *(const f32x2*)(p.dhs + (rowc * T + tc) * QH + unit0) : (f32x2){0.f, 0.f};
         };
         load_step(T - 1, cur);
-        float dbacc[4] = {0.f, 0.f, 0.f, 0.f};
+        f32x2 dbacc[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) dbacc[g] = (f32x2){0.f, 0.f};
         __syncthreads();   // the previous tile's last step is done with the LDS tiles
 
         for (int t = T - 1; t >= 0; --t) {
@@ -402,43 +410,48 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd8n_bf16_kernel(Bwd8Params p) {
 
             B8_STAMP(1);
             // ---- pointwise: dz of this lane's two cells ----
-            float dzv[2][4];
+            f32x2 dzv[4];
 #pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                const float ig = cur[0][r], fg = cur[1][r], gg = cur[2][r], og = cur[3][r], cc = cur[4][r];
-                const float cprev = (t > 0 || p.c0) ? cur[5][r] : 0.f;   // step 0 without a given state: c_{-1} = 0
-                const float dht = dh[r] + cur[6][r];
+            for (int u = 0; u < 2; ++u) {
+                const float ig = cur[0][u], fg = cur[1][u], gg = cur[2][u], og = cur[3][u], cc = cur[4][u];
+                const float cprev = (t > 0 || p.c0) ? cur[5][u] : 0.f;   // step 0 without a given state: c_{-1} = 0
+                const float dht = dh[u] + cur[6][u];
                 const float tc = tanh_f(cc);
-                const float dcv = dc[r] + dht * og * (1.f - tc * tc);
-                dzv[r][0] = live[r] ? dcv * gg * b8_act_grad<ACT>(ig) : 0.f;
-                dzv[r][1] = live[r] ? dcv * cprev * b8_act_grad<ACT>(fg) : 0.f;
-                dzv[r][2] = live[r] ? dcv * ig * (1.f - gg * gg) : 0.f;
-                dzv[r][3] = live[r] ? dht * tc * b8_act_grad<ACT>(og) : 0.f;
-                dc[r] = dcv * fg;
+                const float dcv = dc[u] + dht * og * (1.f - tc * tc);
+                dzv[0][u] = live ? dcv * gg * b8_act_grad<ACT>(ig) : 0.f;
+                dzv[1][u] = live ? dcv * cprev * b8_act_grad<ACT>(fg) : 0.f;
+                dzv[2][u] = live ? dcv * ig * (1.f - gg * gg) : 0.f;
+                dzv[3][u] = live ? dht * tc * b8_act_grad<ACT>(og) : 0.f;
+                dc[u] = dcv * fg;
             }
-            B8_STAMP(2);
             // publish first (the partners wait for it), then the tape traffic of this step
             unsigned dzp[4];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) dzp[g] = pack_bf16(dzv[0][g], dzv[1][g]);
-            q_dz_publish(rs, par, my_row0, unit, dzp, epoch, sDZ, ticket.same_xcd);
+            for (int g = 0; g < 4; ++g) dzp[g] = pack_bf16(dzv[g][0], dzv[g][1]);
+            B8_STAMP_AFTER(2, "+v"(dzp[0]), "+v"(dzp[1]), "+v"(dzp[2]), "+v"(dzp[3]), "+v"(dc[0]), "+v"(dc[1]));
+#ifndef FOV_DBG_B8_NOPUB
+            q_dz_publish2(rs, par, prow, unit0, dzp, epoch, sDZ, ticket.same_xcd);
+#endif
             // Everything that does not depend on the partners goes between the publish and the gather: an sc1 store
             // takes about a microsecond to become visible, a sweep issued earlier comes back stale and costs a second
             // round trip.  The tape of step t-1 is requested here, a whole step before its use.
-            load_step(t - 1, pre);
-#pragma unroll
-            for (int r = 0; r < 2; ++r) {
-#pragma unroll
-                for (int g = 0; g < 4; ++g) dbacc[g] += dzv[r][g];
-                if (live[r]) {
-                    float* zp = p.dz + ((size_t)(b0 + my_row0 + r) * T + t) * H4 + unit;
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) zp[g * QH] = dzv[r][g];
-                }
-            }
             B8_STAMP(3);
+#ifndef FOV_DBG_B8_NOTAPE     // timing experiments (wrong results): tools/b8_variants.sh
+            load_step(t - 1, pre);
+#endif
+#pragma unroll
+            for (int g = 0; g < 4; ++g) dbacc[g] += dzv[g];
+#ifndef FOV_DBG_B8_NODZ
+            if (live) {
+                float* zp = p.dz + ((size_t)row * T + t) * H4 + unit0;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) *(f32x2*)(zp + g * QH) = dzv[g];
+            }
+#endif
             B8_STAMP(4);
-            if (!q_dz_gather(rs, par, slice, tid, epoch, sDZ, p.status)) sFlag[0] = 1;
+#ifndef FOV_DBG_B8_NOGATHER
+            if (!q_dz_gather2(rs, par, slice, tid, epoch, sDZ, p.status)) sFlag[0] = 1;
+#endif
             B8_STAMP(5);
             __syncthreads();   // barrier A: the whole dz tile is in LDS
             B8_STAMP(6);
@@ -473,44 +486,49 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd8n_bf16_kernel(Bwd8Params p) {
             B8_STAMP(7);
             __syncthreads();   // barrier B: the four partial tiles are in LDS; every wave is done reading the dz tile
             B8_STAMP(8);
+            {
+                const float* q = sRed + prow * 33 + pu;
 #pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                const float* q = sRed + (my_row0 + r) * 33 + ul;
-                dh[r] = (q[0] + q[QBT * 33]) + (q[2 * QBT * 33] + q[3 * QBT * 33]);
+                for (int u = 0; u < 2; ++u) dh[u] = (q[u] + q[QBT * 33 + u]) + (q[2 * QBT * 33 + u] + q[3 * QBT * 33 + u]);
                 if constexpr (DX) {
                     const float* qx = q + 4 * QBT * 33;
-                    if (live[r])
-                        p.dx[((size_t)(b0 + my_row0 + r) * T + t) * QH + unit] = (qx[0] + qx[QBT * 33]) + (qx[2 * QBT * 33] + qx[3 * QBT * 33]);
+                    f32x2 dxv;
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) dxv[u] = (qx[u] + qx[QBT * 33 + u]) + (qx[2 * QBT * 33 + u] + qx[3 * QBT * 33 + u]);
+                    if (live) *(f32x2*)(p.dx + ((size_t)row * T + t) * QH + unit0) = dxv;
                 }
             }
 #pragma unroll
-            for (int q = 0; q < 7; ++q)
-#pragma unroll
-                for (int r = 0; r < 2; ++r) cur[q][r] = pre[q][r];   // requested most of a step ago: long landed
+            for (int q = 0; q < 7; ++q) cur[q] = pre[q];   // requested most of a step ago: long landed
             B8_STAMP(9);
         }
         if (!aborted && p.db_part) {
+            // the 16 rows of a unit pair sit on lanes 16 apart (4 rows per wave) and on the four waves: fold in a fixed order
+            // through LDS (sRed is free: the loop ended on barrier B and its read-out)
+            __syncthreads();
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                float v = dbacc[g];
-                v += __shfl_xor(v, 8);
-                const float v1 = __shfl(v, (lane + 16) & 63), v2 = __shfl(v, (lane + 32) & 63), v3 = __shfl(v, (lane + 48) & 63);
-                if (g4 == 0 && hi == 0) p.db_part[(size_t)tile * H4 + g * QH + unit] = (v + v1) + (v2 + v3);
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) sRed[(prow * 4 + g) * 33 + pu + u] = dbacc[g][u];
+            __syncthreads();
+            if (tid < 128) {   // thread = (gate tid >> 5, unit tid & 31)
+                const int g = tid >> 5, u = tid & 31;
+                float v = 0.f;
+#pragma unroll
+                for (int r = 0; r < QBT; ++r) v += sRed[(r * 4 + g) * 33 + u];
+                p.db_part[(size_t)tile * H4 + g * QH + 32 * slice + u] = v;
             }
         }
-        if (!aborted) {
-#pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                const int row = b0 + my_row0 + r;
-                if (row < p.B) {
-                    if (p.dh0) p.dh0[(size_t)row * QH + unit] = dh[r];
-                    if (p.dc0) p.dc0[(size_t)row * QH + unit] = dc[r];
-                }
-            }
+        if (!aborted && live) {
+            if (p.dh0) *(f32x2*)(p.dh0 + (size_t)row * QH + unit0) = dh;
+            if (p.dc0) *(f32x2*)(p.dc0 + (size_t)row * QH + unit0) = dc;
         }
     }
 #ifdef FOV_STAMPS
-    if (stamp_on) g_b8_stamps[31][1] = __builtin_amdgcn_s_memtime();
+    if (stamp_on) {
+        sStamps[31 * 12 + 1] = __builtin_amdgcn_s_memtime();
+        for (int i = 0; i < 32 * 12; ++i) (&g_b8_stamps[0][0])[i] = sStamps[i];
+    }
 #endif
     xch_settle(p.status, ticket, (unsigned)p.epoch_span);
 }
@@ -543,6 +561,11 @@ int launch_bwd8(const float* R, const float* reserve, const float* c0, const flo
     p.num_groups = p.num_tiles < max_groups ? p.num_tiles : max_groups;
     if ((size_t)p.num_groups * 2 * (bf16 ? (size_t)Q_DZ_BYTES : B8_PAR * 8) > kXchBytes - kHelloBytes) { set_error("8-group BPTT kernel: granule area too small"); return FOV_ERR_WORKSPACE; }
     if (bf16 && (((uintptr_t)R) & 15)) { set_error("8-group BPTT kernel: R must be 16-byte aligned"); return FOV_ERR_INVALID; }
+    if (bf16 && ((((uintptr_t)reserve) | ((uintptr_t)c0) | ((uintptr_t)dhs) | ((uintptr_t)dhT) | ((uintptr_t)dcT) | ((uintptr_t)dz) |
+                  ((uintptr_t)dh0) | ((uintptr_t)dc0) | ((uintptr_t)dx)) & 7)) {   // 8-byte tape accesses (two adjacent units per lane)
+        set_error("8-group bf16 BPTT kernel: tapes and state gradients must be 8-byte aligned");
+        return FOV_ERR_INVALID;
+    }
     p.status = (unsigned*)xch_ws;
     p.xch = (unsigned long long*)((char*)xch_ws + kStatusBytes);
     p.epoch_span = T * ((p.num_tiles + p.num_groups - 1) / p.num_groups) + 1;

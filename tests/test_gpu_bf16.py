@@ -327,6 +327,9 @@ def test_weight_gradient_half_on_its_own_equals_the_single_call(dtype, B, T, F, 
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
     for name, a, r in (("dK", dK2, dK), ("dR", dR2, dR), ("db", db2, db)):
+        if name == "db" and not adjacent:   # separate tensors: the single call sums the kernel's per-tile bias partials, the
+            assert torch.allclose(a, r, rtol=1e-5, atol=1e-6)    # half on its own sums dz's columns - another order
+            continue
         assert torch.equal(a, r), (name, float((a - r).abs().max()))
         assert float(r.abs().max()) > 0 or (name == "dR" and T == 1 and not state)     # h_{-1} = 0: no recurrent gradient
     # accumulate: twice the gradient

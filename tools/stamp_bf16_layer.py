@@ -53,8 +53,8 @@ def main():
 
 def main_bwd():
     """python tools/stamp_bf16_layer.py --bwd : the N-split bf16 BPTT kernel (lstm_bwd8n_bf16_kernel)."""
-    SEGB = ["tape loads of step t-2 (issue)", "gates backward", "publish dz + own LDS + dz stores", "rotate", "gather (issue, wait, LDS)",
-            "barrier A", "MFMAs + partials -> LDS", "barrier B", "sum of the four partials"]
+    SEGB = ["top of step", "gates backward (incl. waits for the tape and dh)", "publish dz + own LDS", "tape loads + dz stores (issue)",
+            "gather (issue, wait, LDS)", "barrier A", "MFMAs + partials -> LDS", "barrier B", "sum of the four partials + rotate"]
     B, T, F, H = 512, 10, 256, 256
     rng = np.random.default_rng(0)
     K, R, b = O.init_lstm(rng, F, H, np.float32)
