@@ -177,6 +177,27 @@ int fov_dense_bwd_bf16(const float* x, const float* W, const float* dpre, float*
                        int N, int In, int Out, int accumulate,
                        void* workspace, size_t workspace_bytes, fov_stream_t stream);
 
+/* BPTT of fov_lstm_stack2_fwd's two layers (mycode/lstm.py:218-240 under the train_op of :556-567) in ONE persistent launch: the
+ * upper layer's recurrence, the data-gradient product dx = dz2 . K2^T and the lower layer's recurrence run as three roles on
+ * disjoint CUs, the lower layer about a step behind the upper one (as two fov_lstm_seq_bwd calls: recurrence, split product,
+ * reduce, recurrence, one after the other).  Arguments are those of the two calls: layer 1 = lower (input x (B,T,F), tape hs1,
+ * reserve1), layer 2 = upper (input hs1, tape hs2, reserve2); dhs2 (B,T,H) / dhT2 / dcT2 / dhT1 / dcT1 optional upstream
+ * gradients; dz1, dz2 (B,T,4H) out; dK / dR / db of either layer optional (NULL: data path only); dh0 / dc0 optional.  The
+ * gradient with respect to x is NOT produced (lstm.py's first layer needs none).  Results equal the two-call path's up to the
+ * summation order of dx (sixteen partial sums added in slice order instead of a split GEMM's reduce).
+ * Shapes: fov_lstm_stack2_bwd_supported (H = 512, at most 32 sequences on 256 CUs).  workspace: stateful like every exchange
+ * workspace (zero-filled once), fov_lstm_stack2_bwd_workspace_bytes. */
+int fov_lstm_stack2_bwd_supported(int B, int T, int F, int H);
+size_t fov_lstm_stack2_bwd_workspace_bytes(int B, int T, int F, int H);
+int fov_lstm_stack2_bwd(const float* x, const float* R1, const float* K2, const float* R2,
+                        const float* h0_1, const float* c0_1, const float* h0_2, const float* c0_2,
+                        const float* hs1, const float* reserve1, const float* hs2, const float* reserve2,
+                        const float* dhs2, const float* dhT2, const float* dcT2, const float* dhT1, const float* dcT1,
+                        float* dz1, float* dz2, float* dK1, float* dR1, float* db1, float* dK2, float* dR2, float* db2,
+                        float* dh0_1, float* dc0_1, float* dh0_2, float* dc0_2,
+                        int B, int T, int F, int H, int act, int accumulate,
+                        void* workspace, size_t workspace_bytes, fov_stream_t stream);
+
 /* The weight-gradient half of fov_lstm_seq_bwd[_bf16] on its own: dK (F,4H) = x^T dz, dR (H,4H) = h_{t-1}^T dz (h_{-1} = h0, or
  * zero when h0 is NULL), db (4H) = column sums of dz, from the dz tape (B,T,4H) a call with dK = dR = db = NULL left behind.  Same
  * products in the same order (one fused product when dK, dR, db lie adjacent), so the results equal the single call's bit for bit.

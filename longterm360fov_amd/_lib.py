@@ -101,6 +101,9 @@ SIGNATURES = {
     "fov_conv2d_fwd": (_I, [_P, ctypes.c_int64, ctypes.c_int64, _P, _P, _P, _P] + [_I] * 8 + [_P]),
     "fov_convlstm_cell_fwd": (_I, [_P, ctypes.c_int64, ctypes.c_int64, _I, _P, ctypes.c_int64, ctypes.c_int64] + [_P] * 5 + [ctypes.c_int64, _P] + [_I] * 7 + [_P]),
     "fov_conv2d_fwd2": (_I, [_P, ctypes.c_int64, ctypes.c_int64, _I, _P, ctypes.c_int64, ctypes.c_int64, _I, _P, _P, _P, _P] + [_I] * 7 + [_P]),
+    "fov_lstm_stack2_bwd_supported": (_I, [_I] * 4),
+    "fov_lstm_stack2_bwd_workspace_bytes": (_SZ, [_I] * 4),
+    "fov_lstm_stack2_bwd": (_I, [_P] * 29 + [_I] * 6 + [_P, _SZ, _P]),
     "fov_lstm_seq_wgrad": (_I, [_P] * 7 + [_I] * 6 + [_P, _SZ, _P]),
     "fov_stream_create": (_I, [_I, ctypes.POINTER(ctypes.c_void_p)]),
     "fov_stream_destroy": (_I, [_P]),

@@ -749,6 +749,37 @@ int fov_lstm_seq_bwd_bf16(const float* x, const float* K, const float* R, const 
                         accumulate, (float*)workspace, workspace_bytes / sizeof(float), (hipStream_t)stream, 1);
 }
 
+int fov_lstm_stack2_bwd_supported(int B, int T, int F, int H) { return (F > 0 && bwd16_pair_shape(B, T, H)) ? 1 : 0; }
+
+size_t fov_lstm_stack2_bwd_workspace_bytes(int B, int T, int F, int H) {
+    if (B <= 0 || T < 0 || F <= 0 || H <= 0) return 256;
+    return sizeof(float) * lstm_stack2_bwd_workspace_floats(B, T, F, H);
+}
+
+int fov_lstm_stack2_bwd(const float* x, const float* R1, const float* K2, const float* R2, const float* h0_1, const float* c0_1,
+                        const float* h0_2, const float* c0_2, const float* hs1, const float* reserve1, const float* hs2,
+                        const float* reserve2, const float* dhs2, const float* dhT2, const float* dcT2, const float* dhT1,
+                        const float* dcT1, float* dz1, float* dz2, float* dK1, float* dR1, float* db1, float* dK2, float* dR2,
+                        float* db2, float* dh0_1, float* dc0_1, float* dh0_2, float* dc0_2, int B, int T, int F, int H, int act,
+                        int accumulate, void* workspace, size_t workspace_bytes, fov_stream_t stream) {
+    if (B < 0 || T < 0 || F <= 0 || H <= 0 || !R1 || !K2 || !R2 ||
+        (B > 0 && T > 0 && (!x || !hs1 || !reserve1 || !hs2 || !reserve2 || !dz1 || !dz2)) ||
+        (act != FOV_ACT_SIGMOID && act != FOV_ACT_HARD_SIGMOID)) {
+        set_error("fov_lstm_stack2_bwd: invalid argument");
+        return FOV_ERR_INVALID;
+    }
+    if (B == 0 || T == 0) return FOV_OK;
+    if (!bwd16_pair_shape(B, T, H)) {
+        set_error("fov_lstm_stack2_bwd: H = 512, at most 32 sequences, three role-groups of sixteen workgroups per tile resident only");
+        return FOV_ERR_UNSUPPORTED;
+    }
+    int rc = check_ws(workspace, workspace_bytes, fov_lstm_stack2_bwd_workspace_bytes(B, T, F, H));
+    if (rc) return rc;
+    return lstm_stack2_bwd(x, R1, K2, R2, h0_1, c0_1, h0_2, c0_2, hs1, reserve1, hs2, reserve2, dhs2, dhT2, dcT2, dhT1, dcT1, dz1, dz2, dK1,
+                           dR1, db1, dK2, dR2, db2, dh0_1, dc0_1, dh0_2, dc0_2, B, T, F, H, act, accumulate, (float*)workspace,
+                           workspace_bytes / sizeof(float), (hipStream_t)stream);
+}
+
 int fov_stream_create(int priority, fov_stream_t* stream) {
     if (!stream) { set_error("fov_stream_create: stream is NULL"); return FOV_ERR_INVALID; }
     int least = 0, greatest = 0;     // numerically: least = lowest priority (largest value), greatest = highest (smallest value)

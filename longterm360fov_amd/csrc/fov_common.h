@@ -209,6 +209,17 @@ bool bwd_cluster_shape_ok(int H);
 bool wide16_pair_shape(int B, int T, int F, int H);
 int launch_wide16_pair(const LstmParams& a, const LstmParams& b, hipStream_t stream);
 // lstm_bwd16.hip: BPTT recurrence with 16 / 32 units per workgroup (fp32): width 512, and 128 / 256 at small batches
+bool bwd16_pair_shape(int B, int T, int H);
+int launch_bwd16_pair(const float* R2, const float* K2, const float* reserve2, const float* c0_2, const float* dhs2, const float* dhT2,
+                      const float* dcT2, float* dz2, float* dh0_2, float* dc0_2, float* db_part2, const float* R1, const float* reserve1,
+                      const float* c0_1, const float* dhT1, const float* dcT1, float* dz1, float* dh0_1, float* dc0_1, float* db_part1,
+                      int B, int T, int act, void* xch_ws, hipStream_t stream);
+size_t lstm_stack2_bwd_workspace_floats(int B, int T, int F, int H);
+int lstm_stack2_bwd(const float* x, const float* R1, const float* K2, const float* R2, const float* h0_1, const float* c0_1,
+                    const float* h0_2, const float* c0_2, const float* hs1, const float* res1, const float* hs2, const float* res2,
+                    const float* dhs2, const float* dhT2, const float* dcT2, const float* dhT1, const float* dcT1, float* dz1, float* dz2,
+                    float* dK1, float* dR1, float* db1, float* dK2, float* dR2, float* db2, float* dh0_1, float* dc0_1, float* dh0_2,
+                    float* dc0_2, int B, int T, int F, int H, int act, int accumulate, float* ws, size_t ws_floats, hipStream_t stream);
 bool bwd16_takes(int B, int H);
 int launch_bwd16(const float* R, const float* reserve, const float* c0, const float* dhs, const float* dhT, const float* dcT,
                  float* dz, float* dh0, float* dc0, float* db_part, int B, int T, int H, int act, void* xch_ws, hipStream_t stream);

@@ -1619,6 +1619,52 @@ int lstm_seq_bwd(const float* x, const float* K, const float* R, const float* h0
     return FOV_OK;
 }
 
+// BPTT of two stacked width-512 layers in ONE launch (lstm_bwd16.hip: both recurrences and dx = dz2 . K2^T between them as three
+// roles of one persistent kernel), then the two layers' weight-gradient products.  Same outputs as two lstm_seq_bwd calls
+// (upper layer first, its dx as the lower layer's dhs) except that the intermediate dx is not materialised.
+size_t lstm_stack2_bwd_workspace_floats(int B, int T, int F, int H) {
+    const size_t tiles = (size_t)(B + 15) / 16;
+    return lstm_bwd_workspace_floats(B, T, F > H ? F : H, H) + 2 * tiles * 4 * H + (size_t)4 * B * H + 64;
+}
+
+int lstm_stack2_bwd(const float* x, const float* R1, const float* K2, const float* R2, const float* h0_1, const float* c0_1,
+                    const float* h0_2, const float* c0_2, const float* hs1, const float* res1, const float* hs2, const float* res2,
+                    const float* dhs2, const float* dhT2, const float* dcT2, const float* dhT1, const float* dcT1, float* dz1, float* dz2,
+                    float* dK1, float* dR1, float* db1, float* dK2, float* dR2, float* db2, float* dh0_1, float* dc0_1, float* dh0_2,
+                    float* dc0_2, int B, int T, int F, int H, int act, int accumulate, float* ws, size_t ws_floats, hipStream_t stream) {
+    if (!bwd16_pair_shape(B, T, H)) { set_error("lstm_stack2_bwd: unsupported shape (H = 512, <= 32 sequences on 256 CUs)"); return FOV_ERR_UNSUPPORTED; }
+    if (ws_floats < lstm_stack2_bwd_workspace_floats(B, T, F, H)) { set_error("lstm_stack2_bwd: workspace too small"); return FOV_ERR_WORKSPACE; }
+    const size_t head = (kStatusBytes + kXchBytes) / sizeof(float);
+    const size_t tiles = (size_t)(B + 15) / 16, bh = (size_t)B * H;
+    float* dbp2 = ws + head;
+    float* dbp1 = dbp2 + tiles * 4 * H;
+    float* spare = dbp1 + tiles * 4 * H;          // state gradients the caller does not ask for
+    float* scratch = spare + 4 * bh;
+    const size_t scratch_floats = ws_floats - head - 2 * tiles * 4 * H - 4 * bh;
+    bool kr1, r1, kr2, r2;
+    lstm_seq_wgrad_fusion(x, hs1, dz1, dK1, dR1, db1, T, F, H, &kr1, &r1);
+    lstm_seq_wgrad_fusion(hs1, hs2, dz2, dK2, dR2, db2, T, H, H, &kr2, &r2);
+    float* db_part1 = (db1 && !kr1 && !r1) ? dbp1 : nullptr;
+    float* db_part2 = (db2 && !kr2 && !r2) ? dbp2 : nullptr;
+    int rc = launch_bwd16_pair(R2, K2, res2, c0_2, dhs2, dhT2, dcT2, dz2, dh0_2 ? dh0_2 : spare, dc0_2 ? dc0_2 : spare + bh, db_part2, R1,
+                               res1, c0_1, dhT1, dcT1, dz1, dh0_1 ? dh0_1 : spare + 2 * bh, dc0_1 ? dc0_1 : spare + 3 * bh, db_part1, B,
+                               T, act, ws, stream);
+    if (rc) return rc;
+    for (int l = 2; l >= 1; --l) {
+        float* part = l == 2 ? db_part2 : db_part1;
+        float* db = l == 2 ? db2 : db1;
+        if (part) {
+            if (tiles * 4 * H + (size_t)256 * 4 * H > scratch_floats) { set_error("lstm_stack2_bwd: scratch too small for db"); return FOV_ERR_WORKSPACE; }
+            rc = colsum(part, db, (long)tiles, 4 * H, accumulate, scratch, scratch_floats, stream);
+            if (rc) return rc;
+        }
+        rc = l == 2 ? lstm_seq_weight_products(hs1, hs2, h0_2, dz2, dK2, dR2, db2, B, T, H, H, accumulate, 0, kr2, r2, true, scratch, scratch_floats, stream)
+                    : lstm_seq_weight_products(x, hs1, h0_1, dz1, dK1, dR1, db1, B, T, F, H, accumulate, 0, kr1, r1, true, scratch, scratch_floats, stream);
+        if (rc) return rc;
+    }
+    return FOV_OK;
+}
+
 // Dense backward given dpre (N,Out): dW (In,Out) = x^T dpre, db = colsum(dpre), dx (N,In) = dpre W^T
 int dense_bwd(const float* x, const float* W, const float* dpre, float* dx, float* dW, float* db, int N, int In, int Out,
               int accumulate, float* scratch, size_t scratch_floats, hipStream_t stream, int bf16) {

@@ -402,6 +402,38 @@ def lstm_seq_bwd(x, K, R, hs, reserve, h0=None, c0=None, dhs=None, dhT=None, dcT
     return {"dz": dz, "dx": dx, "dK": dK, "dR": dR, "db": db, "dh0": dh0, "dc0": dc0}
 
 
+def lstm_stack2_bwd_supported(B, T, F, H):
+    return bool(_lib.lib().fov_lstm_stack2_bwd_supported(B, T, F, H))
+
+
+def lstm_stack2_bwd(x, layer1, layer2, tape1, tape2, dhs2=None, dhT2=None, dcT2=None, dhT1=None, dcT1=None, grads1=None, grads2=None,
+                    need_state_grads=False, act="sigmoid", accumulate=False, scratch=None):
+    """BPTT of two stacked width-512 layers in one launch (fov_lstm_stack2_bwd).  layer1 = (K1, R1), layer2 = (K2, R2);
+    tape = (hs, reserve, h0, c0) of the training forward; grads = (dK, dR, db) tensors or None (data path only).
+    -> dict(dz1, dz2, dh0_1, dc0_1, dh0_2, dc0_2)."""
+    x = _dev(x, "x")
+    B, T, F = x.shape
+    R1, K2, R2 = _dev(layer1[1], "R1"), _dev(layer2[0], "K2"), _dev(layer2[1], "R2")
+    H = R1.shape[0]
+    hs1, res1, h01, c01 = tape1
+    hs2, res2, h02, c02 = tape2
+    e = lambda *s: torch.empty(s, dtype=torch.float32, device=x.device)
+    dz1, dz2 = e(B, T, 4 * H), e(B, T, 4 * H)
+    st = [e(B, H) if need_state_grads else None for _ in range(4)]
+    g1 = grads1 if grads1 is not None else (None, None, None)
+    g2 = grads2 if grads2 is not None else (None, None, None)
+    L = _lib.lib()
+    buf = (scratch or _default_bwd_scratch).get(L.fov_lstm_stack2_bwd_workspace_bytes(B, T, F, H), x.device)
+    check(L.fov_lstm_stack2_bwd(_ptr(x), _ptr(R1), _ptr(K2), _ptr(R2), _ptr(_dev(h01, "h0_1")), _ptr(_dev(c01, "c0_1")),
+                                _ptr(_dev(h02, "h0_2")), _ptr(_dev(c02, "c0_2")), _ptr(_dev(hs1, "hs1")), _ptr(_dev(res1, "reserve1")),
+                                _ptr(_dev(hs2, "hs2")), _ptr(_dev(res2, "reserve2")), _ptr(_dev(dhs2, "dhs2")), _ptr(_dev(dhT2, "dhT2")),
+                                _ptr(_dev(dcT2, "dcT2")), _ptr(_dev(dhT1, "dhT1")), _ptr(_dev(dcT1, "dcT1")), _ptr(dz1), _ptr(dz2),
+                                _ptr(g1[0]), _ptr(g1[1]), _ptr(g1[2]), _ptr(g2[0]), _ptr(g2[1]), _ptr(g2[2]), _ptr(st[0]), _ptr(st[1]),
+                                _ptr(st[2]), _ptr(st[3]), B, T, F, H, act_code(act), 1 if accumulate else 0, buf.data_ptr(), buf.numel(),
+                                _stream()))
+    return {"dz1": dz1, "dz2": dz2, "dh0_1": st[0], "dc0_1": st[1], "dh0_2": st[2], "dc0_2": st[3]}
+
+
 def lstm_seq_wgrad(x, hs, dz, dK=None, dR=None, db=None, h0=None, accumulate=False, scratch=None, dtype="f32"):
     """The weight-gradient half of lstm_seq_bwd from the dz tape a `need_weight_grads=False` call left: dK = x^T dz,
     dR = h_{t-1}^T dz, db = colsum(dz), bit-identical to the single call.  `scratch` must not be the workspace of a BPTT kernel

@@ -1643,6 +1643,7 @@ class TFLSTMTrainer:
         first = self.FIRST[head_kind]
         conv = [convert_tf_lstmcell(W, b, forget_bias) for W, b in cells]
         self.L = len(conv)
+        self._stack2_bwd_cache = {}
         # The stack runs at the next matrix-core width Hp (lstm.py's n_hidden = 400 -> 512: lstm_wide16.hip forward, lstm_bwd16.hip
         # BPTT) with zero-padded weights - exact, as in PaddedTrainer: a padded unit has z = 0, c = h = 0, dz = 0, so every
         # gradient in a padded slice is exactly 0 and TF's RMSProp leaves the zeros in place.  States, masks, weights and
@@ -1910,6 +1911,15 @@ class TFLSTMTrainer:
         dh_b, _, _ = ops.dense_bwd(hT, w["var_W1"], d3, dW=g["var_W1"], db=g["var_b1"], scratch=sc, accumulate=accumulate)
         return ops.act_bwd(dh_b, hT, base=dh_a, activation=None)      # dh_a + dh_b
 
+    def _stack2_bwd_ok(self, tape):
+        x0 = tape[0][0]
+        B, T, F = x0.shape
+        H = self.w["R0"].shape[0]
+        key = (B, T, F, H)
+        if key not in self._stack2_bwd_cache:
+            self._stack2_bwd_cache[key] = ops.lstm_stack2_bwd_supported(B, T, F, H)
+        return self._stack2_bwd_cache[key]
+
     def _stack_backward(self, tape, dhT, masks, accumulate, need_dx0=False):
         w, g = self.w, self.g
         dhs, dx0 = None, None
@@ -1918,6 +1928,14 @@ class TFLSTMTrainer:
         # hand-offs per layer) 0.596 -> 0.656 ms; arranged inside fov_lstm_seq_bwd (events, products deferred until the next
         # recurrence is queued) 0.520 -> 0.538 ms: the 45 us of products do overlap in the timeline, but every cross-stream
         # hand-off leaves a 7-16 us gap in a step that is a chain of short launches.)
+        # Two layers, no dropout masks between them, no gradient towards the input: both recurrences and the data-gradient
+        # product between them as ONE launch (fov_lstm_stack2_bwd: three roles on disjoint CUs; FOV_NO_STACK2=1: two launches)
+        if self.L == 2 and masks is None and not need_dx0 and self._stack2_bwd_ok(tape):
+            (x0, hs1, res1, h01, c01), (_, hs2, res2, h02, c02) = tape
+            ops.lstm_stack2_bwd(x0, (w["K0"], w["R0"]), (w["K1"], w["R1"]), (hs1, res1, h01, c01), (hs2, res2, h02, c02), dhT2=dhT,
+                                grads1=(g["K0"], g["R0"], g["b0"]), grads2=(g["K1"], g["R1"], g["b1"]), act="sigmoid",
+                                accumulate=accumulate, scratch=self.bwd_scratch)
+            return None
         for l in range(self.L - 1, -1, -1):
             inp, hs, res, h0, c0 = tape[l]
             b = ops.lstm_seq_bwd(inp, w["K%d" % l], w["R%d" % l], hs, res, h0=h0, c0=c0, dhs=dhs,

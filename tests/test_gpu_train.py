@@ -726,7 +726,7 @@ def _torch_tf_lstm_graph(x, y, cells, head, init, fps, running_length, forget_bi
         mu.detach().numpy(), var.detach().numpy()
 
 
-@pytest.mark.parametrize("H,B,T,with_masks", [(40, 9, 4, False), (400, 12, 3, True)])
+@pytest.mark.parametrize("H,B,T,with_masks", [(40, 9, 4, False), (400, 12, 3, True), (400, 32, 10, False), (400, 20, 2, False)])
 def test_tf_stacked_lstm_training_graph(H, B, T, with_masks):
     """a10 training: mycode/lstm.py (2 x LSTMCell(H) with a fed state, mean / variance heads, Gaussian NLL, TF
     RMSProp with clipping) against torch.autograd fp64; gradients are compared in tf.contrib layout."""
@@ -1772,3 +1772,62 @@ def test_others_future_convlstm_model_gradients_and_fit(H, B, U, fps, T_in, T_ou
     assert abs(h.history["loss"][0] - l0) <= 1e-4 * l0 + 1e-7 and h.history["loss"][-1] < h.history["loss"][0]
     p1 = m.predict([enc, oth, dec0], batch_size=max(1, B // 2))       # batched predict on the trained weights
     assert float(((p1 - tgt) ** 2).mean()) < l0
+
+
+@pytest.mark.parametrize("B,T,F,state,upstream", [(32, 10, 90, True, False), (12, 3, 90, False, True), (17, 1, 6, True, True), (48, 5, 30, False, False)])
+def test_two_layer_bptt_one_launch_equals_two_calls(B, T, F, state, upstream):
+    """fov_lstm_stack2_bwd (both recurrences and dx = dz2 . K2^T between them as three roles of one launch, lstm.py:218-240 under
+    its train_op) against two fov_lstm_seq_bwd calls: dz of both layers, state gradients, every weight gradient.  The only
+    arithmetic difference is the summation order of dx (sixteen slice partials vs a split GEMM): 2e-5 of each tensor's scale;
+    the second launch on the same workspace repeats the first bit for bit."""
+    from longterm360fov_amd import ops
+    H = 512
+    if not ops.lstm_stack2_bwd_supported(B, T, F, H):
+        pytest.skip("needs 3 x 16 workgroups per tile resident")
+    rng = np.random.default_rng(B * 100 + T)
+    K1, R1, b1 = O.init_lstm(rng, F, H, np.float32)
+    K2, R2, b2 = O.init_lstm(rng, H, H, np.float32)
+    x = dev(rng.uniform(-1, 1, (B, T, F)).astype(np.float32))
+    st = lambda: dev((0.3 * rng.standard_normal((B, H))).astype(np.float32)) if state else None
+    h01, c01, h02, c02 = st(), st(), st(), st()
+    dK1, dR1, db1, dK2, dR2, db2 = (dev(a) for a in (K1, R1, b1, K2, R2, b2))
+    hs1, _, _, res1 = ops.lstm_seq_train(x, dK1, dR1, db1, h01, c01, act="sigmoid")
+    hs2, _, _, res2 = ops.lstm_seq_train(hs1, dK2, dR2, db2, h02, c02, act="sigmoid")
+    dhT2 = dev((0.1 * rng.standard_normal((B, H))).astype(np.float32))
+    dcT2 = dev((0.1 * rng.standard_normal((B, H))).astype(np.float32)) if upstream else None
+    dhs2 = dev((0.05 * rng.standard_normal((B, T, H))).astype(np.float32)) if upstream else None
+    dhT1 = dev((0.1 * rng.standard_normal((B, H))).astype(np.float32)) if upstream else None
+    sc = ops.Scratch()
+    # reference: two calls
+    g = lambda *s: torch.zeros(s, dtype=torch.float32, device="cuda")
+    ga = {"K1": g(F, 4 * H), "R1": g(H, 4 * H), "b1": g(4 * H), "K2": g(H, 4 * H), "R2": g(H, 4 * H), "b2": g(4 * H)}
+    e2 = ops.lstm_seq_bwd(hs1, dK2, dR2, hs2, res2, h0=h02, c0=c02, dhs=dhs2, dhT=dhT2, dcT=dcT2, dK=ga["K2"], dR=ga["R2"], db=ga["b2"],
+                          need_dx=True, need_state_grads=True, act="sigmoid", scratch=sc)
+    e1 = ops.lstm_seq_bwd(x, dK1, dR1, hs1, res1, h0=h01, c0=c01, dhs=e2["dx"], dhT=dhT1, dK=ga["K1"], dR=ga["R1"], db=ga["b1"],
+                          need_state_grads=True, act="sigmoid", scratch=sc)
+    sc.check()
+    gb = {k: torch.zeros_like(v) for k, v in ga.items()}
+    sc2 = ops.Scratch()
+    one = ops.lstm_stack2_bwd(x, (dK1, dR1), (dK2, dR2), (hs1, res1, h01, c01), (hs2, res2, h02, c02), dhs2=dhs2, dhT2=dhT2, dcT2=dcT2,
+                              dhT1=dhT1, grads1=(gb["K1"], gb["R1"], gb["b1"]), grads2=(gb["K2"], gb["R2"], gb["b2"]),
+                              need_state_grads=True, act="sigmoid", scratch=sc2)
+    sc2.check()
+    def near(a, r, tag):
+        scale = float(r.abs().max())
+        err = float((a - r).abs().max())
+        print("one-launch two-layer BPTT B=%d T=%d %-6s max|ref| %.3e err %.3e" % (B, T, tag, scale, err))
+        assert err <= 2e-5 * scale + 1e-9, tag
+    near(one["dz2"], e2["dz"], "dz2")        # (the roles are separate instantiations of the body: the compiler may contract
+    near(one["dh0_2"], e2["dh0"], "dh0_2")    # the gates' arithmetic differently - not bit-identical by construction)
+    near(one["dc0_2"], e2["dc0"], "dc0_2")
+    near(one["dz1"], e1["dz"], "dz1")
+    near(one["dh0_1"], e1["dh0"], "dh0_1")
+    near(one["dc0_1"], e1["dc0"], "dc0_1")
+    for k in ga:
+        near(gb[k], ga[k], "d" + k)
+    assert float(ga["K1"].abs().max()) > 0 and float(ga["R2"].abs().max()) > 0 or T == 1
+    # a second launch on the same workspace (epoch tags continue), data path only: same dz
+    two = ops.lstm_stack2_bwd(x, (dK1, dR1), (dK2, dR2), (hs1, res1, h01, c01), (hs2, res2, h02, c02), dhs2=dhs2, dhT2=dhT2, dcT2=dcT2,
+                              dhT1=dhT1, act="sigmoid", scratch=sc2)
+    sc2.check()
+    assert torch.equal(two["dz1"], one["dz1"]) and torch.equal(two["dz2"], one["dz2"])
