@@ -1275,6 +1275,9 @@ int fov_seq2seq_decode_fwd(const float* enc_in, const float* dec_in0, const floa
     p.status = (unsigned*)workspace;
     p.xch = (unsigned long long*)((char*)workspace + kStatusBytes);
     hipStream_t s = (hipStream_t)stream;
+    // small batches (at most eight tiles): the tile spread over H / 16 workgroups instead of H / 64 (lstm_wide16.hip)
+    if (impl == FOV_IMPL_AUTO && want_cluster(impl, F_enc, H, F_dec, true) && wide16_s2s_shape(B, F_enc, F_dec, H) && T_out > 0)
+        return launch_wide16_s2s(p, s);
     if (want_cluster(impl, F_enc, H, F_dec, true)) return launch_cluster(p, true, s);
     return launch_generic(p, true, s);
 }
@@ -1297,6 +1300,10 @@ int fov_seq2seq_decoder_fwd(const float* dec_in0, const float* h0, const float* 
     p.B = B; p.T = 0; p.F = 1; p.H = H; p.T_out = T_out; p.F_dec = F_dec; p.act = act;
     p.status = (unsigned*)workspace;
     p.xch = (unsigned long long*)((char*)workspace + kStatusBytes);
+    if (impl == FOV_IMPL_AUTO && want_cluster(impl, 1, H, F_dec, true) && wide16_s2s_shape(B, 1, F_dec, H) && T_out > 0) {
+        p.K = dec_K; p.R = dec_R; p.b = dec_b;   // (the empty encoder phase's weight slots: any valid pointers)
+        return launch_wide16_s2s(p, (hipStream_t)stream);
+    }
     if (want_cluster(impl, 1, H, F_dec, true)) return launch_cluster_decoder(p, (hipStream_t)stream);
     p.K = dec_K; p.R = dec_R; p.b = dec_b;   // unused by the generic kernel's empty encoder phase (T = 0)
     return launch_generic(p, true, (hipStream_t)stream);

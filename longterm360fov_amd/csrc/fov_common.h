@@ -65,6 +65,8 @@ struct LstmParams {
 
 int launch_generic(const LstmParams& p, bool decode, hipStream_t stream);
 long generic_launch_count();   // launches of the generic (VALU) LSTM kernel so far in this process (diagnostic)
+bool wide16_s2s_shape(int B, int F_enc, int F_dec, int H);   // lstm_wide16.hip: encoder + free-running decoder, small batches
+int launch_wide16_s2s(const LstmParams& p, hipStream_t stream);
 int launch_cluster(const LstmParams& p, bool decode, hipStream_t stream);
 int launch_cluster_decoder(const LstmParams& p, hipStream_t stream);   // MODE_DECODE alone, from (p.h0, p.c0)
 bool cluster_shape_ok(int F, int H);

@@ -455,6 +455,306 @@ __global__ __launch_bounds__(256, 1) void lstm_wide16_pair_kernel(Wide16Pair pp)
     else wide16_body<ACT, WH / 16, WH, 2>(pp.l2, (int)blockIdx.x - per_role, smem);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Round 4: encoder + free-running decoder of the Keras seq2seq (mycode/FoV_seq2seq.py:19-28 encoder, :112-117 decoder,
+// :154-178 the decode loop: y_t = Dense(6, tanh)(h_t) fed back as x_{t+1}) for SMALL batches at widths 128 / 256, ONE launch,
+// in the sixteen-units-per-workgroup form: a 16-sequence tile is spread over WH / 16 workgroups (8 at H = 128) where
+// lstm_cluster.hip's fused kernel spreads it over WH / 64 (2) - at the reference's own batch of 32 that kernel has four
+// workgroups at work and spends 1.7 us of every 3.8 us step on one workgroup's MFMAs (r03: 0.076 ms per call).
+// A wave owns four units x four gates (one 16-column MFMA tile); both phases' weight slices stay in registers (R: WH / 16
+// k-blocks each, encoder K: six k-blocks, decoder K: one).  Every workgroup gathers the whole h_t tile for its recurrent
+// product anyway, so the decoder's Dense needs NO further exchange: each workgroup forms y_t = tanh(h_t . W + b) of its tile
+// redundantly from the gathered tile (thread = (row, output, half of the units), 16-byte LDS reads, one shuffle), writes it
+// as x_{t+1} into LDS and - workgroup 0 of the group - into `out`.  Same granule exchange as the layer kernel above.
+// ---------------------------------------------------------------------------------------------------------------
+template <int ACT, int WH>
+__global__ __launch_bounds__(256, 1) void wide16_s2s_kernel(LstmParams p) {
+    constexpr int WG = WH / 16, NJR = WH / 16, NJX = 6, WLD = WH + 8, WNG = WG / 2, H4 = 4 * WH;
+    constexpr int WDL = WH + 4;          // floats per row of the transposed Dense kernel [output][unit]
+    constexpr unsigned OORB = 0x80000000u;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sH = smem;                     // [16][WLD]
+    float* sX = sH + VBT * WLD;           // [2][16][WLD]: encoder x tiles (columns < F), decoder x tile (columns < F_dec) in [0]
+    float* sT = sX + 2 * VBT * WLD;       // [4 waves][16][17] gate transpose
+    float* sWd = sT + 4 * 16 * 17;        // [8][WDL] Dense kernel transposed, rows >= F_dec zero
+    int* sFlag = (int*)(sWd + 8 * WDL);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, g4 = lane >> 4;
+    int group, slice;
+    const int bx = (int)blockIdx.x;
+    if (p.xcd_pad) {   // fewer than eight groups: padded grid, members of a group 8 blocks apart (one XCD)
+        group = bx & 7;
+        slice = bx >> 3;
+        if (group >= p.num_groups) {
+            __shared__ unsigned sSpare[4];
+            xch_arrive(p.status, sSpare, -1, 0);
+            return;
+        }
+    } else if ((p.num_groups & 7) == 0) {
+        group = (bx / (8 * WG)) * 8 + (bx & 7);
+        slice = (bx >> 3) & (WG - 1);
+    } else {
+        group = bx / WG;
+        slice = bx - group * WG;
+    }
+    const int F = p.F, FD = p.F_dec, T_in = p.T, T_out = p.T_out;
+    const int unit = 16 * slice + 4 * wave + (n & 3);
+    const int col = (n >> 2) * WH + unit;
+    const int row_o = 4 * g4 + (n >> 2);
+    float* tw = sT + wave * (16 * 17);
+    __shared__ unsigned sXch[4];
+    const unsigned arrival = xch_arrive(p.status, sXch, group, slice);
+    const bool poisoned = xch_poisoned(p.status);
+    if (tid == 0) sFlag[0] = poisoned ? 1 : 0;
+
+    // ---- resident weights of both phases (rows past an input's width read as zero: the descriptor ends there) ----
+    const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.K), 0, F * H4 * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.R), 0, WH * H4 * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t dkrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dK), 0, FD * H4 * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t drrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dR), 0, WH * H4 * 4, 0x00020000);
+    float wk[NJX][4], wr[NJR][4], dk[1][4], dr[NJR][4];
+#pragma unroll
+    for (int j = 0; j < NJR; ++j)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const unsigned off = (unsigned)(((16 * j + 4 * g4 + s) * H4 + col) * 4);
+            if (j < NJX) wk[j][s] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(krs, off, 0, 0));
+            if (j < 1) dk[j][s] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(dkrs, off, 0, 0));
+            wr[j][s] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rrs, off, 0, 0));
+            dr[j][s] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(drrs, off, 0, 0));
+        }
+    const float bv_e = p.b[col], bv_d = p.db[col];
+    for (int i = tid; i < 2 * VBT * WLD; i += 256) sX[i] = 0.f;   // columns past the inputs' widths stay zero
+    for (int i = tid; i < 8 * WDL; i += 256) {
+        const int o = i / WDL, k = i - o * WDL;
+        sWd[i] = (o < FD && k < WH) ? p.dW[(size_t)k * FD + o] : 0.f;
+    }
+    // Dense: thread (row drow, output dout < 8, half dkh of the units)
+    const int drow = tid >> 4, dout = tid & 7, dkh = (tid >> 3) & 1;
+    const float dbv = dout < FD ? p.dbias[dout] : 0.f;
+
+    // ---- exchange bookkeeping (two parity slots per group) ----
+    constexpr size_t SLOT = (size_t)VBT * WH;
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(p.xch + (size_t)group * 2 * SLOT, 0,
+                                                                         2 * (int)(SLOT * sizeof(unsigned long long)), 0x00020000);
+    const unsigned pub_off = (unsigned)(row_o * WH + unit) * 8u;
+    const int grow = tid >> 4, ghalf = (tid >> 3) & 1, gp = tid & 7;
+    const unsigned gvoff = (unsigned)(grow * WH + 2 * gp) * 8u;
+    const int lbase = grow * WLD + 2 * gp;
+    constexpr unsigned PARITY = VBT * WH * 8u;
+    xch_hello_poll(p.status, sXch, group, WG, &sFlag[0]);
+    __syncthreads();
+    const XchTicket ticket = xch_ticket(sXch, arrival);
+    unsigned epoch = ticket.base;
+    bool aborted = sFlag[0] != 0;
+    if (tid == 0 && !ticket.same_xcd && !aborted) xch_count_safe(p.status, ticket);
+
+    auto gslice = [&](int j) { return (slice + 1 + ghalf * WNG + j) & (WG - 1); };
+    // the partners' pieces of the h tile (tags `epoch`) -> sH; all loads of a sweep in flight together
+    auto gather = [&](unsigned base) {
+        vu32x4 v[WNG];
+        unsigned bad = 0;
+#pragma unroll
+        for (int j = 0; j < WNG; ++j) {
+            const bool on = !(ghalf == 1 && j == WNG - 1);   // the last load of half 1 would be the own slice
+            v[j] = __builtin_amdgcn_raw_buffer_load_b128(xrs, on ? gvoff + (unsigned)(gslice(j) * 16) * 8u : OORB, base, 16);
+        }
+#pragma unroll
+        for (int j = 0; j < WNG; ++j) {
+            const bool on = !(ghalf == 1 && j == WNG - 1);
+            const int lo = lbase + gslice(j) * 16;
+            if (!on) continue;
+            if (v[j].y == epoch && v[j].w == epoch) {
+                sH[lo] = __uint_as_float(v[j].x);
+                sH[lo + 1] = __uint_as_float(v[j].z);
+            } else {
+                bad |= (1u << j);
+            }
+        }
+        unsigned spins = 0;
+        while (__any(bad != 0)) {
+            ++spins;
+            if (spins > VSPIN || ((spins & 63u) == 0 && xch_poisoned(p.status))) {
+                if (lane == 0) { xch_give_up(p.status); sFlag[0] = 1; }
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+            asm volatile("" ::: "memory");
+            vu32x4 tv[WNG];
+#pragma unroll
+            for (int j = 0; j < WNG; ++j) {
+                const bool on = !(ghalf == 1 && j == WNG - 1);
+                tv[j] = __builtin_amdgcn_raw_buffer_load_b128(xrs, on ? gvoff + (unsigned)(gslice(j) * 16) * 8u : OORB, base, 16);
+            }
+#pragma unroll
+            for (int j = 0; j < WNG; ++j) {
+                const int lo = lbase + gslice(j) * 16;
+                if (((bad >> j) & 1u) && tv[j].y == epoch && tv[j].w == epoch) {
+                    sH[lo] = __uint_as_float(tv[j].x);
+                    sH[lo + 1] = __uint_as_float(tv[j].z);
+                    bad &= ~(1u << j);
+                }
+            }
+        }
+    };
+
+    const float* hrow = sH + n * WLD + 4 * g4;
+    const int xrw = tid >> 4, xc = tid & 15;
+    for (int tile = group; tile < p.num_tiles && !aborted; tile += p.num_groups) {
+        const int b0 = tile * VBT;
+        __syncthreads();   // previous tile fully consumed
+        const int live_rows = p.B - b0 < VBT ? p.B - b0 : VBT;
+        const __amdgpu_buffer_rsrc_t xgrs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(T_in > 0 ? p.x + (size_t)b0 * T_in * F : nullptr), 0, T_in > 0 ? live_rows * T_in * F * 4 : 0, 0x00020000);
+        const __amdgpu_buffer_rsrc_t d0rs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(p.dec_in0 + (size_t)b0 * FD), 0, live_rows * FD * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t h0rs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(p.h0 ? p.h0 + (size_t)b0 * WH : nullptr), 0, p.h0 ? live_rows * WH * 4 : 0, 0x00020000);
+        const __amdgpu_buffer_rsrc_t c0rs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(p.c0 ? p.c0 + (size_t)b0 * WH : nullptr), 0, p.c0 ? live_rows * WH * 4 : 0, 0x00020000);
+        {   // initial state (zero unless the caller passes one: fov_seq2seq_decoder_fwd) into the h tile
+            float hv[VBT * WH / 256];
+#pragma unroll
+            for (int q = 0; q < VBT * WH / 256; ++q) hv[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(h0rs, (unsigned)((tid + 256 * q) * 4), 0, 0));
+#pragma unroll
+            for (int q = 0; q < VBT * WH / 256; ++q) {
+                const int e = tid + 256 * q;
+                sH[(e / WH) * WLD + (e % WH)] = hv[q];
+            }
+        }
+        const unsigned soff = (unsigned)((row_o * WH + unit) * 4);
+        float c = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(c0rs, soff, 0, 0));
+        float hc = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(h0rs, soff, 0, 0));
+        unsigned xoff[NJX];
+#pragma unroll
+        for (int i = 0; i < NJX; ++i) xoff[i] = (xc + 16 * i < F) ? (unsigned)((xrw * T_in * F + xc + 16 * i) * 4) : OORB;
+        auto load_x1 = [&](int i, int t) { return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xgrs, xoff[i], (unsigned)(t * F * 4), 0)); };
+        float* xl = sX + xrw * WLD + xc;
+        const int total = T_in + T_out;           // recurrent steps; step s < T_in: encoder, else decoder step s - T_in
+        {   // x of encoder steps 0 and 1; a launch without an encoder: the decoder's first input
+            float x1[2][NJX];
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                for (int i = 0; i < NJX; ++i) x1[tt][i] = load_x1(i, tt < T_in ? tt : 0);
+            const float d0 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(d0rs, xc < FD ? (unsigned)((xrw * FD + xc) * 4) : OORB, 0, 0));
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt)
+                if (tt < T_in) {
+#pragma unroll
+                    for (int i = 0; i < NJX; ++i)
+                        if (xc + 16 * i < F) xl[tt * VBT * WLD + 16 * i] = x1[tt][i];
+                }
+            if (T_in == 0 && xc < 16) xl[0] = d0;     // (columns FD .. 15 of the decoder tile: zero, d0 read out of range)
+        }
+        __syncthreads();
+        // ---- pre-activations of step 0 ----
+        f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        if (total > 0) {
+            const float bv0 = T_in > 0 ? bv_e : bv_d;
+            acc[0] = (f32x4){bv0, bv0, bv0, bv0};
+            vm_begin(acc);
+            if (T_in > 0) {
+                wide16_mm<NJX>(acc, sX + n * WLD + 4 * g4, wk);
+                wide16_mm<NJR>(acc, hrow, wr);
+            } else {
+                wide16_mm<1>(acc, sX + n * WLD + 4 * g4, dk);
+                wide16_mm<NJR>(acc, hrow, dr);
+            }
+            vm_end(acc);
+        }
+        float xs[NJX] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int s = 0; s < total; ++s) {
+            const bool next_enc = s + 1 < T_in;                 // the NEXT step is an encoder step: its x comes from memory
+            const bool next_dec = !next_enc && s + 1 < total;   // ... a decoder step: its x is dec_in0 (s + 1 == T_in) or y of this step
+            // encoder x pipeline: x_{s+1} (requested during step s-1) registers -> LDS; then request x_{s+2}
+            if (s > 0 && next_enc) {
+                float* xb = xl + ((s + 1) & 1) * VBT * WLD;
+#pragma unroll
+                for (int i = 0; i < NJX; ++i)
+                    if (xc + 16 * i < F) xb[16 * i] = xs[i];
+            }
+            if (s + 2 < T_in) {
+#pragma unroll
+                for (int i = 0; i < NJX; ++i) xs[i] = load_x1(i, s + 2);
+            }
+            float d0 = 0.f;
+            if (s + 1 == T_in) d0 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(d0rs, xc < FD ? (unsigned)((xrw * FD + xc) * 4) : OORB, 0, 0));
+            // ---- the four gates of a cell meet: 16 x 16 transpose through the wave's scratch ----
+#pragma unroll
+            for (int r = 0; r < 4; ++r) tw[(4 * g4 + r) * 17 + n] = acc[0][r] + acc[1][r];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const float zi = tw[row_o * 17 + (n & 3)], zf = tw[row_o * 17 + 4 + (n & 3)], zg = tw[row_o * 17 + 8 + (n & 3)],
+                        zo = tw[row_o * 17 + 12 + (n & 3)];
+            {
+                const float ig = rec_act<ACT>(zi), fg = rec_act<ACT>(zf), gg = tanh_f(zg), og = rec_act<ACT>(zo);
+                c = fmaf(fg, c, ig * gg);
+                hc = og * tanh_f(c);
+            }
+            // every step publishes: the decoder's Dense needs the whole h tile of every decoder step, the encoder's last step
+            // hands its tile to the decoder; only an encoder-only tail (T_out == 0, last step) has no reader
+            const bool need_tile = s + 1 < total || s >= T_in;
+            unsigned par = 0;
+            if (need_tile) {
+                ++epoch;
+                par = (epoch & 1u) * PARITY;
+                XCH_STORE_B64(ticket.same_xcd, ((vu32x2){__float_as_uint(hc), epoch}), xrs, pub_off, par);
+            }
+            __syncthreads();   // barrier 1: every wave is done reading sH and the x tile of this step
+            if (need_tile) sH[row_o * WLD + unit] = hc;
+            if (s + 1 == T_in && xc < 16) xl[0] = d0;   // the decoder's first input into tile 0 (columns FD .. 15: zero)
+            const float bvn = next_enc ? bv_e : bv_d;
+            acc[0] = (f32x4){bvn, bvn, bvn, bvn};
+            acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (next_enc) {   // x_{s+1} . K needs no remote data: it runs under the exchange
+                vm_begin(acc);
+                wide16_mm<NJX>(acc, sX + ((s + 1) & 1) * VBT * WLD + n * WLD + 4 * g4, wk);
+                vm_end(acc);
+            }
+            if (need_tile) gather(par);
+            __syncthreads();   // barrier 2: the whole h tile of this step is in LDS
+            if (sFlag[0]) { aborted = true; break; }
+            if (s >= T_in) {
+                // ---- y = tanh(h . W + b) of this decoder step: every workgroup, its whole tile ----
+                const float* hr = sH + drow * WLD + dkh * (WH / 2);
+                const float* wrow = sWd + dout * WDL + dkh * (WH / 2);
+                float a = 0.f;
+#pragma unroll 8
+                for (int k = 0; k < WH / 2; k += 4) {
+                    const f32x4 hv4 = *(const f32x4*)(hr + k), wv4 = *(const f32x4*)(wrow + k);
+                    a = fmaf(hv4[0], wv4[0], a); a = fmaf(hv4[1], wv4[1], a); a = fmaf(hv4[2], wv4[2], a); a = fmaf(hv4[3], wv4[3], a);
+                }
+                a += __shfl_xor(a, 8);
+                const float y = tanh_f(a + dbv);
+                if (dkh == 0 && dout < FD) {
+                    if (next_dec) sX[drow * WLD + dout] = y;      // x of the next decoder step (tile 0)
+                    if (slice == 0 && b0 + drow < p.B) p.out[((size_t)(b0 + drow) * T_out + (s - T_in)) * FD + dout] = y;
+                }
+                if (next_dec) __syncthreads();   // barrier 3: the next input is in LDS
+            }
+            if (next_enc) {
+                vm_begin(acc);
+                wide16_mm<NJR>(acc, hrow, wr);
+                vm_end(acc);
+            } else if (next_dec) {
+                vm_begin(acc);
+                wide16_mm<1>(acc, sX + n * WLD + 4 * g4, dk);
+                wide16_mm<NJR>(acc, hrow, dr);
+                vm_end(acc);
+            }
+        }
+        if (!aborted) {
+            const int row = b0 + row_o;
+            if (row < p.B) {
+                if (p.hT) p.hT[(size_t)row * WH + unit] = hc;
+                if (p.cT) p.cT[(size_t)row * WH + unit] = c;
+            }
+        }
+    }
+    xch_settle(p.status, ticket, (unsigned)p.epoch_span);
+}
+
 template <int NJX, int WH>
 int launch_wide16_t(LstmParams& p, hipStream_t stream) {
     constexpr int WG = WH / 16;
@@ -527,6 +827,42 @@ int launch_wide16_pair(const LstmParams& a, const LstmParams& b, hipStream_t str
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("two-layer width-512 launch: %s", hipGetErrorString(e)); return FOV_ERR_LAUNCH; }
     return FOV_OK;
+}
+
+// Encoder + free-running decoder in one launch: widths 128 / 256, narrow inputs, at most eight outputs fed back, one tile per group
+// and at most eight tiles (the latency regime the kernel is built for; larger batches stay on lstm_cluster.hip's fused kernel).
+bool wide16_s2s_shape(int B, int F_enc, int F_dec, int H) {
+    if (env_knobs().no_wide16 || !(H == 128 || H == 256) || B <= 0) return false;
+    const int tiles = (B + VBT - 1) / VBT;
+    if (tiles > 8 || tiles > device_cu_count() / (H / 16)) return false;
+    return F_enc >= 1 && F_enc <= 96 && F_dec >= 1 && F_dec <= 8;
+}
+
+template <int WH>
+static int launch_wide16_s2s_t(LstmParams& p, hipStream_t stream) {
+    constexpr int WG = WH / 16;
+    p.num_tiles = (p.B + VBT - 1) / VBT;
+    p.num_groups = p.num_tiles;
+    if ((size_t)p.num_groups * 2 * VBT * WH * sizeof(unsigned long long) > kXchBytes - kHelloBytes) { set_error("seq2seq decode: granule area too small"); return FOV_ERR_WORKSPACE; }
+    p.epoch_span = p.T + p.T_out + 1;
+    if (int rc_ = xch_account(p.status, p.epoch_span, stream)) return rc_;
+    const size_t lds = sizeof(float) * (3 * VBT * (WH + 8) + 4 * 16 * 17 + 8 * (WH + 4)) + 64;
+    void (*kern)(LstmParams) = p.act == FOV_ACT_HARD_SIGMOID ? wide16_s2s_kernel<FOV_ACT_HARD_SIGMOID, WH> : wide16_s2s_kernel<FOV_ACT_SIGMOID, WH>;
+    int rc = ensure_dynamic_lds((const void*)kern, lds);
+    if (rc) return rc;
+    const bool no_pad = env_knobs().no_xcd_pad != 0;
+    p.xcd_pad = (!no_pad && WG <= env_knobs().xcd_pad_max && p.num_groups < 8 && device_cu_count() >= 8 * WG) ? 1 : 0;
+    hipLaunchKernelGGL(kern, dim3(p.xcd_pad ? 8 * WG : p.num_groups * WG), dim3(256), lds, stream, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_error("seq2seq decode (wide16) launch: %s", hipGetErrorString(e)); return FOV_ERR_LAUNCH; }
+    return FOV_OK;
+}
+
+int launch_wide16_s2s(const LstmParams& p_in, hipStream_t stream) {
+    LstmParams p = p_in;
+    if (p.B == 0 || p.T + p.T_out == 0) return FOV_OK;
+    if (!wide16_s2s_shape(p.B, p.F, p.F_dec, p.H)) { set_error("seq2seq decode (wide16): unsupported shape"); return FOV_ERR_UNSUPPORTED; }
+    return p.H == 128 ? launch_wide16_s2s_t<128>(p, stream) : launch_wide16_s2s_t<256>(p, stream);
 }
 
 int launch_wide16(const LstmParams& p_in, hipStream_t stream) {
