@@ -63,7 +63,7 @@ PMC_TRAFFIC_CONFIG, PMC_TRAFFIC_BYTES, PMC_TRAFFIC_SOURCE, MODE_TRAFFIC = _load_
 # (MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 32 cycles per SIMD, v_mfma_f32_16x16x32_bf16 16) at 2.4 GHz.  What the floor
 # leaves out on purpose: the cell update's transcendentals, barriers, launches and prologues, the weight-gradient products -
 # it is a floor, and frac_of_latency_floor = floor / measured says how much of the measured time the two unavoidable terms are.
-XCH_STEP_US = {(128, 2): 0.557, (256, 4): 1.138, (256, 8): 1.405, (512, 16): 1.319, (512, 32): 1.365}      # (width, workgroups per tile)
+XCH_STEP_US = {(128, 2): 0.557, (128, 8): 0.905, (256, 4): 1.138, (256, 8): 1.405, (512, 16): 1.319, (512, 32): 1.365}      # (width, workgroups per tile)
 XCH_SOURCE = "profiles/r04_microbench_xch_step.txt"
 CLOCK_GHZ = 2.4
 
@@ -557,14 +557,18 @@ def bench_config1(args, rank, world, use_dist):
             "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "configs[0]: the reference's native operating point, target-only seq2seq inference, H=128, "
-                                   "batch=32, T 10->10 (latency-bound: 2 of 256 CUs' worth of tiles)", "global_batch": B * world,
+                                   "batch=32, T 10->10 (latency-bound: two 16-sequence tiles, 16 of 256 CUs at work)", "global_batch": B * world,
                        "parallelism": "replicas x%d" % world},
             "latency": {"gpu_ms_per_call_async": ev_ms, "gpu_ms_per_call_host_synchronised_median": float(np.median(lat)) * 1e3,
                         "cpu_ms_per_call": None if cpu is None else min(l["ms_per_pass"] for l in cpu["legs"] if l["ms_per_pass"] is not None)},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach / PEAK_FP32_MFMA_TFLOPS, **mode_traffic("config1", "f32", ev_ms, (B, H) == (32, 128)),
-                         # H = 128: two workgroups per tile, a wave's h . R is 4 gates x 32 k-steps = 128 MFMAs per step
-                         **latency_floor([("encoder + decoder steps", T_in + T_out, 128, 32, (128, 2))], ev_ms),
+                         # H = 128 at <= 8 tiles (round 4, lstm_wide16.hip: wide16_s2s_kernel): EIGHT workgroups per tile, a wave's h . R
+                         # is 8 k-blocks x 4 = 32 MFMAs per step, the decoder's x . K another 4; larger batches: two workgroups
+                         # per tile, 128 MFMAs per wave and step (lstm_cluster.hip)
+                         **(latency_floor([("encoder steps", T_in, 32, 32, (128, 8)), ("decoder steps", T_out, 36, 32, (128, 8))], ev_ms)
+                            if (H == 128 and B <= 128 and args.impl == "auto" and not os.environ.get("FOV_NO_WIDE16"))
+                            else latency_floor([("encoder + decoder steps", T_in + T_out, 128, 32, (128, 2))], ev_ms)),
                          "note": "two 16-sequence tiles: 4 workgroups busy, per-step latency bound by construction"},
             "parity": {"max_abs_err_vs_oracle": err, "sequences_checked": B}, "training": training,
             "cpu_baseline": cpu, "speedup_vs_cpu_baseline": None if cpu is None else world * B * steps / elapsed / cpu["value"]}), flush=True)

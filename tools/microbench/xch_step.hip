@@ -116,6 +116,7 @@ int main(int argc, char** argv) {
         // H = 128: two workgroups (configs[0]); H = 256: four (headline kernel) or eight (wide layers, fused mixing decoder);
         // H = 512: sixteen / thirty-two (lstm.py's padded width)
         for (int groups : {2, 16}) if (run<2>(groups, 2, 128, same, steps)) return 1;
+        for (int groups : {2, 8}) if (run<4>(groups, 8, 128, same, steps)) return 1;    // round 4: the reference-batch decode on eight workgroups per tile
         for (int groups : {1, 8, 64}) if (run<6>(groups, 4, 256, same, steps)) return 1;
         for (int groups : {1, 8, 32}) if (run<7>(groups, 8, 256, same, steps)) return 1;
         for (int groups : {1, 2, 8}) if (run<15>(groups, 16, 512, same, steps)) return 1;
