@@ -237,6 +237,7 @@ constexpr size_t G3_IMG = (size_t)2 * 3 * G3KB * GLD_TN * sizeof(unsigned short)
 constexpr size_t G3_LDS = G3_IMG > G3_TILES ? G3_IMG : G3_TILES;
 struct G3Regs { f32x4 a[G3NR], b[G3NR]; };
 
+template <bool AVEC>   // AVEC: 16-byte loads of A rows; else four 4-byte loads (width or row stride not a multiple of 4: the 90-wide encoder input)
 __global__ __launch_bounds__(G3T, 1) void gemm_bf16_tn3_kernel(GemmTN g) {
     __shared__ __attribute__((aligned(16))) unsigned char sRaw[G3_LDS];   // [A | B][image 3][row][column] bf16; the epilogue's tiles
     unsigned short (*sA)[G3KB * GLD_TN] = reinterpret_cast<unsigned short (*)[G3KB * GLD_TN]>(sRaw);
@@ -308,9 +309,15 @@ __global__ __launch_bounds__(G3T, 1) void gemm_bf16_tn3_kernel(GemmTN g) {
         for (int i = 0; i < G3NR; ++i) {
             const bool rok = c_r[i] < r_hi32;
             const bool a_ok = rok && !(a_shift && c_ri[i] == 0);
-            const qu32x4 ta = __builtin_amdgcn_raw_buffer_load_b128(ars, (a_ok && a_col_ok) ? c_aoff[i] : OOR, 0, 0);
+            if constexpr (AVEC) {
+                const qu32x4 ta = __builtin_amdgcn_raw_buffer_load_b128(ars, (a_ok && a_col_ok) ? c_aoff[i] : OOR, 0, 0);
+                R.a[i] = (f32x4){__uint_as_float(ta[0]), __uint_as_float(ta[1]), __uint_as_float(ta[2]), __uint_as_float(ta[3])};
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    R.a[i][e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ars, (a_ok && am0 + scol + e < a_M) ? c_aoff[i] + 4u * e : OOR, 0, 0));
+            }
             const qu32x4 tb = __builtin_amdgcn_raw_buffer_load_b128(brs, (rok && b_col_ok) ? c_boff[i] : OOR, 0, 0);
-            R.a[i] = (f32x4){__uint_as_float(ta[0]), __uint_as_float(ta[1]), __uint_as_float(ta[2]), __uint_as_float(ta[3])};
             R.b[i] = (f32x4){__uint_as_float(tb[0]), __uint_as_float(tb[1]), __uint_as_float(tb[2]), __uint_as_float(tb[3])};
             c_r[i] += G3KB;
             c_ri[i] += dr;
@@ -557,7 +564,7 @@ int gemm_bf16_tn_fused(const float* a1, long lda1, long a1_so, int M1, int shift
     const int tiles = ((M + GT - 1) / GT) * ((N + GT - 1) / GT);
     const bool avec = (lda1 & 3) == 0 && (a1_so & 3) == 0 && (((uintptr_t)a1) & 15) == 0 && (M1 & 3) == 0 &&
                       (!a2 || ((lda2 & 3) == 0 && (a2_so & 3) == 0 && (((uintptr_t)a2) & 15) == 0 && (M2 & 3) == 0));
-    const bool deep = avec && !env_knobs().gemm_bf16_shallow;   // three stages in flight, one 512-thread block per CU
+    const bool deep = !env_knobs().gemm_bf16_shallow;   // three stages in flight, one 512-thread block per CU
     // enough row slices to fill the chip, at least 8 stages each, at most 32 slices and what the scratch holds; the deep
     // kernel runs one block per CU: as many slices as give at most one block per CU (a second, partial round would double
     // the product's time)
@@ -587,7 +594,8 @@ int gemm_bf16_tn_fused(const float* a1, long lda1, long a1_so, int M1, int shift
     g.grid_m = (M + GT - 1) / GT;
     g.xcd_remap = (split >= 8 && !env_knobs().gemm_bf16_noremap) ? 1 : 0;
     const dim3 grid = g.xcd_remap ? dim3((unsigned)(8 * ((split + 7) / 8) * g.grid_n * g.grid_m)) : dim3(g.grid_n, g.grid_m, split);
-    if (deep) hipLaunchKernelGGL(gemm_bf16_tn3_kernel, grid, dim3(G3T), 0, stream, g);
+    if (deep && avec) hipLaunchKernelGGL(gemm_bf16_tn3_kernel<true>, grid, dim3(G3T), 0, stream, g);
+    else if (deep) hipLaunchKernelGGL(gemm_bf16_tn3_kernel<false>, grid, dim3(G3T), 0, stream, g);
     else if (avec) hipLaunchKernelGGL(gemm_bf16_tn_kernel<true>, grid, dim3(256), 0, stream, g);
     else hipLaunchKernelGGL(gemm_bf16_tn_kernel<false>, grid, dim3(256), 0, stream, g);
     hipError_t e = hipGetLastError();

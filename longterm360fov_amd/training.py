@@ -1183,7 +1183,10 @@ class OthersMixingTrainer(FlatParamTrainer):
         return self.__dict__["_side_warm_set"]
 
     def _wgrad_side_stream(self):
-        if os.environ.get("FOV_WGRAD_STREAM", "1") == "0":
+        # fp32: the products run under the encoder's recurrences on a second stream (0.818 -> 0.801 ms).  bf16: in line - its
+        # recurrences take a whole CU's registers per workgroup and slow down by what a co-resident product gains, what is left
+        # of the second stream are its hand-offs (r04, same box: 0.4557 ms with it, 0.4467 ms without).  FOV_WGRAD_STREAM=0/1 overrides.
+        if os.environ.get("FOV_WGRAD_STREAM", "0" if getattr(self, "dtype", "f32") == "bf16" else "1") == "0":
             return None
         if self._side_stream is None:
             # LOW priority: when a product and a persistent recurrence kernel become ready together (both wait for the same
