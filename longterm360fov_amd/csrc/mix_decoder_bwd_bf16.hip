@@ -3,7 +3,7 @@
 // launch, with bf16 operands into v_mfma_f32_16x16x32_bf16 for the four transposed products
 //     dz2 . R2^T -> dh2_{t-1},   dz2 . K2^T -> dh1_t,   dz1 . R1^T -> dh1_{t-1},   dz1 . K1^T -> dx_t
 // fp32 accumulation, fp32 gates backward / head backward / dc / tapes.  Same ownership (tile of 16 sequences per group
-// of 8 workgroups, workgroup `slice` owns hidden units [32*slice, +32) of both layers, a lane two cells of one unit)
+// of 8 workgroups, workgroup `slice` owns hidden units [32*slice, +32) of both layers, a lane two adjacent units of one row)
 // and the same outputs as the fp32 kernel - but the products are split by OUTPUT unit (N-split), not by gate column:
 //   * the fp32 kernel multiplies its own 128 gate columns of dz into partial sums for ALL 256 units and sends them
 //     to their owners: 48 fp32 {value, epoch} granules per lane and step, 8-byte write-through stores - the expensive
@@ -46,10 +46,11 @@ __global__ __launch_bounds__(256, 1) void mix_decoder_bwd_bf16_kernel(MixDecBwdP
     int group, slice;
     q_group_slice(p.num_groups, group, slice);
     constexpr int H4 = 4 * QH;
-    const int hi = n >> 3;
-    const int ul = 8 * wave + (n & 7);          // unit inside the workgroup (0..31)
-    const int unit = 32 * slice + ul;
-    const int my_row0 = 4 * g4 + 2 * hi;
+    // pointwise phases (round 4, as lstm_bwd8n_bf16_kernel): thread tid owns row tid >> 4 of the tile and the two adjacent units
+    // 2 * (tid & 15), + 1 of the workgroup's 32 - 8-byte tape accesses, whole 128-byte lines per wave instruction
+    const int prow = tid >> 4;
+    const int pu = 2 * (tid & 15);
+    const int unit0 = 32 * slice + pu;
     __shared__ unsigned sXch[4];
     const unsigned arrival = xch_arrive(p.status, sXch, group, slice);
     const bool poisoned = xch_poisoned(p.status);
@@ -70,9 +71,11 @@ __global__ __launch_bounds__(256, 1) void mix_decoder_bwd_bf16_kernel(MixDecBwdP
         k1q[kb] = load_bfrag_rowmajor(p.K1 + (size_t)(n < O ? n : 0) * H4 + QH * wave + 32 * kb + 8 * g4);
         if (n >= O) k1q[kb] = (qu32x4){0u, 0u, 0u, 0u};
     }
-    float wd[8];   // Dense kernel row of this lane's unit
+    float wd[2][8];   // Dense kernel rows of this lane's two units
 #pragma unroll
-    for (int o = 0; o < 8; ++o) wd[o] = (o < O) ? p.Wd[(size_t)unit * O + o] : 0.f;
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int o = 0; o < 8; ++o) wd[u][o] = (o < O) ? p.Wd[(size_t)(unit0 + u) * O + o] : 0.f;
     const int hrow = tid >> 4, ho = tid & 15;   // head: thread = (sequence of the tile, output)
     float wpr[8];   // row `ho` of Wp: dp[ho] = sum_k dm[k] Wp[ho][k]
 #pragma unroll
@@ -93,36 +96,33 @@ __global__ __launch_bounds__(256, 1) void mix_decoder_bwd_bf16_kernel(MixDecBwdP
         const int b0 = tile * QBT;
         __syncthreads();
         if (tid < QBT * 8) sDX[tid] = 0.f;       // no feedback gradient into the last step
-        float dc1[2] = {0.f, 0.f}, dc2[2] = {0.f, 0.f}, dh1r[2] = {0.f, 0.f}, dh2r[2] = {0.f, 0.f};
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        f32x2 dc1 = {0.f, 0.f}, dc2 = {0.f, 0.f}, dh1r = {0.f, 0.f}, dh2r = {0.f, 0.f};
         __syncthreads();
+        const int row = b0 + prow;
+        const bool lv = row < p.B;
+        const size_t rowc = (size_t)(lv ? row : p.B - 1);
         // Tapes (reserve i,f,g,o,c and the previous cell state) of this lane's two cells, both layers, one step AHEAD: the
         // loads of step t-1 are issued at the top of step t.  Vector-memory operations retire in order - HBM loads issued
         // right in front of a gather would put their whole latency into the gather's wait.
-        float tq2[2][6], tq1[2][6];
+        f32x2 tq2[6], tq1[6];
         // UNCONDITIONAL loads (step and row clamped into the tape; dead rows are masked where dz is formed): a load inside
         // a branch gets an s_waitcnt vmcnt(0) at the merge and the step would wait for HBM right there
-        auto load_tape = [&](int t, const float* res, const float* Cst, float (&dst)[2][6]) {
+        auto load_tape = [&](int t, const float* res, const float* Cst, f32x2 (&dst)[6]) {
             const size_t tc = (size_t)(t > 0 ? t : 0);
+            const float* rp = res + ((tc * p.B + rowc) * 5) * QH + unit0;
 #pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                const int row = b0 + my_row0 + r;
-                const size_t rowc = (size_t)(row < p.B ? row : p.B - 1);
-                const float* rp = res + ((tc * p.B + rowc) * 5) * QH + unit;
-#pragma unroll
-                for (int k = 0; k < 5; ++k) dst[r][k] = rp[k * QH];
-                dst[r][5] = Cst[(tc * p.B + rowc) * QH + unit];
-            }
+            for (int k = 0; k < 5; ++k) dst[k] = *(const f32x2*)(rp + k * QH);
+            dst[5] = *(const f32x2*)(Cst + (tc * p.B + rowc) * QH + unit0);
         };
         load_tape(T - 1, p.res2, p.C2, tq2);
         load_tape(T - 1, p.res1, p.C1, tq1);
         for (int t = T - 1; t >= 0; --t) {
             ++epoch;
             const unsigned par = (epoch & 1u) * Q_DZ_BYTES;
-            float tp[2][6], tp1[2][6];
+            f32x2 tp[6], tp1[6];
 #pragma unroll
-            for (int r = 0; r < 2; ++r)
-#pragma unroll
-                for (int k = 0; k < 6; ++k) { tp[r][k] = tq2[r][k]; tp1[r][k] = tq1[r][k]; }
+            for (int k = 0; k < 6; ++k) { tp[k] = tq2[k]; tp1[k] = tq1[k]; }
             load_tape(t - 1, p.res2, p.C2, tq2);
             load_tape(t - 1, p.res1, p.C1, tq1);
             // ================= head backward (every workgroup, its 16 sequences) =================
@@ -146,39 +146,33 @@ __global__ __launch_bounds__(256, 1) void mix_decoder_bwd_bf16_kernel(MixDecBwdP
             __syncthreads();   // barrier 1: dpre_p of the step is in LDS; every wave is past the previous step's LDS reads
             // ================= layer 2: gates backward for this lane's two cells, publish dz2 =================
             {
-                float dz[2][4];
+                f32x2 dz[4];
 #pragma unroll
-                for (int r = 0; r < 2; ++r) {
-                    const int row = b0 + my_row0 + r;
+                for (int u = 0; u < 2; ++u) {
                     float dhd = 0.f;
 #pragma unroll
-                    for (int o = 0; o < 8; ++o) dhd = fmaf(sDP[(my_row0 + r) * 8 + o], wd[o], dhd);
-                    const float ig = tp[r][0], fg = tp[r][1], gg = tp[r][2], og = tp[r][3], ct = tp[r][4], cp = tp[r][5];
+                    for (int o = 0; o < 8; ++o) dhd = fmaf(sDP[prow * 8 + o], wd[u][o], dhd);
+                    const float ig = tp[0][u], fg = tp[1][u], gg = tp[2][u], og = tp[3][u], ct = tp[4][u], cp = tp[5][u];
                     const float tc = tanh_f(ct);
-                    const float dh = dhd + dh2r[r];
-                    const float dct = dc2[r] + dh * og * (1.f - tc * tc);
-                    const bool lv = row < p.B;
-                    dz[r][0] = lv ? dct * gg * db_act_grad<ACT>(ig) : 0.f;
-                    dz[r][1] = lv ? dct * cp * db_act_grad<ACT>(fg) : 0.f;
-                    dz[r][2] = lv ? dct * ig * (1.f - gg * gg) : 0.f;
-                    dz[r][3] = lv ? dh * tc * db_act_grad<ACT>(og) : 0.f;
-                    dc2[r] = dct * fg;
+                    const float dh = dhd + dh2r[u];
+                    const float dct = dc2[u] + dh * og * (1.f - tc * tc);
+                    dz[0][u] = lv ? dct * gg * db_act_grad<ACT>(ig) : 0.f;
+                    dz[1][u] = lv ? dct * cp * db_act_grad<ACT>(fg) : 0.f;
+                    dz[2][u] = lv ? dct * ig * (1.f - gg * gg) : 0.f;
+                    dz[3][u] = lv ? dh * tc * db_act_grad<ACT>(og) : 0.f;
+                    dc2[u] = dct * fg;
                 }
                 unsigned dzp[4];
 #pragma unroll
-                for (int g = 0; g < 4; ++g) dzp[g] = pack_bf16(dz[0][g], dz[1][g]);
-                q_dz_publish(rs, LAYER_BYTES + par, my_row0, unit, dzp, epoch, sDZ, ticket.same_xcd);
+                for (int g = 0; g < 4; ++g) dzp[g] = pack_bf16(dz[g][0], dz[g][1]);
+                q_dz_publish2(rs, LAYER_BYTES + par, prow, unit0, dzp, epoch, sDZ, ticket.same_xcd);
+                if (lv) {
+                    float* zp = p.DZ2 + ((size_t)t * p.B + row) * H4 + unit0;
 #pragma unroll
-                for (int r = 0; r < 2; ++r) {
-                    const int row = b0 + my_row0 + r;
-                    if (row < p.B) {
-                        float* zp = p.DZ2 + ((size_t)t * p.B + row) * H4 + unit;
-#pragma unroll
-                        for (int g = 0; g < 4; ++g) zp[g * QH] = dz[r][g];
-                    }
+                    for (int g = 0; g < 4; ++g) *(f32x2*)(zp + g * QH) = dz[g];
                 }
             }
-            if (!q_dz_gather(rs, LAYER_BYTES + par, slice, tid, epoch, sDZ, p.status)) sFlag[1] = 1;
+            if (!q_dz_gather2(rs, LAYER_BYTES + par, slice, tid, epoch, sDZ, p.status)) sFlag[1] = 1;
             __syncthreads();   // barrier 2: the whole dz2 tile is in LDS
             if (sFlag[1]) { aborted = true; break; }
             // ================= dh2_{t-1} and dh1_t of the own 32 units: this wave's gate =================
@@ -205,46 +199,42 @@ __global__ __launch_bounds__(256, 1) void mix_decoder_bwd_bf16_kernel(MixDecBwdP
                     }
             }
             __syncthreads();   // barrier 3: partial tiles in LDS; every wave is done reading the dz2 tile
-            float dh1in[2];
+            f32x2 dh1in;
+            {
+                const float* qa = sRedA + prow * DRS + pu;
+                const float* qb = sRedB + prow * DRS + pu;
 #pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                const float* qa = sRedA + (my_row0 + r) * DRS + ul;
-                const float* qb = sRedB + (my_row0 + r) * DRS + ul;
-                dh2r[r] = (qa[0] + qa[QBT * DRS]) + (qa[2 * QBT * DRS] + qa[3 * QBT * DRS]);
-                dh1in[r] = (qb[0] + qb[QBT * DRS]) + (qb[2 * QBT * DRS] + qb[3 * QBT * DRS]);
+                for (int u = 0; u < 2; ++u) {
+                    dh2r[u] = (qa[u] + qa[QBT * DRS + u]) + (qa[2 * QBT * DRS + u] + qa[3 * QBT * DRS + u]);
+                    dh1in[u] = (qb[u] + qb[QBT * DRS + u]) + (qb[2 * QBT * DRS + u] + qb[3 * QBT * DRS + u]);
+                }
             }
             // ================= layer 1: gates backward, publish dz1 =================
             {
-                float dz[2][4];
+                f32x2 dz[4];
 #pragma unroll
-                for (int r = 0; r < 2; ++r) {
-                    const int row = b0 + my_row0 + r;
-                    const float ig = tp1[r][0], fg = tp1[r][1], gg = tp1[r][2], og = tp1[r][3], ct = tp1[r][4], cp = tp1[r][5];
+                for (int u = 0; u < 2; ++u) {
+                    const float ig = tp1[0][u], fg = tp1[1][u], gg = tp1[2][u], og = tp1[3][u], ct = tp1[4][u], cp = tp1[5][u];
                     const float tc = tanh_f(ct);
-                    const float dh = dh1in[r] + dh1r[r];
-                    const float dct = dc1[r] + dh * og * (1.f - tc * tc);
-                    const bool lv = row < p.B;
-                    dz[r][0] = lv ? dct * gg * db_act_grad<ACT>(ig) : 0.f;
-                    dz[r][1] = lv ? dct * cp * db_act_grad<ACT>(fg) : 0.f;
-                    dz[r][2] = lv ? dct * ig * (1.f - gg * gg) : 0.f;
-                    dz[r][3] = lv ? dh * tc * db_act_grad<ACT>(og) : 0.f;
-                    dc1[r] = dct * fg;
+                    const float dh = dh1in[u] + dh1r[u];
+                    const float dct = dc1[u] + dh * og * (1.f - tc * tc);
+                    dz[0][u] = lv ? dct * gg * db_act_grad<ACT>(ig) : 0.f;
+                    dz[1][u] = lv ? dct * cp * db_act_grad<ACT>(fg) : 0.f;
+                    dz[2][u] = lv ? dct * ig * (1.f - gg * gg) : 0.f;
+                    dz[3][u] = lv ? dh * tc * db_act_grad<ACT>(og) : 0.f;
+                    dc1[u] = dct * fg;
                 }
                 unsigned dzp[4];
 #pragma unroll
-                for (int g = 0; g < 4; ++g) dzp[g] = pack_bf16(dz[0][g], dz[1][g]);
-                q_dz_publish(rs, par, my_row0, unit, dzp, epoch, sDZ, ticket.same_xcd);
+                for (int g = 0; g < 4; ++g) dzp[g] = pack_bf16(dz[g][0], dz[g][1]);
+                q_dz_publish2(rs, par, prow, unit0, dzp, epoch, sDZ, ticket.same_xcd);
+                if (lv) {
+                    float* zp = p.DZ1 + ((size_t)t * p.B + row) * H4 + unit0;
 #pragma unroll
-                for (int r = 0; r < 2; ++r) {
-                    const int row = b0 + my_row0 + r;
-                    if (row < p.B) {
-                        float* zp = p.DZ1 + ((size_t)t * p.B + row) * H4 + unit;
-#pragma unroll
-                        for (int g = 0; g < 4; ++g) zp[g * QH] = dz[r][g];
-                    }
+                    for (int g = 0; g < 4; ++g) *(f32x2*)(zp + g * QH) = dz[g];
                 }
             }
-            if (!q_dz_gather(rs, par, slice, tid, epoch, sDZ, p.status)) sFlag[2] = 1;
+            if (!q_dz_gather2(rs, par, slice, tid, epoch, sDZ, p.status)) sFlag[2] = 1;
             __syncthreads();   // barrier 4: the whole dz1 tile is in LDS
             if (sFlag[2]) { aborted = true; break; }
             // ================= dh1_{t-1} of the own 32 units and dx_t (all O outputs, every workgroup) =================
@@ -270,10 +260,10 @@ __global__ __launch_bounds__(256, 1) void mix_decoder_bwd_bf16_kernel(MixDecBwdP
                 }
             }
             __syncthreads();   // barrier 5: partial tiles in LDS; every wave is done with the dz1 tile and with sDX of this step
+            {
+                const float* qa = sRedA + prow * DRS + pu;
 #pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                const float* qa = sRedA + (my_row0 + r) * DRS + ul;
-                dh1r[r] = (qa[0] + qa[QBT * DRS]) + (qa[2 * QBT * DRS] + qa[3 * QBT * DRS]);
+                for (int u = 0; u < 2; ++u) dh1r[u] = (qa[u] + qa[QBT * DRS + u]) + (qa[2 * QBT * DRS + u] + qa[3 * QBT * DRS + u]);
             }
             if (ho < 8) {
                 const float* qx = sRedX + hrow * 17 + ho;
@@ -283,17 +273,11 @@ __global__ __launch_bounds__(256, 1) void mix_decoder_bwd_bf16_kernel(MixDecBwdP
             // its own barrier here; the same barrier orders these reads of sRedA / sRedX before their next writes.
             __syncthreads();   // barrier 6: dx_t is in LDS
         }
-        if (!aborted) {
-#pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                const int row = b0 + my_row0 + r;
-                if (row < p.B) {
-                    p.dh1_0[(size_t)row * QH + unit] = dh1r[r];
-                    p.dc1_0[(size_t)row * QH + unit] = dc1[r];
-                    p.dh2_0[(size_t)row * QH + unit] = dh2r[r];
-                    p.dc2_0[(size_t)row * QH + unit] = dc2[r];
-                }
-            }
+        if (!aborted && lv) {
+            *(f32x2*)(p.dh1_0 + (size_t)row * QH + unit0) = dh1r;
+            *(f32x2*)(p.dc1_0 + (size_t)row * QH + unit0) = dc1;
+            *(f32x2*)(p.dh2_0 + (size_t)row * QH + unit0) = dh2r;
+            *(f32x2*)(p.dc2_0 + (size_t)row * QH + unit0) = dc2;
         }
     }
     xch_settle(p.status, ticket, (unsigned)p.epoch_span);
@@ -310,6 +294,11 @@ int mix_decoder_bwd_bf16_launch(MixDecBwdParams p, const float* K2, int act, voi
     if ((size_t)p.num_groups * 4 * Q_DZ_BYTES > kXchBytes - kHelloBytes) { set_error("mix_decoder_bwd_bf16: granule area too small"); return FOV_ERR_WORKSPACE; }
     if ((((uintptr_t)K2) | ((uintptr_t)p.R1) | ((uintptr_t)p.R2) | ((uintptr_t)p.K1)) & 15) {
         set_error("mix_decoder_bwd_bf16: kernels must be 16-byte aligned");
+        return FOV_ERR_INVALID;
+    }
+    if ((((uintptr_t)p.res1) | ((uintptr_t)p.res2) | ((uintptr_t)p.C1) | ((uintptr_t)p.C2) | ((uintptr_t)p.DZ1) | ((uintptr_t)p.DZ2) |
+         ((uintptr_t)p.dh1_0) | ((uintptr_t)p.dc1_0) | ((uintptr_t)p.dh2_0) | ((uintptr_t)p.dc2_0)) & 7) {   // 8-byte tape accesses
+        set_error("mix_decoder_bwd_bf16: tapes and state gradients must be 8-byte aligned");
         return FOV_ERR_INVALID;
     }
     p.status = (unsigned*)workspace;
