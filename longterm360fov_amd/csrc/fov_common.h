@@ -76,7 +76,7 @@ int device_cu_count();                               // CUs of the current devic
 // getenv results cached at first use (fov_reload_env re-reads them): nothing on a launch path calls getenv
 struct EnvKnobs {
     int force_safe_exchange, two_launches, resident_limit;
-    int bwd_stepped, no_wgrad_fusion, no_dx_fusion, bwd_groups4, gemm_bf16_split, gemm_bf16_noremap, gemm_bf16_shallow;   // experiment switches (tools/)
+    int bwd_stepped, no_wgrad_fusion, no_dx_fusion, bwd_groups4, gemm_bf16_split, gemm_bf16_noremap, gemm_bf16_shallow, no_wgrad_group;   // experiment switches (tools/)
     int gemm_variant, gemm_split;   // FOV_GEMM_VARIANT / FOV_GEMM_SPLIT: tile shape / K slices of the fp32 GEMM forced (experiments)
     int no_wide16;       // FOV_NO_WIDE16=1: width-512 layers stay on the 16-workgroup form (tests / A-B timing)
     int no_cell_patch;   // FOV_NO_CELL_PATCH=1: ConvLSTM2D steps stay on the implicit-GEMM cell (tests compare the two forms)
@@ -211,6 +211,9 @@ bool bwd_cluster_shape_ok(int H);
 bool wide16_pair_shape(int B, int T, int F, int H);
 int launch_wide16_pair(const LstmParams& a, const LstmParams& b, hipStream_t stream);
 // lstm_bwd16.hip: BPTT recurrence with 16 / 32 units per workgroup (fp32): width 512, and 128 / 256 at small batches
+bool wgrad_group_takes(int B, int T, int H);   // wgrad_group.hip: few rows - every (product, output tile) one workgroup, one launch
+int wgrad_group_layers(int L, const float* const* x, const int* F, const float* const* hs, const float* const* h0, const float* const* dz,
+                       float* const* dK, float* const* dR, float* const* db, int B, int T, int H, int accumulate, hipStream_t stream);
 bool bwd16_pair_shape(int B, int T, int H);
 int launch_bwd16_pair(const float* R2, const float* K2, const float* reserve2, const float* c0_2, const float* dhs2, const float* dhT2,
                       const float* dcT2, float* dz2, float* dh0_2, float* dc0_2, float* db_part2, const float* R1, const float* reserve1,

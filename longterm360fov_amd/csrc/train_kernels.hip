@@ -1558,6 +1558,11 @@ static int lstm_seq_weight_products(const float* x, const float* hs, const float
     return FOV_OK;
 }
 
+// few rows (batch x time <= ~1000), fp32: all of a layer's weight gradients by wgrad_group.hip - one launch, no split, no reduce
+static bool lstm_seq_wgrad_grouped(int bf16, int B, int T, int H, const float* dz, float* dK, float* dR, float* db) {
+    return !bf16 && wgrad_group_takes(B, T, H) && (dK || dR) && (((uintptr_t)dz) & 15) == 0 && (!db || dK || dR);
+}
+
 static void lstm_seq_wgrad_fusion(const float* x, const float* hs, const float* dz, float* dK, float* dR, float* db, int T, int F, int H,
                                   bool* fuse_kr, bool* fuse_r) {
     const int N4 = 4 * H;
@@ -1580,6 +1585,8 @@ int lstm_seq_wgrad(const float* x, const float* hs, const float* h0, const float
         }
         return FOV_OK;
     }
+    if (lstm_seq_wgrad_grouped(bf16, B, T, H, dz, dK, dR, db))
+        return wgrad_group_layers(1, &x, &F, &hs, &h0, &dz, &dK, &dR, &db, B, T, H, accumulate, stream);
     bool fuse_kr, fuse_r;
     lstm_seq_wgrad_fusion(x, hs, dz, dK, dR, db, T, F, H, &fuse_kr, &fuse_r);
     return lstm_seq_weight_products(x, hs, h0, dz, dK, dR, db, B, T, F, H, accumulate, bf16, fuse_kr, fuse_r, false, scratch,
@@ -1607,7 +1614,7 @@ int lstm_seq_bwd(const float* x, const float* K, const float* R, const float* h0
     }
     const bool wide16 = !bf16 && bwd16_takes(B, H) && (((uintptr_t)R) & 15) == 0;   // width 512, small batches at 128 / 256: lstm_bwd16.hip
     const bool persistent = (bwd_cluster_shape_ok(H) || wide16) && !env_knobs().bwd_stepped;
-    bool fuse_kr = false, fuse_r = false, dx_in_kernel = false;
+    bool fuse_kr = false, fuse_r = false, dx_in_kernel = false, grouped = false;
     const size_t head = (kStatusBytes + kXchBytes) / sizeof(float);
     float* dh_rec = ws + head;
     float* dc = dh_rec + (size_t)B * H;
@@ -1623,7 +1630,9 @@ int lstm_seq_bwd(const float* x, const float* K, const float* R, const float* h0
         // below gives all three (no bias partials from the kernel, no column-sum launches); F too narrow for a row tile:
         // [h_{t-1} | 1]^T dz gives dR and db
         lstm_seq_wgrad_fusion(x, hs, dz, dK, dR, db, T, F, H, &fuse_kr, &fuse_r);
-        float* db_part = (db && !fuse_kr && !fuse_r) ? scratch : nullptr;
+        grouped = lstm_seq_wgrad_grouped(bf16, B, T, H, dz, dK, dR, db);
+        if (grouped) fuse_kr = fuse_r = false;
+        float* db_part = (db && !fuse_kr && !fuse_r && !grouped) ? scratch : nullptr;
         // bf16, 256-wide input (the stacked layer): the BPTT kernel forms dx = dz K^T from the dz tile it has gathered anyway
         dx_in_kernel = bf16 && dx && F == 256 && (((uintptr_t)K) & 15) == 0 && !env_knobs().no_dx_fusion;
         // H = 256: groups of eight workgroups fill the chip up to 32 tiles (the 4-group kernel leaves half of it idle
@@ -1670,8 +1679,9 @@ int lstm_seq_bwd(const float* x, const float* K, const float* R, const float* h0
         if (dh0) { e = hipMemcpyAsync(dh0, dh_rec, bh, hipMemcpyDeviceToDevice, stream); if (e != hipSuccess) { set_error("dh0 copy"); return FOV_ERR_LAUNCH; } }
         if (dc0) { e = hipMemcpyAsync(dc0, dc, bh, hipMemcpyDeviceToDevice, stream); if (e != hipSuccess) { set_error("dc0 copy"); return FOV_ERR_LAUNCH; } }
     }
-    int rc = lstm_seq_weight_products(x, hs, h0, dz, dK, dR, db, B, T, F, H, accumulate, bf16, fuse_kr, fuse_r, /*db_done=*/persistent,
-                                      scratch, scratch_floats, stream);
+    int rc = grouped ? wgrad_group_layers(1, &x, &F, &hs, &h0, &dz, &dK, &dR, &db, B, T, H, accumulate, stream)
+                     : lstm_seq_weight_products(x, hs, h0, dz, dK, dR, db, B, T, F, H, accumulate, bf16, fuse_kr, fuse_r, /*db_done=*/persistent,
+                                                scratch, scratch_floats, stream);
     if (rc) return rc;
     if (dx && !dx_in_kernel) {   // dx (B*T,F) = dz . K^T : A(m,k) = dz[m][k], B(k,n) = K[n][k]
         const long BT = (long)B * T;
@@ -1710,12 +1720,26 @@ int lstm_stack2_bwd(const float* x, const float* R1, const float* K2, const floa
     bool kr1, r1, kr2, r2;
     lstm_seq_wgrad_fusion(x, hs1, dz1, dK1, dR1, db1, T, F, H, &kr1, &r1);
     lstm_seq_wgrad_fusion(hs1, hs2, dz2, dK2, dR2, db2, T, H, H, &kr2, &r2);
+    // few rows: ALL weight gradients of both layers in one launch behind the recurrences (wgrad_group.hip)
+    const bool grouped = lstm_seq_wgrad_grouped(0, B, T, H, dz1, dK1, dR1, db1) && lstm_seq_wgrad_grouped(0, B, T, H, dz2, dK2, dR2, db2);
+    if (grouped) kr1 = r1 = kr2 = r2 = true;      // (no bias partials from the kernel)
     float* db_part1 = (db1 && !kr1 && !r1) ? dbp1 : nullptr;
     float* db_part2 = (db2 && !kr2 && !r2) ? dbp2 : nullptr;
     int rc = launch_bwd16_pair(R2, K2, res2, c0_2, dhs2, dhT2, dcT2, dz2, dh0_2 ? dh0_2 : spare, dc0_2 ? dc0_2 : spare + bh, db_part2, R1,
                                res1, c0_1, dhT1, dcT1, dz1, dh0_1 ? dh0_1 : spare + 2 * bh, dc0_1 ? dc0_1 : spare + 3 * bh, db_part1, B,
                                T, act, ws, stream);
     if (rc) return rc;
+    if (grouped) {
+        const float* xs[2] = {x, hs1};
+        const int Fs[2] = {F, H};
+        const float* hss[2] = {hs1, hs2};
+        const float* h0s[2] = {h0_1, h0_2};
+        const float* dzs[2] = {dz1, dz2};
+        float* dKs[2] = {dK1, dK2};
+        float* dRs[2] = {dR1, dR2};
+        float* dbs[2] = {db1, db2};
+        return wgrad_group_layers(2, xs, Fs, hss, h0s, dzs, dKs, dRs, dbs, B, T, H, accumulate, stream);
+    }
     for (int l = 2; l >= 1; --l) {
         float* part = l == 2 ? db_part2 : db_part1;
         float* db = l == 2 ? db2 : db1;
