@@ -988,7 +988,8 @@ def main():
     # scalar all-reduce, nothing more.  Ten data-parallel training steps of configs[2] (512 sequences per rank, one SUM all-reduce
     # of the 6.7 MB flat gradient buffer per step - given_others_gt_mean_var_seq2seq.py:494-506 under DP) ride along AFTER the
     # timed region, so that the same run also says what the gradient all-reduce costs over xGMI.  Reported under `extra`.
-    extra = dp_probe(args, rank, world) if (use_dist and world > 1 and not args.no_dp_probe) else None
+    probe_on = use_dist and world > 1 and not args.no_dp_probe
+    extra = None
 
     result = None
     if rank == 0:
@@ -1056,10 +1057,27 @@ def main():
                        "max_abs_err_vs_torch_cpu": None if cpu_out is None else float(np.abs(out.cpu().numpy() - cpu_out).max())},
             "cpu_baseline": cpu,
         }
-        if extra is not None:
-            result["extra"] = extra
         if cpu:
             result["speedup_vs_cpu_baseline"] = value / cpu["value"]
+    if probe_on:
+        # The probe runs AFTER rank 0 has its line ready and under a watchdog: if a collective of the probe never returns, every
+        # rank leaves after `limit` seconds and rank 0 still prints the headline line (with the failure under `extra`).
+        import threading
+        limit = int(os.environ.get("FOV_DP_PROBE_LIMIT_S", "150"))
+
+        def bail():
+            if rank == 0 and result is not None:
+                result["extra"] = {"error": "data-parallel probe did not finish within %d s" % limit}
+                print(json.dumps(result), flush=True)
+            os._exit(0)
+        timer = threading.Timer(limit, bail)
+        timer.daemon = True
+        timer.start()
+        extra = dp_probe(args, rank, world)
+        timer.cancel()
+    if rank == 0:
+        if extra is not None:
+            result["extra"] = extra
         print(json.dumps(result), flush=True)
     if use_dist:
         dist.barrier()
