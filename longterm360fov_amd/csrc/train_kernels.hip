@@ -771,8 +771,10 @@ __global__ __launch_bounds__(256) void act_fwd_kernel(const float* x, float* y, 
 __global__ __launch_bounds__(256) void gauss_nll_kernel(const float* __restrict__ mu, const float* __restrict__ var,
                                                         const float* __restrict__ y, float* __restrict__ part,
                                                         float* __restrict__ dmu, float* __restrict__ dvar, int B, int Ty,
-                                                        int fps, float scale) {
+                                                        int fps, float scale, unsigned* __restrict__ ticket, float* __restrict__ loss_out,
+                                                        float loss_scale) {
     __shared__ float red[256][7];
+    __shared__ int is_last;
     const int b = blockIdx.x;
     const int per = Ty * fps * 3;
     float acc[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // loss, dmu[3], dvar[3]
@@ -797,10 +799,35 @@ __global__ __launch_bounds__(256) void gauss_nll_kernel(const float* __restrict_
             for (int k = 0; k < 7; ++k) red[threadIdx.x][k] += red[threadIdx.x + s_][k];
         __syncthreads();
     }
-    if (threadIdx.x == 0) part[b] = red[0][0];
     if (threadIdx.x < 3) {
         dmu[b * 3 + threadIdx.x] = red[0][1 + threadIdx.x] * scale / (float)B;
         dvar[b * 3 + threadIdx.x] = red[0][4 + threadIdx.x] * scale / (float)B;
+    }
+    if (threadIdx.x == 0) {
+        if (ticket) {
+            __hip_atomic_store(part + b, red[0][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __threadfence();
+            is_last = atomicAdd(ticket, 1u) == gridDim.x - 1u;
+        } else {
+            part[b] = red[0][0];
+            is_last = 0;
+        }
+    }
+    __syncthreads();
+    if (is_last) {   // the arithmetic of sum_scale_kernel, by the block that finished last (round 4: one launch less per step)
+        __threadfence();
+        float a = 0.f;
+        for (int i = threadIdx.x; i < B; i += 256) a += __hip_atomic_load(part + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        red[threadIdx.x][0] = a;
+        __syncthreads();
+        for (int m = 128; m >= 1; m >>= 1) {
+            if ((int)threadIdx.x < m) red[threadIdx.x][0] += red[threadIdx.x + m][0];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            loss_out[0] = red[0][0] * loss_scale;
+            __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 }
 
@@ -1899,9 +1926,11 @@ int gauss_nll_grad(const float* mu, const float* var, const float* y, float* los
                    int fps, float scale, float* scratch, size_t scratch_floats, hipStream_t stream) {
     if (B <= 0) return FOV_OK;
     if ((size_t)B > scratch_floats) { set_error("gauss_nll_grad: scratch too small"); return FOV_ERR_WORKSPACE; }
-    hipLaunchKernelGGL(gauss_nll_kernel, dim3(B), dim3(256), 0, stream, mu, var, y, scratch, dmu, dvar, B, Ty, fps, scale);
+    unsigned* ticket = loss ? next_loss_ticket() : nullptr;
+    hipLaunchKernelGGL(gauss_nll_kernel, dim3(B), dim3(256), 0, stream, mu, var, y, scratch, dmu, dvar, B, Ty, fps, scale, ticket, loss,
+                       scale / (float)B);
     int rc = check_launch("gauss_nll");
-    if (rc || !loss) return rc;
+    if (rc || !loss || ticket) return rc;
     hipLaunchKernelGGL(sum_scale_kernel, dim3(1), dim3(256), 0, stream, scratch, loss, B, scale / (float)B);
     return check_launch("sum_scale");
 }
