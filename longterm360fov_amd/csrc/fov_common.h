@@ -76,7 +76,7 @@ int device_cu_count();                               // CUs of the current devic
 // getenv results cached at first use (fov_reload_env re-reads them): nothing on a launch path calls getenv
 struct EnvKnobs {
     int force_safe_exchange, two_launches, resident_limit;
-    int bwd_stepped, no_wgrad_fusion, no_dx_fusion, bwd_groups4, gemm_bf16_split, gemm_bf16_noremap, gemm_bf16_shallow, no_wgrad_group;   // experiment switches (tools/)
+    int bwd_stepped, no_wgrad_fusion, no_dx_fusion, bwd_groups4, gemm_bf16_split, gemm_bf16_noremap, gemm_bf16_shallow, no_wgrad_group, dbg_trace;   // experiment switches (tools/)
     int gemm_variant, gemm_split;   // FOV_GEMM_VARIANT / FOV_GEMM_SPLIT: tile shape / K slices of the fp32 GEMM forced (experiments)
     int no_wide16;       // FOV_NO_WIDE16=1: width-512 layers stay on the 16-workgroup form (tests / A-B timing)
     int no_cell_patch;   // FOV_NO_CELL_PATCH=1: ConvLSTM2D steps stay on the implicit-GEMM cell (tests compare the two forms)

@@ -240,7 +240,12 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
     int f_left = tend - tbeg;   // tiles not fetched yet
     auto fetch = [&]() {
         const int kmax = g.KI - f_kt * GBK;   // >= 16 except for the row's last tile
-        sa.fetch(a_blk + (long)f_ko * a_sko + (long)(f_kt * GBK - (a_period > 0 ? 1 : 0)) * a_ski, kmax, a_ski, a_period, a_inc);
+        // The shifted operand's phases advance only towards a tile that is really fetched next: the extra fetch of the final
+        // iteration re-reads the LAST tile and must mask the same elements again.  (Round 4: with advanced phases it read
+        // element k = 0 for real - the row BEFORE the tensor, `base` points one row back - whenever the slice's only tile
+        // starts at k = 0, i.e. batch x time <= 16: a memory access fault when the tape begins a mapped region.)
+        const int inc_now = f_left > 1 ? a_inc : 0;
+        sa.fetch(a_blk + (long)f_ko * a_sko + (long)(f_kt * GBK - (a_period > 0 ? 1 : 0)) * a_ski, kmax, a_ski, a_period, inc_now);
         sb.fetch(b_blk + (long)f_ko * g.b_sko + (long)(f_kt * GBK) * g.b_ski, kmax, g.b_ski);
         // advance (scalar state only); after the last tile the position stays, so the extra fetch of the final
         // iteration re-reads that tile instead of branching around the loads
@@ -963,6 +968,7 @@ __global__ __launch_bounds__(256) void rmsprop_tf_kernel(float* __restrict__ p, 
 // host helpers
 // ---------------------------------------------------------------------------------------
 static int check_launch(const char* what) {
+    if (env_knobs().dbg_trace) fprintf(stderr, "[fov trace] launched: %s\n", what);   // FOV_DBG_TRACE=1 (with HIP_LAUNCH_BLOCKING=1: the last line names the launch BEFORE a faulting one)
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("%s launch: %s", what, hipGetErrorString(e)); return FOV_ERR_LAUNCH; }
     return FOV_OK;
@@ -1084,6 +1090,9 @@ int gemm_f32(GemmArgs g, int accumulate, float* scratch, size_t scratch_floats, 
     g.grid_m = (g.M + BM - 1) / BM;
     g.xcd_remap = split >= 8 ? 1 : 0;
     const dim3 grid = g.xcd_remap ? dim3((unsigned)(8 * ((split + 7) / 8) * g.grid_n * g.grid_m)) : dim3(g.grid_n, g.grid_m, split);
+    if (env_knobs().dbg_trace)
+        fprintf(stderr, "[fov trace] gemm_f32 next: M=%d N=%d KO=%d KI=%d variant=%d amode=%d bmode=%d split=%d a2=%d periods=%d/%d bias=%d add_c=%d\n", g.M, g.N,
+                g.KO, g.KI, variant, amode, bmode, split, g.a2 ? 1 : 0, g.a_period, g.a2_period, g.bias_row, g.add_c);
 #define FOV_GEMM_LAUNCH(MI_, NI_, WM_, A_, B_) \
     hipLaunchKernelGGL((gemm_f32_kernel<MI_, NI_, WM_, A_, B_>), grid, dim3(256), 0, stream, g)
 #define FOV_GEMM_MODES(MI_, NI_, WM_)                                                            \
@@ -1664,6 +1673,7 @@ int lstm_seq_bwd(const float* x, const float* K, const float* R, const float* h0
         dx_in_kernel = bf16 && dx && F == 256 && (((uintptr_t)K) & 15) == 0 && !env_knobs().no_dx_fusion;
         // H = 256: groups of eight workgroups fill the chip up to 32 tiles (the 4-group kernel leaves half of it idle
         // at 512 sequences); bf16 operands exist in the 8-group kernel only
+        if (env_knobs().dbg_trace) fprintf(stderr, "[fov trace] lstm_seq_bwd B=%d T=%d F=%d H=%d wide16=%d fuse_kr=%d fuse_r=%d grouped=%d acc=%d: recurrence next\n", B, T, F, H, (int)wide16, (int)fuse_kr, (int)fuse_r, (int)grouped, accumulate);
         int rc = wide16 ? launch_bwd16(R, reserve, c0, dhs, dhT, dcT, dz, dh0 ? dh0 : dh_rec, dc0 ? dc0 : dc, db_part, B, T, H, act, ws, stream)
                  : (bf16 || (bwd8_preferred(B, H) && !env_knobs().bwd_groups4))
                      ? launch_bwd8(R, reserve, c0, dhs, dhT, dcT, dz, dh0 ? dh0 : dh_rec, dc0 ? dc0 : dc, db_part, B, T, act, bf16, ws, stream,
@@ -1671,6 +1681,7 @@ int lstm_seq_bwd(const float* x, const float* K, const float* R, const float* h0
                      : launch_bwd_cluster(R, reserve, c0, dhs, dhT, dcT, dz, dh0 ? dh0 : dh_rec, dc0 ? dc0 : dc, db_part, B, T, H,
                                           act, ws, stream);
         if (rc) return rc;
+        if (env_knobs().dbg_trace) fprintf(stderr, "[fov trace] lstm_seq_bwd: recurrence done\n");
         if (db_part) {
             const int tiles = (B + 15) / 16;
             if ((size_t)tiles * 4 * H + (size_t)256 * 4 * H > scratch_floats) { set_error("lstm_seq_bwd: scratch too small for db"); return FOV_ERR_WORKSPACE; }
