@@ -751,3 +751,49 @@ def test_launch_contract_resident_limit_and_epoch_rezero():
     assert hdr[3] < 1000, "epoch base %d: the launch path did not re-zero the workspace" % hdr[3]
     ws.check()
     assert torch.equal(out0, out1)
+
+
+# ---------------------------------------------------------------------------------------
+# Round 4: the same call at small batches runs on H / 16 workgroups per tile (lstm_wide16.hip: wide16_s2s_kernel)
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("H,B,T_in,T_out,F_enc,F_dec,act", [
+    (128, 32, 10, 10, 90, 6, "sigmoid"),        # configs[0]
+    (128, 1, 1, 1, 90, 6, "hard_sigmoid"), (128, 128, 3, 2, 96, 8, "sigmoid"), (128, 17, 0, 4, 90, 6, "sigmoid"),
+    (256, 33, 2, 3, 6, 1, "hard_sigmoid"), (256, 100, 5, 1, 90, 6, "sigmoid"), (256, 16, 7, 5, 33, 3, "sigmoid"),
+    (128, 50, 4, 0, 90, 6, "sigmoid"),          # no decoder step: the call returns an empty prediction, the states are the encoder's
+])
+def test_reference_batch_decode_on_sixteen_units_per_workgroup(H, B, T_in, T_out, F_enc, F_dec, act):
+    """fov_seq2seq_decode_fwd at <= 128 sequences, impl = auto: encoder + free-running decoder in one launch on H / 16 workgroups
+    per tile, the Dense formed from the gathered tile (FoV_seq2seq.py:154-178).  Against the fp64 oracle, against the VALU
+    kernel, final states against the teacher-free oracle rollout; FOV_NO_WIDE16=1 (the H / 64 form) gives the same numbers to
+    rounding."""
+    import os
+    ops = _ops()
+    from longterm360fov_amd import _lib
+    w = O.init_seq2seq(3 + H + B, F_enc=F_enc, F_dec=F_dec, H=H, bias_noise=0.1)
+    rng = np.random.default_rng(B + T_in)
+    enc = rng.uniform(-1, 1, (B, T_in, F_enc)).astype(np.float32)
+    dec0 = rng.uniform(-1, 1, (B, 1, F_dec)).astype(np.float32)
+    ws = ops.Workspace()
+    out = ops.seq2seq_decode(dev(enc), dev(dec0), devw(w), T_out, act=act, impl="auto", workspace=ws)
+    ws.check()
+    assert tuple(out.shape) == (B, T_out, F_dec)
+    if T_out == 0:
+        return
+    ref = O.seq2seq_decode(enc.astype(np.float64), dec0.astype(np.float64), f64(w), T_out, act)
+    assert_parity(out, ref, "wide16 decode H%d B%d %d->%d F%d/%d %s" % (H, B, T_in, T_out, F_enc, F_dec, act))
+    gen = ops.seq2seq_decode(dev(enc), dev(dec0), devw(w), T_out, act=act, impl="generic")
+    assert float((gen - out).abs().max()) < 5e-6
+    # twice on the same workspace (epoch tags continue): bit-identical
+    again = ops.seq2seq_decode(dev(enc), dev(dec0), devw(w), T_out, act=act, impl="auto", workspace=ws)
+    ws.check()
+    assert torch.equal(again, out)
+    os.environ["FOV_NO_WIDE16"] = "1"
+    _lib.lib().fov_reload_env()
+    try:
+        old = ops.seq2seq_decode(dev(enc), dev(dec0), devw(w), T_out, act=act, impl="auto", workspace=ws)
+        ws.check()
+    finally:
+        del os.environ["FOV_NO_WIDE16"]
+        _lib.lib().fov_reload_env()
+    assert float((old - out).abs().max()) < 5e-6

@@ -1774,7 +1774,8 @@ def test_others_future_convlstm_model_gradients_and_fit(H, B, U, fps, T_in, T_ou
     assert float(((p1 - tgt) ** 2).mean()) < l0
 
 
-@pytest.mark.parametrize("B,T,F,state,upstream", [(32, 10, 90, True, False), (12, 3, 90, False, True), (17, 1, 6, True, True), (48, 5, 30, False, False)])
+@pytest.mark.parametrize("B,T,F,state,upstream", [(32, 10, 90, True, False), (12, 3, 90, False, True), (17, 1, 6, True, True), (48, 5, 30, False, False),
+                                                  (1, 2, 90, False, False), (32, 12, 33, True, True)])
 def test_two_layer_bptt_one_launch_equals_two_calls(B, T, F, state, upstream):
     """fov_lstm_stack2_bwd (both recurrences and dx = dz2 . K2^T between them as three roles of one launch, lstm.py:218-240 under
     its train_op) against two fov_lstm_seq_bwd calls: dz of both layers, state gradients, every weight gradient.  The only
