@@ -54,9 +54,14 @@ __device__ __forceinline__ qu32x4 load_bfrag(const float* __restrict__ W, int ld
 // hardware, so every load is UNCONDITIONAL and hipcc keeps a whole batch in flight.  (Written as `k < nrows ? W[..] :
 // 0` each load sits in its own exec-masked branch with an s_waitcnt vmcnt(0) behind it: 2 500 cycles per fragment,
 // 81 000 cycles = 38 us for the 32 fragments of a layer kernel - tools/stamp_bf16_layer.py.)
-template <int NKB, int CHMAX = 4>
+// `behind_first_batch()` runs once, between the requests of the first batch and its packing: the place of
+// xch_arrive_commit (xch_common.h) in a kernel's prologue.
+struct QNothing {
+    __device__ __forceinline__ void operator()() const {}
+};
+template <int NKB, int CHMAX = 4, class Behind = QNothing>
 __device__ __forceinline__ void load_weight_set(qu32x4 (&w)[NKB][2], const float* __restrict__ W, int ld, int nrows, int g4, int col0,
-                                                int col1) {
+                                                int col1, Behind behind_first_batch = Behind()) {
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(W), 0, nrows * ld * 4, 0x00020000);
     constexpr int CH = NKB < CHMAX ? NKB : CHMAX;   // k-blocks per batch: 16*CH loads in flight (CHMAX 2: kernels held to 256 registers)
     static_assert(NKB % CH == 0, "NKB must be a multiple of the batch");
@@ -71,6 +76,7 @@ __device__ __forceinline__ void load_weight_set(qu32x4 (&w)[NKB][2], const float
                 v[i][0][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (row + (unsigned)col0) * 4u, 0, 0));
                 v[i][1][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (row + (unsigned)col1) * 4u, 0, 0));
             }
+        if (c == 0) behind_first_batch();
 #pragma unroll
         for (int i = 0; i < CH; ++i)
 #pragma unroll

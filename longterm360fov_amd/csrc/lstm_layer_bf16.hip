@@ -19,15 +19,14 @@ namespace fov {
 constexpr int QSTAMP_SLOTS = 12;
 constexpr int QSTAMP_STEPS = 32;
 __device__ unsigned long long g_q_stamps[QSTAMP_STEPS][QSTAMP_SLOTS];
+// branch-free and LDS-buffered (round 4, as lstm_bwd8.hip's B8_STAMP): a global store per stamp sat in the wave's vmcnt queue and
+// added ~2 000 cycles to every s_waitcnt vmcnt(0) behind it; a stamp inside `if (stamp_on)` split the basic block and let the
+// optimiser sink the arithmetic in front of it past it
 #define Q_STAMP(slot)                                                                          \
     do {                                                                                       \
-        __builtin_amdgcn_sched_barrier(0);                                                     \
-        if (stamp_on && t < QSTAMP_STEPS) {                                                    \
-            unsigned long long t_;                                                             \
-            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");        \
-            g_q_stamps[t][slot] = t_;                                                          \
-        }                                                                                      \
-        __builtin_amdgcn_sched_barrier(0);                                                     \
+        unsigned long long t_;                                                                 \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");            \
+        sStamps[(stamp_on && t < QSTAMP_STEPS - 1) ? t * QSTAMP_SLOTS + slot : (QSTAMP_STEPS - 1) * QSTAMP_SLOTS + 11] = t_; \
     } while (0)
 #else
 #define Q_STAMP(slot) do { } while (0)
@@ -54,17 +53,20 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_bf16_kernel(LstmParams p) {
     // epoch tags continue from the workspace header, a poisoned workspace skips the body (xch_common.h)
     const bool xch_used = steps > 1;
     __shared__ unsigned sXch[4];
-    const unsigned arrival = xch_used ? xch_arrive(p.status, sXch, group, slice) : 0u;
-    const bool poisoned = xch_used && xch_poisoned(p.status);
-    if (tid == 0) sFlag[0] = poisoned ? 1 : 0;
+    const XchHeader header = xch_arrive_request(p.status, xch_used);   // taken behind the first weight requests (xch_common.h)
+    const unsigned timeout_word = xch_timeout_word(p.status);
+    const unsigned arrival = 0u;
 #ifdef FOV_STAMPS
+    __shared__ unsigned long long sStamps[QSTAMP_STEPS * QSTAMP_SLOTS];
     const bool stamp_on = (blockIdx.x == 5 && tid == 0);
     if (stamp_on) g_q_stamps[QSTAMP_STEPS - 1][0] = __builtin_amdgcn_s_memtime();   // kernel entry
 #endif
 
     // ---- resident weights: packed bf16 B fragments (rows of K beyond F are zero) ----
     qu32x4 wk[NKB][2], wr[8][2];
-    load_weight_set<NKB>(wk, p.K, H4, F, g4, col0, col1);
+    load_weight_set<NKB>(wk, p.K, H4, F, g4, col0, col1, [&]() { xch_arrive_commit(p.status, sXch, header, group, slice, xch_used); });
+    const bool poisoned = xch_timeout_set(timeout_word) && xch_used;
+    if (tid == 0) sFlag[0] = poisoned ? 1 : 0;
     load_weight_set<8>(wr, p.R, H4, QH, g4, col0, col1);
     const float bv[2] = {p.b[col0], p.b[col1]};
     for (int i = tid; i < 2 * QBT * QLD; i += 256) sX[i] = 0;   // columns >= F stay zero
@@ -244,8 +246,8 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_bf16_kernel(LstmParams p) {
                     if (p.hs) p.hs[((size_t)row * p.T + t) * QH + unit] = hc[r];
                 }
             }
+            Q_STAMP(6);
             if (do_xch) {
-                Q_STAMP(6);
                 if (!q_gather_finish(gq, xrs, par, slice, tid, epoch, sH, p.status)) sFlag[0] = 1;
             }
             Q_STAMP(7);
@@ -267,7 +269,10 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_bf16_kernel(LstmParams p) {
         }
     }
 #ifdef FOV_STAMPS
-    if (stamp_on) g_q_stamps[QSTAMP_STEPS - 1][2] = __builtin_amdgcn_s_memtime();   // all tiles done
+    if (stamp_on) {
+        g_q_stamps[QSTAMP_STEPS - 1][2] = __builtin_amdgcn_s_memtime();   // all tiles done
+        for (int i = 0; i < (QSTAMP_STEPS - 1) * QSTAMP_SLOTS; ++i) (&g_q_stamps[0][0])[i] = sStamps[i];
+    }
 #endif
     if (xch_used) xch_settle(p.status, ticket, (unsigned)p.epoch_span);
 #ifdef FOV_STAMPS

@@ -39,8 +39,9 @@ constexpr int S2_NKB1 = 3;   // layer 1: F <= 96
 // load_weight_set of bf16_common.h for a kernel whose rows ALL exist (32 NKB rows): the row part that does not depend on the
 // lane goes into the scalar offset, so the loads share TWO address registers (hipcc precomputed one per load - 256 of them
 // for a layer - and spilled, each spill behind its own vmcnt(0)).
-template <int NKB>
-__device__ __forceinline__ void load_weight_set_full(qu32x4 (&w)[NKB][2], const float* __restrict__ W, int ld, int g4, int col0, int col1) {
+template <int NKB, class Behind = QNothing>
+__device__ __forceinline__ void load_weight_set_full(qu32x4 (&w)[NKB][2], const float* __restrict__ W, int ld, int g4, int col0, int col1,
+                                                     Behind behind_first_batch = Behind()) {
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(W), 0, 32 * NKB * ld * 4, 0x00020000);
     const unsigned v0 = (unsigned)((8 * g4) * ld + col0) * 4u, v1 = (unsigned)((8 * g4) * ld + col1) * 4u;
 #pragma unroll
@@ -54,6 +55,7 @@ __device__ __forceinline__ void load_weight_set_full(qu32x4 (&w)[NKB][2], const 
                 v[i][0][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, v0, so, 0));
                 v[i][1][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, v1, so, 0));
             }
+        if (c == 0) behind_first_batch();
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -84,6 +86,23 @@ __device__ __forceinline__ void qmm4(f32x4 (&acc)[2], const unsigned short* tile
 }
 
 // one layer of the pair.  ROLE 0: producer (x from memory, ring publish), ROLE 1: consumer (x from the producer's ring)
+#ifdef FOV_STAMPS
+// Diagnostic build only (make stamps): thread 0 of slice 0 of group 0 of each role stamps s_memtime at the phase boundaries of
+// every step into LDS (branch-free: every thread reads the clock and writes a junk slot unless it is the stamping one) and
+// copies the table out once at the end -> tools/stamp_bf16_layer.py --stack2
+constexpr int S2STAMP_SLOTS = 12;
+constexpr int S2STAMP_STEPS = 32;
+__device__ unsigned long long g_s2_stamps[2][S2STAMP_STEPS][S2STAMP_SLOTS];
+#define S2_STAMP(slot)                                                                         \
+    do {                                                                                       \
+        unsigned long long t_;                                                                 \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");            \
+        sStamps[(stamp_on && t < S2STAMP_STEPS - 2) ? t * S2STAMP_SLOTS + slot : (S2STAMP_STEPS - 1) * S2STAMP_SLOTS + 11] = t_; \
+    } while (0)
+#else
+#define S2_STAMP(slot) do { } while (0)
+#endif
+
 template <int ACT, int ROLE>
 __device__ __forceinline__ void stack2_body(const Stack2Params& p, unsigned short* sH, unsigned short* sX, int* sFlag, unsigned* sXch,
                                             int group, int slice) {
@@ -103,16 +122,32 @@ __device__ __forceinline__ void stack2_body(const Stack2Params& p, unsigned shor
     float* cT = ROLE == 0 ? p.cT1 : p.cT2;
     float* reserve = ROLE == 0 ? p.res1 : p.res2;
 
-    const unsigned arrival = xch_arrive(p.status, sXch, ROLE * p.num_groups + group, slice);
-    const bool poisoned = xch_poisoned(p.status);
-    if (tid == 0) sFlag[0] = poisoned ? 1 : 0;
-
+#ifdef FOV_STAMPS
+    __shared__ unsigned long long sStamps[S2STAMP_STEPS * S2STAMP_SLOTS];
+    const bool stamp_on = (group == 0 && slice == 0 && tid == 0);
+    if (stamp_on) g_s2_stamps[ROLE][S2STAMP_STEPS - 1][0] = __builtin_amdgcn_s_memtime();   // kernel entry
+#endif
+    const XchHeader header = xch_arrive_request(p.status);   // taken behind the first weight set (xch_common.h)
+    const unsigned timeout_word = xch_timeout_word(p.status);
+    const unsigned arrival = 0u;
     qu32x4 wk[NKB][2], wr[8][2];
-    if constexpr (ROLE == 0) load_weight_set<NKB, 3>(wk, Kp, H4, F, g4, col0, col1);   // rows >= F read as zero (hardware bounds)
-    else load_weight_set_full<NKB>(wk, Kp, H4, g4, col0, col1);
+    auto commit = [&]() { xch_arrive_commit(p.status, sXch, header, ROLE * p.num_groups + group, slice); };
+    if constexpr (ROLE == 0) load_weight_set<NKB, 3>(wk, Kp, H4, F, g4, col0, col1, commit);   // rows >= F read as zero (hardware bounds)
+    else load_weight_set_full<NKB>(wk, Kp, H4, g4, col0, col1, commit);
+    const bool poisoned = xch_timeout_set(timeout_word);
+    if (tid == 0) sFlag[0] = poisoned ? 1 : 0;
+#ifdef FOV_STAMPS
+    if (stamp_on) g_s2_stamps[ROLE][S2STAMP_STEPS - 2][0] = __builtin_amdgcn_s_memtime();   // first weight set packed, arrival counted, hello word out
+#endif
     load_weight_set_full<8>(wr, Rp, H4, g4, col0, col1);
     const float bv[2] = {bp[col0], bp[col1]};
+#ifdef FOV_STAMPS
+    if (stamp_on) g_s2_stamps[ROLE][S2STAMP_STEPS - 2][1] = __builtin_amdgcn_s_memtime();   // weights and bias requested (and packed)
+#endif
     for (int i = tid; i < QBT * QLD; i += 256) { sX[i] = 0; sH[i] = 0; }   // zero initial state; x columns >= F stay zero
+#ifdef FOV_STAMPS
+    if (stamp_on) g_s2_stamps[ROLE][S2STAMP_STEPS - 2][2] = __builtin_amdgcn_s_memtime();   // LDS zeroed
+#endif
 
     // granule areas: the producer ring [group][step][tile], behind it the consumers' parity buffers [group][2][tile]
     const unsigned ring_group_bytes = (unsigned)steps * Q_TILE_BYTES;
@@ -124,8 +159,14 @@ __device__ __forceinline__ void stack2_body(const Stack2Params& p, unsigned shor
     const int my_row0 = 4 * g4 + 2 * hi;
     const unsigned pub_off = (unsigned)((my_row0 >> 1) * QH + unit) * 8u;
     xch_hello_poll(p.status, sXch, ROLE * p.num_groups + group, QG, &sFlag[0]);
+#ifdef FOV_STAMPS
+    if (stamp_on) g_s2_stamps[ROLE][S2STAMP_STEPS - 2][3] = __builtin_amdgcn_s_memtime();   // every member's hello word seen
+#endif
     __syncthreads();
     const XchTicket ticket = xch_ticket(sXch, arrival);
+#ifdef FOV_STAMPS
+    if (stamp_on) g_s2_stamps[ROLE][S2STAMP_STEPS - 2][4] = __builtin_amdgcn_s_memtime();   // first barrier passed
+#endif
     const unsigned base = ticket.base;
     bool aborted = sFlag[0] != 0;
     if (tid == 0 && !ticket.same_xcd && !aborted) xch_count_safe(p.status, ticket);
@@ -196,14 +237,21 @@ __device__ __forceinline__ void stack2_body(const Stack2Params& p, unsigned shor
     }
     __syncthreads();
     if (sFlag[0]) aborted = true;
+#ifdef FOV_STAMPS
+    if (stamp_on) g_s2_stamps[ROLE][S2STAMP_STEPS - 2][5] = __builtin_amdgcn_s_memtime();   // x_0 in LDS (upper role: lower's h_0 gathered)
+#endif
     float c[2] = {0.f, 0.f}, hc[2] = {0.f, 0.f};
     f32x4 acc[2];
     acc[0] = (f32x4){bv[0], bv[0], bv[0], bv[0]};
     acc[1] = (f32x4){bv[1], bv[1], bv[1], bv[1]};
     if (steps > 0 && !aborted) qmm4<NKB>(acc, sX, n, g4, wk);   // h_{-1} = 0: no recurrent term
     QGather gq;
+#ifdef FOV_STAMPS
+    if (stamp_on) g_s2_stamps[ROLE][S2STAMP_STEPS - 1][1] = __builtin_amdgcn_s_memtime();   // weights resident, x_0 . K done
+#endif
     for (int t = 0; t < steps && !aborted; ++t) {
         const bool more = (t + 1 < steps);
+        S2_STAMP(0);
         // ---- cell update (fp32) ----
         float gt[2][4];
         {
@@ -217,6 +265,7 @@ __device__ __forceinline__ void stack2_body(const Stack2Params& p, unsigned shor
                 gt[r][0] = ig; gt[r][1] = fg; gt[r][2] = gg; gt[r][3] = og;
             }
         }
+        S2_STAMP(1);
         const unsigned hpair = pack_bf16(hc[0], hc[1]);
         unsigned epoch, goff;
         if constexpr (ROLE == 0) {   // ring slot t; the LAST step is published too (the consumer's x_{T-1})
@@ -228,7 +277,9 @@ __device__ __forceinline__ void stack2_body(const Stack2Params& p, unsigned shor
             goff = (epoch & 1u) * Q_TILE_BYTES;
             if (more) XCH_STORE_B64(ticket.same_xcd, ((qu32x2){hpair, epoch}), own, pub_off, goff);
         }
+        S2_STAMP(2);
         __syncthreads();   // barrier 1: every wave is done reading sH and sX
+        S2_STAMP(3);
         if (more) {
             sH[my_row0 * QLD + unit] = (unsigned short)(hpair & 0xffffu);
             sH[(my_row0 + 1) * QLD + unit] = (unsigned short)(hpair >> 16);
@@ -247,6 +298,7 @@ __device__ __forceinline__ void stack2_body(const Stack2Params& p, unsigned shor
         if constexpr (ROLE == 1) {
             if (more) gather_x_issue(t + 1);
         }
+        S2_STAMP(4);
 #pragma unroll
         for (int r = 0; r < 2; ++r) {   // tape of the step, under the gather's round trip
             const int row = b0 + my_row0 + r;
@@ -258,13 +310,17 @@ __device__ __forceinline__ void stack2_body(const Stack2Params& p, unsigned shor
                 if (hs) hs[((size_t)row * p.T + t) * QH + unit] = hc[r];
             }
         }
+        S2_STAMP(5);
         if (more) {
             if (!q_gather_finish(gq, ROLE == 0 ? ring : own, goff, slice, tid, epoch, sH, p.status)) sFlag[0] = 1;
-            if constexpr (ROLE == 1) {
-                if (!gather_x(t + 1, true)) sFlag[0] = 1;     // the producer's tile t + 1 (it runs one step ahead)
-            }
         }
+        S2_STAMP(6);
+        if constexpr (ROLE == 1) {
+            if (more && !gather_x(t + 1, true)) sFlag[0] = 1;     // the producer's tile t + 1 (it runs one step ahead)
+        }
+        S2_STAMP(7);
         __syncthreads();   // barrier 2: h_t and x_{t+1} are in LDS
+        S2_STAMP(8);
         if (sFlag[0]) { aborted = true; break; }
         acc[0] = (f32x4){bv[0], bv[0], bv[0], bv[0]};
         acc[1] = (f32x4){bv[1], bv[1], bv[1], bv[1]};
@@ -272,7 +328,14 @@ __device__ __forceinline__ void stack2_body(const Stack2Params& p, unsigned shor
             qmm4<NKB>(acc, sX, n, g4, wk);
             qmm4<8>(acc, sH, n, g4, wr);
         }
+        S2_STAMP(9);
     }
+#ifdef FOV_STAMPS
+    if (stamp_on) {
+        g_s2_stamps[ROLE][S2STAMP_STEPS - 1][2] = __builtin_amdgcn_s_memtime();   // recurrence done
+        for (int i = 0; i < (S2STAMP_STEPS - 2) * S2STAMP_SLOTS; ++i) (&g_s2_stamps[ROLE][0][0])[i] = sStamps[i];
+    }
+#endif
     if (!aborted) {
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
@@ -284,6 +347,9 @@ __device__ __forceinline__ void stack2_body(const Stack2Params& p, unsigned shor
         }
     }
     xch_settle(p.status, ticket, (unsigned)p.epoch_span);
+#ifdef FOV_STAMPS
+    if (stamp_on) g_s2_stamps[ROLE][S2STAMP_STEPS - 1][3] = __builtin_amdgcn_s_memtime();   // left
+#endif
 }
 
 template <int ACT>
@@ -338,3 +404,9 @@ int launch_stack2_bf16(const float* x, const float* K1, const float* R1, const f
 }
 
 }  // namespace fov
+
+#ifdef FOV_STAMPS
+extern "C" int fov_debug_read_s2_stamps(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(fov::g_s2_stamps), sizeof(unsigned long long) * 2 * fov::S2STAMP_STEPS * fov::S2STAMP_SLOTS);
+}
+#endif

@@ -44,12 +44,14 @@ __global__ __launch_bounds__(256, 1) void mix_decoder_bf16_kernel(MixDecParams p
     constexpr int H4 = 4 * QH;
 
     __shared__ unsigned sXch[4];
-    const unsigned arrival = xch_arrive(p.status, sXch, group, slice);
-    const bool poisoned = xch_poisoned(p.status);
-    if (tid == 0) sFlag[0] = poisoned ? 1 : 0;
+    const XchHeader header = xch_arrive_request(p.status);   // taken behind the first weight requests (xch_common.h)
+    const unsigned timeout_word = xch_timeout_word(p.status);
+    const unsigned arrival = 0u;
     // ---- resident weights (packed bf16 B fragments) ----
     qu32x4 w1[8][2], wk2[8][2], w2[8][2], wk1[1][2];
-    load_weight_set<8>(w1, p.R1, H4, QH, g4, col0, col1);
+    load_weight_set<8>(w1, p.R1, H4, QH, g4, col0, col1, [&]() { xch_arrive_commit(p.status, sXch, header, group, slice); });
+    const bool poisoned = xch_timeout_set(timeout_word);
+    if (tid == 0) sFlag[0] = poisoned ? 1 : 0;
     load_weight_set<8>(wk2, p.K2p, H4, QH, g4, col0, col1);    // K2p: here the plain (H,4H) kernel of layer 2
     load_weight_set<8>(w2, p.R2, H4, QH, g4, col0, col1);
     load_weight_set<1>(wk1, p.K1, H4, O, g4, col0, col1);      // K1 (O <= 8 rows): one zero-padded k-block
