@@ -89,6 +89,117 @@ __device__ __forceinline__ void load_weight_set(qu32x4 (&w)[NKB][2], const float
     }
 }
 
+// ---- the same fragment sets through LDS (round 4) ------------------------------------------------------------------
+// load_weight_set asks for a fragment the way the MFMA wants it - lane (n, g4) reads 8 rows of ONE column - so a wave's
+// load instruction touches 8 cache lines for 256 useful bytes, every line of the workgroup's slice is requested by all
+// four waves, and the L1's line rate bounds the prologue: 12 300 cycles for the two sets of a layer kernel, 22 000 for
+// the upper layer of the two-layer kernel that shares its CU with a second workgroup (tools/stamp_bf16_layer.py).
+// Here the WORKGROUP reads its slice as whole lines - a stage is 64 rows x (4 gates x 32 units), 8 dwordx4 loads per
+// thread, 8 lanes to a 128-byte line -, packs row pairs to bf16, transposes through LDS (column-major, 36 words per
+// column, k-words XOR-swizzled so that the 64 lanes of a ds_write_b32 spread over all banks) and every lane picks its
+// fragments up as ds_read_b128.  Two register sets and two LDS buffers: the loads of stage s + 1 are in flight while
+// stage s is packed, written and read; one barrier per stage.
+constexpr int QST_WORDS = 36;                 // words per column: 32 (64 rows as bf16 pairs) + 4 (16-byte aligned, 4 mod 32)
+constexpr int QST_BUF = 128 * QST_WORDS;      // one buffer, in 32-bit words: 18 432 bytes
+constexpr int QST_DEPTH = 2;                  // stages requested ahead of the one being packed (DEPTH + 1 register sets of 32)
+constexpr int QST_LDS_WORDS = 2 * QST_BUF;    // __shared__ __attribute__((aligned(16))) unsigned sStage[QST_LDS_WORDS]
+
+struct QStageLane {
+    unsigned goff;      // byte offset of (row 2 * kp, this thread's 4 columns) in the fp32 matrix
+    unsigned wr_even;   // LDS word of the thread's first column for even / odd 16-row groups of a stage (swizzle folded in)
+    unsigned wr_odd;
+    unsigned rd[2];     // LDS word of fragment (k-block 0 of the stage, N-tile t)
+};
+__device__ __forceinline__ QStageLane q_stage_lane(int ld, int slice) {
+    const int tid = threadIdx.x;
+    const int c = tid & 7, kp = (tid >> 3) & 7, gate = tid >> 6;
+    const int lane = tid & 63, wave = tid >> 6, n = lane & 15, g4 = lane >> 4, hi = n >> 3;
+    QStageLane q;
+    q.goff = (unsigned)((2 * kp) * ld + gate * QH + 32 * slice + 4 * c) * 4u;
+    const int sbw = (c >> 1) & 1;                    // swizzle bit of the columns this thread writes (column bit 3)
+    const unsigned wbase = (unsigned)((32 * gate + 4 * c) * QST_WORDS + kp);
+    q.wr_even = wbase + 8u * sbw;                    // 16-row group it: word 8 * (it ^ sb) + kp
+    q.wr_odd = wbase - 8u * sbw;
+    const int sbr = wave & 1;                        // ... of the columns it reads: 8 * wave + (n & 7)
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+        q.rd[t] = (unsigned)(((2 * t + hi) * 32 + 8 * wave + (n & 7)) * QST_WORDS + 4 * (g4 ^ (2 * sbr)));
+    return q;
+}
+// requests of stage `ls` (rows [64 ls, 64 ls + 64)) of W; rows >= nrows read as zero (whole offset in the vector register:
+// the hardware's range check does not see a scalar offset)
+__device__ __forceinline__ void q_stage_issue(f32x4 (&r)[8], const float* __restrict__ W, int ld, int nrows, int ls, const QStageLane& q) {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(W), 0, nrows * ld * 4, 0x00020000);
+#pragma unroll
+    for (int it = 0; it < 4; ++it)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const qu32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, q.goff + (unsigned)((64 * ls + 16 * it + e) * ld) * 4u, 0, 0);
+            r[2 * it + e] = __builtin_bit_cast(f32x4, v);
+        }
+}
+__device__ __forceinline__ void q_stage_write(const f32x4 (&r)[8], unsigned* buf, const QStageLane& q) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        unsigned* wp = buf + ((it & 1) ? q.wr_odd : q.wr_even) + 8 * it;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wp[j * QST_WORDS] = pack_bf16(r[2 * it][j], r[2 * it + 1][j]);
+    }
+}
+template <int NKB>
+__device__ __forceinline__ void q_stage_read(qu32x4 (&w)[NKB][2], int ls, const unsigned* buf, const QStageLane& q) {
+#pragma unroll
+    for (int kbl = 0; kbl < 2; ++kbl)
+        if (2 * ls + kbl < NKB) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) w[2 * ls + kbl][t] = *(const qu32x4*)(buf + q.rd[t] + 16 * kbl);
+        }
+}
+// Two / three fragment sets in one pipeline (every thread of the 256 calls it; the buffers are free again at return, after
+// a barrier).  `behind_first_stage()` runs once behind the first stage's requests (xch_arrive_commit).
+template <bool HAS_C, int DEPTH, int NA, int NB, int NC, class Behind>
+__device__ __forceinline__ void stage_weight_sets_impl(qu32x4 (&a)[NA][2], const float* __restrict__ Wa, int nra, qu32x4 (&b)[NB][2],
+                                                       const float* __restrict__ Wb, int nrb, qu32x4 (&c)[NC][2],
+                                                       const float* __restrict__ Wc, int nrc, int ld, int slice, unsigned* sStage,
+                                                       Behind behind_first_stage) {
+    constexpr int SA = (NA + 1) / 2, SB = (NB + 1) / 2, SC = HAS_C ? (NC + 1) / 2 : 0, NS = SA + SB + SC;
+    const QStageLane q = q_stage_lane(ld, slice);
+    f32x4 r[DEPTH + 1][8];
+    auto issue = [&](int s) __attribute__((always_inline)) {
+        if (s < SA) q_stage_issue(r[s % (DEPTH + 1)], Wa, ld, nra, s, q);
+        else if (s < SA + SB) q_stage_issue(r[s % (DEPTH + 1)], Wb, ld, nrb, s - SA, q);
+        else q_stage_issue(r[s % (DEPTH + 1)], Wc, ld, nrc, s - SA - SB, q);
+    };
+    issue(0);
+    behind_first_stage();
+#pragma unroll
+    for (int s = 1; s < DEPTH; ++s)
+        if (s < NS) issue(s);
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        if (s + DEPTH < NS) issue(s + DEPTH);
+        unsigned* buf = sStage + (s & 1) * QST_BUF;
+        q_stage_write(r[s % (DEPTH + 1)], buf, q);
+        __syncthreads();   // (buffer s & 1 is written again two stages on, behind the barrier of stage s + 1, which a wave passes after these reads)
+        if (s < SA) q_stage_read<NA>(a, s, buf, q);
+        else if (s < SA + SB) q_stage_read<NB>(b, s - SA, buf, q);
+        else q_stage_read<NC>(c, s - SA - SB, buf, q);
+    }
+    __syncthreads();
+}
+template <int DEPTH = QST_DEPTH, int NA, int NB, class Behind>
+__device__ __forceinline__ void stage_weight_sets(qu32x4 (&a)[NA][2], const float* __restrict__ Wa, int nra, qu32x4 (&b)[NB][2],
+                                                  const float* __restrict__ Wb, int nrb, int ld, int slice, unsigned* sStage,
+                                                  Behind behind_first_stage) {
+    stage_weight_sets_impl<false, DEPTH>(a, Wa, nra, b, Wb, nrb, b, Wb, nrb, ld, slice, sStage, behind_first_stage);
+}
+template <int DEPTH = QST_DEPTH, int NA, int NB, int NC, class Behind>
+__device__ __forceinline__ void stage_weight_sets(qu32x4 (&a)[NA][2], const float* __restrict__ Wa, int nra, qu32x4 (&b)[NB][2],
+                                                  const float* __restrict__ Wb, int nrb, qu32x4 (&c)[NC][2], const float* __restrict__ Wc,
+                                                  int nrc, int ld, int slice, unsigned* sStage, Behind behind_first_stage) {
+    stage_weight_sets_impl<true, DEPTH>(a, Wa, nra, b, Wb, nrb, c, Wc, nrc, ld, slice, sStage, behind_first_stage);
+}
+
 // B fragment of a TRANSPOSED product: B[k][col] = W[row = out][k index along a row]; the 8 values are contiguous
 __device__ __forceinline__ qu32x4 load_bfrag_rowmajor(const float* __restrict__ wrow) {
     const f32x4 a = *(const f32x4*)wrow, b = *(const f32x4*)(wrow + 4);

@@ -41,6 +41,7 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_bf16_kernel(LstmParams p) {
     __shared__ __attribute__((aligned(16))) unsigned short sH[QBT * QLD];
     __shared__ __attribute__((aligned(16))) unsigned short sX[2 * QBT * QLD];
     __shared__ int sFlag[4];
+    __shared__ __attribute__((aligned(16))) unsigned sStage[QST_LDS_WORDS];   // the prologue's weight staging (bf16_common.h)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 15, g4 = lane >> 4;
     int group, slice;
@@ -64,10 +65,9 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_bf16_kernel(LstmParams p) {
 
     // ---- resident weights: packed bf16 B fragments (rows of K beyond F are zero) ----
     qu32x4 wk[NKB][2], wr[8][2];
-    load_weight_set<NKB>(wk, p.K, H4, F, g4, col0, col1, [&]() { xch_arrive_commit(p.status, sXch, header, group, slice, xch_used); });
+    stage_weight_sets(wk, p.K, F, wr, p.R, QH, H4, slice, sStage, [&]() { xch_arrive_commit(p.status, sXch, header, group, slice, xch_used); });
     const bool poisoned = xch_timeout_set(timeout_word) && xch_used;
     if (tid == 0) sFlag[0] = poisoned ? 1 : 0;
-    load_weight_set<8>(wr, p.R, H4, QH, g4, col0, col1);
     const float bv[2] = {p.b[col0], p.b[col1]};
     for (int i = tid; i < 2 * QBT * QLD; i += 256) sX[i] = 0;   // columns >= F stay zero
 

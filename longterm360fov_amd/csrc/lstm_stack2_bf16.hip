@@ -35,6 +35,7 @@ struct Stack2Params {
 namespace {
 
 constexpr int S2_NKB1 = 3;   // layer 1: F <= 96
+constexpr int S2_STAGE_DEPTH = 2;   // weight staging: stages in flight ahead (two workgroups per CU: 256 registers per lane)
 
 // load_weight_set of bf16_common.h for a kernel whose rows ALL exist (32 NKB rows): the row part that does not depend on the
 // lane goes into the scalar offset, so the loads share TWO address registers (hipcc precomputed one per load - 256 of them
@@ -104,7 +105,7 @@ __device__ unsigned long long g_s2_stamps[2][S2STAMP_STEPS][S2STAMP_SLOTS];
 #endif
 
 template <int ACT, int ROLE>
-__device__ __forceinline__ void stack2_body(const Stack2Params& p, unsigned short* sH, unsigned short* sX, int* sFlag, unsigned* sXch,
+__device__ __forceinline__ void stack2_body(const Stack2Params& p, unsigned short* sH, unsigned short* sX, unsigned* sStage, int* sFlag, unsigned* sXch,
                                             int group, int slice) {
     constexpr int NKB = ROLE == 0 ? S2_NKB1 : 8;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -132,14 +133,13 @@ __device__ __forceinline__ void stack2_body(const Stack2Params& p, unsigned shor
     const unsigned arrival = 0u;
     qu32x4 wk[NKB][2], wr[8][2];
     auto commit = [&]() { xch_arrive_commit(p.status, sXch, header, ROLE * p.num_groups + group, slice); };
-    if constexpr (ROLE == 0) load_weight_set<NKB, 3>(wk, Kp, H4, F, g4, col0, col1, commit);   // rows >= F read as zero (hardware bounds)
-    else load_weight_set_full<NKB>(wk, Kp, H4, g4, col0, col1, commit);
+    // both sets through LDS (bf16_common.h); rows of K1 >= F read as zero (hardware bounds)
+    stage_weight_sets<S2_STAGE_DEPTH>(wk, Kp, ROLE == 0 ? F : QH, wr, Rp, QH, H4, slice, sStage, commit);
     const bool poisoned = xch_timeout_set(timeout_word);
     if (tid == 0) sFlag[0] = poisoned ? 1 : 0;
 #ifdef FOV_STAMPS
     if (stamp_on) g_s2_stamps[ROLE][S2STAMP_STEPS - 2][0] = __builtin_amdgcn_s_memtime();   // first weight set packed, arrival counted, hello word out
 #endif
-    load_weight_set_full<8>(wr, Rp, H4, g4, col0, col1);
     const float bv[2] = {bp[col0], bp[col1]};
 #ifdef FOV_STAMPS
     if (stamp_on) g_s2_stamps[ROLE][S2STAMP_STEPS - 2][1] = __builtin_amdgcn_s_memtime();   // weights and bias requested (and packed)
@@ -356,6 +356,7 @@ template <int ACT>
 __global__ __launch_bounds__(256, 2) void lstm_stack2_bf16_kernel(Stack2Params p) {
     __shared__ __attribute__((aligned(16))) unsigned short sH[QBT * QLD];
     __shared__ __attribute__((aligned(16))) unsigned short sX[QBT * QLD];
+    __shared__ __attribute__((aligned(16))) unsigned sStage[QST_LDS_WORDS];   // the prologue's weight staging (bf16_common.h)
     __shared__ int sFlag[4];
     __shared__ unsigned sXch[4];
     const int per_role = p.num_groups * QG;
@@ -369,8 +370,8 @@ __global__ __launch_bounds__(256, 2) void lstm_stack2_bf16_kernel(Stack2Params p
         group = local / QG;
         slice = local - group * QG;
     }
-    if (role == 0) stack2_body<ACT, 0>(p, sH, sX, sFlag, sXch, group, slice);
-    else stack2_body<ACT, 1>(p, sH, sX, sFlag, sXch, group, slice);
+    if (role == 0) stack2_body<ACT, 0>(p, sH, sX, sStage, sFlag, sXch, group, slice);
+    else stack2_body<ACT, 1>(p, sH, sX, sStage, sFlag, sXch, group, slice);
 }
 
 }  // namespace

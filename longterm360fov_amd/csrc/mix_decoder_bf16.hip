@@ -32,6 +32,7 @@ __global__ __launch_bounds__(256, 1) void mix_decoder_bf16_kernel(MixDecParams p
     __shared__ float sWp[64];                                               // [8][8] mixing kernel (pred part)
     __shared__ float sPart[4 * 256];                                        // [4 waves][16 rows][16 cols] partial Dense products
     __shared__ int sFlag[4];
+    __shared__ __attribute__((aligned(16))) unsigned sStage[QST_LDS_WORDS];   // the prologue's weight staging (bf16_common.h)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 15, g4 = lane >> 4;
@@ -49,12 +50,12 @@ __global__ __launch_bounds__(256, 1) void mix_decoder_bf16_kernel(MixDecParams p
     const unsigned arrival = 0u;
     // ---- resident weights (packed bf16 B fragments) ----
     qu32x4 w1[8][2], wk2[8][2], w2[8][2], wk1[1][2];
-    load_weight_set<8>(w1, p.R1, H4, QH, g4, col0, col1, [&]() { xch_arrive_commit(p.status, sXch, header, group, slice); });
+    load_weight_set<1>(wk1, p.K1, H4, O, g4, col0, col1);      // K1 (O <= 8 rows): one zero-padded k-block
+    // the three (H, 4H) sets through LDS (bf16_common.h); K2p: here the plain (H,4H) kernel of layer 2
+    stage_weight_sets(w1, p.R1, QH, wk2, p.K2p, QH, w2, p.R2, QH, H4, slice, sStage,
+                      [&]() { xch_arrive_commit(p.status, sXch, header, group, slice); });
     const bool poisoned = xch_timeout_set(timeout_word);
     if (tid == 0) sFlag[0] = poisoned ? 1 : 0;
-    load_weight_set<8>(wk2, p.K2p, H4, QH, g4, col0, col1);    // K2p: here the plain (H,4H) kernel of layer 2
-    load_weight_set<8>(w2, p.R2, H4, QH, g4, col0, col1);
-    load_weight_set<1>(wk1, p.K1, H4, O, g4, col0, col1);      // K1 (O <= 8 rows): one zero-padded k-block
     const float b1v[2] = {p.b1[col0], p.b1[col1]}, b2v[2] = {p.b2[col0], p.b2[col1]};
     const float bdv = ((tid & 15) < O) ? p.bd[tid & 15] : 0.f;   // Dense bias of this thread's head output
     // Dense kernel as B fragments: wave w contracts hidden units [64w, 64w + 64) = k-blocks 2w, 2w + 1; column n = output
