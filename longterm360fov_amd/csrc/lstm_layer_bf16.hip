@@ -65,11 +65,13 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_bf16_kernel(LstmParams p) {
 
     // ---- resident weights: packed bf16 B fragments (rows of K beyond F are zero) ----
     qu32x4 wk[NKB][2], wr[8][2];
-    stage_weight_sets(wk, p.K, F, wr, p.R, QH, H4, slice, sStage, [&]() { xch_arrive_commit(p.status, sXch, header, group, slice, xch_used); });
+    stage_weight_sets(wk, p.K, F, wr, p.R, QH, H4, slice, sStage, [&]() {
+        xch_arrive_commit(p.status, sXch, header, group, slice, xch_used);
+        for (int i = tid; i < 2 * QBT * QLD; i += 256) sX[i] = 0;   // columns >= F stay zero (under the first stage's round trip)
+    });
     const bool poisoned = xch_timeout_set(timeout_word) && xch_used;
     if (tid == 0) sFlag[0] = poisoned ? 1 : 0;
     const float bv[2] = {p.b[col0], p.b[col1]};
-    for (int i = tid; i < 2 * QBT * QLD; i += 256) sX[i] = 0;   // columns >= F stay zero
 
     // ---- exchange bookkeeping ----
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(

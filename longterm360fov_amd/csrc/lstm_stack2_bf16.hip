@@ -132,7 +132,11 @@ __device__ __forceinline__ void stack2_body(const Stack2Params& p, unsigned shor
     const unsigned timeout_word = xch_timeout_word(p.status);
     const unsigned arrival = 0u;
     qu32x4 wk[NKB][2], wr[8][2];
-    auto commit = [&]() { xch_arrive_commit(p.status, sXch, header, ROLE * p.num_groups + group, slice); };
+    auto commit = [&]() {
+        xch_arrive_commit(p.status, sXch, header, ROLE * p.num_groups + group, slice);
+        // zero initial state; x columns >= F stay zero (under the first stage's round trip)
+        for (int i = tid; i < QBT * QLD; i += 256) { sX[i] = 0; sH[i] = 0; }
+    };
     // both sets through LDS (bf16_common.h); rows of K1 >= F read as zero (hardware bounds)
     stage_weight_sets<S2_STAGE_DEPTH>(wk, Kp, ROLE == 0 ? F : QH, wr, Rp, QH, H4, slice, sStage, commit);
     const bool poisoned = xch_timeout_set(timeout_word);
@@ -144,7 +148,6 @@ __device__ __forceinline__ void stack2_body(const Stack2Params& p, unsigned shor
 #ifdef FOV_STAMPS
     if (stamp_on) g_s2_stamps[ROLE][S2STAMP_STEPS - 2][1] = __builtin_amdgcn_s_memtime();   // weights and bias requested (and packed)
 #endif
-    for (int i = tid; i < QBT * QLD; i += 256) { sX[i] = 0; sH[i] = 0; }   // zero initial state; x columns >= F stay zero
 #ifdef FOV_STAMPS
     if (stamp_on) g_s2_stamps[ROLE][S2STAMP_STEPS - 2][2] = __builtin_amdgcn_s_memtime();   // LDS zeroed
 #endif
@@ -158,6 +161,29 @@ __device__ __forceinline__ void stack2_body(const Stack2Params& p, unsigned shor
         0x00020000);
     const int my_row0 = 4 * g4 + 2 * hi;
     const unsigned pub_off = (unsigned)((my_row0 >> 1) * QH + unit) * 8u;
+    const int b0 = group * QBT;      // one tile per group
+    const int live_rows = p.B - b0 < QBT ? p.B - b0 : QBT;
+    constexpr unsigned OORB = 0x80000000u;
+    // ---- x of step 0 (and 1) ----
+    const int xrw = tid >> 4, xc = tid & 15;
+    constexpr int NXE = 2 * S2_NKB1;
+    unsigned xoff[NXE];
+    const __amdgpu_buffer_rsrc_t xgrs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(ROLE == 0 ? p.x + (size_t)b0 * p.T * F : nullptr), 0, ROLE == 0 ? live_rows * p.T * F * 4 : 0, 0x00020000);
+    auto load_x1 = [&](int i, int t) { return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xgrs, xoff[i], (unsigned)(t * F * 4), 0)); };
+    unsigned short* xl = sX + xrw * QLD + xc;
+    float xs[NXE];
+    // the lower layer requests x_0 and x_1 here, in front of the handshake and the prologue's barrier: their round trip used
+    // to start behind both (1 600 cycles between the barrier and x_0 in LDS, which the upper layer's first step waits for too)
+    float v1[NXE];
+    if constexpr (ROLE == 0) {
+#pragma unroll
+        for (int i = 0; i < NXE; ++i) xoff[i] = (xc + 16 * i < F) ? (unsigned)((xrw * p.T * F + xc + 16 * i) * 4) : OORB;
+#pragma unroll
+        for (int i = 0; i < NXE; ++i) v1[i] = load_x1(i, 0);
+#pragma unroll
+        for (int i = 0; i < NXE; ++i) xs[i] = load_x1(i, steps > 1 ? 1 : 0);
+    }
     xch_hello_poll(p.status, sXch, ROLE * p.num_groups + group, QG, &sFlag[0]);
 #ifdef FOV_STAMPS
     if (stamp_on) g_s2_stamps[ROLE][S2STAMP_STEPS - 2][3] = __builtin_amdgcn_s_memtime();   // every member's hello word seen
@@ -171,19 +197,7 @@ __device__ __forceinline__ void stack2_body(const Stack2Params& p, unsigned shor
     bool aborted = sFlag[0] != 0;
     if (tid == 0 && !ticket.same_xcd && !aborted) xch_count_safe(p.status, ticket);
     // epoch tags: producer step t -> base + 1 + t; consumer's own exchange of step t -> base + 1 + steps + t
-    const int b0 = group * QBT;      // one tile per group
-    const int live_rows = p.B - b0 < QBT ? p.B - b0 : QBT;
-    constexpr unsigned OORB = 0x80000000u;
 
-    // ---- x of step 0 (and 1) ----
-    const int xrw = tid >> 4, xc = tid & 15;
-    constexpr int NXE = 2 * S2_NKB1;
-    unsigned xoff[NXE];
-    const __amdgpu_buffer_rsrc_t xgrs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(ROLE == 0 ? p.x + (size_t)b0 * p.T * F : nullptr), 0, ROLE == 0 ? live_rows * p.T * F * 4 : 0, 0x00020000);
-    auto load_x1 = [&](int i, int t) { return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xgrs, xoff[i], (unsigned)(t * F * 4), 0)); };
-    unsigned short* xl = sX + xrw * QLD + xc;
-    float xs[NXE];
     // all eight slices of the producer's tile `slot` into the x image (consumer); returns false after a give-up
     // (the first sweep is REQUESTED by gather_x_issue together with the own exchange's gather, so the two round trips overlap)
     // thread (row pair tid / 32, half (tid / 16) % 2, unit pair tid % 16): units (2p, 2p + 1) of slices 4 half + j, one 16-byte load each
@@ -222,13 +236,6 @@ __device__ __forceinline__ void stack2_body(const Stack2Params& p, unsigned shor
         }
     };
     if constexpr (ROLE == 0) {
-#pragma unroll
-        for (int i = 0; i < NXE; ++i) xoff[i] = (xc + 16 * i < F) ? (unsigned)((xrw * p.T * F + xc + 16 * i) * 4) : OORB;
-        float v1[NXE];
-#pragma unroll
-        for (int i = 0; i < NXE; ++i) v1[i] = load_x1(i, 0);
-#pragma unroll
-        for (int i = 0; i < NXE; ++i) xs[i] = load_x1(i, steps > 1 ? 1 : 0);
 #pragma unroll
         for (int i = 0; i < NXE; ++i)
             if (xc + 16 * i < F) xl[16 * i] = bf16_bits(v1[i]);

@@ -53,7 +53,10 @@ __global__ __launch_bounds__(256, 1) void mix_decoder_bf16_kernel(MixDecParams p
     load_weight_set<1>(wk1, p.K1, H4, O, g4, col0, col1);      // K1 (O <= 8 rows): one zero-padded k-block
     // the three (H, 4H) sets through LDS (bf16_common.h); K2p: here the plain (H,4H) kernel of layer 2
     stage_weight_sets(w1, p.R1, QH, wk2, p.K2p, QH, w2, p.R2, QH, H4, slice, sStage,
-                      [&]() { xch_arrive_commit(p.status, sXch, header, group, slice); });
+                      [&]() {
+                          xch_arrive_commit(p.status, sXch, header, group, slice);
+                          for (int e = tid; e < QBT * 32; e += 256) sX[e] = 0;   // columns >= 8 stay zero
+                      });
     const bool poisoned = xch_timeout_set(timeout_word);
     if (tid == 0) sFlag[0] = poisoned ? 1 : 0;
     const float b1v[2] = {p.b1[col0], p.b1[col1]}, b2v[2] = {p.b2[col0], p.b2[col1]};
@@ -68,7 +71,6 @@ __global__ __launch_bounds__(256, 1) void mix_decoder_bf16_kernel(MixDecParams p
         wd[q] = (qu32x4){pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7])};
     }
     for (int e = tid; e < 64; e += 256) sWp[e] = ((e >> 3) < O && (e & 7) < O) ? p.Wp[(e >> 3) * O + (e & 7)] : 0.f;
-    for (int e = tid; e < QBT * 32; e += 256) sX[e] = 0;   // columns >= 8 stay zero
 
     // ---- exchange bookkeeping: [layer 2][parity 2][row pair 8][unit 256] granules per group ----
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
