@@ -22,6 +22,7 @@
 
 #include "fov_common.h"
 #include "xch_common.h"
+#include "stage_f32.h"
 
 namespace fov {
 
@@ -101,22 +102,13 @@ __global__ __launch_bounds__(256, 1) void lstm_wide_kernel(LstmParams p) {
     const bool poisoned = xch_used && xch_poisoned(p.status);
     if (tid == 0) sFlag[0] = poisoned ? 1 : 0;
 
-    // ---- resident weights: K rows >= F are zero ----
+    // ---- resident weights through LDS (stage_f32.h; the staging buffers are the h / x tiles, filled after it): K rows >= F
+    // are zero (the descriptor ends with row F - 1) ----
     constexpr unsigned OORB = 0x80000000u;   // buffer-load offset no descriptor covers: reads as 0
-    const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ZXM ? nullptr : p.K), 0, F * H4 * 4, 0x00020000);
     float wk[NJX > 0 ? NJX : 1][4][2], wr[NJR][4][2];
-#pragma unroll
-    for (int j = 0; j < NJR; ++j)
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const int k = 16 * j + 4 * g4 + s;
-            if (j < NJX) {   // the descriptor ends with row F - 1: rows k >= F read as 0, no load sits in a branch
-                wk[j][s][0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(krs, (unsigned)((k * H4 + col0) * 4), 0, 0));
-                wk[j][s][1] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(krs, (unsigned)((k * H4 + col1) * 4), 0, 0));
-            }
-            wr[j][s][0] = p.R[(size_t)k * H4 + col0];
-            wr[j][s][1] = p.R[(size_t)k * H4 + col1];
-        }
+    static_assert((3 * WBT * WLD) >= FST_LDS_WORDS, "the h tile and the two x tiles hold the two staging buffers");
+    if constexpr (ZXM) stage_weight_set_f32<WH>(wr, p.R, WH, slice, (unsigned*)smem, []() {});
+    else stage_weight_sets_f32<WH>(wk, p.K, F, wr, p.R, WH, slice, (unsigned*)smem, []() {});
     const float bv[2] = {p.b[col0], p.b[col1]};
     for (int i = tid; i < 2 * WBT * WLD; i += 256) sX[i] = 0.f;   // columns >= F stay zero
 

@@ -33,6 +33,7 @@
 
 #include "fov_common.h"
 #include "xch_common.h"
+#include "stage_f32.h"
 
 namespace fov {
 
@@ -171,18 +172,10 @@ __global__ __launch_bounds__(256, 1) void mix_decoder_kernel(MixDecParams p) {
     const bool poisoned = xch_poisoned(p.status);
     if (tid == 0) sFlag[0] = poisoned ? 1 : 0;
     // ---- resident weights ----
+    // both (H, 4H) recurrent kernels through LDS (stage_f32.h; the staging buffers are the K2 blocks' area, filled after it)
     float w1[16][4][2], w2[16][4][2];
-#pragma unroll
-    for (int j = 0; j < 16; ++j)
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const size_t k = (size_t)(16 * j + 4 * g4 + s) * H4;
-            w1[j][s][0] = p.R1[k + col0];
-            w1[j][s][1] = p.R1[k + col1];
-            w2[j][s][0] = p.R2[k + col0];
-            w2[j][s][1] = p.R2[k + col1];
-            if (s == 3) __builtin_amdgcn_sched_barrier(0);   // 16 loads at a time: the weights go to AGPRs chunk by chunk
-        }
+    static_assert(4 * K2_LDS_BLOCKS * 256 >= FST_LDS_WORDS, "the K2 area holds the two staging buffers");
+    stage_weight_sets_f32<MH>(w1, p.R1, MH, w2, p.R2, MH, slice, (unsigned*)sK2, []() {});
     // K1 (O <= 8 rows): MFMA step s uses input row k = 4*s + g4
     float k1[2][2];
 #pragma unroll
