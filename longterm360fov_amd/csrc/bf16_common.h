@@ -98,7 +98,9 @@ __device__ __forceinline__ void load_weight_set(qu32x4 (&w)[NKB][2], const float
 // thread, 8 lanes to a 128-byte line -, packs row pairs to bf16, transposes through LDS (column-major, 36 words per
 // column, k-words XOR-swizzled so that the 64 lanes of a ds_write_b32 spread over all banks) and every lane picks its
 // fragments up as ds_read_b128.  Two register sets and two LDS buffers: the loads of stage s + 1 are in flight while
-// stage s is packed, written and read; one barrier per stage.
+// stage s is packed, written and read; one barrier per stage.  The matrices need 4-byte alignment only (a parameter view
+// inside a trainer's flat buffer): a dwordx4 load from such an address returns the right four dwords on gfx950
+// (tools/microbench/unaligned_b128.hip; tests: ..._at_any_four_byte_offset_...).
 constexpr int QST_WORDS = 36;                 // words per column: 32 (64 rows as bf16 pairs) + 4 (16-byte aligned, 4 mod 32)
 constexpr int QST_BUF = 128 * QST_WORDS;      // one buffer, in 32-bit words: 18 432 bytes
 constexpr int QST_DEPTH = 2;                  // stages requested ahead of the one being packed (DEPTH + 1 register sets of 32)

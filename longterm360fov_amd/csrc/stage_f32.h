@@ -10,6 +10,8 @@
 // XOR-swizzled with bit 3 of the column so that the 64 lanes of a ds_write_b32 spread over all banks) and every lane picks
 // its fragments up as ds_read_b128: w[j][0..3][t] are four consecutive words of column t.
 // A stage is 32 rows (4 loads = 16 registers per thread); DEPTH stages are requested ahead of the one being written.
+// The matrices need 4-byte alignment only (a parameter view inside a trainer's flat buffer): a dwordx4 load from such an
+// address returns the right four dwords on gfx950 (tools/microbench/unaligned_b128.hip; tests: ..._at_any_four_byte_offset_...).
 #pragma once
 #include "fov_common.h"
 

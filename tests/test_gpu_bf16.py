@@ -335,3 +335,43 @@ def test_weight_gradient_half_on_its_own_equals_the_single_call(dtype, B, T, F, 
     # accumulate: twice the gradient
     ops.lstm_seq_wgrad(xd, hs, two["dz"], dK=dK2, dR=dR2, db=db2, h0=h0, accumulate=True, scratch=sc2, dtype=dtype)
     assert torch.allclose(dR2, 2 * dR, rtol=1e-6, atol=1e-7) and torch.allclose(db2, 2 * db, rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("B,T,F,shift", [(512, 4, 90, 1), (40, 3, 7, 3), (100, 2, 256, 2), (512, 3, 250, 1)])
+def test_layer_weights_at_any_four_byte_offset_of_a_flat_buffer(dtype, B, T, F, shift):
+    """The eight-workgroup layer kernels read their kernels as 16-byte lines and transpose them in LDS (stage_f32.h,
+    stage_weight_sets of bf16_common.h).  A trainer's parameters are views into ONE flat buffer and start at any multiple
+    of four bytes; K's row count is any number (rows past it read as zero).  Same results as from aligned copies."""
+    from longterm360fov_amd import ops
+    rng = np.random.default_rng(F * 7 + shift)
+    H = 256
+    K, R, b = O.init_lstm(rng, F, H, np.float32)
+    b = (b + 0.1 * rng.standard_normal(b.shape)).astype(np.float32)
+    x = dev(rng.uniform(-1, 1, (B, T, F)))
+    flat = torch.zeros(shift + K.size + 1 + R.size + 3 + b.size, dtype=torch.float32, device="cuda")
+    o = shift
+    Kv = flat[o:o + K.size].view(F, 4 * H); o += K.size + 1
+    Rv = flat[o:o + R.size].view(H, 4 * H); o += R.size + 3
+    bv = flat[o:o + b.size]
+    Kv.copy_(dev(K)); Rv.copy_(dev(R)); bv.copy_(dev(b))
+    assert Kv.data_ptr() % 16 != 0 or Rv.data_ptr() % 16 != 0
+    ws = ops.Workspace()
+    if dtype == "bf16":
+        a = ops.lstm_seq_bf16(x, Kv, Rv, bv, workspace=ws)[:3]
+        r = ops.lstm_seq_bf16(x, dev(K), dev(R), dev(b), workspace=ws)[:3]
+    else:
+        a = ops.lstm_seq(x, Kv, Rv, bv, workspace=ws)
+        r = ops.lstm_seq(x, dev(K), dev(R), dev(b), workspace=ws)
+    ws.check()
+    for u, v in zip(a, r):
+        assert torch.equal(u, v)
+    # ... and they are the oracle's
+    to64 = lambda t: t.astype(np.float64)
+    if dtype == "bf16":
+        with O.bf16_operands():
+            rhs, _, _ = O.lstm_layer(to64(x.cpu().numpy()), to64(K), to64(R), to64(b))
+        assert np.abs(a[0].cpu().numpy() - rhs).max() <= TIGHT
+    else:
+        rhs, _, _ = O.lstm_layer(to64(x.cpu().numpy()), to64(K), to64(R), to64(b))
+        np.testing.assert_allclose(a[0].cpu().numpy(), rhs, rtol=1e-3, atol=1e-5)
