@@ -61,6 +61,7 @@ struct LstmParams {
     int epoch_span;            // epochs this launch may consume: the last workgroup to leave adds it to the header's base
     int force_safe_exchange;   // 1: never take the same-XCD fast path (tests)
     int xcd_pad;               // lstm_wide16.hip: grid padded to 8 x (workgroups per tile), block b = member b / 8 of group b % 8
+    int trio;                  // lstm_wide16.hip: three-role launch - layer 1 also publishes h_t (sc1) into the mirror ring the product role reads
 };
 
 int launch_generic(const LstmParams& p, bool decode, hipStream_t stream);
@@ -76,7 +77,7 @@ int device_cu_count();                               // CUs of the current devic
 // getenv results cached at first use (fov_reload_env re-reads them): nothing on a launch path calls getenv
 struct EnvKnobs {
     int force_safe_exchange, two_launches, resident_limit;
-    int bwd_stepped, no_wgrad_fusion, no_dx_fusion, bwd_groups4, gemm_bf16_split, gemm_bf16_noremap, gemm_bf16_shallow, no_wgrad_group, dbg_trace;   // experiment switches (tools/)
+    int bwd_stepped, no_wgrad_fusion, no_dx_fusion, bwd_groups4, gemm_bf16_split, gemm_bf16_noremap, gemm_bf16_shallow, no_wgrad_group, dbg_trace, no_wide16_trio;   // experiment switches (tools/)
     int gemm_variant, gemm_split;   // FOV_GEMM_VARIANT / FOV_GEMM_SPLIT: tile shape / K slices of the fp32 GEMM forced (experiments)
     int no_wide16;       // FOV_NO_WIDE16=1: width-512 layers stay on the 16-workgroup form (tests / A-B timing)
     int no_cell_patch;   // FOV_NO_CELL_PATCH=1: ConvLSTM2D steps stay on the implicit-GEMM cell (tests compare the two forms)

@@ -26,6 +26,13 @@ namespace {
 constexpr int VBT = 16;
 constexpr unsigned VSPIN = 1u << 20;
 
+// granule offsets of the three-role launch's extra areas behind layer 1's ring (T slots per group) and layer 2's parity slots
+// (2 per group): the mailboxes (T slots of W16_MAIL granules per workgroup of layer 2), then the mirror rings (T slots per group)
+__host__ __device__ constexpr size_t w16_mail_base(int num_groups, int T, int WH) { return (size_t)num_groups * (T + 2) * 16 * WH; }
+__host__ __device__ constexpr size_t w16_mirror_base(int num_groups, int T, int WH) {
+    return w16_mail_base(num_groups, T, WH) + (size_t)num_groups * (WH / 16) * T * (256 * 4);
+}
+constexpr size_t W16_MAIL = 256 * 4;   // granules of one mailbox slot of the three-role launch: 256 lanes x (4 values, each with its tag)
 typedef unsigned vu32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned vu32x4 __attribute__((ext_vector_type(4)));
 
@@ -68,7 +75,8 @@ template <int ACT, int NJX, int WH, int ROLE>
 __device__ __forceinline__ void wide16_body(const LstmParams& p, const int bx, float* smem) {
     constexpr int WG = WH / 16;          // workgroups per tile
     constexpr int NJR = WH / 16;         // k-blocks of R
-    constexpr bool XVEC = ROLE != 2 && NJX == WH / 16;
+    constexpr bool L2 = ROLE == 2 || ROLE == 4;   // layer 2 of a stack (ROLE 4: its input projection arrives from the product role)
+    constexpr bool XVEC = !L2 && NJX == WH / 16;
     constexpr int WLD = WH + 8;          // LDS row stride == 8 (mod 16) floats: conflict-free ds_read_b128 fragments
     constexpr int WNG = WG / 2;          // 16-byte loads (two adjacent units' tagged granules) per thread and step
     constexpr int H4 = 4 * WH;
@@ -100,7 +108,7 @@ __device__ __forceinline__ void wide16_body(const LstmParams& p, const int bx, f
         group = bx / WG;
         slice = bx - group * WG;
     }
-    const int hgroup = group + (ROLE == 2 ? p.num_groups : 0);   // hello words: layer 2's groups behind layer 1's
+    const int hgroup = group + (L2 ? p.num_groups : 0);   // hello words: layer 2's groups behind layer 1's
     const int F = p.F, steps = p.T;
     // MFMA column of this lane: gate n / 4 of unit n % 4 of the wave's four units
     const int unit = 16 * slice + 4 * wave + (n & 3);
@@ -117,7 +125,7 @@ __device__ __forceinline__ void wide16_body(const LstmParams& p, const int bx, f
     // ---- resident weights: K rows >= F read as zero (the descriptor ends with row F - 1) ----
     const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.K), 0, F * H4 * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.R), 0, WH * H4 * 4, 0x00020000);
-    float wk[NJX][4], wr[NJR][4];
+    float wk[NJX > 0 ? NJX : 1][4], wr[NJR][4];
 #pragma unroll
     for (int j = 0; j < NJR; ++j)
 #pragma unroll
@@ -134,6 +142,16 @@ __device__ __forceinline__ void wide16_body(const LstmParams& p, const int bx, f
     // ROLE 0: two parity slots per group.  Pair: layer 1's ring of T slots per group, then layer 2's parity slots.
     const size_t xbase = ROLE == 0 ? (size_t)group * 2 * SLOT
                          : ROLE == 1 ? (size_t)group * p.T * SLOT : ((size_t)p.num_groups * p.T + (size_t)group * 2) * SLOT;
+    // three-role launch, ROLE 1: the mirror of this group's ring for readers on OTHER XCDs (the product role) - the ring itself
+    // may be written with sc0 stores that stay in this XCD's L2
+    const __amdgpu_buffer_rsrc_t mirrs = __builtin_amdgcn_make_buffer_rsrc(
+        p.xch + w16_mirror_base(p.num_groups, p.T, WH) + (size_t)group * p.T * SLOT, 0,
+        (ROLE == 1 && p.trio) ? p.T * (int)(SLOT * sizeof(unsigned long long)) : 0, 0x00020000);
+    // ROLE 4: this workgroup's mailbox - T slots of 256 lanes x 32 bytes, written by its partner of the product role
+    // (wide16_product_body) behind layer 1's ring and layer 2's parity slots
+    const __amdgpu_buffer_rsrc_t mbrs = __builtin_amdgcn_make_buffer_rsrc(
+        p.xch + w16_mail_base(p.num_groups, p.T, WH) + ((size_t)group * WG + slice) * p.T * W16_MAIL, 0,
+        ROLE == 4 ? p.T * (int)(W16_MAIL * sizeof(unsigned long long)) : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
         p.xch + xbase, 0, (ROLE == 1 ? p.T : 2) * (int)(SLOT * sizeof(unsigned long long)), 0x00020000);
     const __amdgpu_buffer_rsrc_t ringrs = __builtin_amdgcn_make_buffer_rsrc(   // ROLE 2: layer 1's ring of the same group
@@ -150,7 +168,7 @@ __device__ __forceinline__ void wide16_body(const LstmParams& p, const int bx, f
     __syncthreads();
     XchTicket ticket = {0u, 0u, 0u};
     if (xch_used) ticket = xch_ticket(sXch, arrival);
-    unsigned epoch = ticket.base + (ROLE == 2 ? (unsigned)p.T : 0u);   // layer 2's own tags follow layer 1's T
+    unsigned epoch = ticket.base + (L2 ? (unsigned)p.T : 0u);   // layer 2's own tags follow layer 1's T
     bool aborted = sFlag[0] != 0;
     if (xch_used && tid == 0 && !ticket.same_xcd && !aborted) xch_count_safe(p.status, ticket);
 
@@ -265,11 +283,45 @@ __device__ __forceinline__ void wide16_body(const LstmParams& p, const int bx, f
         }
     };
 
+    // ROLE 4: z_s = h1_s . K2 of this lane's D-fragment positions (rows 4 g4 + r, column n), two tagged 16-byte pieces
+    vu32x4 zq[2];
+    auto mail_issue = [&](int s_) {
+        if constexpr (ROLE == 4) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) zq[i] = __builtin_amdgcn_raw_buffer_load_b128(mbrs, (unsigned)(tid * 32 + 16 * i), (unsigned)s_ * (W16_MAIL * 8u), 16);
+        }
+    };
+    auto mail_wait = [&](int s_) {   // -> the four values; a give-up poisons the workspace and flags the workgroup
+        f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (ROLE == 4) {
+            const unsigned want = ticket.base + 1u + (unsigned)s_;
+            unsigned spins = 0;
+            while (__any(zq[0].y != want || zq[0].w != want || zq[1].y != want || zq[1].w != want)) {
+#ifdef FOV_DBG_W16_NOZWAIT   // timing experiment (tools/w16_variants.sh): WRONG results
+                break;
+#endif
+                ++spins;
+                if (spins > VSPIN || ((spins & 63u) == 0 && xch_poisoned(p.status))) {
+                    if (lane == 0) {
+                        xch_give_up(p.status);
+                        sFlag[0] = 1;
+                    }
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+                asm volatile("" ::: "memory");
+                mail_issue(s_);
+            }
+            z = (f32x4){__uint_as_float(zq[0].x), __uint_as_float(zq[0].z), __uint_as_float(zq[1].x), __uint_as_float(zq[1].z)};
+        }
+        return z;
+    };
+
     const float* hrow = sH + n * WLD + 4 * g4;
     // x staging: thread (xrw = tid / 16, xc = tid % 16) moves the 16-byte pieces xc, xc + 16, ... of row xrw (narrow: elements)
     const int xrw = tid >> 4, xc = tid & 15;
     const int nx4 = F >> 2;
-    constexpr int NXR = XVEC ? WH / 64 : NJX;
+    constexpr int NXR = XVEC ? WH / 64 : (NJX > 0 ? NJX : 1);
     for (int tile = group; tile < p.num_tiles && !aborted; tile += p.num_groups) {
         const int b0 = tile * VBT;
         __syncthreads();   // previous tile fully consumed
@@ -307,6 +359,7 @@ __device__ __forceinline__ void wide16_body(const LstmParams& p, const int bx, f
         };
         auto load_x1 = [&](int i, int t) { return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xgrs, xoff[i], (unsigned)(t * F * 4), 0)); };
         float* xl = sX + xrw * WLD + (ROLE == 2 ? 2 : XVEC ? 4 : 1) * xc;   // ROLE 2: unit pairs from the ring (ring_store)
+        if constexpr (ROLE == 4) mail_issue(0);
         const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
         if constexpr (ROLE == 2) {   // x_0 and x_1 = layer 1's h_0, h_1: wait for them (layer 2 starts two steps behind)
             ring_issue(0);
@@ -315,7 +368,7 @@ __device__ __forceinline__ void wide16_body(const LstmParams& p, const int bx, f
                 ring_issue(1);
                 ring_store(1, xl + VBT * WLD);
             }
-        } else {
+        } else if constexpr (ROLE != 4) {
             f32x4 x4[2][XVEC ? NXR : 1];
             float x1[2][XVEC ? 1 : NXR];
 #pragma unroll
@@ -344,7 +397,7 @@ __device__ __forceinline__ void wide16_body(const LstmParams& p, const int bx, f
         f32x4 acc[2] = {{bv, bv, bv, bv}, {0.f, 0.f, 0.f, 0.f}};
         if (steps > 0) {
             vm_begin(acc);
-            wide16_mm<NJX>(acc, sX + n * WLD + 4 * g4, wk);
+            if constexpr (NJX > 0) wide16_mm<NJX>(acc, sX + n * WLD + 4 * g4, wk);
             wide16_mm<NJR>(acc, hrow, wr);
             vm_end(acc);
         }
@@ -356,7 +409,7 @@ __device__ __forceinline__ void wide16_body(const LstmParams& p, const int bx, f
                 // layer 1's h_{t+1}, requested late in step t-1 (behind the partner gather: the two sets of granule registers
                 // never live together): registers -> LDS, waiting here if layer 1 is not that far yet
                 if (t > 0 && t + 1 < steps) ring_store(t + 1, xl + ((t + 1) & 1) * VBT * WLD);
-            } else {
+            } else if constexpr (ROLE != 4) {
                 if (t > 0 && t + 1 < steps) {
                     float* xb = xl + ((t + 1) & 1) * VBT * WLD;
 #pragma unroll
@@ -377,6 +430,11 @@ __device__ __forceinline__ void wide16_body(const LstmParams& p, const int bx, f
                 }
             }
             // ---- the four gates of a cell meet: 16 x 16 transpose through the wave's scratch ----
+            if constexpr (ROLE == 4) {   // + h1_t . K2 from the product role (requested a step ago); then the request of the next one
+                const f32x4 z = mail_wait(t);
+                acc[1] += z;
+                if (t + 1 < steps) mail_issue(t + 1);
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) tw[(4 * g4 + r) * 17 + n] = acc[0][r] + acc[1][r];
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // one wave's LDS instructions execute in order; the compiler must not reorder either
@@ -403,18 +461,29 @@ __device__ __forceinline__ void wide16_body(const LstmParams& p, const int bx, f
                 ++epoch;
                 par = ROLE == 1 ? (unsigned)t * PARITY : (epoch & 1u) * PARITY;
                 XCH_STORE_B64(ticket.same_xcd, ((vu32x2){__float_as_uint(hc), epoch}), xrs, pub_off, par);
+                if constexpr (ROLE == 1) {   // (no descriptor range outside the three-role launch: the store is dropped)
+                    __builtin_amdgcn_raw_buffer_store_b64(((vu32x2){__float_as_uint(hc), epoch}), mirrs, pub_off, par, 16 /* sc1 */);
+                }
             }
             __syncthreads();   // barrier 1: every wave is done reading sH; x_{t+1} is in LDS
             if (do_xch) sH[row_o * WLD + unit] = hc;
             acc[0] = (f32x4){bv, bv, bv, bv};
             acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (more) {   // x_{t+1} . K needs no remote data: it runs under the exchange
-                vm_begin(acc);
-                wide16_mm<NJX>(acc, sX + ((t + 1) & 1) * VBT * WLD + n * WLD + 4 * g4, wk);
-                vm_end(acc);
+            if constexpr (NJX > 0) {
+                if (more) {   // x_{t+1} . K needs no remote data: it runs under the exchange
+                    vm_begin(acc);
+                    wide16_mm<NJX>(acc, sX + ((t + 1) & 1) * VBT * WLD + n * WLD + 4 * g4, wk);
+                    vm_end(acc);
+                }
             }
             if (do_xch) gather_issue(par);
+#if defined(FOV_DBG_W16_NOL2GATHER)   // timing experiments (tools/w16_variants.sh): WRONG results
+            if (do_xch && ROLE != 4) gather_finish(par);
+#elif defined(FOV_DBG_W16_NOL1GATHER)
+            if (do_xch && ROLE != 1) gather_finish(par);
+#else
             if (do_xch) gather_finish(par);
+#endif
             __syncthreads();   // barrier 2: the whole h_t tile is in LDS
             if (sFlag[0]) { aborted = true; break; }
             if constexpr (ROLE == 2) {
@@ -447,6 +516,158 @@ __global__ __launch_bounds__(256, 1) void lstm_wide16_kernel(LstmParams p) {
 struct Wide16Pair {
     LstmParams l1, l2;
 };
+
+// ---------------------------------------------------------------------------------------------------------------
+// Round 4: the PRODUCT role of the three-role launch (lstm_wide16_trio_kernel).  In the two-role launch a wave of layer 2
+// issues 256 MFMAs per step - 128 for x_t . K2 (x_t = layer 1's h_t) and 128 for h_{t-1} . R2 - on ONE matrix pipe:
+// 3.9 us of the 6.75 us a step takes (tools/a10_prologue_probe.py), with half of the chip idle at lstm.py's batch of 32
+// (2 tiles x 32 workgroups x 2 layers = 128 CUs).  x_t . K2 does not depend on layer 2's recurrence: here a third set of
+// workgroups, one per workgroup of layer 2 and with the same (group, slice, wave, lane) -> gate column map, keeps the K2
+// slice in its accumulation registers, gathers layer 1's h_t tile from the ring as layer 2 used to, forms
+// z_t = h1_t . K2 for its 64 gate columns and hands every lane's D fragment (rows 4 g4 + r of column n) to THE SAME lane of
+// its layer-2 partner through a mailbox: T slots of 256 lanes x 32 bytes, two 16-byte stores {z0, tag, z1, tag},
+// {z2, tag, z3, tag} with tag = base + 1 + t - the data is the flag, as everywhere in the exchange; a ring of T slots needs
+// no back-pressure.  Layer 2 (ROLE 4 of wide16_body) adds z_t to its pre-activations at the top of step t and keeps R2 only.
+// ---------------------------------------------------------------------------------------------------------------
+template <int WH>
+__device__ __forceinline__ void wide16_product_body(const LstmParams& p, const int bx, float* smem) {
+    constexpr int WG = WH / 16, NJX = WH / 16, WLD = WH + 8, H4 = 4 * WH, NRG = WH / 32;
+    constexpr size_t SLOT = (size_t)VBT * WH;
+    constexpr unsigned PARITY = VBT * WH * 8u;
+    float* sX = smem;                       // [2][16][WLD]: layer 1's h tiles of two consecutive steps
+    int* sFlag = (int*)(sX + 2 * VBT * WLD);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, g4 = lane >> 4;
+    const int group = bx / WG, slice = bx - group * WG;
+    const int steps = p.T;
+    const int unit = 16 * slice + 4 * wave + (n & 3);
+    const int col = (n >> 2) * WH + unit;
+    __shared__ unsigned sXch[4];
+    const unsigned arrival = xch_arrive(p.status, sXch, -1, 0);   // header words + arrival count; no handshake of its own
+    const bool poisoned = xch_poisoned(p.status);
+    if (tid == 0) sFlag[0] = poisoned ? 1 : 0;
+    const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.K), 0, WH * H4 * 4, 0x00020000);
+    float wk[NJX][4];
+#pragma unroll
+    for (int j = 0; j < NJX; ++j)
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+            wk[j][s] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(krs, (unsigned)(((16 * j + 4 * g4 + s) * H4 + col) * 4), 0, 0));
+    const __amdgpu_buffer_rsrc_t ringrs = __builtin_amdgcn_make_buffer_rsrc(   // the MIRROR of layer 1's ring (sc1 stores: visible on every XCD)
+        p.xch + w16_mirror_base(p.num_groups, p.T, WH) + (size_t)group * p.T * SLOT, 0, p.T * (int)(SLOT * sizeof(unsigned long long)), 0x00020000);
+    const __amdgpu_buffer_rsrc_t mbrs = __builtin_amdgcn_make_buffer_rsrc(
+        p.xch + w16_mail_base(p.num_groups, p.T, WH) + ((size_t)group * WG + slice) * p.T * W16_MAIL, 0,
+        p.T * (int)(W16_MAIL * sizeof(unsigned long long)), 0x00020000);
+    __syncthreads();
+    const XchTicket ticket = xch_ticket(sXch, arrival);
+    bool aborted = sFlag[0] != 0;
+
+    // thread (row tid / 16, c = tid % 16) gathers the unit pairs c + 16 i of layer 1's h tile of step s (slot s, tags
+    // base + 1 + s), one 16-byte load per pair (as ROLE 2 of wide16_body)
+    vu32x4 xg[NRG];
+    const unsigned vo = (unsigned)(((tid >> 4) * WH + 2 * (tid & 15)) * 8);
+    auto ring_issue = [&](int s_) {
+#pragma unroll
+        for (int i = 0; i < NRG; ++i) xg[i] = __builtin_amdgcn_raw_buffer_load_b128(ringrs, vo + i * 32 * 8, (unsigned)s_ * PARITY, 16);
+    };
+    auto ring_store = [&](int s_, float* dst) {
+        const unsigned want = ticket.base + 1u + (unsigned)s_;
+        unsigned bad = 0;
+#pragma unroll
+        for (int i = 0; i < NRG; ++i) {
+            if (xg[i].y == want && xg[i].w == want) {
+                dst[32 * i] = __uint_as_float(xg[i].x);
+                dst[32 * i + 1] = __uint_as_float(xg[i].z);
+            } else {
+                bad |= (1u << i);
+            }
+        }
+        unsigned spins = 0;
+#ifdef FOV_DBG_W16_NOPRODGATHER   // timing experiment: WRONG results
+        bad = 0;
+#endif
+        while (__any(bad != 0)) {
+            ++spins;
+            if (spins > VSPIN || ((spins & 63u) == 0 && xch_poisoned(p.status))) {
+                if (lane == 0) {
+                    xch_give_up(p.status);
+                    sFlag[0] = 1;
+                }
+                break;
+            }
+            __builtin_amdgcn_s_sleep(2);
+            asm volatile("" ::: "memory");
+            // ONE 16-byte probe per lane and sweep while layer 1 is not that far (its last piece: the pieces of a step appear
+            // within a fraction of a microsecond of each other); the 16 loads of the full sweep only behind a current probe.
+            // Sweeping all of them polled 64 KB per workgroup and iteration through the fabric the layers exchange over:
+            // 0.7 us per step of the whole launch (tools/w16_variants.sh, NOPRODGATHER).
+            {
+                const vu32x4 pv = __builtin_amdgcn_raw_buffer_load_b128(ringrs, vo + (NRG - 1) * 32 * 8, (unsigned)s_ * PARITY, 16);
+                if (!__any(pv.y == want && pv.w == want)) continue;
+            }
+#pragma unroll
+            for (int i0 = 0; i0 < NRG; i0 += 8) {
+                vu32x4 tv[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) tv[i] = __builtin_amdgcn_raw_buffer_load_b128(ringrs, vo + (i0 + i) * 32 * 8, (unsigned)s_ * PARITY, 16);
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    if (((bad >> (i0 + i)) & 1u) && tv[i].y == want && tv[i].w == want) {
+                        dst[32 * (i0 + i)] = __uint_as_float(tv[i].x);
+                        dst[32 * (i0 + i) + 1] = __uint_as_float(tv[i].z);
+                        bad &= ~(1u << (i0 + i));
+                    }
+            }
+        }
+    };
+    float* xl = sX + (tid >> 4) * WLD + 2 * (tid & 15);
+    if (!aborted && steps > 0) ring_issue(0);
+    for (int t = 0; t < steps && !aborted; ++t) {
+        ring_store(t, xl + (t & 1) * VBT * WLD);   // waits here while layer 1 is not that far yet
+        __syncthreads();   // the tile of step t is in LDS; every wave is done with the MFMAs of step t - 1 (the other buffer)
+        if (sFlag[0]) { aborted = true; break; }
+        if (t + 1 < steps) ring_issue(t + 1);
+        f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#ifndef FOV_DBG_W16_NOPRODMM   // timing experiment (tools/w16_variants.sh): WRONG results without
+        vm_begin(acc);
+        wide16_mm<NJX>(acc, sX + (t & 1) * VBT * WLD + n * WLD + 4 * g4, wk);
+        vm_end(acc);
+#endif
+        const f32x4 z = acc[0] + acc[1];
+        const unsigned tag = ticket.base + 1u + (unsigned)t;
+        const unsigned so = (unsigned)t * (unsigned)(W16_MAIL * 8u);
+        __builtin_amdgcn_raw_buffer_store_b128((vu32x4){__float_as_uint(z[0]), tag, __float_as_uint(z[1]), tag}, mbrs, (unsigned)(tid * 32), so, 16 /* sc1 */);
+        __builtin_amdgcn_raw_buffer_store_b128((vu32x4){__float_as_uint(z[2]), tag, __float_as_uint(z[3]), tag}, mbrs, (unsigned)(tid * 32 + 16), so, 16);
+    }
+    xch_settle(p.status, ticket, (unsigned)p.epoch_span);
+}
+
+// Three roles, one launch (at most two tiles): layer 1, the products x_t . K2, layer 2.  The grid is 8 x 32 blocks, block b is
+// member b / 8 of "XCD group" b % 8 (round-robin dispatch: one XCD, verified by the layers' hello handshakes): XCD groups
+// [0, tiles) are layer 1's tiles, [tiles, 2 tiles) the product role's, [2 tiles, 3 tiles) layer 2's - every 32-workgroup group
+// has an XCD (32 CUs) of its own and the layers exchange through its L2 (sc0 stores, xch_common.h), 4.2 us per step against
+// 5.7 with a group's members dealt over all XCDs (tools/w16_variants.sh); what crosses XCDs - layer 1's h_t to the product
+// role (the mirror ring), z_t to layer 2 (the mailboxes) - is written with sc1 stores.  Spare blocks count as arrived and leave.
+template <int ACT, int WH>
+__global__ __launch_bounds__(256, 1) void lstm_wide16_trio_kernel(Wide16Pair pp) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int WG = WH / 16;
+    const int tiles = pp.l1.num_groups;
+    const int xg = (int)blockIdx.x & 7, member = (int)blockIdx.x >> 3;
+    const int role = xg / tiles, group = xg - role * tiles;
+    if (role > 2) {
+        __shared__ unsigned sSpare[4];
+        xch_arrive(pp.l1.status, sSpare, -1, 0);
+        return;
+    }
+    const int bx = group * WG + member;
+    if (role == 0) wide16_body<ACT, 6, WH, 1>(pp.l1, bx, smem);
+    else if (role == 1) wide16_product_body<WH>(pp.l2, bx, smem);
+    else wide16_body<ACT, 0, WH, 4>(pp.l2, bx, smem);
+}
+
+// Two roles (more than two tiles): the first num_groups * WG blocks are layer 1, the rest layer 2 with K2 in its own registers
 template <int ACT, int WH>
 __global__ __launch_bounds__(256, 1) void lstm_wide16_pair_kernel(Wide16Pair pp) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -819,11 +1040,19 @@ int launch_wide16_pair(const LstmParams& a, const LstmParams& b, hipStream_t str
     }
     if (int rc_ = xch_account(pp.l1.status, pp.l1.epoch_span, stream)) return rc_;
     const size_t lds = sizeof(float) * (3 * VBT * (WH + 8) + 4 * 16 * 17) + 64;
-    void (*kern)(Wide16Pair) = a.act == FOV_ACT_HARD_SIGMOID ? lstm_wide16_pair_kernel<FOV_ACT_HARD_SIGMOID, WH>
-                                                             : lstm_wide16_pair_kernel<FOV_ACT_SIGMOID, WH>;
+    // three roles (layer 2's input projection on workgroups of its own) while they all fit the chip and the mailboxes the
+    // granule area: lstm.py's batch of 32 (two tiles)
+    const int tiles = pp.l1.num_tiles;
+    const bool trio = !env_knobs().no_wide16_trio && tiles <= 2 && 8 * WG <= device_cu_count() &&
+                      (w16_mirror_base(tiles, a.T, WH) + (size_t)tiles * a.T * VBT * WH) * sizeof(unsigned long long) <= kXchBytes - kHelloBytes;
+    pp.l1.trio = pp.l2.trio = trio ? 1 : 0;
+    void (*kern)(Wide16Pair) = trio ? (a.act == FOV_ACT_HARD_SIGMOID ? lstm_wide16_trio_kernel<FOV_ACT_HARD_SIGMOID, WH>
+                                                                     : lstm_wide16_trio_kernel<FOV_ACT_SIGMOID, WH>)
+                                    : (a.act == FOV_ACT_HARD_SIGMOID ? lstm_wide16_pair_kernel<FOV_ACT_HARD_SIGMOID, WH>
+                                                                     : lstm_wide16_pair_kernel<FOV_ACT_SIGMOID, WH>);
     int rc = ensure_dynamic_lds((const void*)kern, lds);
     if (rc) return rc;
-    hipLaunchKernelGGL(kern, dim3(2 * pp.l1.num_groups * WG), dim3(256), lds, stream, pp);
+    hipLaunchKernelGGL(kern, dim3(trio ? 8 * WG : 2 * pp.l1.num_groups * WG), dim3(256), lds, stream, pp);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("two-layer width-512 launch: %s", hipGetErrorString(e)); return FOV_ERR_LAUNCH; }
     return FOV_OK;

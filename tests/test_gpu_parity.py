@@ -243,9 +243,16 @@ def test_two_width_512_layers_one_launch():
         h02, c02 = st[1] if st[1] else (None, None)
         r1 = ops.lstm_seq_train(dev(x), *d1, h01, c01)
         r2 = ops.lstm_seq_train(r1[0], *d2, h02, c02)
-        for got, ref in ((o1, r1), (o2, r2)):
+        # at most two tiles: THREE roles (layer 2's input projection h1_t . K2 on workgroups of its own, lstm_wide16.hip) -
+        # layer 2 then adds that product to bias + h . R2 instead of accumulating all three in one chain: same values up to
+        # the order of the fp32 sums
+        three_roles = B <= 32
+        for li, (got, ref) in enumerate(((o1, r1), (o2, r2))):
             for k in range(4 if reserve else 3):
-                assert torch.equal(got[k], ref[k]), (B, T, k)
+                if li == 1 and three_roles:
+                    assert torch.allclose(got[k], ref[k], rtol=2e-5, atol=2e-6), (B, T, k, float((got[k] - ref[k]).abs().max()))
+                else:
+                    assert torch.equal(got[k], ref[k]), (B, T, k)
         ref = x.astype(np.float64)
         for l, (K, R, b) in enumerate((l1, l2)):
             s0 = st[l]
