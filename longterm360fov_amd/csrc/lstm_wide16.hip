@@ -154,8 +154,9 @@ __device__ __forceinline__ void wide16_body(const LstmParams& p, const int bx, f
         ROLE == 4 ? p.T * (int)(W16_MAIL * sizeof(unsigned long long)) : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
         p.xch + xbase, 0, (ROLE == 1 ? p.T : 2) * (int)(SLOT * sizeof(unsigned long long)), 0x00020000);
-    const __amdgpu_buffer_rsrc_t ringrs = __builtin_amdgcn_make_buffer_rsrc(   // ROLE 2: layer 1's ring of the same group
-        p.xch + (size_t)group * p.T * SLOT, 0, ROLE == 2 ? p.T * (int)(SLOT * sizeof(unsigned long long)) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ringrs = __builtin_amdgcn_make_buffer_rsrc(   // ROLE 2: layer 1's ring of the same group (XCD-placed launch: its mirror)
+        p.xch + (p.trio ? w16_mirror_base(p.num_groups, p.T, WH) : (size_t)0) + (size_t)group * p.T * SLOT, 0,
+        ROLE == 2 ? p.T * (int)(SLOT * sizeof(unsigned long long)) : 0, 0x00020000);
     const unsigned pub_off = (unsigned)(row_o * WH + unit) * 8u;
     // gather: thread (row tid / 16, half (tid / 8) % 2, unit pair tid % 8) brings units (2p, 2p + 1) of partner slices
     // slice + 1 + half * WG/2 + j, j < WG/2, with one 16-byte load each (round 3: half the gather instructions; every 8-byte
@@ -667,13 +668,23 @@ __global__ __launch_bounds__(256, 1) void lstm_wide16_trio_kernel(Wide16Pair pp)
     else wide16_body<ACT, 0, WH, 4>(pp.l2, bx, smem);
 }
 
-// Two roles (more than two tiles): the first num_groups * WG blocks are layer 1, the rest layer 2 with K2 in its own registers
+// Two roles (three or four tiles): layer 1 and layer 2 with K2 in its own registers, placed like the three-role launch - an XCD
+// per 32-workgroup group (XCD groups [0, tiles) layer 1, [tiles, 2 tiles) layer 2), layer 2 reads layer 1's h_t from the mirror ring
 template <int ACT, int WH>
 __global__ __launch_bounds__(256, 1) void lstm_wide16_pair_kernel(Wide16Pair pp) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int per_role = pp.l1.num_groups * (WH / 16);
-    if ((int)blockIdx.x < per_role) wide16_body<ACT, 6, WH, 1>(pp.l1, (int)blockIdx.x, smem);
-    else wide16_body<ACT, WH / 16, WH, 2>(pp.l2, (int)blockIdx.x - per_role, smem);
+    constexpr int WG = WH / 16;
+    const int tiles = pp.l1.num_groups;
+    const int xg = (int)blockIdx.x & 7, member = (int)blockIdx.x >> 3;
+    const int role = xg / tiles, group = xg - role * tiles;
+    if (role > 1) {
+        __shared__ unsigned sSpare[4];
+        xch_arrive(pp.l1.status, sSpare, -1, 0);
+        return;
+    }
+    const int bx = group * WG + member;
+    if (role == 0) wide16_body<ACT, 6, WH, 1>(pp.l1, bx, smem);
+    else wide16_body<ACT, WH / 16, WH, 2>(pp.l2, bx, smem);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1023,8 +1034,8 @@ bool wide16_pair_shape(int B, int T, int F, int H) {
     const bool off = env_knobs().no_stack2 != 0;
     if (off || H != 512 || B <= 0 || T < 2 || F < 1 || F > 96) return false;
     const int tiles = (B + VBT - 1) / VBT;
-    if (2 * tiles * (H / 16) > device_cu_count()) return false;
-    return (size_t)tiles * (T + 2) * VBT * H * sizeof(unsigned long long) <= kXchBytes - kHelloBytes;
+    if (tiles > 4 || 8 * (H / 16) > device_cu_count()) return false;   // an XCD per group: at most 8 groups of 32 workgroups
+    return (w16_mirror_base(tiles, T, H) + (size_t)tiles * T * VBT * H) * sizeof(unsigned long long) <= kXchBytes - kHelloBytes;
 }
 
 int launch_wide16_pair(const LstmParams& a, const LstmParams& b, hipStream_t stream) {
@@ -1043,16 +1054,15 @@ int launch_wide16_pair(const LstmParams& a, const LstmParams& b, hipStream_t str
     // three roles (layer 2's input projection on workgroups of its own) while they all fit the chip and the mailboxes the
     // granule area: lstm.py's batch of 32 (two tiles)
     const int tiles = pp.l1.num_tiles;
-    const bool trio = !env_knobs().no_wide16_trio && tiles <= 2 && 8 * WG <= device_cu_count() &&
-                      (w16_mirror_base(tiles, a.T, WH) + (size_t)tiles * a.T * VBT * WH) * sizeof(unsigned long long) <= kXchBytes - kHelloBytes;
-    pp.l1.trio = pp.l2.trio = trio ? 1 : 0;
+    const bool trio = !env_knobs().no_wide16_trio && tiles <= 2;   // (granule budget: wide16_pair_shape)
+    pp.l1.trio = pp.l2.trio = 1;   // both launches are XCD-placed: layer 1 mirrors its ring for the readers on other XCDs
     void (*kern)(Wide16Pair) = trio ? (a.act == FOV_ACT_HARD_SIGMOID ? lstm_wide16_trio_kernel<FOV_ACT_HARD_SIGMOID, WH>
                                                                      : lstm_wide16_trio_kernel<FOV_ACT_SIGMOID, WH>)
                                     : (a.act == FOV_ACT_HARD_SIGMOID ? lstm_wide16_pair_kernel<FOV_ACT_HARD_SIGMOID, WH>
                                                                      : lstm_wide16_pair_kernel<FOV_ACT_SIGMOID, WH>);
     int rc = ensure_dynamic_lds((const void*)kern, lds);
     if (rc) return rc;
-    hipLaunchKernelGGL(kern, dim3(trio ? 8 * WG : 2 * pp.l1.num_groups * WG), dim3(256), lds, stream, pp);
+    hipLaunchKernelGGL(kern, dim3(8 * WG), dim3(256), lds, stream, pp);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("two-layer width-512 launch: %s", hipGetErrorString(e)); return FOV_ERR_LAUNCH; }
     return FOV_OK;

@@ -1,6 +1,6 @@
 """How much of lstm.py's two-layer forward launch (fov_lstm_stack2_fwd at B = 32, F = 90, H = 512) is its prologue?  Times the
 launch at several sequence lengths: the intercept of the line is what a launch costs before its first step.
-usage: python tools/a10_prologue_probe.py"""
+usage: python tools/a10_prologue_probe.py [batch]"""
 import os
 import sys
 
@@ -11,7 +11,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from longterm360fov_amd import ops  # noqa: E402
 from oracle import fov_oracle as O  # noqa: E402
 
-B, F, H = 32, 90, 512
+B, F, H = (int(sys.argv[1]) if len(sys.argv) > 1 else 32), 90, 512
 rng = np.random.default_rng(0)
 layers = [O.init_lstm(rng, F, H), O.init_lstm(rng, H, H)]
 d = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
