@@ -705,7 +705,8 @@ def bench_a10(args, rank, world, use_dist):
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "lstm.py native shape: 2 x LSTMCell(400), batch 32, 10 steps, 90 features; zero-padded to width 512 "
                                    "on the persistent register-resident kernel (32 workgroups per 16-sequence tile), both layers "
-                                   "in one launch (layer 2 a few steps behind layer 1 on other CUs); flops counted at H = 400",
+                                   "in one launch of three roles, each 32-workgroup group on an XCD of its own (layer 1, the products "
+                                   "h1.K2, layer 2 a few steps behind); flops counted at H = 400",
                        "global_batch": B * world,
                        "parallelism": "replicas x%d" % world},
             "roofline": {"bound": "mfma", "achieved": r["tflops"], "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
