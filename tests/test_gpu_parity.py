@@ -263,6 +263,54 @@ def test_two_width_512_layers_one_launch():
     assert not ops.lstm_stack2_supported(80, 10, F, H) and not ops.lstm_stack2_supported(32, 1, F, H) and not ops.lstm_stack2_supported(32, 10, F, 256)
 
 
+@pytest.mark.parametrize("B,T,with_state,reserve", [(1, 2, False, False), (16, 3, True, True), (17, 5, False, True), (32, 2, True, False),
+                                                     (31, 7, True, True)])
+def test_two_width_512_layers_three_roles_two_roles_two_launches(B, T, with_state, reserve):
+    """At most two tiles: the one-launch form runs as THREE roles (layer 1, the products h1 . K2, layer 2; lstm_wide16.hip).
+    FOV_NO_WIDE16_TRIO=1 keeps two roles on the same XCD-per-group grid - bit-identical to two separate layer launches;
+    the three-role form differs from both in the order of layer 2's fp32 sums only.  Fed states, the tape, ragged tiles,
+    repeated launches on one workspace, and the fp64 oracle."""
+    import os
+    from longterm360fov_amd import _lib
+    ops = _ops()
+    rng = np.random.default_rng(B * 100 + T)
+    H, F = 512, 90
+    l1 = O.init_lstm(rng, F, H, np.float32)
+    l2 = O.init_lstm(rng, H, H, np.float32)
+    d1, d2 = tuple(dev(a) for a in l1), tuple(dev(a) for a in l2)
+    x = rng.uniform(-1, 1, (B, T, F)).astype(np.float32)
+    st = [None, None]
+    if with_state:
+        st = [(dev((0.3 * rng.standard_normal((B, H))).astype(np.float32)), dev((0.3 * rng.standard_normal((B, H))).astype(np.float32)))
+              for _ in range(2)]
+    ws = ops.Workspace()
+    for _ in range(3):
+        t1, t2 = ops.lstm_stack2(dev(x), d1, d2, st[0], st[1], workspace=ws, reserve=reserve)
+    os.environ["FOV_NO_WIDE16_TRIO"] = "1"
+    _lib.lib().fov_reload_env()
+    try:
+        for _ in range(2):
+            p1, p2 = ops.lstm_stack2(dev(x), d1, d2, st[0], st[1], workspace=ws, reserve=reserve)
+    finally:
+        os.environ.pop("FOV_NO_WIDE16_TRIO", None)
+        _lib.lib().fov_reload_env()
+    ws.check()
+    h01, c01 = st[0] if st[0] else (None, None)
+    h02, c02 = st[1] if st[1] else (None, None)
+    r1 = ops.lstm_seq_train(dev(x), *d1, h01, c01)
+    r2 = ops.lstm_seq_train(r1[0], *d2, h02, c02)
+    for k in range(4 if reserve else 3):
+        assert torch.equal(p1[k], r1[k]) and torch.equal(p2[k], r2[k]) and torch.equal(t1[k], r1[k]), (B, T, k)
+        assert torch.allclose(t2[k], r2[k], rtol=2e-5, atol=2e-6), (B, T, k, float((t2[k] - r2[k]).abs().max()))
+    ref = x.astype(np.float64)
+    for l, (K, R, b) in enumerate((l1, l2)):
+        s0 = st[l]
+        ref, _, _ = O.lstm_layer(ref, K.astype(np.float64), R.astype(np.float64), b.astype(np.float64),
+                                 None if s0 is None else s0[0].cpu().numpy().astype(np.float64),
+                                 None if s0 is None else s0[1].cpu().numpy().astype(np.float64), act="sigmoid")
+    assert_parity(t2[0], ref, "three roles B=%d T=%d" % (B, T))
+
+
 def test_fused_decode_padded_grid_group_counts():
     """H = 128 fused encoder + decoder with a group count that is no multiple of eight: the grid is padded so that a group's
     members share an XCD (spare workgroups leave at once); 2, 9 and 13 tiles (the last ragged), repeated launches on one
