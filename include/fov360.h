@@ -406,6 +406,13 @@ int fov_mse_dense_grad_w(const float* y, const float* target, float* dpre, float
                          float weight, int time_major_B, int time_major_T, int O, void* workspace, size_t workspace_bytes,
                          fov_stream_t stream);
 
+/* fov_mse_dense_grad_w (batch-major) that also leaves the Dense head's BIAS gradient: db[o] = sum over the n / O rows of
+ * dpre[row][o] (written, not added) - the `db` half of fov_dense_bwd (keras Dense(O) behind mean_squared_error,
+ * mycode/FoV_seq2seq.py:96-101,267) from the launch that forms dpre; widths O <= 8 inside the kernel, wider heads by a column-sum
+ * launch.  Pass db = NULL to fov_dense_bwd afterwards. */
+int fov_mse_dense_grad_db(const float* y, const float* target, float* dpre, float* loss, float* db, int64_t n, int O, int activation,
+                          float weight, void* workspace, size_t workspace_bytes, fov_stream_t stream);
+
 /* x[0..n) *= s */
 int fov_scale(float* x, int64_t n, float s, fov_stream_t stream);
 

@@ -67,6 +67,7 @@ SIGNATURES = {
     "fov_dense_bwd": (_I, [_P] * 6 + [_I] * 4 + [_P, _SZ, _P]),
     "fov_mse_dense_grad": (_I, [_P] * 4 + [ctypes.c_int64, _I, _P, _SZ, _P]),
     "fov_mse_dense_grad_w": (_I, [_P] * 4 + [ctypes.c_int64, _I, ctypes.c_float, _I, _I, _I, _P, _SZ, _P]),
+    "fov_mse_dense_grad_db": (_I, [_P] * 5 + [ctypes.c_int64, _I, _I, ctypes.c_float, _P, _SZ, _P]),
     "fov_scale": (_I, [_P, ctypes.c_int64, ctypes.c_float, _P]),
     "fov_act_bwd": (_I, [_P] * 4 + [ctypes.c_int64, _I, _P]),
     "fov_act_fwd": (_I, [_P, _P, ctypes.c_int64, _I, _P]),

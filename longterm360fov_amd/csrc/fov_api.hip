@@ -905,6 +905,18 @@ int fov_mse_dense_grad_w(const float* y, const float* target, float* dpre, float
                             tm ? O : 1, (float*)workspace, workspace_bytes / sizeof(float), (hipStream_t)stream);
 }
 
+int fov_mse_dense_grad_db(const float* y, const float* target, float* dpre, float* loss, float* db, int64_t n, int O, int activation,
+                          float weight, void* workspace, size_t workspace_bytes, fov_stream_t stream) {
+    if (n < 0 || O < 1 || n % O || (n > 0 && (!y || !target || !dpre)) || !db || (activation != 0 && activation != 1)) {
+        set_error("fov_mse_dense_grad_db: invalid argument");
+        return FOV_ERR_INVALID;
+    }
+    int rc = check_ws(workspace, workspace_bytes, sizeof(float) * (9 * ((size_t)(n + 255) / 256) + 64 + (size_t)256 * O));
+    if (rc) return rc;
+    return mse_dense_grad_w(y, target, dpre, loss, (long)n, activation, weight, 1, 0, 1, (float*)workspace, workspace_bytes / sizeof(float),
+                            (hipStream_t)stream, db, O);
+}
+
 int fov_scale(float* x, int64_t n, float s, fov_stream_t stream) {
     if (n < 0 || (n > 0 && !x)) { set_error("fov_scale: invalid argument"); return FOV_ERR_INVALID; }
     return scale_inplace(x, (long)n, s, (hipStream_t)stream);

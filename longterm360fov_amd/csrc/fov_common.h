@@ -255,7 +255,7 @@ int dense_bwd(const float* x, const float* W, const float* dpre, float* dx, floa
 int mse_dense_grad(const float* y, const float* target, float* dpre, float* loss, long n, int activation, float* scratch,
                    size_t scratch_floats, hipStream_t stream);
 int mse_dense_grad_w(const float* y, const float* target, float* dpre, float* loss, long n, int activation, float weight,
-                     int tmB, int tmT, int O, float* scratch, size_t scratch_floats, hipStream_t stream);
+                     int tmB, int tmT, int O, float* scratch, size_t scratch_floats, hipStream_t stream, float* db = nullptr, int dbO = 0);
 int scale_inplace(float* x, long n, float s, hipStream_t stream);
 int act_bwd(const float* dy, const float* y, const float* base, float* out, long n, int activation, hipStream_t stream);
 int matmul_f32(const float* a, const float* b, float* c, int M, int K, int N, float* scratch, size_t scratch_floats,

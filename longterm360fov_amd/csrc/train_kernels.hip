@@ -599,13 +599,20 @@ __device__ unsigned g_loss_tickets[kLossTickets];
 __global__ __launch_bounds__(256) void mse_dense_grad_kernel(const float* __restrict__ y, const float* __restrict__ target,
                                                              float* __restrict__ dpre, float* __restrict__ loss_part,
                                                              long n, float scale, int activation, int tmB, int tmT, int O,
-                                                             unsigned* __restrict__ ticket, float* __restrict__ loss_out, float loss_scale) {
+                                                             unsigned* __restrict__ ticket, float* __restrict__ loss_out, float loss_scale,
+                                                             float* __restrict__ col_part = nullptr, float* __restrict__ db_out = nullptr,
+                                                             int dbO = 0) {
     // tmT > 0: y / dpre are time-major (T,B,O) against a batch-major target (B,T,O) - the unrolled decoders keep
     // their tape time-major, no transposed copies
+    // dbO > 0 (batch-major only, with a ticket): the Dense bias gradient db[o] = sum over rows of dpre[row][o] as well - per-block
+    // column sums in a fixed order, added over the blocks (in block order) by the block that takes the last ticket: the
+    // column-sum launches of dense_bwd (7.6 us at the reference's batch) are gone
     __shared__ float red[256];
+    __shared__ float gval[256];
     __shared__ int is_last;
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     float sq = 0.f;
+    if (dbO > 0) gval[threadIdx.x] = 0.f;
     if (i < n) {
         long ti = i;
         if (tmT > 0) {   // i = (t*B + b)*O + o  ->  (b*T + t)*O + o
@@ -619,11 +626,22 @@ __global__ __launch_bounds__(256) void mse_dense_grad_kernel(const float* __rest
         float gsc = 2.f * d * scale;
         if (activation == 1) gsc *= (1.f - yv * yv);
         dpre[i] = gsc;
+        if (dbO > 0) gval[threadIdx.x] = gsc;
     }
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) sq += __shfl_xor(sq, m);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sq;
     __syncthreads();
+    if (dbO > 0) {
+        if ((int)threadIdx.x < dbO) {   // element j of the block is i0 + j, its column (i0 + j) % dbO
+            const int c0 = (int)(((long)blockIdx.x * 256) % dbO);
+            float a = 0.f;
+            for (int j = ((int)threadIdx.x - c0 + dbO) % dbO; j < 256; j += dbO) a += gval[j];
+            __hip_atomic_store(col_part + (size_t)blockIdx.x * 8 + threadIdx.x, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __threadfence();
+        }
+        __syncthreads();
+    }
     if (threadIdx.x == 0) {
         const float part = red[0] + red[1] + red[2] + red[3];
         if (ticket) {
@@ -638,6 +656,11 @@ __global__ __launch_bounds__(256) void mse_dense_grad_kernel(const float* __rest
     __syncthreads();
     if (is_last) {   // the arithmetic of sum_scale_kernel (same order: bit-identical loss), by the block that finished last
         __threadfence();
+        if (dbO > 0 && (int)threadIdx.x < dbO) {
+            float a = 0.f;
+            for (int b = 0; b < (int)gridDim.x; ++b) a += __hip_atomic_load(col_part + (size_t)b * 8 + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            db_out[threadIdx.x] = a;
+        }
         float a = 0.f;
         for (int i = threadIdx.x; i < (int)gridDim.x; i += 256) a += __hip_atomic_load(loss_part + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         red[threadIdx.x] = a;
@@ -1865,15 +1888,25 @@ int mse_dense_grad(const float* y, const float* target, float* dpre, float* loss
 // global mean, so that a SUM all-reduce of gradients and loss gives the global-batch values without a scaling pass)
 // and optionally a time-major prediction.
 int mse_dense_grad_w(const float* y, const float* target, float* dpre, float* loss, long n, int activation, float weight,
-                     int tmB, int tmT, int O, float* scratch, size_t scratch_floats, hipStream_t stream) {
-    if (n <= 0) return FOV_OK;
+                     int tmB, int tmT, int O, float* scratch, size_t scratch_floats, hipStream_t stream, float* db, int dbO) {
+    if (n <= 0) {
+        if (db && dbO > 0) (void)hipMemsetAsync(db, 0, sizeof(float) * dbO, stream);
+        return FOV_OK;
+    }
     const long blocks = (n + 255) / 256;
-    if ((size_t)blocks > scratch_floats) { set_error("mse_dense_grad_w: scratch too small"); return FOV_ERR_WORKSPACE; }
+    if ((size_t)blocks * (db ? 9 : 1) > scratch_floats) { set_error("mse_dense_grad_w: scratch too small"); return FOV_ERR_WORKSPACE; }
     unsigned* ticket = loss ? next_loss_ticket() : nullptr;
+    const bool fused_db = db && ticket && dbO >= 1 && dbO <= 8 && tmT == 0 && n % dbO == 0;
     hipLaunchKernelGGL(mse_dense_grad_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, y, target, dpre, scratch, n,
-                       weight / (float)n, activation, tmB, tmT, O, ticket, loss, weight / (float)n);
+                       weight / (float)n, activation, tmB, tmT, O, ticket, loss, weight / (float)n,
+                       fused_db ? scratch + blocks : nullptr, fused_db ? db : nullptr, fused_db ? dbO : 0);
     int rc = check_launch("mse_dense_grad_w");
     if (rc) return rc;
+    if (db && !fused_db) {   // (no ticket slot, wide or time-major head: the column-sum launches)
+        if (dbO < 1 || n % dbO) { set_error("mse_dense_grad_w: db needs the head's width"); return FOV_ERR_INVALID; }
+        rc = colsum(dpre, db, (int)(n / dbO), dbO, 0, scratch + blocks, scratch_floats - blocks, stream);
+        if (rc) return rc;
+    }
     if (loss && !ticket) {
         hipLaunchKernelGGL(sum_scale_kernel, dim3(1), dim3(256), 0, stream, scratch, loss, (int)blocks, weight / (float)n);
         rc = check_launch("sum_scale");

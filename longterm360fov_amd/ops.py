@@ -747,10 +747,11 @@ def wgrad_fused(x1, x2, dpre, out, bias=True, accumulate=False, scratch=None, dt
     return out
 
 
-def mse_dense_grad(y, target, activation="tanh", scratch=None, dpre=None, loss=None, weight=1.0, time_major=False):
+def mse_dense_grad(y, target, activation="tanh", scratch=None, dpre=None, loss=None, weight=1.0, time_major=False, db=None):
     """Keras mean_squared_error + Dense activation derivative -> (dpre like y, loss (1,) tensor), both multiplied by
     `weight` (a rank's share n_local / n_global under data parallelism).  time_major: y / dpre are (T,B,O) while
-    target is (B,T,O) - the tape layout of the unrolled decoders, no transposed copies."""
+    target is (B,T,O) - the tape layout of the unrolled decoders, no transposed copies.  db (O,): also the head's bias
+    gradient (column sums of dpre), from the same launch - then dense_bwd is called with db=None."""
     y, target = _dev(y, "y"), _dev(target, "target")
     n = y.numel()
     tmB = tmT = O = 0
@@ -761,6 +762,14 @@ def mse_dense_grad(y, target, activation="tanh", scratch=None, dpre=None, loss=N
         assert y.shape == target.shape
     dpre = torch.empty_like(y) if dpre is None else dpre
     loss = torch.empty(1, dtype=torch.float32, device=y.device) if loss is None else loss
+    if db is not None:
+        assert not time_major
+        O = y.shape[-1]
+        assert _dev(db, "db").shape == (O,)
+        buf = (scratch or _default_scratch).get(4 * (9 * ((n + 255) // 256) + 64 + 256 * O), y.device)
+        check(_lib.lib().fov_mse_dense_grad_db(_ptr(y), _ptr(target), _ptr(dpre), _ptr(loss), _ptr(db), n, O,
+                                               1 if activation == "tanh" else 0, float(weight), buf.data_ptr(), buf.numel(), _stream()))
+        return dpre, loss
     buf = (scratch or _default_scratch).get(4 * ((n + 255) // 256 + 64), y.device)
     check(_lib.lib().fov_mse_dense_grad_w(_ptr(y), _ptr(target), _ptr(dpre), _ptr(loss), n,
                                           1 if activation == "tanh" else 0, float(weight), tmB, tmT, O,

@@ -356,9 +356,10 @@ class Seq2SeqTrainer(FlatParamTrainer):
         y = ops.dense(dhs_, w["dense_W"], w["dense_b"], activation="tanh")
         # the DP weight rides on the loss gradient (everything downstream is linear in it); the loss lands in the
         # flat buffer's last slot
+        # ... and the head's bias gradient (the column sums of dpre) comes from the same launch
         dpre, loss = ops.mse_dense_grad(y, target, "tanh", scratch=self.scratch, dpre=bufs["dpre"], loss=self.loss_slot,
-                                        weight=grad_weight)
-        d_hs, _, _ = ops.dense_bwd(dhs_, w["dense_W"], dpre, dW=g["dense_W"], db=g["dense_b"], scratch=self.scratch)
+                                        weight=grad_weight, db=g["dense_b"])
+        d_hs, _, _ = ops.dense_bwd(dhs_, w["dense_W"], dpre, dW=g["dense_W"], need_db=False, scratch=self.scratch)
         bd = ops.lstm_seq_bwd(dec_in, w["dec_K"], w["dec_R"], dhs_, dres, h0=ehT, c0=ecT, dhs=d_hs, dK=g["dec_K"],
                               dR=g["dec_R"], db=g["dec_b"], need_state_grads=True, act=self.act, dz=bufs["dz_dec"],
                               scratch=self.bwd_scratch)

@@ -1858,3 +1858,27 @@ def test_layer_bptt_with_sixteen_rows_or_fewer(B, T, F, H):
         for name, got, r in (("dK", dK, ref["dK"]), ("dR", dR, ref["dR"]), ("db", db, ref["db"])):
             err = np.abs(got.cpu().numpy().astype(np.float64) - (rep + 1) * r).max()
             assert err <= 2e-5 * (np.abs(r).max() + 1e-12) * (rep + 1) + 1e-9, (name, rep, err)
+
+
+@pytest.mark.parametrize("rows,O,act", [(320, 3, "tanh"), (30720, 3, "tanh"), (1000, 6, None), (257, 8, "tanh"), (512, 1, "tanh"), (100, 12, "tanh"), (1, 3, "tanh")])
+def test_dense_bias_gradient_from_the_loss_launch(rows, O, act):
+    """fov_mse_dense_grad_db: dpre, the loss AND the Dense head's bias gradient (column sums of dpre) from one launch -
+    block boundaries that are no multiple of the width, widths up to 8 in the kernel (12: the column-sum launches), a weight;
+    against fp64 column sums of the dpre the same call returns, and dpre / loss against the call without db."""
+    from longterm360fov_amd import ops
+    rng = np.random.default_rng(rows + O)
+    y = dev(np.tanh(rng.standard_normal((rows, O))))
+    t = dev(rng.uniform(-1, 1, (rows, O)))
+    db = torch.full((O,), 7.0, device="cuda")
+    sc = ops.Scratch()
+    for _ in range(3):   # the ticket ring: repeated launches
+        dpre, loss = ops.mse_dense_grad(y, t, act, scratch=sc, weight=0.5, db=db)
+    dpre0, loss0 = ops.mse_dense_grad(y, t, act, scratch=sc, weight=0.5)
+    assert torch.equal(dpre, dpre0) and torch.equal(loss, loss0)
+    ref = dpre.cpu().numpy().astype(np.float64).sum(axis=0)
+    got = db.cpu().numpy().astype(np.float64)
+    assert np.abs(got - ref).max() <= 1e-6 * max(1.0, np.abs(dpre.cpu().numpy()).sum(axis=0).max()), (got, ref)
+    # the same bits every time (fixed summation order)
+    db2 = torch.zeros((O,), device="cuda")
+    ops.mse_dense_grad(y, t, act, scratch=sc, weight=0.5, db=db2)
+    assert torch.equal(db, db2)
