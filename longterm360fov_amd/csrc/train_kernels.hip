@@ -632,13 +632,21 @@ __global__ __launch_bounds__(256) void mse_dense_grad_kernel(const float* __rest
     for (int m = 32; m >= 1; m >>= 1) sq += __shfl_xor(sq, m);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sq;
     __syncthreads();
+    __shared__ float cpart[32][8];
+    const int co = threadIdx.x & 7, cq = threadIdx.x >> 3;   // column, one of 32 strands of it
     if (dbO > 0) {
-        if ((int)threadIdx.x < dbO) {   // element j of the block is i0 + j, its column (i0 + j) % dbO
-            const int c0 = (int)(((long)blockIdx.x * 256) % dbO);
-            float a = 0.f;
-            for (int j = ((int)threadIdx.x - c0 + dbO) % dbO; j < 256; j += dbO) a += gval[j];
-            __hip_atomic_store(col_part + (size_t)blockIdx.x * 8 + threadIdx.x, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __threadfence();
+        // element j of the block is i0 + j, its column (i0 + j) % dbO: strand cq of column co takes every 32nd of them, the
+        // 32 strand sums are added in strand order (a fixed order: the same bits every time)
+        const int c0 = (int)(((long)blockIdx.x * 256) % dbO);
+        float a = 0.f;
+        if (co < dbO)
+            for (int j = (co - c0 + dbO) % dbO + dbO * cq; j < 256; j += dbO * 32) a += gval[j];
+        cpart[cq][co] = a;
+        __syncthreads();
+        if (threadIdx.x < 8) {
+            float sum = 0.f;
+            for (int q = 0; q < 32; ++q) sum += cpart[q][threadIdx.x];
+            gval[threadIdx.x] = sum;   // (every strand has been read: the barrier above; columns >= dbO are zero)
         }
         __syncthreads();
     }
@@ -646,6 +654,14 @@ __global__ __launch_bounds__(256) void mse_dense_grad_kernel(const float* __rest
         const float part = red[0] + red[1] + red[2] + red[3];
         if (ticket) {
             __hip_atomic_store(loss_part + blockIdx.x, part, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // the block's column sums leave through the SAME thread and fence (a fence per storing thread made the kernel
+            // 32 us at 720 blocks where it had been 4.8)
+            // two 16-byte stores (the fence below publishes them; col_part rows are 32 bytes, the area 16-byte aligned)
+            if (dbO > 0) {
+                f32x4* cp = (f32x4*)(col_part + (size_t)blockIdx.x * 8);
+                cp[0] = (f32x4){gval[0], gval[1], gval[2], gval[3]};
+                cp[1] = (f32x4){gval[4], gval[5], gval[6], gval[7]};
+            }
             __threadfence();
             is_last = atomicAdd(ticket, 1u) == gridDim.x - 1u;
         } else {
@@ -656,10 +672,28 @@ __global__ __launch_bounds__(256) void mse_dense_grad_kernel(const float* __rest
     __syncthreads();
     if (is_last) {   // the arithmetic of sum_scale_kernel (same order: bit-identical loss), by the block that finished last
         __threadfence();
-        if (dbO > 0 && (int)threadIdx.x < dbO) {
+        if (dbO > 0) {   // (block-uniform) the blocks' column sums: 32 strands per column over the blocks, then in strand order
+            // (L1-bypassing buffer loads, eight in flight: agent-scope atomic loads are issued one round trip at a time - 23 of them
+            // per lane made this kernel 36 us at 720 blocks)
+            const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(col_part, 0, (int)(gridDim.x * 8u * 4u), 0x00020000);
             float a = 0.f;
-            for (int b = 0; b < (int)gridDim.x; ++b) a += __hip_atomic_load(col_part + (size_t)b * 8 + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            db_out[threadIdx.x] = a;
+            for (int b0 = cq; b0 < (int)gridDim.x; b0 += 32 * 8) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u)   // blocks beyond the grid: offset past the descriptor, reads as 0
+                    v[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(prs, (unsigned)(((b0 + 32 * u) * 8 + co) * 4), 0, 16 /* sc1 */));
+#pragma unroll
+                for (int u = 0; u < 8; ++u) a += v[u];
+            }
+            if (co >= dbO) a = 0.f;
+            cpart[cq][co] = a;
+            __syncthreads();
+            if ((int)threadIdx.x < dbO) {
+                float sum = 0.f;
+                for (int q = 0; q < 32; ++q) sum += cpart[q][threadIdx.x];
+                db_out[threadIdx.x] = sum;
+            }
+            __syncthreads();
         }
         float a = 0.f;
         for (int i = threadIdx.x; i < (int)gridDim.x; i += 256) a += __hip_atomic_load(loss_part + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1894,17 +1928,17 @@ int mse_dense_grad_w(const float* y, const float* target, float* dpre, float* lo
         return FOV_OK;
     }
     const long blocks = (n + 255) / 256;
-    if ((size_t)blocks * (db ? 9 : 1) > scratch_floats) { set_error("mse_dense_grad_w: scratch too small"); return FOV_ERR_WORKSPACE; }
+    if ((size_t)blocks * (db ? 9 : 1) + (db ? 4 : 0) > scratch_floats) { set_error("mse_dense_grad_w: scratch too small"); return FOV_ERR_WORKSPACE; }
     unsigned* ticket = loss ? next_loss_ticket() : nullptr;
     const bool fused_db = db && ticket && dbO >= 1 && dbO <= 8 && tmT == 0 && n % dbO == 0;
     hipLaunchKernelGGL(mse_dense_grad_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, y, target, dpre, scratch, n,
                        weight / (float)n, activation, tmB, tmT, O, ticket, loss, weight / (float)n,
-                       fused_db ? scratch + blocks : nullptr, fused_db ? db : nullptr, fused_db ? dbO : 0);
+                       fused_db ? scratch + ((blocks + 3) & ~3L) : nullptr, fused_db ? db : nullptr, fused_db ? dbO : 0);
     int rc = check_launch("mse_dense_grad_w");
     if (rc) return rc;
     if (db && !fused_db) {   // (no ticket slot, wide or time-major head: the column-sum launches)
         if (dbO < 1 || n % dbO) { set_error("mse_dense_grad_w: db needs the head's width"); return FOV_ERR_INVALID; }
-        rc = colsum(dpre, db, (int)(n / dbO), dbO, 0, scratch + blocks, scratch_floats - blocks, stream);
+        rc = colsum(dpre, db, (int)(n / dbO), dbO, 0, scratch + ((blocks + 3) & ~3L), scratch_floats - ((blocks + 3) & ~3L), stream);
         if (rc) return rc;
     }
     if (loss && !ticket) {
