@@ -61,7 +61,8 @@ struct LstmParams {
     int epoch_span;            // epochs this launch may consume: the last workgroup to leave adds it to the header's base
     int force_safe_exchange;   // 1: never take the same-XCD fast path (tests)
     int xcd_pad;               // lstm_wide16.hip: grid padded to 8 x (workgroups per tile), block b = member b / 8 of group b % 8
-    int trio;                  // lstm_wide16.hip: three-role launch - layer 1 also publishes h_t (sc1) into the mirror ring the product role reads
+    int trio;                  // lstm_wide16.hip, stacked launch on the XCD-per-group grid: 3 three roles, 2 two roles (0: not stacked) -
+                               // layer 1 also publishes h_t (sc1) into a mirror ring for its readers on other XCDs
 };
 
 int launch_generic(const LstmParams& p, bool decode, hipStream_t stream);

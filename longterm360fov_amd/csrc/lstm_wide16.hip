@@ -29,8 +29,9 @@ constexpr unsigned VSPIN = 1u << 20;
 // granule offsets of the three-role launch's extra areas behind layer 1's ring (T slots per group) and layer 2's parity slots
 // (2 per group): the mailboxes (T slots of W16_MAIL granules per workgroup of layer 2), then the mirror rings (T slots per group)
 __host__ __device__ constexpr size_t w16_mail_base(int num_groups, int T, int WH) { return (size_t)num_groups * (T + 2) * 16 * WH; }
-__host__ __device__ constexpr size_t w16_mirror_base(int num_groups, int T, int WH) {
-    return w16_mail_base(num_groups, T, WH) + (size_t)num_groups * (WH / 16) * T * (256 * 4);
+// `roles`: LstmParams::trio - 3: three-role launch (mailboxes in front of the mirror rings), 2: two roles (no mailboxes)
+__host__ __device__ constexpr size_t w16_mirror_base(int num_groups, int T, int WH, int roles) {
+    return w16_mail_base(num_groups, T, WH) + (roles == 3 ? (size_t)num_groups * (WH / 16) * T * (256 * 4) : (size_t)0);
 }
 constexpr size_t W16_MAIL = 256 * 4;   // granules of one mailbox slot of the three-role launch: 256 lanes x (4 values, each with its tag)
 typedef unsigned vu32x2 __attribute__((ext_vector_type(2)));
@@ -145,7 +146,7 @@ __device__ __forceinline__ void wide16_body(const LstmParams& p, const int bx, f
     // three-role launch, ROLE 1: the mirror of this group's ring for readers on OTHER XCDs (the product role) - the ring itself
     // may be written with sc0 stores that stay in this XCD's L2
     const __amdgpu_buffer_rsrc_t mirrs = __builtin_amdgcn_make_buffer_rsrc(
-        p.xch + w16_mirror_base(p.num_groups, p.T, WH) + (size_t)group * p.T * SLOT, 0,
+        p.xch + w16_mirror_base(p.num_groups, p.T, WH, p.trio) + (size_t)group * p.T * SLOT, 0,
         (ROLE == 1 && p.trio) ? p.T * (int)(SLOT * sizeof(unsigned long long)) : 0, 0x00020000);
     // ROLE 4: this workgroup's mailbox - T slots of 256 lanes x 32 bytes, written by its partner of the product role
     // (wide16_product_body) behind layer 1's ring and layer 2's parity slots
@@ -155,7 +156,7 @@ __device__ __forceinline__ void wide16_body(const LstmParams& p, const int bx, f
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
         p.xch + xbase, 0, (ROLE == 1 ? p.T : 2) * (int)(SLOT * sizeof(unsigned long long)), 0x00020000);
     const __amdgpu_buffer_rsrc_t ringrs = __builtin_amdgcn_make_buffer_rsrc(   // ROLE 2: layer 1's ring of the same group (XCD-placed launch: its mirror)
-        p.xch + (p.trio ? w16_mirror_base(p.num_groups, p.T, WH) : (size_t)0) + (size_t)group * p.T * SLOT, 0,
+        p.xch + (p.trio ? w16_mirror_base(p.num_groups, p.T, WH, p.trio) : (size_t)0) + (size_t)group * p.T * SLOT, 0,
         ROLE == 2 ? p.T * (int)(SLOT * sizeof(unsigned long long)) : 0, 0x00020000);
     const unsigned pub_off = (unsigned)(row_o * WH + unit) * 8u;
     // gather: thread (row tid / 16, half (tid / 8) % 2, unit pair tid % 8) brings units (2p, 2p + 1) of partner slices
@@ -556,7 +557,7 @@ __device__ __forceinline__ void wide16_product_body(const LstmParams& p, const i
         for (int s = 0; s < 4; ++s)
             wk[j][s] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(krs, (unsigned)(((16 * j + 4 * g4 + s) * H4 + col) * 4), 0, 0));
     const __amdgpu_buffer_rsrc_t ringrs = __builtin_amdgcn_make_buffer_rsrc(   // the MIRROR of layer 1's ring (sc1 stores: visible on every XCD)
-        p.xch + w16_mirror_base(p.num_groups, p.T, WH) + (size_t)group * p.T * SLOT, 0, p.T * (int)(SLOT * sizeof(unsigned long long)), 0x00020000);
+        p.xch + w16_mirror_base(p.num_groups, p.T, WH, 3) + (size_t)group * p.T * SLOT, 0, p.T * (int)(SLOT * sizeof(unsigned long long)), 0x00020000);
     const __amdgpu_buffer_rsrc_t mbrs = __builtin_amdgcn_make_buffer_rsrc(
         p.xch + w16_mail_base(p.num_groups, p.T, WH) + ((size_t)group * WG + slice) * p.T * W16_MAIL, 0,
         p.T * (int)(W16_MAIL * sizeof(unsigned long long)), 0x00020000);
@@ -1035,7 +1036,9 @@ bool wide16_pair_shape(int B, int T, int F, int H) {
     if (off || H != 512 || B <= 0 || T < 2 || F < 1 || F > 96) return false;
     const int tiles = (B + VBT - 1) / VBT;
     if (tiles > 4 || 8 * (H / 16) > device_cu_count()) return false;   // an XCD per group: at most 8 groups of 32 workgroups
-    return (w16_mirror_base(tiles, T, H) + (size_t)tiles * T * VBT * H) * sizeof(unsigned long long) <= kXchBytes - kHelloBytes;
+    // the rings, layer 2's parity slots and the mirror rings must fit the granule area (the three-role form of at most two tiles
+    // also needs its mailboxes: launch_wide16_pair falls back to two roles where they do not fit)
+    return (w16_mirror_base(tiles, T, H, 2) + (size_t)tiles * T * VBT * H) * sizeof(unsigned long long) <= kXchBytes - kHelloBytes;
 }
 
 int launch_wide16_pair(const LstmParams& a, const LstmParams& b, hipStream_t stream) {
@@ -1054,8 +1057,9 @@ int launch_wide16_pair(const LstmParams& a, const LstmParams& b, hipStream_t str
     // three roles (layer 2's input projection on workgroups of its own) while they all fit the chip and the mailboxes the
     // granule area: lstm.py's batch of 32 (two tiles)
     const int tiles = pp.l1.num_tiles;
-    const bool trio = !env_knobs().no_wide16_trio && tiles <= 2;   // (granule budget: wide16_pair_shape)
-    pp.l1.trio = pp.l2.trio = 1;   // both launches are XCD-placed: layer 1 mirrors its ring for the readers on other XCDs
+    const bool trio = !env_knobs().no_wide16_trio && tiles <= 2 &&
+                      (w16_mirror_base(tiles, a.T, WH, 3) + (size_t)tiles * a.T * VBT * WH) * sizeof(unsigned long long) <= kXchBytes - kHelloBytes;
+    pp.l1.trio = pp.l2.trio = trio ? 3 : 2;   // both launches are XCD-placed: layer 1 mirrors its ring for the readers on other XCDs
     void (*kern)(Wide16Pair) = trio ? (a.act == FOV_ACT_HARD_SIGMOID ? lstm_wide16_trio_kernel<FOV_ACT_HARD_SIGMOID, WH>
                                                                      : lstm_wide16_trio_kernel<FOV_ACT_SIGMOID, WH>)
                                     : (a.act == FOV_ACT_HARD_SIGMOID ? lstm_wide16_pair_kernel<FOV_ACT_HARD_SIGMOID, WH>

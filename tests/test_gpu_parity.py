@@ -264,12 +264,13 @@ def test_two_width_512_layers_one_launch():
 
 
 @pytest.mark.parametrize("B,T,with_state,reserve", [(1, 2, False, False), (16, 3, True, True), (17, 5, False, True), (32, 2, True, False),
-                                                     (31, 7, True, True)])
+                                                     (31, 7, True, True), (16, 200, False, False)])
 def test_two_width_512_layers_three_roles_two_roles_two_launches(B, T, with_state, reserve):
     """At most two tiles: the one-launch form runs as THREE roles (layer 1, the products h1 . K2, layer 2; lstm_wide16.hip).
     FOV_NO_WIDE16_TRIO=1 keeps two roles on the same XCD-per-group grid - bit-identical to two separate layer launches;
     the three-role form differs from both in the order of layer 2's fp32 sums only.  Fed states, the tape, ragged tiles,
-    repeated launches on one workspace, and the fp64 oracle."""
+    repeated launches on one workspace, and the fp64 oracle.  T = 200: the three-role form's mailboxes no longer fit the granule
+    area - the launch falls back to two roles by itself."""
     import os
     from longterm360fov_amd import _lib
     ops = _ops()
@@ -302,6 +303,7 @@ def test_two_width_512_layers_three_roles_two_roles_two_launches(B, T, with_stat
     for k in range(4 if reserve else 3):
         assert torch.equal(p1[k], r1[k]) and torch.equal(p2[k], r2[k]) and torch.equal(t1[k], r1[k]), (B, T, k)
         assert torch.allclose(t2[k], r2[k], rtol=2e-5, atol=2e-6), (B, T, k, float((t2[k] - r2[k]).abs().max()))
+    assert ops.lstm_stack2_supported(B, T, F, H)
     ref = x.astype(np.float64)
     for l, (K, R, b) in enumerate((l1, l2)):
         s0 = st[l]
