@@ -485,17 +485,19 @@ __device__ __forceinline__ bool q_dz_gather2(const __amdgpu_buffer_rsrc_t rs, un
     return ok;
 }
 
-// group / slice of a workgroup: members of a group 8 blocks apart (round-robin dispatch puts them on one XCD when
-// num_groups % 8 == 0); a placement preference only - the exchange is the placement-independent sc1 protocol
-__device__ __forceinline__ void q_group_slice(int num_groups, int& group, int& slice) {
-    if ((num_groups & 7) == 0) {
-        group = (blockIdx.x / (8 * QG)) * 8 + (blockIdx.x & 7);
-        slice = (blockIdx.x >> 3) & (QG - 1);
-    } else {
-        group = blockIdx.x / QG;
-        slice = blockIdx.x - group * QG;
-    }
+// group / slice of a workgroup: the members of a group sit 8 blocks apart - one XCD under round-robin dispatch (a placement
+// preference that the hello handshake verifies at run time; the exchange falls back to the placement-independent sc1 protocol).
+// The grid is padded to a multiple of eight groups (q_padded_groups; round 4, late: a group count that is no multiple of 8 used
+// to deal a group's members over all XCDs, and an exchange step costs 1.4 us more there - DESIGN 4.25): -> false for a block of
+// an absent group, which counts as arrived (q_spare_leaves) and leaves.
+__host__ __device__ constexpr int q_padded_groups(int num_groups) { return xch_padded_groups(num_groups); }
+__device__ __forceinline__ bool q_group_slice(int num_groups, int& group, int& slice) {
+    group = (blockIdx.x / (8 * QG)) * 8 + (blockIdx.x & 7);
+    slice = (blockIdx.x >> 3) & (QG - 1);
+    return group < num_groups;
 }
+// a spare block of the padded grid: it takes part in the launch protocol's arrival count (xch_settle expects the whole grid)
+__device__ __forceinline__ void q_spare_leaves(unsigned* status, bool exchanging = true) { xch_spare_leaves(status, exchanging); }
 
 // host side
 int launch_layer_bf16(const LstmParams& p, hipStream_t stream);   // lstm_layer_bf16.hip

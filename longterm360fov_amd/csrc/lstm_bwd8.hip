@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd8_kernel(Bwd8Params p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 15, g4 = lane >> 4;
     int group, slice;
-    q_group_slice(p.num_groups, group, slice);
+    if (!q_group_slice(p.num_groups, group, slice)) { q_spare_leaves(p.status); return; }
     constexpr int H4 = 4 * QH;
     const int hi = n >> 3;
     const int ul = 8 * wave + (n & 7);          // unit inside the workgroup (0..31)
@@ -336,7 +336,7 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd8n_bf16_kernel(Bwd8Params p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 15, g4 = lane >> 4;
     int group, slice;
-    q_group_slice(p.num_groups, group, slice);
+    if (!q_group_slice(p.num_groups, group, slice)) { q_spare_leaves(p.status); return; }
     constexpr int H4 = 4 * QH;
     const int prow = tid >> 4;                   // row of the tile (0..15)
     const int pu = 2 * (tid & 15);               // first unit of the pair inside the workgroup (0..30)
@@ -574,7 +574,7 @@ int launch_bwd8(const float* R, const float* reserve, const float* c0, const flo
     if (bf16 && with_dx) kern = act == FOV_ACT_HARD_SIGMOID ? lstm_bwd8n_bf16_kernel<FOV_ACT_HARD_SIGMOID, true> : lstm_bwd8n_bf16_kernel<FOV_ACT_SIGMOID, true>;
     else if (bf16) kern = act == FOV_ACT_HARD_SIGMOID ? lstm_bwd8n_bf16_kernel<FOV_ACT_HARD_SIGMOID, false> : lstm_bwd8n_bf16_kernel<FOV_ACT_SIGMOID, false>;
     else kern = act == FOV_ACT_HARD_SIGMOID ? lstm_bwd8_kernel<FOV_ACT_HARD_SIGMOID> : lstm_bwd8_kernel<FOV_ACT_SIGMOID>;
-    hipLaunchKernelGGL(kern, dim3(p.num_groups * QG), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL(kern, dim3(q_padded_groups(p.num_groups) * QG), dim3(256), 0, stream, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("8-group BPTT launch: %s", hipGetErrorString(e)); return FOV_ERR_LAUNCH; }
     return FOV_OK;

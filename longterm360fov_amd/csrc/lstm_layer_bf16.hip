@@ -45,7 +45,7 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_bf16_kernel(LstmParams p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 15, g4 = lane >> 4;
     int group, slice;
-    q_group_slice(p.num_groups, group, slice);
+    if (!q_group_slice(p.num_groups, group, slice)) { q_spare_leaves(p.status, p.T > 1); return; }
     const int F = p.F, steps = p.T;
     const int unit = 32 * slice + 8 * wave + (n & 7);
     const int hi = n >> 3;
@@ -311,7 +311,7 @@ int launch_layer_bf16(const LstmParams& p_in, hipStream_t stream) {
         narrow ? (hs_ ? lstm_layer_bf16_kernel<FOV_ACT_HARD_SIGMOID, 3, false> : lstm_layer_bf16_kernel<FOV_ACT_SIGMOID, 3, false>)
         : xvec ? (hs_ ? lstm_layer_bf16_kernel<FOV_ACT_HARD_SIGMOID, 8, true> : lstm_layer_bf16_kernel<FOV_ACT_SIGMOID, 8, true>)
                : (hs_ ? lstm_layer_bf16_kernel<FOV_ACT_HARD_SIGMOID, 8, false> : lstm_layer_bf16_kernel<FOV_ACT_SIGMOID, 8, false>);
-    hipLaunchKernelGGL(kern, dim3(p.num_groups * QG), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL(kern, dim3(q_padded_groups(p.num_groups) * QG), dim3(256), 0, stream, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("bf16 LSTM layer launch: %s", hipGetErrorString(e)); return FOV_ERR_LAUNCH; }
     return FOV_OK;

@@ -366,17 +366,12 @@ __global__ __launch_bounds__(256, 2) void lstm_stack2_bf16_kernel(Stack2Params p
     __shared__ __attribute__((aligned(16))) unsigned sStage[QST_LDS_WORDS];   // the prologue's weight staging (bf16_common.h)
     __shared__ int sFlag[4];
     __shared__ unsigned sXch[4];
-    const int per_role = p.num_groups * QG;
+    // each role's grid is padded to a multiple of eight groups: members 8 blocks apart, one XCD (q_group_slice, bf16_common.h)
+    const int per_role = q_padded_groups(p.num_groups) * QG;
     const int role = (int)blockIdx.x >= per_role ? 1 : 0;     // producers first: they never wait for a consumer
     const int local = (int)blockIdx.x - role * per_role;
-    int group, slice;
-    if ((p.num_groups & 7) == 0) {   // members 8 blocks apart: likely one XCD (placement preference only)
-        group = (local / (8 * QG)) * 8 + (local & 7);
-        slice = (local >> 3) & (QG - 1);
-    } else {
-        group = local / QG;
-        slice = local - group * QG;
-    }
+    const int group = (local / (8 * QG)) * 8 + (local & 7), slice = (local >> 3) & (QG - 1);
+    if (group >= p.num_groups) { q_spare_leaves(p.status); return; }
     if (role == 0) stack2_body<ACT, 0>(p, sH, sX, sStage, sFlag, sXch, group, slice);
     else stack2_body<ACT, 1>(p, sH, sX, sStage, sFlag, sXch, group, slice);
 }
@@ -405,7 +400,7 @@ int launch_stack2_bf16(const float* x, const float* K1, const float* R1, const f
     if (int rc_ = xch_account(p.status, p.epoch_span, stream)) return rc_;
     void (*kern)(Stack2Params) = act == FOV_ACT_HARD_SIGMOID ? lstm_stack2_bf16_kernel<FOV_ACT_HARD_SIGMOID>
                                                              : lstm_stack2_bf16_kernel<FOV_ACT_SIGMOID>;
-    hipLaunchKernelGGL(kern, dim3(2 * p.num_groups * QG), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL(kern, dim3(2 * q_padded_groups(p.num_groups) * QG), dim3(256), 0, stream, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("bf16 two-layer launch: %s", hipGetErrorString(e)); return FOV_ERR_LAUNCH; }
     return FOV_OK;

@@ -82,14 +82,9 @@ __global__ __launch_bounds__(256, 1) void lstm_wide_kernel(LstmParams p) {
     int* sFlag = (int*)(sX + 2 * WBT * WLD);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 15, g4 = lane >> 4;
-    int group, slice;
-    if ((p.num_groups & 7) == 0) {   // members 8 blocks apart: likely one XCD (placement preference only)
-        group = (blockIdx.x / (8 * WG)) * 8 + (blockIdx.x & 7);
-        slice = (blockIdx.x >> 3) & (WG - 1);
-    } else {
-        group = blockIdx.x / WG;
-        slice = blockIdx.x - group * WG;
-    }
+    // members 8 blocks apart on a grid padded to a multiple of eight groups: one XCD (xch_padded_groups, xch_common.h)
+    const int group = (blockIdx.x / (8 * WG)) * 8 + (blockIdx.x & 7), slice = (blockIdx.x >> 3) & (WG - 1);
+    if (group >= p.num_groups) { xch_spare_leaves(p.status, p.T > 1); return; }
     const int F = ZXM ? 0 : p.F, steps = p.T;
     const int unit = 32 * slice + 8 * wave + (n & 7);
     const int hi = n >> 3;
@@ -424,7 +419,7 @@ static int launch_wide_t(LstmParams& p, hipStream_t stream) {
                                                              : lstm_wide_kernel<FOV_ACT_SIGMOID, NJX, WH, WG>;
     int rc = ensure_dynamic_lds((const void*)kern, lds);
     if (rc) return rc;
-    hipLaunchKernelGGL(kern, dim3(p.num_groups * WG), dim3(256), lds, stream, p);
+    hipLaunchKernelGGL(kern, dim3(xch_padded_groups(p.num_groups) * WG), dim3(256), lds, stream, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("wide LSTM launch: %s", hipGetErrorString(e)); return FOV_ERR_LAUNCH; }
     return FOV_OK;

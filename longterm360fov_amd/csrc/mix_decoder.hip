@@ -151,16 +151,10 @@ __global__ __launch_bounds__(256, 1) void mix_decoder_kernel(MixDecParams p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 15, g4 = lane >> 4;
     const int O = p.O;
-    // members of a group 8 blocks apart (round-robin dispatch puts them on one XCD when num_groups % 8 == 0);
-    // only a placement preference: the exchange below is the placement-independent sc1 protocol
-    int group, slice;
-    if ((p.num_groups & 7) == 0) {
-        group = (blockIdx.x / (8 * MG)) * 8 + (blockIdx.x & 7);
-        slice = (blockIdx.x >> 3) & (MG - 1);
-    } else {
-        group = blockIdx.x / MG;
-        slice = blockIdx.x - group * MG;
-    }
+    // members of a group 8 blocks apart on a grid padded to a multiple of eight groups: one XCD under round-robin dispatch
+    // (xch_padded_groups, xch_common.h); only a placement preference, verified by the hello handshake
+    const int group = (blockIdx.x / (8 * MG)) * 8 + (blockIdx.x & 7), slice = (blockIdx.x >> 3) & (MG - 1);
+    if (group >= p.num_groups) { xch_spare_leaves(p.status); return; }
     const int unit = 32 * slice + 8 * wave + (n & 7);   // hidden unit of this lane's columns
     const int hi = n >> 3;                               // 0: columns i / g, 1: columns f / o
     const int col0 = hi * MH + unit, col1 = (2 + hi) * MH + unit;   // gate columns of tile 0 / tile 1
@@ -557,7 +551,7 @@ int mix_decoder_launch(MixDecParams p, const float* K2, int act, int train, void
     else kern = train ? mix_decoder_kernel<FOV_ACT_SIGMOID, true> : mix_decoder_kernel<FOV_ACT_SIGMOID, false>;
     int rc = ensure_dynamic_lds((const void*)kern, lds);
     if (rc) return rc;
-    hipLaunchKernelGGL(kern, dim3(p.num_groups * MG), dim3(256), lds, stream, p);
+    hipLaunchKernelGGL(kern, dim3(xch_padded_groups(p.num_groups) * MG), dim3(256), lds, stream, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("mix_decoder launch: %s", hipGetErrorString(e)); return FOV_ERR_LAUNCH; }
     return FOV_OK;

@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256, 1) void mix_decoder_bf16_kernel(MixDecParams p
     const int n = lane & 15, g4 = lane >> 4;
     const int O = p.O;
     int group, slice;
-    q_group_slice(p.num_groups, group, slice);
+    if (!q_group_slice(p.num_groups, group, slice)) { q_spare_leaves(p.status); return; }
     const int unit = 32 * slice + 8 * wave + (n & 7);   // hidden unit of this lane's columns
     const int hi = n >> 3;                               // 0: columns i / g, 1: columns f / o
     const int col0 = hi * QH + unit, col1 = (2 + hi) * QH + unit;
@@ -268,7 +268,7 @@ int mix_decoder_bf16_launch(MixDecParams p, const float* K2, int act, int train,
     void (*kern)(MixDecParams) = nullptr;
     if (act == FOV_ACT_HARD_SIGMOID) kern = train ? mix_decoder_bf16_kernel<FOV_ACT_HARD_SIGMOID, true> : mix_decoder_bf16_kernel<FOV_ACT_HARD_SIGMOID, false>;
     else kern = train ? mix_decoder_bf16_kernel<FOV_ACT_SIGMOID, true> : mix_decoder_bf16_kernel<FOV_ACT_SIGMOID, false>;
-    hipLaunchKernelGGL(kern, dim3(p.num_groups * QG), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL(kern, dim3(q_padded_groups(p.num_groups) * QG), dim3(256), 0, stream, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("mix_decoder_bf16 launch: %s", hipGetErrorString(e)); return FOV_ERR_LAUNCH; }
     return FOV_OK;

@@ -103,14 +103,9 @@ __global__ __launch_bounds__(256, 1) void mix_decoder_bwd_kernel(MixDecBwdParams
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 15, g4 = lane >> 4;
     const int O = p.O, T = p.T_out;
-    int group, slice;
-    if ((p.num_groups & 7) == 0) {
-        group = (blockIdx.x / (8 * BG)) * 8 + (blockIdx.x & 7);
-        slice = (blockIdx.x >> 3) & (BG - 1);
-    } else {
-        group = blockIdx.x / BG;
-        slice = blockIdx.x - group * BG;
-    }
+    // (grid padded to a multiple of eight groups, members 8 blocks apart: xch_padded_groups, xch_common.h)
+    const int group = (blockIdx.x / (8 * BG)) * 8 + (blockIdx.x & 7), slice = (blockIdx.x >> 3) & (BG - 1);
+    if (group >= p.num_groups) { xch_spare_leaves(p.status); return; }
     constexpr int H4 = 4 * BH;
     const int hi = n >> 3;
     const int ul = 8 * wave + (n & 7);          // unit inside the workgroup (0..31)
@@ -567,7 +562,7 @@ int mix_decoder_bwd_launch(MixDecBwdParams p, const float* K2, int act, void* wo
     void (*kern)(MixDecBwdParams) = act == FOV_ACT_HARD_SIGMOID ? mix_decoder_bwd_kernel<FOV_ACT_HARD_SIGMOID> : mix_decoder_bwd_kernel<FOV_ACT_SIGMOID>;
     int rc = ensure_dynamic_lds((const void*)kern, lds);
     if (rc) return rc;
-    hipLaunchKernelGGL(kern, dim3(p.num_groups * BG), dim3(256), lds, stream, p);
+    hipLaunchKernelGGL(kern, dim3(xch_padded_groups(p.num_groups) * BG), dim3(256), lds, stream, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("mix_decoder_bwd launch: %s", hipGetErrorString(e)); return FOV_ERR_LAUNCH; }
     return FOV_OK;

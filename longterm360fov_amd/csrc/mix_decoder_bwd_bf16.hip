@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256, 1) void mix_decoder_bwd_bf16_kernel(MixDecBwdP
     const int n = lane & 15, g4 = lane >> 4;
     const int O = p.O, T = p.T_out;
     int group, slice;
-    q_group_slice(p.num_groups, group, slice);
+    if (!q_group_slice(p.num_groups, group, slice)) { q_spare_leaves(p.status); return; }
     constexpr int H4 = 4 * QH;
     // pointwise phases (round 4, as lstm_bwd8n_bf16_kernel): thread tid owns row tid >> 4 of the tile and the two adjacent units
     // 2 * (tid & 15), + 1 of the workgroup's 32 - 8-byte tape accesses, whole 128-byte lines per wave instruction
@@ -307,7 +307,7 @@ int mix_decoder_bwd_bf16_launch(MixDecBwdParams p, const float* K2, int act, voi
     p.epoch_span = p.T_out * ((p.num_tiles + p.num_groups - 1) / p.num_groups) + 1;
     if (int rc_ = xch_account(p.status, p.epoch_span, stream)) return rc_;
     void (*kern)(MixDecBwdParams) = act == FOV_ACT_HARD_SIGMOID ? mix_decoder_bwd_bf16_kernel<FOV_ACT_HARD_SIGMOID> : mix_decoder_bwd_bf16_kernel<FOV_ACT_SIGMOID>;
-    hipLaunchKernelGGL(kern, dim3(p.num_groups * QG), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL(kern, dim3(q_padded_groups(p.num_groups) * QG), dim3(256), 0, stream, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("mix_decoder_bwd_bf16 launch: %s", hipGetErrorString(e)); return FOV_ERR_LAUNCH; }
     return FOV_OK;

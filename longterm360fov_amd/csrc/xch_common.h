@@ -247,6 +247,15 @@ __device__ __forceinline__ void xch_settle(unsigned* status, const XchTicket& t,
         }
     }
 }
+// Grids of G-member groups are padded to a multiple of eight groups: block b is member (b / 8) % G of group
+// (b / (8 G)) * 8 + b % 8, so a group's members sit 8 blocks apart - one XCD under round-robin dispatch - whatever the group
+// count (round 4, late: a count that is no multiple of 8 used to deal every group over all XCDs; an exchange step costs 1.4 us
+// more there).  A block of an absent group counts as arrived (xch_settle expects the whole grid) and leaves.
+__host__ __device__ constexpr int xch_padded_groups(int num_groups) { return (num_groups + 7) & ~7; }
+__device__ __forceinline__ void xch_spare_leaves(unsigned* status, bool exchanging = true) {
+    __shared__ unsigned sSpare[4];
+    if (exchanging) xch_arrive(status, sSpare, -1, 0);
+}
 __device__ __forceinline__ void xch_count_safe(unsigned* status, const XchTicket& t) {
     __hip_atomic_fetch_add(status + ST_SAFE0 + (t.launch & 1u), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
