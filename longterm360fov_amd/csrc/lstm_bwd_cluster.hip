@@ -70,13 +70,15 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_cluster_kernel(BwdParams p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 15, g4 = lane >> 4;
+    // G > 1: members 8 blocks apart on a grid padded to a multiple of eight groups - one XCD (xch_padded_groups, xch_common.h)
     int group, slice;
-    if (G > 1 && (p.num_groups & 7) == 0) {
+    if (G > 1) {
         group = (blockIdx.x / (8 * G)) * 8 + (blockIdx.x & 7);
         slice = (blockIdx.x >> 3) & (G - 1);
+        if (group >= p.num_groups) { xch_spare_leaves(p.status); return; }
     } else {
-        group = blockIdx.x / G;
-        slice = blockIdx.x - group * G;
+        group = blockIdx.x;
+        slice = 0;
     }
     const int unit = slice * 64 + wave * 16 + n;   // the hidden unit this lane owns
     // epoch tags continue from the workspace header, a poisoned workspace skips the body (xch_common.h)
@@ -326,7 +328,7 @@ template <int H>
 static int launch_bwd_h(const BwdParams& p, int act, hipStream_t stream) {
     void (*kern)(BwdParams) = act == FOV_ACT_HARD_SIGMOID ? lstm_bwd_cluster_kernel<H, FOV_ACT_HARD_SIGMOID>
                                                           : lstm_bwd_cluster_kernel<H, FOV_ACT_SIGMOID>;
-    const dim3 grid(p.num_groups * (H / 64)), block(256);
+    const dim3 grid((H > 64 ? xch_padded_groups(p.num_groups) : p.num_groups) * (H / 64)), block(256);
     hipLaunchKernelGGL(kern, grid, block, 0, stream, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("bwd cluster launch: %s", hipGetErrorString(e)); return FOV_ERR_LAUNCH; }

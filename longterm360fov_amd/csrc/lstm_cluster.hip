@@ -400,7 +400,7 @@ __device__ __forceinline__ void cluster_body(const LstmParams& p, ClusterCarry& 
     // count allows it the G members of a group are 8 blocks apart.  This is a SPEED choice only:
     // whether the members really share an XCD is verified at run time below.
     int group, slice;
-    if (G > 1 && ((p.num_groups & 7) == 0 || (H == 128 && p.xcd_pad))) {
+    if (G > 1 && ((p.num_groups & 7) == 0 || p.xcd_pad)) {
         group = (blockIdx.x / (8 * G)) * 8 + (blockIdx.x & 7);
         slice = (blockIdx.x >> 3) & (G - 1);
     } else {
@@ -976,6 +976,15 @@ __device__ __forceinline__ void cluster_body(const LstmParams& p, ClusterCarry& 
 
 template <int H, int ACT, int MODE>
 __global__ __launch_bounds__(256, 1) void lstm_cluster_kernel(LstmParams p) {
+    if constexpr (H >= 128) {
+        // padded grid (see the fused kernel below): a block of an absent group counts as arrived - if this launch exchanges at
+        // all (cluster_body's xch_used) - and leaves
+        if (p.xcd_pad && (int)((blockIdx.x / (8 * (H / 64))) * 8 + (blockIdx.x & 7)) >= p.num_groups) {
+            const bool exchanging = (MODE == MODE_DECODE) || p.T > 1;
+            if (threadIdx.x == 0 && exchanging) xch_count_arrival(p.status);
+            return;
+        }
+    }
     ClusterCarry cy;
     cluster_body<H, ACT, MODE, 0>(p, cy);
 }
@@ -984,10 +993,10 @@ __global__ __launch_bounds__(256, 1) void lstm_cluster_kernel(LstmParams p) {
 // no second header read / handshake, the state stays in registers and the h_T tile in LDS; only the weights are swapped.
 template <int H, int ACT>
 __global__ __launch_bounds__(256, 1) void lstm_cluster_fused_kernel(LstmParams p) {
-    if constexpr (H == 128) {
-        // a group count that is no multiple of eight (the reference's batch of 32 = two groups): the grid is padded to the next
-        // multiple so that a group's members sit 8 blocks apart = on one XCD (lstm_wide16.hip); the blocks of the absent groups
-        // count as arrived and leave
+    if constexpr (H >= 128) {
+        // a group count that is no multiple of eight (the reference's batch of 32 = two groups; any batch that is no multiple of
+        // 128 sequences): the grid is padded to the next multiple so that a group's members sit 8 blocks apart = on one XCD
+        // (lstm_wide16.hip, xch_common.h: xch_padded_groups); the blocks of the absent groups count as arrived and leave
         if (p.xcd_pad && (int)((blockIdx.x / (8 * (H / 64))) * 8 + (blockIdx.x & 7)) >= p.num_groups) {
             if (threadIdx.x == 0) xch_count_arrival(p.status);
             return;
@@ -1085,8 +1094,11 @@ static int launch_cluster_h(const LstmParams& p, int mode, hipStream_t stream) {
     }
     int rc = ensure_dynamic_lds((const void*)kern, lds);
     if (rc) return rc;
-    const dim3 grid(p.num_groups * (H / 64)), block(256);
-    hipLaunchKernelGGL(kern, grid, block, lds, stream, p);
+    LstmParams q = p;
+    const int padded = xch_padded_groups(q.num_groups);
+    q.xcd_pad = (H >= 128 && !env_knobs().no_xcd_pad && (q.num_groups & 7) != 0 && device_cu_count() >= padded * (H / 64)) ? 1 : 0;
+    const dim3 grid((q.xcd_pad ? padded : q.num_groups) * (H / 64)), block(256);
+    hipLaunchKernelGGL(kern, grid, block, lds, stream, q);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("cluster launch: %s", hipGetErrorString(e)); return FOV_ERR_LAUNCH; }
     return FOV_OK;
@@ -1104,7 +1116,7 @@ static int launch_cluster_fused_h(const LstmParams& p, hipStream_t stream) {
     LstmParams q = p;
     const bool no_pad = env_knobs().no_xcd_pad != 0;
     const int padded = (q.num_groups + 7) & ~7;
-    q.xcd_pad = (H == 128 && !no_pad && (q.num_groups & 7) != 0 && device_cu_count() >= padded * (H / 64)) ? 1 : 0;
+    q.xcd_pad = (H >= 128 && !no_pad && (q.num_groups & 7) != 0 && device_cu_count() >= padded * (H / 64)) ? 1 : 0;
     hipLaunchKernelGGL(kern, dim3((q.xcd_pad ? padded : q.num_groups) * (H / 64)), dim3(256), lds, stream, q);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("fused cluster launch: %s", hipGetErrorString(e)); return FOV_ERR_LAUNCH; }
