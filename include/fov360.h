@@ -239,7 +239,10 @@ int fov_lstm_seq_fwd_bf16(const float* x, const float* K, const float* R, const 
  * LSTMCell(400) under dynamic_rnn with a fed state, zero-padded to the matrix-core width 512 (models.pad_lstm).  At the
  * script's batch a layer occupies 64 of 256 CUs, so layer 2 runs beside layer 1, a few steps behind: layer 1 publishes h_t of
  * every step as {value, epoch} granules into a ring of T slots and layer 2 takes its input from there (its 512-wide input never
- * comes from HBM).  Same results as two fov_lstm_seq_fwd[_train] calls (same arithmetic per layer).  h0_* / c0_* (B,H) or
+ * comes from HBM).  At most 32 sequences: THREE roles - a third set of workgroups forms layer 2's input projection h1_t . K2 and
+ * hands it over in tagged mailboxes, layer 2 keeps R2 only; every 32-workgroup group runs on an XCD of its own.  Same results
+ * as two fov_lstm_seq_fwd[_train] calls: bit-identical for layer 1 and for the two-role form (33..64 sequences,
+ * FOV_NO_WIDE16_TRIO=1), up to the order of layer 2's fp32 sums (2e-5 relative) in the three-role form.  h0_* / c0_* (B,H) or
  * NULL; reserve* (B,T,5,H) or NULL (training tape); hs1 may be NULL when only the top layer's sequence is wanted.
  * Shapes: fov_lstm_stack2_supported (H = 512, F <= 96, T >= 2, both layers' groups resident: <= 64 sequences on 256 CUs);
  * workspace >= fov_lstm_seq_workspace_bytes of a width-512 layer (header + granule area). */
