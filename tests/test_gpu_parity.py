@@ -854,3 +854,46 @@ def test_reference_batch_decode_on_sixteen_units_per_workgroup(H, B, T_in, T_out
         del os.environ["FOV_NO_WIDE16"]
         _lib.lib().fov_reload_env()
     assert float((old - out).abs().max()) < 5e-6
+
+
+def test_ragged_batches_take_the_exchange_path_of_aligned_ones():
+    """Grids are padded to a multiple of eight groups so that a group's workgroups sit 8 blocks apart - one XCD - at ANY batch
+    (xch_common.h: xch_padded_groups; lstm_cluster.hip: xcd_pad).  Which exchange a launch takes is decided at run time by the
+    hello handshake, so the check is relative: a batch whose tile count is no multiple of eight takes the same path as one
+    whose is (both the fast one on an idle GPU) - for the fused four-workgroup kernel and for the eight-workgroup bf16 layer
+    kernel.  FOV_NO_XCD_PAD=1 (the unpadded grid of the cluster kernels) deals the groups over the XCDs: mode 2."""
+    from longterm360fov_amd import _lib
+    ops = _ops()
+    H, T_in, T_out = 256, 4, 4
+    w = O.init_seq2seq(77, H=H, bias_noise=0.05)
+    dw = devw(w)
+    ws = ops.Workspace()
+    modes = {}
+    for B in (1024, 1000, 40):
+        enc, dec0, _ = O.synthetic_batch(77, B, T_in, T_out)
+        ops.seq2seq_decode(dev(enc), dev(dec0), dw, T_out, impl="cluster", workspace=ws)
+        ws.check()
+        modes[B] = ws.exchange_mode()
+    print("fused decode: exchange modes", modes)
+    assert modes[1000] == modes[1024] and modes[40] == modes[1024]
+    os.environ["FOV_NO_XCD_PAD"] = "1"
+    _lib.lib().fov_reload_env()
+    try:
+        enc, dec0, _ = O.synthetic_batch(77, 1000, T_in, T_out)
+        out = ops.seq2seq_decode(dev(enc), dev(dec0), dw, T_out, impl="cluster", workspace=ws)
+        ws.check()
+        assert ws.exchange_mode() == 2
+    finally:
+        os.environ.pop("FOV_NO_XCD_PAD", None)
+        _lib.lib().fov_reload_env()
+    out2 = ops.seq2seq_decode(dev(enc), dev(dec0), dw, T_out, impl="cluster", workspace=ws)
+    assert torch.equal(out, out2)   # the two exchanges agree bitwise
+    rng = np.random.default_rng(5)
+    K, R, b = (dev(a) for a in O.init_lstm(rng, 90, 256, np.float32))
+    lm = {}
+    for B in (128, 100, 17):
+        ops.lstm_seq_bf16(dev(rng.uniform(-1, 1, (B, 3, 90))), K, R, b, workspace=ws)
+        ws.check()
+        lm[B] = ws.exchange_mode()
+    print("bf16 layer: exchange modes", lm)
+    assert lm[100] == lm[128] and lm[17] == lm[128]
