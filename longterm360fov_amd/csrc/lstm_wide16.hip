@@ -65,6 +65,90 @@ __device__ __forceinline__ void wide16_mm(f32x4 (&acc)[2], const float* arow, co
     }
 }
 
+// ---- resident weights through LDS (round 4, late; the sixteen-unit twin of stage_f32.h) ------------------------------
+// A lane's fragments are w[j][s] = W[16 j + 4 g4 + s][gate (n / 4) * WH + 16 slice + 4 wave + n % 4]: asked for directly, a wave's
+// load instruction touches SIXTEEN cache lines for 256 bytes (four gates x four rows, 16 bytes of each) and a thread issues 128
+// dword loads per (512, 2048) matrix.  Here the workgroup reads its slice - 4 gates x 16 units = four 64-byte pieces per matrix
+// row - as dwordx4 loads (a stage is 32 rows: two loads per thread), writes the values column-major into LDS (40 words per
+// column: 16-byte aligned, 8 mod 32; the row index is XOR-swizzled with the column's gate and bit 2 so that the 64 lanes of a
+// ds_write_b32 cover all banks twice) and every lane picks its fragments up as ds_read_b128 (8 lanes per bank quad).
+// W16_ST_DEPTH stages are requested ahead of the one being written; two LDS buffers (the h / x tiles' space), a barrier per stage.
+constexpr int W16_ST_WORDS = 40;
+constexpr int W16_ST_BUF = 64 * W16_ST_WORDS;
+constexpr int W16_ST_LDS_WORDS = 2 * W16_ST_BUF;   // 20 480 bytes
+constexpr int W16_ST_DEPTH = 4;
+struct W16StageLane {
+    unsigned goff;     // byte offset of (row kr, this thread's 4 columns) in the matrix
+    unsigned wr[2];    // LDS word of the thread's first column for the two 16-row halves of a stage (swizzle folded in)
+    unsigned rd;       // LDS word of the lane's fragment of 16-row block 0 of a stage (before the half swizzle)
+    unsigned rdx;      // 1: the lane's column reads the halves swapped
+};
+template <int WH>
+__device__ __forceinline__ W16StageLane w16_stage_lane(int slice) {
+    const int tid = threadIdx.x;
+    const int c = tid & 3, gate = (tid >> 2) & 3, kr = tid >> 4;
+    const int lane = tid & 63, wave = tid >> 6, n = lane & 15, g4 = lane >> 4;
+    W16StageLane q;
+    q.goff = (unsigned)(kr * 4 * WH + gate * WH + 16 * slice + 4 * c) * 4u;
+    const unsigned wbase = (unsigned)((gate * 16 + 4 * c) * W16_ST_WORDS + (kr ^ (gate << 2)));
+    q.wr[0] = wbase + 16u * (unsigned)(c & 1);
+    q.wr[1] = wbase + 16u * (unsigned)((c & 1) ^ 1);
+    const int gate_r = n >> 2;
+    q.rd = (unsigned)((gate_r * 16 + 4 * wave + (n & 3)) * W16_ST_WORDS + 4 * (g4 ^ gate_r));
+    q.rdx = (unsigned)(wave & 1);
+    return q;
+}
+template <int WH>
+__device__ __forceinline__ void w16_stage_issue(vu32x4 (&r)[2], const float* __restrict__ W, int nrows, int ls, const W16StageLane& q) {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(W), 0, nrows * 4 * WH * 4, 0x00020000);
+#pragma unroll
+    for (int it = 0; it < 2; ++it)   // rows >= nrows read as zero (the whole offset sits in the vector register)
+        r[it] = __builtin_amdgcn_raw_buffer_load_b128(rs, q.goff + (unsigned)((32 * ls + 16 * it) * 4 * WH) * 4u, 0, 0);
+}
+__device__ __forceinline__ void w16_stage_write(const vu32x4 (&r)[2], unsigned* buf, const W16StageLane& q) {
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        unsigned* wp = buf + q.wr[it];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wp[j * W16_ST_WORDS] = r[it][j];
+    }
+}
+template <int NJ>
+__device__ __forceinline__ void w16_stage_read(float (&w)[NJ][4], int ls, const unsigned* buf, const W16StageLane& q) {
+#pragma unroll
+    for (int jl = 0; jl < 2; ++jl)
+        if (2 * ls + jl < NJ) {
+            const vu32x4 v = *(const vu32x4*)(buf + q.rd + 16u * ((unsigned)jl ^ q.rdx));
+#pragma unroll
+            for (int s = 0; s < 4; ++s) w[2 * ls + jl][s] = __uint_as_float(v[s]);
+        }
+}
+// one (HAS_A false) or two fragment sets in one pipeline; sStage: W16_ST_LDS_WORDS words, 16-byte aligned, free again at return
+template <int WH, bool HAS_A, int NA, int NB>
+__device__ __forceinline__ void w16_stage_weight_sets(float (&a)[NA][4], const float* __restrict__ Wa, int nra, float (&b)[NB][4],
+                                                      const float* __restrict__ Wb, int nrb, int slice, unsigned* sStage) {
+    constexpr int SA = HAS_A ? (NA + 1) / 2 : 0, SB = (NB + 1) / 2, NS = SA + SB, D = W16_ST_DEPTH;
+    const W16StageLane q = w16_stage_lane<WH>(slice);
+    vu32x4 r[D + 1][2];
+    auto issue = [&](int s_) __attribute__((always_inline)) {
+        if (s_ < SA) w16_stage_issue<WH>(r[s_ % (D + 1)], Wa, nra, s_, q);
+        else w16_stage_issue<WH>(r[s_ % (D + 1)], Wb, nrb, s_ - SA, q);
+    };
+#pragma unroll
+    for (int s_ = 0; s_ < D; ++s_)
+        if (s_ < NS) issue(s_);
+#pragma unroll
+    for (int s_ = 0; s_ < NS; ++s_) {
+        if (s_ + D < NS) issue(s_ + D);
+        unsigned* buf = sStage + (s_ & 1) * W16_ST_BUF;
+        w16_stage_write(r[s_ % (D + 1)], buf, q);
+        __syncthreads();   // (buffer s & 1 is written again two stages on, behind the barrier of stage s + 1, which a wave passes after these reads)
+        if (s_ < SA) w16_stage_read<NA>(a, s_, buf, q);
+        else w16_stage_read<NB>(b, s_ - SA, buf, q);
+    }
+    __syncthreads();
+}
+
 // NJX: k-blocks of K in registers - 6 (narrow input, F <= 96, scalar x stage) or WH / 16 (input as wide as the layer, 16-byte
 // x pieces)
 // ROLE 0: one layer per launch.  ROLE 1 / 2: the two layers of a stack as ONE launch (lstm_wide16_pair_kernel), layer 2 a
@@ -123,18 +207,11 @@ __device__ __forceinline__ void wide16_body(const LstmParams& p, const int bx, f
     const bool poisoned = xch_used && xch_poisoned(p.status);
     if (tid == 0) sFlag[0] = poisoned ? 1 : 0;
 
-    // ---- resident weights: K rows >= F read as zero (the descriptor ends with row F - 1) ----
-    const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.K), 0, F * H4 * 4, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.R), 0, WH * H4 * 4, 0x00020000);
+    // ---- resident weights through LDS (w16_stage_weight_sets above; the staging buffers are the h / x tiles, filled after it):
+    // K rows >= F read as zero (the descriptor ends with row F - 1) ----
     float wk[NJX > 0 ? NJX : 1][4], wr[NJR][4];
-#pragma unroll
-    for (int j = 0; j < NJR; ++j)
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const int k = 16 * j + 4 * g4 + s;
-            if (j < NJX) wk[j][s] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(krs, (unsigned)((k * H4 + col) * 4), 0, 0));
-            wr[j][s] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rrs, (unsigned)((k * H4 + col) * 4), 0, 0));
-        }
+    static_assert(3 * VBT * WLD >= W16_ST_LDS_WORDS, "the h tile and the two x tiles hold the two staging buffers");
+    w16_stage_weight_sets<WH, (NJX > 0)>(wk, p.K, F, wr, p.R, WH, slice, (unsigned*)smem);
     const float bv = p.b[col];
     for (int i = tid; i < 2 * VBT * WLD; i += 256) sX[i] = 0.f;   // columns >= F stay zero
 
@@ -549,13 +626,9 @@ __device__ __forceinline__ void wide16_product_body(const LstmParams& p, const i
     const unsigned arrival = xch_arrive(p.status, sXch, -1, 0);   // header words + arrival count; no handshake of its own
     const bool poisoned = xch_poisoned(p.status);
     if (tid == 0) sFlag[0] = poisoned ? 1 : 0;
-    const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.K), 0, WH * H4 * 4, 0x00020000);
     float wk[NJX][4];
-#pragma unroll
-    for (int j = 0; j < NJX; ++j)
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-            wk[j][s] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(krs, (unsigned)(((16 * j + 4 * g4 + s) * H4 + col) * 4), 0, 0));
+    static_assert(2 * VBT * WLD >= W16_ST_LDS_WORDS, "the two h1 tiles hold the two staging buffers");
+    w16_stage_weight_sets<WH, false>(wk, p.K, WH, wk, p.K, WH, slice, (unsigned*)smem);
     const __amdgpu_buffer_rsrc_t ringrs = __builtin_amdgcn_make_buffer_rsrc(   // the MIRROR of layer 1's ring (sc1 stores: visible on every XCD)
         p.xch + w16_mirror_base(p.num_groups, p.T, WH, 3) + (size_t)group * p.T * SLOT, 0, p.T * (int)(SLOT * sizeof(unsigned long long)), 0x00020000);
     const __amdgpu_buffer_rsrc_t mbrs = __builtin_amdgcn_make_buffer_rsrc(
