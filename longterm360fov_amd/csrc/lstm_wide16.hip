@@ -814,22 +814,12 @@ __global__ __launch_bounds__(256, 1) void wide16_s2s_kernel(LstmParams p) {
     const bool poisoned = xch_poisoned(p.status);
     if (tid == 0) sFlag[0] = poisoned ? 1 : 0;
 
-    // ---- resident weights of both phases (rows past an input's width read as zero: the descriptor ends there) ----
-    const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.K), 0, F * H4 * 4, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.R), 0, WH * H4 * 4, 0x00020000);
-    const __amdgpu_buffer_rsrc_t dkrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dK), 0, FD * H4 * 4, 0x00020000);
-    const __amdgpu_buffer_rsrc_t drrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dR), 0, WH * H4 * 4, 0x00020000);
+    // ---- resident weights of both phases through LDS (w16_stage_weight_sets; the staging buffers are the h / x tiles, filled after
+    // it; rows past an input's width read as zero: the descriptor ends there) ----
     float wk[NJX][4], wr[NJR][4], dk[1][4], dr[NJR][4];
-#pragma unroll
-    for (int j = 0; j < NJR; ++j)
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const unsigned off = (unsigned)(((16 * j + 4 * g4 + s) * H4 + col) * 4);
-            if (j < NJX) wk[j][s] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(krs, off, 0, 0));
-            if (j < 1) dk[j][s] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(dkrs, off, 0, 0));
-            wr[j][s] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rrs, off, 0, 0));
-            dr[j][s] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(drrs, off, 0, 0));
-        }
+    static_assert(3 * VBT * WLD >= W16_ST_LDS_WORDS, "the h tile and the two x tiles hold the two staging buffers");
+    w16_stage_weight_sets<WH, true>(wk, p.K, F, wr, p.R, WH, slice, (unsigned*)smem);
+    w16_stage_weight_sets<WH, true>(dk, p.dK, FD, dr, p.dR, WH, slice, (unsigned*)smem);
     const float bv_e = p.b[col], bv_d = p.db[col];
     for (int i = tid; i < 2 * VBT * WLD; i += 256) sX[i] = 0.f;   // columns past the inputs' widths stay zero
     for (int i = tid; i < 8 * WDL; i += 256) {
