@@ -80,18 +80,18 @@ def latency_floor(phases, measured_ms):
             "latency_floor_model": "; ".join(parts) + " [exchange: %s]" % XCH_SOURCE}
 
 
-def mixing_floor_phases(dtype, training):
+def mixing_floor_phases(dtype, training, T_in=10, T_out=10):
     """configs[2] / configs[4] at H = 256, eight workgroups per 16-sequence tile (32 units x 4 gates per workgroup = two 16-wide
     tiles per wave): a layer step's h . R is K = 256 -> 2 x 64 fp32 MFMAs (2 x 8 bf16); the decoder's second layer reads [h1_t | h2]
     (K = 512) inside the step.  Forward 10 + 10 encoder layer-steps (bf16: both layers as one wavefront launch, 11) and 10 decoder
     steps of two layers; backward the same chain in reverse (the BPTT product dz . R^T is K = 4H over 32 units: also 128 per wave)."""
     m, cyc = (16, 16) if dtype == "bf16" else (128, 32)
     key = (256, 8)
-    fwd = [("encoder layers", 11 if dtype == "bf16" else 20, m, cyc, key), ("decoder layer 1", 10, m, cyc, key),
-           ("decoder layer 2", 10, 2 * m, cyc, key)]
+    fwd = [("encoder layers", T_in + 1 if dtype == "bf16" else 2 * T_in, m, cyc, key), ("decoder layer 1", T_out, m, cyc, key),
+           ("decoder layer 2", T_out, 2 * m, cyc, key)]
     if not training:
         return fwd
-    return fwd + [("decoder BPTT (two layers)", 20, m, cyc, key), ("encoder BPTT", 20, m, cyc, key)]
+    return fwd + [("decoder BPTT (two layers)", 2 * T_out, m, cyc, key), ("encoder BPTT", 2 * T_in, m, cyc, key)]
 
 
 def mode_traffic(mode, dtype, ms, profiled_shape=True):
@@ -215,7 +215,7 @@ def bench_train_mixing(args, rank, world, use_dist):
     import torch.distributed as dist
     from longterm360fov_amd.training import OthersMixingTrainer
     from oracle import fov_oracle as O
-    H, T_in, T_out, U = args.hidden, 10, 10, 34
+    H, T_in, T_out, U = args.hidden, args.t_in, args.t_out, 34     # config.py:20-23: running_length / predict_step set T
     B = args.batch if args.batch != 1024 else 512
     w = O.init_others_mixing(1234, H=H, num_user=U, bias_noise=0.05)
     enc, dec0, tgt, oth = O.synthetic_batch(1234 + rank, B, T_in, T_out, num_others=U - 1)
@@ -260,20 +260,21 @@ def bench_train_mixing(args, rank, world, use_dist):
                           "torch %s CPU ops (nn.LSTM 2 layers + 2 LSTMCell + 2 Linear per step, autograd, Adam), fp32" % torch.__version__,
                           args.cpu_budget)
         print(json.dumps({
-            "metric": "training sequences/sec, others-mixing 2+2 layers (batch=%d per GPU, T 10->10, h=%d, U=%d)" % (B, H, U),
+            "metric": "training sequences/sec, others-mixing 2+2 layers (batch=%d per GPU, T %d->%d, h=%d, U=%d)" % (B, T_in, T_out, H, U),
             "value": world * B * args.steps / elapsed, "unit": "sequences/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic", "final_loss": float(loss.item()),
             "config": {"workload": ("configs[4]: bf16 training of configs[2] (bf16 MFMA operands, fp32 accumulate / cell state / master "
                                     "weights), " if args.dtype == "bf16" else "configs[2] shape: ") +
-                                   "given_others_gt_mean_var_seq2seq training step (fused decoder forward and backward launches)", "global_batch": B * world,
+                                   "given_others_gt_mean_var_seq2seq training step (fused decoder forward and backward launches), T_in=%d->T_out=%d" % (T_in, T_out), "global_batch": B * world,
                        "parallelism": "dp%d, one flat-buffer all-reduce per step" % world},
             "roofline": {"bound": "mfma", "achieved": 3 * fwd * B / (ms * 1e-3) / 1e12, "peak": peak_for(args.dtype),
                          "unit": "TFLOP/s", "frac": 3 * fwd * B / (ms * 1e-3) / 1e12 / peak_for(args.dtype),
-                         "note": "whole step, 3x forward FLOPs; at 512 sequences per GPU the step is a chain of 40 dependent recurrent "
-                                 "steps per direction: bound by the per-step exchange latency, not by the matrix rate",
-                         **(latency_floor(mixing_floor_phases(args.dtype, True), ms) if (B, H) == (512, 256) else {}),
-                         **mode_traffic("train_mixing", args.dtype, ms, (B, H) == (512, 256))},
+                         "flop_per_sequence_forward": fwd,
+                         "note": "whole step, 3x forward FLOPs; at 512 sequences per GPU the step is a chain of %d dependent recurrent "
+                                 "steps per direction: bound by the per-step exchange latency, not by the matrix rate" % (2 * T_in + 2 * T_out),
+                         **(latency_floor(mixing_floor_phases(args.dtype, True, T_in, T_out), ms) if (B, H) == (512, 256) else {}),
+                         **mode_traffic("train_mixing", args.dtype, ms, (B, H, T_in, T_out) == (512, 256, 10, 10))},
             "cpu_baseline": cpu}), flush=True)
     if use_dist:
         dist.barrier()
@@ -338,7 +339,7 @@ def bench_infer_mixing(args, rank, world, use_dist):
     import torch.distributed as dist
     from longterm360fov_amd.models import OthersMixingSeq2Seq
     from oracle import fov_oracle as O
-    H, T_in, T_out, U = args.hidden, 10, 10, 34
+    H, T_in, T_out, U = args.hidden, args.t_in, args.t_out, 34     # config.py:20-23: running_length / predict_step set T
     B = args.batch if args.batch != 1024 else 512
     w = O.init_others_mixing(1234, H=H, num_user=U, bias_noise=0.05)
     enc, dec0, tgt, oth = O.synthetic_batch(1234 + rank, B, T_in, T_out, num_others=U - 1)
@@ -385,17 +386,18 @@ def bench_infer_mixing(args, rank, world, use_dist):
             cpu = cpu_leg(lambda: mc.predict(enc, oth, dec0), B, mc.threads,
                           "torch %s CPU ops (nn.LSTM 2 layers + 2 LSTMCell + 2 Linear per step), fp32" % torch.__version__, args.cpu_budget / 2)
         print(json.dumps({
-            "metric": "sequences/sec, others-mixing 2+2 layers inference (batch=%d per GPU, T 10->10, h=%d, U=%d)" % (B, H, U),
+            "metric": "sequences/sec, others-mixing 2+2 layers inference (batch=%d per GPU, T %d->%d, h=%d, U=%d)" % (B, T_in, T_out, H, U),
             "value": world * B * args.steps / elapsed, "unit": "sequences/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "configs[2] shape: given_others_gt_mean_var_seq2seq inference (encoder + unrolled "
-                                   "no-teacher-forcing decoder with others mixing)", "global_batch": B * world,
+                                   "no-teacher-forcing decoder with others mixing), T_in=%d->T_out=%d" % (T_in, T_out), "global_batch": B * world,
                        "parallelism": "replicas x%d (no collective)" % world},
             "roofline": {"bound": "mfma", "achieved": fwd * B / (ms * 1e-3) / 1e12, "peak": peak_for(args.dtype),
                          "unit": "TFLOP/s", "frac": fwd * B / (ms * 1e-3) / 1e12 / peak_for(args.dtype),
-                         **(latency_floor(mixing_floor_phases(args.dtype, False), ms) if (B, H) == (512, 256) else {}),
-                         **mode_traffic("infer_mixing", args.dtype, ms, (B, H) == (512, 256))},
+                         "flop_per_sequence_forward": fwd,
+                         **(latency_floor(mixing_floor_phases(args.dtype, False, T_in, T_out), ms) if (B, H) == (512, 256) else {}),
+                         **mode_traffic("infer_mixing", args.dtype, ms, (B, H, T_in, T_out) == (512, 256, 10, 10))},
             "parity": {"max_abs_err_vs_oracle": err, "max_abs_err_vs_bf16_operand_oracle": err_q, "sequences_checked": 32},
             "cpu_baseline": cpu}), flush=True)
     if use_dist:
@@ -843,8 +845,8 @@ def main():
     ap.add_argument("--steps", type=int, default=300, help="timed steps (default: >= 100 ms of timed region at the headline shape)")
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=1024)
-    ap.add_argument("--t-in", type=int, default=30)
-    ap.add_argument("--t-out", type=int, default=30)
+    ap.add_argument("--t-in", type=int, default=None, help="encoder steps (default: 30, the metric's horizon; the mixing modes default to configs[2]'s 10)")
+    ap.add_argument("--t-out", type=int, default=None, help="decoder steps (default as --t-in)")
     ap.add_argument("--hidden", type=int, default=256)
     ap.add_argument("--impl", default="auto", choices=["auto", "cluster", "generic"])
     ap.add_argument("--act", default="sigmoid", choices=["sigmoid", "hard_sigmoid"])
@@ -874,6 +876,9 @@ def main():
                          "train_mixing / infer_mixing: configs[2] (512 sequences per GPU); config1: configs[0] latency; "
                          "convlstm: configs[3]")
     args = ap.parse_args()
+    t_default = 10 if args.mode in ("train_mixing", "infer_mixing") else 30
+    args.t_in = t_default if args.t_in is None else args.t_in
+    args.t_out = t_default if args.t_out is None else args.t_out
     global CPU_THREADS
     CPU_THREADS = max(1, args.cpu_threads)
 

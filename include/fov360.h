@@ -10,7 +10,7 @@
  *   - extern "C", plain pointers and sizes; no torch / HIP types in the signatures
  *     (fov_stream_t is an opaque hipStream_t; NULL = the default stream).
  *   - All tensors are DEVICE pointers, row-major contiguous fp32.  The caller owns every
- *     buffer; the library allocates nothing persistent.  Scratch comes from a caller-provided
+ *     buffer; the library allocates NO DEVICE MEMORY.  Scratch comes from a caller-provided
  *     workspace whose size is queried first (fov_*_workspace_bytes).
  *   - Weights use the Keras layout so weight files round-trip:
  *       kernel K:(F,4H), recurrent_kernel R:(H,4H), bias b:(4H); gate column blocks i,f,c,o.
@@ -26,8 +26,25 @@
  *     message of the calling thread's last failure.  No host synchronisation inside a call
  *     (except fov_check_status, which is the explicit "did the persistent kernel finish
  *     cleanly" query).
- *   - Re-entrant and thread-compatible: no mutable globals besides a thread-local error string
- *     and a read-only device-property cache.  One stream per call.
+ *   - Threading and state.  One stream per call; calls from different threads are safe as long as they do not
+ *     share a workspace / scratch / gradient buffer (those are single-owner: one stream at a time).  What the
+ *     library keeps between calls, all of it on the HOST, all of it behind mutexes and keyed so that callers do
+ *     not meet:
+ *       * a thread-local error string (fov_last_error);
+ *       * read-only caches filled on first use: device properties per device, and the FOV_* environment knobs
+ *         (diagnostic switches between kernel forms; read once, re-read by fov_reload_env);
+ *       * per WORKSPACE POINTER: the host copy of the workspace's epoch counter / exchange mode and the address
+ *         of a weight matrix a caller pre-packed into it (fov_workspace_init forgets both; call it again when a
+ *         workspace's memory is freed and the address comes back from the allocator);
+ *       * per open fov_reduce_defer_begin region, keyed by its gradient buffer: the table of pending reductions
+ *         (see there);
+ *       * per (device, stream): the index of that stream's word in a 64-word device-side ticket table of the
+ *         loss entry points (a module-level __device__ array, not an allocation).  A device on which more than
+ *         64 distinct streams have issued loss calls takes the two-launch form for the later ones;
+ *       * streams exist only where the caller asked for one (fov_stream_create) and belong to the caller.
+ *     One process per GPU - the deployment this library is written for - and several devices / trainers /
+ *     threads in one process are both within this contract (tests/test_gpu_threads.py drives two trainers
+ *     from two threads on two streams against the serial result).
  */
 #ifndef FOV360_H
 #define FOV360_H
@@ -545,10 +562,16 @@ int fov_rmsprop_step_guarded(float* params, const float* grads, float* accum, in
  * device memory, any size >= 256 bytes: what does not fit is reduced at once) and the flush sums all of them in ONE launch
  * instead of one per product; results are bit-identical.  In-stream order is kept for writes made through this library (a
  * later product over a pending range flushes first); a caller that reads or writes the gradient buffer by other means
- * between _begin and _end calls _flush before.  One deferral at a time per process; grad_base = NULL switches it off. */
+ * between _begin and _end calls _flush before.
+ * A region is KEYED BY ITS GRADIENT BUFFER: each caller (trainer, thread, stream, device) opens its own with _begin and names
+ * it again by grad_base (any address inside the buffer) in _flush / _end; regions of different buffers share nothing - their
+ * arenas and pending records are separate - so several may be open at once from different threads (at most 16 per process;
+ * _begin on a buffer that overlaps an open region flushes and replaces that region).  The library holds the record table of
+ * an open region (16 records, host memory) until _end; it allocates no device memory.  _flush / _end with grad_base = NULL
+ * address every open region of the process; _begin with arena = NULL only closes what overlaps grad_base. */
 int fov_reduce_defer_begin(float* grad_base, size_t grad_floats, void* arena, size_t arena_bytes, fov_stream_t stream);
-int fov_reduce_defer_flush(fov_stream_t stream);
-int fov_reduce_defer_end(fov_stream_t stream);
+int fov_reduce_defer_flush(const float* grad_base, fov_stream_t stream);
+int fov_reduce_defer_end(const float* grad_base, fov_stream_t stream);
 /* Data-parallel training (the all-reduce of model.fit's gradients, given_others_gt_mean_var_seq2seq.py:494-506):
  * *out = 1.0f if the timeout word of one of the workspaces is set, else 0.0f.  The trainers keep `out` inside the flat
  * gradient buffer: after the SUM all-reduce it is nonzero on EVERY rank if any rank's step failed, and handed to the

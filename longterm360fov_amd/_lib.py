@@ -95,8 +95,8 @@ SIGNATURES = {
     "fov_mix_decoder_prepack": (_I, [_P, _P, ctypes.c_size_t, _P, ctypes.c_size_t, _I, _P]),
     "fov_guard_flag": (_I, [_P] * 5),
     "fov_reduce_defer_begin": (_I, [_P, ctypes.c_size_t, _P, ctypes.c_size_t, _P]),
-    "fov_reduce_defer_flush": (_I, [_P]),
-    "fov_reduce_defer_end": (_I, [_P]),
+    "fov_reduce_defer_flush": (_I, [_P, _P]),
+    "fov_reduce_defer_end": (_I, [_P, _P]),
     "fov_adam_step_guarded": (_I, [_P] * 4 + [ctypes.c_int64] + [ctypes.c_float] * 4 + [ctypes.c_int64] + [_P] * 5),
     "fov_rmsprop_step_guarded": (_I, [_P] * 3 + [ctypes.c_int64] + [ctypes.c_float] * 3 + [_P] * 5),
     "fov_conv2d_fwd": (_I, [_P, ctypes.c_int64, ctypes.c_int64, _P, _P, _P, _P] + [_I] * 8 + [_P]),

@@ -1020,8 +1020,8 @@ int fov_reduce_defer_begin(float* grad_base, size_t grad_floats, void* arena, si
     if (grad_base && (!arena || arena_bytes < 256)) { set_error("fov_reduce_defer_begin: invalid arena"); return FOV_ERR_INVALID; }
     return defer_begin(grad_base, grad_floats, (float*)arena, arena_bytes / sizeof(float), (hipStream_t)stream);
 }
-int fov_reduce_defer_flush(fov_stream_t stream) { return defer_flush((hipStream_t)stream); }
-int fov_reduce_defer_end(fov_stream_t stream) { return defer_end((hipStream_t)stream); }
+int fov_reduce_defer_flush(const float* grad_base, fov_stream_t stream) { return defer_flush(grad_base, (hipStream_t)stream); }
+int fov_reduce_defer_end(const float* grad_base, fov_stream_t stream) { return defer_end(grad_base, (hipStream_t)stream); }
 
 int fov_guard_flag(const void* guard0, const void* guard1, const void* guard2, float* out, fov_stream_t stream) {
     if (!out) { set_error("fov_guard_flag: invalid argument"); return FOV_ERR_INVALID; }

@@ -153,8 +153,8 @@ int softmax_lastdim_bwd(const float* dp, const float* p, float* dy, long rows, i
 int splitk_reduce(const float* part, float* out, long n, int S, int accumulate, hipStream_t stream);
 // deferred split reductions of a training step (train_kernels.hip): one reduce launch per step instead of one per product
 int defer_begin(float* grad_base, size_t grad_floats, float* arena, size_t arena_floats, hipStream_t stream);
-int defer_flush(hipStream_t stream);
-int defer_end(hipStream_t stream);
+int defer_flush(const float* grad_base, hipStream_t stream);
+int defer_end(const float* grad_base, hipStream_t stream);
 int defer_touch(const float* out, size_t n, hipStream_t stream);
 float* defer_alloc(const float* out, size_t n, size_t floats, hipStream_t stream);
 void defer_record(const float* part, float* out, long n, int S, int accumulate);

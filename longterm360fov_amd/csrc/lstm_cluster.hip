@@ -33,6 +33,7 @@
 // MFMA s of block q uses k = 16q + 4*g4 + s on lanes with (l>>4) == g4, for A and B alike.
 #include <stdlib.h>
 
+#include <atomic>
 #include <mutex>
 
 #include "fov_common.h"
@@ -1012,15 +1013,17 @@ __global__ __launch_bounds__(256, 1) void lstm_cluster_fused_kernel(LstmParams p
 // --------------------------------------------------------------------------------------
 // CUs of the CURRENT device (cached per device ordinal: a process may drive several GPUs)
 int device_cu_count() {
-    static int cus[64] = {0};
+    static std::atomic<int> cus[64];    // (threads that race on the first use store the same value)
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
-    if (cus[dev] == 0) {
+    int n = cus[dev].load(std::memory_order_relaxed);
+    if (n == 0) {
         hipDeviceProp_t prop;
-        cus[dev] = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+        n = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+        cus[dev].store(n, std::memory_order_relaxed);
     }
     const int lim = env_knobs().resident_limit;   // FOV_DBG_RESIDENT_LIMIT: pretend fewer CUs are available (tests of the fallbacks)
-    return (lim > 0 && lim < cus[dev]) ? lim : cus[dev];
+    return (lim > 0 && lim < n) ? lim : n;
 }
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (device, kernel, size) instead of on every launch

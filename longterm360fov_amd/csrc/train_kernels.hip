@@ -446,25 +446,36 @@ __global__ __launch_bounds__(256) void splitk_reduce_batch_kernel(DeferTable t) 
     else splitk_reduce_body<false>(e.part, e.out, e.n, e.S, e.accumulate, (long)((int)blockIdx.x - e.block0));
 }
 
+// The deferral state is keyed by the registered gradient buffer: every trainer (thread, stream, device) that opened a region
+// with fov_reduce_defer_begin owns ONE entry of the registry below - its arena, its record table - and a product finds its
+// region by the address of its output.  Regions never overlap (begin replaces an overlapping one after flushing it), so two
+// trainers on two threads or two GPUs of one process never see each other's arena or records; the registry itself is guarded
+// by one mutex.
 namespace {
 struct DeferState {
-    bool active = false;
     const float* gbase = nullptr; const float* gend = nullptr;
     float* arena = nullptr; size_t arena_floats = 0, used = 0;
     DeferTable table = {};
 };
-DeferState g_defer;
+constexpr int kDeferRegions = 16;     // open regions per process (one per trainer in flight; begin fails beyond that)
+DeferState g_defer[kDeferRegions];
+int g_defer_open = 0;
 std::mutex g_defer_mu;
 
-bool defer_overlaps(const float* out, size_t n) {
-    for (int i = 0; i < g_defer.table.count; ++i) {
-        const DeferEntry& e = g_defer.table.e[i];
+DeferState* defer_region_of(const float* out, size_t n) {       // the region that holds [out, out + n), or NULL
+    for (int i = 0; i < g_defer_open; ++i)
+        if (out >= g_defer[i].gbase && out + n <= g_defer[i].gend) return &g_defer[i];
+    return nullptr;
+}
+bool defer_overlaps(const DeferState& st, const float* out, size_t n) {
+    for (int i = 0; i < st.table.count; ++i) {
+        const DeferEntry& e = st.table.e[i];
         if (out < e.out + e.n && e.out < out + n) return true;
     }
     return false;
 }
-int defer_flush_locked(hipStream_t stream) {
-    DeferTable& t = g_defer.table;
+int defer_flush_locked(DeferState& st, hipStream_t stream) {
+    DeferTable& t = st.table;
     if (t.count == 0) return FOV_OK;
     hipLaunchKernelGGL(splitk_reduce_batch_kernel, dim3((unsigned)t.blocks), dim3(256), 0, stream, t);
     t.count = 0; t.blocks = 0;
@@ -472,50 +483,79 @@ int defer_flush_locked(hipStream_t stream) {
     // on another - slices are written once per begin ... end, what does not fit any more is reduced at once
     return check_launch("splitk_reduce_batch");
 }
+void defer_close_locked(int i) {
+    g_defer[i] = g_defer[g_defer_open - 1];
+    g_defer[--g_defer_open] = DeferState();
+}
 }  // namespace
 
 int defer_begin(float* grad_base, size_t grad_floats, float* arena, size_t arena_floats, hipStream_t stream) {
     std::lock_guard<std::mutex> lock(g_defer_mu);
-    if (g_defer.active) { int rc = defer_flush_locked(stream); if (rc) return rc; }
-    g_defer.active = grad_base && arena && arena_floats > 0;
-    g_defer.gbase = grad_base; g_defer.gend = grad_base + grad_floats;
-    g_defer.arena = arena; g_defer.arena_floats = arena_floats; g_defer.used = 0;
-    g_defer.table.count = 0; g_defer.table.blocks = 0;
+    if (!grad_base || grad_floats == 0) return FOV_OK;
+    // a region over (part of) the same buffer is replaced: its pending records go first
+    for (int i = g_defer_open - 1; i >= 0; --i)
+        if (grad_base < g_defer[i].gend && g_defer[i].gbase < grad_base + grad_floats) {
+            int rc = defer_flush_locked(g_defer[i], stream);
+            defer_close_locked(i);
+            if (rc) return rc;
+        }
+    if (!arena || arena_floats == 0) return FOV_OK;
+    if (g_defer_open == kDeferRegions) { set_error("fov_reduce_defer_begin: too many open regions (16 per process)"); return FOV_ERR_UNSUPPORTED; }
+    DeferState& st = g_defer[g_defer_open++];
+    st = DeferState();
+    st.gbase = grad_base; st.gend = grad_base + grad_floats;
+    st.arena = arena; st.arena_floats = arena_floats;
     return FOV_OK;
 }
-int defer_flush(hipStream_t stream) {
+// grad_base = the buffer a region was opened on (any address inside it); NULL = every open region of the process
+int defer_flush(const float* grad_base, hipStream_t stream) {
     std::lock_guard<std::mutex> lock(g_defer_mu);
-    return g_defer.active ? defer_flush_locked(stream) : FOV_OK;
+    int rc = FOV_OK;
+    for (int i = 0; i < g_defer_open; ++i)
+        if (!grad_base || (grad_base >= g_defer[i].gbase && grad_base < g_defer[i].gend))
+            if (int r = defer_flush_locked(g_defer[i], stream)) rc = r;
+    return rc;
 }
-int defer_end(hipStream_t stream) {
+int defer_end(const float* grad_base, hipStream_t stream) {
     std::lock_guard<std::mutex> lock(g_defer_mu);
-    int rc = g_defer.active ? defer_flush_locked(stream) : FOV_OK;
-    g_defer.active = false;
-    g_defer.used = 0;
+    int rc = FOV_OK;
+    for (int i = g_defer_open - 1; i >= 0; --i)
+        if (!grad_base || (grad_base >= g_defer[i].gbase && grad_base < g_defer[i].gend)) {
+            if (int r = defer_flush_locked(g_defer[i], stream)) rc = r;
+            defer_close_locked(i);
+        }
     return rc;
 }
 // A producer is about to write [out, out + n) (directly, or through an immediate reduce): pending records over that range
 // go first.
 int defer_touch(const float* out, size_t n, hipStream_t stream) {
     std::lock_guard<std::mutex> lock(g_defer_mu);
-    if (!g_defer.active || g_defer.table.count == 0 || !defer_overlaps(out, n)) return FOV_OK;
-    return defer_flush_locked(stream);
+    for (int i = 0; i < g_defer_open; ++i) {
+        DeferState& st = g_defer[i];
+        if (out < st.gend && st.gbase < out + n && st.table.count > 0 && defer_overlaps(st, out, n))
+            if (int rc = defer_flush_locked(st, stream)) return rc;
+    }
+    return FOV_OK;
 }
 // Where a split product with output [out, out + n) may put its `floats` of partial slices, or NULL: reduce at once.
 float* defer_alloc(const float* out, size_t n, size_t floats, hipStream_t stream) {
     std::lock_guard<std::mutex> lock(g_defer_mu);
-    if (!g_defer.active || out < g_defer.gbase || out + n > g_defer.gend) return nullptr;
-    if (g_defer.table.count > 0 && defer_overlaps(out, n)) { if (defer_flush_locked(stream)) return nullptr; }
+    DeferState* st = defer_region_of(out, n);
+    if (!st) return nullptr;
+    if (st->table.count > 0 && defer_overlaps(*st, out, n)) { if (defer_flush_locked(*st, stream)) return nullptr; }
     const size_t need = (floats + 63) & ~(size_t)63;
-    if (g_defer.table.count == kDeferMax && defer_flush_locked(stream)) return nullptr;
-    if (g_defer.used + need > g_defer.arena_floats) return nullptr;   // arena exhausted for this step: reduce at once
-    float* p = g_defer.arena + g_defer.used;
-    g_defer.used += need;
+    if (st->table.count == kDeferMax && defer_flush_locked(*st, stream)) return nullptr;
+    if (st->used + need > st->arena_floats) return nullptr;   // arena exhausted for this step: reduce at once
+    float* p = st->arena + st->used;
+    st->used += need;
     return p;
 }
+// (only behind a successful defer_alloc for the same output: the region exists and has a free record)
 void defer_record(const float* part, float* out, long n, int S, int accumulate) {
     std::lock_guard<std::mutex> lock(g_defer_mu);
-    DeferTable& t = g_defer.table;
+    DeferState* st = defer_region_of(out, (size_t)n);
+    if (!st) return;
+    DeferTable& t = st->table;
     DeferEntry& e = t.e[t.count++];
     e.part = part; e.out = out; e.n = n; e.S = S; e.accumulate = accumulate; e.block0 = t.blocks;
     e.vec = splitk_reduce_vec(part, out, n) ? 1 : 0;
@@ -591,8 +631,8 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
 // Dense(tanh|linear) + Keras mean_squared_error: dpre = 2 (y - target) / n * act'(y); per-block
 // partial sums of (y - target)^2 into loss_part[blockIdx.x].
 // Tickets of the loss kernels' "last block adds the partials" step (round 4: the separate one-block sum launch is gone, 5 us of
-// every training step's critical path).  Zero at module load, left at zero again by the block that takes the last ticket; a call
-// takes the next slot of the ring, so calls in flight on different streams never share one.
+// every training step's critical path).  Zero at module load, left at zero again by the block that takes the last ticket; every
+// stream of a device has its own slot (loss_ticket_of), so launches in flight never share one.
 constexpr int kLossTickets = 64;
 __device__ unsigned g_loss_tickets[kLossTickets];
 
@@ -1885,20 +1925,30 @@ int dense_bwd(const float* x, const float* W, const float* dpre, float* dx, floa
     return FOV_OK;
 }
 
-// next slot of the ticket ring (device address of g_loss_tickets looked up once per device)
-static unsigned* next_loss_ticket() {
+// The ticket word of a loss launch: one slot of the device's ticket table PER STREAM (first use of a stream on a device takes
+// the next free slot; the device address of g_loss_tickets is looked up once per device).  Launches on one stream run in
+// stream order, so the word a launch finds is the zero its predecessor on that stream left: two launches in flight never share
+// a slot however many there are, whichever threads issued them.  A device whose kLossTickets slots are all taken (more
+// distinct streams than that) gets NULL: the callers below fall back to the separate sum / column-sum launches.
+// (A captured graph replayed on two streams AT ONCE would share the slot of its capture stream: not supported.)
+static unsigned* loss_ticket_of(hipStream_t stream) {
+    struct PerDevice { unsigned* base = nullptr; int used = 0; hipStream_t streams[kLossTickets]; };
     static std::mutex mu;
-    static unsigned* base[64] = {};
-    static unsigned next = 0;
+    static PerDevice devs[64];
     std::lock_guard<std::mutex> lock(mu);
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-    if (!base[dev]) {
+    PerDevice& d = devs[dev];
+    if (!d.base) {
         void* p = nullptr;
         if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_loss_tickets)) != hipSuccess) return nullptr;
-        base[dev] = static_cast<unsigned*>(p);
+        d.base = static_cast<unsigned*>(p);
     }
-    return base[dev] + (next++ % kLossTickets);
+    for (int i = 0; i < d.used; ++i)
+        if (d.streams[i] == stream) return d.base + i;
+    if (d.used == kLossTickets) return nullptr;
+    d.streams[d.used] = stream;
+    return d.base + d.used++;
 }
 
 int mse_dense_grad(const float* y, const float* target, float* dpre, float* loss, long n, int activation, float* scratch,
@@ -1906,7 +1956,7 @@ int mse_dense_grad(const float* y, const float* target, float* dpre, float* loss
     if (n <= 0) return FOV_OK;
     const long blocks = (n + 255) / 256;
     if ((size_t)blocks > scratch_floats) { set_error("mse_dense_grad: scratch too small"); return FOV_ERR_WORKSPACE; }
-    unsigned* ticket = loss ? next_loss_ticket() : nullptr;
+    unsigned* ticket = loss ? loss_ticket_of(stream) : nullptr;
     hipLaunchKernelGGL(mse_dense_grad_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, y, target, dpre, scratch, n,
                        1.0f / (float)n, activation, 0, 0, 1, ticket, loss, 1.0f / (float)n);
     int rc = check_launch("mse_dense_grad");
@@ -1929,7 +1979,7 @@ int mse_dense_grad_w(const float* y, const float* target, float* dpre, float* lo
     }
     const long blocks = (n + 255) / 256;
     if ((size_t)blocks * (db ? 9 : 1) + (db ? 4 : 0) > scratch_floats) { set_error("mse_dense_grad_w: scratch too small"); return FOV_ERR_WORKSPACE; }
-    unsigned* ticket = loss ? next_loss_ticket() : nullptr;
+    unsigned* ticket = loss ? loss_ticket_of(stream) : nullptr;
     const bool fused_db = db && ticket && dbO >= 1 && dbO <= 8 && tmT == 0 && n % dbO == 0;
     hipLaunchKernelGGL(mse_dense_grad_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, y, target, dpre, scratch, n,
                        weight / (float)n, activation, tmB, tmT, O, ticket, loss, weight / (float)n,
@@ -2004,7 +2054,7 @@ int gauss_nll_grad(const float* mu, const float* var, const float* y, float* los
                    int fps, float scale, float* scratch, size_t scratch_floats, hipStream_t stream) {
     if (B <= 0) return FOV_OK;
     if ((size_t)B > scratch_floats) { set_error("gauss_nll_grad: scratch too small"); return FOV_ERR_WORKSPACE; }
-    unsigned* ticket = loss ? next_loss_ticket() : nullptr;
+    unsigned* ticket = loss ? loss_ticket_of(stream) : nullptr;
     hipLaunchKernelGGL(gauss_nll_kernel, dim3(B), dim3(256), 0, stream, mu, var, y, scratch, dmu, dvar, B, Ty, fps, scale, ticket, loss,
                        scale / (float)B);
     int rc = check_launch("gauss_nll");

@@ -449,11 +449,27 @@ def lstm_seq_wgrad(x, hs, dz, dK=None, dR=None, db=None, h0=None, accumulate=Fal
     return {"dK": dK, "dR": dR, "db": db}
 
 
-def side_stream(device, priority=1):
-    """A HIP stream of the given priority (> 0 low, 0 normal, < 0 high) owned by the library, as a torch stream object."""
+def _destroy_stream(handle):
+    try:
+        _lib.lib().fov_stream_destroy(_ct.c_void_p(handle))
+    except Exception:      # interpreter shutdown: the library may be gone already
+        pass
+
+
+def side_stream(device, priority=1, owner=None):
+    """A HIP stream of the given priority (> 0 low, 0 normal, < 0 high), created ON `device` (fov_stream_create makes it on the
+    current HIP device) and wrapped as a torch stream object.  The raw handle goes back to fov_stream_destroy when `owner`
+    (default: the returned stream object) is collected."""
+    import weakref
     h = _ct.c_void_p()
-    check(_lib.lib().fov_stream_create(int(priority), _ct.byref(h)))
-    return torch.cuda.ExternalStream(h.value, device=device)
+    with torch.cuda.device(device):
+        check(_lib.lib().fov_stream_create(int(priority), _ct.byref(h)))
+        st = torch.cuda.ExternalStream(h.value, device=device)
+    try:
+        weakref.finalize(st if owner is None else owner, _destroy_stream, h.value)
+    except TypeError:       # an owner that cannot be weakly referenced: the stream lives as long as the process
+        pass
+    return st
 
 
 def act_bwd(dy, y, base=None, activation="tanh", out=None):
@@ -818,12 +834,14 @@ def reduce_defer_begin(grad, arena):
     check(_lib.lib().fov_reduce_defer_begin(_ptr(grad), grad.numel(), arena.data_ptr(), arena.numel() * arena.element_size(), _stream()))
 
 
-def reduce_defer_flush():
-    check(_lib.lib().fov_reduce_defer_flush(_stream()))
+def reduce_defer_flush(grad=None):
+    """Sum the pending products of the region opened on `grad` now (None: of every open region of the process)."""
+    check(_lib.lib().fov_reduce_defer_flush(None if grad is None else _ptr(grad), _stream()))
 
 
-def reduce_defer_end():
-    check(_lib.lib().fov_reduce_defer_end(_stream()))
+def reduce_defer_end(grad=None):
+    """Flush and close the region opened on `grad` (None: every open region of the process)."""
+    check(_lib.lib().fov_reduce_defer_end(None if grad is None else _ptr(grad), _stream()))
 
 
 def rmsprop_step(params, grads, accum, lr=1e-3, rho=0.9, eps=1e-7, guards=None, applied=None):

@@ -123,7 +123,7 @@ class FlatParamTrainer:
         """Called from forward_backward: every gradient from parameter `name` to the end of the buffer (and the loss
         slot) is final.  Under DP with overlap_allreduce the tail goes out now, overlapping the backward work still to come."""
         if self._dp and self.overlap_allreduce and 4 + self.offset[name] < self._reduced_from:
-            ops.reduce_defer_flush()     # the tail is read now
+            ops.reduce_defer_flush(self.grad)     # the tail is read now
             lo = 4 + self.offset[name]   # (gradbuf index: the gradients sit behind the 16-byte head)
             self._pending.append(torch.distributed.all_reduce(self.gradbuf[lo:self._reduced_from],
                                                               op=torch.distributed.ReduceOp.SUM, async_op=True))
@@ -149,7 +149,7 @@ class FlatParamTrainer:
     def _weigh(self, loss, grad_weight):
         """Fallback for trainers whose loss kernel takes no weight: scale gradients and loss after the fact."""
         if grad_weight != 1.0:
-            ops.reduce_defer_flush()
+            ops.reduce_defer_flush(self.grad)
             ops.scale_(self.grad, grad_weight)
             loss = ops.scale_(loss, grad_weight)
         return loss
@@ -170,7 +170,7 @@ class FlatParamTrainer:
             loss, _ = self.forward_backward(*inputs, grad_weight=weight, **kw)
         finally:
             if deferring:
-                ops.reduce_defer_end()      # flushes: every gradient is final from here on
+                ops.reduce_defer_end(self.grad)      # flushes: every gradient is final from here on
         if self._dp:
             if loss.data_ptr() != self.loss_slot.data_ptr():
                 self.loss_slot.copy_(loss.reshape(1))
@@ -1138,7 +1138,7 @@ class OthersMixingTrainer(FlatParamTrainer):
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 decoder_wgrads(1 if split_side else 3)
-                ops.reduce_defer_flush()   # their slices are summed on the side stream too (under the recurrences), not at the step's end
+                ops.reduce_defer_flush(self.grad)   # their slices are summed on the side stream too (under the recurrences), not at the step's end
         self.grads_final("dec1_K")    # decoder, heads and loss: all-reduced under the encoder's BPTT
         # encoder: layer 2 over hs1 (its dx is the dhs of layer 1), then layer 1
         # (tried: each encoder layer in two parts, its weight-gradient products on the side stream under the NEXT layer's
@@ -1161,7 +1161,7 @@ class OthersMixingTrainer(FlatParamTrainer):
                                        scratch=self._side_scratch(), dtype=dt)
                 if split_side:
                     decoder_wgrads(2)
-                ops.reduce_defer_flush()
+                ops.reduce_defer_flush(self.grad)
         ops.lstm_seq_bwd(enc, w["enc1_K"], w["enc1_R"], hs1, res1, dhs=e2["dx"], dhT=dh1_rec, dcT=dc1, dK=g["enc1_K"],
                          dR=g["enc1_R"], db=g["enc1_b"], act=act, accumulate=acc, scratch=bsc, dtype=dt)
         if side is not None:
@@ -1195,7 +1195,7 @@ class OthersMixingTrainer(FlatParamTrainer):
             # priority the product's 512 blocks take the registers and the recurrence starts only when they have drained
             # (r04 timeline: 42 us between the two encoder BPTT launches).  FOV_SIDE_PRIORITY=normal: a plain torch stream.
             if os.environ.get("FOV_SIDE_PRIORITY", "low") == "low":
-                self._side_stream = ops.side_stream(self.device, 1)
+                self._side_stream = ops.side_stream(self.device, 1, owner=self)
             else:
                 self._side_stream = torch.cuda.Stream(device=self.device)
         return self._side_stream

@@ -79,7 +79,8 @@ def test_bf16_layer_is_deterministic_and_batch_independent():
     np.testing.assert_array_equal(a[:23], d)
 
 
-@pytest.mark.parametrize("B,T_in,T_out,act", [(37, 4, 5, "sigmoid"), (21, 3, 3, "hard_sigmoid"), (16 * 32 + 9, 2, 2, "sigmoid")])
+@pytest.mark.parametrize("B,T_in,T_out,act", [(37, 4, 5, "sigmoid"), (21, 3, 3, "hard_sigmoid"), (16 * 32 + 9, 2, 2, "sigmoid"),
+                                              (48, 30, 30, "sigmoid"), (512, 30, 30, "sigmoid")])       # the metric's horizon
 def test_bf16_mixing_model_matches_bf16_operand_oracle(B, T_in, T_out, act):
     """Whole configs[4] inference path: two bf16 encoder layers + the fused bf16 decoder launch."""
     from longterm360fov_amd.models import OthersMixingSeq2Seq, _MIX_ORDER
@@ -215,7 +216,8 @@ def test_eight_group_bptt_layer(dtype, B, T, F, act, state):
         assert err <= 1e-5 * sep["dx"].abs().max().item() + 1e-8
 
 
-@pytest.mark.parametrize("B,U,T_in,T_out,act", [(37, 5, 2, 4, "hard_sigmoid"), (530, 3, 2, 2, "sigmoid"), (512, 34, 10, 10, "sigmoid")])
+@pytest.mark.parametrize("B,U,T_in,T_out,act", [(37, 5, 2, 4, "hard_sigmoid"), (530, 3, 2, 2, "sigmoid"), (512, 34, 10, 10, "sigmoid"),
+                                                (48, 34, 30, 30, "sigmoid"), (512, 34, 30, 30, "sigmoid")])   # the metric's horizon
 def test_bf16_mixing_training_step(B, U, T_in, T_out, act):
     """configs[4] training: loss and every gradient of the bf16 step against torch.autograd in fp64 on the
     full-precision graph.  Stated bound: loss within 2e-3 relative; every gradient tensor within 3e-2 of its own scale
@@ -256,7 +258,8 @@ def test_bf16_mixing_training_step(B, U, T_in, T_out, act):
     assert abs(l - l32) <= 2e-2 * l32
 
 
-@pytest.mark.parametrize("B,T,F,act", [(512, 10, 90, "sigmoid"), (37, 5, 33, "hard_sigmoid"), (100, 2, 96, "sigmoid"), (16, 7, 6, "sigmoid")])
+@pytest.mark.parametrize("B,T,F,act", [(512, 10, 90, "sigmoid"), (37, 5, 33, "hard_sigmoid"), (100, 2, 96, "sigmoid"), (16, 7, 6, "sigmoid"),
+                                       (512, 30, 90, "sigmoid"), (48, 30, 90, "hard_sigmoid")])
 def test_bf16_two_layer_wavefront_equals_two_launches(B, T, F, act):
     """fov_lstm_stack2_fwd_bf16 (lstm_stack2_bf16.hip): both encoder layers of the others-mixing model in ONE launch, layer 2
     one step behind layer 1 on the same CUs, its input tile taken from layer 1's exchange granules - against two

@@ -413,7 +413,8 @@ def test_exchange_paths_agree_bitwise():
 # a4: target + others mixing, 2+2 layers, no teacher forcing (given_others_gt_mean_var_seq2seq.py)
 # ---------------------------------------------------------------------------------------
 @pytest.mark.parametrize("H,B,U,T_in,T_out,act", [(32, 5, 4, 6, 4, "sigmoid"), (64, 20, 34, 5, 4, "hard_sigmoid"),
-                                                  (256, 48, 34, 10, 10, "sigmoid")])
+                                                  (256, 48, 34, 10, 10, "sigmoid"),
+                                                  (256, 48, 34, 30, 30, "sigmoid"), (256, 512, 34, 30, 30, "hard_sigmoid")])   # the metric's horizon (config.py:20-23)
 def test_others_mixing_forward(H, B, U, T_in, T_out, act):
     from longterm360fov_amd.models import OthersMixingSeq2Seq, _MIX_ORDER
     w = O.init_others_mixing(60 + H, H=H, num_user=U, bias_noise=0.1)
@@ -527,7 +528,7 @@ def test_device_windowing_matches_reference_fixture(golden_dir):
 
 
 @pytest.mark.parametrize("B,T_in,T_out,act", [(16, 3, 4, "sigmoid"), (37, 2, 3, "hard_sigmoid"), (512, 4, 10, "sigmoid"),
-                                              (600, 2, 2, "sigmoid")])
+                                              (600, 2, 2, "sigmoid"), (48, 30, 30, "sigmoid"), (512, 30, 30, "sigmoid")])
 def test_fused_mixing_decoder_matches_oracle(B, T_in, T_out, act):
     """a4: the unrolled no-teacher-forcing decoder with others mixing in ONE launch (fov_mix_decoder_fwd) against the
     oracle's others_mixing_forward; encoder states come from the library's layer kernels.  B = 600 makes a group

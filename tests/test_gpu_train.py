@@ -537,7 +537,8 @@ def _torch_mixing_graph(enc, oth, dec0, tgt, w, act, mixing="mlp"):
 
 @pytest.mark.parametrize("H,B,U,T_in,T_out,act", [(64, 20, 5, 4, 3, "sigmoid"), (128, 33, 34, 5, 4, "hard_sigmoid"),
                                                   (256, 16, 34, 3, 3, "sigmoid"), (256, 37, 5, 2, 4, "hard_sigmoid"),
-                                                  (256, 530, 3, 2, 2, "sigmoid"), (256, 512, 34, 10, 10, "sigmoid")])
+                                                  (256, 530, 3, 2, 2, "sigmoid"), (256, 512, 34, 10, 10, "sigmoid"),
+                                                  (256, 48, 34, 30, 30, "sigmoid"), (256, 512, 34, 30, 30, "sigmoid")])   # the metric's horizon
 def test_others_mixing_gradients_and_training(H, B, U, T_in, T_out, act):
     """a4 training: gradients of the unrolled no-teacher-forcing graph (feedback path included) against
     torch.autograd in fp64, then three Adam steps reduce the loss."""
@@ -1499,7 +1500,7 @@ def test_deferred_split_reductions_equal_immediate(dtype):
         for _ in range(20):                                                                        # more records than the table holds
             ops.wgrad_fused(x1, None, dp, c, accumulate=True, scratch=sc)
         if arena is not None:
-            ops.reduce_defer_end()
+            ops.reduce_defer_end(flat)
         torch.cuda.synchronize()
         return flat.clone(), outside.clone()
 
