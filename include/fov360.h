@@ -456,6 +456,12 @@ int fov_gauss_nll_grad(const float* mu, const float* var, const float* y, float*
                        fov_stream_t stream);
 int fov_rmsprop_tf_step(float* params, const float* grads, float* ms, int64_t n, float lr, float decay, float eps,
                         float clip_value, fov_stream_t stream);
+/* The same, fail-stop like fov_adam_step_guarded: skipped on the device when the sticky timeout word of one of the guard
+ * workspaces (each may be NULL) is set - under data parallelism the all-reduced poison slot of the flat gradient buffer;
+ * *applied += 1 by every update that ran (lstm.py:583-660's loop keeps going, fov_check_status reports once per epoch). */
+int fov_rmsprop_tf_step_guarded(float* params, const float* grads, float* ms, int64_t n, float lr, float decay, float eps,
+                                float clip_value, const void* guard0, const void* guard1, const void* guard2,
+                                int64_t* applied, fov_stream_t stream);
 
 /* The two two-layer heads of _pred_mean_var_xyz2_new (mycode/lstm.py:321-337) on the top layer's final state h (B,H), as one
  * launch each way: a1 = relu(h mu_W1 + mu_b1), mu = tanh(a1 mu_W2 + mu_b2), a3 = relu(h var_W1 + var_b1),

@@ -82,6 +82,7 @@ SIGNATURES = {
     "fov_gmm3d_sample": (_I, [_P, _P, _P, _P, ctypes.c_int64, _I, _I, _I, _P]),
     "fov_gauss_nll_grad": (_I, [_P] * 6 + [_I] * 3 + [ctypes.c_float, _P, _SZ, _P]),
     "fov_rmsprop_tf_step": (_I, [_P] * 3 + [ctypes.c_int64] + [ctypes.c_float] * 4 + [_P]),
+    "fov_rmsprop_tf_step_guarded": (_I, [_P] * 3 + [ctypes.c_int64] + [ctypes.c_float] * 4 + [_P] * 5),
     "fov_categorical_crossentropy_grad": (_I, [_P] * 4 + [ctypes.c_int64, _I, _P, _SZ, _P]),
     "fov_xyz_sum1_grad": (_I, [_P] * 3 + [ctypes.c_int64, _I, _P, _SZ, _P]),
     "fov_sample_refeed_fwd": (_I, [_P] * 4 + [ctypes.c_int64] + [_I] * 4 + [_P]),

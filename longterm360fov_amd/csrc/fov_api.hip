@@ -1001,7 +1001,18 @@ int fov_rmsprop_tf_step(float* params, const float* grads, float* ms, int64_t n,
         set_error("fov_rmsprop_tf_step: invalid argument");
         return FOV_ERR_INVALID;
     }
-    return rmsprop_tf_step(params, grads, ms, (long)n, lr, decay, eps, clip_value, (hipStream_t)stream);
+    return rmsprop_tf_step(params, grads, ms, (long)n, lr, decay, eps, clip_value, nullptr, nullptr, (hipStream_t)stream);
+}
+
+int fov_rmsprop_tf_step_guarded(float* params, const float* grads, float* ms, int64_t n, float lr, float decay, float eps,
+                                float clip_value, const void* guard0, const void* guard1, const void* guard2, int64_t* applied,
+                                fov_stream_t stream) {
+    if (n < 0 || (n > 0 && (!params || !grads || !ms))) {
+        set_error("fov_rmsprop_tf_step_guarded: invalid argument");
+        return FOV_ERR_INVALID;
+    }
+    const unsigned* guards[3] = {(const unsigned*)guard0, (const unsigned*)guard1, (const unsigned*)guard2};
+    return rmsprop_tf_step(params, grads, ms, (long)n, lr, decay, eps, clip_value, guards, (long long*)applied, (hipStream_t)stream);
 }
 
 int fov_adam_step_guarded(float* params, const float* grads, float* m, float* v, int64_t n, float lr, float beta1,

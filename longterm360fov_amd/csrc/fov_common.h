@@ -270,7 +270,7 @@ int act_fwd(const float* x, float* y, long n, int activation, hipStream_t stream
 int gauss_nll_grad(const float* mu, const float* var, const float* y, float* loss, float* dmu, float* dvar, int B, int Ty,
                    int fps, float scale, float* scratch, size_t scratch_floats, hipStream_t stream);
 int rmsprop_tf_step(float* p, const float* g, float* ms, long n, float lr, float decay, float eps, float clip,
-                    hipStream_t stream);
+                    const unsigned* const* guards, long long* applied, hipStream_t stream);
 int cce_grad(const float* p, const float* t, float* dp, float* loss, long n_pix, int C, float* scratch, size_t scratch_floats,
              hipStream_t stream);
 int xyz_sum1_grad(const float* p, float* dp, float* reg, long n_pix, int C, float* scratch, size_t scratch_floats, hipStream_t stream);

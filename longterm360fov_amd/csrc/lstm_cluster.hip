@@ -119,7 +119,7 @@ __host__ __device__ inline ClusterLds cluster_lds(int H, int F, bool decode) {
     L.off_h = L.off_k + fp * 256 + 4 * KPAD * 256;
     L.off_x = L.off_h + BT * L.ldh;
     L.off_w = L.off_x + NXBUF * BT * L.ldx;
-    L.off_bd = L.off_w + (decode ? 4 * BT * 16 : 0);   // DECODE: four per-wave 16x16 Dense partials
+    L.off_bd = L.off_w + (decode ? 2 * (H / 16) * 128 : 0);   // DECODE: the H/16 per-wave Dense partials of the tile (16 x 8 each, two floats per lane), two step parities
     L.off_flag = L.off_bd + 8;
     L.total_floats = L.off_flag + 8 + 64;   // + tail pad for run-ahead reads of the x tile
     return L;
@@ -424,7 +424,7 @@ __device__ __forceinline__ void cluster_body(const LstmParams& p, ClusterCarry& 
     float* sK = smem + L.off_k;
     float* sH = smem + L.off_h;   // h tile, column = ((unit/64 - slice) mod G)*64 + unit%64 (own slice first)
     float* sX = smem + L.off_x;   // LAYER: three x tiles (t mod 3); DECODE: the y tile
-    float* sW = smem + L.off_w;   // DECODE: the four per-wave partial products of the Dense
+    float* sY = smem + L.off_w;   // DECODE: [step parity][partial = absolute wave of the tile][lane][2]: the Dense partials
     int* sFlag = (int*)(smem + L.off_flag);
     float* sKw = sK + wave * (nq * 4 + KPAD) * 256;  // this wave's K slice in B-operand order
 
@@ -513,16 +513,16 @@ __device__ __forceinline__ void cluster_body(const LstmParams& p, ClusterCarry& 
     // zero the x tiles once: pad columns [F, Fp) are never written afterwards
     for (int i = tid; i < NXBUF * BT * LDX; i += 256) sX[i] = 0.f;
 
-    // DECODE: Dense(F_dec, tanh) runs on the matrix pipe, transposed: y^T = Wd^T . h^T.  Wave w
-    // reduces over positions [16*NB*w, 16*NB*(w+1)) of the (rotated) h tile, NB = H/64; lane
-    // (i = l&15, g4) keeps Wd[pos = 16*(NB*w + b) + 4*g4 + s][o(i)], o(i) = 4*(i&3) + (i>>2), as MFMA
-    // A operands (zero where o(i) >= F_dec).  With that row order register r of the D fragment on
-    // lane (n, g4) is y[n][4r + g4]: registers 0,1 are the A operands of the two y . K MFMA steps.
-    // The D fragment of that product has batch on the lane and o = 4*g4 + r in the registers,
-    // which is exactly the A-operand layout of the y . K product that follows: after the 4-way
-    // sum over waves (through LDS) y never leaves registers.
-    constexpr int NB = H / 64;
-    float wd[NB][4];
+    // DECODE: Dense(F_dec, tanh) runs on the matrix pipe, transposed: y^T = Wd^T . h^T, and is DISTRIBUTED (round 5): every wave
+    // forms the partial product over ITS OWN 16 units right behind the cell update (4 MFMAs on the h values it has just
+    // written to LDS) and publishes it next to its slice of h_t; y_t is the sum of the tile's H/16 partials, which arrive
+    // with the gather of h_t - no Dense section behind the gather, no barrier of its own (until round 4: 16 MFMAs per wave
+    // over a quarter of the gathered tile, four partials meeting in LDS behind a third barrier - 27 us of the decoder's 156).
+    // Lane (i = l&15, g4) keeps Wd[unit = col0 + 4*g4 + s][o(i)], o(i) = 4*(i&3) + (i>>2), as MFMA A operands (zero where
+    // o(i) >= F_dec).  With that row order register r of the D fragment on lane (n, g4) is y[n][4r + g4]: registers 0, 1
+    // are what a lane publishes and, summed over the partials, the A operands of the two y . K MFMA steps (batch on the
+    // lane, o = 4*g4 + r in the registers): y never leaves that layout.
+    float wd[4];
     float bd4[4];
     if (!LAYER) {
         const int O = p.F_dec;
@@ -530,14 +530,11 @@ __device__ __forceinline__ void cluster_body(const LstmParams& p, ClusterCarry& 
         const __amdgpu_buffer_rsrc_t wdrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dW), 0, H * O * 4, 0x00020000);
         const __amdgpu_buffer_rsrc_t bdrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dbias), 0, O * 4, 0x00020000);
 #pragma unroll
-        for (int b = 0; b < NB; ++b)
-#pragma unroll
-            for (int ss = 0; ss < 4; ++ss) {
-                const int pos = 16 * (NB * wave + b) + 4 * g4 + ss;
-                const int unit = ((slice + (pos >> 6)) & (G - 1)) * 64 + (pos & 63);
-                const int o = 4 * (n & 3) + (n >> 2);
-                wd[b][ss] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(wdrs, (o < O) ? (unsigned)((unit * O + o) * 4) : OORB, 0, 0));
-            }
+        for (int ss = 0; ss < 4; ++ss) {
+            const int unit = col0 + 4 * g4 + ss;
+            const int o = 4 * (n & 3) + (n >> 2);
+            wd[ss] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(wdrs, (o < O) ? (unsigned)((unit * O + o) * 4) : OORB, 0, 0));
+        }
 #pragma unroll
         for (int ss = 0; ss < 4; ++ss)
             bd4[ss] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(bdrs, (4 * ss + g4 < O) ? (unsigned)((4 * ss + g4) * 4) : OORB, 0, 0));
@@ -585,6 +582,27 @@ __device__ __forceinline__ void cluster_body(const LstmParams& p, ClusterCarry& 
         goff[j] = (unsigned)((within >> 6) * H + osl * 64 + (within & 63)) * 16u;
         loff[j] = 2 * (within >> 6) * LDH + rot * 64 + (within & 63);
     }
+
+    // DECODE: the Dense partials travel like h - tagged granules in an area of their own behind the hello words, [group]
+    // [parity][partial = slice*4 + wave][lane] x 16 bytes {y[n][g4], epoch, y[n][4 + g4], epoch}; thread tid fetches what the
+    // thread of the same number published in each partner workgroup.
+    constexpr int NP = 4 * G;                 // partials per tile
+    constexpr int NYG = LAYER ? 0 : G - 1;    // 16-byte loads per thread per step for them
+    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(
+        p.xch + (size_t)p.num_groups * 2 * BT * H + (size_t)p.num_groups * G + (size_t)group * 2 * NP * 128, 0,
+        LAYER ? 0 : 2 * NP * 128 * (int)sizeof(unsigned long long), 0x00020000);
+    const unsigned ypub_off = (unsigned)(((slice * 4 + wave) * 64 + lane) * 16);
+    const int ypub_lds = ((slice * 4 + wave) * 64 + lane) * 2;
+    unsigned ygoff[NYG > 0 ? NYG : 1];
+    int yloff[NYG > 0 ? NYG : 1];
+#pragma unroll
+    for (int j = 0; j < NYG; ++j) {
+        const int osl = (slice + j + 1) & (G - 1);
+        ygoff[j] = (unsigned)(((osl * 4 + wave) * 64 + lane) * 16);
+        yloff[j] = ((osl * 4 + wave) * 64 + lane) * 2;
+    }
+    constexpr unsigned YPAR_BYTES = NP * 64 * 16;   // one parity of the granule area
+    constexpr int YPAR_LDS = NP * 128;              // one parity of the LDS copy (floats)
 
     const bool h_zero = !F2 && p.h0 == nullptr;   // (the decoder phase of the fused kernel starts from the encoder's state)
     for (int tile = group; tile < p.num_tiles && !aborted; tile += p.num_groups) {
@@ -754,22 +772,26 @@ __device__ __forceinline__ void cluster_body(const LstmParams& p, ClusterCarry& 
             if (LAYER || t == 0) {
                 if (!((h_zero || F2) && t == 0)) recurrent<H, 4, NQ, true, true>(acc, hrow, wR);
             } else {
-                // DECODE: the four partial Dense products of y_{t-1} were written before these MFMAs, which do not need y; they
-                // meet in LDS meanwhile (barrier 3 and the reads sit one k-block before the end), then y_{t-1} . K completes z_t
-                constexpr int JL = NQ - 1 > 4 ? NQ - 1 : 4;   // H = 64 has no partner slices: nothing covers, nothing to split
-                recurrent<H, 4, JL, true, false>(acc, hrow, wR);
-                __syncthreads();  // barrier 3: the four partial products are in LDS
-                // outputs o = 4*ss + g4 < F_dec <= 8 live in ss = 0, 1 only: four independent 8-byte reads, ONE wait (as f32x4 the
-                // four destinations overlapped in hipcc's allocation and each read was waited for before the next was issued)
-                f32x2 part[4];
+                // DECODE: the tile's Dense partials of y_{t-1} are in LDS since barrier 2 of the previous step (own workgroup's
+                // written directly, the partners' by the gather); their reads are issued in front of these MFMAs, which do not
+                // need y, and summed behind them in a FIXED tree order (every workgroup of the group forms the same y, bit for
+                // bit); then y_{t-1} . K completes z_t
+                f32x2 part[NP];
+                {
+                    const float* yb = sY + ((t - 1) & 1) * YPAR_LDS + lane * 2;
 #pragma unroll
-                for (int w2 = 0; w2 < 4; ++w2) part[w2] = *(const f32x2*)(sW + (w2 * 16 + n) * 16 + 4 * g4);
-                recurrent<H, JL, NQ, false, false>(acc, hrow, wR);
+                    for (int q = 0; q < NP; ++q) part[q] = *(const f32x2*)(yb + q * 128);
+                }
+                recurrent<H, 4, NQ, true, false>(acc, hrow, wR);
                 // the sums / tanh BEHIND the MFMA run, not sprinkled into it: a VALU instruction in an fp32-MFMA gap is never
                 // hidden and costs a pipeline turn-around on top (tools/microbench/mfma_f32_overlap.hip)
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int ss = 0; ss < 2; ++ss) y4[ss] = tanh_f(((part[0][ss] + part[1][ss]) + part[2][ss]) + part[3][ss] + bd4[ss]);
+                for (int w2 = NP / 2; w2 >= 1; w2 >>= 1)
+#pragma unroll
+                    for (int q = 0; q < w2; ++q) part[q] += part[q + w2];
+#pragma unroll
+                for (int ss = 0; ss < 2; ++ss) y4[ss] = tanh_f(part[0][ss] + bd4[ss]);
                 // y_{t-1} leaves through a buffer store: lane offset computed once per tile, the step in the scalar offset
                 if (slice == 0 && wave == 0) {
 #pragma unroll
@@ -836,6 +858,28 @@ __device__ __forceinline__ void cluster_body(const LstmParams& p, ClusterCarry& 
             FOV_STAMP(3);
 #pragma unroll
             for (int r = 0; r < 4; ++r) sH[(4 * g4 + r) * LDH + wave * 16 + n] = hcur[r];
+            unsigned ysoff = 0;
+            if (!LAYER) {
+                // this wave's Dense partial over its own 16 units: the columns it has just written (same wave: LDS keeps its
+                // program order), as the B operand h^T of y^T = Wd^T . h^T
+                const f32x4 hb = *(const f32x4*)(hrow + 16 * wave);
+                f32x4 dacc[2];
+                dacc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                dacc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#ifndef FOV_DBG_NODENSE   // (timing experiment only, wrong results: the partial stays zero)
+#pragma unroll
+                for (int ss = 0; ss < 4; ++ss)
+                    mfma_f32<false>(dacc[ss & 1], wd[ss], hb[ss], mf_pos(true, true, ss < 2, ss == 3));
+#endif
+                const float y0 = dacc[0][0] + dacc[1][0], y1 = dacc[0][1] + dacc[1][1];
+                if (do_xch) {      // granule parity = the epoch's (as for h), LDS parity = the step's
+                    ysoff = (epoch & 1u) * YPAR_BYTES;
+                    const u32x4g yg = (u32x4g){__float_as_uint(y0), epoch, __float_as_uint(y1), epoch};
+                    if (same_xcd) __builtin_amdgcn_raw_buffer_store_b128(yg, yrs, ypub_off, ysoff, 1 /* sc0: stays in L2 */);
+                    else __builtin_amdgcn_raw_buffer_store_b128(yg, yrs, ypub_off, ysoff, 16 /* sc1: write-through */);
+                }
+                *(f32x2*)(sY + (t & 1) * YPAR_LDS + ypub_lds) = (f32x2){y0, y1};
+            }
             __syncthreads();  // barrier 1b: the own slice of h_t is visible to all four waves
             FOV_STAMP(4);
             const bool more = (t + 1 < steps);
@@ -850,6 +894,7 @@ __device__ __forceinline__ void cluster_body(const LstmParams& p, ClusterCarry& 
             }
             FOV_STAMP(5);
             u32x4g v[NG > 0 ? NG : 1];
+            u32x4g vy[NYG > 0 ? NYG : 1];   // DECODE: the partners' Dense partials, same sweep
             // DECODE has no x . K block between the publish and the gather: one own-slice k-block goes first, so the sweep is
             // not requested right behind the partners' publish (decoder 0.191 -> 0.188 ms over three paired runs; the
             // eight-workgroup kernels, whose stores are sc1, gain far more from the same delay - lstm_wide.hip)
@@ -860,6 +905,8 @@ __device__ __forceinline__ void cluster_body(const LstmParams& p, ClusterCarry& 
                 if (do_xch) {
 #pragma unroll
                     for (int j = 0; j < NG; ++j) v[j] = __builtin_amdgcn_raw_buffer_load_b128(xrs, goff[j], xsoff, 16);
+#pragma unroll
+                    for (int j = 0; j < NYG; ++j) vy[j] = __builtin_amdgcn_raw_buffer_load_b128(yrs, ygoff[j], ysoff, 16);
                 }
                 // (a ZX layer has no x . K run in front: this run opens; with partner slices the next reader of the accumulators is
                 // the partner-slice MFMA run: no closing wait states)
@@ -867,6 +914,8 @@ __device__ __forceinline__ void cluster_body(const LstmParams& p, ClusterCarry& 
             } else if (do_xch) {
 #pragma unroll
                 for (int j = 0; j < NG; ++j) v[j] = __builtin_amdgcn_raw_buffer_load_b128(xrs, goff[j], xsoff, 16);
+#pragma unroll
+                for (int j = 0; j < NYG; ++j) vy[j] = __builtin_amdgcn_raw_buffer_load_b128(yrs, ygoff[j], ysoff, 16);
             }
             FOV_STAMP(11);
             if (do_xch) {
@@ -880,6 +929,8 @@ __device__ __forceinline__ void cluster_body(const LstmParams& p, ClusterCarry& 
                     bool ok = true;
 #pragma unroll
                     for (int j = 0; j < NG; ++j) ok = ok && (v[j].y == epoch) && (v[j].w == epoch);
+#pragma unroll
+                    for (int j = 0; j < NYG; ++j) ok = ok && (vy[j].y == epoch) && (vy[j].w == epoch);
                     if (__all(ok)) break;
                     ++spins;
                     if (spins > SPIN_LIMIT || ((spins & 63u) == 0 && xch_poisoned(p.status))) {
@@ -893,6 +944,8 @@ __device__ __forceinline__ void cluster_body(const LstmParams& p, ClusterCarry& 
                     asm volatile("" ::: "memory");   // the sweep below must really re-read memory
 #pragma unroll
                     for (int j = 0; j < NG; ++j) v[j] = __builtin_amdgcn_raw_buffer_load_b128(xrs, goff[j], xsoff, 16);
+#pragma unroll
+                    for (int j = 0; j < NYG; ++j) vy[j] = __builtin_amdgcn_raw_buffer_load_b128(yrs, ygoff[j], ysoff, 16);
                 }
 #ifdef FOV_STAMPS
                 if (stamp_on && t < STAMP_STEPS) g_stamps[MODE & 1][t][10] = spins;
@@ -902,49 +955,29 @@ __device__ __forceinline__ void cluster_body(const LstmParams& p, ClusterCarry& 
                     sH[loff[j]] = __uint_as_float(v[j].x);
                     sH[loff[j] + LDH] = __uint_as_float(v[j].z);
                 }
+#pragma unroll
+                for (int j = 0; j < NYG; ++j)
+                    *(f32x2*)(sY + (t & 1) * YPAR_LDS + yloff[j]) = (f32x2){__uint_as_float(vy[j].x), __uint_as_float(vy[j].z)};
             }
             FOV_STAMP(6);
             __syncthreads();  // barrier 2: the whole h_t tile is in LDS
             FOV_STAMP(7);
             if (G > 1 && sFlag[0]) { aborted = true; break; }
-#ifdef FOV_DBG_NODENSE   // timing experiment only (wrong results): no Dense section, y = 0
-            if (false) {
-#else
-            if (!LAYER) {
-#endif
-                // y_t = tanh(h_t . Wd + bias) on the matrix pipe (see the wd[] comment above)
-                f32x4 hb[NB];
-                const float* hq = hrow + 16 * NB * wave;
-#pragma unroll
-                for (int b = 0; b < NB; ++b) hb[b] = *(const f32x4*)(hq + 16 * b);
-                f32x4 dacc[2];
-                dacc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                dacc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int b = 0; b < NB; ++b)
-#pragma unroll
-                    for (int ss = 0; ss < 4; ++ss)
-                        mfma_f32<false>(dacc[ss & 1], wd[b][ss], hb[b][ss], mf_pos(true, true, b == 0 && ss < 2, b == NB - 1 && ss == 3));
-#pragma unroll
-                for (int ss = 0; ss < 4; ++ss) dacc[0][ss] += dacc[1][ss];
-                *(f32x4*)(sW + (wave * 16 + n) * 16 + 4 * g4) = dacc[0];   // partial over this wave's positions
-                FOV_STAMP(8);
-            }
         }
         if (!LAYER && steps > 0 && !aborted) {
-            // y of the last step: nothing is left to cover the meeting of its partials
-            __syncthreads();
-            f32x4 ysum = *(const f32x4*)(sW + n * 16 + 4 * g4);
-#pragma unroll
-            for (int w2 = 1; w2 < 4; ++w2) {
-                const f32x4 part = *(const f32x4*)(sW + (w2 * 16 + n) * 16 + 4 * g4);
-#pragma unroll
-                for (int ss = 0; ss < 4; ++ss) ysum[ss] += part[ss];
-            }
+            // y of the last step: its partials arrived with the last gather (barrier 2 of the last step)
             if (slice == 0 && wave == 0) {
+                f32x2 part[NP];
+                const float* yb = sY + ((steps - 1) & 1) * YPAR_LDS + lane * 2;
+#pragma unroll
+                for (int q = 0; q < NP; ++q) part[q] = *(const f32x2*)(yb + q * 128);
+#pragma unroll
+                for (int w2 = NP / 2; w2 >= 1; w2 >>= 1)
+#pragma unroll
+                    for (int q = 0; q < w2; ++q) part[q] += part[q + w2];
 #pragma unroll
                 for (int ss = 0; ss < 2; ++ss)
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(tanh_f(ysum[ss] + bd4[ss])), yors, yoff[ss],
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(tanh_f(part[0][ss] + bd4[ss])), yors, yoff[ss],
                                                           (unsigned)((steps - 1) * p.F_dec * 4), 0);
             }
         }
@@ -1066,7 +1099,7 @@ int cluster_num_groups(int B, int H) {
 
 static size_t cluster_xch_bytes(int B, int H) {
     const size_t groups = (size_t)cluster_num_groups(B, H);
-    const size_t b = (groups * 2 * BT * H + groups * (H / 64)) * sizeof(unsigned long long);   // granules + hello
+    const size_t b = (groups * 2 * BT * H + groups * (H / 64) + groups * 2 * (H / 16) * 128) * sizeof(unsigned long long);   // granules + hello + (decode) the Dense partials
     return (b + 255) & ~(size_t)255;
 }
 

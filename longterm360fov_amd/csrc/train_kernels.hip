@@ -1051,9 +1051,11 @@ __global__ __launch_bounds__(256) void cce_grad_kernel(const float* __restrict__
 // clip_by_value(grad, -clip, clip):  ms = decay*ms + (1-decay) g^2;  p -= lr * g / sqrt(ms + eps).  (eps INSIDE the
 // root, ms initialised to ONE - both unlike Keras RMSprop.)
 __global__ __launch_bounds__(256) void rmsprop_tf_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ ms,
-                                                         long n, float lr, float decay, float eps, float clip) {
+                                                         long n, float lr, float decay, float eps, float clip, const unsigned* g0,
+                                                         const unsigned* g1, const unsigned* g2, long long* applied) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
+    if (i >= n || optimizer_poisoned(g0, g1, g2)) return;     // fail-stop: a persistent kernel of the step gave up -> no update
+    if (i == 0 && applied) *applied += 1;
     float gi = g[i];
     if (clip > 0.f) gi = fminf(fmaxf(gi, -clip), clip);
     const float m = decay * ms[i] + (1.f - decay) * gi * gi;
@@ -2102,9 +2104,10 @@ int sample_refeed_bwd(const float* dx, long ldx, const float* var, const float* 
 }
 
 int rmsprop_tf_step(float* p, const float* g, float* ms, long n, float lr, float decay, float eps, float clip,
-                    hipStream_t stream) {
+                    const unsigned* const* guards, long long* applied, hipStream_t stream) {
     if (n <= 0) return FOV_OK;
-    hipLaunchKernelGGL(rmsprop_tf_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, p, g, ms, n, lr, decay, eps, clip);
+    hipLaunchKernelGGL(rmsprop_tf_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, p, g, ms, n, lr, decay, eps, clip,
+                       guards ? guards[0] : nullptr, guards ? guards[1] : nullptr, guards ? guards[2] : nullptr, applied);
     return check_launch("rmsprop_tf");
 }
 

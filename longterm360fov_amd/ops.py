@@ -466,7 +466,8 @@ def side_stream(device, priority=1, owner=None):
         check(_lib.lib().fov_stream_create(int(priority), _ct.byref(h)))
         st = torch.cuda.ExternalStream(h.value, device=device)
     try:
-        weakref.finalize(st if owner is None else owner, _destroy_stream, h.value)
+        fin = weakref.finalize(st if owner is None else owner, _destroy_stream, h.value)
+        fin.atexit = False      # at interpreter exit the HIP runtime may be gone before the finalizer runs: the process ends anyway
     except TypeError:       # an owner that cannot be weakly referenced: the stream lives as long as the process
         pass
     return st
@@ -700,11 +701,16 @@ def sample_refeed_bwd(dx, var, noise, dmu, dvar, std="sqrt", planar=False, accum
     return dmu, dvar
 
 
-def rmsprop_tf_step(params, grads, ms, lr, decay=0.9, eps=1e-10, clip_value=0.0):
+def rmsprop_tf_step(params, grads, ms, lr, decay=0.9, eps=1e-10, clip_value=0.0, guards=None, applied=None):
+    """tf.train.RMSPropOptimizer + clip_by_value on flat buffers (lstm.py:556-567); guards / applied as in adam_step."""
     for t in (params, grads, ms):
         _dev(t, "flat buffer")
-    check(_lib.lib().fov_rmsprop_tf_step(_ptr(params), _ptr(grads), _ptr(ms), params.numel(), lr, decay, eps, clip_value,
-                                         _stream()))
+    if guards is None and applied is None:
+        check(_lib.lib().fov_rmsprop_tf_step(_ptr(params), _ptr(grads), _ptr(ms), params.numel(), lr, decay, eps, clip_value,
+                                             _stream()))
+    else:
+        check(_lib.lib().fov_rmsprop_tf_step_guarded(_ptr(params), _ptr(grads), _ptr(ms), params.numel(), lr, decay, eps, clip_value,
+                                                     *_guard_ptrs(guards), _applied_ptr(applied), _stream()))
 
 
 def dense_bwd(x, W, dpre, dW=None, db=None, need_dx=True, accumulate=False, scratch=None, need_dW=True, need_db=True,

@@ -47,6 +47,7 @@ class FlatParamTrainer:
         self.step_count = 0
         self.applied = torch.zeros(1, dtype=torch.int64, device=device)     # optimizer launches that were not skipped on the device
         self._dp_steps_since_check = 0
+        self._dp_seen = False
         self._dp_guard = None
         self.ws = ops.Workspace()
         self.scratch = ops.Scratch()        # split-K partials of the Dense / MSE / matmul calls
@@ -72,21 +73,35 @@ class FlatParamTrainer:
 
         Under data parallelism this is a collective in the sense that every rank must call it at the same points (fit does,
         once per epoch): the timeout word is sticky on the rank that failed, so from the failing step on the all-reduced poison
-        slot is nonzero on EVERY rank at every step - all replicas skip those updates together - and the value the last step
-        left in the slot tells every rank here that some rank failed.  All of them raise, and all set their step counter back
+        slot is nonzero on EVERY rank at every step - all replicas skip those updates together - and one scalar all-reduce
+        here tells every rank that some rank failed, in a step or in a forward pass since.  All of them raise, and all set their step counter back
         to the number of updates that really ran (self.applied, counted on the device by the guarded optimizer: the steps
         before the failing one stay counted, Adam's bias correction continues where the parameters are)."""
-        peer_failed = self._dp_steps_since_check > 0 and float(self.poison_slot.item()) != 0.0
-        self._dp_steps_since_check = 0
+        stepped, self._dp_steps_since_check = self._dp_steps_since_check > 0, 0
+        err = None
         try:
             self.ws.check()
             self.bwd_scratch.check()
             ws_bwd = getattr(self, "ws_bwd", None)
             if ws_bwd is not None:
                 ws_bwd.check()
-        except Exception:
+        except Exception as exc:
+            err = exc
+        # Every rank learns here whether ANY rank's persistent kernel gave up since the last check - in a training step (the
+        # all-reduced poison slot said so already and the replicas skipped those updates together) or in a forward that no
+        # all-reduce follows (model.fit's validation passes run between the last step and this check): one scalar all-reduce per
+        # check, i.e. per epoch, so that all ranks raise together instead of one raising while its peers walk into the next
+        # collective.
+        peer_failed = False
+        if self._dp_seen and parallel.dp_active():
+            flag = torch.tensor([1.0 if err is not None else 0.0], dtype=torch.float32, device=self.gradbuf.device)
+            torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.SUM)
+            peer_failed = float(flag.item()) > (1.0 if err is not None else 0.0)
+        elif stepped:      # (a group of one under FOV_FORCE_DIST, or the group is gone: what the last step's slot says)
+            peer_failed = err is None and float(self.poison_slot.item()) != 0.0
+        if err is not None:
             self.step_count = int(self.applied.item())
-            raise
+            raise err
         if peer_failed:
             self.step_count = int(self.applied.item())
             from ._lib import ERR_TIMEOUT, FovError
@@ -160,17 +175,25 @@ class FlatParamTrainer:
         all-reduces of the flat buffer (one for the tail named by grads_final, overlapped with the remaining backward
         work, one for the head; a trainer that names no tail does a single one), so the update equals the
         single-process one.  Returns the (global) loss as a (1,) tensor that the NEXT step overwrites."""
-        _, world = parallel.world()
-        n_local = inputs[0].shape[0]
-        weight = 1.0 if world == 1 else n_local / float(n_global if n_global else n_local * world)
-        self._dp = parallel.dp_active()   # more than one rank - or FOV_FORCE_DIST=1 on an initialised group of one (RCCL tests)
-        self._pending, self._reduced_from = [], self.gradbuf.numel()
+        weight = self._begin_step(inputs[0].shape[0], n_global)
         deferring = self._defer_begin()
         try:
             loss, _ = self.forward_backward(*inputs, grad_weight=weight, **kw)
         finally:
             if deferring:
                 ops.reduce_defer_end(self.grad)      # flushes: every gradient is final from here on
+        return self._finish_step(loss)
+
+    def _begin_step(self, n_local, n_global=None):
+        """-> this rank's share n_local / n_global of the global batch (1.0 on one rank): the weight of its loss and gradients."""
+        _, world = parallel.world()
+        weight = 1.0 if world == 1 else n_local / float(n_global if n_global else n_local * world)
+        self._dp = parallel.dp_active()   # more than one rank - or FOV_FORCE_DIST=1 on an initialised group of one (RCCL tests)
+        self._pending, self._reduced_from = [], self.gradbuf.numel()
+        return weight
+
+    def _finish_step(self, loss):
+        """Every gradient of the step is in self.grad: the data-parallel all-reduce of the flat buffer, then the (guarded) optimizer."""
         if self._dp:
             if loss.data_ptr() != self.loss_slot.data_ptr():
                 self.loss_slot.copy_(loss.reshape(1))
@@ -188,6 +211,7 @@ class FlatParamTrainer:
             loss = self.loss_slot
             self._dp_guard = self.poison_slot
             self._dp_steps_since_check += 1
+            self._dp_seen = True
         try:
             self.apply_gradients()
         finally:
@@ -1590,7 +1614,7 @@ class ConvLSTMTrainer(FlatParamTrainer):
         return loss
 
 
-class TFLSTMTrainer:
+class TFLSTMTrainer(FlatParamTrainer):
     """Training step of the raw-TensorFlow model of mycode/lstm.py (cfg.use_xyz, cfg.predict_mean_var,
     predict_len == 1 form): MultiRNNCell of LSTMCell(n_hidden) under dynamic_rnn with a fed state (:218-240),
     the two two-layer heads of _pred_mean_var_xyz2_new on the top layer's final h (:321-337: relu -> tanh for the
@@ -1603,7 +1627,14 @@ class TFLSTMTrainer:
     var_b2.  The DropoutWrapper (output_keep_prob) acts on what a layer hands UP, not on its recurrent state: give
     `masks` [(B,T,H) per non-top layer, already scaled by 1/keep] to reproduce it; the head reads the top state h,
     which no mask touches.  The predict_len > 1 form of the script (the value mycode/config.py:21 ships) re-feeds
-    sampled seconds: pass `noise` to forward_backward / train_step (fov_sample_refeed_fwd / _bwd)."""
+    sampled seconds: pass `noise` to forward_backward / train_step (fov_sample_refeed_fwd / _bwd).
+
+    A FlatParamTrainer like the Keras-path trainers: parameters / gradients / the RMSProp slot are flat buffers, check() reports a
+    persistent kernel that gave up, the optimizer launch is guarded by the workspaces' timeout words (skipped on the device,
+    `applied` counts the updates that ran), and under torch.distributed every rank passes its shard and `n_global`: ONE SUM
+    all-reduce of [poison | gradients | loss] per step, the clip and the RMSProp update act on the all-reduced gradient as the
+    single-process step does on the global batch's.  The epoch loop, learning-rate schedule, tf.train.Saver-style save /
+    restore and the test loop of lstm.py:583-828 are in lstm_driver.py."""
 
     HEAD = ("mu_W1", "mu_b1", "mu_W2", "mu_b2", "var_W1", "var_b1", "var_W2", "var_b2")
     GMM_HEAD = ("fc1_W", "fc1_b", "fc2_W", "fc2_b", "fc3_W", "fc3_b", "fc4_W", "fc4_b")
@@ -1647,7 +1678,6 @@ class TFLSTMTrainer:
         first = self.FIRST[head_kind]
         conv = [convert_tf_lstmcell(W, b, forget_bias) for W, b in cells]
         self.L = len(conv)
-        self._stack2_bwd_cache = {}
         # The stack runs at the next matrix-core width Hp (lstm.py's n_hidden = 400 -> 512: lstm_wide16.hip forward, lstm_bwd16.hip
         # BPTT) with zero-padded weights - exact, as in PaddedTrainer: a padded unit has z = 0, c = h = 0, dz = 0, so every
         # gradient in a padded slice is exactly 0 and TF's RMSProp leaves the zeros in place.  States, masks, weights and
@@ -1667,20 +1697,16 @@ class TFLSTMTrainer:
                 widths[ax] = (0, self.Hp - self.H)
                 weights[k] = np.ascontiguousarray(np.pad(weights[k], widths))
         self.order = ["%s%d" % (n, l) for l in range(self.L) for n in ("K", "R", "b")] + list(self.HEAD)
-        n = int(sum(weights[k].size for k in self.order))
-        self.flat = torch.empty(n, dtype=torch.float32, device=device)
-        self.grad = torch.zeros(n, dtype=torch.float32, device=device)
-        self.ms = torch.ones(n, dtype=torch.float32, device=device)      # TF initialises the rms slot to one
-        self.w, self.g = {}, {}
-        off = 0
-        for k in self.order:
-            cnt, shp = weights[k].size, weights[k].shape
-            self.w[k] = self.flat[off:off + cnt].view(*shp)
-            self.g[k] = self.grad[off:off + cnt].view(*shp)
-            self.w[k].copy_(torch.from_numpy(weights[k]))
-            off += cnt
-        self.ws, self.scratch, self.bwd_scratch = ops.Workspace(), ops.Scratch(), ops.Scratch()
+        self._alloc(weights, self.order, "rmsprop_tf", lr, device)     # flat buffers, the [poison | grads | loss] layout, workspaces
+        self.m.fill_(1.0)      # TF initialises the rms slot to one
+        self.ms = self.m
         self._state_pads = {}
+
+    def apply_gradients(self):
+        """tf.train.RMSPropOptimizer on clip_by_value(grad, -1, 1) (lstm.py:556-567), one guarded launch on the flat buffers."""
+        self.step_count += 1
+        ops.rmsprop_tf_step(self.flat, self.grad, self.ms, self.lr, self.decay, self.eps, self.clip, guards=self._guards(),
+                            applied=self.applied)
 
     def _unpadded(self, table, k):
         """Tensor `k` of self.w / self.g at the caller's width H (numpy)."""
@@ -1745,19 +1771,7 @@ class TFLSTMTrainer:
 
     def cells_tf(self):
         """Current LSTM weights back in tf.contrib LSTMCell layout [(W (F+H,4H), b)]."""
-        out = []
-        for l in range(self.L):
-            K, R, b = (self._unpadded(self.w, "%s%d" % (n, l)) for n in ("K", "R", "b"))
-            H = R.shape[0]
-            perm = np.concatenate([np.arange(0, H), np.arange(2 * H, 3 * H), np.arange(H, 2 * H), np.arange(3 * H, 4 * H)])
-            W = np.concatenate([K, R], 0)
-            Wt, bt = np.empty_like(W), np.empty_like(b)
-            Wt[:, perm] = W
-            bk = b.copy()
-            bk[H:2 * H] -= np.float32(self.forget_bias)
-            bt[perm] = bk
-            out.append((Wt, bt))
-        return out
+        return self._cells_from(self.w, True)
 
     def _head_fused(self, h):
         M, O = self.w["mu_W2"].shape
@@ -1916,13 +1930,10 @@ class TFLSTMTrainer:
         return ops.act_bwd(dh_b, hT, base=dh_a, activation=None)      # dh_a + dh_b
 
     def _stack2_bwd_ok(self, tape):
-        x0 = tape[0][0]
-        B, T, F = x0.shape
-        H = self.w["R0"].shape[0]
-        key = (B, T, F, H)
-        if key not in self._stack2_bwd_cache:
-            self._stack2_bwd_cache[key] = ops.lstm_stack2_bwd_supported(B, T, F, H)
-        return self._stack2_bwd_cache[key]
+        """Asked at every step (a cheap C call): the answer depends on FOV_NO_STACK2 and the CU count the library sees, which
+        ops._sync_env reloads live - a cached answer would send a later step into a launch that now refuses."""
+        B, T, F = tape[0][0].shape
+        return ops.lstm_stack2_bwd_supported(B, T, F, self.w["R0"].shape[0])
 
     def _stack_backward(self, tape, dhT, masks, accumulate, need_dx0=False):
         w, g = self.w, self.g
@@ -1951,13 +1962,15 @@ class TFLSTMTrainer:
                 dx0 = b["dx"]
         return dx0
 
-    def _fb_gmm(self, x, y, init_state, masks, head_masks):
+    def _fb_gmm(self, x, y, init_state, masks, head_masks, grad_weight=1.0):
         """lstm.py:482-485: one window, costfunc.mixture_3d_gaussian_loss on y (second 0 under cfg.process_in_seconds,
         every frame of (B,T,3) otherwise), divided by batch_size * running_length [* fps] (cost.py:544-549)."""
         B = x.shape[0]
         pis = self.process_in_seconds
         n_pts = self.fps if pis else y.shape[1]
-        scale = 1.0 / ((self.batch_size or B) * self.running_length * (self.fps if pis else 1))
+        # data parallelism: batch_size (cfg.batch_size) is the GLOBAL batch - the per-rank sums then add up to the script's loss
+        # under the SUM all-reduce as they are; without it the divisor is this rank's B and the rank's share weighs it
+        scale = (1.0 if self.batch_size else grad_weight) / ((self.batch_size or B) * self.running_length * (self.fps if pis else 1))
         init_state, masks = self._pad_state(init_state), self._pad_masks(masks)
         tape, states = self._stack_forward(x, init_state, masks)
         hT = states[-1][1]
@@ -1967,7 +1980,7 @@ class TFLSTMTrainer:
         self._stack_backward(tape, dhT, masks, accumulate=False)
         return loss, acts[-1], None, self._state_out(states)
 
-    def _fb_raw(self, x, y, init_state, masks):
+    def _fb_raw(self, x, y, init_state, masks, grad_weight=1.0):
         """lstm.py:486-508: prediction k is scored against second k (tf.losses.mean_squared_error over every element;
         pred_raw_loss_tf's total-variation term differences an axis of length one and is exactly zero, cost.py:608-618),
         then shifted into the window for prediction k+1 - no sampling, the gradient flows back through the predictions.
@@ -1992,8 +2005,8 @@ class TFLSTMTrainer:
             hT = states[-1][1]
             acts = self._head(hT)
             pred = acts[-1]
-            dP, loss = ops.mse_dense_grad(pred, y[:, k].contiguous(), activation=None, scratch=sc)
-            if self.use_reg:
+            dP, loss = ops.mse_dense_grad(pred, y[:, k].contiguous(), activation=None, scratch=sc, weight=grad_weight)
+            if self.use_reg:      # (a SUM over this rank's frames: ranks add up unweighted)
                 dreg = torch.zeros_like(pred)
                 reg = ops.xyz_sum1_grad(pred.view(B, F // 3, 3), dreg.view(B, F // 3, 3), scratch=sc)   # 0.5 * mean over the B*fps frames
                 w = 0.2 * B * (F // 3)
@@ -2012,8 +2025,9 @@ class TFLSTMTrainer:
                 ops.act_bwd(slot, slot, base=src, activation=None, out=src)
         return total, runs[-1]["acts"][-1], None, self._state_out(states)
 
-    def forward_backward(self, x, y, init_state=None, masks=None, noise=None, head_masks=None):
-        """x (B,T,F), y (B,T_y,3*fps), init_state (L,2,B,H) (c,h) or None.  Fills self.grad; returns
+    def forward_backward(self, x, y, init_state=None, masks=None, noise=None, head_masks=None, grad_weight=1.0):
+        """x (B,T,F), y (B,T_y,3*fps), init_state (L,2,B,H) (c,h) or None.  Fills self.grad (times grad_weight, a data-parallel
+        rank's share of the global batch); returns
         (loss (1,), mu (B,3), var (B,3), final state (L,2,B,H)) - head_kind 'gmm': (loss, params (B,10n), None, state),
         'raw': (loss, last predicted second (B,3*fps), None, state).  head_masks: the two dropouts of _GMM_3dgassian
         [(B,64), (B,128)], pre-scaled; None = the script (tf.layers.dropout without training=True is the identity).
@@ -2025,11 +2039,11 @@ class TFLSTMTrainer:
         flows back through the samples (reparameterisation, as TF differentiates tf.random_normal(mean, stddev)).
         `masks` is then a list of T_y per-window mask lists (DropoutWrapper draws a new mask per dynamic_rnn call)."""
         if self.head_kind == "gmm":
-            return self._fb_gmm(x, y, init_state, masks, head_masks)
+            return self._fb_gmm(x, y, init_state, masks, head_masks, grad_weight)
         if self.head_kind == "raw":
-            return self._fb_raw(x, y, init_state, masks)
+            return self._fb_raw(x, y, init_state, masks, grad_weight)
         sc = self.scratch
-        scale = 1.0 / (self.running_length * self.fps)
+        scale = grad_weight / (self.running_length * self.fps)
         init_state = self._pad_state(init_state)
         unpad = self._state_out
         if noise is None:
@@ -2069,7 +2083,102 @@ class TFLSTMTrainer:
         last = runs[-1]
         return total, last["head"][1], last["head"][3], unpad(states)
 
-    def train_step(self, x, y, init_state=None, masks=None, noise=None, head_masks=None):
+    def train_step(self, x, y, init_state=None, masks=None, noise=None, head_masks=None, n_global=None):
+        """One step of lstm.py:612-620's sess.run([train_op, current_state]) -> (loss (1,), final state (L,2,B,H)) - the state is
+        this rank's own (its sequences'), the loss the global one under data parallelism (n_global = global batch size)."""
+        weight = self._begin_step(x.shape[0], n_global)
+        loss, _, _, state = self.forward_backward(x, y, init_state, masks, noise, head_masks, grad_weight=weight)
+        return self._finish_step(loss), state
+
+    def eval_loss(self, x, y, init_state=None, masks=None, noise=None, head_masks=None):
+        """The `cost` fetch of the script's display step (lstm.py:625-650): loss and state of one batch, no update."""
         loss, _, _, state = self.forward_backward(x, y, init_state, masks, noise, head_masks)
-        ops.rmsprop_tf_step(self.flat, self.grad, self.ms, self.lr, self.decay, self.eps, self.clip)
         return loss, state
+
+    # ---- tf.train.Saver's view of the model (lstm.py:552): every variable and its RMSProp slots under the graph's names ----
+    def _tf_names(self, scope=""):
+        """parameter key -> TF-1.x variable name of lstm.py's graph (MultiRNNCell under dynamic_rnn; contrib fully_connected /
+        tf.layers.conv1d heads numbered in creation order)."""
+        names = {}
+        for l in range(self.L):
+            names["W%d" % l] = "%srnn/multi_rnn_cell/cell_%d/lstm_cell/kernel" % (scope, l)
+            names["B%d" % l] = "%srnn/multi_rnn_cell/cell_%d/lstm_cell/bias" % (scope, l)
+        if self.head_kind == "raw":
+            for i in range(3):
+                sfx = "" if i == 0 else "_%d" % i
+                names["conv%d_W" % (i + 1)] = "conv1d%s/kernel" % sfx
+                names["conv%d_b" % (i + 1)] = "conv1d%s/bias" % sfx
+        else:
+            keys = (("mu_W1", "mu_b1"), ("mu_W2", "mu_b2"), ("var_W1", "var_b1"), ("var_W2", "var_b2")) if self.head_kind == "meanvar" \
+                else tuple(("fc%d_W" % i, "fc%d_b" % i) for i in (1, 2, 3, 4))
+            for i, (kw_, kb_) in enumerate(keys):
+                sfx = "" if i == 0 else "_%d" % i
+                names[kw_] = "fully_connected%s/weights" % sfx
+                names[kb_] = "fully_connected%s/biases" % sfx
+        return names
+
+    def _cells_from(self, table, with_forget_bias):
+        """[(W (F+H,4H), b (4H))] in tf.contrib LSTMCell layout from the flat table (self.w or the slot views)."""
+        out = []
+        for l in range(self.L):
+            K, R, b = (self._unpadded(table, "%s%d" % (n, l)) for n in ("K", "R", "b"))
+            H = R.shape[0]
+            perm = np.concatenate([np.arange(0, H), np.arange(2 * H, 3 * H), np.arange(H, 2 * H), np.arange(3 * H, 4 * H)])
+            W = np.concatenate([K, R], 0)
+            Wt, bt = np.empty_like(W), np.empty_like(b)
+            Wt[:, perm] = W
+            bk = b.copy()
+            if with_forget_bias:
+                bk[H:2 * H] -= np.float32(self.forget_bias)
+            bt[perm] = bk
+            out.append((Wt, bt))
+        return out
+
+    def state_dict(self, scope=""):
+        """{TF variable name: array} of everything tf.train.Saver() writes for this graph: the LSTM cells (tf.contrib layout, the
+        forget bias taken out again), the head, `<name>/RMSProp` (the rms slot, initialised to one) and `<name>/RMSProp_1` (the
+        momentum slot: zeros, momentum is 0), the learning-rate variable and - not a TF variable - the update counter."""
+        slot_views = {k: self.ms[self.offset[k]:self.offset[k] + self.w[k].numel()].view(self.w[k].shape) for k in self.order}
+        names = self._tf_names(scope)
+        out = {}
+        for tag, table, fb in (("", self.w, True), ("/RMSProp", slot_views, False)):
+            for l, (W, b) in enumerate(self._cells_from(table, fb)):
+                out[names["W%d" % l] + tag], out[names["B%d" % l] + tag] = W, b
+            for k in self.HEAD:
+                out[names[k] + tag] = self._unpadded(table, k)
+        for name in [n for n in out if not n.endswith("/RMSProp")]:
+            out[name + "/RMSProp_1"] = np.zeros_like(out[name])
+        out["Variable"] = np.float64(self.lr)          # lr = tf.Variable(cfg.LEARNING_RATE, trainable=False), lstm.py:554 (kept exact)
+        out["fov/applied_updates"] = np.int64(self.step_count)
+        return out
+
+    def load_state_dict(self, sd, scope=""):
+        """saver.restore (lstm.py:589-592,669-672): parameters, rms slots and learning rate back in place (padded slices stay
+        exactly zero / one as a fresh trainer has them)."""
+        from .models import convert_tf_lstmcell, pad_lstm
+        names = self._tf_names(scope)
+
+        def put(table_flat, k, arr):
+            view = table_flat[self.offset[k]:self.offset[k] + self.w[k].numel()].view(self.w[k].shape)
+            arr = np.ascontiguousarray(arr, dtype=np.float32)
+            if tuple(arr.shape) != tuple(view.shape):      # zero-pad the H axis up to Hp (weights: 0; the rms slot of a padded
+                pad = [(0, view.shape[i] - arr.shape[i]) for i in range(arr.ndim)]      # element is never read with a gradient)
+                arr = np.pad(arr, pad, constant_values=0.0 if table_flat is self.flat else 1.0)
+            view.copy_(torch.from_numpy(arr))
+
+        for tag, flat, fb in (("", self.flat, self.forget_bias), ("/RMSProp", self.ms, 0.0)):
+            for l in range(self.L):
+                W, b = sd[names["W%d" % l] + tag], sd[names["B%d" % l] + tag]
+                K, R, bk = convert_tf_lstmcell(np.asarray(W, np.float32), np.asarray(b, np.float32), fb)
+                if self.Hp != self.H:
+                    Kp, Rp, bp = pad_lstm(K, R, bk, self.Hp, pad_input=(l > 0))
+                    if tag:       # slot of a padded element: one, as TF initialises it (its gradient is exactly zero: never used)
+                        ones = pad_lstm(np.ones_like(K), np.ones_like(R), np.ones_like(bk), self.Hp, pad_input=(l > 0))
+                        Kp, Rp, bp = (np.where(o == 1.0, v, np.float32(1.0)) for v, o in zip((Kp, Rp, bp), ones))
+                    K, R, bk = Kp, Rp, bp
+                put(flat, "K%d" % l, K); put(flat, "R%d" % l, R); put(flat, "b%d" % l, bk)
+            for k in self.HEAD:
+                put(flat, k, sd[names[k] + tag])
+        self.lr = float(sd["Variable"])
+        self.step_count = int(sd.get("fov/applied_updates", 0))
+        self.applied.fill_(self.step_count)
