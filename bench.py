@@ -282,54 +282,64 @@ def bench_train_mixing(args, rank, world, use_dist):
 
 
 def dp_probe(args, rank, world, steps=10):
-    """Every rank: `steps` data-parallel training steps of the configs[2] model at 512 sequences per rank (fp32), and the
-    all-reduce of its flat gradient buffer on its own.  -> dict for rank 0's line (times are the MAX over ranks)."""
+    """Every rank: `steps` data-parallel training steps of the configs[2] model at 512 sequences per rank, fp32 (6.7 MB
+    gradient payload) and then bf16 (configs[4]: the same fp32 master-gradient buffer - 6.7 MB on the wire - behind the bf16
+    step), and the all-reduce of the flat gradient buffer on its own.  -> dict for rank 0's line (times are the MAX over ranks)."""
     import torch.distributed as dist
     from longterm360fov_amd.training import OthersMixingTrainer
     from oracle import fov_oracle as O
     H, T_in, T_out, U = 256, 10, 10, 34
     B = int(os.environ.get("FOV_DP_PROBE_BATCH", "512"))     # (rehearsals of two ranks on ONE GPU use a small batch: two full-chip persistent grids cannot be co-resident)
-    out = {"workload": "configs[2] training step, %d sequences per rank x %d ranks, fp32, one flat-buffer SUM all-reduce per step" % (B, world)}
-    try:
-        w = O.init_others_mixing(1234, H=H, num_user=U, bias_noise=0.05)
-        enc, dec0, tgt, oth = O.synthetic_batch(4321 + rank, B, T_in, T_out, num_others=U - 1)
-        d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
-        a = (d(enc), d(oth), d(dec0), d(tgt))
-        tr = OthersMixingTrainer(w)
-        for _ in range(3):
-            tr.train_step(*a, n_global=B * world)
-        tr.check()
-        torch.cuda.synchronize()
-        dist.barrier()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(steps):
-            loss = tr.train_step(*a, n_global=B * world)
-        e1.record()
-        torch.cuda.synchronize()
-        tr.check()
-        step_ms = e0.elapsed_time(e1) / steps
-        final_loss = float(loss.item())       # (read now: the loop below sums the buffer, loss slot included, over and over)
-        # the collective alone: the same buffer, the same call, back to back on the launch stream
-        dist.barrier()
-        e0.record()
-        for _ in range(steps):
-            dist.all_reduce(tr.gradbuf, op=dist.ReduceOp.SUM)
-        e1.record()
-        torch.cuda.synchronize()
-        ar_ms = e0.elapsed_time(e1) / steps
-        t = torch.tensor([step_ms, ar_ms], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        step_ms, ar_ms = (float(v) for v in t.tolist())
-        payload = tr.gradbuf.numel() * 4
-        out.update({"dp_step_ms": step_ms, "allreduce_ms": ar_ms, "allreduce_payload_bytes": payload,
-                    "allreduce_algbw_gbps": payload / (ar_ms * 1e-3) / 1e9,
-                    "dp_sequences_per_s": world * B / (step_ms * 1e-3), "final_loss": final_loss,
-                    "allreduce_share_of_step": ar_ms / step_ms,
-                    "note": "step = forward + BPTT + all-reduce (issued at the end of the step, stream-ordered; FOV_DP_OVERLAP stays off: "
-                            "unvalidated against a real RCCL kernel) + Adam; allreduce_ms = the same collective alone, back to back"})
-    except Exception as exc:      # the headline line must still print
-        out["error"] = "%s: %s" % (type(exc).__name__, exc)
+    out = {"workload": "configs[2] training step, %d sequences per rank x %d ranks, one flat-buffer SUM all-reduce per step" % (B, world)}
+    if os.environ.get("FOV_DP_PROBE_TEST_HANG", "") == str(rank):      # test hook (tests/test_gpu_dist_nccl.py): this rank never arrives
+        time.sleep(3600)
+    w = O.init_others_mixing(1234, H=H, num_user=U, bias_noise=0.05)
+    enc, dec0, tgt, oth = O.synthetic_batch(4321 + rank, B, T_in, T_out, num_others=U - 1)
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    a = (d(enc), d(oth), d(dec0), d(tgt))
+    for dtype in ("f32", "bf16"):
+        leg = {}
+        try:
+            tr = OthersMixingTrainer(w, dtype=dtype)
+            for _ in range(3):
+                tr.train_step(*a, n_global=B * world)
+            tr.check()
+            torch.cuda.synchronize()
+            dist.barrier()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(steps):
+                loss = tr.train_step(*a, n_global=B * world)
+            e1.record()
+            torch.cuda.synchronize()
+            tr.check()
+            step_ms = e0.elapsed_time(e1) / steps
+            final_loss = float(loss.item())       # (read now: the loop below sums the buffer, loss slot included, over and over)
+            # the collective alone: the same buffer, the same call, back to back on the launch stream
+            dist.barrier()
+            e0.record()
+            for _ in range(steps):
+                dist.all_reduce(tr.gradbuf, op=dist.ReduceOp.SUM)
+            e1.record()
+            torch.cuda.synchronize()
+            ar_ms = e0.elapsed_time(e1) / steps
+            t = torch.tensor([step_ms, ar_ms], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            step_ms, ar_ms = (float(v) for v in t.tolist())
+            payload = tr.gradbuf.numel() * 4
+            leg.update({"dp_step_ms": step_ms, "allreduce_ms": ar_ms, "allreduce_payload_bytes": payload,
+                        "allreduce_algbw_gbps": payload / (ar_ms * 1e-3) / 1e9,
+                        "dp_sequences_per_s": world * B / (step_ms * 1e-3), "final_loss": final_loss,
+                        "allreduce_share_of_step": ar_ms / step_ms})
+        except Exception as exc:      # the headline line must still print
+            leg["error"] = "%s: %s" % (type(exc).__name__, exc)
+        if dtype == "f32":
+            out.update(leg)            # (the keys earlier rounds' readers know)
+        else:
+            out["bf16"] = leg
+    out["note"] = ("step = forward + BPTT + all-reduce (issued at the end of the step, stream-ordered; FOV_DP_OVERLAP stays off: "
+                   "unvalidated against a real RCCL kernel) + Adam; allreduce_ms = the same collective alone, back to back; "
+                   "`bf16` = the same with bf16 matrix-core operands (configs[4])")
     return out
 
 
@@ -1071,11 +1081,13 @@ def main():
         import threading
         limit = int(os.environ.get("FOV_DP_PROBE_LIMIT_S", "150"))
 
-        def bail():
+        def bail():      # the headline line still prints (the timed region was complete), but the run FAILS: exit code 3
             if rank == 0 and result is not None:
-                result["extra"] = {"error": "data-parallel probe did not finish within %d s" % limit}
+                result["extra"] = {"error": "data-parallel probe did not finish within %d s (a collective hung?): exit code 3" % limit}
                 print(json.dumps(result), flush=True)
-            os._exit(0)
+            sys.stderr.write("bench.py: rank %d: data-parallel probe timed out after %d s\n" % (rank, limit))
+            sys.stderr.flush()
+            os._exit(3)
         timer = threading.Timer(limit, bail)
         timer.daemon = True
         timer.start()

@@ -119,7 +119,7 @@ __host__ __device__ inline ClusterLds cluster_lds(int H, int F, bool decode) {
     L.off_h = L.off_k + fp * 256 + 4 * KPAD * 256;
     L.off_x = L.off_h + BT * L.ldh;
     L.off_w = L.off_x + NXBUF * BT * L.ldx;
-    L.off_bd = L.off_w + (decode ? 2 * (H / 16) * 128 : 0);   // DECODE: the H/16 per-wave Dense partials of the tile (16 x 8 each, two floats per lane), two step parities
+    L.off_bd = L.off_w + (decode ? 2 * 4 * 128 : 0);   // DECODE: this workgroup's four per-wave Dense partials (16 x 8 each: two floats per lane), two step parities
     L.off_flag = L.off_bd + 8;
     L.total_floats = L.off_flag + 8 + 64;   // + tail pad for run-ahead reads of the x tile
     return L;
@@ -424,7 +424,7 @@ __device__ __forceinline__ void cluster_body(const LstmParams& p, ClusterCarry& 
     float* sK = smem + L.off_k;
     float* sH = smem + L.off_h;   // h tile, column = ((unit/64 - slice) mod G)*64 + unit%64 (own slice first)
     float* sX = smem + L.off_x;   // LAYER: three x tiles (t mod 3); DECODE: the y tile
-    float* sY = smem + L.off_w;   // DECODE: [step parity][partial = absolute wave of the tile][lane][2]: the Dense partials
+    float* sY = smem + L.off_w;   // DECODE: [step parity][wave][lane][2]: the four waves' Dense partials of this workgroup
     int* sFlag = (int*)(smem + L.off_flag);
     float* sKw = sK + wave * (nq * 4 + KPAD) * 256;  // this wave's K slice in B-operand order
 
@@ -514,13 +514,15 @@ __device__ __forceinline__ void cluster_body(const LstmParams& p, ClusterCarry& 
     for (int i = tid; i < NXBUF * BT * LDX; i += 256) sX[i] = 0.f;
 
     // DECODE: Dense(F_dec, tanh) runs on the matrix pipe, transposed: y^T = Wd^T . h^T, and is DISTRIBUTED (round 5): every wave
-    // forms the partial product over ITS OWN 16 units right behind the cell update (4 MFMAs on the h values it has just
-    // written to LDS) and publishes it next to its slice of h_t; y_t is the sum of the tile's H/16 partials, which arrive
-    // with the gather of h_t - no Dense section behind the gather, no barrier of its own (until round 4: 16 MFMAs per wave
-    // over a quarter of the gathered tile, four partials meeting in LDS behind a third barrier - 27 us of the decoder's 156).
+    // forms the partial product over ITS OWN 16 units (4 MFMAs on the columns it wrote to LDS) in the shadow of the gather of
+    // h_t, the four waves' partials meet in LDS at barrier 2, wave 0 publishes their sum - the workgroup's partial, 16 x 8
+    // values as tagged granules - and every wave fetches the G - 1 partner partials in the middle of the next step's
+    // partner-slice MFMAs: y_t is complete when those MFMAs are, nothing of the Dense sits between the gather and them and it
+    // has no barrier of its own.  (Until round 4: 16 MFMAs per wave over a quarter of the gathered tile right behind the
+    // gather, four partials meeting in LDS behind a third barrier.)
     // Lane (i = l&15, g4) keeps Wd[unit = col0 + 4*g4 + s][o(i)], o(i) = 4*(i&3) + (i>>2), as MFMA A operands (zero where
     // o(i) >= F_dec).  With that row order register r of the D fragment on lane (n, g4) is y[n][4r + g4]: registers 0, 1
-    // are what a lane publishes and, summed over the partials, the A operands of the two y . K MFMA steps (batch on the
+    // are what is published and, summed over the partials, the A operands of the two y . K MFMA steps (batch on the
     // lane, o = 4*g4 + r in the registers): y never leaves that layout.
     float wd[4];
     float bd4[4];
@@ -583,26 +585,24 @@ __device__ __forceinline__ void cluster_body(const LstmParams& p, ClusterCarry& 
         loff[j] = 2 * (within >> 6) * LDH + rot * 64 + (within & 63);
     }
 
-    // DECODE: the Dense partials travel like h - tagged granules in an area of their own behind the hello words, [group]
-    // [parity][partial = slice*4 + wave][lane] x 16 bytes {y[n][g4], epoch, y[n][4 + g4], epoch}; thread tid fetches what the
-    // thread of the same number published in each partner workgroup.
-    constexpr int NP = 4 * G;                 // partials per tile
-    constexpr int NYG = LAYER ? 0 : G - 1;    // 16-byte loads per thread per step for them
+    // DECODE: the workgroups' Dense partials travel like h - tagged granules in an area of their own behind the hello words,
+    // [group][parity][slice][lane] x 16 bytes {y[n][g4], epoch, y[n][4 + g4], epoch}; every lane of every wave fetches its own
+    // element of each workgroup's partial.
+    constexpr int NYG = (LAYER || G == 1) ? 0 : G;    // 16-byte loads per lane per step for them (its own workgroup's comes the same way)
     const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(
-        p.xch + (size_t)p.num_groups * 2 * BT * H + (size_t)p.num_groups * G + (size_t)group * 2 * NP * 128, 0,
-        LAYER ? 0 : 2 * NP * 128 * (int)sizeof(unsigned long long), 0x00020000);
-    const unsigned ypub_off = (unsigned)(((slice * 4 + wave) * 64 + lane) * 16);
-    const int ypub_lds = ((slice * 4 + wave) * 64 + lane) * 2;
-    unsigned ygoff[NYG > 0 ? NYG : 1];
-    int yloff[NYG > 0 ? NYG : 1];
-#pragma unroll
-    for (int j = 0; j < NYG; ++j) {
-        const int osl = (slice + j + 1) & (G - 1);
-        ygoff[j] = (unsigned)(((osl * 4 + wave) * 64 + lane) * 16);
-        yloff[j] = ((osl * 4 + wave) * 64 + lane) * 2;
-    }
-    constexpr unsigned YPAR_BYTES = NP * 64 * 16;   // one parity of the granule area
-    constexpr int YPAR_LDS = NP * 128;              // one parity of the LDS copy (floats)
+        p.xch + (size_t)p.num_groups * 2 * BT * H + (size_t)p.num_groups * G + (size_t)group * 2 * G * 128, 0,
+        LAYER ? 0 : 2 * G * 128 * (int)sizeof(unsigned long long), 0x00020000);
+    const unsigned ypub_off = (unsigned)((slice * 64 + lane) * 16);
+    const unsigned ygoff = (unsigned)(lane * 16);      // + q * 1024: the partial of slice q (an instruction immediate)
+    constexpr unsigned YPAR_BYTES = G * 64 * 16;   // one parity of the granule area
+    constexpr int YPAR_LDS = 4 * 128;              // one parity of the LDS partials (floats)
+    // y = tanh(sum of the G workgroup partials in absolute slice order + bias), each partial ((w0 + w1) + (w2 + w3)): every
+    // workgroup of the group forms the same y bit for bit
+    auto own_partial = [&](int par) -> f32x2 {
+        const float* yb = sY + par * YPAR_LDS + lane * 2;
+        const f32x2 a0 = *(const f32x2*)yb, a1 = *(const f32x2*)(yb + 128), a2 = *(const f32x2*)(yb + 256), a3 = *(const f32x2*)(yb + 384);
+        return (a0 + a1) + (a2 + a3);
+    };
 
     const bool h_zero = !F2 && p.h0 == nullptr;   // (the decoder phase of the fused kernel starts from the encoder's state)
     for (int tile = group; tile < p.num_tiles && !aborted; tile += p.num_groups) {
@@ -772,26 +772,49 @@ __device__ __forceinline__ void cluster_body(const LstmParams& p, ClusterCarry& 
             if (LAYER || t == 0) {
                 if (!((h_zero || F2) && t == 0)) recurrent<H, 4, NQ, true, true>(acc, hrow, wR);
             } else {
-                // DECODE: the tile's Dense partials of y_{t-1} are in LDS since barrier 2 of the previous step (own workgroup's
-                // written directly, the partners' by the gather); their reads are issued in front of these MFMAs, which do not
-                // need y, and summed behind them in a FIXED tree order (every workgroup of the group forms the same y, bit for
-                // bit); then y_{t-1} . K completes z_t
-                f32x2 part[NP];
-                {
-                    const float* yb = sY + ((t - 1) & 1) * YPAR_LDS + lane * 2;
+                // DECODE: y_{t-1}.  This workgroup's four wave partials are in LDS since barrier 2 of the previous step; the partners'
+                // partials were published right behind THEIR barrier 2, about when this step began - their loads go out half way
+                // through these MFMAs (which do not need y) and have the other half to land; then y_{t-1} . K completes z_t
+                constexpr int JM = 4 + (NQ - 4) / 2;
+                recurrent<H, 4, JM, true, false>(acc, hrow, wR);
+                u32x4g vy[NYG > 0 ? NYG : 1];
+                const unsigned yso = (epoch & 1u) * YPAR_BYTES;      // (the epoch is still the one h_{t-1} and y_{t-1} were tagged with)
 #pragma unroll
-                    for (int q = 0; q < NP; ++q) part[q] = *(const f32x2*)(yb + q * 128);
-                }
-                recurrent<H, 4, NQ, true, false>(acc, hrow, wR);
+                for (int q = 0; q < NYG; ++q) vy[q] = __builtin_amdgcn_raw_buffer_load_b128(yrs, ygoff, yso + (unsigned)(q * 1024), 16);
+                recurrent<H, JM, NQ, false, false>(acc, hrow, wR);
                 // the sums / tanh BEHIND the MFMA run, not sprinkled into it: a VALU instruction in an fp32-MFMA gap is never
                 // hidden and costs a pipeline turn-around on top (tools/microbench/mfma_f32_overlap.hip)
                 __builtin_amdgcn_sched_barrier(0);
+                f32x2 ysum;
+                if constexpr (NYG > 0) {
+                    unsigned spins = 0;
+                    while (true) {
+                        bool ok = true;
 #pragma unroll
-                for (int w2 = NP / 2; w2 >= 1; w2 >>= 1)
+                        for (int q = 0; q < NYG; ++q) ok = ok && (vy[q].y == epoch) && (vy[q].w == epoch);
+                        if (__all(ok)) break;
+                        if (++spins > SPIN_LIMIT || ((spins & 63u) == 0 && xch_poisoned(p.status))) {
+                            if (lane == 0) { xch_give_up(p.status); sFlag[0] = 1; }      // (seen by every wave behind this step's barrier 2)
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(1);
+                        asm volatile("" ::: "memory");
 #pragma unroll
-                    for (int q = 0; q < w2; ++q) part[q] += part[q + w2];
+                        for (int q = 0; q < NYG; ++q) vy[q] = __builtin_amdgcn_raw_buffer_load_b128(yrs, ygoff, yso + (unsigned)(q * 1024), 16);
+                    }
+                    f32x2 P[NYG];
 #pragma unroll
-                for (int ss = 0; ss < 2; ++ss) y4[ss] = tanh_f(part[0][ss] + bd4[ss]);
+                    for (int q = 0; q < NYG; ++q) P[q] = (f32x2){__uint_as_float(vy[q].x), __uint_as_float(vy[q].z)};
+#pragma unroll
+                    for (int w2 = NYG / 2; w2 >= 1; w2 >>= 1)
+#pragma unroll
+                        for (int q = 0; q < w2; ++q) P[q] += P[q + w2];
+                    ysum = P[0];
+                } else {
+                    ysum = own_partial((t - 1) & 1);
+                }
+#pragma unroll
+                for (int ss = 0; ss < 2; ++ss) y4[ss] = tanh_f(ysum[ss] + bd4[ss]);
                 // y_{t-1} leaves through a buffer store: lane offset computed once per tile, the step in the scalar offset
                 if (slice == 0 && wave == 0) {
 #pragma unroll
@@ -858,28 +881,6 @@ __device__ __forceinline__ void cluster_body(const LstmParams& p, ClusterCarry& 
             FOV_STAMP(3);
 #pragma unroll
             for (int r = 0; r < 4; ++r) sH[(4 * g4 + r) * LDH + wave * 16 + n] = hcur[r];
-            unsigned ysoff = 0;
-            if (!LAYER) {
-                // this wave's Dense partial over its own 16 units: the columns it has just written (same wave: LDS keeps its
-                // program order), as the B operand h^T of y^T = Wd^T . h^T
-                const f32x4 hb = *(const f32x4*)(hrow + 16 * wave);
-                f32x4 dacc[2];
-                dacc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                dacc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#ifndef FOV_DBG_NODENSE   // (timing experiment only, wrong results: the partial stays zero)
-#pragma unroll
-                for (int ss = 0; ss < 4; ++ss)
-                    mfma_f32<false>(dacc[ss & 1], wd[ss], hb[ss], mf_pos(true, true, ss < 2, ss == 3));
-#endif
-                const float y0 = dacc[0][0] + dacc[1][0], y1 = dacc[0][1] + dacc[1][1];
-                if (do_xch) {      // granule parity = the epoch's (as for h), LDS parity = the step's
-                    ysoff = (epoch & 1u) * YPAR_BYTES;
-                    const u32x4g yg = (u32x4g){__float_as_uint(y0), epoch, __float_as_uint(y1), epoch};
-                    if (same_xcd) __builtin_amdgcn_raw_buffer_store_b128(yg, yrs, ypub_off, ysoff, 1 /* sc0: stays in L2 */);
-                    else __builtin_amdgcn_raw_buffer_store_b128(yg, yrs, ypub_off, ysoff, 16 /* sc1: write-through */);
-                }
-                *(f32x2*)(sY + (t & 1) * YPAR_LDS + ypub_lds) = (f32x2){y0, y1};
-            }
             __syncthreads();  // barrier 1b: the own slice of h_t is visible to all four waves
             FOV_STAMP(4);
             const bool more = (t + 1 < steps);
@@ -894,7 +895,6 @@ __device__ __forceinline__ void cluster_body(const LstmParams& p, ClusterCarry& 
             }
             FOV_STAMP(5);
             u32x4g v[NG > 0 ? NG : 1];
-            u32x4g vy[NYG > 0 ? NYG : 1];   // DECODE: the partners' Dense partials, same sweep
             // DECODE has no x . K block between the publish and the gather: one own-slice k-block goes first, so the sweep is
             // not requested right behind the partners' publish (decoder 0.191 -> 0.188 ms over three paired runs; the
             // eight-workgroup kernels, whose stores are sc1, gain far more from the same delay - lstm_wide.hip)
@@ -905,8 +905,6 @@ __device__ __forceinline__ void cluster_body(const LstmParams& p, ClusterCarry& 
                 if (do_xch) {
 #pragma unroll
                     for (int j = 0; j < NG; ++j) v[j] = __builtin_amdgcn_raw_buffer_load_b128(xrs, goff[j], xsoff, 16);
-#pragma unroll
-                    for (int j = 0; j < NYG; ++j) vy[j] = __builtin_amdgcn_raw_buffer_load_b128(yrs, ygoff[j], ysoff, 16);
                 }
                 // (a ZX layer has no x . K run in front: this run opens; with partner slices the next reader of the accumulators is
                 // the partner-slice MFMA run: no closing wait states)
@@ -914,10 +912,22 @@ __device__ __forceinline__ void cluster_body(const LstmParams& p, ClusterCarry& 
             } else if (do_xch) {
 #pragma unroll
                 for (int j = 0; j < NG; ++j) v[j] = __builtin_amdgcn_raw_buffer_load_b128(xrs, goff[j], xsoff, 16);
-#pragma unroll
-                for (int j = 0; j < NYG; ++j) vy[j] = __builtin_amdgcn_raw_buffer_load_b128(yrs, ygoff[j], ysoff, 16);
             }
             FOV_STAMP(11);
+            if (!LAYER) {
+                // this wave's Dense partial over its own 16 units, in the shadow of the gather: the columns it wrote in front of
+                // barrier 1b as the B operand h^T of y^T = Wd^T . h^T; the four waves' partials meet in LDS at barrier 2
+                const f32x4 hb = *(const f32x4*)(hrow + 16 * wave);
+                f32x4 dacc[2];
+                dacc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                dacc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#ifndef FOV_DBG_NODENSE   // (timing experiment only, wrong results: the partial stays zero)
+#pragma unroll
+                for (int ss = 0; ss < 4; ++ss)
+                    mfma_f32<false>(dacc[ss & 1], wd[ss], hb[ss], mf_pos(true, true, ss < 2, ss == 3));
+#endif
+                *(f32x2*)(sY + (t & 1) * YPAR_LDS + wave * 128 + lane * 2) = (f32x2){dacc[0][0] + dacc[1][0], dacc[0][1] + dacc[1][1]};
+            }
             if (do_xch) {
                 // complete the gather: sweep again until every tag equals the epoch
                 unsigned spins = 0;
@@ -929,8 +939,6 @@ __device__ __forceinline__ void cluster_body(const LstmParams& p, ClusterCarry& 
                     bool ok = true;
 #pragma unroll
                     for (int j = 0; j < NG; ++j) ok = ok && (v[j].y == epoch) && (v[j].w == epoch);
-#pragma unroll
-                    for (int j = 0; j < NYG; ++j) ok = ok && (vy[j].y == epoch) && (vy[j].w == epoch);
                     if (__all(ok)) break;
                     ++spins;
                     if (spins > SPIN_LIMIT || ((spins & 63u) == 0 && xch_poisoned(p.status))) {
@@ -944,8 +952,6 @@ __device__ __forceinline__ void cluster_body(const LstmParams& p, ClusterCarry& 
                     asm volatile("" ::: "memory");   // the sweep below must really re-read memory
 #pragma unroll
                     for (int j = 0; j < NG; ++j) v[j] = __builtin_amdgcn_raw_buffer_load_b128(xrs, goff[j], xsoff, 16);
-#pragma unroll
-                    for (int j = 0; j < NYG; ++j) vy[j] = __builtin_amdgcn_raw_buffer_load_b128(yrs, ygoff[j], ysoff, 16);
                 }
 #ifdef FOV_STAMPS
                 if (stamp_on && t < STAMP_STEPS) g_stamps[MODE & 1][t][10] = spins;
@@ -955,30 +961,60 @@ __device__ __forceinline__ void cluster_body(const LstmParams& p, ClusterCarry& 
                     sH[loff[j]] = __uint_as_float(v[j].x);
                     sH[loff[j] + LDH] = __uint_as_float(v[j].z);
                 }
-#pragma unroll
-                for (int j = 0; j < NYG; ++j)
-                    *(f32x2*)(sY + (t & 1) * YPAR_LDS + yloff[j]) = (f32x2){__uint_as_float(vy[j].x), __uint_as_float(vy[j].z)};
             }
             FOV_STAMP(6);
             __syncthreads();  // barrier 2: the whole h_t tile is in LDS
             FOV_STAMP(7);
             if (G > 1 && sFlag[0]) { aborted = true; break; }
+            if (!LAYER && G > 1 && wave == 0) {      // the workgroup's Dense partial of y_t, tagged like h_t
+                const f32x2 mine = own_partial(t & 1);
+                const u32x4g yg = (u32x4g){__float_as_uint(mine[0]), epoch, __float_as_uint(mine[1]), epoch};
+                const unsigned yso = (epoch & 1u) * YPAR_BYTES;
+                if (same_xcd) __builtin_amdgcn_raw_buffer_store_b128(yg, yrs, ypub_off, yso, 1 /* sc0: stays in L2 */);
+                else __builtin_amdgcn_raw_buffer_store_b128(yg, yrs, ypub_off, yso, 16 /* sc1: write-through */);
+            }
         }
         if (!LAYER && steps > 0 && !aborted) {
-            // y of the last step: its partials arrived with the last gather (barrier 2 of the last step)
+            // y of the last step: the workgroups' partials were published behind the last barrier 2 - one wave of the tile waits for them
             if (slice == 0 && wave == 0) {
-                f32x2 part[NP];
-                const float* yb = sY + ((steps - 1) & 1) * YPAR_LDS + lane * 2;
+                f32x2 ysum;
+                bool got = true;
+                if constexpr (NYG > 0) {
+                    u32x4g vy[NYG];
+                    const unsigned yso = (epoch & 1u) * YPAR_BYTES;
+                    unsigned spins = 0;
+                    while (true) {
 #pragma unroll
-                for (int q = 0; q < NP; ++q) part[q] = *(const f32x2*)(yb + q * 128);
+                        for (int q = 0; q < NYG; ++q) vy[q] = __builtin_amdgcn_raw_buffer_load_b128(yrs, ygoff, yso + (unsigned)(q * 1024), 16);
+                        bool ok = true;
 #pragma unroll
-                for (int w2 = NP / 2; w2 >= 1; w2 >>= 1)
+                        for (int q = 0; q < NYG; ++q) ok = ok && (vy[q].y == epoch) && (vy[q].w == epoch);
+                        if (__all(ok)) break;
+                        if (++spins > SPIN_LIMIT || ((spins & 63u) == 0 && xch_poisoned(p.status))) {
+                            if (lane == 0) xch_give_up(p.status);
+                            got = false;
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(1);
+                        asm volatile("" ::: "memory");
+                    }
+                    f32x2 P[NYG];
 #pragma unroll
-                    for (int q = 0; q < w2; ++q) part[q] += part[q + w2];
+                    for (int q = 0; q < NYG; ++q) P[q] = (f32x2){__uint_as_float(vy[q].x), __uint_as_float(vy[q].z)};
 #pragma unroll
-                for (int ss = 0; ss < 2; ++ss)
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(tanh_f(part[0][ss] + bd4[ss])), yors, yoff[ss],
-                                                          (unsigned)((steps - 1) * p.F_dec * 4), 0);
+                    for (int w2 = NYG / 2; w2 >= 1; w2 >>= 1)
+#pragma unroll
+                        for (int q = 0; q < w2; ++q) P[q] += P[q + w2];
+                    ysum = P[0];
+                } else {
+                    ysum = own_partial((steps - 1) & 1);
+                }
+                if (got) {
+#pragma unroll
+                    for (int ss = 0; ss < 2; ++ss)
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(tanh_f(ysum[ss] + bd4[ss])), yors, yoff[ss],
+                                                              (unsigned)((steps - 1) * p.F_dec * 4), 0);
+                }
             }
         }
         if constexpr (F1) {
@@ -1099,7 +1135,7 @@ int cluster_num_groups(int B, int H) {
 
 static size_t cluster_xch_bytes(int B, int H) {
     const size_t groups = (size_t)cluster_num_groups(B, H);
-    const size_t b = (groups * 2 * BT * H + groups * (H / 64) + groups * 2 * (H / 16) * 128) * sizeof(unsigned long long);   // granules + hello + (decode) the Dense partials
+    const size_t b = (groups * 2 * BT * H + groups * (H / 64) + groups * 2 * (H / 64) * 128) * sizeof(unsigned long long);   // granules + hello + (decode) the workgroups' Dense partials
     return (b + 255) & ~(size_t)255;
 }
 

@@ -19,9 +19,9 @@ _lib.LIB_PATH = os.path.join(ROOT, "longterm360fov_amd", "lib", "libfov360_hip_s
 from longterm360fov_amd import ops  # noqa: E402
 from oracle import fov_oracle as O  # noqa: E402
 
-SEG = ["remote-slice h.R MFMAs (192)", "cell update + publish", "barrier 1", "own h -> LDS + barrier 1b",
-       "x(t+1).K MFMAs (96, encoder)", "gather issue + own-slice MFMAs (64) + wait", "barrier 2",
-       "dense + barrier 3 + y.K MFMAs"]
+SEG = ["remote-slice h.R MFMAs (192) [decoder: + sum of the Dense partials, tanh, y.K]", "cell update + publish", "(nothing)",
+       "own h -> LDS [decoder: + own Dense partial, 4 MFMAs, publish] + barrier 1b",
+       "x(t+1).K MFMAs (96, encoder)", "gather issue + own-slice MFMAs (64) + wait", "barrier 2"]
 
 
 def main():
@@ -38,7 +38,7 @@ def main():
     buf = np.zeros((2, 64, 12), dtype=np.uint64)
     L.fov_debug_read_stamps.argtypes = [ctypes.c_void_p]
     assert L.fov_debug_read_stamps(buf.ctypes.data_as(ctypes.c_void_p)) == 0
-    for mode, name, steps, nslot in ((0, "encoder (MODE_LAYER)", T_in, 8), (1, "decoder (MODE_DECODE)", T_out, 9)):
+    for mode, name, steps, nslot in ((0, "encoder (MODE_LAYER)", T_in, 8), (1, "decoder (MODE_DECODE)", T_out, 8)):
         st = buf[mode, :steps, :nslot].astype(np.int64)
         seg = np.diff(st, axis=1)                      # per step, per segment (shader cycles)
         step_total = np.diff(st[:, 0])                 # step start to next step start
