@@ -433,6 +433,7 @@ void env_reload() {
     g_env.no_cell_patch = env_flag("FOV_NO_CELL_PATCH");
     g_env.no_conv_patch = env_flag("FOV_NO_CONV_PATCH");
     g_env.no_wide16 = env_flag("FOV_NO_WIDE16");
+    g_env.pair = env_flag("FOV_PAIR");
     g_env.no_xcd_pad = getenv("FOV_NO_XCD_PAD") ? 1 : 0;
     { const char* pm = getenv("FOV_XCD_PAD_MAX"); g_env.xcd_pad_max = pm ? atoi(pm) : 16; }
     g_env.no_bwd16_narrow = getenv("FOV_NO_BWD16_NARROW") ? 1 : 0;
@@ -1304,6 +1305,10 @@ int fov_seq2seq_decode_fwd(const float* enc_in, const float* dec_in0, const floa
     // small batches (at most eight tiles): the tile spread over H / 16 workgroups instead of H / 64 (lstm_wide16.hip)
     if (impl == FOV_IMPL_AUTO && want_cluster(impl, F_enc, H, F_dec, true) && wide16_s2s_shape(B, F_enc, F_dec, H) && T_out > 0)
         return launch_wide16_s2s(p, s);
+    // batches of 33 .. 64 tiles at H = 256 (the metric's 1024 sequences): two tiles per group of eight workgroups, each tile's
+    // exchange under the other tile's MFMAs (lstm_pair.hip)
+    if (impl == FOV_IMPL_AUTO && want_cluster(impl, F_enc, H, F_dec, true) && pair_s2s_shape(B, T_in, T_out, F_enc, F_dec, H))
+        return launch_pair_s2s(p, s);
     if (want_cluster(impl, F_enc, H, F_dec, true)) return launch_cluster(p, true, s);
     return launch_generic(p, true, s);
 }

@@ -69,6 +69,8 @@ int launch_generic(const LstmParams& p, bool decode, hipStream_t stream);
 long generic_launch_count();   // launches of the generic (VALU) LSTM kernel so far in this process (diagnostic)
 bool wide16_s2s_shape(int B, int F_enc, int F_dec, int H);   // lstm_wide16.hip: encoder + free-running decoder, small batches
 int launch_wide16_s2s(const LstmParams& p, hipStream_t stream);
+bool pair_s2s_shape(int B, int T_in, int T_out, int F_enc, int F_dec, int H);   // lstm_pair.hip: H = 256, two tiles per group of eight workgroups
+int launch_pair_s2s(const LstmParams& p, hipStream_t stream);
 int launch_cluster(const LstmParams& p, bool decode, hipStream_t stream);
 int launch_cluster_decoder(const LstmParams& p, hipStream_t stream);   // MODE_DECODE alone, from (p.h0, p.c0)
 bool cluster_shape_ok(int F, int H);
@@ -80,6 +82,7 @@ struct EnvKnobs {
     int force_safe_exchange, two_launches, resident_limit;
     int bwd_stepped, no_wgrad_fusion, no_dx_fusion, bwd_groups4, gemm_bf16_split, gemm_bf16_noremap, gemm_bf16_shallow, no_wgrad_group, dbg_trace, no_wide16_trio;   // experiment switches (tools/)
     int gemm_variant, gemm_split;   // FOV_GEMM_VARIANT / FOV_GEMM_SPLIT: tile shape / K slices of the fp32 GEMM forced (experiments)
+    int pair;            // FOV_PAIR=1: the fused seq2seq call takes the tile-pair kernel (lstm_pair.hip) at 33 .. 64 tiles, H = 256 (an experiment that lost: off by default)
     int no_wide16;       // FOV_NO_WIDE16=1: width-512 layers stay on the 16-workgroup form (tests / A-B timing)
     int no_cell_patch;   // FOV_NO_CELL_PATCH=1: ConvLSTM2D steps stay on the implicit-GEMM cell (tests compare the two forms)
     int no_conv_patch;   // FOV_NO_CONV_PATCH=1: Conv2D layers stay on the tap-gathering implicit GEMM (tests / A-B timing; conv_patch.hip)

@@ -52,7 +52,7 @@ def _stream():
 
 _ENV_KNOBS = ("FOV_FORCE_SAFE_EXCHANGE", "FOV_TWO_LAUNCHES", "FOV_DBG_RESIDENT_LIMIT", "FOV_NO_CELL_PATCH", "FOV_NO_CONV_PATCH", "FOV_NO_WIDE16", "FOV_BWD_STEPPED",
               "FOV_NO_WGRAD_FUSION", "FOV_NO_DX_FUSION", "FOV_BWD_GROUPS4", "FOV_GEMM_BF16_NOREMAP", "FOV_GEMM_BF16_SPLIT", "FOV_GEMM_BF16_SHALLOW", "FOV_NO_WGRAD_GROUP", "FOV_NO_WIDE16_TRIO", "FOV_DBG_TRACE", "FOV_GEMM_VARIANT",
-              "FOV_GEMM_SPLIT", "FOV_NO_XCD_PAD", "FOV_XCD_PAD_MAX", "FOV_NO_BWD16_NARROW", "FOV_BWD16_GROUPS", "FOV_NO_STACK2")
+              "FOV_GEMM_SPLIT", "FOV_NO_XCD_PAD", "FOV_XCD_PAD_MAX", "FOV_NO_BWD16_NARROW", "FOV_BWD16_GROUPS", "FOV_NO_STACK2", "FOV_PAIR")
 _env_seen = None
 # os.environ.get costs 0.7 us per key (encode, lookup, decode): 9 us for the knob list, paid at every workspace / scratch
 # fetch - 0.15 ms of a 0.3 ms training step at batch 32.  The mapping underneath (bytes -> bytes on POSIX) answers the
@@ -172,8 +172,9 @@ def dense(x, W, b, activation="tanh", out=None):
 _W_ORDER = ("enc_K", "enc_R", "enc_b", "dec_K", "dec_R", "dec_b", "dense_W", "dense_b")
 
 
-def seq2seq_decode(enc_in, dec_in0, w, T_out, act="sigmoid", impl="auto", workspace=None, out=None):
-    """Fused encoder + autoregressive decoder (FoV_seq2seq.py:154-178, batched) -> (B,T_out,F_dec)."""
+def seq2seq_decode(enc_in, dec_in0, w, T_out, act="sigmoid", impl="auto", workspace=None, out=None, hT=None, cT=None):
+    """Fused encoder + autoregressive decoder (FoV_seq2seq.py:154-178, batched) -> (B,T_out,F_dec); hT / cT (B,H): the decoder's
+    final state, if wanted."""
     enc_in, dec_in0 = _dev(enc_in, "enc_in"), _dev(dec_in0, "dec_in0")
     ws_t = [_dev(w[k], k) for k in _W_ORDER]
     B, T_in, F_enc = enc_in.shape
@@ -186,7 +187,8 @@ def seq2seq_decode(enc_in, dec_in0, w, T_out, act="sigmoid", impl="auto", worksp
     impl = impl_code(impl)
     ws = (workspace or default_workspace(enc_in.device))
     buf = ws.get(L.fov_seq2seq_decode_workspace_bytes(B, T_in, T_out, F_enc, F_dec, H, impl), enc_in.device)
-    check(L.fov_seq2seq_decode_fwd(_ptr(enc_in), _ptr(dec_in0), *[_ptr(t) for t in ws_t], _ptr(out), None, None,
+    check(L.fov_seq2seq_decode_fwd(_ptr(enc_in), _ptr(dec_in0), *[_ptr(t) for t in ws_t], _ptr(out),
+                                   None if hT is None else _ptr(_dev(hT, "hT")), None if cT is None else _ptr(_dev(cT, "cT")),
                                    B, T_in, T_out, F_enc, F_dec, H, act_code(act), impl,
                                    buf.data_ptr(), buf.numel(), _stream()))
     return out

@@ -898,3 +898,48 @@ def test_ragged_batches_take_the_exchange_path_of_aligned_ones():
         lm[B] = ws.exchange_mode()
     print("bf16 layer: exchange modes", lm)
     assert lm[100] == lm[128] and lm[17] == lm[128]
+
+
+@pytest.mark.parametrize("B,T_in,T_out,F_enc,F_dec,act", [(1024, 30, 30, 90, 6, "sigmoid"), (530, 3, 4, 90, 6, "hard_sigmoid"), (1000, 2, 1, 33, 8, "sigmoid"),
+                                                          (513, 1, 3, 96, 1, "sigmoid"), (784, 5, 2, 7, 3, "hard_sigmoid")])
+def test_tile_pair_kernel_matches_oracle_and_the_four_workgroup_kernel(B, T_in, T_out, F_enc, F_dec, act):
+    """lstm_pair.hip (round 5, FOV_PAIR=1: an experiment that did not beat the four-workgroup kernel and stays off by default): the
+    fused seq2seq call at 33 .. 64 tiles, H = 256, on groups of eight workgroups that carry TWO tiles each (one tile's exchange
+    under the other's MFMAs).  Against the C / fp64 oracles (1e-3 relative with the 2e-5 floor) and against the four-workgroup
+    kernel (same arithmetic, another summation order); odd tile counts (the last group's second tile is absent), ragged last tiles, one-step phases,
+    narrow and full-width inputs, final states, repeated launches on one workspace."""
+    ops = _ops()
+    from longterm360fov_amd import _lib
+    H = 256
+    assert _lib.lib().fov_version() >= 100
+    w = O.init_seq2seq(900 + B, F_enc, F_dec, H, bias_noise=0.05)
+    rng = np.random.default_rng(901 + B)
+    enc = rng.uniform(-1, 1, (B, T_in, F_enc)).astype(np.float32)
+    dec0 = rng.uniform(-1, 1, (B, 1, F_dec)).astype(np.float32)
+    dw = devw(w)
+    ws = ops.Workspace()
+    hT, cT = (torch.empty((B, H), dtype=torch.float32, device="cuda") for _ in range(2))
+    hT4, cT4 = (torch.empty((B, H), dtype=torch.float32, device="cuda") for _ in range(2))
+    four = ops.seq2seq_decode(dev(enc), dev(dec0), dw, T_out, act=act, workspace=ws, hT=hT4, cT=cT4).clone()
+    ws.check()
+    os.environ["FOV_PAIR"] = "1"
+    try:
+        out = ops.seq2seq_decode(dev(enc), dev(dec0), dw, T_out, act=act, workspace=ws, hT=hT, cT=cT).clone()
+        ws.check()
+        again = ops.seq2seq_decode(dev(enc), dev(dec0), dw, T_out, act=act, workspace=ws)
+        ws.check()
+        perm = np.random.default_rng(3).permutation(B)
+        outp = ops.seq2seq_decode(dev(enc[perm]), dev(dec0[perm]), dw, T_out, act=act, workspace=ws)
+        ws.check()
+    finally:
+        del os.environ["FOV_PAIR"]
+    assert torch.equal(again, out)
+    assert torch.equal(outp, out[perm])         # a sequence does not see its tile-mates
+    d = (out - four).abs().max().item()
+    print("tile-pair vs four-workgroup kernel B=%d: max |diff| %.3e (state %.3e)" % (B, d, (hT - hT4).abs().max().item()))
+    assert 0 < d <= 5e-6, d                     # (not bit-identical: the pair kernel really ran)
+    assert (hT - hT4).abs().max().item() <= 5e-6 and (cT - cT4).abs().max().item() <= 2e-5
+    n = min(B, 96)
+    idx = np.r_[0:n // 2, B - n // 2:B]         # first and last sequences (the ragged / absent tile end)
+    ref = O.seq2seq_decode(enc[idx].astype(np.float64), dec0[idx].astype(np.float64), f64(w), T_out, act=act)
+    assert_parity(out[idx], ref, "tile-pair kernel B=%d" % B)
