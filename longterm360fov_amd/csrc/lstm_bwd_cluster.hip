@@ -173,10 +173,6 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_cluster_kernel(BwdParams p) {
                 dc[r] = live[r] ? dcv * fg : 0.f;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) dbacc[g] += dzv[g][r];
-                if (live[r]) {
-                    float* zp = p.dz + ((size_t)(b0 + 4 * g4 + r) * p.T + t) * 4 * H + unit;
-                    zp[0] = dzv[0][r]; zp[H] = dzv[1][r]; zp[2 * H] = dzv[2][r]; zp[3 * H] = dzv[3][r];
-                }
 #pragma unroll
                 for (int g = 0; g < 4; ++g) sZ[(4 * g4 + r) * LDZ + g * 64 + wave * 16 + n] = dzv[g][r];
             }
@@ -241,6 +237,16 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_cluster_kernel(BwdParams p) {
                         else __builtin_amdgcn_raw_buffer_store_b128(gr, xrs, (unsigned)((d * G + slice) * CHUNK) * 8u + lane_off + r * 1024u, xsoff, 16);
                     }
                 }
+            }
+            // dz of the step leaves for the weight-gradient products FROM THE LDS TILE, as 16-byte pieces: a wave instruction covers one
+            // sequence's four gate runs of 64 units (4 x 256 contiguous bytes: whole cache lines).  Stored from the registers - one
+            // dword per lane, 16 lanes per run of 64 bytes, 16 instructions per step - the kernel wrote 613 MB for a 252 MB tape
+            // (profiles/r04_pmcstep_train_f32.txt: every line written in two halves by two waves).
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int row = wave + 4 * k, gate = lane >> 4, c4 = lane & 15;
+                const f32x4 zq = *(const f32x4*)(sZ + row * LDZ + gate * 64 + 4 * c4);
+                if (b0 + row < p.B) *(f32x4*)(p.dz + ((size_t)(b0 + row) * p.T + t) * 4 * H + gate * H + slice * 64 + 4 * c4) = zq;
             }
             __syncthreads();   // barrier B: every wave is done with the dz tile
             if (G > 1) {
