@@ -82,6 +82,9 @@ SIGNATURES = {
     "fov_gmm3d_sample": (_I, [_P, _P, _P, _P, ctypes.c_int64, _I, _I, _I, _P]),
     "fov_gauss_nll_grad": (_I, [_P] * 6 + [_I] * 3 + [ctypes.c_float, _P, _SZ, _P]),
     "fov_rmsprop_tf_step": (_I, [_P] * 3 + [ctypes.c_int64] + [ctypes.c_float] * 4 + [_P]),
+    "fov_dense_mse_head_supported": (_I, [ctypes.c_int64, _I, _I]),
+    "fov_dense_mse_head_workspace_bytes": (_SZ, [ctypes.c_int64, _I, _I]),
+    "fov_dense_mse_head": (_I, [_P] * 9 + [ctypes.c_int64, _I, _I, _I, ctypes.c_float, _P, _SZ, _P]),
     "fov_rmsprop_tf_step_guarded": (_I, [_P] * 3 + [ctypes.c_int64] + [ctypes.c_float] * 4 + [_P] * 5),
     "fov_categorical_crossentropy_grad": (_I, [_P] * 4 + [ctypes.c_int64, _I, _P, _SZ, _P]),
     "fov_xyz_sum1_grad": (_I, [_P] * 3 + [ctypes.c_int64, _I, _P, _SZ, _P]),

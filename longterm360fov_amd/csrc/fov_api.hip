@@ -918,6 +918,22 @@ int fov_mse_dense_grad_db(const float* y, const float* target, float* dpre, floa
                             (hipStream_t)stream, db, O);
 }
 
+int fov_dense_mse_head_supported(int64_t N, int H, int O) { return dense_mse_head_shape_ok((long)N, H, O) ? 1 : 0; }
+size_t fov_dense_mse_head_workspace_bytes(int64_t N, int H, int O) { return sizeof(float) * dense_mse_head_scratch_floats((long)N, H, O); }
+int fov_dense_mse_head(const float* hs, const float* W, const float* b, const float* target, float* y, float* dX, float* dW, float* db,
+                       float* loss, int64_t N, int H, int O, int activation, float weight, void* workspace, size_t workspace_bytes,
+                       fov_stream_t stream) {
+    if (N < 0 || H <= 0 || O <= 0 || (N > 0 && (!hs || !W || !b || !target || !dW || !db)) || (activation != 0 && activation != 1)) {
+        set_error("fov_dense_mse_head: invalid argument");
+        return FOV_ERR_INVALID;
+    }
+    if (N == 0) return FOV_OK;
+    int rc = check_ws(workspace, workspace_bytes, fov_dense_mse_head_workspace_bytes(N, H, O));
+    if (rc) return rc;
+    return dense_mse_head(hs, W, b, target, y, dX, dW, db, loss, (long)N, H, O, activation, weight, (float*)workspace,
+                          workspace_bytes / sizeof(float), (hipStream_t)stream);
+}
+
 int fov_scale(float* x, int64_t n, float s, fov_stream_t stream) {
     if (n < 0 || (n > 0 && !x)) { set_error("fov_scale: invalid argument"); return FOV_ERR_INVALID; }
     return scale_inplace(x, (long)n, s, (hipStream_t)stream);

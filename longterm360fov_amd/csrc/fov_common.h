@@ -258,6 +258,10 @@ int dense_bwd(const float* x, const float* W, const float* dpre, float* dx, floa
               int accumulate, float* scratch, size_t scratch_floats, hipStream_t stream, int bf16 = 0);
 int mse_dense_grad(const float* y, const float* target, float* dpre, float* loss, long n, int activation, float* scratch,
                    size_t scratch_floats, hipStream_t stream);
+bool dense_mse_head_shape_ok(long N, int H, int O);
+size_t dense_mse_head_scratch_floats(long N, int H, int O);
+int dense_mse_head(const float* hs, const float* W, const float* b, const float* target, float* y, float* dX, float* dW, float* db,
+                   float* loss, long N, int H, int O, int activation, float weight, float* scratch, size_t scratch_floats, hipStream_t stream);
 int mse_dense_grad_w(const float* y, const float* target, float* dpre, float* loss, long n, int activation, float weight,
                      int tmB, int tmT, int O, float* scratch, size_t scratch_floats, hipStream_t stream, float* db = nullptr, int dbO = 0);
 int scale_inplace(float* x, long n, float s, hipStream_t stream);

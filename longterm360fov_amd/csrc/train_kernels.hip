@@ -1047,6 +1047,149 @@ __global__ __launch_bounds__(256) void cce_grad_kernel(const float* __restrict__
     if (threadIdx.x == 0) part[blockIdx.x] = red[0];
 }
 
+// ---------------------------------------------------------------------------------------
+// Dense(O, tanh | linear) head + Keras mean_squared_error, FORWARD AND BACKWARD IN ONE LAUNCH (round 5) - what model.fit runs
+// around the decoder's hidden sequence in mycode/FoV_seq2seq.py:96-103: y = act(hs . W + b), loss = w mean (y - target)^2,
+// dpre = dloss/d(pre-activation), dX = dpre . W^T (into the decoder's BPTT), dW = hs^T . dpre, db = column sums of dpre.
+// At the reference's batch (32 x 10 = 320 rows, H = 128, O = 6) these were five launches of 4-8 us each - the Dense forward,
+// the loss kernel, two GEMMs and a column sum - for 0.5 MFLOP: a sixth of the training step.  A block takes 64 rows: the hs
+// tile and W sit in LDS, four lanes share a row's dot products, dX rows leave as whole 16-byte-per-lane lines, the block's
+// partial dW / db / squared-error sum go to scratch and the block that takes the last ticket adds the partials IN BLOCK ORDER
+// (deterministic).  Rows <= 4096 (64 blocks); larger heads keep the separate launches, which are <= 1 % of their step.
+// ---------------------------------------------------------------------------------------
+constexpr int HD_RB = 64;        // rows per block
+constexpr int HD_MAXB = 64;      // blocks per launch at most
+__host__ __device__ inline size_t dense_mse_head_lds_floats(int H) { return (size_t)HD_RB * (H + 4) + (size_t)H * 8 + HD_RB * 8 + 16; }
+__global__ __launch_bounds__(256) void dense_mse_head_kernel(const float* __restrict__ hs, const float* __restrict__ W, const float* __restrict__ bias,
+                                                             const float* __restrict__ target, float* __restrict__ y_out, float* __restrict__ dX,
+                                                             float* __restrict__ part, float* __restrict__ dW, float* __restrict__ db,
+                                                             float* __restrict__ loss, int N, int H, int O, int activation, float scale,
+                                                             unsigned* __restrict__ ticket) {
+    extern __shared__ __attribute__((aligned(16))) float hd_sm[];
+    const int LDH = H + 4;
+    float* sHs = hd_sm;                       // [64][H + 4]
+    float* sWt = sHs + HD_RB * LDH;           // [H][8] (columns >= O zero)
+    float* sD = sWt + H * 8;                  // dpre [64][8] (rows >= N, columns >= O zero)
+    float* sRed = sD + HD_RB * 8;             // 4 wave sums of the squared error
+    __shared__ int is_last;
+    const int tid = threadIdx.x;
+    const int r0 = blockIdx.x * HD_RB;
+    const int C4 = H >> 2;                    // 16-byte pieces per row
+    // ---- stage the hs tile (rows past N: zero) and W ----
+    for (int i = tid; i < HD_RB * C4; i += 256) {
+        const int r = i / C4, c4 = i - r * C4;
+        f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (r0 + r < N) v = *(const f32x4*)(hs + (size_t)(r0 + r) * H + 4 * c4);
+        *(f32x4*)(sHs + r * LDH + 4 * c4) = v;
+    }
+    for (int i = tid; i < H * 8; i += 256) {
+        const int k = i >> 3, o = i & 7;
+        sWt[i] = o < O ? W[(size_t)k * O + o] : 0.f;
+    }
+    __syncthreads();
+    // ---- forward + loss gradient: lanes 4r .. 4r+3 share row r (k = 4j + q: the four read neighbouring words) ----
+    const int r = tid >> 2, q = tid & 3;
+    float acc[8];
+#pragma unroll
+    for (int o = 0; o < 8; ++o) acc[o] = 0.f;
+    for (int j = 0; j < C4; ++j) {
+        const int k = 4 * j + q;
+        const float h = sHs[r * LDH + k];
+        const f32x4 w0 = *(const f32x4*)(sWt + k * 8), w1 = *(const f32x4*)(sWt + k * 8 + 4);
+#pragma unroll
+        for (int o = 0; o < 4; ++o) { acc[o] = fmaf(h, w0[o], acc[o]); acc[4 + o] = fmaf(h, w1[o], acc[4 + o]); }
+    }
+#pragma unroll
+    for (int o = 0; o < 8; ++o) {
+        acc[o] += __shfl_xor(acc[o], 1);
+        acc[o] += __shfl_xor(acc[o], 2);
+    }
+    float sq = 0.f;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {    // lane q owns the outputs q and q + 4
+        const int o = q + 4 * half;
+        float g = 0.f;
+        if (o < O && r0 + r < N) {
+            const float lo = q == 0 ? acc[0] : (q == 1 ? acc[1] : (q == 2 ? acc[2] : acc[3]));      // (register arrays take no lane-dependent index)
+            const float hi2 = q == 0 ? acc[4] : (q == 1 ? acc[5] : (q == 2 ? acc[6] : acc[7]));
+            const float pre = (half ? hi2 : lo) + bias[o];
+            const float yv = activation == 1 ? tanh_f(pre) : pre;
+            const size_t e = (size_t)(r0 + r) * O + o;
+            if (y_out) y_out[e] = yv;
+            const float d = yv - target[e];
+            sq += d * d;
+            g = 2.f * d * scale;
+            if (activation == 1) g *= (1.f - yv * yv);
+        }
+        sD[r * 8 + o] = g;
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) sq += __shfl_xor(sq, m);
+    if ((tid & 63) == 0) sRed[tid >> 6] = sq;
+    __syncthreads();
+    // ---- dX = dpre . W^T: a thread keeps its four k rows of W, a wave instruction writes whole rows ----
+    if (dX) {
+        const int c4 = tid % C4, rsub = tid / C4, rstep = 256 / C4;      // (H <= 512: C4 <= 128, at least two rows per pass)
+        if (rsub < rstep) {
+            float wk[4][8];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const f32x4 w0 = *(const f32x4*)(sWt + (4 * c4 + i) * 8), w1 = *(const f32x4*)(sWt + (4 * c4 + i) * 8 + 4);
+#pragma unroll
+                for (int o = 0; o < 4; ++o) { wk[i][o] = w0[o]; wk[i][4 + o] = w1[o]; }
+            }
+            for (int rr = rsub; rr < HD_RB && r0 + rr < N; rr += rstep) {
+                const f32x4 g0 = *(const f32x4*)(sD + rr * 8), g1 = *(const f32x4*)(sD + rr * 8 + 4);
+                f32x4 out;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float a = 0.f;
+#pragma unroll
+                    for (int o = 0; o < 4; ++o) a = fmaf(g0[o], wk[i][o], fmaf(g1[o], wk[i][4 + o], a));
+                    out[i] = a;
+                }
+                *(f32x4*)(dX + (size_t)(r0 + rr) * H + 4 * c4) = out;
+            }
+        }
+    }
+    // ---- the block's partial dW[k][o] = sum_r hs[r][k] dpre[r][o], db[o] = sum_r dpre[r][o], squared error ----
+    const int NE = H * O + O + 1;
+    float* mypart = part + (size_t)blockIdx.x * NE;
+    for (int k = tid; k < H; k += 256) {
+        float a[8];
+#pragma unroll
+        for (int o = 0; o < 8; ++o) a[o] = 0.f;
+        for (int rr = 0; rr < HD_RB; ++rr) {
+            const float h = sHs[rr * LDH + k];
+            const f32x4 g0 = *(const f32x4*)(sD + rr * 8), g1 = *(const f32x4*)(sD + rr * 8 + 4);
+#pragma unroll
+            for (int o = 0; o < 4; ++o) { a[o] = fmaf(h, g0[o], a[o]); a[4 + o] = fmaf(h, g1[o], a[4 + o]); }
+        }
+        for (int o = 0; o < O; ++o) mypart[(size_t)k * O + o] = a[o];
+    }
+    if (tid < O) {
+        float a = 0.f;
+        for (int rr = 0; rr < HD_RB; ++rr) a += sD[rr * 8 + tid];
+        mypart[(size_t)H * O + tid] = a;
+    }
+    if (tid == 0) mypart[NE - 1] = (sRed[0] + sRed[1]) + (sRed[2] + sRed[3]);
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) is_last = atomicAdd(ticket, 1u) == gridDim.x - 1u;
+    __syncthreads();
+    if (is_last) {
+        __threadfence();
+        for (int e = tid; e < NE; e += 256) {
+            float a = 0.f;
+            for (unsigned blk = 0; blk < gridDim.x; ++blk) a += __hip_atomic_load(part + (size_t)blk * NE + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (e < H * O) dW[e] = a;
+            else if (e < H * O + O) db[e - H * O] = a;
+            else if (loss) loss[0] = a * scale;
+        }
+        if (tid == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the slot is this stream's again
+    }
+}
+
 // tf.train.RMSPropOptimizer (TF 1.x, momentum 0, not centered; mycode/lstm.py:556-567) with the script's optional
 // clip_by_value(grad, -clip, clip):  ms = decay*ms + (1-decay) g^2;  p -= lr * g / sqrt(ms + eps).  (eps INSIDE the
 // root, ms initialised to ONE - both unlike Keras RMSprop.)
@@ -1998,6 +2141,29 @@ int mse_dense_grad_w(const float* y, const float* target, float* dpre, float* lo
         rc = check_launch("sum_scale");
     }
     return rc;
+}
+
+bool dense_mse_head_shape_ok(long N, int H, int O) {
+    return N >= 1 && N <= (long)HD_RB * HD_MAXB && H >= 4 && H <= 512 && (H & 3) == 0 && O >= 1 && O <= 8;
+}
+size_t dense_mse_head_scratch_floats(long N, int H, int O) { return (size_t)((N + HD_RB - 1) / HD_RB) * ((size_t)H * O + O + 1) + 64; }
+// weight: this rank's share of the global batch (data parallelism), 1 otherwise; loss = weight * mean over all N * O elements
+int dense_mse_head(const float* hs, const float* W, const float* b, const float* target, float* y, float* dX, float* dW, float* db,
+                   float* loss, long N, int H, int O, int activation, float weight, float* scratch, size_t scratch_floats, hipStream_t stream) {
+    if (!dense_mse_head_shape_ok(N, H, O)) { set_error("dense_mse_head: rows <= 4096, H <= 512 (a multiple of 4), O <= 8 only"); return FOV_ERR_UNSUPPORTED; }
+    if (dense_mse_head_scratch_floats(N, H, O) > scratch_floats) { set_error("dense_mse_head: scratch too small"); return FOV_ERR_WORKSPACE; }
+    unsigned* ticket = loss_ticket_of(stream);
+    if (!ticket) { set_error("dense_mse_head: no ticket slot left for this stream (more than 64 streams on the device)"); return FOV_ERR_UNSUPPORTED; }
+    int rc = defer_touch(dW, (size_t)H * O, stream);     // pending deferred reductions over the gradients written here go first
+    if (!rc) rc = defer_touch(db, (size_t)O, stream);
+    if (rc) return rc;
+    const size_t lds = dense_mse_head_lds_floats(H) * sizeof(float);
+    rc = ensure_dynamic_lds((const void*)dense_mse_head_kernel, lds);
+    if (rc) return rc;
+    const int blocks = (int)((N + HD_RB - 1) / HD_RB);
+    hipLaunchKernelGGL(dense_mse_head_kernel, dim3((unsigned)blocks), dim3(256), lds, stream, hs, W, b, target, y, dX, scratch, dW, db, loss,
+                       (int)N, H, O, activation, weight / (float)(N * O), ticket);
+    return check_launch("dense_mse_head");
 }
 
 int scale_inplace(float* x, long n, float s, hipStream_t stream) {

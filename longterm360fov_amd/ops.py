@@ -452,9 +452,12 @@ def lstm_seq_wgrad(x, hs, dz, dK=None, dR=None, db=None, h0=None, accumulate=Fal
 
 
 def _destroy_stream(handle):
+    import sys
+    if sys.is_finalizing():      # interpreter shutdown: the HIP runtime may be gone before this runs, and the process ends anyway
+        return
     try:
         _lib.lib().fov_stream_destroy(_ct.c_void_p(handle))
-    except Exception:      # interpreter shutdown: the library may be gone already
+    except Exception:
         pass
 
 
@@ -701,6 +704,33 @@ def sample_refeed_bwd(dx, var, noise, dmu, dvar, std="sqrt", planar=False, accum
     check(_lib.lib().fov_sample_refeed_bwd(ptr, ld, _ptr(var), _ptr(noise), _ptr(_dev(dmu, "dmu")), _ptr(_dev(dvar, "dvar")), B,
                                            n // 3, 0 if std == "sqrt" else 1, 1 if planar else 0, 1 if accumulate else 0, _stream()))
     return dmu, dvar
+
+
+def dense_mse_head_supported(N, H, O):
+    return bool(_lib.lib().fov_dense_mse_head_supported(int(N), int(H), int(O)))
+
+
+def dense_mse_head(hs, W, b, target, activation="tanh", dW=None, db=None, loss=None, weight=1.0, need_dx=True, need_y=True, scratch=None,
+                   dx=None, y=None):
+    """Dense(O, activation) + Keras mean_squared_error over the rows of hs (..., H), forward AND backward in one launch (rows <= 4096,
+    O <= 8: dense_mse_head_supported) -> (y like target or None, dX like hs or None, loss (1,)); dW (H,O), db (O) are written in
+    place (they may be views of a flat gradient buffer)."""
+    hs, W, b, target = _dev(hs, "hs"), _dev(W, "W"), _dev(b, "b"), _dev(target, "target")
+    H, O = W.shape
+    N = hs.numel() // H
+    assert target.numel() == N * O and dW is not None and db is not None
+    if need_y and y is None:
+        y = torch.empty(target.shape, dtype=torch.float32, device=hs.device)
+    if need_dx and dx is None:
+        dx = torch.empty(hs.shape, dtype=torch.float32, device=hs.device)
+    if loss is None:
+        loss = torch.empty(1, dtype=torch.float32, device=hs.device)
+    L = _lib.lib()
+    buf = (scratch or _default_scratch).get(L.fov_dense_mse_head_workspace_bytes(N, H, O), hs.device)
+    check(L.fov_dense_mse_head(_ptr(hs), _ptr(W), _ptr(b), _ptr(target), None if y is None else _ptr(y), None if dx is None else _ptr(dx),
+                               _ptr(_dev(dW, "dW")), _ptr(_dev(db, "db")), _ptr(loss), N, H, O, 1 if activation == "tanh" else 0, float(weight),
+                               buf.data_ptr(), buf.numel(), _stream()))
+    return y, dx, loss
 
 
 def rmsprop_tf_step(params, grads, ms, lr, decay=0.9, eps=1e-10, clip_value=0.0, guards=None, applied=None):

@@ -362,7 +362,7 @@ class Seq2SeqTrainer(FlatParamTrainer):
                 "enc": (e(B, T_in, H), e(B, H), e(B, H), e(B, T_in, 5, H)),
                 "dec": (e(B, T_out, H), e(B, H), e(B, H), e(B, T_out, 5, H)),
                 "dz_enc": e(B, T_in, 4 * H), "dz_dec": e(B, T_out, 4 * H),
-                "dpre": e(B, T_out, O),
+                "dpre": e(B, T_out, O), "y": e(B, T_out, O), "d_hs": e(B, T_out, H),
             }
         return self._bufs[key]
 
@@ -377,13 +377,18 @@ class Seq2SeqTrainer(FlatParamTrainer):
                                                  workspace=self.ws, out=bufs["enc"])
         dhs_, _, _, dres = ops.lstm_seq_train(dec_in, w["dec_K"], w["dec_R"], w["dec_b"], ehT, ecT, act=self.act,
                                               impl=self.impl, workspace=self.ws, out=bufs["dec"])
-        y = ops.dense(dhs_, w["dense_W"], w["dense_b"], activation="tanh")
         # the DP weight rides on the loss gradient (everything downstream is linear in it); the loss lands in the
         # flat buffer's last slot
-        # ... and the head's bias gradient (the column sums of dpre) comes from the same launch
-        dpre, loss = ops.mse_dense_grad(y, target, "tanh", scratch=self.scratch, dpre=bufs["dpre"], loss=self.loss_slot,
-                                        weight=grad_weight, db=g["dense_b"])
-        d_hs, _, _ = ops.dense_bwd(dhs_, w["dense_W"], dpre, dW=g["dense_W"], need_db=False, scratch=self.scratch)
+        if ops.dense_mse_head_supported(B * T_out, dhs_.shape[2], target.shape[2]):
+            # few rows (the reference's batch: 320): Dense forward, loss, loss gradient, dX, dW and db as ONE launch
+            y, d_hs, loss = ops.dense_mse_head(dhs_, w["dense_W"], w["dense_b"], target, "tanh", dW=g["dense_W"], db=g["dense_b"],
+                                               loss=self.loss_slot, weight=grad_weight, scratch=self.scratch, dx=bufs["d_hs"], y=bufs["y"])
+        else:
+            y = ops.dense(dhs_, w["dense_W"], w["dense_b"], activation="tanh")
+            # ... and the head's bias gradient (the column sums of dpre) comes from the same launch
+            dpre, loss = ops.mse_dense_grad(y, target, "tanh", scratch=self.scratch, dpre=bufs["dpre"], loss=self.loss_slot,
+                                            weight=grad_weight, db=g["dense_b"])
+            d_hs, _, _ = ops.dense_bwd(dhs_, w["dense_W"], dpre, dW=g["dense_W"], need_db=False, scratch=self.scratch)
         bd = ops.lstm_seq_bwd(dec_in, w["dec_K"], w["dec_R"], dhs_, dres, h0=ehT, c0=ecT, dhs=d_hs, dK=g["dec_K"],
                               dR=g["dec_R"], db=g["dec_b"], need_state_grads=True, act=self.act, dz=bufs["dz_dec"],
                               scratch=self.bwd_scratch)

@@ -1883,3 +1883,49 @@ def test_dense_bias_gradient_from_the_loss_launch(rows, O, act):
     db2 = torch.zeros((O,), device="cuda")
     ops.mse_dense_grad(y, t, act, scratch=sc, weight=0.5, db=db2)
     assert torch.equal(db, db2)
+
+
+@pytest.mark.parametrize("N,H,O,act,weight", [(320, 128, 6, "tanh", 1.0), (320, 64, 6, "tanh", 0.37), (37, 256, 3, "tanh", 1.0), (4096, 256, 6, "tanh", 1.0),
+                                              (65, 512, 8, None, 1.0), (1, 32, 1, "tanh", 1.0), (1000, 100, 6, "tanh", 0.5)])
+def test_dense_mse_head_one_launch(N, H, O, act, weight):
+    """fov_dense_mse_head (round 5): Dense(O, tanh) + mean_squared_error of FoV_seq2seq.py:96-103, forward and backward in ONE launch
+    (the reference's batch: 320 rows) - y, loss, dX, dW, db against fp64 NumPy and against the three separate entry points it
+    replaces (fov_dense_fwd, fov_mse_dense_grad_db, fov_dense_bwd); gradients land in place in a flat buffer; deterministic."""
+    from longterm360fov_amd import ops
+    rng = np.random.default_rng(N + H)
+    hs = rng.uniform(-1, 1, (N, H)).astype(np.float32)
+    W = (rng.standard_normal((H, O)) / np.sqrt(H)).astype(np.float32)
+    b = (0.1 * rng.standard_normal(O)).astype(np.float32)
+    tg = rng.uniform(-1, 1, (N, O)).astype(np.float32)
+    assert ops.dense_mse_head_supported(N, H, O) and not ops.dense_mse_head_supported(4097, H, O) and not ops.dense_mse_head_supported(N, H, 9)
+    pre = hs.astype(np.float64) @ W.astype(np.float64) + b
+    y_ref = np.tanh(pre) if act else pre
+    d = y_ref - tg
+    loss_ref = weight * np.mean(d ** 2)
+    dpre = 2.0 * d * weight / (N * O) * ((1 - y_ref ** 2) if act else 1.0)
+    dX_ref, dW_ref, db_ref = dpre @ W.astype(np.float64).T, hs.astype(np.float64).T @ dpre, dpre.sum(0)
+    flat = torch.zeros(H * O + O + 1 + 3, device="cuda")
+    dW, db, loss = flat[:H * O].view(H, O), flat[H * O:H * O + O], flat[H * O + O:H * O + O + 1]
+    y, dX, l = ops.dense_mse_head(dev(hs), dev(W), dev(b), dev(tg), act, dW=dW, db=db, loss=loss, weight=weight, scratch=ops.Scratch())
+    torch.cuda.synchronize()
+    assert l.data_ptr() == loss.data_ptr() and float(flat[-3:].abs().max().item()) == 0.0
+    assert np.abs(y.cpu().numpy() - y_ref).max() <= 2e-6
+    assert abs(float(loss.item()) - loss_ref) <= 1e-5 * abs(loss_ref) + 1e-9
+    for got, ref, tag in ((dX, dX_ref, "dX"), (dW, dW_ref, "dW"), (db, db_ref, "db")):
+        err = np.abs(got.cpu().numpy() - ref).max()
+        assert err <= 2e-5 * np.abs(ref).max() + 1e-9, (tag, err, np.abs(ref).max())
+    # the separate launches it replaces
+    sc = ops.Scratch()
+    y2 = ops.dense(dev(hs), dev(W), dev(b), activation=act)
+    db2 = torch.zeros(O, device="cuda")
+    dpre2, loss2 = ops.mse_dense_grad(y2, dev(tg), act, scratch=sc, weight=weight, db=db2)
+    dW2 = torch.zeros((H, O), device="cuda")
+    dX2, _, _ = ops.dense_bwd(dev(hs), dev(W), dpre2, dW=dW2, need_db=False, scratch=sc)
+    assert (y - y2).abs().max().item() <= 1e-6 and abs(float(loss.item()) - float(loss2.item())) <= 1e-6 * abs(loss_ref) + 1e-9
+    assert (dX - dX2).abs().max().item() <= 2e-5 * np.abs(dX_ref).max() + 1e-9 and (dW - dW2).abs().max().item() <= 2e-5 * np.abs(dW_ref).max() + 1e-9
+    assert (db - db2).abs().max().item() <= 2e-5 * np.abs(db_ref).max() + 1e-9
+    # bit for bit the same on a second call (fixed summation orders, the ticket is back at zero)
+    flat2 = torch.zeros_like(flat)
+    y3, dX3, _ = ops.dense_mse_head(dev(hs), dev(W), dev(b), dev(tg), act, dW=flat2[:H * O].view(H, O), db=flat2[H * O:H * O + O],
+                                    loss=flat2[H * O + O:H * O + O + 1], weight=weight, scratch=ops.Scratch())
+    assert torch.equal(flat2, flat) and torch.equal(y3, y) and torch.equal(dX3, dX)
