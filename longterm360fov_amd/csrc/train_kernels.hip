@@ -1076,15 +1076,39 @@ __global__ __launch_bounds__(256) void dense_mse_head_kernel(const float* __rest
     const int r0 = blockIdx.x * HD_RB;
     const int C4 = H >> 2;                    // 16-byte pieces per row
     // ---- stage the hs tile (rows past N: zero) and W ----
-    for (int i = tid; i < HD_RB * C4; i += 256) {
-        const int r = i / C4, c4 = i - r * C4;
-        f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (r0 + r < N) v = *(const f32x4*)(hs + (size_t)(r0 + r) * H + 4 * c4);
-        *(f32x4*)(sHs + r * LDH + 4 * c4) = v;
-    }
-    for (int i = tid; i < H * 8; i += 256) {
-        const int k = i >> 3, o = i & 7;
-        sWt[i] = o < O ? W[(size_t)k * O + o] : 0.f;
+    // (every request of the tile goes out before the first LDS store: a load-then-store loop is one memory round trip per
+    // iteration on a CU that runs one wave per SIMD - 8 us of the kernel's first 18)
+    {
+        const __amdgpu_buffer_rsrc_t hrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(hs + (size_t)r0 * H), 0,
+                                                                             (N - r0 < HD_RB ? N - r0 : HD_RB) * H * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(W), 0, H * O * 4, 0x00020000);
+        constexpr int HIT = HD_RB * 128 / 256;      // 16-byte pieces per thread at H = 512
+        typedef unsigned hu32x4 __attribute__((ext_vector_type(4)));
+        hu32x4 hv[HIT];
+#pragma unroll
+        for (int it = 0; it < HIT; ++it) {
+            const int i = tid + 256 * it;
+            hv[it] = __builtin_amdgcn_raw_buffer_load_b128(hrs, i < HD_RB * C4 ? (unsigned)(i * 16) : 0x80000000u, 0, 0);   // rows past N: beyond the descriptor = 0
+        }
+        float wv[16];
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int i = tid + 256 * it, k = i >> 3, o = i & 7;
+            wv[it] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(wrs, (i < H * 8 && o < O) ? (unsigned)((k * O + o) * 4) : 0x80000000u, 0, 0));
+        }
+#pragma unroll
+        for (int it = 0; it < HIT; ++it) {
+            const int i = tid + 256 * it;
+            if (i < HD_RB * C4) {
+                const int r = i / C4, c4 = i - r * C4;
+                *(hu32x4*)(sHs + r * LDH + 4 * c4) = hv[it];
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int i = tid + 256 * it;
+            if (i < H * 8) sWt[i] = wv[it];
+        }
     }
     __syncthreads();
     // ---- forward + loss gradient: lanes 4r .. 4r+3 share row r (k = 4j + q: the four read neighbouring words) ----
@@ -1092,6 +1116,7 @@ __global__ __launch_bounds__(256) void dense_mse_head_kernel(const float* __rest
     float acc[8];
 #pragma unroll
     for (int o = 0; o < 8; ++o) acc[o] = 0.f;
+#pragma unroll 8
     for (int j = 0; j < C4; ++j) {
         const int k = 4 * j + q;
         const float h = sHs[r * LDH + k];
@@ -1159,6 +1184,7 @@ __global__ __launch_bounds__(256) void dense_mse_head_kernel(const float* __rest
         float a[8];
 #pragma unroll
         for (int o = 0; o < 8; ++o) a[o] = 0.f;
+#pragma unroll 8
         for (int rr = 0; rr < HD_RB; ++rr) {
             const float h = sHs[rr * LDH + k];
             const f32x4 g0 = *(const f32x4*)(sD + rr * 8), g1 = *(const f32x4*)(sD + rr * 8 + 4);
@@ -1179,9 +1205,18 @@ __global__ __launch_bounds__(256) void dense_mse_head_kernel(const float* __rest
     __syncthreads();
     if (is_last) {
         __threadfence();
+        // L1-bypassing loads (another launch's partials may sit in this CU's L1 under the same addresses), ALL of an element's
+        // requested before the first is used: as a chain of load-then-add the five partials of the reference's batch cost a
+        // memory round trip each (the kernel took 19 us, 14 of them here)
+        const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(part, 0, (int)(gridDim.x * (unsigned)NE * 4u), 0x00020000);
         for (int e = tid; e < NE; e += 256) {
+            float v[HD_MAXB];
+#pragma unroll
+            for (int blk = 0; blk < HD_MAXB; ++blk)
+                v[blk] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(prs, (unsigned)((blk * NE + e) * 4), 0, 16 /* sc1 */));   // blocks past the grid: out of range = 0
             float a = 0.f;
-            for (unsigned blk = 0; blk < gridDim.x; ++blk) a += __hip_atomic_load(part + (size_t)blk * NE + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int blk = 0; blk < HD_MAXB; ++blk) a += v[blk];      // block order: deterministic (absent blocks add +0)
             if (e < H * O) dW[e] = a;
             else if (e < H * O + O) db[e - H * O] = a;
             else if (loss) loss[0] = a * scale;
