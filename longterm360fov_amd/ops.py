@@ -451,30 +451,24 @@ def lstm_seq_wgrad(x, hs, dz, dK=None, dR=None, db=None, h0=None, accumulate=Fal
     return {"dK": dK, "dR": dR, "db": db}
 
 
-def _destroy_stream(handle):
-    import sys
-    if sys.is_finalizing():      # interpreter shutdown: the HIP runtime may be gone before this runs, and the process ends anyway
-        return
-    try:
-        _lib.lib().fov_stream_destroy(_ct.c_void_p(handle))
-    except Exception:
-        pass
+_side_streams = {}
 
 
 def side_stream(device, priority=1, owner=None):
-    """A HIP stream of the given priority (> 0 low, 0 normal, < 0 high), created ON `device` (fov_stream_create makes it on the
-    current HIP device) and wrapped as a torch stream object.  The raw handle goes back to fov_stream_destroy when `owner`
-    (default: the returned stream object) is collected."""
-    import weakref
-    h = _ct.c_void_p()
-    with torch.cuda.device(device):
-        check(_lib.lib().fov_stream_create(int(priority), _ct.byref(h)))
-        st = torch.cuda.ExternalStream(h.value, device=device)
-    try:
-        fin = weakref.finalize(st if owner is None else owner, _destroy_stream, h.value)
-        fin.atexit = False      # at interpreter exit the HIP runtime may be gone before the finalizer runs: the process ends anyway
-    except TypeError:       # an owner that cannot be weakly referenced: the stream lives as long as the process
-        pass
+    """THE HIP stream of the given priority (> 0 low, 0 normal, < 0 high) of `device`, created on that device (fov_stream_create
+    makes it on the current HIP device) on first use and wrapped as a torch stream object.  One stream per (device, priority)
+    for the life of the process: every trainer that wants low-priority side work shares it - nothing leaks per trainer, and
+    nothing is ever destroyed (torch's caching allocator keeps blocks and events bound to a stream it has seen; destroying the
+    handle under it - tried in round 5 from a finalizer - crashed the interpreter at exit)."""
+    dev = torch.device(device)
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), int(priority))
+    st = _side_streams.get(key)
+    if st is None:
+        h = _ct.c_void_p()
+        with torch.cuda.device(key[0]):
+            check(_lib.lib().fov_stream_create(int(priority), _ct.byref(h)))
+            st = torch.cuda.ExternalStream(h.value, device=torch.device("cuda", key[0]))
+        _side_streams[key] = st
     return st
 
 

@@ -70,4 +70,5 @@ def test_bench_probe_watchdog_fails_the_run_but_prints_the_headline():
     print(r.stderr[-3000:])
     assert r.returncode != 0
     d = _json_line(r.stdout)
-    assert d["n_gpus"] == 2 and d["value"] > 0 and "did not finish" in d["extra"]["error"]
+    # (rank 0's own watchdog fires - "did not finish" - or rank 1's fires first and rank 0's collective raises: either way an error)
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["extra"].get("error")
