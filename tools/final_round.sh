@@ -9,6 +9,11 @@ python3 bench.py > $out/bench.json 2> $out/bench.err
 echo "[final_round] bench done"
 for m in train infer_mixing train_mixing; do python3 bench.py --mode $m --steps 200 --warmup 10 --cpu-budget 8 > $out/$m.json 2> $out/$m.err; done
 for m in infer_mixing train_mixing; do python3 bench.py --mode $m --dtype bf16 --steps 200 --warmup 10 --cpu-budget 8 > $out/${m}_bf16.json 2> $out/${m}_bf16.err; done
+# the mixing model at the metric's horizon (config.py:20-23: running_length / predict_step = 30)
+for m in infer_mixing train_mixing; do
+  python3 bench.py --mode $m --t-in 30 --t-out 30 --steps 100 --warmup 5 --cpu-budget 6 > $out/${m}_t30.json 2> $out/${m}_t30.err
+  python3 bench.py --mode $m --dtype bf16 --t-in 30 --t-out 30 --steps 100 --warmup 5 --cpu-budget 6 > $out/${m}_bf16_t30.json 2> $out/${m}_bf16_t30.err
+done
 echo "[final_round] mixing modes done"
 python3 bench.py --mode config1 --train > $out/config1.json 2> $out/config1.err
 python3 bench.py --mode a10 > $out/a10.json 2> $out/a10.err
