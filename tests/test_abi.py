@@ -92,3 +92,26 @@ def test_ctypes_argtypes_match_header_parameter_lists():
                 continue
             assert a is b, "%s: argument %d is %s in the ctypes table, %s in the header" % (name, i, a.__name__, b.__name__)
         assert restype is h_ret, "%s: return type %s vs header %s" % (name, restype, h_ret)
+
+
+def test_deferral_registry_is_keyed_and_bounded_without_a_gpu():
+    """fov_reduce_defer_begin / _flush / _end keep host-side bookkeeping only until a product records something: regions are keyed
+    by their gradient buffer, 16 may be open, the 17th is refused with a message, _end(NULL) closes all (no launch happens with no
+    pending record, so this runs on a box without a GPU)."""
+    L = _lib.lib()
+    base = 0x7f0000000000
+    arena = ctypes.c_void_p(base + (1 << 30))
+    for i in range(16):
+        assert L.fov_reduce_defer_begin(ctypes.c_void_p(base + i * 4096), 1024, arena, 1 << 20, None) == 0
+    assert L.fov_reduce_defer_begin(ctypes.c_void_p(base + 16 * 4096), 1024, arena, 1 << 20, None) == _lib.ERR_UNSUPPORTED
+    assert b"too many open regions" in L.fov_last_error()
+    assert L.fov_reduce_defer_flush(ctypes.c_void_p(base + 3 * 4096 + 8), None) == 0       # any address inside a region names it
+    assert L.fov_reduce_defer_end(ctypes.c_void_p(base + 3 * 4096), None) == 0
+    assert L.fov_reduce_defer_begin(ctypes.c_void_p(base + 16 * 4096), 1024, arena, 1 << 20, None) == 0   # a slot is free again
+    # a region over part of an open one replaces it (still 16 open: the next begin on fresh memory is refused)
+    assert L.fov_reduce_defer_begin(ctypes.c_void_p(base + 5 * 4096 + 64), 16, arena, 1 << 20, None) == 0
+    assert L.fov_reduce_defer_begin(ctypes.c_void_p(base + 40 * 4096), 1024, arena, 1 << 20, None) == _lib.ERR_UNSUPPORTED
+    assert L.fov_reduce_defer_end(None, None) == 0
+    assert L.fov_reduce_defer_begin(ctypes.c_void_p(base + 40 * 4096), 1024, arena, 1 << 20, None) == 0
+    assert L.fov_reduce_defer_end(None, None) == 0
+    assert L.fov_reduce_defer_begin(ctypes.c_void_p(base), 1024, None, 0, None) == _lib.ERR_INVALID     # a buffer without an arena

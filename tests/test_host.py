@@ -297,3 +297,75 @@ def test_model_checkpoint_h5_name_round_trips(tmp_path):
     m2.load_weights(path)
     for a, b in zip(m.get_weights(), m2.get_weights()):
         np.testing.assert_array_equal(a, b)
+
+
+def test_lstm_py_driver_loop_on_a_recording_trainer(tmp_path):
+    """lstm_driver.LSTMPyDriver's host logic without a GPU (the arithmetic lives in the trainer): the order of calls of
+    mycode/lstm.py:583-660 - save + learning-rate change on even epochs BEFORE the epoch's steps, the state handed from step to
+    step, display steps by the script's `count` rule (the mean / variance branch takes the display step's state), the final
+    save - and :590-592's restore-then-start-at-`training_epochs` quirk; total_batch_of against the script's formula."""
+    import torch
+    from longterm360fov_amd.config import default_config
+    from longterm360fov_amd.lstm_driver import LSTMPyDriver, total_batch_of
+
+    class Recorder:
+        L, H, device, head_kind = 2, 4, "cpu", "meanvar"
+
+        def __init__(self):
+            self.lr, self.log, self.n = 1e-3, [], 0
+
+        def train_step(self, x, y, state, masks=None, n_global=None):
+            self.n += 1
+            self.log.append(("step", self.n, float(state.sum()), self.lr, None if masks is None else len(masks)))
+            return torch.tensor([1.0 / self.n]), state + 1.0
+
+        def eval_loss(self, x, y, state, masks=None):
+            self.log.append(("eval", self.n, float(state.sum())))
+            return torch.tensor([0.5]), state + 100.0
+
+        def check(self):
+            self.log.append(("check", self.n))
+
+        def state_dict(self):
+            return {"Variable": np.float64(self.lr), "n": np.int64(self.n)}
+
+        def load_state_dict(self, sd):
+            self.lr, self.n = float(sd["Variable"]), int(sd["n"])
+
+    class Data:
+        def _get_next_minibatch(self, datadb, batch_size):
+            return (np.zeros((batch_size, 3, 6), np.float32), np.zeros((batch_size, 1, 6), np.float32), None, np.zeros((batch_size, 2, 6)), None, None)
+
+    cfg = default_config()
+    cfg.LEARNING_RATE, cfg.lr_epoch_step = 1e-3, 10
+    tr = Recorder()
+    drv = LSTMPyDriver(tr, cfg, model_path=str(tmp_path / "LSTM_x.ckpt"), dropout=0.1)
+    drv.fit(Data(), total_batch=3, training_epochs=3, batch_size=5)
+    steps = [e for e in tr.log if e[0] == "step"]
+    assert len(steps) == 9 and all(e[4] == 1 for e in steps)                       # one DropoutWrapper mask (L - 1 layers) per step
+    assert [e[3] for e in steps[:3]] == [1e-3 * 0.5 ** 0.2] * 3 and [e[3] for e in steps[3:6]] == [1e-3 * 0.5 ** 0.2] * 3   # epoch 2: set; epoch 3: kept
+    assert [e[3] for e in steps[6:]] == [1e-3 * 0.5 ** 0.4] * 3                  # epoch 4: LEARNING_RATE * 0.5 ** (4 / 10)
+    assert [os.path.basename(p) for p in drv.saved] == ["LSTM_xepoch2.ckpt.npz", "LSTM_xepoch4.ckpt.npz", "LSTM_xepoch4.ckpt.npz"]
+    # count = (step + 1) * batch_size + epoch * total_batch * batch_size; display_step 10 below 200: epoch 2 -> 35, 40, 45 ...
+    evals = [e for e in tr.log if e[0] == "eval"]
+    counts = [(s + 1) * 5 + ep * 15 for ep in (2, 3, 4) for s in range(3)]
+    assert len(evals) == sum(1 for c in counts if c % (10 if c < 200 else 200) == 0) == len(drv.history)
+    assert [c for c, _ in drv.history] == [c for c in counts if c % 10 == 0]
+    # the state is carried (each step adds 1 to every element, a display step on this branch adds 100): strictly increasing sums
+    sums = [e[2] for e in steps]
+    assert sums[0] == 0.0 and all(b > a for a, b in zip(sums, sums[1:])) and sums[-1] >= 8 * 2 * 2 * 5 * 4
+    assert [e for e in tr.log if e[0] == "check"] == [("check", 3), ("check", 6), ("check", 9)]
+    # restore-then-start-at-training_epochs: the checkpoint of epoch starting_epoch - 1 = 1 exists
+    os.replace(drv.epoch_path(2) + ".npz", drv.epoch_path(1) + ".npz")
+    tr2 = Recorder()
+    tr2.lr = 123.0
+    d2 = LSTMPyDriver(tr2, cfg, model_path=str(tmp_path / "LSTM_x.ckpt"), dropout=0.0)
+    d2.fit(Data(), total_batch=2, training_epochs=5, batch_size=5)
+    st2 = [e for e in tr2.log if e[0] == "step"]
+    assert tr2.n == 0 + 10 and len(st2) == 10                                      # restored (n = 0 at that save), epochs 5..9
+    assert st2[0][3] == 1e-3 and st2[0][4] is None                                 # epoch 5 is odd: the restored rate stays; no masks at dropout 0
+    assert st2[2][3] == 1e-3 * 0.5 ** 0.6 and st2[-1][3] == 1e-3 * 0.5 ** 0.8     # epochs 6 and 8
+    assert [os.path.basename(p) for p in d2.saved] == ["LSTM_xepoch6.ckpt.npz", "LSTM_xepoch8.ckpt.npz", "LSTM_xepoch9.ckpt.npz"]
+    datadb = {0: {"x": np.zeros((48, 1800))}, 1: {"x": np.zeros((48, 3600))}, 2: {"x": np.zeros((48, 900))}}
+    cfg.test_video_ind = 2
+    assert total_batch_of(datadb, cfg) == int((5400 - 300) / 10 / 32) * 48
