@@ -239,9 +239,11 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_cluster_kernel(BwdParams p) {
                 }
             }
             // dz of the step leaves for the weight-gradient products FROM THE LDS TILE, as 16-byte pieces: a wave instruction covers one
-            // sequence's four gate runs of 64 units (4 x 256 contiguous bytes: whole cache lines).  Stored from the registers - one
-            // dword per lane, 16 lanes per run of 64 bytes, 16 instructions per step - the kernel wrote 613 MB for a 252 MB tape
-            // (profiles/r04_pmcstep_train_f32.txt: every line written in two halves by two waves).
+            // sequence's four gate runs of 64 units (4 x 256 contiguous bytes: whole cache lines) - 4 store instructions per step
+            // instead of 16 dword stores from the registers (one dword per lane, 64-byte runs), behind the MFMAs where the
+            // waves wait for barrier B anyway: config-2 step 1.2600 -> 1.2559 ms.  (It does NOT change the kernel's WRITE_SIZE,
+            // 610 MB per step against a 252 MB tape in profiles/r05_pmcstep_train_f32.txt as in r04: the rest is the exchange -
+            // three destinations' partials as 8-byte granules, 24 KB per workgroup and step, written through for visibility.)
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int row = wave + 4 * k, gate = lane >> 4, c4 = lane & 15;
