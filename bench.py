@@ -672,7 +672,11 @@ def bench_a10(args, rank, world, use_dist):
     tinit = torch.zeros((2, 2, B, 400), device="cuda")
     for tag, pad in (("h400_padded_to_512_persistent_mfma", True), ("h400_stepwise_mfma_gemm", False)):
         tr = TFLSTMTrainer(cells, head, lr=1e-5, fps=30, running_length=10, pad=pad)
-        tstep = lambda: tr.train_step(tx, ty, tinit)
+        carried = [tinit]      # lstm.py:612-620: the state a step returns is the next step's fed state (state_view: no copies around it)
+
+        def tstep(tr=tr, carried=carried):
+            loss, carried[0] = tr.train_step(tx, ty, carried[0], state_view=True)
+            return loss, carried[0]
         for _ in range(5):
             tstep()
         tms = min(event_time_ms(tstep, max(args.steps // 6, 50)) for _ in range(3))
@@ -700,7 +704,11 @@ def bench_a10(args, rank, world, use_dist):
                 hw["conv%d_b" % (l + 1)] = np.zeros(dims[l + 1], np.float32)
             yk = ty
         tr = TFLSTMTrainer(cells, hw, lr=1e-5, fps=30, running_length=10, head_kind=kind)
-        tstep = lambda: tr.train_step(tx, yk, tinit)
+        carried = [tinit]
+
+        def tstep(tr=tr, carried=carried, yk=yk):
+            loss, carried[0] = tr.train_step(tx, yk, carried[0], state_view=True)
+            return loss, carried[0]
         for _ in range(5):
             tstep()
         tms = min(event_time_ms(tstep, max(args.steps // 6, 50)) for _ in range(3))

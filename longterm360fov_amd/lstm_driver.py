@@ -127,11 +127,11 @@ class LSTMPyDriver:
                 batch = self._next(data_io, datadb, batch_size)
                 x, y = self._dev(batch[0]), self._dev(batch[1])
                 masks = self._masks(x.shape[0], x.shape[1])
-                _, state = tr.train_step(x, y, state, masks=masks, n_global=n_global)
+                _, state = tr.train_step(x, y, state, masks=masks, n_global=n_global, state_view=True)      # (the carried state without copies)
                 count = (step + 1) * batch_size + epoch * total_batch * batch_size
                 display_step = 10 if count < 200 else 200
                 if count % display_step == 0:
-                    loss, st = tr.eval_loss(x, y, state, masks=self._masks(x.shape[0], x.shape[1]))
+                    loss, st = tr.eval_loss(x, y, state, masks=self._masks(x.shape[0], x.shape[1]), state_view=True)
                     if tr.head_kind == "meanvar":
                         state = st
                     self.history.append((count, float(loss.item())))

@@ -304,9 +304,10 @@ def lstm_stack2_supported(B, T, F, H):
     return os.environ.get("FOV_NO_STACK2", "") != "1" and bool(_lib.lib().fov_lstm_stack2_supported(B, T, F, H))
 
 
-def lstm_stack2(x, layer1, layer2, state1=None, state2=None, act="sigmoid", workspace=None, reserve=False):
+def lstm_stack2(x, layer1, layer2, state1=None, state2=None, act="sigmoid", workspace=None, reserve=False, final1=None, final2=None):
     """Two stacked fp32 LSTM layers (F <= 96 -> 512 -> 512) as ONE launch, layer 2 a few steps behind layer 1 on other CUs
-    (fov_lstm_stack2_fwd).  layer = (K, R, b); state = (h0, c0) or None.  -> ((hs, hT, cT, reserve), (hs, hT, cT, reserve))."""
+    (fov_lstm_stack2_fwd).  layer = (K, R, b); state = (h0, c0) or None; final = (hT, cT) tensors the layer's final state is
+    written into (e.g. views of a carried-state buffer) or None.  -> ((hs, hT, cT, reserve), (hs, hT, cT, reserve))."""
     x = _dev(x, "x")
     K1, R1, b1 = (_dev(t, "layer1") for t in layer1)
     K2, R2, b2 = (_dev(t, "layer2") for t in layer2)
@@ -315,8 +316,10 @@ def lstm_stack2(x, layer1, layer2, state1=None, state2=None, act="sigmoid", work
     B, T, F = x.shape
     H = R1.shape[0]
     e = lambda *s: torch.empty(s, dtype=torch.float32, device=x.device)
-    out1 = (e(B, T, H), e(B, H), e(B, H), e(B, T, 5, H) if reserve else None)
-    out2 = (e(B, T, H), e(B, H), e(B, H), e(B, T, 5, H) if reserve else None)
+    f1 = (e(B, H), e(B, H)) if final1 is None else (_dev(final1[0], "hT"), _dev(final1[1], "cT"))
+    f2 = (e(B, H), e(B, H)) if final2 is None else (_dev(final2[0], "hT"), _dev(final2[1], "cT"))
+    out1 = (e(B, T, H), f1[0], f1[1], e(B, T, 5, H) if reserve else None)
+    out2 = (e(B, T, H), f2[0], f2[1], e(B, T, 5, H) if reserve else None)
     L = _lib.lib()
     ws = (workspace or default_workspace(x.device))
     buf = ws.get(L.fov_lstm_seq_workspace_bytes(B, T, F, H, IMPL_AUTO), x.device)

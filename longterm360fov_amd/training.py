@@ -1706,6 +1706,7 @@ class TFLSTMTrainer(FlatParamTrainer):
         self.m.fill_(1.0)      # TF initialises the rms slot to one
         self.ms = self.m
         self._state_pads = {}
+        self._carry = {}      # batch -> two (L,2,B,Hp) buffers the final state alternates between (train_step(..., state_view=True))
 
     def apply_gradients(self):
         """tf.train.RMSPropOptimizer on clip_by_value(grad, -1, 1) (lstm.py:556-567), one guarded launch on the flat buffers."""
@@ -1748,6 +1749,9 @@ class TFLSTMTrainer(FlatParamTrainer):
         """(L,2,B,H) -> (L,2,B,Hp), zero columns."""
         if st is None or self.Hp == self.H or st.shape[-1] == self.Hp:
             return st
+        for buf in self._carry.get(st.shape[2], ()):      # the width-H view of a carried-state buffer this trainer returned: no copy
+            if st.data_ptr() == buf.data_ptr() and st.stride() == buf.stride():
+                return buf
         key = tuple(st.shape)
         out = self._state_pads.get(key)      # one buffer per shape: its padded columns are written once (zero), one copy per call
         if out is None:
@@ -1760,6 +1764,15 @@ class TFLSTMTrainer(FlatParamTrainer):
         H = self.H
         flat = [t[:, :H] for pair in states for t in pair]
         return torch.stack(flat, 0).view(len(states), 2, flat[0].shape[0], H)
+
+    def _carry_target(self, B, init_state):
+        """The carried-state buffer of batch B that does NOT hold `init_state` (the kernels read one and write the other)."""
+        bufs = self._carry.get(B)
+        if bufs is None:
+            bufs = self._carry[B] = [torch.zeros((self.L, 2, B, self.Hp), dtype=torch.float32, device=self.device) for _ in range(2)]
+        if init_state is not None and init_state.data_ptr() == bufs[0].data_ptr():
+            return bufs[1]
+        return bufs[0]
 
     def _pad_masks(self, masks):
         if masks is None or self.Hp == self.H:
@@ -1889,16 +1902,18 @@ class TFLSTMTrainer(FlatParamTrainer):
         return (self.L == 2 and self.impl == "auto" and (masks is None or masks[0] is None)
                 and ops.lstm_stack2_supported(x.shape[0], x.shape[1], x.shape[2], self.Hp))
 
-    def _stack2_forward(self, x, init_state, reserve):
+    def _stack2_forward(self, x, init_state, reserve, out_state=None):
         w = self.w
         sts = [None if init_state is None else (init_state[l][1].contiguous(), init_state[l][0].contiguous()) for l in range(2)]
+        fin = [None if out_state is None else (out_state[l, 1], out_state[l, 0]) for l in range(2)]      # (hT, cT) of LSTMStateTuple (c, h)
         return ops.lstm_stack2(x, (w["K0"], w["R0"], w["b0"]), (w["K1"], w["R1"], w["b1"]), sts[0], sts[1], act="sigmoid",
-                               workspace=self.ws, reserve=reserve)
+                               workspace=self.ws, reserve=reserve, final1=fin[0], final2=fin[1])
 
-    def _stack_forward(self, x, init_state, masks):
+    def _stack_forward(self, x, init_state, masks, out_state=None):
+        """out_state: a (L,2,B,Hp) buffer the layers' final (c, h) are written into directly (no stack / copy afterwards)."""
         w = self.w
         if self._stack2(x, masks):
-            o1, o2 = self._stack2_forward(x, init_state, reserve=True)
+            o1, o2 = self._stack2_forward(x, init_state, reserve=True, out_state=out_state)
             sts = [None if init_state is None else (init_state[l][1].contiguous(), init_state[l][0].contiguous()) for l in range(2)]
             tape = [(x, o1[0], o1[3], None if sts[0] is None else sts[0][0], None if sts[0] is None else sts[0][1]),
                     (o1[0], o2[0], o2[3], None if sts[1] is None else sts[1][0], None if sts[1] is None else sts[1][1])]
@@ -1907,8 +1922,12 @@ class TFLSTMTrainer(FlatParamTrainer):
         for l in range(self.L):
             c0 = None if init_state is None else init_state[l, 0].contiguous()
             h0 = None if init_state is None else init_state[l, 1].contiguous()
+            out = None
+            if out_state is not None:
+                e = lambda *shp: torch.empty(shp, dtype=torch.float32, device=x.device)
+                out = (e(x.shape[0], x.shape[1], self.Hp), out_state[l, 1], out_state[l, 0], e(x.shape[0], x.shape[1], 5, self.Hp))
             hs, hT, cT, res = ops.lstm_seq_train(inp, w["K%d" % l], w["R%d" % l], w["b%d" % l], h0, c0, act="sigmoid",
-                                                 impl=self.impl, workspace=self.ws)
+                                                 impl=self.impl, workspace=self.ws, out=out)
             tape.append((inp, hs, res, h0, c0))
             states.append((cT, hT))
             inp = hs if (masks is None or l == self.L - 1) else hs * masks[l]
@@ -1967,7 +1986,7 @@ class TFLSTMTrainer(FlatParamTrainer):
                 dx0 = b["dx"]
         return dx0
 
-    def _fb_gmm(self, x, y, init_state, masks, head_masks, grad_weight=1.0):
+    def _fb_gmm(self, x, y, init_state, masks, head_masks, grad_weight=1.0, state_view=False):
         """lstm.py:482-485: one window, costfunc.mixture_3d_gaussian_loss on y (second 0 under cfg.process_in_seconds,
         every frame of (B,T,3) otherwise), divided by batch_size * running_length [* fps] (cost.py:544-549)."""
         B = x.shape[0]
@@ -1977,13 +1996,14 @@ class TFLSTMTrainer(FlatParamTrainer):
         # under the SUM all-reduce as they are; without it the divisor is this rank's B and the rank's share weighs it
         scale = (1.0 if self.batch_size else grad_weight) / ((self.batch_size or B) * self.running_length * (self.fps if pis else 1))
         init_state, masks = self._pad_state(init_state), self._pad_masks(masks)
-        tape, states = self._stack_forward(x, init_state, masks)
+        carry = self._carry_target(B, init_state) if state_view else None
+        tape, states = self._stack_forward(x, init_state, masks, out_state=carry)
         hT = states[-1][1]
         acts = self._head(hT, head_masks)
         loss, dpre = ops.gmm3d_loss_grad(acts[-1], y, n_pts, scale, self.weight_by_pi, scratch=self.scratch)
         dhT = self._mlp_backward(hT, acts, dpre, accumulate=False, head_masks=head_masks)
         self._stack_backward(tape, dhT, masks, accumulate=False)
-        return loss, acts[-1], None, self._state_out(states)
+        return loss, acts[-1], None, (carry[..., :self.H] if state_view else self._state_out(states))
 
     def _fb_raw(self, x, y, init_state, masks, grad_weight=1.0):
         """lstm.py:486-508: prediction k is scored against second k (tf.losses.mean_squared_error over every element;
@@ -2030,7 +2050,7 @@ class TFLSTMTrainer(FlatParamTrainer):
                 ops.act_bwd(slot, slot, base=src, activation=None, out=src)
         return total, runs[-1]["acts"][-1], None, self._state_out(states)
 
-    def forward_backward(self, x, y, init_state=None, masks=None, noise=None, head_masks=None, grad_weight=1.0):
+    def forward_backward(self, x, y, init_state=None, masks=None, noise=None, head_masks=None, grad_weight=1.0, state_view=False):
         """x (B,T,F), y (B,T_y,3*fps), init_state (L,2,B,H) (c,h) or None.  Fills self.grad (times grad_weight, a data-parallel
         rank's share of the global batch); returns
         (loss (1,), mu (B,3), var (B,3), final state (L,2,B,H)) - head_kind 'gmm': (loss, params (B,10n), None, state),
@@ -2042,9 +2062,13 @@ class TFLSTMTrainer(FlatParamTrainer):
         after re-running the whole stack, from the same fed state, on the window shifted by one second whose last slot
         is a second SAMPLED around the previous prediction (mean mu, stddev sqrt(var)); losses add up and the gradient
         flows back through the samples (reparameterisation, as TF differentiates tf.random_normal(mean, stddev)).
-        `masks` is then a list of T_y per-window mask lists (DropoutWrapper draws a new mask per dynamic_rnn call)."""
+        `masks` is then a list of T_y per-window mask lists (DropoutWrapper draws a new mask per dynamic_rnn call).
+
+        state_view (single-window graphs): the returned state is the width-H VIEW of one of the trainer's two carried-state
+        buffers, which the kernels write directly (no gather / copy launch; fed back, it is taken as it is - no padding copy):
+        the form lstm.py's loop wants (:612-620).  It is overwritten by the call after next; the default returns a copy."""
         if self.head_kind == "gmm":
-            return self._fb_gmm(x, y, init_state, masks, head_masks, grad_weight)
+            return self._fb_gmm(x, y, init_state, masks, head_masks, grad_weight, state_view)
         if self.head_kind == "raw":
             return self._fb_raw(x, y, init_state, masks, grad_weight)
         sc = self.scratch
@@ -2053,13 +2077,14 @@ class TFLSTMTrainer(FlatParamTrainer):
         unpad = self._state_out
         if noise is None:
             masks = self._pad_masks(masks)
-            tape, states = self._stack_forward(x, init_state, masks)
+            carry = self._carry_target(x.shape[0], init_state) if state_view else None
+            tape, states = self._stack_forward(x, init_state, masks, out_state=carry)
             hT = states[-1][1]
             head = self._head(hT)
             loss, dmu, dvar = ops.gauss_nll_grad(head[1], head[3], y, self.fps, scale, scratch=sc)
             dhT = self._head_backward(hT, head, dmu, dvar, accumulate=False)
             self._stack_backward(tape, dhT, masks, accumulate=False)
-            return loss, head[1], head[3], unpad(states)
+            return loss, head[1], head[3], (carry[..., :self.H] if state_view else unpad(states))
         B, T, F = x.shape
         P = y.shape[1]
         assert F == 3 * self.fps and tuple(noise.shape) == (P - 1, B, F)
@@ -2088,16 +2113,19 @@ class TFLSTMTrainer(FlatParamTrainer):
         last = runs[-1]
         return total, last["head"][1], last["head"][3], unpad(states)
 
-    def train_step(self, x, y, init_state=None, masks=None, noise=None, head_masks=None, n_global=None):
+    def train_step(self, x, y, init_state=None, masks=None, noise=None, head_masks=None, n_global=None, state_view=False):
         """One step of lstm.py:612-620's sess.run([train_op, current_state]) -> (loss (1,), final state (L,2,B,H)) - the state is
-        this rank's own (its sequences'), the loss the global one under data parallelism (n_global = global batch size)."""
+        this rank's own (its sequences'), the loss the global one under data parallelism (n_global = global batch size).
+        state_view: see forward_backward (the carried state without copies)."""
         weight = self._begin_step(x.shape[0], n_global)
-        loss, _, _, state = self.forward_backward(x, y, init_state, masks, noise, head_masks, grad_weight=weight)
+        view = bool(state_view) and self.head_kind != "raw" and noise is None
+        loss, _, _, state = self.forward_backward(x, y, init_state, masks, noise, head_masks, grad_weight=weight, state_view=view)
         return self._finish_step(loss), state
 
-    def eval_loss(self, x, y, init_state=None, masks=None, noise=None, head_masks=None):
+    def eval_loss(self, x, y, init_state=None, masks=None, noise=None, head_masks=None, state_view=False):
         """The `cost` fetch of the script's display step (lstm.py:625-650): loss and state of one batch, no update."""
-        loss, _, _, state = self.forward_backward(x, y, init_state, masks, noise, head_masks)
+        view = bool(state_view) and self.head_kind != "raw" and noise is None
+        loss, _, _, state = self.forward_backward(x, y, init_state, masks, noise, head_masks, state_view=view)
         return loss, state
 
     # ---- tf.train.Saver's view of the model (lstm.py:552): every variable and its RMSProp slots under the graph's names ----

@@ -340,3 +340,29 @@ def test_stack2_knob_toggled_between_steps_of_one_trainer():
     tr.check(); ref.check()
     d = (tr.flat - ref.flat).abs().max().item()
     assert d <= 2e-5, d
+
+
+@pytest.mark.parametrize("kind,with_masks", [("meanvar", False), ("gmm", False), ("meanvar", True), ("raw", False)])
+def test_carried_state_views_equal_copied_states(kind, with_masks):
+    """train_step(..., state_view=True): the final state is written by the kernels straight into one of two carried-state
+    buffers and fed back as it is (no padding copy in front of a step, no gather behind it - two launches of lstm.py's step):
+    five steps with the state carried as views equal five steps with copied states bit for bit, the views alternate between the
+    two buffers, and a view is only overwritten by the call after next.  ('raw' re-runs the stack per window: copies, as before.)"""
+    x, y, init = _batch(61, 32, 10, Ty=(2 if kind == "raw" else 1))
+    a, b = _trainer(63, 400, kind), _trainer(63, 400, kind)
+    rng = np.random.default_rng(7)
+    sa = sb = dev(init)
+    ptrs = []
+    for i in range(5):
+        masks = [dev((rng.random((32, 10, 400)) < 0.9) / 0.9), None] if with_masks else None
+        la, sa = a.train_step(dev(x), dev(y), sa, masks=masks)
+        lb, sb_new = b.train_step(dev(x), dev(y), sb, masks=masks, state_view=True)
+        if i > 0 and kind != "raw":
+            assert torch.equal(sb, sa_prev)      # the view handed in is still intact after the step that read it
+        sb, sa_prev = sb_new, sa
+        assert torch.equal(la, lb) and torch.equal(sa, sb) and sb.shape == (2, 2, 32, 400)
+        ptrs.append(sb.data_ptr())
+    a.check(); b.check()
+    assert torch.equal(a.flat, b.flat) and torch.equal(a.ms, b.ms)
+    if kind != "raw":
+        assert len(set(ptrs)) == 2 and ptrs[0] == ptrs[2] == ptrs[4] and ptrs[1] == ptrs[3] and not sb.is_contiguous()

@@ -314,12 +314,13 @@ def test_lstm_py_driver_loop_on_a_recording_trainer(tmp_path):
         def __init__(self):
             self.lr, self.log, self.n = 1e-3, [], 0
 
-        def train_step(self, x, y, state, masks=None, n_global=None):
+        def train_step(self, x, y, state, masks=None, n_global=None, state_view=False):
+            assert state_view
             self.n += 1
             self.log.append(("step", self.n, float(state.sum()), self.lr, None if masks is None else len(masks)))
             return torch.tensor([1.0 / self.n]), state + 1.0
 
-        def eval_loss(self, x, y, state, masks=None):
+        def eval_loss(self, x, y, state, masks=None, state_view=False):
             self.log.append(("eval", self.n, float(state.sum())))
             return torch.tensor([0.5]), state + 100.0
 
