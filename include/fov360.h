@@ -38,9 +38,10 @@
  *         workspace's memory is freed and the address comes back from the allocator);
  *       * per open fov_reduce_defer_begin region, keyed by its gradient buffer: the table of pending reductions
  *         (see there);
- *       * per (device, stream): the index of that stream's word in a 64-word device-side ticket table of the
+ *       * per (device, stream): the index of that stream's word in a 1024-word device-side ticket table of the
  *         loss entry points (a module-level __device__ array, not an allocation).  A device on which more than
- *         64 distinct streams have issued loss calls takes the two-launch form for the later ones;
+ *         1024 distinct streams have issued loss calls takes the two-launch form for the later ones
+ *         (fov_dense_mse_head refuses there);
  *       * streams exist only where the caller asked for one (fov_stream_create) and belong to the caller.
  *     One process per GPU - the deployment this library is written for - and several devices / trainers /
  *     threads in one process are both within this contract (tests/test_gpu_threads.py drives two trainers

@@ -14,6 +14,7 @@
 #include <stdlib.h>
 
 #include <mutex>
+#include <unordered_map>
 
 #include "fov_common.h"
 #include "xch_common.h"
@@ -633,7 +634,7 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
 // Tickets of the loss kernels' "last block adds the partials" step (round 4: the separate one-block sum launch is gone, 5 us of
 // every training step's critical path).  Zero at module load, left at zero again by the block that takes the last ticket; every
 // stream of a device has its own slot (loss_ticket_of), so launches in flight never share one.
-constexpr int kLossTickets = 64;
+constexpr int kLossTickets = 1024;
 __device__ unsigned g_loss_tickets[kLossTickets];
 
 __global__ __launch_bounds__(256) void mse_dense_grad_kernel(const float* __restrict__ y, const float* __restrict__ target,
@@ -2108,11 +2109,12 @@ int dense_bwd(const float* x, const float* W, const float* dpre, float* dx, floa
 // The ticket word of a loss launch: one slot of the device's ticket table PER STREAM (first use of a stream on a device takes
 // the next free slot; the device address of g_loss_tickets is looked up once per device).  Launches on one stream run in
 // stream order, so the word a launch finds is the zero its predecessor on that stream left: two launches in flight never share
-// a slot however many there are, whichever threads issued them.  A device whose kLossTickets slots are all taken (more
-// distinct streams than that) gets NULL: the callers below fall back to the separate sum / column-sum launches.
+// a slot however many there are, whichever threads issued them.  Slots are never handed back (a stream handle may still have a
+// launch in flight when its owner forgets it): a device on which kLossTickets = 1024 distinct streams have issued loss calls
+// gets NULL for further ones - the callers below fall back to the separate sum / column-sum launches, fov_dense_mse_head refuses.
 // (A captured graph replayed on two streams AT ONCE would share the slot of its capture stream: not supported.)
 static unsigned* loss_ticket_of(hipStream_t stream) {
-    struct PerDevice { unsigned* base = nullptr; int used = 0; hipStream_t streams[kLossTickets]; };
+    struct PerDevice { unsigned* base = nullptr; std::unordered_map<hipStream_t, int> slot; };
     static std::mutex mu;
     static PerDevice devs[64];
     std::lock_guard<std::mutex> lock(mu);
@@ -2124,11 +2126,12 @@ static unsigned* loss_ticket_of(hipStream_t stream) {
         if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_loss_tickets)) != hipSuccess) return nullptr;
         d.base = static_cast<unsigned*>(p);
     }
-    for (int i = 0; i < d.used; ++i)
-        if (d.streams[i] == stream) return d.base + i;
-    if (d.used == kLossTickets) return nullptr;
-    d.streams[d.used] = stream;
-    return d.base + d.used++;
+    auto it = d.slot.find(stream);
+    if (it != d.slot.end()) return d.base + it->second;
+    if ((int)d.slot.size() == kLossTickets) return nullptr;
+    const int idx = (int)d.slot.size();
+    d.slot.emplace(stream, idx);
+    return d.base + idx;
 }
 
 int mse_dense_grad(const float* y, const float* target, float* dpre, float* loss, long n, int activation, float* scratch,
@@ -2188,7 +2191,7 @@ int dense_mse_head(const float* hs, const float* W, const float* b, const float*
     if (!dense_mse_head_shape_ok(N, H, O)) { set_error("dense_mse_head: rows <= 4096, H <= 512 (a multiple of 4), O <= 8 only"); return FOV_ERR_UNSUPPORTED; }
     if (dense_mse_head_scratch_floats(N, H, O) > scratch_floats) { set_error("dense_mse_head: scratch too small"); return FOV_ERR_WORKSPACE; }
     unsigned* ticket = loss_ticket_of(stream);
-    if (!ticket) { set_error("dense_mse_head: no ticket slot left for this stream (more than 64 streams on the device)"); return FOV_ERR_UNSUPPORTED; }
+    if (!ticket) { set_error("dense_mse_head: no ticket slot left for this stream (1024 distinct streams have issued loss calls on the device)"); return FOV_ERR_UNSUPPORTED; }
     int rc = defer_touch(dW, (size_t)H * O, stream);     // pending deferred reductions over the gradients written here go first
     if (!rc) rc = defer_touch(db, (size_t)O, stream);
     if (rc) return rc;

@@ -168,9 +168,9 @@ def test_two_deferral_regions_interleaved_equal_immediate():
 
 
 def test_loss_launches_on_many_streams_keep_their_own_ticket():
-    """The loss entry points finish through one ticket word per (device, stream): 80 streams (more than the 64-word table: the
-    last ones take the two-launch form) each issue several MSE-loss launches concurrently; every loss and bias gradient equals
-    the single-stream result bit for bit."""
+    """The loss entry points finish through one ticket word per (device, stream) - launches in flight never share one, however
+    many there are: 80 streams each issue several MSE-loss launches concurrently; every loss and bias gradient equals the
+    single-stream result bit for bit."""
     from longterm360fov_amd import ops
     rng = np.random.default_rng(9)
     rows, Od = 4096, 6
