@@ -227,6 +227,19 @@ int fov_lstm_seq_wgrad(const float* x, const float* hs, const float* h0, const f
                        int B, int T, int F, int H, int accumulate, int bf16,
                        void* workspace, size_t workspace_bytes, fov_stream_t stream);
 
+/* The same for an encoder / decoder pair of layers that share the batch (FoV_seq2seq.py:68-93: layer 1 = encoder over T1 steps,
+ * layer 2 = decoder over T2 steps, h0_2 = the encoder's final h): all six gradients from the two dz tapes.  When
+ * fov_lstm_seq_wgrad_pair_one_launch(B, T1, T2, H) is 1 (few rows, H <= 256: the reference's batch of 32) they are ONE launch
+ * without split products or reduces - a trainer then runs both BPTT calls with dK = dR = db = NULL and calls this once; otherwise
+ * the call equals two fov_lstm_seq_wgrad calls.  workspace: max over the two layers of fov_lstm_seq_bwd_workspace_bytes. */
+int fov_lstm_seq_wgrad_pair_one_launch(int B, int T1, int T2, int H);
+int fov_lstm_seq_wgrad_pair(const float* x1, const float* hs1, const float* h0_1, const float* dz1, float* dK1, float* dR1, float* db1,
+                            int T1, int F1,
+                            const float* x2, const float* hs2, const float* h0_2, const float* dz2, float* dK2, float* dR2, float* db2,
+                            int T2, int F2,
+                            int B, int H, int accumulate,
+                            void* workspace, size_t workspace_bytes, fov_stream_t stream);
+
 /* A HIP stream of a given priority for such side work: priority < 0 high, 0 normal, > 0 low (clamped to the device's range).
  * Work enqueued on a LOW-priority stream yields the compute units to the caller's stream whenever both have workgroups ready:
  * weight-gradient products put there fill the gaps of the persistent recurrence kernels instead of delaying their launch.

@@ -110,6 +110,8 @@ SIGNATURES = {
     "fov_lstm_stack2_bwd_workspace_bytes": (_SZ, [_I] * 4),
     "fov_lstm_stack2_bwd": (_I, [_P] * 29 + [_I] * 6 + [_P, _SZ, _P]),
     "fov_lstm_seq_wgrad": (_I, [_P] * 7 + [_I] * 6 + [_P, _SZ, _P]),
+    "fov_lstm_seq_wgrad_pair_one_launch": (_I, [_I] * 4),
+    "fov_lstm_seq_wgrad_pair": (_I, [_P] * 7 + [_I] * 2 + [_P] * 7 + [_I] * 2 + [_I] * 3 + [_P, _SZ, _P]),
     "fov_stream_create": (_I, [_I, ctypes.POINTER(ctypes.c_void_p)]),
     "fov_stream_destroy": (_I, [_P]),
     "fov_conv2d_dilated_fwd": (_I, [_P, ctypes.c_int64, ctypes.c_int64, _P, _P, _P, _P] + [_I] * 9 + [_P]),

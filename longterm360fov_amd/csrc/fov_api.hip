@@ -818,6 +818,26 @@ int fov_lstm_seq_wgrad(const float* x, const float* hs, const float* h0, const f
                           workspace_bytes / sizeof(float), (hipStream_t)stream);
 }
 
+int fov_lstm_seq_wgrad_pair_one_launch(int B, int T1, int T2, int H) {
+    return (B > 0 && T1 > 0 && T2 > 0 && H > 0 && lstm_seq_wgrad_pair_one_launch(B, T1, T2, H)) ? 1 : 0;
+}
+
+int fov_lstm_seq_wgrad_pair(const float* x1, const float* hs1, const float* h0_1, const float* dz1, float* dK1, float* dR1, float* db1,
+                            int T1, int F1, const float* x2, const float* hs2, const float* h0_2, const float* dz2, float* dK2,
+                            float* dR2, float* db2, int T2, int F2, int B, int H, int accumulate, void* workspace,
+                            size_t workspace_bytes, fov_stream_t stream) {
+    if (B < 0 || T1 < 0 || T2 < 0 || F1 <= 0 || F2 <= 0 || H <= 0 || (B > 0 && T1 > 0 && (!dz1 || (dK1 && !x1) || (dR1 && !hs1))) ||
+        (B > 0 && T2 > 0 && (!dz2 || (dK2 && !x2) || (dR2 && !hs2)))) {
+        set_error("fov_lstm_seq_wgrad_pair: invalid argument");
+        return FOV_ERR_INVALID;
+    }
+    const size_t n1 = fov_lstm_seq_bwd_workspace_bytes(B, T1, F1, H), n2 = fov_lstm_seq_bwd_workspace_bytes(B, T2, F2, H);
+    int rc = check_ws(workspace, workspace_bytes, n1 > n2 ? n1 : n2);
+    if (rc) return rc;
+    return lstm_seq_wgrad_pair(x1, hs1, h0_1, dz1, dK1, dR1, db1, T1, F1, x2, hs2, h0_2, dz2, dK2, dR2, db2, T2, F2, B, H, accumulate,
+                               (float*)workspace, workspace_bytes / sizeof(float), (hipStream_t)stream);
+}
+
 size_t fov_dense_bwd_workspace_bytes(int N, int In, int Out) {
     if (N <= 0 || In <= 0 || Out <= 0) return 256;
     size_t a = (size_t)(Out <= 8 ? 1024 : 64) * In * Out, b = (size_t)256 * Out, c = (size_t)(N + 255) / 256 + 64;

@@ -216,6 +216,13 @@ bool bwd_cluster_shape_ok(int H);
 bool wide16_pair_shape(int B, int T, int F, int H);
 int launch_wide16_pair(const LstmParams& a, const LstmParams& b, hipStream_t stream);
 // lstm_bwd16.hip: BPTT recurrence with 16 / 32 units per workgroup (fp32): width 512, and 128 / 256 at small batches
+bool wgrad_rows_takes(long rows, int H);       // wgrad_group.hip: few rows AND narrow layers - 16 x 64 tiles, rows split over a workgroup's waves
+int wgrad_rows_layers(int L, const float* const* x, const int* F, const int* T, const float* const* hs, const float* const* h0,
+                      const float* const* dz, float* const* dK, float* const* dR, float* const* db, int B, int H, int accumulate, hipStream_t stream);
+bool lstm_seq_wgrad_pair_one_launch(int B, int T1, int T2, int H);
+int lstm_seq_wgrad_pair(const float* x1, const float* hs1, const float* h0_1, const float* dz1, float* dK1, float* dR1, float* db1, int T1, int F1,
+                        const float* x2, const float* hs2, const float* h0_2, const float* dz2, float* dK2, float* dR2, float* db2, int T2, int F2,
+                        int B, int H, int accumulate, float* scratch, size_t scratch_floats, hipStream_t stream);
 bool wgrad_group_takes(int B, int T, int H);   // wgrad_group.hip: few rows - every (product, output tile) one workgroup, one launch
 int wgrad_group_layers(int L, const float* const* x, const int* F, const float* const* hs, const float* const* h0, const float* const* dz,
                        float* const* dK, float* const* dR, float* const* db, int B, int T, int H, int accumulate, hipStream_t stream);

@@ -1877,6 +1877,18 @@ static bool lstm_seq_wgrad_grouped(int bf16, int B, int T, int H, const float* d
     return !bf16 && wgrad_group_takes(B, T, H) && (dK || dR) && (((uintptr_t)dz) & 15) == 0 && (!db || dK || dR);
 }
 
+// few rows AND narrow layers (the reference's batch of 32 at H <= 256): wgrad_rows_kernel, 16 x 64 tiles, rows split over the waves
+static bool lstm_seq_wgrad_rows(int bf16, int B, int T, int F, int H, const float* dz, float* dK, float* dR, float* db) {
+    return !bf16 && wgrad_rows_takes((long)B * T, H) && F <= 2048 && (dK || dR) && (!db || dK || dR) &&
+           ((((uintptr_t)dz) | ((uintptr_t)dK) | ((uintptr_t)dR) | ((uintptr_t)db)) & 15) == 0;
+}
+
+static int wgrad_few_rows(bool rows_form, const float* x, const float* hs, const float* h0, const float* dz, float* dK, float* dR, float* db,
+                          int B, int T, int F, int H, int accumulate, hipStream_t stream) {
+    return rows_form ? wgrad_rows_layers(1, &x, &F, &T, &hs, &h0, &dz, &dK, &dR, &db, B, H, accumulate, stream)
+                     : wgrad_group_layers(1, &x, &F, &hs, &h0, &dz, &dK, &dR, &db, B, T, H, accumulate, stream);
+}
+
 static void lstm_seq_wgrad_fusion(const float* x, const float* hs, const float* dz, float* dK, float* dR, float* db, int T, int F, int H,
                                   bool* fuse_kr, bool* fuse_r) {
     const int N4 = 4 * H;
@@ -1899,12 +1911,38 @@ int lstm_seq_wgrad(const float* x, const float* hs, const float* h0, const float
         }
         return FOV_OK;
     }
-    if (lstm_seq_wgrad_grouped(bf16, B, T, H, dz, dK, dR, db))
-        return wgrad_group_layers(1, &x, &F, &hs, &h0, &dz, &dK, &dR, &db, B, T, H, accumulate, stream);
+    const bool rows_form = lstm_seq_wgrad_rows(bf16, B, T, F, H, dz, dK, dR, db);
+    if (rows_form || lstm_seq_wgrad_grouped(bf16, B, T, H, dz, dK, dR, db))
+        return wgrad_few_rows(rows_form, x, hs, h0, dz, dK, dR, db, B, T, F, H, accumulate, stream);
     bool fuse_kr, fuse_r;
     lstm_seq_wgrad_fusion(x, hs, dz, dK, dR, db, T, F, H, &fuse_kr, &fuse_r);
     return lstm_seq_weight_products(x, hs, h0, dz, dK, dR, db, B, T, F, H, accumulate, bf16, fuse_kr, fuse_r, false, scratch,
                                     scratch_floats, stream);
+}
+
+// Weight gradients of TWO layers that share the batch but not the time length (an encoder and its decoder: FoV_seq2seq.py:68-93)
+// from the dz tapes their BPTT calls left.  At the reference's batch all six gradients are ONE launch (wgrad_rows_kernel).
+bool lstm_seq_wgrad_pair_one_launch(int B, int T1, int T2, int H) {
+    return T1 > 0 && T2 > 0 && wgrad_rows_takes((long)B * (T1 > T2 ? T1 : T2), H);
+}
+
+int lstm_seq_wgrad_pair(const float* x1, const float* hs1, const float* h0_1, const float* dz1, float* dK1, float* dR1, float* db1, int T1, int F1,
+                        const float* x2, const float* hs2, const float* h0_2, const float* dz2, float* dK2, float* dR2, float* db2, int T2, int F2,
+                        int B, int H, int accumulate, float* scratch, size_t scratch_floats, hipStream_t stream) {
+    if (B > 0 && T1 > 0 && T2 > 0 && lstm_seq_wgrad_rows(0, B, T1, F1, H, dz1, dK1, dR1, db1) && lstm_seq_wgrad_rows(0, B, T2, F2, H, dz2, dK2, dR2, db2)) {
+        const float* xs[2] = {x1, x2};
+        const int Fs[2] = {F1, F2}, Ts[2] = {T1, T2};
+        const float* hss[2] = {hs1, hs2};
+        const float* h0s[2] = {h0_1, h0_2};
+        const float* dzs[2] = {dz1, dz2};
+        float* dKs[2] = {dK1, dK2};
+        float* dRs[2] = {dR1, dR2};
+        float* dbs[2] = {db1, db2};
+        return wgrad_rows_layers(2, xs, Fs, Ts, hss, h0s, dzs, dKs, dRs, dbs, B, H, accumulate, stream);
+    }
+    int rc = lstm_seq_wgrad(x1, hs1, h0_1, dz1, dK1, dR1, db1, B, T1, F1, H, accumulate, 0, scratch, scratch_floats, stream);
+    if (rc) return rc;
+    return lstm_seq_wgrad(x2, hs2, h0_2, dz2, dK2, dR2, db2, B, T2, F2, H, accumulate, 0, scratch, scratch_floats, stream);
 }
 
 // BPTT of one layer.  dz:(B,T,4H) is an output (kept: the caller may need it for dx of the layer
@@ -1928,7 +1966,7 @@ int lstm_seq_bwd(const float* x, const float* K, const float* R, const float* h0
     }
     const bool wide16 = !bf16 && bwd16_takes(B, H) && (((uintptr_t)R) & 15) == 0;   // width 512, small batches at 128 / 256: lstm_bwd16.hip
     const bool persistent = (bwd_cluster_shape_ok(H) || wide16) && !env_knobs().bwd_stepped;
-    bool fuse_kr = false, fuse_r = false, dx_in_kernel = false, grouped = false;
+    bool fuse_kr = false, fuse_r = false, dx_in_kernel = false, grouped = false, rows_form = false;
     const size_t head = (kStatusBytes + kXchBytes) / sizeof(float);
     float* dh_rec = ws + head;
     float* dc = dh_rec + (size_t)B * H;
@@ -1944,7 +1982,8 @@ int lstm_seq_bwd(const float* x, const float* K, const float* R, const float* h0
         // below gives all three (no bias partials from the kernel, no column-sum launches); F too narrow for a row tile:
         // [h_{t-1} | 1]^T dz gives dR and db
         lstm_seq_wgrad_fusion(x, hs, dz, dK, dR, db, T, F, H, &fuse_kr, &fuse_r);
-        grouped = lstm_seq_wgrad_grouped(bf16, B, T, H, dz, dK, dR, db);
+        rows_form = lstm_seq_wgrad_rows(bf16, B, T, F, H, dz, dK, dR, db);
+        grouped = rows_form || lstm_seq_wgrad_grouped(bf16, B, T, H, dz, dK, dR, db);
         if (grouped) fuse_kr = fuse_r = false;
         float* db_part = (db && !fuse_kr && !fuse_r && !grouped) ? scratch : nullptr;
         // bf16, 256-wide input (the stacked layer): the BPTT kernel forms dx = dz K^T from the dz tile it has gathered anyway
@@ -1995,7 +2034,7 @@ int lstm_seq_bwd(const float* x, const float* K, const float* R, const float* h0
         if (dh0) { e = hipMemcpyAsync(dh0, dh_rec, bh, hipMemcpyDeviceToDevice, stream); if (e != hipSuccess) { set_error("dh0 copy"); return FOV_ERR_LAUNCH; } }
         if (dc0) { e = hipMemcpyAsync(dc0, dc, bh, hipMemcpyDeviceToDevice, stream); if (e != hipSuccess) { set_error("dc0 copy"); return FOV_ERR_LAUNCH; } }
     }
-    int rc = grouped ? wgrad_group_layers(1, &x, &F, &hs, &h0, &dz, &dK, &dR, &db, B, T, H, accumulate, stream)
+    int rc = grouped ? wgrad_few_rows(rows_form, x, hs, h0, dz, dK, dR, db, B, T, F, H, accumulate, stream)
                      : lstm_seq_weight_products(x, hs, h0, dz, dK, dR, db, B, T, F, H, accumulate, bf16, fuse_kr, fuse_r, /*db_done=*/persistent,
                                                 scratch, scratch_floats, stream);
     if (rc) return rc;
@@ -2037,7 +2076,8 @@ int lstm_stack2_bwd(const float* x, const float* R1, const float* K2, const floa
     lstm_seq_wgrad_fusion(x, hs1, dz1, dK1, dR1, db1, T, F, H, &kr1, &r1);
     lstm_seq_wgrad_fusion(hs1, hs2, dz2, dK2, dR2, db2, T, H, H, &kr2, &r2);
     // few rows: ALL weight gradients of both layers in one launch behind the recurrences (wgrad_group.hip)
-    const bool grouped = lstm_seq_wgrad_grouped(0, B, T, H, dz1, dK1, dR1, db1) && lstm_seq_wgrad_grouped(0, B, T, H, dz2, dK2, dR2, db2);
+    const bool rows_form = lstm_seq_wgrad_rows(0, B, T, F, H, dz1, dK1, dR1, db1) && lstm_seq_wgrad_rows(0, B, T, H, H, dz2, dK2, dR2, db2);
+    const bool grouped = rows_form || (lstm_seq_wgrad_grouped(0, B, T, H, dz1, dK1, dR1, db1) && lstm_seq_wgrad_grouped(0, B, T, H, dz2, dK2, dR2, db2));
     if (grouped) kr1 = r1 = kr2 = r2 = true;      // (no bias partials from the kernel)
     float* db_part1 = (db1 && !kr1 && !r1) ? dbp1 : nullptr;
     float* db_part2 = (db2 && !kr2 && !r2) ? dbp2 : nullptr;
@@ -2054,7 +2094,9 @@ int lstm_stack2_bwd(const float* x, const float* R1, const float* K2, const floa
         float* dKs[2] = {dK1, dK2};
         float* dRs[2] = {dR1, dR2};
         float* dbs[2] = {db1, db2};
-        return wgrad_group_layers(2, xs, Fs, hss, h0s, dzs, dKs, dRs, dbs, B, T, H, accumulate, stream);
+        const int Ts[2] = {T, T};
+        return rows_form ? wgrad_rows_layers(2, xs, Fs, Ts, hss, h0s, dzs, dKs, dRs, dbs, B, H, accumulate, stream)
+                         : wgrad_group_layers(2, xs, Fs, hss, h0s, dzs, dKs, dRs, dbs, B, T, H, accumulate, stream);
     }
     for (int l = 2; l >= 1; --l) {
         float* part = l == 2 ? db_part2 : db_part1;

@@ -454,6 +454,27 @@ def lstm_seq_wgrad(x, hs, dz, dK=None, dR=None, db=None, h0=None, accumulate=Fal
     return {"dK": dK, "dR": dR, "db": db}
 
 
+def lstm_seq_wgrad_pair_one_launch(B, T1, T2, H):
+    return bool(_lib.lib().fov_lstm_seq_wgrad_pair_one_launch(B, T1, T2, H))
+
+
+def lstm_seq_wgrad_pair(layer1, layer2, accumulate=False, scratch=None):
+    """All weight gradients of an encoder / decoder pair from the dz tapes of two `need_weight_grads=False` BPTT calls
+    (fov_lstm_seq_wgrad_pair).  layer = (x (B,T,F), hs (B,T,H), h0 or None, dz (B,T,4H), dK, dR, db)."""
+    a = [_dev(layer1[0], "x1"), _dev(layer1[1], "hs1"), _dev(layer1[2], "h0_1"), _dev(layer1[3], "dz1")]
+    b = [_dev(layer2[0], "x2"), _dev(layer2[1], "hs2"), _dev(layer2[2], "h0_2"), _dev(layer2[3], "dz2")]
+    B, T1, F1 = a[0].shape
+    B2, T2, F2 = b[0].shape
+    H = a[1].shape[-1]
+    assert B == B2 and a[1].shape == (B, T1, H) and b[1].shape == (B, T2, H) and a[3].shape == (B, T1, 4 * H) and b[3].shape == (B, T2, 4 * H)
+    L = _lib.lib()
+    need = max(L.fov_lstm_seq_bwd_workspace_bytes(B, T1, F1, H), L.fov_lstm_seq_bwd_workspace_bytes(B, T2, F2, H))
+    buf = (scratch or _default_scratch).get(need, a[0].device)
+    check(L.fov_lstm_seq_wgrad_pair(_ptr(a[0]), _ptr(a[1]), _ptr(a[2]), _ptr(a[3]), _ptr(layer1[4]), _ptr(layer1[5]), _ptr(layer1[6]), T1, F1,
+                                    _ptr(b[0]), _ptr(b[1]), _ptr(b[2]), _ptr(b[3]), _ptr(layer2[4]), _ptr(layer2[5]), _ptr(layer2[6]), T2, F2,
+                                    B, H, 1 if accumulate else 0, buf.data_ptr(), buf.numel(), _stream()))
+
+
 _side_streams = {}
 
 

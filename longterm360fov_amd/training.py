@@ -389,6 +389,15 @@ class Seq2SeqTrainer(FlatParamTrainer):
             dpre, loss = ops.mse_dense_grad(y, target, "tanh", scratch=self.scratch, dpre=bufs["dpre"], loss=self.loss_slot,
                                             weight=grad_weight, db=g["dense_b"])
             d_hs, _, _ = ops.dense_bwd(dhs_, w["dense_W"], dpre, dW=g["dense_W"], need_db=False, scratch=self.scratch)
+        if ops.lstm_seq_wgrad_pair_one_launch(B, T_in, T_out, dhs_.shape[2]):
+            # few rows (the reference's batch): both recurrences back to back, then ALL six weight gradients as one launch
+            bd = ops.lstm_seq_bwd(dec_in, w["dec_K"], w["dec_R"], dhs_, dres, h0=ehT, c0=ecT, dhs=d_hs, need_state_grads=True,
+                                  act=self.act, dz=bufs["dz_dec"], scratch=self.bwd_scratch, need_weight_grads=False)
+            ops.lstm_seq_bwd(enc, w["enc_K"], w["enc_R"], ehs, eres, dhT=bd["dh0"], dcT=bd["dc0"], act=self.act, dz=bufs["dz_enc"],
+                             scratch=self.bwd_scratch, need_weight_grads=False)
+            ops.lstm_seq_wgrad_pair((enc, ehs, None, bufs["dz_enc"], g["enc_K"], g["enc_R"], g["enc_b"]),
+                                    (dec_in, dhs_, ehT, bufs["dz_dec"], g["dec_K"], g["dec_R"], g["dec_b"]), scratch=self.scratch)
+            return loss, y
         bd = ops.lstm_seq_bwd(dec_in, w["dec_K"], w["dec_R"], dhs_, dres, h0=ehT, c0=ecT, dhs=d_hs, dK=g["dec_K"],
                               dR=g["dec_R"], db=g["dec_b"], need_state_grads=True, act=self.act, dz=bufs["dz_dec"],
                               scratch=self.bwd_scratch)

@@ -1929,3 +1929,87 @@ def test_dense_mse_head_one_launch(N, H, O, act, weight):
     y3, dX3, _ = ops.dense_mse_head(dev(hs), dev(W), dev(b), dev(tg), act, dW=flat2[:H * O].view(H, O), db=flat2[H * O:H * O + O],
                                     loss=flat2[H * O + O:H * O + O + 1], weight=weight, scratch=ops.Scratch())
     assert torch.equal(flat2, flat) and torch.equal(y3, y) and torch.equal(dX3, dX)
+
+
+@pytest.mark.parametrize("B,T1,T2,F1,F2,H,with_h0", [(32, 10, 10, 90, 6, 128, True), (32, 5, 4, 90, 6, 64, True), (7, 3, 9, 5, 6, 32, False),
+                                                     (40, 16, 1, 90, 6, 256, True), (32, 10, 10, 90, 6, 16, True), (1, 1, 1, 3, 3, 16, True),
+                                                     (20, 32, 30, 90, 6, 128, True), (32, 10, 10, 90, 512, 512, True), (9, 7, 2, 30, 6, 512, False),
+                                                     (32, 30, 30, 90, 6, 256, True)])
+def test_encoder_decoder_weight_gradients_one_launch(B, T1, T2, F1, F2, H, with_h0):
+    """fov_lstm_seq_wgrad_pair (round 5): dK = x^T dz, dR = h_{t-1}^T dz (h_{-1} = h0 or 0), db = column sums of dz for the encoder
+    and the decoder of FoV_seq2seq.py:68-93 from their dz tapes - at few rows ONE launch (16 x 64 tiles, 64 x 64 at H = 512 - lstm.py's two
+    stacked layers -, rows split over a workgroup's waves) - against fp64 NumPy, against the per-layer entry point with the few-row kernels switched off, with
+    accumulate, into a flat gradient buffer, and bit for bit the same twice.  The last case has too many rows for one launch and
+    must equal two fov_lstm_seq_wgrad calls bit for bit."""
+    import os
+    from longterm360fov_amd import ops
+    rng = np.random.default_rng(B * 1000 + T1 * 10 + H)
+    u = lambda *s: rng.uniform(-1, 1, s).astype(np.float32)
+    x1, hs1, dz1 = u(B, T1, F1), u(B, T1, H), u(B, T1, 4 * H)
+    x2, hs2, dz2 = u(B, T2, F2), u(B, T2, H), u(B, T2, 4 * H)
+    h0_2 = u(B, H) if with_h0 else None
+    one = ops.lstm_seq_wgrad_pair_one_launch(B, T1, T2, H)
+    assert one == (B * max(T1, T2) <= 640 and H <= 512)
+
+    def ref(x, hs, h0, dz):
+        x, hs, dz = x.astype(np.float64), hs.astype(np.float64), dz.astype(np.float64)
+        hp = np.concatenate([(h0.astype(np.float64) if h0 is not None else np.zeros((x.shape[0], H)))[:, None], hs[:, :-1]], axis=1)
+        return (np.einsum("btf,btn->fn", x, dz), np.einsum("bth,btn->hn", hp, dz), dz.sum((0, 1)))
+
+    refs = ref(x1, hs1, None, dz1) + ref(x2, hs2, h0_2, dz2)
+    sizes = [F1 * 4 * H, H * 4 * H, 4 * H, F2 * 4 * H, H * 4 * H, 4 * H]
+    offs = np.concatenate([[4], 4 + np.cumsum(sizes)])
+
+    def views(flat):
+        shp = [(F1, 4 * H), (H, 4 * H), (4 * H,), (F2, 4 * H), (H, 4 * H), (4 * H,)]
+        return [flat[int(offs[i]):int(offs[i + 1])].view(*shp[i]) for i in range(6)]
+
+    d = lambda a: None if a is None else dev(a)
+    args1 = (d(x1), d(hs1), None, d(dz1))
+    args2 = (d(x2), d(hs2), d(h0_2), d(dz2))
+    flat = torch.full((int(offs[-1]) + 8,), 7.0, device="cuda")
+    v = views(flat)
+    ops.lstm_seq_wgrad_pair(args1 + tuple(v[:3]), args2 + tuple(v[3:]), scratch=ops.Scratch())
+    torch.cuda.synchronize()
+    assert float((flat[:4] - 7).abs().max().item()) == 0.0 and float((flat[int(offs[-1]):] - 7).abs().max().item()) == 0.0
+    for got, r, tag in zip(v, refs, ("dK1", "dR1", "db1", "dK2", "dR2", "db2")):
+        err = np.abs(got.cpu().numpy() - r).max()
+        assert err <= 2e-5 * np.abs(r).max() + 1e-5, (tag, err, np.abs(r).max())
+    # the per-layer entry point without the few-row kernels (split products + reduces)
+    os.environ["FOV_NO_WGRAD_GROUP"] = "1"
+    try:
+        flat_s = torch.zeros_like(flat)
+        s = views(flat_s)
+        sc = ops.Scratch()
+        ops.lstm_seq_wgrad(args1[0], args1[1], args1[3], dK=s[0], dR=s[1], db=s[2], scratch=sc)
+        ops.lstm_seq_wgrad(args2[0], args2[1], args2[3], dK=s[3], dR=s[4], db=s[5], h0=args2[2], scratch=sc)
+        torch.cuda.synchronize()
+    finally:
+        del os.environ["FOV_NO_WGRAD_GROUP"]
+    ops.Scratch().get(256, flat.device)      # (the library re-reads its knobs)
+    for got, sp, r in zip(v, s, refs):
+        assert (got - sp).abs().max().item() <= 2e-5 * np.abs(r).max() + 1e-6
+    if not one:
+        flat_t = torch.zeros_like(flat)
+        t = views(flat_t)
+        sc = ops.Scratch()
+        ops.lstm_seq_wgrad(args1[0], args1[1], args1[3], dK=t[0], dR=t[1], db=t[2], scratch=sc)
+        ops.lstm_seq_wgrad(args2[0], args2[1], args2[3], dK=t[3], dR=t[4], db=t[5], h0=args2[2], scratch=sc)
+        for got, tw in zip(v, t):
+            assert torch.equal(got, tw)
+    # accumulate on top, and the same bits on a second call
+    flat2 = torch.full_like(flat, 7.0)
+    v2 = views(flat2)
+    ops.lstm_seq_wgrad_pair(args1 + tuple(v2[:3]), args2 + tuple(v2[3:]), scratch=ops.Scratch())
+    assert torch.equal(flat2, flat)
+    ops.lstm_seq_wgrad_pair(args1 + tuple(v2[:3]), args2 + tuple(v2[3:]), accumulate=True, scratch=ops.Scratch())
+    torch.cuda.synchronize()
+    for got, once in zip(v2, v):      # (one launch: C + tile in one rounding; the split products add their slices to C in another order)
+        assert torch.equal(got, once + once) if one else (got - 2 * once).abs().max().item() <= 1e-5 * once.abs().max().item()
+    # only some gradients asked for (the bias rides on dR, or on dK when dR is absent)
+    dK_only = torch.zeros((F2, 4 * H), device="cuda")
+    db_only = torch.zeros(4 * H, device="cuda")
+    ops.lstm_seq_wgrad_pair(args1 + (None, v2[1], None), args2 + (dK_only, None, db_only), scratch=ops.Scratch())
+    torch.cuda.synchronize()
+    same = (lambda a, b: torch.equal(a, b)) if one else (lambda a, b: (a - b).abs().max().item() <= 1e-5 * b.abs().max().item())
+    assert same(dK_only, v[3]) and same(db_only, v[5]) and same(v2[1], v[1])
