@@ -37,13 +37,14 @@ elif kind == "raw":
         head["conv%d_W" % (l + 1)] = (rng.uniform(-1, 1, (5, dims[l], dims[l + 1])) * np.sqrt(6.0 / (5 * (dims[l] + dims[l + 1])))).astype(np.float32)
         head["conv%d_b" % (l + 1)] = np.zeros(dims[l + 1], np.float32)
 tr = TFLSTMTrainer(cells, head, lr=1e-5, fps=30, running_length=10, pad=pad, head_kind=kind)
+state = init      # lstm.py:612-620: the state a step returns is the next step's fed state (state_view: no copies around it)
 for _ in range(5):
-    tr.train_step(x, y, init)
+    _, state = tr.train_step(x, y, state, state_view=True)
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
 for _ in range(steps):
-    tr.train_step(x, y, init)
+    _, state = tr.train_step(x, y, state, state_view=True)
 e1.record()
 torch.cuda.synchronize()
 tr.ws.check()

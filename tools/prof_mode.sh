@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools/prof_mode.sh <outdir> <tag> <bench.py arguments...>   : rocprofv3 kernel stats + last-step timeline of one bench mode
+# usage: [STEP_HAS=<kernel substring>] tools/prof_mode.sh <outdir> <tag> <bench.py arguments...>   : rocprofv3 kernel stats + last-step timeline of one bench mode
 out=$1; tag=$2; shift 2
 mkdir -p $GRAFT_REPO_ROOT/$out
 cd /tmp && export TMPDIR=/tmp
@@ -8,5 +8,5 @@ cd $GRAFT_REPO_ROOT
 f=$(find $out/prof_$tag -name "*kernel_stats.csv" | head -1)
 t=$(find $out/prof_$tag -name "*kernel_trace.csv" | head -1)
 [ -n "$f" ] && cp $f $out/${tag}_kernel_stats.csv
-[ -n "$t" ] && python3 tools/step_timeline.py $t adam > $out/${tag}_step_timeline.txt
+[ -n "$t" ] && python3 tools/step_timeline.py $t adam $STEP_HAS > $out/${tag}_step_timeline.txt
 rm -rf $out/prof_$tag
