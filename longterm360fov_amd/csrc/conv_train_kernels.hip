@@ -301,7 +301,11 @@ static int ct_check_launch(const char* what) {
 }
 
 size_t conv2d_wgrad_workspace_floats(int C, int N, int kh, int kw) {
-    return (size_t)64 * kh * kw * C * N + 64;   // up to 64 split-K slices
+    // up to 64 split-K slices; narrow layers (conv_wgrad_lines.hip splits over the maps): up to 256 slices within 128 MB
+    const size_t wn = (size_t)kh * kw * C * N;
+    size_t lines = 256 * wn;
+    if (lines > ((size_t)32 << 20)) lines = (size_t)32 << 20;
+    return (64 * wn > lines ? 64 * wn : lines) + 64;
 }
 
 int conv2d_wgrad(const float* x, long ldx, const float* dz, float* dw, int B, int H, int W, int C, int N, int kh, int kw,
@@ -313,6 +317,9 @@ int conv2d_wgrad(const float* x, long ldx, const float* dz, float* dw, int B, in
         return FOV_OK;
     }
     if ((long)16 * ldx * 4 >= (1L << 30) || (long)16 * N * 4 >= (1L << 30)) { set_error("conv2d_wgrad: strides out of range"); return FOV_ERR_UNSUPPORTED; }
+    // narrow layers: every tap in one workgroup, operands read once (conv_wgrad_lines.hip)
+    if (conv_wgrad_lines_takes(H, W, C, N, kh, kw, dil < 1 ? 1 : dil))
+        return conv_wgrad_lines(x, ldx, dz, dw, B, H, W, C, N, kh, accumulate, scratch, scratch_floats, stream);
     int BM, BN, variant;
     if (C <= 32) { BM = 32; BN = 256; variant = 0; }
     else if (C <= 96) { BM = 96; BN = 256; variant = 1; }

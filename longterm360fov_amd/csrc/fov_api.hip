@@ -446,6 +446,7 @@ void env_reload() {
     g_env.gemm_bf16_noremap = getenv("FOV_GEMM_BF16_NOREMAP") ? 1 : 0;
     g_env.gemm_bf16_shallow = getenv("FOV_GEMM_BF16_SHALLOW") ? 1 : 0;
     g_env.no_wgrad_group = getenv("FOV_NO_WGRAD_GROUP") ? 1 : 0;
+    g_env.no_wgrad_lines = getenv("FOV_NO_WGRAD_LINES") ? 1 : 0;
     g_env.no_wide16_trio = getenv("FOV_NO_WIDE16_TRIO") ? 1 : 0;
     g_env.dbg_trace = getenv("FOV_DBG_TRACE") ? 1 : 0;
     const char* gb = getenv("FOV_GEMM_BF16_SPLIT");

@@ -80,7 +80,7 @@ int device_cu_count();                               // CUs of the current devic
 // getenv results cached at first use (fov_reload_env re-reads them): nothing on a launch path calls getenv
 struct EnvKnobs {
     int force_safe_exchange, two_launches, resident_limit;
-    int bwd_stepped, no_wgrad_fusion, no_dx_fusion, bwd_groups4, gemm_bf16_split, gemm_bf16_noremap, gemm_bf16_shallow, no_wgrad_group, dbg_trace, no_wide16_trio;   // experiment switches (tools/)
+    int bwd_stepped, no_wgrad_fusion, no_dx_fusion, bwd_groups4, gemm_bf16_split, gemm_bf16_noremap, gemm_bf16_shallow, no_wgrad_group, dbg_trace, no_wide16_trio, no_wgrad_lines;   // experiment switches (tools/)
     int gemm_variant, gemm_split;   // FOV_GEMM_VARIANT / FOV_GEMM_SPLIT: tile shape / K slices of the fp32 GEMM forced (experiments)
     int pair;            // FOV_PAIR=1: the fused seq2seq call takes the tile-pair kernel (lstm_pair.hip) at 33 .. 64 tiles, H = 256 (an experiment that lost: off by default)
     int no_wide16;       // FOV_NO_WIDE16=1: width-512 layers stay on the 16-workgroup form (tests / A-B timing)
@@ -144,6 +144,9 @@ int convlstm_cell_fwd(const float* x, long ldx, long ldb, int C, const float* h_
 int softmax_lastdim(const float* x, float* y, long rows, int n, hipStream_t stream);
 
 // ConvLSTM training (conv_train_kernels.hip)
+bool conv_wgrad_lines_takes(int H, int W, int C, int N, int kh, int kw, int dil);      // conv_wgrad_lines.hip
+int conv_wgrad_lines(const float* x, long ldx, const float* dz, float* dw, int B, int H, int W, int C, int N, int ks, int accumulate,
+                     float* scratch, size_t scratch_floats, hipStream_t stream);
 size_t conv2d_wgrad_workspace_floats(int C, int N, int kh, int kw);
 int conv2d_wgrad(const float* x, long ldx, const float* dz, float* dw, int B, int H, int W, int C, int N, int kh, int kw,
                  int accumulate, float* scratch, size_t scratch_floats, hipStream_t stream, int dil = 1);

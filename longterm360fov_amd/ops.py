@@ -52,7 +52,7 @@ def _stream():
 
 _ENV_KNOBS = ("FOV_FORCE_SAFE_EXCHANGE", "FOV_TWO_LAUNCHES", "FOV_DBG_RESIDENT_LIMIT", "FOV_NO_CELL_PATCH", "FOV_NO_CONV_PATCH", "FOV_NO_WIDE16", "FOV_BWD_STEPPED",
               "FOV_NO_WGRAD_FUSION", "FOV_NO_DX_FUSION", "FOV_BWD_GROUPS4", "FOV_GEMM_BF16_NOREMAP", "FOV_GEMM_BF16_SPLIT", "FOV_GEMM_BF16_SHALLOW", "FOV_NO_WGRAD_GROUP", "FOV_NO_WIDE16_TRIO", "FOV_DBG_TRACE", "FOV_GEMM_VARIANT",
-              "FOV_GEMM_SPLIT", "FOV_NO_XCD_PAD", "FOV_XCD_PAD_MAX", "FOV_NO_BWD16_NARROW", "FOV_BWD16_GROUPS", "FOV_NO_STACK2", "FOV_PAIR")
+              "FOV_GEMM_SPLIT", "FOV_NO_XCD_PAD", "FOV_XCD_PAD_MAX", "FOV_NO_BWD16_NARROW", "FOV_BWD16_GROUPS", "FOV_NO_STACK2", "FOV_PAIR", "FOV_NO_WGRAD_LINES")
 _env_seen = None
 # os.environ.get costs 0.7 us per key (encode, lookup, decode): 9 us for the knob list, paid at every workspace / scratch
 # fetch - 0.15 ms of a 0.3 ms training step at batch 32.  The mapping underneath (bytes -> bytes on POSIX) answers the

@@ -136,6 +136,45 @@ def test_conv2d_backward_kernels(B, H, W, C, N, kh, kw):
     close(ops.conv2d_wgrad(dev(wide)[..., 4:4 + C], dev(dy2), kh, kw), tw2.grad.numpy(), "wgrad on a channel slice")
 
 
+@pytest.mark.parametrize("B,H,W,C,N,k,slice_x", [(7, 36, 18, 30, 128, 5, True), (5, 36, 18, 8, 32, 5, False), (3, 36, 18, 56, 512, 5, False),
+                                                 (2, 36, 18, 1024, 30, 5, False), (4, 18, 36, 16, 64, 5, True), (3, 7, 9, 20, 24, 3, False),
+                                                 (70, 5, 6, 32, 64, 5, False), (2, 64, 64, 12, 16, 3, False), (3, 10, 11, 100, 16, 5, True)])
+def test_conv2d_weight_gradient_all_taps_per_workgroup(B, H, W, C, N, k, slice_x):
+    """conv_wgrad_lines.hip (round 5): the weight gradient of a narrow 'same' convolution with every tap in one workgroup and the
+    maps walked line by line (rows, or columns when only that length is a multiple of 4) - against fp64, against the tap-wise kernel
+    it replaces (FOV_NO_WGRAD_LINES=1), with accumulate, on a channel slice of a wider map, and bit for bit the same twice.  Shapes: the ConvLSTM model's cells and narrow head layers (convlstm_seq2seq.py:100-126,
+    209-282 at 36 x 18), 18 x 36, odd line lengths, more maps than slices, 64-pixel lines, a channel count that is no multiple of 16."""
+    import os
+    from longterm360fov_amd import ops
+    rng = np.random.default_rng(B * 100 + C + N)
+    wide = rng.standard_normal((B, H, W, C + 8)).astype(np.float32)
+    xw = dev(wide)
+    x = xw[..., 4:4 + C] if slice_x else dev(np.ascontiguousarray(wide[..., :C]))
+    xn = wide[..., 4:4 + C] if slice_x else wide[..., :C]
+    dy = rng.standard_normal((B, H, W, N)).astype(np.float32)
+    h = k // 2
+    xp = np.pad(xn.astype(np.float64), ((0, 0), (h, h), (h, h), (0, 0)))
+    ref = np.zeros((k, k, C, N))
+    for i in range(k):
+        for j in range(k):
+            ref[i, j] = np.einsum("bhwc,bhwn->cn", xp[:, i:i + H, j:j + W], dy.astype(np.float64))
+    scale = np.abs(ref).max()
+    dw = ops.conv2d_wgrad(x, dev(dy), k, k, scratch=ops.Scratch())
+    assert np.abs(dw.cpu().numpy() - ref).max() <= 3e-6 * scale * max(1.0, np.sqrt(B * H * W / 1000.0))
+    dw2 = ops.conv2d_wgrad(x, dev(dy), k, k, scratch=ops.Scratch())
+    assert torch.equal(dw, dw2)
+    os.environ["FOV_NO_WGRAD_LINES"] = "1"
+    try:
+        old = ops.conv2d_wgrad(x, dev(dy), k, k, scratch=ops.Scratch())
+    finally:
+        del os.environ["FOV_NO_WGRAD_LINES"]
+    ops.Scratch().get(256, dw.device)      # (the library re-reads its knobs)
+    assert (dw - old).abs().max().item() <= 3e-6 * scale * max(1.0, np.sqrt(B * H * W / 1000.0))
+    acc = dw.clone()
+    ops.conv2d_wgrad(x, dev(dy), k, k, dw=acc, accumulate=True, scratch=ops.Scratch())
+    assert (acc - 2 * dw).abs().max().item() <= 1e-6 * scale
+
+
 @pytest.mark.parametrize("act", ["hard_sigmoid", "sigmoid"])
 def test_convlstm_gates_backward_softmax_relu_colsum(act):
     from longterm360fov_amd import ops
