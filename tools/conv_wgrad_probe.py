@@ -10,7 +10,7 @@ maps = int(os.environ.get("PROBE_MAPS", "2560"))
 H, W, k = 36, 18, 5
 shapes = [(30, 128, 32), (32, 128, 32), (32, 64, 32), (16, 64, 16), (16, 32, 16), (8, 32, 8), (56, 512, 56), (1024, 30, 1024)]
 if os.environ.get("PROBE_BIG"):
-    shapes.append((512, 1024, 512))
+    shapes = [(512, 1024, 512)]
 sc = ops.Scratch()
 tot = 0.0
 for C, N, ldx in shapes:
