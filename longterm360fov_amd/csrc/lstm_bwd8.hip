@@ -38,8 +38,10 @@ struct Bwd8Params {
     float* dh0;             // (B,H) or NULL
     float* dc0;             // (B,H) or NULL
     float* db_part;         // (num_tiles, 4H) or NULL
-    const float* K;         // bf16 DX form: input kernel (256, 4H) of the layer ...
-    float* dx;              // ... and its data gradient dx_t = dz_t K^T (B,T,256), the dhs of the layer below
+    const float* K;         // DX forms: input kernel (256, 4H) of the layer ...
+    float* dx;              // ... and its data gradient dx_t = dz_t K^T (B,T,256), the dhs of the layer below (bf16 kernel);
+                            // fp32 kernel: EIGHT partial tapes [slice][B][T][256] - workgroup `slice` contributes its own gate
+                            // columns' share, the host adds them in slice order (splitk_reduce)
     unsigned long long* xch;
     unsigned* status;
     int B, T, num_groups, num_tiles, epoch_span;
@@ -53,7 +55,14 @@ __device__ __forceinline__ float b8_act_grad(float a) {
     return ACT == FOV_ACT_HARD_SIGMOID ? ((a > 0.f && a < 1.f) ? 0.2f : 0.f) : a * (1.f - a);
 }
 
-template <int ACT>
+// DXF (round 5): the layer's data gradient dx_t = dz_t K^T (a 256-wide input: the stacked encoder layer of the mixing model) is
+// formed here as well.  K^T's own-gate-column slice sits in the OTHER 128 accumulation registers (the same fragments as R^T's,
+// read from K), the 128 MFMAs of the partial product run between the publication of the dh partials and their gather - in
+// the shadow of the exchange - and the workgroup's partial [16 x 256] leaves as a tape of its own; the eight tapes are added by
+// one reduce launch.  Before: a 5120 x 1024 x 256 GEMM + reduce (54 us) behind the recurrence, which under model.fit's second
+// stream also waited 90 - 120 us for the weight-gradient GEMMs' workgroups to leave the chip
+// (profiles/r05_train_mixing_f32_step_timeline.txt).
+template <int ACT, bool DXF>
 __global__ __launch_bounds__(256, 1) void lstm_bwd8_kernel(Bwd8Params p) {
     constexpr bool BF16 = false;   // the bf16 form is lstm_bwd8n_bf16_kernel below (N-split)
     __shared__ __attribute__((aligned(16))) float sDZ[BF16 ? 4 : QBT * B8LDZ];
@@ -78,6 +87,7 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd8_kernel(Bwd8Params p) {
     // ---- resident R^T fragments.  Tile tl of this wave: destination slice 2*wave + (tl>>1), half tl&1; its output unit
     // on this lane is nout; k index lc is an own gate column: gate lc>>5, unit 32*slice + (lc & 31). ----
     float rt[BF16 ? 1 : 4][BF16 ? 1 : 8][4];   // fp32: [tl][jb][s], lc = 16*jb + 4*g4 + s
+    float kt[DXF ? 4 : 1][DXF ? 8 : 1][4];      // DXF: the same fragments of K (input unit nout, own gate column lc)
     qu32x4 rq[BF16 ? 4 : 1][BF16 ? 4 : 1];     // bf16: [tl][kb],    lc = 32*kb + 8*g4 + j
 #pragma unroll
     for (int tl = 0; tl < 4; ++tl) {
@@ -92,6 +102,11 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd8_kernel(Bwd8Params p) {
                 const f32x4 v = *(const f32x4*)(p.R + (size_t)nout * H4 + (lc >> 5) * QH + 32 * slice + (lc & 31));
 #pragma unroll
                 for (int s = 0; s < 4; ++s) rt[tl][jb][s] = v[s];
+                if constexpr (DXF) {
+                    const f32x4 w = *(const f32x4*)(p.K + (size_t)nout * H4 + (lc >> 5) * QH + 32 * slice + (lc & 31));
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) kt[tl][jb][s] = w[s];
+                }
             }
         }
     }
@@ -208,6 +223,35 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd8_kernel(Bwd8Params p) {
                     const qu32x4 gr = {__float_as_uint(acc[tl][2 * rp]), epoch, __float_as_uint(acc[tl][2 * rp + 1]), epoch};
                     if (ticket.same_xcd) __builtin_amdgcn_raw_buffer_store_b128(gr, rs, off + rp * 32 * 16, par, 1);
                     else __builtin_amdgcn_raw_buffer_store_b128(gr, rs, off + rp * 32 * 16, par, 16);
+                }
+            }
+            if constexpr (DXF) {
+                // ---- this workgroup's share of dx_t = dz_t K^T while the dh partials travel ----
+                f32x4 ax[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) ax[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                asm volatile("s_nop 3" : "+v"(ax[0]), "+v"(ax[1]), "+v"(ax[2]), "+v"(ax[3]));
+                const float* arow = sDZ + n * B8LDZ + 4 * g4;
+                f32x4 a = *(const f32x4*)arow, an = a;
+#pragma unroll
+                for (int jb = 0; jb < 8; ++jb) {
+                    if (jb + 1 < 8) an = *(const f32x4*)(arow + 16 * (jb + 1));
+                    asm volatile("s_nop 1" : "+v"(a));
+#pragma unroll
+                    for (int tl = 0; tl < 4; ++tl)
+#pragma unroll
+                        for (int s = 0; s < 4; ++s) b8_mfma_a(ax[tl], a[s], kt[tl][jb][s]);
+                    a = an;
+                }
+                asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" : "+v"(ax[0]), "+v"(ax[1]), "+v"(ax[2]), "+v"(ax[3]));
+#pragma unroll
+                for (int tl = 0; tl < 4; ++tl) {
+                    const int col = 32 * (2 * wave + (tl >> 1)) + 16 * (tl & 1) + n;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = b0 + 4 * g4 + r;
+                        if (row < p.B) p.dx[(((size_t)slice * p.B + row) * T + t) * QH + col] = ax[tl][r];
+                    }
                 }
             }
             // ---- gather the 8 pieces of this lane's two cells (one 16-byte load per source), add in slice order ----
@@ -551,7 +595,7 @@ int launch_bwd8(const float* R, const float* reserve, const float* c0, const flo
     if (B == 0 || T == 0) return FOV_OK;
     Bwd8Params p = {};
     p.K = K_dx; p.dx = dx;
-    const bool with_dx = bf16 && K_dx && dx;
+    const bool with_dx = K_dx && dx;      // (fp32: dx = eight partial tapes [slice][B][T][256])
     if (with_dx && (((uintptr_t)K_dx) & 15)) { set_error("8-group BPTT kernel: K must be 16-byte aligned"); return FOV_ERR_INVALID; }
     p.R = R; p.reserve = reserve; p.c0 = c0; p.dhs = dhs; p.dhT = dhT; p.dcT = dcT; p.dz = dz; p.dh0 = dh0; p.dc0 = dc0; p.db_part = db_part;
     p.B = B; p.T = T;
@@ -573,7 +617,8 @@ int launch_bwd8(const float* R, const float* reserve, const float* c0, const flo
     void (*kern)(Bwd8Params) = nullptr;
     if (bf16 && with_dx) kern = act == FOV_ACT_HARD_SIGMOID ? lstm_bwd8n_bf16_kernel<FOV_ACT_HARD_SIGMOID, true> : lstm_bwd8n_bf16_kernel<FOV_ACT_SIGMOID, true>;
     else if (bf16) kern = act == FOV_ACT_HARD_SIGMOID ? lstm_bwd8n_bf16_kernel<FOV_ACT_HARD_SIGMOID, false> : lstm_bwd8n_bf16_kernel<FOV_ACT_SIGMOID, false>;
-    else kern = act == FOV_ACT_HARD_SIGMOID ? lstm_bwd8_kernel<FOV_ACT_HARD_SIGMOID> : lstm_bwd8_kernel<FOV_ACT_SIGMOID>;
+    else if (with_dx) kern = act == FOV_ACT_HARD_SIGMOID ? lstm_bwd8_kernel<FOV_ACT_HARD_SIGMOID, true> : lstm_bwd8_kernel<FOV_ACT_SIGMOID, true>;
+    else kern = act == FOV_ACT_HARD_SIGMOID ? lstm_bwd8_kernel<FOV_ACT_HARD_SIGMOID, false> : lstm_bwd8_kernel<FOV_ACT_SIGMOID, false>;
     hipLaunchKernelGGL(kern, dim3(q_padded_groups(p.num_groups) * QG), dim3(256), 0, stream, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("8-group BPTT launch: %s", hipGetErrorString(e)); return FOV_ERR_LAUNCH; }

@@ -1671,7 +1671,9 @@ size_t lstm_bwd_workspace_floats(int B, int T, int F, int H) {
     size_t cs = (size_t)256 * 4 * H + (size_t)((B + 15) / 16) * 4 * H;   // colsum partials + per-tile db partials
     size_t st = (size_t)8 * B * H;                               // split-K partials of the per-step dh GEMM
     size_t m = wg > cs ? wg : cs;
-    (void)T;
+    // fp32, 256 -> 256 on the eight-workgroup BPTT kernel: the eight partial tapes of dx = dz K^T behind the per-tile db partials
+    const size_t dxp = (F == 256 && H == 256) ? (size_t)8 * B * T * 256 + (size_t)((B + 15) / 16) * 4 * H + 64 : 0;
+    if (dxp > m) m = dxp;
     // head: status word + granule buffers of the persistent BPTT kernel (when the shape allows it)
     size_t head = (kStatusBytes + kXchBytes) / sizeof(float);   // header + the fixed granule area (xch_common.h)
     return head + (size_t)2 * B * H + (m > st ? m : st) + 64;
@@ -1988,16 +1990,28 @@ int lstm_seq_bwd(const float* x, const float* K, const float* R, const float* h0
         float* db_part = (db && !fuse_kr && !fuse_r && !grouped) ? scratch : nullptr;
         // bf16, 256-wide input (the stacked layer): the BPTT kernel forms dx = dz K^T from the dz tile it has gathered anyway
         dx_in_kernel = bf16 && dx && F == 256 && (((uintptr_t)K) & 15) == 0 && !env_knobs().no_dx_fusion;
+        // fp32 on the eight-workgroup kernel (round 5): every workgroup forms its gate columns' share of dx in the shadow of the
+        // exchange; eight partial tapes in the scratch, one reduce launch (was: a GEMM + reduce behind the recurrence)
+        const bool on_bwd8 = !wide16 && !bf16 && bwd8_preferred(B, H) && !env_knobs().bwd_groups4;
+        float* dx_parts = nullptr;
+        if (on_bwd8 && dx && F == 256 && (((uintptr_t)K) & 15) == 0 && (((uintptr_t)dx) & 15) == 0 && !env_knobs().no_dx_fusion) {
+            const size_t off = ((size_t)((B + 15) / 16) * 4 * H + 63) & ~(size_t)63;      // behind the db partials
+            if (off + (size_t)8 * B * T * 256 <= scratch_floats) { dx_parts = scratch + off; dx_in_kernel = true; }
+        }
         // H = 256: groups of eight workgroups fill the chip up to 32 tiles (the 4-group kernel leaves half of it idle
         // at 512 sequences); bf16 operands exist in the 8-group kernel only
         if (env_knobs().dbg_trace) fprintf(stderr, "[fov trace] lstm_seq_bwd B=%d T=%d F=%d H=%d wide16=%d fuse_kr=%d fuse_r=%d grouped=%d acc=%d: recurrence next\n", B, T, F, H, (int)wide16, (int)fuse_kr, (int)fuse_r, (int)grouped, accumulate);
         int rc = wide16 ? launch_bwd16(R, reserve, c0, dhs, dhT, dcT, dz, dh0 ? dh0 : dh_rec, dc0 ? dc0 : dc, db_part, B, T, H, act, ws, stream)
                  : (bf16 || (bwd8_preferred(B, H) && !env_knobs().bwd_groups4))
                      ? launch_bwd8(R, reserve, c0, dhs, dhT, dcT, dz, dh0 ? dh0 : dh_rec, dc0 ? dc0 : dc, db_part, B, T, act, bf16, ws, stream,
-                                   dx_in_kernel ? K : nullptr, dx_in_kernel ? dx : nullptr)
+                                   dx_in_kernel ? K : nullptr, dx_in_kernel ? (dx_parts ? dx_parts : dx) : nullptr)
                      : launch_bwd_cluster(R, reserve, c0, dhs, dhT, dcT, dz, dh0 ? dh0 : dh_rec, dc0 ? dc0 : dc, db_part, B, T, H,
                                           act, ws, stream);
         if (rc) return rc;
+        if (dx_parts) {      // dx = the eight workgroups' shares in slice order (before anything else touches the scratch)
+            rc = splitk_reduce(dx_parts, dx, (long)B * T * 256, 8, 0, stream);
+            if (rc) return rc;
+        }
         if (env_knobs().dbg_trace) fprintf(stderr, "[fov trace] lstm_seq_bwd: recurrence done\n");
         if (db_part) {
             const int tiles = (B + 15) / 16;
