@@ -447,10 +447,11 @@ int fov_mse_dense_grad_w(const float* y, const float* target, float* dpre, float
 int fov_mse_dense_grad_db(const float* y, const float* target, float* dpre, float* loss, float* db, int64_t n, int O, int activation,
                           float weight, void* workspace, size_t workspace_bytes, fov_stream_t stream);
 
-/* Dense(O, tanh | linear) head + Keras mean_squared_error, FORWARD AND BACKWARD as ONE launch (round 5) - what model.fit runs around the
+/* Dense(O, tanh | linear) head + Keras mean_squared_error, FORWARD AND BACKWARD as ONE launch (round 5; two beyond 4 096 rows: the
+ * blocks' partial sums are added by a second one) - what model.fit runs around the
  * decoder's hidden sequence in mycode/FoV_seq2seq.py:96-103: hs (N,H), W (H,O), b (O), target (N,O) ->
  *   y (N,O) = act(hs . W + b) (may be NULL), *loss = weight * mean (y - target)^2 (may be NULL), dX (N,H) = dloss/dhs (may be NULL),
- *   dW (H,O), db (O).  activation 0 linear, 1 tanh; weight as in fov_mse_dense_grad_w.  N <= 4096, H <= 512 (multiple of 4), O <= 8
+ *   dW (H,O), db (O).  activation 0 linear, 1 tanh; weight as in fov_mse_dense_grad_w.  N <= 2^20, H <= 512 (multiple of 4), O <= 8
  *   (fov_dense_mse_head_supported); other shapes: fov_dense_fwd + fov_mse_dense_grad_db + fov_dense_bwd.  Deterministic. */
 int fov_dense_mse_head_supported(int64_t N, int H, int O);
 size_t fov_dense_mse_head_workspace_bytes(int64_t N, int H, int O);

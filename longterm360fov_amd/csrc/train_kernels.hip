@@ -1065,7 +1065,7 @@ __global__ __launch_bounds__(256) void dense_mse_head_kernel(const float* __rest
                                                              const float* __restrict__ target, float* __restrict__ y_out, float* __restrict__ dX,
                                                              float* __restrict__ part, float* __restrict__ dW, float* __restrict__ db,
                                                              float* __restrict__ loss, int N, int H, int O, int activation, float scale,
-                                                             unsigned* __restrict__ ticket) {
+                                                             unsigned* __restrict__ ticket, int chunks_per_block, int finish) {
     extern __shared__ __attribute__((aligned(16))) float hd_sm[];
     const int LDH = H + 4;
     float* sHs = hd_sm;                       // [64][H + 4]
@@ -1074,8 +1074,20 @@ __global__ __launch_bounds__(256) void dense_mse_head_kernel(const float* __rest
     float* sRed = sD + HD_RB * 8;             // 4 wave sums of the squared error
     __shared__ int is_last;
     const int tid = threadIdx.x;
-    const int r0 = blockIdx.x * HD_RB;
     const int C4 = H >> 2;                    // 16-byte pieces per row
+    // More than 64 x 64 rows (round 5: the 30 720 rows of configs[1]'s training step): a block walks `chunks_per_block` tiles of 64
+    // rows, its partial dW / db / squared error stay in registers across them, and a second launch adds the blocks' partials
+    // (finish = 0) - the last-block reduce below is one block reading every partial.
+    float aw[2][8], adb = 0.f, sq_tot = 0.f;      // dW rows tid and tid + 256 (H <= 512), db[tid], squared error (thread 0)
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int o = 0; o < 8; ++o) aw[kk][o] = 0.f;
+    const int chunk0 = blockIdx.x * chunks_per_block;
+    for (int ch = 0; ch < chunks_per_block; ++ch) {
+    const int r0 = (chunk0 + ch) * HD_RB;
+    if (r0 >= N) break;
+    if (ch > 0) __syncthreads();              // the previous tile's readers are done
     // ---- stage the hs tile (rows past N: zero) and W ----
     // (every request of the tile goes out before the first LDS store: a load-then-store loop is one memory round trip per
     // iteration on a CU that runs one wave per SIMD - 8 us of the kernel's first 18)
@@ -1093,9 +1105,9 @@ __global__ __launch_bounds__(256) void dense_mse_head_kernel(const float* __rest
         }
         float wv[16];
 #pragma unroll
-        for (int it = 0; it < 16; ++it) {
+        for (int it = 0; it < 16; ++it) {      // (W: the block's first tile only - later passes request nothing)
             const int i = tid + 256 * it, k = i >> 3, o = i & 7;
-            wv[it] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(wrs, (i < H * 8 && o < O) ? (unsigned)((k * O + o) * 4) : 0x80000000u, 0, 0));
+            wv[it] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(wrs, (ch == 0 && i < H * 8 && o < O) ? (unsigned)((k * O + o) * 4) : 0x80000000u, 0, 0));
         }
 #pragma unroll
         for (int it = 0; it < HIT; ++it) {
@@ -1108,7 +1120,7 @@ __global__ __launch_bounds__(256) void dense_mse_head_kernel(const float* __rest
 #pragma unroll
         for (int it = 0; it < 16; ++it) {
             const int i = tid + 256 * it;
-            if (i < H * 8) sWt[i] = wv[it];
+            if (ch == 0 && i < H * 8) sWt[i] = wv[it];
         }
     }
     __syncthreads();
@@ -1178,28 +1190,42 @@ __global__ __launch_bounds__(256) void dense_mse_head_kernel(const float* __rest
             }
         }
     }
-    // ---- the block's partial dW[k][o] = sum_r hs[r][k] dpre[r][o], db[o] = sum_r dpre[r][o], squared error ----
-    const int NE = H * O + O + 1;
-    float* mypart = part + (size_t)blockIdx.x * NE;
-    for (int k = tid; k < H; k += 256) {
-        float a[8];
+    // ---- the block's partial dW[k][o] += sum_r hs[r][k] dpre[r][o], db[o] += sum_r dpre[r][o], squared error ----
 #pragma unroll
-        for (int o = 0; o < 8; ++o) a[o] = 0.f;
+    for (int kk = 0; kk < 2; ++kk) {
+        const int k = tid + 256 * kk;
+        if (k < H) {
 #pragma unroll 8
-        for (int rr = 0; rr < HD_RB; ++rr) {
-            const float h = sHs[rr * LDH + k];
-            const f32x4 g0 = *(const f32x4*)(sD + rr * 8), g1 = *(const f32x4*)(sD + rr * 8 + 4);
+            for (int rr = 0; rr < HD_RB; ++rr) {
+                const float h = sHs[rr * LDH + k];
+                const f32x4 g0 = *(const f32x4*)(sD + rr * 8), g1 = *(const f32x4*)(sD + rr * 8 + 4);
 #pragma unroll
-            for (int o = 0; o < 4; ++o) { a[o] = fmaf(h, g0[o], a[o]); a[4 + o] = fmaf(h, g1[o], a[4 + o]); }
+                for (int o = 0; o < 4; ++o) { aw[kk][o] = fmaf(h, g0[o], aw[kk][o]); aw[kk][4 + o] = fmaf(h, g1[o], aw[kk][4 + o]); }
+            }
         }
-        for (int o = 0; o < O; ++o) mypart[(size_t)k * O + o] = a[o];
     }
     if (tid < O) {
         float a = 0.f;
         for (int rr = 0; rr < HD_RB; ++rr) a += sD[rr * 8 + tid];
-        mypart[(size_t)H * O + tid] = a;
+        adb += a;
     }
-    if (tid == 0) mypart[NE - 1] = (sRed[0] + sRed[1]) + (sRed[2] + sRed[3]);
+    if (tid == 0) sq_tot += (sRed[0] + sRed[1]) + (sRed[2] + sRed[3]);
+    }   // tiles of this block
+    const int NE = H * O + O + 1;
+    float* mypart = part + (size_t)blockIdx.x * NE;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        const int k = tid + 256 * kk;
+        if (k < H)
+        {
+#pragma unroll
+            for (int o = 0; o < 8; ++o)
+                if (o < O) mypart[(size_t)k * O + o] = aw[kk][o];
+        }
+    }
+    if (tid < O) mypart[(size_t)H * O + tid] = adb;
+    if (tid == 0) mypart[NE - 1] = sq_tot;
+    if (!finish) return;                      // a reduce launch adds the blocks' partials (dense_mse_head_reduce_kernel)
     __threadfence();
     __syncthreads();
     if (tid == 0) is_last = atomicAdd(ticket, 1u) == gridDim.x - 1u;
@@ -1223,6 +1249,39 @@ __global__ __launch_bounds__(256) void dense_mse_head_kernel(const float* __rest
             else if (loss) loss[0] = a * scale;
         }
         if (tid == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the slot is this stream's again
+    }
+}
+
+// The second launch of the head at more than 4 096 rows: element e of (dW | db | squared error) = the blocks' partials in block
+// order.  16 elements x 16 partial groups per block (group q adds partials q, q + 16, ...; the 16 group sums are folded in a fixed
+// order): a hundred blocks instead of one block reading everything.
+__global__ __launch_bounds__(256) void dense_mse_head_reduce_kernel(const float* __restrict__ part, int nb, int NE, int HO, int O,
+                                                                    float* __restrict__ dW, float* __restrict__ db, float* __restrict__ loss,
+                                                                    float scale) {
+    __shared__ float red[16][17];
+    const int el = threadIdx.x & 15, q = threadIdx.x >> 4;
+    const int e = blockIdx.x * 16 + el;
+    float a = 0.f;
+    if (e < NE) {
+        int b = q;
+        for (; b + 7 * 16 < nb; b += 8 * 16) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = part[(size_t)(b + 16 * u) * NE + e];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a += v[u];
+        }
+        for (; b < nb; b += 16) a += part[(size_t)b * NE + e];
+    }
+    red[q][el] = a;
+    __syncthreads();
+    if (q == 0 && e < NE) {
+        float t = 0.f;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) t += red[g][el];
+        if (e < HO) dW[e] = t;
+        else if (e < HO + O) db[e - HO] = t;
+        else if (loss) loss[0] = t * scale;
     }
 }
 
@@ -2238,13 +2297,13 @@ int mse_dense_grad_w(const float* y, const float* target, float* dpre, float* lo
 }
 
 bool dense_mse_head_shape_ok(long N, int H, int O) {
-    return N >= 1 && N <= (long)HD_RB * HD_MAXB && H >= 4 && H <= 512 && (H & 3) == 0 && O >= 1 && O <= 8;
+    return N >= 1 && N <= (1L << 20) && H >= 4 && H <= 512 && (H & 3) == 0 && O >= 1 && O <= 8;
 }
 size_t dense_mse_head_scratch_floats(long N, int H, int O) { return (size_t)((N + HD_RB - 1) / HD_RB) * ((size_t)H * O + O + 1) + 64; }
 // weight: this rank's share of the global batch (data parallelism), 1 otherwise; loss = weight * mean over all N * O elements
 int dense_mse_head(const float* hs, const float* W, const float* b, const float* target, float* y, float* dX, float* dW, float* db,
                    float* loss, long N, int H, int O, int activation, float weight, float* scratch, size_t scratch_floats, hipStream_t stream) {
-    if (!dense_mse_head_shape_ok(N, H, O)) { set_error("dense_mse_head: rows <= 4096, H <= 512 (a multiple of 4), O <= 8 only"); return FOV_ERR_UNSUPPORTED; }
+    if (!dense_mse_head_shape_ok(N, H, O)) { set_error("dense_mse_head: rows <= 2^20, H <= 512 (a multiple of 4), O <= 8 only"); return FOV_ERR_UNSUPPORTED; }
     if (dense_mse_head_scratch_floats(N, H, O) > scratch_floats) { set_error("dense_mse_head: scratch too small"); return FOV_ERR_WORKSPACE; }
     unsigned* ticket = loss_ticket_of(stream);
     if (!ticket) { set_error("dense_mse_head: no ticket slot left for this stream (1024 distinct streams have issued loss calls on the device)"); return FOV_ERR_UNSUPPORTED; }
@@ -2254,10 +2313,25 @@ int dense_mse_head(const float* hs, const float* W, const float* b, const float*
     const size_t lds = dense_mse_head_lds_floats(H) * sizeof(float);
     rc = ensure_dynamic_lds((const void*)dense_mse_head_kernel, lds);
     if (rc) return rc;
-    const int blocks = (int)((N + HD_RB - 1) / HD_RB);
+    const int chunks = (int)((N + HD_RB - 1) / HD_RB);
+    const float scale = weight / (float)(N * O);
+    if (chunks <= HD_MAXB) {      // one launch: the last block to finish adds the partials
+        hipLaunchKernelGGL(dense_mse_head_kernel, dim3((unsigned)chunks), dim3(256), lds, stream, hs, W, b, target, y, dX, scratch, dW, db, loss,
+                           (int)N, H, O, activation, scale, ticket, 1, 1);
+        return check_launch("dense_mse_head");
+    }
+    // many rows: about one block per CU walking several tiles (two per CU measured no faster: 39.9 vs 37.1 us at 30 720 rows), then the reduce launch
+    const int cus = device_cu_count() > 0 ? device_cu_count() : 256;
+    const int cpb = (chunks + cus - 1) / cus;
+    const int blocks = (chunks + cpb - 1) / cpb;
     hipLaunchKernelGGL(dense_mse_head_kernel, dim3((unsigned)blocks), dim3(256), lds, stream, hs, W, b, target, y, dX, scratch, dW, db, loss,
-                       (int)N, H, O, activation, weight / (float)(N * O), ticket);
-    return check_launch("dense_mse_head");
+                       (int)N, H, O, activation, scale, ticket, cpb, 0);
+    rc = check_launch("dense_mse_head");
+    if (rc) return rc;
+    const int NE = H * O + O + 1;
+    hipLaunchKernelGGL(dense_mse_head_reduce_kernel, dim3((unsigned)((NE + 15) / 16)), dim3(256), 0, stream, scratch, blocks, NE, H * O, O, dW, db,
+                       loss, scale);
+    return check_launch("dense_mse_head_reduce");
 }
 
 int scale_inplace(float* x, long n, float s, hipStream_t stream) {

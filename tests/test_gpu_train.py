@@ -1886,6 +1886,7 @@ def test_dense_bias_gradient_from_the_loss_launch(rows, O, act):
 
 
 @pytest.mark.parametrize("N,H,O,act,weight", [(320, 128, 6, "tanh", 1.0), (320, 64, 6, "tanh", 0.37), (37, 256, 3, "tanh", 1.0), (4096, 256, 6, "tanh", 1.0),
+                                              (30720, 256, 6, "tanh", 1.0), (4161, 128, 3, "tanh", 0.5), (50001, 512, 8, None, 1.0),
                                               (65, 512, 8, None, 1.0), (1, 32, 1, "tanh", 1.0), (1000, 100, 6, "tanh", 0.5)])
 def test_dense_mse_head_one_launch(N, H, O, act, weight):
     """fov_dense_mse_head (round 5): Dense(O, tanh) + mean_squared_error of FoV_seq2seq.py:96-103, forward and backward in ONE launch
@@ -1897,7 +1898,7 @@ def test_dense_mse_head_one_launch(N, H, O, act, weight):
     W = (rng.standard_normal((H, O)) / np.sqrt(H)).astype(np.float32)
     b = (0.1 * rng.standard_normal(O)).astype(np.float32)
     tg = rng.uniform(-1, 1, (N, O)).astype(np.float32)
-    assert ops.dense_mse_head_supported(N, H, O) and not ops.dense_mse_head_supported(4097, H, O) and not ops.dense_mse_head_supported(N, H, 9)
+    assert ops.dense_mse_head_supported(N, H, O) and not ops.dense_mse_head_supported((1 << 20) + 1, H, O) and not ops.dense_mse_head_supported(N, H, 9)
     pre = hs.astype(np.float64) @ W.astype(np.float64) + b
     y_ref = np.tanh(pre) if act else pre
     d = y_ref - tg
