@@ -69,6 +69,8 @@ CASES = [
     ("FOV_GEMM_BF16_SPLIT", "3", "mixing_bf16_512"), ("FOV_GEMM_BF16_SHALLOW", "1", "mixing_bf16_512"), ("FOV_GEMM_BF16_NOREMAP", "1", "mixing_bf16_512"),
     # the three weight gradients of a layer as three products instead of one (fov_lstm_seq_bwd)
     ("FOV_NO_WGRAD_FUSION", "1", "seq2seq_256"), ("FOV_NO_WGRAD_FUSION", "1", "mixing_f32"),
+    # the stacked encoder layer's data gradient dz K^T inside the fp32 eight-workgroup BPTT kernel switched off (a GEMM + reduce instead)
+    ("FOV_NO_DX_FUSION", "1", "mixing_f32_512"), ("FOV_NO_DX_FUSION", "1", "mixing_f32"),
     # all weight gradients of a few-row layer stack / encoder-decoder pair in one launch (wgrad_group.hip: tile and row-split forms) switched off
     ("FOV_NO_WGRAD_GROUP", "1", "tf_lstm"), ("FOV_NO_WGRAD_GROUP", "1", "seq2seq_128"), ("FOV_NO_WGRAD_GROUP", "1", "mixing_f32"),
     # BPTT kernel family: four-workgroup groups instead of eight (H = 256, <= 512 sequences); the sixteen-unit narrow form off
