@@ -325,7 +325,8 @@ int conv2d_wgrad(const float* x, long ldx, const float* dz, float* dw, int B, in
     else if (C <= 96) { BM = 96; BN = 256; variant = 1; }
     else if (N <= 32) { BM = 256; BN = 32; variant = 3; }   // skinny output (head 1024 -> 30): a 128-wide column tile was 77 % padding
     else { BM = 128; BN = 128; variant = 2; }
-    // (wide layers, measured at the head's 512 -> 1024: 128 x 128 tiles 359 ms = 0.77 of peak, 128 x 256 437 ms, 256 x 128 459 ms)
+    // (wide layers, measured at the head's 512 -> 1024: 128 x 128 tiles 359 ms = 0.77 of peak, 128 x 256 437 ms, 256 x 128 459 ms; the
+    // blocks that share an x tile pinned to one XCD: 360 ms - the launch is not bound by its operand fetches)
     WgradArgs g = {};
     g.x = x; g.dz = dz; g.H = H; g.W = W; g.C = C; g.N = N; g.kh = kh; g.kw = kw; g.P = P; g.ldx = ldx;
     g.dil = dil < 1 ? 1 : dil;
