@@ -128,6 +128,12 @@ def _keras_fit(model, trainer, inputs, y, batch_size, epochs, validation_split, 
             # not synchronised), then each takes its contiguous shard of every global batch
             idx = parallel.broadcast_index(idx)
         idx_dev = torch.from_numpy(np.ascontiguousarray(idx, dtype=np.int64)).to(model.device) if (resident and shuffle) else None
+        # ... and when twice the training set fits, the WHOLE epoch is gathered once (three launches per epoch): a batch is then
+        # a contiguous slice - at the reference's batch of 32 the three per-step gathers were 11 us of GPU time and as much host
+        # time again in a 0.13 ms step
+        epoch_arrays = None
+        if idx_dev is not None and 2 * (sum(a.nbytes for a in inputs) + tgt.nbytes) <= limit:
+            epoch_arrays = [t.index_select(0, idx_dev) for t in dev_arrays]
         # the epoch's loss sum stays on the device (fp64): no host synchronisation per step, so the launches of step k + 1 are
         # queued while step k runs (the returned loss tensor is overwritten by the NEXT step: the add is queued before it)
         tot_t, cnt = torch.zeros(1, dtype=torch.float64, device=model.device), 0
@@ -138,13 +144,15 @@ def _keras_fit(model, trainer, inputs, y, batch_size, epochs, validation_split, 
             lidx = gidx[a:b]
             if not resident:
                 batch = [d(arr[lidx]) for arr in inputs] + [d(tgt[lidx])]
+            elif epoch_arrays is not None:
+                batch = [t[lo + a:lo + b] for t in epoch_arrays]
             elif shuffle:
                 sel = idx_dev[lo + a:lo + b]
                 batch = [t.index_select(0, sel) for t in dev_arrays]
             else:
                 batch = [t[lo + a:lo + b] for t in dev_arrays]   # idx is the identity: contiguous rows, no copy
             loss = step(*batch, n_global=len(gidx))
-            tot_t.add_(loss.reshape(1).double(), alpha=float(len(gidx)))
+            tot_t.add_(loss.reshape(1), alpha=float(len(gidx)))      # (fp32 into the fp64 sum: one launch)
             cnt += len(gidx)
         tot = float(tot_t.item())
         logs = {"loss": tot / max(cnt, 1), "lr": trainer.lr}
@@ -157,7 +165,7 @@ def _keras_fit(model, trainer, inputs, y, batch_size, epochs, validation_split, 
                 sl = slice(lo, lo + batch_size)
                 k = len(val[1][sl])
                 vb = [t[sl] for t in val_dev] if val_dev is not None else [d(arr[sl]) for arr in val[0]] + [d(val[1][sl])]
-                vt_t.add_(trainer.eval_loss(*vb).reshape(1).double(), alpha=float(k))
+                vt_t.add_(trainer.eval_loss(*vb).reshape(1), alpha=float(k))
                 vc += k
             vt = float(vt_t.item())
             logs["val_loss"] = vt / vc
