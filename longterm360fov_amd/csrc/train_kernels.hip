@@ -1334,6 +1334,10 @@ int gemm_f32(GemmArgs g, int accumulate, float* scratch, size_t scratch_floats, 
     if (variant == 2 && K <= 512 && ((g.M + 127) / 128) * ((g.N + 127) / 128) < 256) { BM = 64; BN = 64; variant = 3; }
     // the same regime with a 33..96-row output (dK of a 90-wide input: eight 96 x 256 tiles): 64 x 64 tiles as well
     if (variant == 1 && K <= 512 && g.N >= 1024) { BM = 64; BN = 64; variant = 3; }
+    // mid-length K on a few dozen 128 x 128 tiles (the 512 x 1024 x 5120 weight gradients of configs[2] at T = 10: 32 tiles x 8 slices):
+    // 64 x 128 tiles halve the slices - and the partials written and re-read - for the same block count; measured on the training
+    // step 0.788 -> 0.775 ms.  Longer K stays (T = 30, K = 15 360: 1.955 -> 1.969 ms; configs[1], K = 30 720: 1.231 -> 1.287 ms).
+    if (variant == 2 && K > 2048 && K <= 8192 && ((g.M + 127) / 128) * ((g.N + 127) / 128) <= 64) { BM = 64; BN = 128; variant = 4; }
     if (const int v = env_knobs().gemm_variant) {   // tuning knob (experiments), FOV_GEMM_VARIANT
         if (v == 2) { BM = 128; BN = 128; variant = 2; }
         if (v == 3) { BM = 64; BN = 64; variant = 3; }
