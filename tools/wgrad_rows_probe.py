@@ -1,5 +1,6 @@
-"""Times fov_lstm_seq_wgrad_pair at lstm.py's shape (two stacked layers, 32 x 10 rows, H = 512) and at config 1's, per variant
-(FOV_DBG_WR_VARIANT is read once per process: run once per variant)."""
+"""Times fov_lstm_seq_wgrad_pair at lstm.py's shape (two stacked layers, 32 x 10 rows, H = 512) and at config 1's widths
+(HIP events around back-to-back calls; run under `rocprofv3 --kernel-trace --stats` for the kernels' own durations).
+FOV_NO_WGRAD_GROUP=1: the split products + reduces the one-launch kernels replaced."""
 import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -23,7 +24,7 @@ def run(B, T, F1, F2, H, group_off=False):
         e1.record(); torch.cuda.synchronize()
         best = min(best, e0.elapsed_time(e1) / 200 * 1e3)
     fl = 2.0 * B * T * 4 * H * (F1 + F2 + 2 * H)
-    print("variant %s  B %d T %d F %d/%d H %d: %.1f us per call (%.1f TFLOP/s)" % (os.environ.get("FOV_DBG_WR_VARIANT", "-"), B, T, F1, F2, H, best, fl / best * 1e-6), flush=True)
+    print("%s  B %d T %d F %d/%d H %d: %.1f us per call (%.1f TFLOP/s)" % ("split products" if os.environ.get("FOV_NO_WGRAD_GROUP") else "one launch", B, T, F1, F2, H, best, fl / best * 1e-6), flush=True)
 
 run(32, 10, 90, 512, 512)
 run(32, 10, 90, 6, 128)
